@@ -1,0 +1,106 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY: may be imported
+from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never from libheif_amd/."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c") or f.endswith(".h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    return so
+
+
+class _Pic(C.Structure):
+    _fields_ = [
+        ("width", C.c_int), ("height", C.c_int), ("chroma_format_idc", C.c_int),
+        ("bit_depth_luma", C.c_int), ("bit_depth_chroma", C.c_int),
+        ("cwidth", C.c_int), ("cheight", C.c_int),
+        ("plane", C.POINTER(C.c_uint16) * 3),
+        ("colour_primaries", C.c_int), ("transfer_characteristics", C.c_int),
+        ("matrix_coeffs", C.c_int), ("full_range_flag", C.c_int),
+        ("coded_width", C.c_int), ("coded_height", C.c_int),
+        ("ccoded_width", C.c_int), ("ccoded_height", C.c_int),
+        ("pre_deblock", C.POINTER(C.c_uint16) * 3),
+        ("post_deblock", C.POINTER(C.c_uint16) * 3),
+        ("final_coded", C.POINTER(C.c_uint16) * 3),
+        ("coeff", C.POINTER(C.c_int32) * 3),
+        ("map_stride", C.c_int), ("map_height", C.c_int),
+        ("map_log2_tb", C.POINTER(C.c_uint8)), ("map_log2_cb", C.POINTER(C.c_uint8)),
+        ("map_intra_luma", C.POINTER(C.c_uint8)), ("map_intra_chroma", C.POINTER(C.c_uint8)),
+        ("map_qp_y", C.POINTER(C.c_int8)), ("map_flags", C.POINTER(C.c_uint8)),
+        ("ctb_log2", C.c_int), ("ctbs_w", C.c_int), ("ctbs_h", C.c_int),
+        ("sao_type", C.POINTER(C.c_uint8)), ("sao_band_or_class", C.POINTER(C.c_uint8)),
+        ("sao_offset", C.POINTER(C.c_int16)),
+        ("n_bins_ctx", C.c_uint64), ("n_bins_bypass", C.c_uint64), ("n_substreams", C.c_int),
+    ]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.hevc_oracle_decode.restype = C.c_int
+        _LIB.hevc_oracle_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(_Pic), C.c_char_p, C.c_size_t]
+        _LIB.hevc_oracle_free_picture.argtypes = [C.POINTER(_Pic)]
+    return _LIB
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _arr(ptr, shape, dtype):
+    if not ptr:
+        return None
+    n = int(np.prod(shape))
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True).reshape(shape)
+
+
+def decode(stream: bytes, taps: bool = False) -> dict:
+    """Decode one length-prefixed-NAL HEVC intra picture.  Returns a dict of numpy arrays."""
+    L = lib()
+    pic = _Pic()
+    err = C.create_string_buffer(512)
+    rc = L.hevc_oracle_decode(stream, len(stream), 1 if taps else 0, C.byref(pic), err, 512)
+    if rc != 0:
+        raise OracleError(err.value.decode("latin1"))
+    try:
+        nc = 3 if pic.chroma_format_idc else 1
+        out = {
+            "width": pic.width, "height": pic.height, "chroma_format_idc": pic.chroma_format_idc,
+            "bit_depth_luma": pic.bit_depth_luma, "bit_depth_chroma": pic.bit_depth_chroma,
+            "nclx": (pic.colour_primaries, pic.transfer_characteristics, pic.matrix_coeffs, pic.full_range_flag),
+            "coded_size": (pic.coded_width, pic.coded_height),
+            "n_bins_ctx": pic.n_bins_ctx, "n_bins_bypass": pic.n_bins_bypass, "n_substreams": pic.n_substreams,
+            "planes": [],
+        }
+        for c in range(nc):
+            w, h = (pic.width, pic.height) if c == 0 else (pic.cwidth, pic.cheight)
+            out["planes"].append(_arr(pic.plane[c], (h, w), np.uint16))
+        if taps:
+            for name in ("pre_deblock", "post_deblock", "final_coded", "coeff"):
+                lst = []
+                for c in range(nc):
+                    w, h = (pic.coded_width, pic.coded_height) if c == 0 else (pic.ccoded_width, pic.ccoded_height)
+                    lst.append(_arr(getattr(pic, name)[c], (h, w), np.int32 if name == "coeff" else np.uint16))
+                out[name] = lst
+            ms, mh = pic.map_stride, pic.map_height
+            for name, dt in (("map_log2_tb", np.uint8), ("map_log2_cb", np.uint8), ("map_intra_luma", np.uint8),
+                             ("map_intra_chroma", np.uint8), ("map_qp_y", np.int8), ("map_flags", np.uint8)):
+                out[name] = _arr(getattr(pic, name), (mh, ms), dt)
+            nctb = pic.ctbs_w * pic.ctbs_h
+            out["ctb_log2"] = pic.ctb_log2
+            out["ctbs"] = (pic.ctbs_w, pic.ctbs_h)
+            out["sao_type"] = _arr(pic.sao_type, (nctb, 3), np.uint8)
+            out["sao_band_or_class"] = _arr(pic.sao_band_or_class, (nctb, 3), np.uint8)
+            out["sao_offset"] = _arr(pic.sao_offset, (nctb, 3, 4), np.int16)
+        return out
+    finally:
+        L.hevc_oracle_free_picture(C.byref(pic))

@@ -1,0 +1,202 @@
+"""Test tooling: a minimal ISO-BMFF/HEIF reader that extracts, for every `hvc1` item, the exact byte
+string libheif hands to a decoder plugin through push_data2() — the hvcC parameter-set NALs followed
+by the item's iloc payload, each NAL prefixed with a 4-byte big-endian length
+(reference: libheif/codecs/decoder.cc:275-308, libheif/codecs/hevc_boxes.cc:288-309).
+
+Container parsing is NOT part of the product (the product sits behind libheif, which does this
+itself); this module exists so the tests can feed the reference's own .heic fixtures to the oracle
+and to the HIP decoder without libheif in the loop.
+"""
+import struct
+
+
+def _boxes(buf, start, end):
+    pos = start
+    while pos + 8 <= end:
+        size, typ = struct.unpack(">I4s", buf[pos:pos + 8])
+        hdr = 8
+        if size == 1:
+            size = struct.unpack(">Q", buf[pos + 8:pos + 16])[0]
+            hdr = 16
+        elif size == 0:
+            size = end - pos
+        if size < hdr or pos + size > end:
+            break
+        yield typ.decode("latin1"), pos + hdr, pos + size
+        pos += size
+
+
+def _find(buf, start, end, typ):
+    for t, s, e in _boxes(buf, start, end):
+        if t == typ:
+            return s, e
+    return None
+
+
+class HeicFile:
+    def __init__(self, path_or_bytes):
+        if isinstance(path_or_bytes, (bytes, bytearray)):
+            self.buf = bytes(path_or_bytes)
+        else:
+            with open(path_or_bytes, "rb") as f:
+                self.buf = f.read()
+        buf = self.buf
+        meta = _find(buf, 0, len(buf), "meta")
+        if meta is None:
+            raise ValueError("no meta box")
+        ms, me = meta[0] + 4, meta[1]  # FullBox
+        self.items = {}       # id -> type
+        self.iloc = {}        # id -> (construction_method, [(offset, length)])
+        self.props = []       # list of (type, payload bytes)
+        self.assoc = {}       # id -> [property index (1-based)]
+        self.refs = {}        # (type, from_id) -> [to_ids]
+        self.primary = None
+        self.idat = b""
+        for t, s, e in _boxes(buf, ms, me):
+            if t == "pitm":
+                ver = buf[s]
+                self.primary = struct.unpack(">H" if ver == 0 else ">I", buf[s + 4:s + (6 if ver == 0 else 8)])[0]
+            elif t == "iinf":
+                ver = buf[s]
+                p = s + 4 + (2 if ver == 0 else 4)
+                for t2, s2, e2 in _boxes(buf, p, e):
+                    if t2 != "infe":
+                        continue
+                    v = buf[s2]
+                    if v == 2:
+                        iid = struct.unpack(">H", buf[s2 + 4:s2 + 6])[0]
+                        ityp = buf[s2 + 8:s2 + 12].decode("latin1")
+                    elif v == 3:
+                        iid = struct.unpack(">I", buf[s2 + 4:s2 + 8])[0]
+                        ityp = buf[s2 + 10:s2 + 14].decode("latin1")
+                    else:
+                        continue
+                    self.items[iid] = ityp
+            elif t == "iloc":
+                self._parse_iloc(s, e)
+            elif t == "iprp":
+                ipco = _find(buf, s, e, "ipco")
+                if ipco:
+                    for t2, s2, e2 in _boxes(buf, ipco[0], ipco[1]):
+                        self.props.append((t2, buf[s2:e2]))
+                for t2, s2, e2 in _boxes(buf, s, e):
+                    if t2 == "ipma":
+                        self._parse_ipma(s2, e2)
+            elif t == "iref":
+                ver = buf[s]
+                for t2, s2, e2 in _boxes(buf, s + 4, e):
+                    fmt, sz = (">H", 2) if ver == 0 else (">I", 4)
+                    frm = struct.unpack(fmt, buf[s2:s2 + sz])[0]
+                    cnt = struct.unpack(">H", buf[s2 + sz:s2 + sz + 2])[0]
+                    to = [struct.unpack(fmt, buf[s2 + sz + 2 + i * sz:s2 + sz + 2 + (i + 1) * sz])[0] for i in range(cnt)]
+                    self.refs.setdefault((t2, frm), []).extend(to)
+            elif t == "idat":
+                self.idat = buf[s:e]
+
+    def _parse_iloc(self, s, e):
+        buf = self.buf
+        ver = buf[s]
+        a, b = buf[s + 4], buf[s + 5]
+        off_sz, len_sz, base_sz, idx_sz = a >> 4, a & 15, b >> 4, (b & 15) if ver in (1, 2) else 0
+        p = s + 6
+        if ver < 2:
+            n = struct.unpack(">H", buf[p:p + 2])[0]; p += 2
+        else:
+            n = struct.unpack(">I", buf[p:p + 4])[0]; p += 4
+
+        def rd(sz):
+            nonlocal p
+            v = int.from_bytes(buf[p:p + sz], "big") if sz else 0
+            p += sz
+            return v
+        for _ in range(n):
+            iid = rd(2 if ver < 2 else 4)
+            cm = 0
+            if ver in (1, 2):
+                cm = rd(2) & 15
+            rd(2)  # data_reference_index
+            base = rd(base_sz)
+            ext = []
+            for _ in range(rd(2)):
+                if ver in (1, 2) and idx_sz:
+                    rd(idx_sz)
+                o = rd(off_sz); l = rd(len_sz)
+                ext.append((base + o, l))
+            self.iloc[iid] = (cm, ext)
+
+    def _parse_ipma(self, s, e):
+        buf = self.buf
+        ver, flags = buf[s], int.from_bytes(buf[s + 1:s + 4], "big")
+        p = s + 4
+        n = struct.unpack(">I", buf[p:p + 4])[0]; p += 4
+        for _ in range(n):
+            if ver < 1:
+                iid = struct.unpack(">H", buf[p:p + 2])[0]; p += 2
+            else:
+                iid = struct.unpack(">I", buf[p:p + 4])[0]; p += 4
+            cnt = buf[p]; p += 1
+            lst = []
+            for _ in range(cnt):
+                if flags & 1:
+                    v = struct.unpack(">H", buf[p:p + 2])[0] & 0x7FFF; p += 2
+                else:
+                    v = buf[p] & 0x7F; p += 1
+                lst.append(v)
+            self.assoc[iid] = lst
+
+    def item_data(self, iid):
+        cm, ext = self.iloc[iid]
+        src = self.idat if cm == 1 else self.buf
+        return b"".join(src[o:o + (l if l else len(src) - o)] for o, l in ext)
+
+    def item_property(self, iid, typ):
+        for idx in self.assoc.get(iid, []):
+            if 1 <= idx <= len(self.props) and self.props[idx - 1][0] == typ:
+                return self.props[idx - 1][1]
+        return None
+
+    def hevc_items(self):
+        return [i for i, t in sorted(self.items.items()) if t == "hvc1"]
+
+    def ispe(self, iid):
+        p = self.item_property(iid, "ispe")
+        if p is None:
+            return None
+        return struct.unpack(">II", p[4:12])
+
+    def plugin_stream(self, iid):
+        """bytes exactly as libheif pushes them into heif_decoder_plugin.push_data2()."""
+        hvcc = self.item_property(iid, "hvcC")
+        if hvcc is None:
+            raise ValueError("item %d has no hvcC" % iid)
+        length_size = (hvcc[21] & 3) + 1
+        out = bytearray()
+        p = 23
+        for _ in range(hvcc[22]):
+            p += 1  # array_completeness / NAL type
+            n = struct.unpack(">H", hvcc[p:p + 2])[0]; p += 2
+            for _ in range(n):
+                l = struct.unpack(">H", hvcc[p:p + 2])[0]; p += 2
+                out += struct.pack(">I", l) + hvcc[p:p + l]
+                p += l
+        data = self.item_data(iid)
+        if length_size == 4:
+            out += data
+        else:
+            q = 0
+            while q + length_size <= len(data):
+                l = int.from_bytes(data[q:q + length_size], "big"); q += length_size
+                out += struct.pack(">I", l) + data[q:q + l]
+                q += l
+        return bytes(out)
+
+    def grid(self, iid):
+        """(rows, cols, out_w, out_h, [tile item ids]) for a 'grid' item (libheif grid.cc:34-73)."""
+        d = self.item_data(iid)
+        flags = d[1]
+        rows, cols = d[2] + 1, d[3] + 1
+        if flags & 1:
+            w, h = struct.unpack(">II", d[4:12])
+        else:
+            w, h = struct.unpack(">HH", d[4:8])
+        return rows, cols, w, h, self.refs.get(("dimg", iid), [])
