@@ -1,0 +1,171 @@
+/*
+ * heif_hipdec.h — C ABI of the MI355X-native HEIC decode path (libheif_amd/libheifhip.so).
+ *
+ * This is the drop-in boundary below libheif's decoder-plugin layer: plain C, pointers and sizes
+ * only, no torch / C++ types.  Two groups of entry points:
+ *
+ *  1. hipdec_decoder_*  — one instance per coded image, the same life cycle libheif drives through
+ *     heif_decoder_plugin (libheif/api/libheif/heif_plugin.h:85-169; call order in
+ *     libheif/codecs/decoder.cc:355-563):
+ *        new_decoder2 -> push_data2 (xN) -> flush_data -> decode_next_image2 -> free_decoder
+ *     and it replaces what libheif/plugins/decoder_libde265.cc does with libde265
+ *     (push: :322-368, decode: :386-457, plane hand-over: :97-171, VUI colour -> nclx: :426-449).
+ *     hipdec_batch_* decodes many independent items (grid tiles, batches of stills) in one set of
+ *     kernel launches — the device-side form of libheif/image-items/grid.cc:405-453.
+ *
+ *  2. hipdec_color_* — the fused colour stage over planes resident in HBM; each entry point
+ *     restates one ColorConversionOperation of libheif/color-conversion (file:line at each
+ *     declaration) bit-exactly (integer ops) or with identical float arithmetic (FMA contraction
+ *     off).
+ *
+ * All `stride` arguments are in BYTES.  Device pointers are HIP device pointers of the device
+ * selected with hipdec_init().  `stream` is a hipStream_t cast to void* (NULL = the library's
+ * default stream).  Every function returns 0 on success or a negative hipdec_status; a
+ * thread-local message is available from hipdec_last_error().
+ */
+#ifndef HEIF_HIPDEC_H
+#define HEIF_HIPDEC_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define HIPDEC_API __attribute__((visibility("default")))
+#else
+#define HIPDEC_API
+#endif
+
+typedef enum hipdec_status {
+  HIPDEC_OK = 0,
+  HIPDEC_ERR_INVALID_ARGUMENT = -1,
+  HIPDEC_ERR_END_OF_DATA = -2,       /* truncated NAL framing (heif_suberror_End_of_data)          */
+  HIPDEC_ERR_BITSTREAM = -3,         /* malformed / non-conformant HEVC syntax                     */
+  HIPDEC_ERR_UNSUPPORTED = -4,       /* valid HEVC outside the implemented tool set                */
+  HIPDEC_ERR_LIMIT = -5,             /* security limit exceeded (max_image_size_pixels)            */
+  HIPDEC_ERR_DEVICE = -6,            /* HIP runtime error / no device / kernel fault               */
+  HIPDEC_ERR_NO_IMAGE = -7,          /* nothing decodable was pushed                               */
+  HIPDEC_ERR_DECODE = -8             /* device-side decode error (substream desynchronised ...)    */
+} hipdec_status;
+
+/* ---- library ---------------------------------------------------------------------------------- */
+HIPDEC_API int hipdec_init(int device_index);          /* idempotent; selects the device            */
+HIPDEC_API void hipdec_shutdown(void);
+HIPDEC_API const char* hipdec_last_error(void);        /* thread-local, never NULL                  */
+HIPDEC_API const char* hipdec_version(void);
+HIPDEC_API int hipdec_device_count(void);
+
+/* small device-memory helpers so that callers without a HIP toolchain (ctypes, cgo, JNI) can stage
+ * buffers; real integrations pass their own device pointers */
+HIPDEC_API void* hipdec_malloc(size_t bytes);
+HIPDEC_API void hipdec_free(void* dptr);
+HIPDEC_API int hipdec_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+HIPDEC_API int hipdec_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+HIPDEC_API int hipdec_memset(void* dst_dev, int value, size_t bytes);
+HIPDEC_API int hipdec_stream_synchronize(void* stream);
+
+/* ---- decoder ---------------------------------------------------------------------------------- */
+typedef struct hipdec_decoder hipdec_decoder;
+
+typedef struct hipdec_image_info {
+  int width, height;              /* luma size after the conformance-window crop (== ispe)        */
+  int chroma_format_idc;          /* 0 = 4:0:0, 1 = 4:2:0  (== heif_chroma numeric value)          */
+  int chroma_width, chroma_height;
+  int bit_depth_luma, bit_depth_chroma;
+  /* VUI colour description as libde265 reports it (decoder_libde265.cc:426-449); H.265 Annex E
+     defaults (2,2,2,limited) when absent */
+  int colour_primaries, transfer_characteristics, matrix_coeffs, full_range_flag;
+  int coded_width, coded_height;  /* pic_width/height_in_luma_samples                              */
+  size_t bitstream_bytes;
+  int num_substreams;             /* independent CABAC substreams (slices x tiles / WPP rows)      */
+} hipdec_image_info;
+
+/* new_decoder2 (heif_plugin.h:158; decoder_libde265.cc:175-214).  max_image_size_pixels == 0
+ * means "no limit" (heif_security_limits.max_image_size_pixels, enforced before allocation as
+ * decoder_libde265.cc:183-199 does). */
+HIPDEC_API int hipdec_decoder_new(hipdec_decoder** out, int strict_decoding, uint64_t max_image_size_pixels);
+HIPDEC_API void hipdec_decoder_free(hipdec_decoder* dec);
+HIPDEC_API void hipdec_decoder_set_strict(hipdec_decoder* dec, int strict_decoding);
+
+/* push_data2 (heif_plugin.h:160; decoder_libde265.cc:322-368): `data` is a concatenation of
+ * [4-byte big-endian length][NAL unit without start code]; parameter sets first.  May be called
+ * several times; the bytes are copied. */
+HIPDEC_API int hipdec_decoder_push_data(hipdec_decoder* dec, const void* data, size_t size);
+
+/* decode_next_image2 (heif_plugin.h:164; decoder_libde265.cc:386-457): parses the headers on the
+ * host, runs the HIP decode pipeline and leaves the planes in HBM.  Returns HIPDEC_ERR_NO_IMAGE
+ * when no picture was pushed (libheif sees "no image yet"). */
+HIPDEC_API int hipdec_decoder_decode(hipdec_decoder* dec, hipdec_image_info* info);
+
+/* plane hand-over (decoder_libde265.cc:97-171): copies plane c (0 = Y, 1 = Cb, 2 = Cr) into a host
+ * buffer with the caller's stride; samples are uint8 for bit depth 8, little-endian uint16
+ * above. */
+HIPDEC_API int hipdec_decoder_read_plane(hipdec_decoder* dec, int c, void* dst_host, size_t dst_stride);
+/* device-resident hand-over for callers that keep the colour stage on the GPU */
+HIPDEC_API int hipdec_decoder_device_plane(hipdec_decoder* dec, int c, const void** dptr, size_t* stride);
+
+/* ---- batch decode (grid tiles / throughput mode) ------------------------------------------- */
+typedef struct hipdec_batch hipdec_batch;
+/* Parses n independent items (same framing as push_data) and uploads them; all items must share
+ * chroma format and bit depth.  The timed hot path is hipdec_batch_run(): inputs are resident in
+ * HBM when it starts and decoded planes are resident in HBM when it (asynchronously) ends. */
+HIPDEC_API int hipdec_batch_create(hipdec_batch** out, int n, const void* const* data, const size_t* sizes,
+                                   uint64_t max_image_size_pixels);
+HIPDEC_API void hipdec_batch_free(hipdec_batch* b);
+HIPDEC_API int hipdec_batch_count(const hipdec_batch* b);
+HIPDEC_API int hipdec_batch_info(const hipdec_batch* b, int i, hipdec_image_info* info);
+HIPDEC_API int hipdec_batch_run(hipdec_batch* b, void* stream);      /* asynchronous                 */
+HIPDEC_API int hipdec_batch_status(hipdec_batch* b);                 /* synchronises; device errors  */
+HIPDEC_API int hipdec_batch_read_plane(hipdec_batch* b, int i, int c, void* dst_host, size_t dst_stride);
+HIPDEC_API int hipdec_batch_device_plane(hipdec_batch* b, int i, int c, const void** dptr, size_t* stride);
+/* Fused colour stage over item i (planes -> interleaved RGB in HBM), see hipdec_color_* below;
+ * out_chroma uses heif_chroma numeric values (10 = RGB, 11 = RGBA, 12/14 = RRGGBB BE/LE). */
+HIPDEC_API int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void* out_dev, size_t out_stride,
+                                   void* stream);
+/* per-kernel device time of the last run in microseconds (HIP events on the launch stream):
+ * [0] CABAC parse, [1] reconstruction, [2] deblock, [3] SAO + crop, [4] total */
+HIPDEC_API int hipdec_batch_last_timing_us(hipdec_batch* b, float out[5]);
+/* debug / test taps of item i after a run (device -> host): which = 0 pre-deblock, 1 post-deblock */
+HIPDEC_API int hipdec_batch_read_tap(hipdec_batch* b, int i, int which, int c, void* dst_host, size_t dst_stride);
+HIPDEC_API int hipdec_batch_read_maps(hipdec_batch* b, int i, uint8_t* log2_tb, uint8_t* log2_cb, uint8_t* intra_luma,
+                                      uint8_t* intra_chroma, int8_t* qp_y, uint8_t* flags, size_t map_elems);
+
+/* ---- colour stage ---------------------------------------------------------------------------- */
+typedef struct hipdec_nclx {
+  int has_nclx;               /* 0: the image carries no nclx profile (reference uses its defaults) */
+  int colour_primaries, transfer_characteristics, matrix_coefficients, full_range_flag;
+} hipdec_nclx;
+
+/* Op_YCbCr420_to_RGB24 / Op_YCbCr420_to_RGB32 (libheif/color-conversion/yuv2rgb.cc:345-426,
+ * :481-562): 8-bit 4:2:0, 8.8 fixed point, nearest-neighbour chroma, alpha filled with 0xFF. */
+HIPDEC_API int hipdec_color_420_to_rgb24(const void* y, size_t ys, const void* cb, size_t cbs, const void* cr, size_t crs,
+                                         int w, int h, const hipdec_nclx* nclx, void* out, size_t out_stride,
+                                         int with_alpha, void* stream);
+/* Op_YCbCr_to_RGB<uint8_t/uint16_t> (yuv2rgb.cc:92-292): float32, NN chroma, planar R,G,B out with
+ * the input's bit depth.  chroma: 1 = 4:2:0, 2 = 4:2:2, 3 = 4:4:4. */
+HIPDEC_API int hipdec_color_ycbcr_to_rgb_planar(const void* y, size_t ys, const void* cb, size_t cbs, const void* cr,
+                                                size_t crs, int w, int h, int bpp, int chroma, const hipdec_nclx* nclx,
+                                                void* r, void* g, void* b, size_t out_stride, void* stream);
+/* Op_YCbCr_to_RGB<uint8_t> followed by Op_RGB_to_RGB24_32 (rgb2rgb.cc:72-150) fused into one pass:
+ * what libheif's planner runs for limited-range 8-bit input. */
+HIPDEC_API int hipdec_color_ycbcr_to_rgb24_float(const void* y, size_t ys, const void* cb, size_t cbs, const void* cr,
+                                                 size_t crs, int w, int h, int chroma, const hipdec_nclx* nclx,
+                                                 void* out, size_t out_stride, int with_alpha, void* stream);
+/* Op_YCbCr420_to_RRGGBBaa (yuv2rgb.cc:622-734): >8-bit 4:2:0 -> 16-bit interleaved BE or LE. */
+HIPDEC_API int hipdec_color_420_to_rrggbb(const void* y, size_t ys, const void* cb, size_t cbs, const void* cr, size_t crs,
+                                          int w, int h, int bpp, const hipdec_nclx* nclx, void* out, size_t out_stride,
+                                          int little_endian, void* stream);
+/* Op_YCbCr420_bilinear_to_YCbCr444<Pixel> (chroma_sampling.cc:501-724), one chroma plane;
+ * (w, h) = luma size; reproduces the reference's border indexing. */
+HIPDEC_API int hipdec_color_bilinear_420_to_444(const void* in, size_t is, int w, int h, int bpp, void* out, size_t os,
+                                                void* stream);
+/* Op_to_sdr_planes (hdr_sdr.cc:146-244): v >> (bits - 8), uint16 -> uint8. */
+HIPDEC_API int hipdec_color_to_sdr(const void* in, size_t is, int w, int h, int bits, void* out, size_t os, void* stream);
+/* nclx.cc:143-173 get_YCbCr_to_RGB_coefficients: {r_cr, g_cb, g_cr, b_cb} */
+HIPDEC_API void hipdec_color_coefficients(const hipdec_nclx* nclx, float out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

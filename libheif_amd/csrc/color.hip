@@ -1,0 +1,466 @@
+// color.hip — fused colour stage over decoded planes in HBM (hand-written HIP for gfx950).
+//
+// Restates, bit-exactly, the ColorConversionOperations that libheif's pipeline planner selects for
+// HEIC stills:
+//   a9   Op_YCbCr420_to_RGB24/_RGB32        libheif/color-conversion/yuv2rgb.cc:345-426, :481-562
+//   a10  Op_YCbCr_to_RGB<u8/u16>            libheif/color-conversion/yuv2rgb.cc:92-292
+//   a11  Op_RGB_to_RGB24_32                 libheif/color-conversion/rgb2rgb.cc:72-150 (fused into a10)
+//   a12  Op_YCbCr420_to_RRGGBBaa            libheif/color-conversion/yuv2rgb.cc:622-734
+//   a13  Op_YCbCr420_bilinear_to_YCbCr444   libheif/color-conversion/chroma_sampling.cc:501-724
+//   a14  Op_to_sdr_planes                   libheif/color-conversion/hdr_sdr.cc:146-244
+//   a15  get_YCbCr_to_RGB_coefficients      libheif/nclx.cc:84-173
+//
+// Roofline: pure streaming, HBM-bound.  Algorithmic bytes per luma pixel: 1.5*s in + 3*s_out out
+// (RGB24 from 8-bit 4:2:0: 4.5 B/px).  Each thread converts a 4x2 luma block so that the chroma
+// pair is read once, Y is read as one dword per row and RGB24 leaves as one 12-byte store per row
+// (64 lanes -> 768 contiguous bytes per wave-store).
+// Float parity: compiled with -ffp-contract=off; the reference build (x86-64 baseline) has no FMA.
+#include "hipdec_internal.h"
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+enum Arith { AR_INT88 = 0, AR_FLOAT = 1, AR_GBR_FULL = 2, AR_GBR_LIMITED = 3, AR_YCGCO = 4, AR_YCGCO_RE = 5 };
+enum Layout { LO_PLANAR = 0, LO_RGB24 = 1, LO_RGBA32 = 2, LO_RRGGBB_BE = 3, LO_RRGGBB_LE = 4 };
+
+struct ColorParams {
+  const uint8_t *y, *cb, *cr;
+  size_t ys, cbs, crs;
+  uint8_t *o0, *o1, *o2;
+  size_t os;
+  int w, h, bpp, shiftH, shiftV;
+  int arith;
+  int i_r_cr, i_g_cb, i_g_cr, i_b_cb;
+  float f_r_cr, f_g_cb, f_g_cr, f_b_cb;
+  int full_range;
+};
+
+__device__ __forceinline__ int clip_i(int x, int maxi) { return x < 0 ? 0 : (x > maxi ? maxi : x); }
+// libheif/common_utils.h:108-114 clip_f_u16: (int32)(fx + 0.5f), then clamp
+__device__ __forceinline__ int clip_f(float fx, int maxi)
+{
+  int x = (int)(fx + 0.5f);
+  return x < 0 ? 0 : (x > maxi ? maxi : x);
+}
+
+__device__ __forceinline__ void convert_px(const ColorParams& p, int Y, int Cb, int Cr, int& R, int& G, int& B)
+{
+  const int fullRange = (1 << p.bpp) - 1;
+  const int halfRange = 1 << (p.bpp - 1);
+  switch (p.arith) {
+    case AR_INT88: {  // yuv2rgb.cc:377-421
+      int cb = Cb - 128, cr = Cr - 128;
+      R = clip_i(Y + ((p.i_r_cr * cr + 128) >> 8), 255);
+      G = clip_i(Y + ((p.i_g_cb * cb + p.i_g_cr * cr + 128) >> 8), 255);
+      B = clip_i(Y + ((p.i_b_cb * cb + 128) >> 8), 255);
+      break;
+    }
+    case AR_GBR_FULL: R = Cr; G = Y; B = Cb; break;  // yuv2rgb.cc:224-229
+    case AR_GBR_LIMITED: {                             // yuv2rgb.cc:230-236
+      float off = (float)(16 << (p.bpp - 8));
+      R = clip_f(((float)Cr - off) * 1.1429f, fullRange);
+      G = clip_f(((float)Y - off) * 1.1689f, fullRange);
+      B = clip_f(((float)Cb - off) * 1.1429f, fullRange);
+      break;
+    }
+    case AR_YCGCO: {  // yuv2rgb.cc:237-249 (clip_int_u8 even for >8 bit, as the reference does)
+      int cb = Cb - halfRange, cr = Cr - halfRange;
+      R = clip_i(Y - cb + cr, 255); G = clip_i(Y + cb, 255); B = clip_i(Y - cb - cr, 255);
+      break;
+    }
+    case AR_YCGCO_RE: {  // yuv2rgb.cc:250-266, int16 arithmetic
+      short yy = (short)Y;
+      short cb = (short)((short)Cb - (short)halfRange), cr = (short)((short)Cr - (short)halfRange);
+      short t = (short)(yy - (cb >> 1));
+      short g = (short)(t + cb);
+      short b = (short)(t - (cr >> 1));
+      short r = (short)(b + cr);
+      R = clip_i(r * 4, fullRange); G = clip_i(g * 4, fullRange); B = clip_i(b * 4, fullRange);
+      break;
+    }
+    default: {  // AR_FLOAT  yuv2rgb.cc:267-282 / :699-710
+      float yv = (float)Y, cb = (float)(Cb - halfRange), cr = (float)(Cr - halfRange);
+      if (!p.full_range) {
+        yv = (yv - (float)(16 << (p.bpp - 8))) * 1.1689f;
+        cb = cb * 1.1429f;
+        cr = cr * 1.1429f;
+      }
+      R = clip_f(yv + p.f_r_cr * cr, fullRange);
+      G = clip_f(yv + p.f_g_cb * cb + p.f_g_cr * cr, fullRange);
+      B = clip_f(yv + p.f_b_cb * cb, fullRange);
+      break;
+    }
+  }
+}
+
+struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
+
+template <typename Pix, int LAYOUT>
+__global__ __launch_bounds__(256) void k_ycbcr_to_rgb(ColorParams p)
+{
+  const int bx = blockIdx.x * blockDim.x + threadIdx.x;  // 4-pixel column group
+  const int by = blockIdx.y * blockDim.y + threadIdx.y;  // row pair
+  const int x0 = bx * 4, y0 = by * 2;
+  if (x0 >= p.w || y0 >= p.h) return;
+  const int npx = min(4, p.w - x0);
+#pragma unroll
+  for (int dy = 0; dy < 2; dy++) {
+    const int yy = y0 + dy;
+    if (yy >= p.h) break;
+    const Pix* yrow = (const Pix*)(p.y + (size_t)yy * p.ys);
+    const Pix* cbrow = (const Pix*)(p.cb + (size_t)(yy >> p.shiftV) * p.cbs);
+    const Pix* crrow = (const Pix*)(p.cr + (size_t)(yy >> p.shiftV) * p.crs);
+    int Y[4], CB[4], CR[4];
+    if (npx == 4 && sizeof(Pix) == 1 && (((uintptr_t)(yrow + x0)) & 3) == 0) {
+      uint32_t v = *(const uint32_t*)(yrow + x0);
+      Y[0] = v & 255; Y[1] = (v >> 8) & 255; Y[2] = (v >> 16) & 255; Y[3] = v >> 24;
+    } else if (npx == 4 && sizeof(Pix) == 2 && (((uintptr_t)(yrow + x0)) & 7) == 0) {
+      uint2 v = *(const uint2*)(yrow + x0);
+      Y[0] = v.x & 0xffff; Y[1] = v.x >> 16; Y[2] = v.y & 0xffff; Y[3] = v.y >> 16;
+    } else {
+      for (int i = 0; i < 4; i++) Y[i] = i < npx ? yrow[x0 + i] : 0;
+    }
+    if (p.shiftH) {
+      int c0 = x0 >> 1;
+      int cbA = cbrow[c0], crA = crrow[c0];
+      int cbB = cbA, crB = crA;
+      if (npx > 2) { cbB = cbrow[c0 + 1]; crB = crrow[c0 + 1]; }
+      CB[0] = CB[1] = cbA; CB[2] = CB[3] = cbB;
+      CR[0] = CR[1] = crA; CR[2] = CR[3] = crB;
+    } else {
+      for (int i = 0; i < 4; i++) { CB[i] = i < npx ? cbrow[x0 + i] : 0; CR[i] = i < npx ? crrow[x0 + i] : 0; }
+    }
+    int R[4], G[4], B[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) convert_px(p, Y[i], CB[i], CR[i], R[i], G[i], B[i]);
+
+    if (LAYOUT == LO_PLANAR) {
+      Pix* r = (Pix*)(p.o0 + (size_t)yy * p.os) + x0;
+      Pix* g = (Pix*)(p.o1 + (size_t)yy * p.os) + x0;
+      Pix* b = (Pix*)(p.o2 + (size_t)yy * p.os) + x0;
+      if (npx == 4 && sizeof(Pix) == 1 && ((p.os | (uintptr_t)p.o0 | (uintptr_t)p.o1 | (uintptr_t)p.o2) & 3) == 0) {
+        *(uint32_t*)r = R[0] | (R[1] << 8) | (R[2] << 16) | ((uint32_t)R[3] << 24);
+        *(uint32_t*)g = G[0] | (G[1] << 8) | (G[2] << 16) | ((uint32_t)G[3] << 24);
+        *(uint32_t*)b = B[0] | (B[1] << 8) | (B[2] << 16) | ((uint32_t)B[3] << 24);
+      } else if (npx == 4 && sizeof(Pix) == 2 && ((p.os | (uintptr_t)p.o0 | (uintptr_t)p.o1 | (uintptr_t)p.o2) & 7) == 0) {
+        *(uint2*)r = make_uint2(R[0] | (R[1] << 16), R[2] | (R[3] << 16));
+        *(uint2*)g = make_uint2(G[0] | (G[1] << 16), G[2] | (G[3] << 16));
+        *(uint2*)b = make_uint2(B[0] | (B[1] << 16), B[2] | (B[3] << 16));
+      } else {
+        for (int i = 0; i < npx; i++) { r[i] = (Pix)R[i]; g[i] = (Pix)G[i]; b[i] = (Pix)B[i]; }
+      }
+    } else if (LAYOUT == LO_RGB24) {
+      uint8_t* o = p.o0 + (size_t)yy * p.os + (size_t)x0 * 3;
+      if (npx == 4 && ((p.os | (uintptr_t)p.o0) & 3) == 0) {
+        U3 v;
+        v.a = R[0] | (G[0] << 8) | (B[0] << 16) | ((uint32_t)R[1] << 24);
+        v.b = G[1] | (B[1] << 8) | (R[2] << 16) | ((uint32_t)G[2] << 24);
+        v.c = B[2] | (R[3] << 8) | (G[3] << 16) | ((uint32_t)B[3] << 24);
+        *(U3*)o = v;
+      } else {
+        for (int i = 0; i < npx; i++) { o[3 * i] = (uint8_t)R[i]; o[3 * i + 1] = (uint8_t)G[i]; o[3 * i + 2] = (uint8_t)B[i]; }
+      }
+    } else if (LAYOUT == LO_RGBA32) {
+      uint8_t* o = p.o0 + (size_t)yy * p.os + (size_t)x0 * 4;
+      if (npx == 4 && ((p.os | (uintptr_t)p.o0) & 15) == 0) {
+        uint4 v;
+        v.x = R[0] | (G[0] << 8) | (B[0] << 16) | 0xFF000000u;
+        v.y = R[1] | (G[1] << 8) | (B[1] << 16) | 0xFF000000u;
+        v.z = R[2] | (G[2] << 8) | (B[2] << 16) | 0xFF000000u;
+        v.w = R[3] | (G[3] << 8) | (B[3] << 16) | 0xFF000000u;
+        *(uint4*)o = v;
+      } else {
+        for (int i = 0; i < npx; i++) { o[4 * i] = (uint8_t)R[i]; o[4 * i + 1] = (uint8_t)G[i]; o[4 * i + 2] = (uint8_t)B[i]; o[4 * i + 3] = 0xFF; }
+      }
+    } else {  // RRGGBB BE / LE, yuv2rgb.cc:717-723
+      uint8_t* o = p.o0 + (size_t)yy * p.os + (size_t)x0 * 6;
+      const bool le = LAYOUT == LO_RRGGBB_LE;
+      uint16_t s[12];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        int r = R[i], g = G[i], b = B[i];
+        if (!le) { r = ((r & 255) << 8) | (r >> 8); g = ((g & 255) << 8) | (g >> 8); b = ((b & 255) << 8) | (b >> 8); }
+        s[3 * i] = (uint16_t)r; s[3 * i + 1] = (uint16_t)g; s[3 * i + 2] = (uint16_t)b;
+      }
+      if (npx == 4 && ((p.os | (uintptr_t)p.o0) & 3) == 0) {
+        U3 v0, v1;
+        v0.a = s[0] | ((uint32_t)s[1] << 16); v0.b = s[2] | ((uint32_t)s[3] << 16); v0.c = s[4] | ((uint32_t)s[5] << 16);
+        v1.a = s[6] | ((uint32_t)s[7] << 16); v1.b = s[8] | ((uint32_t)s[9] << 16); v1.c = s[10] | ((uint32_t)s[11] << 16);
+        ((U3*)o)[0] = v0; ((U3*)o)[1] = v1;
+      } else {
+        for (int i = 0; i < npx * 3; i++) { o[2 * i] = (uint8_t)(s[i] & 255); o[2 * i + 1] = (uint8_t)(s[i] >> 8); }
+      }
+    }
+  }
+}
+
+// a13: one thread per 4 output samples of one row
+template <typename Pix>
+__device__ __forceinline__ int bilinear_at(const Pix* in, size_t is /*samples*/, int w, int h, int x, int y)
+{
+  // chroma_sampling.cc:611-708, expressed per output sample.  `is` is the input stride in samples.
+  if (x == 0 && y == 0) return in[0];
+  if (y == 0) {  // top border (note the reference's cx / 2 indexing, :620-626)
+    if ((x & 1) && (x - 1) / 2 < (w - 1) / 2) { int cx = (x - 1) / 2; return (3 * in[cx / 2] + 1 * in[cx / 2 + 1] + 2) / 4; }
+    if (!(x & 1) && (x - 2) / 2 < (w - 1) / 2) { int cx = (x - 2) / 2; return (1 * in[cx / 2] + 3 * in[cx / 2 + 1] + 2) / 4; }
+    if (w % 2 == 0 && x == w - 1) return in[w / 2 - 1];
+    return 0;
+  }
+  if (x == 0) {  // left border :635-640
+    if ((y & 1) && (y - 1) / 2 < (h - 1) / 2) { int cy = (y - 1) / 2; return (3 * in[(cy / 2) * is] + 1 * in[(cy / 2 + 1) * is] + 2) / 4; }
+    if (!(y & 1) && (y - 2) / 2 < (h - 1) / 2) { int cy = (y - 2) / 2; return (1 * in[(cy / 2) * is] + 3 * in[(cy / 2 + 1) * is] + 2) / 4; }
+    if (h % 2 == 0 && y == h - 1) return in[(h / 2 - 1) * is];
+    return 0;
+  }
+  if (w % 2 == 0 && x == w - 1) {  // right border :649-656
+    if (h % 2 == 0 && y == h - 1) return in[(h / 2 - 1) * is + w / 2 - 1];
+    if ((y & 1) && (y - 1) / 2 < (h - 1) / 2) { int cy = (y - 1) / 2; return (3 * in[(cy / 2) * is + w / 2 - 1] + 1 * in[(cy / 2 + 1) * is + w / 2 - 1] + 2) / 4; }
+    if (!(y & 1) && (y - 2) / 2 < (h - 1) / 2) { int cy = (y - 2) / 2; return (1 * in[(cy / 2) * is + w / 2 - 1] + 3 * in[(cy / 2 + 1) * is + w / 2 - 1] + 2) / 4; }
+    return 0;
+  }
+  if (h % 2 == 0 && y == h - 1) {  // bottom border :660-667
+    const Pix* row = in + (size_t)(h / 2 - 1) * is;
+    if ((x & 1) && (x - 1) / 2 < (w - 1) / 2) { int cx = (x - 1) / 2; return (3 * row[cx / 2] + 1 * row[cx / 2 + 1] + 2) / 4; }
+    if (!(x & 1) && (x - 2) / 2 < (w - 1) / 2) { int cx = (x - 2) / 2; return (1 * row[cx / 2] + 3 * row[cx / 2 + 1] + 2) / 4; }
+    return 0;
+  }
+  // interior :678-708
+  int xb = (x & 1) ? x : x - 1, yb = (y & 1) ? y : y - 1;
+  if (xb >= w - 1 || yb >= h - 1) return 0;
+  int cx = xb / 2, cy = yb / 2;
+  int c00 = in[cy * is + cx], c01 = in[cy * is + cx + 1], c10 = in[(cy + 1) * is + cx], c11 = in[(cy + 1) * is + cx + 1];
+  int wx1 = (x == xb) ? 1 : 3, wx0 = 4 - wx1;  // weight of the right / left chroma sample
+  int wy1 = (y == yb) ? 1 : 3, wy0 = 4 - wy1;
+  return (c00 * wx0 * wy0 + c01 * wx1 * wy0 + c10 * wx0 * wy1 + c11 * wx1 * wy1 + 8) / 16;
+}
+
+template <typename Pix>
+__global__ __launch_bounds__(256) void k_bilinear_420_to_444(const uint8_t* in, size_t is, int w, int h, uint8_t* out, size_t os)
+{
+  const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x0 >= w || y >= h) return;
+  const Pix* src = (const Pix*)in;
+  Pix* dst = (Pix*)(out + (size_t)y * os);
+  const size_t iss = is / sizeof(Pix);
+  for (int i = 0; i < 4 && x0 + i < w; i++) dst[x0 + i] = (Pix)bilinear_at<Pix>(src, iss, w, h, x0 + i, y);
+}
+
+__global__ __launch_bounds__(256) void k_to_sdr(const uint8_t* in, size_t is, int w, int h, int shift, uint8_t* out, size_t os)
+{
+  const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x0 >= w || y >= h) return;
+  const uint16_t* src = (const uint16_t*)(in + (size_t)y * is);
+  uint8_t* dst = out + (size_t)y * os;
+  if (x0 + 3 < w && ((is | (uintptr_t)in) & 7) == 0 && ((os | (uintptr_t)out) & 3) == 0) {
+    uint2 v = *(const uint2*)(src + x0);
+    uint32_t o = ((v.x & 0xffff) >> shift) | (((v.x >> 16) >> shift) << 8) | (((v.y & 0xffff) >> shift) << 16) | (((v.y >> 16) >> shift) << 24);
+    *(uint32_t*)(dst + x0) = o;
+  } else {
+    for (int i = 0; i < 4 && x0 + i < w; i++) dst[x0 + i] = (uint8_t)(src[x0 + i] >> shift);
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------
+
+// libheif/nclx.cc:45-72
+bool primaries_of(int idx, float p[8])
+{
+  static const float t[][9] = {
+      {1, 0.300f, 0.600f, 0.150f, 0.060f, 0.640f, 0.330f, 0.3127f, 0.3290f},
+      {4, 0.21f, 0.71f, 0.14f, 0.08f, 0.67f, 0.33f, 0.310f, 0.316f},
+      {5, 0.29f, 0.60f, 0.15f, 0.06f, 0.64f, 0.33f, 0.3127f, 0.3290f},
+      {6, 0.310f, 0.595f, 0.155f, 0.070f, 0.630f, 0.340f, 0.3127f, 0.3290f},
+      {7, 0.310f, 0.595f, 0.155f, 0.070f, 0.630f, 0.340f, 0.3127f, 0.3290f},
+      {8, 0.243f, 0.692f, 0.145f, 0.049f, 0.681f, 0.319f, 0.310f, 0.316f},
+      {9, 0.170f, 0.797f, 0.131f, 0.046f, 0.708f, 0.292f, 0.3127f, 0.3290f},
+      {10, 0.0f, 1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.333333f, 0.33333f},
+      {11, 0.265f, 0.690f, 0.150f, 0.060f, 0.680f, 0.320f, 0.314f, 0.351f},
+      {12, 0.265f, 0.690f, 0.150f, 0.060f, 0.680f, 0.320f, 0.3127f, 0.3290f},
+      {22, 0.295f, 0.605f, 0.155f, 0.077f, 0.630f, 0.340f, 0.3127f, 0.3290f}};
+  for (auto& r : t)
+    if ((int)r[0] == idx) { memcpy(p, &r[1], 8 * sizeof(float)); return true; }
+  memset(p, 0, 8 * sizeof(float));
+  return false;
+}
+
+// libheif/nclx.cc:84-173.  Host float arithmetic, contraction off, same operation order.
+void coefficients(const hipdec_nclx* n, float out[4])
+{
+  float Kr = 0, Kb = 0;
+  if (n && n->has_nclx) {
+    int m = n->matrix_coefficients;
+    if (m == 12 || m == 13) {
+      float p[8];
+      primaries_of(n->colour_primaries, p);
+      float gx = p[0], gy = p[1], bx = p[2], by = p[3], rx = p[4], ry = p[5], wx = p[6], wy = p[7];
+      float zr = 1 - (rx + ry), zg = 1 - (gx + gy), zb = 1 - (bx + by), zw = 1 - (wx + wy);
+      float denom = wy * (rx * (gy * zb - by * zg) + gx * (by * zr - ry * zb) + bx * (ry * zg - gy * zr));
+      if (denom != 0.0f) {
+        Kr = (ry * (wx * (gy * zb - by * zg) + wy * (bx * zg - gx * zb) + zw * (gx * by - bx * gy))) / denom;
+        Kb = (by * (wx * (ry * zg - gy * zr) + wy * (gx * zr - rx * zg) + zw * (rx * gy - gx * ry))) / denom;
+      }
+    } else {
+      switch (m) {
+        case 1: Kr = 0.2126f; Kb = 0.0722f; break;
+        case 4: Kr = 0.30f; Kb = 0.11f; break;
+        case 5: case 6: Kr = 0.299f; Kb = 0.114f; break;
+        case 7: Kr = 0.212f; Kb = 0.087f; break;
+        case 9: case 10: Kr = 0.2627f; Kb = 0.0593f; break;
+        default: break;
+      }
+    }
+  }
+  if (Kb != 0 || Kr != 0) {
+    out[0] = 2 * (-Kr + 1);
+    out[1] = 2 * Kb * (-Kb + 1) / (Kb + Kr - 1);
+    out[2] = 2 * Kr * (-Kr + 1) / (Kb + Kr - 1);
+    out[3] = 2 * (-Kb + 1);
+  } else {
+    out[0] = 1.402f; out[1] = -0.344136f; out[2] = -0.714136f; out[3] = 1.772f;
+  }
+}
+
+template <typename Pix, int LAYOUT>
+int launch_rgb(const ColorParams& p, hipStream_t s)
+{
+  dim3 block(64, 4);
+  dim3 grid(((p.w + 3) / 4 + 63) / 64, ((p.h + 1) / 2 + 3) / 4);
+  hipLaunchKernelGGL((k_ycbcr_to_rgb<Pix, LAYOUT>), grid, block, 0, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hipdec::set_error(HIPDEC_ERR_DEVICE, "colour kernel launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int fill_common(ColorParams& p, const void* y, size_t ys, const void* cb, size_t cbs, const void* cr, size_t crs, int w,
+                int h, int bpp, int chroma, const hipdec_nclx* nclx)
+{
+  if (!y || !cb || !cr || w <= 0 || h <= 0) return hipdec::set_error(HIPDEC_ERR_INVALID_ARGUMENT, "colour: bad plane arguments");
+  if (chroma < 1 || chroma > 3) return hipdec::set_error(HIPDEC_ERR_INVALID_ARGUMENT, "colour: chroma must be 1 (420), 2 (422) or 3 (444)");
+  memset(&p, 0, sizeof(p));
+  p.y = (const uint8_t*)y; p.cb = (const uint8_t*)cb; p.cr = (const uint8_t*)cr;
+  p.ys = ys; p.cbs = cbs; p.crs = crs; p.w = w; p.h = h; p.bpp = bpp;
+  p.shiftH = chroma == 3 ? 0 : 1;
+  p.shiftV = chroma == 1 ? 1 : 0;
+  float c[4];
+  coefficients(nclx, c);
+  p.f_r_cr = c[0]; p.f_g_cb = c[1]; p.f_g_cr = c[2]; p.f_b_cb = c[3];
+  p.i_r_cr = (int)std::lround(256 * c[0]); p.i_g_cb = (int)std::lround(256 * c[1]);
+  p.i_g_cr = (int)std::lround(256 * c[2]); p.i_b_cb = (int)std::lround(256 * c[3]);
+  p.full_range = (nclx && nclx->has_nclx) ? nclx->full_range_flag : 1;
+  return 0;
+}
+
+// arithmetic selection of Op_YCbCr_to_RGB (yuv2rgb.cc:208-282)
+int generic_arith(const hipdec_nclx* nclx)
+{
+  int matrix = (nclx && nclx->has_nclx) ? nclx->matrix_coefficients : 2;
+  int full = (nclx && nclx->has_nclx) ? nclx->full_range_flag : 1;
+  if (matrix == 0) return full ? AR_GBR_FULL : AR_GBR_LIMITED;
+  if (matrix == 8) return AR_YCGCO;
+  if (matrix == 16) return AR_YCGCO_RE;
+  return AR_FLOAT;
+}
+
+}  // namespace
+
+using namespace hipdec;
+
+extern "C" {
+
+void hipdec_color_coefficients(const hipdec_nclx* nclx, float out[4]) { coefficients(nclx, out); }
+
+int hipdec_color_420_to_rgb24(const void* y, size_t ys, const void* cb, size_t cbs, const void* cr, size_t crs, int w, int h,
+                              const hipdec_nclx* nclx, void* out, size_t out_stride, int with_alpha, void* stream)
+{
+  if (int rc = ensure_init()) return rc;
+  // Op_YCbCr420_to_RGB24::state_after_conversion (yuv2rgb.cc:298-341) refuses these inputs
+  if (nclx && nclx->has_nclx) {
+    int m = nclx->matrix_coefficients;
+    if (m == 0 || m == 8 || m == 11 || m == 14)
+      return set_error(HIPDEC_ERR_UNSUPPORTED, "420_to_rgb24: matrix_coefficients %d is not handled by this op", m);
+    if (!nclx->full_range_flag) return set_error(HIPDEC_ERR_UNSUPPORTED, "420_to_rgb24: limited range is not handled by this op");
+  }
+  ColorParams p;
+  if (int rc = fill_common(p, y, ys, cb, cbs, cr, crs, w, h, 8, 1, nclx)) return rc;
+  if (!out) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "420_to_rgb24: out is NULL");
+  p.arith = AR_INT88; p.o0 = (uint8_t*)out; p.os = out_stride;
+  hipStream_t s = stream ? (hipStream_t)stream : default_stream();
+  return with_alpha ? launch_rgb<uint8_t, LO_RGBA32>(p, s) : launch_rgb<uint8_t, LO_RGB24>(p, s);
+}
+
+int hipdec_color_ycbcr_to_rgb_planar(const void* y, size_t ys, const void* cb, size_t cbs, const void* cr, size_t crs, int w,
+                                     int h, int bpp, int chroma, const hipdec_nclx* nclx, void* r, void* g, void* b,
+                                     size_t out_stride, void* stream)
+{
+  if (int rc = ensure_init()) return rc;
+  if (bpp < 8 || bpp > 14) return set_error(HIPDEC_ERR_UNSUPPORTED, "ycbcr_to_rgb: bits per pixel %d outside 8..14", bpp);
+  if (nclx && nclx->has_nclx && (nclx->matrix_coefficients == 11 || nclx->matrix_coefficients == 14))
+    return set_error(HIPDEC_ERR_UNSUPPORTED, "ycbcr_to_rgb: matrix_coefficients %d unsupported (as in the reference)", nclx->matrix_coefficients);
+  ColorParams p;
+  if (int rc = fill_common(p, y, ys, cb, cbs, cr, crs, w, h, bpp, chroma, nclx)) return rc;
+  if (!r || !g || !b) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "ycbcr_to_rgb: output plane is NULL");
+  p.arith = generic_arith(nclx); p.o0 = (uint8_t*)r; p.o1 = (uint8_t*)g; p.o2 = (uint8_t*)b; p.os = out_stride;
+  hipStream_t s = stream ? (hipStream_t)stream : default_stream();
+  return bpp == 8 ? launch_rgb<uint8_t, LO_PLANAR>(p, s) : launch_rgb<uint16_t, LO_PLANAR>(p, s);
+}
+
+int hipdec_color_ycbcr_to_rgb24_float(const void* y, size_t ys, const void* cb, size_t cbs, const void* cr, size_t crs, int w,
+                                      int h, int chroma, const hipdec_nclx* nclx, void* out, size_t out_stride, int with_alpha,
+                                      void* stream)
+{
+  if (int rc = ensure_init()) return rc;
+  if (nclx && nclx->has_nclx && (nclx->matrix_coefficients == 11 || nclx->matrix_coefficients == 14))
+    return set_error(HIPDEC_ERR_UNSUPPORTED, "ycbcr_to_rgb24: matrix_coefficients %d unsupported (as in the reference)", nclx->matrix_coefficients);
+  ColorParams p;
+  if (int rc = fill_common(p, y, ys, cb, cbs, cr, crs, w, h, 8, chroma, nclx)) return rc;
+  if (!out) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "ycbcr_to_rgb24: out is NULL");
+  p.arith = generic_arith(nclx); p.o0 = (uint8_t*)out; p.os = out_stride;
+  hipStream_t s = stream ? (hipStream_t)stream : default_stream();
+  return with_alpha ? launch_rgb<uint8_t, LO_RGBA32>(p, s) : launch_rgb<uint8_t, LO_RGB24>(p, s);
+}
+
+int hipdec_color_420_to_rrggbb(const void* y, size_t ys, const void* cb, size_t cbs, const void* cr, size_t crs, int w, int h,
+                               int bpp, const hipdec_nclx* nclx, void* out, size_t out_stride, int little_endian, void* stream)
+{
+  if (int rc = ensure_init()) return rc;
+  if (bpp <= 8 || bpp > 16) return set_error(HIPDEC_ERR_UNSUPPORTED, "420_to_rrggbb: needs more than 8 bits per pixel");
+  if (nclx && nclx->has_nclx) {
+    int m = nclx->matrix_coefficients;  // yuv2rgb.cc:590-593
+    if (m == 0 || m == 8 || m == 11 || m == 14)
+      return set_error(HIPDEC_ERR_UNSUPPORTED, "420_to_rrggbb: matrix_coefficients %d is not handled by this op", m);
+  }
+  ColorParams p;
+  if (int rc = fill_common(p, y, ys, cb, cbs, cr, crs, w, h, bpp, 1, nclx)) return rc;
+  if (!out) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "420_to_rrggbb: out is NULL");
+  p.arith = AR_FLOAT; p.o0 = (uint8_t*)out; p.os = out_stride;
+  hipStream_t s = stream ? (hipStream_t)stream : default_stream();
+  return little_endian ? launch_rgb<uint16_t, LO_RRGGBB_LE>(p, s) : launch_rgb<uint16_t, LO_RRGGBB_BE>(p, s);
+}
+
+int hipdec_color_bilinear_420_to_444(const void* in, size_t is, int w, int h, int bpp, void* out, size_t os, void* stream)
+{
+  if (int rc = ensure_init()) return rc;
+  if (!in || !out || w <= 0 || h <= 0) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "bilinear: bad arguments");
+  hipStream_t s = stream ? (hipStream_t)stream : default_stream();
+  dim3 block(64, 4), grid(((w + 3) / 4 + 63) / 64, (h + 3) / 4);
+  if (bpp <= 8) hipLaunchKernelGGL(k_bilinear_420_to_444<uint8_t>, grid, block, 0, s, (const uint8_t*)in, is, w, h, (uint8_t*)out, os);
+  else hipLaunchKernelGGL(k_bilinear_420_to_444<uint16_t>, grid, block, 0, s, (const uint8_t*)in, is, w, h, (uint8_t*)out, os);
+  HIPDEC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int hipdec_color_to_sdr(const void* in, size_t is, int w, int h, int bits, void* out, size_t os, void* stream)
+{
+  if (int rc = ensure_init()) return rc;
+  if (!in || !out || w <= 0 || h <= 0 || bits <= 8 || bits > 16) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "to_sdr: bad arguments");
+  hipStream_t s = stream ? (hipStream_t)stream : default_stream();
+  dim3 block(64, 4), grid(((w + 3) / 4 + 63) / 64, (h + 3) / 4);
+  hipLaunchKernelGGL(k_to_sdr, grid, block, 0, s, (const uint8_t*)in, is, w, h, bits - 8, (uint8_t*)out, os);
+  HIPDEC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+// runtime.hip — library life cycle, error reporting and the small device-memory helpers of the
+// C ABI (include/heif_hipdec.h).  The product path has NO CPU fallback: without a HIP device every
+// compute entry point fails with HIPDEC_ERR_DEVICE.
+#include "hipdec_internal.h"
+#include <mutex>
+
+namespace hipdec {
+
+static thread_local std::string t_last_error = "";
+static std::mutex g_init_mutex;
+static bool g_initialised = false;
+static int g_device = 0;
+static hipStream_t g_stream = nullptr;
+
+int set_error(int code, const char* fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  t_last_error = buf;
+  return code;
+}
+
+int ensure_init()
+{
+  if (g_initialised) {
+    // every host thread needs the device selected once; hipSetDevice is cheap
+    hipError_t e = hipSetDevice(g_device);
+    if (e != hipSuccess) return set_error(HIPDEC_ERR_DEVICE, "hipSetDevice(%d): %s", g_device, hipGetErrorString(e));
+    return 0;
+  }
+  return hipdec_init(-1);
+}
+
+hipStream_t default_stream() { return g_stream; }
+
+}  // namespace hipdec
+
+using namespace hipdec;
+
+extern "C" {
+
+int hipdec_init(int device_index)
+{
+  std::lock_guard<std::mutex> lock(g_init_mutex);
+  if (g_initialised && (device_index < 0 || device_index == g_device)) return 0;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return set_error(HIPDEC_ERR_DEVICE, "no HIP device available (%s); libheifhip has no CPU fallback",
+                     e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  int dev = device_index < 0 ? 0 : device_index;
+  if (dev >= n) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", dev, n);
+  HIPDEC_CHECK_HIP(hipSetDevice(dev));
+  if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+  HIPDEC_CHECK_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  g_device = dev;
+  g_initialised = true;
+  return 0;
+}
+
+void hipdec_shutdown(void)
+{
+  std::lock_guard<std::mutex> lock(g_init_mutex);
+  if (!g_initialised) return;
+  if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+  g_initialised = false;
+}
+
+const char* hipdec_last_error(void) { return t_last_error.c_str(); }
+const char* hipdec_version(void) { return "libheifhip 0.1 (gfx950)"; }
+
+int hipdec_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void* hipdec_malloc(size_t bytes)
+{
+  if (ensure_init()) return nullptr;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+  if (e != hipSuccess) { set_error(HIPDEC_ERR_DEVICE, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+  return p;
+}
+void hipdec_free(void* dptr) { if (dptr) (void)hipFree(dptr); }
+int hipdec_memcpy_h2d(void* dst, const void* src, size_t bytes)
+{
+  if (int rc = ensure_init()) return rc;
+  HIPDEC_CHECK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+int hipdec_memcpy_d2h(void* dst, const void* src, size_t bytes)
+{
+  if (int rc = ensure_init()) return rc;
+  HIPDEC_CHECK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+int hipdec_memset(void* dst, int value, size_t bytes)
+{
+  if (int rc = ensure_init()) return rc;
+  HIPDEC_CHECK_HIP(hipMemset(dst, value, bytes));
+  return 0;
+}
+int hipdec_stream_synchronize(void* stream)
+{
+  if (int rc = ensure_init()) return rc;
+  HIPDEC_CHECK_HIP(hipStreamSynchronize(stream ? (hipStream_t)stream : default_stream()));
+  return 0;
+}
+
+}  // extern "C"

@@ -104,3 +104,81 @@ def decode(stream: bytes, taps: bool = False) -> dict:
         return out
     finally:
         L.hevc_oracle_free_picture(C.byref(pic))
+
+
+# ------------------------------------------------------------------------------------------------
+# colour-stage oracle (oracle/color_oracle.c)
+# ------------------------------------------------------------------------------------------------
+def _u16(a):
+    return np.ascontiguousarray(a, dtype=np.uint16)
+
+
+def _p16(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint16))
+
+
+def color_coeffs(has_nclx, matrix, primaries):
+    out = (C.c_float * 4)()
+    lib().color_oracle_coeffs(int(has_nclx), int(matrix), int(primaries), out)
+    return [float(v) for v in out]
+
+
+def color_420_to_rgb24(y, cb, cr, nclx=None, alpha=False):
+    """a9.  nclx = (primaries, transfer, matrix, full_range) or None."""
+    y, cb, cr = _u16(y), _u16(cb), _u16(cr)
+    h, w = y.shape
+    bpp = 4 if alpha else 3
+    out = np.zeros((h, w * bpp), np.uint8)
+    lib().color_oracle_420_to_rgb24(_p16(y), w, _p16(cb), cb.shape[1], _p16(cr), cr.shape[1], w, h,
+                                    int(nclx is not None), nclx[2] if nclx else 2, nclx[0] if nclx else 2,
+                                    out.ctypes.data_as(C.POINTER(C.c_uint8)), w * bpp, int(alpha))
+    return out.reshape(h, w, bpp)
+
+
+def color_ycbcr_to_rgb_planar(y, cb, cr, bpp, chroma, nclx=None):
+    """a10.  Returns (R, G, B) uint16 arrays."""
+    y, cb, cr = _u16(y), _u16(cb), _u16(cr)
+    h, w = y.shape
+    r, g, b = (np.zeros((h, w), np.uint16) for _ in range(3))
+    lib().color_oracle_ycbcr_to_rgb_planar(_p16(y), w, _p16(cb), cb.shape[1], _p16(cr), cr.shape[1], w, h, bpp, chroma,
+                                           int(nclx is not None), nclx[2] if nclx else 2, nclx[0] if nclx else 2,
+                                           nclx[3] if nclx else 1, _p16(r), _p16(g), _p16(b), w)
+    return r, g, b
+
+
+def color_rgb_planar_to_interleaved8(r, g, b, alpha=False):
+    r, g, b = _u16(r), _u16(g), _u16(b)
+    h, w = r.shape
+    bpp = 4 if alpha else 3
+    out = np.zeros((h, w * bpp), np.uint8)
+    lib().color_oracle_rgb_planar_to_interleaved8(_p16(r), _p16(g), _p16(b), w, w, h,
+                                                  out.ctypes.data_as(C.POINTER(C.c_uint8)), w * bpp, int(alpha))
+    return out.reshape(h, w, bpp)
+
+
+def color_420_to_rrggbb(y, cb, cr, bpp, nclx=None, little_endian=True):
+    """a12.  Returns uint8 array (h, w*6)."""
+    y, cb, cr = _u16(y), _u16(cb), _u16(cr)
+    h, w = y.shape
+    out = np.zeros((h, w * 6), np.uint8)
+    lib().color_oracle_420_to_rrggbb(_p16(y), w, _p16(cb), cb.shape[1], _p16(cr), cr.shape[1], w, h, bpp,
+                                     int(nclx is not None), nclx[2] if nclx else 2, nclx[0] if nclx else 2,
+                                     nclx[3] if nclx else 1, out.ctypes.data_as(C.POINTER(C.c_uint8)), w * 6,
+                                     int(little_endian))
+    return out
+
+
+def color_bilinear_420_to_444(plane, w, h):
+    """a13 for one chroma plane; (w, h) is the luma size."""
+    plane = _u16(plane)
+    out = np.zeros((h, w), np.uint16)
+    lib().color_oracle_bilinear_420_to_444(_p16(plane), plane.shape[1], w, h, _p16(out), w)
+    return out
+
+
+def color_to_sdr(plane, bits):
+    plane = _u16(plane)
+    h, w = plane.shape
+    out = np.zeros((h, w), np.uint16)
+    lib().color_oracle_to_sdr(_p16(plane), w, w, h, bits, _p16(out), w)
+    return out

@@ -1,0 +1,41 @@
+"""CPU-side check that the C-ABI library loads and exports every symbol include/*.h declares
+(no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    names = []
+    for fn in os.listdir(os.path.join(ROOT, "include")):
+        if fn.endswith(".h"):
+            txt = open(os.path.join(ROOT, "include", fn)).read()
+            names += re.findall(r"HIPDEC_API[^;(]*?\b(hipdec_[a-z0-9_]+)\s*\(", txt)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    import libheif_amd
+    lib = libheif_amd.load_library()
+    declared = _declared()
+    assert len(declared) > 20
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, "C ABI symbols declared in include/ but not exported: %s" % missing
+
+
+def test_plugin_info_symbol_exported():
+    import libheif_amd
+    lib = libheif_amd.load_library()
+    assert ctypes.c_void_p.in_dll(lib, "plugin_info") is not None
+
+
+def test_no_gpu_fails_loudly_not_silently():
+    """Without a device the product must error out, never fall back to CPU code."""
+    import libheif_amd
+    lib = libheif_amd.load_library()
+    if lib.hipdec_device_count() > 0:
+        return
+    assert lib.hipdec_init(-1) != 0
+    assert b"no HIP device" in lib.hipdec_last_error()

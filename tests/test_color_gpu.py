@@ -1,0 +1,117 @@
+"""GPU parity of the fused HIP colour stage (through the C ABI) against the colour oracle, and —
+where oracle/_ref was built — against the real reference ops."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+import ref_harness as ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _planes(rng, w, h, bpp, chroma=1):
+    hi = 1 << bpp
+    cw, chh = ((w + 1) // 2, (h + 1) // 2) if chroma == 1 else ((w + 1) // 2, h) if chroma == 2 else (w, h)
+    return rng.integers(0, hi, (h, w)), rng.integers(0, hi, (chh, cw)), rng.integers(0, hi, (chh, cw))
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (66, 50), (130, 34), (1920, 1080), (3840, 2160), (5, 3), (2, 2)])
+@pytest.mark.parametrize("matrix,primaries", [(1, 1), (6, 1), (9, 9), (2, 2), (12, 1)])
+def test_a9_int_rgb24(w, h, matrix, primaries):
+    from libheif_amd import color
+    rng = np.random.default_rng(w + matrix)
+    y, cb, cr = _planes(rng, w, h, 8)
+    nclx = (primaries, 13, matrix, 1)
+    got = color.convert_colorspace([y, cb, cr], 8, 1, nclx, color.CHROMA_RGB, upsampling=color.UPSAMPLING_NEAREST)
+    exp = orc.color_420_to_rgb24(y, cb, cr, nclx).reshape(h, -1)
+    np.testing.assert_array_equal(got, exp)
+    if ref.available() and w * h < 300000:
+        np.testing.assert_array_equal(got, ref.convert([y, cb, cr], 8, ref.CH_420, nclx, ref.CS_RGB, ref.CH_RGB, upsampling=ref.UPS_NN)[0])
+
+
+def test_a9_rgb32():
+    from libheif_amd import color
+    rng = np.random.default_rng(9)
+    y, cb, cr = _planes(rng, 258, 66, 8)
+    nclx = (1, 13, 6, 1)
+    got = color.convert_colorspace([y, cb, cr], 8, 1, nclx, color.CHROMA_RGBA, upsampling=color.UPSAMPLING_NEAREST)
+    np.testing.assert_array_equal(got, orc.color_420_to_rgb24(y, cb, cr, nclx, alpha=True).reshape(66, -1))
+
+
+@pytest.mark.parametrize("matrix,primaries,full", [(6, 1, 0), (1, 1, 0), (2, 2, 0), (9, 9, 0), (0, 1, 0), (0, 1, 1), (8, 1, 1), (12, 9, 0)])
+@pytest.mark.parametrize("w,h", [(96, 40), (1281, 855)])
+def test_a10_a11_float_rgb24_bit_exact(matrix, primaries, full, w, h):
+    """float path: tolerance stated by north_star is for the nclx transform only; we hold 0 LSB
+    (device code is built with -ffp-contract=off)."""
+    from libheif_amd import color
+    rng = np.random.default_rng(matrix * 3 + full + w)
+    y, cb, cr = _planes(rng, w, h, 8)
+    nclx = (primaries, 13, matrix, full)
+    got = color.convert_colorspace([y, cb, cr], 8, 1, nclx, color.CHROMA_RGB, upsampling=color.UPSAMPLING_NEAREST)
+    r, g, b = orc.color_ycbcr_to_rgb_planar(y, cb, cr, 8, 1, nclx)
+    exp = orc.color_rgb_planar_to_interleaved8(r, g, b).reshape(h, -1)
+    np.testing.assert_array_equal(got, exp)
+    if ref.available() and w * h < 300000:
+        np.testing.assert_array_equal(got, ref.convert([y, cb, cr], 8, ref.CH_420, nclx, ref.CS_RGB, ref.CH_RGB, upsampling=ref.UPS_NN)[0])
+
+
+@pytest.mark.parametrize("bpp", [10, 12])
+@pytest.mark.parametrize("le", [True, False])
+@pytest.mark.parametrize("matrix,primaries,full", [(9, 9, 0), (9, 9, 1), (1, 1, 0)])
+def test_a12_rrggbb(bpp, le, matrix, primaries, full):
+    from libheif_amd import color
+    rng = np.random.default_rng(bpp + matrix + full)
+    w, h = 322, 70
+    y, cb, cr = _planes(rng, w, h, bpp)
+    nclx = (primaries, 16, matrix, full)
+    got = color.convert_colorspace([y, cb, cr], bpp, 1, nclx, color.CHROMA_RRGGBB_LE if le else color.CHROMA_RRGGBB_BE,
+                                   upsampling=color.UPSAMPLING_NEAREST)
+    np.testing.assert_array_equal(got, orc.color_420_to_rrggbb(y, cb, cr, bpp, nclx, little_endian=le))
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (65, 49), (34, 130), (4, 4), (1280, 854)])
+@pytest.mark.parametrize("bpp", [8, 10])
+def test_a13_bilinear(w, h, bpp):
+    from libheif_amd import color
+    rng = np.random.default_rng(w + h + bpp)
+    y, cb, cr = _planes(rng, w, h, bpp)
+    got = color.convert_colorspace([y, cb, cr], bpp, 1, (1, 13, 6, 1), color.CHROMA_444,
+                                   upsampling=color.UPSAMPLING_BILINEAR, only_preferred=True)
+    np.testing.assert_array_equal(got[0], y)
+    np.testing.assert_array_equal(got[1], orc.color_bilinear_420_to_444(cb, w, h))
+    np.testing.assert_array_equal(got[2], orc.color_bilinear_420_to_444(cr, w, h))
+
+
+def test_bilinear_then_float_chain_matches_reference_planner():
+    """`heif-dec -C bilinear` chain: 420_bilinear_to_444 -> Op_YCbCr_to_RGB<u8> -> Op_RGB_to_RGB24_32."""
+    from libheif_amd import color
+    rng = np.random.default_rng(77)
+    w, h = 130, 66
+    y, cb, cr = _planes(rng, w, h, 8)
+    nclx = (1, 13, 6, 1)
+    got = color.convert_colorspace([y, cb, cr], 8, 1, nclx, color.CHROMA_RGB, upsampling=color.UPSAMPLING_BILINEAR, only_preferred=True)
+    cb4, cr4 = orc.color_bilinear_420_to_444(cb, w, h), orc.color_bilinear_420_to_444(cr, w, h)
+    r, g, b = orc.color_ycbcr_to_rgb_planar(y, cb4, cr4, 8, 3, nclx)
+    np.testing.assert_array_equal(got, orc.color_rgb_planar_to_interleaved8(r, g, b).reshape(h, -1))
+    if ref.available():
+        exp = ref.convert([y, cb, cr], 8, ref.CH_420, nclx, ref.CS_RGB, ref.CH_RGB, upsampling=ref.UPS_BILINEAR, only_preferred=True)[0]
+        np.testing.assert_array_equal(got, exp)
+
+
+def test_a14_hdr_to_8bit_chain():
+    from libheif_amd import color
+    rng = np.random.default_rng(3)
+    w, h = 194, 50
+    y, cb, cr = _planes(rng, w, h, 10)
+    nclx = (9, 16, 9, 1)
+    got = color.convert_colorspace([y, cb, cr], 10, 1, nclx, color.CHROMA_RGB, upsampling=color.UPSAMPLING_NEAREST)
+    y8, cb8, cr8 = (orc.color_to_sdr(p, 10) for p in (y, cb, cr))
+    np.testing.assert_array_equal(got, orc.color_420_to_rgb24(y8, cb8, cr8, nclx).reshape(h, -1))
+
+
+def test_unsupported_matrix_fails_loudly():
+    from libheif_amd import color, HipDecError
+    rng = np.random.default_rng(1)
+    y, cb, cr = _planes(rng, 32, 16, 8)
+    with pytest.raises(HipDecError):
+        color.convert_colorspace([y, cb, cr], 8, 1, (1, 13, 11, 1), color.CHROMA_RGB)
