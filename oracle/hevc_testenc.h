@@ -1,0 +1,39 @@
+/* hevc_testenc.h — test-only HEVC intra stream generator (see hevc_testenc.c). */
+#ifndef HEVC_TESTENC_H
+#define HEVC_TESTENC_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct hevc_testenc_params {
+  int width, height;            /* display size; coded size is rounded up to the min CB size      */
+  int bit_depth;                /* 8..12 (luma == chroma)                                          */
+  int chroma_format_idc;        /* 0 or 1                                                          */
+  int log2_ctb, log2_min_cb, log2_min_tb, log2_max_tb;
+  int max_transform_hierarchy_depth_intra;
+  int qp;
+  int wpp, tile_cols, tile_rows, num_slices;
+  int sao, deblock_disable, beta_offset_div2, tc_offset_div2;
+  int sign_data_hiding, cu_qp_delta, diff_cu_qp_delta_depth, transform_skip;
+  int lossless_pct;             /* >0 enables transquant bypass; % of CUs coded lossless           */
+  int pcm_pct, pcm_loop_filter_disabled;
+  int strong_intra_smoothing, scaling_list;
+  int cb_qp_offset, cr_qp_offset;
+  int loop_filter_across_tiles, loop_filter_across_slices;
+  int vui_primaries, vui_transfer, vui_matrix, vui_full_range; /* vui_matrix < 0: no VUI           */
+  uint32_t seed;
+  int stress;                   /* 1: random splits / modes (syntax coverage); 0: SAD-driven       */
+  int zero_residual_pct;        /* % of transform blocks forced to cbf = 0                         */
+} hevc_testenc_params;
+
+/* planes: tightly packed uint16 samples at display size (chroma (w+1)/2 x (h+1)/2).
+ * Output: malloc'd [u32 BE length][NAL]... stream (VPS, SPS, PPS, slices); free with
+ * hevc_testenc_free(). */
+int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const planes[3], uint8_t** out,
+                        size_t* out_size, char* errbuf, size_t errbuf_len);
+void hevc_testenc_free(uint8_t* p);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -182,3 +182,84 @@ def color_to_sdr(plane, bits):
     out = np.zeros((h, w), np.uint16)
     lib().color_oracle_to_sdr(_p16(plane), w, w, h, bits, _p16(out), w)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# test-stream generator (oracle/hevc_testenc.c)
+# ------------------------------------------------------------------------------------------------
+class _EncParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "width", "height", "bit_depth", "chroma_format_idc", "log2_ctb", "log2_min_cb", "log2_min_tb", "log2_max_tb",
+        "max_transform_hierarchy_depth_intra", "qp", "wpp", "tile_cols", "tile_rows", "num_slices", "sao",
+        "deblock_disable", "beta_offset_div2", "tc_offset_div2", "sign_data_hiding", "cu_qp_delta",
+        "diff_cu_qp_delta_depth", "transform_skip", "lossless_pct", "pcm_pct", "pcm_loop_filter_disabled",
+        "strong_intra_smoothing", "scaling_list", "cb_qp_offset", "cr_qp_offset", "loop_filter_across_tiles",
+        "loop_filter_across_slices", "vui_primaries", "vui_transfer", "vui_matrix", "vui_full_range")] + \
+        [("seed", C.c_uint32), ("stress", C.c_int), ("zero_residual_pct", C.c_int)]
+
+
+ENC_DEFAULTS = dict(bit_depth=8, chroma_format_idc=1, log2_ctb=6, log2_min_cb=3, log2_min_tb=2, log2_max_tb=5,
+                    max_transform_hierarchy_depth_intra=1, qp=27, wpp=1, tile_cols=1, tile_rows=1, num_slices=1, sao=1,
+                    deblock_disable=0, beta_offset_div2=0, tc_offset_div2=0, sign_data_hiding=1, cu_qp_delta=1,
+                    diff_cu_qp_delta_depth=1, transform_skip=0, lossless_pct=0, pcm_pct=0, pcm_loop_filter_disabled=0,
+                    strong_intra_smoothing=1, scaling_list=0, cb_qp_offset=0, cr_qp_offset=0, loop_filter_across_tiles=1,
+                    loop_filter_across_slices=1, vui_primaries=1, vui_transfer=13, vui_matrix=-1, vui_full_range=0,
+                    seed=1, stress=0, zero_residual_pct=0)
+
+
+def synth_image(width, height, bit_depth=8, chroma_format_idc=1, seed=1):
+    """Seeded band-limited noise + gradients + a few hard edges (SURVEY.md §8d synthetic content)."""
+    rng = np.random.default_rng(seed)
+    hi = (1 << bit_depth) - 1
+
+    def plane(w, h, amp):
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        base = 0.5 + 0.25 * np.sin(xx / (37.0 + seed % 7)) * np.cos(yy / 53.0) + 0.2 * (xx / max(w, 1) - 0.5)
+        lo = rng.standard_normal(((h + 15) // 16 + 1, (w + 15) // 16 + 1)).astype(np.float32)
+        lo = np.kron(lo, np.ones((16, 16), np.float32))[:h, :w]
+        k = np.ones(9, np.float32) / 9
+        for ax in (0, 1):
+            lo = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), ax, lo)
+        fine = rng.standard_normal((h, w)).astype(np.float32)
+        img = base + amp * (0.12 * lo + 0.02 * fine)
+        nrect = 4
+        for _ in range(nrect):
+            x0, y0 = int(rng.integers(0, max(1, w - 8))), int(rng.integers(0, max(1, h - 8)))
+            x1, y1 = min(w, x0 + int(rng.integers(8, max(9, w // 3)))), min(h, y0 + int(rng.integers(8, max(9, h // 3))))
+            img[y0:y1, x0:x1] += float(rng.uniform(-0.25, 0.25))
+        return np.clip(img * hi + 0.5, 0, hi).astype(np.uint16)
+
+    planes = [plane(width, height, 1.0)]
+    if chroma_format_idc:
+        cw, ch = (width + 1) // 2, (height + 1) // 2
+        planes += [plane(cw, ch, 0.5), plane(cw, ch, 0.5)]
+    return planes
+
+
+def encode(planes, **kw):
+    """Encode planes ([Y] or [Y, Cb, Cr], uint16 arrays at display size) into a plugin-framed stream."""
+    prm = dict(ENC_DEFAULTS)
+    prm.update(kw)
+    h, w = planes[0].shape
+    prm.setdefault("width", w)
+    prm.setdefault("height", h)
+    prm["chroma_format_idc"] = 1 if len(planes) == 3 else 0
+    st = _EncParams()
+    for k, v in prm.items():
+        setattr(st, k, int(v))
+    L = lib()
+    L.hevc_testenc_encode.restype = C.c_int
+    ps = [np.ascontiguousarray(p, dtype=np.uint16) for p in planes]
+    while len(ps) < 3:
+        ps.append(ps[0])
+    arr = (C.POINTER(C.c_uint16) * 3)(*[p.ctypes.data_as(C.POINTER(C.c_uint16)) for p in ps])
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    err = C.create_string_buffer(512)
+    rc = L.hevc_testenc_encode(C.byref(st), arr, C.byref(out), C.byref(n), err, 512)
+    if rc != 0:
+        raise OracleError(err.value.decode("latin1"))
+    data = bytes(np.ctypeslib.as_array(out, shape=(n.value,)))
+    L.hevc_testenc_free.argtypes = [C.POINTER(C.c_uint8)]
+    L.hevc_testenc_free(out)
+    return data
