@@ -98,6 +98,14 @@ HIPDEC_API int hipdec_decoder_push_data(hipdec_decoder* dec, const void* data, s
  * when no picture was pushed (libheif sees "no image yet"). */
 HIPDEC_API int hipdec_decoder_decode(hipdec_decoder* dec, hipdec_image_info* info);
 
+/* Host-only header probe: parses the parameter sets and slice segment headers of one pushed item
+ * and fills `info` without touching the GPU (what libheif's own SPS pre-check does in
+ * libheif/codecs/hevc_dec.cc:54-77, extended to the whole front end).  Same error codes as decode. */
+HIPDEC_API int hipdec_probe(const void* data, size_t size, uint64_t max_image_size_pixels, hipdec_image_info* info);
+/* For hosts that register plugins statically: heif_register_decoder_plugin(hipdec_get_decoder_plugin())
+ * (libheif/api/libheif/heif_library.cc:70-81).  Returns a const heif_decoder_plugin*. */
+HIPDEC_API const void* hipdec_get_decoder_plugin(void);
+
 /* plane hand-over (decoder_libde265.cc:97-171): copies plane c (0 = Y, 1 = Cb, 2 = Cr) into a host
  * buffer with the caller's stride; samples are uint8 for bit depth 8, little-endian uint16
  * above. */

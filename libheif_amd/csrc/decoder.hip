@@ -1,0 +1,450 @@
+// decoder.hip — host orchestration of the decode pipeline and the hipdec_decoder_* / hipdec_batch_*
+// entry points of the C ABI (include/heif_hipdec.h).
+//
+// hipdec_decoder mirrors the life cycle libheif drives through heif_decoder_plugin
+// (libheif/codecs/decoder.cc:355-563; reference implementation libheif/plugins/decoder_libde265.cc);
+// hipdec_batch is the device-side form of libheif's per-tile fan-out
+// (libheif/image-items/grid.cc:405-453): all items of a grid / batch are parsed on the host, uploaded
+// with ONE copy and decoded by ONE set of kernel launches, every CABAC substream and every CTB row
+// of every item being an independent unit of GPU work.
+#include "hipdec_internal.h"
+#include "hevc_headers.h"
+#include "kernels.h"
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+
+using namespace hipdec;
+
+struct hipdec_batch {
+  std::vector<ParsedPicture> pics;
+  std::vector<PicParams> params;
+  uint8_t* arena = nullptr;
+  size_t arena_size = 0, upload_size = 0;
+  size_t off_pics = 0, off_subs = 0, off_rows = 0, off_ctrl = 0, ctrl_size = 0;
+  size_t off_progress = 0, off_ctx = 0, off_row_progress = 0, off_ticket = 0, off_status = 0;
+  uint32_t num_subs = 0, num_rows = 0;
+  bool wide = false;  // samples wider than 8 bit -> uint16 planes
+  int max_w = 0, max_h = 0, max_ow = 0, max_oh = 0;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipStream_t last_stream = nullptr;
+  bool ran = false;
+  ~hipdec_batch()
+  {
+    if (arena) (void)hipFree(arena);
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+  }
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels)
+{
+  b.pics.resize(n);
+  for (int i = 0; i < n; i++) {
+    std::string err;
+    int rc = parse_picture((const uint8_t*)data[i], sizes[i], max_pixels, b.pics[i], err);
+    if (rc != HIPDEC_OK) return set_error(rc, "item %d: %s", i, err.c_str());
+  }
+  b.wide = b.pics[0].info.bit_depth_luma > 8 || b.pics[0].info.bit_depth_chroma > 8;
+  for (int i = 0; i < n; i++) {
+    const bool w = b.pics[i].info.bit_depth_luma > 8 || b.pics[i].info.bit_depth_chroma > 8;
+    if (w != b.wide) return set_error(HIPDEC_ERR_UNSUPPORTED, "batch mixes 8-bit and >8-bit items");
+  }
+  const size_t es = b.wide ? 2 : 1;
+  // ---- layout: [upload region: descriptors, tables, bitstreams][control words][device-only buffers] ----
+  size_t off = 0;
+  b.off_pics = off; off = align_up(off + sizeof(PicParams) * n, 256);
+  uint32_t nsubs = 0, nrows = 0;
+  for (auto& p : b.pics) { nsubs += (uint32_t)p.subs.size(); nrows += (uint32_t)((p.sps.pic_height + (1 << p.sps.log2_ctb) - 1) >> p.sps.log2_ctb); }
+  b.num_subs = nsubs; b.num_rows = nrows;
+  b.off_subs = off; off = align_up(off + sizeof(Substream) * nsubs, 256);
+  b.off_rows = off; off = align_up(off + sizeof(RowDesc) * nrows, 256);
+  b.params.assign(n, PicParams{});
+  uint32_t row_base = 0;
+  for (int i = 0; i < n; i++) {
+    const ParsedPicture& pp = b.pics[i];
+    const Sps& S = pp.sps; const Pps& Pp = pp.pps;
+    PicParams& P = b.params[i];
+    P.width = S.pic_width; P.height = S.pic_height;
+    P.chroma_format_idc = S.chroma_format_idc;
+    P.cwidth = S.chroma_format_idc ? S.pic_width / 2 : 0; P.cheight = S.chroma_format_idc ? S.pic_height / 2 : 0;
+    P.out_width = pp.info.width; P.out_height = pp.info.height; P.out_cwidth = pp.info.chroma_width; P.out_cheight = pp.info.chroma_height;
+    const int subc = S.chroma_format_idc == 1 ? 2 : 1;
+    P.crop_x = subc * S.conf_left; P.crop_y = subc * S.conf_top;
+    P.bit_depth_luma = S.bit_depth_luma; P.bit_depth_chroma = S.bit_depth_chroma;
+    P.log2_ctb = S.log2_ctb; P.log2_min_cb = S.log2_min_cb; P.log2_min_tb = S.log2_min_tb; P.log2_max_tb = S.log2_max_tb;
+    P.max_th_depth_intra = S.max_th_depth_intra;
+    P.ctb_w = (S.pic_width + (1 << S.log2_ctb) - 1) >> S.log2_ctb; P.ctb_h = (S.pic_height + (1 << S.log2_ctb) - 1) >> S.log2_ctb;
+    P.units_per_ctb_log2 = 2 * (S.log2_ctb - 2);
+    P.sao_enabled = S.sao; P.sign_data_hiding = Pp.sign_data_hiding; P.transform_skip_enabled = Pp.transform_skip;
+    P.cu_qp_delta_enabled = Pp.cu_qp_delta; P.transquant_bypass_enabled = Pp.transquant_bypass;
+    P.strong_intra_smoothing = S.strong_intra_smoothing; P.tiles_enabled = Pp.tiles; P.wpp = Pp.wpp;
+    P.lf_across_tiles = Pp.lf_across_tiles; P.pcm_loop_filter_disabled = 0;
+    P.log2_min_cu_qp_delta_size = S.log2_ctb - Pp.diff_cu_qp_delta_depth;
+    if (Pp.diff_cu_qp_delta_depth > S.log2_ctb - S.log2_min_cb) return set_error(HIPDEC_ERR_BITSTREAM, "item %d: diff_cu_qp_delta_depth out of range", i);
+    P.first_row = row_base; row_base += (uint32_t)P.ctb_h;
+    P.num_slices = (uint32_t)pp.slice_params.size();
+    const size_t nctb = (size_t)P.ctb_w * P.ctb_h;
+    P.off_ctb_ts_to_rs = off; off = align_up(off + nctb * sizeof(uint16_t), 256);
+    P.off_ctb_info = off; off = align_up(off + nctb * sizeof(CtbInfo), 256);
+    P.off_slices = off; off = align_up(off + pp.slice_params.size() * sizeof(SliceParams), 256);
+    P.off_bitstream = off; P.bitstream_size = sizes[i]; off = align_up(off + sizes[i] + 512, 256);
+    b.max_w = std::max(b.max_w, P.width); b.max_h = std::max(b.max_h, P.height);
+    b.max_ow = std::max(b.max_ow, P.out_width); b.max_oh = std::max(b.max_oh, P.out_height);
+  }
+  b.upload_size = off;
+  // control words (zeroed before every run)
+  b.off_ctrl = off;
+  b.off_progress = off; off = align_up(off + sizeof(uint32_t) * nsubs, 256);
+  b.off_row_progress = off; off = align_up(off + sizeof(uint32_t) * nrows, 256);
+  b.off_ticket = off; off += 256;  // [0] parse ticket, [1] recon ticket
+  b.off_status = off; off += 256;
+  b.ctrl_size = off - b.off_ctrl;
+  b.off_ctx = off; off = align_up(off + (size_t)CTX_STORE * nsubs, 256);
+  for (int i = 0; i < n; i++) {
+    PicParams& P = b.params[i];
+    const size_t nctb = (size_t)P.ctb_w * P.ctb_h;
+    const size_t nunits = nctb << P.units_per_ctb_log2;
+    const size_t ctb2 = (size_t)1 << (2 * P.log2_ctb);
+    P.off_sao = off; off = align_up(off + nctb * 3 * sizeof(SaoParams), 256);
+    P.off_u_size = off; off = align_up(off + nunits, 256);
+    P.off_u_flags = off; off = align_up(off + nunits, 256);
+    P.off_u_ipm = off; off = align_up(off + nunits, 256);
+    P.off_u_ipmc = off; off = align_up(off + nunits, 256);
+    P.off_u_qp = off; off = align_up(off + nunits, 256);
+    P.off_coeff[0] = off; off = align_up(off + nctb * ctb2 * 2, 256);
+    P.off_coeff[1] = off; off = align_up(off + nctb * ctb2 / 2, 256);
+    P.off_coeff[2] = off; off = align_up(off + nctb * ctb2 / 2, 256);
+    const int ctb = 1 << P.log2_ctb;
+    for (int c = 0; c < 3; c++) {
+      const size_t w = c ? (size_t)P.ctb_w * ctb / 2 : (size_t)P.ctb_w * ctb, h = c ? (size_t)P.ctb_h * ctb / 2 : (size_t)P.ctb_h * ctb;
+      P.rec_stride[c] = (uint32_t)align_up(w * es, 64);
+      P.off_rec[c] = off; off = align_up(off + (size_t)P.rec_stride[c] * (h + 1), 256);
+      const size_t ow = c ? P.out_cwidth : P.out_width, oh = c ? P.out_cheight : P.out_height;
+      P.out_stride[c] = (uint32_t)align_up(std::max<size_t>(ow, 1) * es, 64);
+      P.off_out[c] = off; off = align_up(off + (size_t)P.out_stride[c] * std::max<size_t>(oh, 1), 256);
+    }
+  }
+  b.arena_size = off;
+
+  // ---- stage + upload ----
+  HIPDEC_CHECK_HIP(hipMalloc((void**)&b.arena, b.arena_size));
+  std::vector<uint8_t> host(b.upload_size, 0);
+  memcpy(host.data() + b.off_pics, b.params.data(), sizeof(PicParams) * n);
+  Substream* subs = (Substream*)(host.data() + b.off_subs);
+  RowDesc* rows = (RowDesc*)(host.data() + b.off_rows);
+  uint32_t sub_base = 0, r = 0;
+  for (int i = 0; i < n; i++) {
+    const ParsedPicture& pp = b.pics[i];
+    const PicParams& P = b.params[i];
+    for (size_t k = 0; k < pp.subs.size(); k++) {
+      Substream s = pp.subs[k];
+      s.pic = (uint32_t)i;
+      if (s.dep_sub >= 0) s.dep_sub += (int32_t)sub_base;
+      subs[sub_base + k] = s;
+    }
+    sub_base += (uint32_t)pp.subs.size();
+    for (int y = 0; y < P.ctb_h; y++) { rows[r].pic = (uint32_t)i; rows[r].row = (uint32_t)y; r++; }
+    memcpy(host.data() + P.off_ctb_ts_to_rs, pp.ts_to_rs.data(), pp.ts_to_rs.size() * sizeof(uint16_t));
+    memcpy(host.data() + P.off_ctb_info, pp.ctb_info.data(), pp.ctb_info.size() * sizeof(CtbInfo));
+    memcpy(host.data() + P.off_slices, pp.slice_params.data(), pp.slice_params.size() * sizeof(SliceParams));
+    memcpy(host.data() + P.off_bitstream, data[i], sizes[i]);
+  }
+  HIPDEC_CHECK_HIP(hipMemcpy(b.arena, host.data(), b.upload_size, hipMemcpyHostToDevice));
+  for (auto& e : b.ev) HIPDEC_CHECK_HIP(hipEventCreate(&e));
+  return 0;
+}
+
+int launch_all(hipdec_batch& b, hipStream_t s)
+{
+  const int n = (int)b.params.size();
+  ParseArgs pa{(const PicParams*)(b.arena + b.off_pics), (const Substream*)(b.arena + b.off_subs), b.num_subs, b.arena,
+               (uint32_t*)(b.arena + b.off_progress), b.arena + b.off_ctx, (uint32_t*)(b.arena + b.off_ticket), (int32_t*)(b.arena + b.off_status),
+               getenv("HIPDEC_DEBUG_PARSE") ? atoi(getenv("HIPDEC_DEBUG_PARSE")) : 0};
+  ReconArgs ra{(const PicParams*)(b.arena + b.off_pics), (const RowDesc*)(b.arena + b.off_rows), b.num_rows, b.arena,
+               (uint32_t*)(b.arena + b.off_row_progress), (uint32_t*)(b.arena + b.off_ticket) + 1, (int32_t*)(b.arena + b.off_status)};
+  FilterArgs fa{(const PicParams*)(b.arena + b.off_pics), b.arena};
+  const bool dbg = getenv("HIPDEC_DEBUG_SYNC") != nullptr;  // isolate a faulting kernel
+  auto step = [&](const char* what) -> int {
+    if (!dbg) return 0;
+    fprintf(stderr, "[hipdec] %s ...\n", what); fflush(stderr);
+    hipError_t e = hipStreamSynchronize(s);
+    fprintf(stderr, "[hipdec] %s: %s\n", what, hipGetErrorString(e)); fflush(stderr);
+    return e == hipSuccess ? 0 : set_error(HIPDEC_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
+  };
+  HIPDEC_CHECK_HIP(hipMemsetAsync(b.arena + b.off_ctrl, 0, b.ctrl_size, s));
+  HIPDEC_CHECK_HIP(hipEventRecord(b.ev[0], s));
+  if (int rc = step("memset")) return rc;
+  launch_parse(pa, s);
+  HIPDEC_CHECK_HIP(hipEventRecord(b.ev[1], s));
+  if (int rc = step("parse")) return rc;
+  launch_recon(ra, b.wide, s);
+  HIPDEC_CHECK_HIP(hipEventRecord(b.ev[2], s));
+  if (int rc = step("recon")) return rc;
+  launch_deblock(fa, n, b.max_w, b.max_h, b.wide, s);
+  HIPDEC_CHECK_HIP(hipEventRecord(b.ev[3], s));
+  if (int rc = step("deblock")) return rc;
+  launch_sao(fa, n, b.max_ow, b.max_oh, b.wide, s);
+  HIPDEC_CHECK_HIP(hipEventRecord(b.ev[4], s));
+  if (int rc = step("sao")) return rc;
+  HIPDEC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+const char* dev_err_name(int code)
+{
+  switch (code & 0xff) {
+    case DEV_ERR_TERMINATE: return "CABAC substream did not terminate where the slice header says (desynchronised bitstream)";
+    case DEV_ERR_BITSTREAM_END: return "CABAC read past the end of a substream";
+    case DEV_ERR_SYNTAX: return "syntax element out of range";
+    case DEV_ERR_TIMEOUT: return "dependency wait timed out / aborted";
+    default: return "unknown device error";
+  }
+}
+
+int copy_plane_d2h(const hipdec_batch& b, size_t off, uint32_t stride, int w, int h, void* dst, size_t dst_stride)
+{
+  const size_t es = b.wide ? 2 : 1;
+  if (w <= 0 || h <= 0) return 0;
+  HIPDEC_CHECK_HIP(hipMemcpy2D(dst, dst_stride, b.arena + off, stride, (size_t)w * es, (size_t)h, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hipdec_batch_create(hipdec_batch** out, int n, const void* const* data, const size_t* sizes, uint64_t max_image_size_pixels)
+{
+  if (!out || n <= 0 || !data || !sizes) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "batch_create: bad arguments");
+  *out = nullptr;
+  if (int rc = ensure_init()) return rc;
+  std::unique_ptr<hipdec_batch> b(new hipdec_batch());
+  if (int rc = build_batch(*b, n, data, sizes, max_image_size_pixels)) return rc;
+  *out = b.release();
+  return 0;
+}
+
+void hipdec_batch_free(hipdec_batch* b) { delete b; }
+int hipdec_batch_count(const hipdec_batch* b) { return b ? (int)b->pics.size() : 0; }
+
+int hipdec_batch_info(const hipdec_batch* b, int i, hipdec_image_info* info)
+{
+  if (!b || !info || i < 0 || i >= (int)b->pics.size()) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "batch_info: bad arguments");
+  *info = b->pics[i].info;
+  return 0;
+}
+
+int hipdec_batch_run(hipdec_batch* b, void* stream)
+{
+  if (!b) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "batch_run: NULL batch");
+  if (int rc = ensure_init()) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : default_stream();
+  b->last_stream = s;
+  b->ran = true;
+  return launch_all(*b, s);
+}
+
+int hipdec_batch_status(hipdec_batch* b)
+{
+  if (!b || !b->ran) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "batch_status: batch has not been run");
+  if (int rc = ensure_init()) return rc;
+  hipError_t e = hipStreamSynchronize(b->last_stream);
+  if (e != hipSuccess) return set_error(HIPDEC_ERR_DEVICE, "decode kernels failed: %s", hipGetErrorString(e));
+  int32_t st = 0;
+  HIPDEC_CHECK_HIP(hipMemcpy(&st, b->arena + b->off_status, sizeof(st), hipMemcpyDeviceToHost));
+  if (st != 0) return set_error(HIPDEC_ERR_DECODE, "device decode error 0x%x: %s", st, dev_err_name(st));
+  return 0;
+}
+
+int hipdec_batch_read_plane(hipdec_batch* b, int i, int c, void* dst, size_t dst_stride)
+{
+  if (!b || i < 0 || i >= (int)b->pics.size() || c < 0 || c > 2 || !dst) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: bad arguments");
+  const PicParams& P = b->params[i];
+  if (c > 0 && !P.chroma_format_idc) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: monochrome image has no chroma planes");
+  return copy_plane_d2h(*b, P.off_out[c], P.out_stride[c], c ? P.out_cwidth : P.out_width, c ? P.out_cheight : P.out_height, dst, dst_stride);
+}
+
+int hipdec_batch_device_plane(hipdec_batch* b, int i, int c, const void** dptr, size_t* stride)
+{
+  if (!b || i < 0 || i >= (int)b->pics.size() || c < 0 || c > 2 || !dptr || !stride) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "device_plane: bad arguments");
+  const PicParams& P = b->params[i];
+  *dptr = b->arena + P.off_out[c];
+  *stride = P.out_stride[c];
+  return 0;
+}
+
+int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void* out_dev, size_t out_stride, void* stream)
+{
+  if (!b || i < 0 || i >= (int)b->pics.size() || !out_dev) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "to_rgb: bad arguments");
+  const PicParams& P = b->params[i];
+  const hipdec_image_info& I = b->pics[i].info;
+  if (!P.chroma_format_idc) return set_error(HIPDEC_ERR_UNSUPPORTED, "to_rgb: monochrome input");
+  // the decoder reports the VUI colour description exactly as the libde265 plugin would attach it
+  hipdec_nclx nclx{1, I.colour_primaries, I.transfer_characteristics, I.matrix_coeffs, I.full_range_flag};
+  const uint8_t* y = b->arena + P.off_out[0]; const uint8_t* cb = b->arena + P.off_out[1]; const uint8_t* cr = b->arena + P.off_out[2];
+  void* s = stream ? stream : (void*)b->last_stream;
+  if (out_chroma == 10 || out_chroma == 11) {
+    if (b->wide) return set_error(HIPDEC_ERR_UNSUPPORTED, "to_rgb: 8-bit interleaved output from >8-bit planes needs hipdec_color_to_sdr first");
+    // planner rule: integer op only for full range and a matrix it accepts
+    const int m = I.matrix_coeffs == 2 ? 6 : I.matrix_coeffs;
+    if (I.full_range_flag && m != 0 && m != 8)
+      return hipdec_color_420_to_rgb24(y, P.out_stride[0], cb, P.out_stride[1], cr, P.out_stride[2], P.out_width, P.out_height, &nclx, out_dev,
+                                       out_stride, out_chroma == 11, s);
+    return hipdec_color_ycbcr_to_rgb24_float(y, P.out_stride[0], cb, P.out_stride[1], cr, P.out_stride[2], P.out_width, P.out_height, 1, &nclx,
+                                             out_dev, out_stride, out_chroma == 11, s);
+  }
+  if (out_chroma == 12 || out_chroma == 14) {
+    if (!b->wide) return set_error(HIPDEC_ERR_UNSUPPORTED, "to_rgb: RRGGBB output needs >8-bit planes");
+    return hipdec_color_420_to_rrggbb(y, P.out_stride[0], cb, P.out_stride[1], cr, P.out_stride[2], P.out_width, P.out_height, I.bit_depth_luma,
+                                      &nclx, out_dev, out_stride, out_chroma == 14, s);
+  }
+  return set_error(HIPDEC_ERR_UNSUPPORTED, "to_rgb: unsupported output chroma %d", out_chroma);
+}
+
+int hipdec_batch_last_timing_us(hipdec_batch* b, float out[5])
+{
+  if (!b || !b->ran || !out) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "last_timing: batch has not been run");
+  HIPDEC_CHECK_HIP(hipEventSynchronize(b->ev[4]));
+  for (int k = 0; k < 4; k++) {
+    float ms = 0;
+    HIPDEC_CHECK_HIP(hipEventElapsedTime(&ms, b->ev[k], b->ev[k + 1]));
+    out[k] = ms * 1000.0f;
+  }
+  float ms = 0;
+  HIPDEC_CHECK_HIP(hipEventElapsedTime(&ms, b->ev[0], b->ev[4]));
+  out[4] = ms * 1000.0f;
+  return 0;
+}
+
+int hipdec_batch_read_tap(hipdec_batch* b, int i, int which, int c, void* dst, size_t dst_stride)
+{
+  if (!b || i < 0 || i >= (int)b->pics.size() || c < 0 || c > 2 || !dst) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_tap: bad arguments");
+  (void)which;  // the reconstruction buffer holds the deblocked picture after a full run
+  const PicParams& P = b->params[i];
+  return copy_plane_d2h(*b, P.off_rec[c], P.rec_stride[c], c ? P.cwidth : P.width, c ? P.cheight : P.height, dst, dst_stride);
+}
+
+int hipdec_batch_read_maps(hipdec_batch* b, int i, uint8_t* log2_tb, uint8_t* log2_cb, uint8_t* intra_luma, uint8_t* intra_chroma, int8_t* qp_y,
+                           uint8_t* flags, size_t map_elems)
+{
+  if (!b || i < 0 || i >= (int)b->pics.size()) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_maps: bad arguments");
+  const PicParams& P = b->params[i];
+  const int uw = (P.width + 3) / 4, uh = (P.height + 3) / 4;
+  if (map_elems < (size_t)uw * uh) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_maps: buffers too small");
+  const size_t nunits = ((size_t)P.ctb_w * P.ctb_h) << P.units_per_ctb_log2;
+  std::vector<uint8_t> sz(nunits), fl(nunits), ipm(nunits), ipmc(nunits), qp(nunits);
+  HIPDEC_CHECK_HIP(hipMemcpy(sz.data(), b->arena + P.off_u_size, nunits, hipMemcpyDeviceToHost));
+  HIPDEC_CHECK_HIP(hipMemcpy(fl.data(), b->arena + P.off_u_flags, nunits, hipMemcpyDeviceToHost));
+  HIPDEC_CHECK_HIP(hipMemcpy(ipm.data(), b->arena + P.off_u_ipm, nunits, hipMemcpyDeviceToHost));
+  HIPDEC_CHECK_HIP(hipMemcpy(ipmc.data(), b->arena + P.off_u_ipmc, nunits, hipMemcpyDeviceToHost));
+  HIPDEC_CHECK_HIP(hipMemcpy(qp.data(), b->arena + P.off_u_qp, nunits, hipMemcpyDeviceToHost));
+  const int l = P.log2_ctb - 2, mask = (1 << l) - 1;
+  auto il = [](uint32_t x, uint32_t y) {
+    x = (x | (x << 2)) & 0x33; x = (x | (x << 1)) & 0x55; y = (y | (y << 2)) & 0x33; y = (y | (y << 1)) & 0x55; return x | (y << 1);
+  };
+  for (int uy = 0; uy < uh; uy++)
+    for (int ux = 0; ux < uw; ux++) {
+      const size_t idx = (((size_t)(uy >> l) * P.ctb_w + (ux >> l)) << P.units_per_ctb_log2) + il(ux & mask, uy & mask);
+      const size_t o = (size_t)uy * uw + ux;
+      if (log2_tb) log2_tb[o] = sz[idx] & 15;
+      if (log2_cb) log2_cb[o] = sz[idx] >> 4;
+      if (intra_luma) intra_luma[o] = ipm[idx] & 63;
+      if (intra_chroma) intra_chroma[o] = ipmc[idx];
+      if (qp_y) qp_y[o] = (int8_t)qp[idx];
+      if (flags) flags[o] = fl[idx];
+    }
+  return 0;
+}
+
+int hipdec_probe(const void* data, size_t size, uint64_t max_image_size_pixels, hipdec_image_info* info)
+{
+  if (!data || !info) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "probe: bad arguments");
+  ParsedPicture pp;
+  std::string err;
+  int rc = parse_picture((const uint8_t*)data, size, max_image_size_pixels, pp, err);
+  if (rc != HIPDEC_OK) return set_error(rc, "%s", err.c_str());
+  *info = pp.info;
+  return 0;
+}
+
+// ---- single-image decoder: the plugin life cycle ------------------------------------------------
+struct hipdec_decoder {
+  std::vector<uint8_t> data;
+  int strict = 0;
+  uint64_t max_pixels = 0;
+  hipdec_batch* batch = nullptr;
+  bool decoded = false;
+};
+
+int hipdec_decoder_new(hipdec_decoder** out, int strict_decoding, uint64_t max_image_size_pixels)
+{
+  if (!out) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "decoder_new: out is NULL");
+  *out = nullptr;
+  if (int rc = ensure_init()) return rc;  // fail loudly when there is no GPU: there is no CPU fallback
+  hipdec_decoder* d = new hipdec_decoder();
+  d->strict = strict_decoding; d->max_pixels = max_image_size_pixels;
+  *out = d;
+  return 0;
+}
+
+void hipdec_decoder_free(hipdec_decoder* d)
+{
+  if (!d) return;
+  delete d->batch;
+  delete d;
+}
+
+void hipdec_decoder_set_strict(hipdec_decoder* d, int strict) { if (d) d->strict = strict; }
+
+int hipdec_decoder_push_data(hipdec_decoder* d, const void* data, size_t size)
+{
+  if (!d || (!data && size)) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "push_data: bad arguments");
+  if (d->decoded) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "push_data after decode (heif_plugin.h:113-115 forbids it)");
+  // validate the framing now, as decoder_libde265.cc:322-368 does
+  const uint8_t* p = (const uint8_t*)data;
+  size_t ptr = 0;
+  while (ptr < size) {
+    if (size - ptr < 4) return set_error(HIPDEC_ERR_END_OF_DATA, "truncated NAL length field");
+    uint32_t n = ((uint32_t)p[ptr] << 24) | ((uint32_t)p[ptr + 1] << 16) | ((uint32_t)p[ptr + 2] << 8) | p[ptr + 3];
+    ptr += 4;
+    if (n > size - ptr) return set_error(HIPDEC_ERR_END_OF_DATA, "NAL size exceeds the pushed data");
+    ptr += n;
+  }
+  d->data.insert(d->data.end(), p, p + size);
+  return 0;
+}
+
+int hipdec_decoder_decode(hipdec_decoder* d, hipdec_image_info* info)
+{
+  if (!d) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "decode: NULL decoder");
+  if (d->decoded) return set_error(HIPDEC_ERR_NO_IMAGE, "no further image");
+  if (d->data.empty()) return set_error(HIPDEC_ERR_NO_IMAGE, "no data was pushed");
+  const void* ptrs[1] = {d->data.data()};
+  const size_t sizes[1] = {d->data.size()};
+  if (int rc = hipdec_batch_create(&d->batch, 1, ptrs, sizes, d->max_pixels)) return rc;
+  if (int rc = hipdec_batch_run(d->batch, nullptr)) return rc;
+  if (int rc = hipdec_batch_status(d->batch)) return rc;
+  d->decoded = true;
+  if (info) *info = d->batch->pics[0].info;
+  return 0;
+}
+
+int hipdec_decoder_read_plane(hipdec_decoder* d, int c, void* dst, size_t dst_stride)
+{
+  if (!d || !d->decoded) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: nothing decoded");
+  return hipdec_batch_read_plane(d->batch, 0, c, dst, dst_stride);
+}
+
+int hipdec_decoder_device_plane(hipdec_decoder* d, int c, const void** dptr, size_t* stride)
+{
+  if (!d || !d->decoded) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "device_plane: nothing decoded");
+  return hipdec_batch_device_plane(d->batch, 0, c, dptr, stride);
+}
+
+}  // extern "C"

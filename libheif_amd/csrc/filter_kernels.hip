@@ -1,0 +1,267 @@
+// filter_kernels.hip — in-loop filters: deblocking (8.7.2) and sample adaptive offset (8.7.3) with
+// the conformance-window crop fused into the SAO store.
+//
+// Stands in for libde265's deblocking / SAO stages behind de265_decode()
+// (reference call site libheif/plugins/decoder_libde265.cc:402) and for the plane hand-over crop of
+// convert_libde265_image_to_heif_image (libheif/plugins/decoder_libde265.cc:97-171).
+//
+// MI355X mapping: both filters are embarrassingly parallel streaming passes (HBM-bound):
+//   deblock  one thread per 4-sample edge segment; vertical edges of the whole batch first, then
+//            horizontal edges (kernel boundary = the ordering the standard requires); consecutive
+//            lanes take consecutive segments of one sample row so each row access of a wave is one
+//            contiguous 256-512 B span; in place (segments never overlap: edges are 8 apart, at most
+//            3 samples are modified per side).  Algorithmic bytes: 3*s per luma pixel per pass.
+//   SAO      one thread per 4 output samples, reads the deblocked picture, writes the cropped output
+//            plane.  Algorithmic bytes: 1.5*s in + 1.5*s out per luma pixel.
+// grid.y = picture index of the batch, grid.z = colour component where applicable.
+#include <hip/hip_runtime.h>
+#include "hevc_device.h"
+#include "kernels.h"
+
+namespace hipdec {
+
+
+namespace {
+
+__constant__ uint8_t c_beta[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24,
+                                   26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
+__constant__ uint8_t c_tc[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4,
+                                 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
+__constant__ uint8_t c_chroma_qp_f[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37};
+
+__device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ uint32_t interleave4(uint32_t x, uint32_t y)
+{
+  x = (x | (x << 2)) & 0x33; x = (x | (x << 1)) & 0x55;
+  y = (y | (y << 2)) & 0x33; y = (y | (y << 1)) & 0x55;
+  return x | (y << 1);
+}
+// index of 4x4 unit (ux, uy) (picture coordinates) in the CTB-major, z-ordered unit maps
+__device__ __forceinline__ size_t unit_index(const PicParams& P, int ux, int uy, int* ctb_rs)
+{
+  const int l = P.log2_ctb - 2, mask = (1 << l) - 1;
+  const int c = (uy >> l) * P.ctb_w + (ux >> l);
+  *ctb_rs = c;
+  return ((size_t)c << P.units_per_ctb_log2) + interleave4((uint32_t)(ux & mask), (uint32_t)(uy & mask));
+}
+
+// luma edge segment of 4 lines; pix -> q0 of line 0; xs = step across the edge, ys = step along it
+template <typename Pix>
+__device__ __forceinline__ void deblock_luma(Pix* pix, int xs, int ys, int qp_p, int qp_q, int beta_off2, int tc_off2, int bit_depth, int no_p,
+                                             int no_q)
+{
+  const int qpl = (qp_q + qp_p + 1) >> 1;
+  const int beta = c_beta[clip3(0, 51, qpl + (beta_off2 << 1))] * (1 << (bit_depth - 8));
+  const int tc = c_tc[clip3(0, 53, qpl + 2 + (tc_off2 << 1))] * (1 << (bit_depth - 8));
+  int p[4][4], q[4][4];  // [line][i]
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) { p[k][i] = pix[-(i + 1) * xs + k * ys]; q[k][i] = pix[i * xs + k * ys]; }
+  const int dp0 = iabs(p[0][2] - 2 * p[0][1] + p[0][0]), dp3 = iabs(p[3][2] - 2 * p[3][1] + p[3][0]);
+  const int dq0 = iabs(q[0][2] - 2 * q[0][1] + q[0][0]), dq3 = iabs(q[3][2] - 2 * q[3][1] + q[3][0]);
+  const int dpq0 = dp0 + dq0, dpq3 = dp3 + dq3, dp = dp0 + dp3, dq = dq0 + dq3;
+  if (dpq0 + dpq3 >= beta) return;
+  const int s0 = (2 * dpq0 < (beta >> 2)) && (iabs(p[0][3] - p[0][0]) + iabs(q[0][0] - q[0][3]) < (beta >> 3)) &&
+                 (iabs(p[0][0] - q[0][0]) < ((5 * tc + 1) >> 1));
+  const int s3 = (2 * dpq3 < (beta >> 2)) && (iabs(p[3][3] - p[3][0]) + iabs(q[3][0] - q[3][3]) < (beta >> 3)) &&
+                 (iabs(p[3][0] - q[3][0]) < ((5 * tc + 1) >> 1));
+  const int strong = s0 && s3;
+  const int dep = dp < ((beta + (beta >> 1)) >> 3), deq = dq < ((beta + (beta >> 1)) >> 3);
+  const int maxv = (1 << bit_depth) - 1;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int p0 = p[k][0], p1 = p[k][1], p2 = p[k][2], p3 = p[k][3], q0 = q[k][0], q1 = q[k][1], q2 = q[k][2], q3 = q[k][3];
+    Pix* l = pix + k * ys;
+    if (strong) {
+      if (!no_p) {
+        l[-1 * xs] = (Pix)clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+        l[-2 * xs] = (Pix)clip3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2);
+        l[-3 * xs] = (Pix)clip3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+      }
+      if (!no_q) {
+        l[0] = (Pix)clip3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+        l[xs] = (Pix)clip3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2);
+        l[2 * xs] = (Pix)clip3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3);
+      }
+    } else {
+      int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+      if (iabs(delta) < tc * 10) {
+        delta = clip3(-tc, tc, delta);
+        if (!no_p) l[-xs] = (Pix)clip3(0, maxv, p0 + delta);
+        if (!no_q) l[0] = (Pix)clip3(0, maxv, q0 - delta);
+        if (dep && !no_p) l[-2 * xs] = (Pix)clip3(0, maxv, p1 + clip3(-(tc >> 1), tc >> 1, (((p2 + p0 + 1) >> 1) - p1 + delta) >> 1));
+        if (deq && !no_q) l[xs] = (Pix)clip3(0, maxv, q1 + clip3(-(tc >> 1), tc >> 1, (((q2 + q0 + 1) >> 1) - q1 - delta) >> 1));
+      }
+    }
+  }
+}
+
+template <typename Pix>
+__device__ __forceinline__ void deblock_chroma(Pix* pix, int xs, int ys, int qp_p, int qp_q, int c_qp_pic_offset, int tc_off2, int bit_depth,
+                                               int no_p, int no_q)
+{
+  const int qpi = ((qp_q + qp_p + 1) >> 1) + c_qp_pic_offset;
+  const int qpc = qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : c_chroma_qp_f[qpi - 30]);
+  const int tc = c_tc[clip3(0, 53, qpc + 2 + (tc_off2 << 1))] * (1 << (bit_depth - 8));
+  const int maxv = (1 << bit_depth) - 1;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    Pix* l = pix + k * ys;
+    const int p0 = l[-xs], p1 = l[-2 * xs], q0 = l[0], q1 = l[xs];
+    const int delta = clip3(-tc, tc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
+    if (!no_p) l[-xs] = (Pix)clip3(0, maxv, p0 + delta);
+    if (!no_q) l[0] = (Pix)clip3(0, maxv, q0 - delta);
+  }
+}
+
+}  // namespace
+
+// DIR 0: vertical edges (filtering across x), DIR 1: horizontal edges
+template <typename Pix, int DIR>
+__global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
+{
+  const PicParams& P = A.pics[blockIdx.y];
+  const int uw = (P.width + 3) >> 2, uh = (P.height + 3) >> 2;
+  // work item: (edge index along the filtered direction on the 8-sample grid, unit index along the edge)
+  const int n_edges = DIR == 0 ? (P.width + 7) >> 3 : (P.height + 7) >> 3;
+  const int n_along = DIR == 0 ? uh : uw;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n_edges * n_along) return;
+  int e, a;
+  if (DIR == 0) { e = tid % n_edges; a = tid / n_edges; }  // consecutive lanes: consecutive x
+  else { a = tid % n_along; e = tid / n_along; }            // consecutive lanes: consecutive x as well
+  if (e == 0) return;
+  const int x = DIR == 0 ? e * 8 : a * 4, y = DIR == 0 ? a * 4 : e * 8;
+  if (x >= P.width || y >= P.height) return;
+  const uint8_t* u_flags = A.arena + P.off_u_flags;
+  const int8_t* u_qp = (const int8_t*)(A.arena + P.off_u_qp);
+  int ctb_q, ctb_p;
+  const size_t iq = unit_index(P, x >> 2, y >> 2, &ctb_q);
+  const uint8_t fq = u_flags[iq];
+  if (!(fq & (DIR == 0 ? UF_VEDGE : UF_HEDGE))) return;
+  const size_t ip = DIR == 0 ? unit_index(P, (x >> 2) - 1, y >> 2, &ctb_p) : unit_index(P, x >> 2, (y >> 2) - 1, &ctb_p);
+  const uint8_t fp = u_flags[ip];
+  const int qp_q = u_qp[iq], qp_p = u_qp[ip];
+  const int no_q = (fq & UF_BYPASS) != 0, no_p = (fp & UF_BYPASS) != 0;  // PCM never occurs (rejected on the host)
+  const CtbInfo* ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
+  const SliceParams sl = ((const SliceParams*)(A.arena + P.off_slices))[ctb_info[ctb_q].slice_idx];
+  {
+    Pix* rec = (Pix*)(A.arena + P.off_rec[0]);
+    const int stride = P.rec_stride[0] / sizeof(Pix);
+    Pix* pix = rec + (size_t)y * stride + x;
+    if (DIR == 0) deblock_luma<Pix>(pix, 1, stride, qp_p, qp_q, sl.beta_offset_div2, sl.tc_offset_div2, P.bit_depth_luma, no_p, no_q);
+    else deblock_luma<Pix>(pix, stride, 1, qp_p, qp_q, sl.beta_offset_div2, sl.tc_offset_div2, P.bit_depth_luma, no_p, no_q);
+  }
+  if (P.chroma_format_idc == 1) {
+    // chroma edges on the 8x8 chroma grid; one 4-sample chroma segment spans 8 luma samples along the edge
+    const int on_grid = DIR == 0 ? ((x & 15) == 0 && (y & 7) == 0) : ((y & 15) == 0 && (x & 7) == 0);
+    if (on_grid) {
+      for (int c = 1; c < 3; c++) {
+        Pix* rec = (Pix*)(A.arena + P.off_rec[c]);
+        const int stride = P.rec_stride[c] / sizeof(Pix);
+        Pix* pix = rec + (size_t)(y >> 1) * stride + (x >> 1);
+        const int off = c == 1 ? sl.pps_cb_qp_offset : sl.pps_cr_qp_offset;
+        if (DIR == 0) deblock_chroma<Pix>(pix, 1, stride, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q);
+        else deblock_chroma<Pix>(pix, stride, 1, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q);
+      }
+    }
+  }
+}
+
+// SAO + conformance crop; blockIdx.z = colour component
+template <typename Pix>
+__global__ __launch_bounds__(256) void k_sao(FilterArgs A)
+{
+  const PicParams& P = A.pics[blockIdx.y];
+  const int c = blockIdx.z;
+  if (c > 0 && !P.chroma_format_idc) return;
+  const int sub = c ? 2 : 1;
+  const int ow = c ? P.out_cwidth : P.out_width, oh = c ? P.out_cheight : P.out_height;
+  const int groups = (ow + 3) >> 2;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= groups * oh) return;
+  const int ox0 = (tid % groups) * 4, oy = tid / groups;
+  const int W = c ? P.cwidth : P.width, H = c ? P.cheight : P.height;
+  const int bit_depth = c ? P.bit_depth_chroma : P.bit_depth_luma;
+  const int maxv = (1 << bit_depth) - 1;
+  const Pix* rec = (const Pix*)(A.arena + P.off_rec[c]);
+  const int rs = P.rec_stride[c] / sizeof(Pix);
+  Pix* out = (Pix*)(A.arena + P.off_out[c]);
+  const int os = P.out_stride[c] / sizeof(Pix);
+  const uint8_t* u_flags = A.arena + P.off_u_flags;
+  const SaoParams* sao = (const SaoParams*)(A.arena + P.off_sao);
+  const CtbInfo* ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
+  const SliceParams* slices = (const SliceParams*)(A.arena + P.off_slices);
+  const int y = oy + P.crop_y / sub;
+  const int lctb = P.log2_ctb - (c ? 1 : 0);  // log2 CTB size in component samples
+  Pix res[4];
+  const int npx = ow - ox0 < 4 ? ow - ox0 : 4;
+  for (int i = 0; i < npx; i++) {
+    const int x = ox0 + i + P.crop_x / sub;
+    int v = rec[(size_t)y * rs + x];
+    const int ctb = (y >> lctb) * P.ctb_w + (x >> lctb);
+    const SaoParams sp = sao[(size_t)ctb * 3 + c];
+    if (sp.type) {
+      int ctb_dummy;
+      const uint8_t fl = u_flags[unit_index(P, (x * sub) >> 2, (y * sub) >> 2, &ctb_dummy)];
+      if (!(fl & UF_BYPASS)) {
+        if (sp.type == 1) {
+          const int k = ((v >> (bit_depth - 5)) - sp.band_or_class) & 31;
+          if (k < 4) v = clip3(0, maxv, v + sp.offset[k]);
+        } else {
+          const int cls = sp.band_or_class;
+          const int hx = cls == 1 ? 0 : (cls == 3 ? 1 : -1), hy = cls == 0 ? 0 : -1;  // first neighbour; second is the mirror
+          int edge_idx = 2, skip = 0;
+          for (int k = 0; k < 2; k++) {
+            const int xs = x + (k ? -hx : hx), ys = y + (k ? -hy : hy);
+            if (xs < 0 || ys < 0 || xs >= W || ys >= H) { skip = 1; break; }
+            const int ctb_n = (ys >> lctb) * P.ctb_w + (xs >> lctb);
+            if (ctb_n != ctb) {
+              const CtbInfo cn = ctb_info[ctb_n], cc = ctb_info[ctb];
+              if (cn.slice_idx != cc.slice_idx) {
+                if (cn.slice_idx < cc.slice_idx && !slices[cc.slice_idx].lf_across_slices) { skip = 1; break; }
+                if (cn.slice_idx > cc.slice_idx && !slices[cn.slice_idx].lf_across_slices) { skip = 1; break; }
+              }
+              if (!P.lf_across_tiles && cn.tile_id != cc.tile_id) { skip = 1; break; }
+            }
+            const int nv = rec[(size_t)ys * rs + xs];
+            edge_idx += (v > nv) - (v < nv);
+          }
+          if (!skip) {
+            if (edge_idx <= 2) edge_idx = edge_idx == 2 ? 0 : edge_idx + 1;
+            if (edge_idx) v = clip3(0, maxv, v + sp.offset[edge_idx - 1]);
+          }
+        }
+      }
+    }
+    res[i] = (Pix)v;
+  }
+  Pix* o = out + (size_t)oy * os + ox0;
+  if (npx == 4 && sizeof(Pix) == 1) *(uint32_t*)o = res[0] | (res[1] << 8) | (res[2] << 16) | ((uint32_t)res[3] << 24);
+  else if (npx == 4 && sizeof(Pix) == 2) *(uint2*)o = make_uint2(res[0] | ((uint32_t)res[1] << 16), res[2] | ((uint32_t)res[3] << 16));
+  else for (int i = 0; i < npx; i++) o[i] = res[i];
+}
+
+void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s)
+{
+  const int uw = (max_w + 3) / 4, uh = (max_h + 3) / 4;
+  const int work_v = ((max_w + 7) / 8) * uh, work_h = ((max_h + 7) / 8) * uw;
+  if (wide) {
+    hipLaunchKernelGGL((k_deblock<uint16_t, 0>), dim3((work_v + 255) / 256, n_pics), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_deblock<uint16_t, 1>), dim3((work_h + 255) / 256, n_pics), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((k_deblock<uint8_t, 0>), dim3((work_v + 255) / 256, n_pics), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_deblock<uint8_t, 1>), dim3((work_h + 255) / 256, n_pics), dim3(256), 0, s, a);
+  }
+}
+
+void launch_sao(const FilterArgs& a, int n_pics, int max_out_w, int max_out_h, bool wide, hipStream_t s)
+{
+  const int work = ((max_out_w + 3) / 4) * max_out_h;
+  if (wide) hipLaunchKernelGGL((k_sao<uint16_t>), dim3((work + 255) / 256, n_pics, 3), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_sao<uint8_t>), dim3((work + 255) / 256, n_pics, 3), dim3(256), 0, s, a);
+}
+
+}  // namespace hipdec

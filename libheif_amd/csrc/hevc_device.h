@@ -1,0 +1,139 @@
+// hevc_device.h — POD descriptors shared by the host front end and the HIP kernels.
+//
+// Data layout in HBM (per picture, all offsets relative to one arena allocation per batch):
+//   bitstream   raw bytes exactly as pushed (length-prefixed NALs, emulation prevention bytes still
+//               in place; the CABAC reader skips them on the fly)
+//   unit maps   one byte per 4x4 luma unit, stored CTB by CTB (raster CTB order) and in z-scan order
+//               inside a CTB, so that every CU / TU occupies a contiguous index range:
+//                 u_size  low nibble log2 TB size, high nibble log2 CB size
+//                 u_flags bit0 cbf_luma, bit1 cbf_cb, bit2 cbf_cr, bit3 cu_transquant_bypass,
+//                         bit4 pcm (never set: PCM streams are rejected), bit5 vertical deblocking
+//                         edge on the unit's left side, bit6 horizontal edge on its top,
+//                         bit7 transform_skip (luma)
+//                 u_ipm   bits0-5 IntraPredModeY, bit6 transform_skip Cb, bit7 transform_skip Cr
+//                 u_ipmc  IntraPredModeC
+//                 u_qp    QpY of the coding unit (int8)
+//   coeff       int16 TransCoeffLevel, TU-contiguous: a luma TU whose first unit has z-index u owns
+//               [ctb*ctbSize^2 + u*16, +n*n) in raster order inside the TU; chroma likewise at
+//               [ctb*ctbSize^2/4 + u*4, +n*n/4)
+//   rec planes  reconstructed samples (coded size, stride padded to 64 B), deblocked in place
+//   out planes  SAO output cropped to the conformance window (what the plugin hands to libheif)
+#pragma once
+#include <stdint.h>
+
+namespace hipdec {
+
+enum : int {
+  CTX_SAO_MERGE = 0,
+  CTX_SAO_TYPE = 1,
+  CTX_SPLIT_CU = 2,
+  CTX_CU_TQ_BYPASS = 5,
+  CTX_PART_MODE = 6,
+  CTX_PREV_INTRA_LUMA = 7,
+  CTX_INTRA_CHROMA = 8,
+  CTX_SPLIT_TRANSFORM = 9,
+  CTX_CBF_LUMA = 12,
+  CTX_CBF_CHROMA = 14,
+  CTX_CU_QP_DELTA = 18,
+  CTX_TRANSFORM_SKIP = 20,
+  CTX_LAST_X = 22,
+  CTX_LAST_Y = 40,
+  CTX_CODED_SUB_BLOCK = 58,
+  CTX_SIG_COEFF = 62,
+  CTX_GREATER1 = 104,
+  CTX_GREATER2 = 128,
+  CTX_COUNT = 134,
+  CTX_STORE = 160  // bytes reserved per saved context table
+};
+
+enum : uint8_t {
+  UF_CBF_LUMA = 1, UF_CBF_CB = 2, UF_CBF_CR = 4, UF_BYPASS = 8, UF_PCM = 16, UF_VEDGE = 32, UF_HEDGE = 64, UF_TS_LUMA = 128
+};
+
+// per-CTB availability bits computed on the host (6.4.1: same slice, same tile, inside the picture)
+// AV_EDGE_*: the CTB's left / top boundary may be deblocked (8.7.2: picture edge, slice edge with
+// slice_loop_filter_across_slices_enabled_flag = 0, tile edge with loop_filter_across_tiles = 0)
+enum : uint8_t { AV_LEFT = 1, AV_UP = 2, AV_UPRIGHT = 4, AV_UPLEFT = 8, AV_EDGE_LEFT = 16, AV_EDGE_UP = 32 };
+
+struct SliceParams {
+  int32_t slice_qp_y;
+  int8_t cb_qp_offset, cr_qp_offset;        // pps + slice offsets (dequantisation)
+  int8_t pps_cb_qp_offset, pps_cr_qp_offset; // cQpPicOffset for chroma deblocking
+  int8_t beta_offset_div2, tc_offset_div2;
+  uint8_t deblocking_disabled;
+  uint8_t sao_luma, sao_chroma;
+  uint8_t lf_across_slices;                  // slice_loop_filter_across_slices_enabled_flag
+  uint16_t slice_addr_rs;
+};
+
+struct SaoParams {   // per CTB and colour component
+  uint8_t type;      // 0 off, 1 band, 2 edge
+  uint8_t band_or_class;
+  int16_t offset[4]; // SaoOffsetVal[1..4]
+};
+
+struct PicParams {
+  // geometry
+  int32_t width, height;          // coded luma size
+  int32_t cwidth, cheight;        // coded chroma size (0 for 4:0:0)
+  int32_t out_width, out_height;  // cropped luma size
+  int32_t out_cwidth, out_cheight;
+  int32_t crop_x, crop_y;         // luma offset of the conformance window
+  int32_t chroma_format_idc, bit_depth_luma, bit_depth_chroma;
+  int32_t log2_ctb, log2_min_cb, log2_min_tb, log2_max_tb, max_th_depth_intra;
+  int32_t ctb_w, ctb_h, units_per_ctb_log2;  // units_per_ctb = 1 << units_per_ctb_log2
+  // coding tools
+  uint8_t sao_enabled, sign_data_hiding, transform_skip_enabled, cu_qp_delta_enabled;
+  uint8_t transquant_bypass_enabled, strong_intra_smoothing, tiles_enabled, wpp;
+  uint8_t lf_across_tiles, pcm_loop_filter_disabled, pad0, pad1;
+  int32_t log2_min_cu_qp_delta_size;
+  // buffers (byte offsets into the batch arena)
+  uint64_t off_bitstream, bitstream_size;
+  uint64_t off_ctb_ts_to_rs;      // uint16[ctbs]
+  uint64_t off_ctb_info;          // CtbInfo[ctbs] (raster)
+  uint64_t off_slices;            // SliceParams[nslices]
+  uint64_t off_sao;               // SaoParams[ctbs*3]
+  uint64_t off_u_size, off_u_flags, off_u_ipm, off_u_ipmc, off_u_qp;  // uint8[ctbs*units_per_ctb]
+  uint64_t off_coeff[3];          // int16
+  uint64_t off_rec[3];            // Pix (uint8 / uint16), coded size
+  uint64_t off_out[3];            // Pix, cropped size
+  uint32_t rec_stride[3];         // bytes
+  uint32_t out_stride[3];         // bytes
+  uint32_t first_row;             // index of this picture's first CTB row in the batch row table
+  uint32_t num_slices;
+};
+
+struct CtbInfo {
+  uint16_t slice_idx;   // index into the picture's SliceParams
+  uint8_t avail;        // AV_* bits
+  uint8_t tile_id;
+};
+
+struct Substream {
+  uint32_t pic;
+  uint32_t byte_start, byte_end;  // offsets inside the picture's bitstream blob
+  uint32_t first_ctb_ts, num_ctbs;
+  uint32_t slice_idx;
+  int32_t dep_sub;                // substream of the CTB row above when it is a WPP predecessor, else -1
+  uint32_t dep_len;               // number of CTBs in dep_sub
+  uint8_t wpp_sync;               // 1: initialise contexts from dep_sub's stored table (top-right available)
+  uint8_t has_dependent;          // 1: another substream waits on this one's progress
+  uint8_t last_in_slice_segment;  // 1: last CTB ends with end_of_slice_segment_flag = 1
+  uint8_t pad;
+};
+
+struct RowDesc {   // one CTB row of one picture, for the reconstruction wavefront
+  uint32_t pic;
+  uint32_t row;
+};
+
+// device-side error codes written to the batch status word (first error wins)
+enum : int32_t {
+  DEV_OK = 0,
+  DEV_ERR_TERMINATE = 1,    // end_of_slice_segment_flag / end_of_subset_one_bit mismatch (desync)
+  DEV_ERR_BITSTREAM_END = 2,
+  DEV_ERR_SYNTAX = 3,       // value out of range (last position, cu_qp_delta, ...)
+  DEV_ERR_TIMEOUT = 4       // a dependency wait exceeded its bound
+};
+
+}  // namespace hipdec

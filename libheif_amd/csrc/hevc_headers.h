@@ -1,0 +1,64 @@
+// hevc_headers.h — host front end: NAL framing, parameter sets, slice segment headers and the
+// substream / CTB tables the kernels consume.  The pixel path never runs on the host.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "heif_hipdec.h"
+#include "hevc_device.h"
+
+namespace hipdec {
+
+struct Sps {
+  bool valid = false;
+  int chroma_format_idc = 1, pic_width = 0, pic_height = 0;
+  int conf_left = 0, conf_right = 0, conf_top = 0, conf_bottom = 0;
+  int bit_depth_luma = 8, bit_depth_chroma = 8, log2_max_poc_lsb = 4;
+  int log2_min_cb = 3, log2_ctb = 4, log2_min_tb = 2, log2_max_tb = 5;
+  int max_th_depth_inter = 0, max_th_depth_intra = 0;
+  bool scaling_list_enabled = false, amp = false, sao = false, pcm = false, strong_intra_smoothing = false;
+  bool long_term_ref_pics_present = false, temporal_mvp = false, separate_colour_plane = false;
+  int num_short_term_ref_pic_sets = 0, num_long_term_ref_pics_sps = 0;
+  std::vector<int> rps_num_delta_pocs;  // NumDeltaPocs per short-term RPS (needed to skip slice-level RPS)
+  int colour_primaries = 2, transfer_characteristics = 2, matrix_coeffs = 2, full_range = 0;
+};
+
+struct Pps {
+  bool valid = false;
+  int sps_id = 0;
+  bool dependent_slice_segments_enabled = false, output_flag_present = false, sign_data_hiding = false;
+  bool cabac_init_present = false, constrained_intra_pred = false, transform_skip = false, cu_qp_delta = false;
+  bool slice_chroma_qp_offsets_present = false, transquant_bypass = false, tiles = false, wpp = false;
+  bool uniform_spacing = true, lf_across_tiles = true, lf_across_slices = false;
+  bool deblocking_override_enabled = false, deblocking_disabled = false, scaling_list_data_present = false;
+  bool slice_header_extension_present = false;
+  int num_extra_slice_header_bits = 0, init_qp = 26, diff_cu_qp_delta_depth = 0;
+  int cb_qp_offset = 0, cr_qp_offset = 0, beta_offset_div2 = 0, tc_offset_div2 = 0;
+  int tile_cols = 1, tile_rows = 1;
+  std::vector<int> col_width, row_height;  // explicit sizes when !uniform_spacing
+};
+
+struct ParsedSlice {
+  SliceParams sp{};
+  int segment_address = 0;
+  size_t data_offset = 0;  // offset in the pushed blob of the first slice_segment_data byte
+  size_t nal_end = 0;      // offset one past the slice NAL
+  std::vector<uint32_t> entry_point_offsets;  // bytes, escaped domain
+};
+
+struct ParsedPicture {
+  Sps sps;
+  Pps pps;
+  std::vector<ParsedSlice> slices;
+  hipdec_image_info info{};
+  std::vector<uint16_t> ts_to_rs;
+  std::vector<CtbInfo> ctb_info;    // raster
+  std::vector<Substream> subs;      // `pic` and dep indices are picture-local until the batch relocates them
+  std::vector<SliceParams> slice_params;
+};
+
+// Parses one coded picture from libheif's plugin framing.  Returns a hipdec_status.
+int parse_picture(const uint8_t* blob, size_t size, uint64_t max_image_size_pixels, ParsedPicture& out, std::string& err);
+
+}  // namespace hipdec

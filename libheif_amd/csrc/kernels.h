@@ -1,0 +1,40 @@
+// kernels.h — kernel argument blocks and the host-side launchers each kernel translation unit exports.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "hevc_device.h"
+
+namespace hipdec {
+
+struct ParseArgs {
+  const PicParams* pics;
+  const Substream* subs;
+  uint32_t num_subs;
+  uint8_t* arena;
+  uint32_t* progress;   // per substream: CTBs completed
+  uint8_t* ctx_store;   // per substream: CTX_STORE bytes, contexts after the 2nd CTB (WPP)
+  uint32_t* ticket;
+  int32_t* status;
+  int32_t debug_level;  // HIPDEC_DEBUG_PARSE: early-exit points for fault isolation (0 = off)
+};
+
+struct ReconArgs {
+  const PicParams* pics;
+  const RowDesc* rows;
+  uint32_t num_rows;
+  uint8_t* arena;
+  uint32_t* row_progress;  // per batch row: CTBs completed
+  uint32_t* ticket;
+  int32_t* status;
+};
+
+struct FilterArgs {
+  const PicParams* pics;
+  uint8_t* arena;
+};
+
+void launch_parse(const ParseArgs& a, hipStream_t s);
+void launch_recon(const ReconArgs& a, bool wide, hipStream_t s);
+void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s);
+void launch_sao(const FilterArgs& a, int n_pics, int max_out_w, int max_out_h, bool wide, hipStream_t s);
+
+}  // namespace hipdec

@@ -1,0 +1,168 @@
+"""Host-side mirror of the reference's decoder-plugin interface for the HEVC path.
+
+`HipDecoder` follows the call sequence libheif drives through heif_decoder_plugin
+(libheif/codecs/decoder.cc:355-563): new_decoder -> push_data (xN) -> decode_next_image -> free,
+with the same framing contract as libheif/plugins/decoder_libde265.cc:322-368 and the same error
+behaviour (truncated framing -> End_of_data, nothing pushed -> no image).  `Batch` is the grid /
+throughput entry point (libheif/image-items/grid.cc:405-453 on the device).  Both are thin ctypes
+wrappers over the C ABI in include/heif_hipdec.h — no pixel is computed in Python.
+"""
+import ctypes as C
+import numpy as np
+from ._capi import HipDecError, ImageInfo, check, load_library, DeviceBuffer
+
+
+def _bind(lib):
+    if getattr(lib, "_dec_bound", False):
+        return lib
+    vp, sz, ci = C.c_void_p, C.c_size_t, C.c_int
+    lib.hipdec_decoder_new.argtypes = [C.POINTER(vp), ci, C.c_uint64]
+    lib.hipdec_decoder_free.argtypes = [vp]
+    lib.hipdec_decoder_push_data.argtypes = [vp, C.c_char_p, sz]
+    lib.hipdec_decoder_decode.argtypes = [vp, C.POINTER(ImageInfo)]
+    lib.hipdec_decoder_read_plane.argtypes = [vp, ci, vp, sz]
+    lib.hipdec_batch_create.argtypes = [C.POINTER(vp), ci, C.POINTER(C.c_char_p), C.POINTER(sz), C.c_uint64]
+    lib.hipdec_batch_free.argtypes = [vp]
+    lib.hipdec_batch_count.argtypes = [vp]
+    lib.hipdec_batch_info.argtypes = [vp, ci, C.POINTER(ImageInfo)]
+    lib.hipdec_batch_run.argtypes = [vp, vp]
+    lib.hipdec_batch_status.argtypes = [vp]
+    lib.hipdec_batch_read_plane.argtypes = [vp, ci, ci, vp, sz]
+    lib.hipdec_batch_device_plane.argtypes = [vp, ci, ci, C.POINTER(vp), C.POINTER(sz)]
+    lib.hipdec_batch_to_rgb.argtypes = [vp, ci, ci, vp, sz, vp]
+    lib.hipdec_batch_last_timing_us.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.hipdec_batch_read_tap.argtypes = [vp, ci, ci, ci, vp, sz]
+    lib.hipdec_batch_read_maps.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, sz]
+    lib._dec_bound = True
+    return lib
+
+
+def _info_dict(info):
+    return {f: getattr(info, f) for f, _ in ImageInfo._fields_}
+
+
+class DecodedImage:
+    def __init__(self, info, planes):
+        self.info = info
+        self.planes = planes
+        self.nclx = (info["colour_primaries"], info["transfer_characteristics"], info["matrix_coeffs"], info["full_range_flag"])
+
+
+class HipDecoder:
+    def __init__(self, strict_decoding=False, max_image_size_pixels=0):
+        self._lib = _bind(load_library())
+        self._h = C.c_void_p()
+        check(self._lib.hipdec_decoder_new(C.byref(self._h), int(strict_decoding), int(max_image_size_pixels)))
+
+    def push_data(self, data: bytes):
+        check(self._lib.hipdec_decoder_push_data(self._h, data, len(data)))
+
+    def flush_data(self):
+        return None
+
+    def decode_next_image(self):
+        """Returns a DecodedImage, or None when there is nothing (more) to deliver."""
+        info = ImageInfo()
+        rc = self._lib.hipdec_decoder_decode(self._h, C.byref(info))
+        if rc == -7:  # HIPDEC_ERR_NO_IMAGE
+            return None
+        check(rc)
+        d = _info_dict(info)
+        dt = np.uint16 if d["bit_depth_luma"] > 8 else np.uint8
+        planes = []
+        for c in range(3 if d["chroma_format_idc"] else 1):
+            w, h = (d["width"], d["height"]) if c == 0 else (d["chroma_width"], d["chroma_height"])
+            a = np.empty((h, w), dt)
+            check(self._lib.hipdec_decoder_read_plane(self._h, c, a.ctypes.data, w * a.itemsize))
+            planes.append(a)
+        return DecodedImage(d, planes)
+
+    def free(self):
+        if self._h:
+            self._lib.hipdec_decoder_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Batch:
+    """Many independent coded items (grid tiles, batches of stills) decoded by one set of launches."""
+
+    def __init__(self, streams, max_image_size_pixels=0):
+        self._lib = _bind(load_library())
+        self._keep = [bytes(s) for s in streams]
+        n = len(self._keep)
+        arr = (C.c_char_p * n)(*self._keep)
+        sizes = (C.c_size_t * n)(*[len(s) for s in self._keep])
+        self._h = C.c_void_p()
+        check(self._lib.hipdec_batch_create(C.byref(self._h), n, arr, sizes, int(max_image_size_pixels)))
+        self.n = n
+
+    def info(self, i):
+        info = ImageInfo()
+        check(self._lib.hipdec_batch_info(self._h, i, C.byref(info)))
+        return _info_dict(info)
+
+    def run(self, stream=None):
+        check(self._lib.hipdec_batch_run(self._h, stream))
+
+    def status(self):
+        check(self._lib.hipdec_batch_status(self._h))
+
+    def planes(self, i):
+        d = self.info(i)
+        dt = np.uint16 if d["bit_depth_luma"] > 8 else np.uint8
+        out = []
+        for c in range(3 if d["chroma_format_idc"] else 1):
+            w, h = (d["width"], d["height"]) if c == 0 else (d["chroma_width"], d["chroma_height"])
+            a = np.empty((h, w), dt)
+            check(self._lib.hipdec_batch_read_plane(self._h, i, c, a.ctypes.data, w * a.itemsize))
+            out.append(a)
+        return out
+
+    def tap(self, i, c):
+        """deblocked (pre-SAO) picture at coded size — debug tap"""
+        d = self.info(i)
+        dt = np.uint16 if d["bit_depth_luma"] > 8 else np.uint8
+        w, h = (d["coded_width"], d["coded_height"]) if c == 0 else (d["coded_width"] // 2, d["coded_height"] // 2)
+        a = np.empty((h, w), dt)
+        check(self._lib.hipdec_batch_read_tap(self._h, i, 1, c, a.ctypes.data, w * a.itemsize))
+        return a
+
+    def maps(self, i):
+        d = self.info(i)
+        uw, uh = (d["coded_width"] + 3) // 4, (d["coded_height"] + 3) // 4
+        names = ["log2_tb", "log2_cb", "intra_luma", "intra_chroma", "qp_y", "flags"]
+        arrs = [np.zeros((uh, uw), np.int8 if n == "qp_y" else np.uint8) for n in names]
+        check(self._lib.hipdec_batch_read_maps(self._h, i, *[a.ctypes.data for a in arrs], uw * uh))
+        return dict(zip(names, arrs))
+
+    def to_rgb(self, i, out_chroma=10):
+        """fused colour stage on the device planes of item i; returns the interleaved rows (uint8)."""
+        d = self.info(i)
+        bpp = {10: 3, 11: 4, 12: 6, 14: 6}[out_chroma]
+        w, h = d["width"], d["height"]
+        buf = DeviceBuffer(w * h * bpp)
+        check(self._lib.hipdec_batch_to_rgb(self._h, i, out_chroma, buf.ptr, w * bpp, None))
+        check(self._lib.hipdec_stream_synchronize(None))
+        return buf.to_numpy((h, w * bpp), np.uint8)
+
+    def timing_us(self):
+        t = (C.c_float * 5)()
+        check(self._lib.hipdec_batch_last_timing_us(self._h, t))
+        return dict(parse=t[0], recon=t[1], deblock=t[2], sao=t[3], total=t[4])
+
+    def free(self):
+        if self._h:
+            self._lib.hipdec_batch_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -217,9 +217,14 @@ def synth_image(width, height, bit_depth=8, chroma_format_idc=1, seed=1):
         base = 0.5 + 0.25 * np.sin(xx / (37.0 + seed % 7)) * np.cos(yy / 53.0) + 0.2 * (xx / max(w, 1) - 0.5)
         lo = rng.standard_normal(((h + 15) // 16 + 1, (w + 15) // 16 + 1)).astype(np.float32)
         lo = np.kron(lo, np.ones((16, 16), np.float32))[:h, :w]
-        k = np.ones(9, np.float32) / 9
-        for ax in (0, 1):
-            lo = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), ax, lo)
+        for ax in (0, 1):  # 9-tap box filter, zero padded ("same")
+            pad = [(0, 0), (0, 0)]
+            pad[ax] = (5, 4)
+            cs = np.cumsum(np.pad(lo.astype(np.float64), pad), axis=ax)
+            n = lo.shape[ax]
+            hi_s = [slice(None), slice(None)]; lo_s = [slice(None), slice(None)]
+            hi_s[ax] = slice(9, 9 + n); lo_s[ax] = slice(0, n)
+            lo = ((cs[tuple(hi_s)] - cs[tuple(lo_s)]) / 9.0).astype(np.float32)
         fine = rng.standard_normal((h, w)).astype(np.float32)
         img = base + amp * (0.12 * lo + 0.02 * fine)
         nrect = 4
