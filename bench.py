@@ -28,8 +28,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="still4k", choices=["still4k", "still1080", "grid8k"])
     ap.add_argument("--batch", type=int, default=0, help="independent stills per rank and step (0 = workload default)")
     ap.add_argument("--qp", type=int, default=27)
@@ -41,8 +41,8 @@ def parse_args():
 
 WORKLOADS = {
     # name: (width, height, default batch, encoder config)
-    "still4k": (3840, 2160, 16, dict(wpp=1)),
-    "still1080": (1920, 1080, 64, dict(wpp=1)),
+    "still4k": (3840, 2160, 256, dict(wpp=1)),
+    "still1080": (1920, 1080, 1024, dict(wpp=1)),
     "grid8k": (1024, 1024, 48, dict(wpp=1)),
 }
 
@@ -114,7 +114,8 @@ def main():
     for _ in range(a.warmup):
         step(batch)
     sync()
-    batch.status()   # device-side decode errors are loud
+    if a.warmup > 0:
+        batch.status()   # device-side decode errors are loud
     batch.timing_slots(max(1, a.steps))
     barrier(); sync()
     t0 = time.perf_counter()

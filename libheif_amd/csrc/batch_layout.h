@@ -1,0 +1,28 @@
+// batch_layout.h — pure-host layout of one decode batch in its HBM arena (no HIP calls: shared by the
+// device path in decoder.hip and by the CPU-test emulation in tests/emu).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "hevc_headers.h"
+
+namespace hipdec {
+
+struct BatchLayout {
+  std::vector<ParsedPicture> pics;
+  std::vector<PicParams> params;
+  size_t arena_size = 0, upload_size = 0;
+  size_t off_pics = 0, off_subs = 0, off_rows = 0, off_ctrl = 0, ctrl_size = 0;
+  size_t off_progress = 0, off_ctx = 0, off_row_progress = 0, off_ticket = 0, off_status = 0;
+  uint32_t num_subs = 0, num_rows = 0;
+  bool wide = false;  // samples wider than 8 bit -> uint16 planes
+  int max_w = 0, max_h = 0, max_ow = 0, max_oh = 0;
+};
+
+// Parses n items, lays the arena out ([upload region][control words][device-only buffers]) and
+// fills `host_image` with the upload region.  Returns a hipdec_status; `err` holds the message.
+int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* sizes, uint64_t max_image_size_pixels,
+                 std::vector<uint8_t>& host_image, std::string& err);
+
+}  // namespace hipdec

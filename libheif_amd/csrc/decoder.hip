@@ -10,6 +10,7 @@
 #include "hipdec_internal.h"
 #include "hevc_headers.h"
 #include "kernels.h"
+#include "batch_layout.h"
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -18,16 +19,8 @@
 
 using namespace hipdec;
 
-struct hipdec_batch {
-  std::vector<ParsedPicture> pics;
-  std::vector<PicParams> params;
+struct hipdec_batch : BatchLayout {
   uint8_t* arena = nullptr;
-  size_t arena_size = 0, upload_size = 0;
-  size_t off_pics = 0, off_subs = 0, off_rows = 0, off_ctrl = 0, ctrl_size = 0;
-  size_t off_progress = 0, off_ctx = 0, off_row_progress = 0, off_ticket = 0, off_status = 0;
-  uint32_t num_subs = 0, num_rows = 0;
-  bool wide = false;  // samples wider than 8 bit -> uint16 planes
-  int max_w = 0, max_h = 0, max_ow = 0, max_oh = 0;
   std::vector<hipEvent_t> ev;   // 5 events per timing slot; run k records into slot k % slots
   uint64_t runs = 0;
   hipStream_t last_stream = nullptr;
@@ -41,121 +34,13 @@ struct hipdec_batch {
 
 namespace {
 
-size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
 int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels)
 {
-  b.pics.resize(n);
-  for (int i = 0; i < n; i++) {
-    std::string err;
-    int rc = parse_picture((const uint8_t*)data[i], sizes[i], max_pixels, b.pics[i], err);
-    if (rc != HIPDEC_OK) return set_error(rc, "item %d: %s", i, err.c_str());
-  }
-  b.wide = b.pics[0].info.bit_depth_luma > 8 || b.pics[0].info.bit_depth_chroma > 8;
-  for (int i = 0; i < n; i++) {
-    const bool w = b.pics[i].info.bit_depth_luma > 8 || b.pics[i].info.bit_depth_chroma > 8;
-    if (w != b.wide) return set_error(HIPDEC_ERR_UNSUPPORTED, "batch mixes 8-bit and >8-bit items");
-  }
-  const size_t es = b.wide ? 2 : 1;
-  // ---- layout: [upload region: descriptors, tables, bitstreams][control words][device-only buffers] ----
-  size_t off = 0;
-  b.off_pics = off; off = align_up(off + sizeof(PicParams) * n, 256);
-  uint32_t nsubs = 0, nrows = 0;
-  for (auto& p : b.pics) { nsubs += (uint32_t)p.subs.size(); nrows += (uint32_t)((p.sps.pic_height + (1 << p.sps.log2_ctb) - 1) >> p.sps.log2_ctb); }
-  b.num_subs = nsubs; b.num_rows = nrows;
-  b.off_subs = off; off = align_up(off + sizeof(Substream) * nsubs, 256);
-  b.off_rows = off; off = align_up(off + sizeof(RowDesc) * nrows, 256);
-  b.params.assign(n, PicParams{});
-  uint32_t row_base = 0;
-  for (int i = 0; i < n; i++) {
-    const ParsedPicture& pp = b.pics[i];
-    const Sps& S = pp.sps; const Pps& Pp = pp.pps;
-    PicParams& P = b.params[i];
-    P.width = S.pic_width; P.height = S.pic_height;
-    P.chroma_format_idc = S.chroma_format_idc;
-    P.cwidth = S.chroma_format_idc ? S.pic_width / 2 : 0; P.cheight = S.chroma_format_idc ? S.pic_height / 2 : 0;
-    P.out_width = pp.info.width; P.out_height = pp.info.height; P.out_cwidth = pp.info.chroma_width; P.out_cheight = pp.info.chroma_height;
-    const int subc = S.chroma_format_idc == 1 ? 2 : 1;
-    P.crop_x = subc * S.conf_left; P.crop_y = subc * S.conf_top;
-    P.bit_depth_luma = S.bit_depth_luma; P.bit_depth_chroma = S.bit_depth_chroma;
-    P.log2_ctb = S.log2_ctb; P.log2_min_cb = S.log2_min_cb; P.log2_min_tb = S.log2_min_tb; P.log2_max_tb = S.log2_max_tb;
-    P.max_th_depth_intra = S.max_th_depth_intra;
-    P.ctb_w = (S.pic_width + (1 << S.log2_ctb) - 1) >> S.log2_ctb; P.ctb_h = (S.pic_height + (1 << S.log2_ctb) - 1) >> S.log2_ctb;
-    P.units_per_ctb_log2 = 2 * (S.log2_ctb - 2);
-    P.sao_enabled = S.sao; P.sign_data_hiding = Pp.sign_data_hiding; P.transform_skip_enabled = Pp.transform_skip;
-    P.cu_qp_delta_enabled = Pp.cu_qp_delta; P.transquant_bypass_enabled = Pp.transquant_bypass;
-    P.strong_intra_smoothing = S.strong_intra_smoothing; P.tiles_enabled = Pp.tiles; P.wpp = Pp.wpp;
-    P.lf_across_tiles = Pp.lf_across_tiles; P.pcm_loop_filter_disabled = 0;
-    P.log2_min_cu_qp_delta_size = S.log2_ctb - Pp.diff_cu_qp_delta_depth;
-    if (Pp.diff_cu_qp_delta_depth > S.log2_ctb - S.log2_min_cb) return set_error(HIPDEC_ERR_BITSTREAM, "item %d: diff_cu_qp_delta_depth out of range", i);
-    P.first_row = row_base; row_base += (uint32_t)P.ctb_h;
-    P.num_slices = (uint32_t)pp.slice_params.size();
-    const size_t nctb = (size_t)P.ctb_w * P.ctb_h;
-    P.off_ctb_ts_to_rs = off; off = align_up(off + nctb * sizeof(uint16_t), 256);
-    P.off_ctb_info = off; off = align_up(off + nctb * sizeof(CtbInfo), 256);
-    P.off_slices = off; off = align_up(off + pp.slice_params.size() * sizeof(SliceParams), 256);
-    P.off_bitstream = off; P.bitstream_size = sizes[i]; off = align_up(off + sizes[i] + 512, 256);
-    b.max_w = std::max(b.max_w, P.width); b.max_h = std::max(b.max_h, P.height);
-    b.max_ow = std::max(b.max_ow, P.out_width); b.max_oh = std::max(b.max_oh, P.out_height);
-  }
-  b.upload_size = off;
-  // control words (zeroed before every run)
-  b.off_ctrl = off;
-  b.off_progress = off; off = align_up(off + sizeof(uint32_t) * nsubs, 256);
-  b.off_row_progress = off; off = align_up(off + sizeof(uint32_t) * nrows, 256);
-  b.off_ticket = off; off += 256;  // [0] parse ticket, [1] recon ticket
-  b.off_status = off; off += 256;
-  b.ctrl_size = off - b.off_ctrl;
-  b.off_ctx = off; off = align_up(off + (size_t)CTX_STORE * nsubs, 256);
-  for (int i = 0; i < n; i++) {
-    PicParams& P = b.params[i];
-    const size_t nctb = (size_t)P.ctb_w * P.ctb_h;
-    const size_t nunits = nctb << P.units_per_ctb_log2;
-    const size_t ctb2 = (size_t)1 << (2 * P.log2_ctb);
-    P.off_sao = off; off = align_up(off + nctb * 3 * sizeof(SaoParams), 256);
-    P.off_u_size = off; off = align_up(off + nunits, 256);
-    P.off_u_flags = off; off = align_up(off + nunits, 256);
-    P.off_u_ipm = off; off = align_up(off + nunits, 256);
-    P.off_u_ipmc = off; off = align_up(off + nunits, 256);
-    P.off_u_qp = off; off = align_up(off + nunits, 256);
-    P.off_coeff[0] = off; off = align_up(off + nctb * ctb2 * 2, 256);
-    P.off_coeff[1] = off; off = align_up(off + nctb * ctb2 / 2, 256);
-    P.off_coeff[2] = off; off = align_up(off + nctb * ctb2 / 2, 256);
-    const int ctb = 1 << P.log2_ctb;
-    for (int c = 0; c < 3; c++) {
-      const size_t w = c ? (size_t)P.ctb_w * ctb / 2 : (size_t)P.ctb_w * ctb, h = c ? (size_t)P.ctb_h * ctb / 2 : (size_t)P.ctb_h * ctb;
-      P.rec_stride[c] = (uint32_t)align_up(w * es, 64);
-      P.off_rec[c] = off; off = align_up(off + (size_t)P.rec_stride[c] * (h + 1), 256);
-      const size_t ow = c ? P.out_cwidth : P.out_width, oh = c ? P.out_cheight : P.out_height;
-      P.out_stride[c] = (uint32_t)align_up(std::max<size_t>(ow, 1) * es, 64);
-      P.off_out[c] = off; off = align_up(off + (size_t)P.out_stride[c] * std::max<size_t>(oh, 1), 256);
-    }
-  }
-  b.arena_size = off;
-
-  // ---- stage + upload ----
+  std::string err;
+  std::vector<uint8_t> host;
+  int rc = layout_batch(b, n, data, sizes, max_pixels, host, err);
+  if (rc != HIPDEC_OK) return set_error(rc, "%s", err.c_str());
   HIPDEC_CHECK_HIP(hipMalloc((void**)&b.arena, b.arena_size));
-  std::vector<uint8_t> host(b.upload_size, 0);
-  memcpy(host.data() + b.off_pics, b.params.data(), sizeof(PicParams) * n);
-  Substream* subs = (Substream*)(host.data() + b.off_subs);
-  RowDesc* rows = (RowDesc*)(host.data() + b.off_rows);
-  uint32_t sub_base = 0, r = 0;
-  for (int i = 0; i < n; i++) {
-    const ParsedPicture& pp = b.pics[i];
-    const PicParams& P = b.params[i];
-    for (size_t k = 0; k < pp.subs.size(); k++) {
-      Substream s = pp.subs[k];
-      s.pic = (uint32_t)i;
-      if (s.dep_sub >= 0) s.dep_sub += (int32_t)sub_base;
-      subs[sub_base + k] = s;
-    }
-    sub_base += (uint32_t)pp.subs.size();
-    for (int y = 0; y < P.ctb_h; y++) { rows[r].pic = (uint32_t)i; rows[r].row = (uint32_t)y; r++; }
-    memcpy(host.data() + P.off_ctb_ts_to_rs, pp.ts_to_rs.data(), pp.ts_to_rs.size() * sizeof(uint16_t));
-    memcpy(host.data() + P.off_ctb_info, pp.ctb_info.data(), pp.ctb_info.size() * sizeof(CtbInfo));
-    memcpy(host.data() + P.off_slices, pp.slice_params.data(), pp.slice_params.size() * sizeof(SliceParams));
-    memcpy(host.data() + P.off_bitstream, data[i], sizes[i]);
-  }
   HIPDEC_CHECK_HIP(hipMemcpy(b.arena, host.data(), b.upload_size, hipMemcpyHostToDevice));
   b.ev.assign(5, nullptr);
   for (auto& e : b.ev) HIPDEC_CHECK_HIP(hipEventCreate(&e));
@@ -166,8 +51,7 @@ int launch_all(hipdec_batch& b, hipStream_t s)
 {
   const int n = (int)b.params.size();
   ParseArgs pa{(const PicParams*)(b.arena + b.off_pics), (const Substream*)(b.arena + b.off_subs), b.num_subs, b.arena,
-               (uint32_t*)(b.arena + b.off_progress), b.arena + b.off_ctx, (uint32_t*)(b.arena + b.off_ticket), (int32_t*)(b.arena + b.off_status),
-               getenv("HIPDEC_DEBUG_PARSE") ? atoi(getenv("HIPDEC_DEBUG_PARSE")) : 0};
+               (uint32_t*)(b.arena + b.off_progress), b.arena + b.off_ctx, (uint32_t*)(b.arena + b.off_ticket), (int32_t*)(b.arena + b.off_status)};
   ReconArgs ra{(const PicParams*)(b.arena + b.off_pics), (const RowDesc*)(b.arena + b.off_rows), b.num_rows, b.arena,
                (uint32_t*)(b.arena + b.off_row_progress), (uint32_t*)(b.arena + b.off_ticket) + 1, (int32_t*)(b.arena + b.off_status)};
   FilterArgs fa{(const PicParams*)(b.arena + b.off_pics), b.arena};

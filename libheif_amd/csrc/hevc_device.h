@@ -23,28 +23,7 @@
 
 namespace hipdec {
 
-enum : int {
-  CTX_SAO_MERGE = 0,
-  CTX_SAO_TYPE = 1,
-  CTX_SPLIT_CU = 2,
-  CTX_CU_TQ_BYPASS = 5,
-  CTX_PART_MODE = 6,
-  CTX_PREV_INTRA_LUMA = 7,
-  CTX_INTRA_CHROMA = 8,
-  CTX_SPLIT_TRANSFORM = 9,
-  CTX_CBF_LUMA = 12,
-  CTX_CBF_CHROMA = 14,
-  CTX_CU_QP_DELTA = 18,
-  CTX_TRANSFORM_SKIP = 20,
-  CTX_LAST_X = 22,
-  CTX_LAST_Y = 40,
-  CTX_CODED_SUB_BLOCK = 58,
-  CTX_SIG_COEFF = 62,
-  CTX_GREATER1 = 104,
-  CTX_GREATER2 = 128,
-  CTX_COUNT = 134,
-  CTX_STORE = 160  // bytes reserved per saved context table
-};
+enum : int { CTX_STORE = 192 };  // bytes per saved context table: 3 register groups x 64 lanes (parse_core.h)
 
 enum : uint8_t {
   UF_CBF_LUMA = 1, UF_CBF_CB = 2, UF_CBF_CR = 4, UF_BYPASS = 8, UF_PCM = 16, UF_VEDGE = 32, UF_HEDGE = 64, UF_TS_LUMA = 128
@@ -70,6 +49,7 @@ struct SaoParams {   // per CTB and colour component
   uint8_t type;      // 0 off, 1 band, 2 edge
   uint8_t band_or_class;
   int16_t offset[4]; // SaoOffsetVal[1..4]
+  uint16_t pad;      // 12 bytes = 3 dwords (the parse kernel keeps them in three register lanes)
 };
 
 struct PicParams {
@@ -134,6 +114,17 @@ enum : int32_t {
   DEV_ERR_BITSTREAM_END = 2,
   DEV_ERR_SYNTAX = 3,       // value out of range (last position, cu_qp_delta, ...)
   DEV_ERR_TIMEOUT = 4       // a dependency wait exceeded its bound
+};
+
+struct ParseArgs {
+  const PicParams* pics;
+  const Substream* subs;
+  uint32_t num_subs;
+  uint8_t* arena;
+  uint32_t* progress;   // per substream: CTBs completed
+  uint8_t* ctx_store;   // per substream: CTX_STORE bytes, contexts after the 2nd CTB (WPP)
+  uint32_t* ticket;
+  int32_t* status;
 };
 
 }  // namespace hipdec

@@ -5,17 +5,6 @@
 
 namespace hipdec {
 
-struct ParseArgs {
-  const PicParams* pics;
-  const Substream* subs;
-  uint32_t num_subs;
-  uint8_t* arena;
-  uint32_t* progress;   // per substream: CTBs completed
-  uint8_t* ctx_store;   // per substream: CTX_STORE bytes, contexts after the 2nd CTB (WPP)
-  uint32_t* ticket;
-  int32_t* status;
-  int32_t debug_level;  // HIPDEC_DEBUG_PARSE: early-exit points for fault isolation (0 = off)
-};
 
 struct ReconArgs {
   const PicParams* pics;

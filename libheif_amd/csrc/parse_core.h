@@ -1,0 +1,955 @@
+// parse_core.h — the CABAC entropy decoder + slice-data syntax parser, written as ONE wave-uniform
+// (scalar) instruction stream over a handful of lane-indexed registers.
+//
+// Stands in for libde265's slice-data parser behind de265_decode() (reference call site
+// libheif/plugins/decoder_libde265.cc:402).  Syntax and context selection per ITU-T H.265 7.3.8 /
+// 9.3 (intra slices).
+//
+// MI355X mapping (why the code looks the way it does)
+//   * CABAC is a serial dependency chain, so one 64-lane wavefront decodes one substream and the
+//     whole chain is kept on the SCALAR unit: arithmetic-decoder state (range / value / bit count /
+//     byte position) lives in SGPRs and every branch is a scalar branch.  All tables and all
+//     mutable state that a CPU decoder would keep in memory live in VGPRs used as 64-entry
+//     register files addressed with v_readlane / v_writelane (a few cycles) instead of LDS
+//     (~50 cycles per dependent access, microarch guide):
+//        - context variables: three VGPRs, one context per lane (groups A / B / C below)
+//        - rangeTabLps (4 bytes per pStateIdx lane), transIdxLps and the 8x8 diagonal scan
+//        - a 256-byte bitstream window + the prefetched next window (one coalesced 256-B load
+//          per 256 bytes of bitstream)
+//        - the CTB's per-4x4-unit maps (size, flags, intra modes, QP): four units per lane in
+//          z-scan order, so every CU / TU is a contiguous lane range that is filled with one
+//          masked vector move and published with one coalesced store per map
+//        - the previous CTB's maps (left neighbour), the row above's sizes, SAO parameters
+//   * the 64 lanes only do the data-parallel side jobs (context init, window loads, map fills,
+//     coefficient block flush, WPP context save / restore).
+//
+// The same source compiles for the device (parse_kernel.hip) and, with HIPDEC_HOST_EMU, as a
+// lane-emulating host build used ONLY by the CPU tests (tests/emu) to check the parser's logic
+// against the oracle without a GPU.  The emulation is never linked into libheifhip.so.
+#pragma once
+#include <stdint.h>
+#include "hevc_device.h"
+
+#if defined(HIPDEC_HOST_EMU)
+#include <string.h>
+#define PC_DEV static inline
+struct VReg { uint32_t v[64]; };
+#define PC_VEC_BEGIN for (int lane = 0; lane < 64; lane++) { (void)lane;
+#define PC_VEC_END }
+#define PC_L(r) ((r).v[lane])
+PC_DEV uint32_t pc_rdlane(const VReg& r, int l) { return r.v[l & 63]; }
+PC_DEV void pc_wrlane(VReg& r, int l, uint32_t x) { r.v[l & 63] = x; }
+PC_DEV uint32_t pc_uni(uint32_t x) { return x; }
+PC_DEV int pc_clz(uint32_t x) { return x ? __builtin_clz(x) : 32; }
+PC_DEV int pc_ffs(uint32_t x) { return __builtin_ffs((int)x); }
+#define PC_LDS_SYNC() do { } while (0)
+#define PC_CONST static const
+#else
+#include <hip/hip_runtime.h>
+#define PC_DEV __device__ __forceinline__
+typedef uint32_t VReg;
+#define PC_VEC_BEGIN { const int lane = (int)threadIdx.x; (void)lane;
+#define PC_VEC_END }
+#define PC_L(r) (r)
+PC_DEV uint32_t pc_rdlane(const VReg& r, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)r, l); }
+// (hipcc 7.2 exposes no writelane builtin; a compare + select on the lane id is two hazard-free VALU ops)
+PC_DEV void pc_wrlane(VReg& r, int l, uint32_t x) { r = ((int)threadIdx.x == l) ? x : r; }
+PC_DEV uint32_t pc_uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+PC_DEV int pc_clz(uint32_t x) { return __clz((int)x); }
+PC_DEV int pc_ffs(uint32_t x) { return __ffs((int)x); }
+#define PC_LDS_SYNC() __syncthreads()
+#define PC_CONST __constant__
+#endif
+
+namespace hipdec {
+namespace pcore {
+
+// ---- context variables: group (VGPR) and lane -------------------------------------------------
+// group A
+enum : int {
+  A_SAO_MERGE = 0, A_SAO_TYPE = 1, A_SPLIT_CU = 2 /*3*/, A_CU_TQ_BYPASS = 5, A_PART_MODE = 6, A_PREV_INTRA_LUMA = 7,
+  A_INTRA_CHROMA = 8, A_SPLIT_TRANSFORM = 9 /*3*/, A_CBF_LUMA = 12 /*2*/, A_CBF_CHROMA = 14 /*4*/, A_CU_QP_DELTA = 18 /*2*/,
+  A_TRANSFORM_SKIP = 20 /*2*/, A_LAST_X = 22 /*18*/, A_LAST_Y = 40 /*18*/, A_CODED_SUB_BLOCK = 58 /*4*/,
+  // group B: sig_coeff_flag 0..43 (42 used by version 1), greater2 44..49
+  B_SIG_COEFF = 0, B_GREATER2 = 44,
+  // group C: greater1 0..23
+  C_GREATER1 = 0
+};
+
+// initValue for slice_type I (9.3.2.2, tables 9-5 .. 9-37), laid out per group / lane
+PC_CONST uint8_t c_init[3][64] = {
+  {153, 200, 139, 141, 157, 154, 184, 184, 63, 153, 138, 138, 111, 141, 94, 138, 182, 154, 154, 154, 139, 139,
+   110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63,
+   110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63,
+   91, 171, 134, 141, 154, 154},
+  {111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107, 125, 141,
+   179, 153, 125, 140, 139, 182, 182, 152, 136, 152, 136, 153, 136, 139, 111, 136, 139, 111, 141, 111,
+   138, 153, 136, 167, 152, 152, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154},
+  {140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197,
+   154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+   154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154}};
+
+// lane p: rangeTabLps[p][0..3] packed little-endian (table 9-46)
+PC_CONST uint8_t c_range_lps[64 * 4] = {
+  128,176,208,240, 128,167,197,227, 128,158,187,216, 123,150,178,205, 116,142,169,195, 111,135,160,185,
+  105,128,152,175, 100,122,144,166,  95,116,137,158,  90,110,130,150,  85,104,123,142,  81, 99,117,135,
+   77, 94,111,128,  73, 89,105,122,  69, 85,100,116,  66, 80, 95,110,  62, 76, 90,104,  59, 72, 86, 99,
+   56, 69, 81, 94,  53, 65, 77, 89,  51, 62, 73, 85,  48, 59, 69, 80,  46, 56, 66, 76,  43, 53, 63, 72,
+   41, 50, 59, 69,  39, 48, 56, 65,  37, 45, 54, 62,  35, 43, 51, 59,  33, 41, 48, 56,  32, 39, 46, 53,
+   30, 37, 43, 50,  29, 35, 41, 48,  27, 33, 39, 45,  26, 31, 37, 43,  24, 30, 35, 41,  23, 28, 33, 39,
+   22, 27, 32, 37,  21, 26, 30, 35,  20, 24, 29, 33,  19, 23, 27, 31,  18, 22, 26, 30,  17, 21, 25, 28,
+   16, 20, 23, 27,  15, 19, 22, 25,  14, 18, 21, 24,  14, 17, 20, 23,  13, 16, 19, 22,  12, 15, 18, 21,
+   12, 14, 17, 20,  11, 14, 16, 19,  11, 13, 15, 18,  10, 12, 15, 17,  10, 12, 14, 16,   9, 11, 13, 15,
+    9, 11, 12, 14,   8, 10, 12, 14,   8,  9, 11, 13,   7,  9, 11, 12,   7,  9, 10, 12,   7,  8, 10, 11,
+    6,  8,  9, 11,   6,  7,  9, 10,   6,  7,  8,  9,   2,  2,  2,  2};
+// lane p: byte 0 transIdxLps[p] (table 9-47), byte 1 the p-th position of the up-right diagonal
+// scan of an 8x8 array (6.5.3) as x | y << 3
+PC_CONST uint8_t c_next_lps[64] = {
+   0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9,11,11,12, 13,13,15,15,16,16,18,18,19,19,21,21,22,22,23,24,
+  24,25,26,26,27,27,28,29,29,30,30,30,31,32,32,33, 33,33,34,34,35,35,35,36,36,36,37,37,37,38,38,63};
+PC_CONST uint8_t c_diag8[64] = {
+  0, 8, 1, 16, 9, 2, 24, 17, 10, 3, 32, 25, 18, 11, 4, 40, 33, 26, 19, 12, 5, 48, 41, 34, 27, 20, 13, 6, 56, 49, 42, 35,
+  28, 21, 14, 7, 57, 50, 43, 36, 29, 22, 15, 58, 51, 44, 37, 30, 23, 59, 52, 45, 38, 31, 60, 53, 46, 39, 61, 54, 47, 62, 55, 63};
+
+// 4x4 scans: nibble k = raster index (x | y << 2) of the k-th scan position
+#define PC_DIAG4 0xFBE7AD369C258140ULL
+#define PC_HORZ4 0xFEDCBA9876543210ULL
+#define PC_VERT4 0xFB73EA62D951C840ULL
+// sig_coeff_flag ctxIdxMap for 4x4 blocks (9.3.4.2.5), nibble r = ctxIdxMap[raster index r]
+#define PC_CTXIDXMAP4 0x8877886654325410ULL
+// sigCtx of 9.3.4.2.5 for larger blocks before the size / component offsets, two bits per raster
+// position r = x | y << 2 of the 4x4 sub-block, one word per prevCsbf (bit0 right, bit1 below)
+//   0: x+y == 0 ? 2 : x+y < 3 ? 1 : 0      1: y == 0 ? 2 : y == 1 ? 1 : 0
+//   2: x == 0 ? 2 : x == 1 ? 1 : 0          3: 2
+constexpr uint32_t pc_sigpat(int prev_csbf)
+{
+  uint32_t w = 0;
+  for (int r = 0; r < 16; r++) {
+    const int x = r & 3, y = r >> 2;
+    int v = 2;
+    if (prev_csbf == 0) v = (x + y == 0) ? 2 : (x + y < 3) ? 1 : 0;
+    else if (prev_csbf == 1) v = (y == 0) ? 2 : (y == 1) ? 1 : 0;
+    else if (prev_csbf == 2) v = (x == 0) ? 2 : (x == 1) ? 1 : 0;
+    else v = 2;
+    w |= (uint32_t)v << (2 * r);
+  }
+  return w;
+}
+constexpr uint32_t PC_SIGPAT0 = pc_sigpat(0), PC_SIGPAT1 = pc_sigpat(1), PC_SIGPAT2 = pc_sigpat(2), PC_SIGPAT3 = pc_sigpat(3);
+static_assert(PC_SIGPAT0 == 0x00010516u && PC_SIGPAT1 == 0x000055AAu && PC_SIGPAT2 == 0x06060606u && PC_SIGPAT3 == 0xAAAAAAAAu, "sig patterns");
+
+struct Lds {
+  alignas(16) int16_t coef[32 * 32];  // coefficient block being parsed (zero outside the parse of a block)
+};
+
+// everything here is wave-uniform unless it is a VReg
+struct PS {
+  // ---- arithmetic decoder
+  uint32_t range, value;
+  int32_t bits_needed;
+  uint32_t pos, end, win_base;
+  int32_t zeros;
+  int32_t err;
+  const uint8_t* bs;
+  // ---- lane-indexed register files
+  VReg ctxA, ctxB, ctxC;
+  VReg t_lps, t_next;
+  VReg win, win_next;
+  VReg m_size, m_flags, m_ipm, m_ipmc, m_qp;  // 4 units per lane, z-scan order
+  VReg p_size, p_ipm;                           // previous CTB (left neighbour)
+  VReg up_size;                                 // lane ux: size byte of the bottom unit row of the CTB above
+  VReg sao, sao_left;                           // lanes 0..8: 3 dwords per component (SaoParams)
+  // ---- picture constants (copied out of PicParams once)
+  int32_t width, height, log2_ctb, log2_min_cb, log2_min_tb, log2_max_tb, max_th_depth_intra;
+  int32_t chroma_format_idc, bit_depth_luma, bit_depth_chroma, log2_min_cu_qp_delta_size;
+  uint32_t tools;  // bit0 sign_data_hiding 1 transform_skip 2 cu_qp_delta 3 transquant_bypass
+  // ---- slice
+  int32_t slice_qp_y, deblock, sao_luma, sao_chroma;
+  // ---- CTB
+  int32_t x_ctb, y_ctb, ctb_avail;
+  // ---- QP
+  int32_t is_cu_qp_delta_coded, cu_qp_delta_val, qpy_pred, last_qp_y, cur_qp_y;
+  int32_t cu_tq_bypass;
+  Lds* L;
+};
+enum : uint32_t { TOOL_SDH = 1, TOOL_TS = 2, TOOL_CUQPD = 4, TOOL_TQBYPASS = 8 };
+
+PC_DEV uint32_t interleave4(uint32_t x, uint32_t y)  // z-index of unit (x,y), x,y < 16
+{
+  x = (x | (x << 2)) & 0x33; x = (x | (x << 1)) & 0x55;
+  y = (y | (y << 2)) & 0x33; y = (y | (y << 1)) & 0x55;
+  return x | (y << 1);
+}
+PC_DEV uint32_t compact1by1(uint32_t v)
+{
+  v &= 0x55555555u; v = (v | (v >> 1)) & 0x33333333u; v = (v | (v >> 2)) & 0x0f0f0f0fu; v = (v | (v >> 4)) & 0x00ff00ffu;
+  return v;
+}
+
+// ---- lane-indexed byte maps ---------------------------------------------------------------------
+PC_DEV uint32_t map_get(const VReg& m, int z) { return (pc_rdlane(m, z >> 2) >> ((z & 3) * 8)) & 255u; }
+// fills units [zb, zb + n) with byte b; n is 1 or a multiple of 4 with zb aligned to it
+PC_DEV void map_fill(VReg& m, int zb, int n, uint32_t b)
+{
+  if (n >= 4) {
+    const int l0 = zb >> 2, nl = n >> 2;
+    const uint32_t w = b * 0x01010101u;
+    PC_VEC_BEGIN
+      if ((uint32_t)(lane - l0) < (uint32_t)nl) PC_L(m) = w;
+    PC_VEC_END
+  } else {
+    const int sh = (zb & 3) * 8;
+    uint32_t w = pc_rdlane(m, zb >> 2);
+    w = (w & ~(255u << sh)) | (b << sh);
+    pc_wrlane(m, zb >> 2, w);
+  }
+}
+
+// ---- bitstream window + CABAC engine (9.3.4.3, scaled-window formulation) ---------------------
+PC_DEV void load_window(PS& s, uint32_t base)
+{
+  if (base == s.win_base + 256u) {
+    PC_VEC_BEGIN PC_L(s.win) = PC_L(s.win_next); PC_VEC_END
+  } else {
+    PC_VEC_BEGIN PC_L(s.win) = *(const uint32_t*)(s.bs + base + 4u * (uint32_t)lane); PC_VEC_END
+  }
+  PC_VEC_BEGIN PC_L(s.win_next) = *(const uint32_t*)(s.bs + base + 256u + 4u * (uint32_t)lane); PC_VEC_END
+  s.win_base = base;
+}
+PC_DEV uint32_t fetch_byte(PS& s, uint32_t pos)
+{
+  if ((pos & ~255u) != s.win_base) load_window(s, pos & ~255u);
+  return (pc_rdlane(s.win, (int)((pos >> 2) & 63u)) >> ((pos & 3u) * 8u)) & 255u;
+}
+PC_DEV uint32_t read_byte(PS& s)
+{
+  if (s.pos >= s.end) { s.pos++; if (s.pos > s.end + 8) s.err = DEV_ERR_BITSTREAM_END; return 0; }
+  uint32_t b = fetch_byte(s, s.pos++);
+  if (s.zeros >= 2 && b == 3 && s.pos < s.end) {  // emulation_prevention_three_byte
+    b = fetch_byte(s, s.pos++);
+    s.zeros = 0;
+  }
+  s.zeros = b == 0 ? s.zeros + 1 : 0;
+  return b;
+}
+PC_DEV void cabac_start(PS& s, uint32_t start, uint32_t end)
+{
+  s.pos = start; s.end = end; s.zeros = 0; s.win_base = 0xfffff000u;
+  s.range = 510; s.bits_needed = -8;
+  const uint32_t b0 = read_byte(s), b1 = read_byte(s);
+  s.value = (b0 << 8) | b1;
+}
+PC_DEV int decode_bin(PS& s, VReg& grp, int ctx_lane)
+{
+  uint32_t st = pc_rdlane(grp, ctx_lane);
+  uint32_t p_state = st >> 1;
+  const uint32_t lps = (pc_rdlane(s.t_lps, (int)p_state) >> ((s.range >> 3) & 24u)) & 255u;
+  s.range -= lps;
+  const uint32_t scaled = s.range << 7;
+  int bin;
+  if (s.value < scaled) {
+    bin = (int)(st & 1u);
+    if (p_state < 62) { st += 2; pc_wrlane(grp, ctx_lane, st); }
+    if (scaled < (256u << 7)) {
+      s.range = scaled >> 6;
+      s.value <<= 1;
+      if (++s.bits_needed == 0) { s.bits_needed = -8; s.value += read_byte(s); }
+    }
+  } else {
+    uint32_t mps = st & 1u;
+    bin = (int)(mps ^ 1u);
+    const int num_bits = pc_clz(lps) - 23;
+    s.value = (s.value - scaled) << num_bits;
+    s.range = lps << num_bits;
+    if (p_state == 0) mps ^= 1u;
+    p_state = pc_rdlane(s.t_next, (int)p_state) & 63u;
+    pc_wrlane(grp, ctx_lane, (p_state << 1) | mps);
+    s.bits_needed += num_bits;
+    if (s.bits_needed >= 0) { s.value += read_byte(s) << s.bits_needed; s.bits_needed -= 8; }
+  }
+  return bin;
+}
+PC_DEV int decode_bypass(PS& s)
+{
+  s.value <<= 1;
+  if (++s.bits_needed >= 0) { s.bits_needed = -8; s.value += read_byte(s); }
+  const uint32_t scaled = s.range << 7;
+  if (s.value >= scaled) { s.value -= scaled; return 1; }
+  return 0;
+}
+PC_DEV int decode_bypass_bits(PS& s, int n)
+{
+  int v = 0;
+  for (int i = 0; i < n; i++) v = (v << 1) | decode_bypass(s);
+  return v;
+}
+PC_DEV int decode_terminate(PS& s)
+{
+  s.range -= 2;
+  const uint32_t scaled = s.range << 7;
+  if (s.value >= scaled) return 1;
+  if (scaled < (256u << 7)) {
+    s.range = scaled >> 6;
+    s.value <<= 1;
+    if (++s.bits_needed == 0) { s.bits_needed = -8; s.value += read_byte(s); }
+  }
+  return 0;
+}
+
+// ---- context initialisation 9.3.2.2 (lane-parallel: one context per lane and group) ------------
+PC_DEV void init_contexts(PS& s)
+{
+  const int qp = s.slice_qp_y < 0 ? 0 : (s.slice_qp_y > 51 ? 51 : s.slice_qp_y);
+  PC_VEC_BEGIN
+    for (int g = 0; g < 3; g++) {
+      const int init = c_init[g][lane];
+      const int m = (init >> 4) * 5 - 45, n = ((init & 15) << 3) - 16;
+      int pre = ((m * qp) >> 4) + n;
+      pre = pre < 1 ? 1 : (pre > 126 ? 126 : pre);
+      const int mps = pre <= 63 ? 0 : 1;
+      const int p_state = mps ? pre - 64 : 63 - pre;
+      const uint32_t v = (uint32_t)((p_state << 1) | mps);
+      if (g == 0) PC_L(s.ctxA) = v; else if (g == 1) PC_L(s.ctxB) = v; else PC_L(s.ctxC) = v;
+    }
+  PC_VEC_END
+}
+PC_DEV void load_tables(PS& s)
+{
+  PC_VEC_BEGIN
+    PC_L(s.t_lps) = (uint32_t)c_range_lps[lane * 4] | ((uint32_t)c_range_lps[lane * 4 + 1] << 8) | ((uint32_t)c_range_lps[lane * 4 + 2] << 16) |
+                    ((uint32_t)c_range_lps[lane * 4 + 3] << 24);
+    PC_L(s.t_next) = (uint32_t)c_next_lps[lane] | ((uint32_t)c_diag8[lane] << 8);
+  PC_VEC_END
+}
+
+// ---- neighbour helpers over the z-ordered maps ---------------------------------------------------
+// log2 CB size of the unit left of / above unit (ux, uy) of the current CTB, or 0 if unavailable
+PC_DEV int left_cb_log2(PS& s, int ux, int uy)
+{
+  if (ux > 0) return (int)(map_get(s.m_size, (int)interleave4((uint32_t)ux - 1, (uint32_t)uy)) >> 4);
+  if (s.ctb_avail & AV_LEFT) return (int)(map_get(s.p_size, (int)interleave4((uint32_t)(1 << (s.log2_ctb - 2)) - 1, (uint32_t)uy)) >> 4);
+  return 0;
+}
+PC_DEV int up_cb_log2(PS& s, int ux, int uy)
+{
+  if (uy > 0) return (int)(map_get(s.m_size, (int)interleave4((uint32_t)ux, (uint32_t)uy - 1)) >> 4);
+  if (s.ctb_avail & AV_UP) return (int)((pc_rdlane(s.up_size, ux) & 255u) >> 4);
+  return 0;
+}
+// 8.6.1 (qPY_A / qPY_B only count inside the current CTB)
+PC_DEV void derive_qp_pred(PS& s, int ux, int uy)
+{
+  const int prev = s.last_qp_y;
+  int a = prev, b = prev;
+  if (ux > 0) a = (int8_t)map_get(s.m_qp, (int)interleave4((uint32_t)ux - 1, (uint32_t)uy));
+  if (uy > 0) b = (int8_t)map_get(s.m_qp, (int)interleave4((uint32_t)ux, (uint32_t)uy - 1));
+  s.qpy_pred = (a + b + 1) >> 1;
+}
+PC_DEV void set_qp_y(PS& s)
+{
+  const int off = 6 * (s.bit_depth_luma - 8);
+  s.cur_qp_y = ((s.qpy_pred + s.cu_qp_delta_val + 52 + 2 * off) % (52 + off)) - off;
+}
+
+// ---- coefficient block staging (LDS block -> TU-contiguous int16 in HBM) -------------------------
+struct alignas(16) Coef8 { int16_t v[8]; };
+struct alignas(8) Coef4 { int16_t v[4]; };
+PC_DEV void flush_coef(PS& s, int16_t* dst, int n2)
+{
+  PC_LDS_SYNC();
+  PC_VEC_BEGIN
+    if (n2 >= 64) {
+      for (int i = lane * 8; i < n2; i += 512) {
+        *(Coef8*)&dst[i] = *(const Coef8*)&s.L->coef[i];
+        *(Coef8*)&s.L->coef[i] = Coef8{{0, 0, 0, 0, 0, 0, 0, 0}};
+      }
+    } else if (lane < 4) {  // 4x4: 32 bytes
+      *(Coef4*)&dst[lane * 4] = *(const Coef4*)&s.L->coef[lane * 4];
+      *(Coef4*)&s.L->coef[lane * 4] = Coef4{{0, 0, 0, 0}};
+    }
+  PC_VEC_END
+  PC_LDS_SYNC();
+}
+
+// ---- 7.3.8.11 residual_coding ----------------------------------------------------------------
+PC_DEV int decode_remaining(PS& s, int rice)
+{
+  int prefix = 0;
+  while (prefix < 32 && decode_bypass(s)) prefix++;
+  if (prefix >= 32) { s.err = DEV_ERR_SYNTAX; return 0; }
+  if (prefix <= 3) return (prefix << rice) + decode_bypass_bits(s, rice);
+  return (((1 << (prefix - 3)) + 3 - 1) << rice) + decode_bypass_bits(s, prefix - 3 + rice);
+}
+// scan of sub-blocks: lg = log2 of the sub-block grid width (0..3)
+PC_DEV void scan_sb(PS& s, int lg, int scan_idx, int i, int& xs, int& ys)
+{
+  if (lg == 0) { xs = 0; ys = 0; }
+  else if (lg == 1) {
+    if (scan_idx == 1) { xs = i & 1; ys = i >> 1; }  // horizontal
+    else { xs = i >> 1; ys = i & 1; }                // diagonal and vertical coincide for 2x2
+  } else if (lg == 2) { const uint32_t v = (uint32_t)(PC_DIAG4 >> (i * 4)) & 15u; xs = (int)(v & 3u); ys = (int)(v >> 2); }
+  else { const uint32_t v = (pc_rdlane(s.t_next, i) >> 8) & 255u; xs = (int)(v & 7u); ys = (int)(v >> 3); }
+}
+
+// returns transform_skip_flag; coefficients go to L->coef (raster, n x n)
+PC_DEV int residual_coding(PS& s, int log2n, int c_idx, int pred_mode)
+{
+  const int n = 1 << log2n;
+  int ts = 0;
+  if ((s.tools & TOOL_TS) && !s.cu_tq_bypass && log2n <= 2) ts = decode_bin(s, s.ctxA, A_TRANSFORM_SKIP + (c_idx ? 1 : 0));
+  int ctx_offset, ctx_shift;
+  if (c_idx == 0) { ctx_offset = 3 * (log2n - 2) + ((log2n - 1) >> 2); ctx_shift = (log2n + 1) >> 2; }
+  else { ctx_offset = 15; ctx_shift = log2n - 2; }
+  const int c_max = (log2n << 1) - 1;
+  int px = 0, py = 0;
+  while (px < c_max && decode_bin(s, s.ctxA, A_LAST_X + ctx_offset + (px >> ctx_shift))) px++;
+  while (py < c_max && decode_bin(s, s.ctxA, A_LAST_Y + ctx_offset + (py >> ctx_shift))) py++;
+  int last_x = px, last_y = py;
+  if (px > 3) last_x = (1 << ((px >> 1) - 1)) * (2 + (px & 1)) + decode_bypass_bits(s, (px >> 1) - 1);
+  if (py > 3) last_y = (1 << ((py >> 1) - 1)) * (2 + (py & 1)) + decode_bypass_bits(s, (py >> 1) - 1);
+  int scan_idx = 0;
+  if (log2n == 2 || (log2n == 3 && c_idx == 0)) {
+    if (pred_mode >= 6 && pred_mode <= 14) scan_idx = 2;
+    else if (pred_mode >= 22 && pred_mode <= 30) scan_idx = 1;
+  }
+  if (scan_idx == 2) { const int t = last_x; last_x = last_y; last_y = t; }
+  if (last_x >= n || last_y >= n) { s.err = DEV_ERR_SYNTAX; return ts; }
+  const uint64_t scan4 = scan_idx == 0 ? PC_DIAG4 : (scan_idx == 1 ? PC_HORZ4 : PC_VERT4);
+
+  // locate the last position in scan order: sub-block (last_x>>2, last_y>>2), position inside it
+  const int lg = log2n - 2;  // log2 of the sub-block grid width
+  int last_sb = 0, last_pos = 0;
+  {
+    const int xs_t = last_x >> 2, ys_t = last_y >> 2;
+    const uint32_t r_t = (uint32_t)((last_x & 3) | ((last_y & 3) << 2));
+    const int nsb = 1 << (2 * lg);
+    for (int i = 0; i < nsb; i++) { int xs, ys; scan_sb(s, lg, scan_idx, i, xs, ys); if (xs == xs_t && ys == ys_t) { last_sb = i; break; } }
+    for (int k = 0; k < 16; k++) if (((uint32_t)(scan4 >> (k * 4)) & 15u) == r_t) { last_pos = k; break; }
+  }
+  uint64_t csbf = 0;  // coded_sub_block_flag bitmap, bit (ys*8 + xs)
+  const int sbw = 1 << lg;
+  int g1_carry = 1, first_sb_with_g1 = 1;
+  const int sdh = (s.tools & TOOL_SDH) != 0;
+  for (int i = last_sb; i >= 0; i--) {
+    int xs, ys;
+    scan_sb(s, lg, scan_idx, i, xs, ys);
+    int infer_dc = 0, coded;
+    const int right = (xs < sbw - 1) ? (int)((csbf >> (ys * 8 + xs + 1)) & 1) : 0;
+    const int below = (ys < sbw - 1) ? (int)((csbf >> ((ys + 1) * 8 + xs)) & 1) : 0;
+    if (i < last_sb && i > 0) {
+      coded = decode_bin(s, s.ctxA, A_CODED_SUB_BLOCK + ((right | below) ? 1 : 0) + (c_idx ? 2 : 0));
+      infer_dc = 1;
+    } else coded = 1;
+    if (!coded) continue;
+    csbf |= 1ull << (ys * 8 + xs);
+    // per-sub-block sig_coeff_flag context selection: pattern word + constant offset
+    uint32_t pat;
+    int sig_off;
+    if (log2n == 2) { pat = 0; sig_off = c_idx ? 27 : 0; }
+    else {
+      const int prev_csbf = right | (below << 1);
+      pat = prev_csbf == 0 ? PC_SIGPAT0 : (prev_csbf == 1 ? PC_SIGPAT1 : (prev_csbf == 2 ? PC_SIGPAT2 : PC_SIGPAT3));
+      if (c_idx == 0) sig_off = ((xs | ys) ? 3 : 0) + ((log2n == 3) ? (scan_idx == 0 ? 9 : 15) : 21);
+      else sig_off = 27 + ((log2n == 3) ? 9 : 12);
+    }
+    uint32_t sig = 0;  // bit k = sig_coeff_flag at scan position k
+    int n_start = 15;
+    if (i == last_sb) { sig = 1u << last_pos; n_start = last_pos - 1; }
+    for (int k = n_start; k >= 0; k--) {
+      if (k > 0 || !infer_dc) {
+        const uint32_t r = (uint32_t)(scan4 >> (k * 4)) & 15u;
+        int ctx;
+        if (log2n == 2) ctx = sig_off + (int)((PC_CTXIDXMAP4 >> (r * 4)) & 15u);
+        else if ((xs | ys) == 0 && r == 0) ctx = c_idx ? 27 : 0;
+        else ctx = sig_off + (int)((pat >> (r * 2)) & 3u);
+        if (decode_bin(s, s.ctxB, B_SIG_COEFF + ctx)) { sig |= 1u << k; infer_dc = 0; }
+      } else sig |= 1u;  // k == 0 inferred significant
+    }
+    if (!sig) continue;
+    // greater1 / greater2 flags
+    uint32_t g1 = 0;
+    int ctx_set = (i == 0 || c_idx > 0) ? 0 : 2;
+    if (!first_sb_with_g1 && g1_carry == 0) ctx_set++;
+    first_sb_with_g1 = 0;
+    int g1_ctx = 1, num_g1 = 0, last_g1_pos = -1;
+    const int last_sig_pos = 31 - pc_clz(sig), first_sig_pos = pc_ffs(sig) - 1;
+    const int g1_base = C_GREATER1 + ctx_set * 4 + (c_idx ? 16 : 0);
+    {
+      uint32_t rem = sig;
+      while (rem && num_g1 < 8) {
+        const int k = 31 - pc_clz(rem);
+        rem &= ~(1u << k);
+        if (decode_bin(s, s.ctxC, g1_base + (g1_ctx > 3 ? 3 : g1_ctx))) { g1 |= 1u << k; g1_ctx = 0; if (last_g1_pos < 0) last_g1_pos = k; }
+        else if (g1_ctx > 0) g1_ctx++;
+        num_g1++;
+      }
+    }
+    g1_carry = g1_ctx;
+    const int sign_hidden = s.cu_tq_bypass ? 0 : (sdh && (last_sig_pos - first_sig_pos > 3));
+    uint32_t g2 = 0;
+    if (last_g1_pos >= 0 && decode_bin(s, s.ctxB, B_GREATER2 + ctx_set + (c_idx ? 4 : 0))) g2 = 1u << last_g1_pos;
+    uint32_t signs = 0;
+    {
+      uint32_t rem = sig;
+      if (sign_hidden) rem &= ~(1u << first_sig_pos);
+      while (rem) {
+        const int k = 31 - pc_clz(rem);
+        rem &= ~(1u << k);
+        if (decode_bypass(s)) signs |= 1u << k;
+      }
+    }
+    int num_sig = 0, sum_abs = 0, rice = 0;
+    const int sb_base = (ys << 2) * n + (xs << 2);
+    {
+      uint32_t rem = sig;
+      while (rem) {
+        const int k = 31 - pc_clz(rem);
+        rem &= ~(1u << k);
+        const int base = 1 + (int)((g1 >> k) & 1u) + (int)((g2 >> k) & 1u);
+        int abs_level = base;
+        if (base == ((num_sig < 8) ? ((k == last_g1_pos) ? 3 : 2) : 1)) {
+          abs_level += decode_remaining(s, rice);
+          if (abs_level > 3 * (1 << rice)) rice = rice < 4 ? rice + 1 : 4;
+        }
+        int v = ((signs >> k) & 1u) ? -abs_level : abs_level;
+        if (sign_hidden) {
+          sum_abs += abs_level;
+          if (k == first_sig_pos && (sum_abs & 1)) v = -v;
+        }
+        if (v > 32767 || v < -32768) { s.err = DEV_ERR_SYNTAX; v = 0; }
+        const uint32_t r = (uint32_t)(scan4 >> (k * 4)) & 15u;
+        s.L->coef[sb_base + (int)(r >> 2) * n + (int)(r & 3u)] = (int16_t)v;
+        num_sig++;
+      }
+    }
+  }
+  return ts;
+}
+
+// ---- 7.3.8.14 cu_qp_delta -----------------------------------------------------------------------
+PC_DEV void parse_cu_qp_delta(PS& s)
+{
+  int v = 0;
+  if (decode_bin(s, s.ctxA, A_CU_QP_DELTA)) {
+    v = 1;
+    while (v < 5 && decode_bin(s, s.ctxA, A_CU_QP_DELTA + 1)) v++;
+    if (v == 5) {
+      int k = 0;
+      while (decode_bypass(s)) { v += 1 << k; k++; if (k > 16) { s.err = DEV_ERR_SYNTAX; break; } }
+      while (k-- > 0) v += decode_bypass(s) << k;
+    }
+  }
+  const int sign = v ? decode_bypass(s) : 0;
+  s.is_cu_qp_delta_coded = 1;
+  s.cu_qp_delta_val = sign ? -v : v;
+  const int off = 6 * (s.bit_depth_luma - 8);
+  if (s.cu_qp_delta_val < -(26 + off / 2) || s.cu_qp_delta_val > 25 + off / 2) s.err = DEV_ERR_SYNTAX;
+  set_qp_y(s);
+}
+
+// ---- 7.3.8.5 coding_unit + 7.3.8.8 transform_tree, stackless over the z-ordered unit index -------
+PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/, int log2cb, int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr)
+{
+  const int ux0 = (int)compact1by1((uint32_t)zb), uy0 = (int)compact1by1((uint32_t)zb >> 1);
+  const int n_units = 1 << (2 * (log2cb - 2));
+  s.cu_tq_bypass = 0;
+  if (s.tools & TOOL_TQBYPASS) s.cu_tq_bypass = decode_bin(s, s.ctxA, A_CU_TQ_BYPASS);
+  int part_nxn = 0;
+  if (log2cb == s.log2_min_cb) part_nxn = decode_bin(s, s.ctxA, A_PART_MODE) ? 0 : 1;
+  if (part_nxn && log2cb == 3 && s.log2_min_tb > 2) { s.err = DEV_ERR_SYNTAX; part_nxn = 0; }
+  set_qp_y(s);
+  // CU-level map fill (contiguous in z-order)
+  map_fill(s.m_size, zb, n_units, (uint32_t)(log2cb << 4));
+  map_fill(s.m_flags, zb, n_units, (uint32_t)(s.cu_tq_bypass ? UF_BYPASS : 0));
+  map_fill(s.m_ipm, zb, n_units, 1u);
+  // intra prediction modes 7.3.8.5 / 8.4.2
+  const int n_part = part_nxn ? 4 : 1;
+  const int pu_units = n_units / n_part;                    // units per PU (contiguous quadrant)
+  const int pu_w = 1 << (log2cb - 2 - (part_nxn ? 1 : 0));  // PU width in units
+  const int uw = 1 << (s.log2_ctb - 2);
+  uint32_t prev_flags = 0;
+  for (int k = 0; k < n_part; k++) prev_flags |= (uint32_t)decode_bin(s, s.ctxA, A_PREV_INTRA_LUMA) << k;
+  for (int k = 0; k < n_part; k++) {
+    int mpm_idx = 0, rem = 0;
+    if ((prev_flags >> k) & 1u) { if (decode_bypass(s)) mpm_idx = decode_bypass(s) ? 2 : 1; }
+    else rem = decode_bypass_bits(s, 5);
+    const int ux = ux0 + (k & 1) * pu_w, uy = uy0 + (k >> 1) * pu_w;
+    int cand_a = 1, cand_b = 1;
+    if (ux > 0) cand_a = (int)(map_get(s.m_ipm, (int)interleave4((uint32_t)ux - 1, (uint32_t)uy)) & 63u);
+    else if (s.ctb_avail & AV_LEFT) cand_a = (int)(map_get(s.p_ipm, (int)interleave4((uint32_t)uw - 1, (uint32_t)uy)) & 63u);
+    if (uy > 0) cand_b = (int)(map_get(s.m_ipm, (int)interleave4((uint32_t)ux, (uint32_t)uy - 1)) & 63u);  // above CTB row: INTRA_DC (8.4.2)
+    int c0, c1, c2;
+    if (cand_a == cand_b) {
+      if (cand_a < 2) { c0 = 0; c1 = 1; c2 = 26; }
+      else { c0 = cand_a; c1 = 2 + ((cand_a + 29) & 31); c2 = 2 + ((cand_a - 2 + 1) & 31); }
+    } else {
+      c0 = cand_a; c1 = cand_b;
+      if (cand_a != 0 && cand_b != 0) c2 = 0; else if (cand_a != 1 && cand_b != 1) c2 = 1; else c2 = 26;
+    }
+    int mode;
+    if ((prev_flags >> k) & 1u) mode = mpm_idx == 0 ? c0 : (mpm_idx == 1 ? c1 : c2);
+    else {
+      int t;
+      if (c0 > c1) { t = c0; c0 = c1; c1 = t; }
+      if (c0 > c2) { t = c0; c0 = c2; c2 = t; }
+      if (c1 > c2) { t = c1; c1 = c2; c2 = t; }
+      mode = rem;
+      if (mode >= c0) mode++;
+      if (mode >= c1) mode++;
+      if (mode >= c2) mode++;
+    }
+    map_fill(s.m_ipm, zb + k * pu_units, pu_units, (uint32_t)mode);
+  }
+  int chroma_mode = 1;
+  if (s.chroma_format_idc) {
+    int icpm = 4;
+    if (decode_bin(s, s.ctxA, A_INTRA_CHROMA)) icpm = decode_bypass_bits(s, 2);
+    const int lm = (int)(map_get(s.m_ipm, zb) & 63u);
+    if (icpm == 4) chroma_mode = lm;
+    else { const int m = icpm == 0 ? 0 : icpm == 1 ? 26 : icpm == 2 ? 10 : 1; chroma_mode = (m == lm) ? 34 : m; }
+  }
+  map_fill(s.m_ipmc, zb, n_units, (uint32_t)chroma_mode);
+
+  // ---- transform tree ----
+  const int max_trafo_depth = s.max_th_depth_intra + part_nxn;
+  uint32_t cbf_cb_bits = 0, cbf_cr_bits = 0;  // bit d = cbf at trafoDepth d along the current path
+  int q = 0;
+  while (q < n_units && !s.err) {
+    int t;  // log2 size of the node that starts at q
+    if (q == 0) t = log2cb; else { t = 2 + ((pc_ffs((uint32_t)q) - 1) >> 1); if (t > log2cb) t = log2cb; }
+    for (;;) {
+      const int depth = log2cb - t;
+      int split;
+      if (t <= s.log2_max_tb && t > s.log2_min_tb && depth < max_trafo_depth && !(part_nxn && depth == 0))
+        split = decode_bin(s, s.ctxA, A_SPLIT_TRANSFORM + 5 - t);
+      else split = (t > s.log2_max_tb || (part_nxn && depth == 0)) ? 1 : 0;
+      if (s.chroma_format_idc) {
+        const uint32_t bit = 1u << depth, pbit = depth ? (1u << (depth - 1)) : 0;
+        if (t > 2) {
+          int cb = 0, cr = 0;
+          if (depth == 0 || (cbf_cb_bits & pbit)) cb = decode_bin(s, s.ctxA, A_CBF_CHROMA + depth);
+          if (depth == 0 || (cbf_cr_bits & pbit)) cr = decode_bin(s, s.ctxA, A_CBF_CHROMA + depth);
+          cbf_cb_bits = (cbf_cb_bits & ~bit) | (cb ? bit : 0);
+          cbf_cr_bits = (cbf_cr_bits & ~bit) | (cr ? bit : 0);
+        } else {  // 4x4 luma: inherits the parent's flags (7.4.9.8)
+          cbf_cb_bits = (cbf_cb_bits & ~bit) | ((cbf_cb_bits & pbit) ? bit : 0);
+          cbf_cr_bits = (cbf_cr_bits & ~bit) | ((cbf_cr_bits & pbit) ? bit : 0);
+        }
+      }
+      if (!split) break;
+      t--;
+    }
+    // leaf transform unit at unit index zb + q, size 1 << t
+    const int depth = log2cb - t;
+    const int zu = zb + q;
+    const int tu_units = 1 << (2 * (t - 2));
+    const int cbf_luma = decode_bin(s, s.ctxA, A_CBF_LUMA + (depth == 0 ? 1 : 0));
+    const int cbf_cb = (int)((cbf_cb_bits >> depth) & 1u), cbf_cr = (int)((cbf_cr_bits >> depth) & 1u);
+    if ((cbf_luma | cbf_cb | cbf_cr) && (s.tools & TOOL_CUQPD) && !s.is_cu_qp_delta_coded) parse_cu_qp_delta(s);
+    const int luma_mode = (int)(map_get(s.m_ipm, zu) & 63u);
+    int ts_y = 0, ts_cb = 0, ts_cr = 0;
+    if (cbf_luma) { ts_y = residual_coding(s, t, 0, luma_mode); flush_coef(s, coef_y + zu * 16, 1 << (2 * t)); }
+    int do_chroma = 0, zc = zu, tc = t - 1;
+    if (s.chroma_format_idc) {
+      if (t > 2) do_chroma = 1;
+      else if ((q & 3) == 3) { do_chroma = 1; zc = zb + (q & ~3); tc = 2; }
+    }
+    if (do_chroma) {
+      if (cbf_cb) { ts_cb = residual_coding(s, tc, 1, chroma_mode); flush_coef(s, coef_cb + zc * 4, 1 << (2 * tc)); }
+      if (cbf_cr) { ts_cr = residual_coding(s, tc, 2, chroma_mode); flush_coef(s, coef_cr + zc * 4, 1 << (2 * tc)); }
+    }
+    // TU-level map fill: size, cbf, transform-skip, deblocking edges (8.7.2.2 / 8.7.2.3)
+    {
+      const int tux0 = (int)compact1by1((uint32_t)zu), tuy0 = (int)compact1by1((uint32_t)zu >> 1);
+      const int edge_l = s.deblock && (tux0 > 0 || (s.ctb_avail & AV_EDGE_LEFT));
+      const int edge_t = s.deblock && (tuy0 > 0 || (s.ctb_avail & AV_EDGE_UP));
+      const uint32_t fl = (uint32_t)((cbf_luma ? UF_CBF_LUMA : 0) | ((do_chroma && cbf_cb) ? UF_CBF_CB : 0) | ((do_chroma && cbf_cr) ? UF_CBF_CR : 0) |
+                                     (s.cu_tq_bypass ? UF_BYPASS : 0) | (ts_y ? UF_TS_LUMA : 0));
+      const uint32_t ipm = (uint32_t)(luma_mode | (ts_cb ? 64 : 0) | (ts_cr ? 128 : 0));
+      const uint32_t szb = (uint32_t)((log2cb << 4) | t);
+      const uint32_t ve = edge_l ? UF_VEDGE : 0u, he = edge_t ? UF_HEDGE : 0u;
+      if (tu_units >= 4) {
+        const int l0 = zu >> 2, nl = tu_units >> 2;
+        PC_VEC_BEGIN
+          const uint32_t rel = (uint32_t)(lane - l0);
+          if (rel < (uint32_t)nl) {
+            uint32_t wf = 0;
+            for (int k = 0; k < 4; k++) {
+              const uint32_t i = rel * 4u + (uint32_t)k;   // unit index inside the TU, z-order
+              uint32_t f = fl;
+              if ((i & 0x55555555u) == 0) f |= ve;         // x == 0
+              if ((i & 0xAAAAAAAAu) == 0) f |= he;         // y == 0
+              wf |= f << (8 * k);
+            }
+            PC_L(s.m_flags) = wf;
+            PC_L(s.m_size) = szb * 0x01010101u;
+            PC_L(s.m_ipm) = ipm * 0x01010101u;
+          }
+        PC_VEC_END
+      } else {
+        map_fill(s.m_flags, zu, 1, fl | ve | he);
+        map_fill(s.m_size, zu, 1, szb);
+        map_fill(s.m_ipm, zu, 1, ipm);
+      }
+    }
+    q += tu_units;
+  }
+  set_qp_y(s);
+  map_fill(s.m_qp, zb, n_units, (uint32_t)(uint8_t)(int8_t)s.cur_qp_y);
+  s.last_qp_y = s.cur_qp_y;
+}
+
+// ---- 7.3.8.3 sao: parameters are kept in lanes 0..8 of s.sao as SaoParams dwords -----------------
+//   dword 3c+0: type | band_or_class << 8 | offset[0] << 16     3c+1: offset[1] | offset[2] << 16     3c+2: offset[3]
+PC_DEV void parse_sao(PS& s, const uint32_t* sao_up /*global, CTB above*/, int allow_left, int allow_up)
+{
+  int merge_left = 0, merge_up = 0;
+  if (allow_left) merge_left = decode_bin(s, s.ctxA, A_SAO_MERGE);
+  if (allow_up && !merge_left) merge_up = decode_bin(s, s.ctxA, A_SAO_MERGE);
+  const int ncomp = s.chroma_format_idc ? 3 : 1;
+  if (merge_left) { PC_VEC_BEGIN PC_L(s.sao) = PC_L(s.sao_left); PC_VEC_END return; }
+  if (merge_up) { PC_VEC_BEGIN PC_L(s.sao) = lane < 9 ? sao_up[lane] : 0u; PC_VEC_END return; }
+  PC_VEC_BEGIN PC_L(s.sao) = 0u; PC_VEC_END
+  int type1 = 0, cls1 = 0;
+  for (int c = 0; c < ncomp; c++) {
+    const int on = c == 0 ? s.sao_luma : s.sao_chroma;
+    if (!on) continue;
+    int type;
+    if (c == 2) type = type1;
+    else { type = 0; if (decode_bin(s, s.ctxA, A_SAO_TYPE)) type = decode_bypass(s) ? 2 : 1; }
+    if (c == 1) type1 = type;
+    if (!type) continue;
+    const int bd = c ? s.bit_depth_chroma : s.bit_depth_luma;
+    const int c_max = (1 << ((bd < 10 ? bd : 10) - 5)) - 1;
+    int a[4], sg[4] = {0, 0, 1, 1};
+    for (int i = 0; i < 4; i++) { int v = 0; while (v < c_max && decode_bypass(s)) v++; a[i] = v; }
+    int cls;
+    if (type == 1) {
+      for (int i = 0; i < 4; i++) sg[i] = a[i] ? decode_bypass(s) : 0;
+      cls = decode_bypass_bits(s, 5);
+    } else {
+      if (c == 2) cls = cls1; else cls = decode_bypass_bits(s, 2);
+    }
+    if (c == 1) cls1 = cls;
+    const int sh = bd - (bd < 10 ? bd : 10);
+    uint32_t o[4];
+    for (int i = 0; i < 4; i++) o[i] = (uint32_t)(uint16_t)(int16_t)((sg[i] ? -a[i] : a[i]) << sh);
+    pc_wrlane(s.sao, 3 * c + 0, (uint32_t)type | ((uint32_t)cls << 8) | (o[0] << 16));
+    pc_wrlane(s.sao, 3 * c + 1, o[1] | (o[2] << 16));
+    pc_wrlane(s.sao, 3 * c + 2, o[3]);
+  }
+}
+
+// ---- platform glue for the cross-wave protocol ----------------------------------------------------
+#if defined(HIPDEC_HOST_EMU)
+// the emulation runs substreams one after the other in order, so a dependency is always satisfied
+PC_DEV int pc_wait_progress(const uint32_t* word, uint32_t need, const int32_t*) { return *word >= need ? 0 : DEV_ERR_TIMEOUT; }
+PC_DEV void pc_publish(uint32_t* word, uint32_t v) { *word = v; }
+PC_DEV void pc_report(int32_t* status, int32_t code) { if (*status == 0) *status = code; }
+#else
+PC_DEV int pc_wait_progress(const uint32_t* word, uint32_t need, const int32_t* status)
+{
+  // bounded spin: relaxed agent-scope poll + ONE acquire (cdna guide, Guideline 16)
+  int err = 0;
+  uint32_t spins = 0;
+  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > (1u << 24) || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { err = DEV_ERR_TIMEOUT; break; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return err;
+}
+PC_DEV void pc_publish(uint32_t* word, uint32_t v)
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0) __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+PC_DEV void pc_report(int32_t* status, int32_t code) { if (threadIdx.x == 0) atomicCAS((int*)status, 0, code); }
+#endif
+
+PC_DEV uint32_t uload32(const void* p) { return pc_uni(*(const uint32_t*)p); }
+PC_DEV uint64_t uload64(const void* p) { return (uint64_t)uload32(p) | ((uint64_t)uload32((const uint8_t*)p + 4) << 32); }
+
+// One CABAC substream (slice segment / tile / WPP row), start to finish.
+PC_DEV void parse_substream(const ParseArgs& A, uint32_t sub_idx, Lds* lds)
+{
+  PS s;
+  const Substream* subp = A.subs + sub_idx;
+  const uint32_t sub_pic = uload32(&subp->pic), byte_start = uload32(&subp->byte_start), byte_end = uload32(&subp->byte_end);
+  const uint32_t first_ctb_ts = uload32(&subp->first_ctb_ts), num_ctbs = uload32(&subp->num_ctbs), slice_idx = uload32(&subp->slice_idx);
+  const int32_t dep_sub = (int32_t)uload32(&subp->dep_sub);
+  const uint32_t dep_len = uload32(&subp->dep_len);
+  const uint32_t sflags = uload32(&subp->wpp_sync);  // wpp_sync | has_dependent << 8 | last_in_slice_segment << 16
+  const int wpp_sync = (int)(sflags & 255u), has_dependent = (int)((sflags >> 8) & 255u), last_in_slice_segment = (int)((sflags >> 16) & 255u);
+  const PicParams* P = A.pics + sub_pic;
+
+  s.L = lds; s.err = 0;
+  s.width = (int32_t)uload32(&P->width); s.height = (int32_t)uload32(&P->height);
+  s.log2_ctb = (int32_t)uload32(&P->log2_ctb); s.log2_min_cb = (int32_t)uload32(&P->log2_min_cb);
+  s.log2_min_tb = (int32_t)uload32(&P->log2_min_tb); s.log2_max_tb = (int32_t)uload32(&P->log2_max_tb);
+  s.max_th_depth_intra = (int32_t)uload32(&P->max_th_depth_intra);
+  s.chroma_format_idc = (int32_t)uload32(&P->chroma_format_idc);
+  s.bit_depth_luma = (int32_t)uload32(&P->bit_depth_luma); s.bit_depth_chroma = (int32_t)uload32(&P->bit_depth_chroma);
+  s.log2_min_cu_qp_delta_size = (int32_t)uload32(&P->log2_min_cu_qp_delta_size);
+  const int ctb_w = (int32_t)uload32(&P->ctb_w);
+  {
+    const uint32_t t0 = uload32(&P->sao_enabled);        // sao_enabled, sign_data_hiding, transform_skip_enabled, cu_qp_delta_enabled
+    const uint32_t t1 = uload32(&P->transquant_bypass_enabled);
+    s.tools = (((t0 >> 8) & 255u) ? TOOL_SDH : 0u) | (((t0 >> 16) & 255u) ? TOOL_TS : 0u) | (((t0 >> 24) & 255u) ? TOOL_CUQPD : 0u) |
+              ((t1 & 255u) ? TOOL_TQBYPASS : 0u);
+  }
+  uint8_t* const arena = A.arena;
+  s.bs = arena + uload64(&P->off_bitstream);
+  {
+    const SliceParams* sl = (const SliceParams*)(arena + uload64(&P->off_slices)) + slice_idx;
+    s.slice_qp_y = (int32_t)uload32(&sl->slice_qp_y);
+    const uint32_t w1 = uload32(&sl->cb_qp_offset);        // cb, cr, pps_cb, pps_cr
+    const uint32_t w2 = uload32(&sl->beta_offset_div2);    // beta, tc, deblocking_disabled, sao_luma
+    const uint32_t w3 = uload32(&sl->sao_chroma);          // sao_chroma, lf_across_slices, slice_addr_rs
+    (void)w1;
+    s.deblock = ((w2 >> 16) & 255u) ? 0 : 1;
+    s.sao_luma = (int)((w2 >> 24) & 255u);
+    s.sao_chroma = (int)(w3 & 255u);
+  }
+  s.is_cu_qp_delta_coded = 0; s.cu_qp_delta_val = 0; s.qpy_pred = s.slice_qp_y; s.last_qp_y = s.slice_qp_y; s.cur_qp_y = s.slice_qp_y;
+  s.cu_tq_bypass = 0;
+
+  const uint16_t* ts_to_rs = (const uint16_t*)(arena + uload64(&P->off_ctb_ts_to_rs));
+  const CtbInfo* ctb_info = (const CtbInfo*)(arena + uload64(&P->off_ctb_info));
+  uint32_t* sao_all = (uint32_t*)(arena + uload64(&P->off_sao));
+  uint8_t* const g_size = arena + uload64(&P->off_u_size);
+  uint8_t* const g_flags = arena + uload64(&P->off_u_flags);
+  uint8_t* const g_ipm = arena + uload64(&P->off_u_ipm);
+  uint8_t* const g_ipmc = arena + uload64(&P->off_u_ipmc);
+  uint8_t* const g_qp = arena + uload64(&P->off_u_qp);
+  int16_t* const coef_base_y = (int16_t*)(arena + uload64(&P->off_coeff[0]));
+  int16_t* const coef_base_cb = (int16_t*)(arena + uload64(&P->off_coeff[1]));
+  int16_t* const coef_base_cr = (int16_t*)(arena + uload64(&P->off_coeff[2]));
+  const int units_log2 = 2 * (s.log2_ctb - 2);
+  const int units = 1 << units_log2;
+  const int uw = 1 << (s.log2_ctb - 2);  // units per CTB side
+  const int ctb_size = 1 << s.log2_ctb;
+  const int n_mincb_log2 = 2 * (s.log2_ctb - s.log2_min_cb);
+
+  load_tables(s);
+  PC_VEC_BEGIN
+    PC_L(s.m_size) = 0; PC_L(s.m_flags) = 0; PC_L(s.m_ipm) = 0; PC_L(s.m_ipmc) = 0; PC_L(s.m_qp) = 0;
+    PC_L(s.p_size) = 0; PC_L(s.p_ipm) = 0; PC_L(s.up_size) = 0; PC_L(s.sao) = 0; PC_L(s.sao_left) = 0;
+    PC_L(s.ctxA) = 0; PC_L(s.ctxB) = 0; PC_L(s.ctxC) = 0; PC_L(s.win) = 0; PC_L(s.win_next) = 0;
+  PC_VEC_END
+  cabac_start(s, byte_start, byte_end);
+
+  for (uint32_t k = 0; k < num_ctbs && !s.err; k++) {
+    const int ctb_rs = (int)(uload32((const uint8_t*)ts_to_rs + ((first_ctb_ts + k) & ~1u) * 2u) >> (((first_ctb_ts + k) & 1u) * 16u)) & 0xffff;
+    const int cx = ctb_rs % ctb_w, cy = ctb_rs / ctb_w;
+    const uint32_t ci = uload32(ctb_info + ctb_rs);  // slice_idx | avail << 16 | tile_id << 24
+    s.x_ctb = cx << s.log2_ctb; s.y_ctb = cy << s.log2_ctb; s.ctb_avail = (int)((ci >> 16) & 255u);
+
+    // ---- WPP dependency on the CTB row above ----
+    if (dep_sub >= 0) {
+      const uint32_t need = k + 2 < dep_len ? k + 2 : dep_len;
+      const int e = pc_wait_progress(A.progress + dep_sub, need, A.status);
+      if (e) { s.err = e; break; }
+    }
+    // ---- context initialisation / synchronisation (9.3.1) ----
+    if (k == 0) {
+      if (wpp_sync && dep_sub >= 0) {
+        const uint8_t* src = A.ctx_store + (size_t)dep_sub * CTX_STORE;
+        PC_VEC_BEGIN
+          PC_L(s.ctxA) = src[lane]; PC_L(s.ctxB) = src[64 + lane]; PC_L(s.ctxC) = src[128 + lane];
+        PC_VEC_END
+      } else init_contexts(s);
+    }
+    // ---- neighbour row above this CTB ----
+    if (s.ctb_avail & AV_UP) {
+      const uint8_t* src = g_size + ((size_t)(ctb_rs - ctb_w) << units_log2);
+      PC_VEC_BEGIN
+        PC_L(s.up_size) = lane < uw ? (uint32_t)src[interleave4((uint32_t)lane, (uint32_t)uw - 1)] : 0u;
+      PC_VEC_END
+    }
+    // ---- coding_tree_unit ----
+    if (s.sao_luma || s.sao_chroma) {
+      parse_sao(s, sao_all + (size_t)(ctb_rs - ctb_w) * 9, (s.ctb_avail & AV_LEFT) && k > 0, (s.ctb_avail & AV_UP) ? 1 : 0);
+    } else {
+      PC_VEC_BEGIN PC_L(s.sao) = 0u; PC_VEC_END
+    }
+    if (!(s.tools & TOOL_CUQPD)) { s.is_cu_qp_delta_coded = 0; s.cu_qp_delta_val = 0; s.qpy_pred = s.last_qp_y; }
+
+    int16_t* coef_y = coef_base_y + (size_t)ctb_rs * ctb_size * ctb_size;
+    int16_t* coef_cb = coef_base_cb + (size_t)ctb_rs * (ctb_size * ctb_size / 4);
+    int16_t* coef_cr = coef_base_cr + (size_t)ctb_rs * (ctb_size * ctb_size / 4);
+
+    // coding quadtree, stackless over the z-ordered min-CB index
+    const int n_mincb = 1 << n_mincb_log2;
+    const int mincb_units_log2 = 2 * (s.log2_min_cb - 2);
+    int p = 0;
+    while (p < n_mincb && !s.err) {
+      int lg;  // log2 size of the node starting at p
+      if (p == 0) lg = s.log2_ctb; else { lg = s.log2_min_cb + ((pc_ffs((uint32_t)p) - 1) >> 1); if (lg > s.log2_ctb) lg = s.log2_ctb; }
+      const int zb = p << mincb_units_log2;
+      const int ux = (int)compact1by1((uint32_t)zb), uy = (int)compact1by1((uint32_t)zb >> 1);
+      const int x0 = s.x_ctb + (ux << 2), y0 = s.y_ctb + (uy << 2);
+      if (x0 >= s.width || y0 >= s.height) { p += 1 << (2 * (lg - s.log2_min_cb)); continue; }
+      for (;;) {
+        const int size = 1 << lg;
+        int split;
+        if (x0 + size <= s.width && y0 + size <= s.height && lg > s.log2_min_cb) {
+          const int depth = s.log2_ctb - lg;
+          int inc = 0;
+          const int l = left_cb_log2(s, ux, uy), u = up_cb_log2(s, ux, uy);
+          if (l && s.log2_ctb - l > depth) inc++;
+          if (u && s.log2_ctb - u > depth) inc++;
+          split = decode_bin(s, s.ctxA, A_SPLIT_CU + inc);
+        } else split = lg > s.log2_min_cb;
+        if ((s.tools & TOOL_CUQPD) && lg >= s.log2_min_cu_qp_delta_size) {
+          s.is_cu_qp_delta_coded = 0; s.cu_qp_delta_val = 0;
+          derive_qp_pred(s, ux, uy);
+        }
+        if (!split) break;
+        lg--;
+      }
+      if (!(s.tools & TOOL_CUQPD)) s.qpy_pred = s.last_qp_y;
+      coding_unit(s, zb, lg, coef_y, coef_cb, coef_cr);
+      p += 1 << (2 * (lg - s.log2_min_cb));
+    }
+
+    // end_of_slice_segment_flag / end_of_subset_one_bit
+    const int last = (k + 1 == num_ctbs);
+    const int eos = decode_terminate(s);
+    if (last) {
+      if (last_in_slice_segment) { if (!eos) s.err = DEV_ERR_TERMINATE; }
+      else { if (eos || !decode_terminate(s)) s.err = DEV_ERR_TERMINATE; }
+    } else if (eos) s.err = DEV_ERR_TERMINATE;
+
+    // ---- publish the CTB: unit maps, SAO parameters, WPP context table ----
+    {
+      const size_t base = (size_t)ctb_rs << units_log2;
+      const int nl = units >> 2;
+      uint32_t* sao_dst = sao_all + (size_t)ctb_rs * 9;
+      PC_VEC_BEGIN
+        if (lane < nl) {
+          ((uint32_t*)(g_size + base))[lane] = PC_L(s.m_size);
+          ((uint32_t*)(g_flags + base))[lane] = PC_L(s.m_flags);
+          ((uint32_t*)(g_ipm + base))[lane] = PC_L(s.m_ipm);
+          ((uint32_t*)(g_ipmc + base))[lane] = PC_L(s.m_ipmc);
+          ((uint32_t*)(g_qp + base))[lane] = PC_L(s.m_qp);
+        }
+        if (lane < 9) sao_dst[lane] = PC_L(s.sao);
+        // this CTB becomes the left neighbour of the next one
+        PC_L(s.p_size) = PC_L(s.m_size); PC_L(s.p_ipm) = PC_L(s.m_ipm); PC_L(s.sao_left) = PC_L(s.sao);
+      PC_VEC_END
+      if (has_dependent && k == 1) {
+        uint8_t* dst = A.ctx_store + (size_t)sub_idx * CTX_STORE;
+        PC_VEC_BEGIN
+          dst[lane] = (uint8_t)PC_L(s.ctxA); dst[64 + lane] = (uint8_t)PC_L(s.ctxB); dst[128 + lane] = (uint8_t)PC_L(s.ctxC);
+        PC_VEC_END
+      }
+    }
+    if (has_dependent) pc_publish(A.progress + sub_idx, k + 1);
+  }
+  if (s.err) pc_report(A.status, s.err | (int32_t)(sub_idx << 8));
+}
+
+}  // namespace pcore
+}  // namespace hipdec

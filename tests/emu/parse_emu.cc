@@ -1,0 +1,146 @@
+// parse_emu.cc — CPU-TEST-ONLY build of the device parser (libheif_amd/csrc/parse_core.h) with the
+// 64 lanes emulated by loops, plus the pure-host front end and batch layout.  It lets the
+// `-m "not gpu"` suite check the kernel's parsing logic (unit maps, coefficient levels, SAO
+// parameters, substream termination) against the oracle without a GPU.  NOT part of the product:
+// never linked into libheifhip.so, never used by libheif_amd/.
+#define HIPDEC_HOST_EMU 1
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "batch_layout.h"
+#include "hevc_headers.h"
+#include "parse_core.h"
+
+using namespace hipdec;
+
+struct EmuBatch {
+  BatchLayout L;
+  std::vector<uint8_t> arena;
+  int32_t status = 0;
+  std::string err;
+};
+
+extern "C" {
+
+EmuBatch* emu_create(int n, const uint8_t* const* data, const size_t* sizes, char* errbuf, size_t errlen)
+{
+  EmuBatch* b = new EmuBatch();
+  std::vector<uint8_t> host;
+  std::string err;
+  int rc = layout_batch(b->L, n, (const void* const*)data, sizes, 0, host, err);
+  if (rc != 0) {
+    snprintf(errbuf, errlen, "%d: %s", rc, err.c_str());
+    delete b;
+    return nullptr;
+  }
+  b->arena.assign(b->L.arena_size + 1024, 0);
+  memcpy(b->arena.data(), host.data(), host.size());
+  return b;
+}
+
+void emu_free(EmuBatch* b) { delete b; }
+
+// runs every substream in index order (a WPP predecessor always has a smaller index); returns the device status word
+int emu_run_parse(EmuBatch* b)
+{
+  uint8_t* a = b->arena.data();
+  memset(a + b->L.off_ctrl, 0, b->L.ctrl_size);
+  ParseArgs A{(const PicParams*)(a + b->L.off_pics), (const Substream*)(a + b->L.off_subs), b->L.num_subs, a,
+              (uint32_t*)(a + b->L.off_progress), a + b->L.off_ctx, (uint32_t*)(a + b->L.off_ticket), (int32_t*)(a + b->L.off_status)};
+  pcore::Lds lds;
+  memset(&lds, 0, sizeof(lds));
+  for (uint32_t s = 0; s < b->L.num_subs; s++) pcore::parse_substream(A, s, &lds);
+  b->status = *(int32_t*)(a + b->L.off_status);
+  return b->status;
+}
+
+int emu_info(EmuBatch* b, int i, int* out /* width, height, ctb_w, ctb_h, log2_ctb, chroma_format_idc, num_subs */)
+{
+  const PicParams& P = b->L.params[i];
+  out[0] = P.width; out[1] = P.height; out[2] = P.ctb_w; out[3] = P.ctb_h; out[4] = P.log2_ctb; out[5] = P.chroma_format_idc;
+  out[6] = (int)b->L.pics[i].subs.size();
+  return 0;
+}
+
+static inline uint32_t il(uint32_t x, uint32_t y)
+{
+  x = (x | (x << 2)) & 0x33; x = (x | (x << 1)) & 0x55; y = (y | (y << 2)) & 0x33; y = (y | (y << 1)) & 0x55; return x | (y << 1);
+}
+
+// raster (4x4-unit) maps, same layout as hipdec_batch_read_maps
+int emu_maps(EmuBatch* b, int i, uint8_t* log2_tb, uint8_t* log2_cb, uint8_t* intra_luma, uint8_t* intra_chroma, int8_t* qp_y, uint8_t* flags)
+{
+  const PicParams& P = b->L.params[i];
+  const uint8_t* a = b->arena.data();
+  const int uw = (P.width + 3) / 4, uh = (P.height + 3) / 4;
+  const int l = P.log2_ctb - 2, mask = (1 << l) - 1;
+  for (int uy = 0; uy < uh; uy++)
+    for (int ux = 0; ux < uw; ux++) {
+      const size_t idx = (((size_t)(uy >> l) * P.ctb_w + (ux >> l)) << P.units_per_ctb_log2) + il(ux & mask, uy & mask);
+      const size_t o = (size_t)uy * uw + ux;
+      log2_tb[o] = a[P.off_u_size + idx] & 15; log2_cb[o] = a[P.off_u_size + idx] >> 4;
+      intra_luma[o] = a[P.off_u_ipm + idx] & 63; intra_chroma[o] = a[P.off_u_ipmc + idx];
+      qp_y[o] = (int8_t)a[P.off_u_qp + idx]; flags[o] = a[P.off_u_flags + idx];
+    }
+  return 0;
+}
+
+// coefficient levels scattered to their spatial position (coded size planes, int32), like the oracle's `coeff` tap
+int emu_coeffs(EmuBatch* b, int i, int32_t* y, int32_t* cb, int32_t* cr)
+{
+  const PicParams& P = b->L.params[i];
+  const uint8_t* a = b->arena.data();
+  const int ctb = 1 << P.log2_ctb, units = 1 << P.units_per_ctb_log2;
+  int32_t* out[3] = {y, cb, cr};
+  memset(y, 0, sizeof(int32_t) * (size_t)P.width * P.height);
+  if (P.chroma_format_idc) { memset(cb, 0, sizeof(int32_t) * (size_t)P.cwidth * P.cheight); memset(cr, 0, sizeof(int32_t) * (size_t)P.cwidth * P.cheight); }
+  for (int cy = 0; cy < P.ctb_h; cy++)
+    for (int cx = 0; cx < P.ctb_w; cx++) {
+      const int ctb_rs = cy * P.ctb_w + cx;
+      const size_t base = (size_t)ctb_rs * units;
+      int z = 0;
+      while (z < units) {
+        const int ux = (int)pcore::compact1by1((uint32_t)z), uy = (int)pcore::compact1by1((uint32_t)z >> 1);
+        if (cx * ctb + ux * 4 >= P.width || cy * ctb + uy * 4 >= P.height) { z++; continue; }
+        const int t = a[P.off_u_size + base + z] & 15;
+        if (t < 2 || t > 5) return -1;
+        const int fl = a[P.off_u_flags + base + z];
+        if (fl & UF_CBF_LUMA) {
+          const int16_t* src = (const int16_t*)(a + P.off_coeff[0]) + (size_t)ctb_rs * ctb * ctb + z * 16;
+          const int n = 1 << t;
+          for (int yy = 0; yy < n; yy++)
+            for (int xx = 0; xx < n; xx++) y[(size_t)(cy * ctb + uy * 4 + yy) * P.width + cx * ctb + ux * 4 + xx] = src[yy * n + xx];
+        }
+        if (P.chroma_format_idc) {
+          int do_c = 0, zc = z, tc = t - 1;
+          if (t > 2) do_c = 1; else if ((z & 3) == 3) { do_c = 1; zc = z & ~3; tc = 2; }
+          if (do_c) {
+            const int cux = (int)pcore::compact1by1((uint32_t)zc), cuy = (int)pcore::compact1by1((uint32_t)zc >> 1);
+            for (int c = 1; c < 3; c++) {
+              if (!(fl & (c == 1 ? UF_CBF_CB : UF_CBF_CR))) continue;
+              const int16_t* src = (const int16_t*)(a + P.off_coeff[c]) + (size_t)ctb_rs * (ctb * ctb / 4) + zc * 4;
+              const int n = 1 << tc;
+              for (int yy = 0; yy < n; yy++)
+                for (int xx = 0; xx < n; xx++) out[c][(size_t)(cy * ctb / 2 + cuy * 2 + yy) * P.cwidth + cx * ctb / 2 + cux * 2 + xx] = src[yy * n + xx];
+            }
+          }
+        }
+        z += 1 << (2 * (t - 2));
+      }
+    }
+  return 0;
+}
+
+// SAO parameters per CTB (raster) and component: type, band_or_class, 4 offsets
+int emu_sao(EmuBatch* b, int i, uint8_t* type, uint8_t* cls, int16_t* offsets)
+{
+  const PicParams& P = b->L.params[i];
+  const SaoParams* sp = (const SaoParams*)(b->arena.data() + P.off_sao);
+  const int n = P.ctb_w * P.ctb_h * 3;
+  for (int k = 0; k < n; k++) { type[k] = sp[k].type; cls[k] = sp[k].band_or_class; for (int j = 0; j < 4; j++) offsets[k * 4 + j] = sp[k].offset[j]; }
+  return 0;
+}
+
+}  // extern "C"

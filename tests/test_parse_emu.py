@@ -1,0 +1,143 @@
+"""CPU check of the device parser's logic: libheif_amd/csrc/parse_core.h compiled for the host with the
+64 lanes emulated (tests/emu) against the oracle's taps — unit maps, coefficient levels, SAO
+parameters and exact substream termination — over the coding-tool matrix.  The emulation is test
+infrastructure; the product runs the same source on the GPU (tests/test_decode_gpu.py)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def emu():
+    global _LIB
+    if _LIB is None:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "emu")])
+        L = C.CDLL(os.path.join(HERE, "emu", "libparse_emu.so"))
+        L.emu_create.restype = C.c_void_p
+        L.emu_create.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+        L.emu_free.argtypes = [C.c_void_p]
+        L.emu_run_parse.argtypes = [C.c_void_p]
+        L.emu_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.emu_maps.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
+        L.emu_coeffs.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3
+        L.emu_sao.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3
+        _LIB = L
+    return _LIB
+
+
+def run_emu(streams):
+    L = emu()
+    n = len(streams)
+    arr = (C.c_char_p * n)(*streams)
+    sizes = (C.c_size_t * n)(*[len(s) for s in streams])
+    err = C.create_string_buffer(512)
+    h = L.emu_create(n, arr, sizes, err, 512)
+    assert h, err.value.decode()
+    status = L.emu_run_parse(h)
+    out = []
+    if status != 0:   # maps / coefficients of a desynchronised parse are garbage: do not walk them
+        L.emu_free(h)
+        return status, out
+    for i in range(n):
+        info = (C.c_int * 7)()
+        L.emu_info(h, i, info)
+        w, hgt, ctb_w, ctb_h, log2_ctb, cf, nsub = list(info)
+        uw, uh = (w + 3) // 4, (hgt + 3) // 4
+        names = ["log2_tb", "log2_cb", "intra_luma", "intra_chroma", "qp_y", "flags"]
+        maps = [np.zeros((uh, uw), np.int8 if k == "qp_y" else np.uint8) for k in names]
+        L.emu_maps(h, i, *[m.ctypes.data for m in maps])
+        coef = [np.zeros((hgt, w), np.int32), np.zeros((hgt // 2, w // 2), np.int32), np.zeros((hgt // 2, w // 2), np.int32)]
+        assert L.emu_coeffs(h, i, *[c.ctypes.data for c in coef]) == 0
+        nctb = ctb_w * ctb_h
+        st, sc, so = np.zeros((nctb, 3), np.uint8), np.zeros((nctb, 3), np.uint8), np.zeros((nctb, 3, 4), np.int16)
+        L.emu_sao(h, i, st.ctypes.data, sc.ctypes.data, so.ctypes.data)
+        out.append(dict(zip(names, maps), coef=coef, sao_type=st, sao_cls=sc, sao_off=so, cf=cf, nsub=nsub))
+    L.emu_free(h)
+    return status, out
+
+
+def check_against_oracle(stream, got):
+    ref = orc.decode(stream, taps=True)
+    np.testing.assert_array_equal(got["log2_cb"], ref["map_log2_cb"])
+    np.testing.assert_array_equal(got["log2_tb"], ref["map_log2_tb"])
+    np.testing.assert_array_equal(got["intra_luma"], ref["map_intra_luma"])
+    np.testing.assert_array_equal(got["intra_chroma"], ref["map_intra_chroma"])
+    np.testing.assert_array_equal(got["qp_y"], ref["map_qp_y"])
+    np.testing.assert_array_equal(got["flags"] & 0x7f, ref["map_flags"] & 0x7f)
+    for c in range(3 if got["cf"] else 1):
+        np.testing.assert_array_equal(got["coef"][c], ref["coeff"][c], err_msg="coefficients of component %d" % c)
+    ncomp = 3 if got["cf"] else 1
+    np.testing.assert_array_equal(got["sao_type"][:, :ncomp], ref["sao_type"][:, :ncomp])
+    on = got["sao_type"][:, :ncomp] != 0
+    np.testing.assert_array_equal(got["sao_cls"][:, :ncomp][on], ref["sao_band_or_class"][:, :ncomp][on])
+    np.testing.assert_array_equal(got["sao_off"][:, :ncomp][on], ref["sao_offset"][:, :ncomp][on])
+    assert got["nsub"] == ref["n_substreams"]
+
+
+CONFIGS = [
+    dict(),
+    dict(wpp=0),
+    dict(stress=1),
+    dict(stress=1, wpp=0, log2_ctb=4, log2_max_tb=4),
+    dict(stress=1, log2_ctb=5, log2_max_tb=5),
+    dict(tile_cols=2, tile_rows=2, wpp=0),
+    dict(tile_cols=3, tile_rows=2, wpp=1, loop_filter_across_tiles=0),
+    dict(num_slices=3, loop_filter_across_slices=0),
+    dict(num_slices=4, wpp=0, stress=1),
+    dict(transform_skip=1, stress=1),
+    dict(lossless_pct=30),
+    dict(bit_depth=10, vui_matrix=9, vui_primaries=9, vui_transfer=16),
+    dict(log2_ctb=5, log2_min_cb=4, log2_max_tb=5, max_transform_hierarchy_depth_intra=2, stress=1),
+    dict(sao=0, deblock_disable=1),
+    dict(cb_qp_offset=3, cr_qp_offset=-4, beta_offset_div2=2, tc_offset_div2=-2, qp=34),
+    dict(qp=12, stress=1, zero_residual_pct=30),
+    dict(sign_data_hiding=0, cu_qp_delta=0, strong_intra_smoothing=0),
+    dict(qp=40),
+    dict(qp=4, stress=1),
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: ",".join("%s=%s" % kv for kv in c.items()) or "default")
+@pytest.mark.parametrize("size", [(200, 136), (64, 64), (328, 72)])
+def test_parser_emulation_matches_oracle(cfg, size):
+    bd = cfg.get("bit_depth", 8)
+    planes = orc.synth_image(size[0], size[1], bd, 1, seed=3 + size[0])
+    stream = orc.encode(planes, **cfg)
+    status, got = run_emu([stream])
+    assert status == 0, "device status 0x%x" % status
+    check_against_oracle(stream, got[0])
+
+
+def test_parser_emulation_monochrome_and_batch():
+    streams = []
+    for i, (w, h, cf) in enumerate([(75, 41, 0), (70, 42, 1), (8, 8, 1), (136, 24, 1), (264, 200, 1)]):
+        streams.append(orc.encode(orc.synth_image(w, h, 8, cf, seed=5 + i), wpp=i % 2, stress=i % 3 == 0))
+    status, got = run_emu(streams)
+    assert status == 0
+    for s, g in zip(streams, got):
+        check_against_oracle(s, g)
+
+
+def test_parser_emulation_reports_desync():
+    stream = bytearray(orc.encode(orc.synth_image(128, 128, 8, 1, seed=9)))
+    for k in range(len(stream) - 80, len(stream) - 30):
+        stream[k] ^= 0x5A
+    status, _ = run_emu([bytes(stream)])
+    assert status != 0
+
+
+def test_parser_emulation_reference_fixtures(reference_dir):
+    from heic_util import HeicFile
+    for rel in ("examples/example.heic", "tests/data/rainbow-451x461.heic", "tests/data/with-alpha-512x512.heic"):
+        f = HeicFile(os.path.join(reference_dir, rel))
+        for iid in f.hevc_items():
+            s = f.plugin_stream(iid)
+            status, got = run_emu([s])
+            assert status == 0, rel
+            check_against_oracle(s, got[0])
