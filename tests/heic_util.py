@@ -200,3 +200,119 @@ class HeicFile:
         else:
             w, h = struct.unpack(">HH", d[4:8])
         return rows, cols, w, h, self.refs.get(("dimg", iid), [])
+
+
+# ------------------------------------------------------------------------------------------------
+# minimal HEIC writer (test inputs only): wraps plugin-framed HEVC streams into single-item or grid
+# files the REAL libheif can open, so that the drop-in tests drive heif_decode_image() end to end
+# without reading /root/reference (ISO/IEC 23008-12; box layouts as libheif/box.cc parses them).
+# ------------------------------------------------------------------------------------------------
+def _box(typ, payload):
+    return struct.pack(">I4s", 8 + len(payload), typ.encode("latin1")) + payload
+
+
+def _fullbox(typ, version, flags, payload):
+    return _box(typ, struct.pack(">I", (version << 24) | flags) + payload)
+
+
+def split_nals(stream):
+    """[4-byte BE length][NAL]... -> list of NAL byte strings"""
+    out, p = [], 0
+    while p + 4 <= len(stream):
+        n = struct.unpack(">I", stream[p:p + 4])[0]
+        out.append(stream[p + 4:p + 4 + n])
+        p += 4 + n
+    return out
+
+
+def _unescape(nal):
+    out, zeros = bytearray(), 0
+    for b in nal:
+        if zeros >= 2 and b == 3:
+            zeros = 0
+            continue
+        out.append(b)
+        zeros = zeros + 1 if b == 0 else 0
+    return bytes(out)
+
+
+def _hvcc(nals, chroma_format_idc=1, bit_depth=8):
+    sps = [n for n in nals if (n[0] >> 1) & 63 == 33][0]
+    r = _unescape(sps[2:])
+    ptl = r[1:13]                      # general profile_tier_level: 12 bytes after the 1-byte sps header fields
+    body = bytes([1]) + ptl[0:1] + ptl[1:5] + ptl[5:11] + ptl[11:12]
+    body += struct.pack(">H", 0xF000) + bytes([0xFC, 0xFC | chroma_format_idc, 0xF8 | (bit_depth - 8), 0xF8 | (bit_depth - 8)])
+    body += struct.pack(">H", 0) + bytes([0x0F])   # avgFrameRate, constantFrameRate=0 numTemporalLayers=1 nested=1 lengthSizeMinusOne=3
+    arrays = b""
+    count = 0
+    for t in (32, 33, 34):
+        sel = [n for n in nals if (n[0] >> 1) & 63 == t]
+        if not sel:
+            continue
+        count += 1
+        arrays += bytes([0x80 | t]) + struct.pack(">H", len(sel))
+        for n in sel:
+            arrays += struct.pack(">H", len(n)) + n
+    return _box("hvcC", body + bytes([count]) + arrays)
+
+
+def _payload(nals):
+    return b"".join(struct.pack(">I", len(n)) + n for n in nals if (n[0] >> 1) & 63 < 32)
+
+
+def build_heic(items, grid=None, bit_depth=8, chroma_format_idc=1):
+    """items: list of (stream, width, height) coded items (ids 1..n).  grid: None, or
+    (rows, cols, out_w, out_h) -> an extra 'grid' item (id n+1, primary) referencing all items in order."""
+    n = len(items)
+    payloads = [_payload(split_nals(s)) for s, _, _ in items]
+    grid_data = b""
+    if grid is not None:
+        rows, cols, ow, oh = grid
+        grid_data = bytes([0, 0, rows - 1, cols - 1]) + struct.pack(">HH", ow, oh)
+    primary = n + 1 if grid is not None else 1
+    # ---- properties: per item hvcC + ispe (+ ispe for the grid) ----
+    props, assoc = [], {}
+    for i, (s, w, h) in enumerate(items):
+        props.append(_hvcc(split_nals(s), chroma_format_idc, bit_depth))
+        props.append(_fullbox("ispe", 0, 0, struct.pack(">II", w, h)))
+        assoc[i + 1] = [(len(props) - 1, True), (len(props), False)]
+    if grid is not None:
+        props.append(_fullbox("ispe", 0, 0, struct.pack(">II", grid[2], grid[3])))
+        assoc[n + 1] = [(len(props), False)]
+    ipco = _box("ipco", b"".join(props))
+    ipma = struct.pack(">I", len(assoc))
+    for iid in sorted(assoc):
+        ipma += struct.pack(">HB", iid, len(assoc[iid]))
+        for idx, essential in assoc[iid]:
+            ipma += bytes([(0x80 if essential else 0) | idx])
+    iprp = _box("iprp", ipco + _fullbox("ipma", 0, 0, ipma))
+    infes = b""
+    for i in range(n):
+        hidden = 1 if grid is not None else 0
+        infes += _fullbox("infe", 2, hidden, struct.pack(">HH4s", i + 1, 0, b"hvc1") + b"\0")
+    if grid is not None:
+        infes += _fullbox("infe", 2, 0, struct.pack(">HH4s", n + 1, 0, b"grid") + b"\0")
+    n_items = n + (1 if grid is not None else 0)
+    iinf = _fullbox("iinf", 0, 0, struct.pack(">H", n_items) + infes)
+    pitm = _fullbox("pitm", 0, 0, struct.pack(">H", primary))
+    hdlr = _fullbox("hdlr", 0, 0, struct.pack(">I4s", 0, b"pict") + b"\0" * 12 + b"\0")
+    iref = b""
+    if grid is not None:
+        iref = _fullbox("iref", 0, 0, _box("dimg", struct.pack(">HH", n + 1, n) + b"".join(struct.pack(">H", i + 1) for i in range(n))))
+    ftyp = _box("ftyp", b"heic" + struct.pack(">I", 0) + b"mif1heic")
+
+    def make_meta(offsets):
+        iloc = struct.pack(">BBH", 0x44, 0x00, n_items)   # offset_size 4, length_size 4, base_offset_size 0
+        blobs = payloads + ([grid_data] if grid is not None else [])
+        for i, blob in enumerate(blobs):
+            iloc += struct.pack(">HHH", i + 1, 0, 1) + struct.pack(">II", offsets[i], len(blob))
+        return _fullbox("meta", 0, 0, hdlr + pitm + _fullbox("iloc", 0, 0, iloc) + iinf + iref + iprp)
+
+    blobs = payloads + ([grid_data] if grid is not None else [])
+    meta_len = len(make_meta([0] * len(blobs)))
+    pos = len(ftyp) + meta_len + 8
+    offsets = []
+    for blob in blobs:
+        offsets.append(pos)
+        pos += len(blob)
+    return ftyp + make_meta(offsets) + _box("mdat", b"".join(blobs))

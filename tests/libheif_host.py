@@ -1,0 +1,138 @@
+"""Test tooling: drives the REAL reference libheif (oracle/_ref/libheif.so, compiled from
+/root/reference by oracle/Makefile.ref — the prebuilt .so travels to the GPU box) through its public C
+API with ctypes, with libheif_amd/libheifhip.so loaded as a decoder plugin exactly the way an
+application would (heif_load_plugin -> dlopen + dlsym("plugin_info"), libheif/plugins_unix.cc:103-118).
+This is the drop-in proof: heif_decode_image() -> libheif -> heif_decoder_plugin -> HIP kernels."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REF = os.path.join(_HERE, "..", "oracle", "_ref")
+_LIB = None
+_PLUGIN_LOADED = False
+
+COLORSPACE_YCBCR, COLORSPACE_RGB, COLORSPACE_MONO, COLORSPACE_UNDEFINED = 0, 1, 2, 99
+CHROMA_UNDEFINED, CHROMA_MONO, CHROMA_420, CHROMA_RGB, CHROMA_RGBA = 99, 0, 1, 10, 11
+CHANNEL_Y, CHANNEL_CB, CHANNEL_CR, CHANNEL_INTERLEAVED = 0, 1, 2, 10
+COMPRESSION_HEVC = 1
+
+
+class HeifError(C.Structure):
+    _fields_ = [("code", C.c_int), ("subcode", C.c_int), ("message", C.c_char_p)]
+
+
+class LibheifError(RuntimeError):
+    def __init__(self, e):
+        super().__init__("libheif error %d.%d: %s" % (e.code, e.subcode, (e.message or b"").decode("latin1")))
+        self.code, self.subcode = e.code, e.subcode
+
+
+def available():
+    return os.path.exists(os.path.join(_REF, "libheif.so"))
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(os.path.join(_REF, "libheif.so"), mode=C.RTLD_GLOBAL)
+        vp = C.c_void_p
+        L.heif_load_plugin.restype = HeifError
+        L.heif_load_plugin.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.heif_have_decoder_for_format.argtypes = [C.c_int]
+        L.heif_context_alloc.restype = vp
+        L.heif_context_free.argtypes = [vp]
+        L.heif_context_read_from_memory_without_copy.restype = HeifError
+        L.heif_context_read_from_memory_without_copy.argtypes = [vp, C.c_char_p, C.c_size_t, vp]
+        L.heif_context_get_primary_image_handle.restype = HeifError
+        L.heif_context_get_primary_image_handle.argtypes = [vp, C.POINTER(vp)]
+        L.heif_context_set_max_decoding_threads.argtypes = [vp, C.c_int]
+        L.heif_image_handle_get_width.argtypes = [vp]
+        L.heif_image_handle_get_height.argtypes = [vp]
+        L.heif_image_handle_release.argtypes = [vp]
+        L.heif_decode_image.restype = HeifError
+        L.heif_decode_image.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int, vp]
+        L.heif_image_get_plane_readonly2.restype = C.POINTER(C.c_uint8)
+        L.heif_image_get_plane_readonly2.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t)]
+        L.heif_image_get_width.argtypes = [vp, C.c_int]
+        L.heif_image_get_height.argtypes = [vp, C.c_int]
+        L.heif_image_get_bits_per_pixel_range.argtypes = [vp, C.c_int]
+        L.heif_image_release.argtypes = [vp]
+        L.heif_decoding_options_alloc.restype = vp
+        L.heif_decoding_options_free.argtypes = [vp]
+        _LIB = L
+    return _LIB
+
+
+def check(e):
+    if e.code != 0:
+        raise LibheifError(e)
+
+
+def load_hip_plugin():
+    """heif_load_plugin(libheifhip.so): what LIBHEIF_PLUGIN_PATH discovery does for every file in the
+    plugin directory."""
+    global _PLUGIN_LOADED
+    L = lib()
+    if not _PLUGIN_LOADED:
+        import libheif_amd
+        info = C.c_void_p()
+        check(L.heif_load_plugin(libheif_amd.library_path().encode(), C.byref(info)))
+        _PLUGIN_LOADED = True
+    return L
+
+
+def _plane(L, img, channel, bytes_per_sample=1, interleave=1):
+    stride = C.c_size_t()
+    p = L.heif_image_get_plane_readonly2(img, channel, C.byref(stride))
+    if not p:
+        return None
+    w, h = L.heif_image_get_width(img, channel), L.heif_image_get_height(img, channel)
+    rowbytes = w * bytes_per_sample * interleave
+    buf = np.ctypeslib.as_array(p, shape=(h * stride.value,))[:h * stride.value].reshape(h, stride.value)[:, :rowbytes].copy()
+    return buf.view(np.uint16) if bytes_per_sample == 2 else buf
+
+
+def open_heic(data):
+    L = lib()
+    ctx = L.heif_context_alloc()
+    check(L.heif_context_read_from_memory_without_copy(ctx, data, len(data), None))
+    h = C.c_void_p()
+    check(L.heif_context_get_primary_image_handle(ctx, C.byref(h)))
+    return ctx, h
+
+
+def primary_size(data):
+    L = lib()
+    ctx, h = open_heic(data)
+    try:
+        return L.heif_image_handle_get_width(h), L.heif_image_handle_get_height(h)
+    finally:
+        L.heif_image_handle_release(h)
+        L.heif_context_free(ctx)
+
+
+def decode(data, colorspace=COLORSPACE_UNDEFINED, chroma=CHROMA_UNDEFINED, max_threads=None):
+    """heif_decode_image() on the primary item.  Returns a dict: YCbCr -> planes [Y, Cb, Cr];
+    interleaved RGB -> 'rgb' rows."""
+    L = lib()
+    ctx, h = open_heic(data)
+    img = C.c_void_p()
+    try:
+        if max_threads is not None:
+            L.heif_context_set_max_decoding_threads(ctx, max_threads)
+        check(L.heif_decode_image(h, C.byref(img), colorspace, chroma, None))
+        out = {}
+        if chroma in (CHROMA_RGB, CHROMA_RGBA):
+            out["rgb"] = _plane(L, img, CHANNEL_INTERLEAVED, 1, 3 if chroma == CHROMA_RGB else 4)
+        else:
+            bpp = L.heif_image_get_bits_per_pixel_range(img, CHANNEL_Y)
+            bs = 2 if bpp > 8 else 1
+            out["planes"] = [p for p in (_plane(L, img, c, bs) for c in (CHANNEL_Y, CHANNEL_CB, CHANNEL_CR)) if p is not None]
+            out["bit_depth"] = bpp
+        return out
+    finally:
+        if img:
+            L.heif_image_release(img)
+        L.heif_image_handle_release(h)
+        L.heif_context_free(ctx)
