@@ -43,7 +43,7 @@ WORKLOADS = {
     # name: (width, height, default batch, encoder config)
     "still4k": (3840, 2160, 256, dict(wpp=1)),
     "still1080": (1920, 1080, 1024, dict(wpp=1)),
-    "grid8k": (1024, 1024, 48, dict(wpp=1)),
+    "grid8k": (1024, 1024, 48, dict(wpp=1, vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1)),
 }
 
 
@@ -84,22 +84,30 @@ def main():
         specs = [(w, h, 1 + rank * nd + i, 8, enc_cfg) for i in range(nd)]
     # ---- synthetic inputs (outside the timed region) ----
     distinct = streamgen.make_streams(specs)
-    streams = distinct if grid else [distinct[i % len(distinct)] for i in range(nb)]
+    px_item = w * h
+    gd = None
+    if grid:
+        from libheif_amd.grid import GridDecoder, GridLayout
+        layout = GridLayout(6, 8, w, h, 8 * w, 6 * h)
+        gd = GridDecoder(dict(zip(items, distinct)), layout, rank, world)   # tiles sharded t mod G, gather to rank 0
+        batch = gd.batch
+        streams = distinct
+    else:
+        streams = [distinct[i % len(distinct)] for i in range(nb)]
+        batch = Batch(streams)          # parses headers on the host and uploads everything to HBM
+        batch.alloc_rgb(10)
     n_items = len(streams)
     bs_bytes = sum(len(s) for s in streams)
-    px_item = w * h
-    batch = Batch(streams)          # parses headers on the host and uploads everything to HBM
-    batch.alloc_rgb(10)
     batch.timing_slots(max(1, a.steps))
     single = Batch([streams[0]])
     single.alloc_rgb(10)
 
-    canvas = None
-    if grid and world > 1:
-        # root canvas of decoded RGB tiles; every rank contributes its tiles with one all_gather
-        pass
-
     def step(b):
+        if b is batch and gd is not None:
+            gd.decode()
+            if rank == 0:
+                gd.to_rgb((1, 13, 6, 1))
+            return
         b.run()
         b.to_rgb_all()
 

@@ -127,6 +127,15 @@ HIPDEC_API int hipdec_batch_run(hipdec_batch* b, void* stream);      /* asynchro
 HIPDEC_API int hipdec_batch_status(hipdec_batch* b);                 /* synchronises; device errors  */
 HIPDEC_API int hipdec_batch_read_plane(hipdec_batch* b, int i, int c, void* dst_host, size_t dst_stride);
 HIPDEC_API int hipdec_batch_device_plane(hipdec_batch* b, int i, int c, const void** dptr, size_t* stride);
+/* Grid / multi-GPU hand-over (device-side form of HeifPixelImage::copy_image_to,
+ * libheif/image/pixelimage.cc:1115-1172): hipdec_batch_pack_item writes item i's cropped planes tightly
+ * (Y then Cb then Cr, row stride = width * bytes per sample) into a caller-owned device buffer, e.g. the
+ * send buffer of an RCCL gather; hipdec_copy2d_d2d pastes a plane into a canvas at the caller's offset.
+ * Both are asynchronous on `stream`. */
+HIPDEC_API size_t hipdec_batch_item_packed_bytes(const hipdec_batch* b, int i);
+HIPDEC_API int hipdec_batch_pack_item(hipdec_batch* b, int i, void* dst_dev, size_t dst_bytes, void* stream);
+HIPDEC_API int hipdec_copy2d_d2d(void* dst_dev, size_t dst_stride, const void* src_dev, size_t src_stride, size_t width_bytes,
+                                 size_t height, void* stream);
 /* Fused colour stage over item i (planes -> interleaved RGB in HBM), see hipdec_color_* below;
  * out_chroma uses heif_chroma numeric values (10 = RGB, 11 = RGBA, 12/14 = RRGGBB BE/LE). */
 HIPDEC_API int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void* out_dev, size_t out_stride,

@@ -167,6 +167,40 @@ int hipdec_batch_device_plane(hipdec_batch* b, int i, int c, const void** dptr, 
   return 0;
 }
 
+size_t hipdec_batch_item_packed_bytes(const hipdec_batch* b, int i)
+{
+  if (!b || i < 0 || i >= (int)b->pics.size()) return 0;
+  const PicParams& P = b->params[i];
+  const size_t es = b->wide ? 2 : 1;
+  return ((size_t)P.out_width * P.out_height + 2 * (size_t)P.out_cwidth * P.out_cheight) * es;
+}
+
+int hipdec_batch_pack_item(hipdec_batch* b, int i, void* dst_dev, size_t dst_bytes, void* stream)
+{
+  if (!b || i < 0 || i >= (int)b->pics.size() || !dst_dev) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "pack_item: bad arguments");
+  if (dst_bytes < hipdec_batch_item_packed_bytes(b, i)) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "pack_item: destination too small");
+  const PicParams& P = b->params[i];
+  const size_t es = b->wide ? 2 : 1;
+  hipStream_t s = stream ? (hipStream_t)stream : (b->last_stream ? b->last_stream : default_stream());
+  uint8_t* dst = (uint8_t*)dst_dev;
+  for (int c = 0; c < (P.chroma_format_idc ? 3 : 1); c++) {
+    const size_t w = c ? P.out_cwidth : P.out_width, h = c ? P.out_cheight : P.out_height;
+    if (w && h) HIPDEC_CHECK_HIP(hipMemcpy2DAsync(dst, w * es, b->arena + P.off_out[c], P.out_stride[c], w * es, h, hipMemcpyDeviceToDevice, s));
+    dst += w * h * es;
+  }
+  return 0;
+}
+
+int hipdec_copy2d_d2d(void* dst_dev, size_t dst_stride, const void* src_dev, size_t src_stride, size_t width_bytes, size_t height, void* stream)
+{
+  if (!dst_dev || !src_dev) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "copy2d: NULL pointer");
+  if (int rc = ensure_init()) return rc;
+  if (!width_bytes || !height) return 0;
+  HIPDEC_CHECK_HIP(hipMemcpy2DAsync(dst_dev, dst_stride, src_dev, src_stride, width_bytes, height, hipMemcpyDeviceToDevice,
+                                    stream ? (hipStream_t)stream : default_stream()));
+  return 0;
+}
+
 int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void* out_dev, size_t out_stride, void* stream)
 {
   if (!b || i < 0 || i >= (int)b->pics.size() || !out_dev) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "to_rgb: bad arguments");

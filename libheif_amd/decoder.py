@@ -31,6 +31,10 @@ def _bind(lib):
     lib.hipdec_batch_device_plane.argtypes = [vp, ci, ci, C.POINTER(vp), C.POINTER(sz)]
     lib.hipdec_batch_to_rgb.argtypes = [vp, ci, ci, vp, sz, vp]
     lib.hipdec_batch_last_timing_us.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.hipdec_batch_item_packed_bytes.restype = sz
+    lib.hipdec_batch_item_packed_bytes.argtypes = [vp, ci]
+    lib.hipdec_batch_pack_item.argtypes = [vp, ci, vp, sz, vp]
+    lib.hipdec_copy2d_d2d.argtypes = [vp, sz, vp, sz, sz, sz, vp]
     lib.hipdec_batch_timing_slots.argtypes = [vp, ci]
     lib.hipdec_batch_slot_timing_us.argtypes = [vp, ci, C.POINTER(C.c_float)]
     lib.hipdec_batch_read_tap.argtypes = [vp, ci, ci, ci, vp, sz]

@@ -1,0 +1,104 @@
+"""Multi-GPU grid path (libheif_amd/grid.py): tile -> rank partition, the gather of decoded tile planes
+to the root and the paste into the canvas.  CPU part: pure partition logic + a world_size-2 `gloo` run
+in which each rank's tiles are produced by the oracle (standing in for the device decode) and go
+through the SAME gather / paste code as on the GPUs.  GPU part: the real GridDecoder at world size 1."""
+import os
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from libheif_amd import grid as G
+
+
+def _tiles(layout, seed0=40):
+    return {t: orc.encode(orc.synth_image(layout.tile_w, layout.tile_h, layout.bit_depth, 1, seed=seed0 + t), wpp=t % 2)
+            for t in range(layout.n_tiles)}
+
+
+def _expected_canvas(layout, streams):
+    es = layout.sample_bytes
+    full = [np.zeros((layout.rows * layout.tile_h, layout.cols * layout.tile_w), np.uint16),
+            np.zeros((layout.rows * layout.tile_h // 2, layout.cols * layout.tile_w // 2), np.uint16),
+            np.zeros((layout.rows * layout.tile_h // 2, layout.cols * layout.tile_w // 2), np.uint16)]
+    for t, s in streams.items():
+        ref = orc.decode(s)
+        x0, y0 = layout.origin(t)
+        for c in range(3):
+            sub = 1 if c == 0 else 2
+            full[c][y0 // sub:(y0 + layout.tile_h) // sub, x0 // sub:(x0 + layout.tile_w) // sub] = ref["planes"][c]
+    dt = np.uint16 if es == 2 else np.uint8
+    cw, ch = (layout.out_w + 1) // 2, (layout.out_h + 1) // 2
+    return [full[0][:layout.out_h, :layout.out_w].astype(dt), full[1][:ch, :cw].astype(dt), full[2][:ch, :cw].astype(dt)]
+
+
+def _pack(ref_planes, dt):
+    return np.concatenate([np.ascontiguousarray(p, dtype=dt).reshape(-1).view(np.uint8) for p in ref_planes])
+
+
+def test_partition_and_paste_plan():
+    L = G.GridLayout(6, 8, 1024, 1024, 8192, 6144)
+    assert L.n_tiles == 48 and L.tile_bytes == 1024 * 1024 * 3 // 2
+    for world in (1, 2, 4, 8, 5):
+        owned = [G.shard(48, r, world) for r in range(world)]
+        assert sorted(sum(owned, [])) == list(range(48))
+        assert max(len(o) for o in owned) == G.slots_per_rank(48, world)
+        plan = G.paste_plan(L, world)
+        assert len(plan) == 48
+        for t, r, slot, x0, y0, w, h in plan:
+            assert owned[r][slot] == t and (x0, y0) == ((t % 8) * 1024, (t // 8) * 1024) and (w, h) == (1024, 1024)
+    # 8 GPUs: every rank owns one tile column
+    assert all(set(t % 8 for t in G.shard(48, r, 8)) == {r} for r in range(8))
+    clipped = G.paste_plan(G.GridLayout(2, 2, 128, 128, 200, 130), 2)
+    assert [(p[5], p[6]) for p in clipped] == [(128, 128), (72, 128), (128, 2), (72, 2)]
+    with pytest.raises(ValueError):
+        G.GridLayout(2, 2, 128, 128, 300, 100)
+
+
+def _gloo_worker(rank, world, port, bit_depth, result_file):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L = G.GridLayout(2, 3, 64, 64, 180, 120, bit_depth)
+        streams = _tiles(L)
+        dt = np.uint16 if bit_depth > 8 else np.uint8
+        send = torch.zeros((G.slots_per_rank(L.n_tiles, world), L.tile_bytes), dtype=torch.uint8)
+        for slot, t in enumerate(G.shard(L.n_tiles, rank, world)):      # this rank "decodes" only its own tiles
+            send[slot] = torch.from_numpy(_pack(orc.decode(streams[t])["planes"], dt))
+        gathered = G.gather_tiles(send, L, rank, world)
+        if rank == 0:
+            canvas = G.alloc_canvas(L, "cpu")
+            G.paste_tiles(gathered, L, world, canvas)
+            exp = _expected_canvas(L, streams)
+            ok = all(np.array_equal(canvas[c].numpy().view(dt), exp[c]) for c in range(3))
+            open(result_file, "w").write("ok" if ok else "mismatch")
+        else:
+            assert gathered is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bit_depth", [(2, 8), (3, 10)])
+def test_gather_and_paste_over_gloo(tmp_path, world, bit_depth):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    result = str(tmp_path / "result.txt")
+    mp.spawn(_gloo_worker, args=(world, port, bit_depth, result), nprocs=world, join=True)
+    assert open(result).read() == "ok"
+
+
+@pytest.mark.gpu
+def test_grid_decoder_single_gpu_matches_oracle():
+    import torch
+    L = G.GridLayout(2, 3, 128, 128, 380, 250)
+    streams = _tiles(L)
+    gd = G.GridDecoder(streams, L, rank=0, world=1)
+    canvas = gd.decode()
+    exp = _expected_canvas(L, streams)
+    for c in range(3):
+        np.testing.assert_array_equal(canvas[c].cpu().numpy(), exp[c], err_msg="canvas component %d" % c)
+    rgb = gd.to_rgb((1, 13, 6, 1)).cpu().numpy()
+    np.testing.assert_array_equal(rgb, orc.color_420_to_rgb24(exp[0], exp[1], exp[2], (1, 13, 6, 1)).reshape(L.out_h, -1))
