@@ -33,11 +33,32 @@ def library_path():
     return os.path.join(_HERE, "libheifhip.so")
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (soname
+    libamdhip64.so.7, the same as /opt/rocm's) but link it by the un-versioned name, so if libheifhip.so
+    pulls in the system runtime first a later `import torch` loads a SECOND runtime that sees no GPU and
+    device pointers stop being shareable.  When torch is installed, bind to its copy up front."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for loc in (spec.submodule_search_locations if spec and spec.submodule_search_locations else []):
+        p = os.path.join(loc, "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+            return
+
+
 def load_library():
     """Returns the CDLL; raises if the HIP extension has not been built."""
     global _LIB
     if _LIB is not None:
         return _LIB
+    _share_torch_hip_runtime()
     path = library_path()
     if not os.path.exists(path):
         raise ImportError("libheifhip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
