@@ -34,6 +34,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=0, help="independent stills per rank and step (0 = workload default)")
     ap.add_argument("--qp", type=int, default=27)
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic contents cycled through the batch")
+    ap.add_argument("--streams", type=int, default=2, help="independent sub-batches on separate HIP streams (overlaps CABAC with reconstruction)")
+    ap.add_argument("--enc", action="append", default=[], help="override a synthetic-encoder parameter, e.g. --enc wpp=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -41,7 +43,7 @@ def parse_args():
 
 WORKLOADS = {
     # name: (width, height, default batch, encoder config)
-    "still4k": (3840, 2160, 256, dict(wpp=1)),
+    "still4k": (3840, 2160, 1024, dict(wpp=1)),
     "still1080": (1920, 1080, 1024, dict(wpp=1)),
     "grid8k": (1024, 1024, 48, dict(wpp=1, vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1)),
 }
@@ -73,6 +75,9 @@ def main():
 
     w, h, def_batch, enc_cfg = WORKLOADS[a.workload]
     enc_cfg = dict(enc_cfg, qp=a.qp)
+    for kv in a.enc:
+        k, v = kv.split("=")
+        enc_cfg[k] = int(v)
     grid = a.workload == "grid8k"
     if grid:
         total_items = 48
@@ -94,24 +99,44 @@ def main():
         streams = distinct
     else:
         streams = [distinct[i % len(distinct)] for i in range(nb)]
-        batch = Batch(streams)          # parses headers on the host and uploads everything to HBM
-        batch.alloc_rgb(10)
+        batch = None
     n_items = len(streams)
     bs_bytes = sum(len(s) for s in streams)
-    batch.timing_slots(max(1, a.steps))
+    # the step's stills are split into `--streams` sub-batches, each one set of launches on its own HIP stream
+    subs = []
+    if grid:
+        subs = [(batch, None)]
+    else:
+        k = max(1, min(a.streams, n_items))
+        for j in range(k):
+            part = streams[j::k]
+            b = Batch(part)          # parses headers on the host and uploads everything to HBM
+            b.alloc_rgb(10)
+            subs.append((b, lib.hipdec_stream_create() if k > 1 else None))
+        batch = subs[0][0]
+    for b, _ in subs:
+        b.timing_slots(max(1, a.steps))
     single = Batch([streams[0]])
     single.alloc_rgb(10)
 
     def step(b):
-        if b is batch and gd is not None:
+        if gd is not None and b is batch:
             gd.decode()
             if rank == 0:
                 gd.to_rgb((1, 13, 6, 1))
             return
-        b.run()
-        b.to_rgb_all()
+        if b is single:
+            b.run()
+            b.to_rgb_all()
+            return
+        for sb, st in subs:
+            sb.run(st)
+            sb.to_rgb_all(st)
 
     def sync():
+        for _, st in subs:
+            if st:
+                check(lib.hipdec_stream_synchronize(st))
         check(lib.hipdec_stream_synchronize(None))
         torch.cuda.synchronize()
 
@@ -123,8 +148,10 @@ def main():
         step(batch)
     sync()
     if a.warmup > 0:
-        batch.status()   # device-side decode errors are loud
-    batch.timing_slots(max(1, a.steps))
+        for b, _ in subs:
+            b.status()   # device-side decode errors are loud
+    for b, _ in subs:
+        b.timing_slots(max(1, a.steps))
     barrier(); sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -132,7 +159,8 @@ def main():
     sync(); barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    batch.status()
+    for b, _ in subs:
+        b.status()
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -143,10 +171,11 @@ def main():
 
     # ---- per-kernel device time over the timed region (HIP events on the launch stream) ----
     acc = dict(parse=0.0, recon=0.0, deblock=0.0, sao=0.0, total=0.0)
-    for k in range(a.steps):
-        t = batch.slot_timing_us(k)
-        for key in acc:
-            acc[key] += t[key]
+    for b, _ in subs:      # device time per kernel, summed over the sub-batches (they overlap in wall time)
+        for k in range(a.steps):
+            t = b.slot_timing_us(k)
+            for key in acc:
+                acc[key] += t[key]
     avg_us = {k: v / a.steps for k, v in acc.items()}
 
     # single-still latency form (one 4K still per pass)

@@ -64,6 +64,10 @@ HIPDEC_API int hipdec_memcpy_h2d(void* dst_dev, const void* src_host, size_t byt
 HIPDEC_API int hipdec_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
 HIPDEC_API int hipdec_memset(void* dst_dev, int value, size_t bytes);
 HIPDEC_API int hipdec_stream_synchronize(void* stream);
+/* additional HIP streams (hipStream_t as void*) so that independent batches overlap: the CABAC kernel keeps the
+ * scalar pipes busy while another batch's reconstruction / filters / colour stage use the vector pipes and HBM */
+HIPDEC_API void* hipdec_stream_create(void);
+HIPDEC_API void hipdec_stream_destroy(void* stream);
 
 /* ---- decoder ---------------------------------------------------------------------------------- */
 typedef struct hipdec_decoder hipdec_decoder;

@@ -74,6 +74,8 @@ def load_library():
     lib.hipdec_memcpy_d2h.argtypes = [vp, vp, sz]
     lib.hipdec_memset.argtypes = [vp, ci, sz]
     lib.hipdec_stream_synchronize.argtypes = [vp]
+    lib.hipdec_stream_create.restype = vp
+    lib.hipdec_stream_destroy.argtypes = [vp]
     np_ = C.POINTER(Nclx)
     lib.hipdec_color_420_to_rgb24.argtypes = [vp, sz, vp, sz, vp, sz, ci, ci, np_, vp, sz, ci, vp]
     lib.hipdec_color_ycbcr_to_rgb_planar.argtypes = [vp, sz, vp, sz, vp, sz, ci, ci, ci, ci, np_, vp, vp, vp, sz, vp]

@@ -1,6 +1,7 @@
 // batch_layout.hip — see batch_layout.h.  Plain C++ (also compiled by g++ for the CPU-test emulation).
 #include "batch_layout.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace hipdec {
@@ -31,6 +32,28 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
   b.num_subs = nsubs; b.num_rows = nrows;
   b.off_subs = off; off = align_up(off + sizeof(Substream) * nsubs, 256);
   b.off_rows = off; off = align_up(off + sizeof(RowDesc) * nrows, 256);
+  // Parser wavefronts.  A picture's substreams are dealt round-robin to W waves (wave j takes substreams
+  // j, j + W, ...): with WPP a wave that finishes row r continues with row r + W, whose predecessor row
+  // r + W - 1 is by then well ahead, so every resident wave stays busy instead of parking one wave per
+  // row behind its dependency.  W shrinks as the batch grows (the GPU holds ~7k parser waves; ~16 busy
+  // waves per CU saturate its scalar pipe); a lone still keeps one wave per substream (lowest latency).
+  std::vector<ParseWave> waves;
+  {
+    const uint32_t target_waves = 4096;
+    const char* force = getenv("HIPDEC_WAVES_PER_PICTURE");   // test / tuning override
+    uint32_t sub_base = 0;
+    for (auto& p : b.pics) {
+      const uint32_t ns = (uint32_t)p.subs.size();
+      uint32_t w = target_waves / (uint32_t)n;
+      if (force && atoi(force) > 0) w = (uint32_t)atoi(force);
+      if (w < 1) w = 1;
+      if (w > ns) w = ns;
+      for (uint32_t j = 0; j < w; j++) waves.push_back(ParseWave{sub_base + j, w, sub_base + ns, 0});
+      sub_base += ns;
+    }
+  }
+  b.num_waves = (uint32_t)waves.size();
+  b.off_waves = off; off = align_up(off + sizeof(ParseWave) * waves.size(), 256);
   b.params.assign(n, PicParams{});
   uint32_t row_base = 0;
   for (int i = 0; i < n; i++) {
@@ -79,6 +102,7 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
     const size_t nunits = nctb << P.units_per_ctb_log2;
     const size_t ctb2 = (size_t)1 << (2 * P.log2_ctb);
     P.off_sao = off; off = align_up(off + nctb * 3 * sizeof(SaoParams), 256);
+    P.off_handoff = off; off = align_up(off + nctb * HANDOFF_DWORDS * sizeof(uint32_t), 256);
     P.off_u_size = off; off = align_up(off + nunits, 256);
     P.off_u_flags = off; off = align_up(off + nunits, 256);
     P.off_u_ipm = off; off = align_up(off + nunits, 256);
@@ -102,6 +126,7 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
   // ---- stage + upload ----
   host.assign(b.upload_size, 0);
   memcpy(host.data() + b.off_pics, b.params.data(), sizeof(PicParams) * n);
+  memcpy(host.data() + b.off_waves, waves.data(), sizeof(ParseWave) * waves.size());
   Substream* subs = (Substream*)(host.data() + b.off_subs);
   RowDesc* rows = (RowDesc*)(host.data() + b.off_rows);
   uint32_t sub_base = 0, r = 0;

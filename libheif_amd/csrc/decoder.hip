@@ -50,7 +50,8 @@ int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* s
 int launch_all(hipdec_batch& b, hipStream_t s)
 {
   const int n = (int)b.params.size();
-  ParseArgs pa{(const PicParams*)(b.arena + b.off_pics), (const Substream*)(b.arena + b.off_subs), b.num_subs, b.arena,
+  ParseArgs pa{(const PicParams*)(b.arena + b.off_pics), (const Substream*)(b.arena + b.off_subs), (const ParseWave*)(b.arena + b.off_waves),
+               b.num_waves, b.arena,
                (uint32_t*)(b.arena + b.off_progress), b.arena + b.off_ctx, (uint32_t*)(b.arena + b.off_ticket), (int32_t*)(b.arena + b.off_status)};
   ReconArgs ra{(const PicParams*)(b.arena + b.off_pics), (const RowDesc*)(b.arena + b.off_rows), b.num_rows, b.arena,
                (uint32_t*)(b.arena + b.off_row_progress), (uint32_t*)(b.arena + b.off_ticket) + 1, (int32_t*)(b.arena + b.off_status)};

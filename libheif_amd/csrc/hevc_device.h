@@ -23,7 +23,8 @@
 
 namespace hipdec {
 
-enum : int { CTX_STORE = 192 };  // bytes per saved context table: 3 register groups x 64 lanes (parse_core.h)
+enum : int { CTX_STORE = 768,      // bytes per saved context table: 3 register groups x 64 lanes x 1 dword (parse_core.h)
+              HANDOFF_DWORDS = 16 };  // per-CTB record handed to the CTB below (SAO parameters + bottom-row sizes)
 
 enum : uint8_t {
   UF_CBF_LUMA = 1, UF_CBF_CB = 2, UF_CBF_CR = 4, UF_BYPASS = 8, UF_PCM = 16, UF_VEDGE = 32, UF_HEDGE = 64, UF_TS_LUMA = 128
@@ -73,6 +74,7 @@ struct PicParams {
   uint64_t off_ctb_info;          // CtbInfo[ctbs] (raster)
   uint64_t off_slices;            // SliceParams[nslices]
   uint64_t off_sao;               // SaoParams[ctbs*3]
+  uint64_t off_handoff;           // uint32[ctbs * HANDOFF_DWORDS]
   uint64_t off_u_size, off_u_flags, off_u_ipm, off_u_ipmc, off_u_qp;  // uint8[ctbs*units_per_ctb]
   uint64_t off_coeff[3];          // int16
   uint64_t off_rec[3];            // Pix (uint8 / uint16), coded size
@@ -116,10 +118,15 @@ enum : int32_t {
   DEV_ERR_TIMEOUT = 4       // a dependency wait exceeded its bound
 };
 
+struct ParseWave {  // one parser wavefront: substreams first, first + stride, ... < end (batch-global indices)
+  uint32_t first, stride, end, pad;
+};
+
 struct ParseArgs {
   const PicParams* pics;
   const Substream* subs;
-  uint32_t num_subs;
+  const ParseWave* waves;
+  uint32_t num_waves;
   uint8_t* arena;
   uint32_t* progress;   // per substream: CTBs completed
   uint8_t* ctx_store;   // per substream: CTX_STORE bytes, contexts after the 2nd CTB (WPP)

@@ -157,7 +157,8 @@ struct PS {
   VReg win, win_next;
   VReg m_size, m_flags, m_ipm, m_ipmc, m_qp;  // 4 units per lane, z-scan order
   VReg p_size, p_ipm;                           // previous CTB (left neighbour)
-  VReg up_size;                                 // lane ux: size byte of the bottom unit row of the CTB above
+  VReg up;                                      // hand-off record of the CTB above: lanes 0..8 SaoParams dwords, lanes 9..12 the
+                                                //   size bytes of its bottom unit row (4 units per lane)
   VReg sao, sao_left;                           // lanes 0..8: 3 dwords per component (SaoParams)
   // ---- picture constants (copied out of PicParams once)
   int32_t width, height, log2_ctb, log2_min_cb, log2_min_tb, log2_max_tb, max_th_depth_intra;
@@ -223,11 +224,12 @@ PC_DEV uint32_t fetch_byte(PS& s, uint32_t pos)
 }
 PC_DEV uint32_t read_byte(PS& s)
 {
-  if (s.pos >= s.end) { s.pos++; if (s.pos > s.end + 8) s.err = DEV_ERR_BITSTREAM_END; return 0; }
-  uint32_t b = fetch_byte(s, s.pos++);
-  if (s.zeros >= 2 && b == 3 && s.pos < s.end) {  // emulation_prevention_three_byte
+  uint32_t b;
+  for (;;) {   // (a loop so that the window fetch is emitted once per call site)
+    if (s.pos >= s.end) { s.pos++; if (s.pos > s.end + 8) s.err = DEV_ERR_BITSTREAM_END; return 0; }
     b = fetch_byte(s, s.pos++);
-    s.zeros = 0;
+    if (s.zeros >= 2 && b == 3 && s.pos < s.end) { s.zeros = 0; continue; }  // emulation_prevention_three_byte
+    break;
   }
   s.zeros = b == 0 ? s.zeros + 1 : 0;
   return b;
@@ -242,31 +244,29 @@ PC_DEV void cabac_start(PS& s, uint32_t start, uint32_t end)
 PC_DEV int decode_bin(PS& s, VReg& grp, int ctx_lane)
 {
   uint32_t st = pc_rdlane(grp, ctx_lane);
-  uint32_t p_state = st >> 1;
+  const uint32_t p_state = st >> 1;
   const uint32_t lps = (pc_rdlane(s.t_lps, (int)p_state) >> ((s.range >> 3) & 24u)) & 255u;
-  s.range -= lps;
-  const uint32_t scaled = s.range << 7;
-  int bin;
-  if (s.value < scaled) {
+  uint32_t range = s.range - lps;
+  const uint32_t scaled = range << 7;
+  int bin, nb;
+  if (__builtin_expect(s.value < scaled, 1)) {   // MPS: at most one renormalisation shift
     bin = (int)(st & 1u);
-    if (p_state < 62) { st += 2; pc_wrlane(grp, ctx_lane, st); }
-    if (scaled < (256u << 7)) {
-      s.range = scaled >> 6;
-      s.value <<= 1;
-      if (++s.bits_needed == 0) { s.bits_needed = -8; s.value += read_byte(s); }
-    }
-  } else {
-    uint32_t mps = st & 1u;
-    bin = (int)(mps ^ 1u);
-    const int num_bits = pc_clz(lps) - 23;
-    s.value = (s.value - scaled) << num_bits;
-    s.range = lps << num_bits;
-    if (p_state == 0) mps ^= 1u;
-    p_state = pc_rdlane(s.t_next, (int)p_state) & 63u;
-    pc_wrlane(grp, ctx_lane, (p_state << 1) | mps);
-    s.bits_needed += num_bits;
-    if (s.bits_needed >= 0) { s.value += read_byte(s) << s.bits_needed; s.bits_needed -= 8; }
+    st += p_state < 62 ? 2u : 0u;
+    nb = scaled < (256u << 7) ? 1 : 0;
+    range <<= nb;
+  } else {                                        // LPS
+    bin = (int)((st & 1u) ^ 1u);
+    nb = pc_clz(lps) - 23;
+    s.value -= scaled;
+    range = lps << nb;
+    const uint32_t mps = p_state == 0 ? (st & 1u) ^ 1u : (st & 1u);
+    st = ((pc_rdlane(s.t_next, (int)p_state) & 63u) << 1) | mps;
   }
+  pc_wrlane(grp, ctx_lane, st);
+  s.range = range;
+  s.value <<= nb;
+  s.bits_needed += nb;
+  if (__builtin_expect(s.bits_needed >= 0, 0)) { s.value += read_byte(s) << s.bits_needed; s.bits_needed -= 8; }
   return bin;
 }
 PC_DEV int decode_bypass(PS& s)
@@ -333,7 +333,7 @@ PC_DEV int left_cb_log2(PS& s, int ux, int uy)
 PC_DEV int up_cb_log2(PS& s, int ux, int uy)
 {
   if (uy > 0) return (int)(map_get(s.m_size, (int)interleave4((uint32_t)ux, (uint32_t)uy - 1)) >> 4);
-  if (s.ctb_avail & AV_UP) return (int)((pc_rdlane(s.up_size, ux) & 255u) >> 4);
+  if (s.ctb_avail & AV_UP) return (int)(((pc_rdlane(s.up, 9 + (ux >> 2)) >> ((ux & 3) * 8)) & 255u) >> 4);
   return 0;
 }
 // 8.6.1 (qPY_A / qPY_B only count inside the current CTB)
@@ -647,17 +647,23 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
     const int cbf_cb = (int)((cbf_cb_bits >> depth) & 1u), cbf_cr = (int)((cbf_cr_bits >> depth) & 1u);
     if ((cbf_luma | cbf_cb | cbf_cr) && (s.tools & TOOL_CUQPD) && !s.is_cu_qp_delta_coded) parse_cu_qp_delta(s);
     const int luma_mode = (int)(map_get(s.m_ipm, zu) & 63u);
-    int ts_y = 0, ts_cb = 0, ts_cr = 0;
-    if (cbf_luma) { ts_y = residual_coding(s, t, 0, luma_mode); flush_coef(s, coef_y + zu * 16, 1 << (2 * t)); }
     int do_chroma = 0, zc = zu, tc = t - 1;
     if (s.chroma_format_idc) {
       if (t > 2) do_chroma = 1;
       else if ((q & 3) == 3) { do_chroma = 1; zc = zb + (q & ~3); tc = 2; }
     }
-    if (do_chroma) {
-      if (cbf_cb) { ts_cb = residual_coding(s, tc, 1, chroma_mode); flush_coef(s, coef_cb + zc * 4, 1 << (2 * tc)); }
-      if (cbf_cr) { ts_cr = residual_coding(s, tc, 2, chroma_mode); flush_coef(s, coef_cr + zc * 4, 1 << (2 * tc)); }
+    // one residual_coding instance for the three components (keeps the hot code small)
+    uint32_t ts_bits = 0;
+#pragma clang loop unroll(disable)
+    for (int c = 0; c < 3; c++) {
+      const int coded = c == 0 ? cbf_luma : (do_chroma && (c == 1 ? cbf_cb : cbf_cr));
+      if (!coded) continue;
+      const int lg = c == 0 ? t : tc;
+      int16_t* dst = c == 0 ? coef_y + zu * 16 : (c == 1 ? coef_cb : coef_cr) + zc * 4;
+      ts_bits |= (uint32_t)residual_coding(s, lg, c, c == 0 ? luma_mode : chroma_mode) << c;
+      flush_coef(s, dst, 1 << (2 * lg));
     }
+    const int ts_y = (int)(ts_bits & 1u), ts_cb = (int)((ts_bits >> 1) & 1u), ts_cr = (int)((ts_bits >> 2) & 1u);
     // TU-level map fill: size, cbf, transform-skip, deblocking edges (8.7.2.2 / 8.7.2.3)
     {
       const int tux0 = (int)compact1by1((uint32_t)zu), tuy0 = (int)compact1by1((uint32_t)zu >> 1);
@@ -701,14 +707,14 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
 
 // ---- 7.3.8.3 sao: parameters are kept in lanes 0..8 of s.sao as SaoParams dwords -----------------
 //   dword 3c+0: type | band_or_class << 8 | offset[0] << 16     3c+1: offset[1] | offset[2] << 16     3c+2: offset[3]
-PC_DEV void parse_sao(PS& s, const uint32_t* sao_up /*global, CTB above*/, int allow_left, int allow_up)
+PC_DEV void parse_sao(PS& s, int allow_left, int allow_up)
 {
   int merge_left = 0, merge_up = 0;
   if (allow_left) merge_left = decode_bin(s, s.ctxA, A_SAO_MERGE);
   if (allow_up && !merge_left) merge_up = decode_bin(s, s.ctxA, A_SAO_MERGE);
   const int ncomp = s.chroma_format_idc ? 3 : 1;
   if (merge_left) { PC_VEC_BEGIN PC_L(s.sao) = PC_L(s.sao_left); PC_VEC_END return; }
-  if (merge_up) { PC_VEC_BEGIN PC_L(s.sao) = lane < 9 ? sao_up[lane] : 0u; PC_VEC_END return; }
+  if (merge_up) { PC_VEC_BEGIN PC_L(s.sao) = lane < 9 ? PC_L(s.up) : 0u; PC_VEC_END return; }
   PC_VEC_BEGIN PC_L(s.sao) = 0u; PC_VEC_END
   int type1 = 0, cls1 = 0;
   for (int c = 0; c < ncomp; c++) {
@@ -741,38 +747,47 @@ PC_DEV void parse_sao(PS& s, const uint32_t* sao_up /*global, CTB above*/, int a
 }
 
 // ---- platform glue for the cross-wave protocol ----------------------------------------------------
+// Cross-wave hand-off (WPP): what the row below needs from a CTB — its SAO parameters, the size bytes of
+// its bottom unit row and, once per row, the context snapshot — is tiny, so it travels as write-through
+// (sc1) dword stores into a per-CTB record, drained with s_waitcnt and followed by ONE relaxed agent-scope
+// progress store; the consumer polls that word and reads the record with sc1 loads.  No release / acquire
+// fence, i.e. no L2 write-back and no L1 invalidate per CTB (cdna guide, Guideline 16, form R1).  The bulk
+// outputs (unit maps, coefficients) are plain stores: only later kernels read them.
 #if defined(HIPDEC_HOST_EMU)
 // the emulation runs substreams one after the other in order, so a dependency is always satisfied
 PC_DEV int pc_wait_progress(const uint32_t* word, uint32_t need, const int32_t*) { return *word >= need ? 0 : DEV_ERR_TIMEOUT; }
 PC_DEV void pc_publish(uint32_t* word, uint32_t v) { *word = v; }
 PC_DEV void pc_report(int32_t* status, int32_t code) { if (*status == 0) *status = code; }
+PC_DEV void pc_store_wt(uint32_t* p, uint32_t v) { *p = v; }
+PC_DEV uint32_t pc_load_wt(const uint32_t* p) { return *p; }
+PC_DEV void pc_drain() {}
 #else
 PC_DEV int pc_wait_progress(const uint32_t* word, uint32_t need, const int32_t* status)
 {
-  // bounded spin: relaxed agent-scope poll + ONE acquire (cdna guide, Guideline 16)
   int err = 0;
   uint32_t spins = 0;
-  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-    __builtin_amdgcn_s_sleep(2);
+  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {   // bounded spin
+    __builtin_amdgcn_s_sleep(4);
     if (++spins > (1u << 24) || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { err = DEV_ERR_TIMEOUT; break; }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return err;
 }
+PC_DEV void pc_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 PC_DEV void pc_publish(uint32_t* word, uint32_t v)
 {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  pc_drain();   // this wave is the only writer of the record
   if (threadIdx.x == 0) __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 PC_DEV void pc_report(int32_t* status, int32_t code) { if (threadIdx.x == 0) atomicCAS((int*)status, 0, code); }
+PC_DEV void pc_store_wt(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PC_DEV uint32_t pc_load_wt(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 #endif
 
 PC_DEV uint32_t uload32(const void* p) { return pc_uni(*(const uint32_t*)p); }
 PC_DEV uint64_t uload64(const void* p) { return (uint64_t)uload32(p) | ((uint64_t)uload32((const uint8_t*)p + 4) << 32); }
 
 // One CABAC substream (slice segment / tile / WPP row), start to finish.
-PC_DEV void parse_substream(const ParseArgs& A, uint32_t sub_idx, Lds* lds)
+PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_dep, Lds* lds)
 {
   PS s;
   const Substream* subp = A.subs + sub_idx;
@@ -818,6 +833,7 @@ PC_DEV void parse_substream(const ParseArgs& A, uint32_t sub_idx, Lds* lds)
   const uint16_t* ts_to_rs = (const uint16_t*)(arena + uload64(&P->off_ctb_ts_to_rs));
   const CtbInfo* ctb_info = (const CtbInfo*)(arena + uload64(&P->off_ctb_info));
   uint32_t* sao_all = (uint32_t*)(arena + uload64(&P->off_sao));
+  uint32_t* handoff = (uint32_t*)(arena + uload64(&P->off_handoff));   // HANDOFF_DWORDS per CTB (raster)
   uint8_t* const g_size = arena + uload64(&P->off_u_size);
   uint8_t* const g_flags = arena + uload64(&P->off_u_flags);
   uint8_t* const g_ipm = arena + uload64(&P->off_u_ipm);
@@ -835,7 +851,7 @@ PC_DEV void parse_substream(const ParseArgs& A, uint32_t sub_idx, Lds* lds)
   load_tables(s);
   PC_VEC_BEGIN
     PC_L(s.m_size) = 0; PC_L(s.m_flags) = 0; PC_L(s.m_ipm) = 0; PC_L(s.m_ipmc) = 0; PC_L(s.m_qp) = 0;
-    PC_L(s.p_size) = 0; PC_L(s.p_ipm) = 0; PC_L(s.up_size) = 0; PC_L(s.sao) = 0; PC_L(s.sao_left) = 0;
+    PC_L(s.p_size) = 0; PC_L(s.p_ipm) = 0; PC_L(s.up) = 0; PC_L(s.sao) = 0; PC_L(s.sao_left) = 0;
     PC_L(s.ctxA) = 0; PC_L(s.ctxB) = 0; PC_L(s.ctxC) = 0; PC_L(s.win) = 0; PC_L(s.win_next) = 0;
   PC_VEC_END
   cabac_start(s, byte_start, byte_end);
@@ -847,7 +863,7 @@ PC_DEV void parse_substream(const ParseArgs& A, uint32_t sub_idx, Lds* lds)
     s.x_ctb = cx << s.log2_ctb; s.y_ctb = cy << s.log2_ctb; s.ctb_avail = (int)((ci >> 16) & 255u);
 
     // ---- WPP dependency on the CTB row above ----
-    if (dep_sub >= 0) {
+    if (dep_sub >= 0 && !same_wave_dep) {   // (a predecessor decoded earlier by this very wave is complete)
       const uint32_t need = k + 2 < dep_len ? k + 2 : dep_len;
       const int e = pc_wait_progress(A.progress + dep_sub, need, A.status);
       if (e) { s.err = e; break; }
@@ -855,22 +871,22 @@ PC_DEV void parse_substream(const ParseArgs& A, uint32_t sub_idx, Lds* lds)
     // ---- context initialisation / synchronisation (9.3.1) ----
     if (k == 0) {
       if (wpp_sync && dep_sub >= 0) {
-        const uint8_t* src = A.ctx_store + (size_t)dep_sub * CTX_STORE;
+        const uint32_t* src = (const uint32_t*)(A.ctx_store + (size_t)dep_sub * CTX_STORE);
         PC_VEC_BEGIN
-          PC_L(s.ctxA) = src[lane]; PC_L(s.ctxB) = src[64 + lane]; PC_L(s.ctxC) = src[128 + lane];
+          PC_L(s.ctxA) = pc_load_wt(src + lane); PC_L(s.ctxB) = pc_load_wt(src + 64 + lane); PC_L(s.ctxC) = pc_load_wt(src + 128 + lane);
         PC_VEC_END
       } else init_contexts(s);
     }
-    // ---- neighbour row above this CTB ----
+    // ---- hand-off record of the CTB above ----
     if (s.ctb_avail & AV_UP) {
-      const uint8_t* src = g_size + ((size_t)(ctb_rs - ctb_w) << units_log2);
+      const uint32_t* src = handoff + (size_t)(ctb_rs - ctb_w) * HANDOFF_DWORDS;
       PC_VEC_BEGIN
-        PC_L(s.up_size) = lane < uw ? (uint32_t)src[interleave4((uint32_t)lane, (uint32_t)uw - 1)] : 0u;
+        PC_L(s.up) = lane < 13 ? pc_load_wt(src + lane) : 0u;
       PC_VEC_END
     }
     // ---- coding_tree_unit ----
     if (s.sao_luma || s.sao_chroma) {
-      parse_sao(s, sao_all + (size_t)(ctb_rs - ctb_w) * 9, (s.ctb_avail & AV_LEFT) && k > 0, (s.ctb_avail & AV_UP) ? 1 : 0);
+      parse_sao(s, (s.ctb_avail & AV_LEFT) && k > 0, (s.ctb_avail & AV_UP) ? 1 : 0);
     } else {
       PC_VEC_BEGIN PC_L(s.sao) = 0u; PC_VEC_END
     }
@@ -939,16 +955,31 @@ PC_DEV void parse_substream(const ParseArgs& A, uint32_t sub_idx, Lds* lds)
         // this CTB becomes the left neighbour of the next one
         PC_L(s.p_size) = PC_L(s.m_size); PC_L(s.p_ipm) = PC_L(s.m_ipm); PC_L(s.sao_left) = PC_L(s.sao);
       PC_VEC_END
-      if (has_dependent && k == 1) {
-        uint8_t* dst = A.ctx_store + (size_t)sub_idx * CTX_STORE;
+      // hand-off record for the CTB below: lanes 0..8 SAO, 9..12 bottom-row size bytes
+      {
+        VReg rec;
+        PC_VEC_BEGIN PC_L(rec) = PC_L(s.sao); PC_VEC_END
+        for (int j = 0; j < (uw + 3) / 4; j++) {
+          uint32_t w = 0;
+          for (int b = 0; b < 4 && 4 * j + b < uw; b++) w |= map_get(s.m_size, (int)interleave4((uint32_t)(4 * j + b), (uint32_t)uw - 1)) << (8 * b);
+          pc_wrlane(rec, 9 + j, w);
+        }
+        uint32_t* dst = handoff + (size_t)ctb_rs * HANDOFF_DWORDS;
         PC_VEC_BEGIN
-          dst[lane] = (uint8_t)PC_L(s.ctxA); dst[64 + lane] = (uint8_t)PC_L(s.ctxB); dst[128 + lane] = (uint8_t)PC_L(s.ctxC);
+          if (lane < 13) pc_store_wt(dst + lane, PC_L(rec));
+        PC_VEC_END
+      }
+      if (has_dependent && k == 1) {
+        uint32_t* dst = (uint32_t*)(A.ctx_store + (size_t)sub_idx * CTX_STORE);
+        PC_VEC_BEGIN
+          pc_store_wt(dst + lane, PC_L(s.ctxA)); pc_store_wt(dst + 64 + lane, PC_L(s.ctxB)); pc_store_wt(dst + 128 + lane, PC_L(s.ctxC));
         PC_VEC_END
       }
     }
-    if (has_dependent) pc_publish(A.progress + sub_idx, k + 1);
+    if (has_dependent) pc_publish(A.progress + sub_idx, k + 1); else pc_drain();
   }
   if (s.err) pc_report(A.status, s.err | (int32_t)(sub_idx << 8));
+  return s.err;
 }
 
 }  // namespace pcore

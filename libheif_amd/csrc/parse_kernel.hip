@@ -18,16 +18,19 @@ __global__ __launch_bounds__(64) void k_parse(ParseArgs A)
   const int lane = (int)threadIdx.x;
   uint32_t t = 0;
   if (lane == 0) t = atomicAdd(A.ticket, 1u);
-  const uint32_t sub_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+  const uint32_t wave_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
   for (int i = lane * 8; i < 32 * 32; i += 512) *(uint4*)&lds.coef[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
-  if (sub_idx >= A.num_subs) return;
-  pcore::parse_substream(A, sub_idx, &lds);
+  if (wave_idx >= A.num_waves) return;
+  const uint32_t first = pcore::uload32(&A.waves[wave_idx].first), stride = pcore::uload32(&A.waves[wave_idx].stride),
+                 end = pcore::uload32(&A.waves[wave_idx].end);
+  for (uint32_t sub = first; sub < end; sub += stride)
+    if (pcore::parse_substream(A, sub, stride == 1, &lds)) break;
 }
 
 void launch_parse(const ParseArgs& a, hipStream_t s)
 {
-  if (a.num_subs) hipLaunchKernelGGL(k_parse, dim3(a.num_subs), dim3(64), 0, s, a);
+  if (a.num_waves) hipLaunchKernelGGL(k_parse, dim3(a.num_waves), dim3(64), 0, s, a);
 }
 
 }  // namespace hipdec

@@ -106,6 +106,15 @@ int hipdec_memset(void* dst, int value, size_t bytes)
   HIPDEC_CHECK_HIP(hipMemset(dst, value, bytes));
   return 0;
 }
+void* hipdec_stream_create(void)
+{
+  if (ensure_init()) return nullptr;
+  hipStream_t s = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e != hipSuccess) { set_error(HIPDEC_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); return nullptr; }
+  return (void*)s;
+}
+void hipdec_stream_destroy(void* stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
 int hipdec_stream_synchronize(void* stream)
 {
   if (int rc = ensure_init()) return rc;

@@ -47,11 +47,19 @@ int emu_run_parse(EmuBatch* b)
 {
   uint8_t* a = b->arena.data();
   memset(a + b->L.off_ctrl, 0, b->L.ctrl_size);
-  ParseArgs A{(const PicParams*)(a + b->L.off_pics), (const Substream*)(a + b->L.off_subs), b->L.num_subs, a,
+  ParseArgs A{(const PicParams*)(a + b->L.off_pics), (const Substream*)(a + b->L.off_subs), (const ParseWave*)(a + b->L.off_waves),
+              b->L.num_waves, a,
               (uint32_t*)(a + b->L.off_progress), a + b->L.off_ctx, (uint32_t*)(a + b->L.off_ticket), (int32_t*)(a + b->L.off_status)};
   pcore::Lds lds;
   memset(&lds, 0, sizeof(lds));
-  for (uint32_t s = 0; s < b->L.num_subs; s++) pcore::parse_substream(A, s, &lds);
+  // every substream once, in index order (the wave table only changes WHICH wave runs a substream)
+  std::vector<uint8_t> covered(b->L.num_subs, 0);
+  for (uint32_t w = 0; w < A.num_waves; w++)
+    for (uint32_t s = A.waves[w].first; s < A.waves[w].end; s += A.waves[w].stride) covered[s]++;
+  for (uint32_t s = 0; s < b->L.num_subs; s++) {
+    if (covered[s] != 1) { b->status = -1; return -1; }
+    pcore::parse_substream(A, s, 0, &lds);
+  }
   b->status = *(int32_t*)(a + b->L.off_status);
   return b->status;
 }

@@ -102,6 +102,24 @@ def test_batch_of_independent_items_matches_single_decodes():
     assert t["total"] > 0
 
 
+@pytest.mark.parametrize("waves", [1, 2, 3, 5])
+def test_fewer_parser_waves_than_substreams(waves, monkeypatch):
+    """large batches deal a picture's substreams round-robin to W < n waves (WPP rows r, r+W, ... per wave)"""
+    from libheif_amd.decoder import Batch
+    monkeypatch.setenv("HIPDEC_WAVES_PER_PICTURE", str(waves))
+    streams = [orc.encode(orc.synth_image(264, 456, 8, 1, seed=70), log2_ctb=5, log2_max_tb=5),            # 15 WPP rows
+               orc.encode(orc.synth_image(200, 136, 8, 1, seed=71), tile_cols=3, tile_rows=2, wpp=0),       # 6 tiles
+               orc.encode(orc.synth_image(200, 136, 8, 1, seed=72), num_slices=3, wpp=1),
+               orc.encode(orc.synth_image(136, 200, 8, 1, seed=73), wpp=0)]
+    b = Batch(streams)
+    b.run(); b.status()
+    for i, s in enumerate(streams):
+        ref = orc.decode(s)
+        got = b.planes(i)
+        for c in range(3):
+            np.testing.assert_array_equal(got[c], ref["planes"][c], err_msg="item %d component %d" % (i, c))
+
+
 def test_fused_rgb_after_decode_matches_oracle_chain():
     from libheif_amd.decoder import Batch
     planes = orc.synth_image(200, 136, 8, 1, seed=21)
