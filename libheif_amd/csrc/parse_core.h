@@ -269,6 +269,28 @@ PC_DEV int decode_bin(PS& s, VReg& grp, int ctx_lane)
   if (__builtin_expect(s.bits_needed >= 0, 0)) { s.value += read_byte(s) << s.bits_needed; s.bits_needed -= 8; }
   return bin;
 }
+// branch-free variant (selects instead of the MPS / LPS diamond); kept beside decode_bin for the microbenchmark
+PC_DEV int decode_bin_sel(PS& s, VReg& grp, int ctx_lane)
+{
+  const uint32_t st = pc_rdlane(grp, ctx_lane);
+  const uint32_t p_state = st >> 1, mps = st & 1u;
+  const uint32_t lps = (pc_rdlane(s.t_lps, (int)p_state) >> ((s.range >> 3) & 24u)) & 255u;
+  const uint32_t nxt = pc_rdlane(s.t_next, (int)p_state) & 63u;
+  const uint32_t range1 = s.range - lps;
+  const uint32_t scaled = range1 << 7;
+  const bool is_lps = s.value >= scaled;
+  const uint32_t st_m = st + (p_state < 62 ? 2u : 0u);
+  const uint32_t st_l = (nxt << 1) | (p_state == 0 ? mps ^ 1u : mps);
+  const int nb_m = scaled < (256u << 7) ? 1 : 0;
+  const int nb_l = pc_clz(lps) - 23;
+  const int nb = is_lps ? nb_l : nb_m;
+  pc_wrlane(grp, ctx_lane, is_lps ? st_l : st_m);
+  s.value = (is_lps ? s.value - scaled : s.value) << nb;
+  s.range = (is_lps ? lps : range1) << nb;
+  s.bits_needed += nb;
+  if (__builtin_expect(s.bits_needed >= 0, 0)) { s.value += read_byte(s) << s.bits_needed; s.bits_needed -= 8; }
+  return (int)(mps ^ (is_lps ? 1u : 0u));
+}
 PC_DEV int decode_bypass(PS& s)
 {
   s.value <<= 1;

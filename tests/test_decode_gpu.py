@@ -180,3 +180,23 @@ def test_reference_fixtures_match_oracle(reference_dir):
             img = _decode_gpu(s)
             for c in range(len(ref["planes"])):
                 np.testing.assert_array_equal(img.planes[c], ref["planes"][c])
+
+
+@pytest.mark.parametrize("size,cfg", [((3840, 2160), dict()), ((1920, 1080), dict(tile_cols=4, tile_rows=2, wpp=0)), ((1024, 1024), dict(stress=1))],
+                         ids=["4k_wpp", "1080p_tiles", "grid_tile_stress"])
+def test_full_size_stills_match_oracle(size, cfg):
+    """BASELINE.json's full sizes (config 1 still, config 5 still, config 3 tile): bit-exact planes and the
+    fused RGB of the whole picture; a batch of replicas must reproduce the same planes (idempotence)."""
+    import hashlib
+    from libheif_amd.decoder import Batch
+    from tools import streamgen
+    stream = streamgen.make_stream(size[0], size[1], 1, 8, **cfg)
+    ref = orc.decode(stream)
+    b = Batch([stream, stream, stream])
+    b.run(); b.status()
+    b.run(); b.status()      # a second run over the same arena (control words are re-zeroed every run)
+    for i in range(3):
+        got = b.planes(i)
+        for c in range(3):
+            np.testing.assert_array_equal(got[c], ref["planes"][c], err_msg="item %d component %d" % (i, c))
+    assert b.info(0)["num_substreams"] == ref["n_substreams"]
