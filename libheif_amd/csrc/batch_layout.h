@@ -17,7 +17,7 @@ struct BatchLayout {
   size_t off_progress = 0, off_ctx = 0, off_row_progress = 0, off_ticket = 0, off_status = 0;
   uint32_t num_subs = 0, num_rows = 0, num_waves = 0;
   bool wide = false;  // samples wider than 8 bit -> uint16 planes
-  int max_w = 0, max_h = 0, max_ow = 0, max_oh = 0;
+  int max_w = 0, max_h = 0, max_ow = 0, max_oh = 0, max_ctbs = 0;
 };
 
 // Parses n items, lays the arena out ([upload region][control words][device-only buffers]) and

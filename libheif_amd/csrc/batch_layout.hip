@@ -85,13 +85,14 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
     P.off_slices = off; off = align_up(off + pp.slice_params.size() * sizeof(SliceParams), 256);
     P.off_bitstream = off; P.bitstream_size = sizes[i]; off = align_up(off + sizes[i] + 512, 256);
     b.max_w = std::max(b.max_w, P.width); b.max_h = std::max(b.max_h, P.height);
+    b.max_ctbs = std::max(b.max_ctbs, P.ctb_w * P.ctb_h);
     b.max_ow = std::max(b.max_ow, P.out_width); b.max_oh = std::max(b.max_oh, P.out_height);
   }
   b.upload_size = off;
   // control words (zeroed before every run)
   b.off_ctrl = off;
   b.off_progress = off; off = align_up(off + sizeof(uint32_t) * nsubs, 256);
-  b.off_row_progress = off; off = align_up(off + sizeof(uint32_t) * nrows, 256);
+  b.off_row_progress = off; off = align_up(off + sizeof(uint32_t) * nrows * 3, 256);   // per (CTB row, component)
   b.off_ticket = off; off += 256;  // [0] parse ticket, [1] recon ticket
   b.off_status = off; off += 256;
   b.ctrl_size = off - b.off_ctrl;
@@ -116,6 +117,7 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
       const size_t w = c ? (size_t)P.ctb_w * ctb / 2 : (size_t)P.ctb_w * ctb, h = c ? (size_t)P.ctb_h * ctb / 2 : (size_t)P.ctb_h * ctb;
       P.rec_stride[c] = (uint32_t)align_up(w * es, 64);
       P.off_rec[c] = off; off = align_up(off + (size_t)P.rec_stride[c] * (h + 1), 256);
+      P.off_line[c] = off; off = align_up(off + (size_t)P.rec_stride[c] * (size_t)P.ctb_h + 256, 256);
       const size_t ow = c ? P.out_cwidth : P.out_width, oh = c ? P.out_cheight : P.out_height;
       P.out_stride[c] = (uint32_t)align_up(std::max<size_t>(ow, 1) * es, 64);
       P.off_out[c] = off; off = align_up(off + (size_t)P.out_stride[c] * std::max<size_t>(oh, 1), 256);

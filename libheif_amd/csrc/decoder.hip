@@ -72,6 +72,7 @@ int launch_all(hipdec_batch& b, hipStream_t s)
   launch_parse(pa, s);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[1], s));
   if (int rc = step("parse")) return rc;
+  launch_residual(fa, n, b.max_ctbs, s);
   launch_recon(ra, b.wide, s);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[2], s));
   if (int rc = step("recon")) return rc;

@@ -79,6 +79,7 @@ struct PicParams {
   uint64_t off_coeff[3];          // int16
   uint64_t off_rec[3];            // Pix (uint8 / uint16), coded size
   uint64_t off_out[3];            // Pix, cropped size
+  uint64_t off_line[3];           // bottom sample row of every CTB row (ctb_h rows x rec_stride bytes): recon row hand-off
   uint32_t rec_stride[3];         // bytes
   uint32_t out_stride[3];         // bytes
   uint32_t first_row;             // index of this picture's first CTB row in the batch row table

@@ -11,7 +11,7 @@ struct ReconArgs {
   const RowDesc* rows;
   uint32_t num_rows;
   uint8_t* arena;
-  uint32_t* row_progress;  // per batch row: CTBs completed
+  uint32_t* row_progress;  // per (batch row, component): CTBs completed
   uint32_t* ticket;
   int32_t* status;
 };
@@ -22,6 +22,7 @@ struct FilterArgs {
 };
 
 void launch_parse(const ParseArgs& a, hipStream_t s);
+void launch_residual(const FilterArgs& a, int n_pics, int max_ctbs, hipStream_t s);
 void launch_recon(const ReconArgs& a, bool wide, hipStream_t s);
 void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s);
 void launch_sao(const FilterArgs& a, int n_pics, int max_out_w, int max_out_h, bool wide, hipStream_t s);

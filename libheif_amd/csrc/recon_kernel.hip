@@ -1,21 +1,25 @@
-// recon_kernel.hip — intra prediction + dequantisation + inverse DCT/DST + reconstruction.
+// recon_kernel.hip — intra sample prediction + residual add: the reconstruction wavefront.
 //
-// Stands in for libde265's decode_TU / intra-prediction / transform stages behind de265_decode()
-// (reference call site libheif/plugins/decoder_libde265.cc:402).  ITU-T H.265 8.4.4.2 (intra sample
-// prediction incl. reference substitution and smoothing), 8.6.2-8.6.4 (scaling, transforms).
+// Stands in for libde265's intra-prediction / reconstruction stage behind de265_decode()
+// (reference call site libheif/plugins/decoder_libde265.cc:402).  ITU-T H.265 8.4.4.2 (reference sample
+// availability + substitution, [1 2 1] / strong smoothing, planar / DC / angular prediction with their edge
+// filters).  The residuals were already produced in place of the coefficients by residual_kernel.hip.
 //
 // MI355X mapping
 //   * intra prediction makes every block depend on its left / above / above-right neighbours, so the
-//     parallelism is the classic 2-CTB-lag wavefront over CTB rows: one 64-lane wavefront per CTB row
-//     of each picture; rows of ALL pictures of a batch run concurrently (ticket-ordered so a row's
-//     predecessor is always resident; progress words use agent-scope release/acquire).
-//   * the CTB being reconstructed lives in LDS (luma + chroma tiles with their top / left borders), so
-//     reference-sample gathering, smoothing, prediction and the two transform passes never touch
-//     HBM; the finished CTB leaves LDS once with row-contiguous stores.
-//   * inside a block the 64 lanes split the samples (prediction: n*n/64 samples per lane; transform:
-//     n*n/64 outputs per lane per pass), coefficients arrive as one contiguous int16 block per TU.
-//   * HBM traffic per luma pixel: 3 B coefficients (only where cbf) + 0.3 B maps in, 1.5*s out — the
-//     kernel is bound by the dependency wavefront, not by bandwidth.
+//     parallelism is the 2-CTB-lag wavefront over CTB rows, times the colour components (Y, Cb, Cr predict
+//     independently): one 64-lane wavefront per (CTB row, component) of every picture of the batch, all
+//     running concurrently; tickets are handed out row by row so a wave's predecessor (the row above, same
+//     component) always holds an earlier ticket, i.e. is resident or finished.
+//   * the CTB being reconstructed lives in LDS (tile + top / left borders + reference-sample line), so
+//     gathering, substitution, smoothing and prediction never touch HBM; the finished CTB leaves LDS once
+//     with row-contiguous stores.
+//   * row-to-row hand-off without fences (cdna guide, Guideline 16 form R1): the bottom sample row of every
+//     CTB goes to a per-picture line buffer with write-through (sc1) stores, is drained with s_waitcnt and
+//     announced with one relaxed agent-scope progress store; the row below polls that word and reads its
+//     top border from the line buffer with sc1 loads.  The reconstruction planes themselves are plain
+//     stores (only the next kernel reads them).
+//   * HBM traffic per luma pixel: 1.5*s written + <= 3 B residual and 0.3 B unit maps read.
 #include <hip/hip_runtime.h>
 #include "hevc_device.h"
 #include "kernels.h"
@@ -25,26 +29,17 @@ namespace hipdec {
 
 namespace {
 
-__constant__ int8_t c_dct_c[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
-                                   61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0};
-__constant__ int8_t c_dst[16] = {29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29};
 __constant__ int8_t c_angle[35] = {0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
                                    -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32};
 __constant__ int16_t c_inv_angle[15] = {-4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096};
-__constant__ uint8_t c_chroma_qp[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37};
-__constant__ int c_level_scale[6] = {40, 45, 51, 57, 64, 72};
 
 template <typename Pix>
 struct ReconLds {
-  Pix tile_y[64 * 64];
-  Pix tile_c[2][32 * 32];
-  Pix top_y[132], top_c[2][68];
-  Pix left_y[64], left_c[2][32];
+  Pix tile[64 * 64];        // the CTB of this wave's component
+  uint32_t top_raw[72];     // words of the line buffer covering x_ctb - 1 .. x_ctb + 2 * ctb - 1 (+ one pad word in front)
+  Pix left[64];
   uint16_t ref0[132], ref1[132];
-  int16_t blk[32 * 32], tmp[32 * 32];
-  int8_t dct[32 * 32];
   uint8_t m_size[256], m_flags[256], m_ipm[256], m_ipmc[256];
-  int8_t m_qp[256];
 };
 
 __device__ __forceinline__ uint32_t interleave4(uint32_t x, uint32_t y)
@@ -79,15 +74,14 @@ struct Ctx {
   int x_ctb, y_ctb;   // luma origin of the CTB
   int avail;          // CtbInfo.avail
   int ctb;            // CTB size in luma samples
-  SliceParams sl;
 };
 
 // One transform block: prediction (+ residual) into the LDS tile.
 //   c_idx: component; (xb, yb): block origin inside the CTB in component samples; log2n: block size
 //   z_cur: z-index (4x4 luma units) of the block that defines "already decoded" for availability
 template <typename Pix>
-__device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C, int c_idx, int xb, int yb, int log2n, int z_cur, int mode, int cbf,
-                                  int transform_skip, int bypass, int qp_y, const int16_t* coef)
+__device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C, const Pix* top, int c_idx, int xb, int yb, int log2n, int z_cur, int mode,
+                                                  int cbf, const int16_t* res)
 {
   const PicParams& P = *C.pp;
   const int lane = C.lane;
@@ -98,9 +92,8 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
   const int x_abs0 = C.x_ctb / sub, y_abs0 = C.y_ctb / sub;
   const int bit_depth = c_idx ? P.bit_depth_chroma : P.bit_depth_luma;
   const int maxv = (1 << bit_depth) - 1;
-  Pix* tile = c_idx == 0 ? L.tile_y : L.tile_c[c_idx - 1];
-  const Pix* top = c_idx == 0 ? L.top_y : L.top_c[c_idx - 1];
-  const Pix* left = c_idx == 0 ? L.left_y : L.left_c[c_idx - 1];
+  Pix* tile = L.tile;
+  const Pix* left = L.left;
 
   // ---- 8.4.4.2.2 reference samples: gather + availability + substitution ----
   uint64_t m[3] = {0, 0, 0};
@@ -244,66 +237,12 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
   __syncthreads();
   if (!cbf) return;
 
-  // ---- residual: 8.6.2 scaling, 8.6.4 transformation ----
+  // ---- residual (already scaled + inverse transformed in place of the coefficients) ----
   const int nn = n * n;
-  if (bypass) {
-    for (int idx = lane; idx < nn; idx += 64) {
-      const int x = idx & (n - 1), y = idx >> log2n;
-      Pix* p = &tile[(yb + y) * ctbc + xb + x];
-      *p = (Pix)clip3(0, maxv, (int)*p + (int)coef[idx]);
-    }
-    __syncthreads();
-    return;
-  }
-  int qp;
-  if (c_idx == 0) qp = qp_y + 6 * (P.bit_depth_luma - 8);
-  else {
-    const int off_c = 6 * (P.bit_depth_chroma - 8);
-    int qpi = clip3(-off_c, 57, qp_y + (c_idx == 1 ? C.sl.cb_qp_offset : C.sl.cr_qp_offset));
-    int qpc = qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : c_chroma_qp[qpi - 30]);
-    qp = qpc + off_c;
-  }
-  {
-    const int bd_shift = bit_depth + log2n - 5;
-    const long long scale = (long long)(16 * c_level_scale[qp % 6]) << (qp / 6);
-    const long long rnd = 1ll << (bd_shift - 1);
-    for (int idx = lane; idx < nn; idx += 64) {
-      long long v = ((long long)coef[idx] * scale + rnd) >> bd_shift;
-      L.blk[idx] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
-    }
-  }
-  __syncthreads();
-  const int bd_shift2 = 20 - bit_depth;
-  if (transform_skip) {
-    for (int idx = lane; idx < nn; idx += 64) {
-      const int x = idx & (n - 1), y = idx >> log2n;
-      const int r = ((int)L.blk[idx] * 128 + (1 << (bd_shift2 - 1))) >> bd_shift2;
-      Pix* p = &tile[(yb + y) * ctbc + xb + x];
-      *p = (Pix)clip3(0, maxv, (int)*p + r);
-    }
-    __syncthreads();
-    return;
-  }
-  const int dst = c_idx == 0 && n == 4;
-  const int step = 32 >> log2n;  // row stride into the 32-point matrix
-  // first stage: columns.  tmp[i][x] = clip16((sum_j M[j][i] * blk[j][x] + 64) >> 7)
   for (int idx = lane; idx < nn; idx += 64) {
-    const int x = idx & (n - 1), i = idx >> log2n;
-    int sum = 0;
-    if (dst) { for (int j = 0; j < 4; j++) sum += (int)c_dst[j * 4 + i] * (int)L.blk[j * 4 + x]; }
-    else { for (int j = 0; j < n; j++) sum += (int)L.dct[(j * step) * 32 + i] * (int)L.blk[j * n + x]; }
-    L.tmp[idx] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
-  }
-  __syncthreads();
-  // second stage: rows.  res[y][i] = (sum_j M[j][i] * tmp[y][j] + rnd) >> bd_shift2
-  for (int idx = lane; idx < nn; idx += 64) {
-    const int i = idx & (n - 1), y = idx >> log2n;
-    int sum = 0;
-    if (dst) { for (int j = 0; j < 4; j++) sum += (int)c_dst[j * 4 + i] * (int)L.tmp[y * 4 + j]; }
-    else { for (int j = 0; j < n; j++) sum += (int)L.dct[(j * step) * 32 + i] * (int)L.tmp[y * n + j]; }
-    const int r = (sum + (1 << (bd_shift2 - 1))) >> bd_shift2;
-    Pix* p = &tile[(yb + y) * ctbc + xb + i];
-    *p = (Pix)clip3(0, maxv, (int)*p + r);
+    const int x = idx & (n - 1), y = idx >> log2n;
+    Pix* p = &tile[(yb + y) * ctbc + xb + x];
+    *p = (Pix)clip3(0, maxv, (int)*p + (int)res[idx]);
   }
   __syncthreads();
 }
@@ -314,30 +253,29 @@ template <typename Pix>
 __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
 {
   __shared__ ReconLds<Pix> L;
-  __shared__ uint32_t s_ticket;
   const int lane = threadIdx.x;
-  if (lane == 0) s_ticket = atomicAdd(A.ticket, 1u);
-  // 32-point DCT matrix (8.6.4.2): M[m][n] from the 33 distinct magnitudes
-  for (int idx = lane; idx < 1024; idx += 64) {
-    const int mm = idx >> 5, nx = idx & 31;
-    int k = ((2 * nx + 1) * mm) & 127;
-    if (k > 64) k = 128 - k;
-    L.dct[idx] = (int8_t)(k <= 32 ? c_dct_c[k] : -c_dct_c[64 - k]);
-  }
-  __syncthreads();
-  if (s_ticket >= A.num_rows) return;
-  const RowDesc rd = A.rows[s_ticket];
+  uint32_t t = 0;
+  if (lane == 0) t = atomicAdd(A.ticket, 1u);
+  const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+  if (ticket >= A.num_rows * 3u) return;
+  const uint32_t my_row = ticket / 3u;     // batch row index (rows are listed picture by picture)
+  const int c_idx = (int)(ticket % 3u);
+  const RowDesc rd = A.rows[my_row];
   const PicParams& P = A.pics[rd.pic];
-  const uint32_t my_row = s_ticket;  // batch row index == ticket (rows are listed picture by picture)
+  if (c_idx > 0 && !P.chroma_format_idc) return;
   const int cy = (int)rd.row;
-  const int ctb = 1 << P.log2_ctb, ctbc = ctb >> 1;
+  const int sub = c_idx ? 2 : 1;
+  const int ctb = 1 << P.log2_ctb, ctbc = ctb / sub;
   const int units = 1 << P.units_per_ctb_log2;
-  const int has_chroma = P.chroma_format_idc != 0;
   const CtbInfo* ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
-  const SliceParams* slices = (const SliceParams*)(A.arena + P.off_slices);
-  Pix* rec[3];
-  uint32_t stride[3];
-  for (int c = 0; c < 3; c++) { rec[c] = (Pix*)(A.arena + P.off_rec[c]); stride[c] = P.rec_stride[c] / sizeof(Pix); }
+  Pix* rec = (Pix*)(A.arena + P.off_rec[c_idx]);
+  const uint32_t stride = P.rec_stride[c_idx] / sizeof(Pix);
+  // line buffer: bottom sample row of every CTB row of this component, row stride = rec_stride
+  uint32_t* line = (uint32_t*)(A.arena + P.off_line[c_idx]);
+  const uint32_t line_words = P.rec_stride[c_idx] / 4;
+  uint32_t* my_progress = A.row_progress + (size_t)my_row * 3 + c_idx;
+  const uint32_t* up_progress = my_progress - 3;
+  constexpr int ES = (int)sizeof(Pix);
   int err = 0;
 
   for (int cx = 0; cx < P.ctb_w && !err; cx++) {
@@ -345,20 +283,28 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
     const CtbInfo ci = ctb_info[ctb_rs];
     Ctx C;
     C.pp = &P; C.lane = lane; C.x_ctb = cx << P.log2_ctb; C.y_ctb = cy << P.log2_ctb; C.avail = ci.avail; C.ctb = ctb;
-    C.sl = slices[ci.slice_idx];
+    const int xc0 = C.x_ctb / sub;  // component x of the CTB
     // ---- wait for the row above: above-right CTB done (or the row end) ----
+    const Pix* top = (const Pix*)(L.top_raw + 1);
     if (cy > 0) {
       const uint32_t need = (uint32_t)(cx + 2 < P.ctb_w ? cx + 2 : P.ctb_w);
       uint32_t spins = 0;
-      while (__hip_atomic_load(&A.row_progress[my_row - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-        __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1u << 22) || __hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { err = DEV_ERR_TIMEOUT; break; }
+      while (__hip_atomic_load(up_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 24) || __hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { err = DEV_ERR_TIMEOUT; break; }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __syncthreads();
       if (err) break;
+      // top border samples xc0 - 1 .. xc0 + 2 * ctbc - 1 from the line buffer (write-through data: sc1 loads)
+      const int b0 = (xc0 - 1) * ES;                              // byte offset of the above-left sample
+      const int start = b0 < 0 ? 0 : (b0 & ~3);
+      int endb = (xc0 + 2 * ctbc) * ES;
+      if (endb > (int)(line_words * 4)) endb = (int)(line_words * 4);
+      const int nwords = (endb - start + 3) >> 2;
+      const uint32_t* src = line + (size_t)(cy - 1) * line_words + (start >> 2);
+      for (int i = lane; i < nwords; i += 64) L.top_raw[1 + i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      top = (const Pix*)((const uint8_t*)(L.top_raw + 1) + (b0 - start));   // top[0] = above-left sample
     }
-    // ---- stage the CTB's maps and its top border ----
+    // ---- stage the CTB's maps ----
     {
       const size_t base = (size_t)ctb_rs * units;
       for (int i = lane * 4; i < units; i += 256) {
@@ -366,83 +312,53 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
         *(uint32_t*)&L.m_flags[i] = *(const uint32_t*)(A.arena + P.off_u_flags + base + i);
         *(uint32_t*)&L.m_ipm[i] = *(const uint32_t*)(A.arena + P.off_u_ipm + base + i);
         *(uint32_t*)&L.m_ipmc[i] = *(const uint32_t*)(A.arena + P.off_u_ipmc + base + i);
-        *(uint32_t*)&L.m_qp[i] = *(const uint32_t*)(A.arena + P.off_u_qp + base + i);
-      }
-      if (cy > 0) {
-        // luma: x_ctb - 1 .. x_ctb + 2*ctb - 1  (index 0 = above-left corner)
-        for (int i = lane; i <= 2 * ctb; i += 64) {
-          const int x = C.x_ctb - 1 + i;
-          if (x >= 0 && x < P.width) L.top_y[i] = rec[0][(size_t)(C.y_ctb - 1) * stride[0] + x];
-        }
-        if (has_chroma)
-          for (int c = 0; c < 2; c++)
-            for (int i = lane; i <= 2 * ctbc; i += 64) {
-              const int x = C.x_ctb / 2 - 1 + i;
-              if (x >= 0 && x < P.cwidth) L.top_c[c][i] = rec[c + 1][(size_t)(C.y_ctb / 2 - 1) * stride[c + 1] + x];
-            }
       }
     }
     __syncthreads();
 
-    // ---- transform blocks of the CTB in z-scan order ----
-    const int16_t* coef_y = (const int16_t*)(A.arena + P.off_coeff[0]) + (size_t)ctb_rs * ctb * ctb;
-    const int16_t* coef_cb = (const int16_t*)(A.arena + P.off_coeff[1]) + (size_t)ctb_rs * (ctb * ctb / 4);
-    const int16_t* coef_cr = (const int16_t*)(A.arena + P.off_coeff[2]) + (size_t)ctb_rs * (ctb * ctb / 4);
+    // ---- this component's blocks of the CTB in z-scan order ----
+    const int16_t* res_base = (const int16_t*)(A.arena + P.off_coeff[c_idx]) + (size_t)ctb_rs * (ctb * ctb / (sub * sub));
     int z = 0;
     while (z < units) {
       const int ux = (int)compact1by1((uint32_t)z), uy = (int)compact1by1((uint32_t)z >> 1);
       if (C.x_ctb + ux * 4 >= P.width || C.y_ctb + uy * 4 >= P.height) { z++; continue; }
-      const int sz = L.m_size[z];
-      const int t = sz & 15;
-      if (t < 2 || t > 5) { err = DEV_ERR_SYNTAX; break; }
-      const int fl = L.m_flags[z], ipm = L.m_ipm[z];
-      const int qp_y = L.m_qp[z];
-      const int bypass = (fl & UF_BYPASS) != 0;
-      reconstruct_block<Pix>(L, C, 0, ux * 4, uy * 4, t, z, ipm & 63, fl & UF_CBF_LUMA, (fl & UF_TS_LUMA) != 0, bypass, qp_y, coef_y + z * 16);
-      if (has_chroma) {
-        int do_c = 0, zc = z, tc = t - 1;
-        if (t > 2) do_c = 1;
+      const int tb = L.m_size[z] & 15;
+      if (tb < 2 || tb > 5) { err = DEV_ERR_SYNTAX; break; }
+      const int fl = L.m_flags[z];
+      if (c_idx == 0) {
+        reconstruct_block<Pix>(L, C, top, 0, ux * 4, uy * 4, tb, z, L.m_ipm[z] & 63, fl & UF_CBF_LUMA, res_base + z * 16);
+      } else {
+        int do_c = 0, zc = z, tc = tb - 1;
+        if (tb > 2) do_c = 1;
         else if ((z & 3) == 3) { do_c = 1; zc = z & ~3; tc = 2; }
         if (do_c) {
           const int cux = (int)compact1by1((uint32_t)zc), cuy = (int)compact1by1((uint32_t)zc >> 1);
-          const int cmode = L.m_ipmc[z];
-          reconstruct_block<Pix>(L, C, 1, cux * 2, cuy * 2, tc, zc, cmode, fl & UF_CBF_CB, (ipm & 64) != 0, bypass, qp_y, coef_cb + zc * 4);
-          reconstruct_block<Pix>(L, C, 2, cux * 2, cuy * 2, tc, zc, cmode, fl & UF_CBF_CR, (ipm & 128) != 0, bypass, qp_y, coef_cr + zc * 4);
+          reconstruct_block<Pix>(L, C, top, c_idx, cux * 2, cuy * 2, tc, zc, L.m_ipmc[z], fl & (c_idx == 1 ? UF_CBF_CB : UF_CBF_CR), res_base + zc * 4);
         }
       }
-      z += 1 << (2 * (t - 2));
+      z += 1 << (2 * (tb - 2));
     }
     __syncthreads();
 
-    // ---- write the CTB out (planes are allocated CTB-aligned, so no edge guards) and keep its
-    //      right column as the next CTB's left border ----
+    // ---- write the CTB out (planes are allocated CTB-aligned, so no edge guards), hand its bottom row to the
+    //      row below and keep its right column as the next CTB's left border ----
     {
-      constexpr int PPW = 4 / sizeof(Pix);  // pixels per 32-bit word
-      const int wpr = ctb / PPW;            // words per luma row
-      for (int i = lane; i < wpr * ctb; i += 64) {
+      constexpr int PPW = 4 / ES;            // pixels per 32-bit word
+      const int wpr = ctbc / PPW;            // words per tile row
+      const int yc0 = C.y_ctb / sub;
+      for (int i = lane; i < wpr * ctbc; i += 64) {
         const int y = i / wpr, xw = i - y * wpr;
-        *(uint32_t*)&rec[0][(size_t)(C.y_ctb + y) * stride[0] + C.x_ctb + xw * PPW] = *(const uint32_t*)&L.tile_y[y * ctb + xw * PPW];
+        *(uint32_t*)&rec[(size_t)(yc0 + y) * stride + xc0 + xw * PPW] = *(const uint32_t*)&L.tile[y * ctbc + xw * PPW];
       }
-      if (has_chroma) {
-        const int wprc = ctbc / PPW;
-        for (int c = 0; c < 2; c++)
-          for (int i = lane; i < wprc * ctbc; i += 64) {
-            const int y = i / wprc, xw = i - y * wprc;
-            *(uint32_t*)&rec[c + 1][(size_t)(C.y_ctb / 2 + y) * stride[c + 1] + C.x_ctb / 2 + xw * PPW] = *(const uint32_t*)&L.tile_c[c][y * ctbc + xw * PPW];
-          }
-      }
+      uint32_t* dst = line + (size_t)cy * line_words + (size_t)xc0 * ES / 4;
+      for (int i = lane; i < wpr; i += 64)
+        __hip_atomic_store(dst + i, *(const uint32_t*)&L.tile[(ctbc - 1) * ctbc + i * PPW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
-      for (int i = lane; i < ctb; i += 64) L.left_y[i] = L.tile_y[i * ctb + ctb - 1];
-      if (has_chroma)
-        for (int c = 0; c < 2; c++)
-          for (int i = lane; i < ctbc; i += 64) L.left_c[c][i] = L.tile_c[c][i * ctbc + ctbc - 1];
+      for (int i = lane; i < ctbc; i += 64) L.left[i] = L.tile[i * ctbc + ctbc - 1];
     }
     __syncthreads();
-    if (lane == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&A.row_progress[my_row], (uint32_t)(cx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the line-buffer stores have left this wave
+    if (lane == 0) __hip_atomic_store(my_progress, (uint32_t)(cx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (err && lane == 0) atomicCAS((int*)A.status, 0, err | (int)(0x40000000u) | (int)(my_row << 8));
 }
@@ -450,8 +366,8 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
 void launch_recon(const ReconArgs& a, bool wide, hipStream_t s)
 {
   if (!a.num_rows) return;
-  if (wide) hipLaunchKernelGGL((k_recon<uint16_t>), dim3(a.num_rows), dim3(64), 0, s, a);
-  else hipLaunchKernelGGL((k_recon<uint8_t>), dim3(a.num_rows), dim3(64), 0, s, a);
+  if (wide) hipLaunchKernelGGL((k_recon<uint16_t>), dim3(a.num_rows * 3), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((k_recon<uint8_t>), dim3(a.num_rows * 3), dim3(64), 0, s, a);
 }
 
 }  // namespace hipdec

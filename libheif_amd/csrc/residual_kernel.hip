@@ -1,0 +1,190 @@
+// residual_kernel.hip — dequantisation + inverse DCT/DST of every coded transform block, in place.
+//
+// Stands in for libde265's scaling / transform stages behind de265_decode() (reference call site
+// libheif/plugins/decoder_libde265.cc:402).  ITU-T H.265 8.6.2-8.6.4: scaling with flat lists,
+// transform skip, cu_transquant_bypass, DST-VII 4x4 for intra luma, DCT 4..32, 16-bit intermediate clip.
+//
+// MI355X mapping: residuals do not depend on prediction, so they are taken off the intra-prediction
+// dependency chain entirely: this kernel runs over ALL transform blocks of the batch in parallel (one
+// 256-thread workgroup per CTB, its four waves take the CTB's coded blocks round-robin) and overwrites each
+// TU-contiguous int16 coefficient block with its int16 residual block; the reconstruction wavefront
+// (recon_kernel.hip) then only adds.  Per block the wave stages the dequantised coefficients in LDS and runs
+// the two 1-D passes as n MACs per output sample against the LDS-resident 32-point matrix, skipping the
+// all-zero high-frequency rows / columns that dominate real content.  Integer butterflies, no MFMA: the
+// largest block is 32x32x32 int16 MACs with 16-bit clipping between the passes (not a dense contraction
+// worth matrix cores).  Traffic: reads and writes 2 B per coded sample (<= 3 B per luma pixel each way).
+#include <hip/hip_runtime.h>
+#include "hevc_device.h"
+#include "kernels.h"
+
+namespace hipdec {
+namespace {
+
+__constant__ int8_t r_dct_c[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                                   61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0};
+__constant__ int8_t r_dst[16] = {29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29};
+__constant__ uint8_t r_chroma_qp[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37};
+__constant__ int r_level_scale[6] = {40, 45, 51, 57, 64, 72};
+
+struct ResLds {
+  int8_t dct[32 * 32];
+  int16_t blk[4][32 * 32];
+  int16_t tmp[4][32 * 32];
+  uint8_t m_size[256], m_flags[256], m_ipm[256];
+  int8_t m_qp[256];
+  uint16_t list[256];
+  uint32_t count;
+};
+
+__device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ uint32_t compact1by1(uint32_t v)
+{
+  v &= 0x55555555u; v = (v | (v >> 1)) & 0x33333333u; v = (v | (v >> 2)) & 0x0f0f0f0fu; v = (v | (v >> 4)) & 0x00ff00ffu;
+  return v;
+}
+
+// one transform block, by one wave: coef (global, n*n int16, raster) -> residual in place
+__device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, int16_t* coef, int log2n, int bit_depth, int qp, int dst,
+                                               int transform_skip, int bypass)
+{
+  if (bypass) return;  // cu_transquant_bypass: the coefficient levels are the residual (8.6.2)
+  const int n = 1 << log2n, nn = n * n;
+  int16_t* blk = L.blk[wave];
+  int16_t* tmp = L.tmp[wave];
+  // ---- scaling (8.6.3, flat m = 16) + nonzero extent ----
+  const int bd_shift = bit_depth + log2n - 5;
+  const long long scale = (long long)(16 * r_level_scale[qp % 6]) << (qp / 6);
+  const long long rnd = 1ll << (bd_shift - 1);
+  int max_row = -1, max_col = -1;
+  for (int idx = lane * 4; idx < nn; idx += 256) {
+    const uint2 raw = *(const uint2*)&coef[idx];
+    int16_t c[4] = {(int16_t)(raw.x & 0xffff), (int16_t)(raw.x >> 16), (int16_t)(raw.y & 0xffff), (int16_t)(raw.y >> 16)};
+    int16_t d[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const long long v = ((long long)c[k] * scale + rnd) >> bd_shift;
+      d[k] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+      if (c[k]) { const int r = (idx + k) >> log2n, cc = (idx + k) & (n - 1); max_row = r > max_row ? r : max_row; max_col = cc > max_col ? cc : max_col; }
+    }
+    *(uint2*)&blk[idx] = make_uint2((uint16_t)d[0] | ((uint32_t)(uint16_t)d[1] << 16), (uint16_t)d[2] | ((uint32_t)(uint16_t)d[3] << 16));
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const int r = __shfl_xor(max_row, o), c = __shfl_xor(max_col, o);
+    max_row = r > max_row ? r : max_row; max_col = c > max_col ? c : max_col;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const int bd_shift2 = 20 - bit_depth;
+  if (transform_skip) {  // 8.6.4.2: r = d << 7, then the second-stage shift
+    for (int idx = lane * 4; idx < nn; idx += 256) {
+      int16_t r[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) r[k] = (int16_t)(((int)blk[idx + k] * 128 + (1 << (bd_shift2 - 1))) >> bd_shift2);
+      *(uint2*)&coef[idx] = make_uint2((uint16_t)r[0] | ((uint32_t)(uint16_t)r[1] << 16), (uint16_t)r[2] | ((uint32_t)(uint16_t)r[3] << 16));
+    }
+    return;
+  }
+  const int step = 32 >> log2n;  // row stride into the 32-point matrix
+  const int rows_nz = max_row + 1, cols_nz = max_col + 1;   // coefficient rows / columns that can be nonzero
+  // first stage (columns): tmp[i][x] = clip16((sum_j M[j][i] * blk[j][x] + 64) >> 7), only x < cols_nz matter
+  for (int idx = lane; idx < nn; idx += 64) {
+    const int x = idx & (n - 1), i = idx >> log2n;
+    int sum = 0;
+    if (x < cols_nz) {
+      if (dst) { for (int j = 0; j < rows_nz; j++) sum += (int)r_dst[j * 4 + i] * (int)blk[j * 4 + x]; }
+      else { for (int j = 0; j < rows_nz; j++) sum += (int)L.dct[(j * step) * 32 + i] * (int)blk[j * n + x]; }
+    }
+    tmp[idx] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // second stage (rows): res[y][i] = (sum_j M[j][i] * tmp[y][j] + rnd) >> bd_shift2, j < cols_nz
+  for (int idx = lane * 4; idx < nn; idx += 256) {
+    const int y = idx >> log2n, i0 = idx & (n - 1);
+    int16_t r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i = i0 + k;
+      int sum = 0;
+      if (dst) { for (int j = 0; j < cols_nz; j++) sum += (int)r_dst[j * 4 + i] * (int)tmp[y * 4 + j]; }
+      else { for (int j = 0; j < cols_nz; j++) sum += (int)L.dct[(j * step) * 32 + i] * (int)tmp[y * n + j]; }
+      r[k] = (int16_t)((sum + (1 << (bd_shift2 - 1))) >> bd_shift2);
+    }
+    *(uint2*)&coef[idx] = make_uint2((uint16_t)r[0] | ((uint32_t)(uint16_t)r[1] << 16), (uint16_t)r[2] | ((uint32_t)(uint16_t)r[3] << 16));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace
+
+// blockIdx.x = CTB (raster) of picture blockIdx.y
+__global__ __launch_bounds__(256) void k_residual(FilterArgs A)
+{
+  __shared__ ResLds L;
+  const PicParams& P = A.pics[blockIdx.y];
+  const int n_ctb = P.ctb_w * P.ctb_h;
+  const int ctb_rs = blockIdx.x;
+  if (ctb_rs >= n_ctb) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int units = 1 << P.units_per_ctb_log2;
+  const int ctb = 1 << P.log2_ctb;
+  const size_t base = (size_t)ctb_rs * units;
+  for (int idx = tid; idx < 1024; idx += 256) {  // 32-point DCT matrix (8.6.4.2) from its 33 distinct magnitudes
+    const int mm = idx >> 5, nx = idx & 31;
+    int k = ((2 * nx + 1) * mm) & 127;
+    if (k > 64) k = 128 - k;
+    L.dct[idx] = (int8_t)(k <= 32 ? r_dct_c[k] : -r_dct_c[64 - k]);
+  }
+  if (tid == 0) L.count = 0;
+  if (tid < units) {
+    L.m_size[tid] = A.arena[P.off_u_size + base + tid];
+    L.m_flags[tid] = A.arena[P.off_u_flags + base + tid];
+    L.m_ipm[tid] = A.arena[P.off_u_ipm + base + tid];
+    L.m_qp[tid] = (int8_t)A.arena[P.off_u_qp + base + tid];
+  }
+  __syncthreads();
+  // ---- list of units that carry residual blocks: a TU's first unit, or the 4th 4x4 luma unit of a chroma group ----
+  if (tid < units) {
+    const int z = tid;
+    const int ux = (int)compact1by1((uint32_t)z), uy = (int)compact1by1((uint32_t)z >> 1);
+    const int x_ctb = (ctb_rs % P.ctb_w) << P.log2_ctb, y_ctb = (ctb_rs / P.ctb_w) << P.log2_ctb;
+    if (x_ctb + ux * 4 < P.width && y_ctb + uy * 4 < P.height) {
+      const int t = L.m_size[z] & 15;
+      const int first = t >= 2 && t <= 5 && (z & ((1 << (2 * (t - 2))) - 1)) == 0;
+      if (first && (L.m_flags[z] & (UF_CBF_LUMA | UF_CBF_CB | UF_CBF_CR))) L.list[atomicAdd(&L.count, 1u)] = (uint16_t)z;
+    }
+  }
+  __syncthreads();
+  const int count = (int)L.count;
+  const CtbInfo ci = ((const CtbInfo*)(A.arena + P.off_ctb_info))[ctb_rs];
+  const SliceParams sl = ((const SliceParams*)(A.arena + P.off_slices))[ci.slice_idx];
+  int16_t* coef_y = (int16_t*)(A.arena + P.off_coeff[0]) + (size_t)ctb_rs * ctb * ctb;
+  int16_t* coef_c[2] = {(int16_t*)(A.arena + P.off_coeff[1]) + (size_t)ctb_rs * (ctb * ctb / 4),
+                        (int16_t*)(A.arena + P.off_coeff[2]) + (size_t)ctb_rs * (ctb * ctb / 4)};
+  for (int e = wave; e < count; e += 4) {
+    const int z = L.list[e];
+    const int t = L.m_size[z] & 15, fl = L.m_flags[z], ipm = L.m_ipm[z], qp_y = L.m_qp[z];
+    const int bypass = (fl & UF_BYPASS) != 0;
+    if (fl & UF_CBF_LUMA)
+      residual_block(L, wave, lane, coef_y + z * 16, t, P.bit_depth_luma, qp_y + 6 * (P.bit_depth_luma - 8), t == 2, (fl & UF_TS_LUMA) != 0, bypass);
+    if (P.chroma_format_idc && (fl & (UF_CBF_CB | UF_CBF_CR))) {
+      // chroma blocks hang off TUs larger than 4x4, or off the 4th unit of a 4x4 quadruple (flags set there by the parser)
+      const int zc = t > 2 ? z : (z & ~3), tc = t > 2 ? t - 1 : 2;
+      const int off_c = 6 * (P.bit_depth_chroma - 8);
+      for (int c = 0; c < 2; c++) {
+        if (!(fl & (c == 0 ? UF_CBF_CB : UF_CBF_CR))) continue;
+        const int qpi = clip3(-off_c, 57, qp_y + (c == 0 ? sl.cb_qp_offset : sl.cr_qp_offset));
+        const int qpc = qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : r_chroma_qp[qpi - 30]);
+        residual_block(L, wave, lane, coef_c[c] + zc * 4, tc, P.bit_depth_chroma, qpc + off_c, 0, (ipm & (c == 0 ? 64 : 128)) != 0, bypass);
+      }
+    }
+  }
+}
+
+void launch_residual(const FilterArgs& a, int n_pics, int max_ctbs, hipStream_t s)
+{
+  if (n_pics > 0 && max_ctbs > 0) hipLaunchKernelGGL(k_residual, dim3(max_ctbs, n_pics), dim3(256), 0, s, a);
+}
+
+}  // namespace hipdec
