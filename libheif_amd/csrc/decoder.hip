@@ -55,7 +55,7 @@ int launch_all(hipdec_batch& b, hipStream_t s)
                (uint32_t*)(b.arena + b.off_progress), b.arena + b.off_ctx, (uint32_t*)(b.arena + b.off_ticket), (int32_t*)(b.arena + b.off_status)};
   ReconArgs ra{(const PicParams*)(b.arena + b.off_pics), (const RowDesc*)(b.arena + b.off_rows), b.num_rows, b.arena,
                (uint32_t*)(b.arena + b.off_row_progress), (uint32_t*)(b.arena + b.off_ticket) + 1, (int32_t*)(b.arena + b.off_status)};
-  FilterArgs fa{(const PicParams*)(b.arena + b.off_pics), b.arena};
+  FilterArgs fa{(const PicParams*)(b.arena + b.off_pics), b.arena, (const int32_t*)(b.arena + b.off_status)};
   const bool dbg = getenv("HIPDEC_DEBUG_SYNC") != nullptr;  // isolate a faulting kernel
   auto step = [&](const char* what) -> int {
     if (!dbg) return 0;

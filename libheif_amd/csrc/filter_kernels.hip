@@ -122,6 +122,7 @@ __device__ __forceinline__ void deblock_chroma(Pix* pix, int xs, int ys, int qp_
 template <typename Pix, int DIR>
 __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
 {
+  if (*A.status != 0) return;
   const PicParams& P = A.pics[blockIdx.y];
   const int uw = (P.width + 3) >> 2, uh = (P.height + 3) >> 2;
   // work item: (edge index along the filtered direction on the 8-sample grid, unit index along the edge)
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
 template <typename Pix>
 __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
 {
+  if (*A.status != 0) return;
   const PicParams& P = A.pics[blockIdx.y];
   const int c = blockIdx.z;
   if (c > 0 && !P.chroma_format_idc) return;

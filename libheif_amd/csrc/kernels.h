@@ -19,6 +19,7 @@ struct ReconArgs {
 struct FilterArgs {
   const PicParams* pics;
   uint8_t* arena;
+  const int32_t* status;   // batch status word: a failed parse leaves garbage maps, later stages skip the batch
 };
 
 void launch_parse(const ParseArgs& a, hipStream_t s);

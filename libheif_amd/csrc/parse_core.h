@@ -42,6 +42,8 @@ PC_DEV void pc_wrlane(VReg& r, int l, uint32_t x) { r.v[l & 63] = x; }
 PC_DEV uint32_t pc_uni(uint32_t x) { return x; }
 PC_DEV int pc_clz(uint32_t x) { return x ? __builtin_clz(x) : 32; }
 PC_DEV int pc_ffs(uint32_t x) { return __builtin_ffs((int)x); }
+PC_DEV int pc_popc(uint32_t x) { return __builtin_popcount(x); }
+PC_DEV uint64_t pc_ballot(const VReg& r) { uint64_t m = 0; for (int l = 0; l < 64; l++) if (r.v[l]) m |= 1ull << l; return m; }
 #define PC_LDS_SYNC() do { } while (0)
 #define PC_CONST static const
 #else
@@ -57,6 +59,8 @@ PC_DEV void pc_wrlane(VReg& r, int l, uint32_t x) { r = ((int)threadIdx.x == l) 
 PC_DEV uint32_t pc_uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 PC_DEV int pc_clz(uint32_t x) { return __clz((int)x); }
 PC_DEV int pc_ffs(uint32_t x) { return __ffs((int)x); }
+PC_DEV int pc_popc(uint32_t x) { return __popc(x); }
+PC_DEV uint64_t pc_ballot(const VReg& r) { return __ballot(r != 0); }
 #define PC_LDS_SYNC() __syncthreads()
 #define PC_CONST __constant__
 #endif
@@ -251,8 +255,8 @@ PC_DEV int decode_bin(PS& s, VReg& grp, int ctx_lane)
   int bin, nb;
   if (__builtin_expect(s.value < scaled, 1)) {   // MPS: at most one renormalisation shift
     bin = (int)(st & 1u);
-    st += p_state < 62 ? 2u : 0u;
-    nb = scaled < (256u << 7) ? 1 : 0;
+    st += (uint32_t)(((int32_t)(p_state - 62u)) >> 31) & 2u;   // pStateIdx + 1, saturating at 62
+    nb = 1 - (int)(scaled >> 15);                               // range < 256 <=> scaled < 2^15 (scaled < 2^16 always)
     range <<= nb;
   } else {                                        // LPS
     bin = (int)((st & 1u) ^ 1u);
@@ -299,11 +303,30 @@ PC_DEV int decode_bypass(PS& s)
   if (s.value >= scaled) { s.value -= scaled; return 1; }
   return 0;
 }
-PC_DEV int decode_bypass_bits(PS& s, int n)
+// n <= 8 bypass bins at once: n steps of 9.3.4.3.4 are one long division of the scaled window by the scaled
+// range (quotient = the bins, MSB first; remainder = the new offset); at most one byte is needed
+PC_DEV uint32_t decode_bypass_multi(PS& s, int n)
 {
-  int v = 0;
-  for (int i = 0; i < n; i++) v = (v << 1) | decode_bypass(s);
-  return v;
+  s.value <<= n;
+  s.bits_needed += n;
+  if (s.bits_needed >= 0) { s.value += read_byte(s) << s.bits_needed; s.bits_needed -= 8; }
+  const uint32_t scaled = s.range << 7;
+  uint32_t q = s.value / scaled;
+  const uint32_t qmax = (1u << n) - 1u;
+  if (q > qmax) q = qmax;   // only reachable on a corrupt stream
+  s.value -= q * scaled;
+  return q;
+}
+PC_DEV int decode_bypass_bits(PS& s, int n)   // n <= 32, MSB first
+{
+  uint32_t v = 0;
+  while (n > 0) {
+    const int c = n > 8 ? 8 : n;
+    if (c >= 3) v = (v << c) | decode_bypass_multi(s, c);
+    else { for (int i = 0; i < c; i++) v = (v << 1) | (uint32_t)decode_bypass(s); }
+    n -= c;
+  }
+  return (int)v;
 }
 PC_DEV int decode_terminate(PS& s)
 {
@@ -474,22 +497,31 @@ PC_DEV int residual_coding(PS& s, int log2n, int c_idx, int pred_mode)
       if (c_idx == 0) sig_off = ((xs | ys) ? 3 : 0) + ((log2n == 3) ? (scan_idx == 0 ? 9 : 15) : 21);
       else sig_off = 27 + ((log2n == 3) ? 9 : 12);
     }
+    // sig_coeff_flag contexts of the 16 scan positions, one per lane (vector), then the serial bin loop
+    VReg vctx;
+    {
+      const int dc_sb = (xs | ys) == 0;
+      PC_VEC_BEGIN
+        const uint32_t r = (uint32_t)(scan4 >> ((lane & 15) * 4)) & 15u;
+        uint32_t c;
+        if (log2n == 2) c = (uint32_t)sig_off + (uint32_t)((PC_CTXIDXMAP4 >> (r * 4)) & 15u);
+        else if (dc_sb && r == 0) c = c_idx ? 27u : 0u;
+        else c = (uint32_t)sig_off + ((pat >> (r * 2)) & 3u);
+        PC_L(vctx) = c;
+      PC_VEC_END
+    }
     uint32_t sig = 0;  // bit k = sig_coeff_flag at scan position k
     int n_start = 15;
     if (i == last_sb) { sig = 1u << last_pos; n_start = last_pos - 1; }
-    for (int k = n_start; k >= 0; k--) {
-      if (k > 0 || !infer_dc) {
-        const uint32_t r = (uint32_t)(scan4 >> (k * 4)) & 15u;
-        int ctx;
-        if (log2n == 2) ctx = sig_off + (int)((PC_CTXIDXMAP4 >> (r * 4)) & 15u);
-        else if ((xs | ys) == 0 && r == 0) ctx = c_idx ? 27 : 0;
-        else ctx = sig_off + (int)((pat >> (r * 2)) & 3u);
-        if (decode_bin(s, s.ctxB, B_SIG_COEFF + ctx)) { sig |= 1u << k; infer_dc = 0; }
-      } else sig |= 1u;  // k == 0 inferred significant
+    for (int k = n_start; k > 0; k--)
+      sig |= (uint32_t)decode_bin(s, s.ctxB, B_SIG_COEFF + (int)pc_rdlane(vctx, k)) << k;
+    if (n_start >= 0) {   // position 0: inferred significant when the sub-block was signalled coded and nothing else is
+      if (infer_dc && !sig) sig = 1u;
+      else sig |= (uint32_t)decode_bin(s, s.ctxB, B_SIG_COEFF + (int)pc_rdlane(vctx, 0));
     }
     if (!sig) continue;
     // greater1 / greater2 flags
-    uint32_t g1 = 0;
+    uint32_t g1 = 0, g1_coded = 0;
     int ctx_set = (i == 0 || c_idx > 0) ? 0 : 2;
     if (!first_sb_with_g1 && g1_carry == 0) ctx_set++;
     first_sb_with_g1 = 0;
@@ -501,6 +533,7 @@ PC_DEV int residual_coding(PS& s, int log2n, int c_idx, int pred_mode)
       while (rem && num_g1 < 8) {
         const int k = 31 - pc_clz(rem);
         rem &= ~(1u << k);
+        g1_coded |= 1u << k;
         if (decode_bin(s, s.ctxC, g1_base + (g1_ctx > 3 ? 3 : g1_ctx))) { g1 |= 1u << k; g1_ctx = 0; if (last_g1_pos < 0) last_g1_pos = k; }
         else if (g1_ctx > 0) g1_ctx++;
         num_g1++;
@@ -508,42 +541,54 @@ PC_DEV int residual_coding(PS& s, int log2n, int c_idx, int pred_mode)
     }
     g1_carry = g1_ctx;
     const int sign_hidden = s.cu_tq_bypass ? 0 : (sdh && (last_sig_pos - first_sig_pos > 3));
+    const uint32_t first_g1_bit = last_g1_pos >= 0 ? 1u << last_g1_pos : 0u;
     uint32_t g2 = 0;
-    if (last_g1_pos >= 0 && decode_bin(s, s.ctxB, B_GREATER2 + ctx_set + (c_idx ? 4 : 0))) g2 = 1u << last_g1_pos;
-    uint32_t signs = 0;
+    if (first_g1_bit && decode_bin(s, s.ctxB, B_GREATER2 + ctx_set + (c_idx ? 4 : 0))) g2 = first_g1_bit;
+    // coeff_sign_flag: all of the sub-block's sign bins in one multi-bit bypass read (MSB = highest scan position)
+    const uint32_t sig_signed = sign_hidden ? sig & ~(1u << first_sig_pos) : sig;
+    const int n_signs = pc_popc(sig_signed);
+    const uint32_t sign_bits = (uint32_t)decode_bypass_bits(s, n_signs);
+    // coeff_abs_level_remaining for the positions whose base level hit its cap (9.3.3.11 order: descending k)
+    const uint32_t need_rem = (g1_coded & g1 & ~(first_g1_bit & ~g2)) | (sig & ~g1_coded);
+    VReg vrem;
+    PC_VEC_BEGIN PC_L(vrem) = 0u; PC_VEC_END
     {
-      uint32_t rem = sig;
-      if (sign_hidden) rem &= ~(1u << first_sig_pos);
+      uint32_t rem = need_rem;
+      int rice = 0;
       while (rem) {
         const int k = 31 - pc_clz(rem);
         rem &= ~(1u << k);
-        if (decode_bypass(s)) signs |= 1u << k;
+        const int r = decode_remaining(s, rice);
+        const int abs_level = 1 + (int)((g1 >> k) & 1u) + (int)((g2 >> k) & 1u) + r;
+        if (abs_level > 3 * (1 << rice)) rice = rice < 4 ? rice + 1 : 4;
+        pc_wrlane(vrem, k, (uint32_t)r);
       }
     }
-    int num_sig = 0, sum_abs = 0, rice = 0;
+    // levels, signs (incl. the hidden one) and positions of the 16 scan positions in parallel, one lane each
+    VReg vabs, vneg, vodd;
+    PC_VEC_BEGIN
+      const int k = lane & 15;
+      const uint32_t on = lane < 16 ? (sig >> k) & 1u : 0u;
+      const uint32_t a = on ? 1u + ((g1 >> k) & 1u) + ((g2 >> k) & 1u) + PC_L(vrem) : 0u;
+      const int rank = pc_popc(sig_signed >> (k + 1));       // sign bins decoded before this position's
+      const uint32_t sgn = (lane < 16 && ((sig_signed >> k) & 1u)) ? (sign_bits >> (n_signs - 1 - rank)) & 1u : 0u;
+      PC_L(vabs) = a; PC_L(vneg) = sgn; PC_L(vodd) = a & 1u;
+    PC_VEC_END
+    const uint32_t flip_first = sign_hidden ? (uint32_t)(pc_popc((uint32_t)pc_ballot(vodd)) & 1) : 0u;   // 9.3.4.? sign data hiding: parity of sumAbsLevel
     const int sb_base = (ys << 2) * n + (xs << 2);
-    {
-      uint32_t rem = sig;
-      while (rem) {
-        const int k = 31 - pc_clz(rem);
-        rem &= ~(1u << k);
-        const int base = 1 + (int)((g1 >> k) & 1u) + (int)((g2 >> k) & 1u);
-        int abs_level = base;
-        if (base == ((num_sig < 8) ? ((k == last_g1_pos) ? 3 : 2) : 1)) {
-          abs_level += decode_remaining(s, rice);
-          if (abs_level > 3 * (1 << rice)) rice = rice < 4 ? rice + 1 : 4;
-        }
-        int v = ((signs >> k) & 1u) ? -abs_level : abs_level;
-        if (sign_hidden) {
-          sum_abs += abs_level;
-          if (k == first_sig_pos && (sum_abs & 1)) v = -v;
-        }
-        if (v > 32767 || v < -32768) { s.err = DEV_ERR_SYNTAX; v = 0; }
+    VReg vovf;
+    PC_VEC_BEGIN
+      const int k = lane & 15;
+      const uint32_t a = PC_L(vabs);
+      uint32_t neg = PC_L(vneg);
+      if (k == first_sig_pos) neg ^= flip_first;
+      PC_L(vovf) = (a > 32768u || (a == 32768u && !neg)) ? 1u : 0u;
+      if (lane < 16 && a) {
         const uint32_t r = (uint32_t)(scan4 >> (k * 4)) & 15u;
-        s.L->coef[sb_base + (int)(r >> 2) * n + (int)(r & 3u)] = (int16_t)v;
-        num_sig++;
+        s.L->coef[sb_base + (int)(r >> 2) * n + (int)(r & 3u)] = (int16_t)(neg ? -(int32_t)a : (int32_t)a);
       }
-    }
+    PC_VEC_END
+    if (pc_ballot(vovf)) s.err = DEV_ERR_SYNTAX;
   }
   return ts;
 }

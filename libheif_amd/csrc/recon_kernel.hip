@@ -258,6 +258,7 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
   if (lane == 0) t = atomicAdd(A.ticket, 1u);
   const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
   if (ticket >= A.num_rows * 3u) return;
+  if (__hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // failed parse: maps are garbage
   const uint32_t my_row = ticket / 3u;     // batch row index (rows are listed picture by picture)
   const int c_idx = (int)(ticket % 3u);
   const RowDesc rd = A.rows[my_row];

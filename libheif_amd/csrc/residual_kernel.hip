@@ -122,6 +122,7 @@ __device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, in
 __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
 {
   __shared__ ResLds L;
+  if (*A.status != 0) return;
   const PicParams& P = A.pics[blockIdx.y];
   const int n_ctb = P.ctb_w * P.ctb_h;
   const int ctb_rs = blockIdx.x;

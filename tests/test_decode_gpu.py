@@ -200,3 +200,34 @@ def test_full_size_stills_match_oracle(size, cfg):
         for c in range(3):
             np.testing.assert_array_equal(got[c], ref["planes"][c], err_msg="item %d component %d" % (i, c))
     assert b.info(0)["num_substreams"] == ref["n_substreams"]
+
+
+def test_corrupt_streams_never_hang_or_crash():
+    """random corruption of the slice data (and of the headers): every decode returns — success with some
+    picture, or a loud error — and the device stays usable (all device-side loops and waits are bounded)."""
+    from libheif_amd.decoder import HipDecoder
+    from libheif_amd import HipDecError
+    rng = np.random.default_rng(123)
+    base = orc.encode(orc.synth_image(200, 136, 8, 1, seed=31), stress=1)
+    base_t = orc.encode(orc.synth_image(200, 136, 8, 1, seed=32), tile_cols=2, tile_rows=2, wpp=0)
+    outcomes = {"ok": 0, "error": 0}
+    for trial in range(24):
+        s = bytearray(base if trial % 2 == 0 else base_t)
+        lo = 0 if trial % 6 == 5 else 120        # mostly slice data, sometimes parameter sets / slice header too
+        for _ in range(int(rng.integers(1, 12))):
+            s[int(rng.integers(lo, len(s)))] = int(rng.integers(0, 256))
+        d = HipDecoder()
+        try:
+            d.push_data(bytes(s))
+            d.decode_next_image()
+            outcomes["ok"] += 1
+        except HipDecError as e:
+            assert e.code in (-2, -3, -4, -5, -7, -8), e
+            outcomes["error"] += 1
+        d.free()
+    assert outcomes["error"] > 0
+    # the device still decodes correctly afterwards
+    ref = orc.decode(base)
+    d = HipDecoder(); d.push_data(base); img = d.decode_next_image(); d.free()
+    for c in range(3):
+        np.testing.assert_array_equal(img.planes[c], ref["planes"][c])
