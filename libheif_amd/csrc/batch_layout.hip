@@ -48,7 +48,19 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
       if (force && atoi(force) > 0) w = (uint32_t)atoi(force);
       if (w < 1) w = 1;
       if (w > ns) w = ns;
-      for (uint32_t j = 0; j < w; j++) waves.push_back(ParseWave{sub_base + j, w, sub_base + ns, 0});
+      // WPP rows that follow their predecessor at the minimum 2-CTB distance move as a convoy (every CTB waits
+      // for the slowest of the W waves); starting a row only once its predecessor is `lag` CTBs ahead absorbs
+      // the CTB-to-CTB cost variance.  The ring closes after W rows, so W * lag must stay below the row length;
+      // with one wave per row (latency mode) the minimum distance is kept.
+      uint32_t lag = 2;
+      if (w < ns && p.pps.wpp) {
+        const uint32_t row_len = (uint32_t)((p.sps.pic_width + (1 << p.sps.log2_ctb) - 1) >> p.sps.log2_ctb);
+        lag = row_len / (w + 1);
+        if (lag < 2) lag = 2;
+      }
+      const char* force_lag = getenv("HIPDEC_WPP_START_LAG");
+      if (force_lag && atoi(force_lag) >= 2) lag = (uint32_t)atoi(force_lag);
+      for (uint32_t j = 0; j < w; j++) waves.push_back(ParseWave{sub_base + j, w, sub_base + ns, lag});
       sub_base += ns;
     }
   }

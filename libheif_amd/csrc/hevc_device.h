@@ -120,7 +120,8 @@ enum : int32_t {
 };
 
 struct ParseWave {  // one parser wavefront: substreams first, first + stride, ... < end (batch-global indices)
-  uint32_t first, stride, end, pad;
+  uint32_t first, stride, end;
+  uint32_t start_lag;   // CTBs the predecessor row must be ahead before a WPP row is started (>= 2)
 };
 
 struct ParseArgs {

@@ -854,7 +854,7 @@ PC_DEV uint32_t uload32(const void* p) { return pc_uni(*(const uint32_t*)p); }
 PC_DEV uint64_t uload64(const void* p) { return (uint64_t)uload32(p) | ((uint64_t)uload32((const uint8_t*)p + 4) << 32); }
 
 // One CABAC substream (slice segment / tile / WPP row), start to finish.
-PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_dep, Lds* lds)
+PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_dep, uint32_t start_lag, Lds* lds)
 {
   PS s;
   const Substream* subp = A.subs + sub_idx;
@@ -931,7 +931,8 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
 
     // ---- WPP dependency on the CTB row above ----
     if (dep_sub >= 0 && !same_wave_dep) {   // (a predecessor decoded earlier by this very wave is complete)
-      const uint32_t need = k + 2 < dep_len ? k + 2 : dep_len;
+      uint32_t need = k == 0 ? start_lag : k + 2;   // 9.3.1 needs 2; a larger start distance decouples the rows
+      if (need > dep_len) need = dep_len;
       const int e = pc_wait_progress(A.progress + dep_sub, need, A.status);
       if (e) { s.err = e; break; }
     }

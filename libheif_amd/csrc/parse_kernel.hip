@@ -23,9 +23,9 @@ __global__ __launch_bounds__(64) void k_parse(ParseArgs A)
   __syncthreads();
   if (wave_idx >= A.num_waves) return;
   const uint32_t first = pcore::uload32(&A.waves[wave_idx].first), stride = pcore::uload32(&A.waves[wave_idx].stride),
-                 end = pcore::uload32(&A.waves[wave_idx].end);
+                 end = pcore::uload32(&A.waves[wave_idx].end), lag = pcore::uload32(&A.waves[wave_idx].start_lag);
   for (uint32_t sub = first; sub < end; sub += stride)
-    if (pcore::parse_substream(A, sub, stride == 1, &lds)) break;
+    if (pcore::parse_substream(A, sub, stride == 1, lag, &lds)) break;
 }
 
 void launch_parse(const ParseArgs& a, hipStream_t s)

@@ -58,7 +58,7 @@ int emu_run_parse(EmuBatch* b)
     for (uint32_t s = A.waves[w].first; s < A.waves[w].end; s += A.waves[w].stride) covered[s]++;
   for (uint32_t s = 0; s < b->L.num_subs; s++) {
     if (covered[s] != 1) { b->status = -1; return -1; }
-    pcore::parse_substream(A, s, 0, &lds);
+    pcore::parse_substream(A, s, 0, 2, &lds);
   }
   b->status = *(int32_t*)(a + b->L.off_status);
   return b->status;
