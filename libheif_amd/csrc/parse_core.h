@@ -831,11 +831,14 @@ PC_DEV void pc_drain() {}
 #else
 PC_DEV int pc_wait_progress(const uint32_t* word, uint32_t need, const int32_t* status)
 {
+  // A blocked row waits milliseconds (its predecessor is busy with a whole CTB), so poll rarely: every poll
+  // is an L2 round trip plus issue slots taken from the waves that are decoding.  Bounded: ~2^20 polls of
+  // ~8k cycles each; a failing substream releases the waiters through the status word.
   int err = 0;
   uint32_t spins = 0;
-  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {   // bounded spin
-    __builtin_amdgcn_s_sleep(4);
-    if (++spins > (1u << 24) || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { err = DEV_ERR_TIMEOUT; break; }
+  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+    if (spins < 4) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(127);
+    if (++spins > (1u << 20) || ((spins & 7u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { err = DEV_ERR_TIMEOUT; break; }
   }
   return err;
 }
