@@ -44,6 +44,10 @@ PC_DEV int pc_clz(uint32_t x) { return x ? __builtin_clz(x) : 32; }
 PC_DEV int pc_ffs(uint32_t x) { return __builtin_ffs((int)x); }
 PC_DEV int pc_popc(uint32_t x) { return __builtin_popcount(x); }
 PC_DEV uint64_t pc_ballot(const VReg& r) { uint64_t m = 0; for (int l = 0; l < 64; l++) if (r.v[l]) m |= 1ull << l; return m; }
+// a wave-uniform value deliberately kept in a VECTOR register (see "VALU-resident arithmetic decoder" below)
+typedef uint32_t UReg;
+PC_DEV UReg pc_vec(uint32_t x) { return x; }
+PC_DEV bool pc_any(bool b) { return b; }
 #define PC_LDS_SYNC() do { } while (0)
 #define PC_CONST static const
 #else
@@ -61,6 +65,11 @@ PC_DEV int pc_clz(uint32_t x) { return __clz((int)x); }
 PC_DEV int pc_ffs(uint32_t x) { return __ffs((int)x); }
 PC_DEV int pc_popc(uint32_t x) { return __popc(x); }
 PC_DEV uint64_t pc_ballot(const VReg& r) { return __ballot(r != 0); }
+// a wave-uniform value deliberately kept in a VECTOR register: the asm move hides its uniformity from the compiler,
+// so arithmetic on it is issued to the SIMD's VALU instead of the CU-shared scalar pipe
+typedef uint32_t UReg;
+PC_DEV UReg pc_vec(uint32_t x) { UReg r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
+PC_DEV bool pc_any(bool b) { return __ballot(b) != 0; }   // uniform branch condition from a (uniform-valued) vector compare
 #define PC_LDS_SYNC() __syncthreads()
 #define PC_CONST __constant__
 #endif
@@ -148,9 +157,9 @@ struct Lds {
 
 // everything here is wave-uniform unless it is a VReg
 struct PS {
-  // ---- arithmetic decoder
-  uint32_t range, value;
-  int32_t bits_needed;
+  // ---- arithmetic decoder: range / value / bits_needed are wave-uniform values kept in VECTOR registers (UReg), so the
+  //      decoder's arithmetic issues on the SIMD's VALU while the CU-shared scalar pipe keeps the syntax control flow
+  UReg range, value, bits_needed;
   uint32_t pos, end, win_base;
   int32_t zeros;
   int32_t err;
@@ -241,26 +250,28 @@ PC_DEV uint32_t read_byte(PS& s)
 PC_DEV void cabac_start(PS& s, uint32_t start, uint32_t end)
 {
   s.pos = start; s.end = end; s.zeros = 0; s.win_base = 0xfffff000u;
-  s.range = 510; s.bits_needed = -8;
+  s.range = pc_vec(510u); s.bits_needed = pc_vec((uint32_t)-8);
   const uint32_t b0 = read_byte(s), b1 = read_byte(s);
-  s.value = (b0 << 8) | b1;
+  s.value = pc_vec((b0 << 8) | b1);
 }
 PC_DEV int decode_bin(PS& s, VReg& grp, int ctx_lane)
 {
   uint32_t st = pc_rdlane(grp, ctx_lane);
   const uint32_t p_state = st >> 1;
-  const uint32_t lps = (pc_rdlane(s.t_lps, (int)p_state) >> ((s.range >> 3) & 24u)) & 255u;
-  uint32_t range = s.range - lps;
-  const uint32_t scaled = range << 7;
-  int bin, nb;
-  if (__builtin_expect(s.value < scaled, 1)) {   // MPS: at most one renormalisation shift
+  const uint32_t row = pc_rdlane(s.t_lps, (int)p_state);
+  const UReg lps = (row >> ((s.range >> 3) & 24u)) & 255u;
+  UReg range = s.range - lps;
+  const UReg scaled = range << 7;
+  int bin;
+  UReg nb;
+  if (__builtin_expect(pc_any(s.value < scaled), 1)) {   // MPS: at most one renormalisation shift
     bin = (int)(st & 1u);
     st += (uint32_t)(((int32_t)(p_state - 62u)) >> 31) & 2u;   // pStateIdx + 1, saturating at 62
-    nb = 1 - (int)(scaled >> 15);                               // range < 256 <=> scaled < 2^15 (scaled < 2^16 always)
+    nb = 1u - (scaled >> 15);                                   // range < 256 <=> scaled < 2^15 (scaled < 2^16 always)
     range <<= nb;
-  } else {                                        // LPS
+  } else {                                                      // LPS
     bin = (int)((st & 1u) ^ 1u);
-    nb = pc_clz(lps) - 23;
+    nb = (UReg)pc_clz(lps) - 23u;
     s.value -= scaled;
     range = lps << nb;
     const uint32_t mps = p_state == 0 ? (st & 1u) ^ 1u : (st & 1u);
@@ -270,37 +281,16 @@ PC_DEV int decode_bin(PS& s, VReg& grp, int ctx_lane)
   s.range = range;
   s.value <<= nb;
   s.bits_needed += nb;
-  if (__builtin_expect(s.bits_needed >= 0, 0)) { s.value += read_byte(s) << s.bits_needed; s.bits_needed -= 8; }
+  if (__builtin_expect(pc_any((int32_t)s.bits_needed >= 0), 0)) { s.value += read_byte(s) << s.bits_needed; s.bits_needed -= 8u; }
   return bin;
-}
-// branch-free variant (selects instead of the MPS / LPS diamond); kept beside decode_bin for the microbenchmark
-PC_DEV int decode_bin_sel(PS& s, VReg& grp, int ctx_lane)
-{
-  const uint32_t st = pc_rdlane(grp, ctx_lane);
-  const uint32_t p_state = st >> 1, mps = st & 1u;
-  const uint32_t lps = (pc_rdlane(s.t_lps, (int)p_state) >> ((s.range >> 3) & 24u)) & 255u;
-  const uint32_t nxt = pc_rdlane(s.t_next, (int)p_state) & 63u;
-  const uint32_t range1 = s.range - lps;
-  const uint32_t scaled = range1 << 7;
-  const bool is_lps = s.value >= scaled;
-  const uint32_t st_m = st + (p_state < 62 ? 2u : 0u);
-  const uint32_t st_l = (nxt << 1) | (p_state == 0 ? mps ^ 1u : mps);
-  const int nb_m = scaled < (256u << 7) ? 1 : 0;
-  const int nb_l = pc_clz(lps) - 23;
-  const int nb = is_lps ? nb_l : nb_m;
-  pc_wrlane(grp, ctx_lane, is_lps ? st_l : st_m);
-  s.value = (is_lps ? s.value - scaled : s.value) << nb;
-  s.range = (is_lps ? lps : range1) << nb;
-  s.bits_needed += nb;
-  if (__builtin_expect(s.bits_needed >= 0, 0)) { s.value += read_byte(s) << s.bits_needed; s.bits_needed -= 8; }
-  return (int)(mps ^ (is_lps ? 1u : 0u));
 }
 PC_DEV int decode_bypass(PS& s)
 {
   s.value <<= 1;
-  if (++s.bits_needed >= 0) { s.bits_needed = -8; s.value += read_byte(s); }
-  const uint32_t scaled = s.range << 7;
-  if (s.value >= scaled) { s.value -= scaled; return 1; }
+  s.bits_needed += 1u;
+  if (pc_any((int32_t)s.bits_needed >= 0)) { s.bits_needed = pc_vec((uint32_t)-8); s.value += read_byte(s); }
+  const UReg scaled = s.range << 7;
+  if (pc_any(s.value >= scaled)) { s.value -= scaled; return 1; }
   return 0;
 }
 // n <= 8 bypass bins at once: n steps of 9.3.4.3.4 are one long division of the scaled window by the scaled
@@ -308,14 +298,14 @@ PC_DEV int decode_bypass(PS& s)
 PC_DEV uint32_t decode_bypass_multi(PS& s, int n)
 {
   s.value <<= n;
-  s.bits_needed += n;
-  if (s.bits_needed >= 0) { s.value += read_byte(s) << s.bits_needed; s.bits_needed -= 8; }
-  const uint32_t scaled = s.range << 7;
-  uint32_t q = s.value / scaled;
+  s.bits_needed += (uint32_t)n;
+  if (pc_any((int32_t)s.bits_needed >= 0)) { s.value += read_byte(s) << s.bits_needed; s.bits_needed -= 8u; }
+  const UReg scaled = s.range << 7;
+  UReg q = s.value / scaled;
   const uint32_t qmax = (1u << n) - 1u;
-  if (q > qmax) q = qmax;   // only reachable on a corrupt stream
+  q = q > qmax ? qmax : q;   // only reachable on a corrupt stream
   s.value -= q * scaled;
-  return q;
+  return pc_uni(q);
 }
 PC_DEV int decode_bypass_bits(PS& s, int n)   // n <= 32, MSB first
 {
@@ -330,13 +320,14 @@ PC_DEV int decode_bypass_bits(PS& s, int n)   // n <= 32, MSB first
 }
 PC_DEV int decode_terminate(PS& s)
 {
-  s.range -= 2;
-  const uint32_t scaled = s.range << 7;
-  if (s.value >= scaled) return 1;
-  if (scaled < (256u << 7)) {
+  s.range -= 2u;
+  const UReg scaled = s.range << 7;
+  if (pc_any(s.value >= scaled)) return 1;
+  if (pc_any(scaled < (256u << 7))) {
     s.range = scaled >> 6;
     s.value <<= 1;
-    if (++s.bits_needed == 0) { s.bits_needed = -8; s.value += read_byte(s); }
+    s.bits_needed += 1u;
+    if (pc_any((int32_t)s.bits_needed == 0)) { s.bits_needed = pc_vec((uint32_t)-8); s.value += read_byte(s); }
   }
   return 0;
 }
