@@ -6,31 +6,43 @@
 // substream index) is resident or finished before the row can wait on it, and every wait is
 // bounded.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "hevc_device.h"
 #include "kernels.h"
 #include "parse_core.h"
 
 namespace hipdec {
 
-__global__ __launch_bounds__(64) void k_parse(ParseArgs A)
-{
-  __shared__ pcore::Lds lds;
-  const int lane = (int)threadIdx.x;
-  uint32_t t = 0;
-  if (lane == 0) t = atomicAdd(A.ticket, 1u);
-  const uint32_t wave_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-  for (int i = lane * 8; i < 32 * 32; i += 512) *(uint4*)&lds.coef[i] = make_uint4(0, 0, 0, 0);
-  __syncthreads();
-  if (wave_idx >= A.num_waves) return;
-  const uint32_t first = pcore::uload32(&A.waves[wave_idx].first), stride = pcore::uload32(&A.waves[wave_idx].stride),
-                 end = pcore::uload32(&A.waves[wave_idx].end), lag = pcore::uload32(&A.waves[wave_idx].start_lag);
-  for (uint32_t sub = first; sub < end; sub += stride)
-    if (pcore::parse_substream(A, sub, stride == 1, lag, &lds)) break;
-}
+// The kernel body, stamped out at several register budgets: more resident waves per SIMD hide more of the WPP
+// dependency stalls and scalar-pipe latency, fewer registers mean spills in the cold paths.  HIPDEC_PARSE_OCCUPANCY
+// picks one at run time (tuning knob; default = the measured best on MI355X).
+#define HIPDEC_PARSE_BODY                                                                                   \
+    __shared__ pcore::Lds lds;                                                                            \
+    const int lane = (int)threadIdx.x;                                                                    \
+    uint32_t t = 0;                                                                                       \
+    if (lane == 0) t = atomicAdd(A.ticket, 1u);                                                           \
+    const uint32_t wave_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);                           \
+    for (int i = lane * 8; i < 32 * 32; i += 512) *(uint4*)&lds.coef[i] = make_uint4(0, 0, 0, 0);         \
+    __syncthreads();                                                                                      \
+    if (wave_idx >= A.num_waves) return;                                                                  \
+    const uint32_t first = pcore::uload32(&A.waves[wave_idx].first), stride = pcore::uload32(&A.waves[wave_idx].stride),\
+                   end = pcore::uload32(&A.waves[wave_idx].end), lag = pcore::uload32(&A.waves[wave_idx].start_lag);\
+    for (uint32_t sub = first; sub < end; sub += stride)                                                  \
+      if (pcore::parse_substream(A, sub, stride == 1, lag, &lds)) break;                                  \
+
+__global__ __launch_bounds__(64) void k_parse(ParseArgs A) { HIPDEC_PARSE_BODY }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_parse_occ7(ParseArgs A) { HIPDEC_PARSE_BODY }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_parse_occ8(ParseArgs A) { HIPDEC_PARSE_BODY }
 
 void launch_parse(const ParseArgs& a, hipStream_t s)
 {
-  if (a.num_waves) hipLaunchKernelGGL(k_parse, dim3(a.num_waves), dim3(64), 0, s, a);
+  if (!a.num_waves) return;
+  static const int forced = getenv("HIPDEC_PARSE_OCCUPANCY") ? atoi(getenv("HIPDEC_PARSE_OCCUPANCY")) : -1;
+  // throughput mode (the chip is oversubscribed with parser waves): 8 waves per SIMD; latency mode: all registers
+  const int occ = forced >= 0 ? forced : (a.num_waves >= 2048 ? 8 : 0);
+  if (occ == 8) hipLaunchKernelGGL(k_parse_occ8, dim3(a.num_waves), dim3(64), 0, s, a);
+  else if (occ == 7) hipLaunchKernelGGL(k_parse_occ7, dim3(a.num_waves), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL(k_parse, dim3(a.num_waves), dim3(64), 0, s, a);
 }
 
 }  // namespace hipdec
