@@ -72,14 +72,15 @@ int launch_all(hipdec_batch& b, hipStream_t s)
   launch_parse(pa, s);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[1], s));
   if (int rc = step("parse")) return rc;
-  launch_residual(fa, n, b.max_ctbs, s);
-  launch_recon(ra, b.wide, s);
+  static const bool parse_only = getenv("HIPDEC_DEBUG_PARSE_ONLY") != nullptr;   // tuning knob: isolate the CABAC kernel
+  if (!parse_only) launch_residual(fa, n, b.max_ctbs, s);
+  if (!parse_only) launch_recon(ra, b.wide, s);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[2], s));
   if (int rc = step("recon")) return rc;
-  launch_deblock(fa, n, b.max_w, b.max_h, b.wide, s);
+  if (!parse_only) launch_deblock(fa, n, b.max_w, b.max_h, b.wide, s);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[3], s));
   if (int rc = step("deblock")) return rc;
-  launch_sao(fa, n, b.max_ow, b.max_oh, b.wide, s);
+  if (!parse_only) launch_sao(fa, n, b.max_ow, b.max_oh, b.wide, s);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[4], s));
   if (int rc = step("sao")) return rc;
   HIPDEC_CHECK_HIP(hipGetLastError());

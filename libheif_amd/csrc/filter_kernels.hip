@@ -200,14 +200,20 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
   const int lctb = P.log2_ctb - (c ? 1 : 0);  // log2 CTB size in component samples
   Pix res[4];
   const int npx = ow - ox0 < 4 ? ow - ox0 : 4;
+  // the thread's pixels usually sit in ONE CTB: its SAO parameters are loaded once; type 0 is a plain copy
+  const int xf = ox0 + P.crop_x / sub, xl = xf + npx - 1;
+  const int ctb_first = (y >> lctb) * P.ctb_w + (xf >> lctb);
+  const bool one_ctb = (xf >> lctb) == (xl >> lctb);
+  SaoParams sp_first = sao[(size_t)ctb_first * 3 + c];
+  const bool check_bypass = P.transquant_bypass_enabled != 0;
   for (int i = 0; i < npx; i++) {
-    const int x = ox0 + i + P.crop_x / sub;
+    const int x = xf + i;
     int v = rec[(size_t)y * rs + x];
-    const int ctb = (y >> lctb) * P.ctb_w + (x >> lctb);
-    const SaoParams sp = sao[(size_t)ctb * 3 + c];
+    const int ctb = one_ctb ? ctb_first : (y >> lctb) * P.ctb_w + (x >> lctb);
+    const SaoParams sp = one_ctb ? sp_first : sao[(size_t)ctb * 3 + c];
     if (sp.type) {
       int ctb_dummy;
-      const uint8_t fl = u_flags[unit_index(P, (x * sub) >> 2, (y * sub) >> 2, &ctb_dummy)];
+      const uint8_t fl = check_bypass ? u_flags[unit_index(P, (x * sub) >> 2, (y * sub) >> 2, &ctb_dummy)] : (uint8_t)0;
       if (!(fl & UF_BYPASS)) {
         if (sp.type == 1) {
           const int k = ((v >> (bit_depth - 5)) - sp.band_or_class) & 31;

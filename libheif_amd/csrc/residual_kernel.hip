@@ -55,22 +55,37 @@ __device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, in
   const int bd_shift = bit_depth + log2n - 5;
   const long long scale = (long long)(16 * r_level_scale[qp % 6]) << (qp / 6);
   const long long rnd = 1ll << (bd_shift - 1);
-  int max_row = -1, max_col = -1;
-  for (int idx = lane * 4; idx < nn; idx += 256) {
-    const uint2 raw = *(const uint2*)&coef[idx];
+  // nonzero extent (max_row, max_col) without cross-lane shuffles: rows grow with the lane index, so the last
+  // nonzero row falls out of one ballot per pass; the last nonzero column is found bit by bit with five ballots
+  int max_row = -1;
+  int my_col = -1;   // highest nonzero column held by this lane
+  for (int base = 0; base < nn; base += 256) {   // wave-uniform trip count: every lane takes part in the ballot
+    const int idx = base + lane * 4;
+    const bool active = idx < nn;
+    uint2 raw = make_uint2(0, 0);
+    if (active) raw = *(const uint2*)&coef[idx];
     int16_t c[4] = {(int16_t)(raw.x & 0xffff), (int16_t)(raw.x >> 16), (int16_t)(raw.y & 0xffff), (int16_t)(raw.y >> 16)};
     int16_t d[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const long long v = ((long long)c[k] * scale + rnd) >> bd_shift;
       d[k] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
-      if (c[k]) { const int r = (idx + k) >> log2n, cc = (idx + k) & (n - 1); max_row = r > max_row ? r : max_row; max_col = cc > max_col ? cc : max_col; }
+      if (c[k]) { const int cc = (idx + k) & (n - 1); my_col = cc > my_col ? cc : my_col; }
     }
-    *(uint2*)&blk[idx] = make_uint2((uint16_t)d[0] | ((uint32_t)(uint16_t)d[1] << 16), (uint16_t)d[2] | ((uint32_t)(uint16_t)d[3] << 16));
+    if (active) *(uint2*)&blk[idx] = make_uint2((uint16_t)d[0] | ((uint32_t)(uint16_t)d[1] << 16), (uint16_t)d[2] | ((uint32_t)(uint16_t)d[3] << 16));
+    const unsigned long long nz = __ballot((raw.x | raw.y) != 0);
+    if (nz) { const int last_lane = 63 - __clzll((long long)nz); const int r = (base + last_lane * 4) >> log2n; max_row = r > max_row ? r : max_row; }
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    const int r = __shfl_xor(max_row, o), c = __shfl_xor(max_col, o);
-    max_row = r > max_row ? r : max_row; max_col = c > max_col ? c : max_col;
+  int max_col = -1;
+  {
+    unsigned long long cand = __ballot(my_col >= 0);
+    if (cand) {
+      max_col = 0;
+      for (int b = 4; b >= 0; b--) {
+        const unsigned long long t = __ballot(my_col >= 0 && ((my_col >> b) & 1)) & cand;
+        if (t) { cand = t; max_col |= 1 << b; }
+      }
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
