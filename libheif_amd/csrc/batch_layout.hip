@@ -105,10 +105,25 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
   b.off_ctrl = off;
   b.off_progress = off; off = align_up(off + sizeof(uint32_t) * nsubs, 256);
   b.off_row_progress = off; off = align_up(off + sizeof(uint32_t) * nrows * 3, 256);   // per (CTB row, component)
+  b.off_waitneed = off; off = align_up(off + sizeof(uint32_t) * nsubs, 256);
+  b.off_resume_k = off; off = align_up(off + sizeof(uint32_t) * nsubs, 256);
+  b.queue_cap = 1; while (b.queue_cap < nsubs) b.queue_cap <<= 1;
+  b.off_queue = off; off = align_up(off + sizeof(uint32_t) * b.queue_cap, 256);
+  b.off_qctl = off; off += 256;
   b.off_ticket = off; off += 256;  // [0] parse ticket, [1] recon ticket
   b.off_status = off; off += 256;
   b.ctrl_size = off - b.off_ctrl;
   b.off_ctx = off; off = align_up(off + (size_t)CTX_STORE * nsubs, 256);
+  b.off_saved = off; off = align_up(off + (size_t)SAVE_DWORDS * 4 * nsubs, 256);
+  // throughput mode: rows become tasks of a work pool (parse_core.h); latency mode keeps one wave per substream chain
+  {
+    const char* e = getenv("HIPDEC_PARSE_POOL");
+    b.pool = e ? (uint32_t)atoi(e) : (nsubs >= 2048 ? 1u : 0u);
+    const char* w = getenv("HIPDEC_POOL_WAVES");
+    b.pool_waves = w ? (uint32_t)atoi(w) : 3072u;
+    if (b.pool_waves > nsubs) b.pool_waves = nsubs;
+    if (b.pool_waves < 1) b.pool_waves = 1;
+  }
   for (int i = 0; i < n; i++) {
     PicParams& P = b.params[i];
     const size_t nctb = (size_t)P.ctb_w * P.ctb_h;
@@ -151,8 +166,11 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
       Substream s = pp.subs[k];
       s.pic = (uint32_t)i;
       if (s.dep_sub >= 0) s.dep_sub += (int32_t)sub_base;
+      s.dependent = -1;
       subs[sub_base + k] = s;
     }
+    for (size_t k = 0; k < pp.subs.size(); k++)
+      if (subs[sub_base + k].dep_sub >= 0) subs[subs[sub_base + k].dep_sub].dependent = (int32_t)(sub_base + k);
     sub_base += (uint32_t)pp.subs.size();
     for (int y = 0; y < P.ctb_h; y++) { rows[r].pic = (uint32_t)i; rows[r].row = (uint32_t)y; r++; }
     memcpy(host.data() + P.off_ctb_ts_to_rs, pp.ts_to_rs.data(), pp.ts_to_rs.size() * sizeof(uint16_t));

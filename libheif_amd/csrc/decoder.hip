@@ -50,9 +50,15 @@ int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* s
 int launch_all(hipdec_batch& b, hipStream_t s)
 {
   const int n = (int)b.params.size();
-  ParseArgs pa{(const PicParams*)(b.arena + b.off_pics), (const Substream*)(b.arena + b.off_subs), (const ParseWave*)(b.arena + b.off_waves),
-               b.num_waves, b.arena,
-               (uint32_t*)(b.arena + b.off_progress), b.arena + b.off_ctx, (uint32_t*)(b.arena + b.off_ticket), (int32_t*)(b.arena + b.off_status)};
+  ParseArgs pa{};
+  pa.pics = (const PicParams*)(b.arena + b.off_pics); pa.subs = (const Substream*)(b.arena + b.off_subs);
+  pa.waves = (const ParseWave*)(b.arena + b.off_waves); pa.num_waves = b.pool ? b.pool_waves : b.num_waves; pa.arena = b.arena;
+  pa.progress = (uint32_t*)(b.arena + b.off_progress); pa.ctx_store = b.arena + b.off_ctx;
+  pa.ticket = (uint32_t*)(b.arena + b.off_ticket); pa.status = (int32_t*)(b.arena + b.off_status);
+  pa.yield_ctbs = getenv("HIPDEC_POOL_YIELD") ? (uint32_t)atoi(getenv("HIPDEC_POOL_YIELD")) : 0;
+  pa.pool = b.pool; pa.queue_cap = b.queue_cap; pa.num_subs = b.num_subs;
+  pa.waitneed = (uint32_t*)(b.arena + b.off_waitneed); pa.resume_k = (uint32_t*)(b.arena + b.off_resume_k);
+  pa.queue = (uint32_t*)(b.arena + b.off_queue); pa.qctl = (uint32_t*)(b.arena + b.off_qctl); pa.saved = (uint32_t*)(b.arena + b.off_saved);
   ReconArgs ra{(const PicParams*)(b.arena + b.off_pics), (const RowDesc*)(b.arena + b.off_rows), b.num_rows, b.arena,
                (uint32_t*)(b.arena + b.off_row_progress), (uint32_t*)(b.arena + b.off_ticket) + 1, (int32_t*)(b.arena + b.off_status)};
   FilterArgs fa{(const PicParams*)(b.arena + b.off_pics), b.arena, (const int32_t*)(b.arena + b.off_status)};

@@ -171,7 +171,9 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
   }
 }
 
-// SAO + conformance crop; blockIdx.z = colour component
+// SAO + conformance crop; blockIdx.z = colour component.  A thread handles 4 samples of SAO_ROWS consecutive rows so that the
+// per-thread setup (picture constants, pointers) is amortised; lanes run along x, so every row access of a wave is contiguous.
+constexpr int SAO_ROWS = 8;
 template <typename Pix>
 __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
 {
@@ -182,9 +184,10 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
   const int sub = c ? 2 : 1;
   const int ow = c ? P.out_cwidth : P.out_width, oh = c ? P.out_cheight : P.out_height;
   const int groups = (ow + 3) >> 2;
+  const int row_blocks = (oh + SAO_ROWS - 1) / SAO_ROWS;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= groups * oh) return;
-  const int ox0 = (tid % groups) * 4, oy = tid / groups;
+  if (tid >= groups * row_blocks) return;
+  const int ox0 = (tid % groups) * 4, oy0 = (tid / groups) * SAO_ROWS;
   const int W = c ? P.cwidth : P.width, H = c ? P.cheight : P.height;
   const int bit_depth = c ? P.bit_depth_chroma : P.bit_depth_luma;
   const int maxv = (1 << bit_depth) - 1;
@@ -196,20 +199,23 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
   const SaoParams* sao = (const SaoParams*)(A.arena + P.off_sao);
   const CtbInfo* ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
   const SliceParams* slices = (const SliceParams*)(A.arena + P.off_slices);
-  const int y = oy + P.crop_y / sub;
   const int lctb = P.log2_ctb - (c ? 1 : 0);  // log2 CTB size in component samples
-  Pix res[4];
   const int npx = ow - ox0 < 4 ? ow - ox0 : 4;
+  const int crop_xc = P.crop_x / sub, crop_yc = P.crop_y / sub, ctb_w = P.ctb_w;
+  const bool check_bypass = P.transquant_bypass_enabled != 0;
+  const bool lf_across_tiles = P.lf_across_tiles != 0;
+  for (int oy = oy0; oy < oy0 + SAO_ROWS && oy < oh; oy++) {
+  const int y = oy + crop_yc;
+  Pix res[4];
   // the thread's pixels usually sit in ONE CTB: its SAO parameters are loaded once; type 0 is a plain copy
-  const int xf = ox0 + P.crop_x / sub, xl = xf + npx - 1;
-  const int ctb_first = (y >> lctb) * P.ctb_w + (xf >> lctb);
+  const int xf = ox0 + crop_xc, xl = xf + npx - 1;
+  const int ctb_first = (y >> lctb) * ctb_w + (xf >> lctb);
   const bool one_ctb = (xf >> lctb) == (xl >> lctb);
   SaoParams sp_first = sao[(size_t)ctb_first * 3 + c];
-  const bool check_bypass = P.transquant_bypass_enabled != 0;
   for (int i = 0; i < npx; i++) {
     const int x = xf + i;
     int v = rec[(size_t)y * rs + x];
-    const int ctb = one_ctb ? ctb_first : (y >> lctb) * P.ctb_w + (x >> lctb);
+    const int ctb = one_ctb ? ctb_first : (y >> lctb) * ctb_w + (x >> lctb);
     const SaoParams sp = one_ctb ? sp_first : sao[(size_t)ctb * 3 + c];
     if (sp.type) {
       int ctb_dummy;
@@ -225,14 +231,14 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
           for (int k = 0; k < 2; k++) {
             const int xs = x + (k ? -hx : hx), ys = y + (k ? -hy : hy);
             if (xs < 0 || ys < 0 || xs >= W || ys >= H) { skip = 1; break; }
-            const int ctb_n = (ys >> lctb) * P.ctb_w + (xs >> lctb);
+            const int ctb_n = (ys >> lctb) * ctb_w + (xs >> lctb);
             if (ctb_n != ctb) {
               const CtbInfo cn = ctb_info[ctb_n], cc = ctb_info[ctb];
               if (cn.slice_idx != cc.slice_idx) {
                 if (cn.slice_idx < cc.slice_idx && !slices[cc.slice_idx].lf_across_slices) { skip = 1; break; }
                 if (cn.slice_idx > cc.slice_idx && !slices[cn.slice_idx].lf_across_slices) { skip = 1; break; }
               }
-              if (!P.lf_across_tiles && cn.tile_id != cc.tile_id) { skip = 1; break; }
+              if (!lf_across_tiles && cn.tile_id != cc.tile_id) { skip = 1; break; }
             }
             const int nv = rec[(size_t)ys * rs + xs];
             edge_idx += (v > nv) - (v < nv);
@@ -250,6 +256,7 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
   if (npx == 4 && sizeof(Pix) == 1) *(uint32_t*)o = res[0] | (res[1] << 8) | (res[2] << 16) | ((uint32_t)res[3] << 24);
   else if (npx == 4 && sizeof(Pix) == 2) *(uint2*)o = make_uint2(res[0] | ((uint32_t)res[1] << 16), res[2] | ((uint32_t)res[3] << 16));
   else for (int i = 0; i < npx; i++) o[i] = res[i];
+  }
 }
 
 void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s)
@@ -267,7 +274,7 @@ void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool 
 
 void launch_sao(const FilterArgs& a, int n_pics, int max_out_w, int max_out_h, bool wide, hipStream_t s)
 {
-  const int work = ((max_out_w + 3) / 4) * max_out_h;
+  const int work = ((max_out_w + 3) / 4) * ((max_out_h + SAO_ROWS - 1) / SAO_ROWS);
   if (wide) hipLaunchKernelGGL((k_sao<uint16_t>), dim3((work + 255) / 256, n_pics, 3), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((k_sao<uint8_t>), dim3((work + 255) / 256, n_pics, 3), dim3(256), 0, s, a);
 }

@@ -24,7 +24,8 @@
 namespace hipdec {
 
 enum : int { CTX_STORE = 768,      // bytes per saved context table: 3 register groups x 64 lanes x 1 dword (parse_core.h)
-              HANDOFF_DWORDS = 16 };  // per-CTB record handed to the CTB below (SAO parameters + bottom-row sizes)
+              HANDOFF_DWORDS = 16,
+              SAVE_DWORDS = 7 * 64 }; // suspended-row state: 6 lane-indexed registers + one row of scalars (pool scheduler)  // per-CTB record handed to the CTB below (SAO parameters + bottom-row sizes)
 
 enum : uint8_t {
   UF_CBF_LUMA = 1, UF_CBF_CB = 2, UF_CBF_CR = 4, UF_BYPASS = 8, UF_PCM = 16, UF_VEDGE = 32, UF_HEDGE = 64, UF_TS_LUMA = 128
@@ -103,6 +104,8 @@ struct Substream {
   uint8_t has_dependent;          // 1: another substream waits on this one's progress
   uint8_t last_in_slice_segment;  // 1: last CTB ends with end_of_slice_segment_flag = 1
   uint8_t pad;
+  int32_t dependent;              // the substream whose dep_sub is this one (batch-global index), or -1
+  uint32_t pad2;
 };
 
 struct RowDesc {   // one CTB row of one picture, for the reconstruction wavefront
@@ -134,6 +137,16 @@ struct ParseArgs {
   uint8_t* ctx_store;   // per substream: CTX_STORE bytes, contexts after the 2nd CTB (WPP)
   uint32_t* ticket;
   int32_t* status;
+  // ---- pool scheduler (throughput mode): rows are tasks, any wave runs any ready row ----
+  uint32_t pool;         // 0: static assignment through `waves`; 1: work pool
+  uint32_t queue_cap;    // power of two >= num_subs
+  uint32_t num_subs;
+  uint32_t* waitneed;    // per substream: 0, or the predecessor progress a suspended row waits for
+  uint32_t* resume_k;    // per substream: CTB index to resume at (0 = fresh)
+  uint32_t* queue;       // ready queue: substream index + 1, 0 = empty slot
+  uint32_t* qctl;        // [0] head ticket, [1] tail ticket, [2] finished substreams
+  uint32_t* saved;       // per substream: SAVE_DWORDS of suspended state
+  uint32_t yield_ctbs;   // test knob (0 = off): a row yields after this many CTBs per activation
 };
 
 }  // namespace hipdec

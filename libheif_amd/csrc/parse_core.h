@@ -819,6 +819,12 @@ PC_DEV void pc_report(int32_t* status, int32_t code) { if (*status == 0) *status
 PC_DEV void pc_store_wt(uint32_t* p, uint32_t v) { *p = v; }
 PC_DEV uint32_t pc_load_wt(const uint32_t* p) { return *p; }
 PC_DEV void pc_drain() {}
+// returned (completed-before-continuing) atomics of the pool scheduler; the emulation is single threaded
+PC_DEV uint32_t pc_atomic_exch(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = v; return o; }
+PC_DEV uint32_t pc_atomic_add(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
+PC_DEV uint32_t pc_atomic_cas(uint32_t* p, uint32_t expect, uint32_t v) { const uint32_t o = *p; if (o == expect) *p = v; return o; }
+PC_DEV void pc_idle() {}
+#define PC_POOL_SPINS 1   /* an empty queue means "nothing runnable now": the single emulated wave returns */
 #else
 PC_DEV int pc_wait_progress(const uint32_t* word, uint32_t need, const int32_t* status)
 {
@@ -842,12 +848,85 @@ PC_DEV void pc_publish(uint32_t* word, uint32_t v)
 PC_DEV void pc_report(int32_t* status, int32_t code) { if (threadIdx.x == 0) atomicCAS((int*)status, 0, code); }
 PC_DEV void pc_store_wt(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 PC_DEV uint32_t pc_load_wt(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// returned atomics by lane 0, result broadcast: the wave continues only after the operation was performed at the
+// device-wide coherence point, which gives the store->load ordering the suspend / wake-up handshake relies on
+// (the empty asm consumes the broadcast result so that the compiler can neither drop the return path — a no-return
+// atomic is fire-and-forget — nor move later memory operations above the wait for it)
+PC_DEV uint32_t pc_atomic_done(uint32_t o) { const uint32_t r = pc_uni(o); asm volatile("" :: "s"(r) : "memory"); return r; }
+PC_DEV uint32_t pc_atomic_exch(uint32_t* p, uint32_t v)
+{
+  uint32_t o = 0;
+  if (threadIdx.x == 0) o = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return pc_atomic_done(o);
+}
+PC_DEV uint32_t pc_atomic_add(uint32_t* p, uint32_t v)
+{
+  uint32_t o = 0;
+  if (threadIdx.x == 0) o = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return pc_atomic_done(o);
+}
+PC_DEV uint32_t pc_atomic_cas(uint32_t* p, uint32_t expect, uint32_t v)
+{
+  uint32_t o = 0;
+  if (threadIdx.x == 0) { o = expect; __hip_atomic_compare_exchange_strong(p, &o, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  return pc_atomic_done(o);
+}
+PC_DEV void pc_idle() { __builtin_amdgcn_s_sleep(64); }
+#define PC_POOL_SPINS (1u << 22)
 #endif
 
 PC_DEV uint32_t uload32(const void* p) { return pc_uni(*(const uint32_t*)p); }
+PC_DEV uint32_t pc_load_wt_uni(const uint32_t* p) { return pc_uni(pc_load_wt(p)); }
 PC_DEV uint64_t uload64(const void* p) { return (uint64_t)uload32(p) | ((uint64_t)uload32((const uint8_t*)p + 4) << 32); }
 
-// One CABAC substream (slice segment / tile / WPP row), start to finish.
+// ---- pool scheduler: ready queue --------------------------------------------------------------------------
+// Rows (substreams) are tasks.  A task that finds its WPP predecessor not far enough ahead saves its parser state
+// and leaves; the predecessor's wave re-queues it when its progress reaches the recorded need.  Arbitration of
+// "who continues the row" is one CAS on waitneed[row]; all handshake words use returned atomics (see above).
+PC_DEV void pool_push(const ParseArgs& A, uint32_t sub)
+{
+  const uint32_t t = pc_atomic_add(A.qctl + 1, 1u);
+  PC_VEC_BEGIN if (lane == 0) pc_store_wt(A.queue + (t & (A.queue_cap - 1u)), sub + 1u); PC_VEC_END
+}
+// arms `sub` to be woken when its predecessor reaches `need`; returns 1 if the caller may run it right away
+PC_DEV int pool_arm(const ParseArgs& A, uint32_t sub, uint32_t dep, uint32_t need)
+{
+  pc_atomic_exch(A.waitneed + sub, need);
+  const uint32_t p = pc_atomic_add(A.progress + dep, 0u);
+  if (p >= need) return pc_atomic_cas(A.waitneed + sub, need, 0u) == need;   // lost the race: the producer queued it
+  return 0;
+}
+// the predecessor side: after publishing progress `done` of substream `sub`
+PC_DEV void pool_wake_dependent(const ParseArgs& A, int32_t dependent, uint32_t done)
+{
+  if (dependent < 0) return;
+  const uint32_t w = pc_atomic_add(A.waitneed + dependent, 0u);
+  if (w != 0 && done >= w && pc_atomic_cas(A.waitneed + dependent, w, 0u) == w) pool_push(A, (uint32_t)dependent);
+}
+
+// suspended-row state -> HBM (write-through, drained): six lane-indexed registers + one row of scalars
+PC_DEV void save_row_state(PS& s, const ParseArgs& A, uint32_t sub_idx, uint32_t* saved, uint32_t k)
+{
+  VReg sc;
+  PC_VEC_BEGIN
+    uint32_t v = 0;
+    if (lane == 0) v = s.range; else if (lane == 1) v = s.value; else if (lane == 2) v = s.bits_needed;
+    else if (lane == 3) v = s.pos; else if (lane == 4) v = s.end; else if (lane == 5) v = (uint32_t)s.zeros;
+    else if (lane == 6) v = (uint32_t)s.last_qp_y; else if (lane == 7) v = (uint32_t)s.qpy_pred; else if (lane == 8) v = (uint32_t)s.cur_qp_y;
+    else if (lane == 9) v = (uint32_t)s.is_cu_qp_delta_coded; else if (lane == 10) v = (uint32_t)s.cu_qp_delta_val;
+    PC_L(sc) = v;
+    pc_store_wt(saved + lane, PC_L(s.ctxA)); pc_store_wt(saved + 64 + lane, PC_L(s.ctxB)); pc_store_wt(saved + 128 + lane, PC_L(s.ctxC));
+    pc_store_wt(saved + 192 + lane, PC_L(s.p_size)); pc_store_wt(saved + 256 + lane, PC_L(s.p_ipm)); pc_store_wt(saved + 320 + lane, PC_L(s.sao_left));
+    pc_store_wt(saved + 384 + lane, PC_L(sc));
+    if (lane == 0) pc_store_wt(A.resume_k + sub_idx, k);
+  PC_VEC_END
+  pc_drain();
+}
+
+enum : int { PARSE_DONE = 0, PARSE_SUSPENDED = -1 };   // > 0: device error code
+
+// One CABAC substream (slice segment / tile / WPP row).  Static mode (A.pool == 0): start to finish, waiting for the
+// predecessor row in place.  Pool mode: from the row's resume point until it finishes or has to wait.
 PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_dep, uint32_t start_lag, Lds* lds)
 {
   PS s;
@@ -858,6 +937,8 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
   const uint32_t dep_len = uload32(&subp->dep_len);
   const uint32_t sflags = uload32(&subp->wpp_sync);  // wpp_sync | has_dependent << 8 | last_in_slice_segment << 16
   const int wpp_sync = (int)(sflags & 255u), has_dependent = (int)((sflags >> 8) & 255u), last_in_slice_segment = (int)((sflags >> 16) & 255u);
+  const int32_t dependent = (int32_t)uload32(&subp->dependent);
+  const uint32_t pool = A.pool;
   const PicParams* P = A.pics + sub_pic;
 
   s.L = lds; s.err = 0;
@@ -915,9 +996,29 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
     PC_L(s.p_size) = 0; PC_L(s.p_ipm) = 0; PC_L(s.up) = 0; PC_L(s.sao) = 0; PC_L(s.sao_left) = 0;
     PC_L(s.ctxA) = 0; PC_L(s.ctxB) = 0; PC_L(s.ctxC) = 0; PC_L(s.win) = 0; PC_L(s.win_next) = 0;
   PC_VEC_END
-  cabac_start(s, byte_start, byte_end);
+  uint32_t k0 = 0;
+  uint32_t* saved = A.saved + (size_t)sub_idx * SAVE_DWORDS;
+  if (pool) k0 = pc_load_wt_uni(A.resume_k + sub_idx);
+  if (k0 == 0) cabac_start(s, byte_start, byte_end);
+  else {   // resume a suspended row: six lane-indexed registers + one row of scalars
+    VReg sc;
+    PC_VEC_BEGIN
+      PC_L(s.ctxA) = pc_load_wt(saved + lane); PC_L(s.ctxB) = pc_load_wt(saved + 64 + lane); PC_L(s.ctxC) = pc_load_wt(saved + 128 + lane);
+      PC_L(s.p_size) = pc_load_wt(saved + 192 + lane); PC_L(s.p_ipm) = pc_load_wt(saved + 256 + lane); PC_L(s.sao_left) = pc_load_wt(saved + 320 + lane);
+      PC_L(sc) = pc_load_wt(saved + 384 + lane);
+    PC_VEC_END
+    s.range = pc_vec(pc_rdlane(sc, 0)); s.value = pc_vec(pc_rdlane(sc, 1)); s.bits_needed = pc_vec(pc_rdlane(sc, 2));
+    s.pos = pc_rdlane(sc, 3); s.end = pc_rdlane(sc, 4); s.zeros = (int32_t)pc_rdlane(sc, 5); s.win_base = 0xfffff000u;
+    s.last_qp_y = (int32_t)pc_rdlane(sc, 6); s.qpy_pred = (int32_t)pc_rdlane(sc, 7); s.cur_qp_y = (int32_t)pc_rdlane(sc, 8);
+    s.is_cu_qp_delta_coded = (int32_t)pc_rdlane(sc, 9); s.cu_qp_delta_val = (int32_t)pc_rdlane(sc, 10);
+  }
 
-  for (uint32_t k = 0; k < num_ctbs && !s.err; k++) {
+  for (uint32_t k = k0; k < num_ctbs && !s.err; k++) {
+    if (pool && A.yield_ctbs && k > k0 && (k - k0) % A.yield_ctbs == 0) {   // test knob: forced yield every N CTBs
+      save_row_state(s, A, sub_idx, saved, k);
+      pool_push(A, sub_idx);
+      return PARSE_SUSPENDED;
+    }
     const int ctb_rs = (int)(uload32((const uint8_t*)ts_to_rs + ((first_ctb_ts + k) & ~1u) * 2u) >> (((first_ctb_ts + k) & 1u) * 16u)) & 0xffff;
     const int cx = ctb_rs % ctb_w, cy = ctb_rs / ctb_w;
     const uint32_t ci = uload32(ctb_info + ctb_rs);  // slice_idx | avail << 16 | tile_id << 24
@@ -927,8 +1028,16 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
     if (dep_sub >= 0 && !same_wave_dep) {   // (a predecessor decoded earlier by this very wave is complete)
       uint32_t need = k == 0 ? start_lag : k + 2;   // 9.3.1 needs 2; a larger start distance decouples the rows
       if (need > dep_len) need = dep_len;
-      const int e = pc_wait_progress(A.progress + dep_sub, need, A.status);
-      if (e) { s.err = e; break; }
+      if (!pool) {
+        const int e = pc_wait_progress(A.progress + dep_sub, need, A.status);
+        if (e) { s.err = e; break; }
+      } else if (pc_load_wt_uni(A.progress + dep_sub) < need) {
+        // suspend: save the row's state, record what it waits for (with two CTBs of hysteresis), re-check
+        if (k > 0) save_row_state(s, A, sub_idx, saved, k);
+        uint32_t wake = need + 2u;
+        if (wake > dep_len) wake = dep_len;
+        if (!pool_arm(A, sub_idx, (uint32_t)dep_sub, wake)) return PARSE_SUSPENDED;
+      }
     }
     // ---- context initialisation / synchronisation (9.3.1) ----
     if (k == 0) {
@@ -1038,10 +1147,63 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
         PC_VEC_END
       }
     }
-    if (has_dependent) pc_publish(A.progress + sub_idx, k + 1); else pc_drain();
+    if (!pool) { if (has_dependent) pc_publish(A.progress + sub_idx, k + 1); else pc_drain(); }
+    else {
+      pc_drain();
+      if (has_dependent) { pc_atomic_exch(A.progress + sub_idx, k + 1); pool_wake_dependent(A, dependent, k + 1); }
+    }
   }
   if (s.err) pc_report(A.status, s.err | (int32_t)(sub_idx << 8));
   return s.err;
+}
+
+// Pool mode driver of one wave: start-up share of the task list, then run ready rows until every row is finished.
+PC_DEV void parse_pool_wave(const ParseArgs& A, uint32_t wave_idx, uint32_t n_waves, Lds* lds)
+{
+  // start-up: rows without a predecessor are ready; the others are armed to be woken at distance 2.  Only the first
+  // waves to RUN (low tickets) share this work: a wave that is not resident yet must not own a share, or the resident
+  // ones would starve waiting for rows nobody queued.
+  const uint32_t n_init = n_waves < 64u ? n_waves : 64u;
+  for (uint32_t sub = wave_idx; wave_idx < n_init && sub < A.num_subs; sub += n_init) {
+    const int32_t dep = (int32_t)uload32(&A.subs[sub].dep_sub);
+    if (dep < 0) pool_push(A, sub);
+    else {
+      uint32_t need = 2u;
+      const uint32_t dep_len = uload32(&A.subs[sub].dep_len);
+      if (need > dep_len) need = dep_len;
+      if (pool_arm(A, sub, (uint32_t)dep, need)) pool_push(A, sub);
+    }
+  }
+  for (;;) {
+    if (pc_load_wt_uni(A.qctl + 2) >= A.num_subs) return;                      // every row finished
+    if (pc_load_wt_uni((const uint32_t*)A.status) != 0) return;               // a row failed: stop the batch
+    const uint32_t h = pc_atomic_add(A.qctl + 0, 1u);
+    uint32_t* slot = A.queue + (h & (A.queue_cap - 1u));
+    uint32_t v = 0, spins = 0;
+    for (;;) {
+      v = pc_load_wt_uni(slot);
+      if (v != 0) break;
+      if (++spins >= PC_POOL_SPINS) break;
+      if ((spins & 15u) == 0 && (pc_load_wt_uni(A.qctl + 2) >= A.num_subs || pc_load_wt_uni((const uint32_t*)A.status) != 0)) break;
+      pc_idle();
+    }
+    if (v == 0) {
+#if defined(HIPDEC_HOST_EMU)
+      pc_atomic_add(A.qctl + 0, (uint32_t)-1);   // single emulated wave: give the ticket back, nothing is runnable now
+#endif
+      if (pc_load_wt_uni(A.qctl + 2) >= A.num_subs || pc_load_wt_uni((const uint32_t*)A.status) != 0) return;
+#if defined(HIPDEC_HOST_EMU)
+      pc_report(A.status, DEV_ERR_TIMEOUT | (int32_t)0x20000000);   // queue empty but rows unfinished: scheduler bug
+#else
+      pc_report(A.status, DEV_ERR_TIMEOUT | (int32_t)0x20000000);   // starved for ~seconds: give up loudly
+#endif
+      return;
+    }
+    PC_VEC_BEGIN if (lane == 0) pc_store_wt(slot, 0u); PC_VEC_END
+    const int r = parse_substream(A, v - 1u, 0, 2u, lds);
+    if (r == PARSE_DONE) pc_atomic_add(A.qctl + 2, 1u);
+    else if (r > 0) return;
+  }
 }
 
 }  // namespace pcore

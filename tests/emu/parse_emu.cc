@@ -47,18 +47,29 @@ int emu_run_parse(EmuBatch* b)
 {
   uint8_t* a = b->arena.data();
   memset(a + b->L.off_ctrl, 0, b->L.ctrl_size);
-  ParseArgs A{(const PicParams*)(a + b->L.off_pics), (const Substream*)(a + b->L.off_subs), (const ParseWave*)(a + b->L.off_waves),
-              b->L.num_waves, a,
-              (uint32_t*)(a + b->L.off_progress), a + b->L.off_ctx, (uint32_t*)(a + b->L.off_ticket), (int32_t*)(a + b->L.off_status)};
+  ParseArgs A{};
+  A.pics = (const PicParams*)(a + b->L.off_pics); A.subs = (const Substream*)(a + b->L.off_subs);
+  A.waves = (const ParseWave*)(a + b->L.off_waves); A.num_waves = b->L.num_waves; A.arena = a;
+  A.progress = (uint32_t*)(a + b->L.off_progress); A.ctx_store = a + b->L.off_ctx;
+  A.ticket = (uint32_t*)(a + b->L.off_ticket); A.status = (int32_t*)(a + b->L.off_status);
+  A.yield_ctbs = getenv("HIPDEC_POOL_YIELD") ? (uint32_t)atoi(getenv("HIPDEC_POOL_YIELD")) : 0;
+  A.pool = b->L.pool; A.queue_cap = b->L.queue_cap; A.num_subs = b->L.num_subs;
+  A.waitneed = (uint32_t*)(a + b->L.off_waitneed); A.resume_k = (uint32_t*)(a + b->L.off_resume_k);
+  A.queue = (uint32_t*)(a + b->L.off_queue); A.qctl = (uint32_t*)(a + b->L.off_qctl); A.saved = (uint32_t*)(a + b->L.off_saved);
   pcore::Lds lds;
   memset(&lds, 0, sizeof(lds));
-  // every substream once, in index order (the wave table only changes WHICH wave runs a substream)
-  std::vector<uint8_t> covered(b->L.num_subs, 0);
-  for (uint32_t w = 0; w < A.num_waves; w++)
-    for (uint32_t s = A.waves[w].first; s < A.waves[w].end; s += A.waves[w].stride) covered[s]++;
-  for (uint32_t s = 0; s < b->L.num_subs; s++) {
-    if (covered[s] != 1) { b->status = -1; return -1; }
-    pcore::parse_substream(A, s, 0, 2, &lds);
+  if (A.pool) {
+    // pool mode: one emulated wave drains the ready queue (rows suspend and get re-queued exactly as on the device)
+    pcore::parse_pool_wave(A, 0, 1, &lds);
+  } else {
+    // every substream once, in index order (the wave table only changes WHICH wave runs a substream)
+    std::vector<uint8_t> covered(b->L.num_subs, 0);
+    for (uint32_t w = 0; w < A.num_waves; w++)
+      for (uint32_t s = A.waves[w].first; s < A.waves[w].end; s += A.waves[w].stride) covered[s]++;
+    for (uint32_t s = 0; s < b->L.num_subs; s++) {
+      if (covered[s] != 1) { b->status = -1; return -1; }
+      pcore::parse_substream(A, s, 0, 2, &lds);
+    }
   }
   b->status = *(int32_t*)(a + b->L.off_status);
   return b->status;

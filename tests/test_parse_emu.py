@@ -141,3 +141,19 @@ def test_parser_emulation_reference_fixtures(reference_dir):
             status, got = run_emu([s])
             assert status == 0, rel
             check_against_oracle(s, got[0])
+
+
+@pytest.mark.parametrize("yield_ctbs", [0, 1, 3])
+@pytest.mark.parametrize("cfg", [dict(), dict(stress=1, log2_ctb=4, log2_max_tb=4), dict(tile_cols=3, tile_rows=2, wpp=1),
+                                 dict(num_slices=3), dict(wpp=0), dict(bit_depth=10)],
+                         ids=["default", "ctb16", "tiles_wpp", "slices", "nowpp", "main10"])
+def test_parser_pool_scheduler_emulation(cfg, yield_ctbs, monkeypatch):
+    """throughput-mode scheduling: rows as tasks of a work pool with suspend / resume through HBM state.  The forced
+    yield makes rows interleave so that real dependency suspensions, wake-ups and state restores happen."""
+    monkeypatch.setenv("HIPDEC_PARSE_POOL", "1")
+    monkeypatch.setenv("HIPDEC_POOL_YIELD", str(yield_ctbs))
+    streams = [orc.encode(orc.synth_image(w, h, cfg.get("bit_depth", 8), 1, seed=50 + i), **cfg) for i, (w, h) in enumerate([(264, 200), (200, 136), (328, 72)])]
+    status, got = run_emu(streams)
+    assert status == 0, "device status 0x%x" % status
+    for s, g in zip(streams, got):
+        check_against_oracle(s, g)
