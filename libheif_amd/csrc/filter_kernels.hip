@@ -171,91 +171,156 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
   }
 }
 
-// SAO + conformance crop; blockIdx.z = colour component.  A thread handles 4 samples of SAO_ROWS consecutive rows so that the
-// per-thread setup (picture constants, pointers) is amortised; lanes run along x, so every row access of a wave is contiguous.
-constexpr int SAO_ROWS = 8;
+// SAO + conformance crop.  One 256-thread workgroup per 128x16 tile of OUTPUT samples of one component (blockIdx.z) of one
+// picture (blockIdx.y): the deblocked source tile plus a one-sample halo is staged in LDS with coalesced dword loads issued
+// back to back (memory-level parallelism instead of a dependent load chain per thread), then every thread classifies and
+// offsets 4 samples of SAO_RPT rows out of LDS and stores one dword per row.
+constexpr int SAO_TW = 128, SAO_TH = 32, SAO_RPT = SAO_TH / 8;   // rows per thread
 template <typename Pix>
 __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
 {
+  constexpr int ES = (int)sizeof(Pix);
+  constexpr int ROW_WORDS = ((SAO_TW + 2) * ES + 3) / 4 + 2;
+  __shared__ uint32_t tile[SAO_TH + 2][ROW_WORDS];
   if (*A.status != 0) return;
   const PicParams& P = A.pics[blockIdx.y];
   const int c = blockIdx.z;
   if (c > 0 && !P.chroma_format_idc) return;
   const int sub = c ? 2 : 1;
   const int ow = c ? P.out_cwidth : P.out_width, oh = c ? P.out_cheight : P.out_height;
-  const int groups = (ow + 3) >> 2;
-  const int row_blocks = (oh + SAO_ROWS - 1) / SAO_ROWS;
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= groups * row_blocks) return;
-  const int ox0 = (tid % groups) * 4, oy0 = (tid / groups) * SAO_ROWS;
+  const int tiles_x = (ow + SAO_TW - 1) / SAO_TW, tiles_y = (oh + SAO_TH - 1) / SAO_TH;
+  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+  const int ox_t = ((int)blockIdx.x % tiles_x) * SAO_TW, oy_t = ((int)blockIdx.x / tiles_x) * SAO_TH;
   const int W = c ? P.cwidth : P.width, H = c ? P.cheight : P.height;
   const int bit_depth = c ? P.bit_depth_chroma : P.bit_depth_luma;
   const int maxv = (1 << bit_depth) - 1;
-  const Pix* rec = (const Pix*)(A.arena + P.off_rec[c]);
-  const int rs = P.rec_stride[c] / sizeof(Pix);
-  Pix* out = (Pix*)(A.arena + P.off_out[c]);
-  const int os = P.out_stride[c] / sizeof(Pix);
+  const uint8_t* __restrict__ rec = A.arena + P.off_rec[c];
+  const int rs_bytes = (int)P.rec_stride[c];
+  Pix* __restrict__ out = (Pix*)(A.arena + P.off_out[c]);
+  const int os = P.out_stride[c] / ES;
   const uint8_t* u_flags = A.arena + P.off_u_flags;
   const SaoParams* sao = (const SaoParams*)(A.arena + P.off_sao);
   const CtbInfo* ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
   const SliceParams* slices = (const SliceParams*)(A.arena + P.off_slices);
   const int lctb = P.log2_ctb - (c ? 1 : 0);  // log2 CTB size in component samples
-  const int npx = ow - ox0 < 4 ? ow - ox0 : 4;
   const int crop_xc = P.crop_x / sub, crop_yc = P.crop_y / sub, ctb_w = P.ctb_w;
   const bool check_bypass = P.transquant_bypass_enabled != 0;
   const bool lf_across_tiles = P.lf_across_tiles != 0;
-  for (int oy = oy0; oy < oy0 + SAO_ROWS && oy < oh; oy++) {
-  const int y = oy + crop_yc;
-  Pix res[4];
-  // the thread's pixels usually sit in ONE CTB: its SAO parameters are loaded once; type 0 is a plain copy
-  const int xf = ox0 + crop_xc, xl = xf + npx - 1;
-  const int ctb_first = (y >> lctb) * ctb_w + (xf >> lctb);
-  const bool one_ctb = (xf >> lctb) == (xl >> lctb);
-  SaoParams sp_first = sao[(size_t)ctb_first * 3 + c];
-  for (int i = 0; i < npx; i++) {
-    const int x = xf + i;
-    int v = rec[(size_t)y * rs + x];
-    const int ctb = one_ctb ? ctb_first : (y >> lctb) * ctb_w + (x >> lctb);
-    const SaoParams sp = one_ctb ? sp_first : sao[(size_t)ctb * 3 + c];
-    if (sp.type) {
-      int ctb_dummy;
-      const uint8_t fl = check_bypass ? u_flags[unit_index(P, (x * sub) >> 2, (y * sub) >> 2, &ctb_dummy)] : (uint8_t)0;
-      if (!(fl & UF_BYPASS)) {
-        if (sp.type == 1) {
+  const int tid = threadIdx.x;
+  const int tx = (tid & 31) * 4, ty = tid >> 5;
+  const int xs0 = ox_t + crop_xc, ys0 = oy_t + crop_yc;
+  // the SAO parameters of this thread's rows are requested first so that they travel together with the tile loads
+  SaoParams sp_row[SAO_RPT];
+#pragma unroll
+  for (int rr = 0; rr < SAO_RPT; rr++) {
+    int y = oy_t + ty + rr * 8 + crop_yc, x = ox_t + tx + crop_xc;
+    y = y < H ? y : H - 1; x = x < W ? x : W - 1;
+    sp_row[rr] = sao[(size_t)((y >> lctb) * ctb_w + (x >> lctb)) * 3 + c];
+  }
+  // ---- stage source rows ys0-1 .. ys0+TH, bytes [ab, ...) of each row ----
+  int ab = (xs0 - 1) * ES;
+  ab = ab < 0 ? 0 : (ab & ~3);
+  for (int i = tid; i < (SAO_TH + 2) * ROW_WORDS; i += 256) {
+    const int r = i / ROW_WORDS, wi = i - r * ROW_WORDS;
+    const int ys = ys0 - 1 + r, bo = ab + wi * 4;
+    uint32_t v = 0;
+    if (ys >= 0 && ys < H && bo < rs_bytes) v = *(const uint32_t*)(rec + (size_t)ys * rs_bytes + bo);
+    tile[r][wi] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < SAO_RPT; rr++) {
+    const int oy = oy_t + ty + rr * 8, ox0 = ox_t + tx;
+    if (oy >= oh || ox0 >= ow) continue;
+    const int y = oy + crop_yc, lr = ty + rr * 8 + 1;   // tile row of y
+    const int npx = ow - ox0 < 4 ? ow - ox0 : 4;
+    const int xf = ox0 + crop_xc, xl = xf + npx - 1;
+    const int ctb_first = (y >> lctb) * ctb_w + (xf >> lctb);
+    const bool one_ctb = (xf >> lctb) == (xl >> lctb);
+    const SaoParams sp_first = sp_row[rr];
+    Pix res[4];
+#define SAO_AT(row, x) (((const Pix*)((const uint8_t*)tile[row] + ((x) * ES - ab)))[0])
+    // fast paths: the 4 samples share one CTB (one parameter set) and no per-sample lossless check is needed
+    const int cmask = (1 << lctb) - 1;
+    const bool interior = (xf & cmask) > 0 && (xl & cmask) < cmask && (y & cmask) > 0 && (y & cmask) < cmask &&   // no neighbour leaves the CTB
+                          xl + 1 < W && y + 1 < H;                                                                  // ... or the picture
+    bool done = false;
+    if (one_ctb && !check_bypass && npx == 4) {
+      const SaoParams sp = sp_first;
+      if (sp.type == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) res[i] = SAO_AT(lr, xf + i);
+        done = true;
+      } else if (sp.type == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          int v = SAO_AT(lr, xf + i);
           const int k = ((v >> (bit_depth - 5)) - sp.band_or_class) & 31;
-          if (k < 4) v = clip3(0, maxv, v + sp.offset[k]);
-        } else {
-          const int cls = sp.band_or_class;
-          const int hx = cls == 1 ? 0 : (cls == 3 ? 1 : -1), hy = cls == 0 ? 0 : -1;  // first neighbour; second is the mirror
-          int edge_idx = 2, skip = 0;
-          for (int k = 0; k < 2; k++) {
-            const int xs = x + (k ? -hx : hx), ys = y + (k ? -hy : hy);
-            if (xs < 0 || ys < 0 || xs >= W || ys >= H) { skip = 1; break; }
-            const int ctb_n = (ys >> lctb) * ctb_w + (xs >> lctb);
-            if (ctb_n != ctb) {
-              const CtbInfo cn = ctb_info[ctb_n], cc = ctb_info[ctb];
-              if (cn.slice_idx != cc.slice_idx) {
-                if (cn.slice_idx < cc.slice_idx && !slices[cc.slice_idx].lf_across_slices) { skip = 1; break; }
-                if (cn.slice_idx > cc.slice_idx && !slices[cn.slice_idx].lf_across_slices) { skip = 1; break; }
+          const int off = k == 0 ? sp.offset[0] : (k == 1 ? sp.offset[1] : (k == 2 ? sp.offset[2] : (k == 3 ? sp.offset[3] : 0)));
+          res[i] = (Pix)clip3(0, maxv, v + off);
+        }
+        done = true;
+      } else if (interior) {
+        const int cls = sp.band_or_class;
+        const int hx = cls == 1 ? 0 : (cls == 3 ? 1 : -1), hy = cls == 0 ? 0 : -1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int x = xf + i;
+          const int v = SAO_AT(lr, x), a = SAO_AT(lr + hy, x + hx), b = SAO_AT(lr - hy, x - hx);
+          const int e = ((v > a) - (v < a)) + ((v > b) - (v < b));     // -2 .. 2 ; edgeIdx = 2 + e remapped {0,1,2,3,4} -> {1,2,0,3,4}
+          const int off = e == -2 ? sp.offset[0] : (e == -1 ? sp.offset[1] : (e == 1 ? sp.offset[2] : (e == 2 ? sp.offset[3] : 0)));
+          res[i] = (Pix)clip3(0, maxv, v + off);
+        }
+        done = true;
+      }
+    }
+    if (!done)
+    for (int i = 0; i < npx; i++) {
+      const int x = xf + i;
+      int v = SAO_AT(lr, x);
+      const int ctb = one_ctb ? ctb_first : (y >> lctb) * ctb_w + (x >> lctb);
+      const SaoParams sp = one_ctb ? sp_first : sao[(size_t)ctb * 3 + c];
+      if (sp.type) {
+        int ctb_dummy;
+        const uint8_t fl = check_bypass ? u_flags[unit_index(P, (x * sub) >> 2, (y * sub) >> 2, &ctb_dummy)] : (uint8_t)0;
+        if (!(fl & UF_BYPASS)) {
+          if (sp.type == 1) {
+            const int k = ((v >> (bit_depth - 5)) - sp.band_or_class) & 31;
+            if (k < 4) v = clip3(0, maxv, v + sp.offset[k]);
+          } else {
+            const int cls = sp.band_or_class;
+            const int hx = cls == 1 ? 0 : (cls == 3 ? 1 : -1), hy = cls == 0 ? 0 : -1;  // first neighbour; second is the mirror
+            int edge_idx = 2, skip = 0;
+            for (int k = 0; k < 2; k++) {
+              const int dx = k ? -hx : hx, dy = k ? -hy : hy;
+              const int xs = x + dx, ys = y + dy;
+              if (xs < 0 || ys < 0 || xs >= W || ys >= H) { skip = 1; break; }
+              const int ctb_n = (ys >> lctb) * ctb_w + (xs >> lctb);
+              if (ctb_n != ctb) {
+                const CtbInfo cn = ctb_info[ctb_n], cc = ctb_info[ctb];
+                if (cn.slice_idx != cc.slice_idx) {
+                  if (cn.slice_idx < cc.slice_idx && !slices[cc.slice_idx].lf_across_slices) { skip = 1; break; }
+                  if (cn.slice_idx > cc.slice_idx && !slices[cn.slice_idx].lf_across_slices) { skip = 1; break; }
+                }
+                if (!lf_across_tiles && cn.tile_id != cc.tile_id) { skip = 1; break; }
               }
-              if (!lf_across_tiles && cn.tile_id != cc.tile_id) { skip = 1; break; }
+              const int nv = SAO_AT(lr + dy, xs);
+              edge_idx += (v > nv) - (v < nv);
             }
-            const int nv = rec[(size_t)ys * rs + xs];
-            edge_idx += (v > nv) - (v < nv);
-          }
-          if (!skip) {
-            if (edge_idx <= 2) edge_idx = edge_idx == 2 ? 0 : edge_idx + 1;
-            if (edge_idx) v = clip3(0, maxv, v + sp.offset[edge_idx - 1]);
+            if (!skip) {
+              if (edge_idx <= 2) edge_idx = edge_idx == 2 ? 0 : edge_idx + 1;
+              if (edge_idx) v = clip3(0, maxv, v + sp.offset[edge_idx - 1]);
+            }
           }
         }
       }
+      res[i] = (Pix)v;
     }
-    res[i] = (Pix)v;
-  }
-  Pix* o = out + (size_t)oy * os + ox0;
-  if (npx == 4 && sizeof(Pix) == 1) *(uint32_t*)o = res[0] | (res[1] << 8) | (res[2] << 16) | ((uint32_t)res[3] << 24);
-  else if (npx == 4 && sizeof(Pix) == 2) *(uint2*)o = make_uint2(res[0] | ((uint32_t)res[1] << 16), res[2] | ((uint32_t)res[3] << 16));
-  else for (int i = 0; i < npx; i++) o[i] = res[i];
+#undef SAO_AT
+    Pix* o = out + (size_t)oy * os + ox0;
+    if (npx == 4 && ES == 1) *(uint32_t*)o = res[0] | (res[1] << 8) | (res[2] << 16) | ((uint32_t)res[3] << 24);
+    else if (npx == 4 && ES == 2) *(uint2*)o = make_uint2(res[0] | ((uint32_t)res[1] << 16), res[2] | ((uint32_t)res[3] << 16));
+    else for (int i = 0; i < npx; i++) o[i] = res[i];
   }
 }
 
@@ -274,9 +339,9 @@ void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool 
 
 void launch_sao(const FilterArgs& a, int n_pics, int max_out_w, int max_out_h, bool wide, hipStream_t s)
 {
-  const int work = ((max_out_w + 3) / 4) * ((max_out_h + SAO_ROWS - 1) / SAO_ROWS);
-  if (wide) hipLaunchKernelGGL((k_sao<uint16_t>), dim3((work + 255) / 256, n_pics, 3), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_sao<uint8_t>), dim3((work + 255) / 256, n_pics, 3), dim3(256), 0, s, a);
+  const int tiles = ((max_out_w + SAO_TW - 1) / SAO_TW) * ((max_out_h + SAO_TH - 1) / SAO_TH);
+  if (wide) hipLaunchKernelGGL((k_sao<uint16_t>), dim3(tiles, n_pics, 3), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_sao<uint8_t>), dim3(tiles, n_pics, 3), dim3(256), 0, s, a);
 }
 
 }  // namespace hipdec
