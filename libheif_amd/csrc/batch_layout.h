@@ -17,6 +17,8 @@ struct BatchLayout {
   size_t off_progress = 0, off_ctx = 0, off_row_progress = 0, off_ticket = 0, off_status = 0;
   size_t off_waitneed = 0, off_resume_k = 0, off_queue = 0, off_qctl = 0, off_saved = 0;
   uint32_t queue_cap = 0, pool = 0, pool_waves = 0;
+  size_t off_rwaves = 0;
+  uint32_t num_rwaves = 0;
   uint32_t num_subs = 0, num_rows = 0, num_waves = 0;
   bool wide = false;  // samples wider than 8 bit -> uint16 planes
   int max_w = 0, max_h = 0, max_ow = 0, max_oh = 0, max_ctbs = 0;

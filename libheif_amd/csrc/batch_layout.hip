@@ -66,6 +66,30 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
   }
   b.num_waves = (uint32_t)waves.size();
   b.off_waves = off; off = align_up(off + sizeof(ParseWave) * waves.size(), 256);
+  // Reconstruction wavefronts: the same dealing of a picture's CTB rows to W waves per colour component (a wave that
+  // finishes row r continues with row r + W), so that in large batches the resident waves are mostly busy ones.
+  std::vector<ReconWave> rwaves;
+  {
+    const uint32_t target = 24576;   // ~8 waves per component of a 4K still at 1024 stills in flight (measured optimum 4-16)
+    const char* force = getenv("HIPDEC_RECON_WAVES_PER_PICTURE");
+    uint32_t row_base = 0;
+    for (int i = 0; i < n; i++) {
+      const auto& p = b.pics[i];
+      const uint32_t rows = (uint32_t)((p.sps.pic_height + (1 << p.sps.log2_ctb) - 1) >> p.sps.log2_ctb);
+      const uint32_t row_len = (uint32_t)((p.sps.pic_width + (1 << p.sps.log2_ctb) - 1) >> p.sps.log2_ctb);
+      uint32_t w = target / (3u * (uint32_t)n);
+      if (force && atoi(force) > 0) w = (uint32_t)atoi(force);
+      if (w < 1) w = 1;
+      if (w > rows) w = rows;
+      uint32_t lag = 2;
+      if (w < rows) { lag = row_len / (w + 1); if (lag < 2) lag = 2; }
+      for (uint32_t j = 0; j < w; j++)
+        for (uint32_t c = 0; c < 3; c++) rwaves.push_back(ReconWave{(uint32_t)i, c, j, w, row_base, lag, 0, 0});
+      row_base += rows;
+    }
+  }
+  b.num_rwaves = (uint32_t)rwaves.size();
+  b.off_rwaves = off; off = align_up(off + sizeof(ReconWave) * rwaves.size(), 256);
   b.params.assign(n, PicParams{});
   uint32_t row_base = 0;
   for (int i = 0; i < n; i++) {
@@ -156,6 +180,7 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
   host.assign(b.upload_size, 0);
   memcpy(host.data() + b.off_pics, b.params.data(), sizeof(PicParams) * n);
   memcpy(host.data() + b.off_waves, waves.data(), sizeof(ParseWave) * waves.size());
+  memcpy(host.data() + b.off_rwaves, rwaves.data(), sizeof(ReconWave) * rwaves.size());
   Substream* subs = (Substream*)(host.data() + b.off_subs);
   RowDesc* rows = (RowDesc*)(host.data() + b.off_rows);
   uint32_t sub_base = 0, r = 0;

@@ -59,7 +59,7 @@ int launch_all(hipdec_batch& b, hipStream_t s)
   pa.pool = b.pool; pa.queue_cap = b.queue_cap; pa.num_subs = b.num_subs;
   pa.waitneed = (uint32_t*)(b.arena + b.off_waitneed); pa.resume_k = (uint32_t*)(b.arena + b.off_resume_k);
   pa.queue = (uint32_t*)(b.arena + b.off_queue); pa.qctl = (uint32_t*)(b.arena + b.off_qctl); pa.saved = (uint32_t*)(b.arena + b.off_saved);
-  ReconArgs ra{(const PicParams*)(b.arena + b.off_pics), (const RowDesc*)(b.arena + b.off_rows), b.num_rows, b.arena,
+  ReconArgs ra{(const PicParams*)(b.arena + b.off_pics), (const ReconWave*)(b.arena + b.off_rwaves), b.num_rwaves, b.arena,
                (uint32_t*)(b.arena + b.off_row_progress), (uint32_t*)(b.arena + b.off_ticket) + 1, (int32_t*)(b.arena + b.off_status)};
   FilterArgs fa{(const PicParams*)(b.arena + b.off_pics), b.arena, (const int32_t*)(b.arena + b.off_status)};
   const bool dbg = getenv("HIPDEC_DEBUG_SYNC") != nullptr;  // isolate a faulting kernel

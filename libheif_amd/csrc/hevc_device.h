@@ -108,6 +108,13 @@ struct Substream {
   uint32_t pad2;
 };
 
+struct ReconWave {  // one reconstruction wavefront: CTB rows first_row, first_row + stride, ... of one colour component of one picture
+  uint32_t pic, comp, first_row, stride;
+  uint32_t base_row;    // batch row index of the picture's CTB row 0 (progress words are per batch row and component)
+  uint32_t start_lag;   // CTBs the row above must be ahead before a row is started (>= 2)
+  uint32_t pad0, pad1;
+};
+
 struct RowDesc {   // one CTB row of one picture, for the reconstruction wavefront
   uint32_t pic;
   uint32_t row;

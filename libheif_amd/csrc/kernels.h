@@ -8,8 +8,8 @@ namespace hipdec {
 
 struct ReconArgs {
   const PicParams* pics;
-  const RowDesc* rows;
-  uint32_t num_rows;
+  const ReconWave* waves;
+  uint32_t num_waves;
   uint8_t* arena;
   uint32_t* row_progress;  // per (batch row, component): CTBs completed
   uint32_t* ticket;

@@ -257,14 +257,12 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
   uint32_t t = 0;
   if (lane == 0) t = atomicAdd(A.ticket, 1u);
   const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-  if (ticket >= A.num_rows * 3u) return;
+  if (ticket >= A.num_waves) return;
   if (__hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // failed parse: maps are garbage
-  const uint32_t my_row = ticket / 3u;     // batch row index (rows are listed picture by picture)
-  const int c_idx = (int)(ticket % 3u);
-  const RowDesc rd = A.rows[my_row];
-  const PicParams& P = A.pics[rd.pic];
+  const ReconWave wd = A.waves[ticket];
+  const int c_idx = (int)wd.comp;
+  const PicParams& P = A.pics[wd.pic];
   if (c_idx > 0 && !P.chroma_format_idc) return;
-  const int cy = (int)rd.row;
   const int sub = c_idx ? 2 : 1;
   const int ctb = 1 << P.log2_ctb, ctbc = ctb / sub;
   const int units = 1 << P.units_per_ctb_log2;
@@ -274,11 +272,14 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
   // line buffer: bottom sample row of every CTB row of this component, row stride = rec_stride
   uint32_t* line = (uint32_t*)(A.arena + P.off_line[c_idx]);
   const uint32_t line_words = P.rec_stride[c_idx] / 4;
-  uint32_t* my_progress = A.row_progress + (size_t)my_row * 3 + c_idx;
-  const uint32_t* up_progress = my_progress - 3;
   constexpr int ES = (int)sizeof(Pix);
   int err = 0;
+  uint32_t my_row = 0;
 
+  for (int cy = (int)wd.first_row; cy < P.ctb_h && !err; cy += (int)wd.stride) {
+  my_row = wd.base_row + (uint32_t)cy;     // batch row index
+  uint32_t* my_progress = A.row_progress + (size_t)my_row * 3 + c_idx;
+  const uint32_t* up_progress = my_progress - 3;
   for (int cx = 0; cx < P.ctb_w && !err; cx++) {
     const int ctb_rs = cy * P.ctb_w + cx;
     const CtbInfo ci = ctb_info[ctb_rs];
@@ -288,11 +289,12 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
     // ---- wait for the row above: above-right CTB done (or the row end) ----
     const Pix* top = (const Pix*)(L.top_raw + 1);
     if (cy > 0) {
-      const uint32_t need = (uint32_t)(cx + 2 < P.ctb_w ? cx + 2 : P.ctb_w);
+      uint32_t need = cx == 0 ? wd.start_lag : (uint32_t)(cx + 2);   // 2 = above-right CTB; a larger start distance decouples the rows
+      if (need > (uint32_t)P.ctb_w) need = (uint32_t)P.ctb_w;
       uint32_t spins = 0;
       while (__hip_atomic_load(up_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1u << 24) || __hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { err = DEV_ERR_TIMEOUT; break; }
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > (1u << 22) || __hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { err = DEV_ERR_TIMEOUT; break; }
       }
       if (err) break;
       // top border samples xc0 - 1 .. xc0 + 2 * ctbc - 1 from the line buffer (write-through data: sc1 loads)
@@ -361,14 +363,15 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the line-buffer stores have left this wave
     if (lane == 0) __hip_atomic_store(my_progress, (uint32_t)(cx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  }
   if (err && lane == 0) atomicCAS((int*)A.status, 0, err | (int)(0x40000000u) | (int)(my_row << 8));
 }
 
 void launch_recon(const ReconArgs& a, bool wide, hipStream_t s)
 {
-  if (!a.num_rows) return;
-  if (wide) hipLaunchKernelGGL((k_recon<uint16_t>), dim3(a.num_rows * 3), dim3(64), 0, s, a);
-  else hipLaunchKernelGGL((k_recon<uint8_t>), dim3(a.num_rows * 3), dim3(64), 0, s, a);
+  if (!a.num_waves) return;
+  if (wide) hipLaunchKernelGGL((k_recon<uint16_t>), dim3(a.num_waves), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((k_recon<uint8_t>), dim3(a.num_waves), dim3(64), 0, s, a);
 }
 
 }  // namespace hipdec

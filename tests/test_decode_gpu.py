@@ -107,6 +107,7 @@ def test_fewer_parser_waves_than_substreams(waves, monkeypatch):
     """large batches deal a picture's substreams round-robin to W < n waves (WPP rows r, r+W, ... per wave)"""
     from libheif_amd.decoder import Batch
     monkeypatch.setenv("HIPDEC_WAVES_PER_PICTURE", str(waves))
+    monkeypatch.setenv("HIPDEC_RECON_WAVES_PER_PICTURE", str(waves))     # same dealing for the reconstruction wavefronts
     streams = [orc.encode(orc.synth_image(264, 456, 8, 1, seed=70), log2_ctb=5, log2_max_tb=5),            # 15 WPP rows
                orc.encode(orc.synth_image(200, 136, 8, 1, seed=71), tile_cols=3, tile_rows=2, wpp=0),       # 6 tiles
                orc.encode(orc.synth_image(200, 136, 8, 1, seed=72), num_slices=3, wpp=1),
