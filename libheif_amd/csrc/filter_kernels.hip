@@ -175,6 +175,17 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
 // picture (blockIdx.y): the deblocked source tile plus a one-sample halo is staged in LDS with coalesced dword loads issued
 // back to back (memory-level parallelism instead of a dependent load chain per thread), then every thread classifies and
 // offsets 4 samples of SAO_RPT rows out of LDS and stores one dword per row.
+// a CTB's parameter set in registers (never a struct in memory: dynamic indexing would push it to scratch)
+struct SaoRegs { int type, cls, o0, o1, o2, o3; };
+__device__ __forceinline__ SaoRegs sao_unpack(uint32_t w0, uint32_t w1, uint32_t w2)
+{
+  SaoRegs r;
+  r.type = (int)(w0 & 255u); r.cls = (int)((w0 >> 8) & 255u);
+  r.o0 = (int)(int16_t)(w0 >> 16); r.o1 = (int)(int16_t)(w1 & 0xffffu); r.o2 = (int)(int16_t)(w1 >> 16); r.o3 = (int)(int16_t)(w2 & 0xffffu);
+  return r;
+}
+__device__ __forceinline__ int sao_off(const SaoRegs& sp, int i) { return i == 0 ? sp.o0 : (i == 1 ? sp.o1 : (i == 2 ? sp.o2 : sp.o3)); }
+
 constexpr int SAO_TW = 128, SAO_TH = 32, SAO_RPT = SAO_TH / 8;   // rows per thread
 template <typename Pix>
 __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
@@ -210,12 +221,13 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
   const int tx = (tid & 31) * 4, ty = tid >> 5;
   const int xs0 = ox_t + crop_xc, ys0 = oy_t + crop_yc;
   // the SAO parameters of this thread's rows are requested first so that they travel together with the tile loads
-  SaoParams sp_row[SAO_RPT];
+  uint32_t spw[SAO_RPT][3];   // SaoParams as three dwords per row (statically indexed: stays in registers)
 #pragma unroll
   for (int rr = 0; rr < SAO_RPT; rr++) {
     int y = oy_t + ty + rr * 8 + crop_yc, x = ox_t + tx + crop_xc;
     y = y < H ? y : H - 1; x = x < W ? x : W - 1;
-    sp_row[rr] = sao[(size_t)((y >> lctb) * ctb_w + (x >> lctb)) * 3 + c];
+    const uint32_t* src = (const uint32_t*)&sao[(size_t)((y >> lctb) * ctb_w + (x >> lctb)) * 3 + c];
+    spw[rr][0] = src[0]; spw[rr][1] = src[1]; spw[rr][2] = src[2];
   }
   // ---- stage source rows ys0-1 .. ys0+TH, bytes [ab, ...) of each row ----
   int ab = (xs0 - 1) * ES;
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
     const int xf = ox0 + crop_xc, xl = xf + npx - 1;
     const int ctb_first = (y >> lctb) * ctb_w + (xf >> lctb);
     const bool one_ctb = (xf >> lctb) == (xl >> lctb);
-    const SaoParams sp_first = sp_row[rr];
+    const SaoRegs sp_first = sao_unpack(spw[rr][0], spw[rr][1], spw[rr][2]);
     Pix res[4];
 #define SAO_AT(row, x) (((const Pix*)((const uint8_t*)tile[row] + ((x) * ES - ab)))[0])
     // fast paths: the 4 samples share one CTB (one parameter set) and no per-sample lossless check is needed
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
                           xl + 1 < W && y + 1 < H;                                                                  // ... or the picture
     bool done = false;
     if (one_ctb && !check_bypass && npx == 4) {
-      const SaoParams sp = sp_first;
+      const SaoRegs sp = sp_first;
       if (sp.type == 0) {
 #pragma unroll
         for (int i = 0; i < 4; i++) res[i] = SAO_AT(lr, xf + i);
@@ -255,40 +267,43 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           int v = SAO_AT(lr, xf + i);
-          const int k = ((v >> (bit_depth - 5)) - sp.band_or_class) & 31;
-          const int off = k == 0 ? sp.offset[0] : (k == 1 ? sp.offset[1] : (k == 2 ? sp.offset[2] : (k == 3 ? sp.offset[3] : 0)));
+          const int k = ((v >> (bit_depth - 5)) - sp.cls) & 31;
+          const int off = k < 4 ? sao_off(sp, k) : 0;
           res[i] = (Pix)clip3(0, maxv, v + off);
         }
         done = true;
       } else if (interior) {
-        const int cls = sp.band_or_class;
+        const int cls = sp.cls;
         const int hx = cls == 1 ? 0 : (cls == 3 ? 1 : -1), hy = cls == 0 ? 0 : -1;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const int x = xf + i;
           const int v = SAO_AT(lr, x), a = SAO_AT(lr + hy, x + hx), b = SAO_AT(lr - hy, x - hx);
           const int e = ((v > a) - (v < a)) + ((v > b) - (v < b));     // -2 .. 2 ; edgeIdx = 2 + e remapped {0,1,2,3,4} -> {1,2,0,3,4}
-          const int off = e == -2 ? sp.offset[0] : (e == -1 ? sp.offset[1] : (e == 1 ? sp.offset[2] : (e == 2 ? sp.offset[3] : 0)));
+          const int off = e == -2 ? sp.o0 : (e == -1 ? sp.o1 : (e == 1 ? sp.o2 : (e == 2 ? sp.o3 : 0)));
           res[i] = (Pix)clip3(0, maxv, v + off);
         }
         done = true;
       }
     }
     if (!done)
-    for (int i = 0; i < npx; i++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (i >= npx) { res[i] = 0; continue; }
       const int x = xf + i;
       int v = SAO_AT(lr, x);
       const int ctb = one_ctb ? ctb_first : (y >> lctb) * ctb_w + (x >> lctb);
-      const SaoParams sp = one_ctb ? sp_first : sao[(size_t)ctb * 3 + c];
+      SaoRegs sp = sp_first;
+      if (!one_ctb) { const uint32_t* q = (const uint32_t*)&sao[(size_t)ctb * 3 + c]; sp = sao_unpack(q[0], q[1], q[2]); }
       if (sp.type) {
         int ctb_dummy;
         const uint8_t fl = check_bypass ? u_flags[unit_index(P, (x * sub) >> 2, (y * sub) >> 2, &ctb_dummy)] : (uint8_t)0;
         if (!(fl & UF_BYPASS)) {
           if (sp.type == 1) {
-            const int k = ((v >> (bit_depth - 5)) - sp.band_or_class) & 31;
-            if (k < 4) v = clip3(0, maxv, v + sp.offset[k]);
+            const int k = ((v >> (bit_depth - 5)) - sp.cls) & 31;
+            if (k < 4) v = clip3(0, maxv, v + sao_off(sp, k));
           } else {
-            const int cls = sp.band_or_class;
+            const int cls = sp.cls;
             const int hx = cls == 1 ? 0 : (cls == 3 ? 1 : -1), hy = cls == 0 ? 0 : -1;  // first neighbour; second is the mirror
             int edge_idx = 2, skip = 0;
             for (int k = 0; k < 2; k++) {
@@ -309,7 +324,7 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
             }
             if (!skip) {
               if (edge_idx <= 2) edge_idx = edge_idx == 2 ? 0 : edge_idx + 1;
-              if (edge_idx) v = clip3(0, maxv, v + sp.offset[edge_idx - 1]);
+              if (edge_idx) v = clip3(0, maxv, v + sao_off(sp, edge_idx - 1));
             }
           }
         }
@@ -320,7 +335,10 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
     Pix* o = out + (size_t)oy * os + ox0;
     if (npx == 4 && ES == 1) *(uint32_t*)o = res[0] | (res[1] << 8) | (res[2] << 16) | ((uint32_t)res[3] << 24);
     else if (npx == 4 && ES == 2) *(uint2*)o = make_uint2(res[0] | ((uint32_t)res[1] << 16), res[2] | ((uint32_t)res[3] << 16));
-    else for (int i = 0; i < npx; i++) o[i] = res[i];
+    else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) if (i < npx) o[i] = res[i];
+    }
   }
 }
 

@@ -1157,51 +1157,62 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
   return s.err;
 }
 
-// Pool mode driver of one wave: start-up share of the task list, then run ready rows until every row is finished.
-PC_DEV void parse_pool_wave(const ParseArgs& A, uint32_t wave_idx, uint32_t n_waves, Lds* lds)
+// Driver of one parser wave, both modes, with ONE call site of the (fully inlined) substream parser.
+//   static mode: substreams first, first + stride, ... < end of the wave's table entry, each start to finish;
+//   pool mode  : start-up share of the task list, then ready rows from the queue until every row is finished.
+PC_DEV void parse_wave(const ParseArgs& A, uint32_t wave_idx, Lds* lds)
 {
-  // start-up: rows without a predecessor are ready; the others are armed to be woken at distance 2.  Only the first
-  // waves to RUN (low tickets) share this work: a wave that is not resident yet must not own a share, or the resident
-  // ones would starve waiting for rows nobody queued.
-  const uint32_t n_init = n_waves < 64u ? n_waves : 64u;
-  for (uint32_t sub = wave_idx; wave_idx < n_init && sub < A.num_subs; sub += n_init) {
-    const int32_t dep = (int32_t)uload32(&A.subs[sub].dep_sub);
-    if (dep < 0) pool_push(A, sub);
-    else {
-      uint32_t need = 2u;
-      const uint32_t dep_len = uload32(&A.subs[sub].dep_len);
-      if (need > dep_len) need = dep_len;
-      if (pool_arm(A, sub, (uint32_t)dep, need)) pool_push(A, sub);
+  const uint32_t pool = A.pool;
+  uint32_t sub = 0, stride = 1, end = 0, lag = 2;
+  if (!pool) {
+    sub = uload32(&A.waves[wave_idx].first); stride = uload32(&A.waves[wave_idx].stride);
+    end = uload32(&A.waves[wave_idx].end); lag = uload32(&A.waves[wave_idx].start_lag);
+  } else {
+    // start-up: rows without a predecessor are ready; the others are armed to be woken at distance 2.  Only the first
+    // waves to RUN (low tickets) share this work: a wave that is not resident yet must not own a share, or the resident
+    // ones would starve waiting for rows nobody queued.
+    const uint32_t n_init = A.num_waves < 64u ? A.num_waves : 64u;
+    for (uint32_t s0 = wave_idx; wave_idx < n_init && s0 < A.num_subs; s0 += n_init) {
+      const int32_t dep = (int32_t)uload32(&A.subs[s0].dep_sub);
+      if (dep < 0) pool_push(A, s0);
+      else {
+        uint32_t need = 2u;
+        const uint32_t dep_len = uload32(&A.subs[s0].dep_len);
+        if (need > dep_len) need = dep_len;
+        if (pool_arm(A, s0, (uint32_t)dep, need)) pool_push(A, s0);
+      }
     }
   }
   for (;;) {
-    if (pc_load_wt_uni(A.qctl + 2) >= A.num_subs) return;                      // every row finished
-    if (pc_load_wt_uni((const uint32_t*)A.status) != 0) return;               // a row failed: stop the batch
-    const uint32_t h = pc_atomic_add(A.qctl + 0, 1u);
-    uint32_t* slot = A.queue + (h & (A.queue_cap - 1u));
-    uint32_t v = 0, spins = 0;
-    for (;;) {
-      v = pc_load_wt_uni(slot);
-      if (v != 0) break;
-      if (++spins >= PC_POOL_SPINS) break;
-      if ((spins & 15u) == 0 && (pc_load_wt_uni(A.qctl + 2) >= A.num_subs || pc_load_wt_uni((const uint32_t*)A.status) != 0)) break;
-      pc_idle();
-    }
-    if (v == 0) {
+    uint32_t* slot = A.queue;
+    if (!pool) { if (sub >= end) return; }
+    else {
+      if (pc_load_wt_uni(A.qctl + 2) >= A.num_subs) return;                      // every row finished
+      if (pc_load_wt_uni((const uint32_t*)A.status) != 0) return;               // a row failed: stop the batch
+      const uint32_t h = pc_atomic_add(A.qctl + 0, 1u);
+      slot = A.queue + (h & (A.queue_cap - 1u));
+      uint32_t v = 0, spins = 0;
+      for (;;) {
+        v = pc_load_wt_uni(slot);
+        if (v != 0) break;
+        if (++spins >= PC_POOL_SPINS) break;
+        if ((spins & 15u) == 0 && (pc_load_wt_uni(A.qctl + 2) >= A.num_subs || pc_load_wt_uni((const uint32_t*)A.status) != 0)) break;
+        pc_idle();
+      }
+      if (v == 0) {
 #if defined(HIPDEC_HOST_EMU)
-      pc_atomic_add(A.qctl + 0, (uint32_t)-1);   // single emulated wave: give the ticket back, nothing is runnable now
+        pc_atomic_add(A.qctl + 0, (uint32_t)-1);   // single emulated wave: give the ticket back, nothing is runnable now
 #endif
-      if (pc_load_wt_uni(A.qctl + 2) >= A.num_subs || pc_load_wt_uni((const uint32_t*)A.status) != 0) return;
-#if defined(HIPDEC_HOST_EMU)
-      pc_report(A.status, DEV_ERR_TIMEOUT | (int32_t)0x20000000);   // queue empty but rows unfinished: scheduler bug
-#else
-      pc_report(A.status, DEV_ERR_TIMEOUT | (int32_t)0x20000000);   // starved for ~seconds: give up loudly
-#endif
-      return;
+        if (pc_load_wt_uni(A.qctl + 2) >= A.num_subs || pc_load_wt_uni((const uint32_t*)A.status) != 0) return;
+        pc_report(A.status, DEV_ERR_TIMEOUT | (int32_t)0x20000000);   // queue empty (emulation) / starved for seconds (device): loud
+        return;
+      }
+      PC_VEC_BEGIN if (lane == 0) pc_store_wt(slot, 0u); PC_VEC_END
+      sub = v - 1u;
     }
-    PC_VEC_BEGIN if (lane == 0) pc_store_wt(slot, 0u); PC_VEC_END
-    const int r = parse_substream(A, v - 1u, 0, 2u, lds);
-    if (r == PARSE_DONE) pc_atomic_add(A.qctl + 2, 1u);
+    const int r = parse_substream(A, sub, !pool && stride == 1, lag, lds);
+    if (!pool) { if (r) return; sub += stride; }
+    else if (r == PARSE_DONE) pc_atomic_add(A.qctl + 2, 1u);
     else if (r > 0) return;
   }
 }

@@ -25,11 +25,7 @@ namespace hipdec {
     for (int i = lane * 8; i < 32 * 32; i += 512) *(uint4*)&lds.coef[i] = make_uint4(0, 0, 0, 0);         \
     __syncthreads();                                                                                      \
     if (wave_idx >= A.num_waves) return;                                                                  \
-    if (A.pool) { pcore::parse_pool_wave(A, wave_idx, A.num_waves, &lds); return; }                       \
-    const uint32_t first = pcore::uload32(&A.waves[wave_idx].first), stride = pcore::uload32(&A.waves[wave_idx].stride),\
-                   end = pcore::uload32(&A.waves[wave_idx].end), lag = pcore::uload32(&A.waves[wave_idx].start_lag);\
-    for (uint32_t sub = first; sub < end; sub += stride)                                                  \
-      if (pcore::parse_substream(A, sub, stride == 1, lag, &lds)) break;                                  \
+    pcore::parse_wave(A, wave_idx, &lds);                                                                 \
 
 __global__ __launch_bounds__(64) void k_parse(ParseArgs A) { HIPDEC_PARSE_BODY }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_parse_occ7(ParseArgs A) { HIPDEC_PARSE_BODY }

@@ -60,16 +60,21 @@ int emu_run_parse(EmuBatch* b)
   memset(&lds, 0, sizeof(lds));
   if (A.pool) {
     // pool mode: one emulated wave drains the ready queue (rows suspend and get re-queued exactly as on the device)
-    pcore::parse_pool_wave(A, 0, 1, &lds);
+    A.num_waves = 1;
+    pcore::parse_wave(A, 0, &lds);
   } else {
-    // every substream once, in index order (the wave table only changes WHICH wave runs a substream)
+    // static mode: the waves one after the other in ticket order; a wave's rows are complete before a later wave needs them
+    // only if every substream's predecessor has a smaller index AND is run first, so run substream by substream instead:
+    // the per-wave table must cover every substream exactly once, then each wave entry is replayed with stride 1 semantics
     std::vector<uint8_t> covered(b->L.num_subs, 0);
     for (uint32_t w = 0; w < A.num_waves; w++)
       for (uint32_t s = A.waves[w].first; s < A.waves[w].end; s += A.waves[w].stride) covered[s]++;
-    for (uint32_t s = 0; s < b->L.num_subs; s++) {
+    for (uint32_t s = 0; s < b->L.num_subs; s++)
       if (covered[s] != 1) { b->status = -1; return -1; }
-      pcore::parse_substream(A, s, 0, 2, &lds);
-    }
+    std::vector<ParseWave> one(b->L.num_subs);
+    for (uint32_t s = 0; s < b->L.num_subs; s++) one[s] = ParseWave{s, 1, s + 1, 2};
+    A.waves = one.data();
+    for (uint32_t s = 0; s < b->L.num_subs; s++) pcore::parse_wave(A, s, &lds);
   }
   b->status = *(int32_t*)(a + b->L.off_status);
   return b->status;
