@@ -28,6 +28,7 @@ namespace hipdec {
     pcore::parse_wave(A, wave_idx, &lds);                                                                 \
 
 __global__ __launch_bounds__(64) void k_parse(ParseArgs A) { HIPDEC_PARSE_BODY }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_parse_occ6(ParseArgs A) { HIPDEC_PARSE_BODY }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_parse_occ7(ParseArgs A) { HIPDEC_PARSE_BODY }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_parse_occ8(ParseArgs A) { HIPDEC_PARSE_BODY }
 
@@ -36,9 +37,10 @@ void launch_parse(const ParseArgs& a, hipStream_t s)
   if (!a.num_waves) return;
   static const int forced = getenv("HIPDEC_PARSE_OCCUPANCY") ? atoi(getenv("HIPDEC_PARSE_OCCUPANCY")) : -1;
   // throughput mode (the chip is oversubscribed with parser waves): 8 waves per SIMD; latency mode: all registers
-  const int occ = forced >= 0 ? forced : (a.num_waves >= 2048 ? 8 : 0);
+  const int occ = forced >= 0 ? forced : (a.pool ? 7 : (a.num_waves >= 2048 ? 8 : 0));
   if (occ == 8) hipLaunchKernelGGL(k_parse_occ8, dim3(a.num_waves), dim3(64), 0, s, a);
   else if (occ == 7) hipLaunchKernelGGL(k_parse_occ7, dim3(a.num_waves), dim3(64), 0, s, a);
+  else if (occ == 6) hipLaunchKernelGGL(k_parse_occ6, dim3(a.num_waves), dim3(64), 0, s, a);
   else hipLaunchKernelGGL(k_parse, dim3(a.num_waves), dim3(64), 0, s, a);
 }
 
