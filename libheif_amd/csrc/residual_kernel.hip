@@ -26,10 +26,13 @@ __constant__ int8_t r_dst[16] = {29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 5
 __constant__ uint8_t r_chroma_qp[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37};
 __constant__ int r_level_scale[6] = {40, 45, 51, 57, 64, 72};
 
+// Transposed, j-contiguous operands so that both 1-D passes are chains of v_dot2_i32_i16 (two MACs per instruction,
+// one 32-bit LDS read per operand pair).  Rows are padded by 2 samples: consecutive lanes then hit distinct banks.
+constexpr int RPAD = 2;
 struct ResLds {
-  int8_t dct[32 * 32];
-  int16_t blk[4][32 * 32];
-  int16_t tmp[4][32 * 32];
+  alignas(4) int16_t et32[32 * 32], et16[16 * 16], et8[8 * 8], et4[4 * 4], est4[4 * 4];   // E^T[i][j] per size, DST last
+  alignas(4) int16_t blk[4][32 * (32 + RPAD)];   // per wave: scaled levels, TRANSPOSED: blk[x][j] = d[j][x]
+  alignas(4) int16_t tmp[4][32 * (32 + RPAD)];   // per wave: first-stage output tmp[y][j]
   uint8_t m_size[256], m_flags[256], m_ipm[256];
   int8_t m_qp[256];
   uint16_t list[256];
@@ -43,18 +46,26 @@ __device__ __forceinline__ uint32_t compact1by1(uint32_t v)
   return v;
 }
 
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int acc)
+{
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), acc, false);
+}
+
 // one transform block, by one wave: coef (global, n*n int16, raster) -> residual in place
 __device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, int16_t* coef, int log2n, int bit_depth, int qp, int dst,
                                                int transform_skip, int bypass)
 {
   if (bypass) return;  // cu_transquant_bypass: the coefficient levels are the residual (8.6.2)
-  const int n = 1 << log2n, nn = n * n;
+  const int n = 1 << log2n, nn = n * n, rs = n + RPAD;
   int16_t* blk = L.blk[wave];
   int16_t* tmp = L.tmp[wave];
+  const int16_t* et = dst ? L.est4 : (log2n == 2 ? L.et4 : (log2n == 3 ? L.et8 : (log2n == 4 ? L.et16 : L.et32)));
   // ---- scaling (8.6.3, flat m = 16) + nonzero extent ----
   const int bd_shift = bit_depth + log2n - 5;
   const long long scale = (long long)(16 * r_level_scale[qp % 6]) << (qp / 6);
   const long long rnd = 1ll << (bd_shift - 1);
+  const int bd_shift2 = 20 - bit_depth;
   // nonzero extent (max_row, max_col) without cross-lane shuffles: rows grow with the lane index, so the last
   // nonzero row falls out of one ballot per pass; the last nonzero column is found bit by bit with five ballots
   int max_row = -1;
@@ -72,10 +83,22 @@ __device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, in
       d[k] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
       if (c[k]) { const int cc = (idx + k) & (n - 1); my_col = cc > my_col ? cc : my_col; }
     }
-    if (active) *(uint2*)&blk[idx] = make_uint2((uint16_t)d[0] | ((uint32_t)(uint16_t)d[1] << 16), (uint16_t)d[2] | ((uint32_t)(uint16_t)d[3] << 16));
+    if (active) {
+      if (transform_skip) {  // 8.6.4.2: r = d << 7, then the second-stage shift; no transform, no LDS
+        int16_t r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = (int16_t)(((int)d[k] * 128 + (1 << (bd_shift2 - 1))) >> bd_shift2);
+        *(uint2*)&coef[idx] = make_uint2((uint16_t)r[0] | ((uint32_t)(uint16_t)r[1] << 16), (uint16_t)r[2] | ((uint32_t)(uint16_t)r[3] << 16));
+      } else {
+        const int y = idx >> log2n, x0 = idx & (n - 1);   // the lane's 4 levels sit in row y, columns x0..x0+3
+#pragma unroll
+        for (int k = 0; k < 4; k++) blk[(x0 + k) * rs + y] = d[k];
+      }
+    }
     const unsigned long long nz = __ballot((raw.x | raw.y) != 0);
     if (nz) { const int last_lane = 63 - __clzll((long long)nz); const int r = (base + last_lane * 4) >> log2n; max_row = r > max_row ? r : max_row; }
   }
+  if (transform_skip) return;
   int max_col = -1;
   {
     unsigned long long cand = __ballot(my_col >= 0);
@@ -89,42 +112,34 @@ __device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, in
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  const int bd_shift2 = 20 - bit_depth;
-  if (transform_skip) {  // 8.6.4.2: r = d << 7, then the second-stage shift
-    for (int idx = lane * 4; idx < nn; idx += 256) {
-      int16_t r[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) r[k] = (int16_t)(((int)blk[idx + k] * 128 + (1 << (bd_shift2 - 1))) >> bd_shift2);
-      *(uint2*)&coef[idx] = make_uint2((uint16_t)r[0] | ((uint32_t)(uint16_t)r[1] << 16), (uint16_t)r[2] | ((uint32_t)(uint16_t)r[3] << 16));
-    }
-    return;
-  }
-  const int step = 32 >> log2n;  // row stride into the 32-point matrix
-  const int rows_nz = max_row + 1, cols_nz = max_col + 1;   // coefficient rows / columns that can be nonzero
-  // first stage (columns): tmp[i][x] = clip16((sum_j M[j][i] * blk[j][x] + 64) >> 7), only x < cols_nz matter
+  const int rows_nz2 = (max_row + 2) >> 1, cols_nz = max_col + 1, cols_nz2 = (max_col + 2) >> 1;   // nonzero extents (pairs)
+  // first stage (columns): tmp[i][x] = clip16((sum_j E[j][i] * d[j][x] + 64) >> 7); only x < cols_nz can be nonzero.
+  // (pairs beyond max_row read zeros: the levels there are zero and were written)
   for (int idx = lane; idx < nn; idx += 64) {
     const int x = idx & (n - 1), i = idx >> log2n;
     int sum = 0;
     if (x < cols_nz) {
-      if (dst) { for (int j = 0; j < rows_nz; j++) sum += (int)r_dst[j * 4 + i] * (int)blk[j * 4 + x]; }
-      else { for (int j = 0; j < rows_nz; j++) sum += (int)L.dct[(j * step) * 32 + i] * (int)blk[j * n + x]; }
+      const uint32_t* e = (const uint32_t*)(et + i * n);
+      const uint32_t* v = (const uint32_t*)(blk + x * rs);
+      for (int j = 0; j < rows_nz2; j++) sum = dot2(e[j], v[j], sum);
     }
-    tmp[idx] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
+    tmp[i * rs + x] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  // second stage (rows): res[y][i] = (sum_j M[j][i] * tmp[y][j] + rnd) >> bd_shift2, j < cols_nz
+  // second stage (rows): res[y][i] = (sum_j E[j][i] * tmp[y][j] + rnd) >> bd_shift2, j < cols_nz
   for (int idx = lane * 4; idx < nn; idx += 256) {
     const int y = idx >> log2n, i0 = idx & (n - 1);
+    const uint32_t* v = (const uint32_t*)(tmp + y * rs);
+    int sum[4] = {0, 0, 0, 0};
+    for (int j = 0; j < cols_nz2; j++) {
+      const uint32_t t = v[j];
+#pragma unroll
+      for (int k = 0; k < 4; k++) sum[k] = dot2(((const uint32_t*)(et + (i0 + k) * n))[j], t, sum[k]);
+    }
     int16_t r[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int i = i0 + k;
-      int sum = 0;
-      if (dst) { for (int j = 0; j < cols_nz; j++) sum += (int)r_dst[j * 4 + i] * (int)tmp[y * 4 + j]; }
-      else { for (int j = 0; j < cols_nz; j++) sum += (int)L.dct[(j * step) * 32 + i] * (int)tmp[y * n + j]; }
-      r[k] = (int16_t)((sum + (1 << (bd_shift2 - 1))) >> bd_shift2);
-    }
+    for (int k = 0; k < 4; k++) r[k] = (int16_t)((sum[k] + (1 << (bd_shift2 - 1))) >> bd_shift2);
     *(uint2*)&coef[idx] = make_uint2((uint16_t)r[0] | ((uint32_t)(uint16_t)r[1] << 16), (uint16_t)r[2] | ((uint32_t)(uint16_t)r[3] << 16));
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -146,11 +161,23 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
   const int units = 1 << P.units_per_ctb_log2;
   const int ctb = 1 << P.log2_ctb;
   const size_t base = (size_t)ctb_rs * units;
-  for (int idx = tid; idx < 1024; idx += 256) {  // 32-point DCT matrix (8.6.4.2) from its 33 distinct magnitudes
-    const int mm = idx >> 5, nx = idx & 31;
-    int k = ((2 * nx + 1) * mm) & 127;
-    if (k > 64) k = 128 - k;
-    L.dct[idx] = (int8_t)(k <= 32 ? r_dct_c[k] : -r_dct_c[64 - k]);
+  // E^T[i][j] for every transform size (8.6.4.2): E_n[j][i] = M32[j * 32/n][i], the 32-point matrix from its 33 magnitudes
+  for (int idx = tid; idx < 1024 + 256 + 64 + 16 + 16; idx += 256) {
+    int lg, off;
+    int16_t* dstp;
+    if (idx < 1024) { lg = 5; off = idx; dstp = L.et32; }
+    else if (idx < 1280) { lg = 4; off = idx - 1024; dstp = L.et16; }
+    else if (idx < 1344) { lg = 3; off = idx - 1280; dstp = L.et8; }
+    else if (idx < 1360) { lg = 2; off = idx - 1344; dstp = L.et4; }
+    else { lg = -1; off = idx - 1360; dstp = L.est4; }
+    if (lg < 0) { const int i = off >> 2, j = off & 3; dstp[off] = r_dst[j * 4 + i]; }
+    else {
+      const int nsz = 1 << lg, i = off >> lg, j = off & (nsz - 1);
+      const int mm = j * (32 >> lg);          // row of the 32-point matrix
+      int k = ((2 * i + 1) * mm) & 127;
+      if (k > 64) k = 128 - k;
+      dstp[off] = (int16_t)(k <= 32 ? r_dct_c[k] : -r_dct_c[64 - k]);
+    }
   }
   if (tid == 0) L.count = 0;
   if (tid < units) {
