@@ -100,6 +100,7 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
   int val[3] = {0, 0, 0}, av[3] = {0, 0, 0};
 #pragma unroll
   for (int j = 0; j < 3; j++) {
+    if (64 * j >= N) continue;          // wave-uniform: small blocks have 17 / 33 / 65 reference samples
     const int e = lane + 64 * j;
     int a = 0, v = 0;
     if (e < N) {
@@ -124,32 +125,32 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
     }
     av[j] = a; val[j] = v;
     m[j] = __ballot(a);
+    if (e < N && a) L.ref0[e] = (uint16_t)v;
   }
   __syncthreads();
+  const int n_av = __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]);
+  if (n_av != N) {          // substitution process only where something is missing (wave-uniform)
+    const int any = n_av != 0;
 #pragma unroll
-  for (int j = 0; j < 3; j++) {
-    const int e = lane + 64 * j;
-    if (e < N && av[j]) L.ref0[e] = (uint16_t)val[j];
-  }
-  __syncthreads();
-  const int any = (m[0] | m[1] | m[2]) != 0;
-#pragma unroll
-  for (int j = 0; j < 3; j++) {
-    const int e = lane + 64 * j;
-    if (e < N && !av[j]) {
-      int v;
-      if (!any) v = 1 << (bit_depth - 1);
-      else v = L.ref0[find_src(e, m[0], m[1], m[2])];
-      val[j] = v;
+    for (int j = 0; j < 3; j++) {
+      if (64 * j >= N) continue;
+      const int e = lane + 64 * j;
+      if (e < N && !av[j]) {
+        int v;
+        if (!any) v = 1 << (bit_depth - 1);
+        else v = L.ref0[find_src(e, m[0], m[1], m[2])];
+        val[j] = v;
+      }
     }
-  }
-  __syncthreads();
+    __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 3; j++) {
-    const int e = lane + 64 * j;
-    if (e < N && !av[j]) L.ref0[e] = (uint16_t)val[j];
+    for (int j = 0; j < 3; j++) {
+      if (64 * j >= N) continue;
+      const int e = lane + 64 * j;
+      if (e < N && !av[j]) L.ref0[e] = (uint16_t)val[j];
+    }
+    __syncthreads();
   }
-  __syncthreads();
   // accessors in scan order: left column p[-1][k-1] = ref[2n - k], top row p[k-1][-1] = ref[2n + k]
   uint16_t* ref = L.ref0;
   // ---- 8.4.4.2.3 smoothing of the reference samples (luma only in 4:2:0) ----
@@ -168,6 +169,7 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
       }
 #pragma unroll
       for (int j = 0; j < 3; j++) {
+        if (64 * j >= N) continue;
         const int e = lane + 64 * j;
         if (e < N) {
           int v;
