@@ -212,7 +212,7 @@ def main():
                               frac=round(gbs / HBM_PEAK_GBS, 5))
         dom = max(("parse", "recon", "deblock", "sao"), key=lambda k: avg_us[k])
         # HBM traffic of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE separately) over this
-        # same workload, recorded per luma pixel in profiles/pmc_traffic.json by tools/_traffic.sh
+        # same workload, recorded per luma pixel in profiles/pmc_traffic.json by tools/prof_hbm_traffic.sh
         traffic = None
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))

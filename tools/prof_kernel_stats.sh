@@ -1,4 +1,4 @@
-# usage: bash tools/_prof.sh <tag> [bench args...]; leaves rocprofv3 stats CSVs under gpurun_out/prof_<tag>/
+# usage: bash tools/prof_kernel_stats.sh <tag> [bench args...]; leaves rocprofv3 stats CSVs under gpurun_out/prof_<tag>/
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag

@@ -1,4 +1,4 @@
-# usage: bash tools/_pmc.sh <tag> "<counters>" [bench args...]
+# usage: bash tools/prof_pmc.sh <tag> "<counters>" [bench args...]
 tag=$1; shift; ctrs=$1; shift
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
