@@ -190,6 +190,13 @@ def main():
     sync()
     single_ms = (time.perf_counter() - ts) / reps * 1e3
     single_t = single.timing_us()
+    # the plugin life cycle on one still, host to host (new_decoder -> push_data -> decode -> D2H of the planes -> free):
+    # what heif_decode_image() pays per item through libheif, PCIe included
+    from libheif_amd.decoder import HipDecoder
+    tp = time.perf_counter()
+    for _ in range(3):
+        dec = HipDecoder(); dec.push_data(streams[0]); dec.decode_next_image(); dec.free()
+    plugin_ms = (time.perf_counter() - tp) / 3 * 1e3
 
     out = None
     if rank == 0:
@@ -243,7 +250,8 @@ def main():
                            "achieved_gbs": round(e2e_alg / (elapsed / a.steps) / 1e9, 2),
                            "frac_of_hbm_peak": round(e2e_alg / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS, 5)},
             "single_still": {"ms": round(single_ms, 3), "mpixel_s": round(px_item / single_ms / 1e3, 2),
-                             "kernel_us": {k: round(v, 1) for k, v in single_t.items()}},
+                             "kernel_us": {k: round(v, 1) for k, v in single_t.items()},
+                             "plugin_lifecycle_host_to_host_ms": round(plugin_ms, 3)},
         }
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(streams[0], px_item, a.cpu_seconds, a.cpu_procs)

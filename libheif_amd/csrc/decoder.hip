@@ -21,13 +21,17 @@ using namespace hipdec;
 
 struct hipdec_batch : BatchLayout {
   uint8_t* arena = nullptr;
+  size_t arena_capacity = 0;
   std::vector<hipEvent_t> ev;   // 5 events per timing slot; run k records into slot k % slots
   uint64_t runs = 0;
   hipStream_t last_stream = nullptr;
   bool ran = false;
   ~hipdec_batch()
   {
-    if (arena) (void)hipFree(arena);
+    if (arena) {
+      if (last_stream) (void)hipStreamSynchronize(last_stream);   // nothing of this batch may still be running when the arena is recycled
+      arena_release(arena, arena_capacity);
+    }
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
   }
 };
@@ -40,7 +44,7 @@ int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* s
   std::vector<uint8_t> host;
   int rc = layout_batch(b, n, data, sizes, max_pixels, host, err);
   if (rc != HIPDEC_OK) return set_error(rc, "%s", err.c_str());
-  HIPDEC_CHECK_HIP(hipMalloc((void**)&b.arena, b.arena_size));
+  HIPDEC_CHECK_HIP(arena_acquire((void**)&b.arena, b.arena_size, &b.arena_capacity));
   HIPDEC_CHECK_HIP(hipMemcpy(b.arena, host.data(), b.upload_size, hipMemcpyHostToDevice));
   b.ev.assign(5, nullptr);
   for (auto& e : b.ev) HIPDEC_CHECK_HIP(hipEventCreate(&e));

@@ -12,6 +12,12 @@ int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3
 int ensure_init();
 hipStream_t default_stream();
 
+// Process-wide pool of decode arenas.  libheif creates and destroys one plugin decoder per item and per grid tile
+// (libheif/codecs/decoder.cc:388-405,549), so arenas are recycled by size instead of hipMalloc / hipFree per image.
+hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity);
+void arena_release(void* p, size_t capacity);
+void arena_pool_clear();
+
 #define HIPDEC_CHECK_HIP(expr)                                                                  \
   do {                                                                                          \
     hipError_t _e = (expr);                                                                     \

@@ -3,6 +3,9 @@
 // compute entry point fails with HIPDEC_ERR_DEVICE.
 #include "hipdec_internal.h"
 #include <mutex>
+#include <utility>
+#include <vector>
+#include <cstdint>
 
 namespace hipdec {
 
@@ -36,6 +39,67 @@ int ensure_init()
 
 hipStream_t default_stream() { return g_stream; }
 
+namespace {
+struct ArenaPool {
+  std::mutex mu;
+  std::vector<std::pair<size_t, void*>> free_list;   // (capacity, pointer)
+  size_t cached_bytes = 0;
+};
+ArenaPool g_pool;
+constexpr size_t kMaxCachedBytes = size_t(8) << 30;    // keep at most 8 GiB parked
+constexpr size_t kMaxPooledArena = size_t(1) << 30;    // bigger arenas (large batches) are not worth caching
+}  // namespace
+
+hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity)
+{
+  {
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    size_t best = SIZE_MAX;
+    for (size_t i = 0; i < g_pool.free_list.size(); i++) {
+      const size_t cap = g_pool.free_list[i].first;
+      if (cap >= bytes && cap <= bytes + bytes / 2 && (best == SIZE_MAX || cap < g_pool.free_list[best].first)) best = i;
+    }
+    if (best != SIZE_MAX) {
+      *out = g_pool.free_list[best].second; *capacity = g_pool.free_list[best].first;
+      g_pool.cached_bytes -= *capacity;
+      g_pool.free_list.erase(g_pool.free_list.begin() + (long)best);
+      return hipSuccess;
+    }
+  }
+  // round small arenas up so that items of similar size share a class
+  size_t cap = bytes;
+  if (bytes <= kMaxPooledArena) cap = (bytes + (size_t(4) << 20) - 1) / (size_t(4) << 20) * (size_t(4) << 20);
+  hipError_t e = hipMalloc(out, cap);
+  if (e != hipSuccess) {   // out of memory: drop the cache and retry once
+    arena_pool_clear();
+    e = hipMalloc(out, cap);
+  }
+  *capacity = cap;
+  return e;
+}
+
+void arena_release(void* p, size_t capacity)
+{
+  if (!p) return;
+  if (capacity <= kMaxPooledArena) {
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    if (g_pool.cached_bytes + capacity <= kMaxCachedBytes) {
+      g_pool.free_list.emplace_back(capacity, p);
+      g_pool.cached_bytes += capacity;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+
+void arena_pool_clear()
+{
+  std::lock_guard<std::mutex> lock(g_pool.mu);
+  for (auto& e : g_pool.free_list) (void)hipFree(e.second);
+  g_pool.free_list.clear();
+  g_pool.cached_bytes = 0;
+}
+
 }  // namespace hipdec
 
 using namespace hipdec;
@@ -65,6 +129,7 @@ void hipdec_shutdown(void)
 {
   std::lock_guard<std::mutex> lock(g_init_mutex);
   if (!g_initialised) return;
+  arena_pool_clear();
   if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
   g_initialised = false;
 }
