@@ -232,3 +232,34 @@ def test_corrupt_streams_never_hang_or_crash():
     d = HipDecoder(); d.push_data(base); img = d.decode_next_image(); d.free()
     for c in range(3):
         np.testing.assert_array_equal(img.planes[c], ref["planes"][c])
+
+
+def test_pool_scheduler_batch_and_error_path(monkeypatch):
+    """throughput-mode scheduling on the device (rows as pool tasks with suspend / resume): a mixed batch decodes
+    bit-exactly, a corrupt member fails the batch loudly without hanging, and the next batch is unaffected."""
+    from libheif_amd.decoder import Batch
+    from libheif_amd import HipDecError
+    monkeypatch.setenv("HIPDEC_PARSE_POOL", "1")
+    monkeypatch.setenv("HIPDEC_POOL_WAVES", "48")          # fewer waves than rows: rows queue up and get parked
+    cfgs = [dict(), dict(log2_ctb=4, log2_max_tb=4, stress=1), dict(tile_cols=2, tile_rows=2, wpp=1), dict(num_slices=3), dict(wpp=0)]
+    streams = [orc.encode(orc.synth_image(264 + 8 * (i % 4), 200 + 8 * (i % 3), 8, 1, seed=300 + i), **cfgs[i % len(cfgs)]) for i in range(24)]
+    b = Batch(streams)
+    for _ in range(2):
+        b.run(); b.status()
+    for i, s in enumerate(streams):
+        ref = orc.decode(s)
+        got = b.planes(i)
+        for c in range(3):
+            np.testing.assert_array_equal(got[c], ref["planes"][c], err_msg="item %d component %d" % (i, c))
+    bad = bytearray(streams[5])
+    for k in range(len(bad) // 2, len(bad) // 2 + 40):
+        bad[k] ^= 0xC3
+    b2 = Batch(streams[:5] + [bytes(bad)] + streams[6:])
+    b2.run()
+    with pytest.raises(HipDecError) as e:
+        b2.status()
+    assert e.value.code == -8
+    b3 = Batch(streams[:4])
+    b3.run(); b3.status()
+    for c in range(3):
+        np.testing.assert_array_equal(b3.planes(2)[c], orc.decode(streams[2])["planes"][c])
