@@ -54,6 +54,13 @@ __device__ __forceinline__ uint32_t compact1by1(uint32_t v)
   return v;
 }
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+// The workgroup is ONE wave: lanes only need their LDS traffic drained before they read each other's values.  (A
+// __syncthreads() would also wait for the outstanding global loads, i.e. serialise the residual prefetch.)
+__device__ __forceinline__ void lds_sync()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
 
 __device__ __forceinline__ int find_src(int e, uint64_t m0, uint64_t m1, uint64_t m2)
 {
@@ -95,6 +102,13 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
   Pix* tile = L.tile;
   const Pix* left = L.left;
 
+  // the block's residual is requested from HBM first, so that its latency hides behind the prediction
+  // (lane l owns samples l, l + 64, ...; the first 4 cover blocks up to 16x16, a 32x32 block reads the rest late)
+  int16_t rpre[4];
+  const int nn = n * n;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const int idx = lane + 64 * k; rpre[k] = (cbf && idx < nn) ? res[idx] : (int16_t)0; }
+
   // ---- 8.4.4.2.2 reference samples: gather + availability + substitution ----
   uint64_t m[3] = {0, 0, 0};
   int val[3] = {0, 0, 0}, av[3] = {0, 0, 0};
@@ -127,7 +141,7 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
     m[j] = __ballot(a);
     if (e < N && a) L.ref0[e] = (uint16_t)v;
   }
-  __syncthreads();
+  lds_sync();
   const int n_av = __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]);
   if (n_av != N) {          // substitution process only where something is missing (wave-uniform)
     const int any = n_av != 0;
@@ -142,14 +156,14 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
         val[j] = v;
       }
     }
-    __syncthreads();
+    lds_sync();
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       if (64 * j >= N) continue;
       const int e = lane + 64 * j;
       if (e < N && !av[j]) L.ref0[e] = (uint16_t)val[j];
     }
-    __syncthreads();
+    lds_sync();
   }
   // accessors in scan order: left column p[-1][k-1] = ref[2n - k], top row p[k-1][-1] = ref[2n + k]
   uint16_t* ref = L.ref0;
@@ -182,7 +196,7 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
           L.ref1[e] = (uint16_t)v;
         }
       }
-      __syncthreads();
+      lds_sync();
       ref = L.ref1;
     }
   }
@@ -236,17 +250,25 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
   }
 #undef RL
 #undef RT
-  __syncthreads();
+  lds_sync();
   if (!cbf) return;
 
   // ---- residual (already scaled + inverse transformed in place of the coefficients) ----
-  const int nn = n * n;
-  for (int idx = lane; idx < nn; idx += 64) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int idx = lane + 64 * k;
+    if (idx < nn) {
+      const int x = idx & (n - 1), y = idx >> log2n;
+      Pix* p = &tile[(yb + y) * ctbc + xb + x];
+      *p = (Pix)clip3(0, maxv, (int)*p + (int)rpre[k]);
+    }
+  }
+  for (int idx = lane + 256; idx < nn; idx += 64) {   // 32x32 only
     const int x = idx & (n - 1), y = idx >> log2n;
     Pix* p = &tile[(yb + y) * ctbc + xb + x];
     *p = (Pix)clip3(0, maxv, (int)*p + (int)res[idx]);
   }
-  __syncthreads();
+  lds_sync();
 }
 
 }  // namespace
@@ -319,7 +341,7 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
         *(uint32_t*)&L.m_ipmc[i] = *(const uint32_t*)(A.arena + P.off_u_ipmc + base + i);
       }
     }
-    __syncthreads();
+    lds_sync();
 
     // ---- this component's blocks of the CTB in z-scan order ----
     const int16_t* res_base = (const int16_t*)(A.arena + P.off_coeff[c_idx]) + (size_t)ctb_rs * (ctb * ctb / (sub * sub));
@@ -343,7 +365,7 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
       }
       z += 1 << (2 * (tb - 2));
     }
-    __syncthreads();
+    lds_sync();
 
     // ---- write the CTB out (planes are allocated CTB-aligned, so no edge guards), hand its bottom row to the
     //      row below and keep its right column as the next CTB's left border ----
@@ -358,10 +380,10 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
       uint32_t* dst = line + (size_t)cy * line_words + (size_t)xc0 * ES / 4;
       for (int i = lane; i < wpr; i += 64)
         __hip_atomic_store(dst + i, *(const uint32_t*)&L.tile[(ctbc - 1) * ctbc + i * PPW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
+      lds_sync();
       for (int i = lane; i < ctbc; i += 64) L.left[i] = L.tile[i * ctbc + ctbc - 1];
     }
-    __syncthreads();
+    lds_sync();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the line-buffer stores have left this wave
     if (lane == 0) __hip_atomic_store(my_progress, (uint32_t)(cx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
