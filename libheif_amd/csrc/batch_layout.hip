@@ -144,7 +144,7 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
     const char* e = getenv("HIPDEC_PARSE_POOL");
     b.pool = e ? (uint32_t)atoi(e) : (nsubs >= 2048 ? 1u : 0u);
     const char* w = getenv("HIPDEC_POOL_WAVES");
-    b.pool_waves = w ? (uint32_t)atoi(w) : 3072u;
+    b.pool_waves = w ? (uint32_t)atoi(w) : 4096u;
     if (b.pool_waves > nsubs) b.pool_waves = nsubs;
     if (b.pool_waves < 1) b.pool_waves = 1;
   }

@@ -60,6 +60,7 @@ int launch_all(hipdec_batch& b, hipStream_t s)
   pa.progress = (uint32_t*)(b.arena + b.off_progress); pa.ctx_store = b.arena + b.off_ctx;
   pa.ticket = (uint32_t*)(b.arena + b.off_ticket); pa.status = (int32_t*)(b.arena + b.off_status);
   pa.yield_ctbs = getenv("HIPDEC_POOL_YIELD") ? (uint32_t)atoi(getenv("HIPDEC_POOL_YIELD")) : 0;
+  pa.wake_hyst = getenv("HIPDEC_POOL_HYST") ? (uint32_t)atoi(getenv("HIPDEC_POOL_HYST")) : 0u;
   pa.pool = b.pool; pa.queue_cap = b.queue_cap; pa.num_subs = b.num_subs;
   pa.waitneed = (uint32_t*)(b.arena + b.off_waitneed); pa.resume_k = (uint32_t*)(b.arena + b.off_resume_k);
   pa.queue = (uint32_t*)(b.arena + b.off_queue); pa.qctl = (uint32_t*)(b.arena + b.off_qctl); pa.saved = (uint32_t*)(b.arena + b.off_saved);

@@ -154,6 +154,7 @@ struct ParseArgs {
   uint32_t* qctl;        // [0] head ticket, [1] tail ticket, [2] finished substreams
   uint32_t* saved;       // per substream: SAVE_DWORDS of suspended state
   uint32_t yield_ctbs;   // test knob (0 = off): a row yields after this many CTBs per activation
+  uint32_t wake_hyst;    // a parked row is woken when its predecessor is this many CTBs beyond the minimum distance
 };
 
 }  // namespace hipdec

@@ -1034,7 +1034,7 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
       } else if (pc_load_wt_uni(A.progress + dep_sub) < need) {
         // suspend: save the row's state, record what it waits for (with two CTBs of hysteresis), re-check
         if (k > 0) save_row_state(s, A, sub_idx, saved, k);
-        uint32_t wake = need + 2u;
+        uint32_t wake = need + A.wake_hyst;
         if (wake > dep_len) wake = dep_len;
         if (!pool_arm(A, sub_idx, (uint32_t)dep_sub, wake)) return PARSE_SUSPENDED;
       }
