@@ -37,11 +37,20 @@ def _share_torch_hip_runtime():
     """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (soname
     libamdhip64.so.7, the same as /opt/rocm's) but link it by the un-versioned name, so if libheifhip.so
     pulls in the system runtime first a later `import torch` loads a SECOND runtime that sees no GPU and
-    device pointers stop being shareable.  When torch is installed, bind to its copy up front."""
+    device pointers stop being shareable.  When torch is installed, bind to its copy up front.
+
+    Never when a HIP runtime is already mapped (e.g. libheif dlopen()ed the plugin earlier in this process):
+    a second runtime loaded RTLD_GLOBAL would interpose its un-initialised hsa_* symbols under the first."""
     import importlib.util
     import sys
     if "torch" in sys.modules:
         return
+    try:
+        with open("/proc/self/maps") as f:
+            if "libamdhip64" in f.read():
+                return
+    except OSError:
+        pass
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):

@@ -383,8 +383,14 @@ int hipdec_decoder_decode(hipdec_decoder* d, hipdec_image_info* info)
   const void* ptrs[1] = {d->data.data()};
   const size_t sizes[1] = {d->data.size()};
   if (int rc = hipdec_batch_create(&d->batch, 1, ptrs, sizes, d->max_pixels)) return rc;
-  if (int rc = hipdec_batch_run(d->batch, nullptr)) return rc;
-  if (int rc = hipdec_batch_status(d->batch)) return rc;
+  // own stream per decode: decoder instances driven from different libheif threads overlap on the GPU
+  hipStream_t s = stream_acquire();
+  int rc = hipdec_batch_run(d->batch, (void*)s);
+  if (!rc) rc = hipdec_batch_status(d->batch);     // synchronises s
+  else (void)hipStreamSynchronize(s);
+  d->batch->last_stream = nullptr;                  // the stream goes back to the pool: nothing of this batch is in flight
+  stream_release(s);
+  if (rc) return rc;
   d->decoded = true;
   if (info) *info = d->batch->pics[0].info;
   return 0;

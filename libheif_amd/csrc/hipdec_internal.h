@@ -18,6 +18,11 @@ hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity);
 void arena_release(void* p, size_t capacity);
 void arena_pool_clear();
 
+// A small pool of HIP streams: concurrent plugin decoder instances (libheif decodes grid tiles on several threads,
+// libheif/image-items/grid.cc:436) each run on their own stream so that their kernels overlap on the GPU.
+hipStream_t stream_acquire();
+void stream_release(hipStream_t s);
+
 #define HIPDEC_CHECK_HIP(expr)                                                                  \
   do {                                                                                          \
     hipError_t _e = (expr);                                                                     \

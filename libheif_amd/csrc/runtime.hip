@@ -52,6 +52,9 @@ constexpr size_t kMaxPooledArena = size_t(1) << 30;    // bigger arenas (large b
 
 hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity)
 {
+  // round small arenas up so that items of similar size share a class
+  const size_t kClass = size_t(4) << 20;
+  if (bytes <= kMaxPooledArena) bytes = (bytes + kClass - 1) / kClass * kClass;
   {
     std::lock_guard<std::mutex> lock(g_pool.mu);
     size_t best = SIZE_MAX;
@@ -66,9 +69,7 @@ hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity)
       return hipSuccess;
     }
   }
-  // round small arenas up so that items of similar size share a class
-  size_t cap = bytes;
-  if (bytes <= kMaxPooledArena) cap = (bytes + (size_t(4) << 20) - 1) / (size_t(4) << 20) * (size_t(4) << 20);
+  const size_t cap = bytes;
   hipError_t e = hipMalloc(out, cap);
   if (e != hipSuccess) {   // out of memory: drop the cache and retry once
     arena_pool_clear();
@@ -90,6 +91,29 @@ void arena_release(void* p, size_t capacity)
     }
   }
   (void)hipFree(p);
+}
+
+namespace {
+std::mutex g_stream_mu;
+std::vector<hipStream_t> g_free_streams;
+}  // namespace
+
+hipStream_t stream_acquire()
+{
+  {
+    std::lock_guard<std::mutex> lock(g_stream_mu);
+    if (!g_free_streams.empty()) { hipStream_t s = g_free_streams.back(); g_free_streams.pop_back(); return s; }
+  }
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return g_stream;   // fall back to the shared stream
+  return s;
+}
+
+void stream_release(hipStream_t s)
+{
+  if (!s || s == g_stream) return;
+  std::lock_guard<std::mutex> lock(g_stream_mu);
+  if (g_free_streams.size() < 64) g_free_streams.push_back(s); else (void)hipStreamDestroy(s);
 }
 
 void arena_pool_clear()
@@ -130,6 +154,11 @@ void hipdec_shutdown(void)
   std::lock_guard<std::mutex> lock(g_init_mutex);
   if (!g_initialised) return;
   arena_pool_clear();
+  {
+    std::lock_guard<std::mutex> lock(g_stream_mu);
+    for (auto st : g_free_streams) (void)hipStreamDestroy(st);
+    g_free_streams.clear();
+  }
   if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
   g_initialised = false;
 }

@@ -76,6 +76,10 @@ def load_hip_plugin():
     L = lib()
     if not _PLUGIN_LOADED:
         import libheif_amd
+        from libheif_amd import _capi
+        # this interpreter may `import torch` later (grid tests): keep the process on ONE HIP runtime whatever
+        # the test order (see _capi._share_torch_hip_runtime); a C host without torch has nothing to do here
+        _capi._share_torch_hip_runtime()
         info = C.c_void_p()
         check(L.heif_load_plugin(libheif_amd.library_path().encode(), C.byref(info)))
         _PLUGIN_LOADED = True
