@@ -101,6 +101,11 @@ HIPDEC_API int hipdec_decoder_push_data(hipdec_decoder* dec, const void* data, s
  * host, runs the HIP decode pipeline and leaves the planes in HBM.  Returns HIPDEC_ERR_NO_IMAGE
  * when no picture was pushed (libheif sees "no image yet"). */
 HIPDEC_API int hipdec_decoder_decode(hipdec_decoder* dec, hipdec_image_info* info);
+/* Concurrent hipdec_decoder_decode() calls (libheif decodes the tiles of a 'grid' item on worker threads,
+ * libheif/image-items/grid.cc:405-453, one decoder instance per tile) are coalesced into shared launch sets; a
+ * serial host never waits.  HIPDEC_COALESCE_WINDOW_US (default 2000, 0 = off) bounds the gathering time.
+ * Counters since load: decode requests, launch sets issued, requests that shared a launch set with others. */
+HIPDEC_API void hipdec_decoder_coalesce_stats(uint64_t* requests, uint64_t* launch_sets, uint64_t* shared_requests);
 
 /* Host-only header probe: parses the parameter sets and slice segment headers of one pushed item
  * and fills `info` without touching the GPU (what libheif's own SPS pre-check does in

@@ -11,9 +11,14 @@
 #include "hevc_headers.h"
 #include "kernels.h"
 #include "batch_layout.h"
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <string>
 #include <vector>
 
 
@@ -329,13 +334,128 @@ int hipdec_probe(const void* data, size_t size, uint64_t max_image_size_pixels, 
 }
 
 // ---- single-image decoder: the plugin life cycle ------------------------------------------------
+//
+// libheif drives one decoder instance per coded item and, for 'grid' images, one worker thread per tile
+// (libheif/image-items/grid.cc:405-453).  A CABAC substream is sequential, so a lone tile occupies a handful of
+// waves for its whole latency; the GPU only pays off when the tiles of a photo are decoded TOGETHER.  The plugin
+// boundary has no batch call, so concurrent hipdec_decoder_decode() calls are coalesced here: the first caller
+// becomes the leader, gathers the requests of the other threads for a short window and runs ONE batch (one upload,
+// one set of launches) for all of them; every instance then reads its own planes out of the shared batch.
+// A host that decodes serially never waits: the window only opens when other instances exist that have not decoded
+// yet, or when overlapping requests were seen a moment ago.
 struct hipdec_decoder {
   std::vector<uint8_t> data;
   int strict = 0;
   uint64_t max_pixels = 0;
-  hipdec_batch* batch = nullptr;
+  std::shared_ptr<hipdec_batch> batch;   // shared with the other instances decoded in the same launch
+  int item = 0;                          // this instance's picture inside `batch`
   bool decoded = false;
+  bool counted = false;                  // included in Coalescer::armed
 };
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+
+struct DecodeRequest {
+  hipdec_decoder* d = nullptr;
+  int rc = 0;
+  std::string err;
+  bool taken = false, done = false;
+};
+
+struct Coalescer {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<DecodeRequest*> pending;
+  bool collecting = false;               // a leader is gathering `pending`
+  int armed = 0;                         // live instances that have not been decoded (potential joiners)
+  int in_flight = 0;                     // requests inside a running batch
+  Clock::time_point last_arrival{}, last_overlap{};
+  long window_us = -1, quiet_us = 300;
+  uint64_t n_requests = 0, n_launch_sets = 0, n_shared = 0;   // statistics (hipdec_decoder_coalesce_stats)
+} g_co;
+
+long coalesce_window_us()
+{
+  if (g_co.window_us < 0) {
+    const char* e = std::getenv("HIPDEC_COALESCE_WINDOW_US");   // 0 disables coalescing
+    g_co.window_us = e ? std::max(0L, std::atol(e)) : 2000;
+    if (const char* q = std::getenv("HIPDEC_COALESCE_QUIET_US")) g_co.quiet_us = std::max(1L, std::atol(q));
+  }
+  return g_co.window_us;
+}
+
+// one decoder in a batch of its own: the reference behaviour, and the fallback that gives every request its own
+// error when a shared batch could not be built or failed on the device
+void run_single(DecodeRequest& r, hipStream_t s)
+{
+  hipdec_decoder* d = r.d;
+  const void* ptrs[1] = {d->data.data()};
+  const size_t sizes[1] = {d->data.size()};
+  hipdec_batch* b = nullptr;
+  r.rc = hipdec_batch_create(&b, 1, ptrs, sizes, d->max_pixels);
+  if (!r.rc) {
+    r.rc = hipdec_batch_run(b, (void*)s);
+    if (!r.rc) r.rc = hipdec_batch_status(b);   // synchronises s
+    else (void)hipStreamSynchronize(s);
+    b->last_stream = nullptr;                   // the stream goes back to the pool: nothing of this batch is in flight
+  }
+  {
+    std::lock_guard<std::mutex> lock(g_co.mu);
+    g_co.n_launch_sets++;
+  }
+  if (r.rc) { r.err = hipdec_last_error(); delete b; return; }
+  d->batch.reset(b);
+  d->item = 0;
+}
+
+void run_group(std::vector<DecodeRequest*>& group, hipStream_t s)
+{
+  if (group.size() > 1) {
+    std::vector<const void*> ptrs;
+    std::vector<size_t> sizes;
+    for (auto* r : group) { ptrs.push_back(r->d->data.data()); sizes.push_back(r->d->data.size()); }
+    hipdec_batch* b = nullptr;
+    int rc = hipdec_batch_create(&b, (int)group.size(), ptrs.data(), sizes.data(), group[0]->d->max_pixels);
+    if (!rc) {
+      rc = hipdec_batch_run(b, (void*)s);
+      if (!rc) rc = hipdec_batch_status(b);
+      else (void)hipStreamSynchronize(s);
+      b->last_stream = nullptr;
+    }
+    if (!rc) {
+      std::shared_ptr<hipdec_batch> sp(b);
+      for (size_t i = 0; i < group.size(); i++) { group[i]->d->batch = sp; group[i]->d->item = (int)i; group[i]->rc = 0; }
+      std::lock_guard<std::mutex> lock(g_co.mu);
+      g_co.n_launch_sets++; g_co.n_shared += group.size();
+      return;
+    }
+    delete b;   // a bad item (or a mix the batch layout refuses): decode one by one so that only the culprit fails
+  }
+  for (auto* r : group) run_single(*r, s);
+}
+
+void run_requests(std::vector<DecodeRequest*>& take)
+{
+  hipStream_t s = stream_acquire();   // own stream per launch set: batches of different leaders overlap on the GPU
+  std::vector<bool> used(take.size(), false);
+  for (size_t i = 0; i < take.size(); i++) {
+    if (used[i]) continue;
+    std::vector<DecodeRequest*> group;   // security limits are per instance: only equal limits share a batch
+    for (size_t j = i; j < take.size(); j++)
+      if (!used[j] && take[j]->d->max_pixels == take[i]->d->max_pixels) { used[j] = true; group.push_back(take[j]); }
+    run_group(group, s);
+  }
+  stream_release(s);
+}
+
+void uncount(hipdec_decoder* d)   // g_co.mu held
+{
+  if (d->counted) { d->counted = false; g_co.armed--; }
+}
+
+}  // namespace
 
 int hipdec_decoder_new(hipdec_decoder** out, int strict_decoding, uint64_t max_image_size_pixels)
 {
@@ -344,6 +464,11 @@ int hipdec_decoder_new(hipdec_decoder** out, int strict_decoding, uint64_t max_i
   if (int rc = ensure_init()) return rc;  // fail loudly when there is no GPU: there is no CPU fallback
   hipdec_decoder* d = new hipdec_decoder();
   d->strict = strict_decoding; d->max_pixels = max_image_size_pixels;
+  {
+    std::lock_guard<std::mutex> lock(g_co.mu);
+    d->counted = true;
+    g_co.armed++;
+  }
   *out = d;
   return 0;
 }
@@ -351,7 +476,11 @@ int hipdec_decoder_new(hipdec_decoder** out, int strict_decoding, uint64_t max_i
 void hipdec_decoder_free(hipdec_decoder* d)
 {
   if (!d) return;
-  delete d->batch;
+  {
+    std::lock_guard<std::mutex> lock(g_co.mu);
+    uncount(d);
+    g_co.cv.notify_all();   // a leader may be waiting for this instance to join
+  }
   delete d;
 }
 
@@ -380,32 +509,83 @@ int hipdec_decoder_decode(hipdec_decoder* d, hipdec_image_info* info)
   if (!d) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "decode: NULL decoder");
   if (d->decoded) return set_error(HIPDEC_ERR_NO_IMAGE, "no further image");
   if (d->data.empty()) return set_error(HIPDEC_ERR_NO_IMAGE, "no data was pushed");
-  const void* ptrs[1] = {d->data.data()};
-  const size_t sizes[1] = {d->data.size()};
-  if (int rc = hipdec_batch_create(&d->batch, 1, ptrs, sizes, d->max_pixels)) return rc;
-  // own stream per decode: decoder instances driven from different libheif threads overlap on the GPU
-  hipStream_t s = stream_acquire();
-  int rc = hipdec_batch_run(d->batch, (void*)s);
-  if (!rc) rc = hipdec_batch_status(d->batch);     // synchronises s
-  else (void)hipStreamSynchronize(s);
-  d->batch->last_stream = nullptr;                  // the stream goes back to the pool: nothing of this batch is in flight
-  stream_release(s);
-  if (rc) return rc;
+  DecodeRequest req;
+  req.d = d;
+  const long window = coalesce_window_us();
+  {
+    std::lock_guard<std::mutex> lock(g_co.mu);
+    g_co.n_requests++;
+  }
+  if (window == 0) {
+    hipStream_t s = stream_acquire();
+    run_single(req, s);
+    stream_release(s);
+    std::lock_guard<std::mutex> lock(g_co.mu);
+    uncount(d);
+  } else {
+    std::unique_lock<std::mutex> lk(g_co.mu);
+    const auto now = Clock::now();
+    if (!g_co.pending.empty() || g_co.in_flight > 0) g_co.last_overlap = now;
+    g_co.last_arrival = now;
+    g_co.pending.push_back(&req);
+    g_co.cv.notify_all();
+    while (!req.done) {
+      if (req.taken || g_co.collecting) { g_co.cv.wait(lk); continue; }
+      // leader: gather the requests of the other threads, then run them as one batch
+      g_co.collecting = true;
+      const auto t0 = Clock::now();
+      const auto deadline = t0 + std::chrono::microseconds(window);
+      const bool overlapping = g_co.last_overlap.time_since_epoch().count() != 0 &&
+                               t0 - g_co.last_overlap < std::chrono::milliseconds(250);
+      for (;;) {
+        const auto t = Clock::now();
+        if (t >= deadline) break;
+        int pending_counted = 0;
+        for (auto* r : g_co.pending) pending_counted += r->d->counted ? 1 : 0;
+        const bool joiners = g_co.armed > pending_counted;                                  // instances that exist and have not asked yet
+        const auto quiet_at = g_co.last_arrival + std::chrono::microseconds(g_co.quiet_us);
+        const bool quiet = t >= quiet_at;
+        if (!joiners && (!overlapping || quiet)) break;
+        g_co.cv.wait_until(lk, joiners ? deadline : std::min(deadline, quiet_at));
+      }
+      std::vector<DecodeRequest*> take;
+      take.swap(g_co.pending);
+      for (auto* r : take) { r->taken = true; uncount(r->d); }
+      g_co.in_flight += (int)take.size();
+      g_co.collecting = false;
+      g_co.cv.notify_all();
+      lk.unlock();
+      run_requests(take);
+      lk.lock();
+      g_co.in_flight -= (int)take.size();
+      for (auto* r : take) r->done = true;
+      g_co.cv.notify_all();
+    }
+  }
+  if (req.rc) return set_error(req.rc, "%s", req.err.c_str());
   d->decoded = true;
-  if (info) *info = d->batch->pics[0].info;
+  if (info) *info = d->batch->pics[d->item].info;
   return 0;
+}
+
+void hipdec_decoder_coalesce_stats(uint64_t* requests, uint64_t* launch_sets, uint64_t* shared_requests)
+{
+  std::lock_guard<std::mutex> lock(g_co.mu);
+  if (requests) *requests = g_co.n_requests;
+  if (launch_sets) *launch_sets = g_co.n_launch_sets;
+  if (shared_requests) *shared_requests = g_co.n_shared;
 }
 
 int hipdec_decoder_read_plane(hipdec_decoder* d, int c, void* dst, size_t dst_stride)
 {
   if (!d || !d->decoded) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: nothing decoded");
-  return hipdec_batch_read_plane(d->batch, 0, c, dst, dst_stride);
+  return hipdec_batch_read_plane(d->batch.get(), d->item, c, dst, dst_stride);
 }
 
 int hipdec_decoder_device_plane(hipdec_decoder* d, int c, const void** dptr, size_t* stride)
 {
   if (!d || !d->decoded) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "device_plane: nothing decoded");
-  return hipdec_batch_device_plane(d->batch, 0, c, dptr, stride);
+  return hipdec_batch_device_plane(d->batch.get(), d->item, c, dptr, stride);
 }
 
 }  // extern "C"

@@ -21,6 +21,8 @@ def _bind(lib):
     lib.hipdec_decoder_push_data.argtypes = [vp, C.c_char_p, sz]
     lib.hipdec_decoder_decode.argtypes = [vp, C.POINTER(ImageInfo)]
     lib.hipdec_decoder_read_plane.argtypes = [vp, ci, vp, sz]
+    lib.hipdec_decoder_coalesce_stats.restype = None
+    lib.hipdec_decoder_coalesce_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
     lib.hipdec_batch_create.argtypes = [C.POINTER(vp), ci, C.POINTER(C.c_char_p), C.POINTER(sz), C.c_uint64]
     lib.hipdec_batch_free.argtypes = [vp]
     lib.hipdec_batch_count.argtypes = [vp]
@@ -45,6 +47,14 @@ def _bind(lib):
 
 def _info_dict(info):
     return {f: getattr(info, f) for f, _ in ImageInfo._fields_}
+
+
+def coalesce_stats():
+    """(decode requests, launch sets, requests that shared a launch set) since the library was loaded"""
+    lib = _bind(load_library())
+    a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    lib.hipdec_decoder_coalesce_stats(C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
 
 
 class DecodedImage:

@@ -263,3 +263,56 @@ def test_pool_scheduler_batch_and_error_path(monkeypatch):
     b3.run(); b3.status()
     for c in range(3):
         np.testing.assert_array_equal(b3.planes(2)[c], orc.decode(streams[2])["planes"][c])
+
+
+def test_concurrent_decoders_share_launch_sets():
+    """libheif decodes grid tiles on worker threads, one plugin decoder instance each (grid.cc:405-453): concurrent
+    decode calls are coalesced into shared batches; every instance must still get exactly its own picture, and a
+    corrupt or odd-one-out item must fail / succeed alone."""
+    import threading
+    from libheif_amd.decoder import HipDecoder, coalesce_stats
+    from libheif_amd._capi import HipDecError
+    items = []
+    for i in range(12):
+        w, h = [(128, 64), (64, 128), (200, 136), (72, 40)][i % 4]
+        planes = orc.synth_image(w, h, 8, 1, seed=100 + i)
+        items.append(orc.encode(planes, qp=22 + i, stress=i & 1))
+    items.append(orc.encode(orc.synth_image(64, 64, 10, 1, seed=7), bit_depth=10))    # cannot share an 8-bit batch
+    items.append(orc.encode(orc.synth_image(80, 48, 8, 0, seed=8)))                   # monochrome
+    bad = bytearray(items[2]); bad[len(bad) * 2 // 3] ^= 0x5a; bad[len(bad) * 2 // 3 + 7] ^= 0xff
+    refs = [orc.decode(s) for s in items]
+    bad_alone = None
+    try:
+        _decode_gpu(bytes(bad))
+    except HipDecError as e:
+        bad_alone = e.code
+    items.append(bytes(bad))
+    for rnd in range(3):
+        r0, _, s0 = coalesce_stats()
+        out = [None] * len(items)
+        gate = threading.Barrier(len(items))
+
+        def work(k):
+            d = HipDecoder()
+            d.push_data(items[k])
+            gate.wait()
+            try:
+                out[k] = d.decode_next_image()
+            except HipDecError as e:
+                out[k] = e
+            d.free()
+
+        th = [threading.Thread(target=work, args=(k,)) for k in range(len(items))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        for k, ref in enumerate(refs):
+            assert not isinstance(out[k], Exception), (k, out[k])
+            assert len(out[k].planes) == len(ref["planes"])
+            for c in range(len(ref["planes"])):
+                np.testing.assert_array_equal(out[k].planes[c], ref["planes"][c], err_msg="item %d comp %d" % (k, c))
+        if bad_alone is not None:
+            assert isinstance(out[-1], HipDecError) and out[-1].code == bad_alone
+        r1, _, s1 = coalesce_stats()
+        assert r1 - r0 == len(items)
+    # the barrier releases all threads together: at least some rounds must have shared a launch set
+    assert coalesce_stats()[2] > 0

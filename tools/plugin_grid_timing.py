@@ -13,9 +13,13 @@ streams = streamgen.make_streams([(tw, th, 100 + i, 8, cfg) for i in range(rows 
 heic = hu.build_heic([(s, tw, th) for s in streams], grid=(rows, cols, cols * tw, rows * th))
 lh.load_hip_plugin()
 lh.decode(heic, lh.COLORSPACE_YCBCR, lh.CHROMA_420, max_threads=4)     # warm-up
+from libheif_amd.decoder import coalesce_stats
 for threads in (1, 4, 16, 48):
+    c0 = coalesce_stats()
     t0 = time.perf_counter()
     for _ in range(3):
         lh.decode(heic, lh.COLORSPACE_YCBCR, lh.CHROMA_420, max_threads=threads)
     dt = (time.perf_counter() - t0) / 3
-    print("max_decoding_threads %2d: %.1f ms per %dx%d grid photo (%.1f Mpixel/s)" % (threads, dt * 1e3, cols * tw, rows * th, cols * tw * rows * th / dt / 1e6), flush=True)
+    c1 = coalesce_stats()
+    print("max_decoding_threads %2d: %.1f ms per %dx%d grid photo (%.1f Mpixel/s); %d tile decodes in %d launch sets" %
+          (threads, dt * 1e3, cols * tw, rows * th, cols * tw * rows * th / dt / 1e6, c1[0] - c0[0], c1[1] - c0[1]), flush=True)
