@@ -58,8 +58,19 @@ __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo
 // __syncthreads() would also wait for the outstanding global loads, i.e. serialise the residual prefetch.)
 __device__ __forceinline__ void lds_sync()
 {
+#ifndef HIPDEC_HOST_EMU
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
   __builtin_amdgcn_wave_barrier();
+}
+// all of this wave's global stores have left it (the CPU-test build of tests/emu orders them with a fence instead)
+__device__ __forceinline__ void drain_stores()
+{
+#ifndef HIPDEC_HOST_EMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
 }
 
 __device__ __forceinline__ int find_src(int e, uint64_t m0, uint64_t m1, uint64_t m2)
@@ -384,7 +395,7 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
       for (int i = lane; i < ctbc; i += 64) L.left[i] = L.tile[i * ctbc + ctbc - 1];
     }
     lds_sync();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the line-buffer stores have left this wave
+    drain_stores();   // the line-buffer stores have left this wave
     if (lane == 0) __hip_atomic_store(my_progress, (uint32_t)(cx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   }

@@ -46,11 +46,18 @@ __device__ __forceinline__ uint32_t compact1by1(uint32_t v)
   return v;
 }
 
+#ifndef HIPDEC_HOST_EMU
 typedef short short2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int acc)
 {
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), acc, false);
 }
+#else   // CPU-test build (tests/emu): v_dot2_i32_i16 spelled out
+inline int dot2(uint32_t a, uint32_t b, int acc)
+{
+  return acc + (int)(int16_t)(a & 0xffff) * (int)(int16_t)(b & 0xffff) + (int)(int16_t)(a >> 16) * (int)(int16_t)(b >> 16);
+}
+#endif
 
 // one transform block, by one wave: coef (global, n*n int16, raster) -> residual in place
 __device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, int16_t* coef, int log2n, int bit_depth, int qp, int dst,

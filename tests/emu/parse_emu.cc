@@ -10,17 +10,12 @@
 #include <string>
 #include <vector>
 #include "batch_layout.h"
+#include "emu_batch.h"
 #include "hevc_headers.h"
 #include "parse_core.h"
 
 using namespace hipdec;
 
-struct EmuBatch {
-  BatchLayout L;
-  std::vector<uint8_t> arena;
-  int32_t status = 0;
-  std::string err;
-};
 
 extern "C" {
 

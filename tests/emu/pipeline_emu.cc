@@ -1,0 +1,47 @@
+// pipeline_emu.cc — CPU-TEST-ONLY: runs the kernels AFTER the parser (residual, reconstruction, deblocking, SAO; the very
+// sources of libheif_amd/csrc/*.hip, compiled for the host against tests/emu/shim/hip/hip_runtime.h) on a batch that
+// emu_run_parse() has parsed, with the same argument blocks as decoder.hip:launch_all.  NOT part of the product.
+#include <cstring>
+#include "emu_batch.h"
+#include "kernels.h"
+
+using namespace hipdec;
+
+extern "C" {
+
+// stages: bit 0 residual, 1 recon, 2 deblock, 3 sao.  Returns the device status word.
+int emu_run_pipeline(EmuBatch* b, int stages)
+{
+  uint8_t* a = b->arena.data();
+  const BatchLayout& L = b->L;
+  const int n = (int)L.params.size();
+  ReconArgs ra{(const PicParams*)(a + L.off_pics), (const ReconWave*)(a + L.off_rwaves), L.num_rwaves, a,
+               (uint32_t*)(a + L.off_row_progress), (uint32_t*)(a + L.off_ticket) + 1, (int32_t*)(a + L.off_status)};
+  FilterArgs fa{(const PicParams*)(a + L.off_pics), a, (const int32_t*)(a + L.off_status)};
+  if (stages & 1) launch_residual(fa, n, L.max_ctbs, nullptr);
+  if (stages & 2) launch_recon(ra, L.wide, nullptr);
+  if (stages & 4) launch_deblock(fa, n, L.max_w, L.max_h, L.wide, nullptr);
+  if (stages & 8) launch_sao(fa, n, L.max_ow, L.max_oh, L.wide, nullptr);
+  b->status = *(int32_t*)(a + L.off_status);
+  return b->status;
+}
+
+// output plane c of item i (cropped size, as hipdec_batch_read_plane); dst rows are tightly packed
+int emu_plane(EmuBatch* b, int i, int c, void* dst)
+{
+  const PicParams& P = b->L.params[i];
+  const size_t es = b->L.wide ? 2 : 1;
+  const int w = c ? P.out_cwidth : P.out_width, h = c ? P.out_cheight : P.out_height;
+  for (int y = 0; y < h; y++)
+    memcpy((uint8_t*)dst + (size_t)y * w * es, b->arena.data() + P.off_out[c] + (size_t)y * P.out_stride[c], (size_t)w * es);
+  return 0;
+}
+
+int emu_out_size(EmuBatch* b, int i, int* out /* w, h, cw, ch, bytes per sample */)
+{
+  const PicParams& P = b->L.params[i];
+  out[0] = P.out_width; out[1] = P.out_height; out[2] = P.out_cwidth; out[3] = P.out_cheight; out[4] = b->L.wide ? 2 : 1;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,230 @@
+// CPU-TEST-ONLY stand-in for <hip/hip_runtime.h>: a small SIMT emulator that lets the `-m "not gpu"` suite compile the
+// kernel sources of libheif_amd/csrc (*.hip) with g++ and run them on the host, so that their logic is checked against
+// the oracle without a GPU.  NOT part of the product: nothing under libheif_amd/ includes this file.
+//
+// Model: a workgroup runs on one OS thread; each of its threads is a ucontext coroutine.  Threads run until they reach a
+// convergence point (wave barrier, __syncthreads, ballot, shuffle, readfirstlane) and are resumed when all live threads of
+// the wave / group have arrived, which is exactly the guarantee the kernels rely on.  Workgroups of one launch are handed
+// to a pool of OS threads in launch order, so a group only ever waits (progress words in "HBM") for groups that hold an
+// earlier ticket and are therefore running or finished — as on the device.  `__shared__` variables are thread_local
+// statics of the OS thread that runs the group.
+#pragma once
+#include <ucontext.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
+typedef void* hipStream_t;
+
+namespace hipemu {
+
+constexpr size_t kStack = 256 << 10;
+
+struct Lane {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  bool done = false;
+  dim3 tid;
+};
+
+struct Coll {             // one convergence point of a wave (or of the whole group)
+  int arrived = 0;
+  uint64_t gen = 0;
+  uint64_t ballot_acc = 0, part_acc = 0;
+  uint32_t val_acc[64];
+  uint64_t ballot_res[2], part_res[2];
+  uint32_t val_res[2][64];
+  void finalize()
+  {
+    const int s = (int)(gen & 1);
+    ballot_res[s] = ballot_acc; part_res[s] = part_acc;
+    memcpy(val_res[s], val_acc, sizeof(val_acc));
+    ballot_acc = 0; part_acc = 0; arrived = 0;
+    gen++;
+  }
+};
+
+struct Group {
+  dim3 bid, bdim, gdim;
+  std::vector<Lane> lanes;
+  std::vector<Coll> waves;
+  std::vector<int> alive_in_wave;
+  Coll bar;
+  int alive = 0, cur = 0;
+  ucontext_t sched;
+  const std::function<void()>* body = nullptr;
+};
+
+inline thread_local Group* g = nullptr;
+
+inline void yield_lane() { Group* G = g; swapcontext(&G->lanes[G->cur].ctx, &G->sched); }
+
+// returns the result slot of the convergence point the calling lane took part in
+inline int wave_converge(bool pred, uint32_t val)
+{
+  Group* G = g;
+  const int t = G->cur, w = t >> 6, l = t & 63;
+  Coll& C = G->waves[w];
+  const uint64_t my = C.gen;
+  if (pred) C.ballot_acc |= 1ull << l;
+  C.part_acc |= 1ull << l;
+  C.val_acc[l] = val;
+  C.arrived++;
+  if (C.arrived == G->alive_in_wave[w]) C.finalize();
+  else while (C.gen == my) yield_lane();
+  return (int)(my & 1);
+}
+
+inline void group_converge()
+{
+  Group* G = g;
+  Coll& C = G->bar;
+  const uint64_t my = C.gen;
+  C.arrived++;
+  if (C.arrived == G->alive) C.finalize();
+  else while (C.gen == my) yield_lane();
+}
+
+inline void lane_entry()
+{
+  Group* G = g;
+  (*G->body)();
+  G = g;
+  Lane& L = G->lanes[G->cur];
+  L.done = true;
+  const int w = G->cur >> 6;
+  G->alive--; G->alive_in_wave[w]--;
+  // the threads still waiting at a convergence point no longer wait for this one
+  Coll& C = G->waves[w];
+  if (C.arrived > 0 && C.arrived == G->alive_in_wave[w]) C.finalize();
+  if (G->bar.arrived > 0 && G->bar.arrived == G->alive) G->bar.finalize();
+  swapcontext(&L.ctx, &G->sched);
+}
+
+inline void run_group(Group& G)
+{
+  const int n = (int)(G.bdim.x * G.bdim.y * G.bdim.z);
+  g = &G;
+  G.alive = n;
+  const int nw = (n + 63) / 64;
+  G.waves.assign((size_t)nw, Coll());
+  G.alive_in_wave.assign((size_t)nw, 0);
+  G.bar = Coll();
+  for (int i = 0; i < n; i++) {
+    Lane& L = G.lanes[i];
+    L.done = false;
+    L.tid = dim3((unsigned)i % G.bdim.x, ((unsigned)i / G.bdim.x) % G.bdim.y, (unsigned)i / (G.bdim.x * G.bdim.y));
+    G.alive_in_wave[i >> 6]++;
+    getcontext(&L.ctx);
+    L.ctx.uc_stack.ss_sp = L.stack; L.ctx.uc_stack.ss_size = kStack; L.ctx.uc_link = &G.sched;
+    makecontext(&L.ctx, (void (*)())lane_entry, 0);
+  }
+  while (G.alive > 0)
+    for (int i = 0; i < n; i++) {
+      if (G.lanes[i].done) continue;
+      G.cur = i;
+      swapcontext(&G.sched, &G.lanes[i].ctx);
+    }
+  g = nullptr;
+}
+
+inline int pool_threads()
+{
+  const char* e = getenv("HIPEMU_THREADS");
+  return e ? atoi(e) : 96;
+}
+
+template <typename F>
+void launch(dim3 grid, dim3 block, F&& fn)
+{
+  const std::function<void()> body = fn;
+  const size_t total = (size_t)grid.x * grid.y * grid.z;
+  const int n = (int)(block.x * block.y * block.z);
+  std::atomic<size_t> next{0};
+  auto worker = [&]() {
+    Group G;
+    G.gdim = grid; G.bdim = block; G.body = &body;
+    G.lanes.resize((size_t)n);
+    char* stacks = (char*)mmap(nullptr, kStack * (size_t)n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (stacks == (char*)MAP_FAILED) { fprintf(stderr, "hipemu: mmap failed\n"); abort(); }
+    for (int i = 0; i < n; i++) G.lanes[(size_t)i].stack = stacks + kStack * (size_t)i;
+    for (;;) {
+      const size_t w = next.fetch_add(1);
+      if (w >= total) break;
+      G.bid = dim3((unsigned)(w % grid.x), (unsigned)((w / grid.x) % grid.y), (unsigned)(w / ((size_t)grid.x * grid.y)));
+      run_group(G);
+    }
+    munmap(stacks, kStack * (size_t)n);
+  };
+  const int nt = (int)std::min<size_t>(total, (size_t)std::max(1, pool_threads()));
+  std::vector<std::thread> th;
+  for (int i = 0; i < nt; i++) th.emplace_back(worker);
+  for (auto& t : th) t.join();
+}
+
+}  // namespace hipemu
+
+// ---- language surface used by libheif_amd/csrc/*.hip -----------------------------------------------------------------
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __constant__ static const
+#define __shared__ static thread_local
+#define __launch_bounds__(...)
+#define threadIdx (hipemu::g->lanes[hipemu::g->cur].tid)
+#define blockIdx (hipemu::g->bid)
+#define blockDim (hipemu::g->bdim)
+#define gridDim (hipemu::g->gdim)
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_ACQUIRE)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
+#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define __builtin_amdgcn_s_sleep(n) do { hipemu::yield_lane(); sched_yield(); } while (0)
+#define __builtin_amdgcn_wave_barrier() ((void)hipemu::wave_converge(false, 0))
+#define __syncthreads() hipemu::group_converge()
+
+template <typename T> static inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
+static inline int atomicCAS(int* p, int cmp, int v) { __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE); return cmp; }
+static inline unsigned atomicCAS(unsigned* p, unsigned cmp, unsigned v) { __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE); return cmp; }
+
+static inline uint64_t __ballot(int pred)
+{
+  const int s = hipemu::wave_converge(pred != 0, 0);
+  return hipemu::g->waves[hipemu::g->cur >> 6].ballot_res[s];
+}
+static inline int __shfl_xor(int v, int mask)
+{
+  const int s = hipemu::wave_converge(false, (uint32_t)v);
+  return (int)hipemu::g->waves[hipemu::g->cur >> 6].val_res[s][((hipemu::g->cur & 63) ^ mask) & 63];
+}
+static inline int __shfl(int v, int src)
+{
+  const int s = hipemu::wave_converge(false, (uint32_t)v);
+  return (int)hipemu::g->waves[hipemu::g->cur >> 6].val_res[s][src & 63];
+}
+static inline int hipemu_readfirstlane(int v)
+{
+  const int s = hipemu::wave_converge(false, (uint32_t)v);
+  const hipemu::Coll& C = hipemu::g->waves[hipemu::g->cur >> 6];
+  return (int)C.val_res[s][__builtin_ctzll(C.part_res[s])];
+}
+#define __builtin_amdgcn_readfirstlane(v) hipemu_readfirstlane(v)
+static inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }
+static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }

@@ -1,0 +1,108 @@
+"""CPU check of the WHOLE device pipeline's logic: the kernel sources of libheif_amd/csrc (parse_core.h,
+residual_kernel.hip, recon_kernel.hip, filter_kernels.hip) compiled for the host against the SIMT emulator of
+tests/emu/shim and run end to end (CABAC parse -> dequant + inverse transforms -> intra reconstruction wavefront ->
+deblocking -> SAO -> crop), decoded planes bit-exact against the oracle over the coding-tool matrix.  The emulation is
+test infrastructure; the product runs the same sources on the GPU (tests/test_decode_gpu.py)."""
+import ctypes as C
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+import test_parse_emu as tpe
+
+
+def _lib():
+    L = tpe.emu()
+    L.emu_run_pipeline.argtypes = [C.c_void_p, C.c_int]
+    L.emu_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.emu_out_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    return L
+
+
+def decode_emu(streams):
+    """[planes per item] decoded by the emulated kernels; raises on a device status != 0"""
+    L = _lib()
+    n = len(streams)
+    arr = (C.c_char_p * n)(*streams)
+    sizes = (C.c_size_t * n)(*[len(s) for s in streams])
+    err = C.create_string_buffer(512)
+    h = L.emu_create(n, arr, sizes, err, 512)
+    assert h, err.value.decode()
+    try:
+        st = L.emu_run_parse(h)
+        assert st == 0, "parse status 0x%x" % (st & 0xffffffff)
+        st = L.emu_run_pipeline(h, 15)
+        assert st == 0, "pipeline status 0x%x" % (st & 0xffffffff)
+        out = []
+        for i in range(n):
+            sz = (C.c_int * 5)()
+            L.emu_out_size(h, i, sz)
+            w, hh, cw, ch, es = list(sz)
+            dt = np.uint16 if es == 2 else np.uint8
+            planes = [np.zeros((hh, w), dt)]
+            L.emu_plane(h, i, 0, planes[0].ctypes.data)
+            for c in (1, 2):
+                if cw and ch:
+                    p = np.zeros((ch, cw), dt)
+                    L.emu_plane(h, i, c, p.ctypes.data)
+                    planes.append(p)
+            out.append(planes)
+        return out
+    finally:
+        L.emu_free(h)
+
+
+def _check(stream, planes):
+    ref = orc.decode(stream)
+    assert len(planes) == len(ref["planes"])
+    for c in range(len(ref["planes"])):
+        np.testing.assert_array_equal(planes[c], ref["planes"][c], err_msg="component %d" % c)
+
+
+CONFIGS = [
+    dict(),
+    dict(stress=1),
+    dict(wpp=0, stress=1),
+    dict(num_slices=3, loop_filter_across_slices=0),
+    dict(transform_skip=1, stress=1),
+    dict(lossless_pct=30),
+    dict(bit_depth=10),
+    dict(log2_ctb=5, log2_min_cb=4, log2_max_tb=5, max_transform_hierarchy_depth_intra=2, stress=1),
+    dict(log2_ctb=4, log2_min_cb=3, log2_max_tb=4, stress=1),
+    dict(sao=0, deblock_disable=1),
+    dict(cb_qp_offset=3, cr_qp_offset=-4, beta_offset_div2=2, tc_offset_div2=-2, qp=34),
+    dict(qp=12, stress=1, zero_residual_pct=30),
+    dict(sign_data_hiding=0, cu_qp_delta=0, strong_intra_smoothing=0),
+    dict(qp=40),
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: ",".join("%s=%s" % kv for kv in c.items()) or "default")
+def test_emulated_pipeline_matches_oracle(cfg):
+    planes = orc.synth_image(200, 136, cfg.get("bit_depth", 8), 1, seed=21)
+    stream = orc.encode(planes, **cfg)
+    _check(stream, decode_emu([stream])[0])
+
+
+def test_emulated_pipeline_monochrome_and_cropped_sizes():
+    for w, h, cf in [(75, 41, 0), (70, 42, 1), (8, 8, 1), (136, 24, 1)]:
+        stream = orc.encode(orc.synth_image(w, h, 8, cf, seed=5))
+        _check(stream, decode_emu([stream])[0])
+
+
+def test_emulated_pipeline_batch_of_mixed_sizes():
+    """several items in one batch: one set of (emulated) launches, every item exactly its own picture"""
+    streams = []
+    for i, (w, h) in enumerate([(128, 64), (64, 128), (200, 136), (72, 40)]):
+        streams.append(orc.encode(orc.synth_image(w, h, 8, 1, seed=40 + i), qp=24 + 3 * i, stress=i & 1))
+    for s, planes in zip(streams, decode_emu(streams)):
+        _check(s, planes)
+
+
+def test_emulated_pipeline_strong_smoothing_32x32():
+    """smooth content at a coarse QP: 32x32 transform blocks with strong intra smoothing"""
+    yy, xx = np.mgrid[0:192, 0:256]
+    y = (40 + 0.5 * xx + 0.25 * yy).astype(np.uint8)
+    planes = [y, np.full((96, 128), 120, np.uint8), np.full((96, 128), 135, np.uint8)]
+    stream = orc.encode(planes, qp=38)
+    _check(stream, decode_emu([stream])[0])
