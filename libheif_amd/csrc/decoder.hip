@@ -412,28 +412,31 @@ void run_single(DecodeRequest& r, hipStream_t s)
 
 void run_group(std::vector<DecodeRequest*>& group, hipStream_t s)
 {
-  if (group.size() > 1) {
-    std::vector<const void*> ptrs;
-    std::vector<size_t> sizes;
-    for (auto* r : group) { ptrs.push_back(r->d->data.data()); sizes.push_back(r->d->data.size()); }
-    hipdec_batch* b = nullptr;
-    int rc = hipdec_batch_create(&b, (int)group.size(), ptrs.data(), sizes.data(), group[0]->d->max_pixels);
-    if (!rc) {
-      rc = hipdec_batch_run(b, (void*)s);
-      if (!rc) rc = hipdec_batch_status(b);
-      else (void)hipStreamSynchronize(s);
-      b->last_stream = nullptr;
-    }
-    if (!rc) {
-      std::shared_ptr<hipdec_batch> sp(b);
-      for (size_t i = 0; i < group.size(); i++) { group[i]->d->batch = sp; group[i]->d->item = (int)i; group[i]->rc = 0; }
-      std::lock_guard<std::mutex> lock(g_co.mu);
-      g_co.n_launch_sets++; g_co.n_shared += group.size();
-      return;
-    }
-    delete b;   // a bad item (or a mix the batch layout refuses): decode one by one so that only the culprit fails
+  if (group.size() == 1) { run_single(*group[0], s); return; }
+  std::vector<const void*> ptrs;
+  std::vector<size_t> sizes;
+  for (auto* r : group) { ptrs.push_back(r->d->data.data()); sizes.push_back(r->d->data.size()); }
+  hipdec_batch* b = nullptr;
+  int rc = hipdec_batch_create(&b, (int)group.size(), ptrs.data(), sizes.data(), group[0]->d->max_pixels);
+  if (!rc) {
+    rc = hipdec_batch_run(b, (void*)s);
+    if (!rc) rc = hipdec_batch_status(b);
+    else (void)hipStreamSynchronize(s);
+    b->last_stream = nullptr;
   }
-  for (auto* r : group) run_single(*r, s);
+  if (!rc) {
+    std::shared_ptr<hipdec_batch> sp(b);
+    for (size_t i = 0; i < group.size(); i++) { group[i]->d->batch = sp; group[i]->d->item = (int)i; group[i]->rc = 0; }
+    std::lock_guard<std::mutex> lock(g_co.mu);
+    g_co.n_launch_sets++; g_co.n_shared += group.size();
+    return;
+  }
+  delete b;
+  // a bad item, or a mix the batch layout refuses (8-bit with 10-bit items): halve the group until the culprit is alone,
+  // so that it alone gets the error and the others still share launch sets
+  std::vector<DecodeRequest*> lo(group.begin(), group.begin() + (long)(group.size() / 2)), hi(group.begin() + (long)(group.size() / 2), group.end());
+  run_group(lo, s);
+  run_group(hi, s);
 }
 
 void run_requests(std::vector<DecodeRequest*>& take)

@@ -38,16 +38,14 @@ struct ReconLds {
   Pix tile[64 * 64];        // the CTB of this wave's component
   uint32_t top_raw[72];     // words of the line buffer covering x_ctb - 1 .. x_ctb + 2 * ctb - 1 (+ one pad word in front)
   Pix left[64];
-  uint16_t ref0[132], ref1[132];
-  uint8_t m_size[256], m_flags[256], m_ipm[256], m_ipmc[256];
+  uint16_t refbuf0[134], refbuf1[134];   // reference samples in scan order, one pad element in front (an unused weight-0 tap may read index -1)
+  // availability of the neighbourhood in 4x4-luma units, one row of bits per unit row: row uy + 1, bit ux + 1 for the
+  // units ux, uy in [-1, 2 * units_per_side): row 0 / bit 0 are the borders owned by the neighbouring CTBs, rows and bits
+  // past the CTB stay 0 (not decoded yet), a unit of the CTB is set when its block has been reconstructed
+  uint64_t avrow[33];
+  uint8_t m_size[256], m_flags[256], m_mode[256];
 };
 
-__device__ __forceinline__ uint32_t interleave4(uint32_t x, uint32_t y)
-{
-  x = (x | (x << 2)) & 0x33; x = (x | (x << 1)) & 0x55;
-  y = (y | (y << 2)) & 0x33; y = (y | (y << 1)) & 0x55;
-  return x | (y << 1);
-}
 __device__ __forceinline__ uint32_t compact1by1(uint32_t v)
 {
   v &= 0x55555555u; v = (v | (v >> 1)) & 0x33333333u; v = (v | (v >> 2)) & 0x0f0f0f0fu; v = (v | (v >> 4)) & 0x00ff00ffu;
@@ -73,211 +71,198 @@ __device__ __forceinline__ void drain_stores()
 #endif
 }
 
-__device__ __forceinline__ int find_src(int e, uint64_t m0, uint64_t m1, uint64_t m2)
-{
-  const int j = e >> 6, b = e & 63;
-  uint64_t mm = (j == 0 ? m0 : (j == 1 ? m1 : m2)) & ((1ull << b) - 1ull);
-  if (mm) return j * 64 + 63 - __clzll((long long)mm);
-  if (j >= 2 && m1) return 64 + 63 - __clzll((long long)m1);
-  if (j >= 1 && m0) return 63 - __clzll((long long)m0);
-  if (m0) return __ffsll((long long)m0) - 1;
-  if (m1) return 64 + __ffsll((long long)m1) - 1;
-  if (m2) return 128 + __ffsll((long long)m2) - 1;
-  return -1;
-}
-
 struct Ctx {
-  const PicParams* pp;
   int lane;
-  int x_ctb, y_ctb;   // luma origin of the CTB
-  int avail;          // CtbInfo.avail
-  int ctb;            // CTB size in luma samples
+  uint64_t lt;        // bits below this lane
+  int ctbc;           // CTB size in component samples
+  int ush;            // component samples -> 4x4-luma units: >> ush (2 for luma, 1 for 4:2:0 chroma)
+  int bit_depth, maxv;
+  int luma;           // c_idx == 0
+  int strong;         // sps strong_intra_smoothing_enabled_flag
 };
 
 // One transform block: prediction (+ residual) into the LDS tile.
-//   c_idx: component; (xb, yb): block origin inside the CTB in component samples; log2n: block size
-//   z_cur: z-index (4x4 luma units) of the block that defines "already decoded" for availability
+//   (xb, yb): block origin inside the CTB in component samples; log2n: block size
 template <typename Pix>
-__device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C, const Pix* top, int c_idx, int xb, int yb, int log2n, int z_cur, int mode,
-                                                  int cbf, const int16_t* res)
+__device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C, const Pix* top, int xb, int yb, int log2n, int mode, int cbf, const int16_t* res)
 {
-  const PicParams& P = *C.pp;
   const int lane = C.lane;
-  const int n = 1 << log2n, n2 = 2 * n, N = 4 * n + 1;
-  const int sub = c_idx ? 2 : 1;                      // 4:2:0
-  const int ctbc = C.ctb / sub;                       // CTB size in component samples
-  const int Wc = c_idx ? P.cwidth : P.width, Hc = c_idx ? P.cheight : P.height;
-  const int x_abs0 = C.x_ctb / sub, y_abs0 = C.y_ctb / sub;
-  const int bit_depth = c_idx ? P.bit_depth_chroma : P.bit_depth_luma;
-  const int maxv = (1 << bit_depth) - 1;
+  const int n = 1 << log2n, n2 = 2 * n, N = 4 * n + 1, nn = n * n;
+  const int ctbc = C.ctbc, maxv = C.maxv;
   Pix* tile = L.tile;
-  const Pix* left = L.left;
+  uint16_t* ref0 = L.refbuf0 + 1;
+  uint16_t* ref1 = L.refbuf1 + 1;
 
   // the block's residual is requested from HBM first, so that its latency hides behind the prediction
   // (lane l owns samples l, l + 64, ...; the first 4 cover blocks up to 16x16, a 32x32 block reads the rest late)
-  int16_t rpre[4];
-  const int nn = n * n;
-#pragma unroll
-  for (int k = 0; k < 4; k++) { const int idx = lane + 64 * k; rpre[k] = (cbf && idx < nn) ? res[idx] : (int16_t)0; }
+  int rp0 = 0, rp1 = 0, rp2 = 0, rp3 = 0;
+  if (cbf) {
+    if (lane < nn) rp0 = res[lane];
+    if (nn > 64) { rp1 = res[lane + 64]; rp2 = res[lane + 128]; rp3 = res[lane + 192]; }
+  }
+  // residual of iteration `it` (wave-uniform selects; a register array indexed by `it` would live in scratch memory)
+#define RES_AT(it, idx) ((it) == 0 ? rp0 : ((it) == 1 ? rp1 : ((it) == 2 ? rp2 : ((it) == 3 ? rp3 : (int)res[idx]))))
 
-  // ---- 8.4.4.2.2 reference samples: gather + availability + substitution ----
-  uint64_t m[3] = {0, 0, 0};
-  int val[3] = {0, 0, 0}, av[3] = {0, 0, 0};
+  // ---- 8.4.4.2.2 reference samples: gather + availability ----
+  // scan order e: left column bottom-up (e < 2n), corner (e = 2n), top row left to right.  Lanes take e = lane + 64 j for
+  // the J = 1 (2 for 32x32) full passes; blocks of 16x16 and up have one more sample (e = 64 J = 4n, the last one of the
+  // top row), which all lanes handle uniformly.
+  const int J = n == 32 ? 2 : 1;
+  uint64_t m[2] = {0, 0};
+  int av[2] = {0, 0};
 #pragma unroll
-  for (int j = 0; j < 3; j++) {
-    if (64 * j >= N) continue;          // wave-uniform: small blocks have 17 / 33 / 65 reference samples
+  for (int j = 0; j < 2; j++) {
+    if (j >= J) continue;               // wave-uniform
     const int e = lane + 64 * j;
-    int a = 0, v = 0;
-    if (e < N) {
-      int px, py;
-      if (e < n2) { px = -1; py = n2 - 1 - e; }
-      else if (e == n2) { px = -1; py = -1; }
-      else { px = e - n2 - 1; py = -1; }
-      const int X = xb + px, Y = yb + py;
-      const int inside = (x_abs0 + X) < Wc && (y_abs0 + Y) < Hc && (x_abs0 + X) >= 0 && (y_abs0 + Y) >= 0;
-      if (Y < 0) {           // row above the CTB
-        const int bit = X < 0 ? AV_UPLEFT : (X < ctbc ? AV_UP : AV_UPRIGHT);
-        a = inside && (C.avail & bit);
-        if (a) v = top[X + 1];
-      } else if (X < 0) {    // column left of the CTB
-        a = inside && Y < ctbc && (C.avail & AV_LEFT);
-        if (a) v = left[Y];
-      } else if (X < ctbc && Y < ctbc) {
-        const int z = (int)interleave4((uint32_t)(X * sub) >> 2, (uint32_t)(Y * sub) >> 2);
-        a = inside && z < z_cur;
-        if (a) v = tile[Y * ctbc + X];
-      }
+    const int is_left = e < n2;
+    const int px = is_left ? -1 : e - n2 - 1, py = is_left ? n2 - 1 - e : -1;
+    const int X = xb + px, Y = yb + py;
+    int a = 0;
+    if (e < N) a = (int)((L.avrow[(Y >> C.ush) + 1] >> ((X >> C.ush) + 1)) & 1u);
+    if (a) {
+      const Pix* src = Y < 0 ? &top[X + 1] : (X < 0 ? &L.left[Y] : &tile[Y * ctbc + X]);
+      ref0[e] = (uint16_t)*src;
     }
-    av[j] = a; val[j] = v;
+    av[j] = a;
     m[j] = __ballot(a);
-    if (e < N && a) L.ref0[e] = (uint16_t)v;
+  }
+  int ax = 1;          // availability of the extra sample (blocks below 16x16 have none: counts as present)
+  const int has_x = n >= 16;
+  if (has_x) {
+    const int X = xb + n2 - 1, Y = yb - 1;
+    ax = (int)((L.avrow[(Y >> C.ush) + 1] >> ((X >> C.ush) + 1)) & 1u);
+    if (ax && lane == 0) ref0[N - 1] = (uint16_t)(Y < 0 ? top[X + 1] : tile[Y * ctbc + X]);
   }
   lds_sync();
-  const int n_av = __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]);
-  if (n_av != N) {          // substitution process only where something is missing (wave-uniform)
-    const int any = n_av != 0;
+  // ---- substitution process, only where something is missing (wave-uniform) ----
+  const int n_av = __popcll(m[0]) + __popcll(m[1]) + (has_x ? ax : 0);
+  if (n_av != N) {
+    if (n_av == 0) {
+      const uint16_t half = (uint16_t)(1 << (C.bit_depth - 1));
+      for (int e = lane; e < N; e += 64) ref0[e] = half;
+    } else {
+      // an unavailable sample takes the nearest available one below it in scan order, those below the first available
+      // one take that one
+      const int hi0 = m[0] ? 63 - __clzll((long long)m[0]) : -1;
+      const int hi1 = m[1] ? 127 - __clzll((long long)m[1]) : -1;
+      const int first = m[0] ? __ffsll((long long)m[0]) - 1 : (m[1] ? 63 + __ffsll((long long)m[1]) : N - 1);
+      int val[2] = {0, 0};
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-      if (64 * j >= N) continue;
-      const int e = lane + 64 * j;
-      if (e < N && !av[j]) {
-        int v;
-        if (!any) v = 1 << (bit_depth - 1);
-        else v = L.ref0[find_src(e, m[0], m[1], m[2])];
-        val[j] = v;
+      for (int j = 0; j < 2; j++) {
+        if (j >= J) continue;
+        const int e = lane + 64 * j;
+        if (e < N && !av[j]) {
+          const uint64_t mm = m[j] & C.lt;
+          const int src = mm ? 64 * j + 63 - __clzll((long long)mm) : (j == 1 && hi0 >= 0 ? hi0 : first);
+          val[j] = ref0[src];
+        }
       }
-    }
-    lds_sync();
+      int valx = 0;
+      if (has_x && !ax) valx = ref0[hi1 >= 0 ? hi1 : hi0];   // something below is available (n_av > 0)
+      // (reads hit available positions, writes unavailable ones: no barrier needed in between)
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-      if (64 * j >= N) continue;
-      const int e = lane + 64 * j;
-      if (e < N && !av[j]) L.ref0[e] = (uint16_t)val[j];
+      for (int j = 0; j < 2; j++) {
+        if (j >= J) continue;
+        const int e = lane + 64 * j;
+        if (e < N && !av[j]) ref0[e] = (uint16_t)val[j];
+      }
+      if (has_x && !ax && lane == 0) ref0[N - 1] = (uint16_t)valx;
     }
     lds_sync();
   }
   // accessors in scan order: left column p[-1][k-1] = ref[2n - k], top row p[k-1][-1] = ref[2n + k]
-  uint16_t* ref = L.ref0;
+  const uint16_t* ref = ref0;
   // ---- 8.4.4.2.3 smoothing of the reference samples (luma only in 4:2:0) ----
-  if (c_idx == 0 && mode != 1 && n != 4) {
+  if (C.luma && mode != 1 && n != 4) {
     int d1 = mode - 26, d2 = mode - 10;
     d1 = d1 < 0 ? -d1 : d1; d2 = d2 < 0 ? -d2 : d2;
     const int min_dist = d1 < d2 ? d1 : d2;
     const int thres = n == 8 ? 7 : (n == 16 ? 1 : 0);
     if (min_dist > thres) {
       int strong = 0;
-      if (P.strong_intra_smoothing && n == 32) {
+      if (C.strong && n == 32) {
         const int c0 = ref[n2], tl = ref[0], tm = ref[n], rt = ref[N - 1], rm = ref[n2 + n];  // corner, p[-1][63], p[-1][31], p[63][-1], p[31][-1]
         int a1 = c0 + rt - 2 * rm, a2 = c0 + tl - 2 * tm;
         a1 = a1 < 0 ? -a1 : a1; a2 = a2 < 0 ? -a2 : a2;
-        strong = a1 < (1 << (bit_depth - 5)) && a2 < (1 << (bit_depth - 5));
+        strong = a1 < (1 << (C.bit_depth - 5)) && a2 < (1 << (C.bit_depth - 5));
       }
-#pragma unroll
-      for (int j = 0; j < 3; j++) {
-        if (64 * j >= N) continue;
-        const int e = lane + 64 * j;
-        if (e < N) {
-          int v;
-          if (e == 0 || e == N - 1) v = ref[e];
-          else if (strong) {
-            if (e == n2) v = ref[n2];
-            else if (e < n2) { const int y = 63 - e; v = ((63 - y) * ref[n2] + (y + 1) * ref[0] + 32) >> 6; }
-            else { const int x = e - n2 - 1; v = ((63 - x) * ref[n2] + (x + 1) * ref[N - 1] + 32) >> 6; }
-          } else v = (ref[e - 1] + 2 * ref[e] + ref[e + 1] + 2) >> 2;
-          L.ref1[e] = (uint16_t)v;
-        }
+      for (int e = lane; e < N; e += 64) {
+        int v;
+        if (e == 0 || e == N - 1) v = ref[e];
+        else if (strong) {
+          if (e == n2) v = ref[n2];
+          else if (e < n2) { const int y = 63 - e; v = ((63 - y) * ref[n2] + (y + 1) * ref[0] + 32) >> 6; }
+          else { const int x = e - n2 - 1; v = ((63 - x) * ref[n2] + (x + 1) * ref[N - 1] + 32) >> 6; }
+        } else v = (ref[e - 1] + 2 * ref[e] + ref[e + 1] + 2) >> 2;
+        ref1[e] = (uint16_t)v;
       }
       lds_sync();
-      ref = L.ref1;
+      ref = ref1;
     }
   }
 #define RL(k) ((int)ref[n2 - (k)])
 #define RT(k) ((int)ref[n2 + (k)])
-  // ---- prediction 8.4.4.2.4 - 8.4.4.2.6 ----
-  int dc_val = 0;
-  if (mode == 1) {
-    int part = lane < n ? RT(lane + 1) + RL(lane + 1) : 0;
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-    dc_val = (part + n) >> (log2n + 1);
-  }
-  const int angle = c_angle[mode];
-  const int inv_angle = (mode >= 11 && mode <= 25) ? c_inv_angle[mode - 11] : 0;
-  const int edge = c_idx == 0 && n < 32;  // DC / horizontal / vertical boundary smoothing
-  for (int idx = lane; idx < n * n; idx += 64) {
-    const int x = idx & (n - 1), y = idx >> log2n;
-    int v;
-    if (mode == 0) {
-      v = ((n - 1 - x) * RL(y + 1) + (x + 1) * RT(n + 1) + (n - 1 - y) * RT(x + 1) + (y + 1) * RL(n + 1) + n) >> (log2n + 1);
-    } else if (mode == 1) {
-      v = dc_val;
-      if (edge) {
-        if (x == 0 && y == 0) v = (RL(1) + 2 * dc_val + RT(1) + 2) >> 2;
-        else if (y == 0) v = (RT(x + 1) + 3 * dc_val + 2) >> 2;
-        else if (x == 0) v = (RL(y + 1) + 3 * dc_val + 2) >> 2;
+  // ---- prediction 8.4.4.2.4 - 8.4.4.2.6, residual add, store into the tile ----
+  const int edge = C.luma && n < 32;  // DC / horizontal / vertical boundary smoothing
+  const int iters = nn > 64 ? nn >> 6 : 1;
+  Pix* dst0 = &tile[yb * ctbc + xb];
+  if (mode == 0) {
+    const int tr = RT(n + 1), bl = RL(n + 1);
+    for (int it = 0; it < iters; it++) {
+      const int idx = lane + 64 * it, x = idx & (n - 1), y = idx >> log2n;
+      if (idx < nn) {
+        int v = ((n - 1 - x) * RL(y + 1) + (x + 1) * tr + (n - 1 - y) * RT(x + 1) + (y + 1) * bl + n) >> (log2n + 1);
+        if (cbf) v = clip3(0, maxv, v + RES_AT(it, idx));
+        dst0[y * ctbc + x] = (Pix)v;
       }
-    } else if (mode >= 18) {
-      const int i_idx = ((y + 1) * angle) >> 5, i_fact = ((y + 1) * angle) & 31;
-      const int k0 = x + i_idx + 1;
-      // ref[k] = p[-1+k][-1] for k >= 0, projected left column for k < 0
-      const int r0 = k0 >= 0 ? RT(k0) : RL((k0 * inv_angle + 128) >> 8);
-      if (i_fact) {
-        const int k1 = k0 + 1;
-        const int r1 = k1 >= 0 ? RT(k1) : RL((k1 * inv_angle + 128) >> 8);
-        v = ((32 - i_fact) * r0 + i_fact * r1 + 16) >> 5;
-      } else v = r0;
-      if (mode == 26 && edge && x == 0) v = clip3(0, maxv, RT(1) + ((RL(y + 1) - RL(0)) >> 1));
-    } else {
-      const int i_idx = ((x + 1) * angle) >> 5, i_fact = ((x + 1) * angle) & 31;
-      const int k0 = y + i_idx + 1;
-      const int r0 = k0 >= 0 ? RL(k0) : RT((k0 * inv_angle + 128) >> 8);
-      if (i_fact) {
-        const int k1 = k0 + 1;
-        const int r1 = k1 >= 0 ? RL(k1) : RT((k1 * inv_angle + 128) >> 8);
-        v = ((32 - i_fact) * r0 + i_fact * r1 + 16) >> 5;
-      } else v = r0;
-      if (mode == 10 && edge && y == 0) v = clip3(0, maxv, RL(1) + ((RT(x + 1) - RT(0)) >> 1));
     }
-    tile[(yb + y) * ctbc + xb + x] = (Pix)v;
+  } else if (mode == 1) {
+    int part = lane < n ? RT(lane + 1) + RL(lane + 1) : 0;
+    for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o);      // n <= 32 lanes carry a term: lanes 0..31 hold the sum
+    const int dc_val = (__builtin_amdgcn_readfirstlane(part) + n) >> (log2n + 1);
+    for (int it = 0; it < iters; it++) {
+      const int idx = lane + 64 * it, x = idx & (n - 1), y = idx >> log2n;
+      if (idx < nn) {
+        int v = dc_val;
+        if (edge) {
+          if (x == 0 && y == 0) v = (RL(1) + 2 * dc_val + RT(1) + 2) >> 2;
+          else if (y == 0) v = (RT(x + 1) + 3 * dc_val + 2) >> 2;
+          else if (x == 0) v = (RL(y + 1) + 3 * dc_val + 2) >> 2;
+        }
+        if (cbf) v = clip3(0, maxv, v + RES_AT(it, idx));
+        dst0[y * ctbc + x] = (Pix)v;
+      }
+    }
+  } else {
+    // angular: with the roles of the two reference arms swapped for the horizontal modes (2..17) both families read
+    // main(k) = ref[2n + s k], side(k) = ref[2n - s k]  (s = +1 vertical, -1 horizontal)
+    const int vertical = mode >= 18;
+    const int s = vertical ? 1 : -1;
+    const int angle = c_angle[mode];
+    const int inv_angle = (mode >= 11 && mode <= 25) ? c_inv_angle[mode - 11] : 0;
+    const int pure = edge && (mode == 26 || mode == 10);     // pure vertical / horizontal with boundary smoothing
+    for (int it = 0; it < iters; it++) {
+      const int idx = lane + 64 * it, x = idx & (n - 1), y = idx >> log2n;
+      if (idx < nn) {
+        const int a = vertical ? x : y, b = vertical ? y : x;   // along / across the main arm
+        const int t = (b + 1) * angle, i_idx = t >> 5, i_fact = t & 31;
+        const int k0 = a + i_idx + 1, k1 = k0 + 1;
+        const int r0 = ref[k0 >= 0 ? n2 + s * k0 : n2 - s * ((k0 * inv_angle + 128) >> 8)];
+        const int r1 = ref[k1 >= 0 ? n2 + s * k1 : n2 - s * ((k1 * inv_angle + 128) >> 8)];
+        int v = ((32 - i_fact) * r0 + i_fact * r1 + 16) >> 5;      // i_fact == 0 gives r0
+        if (pure && a == 0) v = clip3(0, maxv, (int)ref[n2 + s] + (((int)ref[n2 - s * (b + 1)] - (int)ref[n2]) >> 1));
+        if (cbf) v = clip3(0, maxv, v + RES_AT(it, idx));
+        dst0[y * ctbc + x] = (Pix)v;
+      }
+    }
   }
 #undef RL
 #undef RT
-  lds_sync();
-  if (!cbf) return;
-
-  // ---- residual (already scaled + inverse transformed in place of the coefficients) ----
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int idx = lane + 64 * k;
-    if (idx < nn) {
-      const int x = idx & (n - 1), y = idx >> log2n;
-      Pix* p = &tile[(yb + y) * ctbc + xb + x];
-      *p = (Pix)clip3(0, maxv, (int)*p + (int)rpre[k]);
-    }
-  }
-  for (int idx = lane + 256; idx < nn; idx += 64) {   // 32x32 only
-    const int x = idx & (n - 1), y = idx >> log2n;
-    Pix* p = &tile[(yb + y) * ctbc + xb + x];
-    *p = (Pix)clip3(0, maxv, (int)*p + (int)res[idx]);
+#undef RES_AT
+  // ---- the block's units are decoded now ----
+  {
+    const int k = n >> C.ush;    // units per side (>= 1)
+    if (lane < k) L.avrow[(yb >> C.ush) + 1 + lane] |= ((1ull << k) - 1ull) << ((xb >> C.ush) + 1);
   }
   lds_sync();
 }
@@ -310,6 +295,12 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
   constexpr int ES = (int)sizeof(Pix);
   int err = 0;
   uint32_t my_row = 0;
+  Ctx C;
+  C.lane = lane; C.lt = (1ull << lane) - 1ull; C.ctbc = ctbc; C.ush = c_idx ? 1 : 2;
+  C.bit_depth = c_idx ? P.bit_depth_chroma : P.bit_depth_luma; C.maxv = (1 << C.bit_depth) - 1;
+  C.luma = c_idx == 0; C.strong = P.strong_intra_smoothing;
+  const int Wc = c_idx ? P.cwidth : P.width, Hc = c_idx ? P.cheight : P.height;   // component plane size in samples
+  const int side = 1 << (P.log2_ctb - 2);                                          // 4x4-luma units per CTB side
 
   for (int cy = (int)wd.first_row; cy < P.ctb_h && !err; cy += (int)wd.stride) {
   my_row = wd.base_row + (uint32_t)cy;     // batch row index
@@ -318,9 +309,8 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
   for (int cx = 0; cx < P.ctb_w && !err; cx++) {
     const int ctb_rs = cy * P.ctb_w + cx;
     const CtbInfo ci = ctb_info[ctb_rs];
-    Ctx C;
-    C.pp = &P; C.lane = lane; C.x_ctb = cx << P.log2_ctb; C.y_ctb = cy << P.log2_ctb; C.avail = ci.avail; C.ctb = ctb;
-    const int xc0 = C.x_ctb / sub;  // component x of the CTB
+    const int x_ctb = cx << P.log2_ctb, y_ctb = cy << P.log2_ctb;   // luma origin of the CTB
+    const int xc0 = x_ctb / sub;  // component x of the CTB
     // ---- wait for the row above: above-right CTB done (or the row end) ----
     const Pix* top = (const Pix*)(L.top_raw + 1);
     if (cy > 0) {
@@ -348,8 +338,22 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
       for (int i = lane * 4; i < units; i += 256) {
         *(uint32_t*)&L.m_size[i] = *(const uint32_t*)(A.arena + P.off_u_size + base + i);
         *(uint32_t*)&L.m_flags[i] = *(const uint32_t*)(A.arena + P.off_u_flags + base + i);
-        *(uint32_t*)&L.m_ipm[i] = *(const uint32_t*)(A.arena + P.off_u_ipm + base + i);
-        *(uint32_t*)&L.m_ipmc[i] = *(const uint32_t*)(A.arena + P.off_u_ipmc + base + i);
+        *(uint32_t*)&L.m_mode[i] = *(const uint32_t*)(A.arena + (c_idx ? P.off_u_ipmc : P.off_u_ipm) + base + i);
+      }
+      // availability rows: the borders come from the neighbouring CTBs (slice / tile / picture limits are in ci.avail,
+      // units right of or below the picture never become available), the CTB's own units are set block by block
+      if (lane < 33) {
+        const int usz = 4 / sub;                                        // component samples per unit
+        uint64_t row = 0;
+        if (lane == 0) {
+          int nu = (Wc - xc0 + usz - 1) / usz;                          // units up to the right picture edge
+          nu = nu > 2 * side ? 2 * side : nu;
+          const int n_up = nu < side ? nu : side;
+          if (ci.avail & AV_UPLEFT) row |= 1ull;
+          if (ci.avail & AV_UP) row |= ((1ull << n_up) - 1ull) << 1;
+          if ((ci.avail & AV_UPRIGHT) && nu > side) row |= ((1ull << (nu - side)) - 1ull) << (side + 1);
+        } else if (lane <= side && (ci.avail & AV_LEFT) && y_ctb / sub + (lane - 1) * usz < Hc) row = 1ull;
+        L.avrow[lane] = row;
       }
     }
     lds_sync();
@@ -359,19 +363,19 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
     int z = 0;
     while (z < units) {
       const int ux = (int)compact1by1((uint32_t)z), uy = (int)compact1by1((uint32_t)z >> 1);
-      if (C.x_ctb + ux * 4 >= P.width || C.y_ctb + uy * 4 >= P.height) { z++; continue; }
+      if (x_ctb + ux * 4 >= P.width || y_ctb + uy * 4 >= P.height) { z++; continue; }
       const int tb = L.m_size[z] & 15;
       if (tb < 2 || tb > 5) { err = DEV_ERR_SYNTAX; break; }
       const int fl = L.m_flags[z];
       if (c_idx == 0) {
-        reconstruct_block<Pix>(L, C, top, 0, ux * 4, uy * 4, tb, z, L.m_ipm[z] & 63, fl & UF_CBF_LUMA, res_base + z * 16);
+        reconstruct_block<Pix>(L, C, top, ux * 4, uy * 4, tb, L.m_mode[z] & 63, fl & UF_CBF_LUMA, res_base + z * 16);
       } else {
         int do_c = 0, zc = z, tc = tb - 1;
         if (tb > 2) do_c = 1;
         else if ((z & 3) == 3) { do_c = 1; zc = z & ~3; tc = 2; }
         if (do_c) {
           const int cux = (int)compact1by1((uint32_t)zc), cuy = (int)compact1by1((uint32_t)zc >> 1);
-          reconstruct_block<Pix>(L, C, top, c_idx, cux * 2, cuy * 2, tc, zc, L.m_ipmc[z], fl & (c_idx == 1 ? UF_CBF_CB : UF_CBF_CR), res_base + zc * 4);
+          reconstruct_block<Pix>(L, C, top, cux * 2, cuy * 2, tc, L.m_mode[z], fl & (c_idx == 1 ? UF_CBF_CB : UF_CBF_CR), res_base + zc * 4);
         }
       }
       z += 1 << (2 * (tb - 2));
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
     {
       constexpr int PPW = 4 / ES;            // pixels per 32-bit word
       const int wpr = ctbc / PPW;            // words per tile row
-      const int yc0 = C.y_ctb / sub;
+      const int yc0 = y_ctb / sub;
       for (int i = lane; i < wpr * ctbc; i += 64) {
         const int y = i / wpr, xw = i - y * wpr;
         *(uint32_t*)&rec[(size_t)(yc0 + y) * stride + xc0 + xw * PPW] = *(const uint32_t*)&L.tile[y * ctbc + xw * PPW];
