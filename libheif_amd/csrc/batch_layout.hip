@@ -115,6 +115,11 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
     if (Pp.diff_cu_qp_delta_depth > S.log2_ctb - S.log2_min_cb) { err_out = "item " + std::to_string(i) + ": diff_cu_qp_delta_depth out of range"; return HIPDEC_ERR_BITSTREAM; }
     P.first_row = row_base; row_base += (uint32_t)P.ctb_h;
     P.num_slices = (uint32_t)pp.slice_params.size();
+    {
+      bool free_nb = !Pp.transquant_bypass && (!Pp.tiles || Pp.lf_across_tiles);
+      if (pp.slice_params.size() > 1) for (const auto& sl : pp.slice_params) free_nb = free_nb && sl.lf_across_slices;
+      P.sao_free_neighbours = free_nb ? 1 : 0;
+    }
     const size_t nctb = (size_t)P.ctb_w * P.ctb_h;
     P.off_ctb_ts_to_rs = off; off = align_up(off + nctb * sizeof(uint16_t), 256);
     P.off_ctb_info = off; off = align_up(off + nctb * sizeof(CtbInfo), 256);

@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
   const int crop_xc = P.crop_x / sub, crop_yc = P.crop_y / sub, ctb_w = P.ctb_w;
   const bool check_bypass = P.transquant_bypass_enabled != 0;
   const bool lf_across_tiles = P.lf_across_tiles != 0;
+  const bool free_nb = P.sao_free_neighbours != 0;
   const int tid = threadIdx.x;
   const int tx = (tid & 31) * 4, ty = tid >> 5;
   const int xs0 = ox_t + crop_xc, ys0 = oy_t + crop_yc;
@@ -254,8 +255,10 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
 #define SAO_AT(row, x) (((const Pix*)((const uint8_t*)tile[row] + ((x) * ES - ab)))[0])
     // fast paths: the 4 samples share one CTB (one parameter set) and no per-sample lossless check is needed
     const int cmask = (1 << lctb) - 1;
-    const bool interior = (xf & cmask) > 0 && (xl & cmask) < cmask && (y & cmask) > 0 && (y & cmask) < cmask &&   // no neighbour leaves the CTB
-                          xl + 1 < W && y + 1 < H;                                                                  // ... or the picture
+    // edge offsets without per-neighbour checks: no neighbour leaves the CTB - or nothing restricts neighbours in other
+    // CTBs (one slice or filtering across slices / tiles allowed, no lossless CUs) - and none leaves the picture
+    const bool interior = (free_nb ? (xf > 0 && y > 0) : ((xf & cmask) > 0 && (xl & cmask) < cmask && (y & cmask) > 0 && (y & cmask) < cmask)) &&
+                          xl + 1 < W && y + 1 < H;
     bool done = false;
     if (one_ctb && !check_bypass && npx == 4) {
       const SaoRegs sp = sp_first;

@@ -67,7 +67,9 @@ struct PicParams {
   // coding tools
   uint8_t sao_enabled, sign_data_hiding, transform_skip_enabled, cu_qp_delta_enabled;
   uint8_t transquant_bypass_enabled, strong_intra_smoothing, tiles_enabled, wpp;
-  uint8_t lf_across_tiles, pcm_loop_filter_disabled, pad0, pad1;
+  uint8_t lf_across_tiles, pcm_loop_filter_disabled;
+  uint8_t sao_free_neighbours;   // 1: no slice / tile boundary restricts the SAO edge neighbours and no lossless CU can occur
+  uint8_t pad1;
   int32_t log2_min_cu_qp_delta_size;
   // buffers (byte offsets into the batch arena)
   uint64_t off_bitstream, bitstream_size;

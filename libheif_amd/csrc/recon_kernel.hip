@@ -26,12 +26,29 @@
 
 namespace hipdec {
 
+// 7 waves per SIMD (<= 72 VGPRs): the reconstruction wavefront hides its LDS / HBM latencies with resident waves
+#ifndef HIPDEC_HOST_EMU
+#define RECON_OCCUPANCY __attribute__((amdgpu_waves_per_eu(7, 8)))
+#else
+#define RECON_OCCUPANCY
+#endif
 
 namespace {
 
-__constant__ int8_t c_angle[35] = {0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
-                                   -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32};
-__constant__ int16_t c_inv_angle[15] = {-4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096};
+// intraPredAngle / invAngle (8.4.4.2.6, tables 8-4 and 8-5) are functions of the distance k of the mode from the pure
+// horizontal (10) or vertical (26) direction; they are kept as packed immediates (a __constant__ array indexed by the mode
+// costs a global load and a vmcnt(0) wait - which also waits for the residual prefetch - in every angular block)
+__device__ __forceinline__ int angle_magnitude(int k)   // k = 0..8 -> 0, 2, 5, 9, 13, 17, 21, 26, 32
+{
+  constexpr uint64_t kMag = 0ull | (2ull << 7) | (5ull << 14) | (9ull << 21) | (13ull << 28) | (17ull << 35) | (21ull << 42) | (26ull << 49) | (32ull << 56);
+  return (int)((kMag >> (k * 7)) & 127u);
+}
+__device__ __forceinline__ int inv_angle_magnitude(int k)   // k = 1..8 -> round(8192 / angle): 4096, 1638, 910, 630, 482, 390, 315, 256
+{
+  constexpr uint64_t kLo = 4096ull | (1638ull << 16) | (910ull << 32) | (630ull << 48);
+  constexpr uint64_t kHi = 482ull | (390ull << 16) | (315ull << 32) | (256ull << 48);
+  return (int)(((k <= 4 ? kLo : kHi) >> (((k - 1) & 3) * 16)) & 0xffffu);
+}
 
 template <typename Pix>
 struct ReconLds {
@@ -52,6 +69,18 @@ __device__ __forceinline__ uint32_t compact1by1(uint32_t v)
   return v;
 }
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+// full-rate 24-bit multiply (v_mul_i32_i24); a plain `*` becomes the quarter-rate v_mul_lo_u32 unless the compiler can
+// prove the operand ranges.  All operands here are sample values, block coordinates or table entries (< 2^17).
+__device__ __forceinline__ int mul24(int a, int b)
+{
+#ifndef HIPDEC_HOST_EMU
+  int r;
+  asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return a * b;
+#endif
+}
 // The workgroup is ONE wave: lanes only need their LDS traffic drained before they read each other's values.  (A
 // __syncthreads() would also wait for the outstanding global loads, i.e. serialise the residual prefetch.)
 __device__ __forceinline__ void lds_sync()
@@ -74,7 +103,7 @@ __device__ __forceinline__ void drain_stores()
 struct Ctx {
   int lane;
   uint64_t lt;        // bits below this lane
-  int ctbc;           // CTB size in component samples
+  int ctbc, lg_ctbc;  // CTB size in component samples (and its log2)
   int ush;            // component samples -> 4x4-luma units: >> ush (2 for luma, 1 for 4:2:0 chroma)
   int bit_depth, maxv;
   int luma;           // c_idx == 0
@@ -88,7 +117,7 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
 {
   const int lane = C.lane;
   const int n = 1 << log2n, n2 = 2 * n, N = 4 * n + 1, nn = n * n;
-  const int ctbc = C.ctbc, maxv = C.maxv;
+  const int lg_ctbc = C.lg_ctbc, maxv = C.maxv;
   Pix* tile = L.tile;
   uint16_t* ref0 = L.refbuf0 + 1;
   uint16_t* ref1 = L.refbuf1 + 1;
@@ -100,8 +129,9 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
     if (lane < nn) rp0 = res[lane];
     if (nn > 64) { rp1 = res[lane + 64]; rp2 = res[lane + 128]; rp3 = res[lane + 192]; }
   }
-  // residual of iteration `it` (wave-uniform selects; a register array indexed by `it` would live in scratch memory)
-#define RES_AT(it, idx) ((it) == 0 ? rp0 : ((it) == 1 ? rp1 : ((it) == 2 ? rp2 : ((it) == 3 ? rp3 : (int)res[idx]))))
+  // the residual of the current iteration is always rp0: the four prefetched values rotate (a register array indexed by
+  // the iteration would live in scratch memory), a 32x32 block refills the free slot four iterations ahead
+#define NEXT_RES(it) do { rp0 = rp1; rp1 = rp2; rp2 = rp3; rp3 = (cbf && (it) + 4 < iters) ? (int)res[lane + 64 * ((it) + 4)] : 0; } while (0)
 
   // ---- 8.4.4.2.2 reference samples: gather + availability ----
   // scan order e: left column bottom-up (e < 2n), corner (e = 2n), top row left to right.  Lanes take e = lane + 64 j for
@@ -120,7 +150,7 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
     int a = 0;
     if (e < N) a = (int)((L.avrow[(Y >> C.ush) + 1] >> ((X >> C.ush) + 1)) & 1u);
     if (a) {
-      const Pix* src = Y < 0 ? &top[X + 1] : (X < 0 ? &L.left[Y] : &tile[Y * ctbc + X]);
+      const Pix* src = Y < 0 ? &top[X + 1] : (X < 0 ? &L.left[Y] : &tile[(Y << lg_ctbc) + X]);
       ref0[e] = (uint16_t)*src;
     }
     av[j] = a;
@@ -131,7 +161,7 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
   if (has_x) {
     const int X = xb + n2 - 1, Y = yb - 1;
     ax = (int)((L.avrow[(Y >> C.ush) + 1] >> ((X >> C.ush) + 1)) & 1u);
-    if (ax && lane == 0) ref0[N - 1] = (uint16_t)(Y < 0 ? top[X + 1] : tile[Y * ctbc + X]);
+    if (ax && lane == 0) ref0[N - 1] = (uint16_t)(Y < 0 ? top[X + 1] : tile[(Y << lg_ctbc) + X]);
   }
   lds_sync();
   // ---- substitution process, only where something is missing (wave-uniform) ----
@@ -205,16 +235,17 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
   // ---- prediction 8.4.4.2.4 - 8.4.4.2.6, residual add, store into the tile ----
   const int edge = C.luma && n < 32;  // DC / horizontal / vertical boundary smoothing
   const int iters = nn > 64 ? nn >> 6 : 1;
-  Pix* dst0 = &tile[yb * ctbc + xb];
+  Pix* dst0 = &tile[(yb << lg_ctbc) + xb];
   if (mode == 0) {
     const int tr = RT(n + 1), bl = RL(n + 1);
     for (int it = 0; it < iters; it++) {
       const int idx = lane + 64 * it, x = idx & (n - 1), y = idx >> log2n;
       if (idx < nn) {
-        int v = ((n - 1 - x) * RL(y + 1) + (x + 1) * tr + (n - 1 - y) * RT(x + 1) + (y + 1) * bl + n) >> (log2n + 1);
-        if (cbf) v = clip3(0, maxv, v + RES_AT(it, idx));
-        dst0[y * ctbc + x] = (Pix)v;
+        int v = (mul24(n - 1 - x, RL(y + 1)) + mul24(x + 1, tr) + mul24(n - 1 - y, RT(x + 1)) + mul24(y + 1, bl) + n) >> (log2n + 1);
+        if (cbf) v = clip3(0, maxv, v + rp0);
+        dst0[(y << lg_ctbc) + x] = (Pix)v;
       }
+      NEXT_RES(it);
     }
   } else if (mode == 1) {
     int part = lane < n ? RT(lane + 1) + RL(lane + 1) : 0;
@@ -229,36 +260,41 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
           else if (y == 0) v = (RT(x + 1) + 3 * dc_val + 2) >> 2;
           else if (x == 0) v = (RL(y + 1) + 3 * dc_val + 2) >> 2;
         }
-        if (cbf) v = clip3(0, maxv, v + RES_AT(it, idx));
-        dst0[y * ctbc + x] = (Pix)v;
+        if (cbf) v = clip3(0, maxv, v + rp0);
+        dst0[(y << lg_ctbc) + x] = (Pix)v;
       }
+      NEXT_RES(it);
     }
   } else {
     // angular: with the roles of the two reference arms swapped for the horizontal modes (2..17) both families read
     // main(k) = ref[2n + s k], side(k) = ref[2n - s k]  (s = +1 vertical, -1 horizontal)
     const int vertical = mode >= 18;
     const int s = vertical ? 1 : -1;
-    const int angle = c_angle[mode];
-    const int inv_angle = (mode >= 11 && mode <= 25) ? c_inv_angle[mode - 11] : 0;
+    const int dm = mode - (vertical ? 26 : 10), k_dir = dm < 0 ? -dm : dm;                       // distance from the pure direction
+    const int angle = ((dm < 0) == vertical) ? -angle_magnitude(k_dir) : angle_magnitude(k_dir);   // modes 11..25 point up-left
+    const int inv_angle = angle < 0 ? -inv_angle_magnitude(k_dir) : 0;
     const int pure = edge && (mode == 26 || mode == 10);     // pure vertical / horizontal with boundary smoothing
     for (int it = 0; it < iters; it++) {
       const int idx = lane + 64 * it, x = idx & (n - 1), y = idx >> log2n;
       if (idx < nn) {
         const int a = vertical ? x : y, b = vertical ? y : x;   // along / across the main arm
-        const int t = (b + 1) * angle, i_idx = t >> 5, i_fact = t & 31;
+        const int t = mul24(b + 1, angle), i_idx = t >> 5, i_fact = t & 31;
         const int k0 = a + i_idx + 1, k1 = k0 + 1;
-        const int r0 = ref[k0 >= 0 ? n2 + s * k0 : n2 - s * ((k0 * inv_angle + 128) >> 8)];
-        const int r1 = ref[k1 >= 0 ? n2 + s * k1 : n2 - s * ((k1 * inv_angle + 128) >> 8)];
-        int v = ((32 - i_fact) * r0 + i_fact * r1 + 16) >> 5;      // i_fact == 0 gives r0
-        if (pure && a == 0) v = clip3(0, maxv, (int)ref[n2 + s] + (((int)ref[n2 - s * (b + 1)] - (int)ref[n2]) >> 1));
-        if (cbf) v = clip3(0, maxv, v + RES_AT(it, idx));
-        dst0[y * ctbc + x] = (Pix)v;
+        // taps with a negative index come from the other arm, projected with invAngle (24-bit multiplies: full rate)
+        const int p0 = -((mul24(k0, inv_angle) + 128) >> 8), p1 = -((mul24(k1, inv_angle) + 128) >> 8);
+        const int r0 = ref[n2 + mul24(s, k0 >= 0 ? k0 : p0)];
+        const int r1 = ref[n2 + mul24(s, k1 >= 0 ? k1 : p1)];
+        int v = (mul24(32 - i_fact, r0) + mul24(i_fact, r1) + 16) >> 5;      // i_fact == 0 gives r0
+        if (pure && a == 0) v = clip3(0, maxv, (int)ref[n2 + s] + (((int)ref[n2 - mul24(s, b + 1)] - (int)ref[n2]) >> 1));
+        if (cbf) v = clip3(0, maxv, v + rp0);
+        dst0[(y << lg_ctbc) + x] = (Pix)v;
       }
+      NEXT_RES(it);
     }
   }
 #undef RL
 #undef RT
-#undef RES_AT
+#undef NEXT_RES
   // ---- the block's units are decoded now ----
   {
     const int k = n >> C.ush;    // units per side (>= 1)
@@ -270,7 +306,7 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
 }  // namespace
 
 template <typename Pix>
-__global__ __launch_bounds__(64) void k_recon(ReconArgs A)
+__device__ __forceinline__ void recon_wave(const ReconArgs& A)
 {
   __shared__ ReconLds<Pix> L;
   const int lane = threadIdx.x;
@@ -296,7 +332,7 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
   int err = 0;
   uint32_t my_row = 0;
   Ctx C;
-  C.lane = lane; C.lt = (1ull << lane) - 1ull; C.ctbc = ctbc; C.ush = c_idx ? 1 : 2;
+  C.lane = lane; C.lt = (1ull << lane) - 1ull; C.ctbc = ctbc; C.lg_ctbc = P.log2_ctb - (c_idx ? 1 : 0); C.ush = c_idx ? 1 : 2;
   C.bit_depth = c_idx ? P.bit_depth_chroma : P.bit_depth_luma; C.maxv = (1 << C.bit_depth) - 1;
   C.luma = c_idx == 0; C.strong = P.strong_intra_smoothing;
   const int Wc = c_idx ? P.cwidth : P.width, Hc = c_idx ? P.cheight : P.height;   // component plane size in samples
@@ -388,10 +424,14 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
       constexpr int PPW = 4 / ES;            // pixels per 32-bit word
       const int wpr = ctbc / PPW;            // words per tile row
       const int yc0 = y_ctb / sub;
-      for (int i = lane; i < wpr * ctbc; i += 64) {
-        const int y = i / wpr, xw = i - y * wpr;
-        *(uint32_t*)&rec[(size_t)(yc0 + y) * stride + xc0 + xw * PPW] = *(const uint32_t*)&L.tile[y * ctbc + xw * PPW];
-      }
+      // 64 lanes cover 64 / wpr whole tile rows per pass (wpr <= 32 is a power of two): the plane offset advances by a
+      // wave-uniform step, no per-pass multiplies or divisions
+      const int lg_wpr = C.lg_ctbc - (ES == 1 ? 2 : 1);
+      const int y0 = lane >> lg_wpr, xw = lane & (wpr - 1);
+      uint32_t off = (uint32_t)(yc0 + y0) * stride + (uint32_t)(xc0 + xw * PPW);
+      const uint32_t step = (64u >> lg_wpr) * stride;
+      for (int i = lane; i < wpr * ctbc; i += 64, off += step)
+        *(uint32_t*)&rec[off] = *(const uint32_t*)&L.tile[i * PPW];     // tile rows are wpr words: word i of the tile
       uint32_t* dst = line + (size_t)cy * line_words + (size_t)xc0 * ES / 4;
       for (int i = lane; i < wpr; i += 64)
         __hip_atomic_store(dst + i, *(const uint32_t*)&L.tile[(ctbc - 1) * ctbc + i * PPW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -406,11 +446,16 @@ __global__ __launch_bounds__(64) void k_recon(ReconArgs A)
   if (err && lane == 0) atomicCAS((int*)A.status, 0, err | (int)(0x40000000u) | (int)(my_row << 8));
 }
 
+// 8-bit pictures: 7 waves per SIMD (<= 72 VGPRs; 6 KB of LDS per wave allows 26 per CU).  The 16-bit variant is limited by
+// its 10 KB of LDS per wave either way.
+__global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8(ReconArgs A) { recon_wave<uint8_t>(A); }
+__global__ __launch_bounds__(64) void k_recon16(ReconArgs A) { recon_wave<uint16_t>(A); }
+
 void launch_recon(const ReconArgs& a, bool wide, hipStream_t s)
 {
   if (!a.num_waves) return;
-  if (wide) hipLaunchKernelGGL((k_recon<uint16_t>), dim3(a.num_waves), dim3(64), 0, s, a);
-  else hipLaunchKernelGGL((k_recon<uint8_t>), dim3(a.num_waves), dim3(64), 0, s, a);
+  if (wide) hipLaunchKernelGGL(k_recon16, dim3(a.num_waves), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL(k_recon8, dim3(a.num_waves), dim3(64), 0, s, a);
 }
 
 }  // namespace hipdec

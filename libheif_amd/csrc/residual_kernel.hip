@@ -23,8 +23,19 @@ namespace {
 __constant__ int8_t r_dct_c[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
                                    61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0};
 __constant__ int8_t r_dst[16] = {29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29};
-__constant__ uint8_t r_chroma_qp[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37};
-__constant__ int r_level_scale[6] = {40, 45, 51, 57, 64, 72};
+// small per-block lookups as packed immediates: a __constant__ array indexed at run time is a global load plus a wait
+// in front of every block
+__device__ __forceinline__ int chroma_qp_table(int qpi)   // table 8-10 for ChromaArrayType 1, qPi in [30, 43]
+{
+  constexpr uint64_t kT = 0ull | (1ull << 4) | (2ull << 8) | (3ull << 12) | (4ull << 16) | (4ull << 20) | (5ull << 24) | (5ull << 28) |
+                          (6ull << 32) | (6ull << 36) | (7ull << 40) | (7ull << 44) | (8ull << 48) | (8ull << 52);
+  return 29 + (int)((kT >> ((qpi - 30) * 4)) & 15u);
+}
+__device__ __forceinline__ int level_scale(int r)         // levelScale[qP % 6] (8.6.3)
+{
+  constexpr uint64_t kS = 40ull | (45ull << 8) | (51ull << 16) | (57ull << 24) | (64ull << 32) | (72ull << 40);
+  return (int)((kS >> (r * 8)) & 255u);
+}
 
 // Transposed, j-contiguous operands so that both 1-D passes are chains of v_dot2_i32_i16 (two MACs per instruction,
 // one 32-bit LDS read per operand pair).  Rows are padded by 2 samples: consecutive lanes then hit distinct banks.
@@ -70,7 +81,7 @@ __device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, in
   const int16_t* et = dst ? L.est4 : (log2n == 2 ? L.et4 : (log2n == 3 ? L.et8 : (log2n == 4 ? L.et16 : L.et32)));
   // ---- scaling (8.6.3, flat m = 16) + nonzero extent ----
   const int bd_shift = bit_depth + log2n - 5;
-  const long long scale = (long long)(16 * r_level_scale[qp % 6]) << (qp / 6);
+  const long long scale = (long long)(16 * level_scale(qp % 6)) << (qp / 6);
   const long long rnd = 1ll << (bd_shift - 1);
   const int bd_shift2 = 20 - bit_depth;
   // nonzero extent (max_row, max_col) without cross-lane shuffles: rows grow with the lane index, so the last
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
       for (int c = 0; c < 2; c++) {
         if (!(fl & (c == 0 ? UF_CBF_CB : UF_CBF_CR))) continue;
         const int qpi = clip3(-off_c, 57, qp_y + (c == 0 ? sl.cb_qp_offset : sl.cr_qp_offset));
-        const int qpc = qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : r_chroma_qp[qpi - 30]);
+        const int qpc = qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : chroma_qp_table(qpi));
         residual_block(L, wave, lane, coef_c[c] + zc * 4, tc, P.bit_depth_chroma, qpc + off_c, 0, (ipm & (c == 0 ? 64 : 128)) != 0, bypass);
       }
     }

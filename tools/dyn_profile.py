@@ -1,0 +1,78 @@
+"""Estimated DYNAMIC instruction profile of a kernel by source line: static ISA count per line (hipcc -S -g) x execution
+count per line from a gcov run of the host emulation (tests/emu built with --coverage).  Lines inside the emulated-lane
+loops of parse_core.h (PC_VEC_BEGIN..PC_VEC_END) run 64x per wave step on the host and are scaled back.  Dev tool.
+usage: dyn_profile.py <kernel.hip> <kernel-symbol-substring> <source-with-gcov> <file.gcov> [pixels]"""
+import collections, os, re, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+kern, sym, srcname, gcovf = sys.argv[1:5]
+px = float(sys.argv[5]) if len(sys.argv) > 5 else None
+out = "/tmp/isa_%s.s" % os.path.basename(kern)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-g", "-std=c++17", "-ffp-contract=off", "-I%s/include" % ROOT,
+                       "-I%s/libheif_amd/csrc" % ROOT, "-S", "--cuda-device-only", "-o", out, kern], stderr=subprocess.DEVNULL)
+lines = open(out).read().split("\n")
+start = [i for i, l in enumerate(lines) if re.match(r"^_Z\S*%s\S*:" % re.escape(sym), l)][0]
+files = {}
+for l in lines:
+    m = re.match(r'\s+\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', l)
+    if m: files[int(m.group(1))] = (m.group(3) or m.group(2))
+static = collections.Counter(); cur = None
+for l in lines[start:]:
+    m = re.match(r"\s+\.loc\s+(\d+)\s+(\d+)", l)
+    if m: cur = (files.get(int(m.group(1)), ""), int(m.group(2))); continue
+    if l.startswith(".Lfunc_end"): break
+    if re.match(r"\s+[a-z_0-9]+(\s|$)", l) and not l.strip().startswith((".", ";")):
+        static[cur] += 1
+st_line = collections.Counter()
+unattributed = 0
+for (f, ln), c in static.items():
+    if f.endswith(srcname) and ln: st_line[ln] += c
+    else: unattributed += c
+print("static instructions: %d in %s, %d elsewhere / line 0" % (sum(st_line.values()), srcname, unattributed))
+# gcov
+dyn = {}
+text = {}
+for l in open(gcovf):
+    m = re.match(r"\s*([0-9#=\-\*]+)\*?:\s*(\d+):(.*)", l)
+    if not m: continue
+    ln = int(m.group(2)); text[ln] = m.group(3)
+    c = m.group(1)
+    if c.rstrip("*").isdigit(): dyn[ln] = int(c.rstrip("*"))
+# vector regions
+invec = set(); on = False
+for ln in sorted(text):
+    t = text[ln]
+    if "PC_VEC_BEGIN" in t and "define" not in t: on = True
+    if on: invec.add(ln)
+    if "PC_VEC_END" in t and "define" not in t: on = False
+def count(ln):
+    # nearest executed line at or before ln (declarations / continuation lines carry no count)
+    for k in range(ln, max(ln - 6, 0), -1):
+        if k in dyn:
+            c = dyn[k]
+            return c / 64.0 if k in invec and "PC_VEC_BEGIN" not in text[k] else c
+    return 0
+# enclosing function of every line (heuristic) and the number of inlined copies of each function: every copy
+# contributes at least one instruction to each executed statement, so the smallest static count of a function's
+# lines estimates the number of copies; static counts are divided by it before weighting with the execution counts
+func_at = {}; curf = "?"
+for ln in sorted(text):
+    t = text[ln]
+    m = re.match(r"(?:PC_DEV|__device__|static|template|inline)\b.*?\b([a-z_0-9]+)\s*\(", t)
+    if m and not t.startswith(" "): curf = m.group(1)
+    func_at[ln] = curf
+copies = {}
+for ln, c in st_line.items():
+    if count(ln) > 0:
+        f = func_at.get(ln, "?"); copies[f] = min(copies.get(f, 1 << 30), c)
+tot = 0; rows = []
+for ln, c in st_line.items():
+    k = max(1, copies.get(func_at.get(ln, "?"), 1))
+    d = c / k * count(ln); tot += d; rows.append((d, ln, c / k, count(ln)))
+rows.sort(reverse=True)
+print("estimated dynamic wave-instructions: %.3g%s" % (tot, (" = %.1f per pixel" % (tot / px)) if px else ""))
+byf = collections.Counter()
+for d, ln, c, k in rows: byf[func_at.get(ln, "?")] += d
+print("-- by function")
+for f, d in byf.most_common(25): print("%6.2f%%  %s" % (100 * d / tot, f))
+print("-- top lines")
+for d, ln, c, k in rows[:int(os.environ.get("TOPN", "45"))]: print("%5.2f%% line %4d static %5.1f x %9.0f  %s" % (100 * d / tot, ln, c, k, text[ln].strip()[:100]))
