@@ -46,8 +46,9 @@ struct ResLds {
   alignas(4) int16_t tmp[4][32 * (32 + RPAD)];   // per wave: first-stage output tmp[y][j]
   uint8_t m_size[256], m_flags[256], m_ipm[256];
   int8_t m_qp[256];
-  uint16_t list[256];
-  uint32_t count;
+  uint16_t list[448];    // blocks larger than 4x4: z | component << 8 (z = the unit that carries the TU's flags)
+  uint16_t list4[448];   // 4x4 blocks, four of them per wave pass
+  uint32_t count, count4;
 };
 
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -164,6 +165,64 @@ __device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, in
   __builtin_amdgcn_wave_barrier();
 }
 
+// Four independent 4x4 blocks per wave pass: lane = 16 g + 4 y + x works on sample (y, x) of block g.  entry = z | c << 8.
+// (8.6.2 - 8.6.4 as in residual_block; both 1-D stages are two v_dot2 per output, no nonzero-extent bookkeeping)
+__device__ __forceinline__ void residual_quad(ResLds& L, const PicParams& P, const SliceParams& sl, int wave, int lane, int entry, bool valid,
+                                              int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr)
+{
+  const int g = lane >> 4, l = lane & 15;
+  const int z = entry & 255, c = (entry >> 8) & 3;
+  const int t = L.m_size[z] & 15, fl = L.m_flags[z], ipm = L.m_ipm[z], qp_y = L.m_qp[z];
+  const bool bypass = (fl & UF_BYPASS) != 0;
+  int16_t* coef;
+  int bit_depth, qp, ts;
+  if (c == 0) {
+    coef = coef_y + z * 16; bit_depth = P.bit_depth_luma; qp = qp_y + 6 * (P.bit_depth_luma - 8); ts = (fl & UF_TS_LUMA) != 0;
+  } else {
+    const int zc = t > 2 ? z : (z & ~3);
+    const int off_c = 6 * (P.bit_depth_chroma - 8);
+    const int qpi = clip3(-off_c, 57, qp_y + (c == 1 ? sl.cb_qp_offset : sl.cr_qp_offset));
+    const int qpc = qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : chroma_qp_table(qpi));
+    coef = (c == 1 ? coef_cb : coef_cr) + zc * 4; bit_depth = P.bit_depth_chroma; qp = qpc + off_c; ts = (ipm & (c == 1 ? 64 : 128)) != 0;
+  }
+  const bool act = valid && !bypass;      // cu_transquant_bypass: the coefficient levels are the residual
+  const int q6 = (qp * 43) >> 8;          // qp / 6 for 0 <= qp < 128
+  const int bd_shift = bit_depth - 3;     // bitDepth + log2(4) - 5
+  const int bd_shift2 = 20 - bit_depth;
+  const long long scale = (long long)(16 * level_scale(qp - 6 * q6)) << q6;
+  int lev = 0;
+  if (act) lev = coef[l];
+  const long long sv = ((long long)lev * scale + (1ll << (bd_shift - 1))) >> bd_shift;
+  const int d = (int)(sv < -32768 ? -32768 : (sv > 32767 ? 32767 : sv));
+  int16_t* blk = L.blk[wave] + g * 16;    // blk[x][j] = d[j][x]
+  int16_t* tmp = L.tmp[wave] + g * 16;    // tmp[i][x]
+  const int y = l >> 2, x = l & 3;
+  blk[x * 4 + y] = (int16_t)d;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t* e = (const uint32_t*)((c == 0 ? L.est4 : L.et4) + y * 4);   // E^T row of this lane's output index (luma 4x4: DST)
+  {
+    // first stage, lane (i = y, x): tmp[i][x] = clip16((sum_j E[j][i] d[j][x] + 64) >> 7)
+    const uint32_t* v = (const uint32_t*)(blk + x * 4);
+    const int sum = dot2(e[1], v[1], dot2(e[0], v[0], 0));
+    tmp[y * 4 + x] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  int r;
+  {
+    // second stage, lane (y, i = x): res[y][i] = (sum_j E[j][i] tmp[y][j] + rnd) >> bdShift
+    const uint32_t* ei = (const uint32_t*)((c == 0 ? L.est4 : L.et4) + x * 4);
+    const uint32_t* v = (const uint32_t*)(tmp + y * 4);
+    const int sum = dot2(ei[1], v[1], dot2(ei[0], v[0], 0));
+    r = (sum + (1 << (bd_shift2 - 1))) >> bd_shift2;
+  }
+  if (ts) r = (d * 128 + (1 << (bd_shift2 - 1))) >> bd_shift2;   // 8.6.4.2 with transform_skip_flag: r = d << 7
+  if (act) coef[l] = (int16_t)r;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
 }  // namespace
 
 // blockIdx.x = CTB (raster) of picture blockIdx.y
@@ -197,7 +256,7 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
       dstp[off] = (int16_t)(k <= 32 ? r_dct_c[k] : -r_dct_c[64 - k]);
     }
   }
-  if (tid == 0) L.count = 0;
+  if (tid == 0) { L.count = 0; L.count4 = 0; }
   if (tid < units) {
     L.m_size[tid] = A.arena[P.off_u_size + base + tid];
     L.m_flags[tid] = A.arena[P.off_u_flags + base + tid];
@@ -205,40 +264,53 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
     L.m_qp[tid] = (int8_t)A.arena[P.off_u_qp + base + tid];
   }
   __syncthreads();
-  // ---- list of units that carry residual blocks: a TU's first unit, or the 4th 4x4 luma unit of a chroma group ----
+  // ---- lists of coded blocks, one entry per block and component: z | c << 8 with z the unit that carries the flags (a TU's
+  //      first unit; for the chroma blocks of four 4x4 luma TUs the 4th unit, where the parser leaves their flags) ----
   if (tid < units) {
     const int z = tid;
     const int ux = (int)compact1by1((uint32_t)z), uy = (int)compact1by1((uint32_t)z >> 1);
     const int x_ctb = (ctb_rs % P.ctb_w) << P.log2_ctb, y_ctb = (ctb_rs / P.ctb_w) << P.log2_ctb;
     if (x_ctb + ux * 4 < P.width && y_ctb + uy * 4 < P.height) {
-      const int t = L.m_size[z] & 15;
+      const int t = L.m_size[z] & 15, fl = L.m_flags[z];
       const int first = t >= 2 && t <= 5 && (z & ((1 << (2 * (t - 2))) - 1)) == 0;
-      if (first && (L.m_flags[z] & (UF_CBF_LUMA | UF_CBF_CB | UF_CBF_CR))) L.list[atomicAdd(&L.count, 1u)] = (uint16_t)z;
+      if (first && !(fl & UF_BYPASS)) {
+        if (fl & UF_CBF_LUMA) {
+          if (t == 2) L.list4[atomicAdd(&L.count4, 1u)] = (uint16_t)z;
+          else L.list[atomicAdd(&L.count, 1u)] = (uint16_t)z;
+        }
+        if (P.chroma_format_idc)
+          for (int c = 1; c < 3; c++)
+            if (fl & (c == 1 ? UF_CBF_CB : UF_CBF_CR)) {
+              if (t <= 3) L.list4[atomicAdd(&L.count4, 1u)] = (uint16_t)(z | (c << 8));
+              else L.list[atomicAdd(&L.count, 1u)] = (uint16_t)(z | (c << 8));
+            }
+      }
     }
   }
   __syncthreads();
-  const int count = (int)L.count;
+  const int count = (int)L.count, count4 = (int)L.count4;
   const CtbInfo ci = ((const CtbInfo*)(A.arena + P.off_ctb_info))[ctb_rs];
   const SliceParams sl = ((const SliceParams*)(A.arena + P.off_slices))[ci.slice_idx];
   int16_t* coef_y = (int16_t*)(A.arena + P.off_coeff[0]) + (size_t)ctb_rs * ctb * ctb;
   int16_t* coef_c[2] = {(int16_t*)(A.arena + P.off_coeff[1]) + (size_t)ctb_rs * (ctb * ctb / 4),
                         (int16_t*)(A.arena + P.off_coeff[2]) + (size_t)ctb_rs * (ctb * ctb / 4)};
+  // 4x4 blocks, four per wave pass
+  for (int q = wave; q * 4 < count4; q += 4) {
+    const int idx = q * 4 + (lane >> 4);
+    const bool valid = idx < count4;
+    residual_quad(L, P, sl, wave, lane, valid ? (int)L.list4[idx] : 0, valid, coef_y, coef_c[0], coef_c[1]);
+  }
+  // larger blocks, one per wave pass
   for (int e = wave; e < count; e += 4) {
-    const int z = L.list[e];
+    const int z = L.list[e] & 255, c = L.list[e] >> 8;
     const int t = L.m_size[z] & 15, fl = L.m_flags[z], ipm = L.m_ipm[z], qp_y = L.m_qp[z];
-    const int bypass = (fl & UF_BYPASS) != 0;
-    if (fl & UF_CBF_LUMA)
-      residual_block(L, wave, lane, coef_y + z * 16, t, P.bit_depth_luma, qp_y + 6 * (P.bit_depth_luma - 8), t == 2, (fl & UF_TS_LUMA) != 0, bypass);
-    if (P.chroma_format_idc && (fl & (UF_CBF_CB | UF_CBF_CR))) {
-      // chroma blocks hang off TUs larger than 4x4, or off the 4th unit of a 4x4 quadruple (flags set there by the parser)
-      const int zc = t > 2 ? z : (z & ~3), tc = t > 2 ? t - 1 : 2;
+    if (c == 0)
+      residual_block(L, wave, lane, coef_y + z * 16, t, P.bit_depth_luma, qp_y + 6 * (P.bit_depth_luma - 8), 0, (fl & UF_TS_LUMA) != 0, 0);
+    else {
       const int off_c = 6 * (P.bit_depth_chroma - 8);
-      for (int c = 0; c < 2; c++) {
-        if (!(fl & (c == 0 ? UF_CBF_CB : UF_CBF_CR))) continue;
-        const int qpi = clip3(-off_c, 57, qp_y + (c == 0 ? sl.cb_qp_offset : sl.cr_qp_offset));
-        const int qpc = qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : chroma_qp_table(qpi));
-        residual_block(L, wave, lane, coef_c[c] + zc * 4, tc, P.bit_depth_chroma, qpc + off_c, 0, (ipm & (c == 0 ? 64 : 128)) != 0, bypass);
-      }
+      const int qpi = clip3(-off_c, 57, qp_y + (c == 1 ? sl.cb_qp_offset : sl.cr_qp_offset));
+      const int qpc = qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : chroma_qp_table(qpi));
+      residual_block(L, wave, lane, coef_c[c - 1] + z * 4, t - 1, P.bit_depth_chroma, qpc + off_c, 0, (ipm & (c == 1 ? 64 : 128)) != 0, 0);
     }
   }
 }
