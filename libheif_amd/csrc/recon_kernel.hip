@@ -60,7 +60,9 @@ struct ReconLds {
   // units ux, uy in [-1, 2 * units_per_side): row 0 / bit 0 are the borders owned by the neighbouring CTBs, rows and bits
   // past the CTB stay 0 (not decoded yet), a unit of the CTB is set when its block has been reconstructed
   uint64_t avrow[33];
-  uint8_t m_size[256], m_flags[256], m_mode[256];
+  // per 4x4-luma unit (z order): log2 TU size | log2 CB size << 4 | UF_* flags << 8 | intra mode of this component << 16 |
+  // unit x << 24 | unit y << 28
+  uint32_t m_unit[256];
 };
 
 __device__ __forceinline__ uint32_t compact1by1(uint32_t v)
@@ -102,7 +104,6 @@ __device__ __forceinline__ void drain_stores()
 
 struct Ctx {
   int lane;
-  uint64_t lt;        // bits below this lane
   int ctbc, lg_ctbc;  // CTB size in component samples (and its log2)
   int ush;            // component samples -> 4x4-luma units: >> ush (2 for luma, 1 for 4:2:0 chroma)
   int bit_depth, maxv;
@@ -182,7 +183,7 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
         if (j >= J) continue;
         const int e = lane + 64 * j;
         if (e < N && !av[j]) {
-          const uint64_t mm = m[j] & C.lt;
+          const uint64_t mm = m[j] & ((1ull << lane) - 1ull);   // available samples below this lane's
           const int src = mm ? 64 * j + 63 - __clzll((long long)mm) : (j == 1 && hi0 >= 0 ? hi0 : first);
           val[j] = ref0[src];
         }
@@ -332,10 +333,11 @@ __device__ __forceinline__ void recon_wave(const ReconArgs& A)
   int err = 0;
   uint32_t my_row = 0;
   Ctx C;
-  C.lane = lane; C.lt = (1ull << lane) - 1ull; C.ctbc = ctbc; C.lg_ctbc = P.log2_ctb - (c_idx ? 1 : 0); C.ush = c_idx ? 1 : 2;
+  C.lane = lane; C.ctbc = ctbc; C.lg_ctbc = P.log2_ctb - (c_idx ? 1 : 0); C.ush = c_idx ? 1 : 2;
   C.bit_depth = c_idx ? P.bit_depth_chroma : P.bit_depth_luma; C.maxv = (1 << C.bit_depth) - 1;
   C.luma = c_idx == 0; C.strong = P.strong_intra_smoothing;
   const int Wc = c_idx ? P.cwidth : P.width, Hc = c_idx ? P.cheight : P.height;   // component plane size in samples
+  const int pic_w = P.width, pic_h = P.height;
   const int side = 1 << (P.log2_ctb - 2);                                          // 4x4-luma units per CTB side
 
   for (int cy = (int)wd.first_row; cy < P.ctb_h && !err; cy += (int)wd.stride) {
@@ -368,13 +370,18 @@ __device__ __forceinline__ void recon_wave(const ReconArgs& A)
       for (int i = lane; i < nwords; i += 64) L.top_raw[1 + i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       top = (const Pix*)((const uint8_t*)(L.top_raw + 1) + (b0 - start));   // top[0] = above-left sample
     }
-    // ---- stage the CTB's maps ----
+    // ---- stage the CTB's maps, one packed word per unit ----
     {
       const size_t base = (size_t)ctb_rs * units;
       for (int i = lane * 4; i < units; i += 256) {
-        *(uint32_t*)&L.m_size[i] = *(const uint32_t*)(A.arena + P.off_u_size + base + i);
-        *(uint32_t*)&L.m_flags[i] = *(const uint32_t*)(A.arena + P.off_u_flags + base + i);
-        *(uint32_t*)&L.m_mode[i] = *(const uint32_t*)(A.arena + (c_idx ? P.off_u_ipmc : P.off_u_ipm) + base + i);
+        const uint32_t sz = *(const uint32_t*)(A.arena + P.off_u_size + base + i);
+        const uint32_t fl = *(const uint32_t*)(A.arena + P.off_u_flags + base + i);
+        const uint32_t md = *(const uint32_t*)(A.arena + (c_idx ? P.off_u_ipmc : P.off_u_ipm) + base + i);
+        const uint32_t ux = compact1by1((uint32_t)i), uy = compact1by1((uint32_t)i >> 1);   // i is a multiple of 4: units i..i+3 are a 2x2 quad
+#pragma nounroll
+        for (int k = 0; k < 4; k++)
+          L.m_unit[i + k] = ((sz >> (8 * k)) & 255u) | (((fl >> (8 * k)) & 255u) << 8) | (((md >> (8 * k)) & (c_idx ? 255u : 63u)) << 16) |
+                            ((ux + (k & 1)) << 24) | ((uy + (k >> 1)) << 28);
       }
       // availability rows: the borders come from the neighbouring CTBs (slice / tile / picture limits are in ci.avail,
       // units right of or below the picture never become available), the CTB's own units are set block by block
@@ -398,21 +405,18 @@ __device__ __forceinline__ void recon_wave(const ReconArgs& A)
     const int16_t* res_base = (const int16_t*)(A.arena + P.off_coeff[c_idx]) + (size_t)ctb_rs * (ctb * ctb / (sub * sub));
     int z = 0;
     while (z < units) {
-      const int ux = (int)compact1by1((uint32_t)z), uy = (int)compact1by1((uint32_t)z >> 1);
-      if (x_ctb + ux * 4 >= P.width || y_ctb + uy * 4 >= P.height) { z++; continue; }
-      const int tb = L.m_size[z] & 15;
+      const uint32_t w = L.m_unit[z];
+      const int ux = (int)((w >> 24) & 15u), uy = (int)(w >> 28);
+      if (x_ctb + ux * 4 >= pic_w || y_ctb + uy * 4 >= pic_h) { z++; continue; }
+      const int tb = (int)(w & 15u), fl = (int)((w >> 8) & 255u), mode = (int)((w >> 16) & 255u);
       if (tb < 2 || tb > 5) { err = DEV_ERR_SYNTAX; break; }
-      const int fl = L.m_flags[z];
       if (c_idx == 0) {
-        reconstruct_block<Pix>(L, C, top, ux * 4, uy * 4, tb, L.m_mode[z] & 63, fl & UF_CBF_LUMA, res_base + z * 16);
-      } else {
-        int do_c = 0, zc = z, tc = tb - 1;
-        if (tb > 2) do_c = 1;
-        else if ((z & 3) == 3) { do_c = 1; zc = z & ~3; tc = 2; }
-        if (do_c) {
-          const int cux = (int)compact1by1((uint32_t)zc), cuy = (int)compact1by1((uint32_t)zc >> 1);
-          reconstruct_block<Pix>(L, C, top, cux * 2, cuy * 2, tc, L.m_mode[z], fl & (c_idx == 1 ? UF_CBF_CB : UF_CBF_CR), res_base + zc * 4);
-        }
+        reconstruct_block<Pix>(L, C, top, ux * 4, uy * 4, tb, mode, fl & UF_CBF_LUMA, res_base + z * 16);
+      } else if (tb > 2 || (z & 3) == 3) {
+        // the 4x4 chroma block of four 4x4 luma TUs hangs off the 4th unit (its flags are there); it sits at the quad's origin
+        const int quad = tb == 2;
+        const int zc = quad ? (z & ~3) : z, cux = quad ? (ux & ~1) : ux, cuy = quad ? (uy & ~1) : uy;
+        reconstruct_block<Pix>(L, C, top, cux * 2, cuy * 2, quad ? 2 : tb - 1, mode, fl & (c_idx == 1 ? UF_CBF_CB : UF_CBF_CR), res_base + zc * 4);
       }
       z += 1 << (2 * (tb - 2));
     }
