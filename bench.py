@@ -109,6 +109,7 @@ def main():
         subs = [(batch, None)]
     else:
         k = max(1, min(a.streams, n_items))
+        lib.hipdec_set_concurrent_batches(k)   # the sub-batches overlap on the GPU: they share the CABAC pool's wave slots
         for j in range(k):
             part = streams[j::k]
             b = Batch(part)          # parses headers on the host and uploads everything to HBM

@@ -122,6 +122,10 @@ HIPDEC_API int hipdec_decoder_read_plane(hipdec_decoder* dec, int c, void* dst_h
 /* device-resident hand-over for callers that keep the colour stage on the GPU */
 HIPDEC_API int hipdec_decoder_device_plane(hipdec_decoder* dec, int c, const void** dptr, size_t* stride);
 
+/* Number of large batches the host keeps in flight at a time on separate streams (default 1).  The CABAC work pool of a
+ * batch needs all its waves resident, so concurrent batches share the device's wave slots. */
+HIPDEC_API int hipdec_set_concurrent_batches(int n);
+
 /* ---- batch decode (grid tiles / throughput mode) ------------------------------------------- */
 typedef struct hipdec_batch hipdec_batch;
 /* Parses n independent items (same framing as push_data) and uploads them; all items must share

@@ -11,6 +11,7 @@ namespace hipdec {
 int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 int ensure_init();
 hipStream_t default_stream();
+uint32_t parse_wave_budget();   // CABAC pool waves one batch may launch (wave slots / concurrent batches)
 
 // Process-wide pool of decode arenas.  libheif creates and destroys one plugin decoder per item and per grid tile
 // (libheif/codecs/decoder.cc:388-405,549), so arenas are recycled by size instead of hipMalloc / hipFree per image.

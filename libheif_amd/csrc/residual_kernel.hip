@@ -167,7 +167,7 @@ __device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, in
 
 // Four independent 4x4 blocks per wave pass: lane = 16 g + 4 y + x works on sample (y, x) of block g.  entry = z | c << 8.
 // (8.6.2 - 8.6.4 as in residual_block; both 1-D stages are two v_dot2 per output, no nonzero-extent bookkeeping)
-__device__ __forceinline__ void residual_quad(ResLds& L, const PicParams& P, const SliceParams& sl, int wave, int lane, int entry, bool valid,
+__device__ __forceinline__ void residual_quad(ResLds& L, int bd_luma, int bd_chroma, int cb_qp_offset, int cr_qp_offset, int wave, int lane, int entry, bool valid,
                                               int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr)
 {
   const int g = lane >> 4, l = lane & 15;
@@ -177,13 +177,13 @@ __device__ __forceinline__ void residual_quad(ResLds& L, const PicParams& P, con
   int16_t* coef;
   int bit_depth, qp, ts;
   if (c == 0) {
-    coef = coef_y + z * 16; bit_depth = P.bit_depth_luma; qp = qp_y + 6 * (P.bit_depth_luma - 8); ts = (fl & UF_TS_LUMA) != 0;
+    coef = coef_y + z * 16; bit_depth = bd_luma; qp = qp_y + 6 * (bd_luma - 8); ts = (fl & UF_TS_LUMA) != 0;
   } else {
     const int zc = t > 2 ? z : (z & ~3);
-    const int off_c = 6 * (P.bit_depth_chroma - 8);
-    const int qpi = clip3(-off_c, 57, qp_y + (c == 1 ? sl.cb_qp_offset : sl.cr_qp_offset));
+    const int off_c = 6 * (bd_chroma - 8);
+    const int qpi = clip3(-off_c, 57, qp_y + (c == 1 ? cb_qp_offset : cr_qp_offset));
     const int qpc = qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : chroma_qp_table(qpi));
-    coef = (c == 1 ? coef_cb : coef_cr) + zc * 4; bit_depth = P.bit_depth_chroma; qp = qpc + off_c; ts = (ipm & (c == 1 ? 64 : 128)) != 0;
+    coef = (c == 1 ? coef_cb : coef_cr) + zc * 4; bit_depth = bd_chroma; qp = qpc + off_c; ts = (ipm & (c == 1 ? 64 : 128)) != 0;
   }
   const bool act = valid && !bypass;      // cu_transquant_bypass: the coefficient levels are the residual
   const int q6 = (qp * 43) >> 8;          // qp / 6 for 0 <= qp < 128
@@ -294,23 +294,24 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
   int16_t* coef_y = (int16_t*)(A.arena + P.off_coeff[0]) + (size_t)ctb_rs * ctb * ctb;
   int16_t* coef_c[2] = {(int16_t*)(A.arena + P.off_coeff[1]) + (size_t)ctb_rs * (ctb * ctb / 4),
                         (int16_t*)(A.arena + P.off_coeff[2]) + (size_t)ctb_rs * (ctb * ctb / 4)};
+  const int bd_luma = P.bit_depth_luma, bd_chroma = P.bit_depth_chroma, cb_off = sl.cb_qp_offset, cr_off = sl.cr_qp_offset;
   // 4x4 blocks, four per wave pass
   for (int q = wave; q * 4 < count4; q += 4) {
     const int idx = q * 4 + (lane >> 4);
     const bool valid = idx < count4;
-    residual_quad(L, P, sl, wave, lane, valid ? (int)L.list4[idx] : 0, valid, coef_y, coef_c[0], coef_c[1]);
+    residual_quad(L, bd_luma, bd_chroma, cb_off, cr_off, wave, lane, valid ? (int)L.list4[idx] : 0, valid, coef_y, coef_c[0], coef_c[1]);
   }
   // larger blocks, one per wave pass
   for (int e = wave; e < count; e += 4) {
     const int z = L.list[e] & 255, c = L.list[e] >> 8;
     const int t = L.m_size[z] & 15, fl = L.m_flags[z], ipm = L.m_ipm[z], qp_y = L.m_qp[z];
     if (c == 0)
-      residual_block(L, wave, lane, coef_y + z * 16, t, P.bit_depth_luma, qp_y + 6 * (P.bit_depth_luma - 8), 0, (fl & UF_TS_LUMA) != 0, 0);
+      residual_block(L, wave, lane, coef_y + z * 16, t, bd_luma, qp_y + 6 * (bd_luma - 8), 0, (fl & UF_TS_LUMA) != 0, 0);
     else {
-      const int off_c = 6 * (P.bit_depth_chroma - 8);
-      const int qpi = clip3(-off_c, 57, qp_y + (c == 1 ? sl.cb_qp_offset : sl.cr_qp_offset));
+      const int off_c = 6 * (bd_chroma - 8);
+      const int qpi = clip3(-off_c, 57, qp_y + (c == 1 ? cb_off : cr_off));
       const int qpc = qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : chroma_qp_table(qpi));
-      residual_block(L, wave, lane, coef_c[c - 1] + z * 4, t - 1, P.bit_depth_chroma, qpc + off_c, 0, (ipm & (c == 1 ? 64 : 128)) != 0, 0);
+      residual_block(L, wave, lane, coef_c[c - 1] + z * 4, t - 1, bd_chroma, qpc + off_c, 0, (ipm & (c == 1 ? 64 : 128)) != 0, 0);
     }
   }
 }

@@ -2,6 +2,7 @@
 // C ABI (include/heif_hipdec.h).  The product path has NO CPU fallback: without a HIP device every
 // compute entry point fails with HIPDEC_ERR_DEVICE.
 #include "hipdec_internal.h"
+#include <atomic>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -14,6 +15,8 @@ static std::mutex g_init_mutex;
 static bool g_initialised = false;
 static int g_device = 0;
 static hipStream_t g_stream = nullptr;
+static int g_cu_count = 256;                 // compute units of the selected device
+static std::atomic<int> g_concurrent{1};      // batches the host keeps in flight at a time (hipdec_set_concurrent_batches)
 
 int set_error(int code, const char* fmt, ...)
 {
@@ -38,6 +41,15 @@ int ensure_init()
 }
 
 hipStream_t default_stream() { return g_stream; }
+
+// Waves of the CABAC work pool one batch may launch: the pool only works while ALL its waves are resident (7 per SIMD with
+// the kernel's register budget), so concurrent batches have to share the machine's wave slots.
+uint32_t parse_wave_budget()
+{
+  const int c = g_concurrent.load(std::memory_order_relaxed);
+  const uint32_t slots = (uint32_t)g_cu_count * 4u * 7u;
+  return slots / (uint32_t)(c < 1 ? 1 : c);
+}
 
 namespace {
 struct ArenaPool {
@@ -142,6 +154,10 @@ int hipdec_init(int device_index)
   int dev = device_index < 0 ? 0 : device_index;
   if (dev >= n) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", dev, n);
   HIPDEC_CHECK_HIP(hipSetDevice(dev));
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) g_cu_count = cus;
+  }
   if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
   HIPDEC_CHECK_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   g_device = dev;
@@ -161,6 +177,13 @@ void hipdec_shutdown(void)
   }
   if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
   g_initialised = false;
+}
+
+int hipdec_set_concurrent_batches(int n)
+{
+  if (n < 1 || n > 64) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "set_concurrent_batches: n must be in [1, 64]");
+  g_concurrent.store(n, std::memory_order_relaxed);
+  return 0;
 }
 
 const char* hipdec_last_error(void) { return t_last_error.c_str(); }

@@ -47,7 +47,7 @@ int emu_run_parse(EmuBatch* b)
   A.waves = (const ParseWave*)(a + b->L.off_waves); A.num_waves = b->L.num_waves; A.arena = a;
   A.progress = (uint32_t*)(a + b->L.off_progress); A.ctx_store = a + b->L.off_ctx;
   A.ticket = (uint32_t*)(a + b->L.off_ticket); A.status = (int32_t*)(a + b->L.off_status);
-  A.yield_ctbs = getenv("HIPDEC_POOL_YIELD") ? (uint32_t)atoi(getenv("HIPDEC_POOL_YIELD")) : 0;
+  A.yield_ctbs = getenv("HIPDEC_POOL_YIELD") ? (uint32_t)atoi(getenv("HIPDEC_POOL_YIELD")) : 1;   // the product default (decoder.hip)
   A.wake_hyst = 2;
   A.pool = b->L.pool; A.queue_cap = b->L.queue_cap; A.num_subs = b->L.num_subs;
   A.waitneed = (uint32_t*)(a + b->L.off_waitneed); A.resume_k = (uint32_t*)(a + b->L.off_resume_k);
