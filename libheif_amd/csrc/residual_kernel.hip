@@ -31,6 +31,14 @@ __device__ __forceinline__ int chroma_qp_table(int qpi)   // table 8-10 for Chro
                           (6ull << 32) | (6ull << 36) | (7ull << 40) | (7ull << 44) | (8ull << 48) | (8ull << 52);
   return 29 + (int)((kT >> ((qpi - 30) * 4)) & 15u);
 }
+// Scaling (8.6.3, flat m = 16) in 32 bits: level * 16 * levelScale < 2^27, and with q = qP / 6, b = bdShift
+//   ((p << q) + (1 << (b - 1))) >> b  ==  q < b ? (p + (1 << (b - q - 1))) >> (b - q) : p << (q - b)      (q - b <= 3)
+// `rs` / `ls` are the right / left shift of the block (one of them is 0), `rnd` = rs ? 1 << (rs - 1) : 0.
+__device__ __forceinline__ int scale_level(int level, int f, int rs, int ls, int rnd)
+{
+  const int v = ((level * f + rnd) >> rs) << ls;
+  return v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+}
 __device__ __forceinline__ int level_scale(int r)         // levelScale[qP % 6] (8.6.3)
 {
   constexpr uint64_t kS = 40ull | (45ull << 8) | (51ull << 16) | (57ull << 24) | (64ull << 32) | (72ull << 40);
@@ -82,8 +90,8 @@ __device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, in
   const int16_t* et = dst ? L.est4 : (log2n == 2 ? L.et4 : (log2n == 3 ? L.et8 : (log2n == 4 ? L.et16 : L.et32)));
   // ---- scaling (8.6.3, flat m = 16) + nonzero extent ----
   const int bd_shift = bit_depth + log2n - 5;
-  const long long scale = (long long)(16 * level_scale(qp % 6)) << (qp / 6);
-  const long long rnd = 1ll << (bd_shift - 1);
+  const int q6 = qp / 6, f = 16 * level_scale(qp - 6 * q6);
+  const int sh_r = q6 < bd_shift ? bd_shift - q6 : 0, sh_l = q6 < bd_shift ? 0 : q6 - bd_shift, rnd = sh_r ? 1 << (sh_r - 1) : 0;
   const int bd_shift2 = 20 - bit_depth;
   // nonzero extent (max_row, max_col) without cross-lane shuffles: rows grow with the lane index, so the last
   // nonzero row falls out of one ballot per pass; the last nonzero column is found bit by bit with five ballots
@@ -98,8 +106,7 @@ __device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, in
     int16_t d[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const long long v = ((long long)c[k] * scale + rnd) >> bd_shift;
-      d[k] = (int16_t)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v));
+      d[k] = (int16_t)scale_level(c[k], f, sh_r, sh_l, rnd);
       if (c[k]) { const int cc = (idx + k) & (n - 1); my_col = cc > my_col ? cc : my_col; }
     }
     if (active) {
@@ -189,11 +196,11 @@ __device__ __forceinline__ void residual_quad(ResLds& L, int bd_luma, int bd_chr
   const int q6 = (qp * 43) >> 8;          // qp / 6 for 0 <= qp < 128
   const int bd_shift = bit_depth - 3;     // bitDepth + log2(4) - 5
   const int bd_shift2 = 20 - bit_depth;
-  const long long scale = (long long)(16 * level_scale(qp - 6 * q6)) << q6;
+  const int f = 16 * level_scale(qp - 6 * q6);
+  const int sh_r = q6 < bd_shift ? bd_shift - q6 : 0, sh_l = q6 < bd_shift ? 0 : q6 - bd_shift, rnd = sh_r ? 1 << (sh_r - 1) : 0;
   int lev = 0;
   if (act) lev = coef[l];
-  const long long sv = ((long long)lev * scale + (1ll << (bd_shift - 1))) >> bd_shift;
-  const int d = (int)(sv < -32768 ? -32768 : (sv > 32767 ? 32767 : sv));
+  const int d = scale_level(lev, f, sh_r, sh_l, rnd);
   int16_t* blk = L.blk[wave] + g * 16;    // blk[x][j] = d[j][x]
   int16_t* tmp = L.tmp[wave] + g * 16;    // tmp[i][x]
   const int y = l >> 2, x = l & 3;
