@@ -233,7 +233,7 @@ def main():
                         frac=kernels[dom]["frac"], traffic=traffic,
                         launches_per_step=len(subs),
                         note="dominant kernel by device time (device times of the sub-batches are summed; they overlap in wall time); "
-                             "CABAC parsing is bound by its serial dependency chain on the scalar pipe, not by HBM (DESIGN.md §4)")
+                             "CABAC parsing is bound by instruction issue (one dependency chain per substream, ~60 wave-instructions per pixel), not by HBM (DESIGN.md §4)")
         e2e_alg = (beta + 6.0) * px_rank   # drop-in end-to-end bytes: beta + 1.5 + 1.5 + 3
         out = {
             "metric": "Mpixels/s HEIC 4:2:0 8-bit decode", "value": round(value, 2), "unit": "Mpixel/s",

@@ -39,3 +39,16 @@ def test_no_gpu_fails_loudly_not_silently():
         return
     assert lib.hipdec_init(-1) != 0
     assert b"no HIP device" in lib.hipdec_last_error()
+
+
+def test_concurrent_batches_setting_validates_its_argument():
+    """host-only setting (no GPU touched): how many large batches share the CABAC pool's wave slots"""
+    import ctypes as C
+    from libheif_amd._capi import library_path
+    lib = C.CDLL(library_path())
+    lib.hipdec_last_error.restype = C.c_char_p
+    assert lib.hipdec_set_concurrent_batches(0) != 0
+    assert b"concurrent" in lib.hipdec_last_error()
+    assert lib.hipdec_set_concurrent_batches(65) != 0
+    assert lib.hipdec_set_concurrent_batches(2) == 0
+    assert lib.hipdec_set_concurrent_batches(1) == 0
