@@ -153,6 +153,9 @@ HIPDEC_API int hipdec_copy2d_d2d(void* dst_dev, size_t dst_stride, const void* s
  * out_chroma uses heif_chroma numeric values (10 = RGB, 11 = RGBA, 12/14 = RRGGBB BE/LE). */
 HIPDEC_API int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void* out_dev, size_t out_stride,
                                    void* stream);
+/* The same for ALL items of the batch as one kernel launch (outs_dev[i] / out_strides[i] per item; every item must
+ * select the same output layout, which out_chroma guarantees). */
+HIPDEC_API int hipdec_batch_to_rgb_all(hipdec_batch* b, int out_chroma, void* const* outs_dev, const size_t* out_strides, void* stream);
 /* per-kernel device time of the last run in microseconds (HIP events on the launch stream):
  * [0] CABAC parse, [1] reconstruction, [2] deblock, [3] SAO + crop, [4] total */
 HIPDEC_API int hipdec_batch_last_timing_us(hipdec_batch* b, float out[5]);

@@ -18,6 +18,7 @@
 #include "hipdec_internal.h"
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 namespace {
 
@@ -97,7 +98,7 @@ __device__ __forceinline__ void convert_px(const ColorParams& p, int Y, int Cb, 
 struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
 
 template <typename Pix, int LAYOUT>
-__global__ __launch_bounds__(256) void k_ycbcr_to_rgb(ColorParams p)
+__device__ __forceinline__ void rgb_block(const ColorParams& p)
 {
   const int bx = blockIdx.x * blockDim.x + threadIdx.x;  // 4-pixel column group
   const int by = blockIdx.y * blockDim.y + threadIdx.y;  // row pair
@@ -193,6 +194,17 @@ __global__ __launch_bounds__(256) void k_ycbcr_to_rgb(ColorParams p)
       }
     }
   }
+}
+
+template <typename Pix, int LAYOUT>
+__global__ __launch_bounds__(256) void k_ycbcr_to_rgb(ColorParams p) { rgb_block<Pix, LAYOUT>(p); }
+
+// all pictures of a batch in ONE launch: blockIdx.z selects the picture's parameter block (grid x / y cover the largest one)
+template <typename Pix, int LAYOUT>
+__global__ __launch_bounds__(256) void k_ycbcr_to_rgb_batch(const ColorParams* __restrict__ ps)
+{
+  const ColorParams p = ps[blockIdx.z];   // wave-uniform: scalar loads into SGPRs
+  rgb_block<Pix, LAYOUT>(p);
 }
 
 // a13: one thread per 4 output samples of one row
@@ -323,9 +335,16 @@ void coefficients(const hipdec_nclx* n, float out[4])
   }
 }
 
+// Capture mode (hipdec_batch_to_rgb_all): the per-picture entry points run their argument checks and the planner rules
+// as usual, but instead of launching they record the parameter block; the recorded blocks then go out as one launch.
+struct Captured { ColorParams p; int variant; };
+thread_local std::vector<Captured> t_captured;
+thread_local bool t_capture = false;
+
 template <typename Pix, int LAYOUT>
 int launch_rgb(const ColorParams& p, hipStream_t s)
 {
+  if (t_capture) { t_captured.push_back(Captured{p, (int)sizeof(Pix) * 16 + LAYOUT}); return 0; }
   dim3 block(64, 4);
   dim3 grid(((p.w + 3) / 4 + 63) / 64, ((p.h + 1) / 2 + 3) / 4);
   hipLaunchKernelGGL((k_ycbcr_to_rgb<Pix, LAYOUT>), grid, block, 0, s, p);
@@ -364,7 +383,89 @@ int generic_arith(const hipdec_nclx* nclx)
   return AR_FLOAT;
 }
 
+template <typename Pix, int LAYOUT>
+void launch_rgb_batch(const ColorParams* dev, int n, int max_w, int max_h, hipStream_t s)
+{
+  dim3 block(64, 4);
+  dim3 grid(((max_w + 3) / 4 + 63) / 64, ((max_h + 1) / 2 + 3) / 4, n);
+  hipLaunchKernelGGL((k_ycbcr_to_rgb_batch<Pix, LAYOUT>), grid, block, 0, s, dev);
+}
+
 }  // namespace
+
+// variant = sizeof(Pix) * 16 + LAYOUT, as recorded by launch_rgb
+#define HIPDEC_RGB_VARIANTS(X)                                                                                     \
+  X(16 + LO_PLANAR, uint8_t, LO_PLANAR) X(32 + LO_PLANAR, uint16_t, LO_PLANAR) X(16 + LO_RGB24, uint8_t, LO_RGB24) \
+  X(16 + LO_RGBA32, uint8_t, LO_RGBA32) X(32 + LO_RRGGBB_BE, uint16_t, LO_RRGGBB_BE) X(32 + LO_RRGGBB_LE, uint16_t, LO_RRGGBB_LE)
+
+namespace hipdec {
+
+void color_capture_begin()
+{
+  t_captured.clear();
+  t_capture = true;
+}
+
+void color_capture_abort()
+{
+  t_captured.clear();
+  t_capture = false;
+}
+
+int color_capture_launch(ColorBatchState& st, hipStream_t s)
+{
+  t_capture = false;
+  std::vector<Captured> caps;
+  caps.swap(t_captured);
+  if (caps.empty()) return 0;
+  bool same = true;
+  int max_w = 0, max_h = 0;
+  for (const auto& c : caps) { same = same && c.variant == caps[0].variant; max_w = c.p.w > max_w ? c.p.w : max_w; max_h = c.p.h > max_h ? c.p.h : max_h; }
+  if (!same || caps.size() == 1) {   // mixed kernel variants cannot share a launch
+    for (const auto& c : caps) {
+      int rc = HIPDEC_ERR_UNSUPPORTED;
+      switch (c.variant) {
+#define X(id, Pix, LO) case id: rc = launch_rgb<Pix, LO>(c.p, s); break;
+        HIPDEC_RGB_VARIANTS(X)
+#undef X
+        default: break;
+      }
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  const size_t bytes = caps.size() * sizeof(ColorParams);
+  std::vector<uint8_t> host(bytes);
+  for (size_t i = 0; i < caps.size(); i++) memcpy(host.data() + i * sizeof(ColorParams), &caps[i].p, sizeof(ColorParams));
+  if (st.dev_bytes < bytes) {
+    if (st.dev) (void)hipFree(st.dev);
+    st.dev = nullptr; st.dev_bytes = 0; st.host.clear();
+    HIPDEC_CHECK_HIP(hipMalloc(&st.dev, bytes));
+    st.dev_bytes = bytes;
+  }
+  if (st.host != host) {   // steady state (same planes, same outputs): nothing to upload
+    st.host.swap(host);
+    HIPDEC_CHECK_HIP(hipMemcpyAsync(st.dev, st.host.data(), bytes, hipMemcpyHostToDevice, s));
+  }
+  const ColorParams* dev = (const ColorParams*)st.dev;
+  switch (caps[0].variant) {
+#define X(id, Pix, LO) case id: launch_rgb_batch<Pix, LO>(dev, (int)caps.size(), max_w, max_h, s); break;
+    HIPDEC_RGB_VARIANTS(X)
+#undef X
+    default: return set_error(HIPDEC_ERR_UNSUPPORTED, "colour batch: unknown kernel variant");
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(HIPDEC_ERR_DEVICE, "colour batch launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+void color_batch_state_free(ColorBatchState& st)
+{
+  if (st.dev) (void)hipFree(st.dev);
+  st.dev = nullptr; st.dev_bytes = 0; st.host.clear();
+}
+
+}  // namespace hipdec
 
 using namespace hipdec;
 

@@ -31,8 +31,10 @@ struct hipdec_batch : BatchLayout {
   uint64_t runs = 0;
   hipStream_t last_stream = nullptr;
   bool ran = false;
+  ColorBatchState color;        // parameter blocks of hipdec_batch_to_rgb_all
   ~hipdec_batch()
   {
+    color_batch_state_free(color);
     if (arena) {
       if (last_stream) (void)hipStreamSynchronize(last_stream);   // nothing of this batch may still be running when the arena is recycled
       arena_release(arena, arena_capacity);
@@ -256,6 +258,17 @@ int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void* out_dev, s
                                       &nclx, out_dev, out_stride, out_chroma == 14, s);
   }
   return set_error(HIPDEC_ERR_UNSUPPORTED, "to_rgb: unsupported output chroma %d", out_chroma);
+}
+
+int hipdec_batch_to_rgb_all(hipdec_batch* b, int out_chroma, void* const* outs_dev, const size_t* out_strides, void* stream)
+{
+  if (!b || !outs_dev || !out_strides) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "to_rgb_all: bad arguments");
+  hipStream_t s = stream ? (hipStream_t)stream : (b->last_stream ? b->last_stream : default_stream());
+  // every item goes through the per-item entry point (argument checks, planner rule, coefficients) in capture mode
+  color_capture_begin();
+  for (int i = 0; i < (int)b->pics.size(); i++)
+    if (int rc = hipdec_batch_to_rgb(b, i, out_chroma, outs_dev[i], out_strides[i], (void*)s)) { color_capture_abort(); return rc; }
+  return color_capture_launch(b->color, s);
 }
 
 int hipdec_batch_timing_slots(hipdec_batch* b, int slots)

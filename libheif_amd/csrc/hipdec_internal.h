@@ -1,6 +1,7 @@
 // hipdec_internal.h — internal glue shared by the host side of libheifhip.so
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <cstdarg>
 #include <cstdio>
 #include <string>
@@ -23,6 +24,18 @@ void arena_pool_clear();
 // libheif/image-items/grid.cc:436) each run on their own stream so that their kernels overlap on the GPU.
 hipStream_t stream_acquire();
 void stream_release(hipStream_t s);
+
+// Colour stage of a whole batch as ONE launch (color.hip): between begin and launch this thread's hipdec_color_* calls record
+// their parameter blocks instead of launching; the blocks live in a device array owned by the batch.
+struct ColorBatchState {
+  void* dev = nullptr;
+  size_t dev_bytes = 0;
+  std::vector<uint8_t> host;   // the blocks last uploaded
+};
+void color_capture_begin();
+void color_capture_abort();
+int color_capture_launch(ColorBatchState& st, hipStream_t s);
+void color_batch_state_free(ColorBatchState& st);
 
 #define HIPDEC_CHECK_HIP(expr)                                                                  \
   do {                                                                                          \

@@ -32,6 +32,7 @@ def _bind(lib):
     lib.hipdec_batch_read_plane.argtypes = [vp, ci, ci, vp, sz]
     lib.hipdec_batch_device_plane.argtypes = [vp, ci, ci, C.POINTER(vp), C.POINTER(sz)]
     lib.hipdec_batch_to_rgb.argtypes = [vp, ci, ci, vp, sz, vp]
+    lib.hipdec_batch_to_rgb_all.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(sz), vp]
     lib.hipdec_batch_last_timing_us.argtypes = [vp, C.POINTER(C.c_float)]
     lib.hipdec_batch_item_packed_bytes.restype = sz
     lib.hipdec_batch_item_packed_bytes.argtypes = [vp, ci]
@@ -175,11 +176,12 @@ class Batch:
             d = self.info(i)
             self._rgb.append((DeviceBuffer(d["width"] * d["height"] * bpp), d["width"] * bpp, d["height"]))
         self._rgb_chroma = out_chroma
+        self._rgb_ptrs = (C.c_void_p * self.n)(*[buf.ptr for buf, _, _ in self._rgb])
+        self._rgb_strides = (C.c_size_t * self.n)(*[stride for _, stride, _ in self._rgb])
 
     def to_rgb_all(self, stream=None):
-        """asynchronous: fused colour stage over every item's planes into the pre-allocated buffers"""
-        for i, (buf, stride, _) in enumerate(self._rgb):
-            check(self._lib.hipdec_batch_to_rgb(self._h, i, self._rgb_chroma, buf.ptr, stride, stream))
+        """asynchronous: fused colour stage over every item's planes into the pre-allocated buffers, ONE launch"""
+        check(self._lib.hipdec_batch_to_rgb_all(self._h, self._rgb_chroma, self._rgb_ptrs, self._rgb_strides, stream))
 
     def rgb(self, i):
         buf, stride, h = self._rgb[i]

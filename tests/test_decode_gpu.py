@@ -316,3 +316,28 @@ def test_concurrent_decoders_share_launch_sets():
         assert r1 - r0 == len(items)
     # the barrier releases all threads together: at least some rounds must have shared a launch set
     assert coalesce_stats()[2] > 0
+
+
+def test_batch_colour_stage_in_one_launch():
+    """hipdec_batch_to_rgb_all (every item's colour conversion in ONE kernel launch) against the per-item entry point:
+    mixed picture sizes, and mixed planner decisions (integer op for full range, float op for limited range)."""
+    from libheif_amd.decoder import Batch
+    specs = [((128, 64), dict(vui_matrix=6, vui_primaries=1, vui_transfer=13, vui_full_range=1)),
+             ((200, 136), dict(vui_matrix=1, vui_primaries=1, vui_transfer=1, vui_full_range=0)),
+             ((70, 42), dict(vui_matrix=6, vui_primaries=1, vui_transfer=13, vui_full_range=1)),
+             ((64, 128), dict())]
+    streams = [orc.encode(orc.synth_image(w, h, 8, 1, seed=60 + i), **cfg) for i, ((w, h), cfg) in enumerate(specs)]
+    b = Batch(streams)
+    b.run(); b.status()
+    single = [b.to_rgb(i, 10) for i in range(len(streams))]
+    b.alloc_rgb(10)
+    for _ in range(2):                 # the second call reuses the uploaded parameter blocks
+        b.to_rgb_all()
+        for i in range(len(streams)):
+            np.testing.assert_array_equal(b.rgb(i), single[i], err_msg="item %d" % i)
+    b.alloc_rgb(11)                    # other layout (RGBA): new outputs -> new parameter blocks
+    b.to_rgb_all()
+    for i in range(len(streams)):
+        rgba = b.rgb(i).reshape(single[i].shape[0], -1, 4)
+        np.testing.assert_array_equal(rgba[:, :, :3].reshape(single[i].shape), single[i])
+        assert (rgba[:, :, 3] == 255).all()
