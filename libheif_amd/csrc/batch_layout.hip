@@ -84,7 +84,7 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
       uint32_t lag = 2;
       if (w < rows) { lag = row_len / (w + 1); if (lag < 2) lag = 2; }
       for (uint32_t j = 0; j < w; j++)
-        for (uint32_t c = 0; c < 3; c++) rwaves.push_back(ReconWave{(uint32_t)i, c, j, w, row_base, lag, 0, 0});
+        for (uint32_t c = 0; c < 2; c++) rwaves.push_back(ReconWave{(uint32_t)i, c, j, w, row_base, lag, 0, 0});   // 0 = luma, 1 = Cb + Cr in one wave
       row_base += rows;
     }
   }

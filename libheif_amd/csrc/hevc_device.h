@@ -110,7 +110,8 @@ struct Substream {
   uint32_t pad2;
 };
 
-struct ReconWave {  // one reconstruction wavefront: CTB rows first_row, first_row + stride, ... of one colour component of one picture
+struct ReconWave {  // one reconstruction wavefront: CTB rows first_row, first_row + stride, ... of the luma plane (comp 0) or of the
+                    // two chroma planes together (comp 1) of one picture
   uint32_t pic, comp, first_row, stride;
   uint32_t base_row;    // batch row index of the picture's CTB row 0 (progress words are per batch row and component)
   uint32_t start_lag;   // CTBs the row above must be ahead before a row is started (>= 2)

@@ -304,56 +304,205 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
   lds_sync();
 }
 
+// Cb and Cr blocks of one position TOGETHER: lanes 0..31 work on Cb, lanes 32..63 on Cr.  Geometry, availability, substitution
+// pattern and prediction mode are the same for both (4:2:0 chroma has neither reference smoothing nor boundary filters), only
+// the samples, the residuals and the coded-block flags differ — so one instruction stream reconstructs both blocks.
+//   LDS: the Cr tile sits behind the Cb tile (ctbc x ctbc each), left borders at left[0..31] / left[32..63], reference lines
+//   at refbuf0[1 + 67 h ...];  `top`, `cbf` and `res` are this lane's half's.
+template <typename Pix>
+__device__ __forceinline__ void reconstruct_chroma_pair(ReconLds<Pix>& L, const Ctx& C, const Pix* top, int xb, int yb, int log2n, int mode, int cbf,
+                                                        const int16_t* res)
+{
+  const int lane = C.lane, l = lane & 31, h = lane >> 5;
+  const int n = 1 << log2n, n2 = 2 * n, N = 4 * n + 1, nn = n * n;
+  const int lg_ctbc = C.lg_ctbc, maxv = C.maxv;
+  Pix* tile = L.tile + (h << (2 * lg_ctbc));
+  const Pix* left = L.left + h * 32;
+  uint16_t* ref0 = L.refbuf0 + 1 + h * 67;
+  const int iters = nn > 32 ? nn >> 5 : 1;   // 32 samples per pass and half: 1 / 2 / 8 passes for 4x4 / 8x8 / 16x16
+
+  int rp0 = 0, rp1 = 0, rp2 = 0, rp3 = 0;
+  if (cbf) {
+    if (l < nn) rp0 = res[l];
+    if (nn > 32) rp1 = res[l + 32];
+    if (nn > 64) { rp2 = res[l + 64]; rp3 = res[l + 96]; }
+  }
+#define NEXT_RES(it) do { rp0 = rp1; rp1 = rp2; rp2 = rp3; rp3 = (cbf && (it) + 4 < iters) ? (int)res[l + 32 * ((it) + 4)] : 0; } while (0)
+
+  // ---- reference samples: e = l + 32 j for J = 1 (2 for 16x16) passes; blocks from 8x8 up have the extra sample e = 4n ----
+  const int J = n == 16 ? 2 : 1;
+  uint64_t m0 = 0;        // availability over e < 64 (identical in both halves: taken from the Cb lanes)
+  int av[2] = {0, 0};
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    if (j >= J) continue;
+    const int e = l + 32 * j;
+    const int is_left = e < n2;
+    const int px = is_left ? -1 : e - n2 - 1, py = is_left ? n2 - 1 - e : -1;
+    const int X = xb + px, Y = yb + py;
+    int a = 0;
+    if (e < N) a = (int)((L.avrow[(Y >> 1) + 1] >> ((X >> 1) + 1)) & 1u);
+    if (a) {
+      const Pix* src = Y < 0 ? &top[X + 1] : (X < 0 ? &left[Y] : &tile[(Y << lg_ctbc) + X]);
+      ref0[e] = (uint16_t)*src;
+    }
+    av[j] = a;
+    m0 |= (__ballot(a) & 0xffffffffull) << (32 * j);
+  }
+  int ax = 1;
+  const int has_x = n >= 8;
+  if (has_x) {
+    const int X = xb + n2 - 1, Y = yb - 1;
+    ax = (int)((L.avrow[(Y >> 1) + 1] >> ((X >> 1) + 1)) & 1u);
+    if (ax && l == 0) ref0[N - 1] = (uint16_t)(Y < 0 ? top[X + 1] : tile[(Y << lg_ctbc) + X]);
+  }
+  lds_sync();
+  const int n_av = __popcll(m0) + (has_x ? ax : 0);
+  if (n_av != N) {
+    if (n_av == 0) {
+      const uint16_t half = (uint16_t)(1 << (C.bit_depth - 1));
+      for (int e = l; e < N; e += 32) ref0[e] = half;
+    } else {
+      const int hi0 = m0 ? 63 - __clzll((long long)m0) : -1;
+      const int first = m0 ? __ffsll((long long)m0) - 1 : N - 1;
+      int val[2] = {0, 0};
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        if (j >= J) continue;
+        const int e = l + 32 * j;
+        if (e < N && !av[j]) {
+          const uint64_t mm = m0 & ((1ull << e) - 1ull);
+          val[j] = ref0[mm ? 63 - __clzll((long long)mm) : first];
+        }
+      }
+      int valx = 0;
+      if (has_x && !ax) valx = ref0[hi0];
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        if (j >= J) continue;
+        const int e = l + 32 * j;
+        if (e < N && !av[j]) ref0[e] = (uint16_t)val[j];
+      }
+      if (has_x && !ax && l == 0) ref0[N - 1] = (uint16_t)valx;
+    }
+    lds_sync();
+  }
+  const uint16_t* ref = ref0;
+#define RL(k) ((int)ref[n2 - (k)])
+#define RT(k) ((int)ref[n2 + (k)])
+  Pix* dst0 = &tile[(yb << lg_ctbc) + xb];
+  if (mode == 0) {
+    const int tr = RT(n + 1), bl = RL(n + 1);
+    for (int it = 0; it < iters; it++) {
+      const int idx = l + 32 * it, x = idx & (n - 1), y = idx >> log2n;
+      if (idx < nn) {
+        int v = (mul24(n - 1 - x, RL(y + 1)) + mul24(x + 1, tr) + mul24(n - 1 - y, RT(x + 1)) + mul24(y + 1, bl) + n) >> (log2n + 1);
+        if (cbf) v = clip3(0, maxv, v + rp0);
+        dst0[(y << lg_ctbc) + x] = (Pix)v;
+      }
+      NEXT_RES(it);
+    }
+  } else if (mode == 1) {
+    int part = l < n ? RT(l + 1) + RL(l + 1) : 0;
+    for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o);      // every lane of a half ends up with its half's sum
+    const int dc_val = (part + n) >> (log2n + 1);
+    for (int it = 0; it < iters; it++) {
+      const int idx = l + 32 * it, x = idx & (n - 1), y = idx >> log2n;
+      if (idx < nn) {
+        int v = dc_val;
+        if (cbf) v = clip3(0, maxv, v + rp0);
+        dst0[(y << lg_ctbc) + x] = (Pix)v;
+      }
+      NEXT_RES(it);
+    }
+  } else {
+    const int vertical = mode >= 18;
+    const int s = vertical ? 1 : -1;
+    const int dm = mode - (vertical ? 26 : 10), k_dir = dm < 0 ? -dm : dm;
+    const int angle = ((dm < 0) == vertical) ? -angle_magnitude(k_dir) : angle_magnitude(k_dir);
+    const int inv_angle = angle < 0 ? -inv_angle_magnitude(k_dir) : 0;
+    for (int it = 0; it < iters; it++) {
+      const int idx = l + 32 * it, x = idx & (n - 1), y = idx >> log2n;
+      if (idx < nn) {
+        const int a = vertical ? x : y, b = vertical ? y : x;
+        const int t = mul24(b + 1, angle), i_idx = t >> 5, i_fact = t & 31;
+        const int k0 = a + i_idx + 1, k1 = k0 + 1;
+        const int p0 = -((mul24(k0, inv_angle) + 128) >> 8), p1 = -((mul24(k1, inv_angle) + 128) >> 8);
+        const int r0 = ref[n2 + mul24(s, k0 >= 0 ? k0 : p0)];
+        const int r1 = ref[n2 + mul24(s, k1 >= 0 ? k1 : p1)];
+        int v = (mul24(32 - i_fact, r0) + mul24(i_fact, r1) + 16) >> 5;
+        if (cbf) v = clip3(0, maxv, v + rp0);
+        dst0[(y << lg_ctbc) + x] = (Pix)v;
+      }
+      NEXT_RES(it);
+    }
+  }
+#undef RL
+#undef RT
+#undef NEXT_RES
+  {
+    const int k = n >> 1;    // units per side
+    if (lane < k) L.avrow[(yb >> 1) + 1 + lane] |= ((1ull << k) - 1ull) << ((xb >> 1) + 1);
+  }
+  lds_sync();
+}
+
 }  // namespace
 
-template <typename Pix>
-__device__ __forceinline__ void recon_wave(const ReconArgs& A)
+// The CTB rows of one wave.  DUAL = false: the luma plane, 64 lanes per block.  DUAL = true: Cb (lanes 0..31) and Cr (lanes
+// 32..63) side by side — h / l below are a lane's half and its index inside the half, LW the lanes one component has.
+template <typename Pix, bool DUAL>
+__device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& wd, ReconLds<Pix>& L, int lane)
 {
-  __shared__ ReconLds<Pix> L;
-  const int lane = threadIdx.x;
-  uint32_t t = 0;
-  if (lane == 0) t = atomicAdd(A.ticket, 1u);
-  const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-  if (ticket >= A.num_waves) return;
-  if (__hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // failed parse: maps are garbage
-  const ReconWave wd = A.waves[ticket];
-  const int c_idx = (int)wd.comp;
+  constexpr int ES = (int)sizeof(Pix);
+  constexpr int LW = DUAL ? 32 : 64;
+  constexpr int PPW = 4 / ES;            // pixels per 32-bit word
+  const int h = DUAL ? lane >> 5 : 0, l = DUAL ? lane & 31 : lane;
+  const int comp = DUAL ? 1 + h : 0;     // colour component this lane works on
+  const int c_idx = DUAL ? 1 : 0;        // progress words / wave table: 0 = luma, 1 = the chroma pair
   const PicParams& P = A.pics[wd.pic];
-  if (c_idx > 0 && !P.chroma_format_idc) return;
-  const int sub = c_idx ? 2 : 1;
+  const int sub = DUAL ? 2 : 1;
   const int ctb = 1 << P.log2_ctb, ctbc = ctb / sub;
   const int units = 1 << P.units_per_ctb_log2;
   const CtbInfo* ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
-  Pix* rec = (Pix*)(A.arena + P.off_rec[c_idx]);
-  const uint32_t stride = P.rec_stride[c_idx] / sizeof(Pix);
+  Pix* rec = (Pix*)(A.arena + P.off_rec[comp]);
+  const uint32_t stride = P.rec_stride[c_idx] / sizeof(Pix);           // Cb and Cr planes share their geometry
   // line buffer: bottom sample row of every CTB row of this component, row stride = rec_stride
-  uint32_t* line = (uint32_t*)(A.arena + P.off_line[c_idx]);
+  uint32_t* line = (uint32_t*)(A.arena + P.off_line[comp]);
   const uint32_t line_words = P.rec_stride[c_idx] / 4;
-  constexpr int ES = (int)sizeof(Pix);
+  const int16_t* coeff = (const int16_t*)(A.arena + P.off_coeff[comp]);
+  const size_t off_mode = DUAL ? P.off_u_ipmc : P.off_u_ipm, off_size = P.off_u_size, off_flags = P.off_u_flags;
   int err = 0;
   uint32_t my_row = 0;
   Ctx C;
-  C.lane = lane; C.ctbc = ctbc; C.lg_ctbc = P.log2_ctb - (c_idx ? 1 : 0); C.ush = c_idx ? 1 : 2;
-  C.bit_depth = c_idx ? P.bit_depth_chroma : P.bit_depth_luma; C.maxv = (1 << C.bit_depth) - 1;
-  C.luma = c_idx == 0; C.strong = P.strong_intra_smoothing;
-  const int Wc = c_idx ? P.cwidth : P.width, Hc = c_idx ? P.cheight : P.height;   // component plane size in samples
-  const int pic_w = P.width, pic_h = P.height;
-  const int side = 1 << (P.log2_ctb - 2);                                          // 4x4-luma units per CTB side
+  C.lane = lane; C.ctbc = ctbc; C.lg_ctbc = P.log2_ctb - (DUAL ? 1 : 0); C.ush = DUAL ? 1 : 2;
+  C.bit_depth = DUAL ? P.bit_depth_chroma : P.bit_depth_luma; C.maxv = (1 << C.bit_depth) - 1;
+  C.luma = !DUAL; C.strong = P.strong_intra_smoothing;
+  const int Wc = DUAL ? P.cwidth : P.width, Hc = DUAL ? P.cheight : P.height;   // component plane size in samples
+  const int pic_w = P.width, pic_h = P.height, ctb_w = P.ctb_w, ctb_h = P.ctb_h, log2_ctb = P.log2_ctb;
+  const int side = 1 << (log2_ctb - 2);                                         // 4x4-luma units per CTB side
+  const int cbf_bit = DUAL ? (h ? UF_CBF_CR : UF_CBF_CB) : UF_CBF_LUMA;
+  // this lane's slices of the shared LDS arrays
+  Pix* tile = L.tile + (DUAL ? h << (2 * C.lg_ctbc) : 0);
+  Pix* left = L.left + (DUAL ? h * 32 : 0);
+  uint32_t* top_raw = L.top_raw + (DUAL ? h * 36 : 0);
+  const int lg_wpr = C.lg_ctbc - (ES == 1 ? 2 : 1);      // log2 of the words per tile row
+  const int wpr = 1 << lg_wpr;
 
-  for (int cy = (int)wd.first_row; cy < P.ctb_h && !err; cy += (int)wd.stride) {
+  for (int cy = (int)wd.first_row; cy < ctb_h && !err; cy += (int)wd.stride) {
   my_row = wd.base_row + (uint32_t)cy;     // batch row index
   uint32_t* my_progress = A.row_progress + (size_t)my_row * 3 + c_idx;
   const uint32_t* up_progress = my_progress - 3;
-  for (int cx = 0; cx < P.ctb_w && !err; cx++) {
-    const int ctb_rs = cy * P.ctb_w + cx;
+  for (int cx = 0; cx < ctb_w && !err; cx++) {
+    const int ctb_rs = cy * ctb_w + cx;
     const CtbInfo ci = ctb_info[ctb_rs];
-    const int x_ctb = cx << P.log2_ctb, y_ctb = cy << P.log2_ctb;   // luma origin of the CTB
+    const int x_ctb = cx << log2_ctb, y_ctb = cy << log2_ctb;   // luma origin of the CTB
     const int xc0 = x_ctb / sub;  // component x of the CTB
     // ---- wait for the row above: above-right CTB done (or the row end) ----
-    const Pix* top = (const Pix*)(L.top_raw + 1);
+    const Pix* top = (const Pix*)(top_raw + 1);
     if (cy > 0) {
       uint32_t need = cx == 0 ? wd.start_lag : (uint32_t)(cx + 2);   // 2 = above-right CTB; a larger start distance decouples the rows
-      if (need > (uint32_t)P.ctb_w) need = (uint32_t)P.ctb_w;
+      if (need > (uint32_t)ctb_w) need = (uint32_t)ctb_w;
       uint32_t spins = 0;
       while (__hip_atomic_load(up_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
         __builtin_amdgcn_s_sleep(32);
@@ -367,20 +516,20 @@ __device__ __forceinline__ void recon_wave(const ReconArgs& A)
       if (endb > (int)(line_words * 4)) endb = (int)(line_words * 4);
       const int nwords = (endb - start + 3) >> 2;
       const uint32_t* src = line + (size_t)(cy - 1) * line_words + (start >> 2);
-      for (int i = lane; i < nwords; i += 64) L.top_raw[1 + i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      top = (const Pix*)((const uint8_t*)(L.top_raw + 1) + (b0 - start));   // top[0] = above-left sample
+      for (int i = l; i < nwords; i += LW) top_raw[1 + i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      top = (const Pix*)((const uint8_t*)(top_raw + 1) + (b0 - start));   // top[0] = above-left sample
     }
     // ---- stage the CTB's maps, one packed word per unit ----
     {
       const size_t base = (size_t)ctb_rs * units;
       for (int i = lane * 4; i < units; i += 256) {
-        const uint32_t sz = *(const uint32_t*)(A.arena + P.off_u_size + base + i);
-        const uint32_t fl = *(const uint32_t*)(A.arena + P.off_u_flags + base + i);
-        const uint32_t md = *(const uint32_t*)(A.arena + (c_idx ? P.off_u_ipmc : P.off_u_ipm) + base + i);
+        const uint32_t sz = *(const uint32_t*)(A.arena + off_size + base + i);
+        const uint32_t fl = *(const uint32_t*)(A.arena + off_flags + base + i);
+        const uint32_t md = *(const uint32_t*)(A.arena + off_mode + base + i);
         const uint32_t ux = compact1by1((uint32_t)i), uy = compact1by1((uint32_t)i >> 1);   // i is a multiple of 4: units i..i+3 are a 2x2 quad
 #pragma nounroll
         for (int k = 0; k < 4; k++)
-          L.m_unit[i + k] = ((sz >> (8 * k)) & 255u) | (((fl >> (8 * k)) & 255u) << 8) | (((md >> (8 * k)) & (c_idx ? 255u : 63u)) << 16) |
+          L.m_unit[i + k] = ((sz >> (8 * k)) & 255u) | (((fl >> (8 * k)) & 255u) << 8) | (((md >> (8 * k)) & (DUAL ? 255u : 63u)) << 16) |
                             ((ux + (k & 1)) << 24) | ((uy + (k >> 1)) << 28);
       }
       // availability rows: the borders come from the neighbouring CTBs (slice / tile / picture limits are in ci.avail,
@@ -401,8 +550,8 @@ __device__ __forceinline__ void recon_wave(const ReconArgs& A)
     }
     lds_sync();
 
-    // ---- this component's blocks of the CTB in z-scan order ----
-    const int16_t* res_base = (const int16_t*)(A.arena + P.off_coeff[c_idx]) + (size_t)ctb_rs * (ctb * ctb / (sub * sub));
+    // ---- the blocks of the CTB in z-scan order ----
+    const int16_t* res_base = coeff + (size_t)ctb_rs * (ctb * ctb / (sub * sub));
     int z = 0;
     while (z < units) {
       const uint32_t w = L.m_unit[z];
@@ -410,13 +559,13 @@ __device__ __forceinline__ void recon_wave(const ReconArgs& A)
       if (x_ctb + ux * 4 >= pic_w || y_ctb + uy * 4 >= pic_h) { z++; continue; }
       const int tb = (int)(w & 15u), fl = (int)((w >> 8) & 255u), mode = (int)((w >> 16) & 255u);
       if (tb < 2 || tb > 5) { err = DEV_ERR_SYNTAX; break; }
-      if (c_idx == 0) {
-        reconstruct_block<Pix>(L, C, top, ux * 4, uy * 4, tb, mode, fl & UF_CBF_LUMA, res_base + z * 16);
+      if (!DUAL) {
+        reconstruct_block<Pix>(L, C, top, ux * 4, uy * 4, tb, mode, fl & cbf_bit, res_base + z * 16);
       } else if (tb > 2 || (z & 3) == 3) {
-        // the 4x4 chroma block of four 4x4 luma TUs hangs off the 4th unit (its flags are there); it sits at the quad's origin
+        // the 4x4 chroma blocks of four 4x4 luma TUs hang off the 4th unit (their flags are there); they sit at the quad's origin
         const int quad = tb == 2;
         const int zc = quad ? (z & ~3) : z, cux = quad ? (ux & ~1) : ux, cuy = quad ? (uy & ~1) : uy;
-        reconstruct_block<Pix>(L, C, top, cux * 2, cuy * 2, quad ? 2 : tb - 1, mode, fl & (c_idx == 1 ? UF_CBF_CB : UF_CBF_CR), res_base + zc * 4);
+        reconstruct_chroma_pair<Pix>(L, C, top, cux * 2, cuy * 2, quad ? 2 : tb - 1, mode, fl & cbf_bit, res_base + zc * 4);
       }
       z += 1 << (2 * (tb - 2));
     }
@@ -425,22 +574,19 @@ __device__ __forceinline__ void recon_wave(const ReconArgs& A)
     // ---- write the CTB out (planes are allocated CTB-aligned, so no edge guards), hand its bottom row to the
     //      row below and keep its right column as the next CTB's left border ----
     {
-      constexpr int PPW = 4 / ES;            // pixels per 32-bit word
-      const int wpr = ctbc / PPW;            // words per tile row
       const int yc0 = y_ctb / sub;
-      // 64 lanes cover 64 / wpr whole tile rows per pass (wpr <= 32 is a power of two): the plane offset advances by a
+      // LW lanes cover LW / wpr whole tile rows per pass (wpr <= 32 is a power of two): the plane offset advances by a
       // wave-uniform step, no per-pass multiplies or divisions
-      const int lg_wpr = C.lg_ctbc - (ES == 1 ? 2 : 1);
-      const int y0 = lane >> lg_wpr, xw = lane & (wpr - 1);
+      const int y0 = l >> lg_wpr, xw = l & (wpr - 1);
       uint32_t off = (uint32_t)(yc0 + y0) * stride + (uint32_t)(xc0 + xw * PPW);
-      const uint32_t step = (64u >> lg_wpr) * stride;
-      for (int i = lane; i < wpr * ctbc; i += 64, off += step)
-        *(uint32_t*)&rec[off] = *(const uint32_t*)&L.tile[i * PPW];     // tile rows are wpr words: word i of the tile
+      const uint32_t step = ((uint32_t)LW >> lg_wpr) * stride;
+      for (int i = l; i < wpr * ctbc; i += LW, off += step)
+        *(uint32_t*)&rec[off] = *(const uint32_t*)&tile[i * PPW];     // tile rows are wpr words: word i of the tile
       uint32_t* dst = line + (size_t)cy * line_words + (size_t)xc0 * ES / 4;
-      for (int i = lane; i < wpr; i += 64)
-        __hip_atomic_store(dst + i, *(const uint32_t*)&L.tile[(ctbc - 1) * ctbc + i * PPW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = l; i < wpr; i += LW)
+        __hip_atomic_store(dst + i, *(const uint32_t*)&tile[(ctbc - 1) * ctbc + i * PPW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       lds_sync();
-      for (int i = lane; i < ctbc; i += 64) L.left[i] = L.tile[i * ctbc + ctbc - 1];
+      for (int i = l; i < ctbc; i += LW) left[i] = tile[i * ctbc + ctbc - 1];
     }
     lds_sync();
     drain_stores();   // the line-buffer stores have left this wave
@@ -448,6 +594,21 @@ __device__ __forceinline__ void recon_wave(const ReconArgs& A)
   }
   }
   if (err && lane == 0) atomicCAS((int*)A.status, 0, err | (int)(0x40000000u) | (int)(my_row << 8));
+}
+
+template <typename Pix>
+__device__ __forceinline__ void recon_wave(const ReconArgs& A)
+{
+  __shared__ ReconLds<Pix> L;
+  const int lane = threadIdx.x;
+  uint32_t t = 0;
+  if (lane == 0) t = atomicAdd(A.ticket, 1u);
+  const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+  if (ticket >= A.num_waves) return;
+  if (__hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // failed parse: maps are garbage
+  const ReconWave wd = A.waves[ticket];
+  if (wd.comp == 0) recon_rows<Pix, false>(A, wd, L, lane);
+  else if (A.pics[wd.pic].chroma_format_idc) recon_rows<Pix, true>(A, wd, L, lane);   // comp 1 = Cb and Cr together
 }
 
 // 8-bit pictures: 7 waves per SIMD (<= 72 VGPRs; 6 KB of LDS per wave allows 26 per CU).  The 16-bit variant is limited by
