@@ -7,13 +7,19 @@
 //
 // MI355X mapping
 //   * intra prediction makes every block depend on its left / above / above-right neighbours, so the
-//     parallelism is the 2-CTB-lag wavefront over CTB rows, times the colour components (Y, Cb, Cr predict
-//     independently): one 64-lane wavefront per (CTB row, component) of every picture of the batch, all
-//     running concurrently; tickets are handed out row by row so a wave's predecessor (the row above, same
-//     component) always holds an earlier ticket, i.e. is resident or finished.
-//   * the CTB being reconstructed lives in LDS (tile + top / left borders + reference-sample line), so
-//     gathering, substitution, smoothing and prediction never touch HBM; the finished CTB leaves LDS once
-//     with row-contiguous stores.
+//     parallelism is the 2-CTB-lag wavefront over CTB rows, times luma / chroma (they predict independently):
+//     one 64-lane wavefront per CTB-row chain of the luma plane and one per chain of the chroma planes, for every
+//     picture of the batch, all running concurrently.  The chroma wave reconstructs Cb on lanes 0..31 and Cr on
+//     lanes 32..63 with ONE instruction stream (block geometry, neighbour availability, substitution pattern and
+//     prediction mode are shared; only samples, residuals and coded-block flags differ).  Tickets are handed out
+//     row by row so a wave's predecessor (the row above, same planes) always holds an earlier ticket, i.e. is
+//     resident or finished.
+//   * the CTB being reconstructed lives in LDS (tile(s) + top / left borders + reference-sample line(s), one packed
+//     word per 4x4 unit, a bitmap of the units decoded so far), so gathering, substitution, smoothing and
+//     prediction never touch HBM; the finished CTB leaves LDS once with row-contiguous stores.
+//   * the kernel is VALU-issue bound (a 4x4 block uses 16 of the lanes but costs whole wave instructions), so the
+//     block path avoids quarter-rate multiplies (v_mul_i32_i24), constant-memory tables (packed immediates) and
+//     anything that waits on global memory besides the prefetched residual.
 //   * row-to-row hand-off without fences (cdna guide, Guideline 16 form R1): the bottom sample row of every
 //     CTB goes to a per-picture line buffer with write-through (sc1) stores, is drained with s_waitcnt and
 //     announced with one relaxed agent-scope progress store; the row below polls that word and reads its
