@@ -55,24 +55,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    import torch
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-
-    import numpy as np
-    import libheif_amd
-    from libheif_amd.decoder import Batch
-    from libheif_amd._capi import check
     from tools import streamgen
-
-    lib = libheif_amd.load_library()
-    check(lib.hipdec_init(local_rank))
 
     w, h, def_batch, enc_cfg = WORKLOADS[a.workload]
     enc_cfg = dict(enc_cfg, qp=a.qp)
@@ -88,8 +71,28 @@ def main():
         nb = a.batch or def_batch
         nd = max(1, min(a.distinct, nb))
         specs = [(w, h, 1 + rank * nd + i, 8, enc_cfg) for i in range(nd)]
-    # ---- synthetic inputs (outside the timed region) ----
+    # ---- synthetic inputs (outside the timed region).  Generated in forked worker processes BEFORE this process touches
+    #      the GPU or starts RCCL: forking a process that holds a HIP context / communicator threads is fragile ----
     distinct = streamgen.make_streams(specs)
+
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    import numpy as np
+    import libheif_amd
+    from libheif_amd.decoder import Batch
+    from libheif_amd._capi import check
+
+    lib = libheif_amd.load_library()
+    check(lib.hipdec_init(local_rank))
+
     px_item = w * h
     gd = None
     if grid:
