@@ -12,6 +12,7 @@
 #include <ucontext.h>
 #include <sched.h>
 #include <sys/mman.h>
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
@@ -27,7 +28,19 @@ struct dim3 {
 };
 struct uint2 { unsigned x, y; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
+struct uint4 { unsigned x, y, z, w; };
 typedef void* hipStream_t;
+// the few runtime calls the host side of color.hip makes (parameter-block upload of the batched colour launch)
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 1; }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+using std::min;
+using std::max;
 
 namespace hipemu {
 

@@ -1,0 +1,97 @@
+"""CPU check of the colour kernels' logic: libheif_amd/csrc/color.hip compiled for the host against the SIMT emulator of
+tests/emu/shim and called through its own C entry points (hipdec_color_*), against the colour oracle — which is itself
+pinned to the reference's compiled ops (tests/test_color_oracle.py).  Test infrastructure; the product runs the same
+source on the GPU (tests/test_color_gpu.py)."""
+import ctypes as C
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+import test_parse_emu as tpe
+
+
+class Nclx(C.Structure):
+    _fields_ = [("has_nclx", C.c_int), ("colour_primaries", C.c_int), ("transfer_characteristics", C.c_int),
+                ("matrix_coefficients", C.c_int), ("full_range_flag", C.c_int)]
+
+
+def _lib():
+    L = tpe.emu()
+    vp, sz, ci = C.c_void_p, C.c_size_t, C.c_int
+    np_ = C.POINTER(Nclx)
+    L.hipdec_color_420_to_rgb24.argtypes = [vp, sz, vp, sz, vp, sz, ci, ci, np_, vp, sz, ci, vp]
+    L.hipdec_color_ycbcr_to_rgb24_float.argtypes = [vp, sz, vp, sz, vp, sz, ci, ci, ci, np_, vp, sz, ci, vp]
+    L.hipdec_color_420_to_rrggbb.argtypes = [vp, sz, vp, sz, vp, sz, ci, ci, ci, np_, vp, sz, ci, vp]
+    L.hipdec_color_bilinear_420_to_444.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
+    L.hipdec_color_to_sdr.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
+    L.emu_color_last_error.restype = C.c_char_p
+    return L
+
+
+def _planes(rng, w, h, bpp):
+    dt = np.uint8 if bpp == 8 else np.uint16
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    return [np.ascontiguousarray(rng.integers(0, 1 << bpp, s).astype(dt)) for s in ((h, w), (ch, cw), (ch, cw))]
+
+
+def _args(planes):
+    out = []
+    for p in planes:
+        out += [p.ctypes.data, p.strides[0]]
+    return out
+
+
+def _ok(L, rc):
+    assert rc == 0, L.emu_color_last_error().decode()
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (66, 50), (130, 34), (5, 3), (2, 2)])
+@pytest.mark.parametrize("matrix,primaries", [(1, 1), (6, 1), (9, 9), (2, 2), (12, 1)])
+def test_emulated_int_rgb24(w, h, matrix, primaries):
+    L = _lib()
+    y, cb, cr = _planes(np.random.default_rng(w + matrix), w, h, 8)
+    nclx = (primaries, 13, matrix, 1)
+    for alpha in (0, 1):
+        bpp = 4 if alpha else 3
+        out = np.zeros((h, w * bpp), np.uint8)
+        _ok(L, L.hipdec_color_420_to_rgb24(*_args([y, cb, cr]), w, h, C.byref(Nclx(1, *nclx)), out.ctypes.data, out.strides[0], alpha, None))
+        np.testing.assert_array_equal(out, orc.color_420_to_rgb24(y, cb, cr, nclx, alpha=bool(alpha)).reshape(h, -1))
+
+
+@pytest.mark.parametrize("matrix,primaries,full", [(6, 1, 0), (1, 1, 0), (2, 2, 0), (9, 9, 0), (0, 1, 0), (0, 1, 1), (8, 1, 1), (12, 9, 0)])
+def test_emulated_float_rgb24_bit_exact(matrix, primaries, full):
+    L = _lib()
+    w, h = 98, 42
+    y, cb, cr = _planes(np.random.default_rng(matrix * 3 + full), w, h, 8)
+    nclx = (primaries, 13, matrix, full)
+    out = np.zeros((h, w * 3), np.uint8)
+    _ok(L, L.hipdec_color_ycbcr_to_rgb24_float(*_args([y, cb, cr]), w, h, 1, C.byref(Nclx(1, *nclx)), out.ctypes.data, out.strides[0], 0, None))
+    r, g, b = orc.color_ycbcr_to_rgb_planar(y, cb, cr, 8, 1, nclx)
+    np.testing.assert_array_equal(out, orc.color_rgb_planar_to_interleaved8(r, g, b).reshape(h, -1))
+
+
+@pytest.mark.parametrize("bpp", [10, 12])
+@pytest.mark.parametrize("le", [True, False])
+def test_emulated_rrggbb(bpp, le):
+    L = _lib()
+    w, h = 70, 38
+    y, cb, cr = _planes(np.random.default_rng(bpp + le), w, h, bpp)
+    nclx = (9, 16, 9, 0)
+    out = np.zeros((h, w * 6), np.uint8)
+    _ok(L, L.hipdec_color_420_to_rrggbb(*_args([y, cb, cr]), w, h, bpp, C.byref(Nclx(1, *nclx)), out.ctypes.data, out.strides[0], int(le), None))
+    np.testing.assert_array_equal(out, np.asarray(orc.color_420_to_rrggbb(y, cb, cr, bpp, nclx, little_endian=le)).reshape(h, -1))
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (65, 49), (34, 130), (4, 4)])
+@pytest.mark.parametrize("bpp", [8, 10])
+def test_emulated_bilinear_and_sdr(w, h, bpp):
+    L = _lib()
+    y, cb, cr = _planes(np.random.default_rng(w + h + bpp), w, h, bpp)
+    for plane in (cb, cr):
+        out = np.zeros((h, w), plane.dtype)
+        _ok(L, L.hipdec_color_bilinear_420_to_444(plane.ctypes.data, plane.strides[0], w, h, bpp, out.ctypes.data, out.strides[0], None))
+        np.testing.assert_array_equal(out, orc.color_bilinear_420_to_444(plane, w, h))
+    if bpp > 8:
+        out = np.zeros((h, w), np.uint8)
+        _ok(L, L.hipdec_color_to_sdr(y.ctypes.data, y.strides[0], w, h, bpp, out.ctypes.data, out.strides[0], None))
+        np.testing.assert_array_equal(out, orc.color_to_sdr(y, bpp))

@@ -106,3 +106,27 @@ def test_emulated_pipeline_strong_smoothing_32x32():
     planes = [y, np.full((96, 128), 120, np.uint8), np.full((96, 128), 135, np.uint8)]
     stream = orc.encode(planes, qp=38)
     _check(stream, decode_emu([stream])[0])
+
+
+def test_emulated_pipeline_random_tool_mixes():
+    """a fixed-seed sweep over CTB / CB / TB sizes, slices, WPP, transform skip, lossless CUs, SAO, bit depth and picture
+    sizes that are not CTB multiples (the development fuzz loop of the kernels, shortened)"""
+    import random
+    rng = random.Random(20260922)
+    done = 0
+    while done < 14:
+        lc = rng.choice([4, 5, 6])
+        cfg = dict(log2_ctb=lc, log2_min_cb=rng.choice([3, min(4, lc)]), qp=rng.choice([10, 18, 26, 32, 38, 44]), stress=rng.choice([0, 1]),
+                   wpp=rng.choice([0, 1]), num_slices=rng.choice([1, 1, 2, 4]), transform_skip=rng.choice([0, 1]),
+                   strong_intra_smoothing=rng.choice([0, 1]), sao=rng.choice([0, 1]), lossless_pct=rng.choice([0, 0, 15]))
+        cfg["log2_max_tb"] = max(cfg["log2_min_cb"], rng.choice([t for t in (3, 4, 5) if t <= lc]))
+        bd = rng.choice([8, 8, 10])
+        if bd == 10:
+            cfg["bit_depth"] = 10
+        w, h = rng.choice([8, 16, 40, 72, 136, 200, 264]), rng.choice([8, 24, 40, 72, 136])
+        try:
+            stream = orc.encode(orc.synth_image(w, h, bd, 1, seed=done + 7), **cfg)
+        except orc.OracleError:
+            continue      # a parameter mix the test encoder refuses
+        _check(stream, decode_emu([stream])[0])
+        done += 1
