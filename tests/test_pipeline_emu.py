@@ -130,3 +130,17 @@ def test_emulated_pipeline_random_tool_mixes():
             continue      # a parameter mix the test encoder refuses
         _check(stream, decode_emu([stream])[0])
         done += 1
+
+
+def test_emulated_pipeline_decodes_reference_fixtures(reference_dir):
+    """the reference's real x265-coded fixtures through the emulated device pipeline: planes identical to the oracle's"""
+    import os
+    from heic_util import HeicFile
+    for rel, items in (("tests/data/rainbow-451x461.heic", None), ("examples/example.heic", "thumbnails")):
+        h = HeicFile(os.path.join(reference_dir, rel))
+        ids = h.hevc_items()
+        if items == "thumbnails":
+            ids = [k[1] for k in h.refs if k[0] == "thmb"]      # 320x212 each (the 1280x854 masters run on the GPU suite)
+        for iid in ids:
+            stream = h.plugin_stream(iid)
+            _check(stream, decode_emu([stream])[0])
