@@ -68,8 +68,15 @@ PC_DEV uint64_t pc_ballot(const VReg& r) { return __ballot(r != 0); }
 // a wave-uniform value deliberately kept in a VECTOR register: the asm move hides its uniformity from the compiler,
 // so arithmetic on it is issued to the SIMD's VALU instead of the CU-shared scalar pipe
 typedef uint32_t UReg;
+#if defined(HIPDEC_PARSE_SCALAR_CABAC)
+// latency variant (parse_kernel_scalar.hip): with a handful of waves on the chip the scalar pipe is idle and its dependent-
+// issue latency is shorter than the VALU's, so the arithmetic decoder's state stays in SGPRs
+PC_DEV UReg pc_vec(uint32_t x) { return x; }
+PC_DEV bool pc_any(bool b) { return b; }
+#else
 PC_DEV UReg pc_vec(uint32_t x) { UReg r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
 PC_DEV bool pc_any(bool b) { return __ballot(b) != 0; }   // uniform branch condition from a (uniform-valued) vector compare
+#endif
 #define PC_LDS_SYNC() __syncthreads()
 #define PC_CONST __constant__
 #endif

@@ -36,6 +36,9 @@ void launch_parse(const ParseArgs& a, hipStream_t s)
 {
   if (!a.num_waves) return;
   static const int forced = getenv("HIPDEC_PARSE_OCCUPANCY") ? atoi(getenv("HIPDEC_PARSE_OCCUPANCY")) : -1;
+  // latency mode (a still, a small grid: at most a couple of waves per CU): the scalar-register variant
+  static const int scalar_below = getenv("HIPDEC_PARSE_SCALAR_BELOW") ? atoi(getenv("HIPDEC_PARSE_SCALAR_BELOW")) : 512;
+  if (forced < 0 && !a.pool && (int)a.num_waves <= scalar_below) { launch_parse_scalar(a, s); return; }
   // throughput mode (the chip is oversubscribed with parser waves): 8 waves per SIMD; latency mode: all registers
   const int occ = forced >= 0 ? forced : (a.pool ? 7 : (a.num_waves >= 2048 ? 8 : 0));
   if (occ == 8) hipLaunchKernelGGL(k_parse_occ8, dim3(a.num_waves), dim3(64), 0, s, a);
