@@ -1,0 +1,38 @@
+"""Memory-safety fuzz of the DEVICE code on the CPU: the kernel sources compiled for the host (tests/emu) with AddressSanitizer,
+fed randomly corrupted streams (bit flips, random bytes, 0xff bytes in slice data and headers).  Every run must end in a host
+rejection or a device status word - never in an out-of-bounds access.  Dev tool:
+    bash tools/emu_asan_fuzz.sh <seed> <count>"""
+import sys, ctypes as C, random, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+from oracle import pyoracle as orc
+L = C.CDLL(os.path.join(ROOT, 'build/asan/libparse_emu_asan.so'))
+L.emu_create.restype = C.c_void_p
+L.emu_create.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+L.emu_free.argtypes=[C.c_void_p]; L.emu_run_parse.argtypes=[C.c_void_p]; L.emu_run_pipeline.argtypes=[C.c_void_p, C.c_int]
+def run(s):
+    arr=(C.c_char_p*1)(s); sizes=(C.c_size_t*1)(len(s)); err=C.create_string_buffer(512)
+    h=L.emu_create(1,arr,sizes,err,512)
+    if not h: return 'rejected: '+err.value.decode()[:60]
+    st=L.emu_run_parse(h)
+    if st==0: st=L.emu_run_pipeline(h,15)
+    L.emu_free(h)
+    return 'status 0x%x'%(st&0xffffffff)
+rng=random.Random(int(sys.argv[1]))
+n=int(sys.argv[2])
+cfgs=[dict(), dict(stress=1, num_slices=2), dict(log2_ctb=4,log2_min_cb=3,log2_max_tb=4,stress=1), dict(bit_depth=10), dict(wpp=0, transform_skip=1, lossless_pct=10)]
+base=[orc.encode(orc.synth_image(136,72,c.get('bit_depth',8),1,seed=3+i),**c) for i,c in enumerate(cfgs)]
+print('clean:', [run(s) for s in base]); sys.stdout.flush()
+res={}
+for it in range(n):
+    s=bytearray(rng.choice(base))
+    k=rng.choice([1,1,2,4,16])
+    for _ in range(k):
+        p=rng.randrange(len(s)); 
+        mode=rng.randrange(3)
+        if mode==0: s[p]^=1<<rng.randrange(8)
+        elif mode==1: s[p]=rng.randrange(256)
+        else: s[p]=0xff
+    r=run(bytes(s)); res[r.split(':')[0]]=res.get(r.split(':')[0],0)+1
+print(res)
