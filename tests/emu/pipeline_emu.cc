@@ -37,6 +37,14 @@ int emu_plane(EmuBatch* b, int i, int c, void* dst)
   return 0;
 }
 
+// FNV-1a over the read-only upload region (parameter blocks, tables, bitstreams): no kernel may ever write there
+uint64_t emu_upload_hash(EmuBatch* b)
+{
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < b->L.upload_size; i++) { h ^= b->arena[i]; h *= 1099511628211ull; }
+  return h;
+}
+
 int emu_out_size(EmuBatch* b, int i, int* out /* w, h, cw, ch, bytes per sample */)
 {
   const PicParams& P = b->L.params[i];
