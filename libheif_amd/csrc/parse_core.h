@@ -48,6 +48,8 @@ PC_DEV uint64_t pc_ballot(const VReg& r) { uint64_t m = 0; for (int l = 0; l < 6
 typedef uint32_t UReg;
 PC_DEV UReg pc_vec(uint32_t x) { return x; }
 PC_DEV bool pc_any(bool b) { return b; }
+PC_DEV float pc_rcp(float x) { return 1.0f / x; }
+PC_DEV uint32_t pc_mul24(uint32_t a, uint32_t b) { return a * b; }
 #define PC_LDS_SYNC() do { } while (0)
 #define PC_CONST static const
 #else
@@ -77,6 +79,8 @@ PC_DEV bool pc_any(bool b) { return b; }
 PC_DEV UReg pc_vec(uint32_t x) { UReg r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
 PC_DEV bool pc_any(bool b) { return __ballot(b) != 0; }   // uniform branch condition from a (uniform-valued) vector compare
 #endif
+PC_DEV float pc_rcp(float x) { return __builtin_amdgcn_rcpf(x); }                       // v_rcp_f32, 1 ulp
+PC_DEV uint32_t pc_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }              // operands < 2^24
 #define PC_LDS_SYNC() __syncthreads()
 #define PC_CONST __constant__
 #endif
@@ -308,10 +312,15 @@ PC_DEV uint32_t decode_bypass_multi(PS& s, int n)
   s.bits_needed += (uint32_t)n;
   if (pc_any((int32_t)s.bits_needed >= 0)) { s.value += read_byte(s) << s.bits_needed; s.bits_needed -= 8u; }
   const UReg scaled = s.range << 7;
-  UReg q = s.value / scaled;
+  // value < scaled * 2^n <= 2^24 and scaled < 2^16 are exact in fp32: the quotient estimate from one reciprocal is off by at
+  // most one, which the remainder check repairs (an integer division expands to ~40 instructions)
+  UReg q = (UReg)((float)s.value * pc_rcp((float)scaled));
+  UReg r = s.value - pc_mul24(q, scaled);
+  if (pc_any((int32_t)r < 0)) { q -= 1u; r += scaled; }
+  else if (pc_any(r >= scaled)) { q += 1u; r -= scaled; }
   const uint32_t qmax = (1u << n) - 1u;
-  q = q > qmax ? qmax : q;   // only reachable on a corrupt stream
-  s.value -= q * scaled;
+  if (pc_any(q > qmax)) { r += pc_mul24(q - qmax, scaled); q = pc_vec(qmax); }   // only reachable on a corrupt stream
+  s.value = r;
   return pc_uni(q);
 }
 PC_DEV int decode_bypass_bits(PS& s, int n)   // n <= 32, MSB first
