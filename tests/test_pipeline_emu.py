@@ -144,3 +144,15 @@ def test_emulated_pipeline_decodes_reference_fixtures(reference_dir):
         for iid in ids:
             stream = h.plugin_stream(iid)
             _check(stream, decode_emu([stream])[0])
+
+
+@pytest.mark.parametrize("yield_ctbs", [1, 0])
+def test_emulated_pipeline_after_pool_scheduled_parse(yield_ctbs, monkeypatch):
+    """throughput mode end to end: the parser runs as the work pool (rows as tasks, a row hands its wave back after every
+    CTB - the product default - or runs until blocked), then the rest of the pipeline; several pictures in one batch"""
+    monkeypatch.setenv("HIPDEC_PARSE_POOL", "1")
+    monkeypatch.setenv("HIPDEC_POOL_YIELD", str(yield_ctbs))
+    streams = [orc.encode(orc.synth_image(w, h, 8, 1, seed=70 + i), stress=i & 1, qp=24 + 4 * i)
+               for i, (w, h) in enumerate([(264, 200), (200, 136), (328, 72), (72, 264)])]
+    for s, planes in zip(streams, decode_emu(streams)):
+        _check(s, planes)
