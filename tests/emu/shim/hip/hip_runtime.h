@@ -202,7 +202,8 @@ void launch(dim3 grid, dim3 block, F&& fn)
 #define blockIdx (hipemu::g->bid)
 #define blockDim (hipemu::g->bdim)
 #define gridDim (hipemu::g->gdim)
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  do { (void)(stream); hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); }); } while (0)
 
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_ACQUIRE)
