@@ -124,6 +124,9 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
     P.off_ctb_ts_to_rs = off; off = align_up(off + nctb * sizeof(uint16_t), 256);
     P.off_ctb_info = off; off = align_up(off + nctb * sizeof(CtbInfo), 256);
     P.off_slices = off; off = align_up(off + pp.slice_params.size() * sizeof(SliceParams), 256);
+    P.scaling_lists = pp.scaling_tables.empty() ? 0 : 1;
+    P.off_scaling = off;
+    if (P.scaling_lists) off = align_up(off + pp.scaling_tables.size(), 256);
     P.off_bitstream = off; P.bitstream_size = sizes[i]; off = align_up(off + sizes[i] + 512, 256);
     b.max_w = std::max(b.max_w, P.width); b.max_h = std::max(b.max_h, P.height);
     b.max_ctbs = std::max(b.max_ctbs, P.ctb_w * P.ctb_h);
@@ -206,6 +209,7 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
     memcpy(host.data() + P.off_ctb_ts_to_rs, pp.ts_to_rs.data(), pp.ts_to_rs.size() * sizeof(uint16_t));
     memcpy(host.data() + P.off_ctb_info, pp.ctb_info.data(), pp.ctb_info.size() * sizeof(CtbInfo));
     memcpy(host.data() + P.off_slices, pp.slice_params.data(), pp.slice_params.size() * sizeof(SliceParams));
+    if (P.scaling_lists) memcpy(host.data() + P.off_scaling, pp.scaling_tables.data(), pp.scaling_tables.size());
     memcpy(host.data() + P.off_bitstream, data[i], sizes[i]);
   }
   return HIPDEC_OK;

@@ -69,7 +69,7 @@ struct PicParams {
   uint8_t transquant_bypass_enabled, strong_intra_smoothing, tiles_enabled, wpp;
   uint8_t lf_across_tiles, pcm_loop_filter_disabled;
   uint8_t sao_free_neighbours;   // 1: no slice / tile boundary restricts the SAO edge neighbours and no lossless CU can occur
-  uint8_t pad1;
+  uint8_t scaling_lists;         // scaling_list_enabled_flag: the factor tables at off_scaling apply (8.6.4.2)
   int32_t log2_min_cu_qp_delta_size;
   // buffers (byte offsets into the batch arena)
   uint64_t off_bitstream, bitstream_size;
@@ -77,6 +77,7 @@ struct PicParams {
   uint64_t off_ctb_info;          // CtbInfo[ctbs] (raster)
   uint64_t off_slices;            // SliceParams[nslices]
   uint64_t off_sao;               // SaoParams[ctbs*3]
+  uint64_t off_scaling;           // uint8[2048] ScalingFactor m[y][x], intra matrices: component c at c * 336 (4x4, 8x8 at +16, 16x16 at +80), luma 32x32 at 1008
   uint64_t off_handoff;           // uint32[ctbs * HANDOFF_DWORDS]
   uint64_t off_u_size, off_u_flags, off_u_ipm, off_u_ipmc, off_u_qp;  // uint8[ctbs*units_per_ctb]
   uint64_t off_coeff[3];          // int16

@@ -10,6 +10,14 @@
 
 namespace hipdec {
 
+// scaling_list_data() (7.3.4) as ScalingList[sizeId][matrixId] in RASTER order (index y * side + x of the 4x4 / 8x8 base
+// list), with the DC values of the 16x16 and 32x32 lists kept apart (7.4.5)
+struct ScalingLists {
+  uint8_t l4[6][16], l8[6][64], l16[6][64], l32[6][64];
+  uint8_t dc16[6], dc32[6];
+};
+void scaling_lists_default(ScalingLists& sl);   // Table 7-5 (flat 16) and Table 7-6
+
 struct Sps {
   bool valid = false;
   int chroma_format_idc = 1, pic_width = 0, pic_height = 0;
@@ -22,6 +30,7 @@ struct Sps {
   int num_short_term_ref_pic_sets = 0, num_long_term_ref_pics_sps = 0;
   std::vector<int> rps_num_delta_pocs;  // NumDeltaPocs per short-term RPS (needed to skip slice-level RPS)
   int colour_primaries = 2, transfer_characteristics = 2, matrix_coeffs = 2, full_range = 0;
+  ScalingLists sl{};   // valid when scaling_list_enabled (explicit lists or the defaults)
 };
 
 struct Pps {
@@ -37,6 +46,7 @@ struct Pps {
   int cb_qp_offset = 0, cr_qp_offset = 0, beta_offset_div2 = 0, tc_offset_div2 = 0;
   int tile_cols = 1, tile_rows = 1;
   std::vector<int> col_width, row_height;  // explicit sizes when !uniform_spacing
+  ScalingLists sl{};   // valid when scaling_list_data_present
 };
 
 struct ParsedSlice {
@@ -56,6 +66,9 @@ struct ParsedPicture {
   std::vector<CtbInfo> ctb_info;    // raster
   std::vector<Substream> subs;      // `pic` and dep indices are picture-local until the batch relocates them
   std::vector<SliceParams> slice_params;
+  // ScalingFactor m[y][x] of the intra matrices, expanded (8.6.4.2 / 7.4.5): per component c the 4x4 (16 B), 8x8 (64 B) and
+  // 16x16 (256 B) factors at c * 336, then the luma 32x32 factors (1024 B) at 1008; empty when scaling lists are off
+  std::vector<uint8_t> scaling_tables;
 };
 
 // Parses one coded picture from libheif's plugin framing.  Returns a hipdec_status.

@@ -110,6 +110,89 @@ void skip_hrd(NalReader& r, bool common, int max_sub)
 }
 
 // 7.3.7: returns NumDeltaPocs of the parsed set; only the count matters for an intra-only decoder
+// Table 7-6: default 8x8 intra lists (matrixId 0..2) and inter lists (3..5); symmetric, so raster == diagonal order
+const uint8_t kDefaultIntra8[64] = {16, 16, 16, 16, 17, 18, 21, 24, 16, 16, 16, 16, 17, 19, 22, 25, 16, 16, 17, 18, 20, 22, 25, 29,
+                                    16, 16, 18, 21, 24, 27, 31, 36, 17, 17, 20, 24, 30, 35, 41, 47, 18, 19, 22, 27, 35, 44, 54, 65,
+                                    21, 22, 25, 31, 41, 54, 70, 88, 24, 25, 29, 36, 47, 65, 88, 115};
+const uint8_t kDefaultInter8[64] = {16, 16, 16, 16, 17, 18, 20, 24, 16, 16, 16, 17, 18, 20, 24, 25, 16, 16, 17, 18, 20, 24, 25, 28,
+                                    16, 17, 18, 20, 24, 25, 28, 33, 17, 18, 20, 24, 25, 28, 33, 41, 18, 20, 24, 25, 28, 33, 41, 54,
+                                    20, 24, 25, 28, 33, 41, 54, 71, 24, 25, 28, 33, 41, 54, 71, 91};
+
+// 6.5.3 up-right diagonal scan of a side x side block: position i -> raster index y * side + x
+void diag_scan(int side, uint8_t* raster_of)
+{
+  int i = 0, x = 0, y = 0;
+  while (i < side * side) {
+    while (y >= 0) {
+      if (x < side && y < side) raster_of[i++] = (uint8_t)(y * side + x);
+      y--; x++;
+    }
+    y = x; x = 0;
+  }
+}
+
+// 7.3.4 scaling_list_data() / 7.4.5 semantics
+void parse_scaling_list_data(NalReader& r, ScalingLists& sl)
+{
+  uint8_t scan4[16], scan8[64];
+  diag_scan(4, scan4);
+  diag_scan(8, scan8);
+  for (int size_id = 0; size_id < 4; size_id++)
+    for (int m = 0; m < 6; m += (size_id == 3 ? 3 : 1)) {
+      uint8_t* dst = size_id == 0 ? sl.l4[m] : (size_id == 1 ? sl.l8[m] : (size_id == 2 ? sl.l16[m] : sl.l32[m]));
+      const int n = size_id == 0 ? 16 : 64;
+      if (!r.u(1)) {                                        // scaling_list_pred_mode_flag = 0: copy
+        const unsigned delta = r.ue();                      // scaling_list_pred_matrix_id_delta
+        if (delta == 0) {                                   // ... the default list
+          if (size_id == 0) memset(dst, 16, 16);
+          else memcpy(dst, m < 3 ? kDefaultIntra8 : kDefaultInter8, 64);
+          if (size_id == 2) sl.dc16[m] = 16;
+          if (size_id == 3) sl.dc32[m] = 16;
+        } else {                                            // ... an earlier list of the same size
+          const long ref = (long)m - (long)delta * (size_id == 3 ? 3 : 1);
+          if (ref < 0) bad("scaling_list_pred_matrix_id_delta out of range");
+          const uint8_t* src = size_id == 0 ? sl.l4[ref] : (size_id == 1 ? sl.l8[ref] : (size_id == 2 ? sl.l16[ref] : sl.l32[ref]));
+          memcpy(dst, src, (size_t)n);
+          if (size_id == 2) sl.dc16[m] = sl.dc16[ref];
+          if (size_id == 3) sl.dc32[m] = sl.dc32[ref];
+        }
+      } else {                                              // explicit coefficients, DPCM in diagonal order
+        int next = 8;
+        if (size_id > 1) {
+          const int dc = r.se();                            // scaling_list_dc_coef_minus8
+          if (dc < -7 || dc > 247) bad("scaling_list_dc_coef_minus8 out of range");
+          next = dc + 8;
+          if (size_id == 2) sl.dc16[m] = (uint8_t)next; else sl.dc32[m] = (uint8_t)next;
+        }
+        const uint8_t* scan = size_id == 0 ? scan4 : scan8;
+        for (int i = 0; i < n; i++) {
+          const int d = r.se();                             // scaling_list_delta_coef
+          if (d < -128 || d > 127) bad("scaling_list_delta_coef out of range");
+          next = (next + d + 256) % 256;
+          dst[scan[i]] = (uint8_t)next;
+        }
+      }
+    }
+}
+
+// 8.6.4.2 / 7.4.5: the factors m[y][x] a block of the given size and (intra) component uses
+void build_scaling_tables(const ScalingLists& sl, std::vector<uint8_t>& out)
+{
+  out.assign(2048, 16);
+  for (int c = 0; c < 3; c++) {
+    uint8_t* t = out.data() + c * 336;
+    memcpy(t, sl.l4[c], 16);
+    memcpy(t + 16, sl.l8[c], 64);
+    for (int y = 0; y < 16; y++)
+      for (int x = 0; x < 16; x++) t[80 + y * 16 + x] = sl.l16[c][(y >> 1) * 8 + (x >> 1)];
+    t[80] = sl.dc16[c];
+  }
+  uint8_t* t32 = out.data() + 1008;
+  for (int y = 0; y < 32; y++)
+    for (int x = 0; x < 32; x++) t32[y * 32 + x] = sl.l32[0][(y >> 2) * 8 + (x >> 2)];
+  t32[0] = sl.dc32[0];
+}
+
 int parse_short_term_rps(NalReader& r, int idx, int num_sets, const std::vector<int>& num_delta_pocs)
 {
   bool inter = idx != 0 ? r.u(1) : false;
@@ -160,7 +243,10 @@ void parse_sps(NalReader& r, Sps& s)
   s.max_th_depth_inter = (int)r.ue();
   s.max_th_depth_intra = (int)r.ue();
   s.scaling_list_enabled = r.u(1);
-  if (s.scaling_list_enabled) unsupported("scaling lists (scaling_list_enabled_flag = 1)");
+  if (s.scaling_list_enabled) {
+    scaling_lists_default(s.sl);                         // sps_infer: Table 7-5 / 7-6 unless lists follow
+    if (r.u(1)) parse_scaling_list_data(r, s.sl);        // sps_scaling_list_data_present_flag
+  }
   s.amp = r.u(1);
   s.sao = r.u(1);
   s.pcm = r.u(1);
@@ -260,7 +346,7 @@ void parse_pps(NalReader& r, Pps& p)
     if (!p.deblocking_disabled) { p.beta_offset_div2 = r.se(); p.tc_offset_div2 = r.se(); }
   }
   p.scaling_list_data_present = r.u(1);
-  if (p.scaling_list_data_present) unsupported("scaling lists in the PPS");
+  if (p.scaling_list_data_present) { scaling_lists_default(p.sl); parse_scaling_list_data(r, p.sl); }
   r.skip(1);
   r.ue();
   p.slice_header_extension_present = r.u(1);
@@ -317,6 +403,16 @@ TileLayout build_tiles(const Sps& s, const Pps& p, int ctb_w, int ctb_h)  // 6.5
 }
 
 }  // namespace
+
+void scaling_lists_default(ScalingLists& sl)
+{
+  for (int m = 0; m < 6; m++) {
+    memset(sl.l4[m], 16, 16);
+    const uint8_t* def = m < 3 ? kDefaultIntra8 : kDefaultInter8;
+    memcpy(sl.l8[m], def, 64); memcpy(sl.l16[m], def, 64); memcpy(sl.l32[m], def, 64);
+    sl.dc16[m] = 16; sl.dc32[m] = 16;
+  }
+}
 
 int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedPicture& out, std::string& err)
 {
@@ -456,6 +552,8 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
     out.ts_to_rs = tiles.ts_to_rs;
     out.subs.clear();
     out.slice_params.clear();
+    out.scaling_tables.clear();
+    if (S.scaling_list_enabled) build_scaling_tables(P.scaling_list_data_present ? P.sl : S.sl, out.scaling_tables);
     for (size_t si = 0; si < out.slices.size(); si++) {
       const ParsedSlice& sl = out.slices[si];
       out.slice_params.push_back(sl.sp);

@@ -42,6 +42,46 @@ static void bw_ue(BW* w, unsigned v)
   bw_u(w, x, len + 1);
 }
 static void bw_se(BW* w, int v) { bw_ue(w, v > 0 ? (unsigned)(2 * v - 1) : (unsigned)(-2 * v)); }
+/* 7.3.4 scaling_list_data() with pseudo-random content that exercises every branch of the syntax: lists copied from the
+ * default, lists copied from an earlier matrix (incl. its DC), explicit DPCM-coded lists with DC coefficients.  The lists the
+ * decoder will derive are obtained by parsing the bits just written with the oracle's own parser. */
+static void write_scaling_list_data(Dec* d, BW* w, ScalingList* sl, unsigned seed)
+{
+  const size_t start = w->nbits;
+  unsigned st = seed * 2654435761u + 12345u;
+  init_scans();
+  for (int sizeId = 0; sizeId < 4; sizeId++)
+    for (int matrixId = 0; matrixId < 6; matrixId += (sizeId == 3) ? 3 : 1) {
+      st = st * 1664525u + 1013904223u;
+      const unsigned choice = (st >> 24) % 4;
+      const int step = sizeId == 3 ? 3 : 1;
+      if (choice == 0) { bw_u(w, 0, 1); bw_ue(w, 0); }                                   /* the default list */
+      else if (choice == 1 && matrixId >= step) { bw_u(w, 0, 1); bw_ue(w, 1 + ((st >> 8) % (unsigned)(matrixId / step))); }  /* copy an earlier one */
+      else {
+        bw_u(w, 1, 1);
+        const int n = sizeId == 0 ? 16 : 64;
+        int next = 8;
+        if (sizeId > 1) { int dc = 4 + (int)((st >> 12) % 40); bw_se(w, dc - 8); next = dc; }
+        int v = 10 + (int)((st >> 4) % 20);
+        for (int i = 0; i < n; i++) {
+          st = st * 1664525u + 1013904223u;
+          v += (int)((st >> 20) % 9) - 3 + (i > n / 2);          /* a rising random walk like real perceptual lists */
+          if (v < 1) v = 1;
+          if (v > 255) v = 255;
+          int delta = v - next;
+          if (delta > 127) delta -= 256;
+          if (delta < -128) delta += 256;
+          bw_se(w, delta);
+          next = v;
+        }
+      }
+    }
+  BR b; memset(&b, 0, sizeof(b));
+  b.d = d; b.p = w->p; b.pos = start; b.nbits = w->nbits;
+  parse_scaling_list_data(d, &b, sl);
+  if (b.pos != w->nbits) fail(d, "testenc: scaling list writer / parser disagree");
+}
+
 static void bw_trailing(BW* w) { bw_put(w, 1); while (w->nbits & 7) bw_put(w, 0); }
 static void bw_free(BW* w) { free(w->p); memset(w, 0, sizeof(*w)); }
 
@@ -967,7 +1007,10 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
   bw_ue(&w, s->log2_min_tb - 2); bw_ue(&w, s->log2_max_tb - s->log2_min_tb);
   bw_ue(&w, s->max_transform_hierarchy_depth_inter); bw_ue(&w, s->max_transform_hierarchy_depth_intra);
   bw_u(&w, s->scaling_list_enabled_flag, 1);
-  if (s->scaling_list_enabled_flag) bw_u(&w, 0, 1); /* default lists */
+  if (s->scaling_list_enabled_flag) {   /* scaling_list: 1 = default lists, 2 = explicit lists in the SPS, 3 = in the PPS */
+    bw_u(&w, prm->scaling_list == 2, 1);
+    if (prm->scaling_list == 2) write_scaling_list_data(d, &w, &s->sl, (unsigned)prm->seed + 17u);
+  }
   bw_u(&w, 0, 1); bw_u(&w, s->sao_enabled_flag, 1); bw_u(&w, s->pcm_enabled_flag, 1);
   if (s->pcm_enabled_flag) {
     bw_u(&w, s->pcm_bit_depth_luma - 1, 4); bw_u(&w, s->pcm_bit_depth_chroma - 1, 4);
@@ -1004,7 +1047,10 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
   bw_u(&w, p->pps_loop_filter_across_slices_enabled_flag, 1);
   bw_u(&w, 1, 1); bw_u(&w, 0, 1); bw_u(&w, p->pps_deblocking_filter_disabled_flag, 1);
   if (!p->pps_deblocking_filter_disabled_flag) { bw_se(&w, p->pps_beta_offset_div2); bw_se(&w, p->pps_tc_offset_div2); }
-  bw_u(&w, 0, 1); bw_u(&w, 0, 1); bw_ue(&w, 0); bw_u(&w, 0, 1); bw_u(&w, 0, 1);
+  p->pps_scaling_list_data_present_flag = prm->scaling_list == 3;
+  bw_u(&w, p->pps_scaling_list_data_present_flag, 1);
+  if (p->pps_scaling_list_data_present_flag) write_scaling_list_data(d, &w, &p->sl, (unsigned)prm->seed + 29u);
+  bw_u(&w, 0, 1); bw_ue(&w, 0); bw_u(&w, 0, 1); bw_u(&w, 0, 1);
   bw_trailing(&w);
   put_nal(&stream, 34, w.p, w.nbits >> 3);
   bw_free(&w);

@@ -56,7 +56,8 @@ def test_framing_errors_are_end_of_data():
 def test_unsupported_tools_and_limits_are_loud():
     planes = orc.synth_image(64, 64, 8, 1, seed=2)
     assert probe(orc.encode(planes, pcm_pct=30))[0] == -4
-    assert probe(orc.encode(planes, scaling_list=1))[0] == -4
+    for sl in (1, 2, 3):   # scaling lists (default / SPS / PPS) are part of the supported tool set
+        assert probe(orc.encode(planes, scaling_list=sl))[0] == 0
     s = orc.encode(planes)
     assert probe(s, max_px=64 * 64 - 1)[0] == -5 and probe(s, max_px=64 * 64)[0] == 0
     # a second coded picture in the same item is outside the still-image path: rejected, not mis-decoded

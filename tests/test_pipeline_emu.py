@@ -156,3 +156,25 @@ def test_emulated_pipeline_after_pool_scheduled_parse(yield_ctbs, monkeypatch):
                for i, (w, h) in enumerate([(264, 200), (200, 136), (328, 72), (72, 264)])]
     for s, planes in zip(streams, decode_emu(streams)):
         _check(s, planes)
+
+
+@pytest.mark.parametrize("scaling_list", [1, 2, 3], ids=["default_lists", "sps_lists", "pps_lists"])
+@pytest.mark.parametrize("cfg", [dict(), dict(stress=1, transform_skip=1), dict(bit_depth=10), dict(log2_ctb=4, log2_min_cb=3, log2_max_tb=4, stress=1),
+                                 dict(qp=44), dict(qp=10, stress=1), dict(log2_ctb=5, log2_max_tb=5, qp=38), dict(lossless_pct=20, num_slices=2)],
+                         ids=["default", "tskip", "main10", "ctb16", "qp44", "qp10", "tb32", "lossless_slices"])
+def test_emulated_pipeline_with_scaling_lists(cfg, scaling_list):
+    """scaling_list_enabled_flag (8.6.4.2): the default lists of Table 7-6, explicit lists in the SPS, explicit lists in
+    the PPS (copies of the default / of earlier matrices, DPCM-coded lists with DC coefficients)"""
+    c = dict(cfg, scaling_list=scaling_list)
+    stream = orc.encode(orc.synth_image(200, 136, c.get("bit_depth", 8), 1, seed=33 + scaling_list), **c)
+    _check(stream, decode_emu([stream])[0])
+
+
+def test_emulated_pipeline_scaling_lists_32x32():
+    yy, xx = np.mgrid[0:192, 0:256]
+    planes = [(40 + 0.5 * xx + 0.25 * yy).astype(np.uint8), np.full((96, 128), 120, np.uint8), np.full((96, 128), 135, np.uint8)]
+    for sl in (1, 2, 3):
+        stream = orc.encode(planes, qp=34, scaling_list=sl)
+        ref = orc.decode(stream, taps=True)
+        assert (ref["map_log2_tb"] == 5).any(), "the stream was meant to carry 32x32 transform blocks"
+        _check(stream, decode_emu([stream])[0])
