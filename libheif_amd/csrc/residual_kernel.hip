@@ -63,7 +63,6 @@ struct ResLds {
   alignas(4) int16_t tmp[4][32 * (32 + RPAD)];   // per wave: first-stage output tmp[y][j]
   uint8_t m_size[256], m_flags[256], m_ipm[256];
   int8_t m_qp[256];
-  alignas(8) uint8_t sl[2048];   // ScalingFactor tables of the picture (PicParams.off_scaling), staged only when scaling lists are on
   uint16_t list[448];    // blocks larger than 4x4: z | component << 8 (z = the unit that carries the TU's flags)
   uint16_t list4[448];   // 4x4 blocks, four of them per wave pass
   uint32_t count, count4;
@@ -90,7 +89,8 @@ inline int dot2(uint32_t a, uint32_t b, int acc)
 #endif
 
 // one transform block, by one wave: coef (global, n*n int16, raster) -> residual in place
-// SL: the block's ScalingFactor table m[y * n + x] (LDS) replaces the flat factor 16 (8.6.4.2)
+// SL: the block's ScalingFactor table m[y * n + x] (read from the picture's 2 KB table in HBM: cache-resident, and only
+// streams with scaling lists pay for it - no LDS is set aside) replaces the flat factor 16 (8.6.4.2)
 template <bool SL>
 __device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, int16_t* coef, int log2n, int bit_depth, int qp, int dst,
                                                int transform_skip, int bypass, const uint8_t* m)
@@ -186,7 +186,7 @@ __device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, in
 
 // Four independent 4x4 blocks per wave pass: lane = 16 g + 4 y + x works on sample (y, x) of block g.  entry = z | c << 8.
 // (8.6.2 - 8.6.4 as in residual_block; both 1-D stages are two v_dot2 per output, no nonzero-extent bookkeeping)
-__device__ __forceinline__ void residual_quad(ResLds& L, int bd_luma, int bd_chroma, int cb_qp_offset, int cr_qp_offset, bool use_sl, int wave, int lane, int entry, bool valid,
+__device__ __forceinline__ void residual_quad(ResLds& L, int bd_luma, int bd_chroma, int cb_qp_offset, int cr_qp_offset, const uint8_t* sl_tab, int wave, int lane, int entry, bool valid,
                                               int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr)
 {
   const int g = lane >> 4, l = lane & 15;
@@ -208,7 +208,8 @@ __device__ __forceinline__ void residual_quad(ResLds& L, int bd_luma, int bd_chr
   const int q6 = (qp * 43) >> 8;          // qp / 6 for 0 <= qp < 128
   const int bd_shift = bit_depth - 3;     // bitDepth + log2(4) - 5
   const int bd_shift2 = 20 - bit_depth;
-  const int mfac = use_sl ? (int)L.sl[c * 336 + l] : 16;      // 4x4 ScalingFactor of this lane's coefficient (8.6.4.2)
+  const bool use_sl = sl_tab != nullptr;
+  const int mfac = use_sl ? (int)sl_tab[c * 336 + l] : 16;    // 4x4 ScalingFactor of this lane's coefficient (8.6.4.2)
   const int f = mfac * level_scale(qp - 6 * q6);
   const int sh_r = q6 < bd_shift ? bd_shift - q6 : 0, sh_l = q6 < bd_shift ? 0 : q6 - bd_shift, rnd = sh_r ? 1 << (sh_r - 1) : 0;
   int lev = 0;
@@ -276,8 +277,8 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
       dstp[off] = (int16_t)(k <= 32 ? r_dct_c[k] : -r_dct_c[64 - k]);
     }
   }
-  const bool use_sl = P.scaling_lists != 0;
-  if (use_sl) ((uint2*)L.sl)[tid] = ((const uint2*)(A.arena + P.off_scaling))[tid];   // 256 threads x 8 bytes
+  const uint8_t* sl_tab = P.scaling_lists ? A.arena + P.off_scaling : nullptr;   // ScalingFactor tables of the picture
+  const bool use_sl = sl_tab != nullptr;
   if (tid == 0) { L.count = 0; L.count4 = 0; }
   if (tid < units) {
     L.m_size[tid] = A.arena[P.off_u_size + base + tid];
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
   for (int q = wave; q * 4 < count4; q += 4) {
     const int idx = q * 4 + (lane >> 4);
     const bool valid = idx < count4;
-    residual_quad(L, bd_luma, bd_chroma, cb_off, cr_off, use_sl, wave, lane, valid ? (int)L.list4[idx] : 0, valid, coef_y, coef_c[0], coef_c[1]);
+    residual_quad(L, bd_luma, bd_chroma, cb_off, cr_off, sl_tab, wave, lane, valid ? (int)L.list4[idx] : 0, valid, coef_y, coef_c[0], coef_c[1]);
   }
   // larger blocks, one per wave pass
   for (int e = wave; e < count; e += 4) {
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
     const int t = L.m_size[z] & 15, fl = L.m_flags[z], ipm = L.m_ipm[z], qp_y = L.m_qp[z];
     if (c == 0) {
       if (use_sl) residual_block<true>(L, wave, lane, coef_y + z * 16, t, bd_luma, qp_y + 6 * (bd_luma - 8), 0, (fl & UF_TS_LUMA) != 0, 0,
-                                       L.sl + (t == 5 ? 1008 : (t == 3 ? 16 : 80)));
+                                       sl_tab + (t == 5 ? 1008 : (t == 3 ? 16 : 80)));
       else residual_block<false>(L, wave, lane, coef_y + z * 16, t, bd_luma, qp_y + 6 * (bd_luma - 8), 0, (fl & UF_TS_LUMA) != 0, 0, nullptr);
     }
     else {
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
       const int qpi = clip3(-off_c, 57, qp_y + (c == 1 ? cb_off : cr_off));
       const int qpc = qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : chroma_qp_table(qpi));
       if (use_sl) residual_block<true>(L, wave, lane, coef_c[c - 1] + z * 4, t - 1, bd_chroma, qpc + off_c, 0, (ipm & (c == 1 ? 64 : 128)) != 0, 0,
-                                       L.sl + c * 336 + (t - 1 == 3 ? 16 : 80));
+                                       sl_tab + c * 336 + (t - 1 == 3 ? 16 : 80));
       else residual_block<false>(L, wave, lane, coef_c[c - 1] + z * 4, t - 1, bd_chroma, qpc + off_c, 0, (ipm & (c == 1 ? 64 : 128)) != 0, 0, nullptr);
     }
   }
