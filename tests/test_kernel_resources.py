@@ -1,0 +1,69 @@
+"""Resource budgets of the compiled gfx950 kernels, read from the code objects embedded in libheifhip.so (no GPU needed).
+Guards the two things that silently cost performance on this path: scratch memory in a streaming kernel (a dynamically indexed
+register array once made k_sao write 9 B/px) and a kernel sliding over an occupancy step (VGPRs / LDS per workgroup)."""
+import os
+import re
+import struct
+import subprocess
+import tempfile
+import pytest
+
+import libheif_amd
+
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def _kernels():
+    so = libheif_amd.library_path()
+    if not os.path.exists(so) or not os.path.exists(READELF):
+        pytest.skip("built library or llvm-readelf not available")
+    data = open(so, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out, pos = {}, 0
+    while True:
+        i = data.find(magic, pos)
+        if i < 0:
+            break
+        n = struct.unpack_from("<Q", data, i + 24)[0]
+        p = i + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", data, p); p += 24
+            triple = data[p:p + tl].decode(); p += tl
+            if "amdgcn" in triple and size:
+                with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
+                    f.write(data[i + off:i + off + size]); name = f.name
+                txt = subprocess.run([READELF, "--notes", name], capture_output=True, text=True).stdout
+                os.unlink(name)
+                for blk in txt.split("- .agpr_count")[1:]:
+                    g = lambda k: re.search(r"\.%s:\s+(\S+)" % k, blk)
+                    if g("name"):
+                        out[g("name").group(1)] = dict(vgpr=int(g("vgpr_count").group(1)), scratch=int(g("private_segment_fixed_size").group(1)),
+                                                       lds=int(g("group_segment_fixed_size").group(1)))
+        pos = i + 32
+    return out
+
+
+def _find(ks, *parts):
+    hits = [v for k, v in ks.items() if all(p in k for p in parts)]
+    assert hits, "kernel %s not found in libheifhip.so" % (parts,)
+    return hits
+
+
+def test_streaming_kernels_use_no_scratch_memory():
+    ks = _kernels()
+    for parts in (("k_sao",), ("k_deblock",), ("k_ycbcr_to_rgb",), ("k_bilinear",), ("k_to_sdr",), ("k_residual",), ("k_recon16",)):
+        for k in _find(ks, *parts):
+            assert k["scratch"] == 0, parts
+
+
+def test_occupancy_budgets():
+    ks = _kernels()
+    parse7 = _find(ks, "k_parse_occ7")[0]
+    assert parse7["vgpr"] <= 72 and parse7["scratch"] <= 160          # 7 waves / SIMD; the spills sit in per-CTB code
+    recon8 = _find(ks, "k_recon8")[0]
+    assert recon8["vgpr"] <= 72 and recon8["scratch"] <= 128 and recon8["lds"] <= 6400   # 7 waves / SIMD, 26 one-wave groups per CU
+    residual = _find(ks, "k_residual")[0]
+    assert residual["lds"] <= 163840 // 7 and residual["vgpr"] <= 64    # 7 workgroups of 4 waves per CU
+    assert _find(ks, "k_parse_scalar")[0]["scratch"] == 0
+    for k in _find(ks, "k_sao"):
+        assert k["lds"] <= 10240
