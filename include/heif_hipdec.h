@@ -46,7 +46,8 @@ typedef enum hipdec_status {
   HIPDEC_ERR_LIMIT = -5,             /* security limit exceeded (max_image_size_pixels)            */
   HIPDEC_ERR_DEVICE = -6,            /* HIP runtime error / no device / kernel fault               */
   HIPDEC_ERR_NO_IMAGE = -7,          /* nothing decodable was pushed                               */
-  HIPDEC_ERR_DECODE = -8             /* device-side decode error (substream desynchronised ...)    */
+  HIPDEC_ERR_DECODE = -8,            /* device-side decode error (substream desynchronised ...)    */
+  HIPDEC_ERR_MEMORY = -9             /* host allocation failed (heif_error_Memory_allocation_error) */
 } hipdec_status;
 
 /* ---- library ---------------------------------------------------------------------------------- */

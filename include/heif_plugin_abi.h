@@ -10,7 +10,7 @@
  *   heif_security_limits (head)   libheif/api/libheif/heif_security.h:37-46
  *   heif_color_profile_nclx (head) libheif/api/libheif/heif_color.h:195-204
  *   enum values                   heif_context.h:46-52, heif_image.h:55-66, :86-101, :117-119
- * tests/test_plugin_abi.py checks sizes / offsets against the real headers when /root/reference exists.
+ * tests/test_plugin_dropin.py::test_plugin_abi_matches_reference_headers checks sizes / offsets against the real headers when /root/reference exists.
  */
 #ifndef HEIF_PLUGIN_ABI_H
 #define HEIF_PLUGIN_ABI_H
@@ -56,7 +56,7 @@ typedef struct hp_decoder_options {       /* == heif_decoder_plugin_options */
   const void* limits;                     /* heif_security_limits*, plugin_api_version >= 6 */
 } hp_decoder_options;
 
-typedef struct hp_decoder_plugin {        /* == heif_decoder_plugin, plugin_api_version 5 */
+typedef struct hp_decoder_plugin {        /* == heif_decoder_plugin, plugin_api_version 6 */
   int plugin_api_version;
   const char* (*get_plugin_name)(void);
   void (*init_plugin)(void);

@@ -143,10 +143,12 @@ int hipdec_batch_create(hipdec_batch** out, int n, const void* const* data, cons
   if (!out || n <= 0 || !data || !sizes) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "batch_create: bad arguments");
   *out = nullptr;
   if (int rc = ensure_init()) return rc;
-  std::unique_ptr<hipdec_batch> b(new hipdec_batch());
-  if (int rc = build_batch(*b, n, data, sizes, max_image_size_pixels)) return rc;
-  *out = b.release();
-  return 0;
+  return guarded("batch_create", [&]() -> int {
+    std::unique_ptr<hipdec_batch> b(new hipdec_batch());
+    if (int rc = build_batch(*b, n, data, sizes, max_image_size_pixels)) return rc;
+    *out = b.release();
+    return 0;
+  });
 }
 
 void hipdec_batch_free(hipdec_batch* b) { delete b; }
@@ -348,12 +350,14 @@ int hipdec_batch_read_maps(hipdec_batch* b, int i, uint8_t* log2_tb, uint8_t* lo
 int hipdec_probe(const void* data, size_t size, uint64_t max_image_size_pixels, hipdec_image_info* info)
 {
   if (!data || !info) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "probe: bad arguments");
-  ParsedPicture pp;
-  std::string err;
-  int rc = parse_picture((const uint8_t*)data, size, max_image_size_pixels, pp, err);
-  if (rc != HIPDEC_OK) return set_error(rc, "%s", err.c_str());
-  *info = pp.info;
-  return 0;
+  return guarded("probe", [&]() -> int {
+    ParsedPicture pp;
+    std::string err;
+    int rc = parse_picture((const uint8_t*)data, size, max_image_size_pixels, pp, err);
+    if (rc != HIPDEC_OK) return set_error(rc, "%s", err.c_str());
+    *info = pp.info;
+    return 0;
+  });
 }
 
 // ---- single-image decoder: the plugin life cycle ------------------------------------------------
@@ -488,7 +492,8 @@ int hipdec_decoder_new(hipdec_decoder** out, int strict_decoding, uint64_t max_i
   if (!out) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "decoder_new: out is NULL");
   *out = nullptr;
   if (int rc = ensure_init()) return rc;  // fail loudly when there is no GPU: there is no CPU fallback
-  hipdec_decoder* d = new hipdec_decoder();
+  hipdec_decoder* d = new (std::nothrow) hipdec_decoder();
+  if (!d) return set_error(HIPDEC_ERR_MEMORY, "decoder_new: out of host memory");
   d->strict = strict_decoding; d->max_pixels = max_image_size_pixels;
   {
     std::lock_guard<std::mutex> lock(g_co.mu);
@@ -526,11 +531,15 @@ int hipdec_decoder_push_data(hipdec_decoder* d, const void* data, size_t size)
     if (n > size - ptr) return set_error(HIPDEC_ERR_END_OF_DATA, "NAL size exceeds the pushed data");
     ptr += n;
   }
-  d->data.insert(d->data.end(), p, p + size);
-  return 0;
+  return guarded("push_data", [&]() -> int { d->data.insert(d->data.end(), p, p + size); return 0; });
 }
 
+static int decoder_decode_impl(hipdec_decoder* d, hipdec_image_info* info);
 int hipdec_decoder_decode(hipdec_decoder* d, hipdec_image_info* info)
+{
+  return guarded("decode", [&]() -> int { return decoder_decode_impl(d, info); });
+}
+static int decoder_decode_impl(hipdec_decoder* d, hipdec_image_info* info)
 {
   if (!d) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "decode: NULL decoder");
   if (d->decoded) return set_error(HIPDEC_ERR_NO_IMAGE, "no further image");

@@ -30,16 +30,30 @@ class NalReader {
     for (int i = 0; i < bits; i++) v = (v << 1) | bit();
     return v;
   }
-  unsigned ue()
+  // 9.2: ue(v) with at most 31 leading zeros (values up to 2^32 - 2 never occur in a valid stream)
+  uint32_t ue()
   {
     int lz = 0;
-    while (bit() == 0) { if (++lz > 32) bad("exp-golomb code too long"); }
-    return lz == 0 ? 0u : ((1u << lz) - 1u + u(lz));
+    while (bit() == 0) { if (++lz > 31) bad("exp-golomb code too long"); }
+    return lz == 0 ? 0u : (uint32_t)(((uint64_t)1 << lz) - 1u + u(lz));
+  }
+  // ue(v) range-checked while still unsigned: every syntax element that is narrowed or used as an index goes through here
+  int ue_max(uint32_t limit, const char* what)
+  {
+    uint32_t v = ue();
+    if (v > limit) bad(std::string(what) + " out of range");
+    return (int)v;
   }
   int se()
   {
-    unsigned k = ue();
-    return (k & 1) ? (int)((k + 1) >> 1) : -(int)(k >> 1);
+    uint32_t k = ue();
+    return (k & 1) ? (int)((k >> 1) + 1) : -(int)(k >> 1);
+  }
+  int se_range(int lo, int hi, const char* what)
+  {
+    int v = se();
+    if (v < lo || v > hi) bad(std::string(what) + " out of range");
+    return v;
   }
   void skip(size_t bits) { for (size_t i = 0; i < bits; i++) bit(); }
   bool aligned() const { return bitpos_ == 0; }
@@ -103,7 +117,7 @@ void skip_hrd(NalReader& r, bool common, int max_sub)
     int cpb_cnt = 0;
     if (!fixed_general) fixed_cvs = r.u(1);
     if (fixed_cvs) r.ue(); else low_delay = r.u(1);
-    if (!low_delay) cpb_cnt = (int)r.ue();
+    if (!low_delay) cpb_cnt = r.ue_max(31, "cpb_cnt_minus1");
     if (nal) skip_sub_layer_hrd(r, cpb_cnt, sub_pic);
     if (vcl) skip_sub_layer_hrd(r, cpb_cnt, sub_pic);
   }
@@ -197,7 +211,7 @@ int parse_short_term_rps(NalReader& r, int idx, int num_sets, const std::vector<
 {
   bool inter = idx != 0 ? r.u(1) : false;
   if (inter) {
-    int delta_idx_minus1 = idx == num_sets ? (int)r.ue() : 0;
+    int delta_idx_minus1 = idx == num_sets ? r.ue_max(63, "delta_idx_minus1") : 0;
     int ref = idx - (delta_idx_minus1 + 1);
     if (ref < 0 || ref >= (int)num_delta_pocs.size()) bad("short-term RPS refers to a missing set");
     r.u(1); r.ue();
@@ -212,8 +226,7 @@ int parse_short_term_rps(NalReader& r, int idx, int num_sets, const std::vector<
     // desynchronise the parse — so reject streams that chain inter RPS prediction.
     return -n - 1;
   }
-  int nn = (int)r.ue(), np = (int)r.ue();
-  if (nn > 16 || np > 16) bad("short-term RPS too large");
+  int nn = r.ue_max(16, "num_negative_pics"), np = r.ue_max(16, "num_positive_pics");
   for (int i = 0; i < nn + np; i++) { r.ue(); r.u(1); }
   return nn + np;
 }
@@ -224,24 +237,27 @@ void parse_sps(NalReader& r, Sps& s)
   int max_sub_layers_minus1 = r.u(3);
   r.skip(1);
   skip_profile_tier_level(r, max_sub_layers_minus1);
-  unsigned id = r.ue();
-  if (id > 15) bad("sps id out of range");
-  s.chroma_format_idc = (int)r.ue();
+  r.ue_max(15, "sps_seq_parameter_set_id");
+  s.chroma_format_idc = r.ue_max(3, "chroma_format_idc");
   if (s.chroma_format_idc == 3) s.separate_colour_plane = r.u(1);
-  s.pic_width = (int)r.ue();
-  s.pic_height = (int)r.ue();
-  if (r.u(1)) { s.conf_left = (int)r.ue(); s.conf_right = (int)r.ue(); s.conf_top = (int)r.ue(); s.conf_bottom = (int)r.ue(); }
-  s.bit_depth_luma = (int)r.ue() + 8;
-  s.bit_depth_chroma = (int)r.ue() + 8;
-  s.log2_max_poc_lsb = (int)r.ue() + 4;
+  // A.4: no level allows a picture side beyond 8 * sqrt(MaxLumaPs) = 16888; 65535 keeps every later product inside 32 bits
+  s.pic_width = r.ue_max(65535, "pic_width_in_luma_samples");
+  s.pic_height = r.ue_max(65535, "pic_height_in_luma_samples");
+  if (r.u(1)) {
+    s.conf_left = r.ue_max(65535, "conf_win_left_offset"); s.conf_right = r.ue_max(65535, "conf_win_right_offset");
+    s.conf_top = r.ue_max(65535, "conf_win_top_offset"); s.conf_bottom = r.ue_max(65535, "conf_win_bottom_offset");
+  }
+  s.bit_depth_luma = r.ue_max(8, "bit_depth_luma_minus8") + 8;
+  s.bit_depth_chroma = r.ue_max(8, "bit_depth_chroma_minus8") + 8;
+  s.log2_max_poc_lsb = r.ue_max(12, "log2_max_pic_order_cnt_lsb_minus4") + 4;
   bool sub_layer_ordering = r.u(1);
   for (int i = sub_layer_ordering ? 0 : max_sub_layers_minus1; i <= max_sub_layers_minus1; i++) { r.ue(); r.ue(); r.ue(); }
-  s.log2_min_cb = (int)r.ue() + 3;
-  s.log2_ctb = s.log2_min_cb + (int)r.ue();
-  s.log2_min_tb = (int)r.ue() + 2;
-  s.log2_max_tb = s.log2_min_tb + (int)r.ue();
-  s.max_th_depth_inter = (int)r.ue();
-  s.max_th_depth_intra = (int)r.ue();
+  s.log2_min_cb = r.ue_max(3, "log2_min_luma_coding_block_size_minus3") + 3;
+  s.log2_ctb = s.log2_min_cb + r.ue_max(3, "log2_diff_max_min_luma_coding_block_size");
+  s.log2_min_tb = r.ue_max(3, "log2_min_luma_transform_block_size_minus2") + 2;
+  s.log2_max_tb = s.log2_min_tb + r.ue_max(3, "log2_diff_max_min_luma_transform_block_size");
+  s.max_th_depth_inter = r.ue_max(4, "max_transform_hierarchy_depth_inter");
+  s.max_th_depth_intra = r.ue_max(4, "max_transform_hierarchy_depth_intra");
   s.scaling_list_enabled = r.u(1);
   if (s.scaling_list_enabled) {
     scaling_lists_default(s.sl);                         // sps_infer: Table 7-5 / 7-6 unless lists follow
@@ -251,8 +267,7 @@ void parse_sps(NalReader& r, Sps& s)
   s.sao = r.u(1);
   s.pcm = r.u(1);
   if (s.pcm) unsupported("PCM coding units (pcm_enabled_flag = 1)");
-  s.num_short_term_ref_pic_sets = (int)r.ue();
-  if (s.num_short_term_ref_pic_sets > 64) bad("too many short-term RPS");
+  s.num_short_term_ref_pic_sets = r.ue_max(64, "num_short_term_ref_pic_sets");
   s.rps_num_delta_pocs.clear();
   for (int i = 0; i < s.num_short_term_ref_pic_sets; i++) {
     int n = parse_short_term_rps(r, i, s.num_short_term_ref_pic_sets, s.rps_num_delta_pocs);
@@ -265,7 +280,7 @@ void parse_sps(NalReader& r, Sps& s)
   }
   s.long_term_ref_pics_present = r.u(1);
   if (s.long_term_ref_pics_present) {
-    s.num_long_term_ref_pics_sps = (int)r.ue();
+    s.num_long_term_ref_pics_sps = r.ue_max(32, "num_long_term_ref_pics_sps");
     for (int i = 0; i < s.num_long_term_ref_pics_sps; i++) { r.skip(s.log2_max_poc_lsb); r.skip(1); }
   }
   s.temporal_mvp = r.u(1);
@@ -298,44 +313,53 @@ void parse_sps(NalReader& r, Sps& s)
   }
   if (s.chroma_format_idc != 0 && s.chroma_format_idc != 1) unsupported("chroma_format_idc " + std::to_string(s.chroma_format_idc));
   if (s.bit_depth_luma > 12 || s.bit_depth_chroma > 12) unsupported("bit depth above 12");
-  if (s.log2_ctb < 4 || s.log2_ctb > 6) bad("CTB size out of range");
-  if (s.log2_max_tb > 5 || s.log2_max_tb > s.log2_ctb || s.log2_min_tb >= s.log2_min_cb || s.log2_min_tb < 2) bad("transform block sizes out of range");
+  // 7.4.3.2.1: 3 <= MinCbLog2SizeY <= CtbLog2SizeY, CtbLog2SizeY in 4..6; 2 <= MinTbLog2SizeY < MinCbLog2SizeY;
+  // MinTbLog2SizeY <= MaxTbLog2SizeY <= Min(CtbLog2SizeY, 5); max_transform_hierarchy_depth_* <= CtbLog2SizeY - MinTbLog2SizeY
+  if (s.log2_ctb < 4 || s.log2_ctb > 6 || s.log2_min_cb < 3 || s.log2_min_cb > s.log2_ctb) bad("coding block sizes out of range");
+  if (s.log2_min_tb < 2 || s.log2_min_tb >= s.log2_min_cb || s.log2_max_tb < s.log2_min_tb || s.log2_max_tb > 5 || s.log2_max_tb > s.log2_ctb)
+    bad("transform block sizes out of range");
+  if (s.max_th_depth_intra > s.log2_ctb - s.log2_min_tb || s.max_th_depth_inter > s.log2_ctb - s.log2_min_tb)
+    bad("max_transform_hierarchy_depth out of range");
   if (s.pic_width <= 0 || s.pic_height <= 0 || (s.pic_width & ((1 << s.log2_min_cb) - 1)) || (s.pic_height & ((1 << s.log2_min_cb) - 1)))
     bad("picture size is not a multiple of the minimum coding block size");
+  {
+    const int64_t sub_w = s.chroma_format_idc == 1 || s.chroma_format_idc == 2 ? 2 : 1, sub_h = s.chroma_format_idc == 1 ? 2 : 1;
+    if (sub_w * ((int64_t)s.conf_left + s.conf_right) >= s.pic_width || sub_h * ((int64_t)s.conf_top + s.conf_bottom) >= s.pic_height)
+      bad("conformance window larger than the picture");
+  }
   s.valid = true;
 }
 
 void parse_pps(NalReader& r, Pps& p)
 {
-  unsigned id = r.ue();
-  if (id > 63) bad("pps id out of range");
-  p.sps_id = (int)r.ue();
+  r.ue_max(63, "pps_pic_parameter_set_id");
+  p.sps_id = r.ue_max(15, "pps_seq_parameter_set_id");
   p.dependent_slice_segments_enabled = r.u(1);
   p.output_flag_present = r.u(1);
   p.num_extra_slice_header_bits = r.u(3);
   p.sign_data_hiding = r.u(1);
   p.cabac_init_present = r.u(1);
-  r.ue(); r.ue();
-  p.init_qp = 26 + r.se();
+  r.ue_max(14, "num_ref_idx_l0_default_active_minus1"); r.ue_max(14, "num_ref_idx_l1_default_active_minus1");
+  p.init_qp = 26 + r.se_range(-(26 + 6 * 8), 25, "init_qp_minus26");
   p.constrained_intra_pred = r.u(1);
   p.transform_skip = r.u(1);
   p.cu_qp_delta = r.u(1);
-  if (p.cu_qp_delta) p.diff_cu_qp_delta_depth = (int)r.ue();
-  p.cb_qp_offset = r.se();
-  p.cr_qp_offset = r.se();
+  if (p.cu_qp_delta) p.diff_cu_qp_delta_depth = r.ue_max(3, "diff_cu_qp_delta_depth");
+  p.cb_qp_offset = r.se_range(-12, 12, "pps_cb_qp_offset");
+  p.cr_qp_offset = r.se_range(-12, 12, "pps_cr_qp_offset");
   p.slice_chroma_qp_offsets_present = r.u(1);
   r.skip(2);
   p.transquant_bypass = r.u(1);
   p.tiles = r.u(1);
   p.wpp = r.u(1);
   if (p.tiles) {
-    p.tile_cols = (int)r.ue() + 1;
-    p.tile_rows = (int)r.ue() + 1;
-    if (p.tile_cols > 20 || p.tile_rows > 22) bad("too many tiles");
+    p.tile_cols = r.ue_max(19, "num_tile_columns_minus1") + 1;    // A.4.1: at most 20 x 22 tiles at any level
+    p.tile_rows = r.ue_max(21, "num_tile_rows_minus1") + 1;
     p.uniform_spacing = r.u(1);
     if (!p.uniform_spacing) {
-      for (int i = 0; i < p.tile_cols - 1; i++) p.col_width.push_back((int)r.ue() + 1);
-      for (int i = 0; i < p.tile_rows - 1; i++) p.row_height.push_back((int)r.ue() + 1);
+      // a CTB row / column holds at most 65535 / 16 CTBs; the sums are checked against the picture in build_tiles
+      for (int i = 0; i < p.tile_cols - 1; i++) p.col_width.push_back(r.ue_max(4095, "column_width_minus1") + 1);
+      for (int i = 0; i < p.tile_rows - 1; i++) p.row_height.push_back(r.ue_max(4095, "row_height_minus1") + 1);
     }
     p.lf_across_tiles = r.u(1);
   }
@@ -343,7 +367,7 @@ void parse_pps(NalReader& r, Pps& p)
   if (r.u(1)) {  // deblocking_filter_control_present_flag
     p.deblocking_override_enabled = r.u(1);
     p.deblocking_disabled = r.u(1);
-    if (!p.deblocking_disabled) { p.beta_offset_div2 = r.se(); p.tc_offset_div2 = r.se(); }
+    if (!p.deblocking_disabled) { p.beta_offset_div2 = r.se_range(-6, 6, "pps_beta_offset_div2"); p.tc_offset_div2 = r.se_range(-6, 6, "pps_tc_offset_div2"); }
   }
   p.scaling_list_data_present = r.u(1);
   if (p.scaling_list_data_present) { scaling_lists_default(p.sl); parse_scaling_list_data(r, p.sl); }
@@ -368,17 +392,18 @@ TileLayout build_tiles(const Sps& s, const Pps& p, int ctb_w, int ctb_h)  // 6.5
 {
   TileLayout t;
   int nc = p.tile_cols, nr = p.tile_rows;
-  if (nc > ctb_w || nr > ctb_h) bad("more tiles than CTBs");
+  if (nc < 1 || nr < 1 || nc > 20 || nr > 22 || nc > ctb_w || nr > ctb_h) bad("more tiles than CTBs");
+  if (!p.uniform_spacing && ((int)p.col_width.size() != nc - 1 || (int)p.row_height.size() != nr - 1)) bad("tile size lists are incomplete");
   std::vector<int> cw(nc), rh(nr);
   if (p.uniform_spacing) {
     for (int i = 0; i < nc; i++) cw[i] = ((i + 1) * ctb_w) / nc - (i * ctb_w) / nc;
     for (int j = 0; j < nr; j++) rh[j] = ((j + 1) * ctb_h) / nr - (j * ctb_h) / nr;
   } else {
     int acc = 0;
-    for (int i = 0; i < nc - 1; i++) { cw[i] = p.col_width[i]; acc += cw[i]; }
+    for (int i = 0; i < nc - 1; i++) { cw[i] = p.col_width[i]; acc += cw[i]; if (cw[i] < 1 || acc >= ctb_w) bad("tile sizes exceed the picture"); }
     cw[nc - 1] = ctb_w - acc;
     acc = 0;
-    for (int j = 0; j < nr - 1; j++) { rh[j] = p.row_height[j]; acc += rh[j]; }
+    for (int j = 0; j < nr - 1; j++) { rh[j] = p.row_height[j]; acc += rh[j]; if (rh[j] < 1 || acc >= ctb_h) bad("tile sizes exceed the picture"); }
     rh[nr - 1] = ctb_h - acc;
     if (cw[nc - 1] <= 0 || rh[nr - 1] <= 0) bad("tile sizes exceed the picture");
   }
@@ -458,10 +483,10 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
         NalReader r(nal + 2, nal_size - 2);
         bool first = r.u(1);
         if (type >= 16 && type <= 23) r.skip(1);
-        unsigned pps_id = r.ue();
-        if (pps_id > 63 || !pps_tab[pps_id].valid) bad("slice refers to a missing PPS");
+        const int pps_id = r.ue_max(63, "slice_pic_parameter_set_id");
+        if (!pps_tab[pps_id].valid) bad("slice refers to a missing PPS");
         const Pps& p = pps_tab[pps_id];
-        if (p.sps_id > 15 || !sps_tab[p.sps_id].valid) bad("PPS refers to a missing SPS");
+        if (p.sps_id < 0 || p.sps_id > 15 || !sps_tab[p.sps_id].valid) bad("PPS refers to a missing SPS");
         const Sps& s = sps_tab[p.sps_id];
         if (first) {
           if (have_picture) unsupported("more than one coded picture in an item");
@@ -470,8 +495,8 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
           if (max_pixels && px > max_pixels) { err = "coded image size exceeds max_image_size_pixels"; return HIPDEC_ERR_LIMIT; }
           ctb_w = (s.pic_width + (1 << s.log2_ctb) - 1) >> s.log2_ctb;
           ctb_h = (s.pic_height + (1 << s.log2_ctb) - 1) >> s.log2_ctb;
+          if ((int64_t)ctb_w * (int64_t)ctb_h > 65535) unsupported("more than 65535 CTBs in one picture");
           n_ctb = ctb_w * ctb_h;
-          if (n_ctb > 65535) unsupported("more than 65535 CTBs in one picture");
           tiles = build_tiles(s, p, ctb_w, ctb_h);
           ctb_slice.assign(n_ctb, -1); ctb_slice_addr.assign(n_ctb, -1);
           have_picture = true;
@@ -496,8 +521,8 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
           if (!st_sps) parse_short_term_rps(r, S.num_short_term_ref_pic_sets, S.num_short_term_ref_pic_sets, S.rps_num_delta_pocs);
           else if (S.num_short_term_ref_pic_sets > 1) r.skip(ceil_log2(S.num_short_term_ref_pic_sets));
           if (S.long_term_ref_pics_present) {
-            int lt_sps = S.num_long_term_ref_pics_sps > 0 ? (int)r.ue() : 0;
-            int lt_pics = (int)r.ue();
+            int lt_sps = S.num_long_term_ref_pics_sps > 0 ? r.ue_max(32, "num_long_term_sps") : 0;
+            int lt_pics = r.ue_max(32, "num_long_term_pics");
             for (int i = 0; i < lt_sps + lt_pics; i++) {
               if (i < lt_sps) { if (S.num_long_term_ref_pics_sps > 1) r.skip(ceil_log2(S.num_long_term_ref_pics_sps)); }
               else { r.skip(S.log2_max_poc_lsb); r.skip(1); }
@@ -507,36 +532,41 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
           if (S.temporal_mvp) r.skip(1);
         }
         if (S.sao) { sl.sp.sao_luma = r.u(1); if (S.chroma_format_idc) sl.sp.sao_chroma = r.u(1); }
-        int slice_qp_delta = r.se();
+        int slice_qp_delta = r.se_range(-128, 128, "slice_qp_delta");
         int s_cb = 0, s_cr = 0;
-        if (P.slice_chroma_qp_offsets_present) { s_cb = r.se(); s_cr = r.se(); }
+        if (P.slice_chroma_qp_offsets_present) { s_cb = r.se_range(-12, 12, "slice_cb_qp_offset"); s_cr = r.se_range(-12, 12, "slice_cr_qp_offset"); }
         bool override_flag = P.deblocking_override_enabled ? r.u(1) : false;
         sl.sp.deblocking_disabled = P.deblocking_disabled;
         sl.sp.beta_offset_div2 = (int8_t)P.beta_offset_div2;
         sl.sp.tc_offset_div2 = (int8_t)P.tc_offset_div2;
         if (override_flag) {
           sl.sp.deblocking_disabled = r.u(1);
-          if (!sl.sp.deblocking_disabled) { sl.sp.beta_offset_div2 = (int8_t)r.se(); sl.sp.tc_offset_div2 = (int8_t)r.se(); }
+          if (!sl.sp.deblocking_disabled) { sl.sp.beta_offset_div2 = (int8_t)r.se_range(-6, 6, "slice_beta_offset_div2"); sl.sp.tc_offset_div2 = (int8_t)r.se_range(-6, 6, "slice_tc_offset_div2"); }
         }
         sl.sp.lf_across_slices = P.lf_across_slices;
         if (P.lf_across_slices && (sl.sp.sao_luma || sl.sp.sao_chroma || !sl.sp.deblocking_disabled)) sl.sp.lf_across_slices = r.u(1);
         sl.sp.slice_qp_y = P.init_qp + slice_qp_delta;
         if (sl.sp.slice_qp_y < -6 * (S.bit_depth_luma - 8) || sl.sp.slice_qp_y > 51) bad("SliceQpY out of range");
+        if (P.cb_qp_offset + s_cb < -12 || P.cb_qp_offset + s_cb > 12 || P.cr_qp_offset + s_cr < -12 || P.cr_qp_offset + s_cr > 12)
+          bad("chroma QP offset out of range");
         sl.sp.cb_qp_offset = (int8_t)(P.cb_qp_offset + s_cb);
         sl.sp.cr_qp_offset = (int8_t)(P.cr_qp_offset + s_cr);
         sl.sp.pps_cb_qp_offset = (int8_t)P.cb_qp_offset;
         sl.sp.pps_cr_qp_offset = (int8_t)P.cr_qp_offset;
         sl.sp.slice_addr_rs = (uint16_t)sl.segment_address;
         if (P.tiles || P.wpp) {
-          unsigned n = r.ue();
-          if ((int)n > n_ctb) bad("too many entry points");
+          const int n = r.ue_max((uint32_t)n_ctb, "num_entry_point_offsets");
           if (n > 0) {
-            int len = (int)r.ue() + 1;
-            if (len > 32) bad("offset_len_minus1 out of range");
-            for (unsigned i = 0; i < n; i++) sl.entry_point_offsets.push_back(r.u(len) + 1);
+            const int len = r.ue_max(31, "offset_len_minus1") + 1;
+            sl.entry_point_offsets.reserve((size_t)n);
+            for (int i = 0; i < n; i++) {
+              const uint64_t off = (uint64_t)r.u(len) + 1;
+              if (off > nal_size) bad("entry point beyond the slice NAL");
+              sl.entry_point_offsets.push_back((uint32_t)off);
+            }
           }
         }
-        if (P.slice_header_extension_present) { unsigned len = r.ue(); r.skip((size_t)len * 8); }
+        if (P.slice_header_extension_present) { const int len = r.ue_max(256, "slice_segment_header_extension_length"); r.skip((size_t)len * 8); }
         if (r.u(1) != 1) bad("slice header alignment bit is not 1");
         while (!r.aligned()) if (r.u(1)) bad("slice header alignment bits are not zero");
         sl.data_offset = nal_off + 2 + r.byte_pos();
@@ -671,6 +701,12 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
   } catch (const ParseError& e) {
     err = e.what();
     return e.code;
+  } catch (const std::bad_alloc&) {
+    err = "out of host memory while parsing the bitstream headers";
+    return HIPDEC_ERR_MEMORY;
+  } catch (const std::exception& e) {
+    err = std::string("bitstream header parsing failed: ") + e.what();
+    return HIPDEC_ERR_BITSTREAM;
   }
 }
 

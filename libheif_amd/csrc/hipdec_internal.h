@@ -5,6 +5,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <string>
+#include <new>
+#include <exception>
 #include "heif_hipdec.h"
 
 namespace hipdec {
@@ -36,6 +38,21 @@ void color_capture_begin();
 void color_capture_abort();
 int color_capture_launch(ColorBatchState& st, hipStream_t s);
 void color_batch_state_free(ColorBatchState& st);
+
+// No C++ exception may cross the C ABI (the caller is libheif, or cgo / JNI / ctypes): every entry point that parses untrusted
+// input or allocates runs its body through guarded().
+template <class F> int guarded(const char* what, F&& body)
+{
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return set_error(HIPDEC_ERR_MEMORY, "%s: out of host memory", what);
+  } catch (const std::exception& e) {
+    return set_error(HIPDEC_ERR_BITSTREAM, "%s: %s", what, e.what());
+  } catch (...) {
+    return set_error(HIPDEC_ERR_BITSTREAM, "%s: unknown failure", what);
+  }
+}
 
 #define HIPDEC_CHECK_HIP(expr)                                                                  \
   do {                                                                                          \

@@ -161,11 +161,23 @@ hp_error decode_next_image2(void* p, hp_image** out_img, uintptr_t* out_user_dat
     if (rc) { g_api.image_release(img); return make_error(d, rc); }
   }
   // VUI colour description -> nclx, as decoder_libde265.cc:426-449
+  // Each setter rejects values outside the enumerations it knows; like HEIF_WARN_OR_FAIL (heif_plugin.h:369-380) that is an
+  // error under strict decoding (image released, *out_img NULL) and a decoding warning on the image otherwise.
   hp_nclx_head* nclx = g_api.nclx_alloc();
   if (nclx) {
-    if (g_api.nclx_set_primaries) g_api.nclx_set_primaries(nclx, (uint16_t)info.colour_primaries);
-    if (g_api.nclx_set_transfer) g_api.nclx_set_transfer(nclx, (uint16_t)info.transfer_characteristics);
-    if (g_api.nclx_set_matrix) g_api.nclx_set_matrix(nclx, (uint16_t)info.matrix_coeffs);
+    hp_error (*const setters[3])(hp_nclx_head*, uint16_t) = {g_api.nclx_set_primaries, g_api.nclx_set_transfer, g_api.nclx_set_matrix};
+    const int values[3] = {info.colour_primaries, info.transfer_characteristics, info.matrix_coeffs};
+    for (int k = 0; k < 3; k++) {
+      if (!setters[k]) continue;
+      hp_error e = setters[k](nclx, (uint16_t)values[k]);
+      if (e.code == HP_ERR_OK) continue;
+      if (d->strict) {
+        g_api.nclx_free(nclx);
+        g_api.image_release(img);
+        return e;                      // the setters return static message strings
+      }
+      if (g_api.image_add_warning) g_api.image_add_warning(img, e);
+    }
     nclx->full_range_flag = (uint8_t)info.full_range_flag;
     g_api.image_set_nclx(img, nclx);
     g_api.nclx_free(nclx);
@@ -176,8 +188,11 @@ hp_error decode_next_image2(void* p, hp_image** out_img, uintptr_t* out_user_dat
 hp_error decode_next_image(void* p, hp_image** out, const void* limits) { return decode_next_image2(p, out, nullptr, limits); }
 hp_error decode_image(void* p, hp_image** out) { return decode_next_image2(p, out, nullptr, g_api.get_global_limits ? g_api.get_global_limits() : nullptr); }
 
+// plugin_api_version 6: new_decoder2 reads heif_decoder_plugin_options.limits, which only exists from version 6 on
+// (heif_plugin.h:70-82, "only read by plugins reporting plugin_api_version >= 6"); libheif 1.22.0 is the first release with it
+// (version table heif_plugin.h:40-48) and rejects plugins newer than it knows (heif_library.cc:75).
 const hp_decoder_plugin g_plugin = {
-    5,
+    6,
     plugin_name,
     init_plugin,
     deinit_plugin,
@@ -189,7 +204,7 @@ const hp_decoder_plugin g_plugin = {
     set_strict_decoding,
     "hipdec",
     decode_next_image,
-    (1u << 24) | (21u << 16),  // LIBHEIF_MAKE_VERSION(1,21,0): first release with plugin API 5
+    (1u << 24) | (22u << 16),  // LIBHEIF_MAKE_VERSION(1,22,0): first release with plugin API 6
     does_support_format2,
     new_decoder2,
     push_data2,
