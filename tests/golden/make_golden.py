@@ -1,7 +1,15 @@
 """Generates the committed golden vectors: seeded synthetic HEVC intra streams (test encoder) and the
-SHA-256 of the planes the CPU oracle decodes from them, plus the hashes of the oracle's decode of the
-reference's own HEVC fixtures (only hashes: the .heic files stay in /root/reference).
-Run from the repo root in the build container:  python tests/golden/make_golden.py"""
+SHA-256 of the planes the CPU oracle decodes from them, plus — the independent inputs — the plugin-framed HEVC
+streams ([u32 BE length][NAL]..., what libheif hands to push_data2, libheif/codecs/decoder.cc:275-308) of every HEVC
+item in the reference's own x265-coded fixtures and fuzz corpus:
+  ref_*.hevc        items the oracle decodes (examples/example.heic, tests/data/*.heic, fuzzing/data/corpus/*.hei[cf]),
+                    with the oracle's plane hashes;
+  ref_reject_*.hevc corpus items the oracle refuses (deliberately malformed fuzz cases): the HIP front end must refuse them
+                    too or fail loudly on the device — never hang.
+The GPU box has no /root/reference, so these extracted streams are what puts real-encoder bitstreams through the compiled
+gfx950 kernels (tests/test_golden.py).  Run from the repo root in the build container:  python tests/golden/make_golden.py"""
+import glob
+import re
 import hashlib
 import json
 import os
@@ -38,8 +46,48 @@ def main():
         index["streams"][name] = {"width": ref["width"], "height": ref["height"], "bit_depth": ref["bit_depth_luma"], "nclx": list(ref["nclx"]),
                                   "stream_sha256": hashlib.sha256(stream).hexdigest(), "planes_sha256": plane_hashes(ref["planes"])}
     refdir = "/root/reference"
+    index["reference_streams"] = {}
+    index["reference_rejects"] = {}
     if os.path.isdir(refdir):
         from heic_util import HeicFile
+        for old in glob.glob(os.path.join(HERE, "ref_*.hevc")):
+            os.remove(old)
+        rels = ["examples/example.heic", "tests/data/rainbow-451x461.heic", "tests/data/with-alpha-512x512.heic"]
+        rels += sorted(os.path.relpath(p, refdir) for p in glob.glob(os.path.join(refdir, "fuzzing/data/corpus/*.hei[cf]")))
+        seen = set()
+        per_file = {}
+        for rel in rels:
+            try:
+                f = HeicFile(os.path.join(refdir, rel))
+                items = f.hevc_items()
+            except Exception:
+                continue                      # not an ISOBMFF/HEVC file this test-side box reader handles
+            for iid in items:
+                try:
+                    stream = f.plugin_stream(iid)
+                except Exception:
+                    continue
+                sha = hashlib.sha256(stream).hexdigest()
+                if sha in seen:
+                    continue
+                seen.add(sha)
+                stem = re.sub(r"[^A-Za-z0-9]+", "_", os.path.splitext(os.path.basename(rel))[0]).strip("_")[-40:]
+                try:
+                    ref = orc.decode(stream)
+                except orc.OracleError as e:
+                    per_file[rel] = per_file.get(rel, 0) + 1
+                    if len(stream) > 4096 or per_file[rel] > 3:       # the corpus repeats near-identical items: three per file
+                        continue
+                    name = "ref_reject_%s_%d" % (stem, iid)
+                    index["reference_rejects"][name] = {"source": "%s#%d" % (rel, iid), "stream_sha256": sha, "oracle_error": str(e)[:120]}
+                else:
+                    name = "ref_%s_%d" % (stem, iid)
+                    index["reference_streams"][name] = {"source": "%s#%d" % (rel, iid), "width": ref["width"], "height": ref["height"],
+                                                        "bit_depth": ref["bit_depth_luma"], "chroma_format_idc": ref["chroma_format_idc"],
+                                                        "nclx": list(ref["nclx"]), "n_substreams": ref["n_substreams"],
+                                                        "stream_sha256": sha, "planes_sha256": plane_hashes(ref["planes"])}
+                with open(os.path.join(HERE, name + ".hevc"), "wb") as out:
+                    out.write(stream)
         for rel in ("examples/example.heic", "tests/data/rainbow-451x461.heic", "tests/data/with-alpha-512x512.heic"):
             f = HeicFile(os.path.join(refdir, rel))
             for iid in f.hevc_items():
@@ -48,7 +96,8 @@ def main():
                                                                      "planes_sha256": plane_hashes(ref["planes"])}
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(index, f, indent=1, sort_keys=True)
-    print("wrote %d streams, %d reference fixture hashes" % (len(index["streams"]), len(index["reference_fixtures"])))
+    print("wrote %d synthetic streams, %d reference streams, %d reference rejects, %d reference fixture hashes" %
+          (len(index["streams"]), len(index["reference_streams"]), len(index["reference_rejects"]), len(index["reference_fixtures"])))
 
 
 if __name__ == "__main__":

@@ -171,16 +171,20 @@ def test_errors_are_loud():
         assert ex.code in (-8, -3)
 
 
-def test_reference_fixtures_match_oracle(reference_dir):
-    from heic_util import HeicFile
-    for rel in ("examples/example.heic", "tests/data/rainbow-451x461.heic", "tests/data/with-alpha-512x512.heic"):
-        f = HeicFile(os.path.join(reference_dir, rel))
-        for iid in f.hevc_items():
-            s = f.plugin_stream(iid)
-            ref = orc.decode(s)
-            img = _decode_gpu(s)
-            for c in range(len(ref["planes"])):
-                np.testing.assert_array_equal(img.planes[c], ref["planes"][c])
+def test_reference_fixtures_match_oracle():
+    """the reference's x265-coded items (committed plugin-framed streams, tests/golden/ref_*.hevc — the GPU box has no
+    /root/reference) against the oracle run live: planes AND the parser's unit maps"""
+    import glob
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    paths = [p for p in sorted(glob.glob(os.path.join(gold, "ref_*.hevc"))) if "ref_reject_" not in p]
+    assert len(paths) >= 14
+    for p in paths:
+        s = open(p, "rb").read()
+        ref = orc.decode(s)
+        img = _decode_gpu(s)
+        assert len(img.planes) == len(ref["planes"])
+        for c in range(len(ref["planes"])):
+            np.testing.assert_array_equal(img.planes[c], ref["planes"][c], err_msg="%s component %d" % (os.path.basename(p), c))
 
 
 @pytest.mark.parametrize("size,cfg", [((3840, 2160), dict()), ((1920, 1080), dict(tile_cols=4, tile_rows=2, wpp=0)), ((1024, 1024), dict(stress=1))],
