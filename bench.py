@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
 """bench.py — Mpixel/s of the MI355X HEIC decode hot path (BASELINE.json metric).
 
-One "step" = one pass of the whole hot path over one batch of synthetic coded stills that are
-already resident in HBM: CABAC parse -> intra/transform reconstruction -> deblock -> SAO+crop ->
-fused YCbCr->RGB, all through the C ABI (include/heif_hipdec.h).  N=1 workload = BASELINE config 1
-(3840x2160 4:2:0 8-bit stills, fused YCbCr->RGB24), `--batch` independent stills per step
-(throughput form); the single-still latency form is reported beside it as `single_still`.
-With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank decodes its own batch
-(weak scaling, no data-path collective: independent stills do not exchange anything); the
-`--workload grid` form shards the 48 tiles of an 8K grid over the ranks and gathers the decoded
-tiles onto rank 0's canvas with RCCL (strong scaling).
+One "step" = one pass of the whole hot path over one batch of synthetic coded stills: CABAC parse -> dequantisation /
+inverse transforms -> intra reconstruction -> deblock -> SAO + crop -> fused YCbCr->RGB, all through the C ABI
+(include/heif_hipdec.h).  N=1 workload = BASELINE config 1 (3840x2160 4:2:0 8-bit stills, fused YCbCr->RGB24), `--batch`
+independent stills per step (throughput form).  Two timed regions are reported:
+
+  value / ms_per_step   inputs resident in HBM when the timed region starts (the bench contract): hipdec_batch_run +
+                        hipdec_batch_to_rgb_all per step;
+  from_host_bytes       SURVEY.md §8(d)'s definition, "from compressed bytes in host memory to planes + RGB complete in HBM":
+                        every step also pays hipdec_batch_create (host header parsing on worker threads, pinned staging, the
+                        H2D upload), double-buffered against the previous step's kernels.
+
+Beside them: per-kernel device times (HIP events on the launch stream) with §8(d)'s algorithmic bytes, the single-still
+latency form, the other synthetic inputs of §8(d) (S2 at QP 17, S3 grid, S4 Main10, S5 1080p) as `extra_workloads`, and the
+CPU oracle on the host cores.  With --gpus N (torch.distributed.run, one rank per GPU) every rank decodes its own batch
+(weak scaling, no data-path collective: independent stills exchange nothing); `--workload grid8k` shards the 48 tiles of
+an 8K grid over the ranks and gathers the decoded tiles onto rank 0's canvas with RCCL (strong scaling).
 
 Prints ONE JSON line (rank 0).
 """
@@ -24,30 +31,118 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
+KERNEL_KEYS = ("parse", "residual", "recon", "deblock", "sao", "colour")
+KERNEL_NAMES = {"parse": "k_parse", "residual": "k_residual", "recon": "k_recon", "deblock": "k_deblock", "sao": "k_sao", "colour": "k_ycbcr_to_rgb"}
+
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="still4k", choices=["still4k", "still1080", "grid8k"])
+    ap.add_argument("--workload", default="still4k", choices=["still4k", "still1080", "main10_4k", "grid8k"])
     ap.add_argument("--batch", type=int, default=0, help="independent stills per rank and step (0 = workload default)")
     ap.add_argument("--qp", type=int, default=27)
-    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic contents cycled through the batch")
-    ap.add_argument("--streams", type=int, default=1, help="independent sub-batches on separate HIP streams (the pipeline is instruction-issue bound: overlapping sub-batches gains nothing, measured 10.6 vs 11.0 Gpixel/s)")
+    ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic contents cycled through the batch")
     ap.add_argument("--enc", action="append", default=[], help="override a synthetic-encoder parameter, e.g. --enc wpp=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads (S2 @ QP 17, S3, S4, S5) and the from-host form")
+    ap.add_argument("--only-main", action="store_true", help="main resident measurement only (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the CPU baseline (0 = min(32, host cores))")
     return ap.parse_args()
 
 
 WORKLOADS = {
-    # name: (width, height, default batch, encoder config)
-    "still4k": (3840, 2160, 1024, dict(wpp=1)),
-    "still1080": (1920, 1080, 1024, dict(wpp=1)),
-    "grid8k": (1024, 1024, 48, dict(wpp=1, vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1)),
+    # name: (width, height, default batch, bit depth, encoder config, output heif_chroma)
+    "still4k": (3840, 2160, 1024, 8, dict(wpp=1), 10),
+    "still1080": (1920, 1080, 1024, 8, dict(wpp=1), 10),
+    "main10_4k": (3840, 2160, 256, 10, dict(wpp=1, vui_matrix=9, vui_primaries=9, vui_transfer=16), 14),
+    "grid8k": (1024, 1024, 48, 8, dict(wpp=1, vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1), 10),
 }
+
+
+def gen_streams(specs, rank=0, world=1):
+    """Synthetic inputs (outside every timed region), generated in forked worker processes BEFORE this process touches the GPU
+    or starts RCCL.  With several ranks each one codes a share of the set and picks the rest up from the on-disk cache."""
+    from tools import streamgen
+    if world > 1:
+        streamgen.make_streams([sp for i, sp in enumerate(specs) if i % world == rank], workers=max(1, (os.cpu_count() or 2) // world))
+        deadline = time.time() + 900
+        while True:
+            missing = [sp for sp in specs if not os.path.exists(streamgen.stream_path(*sp))]
+            if not missing:
+                break
+            if time.time() > deadline:
+                raise SystemExit("bench.py: synthetic streams of another rank did not appear")
+            time.sleep(0.2)
+    return streamgen.make_streams(specs)
+
+
+class Workload:
+    """n coded stills (cycled from `distinct` contents) as ONE hipdec batch + one RGB output buffer per still."""
+
+    def __init__(self, lib, name, distinct, n, out_chroma, w, h, bit_depth):
+        self.lib, self.name, self.out_chroma = lib, name, out_chroma
+        self.w, self.h, self.bit_depth = w, h, bit_depth
+        self.streams = [distinct[i % len(distinct)] for i in range(n)]
+        self.n = n
+        self.bs_bytes = sum(len(s) for s in self.streams)
+        self.px = w * h * n
+        self.batch = None
+        self.rgb = None            # the batch that owns the RGB output buffers
+
+    def make_resident(self):
+        from libheif_amd.decoder import Batch
+        self.batch = Batch(self.streams)       # host header parsing + upload: outside the resident form's timed region
+        self.batch.alloc_rgb(self.out_chroma)
+        self.rgb = self.batch
+        return self.batch
+
+    def step_resident(self):
+        self.batch.run()
+        self.batch.to_rgb_all()
+
+    def free(self):
+        if self.batch is not None:
+            self.batch.free()
+        self.batch = self.rgb = None
+
+
+def kernel_times(batch, steps):
+    acc = {k: 0.0 for k in KERNEL_KEYS + ("decode_total",)}
+    for s in range(steps):
+        t = batch.slot_kernel_timing_us(s)
+        for k in acc:
+            acc[k] += t[k]
+    return {k: v / steps for k, v in acc.items()}
+
+
+def coded_fraction(batch):
+    """coded samples per luma pixel (luma + 2 x quarter-size chroma) from the device unit maps of item 0"""
+    m = batch.maps(0)["flags"]
+    return float((m & 1).mean() + 0.25 * ((m >> 1) & 1).mean() + 0.25 * ((m >> 2) & 1).mean())
+
+
+def alg_bytes(beta, coded, s, s_out):
+    """algorithmic bytes per luma pixel: s = bytes per sample, s_out = bytes per output sample
+         parse     beta (bitstream) in + 5/16 B unit maps + 2 B per coded sample (coefficient levels) out
+         residual  2 B per coded sample in + 2 B out (in place)
+         recon     1.5 s written + 2 B per coded sample read                              (§8d "recon")
+         deblock   3 s + 1/16 (bS / QP metadata), both edge directions together          (§8d "deblock")
+         sao       1.5 s in + 1.5 s out                                                   (§8d "SAO")
+         colour    1.5 s in + 3 s_out out                                                 (§8d "fused colour stage")"""
+    return dict(parse=beta + 5 / 16 + 2 * coded, residual=4 * coded, recon=1.5 * s + 2 * coded, deblock=3 * s + 1 / 16,
+                sao=3 * s, colour=1.5 * s + 3 * s_out)
+
+
+def kernel_table(avg_us, alg, px):
+    out = {}
+    for k in KERNEL_KEYS:
+        gbs = alg[k] * px / (avg_us[k] * 1e-6) / 1e9 if avg_us[k] > 0 else 0.0
+        out[k] = dict(kernel=KERNEL_NAMES[k], avg_us=round(avg_us[k], 1), alg_bytes_per_px=round(alg[k], 4), achieved_gbs=round(gbs, 2),
+                      frac=round(gbs / HBM_PEAK_GBS, 5))
+    return out
 
 
 def main():
@@ -55,25 +150,32 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    from tools import streamgen
 
-    w, h, def_batch, enc_cfg = WORKLOADS[a.workload]
+    w, h, def_batch, bit_depth, enc_cfg, out_chroma = WORKLOADS[a.workload]
     enc_cfg = dict(enc_cfg, qp=a.qp)
     for kv in a.enc:
         k, v = kv.split("=")
         enc_cfg[k] = int(v)
     grid = a.workload == "grid8k"
+    extras_on = not (a.no_extras or a.only_main) and world == 1 and not grid
     if grid:
-        total_items = 48
-        items = [t for t in range(total_items) if t % world == rank]   # tile t -> GPU t mod G
-        specs = [(w, h, 2 + t, 8, enc_cfg) for t in items]
+        items = [t for t in range(48) if t % world == rank]   # tile t -> GPU t mod G
+        specs = [(w, h, 2 + t, 8, enc_cfg) for t in range(48)]
+        nb = len(items)
     else:
         nb = a.batch or def_batch
         nd = max(1, min(a.distinct, nb))
-        specs = [(w, h, 1 + rank * nd + i, 8, enc_cfg) for i in range(nd)]
-    # ---- synthetic inputs (outside the timed region).  Generated in forked worker processes BEFORE this process touches
-    #      the GPU or starts RCCL: forking a process that holds a HIP context / communicator threads is fragile ----
-    distinct = streamgen.make_streams(specs)
+        specs = [(w, h, 1 + i, bit_depth, enc_cfg) for i in range(nd)]      # S2 / S4 / S5: seeds 1..nd (every rank cycles the same set,
+    distinct = gen_streams(specs, rank, world)                                 # starting at its own offset)
+    extra_specs = {}
+    if extras_on:
+        extra_specs = {
+            "s2_4k_qp17": ("still4k", [(3840, 2160, 1 + i, 8, dict(wpp=1, qp=17)) for i in range(32)], 256),
+            "s4_main10_4k": ("main10_4k", [(3840, 2160, 3 + i, 10, dict(WORKLOADS["main10_4k"][4], qp=a.qp)) for i in range(32)], 256),
+            "s5_1080p": ("still1080", [(1920, 1080, 1000 + i, 8, dict(wpp=1, qp=a.qp)) for i in range(256)], 1024),
+            "s3_grid8k": ("grid8k", [(1024, 1024, 2 + t, 8, dict(WORKLOADS["grid8k"][4], qp=a.qp)) for t in range(48)], 48),
+        }
+        extra_streams = {k: gen_streams(v[1]) for k, v in extra_specs.items()}
 
     dist = None
     import torch
@@ -85,63 +187,15 @@ def main():
         raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
     torch.cuda.set_device(local_rank)
 
-    import numpy as np
     import libheif_amd
-    from libheif_amd.decoder import Batch
+    from libheif_amd.decoder import Batch, HipDecoder
     from libheif_amd._capi import check
 
     lib = libheif_amd.load_library()
     check(lib.hipdec_init(local_rank))
-
-    px_item = w * h
-    gd = None
-    if grid:
-        from libheif_amd.grid import GridDecoder, GridLayout
-        layout = GridLayout(6, 8, w, h, 8 * w, 6 * h)
-        gd = GridDecoder(dict(zip(items, distinct)), layout, rank, world)   # tiles sharded t mod G, gather to rank 0
-        batch = gd.batch
-        streams = distinct
-    else:
-        streams = [distinct[i % len(distinct)] for i in range(nb)]
-        batch = None
-    n_items = len(streams)
-    bs_bytes = sum(len(s) for s in streams)
-    # the step's stills are split into `--streams` sub-batches, each one set of launches on its own HIP stream
-    subs = []
-    if grid:
-        subs = [(batch, None)]
-    else:
-        k = max(1, min(a.streams, n_items))
-        lib.hipdec_set_concurrent_batches(k)   # the sub-batches overlap on the GPU: they share the CABAC pool's wave slots
-        for j in range(k):
-            part = streams[j::k]
-            b = Batch(part)          # parses headers on the host and uploads everything to HBM
-            b.alloc_rgb(10)
-            subs.append((b, lib.hipdec_stream_create() if k > 1 else None))
-        batch = subs[0][0]
-    for b, _ in subs:
-        b.timing_slots(max(1, a.steps))
-    single = Batch([streams[0]])
-    single.alloc_rgb(10)
-
-    def step(b):
-        if gd is not None and b is batch:
-            gd.decode()
-            if rank == 0:
-                gd.to_rgb((1, 13, 6, 1))
-            return
-        if b is single:
-            b.run()
-            b.to_rgb_all()
-            return
-        for sb, st in subs:
-            sb.run(st)
-            sb.to_rgb_all(st)
+    lib.hipdec_set_arena_cache_bytes.argtypes = [__import__("ctypes").c_size_t]
 
     def sync():
-        for _, st in subs:
-            if st:
-                check(lib.hipdec_stream_synchronize(st))
         check(lib.hipdec_stream_synchronize(None))
         torch.cuda.synchronize()
 
@@ -149,116 +203,216 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(a.warmup):
-        step(batch)
-    sync()
-    if a.warmup > 0:
-        for b, _ in subs:
-            b.status()   # device-side decode errors are loud
-    for b, _ in subs:
-        b.timing_slots(max(1, a.steps))
-    barrier(); sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(batch)
-    sync(); barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    for b, _ in subs:
-        b.status()
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed(step_fn, steps, warmup, before_timed=None):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; max over ranks"""
+        for _ in range(warmup):
+            step_fn()
+        sync()
+        if before_timed:
+            before_timed()
+        barrier(); sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        sync(); barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # main measurement: inputs resident in HBM
+    # ------------------------------------------------------------------------------------------------------------------
+    gd = None
+    if grid:
+        from libheif_amd.grid import GridDecoder, GridLayout
+        layout = GridLayout(6, 8, w, h, 8 * w, 6 * h)
+        gd = GridDecoder({t: distinct[t] for t in items}, layout, rank, world)   # tiles sharded t mod G, gather to rank 0
+        batch = gd.batch
+        n_items, px_rank, bs_bytes = len(items), w * h * len(items), sum(len(distinct[t]) for t in items)
+        total_px = w * h * 48
+
+        def step():
+            gd.decode()
+            if rank == 0:
+                gd.to_rgb((1, 13, 6, 1))
+    else:
+        off = (rank * len(distinct)) // max(1, world)
+        wl = Workload(lib, a.workload, distinct[off:] + distinct[:off], nb, out_chroma, w, h, bit_depth)
+        batch = wl.make_resident()
+        n_items, px_rank, bs_bytes = wl.n, wl.px, wl.bs_bytes
+        total_px = wl.px * world
+        step = wl.step_resident
+    batch.timing_slots(max(1, a.steps))
+    elapsed = timed(step, a.steps, a.warmup, before_timed=lambda: (batch.status(), batch.timing_slots(max(1, a.steps))))
+    batch.status()         # device-side decode errors are loud
     ms_per_step = elapsed / a.steps * 1e3
-    total_px = px_item * (48 if grid else n_items * world)
     value = total_px / (elapsed / a.steps) / 1e6
-
-    # ---- per-kernel device time over the timed region (HIP events on the launch stream) ----
-    acc = dict(parse=0.0, recon=0.0, deblock=0.0, sao=0.0, total=0.0)
-    for b, _ in subs:      # device time per kernel, summed over the sub-batches (they overlap in wall time)
-        for k in range(a.steps):
-            t = b.slot_timing_us(k)
-            for key in acc:
-                acc[key] += t[key]
-    avg_us = {k: v / a.steps for k, v in acc.items()}
-
-    # single-still latency form (one 4K still per pass)
-    for _ in range(2):
-        step(single)
-    sync()
-    ts = time.perf_counter()
-    reps = 5
-    for _ in range(reps):
-        step(single)
-    sync()
-    single_ms = (time.perf_counter() - ts) / reps * 1e3
-    single_t = single.timing_us()
-    # the plugin life cycle on one still, host to host (new_decoder -> push_data -> decode -> D2H of the planes -> free):
-    # what heif_decode_image() pays per item through libheif, PCIe included
-    from libheif_amd.decoder import HipDecoder
-    tp = time.perf_counter()
-    for _ in range(3):
-        dec = HipDecoder(); dec.push_data(streams[0]); dec.decode_next_image(); dec.free()
-    plugin_ms = (time.perf_counter() - tp) / 3 * 1e3
+    avg_us = kernel_times(batch, a.steps) if not grid else None
 
     out = None
     if rank == 0:
-        px_rank = px_item * n_items
+        s = 2 if bit_depth > 8 else 1
+        s_out = 2 if out_chroma in (12, 14) else 1
         beta = bs_bytes / px_rank
-        # coded-sample fraction of the workload (from the device unit maps of one still, outside the timed region):
-        # the parser writes and the residual / reconstruction kernels read 2 B per coded sample
-        m = single.maps(0)["flags"]
-        coded = float((m & 1).mean() + 0.25 * ((m >> 1) & 1).mean() + 0.25 * ((m >> 2) & 1).mean())
-        # algorithmic bytes per luma pixel, 8-bit samples:
-        #   parse    beta (bitstream) in + 5/16 B unit maps + 2 B per coded sample (coefficient levels) out
-        #   recon    (residual kernel + prediction wavefront) 2 x 2 B per coded sample in/out + 2 B in + 1.5 B out + maps
-        #   deblock  3 B (1.5 read + 1.5 write) per pass, two passes (vertical + horizontal edges)
-        #   sao      1.5 B in + 1.5 B out
-        alg = dict(parse=beta + 5 / 16 + 2 * coded, recon=6 * coded + 1.5 + 5 / 16, deblock=2 * 3.0, sao=3.0)
-        kernels = {}
-        for k in ("parse", "recon", "deblock", "sao"):
-            gbs = alg[k] * px_rank / (avg_us[k] * 1e-6) / 1e9 if avg_us[k] > 0 else 0.0
-            kernels[k] = dict(avg_us=round(avg_us[k], 1), alg_bytes_per_px=round(alg[k], 4), achieved_gbs=round(gbs, 2),
-                              frac=round(gbs / HBM_PEAK_GBS, 5))
-        dom = max(("parse", "recon", "deblock", "sao"), key=lambda k: avg_us[k])
-        # HBM traffic of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE separately) over this
-        # same workload, recorded per luma pixel in profiles/pmc_traffic.json by tools/prof_hbm_traffic.sh
-        traffic = None
-        try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            kname = {"parse": "k_parse", "recon": "k_recon", "deblock": "k_deblock", "sao": "k_sao"}[dom]
-            traffic = round(rec["bytes_per_px"][kname] * px_rank / len(subs), 0)
-        except Exception:
-            pass
-        roofline = dict(bound="hbm", kernel={"parse": "k_parse", "recon": "k_residual+k_recon", "deblock": "k_deblock", "sao": "k_sao"}[dom],
-                        achieved=round(kernels[dom]["achieved_gbs"] , 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=kernels[dom]["frac"], traffic=traffic,
-                        launches_per_step=len(subs),
-                        note="dominant kernel by device time (device times of the sub-batches are summed; they overlap in wall time); "
-                             "CABAC parsing is bound by instruction issue (one dependency chain per substream, ~60 wave-instructions per pixel), not by HBM (DESIGN.md §4)")
-        e2e_alg = (beta + 6.0) * px_rank   # drop-in end-to-end bytes: beta + 1.5 + 1.5 + 3
         out = {
-            "metric": "Mpixels/s HEIC 4:2:0 8-bit decode", "value": round(value, 2), "unit": "Mpixel/s",
+            "metric": "Mpixels/s HEIC 4:2:0 8-bit decode" if bit_depth == 8 else "Mpixels/s HEIC 4:2:0 %d-bit decode" % bit_depth,
+            "value": round(value, 2), "unit": "Mpixel/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong" if grid else "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic (seeded noise+gradient stills coded by the test-only HEVC intra encoder, QP %d)" % a.qp,
-            "config": {"workload": ("8K grid, 48 tiles of 1024x1024, tiles sharded over ranks" if grid else
-                                    "%dx%d HEIC 4:2:0 8-bit stills, WPP, CTB 64, fused YCbCr->RGB24" % (w, h)),
-                       "stills_per_step_per_gpu": n_items, "bitstream_bytes_per_px": round(beta, 4),
-                       "substreams_per_still": batch.info(0)["num_substreams"], "hip_streams": len(subs),
-                       "parallelism": "replicas x%d" % world},
-            "roofline": roofline,
-            "kernels": kernels,
-            "end_to_end": {"alg_bytes_per_px": round(beta + 6.0, 3),
-                           "achieved_gbs": round(e2e_alg / (elapsed / a.steps) / 1e9, 2),
-                           "frac_of_hbm_peak": round(e2e_alg / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS, 5)},
-            "single_still": {"ms": round(single_ms, 3), "mpixel_s": round(px_item / single_ms / 1e3, 2),
-                             "kernel_us": {k: round(v, 1) for k, v in single_t.items()},
-                             "plugin_lifecycle_host_to_host_ms": round(plugin_ms, 3)},
+            "dtype": "u8" if bit_depth == 8 else "u16",
+            "data": "synthetic (seeded noise+gradient stills coded by the test-only HEVC intra encoder, QP %d, %d distinct contents)" % (a.qp, len(distinct)),
+            "config": {"workload": ("8K grid, 48 tiles of 1024x1024, tiles sharded over ranks, RCCL gather, paste + colour on rank 0" if grid else
+                                    "%d x %dx%d HEIC 4:2:0 %d-bit stills per GPU and step, WPP, CTB 64, fused YCbCr->%s" %
+                                    (n_items, w, h, bit_depth, "RGB24" if out_chroma == 10 else "RRGGBB")),
+                       "timed_region": "inputs resident in HBM: hipdec_batch_run + hipdec_batch_to_rgb_all per step (from host bytes: see from_host_bytes)",
+                       "stills_per_step_per_gpu": n_items, "distinct_contents": len(distinct), "bitstream_bytes_per_px": round(beta, 4),
+                       "substreams_per_still": batch.info(0)["num_substreams"], "parallelism": "replicas x%d" % world},
         }
-        if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(streams[0], px_item, a.cpu_seconds, a.cpu_procs)
+        if avg_us is not None:
+            coded = coded_fraction(batch)
+            alg = alg_bytes(beta, coded, s, s_out)
+            kernels = kernel_table(avg_us, alg, px_rank)
+            dom = max(KERNEL_KEYS, key=lambda k: avg_us[k])
+            # HBM traffic of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE separately) over this same
+            # command line, recorded per luma pixel in profiles/pmc_traffic.json by tools/prof_hbm_traffic.sh; only used when
+            # the recorded workload is the one benchmarked now
+            traffic = None
+            try:
+                rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                if rec.get("stills_per_step") == n_items and rec.get("workload") == a.workload and rec.get("qp") == a.qp:
+                    traffic = round(rec["bytes_per_px"][KERNEL_NAMES[dom]] * px_rank, 0)
+            except Exception:
+                pass
+            out["roofline"] = dict(bound="hbm", kernel=KERNEL_NAMES[dom], achieved=kernels[dom]["achieved_gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                                   frac=kernels[dom]["frac"], traffic=traffic,
+                                   note="dominant kernel by device time; CABAC parsing is bound by instruction issue (one dependency chain per "
+                                        "substream), not by HBM (DESIGN.md §4); streaming kernels: see `kernels`")
+            out["kernels"] = kernels
+            out["coded_samples_per_px"] = round(coded, 4)
+            e2e = (beta + 3.0 * s + 3.0 * s_out) * px_rank    # drop-in end-to-end bytes (SURVEY §8d): beta + 1.5 s + 1.5 s + 3 s_out
+            out["end_to_end"] = {"alg_bytes_per_px": round(beta + 3.0 * s + 3.0 * s_out, 3), "achieved_gbs": round(e2e / (elapsed / a.steps) / 1e9, 2),
+                                 "frac_of_hbm_peak": round(e2e / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS, 5)}
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # the same workload from compressed bytes in host memory (SURVEY §8d): batch_create inside the step, double-buffered
+    # ------------------------------------------------------------------------------------------------------------------
+    if not grid and not a.only_main:
+        arena_bytes = 2 * int(6.5 * (2 if bit_depth > 8 else 1) * wl.px) + (4 << 30)
+        lib.hipdec_set_arena_cache_bytes(arena_bytes)
+        rgb_state = wl.batch.rgb_state()  # keep the RGB output buffers, retire the resident arena (it is parked for the loop below)
+        wl.free()
+        state = {"next": None, "prev": None, "host_s": 0.0, "creates": 0}
+
+        def create():
+            t = time.perf_counter()
+            b = Batch(wl.streams)         # host parse (worker threads) + pinned staging + asynchronous upload
+            b.use_rgb(rgb_state)
+            state["host_s"] += time.perf_counter() - t
+            state["creates"] += 1
+            return b
+
+        state["next"] = create()
+
+        def step_host():
+            cur = state["next"]
+            cur.run()
+            cur.to_rgb_all()
+            if state["prev"] is not None:     # batch k-1 has finished by now or does so while batch k runs
+                state["prev"].status()
+                state["prev"].free()
+            state["prev"] = cur
+            state["next"] = create()          # host work for batch k+1 overlaps the kernels of batch k
+
+        def reset_counters():
+            state["host_s"], state["creates"] = 0.0, 0
+
+        el_h = timed(step_host, a.steps, a.warmup, before_timed=reset_counters)
+        for key in ("prev", "next"):
+            if state[key] is not None:
+                if key == "prev":
+                    state[key].status()
+                state[key].free()
+        lib.hipdec_set_arena_cache_bytes(8 << 30)
+        if rank == 0:
+            out["from_host_bytes"] = {
+                "value": round(total_px / (el_h / a.steps) / 1e6, 2), "unit": "Mpixel/s", "ms_per_step": round(el_h / a.steps * 1e3, 3),
+                "host_ms_per_batch_create": round(state["host_s"] / max(1, state["creates"]) * 1e3, 2),
+                "h2d_bytes_per_step": wl.bs_bytes,
+                "timed_region": "compressed bytes in host memory -> planes + RGB complete in HBM: hipdec_batch_create (header parsing, pinned "
+                                "staging, asynchronous H2D upload) + run + colour per step; batch k+1 is created while batch k decodes"}
+        del rgb_state
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # single-still latency form, plugin life cycle
+    # ------------------------------------------------------------------------------------------------------------------
+    if rank == 0 and not a.only_main:
+        first = distinct[0]
+        single = Batch([first])
+        single.alloc_rgb(out_chroma)
+        for _ in range(2):
+            single.run(); single.to_rgb_all()
+        sync()
+        ts = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            single.run(); single.to_rgb_all()
+        sync()
+        single_ms = (time.perf_counter() - ts) / reps * 1e3
+        single_t = single.kernel_timing_us()
+        # the plugin life cycle on one still, host to host (new_decoder -> push_data -> decode -> D2H of the planes -> free):
+        # what heif_decode_image() pays per item through libheif, PCIe included
+        tp = time.perf_counter()
+        for _ in range(3):
+            dec = HipDecoder(); dec.push_data(first); dec.decode_next_image(); dec.free()
+        plugin_ms = (time.perf_counter() - tp) / 3 * 1e3
+        single.free()
+        iw, ih = (w, h)
+        out["single_still"] = {"ms": round(single_ms, 3), "mpixel_s": round(iw * ih / single_ms / 1e3, 2),
+                               "kernel_us": {k: round(v, 1) for k, v in single_t.items()},
+                               "plugin_lifecycle_host_to_host_ms": round(plugin_ms, 3)}
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # the other synthetic inputs of SURVEY §8(d), resident form, 1 warm-up + 2 timed steps each
+    # ------------------------------------------------------------------------------------------------------------------
+    if extras_on and rank == 0:
+        extras = {}
+        for key, (wname, sp, n) in extra_specs.items():
+            ew, eh, _, ebd, _, eout = WORKLOADS[wname]
+            st = extra_streams[key]
+            if wname == "grid8k":
+                from libheif_amd.grid import GridDecoder, GridLayout
+                g = GridDecoder({t: st[t] for t in range(48)}, GridLayout(6, 8, ew, eh, 8 * ew, 6 * eh), 0, 1)
+
+                def estep():
+                    g.decode(); g.to_rgb((1, 13, 6, 1))
+                el = timed(estep, 2, 1)
+                px = ew * eh * 48
+                extras[key] = {"workload": "one 8192x6144 grid photo = 48 tiles of 1024x1024 (768 substreams), batch API + paste + RGB24 on one GPU",
+                               "value": round(px / (el / 2) / 1e6, 2), "unit": "Mpixel/s", "ms_per_step": round(el / 2 * 1e3, 3),
+                               "bitstream_bytes_per_px": round(sum(len(x) for x in st) / px, 4)}
+                del g
+                continue
+            e = Workload(lib, wname, st, n, eout, ew, eh, ebd)
+            eb = e.make_resident()
+            eb.timing_slots(2)
+            el = timed(e.step_resident, 2, 1, before_timed=lambda: (eb.status(), eb.timing_slots(2)))
+            eb.status()
+            eavg = kernel_times(eb, 2)
+            es, eso = (2 if ebd > 8 else 1), (2 if eout in (12, 14) else 1)
+            ebeta = e.bs_bytes / e.px
+            extras[key] = {"workload": "%d x %dx%d %d-bit stills (%d distinct), QP %d, fused YCbCr->%s" %
+                                       (n, ew, eh, ebd, len(st), sp[0][4].get("qp", a.qp), "RGB24" if eout == 10 else "RRGGBB"),
+                           "value": round(e.px / (el / 2) / 1e6, 2), "unit": "Mpixel/s", "ms_per_step": round(el / 2 * 1e3, 3),
+                           "bitstream_bytes_per_px": round(ebeta, 4),
+                           "kernels": kernel_table(eavg, alg_bytes(ebeta, coded_fraction(eb), es, eso), e.px)}
+            e.free()
+        out["extra_workloads"] = extras
+
+    if rank == 0 and not a.no_cpu_baseline and not a.only_main and world == 1:
+        out["cpu_baseline"] = cpu_baseline(distinct[0], w * h, a.cpu_seconds, a.cpu_procs, bit_depth)
     barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -267,21 +421,24 @@ def main():
 
 
 def _cpu_worker(arg):
-    stream, budget_s, max_n = arg
+    stream, budget_s, max_n, bit_depth = arg
     from oracle import pyoracle as orc
     n = 0
     t0 = time.perf_counter()
     while True:
         r = orc.decode(stream)
         y, cb, cr = r["planes"]
-        orc.color_420_to_rgb24(y, cb, cr, (1, 13, 6, 1))
+        if bit_depth == 8:
+            orc.color_420_to_rgb24(y, cb, cr, (1, 13, 6, 1))
+        else:
+            orc.color_420_to_rrggbb(y, cb, cr, bit_depth, tuple(r["nclx"]))
         n += 1
         if time.perf_counter() - t0 > budget_s or n >= max_n:
             break
     return n, time.perf_counter() - t0
 
 
-def cpu_baseline(stream, px, budget_s, procs):
+def cpu_baseline(stream, px, budget_s, procs, bit_depth=8):
     """The CPU oracle (a scalar, spec-literal port: libde265 itself is not available here) on this host: `procs`
     independent processes, each decoding the same still of the bench workload (+ the reference's integer
     4:2:0->RGB24 op) for a bounded time; throughput = all decodes / the slowest process' time."""
@@ -289,12 +446,12 @@ def cpu_baseline(stream, px, budget_s, procs):
     procs = procs or min(32, os.cpu_count() or 1)
     per_proc_s = max(1.0, budget_s / 2)      # ~2 x budget_s core-seconds per process pair keeps the run short
     with mp.get_context("fork").Pool(procs) as pool:
-        res = pool.map(_cpu_worker, [(stream, per_proc_s, 6)] * procs)
+        res = pool.map(_cpu_worker, [(stream, per_proc_s, 6, bit_depth)] * procs)
     n = sum(r[0] for r in res)
     dt = max(r[1] for r in res)
     return {"value": round(px * n / dt / 1e6, 2), "unit": "Mpixel/s", "cores": procs, "kind": "port",
-            "sample": "%d processes x ~%d decode(s) of one still of the bench workload (CPU oracle decode + integer "
-                      "4:2:0->RGB24), %.1f s wall, %.0f core-seconds" % (procs, n // procs, dt, sum(r[1] for r in res))}
+            "sample": "%d processes x ~%d decode(s) of one still of the bench workload (CPU oracle decode + the reference's "
+                      "4:2:0->RGB op), %.1f s wall, %.0f core-seconds" % (procs, n // procs, dt, sum(r[1] for r in res))}
 
 
 if __name__ == "__main__":

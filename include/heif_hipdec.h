@@ -123,22 +123,31 @@ HIPDEC_API int hipdec_decoder_read_plane(hipdec_decoder* dec, int c, void* dst_h
 /* device-resident hand-over for callers that keep the colour stage on the GPU */
 HIPDEC_API int hipdec_decoder_device_plane(hipdec_decoder* dec, int c, const void** dptr, size_t* stride);
 
+/* Device arenas and pinned staging buffers of retired batches are parked for reuse up to this many bytes (default 8 GiB, arenas
+ * above 1 GiB not at all: right for the plugin path).  A throughput host that streams large batches raises it to about two
+ * batch arenas: hipFree() synchronises the device and would serialise "parse + upload batch k+1 while batch k decodes".
+ * 0 empties the cache. */
+HIPDEC_API int hipdec_set_arena_cache_bytes(size_t bytes);
+
 /* Number of large batches the host keeps in flight at a time on separate streams (default 1).  The CABAC work pool of a
  * batch needs all its waves resident, so concurrent batches share the device's wave slots. */
 HIPDEC_API int hipdec_set_concurrent_batches(int n);
 
 /* ---- batch decode (grid tiles / throughput mode) ------------------------------------------- */
 typedef struct hipdec_batch hipdec_batch;
-/* Parses n independent items (same framing as push_data) and uploads them; all items must share
- * chroma format and bit depth.  The timed hot path is hipdec_batch_run(): inputs are resident in
- * HBM when it starts and decoded planes are resident in HBM when it (asynchronously) ends. */
+/* Parses n independent items (same framing as push_data; host worker threads for large batches) and uploads them; all
+ * items must share chroma format and bit depth.  Large batches are staged in pinned memory and uploaded ASYNCHRONOUSLY on the
+ * library's upload stream: the call returns when the host work is done, hipdec_batch_run() orders itself behind the copy, so
+ * creating batch k+1 overlaps the kernels of batch k ("from compressed bytes in host memory").  `data` may be
+ * released when the call returns.  hipdec_batch_run() is the device-resident hot path: inputs in HBM when it starts, decoded
+ * planes in HBM when it (asynchronously) ends. */
 HIPDEC_API int hipdec_batch_create(hipdec_batch** out, int n, const void* const* data, const size_t* sizes,
                                    uint64_t max_image_size_pixels);
 HIPDEC_API void hipdec_batch_free(hipdec_batch* b);
 HIPDEC_API int hipdec_batch_count(const hipdec_batch* b);
 HIPDEC_API int hipdec_batch_info(const hipdec_batch* b, int i, hipdec_image_info* info);
 HIPDEC_API int hipdec_batch_run(hipdec_batch* b, void* stream);      /* asynchronous                 */
-HIPDEC_API int hipdec_batch_status(hipdec_batch* b);                 /* synchronises; device errors  */
+HIPDEC_API int hipdec_batch_status(hipdec_batch* b);                 /* waits for THIS batch's work (not the stream); device errors */
 HIPDEC_API int hipdec_batch_read_plane(hipdec_batch* b, int i, int c, void* dst_host, size_t dst_stride);
 HIPDEC_API int hipdec_batch_device_plane(hipdec_batch* b, int i, int c, const void** dptr, size_t* stride);
 /* Grid / multi-GPU hand-over (device-side form of HeifPixelImage::copy_image_to,
@@ -164,6 +173,10 @@ HIPDEC_API int hipdec_batch_last_timing_us(hipdec_batch* b, float out[5]);
  * average per-kernel device time over its whole timed region without synchronising between runs */
 HIPDEC_API int hipdec_batch_timing_slots(hipdec_batch* b, int slots);
 HIPDEC_API int hipdec_batch_slot_timing_us(hipdec_batch* b, int slot, float out[5]);
+/* the same per kernel: [0] CABAC parse, [1] residual (dequantisation + inverse transforms), [2] intra reconstruction,
+ * [3] deblock, [4] SAO + crop, [5] colour stage (hipdec_batch_to_rgb_all after that run; 0 if none), [6] decode total
+ * (parse .. SAO), [7] reserved */
+HIPDEC_API int hipdec_batch_slot_kernel_timing_us(hipdec_batch* b, int slot, float out[8]);
 /* debug / test taps of item i after a run (device -> host): which = 0 pre-deblock, 1 post-deblock */
 HIPDEC_API int hipdec_batch_read_tap(hipdec_batch* b, int i, int which, int c, void* dst_host, size_t dst_stride);
 HIPDEC_API int hipdec_batch_read_maps(hipdec_batch* b, int i, uint8_t* log2_tb, uint8_t* log2_cb, uint8_t* intra_luma,

@@ -20,12 +20,20 @@ struct BatchLayout {
   size_t off_rwaves = 0;
   uint32_t num_rwaves = 0;
   uint32_t num_subs = 0, num_rows = 0, num_waves = 0;
+  std::vector<ParseWave> parse_waves;   // plan -> fill
+  std::vector<ReconWave> recon_waves;
   bool wide = false;  // samples wider than 8 bit -> uint16 planes
   int max_w = 0, max_h = 0, max_ow = 0, max_oh = 0, max_ctbs = 0;
 };
 
-// Parses n items, lays the arena out ([upload region][control words][device-only buffers]) and
-// fills `host_image` with the upload region.  Returns a hipdec_status; `err` holds the message.
+// Parses n items (host worker threads for large batches) and lays the arena out ([upload region][control words][device-only
+// buffers]).  Returns a hipdec_status; `err` holds the message.
+int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size_t* sizes, uint64_t max_image_size_pixels,
+                      std::string& err);
+// Writes the upload region (b.upload_size bytes: descriptors, tables, the bitstreams as pushed) into `dst`, e.g. a pinned
+// staging buffer.  The wave tables built by the plan are released afterwards.
+void layout_batch_fill(BatchLayout& b, const void* const* data, const size_t* sizes, uint8_t* dst);
+// plan + fill into a vector (CPU-test emulation, small batches)
 int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* sizes, uint64_t max_image_size_pixels,
                  std::vector<uint8_t>& host_image, std::string& err);
 

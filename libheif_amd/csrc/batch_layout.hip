@@ -1,22 +1,56 @@
 // batch_layout.hip — see batch_layout.h.  Plain C++ (also compiled by g++ for the CPU-test emulation).
 #include "batch_layout.h"
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace hipdec {
 namespace {
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Host worker threads for the per-item work of large batches (header parsing, staging copies): items are independent, so they
+// are handed out through one atomic counter.  Small batches (the plugin path: one item, or the tiles of a grid) stay on the
+// calling thread.
+template <class F> void for_each_item(int n, size_t total_bytes, F&& fn)
+{
+  unsigned hw = std::thread::hardware_concurrency();
+  unsigned nt = hw > 16 ? 16 : hw;
+  if (const char* e = getenv("HIPDEC_HOST_THREADS")) nt = (unsigned)std::max(1, atoi(e));
+  if (n < 32 || total_bytes < (size_t(8) << 20) || nt <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+  std::atomic<int> next{0};
+  auto body = [&]() { for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < n;) fn(i); };
+  std::vector<std::thread> th;
+  try {
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(body);
+  } catch (...) {}   // could not start (all of) the workers: the calling thread does the rest
+  body();
+  for (auto& t : th) t.join();
+}
 }  // namespace
 
 int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels,
                  std::vector<uint8_t>& host, std::string& err_out)
 {
+  int rc = layout_batch_plan(b, n, data, sizes, max_pixels, err_out);
+  if (rc != HIPDEC_OK) return rc;
+  host.assign(b.upload_size, 0);
+  layout_batch_fill(b, data, sizes, host.data());
+  return HIPDEC_OK;
+}
+
+int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels, std::string& err_out)
+{
   b.pics.resize(n);
-  for (int i = 0; i < n; i++) {
-    std::string err;
-    int rc = parse_picture((const uint8_t*)data[i], sizes[i], max_pixels, b.pics[i], err);
-    if (rc != HIPDEC_OK) { err_out = "item " + std::to_string(i) + ": " + err; return rc; }
+  {
+    size_t total = 0;
+    for (int i = 0; i < n; i++) total += sizes[i];
+    std::vector<int> rcs((size_t)n, HIPDEC_OK);
+    std::vector<std::string> errs((size_t)n);
+    for_each_item(n, total, [&](int i) { rcs[i] = parse_picture((const uint8_t*)data[i], sizes[i], max_pixels, b.pics[i], errs[i]); });
+    for (int i = 0; i < n; i++)
+      if (rcs[i] != HIPDEC_OK) { err_out = "item " + std::to_string(i) + ": " + errs[i]; return rcs[i]; }
   }
   b.wide = b.pics[0].info.bit_depth_luma > 8 || b.pics[0].info.bit_depth_chroma > 8;
   for (int i = 0; i < n; i++) {
@@ -37,7 +71,8 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
   // r + W - 1 is by then well ahead, so every resident wave stays busy instead of parking one wave per
   // row behind its dependency.  W shrinks as the batch grows (the GPU holds ~7k parser waves; ~16 busy
   // waves per CU saturate its scalar pipe); a lone still keeps one wave per substream (lowest latency).
-  std::vector<ParseWave> waves;
+  std::vector<ParseWave>& waves = b.parse_waves;
+  waves.clear();
   {
     const uint32_t target_waves = 4096;
     const char* force = getenv("HIPDEC_WAVES_PER_PICTURE");   // test / tuning override
@@ -68,7 +103,8 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
   b.off_waves = off; off = align_up(off + sizeof(ParseWave) * waves.size(), 256);
   // Reconstruction wavefronts: the same dealing of a picture's CTB rows to W waves per colour component (a wave that
   // finishes row r continues with row r + W), so that in large batches the resident waves are mostly busy ones.
-  std::vector<ReconWave> rwaves;
+  std::vector<ReconWave>& rwaves = b.recon_waves;
+  rwaves.clear();
   {
     const uint32_t target = 24576;   // ~8 waves per component of a 4K still at 1024 stills in flight (measured optimum 4-16)
     const char* force = getenv("HIPDEC_RECON_WAVES_PER_PICTURE");
@@ -183,14 +219,20 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
     }
   }
   b.arena_size = off;
+  return HIPDEC_OK;
+}
 
-  // ---- stage + upload ----
-  host.assign(b.upload_size, 0);
-  memcpy(host.data() + b.off_pics, b.params.data(), sizeof(PicParams) * n);
-  memcpy(host.data() + b.off_waves, waves.data(), sizeof(ParseWave) * waves.size());
-  memcpy(host.data() + b.off_rwaves, rwaves.data(), sizeof(ReconWave) * rwaves.size());
-  Substream* subs = (Substream*)(host.data() + b.off_subs);
-  RowDesc* rows = (RowDesc*)(host.data() + b.off_rows);
+void layout_batch_fill(BatchLayout& b, const void* const* data, const size_t* sizes, uint8_t* host)
+{
+  const int n = (int)b.pics.size();
+  // alignment gaps of the descriptor area are zeroed; the gap behind every bitstream (the parser's window loads run up to 512 B
+  // past the end) is zeroed with the bitstream copy below
+  memset(host, 0, b.params.empty() ? b.upload_size : std::min(b.upload_size, (size_t)b.params[0].off_ctb_ts_to_rs));
+  memcpy(host + b.off_pics, b.params.data(), sizeof(PicParams) * n);
+  memcpy(host + b.off_waves, b.parse_waves.data(), sizeof(ParseWave) * b.parse_waves.size());
+  memcpy(host + b.off_rwaves, b.recon_waves.data(), sizeof(ReconWave) * b.recon_waves.size());
+  Substream* subs = (Substream*)(host + b.off_subs);
+  RowDesc* rows = (RowDesc*)(host + b.off_rows);
   uint32_t sub_base = 0, r = 0;
   for (int i = 0; i < n; i++) {
     const ParsedPicture& pp = b.pics[i];
@@ -206,13 +248,25 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
       if (subs[sub_base + k].dep_sub >= 0) subs[subs[sub_base + k].dep_sub].dependent = (int32_t)(sub_base + k);
     sub_base += (uint32_t)pp.subs.size();
     for (int y = 0; y < P.ctb_h; y++) { rows[r].pic = (uint32_t)i; rows[r].row = (uint32_t)y; r++; }
-    memcpy(host.data() + P.off_ctb_ts_to_rs, pp.ts_to_rs.data(), pp.ts_to_rs.size() * sizeof(uint16_t));
-    memcpy(host.data() + P.off_ctb_info, pp.ctb_info.data(), pp.ctb_info.size() * sizeof(CtbInfo));
-    memcpy(host.data() + P.off_slices, pp.slice_params.data(), pp.slice_params.size() * sizeof(SliceParams));
-    if (P.scaling_lists) memcpy(host.data() + P.off_scaling, pp.scaling_tables.data(), pp.scaling_tables.size());
-    memcpy(host.data() + P.off_bitstream, data[i], sizes[i]);
   }
-  return HIPDEC_OK;
+  size_t total = 0;
+  for (int i = 0; i < n; i++) total += sizes[i];
+  for_each_item(n, total, [&](int i) {
+    const ParsedPicture& pp = b.pics[i];
+    const PicParams& P = b.params[i];
+    const size_t end = i + 1 < n ? (size_t)b.params[i + 1].off_ctb_ts_to_rs : b.upload_size;   // this item's slice of the upload region
+    auto put = [&](size_t off, const void* src, size_t bytes, size_t next) {
+      memcpy(host + off, src, bytes);
+      memset(host + off + bytes, 0, next - off - bytes);
+    };
+    put(P.off_ctb_ts_to_rs, pp.ts_to_rs.data(), pp.ts_to_rs.size() * sizeof(uint16_t), P.off_ctb_info);
+    put(P.off_ctb_info, pp.ctb_info.data(), pp.ctb_info.size() * sizeof(CtbInfo), P.off_slices);
+    put(P.off_slices, pp.slice_params.data(), pp.slice_params.size() * sizeof(SliceParams), P.off_scaling);
+    if (P.scaling_lists) put(P.off_scaling, pp.scaling_tables.data(), pp.scaling_tables.size(), P.off_bitstream);
+    put(P.off_bitstream, data[i], sizes[i], end);
+  });
+  b.parse_waves.clear(); b.parse_waves.shrink_to_fit();
+  b.recon_waves.clear(); b.recon_waves.shrink_to_fit();
 }
 
 }  // namespace hipdec

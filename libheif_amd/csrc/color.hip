@@ -437,11 +437,10 @@ int color_capture_launch(ColorBatchState& st, hipStream_t s)
   const size_t bytes = caps.size() * sizeof(ColorParams);
   std::vector<uint8_t> host(bytes);
   for (size_t i = 0; i < caps.size(); i++) memcpy(host.data() + i * sizeof(ColorParams), &caps[i].p, sizeof(ColorParams));
-  if (st.dev_bytes < bytes) {
-    if (st.dev) (void)hipFree(st.dev);
+  if (st.dev_bytes < bytes) {   // from the arena pool: hipFree() would synchronise the device every time a batch is retired
+    if (st.dev) arena_release(st.dev, st.dev_bytes);
     st.dev = nullptr; st.dev_bytes = 0; st.host.clear();
-    HIPDEC_CHECK_HIP(hipMalloc(&st.dev, bytes));
-    st.dev_bytes = bytes;
+    HIPDEC_CHECK_HIP(arena_acquire(&st.dev, bytes, &st.dev_bytes));
   }
   if (st.host != host) {   // steady state (same planes, same outputs): nothing to upload
     st.host.swap(host);
@@ -461,7 +460,7 @@ int color_capture_launch(ColorBatchState& st, hipStream_t s)
 
 void color_batch_state_free(ColorBatchState& st)
 {
-  if (st.dev) (void)hipFree(st.dev);
+  if (st.dev) arena_release(st.dev, st.dev_bytes);
   st.dev = nullptr; st.dev_bytes = 0; st.host.clear();
 }
 

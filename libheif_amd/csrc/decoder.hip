@@ -24,36 +24,81 @@
 
 using namespace hipdec;
 
+constexpr int kEv = 8;   // events per timing slot: start, parse, residual, recon, deblock, sao | colour begin, colour end
+
 struct hipdec_batch : BatchLayout {
   uint8_t* arena = nullptr;
   size_t arena_capacity = 0;
-  std::vector<hipEvent_t> ev;   // 5 events per timing slot; run k records into slot k % slots
+  void* staging = nullptr;      // pinned upload staging (large batches), returned to its pool once the upload has completed
+  size_t staging_capacity = 0;
+  hipEvent_t uploaded = nullptr;   // recorded on the upload stream behind the H2D copy; launch streams wait on it
+  hipEvent_t done = nullptr;       // recorded behind the last piece of work enqueued for this batch (decode, colour stage, packs)
+  bool done_recorded = false;
+  std::vector<hipEvent_t> ev;   // kEv events per timing slot; run k records into slot k % slots
+  std::vector<uint8_t> colour_timed;   // per slot: the colour stage of that run was recorded
   uint64_t runs = 0;
   hipStream_t last_stream = nullptr;
   bool ran = false;
   ColorBatchState color;        // parameter blocks of hipdec_batch_to_rgb_all
+  // Waits for everything enqueued for THIS batch — not for the stream, which may already carry the next batch.
+  hipError_t wait() const
+  {
+    hipError_t e = hipSuccess;
+    if (uploaded) e = hipEventSynchronize(uploaded);
+    if (e == hipSuccess && done_recorded) e = hipEventSynchronize(done);
+    return e;
+  }
+  void mark_done(hipStream_t s)
+  {
+    if (done && hipEventRecord(done, s) == hipSuccess) done_recorded = true;
+  }
+  void release_staging()
+  {
+    if (!staging) return;
+    if (uploaded) (void)hipEventSynchronize(uploaded);
+    pinned_release(staging, staging_capacity);
+    staging = nullptr;
+  }
   ~hipdec_batch()
   {
+    if (arena || staging) (void)wait();   // nothing of this batch may still be running when the arena is recycled
+    release_staging();
     color_batch_state_free(color);
-    if (arena) {
-      if (last_stream) (void)hipStreamSynchronize(last_stream);   // nothing of this batch may still be running when the arena is recycled
-      arena_release(arena, arena_capacity);
-    }
+    if (arena) arena_release(arena, arena_capacity);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    if (uploaded) (void)hipEventDestroy(uploaded);
+    if (done) (void)hipEventDestroy(done);
   }
 };
 
 namespace {
 
+// The host side of "compressed bytes in host memory -> decode" (SURVEY.md §8d): header parsing (worker threads for large
+// batches), staging and the upload.  Large upload regions go through pinned staging and ONE asynchronous copy on the
+// library's upload stream, so that hipdec_batch_create() of batch k+1 overlaps the kernels of batch k; small ones (a still, the
+// tiles of a grid photo) are copied synchronously from pageable memory, which is quicker than pinning.
 int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels)
 {
   std::string err;
-  std::vector<uint8_t> host;
-  int rc = layout_batch(b, n, data, sizes, max_pixels, host, err);
+  int rc = layout_batch_plan(b, n, data, sizes, max_pixels, err);
   if (rc != HIPDEC_OK) return set_error(rc, "%s", err.c_str());
-  HIPDEC_CHECK_HIP(arena_acquire((void**)&b.arena, b.arena_size, &b.arena_capacity));
-  HIPDEC_CHECK_HIP(hipMemcpy(b.arena, host.data(), b.upload_size, hipMemcpyHostToDevice));
-  b.ev.assign(5, nullptr);
+  HIPDEC_CHECK_HIP(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+  if (b.upload_size > (size_t(4) << 20)) {
+    HIPDEC_CHECK_HIP(pinned_acquire(&b.staging, b.upload_size, &b.staging_capacity));
+    layout_batch_fill(b, data, sizes, (uint8_t*)b.staging);
+    HIPDEC_CHECK_HIP(arena_acquire((void**)&b.arena, b.arena_size, &b.arena_capacity));
+    HIPDEC_CHECK_HIP(hipEventCreateWithFlags(&b.uploaded, hipEventDisableTiming));
+    hipStream_t us = upload_stream();
+    HIPDEC_CHECK_HIP(hipMemcpyAsync(b.arena, b.staging, b.upload_size, hipMemcpyHostToDevice, us));
+    HIPDEC_CHECK_HIP(hipEventRecord(b.uploaded, us));
+  } else {
+    std::vector<uint8_t> host(b.upload_size);
+    layout_batch_fill(b, data, sizes, host.data());
+    HIPDEC_CHECK_HIP(arena_acquire((void**)&b.arena, b.arena_size, &b.arena_capacity));
+    HIPDEC_CHECK_HIP(hipMemcpy(b.arena, host.data(), b.upload_size, hipMemcpyHostToDevice));
+  }
+  b.ev.assign(kEv, nullptr);
+  b.colour_timed.assign(1, 0);
   for (auto& e : b.ev) HIPDEC_CHECK_HIP(hipEventCreate(&e));
   return 0;
 }
@@ -92,8 +137,11 @@ int launch_all(hipdec_batch& b, hipStream_t s)
     fprintf(stderr, "[hipdec] %s: %s\n", what, hipGetErrorString(e)); fflush(stderr);
     return e == hipSuccess ? 0 : set_error(HIPDEC_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
   };
-  hipEvent_t* ev = b.ev.data() + 5 * (b.runs % (b.ev.size() / 5));
+  const size_t slot = b.runs % (b.ev.size() / kEv);
+  hipEvent_t* ev = b.ev.data() + kEv * slot;
+  b.colour_timed[slot] = 0;
   b.runs++;
+  if (b.uploaded) HIPDEC_CHECK_HIP(hipStreamWaitEvent(s, b.uploaded, 0));
   HIPDEC_CHECK_HIP(hipMemsetAsync(b.arena + b.off_ctrl, 0, b.ctrl_size, s));
   HIPDEC_CHECK_HIP(hipEventRecord(ev[0], s));
   if (int rc = step("memset")) return rc;
@@ -102,16 +150,19 @@ int launch_all(hipdec_batch& b, hipStream_t s)
   if (int rc = step("parse")) return rc;
   static const bool parse_only = getenv("HIPDEC_DEBUG_PARSE_ONLY") != nullptr;   // tuning knob: isolate the CABAC kernel
   if (!parse_only) launch_residual(fa, n, b.max_ctbs, s);
-  if (!parse_only) launch_recon(ra, b.wide, s);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[2], s));
+  if (int rc = step("residual")) return rc;
+  if (!parse_only) launch_recon(ra, b.wide, s);
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[3], s));
   if (int rc = step("recon")) return rc;
   if (!parse_only) launch_deblock(fa, n, b.max_w, b.max_h, b.wide, s);
-  HIPDEC_CHECK_HIP(hipEventRecord(ev[3], s));
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[4], s));
   if (int rc = step("deblock")) return rc;
   if (!parse_only) launch_sao(fa, n, b.max_ow, b.max_oh, b.wide, s);
-  HIPDEC_CHECK_HIP(hipEventRecord(ev[4], s));
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[5], s));
   if (int rc = step("sao")) return rc;
   HIPDEC_CHECK_HIP(hipGetLastError());
+  b.mark_done(s);
   return 0;
 }
 
@@ -175,8 +226,9 @@ int hipdec_batch_status(hipdec_batch* b)
 {
   if (!b || !b->ran) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "batch_status: batch has not been run");
   if (int rc = ensure_init()) return rc;
-  hipError_t e = hipStreamSynchronize(b->last_stream);
+  hipError_t e = b->wait();
   if (e != hipSuccess) return set_error(HIPDEC_ERR_DEVICE, "decode kernels failed: %s", hipGetErrorString(e));
+  b->release_staging();
   int32_t st = 0;
   HIPDEC_CHECK_HIP(hipMemcpy(&st, b->arena + b->off_status, sizeof(st), hipMemcpyDeviceToHost));
   if (st != 0) return set_error(HIPDEC_ERR_DECODE, "device decode error 0x%x: %s", st, dev_err_name(st));
@@ -221,6 +273,7 @@ int hipdec_batch_pack_item(hipdec_batch* b, int i, void* dst_dev, size_t dst_byt
     if (w && h) HIPDEC_CHECK_HIP(hipMemcpy2DAsync(dst, w * es, b->arena + P.off_out[c], P.out_stride[c], w * es, h, hipMemcpyDeviceToDevice, s));
     dst += w * h * es;
   }
+  b->mark_done(s);
   return 0;
 }
 
@@ -244,6 +297,10 @@ int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void* out_dev, s
   hipdec_nclx nclx{1, I.colour_primaries, I.transfer_characteristics, I.matrix_coeffs, I.full_range_flag};
   const uint8_t* y = b->arena + P.off_out[0]; const uint8_t* cb = b->arena + P.off_out[1]; const uint8_t* cr = b->arena + P.off_out[2];
   void* s = stream ? stream : (void*)b->last_stream;
+  struct MarkDone {   // whatever is enqueued below belongs to this batch (hipdec_batch_status / free wait for it)
+    hipdec_batch* b; hipStream_t s;
+    ~MarkDone() { b->mark_done(s ? s : default_stream()); }
+  } mark{b, (hipStream_t)s};
   if (out_chroma == 10 || out_chroma == 11) {
     if (b->wide) return set_error(HIPDEC_ERR_UNSUPPORTED, "to_rgb: 8-bit interleaved output from >8-bit planes needs hipdec_color_to_sdr first");
     // planner rule: integer op only for full range and a matrix it accepts
@@ -270,41 +327,66 @@ int hipdec_batch_to_rgb_all(hipdec_batch* b, int out_chroma, void* const* outs_d
   color_capture_begin();
   for (int i = 0; i < (int)b->pics.size(); i++)
     if (int rc = hipdec_batch_to_rgb(b, i, out_chroma, outs_dev[i], out_strides[i], (void*)s)) { color_capture_abort(); return rc; }
-  return color_capture_launch(b->color, s);
+  // device time of the colour stage goes into the timing slot of the decode run it follows
+  const size_t slot = b->runs ? (b->runs - 1) % (b->ev.size() / kEv) : 0;
+  hipEvent_t* ev = b->ev.data() + kEv * slot;
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[6], s));
+  int rc = color_capture_launch(b->color, s);
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[7], s));
+  if (!rc && b->runs) b->colour_timed[slot] = 1;
+  b->mark_done(s);
+  return rc;
 }
 
 int hipdec_batch_timing_slots(hipdec_batch* b, int slots)
 {
   if (!b || slots < 1 || slots > 4096) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "timing_slots: bad arguments");
-  if (b->ran) HIPDEC_CHECK_HIP(hipStreamSynchronize(b->last_stream));
+  if (b->ran) HIPDEC_CHECK_HIP(b->wait());
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
-  b->ev.assign((size_t)slots * 5, nullptr);
+  b->ev.assign((size_t)slots * kEv, nullptr);
+  b->colour_timed.assign((size_t)slots, 0);
   for (auto& e : b->ev) HIPDEC_CHECK_HIP(hipEventCreate(&e));
   b->runs = 0; b->ran = false;
   return 0;
 }
 
-int hipdec_batch_slot_timing_us(hipdec_batch* b, int slot, float out[5])
+int hipdec_batch_slot_kernel_timing_us(hipdec_batch* b, int slot, float out[8])
 {
-  if (!b || !out || slot < 0 || (size_t)slot >= b->ev.size() / 5 || (uint64_t)slot >= b->runs)
+  if (!b || !out || slot < 0 || (size_t)slot >= b->ev.size() / kEv || (uint64_t)slot >= b->runs)
     return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "slot_timing: no run recorded in slot %d", slot);
-  hipEvent_t* ev = b->ev.data() + 5 * (size_t)slot;
-  HIPDEC_CHECK_HIP(hipEventSynchronize(ev[4]));
-  for (int k = 0; k < 4; k++) {
+  hipEvent_t* ev = b->ev.data() + kEv * (size_t)slot;
+  HIPDEC_CHECK_HIP(hipEventSynchronize(ev[5]));
+  for (int k = 0; k < 5; k++) {
     float ms = 0;
     HIPDEC_CHECK_HIP(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
     out[k] = ms * 1000.0f;
   }
+  out[5] = 0.0f;
+  if (b->colour_timed[(size_t)slot]) {
+    float ms = 0;
+    HIPDEC_CHECK_HIP(hipEventSynchronize(ev[7]));
+    HIPDEC_CHECK_HIP(hipEventElapsedTime(&ms, ev[6], ev[7]));
+    out[5] = ms * 1000.0f;
+  }
   float ms = 0;
-  HIPDEC_CHECK_HIP(hipEventElapsedTime(&ms, ev[0], ev[4]));
-  out[4] = ms * 1000.0f;
+  HIPDEC_CHECK_HIP(hipEventElapsedTime(&ms, ev[0], ev[5]));
+  out[6] = ms * 1000.0f;
+  out[7] = 0.0f;
+  return 0;
+}
+
+int hipdec_batch_slot_timing_us(hipdec_batch* b, int slot, float out[5])
+{
+  float k[8];
+  if (int rc = hipdec_batch_slot_kernel_timing_us(b, slot, k)) return rc;
+  out[0] = k[0]; out[1] = k[1] + k[2]; out[2] = k[3]; out[3] = k[4]; out[4] = k[6];
   return 0;
 }
 
 int hipdec_batch_last_timing_us(hipdec_batch* b, float out[5])
 {
   if (!b || !b->ran || !out) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "last_timing: batch has not been run");
-  return hipdec_batch_slot_timing_us(b, (int)((b->runs - 1) % (b->ev.size() / 5)), out);
+  return hipdec_batch_slot_timing_us(b, (int)((b->runs - 1) % (b->ev.size() / kEv)), out);
 }
 
 int hipdec_batch_read_tap(hipdec_batch* b, int i, int which, int c, void* dst, size_t dst_stride)

@@ -14,6 +14,7 @@ namespace hipdec {
 int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 int ensure_init();
 hipStream_t default_stream();
+hipStream_t upload_stream();    // H2D copies of large batches (overlaps the kernels of the batch before)
 uint32_t parse_wave_budget();   // CABAC pool waves one batch may launch (wave slots / concurrent batches)
 
 // Process-wide pool of decode arenas.  libheif creates and destroys one plugin decoder per item and per grid tile
@@ -21,6 +22,9 @@ uint32_t parse_wave_budget();   // CABAC pool waves one batch may launch (wave s
 hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity);
 void arena_release(void* p, size_t capacity);
 void arena_pool_clear();
+hipError_t pinned_acquire(void** out, size_t bytes, size_t* capacity);   // pinned host staging for large uploads, recycled
+void pinned_release(void* p, size_t capacity);
+void pinned_pool_clear();
 
 // A small pool of HIP streams: concurrent plugin decoder instances (libheif decodes grid tiles on several threads,
 // libheif/image-items/grid.cc:436) each run on their own stream so that their kernels overlap on the GPU.

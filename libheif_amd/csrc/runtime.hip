@@ -15,6 +15,7 @@ static std::mutex g_init_mutex;
 static bool g_initialised = false;
 static int g_device = 0;
 static hipStream_t g_stream = nullptr;
+static hipStream_t g_upload_stream = nullptr;
 static int g_cu_count = 256;                 // compute units of the selected device
 static std::atomic<int> g_concurrent{1};      // batches the host keeps in flight at a time (hipdec_set_concurrent_batches)
 
@@ -41,6 +42,7 @@ int ensure_init()
 }
 
 hipStream_t default_stream() { return g_stream; }
+hipStream_t upload_stream() { return g_upload_stream ? g_upload_stream : g_stream; }
 
 // Waves of the CABAC work pool one batch may launch: the pool only works while ALL its waves are resident (7 per SIMD with
 // the kernel's register budget), so concurrent batches have to share the machine's wave slots.
@@ -58,15 +60,64 @@ struct ArenaPool {
   size_t cached_bytes = 0;
 };
 ArenaPool g_pool;
-constexpr size_t kMaxCachedBytes = size_t(8) << 30;    // keep at most 8 GiB parked
-constexpr size_t kMaxPooledArena = size_t(1) << 30;    // bigger arenas (large batches) are not worth caching
+// Defaults suit the plugin path (one arena per item / grid photo).  A throughput host that streams large batches raises both
+// with hipdec_set_arena_cache_bytes(): hipFree() of a batch arena synchronises the device, which would serialise the
+// double-buffered "parse + upload batch k+1 while batch k decodes" pipeline.
+std::atomic<size_t> g_max_cached_bytes{size_t(8) << 30};    // keep at most 8 GiB parked
+std::atomic<size_t> g_max_pooled_arena{size_t(1) << 30};    // bigger arenas are not cached by default
+
+struct PinnedPool {
+  std::mutex mu;
+  std::vector<std::pair<size_t, void*>> free_list;
+};
+PinnedPool g_pinned;
 }  // namespace
+
+// Pinned host staging buffers for the upload region of large batches (so that the H2D copy is asynchronous and runs at PCIe
+// speed); recycled, because hipHostMalloc of a GiB costs more than the copy it feeds.
+hipError_t pinned_acquire(void** out, size_t bytes, size_t* capacity)
+{
+  const size_t kClass = size_t(16) << 20;
+  bytes = (bytes + kClass - 1) / kClass * kClass;
+  {
+    std::lock_guard<std::mutex> lock(g_pinned.mu);
+    size_t best = SIZE_MAX;
+    for (size_t i = 0; i < g_pinned.free_list.size(); i++) {
+      const size_t cap = g_pinned.free_list[i].first;
+      if (cap >= bytes && cap <= 2 * bytes && (best == SIZE_MAX || cap < g_pinned.free_list[best].first)) best = i;
+    }
+    if (best != SIZE_MAX) {
+      *out = g_pinned.free_list[best].second; *capacity = g_pinned.free_list[best].first;
+      g_pinned.free_list.erase(g_pinned.free_list.begin() + (long)best);
+      return hipSuccess;
+    }
+  }
+  *capacity = bytes;
+  return hipHostMalloc(out, bytes, hipHostMallocDefault);
+}
+
+void pinned_release(void* p, size_t capacity)
+{
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lock(g_pinned.mu);
+    if (g_pinned.free_list.size() < 4) { g_pinned.free_list.emplace_back(capacity, p); return; }
+  }
+  (void)hipHostFree(p);
+}
+
+void pinned_pool_clear()
+{
+  std::lock_guard<std::mutex> lock(g_pinned.mu);
+  for (auto& e : g_pinned.free_list) (void)hipHostFree(e.second);
+  g_pinned.free_list.clear();
+}
 
 hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity)
 {
   // round small arenas up so that items of similar size share a class
   const size_t kClass = size_t(4) << 20;
-  if (bytes <= kMaxPooledArena) bytes = (bytes + kClass - 1) / kClass * kClass;
+  if (bytes <= g_max_pooled_arena.load()) bytes = (bytes + kClass - 1) / kClass * kClass;
   {
     std::lock_guard<std::mutex> lock(g_pool.mu);
     size_t best = SIZE_MAX;
@@ -94,9 +145,9 @@ hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity)
 void arena_release(void* p, size_t capacity)
 {
   if (!p) return;
-  if (capacity <= kMaxPooledArena) {
+  if (capacity <= g_max_pooled_arena.load()) {
     std::lock_guard<std::mutex> lock(g_pool.mu);
-    if (g_pool.cached_bytes + capacity <= kMaxCachedBytes) {
+    if (g_pool.cached_bytes + capacity <= g_max_cached_bytes.load()) {
       g_pool.free_list.emplace_back(capacity, p);
       g_pool.cached_bytes += capacity;
       return;
@@ -160,6 +211,8 @@ int hipdec_init(int device_index)
   }
   if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
   HIPDEC_CHECK_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  if (g_upload_stream) { (void)hipStreamDestroy(g_upload_stream); g_upload_stream = nullptr; }
+  HIPDEC_CHECK_HIP(hipStreamCreateWithFlags(&g_upload_stream, hipStreamNonBlocking));
   g_device = dev;
   g_initialised = true;
   return 0;
@@ -170,13 +223,23 @@ void hipdec_shutdown(void)
   std::lock_guard<std::mutex> lock(g_init_mutex);
   if (!g_initialised) return;
   arena_pool_clear();
+  pinned_pool_clear();
   {
     std::lock_guard<std::mutex> lock(g_stream_mu);
     for (auto st : g_free_streams) (void)hipStreamDestroy(st);
     g_free_streams.clear();
   }
   if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+  if (g_upload_stream) { (void)hipStreamDestroy(g_upload_stream); g_upload_stream = nullptr; }
   g_initialised = false;
+}
+
+int hipdec_set_arena_cache_bytes(size_t bytes)
+{
+  g_max_cached_bytes.store(bytes);
+  g_max_pooled_arena.store(bytes > (size_t(1) << 30) ? bytes : (size_t(1) << 30));
+  if (bytes == 0) { arena_pool_clear(); pinned_pool_clear(); }
+  return 0;
 }
 
 int hipdec_set_concurrent_batches(int n)

@@ -40,6 +40,7 @@ def _bind(lib):
     lib.hipdec_copy2d_d2d.argtypes = [vp, sz, vp, sz, sz, sz, vp]
     lib.hipdec_batch_timing_slots.argtypes = [vp, ci]
     lib.hipdec_batch_slot_timing_us.argtypes = [vp, ci, C.POINTER(C.c_float)]
+    lib.hipdec_batch_slot_kernel_timing_us.argtypes = [vp, ci, C.POINTER(C.c_float)]
     lib.hipdec_batch_read_tap.argtypes = [vp, ci, ci, ci, vp, sz]
     lib.hipdec_batch_read_maps.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, sz]
     lib._dec_bound = True
@@ -179,6 +180,13 @@ class Batch:
         self._rgb_ptrs = (C.c_void_p * self.n)(*[buf.ptr for buf, _, _ in self._rgb])
         self._rgb_strides = (C.c_size_t * self.n)(*[stride for _, stride, _ in self._rgb])
 
+    def rgb_state(self):
+        """the pre-allocated output buffers (device memory owned by Python objects), to hand to another batch of the same shape"""
+        return (self._rgb, self._rgb_chroma, self._rgb_ptrs, self._rgb_strides)
+
+    def use_rgb(self, state):
+        self._rgb, self._rgb_chroma, self._rgb_ptrs, self._rgb_strides = state
+
     def to_rgb_all(self, stream=None):
         """asynchronous: fused colour stage over every item's planes into the pre-allocated buffers, ONE launch"""
         check(self._lib.hipdec_batch_to_rgb_all(self._h, self._rgb_chroma, self._rgb_ptrs, self._rgb_strides, stream))
@@ -200,6 +208,18 @@ class Batch:
         t = (C.c_float * 5)()
         check(self._lib.hipdec_batch_slot_timing_us(self._h, slot, t))
         return dict(parse=t[0], recon=t[1], deblock=t[2], sao=t[3], total=t[4])
+
+    _KERNELS = ("parse", "residual", "recon", "deblock", "sao", "colour", "decode_total")
+
+    def slot_kernel_timing_us(self, slot):
+        """device time per kernel of the run recorded in `slot` (HIP events on the launch stream), microseconds"""
+        t = (C.c_float * 8)()
+        check(self._lib.hipdec_batch_slot_kernel_timing_us(self._h, slot, t))
+        return {k: t[i] for i, k in enumerate(self._KERNELS)}
+
+    def kernel_timing_us(self):
+        """of the last run when the batch keeps one timing slot (the default)"""
+        return self.slot_kernel_timing_us(0)
 
     def free(self):
         if self._h:

@@ -22,6 +22,8 @@ int set_error(int code, const char* fmt, ...)
 int ensure_init() { return 0; }
 hipStream_t default_stream() { return nullptr; }
 uint32_t parse_wave_budget() { return 0; }
+hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity) { *capacity = bytes; return hipMalloc(out, bytes); }
+void arena_release(void* p, size_t) { (void)hipFree(p); }
 
 }  // namespace hipdec
 

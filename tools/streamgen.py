@@ -21,10 +21,14 @@ def _key(w, h, bit_depth, seed, cfg):
     return hashlib.sha1(s.encode()).hexdigest()[:20]
 
 
+def stream_path(w, h, seed, bit_depth, cfg):
+    return os.path.join(CACHE, "s_%dx%d_%s.hevc" % (w, h, _key(w, h, bit_depth, seed, cfg)))
+
+
 def make_stream(w, h, seed=1, bit_depth=8, **cfg):
     """One coded picture in libheif's plugin framing ([u32 BE length][NAL]...), cached."""
     os.makedirs(CACHE, exist_ok=True)
-    path = os.path.join(CACHE, "s_%dx%d_%s.hevc" % (w, h, _key(w, h, bit_depth, seed, cfg)))
+    path = stream_path(w, h, seed, bit_depth, cfg)
     if os.path.exists(path):
         with open(path, "rb") as f:
             return f.read()
@@ -46,9 +50,9 @@ def _job(a):
 def make_streams(specs, workers=None):
     """specs: list of (w, h, seed, bit_depth, cfg dict).  Generated in parallel processes."""
     todo = list(specs)
-    if len(todo) <= 1:
+    if len(todo) <= 1 or all(os.path.exists(stream_path(*a)) for a in todo):
         return [_job(a) for a in todo]
     import multiprocessing as mp
-    workers = workers or min(len(todo), max(1, (os.cpu_count() or 2) - 1), 32)
+    workers = min(len(todo), workers or max(1, (os.cpu_count() or 2) - 1), 192)
     with mp.get_context("fork").Pool(workers) as pool:
         return pool.map(_job, todo)
