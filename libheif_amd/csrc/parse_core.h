@@ -52,6 +52,8 @@ PC_DEV float pc_rcp(float x) { return 1.0f / x; }
 PC_DEV uint32_t pc_mul24(uint32_t a, uint32_t b) { return a * b; }
 #define PC_LDS_SYNC() do { } while (0)
 #define PC_CONST static const
+// value of the lane below (lane 0: its own); only valid inside PC_VEC_BEGIN .. PC_VEC_END
+#define PC_FROM_LANE_BELOW(r) ((r).v[lane ? lane - 1 : 0])
 #else
 #include <hip/hip_runtime.h>
 #define PC_DEV __device__ __forceinline__
@@ -83,6 +85,7 @@ PC_DEV float pc_rcp(float x) { return __builtin_amdgcn_rcpf(x); }               
 PC_DEV uint32_t pc_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }              // operands < 2^24
 #define PC_LDS_SYNC() __syncthreads()
 #define PC_CONST __constant__
+#define PC_FROM_LANE_BELOW(r) ((uint32_t)__shfl_up((int)(r), 1))
 #endif
 
 namespace hipdec {
@@ -127,7 +130,7 @@ PC_CONST uint8_t c_range_lps[64 * 4] = {
     9, 11, 12, 14,   8, 10, 12, 14,   8,  9, 11, 13,   7,  9, 11, 12,   7,  9, 10, 12,   7,  8, 10, 11,
     6,  8,  9, 11,   6,  7,  9, 10,   6,  7,  8,  9,   2,  2,  2,  2};
 // lane p: byte 0 transIdxLps[p] (table 9-47), byte 1 the p-th position of the up-right diagonal
-// scan of an 8x8 array (6.5.3) as x | y << 3
+// scan of an 8x8 array (6.5.3) as x | y << 3, byte 2 the inverse of that scan (lane x | y << 3 -> scan position)
 PC_CONST uint8_t c_next_lps[64] = {
    0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9,11,11,12, 13,13,15,15,16,16,18,18,19,19,21,21,22,22,23,24,
   24,25,26,26,27,27,28,29,29,30,30,30,31,32,32,33, 33,33,34,34,35,35,35,36,36,36,37,37,37,38,38,63};
@@ -139,6 +142,15 @@ PC_CONST uint8_t c_diag8[64] = {
 #define PC_DIAG4 0xFBE7AD369C258140ULL
 #define PC_HORZ4 0xFEDCBA9876543210ULL
 #define PC_VERT4 0xFB73EA62D951C840ULL
+// their inverses: nibble r = scan position of raster index r (constexpr-derived, so they cannot drift from the scans)
+constexpr uint64_t pc_invert_scan4(uint64_t scan)
+{
+  uint64_t inv = 0;
+  for (int k = 0; k < 16; k++) inv |= (uint64_t)k << (4 * ((scan >> (4 * k)) & 15u));
+  return inv;
+}
+constexpr uint64_t PC_INV_DIAG4 = pc_invert_scan4(PC_DIAG4), PC_INV_HORZ4 = pc_invert_scan4(PC_HORZ4), PC_INV_VERT4 = pc_invert_scan4(PC_VERT4);
+static_assert(PC_INV_HORZ4 == PC_HORZ4 && ((PC_INV_DIAG4 >> (4 * 4)) & 15u) == 1u && ((PC_INV_VERT4 >> (4 * 1)) & 15u) == 4u, "inverse scans");
 // sig_coeff_flag ctxIdxMap for 4x4 blocks (9.3.4.2.5), nibble r = ctxIdxMap[raster index r]
 #define PC_CTXIDXMAP4 0x8877886654325410ULL
 // sigCtx of 9.3.4.2.5 for larger blocks before the size / component offsets, two bits per raster
@@ -172,6 +184,7 @@ struct PS {
   //      decoder's arithmetic issues on the SIMD's VALU while the CU-shared scalar pipe keeps the syntax control flow
   UReg range, value, bits_needed;
   uint32_t pos, end, win_base;
+  uint32_t fast_limit;   // bytes [pos, fast_limit) of the current window hold no emulation-prevention candidate: read without the 00 00 03 tracking
   int32_t zeros;
   int32_t err;
   const uint8_t* bs;
@@ -231,36 +244,65 @@ PC_DEV void map_fill(VReg& m, int zb, int n, uint32_t b)
 }
 
 // ---- bitstream window + CABAC engine (9.3.4.3, scaled-window formulation) ---------------------
-PC_DEV void load_window(PS& s, uint32_t base)
+// Emulation-prevention bytes (00 00 03, one per ~4 MB of random payload) are looked for ONCE per 256-byte window, by all 64
+// lanes: a window without a candidate ("03" behind a zero byte, or an "03" in front whose predecessors are unknown) is read
+// through the short path of read_byte(), which neither tracks the zero run nor tests the byte; only windows with a candidate
+// take the per-byte path.  Entering such a window at its first byte, the zero run is recovered from the two bytes in front of
+// it (the short path does not maintain it); entered in the middle (a resumed row), the saved run is the per-byte path's own.
+PC_DEV void load_window(PS& s, uint32_t base, uint32_t first_pos)
 {
-  if (base == s.win_base + 256u) {
+  const bool contiguous = base == s.win_base + 256u;
+  uint32_t tail;             // the two bytes in front of the window
+  if (contiguous) {
+    tail = pc_rdlane(s.win, 63) >> 16;
     PC_VEC_BEGIN PC_L(s.win) = PC_L(s.win_next); PC_VEC_END
   } else {
+    tail = base >= 4u ? pc_uni(*(const uint32_t*)(s.bs + base - 4u)) >> 16 : 0x0101u;
     PC_VEC_BEGIN PC_L(s.win) = *(const uint32_t*)(s.bs + base + 4u * (uint32_t)lane); PC_VEC_END
   }
   PC_VEC_BEGIN PC_L(s.win_next) = *(const uint32_t*)(s.bs + base + 256u + 4u * (uint32_t)lane); PC_VEC_END
   s.win_base = base;
+  VReg cand;
+  PC_VEC_BEGIN
+    const uint32_t w = PC_L(s.win);
+    const uint32_t below = PC_FROM_LANE_BELOW(s.win);
+    const uint32_t b0 = w & 255u, b1 = (w >> 8) & 255u, b2 = (w >> 16) & 255u, b3 = w >> 24;
+    const uint32_t p3 = lane ? below >> 24 : 0u;
+    PC_L(cand) = ((b0 == 3u && p3 == 0u) || (b1 == 3u && b0 == 0u) || (b2 == 3u && b1 == 0u) || (b3 == 3u && b2 == 0u)) ? 1u : 0u;
+  PC_VEC_END
+  if (pc_ballot(cand) == 0) {
+    const uint32_t lim = base + 256u;
+    s.fast_limit = lim < s.end ? lim : s.end;
+  } else {
+    s.fast_limit = 0;
+    if (first_pos == base) s.zeros = (tail & 0xffffu) == 0 ? 2 : ((tail >> 8) == 0 ? 1 : 0);
+  }
 }
 PC_DEV uint32_t fetch_byte(PS& s, uint32_t pos)
 {
-  if ((pos & ~255u) != s.win_base) load_window(s, pos & ~255u);
+  if ((pos & ~255u) != s.win_base) load_window(s, pos & ~255u, pos);
   return (pc_rdlane(s.win, (int)((pos >> 2) & 63u)) >> ((pos & 3u) * 8u)) & 255u;
 }
 PC_DEV uint32_t read_byte(PS& s)
 {
+  if (__builtin_expect(s.pos < s.fast_limit, 1)) {   // inside a window without emulation-prevention candidates, before the end
+    const uint32_t p = s.pos++;
+    return (pc_rdlane(s.win, (int)((p >> 2) & 63u)) >> ((p & 3u) * 8u)) & 255u;
+  }
   uint32_t b;
   for (;;) {   // (a loop so that the window fetch is emitted once per call site)
     if (s.pos >= s.end) { s.pos++; if (s.pos > s.end + 8) s.err = DEV_ERR_BITSTREAM_END; return 0; }
     b = fetch_byte(s, s.pos++);
+    if (s.fast_limit) break;                                                   // a fresh window without candidates
     if (s.zeros >= 2 && b == 3 && s.pos < s.end) { s.zeros = 0; continue; }  // emulation_prevention_three_byte
+    s.zeros = b == 0 ? s.zeros + 1 : 0;
     break;
   }
-  s.zeros = b == 0 ? s.zeros + 1 : 0;
   return b;
 }
 PC_DEV void cabac_start(PS& s, uint32_t start, uint32_t end)
 {
-  s.pos = start; s.end = end; s.zeros = 0; s.win_base = 0xfffff000u;
+  s.pos = start; s.end = end; s.zeros = 0; s.win_base = 0xfffff000u; s.fast_limit = 0;
   s.range = pc_vec(510u); s.bits_needed = pc_vec((uint32_t)-8);
   const uint32_t b0 = read_byte(s), b1 = read_byte(s);
   s.value = pc_vec((b0 << 8) | b1);
@@ -372,6 +414,12 @@ PC_DEV void load_tables(PS& s)
                     ((uint32_t)c_range_lps[lane * 4 + 3] << 24);
     PC_L(s.t_next) = (uint32_t)c_next_lps[lane] | ((uint32_t)c_diag8[lane] << 8);
   PC_VEC_END
+  {   // inverse of the 8x8 diagonal scan, scattered with one masked move per position (once per substream)
+    VReg inv;
+    PC_VEC_BEGIN PC_L(inv) = 0u; PC_VEC_END
+    for (int k = 0; k < 64; k++) pc_wrlane(inv, (int)((pc_rdlane(s.t_next, k) >> 8) & 63u), (uint32_t)k);
+    PC_VEC_BEGIN PC_L(s.t_next) |= PC_L(inv) << 16; PC_VEC_END
+  }
 }
 
 // ---- neighbour helpers over the z-ordered maps ---------------------------------------------------
@@ -468,15 +516,18 @@ PC_DEV int residual_coding(PS& s, int log2n, int c_idx, int pred_mode)
   if (last_x >= n || last_y >= n) { s.err = DEV_ERR_SYNTAX; return ts; }
   const uint64_t scan4 = scan_idx == 0 ? PC_DIAG4 : (scan_idx == 1 ? PC_HORZ4 : PC_VERT4);
 
-  // locate the last position in scan order: sub-block (last_x>>2, last_y>>2), position inside it
+  // locate the last position in scan order — sub-block (last_x >> 2, last_y >> 2), position inside it — through the inverse scans
   const int lg = log2n - 2;  // log2 of the sub-block grid width
-  int last_sb = 0, last_pos = 0;
+  int last_sb, last_pos;
   {
     const int xs_t = last_x >> 2, ys_t = last_y >> 2;
     const uint32_t r_t = (uint32_t)((last_x & 3) | ((last_y & 3) << 2));
-    const int nsb = 1 << (2 * lg);
-    for (int i = 0; i < nsb; i++) { int xs, ys; scan_sb(s, lg, scan_idx, i, xs, ys); if (xs == xs_t && ys == ys_t) { last_sb = i; break; } }
-    for (int k = 0; k < 16; k++) if (((uint32_t)(scan4 >> (k * 4)) & 15u) == r_t) { last_pos = k; break; }
+    const uint64_t inv4 = scan_idx == 0 ? PC_INV_DIAG4 : (scan_idx == 1 ? PC_INV_HORZ4 : PC_INV_VERT4);
+    last_pos = (int)((uint32_t)(inv4 >> (r_t * 4u)) & 15u);
+    if (lg == 0) last_sb = 0;
+    else if (lg == 1) last_sb = scan_idx == 1 ? (xs_t | (ys_t << 1)) : ((xs_t << 1) | ys_t);   // see scan_sb
+    else if (lg == 2) last_sb = (int)((uint32_t)(PC_INV_DIAG4 >> ((uint32_t)(xs_t | (ys_t << 2)) * 4u)) & 15u);
+    else last_sb = (int)((pc_rdlane(s.t_next, xs_t | (ys_t << 3)) >> 16) & 255u);
   }
   uint64_t csbf = 0;  // coded_sub_block_flag bitmap, bit (ys*8 + xs)
   const int sbw = 1 << lg;
@@ -988,18 +1039,9 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
   s.is_cu_qp_delta_coded = 0; s.cu_qp_delta_val = 0; s.qpy_pred = s.slice_qp_y; s.last_qp_y = s.slice_qp_y; s.cur_qp_y = s.slice_qp_y;
   s.cu_tq_bypass = 0;
 
-  const uint16_t* ts_to_rs = (const uint16_t*)(arena + uload64(&P->off_ctb_ts_to_rs));
-  const CtbInfo* ctb_info = (const CtbInfo*)(arena + uload64(&P->off_ctb_info));
-  uint32_t* sao_all = (uint32_t*)(arena + uload64(&P->off_sao));
-  uint32_t* handoff = (uint32_t*)(arena + uload64(&P->off_handoff));   // HANDOFF_DWORDS per CTB (raster)
-  uint8_t* const g_size = arena + uload64(&P->off_u_size);
-  uint8_t* const g_flags = arena + uload64(&P->off_u_flags);
-  uint8_t* const g_ipm = arena + uload64(&P->off_u_ipm);
-  uint8_t* const g_ipmc = arena + uload64(&P->off_u_ipmc);
-  uint8_t* const g_qp = arena + uload64(&P->off_u_qp);
-  int16_t* const coef_base_y = (int16_t*)(arena + uload64(&P->off_coeff[0]));
-  int16_t* const coef_base_cb = (int16_t*)(arena + uload64(&P->off_coeff[1]));
-  int16_t* const coef_base_cr = (int16_t*)(arena + uload64(&P->off_coeff[2]));
+  // Per-picture base pointers are NOT kept live across the CTB body (the CABAC state machine needs every register it can get:
+  // held here, they were spilled to scratch and reloaded once per CTB anyway); each use site below loads its offset from
+  // PicParams again — a handful of cache-resident dword loads per CTB.
   const int units_log2 = 2 * (s.log2_ctb - 2);
   const int units = 1 << units_log2;
   const int uw = 1 << (s.log2_ctb - 2);  // units per CTB side
@@ -1024,7 +1066,7 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
       PC_L(sc) = pc_load_wt(saved + 384 + lane);
     PC_VEC_END
     s.range = pc_vec(pc_rdlane(sc, 0)); s.value = pc_vec(pc_rdlane(sc, 1)); s.bits_needed = pc_vec(pc_rdlane(sc, 2));
-    s.pos = pc_rdlane(sc, 3); s.end = pc_rdlane(sc, 4); s.zeros = (int32_t)pc_rdlane(sc, 5); s.win_base = 0xfffff000u;
+    s.pos = pc_rdlane(sc, 3); s.end = pc_rdlane(sc, 4); s.zeros = (int32_t)pc_rdlane(sc, 5); s.win_base = 0xfffff000u; s.fast_limit = 0;
     s.last_qp_y = (int32_t)pc_rdlane(sc, 6); s.qpy_pred = (int32_t)pc_rdlane(sc, 7); s.cur_qp_y = (int32_t)pc_rdlane(sc, 8);
     s.is_cu_qp_delta_coded = (int32_t)pc_rdlane(sc, 9); s.cu_qp_delta_val = (int32_t)pc_rdlane(sc, 10);
   }
@@ -1035,9 +1077,10 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
       pool_push(A, sub_idx);
       return PARSE_SUSPENDED;
     }
-    const int ctb_rs = (int)(uload32((const uint8_t*)ts_to_rs + ((first_ctb_ts + k) & ~1u) * 2u) >> (((first_ctb_ts + k) & 1u) * 16u)) & 0xffff;
+    const uint8_t* const ts_to_rs = arena + uload64(&P->off_ctb_ts_to_rs);   // uint16_t per CTB
+    const int ctb_rs = (int)(uload32(ts_to_rs + ((first_ctb_ts + k) & ~1u) * 2u) >> (((first_ctb_ts + k) & 1u) * 16u)) & 0xffff;
     const int cx = ctb_rs % ctb_w, cy = ctb_rs / ctb_w;
-    const uint32_t ci = uload32(ctb_info + ctb_rs);  // slice_idx | avail << 16 | tile_id << 24
+    const uint32_t ci = uload32((const CtbInfo*)(arena + uload64(&P->off_ctb_info)) + ctb_rs);  // slice_idx | avail << 16 | tile_id << 24
     s.x_ctb = cx << s.log2_ctb; s.y_ctb = cy << s.log2_ctb; s.ctb_avail = (int)((ci >> 16) & 255u);
 
     // ---- WPP dependency on the CTB row above ----
@@ -1066,7 +1109,7 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
     }
     // ---- hand-off record of the CTB above ----
     if (s.ctb_avail & AV_UP) {
-      const uint32_t* src = handoff + (size_t)(ctb_rs - ctb_w) * HANDOFF_DWORDS;
+      const uint32_t* src = (const uint32_t*)(arena + uload64(&P->off_handoff)) + (size_t)(ctb_rs - ctb_w) * HANDOFF_DWORDS;   // HANDOFF_DWORDS per CTB (raster)
       PC_VEC_BEGIN
         PC_L(s.up) = lane < 13 ? pc_load_wt(src + lane) : 0u;
       PC_VEC_END
@@ -1079,9 +1122,9 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
     }
     if (!(s.tools & TOOL_CUQPD)) { s.is_cu_qp_delta_coded = 0; s.cu_qp_delta_val = 0; s.qpy_pred = s.last_qp_y; }
 
-    int16_t* coef_y = coef_base_y + (size_t)ctb_rs * ctb_size * ctb_size;
-    int16_t* coef_cb = coef_base_cb + (size_t)ctb_rs * (ctb_size * ctb_size / 4);
-    int16_t* coef_cr = coef_base_cr + (size_t)ctb_rs * (ctb_size * ctb_size / 4);
+    int16_t* coef_y = (int16_t*)(arena + uload64(&P->off_coeff[0])) + (size_t)ctb_rs * ctb_size * ctb_size;
+    int16_t* coef_cb = (int16_t*)(arena + uload64(&P->off_coeff[1])) + (size_t)ctb_rs * (ctb_size * ctb_size / 4);
+    int16_t* coef_cr = (int16_t*)(arena + uload64(&P->off_coeff[2])) + (size_t)ctb_rs * (ctb_size * ctb_size / 4);
 
     // coding quadtree, stackless over the z-ordered min-CB index
     const int n_mincb = 1 << n_mincb_log2;
@@ -1129,7 +1172,12 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
     {
       const size_t base = (size_t)ctb_rs << units_log2;
       const int nl = units >> 2;
-      uint32_t* sao_dst = sao_all + (size_t)ctb_rs * 9;
+      uint32_t* sao_dst = (uint32_t*)(arena + uload64(&P->off_sao)) + (size_t)ctb_rs * 9;
+      uint8_t* const g_size = arena + uload64(&P->off_u_size);
+      uint8_t* const g_flags = arena + uload64(&P->off_u_flags);
+      uint8_t* const g_ipm = arena + uload64(&P->off_u_ipm);
+      uint8_t* const g_ipmc = arena + uload64(&P->off_u_ipmc);
+      uint8_t* const g_qp = arena + uload64(&P->off_u_qp);
       PC_VEC_BEGIN
         if (lane < nl) {
           ((uint32_t*)(g_size + base))[lane] = PC_L(s.m_size);
@@ -1151,7 +1199,7 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
           for (int b = 0; b < 4 && 4 * j + b < uw; b++) w |= map_get(s.m_size, (int)interleave4((uint32_t)(4 * j + b), (uint32_t)uw - 1)) << (8 * b);
           pc_wrlane(rec, 9 + j, w);
         }
-        uint32_t* dst = handoff + (size_t)ctb_rs * HANDOFF_DWORDS;
+        uint32_t* dst = (uint32_t*)(arena + uload64(&P->off_handoff)) + (size_t)ctb_rs * HANDOFF_DWORDS;
         PC_VEC_BEGIN
           if (lane < 13) pc_store_wt(dst + lane, PC_L(rec));
         PC_VEC_END

@@ -153,6 +153,32 @@ int emu_coeffs(EmuBatch* b, int i, int32_t* y, int32_t* cb, int32_t* cr)
   return 0;
 }
 
+// The parser's byte reader (bitstream window + emulation-prevention skipping) on its own: reads bytes [start, end) of `buf`
+// (which must be followed by >= 768 readable bytes) into `out` and returns the count.  Every `resume_every` bytes (0 = never)
+// the reader's position state is carried into a FRESH reader, the way a suspended WPP row resumes (parse_substream): pos, end
+// and the zero run are kept, the window is loaded again.
+int emu_read_bytes(const uint8_t* buf, uint32_t start, uint32_t end, uint8_t* out, uint32_t max_out, uint32_t resume_every)
+{
+  pcore::PS* s = new pcore::PS();
+  memset((void*)s, 0, sizeof(*s));
+  s->bs = buf;
+  s->pos = start; s->end = end; s->zeros = 0; s->win_base = 0xfffff000u; s->fast_limit = 0;
+  uint32_t n = 0;
+  while (s->pos < s->end && n < max_out) {
+    if (resume_every && n && n % resume_every == 0) {
+      pcore::PS* t = new pcore::PS();
+      memset((void*)t, 0, sizeof(*t));
+      t->bs = buf; t->pos = s->pos; t->end = s->end; t->zeros = s->zeros; t->win_base = 0xfffff000u; t->fast_limit = 0;
+      delete s; s = t;
+    }
+    const uint32_t b = pcore::read_byte(*s);
+    if (s->pos > s->end) break;      // the byte consumed was an emulation-prevention byte at the very end
+    out[n++] = (uint8_t)b;
+  }
+  delete s;
+  return (int)n;
+}
+
 // SAO parameters per CTB (raster) and component: type, band_or_class, 4 offsets
 int emu_sao(EmuBatch* b, int i, uint8_t* type, uint8_t* cls, int16_t* offsets)
 {

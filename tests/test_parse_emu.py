@@ -157,3 +157,49 @@ def test_parser_pool_scheduler_emulation(cfg, yield_ctbs, monkeypatch):
     assert status == 0, "device status 0x%x" % status
     for s, g in zip(streams, got):
         check_against_oracle(s, g)
+
+
+def _unescape_like_the_spec(buf):
+    """7.4.2: 00 00 03 -> 00 00 inside a NAL unit; a trailing 03 (no byte behind it) is data"""
+    out, zeros, i = bytearray(), 0, 0
+    while i < len(buf):
+        b = buf[i]
+        if zeros >= 2 and b == 3 and i + 1 < len(buf):
+            zeros = 0; i += 1
+            continue
+        out.append(b)
+        zeros = zeros + 1 if b == 0 else 0
+        i += 1
+    return bytes(out)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_byte_reader_skips_emulation_prevention_across_windows_and_resumes(seed):
+    """the 256-byte-window reader of parse_core.h (candidate detection once per window, short path in clean windows, per-byte
+    path elsewhere) against the definition, on buffers dense in 00 00 03 / 00 03 / 03 patterns placed around the window
+    boundaries, from every kind of start offset, with and without suspend / resume in between"""
+    import ctypes as C
+    import random
+    lib = emu()
+    lib.emu_read_bytes.restype = C.c_int
+    lib.emu_read_bytes.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32]
+    rng = random.Random(seed)
+    n = 256 * 9
+    if seed == 0:
+        body = bytearray(rng.randrange(1, 256) for _ in range(n))              # clean windows only ...
+        for at in (254, 255, 256, 510, 511, 512, 513, 767, 1024 + 1, 1280 - 3, 1535, 2047, 2048):
+            body[at:at + 3] = b"\x00\x00\x03"                                    # ... except patterns on the seams
+    elif seed == 1:
+        body = bytearray(rng.choice(b"\x00\x00\x00\x03\x03\x01\x02\xff") for _ in range(n))   # dense
+    else:
+        body = bytearray(rng.randrange(256) for _ in range(n))
+        for _ in range(60):
+            at = rng.randrange(n - 4)
+            body[at:at + rng.choice([3, 4, 5])] = rng.choice([b"\x00\x00\x03", b"\x00\x00\x03\x00\x00\x03", b"\x00\x03", b"\x00\x00\x00\x03\x01"])[:5]
+    buf = bytes(body) + bytes(1024)
+    out = C.create_string_buffer(n + 16)
+    for start, end in [(0, n), (5, n - 7), (255, 1300), (256, 1024), (257, 770), (511, 515), (700, 701), (1000, 1000 + 256), (3, 256 * 8 + 1)]:
+        want = _unescape_like_the_spec(buf[start:end])
+        for resume_every in (0, 1, 7, 255, 256, 300):
+            got = lib.emu_read_bytes(buf, start, end, out, n + 16, resume_every)
+            assert out.raw[:got] == want, (seed, start, end, resume_every)
