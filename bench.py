@@ -55,7 +55,7 @@ def parse_args():
 
 WORKLOADS = {
     # name: (width, height, default batch, bit depth, encoder config, output heif_chroma)
-    "still4k": (3840, 2160, 1024, 8, dict(wpp=1), 10),
+    "still4k": (3840, 2160, 1536, 8, dict(wpp=1), 10),
     "still1080": (1920, 1080, 1024, 8, dict(wpp=1), 10),
     "main10_4k": (3840, 2160, 256, 10, dict(wpp=1, vui_matrix=9, vui_primaries=9, vui_transfer=16), 14),
     "grid8k": (1024, 1024, 48, 8, dict(wpp=1, vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1), 10),

@@ -62,8 +62,20 @@ typedef uint32_t VReg;
 #define PC_VEC_END }
 #define PC_L(r) (r)
 PC_DEV uint32_t pc_rdlane(const VReg& r, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)r, l); }
-// (hipcc 7.2 exposes no writelane builtin; a compare + select on the lane id is two hazard-free VALU ops)
+// v_writelane_b32 (hipcc 7.2 exposes no builtin for it): two instructions instead of move + compare + wait state + select.  gfx9
+// encodings may read only ONE SGPR besides M0, so the lane select travels in M0 (what the compiler's own legalisation of this
+// instruction does).  The value must be provably uniform for the "s" constraint; the latency variant (HIPDEC_PARSE_SCALAR_CABAC), whose
+// arithmetic-decoder values pass through VALU float code, keeps the select form.
+#if defined(HIPDEC_PARSE_SCALAR_CABAC)
 PC_DEV void pc_wrlane(VReg& r, int l, uint32_t x) { r = ((int)threadIdx.x == l) ? x : r; }
+#else
+PC_DEV void pc_wrlane(VReg& r, int l, uint32_t x)
+{
+  // (M0 is not declared clobbered: it is a reserved register the compiler ignores in clobber lists; nothing else in these
+  //  kernels uses it — gfx9 LDS instructions no longer need it — and every use here sets it immediately before reading it)
+  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(r) : "s"(x), "s"(l));
+}
+#endif
 PC_DEV uint32_t pc_uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 PC_DEV int pc_clz(uint32_t x) { return __clz((int)x); }
 PC_DEV int pc_ffs(uint32_t x) { return __ffs((int)x); }
@@ -571,8 +583,10 @@ PC_DEV int residual_coding(PS& s, int log2n, int c_idx, int pred_mode)
     uint32_t sig = 0;  // bit k = sig_coeff_flag at scan position k
     int n_start = 15;
     if (i == last_sb) { sig = 1u << last_pos; n_start = last_pos - 1; }
-    for (int k = n_start; k > 0; k--)
-      sig |= (uint32_t)decode_bin(s, s.ctxB, B_SIG_COEFF + (int)pc_rdlane(vctx, k)) << k;
+    if (n_start > 0) {
+      int k = n_start;
+      do sig |= (uint32_t)decode_bin(s, s.ctxB, B_SIG_COEFF + (int)pc_rdlane(vctx, k)) << k; while (--k > 0);
+    }
     if (n_start >= 0) {   // position 0: inferred significant when the sub-block was signalled coded and nothing else is
       if (infer_dc && !sig) sig = 1u;
       else sig |= (uint32_t)decode_bin(s, s.ctxB, B_SIG_COEFF + (int)pc_rdlane(vctx, 0));
@@ -1085,7 +1099,11 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
 
     // ---- WPP dependency on the CTB row above ----
     if (dep_sub >= 0 && !same_wave_dep) {   // (a predecessor decoded earlier by this very wave is complete)
-      uint32_t need = k == 0 ? start_lag : k + 2;   // 9.3.1 needs 2; a larger start distance decouples the rows
+      // What CTB k needs from the row above is the hand-off record of the CTB directly above it (SAO parameters for sao_merge_up,
+      // the CB sizes for split_cu_flag's context): k + 1 finished CTBs.  Only the row's first CTB needs two (9.3.1: the context
+      // tables are those stored after the second CTB above).  The top-right CTB is an intra-PREDICTION dependency — that is the
+      // reconstruction kernel's wavefront, not the parser's.  (A larger start distance decouples the rows in static mode.)
+      uint32_t need = k == 0 ? start_lag : k + 1;
       if (need > dep_len) need = dep_len;
       if (!pool) {
         const int e = pc_wait_progress(A.progress + dep_sub, need, A.status);
