@@ -73,7 +73,11 @@ PC_DEV void pc_wrlane(VReg& r, int l, uint32_t x)
 {
   // (M0 in the clobber list draws a "reserved register" warning: the compiler does not allocate it; nothing else in these kernels
   //  uses it — gfx9 LDS instructions no longer need it — and every use here sets it immediately before reading it)
-  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(r) : "s"(x), "s"(l) : "m0");
+  // (readfirstlane is free for a value the compiler already holds in an SGPR and moves a uniform value out of a VGPR otherwise: the
+  //  "s" constraint does not legalise by itself)
+  const uint32_t xs = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+  const int ls = __builtin_amdgcn_readfirstlane(l);
+  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(r) : "s"(xs), "s"(ls) : "m0");
 }
 #endif
 PC_DEV uint32_t pc_uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
