@@ -143,6 +143,13 @@ typedef struct hipdec_batch hipdec_batch;
  * planes in HBM when it (asynchronously) ends. */
 HIPDEC_API int hipdec_batch_create(hipdec_batch** out, int n, const void* const* data, const size_t* sizes,
                                    uint64_t max_image_size_pixels);
+/* The same for a stream of batches of one shape: the new batch takes over `recycle`'s arena (when it is large enough; `recycle`
+ * may be NULL) and its upload is ordered behind whatever `recycle` still has in flight — decode, colour stage, packs.  One arena
+ * then serves the whole stream while the host work of batch k+1 (header parsing, staging) overlaps the kernels of batch k.  After
+ * the call `recycle` only answers hipdec_batch_status / timing queries and hipdec_batch_free: its planes are gone, so consume
+ * them (hipdec_batch_to_rgb_all, hipdec_batch_pack_item) before creating the successor. */
+HIPDEC_API int hipdec_batch_create_recycling(hipdec_batch** out, int n, const void* const* data, const size_t* sizes,
+                                             uint64_t max_image_size_pixels, hipdec_batch* recycle);
 HIPDEC_API void hipdec_batch_free(hipdec_batch* b);
 HIPDEC_API int hipdec_batch_count(const hipdec_batch* b);
 HIPDEC_API int hipdec_batch_info(const hipdec_batch* b, int i, hipdec_image_info* info);

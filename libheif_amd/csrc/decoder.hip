@@ -34,11 +34,14 @@ struct hipdec_batch : BatchLayout {
   hipEvent_t uploaded = nullptr;   // recorded on the upload stream behind the H2D copy; launch streams wait on it
   hipEvent_t done = nullptr;       // recorded behind the last piece of work enqueued for this batch (decode, colour stage, packs)
   bool done_recorded = false;
+  int32_t* host_status = nullptr;  // pinned: the device status word of the last run, copied behind its kernels (the arena may already
+                                   // belong to the next batch when hipdec_batch_status() looks)
   std::vector<hipEvent_t> ev;   // kEv events per timing slot; run k records into slot k % slots
   std::vector<uint8_t> colour_timed;   // per slot: the colour stage of that run was recorded
   uint64_t runs = 0;
   hipStream_t last_stream = nullptr;
   bool ran = false;
+  bool retired = false;         // its arena went to another batch (hipdec_batch_create_recycling): only status / timing / free remain
   ColorBatchState color;        // parameter blocks of hipdec_batch_to_rgb_all
   // Waits for everything enqueued for THIS batch — not for the stream, which may already carry the next batch.
   hipError_t wait() const
@@ -68,6 +71,7 @@ struct hipdec_batch : BatchLayout {
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (uploaded) (void)hipEventDestroy(uploaded);
     if (done) (void)hipEventDestroy(done);
+    status_slot_release(host_status);
   }
 };
 
@@ -77,24 +81,38 @@ namespace {
 // batches), staging and the upload.  Large upload regions go through pinned staging and ONE asynchronous copy on the
 // library's upload stream, so that hipdec_batch_create() of batch k+1 overlaps the kernels of batch k; small ones (a still, the
 // tiles of a grid photo) are copied synchronously from pageable memory, which is quicker than pinning.
-int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels)
+int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels, hipdec_batch* recycle = nullptr)
 {
   std::string err;
   int rc = layout_batch_plan(b, n, data, sizes, max_pixels, err);
   if (rc != HIPDEC_OK) return set_error(rc, "%s", err.c_str());
   HIPDEC_CHECK_HIP(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+  b.host_status = status_slot_acquire();
+  if (!b.host_status) return set_error(HIPDEC_ERR_MEMORY, "batch_create: more than 4096 live batches (no pinned status slot left)");
+  *b.host_status = 0;
+  // a retired batch of the same shape hands its arena over (hipdec_batch_create_recycling): the upload is ordered behind
+  // everything that batch still has in flight, so one arena serves a stream of batches
+  hipEvent_t after = nullptr;
+  if (recycle && recycle->arena && recycle->arena_capacity >= b.arena_size) {
+    b.arena = recycle->arena; b.arena_capacity = recycle->arena_capacity;
+    recycle->arena = nullptr; recycle->arena_capacity = 0;
+    if (recycle->done_recorded) after = recycle->done;
+    recycle->retired = true;
+  }
   if (b.upload_size > (size_t(4) << 20)) {
     HIPDEC_CHECK_HIP(pinned_acquire(&b.staging, b.upload_size, &b.staging_capacity));
     layout_batch_fill(b, data, sizes, (uint8_t*)b.staging);
-    HIPDEC_CHECK_HIP(arena_acquire((void**)&b.arena, b.arena_size, &b.arena_capacity));
+    if (!b.arena) HIPDEC_CHECK_HIP(arena_acquire((void**)&b.arena, b.arena_size, &b.arena_capacity));
     HIPDEC_CHECK_HIP(hipEventCreateWithFlags(&b.uploaded, hipEventDisableTiming));
     hipStream_t us = upload_stream();
+    if (after) HIPDEC_CHECK_HIP(hipStreamWaitEvent(us, after, 0));
     HIPDEC_CHECK_HIP(hipMemcpyAsync(b.arena, b.staging, b.upload_size, hipMemcpyHostToDevice, us));
     HIPDEC_CHECK_HIP(hipEventRecord(b.uploaded, us));
   } else {
     std::vector<uint8_t> host(b.upload_size);
     layout_batch_fill(b, data, sizes, host.data());
-    HIPDEC_CHECK_HIP(arena_acquire((void**)&b.arena, b.arena_size, &b.arena_capacity));
+    if (!b.arena) HIPDEC_CHECK_HIP(arena_acquire((void**)&b.arena, b.arena_size, &b.arena_capacity));
+    if (after) HIPDEC_CHECK_HIP(hipEventSynchronize(after));
     HIPDEC_CHECK_HIP(hipMemcpy(b.arena, host.data(), b.upload_size, hipMemcpyHostToDevice));
   }
   b.ev.assign(kEv, nullptr);
@@ -162,6 +180,7 @@ int launch_all(hipdec_batch& b, hipStream_t s)
   HIPDEC_CHECK_HIP(hipEventRecord(ev[5], s));
   if (int rc = step("sao")) return rc;
   HIPDEC_CHECK_HIP(hipGetLastError());
+  HIPDEC_CHECK_HIP(hipMemcpyAsync(b.host_status, b.arena + b.off_status, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   b.mark_done(s);
   return 0;
 }
@@ -202,6 +221,20 @@ int hipdec_batch_create(hipdec_batch** out, int n, const void* const* data, cons
   });
 }
 
+int hipdec_batch_create_recycling(hipdec_batch** out, int n, const void* const* data, const size_t* sizes, uint64_t max_image_size_pixels,
+                                  hipdec_batch* recycle)
+{
+  if (!out || n <= 0 || !data || !sizes) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "batch_create: bad arguments");
+  *out = nullptr;
+  if (int rc = ensure_init()) return rc;
+  return guarded("batch_create", [&]() -> int {
+    std::unique_ptr<hipdec_batch> b(new hipdec_batch());
+    if (int rc = build_batch(*b, n, data, sizes, max_image_size_pixels, recycle)) return rc;
+    *out = b.release();
+    return 0;
+  });
+}
+
 void hipdec_batch_free(hipdec_batch* b) { delete b; }
 int hipdec_batch_count(const hipdec_batch* b) { return b ? (int)b->pics.size() : 0; }
 
@@ -215,6 +248,7 @@ int hipdec_batch_info(const hipdec_batch* b, int i, hipdec_image_info* info)
 int hipdec_batch_run(hipdec_batch* b, void* stream)
 {
   if (!b) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "batch_run: NULL batch");
+  if (b->retired) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "batch_run: the batch's arena was handed to another batch");
   if (int rc = ensure_init()) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : default_stream();
   b->last_stream = s;
@@ -229,8 +263,7 @@ int hipdec_batch_status(hipdec_batch* b)
   hipError_t e = b->wait();
   if (e != hipSuccess) return set_error(HIPDEC_ERR_DEVICE, "decode kernels failed: %s", hipGetErrorString(e));
   b->release_staging();
-  int32_t st = 0;
-  HIPDEC_CHECK_HIP(hipMemcpy(&st, b->arena + b->off_status, sizeof(st), hipMemcpyDeviceToHost));
+  const int32_t st = *b->host_status;
   if (st != 0) return set_error(HIPDEC_ERR_DECODE, "device decode error 0x%x: %s", st, dev_err_name(st));
   return 0;
 }
@@ -238,6 +271,7 @@ int hipdec_batch_status(hipdec_batch* b)
 int hipdec_batch_read_plane(hipdec_batch* b, int i, int c, void* dst, size_t dst_stride)
 {
   if (!b || i < 0 || i >= (int)b->pics.size() || c < 0 || c > 2 || !dst) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: bad arguments");
+  if (b->retired) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: the batch's arena was handed to another batch");
   const PicParams& P = b->params[i];
   if (c > 0 && !P.chroma_format_idc) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: monochrome image has no chroma planes");
   return copy_plane_d2h(*b, P.off_out[c], P.out_stride[c], c ? P.out_cwidth : P.out_width, c ? P.out_cheight : P.out_height, dst, dst_stride);
@@ -246,6 +280,7 @@ int hipdec_batch_read_plane(hipdec_batch* b, int i, int c, void* dst, size_t dst
 int hipdec_batch_device_plane(hipdec_batch* b, int i, int c, const void** dptr, size_t* stride)
 {
   if (!b || i < 0 || i >= (int)b->pics.size() || c < 0 || c > 2 || !dptr || !stride) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "device_plane: bad arguments");
+  if (b->retired) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "device_plane: the batch's arena was handed to another batch");
   const PicParams& P = b->params[i];
   *dptr = b->arena + P.off_out[c];
   *stride = P.out_stride[c];
@@ -263,6 +298,7 @@ size_t hipdec_batch_item_packed_bytes(const hipdec_batch* b, int i)
 int hipdec_batch_pack_item(hipdec_batch* b, int i, void* dst_dev, size_t dst_bytes, void* stream)
 {
   if (!b || i < 0 || i >= (int)b->pics.size() || !dst_dev) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "pack_item: bad arguments");
+  if (b->retired) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "pack_item: the batch's arena was handed to another batch");
   if (dst_bytes < hipdec_batch_item_packed_bytes(b, i)) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "pack_item: destination too small");
   const PicParams& P = b->params[i];
   const size_t es = b->wide ? 2 : 1;
@@ -290,6 +326,7 @@ int hipdec_copy2d_d2d(void* dst_dev, size_t dst_stride, const void* src_dev, siz
 int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void* out_dev, size_t out_stride, void* stream)
 {
   if (!b || i < 0 || i >= (int)b->pics.size() || !out_dev) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "to_rgb: bad arguments");
+  if (b->retired) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "to_rgb: the batch's arena was handed to another batch");
   const PicParams& P = b->params[i];
   const hipdec_image_info& I = b->pics[i].info;
   if (!P.chroma_format_idc) return set_error(HIPDEC_ERR_UNSUPPORTED, "to_rgb: monochrome input");
@@ -392,6 +429,7 @@ int hipdec_batch_last_timing_us(hipdec_batch* b, float out[5])
 int hipdec_batch_read_tap(hipdec_batch* b, int i, int which, int c, void* dst, size_t dst_stride)
 {
   if (!b || i < 0 || i >= (int)b->pics.size() || c < 0 || c > 2 || !dst) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_tap: bad arguments");
+  if (b->retired) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_tap: the batch's arena was handed to another batch");
   (void)which;  // the reconstruction buffer holds the deblocked picture after a full run
   const PicParams& P = b->params[i];
   return copy_plane_d2h(*b, P.off_rec[c], P.rec_stride[c], c ? P.cwidth : P.width, c ? P.cheight : P.height, dst, dst_stride);
@@ -401,6 +439,7 @@ int hipdec_batch_read_maps(hipdec_batch* b, int i, uint8_t* log2_tb, uint8_t* lo
                            uint8_t* flags, size_t map_elems)
 {
   if (!b || i < 0 || i >= (int)b->pics.size()) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_maps: bad arguments");
+  if (b->retired) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_maps: the batch's arena was handed to another batch");
   const PicParams& P = b->params[i];
   const int uw = (P.width + 3) / 4, uh = (P.height + 3) / 4;
   if (map_elems < (size_t)uw * uh) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_maps: buffers too small");

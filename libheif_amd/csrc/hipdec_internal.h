@@ -25,6 +25,8 @@ void arena_pool_clear();
 hipError_t pinned_acquire(void** out, size_t bytes, size_t* capacity);   // pinned host staging for large uploads, recycled
 void pinned_release(void* p, size_t capacity);
 void pinned_pool_clear();
+int32_t* status_slot_acquire();                 // pinned 64-byte slot for a batch's status word (NULL: none left)
+void status_slot_release(int32_t* p);
 
 // A small pool of HIP streams: concurrent plugin decoder instances (libheif decodes grid tiles on several threads,
 // libheif/image-items/grid.cc:436) each run on their own stream so that their kernels overlap on the GPU.

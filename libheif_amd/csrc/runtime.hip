@@ -106,6 +106,38 @@ void pinned_release(void* p, size_t capacity)
   (void)hipHostFree(p);
 }
 
+// One pinned 64-byte slot per live batch for the status word its last run copies back (decoder.hip): carved out of a slab so that
+// creating / retiring a batch costs no hipHostMalloc / hipHostFree (the latter may synchronise the device).
+namespace {
+struct StatusSlab {
+  std::mutex mu;
+  uint8_t* base = nullptr;
+  std::vector<int32_t*> free_list;
+};
+StatusSlab g_status;
+constexpr size_t kStatusSlots = 4096;
+}  // namespace
+
+int32_t* status_slot_acquire()
+{
+  std::lock_guard<std::mutex> lock(g_status.mu);
+  if (!g_status.base) {
+    if (hipHostMalloc((void**)&g_status.base, kStatusSlots * 64, hipHostMallocDefault) != hipSuccess) { g_status.base = nullptr; return nullptr; }
+    for (size_t i = kStatusSlots; i-- > 0;) g_status.free_list.push_back((int32_t*)(g_status.base + i * 64));
+  }
+  if (g_status.free_list.empty()) return nullptr;
+  int32_t* p = g_status.free_list.back();
+  g_status.free_list.pop_back();
+  return p;
+}
+
+void status_slot_release(int32_t* p)
+{
+  if (!p) return;
+  std::lock_guard<std::mutex> lock(g_status.mu);
+  g_status.free_list.push_back(p);
+}
+
 void pinned_pool_clear()
 {
   std::lock_guard<std::mutex> lock(g_pinned.mu);

@@ -24,6 +24,7 @@ def _bind(lib):
     lib.hipdec_decoder_coalesce_stats.restype = None
     lib.hipdec_decoder_coalesce_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
     lib.hipdec_batch_create.argtypes = [C.POINTER(vp), ci, C.POINTER(C.c_char_p), C.POINTER(sz), C.c_uint64]
+    lib.hipdec_batch_create_recycling.argtypes = [C.POINTER(vp), ci, C.POINTER(C.c_char_p), C.POINTER(sz), C.c_uint64, vp]
     lib.hipdec_batch_free.argtypes = [vp]
     lib.hipdec_batch_count.argtypes = [vp]
     lib.hipdec_batch_info.argtypes = [vp, ci, C.POINTER(ImageInfo)]
@@ -110,14 +111,18 @@ class HipDecoder:
 class Batch:
     """Many independent coded items (grid tiles, batches of stills) decoded by one set of launches."""
 
-    def __init__(self, streams, max_image_size_pixels=0):
+    def __init__(self, streams, max_image_size_pixels=0, recycle=None):
+        """recycle: a batch of the same shape whose planes have been consumed; its arena is taken over (a stream of batches)"""
         self._lib = _bind(load_library())
         self._keep = [bytes(s) for s in streams]
         n = len(self._keep)
         arr = (C.c_char_p * n)(*self._keep)
         sizes = (C.c_size_t * n)(*[len(s) for s in self._keep])
         self._h = C.c_void_p()
-        check(self._lib.hipdec_batch_create(C.byref(self._h), n, arr, sizes, int(max_image_size_pixels)))
+        if recycle is None:
+            check(self._lib.hipdec_batch_create(C.byref(self._h), n, arr, sizes, int(max_image_size_pixels)))
+        else:
+            check(self._lib.hipdec_batch_create_recycling(C.byref(self._h), n, arr, sizes, int(max_image_size_pixels), recycle._h))
         self.n = n
 
     def info(self, i):

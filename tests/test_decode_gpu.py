@@ -345,3 +345,48 @@ def test_batch_colour_stage_in_one_launch():
         rgba = b.rgb(i).reshape(single[i].shape[0], -1, 4)
         np.testing.assert_array_equal(rgba[:, :, :3].reshape(single[i].shape), single[i])
         assert (rgba[:, :, 3] == 255).all()
+
+
+def test_a_stream_of_batches_recycles_one_arena():
+    """hipdec_batch_create_recycling: batch k+1 is created (host parsing, staging, upload) while batch k is still in flight and takes
+    over its arena; every batch's planes are consumed through the colour stage before its successor exists; a retired batch still
+    reports its status but refuses plane reads loudly"""
+    from libheif_amd.decoder import Batch
+    from libheif_amd import HipDecError
+    from tools import streamgen
+    sets = [[streamgen.make_stream(1280, 720, 40 + 8 * j + i, 8) for i in range(8)] for j in range(4)]   # upload region > 4 MiB: async path
+    first = Batch(sets[0])
+    first.alloc_rgb(10)
+    rgb_state = first.rgb_state()
+    cur, results = first, []
+    for j in range(4):
+        cur.run()
+        cur.to_rgb_all()
+        nxt = Batch(sets[j + 1], recycle=cur) if j + 1 < 4 else None     # created while `cur` may still be decoding
+        if nxt is not None:
+            nxt.use_rgb(rgb_state)
+        cur.status()                                                      # the status word was copied back behind cur's kernels
+        if nxt is not None:
+            with pytest.raises(HipDecError):
+                cur.planes(0)
+        # the RGB buffers are shared: read them back before the successor's colour stage overwrites them (stream order makes the
+        # successor's kernels wait for nothing but its own upload, so synchronise through status() above and read now)
+        results.append([np.array(cur.rgb(i), copy=True) for i in (0, 7)])
+        if nxt is None:
+            planes_last = [cur.planes(i) for i in (0, 7)]
+        prev, cur = cur, nxt
+        prev.free() if nxt is not None else None
+    for j in range(4):
+        for n, i in enumerate((0, 7)):
+            ref = orc.decode(sets[j][i])
+            nclx = tuple(ref["nclx"])
+            if nclx[3] and (6 if nclx[2] == 2 else nclx[2]) not in (0, 8):
+                want = orc.color_420_to_rgb24(ref["planes"][0], ref["planes"][1], ref["planes"][2], nclx).reshape(720, -1)
+            else:
+                r, g, b = orc.color_ycbcr_to_rgb_planar(ref["planes"][0], ref["planes"][1], ref["planes"][2], 8, 1, nclx)
+                want = orc.color_rgb_planar_to_interleaved8(r, g, b).reshape(720, -1)
+            np.testing.assert_array_equal(results[j][n], want, err_msg="batch %d item %d" % (j, i))
+    for n, i in enumerate((0, 7)):
+        ref = orc.decode(sets[3][i])
+        for c in range(3):
+            np.testing.assert_array_equal(planes_last[n][c], ref["planes"][c])
