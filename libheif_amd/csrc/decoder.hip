@@ -99,7 +99,8 @@ int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* s
     if (recycle->done_recorded) after = recycle->done;
     recycle->retired = true;
   }
-  if (b.upload_size > (size_t(4) << 20)) {
+  static const bool sync_upload = getenv("HIPDEC_SYNC_UPLOAD") != nullptr;   // profiling knob: one stream, no cross-stream event waits
+  if (b.upload_size > (size_t(4) << 20) && !sync_upload) {
     HIPDEC_CHECK_HIP(pinned_acquire(&b.staging, b.upload_size, &b.staging_capacity));
     layout_batch_fill(b, data, sizes, (uint8_t*)b.staging);
     if (!b.arena) HIPDEC_CHECK_HIP(arena_acquire((void**)&b.arena, b.arena_size, &b.arena_capacity));
