@@ -227,17 +227,22 @@ def main():
     # ------------------------------------------------------------------------------------------------------------------
     gd = None
     if grid:
-        from libheif_amd.grid import GridDecoder, GridLayout
+        # the product path: hipdec_grid_* in C++ (include/heif_hipdec.h), ONE process over the node's GPUs — rank 0 shards the 48 tiles
+        # t mod N over devices 0..N-1, every decoded tile is pasted into the canvas on device 0 by a strided peer copy (xGMI), the colour
+        # stage runs over the canvas; the other ranks the launcher started only take part in the barriers
+        from libheif_amd.grid import GridDecoderC, GridLayout
         layout = GridLayout(6, 8, w, h, 8 * w, 6 * h)
-        gd = GridDecoder({t: distinct[t] for t in items}, layout, rank, world)   # tiles sharded t mod G, gather to rank 0
-        batch = gd.batch
-        n_items, px_rank, bs_bytes = len(items), w * h * len(items), sum(len(distinct[t]) for t in items)
+        n_items, px_rank, bs_bytes = 48, w * h * 48, sum(len(x) for x in distinct)
         total_px = w * h * 48
+        batch = None
+        if rank == 0:
+            gd = GridDecoderC({t: distinct[t] for t in range(48)}, layout, list(range(world)))
+            rgb_out = torch.empty((6 * h, 8 * w * 3), dtype=torch.uint8, device="cuda:0")
 
         def step():
-            gd.decode()
             if rank == 0:
-                gd.to_rgb((1, 13, 6, 1))
+                gd.decode()
+                gd.to_rgb(10, out_dev=(rgb_out.data_ptr(), rgb_out.stride(0)))     # waits for the shards, colour stage into HBM
     else:
         off = (rank * len(distinct)) // max(1, world)
         wl = Workload(lib, a.workload, distinct[off:] + distinct[:off], nb, out_chroma, w, h, bit_depth)
@@ -245,9 +250,13 @@ def main():
         n_items, px_rank, bs_bytes = wl.n, wl.px, wl.bs_bytes
         total_px = wl.px * world
         step = wl.step_resident
-    batch.timing_slots(max(1, a.steps))
-    elapsed = timed(step, a.steps, a.warmup, before_timed=lambda: (batch.status() if a.warmup else None, batch.timing_slots(max(1, a.steps))))
-    batch.status()         # device-side decode errors are loud
+    if batch is not None:
+        batch.timing_slots(max(1, a.steps))
+    elapsed = timed(step, a.steps, a.warmup, before_timed=(lambda: (batch.status() if a.warmup else None, batch.timing_slots(max(1, a.steps)))) if batch is not None else None)
+    if batch is not None:
+        batch.status()         # device-side decode errors are loud
+    elif gd is not None:
+        gd.wait()
     ms_per_step = elapsed / a.steps * 1e3
     value = total_px / (elapsed / a.steps) / 1e6
     avg_us = kernel_times(batch, a.steps) if not grid else None
@@ -264,12 +273,13 @@ def main():
             "higher_is_better": True, "scaling": "strong" if grid else "weak", "vs_baseline": None,
             "dtype": "u8" if bit_depth == 8 else "u16",
             "data": "synthetic (seeded noise+gradient stills coded by the test-only HEVC intra encoder, QP %d, %d distinct contents)" % (a.qp, len(distinct)),
-            "config": {"workload": ("8K grid, 48 tiles of 1024x1024, tiles sharded over ranks, RCCL gather, paste + colour on rank 0" if grid else
+            "config": {"workload": ("one 8192x6144 grid photo = 48 tiles of 1024x1024, tiles t mod N over N GPUs in one process (hipdec_grid_*), peer-copy paste + RGB24 on GPU 0" if grid else
                                     "%d x %dx%d HEIC 4:2:0 %d-bit stills per GPU and step, WPP, CTB 64, fused YCbCr->%s" %
                                     (n_items, w, h, bit_depth, "RGB24" if out_chroma == 10 else "RRGGBB")),
                        "timed_region": "inputs resident in HBM: hipdec_batch_run + hipdec_batch_to_rgb_all per step (from host bytes: see from_host_bytes)",
                        "stills_per_step_per_gpu": n_items, "distinct_contents": len(distinct), "bitstream_bytes_per_px": round(beta, 4),
-                       "substreams_per_still": batch.info(0)["num_substreams"], "parallelism": "replicas x%d" % world},
+                       "substreams_per_still": batch.info(0)["num_substreams"] if batch is not None else 16,
+                       "parallelism": ("tiles sharded over %d GPUs, one process" % world) if grid else "replicas x%d" % world},
         }
         if avg_us is not None:
             coded = coded_fraction(batch)
@@ -380,17 +390,18 @@ def main():
             ew, eh, _, ebd, _, eout = WORKLOADS[wname]
             st = extra_streams[key]
             if wname == "grid8k":
-                from libheif_amd.grid import GridDecoder, GridLayout
-                g = GridDecoder({t: st[t] for t in range(48)}, GridLayout(6, 8, ew, eh, 8 * ew, 6 * eh), 0, 1)
+                from libheif_amd.grid import GridDecoderC, GridLayout
+                g = GridDecoderC({t: st[t] for t in range(48)}, GridLayout(6, 8, ew, eh, 8 * ew, 6 * eh), [0])
+                grgb = torch.empty((6 * eh, 8 * ew * 3), dtype=torch.uint8, device="cuda")
 
                 def estep():
-                    g.decode(); g.to_rgb((1, 13, 6, 1))
+                    g.decode(); g.to_rgb(10, out_dev=(grgb.data_ptr(), grgb.stride(0)))
                 el = timed(estep, 2, 1)
                 px = ew * eh * 48
-                extras[key] = {"workload": "one 8192x6144 grid photo = 48 tiles of 1024x1024 (768 substreams), batch API + paste + RGB24 on one GPU",
+                extras[key] = {"workload": "one 8192x6144 grid photo = 48 tiles of 1024x1024 (768 substreams), hipdec_grid_* + RGB24 on one GPU",
                                "value": round(px / (el / 2) / 1e6, 2), "unit": "Mpixel/s", "ms_per_step": round(el / 2 * 1e3, 3),
                                "bitstream_bytes_per_px": round(sum(len(x) for x in st) / px, 4)}
-                del g
+                g.free()
                 continue
             e = Workload(lib, wname, st, n, eout, ew, eh, ebd)
             eb = e.make_resident()

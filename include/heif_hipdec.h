@@ -120,6 +120,9 @@ HIPDEC_API const void* hipdec_get_decoder_plugin(void);
  * buffer with the caller's stride; samples are uint8 for bit depth 8, little-endian uint16
  * above. */
 HIPDEC_API int hipdec_decoder_read_plane(hipdec_decoder* dec, int c, void* dst_host, size_t dst_stride);
+/* the same, and remembers (host pointer -> device copy) so that hipdec_color_convert() on those very host planes skips the upload:
+ * what the libheif plugin uses */
+HIPDEC_API int hipdec_decoder_read_plane_tracked(hipdec_decoder* dec, int c, void* dst_host, size_t dst_stride);
 /* device-resident hand-over for callers that keep the colour stage on the GPU */
 HIPDEC_API int hipdec_decoder_device_plane(hipdec_decoder* dec, int c, const void** dptr, size_t* stride);
 
@@ -189,6 +192,28 @@ HIPDEC_API int hipdec_batch_read_tap(hipdec_batch* b, int i, int which, int c, v
 HIPDEC_API int hipdec_batch_read_maps(hipdec_batch* b, int i, uint8_t* log2_tb, uint8_t* log2_cb, uint8_t* intra_luma,
                                       uint8_t* intra_chroma, int8_t* qp_y, uint8_t* flags, size_t map_elems);
 
+/* ---- grid images across the GPUs of one node ------------------------------------------------- */
+/* Device-side form of ImageItem_Grid::decode_full_grid_image + decode_and_paste_tile_image (libheif/image-items/grid.cc:250-468,
+ * :482-577; HeifPixelImage::copy_image_to, libheif/image/pixelimage.cc:1115-1172) in ONE process over several HIP devices: tile
+ * t = row * cols + col (order of the 'dimg' references) is decoded by shard t mod n_devices on that shard's device, each decoded
+ * plane is pasted with one strided device-to-device copy (xGMI peer access where available) at its position in the canvas on
+ * devices[0], clipped to the output size; the colour conversion then runs once over the canvas.
+ * devices: n_devices device indices (entries may repeat: several shards on one device); NULL = devices 0 .. n_devices-1,
+ * n_devices 0 = all visible devices.  tile_data[t] / tile_sizes[t]: the tiles in grid order, push_data framing. */
+typedef struct hipdec_grid hipdec_grid;
+HIPDEC_API int hipdec_grid_create(hipdec_grid** out, int rows, int cols, int out_width, int out_height, const void* const* tile_data,
+                                  const size_t* tile_sizes, const int* devices, int n_devices, uint64_t max_image_size_pixels);
+HIPDEC_API void hipdec_grid_free(hipdec_grid* g);
+/* info of the composed image (width / height = output size, coded size = tiled area, VUI colour description of tile 0) */
+HIPDEC_API int hipdec_grid_info(const hipdec_grid* g, hipdec_image_info* info, int* n_shards);
+HIPDEC_API int hipdec_grid_decode(hipdec_grid* g);                  /* asynchronous: decode + paste queued on every shard */
+HIPDEC_API int hipdec_grid_wait(hipdec_grid* g);                    /* waits for all shards; device-side errors */
+HIPDEC_API int hipdec_grid_canvas_plane(hipdec_grid* g, int c, const void** dptr, size_t* stride, int* device);
+HIPDEC_API int hipdec_grid_read_plane(hipdec_grid* g, int c, void* dst_host, size_t dst_stride);
+/* the planner + fused colour stage over the canvas (hipdec_color_convert); out on the host, or on devices[0] */
+HIPDEC_API int hipdec_grid_to_rgb(hipdec_grid* g, int out_chroma, int upsampling, int only_preferred, void* out, size_t out_stride,
+                                  int out_on_device);
+
 /* ---- colour stage ---------------------------------------------------------------------------- */
 typedef struct hipdec_nclx {
   int has_nclx;               /* 0: the image carries no nclx profile (reference uses its defaults) */
@@ -220,6 +245,47 @@ HIPDEC_API int hipdec_color_bilinear_420_to_444(const void* in, size_t is, int w
                                                 void* stream);
 /* Op_to_sdr_planes (hdr_sdr.cc:146-244): v >> (bits - 8), uint16 -> uint8. */
 HIPDEC_API int hipdec_color_to_sdr(const void* in, size_t is, int w, int h, int bits, void* out, size_t os, void* stream);
+/* Op_YCbCr420_to_RGB32 with a real alpha plane (yuv2rgb.cc:481-562; alpha copied as :552) when integer_op != 0, else the float
+ * chain Op_YCbCr_to_RGB<uint8_t> + Op_RGB_to_RGB24_32 with the alpha plane interleaved (rgb2rgb.cc:72-150).  alpha NULL: 0xFF. */
+HIPDEC_API int hipdec_color_420_to_rgba_alpha(const void* y, size_t ys, const void* cb, size_t cbs, const void* cr, size_t crs,
+                                              int w, int h, const hipdec_nclx* nclx, const void* alpha, size_t alpha_stride,
+                                              int integer_op, int chroma, void* out, size_t out_stride, void* stream);
+
+/* ---- the colour boundary: planner (a8) + image-level conversion ------------------------------------------------------
+ * What ColorConversionPipeline::construct_pipeline + convert_image do for a decoded HEIC image
+ * (libheif/color-conversion/colorconversion.cc:279-623), behind ONE call.  The integration op registered in init_ops()
+ * (libheif_amd/integration/colorconversion_hip.cc) forwards to hipdec_color_convert(). */
+typedef enum hipdec_color_op {   /* the reference operations a plan is made of */
+  HIPDEC_OP_TO_SDR = 1,                 /* Op_to_sdr_planes                  hdr_sdr.cc:146-244 */
+  HIPDEC_OP_BILINEAR_420_TO_444 = 2,    /* Op_YCbCr420_bilinear_to_YCbCr444  chroma_sampling.cc:501-724 */
+  HIPDEC_OP_420_TO_RGB24 = 3,           /* Op_YCbCr420_to_RGB24              yuv2rgb.cc:345-426 */
+  HIPDEC_OP_420_TO_RGB32 = 4,           /* Op_YCbCr420_to_RGB32              yuv2rgb.cc:481-562 */
+  HIPDEC_OP_YCBCR_TO_RGB = 5,           /* Op_YCbCr_to_RGB<Pixel>            yuv2rgb.cc:92-292 */
+  HIPDEC_OP_RGB_TO_RGB24_32 = 6,        /* Op_RGB_to_RGB24_32                rgb2rgb.cc:72-150 (fused into the op before it) */
+  HIPDEC_OP_420_TO_RRGGBB = 7           /* Op_YCbCr420_to_RRGGBBaa           yuv2rgb.cc:622-734 */
+} hipdec_color_op;
+
+typedef struct hipdec_color_image {
+  int width, height;       /* luma size */
+  int chroma;              /* heif_chroma of the planes: 1 = 4:2:0, 2 = 4:2:2, 3 = 4:4:4 */
+  int bit_depth;
+  const void* plane[4];    /* Y, Cb, Cr, alpha (NULL: none) */
+  size_t stride[4];        /* bytes */
+  int on_device;           /* 0: host pointers (libheif's HeifPixelImage planes), 1: device pointers */
+} hipdec_color_image;
+
+/* a8: the chain the reference's planner selects for (input state, output heif_chroma, chroma-upsampling options:
+ * upsampling 1 = nearest neighbour, 2 = bilinear; only_preferred as heif_color_conversion_options).  HIPDEC_ERR_UNSUPPORTED for
+ * states outside the HEIC hot path (the stock ops keep those). */
+HIPDEC_API int hipdec_color_plan(int bit_depth, int chroma, int has_alpha, const hipdec_nclx* nclx, int out_chroma, int upsampling,
+                                 int only_preferred, int ops[8], int* n_ops);
+/* plan + execute on the GPU.  Host planes that a hipdec decoder has just handed to libheif (hipdec_decoder_read_plane_tracked)
+ * are read from their device-resident copy, others are uploaded; `out` is a host buffer (or a device buffer, out_on_device). */
+HIPDEC_API int hipdec_color_convert(const hipdec_color_image* in, const hipdec_nclx* nclx, int out_chroma, int upsampling,
+                                    int only_preferred, void* out, size_t out_stride, int out_on_device);
+/* counters since load: conversions through hipdec_color_convert, input planes found device-resident, colour kernels launched */
+HIPDEC_API void hipdec_color_boundary_stats(uint64_t* conversions, uint64_t* resident_planes, uint64_t* kernel_launches);
+
 /* nclx.cc:143-173 get_YCbCr_to_RGB_coefficients: {r_cr, g_cb, g_cr, b_cb} */
 HIPDEC_API void hipdec_color_coefficients(const hipdec_nclx* nclx, float out[4]);
 

@@ -30,6 +30,8 @@ struct ColorParams {
   size_t ys, cbs, crs;
   uint8_t *o0, *o1, *o2;
   size_t os;
+  const uint8_t* a;       // 8-bit alpha plane for the RGBA layout (yuv2rgb.cc:521-553), NULL: filled with 0xFF
+  size_t as;
   int w, h, bpp, shiftH, shiftV;
   int arith;
   int i_r_cr, i_g_cb, i_g_cr, i_b_cb;
@@ -164,15 +166,25 @@ __device__ __forceinline__ void rgb_block(const ColorParams& p)
       }
     } else if (LAYOUT == LO_RGBA32) {
       uint8_t* o = p.o0 + (size_t)yy * p.os + (size_t)x0 * 4;
+      uint32_t A[4] = {255u, 255u, 255u, 255u};
+      if (p.a) {
+        const uint8_t* arow = p.a + (size_t)yy * p.as + x0;
+        if (npx == 4 && (((uintptr_t)arow) & 3) == 0) {
+          const uint32_t v = *(const uint32_t*)arow;
+          A[0] = v & 255u; A[1] = (v >> 8) & 255u; A[2] = (v >> 16) & 255u; A[3] = v >> 24;
+        } else {
+          for (int i = 0; i < npx; i++) A[i] = arow[i];
+        }
+      }
       if (npx == 4 && ((p.os | (uintptr_t)p.o0) & 15) == 0) {
         uint4 v;
-        v.x = R[0] | (G[0] << 8) | (B[0] << 16) | 0xFF000000u;
-        v.y = R[1] | (G[1] << 8) | (B[1] << 16) | 0xFF000000u;
-        v.z = R[2] | (G[2] << 8) | (B[2] << 16) | 0xFF000000u;
-        v.w = R[3] | (G[3] << 8) | (B[3] << 16) | 0xFF000000u;
+        v.x = R[0] | (G[0] << 8) | (B[0] << 16) | (A[0] << 24);
+        v.y = R[1] | (G[1] << 8) | (B[1] << 16) | (A[1] << 24);
+        v.z = R[2] | (G[2] << 8) | (B[2] << 16) | (A[2] << 24);
+        v.w = R[3] | (G[3] << 8) | (B[3] << 16) | (A[3] << 24);
         *(uint4*)o = v;
       } else {
-        for (int i = 0; i < npx; i++) { o[4 * i] = (uint8_t)R[i]; o[4 * i + 1] = (uint8_t)G[i]; o[4 * i + 2] = (uint8_t)B[i]; o[4 * i + 3] = 0xFF; }
+        for (int i = 0; i < npx; i++) { o[4 * i] = (uint8_t)R[i]; o[4 * i + 1] = (uint8_t)G[i]; o[4 * i + 2] = (uint8_t)B[i]; o[4 * i + 3] = (uint8_t)A[i]; }
       }
     } else {  // RRGGBB BE / LE, yuv2rgb.cc:717-723
       uint8_t* o = p.o0 + (size_t)yy * p.os + (size_t)x0 * 6;
@@ -489,6 +501,21 @@ int hipdec_color_420_to_rgb24(const void* y, size_t ys, const void* cb, size_t c
   p.arith = AR_INT88; p.o0 = (uint8_t*)out; p.os = out_stride;
   hipStream_t s = stream ? (hipStream_t)stream : default_stream();
   return with_alpha ? launch_rgb<uint8_t, LO_RGBA32>(p, s) : launch_rgb<uint8_t, LO_RGB24>(p, s);
+}
+
+/* RGBA with a real alpha plane (Op_YCbCr420_to_RGB32 with an alpha channel, yuv2rgb.cc:521-553; the float chain copies the alpha
+ * plane the same way, rgb2rgb.cc:72-150): `alpha` NULL fills 0xFF */
+int hipdec_color_420_to_rgba_alpha(const void* y, size_t ys, const void* cb, size_t cbs, const void* cr, size_t crs, int w, int h,
+                                   const hipdec_nclx* nclx, const void* alpha, size_t alpha_stride, int integer_op, int chroma,
+                                   void* out, size_t out_stride, void* stream)
+{
+  if (int rc = ensure_init()) return rc;
+  ColorParams p;
+  if (int rc = fill_common(p, y, ys, cb, cbs, cr, crs, w, h, 8, integer_op ? 1 : chroma, nclx)) return rc;
+  if (!out) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "420_to_rgba: out is NULL");
+  p.arith = integer_op ? AR_INT88 : generic_arith(nclx);
+  p.o0 = (uint8_t*)out; p.os = out_stride; p.a = (const uint8_t*)alpha; p.as = alpha_stride;
+  return launch_rgb<uint8_t, LO_RGBA32>(p, stream ? (hipStream_t)stream : default_stream());
 }
 
 int hipdec_color_ycbcr_to_rgb_planar(const void* y, size_t ys, const void* cb, size_t cbs, const void* cr, size_t crs, int w,

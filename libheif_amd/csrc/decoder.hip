@@ -12,6 +12,7 @@
 #include "kernels.h"
 #include "batch_layout.h"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -27,6 +28,7 @@ using namespace hipdec;
 constexpr int kEv = 8;   // events per timing slot: start, parse, residual, recon, deblock, sao | colour begin, colour end
 
 struct hipdec_batch : BatchLayout {
+  int device = 0;               // the device the arena lives on: every entry point that touches the batch runs under its scope
   uint8_t* arena = nullptr;
   size_t arena_capacity = 0;
   void* staging = nullptr;      // pinned upload staging (large batches), returned to its pool once the upload has completed
@@ -64,6 +66,7 @@ struct hipdec_batch : BatchLayout {
   }
   ~hipdec_batch()
   {
+    DeviceScope scope(device);
     if (arena || staging) (void)wait();   // nothing of this batch may still be running when the arena is recycled
     release_staging();
     color_batch_state_free(color);
@@ -84,6 +87,7 @@ namespace {
 int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels, hipdec_batch* recycle = nullptr)
 {
   std::string err;
+  b.device = active_device();
   int rc = layout_batch_plan(b, n, data, sizes, max_pixels, err);
   if (rc != HIPDEC_OK) return set_error(rc, "%s", err.c_str());
   HIPDEC_CHECK_HIP(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
@@ -93,7 +97,7 @@ int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* s
   // a retired batch of the same shape hands its arena over (hipdec_batch_create_recycling): the upload is ordered behind
   // everything that batch still has in flight, so one arena serves a stream of batches
   hipEvent_t after = nullptr;
-  if (recycle && recycle->arena && recycle->arena_capacity >= b.arena_size) {
+  if (recycle && recycle->arena && recycle->arena_capacity >= b.arena_size && recycle->device == b.device) {
     b.arena = recycle->arena; b.arena_capacity = recycle->arena_capacity;
     recycle->arena = nullptr; recycle->arena_capacity = 0;
     if (recycle->done_recorded) after = recycle->done;
@@ -249,6 +253,7 @@ int hipdec_batch_info(const hipdec_batch* b, int i, hipdec_image_info* info)
 int hipdec_batch_run(hipdec_batch* b, void* stream)
 {
   if (!b) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "batch_run: NULL batch");
+  DeviceScope scope(b->device);
   if (b->retired) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "batch_run: the batch's arena was handed to another batch");
   if (int rc = ensure_init()) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : default_stream();
@@ -260,6 +265,7 @@ int hipdec_batch_run(hipdec_batch* b, void* stream)
 int hipdec_batch_status(hipdec_batch* b)
 {
   if (!b || !b->ran) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "batch_status: batch has not been run");
+  DeviceScope scope(b->device);
   if (int rc = ensure_init()) return rc;
   hipError_t e = b->wait();
   if (e != hipSuccess) return set_error(HIPDEC_ERR_DEVICE, "decode kernels failed: %s", hipGetErrorString(e));
@@ -272,6 +278,7 @@ int hipdec_batch_status(hipdec_batch* b)
 int hipdec_batch_read_plane(hipdec_batch* b, int i, int c, void* dst, size_t dst_stride)
 {
   if (!b || i < 0 || i >= (int)b->pics.size() || c < 0 || c > 2 || !dst) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: bad arguments");
+  DeviceScope scope(b->device);
   if (b->retired) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: the batch's arena was handed to another batch");
   const PicParams& P = b->params[i];
   if (c > 0 && !P.chroma_format_idc) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: monochrome image has no chroma planes");
@@ -299,6 +306,7 @@ size_t hipdec_batch_item_packed_bytes(const hipdec_batch* b, int i)
 int hipdec_batch_pack_item(hipdec_batch* b, int i, void* dst_dev, size_t dst_bytes, void* stream)
 {
   if (!b || i < 0 || i >= (int)b->pics.size() || !dst_dev) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "pack_item: bad arguments");
+  DeviceScope scope(b->device);
   if (b->retired) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "pack_item: the batch's arena was handed to another batch");
   if (dst_bytes < hipdec_batch_item_packed_bytes(b, i)) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "pack_item: destination too small");
   const PicParams& P = b->params[i];
@@ -327,6 +335,7 @@ int hipdec_copy2d_d2d(void* dst_dev, size_t dst_stride, const void* src_dev, siz
 int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void* out_dev, size_t out_stride, void* stream)
 {
   if (!b || i < 0 || i >= (int)b->pics.size() || !out_dev) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "to_rgb: bad arguments");
+  DeviceScope scope(b->device);
   if (b->retired) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "to_rgb: the batch's arena was handed to another batch");
   const PicParams& P = b->params[i];
   const hipdec_image_info& I = b->pics[i].info;
@@ -360,6 +369,7 @@ int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void* out_dev, s
 int hipdec_batch_to_rgb_all(hipdec_batch* b, int out_chroma, void* const* outs_dev, const size_t* out_strides, void* stream)
 {
   if (!b || !outs_dev || !out_strides) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "to_rgb_all: bad arguments");
+  DeviceScope scope(b->device);
   hipStream_t s = stream ? (hipStream_t)stream : (b->last_stream ? b->last_stream : default_stream());
   // every item goes through the per-item entry point (argument checks, planner rule, coefficients) in capture mode
   color_capture_begin();
@@ -379,6 +389,7 @@ int hipdec_batch_to_rgb_all(hipdec_batch* b, int out_chroma, void* const* outs_d
 int hipdec_batch_timing_slots(hipdec_batch* b, int slots)
 {
   if (!b || slots < 1 || slots > 4096) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "timing_slots: bad arguments");
+  DeviceScope scope(b->device);
   if (b->ran) HIPDEC_CHECK_HIP(b->wait());
   for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
   b->ev.assign((size_t)slots * kEv, nullptr);
@@ -391,6 +402,7 @@ int hipdec_batch_timing_slots(hipdec_batch* b, int slots)
 int hipdec_batch_slot_kernel_timing_us(hipdec_batch* b, int slot, float out[8])
 {
   if (!b || !out || slot < 0 || (size_t)slot >= b->ev.size() / kEv || (uint64_t)slot >= b->runs)
+  DeviceScope scope(b->device);
     return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "slot_timing: no run recorded in slot %d", slot);
   hipEvent_t* ev = b->ev.data() + kEv * (size_t)slot;
   HIPDEC_CHECK_HIP(hipEventSynchronize(ev[5]));
@@ -430,6 +442,7 @@ int hipdec_batch_last_timing_us(hipdec_batch* b, float out[5])
 int hipdec_batch_read_tap(hipdec_batch* b, int i, int which, int c, void* dst, size_t dst_stride)
 {
   if (!b || i < 0 || i >= (int)b->pics.size() || c < 0 || c > 2 || !dst) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_tap: bad arguments");
+  DeviceScope scope(b->device);
   if (b->retired) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_tap: the batch's arena was handed to another batch");
   (void)which;  // the reconstruction buffer holds the deblocked picture after a full run
   const PicParams& P = b->params[i];
@@ -440,6 +453,7 @@ int hipdec_batch_read_maps(hipdec_batch* b, int i, uint8_t* log2_tb, uint8_t* lo
                            uint8_t* flags, size_t map_elems)
 {
   if (!b || i < 0 || i >= (int)b->pics.size()) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_maps: bad arguments");
+  DeviceScope scope(b->device);
   if (b->retired) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_maps: the batch's arena was handed to another batch");
   const PicParams& P = b->params[i];
   const int uw = (P.width + 3) / 4, uh = (P.height + 3) / 4;
@@ -743,6 +757,432 @@ int hipdec_decoder_device_plane(hipdec_decoder* d, int c, const void** dptr, siz
 {
   if (!d || !d->decoded) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "device_plane: nothing decoded");
   return hipdec_batch_device_plane(d->batch.get(), d->item, c, dptr, stride);
+}
+
+}  // extern "C"
+
+// ---- colour boundary: device-resident planes, the planner (a8) and the image-level conversion ---------------------------
+//
+// libheif converts a decoded image through its own ColorConversionPipeline (libheif/color-conversion/colorconversion.cc:
+// 279-623): a Dijkstra search over the registered ColorConversionOperations, then the chosen chain on host planes.  The
+// integration op (libheif_amd/integration/colorconversion_hip.cc, registered in init_ops() with SpeedCosts_Hardware) hands
+// the whole conversion to hipdec_color_convert(): the planner below restates the decisions of that search for the in-scope
+// states, the fused HIP kernels of color.hip execute the chain, and when the input planes are the ones a
+// hipdec decoder has just copied into libheif's image, the kernels read the DEVICE copy instead of uploading them again.
+namespace {
+
+struct ResidentPlane {
+  const void* host = nullptr;      // where hipdec_decoder_read_plane_tracked() copied the plane
+  size_t host_stride = 0;
+  int w = 0, h = 0, bits = 0;
+  uint64_t sample = 0;             // sparse hash of the host copy at hand-over time: a recycled pointer with other content misses
+  std::shared_ptr<hipdec_batch> batch;
+  int item = 0, comp = 0;
+  uint64_t tick = 0;
+};
+std::mutex g_res_mu;
+std::vector<ResidentPlane> g_resident;
+uint64_t g_res_tick = 0;
+std::atomic<uint64_t> g_cb_conversions{0}, g_cb_resident{0}, g_cb_launches{0};
+constexpr size_t kMaxResident = 24;    // planes (8 images): every entry keeps its batch arena alive
+
+uint64_t sparse_hash(const uint8_t* p, size_t stride, int w_bytes, int h)
+{
+  uint64_t x = 1469598103934665603ull;
+  auto mix = [&](const uint8_t* q, int n) { for (int i = 0; i < n; i++) { x ^= q[i]; x *= 1099511628211ull; } };
+  const int rows = h < 16 ? h : 16;
+  for (int k = 0; k < rows; k++) {
+    const uint8_t* row = p + (size_t)((long long)k * (h - 1) / (rows > 1 ? rows - 1 : 1)) * stride;
+    const int n = w_bytes < 32 ? w_bytes : 32;
+    mix(row, n); mix(row + (w_bytes - n) / 2, n); mix(row + w_bytes - n, n);
+  }
+  return x;
+}
+
+void resident_note(hipdec_decoder* d, int c, const void* host, size_t stride)
+{
+  const PicParams& P = d->batch->params[d->item];
+  ResidentPlane r;
+  r.host = host; r.host_stride = stride;
+  r.w = c ? P.out_cwidth : P.out_width; r.h = c ? P.out_cheight : P.out_height;
+  r.bits = c ? P.bit_depth_chroma : P.bit_depth_luma;
+  r.sample = sparse_hash((const uint8_t*)host, stride, r.w * (d->batch->wide ? 2 : 1), r.h);
+  r.batch = d->batch; r.item = d->item; r.comp = c;
+  std::lock_guard<std::mutex> lock(g_res_mu);
+  r.tick = ++g_res_tick;
+  for (auto& e : g_resident) if (e.host == host) { e = r; return; }
+  if (g_resident.size() >= kMaxResident) {
+    size_t old = 0;
+    for (size_t i = 1; i < g_resident.size(); i++) if (g_resident[i].tick < g_resident[old].tick) old = i;
+    g_resident[old] = r;
+  } else g_resident.push_back(r);
+}
+
+// device copy of a host plane handed over by a decoder of this library, if it still is that plane
+bool resident_find(const void* host, size_t stride, int w, int h, int bits, const uint8_t** dev, size_t* dev_stride, std::shared_ptr<hipdec_batch>& keep)
+{
+  ResidentPlane r;
+  {
+    std::lock_guard<std::mutex> lock(g_res_mu);
+    bool hit = false;
+    for (auto& e : g_resident) if (e.host == host) { e.tick = ++g_res_tick; r = e; hit = true; break; }
+    if (!hit) return false;
+  }
+  if (r.host_stride != stride || r.w != w || r.h != h || r.bits != bits || r.batch->retired || !r.batch->arena) return false;
+  if (sparse_hash((const uint8_t*)host, stride, w * (bits > 8 ? 2 : 1), h) != r.sample) return false;
+  const PicParams& P = r.batch->params[r.item];
+  *dev = r.batch->arena + P.off_out[r.comp];
+  *dev_stride = P.out_stride[r.comp];
+  keep = r.batch;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hipdec_decoder_read_plane_tracked(hipdec_decoder* d, int c, void* dst, size_t dst_stride)
+{
+  int rc = hipdec_decoder_read_plane(d, c, dst, dst_stride);
+  if (rc) return rc;
+  return guarded("read_plane", [&]() -> int { resident_note(d, c, dst, dst_stride); return 0; });
+}
+
+void hipdec_color_boundary_stats(uint64_t* conversions, uint64_t* resident_planes, uint64_t* kernel_launches)
+{
+  if (conversions) *conversions = g_cb_conversions.load();
+  if (resident_planes) *resident_planes = g_cb_resident.load();
+  if (kernel_launches) *kernel_launches = g_cb_launches.load();
+}
+
+// a8 for the in-scope states: which chain ColorConversionPipeline::construct_pipeline (colorconversion.cc:279-435) ends up with.
+// Every stock op costs SpeedCosts_Unoptimized, so the search returns the chain with the fewest steps; the rules below are the
+// state_after_conversion() conditions of those ops (yuv2rgb.cc:35-92, :298-341, :430-478, :566-620; chroma_sampling.cc:501-560;
+// hdr_sdr.cc:146-190; rgb2rgb.cc:30-70).  nclx "unspecified" (2) counts as the sRGB defaults for planning (nclx.cc:360-373).
+int hipdec_color_plan(int bit_depth, int chroma, int has_alpha, const hipdec_nclx* nclx, int out_chroma, int upsampling, int only_preferred,
+                      int ops[8], int* n_ops)
+{
+  if (!ops || !n_ops) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "color_plan: bad arguments");
+  *n_ops = 0;
+  int matrix = 6, full = 1;
+  if (nclx && nclx->has_nclx) { matrix = nclx->matrix_coefficients == 2 ? 6 : nclx->matrix_coefficients; full = nclx->full_range_flag; }
+  if (matrix == 11 || matrix == 14) return set_error(HIPDEC_ERR_UNSUPPORTED, "Unsupported color conversion (matrix_coefficients %d), as in the reference", matrix);
+  if (chroma < 1 || chroma > 3) return set_error(HIPDEC_ERR_UNSUPPORTED, "color_plan: input chroma %d is outside the HEIC hot path", chroma);
+  const bool nn_allowed = !(only_preferred && upsampling != 1);
+  auto push = [&](int op) { ops[(*n_ops)++] = op; };
+  if (out_chroma == 10 || out_chroma == 11) {          // interleaved RGB / RGBA, 8 bit
+    if (out_chroma == 10 && has_alpha) return set_error(HIPDEC_ERR_UNSUPPORTED, "color_plan: dropping an alpha plane is left to the stock ops");
+    if (bit_depth > 8) { push(HIPDEC_OP_TO_SDR); bit_depth = 8; }
+    if (chroma == 1 && nn_allowed && full && matrix != 0 && matrix != 8) { push(out_chroma == 10 ? HIPDEC_OP_420_TO_RGB24 : HIPDEC_OP_420_TO_RGB32); return 0; }
+    if (chroma != 3 && !nn_allowed) {
+      if (chroma != 1) return set_error(HIPDEC_ERR_UNSUPPORTED, "color_plan: bilinear 4:2:2 upsampling is outside the HEIC hot path");
+      push(HIPDEC_OP_BILINEAR_420_TO_444);
+    }
+    push(HIPDEC_OP_YCBCR_TO_RGB); push(HIPDEC_OP_RGB_TO_RGB24_32);
+    return 0;
+  }
+  if (out_chroma == 12 || out_chroma == 14) {          // RRGGBB big / little endian
+    if (has_alpha) return set_error(HIPDEC_ERR_UNSUPPORTED, "color_plan: RRGGBB from an image with alpha is left to the stock ops");
+    if (bit_depth <= 8) return set_error(HIPDEC_ERR_UNSUPPORTED, "color_plan: 8-bit to RRGGBB needs Op_to_hdr_planes, outside the hot path");
+    if (chroma == 1 && nn_allowed && matrix != 0 && matrix != 8) { push(HIPDEC_OP_420_TO_RRGGBB); return 0; }
+    return set_error(HIPDEC_ERR_UNSUPPORTED, "color_plan: this RRGGBB chain is outside the hot path");
+  }
+  return set_error(HIPDEC_ERR_UNSUPPORTED, "color_plan: output chroma %d is outside the HEIC hot path", out_chroma);
+}
+
+int hipdec_color_convert(const hipdec_color_image* in, const hipdec_nclx* nclx, int out_chroma, int upsampling, int only_preferred,
+                         void* out, size_t out_stride, int out_on_device)
+{
+  if (!in || !out || in->width <= 0 || in->height <= 0 || !in->plane[0] || !in->plane[1] || !in->plane[2])
+    return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "color_convert: bad arguments");
+  if (int rc = ensure_init()) return rc;
+  return guarded("color_convert", [&]() -> int {
+    int ops[8], n_ops = 0;
+    const bool has_alpha = in->plane[3] != nullptr;
+    if (int rc = hipdec_color_plan(in->bit_depth, in->chroma, has_alpha, nclx, out_chroma, upsampling, only_preferred, ops, &n_ops)) return rc;
+    const int w = in->width, h = in->height;
+    const int cw = in->chroma == 3 ? w : (w + 1) / 2, ch = in->chroma == 1 ? (h + 1) / 2 : h;
+    int bits = in->bit_depth;
+    size_t es = bits > 8 ? 2 : 1;
+    const size_t out_bpp = out_chroma == 10 ? 3 : (out_chroma == 11 ? 4 : 6);
+    hipStream_t s = stream_acquire();
+    struct Release { hipStream_t s; std::vector<std::pair<void*, size_t>> bufs;
+                     ~Release() { (void)hipStreamSynchronize(s); for (auto& b : bufs) arena_release(b.first, b.second); stream_release(s); } } rel{s, {}};
+    auto scratch = [&](size_t bytes, uint8_t** p) -> int {
+      void* d = nullptr; size_t cap = 0;
+      HIPDEC_CHECK_HIP(arena_acquire(&d, bytes ? bytes : 256, &cap));
+      rel.bufs.emplace_back(d, cap); *p = (uint8_t*)d;
+      return 0;
+    };
+    // ---- the input planes on the device: the decoder's own copy when the host planes are still the ones it handed over
+    const uint8_t* dp[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t ds[4] = {0, 0, 0, 0};
+    std::shared_ptr<hipdec_batch> keep[4];
+    for (int c = 0; c < 4; c++) {
+      if (!in->plane[c]) continue;
+      const int pw = (c == 0 || c == 3) ? w : cw, ph = (c == 0 || c == 3) ? h : ch;
+      if (in->on_device) { dp[c] = (const uint8_t*)in->plane[c]; ds[c] = in->stride[c]; continue; }
+      if (resident_find(in->plane[c], in->stride[c], pw, ph, bits, &dp[c], &ds[c], keep[c])) { g_cb_resident++; continue; }
+      uint8_t* d = nullptr;
+      const size_t st = ((size_t)pw * es + 255) & ~(size_t)255;
+      if (int rc = scratch(st * ph, &d)) return rc;
+      HIPDEC_CHECK_HIP(hipMemcpy2DAsync(d, st, in->plane[c], in->stride[c], (size_t)pw * es, ph, hipMemcpyHostToDevice, s));
+      dp[c] = d; ds[c] = st;
+    }
+    // ---- the chain
+    int chroma = in->chroma, k = 0;
+    if (k < n_ops && ops[k] == HIPDEC_OP_TO_SDR) {                     // a14 on every plane
+      for (int c = 0; c < 4; c++) {
+        if (!dp[c]) continue;
+        const int pw = (c == 0 || c == 3) ? w : cw, ph = (c == 0 || c == 3) ? h : ch;
+        uint8_t* d = nullptr;
+        const size_t st = ((size_t)pw + 255) & ~(size_t)255;
+        if (int rc = scratch(st * ph, &d)) return rc;
+        if (int rc = hipdec_color_to_sdr(dp[c], ds[c], pw, ph, bits, d, st, (void*)s)) return rc;
+        g_cb_launches++;
+        dp[c] = d; ds[c] = st;
+      }
+      bits = 8; es = 1; k++;
+    }
+    if (k < n_ops && ops[k] == HIPDEC_OP_BILINEAR_420_TO_444) {         // a13 on both chroma planes
+      for (int c = 1; c < 3; c++) {
+        uint8_t* d = nullptr;
+        const size_t st = ((size_t)w * es + 255) & ~(size_t)255;
+        if (int rc = scratch(st * h, &d)) return rc;
+        if (int rc = hipdec_color_bilinear_420_to_444(dp[c], ds[c], w, h, bits, d, st, (void*)s)) return rc;
+        g_cb_launches++;
+        dp[c] = d; ds[c] = st;
+      }
+      chroma = 3; k++;
+    }
+    uint8_t* dout = (uint8_t*)out;
+    size_t dout_stride = out_stride;
+    if (!out_on_device) {
+      dout_stride = ((size_t)w * out_bpp + 255) & ~(size_t)255;
+      if (int rc = scratch(dout_stride * h, &dout)) return rc;
+    }
+    if (k >= n_ops) return set_error(HIPDEC_ERR_UNSUPPORTED, "color_convert: empty chain");
+    int rc = 0;
+    switch (ops[k]) {
+      case HIPDEC_OP_420_TO_RGB24:
+        rc = hipdec_color_420_to_rgb24(dp[0], ds[0], dp[1], ds[1], dp[2], ds[2], w, h, nclx, dout, dout_stride, 0, (void*)s); break;
+      case HIPDEC_OP_420_TO_RGB32:
+        rc = hipdec_color_420_to_rgba_alpha(dp[0], ds[0], dp[1], ds[1], dp[2], ds[2], w, h, nclx, dp[3], ds[3], 1, 1, dout, dout_stride, (void*)s); break;
+      case HIPDEC_OP_YCBCR_TO_RGB:   // a10 + a11 as one pass
+        if (out_chroma == 11) rc = hipdec_color_420_to_rgba_alpha(dp[0], ds[0], dp[1], ds[1], dp[2], ds[2], w, h, nclx, dp[3], ds[3], 0, chroma, dout, dout_stride, (void*)s);
+        else rc = hipdec_color_ycbcr_to_rgb24_float(dp[0], ds[0], dp[1], ds[1], dp[2], ds[2], w, h, chroma, nclx, dout, dout_stride, 0, (void*)s);
+        break;
+      case HIPDEC_OP_420_TO_RRGGBB:
+        rc = hipdec_color_420_to_rrggbb(dp[0], ds[0], dp[1], ds[1], dp[2], ds[2], w, h, bits, nclx, dout, dout_stride, out_chroma == 14, (void*)s); break;
+      default: rc = set_error(HIPDEC_ERR_UNSUPPORTED, "color_convert: unplanned op %d", ops[k]); break;
+    }
+    if (rc) return rc;
+    g_cb_launches++;
+    if (!out_on_device) HIPDEC_CHECK_HIP(hipMemcpy2DAsync(out, out_stride, dout, dout_stride, (size_t)w * out_bpp, h, hipMemcpyDeviceToHost, s));
+    HIPDEC_CHECK_HIP(hipStreamSynchronize(s));
+    g_cb_conversions++;
+    return 0;
+  });
+}
+
+}  // extern "C"
+
+// ---- grid images across the GPUs of one node ------------------------------------------------------------------------------
+//
+// Device-side form of ImageItem_Grid::decode_full_grid_image (libheif/image-items/grid.cc:250-468: tile fan-out :405-453) and
+// decode_and_paste_tile_image (:482-577, HeifPixelImage::copy_image_to image/pixelimage.cc:1115-1172), in ONE process over
+// `n_devices` HIP devices:
+//   * tile t = row * cols + col (the order of the 'dimg' references, grid.cc:193,319) belongs to shard t mod G; every shard
+//     decodes its tiles as one batch — arena, streams and launches on its own device (DeviceScope);
+//   * the one exchange step is the paste: each decoded tile plane goes straight from its device to its (x0, y0) position in the
+//     canvas on the root device with one strided device-to-device copy (peer access over xGMI when the devices allow it, staged
+//     by the runtime otherwise), queued on the OWNER's stream right behind the tile's decode; 1.5 bytes per pixel in total, no
+//     intermediate packing and no collective — a gather whose every message lands at its final address;
+//   * the root's stream waits for one event per shard, then the fused colour conversion runs once over the canvas (bilinear
+//     chroma taps cross tile borders, so the colour stage sees the whole canvas).
+// The Python path (libheif_amd/grid.py: one process per GPU, torch.distributed gather) stays as the multi-process test driver.
+struct hipdec_grid {
+  int rows = 0, cols = 0, out_w = 0, out_h = 0, tile_w = 0, tile_h = 0, bits = 8;
+  std::vector<int> devices;                       // one entry per shard; entries may repeat (several shards on one device)
+  std::vector<std::unique_ptr<hipdec_batch>> shard;
+  std::vector<std::vector<int>> shard_tiles;      // tile indices of shard s, in batch order
+  std::vector<hipStream_t> stream;                // one per shard, on its device
+  std::vector<hipEvent_t> pasted;                 // per shard: its tiles are in the canvas
+  int root = 0;                                   // device of the canvas
+  uint8_t* canvas = nullptr;
+  size_t canvas_capacity = 0;
+  size_t off[3] = {0, 0, 0}, stride[3] = {0, 0, 0};
+  hipdec_image_info info{};                       // of tile 0 (colour description for the canvas)
+  bool decoded = false;
+  ~hipdec_grid()
+  {
+    for (size_t s = 0; s < shard.size(); s++) {
+      DeviceScope scope(devices[s]);
+      if (stream[s]) { (void)hipStreamSynchronize(stream[s]); stream_release(stream[s]); }
+      if (pasted[s]) (void)hipEventDestroy(pasted[s]);
+      shard[s].reset();
+    }
+    if (canvas) { DeviceScope scope(root); arena_release(canvas, canvas_capacity); }
+  }
+};
+
+extern "C" {
+
+int hipdec_grid_create(hipdec_grid** out, int rows, int cols, int out_width, int out_height, const void* const* tile_data,
+                       const size_t* tile_sizes, const int* devices, int n_devices, uint64_t max_image_size_pixels)
+{
+  if (!out || rows <= 0 || cols <= 0 || rows > 256 || cols > 256 || out_width <= 0 || out_height <= 0 || !tile_data || !tile_sizes)
+    return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_create: bad arguments");
+  *out = nullptr;
+  if (int rc = ensure_init()) return rc;
+  return guarded("grid_create", [&]() -> int {
+    const int n_tiles = rows * cols;
+    int visible = 0;
+    HIPDEC_CHECK_HIP(hipGetDeviceCount(&visible));
+    std::unique_ptr<hipdec_grid> g(new hipdec_grid());
+    if (devices && n_devices > 0) g->devices.assign(devices, devices + n_devices);
+    else { const int n = n_devices > 0 ? n_devices : visible; for (int d = 0; d < n; d++) g->devices.push_back(d % visible); }
+    if ((int)g->devices.size() > n_tiles) g->devices.resize((size_t)n_tiles);
+    for (int d : g->devices) if (d < 0 || d >= visible) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_create: device %d is not visible (%d devices)", d, visible);
+    const int G = (int)g->devices.size();
+    g->rows = rows; g->cols = cols; g->out_w = out_width; g->out_h = out_height; g->root = g->devices[0];
+    g->shard.resize((size_t)G); g->shard_tiles.resize((size_t)G); g->stream.assign((size_t)G, nullptr); g->pasted.assign((size_t)G, nullptr);
+    for (int t = 0; t < n_tiles; t++) g->shard_tiles[(size_t)(t % G)].push_back(t);
+    for (int s = 0; s < G; s++) {
+      DeviceScope scope(g->devices[s]);
+      if (g->devices[s] != g->root) {   // direct peer copies into the canvas where the topology allows them
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, g->devices[s], g->root) == hipSuccess && can) { (void)hipDeviceEnablePeerAccess(g->root, 0); (void)hipGetLastError(); }
+      }
+      std::vector<const void*> ptrs;
+      std::vector<size_t> sizes;
+      for (int t : g->shard_tiles[(size_t)s]) { ptrs.push_back(tile_data[t]); sizes.push_back(tile_sizes[t]); }
+      hipdec_batch* b = nullptr;
+      if (int rc = hipdec_batch_create(&b, (int)ptrs.size(), ptrs.data(), sizes.data(), max_image_size_pixels)) return rc;
+      g->shard[(size_t)s].reset(b);
+      g->stream[(size_t)s] = stream_acquire();
+      HIPDEC_CHECK_HIP(hipEventCreateWithFlags(&g->pasted[(size_t)s], hipEventDisableTiming));
+    }
+    // every tile has the size / bit depth / chroma format of tile 0 and the output fits the tiled area (grid.cc:270-282)
+    g->info = g->shard[0]->pics[0].info;
+    g->tile_w = g->info.width; g->tile_h = g->info.height; g->bits = g->info.bit_depth_luma;
+    for (int s = 0; s < G; s++)
+      for (const auto& p : g->shard[(size_t)s]->pics)
+        if (p.info.width != g->tile_w || p.info.height != g->tile_h || p.info.bit_depth_luma != g->bits || p.info.chroma_format_idc != g->info.chroma_format_idc)
+          return set_error(HIPDEC_ERR_BITSTREAM, "grid_create: tiles differ in size, bit depth or chroma format");
+    if (out_width > cols * g->tile_w || out_height > rows * g->tile_h)
+      return set_error(HIPDEC_ERR_BITSTREAM, "grid_create: the output size exceeds the tiled area");
+    if (g->info.chroma_format_idc && ((g->tile_w | g->tile_h) & 1)) return set_error(HIPDEC_ERR_UNSUPPORTED, "grid_create: 4:2:0 tiles with odd dimensions");
+    {
+      DeviceScope scope(g->root);
+      const size_t es = g->bits > 8 ? 2 : 1;
+      const size_t cw = g->info.chroma_format_idc ? (size_t)(out_width + 1) / 2 : 0, ch = g->info.chroma_format_idc ? (size_t)(out_height + 1) / 2 : 0;
+      size_t o = 0;
+      g->stride[0] = ((size_t)out_width * es + 255) & ~(size_t)255; g->off[0] = o; o += g->stride[0] * (size_t)out_height;
+      g->stride[1] = g->stride[2] = (cw * es + 255) & ~(size_t)255;
+      g->off[1] = o; o += g->stride[1] * ch; g->off[2] = o; o += g->stride[2] * ch;
+      HIPDEC_CHECK_HIP(arena_acquire((void**)&g->canvas, o ? o : 256, &g->canvas_capacity));
+    }
+    *out = g.release();
+    return 0;
+  });
+}
+
+void hipdec_grid_free(hipdec_grid* g) { delete g; }
+
+int hipdec_grid_info(const hipdec_grid* g, hipdec_image_info* info, int* n_shards)
+{
+  if (!g || !info) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_info: bad arguments");
+  *info = g->info;
+  info->width = g->out_w; info->height = g->out_h;
+  info->chroma_width = g->info.chroma_format_idc ? (g->out_w + 1) / 2 : 0; info->chroma_height = g->info.chroma_format_idc ? (g->out_h + 1) / 2 : 0;
+  info->coded_width = g->cols * g->tile_w; info->coded_height = g->rows * g->tile_h;
+  size_t bytes = 0; int subs = 0;
+  for (const auto& b : g->shard) for (const auto& p : b->pics) { bytes += p.info.bitstream_bytes; subs += p.info.num_substreams; }
+  info->bitstream_bytes = bytes; info->num_substreams = subs;
+  if (n_shards) *n_shards = (int)g->shard.size();
+  return 0;
+}
+
+int hipdec_grid_decode(hipdec_grid* g)
+{
+  if (!g) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_decode: NULL grid");
+  return guarded("grid_decode", [&]() -> int {
+    const size_t es = g->bits > 8 ? 2 : 1;
+    const int ncomp = g->info.chroma_format_idc ? 3 : 1;
+    for (size_t s = 0; s < g->shard.size(); s++) {
+      DeviceScope scope(g->devices[s]);
+      hipdec_batch* b = g->shard[s].get();
+      if (int rc = hipdec_batch_run(b, (void*)g->stream[s])) return rc;
+      for (size_t i = 0; i < g->shard_tiles[s].size(); i++) {
+        const int t = g->shard_tiles[s][i];
+        const int x0 = (t % g->cols) * g->tile_w, y0 = (t / g->cols) * g->tile_h;
+        const int w = std::min(g->tile_w, g->out_w - x0), h = std::min(g->tile_h, g->out_h - y0);   // clipped to the output (pixelimage.cc:1130-1160)
+        if (w <= 0 || h <= 0) continue;
+        const PicParams& P = b->params[i];
+        for (int c = 0; c < ncomp; c++) {
+          const size_t pw = c ? (size_t)(w + 1) / 2 : (size_t)w, ph = c ? (size_t)(h + 1) / 2 : (size_t)h;
+          const size_t px = c ? (size_t)x0 / 2 : (size_t)x0, py = c ? (size_t)y0 / 2 : (size_t)y0;
+          HIPDEC_CHECK_HIP(hipMemcpy2DAsync(g->canvas + g->off[c] + py * g->stride[c] + px * es, g->stride[c], b->arena + P.off_out[c], P.out_stride[c],
+                                            pw * es, ph, hipMemcpyDefault, g->stream[s]));   // (kind from the pointers: the canvas may sit on another device)
+        }
+      }
+      b->mark_done(g->stream[s]);
+      HIPDEC_CHECK_HIP(hipEventRecord(g->pasted[s], g->stream[s]));
+    }
+    {
+      DeviceScope scope(g->root);   // whatever the caller queues on the root's stream next sees the whole canvas
+      for (size_t s = 0; s < g->shard.size(); s++) HIPDEC_CHECK_HIP(hipStreamWaitEvent(default_stream(), g->pasted[s], 0));
+    }
+    g->decoded = true;
+    return 0;
+  });
+}
+
+int hipdec_grid_wait(hipdec_grid* g)
+{
+  if (!g || !g->decoded) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_wait: nothing was decoded");
+  for (size_t s = 0; s < g->shard.size(); s++) {
+    DeviceScope scope(g->devices[s]);
+    if (int rc = hipdec_batch_status(g->shard[s].get())) return rc;       // device-side decode errors are loud, per shard
+    HIPDEC_CHECK_HIP(hipEventSynchronize(g->pasted[s]));
+  }
+  DeviceScope scope(g->root);
+  HIPDEC_CHECK_HIP(hipStreamSynchronize(default_stream()));
+  return 0;
+}
+
+int hipdec_grid_canvas_plane(hipdec_grid* g, int c, const void** dptr, size_t* stride, int* device)
+{
+  if (!g || c < 0 || c > 2 || !dptr || !stride) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_canvas_plane: bad arguments");
+  if (c > 0 && !g->info.chroma_format_idc) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_canvas_plane: monochrome grid has no chroma planes");
+  *dptr = g->canvas + g->off[c]; *stride = g->stride[c];
+  if (device) *device = g->root;
+  return 0;
+}
+
+int hipdec_grid_read_plane(hipdec_grid* g, int c, void* dst_host, size_t dst_stride)
+{
+  if (!g || !g->decoded || c < 0 || c > 2 || !dst_host) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_read_plane: bad arguments");
+  if (int rc = hipdec_grid_wait(g)) return rc;
+  DeviceScope scope(g->root);
+  const size_t es = g->bits > 8 ? 2 : 1;
+  const size_t w = c ? (size_t)(g->out_w + 1) / 2 : (size_t)g->out_w, h = c ? (size_t)(g->out_h + 1) / 2 : (size_t)g->out_h;
+  HIPDEC_CHECK_HIP(hipMemcpy2D(dst_host, dst_stride, g->canvas + g->off[c], g->stride[c], w * es, h, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int hipdec_grid_to_rgb(hipdec_grid* g, int out_chroma, int upsampling, int only_preferred, void* out, size_t out_stride, int out_on_device)
+{
+  if (!g || !g->decoded || !out) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_to_rgb: bad arguments");
+  if (!g->info.chroma_format_idc) return set_error(HIPDEC_ERR_UNSUPPORTED, "grid_to_rgb: monochrome grid");
+  if (int rc = hipdec_grid_wait(g)) return rc;
+  DeviceScope scope(g->root);
+  hipdec_color_image img{};
+  img.width = g->out_w; img.height = g->out_h; img.chroma = 1; img.bit_depth = g->bits; img.on_device = 1;
+  for (int c = 0; c < 3; c++) { img.plane[c] = g->canvas + g->off[c]; img.stride[c] = g->stride[c]; }
+  hipdec_nclx nclx{1, g->info.colour_primaries, g->info.transfer_characteristics, g->info.matrix_coeffs, g->info.full_range_flag};
+  return hipdec_color_convert(&img, &nclx, out_chroma, upsampling, only_preferred, out, out_stride, out_on_device);
 }
 
 }  // extern "C"

@@ -13,6 +13,18 @@ namespace hipdec {
 
 int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 int ensure_init();
+// The device hipdec_init() selected — or, inside a DeviceScope on this thread, the scope's device: arenas, streams and launches of a
+// multi-device grid decode (grid.hip) are created under the scope of the shard's device.
+int active_device();
+class DeviceScope {
+ public:
+  explicit DeviceScope(int device);
+  ~DeviceScope();
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+ private:
+  int prev_;
+};
 hipStream_t default_stream();
 hipStream_t upload_stream();    // H2D copies of large batches (overlaps the kernels of the batch before)
 uint32_t parse_wave_budget();   // CABAC pool waves one batch may launch (wave slots / concurrent batches)

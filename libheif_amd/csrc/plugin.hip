@@ -157,7 +157,7 @@ hp_error decode_next_image2(void* p, hp_image** out_img, uintptr_t* out_user_dat
     }
     size_t stride = 0;
     uint8_t* dst = g_api.image_get_plane2(img, channel[c], &stride);
-    rc = hipdec_decoder_read_plane(d->dec, c, dst, stride);   // D2H straight into libheif's plane
+    rc = hipdec_decoder_read_plane_tracked(d->dec, c, dst, stride);   // D2H straight into libheif's plane; the device copy stays findable
     if (rc) { g_api.image_release(img); return make_error(d, rc); }
   }
   // VUI colour description -> nclx, as decoder_libde265.cc:426-449

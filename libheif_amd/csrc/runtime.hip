@@ -13,9 +13,12 @@ namespace hipdec {
 static thread_local std::string t_last_error = "";
 static std::mutex g_init_mutex;
 static bool g_initialised = false;
-static int g_device = 0;
-static hipStream_t g_stream = nullptr;
-static hipStream_t g_upload_stream = nullptr;
+static int g_device = 0;                      // the device hipdec_init() selected: what every entry point uses ...
+static thread_local int t_device_override = -1;   // ... unless a DeviceScope is active on this thread (multi-device grid decode)
+constexpr int kMaxDevices = 16;
+struct DeviceStreams { hipStream_t stream = nullptr, upload = nullptr; };
+static DeviceStreams g_streams[kMaxDevices];   // created on first use of a device, destroyed by hipdec_shutdown()
+static std::mutex g_streams_mu;
 static int g_cu_count = 256;                 // compute units of the selected device
 static std::atomic<int> g_concurrent{1};      // batches the host keeps in flight at a time (hipdec_set_concurrent_batches)
 
@@ -30,19 +33,52 @@ int set_error(int code, const char* fmt, ...)
   return code;
 }
 
+int active_device() { return t_device_override >= 0 ? t_device_override : g_device; }
+
 int ensure_init()
 {
   if (g_initialised) {
     // every host thread needs the device selected once; hipSetDevice is cheap
-    hipError_t e = hipSetDevice(g_device);
-    if (e != hipSuccess) return set_error(HIPDEC_ERR_DEVICE, "hipSetDevice(%d): %s", g_device, hipGetErrorString(e));
+    const int dev = active_device();
+    hipError_t e = hipSetDevice(dev);
+    if (e != hipSuccess) return set_error(HIPDEC_ERR_DEVICE, "hipSetDevice(%d): %s", dev, hipGetErrorString(e));
     return 0;
   }
   return hipdec_init(-1);
 }
 
-hipStream_t default_stream() { return g_stream; }
-hipStream_t upload_stream() { return g_upload_stream ? g_upload_stream : g_stream; }
+DeviceScope::DeviceScope(int device) : prev_(t_device_override)
+{
+  if (device >= 0 && device != active_device()) { t_device_override = device; (void)hipSetDevice(device); }
+  else if (device >= 0) t_device_override = device;
+}
+DeviceScope::~DeviceScope()
+{
+  const int was = active_device();
+  t_device_override = prev_;
+  if (active_device() != was) (void)hipSetDevice(active_device());
+}
+
+static DeviceStreams& streams_of_active_device()
+{
+  int dev = active_device();
+  if (dev < 0 || dev >= kMaxDevices) dev = 0;
+  DeviceStreams& d = g_streams[dev];
+  if (!d.stream) {
+    std::lock_guard<std::mutex> lock(g_streams_mu);
+    if (!d.stream) {
+      (void)hipSetDevice(dev);
+      hipStream_t up = nullptr, st = nullptr;
+      (void)hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+      (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+      d.upload = up;
+      d.stream = st;
+    }
+  }
+  return d;
+}
+hipStream_t default_stream() { return streams_of_active_device().stream; }
+hipStream_t upload_stream() { DeviceStreams& d = streams_of_active_device(); return d.upload ? d.upload : d.stream; }
 
 // Waves of the CABAC work pool one batch may launch: the pool only works while ALL its waves are resident (7 per SIMD with
 // the kernel's register budget), so concurrent batches have to share the machine's wave slots.
@@ -54,9 +90,10 @@ uint32_t parse_wave_budget()
 }
 
 namespace {
+struct ArenaEntry { size_t first; void* second; int device; };   // (capacity, pointer, device that owns the allocation)
 struct ArenaPool {
   std::mutex mu;
-  std::vector<std::pair<size_t, void*>> free_list;   // (capacity, pointer)
+  std::vector<ArenaEntry> free_list;
   size_t cached_bytes = 0;
 };
 ArenaPool g_pool;
@@ -153,8 +190,10 @@ hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity)
   {
     std::lock_guard<std::mutex> lock(g_pool.mu);
     size_t best = SIZE_MAX;
+    const int dev = active_device();
     for (size_t i = 0; i < g_pool.free_list.size(); i++) {
       const size_t cap = g_pool.free_list[i].first;
+      if (g_pool.free_list[i].device != dev) continue;
       if (cap >= bytes && cap <= bytes + bytes / 2 && (best == SIZE_MAX || cap < g_pool.free_list[best].first)) best = i;
     }
     if (best != SIZE_MAX) {
@@ -180,7 +219,7 @@ void arena_release(void* p, size_t capacity)
   if (capacity <= g_max_pooled_arena.load()) {
     std::lock_guard<std::mutex> lock(g_pool.mu);
     if (g_pool.cached_bytes + capacity <= g_max_cached_bytes.load()) {
-      g_pool.free_list.emplace_back(capacity, p);
+      g_pool.free_list.push_back(ArenaEntry{capacity, p, active_device()});
       g_pool.cached_bytes += capacity;
       return;
     }
@@ -190,25 +229,28 @@ void arena_release(void* p, size_t capacity)
 
 namespace {
 std::mutex g_stream_mu;
-std::vector<hipStream_t> g_free_streams;
+std::vector<std::pair<hipStream_t, int>> g_free_streams;   // (stream, device)
 }  // namespace
 
 hipStream_t stream_acquire()
 {
+  const int dev = active_device();
   {
     std::lock_guard<std::mutex> lock(g_stream_mu);
-    if (!g_free_streams.empty()) { hipStream_t s = g_free_streams.back(); g_free_streams.pop_back(); return s; }
+    for (size_t i = g_free_streams.size(); i-- > 0;)
+      if (g_free_streams[i].second == dev) { hipStream_t s = g_free_streams[i].first; g_free_streams.erase(g_free_streams.begin() + (long)i); return s; }
   }
   hipStream_t s = nullptr;
-  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return g_stream;   // fall back to the shared stream
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return default_stream();   // fall back to the shared stream
   return s;
 }
 
 void stream_release(hipStream_t s)
 {
-  if (!s || s == g_stream) return;
+  if (!s) return;
+  for (const auto& d : g_streams) if (s == d.stream || s == d.upload) return;
   std::lock_guard<std::mutex> lock(g_stream_mu);
-  if (g_free_streams.size() < 64) g_free_streams.push_back(s); else (void)hipStreamDestroy(s);
+  if (g_free_streams.size() < 64) g_free_streams.emplace_back(s, active_device()); else (void)hipStreamDestroy(s);
 }
 
 void arena_pool_clear()
@@ -241,12 +283,9 @@ int hipdec_init(int device_index)
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) g_cu_count = cus;
   }
-  if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
-  HIPDEC_CHECK_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-  if (g_upload_stream) { (void)hipStreamDestroy(g_upload_stream); g_upload_stream = nullptr; }
-  HIPDEC_CHECK_HIP(hipStreamCreateWithFlags(&g_upload_stream, hipStreamNonBlocking));
   g_device = dev;
   g_initialised = true;
+  if (!default_stream()) { g_initialised = false; return set_error(HIPDEC_ERR_DEVICE, "could not create a HIP stream on device %d", dev); }
   return 0;
 }
 
@@ -258,11 +297,17 @@ void hipdec_shutdown(void)
   pinned_pool_clear();
   {
     std::lock_guard<std::mutex> lock(g_stream_mu);
-    for (auto st : g_free_streams) (void)hipStreamDestroy(st);
+    for (auto& st : g_free_streams) (void)hipStreamDestroy(st.first);
     g_free_streams.clear();
   }
-  if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
-  if (g_upload_stream) { (void)hipStreamDestroy(g_upload_stream); g_upload_stream = nullptr; }
+  {
+    std::lock_guard<std::mutex> lock(g_streams_mu);
+    for (auto& d : g_streams) {
+      if (d.stream) (void)hipStreamDestroy(d.stream);
+      if (d.upload) (void)hipStreamDestroy(d.upload);
+      d = DeviceStreams{};
+    }
+  }
   g_initialised = false;
 }
 

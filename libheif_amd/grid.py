@@ -179,3 +179,73 @@ class GridDecoder:
                                                              L.out_w, L.out_h, 1, C.byref(ns), out.data_ptr(), out.stride(0), 0, None))
         check(self.lib.hipdec_stream_synchronize(None))
         return out
+
+
+class GridDecoderC:
+    """The same grid decode through the C ABI's hipdec_grid_* (include/heif_hipdec.h): ONE process, the tiles sharded over `devices`
+    (device indices, entries may repeat), every decoded tile pasted into the canvas on devices[0] by a strided peer copy.  This is the
+    product path; GridDecoder above is the multi-process (torch.distributed) test driver of the same partition."""
+
+    def __init__(self, tile_streams, layout, devices=None, max_image_size_pixels=0):
+        import ctypes as C
+        from .decoder import _bind
+        self._C = C
+        self.layout = layout
+        self.lib = lib = _bind(load_library())
+        vp, sz, ci = C.c_void_p, C.c_size_t, C.c_int
+        lib.hipdec_grid_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, C.POINTER(C.c_char_p), C.POINTER(sz), C.POINTER(ci), ci, C.c_uint64]
+        lib.hipdec_grid_free.argtypes = [vp]
+        lib.hipdec_grid_decode.argtypes = [vp]
+        lib.hipdec_grid_wait.argtypes = [vp]
+        lib.hipdec_grid_read_plane.argtypes = [vp, ci, vp, sz]
+        lib.hipdec_grid_to_rgb.argtypes = [vp, ci, ci, ci, vp, sz, ci]
+        lib.hipdec_grid_canvas_plane.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(sz), C.POINTER(ci)]
+        n = layout.n_tiles
+        self._keep = [bytes(tile_streams[t]) for t in range(n)]
+        arr = (C.c_char_p * n)(*self._keep)
+        sizes = (sz * n)(*[len(s) for s in self._keep])
+        devs = None
+        if devices is not None:
+            devs = (ci * len(devices))(*[int(d) for d in devices])
+        self._h = vp()
+        check(lib.hipdec_grid_create(C.byref(self._h), layout.rows, layout.cols, layout.out_w, layout.out_h, arr, sizes, devs,
+                                     len(devices) if devices is not None else 0, int(max_image_size_pixels)))
+
+    def decode(self):
+        check(self.lib.hipdec_grid_decode(self._h))
+
+    def wait(self):
+        check(self.lib.hipdec_grid_wait(self._h))
+
+    def planes(self):
+        L = self.layout
+        dt = np.uint16 if L.bit_depth > 8 else np.uint8
+        out = []
+        for c in range(3):
+            w, h = (L.out_w, L.out_h) if c == 0 else ((L.out_w + 1) // 2, (L.out_h + 1) // 2)
+            a = np.empty((h, w), dt)
+            check(self.lib.hipdec_grid_read_plane(self._h, c, a.ctypes.data, w * a.itemsize))
+            out.append(a)
+        return out
+
+    def to_rgb(self, out_chroma=10, upsampling=1, only_preferred=False, out_dev=None):
+        """host array (h, w * bytes per pixel) — or, with out_dev = (device pointer, stride), converts into that device buffer"""
+        L = self.layout
+        bpp = {10: 3, 11: 4, 12: 6, 14: 6}[out_chroma]
+        if out_dev is not None:
+            check(self.lib.hipdec_grid_to_rgb(self._h, out_chroma, upsampling, int(only_preferred), out_dev[0], out_dev[1], 1))
+            return None
+        a = np.empty((L.out_h, L.out_w * bpp), np.uint8)
+        check(self.lib.hipdec_grid_to_rgb(self._h, out_chroma, upsampling, int(only_preferred), a.ctypes.data, L.out_w * bpp, 0))
+        return a
+
+    def free(self):
+        if self._h:
+            self.lib.hipdec_grid_free(self._h)
+            self._h = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -260,9 +260,14 @@ def _payload(nals):
     return b"".join(struct.pack(">I", len(n)) + n for n in nals if (n[0] >> 1) & 63 < 32)
 
 
-def build_heic(items, grid=None, bit_depth=8, chroma_format_idc=1):
-    """items: list of (stream, width, height) coded items (ids 1..n).  grid: None, or
-    (rows, cols, out_w, out_h) -> an extra 'grid' item (id n+1, primary) referencing all items in order."""
+def build_heic(items, grid=None, bit_depth=8, chroma_format_idc=1, alpha_of=None):
+    """items: list of (stream, width, height[, chroma_format_idc]) coded items (ids 1..n).  grid: None, or
+    (rows, cols, out_w, out_h) -> an extra 'grid' item (id n+1, primary) referencing all items in order.
+    alpha_of: {alpha item id: master item id} -> the alpha item becomes a hidden auxiliary image of its master ('auxC' property
+    urn:mpeg:hevc:2015:auxid:1 + 'auxl' reference), what libheif attaches as the alpha channel (image_item.cc:949-1081)."""
+    alpha_of = alpha_of or {}
+    cfs = [it[3] if len(it) > 3 else chroma_format_idc for it in items]
+    items = [it[:3] for it in items]
     n = len(items)
     payloads = [_payload(split_nals(s)) for s, _, _ in items]
     grid_data = b""
@@ -273,9 +278,12 @@ def build_heic(items, grid=None, bit_depth=8, chroma_format_idc=1):
     # ---- properties: per item hvcC + ispe (+ ispe for the grid) ----
     props, assoc = [], {}
     for i, (s, w, h) in enumerate(items):
-        props.append(_hvcc(split_nals(s), chroma_format_idc, bit_depth))
+        props.append(_hvcc(split_nals(s), cfs[i], bit_depth))
         props.append(_fullbox("ispe", 0, 0, struct.pack(">II", w, h)))
         assoc[i + 1] = [(len(props) - 1, True), (len(props), False)]
+        if i + 1 in alpha_of:
+            props.append(_fullbox("auxC", 0, 0, b"urn:mpeg:hevc:2015:auxid:1\0"))
+            assoc[i + 1].append((len(props), True))
     if grid is not None:
         props.append(_fullbox("ispe", 0, 0, struct.pack(">II", grid[2], grid[3])))
         assoc[n + 1] = [(len(props), False)]
@@ -288,7 +296,7 @@ def build_heic(items, grid=None, bit_depth=8, chroma_format_idc=1):
     iprp = _box("iprp", ipco + _fullbox("ipma", 0, 0, ipma))
     infes = b""
     for i in range(n):
-        hidden = 1 if grid is not None else 0
+        hidden = 1 if (grid is not None or (i + 1) in alpha_of) else 0
         infes += _fullbox("infe", 2, hidden, struct.pack(">HH4s", i + 1, 0, b"hvc1") + b"\0")
     if grid is not None:
         infes += _fullbox("infe", 2, 0, struct.pack(">HH4s", n + 1, 0, b"grid") + b"\0")
@@ -297,8 +305,14 @@ def build_heic(items, grid=None, bit_depth=8, chroma_format_idc=1):
     pitm = _fullbox("pitm", 0, 0, struct.pack(">H", primary))
     hdlr = _fullbox("hdlr", 0, 0, struct.pack(">I4s", 0, b"pict") + b"\0" * 12 + b"\0")
     iref = b""
+    refs = b""
     if grid is not None:
-        iref = _fullbox("iref", 0, 0, _box("dimg", struct.pack(">HH", n + 1, n) + b"".join(struct.pack(">H", i + 1) for i in range(n))))
+        tiles = [i + 1 for i in range(n) if (i + 1) not in alpha_of]
+        refs += _box("dimg", struct.pack(">HH", n + 1, len(tiles)) + b"".join(struct.pack(">H", t) for t in tiles))
+    for a, m in sorted(alpha_of.items()):
+        refs += _box("auxl", struct.pack(">HHH", a, 1, m))
+    if refs:
+        iref = _fullbox("iref", 0, 0, refs)
     ftyp = _box("ftyp", b"heic" + struct.pack(">I", 0) + b"mif1heic")
 
     def make_meta(offsets):

@@ -14,6 +14,7 @@ _PLUGIN_LOADED = False
 
 COLORSPACE_YCBCR, COLORSPACE_RGB, COLORSPACE_MONO, COLORSPACE_UNDEFINED = 0, 1, 2, 99
 CHROMA_UNDEFINED, CHROMA_MONO, CHROMA_420, CHROMA_RGB, CHROMA_RGBA = 99, 0, 1, 10, 11
+CHROMA_RRGGBB_BE, CHROMA_RRGGBB_LE = 12, 14
 CHANNEL_Y, CHANNEL_CB, CHANNEL_CR, CHANNEL_INTERLEAVED = 0, 1, 2, 10
 COMPRESSION_HEVC = 1
 
@@ -28,14 +29,19 @@ class LibheifError(RuntimeError):
         self.code, self.subcode = e.code, e.subcode
 
 
-def available():
-    return os.path.exists(os.path.join(_REF, "libheif.so"))
+# HIPDEC_TEST_LIBHEIF selects the build of the reference to drive: libheif.so (stock) or libheif_hipcolor.so (the same sources with the
+# HIP colour op registered in init_ops(), oracle/Makefile.ref) — one per process, both export the same symbols
+_NAME = os.environ.get("HIPDEC_TEST_LIBHEIF", "libheif.so")
+
+
+def available(name=None):
+    return os.path.exists(os.path.join(_REF, name or _NAME))
 
 
 def lib():
     global _LIB
     if _LIB is None:
-        L = C.CDLL(os.path.join(_REF, "libheif.so"), mode=C.RTLD_GLOBAL)
+        L = C.CDLL(os.path.join(_REF, _NAME), mode=C.RTLD_GLOBAL)
         vp = C.c_void_p
         L.heif_load_plugin.restype = HeifError
         L.heif_load_plugin.argtypes = [C.c_char_p, C.POINTER(vp)]
@@ -129,6 +135,8 @@ def decode(data, colorspace=COLORSPACE_UNDEFINED, chroma=CHROMA_UNDEFINED, max_t
         out = {}
         if chroma in (CHROMA_RGB, CHROMA_RGBA):
             out["rgb"] = _plane(L, img, CHANNEL_INTERLEAVED, 1, 3 if chroma == CHROMA_RGB else 4)
+        elif chroma in (CHROMA_RRGGBB_BE, CHROMA_RRGGBB_LE):
+            out["rgb"] = _plane(L, img, CHANNEL_INTERLEAVED, 1, 6)
         else:
             bpp = L.heif_image_get_bits_per_pixel_range(img, CHANNEL_Y)
             bs = 2 if bpp > 8 else 1

@@ -1,0 +1,126 @@
+"""The colour boundary (SURVEY.md §8b "second boundary", §8a row a8): libheif's ColorConversionPipeline with the HIP op registered in
+init_ops() (libheif_amd/integration/colorconversion_hip.cc, built into oracle/_ref/libheif_hipcolor.so by oracle/Makefile.ref) against
+the STOCK pipeline of the same reference (oracle/_ref/libheif.so).
+
+CPU part: the C planner hipdec_color_plan() makes the decisions of ColorConversionPipeline::construct_pipeline
+(colorconversion.cc:279-435) — checked against the chains the real planner builds, probed through the compiled reference — and
+the patched library exists and exports the same API.  GPU part: heif_decode_image(..., RGB, interleaved) through the patched libheif
++ the decoder plugin runs the HIP colour kernels (counters of the boundary as proof; profiles/ holds the rocprofv3 kernel trace of
+the same test) on the decoder's device-resident planes, bit-exact against the stock pipeline."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+
+import libheif_amd
+from libheif_amd._capi import Nclx
+from oracle import pyoracle as orc
+import heic_util as hu
+import libheif_host as lh
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OPS = {1: "to_sdr", 2: "bilinear", 3: "420_to_rgb24", 4: "420_to_rgb32", 5: "ycbcr_to_rgb", 6: "rgb_to_rgb24_32", 7: "420_to_rrggbb"}
+
+
+def _plan(bpp, chroma, has_alpha, nclx, out_chroma, ups, only):
+    lib = libheif_amd.load_library()
+    lib.hipdec_color_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Nclx), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    ops, n = (C.c_int * 8)(), C.c_int()
+    ns = Nclx(1, *[int(v) for v in nclx]) if nclx is not None else Nclx(0, 2, 2, 2, 1)
+    rc = lib.hipdec_color_plan(bpp, chroma, int(has_alpha), C.byref(ns), out_chroma, ups, int(only), ops, C.byref(n))
+    return rc, [OPS[ops[i]] for i in range(n.value)]
+
+
+def test_c_planner_matches_the_python_mirror_and_the_reference_rules():
+    """every in-scope state: same chain as libheif_amd/color.py:plan (round 1's mirror, itself checked against the compiled
+    reference planner in tests/test_color_oracle.py)"""
+    from libheif_amd import color
+    names = {"Op_to_sdr_planes": "to_sdr", "Op_YCbCr420_bilinear_to_YCbCr444": "bilinear", "Op_YCbCr420_to_RGB24": "420_to_rgb24",
+             "Op_YCbCr420_to_RGB32": "420_to_rgb32", "Op_YCbCr_to_RGB<u8>": "ycbcr_to_rgb", "Op_RGB_to_RGB24_32": "rgb_to_rgb24_32",
+             "Op_YCbCr420_to_RRGGBBaa": "420_to_rrggbb"}
+    n = 0
+    for bpp in (8, 10, 12):
+        for nclx in (None, (1, 13, 6, 1), (1, 13, 6, 0), (9, 16, 9, 0), (9, 16, 9, 1), (1, 1, 1, 0), (2, 2, 2, 1), (1, 13, 0, 1), (1, 13, 8, 1), (1, 13, 11, 1)):
+            for out in (10, 11, 12, 14):
+                for ups, only in ((1, False), (2, False), (2, True), (1, True)):
+                    try:
+                        want = [names[x] for x in color.plan(bpp, 1, nclx, out, ups, only)]
+                    except libheif_amd.HipDecError:
+                        want = None
+                    rc, got = _plan(bpp, 1, False, nclx, out, ups, only)
+                    assert (rc == 0) == (want is not None), (bpp, nclx, out, ups, only, rc, want)
+                    if want is not None:
+                        assert got == want, (bpp, nclx, out, ups, only)
+                        n += 1
+    assert n > 100
+    assert _plan(8, 1, True, (1, 13, 6, 1), 11, 1, False) == (0, ["420_to_rgb32"])       # alpha plane travels with the integer op
+    assert _plan(8, 1, True, (1, 13, 6, 0), 11, 1, False) == (0, ["ycbcr_to_rgb", "rgb_to_rgb24_32"])
+    assert _plan(8, 1, True, (1, 13, 6, 1), 10, 1, False)[0] != 0                          # dropping alpha: stock ops
+
+
+def test_patched_reference_is_built_with_the_op():
+    if not os.path.isdir("/root/reference") and not lh.available("libheif_hipcolor.so"):
+        pytest.fail("oracle/_ref/libheif_hipcolor.so missing: build() must run where /root/reference exists")
+    if not lh.available("libheif_hipcolor.so"):
+        pytest.skip("oracle/_ref not built")
+    so = os.path.join(HERE, "..", "oracle", "_ref", "libheif_hipcolor.so")
+    syms = subprocess.run(["nm", "-DC", "--defined-only", so], capture_output=True, text=True).stdout
+    assert "Op_YCbCr_to_RGB_hip::convert_colorspace" in syms and "heif_decode_image" in syms
+    stock = subprocess.run(["nm", "-DC", "--defined-only", os.path.join(HERE, "..", "oracle", "_ref", "libheif.so")], capture_output=True, text=True).stdout
+    assert "Op_YCbCr_to_RGB_hip" not in stock
+
+
+SRGB = dict(vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1)
+
+
+def _run_child(libname, jobs, tmp_path):
+    jf, of = str(tmp_path / ("jobs_%s.json" % libname)), str(tmp_path / ("out_%s.npz" % libname))
+    json.dump(jobs, open(jf, "w"))
+    env = dict(os.environ, HIPDEC_TEST_LIBHEIF=libname, PYTHONPATH=os.pathsep.join([os.path.join(HERE, ".."), HERE]))
+    subprocess.run([sys.executable, os.path.join(HERE, "colorboundary_child.py"), jf, of], check=True, env=env, timeout=600)
+    return np.load(of)
+
+
+@pytest.mark.gpu
+def test_heif_decode_image_to_rgb_runs_the_hip_colour_op_bit_exact(tmp_path):
+    if not (lh.available("libheif.so") and lh.available("libheif_hipcolor.so")):
+        pytest.fail("oracle/_ref libraries missing on the GPU box")
+    cases = []
+
+    def add(name, heic, chroma, threads=None):
+        path = str(tmp_path / (name + ".heic"))
+        open(path, "wb").write(heic)
+        cases.append(dict(name=name, heic=path, colorspace=lh.COLORSPACE_RGB, chroma=chroma, threads=threads))
+
+    s = orc.encode(orc.synth_image(456, 264, 8, 1, seed=21), **SRGB)
+    add("srgb_rgb", hu.build_heic([(s, 456, 264)]), lh.CHROMA_RGB)                         # integer op, planes device-resident
+    add("srgb_rgba", hu.build_heic([(s, 456, 264)]), lh.CHROMA_RGBA)
+    s = orc.encode(orc.synth_image(322, 200, 8, 1, seed=22), vui_primaries=1, vui_transfer=1, vui_matrix=1, vui_full_range=0)
+    add("bt709_limited_rgb", hu.build_heic([(s, 322, 200)]), lh.CHROMA_RGB)                # float chain
+    s = orc.encode(orc.synth_image(200, 136, 8, 1, seed=23))
+    add("no_vui_rgb", hu.build_heic([(s, 200, 136)]), lh.CHROMA_RGB)                       # unspecified nclx
+    s10 = orc.encode(orc.synth_image(264, 200, 10, 1, seed=24), bit_depth=10, vui_matrix=9, vui_primaries=9, vui_transfer=16)
+    add("main10_rrggbb_le", hu.build_heic([(s10, 264, 200)], bit_depth=10), lh.CHROMA_RRGGBB_LE)
+    add("main10_rrggbb_be", hu.build_heic([(s10, 264, 200)], bit_depth=10), lh.CHROMA_RRGGBB_BE)
+    tiles = [(orc.encode(orc.synth_image(128, 128, 8, 1, seed=30 + i), **SRGB), 128, 128) for i in range(6)]
+    add("grid_rgb", hu.build_heic(tiles, grid=(2, 3, 380, 250)), lh.CHROMA_RGB, threads=6)  # canvas assembled by libheif: upload path
+    master = orc.encode(orc.synth_image(200, 136, 8, 1, seed=25), **SRGB)
+    alpha = orc.encode(orc.synth_image(200, 136, 8, 0, seed=26))
+    add("alpha_rgba", hu.build_heic([(master, 200, 136, 1), (alpha, 200, 136, 0)], alpha_of={2: 1}), lh.CHROMA_RGBA)
+
+    stock = _run_child("libheif.so", cases, tmp_path)
+    hipc = _run_child("libheif_hipcolor.so", cases, tmp_path)
+    for c in cases:
+        n = c["name"]
+        np.testing.assert_array_equal(hipc[n + ".rgb"], stock[n + ".rgb"], err_msg=n)
+        conv, resident, launches = [int(v) for v in hipc[n + ".stats"]]
+        assert tuple(int(v) for v in stock[n + ".stats"]) == (0, 0, 0), n                   # the stock build never reaches the boundary
+        assert conv == 1 and launches >= 1, (n, conv, resident, launches)
+        if n not in ("grid_rgb",):
+            assert resident >= 3, (n, resident)                                              # the decoder's own device planes were used
+    # the alpha really is the auxiliary image's plane
+    a_ref = orc.decode(alpha)["planes"][0]
+    np.testing.assert_array_equal(hipc["alpha_rgba.rgb"].reshape(136, 200, 4)[:, :, 3], a_ref)

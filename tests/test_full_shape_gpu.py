@@ -130,6 +130,25 @@ def test_config3_8k_grid_through_grid_decoder():
     np.testing.assert_array_equal(rgb, want)
 
 
+@pytest.mark.parametrize("devices", [[0], [0] * 8], ids=["one_shard", "eight_shards"])
+def test_config3_8k_grid_through_the_c_grid_api(devices):
+    """the product path of config 3: hipdec_grid_* (C++, one process); eight shards = the t mod 8 partition of an 8-GPU node, here
+    all on the one device of the GPU box"""
+    from libheif_amd.grid import GridDecoderC, GridLayout
+    rows, cols, tw, th = 6, 8, 1024, 1024
+    streams = _grid_streams()
+    canvas = _grid_canvas(streams, rows, cols, tw, th)
+    g = GridDecoderC({t: s for t, s in enumerate(streams)}, GridLayout(rows, cols, tw, th, cols * tw, rows * th), devices)
+    g.decode(); g.wait()
+    planes = g.planes()
+    for k in range(3):
+        np.testing.assert_array_equal(planes[k], canvas[k], err_msg="component %d" % k)
+    rgb = g.to_rgb(10)
+    want = orc.color_420_to_rgb24(canvas[0], canvas[1], canvas[2], (1, 13, 6, 1)).reshape(rows * th, -1)
+    np.testing.assert_array_equal(rgb, want)
+    g.free()
+
+
 def test_config3_8k_grid_through_libheif_and_the_plugin():
     import heic_util as hu
     import libheif_host as lh

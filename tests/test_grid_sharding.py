@@ -102,3 +102,66 @@ def test_grid_decoder_single_gpu_matches_oracle():
         np.testing.assert_array_equal(canvas[c].cpu().numpy(), exp[c], err_msg="canvas component %d" % c)
     rgb = gd.to_rgb((1, 13, 6, 1)).cpu().numpy()
     np.testing.assert_array_equal(rgb, orc.color_420_to_rgb24(exp[0], exp[1], exp[2], (1, 13, 6, 1)).reshape(L.out_h, -1))
+
+
+# ---- the product path: hipdec_grid_* in C++, one process over several devices (include/heif_hipdec.h) ---------------------------------
+def test_grid_c_api_without_gpu_fails_loudly():
+    import libheif_amd
+    from libheif_amd import HipDecError
+    from libheif_amd.grid import GridDecoderC, GridLayout
+    if libheif_amd.load_library().hipdec_device_count() > 0:
+        pytest.skip("a GPU is present")
+    s = orc.encode(orc.synth_image(64, 64, 8, 1, seed=1))
+    with pytest.raises(HipDecError) as e:
+        GridDecoderC({0: s, 1: s}, GridLayout(1, 2, 64, 64, 128, 64))
+    assert e.value.code == -6
+
+
+def _c_grid_case(rows, cols, tw, th, ow, oh, devices, seed0=70, **cfg):
+    from libheif_amd.grid import GridDecoderC, GridLayout
+    streams = [orc.encode(orc.synth_image(tw, th, cfg.get("bit_depth", 8), 1, seed=seed0 + t), **cfg) for t in range(rows * cols)]
+    es = np.uint16 if cfg.get("bit_depth", 8) > 8 else np.uint8
+    canvas = [np.zeros((rows * th, cols * tw), es), np.zeros((rows * th // 2, cols * tw // 2), es), np.zeros((rows * th // 2, cols * tw // 2), es)]
+    for t, s in enumerate(streams):
+        ref = orc.decode(s)
+        r, c = divmod(t, cols)
+        for k in range(3):
+            d = 1 if k == 0 else 2
+            canvas[k][r * th // d:(r + 1) * th // d, c * tw // d:(c + 1) * tw // d] = ref["planes"][k]
+    g = GridDecoderC({t: s for t, s in enumerate(streams)}, GridLayout(rows, cols, tw, th, ow, oh, cfg.get("bit_depth", 8)), devices)
+    g.decode(); g.wait()
+    got = g.planes()
+    np.testing.assert_array_equal(got[0], canvas[0][:oh, :ow])
+    np.testing.assert_array_equal(got[1], canvas[1][:(oh + 1) // 2, :(ow + 1) // 2])
+    np.testing.assert_array_equal(got[2], canvas[2][:(oh + 1) // 2, :(ow + 1) // 2])
+    return g, [c for c in canvas]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [None, [0], [0, 0], [0, 0, 0, 0, 0]], ids=["all_visible", "one", "two_shards", "five_shards"])
+def test_grid_c_api_shards_paste_into_the_canvas(devices):
+    """tiles t mod G per shard (several shards on the one device of the GPU box exercise the partition, the per-shard batches and
+    the strided pastes), clipped output, fused colour stage over the canvas"""
+    vui = dict(vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1)
+    g, canvas = _c_grid_case(2, 3, 128, 128, 380, 250, devices, **vui)
+    rgb = g.to_rgb(10)
+    want = orc.color_420_to_rgb24(canvas[0][:250, :380], canvas[1][:125, :190], canvas[2][:125, :190], (1, 13, 6, 1)).reshape(250, -1)
+    np.testing.assert_array_equal(rgb, want)
+    g.decode(); g.wait()          # a second decode over the same arenas
+    np.testing.assert_array_equal(g.planes()[0], canvas[0][:250, :380])
+    g.free()
+
+
+@pytest.mark.gpu
+def test_grid_c_api_main10_and_errors():
+    from libheif_amd import HipDecError
+    from libheif_amd.grid import GridDecoderC, GridLayout
+    g, canvas = _c_grid_case(2, 2, 136, 72, 272, 144, [0, 0], bit_depth=10, vui_matrix=9, vui_primaries=9, vui_transfer=16)
+    rgb = g.to_rgb(14)
+    np.testing.assert_array_equal(rgb, orc.color_420_to_rrggbb(canvas[0], canvas[1], canvas[2], 10, (9, 16, 9, 0), little_endian=True))
+    g.free()
+    a = orc.encode(orc.synth_image(64, 64, 8, 1, seed=1)); b = orc.encode(orc.synth_image(128, 64, 8, 1, seed=2))
+    with pytest.raises(HipDecError):           # tiles of different size (grid.cc rejects such grids)
+        GridDecoderC({0: a, 1: b}, GridLayout(1, 2, 64, 64, 128, 64))
+    with pytest.raises(HipDecError):           # a device that does not exist
+        GridDecoderC({0: a, 1: a}, GridLayout(1, 2, 64, 64, 128, 64), [0, 99])

@@ -143,3 +143,79 @@ def test_heif_decode_image_to_rgb_matches_reference_colour_ops_on_oracle_planes(
     out = lh.decode(hu.build_heic([(s, w, h)]), lh.COLORSPACE_RGB, lh.CHROMA_RGB)
     exp = rh.convert(ref["planes"], 8, rh.CH_420, ref["nclx"], rh.CS_RGB, rh.CH_RGB)[0]
     np.testing.assert_array_equal(out["rgb"], exp[:, :w * 3])
+
+
+# ---- f2: alpha auxiliary image (libheif/image-items/image_item.cc:949-1081) -------------------------------------------------
+def _with_alpha_fixture():
+    """the reference's tests/data/with-alpha-512x512.heic, rebuilt from its two committed HEVC items (tests/golden/ref_with_alpha_*:
+    item 1 colour 4:2:0, item 2 the monochrome alpha auxiliary image) — the GPU box has no /root/reference"""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    colour = open(os.path.join(gold, "ref_with_alpha_512x512_1.hevc"), "rb").read()
+    alpha = open(os.path.join(gold, "ref_with_alpha_512x512_2.hevc"), "rb").read()
+    return colour, alpha, hu.build_heic([(colour, 512, 512, 1), (alpha, 512, 512, 0)], alpha_of={2: 1})
+
+
+@needs_ref
+def test_alpha_auxiliary_heic_is_recognised_by_the_reference():
+    """tests/component_descriptions.cc:362-366 asserts alpha as the 4th component of this file"""
+    import ctypes as C
+    _, _, heic = _with_alpha_fixture()
+    L = lh.lib()
+    ctx, h = lh.open_heic(heic)
+    try:
+        L.heif_image_handle_has_alpha_channel.argtypes = [C.c_void_p]
+        assert L.heif_image_handle_has_alpha_channel(h) == 1
+        assert (L.heif_image_handle_get_width(h), L.heif_image_handle_get_height(h)) == (512, 512)
+    finally:
+        L.heif_image_handle_release(h)
+        L.heif_context_free(ctx)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_with_alpha_fixture_decodes_to_rgba_with_the_real_alpha_plane():
+    """two plugin decodes (colour item + monochrome alpha item, x265-coded), libheif attaches the alpha plane, RGBA out: colour
+    equals the reference colour ops over the oracle's planes, the alpha channel equals the oracle's decode of the alpha item"""
+    import ref_harness as rh
+    lh.load_hip_plugin()
+    colour, alpha, heic = _with_alpha_fixture()
+    ref = orc.decode(colour)
+    aref = orc.decode(alpha)
+    assert aref["chroma_format_idc"] == 0
+    out = lh.decode(heic, lh.COLORSPACE_RGB, lh.CHROMA_RGBA)["rgb"].reshape(512, 512, 4)
+    exp = rh.convert(ref["planes"], 8, rh.CH_420, ref["nclx"], rh.CS_RGB, rh.CH_RGBA)[0][:, :512 * 4].reshape(512, 512, 4)
+    np.testing.assert_array_equal(out[:, :, :3], exp[:, :, :3])
+    np.testing.assert_array_equal(out[:, :, 3], aref["planes"][0])
+    # and as planes: YCbCr + alpha
+    yuv = lh.decode(heic, lh.COLORSPACE_YCBCR, lh.CHROMA_420)
+    for c in range(3):
+        np.testing.assert_array_equal(yuv["planes"][c], ref["planes"][c])
+
+
+# ---- f1: one tile of a grid (libheif/api/libheif/heif_tiling.cc:99-133, image-items/grid.cc:580-603) -------------------------
+@needs_ref
+@pytest.mark.gpu
+def test_heif_image_handle_decode_image_tile_decodes_only_that_tile():
+    import ctypes as C
+    from libheif_amd.decoder import coalesce_stats
+    L = lh.load_hip_plugin()
+    rows, cols, tw, th = 2, 3, 128, 128
+    streams = [_still(tw, th, seed=60 + i) for i in range(rows * cols)]
+    heic = hu.build_heic([(s, tw, th) for s in streams], grid=(rows, cols, cols * tw, rows * th))
+    ctx, h = lh.open_heic(heic)
+    L.heif_image_handle_decode_image_tile.restype = lh.HeifError
+    L.heif_image_handle_decode_image_tile.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32]
+    try:
+        for (tx, ty) in ((0, 0), (2, 1), (1, 0)):
+            before = coalesce_stats()[0]
+            img = C.c_void_p()
+            lh.check(L.heif_image_handle_decode_image_tile(h, C.byref(img), lh.COLORSPACE_YCBCR, lh.CHROMA_420, None, tx, ty))
+            assert coalesce_stats()[0] - before == 1          # exactly one plugin decode: the requested tile
+            ref = orc.decode(streams[ty * cols + tx])
+            for c, ch in enumerate((lh.CHANNEL_Y, lh.CHANNEL_CB, lh.CHANNEL_CR)):
+                np.testing.assert_array_equal(lh._plane(L, img, ch), ref["planes"][c])
+            L.heif_image_release(img)
+    finally:
+        L.heif_image_handle_release(h)
+        L.heif_context_free(ctx)
