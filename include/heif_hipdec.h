@@ -123,6 +123,9 @@ HIPDEC_API int hipdec_decoder_read_plane(hipdec_decoder* dec, int c, void* dst_h
 /* the same, and remembers (host pointer -> device copy) so that hipdec_color_convert() on those very host planes skips the upload:
  * what the libheif plugin uses */
 HIPDEC_API int hipdec_decoder_read_plane_tracked(hipdec_decoder* dec, int c, void* dst_host, size_t dst_stride);
+/* drops every remembered (host pointer -> device copy) pair and with them the decode arenas they keep alive; hipdec_shutdown() and the
+ * plugin's deinit_plugin() call it */
+HIPDEC_API void hipdec_forget_resident_planes(void);
 /* device-resident hand-over for callers that keep the colour stage on the GPU */
 HIPDEC_API int hipdec_decoder_device_plane(hipdec_decoder* dec, int c, const void** dptr, size_t* stride);
 

@@ -402,8 +402,8 @@ int hipdec_batch_timing_slots(hipdec_batch* b, int slots)
 int hipdec_batch_slot_kernel_timing_us(hipdec_batch* b, int slot, float out[8])
 {
   if (!b || !out || slot < 0 || (size_t)slot >= b->ev.size() / kEv || (uint64_t)slot >= b->runs)
-  DeviceScope scope(b->device);
     return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "slot_timing: no run recorded in slot %d", slot);
+  DeviceScope scope(b->device);
   hipEvent_t* ev = b->ev.data() + kEv * (size_t)slot;
   HIPDEC_CHECK_HIP(hipEventSynchronize(ev[5]));
   for (int k = 0; k < 5; k++) {
@@ -781,7 +781,9 @@ struct ResidentPlane {
   uint64_t tick = 0;
 };
 std::mutex g_res_mu;
-std::vector<ResidentPlane> g_resident;
+// (heap-allocated and never destroyed: its entries own batches, and destroying those from a static destructor at process exit would
+//  run after the HIP runtime and this library's pools are gone; hipdec_shutdown() / the plugin's deinit empty it in good time)
+std::vector<ResidentPlane>& g_resident = *new std::vector<ResidentPlane>();
 uint64_t g_res_tick = 0;
 std::atomic<uint64_t> g_cb_conversions{0}, g_cb_resident{0}, g_cb_launches{0};
 constexpr size_t kMaxResident = 24;    // planes (8 images): every entry keeps its batch arena alive
@@ -840,6 +842,15 @@ bool resident_find(const void* host, size_t stride, int w, int h, int bits, cons
 }  // namespace
 
 extern "C" {
+
+void hipdec_forget_resident_planes(void)
+{
+  std::vector<ResidentPlane> drop;
+  {
+    std::lock_guard<std::mutex> lock(g_res_mu);
+    drop.swap(g_resident);
+  }
+}   // the batches die here, outside the lock
 
 int hipdec_decoder_read_plane_tracked(hipdec_decoder* d, int c, void* dst, size_t dst_stride)
 {

@@ -80,7 +80,7 @@ hp_error make_error(PluginDecoder* d, int rc)
 
 const char* plugin_name() { return "MI355X HIP HEVC decoder (libheif-hipdec), gfx950"; }
 void init_plugin() { std::call_once(g_api_once, resolve_api); }
-void deinit_plugin() {}
+void deinit_plugin() { hipdec_forget_resident_planes(); }   // heif_deinit(): nothing of ours may outlive the host's use of the library
 int does_support_format(int format) { return format == HP_COMPRESSION_HEVC ? 200 /* above libde265's 100 */ : 0; }
 int does_support_format2(const hp_format_description* f) { return f ? does_support_format(f->format) : 0; }
 

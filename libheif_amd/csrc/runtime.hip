@@ -293,6 +293,7 @@ void hipdec_shutdown(void)
 {
   std::lock_guard<std::mutex> lock(g_init_mutex);
   if (!g_initialised) return;
+  hipdec_forget_resident_planes();
   arena_pool_clear();
   pinned_pool_clear();
   {
