@@ -79,7 +79,21 @@ hp_error make_error(PluginDecoder* d, int rc)
 }
 
 const char* plugin_name() { return "MI355X HIP HEVC decoder (libheif-hipdec), gfx950"; }
-void init_plugin() { std::call_once(g_api_once, resolve_api); }
+// Hands the colour boundary's entry points to a libheif that carries the HIP colour op (libheif_amd/integration/colorconversion_hip.cc):
+// the plugin is loaded with local symbol scope, so the op cannot look them up itself.  A stock libheif has no such symbol: nothing
+// happens and its CPU colour ops run.
+void announce_color_backend()
+{
+  using reg_fn = void (*)(int (*)(int, int, int, const hipdec_nclx*, int, int, int, int*, int*),
+                          int (*)(const hipdec_color_image*, const hipdec_nclx*, int, int, int, void*, size_t, int), const char* (*)(void), int);
+  if (auto reg = (reg_fn)dlsym(RTLD_DEFAULT, "heif_color_conversion_register_hip_backend"))
+    reg(hipdec_color_plan, hipdec_color_convert, hipdec_last_error, hipdec_device_count() > 0 ? 1 : 0);
+}
+void init_plugin()
+{
+  std::call_once(g_api_once, resolve_api);
+  announce_color_backend();
+}
 void deinit_plugin() { hipdec_forget_resident_planes(); }   // heif_deinit(): nothing of ours may outlive the host's use of the library
 int does_support_format(int format) { return format == HP_COMPRESSION_HEVC ? 200 /* above libde265's 100 */ : 0; }
 int does_support_format2(const hp_format_description* f) { return f ? does_support_format(f->format) : 0; }

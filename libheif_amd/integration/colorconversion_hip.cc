@@ -35,18 +35,23 @@ struct HipApi {
   bool usable = false;
 };
 
-const HipApi& hip_api()
+std::mutex g_api_mutex;
+HipApi g_api;
+bool g_api_probed = false;
+
+HipApi hip_api()
 {
-  static HipApi api;
-  static std::once_flag once;
-  std::call_once(once, [] {
-    api.plan = (plan_fn) dlsym(RTLD_DEFAULT, "hipdec_color_plan");
-    api.convert = (convert_fn) dlsym(RTLD_DEFAULT, "hipdec_color_convert");
-    api.last_error = (last_error_fn) dlsym(RTLD_DEFAULT, "hipdec_last_error");
+  std::lock_guard<std::mutex> lock(g_api_mutex);
+  if (!g_api.usable && !g_api_probed) {
+    // a host that links libheifhip.so itself (static plugin registration) exposes the entry points globally
+    g_api_probed = true;
+    g_api.plan = (plan_fn) dlsym(RTLD_DEFAULT, "hipdec_color_plan");
+    g_api.convert = (convert_fn) dlsym(RTLD_DEFAULT, "hipdec_color_convert");
+    g_api.last_error = (last_error_fn) dlsym(RTLD_DEFAULT, "hipdec_last_error");
     auto count = (device_count_fn) dlsym(RTLD_DEFAULT, "hipdec_device_count");
-    api.usable = api.plan && api.convert && count && count() > 0;
-  });
-  return api;
+    g_api.usable = g_api.plan && g_api.convert && count && count() > 0;
+  }
+  return g_api;
 }
 
 hipdec_nclx to_hipdec(const nclx_profile& p)
@@ -63,13 +68,30 @@ int upsampling_of(const heif_color_conversion_options& options)
 }  // namespace
 
 
+// The decoder plugin is dlopen()ed with local symbol scope (libheif/plugins_unix.cc:103-118), so it announces its colour entry
+// points itself: libheifhip's init_plugin() looks this function up in the hosting process and calls it (csrc/plugin.hip).
+// `usable` = a HIP device is present.
+extern "C" __attribute__((visibility("default")))
+void heif_color_conversion_register_hip_backend(int (*plan)(int, int, int, const void*, int, int, int, int*, int*),
+                                                int (*convert)(const void*, const void*, int, int, int, void*, size_t, int),
+                                                const char* (*last_error)(void), int usable)
+{
+  std::lock_guard<std::mutex> lock(g_api_mutex);
+  g_api.plan = (plan_fn) plan;
+  g_api.convert = (convert_fn) convert;
+  g_api.last_error = last_error;
+  g_api.usable = plan && convert && usable;
+  g_api_probed = true;
+}
+
+
 std::vector<ColorStateWithCost>
 Op_YCbCr_to_RGB_hip::state_after_conversion(const ColorState& input_state,
                                             const ColorState& target_state,
                                             const heif_color_conversion_options& options,
                                             const heif_color_conversion_options_ext& options_ext) const
 {
-  const HipApi& api = hip_api();
+  const HipApi api = hip_api();
   if (!api.usable) {
     return {};
   }
@@ -131,7 +153,7 @@ Op_YCbCr_to_RGB_hip::convert_colorspace(const std::shared_ptr<const HeifPixelIma
                                         const heif_color_conversion_options_ext& options_ext,
                                         const heif_security_limits* limits) const
 {
-  const HipApi& api = hip_api();
+  const HipApi api = hip_api();
   if (!api.usable) {
     return Error::InternalError;
   }
