@@ -39,6 +39,7 @@ struct VReg { uint32_t v[64]; };
 #define PC_L(r) ((r).v[lane])
 PC_DEV uint32_t pc_rdlane(const VReg& r, int l) { return r.v[l & 63]; }
 PC_DEV void pc_wrlane(VReg& r, int l, uint32_t x) { r.v[l & 63] = x; }
+PC_DEV void pc_wrlane_v(VReg& r, int l, uint32_t x) { r.v[l & 63] = x; }   // value given in a vector register on the device
 PC_DEV uint32_t pc_uni(uint32_t x) { return x; }
 PC_DEV int pc_clz(uint32_t x) { return x ? __builtin_clz(x) : 32; }
 PC_DEV int pc_ffs(uint32_t x) { return __builtin_ffs((int)x); }
@@ -80,6 +81,8 @@ PC_DEV void pc_wrlane(VReg& r, int l, uint32_t x)
   asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(r) : "s"(xs), "s"(ls) : "m0");
 }
 #endif
+// the same with the (wave-uniform) value in a VECTOR register: compare + select, no scalar instruction
+PC_DEV void pc_wrlane_v(VReg& r, int l, uint32_t x) { r = ((int)threadIdx.x == l) ? x : r; }
 PC_DEV uint32_t pc_uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 PC_DEV int pc_clz(uint32_t x) { return __clz((int)x); }
 PC_DEV int pc_ffs(uint32_t x) { return __ffs((int)x); }
@@ -145,7 +148,7 @@ PC_CONST uint8_t c_range_lps[64 * 4] = {
    12, 14, 17, 20,  11, 14, 16, 19,  11, 13, 15, 18,  10, 12, 15, 17,  10, 12, 14, 16,   9, 11, 13, 15,
     9, 11, 12, 14,   8, 10, 12, 14,   8,  9, 11, 13,   7,  9, 11, 12,   7,  9, 10, 12,   7,  8, 10, 11,
     6,  8,  9, 11,   6,  7,  9, 10,   6,  7,  8,  9,   2,  2,  2,  2};
-// lane p: byte 0 transIdxLps[p] (table 9-47), byte 1 the p-th position of the up-right diagonal
+// lane p: byte 0 transIdxLps[p] (table 9-47; load_tables adds bit 6 for p = 0, where an LPS flips valMps), byte 1 the p-th position of the up-right diagonal
 // scan of an 8x8 array (6.5.3) as x | y << 3, byte 2 the inverse of that scan (lane x | y << 3 -> scan position)
 PC_CONST uint8_t c_next_lps[64] = {
    0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9,11,11,12, 13,13,15,15,16,16,18,18,19,19,21,21,22,22,23,24,
@@ -323,30 +326,35 @@ PC_DEV void cabac_start(PS& s, uint32_t start, uint32_t end)
   const uint32_t b0 = read_byte(s), b1 = read_byte(s);
   s.value = pc_vec((b0 << 8) | b1);
 }
+// Context variable = pStateIdx | valMps << 6.  Both table reads use the variable itself as lane select — v_readlane takes the lane from
+// bits 5:0 of the SGPR (wave64), so pStateIdx never has to be shifted out — and the state update and its write-back run on the VALU: the
+// scalar pipe, shared by the CU's four SIMDs, is the parser's bottleneck (profiles/r02g_pmc_parse_b512.txt: 32 SALU + 8 branch against
+// 23 VALU instructions per pixel before this change), while the vector pipes have room.
 PC_DEV int decode_bin(PS& s, VReg& grp, int ctx_lane)
 {
-  uint32_t st = pc_rdlane(grp, ctx_lane);
-  const uint32_t p_state = st >> 1;
-  const uint32_t row = pc_rdlane(s.t_lps, (int)p_state);
+  const uint32_t st = pc_rdlane(grp, ctx_lane);
+  const uint32_t row = pc_rdlane(s.t_lps, (int)st);
   const UReg lps = (row >> ((s.range >> 3) & 24u)) & 255u;
   UReg range = s.range - lps;
   const UReg scaled = range << 7;
+  const UReg vst = pc_vec(st);
+  UReg nst;
   int bin;
   UReg nb;
   if (__builtin_expect(pc_any(s.value < scaled), 1)) {   // MPS: at most one renormalisation shift
-    bin = (int)(st & 1u);
-    st += (uint32_t)(((int32_t)(p_state - 62u)) >> 31) & 2u;   // pStateIdx + 1, saturating at 62
+    bin = (int)(st >> 6);
+    nst = vst + (((vst & 63u) != 62u) ? 1u : 0u);             // pStateIdx + 1, saturating at 62 (table 9-47 transIdxMps)
     nb = 1u - (scaled >> 15);                                   // range < 256 <=> scaled < 2^15 (scaled < 2^16 always)
     range <<= nb;
   } else {                                                      // LPS
-    bin = (int)((st & 1u) ^ 1u);
+    bin = (int)((st >> 6) ^ 1u);
     nb = (UReg)pc_clz(lps) - 23u;
     s.value -= scaled;
     range = lps << nb;
-    const uint32_t mps = p_state == 0 ? (st & 1u) ^ 1u : (st & 1u);
-    st = ((pc_rdlane(s.t_next, (int)p_state) & 63u) << 1) | mps;
+    const UReg tr = pc_vec(pc_rdlane(s.t_next, (int)st));      // byte 0: transIdxLps | 64 where valMps flips (pStateIdx 0)
+    nst = (tr & 127u) ^ (vst & 64u);
   }
-  pc_wrlane(grp, ctx_lane, st);
+  pc_wrlane_v(grp, ctx_lane, nst);
   s.range = range;
   s.value <<= nb;
   s.bits_needed += nb;
@@ -418,7 +426,7 @@ PC_DEV void init_contexts(PS& s)
       pre = pre < 1 ? 1 : (pre > 126 ? 126 : pre);
       const int mps = pre <= 63 ? 0 : 1;
       const int p_state = mps ? pre - 64 : 63 - pre;
-      const uint32_t v = (uint32_t)((p_state << 1) | mps);
+      const uint32_t v = (uint32_t)(p_state | (mps << 6));
       if (g == 0) PC_L(s.ctxA) = v; else if (g == 1) PC_L(s.ctxB) = v; else PC_L(s.ctxC) = v;
     }
   PC_VEC_END
@@ -428,7 +436,7 @@ PC_DEV void load_tables(PS& s)
   PC_VEC_BEGIN
     PC_L(s.t_lps) = (uint32_t)c_range_lps[lane * 4] | ((uint32_t)c_range_lps[lane * 4 + 1] << 8) | ((uint32_t)c_range_lps[lane * 4 + 2] << 16) |
                     ((uint32_t)c_range_lps[lane * 4 + 3] << 24);
-    PC_L(s.t_next) = (uint32_t)c_next_lps[lane] | ((uint32_t)c_diag8[lane] << 8);
+    PC_L(s.t_next) = (uint32_t)c_next_lps[lane] | (lane == 0 ? 64u : 0u) | ((uint32_t)c_diag8[lane] << 8);
   PC_VEC_END
   {   // inverse of the 8x8 diagonal scan, scattered with one masked move per position (once per substream)
     VReg inv;
