@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads (S2 @ QP 17, S3, S4, S5) and the from-host form")
     ap.add_argument("--only-main", action="store_true", help="main resident measurement only (profiling runs)")
+    ap.add_argument("--parts", type=int, default=2, help="batches a step is split into; with 2, batch k+1's CABAC parse runs beside batch k's "
+                    "pixel stages on a second stream (hipdec_set_stage_overlap); 1 = one batch per step, one stream")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the CPU baseline (0 = min(32, host cores))")
     return ap.parse_args()
@@ -80,41 +82,60 @@ def gen_streams(specs, rank=0, world=1):
 
 
 class Workload:
-    """n coded stills (cycled from `distinct` contents) as ONE hipdec batch + one RGB output buffer per still."""
+    """n coded stills (cycled from `distinct` contents) as `parts` hipdec batches + one RGB output buffer per still."""
 
-    def __init__(self, lib, name, distinct, n, out_chroma, w, h, bit_depth):
+    def __init__(self, lib, name, distinct, n, out_chroma, w, h, bit_depth, parts=1):
         self.lib, self.name, self.out_chroma = lib, name, out_chroma
         self.w, self.h, self.bit_depth = w, h, bit_depth
         self.streams = [distinct[i % len(distinct)] for i in range(n)]
         self.n = n
         self.bs_bytes = sum(len(s) for s in self.streams)
         self.px = w * h * n
-        self.batch = None
-        self.rgb = None            # the batch that owns the RGB output buffers
+        self.parts = max(1, min(parts, n))
+        self.part_streams = [self.streams[j::self.parts] for j in range(self.parts)]
+        self.batches = []
+
+    @property
+    def batch(self):
+        return self.batches[0] if self.batches else None
 
     def make_resident(self):
         from libheif_amd.decoder import Batch
-        self.batch = Batch(self.streams)       # host header parsing + upload: outside the resident form's timed region
-        self.batch.alloc_rgb(self.out_chroma)
-        self.rgb = self.batch
-        return self.batch
+        self.batches = []
+        for st in self.part_streams:
+            b = Batch(st)                       # host header parsing + upload: outside the resident form's timed region
+            b.alloc_rgb(self.out_chroma)
+            self.batches.append(b)
+        return self.batches
 
     def step_resident(self):
-        self.batch.run()
-        self.batch.to_rgb_all()
+        for b in self.batches:
+            b.run()
+            b.to_rgb_all()
+
+    def status(self):
+        for b in self.batches:
+            b.status()
+
+    def timing_slots(self, n):
+        for b in self.batches:
+            b.timing_slots(n)
 
     def free(self):
-        if self.batch is not None:
-            self.batch.free()
-        self.batch = self.rgb = None
+        for b in self.batches:
+            b.free()
+        self.batches = []
 
 
-def kernel_times(batch, steps):
+def kernel_times(batches, steps):
+    """device time per kernel and step, summed over the step's batches (with stage overlap they run beside each other: the sum of the
+    kernel times then exceeds the step time)"""
     acc = {k: 0.0 for k in KERNEL_KEYS + ("decode_total",)}
-    for s in range(steps):
-        t = batch.slot_kernel_timing_us(s)
-        for k in acc:
-            acc[k] += t[k]
+    for b in batches:
+        for s in range(steps):
+            t = b.slot_kernel_timing_us(s)
+            for k in acc:
+                acc[k] += t[k]
     return {k: v / steps for k, v in acc.items()}
 
 
@@ -245,21 +266,23 @@ def main():
                 gd.to_rgb(10, out_dev=(rgb_out.data_ptr(), rgb_out.stride(0)))     # waits for the shards, colour stage into HBM
     else:
         off = (rank * len(distinct)) // max(1, world)
-        wl = Workload(lib, a.workload, distinct[off:] + distinct[:off], nb, out_chroma, w, h, bit_depth)
-        batch = wl.make_resident()
+        lib.hipdec_set_stage_overlap(1 if a.parts > 1 else 0)
+        wl = Workload(lib, a.workload, distinct[off:] + distinct[:off], nb, out_chroma, w, h, bit_depth, a.parts)
+        wl.make_resident()
+        batch = wl.batch
         n_items, px_rank, bs_bytes = wl.n, wl.px, wl.bs_bytes
         total_px = wl.px * world
         step = wl.step_resident
     if batch is not None:
-        batch.timing_slots(max(1, a.steps))
-    elapsed = timed(step, a.steps, a.warmup, before_timed=(lambda: (batch.status() if a.warmup else None, batch.timing_slots(max(1, a.steps)))) if batch is not None else None)
+        wl.timing_slots(max(1, a.steps))
+    elapsed = timed(step, a.steps, a.warmup, before_timed=(lambda: (wl.status() if a.warmup else None, wl.timing_slots(max(1, a.steps)))) if batch is not None else None)
     if batch is not None:
-        batch.status()         # device-side decode errors are loud
+        wl.status()            # device-side decode errors are loud
     elif gd is not None:
         gd.wait()
     ms_per_step = elapsed / a.steps * 1e3
     value = total_px / (elapsed / a.steps) / 1e6
-    avg_us = kernel_times(batch, a.steps) if not grid else None
+    avg_us = kernel_times(wl.batches, a.steps) if not grid else None
 
     out = None
     if rank == 0:
@@ -277,6 +300,8 @@ def main():
                                     "%d x %dx%d HEIC 4:2:0 %d-bit stills per GPU and step, WPP, CTB 64, fused YCbCr->%s" %
                                     (n_items, w, h, bit_depth, "RGB24" if out_chroma == 10 else "RRGGBB")),
                        "timed_region": "inputs resident in HBM: hipdec_batch_run + hipdec_batch_to_rgb_all per step (from host bytes: see from_host_bytes)",
+                       "batches_per_step": a.parts if not grid else 1,
+                       "stage_overlap": bool(a.parts > 1 and not grid),
                        "stills_per_step_per_gpu": n_items, "distinct_contents": len(distinct), "bitstream_bytes_per_px": round(beta, 4),
                        "substreams_per_still": batch.info(0)["num_substreams"] if batch is not None else 16,
                        "parallelism": ("tiles sharded over %d GPUs, one process" % world) if grid else "replicas x%d" % world},
@@ -310,52 +335,56 @@ def main():
     # the same workload from compressed bytes in host memory: batch_create inside the step, double-buffered
     # ------------------------------------------------------------------------------------------------------------------
     if not grid and not a.only_main:
-        rgb_state = wl.batch.rgb_state()  # keep the RGB output buffers; the resident batch's arena starts the chain below
-        state = {"next": None, "prev": None, "host_s": 0.0, "creates": 0}
+        # one chain of batches per part: batch k+1 of a chain takes over batch k's arena and RGB buffers
+        chains = []
+        state = {"host_s": 0.0, "creates": 0}
 
-        def create(recycle):
+        def create(streams, recycle, rgb_state):
             t = time.perf_counter()
-            b = Batch(wl.streams, recycle=recycle)   # host parse (worker threads) + pinned staging + asynchronous upload into the
-            b.use_rgb(rgb_state)                     # predecessor's arena, ordered behind the predecessor's kernels
+            b = Batch(streams, recycle=recycle)   # host parse (worker threads) + pinned staging + asynchronous upload into the predecessor's
+            b.use_rgb(rgb_state)                  # arena, ordered behind the predecessor's kernels
             state["host_s"] += time.perf_counter() - t
             state["creates"] += 1
             return b
 
-        state["next"] = create(wl.batch)
-        state["prev"] = wl.batch
-        wl.batch = None
+        for j, b0 in enumerate(wl.batches):
+            rs = b0.rgb_state()
+            chains.append({"streams": wl.part_streams[j], "rgb": rs, "prev": b0, "next": create(wl.part_streams[j], b0, rs)})
+        wl.batches = []
 
         def step_host():
-            cur = state["next"]
-            cur.run()
-            cur.to_rgb_all()
-            state["next"] = create(cur)       # host work for batch k+1 overlaps the kernels of batch k; ONE arena serves the stream
-            if state["prev"] is not None:     # batch k-1 (arena already handed on): its status word was copied back behind its kernels
-                state["prev"].status()
-                state["prev"].free()
-            state["prev"] = cur
+            for ch in chains:
+                cur = ch["next"]
+                cur.run()
+                cur.to_rgb_all()
+                ch["next"] = create(ch["streams"], cur, ch["rgb"])   # host work for the chain's next batch overlaps the kernels in flight
+                ch["prev"].status()             # (arena already handed on: the status word was copied back behind its kernels)
+                ch["prev"].free()
+                ch["prev"] = cur
 
         def reset_counters():
             state["host_s"], state["creates"] = 0.0, 0
 
         el_h = timed(step_host, a.steps, a.warmup, before_timed=reset_counters)
-        state["prev"].status()
-        state["prev"].free()
-        state["next"].free()
+        for ch in chains:
+            ch["prev"].status()
+            ch["prev"].free()
+            ch["next"].free()
         if rank == 0:
             out["from_host_bytes"] = {
                 "value": round(total_px / (el_h / a.steps) / 1e6, 2), "unit": "Mpixel/s", "ms_per_step": round(el_h / a.steps * 1e3, 3),
-                "host_ms_per_batch_create": round(state["host_s"] / max(1, state["creates"]) * 1e3, 2),
+                "host_ms_per_batch_create": round(state["host_s"] / max(1, state["creates"]) * 1e3, 2), "batches_per_step": len(wl.part_streams),
                 "h2d_bytes_per_step": wl.bs_bytes,
                 "timed_region": "compressed bytes in host memory -> planes + RGB complete in HBM: hipdec_batch_create_recycling (header parsing, "
                                 "pinned staging, asynchronous H2D upload into the predecessor's arena) + run + colour per step; the host work of "
                                 "batch k+1 overlaps the kernels of batch k, its upload follows them"}
-        del rgb_state
+        del chains
 
     # ------------------------------------------------------------------------------------------------------------------
     # single-still latency form, plugin life cycle
     # ------------------------------------------------------------------------------------------------------------------
     if rank == 0 and not a.only_main:
+        lib.hipdec_set_stage_overlap(0)
         first = distinct[0]
         single = Batch([first])
         single.alloc_rgb(out_chroma)
@@ -385,6 +414,7 @@ def main():
     # the other synthetic inputs of SURVEY §8(d), resident form, 1 warm-up + 2 timed steps each
     # ------------------------------------------------------------------------------------------------------------------
     if extras_on and rank == 0:
+        lib.hipdec_set_stage_overlap(1 if a.parts > 1 else 0)
         extras = {}
         for key, (wname, sp, n) in extra_specs.items():
             ew, eh, _, ebd, _, eout = WORKLOADS[wname]
@@ -403,12 +433,13 @@ def main():
                                "bitstream_bytes_per_px": round(sum(len(x) for x in st) / px, 4)}
                 g.free()
                 continue
-            e = Workload(lib, wname, st, n, eout, ew, eh, ebd)
-            eb = e.make_resident()
-            eb.timing_slots(2)
-            el = timed(e.step_resident, 2, 1, before_timed=lambda: (eb.status(), eb.timing_slots(2)))
-            eb.status()
-            eavg = kernel_times(eb, 2)
+            e = Workload(lib, wname, st, n, eout, ew, eh, ebd, a.parts)
+            e.make_resident()
+            eb = e.batch
+            e.timing_slots(2)
+            el = timed(e.step_resident, 2, 1, before_timed=lambda: (e.status(), e.timing_slots(2)))
+            e.status()
+            eavg = kernel_times(e.batches, 2)
             es, eso = (2 if ebd > 8 else 1), (2 if eout in (12, 14) else 1)
             ebeta = e.bs_bytes / e.px
             extras[key] = {"workload": "%d x %dx%d %d-bit stills (%d distinct), QP %d, fused YCbCr->%s" %

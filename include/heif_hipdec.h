@@ -135,6 +135,12 @@ HIPDEC_API int hipdec_decoder_device_plane(hipdec_decoder* dec, int c, const voi
  * 0 empties the cache. */
 HIPDEC_API int hipdec_set_arena_cache_bytes(size_t bytes);
 
+/* Two-stage pipeline across batches (default off): hipdec_batch_run() keeps the CABAC kernel on the caller's stream and queues residual /
+ * reconstruction / deblock / SAO — and whatever follows for that batch: colour stage, packs — on a second stream of the device.  A host
+ * that alternates two batches (two arenas) then has batch k+1's CABAC parse, which is issue- and dependency-bound, running beside batch k's
+ * pixel stages.  hipdec_batch_status() / free wait for the batch as before. */
+HIPDEC_API int hipdec_set_stage_overlap(int on);
+
 /* Number of large batches the host keeps in flight at a time on separate streams (default 1).  The CABAC work pool of a
  * batch needs all its waves resident, so concurrent batches share the device's wave slots. */
 HIPDEC_API int hipdec_set_concurrent_batches(int n);

@@ -165,28 +165,37 @@ int launch_all(hipdec_batch& b, hipStream_t s)
   b.colour_timed[slot] = 0;
   b.runs++;
   if (b.uploaded) HIPDEC_CHECK_HIP(hipStreamWaitEvent(s, b.uploaded, 0));
+  // Two-stage pipeline across batches (hipdec_set_stage_overlap): the CABAC kernel runs on the caller's stream, everything behind it on the
+  // device's post stream.  With two batches alternating, batch k+1's parse — scalar / vector issue bound, its dependency tail leaves the
+  // chip half empty — overlaps batch k's reconstruction, filters and colour stage (VALU + HBM).  A batch's own previous run must have
+  // left the arena before the control words are zeroed again.
+  const bool split = stage_overlap();
+  hipStream_t ps = split ? post_stream() : s;
+  if (split && b.done_recorded) HIPDEC_CHECK_HIP(hipStreamWaitEvent(s, b.done, 0));
   HIPDEC_CHECK_HIP(hipMemsetAsync(b.arena + b.off_ctrl, 0, b.ctrl_size, s));
   HIPDEC_CHECK_HIP(hipEventRecord(ev[0], s));
   if (int rc = step("memset")) return rc;
   launch_parse(pa, s);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[1], s));
   if (int rc = step("parse")) return rc;
+  if (split) HIPDEC_CHECK_HIP(hipStreamWaitEvent(ps, ev[1], 0));
   static const bool parse_only = getenv("HIPDEC_DEBUG_PARSE_ONLY") != nullptr;   // tuning knob: isolate the CABAC kernel
-  if (!parse_only) launch_residual(fa, n, b.max_ctbs, s);
-  HIPDEC_CHECK_HIP(hipEventRecord(ev[2], s));
+  if (!parse_only) launch_residual(fa, n, b.max_ctbs, ps);
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[2], ps));
   if (int rc = step("residual")) return rc;
-  if (!parse_only) launch_recon(ra, b.wide, s);
-  HIPDEC_CHECK_HIP(hipEventRecord(ev[3], s));
+  if (!parse_only) launch_recon(ra, b.wide, ps);
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[3], ps));
   if (int rc = step("recon")) return rc;
-  if (!parse_only) launch_deblock(fa, n, b.max_w, b.max_h, b.wide, s);
-  HIPDEC_CHECK_HIP(hipEventRecord(ev[4], s));
+  if (!parse_only) launch_deblock(fa, n, b.max_w, b.max_h, b.wide, ps);
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[4], ps));
   if (int rc = step("deblock")) return rc;
-  if (!parse_only) launch_sao(fa, n, b.max_ow, b.max_oh, b.wide, s);
-  HIPDEC_CHECK_HIP(hipEventRecord(ev[5], s));
+  if (!parse_only) launch_sao(fa, n, b.max_ow, b.max_oh, b.wide, ps);
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[5], ps));
   if (int rc = step("sao")) return rc;
   HIPDEC_CHECK_HIP(hipGetLastError());
-  HIPDEC_CHECK_HIP(hipMemcpyAsync(b.host_status, b.arena + b.off_status, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  b.mark_done(s);
+  HIPDEC_CHECK_HIP(hipMemcpyAsync(b.host_status, b.arena + b.off_status, sizeof(int32_t), hipMemcpyDeviceToHost, ps));
+  b.last_stream = ps;     // the colour stage, packs and plane reads of this run follow its last kernel
+  b.mark_done(ps);
   return 0;
 }
 
@@ -259,7 +268,7 @@ int hipdec_batch_run(hipdec_batch* b, void* stream)
   hipStream_t s = stream ? (hipStream_t)stream : default_stream();
   b->last_stream = s;
   b->ran = true;
-  return launch_all(*b, s);
+  return launch_all(*b, s);   // (may move last_stream to the post stream)
 }
 
 int hipdec_batch_status(hipdec_batch* b)

@@ -26,6 +26,8 @@ class DeviceScope {
   int prev_;
 };
 hipStream_t default_stream();
+hipStream_t post_stream();      // everything behind the CABAC kernel when stage overlap is on (hipdec_set_stage_overlap)
+bool stage_overlap();
 hipStream_t upload_stream();    // H2D copies of large batches (overlaps the kernels of the batch before)
 uint32_t parse_wave_budget();   // CABAC pool waves one batch may launch (wave slots / concurrent batches)
 

@@ -1,27 +1,31 @@
 // parse_core.h — the CABAC entropy decoder + slice-data syntax parser, written as ONE wave-uniform
-// (scalar) instruction stream over a handful of lane-indexed registers.
+// instruction stream over a handful of lane-indexed registers.
 //
 // Stands in for libde265's slice-data parser behind de265_decode() (reference call site
 // libheif/plugins/decoder_libde265.cc:402).  Syntax and context selection per ITU-T H.265 7.3.8 /
 // 9.3 (intra slices).
 //
 // MI355X mapping (why the code looks the way it does)
-//   * CABAC is a serial dependency chain, so one 64-lane wavefront decodes one substream and the
-//     whole chain is kept on the SCALAR unit: arithmetic-decoder state (range / value / bit count /
-//     byte position) lives in SGPRs and every branch is a scalar branch.  All tables and all
-//     mutable state that a CPU decoder would keep in memory live in VGPRs used as 64-entry
-//     register files addressed with v_readlane / v_writelane (a few cycles) instead of LDS
-//     (~50 cycles per dependent access, microarch guide):
-//        - context variables: three VGPRs, one context per lane (groups A / B / C below)
-//        - rangeTabLps (4 bytes per pStateIdx lane), transIdxLps and the 8x8 diagonal scan
-//        - a 256-byte bitstream window + the prefetched next window (one coalesced 256-B load
-//          per 256 bytes of bitstream)
-//        - the CTB's per-4x4-unit maps (size, flags, intra modes, QP): four units per lane in
-//          z-scan order, so every CU / TU is a contiguous lane range that is filled with one
-//          masked vector move and published with one coalesced store per map
+//   * CABAC is a serial dependency chain, so one 64-lane wavefront decodes one substream as ONE wave-uniform instruction stream
+//     (every branch is a scalar branch).  All tables and all mutable state that a CPU decoder would keep in memory live in VGPRs
+//     used as 64-entry register files addressed with v_readlane / v_writelane (a few cycles) instead of LDS (~50 cycles per
+//     dependent access, microarch guide):
+//        - context variables: three VGPRs, one context per lane (groups A / B / C below), pStateIdx | valMps << 6
+//        - rangeTabLps (4 bytes per pStateIdx lane), transIdxLps, the 8x8 diagonal scan and its inverse
+//        - a 256-byte bitstream window + the prefetched next window (one coalesced 256-B load per 256 bytes of bitstream;
+//          emulation-prevention bytes are looked for once per window by all lanes)
+//        - the CTB's per-4x4-unit maps (size, flags, intra modes, QP): four units per lane in z-scan order, so every CU / TU
+//          is a contiguous lane range that is filled with one masked vector move and published with one coalesced store per map
 //        - the previous CTB's maps (left neighbour), the row above's sizes, SAO parameters
-//   * the 64 lanes only do the data-parallel side jobs (context init, window loads, map fills,
-//     coefficient block flush, WPP context save / restore).
+//   * WHERE a wave-uniform value lives decides which pipe its arithmetic issues on.  The scalar ALU is shared by the CU's four
+//     SIMDs (one instruction per cycle per CU), each SIMD has its own vector ALU; measured, the parser was scalar-bound (32 SALU +
+//     8 branch against 23 VALU instructions per pixel, profiles/r02g_pmc_parse_b512.txt).  So the arithmetic decoder's state
+//     (range / value / bit count: UReg) and the context-state update are deliberately kept in VECTOR registers although they are
+//     uniform; syntax control flow, lane selects and the bin values the syntax branches on stay scalar.  After the rebalancing:
+//     26.4 SALU + 26.1 VALU + 8 branch per pixel (profiles/r02l_pmc_parse_b512_after_valu_state.txt).  The latency variant
+//     (parse_kernel_scalar.hip, a handful of waves on the chip) keeps everything scalar: shorter dependent-issue latency.
+//   * the 64 lanes do the data-parallel side jobs (context init, window loads and emulation-prevention scan, map fills, per-sub-
+//     block context selection and level finalisation, coefficient block flush, WPP context save / restore).
 //
 // The same source compiles for the device (parse_kernel.hip) and, with HIPDEC_HOST_EMU, as a
 // lane-emulating host build used ONLY by the CPU tests (tests/emu) to check the parser's logic

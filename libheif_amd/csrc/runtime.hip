@@ -16,7 +16,8 @@ static bool g_initialised = false;
 static int g_device = 0;                      // the device hipdec_init() selected: what every entry point uses ...
 static thread_local int t_device_override = -1;   // ... unless a DeviceScope is active on this thread (multi-device grid decode)
 constexpr int kMaxDevices = 16;
-struct DeviceStreams { hipStream_t stream = nullptr, upload = nullptr; };
+struct DeviceStreams { hipStream_t stream = nullptr, upload = nullptr, post = nullptr; };
+static std::atomic<int> g_stage_overlap{0};
 static DeviceStreams g_streams[kMaxDevices];   // created on first use of a device, destroyed by hipdec_shutdown()
 static std::mutex g_streams_mu;
 static int g_cu_count = 256;                 // compute units of the selected device
@@ -68,10 +69,12 @@ static DeviceStreams& streams_of_active_device()
     std::lock_guard<std::mutex> lock(g_streams_mu);
     if (!d.stream) {
       (void)hipSetDevice(dev);
-      hipStream_t up = nullptr, st = nullptr;
+      hipStream_t up = nullptr, st = nullptr, po = nullptr;
       (void)hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+      (void)hipStreamCreateWithFlags(&po, hipStreamNonBlocking);
       (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
       d.upload = up;
+      d.post = po;
       d.stream = st;
     }
   }
@@ -79,6 +82,8 @@ static DeviceStreams& streams_of_active_device()
 }
 hipStream_t default_stream() { return streams_of_active_device().stream; }
 hipStream_t upload_stream() { DeviceStreams& d = streams_of_active_device(); return d.upload ? d.upload : d.stream; }
+hipStream_t post_stream() { DeviceStreams& d = streams_of_active_device(); return d.post ? d.post : d.stream; }
+bool stage_overlap() { return g_stage_overlap.load(std::memory_order_relaxed) != 0; }
 
 // Waves of the CABAC work pool one batch may launch: the pool only works while ALL its waves are resident (7 per SIMD with
 // the kernel's register budget), so concurrent batches have to share the machine's wave slots.
@@ -248,7 +253,7 @@ hipStream_t stream_acquire()
 void stream_release(hipStream_t s)
 {
   if (!s) return;
-  for (const auto& d : g_streams) if (s == d.stream || s == d.upload) return;
+  for (const auto& d : g_streams) if (s == d.stream || s == d.upload || s == d.post) return;
   std::lock_guard<std::mutex> lock(g_stream_mu);
   if (g_free_streams.size() < 64) g_free_streams.emplace_back(s, active_device()); else (void)hipStreamDestroy(s);
 }
@@ -306,6 +311,7 @@ void hipdec_shutdown(void)
     for (auto& d : g_streams) {
       if (d.stream) (void)hipStreamDestroy(d.stream);
       if (d.upload) (void)hipStreamDestroy(d.upload);
+      if (d.post) (void)hipStreamDestroy(d.post);
       d = DeviceStreams{};
     }
   }
@@ -317,6 +323,12 @@ int hipdec_set_arena_cache_bytes(size_t bytes)
   g_max_cached_bytes.store(bytes);
   g_max_pooled_arena.store(bytes > (size_t(1) << 30) ? bytes : (size_t(1) << 30));
   if (bytes == 0) { arena_pool_clear(); pinned_pool_clear(); }
+  return 0;
+}
+
+int hipdec_set_stage_overlap(int on)
+{
+  g_stage_overlap.store(on ? 1 : 0, std::memory_order_relaxed);
   return 0;
 }
 
