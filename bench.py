@@ -48,8 +48,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads (S2 @ QP 17, S3, S4, S5) and the from-host form")
     ap.add_argument("--only-main", action="store_true", help="main resident measurement only (profiling runs)")
-    ap.add_argument("--parts", type=int, default=2, help="batches a step is split into; with 2, batch k+1's CABAC parse runs beside batch k's "
-                    "pixel stages on a second stream (hipdec_set_stage_overlap); 1 = one batch per step, one stream")
+    ap.add_argument("--parts", type=int, default=1, help="batches a step is split into; with 2, batch k+1's CABAC parse is queued beside batch k's "
+                    "pixel stages on a second stream (hipdec_set_stage_overlap).  Measured SLOWER (12.1 against 13.7 Gpixel/s): the CABAC work pool "
+                    "holds every wave slot of the chip, the other kernels only start when it exits, and smaller batches parse less efficiently")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the CPU baseline (0 = min(32, host cores))")
     return ap.parse_args()
