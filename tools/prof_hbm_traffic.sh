@@ -16,7 +16,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(os.path.join(root, "gpurun_out", "pmc_" + c, "**", "*counter_collection.csv"), recursive=True)
     agg = collections.defaultdict(float)
     for r in csv.DictReader(open(f[0])):
-        agg[r["Kernel_Name"].split("(")[0].split("<")[0].replace("hipdec::", "").replace("(anonymous namespace)::", "")] += float(r["Counter_Value"])
+        agg[r["Kernel_Name"]] += float(r["Counter_Value"])
     res[c] = agg
 bench = json.load(open(os.path.join(root, "gpurun_out", "pmc_FETCH_SIZE", "bench.json")))
 px = bench["config"]["stills_per_step_per_gpu"] * 3840 * 2160
@@ -24,7 +24,7 @@ names = {"k_parse": "k_parse", "k_residual": "k_residual", "k_recon": "k_recon",
 def per_px(agg):
     out = {}
     for short in names:
-        tot = sum(v for k, v in agg.items() if k.startswith(short))
+        tot = sum(v for k, v in agg.items() if short in k)
         out[short] = round(tot * 1024.0 / px, 4)      # counter unit: KiB
     return out
 f, w = per_px(res["FETCH_SIZE"]), per_px(res["WRITE_SIZE"])
