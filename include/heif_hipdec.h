@@ -185,6 +185,10 @@ HIPDEC_API int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void*
 /* The same for ALL items of the batch as one kernel launch (outs_dev[i] / out_strides[i] per item; every item must
  * select the same output layout, which out_chroma guarantees). */
 HIPDEC_API int hipdec_batch_to_rgb_all(hipdec_batch* b, int out_chroma, void* const* outs_dev, const size_t* out_strides, void* stream);
+/* hipdec_batch_run + hipdec_batch_to_rgb_all as one call.  For 8-bit 4:2:0 batches and interleaved RGB24 the colour conversion is FUSED into the
+ * SAO kernel's store path (the planes are still written; the colour pass's re-read of them and its launch disappear); other cases run the two
+ * steps one after the other.  Same pixels either way. */
+HIPDEC_API int hipdec_batch_run_rgb(hipdec_batch* b, int out_chroma, void* const* outs_dev, const size_t* out_strides, void* stream);
 /* per-kernel device time of the last run in microseconds (HIP events on the launch stream):
  * [0] CABAC parse, [1] reconstruction, [2] deblock, [3] SAO + crop, [4] total */
 HIPDEC_API int hipdec_batch_last_timing_us(hipdec_batch* b, float out[5]);

@@ -16,88 +16,15 @@
 // (64 lanes -> 768 contiguous bytes per wave-store).
 // Float parity: compiled with -ffp-contract=off; the reference build (x86-64 baseline) has no FMA.
 #include "hipdec_internal.h"
+#include "color_device.h"
 #include <cmath>
 #include <cstring>
 #include <vector>
 
 namespace {
 
-enum Arith { AR_INT88 = 0, AR_FLOAT = 1, AR_GBR_FULL = 2, AR_GBR_LIMITED = 3, AR_YCGCO = 4, AR_YCGCO_RE = 5 };
-enum Layout { LO_PLANAR = 0, LO_RGB24 = 1, LO_RGBA32 = 2, LO_RRGGBB_BE = 3, LO_RRGGBB_LE = 4 };
+using namespace hipdec::colordev;
 
-struct ColorParams {
-  const uint8_t *y, *cb, *cr;
-  size_t ys, cbs, crs;
-  uint8_t *o0, *o1, *o2;
-  size_t os;
-  const uint8_t* a;       // 8-bit alpha plane for the RGBA layout (yuv2rgb.cc:521-553), NULL: filled with 0xFF
-  size_t as;
-  int w, h, bpp, shiftH, shiftV;
-  int arith;
-  int i_r_cr, i_g_cb, i_g_cr, i_b_cb;
-  float f_r_cr, f_g_cb, f_g_cr, f_b_cb;
-  int full_range;
-};
-
-__device__ __forceinline__ int clip_i(int x, int maxi) { return x < 0 ? 0 : (x > maxi ? maxi : x); }
-// libheif/common_utils.h:108-114 clip_f_u16: (int32)(fx + 0.5f), then clamp
-__device__ __forceinline__ int clip_f(float fx, int maxi)
-{
-  int x = (int)(fx + 0.5f);
-  return x < 0 ? 0 : (x > maxi ? maxi : x);
-}
-
-__device__ __forceinline__ void convert_px(const ColorParams& p, int Y, int Cb, int Cr, int& R, int& G, int& B)
-{
-  const int fullRange = (1 << p.bpp) - 1;
-  const int halfRange = 1 << (p.bpp - 1);
-  switch (p.arith) {
-    case AR_INT88: {  // yuv2rgb.cc:377-421
-      int cb = Cb - 128, cr = Cr - 128;
-      R = clip_i(Y + ((p.i_r_cr * cr + 128) >> 8), 255);
-      G = clip_i(Y + ((p.i_g_cb * cb + p.i_g_cr * cr + 128) >> 8), 255);
-      B = clip_i(Y + ((p.i_b_cb * cb + 128) >> 8), 255);
-      break;
-    }
-    case AR_GBR_FULL: R = Cr; G = Y; B = Cb; break;  // yuv2rgb.cc:224-229
-    case AR_GBR_LIMITED: {                             // yuv2rgb.cc:230-236
-      float off = (float)(16 << (p.bpp - 8));
-      R = clip_f(((float)Cr - off) * 1.1429f, fullRange);
-      G = clip_f(((float)Y - off) * 1.1689f, fullRange);
-      B = clip_f(((float)Cb - off) * 1.1429f, fullRange);
-      break;
-    }
-    case AR_YCGCO: {  // yuv2rgb.cc:237-249 (clip_int_u8 even for >8 bit, as the reference does)
-      int cb = Cb - halfRange, cr = Cr - halfRange;
-      R = clip_i(Y - cb + cr, 255); G = clip_i(Y + cb, 255); B = clip_i(Y - cb - cr, 255);
-      break;
-    }
-    case AR_YCGCO_RE: {  // yuv2rgb.cc:250-266, int16 arithmetic
-      short yy = (short)Y;
-      short cb = (short)((short)Cb - (short)halfRange), cr = (short)((short)Cr - (short)halfRange);
-      short t = (short)(yy - (cb >> 1));
-      short g = (short)(t + cb);
-      short b = (short)(t - (cr >> 1));
-      short r = (short)(b + cr);
-      R = clip_i(r * 4, fullRange); G = clip_i(g * 4, fullRange); B = clip_i(b * 4, fullRange);
-      break;
-    }
-    default: {  // AR_FLOAT  yuv2rgb.cc:267-282 / :699-710
-      float yv = (float)Y, cb = (float)(Cb - halfRange), cr = (float)(Cr - halfRange);
-      if (!p.full_range) {
-        yv = (yv - (float)(16 << (p.bpp - 8))) * 1.1689f;
-        cb = cb * 1.1429f;
-        cr = cr * 1.1429f;
-      }
-      R = clip_f(yv + p.f_r_cr * cr, fullRange);
-      G = clip_f(yv + p.f_g_cb * cb + p.f_g_cr * cr, fullRange);
-      B = clip_f(yv + p.f_b_cb * cb, fullRange);
-      break;
-    }
-  }
-}
-
-struct __attribute__((packed, aligned(4))) U3 { uint32_t a, b, c; };
 
 template <typename Pix, int LAYOUT>
 __device__ __forceinline__ void rgb_block(const ColorParams& p)
@@ -423,6 +350,36 @@ void color_capture_abort()
   t_captured.clear();
   t_capture = false;
 }
+
+// Ends capture mode WITHOUT launching: uploads the recorded parameter blocks (one per captured call, in call order) and hands back the
+// device array — for a kernel of another translation unit that consumes them (SAO with fused RGB emission, filter_kernels.hip).
+// *uniform_variant = the kernel variant all blocks share (sizeof(Pix) * 16 + LAYOUT), or -1 when they differ.
+int color_capture_take(ColorBatchState& st, hipStream_t s, const void** dev, int* uniform_variant, int* count)
+{
+  t_capture = false;
+  std::vector<Captured> caps;
+  caps.swap(t_captured);
+  *dev = nullptr; *uniform_variant = -1; *count = (int)caps.size();
+  if (caps.empty()) return 0;
+  bool same = true;
+  for (const auto& c : caps) same = same && c.variant == caps[0].variant;
+  const size_t bytes = caps.size() * sizeof(ColorParams);
+  std::vector<uint8_t> host(bytes);
+  for (size_t i = 0; i < caps.size(); i++) memcpy(host.data() + i * sizeof(ColorParams), &caps[i].p, sizeof(ColorParams));
+  if (st.dev_bytes < bytes) {
+    if (st.dev) arena_release(st.dev, st.dev_bytes);
+    st.dev = nullptr; st.dev_bytes = 0; st.host.clear();
+    HIPDEC_CHECK_HIP(arena_acquire(&st.dev, bytes, &st.dev_bytes));
+  }
+  if (st.host != host) {
+    st.host.swap(host);
+    HIPDEC_CHECK_HIP(hipMemcpyAsync(st.dev, st.host.data(), bytes, hipMemcpyHostToDevice, s));
+  }
+  *dev = st.dev;
+  if (same) *uniform_variant = caps[0].variant;
+  return 0;
+}
+int color_variant_rgb24_u8() { return (int)sizeof(uint8_t) * 16 + LO_RGB24; }
 
 int color_capture_launch(ColorBatchState& st, hipStream_t s)
 {

@@ -126,7 +126,7 @@ int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* s
   return 0;
 }
 
-int launch_all(hipdec_batch& b, hipStream_t s)
+int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nullptr)
 {
   const int n = (int)b.params.size();
   ParseArgs pa{};
@@ -189,7 +189,10 @@ int launch_all(hipdec_batch& b, hipStream_t s)
   if (!parse_only) launch_deblock(fa, n, b.max_w, b.max_h, b.wide, ps);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[4], ps));
   if (int rc = step("deblock")) return rc;
-  if (!parse_only) launch_sao(fa, n, b.max_ow, b.max_oh, b.wide, ps);
+  if (!parse_only) {
+    if (fused_rgb_params) launch_sao_rgb(fa, fused_rgb_params, n, b.max_ow, b.max_oh, ps);   // SAO + crop + RGB24 in one pass
+    else launch_sao(fa, n, b.max_ow, b.max_oh, b.wide, ps);
+  }
   HIPDEC_CHECK_HIP(hipEventRecord(ev[5], ps));
   if (int rc = step("sao")) return rc;
   HIPDEC_CHECK_HIP(hipGetLastError());
@@ -393,6 +396,37 @@ int hipdec_batch_to_rgb_all(hipdec_batch* b, int out_chroma, void* const* outs_d
   if (!rc && b->runs) b->colour_timed[slot] = 1;
   b->mark_done(s);
   return rc;
+}
+
+// decode + colour stage of every item as ONE call: for 8-bit 4:2:0 batches going to interleaved RGB24 the colour conversion is fused into
+// the SAO kernel's store path (planes are still written: the ABI hands them out); every other case runs the decode kernels followed by the
+// batched colour kernel, exactly like hipdec_batch_run + hipdec_batch_to_rgb_all.
+int hipdec_batch_run_rgb(hipdec_batch* b, int out_chroma, void* const* outs_dev, const size_t* out_strides, void* stream)
+{
+  if (!b || !outs_dev || !out_strides) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "run_rgb: bad arguments");
+  DeviceScope scope(b->device);
+  if (b->retired) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "run_rgb: the batch's arena was handed to another batch");
+  if (int rc = ensure_init()) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : default_stream();
+  static const bool no_fusion = getenv("HIPDEC_NO_SAO_RGB_FUSION") != nullptr;
+  bool fuse = out_chroma == 10 && !b->wide && !no_fusion;
+  for (const auto& P : b->params) fuse = fuse && P.chroma_format_idc == 1;
+  if (!fuse) {
+    if (int rc = hipdec_batch_run(b, stream)) return rc;
+    return hipdec_batch_to_rgb_all(b, out_chroma, outs_dev, out_strides, nullptr);
+  }
+  // the per-item entry points check the arguments, apply the planner rule and fill the coefficient blocks (capture mode: nothing is launched)
+  hipStream_t ps = stage_overlap() ? post_stream() : s;
+  color_capture_begin();
+  for (int i = 0; i < (int)b->pics.size(); i++)
+    if (int rc = hipdec_batch_to_rgb(b, i, out_chroma, outs_dev[i], out_strides[i], (void*)ps)) { color_capture_abort(); return rc; }
+  const void* dev = nullptr;
+  int variant = -1, count = 0;
+  if (int rc = color_capture_take(b->color, ps, &dev, &variant, &count)) return rc;
+  if (variant != color_variant_rgb24_u8() || count != (int)b->pics.size()) return set_error(HIPDEC_ERR_UNSUPPORTED, "run_rgb: unexpected colour variant");
+  b->last_stream = s;
+  b->ran = true;
+  return launch_all(*b, s, dev);
 }
 
 int hipdec_batch_timing_slots(hipdec_batch* b, int slots)

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include "hevc_device.h"
 #include "kernels.h"
+#include "color_device.h"
 
 namespace hipdec {
 
@@ -187,160 +188,286 @@ __device__ __forceinline__ SaoRegs sao_unpack(uint32_t w0, uint32_t w1, uint32_t
 __device__ __forceinline__ int sao_off(const SaoRegs& sp, int i) { return i == 0 ? sp.o0 : (i == 1 ? sp.o1 : (i == 2 ? sp.o2 : sp.o3)); }
 
 constexpr int SAO_TW = 128, SAO_TH = 32, SAO_RPT = SAO_TH / 8;   // rows per thread
+
+// What one component of one picture needs for SAO, gathered once per workgroup (wave-uniform)
+template <typename Pix>
+struct SaoComp {
+  const PicParams* P;
+  int c, sub, ow, oh, W, H, bit_depth, maxv, rs_bytes, os, lctb, crop_xc, crop_yc, ctb_w;
+  const uint8_t* rec;
+  Pix* out;
+  const uint8_t* u_flags;
+  const SaoParams* sao;
+  const CtbInfo* ctb_info;
+  const SliceParams* slices;
+  bool check_bypass, lf_across_tiles, free_nb;
+};
+template <typename Pix>
+__device__ __forceinline__ SaoComp<Pix> sao_comp(const FilterArgs& A, const PicParams& P, int c)
+{
+  SaoComp<Pix> S;
+  S.P = &P; S.c = c; S.sub = c ? 2 : 1;
+  S.ow = c ? P.out_cwidth : P.out_width; S.oh = c ? P.out_cheight : P.out_height;
+  S.W = c ? P.cwidth : P.width; S.H = c ? P.cheight : P.height;
+  S.bit_depth = c ? P.bit_depth_chroma : P.bit_depth_luma; S.maxv = (1 << S.bit_depth) - 1;
+  S.rec = A.arena + P.off_rec[c]; S.rs_bytes = (int)P.rec_stride[c];
+  S.out = (Pix*)(A.arena + P.off_out[c]); S.os = P.out_stride[c] / (int)sizeof(Pix);
+  S.u_flags = A.arena + P.off_u_flags;
+  S.sao = (const SaoParams*)(A.arena + P.off_sao);
+  S.ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
+  S.slices = (const SliceParams*)(A.arena + P.off_slices);
+  S.lctb = P.log2_ctb - (c ? 1 : 0);   // log2 CTB size in component samples
+  S.crop_xc = P.crop_x / S.sub; S.crop_yc = P.crop_y / S.sub; S.ctb_w = P.ctb_w;
+  S.check_bypass = P.transquant_bypass_enabled != 0;
+  S.lf_across_tiles = P.lf_across_tiles != 0;
+  S.free_nb = P.sao_free_neighbours != 0;
+  return S;
+}
+// the SAO parameters (three dwords) of the CTB that holds output sample (ox, oy) — requested before the tile loads so that they travel with them
+template <typename Pix>
+__device__ __forceinline__ void sao_params_at(const SaoComp<Pix>& S, int ox, int oy, uint32_t spw[3])
+{
+  int y = oy + S.crop_yc, x = ox + S.crop_xc;
+  y = y < S.H ? y : S.H - 1; x = x < S.W ? x : S.W - 1;
+  const uint32_t* src = (const uint32_t*)&S.sao[(size_t)((y >> S.lctb) * S.ctb_w + (x >> S.lctb)) * 3 + S.c];
+  spw[0] = src[0]; spw[1] = src[1]; spw[2] = src[2];
+}
+// stages source rows ys0-1 .. ys0+TH, bytes [ab, ...) of each row, into tile[TH + 2][ROW_WORDS]; returns ab.  All threads of the workgroup
+// (NT of them) take part; the caller synchronises.
+template <typename Pix, int TH, int ROW_WORDS, int NT>
+__device__ __forceinline__ int sao_stage(const SaoComp<Pix>& S, uint32_t* tile, int ox_t, int oy_t, int tid)
+{
+  constexpr int ES = (int)sizeof(Pix);
+  const int xs0 = ox_t + S.crop_xc, ys0 = oy_t + S.crop_yc;
+  int ab = (xs0 - 1) * ES;
+  ab = ab < 0 ? 0 : (ab & ~3);
+  for (int i = tid; i < (TH + 2) * ROW_WORDS; i += NT) {
+    const int r = i / ROW_WORDS, wi = i - r * ROW_WORDS;
+    const int ys = ys0 - 1 + r, bo = ab + wi * 4;
+    uint32_t v = 0;
+    if (ys >= 0 && ys < S.H && bo < S.rs_bytes) v = *(const uint32_t*)(S.rec + (size_t)ys * S.rs_bytes + bo);
+    tile[i] = v;
+  }
+  return ab;
+}
+// SAO of the (up to) 4 output samples (ox0 .. ox0+3, oy) out of the staged tile (tile row `lr` holds source row oy + crop); returns the
+// number of valid samples (0: outside the output)
+template <typename Pix, int ROW_WORDS>
+__device__ __forceinline__ int sao_quad(const SaoComp<Pix>& S, const uint32_t* tile, int ab, int ox0, int oy, int lr, const uint32_t spw[3], Pix res[4])
+{
+  constexpr int ES = (int)sizeof(Pix);
+  if (oy >= S.oh || ox0 >= S.ow) return 0;
+  const int W = S.W, H = S.H, lctb = S.lctb, ctb_w = S.ctb_w, bit_depth = S.bit_depth, maxv = S.maxv, sub = S.sub, c = S.c;
+  const int y = oy + S.crop_yc;
+  const int npx = S.ow - ox0 < 4 ? S.ow - ox0 : 4;
+  const int xf = ox0 + S.crop_xc, xl = xf + npx - 1;
+  const int ctb_first = (y >> lctb) * ctb_w + (xf >> lctb);
+  const bool one_ctb = (xf >> lctb) == (xl >> lctb);
+  const SaoRegs sp_first = sao_unpack(spw[0], spw[1], spw[2]);
+#define SAO_AT(row, x) (((const Pix*)((const uint8_t*)(tile + (row) * ROW_WORDS) + ((x) * ES - ab)))[0])
+  // fast paths: the 4 samples share one CTB (one parameter set) and no per-sample lossless check is needed
+  const int cmask = (1 << lctb) - 1;
+  // edge offsets without per-neighbour checks: no neighbour leaves the CTB - or nothing restricts neighbours in other
+  // CTBs (one slice or filtering across slices / tiles allowed, no lossless CUs) - and none leaves the picture
+  const bool interior = (S.free_nb ? (xf > 0 && y > 0) : ((xf & cmask) > 0 && (xl & cmask) < cmask && (y & cmask) > 0 && (y & cmask) < cmask)) &&
+                        xl + 1 < W && y + 1 < H;
+  bool done = false;
+  if (one_ctb && !S.check_bypass && npx == 4) {
+    const SaoRegs sp = sp_first;
+    if (sp.type == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) res[i] = SAO_AT(lr, xf + i);
+      done = true;
+    } else if (sp.type == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        int v = SAO_AT(lr, xf + i);
+        const int k = ((v >> (bit_depth - 5)) - sp.cls) & 31;
+        const int off = k < 4 ? sao_off(sp, k) : 0;
+        res[i] = (Pix)clip3(0, maxv, v + off);
+      }
+      done = true;
+    } else if (interior) {
+      const int cls = sp.cls;
+      const int hx = cls == 1 ? 0 : (cls == 3 ? 1 : -1), hy = cls == 0 ? 0 : -1;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int x = xf + i;
+        const int v = SAO_AT(lr, x), a = SAO_AT(lr + hy, x + hx), b = SAO_AT(lr - hy, x - hx);
+        const int e = ((v > a) - (v < a)) + ((v > b) - (v < b));     // -2 .. 2 ; edgeIdx = 2 + e remapped {0,1,2,3,4} -> {1,2,0,3,4}
+        const int off = e == -2 ? sp.o0 : (e == -1 ? sp.o1 : (e == 1 ? sp.o2 : (e == 2 ? sp.o3 : 0)));
+        res[i] = (Pix)clip3(0, maxv, v + off);
+      }
+      done = true;
+    }
+  }
+  if (!done)
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (i >= npx) { res[i] = 0; continue; }
+    const int x = xf + i;
+    int v = SAO_AT(lr, x);
+    const int ctb = one_ctb ? ctb_first : (y >> lctb) * ctb_w + (x >> lctb);
+    SaoRegs sp = sp_first;
+    if (!one_ctb) { const uint32_t* q = (const uint32_t*)&S.sao[(size_t)ctb * 3 + c]; sp = sao_unpack(q[0], q[1], q[2]); }
+    if (sp.type) {
+      int ctb_dummy;
+      const uint8_t fl = S.check_bypass ? S.u_flags[unit_index(*S.P, (x * sub) >> 2, (y * sub) >> 2, &ctb_dummy)] : (uint8_t)0;
+      if (!(fl & UF_BYPASS)) {
+        if (sp.type == 1) {
+          const int k = ((v >> (bit_depth - 5)) - sp.cls) & 31;
+          if (k < 4) v = clip3(0, maxv, v + sao_off(sp, k));
+        } else {
+          const int cls = sp.cls;
+          const int hx = cls == 1 ? 0 : (cls == 3 ? 1 : -1), hy = cls == 0 ? 0 : -1;  // first neighbour; second is the mirror
+          int edge_idx = 2, skip = 0;
+          for (int k = 0; k < 2; k++) {
+            const int dx = k ? -hx : hx, dy = k ? -hy : hy;
+            const int xs = x + dx, ys = y + dy;
+            if (xs < 0 || ys < 0 || xs >= W || ys >= H) { skip = 1; break; }
+            const int ctb_n = (ys >> lctb) * ctb_w + (xs >> lctb);
+            if (ctb_n != ctb) {
+              const CtbInfo cn = S.ctb_info[ctb_n], cc = S.ctb_info[ctb];
+              if (cn.slice_idx != cc.slice_idx) {
+                if (cn.slice_idx < cc.slice_idx && !S.slices[cc.slice_idx].lf_across_slices) { skip = 1; break; }
+                if (cn.slice_idx > cc.slice_idx && !S.slices[cn.slice_idx].lf_across_slices) { skip = 1; break; }
+              }
+              if (!S.lf_across_tiles && cn.tile_id != cc.tile_id) { skip = 1; break; }
+            }
+            const int nv = SAO_AT(lr + dy, xs);
+            edge_idx += (v > nv) - (v < nv);
+          }
+          if (!skip) {
+            if (edge_idx <= 2) edge_idx = edge_idx == 2 ? 0 : edge_idx + 1;
+            if (edge_idx) v = clip3(0, maxv, v + sao_off(sp, edge_idx - 1));
+          }
+        }
+      }
+    }
+    res[i] = (Pix)v;
+  }
+#undef SAO_AT
+  return npx;
+}
+template <typename Pix>
+__device__ __forceinline__ void sao_store(const SaoComp<Pix>& S, int ox0, int oy, int npx, const Pix res[4])
+{
+  constexpr int ES = (int)sizeof(Pix);
+  Pix* o = S.out + (size_t)oy * S.os + ox0;
+  if (npx == 4 && ES == 1) *(uint32_t*)o = res[0] | (res[1] << 8) | (res[2] << 16) | ((uint32_t)res[3] << 24);
+  else if (npx == 4 && ES == 2) *(uint2*)o = make_uint2(res[0] | ((uint32_t)res[1] << 16), res[2] | ((uint32_t)res[3] << 16));
+  else {
+#pragma unroll
+    for (int i = 0; i < 4; i++) if (i < npx) o[i] = res[i];
+  }
+}
+
 template <typename Pix>
 __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
 {
   constexpr int ES = (int)sizeof(Pix);
   constexpr int ROW_WORDS = ((SAO_TW + 2) * ES + 3) / 4 + 2;
-  __shared__ uint32_t tile[SAO_TH + 2][ROW_WORDS];
+  __shared__ uint32_t tile[(SAO_TH + 2) * ROW_WORDS];
   if (*A.status != 0) return;
   const PicParams& P = A.pics[blockIdx.y];
   const int c = blockIdx.z;
   if (c > 0 && !P.chroma_format_idc) return;
-  const int sub = c ? 2 : 1;
-  const int ow = c ? P.out_cwidth : P.out_width, oh = c ? P.out_cheight : P.out_height;
-  const int tiles_x = (ow + SAO_TW - 1) / SAO_TW, tiles_y = (oh + SAO_TH - 1) / SAO_TH;
+  const SaoComp<Pix> S = sao_comp<Pix>(A, P, c);
+  const int tiles_x = (S.ow + SAO_TW - 1) / SAO_TW, tiles_y = (S.oh + SAO_TH - 1) / SAO_TH;
   if ((int)blockIdx.x >= tiles_x * tiles_y) return;
   const int ox_t = ((int)blockIdx.x % tiles_x) * SAO_TW, oy_t = ((int)blockIdx.x / tiles_x) * SAO_TH;
-  const int W = c ? P.cwidth : P.width, H = c ? P.cheight : P.height;
-  const int bit_depth = c ? P.bit_depth_chroma : P.bit_depth_luma;
-  const int maxv = (1 << bit_depth) - 1;
-  const uint8_t* __restrict__ rec = A.arena + P.off_rec[c];
-  const int rs_bytes = (int)P.rec_stride[c];
-  Pix* __restrict__ out = (Pix*)(A.arena + P.off_out[c]);
-  const int os = P.out_stride[c] / ES;
-  const uint8_t* u_flags = A.arena + P.off_u_flags;
-  const SaoParams* sao = (const SaoParams*)(A.arena + P.off_sao);
-  const CtbInfo* ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
-  const SliceParams* slices = (const SliceParams*)(A.arena + P.off_slices);
-  const int lctb = P.log2_ctb - (c ? 1 : 0);  // log2 CTB size in component samples
-  const int crop_xc = P.crop_x / sub, crop_yc = P.crop_y / sub, ctb_w = P.ctb_w;
-  const bool check_bypass = P.transquant_bypass_enabled != 0;
-  const bool lf_across_tiles = P.lf_across_tiles != 0;
-  const bool free_nb = P.sao_free_neighbours != 0;
   const int tid = threadIdx.x;
   const int tx = (tid & 31) * 4, ty = tid >> 5;
-  const int xs0 = ox_t + crop_xc, ys0 = oy_t + crop_yc;
-  // the SAO parameters of this thread's rows are requested first so that they travel together with the tile loads
   uint32_t spw[SAO_RPT][3];   // SaoParams as three dwords per row (statically indexed: stays in registers)
 #pragma unroll
-  for (int rr = 0; rr < SAO_RPT; rr++) {
-    int y = oy_t + ty + rr * 8 + crop_yc, x = ox_t + tx + crop_xc;
-    y = y < H ? y : H - 1; x = x < W ? x : W - 1;
-    const uint32_t* src = (const uint32_t*)&sao[(size_t)((y >> lctb) * ctb_w + (x >> lctb)) * 3 + c];
-    spw[rr][0] = src[0]; spw[rr][1] = src[1]; spw[rr][2] = src[2];
-  }
-  // ---- stage source rows ys0-1 .. ys0+TH, bytes [ab, ...) of each row ----
-  int ab = (xs0 - 1) * ES;
-  ab = ab < 0 ? 0 : (ab & ~3);
-  for (int i = tid; i < (SAO_TH + 2) * ROW_WORDS; i += 256) {
-    const int r = i / ROW_WORDS, wi = i - r * ROW_WORDS;
-    const int ys = ys0 - 1 + r, bo = ab + wi * 4;
-    uint32_t v = 0;
-    if (ys >= 0 && ys < H && bo < rs_bytes) v = *(const uint32_t*)(rec + (size_t)ys * rs_bytes + bo);
-    tile[r][wi] = v;
-  }
+  for (int rr = 0; rr < SAO_RPT; rr++) sao_params_at(S, ox_t + tx, oy_t + ty + rr * 8, spw[rr]);
+  const int ab = sao_stage<Pix, SAO_TH, ROW_WORDS, 256>(S, tile, ox_t, oy_t, tid);
   __syncthreads();
 #pragma unroll
   for (int rr = 0; rr < SAO_RPT; rr++) {
     const int oy = oy_t + ty + rr * 8, ox0 = ox_t + tx;
-    if (oy >= oh || ox0 >= ow) continue;
-    const int y = oy + crop_yc, lr = ty + rr * 8 + 1;   // tile row of y
-    const int npx = ow - ox0 < 4 ? ow - ox0 : 4;
-    const int xf = ox0 + crop_xc, xl = xf + npx - 1;
-    const int ctb_first = (y >> lctb) * ctb_w + (xf >> lctb);
-    const bool one_ctb = (xf >> lctb) == (xl >> lctb);
-    const SaoRegs sp_first = sao_unpack(spw[rr][0], spw[rr][1], spw[rr][2]);
     Pix res[4];
-#define SAO_AT(row, x) (((const Pix*)((const uint8_t*)tile[row] + ((x) * ES - ab)))[0])
-    // fast paths: the 4 samples share one CTB (one parameter set) and no per-sample lossless check is needed
-    const int cmask = (1 << lctb) - 1;
-    // edge offsets without per-neighbour checks: no neighbour leaves the CTB - or nothing restricts neighbours in other
-    // CTBs (one slice or filtering across slices / tiles allowed, no lossless CUs) - and none leaves the picture
-    const bool interior = (free_nb ? (xf > 0 && y > 0) : ((xf & cmask) > 0 && (xl & cmask) < cmask && (y & cmask) > 0 && (y & cmask) < cmask)) &&
-                          xl + 1 < W && y + 1 < H;
-    bool done = false;
-    if (one_ctb && !check_bypass && npx == 4) {
-      const SaoRegs sp = sp_first;
-      if (sp.type == 0) {
+    const int npx = sao_quad<Pix, ROW_WORDS>(S, tile, ab, ox0, oy, ty + rr * 8 + 1, spw[rr], res);
+    if (npx) sao_store(S, ox0, oy, npx, res);
+  }
+}
+
+// SAO of all three components of a 128x32 luma tile (8-bit 4:2:0) with the colour stage fused into the store path: the workgroup filters the
+// luma tile (results stay in registers), then the 64x16 Cb and Cr tiles (results also go to LDS), writes the three output planes — the
+// plugin ABI hands those to libheif — and emits the tile's interleaved RGB24 from registers + LDS.  Against k_sao + k_ycbcr_to_rgb_batch
+// this saves the colour pass's 1.5 B/px re-read of the planes and one launch.  Same arithmetic: colordev::convert_px.
+constexpr int SAO_CW = SAO_TW / 2, SAO_CH = SAO_TH / 2;
+__global__ __launch_bounds__(256) void k_sao_rgb(FilterArgs A, const colordev::ColorParams* __restrict__ cps)
+{
+  typedef uint8_t Pix;
+  constexpr int ROW_WORDS = ((SAO_TW + 2) + 3) / 4 + 2;
+  constexpr int CROW_WORDS = ((SAO_CW + 2) + 3) / 4 + 2;
+  __shared__ uint32_t tile[(SAO_TH + 2) * ROW_WORDS];
+  __shared__ uint8_t chroma_s[2][SAO_CH][SAO_CW];
+  if (*A.status != 0) return;
+  const PicParams& P = A.pics[blockIdx.y];
+  const SaoComp<Pix> SY = sao_comp<Pix>(A, P, 0);
+  const int tiles_x = (SY.ow + SAO_TW - 1) / SAO_TW, tiles_y = (SY.oh + SAO_TH - 1) / SAO_TH;
+  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+  const int ox_t = ((int)blockIdx.x % tiles_x) * SAO_TW, oy_t = ((int)blockIdx.x / tiles_x) * SAO_TH;
+  const int tid = threadIdx.x;
+  const int tx = (tid & 31) * 4, ty = tid >> 5;
+  // ---- luma
+  Pix yres[SAO_RPT][4];
+  int ynpx[SAO_RPT];
+  {
+    uint32_t spw[SAO_RPT][3];
 #pragma unroll
-        for (int i = 0; i < 4; i++) res[i] = SAO_AT(lr, xf + i);
-        done = true;
-      } else if (sp.type == 1) {
+    for (int rr = 0; rr < SAO_RPT; rr++) sao_params_at(SY, ox_t + tx, oy_t + ty + rr * 8, spw[rr]);
+    const int ab = sao_stage<Pix, SAO_TH, ROW_WORDS, 256>(SY, tile, ox_t, oy_t, tid);
+    __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          int v = SAO_AT(lr, xf + i);
-          const int k = ((v >> (bit_depth - 5)) - sp.cls) & 31;
-          const int off = k < 4 ? sao_off(sp, k) : 0;
-          res[i] = (Pix)clip3(0, maxv, v + off);
-        }
-        done = true;
-      } else if (interior) {
-        const int cls = sp.cls;
-        const int hx = cls == 1 ? 0 : (cls == 3 ? 1 : -1), hy = cls == 0 ? 0 : -1;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int x = xf + i;
-          const int v = SAO_AT(lr, x), a = SAO_AT(lr + hy, x + hx), b = SAO_AT(lr - hy, x - hx);
-          const int e = ((v > a) - (v < a)) + ((v > b) - (v < b));     // -2 .. 2 ; edgeIdx = 2 + e remapped {0,1,2,3,4} -> {1,2,0,3,4}
-          const int off = e == -2 ? sp.o0 : (e == -1 ? sp.o1 : (e == 1 ? sp.o2 : (e == 2 ? sp.o3 : 0)));
-          res[i] = (Pix)clip3(0, maxv, v + off);
-        }
-        done = true;
-      }
+    for (int rr = 0; rr < SAO_RPT; rr++) {
+      const int oy = oy_t + ty + rr * 8, ox0 = ox_t + tx;
+      ynpx[rr] = sao_quad<Pix, ROW_WORDS>(SY, tile, ab, ox0, oy, ty + rr * 8 + 1, spw[rr], yres[rr]);
+      if (ynpx[rr]) sao_store(SY, ox0, oy, ynpx[rr], yres[rr]);
     }
-    if (!done)
+  }
+  // ---- Cb, Cr: 64 x 16 samples each, one row of 4 samples per thread
+  const int ctx = (tid & 15) * 4, cty = tid >> 4;
+#pragma unroll
+  for (int c = 1; c < 3; c++) {
+    const SaoComp<Pix> SC = sao_comp<Pix>(A, P, c);
+    uint32_t spw[3];
+    sao_params_at(SC, ox_t / 2 + ctx, oy_t / 2 + cty, spw);
+    __syncthreads();                       // the previous component's reads of `tile` are done
+    const int ab = sao_stage<Pix, SAO_CH, CROW_WORDS, 256>(SC, tile, ox_t / 2, oy_t / 2, tid);
+    __syncthreads();
+    Pix res[4];
+    const int ox0 = ox_t / 2 + ctx, oy = oy_t / 2 + cty;
+    const int npx = sao_quad<Pix, CROW_WORDS>(SC, tile, ab, ox0, oy, cty + 1, spw, res);
+    if (npx) sao_store(SC, ox0, oy, npx, res);
+#pragma unroll
+    for (int i = 0; i < 4; i++) chroma_s[c - 1][cty][ctx + i] = i < npx ? res[i] : (Pix)0;
+  }
+  __syncthreads();
+  // ---- RGB24 of this thread's luma samples (nearest-neighbour chroma: x / 2, y / 2)
+  const colordev::ColorParams cp = cps[blockIdx.y];
+#pragma unroll
+  for (int rr = 0; rr < SAO_RPT; rr++) {
+    const int npx = ynpx[rr];
+    if (!npx) continue;
+    const int ly = ty + rr * 8, oy = oy_t + ly, ox0 = ox_t + tx;
+    int R[4], G[4], B[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      if (i >= npx) { res[i] = 0; continue; }
-      const int x = xf + i;
-      int v = SAO_AT(lr, x);
-      const int ctb = one_ctb ? ctb_first : (y >> lctb) * ctb_w + (x >> lctb);
-      SaoRegs sp = sp_first;
-      if (!one_ctb) { const uint32_t* q = (const uint32_t*)&sao[(size_t)ctb * 3 + c]; sp = sao_unpack(q[0], q[1], q[2]); }
-      if (sp.type) {
-        int ctb_dummy;
-        const uint8_t fl = check_bypass ? u_flags[unit_index(P, (x * sub) >> 2, (y * sub) >> 2, &ctb_dummy)] : (uint8_t)0;
-        if (!(fl & UF_BYPASS)) {
-          if (sp.type == 1) {
-            const int k = ((v >> (bit_depth - 5)) - sp.cls) & 31;
-            if (k < 4) v = clip3(0, maxv, v + sao_off(sp, k));
-          } else {
-            const int cls = sp.cls;
-            const int hx = cls == 1 ? 0 : (cls == 3 ? 1 : -1), hy = cls == 0 ? 0 : -1;  // first neighbour; second is the mirror
-            int edge_idx = 2, skip = 0;
-            for (int k = 0; k < 2; k++) {
-              const int dx = k ? -hx : hx, dy = k ? -hy : hy;
-              const int xs = x + dx, ys = y + dy;
-              if (xs < 0 || ys < 0 || xs >= W || ys >= H) { skip = 1; break; }
-              const int ctb_n = (ys >> lctb) * ctb_w + (xs >> lctb);
-              if (ctb_n != ctb) {
-                const CtbInfo cn = ctb_info[ctb_n], cc = ctb_info[ctb];
-                if (cn.slice_idx != cc.slice_idx) {
-                  if (cn.slice_idx < cc.slice_idx && !slices[cc.slice_idx].lf_across_slices) { skip = 1; break; }
-                  if (cn.slice_idx > cc.slice_idx && !slices[cn.slice_idx].lf_across_slices) { skip = 1; break; }
-                }
-                if (!lf_across_tiles && cn.tile_id != cc.tile_id) { skip = 1; break; }
-              }
-              const int nv = SAO_AT(lr + dy, xs);
-              edge_idx += (v > nv) - (v < nv);
-            }
-            if (!skip) {
-              if (edge_idx <= 2) edge_idx = edge_idx == 2 ? 0 : edge_idx + 1;
-              if (edge_idx) v = clip3(0, maxv, v + sao_off(sp, edge_idx - 1));
-            }
-          }
-        }
-      }
-      res[i] = (Pix)v;
+      const int cb = chroma_s[0][ly >> 1][(tx + i) >> 1], cr = chroma_s[1][ly >> 1][(tx + i) >> 1];
+      colordev::convert_px(cp, yres[rr][i], cb, cr, R[i], G[i], B[i]);
     }
-#undef SAO_AT
-    Pix* o = out + (size_t)oy * os + ox0;
-    if (npx == 4 && ES == 1) *(uint32_t*)o = res[0] | (res[1] << 8) | (res[2] << 16) | ((uint32_t)res[3] << 24);
-    else if (npx == 4 && ES == 2) *(uint2*)o = make_uint2(res[0] | ((uint32_t)res[1] << 16), res[2] | ((uint32_t)res[3] << 16));
-    else {
-#pragma unroll
-      for (int i = 0; i < 4; i++) if (i < npx) o[i] = res[i];
+    uint8_t* o = cp.o0 + (size_t)oy * cp.os + (size_t)ox0 * 3;
+    if (npx == 4 && ((cp.os | (uintptr_t)cp.o0) & 3) == 0) {
+      colordev::U3 v;
+      v.a = R[0] | (G[0] << 8) | (B[0] << 16) | ((uint32_t)R[1] << 24);
+      v.b = G[1] | (B[1] << 8) | (R[2] << 16) | ((uint32_t)G[2] << 24);
+      v.c = B[2] | (R[3] << 8) | (G[3] << 16) | ((uint32_t)B[3] << 24);
+      *(colordev::U3*)o = v;
+    } else {
+      for (int i = 0; i < npx; i++) { o[3 * i] = (uint8_t)R[i]; o[3 * i + 1] = (uint8_t)G[i]; o[3 * i + 2] = (uint8_t)B[i]; }
     }
   }
 }
@@ -356,6 +483,12 @@ void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool 
     hipLaunchKernelGGL((k_deblock<uint8_t, 0>), dim3((work_v + 255) / 256, n_pics), dim3(256), 0, s, a);
     hipLaunchKernelGGL((k_deblock<uint8_t, 1>), dim3((work_h + 255) / 256, n_pics), dim3(256), 0, s, a);
   }
+}
+
+void launch_sao_rgb(const FilterArgs& a, const void* color_params_dev, int n_pics, int max_out_w, int max_out_h, hipStream_t s)
+{
+  const int tiles = ((max_out_w + SAO_TW - 1) / SAO_TW) * ((max_out_h + SAO_TH - 1) / SAO_TH);
+  hipLaunchKernelGGL(k_sao_rgb, dim3(tiles, n_pics), dim3(256), 0, s, a, (const colordev::ColorParams*)color_params_dev);
 }
 
 void launch_sao(const FilterArgs& a, int n_pics, int max_out_w, int max_out_h, bool wide, hipStream_t s)

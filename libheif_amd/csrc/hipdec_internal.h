@@ -57,6 +57,8 @@ struct ColorBatchState {
 void color_capture_begin();
 void color_capture_abort();
 int color_capture_launch(ColorBatchState& st, hipStream_t s);
+int color_capture_take(ColorBatchState& st, hipStream_t s, const void** dev, int* uniform_variant, int* count);   // upload only
+int color_variant_rgb24_u8();
 void color_batch_state_free(ColorBatchState& st);
 
 // No C++ exception may cross the C ABI (the caller is libheif, or cgo / JNI / ctypes): every entry point that parses untrusted

@@ -28,5 +28,7 @@ void launch_residual(const FilterArgs& a, int n_pics, int max_ctbs, hipStream_t 
 void launch_recon(const ReconArgs& a, bool wide, hipStream_t s);
 void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s);
 void launch_sao(const FilterArgs& a, int n_pics, int max_out_w, int max_out_h, bool wide, hipStream_t s);
+// SAO + crop with the RGB24 emission fused into the store path (8-bit 4:2:0 only); color_params_dev: one colordev::ColorParams per picture
+void launch_sao_rgb(const FilterArgs& a, const void* color_params_dev, int n_pics, int max_out_w, int max_out_h, hipStream_t s);
 
 }  // namespace hipdec

@@ -34,6 +34,7 @@ def _bind(lib):
     lib.hipdec_batch_device_plane.argtypes = [vp, ci, ci, C.POINTER(vp), C.POINTER(sz)]
     lib.hipdec_batch_to_rgb.argtypes = [vp, ci, ci, vp, sz, vp]
     lib.hipdec_batch_to_rgb_all.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(sz), vp]
+    lib.hipdec_batch_run_rgb.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(sz), vp]
     lib.hipdec_batch_last_timing_us.argtypes = [vp, C.POINTER(C.c_float)]
     lib.hipdec_batch_item_packed_bytes.restype = sz
     lib.hipdec_batch_item_packed_bytes.argtypes = [vp, ci]
@@ -195,6 +196,11 @@ class Batch:
     def to_rgb_all(self, stream=None):
         """asynchronous: fused colour stage over every item's planes into the pre-allocated buffers, ONE launch"""
         check(self._lib.hipdec_batch_to_rgb_all(self._h, self._rgb_chroma, self._rgb_ptrs, self._rgb_strides, stream))
+
+    def run_rgb(self, stream=None):
+        """asynchronous: decode + colour stage into the pre-allocated buffers as ONE call (for 8-bit 4:2:0 -> RGB24 the colour conversion is
+        fused into the SAO kernel's store path)"""
+        check(self._lib.hipdec_batch_run_rgb(self._h, self._rgb_chroma, self._rgb_ptrs, self._rgb_strides, stream))
 
     def rgb(self, i):
         buf, stride, h = self._rgb[i]

@@ -4,13 +4,18 @@
 #include <cstring>
 #include "emu_batch.h"
 #include "kernels.h"
+#include "hipdec_internal.h"
+#include <vector>
 
 using namespace hipdec;
 
 extern "C" {
 
-// stages: bit 0 residual, 1 recon, 2 deblock, 3 sao.  Returns the device status word.
-int emu_run_pipeline(EmuBatch* b, int stages)
+// stages: bit 0 residual, 1 recon, 2 deblock, 3 sao, 4 sao with the RGB24 emission fused into its store path (then `rgb` receives the
+// interleaved rows of every item, tightly packed one after the other).  Returns the device status word.
+int emu_run_pipeline_rgb(EmuBatch* b, int stages, uint8_t* rgb);
+int emu_run_pipeline(EmuBatch* b, int stages) { return emu_run_pipeline_rgb(b, stages, nullptr); }
+int emu_run_pipeline_rgb(EmuBatch* b, int stages, uint8_t* rgb)
 {
   uint8_t* a = b->arena.data();
   const BatchLayout& L = b->L;
@@ -22,6 +27,30 @@ int emu_run_pipeline(EmuBatch* b, int stages)
   if (stages & 2) launch_recon(ra, L.wide, nullptr);
   if (stages & 4) launch_deblock(fa, n, L.max_w, L.max_h, L.wide, nullptr);
   if (stages & 8) launch_sao(fa, n, L.max_ow, L.max_oh, L.wide, nullptr);
+  if ((stages & 16) && rgb) {
+    // the parameter blocks come from the product's own entry points in capture mode, as in hipdec_batch_run_rgb (decoder.hip)
+    static ColorBatchState st;
+    color_capture_begin();
+    uint8_t* dst = rgb;
+    for (int i = 0; i < n; i++) {
+      const PicParams& P = L.params[i];
+      const hipdec_image_info& I = L.pics[i].info;
+      hipdec_nclx nclx{1, I.colour_primaries, I.transfer_characteristics, I.matrix_coeffs, I.full_range_flag};
+      const int m = I.matrix_coeffs == 2 ? 6 : I.matrix_coeffs;
+      int rc;
+      if (I.full_range_flag && m != 0 && m != 8)
+        rc = hipdec_color_420_to_rgb24(a + P.off_out[0], P.out_stride[0], a + P.off_out[1], P.out_stride[1], a + P.off_out[2], P.out_stride[2], P.out_width,
+                                       P.out_height, &nclx, dst, (size_t)P.out_width * 3, 0, nullptr);
+      else
+        rc = hipdec_color_ycbcr_to_rgb24_float(a + P.off_out[0], P.out_stride[0], a + P.off_out[1], P.out_stride[1], a + P.off_out[2], P.out_stride[2],
+                                               P.out_width, P.out_height, 1, &nclx, dst, (size_t)P.out_width * 3, 0, nullptr);
+      if (rc) { color_capture_abort(); return -100 + rc; }
+      dst += (size_t)P.out_width * P.out_height * 3;
+    }
+    const void* dev = nullptr; int variant = -1, count = 0;
+    if (color_capture_take(st, nullptr, &dev, &variant, &count) || variant != color_variant_rgb24_u8()) return -200;
+    launch_sao_rgb(fa, dev, n, L.max_ow, L.max_oh, nullptr);
+  }
   b->status = *(int32_t*)(a + L.off_status);
   return b->status;
 }

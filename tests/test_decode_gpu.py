@@ -390,3 +390,27 @@ def test_a_stream_of_batches_recycles_one_arena():
         ref = orc.decode(sets[3][i])
         for c in range(3):
             np.testing.assert_array_equal(planes_last[n][c], ref["planes"][c])
+
+
+@pytest.mark.parametrize("cfg", [dict(vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1), dict(vui_primaries=1, vui_transfer=1, vui_matrix=1, vui_full_range=0),
+                                 dict(bit_depth=10, vui_matrix=9, vui_primaries=9, vui_transfer=16)], ids=["srgb", "bt709_limited", "main10_unfused"])
+def test_run_rgb_fused_sao_colour_equals_the_two_step_path(cfg):
+    """hipdec_batch_run_rgb: planes and RGB of the fused SAO + colour kernel (8-bit -> RGB24) — and of the unfused fallback (Main10 ->
+    RRGGBB) — equal hipdec_batch_run + hipdec_batch_to_rgb_all, which tests/test_color_gpu.py and the parity tests pin to the oracle"""
+    from libheif_amd.decoder import Batch
+    bd = cfg.get("bit_depth", 8)
+    out_chroma = 10 if bd == 8 else 14
+    streams = [orc.encode(orc.synth_image(w, h, bd, 1, seed=80 + k), **cfg) for k, (w, h) in enumerate([(456, 264), (200, 136), (70, 42), (1288, 728)])]
+    groups = [[streams[0]], [streams[1], streams[1]], [streams[2]], [streams[3]]]
+    for g in groups:
+        a = Batch(g); a.alloc_rgb(out_chroma); a.run(); a.to_rgb_all(); a.status()
+        f = Batch(g); f.alloc_rgb(out_chroma); f.run_rgb(); f.status()
+        f.run_rgb(); f.status()                                # and again over the same arena
+        for i in range(len(g)):
+            np.testing.assert_array_equal(f.rgb(i), a.rgb(i))
+            ref = orc.decode(g[i])
+            for c in range(3):
+                np.testing.assert_array_equal(f.planes(i)[c], ref["planes"][c])
+        t = f.kernel_timing_us()
+        assert (t["colour"] == 0.0) == (bd == 8)               # fused: no separate colour kernel was timed
+        a.free(); f.free()

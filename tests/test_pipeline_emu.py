@@ -178,3 +178,42 @@ def test_emulated_pipeline_scaling_lists_32x32():
         ref = orc.decode(stream, taps=True)
         assert (ref["map_log2_tb"] == 5).any(), "the stream was meant to carry 32x32 transform blocks"
         _check(stream, decode_emu([stream])[0])
+
+
+@pytest.mark.parametrize("cfg", [dict(vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1), dict(),
+                                 dict(vui_primaries=1, vui_transfer=1, vui_matrix=1, vui_full_range=0, stress=1),
+                                 dict(num_slices=3, loop_filter_across_slices=0, vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1),
+                                 dict(lossless_pct=30, tile_cols=2, tile_rows=2, wpp=0, loop_filter_across_tiles=0)],
+                         ids=["srgb_int_op", "unspecified", "bt709_limited_float", "slices", "lossless_tiles"])
+@pytest.mark.parametrize("size", [(200, 136), (70, 42), (452, 264)])
+def test_sao_with_fused_rgb_emission_matches_planes_and_colour_oracle(cfg, size):
+    """k_sao_rgb (SAO + crop of the three components of a tile, RGB24 emitted from registers + LDS): planes as the plain SAO kernel's, RGB as
+    the colour oracle over those planes with the planner's choice of op (integer for full range, float chain otherwise)"""
+    L = _lib()
+    L.emu_run_pipeline_rgb.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    w, h = size
+    streams = [orc.encode(orc.synth_image(w, h, 8, 1, seed=5 + k), **cfg) for k in range(2)]
+    arr = (C.c_char_p * 2)(*streams)
+    sizes = (C.c_size_t * 2)(*[len(s) for s in streams])
+    err = C.create_string_buffer(512)
+    hnd = L.emu_create(2, arr, sizes, err, 512)
+    assert hnd, err.value.decode()
+    try:
+        assert L.emu_run_parse(hnd) == 0
+        rgb = np.zeros((2, h, w * 3), np.uint8)
+        assert L.emu_run_pipeline_rgb(hnd, 1 | 2 | 4 | 16, rgb.ctypes.data) == 0
+        for i, s in enumerate(streams):
+            ref = orc.decode(s)
+            for c in range(3):
+                p = np.zeros(ref["planes"][c].shape, np.uint8)
+                L.emu_plane(hnd, i, c, p.ctypes.data)
+                np.testing.assert_array_equal(p, ref["planes"][c], err_msg="item %d component %d" % (i, c))
+            nclx = tuple(ref["nclx"])
+            if nclx[3] and (6 if nclx[2] == 2 else nclx[2]) not in (0, 8):
+                want = orc.color_420_to_rgb24(ref["planes"][0], ref["planes"][1], ref["planes"][2], nclx).reshape(h, -1)
+            else:
+                r, g, b = orc.color_ycbcr_to_rgb_planar(ref["planes"][0], ref["planes"][1], ref["planes"][2], 8, 1, nclx)
+                want = orc.color_rgb_planar_to_interleaved8(r, g, b).reshape(h, -1)
+            np.testing.assert_array_equal(rgb[i], want, err_msg="item %d RGB" % i)
+    finally:
+        L.emu_free(hnd)
