@@ -29,6 +29,11 @@ import heic_util as hu, struct
 ref='/root/reference/examples/example.heic'
 if os.path.exists(ref):
     h=hu.HeicFile(ref); base.append(h.plugin_stream(h.hevc_items()[1]))
+# the hand-written hostile parameter sets / slice headers of tests/test_hostile_headers.py, as they are and as fuzz seeds
+import test_hostile_headers as hh
+for name, stream in sorted(hh.HOSTILE.items()):
+    assert run(stream) == 0, "hostile stream accepted: " + name
+base += [hh.sps() + hh.pps(wpp=1) + hh.idr(entry=(0, 0, [])), hh.sps(width=128) + hh.pps(wpp=1, tiles=dict(cols_m1=1, rows_m1=0, uniform=0, col_w_m1=[0])) + hh.idr(entry=(1, 7, [5]))]
 acc=0
 for it in range(n):
     s=bytearray(rng.choice(base))
