@@ -40,7 +40,9 @@ void launch_parse(const ParseArgs& a, hipStream_t s)
   static const int scalar_below = getenv("HIPDEC_PARSE_SCALAR_BELOW") ? atoi(getenv("HIPDEC_PARSE_SCALAR_BELOW")) : 512;
   if (forced < 0 && !a.pool && (int)a.num_waves <= scalar_below) { launch_parse_scalar(a, s); return; }
   // throughput mode (the chip is oversubscribed with parser waves): 8 waves per SIMD; latency mode: all registers
-  const int occ = forced >= 0 ? forced : (a.pool ? 7 : (a.num_waves >= 2048 ? 8 : 0));
+  // (pool mode: 8 waves per SIMD since the scalar / vector rebalancing of round 2 — 895 against 907 ms per 2048 4K stills with 7; before it the
+  //  scalar pipe was saturated and the eighth wave bought nothing)
+  const int occ = forced >= 0 ? forced : (a.pool ? 8 : (a.num_waves >= 2048 ? 8 : 0));
   if (occ == 8) hipLaunchKernelGGL(k_parse_occ8, dim3(a.num_waves), dim3(64), 0, s, a);
   else if (occ == 7) hipLaunchKernelGGL(k_parse_occ7, dim3(a.num_waves), dim3(64), 0, s, a);
   else if (occ == 6) hipLaunchKernelGGL(k_parse_occ6, dim3(a.num_waves), dim3(64), 0, s, a);

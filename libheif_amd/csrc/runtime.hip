@@ -85,12 +85,12 @@ hipStream_t upload_stream() { DeviceStreams& d = streams_of_active_device(); ret
 hipStream_t post_stream() { DeviceStreams& d = streams_of_active_device(); return d.post ? d.post : d.stream; }
 bool stage_overlap() { return g_stage_overlap.load(std::memory_order_relaxed) != 0; }
 
-// Waves of the CABAC work pool one batch may launch: the pool only works while ALL its waves are resident (7 per SIMD with
+// Waves of the CABAC work pool one batch may launch: the pool only works while ALL its waves are resident (8 per SIMD with
 // the kernel's register budget), so concurrent batches have to share the machine's wave slots.
 uint32_t parse_wave_budget()
 {
   const int c = g_concurrent.load(std::memory_order_relaxed);
-  const uint32_t slots = (uint32_t)g_cu_count * 4u * 7u;
+  const uint32_t slots = (uint32_t)g_cu_count * 4u * 8u;   // k_parse_occ8: 64 VGPRs, 8 waves per SIMD
   return slots / (uint32_t)(c < 1 ? 1 : c);
 }
 
