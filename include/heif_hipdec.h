@@ -299,6 +299,15 @@ HIPDEC_API int hipdec_color_convert(const hipdec_color_image* in, const hipdec_n
 /* counters since load: conversions through hipdec_color_convert, input planes found device-resident, colour kernels launched */
 HIPDEC_API void hipdec_color_boundary_stats(uint64_t* conversions, uint64_t* resident_planes, uint64_t* kernel_launches);
 
+/* Op_to_hdr_planes (hdr_sdr.cc:25-109): 8-bit plane -> uint16 plane of out_bits (9..16): (v << (out_bits - 8)) | (v >> (16 - out_bits)). */
+HIPDEC_API int hipdec_color_to_hdr(const void* in, size_t is, int w, int h, int out_bits, void* out, size_t os, void* stream);
+/* Op_RRGGBBaa_swap_endianness (rgb2rgb.cc:647-764): interleaved RRGGBB (components 3) / RRGGBBAA (4) LE <-> BE. */
+HIPDEC_API int hipdec_color_swap_endianness(const void* in, size_t is, int w, int h, int components, void* out, size_t os, void* stream);
+/* PQ code values -> linear light (SMPTE ST 2084 / BT.2100 EOTF; 1.0 = 10000 cd/m2), float32 out with `components` values per pixel.
+ * Input: 16-bit samples (interleaved RRGGBB[AA] rows or a plane, components = 1) of bit depth `bits`.  Not in the reference (libheif has
+ * no transfer-function maths): BASELINE config 4's "PQ -> linear" stage; evaluated in fp64, tolerance against the published formula 1e-6 relative. */
+HIPDEC_API int hipdec_color_pq_to_linear(const void* in, size_t is, int w, int h, int components, int bits, int big_endian, void* out, size_t os,
+                                         void* stream);
 /* nclx.cc:143-173 get_YCbCr_to_RGB_coefficients: {r_cr, g_cb, g_cr, b_cb} */
 HIPDEC_API void hipdec_color_coefficients(const hipdec_nclx* nclx, float out[4]);
 

@@ -214,6 +214,52 @@ __global__ __launch_bounds__(256) void k_to_sdr(const uint8_t* in, size_t is, in
   }
 }
 
+// Op_to_hdr_planes (libheif/color-conversion/hdr_sdr.cc:25-109): 8-bit plane -> out_bits (<= 16) by replicating the bit pattern
+__global__ __launch_bounds__(256) void k_to_hdr(const uint8_t* in, size_t is, int w, int h, int out_bits, uint8_t* out, size_t os)
+{
+  const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x0 >= w || y >= h) return;
+  const uint8_t* src = in + (size_t)y * is;
+  uint16_t* dst = (uint16_t*)(out + (size_t)y * os);
+  const int shift1 = out_bits - 8, shift2 = 16 - out_bits;
+  for (int i = 0; i < 4 && x0 + i < w; i++) { const int v = src[x0 + i]; dst[x0 + i] = (uint16_t)((v << shift1) | (v >> shift2)); }
+}
+
+// Op_RRGGBBaa_swap_endianness (libheif/color-conversion/rgb2rgb.cc:647-764): the two bytes of every 16-bit component trade places
+__global__ __launch_bounds__(256) void k_swap16(const uint8_t* in, size_t is, int row_bytes, int h, uint8_t* out, size_t os)
+{
+  const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;     // byte offset, two components per thread
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x0 >= row_bytes || y >= h) return;
+  const uint8_t* src = in + (size_t)y * is + x0;
+  uint8_t* dst = out + (size_t)y * os + x0;
+  if (x0 + 4 <= row_bytes && ((((uintptr_t)src) | ((uintptr_t)dst)) & 3) == 0) {
+    const uint32_t v = *(const uint32_t*)src;
+    *(uint32_t*)dst = ((v & 0x00ff00ffu) << 8) | ((v >> 8) & 0x00ff00ffu);
+  } else {
+    for (int i = 0; i + 1 < 4 && x0 + i + 1 < row_bytes; i += 2) { dst[i] = src[i + 1]; dst[i + 1] = src[i]; }
+  }
+}
+
+// SMPTE ST 2084 / Rec. ITU-R BT.2100 PQ EOTF on code values: E' = v / (2^bits - 1), Y = (max(E'^(1/m2) - c1, 0) / (c2 - c3 E'^(1/m2)))^(1/m1),
+// output linear light normalised to 1.0 = 10000 cd/m2, float32.  NOT in the reference (libheif has no transfer-function maths, SURVEY.md §0
+// fact 5): BASELINE.json's config 4 asks for it, the oracle is the published formula in fp64 (tests), tolerance 1e-6 relative (the fp32 result's rounding).
+__global__ __launch_bounds__(256) void k_pq_to_linear(const uint8_t* in, size_t is, int n_per_row, int h, int bits, int big_endian, float* out, size_t os)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= n_per_row || y >= h) return;
+  uint32_t v = ((const uint16_t*)(in + (size_t)y * is))[x];
+  if (big_endian) v = ((v & 255u) << 8) | (v >> 8);
+  // evaluated in fp64 (the two pow() calls amplify fp32 rounding to ~5e-5 relative; the MI355X has the fp64 rate to spare on a streaming op)
+  const double m1 = 2610.0 / 16384.0, m2 = 2523.0 / 4096.0 * 128.0, c1 = 3424.0 / 4096.0, c2 = 2413.0 / 4096.0 * 32.0, c3 = 2392.0 / 4096.0 * 32.0;
+  const double e = (double)v / (double)((1u << bits) - 1u);
+  const double p = pow(e, 1.0 / m2);
+  const double num = fmax(p - c1, 0.0), den = c2 - c3 * p;
+  ((float*)((uint8_t*)out + (size_t)y * os))[x] = (float)pow(num / den, 1.0 / m1);
+}
+
 // ---- host side -------------------------------------------------------------------------------
 
 // libheif/nclx.cc:45-72
@@ -543,6 +589,42 @@ int hipdec_color_to_sdr(const void* in, size_t is, int w, int h, int bits, void*
   hipStream_t s = stream ? (hipStream_t)stream : default_stream();
   dim3 block(64, 4), grid(((w + 3) / 4 + 63) / 64, (h + 3) / 4);
   hipLaunchKernelGGL(k_to_sdr, grid, block, 0, s, (const uint8_t*)in, is, w, h, bits - 8, (uint8_t*)out, os);
+  HIPDEC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int hipdec_color_to_hdr(const void* in, size_t is, int w, int h, int out_bits, void* out, size_t os, void* stream)
+{
+  if (int rc = ensure_init()) return rc;
+  if (!in || !out || w <= 0 || h <= 0 || out_bits <= 8 || out_bits > 16) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "to_hdr: bad arguments");
+  hipStream_t s = stream ? (hipStream_t)stream : default_stream();
+  dim3 block(64, 4), grid(((w + 3) / 4 + 63) / 64, (h + 3) / 4);
+  hipLaunchKernelGGL(k_to_hdr, grid, block, 0, s, (const uint8_t*)in, is, w, h, out_bits, (uint8_t*)out, os);
+  HIPDEC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int hipdec_color_swap_endianness(const void* in, size_t is, int w, int h, int components, void* out, size_t os, void* stream)
+{
+  if (int rc = ensure_init()) return rc;
+  if (!in || !out || w <= 0 || h <= 0 || (components != 3 && components != 4)) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "swap_endianness: bad arguments");
+  hipStream_t s = stream ? (hipStream_t)stream : default_stream();
+  const int row_bytes = w * components * 2;
+  dim3 block(64, 4), grid(((row_bytes + 3) / 4 + 63) / 64, (h + 3) / 4);
+  hipLaunchKernelGGL(k_swap16, grid, block, 0, s, (const uint8_t*)in, is, row_bytes, h, (uint8_t*)out, os);
+  HIPDEC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int hipdec_color_pq_to_linear(const void* in, size_t is, int w, int h, int components, int bits, int big_endian, void* out, size_t os, void* stream)
+{
+  if (int rc = ensure_init()) return rc;
+  if (!in || !out || w <= 0 || h <= 0 || components < 1 || components > 4 || bits < 8 || bits > 16)
+    return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "pq_to_linear: bad arguments");
+  hipStream_t s = stream ? (hipStream_t)stream : default_stream();
+  const int n = w * components;
+  dim3 block(64, 4), grid((n + 63) / 64, (h + 3) / 4);
+  hipLaunchKernelGGL(k_pq_to_linear, grid, block, 0, s, (const uint8_t*)in, is, n, h, bits, big_endian, (float*)out, os);
   HIPDEC_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -95,3 +95,45 @@ def test_emulated_bilinear_and_sdr(w, h, bpp):
         out = np.zeros((h, w), np.uint8)
         _ok(L, L.hipdec_color_to_sdr(y.ctypes.data, y.strides[0], w, h, bpp, out.ctypes.data, out.strides[0], None))
         np.testing.assert_array_equal(out, orc.color_to_sdr(y, bpp))
+
+
+def _pq_reference(code, bits):
+    """SMPTE ST 2084 / BT.2100 table 4 in float64"""
+    m1, m2, c1, c2, c3 = 2610 / 16384, 2523 / 4096 * 128, 3424 / 4096, 2413 / 4096 * 32, 2392 / 4096 * 32
+    e = code.astype(np.float64) / ((1 << bits) - 1)
+    p = e ** (1 / m2)
+    return (np.maximum(p - c1, 0) / (c2 - c3 * p)) ** (1 / m1)
+
+
+def _bind_f4(L):
+    vp, sz, ci = C.c_void_p, C.c_size_t, C.c_int
+    L.hipdec_color_to_hdr.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
+    L.hipdec_color_swap_endianness.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
+    L.hipdec_color_pq_to_linear.argtypes = [vp, sz, ci, ci, ci, ci, ci, vp, sz, vp]
+    return L
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (67, 5), (1, 1), (130, 33)])
+def test_emulated_to_hdr_swap_and_pq(w, h):
+    """the remaining colour ops of SURVEY §8(f4): Op_to_hdr_planes (hdr_sdr.cc:60-103), Op_RRGGBBaa_swap_endianness (rgb2rgb.cc:738-761) — both
+    byte-exact restatements — and the PQ EOTF the reference does not have (published formula, stated tolerance 1e-6)"""
+    L = _bind_f4(_lib())
+    rng = np.random.default_rng(w * 7 + h)
+    p8 = np.ascontiguousarray(rng.integers(0, 256, (h, w)).astype(np.uint8))
+    for bits in (10, 12, 16):
+        out = np.zeros((h, w), np.uint16)
+        _ok(L, L.hipdec_color_to_hdr(p8.ctypes.data, p8.strides[0], w, h, bits, out.ctypes.data, out.strides[0], None))
+        np.testing.assert_array_equal(out, (p8.astype(np.uint32) << (bits - 8)) | (p8.astype(np.uint32) >> (16 - bits)))
+    for comps in (3, 4):
+        px = np.ascontiguousarray(rng.integers(0, 1 << 16, (h, w * comps)).astype(np.uint16))
+        out = np.zeros_like(px)
+        _ok(L, L.hipdec_color_swap_endianness(px.ctypes.data, px.strides[0], w, h, comps, out.ctypes.data, out.strides[0], None))
+        np.testing.assert_array_equal(out, px.byteswap())
+    for bits, be in ((10, 0), (12, 1)):
+        code = np.ascontiguousarray(rng.integers(0, 1 << bits, (h, w * 3)).astype(np.uint16))
+        code[0, :3] = (0, (1 << bits) - 1, 1)
+        src = code.byteswap() if be else code
+        out = np.zeros((h, w * 3), np.float32)
+        _ok(L, L.hipdec_color_pq_to_linear(src.ctypes.data, src.strides[0], w, h, 3, bits, be, out.ctypes.data, out.strides[0], None))
+        np.testing.assert_allclose(out, _pq_reference(code, bits), rtol=1e-6, atol=1e-9)
+        assert out[0, 0] == 0.0 and abs(out[0, 1] - 1.0) < 1e-6

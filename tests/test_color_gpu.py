@@ -115,3 +115,42 @@ def test_unsupported_matrix_fails_loudly():
     y, cb, cr = _planes(rng, 32, 16, 8)
     with pytest.raises(HipDecError):
         color.convert_colorspace([y, cb, cr], 8, 1, (1, 13, 11, 1), color.CHROMA_RGB)
+
+
+def test_f4_to_hdr_matches_the_compiled_reference_and_swap_pq():
+    """Op_to_hdr_planes against the reference's own pipeline (YCbCr 8 bit -> YCbCr 10 / 12 bit planes through oracle/_ref), the endianness swap
+    against numpy, the PQ EOTF against the published formula (1e-6 relative)"""
+    import ctypes as C
+    import libheif_amd
+    from libheif_amd._capi import DeviceBuffer, check
+    from test_color_emu import _pq_reference
+    lib = libheif_amd.load_library()
+    vp, sz, ci = C.c_void_p, C.c_size_t, C.c_int
+    lib.hipdec_color_to_hdr.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
+    lib.hipdec_color_swap_endianness.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
+    lib.hipdec_color_pq_to_linear.argtypes = [vp, sz, ci, ci, ci, ci, ci, vp, sz, vp]
+    rng = np.random.default_rng(5)
+    w, h = 322, 70
+    planes = [np.ascontiguousarray(rng.integers(0, 256, s).astype(np.uint8)) for s in ((h, w), (h // 2, w // 2), (h // 2, w // 2))]
+    for bits in (10, 12):
+        got = []
+        for p in planes:
+            src = DeviceBuffer.from_numpy(p); dst = DeviceBuffer(p.size * 2)
+            check(lib.hipdec_color_to_hdr(src.ptr, p.shape[1], p.shape[1], p.shape[0], bits, dst.ptr, p.shape[1] * 2, None))
+            check(lib.hipdec_stream_synchronize(None))
+            got.append(dst.to_numpy(p.shape, np.uint16))
+        if ref.available():
+            want = ref.convert(planes, 8, ref.CH_420, (1, 13, 6, 1), ref.CS_YCBCR, ref.CH_420, out_bpp=bits)
+            for g, e in zip(got, want):
+                np.testing.assert_array_equal(g, e[:, :g.shape[1]])
+        np.testing.assert_array_equal(got[0], (planes[0].astype(np.uint32) << (bits - 8)) | (planes[0].astype(np.uint32) >> (16 - bits)))
+    px = np.ascontiguousarray(rng.integers(0, 1 << 16, (h, w * 3)).astype(np.uint16))
+    src = DeviceBuffer.from_numpy(px); dst = DeviceBuffer(px.nbytes)
+    check(lib.hipdec_color_swap_endianness(src.ptr, w * 6, w, h, 3, dst.ptr, w * 6, None))
+    check(lib.hipdec_stream_synchronize(None))
+    np.testing.assert_array_equal(dst.to_numpy((h, w * 3), np.uint16), px.byteswap())
+    code = np.ascontiguousarray(rng.integers(0, 1 << 10, (h, w * 3)).astype(np.uint16))
+    src = DeviceBuffer.from_numpy(code); dst = DeviceBuffer(code.size * 4)
+    check(lib.hipdec_color_pq_to_linear(src.ptr, w * 6, w, h, 3, 10, 0, dst.ptr, w * 12, None))
+    check(lib.hipdec_stream_synchronize(None))
+    np.testing.assert_allclose(dst.to_numpy((h, w * 3), np.float32), _pq_reference(code, 10), rtol=1e-6, atol=1e-9)
