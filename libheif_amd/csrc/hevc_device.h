@@ -159,6 +159,9 @@ struct ParseArgs {
   uint32_t* saved;       // per substream: SAVE_DWORDS of suspended state
   uint32_t yield_ctbs;   // test knob (0 = off): a row yields after this many CTBs per activation
   uint32_t wake_hyst;    // a parked row is woken when its predecessor is this many CTBs beyond the minimum distance
+  // ---- lane-per-substream parser (parse_lanes_kernel.hip) ----
+  const uint32_t* lane_subs;   // substream of lane l of wave w at [w * 64 + l], 0xffffffff = idle lane
+  uint32_t num_lane_waves;
 };
 
 }  // namespace hipdec

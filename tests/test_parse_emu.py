@@ -23,6 +23,7 @@ def emu():
         L.emu_create.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
         L.emu_free.argtypes = [C.c_void_p]
         L.emu_run_parse.argtypes = [C.c_void_p]
+        L.emu_run_parse_lanes.argtypes = [C.c_void_p]
         L.emu_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.emu_maps.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
         L.emu_coeffs.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3
@@ -31,7 +32,7 @@ def emu():
     return _LIB
 
 
-def run_emu(streams):
+def run_emu(streams, lanes=False):
     L = emu()
     n = len(streams)
     arr = (C.c_char_p * n)(*streams)
@@ -39,7 +40,7 @@ def run_emu(streams):
     err = C.create_string_buffer(512)
     h = L.emu_create(n, arr, sizes, err, 512)
     assert h, err.value.decode()
-    status = L.emu_run_parse(h)
+    status = (L.emu_run_parse_lanes if lanes else L.emu_run_parse)(h)
     out = []
     if status != 0:   # maps / coefficients of a desynchronised parse are garbage: do not walk them
         L.emu_free(h)
@@ -203,3 +204,49 @@ def test_byte_reader_skips_emulation_prevention_across_windows_and_resumes(seed)
         for resume_every in (0, 1, 7, 255, 256, 300):
             got = lib.emu_read_bytes(buf, start, end, out, n + 16, resume_every)
             assert out.raw[:got] == want, (seed, start, end, resume_every)
+
+
+# ---- the lane-per-substream parser (libheif_amd/csrc/parse_lanes_kernel.hip) under the SIMT shim ------------------------------------
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: ",".join("%s=%s" % kv for kv in c.items()) or "default")
+@pytest.mark.parametrize("size", [(200, 136), (64, 64), (328, 72)])
+def test_lane_parser_emulation_matches_oracle(cfg, size):
+    bd = cfg.get("bit_depth", 8)
+    planes = orc.synth_image(size[0], size[1], bd, 1, seed=3 + size[0])
+    stream = orc.encode(planes, **cfg)
+    status, got = run_emu([stream], lanes=True)
+    assert status == 0, "device status 0x%x" % status
+    check_against_oracle(stream, got[0])
+
+
+def test_lane_parser_emulation_batch_mixes_pictures_in_a_wave():
+    """more pictures than one wave has lanes, of different sizes / tools: lanes of one wave hold the same row of different pictures,
+    WPP predecessors sit in the same wave (small pictures) or in an earlier one"""
+    streams = []
+    shapes = [(75, 41, 0), (70, 42, 1), (8, 8, 1), (136, 24, 1), (264, 200, 1), (64, 200, 1), (328, 72, 1)]
+    for i in range(70):
+        w, h, cf = shapes[i % len(shapes)]
+        streams.append(orc.encode(orc.synth_image(w, h, 8, cf, seed=100 + i), wpp=(i % 3 != 0), stress=i % 4 == 0, qp=20 + (i % 5) * 5,
+                                  tile_cols=2 if i % 7 == 3 else 1, num_slices=2 if i % 11 == 5 else 1))
+    status, got = run_emu(streams, lanes=True)
+    assert status == 0
+    for s, g in zip(streams, got):
+        check_against_oracle(s, g)
+
+
+def test_lane_parser_emulation_reports_desync():
+    stream = bytearray(orc.encode(orc.synth_image(128, 128, 8, 1, seed=9)))
+    for k in range(len(stream) - 80, len(stream) - 30):
+        stream[k] ^= 0x5A
+    status, _ = run_emu([bytes(stream)], lanes=True)
+    assert status != 0
+
+
+def test_lane_parser_emulation_reference_fixtures(reference_dir):
+    from heic_util import HeicFile
+    for rel in ("examples/example.heic", "tests/data/rainbow-451x461.heic", "tests/data/with-alpha-512x512.heic"):
+        f = HeicFile(os.path.join(reference_dir, rel))
+        for iid in f.hevc_items():
+            s = f.plugin_stream(iid)
+            status, got = run_emu([s], lanes=True)
+            assert status == 0, rel
+            check_against_oracle(s, got[0])
