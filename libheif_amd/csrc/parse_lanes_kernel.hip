@@ -65,8 +65,15 @@ enum : int { CTX_A = 0, CTX_B = 64, CTX_C = 128, N_CTX = 192 };
 
 struct alignas(16) Q4 { uint32_t v[4]; };
 
+enum : int { LN_LEFT_CB = 0, LN_UP_CB = 1, LN_LEFT_IPM = 2, LN_UP_IPM = 3, LN_LEFT_QP = 4, LN_UP_QP = 5 };
+
 struct Shared {
   uint8_t ctx[N_CTX * 64];   // context variable pStateIdx | valMps << 6 of lane l: ctx[c * 64 + l]
+  uint32_t ring[16 * 64];    // 64 bytes of bitstream look-ahead per lane: dword (pos >> 2) & 15 of lane l at ring[slot * 64 + l]
+  uint32_t line[6 * 4 * 64]; // neighbour line buffers per lane (LN_*): entries 4j..4j+3 (bytes) of array a of lane l at line[(a * 4 + j) * 64 + l].
+                             //   "left" arrays are indexed by the unit row inside the CTB, "up" arrays by the unit column: the value of the block
+                             //   decoded last in that row / column, which in z-scan order is the left / upper neighbour of the next one
+  uint32_t sao[9 * 64];      // SaoParams dwords of the lane's current CTB (the previous CTB's until parse_sao rewrites them: sao_merge_left)
   uint32_t t_lps[64];        // rangeTabLps[p][0..3] packed
   uint8_t t_next[64];        // transIdxLps[p], | 64 where valMps flips (p = 0)
   uint8_t diag8[64];         // k-th position of the 8x8 up-right diagonal scan, x | y << 3
@@ -79,7 +86,9 @@ struct LS {
   uint32_t range, value;
   int32_t bits;
   const uint8_t* bs;
-  uint32_t pos, end, cur, nxt;
+  uint32_t pos, end, cur, fill;   // fill: stream offset (multiple of 16) up to which the ring is loaded
+  uint64_t rv;                    // reservoir: next unescaped bytes, first one in bits 63..56
+  int32_t rn;                     // bytes in it
   int32_t zeros, err;
   // request to the decode step / syntax state
   int32_t kind, arg, state;
@@ -130,30 +139,63 @@ PL_DEV uint32_t compact1by1(uint32_t v)
 PL_DEV void wt_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 PL_DEV uint32_t wt_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// ---- byte reader: a dword of look-ahead per lane, emulation prevention (7.4.2) on the fly -----------------------------------------
-PL_DEV void reader_start(LS& L, uint32_t start, uint32_t end)
+// ---- byte reader ------------------------------------------------------------------------------------------------------------------
+// Two levels of look-ahead per lane, both refilled at ONE place of the wave's loop (parse_lanes_wave) so that the decode paths hold neither
+// a global load (its s_waitcnt would also wait for the lane's outstanding stores, and the wave for the lane) nor the emulation-prevention logic:
+//   ring       64 raw bytes of the NAL payload in LDS, topped up by all lanes together when one of them is below RING_LOW bytes
+//   reservoir  up to 8 bytes with the emulation prevention bytes (7.4.2) already removed, in a register pair; take_byte() is a shift.
+// One request consumes at most 6 bytes of a valid stream (coeff_abs_level_remaining: <= 20 + 21 bins); a corrupt one that asks for more gets zero
+// bytes and is caught by the position check.  The only longer run, the SAO syntax at a CTB start, refills as it goes.
+enum : uint32_t { RING_LOW = 40 };
+PL_DEV void ring_fill(LS& L, Shared& S, int lane)
+{
+  while (L.fill - (L.pos & ~15u) <= 48u) {
+    const Q4 v = *(const Q4*)(L.bs + L.fill);
+    const uint32_t slot = (L.fill >> 2) & 15u;
+    S.ring[(slot + 0) * 64 + lane] = v.v[0]; S.ring[(slot + 1) * 64 + lane] = v.v[1];
+    S.ring[(slot + 2) * 64 + lane] = v.v[2]; S.ring[(slot + 3) * 64 + lane] = v.v[3];
+    L.fill += 16u;
+  }
+}
+PL_DEV void reservoir_fill(LS& L, Shared& S, int lane)
+{
+  if (L.pos - (uint32_t)L.rn > L.end + 8u) L.err = DEV_ERR_BITSTREAM_END;   // consumed more than 8 bytes behind the end of the substream
+#pragma clang loop unroll(disable)
+  while (L.rn < 8) {
+    uint32_t b = 0;
+    if (L.pos >= L.end) L.pos++;
+    else {
+      b = (L.cur >> ((L.pos & 3u) * 8u)) & 255u;
+      L.pos++;
+      if ((L.pos & 3u) == 0) L.cur = S.ring[((L.pos >> 2) & 15u) * 64 + lane];
+      if (L.zeros >= 2 && b == 3u && L.pos < L.end) { L.zeros = 0; continue; }   // emulation_prevention_three_byte
+      L.zeros = b == 0 ? L.zeros + 1 : 0;
+    }
+    L.rv |= (uint64_t)b << (56 - 8 * L.rn);
+    L.rn++;
+  }
+}
+PL_DEV void reader_start(LS& L, Shared& S, int lane, uint32_t start, uint32_t end)
 {
   L.pos = start; L.end = end; L.zeros = 0;
-  L.cur = *(const uint32_t*)(L.bs + (start & ~3u));
-  L.nxt = *(const uint32_t*)(L.bs + (start & ~3u) + 4u);
+  L.fill = start & ~15u;
+  ring_fill(L, S, lane);
+  L.cur = S.ring[((start >> 2) & 15u) * 64 + lane];
+  L.rv = 0; L.rn = 0;
+  reservoir_fill(L, S, lane);
 }
 PL_DEV uint32_t next_byte(LS& L)
 {
-  for (;;) {
-    if (L.pos >= L.end) { L.pos++; if (L.pos > L.end + 8u) L.err = DEV_ERR_BITSTREAM_END; return 0; }
-    const uint32_t b = (L.cur >> ((L.pos & 3u) * 8u)) & 255u;
-    L.pos++;
-    if ((L.pos & 3u) == 0) { L.cur = L.nxt; L.nxt = *(const uint32_t*)(L.bs + L.pos + 4u); }
-    if (L.zeros >= 2 && b == 3u && L.pos < L.end) { L.zeros = 0; continue; }   // emulation_prevention_three_byte
-    L.zeros = b == 0 ? L.zeros + 1 : 0;
-    return b;
-  }
+  const uint32_t b = (uint32_t)(L.rv >> 56);
+  L.rv <<= 8;
+  if (L.rn > 0) L.rn--; else L.err = DEV_ERR_SYNTAX;   // more than 8 bytes in one request: no valid stream does that
+  return b;
 }
 
 // ---- arithmetic decoder ------------------------------------------------------------------------------------------------------------
-PL_DEV void cabac_start(LS& L, uint32_t start, uint32_t end)
+PL_DEV void cabac_start(LS& L, Shared& S, int lane, uint32_t start, uint32_t end)
 {
-  reader_start(L, start, end);
+  reader_start(L, S, lane, start, end);
   L.range = 510u; L.bits = -8;
   const uint32_t b0 = next_byte(L), b1 = next_byte(L);
   L.value = (b0 << 8) | b1;
@@ -175,7 +217,7 @@ PL_DEV uint32_t dec_ctx(LS& L, Shared& S, int lane, int c)
   if (L.bits >= 0) { L.value += next_byte(L) << L.bits; L.bits -= 8; }
   return (st >> 6) ^ (is_lps ? 1u : 0u);
 }
-PL_DEV uint32_t dec_byp1(LS& L)
+PL_DEV uint32_t dec_byp1(LS& L, Shared& S, int lane)
 {
   L.value <<= 1;
   L.bits += 1;
@@ -184,13 +226,40 @@ PL_DEV uint32_t dec_byp1(LS& L)
   if (L.value >= scaled) { L.value -= scaled; return 1u; }
   return 0u;
 }
-PL_DEV uint32_t dec_byp(LS& L, int n)   // n <= 32 bins, MSB first
+// n <= 8 bypass bins at once: n steps of 9.3.4.3.4 are one long division of the scaled window by the scaled range (quotient = the bins, MSB
+// first; remainder = the new offset); at most one byte is needed.  value < scaled * 2^n <= 2^24 and scaled < 2^16 are exact in fp32: the
+// quotient estimate from one reciprocal is off by at most one, which the remainder check repairs (as decode_bypass_multi of parse_core.h).
+PL_DEV uint32_t dec_byp_multi(LS& L, int n)
+{
+  L.value <<= n;
+  L.bits += n;
+  if (L.bits >= 0) { L.value += next_byte(L) << L.bits; L.bits -= 8; }
+  const uint32_t scaled = L.range << 7;
+#if defined(HIPDEC_HOST_EMU)
+  uint32_t q = (uint32_t)((float)L.value * (1.0f / (float)scaled));
+#else
+  uint32_t q = (uint32_t)((float)L.value * __builtin_amdgcn_rcpf((float)scaled));
+#endif
+  int32_t r = (int32_t)(L.value - q * scaled);
+  if (r < 0) { q -= 1u; r += (int32_t)scaled; }
+  else if ((uint32_t)r >= scaled) { q += 1u; r -= (int32_t)scaled; }
+  const uint32_t qmax = (1u << n) - 1u;
+  if (q > qmax) { r += (int32_t)((q - qmax) * scaled); q = qmax; }   // only reachable on a corrupt stream
+  L.value = (uint32_t)r;
+  return q;
+}
+PL_DEV uint32_t dec_byp(LS& L, Shared& S, int lane, int n)   // n <= 32 bins, MSB first
 {
   uint32_t v = 0;
-  for (int i = 0; i < n; i++) v = (v << 1) | dec_byp1(L);
+#pragma clang loop unroll(disable)
+  while (n > 0) {
+    const int c = n > 8 ? 8 : n;
+    v = (v << c) | dec_byp_multi(L, c);
+    n -= c;
+  }
   return v;
 }
-PL_DEV uint32_t dec_term(LS& L)
+PL_DEV uint32_t dec_term(LS& L, Shared& S, int lane)
 {
   L.range -= 2u;
   const uint32_t scaled = L.range << 7;
@@ -203,19 +272,20 @@ PL_DEV uint32_t dec_term(LS& L)
   }
   return 0u;
 }
-PL_DEV uint32_t dec_rem(LS& L, int rice)   // 9.3.3.11 coeff_abs_level_remaining
+PL_DEV uint32_t dec_rem(LS& L, Shared& S, int lane, int rice)   // 9.3.3.11 coeff_abs_level_remaining
 {
   int prefix = 0;
-  while (prefix < 32 && dec_byp1(L)) prefix++;
+  while (prefix < 32 && dec_byp1(L, S, lane)) prefix++;
   if (prefix >= 32) { L.err = DEV_ERR_SYNTAX; return 0; }
-  if (prefix <= 3) return ((uint32_t)prefix << rice) + dec_byp(L, rice);
-  return ((((1u << (prefix - 3)) + 3u - 1u) << rice)) + dec_byp(L, prefix - 3 + rice);
+  if (prefix <= 3) return ((uint32_t)prefix << rice) + dec_byp(L, S, lane, rice);
+  return ((((1u << (prefix - 3)) + 3u - 1u) << rice)) + dec_byp(L, S, lane, prefix - 3 + rice);
 }
 
 // ---- contexts (9.3.2.2; 9.3.2.4 storage / synchronisation for WPP) ----------------------------------------------------------------------
 PL_DEV void init_contexts(LS& L, Shared& S, int lane)
 {
   const int qp = L.slice_qp < 0 ? 0 : (L.slice_qp > 51 ? 51 : L.slice_qp);
+#pragma clang loop unroll(disable)
   for (int c = 0; c < N_CTX; c++) {
     const int init = c_init[c >> 6][c & 63];
     const int m = (init >> 4) * 5 - 45, n = ((init & 15) << 3) - 16;
@@ -228,6 +298,7 @@ PL_DEV void init_contexts(LS& L, Shared& S, int lane)
 }
 PL_DEV void load_contexts(Shared& S, int lane, const uint32_t* src)
 {
+#pragma clang loop unroll(disable)
   for (int j = 0; j < N_CTX / 4; j++) {
     const uint32_t w = wt_load(src + j);
     for (int b = 0; b < 4; b++) S.ctx[(4 * j + b) * 64 + lane] = (uint8_t)(w >> (8 * b));
@@ -235,6 +306,7 @@ PL_DEV void load_contexts(Shared& S, int lane, const uint32_t* src)
 }
 PL_DEV void save_contexts(Shared& S, int lane, uint32_t* dst)
 {
+#pragma clang loop unroll(disable)
   for (int j = 0; j < N_CTX / 4; j++) {
     uint32_t w = 0;
     for (int b = 0; b < 4; b++) w |= (uint32_t)S.ctx[(4 * j + b) * 64 + lane] << (8 * b);
@@ -246,28 +318,36 @@ PL_DEV void save_contexts(Shared& S, int lane, uint32_t* dst)
 PL_DEV void fill_units(uint8_t* p, int n, uint32_t b)   // n = 1, 4, 16, 64, 256 units, p aligned to n
 {
   const uint32_t w = b * 0x01010101u;
-  if (n >= 16) { const Q4 q{{w, w, w, w}}; for (int i = 0; i < n; i += 16) *(Q4*)(p + i) = q; }
+  if (n >= 16) {
+    const Q4 q{{w, w, w, w}};
+#pragma clang loop unroll(disable)
+    for (int i = 0; i < n; i += 16) *(Q4*)(p + i) = q;
+  }
   else if (n == 4) *(uint32_t*)p = w;
   else *p = (uint8_t)b;
 }
-PL_DEV uint32_t unit_at(const LS& L, const uint8_t* arena, uint64_t off, int ux, int uy)
+PL_DEV uint32_t line_get(const Shared& S, int lane, int arr, int i) { return (S.line[(arr * 4 + (i >> 2)) * 64 + lane] >> ((i & 3) * 8)) & 255u; }
+PL_DEV void line_set(Shared& S, int lane, int arr, int i0, int n, uint32_t v)   // n = 1, 2, 4, 8, 16 entries from i0 (a multiple of n)
 {
-  return arena[off + L.ubase + interleave4((uint32_t)ux, (uint32_t)uy)];
+  v &= 255u;
+  if (n >= 4) {
+#pragma clang loop unroll(disable)
+    for (int j = 0; j < n; j += 4) S.line[(arr * 4 + ((i0 + j) >> 2)) * 64 + lane] = v * 0x01010101u;
+  } else {
+    const uint32_t mask = (n == 2 ? 0xffffu : 0xffu) << ((i0 & 3) * 8);
+    uint32_t& w = S.line[(arr * 4 + (i0 >> 2)) * 64 + lane];
+    w = (w & ~mask) | ((v * 0x01010101u) & mask);
+  }
 }
-PL_DEV uint32_t unit_left_ctb(const LS& L, const uint8_t* arena, uint64_t off, int uy)   // rightmost column of the CTB to the left
+// log2 CB size of the unit left of / above unit (ux, uy) of the current CTB, or 0 if unavailable
+PL_DEV int left_cb_log2(const LS& L, const Shared& S, int lane, int ux, int uy)
 {
-  const uint32_t uw = 1u << (L.log2_ctb - 2);
-  return arena[off + L.ubase - (1u << (2 * (L.log2_ctb - 2))) + interleave4(uw - 1u, (uint32_t)uy)];
-}
-PL_DEV int left_cb_log2(const LS& L, const uint8_t* arena, int ux, int uy)
-{
-  if (ux > 0) return (int)(unit_at(L, arena, L.o_size, ux - 1, uy) >> 4);
-  if (L.avail & AV_LEFT) return (int)(unit_left_ctb(L, arena, L.o_size, uy) >> 4);
+  if (ux > 0 || (L.avail & AV_LEFT)) return (int)line_get(S, lane, LN_LEFT_CB, uy);
   return 0;
 }
-PL_DEV int up_cb_log2(const LS& L, const uint8_t* arena, int ux, int uy)
+PL_DEV int up_cb_log2(const LS& L, const Shared& S, int lane, int ux, int uy)
 {
-  if (uy > 0) return (int)(unit_at(L, arena, L.o_size, ux, uy - 1) >> 4);
+  if (uy > 0) return (int)line_get(S, lane, LN_UP_CB, ux);
   if (L.avail & AV_UP) {
     const uint64_t lo = L.up_lo, hi = L.up_hi;   // (two 64-bit values, not four dwords: a select chain over adjacent struct fields turns
     const uint64_t w = (ux & 8) ? hi : lo;        //  into an indexed load, which keeps the whole lane state in scratch memory)
@@ -275,11 +355,11 @@ PL_DEV int up_cb_log2(const LS& L, const uint8_t* arena, int ux, int uy)
   }
   return 0;
 }
-PL_DEV void derive_qp_pred(LS& L, const uint8_t* arena, int ux, int uy)   // 8.6.1
+PL_DEV void derive_qp_pred(LS& L, const Shared& S, int lane, int ux, int uy)   // 8.6.1 (qPY_A / qPY_B only count inside the current CTB)
 {
   int a = L.last_qp, b = L.last_qp;
-  if (ux > 0) a = (int8_t)unit_at(L, arena, L.o_qp, ux - 1, uy);
-  if (uy > 0) b = (int8_t)unit_at(L, arena, L.o_qp, ux, uy - 1);
+  if (ux > 0) a = (int8_t)line_get(S, lane, LN_LEFT_QP, uy);
+  if (uy > 0) b = (int8_t)line_get(S, lane, LN_UP_QP, ux);
   L.qp_pred = (a + b + 1) >> 1;
 }
 PL_DEV void set_qp_y(LS& L)
@@ -290,15 +370,15 @@ PL_DEV void set_qp_y(LS& L)
 
 // ---- 7.3.8.3 sao: once per CTB, plain per-lane code (the lanes that are at a CTB start run it, the others wait) -----------------------
 //   SaoParams dwords per component c: 3c+0 type | band_or_class << 8 | offset[0] << 16, 3c+1 offset[1] | offset[2] << 16, 3c+2 offset[3]
-PL_DEV void parse_sao(LS& L, Shared& S, int lane, uint8_t* arena, uint32_t* sao_dst, int allow_left, int allow_up)
+PL_DEV void parse_sao(LS& L, Shared& S, int lane, uint8_t* arena, int allow_left, int allow_up)
 {
   int merge_left = 0, merge_up = 0;
   if (allow_left) merge_left = (int)dec_ctx(L, S, lane, CTX_A + A_SAO_MERGE);
   if (allow_up && !merge_left) merge_up = (int)dec_ctx(L, S, lane, CTX_A + A_SAO_MERGE);
-  if (merge_left) { for (int j = 0; j < 9; j++) sao_dst[j] = sao_dst[j - 9]; return; }
+  if (merge_left) return;   // S.sao still holds the parameters of the CTB to the left
   if (merge_up) {
     const uint32_t* src = (const uint32_t*)(arena + L.P->off_handoff) + (size_t)(L.ctb_rs - L.ctb_w) * HANDOFF_DWORDS;
-    for (int j = 0; j < 9; j++) sao_dst[j] = wt_load(src + j);
+    for (int j = 0; j < 9; j++) S.sao[j * 64 + lane] = wt_load(src + j);
     return;
   }
   const int ncomp = L.chroma ? 3 : 1;
@@ -309,32 +389,35 @@ PL_DEV void parse_sao(LS& L, Shared& S, int lane, uint8_t* arena, uint32_t* sao_
     if (on) {
       int type;
       if (c == 2) type = type1;
-      else { type = 0; if (dec_ctx(L, S, lane, CTX_A + A_SAO_TYPE)) type = dec_byp1(L) ? 2 : 1; }
+      else { type = 0; if (dec_ctx(L, S, lane, CTX_A + A_SAO_TYPE)) type = dec_byp1(L, S, lane) ? 2 : 1; }
       if (c == 1) type1 = type;
       if (type) {
         const int bd = c ? +L.bd_chroma : +L.bd_luma;
         const int c_max = (1 << ((bd < 10 ? bd : 10) - 5)) - 1;
         uint32_t a = 0, sg = 0xCu;   // |offset| four bytes; sign bits (edge offset: + + - -)
-        for (int i = 0; i < 4; i++) { uint32_t v = 0; while ((int)v < c_max && dec_byp1(L)) v++; a |= v << (8 * i); }
+        for (int i = 0; i < 4; i++) { uint32_t v = 0; while ((int)v < c_max && dec_byp1(L, S, lane)) v++; a |= v << (8 * i); reservoir_fill(L, S, lane); }
         int cls;
         if (type == 1) {
           sg = 0;
-          for (int i = 0; i < 4; i++) if ((a >> (8 * i)) & 255u) sg |= dec_byp1(L) << i;
-          cls = (int)dec_byp(L, 5);
+          for (int i = 0; i < 4; i++) if ((a >> (8 * i)) & 255u) sg |= dec_byp1(L, S, lane) << i;
+          cls = (int)dec_byp(L, S, lane, 5);
         } else {
-          if (c == 2) cls = cls1; else cls = (int)dec_byp(L, 2);
+          if (c == 2) cls = cls1; else cls = (int)dec_byp(L, S, lane, 2);
         }
         if (c == 1) cls1 = cls;
         const int sh = bd - (bd < 10 ? bd : 10);
-        uint32_t o[4];
-        for (int i = 0; i < 4; i++) {
-          const int v = (int)((a >> (8 * i)) & 255u);
-          o[i] = (uint32_t)(uint16_t)(int16_t)((((sg >> i) & 1u) ? -v : v) << sh);
+        uint32_t o0, o1, o2, o3;
+        {
+          const int v0 = (int)(a & 255u), v1 = (int)((a >> 8) & 255u), v2 = (int)((a >> 16) & 255u), v3 = (int)(a >> 24);
+          o0 = (uint32_t)(uint16_t)(int16_t)(((sg & 1u) ? -v0 : v0) << sh); o1 = (uint32_t)(uint16_t)(int16_t)(((sg & 2u) ? -v1 : v1) << sh);
+          o2 = (uint32_t)(uint16_t)(int16_t)(((sg & 4u) ? -v2 : v2) << sh); o3 = (uint32_t)(uint16_t)(int16_t)(((sg & 8u) ? -v3 : v3) << sh);
         }
-        d0 = (uint32_t)type | ((uint32_t)cls << 8) | (o[0] << 16); d1 = o[1] | (o[2] << 16); d2 = o[3];
+        d0 = (uint32_t)type | ((uint32_t)cls << 8) | (o0 << 16); d1 = o1 | (o2 << 16); d2 = o3;
       }
     }
-    sao_dst[3 * c + 0] = d0; sao_dst[3 * c + 1] = d1; sao_dst[3 * c + 2] = d2;
+    S.sao[(3 * c + 0) * 64 + lane] = d0; S.sao[(3 * c + 1) * 64 + lane] = d1; S.sao[(3 * c + 2) * 64 + lane] = d2;
+    ring_fill(L, S, lane);   // a component is at most 4 * 31 + 9 bins
+    reservoir_fill(L, S, lane);
   }
 }
 
@@ -407,9 +490,10 @@ PL_DEV void step(LS& L, Shared& S, const int lane, const ParseArgs& A, uint32_t 
     if (L.dep_sub >= 0) {
       uint32_t need = L.k == 0 ? 2u : L.k + 1u;
       if (need > L.dep_len) need = L.dep_len;
-      if (wt_load(A.progress + L.dep_sub) < need) {
+      // (polled on every 8th iteration only: the load's s_waitcnt stalls the whole wave for a round trip to the coherence point)
+      if ((L.waits & 7u) != 0 || wt_load(A.progress + L.dep_sub) < need) {
         L.waits++;
-        if (L.waits > (1u << 22) || ((L.waits & 63u) == 0 && wt_load((const uint32_t*)A.status) != 0)) L.err = DEV_ERR_TIMEOUT;
+        if (L.waits > (1u << 22) || ((L.waits & 1023u) == 1 && wt_load((const uint32_t*)A.status) != 0)) L.err = DEV_ERR_TIMEOUT;
         L.kind = K_NONE;
         goto step_done;
       }
@@ -429,9 +513,12 @@ PL_DEV void step(LS& L, Shared& S, const int lane, const ParseArgs& A, uint32_t 
       L.up_lo = (uint64_t)wt_load(src + 9) | ((uint64_t)wt_load(src + 10) << 32);
       L.up_hi = (uint64_t)wt_load(src + 11) | ((uint64_t)wt_load(src + 12) << 32);
     }
-    uint32_t* sao_dst = (uint32_t*)(arena + P->off_sao) + (size_t)L.ctb_rs * 9;
-    if (L.sao_luma || L.sao_chroma) parse_sao(L, S, lane, arena, sao_dst, (L.avail & AV_LEFT) && L.k > 0, (L.avail & AV_UP) ? 1 : 0);
-    else for (int j = 0; j < 9; j++) sao_dst[j] = 0;
+    if (L.sao_luma || L.sao_chroma) parse_sao(L, S, lane, arena, (L.avail & AV_LEFT) && L.k > 0, (L.avail & AV_UP) ? 1 : 0);
+    else for (int j = 0; j < 9; j++) S.sao[j * 64 + lane] = 0;
+    {
+      uint32_t* sao_dst = (uint32_t*)(arena + P->off_sao) + (size_t)L.ctb_rs * 9;
+      for (int j = 0; j < 9; j++) sao_dst[j] = S.sao[j * 64 + lane];
+    }
     if (!(L.tools & TOOL_CUQPD)) { L.qp_coded = 0; L.qp_delta = 0; L.qp_pred = L.last_qp; }
     L.p = 0;
   }
@@ -456,7 +543,7 @@ PL_DEV void step(LS& L, Shared& S, const int lane, const ParseArgs& A, uint32_t 
     if (x0 + size <= L.width && y0 + size <= L.height && L.lg > L.log2_min_cb) {
       const int depth = L.log2_ctb - L.lg;
       int inc = 0;
-      const int l = left_cb_log2(L, arena, ux, uy), u = up_cb_log2(L, arena, ux, uy);
+      const int l = left_cb_log2(L, S, lane, ux, uy), u = up_cb_log2(L, S, lane, ux, uy);
       if (l && L.log2_ctb - l > depth) inc++;
       if (u && L.log2_ctb - u > depth) inc++;
       REQ(K_CTX, CTX_A + A_SPLIT_CU + inc, S_SPLIT_R);
@@ -467,7 +554,7 @@ PL_DEV void step(LS& L, Shared& S, const int lane, const ParseArgs& A, uint32_t 
   case S_SPLIT_R: {
     if ((L.tools & TOOL_CUQPD) && L.lg >= L.log2_min_qg) {
       L.qp_coded = 0; L.qp_delta = 0;
-      derive_qp_pred(L, arena, (int)compact1by1((uint32_t)L.zb), (int)compact1by1((uint32_t)L.zb >> 1));
+      derive_qp_pred(L, S, lane, (int)compact1by1((uint32_t)L.zb), (int)compact1by1((uint32_t)L.zb >> 1));
     }
     if (r) { L.lg--; HOP(S_SPLIT); }
     if (!(L.tools & TOOL_CUQPD)) L.qp_pred = L.last_qp;
@@ -494,6 +581,11 @@ PL_DEV void step(LS& L, Shared& S, const int lane, const ParseArgs& A, uint32_t 
     fill_units(arena + L.o_size + L.ubase + L.zb, n_units, (uint32_t)(L.log2cb << 4));
     fill_units(arena + L.o_flags + L.ubase + L.zb, n_units, (uint32_t)(L.tqb ? UF_BYPASS : 0));
     fill_units(arena + L.o_ipm + L.ubase + L.zb, n_units, 1u);
+    {
+      const int cw = 1 << (L.log2cb - 2);
+      line_set(S, lane, LN_LEFT_CB, (int)compact1by1((uint32_t)L.zb >> 1), cw, (uint32_t)L.log2cb);
+      line_set(S, lane, LN_UP_CB, (int)compact1by1((uint32_t)L.zb), cw, (uint32_t)L.log2cb);
+    }
     L.pk = 0; L.prev_flags = 0; L.ipm_pack = 0;
     REQ(K_CTX, CTX_A + A_PREV_INTRA_LUMA, S_PREV_R);
   }
@@ -524,9 +616,8 @@ PL_DEV void step(LS& L, Shared& S, const int lane, const ParseArgs& A, uint32_t 
     const int pu_w = 1 << (L.log2cb - 2 - (L.part_nxn ? 1 : 0));
     const int ux = ux0 + (L.pk & 1) * pu_w, uy = uy0 + (L.pk >> 1) * pu_w;
     int cand_a = 1, cand_b = 1;
-    if (ux > 0) cand_a = (int)(unit_at(L, arena, L.o_ipm, ux - 1, uy) & 63u);
-    else if (L.avail & AV_LEFT) cand_a = (int)(unit_left_ctb(L, arena, L.o_ipm, uy) & 63u);
-    if (uy > 0) cand_b = (int)(unit_at(L, arena, L.o_ipm, ux, uy - 1) & 63u);   // above the CTB row: INTRA_DC
+    if (ux > 0 || (L.avail & AV_LEFT)) cand_a = (int)line_get(S, lane, LN_LEFT_IPM, uy);
+    if (uy > 0) cand_b = (int)line_get(S, lane, LN_UP_IPM, ux);   // above the CTB row: INTRA_DC
     int c0, c1, c2;
     if (cand_a == cand_b) {
       if (cand_a < 2) { c0 = 0; c1 = 1; c2 = 26; }
@@ -548,6 +639,8 @@ PL_DEV void step(LS& L, Shared& S, const int lane, const ParseArgs& A, uint32_t 
       if (mode >= c2) mode++;
     }
     fill_units(arena + L.o_ipm + L.ubase + L.zb + L.pk * pu_units, pu_units, (uint32_t)mode);
+    line_set(S, lane, LN_LEFT_IPM, uy, pu_w, (uint32_t)mode);
+    line_set(S, lane, LN_UP_IPM, ux, pu_w, (uint32_t)mode);
     L.ipm_pack |= (uint32_t)mode << (8 * L.pk);
     L.pk++;
     if (L.pk < n_part) HOP(S_IPM);
@@ -848,16 +941,14 @@ PL_DEV void step(LS& L, Shared& S, const int lane, const ParseArgs& A, uint32_t 
     fill_units(arena + L.o_ipm + L.ubase + zu, tu_units, ipm);
     uint8_t* pf = arena + L.o_flags + L.ubase + zu;
     if (tu_units == 1) *pf = (uint8_t)(fl | ve | he);
-    else for (int j = 0; j < tu_units; j += 4) {
-      uint32_t wf = 0;
-      for (int b = 0; b < 4; b++) {
-        const uint32_t idx = (uint32_t)(j + b);   // unit index inside the TU, z-order
-        uint32_t f = fl;
-        if ((idx & 0x55555555u) == 0) f |= ve;   // x == 0
-        if ((idx & 0xAAAAAAAAu) == 0) f |= he;   // y == 0
-        wf |= f << (8 * b);
+    else {
+#pragma clang loop unroll(disable)
+      for (int j = 0; j < tu_units; j += 4) {   // units j .. j+3 in z-order: (x0, y0), (x0+1, y0), (x0, y0+1), (x0+1, y0+1)
+        uint32_t wf = fl * 0x01010101u;
+        if (((uint32_t)j & 0x55555555u) == 0) wf |= ve * 0x00010001u;   // x == 0: the left column of the quad
+        if (((uint32_t)j & 0xAAAAAAAAu) == 0) wf |= he * 0x00000101u;   // y == 0: its top row
+        *(uint32_t*)(pf + j) = wf;
       }
-      *(uint32_t*)(pf + j) = wf;
     }
     L.q += tu_units;
     const int n_units = 1 << (2 * (L.log2cb - 2));
@@ -871,6 +962,11 @@ PL_DEV void step(LS& L, Shared& S, const int lane, const ParseArgs& A, uint32_t 
     set_qp_y(L);
     fill_units(arena + L.o_qp + L.ubase + L.zb, n_units, (uint32_t)(uint8_t)(int8_t)L.cur_qp);
     L.last_qp = L.cur_qp;
+    {
+      const int cw = 1 << (L.log2cb - 2);
+      line_set(S, lane, LN_LEFT_QP, (int)compact1by1((uint32_t)L.zb >> 1), cw, (uint32_t)(uint8_t)(int8_t)L.cur_qp);
+      line_set(S, lane, LN_UP_QP, (int)compact1by1((uint32_t)L.zb), cw, (uint32_t)(uint8_t)(int8_t)L.cur_qp);
+    }
     L.p += 1 << (2 * (L.log2cb - L.log2_min_cb));
     HOP(S_CQT);
   }
@@ -888,13 +984,12 @@ PL_DEV void step(LS& L, Shared& S, const int lane, const ParseArgs& A, uint32_t 
   publish: {
     // hand-off record for the CTB below (SAO parameters, CB sizes of the bottom unit row), WPP context snapshot, progress
     const PicParams* P = L.P;
-    const uint32_t* sao_src = (const uint32_t*)(arena + P->off_sao) + (size_t)L.ctb_rs * 9;
     uint32_t* dst = (uint32_t*)(arena + P->off_handoff) + (size_t)L.ctb_rs * HANDOFF_DWORDS;
-    for (int j = 0; j < 9; j++) wt_store(dst + j, sao_src[j]);
+    for (int j = 0; j < 9; j++) wt_store(dst + j, S.sao[j * 64 + lane]);
     const int uw = 1 << (L.log2_ctb - 2);
-    for (int j = 0; j < (uw + 3) / 4; j++) {
+    for (int j = 0; j < (uw + 3) / 4; j++) {   // the up line buffer now holds the CB sizes of the CTB's bottom unit row
       uint32_t w = 0;
-      for (int b = 0; b < 4 && 4 * j + b < uw; b++) w |= unit_at(L, arena, L.o_size, 4 * j + b, uw - 1) << (8 * b);
+      for (int b = 0; b < 4 && 4 * j + b < uw; b++) w |= (line_get(S, lane, LN_UP_CB, 4 * j + b) << 4) << (8 * b);
       wt_store(dst + 9 + j, w);
     }
     const int has_dependent = (int)((L.sflags >> 8) & 255u);
@@ -910,7 +1005,7 @@ step_done:
   return;
 }
 
-PL_DEV void lane_start(LS& L, const ParseArgs& A, uint32_t sub)
+PL_DEV void lane_start(LS& L, Shared& S, int lane, const ParseArgs& A, uint32_t sub)
 {
   const Substream* sp = A.subs + sub;
   L.sub = sub;
@@ -930,7 +1025,7 @@ PL_DEV void lane_start(LS& L, const ParseArgs& A, uint32_t sub)
   L.o_coef0 = P->off_coeff[0]; L.o_coef1 = P->off_coeff[1]; L.o_coef2 = P->off_coeff[2];
   L.bs = A.arena + P->off_bitstream;
   L.qp_coded = 0; L.qp_delta = 0; L.qp_pred = L.slice_qp; L.last_qp = L.slice_qp; L.cur_qp = L.slice_qp;
-  cabac_start(L, sp->byte_start, sp->byte_end);
+  cabac_start(L, S, lane, sp->byte_start, sp->byte_end);
   L.state = S_CTB;
 }
 
@@ -947,13 +1042,15 @@ PL_DEV void parse_lanes_wave(const ParseArgs& A, uint32_t wave_idx, Shared& S)
   LS L{};
   L.kind = K_NONE; L.state = S_DONE;
   const uint32_t sub = A.lane_subs[(size_t)wave_idx * 64u + (uint32_t)lane];
-  if (sub != 0xffffffffu) lane_start(L, A, sub);
+  if (sub != 0xffffffffu) lane_start(L, S, lane, A, sub);
   for (;;) {
+    if (__ballot(L.state != S_DONE && L.fill - L.pos < RING_LOW) != 0) { if (L.state != S_DONE) ring_fill(L, S, lane); }   // top every ring up together
+    if (L.state != S_DONE) reservoir_fill(L, S, lane);
     uint32_t r = 0;
     if (L.kind == K_CTX) r = dec_ctx(L, S, lane, L.arg);
-    else if (L.kind == K_BYP) r = dec_byp(L, L.arg);
-    else if (L.kind == K_REM) r = dec_rem(L, L.arg);
-    else if (L.kind == K_TERM) r = dec_term(L);
+    else if (L.kind == K_BYP) r = dec_byp(L, S, lane, L.arg);
+    else if (L.kind == K_REM) r = dec_rem(L, S, lane, L.arg);
+    else if (L.kind == K_TERM) r = dec_term(L, S, lane);
     if (L.state != S_DONE) {
       step(L, S, lane, A, r);
       if (L.err) {
