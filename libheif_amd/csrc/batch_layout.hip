@@ -166,13 +166,15 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
     P.sao_enabled = S.sao; P.sign_data_hiding = Pp.sign_data_hiding; P.transform_skip_enabled = Pp.transform_skip;
     P.cu_qp_delta_enabled = Pp.cu_qp_delta; P.transquant_bypass_enabled = Pp.transquant_bypass;
     P.strong_intra_smoothing = S.strong_intra_smoothing; P.tiles_enabled = Pp.tiles; P.wpp = Pp.wpp;
-    P.lf_across_tiles = Pp.lf_across_tiles; P.pcm_loop_filter_disabled = 0;
+    P.lf_across_tiles = Pp.lf_across_tiles; P.pcm_loop_filter_disabled = S.pcm && S.pcm_loop_filter_disabled ? 1 : 0;
+    P.pcm_enabled = S.pcm ? 1 : 0; P.pcm_bd_luma = (uint8_t)S.pcm_bit_depth_luma; P.pcm_bd_chroma = (uint8_t)S.pcm_bit_depth_chroma;
+    P.pcm_cb_range = (uint8_t)(S.log2_min_pcm_cb | (S.log2_max_pcm_cb << 4));
     P.log2_min_cu_qp_delta_size = S.log2_ctb - Pp.diff_cu_qp_delta_depth;
     if (Pp.diff_cu_qp_delta_depth > S.log2_ctb - S.log2_min_cb) { err_out = "item " + std::to_string(i) + ": diff_cu_qp_delta_depth out of range"; return HIPDEC_ERR_BITSTREAM; }
     P.first_row = row_base; row_base += (uint32_t)P.ctb_h;
     P.num_slices = (uint32_t)pp.slice_params.size();
     {
-      bool free_nb = !Pp.transquant_bypass && (!Pp.tiles || Pp.lf_across_tiles);
+      bool free_nb = !Pp.transquant_bypass && !(S.pcm && S.pcm_loop_filter_disabled) && (!Pp.tiles || Pp.lf_across_tiles);
       if (pp.slice_params.size() > 1) for (const auto& sl : pp.slice_params) free_nb = free_nb && sl.lf_across_slices;
       P.sao_free_neighbours = free_nb ? 1 : 0;
     }

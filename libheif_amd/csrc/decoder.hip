@@ -180,7 +180,8 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
   pa.lane_subs = (const uint32_t*)(b.arena + b.off_lane_subs); pa.num_lane_waves = b.num_lane_waves;
   static const int lanes_forced = getenv("HIPDEC_PARSE_LANES") ? atoi(getenv("HIPDEC_PARSE_LANES")) : -1;
   static const uint32_t lanes_from = getenv("HIPDEC_PARSE_LANES_FROM") ? (uint32_t)atoi(getenv("HIPDEC_PARSE_LANES_FROM")) : 0xffffffffu;
-  const bool lanes = lanes_forced >= 0 ? lanes_forced != 0 : b.num_subs >= lanes_from;
+  bool lanes = lanes_forced >= 0 ? lanes_forced != 0 : b.num_subs >= lanes_from;
+  if (lanes) for (const PicParams& P : b.params) if (P.pcm_enabled) { lanes = false; break; }   // pcm_sample is only in the wave-per-substream parser
   if (lanes) launch_parse_lanes(pa, s); else launch_parse(pa, s);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[1], s));
   if (int rc = step("parse")) return rc;

@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
   const size_t ip = DIR == 0 ? unit_index(P, (x >> 2) - 1, y >> 2, &ctb_p) : unit_index(P, x >> 2, (y >> 2) - 1, &ctb_p);
   const uint8_t fp = u_flags[ip];
   const int qp_q = u_qp[iq], qp_p = u_qp[ip];
-  const int no_q = (fq & UF_BYPASS) != 0, no_p = (fp & UF_BYPASS) != 0;  // PCM never occurs (rejected on the host)
+  // 8.7.2.5.7: samples of cu_transquant_bypass units, and of PCM units when pcm_loop_filter_disabled_flag = 1, are left unchanged
+  const int keep = UF_BYPASS | (P.pcm_loop_filter_disabled ? UF_PCM : 0);
+  const int no_q = (fq & keep) != 0, no_p = (fp & keep) != 0;
   const CtbInfo* ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
   const SliceParams sl = ((const SliceParams*)(A.arena + P.off_slices))[ctb_info[ctb_q].slice_idx];
   {
@@ -201,6 +203,7 @@ struct SaoComp {
   const CtbInfo* ctb_info;
   const SliceParams* slices;
   bool check_bypass, lf_across_tiles, free_nb;
+  uint8_t keep_mask;
 };
 template <typename Pix>
 __device__ __forceinline__ SaoComp<Pix> sao_comp(const FilterArgs& A, const PicParams& P, int c)
@@ -218,7 +221,8 @@ __device__ __forceinline__ SaoComp<Pix> sao_comp(const FilterArgs& A, const PicP
   S.slices = (const SliceParams*)(A.arena + P.off_slices);
   S.lctb = P.log2_ctb - (c ? 1 : 0);   // log2 CTB size in component samples
   S.crop_xc = P.crop_x / S.sub; S.crop_yc = P.crop_y / S.sub; S.ctb_w = P.ctb_w;
-  S.check_bypass = P.transquant_bypass_enabled != 0;
+  S.check_bypass = P.transquant_bypass_enabled != 0 || (P.pcm_enabled && P.pcm_loop_filter_disabled);
+  S.keep_mask = (uint8_t)(UF_BYPASS | (P.pcm_loop_filter_disabled ? UF_PCM : 0));   // 8.7.3: SAO leaves these units' samples unchanged
   S.lf_across_tiles = P.lf_across_tiles != 0;
   S.free_nb = P.sao_free_neighbours != 0;
   return S;
@@ -313,7 +317,7 @@ __device__ __forceinline__ int sao_quad(const SaoComp<Pix>& S, const uint32_t* t
     if (sp.type) {
       int ctb_dummy;
       const uint8_t fl = S.check_bypass ? S.u_flags[unit_index(*S.P, (x * sub) >> 2, (y * sub) >> 2, &ctb_dummy)] : (uint8_t)0;
-      if (!(fl & UF_BYPASS)) {
+      if (!(fl & S.keep_mask)) {
         if (sp.type == 1) {
           const int k = ((v >> (bit_depth - 5)) - sp.cls) & 31;
           if (k < 4) v = clip3(0, maxv, v + sao_off(sp, k));

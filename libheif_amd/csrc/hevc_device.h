@@ -7,7 +7,7 @@
 //               inside a CTB, so that every CU / TU occupies a contiguous index range:
 //                 u_size  low nibble log2 TB size, high nibble log2 CB size
 //                 u_flags bit0 cbf_luma, bit1 cbf_cb, bit2 cbf_cr, bit3 cu_transquant_bypass,
-//                         bit4 pcm (never set: PCM streams are rejected), bit5 vertical deblocking
+//                         bit4 pcm_flag (the unit's "coefficients" are its samples, see coeff), bit5 vertical deblocking
 //                         edge on the unit's left side, bit6 horizontal edge on its top,
 //                         bit7 transform_skip (luma)
 //                 u_ipm   bits0-5 IntraPredModeY, bit6 transform_skip Cb, bit7 transform_skip Cr
@@ -15,7 +15,8 @@
 //                 u_qp    QpY of the coding unit (int8)
 //   coeff       int16 TransCoeffLevel, TU-contiguous: a luma TU whose first unit has z-index u owns
 //               [ctb*ctbSize^2 + u*16, +n*n) in raster order inside the TU; chroma likewise at
-//               [ctb*ctbSize^2/4 + u*4, +n*n/4)
+//               [ctb*ctbSize^2/4 + u*4, +n*n/4).  A PCM coding unit is stored as one block of CU size per component whose
+//               "levels" are its samples (pcm_sample << (BitDepth - PcmBitDepth)); its coded-block flags stay 0
 //   rec planes  reconstructed samples (coded size, stride padded to 64 B), deblocked in place
 //   out planes  SAO output cropped to the conformance window (what the plugin hands to libheif)
 #pragma once
@@ -70,6 +71,8 @@ struct PicParams {
   uint8_t lf_across_tiles, pcm_loop_filter_disabled;
   uint8_t sao_free_neighbours;   // 1: no slice / tile boundary restricts the SAO edge neighbours and no lossless CU can occur
   uint8_t scaling_lists;         // scaling_list_enabled_flag: the factor tables at off_scaling apply (8.6.4.2)
+  uint8_t pcm_enabled, pcm_bd_luma, pcm_bd_chroma;   // pcm_enabled_flag, PcmBitDepthY / C
+  uint8_t pcm_cb_range;          // Log2MinIpcmCbSizeY | Log2MaxIpcmCbSizeY << 4
   int32_t log2_min_cu_qp_delta_size;
   // buffers (byte offsets into the batch arena)
   uint64_t off_bitstream, bitstream_size;

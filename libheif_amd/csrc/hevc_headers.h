@@ -26,6 +26,8 @@ struct Sps {
   int log2_min_cb = 3, log2_ctb = 4, log2_min_tb = 2, log2_max_tb = 5;
   int max_th_depth_inter = 0, max_th_depth_intra = 0;
   bool scaling_list_enabled = false, amp = false, sao = false, pcm = false, strong_intra_smoothing = false;
+  int pcm_bit_depth_luma = 8, pcm_bit_depth_chroma = 8, log2_min_pcm_cb = 3, log2_max_pcm_cb = 3;   // valid when pcm
+  bool pcm_loop_filter_disabled = false;
   bool long_term_ref_pics_present = false, temporal_mvp = false, separate_colour_plane = false;
   int num_short_term_ref_pic_sets = 0, num_long_term_ref_pics_sps = 0;
   std::vector<int> rps_num_delta_pocs;  // NumDeltaPocs per short-term RPS (needed to skip slice-level RPS)

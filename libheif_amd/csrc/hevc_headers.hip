@@ -266,7 +266,16 @@ void parse_sps(NalReader& r, Sps& s)
   s.amp = r.u(1);
   s.sao = r.u(1);
   s.pcm = r.u(1);
-  if (s.pcm) unsupported("PCM coding units (pcm_enabled_flag = 1)");
+  if (s.pcm) {   // 7.3.2.2.1 / 7.4.3.2.1
+    s.pcm_bit_depth_luma = (int)r.u(4) + 1;
+    s.pcm_bit_depth_chroma = (int)r.u(4) + 1;
+    if (s.pcm_bit_depth_luma > s.bit_depth_luma || s.pcm_bit_depth_chroma > s.bit_depth_chroma) bad("PCM sample bit depth above the picture's bit depth");
+    s.log2_min_pcm_cb = r.ue_max(2, "log2_min_pcm_luma_coding_block_size_minus3") + 3;
+    s.log2_max_pcm_cb = s.log2_min_pcm_cb + r.ue_max(2, "log2_diff_max_min_pcm_luma_coding_block_size");
+    const int lo = s.log2_min_cb < 5 ? s.log2_min_cb : 5, hi = s.log2_ctb < 5 ? s.log2_ctb : 5;
+    if (s.log2_min_pcm_cb < lo || s.log2_min_pcm_cb > hi || s.log2_max_pcm_cb > hi) bad("PCM coding block size range outside the coding block sizes");
+    s.pcm_loop_filter_disabled = r.u(1) != 0;
+  }
   s.num_short_term_ref_pic_sets = r.ue_max(64, "num_short_term_ref_pic_sets");
   s.rps_num_delta_pocs.clear();
   for (int i = 0; i < s.num_short_term_ref_pic_sets; i++) {

@@ -143,6 +143,7 @@ struct PS {
   int32_t width, height, log2_ctb, log2_min_cb, log2_min_tb, log2_max_tb, max_th_depth_intra;
   int32_t chroma_format_idc, bit_depth_luma, bit_depth_chroma, log2_min_cu_qp_delta_size;
   uint32_t tools;  // bit0 sign_data_hiding 1 transform_skip 2 cu_qp_delta 3 transquant_bypass
+  uint32_t pcm;    // PicParams bytes pcm_enabled, pcm_bd_luma, pcm_bd_chroma, pcm_cb_range
   // ---- slice
   int32_t slice_qp_y, deblock, sao_luma, sao_chroma;
   // ---- CTB
@@ -621,6 +622,72 @@ PC_DEV void parse_cu_qp_delta(PS& s)
   set_qp_y(s);
 }
 
+// maps of one transform block (units zu .. zu + tu_units - 1): flags with the deblocking edges of its left column / top row (8.7.2.2 /
+// 8.7.2.3), size byte, intra mode byte
+PC_DEV void fill_tu_maps(PS& s, int zu, int tu_units, uint32_t fl, uint32_t ipm, uint32_t szb)
+{
+  const int tux0 = (int)compact1by1((uint32_t)zu), tuy0 = (int)compact1by1((uint32_t)zu >> 1);
+  const int edge_l = s.deblock && (tux0 > 0 || (s.ctb_avail & AV_EDGE_LEFT));
+  const int edge_t = s.deblock && (tuy0 > 0 || (s.ctb_avail & AV_EDGE_UP));
+  const uint32_t ve = edge_l ? UF_VEDGE : 0u, he = edge_t ? UF_HEDGE : 0u;
+  if (tu_units >= 4) {
+    const int l0 = zu >> 2, nl = tu_units >> 2;
+    PC_VEC_BEGIN
+      const uint32_t rel = (uint32_t)(lane - l0);
+      if (rel < (uint32_t)nl) {
+        uint32_t wf = 0;
+        for (int k = 0; k < 4; k++) {
+          const uint32_t i = rel * 4u + (uint32_t)k;   // unit index inside the TU, z-order
+          uint32_t f = fl;
+          if ((i & 0x55555555u) == 0) f |= ve;         // x == 0
+          if ((i & 0xAAAAAAAAu) == 0) f |= he;         // y == 0
+          wf |= f << (8 * k);
+        }
+        PC_L(s.m_flags) = wf;
+        PC_L(s.m_size) = szb * 0x01010101u;
+        PC_L(s.m_ipm) = ipm * 0x01010101u;
+      }
+    PC_VEC_END
+  } else {
+    map_fill(s.m_flags, zu, 1, fl | ve | he);
+    map_fill(s.m_size, zu, 1, szb);
+    map_fill(s.m_ipm, zu, 1, ipm);
+  }
+}
+
+// 7.3.8.7 pcm_sample of a coding unit whose pcm_flag (a terminate bin) was 1.  The arithmetic decoder stops on a byte boundary of the
+// payload: with the scaled window of this engine the next unread byte (s.pos) is the first sample byte (the decoder has consumed
+// 8 * bytes - (-bits_needed - 1) bits; the bit it read last lies in the byte before s.pos, pcm_alignment_zero_bits fill the rest of it).
+// The samples go where a transform block of CU size would put its levels (one block per component), so that the reconstruction kernel
+// finds them as the block's "residual"; the decoder is initialised again behind them (9.3.2.5), the context variables are kept.
+PC_DEV void pcm_coding_unit(PS& s, int zb, int log2cb, int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr)
+{
+  set_qp_y(s);
+  const int n_units = 1 << (2 * (log2cb - 2));
+  uint32_t acc = 0;
+  int nacc = 0;
+  for (int c = 0; c < (s.chroma_format_idc ? 3 : 1); c++) {
+    const int lg = c ? log2cb - 1 : log2cb, n2 = 1 << (2 * lg);
+    const int depth = (int)((s.pcm >> (c ? 16 : 8)) & 255u), shift = (c ? s.bit_depth_chroma : s.bit_depth_luma) - depth;
+    for (int i = 0; i < n2; i++) {
+      while (nacc < depth) { acc = (acc << 8) | read_byte(s); nacc += 8; }
+      const uint32_t v = (acc >> (nacc - depth)) & ((1u << depth) - 1u);
+      nacc -= depth;
+      PC_VEC_BEGIN if (lane == 0) s.L->coef[i] = (int16_t)(v << shift); PC_VEC_END
+    }
+    flush_coef(s, c == 0 ? coef_y + zb * 16 : (c == 1 ? coef_cb : coef_cr) + zb * 4, n2);
+  }
+  s.range = pc_vec(510u); s.bits_needed = pc_vec((uint32_t)-8);
+  {
+    const uint32_t b0 = read_byte(s), b1 = read_byte(s);
+    s.value = pc_vec((b0 << 8) | b1);
+  }
+  fill_tu_maps(s, zb, n_units, (uint32_t)(UF_PCM | (s.cu_tq_bypass ? UF_BYPASS : 0)), 1u, (uint32_t)((log2cb << 4) | log2cb));
+  map_fill(s.m_ipmc, zb, n_units, 1u);
+  map_fill(s.m_qp, zb, n_units, (uint32_t)(uint8_t)(int8_t)s.cur_qp_y);
+  s.last_qp_y = s.cur_qp_y;
+}
+
 // ---- 7.3.8.5 coding_unit + 7.3.8.8 transform_tree, stackless over the z-ordered unit index -------
 PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/, int log2cb, int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr)
 {
@@ -631,6 +698,9 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
   int part_nxn = 0;
   if (log2cb == s.log2_min_cb) part_nxn = decode_bin(s, s.ctxA, A_PART_MODE) ? 0 : 1;
   if (part_nxn && log2cb == 3 && s.log2_min_tb > 2) { s.err = DEV_ERR_SYNTAX; part_nxn = 0; }
+  if ((s.pcm & 255u) && !part_nxn && log2cb >= (int)((s.pcm >> 24) & 15u) && log2cb <= (int)(s.pcm >> 28)) {
+    if (decode_terminate(s)) { pcm_coding_unit(s, zb, log2cb, coef_y, coef_cb, coef_cr); return; }   // pcm_flag
+  }
   set_qp_y(s);
   // CU-level map fill (contiguous in z-order)
   map_fill(s.m_size, zb, n_units, (uint32_t)(log2cb << 4));
@@ -739,39 +809,10 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
     }
     const int ts_y = (int)(ts_bits & 1u), ts_cb = (int)((ts_bits >> 1) & 1u), ts_cr = (int)((ts_bits >> 2) & 1u);
     // TU-level map fill: size, cbf, transform-skip, deblocking edges (8.7.2.2 / 8.7.2.3)
-    {
-      const int tux0 = (int)compact1by1((uint32_t)zu), tuy0 = (int)compact1by1((uint32_t)zu >> 1);
-      const int edge_l = s.deblock && (tux0 > 0 || (s.ctb_avail & AV_EDGE_LEFT));
-      const int edge_t = s.deblock && (tuy0 > 0 || (s.ctb_avail & AV_EDGE_UP));
-      const uint32_t fl = (uint32_t)((cbf_luma ? UF_CBF_LUMA : 0) | ((do_chroma && cbf_cb) ? UF_CBF_CB : 0) | ((do_chroma && cbf_cr) ? UF_CBF_CR : 0) |
-                                     (s.cu_tq_bypass ? UF_BYPASS : 0) | (ts_y ? UF_TS_LUMA : 0));
-      const uint32_t ipm = (uint32_t)(luma_mode | (ts_cb ? 64 : 0) | (ts_cr ? 128 : 0));
-      const uint32_t szb = (uint32_t)((log2cb << 4) | t);
-      const uint32_t ve = edge_l ? UF_VEDGE : 0u, he = edge_t ? UF_HEDGE : 0u;
-      if (tu_units >= 4) {
-        const int l0 = zu >> 2, nl = tu_units >> 2;
-        PC_VEC_BEGIN
-          const uint32_t rel = (uint32_t)(lane - l0);
-          if (rel < (uint32_t)nl) {
-            uint32_t wf = 0;
-            for (int k = 0; k < 4; k++) {
-              const uint32_t i = rel * 4u + (uint32_t)k;   // unit index inside the TU, z-order
-              uint32_t f = fl;
-              if ((i & 0x55555555u) == 0) f |= ve;         // x == 0
-              if ((i & 0xAAAAAAAAu) == 0) f |= he;         // y == 0
-              wf |= f << (8 * k);
-            }
-            PC_L(s.m_flags) = wf;
-            PC_L(s.m_size) = szb * 0x01010101u;
-            PC_L(s.m_ipm) = ipm * 0x01010101u;
-          }
-        PC_VEC_END
-      } else {
-        map_fill(s.m_flags, zu, 1, fl | ve | he);
-        map_fill(s.m_size, zu, 1, szb);
-        map_fill(s.m_ipm, zu, 1, ipm);
-      }
-    }
+    fill_tu_maps(s, zu, tu_units,
+                 (uint32_t)((cbf_luma ? UF_CBF_LUMA : 0) | ((do_chroma && cbf_cb) ? UF_CBF_CB : 0) | ((do_chroma && cbf_cr) ? UF_CBF_CR : 0) |
+                            (s.cu_tq_bypass ? UF_BYPASS : 0) | (ts_y ? UF_TS_LUMA : 0)),
+                 (uint32_t)(luma_mode | (ts_cb ? 64 : 0) | (ts_cr ? 128 : 0)), (uint32_t)((log2cb << 4) | t));
     q += tu_units;
   }
   set_qp_y(s);
@@ -971,6 +1012,7 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
     const uint32_t t1 = uload32(&P->transquant_bypass_enabled);
     s.tools = (((t0 >> 8) & 255u) ? TOOL_SDH : 0u) | (((t0 >> 16) & 255u) ? TOOL_TS : 0u) | (((t0 >> 24) & 255u) ? TOOL_CUQPD : 0u) |
               ((t1 & 255u) ? TOOL_TQBYPASS : 0u);
+    s.pcm = uload32(&P->pcm_enabled);
   }
   uint8_t* const arena = A.arena;
   s.bs = arena + uload64(&P->off_bitstream);

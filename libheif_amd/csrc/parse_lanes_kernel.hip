@@ -1005,6 +1005,10 @@ step_done:
   return;
 }
 
+#if defined(HIPDEC_HOST_EMU) && defined(HIPDEC_LANES_STATS)
+void hipdec_lanes_stats(int lane, int state, int kind, int waiting);   // tests/emu/lanes_stats.cc
+#endif
+
 PL_DEV void lane_start(LS& L, Shared& S, int lane, const ParseArgs& A, uint32_t sub)
 {
   const Substream* sp = A.subs + sub;
@@ -1058,6 +1062,11 @@ PL_DEV void parse_lanes_wave(const ParseArgs& A, uint32_t wave_idx, Shared& S)
         L.kind = K_NONE; L.state = S_DONE;
       }
     }
+#if defined(HIPDEC_HOST_EMU) && defined(HIPDEC_LANES_STATS)
+    {   // CPU-test instrumentation: iterations of the wave's loop, populated states and busy lanes per iteration
+      hipdec_lanes_stats(lane, L.state, L.kind, L.state == S_CTB && L.waits);
+    }
+#endif
     if (__ballot(L.state != S_DONE) == 0) break;
     if (__ballot(L.state != S_DONE && !(L.state == S_CTB && L.waits)) == 0) __builtin_amdgcn_s_sleep(32);   // every live lane waits for a row above
   }

@@ -249,7 +249,7 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
       const int idx = lane + 64 * it, x = idx & (n - 1), y = idx >> log2n;
       if (idx < nn) {
         int v = (mul24(n - 1 - x, RL(y + 1)) + mul24(x + 1, tr) + mul24(n - 1 - y, RT(x + 1)) + mul24(y + 1, bl) + n) >> (log2n + 1);
-        if (cbf) v = clip3(0, maxv, v + rp0);
+        if (cbf) v = (cbf & UF_PCM) ? rp0 : clip3(0, maxv, v + rp0);   // a PCM unit's "residual" is the sample itself
         dst0[(y << lg_ctbc) + x] = (Pix)v;
       }
       NEXT_RES(it);
@@ -267,7 +267,7 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
           else if (y == 0) v = (RT(x + 1) + 3 * dc_val + 2) >> 2;
           else if (x == 0) v = (RL(y + 1) + 3 * dc_val + 2) >> 2;
         }
-        if (cbf) v = clip3(0, maxv, v + rp0);
+        if (cbf) v = (cbf & UF_PCM) ? rp0 : clip3(0, maxv, v + rp0);   // a PCM unit's "residual" is the sample itself
         dst0[(y << lg_ctbc) + x] = (Pix)v;
       }
       NEXT_RES(it);
@@ -293,7 +293,7 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
         const int r1 = ref[n2 + mul24(s, k1 >= 0 ? k1 : p1)];
         int v = (mul24(32 - i_fact, r0) + mul24(i_fact, r1) + 16) >> 5;      // i_fact == 0 gives r0
         if (pure && a == 0) v = clip3(0, maxv, (int)ref[n2 + s] + (((int)ref[n2 - mul24(s, b + 1)] - (int)ref[n2]) >> 1));
-        if (cbf) v = clip3(0, maxv, v + rp0);
+        if (cbf) v = (cbf & UF_PCM) ? rp0 : clip3(0, maxv, v + rp0);   // a PCM unit's "residual" is the sample itself
         dst0[(y << lg_ctbc) + x] = (Pix)v;
       }
       NEXT_RES(it);
@@ -403,7 +403,7 @@ __device__ __forceinline__ void reconstruct_chroma_pair(ReconLds<Pix>& L, const 
       const int idx = l + 32 * it, x = idx & (n - 1), y = idx >> log2n;
       if (idx < nn) {
         int v = (mul24(n - 1 - x, RL(y + 1)) + mul24(x + 1, tr) + mul24(n - 1 - y, RT(x + 1)) + mul24(y + 1, bl) + n) >> (log2n + 1);
-        if (cbf) v = clip3(0, maxv, v + rp0);
+        if (cbf) v = (cbf & UF_PCM) ? rp0 : clip3(0, maxv, v + rp0);   // a PCM unit's "residual" is the sample itself
         dst0[(y << lg_ctbc) + x] = (Pix)v;
       }
       NEXT_RES(it);
@@ -416,7 +416,7 @@ __device__ __forceinline__ void reconstruct_chroma_pair(ReconLds<Pix>& L, const 
       const int idx = l + 32 * it, x = idx & (n - 1), y = idx >> log2n;
       if (idx < nn) {
         int v = dc_val;
-        if (cbf) v = clip3(0, maxv, v + rp0);
+        if (cbf) v = (cbf & UF_PCM) ? rp0 : clip3(0, maxv, v + rp0);   // a PCM unit's "residual" is the sample itself
         dst0[(y << lg_ctbc) + x] = (Pix)v;
       }
       NEXT_RES(it);
@@ -437,7 +437,7 @@ __device__ __forceinline__ void reconstruct_chroma_pair(ReconLds<Pix>& L, const 
         const int r0 = ref[n2 + mul24(s, k0 >= 0 ? k0 : p0)];
         const int r1 = ref[n2 + mul24(s, k1 >= 0 ? k1 : p1)];
         int v = (mul24(32 - i_fact, r0) + mul24(i_fact, r1) + 16) >> 5;
-        if (cbf) v = clip3(0, maxv, v + rp0);
+        if (cbf) v = (cbf & UF_PCM) ? rp0 : clip3(0, maxv, v + rp0);   // a PCM unit's "residual" is the sample itself
         dst0[(y << lg_ctbc) + x] = (Pix)v;
       }
       NEXT_RES(it);
@@ -566,12 +566,12 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
       const int tb = (int)(w & 15u), fl = (int)((w >> 8) & 255u), mode = (int)((w >> 16) & 255u);
       if (tb < 2 || tb > 5) { err = DEV_ERR_SYNTAX; break; }
       if (!DUAL) {
-        reconstruct_block<Pix>(L, C, top, ux * 4, uy * 4, tb, mode, fl & cbf_bit, res_base + z * 16);
+        reconstruct_block<Pix>(L, C, top, ux * 4, uy * 4, tb, mode, fl & (cbf_bit | UF_PCM), res_base + z * 16);
       } else if (tb > 2 || (z & 3) == 3) {
         // the 4x4 chroma blocks of four 4x4 luma TUs hang off the 4th unit (their flags are there); they sit at the quad's origin
         const int quad = tb == 2;
         const int zc = quad ? (z & ~3) : z, cux = quad ? (ux & ~1) : ux, cuy = quad ? (uy & ~1) : uy;
-        reconstruct_chroma_pair<Pix>(L, C, top, cux * 2, cuy * 2, quad ? 2 : tb - 1, mode, fl & cbf_bit, res_base + zc * 4);
+        reconstruct_chroma_pair<Pix>(L, C, top, cux * 2, cuy * 2, quad ? 2 : tb - 1, mode, fl & (cbf_bit | UF_PCM), res_base + zc * 4);
       }
       z += 1 << (2 * (tb - 2));
     }

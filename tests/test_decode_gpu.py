@@ -28,6 +28,9 @@ CONFIGS = [
     dict(qp=12, stress=1, zero_residual_pct=30),
     dict(sign_data_hiding=0, cu_qp_delta=0, strong_intra_smoothing=0),
     dict(qp=40),
+    dict(pcm_pct=25),
+    dict(pcm_pct=30, pcm_loop_filter_disabled=1, stress=1, bit_depth=10),
+    dict(pcm_pct=40, log2_ctb=5, log2_max_tb=4, wpp=0, lossless_pct=20),
 ]
 
 
@@ -150,7 +153,10 @@ def test_errors_are_loud():
     assert e.value.code == -2
     assert d.decode_next_image() is None            # nothing pushed -> no image
     d = HipDecoder()
-    d.push_data(orc.encode(planes, pcm_pct=20))     # PCM is outside the implemented tool set
+    nals, p = [], 0
+    while p < len(stream):
+        n = int.from_bytes(stream[p:p + 4], "big"); nals.append(stream[p:p + 4 + n]); p += 4 + n
+    d.push_data(stream + b"".join(x for x in nals if (x[4] >> 1) & 63 < 32))   # a second coded picture: outside the still-image path
     with pytest.raises(HipDecError) as e:
         d.decode_next_image()
     assert e.value.code == -4

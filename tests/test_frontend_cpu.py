@@ -55,7 +55,7 @@ def test_framing_errors_are_end_of_data():
 
 def test_unsupported_tools_and_limits_are_loud():
     planes = orc.synth_image(64, 64, 8, 1, seed=2)
-    assert probe(orc.encode(planes, pcm_pct=30))[0] == -4
+    assert probe(orc.encode(planes, pcm_pct=30))[0] == 0        # PCM coding units are part of the supported tool set
     for sl in (1, 2, 3):   # scaling lists (default / SPS / PPS) are part of the supported tool set
         assert probe(orc.encode(planes, scaling_list=sl))[0] == 0
     s = orc.encode(planes)

@@ -74,6 +74,10 @@ CONFIGS = [
     dict(qp=12, stress=1, zero_residual_pct=30),
     dict(sign_data_hiding=0, cu_qp_delta=0, strong_intra_smoothing=0),
     dict(qp=40),
+    dict(pcm_pct=25),                                                     # pcm_sample blocks, loop filters across them
+    dict(pcm_pct=30, pcm_loop_filter_disabled=1, stress=1),               # ... and left untouched by deblocking / SAO
+    dict(pcm_pct=25, bit_depth=10, lossless_pct=20),                      # PcmBitDepth below BitDepth (shifted samples), beside lossless CUs
+    dict(pcm_pct=40, log2_ctb=5, log2_max_tb=4, wpp=0),                   # 32x32 PCM units above the maximum transform size
 ]
 
 

@@ -1,13 +1,10 @@
 #!/bin/bash
-# GPU probe of the lane-per-substream parser: parity tests with it forced on, then the headline bench with either parser.
+# GPU probe of the lane-per-substream parser (parse kernel time per batch size; parity is tests/ with HIPDEC_PARSE_LANES=1)
 mkdir -p gpurun_out
-export HIPDEC_PARSE_LANES=1
-timeout 900 python -m pytest tests/test_decode_gpu.py tests/test_full_shape_gpu.py -m gpu -q -x > gpurun_out/lanes_tests.log 2>&1
-echo "tests rc=$?" >> gpurun_out/lanes_tests.log
-tail -5 gpurun_out/lanes_tests.log
-for n in 2048 1024 256; do
-  HIPDEC_PARSE_LANES=1 timeout 600 python bench.py --only-main --no-extras --no-cpu-baseline --steps 2 --warmup 1 --batch $n > gpurun_out/lanes_bench_$n.json 2> gpurun_out/lanes_bench_$n.err
-  echo "lanes n=$n rc=$?"; tail -c 1500 gpurun_out/lanes_bench_$n.json
+for n in ${LANES_PROBE_BATCHES:-2048}; do
+  HIPDEC_PARSE_LANES=1 timeout 400 python bench.py --only-main --no-extras --no-cpu-baseline --steps 1 --warmup 1 --batch $n --distinct ${LANES_PROBE_DISTINCT:-64} > gpurun_out/lanes_bench_$n.json 2> gpurun_out/lanes_bench_$n.err
+  echo "lanes n=$n rc=$?"; python3 -c "
+import json,sys
+d=json.loads(open('gpurun_out/lanes_bench_$n.json').read().strip().split('\n')[-1])
+print('value',d['value'],'ms/step',d['ms_per_step'],{k:round(v['avg_us']/1000,1) for k,v in d['kernels'].items()})"
 done
-HIPDEC_PARSE_LANES=0 timeout 600 python bench.py --only-main --no-extras --no-cpu-baseline --steps 2 --warmup 1 > gpurun_out/waves_bench_2048.json 2> gpurun_out/waves_bench_2048.err
-echo "waves rc=$?"; tail -c 1500 gpurun_out/waves_bench_2048.json
