@@ -296,6 +296,24 @@ HIPDEC_API int hipdec_color_plan(int bit_depth, int chroma, int has_alpha, const
  * are read from their device-resident copy, others are uploaded; `out` is a host buffer (or a device buffer, out_on_device). */
 HIPDEC_API int hipdec_color_convert(const hipdec_color_image* in, const hipdec_nclx* nclx, int out_chroma, int upsampling,
                                     int only_preferred, void* out, size_t out_stride, int out_on_device);
+/* ---- transformative item properties on the device: what ImageItem::decode_image applies to the decoded image on the host
+ * (libheif/image-items/image_item.cc:949-1081: 'irot' :958-966, 'imir' :968-977, 'clap' :981-1010) ---------------------------------------- */
+typedef enum hipdec_transform_op {
+  HIPDEC_XF_ROTATE_CCW = 0,   /* args[0] = 90 / 180 / 270      HeifPixelImage::rotate_ccw      libheif/image/pixelimage.cc:1175-1333 */
+  HIPDEC_XF_MIRROR = 1,       /* args[0] = heif_transform_mirror_direction (0 vertical, 1 horizontal)   mirror_inplace   :1337-1430 */
+  HIPDEC_XF_CROP = 2          /* args = left, right, top, bottom (inclusive end points)        HeifPixelImage::crop            :1433-1530 */
+} hipdec_transform_op;
+/* Every plane of `in` (host or device pointers; host planes the decoder handed over are found device-resident) through the op, into the planes
+ * `out` brings (same on_device convention; NULL where `in` has no plane); out->width / height / chroma / bit_depth are filled in.  Returns
+ * HIPDEC_ERR_UNSUPPORTED where the reference converts the image to 4:4:4 first (odd size / offset of a subsampled image). */
+HIPDEC_API int hipdec_image_transform(const hipdec_color_image* in, int op, const int* args, hipdec_color_image* out);
+/* the plane kernels (device pointers, `stream` a hipStream_t or NULL): ComponentStorage::rotate_ccw<T> / mirror_inplace<T> (pixelimage.cc:1305-1355)
+ * and the per-plane copy of HeifPixelImage::crop; bytes_per_sample 1 or 2 */
+HIPDEC_API int hipdec_plane_rotate_ccw(const void* in, size_t in_stride, int w, int h, int bytes_per_sample, int angle, void* out, size_t out_stride, void* stream);
+HIPDEC_API int hipdec_plane_mirror(const void* in, size_t in_stride, int w, int h, int bytes_per_sample, int direction, void* out, size_t out_stride, void* stream);
+HIPDEC_API int hipdec_plane_crop(const void* in, size_t in_stride, int w, int h, int bytes_per_sample, int left, int top, int out_w, int out_h, void* out,
+                                 size_t out_stride, void* stream);
+
 /* counters since load: conversions through hipdec_color_convert, input planes found device-resident, colour kernels launched */
 HIPDEC_API void hipdec_color_boundary_stats(uint64_t* conversions, uint64_t* resident_planes, uint64_t* kernel_launches);
 

@@ -1046,6 +1046,99 @@ int hipdec_color_convert(const hipdec_color_image* in, const hipdec_nclx* nclx, 
   });
 }
 
+// 'irot' / 'imir' / 'clap' of ImageItem::decode_image (libheif/image-items/image_item.cc:949-1081) over the planes of an image, on the device
+// (plane kernels: transform.hip).  op HIPDEC_XF_ROTATE_CCW: args[0] = 90 / 180 / 270 (HeifPixelImage::rotate_ccw, image/pixelimage.cc:1175-1300);
+// HIPDEC_XF_MIRROR: args[0] = heif_transform_mirror_direction (mirror_inplace, :1358-1430); HIPDEC_XF_CROP: args = left, right, top, bottom, the
+// inclusive end points HeifPixelImage::crop takes (:1433-1530).  Where the reference first converts a subsampled image to 4:4:4 (odd sizes /
+// offsets, the checks at :1187-1204, :1371-1381, :1457-1464) this returns HIPDEC_ERR_UNSUPPORTED and the caller keeps the host path.  The input
+// planes are host or device pointers (host planes the decoder handed over are found device-resident); `out` brings the destination planes
+// (NULL where the input has none) and receives the geometry.
+int hipdec_image_transform(const hipdec_color_image* in, int op, const int* args, hipdec_color_image* out)
+{
+  if (!in || !out || !args || in->width <= 0 || in->height <= 0 || !in->plane[0] || in->bit_depth < 8 || in->bit_depth > 16)
+    return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "image_transform: bad arguments");
+  if (int rc = ensure_init()) return rc;
+  return guarded("image_transform", [&]() -> int {
+    const int w = in->width, h = in->height;
+    const bool has_chroma = in->plane[1] && in->plane[2];
+    const int chroma = has_chroma ? in->chroma : 0;
+    if (has_chroma && (chroma < 1 || chroma > 3)) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "image_transform: chroma must be 1 (4:2:0), 2 (4:2:2) or 3 (4:4:4)");
+    const bool odd_w = w & 1, odd_h = h & 1;
+    int ow = w, oh = h, left = 0, top = 0;
+    bool needs_444 = false;
+    if (op == HIPDEC_XF_ROTATE_CCW) {
+      const int a = args[0];
+      if (a != 90 && a != 180 && a != 270) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "image_transform: rotation must be 90, 180 or 270");
+      if (chroma == 2) needs_444 = a != 180 || odd_h;
+      else if (chroma == 1) needs_444 = (a == 90 && odd_w) || (a == 180 && (odd_w || odd_h)) || (a == 270 && odd_h);
+      if (a != 180) { ow = h; oh = w; }
+    } else if (op == HIPDEC_XF_MIRROR) {
+      if (args[0] != 0 && args[0] != 1) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "image_transform: mirror direction must be 0 or 1");
+      if (chroma == 2) needs_444 = args[0] == 1 && odd_w;
+      else if (chroma == 1) needs_444 = odd_w || odd_h;
+    } else if (op == HIPDEC_XF_CROP) {
+      const int l = args[0], r = args[1], t = args[2], b = args[3];
+      if (l < 0 || t < 0 || r < l || b < t || r >= w || b >= h) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "image_transform: invalid crop region");
+      if (chroma == 2) needs_444 = l & 1;
+      else if (chroma == 1) needs_444 = (l & 1) || (t & 1);
+      left = l; top = t; ow = r - l + 1; oh = b - t + 1;
+    } else return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "image_transform: unknown operation %d", op);
+    if (needs_444) return set_error(HIPDEC_ERR_UNSUPPORTED, "image_transform: the reference converts this image to 4:4:4 first (odd size / offset of a subsampled image)");
+    const size_t es = in->bit_depth > 8 ? 2 : 1;
+    const int sx = (chroma == 1 || chroma == 2) ? 2 : 1, sy = chroma == 1 ? 2 : 1;
+    hipStream_t s = stream_acquire();
+    struct Release { hipStream_t s; std::vector<std::pair<void*, size_t>> bufs;
+                     ~Release() { (void)hipStreamSynchronize(s); for (auto& b : bufs) arena_release(b.first, b.second); stream_release(s); } } rel{s, {}};
+    auto scratch = [&](size_t bytes, uint8_t** p) -> int {
+      void* d = nullptr; size_t cap = 0;
+      HIPDEC_CHECK_HIP(arena_acquire(&d, bytes ? bytes : 256, &cap));
+      rel.bufs.emplace_back(d, cap); *p = (uint8_t*)d;
+      return 0;
+    };
+    std::shared_ptr<hipdec_batch> keep[4];
+    for (int c = 0; c < 4; c++) {
+      if (!in->plane[c]) continue;
+      if ((c == 1 || c == 2) && !has_chroma) continue;
+      if (!out->plane[c]) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "image_transform: no destination for plane %d", c);
+      const bool sub = c == 1 || c == 2;
+      const int pw = sub ? (w + sx - 1) / sx : w, ph = sub ? (h + sy - 1) / sy : h;
+      // geometry of this plane's result (crop: HeifPixelImage::crop's plane_left .. plane_right, pixelimage.cc:1497-1500)
+      int pl = left, pt = top, pow_ = ow, poh = oh;
+      if (sub) {
+        if (op == HIPDEC_XF_CROP) { pl = left / sx; pt = top / sy; pow_ = (left + ow - 1) / sx - pl + 1; poh = (top + oh - 1) / sy - pt + 1; }
+        else if (op == HIPDEC_XF_ROTATE_CCW && args[0] != 180) { pow_ = ph; poh = pw; }
+        else { pow_ = pw; poh = ph; }
+      }
+      if (out->stride[c] < (size_t)pow_ * es) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "image_transform: destination stride of plane %d too small", c);
+      const uint8_t* dp = nullptr; size_t ds = 0;
+      if (in->on_device) { dp = (const uint8_t*)in->plane[c]; ds = in->stride[c]; }
+      else if (resident_find(in->plane[c], in->stride[c], pw, ph, in->bit_depth, &dp, &ds, keep[c])) g_cb_resident++;
+      else {
+        uint8_t* d = nullptr;
+        const size_t st = ((size_t)pw * es + 255) & ~(size_t)255;
+        if (int rc = scratch(st * ph, &d)) return rc;
+        HIPDEC_CHECK_HIP(hipMemcpy2DAsync(d, st, in->plane[c], in->stride[c], (size_t)pw * es, ph, hipMemcpyHostToDevice, s));
+        dp = d; ds = st;
+      }
+      uint8_t* dout = (uint8_t*)out->plane[c];
+      size_t dout_stride = out->stride[c];
+      if (!out->on_device) {
+        dout_stride = ((size_t)pow_ * es + 255) & ~(size_t)255;
+        if (int rc = scratch(dout_stride * poh, &dout)) return rc;
+      }
+      int rc;
+      if (op == HIPDEC_XF_ROTATE_CCW) rc = hipdec_plane_rotate_ccw(dp, ds, pw, ph, (int)es, args[0], dout, dout_stride, (void*)s);
+      else if (op == HIPDEC_XF_MIRROR) rc = hipdec_plane_mirror(dp, ds, pw, ph, (int)es, args[0], dout, dout_stride, (void*)s);
+      else rc = hipdec_plane_crop(dp, ds, pw, ph, (int)es, pl, pt, pow_, poh, dout, dout_stride, (void*)s);
+      if (rc) return rc;
+      if (!out->on_device) HIPDEC_CHECK_HIP(hipMemcpy2DAsync((void*)out->plane[c], out->stride[c], dout, dout_stride, (size_t)pow_ * es, poh, hipMemcpyDeviceToHost, s));
+    }
+    HIPDEC_CHECK_HIP(hipStreamSynchronize(s));
+    out->width = ow; out->height = oh; out->chroma = in->chroma; out->bit_depth = in->bit_depth;
+    return 0;
+  });
+}
+
 }  // extern "C"
 
 // ---- grid images across the GPUs of one node ------------------------------------------------------------------------------

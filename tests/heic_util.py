@@ -260,11 +260,13 @@ def _payload(nals):
     return b"".join(struct.pack(">I", len(n)) + n for n in nals if (n[0] >> 1) & 63 < 32)
 
 
-def build_heic(items, grid=None, bit_depth=8, chroma_format_idc=1, alpha_of=None):
+def build_heic(items, grid=None, bit_depth=8, chroma_format_idc=1, alpha_of=None, transforms=None):
     """items: list of (stream, width, height[, chroma_format_idc]) coded items (ids 1..n).  grid: None, or
     (rows, cols, out_w, out_h) -> an extra 'grid' item (id n+1, primary) referencing all items in order.
     alpha_of: {alpha item id: master item id} -> the alpha item becomes a hidden auxiliary image of its master ('auxC' property
-    urn:mpeg:hevc:2015:auxid:1 + 'auxl' reference), what libheif attaches as the alpha channel (image_item.cc:949-1081)."""
+    urn:mpeg:hevc:2015:auxid:1 + 'auxl' reference), what libheif attaches as the alpha channel (image_item.cc:949-1081).
+    transforms: transformative properties of the primary item, applied in order (essential): ("irot", quarter turns ccw 0..3),
+    ("imir", axis byte 0 / 1), ("clap", (width, height, left, top)) -> the 'clap' whose rounded edges are exactly that window."""
     alpha_of = alpha_of or {}
     cfs = [it[3] if len(it) > 3 else chroma_format_idc for it in items]
     items = [it[:3] for it in items]
@@ -287,6 +289,19 @@ def build_heic(items, grid=None, bit_depth=8, chroma_format_idc=1, alpha_of=None
     if grid is not None:
         props.append(_fullbox("ispe", 0, 0, struct.pack(">II", grid[2], grid[3])))
         assoc[n + 1] = [(len(props), False)]
+    for kind, arg in (transforms or []):
+        pid = n + 1 if grid is not None else 1
+        pw, ph = (grid[2], grid[3]) if grid is not None else (items[0][1], items[0][2])
+        if kind == "irot":
+            props.append(_box("irot", bytes([arg & 3])))
+        elif kind == "imir":
+            props.append(_box("imir", bytes([arg & 1])))
+        elif kind == "clap":   # left = horizOff + (W - 1) / 2 - (cw - 1) / 2 (box.cc Box_clap::left_rounded): offsets in halves
+            cw, ch, left, top = arg
+            props.append(_box("clap", struct.pack(">IIIIiIiI", cw, 1, ch, 1, 2 * left + (cw - 1) - (pw - 1), 2, 2 * top + (ch - 1) - (ph - 1), 2)))
+        else:
+            raise ValueError(kind)
+        assoc[pid].append((len(props), True))
     ipco = _box("ipco", b"".join(props))
     ipma = struct.pack(">I", len(assoc))
     for iid in sorted(assoc):

@@ -122,7 +122,7 @@ def primary_size(data):
         L.heif_context_free(ctx)
 
 
-def decode(data, colorspace=COLORSPACE_UNDEFINED, chroma=CHROMA_UNDEFINED, max_threads=None):
+def decode(data, colorspace=COLORSPACE_UNDEFINED, chroma=CHROMA_UNDEFINED, max_threads=None, ignore_transformations=False):
     """heif_decode_image() on the primary item.  Returns a dict: YCbCr -> planes [Y, Cb, Cr];
     interleaved RGB -> 'rgb' rows."""
     L = lib()
@@ -131,7 +131,17 @@ def decode(data, colorspace=COLORSPACE_UNDEFINED, chroma=CHROMA_UNDEFINED, max_t
     try:
         if max_threads is not None:
             L.heif_context_set_max_decoding_threads(ctx, max_threads)
-        check(L.heif_decode_image(h, C.byref(img), colorspace, chroma, None))
+        opts = None
+        if ignore_transformations:   # heif_decoding_options: uint8 version, uint8 ignore_transformations, ... (api/libheif/heif_decoding.h:63-71)
+            L.heif_decoding_options_alloc.restype = C.c_void_p
+            L.heif_decoding_options_free.argtypes = [C.c_void_p]
+            opts = C.c_void_p(L.heif_decoding_options_alloc())
+            C.cast(opts, C.POINTER(C.c_uint8))[1] = 1
+        try:
+            check(L.heif_decode_image(h, C.byref(img), colorspace, chroma, opts))
+        finally:
+            if opts:
+                L.heif_decoding_options_free(opts)
         out = {}
         if chroma in (CHROMA_RGB, CHROMA_RGBA):
             out["rgb"] = _plane(L, img, CHANNEL_INTERLEAVED, 1, 3 if chroma == CHROMA_RGB else 4)
