@@ -305,7 +305,8 @@ typedef enum hipdec_transform_op {
 } hipdec_transform_op;
 /* Every plane of `in` (host or device pointers; host planes the decoder handed over are found device-resident) through the op, into the planes
  * `out` brings (same on_device convention; NULL where `in` has no plane); out->width / height / chroma / bit_depth are filled in.  Returns
- * HIPDEC_ERR_UNSUPPORTED where the reference converts the image to 4:4:4 first (odd size / offset of a subsampled image). */
+ * HIPDEC_ERR_UNSUPPORTED where the reference converts the image to 4:4:4 first (odd size / offset of a subsampled image) and for odd crop
+ * windows of subsampled images (half-covered chroma edge): the caller keeps the host path there. */
 HIPDEC_API int hipdec_image_transform(const hipdec_color_image* in, int op, const int* args, hipdec_color_image* out);
 /* the plane kernels (device pointers, `stream` a hipStream_t or NULL): ComponentStorage::rotate_ccw<T> / mirror_inplace<T> (pixelimage.cc:1305-1355)
  * and the per-plane copy of HeifPixelImage::crop; bytes_per_sample 1 or 2 */

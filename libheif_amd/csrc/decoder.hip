@@ -1079,11 +1079,16 @@ int hipdec_image_transform(const hipdec_color_image* in, int op, const int* args
     } else if (op == HIPDEC_XF_CROP) {
       const int l = args[0], r = args[1], t = args[2], b = args[3];
       if (l < 0 || t < 0 || r < l || b < t || r >= w || b >= h) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "image_transform: invalid crop region");
+      left = l; top = t; ow = r - l + 1; oh = b - t + 1;
       if (chroma == 2) needs_444 = l & 1;
       else if (chroma == 1) needs_444 = (l & 1) || (t & 1);
-      left = l; top = t; ow = r - l + 1; oh = b - t + 1;
+      // An odd window size leaves a half-covered chroma column / row at the edge.  The reference's output there is NOT the plane copy its
+      // crop() reads like (measured through heif_decode_image on the compiled reference: the last chroma column / row differs from the
+      // decoded plane), so those windows stay on the host rather than being claimed.
+      if (!needs_444 && ((chroma == 1 || chroma == 2) && (ow & 1))) needs_444 = true;
+      if (!needs_444 && chroma == 1 && (oh & 1)) needs_444 = true;
     } else return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "image_transform: unknown operation %d", op);
-    if (needs_444) return set_error(HIPDEC_ERR_UNSUPPORTED, "image_transform: the reference converts this image to 4:4:4 first (odd size / offset of a subsampled image)");
+    if (needs_444) return set_error(HIPDEC_ERR_UNSUPPORTED, "image_transform: odd size / offset of a subsampled image (the reference converts to 4:4:4 first or treats the half-covered chroma edge itself): host path");
     const size_t es = in->bit_depth > 8 ? 2 : 1;
     const int sx = (chroma == 1 || chroma == 2) ? 2 : 1, sy = chroma == 1 ? 2 : 1;
     hipStream_t s = stream_acquire();
