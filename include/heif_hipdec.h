@@ -256,6 +256,9 @@ HIPDEC_API int hipdec_color_420_to_rrggbb(const void* y, size_t ys, const void* 
  * (w, h) = luma size; reproduces the reference's border indexing. */
 HIPDEC_API int hipdec_color_bilinear_420_to_444(const void* in, size_t is, int w, int h, int bpp, void* out, size_t os,
                                                 void* stream);
+/* Op_YCbCr422_bilinear_to_YCbCr444<Pixel> (chroma_sampling.cc:732-954), one chroma plane of ((w + 1) / 2) x h samples -> w x h. */
+HIPDEC_API int hipdec_color_bilinear_422_to_444(const void* in, size_t is, int w, int h, int bpp, void* out, size_t os,
+                                                void* stream);
 /* Op_to_sdr_planes (hdr_sdr.cc:146-244): v >> (bits - 8), uint16 -> uint8. */
 HIPDEC_API int hipdec_color_to_sdr(const void* in, size_t is, int w, int h, int bits, void* out, size_t os, void* stream);
 /* Op_YCbCr420_to_RGB32 with a real alpha plane (yuv2rgb.cc:481-562; alpha copied as :552) when integer_op != 0, else the float
@@ -275,7 +278,8 @@ typedef enum hipdec_color_op {   /* the reference operations a plan is made of *
   HIPDEC_OP_420_TO_RGB32 = 4,           /* Op_YCbCr420_to_RGB32              yuv2rgb.cc:481-562 */
   HIPDEC_OP_YCBCR_TO_RGB = 5,           /* Op_YCbCr_to_RGB<Pixel>            yuv2rgb.cc:92-292 */
   HIPDEC_OP_RGB_TO_RGB24_32 = 6,        /* Op_RGB_to_RGB24_32                rgb2rgb.cc:72-150 (fused into the op before it) */
-  HIPDEC_OP_420_TO_RRGGBB = 7           /* Op_YCbCr420_to_RRGGBBaa           yuv2rgb.cc:622-734 */
+  HIPDEC_OP_420_TO_RRGGBB = 7,          /* Op_YCbCr420_to_RRGGBBaa           yuv2rgb.cc:622-734 */
+  HIPDEC_OP_BILINEAR_422_TO_444 = 8     /* Op_YCbCr422_bilinear_to_YCbCr444  chroma_sampling.cc:732-954 */
 } hipdec_color_op;
 
 typedef struct hipdec_color_image {

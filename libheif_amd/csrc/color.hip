@@ -198,6 +198,30 @@ __global__ __launch_bounds__(256) void k_bilinear_420_to_444(const uint8_t* in, 
   for (int i = 0; i < 4 && x0 + i < w; i++) dst[x0 + i] = (Pix)bilinear_at<Pix>(src, iss, w, h, x0 + i, y);
 }
 
+// Op_YCbCr422_bilinear_to_YCbCr444 (libheif/color-conversion/chroma_sampling.cc:732-954) for one chroma plane: out(0) = in(0); for even widths
+// out(w - 1) = in(w / 2 - 1); the pairs (x, x + 1), x odd, between them are (3 a + b + 2) / 4 and (a + 3 b + 2) / 4 of the chroma samples
+// a = in(x / 2), b = in(x / 2 + 1) (:911-927).  Four output samples per lane.
+template <typename Pix>
+__global__ __launch_bounds__(256) void k_bilinear_422_to_444(const uint8_t* in, size_t is, int w, int h, uint8_t* out, size_t os)
+{
+  const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x0 >= w || y >= h) return;
+  const Pix* src = (const Pix*)(in + (size_t)y * is);
+  Pix* dst = (Pix*)(out + (size_t)y * os);
+  for (int i = 0; i < 4 && x0 + i < w; i++) {
+    const int x = x0 + i;
+    int v;
+    if (x == 0) v = src[0];
+    else if (x == w - 1 && (w & 1) == 0) v = src[w / 2 - 1];
+    else {
+      const int cx = (x - 1) >> 1, a = src[cx], b = src[cx + 1];     // x odd: first of the pair, x even: second
+      v = (x & 1) ? (a * 3 + b + 2) / 4 : (a + b * 3 + 2) / 4;
+    }
+    dst[x] = (Pix)v;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_to_sdr(const uint8_t* in, size_t is, int w, int h, int shift, uint8_t* out, size_t os)
 {
   const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -578,6 +602,18 @@ int hipdec_color_bilinear_420_to_444(const void* in, size_t is, int w, int h, in
   dim3 block(64, 4), grid(((w + 3) / 4 + 63) / 64, (h + 3) / 4);
   if (bpp <= 8) hipLaunchKernelGGL(k_bilinear_420_to_444<uint8_t>, grid, block, 0, s, (const uint8_t*)in, is, w, h, (uint8_t*)out, os);
   else hipLaunchKernelGGL(k_bilinear_420_to_444<uint16_t>, grid, block, 0, s, (const uint8_t*)in, is, w, h, (uint8_t*)out, os);
+  HIPDEC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int hipdec_color_bilinear_422_to_444(const void* in, size_t is, int w, int h, int bpp, void* out, size_t os, void* stream)
+{
+  if (int rc = ensure_init()) return rc;
+  if (!in || !out || w <= 0 || h <= 0) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "bilinear 4:2:2: bad arguments");
+  hipStream_t s = stream ? (hipStream_t)stream : default_stream();
+  dim3 block(64, 4), grid(((w + 3) / 4 + 63) / 64, (h + 3) / 4);
+  if (bpp <= 8) hipLaunchKernelGGL(k_bilinear_422_to_444<uint8_t>, grid, block, 0, s, (const uint8_t*)in, is, w, h, (uint8_t*)out, os);
+  else hipLaunchKernelGGL(k_bilinear_422_to_444<uint16_t>, grid, block, 0, s, (const uint8_t*)in, is, w, h, (uint8_t*)out, os);
   HIPDEC_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -936,8 +936,7 @@ int hipdec_color_plan(int bit_depth, int chroma, int has_alpha, const hipdec_ncl
     if (bit_depth > 8) { push(HIPDEC_OP_TO_SDR); bit_depth = 8; }
     if (chroma == 1 && nn_allowed && full && matrix != 0 && matrix != 8) { push(out_chroma == 10 ? HIPDEC_OP_420_TO_RGB24 : HIPDEC_OP_420_TO_RGB32); return 0; }
     if (chroma != 3 && !nn_allowed) {
-      if (chroma != 1) return set_error(HIPDEC_ERR_UNSUPPORTED, "color_plan: bilinear 4:2:2 upsampling is outside the HEIC hot path");
-      push(HIPDEC_OP_BILINEAR_420_TO_444);
+      push(chroma == 1 ? HIPDEC_OP_BILINEAR_420_TO_444 : HIPDEC_OP_BILINEAR_422_TO_444);
     }
     push(HIPDEC_OP_YCBCR_TO_RGB); push(HIPDEC_OP_RGB_TO_RGB24_32);
     return 0;
@@ -1011,6 +1010,17 @@ int hipdec_color_convert(const hipdec_color_image* in, const hipdec_nclx* nclx, 
         const size_t st = ((size_t)w * es + 255) & ~(size_t)255;
         if (int rc = scratch(st * h, &d)) return rc;
         if (int rc = hipdec_color_bilinear_420_to_444(dp[c], ds[c], w, h, bits, d, st, (void*)s)) return rc;
+        g_cb_launches++;
+        dp[c] = d; ds[c] = st;
+      }
+      chroma = 3; k++;
+    }
+    if (k < n_ops && ops[k] == HIPDEC_OP_BILINEAR_422_TO_444) {         // SURVEY 8 f4, on both chroma planes
+      for (int c = 1; c < 3; c++) {
+        uint8_t* d = nullptr;
+        const size_t st = ((size_t)w * es + 255) & ~(size_t)255;
+        if (int rc = scratch(st * h, &d)) return rc;
+        if (int rc = hipdec_color_bilinear_422_to_444(dp[c], ds[c], w, h, bits, d, st, (void*)s)) return rc;
         g_cb_launches++;
         dp[c] = d; ds[c] = st;
       }

@@ -234,6 +234,25 @@ void color_oracle_bilinear_420_to_444(const uint16_t* in, int is, int w, int h, 
     }
 }
 
+/* Op_YCbCr422_bilinear_to_YCbCr444 (libheif/color-conversion/chroma_sampling.cc:732-954), one chroma plane: the left
+   border copies, the right border copies for even widths (:895-906), the inner pairs are 3-1 / 4 (+2) filtered (:911-927); for odd
+   widths the reference's inner loop also writes the last column */
+void color_oracle_bilinear_422_to_444(const uint16_t* in, int is, int w, int h, uint16_t* out, int os)
+{
+  for (int y = 0; y < h; y++) {
+    const uint16_t* s = in + (size_t)y * is;
+    uint16_t* d = out + (size_t)y * os;
+    memset(d, 0, sizeof(uint16_t) * w);
+    d[0] = s[0];
+    if (w % 2 == 0) d[w - 1] = s[w / 2 - 1];
+    for (int x = 1; x < w - 1; x += 2) {
+      const int cx = x / 2;
+      d[x + 0] = (uint16_t)((s[cx] * 3 + s[cx + 1] * 1 + 2) / 4);
+      d[x + 1] = (uint16_t)((s[cx] * 1 + s[cx + 1] * 3 + 2) / 4);
+    }
+  }
+}
+
 /* a14: Op_to_sdr_planes (libheif/color-conversion/hdr_sdr.cc:146-244): v >> (bits-8), no rounding */
 void color_oracle_to_sdr(const uint16_t* in, int is, int w, int h, int bits, uint16_t* out, int os)
 {

@@ -176,6 +176,14 @@ def color_bilinear_420_to_444(plane, w, h):
     return out
 
 
+def color_bilinear_422_to_444(plane, w, h):
+    """Op_YCbCr422_bilinear_to_YCbCr444 for one chroma plane; (w, h) is the luma size."""
+    plane = _u16(plane)
+    out = np.zeros((h, w), np.uint16)
+    lib().color_oracle_bilinear_422_to_444(_p16(plane), plane.shape[1], w, h, _p16(out), w)
+    return out
+
+
 def color_to_sdr(plane, bits):
     plane = _u16(plane)
     h, w = plane.shape

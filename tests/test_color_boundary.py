@@ -22,7 +22,7 @@ import heic_util as hu
 import libheif_host as lh
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-OPS = {1: "to_sdr", 2: "bilinear", 3: "420_to_rgb24", 4: "420_to_rgb32", 5: "ycbcr_to_rgb", 6: "rgb_to_rgb24_32", 7: "420_to_rrggbb"}
+OPS = {1: "to_sdr", 2: "bilinear", 3: "420_to_rgb24", 4: "420_to_rgb32", 5: "ycbcr_to_rgb", 6: "rgb_to_rgb24_32", 7: "420_to_rrggbb", 8: "bilinear_422"}
 
 
 def _plan(bpp, chroma, has_alpha, nclx, out_chroma, ups, only):

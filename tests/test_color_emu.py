@@ -95,6 +95,13 @@ def test_emulated_bilinear_and_sdr(w, h, bpp):
         out = np.zeros((h, w), np.uint8)
         _ok(L, L.hipdec_color_to_sdr(y.ctypes.data, y.strides[0], w, h, bpp, out.ctypes.data, out.strides[0], None))
         np.testing.assert_array_equal(out, orc.color_to_sdr(y, bpp))
+    # Op_YCbCr422_bilinear_to_YCbCr444: a chroma plane of (w + 1) / 2 x h samples
+    L.hipdec_color_bilinear_422_to_444.argtypes = L.hipdec_color_bilinear_420_to_444.argtypes
+    p422 = np.random.default_rng(w * 3 + h).integers(0, 1 << bpp, (h, (w + 1) // 2)).astype(cb.dtype)
+    out = np.full((h, w + 2), 0xEE, cb.dtype)
+    _ok(L, L.hipdec_color_bilinear_422_to_444(p422.ctypes.data, p422.strides[0], w, h, bpp, out.ctypes.data, out.strides[0], None))
+    np.testing.assert_array_equal(out[:, :w], orc.color_bilinear_422_to_444(p422, w, h))
+    assert (out[:, w:] == 0xEE).all()
 
 
 def _pq_reference(code, bits):

@@ -154,3 +154,61 @@ def test_f4_to_hdr_matches_the_compiled_reference_and_swap_pq():
     check(lib.hipdec_color_pq_to_linear(src.ptr, w * 6, w, h, 3, 10, 0, dst.ptr, w * 12, None))
     check(lib.hipdec_stream_synchronize(None))
     np.testing.assert_allclose(dst.to_numpy((h, w * 3), np.float32), _pq_reference(code, 10), rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (65, 49), (34, 13), (2, 3), (1, 2), (1281, 33)])
+@pytest.mark.parametrize("bpp", [8, 10])
+def test_f4_bilinear_422_to_444(w, h, bpp):
+    """Op_YCbCr422_bilinear_to_YCbCr444 (chroma_sampling.cc:732-954) on the device against the restatement (pinned to the compiled reference op
+    in tests/test_color_oracle.py) and, when oracle/_ref is present, against the compiled reference itself"""
+    import ctypes as C
+    import libheif_amd
+    from libheif_amd._capi import DeviceBuffer, check
+    lib = libheif_amd.load_library()
+    vp, sz, ci = C.c_void_p, C.c_size_t, C.c_int
+    lib.hipdec_color_bilinear_422_to_444.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
+    rng = np.random.default_rng(w * 7 + h + bpp)
+    dt = np.uint8 if bpp <= 8 else np.uint16
+    y = rng.integers(0, 1 << bpp, (h, w)).astype(dt)
+    chroma = [np.ascontiguousarray(rng.integers(0, 1 << bpp, (h, (w + 1) // 2)).astype(dt)) for _ in range(2)]
+    got = []
+    for p in chroma:
+        src = DeviceBuffer.from_numpy(p); dst = DeviceBuffer(w * h * p.itemsize)
+        check(lib.hipdec_color_bilinear_422_to_444(src.ptr, p.strides[0], w, h, bpp, dst.ptr, w * p.itemsize, None))
+        check(lib.hipdec_stream_synchronize(None))
+        got.append(dst.to_numpy((h, w), dt))
+        np.testing.assert_array_equal(got[-1], orc.color_bilinear_422_to_444(p, w, h))
+    if ref.available():
+        want = ref.convert([y] + chroma, bpp, ref.CH_422, (1, 13, 6, 1), ref.CS_YCBCR, ref.CH_444, upsampling=ref.UPS_BILINEAR, only_preferred=True)
+        np.testing.assert_array_equal(got[0], want[1])
+        np.testing.assert_array_equal(got[1], want[2])
+
+
+@pytest.mark.parametrize("bpp,nclx", [(8, (1, 13, 6, 1)), (8, (1, 13, 1, 0)), (10, (9, 16, 9, 0))])
+def test_f4_422_input_through_the_c_planner_matches_the_compiled_reference(bpp, nclx):
+    """4:2:2 planes -> interleaved RGB with bilinear upsampling forced: hipdec_color_convert (planner + Op_YCbCr422_bilinear_to_YCbCr444 + the
+    float op + interleave, all on the device) against the compiled reference pipeline on the same planes"""
+    import ctypes as C
+    import libheif_amd
+    from test_transform_gpu import ColorImage
+    if not ref.available():
+        pytest.skip("oracle/_ref not built")
+    lib = libheif_amd.load_library()
+
+    class Nclx(C.Structure):
+        _fields_ = [("has_nclx", C.c_int), ("colour_primaries", C.c_int), ("transfer_characteristics", C.c_int), ("matrix_coefficients", C.c_int), ("full_range_flag", C.c_int)]
+    lib.hipdec_color_convert.argtypes = [C.POINTER(ColorImage), C.POINTER(Nclx), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int]
+    w, h = 130, 46
+    rng = np.random.default_rng(bpp + nclx[2])
+    dt = np.uint8 if bpp <= 8 else np.uint16
+    planes = [np.ascontiguousarray(rng.integers(0, 1 << bpp, s).astype(dt)) for s in ((h, w), (h, w // 2), (h, w // 2))]
+    img = ColorImage(w, h, 2, bpp)
+    for c, p in enumerate(planes):
+        img.plane[c] = p.ctypes.data
+        img.stride[c] = p.strides[0]
+    out = np.zeros((h, w * 3), np.uint8)
+    n = Nclx(1, *nclx)
+    rc = lib.hipdec_color_convert(C.byref(img), C.byref(n), 10, 2, 1, out.ctypes.data, out.strides[0], 0)
+    assert rc == 0
+    want = ref.convert(planes, bpp, ref.CH_422, nclx, ref.CS_RGB, ref.CH_RGB, out_bpp=8, upsampling=ref.UPS_BILINEAR, only_preferred=True)[0]
+    np.testing.assert_array_equal(out, want)

@@ -92,6 +92,24 @@ def test_a13_bilinear_matches_reference(w, h, bpp):
 
 
 @needs_ref
+@pytest.mark.parametrize("w,h", [(64, 48), (65, 49), (34, 13), (2, 3), (1, 2), (3, 1)])
+@pytest.mark.parametrize("bpp", [8, 10])
+def test_f4_bilinear_422_matches_reference(w, h, bpp):
+    """Op_YCbCr422_bilinear_to_YCbCr444 (chroma_sampling.cc:732-954): the compiled reference op against the restatement"""
+    rng = np.random.default_rng(w * 7 + h + bpp)
+    hi = 1 << bpp
+    dt = np.uint8 if bpp <= 8 else np.uint16
+    y = rng.integers(0, hi, (h, w)).astype(dt)
+    cb = rng.integers(0, hi, (h, (w + 1) // 2)).astype(dt)
+    cr = rng.integers(0, hi, (h, (w + 1) // 2)).astype(dt)
+    exp = ref.convert([y, cb, cr], bpp, ref.CH_422, (1, 13, 6, 1), ref.CS_YCBCR, ref.CH_444,
+                      upsampling=ref.UPS_BILINEAR, only_preferred=True)
+    np.testing.assert_array_equal(exp[0], y)
+    np.testing.assert_array_equal(orc.color_bilinear_422_to_444(cb, w, h), exp[1])
+    np.testing.assert_array_equal(orc.color_bilinear_422_to_444(cr, w, h), exp[2])
+
+
+@needs_ref
 def test_a14_to_sdr_then_default_pipeline():
     """10-bit + convert_hdr_to_8bit: Op_to_sdr_planes first, then the 8-bit row."""
     rng = np.random.default_rng(3)
