@@ -95,7 +95,8 @@ HIPDEC_API void hipdec_decoder_set_strict(hipdec_decoder* dec, int strict_decodi
 
 /* push_data2 (heif_plugin.h:160; decoder_libde265.cc:322-368): `data` is a concatenation of
  * [4-byte big-endian length][NAL unit without start code]; parameter sets first.  May be called
- * several times; the bytes are copied. */
+ * several times; the bytes are copied.  A push AFTER a decode starts the next picture (the samples of an intra-only image sequence,
+ * libheif/sequences/track_visual.cc:200-280): the parameter sets seen so far stay active, so later samples may carry slice data only. */
 HIPDEC_API int hipdec_decoder_push_data(hipdec_decoder* dec, const void* data, size_t size);
 
 /* decode_next_image2 (heif_plugin.h:164; decoder_libde265.cc:386-457): parses the headers on the

@@ -558,6 +558,7 @@ int hipdec_probe(const void* data, size_t size, uint64_t max_image_size_pixels, 
 // yet, or when overlapping requests were seen a moment ago.
 struct hipdec_decoder {
   std::vector<uint8_t> data;
+  std::vector<uint8_t> param_sets;       // VPS / SPS / PPS NAL units of the picture decoded last (framed): samples of an image sequence carry them once
   int strict = 0;
   uint64_t max_pixels = 0;
   std::shared_ptr<hipdec_batch> batch;   // shared with the other instances decoded in the same launch
@@ -706,7 +707,6 @@ void hipdec_decoder_set_strict(hipdec_decoder* d, int strict) { if (d) d->strict
 int hipdec_decoder_push_data(hipdec_decoder* d, const void* data, size_t size)
 {
   if (!d || (!data && size)) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "push_data: bad arguments");
-  if (d->decoded) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "push_data after decode (heif_plugin.h:113-115 forbids it)");
   // validate the framing now, as decoder_libde265.cc:322-368 does
   const uint8_t* p = (const uint8_t*)data;
   size_t ptr = 0;
@@ -717,7 +717,20 @@ int hipdec_decoder_push_data(hipdec_decoder* d, const void* data, size_t size)
     if (n > size - ptr) return set_error(HIPDEC_ERR_END_OF_DATA, "NAL size exceeds the pushed data");
     ptr += n;
   }
-  return guarded("push_data", [&]() -> int { d->data.insert(d->data.end(), p, p + size); return 0; });
+  return guarded("push_data", [&]() -> int {
+    if (d->decoded) {
+      // The next sample of an image sequence (libheif/sequences/track_visual.cc:200-280 pushes one sample, polls for its frame, pushes
+      // the next; only a chunk's first sample carries the parameter sets, codecs/decoder.cc:422): the instance is armed again with the
+      // parameter sets it has seen in front of the new sample.  Intra pictures only — a P / B slice is refused loudly by the header parser.
+      d->decoded = false;
+      d->batch.reset();
+      d->data = d->param_sets;
+      std::lock_guard<std::mutex> lock(g_co.mu);
+      if (!d->counted) { d->counted = true; g_co.armed++; }
+    }
+    d->data.insert(d->data.end(), p, p + size);
+    return 0;
+  });
 }
 
 static int decoder_decode_impl(hipdec_decoder* d, hipdec_image_info* info);
@@ -785,6 +798,18 @@ static int decoder_decode_impl(hipdec_decoder* d, hipdec_image_info* info)
   }
   if (req.rc) return set_error(req.rc, "%s", req.err.c_str());
   d->decoded = true;
+  {   // keep the parameter sets for a following sample (nal_unit_type 32 VPS, 33 SPS, 34 PPS; later ones replace earlier ones when parsed)
+    d->param_sets.clear();
+    const uint8_t* p = d->data.data();
+    const size_t size = d->data.size();
+    for (size_t ptr = 0; ptr + 4 <= size;) {
+      const uint32_t n = ((uint32_t)p[ptr] << 24) | ((uint32_t)p[ptr + 1] << 16) | ((uint32_t)p[ptr + 2] << 8) | p[ptr + 3];
+      if (n > size - ptr - 4) break;
+      if (n >= 2) { const int t = (p[ptr + 4] >> 1) & 63; if (t >= 32 && t <= 34) d->param_sets.insert(d->param_sets.end(), p + ptr, p + ptr + 4 + n); }
+      ptr += 4 + (size_t)n;
+    }
+    d->data.clear(); d->data.shrink_to_fit();
+  }
   if (info) *info = d->batch->pics[d->item].info;
   return 0;
 }

@@ -61,6 +61,7 @@ struct PluginDecoder {
   hipdec_decoder* dec = nullptr;
   int strict = 0;
   const void* limits = nullptr;
+  uintptr_t user_data = 0;    // of the push that completed the pending picture
   std::string error_message;  // keeps messages alive beyond the call (decoder_libde265.cc:150-156)
 };
 
@@ -132,9 +133,10 @@ void set_strict_decoding(void* p, int flag)
   d->strict = flag;
   hipdec_decoder_set_strict(d->dec, flag);
 }
-hp_error push_data2(void* p, const void* data, size_t size, uintptr_t)
+hp_error push_data2(void* p, const void* data, size_t size, uintptr_t user_data)
 {
   PluginDecoder* d = (PluginDecoder*)p;
+  d->user_data = user_data;   // handed back with the picture this data decodes to (decoder_libde265.cc:360, :417-419)
   int rc = hipdec_decoder_push_data(d->dec, data, size);
   return rc ? make_error(d, rc) : kOk;
 }
@@ -196,6 +198,7 @@ hp_error decode_next_image2(void* p, hp_image** out_img, uintptr_t* out_user_dat
     g_api.image_set_nclx(img, nclx);
     g_api.nclx_free(nclx);
   }
+  if (out_user_data) *out_user_data = d->user_data;
   *out_img = img;
   return kOk;
 }

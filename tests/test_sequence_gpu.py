@@ -1,0 +1,137 @@
+"""Intra-only image sequences through the decoder boundary (the part that needs no inter prediction): libheif pushes one
+sample per push_data2 with a user_data, polls decode_next_image2 for its frame, pushes the next (sequences/track_visual.cc:200-280,
+codecs/decoder.cc:355-563); only a chunk's first sample carries the parameter sets.  Checked at the C decoder object and at the plugin's own
+function table (the slots libheif calls), every frame against the oracle."""
+import ctypes as C
+import os
+import sys
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from oracle import pyoracle as orc
+import libheif_host as lh
+
+pytestmark = pytest.mark.gpu
+
+
+def _nals(stream):
+    out, p = [], 0
+    while p < len(stream):
+        n = int.from_bytes(stream[p:p + 4], "big")
+        out.append(stream[p:p + 4 + n])
+        p += 4 + n
+    return out
+
+
+def _samples(n, w=200, h=136, **cfg):
+    """n pictures of one configuration: the first sample with parameter sets, the others slice data only; plus the oracle's planes"""
+    streams = [orc.encode(orc.synth_image(w, h, cfg.get("bit_depth", 8), 1, seed=40 + i), **cfg) for i in range(n)]
+    refs = [orc.decode(s) for s in streams]
+    samples = [streams[0]] + [b"".join(x for x in _nals(s) if (x[4] >> 1) & 63 < 32) for s in streams[1:]]
+    assert all(all((x[4] >> 1) & 63 < 32 for x in _nals(s)) for s in samples[1:])
+    return samples, refs
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(wpp=0, stress=1, num_slices=2), dict(bit_depth=10)], ids=["default", "slices", "main10"])
+def test_samples_after_the_first_reuse_the_parameter_sets(cfg):
+    from libheif_amd.decoder import HipDecoder
+    samples, refs = _samples(4, **cfg)
+    d = HipDecoder()
+    for s, ref in zip(samples, refs):
+        d.push_data(s)
+        img = d.decode_next_image()
+        assert img is not None and d.decode_next_image() is None      # one frame per sample, nothing pending behind it
+        for c in range(3):
+            np.testing.assert_array_equal(img.planes[c], ref["planes"][c])
+    # a sample that brings new parameter sets (another picture size) replaces them
+    other = orc.encode(orc.synth_image(64, 72, cfg.get("bit_depth", 8), 1, seed=9), **cfg)
+    d.push_data(other)
+    img = d.decode_next_image()
+    ref = orc.decode(other)
+    assert (img.info["width"], img.info["height"]) == (64, 72)
+    for c in range(3):
+        np.testing.assert_array_equal(img.planes[c], ref["planes"][c])
+    d.free()
+
+
+class HeifError(C.Structure):
+    _fields_ = [("code", C.c_int), ("subcode", C.c_int), ("message", C.c_char_p)]
+
+
+@pytest.mark.skipif(not lh.available(), reason="oracle/_ref/libheif.so not built")
+def test_plugin_function_table_round_trips_user_data_per_sample():
+    """the slots of heif_decoder_plugin as libheif calls them for a track: new_decoder2, then per sample push_data2(user_data) and
+    decode_next_image2(&user_data) (api/libheif/heif_plugin.h:85-169)"""
+    import libheif_amd
+    L = lh.load_hip_plugin()           # libheif in the process (the plugin resolves heif_image_create & co from it) + init_plugin
+    P = C.CDLL(libheif_amd.library_path())
+    vp = C.c_void_p
+
+    class PluginInfo(C.Structure):
+        _fields_ = [("version", C.c_int), ("type", C.c_int), ("plugin", vp)]
+
+    class Plugin(C.Structure):
+        _fields_ = [("plugin_api_version", C.c_int), ("get_plugin_name", vp), ("init_plugin", vp), ("deinit_plugin", vp), ("does_support_format", vp),
+                    ("new_decoder", vp), ("free_decoder", C.CFUNCTYPE(None, vp)), ("push_data", vp), ("decode_image", vp), ("set_strict_decoding", vp),
+                    ("id_name", C.c_char_p), ("decode_next_image", vp), ("minimum_required_libheif_version", C.c_uint32), ("does_support_format2", vp),
+                    ("new_decoder2", C.CFUNCTYPE(HeifError, C.POINTER(vp), vp)),
+                    ("push_data2", C.CFUNCTYPE(HeifError, vp, C.c_char_p, C.c_size_t, C.c_size_t)),
+                    ("flush_data", C.CFUNCTYPE(HeifError, vp)),
+                    ("decode_next_image2", C.CFUNCTYPE(HeifError, vp, C.POINTER(vp), C.POINTER(C.c_size_t), vp))]
+
+    info = PluginInfo.in_dll(P, "plugin_info")
+    plug = C.cast(info.plugin, C.POINTER(Plugin)).contents
+    assert plug.plugin_api_version >= 5
+
+    class Options(C.Structure):   # heif_decoder_plugin_options (heif_plugin.h:70-82)
+        _fields_ = [("format", C.c_int), ("strict_decoding", C.c_int), ("num_threads", C.c_int), ("limits", vp)]
+
+    opts = Options(lh.COMPRESSION_HEVC, 0, 0, None)
+    dec = vp()
+    e = plug.new_decoder2(C.byref(dec), C.cast(C.byref(opts), vp))
+    assert e.code == 0, e.message
+    samples, refs = _samples(3)
+    try:
+        for k, (s, ref) in enumerate(zip(samples, refs)):
+            e = plug.push_data2(dec, s, len(s), 1000 + k)
+            assert e.code == 0, e.message
+            img, ud = vp(), C.c_size_t(12345)
+            e = plug.decode_next_image2(dec, C.byref(img), C.byref(ud), None)
+            assert e.code == 0, e.message
+            assert img.value and ud.value == 1000 + k
+            for c, ch in enumerate((lh.CHANNEL_Y, lh.CHANNEL_CB, lh.CHANNEL_CR)):
+                np.testing.assert_array_equal(lh._plane(L, img, ch), ref["planes"][c])
+            L.heif_image_release(img)
+            img2, ud2 = vp(), C.c_size_t(0)
+            e = plug.decode_next_image2(dec, C.byref(img2), C.byref(ud2), None)   # nothing behind it: Ok with *out == NULL (decoder.cc:538-552)
+            assert e.code == 0 and not img2.value
+        assert plug.flush_data(dec).code == 0
+    finally:
+        plug.free_decoder(dec)
+
+
+def test_inter_slices_are_refused_loudly():
+    """a P slice header (slice_type 1) in place of the I slice: UNSUPPORTED, not a mis-decode"""
+    from libheif_amd.decoder import HipDecoder
+    from libheif_amd import HipDecError
+    s = orc.encode(orc.synth_image(64, 64, 8, 1, seed=3), wpp=0)
+    nals = _nals(s)
+    out = []
+    for x in nals:
+        t = (x[4] >> 1) & 63
+        if t < 32:
+            b = bytearray(x)
+            # slice_segment_header of an IDR: first_slice_segment_in_pic_flag(1) no_output_of_prior_pics_flag(1) slice_pic_parameter_set_id ue(v)=1
+            # then slice_type ue(v): I = 2 -> '011'; P = 1 -> '010'.  bits: 1 x 1 | 011 ... -> flip the last bit of '011'
+            assert (b[6] >> 2) & 7 == 0b011, "unexpected slice header layout"
+            b[6] &= ~(1 << 2) & 0xff
+            x = bytes(b)
+        out.append(x)
+    d = HipDecoder()
+    d.push_data(b"".join(out))
+    with pytest.raises(HipDecError) as e:
+        d.decode_next_image()
+    assert e.value.code == -4
+    d.free()
