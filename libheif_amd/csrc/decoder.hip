@@ -182,6 +182,7 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
   static const uint32_t lanes_from = getenv("HIPDEC_PARSE_LANES_FROM") ? (uint32_t)atoi(getenv("HIPDEC_PARSE_LANES_FROM")) : 0xffffffffu;
   bool lanes = lanes_forced >= 0 ? lanes_forced != 0 : b.num_subs >= lanes_from;
   if (lanes) for (const PicParams& P : b.params) if (P.pcm_enabled) { lanes = false; break; }   // pcm_sample is only in the wave-per-substream parser
+  if (lanes) for (const ParsedPicture& pp : b.pics) if (pp.uses_end_sync) { lanes = false; break; }   // ... and so are dependent slice segments
   if (lanes) launch_parse_lanes(pa, s); else launch_parse(pa, s);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[1], s));
   if (int rc = step("parse")) return rc;

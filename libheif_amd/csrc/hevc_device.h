@@ -106,8 +106,9 @@ struct Substream {
   uint32_t slice_idx;
   int32_t dep_sub;                // substream of the CTB row above when it is a WPP predecessor, else -1
   uint32_t dep_len;               // number of CTBs in dep_sub
-  uint8_t wpp_sync;               // 1: initialise contexts from dep_sub's stored table (top-right available)
-  uint8_t has_dependent;          // 1: another substream waits on this one's progress
+  uint8_t wpp_sync;               // 1: initialise contexts from dep_sub's table stored after its 2nd CTB (WPP, top-right available);
+                                  // 2: from the table (and QpY) stored at dep_sub's END, which must be complete (dependent slice segment)
+  uint8_t has_dependent;          // 1: another substream waits on this one's progress (table stored after the 2nd CTB); 2: ... (stored at the end)
   uint8_t last_in_slice_segment;  // 1: last CTB ends with end_of_slice_segment_flag = 1
   uint8_t pad;
   int32_t dependent;              // the substream whose dep_sub is this one (batch-global index), or -1

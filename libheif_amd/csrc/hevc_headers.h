@@ -54,6 +54,7 @@ struct Pps {
 struct ParsedSlice {
   SliceParams sp{};
   int segment_address = 0;
+  bool dependent = false;  // dependent_slice_segment_flag: header fields (sp) are those of the preceding slice segment, sp.slice_addr_rs = SliceAddrRs
   size_t data_offset = 0;  // offset in the pushed blob of the first slice_segment_data byte
   size_t nal_end = 0;      // offset one past the slice NAL
   std::vector<uint32_t> entry_point_offsets;  // bytes, escaped domain
@@ -63,6 +64,7 @@ struct ParsedPicture {
   Sps sps;
   Pps pps;
   std::vector<ParsedSlice> slices;
+  bool uses_end_sync = false;   // some substream continues the contexts of the end of another (dependent slice segments)
   hipdec_image_info info{};
   std::vector<uint16_t> ts_to_rs;
   std::vector<CtbInfo> ctb_info;    // raster

@@ -518,7 +518,11 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
           sl.segment_address = (int)r.u(ceil_log2(n_ctb));
           if (sl.segment_address >= n_ctb) bad("slice_segment_address out of range");
         }
-        if (dependent) unsupported("dependent slice segments");
+        if (dependent) {   // 7.3.6.1: the remaining header fields are inferred from the preceding slice segment (7.4.7.1)
+          if (out.slices.empty()) bad("dependent slice segment without a preceding slice segment");
+          sl.sp = out.slices.back().sp;
+          sl.dependent = true;
+        } else {
         r.skip(P.num_extra_slice_header_bits);
         unsigned slice_type = r.ue();
         if (slice_type != 2) unsupported("non-intra slice (slice_type " + std::to_string(slice_type) + ")");
@@ -563,6 +567,7 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
         sl.sp.pps_cb_qp_offset = (int8_t)P.cb_qp_offset;
         sl.sp.pps_cr_qp_offset = (int8_t)P.cr_qp_offset;
         sl.sp.slice_addr_rs = (uint16_t)sl.segment_address;
+        }   // !dependent
         if (P.tiles || P.wpp) {
           const int n = r.ue_max((uint32_t)n_ctb, "num_entry_point_offsets");
           if (n > 0) {
@@ -593,8 +598,11 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
     out.slice_params.clear();
     out.scaling_tables.clear();
     if (S.scaling_list_enabled) build_scaling_tables(P.scaling_list_data_present ? P.sl : S.sl, out.scaling_tables);
+    std::vector<int> slice_head(out.slices.size(), 0);   // index of the (independent) slice segment that starts the slice a segment belongs to:
+                                                         // what the kernels compare to tell slices apart (CtbInfo::slice_idx)
     for (size_t si = 0; si < out.slices.size(); si++) {
       const ParsedSlice& sl = out.slices[si];
+      slice_head[si] = sl.dependent && si > 0 ? slice_head[si - 1] : (int)si;
       out.slice_params.push_back(sl.sp);
       int ts0 = tiles.rs_to_ts[sl.segment_address];
       // the slice extends to the next slice's start (in tile scan) or the end of the picture
@@ -616,8 +624,8 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
         for (;;) {
           int rs = tiles.ts_to_rs[t];
           if (ctb_slice[rs] >= 0) bad("a CTB is covered by two slices");
-          ctb_slice[rs] = (int)si;
-          ctb_slice_addr[rs] = sl.segment_address;
+          ctb_slice[rs] = slice_head[si];
+          ctb_slice_addr[rs] = sl.sp.slice_addr_rs;   // SliceAddrRs: dependent slice segments belong to the slice of the segment they continue
           t++;
           if (t >= ts_end) break;
           int nrs = tiles.ts_to_rs[t];
@@ -634,6 +642,24 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
         } else {
           sub.byte_end = (uint32_t)sl.nal_end;
           sub.last_in_slice_segment = 1;
+        }
+        if (sl.dependent && ts == ts0) {
+          // 9.3.1 / 9.3.2.4: the first CTB of a dependent slice segment continues the context variables (and qPY_PREV, 8.6.1) of the END of the
+          // preceding slice segment, unless it starts a tile (initialisation) or a CTB row under WPP (the WPP rules apply, linked below)
+          const int rs0 = tiles.ts_to_rs[ts0];
+          const bool tile_first = ts0 == 0 || tiles.tile_id_rs[rs0] != tiles.tile_id_rs[tiles.ts_to_rs[ts0 - 1]];
+          const bool row_first = P.wpp && (rs0 % ctb_w == 0 || tiles.tile_id_rs[rs0] != tiles.tile_id_rs[rs0 - 1]);
+          if (!tile_first && !row_first) {
+            if (P.wpp) unsupported("dependent slice segment that starts inside a CTB row with entropy_coding_sync enabled");
+            if (out.subs.empty()) bad("dependent slice segment without a preceding substream");
+            Substream& prev = out.subs.back();
+            if ((int)(prev.first_ctb_ts + prev.num_ctbs) != ts0) bad("dependent slice segment does not continue the preceding slice segment");
+            sub.dep_sub = (int32_t)out.subs.size() - 1;
+            sub.dep_len = prev.num_ctbs;
+            sub.wpp_sync = 2;          // synchronise with the tables stored at the end of dep_sub
+            prev.has_dependent = 2;    // ... which stores them there
+            out.uses_end_sync = true;
+          }
         }
         out.subs.push_back(sub);
         ts = t;

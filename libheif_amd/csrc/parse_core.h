@@ -962,7 +962,9 @@ PC_DEV void pool_wake_dependent(const ParseArgs& A, int32_t dependent, uint32_t 
 }
 
 // suspended-row state -> HBM (write-through, drained): six lane-indexed registers + one row of scalars
-PC_DEV void save_row_state(PS& s, const ParseArgs& A, uint32_t sub_idx, uint32_t* saved, uint32_t k)
+// resume_word: where the CTB index to resume at goes (a suspended row), or nullptr (the END state of a finished substream, which the first
+// substream of a dependent slice segment continues: contexts, left-neighbour maps, SAO parameters, QP state)
+PC_DEV void save_row_state(PS& s, uint32_t* resume_word, uint32_t* saved, uint32_t k)
 {
   VReg sc;
   PC_VEC_BEGIN
@@ -975,7 +977,7 @@ PC_DEV void save_row_state(PS& s, const ParseArgs& A, uint32_t sub_idx, uint32_t
     pc_store_wt(saved + lane, PC_L(s.ctxA)); pc_store_wt(saved + 64 + lane, PC_L(s.ctxB)); pc_store_wt(saved + 128 + lane, PC_L(s.ctxC));
     pc_store_wt(saved + 192 + lane, PC_L(s.p_size)); pc_store_wt(saved + 256 + lane, PC_L(s.p_ipm)); pc_store_wt(saved + 320 + lane, PC_L(s.sao_left));
     pc_store_wt(saved + 384 + lane, PC_L(sc));
-    if (lane == 0) pc_store_wt(A.resume_k + sub_idx, k);
+    if (lane == 0 && resume_word) pc_store_wt(resume_word, k);
   PC_VEC_END
   pc_drain();
 }
@@ -1064,7 +1066,7 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
 
   for (uint32_t k = k0; k < num_ctbs && !s.err; k++) {
     if (pool && A.yield_ctbs && k > k0 && (k - k0) % A.yield_ctbs == 0) {   // test knob: forced yield every N CTBs
-      save_row_state(s, A, sub_idx, saved, k);
+      save_row_state(s, A.resume_k + sub_idx, saved, k);
       pool_push(A, sub_idx);
       return PARSE_SUSPENDED;
     }
@@ -1081,13 +1083,13 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
       // tables are those stored after the second CTB above).  The top-right CTB is an intra-PREDICTION dependency — that is the
       // reconstruction kernel's wavefront, not the parser's.  (A larger start distance decouples the rows in static mode.)
       uint32_t need = k == 0 ? start_lag : k + 1;
-      if (need > dep_len) need = dep_len;
+      if (need > dep_len || wpp_sync == 2) need = dep_len;   // (a dependent slice segment continues the END of its predecessor: all of it)
       if (!pool) {
         const int e = pc_wait_progress(A.progress + dep_sub, need, A.status);
         if (e) { s.err = e; break; }
       } else if (pc_load_wt_uni(A.progress + dep_sub) < need) {
         // suspend: save the row's state, record what it waits for (with two CTBs of hysteresis), re-check
-        if (k > 0) save_row_state(s, A, sub_idx, saved, k);
+        if (k > 0) save_row_state(s, A.resume_k + sub_idx, saved, k);
         uint32_t wake = need + A.wake_hyst;
         if (wake > dep_len) wake = dep_len;
         if (!pool_arm(A, sub_idx, (uint32_t)dep_sub, wake)) return PARSE_SUSPENDED;
@@ -1095,7 +1097,19 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
     }
     // ---- context initialisation / synchronisation (9.3.1) ----
     if (k == 0) {
-      if (wpp_sync && dep_sub >= 0) {
+      if (wpp_sync == 2 && dep_sub >= 0) {
+        // first CTB of a dependent slice segment (9.3.1, 9.3.2.4): everything but the arithmetic decoder continues where the preceding slice
+        // segment ended — context variables, the CTB to the left (same slice: available), its SAO parameters, qPY_PREV (8.6.1)
+        const uint32_t* src = A.saved + (size_t)dep_sub * SAVE_DWORDS;
+        VReg sc;
+        PC_VEC_BEGIN
+          PC_L(s.ctxA) = pc_load_wt(src + lane); PC_L(s.ctxB) = pc_load_wt(src + 64 + lane); PC_L(s.ctxC) = pc_load_wt(src + 128 + lane);
+          PC_L(s.p_size) = pc_load_wt(src + 192 + lane); PC_L(s.p_ipm) = pc_load_wt(src + 256 + lane); PC_L(s.sao_left) = pc_load_wt(src + 320 + lane);
+          PC_L(sc) = pc_load_wt(src + 384 + lane);
+        PC_VEC_END
+        s.last_qp_y = (int32_t)pc_rdlane(sc, 6); s.qpy_pred = (int32_t)pc_rdlane(sc, 7); s.cur_qp_y = (int32_t)pc_rdlane(sc, 8);
+        s.is_cu_qp_delta_coded = (int32_t)pc_rdlane(sc, 9); s.cu_qp_delta_val = (int32_t)pc_rdlane(sc, 10);
+      } else if (wpp_sync && dep_sub >= 0) {
         const uint32_t* src = (const uint32_t*)(A.ctx_store + (size_t)dep_sub * CTX_STORE);
         PC_VEC_BEGIN
           PC_L(s.ctxA) = pc_load_wt(src + lane); PC_L(s.ctxB) = pc_load_wt(src + 64 + lane); PC_L(s.ctxC) = pc_load_wt(src + 128 + lane);
@@ -1111,7 +1125,7 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
     }
     // ---- coding_tree_unit ----
     if (s.sao_luma || s.sao_chroma) {
-      parse_sao(s, (s.ctb_avail & AV_LEFT) && k > 0, (s.ctb_avail & AV_UP) ? 1 : 0);
+      parse_sao(s, (s.ctb_avail & AV_LEFT) && (k > 0 || wpp_sync == 2), (s.ctb_avail & AV_UP) ? 1 : 0);
     } else {
       PC_VEC_BEGIN PC_L(s.sao) = 0u; PC_VEC_END
     }
@@ -1199,7 +1213,8 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
           if (lane < 13) pc_store_wt(dst + lane, PC_L(rec));
         PC_VEC_END
       }
-      if (has_dependent && k == 1) {
+      if (has_dependent == 2 && k + 1 == num_ctbs) save_row_state(s, nullptr, saved, num_ctbs);   // (the registers already hold this CTB as "the previous one")
+      if (has_dependent == 1 && k == 1) {
         uint32_t* dst = (uint32_t*)(A.ctx_store + (size_t)sub_idx * CTX_STORE);
         PC_VEC_BEGIN
           pc_store_wt(dst + lane, PC_L(s.ctxA)); pc_store_wt(dst + 64 + lane, PC_L(s.ctxB)); pc_store_wt(dst + 128 + lane, PC_L(s.ctxC));
@@ -1237,7 +1252,7 @@ PC_DEV void parse_wave(const ParseArgs& A, uint32_t wave_idx, Lds* lds)
       else {
         uint32_t need = 2u;
         const uint32_t dep_len = uload32(&A.subs[s0].dep_len);
-        if (need > dep_len) need = dep_len;
+        if (need > dep_len || (uload32(&A.subs[s0].wpp_sync) & 255u) == 2u) need = dep_len;
         if (pool_arm(A, s0, (uint32_t)dep, need)) pool_push(A, s0);
       }
     }

@@ -1032,7 +1032,8 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
   put_nal(&stream, 33, w.p, w.nbits >> 3);
   bw_free(&w);
   /* PPS 7.3.2.3 */
-  bw_ue(&w, 0); bw_ue(&w, 0); bw_u(&w, 0, 1); bw_u(&w, 0, 1); bw_u(&w, 0, 3);
+  p->dependent_slice_segments_enabled_flag = prm->dependent_segments > 1;
+  bw_ue(&w, 0); bw_ue(&w, 0); bw_u(&w, p->dependent_slice_segments_enabled_flag, 1); bw_u(&w, 0, 1); bw_u(&w, 0, 3);
   bw_u(&w, p->sign_data_hiding_enabled_flag, 1); bw_u(&w, 0, 1); bw_ue(&w, 0); bw_ue(&w, 0);
   bw_se(&w, p->init_qp_minus26); bw_u(&w, 0, 1); bw_u(&w, p->transform_skip_enabled_flag, 1);
   bw_u(&w, p->cu_qp_delta_enabled_flag, 1);
@@ -1065,6 +1066,7 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
       for (int x = 0; x < W; x++) src[c][y * W + x] = planes[c][(size_t)Min(y, sh_ - 1) * sw + Min(x, sw - 1)];
     e->src[c] = src[c];
   }
+  uint8_t* seg_dependent = NULL;   /* per slice segment: 1 = dependent slice segment */
   /* slices: boundaries in tile-scan CTB addresses */
   int nsl = Max(1, prm->num_slices);
   int* slice_start = (int*)xcalloc(d, nsl + 1, sizeof(int));
@@ -1088,9 +1090,32 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
     }
     nsl = cnt; slice_start[nsl] = d->nCtb;
   }
+  /* slice segments: every slice in dependent_segments parts; all but a slice's first are dependent slice segments (7.3.6.1).  With WPP the
+     parts start at CTB row starts; with tiles the slices (complete tiles) are not split any further */
+  if (prm->dependent_segments > 1 && !p->tiles_enabled_flag) {
+    int* seg = (int*)xcalloc(d, (size_t)nsl * prm->dependent_segments + 2, sizeof(int));
+    uint8_t* dep = (uint8_t*)xcalloc(d, (size_t)nsl * prm->dependent_segments + 2, 1);
+    int cnt = 0;
+    for (int si = 0; si < nsl; si++) {
+      const int a0 = slice_start[si], a1 = slice_start[si + 1];
+      for (int k = 0; k < prm->dependent_segments; k++) {
+        int a = a0 + (int)(((int64_t)k * (a1 - a0)) / prm->dependent_segments);
+        if (p->entropy_coding_sync_enabled_flag) a = a / d->ctbW * d->ctbW;
+        if (a < a0) a = a0;
+        if (cnt && a <= seg[cnt - 1]) continue;
+        seg[cnt] = a; dep[cnt] = k > 0; cnt++;
+      }
+    }
+    seg[cnt] = d->nCtb;
+    free(slice_start);
+    slice_start = seg; seg_dependent = dep; nsl = cnt;
+  }
   int CtbSizeY = 1 << s->log2_ctb;
+  SliceHdr cur_hdr; memset(&cur_hdr, 0, sizeof(cur_hdr));
   for (int si = 0; si < nsl; si++) {
+    const int is_dep = seg_dependent ? seg_dependent[si] : 0;
     SliceHdr hdr; memset(&hdr, 0, sizeof(hdr));
+    if (is_dep) goto segment_data;   /* a dependent slice segment continues the slice: its header fields are those of cur_hdr */
     hdr.first_slice_segment_in_pic_flag = si == 0;
     hdr.slice_segment_address = d->CtbAddrTsToRs[slice_start[si]];
     hdr.slice_type = 2;
@@ -1108,6 +1133,11 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
     hdr.SliceQpY = 26 + p->init_qp_minus26 + hdr.slice_qp_delta;
     if (d->nslices == d->capslices) { d->capslices = d->capslices ? d->capslices * 2 : 8; d->slices = (SliceHdr*)realloc(d->slices, sizeof(SliceHdr) * d->capslices); }
     d->slices[d->nslices] = hdr; d->sh = &d->slices[d->nslices]; d->sh_idx = d->nslices; d->nslices++;
+    cur_hdr = hdr;
+  segment_data:
+    if (is_dep) { hdr = cur_hdr; hdr.first_slice_segment_in_pic_flag = 0; hdr.slice_segment_address = d->CtbAddrTsToRs[slice_start[si]]; d->sh = &d->slices[d->nslices - 1]; }
+    const int lf_present = p->pps_loop_filter_across_slices_enabled_flag &&
+                           (hdr.slice_sao_luma_flag || hdr.slice_sao_chroma_flag || !hdr.slice_deblocking_filter_disabled_flag);
 
     /* substreams */
     Bytes subs = {0, 0, 0};
@@ -1126,7 +1156,9 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
         row_first = (d->CtbAddrInRs % d->ctbW == 0) || d->TileId[d->CtbAddrInTs] != d->TileId[d->CtbAddrRsToTs[d->CtbAddrInRs - 1]];
       d->ctb_slice_addr[d->CtbAddrInRs] = d->sh->SliceAddrRs;
       d->ctb_slice_idx[d->CtbAddrInRs] = d->sh_idx;
-      if (first_ctb_in_segment || tile_first || row_first) {
+      if (first_ctb_in_segment && is_dep && !tile_first && !row_first) {
+        first_ctb_in_segment = 0;   /* 9.3.1: the contexts (and qPY_PREV, 8.6.1) continue from the end of the previous slice segment */
+      } else if (first_ctb_in_segment || tile_first || row_first) {
         /* the encoder keeps its own context array (e->ctx); derive via the decoder's initialiser */
         if (tile_first || !row_first) { cabac_init_contexts(d); memcpy(e->ctx, d->c.ctx, MAXCTX); }
         else {
@@ -1183,11 +1215,16 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
     bw_u(&w, hdr.first_slice_segment_in_pic_flag, 1);
     bw_u(&w, 0, 1); /* no_output_of_prior_pics_flag (IDR) */
     bw_ue(&w, 0);
-    if (!hdr.first_slice_segment_in_pic_flag) bw_u(&w, hdr.slice_segment_address, ceil_log2(d->nCtb));
-    bw_ue(&w, 2);
-    if (s->sao_enabled_flag) { bw_u(&w, hdr.slice_sao_luma_flag, 1); if (s->chroma_format_idc) bw_u(&w, hdr.slice_sao_chroma_flag, 1); }
-    bw_se(&w, hdr.slice_qp_delta);
-    if (lf_flag_present) bw_u(&w, hdr.slice_loop_filter_across_slices_enabled_flag, 1);
+    if (!hdr.first_slice_segment_in_pic_flag) {
+      if (p->dependent_slice_segments_enabled_flag) bw_u(&w, is_dep, 1);
+      bw_u(&w, hdr.slice_segment_address, ceil_log2(d->nCtb));
+    }
+    if (!is_dep) {
+      bw_ue(&w, 2);
+      if (s->sao_enabled_flag) { bw_u(&w, hdr.slice_sao_luma_flag, 1); if (s->chroma_format_idc) bw_u(&w, hdr.slice_sao_chroma_flag, 1); }
+      bw_se(&w, hdr.slice_qp_delta);
+      if (lf_present) bw_u(&w, hdr.slice_loop_filter_across_slices_enabled_flag, 1);
+    }
     if (p->tiles_enabled_flag || p->entropy_coding_sync_enabled_flag) {
       bw_ue(&w, nsub - 1);
       if (nsub > 1) {
@@ -1209,7 +1246,7 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
     by_push(&stream, nal.p, nal.n);
     bw_free(&w); free(nal.p); free(esc.p); free(esz); free(subs.p); free(sizes);
   }
-  free(slice_start);
+  free(slice_start); free(seg_dependent);
   for (int c = 0; c < 3; c++) free(src[c]);
   free(e->ev); free(e->pcm_blob);
   free_dec(d);

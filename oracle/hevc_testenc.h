@@ -25,6 +25,7 @@ typedef struct hevc_testenc_params {
   uint32_t seed;
   int stress;                   /* 1: random splits / modes (syntax coverage); 0: SAD-driven       */
   int zero_residual_pct;        /* % of transform blocks forced to cbf = 0                         */
+  int dependent_segments;       /* > 1: every slice is split into that many slice segments, all but its first dependent */
 } hevc_testenc_params;
 
 /* planes: tightly packed uint16 samples at display size (chroma (w+1)/2 x (h+1)/2).

@@ -203,7 +203,7 @@ class _EncParams(C.Structure):
         "diff_cu_qp_delta_depth", "transform_skip", "lossless_pct", "pcm_pct", "pcm_loop_filter_disabled",
         "strong_intra_smoothing", "scaling_list", "cb_qp_offset", "cr_qp_offset", "loop_filter_across_tiles",
         "loop_filter_across_slices", "vui_primaries", "vui_transfer", "vui_matrix", "vui_full_range")] + \
-        [("seed", C.c_uint32), ("stress", C.c_int), ("zero_residual_pct", C.c_int)]
+        [("seed", C.c_uint32), ("stress", C.c_int), ("zero_residual_pct", C.c_int), ("dependent_segments", C.c_int)]
 
 
 ENC_DEFAULTS = dict(bit_depth=8, chroma_format_idc=1, log2_ctb=6, log2_min_cb=3, log2_min_tb=2, log2_max_tb=5,
@@ -212,7 +212,7 @@ ENC_DEFAULTS = dict(bit_depth=8, chroma_format_idc=1, log2_ctb=6, log2_min_cb=3,
                     diff_cu_qp_delta_depth=1, transform_skip=0, lossless_pct=0, pcm_pct=0, pcm_loop_filter_disabled=0,
                     strong_intra_smoothing=1, scaling_list=0, cb_qp_offset=0, cr_qp_offset=0, loop_filter_across_tiles=1,
                     loop_filter_across_slices=1, vui_primaries=1, vui_transfer=13, vui_matrix=-1, vui_full_range=0,
-                    seed=1, stress=0, zero_residual_pct=0)
+                    seed=1, stress=0, zero_residual_pct=0, dependent_segments=0)
 
 
 def synth_image(width, height, bit_depth=8, chroma_format_idc=1, seed=1):

@@ -31,6 +31,9 @@ CONFIGS = [
     dict(pcm_pct=25),
     dict(pcm_pct=30, pcm_loop_filter_disabled=1, stress=1, bit_depth=10),
     dict(pcm_pct=40, log2_ctb=5, log2_max_tb=4, wpp=0, lossless_pct=20),
+    dict(dependent_segments=3, wpp=0, stress=1),
+    dict(dependent_segments=4, num_slices=2, wpp=0, log2_ctb=4, log2_max_tb=4, loop_filter_across_slices=0),
+    dict(dependent_segments=3, wpp=1),
 ]
 
 

@@ -101,6 +101,8 @@ CONFIGS = [
     dict(cb_qp_offset=3, cr_qp_offset=-4, beta_offset_div2=2, tc_offset_div2=-2, qp=34),
     dict(qp=12, stress=1, zero_residual_pct=30),
     dict(sign_data_hiding=0, cu_qp_delta=0, strong_intra_smoothing=0),
+    dict(dependent_segments=3, wpp=0, stress=1),
+    dict(dependent_segments=2, num_slices=2, wpp=1),
 ]
 
 
@@ -122,6 +124,24 @@ def test_lossless_round_trip_is_exact_before_loop_filters():
     in-loop filters must leave bypass samples untouched (8.7.2 / 8.7.3 pcm/bypass rules)."""
     planes = orc.synth_image(136, 72, 8, 1, seed=9)
     r = orc.decode(orc.encode(planes, lossless_pct=100, sao=1))
+    for c in range(3):
+        np.testing.assert_array_equal(r["planes"][c], planes[c])
+
+
+@pytest.mark.parametrize("cfg", [dict(dependent_segments=3, wpp=0), dict(dependent_segments=5, wpp=0, log2_ctb=4, log2_max_tb=4, stress=1),
+                                 dict(dependent_segments=3, wpp=1), dict(dependent_segments=4, num_slices=2, wpp=0, stress=1)],
+                         ids=lambda c: ",".join("%s=%s" % kv for kv in c.items()))
+def test_dependent_slice_segments_round_trip_exactly_when_lossless(cfg):
+    """the generator's dependent slice segments (contexts, qPY_PREV and availability continue across segment boundaries, 9.3.1 / 8.6.1 /
+    6.4.1) against the oracle's reading of the same clauses: with every CU lossless the decoded picture IS the source"""
+    planes = orc.synth_image(200, 136, 8, 1, seed=13)
+    stream = orc.encode(planes, lossless_pct=100, **cfg)
+    nals = []
+    p = 0
+    while p < len(stream):
+        n = int.from_bytes(stream[p:p + 4], "big"); nals.append(stream[p + 4:p + 4 + n]); p += 4 + n
+    assert sum(1 for x in nals if (x[0] >> 1) & 63 < 32) >= 3          # really several slice segment NAL units
+    r = orc.decode(stream)
     for c in range(3):
         np.testing.assert_array_equal(r["planes"][c], planes[c])
 

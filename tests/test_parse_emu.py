@@ -104,6 +104,9 @@ CONFIGS = [
     dict(pcm_pct=20),
     dict(pcm_pct=30, pcm_loop_filter_disabled=1, bit_depth=10, stress=1),
     dict(pcm_pct=40, wpp=0, log2_ctb=5, log2_max_tb=5, lossless_pct=20),
+    dict(dependent_segments=3, wpp=0),                                        # dependent slice segments: contexts / QP / left neighbour continue
+    dict(dependent_segments=4, wpp=0, num_slices=2, stress=1, log2_ctb=4, log2_max_tb=4),
+    dict(dependent_segments=3, wpp=1, stress=1),                              # ... starting at CTB row starts under WPP
 ]
 
 
@@ -210,7 +213,7 @@ def test_byte_reader_skips_emulation_prevention_across_windows_and_resumes(seed)
 
 
 # ---- the lane-per-substream parser (libheif_amd/csrc/parse_lanes_kernel.hip) under the SIMT shim ------------------------------------
-@pytest.mark.parametrize("cfg", [c for c in CONFIGS if "pcm_pct" not in c],   # (pcm_sample is only in the wave-per-substream parser; the product never
+@pytest.mark.parametrize("cfg", [c for c in CONFIGS if "pcm_pct" not in c and ("dependent_segments" not in c or c.get("wpp", 1))],   # (pcm_sample is only in the wave-per-substream parser; the product never
                          ids=lambda c: ",".join("%s=%s" % kv for kv in c.items()) or "default")   #  hands a PCM stream to the lane parser)
 @pytest.mark.parametrize("size", [(200, 136), (64, 64), (328, 72)])
 def test_lane_parser_emulation_matches_oracle(cfg, size):

@@ -78,6 +78,8 @@ CONFIGS = [
     dict(pcm_pct=30, pcm_loop_filter_disabled=1, stress=1),               # ... and left untouched by deblocking / SAO
     dict(pcm_pct=25, bit_depth=10, lossless_pct=20),                      # PcmBitDepth below BitDepth (shifted samples), beside lossless CUs
     dict(pcm_pct=40, log2_ctb=5, log2_max_tb=4, wpp=0),                   # 32x32 PCM units above the maximum transform size
+    dict(dependent_segments=3, wpp=0, stress=1),                          # dependent slice segments: no slice boundary for prediction / filters inside the slice
+    dict(dependent_segments=2, num_slices=2, wpp=0, loop_filter_across_slices=0, log2_ctb=4, log2_max_tb=4),
 ]
 
 
