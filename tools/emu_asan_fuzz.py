@@ -23,7 +23,7 @@ def run(s):
     return 'status 0x%x'%(st&0xffffffff)
 rng=random.Random(int(sys.argv[1]))
 n=int(sys.argv[2])
-cfgs=[dict(scaling_list=2, stress=1), dict(scaling_list=3), dict(), dict(stress=1, num_slices=2), dict(log2_ctb=4,log2_min_cb=3,log2_max_tb=4,stress=1), dict(bit_depth=10), dict(wpp=0, transform_skip=1, lossless_pct=10), dict(pcm_pct=30, stress=1), dict(pcm_pct=25, pcm_loop_filter_disabled=1, bit_depth=10)]
+cfgs=[dict(scaling_list=2, stress=1), dict(scaling_list=3), dict(), dict(stress=1, num_slices=2), dict(log2_ctb=4,log2_min_cb=3,log2_max_tb=4,stress=1), dict(bit_depth=10), dict(wpp=0, transform_skip=1, lossless_pct=10), dict(pcm_pct=30, stress=1), dict(pcm_pct=25, pcm_loop_filter_disabled=1, bit_depth=10), dict(dependent_segments=3, wpp=0, stress=1), dict(dependent_segments=2, num_slices=2, wpp=1)]
 base=[orc.encode(orc.synth_image(136,72,c.get('bit_depth',8),1,seed=3+i),**c) for i,c in enumerate(cfgs)]
 print('clean:', [run(s) for s in base]); sys.stdout.flush()
 res={}
