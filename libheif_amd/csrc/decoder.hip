@@ -198,8 +198,13 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
   HIPDEC_CHECK_HIP(hipEventRecord(ev[4], ps));
   if (int rc = step("deblock")) return rc;
   if (!parse_only) {
-    if (fused_rgb_params) launch_sao_rgb(fa, fused_rgb_params, n, b.max_ow, b.max_oh, ps);   // SAO + crop + RGB24 in one pass
-    else launch_sao(fa, n, b.max_ow, b.max_oh, b.wide, ps);
+    bool may_keep = false, restricted = false;
+    for (const PicParams& P : b.params) {
+      if (P.transquant_bypass_enabled || (P.pcm_enabled && P.pcm_loop_filter_disabled)) may_keep = true;
+      if (!P.sao_free_neighbours) restricted = true;
+    }
+    if (fused_rgb_params) launch_sao_rgb(fa, fused_rgb_params, n, b.max_ow, b.max_oh, ps, may_keep, restricted);   // SAO + crop + RGB24 in one pass
+    else launch_sao(fa, n, b.max_ow, b.max_oh, b.wide, ps, may_keep, restricted);
   }
   HIPDEC_CHECK_HIP(hipEventRecord(ev[5], ps));
   if (int rc = step("sao")) return rc;

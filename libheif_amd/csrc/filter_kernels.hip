@@ -203,10 +203,9 @@ struct SaoComp {
   const CtbInfo* ctb_info;
   const SliceParams* slices;
   bool check_bypass, lf_across_tiles, free_nb;
-  uint8_t keep_mask;
 };
 template <typename Pix>
-__device__ __forceinline__ SaoComp<Pix> sao_comp(const FilterArgs& A, const PicParams& P, int c)
+__device__ __forceinline__ SaoComp<Pix> sao_comp(const FilterArgs& A, const PicParams& P, int c, bool may_keep, bool restricted)
 {
   SaoComp<Pix> S;
   S.P = &P; S.c = c; S.sub = c ? 2 : 1;
@@ -221,10 +220,13 @@ __device__ __forceinline__ SaoComp<Pix> sao_comp(const FilterArgs& A, const PicP
   S.slices = (const SliceParams*)(A.arena + P.off_slices);
   S.lctb = P.log2_ctb - (c ? 1 : 0);   // log2 CTB size in component samples
   S.crop_xc = P.crop_x / S.sub; S.crop_yc = P.crop_y / S.sub; S.ctb_w = P.ctb_w;
-  S.check_bypass = P.transquant_bypass_enabled != 0 || (P.pcm_enabled && P.pcm_loop_filter_disabled);
-  S.keep_mask = (uint8_t)(UF_BYPASS | (P.pcm_loop_filter_disabled ? UF_PCM : 0));   // 8.7.3: SAO leaves these units' samples unchanged
+  // may_keep: compile-time false in the kernel variant for batches without lossless CUs / unfiltered PCM (the common case): the per-sample
+  // unit look-ups and the paths behind them leave the kernel, which is larger than the instruction cache
+  S.check_bypass = may_keep && (P.transquant_bypass_enabled != 0 || (P.pcm_enabled && P.pcm_loop_filter_disabled));
   S.lf_across_tiles = P.lf_across_tiles != 0;
-  S.free_nb = P.sao_free_neighbours != 0;
+  // restricted: compile-time false in the variant for batches whose pictures all have sao_free_neighbours (one slice or filtering across slices
+  // / tiles allowed): the per-neighbour slice / tile checks leave the kernel
+  S.free_nb = restricted ? P.sao_free_neighbours != 0 : true;
   return S;
 }
 // the SAO parameters (three dwords) of the CTB that holds output sample (ox, oy) — requested before the tile loads so that they travel with them
@@ -316,8 +318,12 @@ __device__ __forceinline__ int sao_quad(const SaoComp<Pix>& S, const uint32_t* t
     if (!one_ctb) { const uint32_t* q = (const uint32_t*)&S.sao[(size_t)ctb * 3 + c]; sp = sao_unpack(q[0], q[1], q[2]); }
     if (sp.type) {
       int ctb_dummy;
-      const uint8_t fl = S.check_bypass ? S.u_flags[unit_index(*S.P, (x * sub) >> 2, (y * sub) >> 2, &ctb_dummy)] : (uint8_t)0;
-      if (!(fl & S.keep_mask)) {
+      bool keep = false;   // 8.7.3: samples of cu_transquant_bypass units, and of PCM units with pcm_loop_filter_disabled_flag, stay as they are
+      if (S.check_bypass) {
+        const uint8_t fl = S.u_flags[unit_index(*S.P, (x * sub) >> 2, (y * sub) >> 2, &ctb_dummy)];
+        keep = (fl & (UF_BYPASS | (S.P->pcm_loop_filter_disabled ? UF_PCM : 0))) != 0;
+      }
+      if (!keep) {
         if (sp.type == 1) {
           const int k = ((v >> (bit_depth - 5)) - sp.cls) & 31;
           if (k < 4) v = clip3(0, maxv, v + sao_off(sp, k));
@@ -366,7 +372,7 @@ __device__ __forceinline__ void sao_store(const SaoComp<Pix>& S, int ox0, int oy
   }
 }
 
-template <typename Pix>
+template <typename Pix, bool MAY_KEEP, bool RESTRICTED>
 __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
 {
   constexpr int ES = (int)sizeof(Pix);
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
   const PicParams& P = A.pics[blockIdx.y];
   const int c = blockIdx.z;
   if (c > 0 && !P.chroma_format_idc) return;
-  const SaoComp<Pix> S = sao_comp<Pix>(A, P, c);
+  const SaoComp<Pix> S = sao_comp<Pix>(A, P, c, MAY_KEEP, RESTRICTED);
   const int tiles_x = (S.ow + SAO_TW - 1) / SAO_TW, tiles_y = (S.oh + SAO_TH - 1) / SAO_TH;
   if ((int)blockIdx.x >= tiles_x * tiles_y) return;
   const int ox_t = ((int)blockIdx.x % tiles_x) * SAO_TW, oy_t = ((int)blockIdx.x / tiles_x) * SAO_TH;
@@ -401,6 +407,7 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
 // plugin ABI hands those to libheif — and emits the tile's interleaved RGB24 from registers + LDS.  Against k_sao + k_ycbcr_to_rgb_batch
 // this saves the colour pass's 1.5 B/px re-read of the planes and one launch.  Same arithmetic: colordev::convert_px.
 constexpr int SAO_CW = SAO_TW / 2, SAO_CH = SAO_TH / 2;
+template <bool MAY_KEEP, bool RESTRICTED>
 __global__ __launch_bounds__(256) void k_sao_rgb(FilterArgs A, const colordev::ColorParams* __restrict__ cps)
 {
   typedef uint8_t Pix;
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(256) void k_sao_rgb(FilterArgs A, const colordev::C
   __shared__ uint8_t chroma_s[2][SAO_CH][SAO_CW];
   if (*A.status != 0) return;
   const PicParams& P = A.pics[blockIdx.y];
-  const SaoComp<Pix> SY = sao_comp<Pix>(A, P, 0);
+  const SaoComp<Pix> SY = sao_comp<Pix>(A, P, 0, MAY_KEEP, RESTRICTED);
   const int tiles_x = (SY.ow + SAO_TW - 1) / SAO_TW, tiles_y = (SY.oh + SAO_TH - 1) / SAO_TH;
   if ((int)blockIdx.x >= tiles_x * tiles_y) return;
   const int ox_t = ((int)blockIdx.x % tiles_x) * SAO_TW, oy_t = ((int)blockIdx.x / tiles_x) * SAO_TH;
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(256) void k_sao_rgb(FilterArgs A, const colordev::C
   const int ctx = (tid & 15) * 4, cty = tid >> 4;
 #pragma unroll
   for (int c = 1; c < 3; c++) {
-    const SaoComp<Pix> SC = sao_comp<Pix>(A, P, c);
+    const SaoComp<Pix> SC = sao_comp<Pix>(A, P, c, MAY_KEEP, RESTRICTED);
     uint32_t spw[3];
     sao_params_at(SC, ox_t / 2 + ctx, oy_t / 2 + cty, spw);
     __syncthreads();                       // the previous component's reads of `tile` are done
@@ -489,17 +496,32 @@ void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool 
   }
 }
 
-void launch_sao_rgb(const FilterArgs& a, const void* color_params_dev, int n_pics, int max_out_w, int max_out_h, hipStream_t s)
+// kernel variants: without the "samples stay as they are" paths (no lossless CUs / unfiltered PCM in the batch) and / or without the per-neighbour
+// slice / tile checks (every picture has sao_free_neighbours) — the common batch takes the leanest one
+#define HIPDEC_SAO_DISPATCH(LAUNCH)                          \
+  do {                                                       \
+    if (may_keep && restricted) { LAUNCH(true, true); }      \
+    else if (may_keep) { LAUNCH(true, false); }              \
+    else if (restricted) { LAUNCH(false, true); }            \
+    else { LAUNCH(false, false); }                           \
+  } while (0)
+
+void launch_sao_rgb(const FilterArgs& a, const void* color_params_dev, int n_pics, int max_out_w, int max_out_h, hipStream_t s, bool may_keep, bool restricted)
 {
   const int tiles = ((max_out_w + SAO_TW - 1) / SAO_TW) * ((max_out_h + SAO_TH - 1) / SAO_TH);
-  hipLaunchKernelGGL(k_sao_rgb, dim3(tiles, n_pics), dim3(256), 0, s, a, (const colordev::ColorParams*)color_params_dev);
+#define L_RGB(K, R) hipLaunchKernelGGL((k_sao_rgb<K, R>), dim3(tiles, n_pics), dim3(256), 0, s, a, (const colordev::ColorParams*)color_params_dev)
+  HIPDEC_SAO_DISPATCH(L_RGB);
+#undef L_RGB
 }
 
-void launch_sao(const FilterArgs& a, int n_pics, int max_out_w, int max_out_h, bool wide, hipStream_t s)
+void launch_sao(const FilterArgs& a, int n_pics, int max_out_w, int max_out_h, bool wide, hipStream_t s, bool may_keep, bool restricted)
 {
   const int tiles = ((max_out_w + SAO_TW - 1) / SAO_TW) * ((max_out_h + SAO_TH - 1) / SAO_TH);
-  if (wide) hipLaunchKernelGGL((k_sao<uint16_t>), dim3(tiles, n_pics, 3), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_sao<uint8_t>), dim3(tiles, n_pics, 3), dim3(256), 0, s, a);
+#define L_16(K, R) hipLaunchKernelGGL((k_sao<uint16_t, K, R>), dim3(tiles, n_pics, 3), dim3(256), 0, s, a)
+#define L_8(K, R) hipLaunchKernelGGL((k_sao<uint8_t, K, R>), dim3(tiles, n_pics, 3), dim3(256), 0, s, a)
+  if (wide) HIPDEC_SAO_DISPATCH(L_16); else HIPDEC_SAO_DISPATCH(L_8);
+#undef L_16
+#undef L_8
 }
 
 }  // namespace hipdec

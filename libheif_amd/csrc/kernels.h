@@ -28,8 +28,10 @@ void launch_parse_lanes(const ParseArgs& a, hipStream_t s);    // parse_lanes_ke
 void launch_residual(const FilterArgs& a, int n_pics, int max_ctbs, hipStream_t s);
 void launch_recon(const ReconArgs& a, bool wide, hipStream_t s);
 void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s);
-void launch_sao(const FilterArgs& a, int n_pics, int max_out_w, int max_out_h, bool wide, hipStream_t s);
+// may_keep = false: no picture of the batch has lossless CUs or unfiltered PCM units (8.7.3 "samples stay as they are"): the kernel variant without those paths
+// restricted = false: every picture has PicParams::sao_free_neighbours (no slice / tile boundary restricts the edge-offset neighbours)
+void launch_sao(const FilterArgs& a, int n_pics, int max_out_w, int max_out_h, bool wide, hipStream_t s, bool may_keep = true, bool restricted = true);
 // SAO + crop with the RGB24 emission fused into the store path (8-bit 4:2:0 only); color_params_dev: one colordev::ColorParams per picture
-void launch_sao_rgb(const FilterArgs& a, const void* color_params_dev, int n_pics, int max_out_w, int max_out_h, hipStream_t s);
+void launch_sao_rgb(const FilterArgs& a, const void* color_params_dev, int n_pics, int max_out_w, int max_out_h, hipStream_t s, bool may_keep = true, bool restricted = true);
 
 }  // namespace hipdec

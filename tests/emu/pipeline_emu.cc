@@ -43,7 +43,12 @@ int emu_run_pipeline_rgb(EmuBatch* b, int stages, uint8_t* rgb)
   if (stages & 1) launch_residual(fa, n, L.max_ctbs, nullptr);
   if (stages & 2) launch_recon(ra, L.wide, nullptr);
   if (stages & 4) launch_deblock(fa, n, L.max_w, L.max_h, L.wide, nullptr);
-  if (stages & 8) launch_sao(fa, n, L.max_ow, L.max_oh, L.wide, nullptr);
+  bool may_keep = false, restricted = false;   // as decoder.hip:launch_all picks the kernel variant
+  for (const PicParams& P : L.params) {
+    if (P.transquant_bypass_enabled || (P.pcm_enabled && P.pcm_loop_filter_disabled)) may_keep = true;
+    if (!P.sao_free_neighbours) restricted = true;
+  }
+  if (stages & 8) launch_sao(fa, n, L.max_ow, L.max_oh, L.wide, nullptr, may_keep, restricted);
   if ((stages & 16) && rgb) {
     // the parameter blocks come from the product's own entry points in capture mode, as in hipdec_batch_run_rgb (decoder.hip)
     static ColorBatchState st;
@@ -66,7 +71,7 @@ int emu_run_pipeline_rgb(EmuBatch* b, int stages, uint8_t* rgb)
     }
     const void* dev = nullptr; int variant = -1, count = 0;
     if (color_capture_take(st, nullptr, &dev, &variant, &count) || variant != color_variant_rgb24_u8()) return -200;
-    launch_sao_rgb(fa, dev, n, L.max_ow, L.max_oh, nullptr);
+    launch_sao_rgb(fa, dev, n, L.max_ow, L.max_oh, nullptr, may_keep, restricted);
   }
   b->status = *(int32_t*)(a + L.off_status);
   return b->status;
