@@ -92,3 +92,23 @@ def test_probe_reference_fixture_dimensions(reference_dir):
         rc, info, msg = probe(f.plugin_stream(iid))
         assert rc == 0, msg
         assert (info.width, info.height) == tuple(f.ispe(iid))
+
+
+def test_dependent_slice_segments_are_parsed_and_broken_ones_are_refused():
+    """host side of dependent_slice_segment_flag (hevc_headers.hip): the segments of a slice probe as one picture; a missing first or middle
+    segment is an incomplete / inconsistent picture, never a crash"""
+    planes = orc.synth_image(200, 136, 8, 1, seed=4)
+    s = orc.encode(planes, dependent_segments=3, wpp=0)
+    assert probe(s)[0] == 0
+    nals, p = [], 0
+    while p < len(s):
+        n = int.from_bytes(s[p:p + 4], "big"); nals.append(s[p:p + 4 + n]); p += 4 + n
+    ps = [x for x in nals if (x[4] >> 1) & 63 >= 32]
+    sl = [x for x in nals if (x[4] >> 1) & 63 < 32]
+    assert len(sl) == 3
+    assert probe(b"".join(ps + sl[1:]))[0] in (-2, -3, -4, -6, -7)            # no first slice segment
+    # the middle segment gone: the headers alone look like a longer first segment (the parse kernel then finds end_of_slice_segment_flag
+    # too early and reports it: tests/test_parse_emu.py::test_missing_dependent_segment_is_a_device_error)
+    assert probe(b"".join(ps + [sl[0], sl[2]]))[0] in (0, -2, -3, -4, -6)
+    assert probe(b"".join(ps + [sl[0], sl[1]]))[0] in (0, -2, -3, -4, -6)     # (likewise: the second segment looks longer; the device reports the early end)
+    assert probe(orc.encode(planes, dependent_segments=3, wpp=1))[0] == 0     # under WPP the segments start at CTB row starts
