@@ -52,3 +52,25 @@ def test_concurrent_batches_setting_validates_its_argument():
     assert lib.hipdec_set_concurrent_batches(65) != 0
     assert lib.hipdec_set_concurrent_batches(2) == 0
     assert lib.hipdec_set_concurrent_batches(1) == 0
+
+
+def test_example_hosts_compile_against_the_public_header():
+    """examples/decode_batch.c is plain C over include/heif_hipdec.h (the header must stay C-compatible) and links against the built library;
+    without a GPU it stops at the first device call with the library's loud "no CPU fallback" error.  examples/decode_with_libheif.c is
+    syntax-checked against the reference's public headers when they are around."""
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "libheif_amd")
+    if not os.path.exists(os.path.join(lib_dir, "libheifhip.so")):
+        pytest.skip("libheifhip.so not built")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "decode_batch")
+        subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "decode_batch.c"),
+                               "-L", lib_dir, "-lheifhip", "-Wl,-rpath," + lib_dir, "-o", exe])
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 2 and "usage" in r.stderr
+    api = "/root/reference/libheif/api"
+    gen = os.path.join(root, "oracle", "_ref", "gen")
+    if os.path.isdir(api) and os.path.isdir(gen):
+        subprocess.check_call(["gcc", "-std=c11", "-Wall", "-fsyntax-only", "-I", api, "-I", gen, os.path.join(root, "examples", "decode_with_libheif.c")])
