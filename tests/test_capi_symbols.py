@@ -1,6 +1,7 @@
 """CPU-side check that the C-ABI library loads and exports every symbol include/*.h declares
 (no compute calls: there is no GPU here)."""
 import ctypes
+import pytest
 import os
 import re
 
