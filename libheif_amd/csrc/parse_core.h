@@ -246,52 +246,242 @@ PC_DEV uint32_t read_byte(PS& s)
 PC_DEV void cabac_start(PS& s, uint32_t start, uint32_t end)
 {
   s.pos = start; s.end = end; s.zeros = 0; s.win_base = 0xfffff000u; s.fast_limit = 0;
-  s.range = pc_vec(510u); s.bits_needed = pc_vec((uint32_t)-8);
+  s.range = pc_vec(510u << 7); s.bits_needed = pc_vec((uint32_t)-8);
   const uint32_t b0 = read_byte(s), b1 = read_byte(s);
   s.value = pc_vec((b0 << 8) | b1);
 }
-// Context variable = pStateIdx | valMps << 6.  Both table reads use the variable itself as lane select — v_readlane takes the lane from
-// bits 5:0 of the SGPR (wave64), so pStateIdx never has to be shifted out — and the state update and its write-back run on the VALU: the
-// scalar pipe, shared by the CU's four SIMDs, is the parser's bottleneck (profiles/r02g_pmc_parse_b512.txt: 32 SALU + 8 branch against
-// 23 VALU instructions per pixel before this change), while the vector pipes have room.
-PC_DEV int decode_bin(PS& s, VReg& grp, int ctx_lane)
+// Representation of the arithmetic decoder (9.3.4.3, scaled-window formulation):
+//   s.range        ivlCurrRange << 7 (the scaled range the window is compared with: no shift per bin)
+//   s.value        the scaled window (ivlOffset with 7 look-ahead bits), s.bits_needed in -8 .. -1 counts the shifts until the next byte
+//   context var.   p' | valMps << 16 with p' = 62 - pStateIdx.  The MPS transition (pStateIdx + 1, saturating at 62: table 9-47) is then ONE
+//                  packed 16-bit saturating subtraction (v_pk_sub_u16 ... clamp: low half p' - 1 >= 0, high half valMps - 0), and the variable
+//                  itself is the lane select of both table reads (v_readlane takes the lane from bits 5:0).
+//   t_lps          lane p': rangeTabLps[62 - p'][0..3], one byte per qRangeIdx
+//   t_next         lane p': bits 5:0 the state after an LPS (62 - transIdxLps[62 - p']), bit 16 set where the LPS flips valMps (pStateIdx 0);
+//                  bits 13:8 / 29:24 carry the 8x8 diagonal scan and its inverse (lane = scan position / raster index)
+// Both pipes matter: the scalar ALU is shared by the CU's four SIMDs, so the decoder's arithmetic runs on the VALU (UReg) and only lane
+// selects, the bin value and the syntax control flow are scalar (profiles/r02g_pmc_parse_b512.txt).
+PC_DEV void refill_byte(PS& s) { s.value += read_byte(s) << s.bits_needed; s.bits_needed -= 8u; }
+
+PC_DEV int decode_bin_cxx(PS& s, VReg& grp, int ctx_lane)
 {
   const uint32_t st = pc_rdlane(grp, ctx_lane);
   const uint32_t row = pc_rdlane(s.t_lps, (int)st);
-  const UReg lps = (row >> ((s.range >> 3) & 24u)) & 255u;
-  UReg range = s.range - lps;
-  const UReg scaled = range << 7;
+  const UReg lps = (row >> ((s.range >> 10) & 24u)) & 255u;
+  UReg range = s.range - (lps << 7);
   const UReg vst = pc_vec(st);
   UReg nst;
   int bin;
   UReg nb;
-  if (__builtin_expect(pc_any(s.value < scaled), 1)) {   // MPS: at most one renormalisation shift
-    bin = (int)(st >> 6);
-    nst = vst + (((vst & 63u) != 62u) ? 1u : 0u);             // pStateIdx + 1, saturating at 62 (table 9-47 transIdxMps)
-    nb = 1u - (scaled >> 15);                                   // range < 256 <=> scaled < 2^15 (scaled < 2^16 always)
+  if (__builtin_expect(pc_any(s.value < range), 1)) {   // MPS: at most one renormalisation shift
+    bin = (int)(st >> 16);
+    nst = vst - (((vst & 63u) != 0u) ? 1u : 0u);
+    nb = 1u - (range >> 15);                                    // ivlCurrRange < 256 <=> range < 2^15 (range < 2^16 always)
     range <<= nb;
   } else {                                                      // LPS
-    bin = (int)((st >> 6) ^ 1u);
+    bin = (int)((st >> 16) ^ 1u);
     nb = (UReg)pc_clz(lps) - 23u;
-    s.value -= scaled;
-    range = lps << nb;
-    const UReg tr = pc_vec(pc_rdlane(s.t_next, (int)st));      // byte 0: transIdxLps | 64 where valMps flips (pStateIdx 0)
-    nst = (tr & 127u) ^ (vst & 64u);
+    s.value -= range;
+    range = lps << (nb + 7u);
+    const UReg tr = pc_vec(pc_rdlane(s.t_next, (int)st));
+    nst = (tr & 0x1003fu) ^ (vst & 0x10000u);
   }
   pc_wrlane_v(grp, ctx_lane, nst);
   s.range = range;
   s.value <<= nb;
   s.bits_needed += nb;
-  if (__builtin_expect(pc_any((int32_t)s.bits_needed >= 0), 0)) { s.value += read_byte(s) << s.bits_needed; s.bits_needed -= 8u; }
+  if (__builtin_expect(pc_any((int32_t)s.bits_needed >= 0), 0)) refill_byte(s);
   return bin;
 }
+
+#if !defined(HIPDEC_HOST_EMU) && !defined(HIPDEC_PARSE_SCALAR_CABAC) && !defined(HIPDEC_PARSE_CXX_BINS)
+#define PC_ASM_BINS 1
+// ---- hand-scheduled gfx950 forms of the two hot primitives ---------------------------------------------------------------------------
+// The compiler's code for decode_bin_cxx inside the sig_coeff_flag loop is 37 instructions per MPS bin (profiles/r03a_*): four hazard
+// s_nops, a v_mov per SGPR->VGPR hand-over, three instructions for the saturating state increment, shift / add / compare / branch of the
+// renormalisation although an MPS whose range stays >= 256 shifts nothing, phi copies around the byte refill.  Written by hand the same
+// bin is 18 instructions with every hazard slot filled by useful work:
+//   * the wait states a VALU-written SGPR needs before it can be a lane select (4) or a VALU operand (2) are filled with the qRangeIdx
+//     extraction, the write-back mask compare and (in the run) the read of the NEXT position's context index;
+//   * R - (lps << 7) is one v_mad_i32_i24 on the scaled range, the MPS state update one v_pk_sub_u16 ... clamp;
+//   * an MPS that needs no renormalisation skips shift, bit count and refill test with one compare + branch;
+//   * the byte refill reads the 256-byte window register directly; only a window change / an emulation-prevention candidate / the end
+//     of the substream leaves the statement (flag bit 1 of the result), where refill_byte() does it the general way.
+// The statements are opaque to the compiler: all wait states are inside the strings (cdna guide §5.7).  The host emulation and the
+// latency variant run decode_bin_cxx — the same arithmetic — and the GPU parity suite runs these.
+#define PC_ASM_HEAD_Q   "v_lshrrev_b32 %[vt], 10, %[R]\n\tv_and_b32 %[vt], 24, %[vt]\n\t"
+// LPS tail shared by both statements: value -= R, renormalise by clz(lps), next state from t_next (valMps flips at pStateIdx 0)
+#define PC_ASM_LPS(BIN_FIX)                                                                                                        \
+  "v_sub_u32 %[val], %[val], %[R]\n\t"                                                                                              \
+  "v_ffbh_u32 %[vt], %[vl]\n\t"                                                                                                     \
+  "v_add_u32 %[vt], -16, %[vt]\n\t"                                                                                                 \
+  "v_lshlrev_b32 %[R], %[vt], %[vl]\n\t"                                                                                            \
+  "v_add_u32 %[vt], -7, %[vt]\n\t"                                                                                                  \
+  "v_lshlrev_b32 %[val], %[vt], %[val]\n\t"                                                                                         \
+  "v_add_u32 %[bits], %[vt], %[bits]\n\t"                                                                                           \
+  "v_readlane_b32 %[row], %[tn], %[st]\n\t"                                                                                         \
+  BIN_FIX                                                                                                                            \
+  "s_and_b32 %[st], %[st], 0x10000\n\t"                                                                                             \
+  "s_and_b32 %[row], %[row], 0x1003f\n\t"                                                                                           \
+  "s_xor_b32 %[row], %[row], %[st]\n\t"                                                                                             \
+  "v_mov_b32 %[vn], %[row]\n\t"
+// byte refill from the window register; branches to SLOW when the fast window is exhausted
+#define PC_ASM_REFILL(SLOW)                                                                                                        \
+  "s_cmp_lt_u32 %[pos], %[flim]\n\t"                                                                                                \
+  "s_cbranch_scc0 " SLOW "\n\t"                                                                                                     \
+  "s_lshr_b32 %[st], %[pos], 2\n\t"                                                                                                 \
+  "s_lshl_b32 %[row], %[pos], 3\n\t"                                                                                                \
+  "v_readlane_b32 %[st], %[win], %[st]\n\t"                                                                                         \
+  "s_add_u32 %[pos], %[pos], 1\n\t"                                                                                                 \
+  "s_nop 0\n\t"                                                                                                                     \
+  "s_lshr_b32 %[st], %[st], %[row]\n\t"                                                                                             \
+  "s_and_b32 %[st], %[st], 0xff\n\t"                                                                                                \
+  "v_lshl_add_u32 %[val], %[st], %[bits], %[val]\n\t"                                                                               \
+  "v_add_u32 %[bits], -8, %[bits]\n\t"
+
+PC_DEV int decode_bin(PS& s, VReg& grp, int ctx_lane)
+{
+  uint32_t r, st, row;
+  uint64_t mask;
+  uint32_t vt, vl, vn;
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane(ctx_lane);
+  uint32_t pos = pc_uni(s.pos);
+  const uint32_t flim = pc_uni(s.fast_limit);
+  asm volatile(
+    PC_ASM_HEAD_Q
+    "v_cmp_eq_u32_e64 %[mask], %[c], %[lane]\n\t"
+    "s_nop 0\n\t"
+    "v_readlane_b32 %[st], %[grp], %[c]\n\t"
+    "s_nop 3\n\t"
+    "v_readlane_b32 %[row], %[tl], %[st]\n\t"
+    "s_lshr_b32 %[r], %[st], 16\n\t"
+    "s_nop 0\n\t"
+    "v_bfe_u32 %[vl], %[row], %[vt], 8\n\t"
+    "v_mad_i32_i24 %[R], %[vl], %[m128], %[R]\n\t"
+    "v_cmp_lt_u32_e32 vcc, %[val], %[R]\n\t"
+    "s_cbranch_vccnz 5f\n\t"
+    PC_ASM_LPS("s_xor_b32 %[r], %[r], 1\n\t")
+    "s_branch 2f\n"
+    "1:\n\t"                                    // MPS with renormalisation: exactly one shift
+    "v_lshlrev_b32 %[R], 1, %[R]\n\t"
+    "v_lshlrev_b32 %[val], 1, %[val]\n\t"
+    "v_add_u32 %[bits], 1, %[bits]\n"
+    "2:\n\t"
+    "v_cmp_lt_i32_e32 vcc, -1, %[bits]\n\t"
+    "s_cbranch_vccz 6f\n\t"
+    PC_ASM_REFILL("3f")
+    "s_branch 6f\n"
+    "3:\n\t"
+    "s_or_b32 %[r], %[r], 2\n\t"
+    "s_branch 6f\n"
+    "5:\n\t"                                    // MPS
+    "v_pk_sub_u16 %[vn], %[st], 1 clamp\n\t"
+    "v_cmp_gt_u32_e32 vcc, 0x8000, %[R]\n\t"
+    "s_cbranch_vccnz 1b\n"
+    "6:\n\t"
+    "v_cndmask_b32_e64 %[grp], %[grp], %[vn], %[mask]\n\t"
+    : [grp] "+v"(grp), [R] "+v"(s.range), [val] "+v"(s.value), [bits] "+v"(s.bits_needed), [pos] "+s"(pos),
+      [r] "=&s"(r), [st] "=&s"(st), [row] "=&s"(row), [mask] "=&s"(mask), [vt] "=&v"(vt), [vl] "=&v"(vl), [vn] "=&v"(vn)
+    : [c] "s"(c), [tl] "v"(s.t_lps), [tn] "v"(s.t_next), [lane] "v"((uint32_t)threadIdx.x), [win] "v"(s.win), [flim] "s"(flim),
+      [m128] "s"(0xffffff80u)
+    : "vcc", "scc");
+  s.pos = pc_uni(pos);
+  r = pc_uni(r);
+  if (__builtin_expect(r > 1u, 0)) { refill_byte(s); r &= 1u; }
+  return (int)r;
+}
+
+// sig_coeff_flag of the scan positions n_start .. 1 of one sub-block (bit k of the result = position k); lane k of vctx is the
+// position's context variable (lane of group B).  One statement per run: the loop, the context read of the next position and the
+// refills stay inside; it is left early only for a refill the window register cannot serve.
+#define PC_ASM_SIG_ITER(P, CA, CB, NEXT)                                                                                           \
+  "1" P "0:\n\t"                                                                                                                    \
+  "v_readlane_b32 %[st], %[grp], %[" CA "]\n\t"                                                                                     \
+  PC_ASM_HEAD_Q                                                                                                                     \
+  "v_cmp_eq_u32_e64 %[mask], %[" CA "], %[lane]\n\t"                                                                                \
+  "v_readlane_b32 %[" CB "], %[vx], %[j]\n\t"                                                                                       \
+  "v_readlane_b32 %[row], %[tl], %[st]\n\t"                                                                                         \
+  "s_lshr_b32 %[t], %[st], 16\n\t"                                                                                                  \
+  "s_lshl1_add_u32 %[acc], %[acc], %[t]\n\t"                                                                                        \
+  "v_bfe_u32 %[vl], %[row], %[vt], 8\n\t"                                                                                           \
+  "v_mad_i32_i24 %[R], %[vl], %[m128], %[R]\n\t"                                                                                    \
+  "v_cmp_lt_u32_e32 vcc, %[val], %[R]\n\t"                                                                                          \
+  "s_cbranch_vccz 1" P "1f\n\t"                                                                                                     \
+  "v_pk_sub_u16 %[vn], %[st], 1 clamp\n\t"                                                                                          \
+  "v_cmp_gt_u32_e32 vcc, 0x8000, %[R]\n\t"                                                                                          \
+  "s_cbranch_vccnz 1" P "2f\n"                                                                                                      \
+  "1" P "4:\n\t"                                                                                                                    \
+  "v_cndmask_b32_e64 %[grp], %[grp], %[vn], %[mask]\n\t"                                                                            \
+  "s_add_u32 %[j], %[j], -1\n\t"                                                                                                    \
+  "s_cbranch_scc1 " NEXT "\n\t"                                                                                                     \
+  "s_branch 190f\n"                                                                                                                 \
+  "1" P "1:\n\t"                                                                                                                    \
+  PC_ASM_LPS("s_xor_b32 %[acc], %[acc], 1\n\t")                                                                                     \
+  "s_branch 1" P "3f\n"                                                                                                             \
+  "1" P "2:\n\t"                                                                                                                    \
+  "v_lshlrev_b32 %[R], 1, %[R]\n\t"                                                                                                 \
+  "v_lshlrev_b32 %[val], 1, %[val]\n\t"                                                                                             \
+  "v_add_u32 %[bits], 1, %[bits]\n"                                                                                                 \
+  "1" P "3:\n\t"                                                                                                                    \
+  "v_cmp_lt_i32_e32 vcc, -1, %[bits]\n\t"                                                                                           \
+  "s_cbranch_vccz 1" P "4b\n\t"                                                                                                     \
+  PC_ASM_REFILL("1" P "5f")                                                                                                         \
+  "s_branch 1" P "4b\n"                                                                                                             \
+  "1" P "5:\n\t"                                                                                                                    \
+  "v_cndmask_b32_e64 %[grp], %[grp], %[vn], %[mask]\n\t"                                                                            \
+  "s_add_u32 %[j], %[j], -1\n\t"                                                                                                    \
+  "s_mov_b32 %[flag], 1\n\t"                                                                                                        \
+  "s_branch 190f\n"
+
+PC_DEV uint32_t decode_sig_run(PS& s, const VReg& vctx, int n_start)
+{
+  uint32_t acc = 0;
+  int32_t j = __builtin_amdgcn_readfirstlane(n_start - 1);   // the position after the current one; the run ends when it leaves 0 .. 15
+  for (;;) {
+    uint32_t flag, ca, cb, st, row, t;
+    uint64_t mask;
+    uint32_t vt, vl, vn;
+    uint32_t pos = pc_uni(s.pos);
+    const uint32_t flim = pc_uni(s.fast_limit);
+    asm volatile(
+      "s_add_u32 %[t], %[j], 1\n\t"
+      "s_mov_b32 %[flag], 0\n\t"
+      "v_readlane_b32 %[ca], %[vx], %[t]\n\t"
+      "s_nop 3\n\t"
+      PC_ASM_SIG_ITER("0", "ca", "cb", "110f")
+      PC_ASM_SIG_ITER("1", "cb", "ca", "100b")
+      "190:\n\t"
+      : [grp] "+v"(s.ctxB), [R] "+v"(s.range), [val] "+v"(s.value), [bits] "+v"(s.bits_needed), [pos] "+s"(pos), [j] "+s"(j), [acc] "+s"(acc),
+        [flag] "=&s"(flag), [ca] "=&s"(ca), [cb] "=&s"(cb), [st] "=&s"(st), [row] "=&s"(row), [t] "=&s"(t), [mask] "=&s"(mask),
+        [vt] "=&v"(vt), [vl] "=&v"(vl), [vn] "=&v"(vn)
+      : [vx] "v"(vctx), [tl] "v"(s.t_lps), [tn] "v"(s.t_next), [lane] "v"((uint32_t)threadIdx.x), [win] "v"(s.win), [flim] "s"(flim),
+        [m128] "s"(0xffffff80u)
+      : "vcc", "scc");
+    s.pos = pc_uni(pos);
+    acc = pc_uni(acc);
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)flag) != 0, 0)) refill_byte(s);
+    j = __builtin_amdgcn_readfirstlane(j);
+    if (j < 0) break;
+  }
+  return acc << 1;
+}
+#else
+PC_DEV int decode_bin(PS& s, VReg& grp, int ctx_lane) { return decode_bin_cxx(s, grp, ctx_lane); }
+PC_DEV uint32_t decode_sig_run(PS& s, const VReg& vctx, int n_start)
+{
+  uint32_t sig = 0;
+  int k = n_start;
+  do sig |= (uint32_t)decode_bin(s, s.ctxB, (int)pc_rdlane(vctx, k)) << k; while (--k > 0);
+  return sig;
+}
+#endif
+
 PC_DEV int decode_bypass(PS& s)
 {
   s.value <<= 1;
   s.bits_needed += 1u;
   if (pc_any((int32_t)s.bits_needed >= 0)) { s.bits_needed = pc_vec((uint32_t)-8); s.value += read_byte(s); }
-  const UReg scaled = s.range << 7;
-  if (pc_any(s.value >= scaled)) { s.value -= scaled; return 1; }
+  if (pc_any(s.value >= s.range)) { s.value -= s.range; return 1; }
   return 0;
 }
 // n <= 8 bypass bins at once: n steps of 9.3.4.3.4 are one long division of the scaled window by the scaled
@@ -300,8 +490,8 @@ PC_DEV uint32_t decode_bypass_multi(PS& s, int n)
 {
   s.value <<= n;
   s.bits_needed += (uint32_t)n;
-  if (pc_any((int32_t)s.bits_needed >= 0)) { s.value += read_byte(s) << s.bits_needed; s.bits_needed -= 8u; }
-  const UReg scaled = s.range << 7;
+  if (pc_any((int32_t)s.bits_needed >= 0)) refill_byte(s);
+  const UReg scaled = s.range;
   // value < scaled * 2^n <= 2^24 and scaled < 2^16 are exact in fp32: the quotient estimate from one reciprocal is off by at
   // most one, which the remainder check repairs (an integer division expands to ~40 instructions)
   UReg q = (UReg)((float)s.value * pc_rcp((float)scaled));
@@ -326,11 +516,10 @@ PC_DEV int decode_bypass_bits(PS& s, int n)   // n <= 32, MSB first
 }
 PC_DEV int decode_terminate(PS& s)
 {
-  s.range -= 2u;
-  const UReg scaled = s.range << 7;
-  if (pc_any(s.value >= scaled)) return 1;
-  if (pc_any(scaled < (256u << 7))) {
-    s.range = scaled >> 6;
+  s.range -= 2u << 7;
+  if (pc_any(s.value >= s.range)) return 1;
+  if (pc_any(s.range < (256u << 7))) {
+    s.range <<= 1;
     s.value <<= 1;
     s.bits_needed += 1u;
     if (pc_any((int32_t)s.bits_needed == 0)) { s.bits_needed = pc_vec((uint32_t)-8); s.value += read_byte(s); }
@@ -350,7 +539,7 @@ PC_DEV void init_contexts(PS& s)
       pre = pre < 1 ? 1 : (pre > 126 ? 126 : pre);
       const int mps = pre <= 63 ? 0 : 1;
       const int p_state = mps ? pre - 64 : 63 - pre;
-      const uint32_t v = (uint32_t)(p_state | (mps << 6));
+      const uint32_t v = (uint32_t)((62 - p_state) | (mps << 16));   // p' | valMps << 16
       if (g == 0) PC_L(s.ctxA) = v; else if (g == 1) PC_L(s.ctxB) = v; else PC_L(s.ctxC) = v;
     }
   PC_VEC_END
@@ -358,15 +547,16 @@ PC_DEV void init_contexts(PS& s)
 PC_DEV void load_tables(PS& s)
 {
   PC_VEC_BEGIN
-    PC_L(s.t_lps) = (uint32_t)c_range_lps[lane * 4] | ((uint32_t)c_range_lps[lane * 4 + 1] << 8) | ((uint32_t)c_range_lps[lane * 4 + 2] << 16) |
-                    ((uint32_t)c_range_lps[lane * 4 + 3] << 24);
-    PC_L(s.t_next) = (uint32_t)c_next_lps[lane] | (lane == 0 ? 64u : 0u) | ((uint32_t)c_diag8[lane] << 8);
+    const int ps = lane < 63 ? 62 - lane : 63;   // lane p' serves pStateIdx 62 - p' (lane 63: the terminate state's row, never addressed)
+    PC_L(s.t_lps) = (uint32_t)c_range_lps[ps * 4] | ((uint32_t)c_range_lps[ps * 4 + 1] << 8) | ((uint32_t)c_range_lps[ps * 4 + 2] << 16) |
+                    ((uint32_t)c_range_lps[ps * 4 + 3] << 24);
+    PC_L(s.t_next) = (lane < 63 ? (uint32_t)(62 - c_next_lps[ps]) : 0u) | (lane == 62 ? 0x10000u : 0u) | ((uint32_t)c_diag8[lane] << 8);
   PC_VEC_END
   {   // inverse of the 8x8 diagonal scan, scattered with one masked move per position (once per substream)
     VReg inv;
     PC_VEC_BEGIN PC_L(inv) = 0u; PC_VEC_END
     for (int k = 0; k < 64; k++) pc_wrlane(inv, (int)((pc_rdlane(s.t_next, k) >> 8) & 63u), (uint32_t)k);
-    PC_VEC_BEGIN PC_L(s.t_next) |= PC_L(inv) << 16; PC_VEC_END
+    PC_VEC_BEGIN PC_L(s.t_next) |= PC_L(inv) << 24; PC_VEC_END
   }
 }
 
@@ -436,7 +626,7 @@ PC_DEV void scan_sb(PS& s, int lg, int scan_idx, int i, int& xs, int& ys)
     if (scan_idx == 1) { xs = i & 1; ys = i >> 1; }  // horizontal
     else { xs = i >> 1; ys = i & 1; }                // diagonal and vertical coincide for 2x2
   } else if (lg == 2) { const uint32_t v = (uint32_t)(PC_DIAG4 >> (i * 4)) & 15u; xs = (int)(v & 3u); ys = (int)(v >> 2); }
-  else { const uint32_t v = (pc_rdlane(s.t_next, i) >> 8) & 255u; xs = (int)(v & 7u); ys = (int)(v >> 3); }
+  else { const uint32_t v = (pc_rdlane(s.t_next, i) >> 8) & 63u; xs = (int)(v & 7u); ys = (int)(v >> 3); }
 }
 
 // returns transform_skip_flag; coefficients go to L->coef (raster, n x n)
@@ -475,7 +665,7 @@ PC_DEV int residual_coding(PS& s, int log2n, int c_idx, int pred_mode)
     if (lg == 0) last_sb = 0;
     else if (lg == 1) last_sb = scan_idx == 1 ? (xs_t | (ys_t << 1)) : ((xs_t << 1) | ys_t);   // see scan_sb
     else if (lg == 2) last_sb = (int)((uint32_t)(PC_INV_DIAG4 >> ((uint32_t)(xs_t | (ys_t << 2)) * 4u)) & 15u);
-    else last_sb = (int)((pc_rdlane(s.t_next, xs_t | (ys_t << 3)) >> 16) & 255u);
+    else last_sb = (int)((pc_rdlane(s.t_next, xs_t | (ys_t << 3)) >> 24) & 63u);
   }
   uint64_t csbf = 0;  // coded_sub_block_flag bitmap, bit (ys*8 + xs)
   const int sbw = 1 << lg;
@@ -520,8 +710,7 @@ PC_DEV int residual_coding(PS& s, int log2n, int c_idx, int pred_mode)
     int n_start = 15;
     if (i == last_sb) { sig = 1u << last_pos; n_start = last_pos - 1; }
     if (n_start > 0) {
-      int k = n_start;
-      do sig |= (uint32_t)decode_bin(s, s.ctxB, B_SIG_COEFF + (int)pc_rdlane(vctx, k)) << k; while (--k > 0);
+      sig |= decode_sig_run(s, vctx, n_start);
     }
     if (n_start >= 0) {   // position 0: inferred significant when the sub-block was signalled coded and nothing else is
       if (infer_dc && !sig) sig = 1u;
@@ -677,7 +866,7 @@ PC_DEV void pcm_coding_unit(PS& s, int zb, int log2cb, int16_t* coef_y, int16_t*
     }
     flush_coef(s, c == 0 ? coef_y + zb * 16 : (c == 1 ? coef_cb : coef_cr) + zb * 4, n2);
   }
-  s.range = pc_vec(510u); s.bits_needed = pc_vec((uint32_t)-8);
+  s.range = pc_vec(510u << 7); s.bits_needed = pc_vec((uint32_t)-8);
   {
     const uint32_t b0 = read_byte(s), b1 = read_byte(s);
     s.value = pc_vec((b0 << 8) | b1);
