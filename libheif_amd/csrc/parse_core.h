@@ -465,8 +465,96 @@ PC_DEV uint32_t decode_sig_run(PS& s, const VReg& vctx, int n_start)
   }
   return acc << 1;
 }
+
+// coeff_abs_level_greater1_flag of one sub-block: n (1 .. 8) flags from the highest significant position down, ctxInc = min(greater1Ctx, 3)
+// with greater1Ctx (g) reset by a 1 and counted up by 0s (9.3.4.2.6).  Returns the flags MSB-first (the first decoded flag in bit n - 1).
+// One statement per run, the context state machine inside on the scalar side in the engine's hazard slots.
+PC_DEV uint32_t decode_g1_run(PS& s, int base_lane, int n, int& g_io)
+{
+  uint32_t gb = 0;
+  int32_t m = __builtin_amdgcn_readfirstlane(n - 1);
+  uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane(g_io);
+  const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane(base_lane);
+  for (;;) {
+    uint32_t flag, c, st, row, b, g2;
+    uint64_t mask;
+    uint32_t vt, vl, vn;
+    uint32_t pos = pc_uni(s.pos);
+    const uint32_t flim = pc_uni(s.fast_limit);
+    asm volatile(
+      "s_mov_b32 %[flag], 0\n\t"
+      "s_nop 1\n"
+      "200:\n\t"
+      "s_min_u32 %[c], %[g], 3\n\t"
+      "s_add_u32 %[c], %[base], %[c]\n\t"
+      "v_cmp_eq_u32_e64 %[mask], %[c], %[lane]\n\t"
+      "v_readlane_b32 %[st], %[grp], %[c]\n\t"
+      PC_ASM_HEAD_Q
+      "s_cmp_lg_u32 %[g], 0\n\t"
+      "s_addc_u32 %[g2], %[g], 0\n\t"
+      "v_readlane_b32 %[row], %[tl], %[st]\n\t"
+      "s_lshr_b32 %[b], %[st], 16\n\t"
+      "s_lshl1_add_u32 %[gb], %[gb], %[b]\n\t"
+      "v_bfe_u32 %[vl], %[row], %[vt], 8\n\t"
+      "v_mad_i32_i24 %[R], %[vl], %[m128], %[R]\n\t"
+      "v_cmp_lt_u32_e32 vcc, %[val], %[R]\n\t"
+      "s_cbranch_vccz 201f\n\t"
+      "v_pk_sub_u16 %[vn], %[st], 1 clamp\n\t"
+      "v_cmp_gt_u32_e32 vcc, 0x8000, %[R]\n\t"
+      "s_cbranch_vccnz 202f\n"
+      "204:\n\t"
+      "v_cndmask_b32_e64 %[grp], %[grp], %[vn], %[mask]\n\t"
+      "s_cmp_eq_u32 %[b], 0\n\t"
+      "s_cselect_b32 %[g], %[g2], 0\n\t"
+      "s_add_u32 %[m], %[m], -1\n\t"
+      "s_cbranch_scc1 200b\n\t"
+      "s_branch 290f\n"
+      "201:\n\t"
+      PC_ASM_LPS("s_xor_b32 %[gb], %[gb], 1\n\ts_xor_b32 %[b], %[b], 1\n\t")
+      "s_branch 203f\n"
+      "202:\n\t"
+      "v_lshlrev_b32 %[R], 1, %[R]\n\t"
+      "v_lshlrev_b32 %[val], 1, %[val]\n\t"
+      "v_add_u32 %[bits], 1, %[bits]\n"
+      "203:\n\t"
+      "v_cmp_lt_i32_e32 vcc, -1, %[bits]\n\t"
+      "s_cbranch_vccz 204b\n\t"
+      PC_ASM_REFILL("205f")
+      "s_branch 204b\n"
+      "205:\n\t"
+      "v_cndmask_b32_e64 %[grp], %[grp], %[vn], %[mask]\n\t"
+      "s_cmp_eq_u32 %[b], 0\n\t"
+      "s_cselect_b32 %[g], %[g2], 0\n\t"
+      "s_add_u32 %[m], %[m], -1\n\t"
+      "s_mov_b32 %[flag], 1\n"
+      "290:\n\t"
+      : [grp] "+v"(s.ctxC), [R] "+v"(s.range), [val] "+v"(s.value), [bits] "+v"(s.bits_needed), [pos] "+s"(pos), [m] "+s"(m), [gb] "+s"(gb), [g] "+s"(g),
+        [flag] "=&s"(flag), [c] "=&s"(c), [st] "=&s"(st), [row] "=&s"(row), [b] "=&s"(b), [g2] "=&s"(g2), [mask] "=&s"(mask),
+        [vt] "=&v"(vt), [vl] "=&v"(vl), [vn] "=&v"(vn)
+      : [base] "s"(base), [tl] "v"(s.t_lps), [tn] "v"(s.t_next), [lane] "v"((uint32_t)threadIdx.x), [win] "v"(s.win), [flim] "s"(flim),
+        [m128] "s"(0xffffff80u)
+      : "vcc", "scc");
+    s.pos = pc_uni(pos);
+    gb = pc_uni(gb); g = pc_uni(g);
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)flag) != 0, 0)) refill_byte(s);
+    m = __builtin_amdgcn_readfirstlane(m);
+    if (m < 0) break;
+  }
+  g_io = (int)g;
+  return gb;
+}
 #else
 PC_DEV int decode_bin(PS& s, VReg& grp, int ctx_lane) { return decode_bin_cxx(s, grp, ctx_lane); }
+PC_DEV uint32_t decode_g1_run(PS& s, int base_lane, int n, int& g)
+{
+  uint32_t gb = 0;
+  for (int i = 0; i < n; i++) {
+    const int b = decode_bin(s, s.ctxC, base_lane + (g > 3 ? 3 : g));
+    gb = (gb << 1) | (uint32_t)b;
+    if (b) g = 0; else if (g > 0) g++;
+  }
+  return gb;
+}
 PC_DEV uint32_t decode_sig_run(PS& s, const VReg& vctx, int n_start)
 {
   uint32_t sig = 0;
@@ -718,27 +806,30 @@ PC_DEV int residual_coding(PS& s, int log2n, int c_idx, int pred_mode)
     }
     if (!sig) continue;
     // greater1 / greater2 flags
-    uint32_t g1 = 0, g1_coded = 0;
     int ctx_set = (i == 0 || c_idx > 0) ? 0 : 2;
     if (!first_sb_with_g1 && g1_carry == 0) ctx_set++;
     first_sb_with_g1 = 0;
-    int g1_ctx = 1, num_g1 = 0, last_g1_pos = -1;
     const int last_sig_pos = 31 - pc_clz(sig), first_sig_pos = pc_ffs(sig) - 1;
-    const int g1_base = C_GREATER1 + ctx_set * 4 + (c_idx ? 16 : 0);
-    {
-      uint32_t rem = sig;
-      while (rem && num_g1 < 8) {
-        const int k = 31 - pc_clz(rem);
-        rem &= ~(1u << k);
-        g1_coded |= 1u << k;
-        if (decode_bin(s, s.ctxC, g1_base + (g1_ctx > 3 ? 3 : g1_ctx))) { g1 |= 1u << k; g1_ctx = 0; if (last_g1_pos < 0) last_g1_pos = k; }
-        else if (g1_ctx > 0) g1_ctx++;
-        num_g1++;
-      }
-    }
+    const int n_sig = pc_popc(sig), n_g1 = n_sig < 8 ? n_sig : 8;
+    int g1_ctx = 1;
+    const uint32_t gbits = decode_g1_run(s, C_GREATER1 + ctx_set * 4 + (c_idx ? 16 : 0), n_g1, g1_ctx);
     g1_carry = g1_ctx;
+    // the run's flags back at their scan positions: the r-th significant position from the top carries flag r (r < 8)
+    uint32_t g1, g1_coded;
+    {
+      VReg vcoded, vg1;
+      PC_VEC_BEGIN
+        const int k = lane & 15;
+        const int rank = pc_popc(sig >> (k + 1));
+        const uint32_t coded = (lane < 16 && ((sig >> k) & 1u) && rank < 8) ? 1u : 0u;
+        PC_L(vcoded) = coded;
+        PC_L(vg1) = coded & (gbits >> ((n_g1 - 1 - rank) & 31));
+      PC_VEC_END
+      g1_coded = (uint32_t)pc_ballot(vcoded);
+      g1 = (uint32_t)pc_ballot(vg1);
+    }
     const int sign_hidden = s.cu_tq_bypass ? 0 : (sdh && (last_sig_pos - first_sig_pos > 3));
-    const uint32_t first_g1_bit = last_g1_pos >= 0 ? 1u << last_g1_pos : 0u;
+    const uint32_t first_g1_bit = g1 ? 1u << (31 - pc_clz(g1)) : 0u;   // the first flag that was 1 (descending scan order)
     uint32_t g2 = 0;
     if (first_g1_bit && decode_bin(s, s.ctxB, B_GREATER2 + ctx_set + (c_idx ? 4 : 0))) g2 = first_g1_bit;
     // coeff_sign_flag: all of the sub-block's sign bins in one multi-bit bypass read (MSB = highest scan position)

@@ -15,13 +15,16 @@ files = {}
 for l in lines:
     m = re.match(r'\s+\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', l)
     if m: files[int(m.group(1))] = (m.group(3) or m.group(2))
-static = collections.Counter(); cur = None
+static = collections.Counter(); static_cls = collections.Counter(); cur = None
 for l in lines[start:]:
     m = re.match(r"\s+\.loc\s+(\d+)\s+(\d+)", l)
     if m: cur = (files.get(int(m.group(1)), ""), int(m.group(2))); continue
     if l.startswith(".Lfunc_end"): break
     if re.match(r"\s+[a-z_0-9]+(\s|$)", l) and not l.strip().startswith((".", ";")):
         static[cur] += 1
+        op = l.split()[0]
+        cls = "B" if op.startswith(("s_cbranch", "s_branch")) else ("N" if op.startswith(("s_nop", "s_waitcnt")) else ("S" if op.startswith("s_") else ("V" if op.startswith("v_") else "M")))
+        static_cls[(cur, cls)] += 1
 st_line = collections.Counter()
 unattributed = 0
 for (f, ln), c in static.items():
@@ -65,9 +68,13 @@ for ln, c in st_line.items():
     if count(ln) > 0:
         f = func_at.get(ln, "?"); copies[f] = min(copies.get(f, 1 << 30), c)
 tot = 0; rows = []
+cls_tot = collections.Counter()
 for ln, c in st_line.items():
     k = max(1, copies.get(func_at.get(ln, "?"), 1))
     d = c / k * count(ln); tot += d; rows.append((d, ln, c / k, count(ln)))
+    for (key, cls), cc in static_cls.items():
+        if key[1] == ln and key[0].endswith(srcname): cls_tot[cls] += cc / k * count(ln)
+print("by class (S salu, V valu, B branch, N nop/waitcnt, M memory/lds):", {k: round(v / (px or 1), 2) for k, v in cls_tot.items()})
 rows.sort(reverse=True)
 print("estimated dynamic wave-instructions: %.3g%s" % (tot, (" = %.1f per pixel" % (tot / px)) if px else ""))
 byf = collections.Counter()
