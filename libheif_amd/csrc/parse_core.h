@@ -564,7 +564,7 @@ PC_DEV uint32_t decode_sig_run(PS& s, const VReg& vctx, int n_start)
 }
 #endif
 
-PC_DEV int decode_bypass_cxx(PS& s)
+PC_DEV int decode_bypass(PS& s)
 {
   s.value <<= 1;
   s.bits_needed += 1u;
@@ -574,7 +574,7 @@ PC_DEV int decode_bypass_cxx(PS& s)
 }
 // n <= 8 bypass bins at once: n steps of 9.3.4.3.4 are one long division of the scaled window by the scaled
 // range (quotient = the bins, MSB first; remainder = the new offset); at most one byte is needed
-PC_DEV uint32_t decode_bypass_multi_cxx(PS& s, int n)
+PC_DEV uint32_t decode_bypass_multi(PS& s, int n)
 {
   s.value <<= n;
   s.bits_needed += (uint32_t)n;
@@ -586,165 +586,18 @@ PC_DEV uint32_t decode_bypass_multi_cxx(PS& s, int n)
   UReg r = s.value - pc_mul24(q, scaled);
   if (pc_any((int32_t)r < 0)) { q -= 1u; r += scaled; }
   else if (pc_any(r >= scaled)) { q += 1u; r -= scaled; }
+  const uint32_t qmax = (1u << n) - 1u;
+  if (pc_any(q > qmax)) { r += pc_mul24(q - qmax, scaled); q = pc_vec(qmax); }   // only reachable on a corrupt stream
   s.value = r;
-  const uint32_t qs = pc_uni(q), qmax = (1u << n) - 1u;
-  return qs < qmax ? qs : qmax;   // value < range is an invariant of the arithmetic whatever the bytes, EXCEPT after an initialisation from bytes
-}                                 // >= 0xFF00 (no encoder writes them): a corrupt stream must not hand back more than n bits
-#if defined(PC_ASM_BINS)
-// The bypass primitives as single statements for the same reason as the decision bin: the compiler's join of the (rare) window
-// change with the byte refill costs ~14 register copies on every refill, and the wrappers around decode_bypass ~10 instructions a bin.
-//   mode 0: shift, refill, then the compare / division; mode 1: the compare / division only (re-entry after refill_byte() served a
-//   refill the window register could not: flag 1)
-PC_DEV int decode_bypass(PS& s)
-{
-  uint32_t r, st, row;
-  uint32_t pos = pc_uni(s.pos);
-  const uint32_t flim = pc_uni(s.fast_limit);
-  asm volatile(
-    "v_lshlrev_b32 %[val], 1, %[val]\n\t"
-    "v_add_u32 %[bits], 1, %[bits]\n\t"
-    "s_mov_b32 %[r], 0\n\t"
-    "v_cmp_lt_i32_e32 vcc, -1, %[bits]\n\t"
-    "s_cbranch_vccz 1f\n\t"
-    PC_ASM_REFILL("3f")
-    "1:\n\t"
-    "v_cmp_ge_u32_e32 vcc, %[val], %[R]\n\t"
-    "s_cbranch_vccz 9f\n\t"
-    "v_sub_u32 %[val], %[val], %[R]\n\t"
-    "s_mov_b32 %[r], 1\n\t"
-    "s_branch 9f\n"
-    "3:\n\t"
-    "s_mov_b32 %[r], 2\n"
-    "9:\n\t"
-    : [val] "+v"(s.value), [bits] "+v"(s.bits_needed), [pos] "+s"(pos), [r] "=&s"(r), [st] "=&s"(st), [row] "=&s"(row)
-    : [R] "v"(s.range), [win] "v"(s.win), [flim] "s"(flim)
-    : "vcc", "scc");
-  s.pos = pc_uni(pos);
-  r = pc_uni(r);
-  if (__builtin_expect(r > 1u, 0)) {
-    refill_byte(s);
-    r = 0;
-    if (pc_any(s.value >= s.range)) { s.value -= s.range; r = 1; }
-  }
-  return (int)r;
-}
-// up to `max` bypass bins while they are 1 (a unary prefix): the number of 1s; the terminating 0 is consumed unless the count reached max
-PC_DEV int decode_bypass_unary(PS& s, int max)
-{
-  uint32_t cnt = 0, mode = 0;
-  const uint32_t mx = (uint32_t)__builtin_amdgcn_readfirstlane(max);
-  if (mx == 0) return 0;
-  for (;;) {
-    uint32_t flag, st, row;
-    uint32_t pos = pc_uni(s.pos);
-    const uint32_t flim = pc_uni(s.fast_limit);
-    asm volatile(
-      "s_cmp_lg_u32 %[mode], 0\n\t"
-      "s_mov_b32 %[flag], 0\n\t"
-      "s_cbranch_scc1 1f\n"
-      "0:\n\t"
-      "v_lshlrev_b32 %[val], 1, %[val]\n\t"
-      "v_add_u32 %[bits], 1, %[bits]\n\t"
-      "v_cmp_lt_i32_e32 vcc, -1, %[bits]\n\t"
-      "s_cbranch_vccz 1f\n\t"
-      PC_ASM_REFILL("3f")
-      "1:\n\t"
-      "v_cmp_ge_u32_e32 vcc, %[val], %[R]\n\t"
-      "s_cbranch_vccz 9f\n\t"
-      "v_sub_u32 %[val], %[val], %[R]\n\t"
-      "s_add_u32 %[cnt], %[cnt], 1\n\t"
-      "s_cmp_lt_u32 %[cnt], %[mx]\n\t"
-      "s_cbranch_scc1 0b\n\t"
-      "s_branch 9f\n"
-      "3:\n\t"
-      "s_mov_b32 %[flag], 1\n"
-      "9:\n\t"
-      : [val] "+v"(s.value), [bits] "+v"(s.bits_needed), [pos] "+s"(pos), [cnt] "+s"(cnt), [flag] "=&s"(flag), [st] "=&s"(st), [row] "=&s"(row)
-      : [R] "v"(s.range), [win] "v"(s.win), [flim] "s"(flim), [mode] "s"(mode), [mx] "s"(mx)
-      : "vcc", "scc");
-    s.pos = pc_uni(pos);
-    cnt = pc_uni(cnt);
-    if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)flag) == 0, 1)) break;
-    refill_byte(s);
-    mode = 1;
-  }
-  return (int)cnt;
-}
-PC_DEV uint32_t decode_bypass_multi(PS& s, int n)   // 1 <= n <= 8
-{
-  uint32_t q, mode = 0;
-  const uint32_t ns = (uint32_t)__builtin_amdgcn_readfirstlane(n);
-  for (;;) {
-    uint32_t flag, st, row, vt, vl, vn;
-    uint32_t pos = pc_uni(s.pos);
-    const uint32_t flim = pc_uni(s.fast_limit);
-    asm volatile(
-      "s_cmp_lg_u32 %[mode], 0\n\t"
-      "s_mov_b32 %[flag], 0\n\t"
-      "v_cvt_f32_u32 %[vt], %[R]\n\t"
-      "s_cbranch_scc1 1f\n\t"
-      "v_lshlrev_b32 %[val], %[n], %[val]\n\t"
-      "v_add_u32 %[bits], %[n], %[bits]\n\t"
-      "v_cmp_lt_i32_e32 vcc, -1, %[bits]\n\t"
-      "s_cbranch_vccz 1f\n\t"
-      PC_ASM_REFILL("3f")
-      "1:\n\t"
-      "v_rcp_f32 %[vt], %[vt]\n\t"
-      "v_cvt_f32_u32 %[vl], %[val]\n\t"
-      "s_nop 0\n\t"
-      "v_mul_f32 %[vl], %[vl], %[vt]\n\t"
-      "v_cvt_u32_f32 %[vl], %[vl]\n\t"
-      "v_mul_u32_u24 %[vn], %[vl], %[R]\n\t"
-      "v_sub_u32 %[val], %[val], %[vn]\n\t"
-      "v_cmp_ge_u32_e32 vcc, %[val], %[R]\n\t"
-      "s_cbranch_vccnz 4f\n"
-      "2:\n\t"
-      "s_bfm_b32 %[st], %[n], 0\n\t"
-      "v_readfirstlane_b32 %[q], %[vl]\n\t"
-      "s_nop 0\n\t"
-      "s_min_u32 %[q], %[q], %[st]\n\t"
-      "s_branch 9f\n"
-      "4:\n\t"                                   // the estimate was off by one (a quotient within 2^-15 of an integer)
-      "v_cmp_gt_i32_e32 vcc, 0, %[val]\n\t"
-      "s_cbranch_vccz 5f\n\t"
-      "v_add_u32 %[val], %[val], %[R]\n\t"
-      "v_add_u32 %[vl], -1, %[vl]\n\t"
-      "s_branch 2b\n"
-      "5:\n\t"
-      "v_sub_u32 %[val], %[val], %[R]\n\t"
-      "v_add_u32 %[vl], 1, %[vl]\n\t"
-      "s_branch 2b\n"
-      "3:\n\t"
-      "s_mov_b32 %[flag], 1\n\t"
-      "s_mov_b32 %[q], 0\n"
-      "9:\n\t"
-      : [val] "+v"(s.value), [bits] "+v"(s.bits_needed), [pos] "+s"(pos), [q] "=&s"(q), [flag] "=&s"(flag), [st] "=&s"(st), [row] "=&s"(row),
-        [vt] "=&v"(vt), [vl] "=&v"(vl), [vn] "=&v"(vn)
-      : [R] "v"(s.range), [win] "v"(s.win), [flim] "s"(flim), [mode] "s"(mode), [n] "s"(ns)
-      : "vcc", "scc");
-    s.pos = pc_uni(pos);
-    if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)flag) == 0, 1)) break;
-    refill_byte(s);
-    mode = 1;
-  }
   return pc_uni(q);
 }
-#else
-PC_DEV int decode_bypass(PS& s) { return decode_bypass_cxx(s); }
-PC_DEV uint32_t decode_bypass_multi(PS& s, int n) { return decode_bypass_multi_cxx(s, n); }
-PC_DEV int decode_bypass_unary(PS& s, int max)
-{
-  int n = 0;
-  while (n < max && decode_bypass(s)) n++;
-  return n;
-}
-#endif
 PC_DEV int decode_bypass_bits(PS& s, int n)   // n <= 32, MSB first
 {
   uint32_t v = 0;
-  while (n > 0) {   // (one call site: the statement is ~45 instructions)
+  while (n > 0) {
     const int c = n > 8 ? 8 : n;
-    v = (v << c) | decode_bypass_multi(s, c);
+    if (c >= 3) v = (v << c) | decode_bypass_multi(s, c);
+    else { for (int i = 0; i < c; i++) v = (v << 1) | (uint32_t)decode_bypass(s); }
     n -= c;
   }
   return (int)v;
@@ -847,7 +700,8 @@ PC_DEV void flush_coef(PS& s, int16_t* dst, int n2)
 // ---- 7.3.8.11 residual_coding ----------------------------------------------------------------
 PC_DEV int decode_remaining(PS& s, int rice)
 {
-  const int prefix = decode_bypass_unary(s, 32);
+  int prefix = 0;
+  while (prefix < 32 && decode_bypass(s)) prefix++;
   if (prefix >= 32) { s.err = DEV_ERR_SYNTAX; return 0; }
   if (prefix <= 3) return (prefix << rice) + decode_bypass_bits(s, rice);
   return (((1 << (prefix - 3)) + 3 - 1) << rice) + decode_bypass_bits(s, prefix - 3 + rice);
@@ -1269,7 +1123,7 @@ PC_DEV void parse_sao(PS& s, int allow_left, int allow_up)
     const int bd = c ? s.bit_depth_chroma : s.bit_depth_luma;
     const int c_max = (1 << ((bd < 10 ? bd : 10) - 5)) - 1;
     int a[4], sg[4] = {0, 0, 1, 1};
-    for (int i = 0; i < 4; i++) a[i] = decode_bypass_unary(s, c_max);
+    for (int i = 0; i < 4; i++) { int v = 0; while (v < c_max && decode_bypass(s)) v++; a[i] = v; }
     int cls;
     if (type == 1) {
       for (int i = 0; i < 4; i++) sg[i] = a[i] ? decode_bypass(s) : 0;
