@@ -19,9 +19,6 @@ struct BatchLayout {
   uint32_t queue_cap = 0, pool = 0, pool_waves = 0;
   size_t off_rwaves = 0;
   uint32_t num_rwaves = 0;
-  size_t off_lane_subs = 0;             // lane-per-substream parser (parse_lanes_kernel.hip): substream of every lane, 64 per wave
-  uint32_t num_lane_waves = 0;
-  std::vector<uint32_t> lane_subs;      // plan -> fill
   uint32_t num_subs = 0, num_rows = 0, num_waves = 0;
   std::vector<ParseWave> parse_waves;   // plan -> fill
   std::vector<ReconWave> recon_waves;

@@ -127,25 +127,6 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
   }
   b.num_rwaves = (uint32_t)rwaves.size();
   b.off_rwaves = off; off = align_up(off + sizeof(ReconWave) * rwaves.size(), 256);
-  // Lane table of the lane-per-substream parser: substreams sorted by (index inside the picture, picture), 64 per wave — in a large
-  // batch a wave holds the same CTB row of 64 pictures (all lanes busy at the same time); a WPP predecessor (the row above: a smaller
-  // index inside the same picture) is always an earlier entry, i.e. the same wave or one with an earlier ticket.
-  {
-    std::vector<uint32_t>& ls = b.lane_subs;
-    ls.clear();
-    size_t max_subs = 0;
-    for (auto& p : b.pics) max_subs = std::max(max_subs, p.subs.size());
-    std::vector<uint32_t> base((size_t)n);
-    uint32_t sb = 0;
-    for (int i = 0; i < n; i++) { base[(size_t)i] = sb; sb += (uint32_t)b.pics[(size_t)i].subs.size(); }
-    ls.reserve((nsubs + 63u) / 64u * 64u);
-    for (size_t j = 0; j < max_subs; j++)
-      for (int i = 0; i < n; i++)
-        if (j < b.pics[(size_t)i].subs.size()) ls.push_back(base[(size_t)i] + (uint32_t)j);
-    while (ls.size() % 64u) ls.push_back(0xffffffffu);
-    b.num_lane_waves = (uint32_t)(ls.size() / 64u);
-    b.off_lane_subs = off; off = align_up(off + sizeof(uint32_t) * ls.size(), 256);
-  }
   b.params.assign(n, PicParams{});
   uint32_t row_base = 0;
   for (int i = 0; i < n; i++) {
@@ -253,7 +234,6 @@ void layout_batch_fill(BatchLayout& b, const void* const* data, const size_t* si
   memcpy(host + b.off_pics, b.params.data(), sizeof(PicParams) * n);
   memcpy(host + b.off_waves, b.parse_waves.data(), sizeof(ParseWave) * b.parse_waves.size());
   memcpy(host + b.off_rwaves, b.recon_waves.data(), sizeof(ReconWave) * b.recon_waves.size());
-  memcpy(host + b.off_lane_subs, b.lane_subs.data(), sizeof(uint32_t) * b.lane_subs.size());
   Substream* subs = (Substream*)(host + b.off_subs);
   RowDesc* rows = (RowDesc*)(host + b.off_rows);
   uint32_t sub_base = 0, r = 0;
@@ -290,7 +270,6 @@ void layout_batch_fill(BatchLayout& b, const void* const* data, const size_t* si
   });
   b.parse_waves.clear(); b.parse_waves.shrink_to_fit();
   b.recon_waves.clear(); b.recon_waves.shrink_to_fit();
-  b.lane_subs.clear(); b.lane_subs.shrink_to_fit();
 }
 
 }  // namespace hipdec

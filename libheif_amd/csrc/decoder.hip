@@ -175,15 +175,7 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
   HIPDEC_CHECK_HIP(hipMemsetAsync(b.arena + b.off_ctrl, 0, b.ctrl_size, s));
   HIPDEC_CHECK_HIP(hipEventRecord(ev[0], s));
   if (int rc = step("memset")) return rc;
-  // Two CABAC kernels: one wave per substream (parse_core.h; lowest latency, scalar-pipe bound in throughput) and one LANE per substream
-  // (parse_lanes_kernel.hip; 64 substreams per wave in lockstep, for batches with thousands of substreams).  HIPDEC_PARSE_LANES=0/1 forces one.
-  pa.lane_subs = (const uint32_t*)(b.arena + b.off_lane_subs); pa.num_lane_waves = b.num_lane_waves;
-  static const int lanes_forced = getenv("HIPDEC_PARSE_LANES") ? atoi(getenv("HIPDEC_PARSE_LANES")) : -1;
-  static const uint32_t lanes_from = getenv("HIPDEC_PARSE_LANES_FROM") ? (uint32_t)atoi(getenv("HIPDEC_PARSE_LANES_FROM")) : 0xffffffffu;
-  bool lanes = lanes_forced >= 0 ? lanes_forced != 0 : b.num_subs >= lanes_from;
-  if (lanes) for (const PicParams& P : b.params) if (P.pcm_enabled) { lanes = false; break; }   // pcm_sample is only in the wave-per-substream parser
-  if (lanes) for (const ParsedPicture& pp : b.pics) if (pp.uses_end_sync) { lanes = false; break; }   // ... and so are dependent slice segments
-  if (lanes) launch_parse_lanes(pa, s); else launch_parse(pa, s);
+  launch_parse(pa, s);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[1], s));
   if (int rc = step("parse")) return rc;
   if (split) HIPDEC_CHECK_HIP(hipStreamWaitEvent(ps, ev[1], 0));

@@ -24,9 +24,9 @@
 
 namespace hipdec {
 
-enum : int { CTX_STORE = 768,      // bytes per saved context table: 3 register groups x 64 lanes x 1 dword (parse_core.h)
-              HANDOFF_DWORDS = 16,
-              SAVE_DWORDS = 7 * 64 }; // suspended-row state: 6 lane-indexed registers + one row of scalars (pool scheduler)  // per-CTB record handed to the CTB below (SAO parameters + bottom-row sizes)
+enum : int { CTX_STORE = 192,      // bytes per saved context table: 3 groups x 64 context variables x 1 byte (parse_core.h)
+              HANDOFF_DWORDS = 16, // per-CTB record handed to the CTB below (SAO parameters + bottom-row sizes)
+              SAVE_DWORDS = 96 };  // suspended-row state (pool scheduler): 84 dwords used, see parse_core.h "parked row state"
 
 enum : uint8_t {
   UF_CBF_LUMA = 1, UF_CBF_CB = 2, UF_CBF_CR = 4, UF_BYPASS = 8, UF_PCM = 16, UF_VEDGE = 32, UF_HEDGE = 64, UF_TS_LUMA = 128
@@ -163,9 +163,6 @@ struct ParseArgs {
   uint32_t* saved;       // per substream: SAVE_DWORDS of suspended state
   uint32_t yield_ctbs;   // test knob (0 = off): a row yields after this many CTBs per activation
   uint32_t wake_hyst;    // a parked row is woken when its predecessor is this many CTBs beyond the minimum distance
-  // ---- lane-per-substream parser (parse_lanes_kernel.hip) ----
-  const uint32_t* lane_subs;   // substream of lane l of wave w at [w * 64 + l], 0xffffffff = idle lane
-  uint32_t num_lane_waves;
 };
 
 }  // namespace hipdec

@@ -118,6 +118,7 @@ namespace pcore {
 
 struct Lds {
   alignas(16) int16_t coef[32 * 32];  // coefficient block being parsed (zero outside the parse of a block)
+  alignas(16) uint32_t park[SAVE_DWORDS];   // staging image of a parked row's record (save_row_state / load_row_state)
 };
 
 // everything here is wave-uniform unless it is a VReg
@@ -135,7 +136,7 @@ struct PS {
   VReg t_lps, t_next;
   VReg win, win_next;
   VReg m_size, m_flags, m_ipm, m_ipmc, m_qp;  // 4 units per lane, z-scan order
-  VReg p_size, p_ipm;                           // previous CTB (left neighbour)
+  VReg p_left;                                  // left neighbour CTB: lane y = size byte | intra mode byte << 8 of its rightmost unit in unit row y
   VReg up;                                      // hand-off record of the CTB above: lanes 0..8 SaoParams dwords, lanes 9..12 the
                                                 //   size bytes of its bottom unit row (4 units per lane)
   VReg sao, sao_left;                           // lanes 0..8: 3 dwords per component (SaoParams)
@@ -653,7 +654,7 @@ PC_DEV void load_tables(PS& s)
 PC_DEV int left_cb_log2(PS& s, int ux, int uy)
 {
   if (ux > 0) return (int)(map_get(s.m_size, (int)interleave4((uint32_t)ux - 1, (uint32_t)uy)) >> 4);
-  if (s.ctb_avail & AV_LEFT) return (int)(map_get(s.p_size, (int)interleave4((uint32_t)(1 << (s.log2_ctb - 2)) - 1, (uint32_t)uy)) >> 4);
+  if (s.ctb_avail & AV_LEFT) return (int)((pc_rdlane(s.p_left, uy) & 255u) >> 4);
   return 0;
 }
 PC_DEV int up_cb_log2(PS& s, int ux, int uy)
@@ -990,7 +991,6 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
   const int n_part = part_nxn ? 4 : 1;
   const int pu_units = n_units / n_part;                    // units per PU (contiguous quadrant)
   const int pu_w = 1 << (log2cb - 2 - (part_nxn ? 1 : 0));  // PU width in units
-  const int uw = 1 << (s.log2_ctb - 2);
   uint32_t prev_flags = 0;
   for (int k = 0; k < n_part; k++) prev_flags |= (uint32_t)decode_bin(s, s.ctxA, A_PREV_INTRA_LUMA) << k;
   for (int k = 0; k < n_part; k++) {
@@ -1000,7 +1000,7 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
     const int ux = ux0 + (k & 1) * pu_w, uy = uy0 + (k >> 1) * pu_w;
     int cand_a = 1, cand_b = 1;
     if (ux > 0) cand_a = (int)(map_get(s.m_ipm, (int)interleave4((uint32_t)ux - 1, (uint32_t)uy)) & 63u);
-    else if (s.ctb_avail & AV_LEFT) cand_a = (int)(map_get(s.p_ipm, (int)interleave4((uint32_t)uw - 1, (uint32_t)uy)) & 63u);
+    else if (s.ctb_avail & AV_LEFT) cand_a = (int)((pc_rdlane(s.p_left, uy) >> 8) & 63u);
     if (uy > 0) cand_b = (int)(map_get(s.m_ipm, (int)interleave4((uint32_t)ux, (uint32_t)uy - 1)) & 63u);  // above CTB row: INTRA_DC (8.4.2)
     int c0, c1, c2;
     if (cand_a == cand_b) {
@@ -1155,6 +1155,9 @@ PC_DEV void pc_publish(uint32_t* word, uint32_t v) { *word = v; }
 PC_DEV void pc_report(int32_t* status, int32_t code) { if (*status == 0) *status = code; }
 PC_DEV void pc_store_wt(uint32_t* p, uint32_t v) { *p = v; }
 PC_DEV uint32_t pc_load_wt(const uint32_t* p) { return *p; }
+PC_DEV void pc_store16_wt(uint32_t* p, const uint32_t* v) { memcpy(p, v, 16); }
+PC_DEV void pc_load16_wt(uint32_t* v, const uint32_t* p) { memcpy(v, p, 16); }
+#define PC_GATHER(r, idx) ((r).v[(idx) & 63])   /* value of lane idx; only inside PC_VEC_BEGIN .. PC_VEC_END, r not written there */
 PC_DEV void pc_drain() {}
 // returned (completed-before-continuing) atomics of the pool scheduler; the emulation is single threaded
 PC_DEV uint32_t pc_atomic_exch(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = v; return o; }
@@ -1185,6 +1188,21 @@ PC_DEV void pc_publish(uint32_t* word, uint32_t v)
 PC_DEV void pc_report(int32_t* status, int32_t code) { if (threadIdx.x == 0) atomicCAS((int*)status, 0, code); }
 PC_DEV void pc_store_wt(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 PC_DEV uint32_t pc_load_wt(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16 bytes per lane, write-through / L1-bypassing (sc1): a relaxed agent-scope atomic lowers to sc1 only up to 8 bytes, and narrow sc1
+// stores are one fabric write per LANE (microarch guide), so the parked record travels as 21 x 16 B instead of 448 x 4 B
+typedef uint32_t PcU4 __attribute__((ext_vector_type(4)));
+PC_DEV void pc_store16_wt(uint32_t* p, const uint32_t* v)
+{
+  const PcU4 d = *(const PcU4*)v;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
+}
+PC_DEV void pc_load16_wt(uint32_t* v, const uint32_t* p)
+{
+  PcU4 d;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(d) : "v"(p) : "memory");
+  *(PcU4*)v = d;
+}
+#define PC_GATHER(r, idx) ((uint32_t)__shfl((int)(r), (int)(idx)))
 // returned atomics by lane 0, result broadcast: the wave continues only after the operation was performed at the
 // device-wide coherence point, which gives the store->load ordering the suspend / wake-up handshake relies on
 // (the empty asm consumes the broadcast result so that the compiler can neither drop the return path — a no-return
@@ -1241,25 +1259,79 @@ PC_DEV void pool_wake_dependent(const ParseArgs& A, int32_t dependent, uint32_t 
   if (w != 0 && done >= w && pc_atomic_cas(A.waitneed + dependent, w, 0u) == w) pool_push(A, (uint32_t)dependent);
 }
 
-// suspended-row state -> HBM (write-through, drained): six lane-indexed registers + one row of scalars
+// ---- parked row state ------------------------------------------------------------------------------------------------------------
+// What a row needs to continue on another wave: the context variables (one byte each: p' | valMps << 6), the left neighbour column,
+// the left CTB's SAO parameters and 11 scalars — 84 dwords.  The image is assembled in LDS and leaves as 21 write-through 16-byte
+// stores (round 2 parked six whole registers: 448 dword stores, each a fabric write of its own: profiles/pmc_traffic.json 4.7 B/px).
+//   dwords  0..47  ctxA | ctxB | ctxC, byte = lane        48..63  p_left lanes 0..15        64..72  sao_left        73..83  scalars
+enum : int { PARK_CTX = 0, PARK_LEFT = 48, PARK_SAO = 64, PARK_SCALARS = 73, PARK_USED = 84 };
+static_assert((int)PARK_USED <= (int)SAVE_DWORDS && PARK_USED % 4 == 0, "parked record");
+PC_DEV uint32_t ctx_pack(uint32_t v) { return (v & 63u) | ((v >> 16) << 6); }
+PC_DEV uint32_t ctx_unpack(uint32_t b) { return (b & 63u) | ((b >> 6) << 16); }
+PC_DEV void stage_contexts(PS& s)   // -> bytes 0 .. 191 of the LDS image
+{
+  uint8_t* pb = (uint8_t*)s.L->park;
+  PC_VEC_BEGIN
+    pb[lane] = (uint8_t)ctx_pack(PC_L(s.ctxA)); pb[64 + lane] = (uint8_t)ctx_pack(PC_L(s.ctxB)); pb[128 + lane] = (uint8_t)ctx_pack(PC_L(s.ctxC));
+  PC_VEC_END
+}
+PC_DEV void unstage_contexts(PS& s)
+{
+  const uint8_t* pb = (const uint8_t*)s.L->park;
+  PC_VEC_BEGIN
+    PC_L(s.ctxA) = ctx_unpack(pb[lane]); PC_L(s.ctxB) = ctx_unpack(pb[64 + lane]); PC_L(s.ctxC) = ctx_unpack(pb[128 + lane]);
+  PC_VEC_END
+}
+PC_DEV void park_flush(PS& s, uint32_t* dst, int dwords)   // LDS image -> HBM, write-through; the caller drains
+{
+  PC_LDS_SYNC();
+  PC_VEC_BEGIN if (lane * 4 < dwords) pc_store16_wt(dst + lane * 4, s.L->park + lane * 4); PC_VEC_END
+}
+PC_DEV void park_fetch(PS& s, const uint32_t* src, int dwords)
+{
+  PC_LDS_SYNC();
+  PC_VEC_BEGIN if (lane * 4 < dwords) pc_load16_wt(s.L->park + lane * 4, src + lane * 4); PC_VEC_END
+  PC_LDS_SYNC();
+}
 // resume_word: where the CTB index to resume at goes (a suspended row), or nullptr (the END state of a finished substream, which the first
-// substream of a dependent slice segment continues: contexts, left-neighbour maps, SAO parameters, QP state)
+// substream of a dependent slice segment continues: contexts, left-neighbour column, SAO parameters, QP state)
 PC_DEV void save_row_state(PS& s, uint32_t* resume_word, uint32_t* saved, uint32_t k)
 {
-  VReg sc;
+  stage_contexts(s);
+  uint32_t* pd = s.L->park;
   PC_VEC_BEGIN
     uint32_t v = 0;
     if (lane == 0) v = s.range; else if (lane == 1) v = s.value; else if (lane == 2) v = s.bits_needed;
     else if (lane == 3) v = s.pos; else if (lane == 4) v = s.end; else if (lane == 5) v = (uint32_t)s.zeros;
     else if (lane == 6) v = (uint32_t)s.last_qp_y; else if (lane == 7) v = (uint32_t)s.qpy_pred; else if (lane == 8) v = (uint32_t)s.cur_qp_y;
     else if (lane == 9) v = (uint32_t)s.is_cu_qp_delta_coded; else if (lane == 10) v = (uint32_t)s.cu_qp_delta_val;
-    PC_L(sc) = v;
-    pc_store_wt(saved + lane, PC_L(s.ctxA)); pc_store_wt(saved + 64 + lane, PC_L(s.ctxB)); pc_store_wt(saved + 128 + lane, PC_L(s.ctxC));
-    pc_store_wt(saved + 192 + lane, PC_L(s.p_size)); pc_store_wt(saved + 256 + lane, PC_L(s.p_ipm)); pc_store_wt(saved + 320 + lane, PC_L(s.sao_left));
-    pc_store_wt(saved + 384 + lane, PC_L(sc));
-    if (lane == 0 && resume_word) pc_store_wt(resume_word, k);
+    if (lane < 16) pd[PARK_LEFT + lane] = PC_L(s.p_left);
+    if (lane < 9) pd[PARK_SAO + lane] = PC_L(s.sao_left);
+    if (lane < 11) pd[PARK_SCALARS + lane] = v;
   PC_VEC_END
+  park_flush(s, saved, PARK_USED);
+  PC_VEC_BEGIN if (lane == 0 && resume_word) pc_store_wt(resume_word, k); PC_VEC_END
   pc_drain();
+}
+// the inverse; `all` = 0 leaves the arithmetic decoder alone (a dependent slice segment starts its own)
+PC_DEV void load_row_state(PS& s, const uint32_t* saved, int all)
+{
+  park_fetch(s, saved, PARK_USED);
+  unstage_contexts(s);
+  const uint32_t* pd = s.L->park;
+  VReg sc;
+  PC_VEC_BEGIN
+    PC_L(s.p_left) = lane < 16 ? pd[PARK_LEFT + lane] : 0u;
+    PC_L(s.sao_left) = lane < 9 ? pd[PARK_SAO + lane] : 0u;
+    PC_L(sc) = lane < 11 ? pd[PARK_SCALARS + lane] : 0u;
+  PC_VEC_END
+  PC_LDS_SYNC();
+  if (all) {
+    s.range = pc_vec(pc_rdlane(sc, 0)); s.value = pc_vec(pc_rdlane(sc, 1)); s.bits_needed = pc_vec(pc_rdlane(sc, 2));
+    s.pos = pc_rdlane(sc, 3); s.end = pc_rdlane(sc, 4); s.zeros = (int32_t)pc_rdlane(sc, 5); s.win_base = 0xfffff000u; s.fast_limit = 0;
+  }
+  s.last_qp_y = (int32_t)pc_rdlane(sc, 6); s.qpy_pred = (int32_t)pc_rdlane(sc, 7); s.cur_qp_y = (int32_t)pc_rdlane(sc, 8);
+  s.is_cu_qp_delta_coded = (int32_t)pc_rdlane(sc, 9); s.cu_qp_delta_val = (int32_t)pc_rdlane(sc, 10);
 }
 
 enum : int { PARSE_DONE = 0, PARSE_SUSPENDED = -1 };   // > 0: device error code
@@ -1324,25 +1396,14 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
   load_tables(s);
   PC_VEC_BEGIN
     PC_L(s.m_size) = 0; PC_L(s.m_flags) = 0; PC_L(s.m_ipm) = 0; PC_L(s.m_ipmc) = 0; PC_L(s.m_qp) = 0;
-    PC_L(s.p_size) = 0; PC_L(s.p_ipm) = 0; PC_L(s.up) = 0; PC_L(s.sao) = 0; PC_L(s.sao_left) = 0;
+    PC_L(s.p_left) = 0; PC_L(s.up) = 0; PC_L(s.sao) = 0; PC_L(s.sao_left) = 0;
     PC_L(s.ctxA) = 0; PC_L(s.ctxB) = 0; PC_L(s.ctxC) = 0; PC_L(s.win) = 0; PC_L(s.win_next) = 0;
   PC_VEC_END
   uint32_t k0 = 0;
   uint32_t* saved = A.saved + (size_t)sub_idx * SAVE_DWORDS;
   if (pool) k0 = pc_load_wt_uni(A.resume_k + sub_idx);
   if (k0 == 0) cabac_start(s, byte_start, byte_end);
-  else {   // resume a suspended row: six lane-indexed registers + one row of scalars
-    VReg sc;
-    PC_VEC_BEGIN
-      PC_L(s.ctxA) = pc_load_wt(saved + lane); PC_L(s.ctxB) = pc_load_wt(saved + 64 + lane); PC_L(s.ctxC) = pc_load_wt(saved + 128 + lane);
-      PC_L(s.p_size) = pc_load_wt(saved + 192 + lane); PC_L(s.p_ipm) = pc_load_wt(saved + 256 + lane); PC_L(s.sao_left) = pc_load_wt(saved + 320 + lane);
-      PC_L(sc) = pc_load_wt(saved + 384 + lane);
-    PC_VEC_END
-    s.range = pc_vec(pc_rdlane(sc, 0)); s.value = pc_vec(pc_rdlane(sc, 1)); s.bits_needed = pc_vec(pc_rdlane(sc, 2));
-    s.pos = pc_rdlane(sc, 3); s.end = pc_rdlane(sc, 4); s.zeros = (int32_t)pc_rdlane(sc, 5); s.win_base = 0xfffff000u; s.fast_limit = 0;
-    s.last_qp_y = (int32_t)pc_rdlane(sc, 6); s.qpy_pred = (int32_t)pc_rdlane(sc, 7); s.cur_qp_y = (int32_t)pc_rdlane(sc, 8);
-    s.is_cu_qp_delta_coded = (int32_t)pc_rdlane(sc, 9); s.cu_qp_delta_val = (int32_t)pc_rdlane(sc, 10);
-  }
+  else load_row_state(s, saved, 1);   // resume a suspended row
 
   for (uint32_t k = k0; k < num_ctbs && !s.err; k++) {
     if (pool && A.yield_ctbs && k > k0 && (k - k0) % A.yield_ctbs == 0) {   // test knob: forced yield every N CTBs
@@ -1380,20 +1441,11 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
       if (wpp_sync == 2 && dep_sub >= 0) {
         // first CTB of a dependent slice segment (9.3.1, 9.3.2.4): everything but the arithmetic decoder continues where the preceding slice
         // segment ended — context variables, the CTB to the left (same slice: available), its SAO parameters, qPY_PREV (8.6.1)
-        const uint32_t* src = A.saved + (size_t)dep_sub * SAVE_DWORDS;
-        VReg sc;
-        PC_VEC_BEGIN
-          PC_L(s.ctxA) = pc_load_wt(src + lane); PC_L(s.ctxB) = pc_load_wt(src + 64 + lane); PC_L(s.ctxC) = pc_load_wt(src + 128 + lane);
-          PC_L(s.p_size) = pc_load_wt(src + 192 + lane); PC_L(s.p_ipm) = pc_load_wt(src + 256 + lane); PC_L(s.sao_left) = pc_load_wt(src + 320 + lane);
-          PC_L(sc) = pc_load_wt(src + 384 + lane);
-        PC_VEC_END
-        s.last_qp_y = (int32_t)pc_rdlane(sc, 6); s.qpy_pred = (int32_t)pc_rdlane(sc, 7); s.cur_qp_y = (int32_t)pc_rdlane(sc, 8);
-        s.is_cu_qp_delta_coded = (int32_t)pc_rdlane(sc, 9); s.cu_qp_delta_val = (int32_t)pc_rdlane(sc, 10);
+        load_row_state(s, A.saved + (size_t)dep_sub * SAVE_DWORDS, 0);
       } else if (wpp_sync && dep_sub >= 0) {
-        const uint32_t* src = (const uint32_t*)(A.ctx_store + (size_t)dep_sub * CTX_STORE);
-        PC_VEC_BEGIN
-          PC_L(s.ctxA) = pc_load_wt(src + lane); PC_L(s.ctxB) = pc_load_wt(src + 64 + lane); PC_L(s.ctxC) = pc_load_wt(src + 128 + lane);
-        PC_VEC_END
+        park_fetch(s, (const uint32_t*)(A.ctx_store + (size_t)dep_sub * CTX_STORE), CTX_STORE / 4);
+        unstage_contexts(s);
+        PC_LDS_SYNC();
       } else init_contexts(s);
     }
     // ---- hand-off record of the CTB above ----
@@ -1477,8 +1529,17 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
         }
         if (lane < 9) sao_dst[lane] = PC_L(s.sao);
         // this CTB becomes the left neighbour of the next one
-        PC_L(s.p_size) = PC_L(s.m_size); PC_L(s.p_ipm) = PC_L(s.m_ipm); PC_L(s.sao_left) = PC_L(s.sao);
+        PC_L(s.sao_left) = PC_L(s.sao);
       PC_VEC_END
+      {   // the rightmost unit column, one unit row per lane (what split_cu_flag's context and the MPM candidate A look at)
+        VReg col;
+        PC_VEC_BEGIN
+          const uint32_t z = interleave4((uint32_t)uw - 1u, (uint32_t)lane & 15u);
+          const uint32_t sz = (PC_GATHER(s.m_size, z >> 2) >> ((z & 3u) * 8u)) & 255u, im = (PC_GATHER(s.m_ipm, z >> 2) >> ((z & 3u) * 8u)) & 255u;
+          PC_L(col) = (lane < uw) ? (sz | (im << 8)) : 0u;
+        PC_VEC_END
+        PC_VEC_BEGIN PC_L(s.p_left) = PC_L(col); PC_VEC_END
+      }
       // hand-off record for the CTB below: lanes 0..8 SAO, 9..12 bottom-row size bytes
       {
         VReg rec;
@@ -1495,10 +1556,8 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
       }
       if (has_dependent == 2 && k + 1 == num_ctbs) save_row_state(s, nullptr, saved, num_ctbs);   // (the registers already hold this CTB as "the previous one")
       if (has_dependent == 1 && k == 1) {
-        uint32_t* dst = (uint32_t*)(A.ctx_store + (size_t)sub_idx * CTX_STORE);
-        PC_VEC_BEGIN
-          pc_store_wt(dst + lane, PC_L(s.ctxA)); pc_store_wt(dst + 64 + lane, PC_L(s.ctxB)); pc_store_wt(dst + 128 + lane, PC_L(s.ctxC));
-        PC_VEC_END
+        stage_contexts(s);
+        park_flush(s, (uint32_t*)(A.ctx_store + (size_t)sub_idx * CTX_STORE), CTX_STORE / 4);
       }
     }
     if (!pool) { if (has_dependent) pc_publish(A.progress + sub_idx, k + 1); else pc_drain(); }

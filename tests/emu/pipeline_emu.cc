@@ -11,23 +11,6 @@ using namespace hipdec;
 
 extern "C" {
 
-// the lane-per-substream parser (libheif_amd/csrc/parse_lanes_kernel.hip) under the SIMT shim: same outputs as emu_run_parse()
-int emu_run_parse_lanes(EmuBatch* b)
-{
-  uint8_t* a = b->arena.data();
-  const BatchLayout& L = b->L;
-  memset(a + L.off_ctrl, 0, L.ctrl_size);
-  ParseArgs A{};
-  A.pics = (const PicParams*)(a + L.off_pics); A.subs = (const Substream*)(a + L.off_subs); A.arena = a;
-  A.progress = (uint32_t*)(a + L.off_progress); A.ctx_store = a + L.off_ctx;
-  A.ticket = (uint32_t*)(a + L.off_ticket); A.status = (int32_t*)(a + L.off_status);
-  A.num_subs = L.num_subs;
-  A.lane_subs = (const uint32_t*)(a + L.off_lane_subs); A.num_lane_waves = L.num_lane_waves;
-  launch_parse_lanes(A, nullptr);
-  b->status = *(int32_t*)(a + L.off_status);
-  return b->status;
-}
-
 // stages: bit 0 residual, 1 recon, 2 deblock, 3 sao, 4 sao with the RGB24 emission fused into its store path (then `rgb` receives the
 // interleaved rows of every item, tightly packed one after the other).  Returns the device status word.
 int emu_run_pipeline_rgb(EmuBatch* b, int stages, uint8_t* rgb);

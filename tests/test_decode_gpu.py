@@ -423,13 +423,3 @@ def test_run_rgb_fused_sao_colour_equals_the_two_step_path(cfg):
         t = f.kernel_timing_us()
         assert (t["colour"] == 0.0) == (bd == 8)               # fused: no separate colour kernel was timed
         a.free(); f.free()
-
-
-def test_lane_parser_on_the_gpu():
-    """the lane-per-substream CABAC kernel (parse_lanes_kernel.hip; an alternative, never the default — DESIGN.md §4) in a process of its own"""
-    import subprocess
-    import sys
-    env = dict(os.environ, HIPDEC_PARSE_LANES="1")
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lanes_child.py")], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert "bit-exact" in r.stdout

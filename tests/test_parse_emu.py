@@ -23,7 +23,6 @@ def emu():
         L.emu_create.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
         L.emu_free.argtypes = [C.c_void_p]
         L.emu_run_parse.argtypes = [C.c_void_p]
-        L.emu_run_parse_lanes.argtypes = [C.c_void_p]
         L.emu_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.emu_maps.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
         L.emu_coeffs.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3
@@ -32,7 +31,7 @@ def emu():
     return _LIB
 
 
-def run_emu(streams, lanes=False):
+def run_emu(streams):
     L = emu()
     n = len(streams)
     arr = (C.c_char_p * n)(*streams)
@@ -40,7 +39,7 @@ def run_emu(streams, lanes=False):
     err = C.create_string_buffer(512)
     h = L.emu_create(n, arr, sizes, err, 512)
     assert h, err.value.decode()
-    status = (L.emu_run_parse_lanes if lanes else L.emu_run_parse)(h)
+    status = L.emu_run_parse(h)
     out = []
     if status != 0:   # maps / coefficients of a desynchronised parse are garbage: do not walk them
         L.emu_free(h)
@@ -226,50 +225,3 @@ def test_missing_dependent_segment_is_a_device_error():
     except AssertionError:
         return          # refused by the host front end: also fine
     assert status != 0
-
-
-# ---- the lane-per-substream parser (libheif_amd/csrc/parse_lanes_kernel.hip) under the SIMT shim ------------------------------------
-@pytest.mark.parametrize("cfg", [c for c in CONFIGS if "pcm_pct" not in c and ("dependent_segments" not in c or c.get("wpp", 1))],   # (pcm_sample is only in the wave-per-substream parser; the product never
-                         ids=lambda c: ",".join("%s=%s" % kv for kv in c.items()) or "default")   #  hands a PCM stream to the lane parser)
-@pytest.mark.parametrize("size", [(200, 136), (64, 64), (328, 72)])
-def test_lane_parser_emulation_matches_oracle(cfg, size):
-    bd = cfg.get("bit_depth", 8)
-    planes = orc.synth_image(size[0], size[1], bd, 1, seed=3 + size[0])
-    stream = orc.encode(planes, **cfg)
-    status, got = run_emu([stream], lanes=True)
-    assert status == 0, "device status 0x%x" % status
-    check_against_oracle(stream, got[0])
-
-
-def test_lane_parser_emulation_batch_mixes_pictures_in_a_wave():
-    """more pictures than one wave has lanes, of different sizes / tools: lanes of one wave hold the same row of different pictures,
-    WPP predecessors sit in the same wave (small pictures) or in an earlier one"""
-    streams = []
-    shapes = [(75, 41, 0), (70, 42, 1), (8, 8, 1), (136, 24, 1), (264, 200, 1), (64, 200, 1), (328, 72, 1)]
-    for i in range(70):
-        w, h, cf = shapes[i % len(shapes)]
-        streams.append(orc.encode(orc.synth_image(w, h, 8, cf, seed=100 + i), wpp=(i % 3 != 0), stress=i % 4 == 0, qp=20 + (i % 5) * 5,
-                                  tile_cols=2 if i % 7 == 3 else 1, num_slices=2 if i % 11 == 5 else 1))
-    status, got = run_emu(streams, lanes=True)
-    assert status == 0
-    for s, g in zip(streams, got):
-        check_against_oracle(s, g)
-
-
-def test_lane_parser_emulation_reports_desync():
-    stream = bytearray(orc.encode(orc.synth_image(128, 128, 8, 1, seed=9)))
-    for k in range(len(stream) - 80, len(stream) - 30):
-        stream[k] ^= 0x5A
-    status, _ = run_emu([bytes(stream)], lanes=True)
-    assert status != 0
-
-
-def test_lane_parser_emulation_reference_fixtures(reference_dir):
-    from heic_util import HeicFile
-    for rel in ("examples/example.heic", "tests/data/rainbow-451x461.heic", "tests/data/with-alpha-512x512.heic"):
-        f = HeicFile(os.path.join(reference_dir, rel))
-        for iid in f.hevc_items():
-            s = f.plugin_stream(iid)
-            status, got = run_emu([s], lanes=True)
-            assert status == 0, rel
-            check_against_oracle(s, got[0])

@@ -75,6 +75,15 @@ for ln, c in st_line.items():
     for (key, cls), cc in static_cls.items():
         if key[1] == ln and key[0].endswith(srcname): cls_tot[cls] += cc / k * count(ln)
 print("by class (S salu, V valu, B branch, N nop/waitcnt, M memory/lds):", {k: round(v / (px or 1), 2) for k, v in cls_tot.items()})
+srows = []
+for (key, cls), cc in static_cls.items():
+    if cls == "S" and key[0].endswith(srcname) and key[1]:
+        ln = key[1]; k = max(1, copies.get(func_at.get(ln, "?"), 1))
+        srows.append((cc / k * count(ln), ln, cc / k, count(ln)))
+srows.sort(reverse=True)
+if os.environ.get("SALU"):
+    print("-- top SALU lines")
+    for d, ln, c, k in srows[:int(os.environ.get("TOPN", "45"))]: print("%5.2f/px line %4d static %5.1f x %9.0f  %s" % (d / (px or 1), ln, c, k, text[ln].strip()[:100]))
 rows.sort(reverse=True)
 print("estimated dynamic wave-instructions: %.3g%s" % (tot, (" = %.1f per pixel" % (tot / px)) if px else ""))
 byf = collections.Counter()

@@ -10,13 +10,13 @@ from oracle import pyoracle as orc
 L = C.CDLL(os.path.join(ROOT, 'build/asan/libparse_emu_asan.so'))
 L.emu_create.restype = C.c_void_p
 L.emu_create.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
-L.emu_free.argtypes=[C.c_void_p]; L.emu_upload_hash.restype=C.c_uint64; L.emu_upload_hash.argtypes=[C.c_void_p]; L.emu_run_parse.argtypes=[C.c_void_p]; L.emu_run_parse_lanes.argtypes=[C.c_void_p]; L.emu_run_pipeline.argtypes=[C.c_void_p, C.c_int]
+L.emu_free.argtypes=[C.c_void_p]; L.emu_upload_hash.restype=C.c_uint64; L.emu_upload_hash.argtypes=[C.c_void_p]; L.emu_run_parse.argtypes=[C.c_void_p]; L.emu_run_pipeline.argtypes=[C.c_void_p, C.c_int]
 def run(s):
     arr=(C.c_char_p*1)(s); sizes=(C.c_size_t*1)(len(s)); err=C.create_string_buffer(512)
     h=L.emu_create(1,arr,sizes,err,512)
     if not h: return 'rejected: '+err.value.decode()[:60]
     h0=L.emu_upload_hash(h)
-    st=(L.emu_run_parse_lanes if os.environ.get('HIPDEC_FUZZ_LANES') else L.emu_run_parse)(h)   # HIPDEC_FUZZ_LANES=1: the lane-per-substream parser
+    st=L.emu_run_parse(h)
     if st==0: st=L.emu_run_pipeline(h,15)
     assert L.emu_upload_hash(h)==h0, "a kernel wrote into the read-only upload region"
     L.emu_free(h)
