@@ -124,6 +124,13 @@ HIPDEC_API int hipdec_decoder_read_plane(hipdec_decoder* dec, int c, void* dst_h
 /* the same, and remembers (host pointer -> device copy) so that hipdec_color_convert() on those very host planes skips the upload:
  * what the libheif plugin uses */
 HIPDEC_API int hipdec_decoder_read_plane_tracked(hipdec_decoder* dec, int c, void* dst_host, size_t dst_stride);
+/* Plane tracking on / off (default off; HIPDEC_TRACK_PLANES=1 in the environment turns it on).  While it is on,
+ * hipdec_decoder_read_plane_tracked() records a hash over EVERY byte of the plane it copied out, so that a later
+ * hipdec_color_convert() on the same host pointer can read the decoder's device copy instead of uploading — but only if the host
+ * bytes are still exactly those (libheif edits planes in place between decode and conversion: image_item.cc:969 mirror_inplace).
+ * An entry serves one conversion.  The plugin switches tracking on when the hosting libheif registers the HIP colour op
+ * (INTEGRATION.md §4); the first hipdec_color_convert() call switches it on as well. */
+HIPDEC_API void hipdec_set_plane_tracking(int on);
 /* drops every remembered (host pointer -> device copy) pair and with them the decode arenas they keep alive; hipdec_shutdown() and the
  * plugin's deinit_plugin() call it */
 HIPDEC_API void hipdec_forget_resident_planes(void);

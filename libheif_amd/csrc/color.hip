@@ -442,6 +442,7 @@ int color_capture_take(ColorBatchState& st, hipStream_t s, const void** dev, int
     HIPDEC_CHECK_HIP(arena_acquire(&st.dev, bytes, &st.dev_bytes));
   }
   if (st.host != host) {
+    st.prev.swap(st.host);   // (not freed while its copy may be pending)
     st.host.swap(host);
     HIPDEC_CHECK_HIP(hipMemcpyAsync(st.dev, st.host.data(), bytes, hipMemcpyHostToDevice, s));
   }
@@ -482,6 +483,7 @@ int color_capture_launch(ColorBatchState& st, hipStream_t s)
     HIPDEC_CHECK_HIP(arena_acquire(&st.dev, bytes, &st.dev_bytes));
   }
   if (st.host != host) {   // steady state (same planes, same outputs): nothing to upload
+    st.prev.swap(st.host);   // (not freed while its copy may be pending)
     st.host.swap(host);
     HIPDEC_CHECK_HIP(hipMemcpyAsync(st.dev, st.host.data(), bytes, hipMemcpyHostToDevice, s));
   }

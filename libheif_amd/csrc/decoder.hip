@@ -103,6 +103,11 @@ int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* s
     if (recycle->done_recorded) after = recycle->done;
     recycle->retired = true;
   }
+  // if anything below fails, the arena goes back to the pool with this batch: not before the retired batch's kernels have left it
+  struct TakeoverGuard {
+    hipEvent_t after; bool ok;
+    ~TakeoverGuard() { if (!ok && after) (void)hipEventSynchronize(after); }
+  } takeover{after, false};
   static const bool sync_upload = getenv("HIPDEC_SYNC_UPLOAD") != nullptr;   // profiling knob: one stream, no cross-stream event waits
   if (b.upload_size > (size_t(4) << 20) && !sync_upload) {
     HIPDEC_CHECK_HIP(pinned_acquire(&b.staging, b.upload_size, &b.staging_capacity));
@@ -123,7 +128,20 @@ int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* s
   b.ev.assign(kEv, nullptr);
   b.colour_timed.assign(1, 0);
   for (auto& e : b.ev) HIPDEC_CHECK_HIP(hipEventCreate(&e));
+  takeover.ok = true;
   return 0;
+}
+
+// The stream follow-up work of a batch (colour stage, packs, pastes) goes on: the caller's, made to wait for the batch's last recorded
+// work when that was enqueued elsewhere — with hipdec_set_stage_overlap(1) the pixel stages of a run leave the caller's stream for the
+// post stream, so a copy queued on the caller's stream right behind hipdec_batch_run() would otherwise read unfinished planes
+//  — or the batch's own last stream.
+hipStream_t follow_stream(hipdec_batch* b, void* stream)
+{
+  if (!stream) return b->last_stream ? b->last_stream : default_stream();
+  hipStream_t s = (hipStream_t)stream;
+  if (s != b->last_stream && b->done_recorded) (void)hipStreamWaitEvent(s, b->done, 0);
+  return s;
 }
 
 int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nullptr)
@@ -328,7 +346,7 @@ int hipdec_batch_pack_item(hipdec_batch* b, int i, void* dst_dev, size_t dst_byt
   if (dst_bytes < hipdec_batch_item_packed_bytes(b, i)) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "pack_item: destination too small");
   const PicParams& P = b->params[i];
   const size_t es = b->wide ? 2 : 1;
-  hipStream_t s = stream ? (hipStream_t)stream : (b->last_stream ? b->last_stream : default_stream());
+  hipStream_t s = follow_stream(b, stream);
   uint8_t* dst = (uint8_t*)dst_dev;
   for (int c = 0; c < (P.chroma_format_idc ? 3 : 1); c++) {
     const size_t w = c ? P.out_cwidth : P.out_width, h = c ? P.out_cheight : P.out_height;
@@ -360,7 +378,7 @@ int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void* out_dev, s
   // the decoder reports the VUI colour description exactly as the libde265 plugin would attach it
   hipdec_nclx nclx{1, I.colour_primaries, I.transfer_characteristics, I.matrix_coeffs, I.full_range_flag};
   const uint8_t* y = b->arena + P.off_out[0]; const uint8_t* cb = b->arena + P.off_out[1]; const uint8_t* cr = b->arena + P.off_out[2];
-  void* s = stream ? stream : (void*)b->last_stream;
+  void* s = stream ? (void*)follow_stream(b, stream) : (void*)b->last_stream;
   struct MarkDone {   // whatever is enqueued below belongs to this batch (hipdec_batch_status / free wait for it)
     hipdec_batch* b; hipStream_t s;
     ~MarkDone() { b->mark_done(s ? s : default_stream()); }
@@ -387,7 +405,7 @@ int hipdec_batch_to_rgb_all(hipdec_batch* b, int out_chroma, void* const* outs_d
 {
   if (!b || !outs_dev || !out_strides) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "to_rgb_all: bad arguments");
   DeviceScope scope(b->device);
-  hipStream_t s = stream ? (hipStream_t)stream : (b->last_stream ? b->last_stream : default_stream());
+  hipStream_t s = follow_stream(b, stream);
   // every item goes through the per-item entry point (argument checks, planner rule, coefficients) in capture mode
   color_capture_begin();
   for (int i = 0; i < (int)b->pics.size(); i++)
@@ -765,30 +783,49 @@ static int decoder_decode_impl(hipdec_decoder* d, hipdec_image_info* info)
       if (req.taken || g_co.collecting) { g_co.cv.wait(lk); continue; }
       // leader: gather the requests of the other threads, then run them as one batch
       g_co.collecting = true;
-      const auto t0 = Clock::now();
-      const auto deadline = t0 + std::chrono::microseconds(window);
-      const bool overlapping = g_co.last_overlap.time_since_epoch().count() != 0 &&
-                               t0 - g_co.last_overlap < std::chrono::milliseconds(250);
-      for (;;) {
-        const auto t = Clock::now();
-        if (t >= deadline) break;
-        int pending_counted = 0;
-        for (auto* r : g_co.pending) pending_counted += r->d->counted ? 1 : 0;
-        const bool joiners = g_co.armed > pending_counted;                                  // instances that exist and have not asked yet
-        const auto quiet_at = g_co.last_arrival + std::chrono::microseconds(g_co.quiet_us);
-        const bool quiet = t >= quiet_at;
-        if (!joiners && (!overlapping || quiet)) break;
-        g_co.cv.wait_until(lk, joiners ? deadline : std::min(deadline, quiet_at));
-      }
       std::vector<DecodeRequest*> take;
-      take.swap(g_co.pending);
-      for (auto* r : take) { r->taken = true; uncount(r->d); }
-      g_co.in_flight += (int)take.size();
-      g_co.collecting = false;
-      g_co.cv.notify_all();
-      lk.unlock();
-      run_requests(take);
-      lk.lock();
+      bool counted_in_flight = false;
+      try {
+        const auto t0 = Clock::now();
+        const auto deadline = t0 + std::chrono::microseconds(window);
+        const bool overlapping = g_co.last_overlap.time_since_epoch().count() != 0 &&
+                                 t0 - g_co.last_overlap < std::chrono::milliseconds(250);
+        for (;;) {
+          const auto t = Clock::now();
+          if (t >= deadline) break;
+          int pending_counted = 0;
+          for (auto* r : g_co.pending) pending_counted += r->d->counted ? 1 : 0;
+          const bool joiners = g_co.armed > pending_counted;                                  // instances that exist and have not asked yet
+          const auto quiet_at = g_co.last_arrival + std::chrono::microseconds(g_co.quiet_us);
+          const bool quiet = t >= quiet_at;
+          if (!joiners && (!overlapping || quiet)) break;
+          g_co.cv.wait_until(lk, joiners ? deadline : std::min(deadline, quiet_at));
+        }
+        take.swap(g_co.pending);
+        for (auto* r : take) { r->taken = true; uncount(r->d); }
+        g_co.in_flight += (int)take.size();
+        counted_in_flight = true;
+        g_co.collecting = false;
+        g_co.cv.notify_all();
+        lk.unlock();
+        run_requests(take);
+        lk.lock();
+      } catch (...) {
+        // (bad_alloc in the group vectors / batch construction): no follower may be left waiting on a request this leader took, and the
+        // pointer to this frame's request must not stay queued
+        if (!lk.owns_lock()) lk.lock();
+        g_co.collecting = false;
+        g_co.pending.erase(std::remove(g_co.pending.begin(), g_co.pending.end(), &req), g_co.pending.end());
+        if (counted_in_flight) g_co.in_flight -= (int)take.size();
+        for (auto* r : take)
+          if (!r->done) {
+            if (!r->rc && !r->d->batch) { r->rc = HIPDEC_ERR_MEMORY; r->err = "decode: out of memory while building a shared launch set"; }
+            r->done = true;
+          }
+        uncount(d);
+        g_co.cv.notify_all();
+        throw;
+      }
       g_co.in_flight -= (int)take.size();
       for (auto* r : take) r->done = true;
       g_co.cv.notify_all();
@@ -848,7 +885,7 @@ struct ResidentPlane {
   const void* host = nullptr;      // where hipdec_decoder_read_plane_tracked() copied the plane
   size_t host_stride = 0;
   int w = 0, h = 0, bits = 0;
-  uint64_t sample = 0;             // sparse hash of the host copy at hand-over time: a recycled pointer with other content misses
+  uint64_t sample = 0;             // hash of EVERY byte of the host copy at hand-over time (plane_hash)
   std::shared_ptr<hipdec_batch> batch;
   int item = 0, comp = 0;
   uint64_t tick = 0;
@@ -859,52 +896,79 @@ std::mutex g_res_mu;
 std::vector<ResidentPlane>& g_resident = *new std::vector<ResidentPlane>();
 uint64_t g_res_tick = 0;
 std::atomic<uint64_t> g_cb_conversions{0}, g_cb_resident{0}, g_cb_launches{0};
-constexpr size_t kMaxResident = 24;    // planes (8 images): every entry keeps its batch arena alive
 
-uint64_t sparse_hash(const uint8_t* p, size_t stride, int w_bytes, int h)
+// Content identity of a host plane: EVERY byte of every row (64-bit lanes, four independent multiply-rotate chains, ~10 GB/s on one
+// host core).  libheif edits decoded planes in place between the plugin's hand-over and the colour conversion (mirror_inplace,
+// image_item.cc:969: same pointer, stride and size), so a sampled hash is not an identity — round 2 sampled 16 rows x 96 bytes and could
+// pair a mirrored luma plane with the un-mirrored device chroma when the samples happened to be symmetric.
+uint64_t plane_hash(const uint8_t* p, size_t stride, int w_bytes, int h)
 {
-  uint64_t x = 1469598103934665603ull;
-  auto mix = [&](const uint8_t* q, int n) { for (int i = 0; i < n; i++) { x ^= q[i]; x *= 1099511628211ull; } };
-  const int rows = h < 16 ? h : 16;
-  for (int k = 0; k < rows; k++) {
-    const uint8_t* row = p + (size_t)((long long)k * (h - 1) / (rows > 1 ? rows - 1 : 1)) * stride;
-    const int n = w_bytes < 32 ? w_bytes : 32;
-    mix(row, n); mix(row + (w_bytes - n) / 2, n); mix(row + w_bytes - n, n);
+  const uint64_t K1 = 0x9E3779B185EBCA87ull, K2 = 0xC2B2AE3D27D4EB4Full;
+  uint64_t a = K1, b = K2, c = K1 ^ K2, d = ~K1;
+  auto rot = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
+  for (int y = 0; y < h; y++) {
+    const uint8_t* q = p + (size_t)y * stride;
+    int i = 0;
+    for (; i + 32 <= w_bytes; i += 32) {
+      uint64_t w[4];
+      memcpy(w, q + i, 32);
+      a = rot(a ^ (w[0] * K2), 31) * K1; b = rot(b ^ (w[1] * K2), 29) * K1; c = rot(c ^ (w[2] * K2), 27) * K1; d = rot(d ^ (w[3] * K2), 33) * K1;
+    }
+    uint64_t tail[4] = {0, 0, 0, 0};
+    if (i < w_bytes) {
+      memcpy(tail, q + i, (size_t)(w_bytes - i));
+      a = rot(a ^ (tail[0] * K2), 31) * K1; b = rot(b ^ (tail[1] * K2), 29) * K1; c = rot(c ^ (tail[2] * K2), 27) * K1; d = rot(d ^ (tail[3] * K2), 33) * K1;
+    }
+    a ^= (uint64_t)y * K2;   // the row index: swapped rows hash differently
   }
+  uint64_t x = a ^ rot(b, 17) ^ rot(c, 33) ^ rot(d, 49);
+  x ^= x >> 29; x *= K1; x ^= x >> 32;
   return x;
 }
 
+// Tracking costs a pass over every decoded plane, so it only runs once a colour conversion has actually arrived at this library (the
+// stock libheif never calls hipdec_color_convert: no hashing there); an entry serves ONE conversion and is dropped, which also bounds
+// what the registry pins: at most kMaxResident (6) planes' batches, normally those of the image being converted.
+std::atomic<bool> g_track_planes{getenv("HIPDEC_TRACK_PLANES") ? atoi(getenv("HIPDEC_TRACK_PLANES")) != 0 : false};
+constexpr size_t kMaxResident = 6;
+
 void resident_note(hipdec_decoder* d, int c, const void* host, size_t stride)
 {
+  if (!g_track_planes.load(std::memory_order_relaxed)) return;
   const PicParams& P = d->batch->params[d->item];
   ResidentPlane r;
   r.host = host; r.host_stride = stride;
   r.w = c ? P.out_cwidth : P.out_width; r.h = c ? P.out_cheight : P.out_height;
   r.bits = c ? P.bit_depth_chroma : P.bit_depth_luma;
-  r.sample = sparse_hash((const uint8_t*)host, stride, r.w * (d->batch->wide ? 2 : 1), r.h);
+  r.sample = plane_hash((const uint8_t*)host, stride, r.w * (d->batch->wide ? 2 : 1), r.h);
   r.batch = d->batch; r.item = d->item; r.comp = c;
+  std::shared_ptr<hipdec_batch> evicted;   // dies outside the lock
   std::lock_guard<std::mutex> lock(g_res_mu);
   r.tick = ++g_res_tick;
-  for (auto& e : g_resident) if (e.host == host) { e = r; return; }
+  for (auto& e : g_resident) if (e.host == host) { evicted = std::move(e.batch); e = r; return; }
   if (g_resident.size() >= kMaxResident) {
     size_t old = 0;
     for (size_t i = 1; i < g_resident.size(); i++) if (g_resident[i].tick < g_resident[old].tick) old = i;
+    evicted = std::move(g_resident[old].batch);
     g_resident[old] = r;
   } else g_resident.push_back(r);
 }
 
-// device copy of a host plane handed over by a decoder of this library, if it still is that plane
+// device copy of a host plane handed over by a decoder of this library, if the host plane still holds exactly those bytes; the entry
+// is consumed either way
 bool resident_find(const void* host, size_t stride, int w, int h, int bits, const uint8_t** dev, size_t* dev_stride, std::shared_ptr<hipdec_batch>& keep)
 {
+  g_track_planes.store(true, std::memory_order_relaxed);
   ResidentPlane r;
   {
     std::lock_guard<std::mutex> lock(g_res_mu);
     bool hit = false;
-    for (auto& e : g_resident) if (e.host == host) { e.tick = ++g_res_tick; r = e; hit = true; break; }
+    for (size_t i = 0; i < g_resident.size(); i++)
+      if (g_resident[i].host == host) { r = std::move(g_resident[i]); g_resident.erase(g_resident.begin() + (long)i); hit = true; break; }
     if (!hit) return false;
   }
   if (r.host_stride != stride || r.w != w || r.h != h || r.bits != bits || r.batch->retired || !r.batch->arena) return false;
-  if (sparse_hash((const uint8_t*)host, stride, w * (bits > 8 ? 2 : 1), h) != r.sample) return false;
+  if (plane_hash((const uint8_t*)host, stride, w * (bits > 8 ? 2 : 1), h) != r.sample) return false;
   const PicParams& P = r.batch->params[r.item];
   *dev = r.batch->arena + P.off_out[r.comp];
   *dev_stride = P.out_stride[r.comp];
@@ -915,6 +979,8 @@ bool resident_find(const void* host, size_t stride, int w, int h, int bits, cons
 }  // namespace
 
 extern "C" {
+
+void hipdec_set_plane_tracking(int on) { g_track_planes.store(on != 0, std::memory_order_relaxed); }
 
 void hipdec_forget_resident_planes(void)
 {
@@ -1235,7 +1301,9 @@ int hipdec_grid_create(hipdec_grid** out, int rows, int cols, int out_width, int
     if (devices && n_devices > 0) g->devices.assign(devices, devices + n_devices);
     else { const int n = n_devices > 0 ? n_devices : visible; for (int d = 0; d < n; d++) g->devices.push_back(d % visible); }
     if ((int)g->devices.size() > n_tiles) g->devices.resize((size_t)n_tiles);
-    for (int d : g->devices) if (d < 0 || d >= visible) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_create: device %d is not visible (%d devices)", d, visible);
+    for (int d : g->devices)
+      if (d < 0 || d >= visible || d >= max_devices())
+        return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_create: device %d is not usable (%d devices visible, at most %d supported)", d, visible, max_devices());
     const int G = (int)g->devices.size();
     g->rows = rows; g->cols = cols; g->out_w = out_width; g->out_h = out_height; g->root = g->devices[0];
     g->shard.resize((size_t)G); g->shard_tiles.resize((size_t)G); g->stream.assign((size_t)G, nullptr); g->pasted.assign((size_t)G, nullptr);
@@ -1306,6 +1374,7 @@ int hipdec_grid_decode(hipdec_grid* g)
       DeviceScope scope(g->devices[s]);
       hipdec_batch* b = g->shard[s].get();
       if (int rc = hipdec_batch_run(b, (void*)g->stream[s])) return rc;
+      (void)follow_stream(b, (void*)g->stream[s]);   // with stage overlap the pixel stages run on the post stream: the pastes below wait for them
       for (size_t i = 0; i < g->shard_tiles[s].size(); i++) {
         const int t = g->shard_tiles[s][i];
         const int x0 = (t % g->cols) * g->tile_w, y0 = (t / g->cols) * g->tile_h;

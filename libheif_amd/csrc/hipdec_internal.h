@@ -28,6 +28,7 @@ class DeviceScope {
 hipStream_t default_stream();
 hipStream_t post_stream();      // everything behind the CABAC kernel when stage overlap is on (hipdec_set_stage_overlap)
 bool stage_overlap();
+int max_devices();              // size of the per-device stream table: device indices beyond it are refused
 hipStream_t upload_stream();    // H2D copies of large batches (overlaps the kernels of the batch before)
 uint32_t parse_wave_budget();   // CABAC pool waves one batch may launch (wave slots / concurrent batches)
 
@@ -53,6 +54,7 @@ struct ColorBatchState {
   void* dev = nullptr;
   size_t dev_bytes = 0;
   std::vector<uint8_t> host;   // the blocks last uploaded
+  std::vector<uint8_t> prev;   // the upload before: kept alive while a copy from it may still be pending (pageable source of an async copy)
 };
 void color_capture_begin();
 void color_capture_abort();

@@ -28,6 +28,8 @@ namespace hipdec {
     pcore::parse_wave(A, wave_idx, &lds);                                                                 \
 
 __global__ __launch_bounds__(64) void k_parse(ParseArgs A) { HIPDEC_PARSE_BODY }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_parse_occ4(ParseArgs A) { HIPDEC_PARSE_BODY }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_parse_occ5(ParseArgs A) { HIPDEC_PARSE_BODY }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_parse_occ6(ParseArgs A) { HIPDEC_PARSE_BODY }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_parse_occ7(ParseArgs A) { HIPDEC_PARSE_BODY }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_parse_occ8(ParseArgs A) { HIPDEC_PARSE_BODY }
@@ -46,6 +48,8 @@ void launch_parse(const ParseArgs& a, hipStream_t s)
   if (occ == 8) hipLaunchKernelGGL(k_parse_occ8, dim3(a.num_waves), dim3(64), 0, s, a);
   else if (occ == 7) hipLaunchKernelGGL(k_parse_occ7, dim3(a.num_waves), dim3(64), 0, s, a);
   else if (occ == 6) hipLaunchKernelGGL(k_parse_occ6, dim3(a.num_waves), dim3(64), 0, s, a);
+  else if (occ == 5) hipLaunchKernelGGL(k_parse_occ5, dim3(a.num_waves), dim3(64), 0, s, a);
+  else if (occ == 4) hipLaunchKernelGGL(k_parse_occ4, dim3(a.num_waves), dim3(64), 0, s, a);
   else hipLaunchKernelGGL(k_parse, dim3(a.num_waves), dim3(64), 0, s, a);
 }
 

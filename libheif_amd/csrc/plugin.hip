@@ -87,8 +87,10 @@ void announce_color_backend()
 {
   using reg_fn = void (*)(int (*)(int, int, int, const hipdec_nclx*, int, int, int, int*, int*),
                           int (*)(const hipdec_color_image*, const hipdec_nclx*, int, int, int, void*, size_t, int), const char* (*)(void), int);
-  if (auto reg = (reg_fn)dlsym(RTLD_DEFAULT, "heif_color_conversion_register_hip_backend"))
+  if (auto reg = (reg_fn)dlsym(RTLD_DEFAULT, "heif_color_conversion_register_hip_backend")) {
     reg(hipdec_color_plan, hipdec_color_convert, hipdec_last_error, hipdec_device_count() > 0 ? 1 : 0);
+    hipdec_set_plane_tracking(1);   // this libheif converts on the GPU: keep decoded planes findable on the device (costs a hash pass per plane)
+  }
 }
 void init_plugin()
 {

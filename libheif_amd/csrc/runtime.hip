@@ -62,11 +62,12 @@ DeviceScope::~DeviceScope()
 
 static DeviceStreams& streams_of_active_device()
 {
+  // (device indices are validated where they enter the library: hipdec_init, hipdec_grid_create — max_devices())
   int dev = active_device();
   if (dev < 0 || dev >= kMaxDevices) dev = 0;
   DeviceStreams& d = g_streams[dev];
-  if (!d.stream) {
-    std::lock_guard<std::mutex> lock(g_streams_mu);
+  {
+    std::lock_guard<std::mutex> lock(g_streams_mu);   // always taken: the creation below must not race a reader of d.stream
     if (!d.stream) {
       (void)hipSetDevice(dev);
       hipStream_t up = nullptr, st = nullptr, po = nullptr;
@@ -80,6 +81,7 @@ static DeviceStreams& streams_of_active_device()
   }
   return d;
 }
+int max_devices() { return kMaxDevices; }
 hipStream_t default_stream() { return streams_of_active_device().stream; }
 hipStream_t upload_stream() { DeviceStreams& d = streams_of_active_device(); return d.upload ? d.upload : d.stream; }
 hipStream_t post_stream() { DeviceStreams& d = streams_of_active_device(); return d.post ? d.post : d.stream; }
@@ -282,7 +284,7 @@ int hipdec_init(int device_index)
     return set_error(HIPDEC_ERR_DEVICE, "no HIP device available (%s); libheifhip has no CPU fallback",
                      e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
   int dev = device_index < 0 ? 0 : device_index;
-  if (dev >= n) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", dev, n);
+  if (dev >= n || dev >= kMaxDevices) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices, at most %d supported)", dev, n, kMaxDevices);
   HIPDEC_CHECK_HIP(hipSetDevice(dev));
   {
     int cus = 0;
