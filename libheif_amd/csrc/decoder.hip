@@ -603,6 +603,8 @@ struct Coalescer {
   int in_flight = 0;                     // requests inside a running batch
   Clock::time_point last_arrival{}, last_overlap{};
   long window_us = -1, quiet_us = 300;
+  long busy_requests = 16;               // a leader keeps gathering while more requests than this are inside running launch sets ...
+  long hold_us = 1000000;                // ... for at most this long (HIPDEC_COALESCE_BUSY / HIPDEC_COALESCE_HOLD_US)
   uint64_t n_requests = 0, n_launch_sets = 0, n_shared = 0;   // statistics (hipdec_decoder_coalesce_stats)
 } g_co;
 
@@ -612,6 +614,8 @@ long coalesce_window_us()
     const char* e = std::getenv("HIPDEC_COALESCE_WINDOW_US");   // 0 disables coalescing
     g_co.window_us = e ? std::max(0L, std::atol(e)) : 2000;
     if (const char* q = std::getenv("HIPDEC_COALESCE_QUIET_US")) g_co.quiet_us = std::max(1L, std::atol(q));
+    if (const char* q = std::getenv("HIPDEC_COALESCE_BUSY")) g_co.busy_requests = std::max(0L, std::atol(q));
+    if (const char* q = std::getenv("HIPDEC_COALESCE_HOLD_US")) g_co.hold_us = std::max(0L, std::atol(q));
   }
   return g_co.window_us;
 }
@@ -790,6 +794,12 @@ static int decoder_decode_impl(hipdec_decoder* d, hipdec_image_info* info)
         const auto deadline = t0 + std::chrono::microseconds(window);
         const bool overlapping = g_co.last_overlap.time_since_epoch().count() != 0 &&
                                  t0 - g_co.last_overlap < std::chrono::milliseconds(250);
+        // Batching while busy: as long as the GPU is working on many requests already, launching another small set beside them buys
+        // nothing (a lone still is one CABAC critical path, ~250 ms, whatever else runs) while gathering lets the NEXT set be large
+        // enough for the work pool; so the leader keeps collecting until the running sets are (nearly) done.  A host with a few
+        // threads never holds (in_flight <= busy_requests); one with hundreds gets sets of hundreds instead of sets of three.
+        const auto hold_until = t0 + std::chrono::microseconds(g_co.hold_us);
+        while (g_co.in_flight > g_co.busy_requests && Clock::now() < hold_until) g_co.cv.wait_until(lk, hold_until);
         for (;;) {
           const auto t = Clock::now();
           if (t >= deadline) break;

@@ -1,0 +1,108 @@
+/* dropin_host.c — T application threads, each calling heif_decode_image() on HEIC files in host memory through an UNMODIFIED libheif
+ * with libheifhip.so as decoder plugin (the usage of /root/reference/tests/test-race.go:73-106).  The few libheif entry points used are
+ * declared here by prototype (public C API, /root/reference/libheif/api/libheif/heif_*.h) so that the file compiles where the headers are
+ * not installed; the library itself is linked at run time with dlopen.
+ *
+ *   gcc -O2 -pthread tools/dropin_host.c -ldl -o build/dropin_host
+ *   build/dropin_host <libheif.so> <libheifhip.so> <threads> <seconds> <rgb 0|1> file0.heic file1.heic ...
+ * prints: decodes seconds mpixel_s requests launch_sets
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+struct heif_error { int code; int subcode; const char* message; };
+typedef struct heif_error (*load_plugin_fn)(const char*, const void**);
+typedef void* (*ctx_alloc_fn)(void);
+typedef void (*ctx_free_fn)(void*);
+typedef struct heif_error (*read_mem_fn)(void*, const void*, size_t, const void*);
+typedef struct heif_error (*primary_fn)(void*, void**);
+typedef struct heif_error (*decode_fn)(void*, void**, int, int, const void*);
+typedef void (*release_fn)(void*);
+typedef int (*dim_fn)(void*);
+
+static ctx_alloc_fn ctx_alloc; static ctx_free_fn ctx_free; static read_mem_fn read_mem; static primary_fn primary; static decode_fn decode;
+static release_fn image_release, handle_release; static dim_fn handle_w, handle_h;
+
+struct file { uint8_t* data; size_t size; };
+static struct file* files; static int n_files; static int n_threads; static int want_rgb;
+static volatile int stop_flag; static pthread_barrier_t start_barrier;
+struct worker { pthread_t th; int k; long decodes; double px; int failed; };
+
+static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+static int decode_one(const struct file* f, double* px)
+{
+  void* ctx = ctx_alloc();
+  struct heif_error e = read_mem(ctx, f->data, f->size, NULL);
+  void* h = NULL; void* img = NULL;
+  if (!e.code) e = primary(ctx, &h);
+  if (!e.code) e = decode(h, &img, want_rgb ? 1 /* heif_colorspace_RGB */ : 0 /* YCbCr */, want_rgb ? 10 /* interleaved RGB */ : 1 /* 4:2:0 */, NULL);
+  if (!e.code) *px += (double)handle_w(h) * handle_h(h);
+  else fprintf(stderr, "decode failed: %d.%d %s\n", e.code, e.subcode, e.message ? e.message : "");
+  if (img) image_release(img);
+  if (h) handle_release(h);
+  ctx_free(ctx);
+  return e.code;
+}
+
+static void* run(void* arg)
+{
+  struct worker* w = (struct worker*)arg;
+  pthread_barrier_wait(&start_barrier);
+  for (int i = w->k; !stop_flag; i += n_threads) {
+    if (decode_one(&files[i % n_files], &w->px)) { w->failed = 1; break; }
+    w->decodes++;
+  }
+  return NULL;
+}
+
+int main(int argc, char** argv)
+{
+  if (argc < 7) { fprintf(stderr, "usage: %s libheif.so libheifhip.so threads seconds rgb files...\n", argv[0]); return 2; }
+  void* L = dlopen(argv[1], RTLD_NOW | RTLD_GLOBAL);
+  if (!L) { fprintf(stderr, "%s\n", dlerror()); return 1; }
+  load_plugin_fn load_plugin = (load_plugin_fn)dlsym(L, "heif_load_plugin");
+  ctx_alloc = (ctx_alloc_fn)dlsym(L, "heif_context_alloc"); ctx_free = (ctx_free_fn)dlsym(L, "heif_context_free");
+  read_mem = (read_mem_fn)dlsym(L, "heif_context_read_from_memory_without_copy"); primary = (primary_fn)dlsym(L, "heif_context_get_primary_image_handle");
+  decode = (decode_fn)dlsym(L, "heif_decode_image"); image_release = (release_fn)dlsym(L, "heif_image_release");
+  handle_release = (release_fn)dlsym(L, "heif_image_handle_release");
+  handle_w = (dim_fn)dlsym(L, "heif_image_handle_get_width"); handle_h = (dim_fn)dlsym(L, "heif_image_handle_get_height");
+  const void* info = NULL;
+  struct heif_error e = load_plugin(argv[2], &info);
+  if (e.code) { fprintf(stderr, "heif_load_plugin: %s\n", e.message); return 1; }
+  n_threads = atoi(argv[3]); const double seconds = atof(argv[4]); want_rgb = atoi(argv[5]);
+  n_files = argc - 6; files = (struct file*)calloc((size_t)n_files, sizeof(struct file));
+  for (int i = 0; i < n_files; i++) {
+    FILE* f = fopen(argv[6 + i], "rb"); if (!f) { perror(argv[6 + i]); return 1; }
+    fseek(f, 0, SEEK_END); files[i].size = (size_t)ftell(f); fseek(f, 0, SEEK_SET);
+    files[i].data = (uint8_t*)malloc(files[i].size);
+    if (fread(files[i].data, 1, files[i].size, f) != files[i].size) return 1;
+    fclose(f);
+  }
+  double px0 = 0; if (decode_one(&files[0], &px0)) return 1;   /* warm-up: HIP runtime, code objects, arena pool */
+  void* hip = dlopen(argv[2], RTLD_NOW | RTLD_NOLOAD);
+  void (*stats)(uint64_t*, uint64_t*, uint64_t*) = hip ? (void (*)(uint64_t*, uint64_t*, uint64_t*))dlsym(hip, "hipdec_decoder_coalesce_stats") : NULL;
+  uint64_t r0 = 0, s0 = 0, x0 = 0, r1 = 0, s1 = 0, x1 = 0;
+  struct worker* ws = (struct worker*)calloc((size_t)n_threads, sizeof(struct worker));
+  pthread_barrier_init(&start_barrier, NULL, (unsigned)n_threads + 1);
+  pthread_attr_t at; pthread_attr_init(&at); pthread_attr_setstacksize(&at, 1 << 20);
+  for (int k = 0; k < n_threads; k++) { ws[k].k = k; pthread_create(&ws[k].th, &at, run, &ws[k]); }
+  if (stats) stats(&r0, &s0, &x0);
+  pthread_barrier_wait(&start_barrier);
+  const double t0 = now();
+  usleep((useconds_t)(seconds * 1e6));
+  stop_flag = 1;
+  long n = 0; double px = 0; int failed = 0;
+  for (int k = 0; k < n_threads; k++) { pthread_join(ws[k].th, NULL); n += ws[k].decodes; px += ws[k].px; failed |= ws[k].failed; }
+  const double dt = now() - t0;   /* every counted decode completed inside dt */
+  if (stats) stats(&r1, &s1, &x1);
+  printf("%ld %.3f %.1f %llu %llu %d\n", n, dt, px / dt / 1e6, (unsigned long long)(r1 - r0), (unsigned long long)(s1 - s0), failed);
+  return failed;
+}

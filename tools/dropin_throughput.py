@@ -19,74 +19,47 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def measure(threads_list=(64, 256), n_files=64, seconds=6.0, w=3840, h=2160, qp=27, rgb=False, quiet=True):
+def measure(threads_list=(64, 256), n_files=64, seconds=6.0, w=3840, h=2160, qp=27, rgb=False, quiet=True, libheif="libheif.so"):
+    """Runs the C harness (tools/dropin_host.c: pthreads, no Python in the timed loop) once per thread count."""
+    import subprocess
+    import tempfile
     from tools import streamgen
     import heic_util as hu
-    import libheif_host as lh
-    from libheif_amd.decoder import coalesce_stats
+    import libheif_amd
+    ref = os.path.join(ROOT, "oracle", "_ref", libheif)
+    if not os.path.exists(ref):
+        raise RuntimeError("oracle/_ref/%s is not built (make -C oracle ref)" % libheif)
+    exe = os.path.join(ROOT, "build", "dropin_host")
+    src = os.path.join(ROOT, "tools", "dropin_host.c")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-pthread", src, "-ldl", "-o", exe])
     cfg = dict(wpp=1, qp=qp, vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1)
     streams = streamgen.make_streams([(w, h, 5000 + i, 8, cfg) for i in range(n_files)])
-    heics = [hu.build_heic([(s, w, h)]) for s in streams]
-    L = lh.load_hip_plugin()
-    cs, ch = (lh.COLORSPACE_RGB, lh.CHROMA_RGB) if rgb else (lh.COLORSPACE_YCBCR, lh.CHROMA_420)
-
-    def one(data):
-        ctx = L.heif_context_alloc()
-        try:
-            lh.check(L.heif_context_read_from_memory_without_copy(ctx, data, len(data), None))
-            hd = C.c_void_p()
-            lh.check(L.heif_context_get_primary_image_handle(ctx, C.byref(hd)))
-            img = C.c_void_p()
-            try:
-                lh.check(L.heif_decode_image(hd, C.byref(img), cs, ch, None))
-            finally:
-                if img:
-                    L.heif_image_release(img)
-                L.heif_image_handle_release(hd)
-        finally:
-            L.heif_context_free(ctx)
-
-    one(heics[0])     # warm-up: HIP runtime, code objects, arena pool
+    tmp = tempfile.mkdtemp(prefix="hipdec_dropin_")
+    paths = []
+    for i, s in enumerate(streams):
+        pth = os.path.join(tmp, "f%04d.heic" % i)
+        with open(pth, "wb") as f:
+            f.write(hu.build_heic([(s, w, h)]))
+        paths.append(pth)
     results = []
     for T in threads_list:
-        stop = [False]
-        counts = [0] * T
-        errors = []
-        start_evt = threading.Event()
-
-        def worker(k):
-            start_evt.wait()
-            i = k
-            while not stop[0]:
-                try:
-                    one(heics[i % len(heics)])
-                except Exception as e:   # noqa
-                    errors.append(repr(e)); return
-                counts[k] += 1
-                i += T
-
-        ths = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(T)]
-        for t in ths:
-            t.start()
-        c0 = coalesce_stats()
-        t0 = time.perf_counter()
-        start_evt.set()
-        time.sleep(seconds)
-        stop[0] = True
-        for t in ths:
-            t.join()
-        dt = time.perf_counter() - t0      # includes the decodes in flight at `stop`: every counted decode completed inside dt
-        c1 = coalesce_stats()
-        n = sum(counts)
-        r = {"threads": T, "decodes": n, "seconds": round(dt, 3), "mpixel_s": round(n * w * h / dt / 1e6, 1),
-             "ms_per_decode_per_thread": round(dt * 1e3 * T / max(1, n), 1),
-             "decoder_requests": c1[0] - c0[0], "launch_sets": c1[1] - c0[1],
-             "stills_per_launch_set": round((c1[0] - c0[0]) / max(1, c1[1] - c0[1]), 1), "errors": errors[:3]}
-        results.append(r)
+        r = subprocess.run([exe, ref, libheif_amd.library_path(), str(T), str(seconds), "1" if rgb else "0"] + paths, capture_output=True, text=True, timeout=seconds * 4 + 120)
+        if r.returncode != 0:
+            results.append({"threads": T, "error": (r.stderr or r.stdout)[-400:]})
+            continue
+        n, dt, mpx, req, sets, failed = r.stdout.split()[-6:]
+        rec = {"threads": T, "decodes": int(n), "seconds": float(dt), "mpixel_s": float(mpx), "decoder_requests": int(req), "launch_sets": int(sets),
+               "stills_per_launch_set": round(int(req) / max(1, int(sets)), 1)}
+        results.append(rec)
         if not quiet:
-            print(json.dumps(r), flush=True)
-    return {"workload": "%d distinct %dx%d 8-bit 4:2:0 HEIC files (QP %d, WPP), T threads x heif_decode_image() -> %s through the real libheif + plugin, host to host"
-                        % (n_files, w, h, qp, "RGB24 (colour stage per the loaded libheif build)" if rgb else "YCbCr planes"),
+            print(json.dumps(rec), flush=True)
+    for pth in paths:
+        os.unlink(pth)
+    os.rmdir(tmp)
+    return {"workload": "%d distinct %dx%d 8-bit 4:2:0 HEIC files (QP %d, WPP), T pthreads x heif_decode_image() -> %s through the real libheif (%s) + plugin, host to host"
+                        % (n_files, w, h, qp, "RGB24" if rgb else "YCbCr planes", libheif),
             "coalesce_window_us": int(os.environ.get("HIPDEC_COALESCE_WINDOW_US", "2000")), "runs": results}
 
 
@@ -97,7 +70,8 @@ if __name__ == "__main__":
     ap.add_argument("--seconds", type=float, default=6.0)
     ap.add_argument("--rgb", action="store_true")
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--libheif", default="libheif.so", help="build of the reference under oracle/_ref: libheif.so (stock) or libheif_hipcolor.so (HIP colour op)")
     a = ap.parse_args()
-    out = measure([int(x) for x in a.threads.split(",")], a.files, a.seconds, rgb=a.rgb, quiet=a.json)
+    out = measure([int(x) for x in a.threads.split(",")], a.files, a.seconds, rgb=a.rgb, quiet=a.json, libheif=a.libheif)
     if a.json:
         print(json.dumps(out))
