@@ -45,6 +45,10 @@ struct hipdec_batch : BatchLayout {
   bool ran = false;
   bool retired = false;         // its arena went to another batch (hipdec_batch_create_recycling): only status / timing / free remain
   ColorBatchState color;        // parameter blocks of hipdec_batch_to_rgb_all
+  // decoder path (plugin): the output planes of every item staged in pinned host memory by ONE set of asynchronous copies behind the
+  // kernels, so that N decoder instances sharing the batch do not queue N x 3 pageable device-to-host copies (stage_planes_to_host)
+  struct HostItem { void* p = nullptr; size_t capacity = 0; size_t off[3] = {0, 0, 0}; };
+  std::vector<HostItem> host_items;
   // Waits for everything enqueued for THIS batch — not for the stream, which may already carry the next batch.
   hipError_t wait() const
   {
@@ -69,6 +73,7 @@ struct hipdec_batch : BatchLayout {
     DeviceScope scope(device);
     if (arena || staging) (void)wait();   // nothing of this batch may still be running when the arena is recycled
     release_staging();
+    for (auto& h : host_items) pinned_release(h.p, h.capacity);
     color_batch_state_free(color);
     if (arena) arena_release(arena, arena_capacity);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -234,6 +239,35 @@ const char* dev_err_name(int code)
     case DEV_ERR_TIMEOUT: return "dependency wait timed out / aborted";
     default: return "unknown device error";
   }
+}
+
+// The decoder path's hand-over: every item's cropped planes, tight rows, into a pinned buffer of its own (pooled), queued on the
+// launch set's stream behind its kernels.  hipdec_decoder_read_plane() then is a host memcpy into libheif's plane — in parallel on the
+// application's threads — instead of one synchronous pageable device-to-host copy per plane and instance.
+int stage_planes_to_host(hipdec_batch& b, hipStream_t s)
+{
+  static const bool off = getenv("HIPDEC_NO_HOST_STAGING") != nullptr;
+  if (off) return 0;
+  const size_t es = b.wide ? 2 : 1;
+  b.host_items.assign(b.params.size(), hipdec_batch::HostItem{});
+  for (size_t i = 0; i < b.params.size(); i++) {
+    const PicParams& P = b.params[i];
+    hipdec_batch::HostItem& h = b.host_items[i];
+    size_t total = 0;
+    for (int c = 0; c < (P.chroma_format_idc ? 3 : 1); c++) {
+      h.off[c] = total;
+      total += (size_t)(c ? P.out_cwidth : P.out_width) * es * (size_t)(c ? P.out_cheight : P.out_height);
+      total = (total + 255) & ~size_t(255);
+    }
+    if (!total) continue;
+    HIPDEC_CHECK_HIP(pinned_acquire(&h.p, total, &h.capacity));
+    for (int c = 0; c < (P.chroma_format_idc ? 3 : 1); c++) {
+      const size_t w = (size_t)(c ? P.out_cwidth : P.out_width) * es, hh = (size_t)(c ? P.out_cheight : P.out_height);
+      if (w && hh) HIPDEC_CHECK_HIP(hipMemcpy2DAsync((uint8_t*)h.p + h.off[c], w, b.arena + P.off_out[c], P.out_stride[c], w, hh, hipMemcpyDeviceToHost, s));
+    }
+  }
+  b.mark_done(s);
+  return 0;
 }
 
 int copy_plane_d2h(const hipdec_batch& b, size_t off, uint32_t stride, int w, int h, void* dst, size_t dst_stride)
@@ -631,6 +665,7 @@ void run_single(DecodeRequest& r, hipStream_t s)
   r.rc = hipdec_batch_create(&b, 1, ptrs, sizes, d->max_pixels);
   if (!r.rc) {
     r.rc = hipdec_batch_run(b, (void*)s);
+    if (!r.rc) r.rc = stage_planes_to_host(*b, follow_stream(b, (void*)s));
     if (!r.rc) r.rc = hipdec_batch_status(b);   // synchronises s
     else (void)hipStreamSynchronize(s);
     b->last_stream = nullptr;                   // the stream goes back to the pool: nothing of this batch is in flight
@@ -654,6 +689,7 @@ void run_group(std::vector<DecodeRequest*>& group, hipStream_t s)
   int rc = hipdec_batch_create(&b, (int)group.size(), ptrs.data(), sizes.data(), group[0]->d->max_pixels);
   if (!rc) {
     rc = hipdec_batch_run(b, (void*)s);
+    if (!rc) rc = stage_planes_to_host(*b, follow_stream(b, (void*)s));
     if (!rc) rc = hipdec_batch_status(b);
     else (void)hipStreamSynchronize(s);
     b->last_stream = nullptr;
@@ -870,7 +906,17 @@ void hipdec_decoder_coalesce_stats(uint64_t* requests, uint64_t* launch_sets, ui
 int hipdec_decoder_read_plane(hipdec_decoder* d, int c, void* dst, size_t dst_stride)
 {
   if (!d || !d->decoded) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: nothing decoded");
-  return hipdec_batch_read_plane(d->batch.get(), d->item, c, dst, dst_stride);
+  hipdec_batch* b = d->batch.get();
+  if (b && c >= 0 && c <= 2 && dst && d->item < (int)b->host_items.size() && b->host_items[(size_t)d->item].p) {   // staged by the launch set
+    const PicParams& P = b->params[(size_t)d->item];
+    if (c > 0 && !P.chroma_format_idc) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: monochrome image has no chroma planes");
+    const size_t w = (size_t)(c ? P.out_cwidth : P.out_width) * (b->wide ? 2 : 1), h = (size_t)(c ? P.out_cheight : P.out_height);
+    const uint8_t* src = (const uint8_t*)b->host_items[(size_t)d->item].p + b->host_items[(size_t)d->item].off[c];
+    if (dst_stride == w) memcpy(dst, src, w * h);
+    else for (size_t y = 0; y < h; y++) memcpy((uint8_t*)dst + y * dst_stride, src + y * w, w);
+    return 0;
+  }
+  return hipdec_batch_read_plane(b, d->item, c, dst, dst_stride);
 }
 
 int hipdec_decoder_device_plane(hipdec_decoder* d, int c, const void** dptr, size_t* stride)

@@ -113,7 +113,9 @@ std::atomic<size_t> g_max_pooled_arena{size_t(1) << 30};    // bigger arenas are
 struct PinnedPool {
   std::mutex mu;
   std::vector<std::pair<size_t, void*>> free_list;
+  size_t cached_bytes = 0;
 };
+constexpr size_t kMaxPinnedCached = size_t(24) << 30;   // pinned buffers parked for reuse (upload staging, per-item plane staging of the decoder path)
 PinnedPool g_pinned;
 }  // namespace
 
@@ -132,7 +134,9 @@ hipError_t pinned_acquire(void** out, size_t bytes, size_t* capacity)
     }
     if (best != SIZE_MAX) {
       *out = g_pinned.free_list[best].second; *capacity = g_pinned.free_list[best].first;
-      g_pinned.free_list.erase(g_pinned.free_list.begin() + (long)best);
+      g_pinned.cached_bytes -= *capacity;
+      g_pinned.free_list[best] = g_pinned.free_list.back();
+      g_pinned.free_list.pop_back();
       return hipSuccess;
     }
   }
@@ -145,7 +149,9 @@ void pinned_release(void* p, size_t capacity)
   if (!p) return;
   {
     std::lock_guard<std::mutex> lock(g_pinned.mu);
-    if (g_pinned.free_list.size() < 4) { g_pinned.free_list.emplace_back(capacity, p); return; }
+    if (g_pinned.cached_bytes + capacity <= kMaxPinnedCached && g_pinned.free_list.size() < 8192) {
+      g_pinned.free_list.emplace_back(capacity, p); g_pinned.cached_bytes += capacity; return;
+    }
   }
   (void)hipHostFree(p);
 }
@@ -187,6 +193,7 @@ void pinned_pool_clear()
   std::lock_guard<std::mutex> lock(g_pinned.mu);
   for (auto& e : g_pinned.free_list) (void)hipHostFree(e.second);
   g_pinned.free_list.clear();
+  g_pinned.cached_bytes = 0;
 }
 
 hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity)
