@@ -137,10 +137,9 @@ HIPDEC_API void hipdec_forget_resident_planes(void);
 /* device-resident hand-over for callers that keep the colour stage on the GPU */
 HIPDEC_API int hipdec_decoder_device_plane(hipdec_decoder* dec, int c, const void** dptr, size_t* stride);
 
-/* Device arenas and pinned staging buffers of retired batches are parked for reuse up to this many bytes (default 8 GiB, arenas
- * above 1 GiB not at all: right for the plugin path).  A throughput host that streams large batches raises it to about two
- * batch arenas: hipFree() synchronises the device and would serialise "parse + upload batch k+1 while batch k decodes".
- * 0 empties the cache. */
+/* Device arenas and pinned staging buffers of retired batches are parked for reuse up to this many bytes (default 96 GiB of the
+ * MI355X's 288 GB, single arenas up to 64 GiB: hipFree() synchronises the device, and the decoder path builds one batch per launch
+ * set of concurrently decoding instances).  A host that wants the memory back lowers it; 0 empties the cache. */
 HIPDEC_API int hipdec_set_arena_cache_bytes(size_t bytes);
 
 /* Two-stage pipeline across batches (default off): hipdec_batch_run() keeps the CABAC kernel on the caller's stream and queues residual /

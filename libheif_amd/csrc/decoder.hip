@@ -44,6 +44,7 @@ struct hipdec_batch : BatchLayout {
   hipStream_t last_stream = nullptr;
   bool ran = false;
   bool retired = false;         // its arena went to another batch (hipdec_batch_create_recycling): only status / timing / free remain
+  uint32_t wave_share = 1;      // the CABAC work pool of this batch takes 1 / wave_share of the wave budget (launch sets of the decoder path overlap in pairs)
   ColorBatchState color;        // parameter blocks of hipdec_batch_to_rgb_all
   // decoder path (plugin): the output planes of every item staged in pinned host memory by ONE set of asynchronous copies behind the
   // kernels, so that N decoder instances sharing the batch do not queue N x 3 pageable device-to-host copies (stage_planes_to_host)
@@ -161,7 +162,7 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
     // pool size: every pool wave must be resident, so the batches in flight share the wave slots (runtime.hip); measured on
     // MI355X, 1024 4K stills: 7168 waves for one batch, 2 x 3584 for two overlapping ones (2 x 4096 oversubscribes and
     // loses 20 %)
-    uint32_t waves = getenv("HIPDEC_POOL_WAVES") ? (uint32_t)atoi(getenv("HIPDEC_POOL_WAVES")) : parse_wave_budget();
+    uint32_t waves = getenv("HIPDEC_POOL_WAVES") ? (uint32_t)atoi(getenv("HIPDEC_POOL_WAVES")) : parse_wave_budget() / (b.wave_share ? b.wave_share : 1u);
     waves = waves > b.num_subs ? b.num_subs : waves;
     pa.num_waves = waves < 1 ? 1 : waves;
   }
@@ -263,7 +264,9 @@ int stage_planes_to_host(hipdec_batch& b, hipStream_t s)
     HIPDEC_CHECK_HIP(pinned_acquire(&h.p, total, &h.capacity));
     for (int c = 0; c < (P.chroma_format_idc ? 3 : 1); c++) {
       const size_t w = (size_t)(c ? P.out_cwidth : P.out_width) * es, hh = (size_t)(c ? P.out_cheight : P.out_height);
-      if (w && hh) HIPDEC_CHECK_HIP(hipMemcpy2DAsync((uint8_t*)h.p + h.off[c], w, b.arena + P.off_out[c], P.out_stride[c], w, hh, hipMemcpyDeviceToHost, s));
+      if (!w || !hh) continue;
+      if (P.out_stride[c] == w) HIPDEC_CHECK_HIP(hipMemcpyAsync((uint8_t*)h.p + h.off[c], b.arena + P.off_out[c], w * hh, hipMemcpyDeviceToHost, s));   // (the usual case: one DMA)
+      else HIPDEC_CHECK_HIP(hipMemcpy2DAsync((uint8_t*)h.p + h.off[c], w, b.arena + P.off_out[c], P.out_stride[c], w, hh, hipMemcpyDeviceToHost, s));
     }
   }
   b.mark_done(s);
@@ -637,8 +640,14 @@ struct Coalescer {
   int in_flight = 0;                     // requests inside a running batch
   Clock::time_point last_arrival{}, last_overlap{};
   long window_us = -1, quiet_us = 300;
-  long busy_requests = 16;               // a leader keeps gathering while more requests than this are inside running launch sets ...
+  long busy_requests = 16;               // a leader keeps gathering while max_sets launch sets with more requests than this are running ...
   long hold_us = 1000000;                // ... for at most this long (HIPDEC_COALESCE_BUSY / HIPDEC_COALESCE_HOLD_US)
+  int max_sets = 3;                      // launch sets in flight before a leader holds (HIPDEC_COALESCE_SETS): they overlap, each with a third of the pool
+                                         // waves (measured, direct C ABI, 256 / 1024 threads: 3.8 / 7.4 Gpixel/s with 2, 4.2 / 7.9 with 3, 3.5 / 7.7 with 4)
+  long max_set = 256;                    // requests per launch set at most (HIPDEC_COALESCE_MAX_SET): keeps the sets' arenas and staging buffers in a
+                                         // few size classes the pools can serve (a 683-still set spent 1.3 s in hipMalloc / hipHostMalloc), and a batch
+                                         // of 256 4K stills already parses within ~25 % of the asymptotic rate
+  int sets_in_flight = 0;
   uint64_t n_requests = 0, n_launch_sets = 0, n_shared = 0;   // statistics (hipdec_decoder_coalesce_stats)
 } g_co;
 
@@ -650,6 +659,8 @@ long coalesce_window_us()
     if (const char* q = std::getenv("HIPDEC_COALESCE_QUIET_US")) g_co.quiet_us = std::max(1L, std::atol(q));
     if (const char* q = std::getenv("HIPDEC_COALESCE_BUSY")) g_co.busy_requests = std::max(0L, std::atol(q));
     if (const char* q = std::getenv("HIPDEC_COALESCE_HOLD_US")) g_co.hold_us = std::max(0L, std::atol(q));
+    if (const char* q = std::getenv("HIPDEC_COALESCE_SETS")) g_co.max_sets = (int)std::max(1L, std::atol(q));
+    if (const char* q = std::getenv("HIPDEC_COALESCE_MAX_SET")) g_co.max_set = std::max(1L, std::atol(q));
   }
   return g_co.window_us;
 }
@@ -686,13 +697,25 @@ void run_group(std::vector<DecodeRequest*>& group, hipStream_t s)
   std::vector<size_t> sizes;
   for (auto* r : group) { ptrs.push_back(r->d->data.data()); sizes.push_back(r->d->data.size()); }
   hipdec_batch* b = nullptr;
+  static const bool trace = getenv("HIPDEC_COALESCE_TRACE") != nullptr;   // dev knob: where a launch set's wall time goes
+  const auto t0 = Clock::now();
   int rc = hipdec_batch_create(&b, (int)group.size(), ptrs.data(), sizes.data(), group[0]->d->max_pixels);
+  const auto t1 = Clock::now();
+  auto t2 = t1, t3 = t1;
   if (!rc) {
+    b->wave_share = (uint32_t)g_co.max_sets;
     rc = hipdec_batch_run(b, (void*)s);
+    t2 = Clock::now();
     if (!rc) rc = stage_planes_to_host(*b, follow_stream(b, (void*)s));
+    t3 = Clock::now();
     if (!rc) rc = hipdec_batch_status(b);
     else (void)hipStreamSynchronize(s);
     b->last_stream = nullptr;
+  }
+  if (trace) {
+    auto ms = [](Clock::time_point a, Clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+    fprintf(stderr, "[hipdec] launch set of %zu: create %.1f ms, launch %.1f ms, stage-enqueue %.1f ms, wait %.1f ms\n", group.size(), ms(t0, t1), ms(t1, t2),
+            ms(t2, t3), ms(t3, Clock::now()));
   }
   if (!rc) {
     std::shared_ptr<hipdec_batch> sp(b);
@@ -830,12 +853,14 @@ static int decoder_decode_impl(hipdec_decoder* d, hipdec_image_info* info)
         const auto deadline = t0 + std::chrono::microseconds(window);
         const bool overlapping = g_co.last_overlap.time_since_epoch().count() != 0 &&
                                  t0 - g_co.last_overlap < std::chrono::milliseconds(250);
-        // Batching while busy: as long as the GPU is working on many requests already, launching another small set beside them buys
-        // nothing (a lone still is one CABAC critical path, ~250 ms, whatever else runs) while gathering lets the NEXT set be large
-        // enough for the work pool; so the leader keeps collecting until the running sets are (nearly) done.  A host with a few
-        // threads never holds (in_flight <= busy_requests); one with hundreds gets sets of hundreds instead of sets of three.
+        // Batching while busy: while max_sets launch sets with many requests are running, another small set beside them buys nothing
+        // (a lone still is one CABAC critical path, ~250 ms, whatever else runs) and gathering lets the NEXT set be large enough for the
+        // work pool; so the leader keeps collecting until one of them is done.  A few sets overlap (each with its share of the pool's
+        // waves): the application threads rotate through them and one set's dependency tail is covered by the others' bulk.
+        // A host with a few threads never holds; one with hundreds gets sets of a hundred instead of sets of three (measured through the
+        // real libheif, 256 threads x 4K stills: 0.36 -> 2.4 Gpixel/s with one set at a time, profiles/r03_dropin_*.txt).
         const auto hold_until = t0 + std::chrono::microseconds(g_co.hold_us);
-        while (g_co.in_flight > g_co.busy_requests && Clock::now() < hold_until) g_co.cv.wait_until(lk, hold_until);
+        while (g_co.sets_in_flight >= g_co.max_sets && g_co.in_flight > g_co.busy_requests && Clock::now() < hold_until) g_co.cv.wait_until(lk, hold_until);
         for (;;) {
           const auto t = Clock::now();
           if (t >= deadline) break;
@@ -847,9 +872,16 @@ static int decoder_decode_impl(hipdec_decoder* d, hipdec_image_info* info)
           if (!joiners && (!overlapping || quiet)) break;
           g_co.cv.wait_until(lk, joiners ? deadline : std::min(deadline, quiet_at));
         }
-        take.swap(g_co.pending);
+        if ((long)g_co.pending.size() <= g_co.max_set) take.swap(g_co.pending);
+        else {   // the leader's own request first, then the oldest ones; the rest elect the next leader
+          take.push_back(&req);
+          for (auto* r : g_co.pending) if (r != &req && (long)take.size() < g_co.max_set) take.push_back(r);
+          g_co.pending.erase(std::remove_if(g_co.pending.begin(), g_co.pending.end(), [&](DecodeRequest* r) { return std::find(take.begin(), take.end(), r) != take.end(); }),
+                             g_co.pending.end());
+        }
         for (auto* r : take) { r->taken = true; uncount(r->d); }
         g_co.in_flight += (int)take.size();
+        g_co.sets_in_flight++;
         counted_in_flight = true;
         g_co.collecting = false;
         g_co.cv.notify_all();
@@ -862,7 +894,7 @@ static int decoder_decode_impl(hipdec_decoder* d, hipdec_image_info* info)
         if (!lk.owns_lock()) lk.lock();
         g_co.collecting = false;
         g_co.pending.erase(std::remove(g_co.pending.begin(), g_co.pending.end(), &req), g_co.pending.end());
-        if (counted_in_flight) g_co.in_flight -= (int)take.size();
+        if (counted_in_flight) { g_co.in_flight -= (int)take.size(); g_co.sets_in_flight--; }
         for (auto* r : take)
           if (!r->done) {
             if (!r->rc && !r->d->batch) { r->rc = HIPDEC_ERR_MEMORY; r->err = "decode: out of memory while building a shared launch set"; }
@@ -873,6 +905,7 @@ static int decoder_decode_impl(hipdec_decoder* d, hipdec_image_info* info)
         throw;
       }
       g_co.in_flight -= (int)take.size();
+      g_co.sets_in_flight--;
       for (auto* r : take) r->done = true;
       g_co.cv.notify_all();
     }

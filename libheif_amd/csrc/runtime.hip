@@ -107,8 +107,10 @@ ArenaPool g_pool;
 // Defaults suit the plugin path (one arena per item / grid photo).  A throughput host that streams large batches raises both
 // with hipdec_set_arena_cache_bytes(): hipFree() of a batch arena synchronises the device, which would serialise the
 // double-buffered "parse + upload batch k+1 while batch k decodes" pipeline.
-std::atomic<size_t> g_max_cached_bytes{size_t(8) << 30};    // keep at most 8 GiB parked
-std::atomic<size_t> g_max_pooled_arena{size_t(1) << 30};    // bigger arenas are not cached by default
+// (round 3: sized for the 288 GB of an MI355X.  The decoder path builds a batch per launch set — hundreds of stills, several GiB —
+//  and with the round-2 defaults (8 GiB parked, arenas above 1 GiB never) every set paid a hipMalloc and a device-synchronising hipFree.)
+std::atomic<size_t> g_max_cached_bytes{size_t(96) << 30};   // keep at most 96 GiB parked
+std::atomic<size_t> g_max_pooled_arena{size_t(64) << 30};   // bigger arenas are not cached
 
 struct PinnedPool {
   std::mutex mu;
@@ -199,7 +201,10 @@ void pinned_pool_clear()
 hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity)
 {
   // round small arenas up so that items of similar size share a class
-  const size_t kClass = size_t(4) << 20;
+  // size classes: 4 MiB steps up to 64 MiB, then a quarter of the largest power of two below the size (at most 25 % slack, a handful of
+  // classes per octave), so that launch sets of varying size share parked arenas
+  size_t kClass = size_t(4) << 20;
+  if (bytes > (size_t(64) << 20)) { size_t p2 = size_t(1) << 26; while ((p2 << 1) <= bytes) p2 <<= 1; kClass = p2 >> 2; }
   if (bytes <= g_max_pooled_arena.load()) bytes = (bytes + kClass - 1) / kClass * kClass;
   {
     std::lock_guard<std::mutex> lock(g_pool.mu);
@@ -208,7 +213,7 @@ hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity)
     for (size_t i = 0; i < g_pool.free_list.size(); i++) {
       const size_t cap = g_pool.free_list[i].first;
       if (g_pool.free_list[i].device != dev) continue;
-      if (cap >= bytes && cap <= bytes + bytes / 2 && (best == SIZE_MAX || cap < g_pool.free_list[best].first)) best = i;
+      if (cap >= bytes && cap <= 2 * bytes && (best == SIZE_MAX || cap < g_pool.free_list[best].first)) best = i;
     }
     if (best != SIZE_MAX) {
       *out = g_pool.free_list[best].second; *capacity = g_pool.free_list[best].first;

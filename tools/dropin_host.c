@@ -33,11 +33,36 @@ static release_fn image_release, handle_release; static dim_fn handle_w, handle_
 struct file { uint8_t* data; size_t size; };
 static struct file* files; static int n_files; static int n_threads; static int want_rgb;
 static volatile int stop_flag; static pthread_barrier_t start_barrier;
-struct worker { pthread_t th; int k; long decodes; double px; int failed; };
+struct worker { pthread_t th; int k; volatile long decodes; volatile double px; int failed; };
 
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
-static int decode_one(const struct file* f, double* px)
+/* mode 2 ("direct"): the same threads drive the plugin's C ABI themselves (hipdec_decoder_new -> push_data -> decode -> read_plane into
+ * buffers each thread allocated once): what is left when libheif's container parsing and per-image plane allocation are taken away.  The
+ * files then are the plugin-framed HEVC streams. */
+typedef int (*dnew_fn)(void**, int, uint64_t); typedef void (*dfree_fn)(void*); typedef int (*dpush_fn)(void*, const void*, size_t);
+typedef int (*ddec_fn)(void*, void*); typedef int (*dread_fn)(void*, int, void*, size_t);
+static dnew_fn d_new; static dfree_fn d_free; static dpush_fn d_push; static ddec_fn d_decode; static dread_fn d_read;
+static int direct_mode;
+static int decode_direct(const struct file* f, volatile double* px, uint8_t* buf)
+{
+  void* d = NULL;
+  int info[32];
+  if (d_new(&d, 0, 0)) return 1;
+  int rc = d_push(d, f->data, f->size);
+  if (!rc) rc = d_decode(d, info);
+  if (!rc) {
+    const int w = info[0], h = info[1];     /* hipdec_image_info starts with width, height */
+    rc = d_read(d, 0, buf, (size_t)w);
+    if (!rc) rc = d_read(d, 1, buf + (size_t)w * h, (size_t)w / 2);
+    if (!rc) rc = d_read(d, 2, buf + (size_t)w * h * 5 / 4, (size_t)w / 2);
+    *px += (double)w * h;
+  }
+  d_free(d);
+  return rc;
+}
+
+static int decode_one(const struct file* f, volatile double* px)
 {
   void* ctx = ctx_alloc();
   struct heif_error e = read_mem(ctx, f->data, f->size, NULL);
@@ -55,11 +80,14 @@ static int decode_one(const struct file* f, double* px)
 static void* run(void* arg)
 {
   struct worker* w = (struct worker*)arg;
+  uint8_t* buf = direct_mode ? (uint8_t*)malloc((size_t)3840 * 2160 * 2) : NULL;
+  if (buf) memset(buf, 1, (size_t)3840 * 2160 * 2);
   pthread_barrier_wait(&start_barrier);
   for (int i = w->k; !stop_flag; i += n_threads) {
-    if (decode_one(&files[i % n_files], &w->px)) { w->failed = 1; break; }
+    if (direct_mode ? decode_direct(&files[i % n_files], &w->px, buf) : decode_one(&files[i % n_files], &w->px)) { w->failed = 1; break; }
     w->decodes++;
   }
+  free(buf);
   return NULL;
 }
 
@@ -78,6 +106,14 @@ int main(int argc, char** argv)
   struct heif_error e = load_plugin(argv[2], &info);
   if (e.code) { fprintf(stderr, "heif_load_plugin: %s\n", e.message); return 1; }
   n_threads = atoi(argv[3]); const double seconds = atof(argv[4]); want_rgb = atoi(argv[5]);
+  if (want_rgb == 2) {
+    direct_mode = 1; want_rgb = 0;
+    void* hp = dlopen(argv[2], RTLD_NOW | RTLD_NOLOAD);
+    if (!hp) hp = dlopen(argv[2], RTLD_NOW);
+    d_new = (dnew_fn)dlsym(hp, "hipdec_decoder_new"); d_free = (dfree_fn)dlsym(hp, "hipdec_decoder_free"); d_push = (dpush_fn)dlsym(hp, "hipdec_decoder_push_data");
+    d_decode = (ddec_fn)dlsym(hp, "hipdec_decoder_decode"); d_read = (dread_fn)dlsym(hp, "hipdec_decoder_read_plane");
+    if (!d_new || !d_read) { fprintf(stderr, "plugin C ABI not found\n"); return 1; }
+  }
   n_files = argc - 6; files = (struct file*)calloc((size_t)n_files, sizeof(struct file));
   for (int i = 0; i < n_files; i++) {
     FILE* f = fopen(argv[6 + i], "rb"); if (!f) { perror(argv[6 + i]); return 1; }
@@ -86,7 +122,9 @@ int main(int argc, char** argv)
     if (fread(files[i].data, 1, files[i].size, f) != files[i].size) return 1;
     fclose(f);
   }
-  double px0 = 0; if (decode_one(&files[0], &px0)) return 1;   /* warm-up: HIP runtime, code objects, arena pool */
+  double px0 = 0;   /* warm-up: HIP runtime, code objects, arena pool */
+  if (direct_mode) { uint8_t* b0 = (uint8_t*)malloc((size_t)3840 * 2160 * 2); if (decode_direct(&files[0], &px0, b0)) return 1; free(b0); }
+  else if (decode_one(&files[0], &px0)) return 1;
   void* hip = dlopen(argv[2], RTLD_NOW | RTLD_NOLOAD);
   void (*stats)(uint64_t*, uint64_t*, uint64_t*) = hip ? (void (*)(uint64_t*, uint64_t*, uint64_t*))dlsym(hip, "hipdec_decoder_coalesce_stats") : NULL;
   uint64_t r0 = 0, s0 = 0, x0 = 0, r1 = 0, s1 = 0, x1 = 0;
@@ -96,13 +134,22 @@ int main(int argc, char** argv)
   for (int k = 0; k < n_threads; k++) { ws[k].k = k; pthread_create(&ws[k].th, &at, run, &ws[k]); }
   if (stats) stats(&r0, &s0, &x0);
   pthread_barrier_wait(&start_barrier);
+  /* warm-up inside the run: the first launch sets allocate what later ones reuse (device arenas, pinned staging); the counters are read at
+   * the end of the warm-up and at the end of the measurement, both while all threads keep decoding (steady state) */
+  const double warm = getenv("DROPIN_WARMUP_S") ? atof(getenv("DROPIN_WARMUP_S")) : 3.0;
+  usleep((useconds_t)(warm * 1e6));
+  long n0 = 0; double p0 = 0;
+  for (int k = 0; k < n_threads; k++) { n0 += ws[k].decodes; p0 += ws[k].px; }
+  if (stats) stats(&r0, &s0, &x0);
   const double t0 = now();
   usleep((useconds_t)(seconds * 1e6));
-  stop_flag = 1;
   long n = 0; double px = 0; int failed = 0;
-  for (int k = 0; k < n_threads; k++) { pthread_join(ws[k].th, NULL); n += ws[k].decodes; px += ws[k].px; failed |= ws[k].failed; }
-  const double dt = now() - t0;   /* every counted decode completed inside dt */
+  for (int k = 0; k < n_threads; k++) { n += ws[k].decodes; px += ws[k].px; }
+  const double dt = now() - t0;
   if (stats) stats(&r1, &s1, &x1);
+  n -= n0; px -= p0;
+  stop_flag = 1;
+  for (int k = 0; k < n_threads; k++) { pthread_join(ws[k].th, NULL); failed |= ws[k].failed; }
   printf("%ld %.3f %.1f %llu %llu %d\n", n, dt, px / dt / 1e6, (unsigned long long)(r1 - r0), (unsigned long long)(s1 - s0), failed);
   return failed;
 }

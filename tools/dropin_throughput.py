@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def measure(threads_list=(64, 256), n_files=64, seconds=6.0, w=3840, h=2160, qp=27, rgb=False, quiet=True, libheif="libheif.so"):
+def measure(threads_list=(64, 256), n_files=64, seconds=6.0, w=3840, h=2160, qp=27, rgb=False, quiet=True, libheif="libheif.so", direct=False):
     """Runs the C harness (tools/dropin_host.c: pthreads, no Python in the timed loop) once per thread count."""
     import subprocess
     import tempfile
@@ -41,11 +41,12 @@ def measure(threads_list=(64, 256), n_files=64, seconds=6.0, w=3840, h=2160, qp=
     for i, s in enumerate(streams):
         pth = os.path.join(tmp, "f%04d.heic" % i)
         with open(pth, "wb") as f:
-            f.write(hu.build_heic([(s, w, h)]))
+            f.write(s if direct else hu.build_heic([(s, w, h)]))
         paths.append(pth)
     results = []
     for T in threads_list:
-        r = subprocess.run([exe, ref, libheif_amd.library_path(), str(T), str(seconds), "1" if rgb else "0"] + paths, capture_output=True, text=True, timeout=seconds * 4 + 120)
+        r = subprocess.run([exe, ref, libheif_amd.library_path(), str(T), str(seconds), "2" if direct else ("1" if rgb else "0")] + paths, capture_output=True, text=True, timeout=seconds * 4 + 120)
+        sys.stderr.write(r.stderr)
         if r.returncode != 0:
             results.append({"threads": T, "error": (r.stderr or r.stdout)[-400:]})
             continue
@@ -70,8 +71,9 @@ if __name__ == "__main__":
     ap.add_argument("--seconds", type=float, default=6.0)
     ap.add_argument("--rgb", action="store_true")
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--direct", action="store_true", help="the threads call the plugin's C ABI themselves (no libheif, planes into per-thread buffers): isolates the host side")
     ap.add_argument("--libheif", default="libheif.so", help="build of the reference under oracle/_ref: libheif.so (stock) or libheif_hipcolor.so (HIP colour op)")
     a = ap.parse_args()
-    out = measure([int(x) for x in a.threads.split(",")], a.files, a.seconds, rgb=a.rgb, quiet=a.json, libheif=a.libheif)
+    out = measure([int(x) for x in a.threads.split(",")], a.files, a.seconds, rgb=a.rgb, quiet=a.json, libheif=a.libheif, direct=a.direct)
     if a.json:
         print(json.dumps(out))
