@@ -15,8 +15,13 @@ independent stills per step (throughput form).  Two timed regions are reported:
 Beside them: per-kernel device times (HIP events on the launch stream) with §8(d)'s algorithmic bytes, the single-still
 latency form, the other synthetic inputs of §8(d) (S2 at QP 17, S3 grid, S4 Main10, S5 1080p) as `extra_workloads`, and the
 CPU oracle on the host cores.  With --gpus N (torch.distributed.run, one rank per GPU) every rank decodes its own batch
-(weak scaling, no data-path collective: independent stills exchange nothing); `--workload grid8k` shards the 48 tiles of
-an 8K grid over the ranks and gathers the decoded tiles onto rank 0's canvas with RCCL (strong scaling).
+(weak scaling, no data-path collective: independent stills exchange nothing).  `--workload grid8k` measures grid photos:
+every rank decodes its own stream of 8K grid photos (photo i -> GPU i mod N: throughput scales with independent photos);
+`--workload grid8k --grid-single` is the single-photo latency form (rank 0 shards the 48 tiles t mod N over the N devices with
+hipdec_grid_*, strided peer-copy paste into the canvas on device 0: expected flat).
+
+After the timed regions the run CHECKS a result: the planes and the RGB24 of still 0 are read back and compared with the CPU oracle's
+decode of the same stream (the cpu_baseline leg decodes it anyway); a mismatch fails the run.
 
 Prints ONE JSON line (rank 0).
 """
@@ -43,6 +48,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="still4k", choices=["still4k", "still1080", "main10_4k", "grid8k"])
     ap.add_argument("--batch", type=int, default=0, help="independent stills per rank and step (0 = workload default)")
+    ap.add_argument("--grid-single", action="store_true", help="grid8k: ONE photo, its 48 tiles sharded t mod N over the N devices by rank 0 (latency form; the "
+                    "default grid8k mode gives every rank its own photos: photo i -> GPU i mod N)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the T threads x heif_decode_image() measurement through the real libheif + plugin")
     ap.add_argument("--qp", type=int, default=27)
     ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic contents cycled through the batch")
     ap.add_argument("--enc", action="append", default=[], help="override a synthetic-encoder parameter, e.g. --enc wpp=0")
@@ -188,9 +196,8 @@ def main():
     grid = a.workload == "grid8k"
     extras_on = not (a.no_extras or a.only_main) and world == 1 and not grid
     if grid:
-        items = [t for t in range(48) if t % world == rank]   # tile t -> GPU t mod G
         specs = [(w, h, 2 + t, 8, enc_cfg) for t in range(48)]
-        nb = len(items)
+        nb = 48
     else:
         nb = a.batch or def_batch
         nd = max(1, min(a.distinct, nb))
@@ -256,20 +263,26 @@ def main():
     # ------------------------------------------------------------------------------------------------------------------
     gd = None
     if grid:
-        # the product path: hipdec_grid_* in C++ (include/heif_hipdec.h), ONE process over the node's GPUs — rank 0 shards the 48 tiles
-        # t mod N over devices 0..N-1, every decoded tile is pasted into the canvas on device 0 by a strided peer copy (xGMI), the colour
-        # stage runs over the canvas; the other ranks the launcher started only take part in the barriers
+        # the product path: hipdec_grid_* in C++ (include/heif_hipdec.h).  Default: every rank decodes its own photos on its own GPU
+        # (photo i -> GPU i mod N; independent photos are what scales: DESIGN.md section 5).  --grid-single: ONE photo, rank 0 shards its
+        # 48 tiles t mod N over devices 0..N-1, every decoded tile is pasted into the canvas on device 0 by a strided peer copy
+        # (xGMI), the colour stage runs over the canvas; the other ranks only take part in the barriers.
         from libheif_amd.grid import GridDecoderC, GridLayout
         layout = GridLayout(6, 8, w, h, 8 * w, 6 * h)
+        single = a.grid_single
         n_items, px_rank, bs_bytes = 48, w * h * 48, sum(len(x) for x in distinct)
-        total_px = w * h * 48
+        total_px = w * h * 48 * (1 if single else world)
         batch = None
-        if rank == 0:
-            gd = GridDecoderC({t: distinct[t] for t in range(48)}, layout, list(range(world)))
-            rgb_out = torch.empty((6 * h, 8 * w * 3), dtype=torch.uint8, device="cuda:0")
+        if single:
+            if rank == 0:
+                gd = GridDecoderC({t: distinct[t] for t in range(48)}, layout, list(range(world)))
+                rgb_out = torch.empty((6 * h, 8 * w * 3), dtype=torch.uint8, device="cuda:0")
+        else:
+            gd = GridDecoderC({t: distinct[t] for t in range(48)}, layout, [local_rank])
+            rgb_out = torch.empty((6 * h, 8 * w * 3), dtype=torch.uint8, device="cuda:%d" % local_rank)
 
         def step():
-            if rank == 0:
+            if gd is not None:
                 gd.decode()
                 gd.to_rgb(10, out_dev=(rgb_out.data_ptr(), rgb_out.stride(0)))     # waits for the shards, colour stage into HBM
     else:
@@ -291,6 +304,15 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     value = total_px / (elapsed / a.steps) / 1e6
     avg_us = kernel_times(wl.batches, a.steps) if not grid else None
+    # what the timed steps produced for still 0 (checked against the CPU oracle further down; outside every timed region)
+    check_item = None
+    if batch is not None and rank == 0 and not a.only_main and not a.no_cpu_baseline:
+        import hashlib
+        import numpy as np
+        got_planes = batch.planes(0)
+        got_rgb = batch.rgb(0)
+        check_item = {"planes": [hashlib.sha1(np.ascontiguousarray(p).tobytes()).hexdigest() for p in got_planes],
+                      "rgb": hashlib.sha1(np.ascontiguousarray(got_rgb).tobytes()).hexdigest()}
 
     out = None
     if rank == 0:
@@ -301,10 +323,11 @@ def main():
             "metric": "Mpixels/s HEIC 4:2:0 8-bit decode" if bit_depth == 8 else "Mpixels/s HEIC 4:2:0 %d-bit decode" % bit_depth,
             "value": round(value, 2), "unit": "Mpixel/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "strong" if grid else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if (grid and a.grid_single) else "weak", "vs_baseline": None,
             "dtype": "u8" if bit_depth == 8 else "u16",
             "data": "synthetic (seeded noise+gradient stills coded by the test-only HEVC intra encoder, QP %d, %d distinct contents)" % (a.qp, len(distinct)),
-            "config": {"workload": ("one 8192x6144 grid photo = 48 tiles of 1024x1024, tiles t mod N over N GPUs in one process (hipdec_grid_*), peer-copy paste + RGB24 on GPU 0" if grid else
+            "config": {"workload": (("one 8192x6144 grid photo = 48 tiles of 1024x1024, tiles t mod N over N GPUs in one process (hipdec_grid_*), peer-copy paste + RGB24 on GPU 0"
+                                     if a.grid_single else "one 8192x6144 grid photo (48 tiles of 1024x1024) per GPU and step through hipdec_grid_* + RGB24; photo i -> GPU i mod N") if grid else
                                     "%d x %dx%d HEIC 4:2:0 %d-bit stills per GPU and step, WPP, CTB 64, fused YCbCr->%s" %
                                     (n_items, w, h, bit_depth, "RGB24" if out_chroma == 10 else "RRGGBB")),
                        "timed_region": "inputs resident in HBM: hipdec_batch_run_rgb (decode + colour stage) per step (from host bytes: see from_host_bytes)",
@@ -312,7 +335,7 @@ def main():
                        "stage_overlap": bool(a.parts > 1 and not grid),
                        "stills_per_step_per_gpu": n_items, "distinct_contents": len(distinct), "bitstream_bytes_per_px": round(beta, 4),
                        "substreams_per_still": batch.info(0)["num_substreams"] if batch is not None else 16,
-                       "parallelism": ("tiles sharded over %d GPUs, one process" % world) if grid else "replicas x%d" % world},
+                       "parallelism": (("tiles sharded over %d GPUs, one process" % world) if a.grid_single else "independent photos, replicas x%d" % world) if grid else "replicas x%d" % world},
         }
         if avg_us is not None:
             coded = coded_fraction(batch)
@@ -322,15 +345,16 @@ def main():
             # HBM traffic of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE separately) over this same
             # command line, recorded per luma pixel in profiles/pmc_traffic.json by tools/prof_hbm_traffic.sh; only used when
             # the recorded workload is the one benchmarked now
-            traffic = None
+            traffic, traffic_source = None, None
             try:
                 rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
                 if rec.get("stills_per_step") == n_items and rec.get("workload") == a.workload and rec.get("qp") == a.qp:
                     traffic = round(rec["bytes_per_px"][KERNEL_NAMES[dom]] * px_rank, 0)
+                    traffic_source = "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command line, kernels of commit %s" % rec.get("commit", "?")
             except Exception:
                 pass
             out["roofline"] = dict(bound="hbm", kernel=KERNEL_NAMES[dom], achieved=kernels[dom]["achieved_gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                                   frac=kernels[dom]["frac"], traffic=traffic,
+                                   frac=kernels[dom]["frac"], traffic=traffic, traffic_source=traffic_source,
                                    note="dominant kernel by device time; CABAC parsing is bound by instruction issue (one dependency chain per "
                                         "substream), not by HBM (DESIGN.md §4); streaming kernels: see `kernels`")
             out["kernels"] = kernels
@@ -378,6 +402,7 @@ def main():
             ch["prev"].free()
             ch["next"].free()
         if rank == 0:
+            out["value_from_host_bytes"] = round(total_px / (el_h / a.steps) / 1e6, 2)   # SURVEY 8(d)'s wall-clock definition, as a first-class key
             out["from_host_bytes"] = {
                 "value": round(total_px / (el_h / a.steps) / 1e6, 2), "unit": "Mpixel/s", "ms_per_step": round(el_h / a.steps * 1e3, 3),
                 "host_ms_per_batch_create": round(state["host_s"] / max(1, state["creates"]) * 1e3, 2), "batches_per_step": len(wl.part_streams),
@@ -457,8 +482,27 @@ def main():
             e.free()
         out["extra_workloads"] = extras
 
+    # ------------------------------------------------------------------------------------------------------------------
+    # the drop-in form: T application threads x heif_decode_image() on distinct 4K HEIC files through the UNMODIFIED reference libheif
+    # (oracle/_ref/libheif.so, the host application here, prebuilt) + the plugin, host to host (tools/dropin_throughput.py, C pthreads)
+    # ------------------------------------------------------------------------------------------------------------------
+    if rank == 0 and not a.only_main and not a.no_dropin and not a.no_extras and world == 1 and not grid and a.workload == "still4k":
+        try:
+            from tools import dropin_throughput
+            out["dropin_through_libheif"] = dropin_throughput.measure((256, 1024), n_files=64, seconds=4.0, qp=a.qp)
+        except Exception as e:   # the reference build is test infrastructure: its absence must not fail the bench
+            out["dropin_through_libheif"] = {"error": repr(e)[:300]}
+
     if rank == 0 and not a.no_cpu_baseline and not a.only_main and world == 1:
         out["cpu_baseline"] = cpu_baseline(distinct[0], w * h, a.cpu_seconds, a.cpu_procs, bit_depth)
+        ref = out["cpu_baseline"].pop("_hashes")
+        if check_item is not None:
+            ok = check_item["planes"] == ref["planes"] and check_item["rgb"] == ref["rgb"]
+            out["verified"] = {"still": 0, "against": "CPU oracle decode + the reference's colour op of the same stream (sha1 of Y, Cb, Cr and of the RGB rows)",
+                               "planes_match": check_item["planes"] == ref["planes"], "rgb_match": check_item["rgb"] == ref["rgb"]}
+            if not ok:
+                print(json.dumps(out), flush=True)
+                raise SystemExit("bench.py: the decoded still 0 differs from the CPU oracle: %r vs %r" % (check_item, ref))
     barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -467,21 +511,32 @@ def main():
 
 
 def _cpu_worker(arg):
-    stream, budget_s, max_n, bit_depth = arg
+    stream, budget_s, max_n, bit_depth, want_hash = arg
     from oracle import pyoracle as orc
     n = 0
+    hashes = None
     t0 = time.perf_counter()
     while True:
         r = orc.decode(stream)
         y, cb, cr = r["planes"]
         if bit_depth == 8:
-            orc.color_420_to_rgb24(y, cb, cr, (1, 13, 6, 1))
+            nclx = tuple(r["nclx"])
+            m = 6 if nclx[2] == 2 else nclx[2]
+            if nclx[3] and m not in (0, 8):      # the reference planner's rule: integer op for full range, else the float chain
+                rgb = orc.color_420_to_rgb24(y, cb, cr, nclx)
+            else:
+                rgb = orc.color_rgb_planar_to_interleaved8(*orc.color_ycbcr_to_rgb_planar(y, cb, cr, 8, 1, nclx))
         else:
-            orc.color_420_to_rrggbb(y, cb, cr, bit_depth, tuple(r["nclx"]))
+            rgb = orc.color_420_to_rrggbb(y, cb, cr, bit_depth, tuple(r["nclx"]))
         n += 1
+        if want_hash and hashes is None:
+            import hashlib
+            import numpy as np
+            hashes = {"planes": [hashlib.sha1(np.ascontiguousarray(p).tobytes()).hexdigest() for p in (y, cb, cr)],
+                      "rgb": hashlib.sha1(np.ascontiguousarray(rgb).tobytes()).hexdigest()}
         if time.perf_counter() - t0 > budget_s or n >= max_n:
             break
-    return n, time.perf_counter() - t0
+    return n, time.perf_counter() - t0, hashes
 
 
 def cpu_baseline(stream, px, budget_s, procs, bit_depth=8):
@@ -492,12 +547,12 @@ def cpu_baseline(stream, px, budget_s, procs, bit_depth=8):
     procs = procs or min(32, os.cpu_count() or 1)
     per_proc_s = max(1.0, budget_s / 2)      # ~2 x budget_s core-seconds per process pair keeps the run short
     with mp.get_context("fork").Pool(procs) as pool:
-        res = pool.map(_cpu_worker, [(stream, per_proc_s, 6, bit_depth)] * procs)
+        res = pool.map(_cpu_worker, [(stream, per_proc_s, 6, bit_depth, i == 0) for i in range(procs)])
     n = sum(r[0] for r in res)
     dt = max(r[1] for r in res)
-    return {"value": round(px * n / dt / 1e6, 2), "unit": "Mpixel/s", "cores": procs, "kind": "port",
+    return {"_hashes": res[0][2], "value": round(px * n / dt / 1e6, 2), "unit": "Mpixel/s", "cores": procs, "kind": "port",
             "sample": "%d processes x ~%d decode(s) of one still of the bench workload (CPU oracle decode + the reference's "
-                      "4:2:0->RGB op), %.1f s wall, %.0f core-seconds" % (procs, n // procs, dt, sum(r[1] for r in res))}
+                      "4:2:0->RGB ops), %.1f s wall, %.0f core-seconds" % (procs, n // procs, dt, sum(r[1] for r in res))}
 
 
 if __name__ == "__main__":
