@@ -311,7 +311,7 @@ def main():
         import numpy as np
         got_planes = batch.planes(0)
         got_rgb = batch.rgb(0)
-        check_item = {"planes": [hashlib.sha1(np.ascontiguousarray(p).tobytes()).hexdigest() for p in got_planes],
+        check_item = {"planes": [hashlib.sha1(np.ascontiguousarray(p, dtype=np.uint16).tobytes()).hexdigest() for p in got_planes],
                       "rgb": hashlib.sha1(np.ascontiguousarray(got_rgb).tobytes()).hexdigest()}
 
     out = None
@@ -532,7 +532,7 @@ def _cpu_worker(arg):
         if want_hash and hashes is None:
             import hashlib
             import numpy as np
-            hashes = {"planes": [hashlib.sha1(np.ascontiguousarray(p).tobytes()).hexdigest() for p in (y, cb, cr)],
+            hashes = {"planes": [hashlib.sha1(np.ascontiguousarray(p, dtype=np.uint16).tobytes()).hexdigest() for p in (y, cb, cr)],
                       "rgb": hashlib.sha1(np.ascontiguousarray(rgb).tobytes()).hexdigest()}
         if time.perf_counter() - t0 > budget_s or n >= max_n:
             break

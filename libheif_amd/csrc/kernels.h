@@ -23,7 +23,6 @@ struct FilterArgs {
 };
 
 void launch_parse(const ParseArgs& a, hipStream_t s);
-void launch_parse_scalar(const ParseArgs& a, hipStream_t s);   // parse_kernel_scalar.hip: latency variant
 void launch_residual(const FilterArgs& a, int n_pics, int max_ctbs, hipStream_t s);
 void launch_recon(const ReconArgs& a, bool wide, hipStream_t s);
 void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s);

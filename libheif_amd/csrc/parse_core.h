@@ -22,8 +22,8 @@
 //     8 branch against 23 VALU instructions per pixel, profiles/r02g_pmc_parse_b512.txt).  So the arithmetic decoder's state
 //     (range / value / bit count: UReg) and the context-state update are deliberately kept in VECTOR registers although they are
 //     uniform; syntax control flow, lane selects and the bin values the syntax branches on stay scalar.  After the rebalancing:
-//     26.4 SALU + 26.1 VALU + 8 branch per pixel (profiles/r02l_pmc_parse_b512_after_valu_state.txt).  The latency variant
-//     (parse_kernel_scalar.hip, a handful of waves on the chip) keeps everything scalar: shorter dependent-issue latency.
+//     26.4 SALU + 26.1 VALU + 8 branch per pixel (profiles/r02l_pmc_parse_b512_after_valu_state.txt); round 3's hand-scheduled
+//     statements for the bins: 23.4 + 21.9 + 7.3 (profiles/r03b_pmc_parse_b512.txt).
 //   * the 64 lanes do the data-parallel side jobs (context init, window loads and emulation-prevention scan, map fills, per-sub-
 //     block context selection and level finalisation, coefficient block flush, WPP context save / restore).
 //
@@ -69,11 +69,7 @@ typedef uint32_t VReg;
 PC_DEV uint32_t pc_rdlane(const VReg& r, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)r, l); }
 // v_writelane_b32 (hipcc 7.2 exposes no builtin for it): two instructions instead of move + compare + wait state + select.  gfx9
 // encodings may read only ONE SGPR besides M0, so the lane select travels in M0 (what the compiler's own legalisation of this
-// instruction does).  The value must be provably uniform for the "s" constraint; the latency variant (HIPDEC_PARSE_SCALAR_CABAC), whose
-// arithmetic-decoder values pass through VALU float code, keeps the select form.
-#if defined(HIPDEC_PARSE_SCALAR_CABAC)
-PC_DEV void pc_wrlane(VReg& r, int l, uint32_t x) { r = ((int)threadIdx.x == l) ? x : r; }
-#else
+// instruction does).  The value must be provably uniform for the "s" constraint.
 PC_DEV void pc_wrlane(VReg& r, int l, uint32_t x)
 {
   // (M0 in the clobber list draws a "reserved register" warning: the compiler does not allocate it; nothing else in these kernels
@@ -84,7 +80,6 @@ PC_DEV void pc_wrlane(VReg& r, int l, uint32_t x)
   const int ls = __builtin_amdgcn_readfirstlane(l);
   asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(r) : "s"(xs), "s"(ls) : "m0");
 }
-#endif
 // the same with the (wave-uniform) value in a VECTOR register: compare + select, no scalar instruction
 PC_DEV void pc_wrlane_v(VReg& r, int l, uint32_t x) { r = ((int)threadIdx.x == l) ? x : r; }
 PC_DEV uint32_t pc_uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
@@ -95,15 +90,8 @@ PC_DEV uint64_t pc_ballot(const VReg& r) { return __ballot(r != 0); }
 // a wave-uniform value deliberately kept in a VECTOR register: the asm move hides its uniformity from the compiler,
 // so arithmetic on it is issued to the SIMD's VALU instead of the CU-shared scalar pipe
 typedef uint32_t UReg;
-#if defined(HIPDEC_PARSE_SCALAR_CABAC)
-// latency variant (parse_kernel_scalar.hip): with a handful of waves on the chip the scalar pipe is idle and its dependent-
-// issue latency is shorter than the VALU's, so the arithmetic decoder's state stays in SGPRs
-PC_DEV UReg pc_vec(uint32_t x) { return x; }
-PC_DEV bool pc_any(bool b) { return b; }
-#else
 PC_DEV UReg pc_vec(uint32_t x) { UReg r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
 PC_DEV bool pc_any(bool b) { return __ballot(b) != 0; }   // uniform branch condition from a (uniform-valued) vector compare
-#endif
 PC_DEV float pc_rcp(float x) { return __builtin_amdgcn_rcpf(x); }                       // v_rcp_f32, 1 ulp
 PC_DEV uint32_t pc_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }              // operands < 2^24
 #define PC_LDS_SYNC() __syncthreads()
@@ -295,7 +283,7 @@ PC_DEV int decode_bin_cxx(PS& s, VReg& grp, int ctx_lane)
   return bin;
 }
 
-#if !defined(HIPDEC_HOST_EMU) && !defined(HIPDEC_PARSE_SCALAR_CABAC) && !defined(HIPDEC_PARSE_CXX_BINS)
+#if !defined(HIPDEC_HOST_EMU) && !defined(HIPDEC_PARSE_CXX_BINS)
 #define PC_ASM_BINS 1
 // ---- hand-scheduled gfx950 forms of the two hot primitives ---------------------------------------------------------------------------
 // The compiler's code for decode_bin_cxx inside the sig_coeff_flag loop is 37 instructions per MPS bin (profiles/r03a_*): four hazard
@@ -308,8 +296,8 @@ PC_DEV int decode_bin_cxx(PS& s, VReg& grp, int ctx_lane)
 //   * an MPS that needs no renormalisation skips shift, bit count and refill test with one compare + branch;
 //   * the byte refill reads the 256-byte window register directly; only a window change / an emulation-prevention candidate / the end
 //     of the substream leaves the statement (flag bit 1 of the result), where refill_byte() does it the general way.
-// The statements are opaque to the compiler: all wait states are inside the strings (cdna guide §5.7).  The host emulation and the
-// latency variant run decode_bin_cxx — the same arithmetic — and the GPU parity suite runs these.
+// The statements are opaque to the compiler: all wait states are inside the strings (cdna guide section 5.7).  The host emulation runs
+// decode_bin_cxx — the same arithmetic — and the GPU parity suite runs these (build with -DHIPDEC_PARSE_CXX_BINS for the C++ form on the device).
 #define PC_ASM_HEAD_Q   "v_lshrrev_b32 %[vt], 10, %[R]\n\tv_and_b32 %[vt], 24, %[vt]\n\t"
 // LPS tail shared by both statements: value -= R, renormalise by clz(lps), next state from t_next (valMps flips at pStateIdx 0)
 #define PC_ASM_LPS(BIN_FIX)                                                                                                        \

@@ -38,9 +38,8 @@ void launch_parse(const ParseArgs& a, hipStream_t s)
 {
   if (!a.num_waves) return;
   static const int forced = getenv("HIPDEC_PARSE_OCCUPANCY") ? atoi(getenv("HIPDEC_PARSE_OCCUPANCY")) : -1;
-  // latency mode (a still, a small grid: at most a couple of waves per CU): the scalar-register variant
-  static const int scalar_below = getenv("HIPDEC_PARSE_SCALAR_BELOW") ? atoi(getenv("HIPDEC_PARSE_SCALAR_BELOW")) : 512;
-  if (forced < 0 && !a.pool && (int)a.num_waves <= scalar_below) { launch_parse_scalar(a, s); return; }
+  // (round 2 kept a scalar-register variant of the arithmetic decoder for lone stills; with the hand-scheduled statements the vector
+  //  form is faster there too — one 4K still: parse 247 -> 209 ms — and the variant is gone)
   // throughput mode (the chip is oversubscribed with parser waves): 8 waves per SIMD; latency mode: all registers
   // (pool mode: 8 waves per SIMD since the scalar / vector rebalancing of round 2 — 895 against 907 ms per 2048 4K stills with 7; before it the
   //  scalar pipe was saturated and the eighth wave bought nothing)
