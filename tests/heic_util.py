@@ -345,3 +345,41 @@ def build_heic(items, grid=None, bit_depth=8, chroma_format_idc=1, alpha_of=None
         offsets.append(pos)
         pos += len(blob)
     return ftyp + make_meta(offsets) + _box("mdat", b"".join(blobs))
+
+
+def build_tili(tiles, rows, cols, tile_w, tile_h, out_w, out_h, bit_depth=8, chroma_format_idc=1):
+    """A 'tili' tiled-image item (libheif/image-items/tiled.cc): ONE item whose data is an offset table ([u32 offset][u32 size] per tile,
+    row-major, offsets relative to the item data) followed by the tiles' coded slice data; the tiles share one decoder configuration
+    (the 'hvcC' child of the item's 'tilC' property, version 0 layout: tiled.cc:244-340), so every tile stream must carry the same
+    parameter sets.  tiles: plugin-framed HEVC streams, row-major."""
+    assert len(tiles) == rows * cols
+    nal_sets = [split_nals(s) for s in tiles]
+    ps0 = [n for n in nal_sets[0] if (n[0] >> 1) & 63 >= 32]
+    for ns in nal_sets[1:]:
+        assert [n for n in ns if (n[0] >> 1) & 63 >= 32] == ps0, "tili tiles must share their parameter sets"
+    payloads = [_payload(ns) for ns in nal_sets]
+    table_len = 8 * len(tiles)
+    table, pos = b"", table_len
+    for p in payloads:
+        table += struct.pack(">II", pos, len(p))
+        pos += len(p)
+    item_data = table + b"".join(payloads)
+    hvcc = _hvcc(nal_sets[0], chroma_format_idc, bit_depth)
+    tile_ispe = _fullbox("ispe", 0, 0, struct.pack(">II", tile_w, tile_h))
+    # tilC: flags bits 0-1 offset field length (0 = 32 bit), bits 2-3 size field length (2 = 32 bit)
+    tilc = _fullbox("tilC", 0, 0x08, struct.pack(">II4sB", tile_w, tile_h, b"hvc1", 0) + bytes([2]) + hvcc + tile_ispe)
+    ispe = _fullbox("ispe", 0, 0, struct.pack(">II", out_w, out_h))
+    ipco = _box("ipco", tilc + ispe)
+    ipma = struct.pack(">I", 1) + struct.pack(">HB", 1, 2) + bytes([0x80 | 1, 2])
+    iprp = _box("iprp", ipco + _fullbox("ipma", 0, 0, ipma))
+    iinf = _fullbox("iinf", 0, 0, struct.pack(">H", 1) + _fullbox("infe", 2, 0, struct.pack(">HH4s", 1, 0, b"tili") + b"\0"))
+    pitm = _fullbox("pitm", 0, 0, struct.pack(">H", 1))
+    hdlr = _fullbox("hdlr", 0, 0, struct.pack(">I4s", 0, b"pict") + b"\0" * 12 + b"\0")
+    ftyp = _box("ftyp", b"heic" + struct.pack(">I", 0) + b"mif1heic")
+
+    def make_meta(offset):
+        iloc = struct.pack(">BBH", 0x44, 0x00, 1) + struct.pack(">HHH", 1, 0, 1) + struct.pack(">II", offset, len(item_data))
+        return _fullbox("meta", 0, 0, hdlr + pitm + _fullbox("iloc", 0, 0, iloc) + iinf + iprp)
+
+    off = len(ftyp) + len(make_meta(0)) + 8
+    return ftyp + make_meta(off) + _box("mdat", item_data)
