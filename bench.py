@@ -210,6 +210,9 @@ def main():
             "s4_main10_4k": ("main10_4k", [(3840, 2160, 3 + i, 10, dict(WORKLOADS["main10_4k"][4], qp=a.qp)) for i in range(64)], 768),
             "s5_1080p": ("still1080", [(1920, 1080, 1000 + i, 8, dict(wpp=1, qp=a.qp)) for i in range(256)], 2048),
             "s3_grid8k": ("grid8k", [(1024, 1024, 2 + t, 8, dict(WORKLOADS["grid8k"][4], qp=a.qp)) for t in range(48)], 48),
+            # tiles-within-tiles expose more CABAC substreams per grid tile (WPP rows inside PPS tiles): 16 -> 32 -> 64
+            "s3t_grid8k_pps_tiles_2x2": ("grid8k", [(1024, 1024, 2 + t, 8, dict(WORKLOADS["grid8k"][4], qp=a.qp, tile_cols=2, tile_rows=2)) for t in range(48)], 48),
+            "s3t_grid8k_pps_tiles_4x4": ("grid8k", [(1024, 1024, 2 + t, 8, dict(WORKLOADS["grid8k"][4], qp=a.qp, tile_cols=4, tile_rows=4)) for t in range(48)], 48),
         }
         extra_streams = {k: gen_streams(v[1]) for k, v in extra_specs.items()}
 
@@ -460,7 +463,8 @@ def main():
                     g.decode(); g.to_rgb(10, out_dev=(grgb.data_ptr(), grgb.stride(0)))
                 el = timed(estep, 2, 1)
                 px = ew * eh * 48
-                extras[key] = {"workload": "one 8192x6144 grid photo = 48 tiles of 1024x1024 (768 substreams), hipdec_grid_* + RGB24 on one GPU",
+                nsub = 16 * (4 if "2x2" in key else (16 if "4x4" in key else 1)) // (1 if "pps" not in key else (2 if "2x2" in key else 4))
+                extras[key] = {"workload": "one 8192x6144 grid photo = 48 tiles of 1024x1024 (%d substreams per tile, %d in all), hipdec_grid_* + RGB24 on one GPU" % (nsub, 48 * nsub),
                                "value": round(px / (el / 2) / 1e6, 2), "unit": "Mpixel/s", "ms_per_step": round(el / 2 * 1e3, 3),
                                "bitstream_bytes_per_px": round(sum(len(x) for x in st) / px, 4)}
                 g.free()
