@@ -138,46 +138,63 @@ template <typename Pix> struct Px4;
 template <> struct Px4<uint8_t> { typedef uint32_t type; };
 template <> struct Px4<uint16_t> { typedef uint2 type; };
 
-// one edge segment (4 lines) of the luma plane and, where the chroma grid has an edge there, of the chroma planes — out of / into LDS
-template <typename Pix, int DIR>
-__device__ __forceinline__ void deblock_tile_edges(const FilterArgs& A, const PicParams& P, DeblockLds<Pix>& L, int tx, int ty, int item)
+// What filtering one edge segment (4 lines) needs besides the samples.  Gathered for BOTH directions before the tile's first barrier: the
+// look-ups are chains of dependent, L2-latency loads (unit index -> flags -> QP -> slice parameters), and fetched inside the phases they
+// left every workgroup waiting twice between barriers (first version of this kernel: 49.8 ms per 2048 4K stills against 27.4 ms for the two
+// passes of round 2; profiles/r03f_bench.json).
+struct EdgeMeta {
+  int valid;          // the segment lies on a filtered edge inside the picture
+  int luma, e, sg;
+  int qp_p, qp_q, no_p, no_q, beta_off2, tc_off2, cb_off, cr_off;
+};
+template <int DIR>
+__device__ __forceinline__ EdgeMeta deblock_edge_meta(const FilterArgs& A, const PicParams& P, int tx, int ty, int item)
 {
+  EdgeMeta M;
+  M.valid = 0;
+  // items 0..127: luma (edge e = item & 7 of the tile, segment s = item >> 3 along it); 128..159: chroma (e = item & 3, s = (item >> 2) & 7,
+  // both planes by the same lane: they share every decision input)
+  M.luma = item < 128;
+  M.e = M.luma ? item & 7 : item & 3; M.sg = M.luma ? item >> 3 : (item >> 2) & 7;
+  M.qp_p = M.qp_q = M.no_p = M.no_q = M.beta_off2 = M.tc_off2 = M.cb_off = M.cr_off = 0;
+  if (!M.luma && (item >= 160 || P.chroma_format_idc != 1)) return M;
+  // position in the component's plane: `across` runs across the edge (the edge lies at it), `along` along it
+  const int t_across = DIR == 0 ? tx : ty, t_along = DIR == 0 ? ty : tx;
+  const int csz = M.luma ? DB_TILE : DB_CT;
+  const int across = csz * t_across + 8 * M.e, along = csz * t_along - 4 + 4 * M.sg;
+  const int x = DIR == 0 ? across : along, y = DIR == 0 ? along : across;       // component samples
+  const int lx = M.luma ? x : 2 * x, ly = M.luma ? y : 2 * y;                     // luma samples
+  if (across == 0 || along < 0 || lx >= P.width || ly >= P.height) return M;
   const uint8_t* u_flags = A.arena + P.off_u_flags;
   const int8_t* u_qp = (const int8_t*)(A.arena + P.off_u_qp);
   const CtbInfo* ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
-  const int keep = UF_BYPASS | (P.pcm_loop_filter_disabled ? UF_PCM : 0);
-  // items 0..127: luma (edge e = item & 7 of the tile, segment s = item >> 3 along it); 128..159: chroma (e = item & 3, s = (item >> 2) & 7,
-  // both planes by the same lane: they share every decision input)
-  const bool luma = item < 128;
-  if (!luma && (item >= 160 || P.chroma_format_idc != 1)) return;
-  const int e = luma ? item & 7 : item & 3, sg = luma ? item >> 3 : (item >> 2) & 7;
-  // position in the component's plane: `across` runs across the edge (the edge lies at it), `along` along it
-  const int t_across = DIR == 0 ? tx : ty, t_along = DIR == 0 ? ty : tx;
-  const int csz = luma ? DB_TILE : DB_CT;
-  const int across = csz * t_across + 8 * e, along = csz * t_along - 4 + 4 * sg;
-  const int x = DIR == 0 ? across : along, y = DIR == 0 ? along : across;       // component samples
-  const int lx = luma ? x : 2 * x, ly = luma ? y : 2 * y;                         // luma samples
-  if (across == 0 || along < 0 || lx >= P.width || ly >= P.height) return;
   int ctb_q, ctb_p;
   const size_t iq = unit_index(P, lx >> 2, ly >> 2, &ctb_q);
-  const uint8_t fq = u_flags[iq];
-  if (!(fq & (DIR == 0 ? UF_VEDGE : UF_HEDGE))) return;
   const size_t ip = DIR == 0 ? unit_index(P, (lx >> 2) - 1, ly >> 2, &ctb_p) : unit_index(P, lx >> 2, (ly >> 2) - 1, &ctb_p);
-  const uint8_t fp = u_flags[ip];
-  const int qp_q = u_qp[iq], qp_p = u_qp[ip];
-  // 8.7.2.5.7: samples of cu_transquant_bypass units, and of PCM units when pcm_loop_filter_disabled_flag = 1, are left unchanged
-  const int no_q = (fq & keep) != 0, no_p = (fp & keep) != 0;
+  const uint8_t fq = u_flags[iq], fp = u_flags[ip];       // (independent loads, issued together)
+  const int qq = u_qp[iq], qp = u_qp[ip];
   const SliceParams sl = ((const SliceParams*)(A.arena + P.off_slices))[ctb_info[ctb_q].slice_idx];
-  const int l_across = 4 + 8 * e, l_along = 4 * sg;     // inside the tile (the tile starts 4 samples before the first edge)
-  if (luma) {
+  if (!(fq & (DIR == 0 ? UF_VEDGE : UF_HEDGE))) return M;
+  // 8.7.2.5.7: samples of cu_transquant_bypass units, and of PCM units when pcm_loop_filter_disabled_flag = 1, are left unchanged
+  const int keep = UF_BYPASS | (P.pcm_loop_filter_disabled ? UF_PCM : 0);
+  M.valid = 1; M.qp_q = qq; M.qp_p = qp; M.no_q = (fq & keep) != 0; M.no_p = (fp & keep) != 0;
+  M.beta_off2 = sl.beta_offset_div2; M.tc_off2 = sl.tc_offset_div2; M.cb_off = sl.pps_cb_qp_offset; M.cr_off = sl.pps_cr_qp_offset;
+  return M;
+}
+template <typename Pix, int DIR>
+__device__ __forceinline__ void deblock_tile_edge(const PicParams& P, DeblockLds<Pix>& L, const EdgeMeta& M)
+{
+  if (!M.valid) return;
+  const int l_across = 4 + 8 * M.e, l_along = 4 * M.sg;     // inside the tile (the tile starts 4 samples before the first edge)
+  if (M.luma) {
     Pix* pix = L.y + (DIR == 0 ? l_along * DB_LS + l_across : l_across * DB_LS + l_along);
-    deblock_luma<Pix>(pix, DIR == 0 ? 1 : DB_LS, DIR == 0 ? DB_LS : 1, qp_p, qp_q, sl.beta_offset_div2, sl.tc_offset_div2, P.bit_depth_luma, no_p, no_q);
+    deblock_luma<Pix>(pix, DIR == 0 ? 1 : DB_LS, DIR == 0 ? DB_LS : 1, M.qp_p, M.qp_q, M.beta_off2, M.tc_off2, P.bit_depth_luma, M.no_p, M.no_q);
   } else {
 #pragma unroll
     for (int c = 0; c < 2; c++) {
       Pix* pix = L.c[c] + (DIR == 0 ? l_along * DB_CS + l_across : l_across * DB_CS + l_along);
-      deblock_chroma<Pix>(pix, DIR == 0 ? 1 : DB_CS, DIR == 0 ? DB_CS : 1, qp_p, qp_q, c == 0 ? sl.pps_cb_qp_offset : sl.pps_cr_qp_offset, sl.tc_offset_div2,
-                          P.bit_depth_chroma, no_p, no_q);
+      deblock_chroma<Pix>(pix, DIR == 0 ? 1 : DB_CS, DIR == 0 ? DB_CS : 1, M.qp_p, M.qp_q, c == 0 ? M.cb_off : M.cr_off, M.tc_off2, P.bit_depth_chroma, M.no_p,
+                          M.no_q);
     }
   }
 }
@@ -192,6 +209,7 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A, int tiles_x)
   if (64 * tx - 4 >= P.width + 4 || 64 * ty - 4 >= P.height + 4) return;     // (a smaller picture of a mixed batch)
   typedef typename Px4<Pix>::type V4;
   const int tid = (int)threadIdx.x;
+  const EdgeMeta mv = deblock_edge_meta<0>(A, P, tx, ty, tid), mh = deblock_edge_meta<1>(A, P, tx, ty, tid);   // in flight beside the tile loads
   // ---- load: groups of 4 samples (plane widths are multiples of 8 luma / 4 chroma samples: a group never straddles the plane's edge)
   {
     const Pix* rec = (const Pix*)(A.arena + P.off_rec[0]);
@@ -212,9 +230,9 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A, int tiles_x)
     }
   }
   __syncthreads();
-  deblock_tile_edges<Pix, 0>(A, P, L, tx, ty, tid);     // vertical edges of the tile
+  deblock_tile_edge<Pix, 0>(P, L, mv);     // vertical edges of the tile
   __syncthreads();
-  deblock_tile_edges<Pix, 1>(A, P, L, tx, ty, tid);     // horizontal edges, on the vertically filtered samples
+  deblock_tile_edge<Pix, 1>(P, L, mh);     // horizontal edges, on the vertically filtered samples
   __syncthreads();
   // ---- store
   {
