@@ -6,7 +6,7 @@
 // convert_libde265_image_to_heif_image (libheif/plugins/decoder_libde265.cc:97-171).
 //
 // MI355X mapping: both filters are embarrassingly parallel streaming passes (HBM-bound):
-//   deblock  one pass: a 64x64 luma tile (+ both 32x32 chroma tiles) displaced by -4 samples is staged in LDS, its vertical edges are
+//   deblock  one pass: a 256x16 luma tile (+ both 128x8 chroma tiles) displaced by -4 samples is staged in LDS, its vertical edges are
 //            filtered there, then its horizontal ones, and the tile is stored back in place (see k_deblock).  Algorithmic bytes:
 //            3*s + 1/16 per luma pixel for both directions together.
 //   SAO      one thread per 4 output samples, reads the deblocked picture, writes the cropped output
@@ -121,17 +121,20 @@ __device__ __forceinline__ void deblock_chroma(Pix* pix, int xs, int ys, int qp_
 // Vertical edges must be filtered before horizontal ones (8.7.2), which round 1 / 2 enforced with a kernel boundary: two passes, each
 // reading and writing the planes with byte accesses (23.6 % of the HBM peak by the algorithmic 3 s + 1/16 B per luma pixel).  The filter
 // touches at most 4 samples on either side of an edge and edges lie on the 8-sample grid, so a tile displaced by -4 samples in both
-// directions — [64 i - 4, 64 i + 60) — holds every sample its own edges read or write: the workgroup loads the tile once (4 samples per
+// directions — [T i - 4, T i + T - 4) — holds every sample its own edges read or write: the workgroup loads the tile once (4 samples per
 // lane and access), filters its vertical edges in LDS, then its horizontal edges on the result, and stores the tile.  Tiles partition the
 // plane, no tile reads another tile's samples, so the pass is in place and needs no ordering between workgroups.  Chroma (4:2:0) rides
-// along: its tile is [32 i - 4, 32 i + 28) of both chroma planes, edges on the 8-sample chroma grid.  Algorithmic bytes: 3 s + 1/16 per
+// along: its tile is the half-size one of both chroma planes (displaced by -4 chroma samples), edges on the 8-sample chroma grid.  Algorithmic bytes: 3 s + 1/16 per
 // luma pixel for BOTH directions together (read once, written once).
-constexpr int DB_TILE = 64, DB_LS = DB_TILE + 4, DB_CT = 32, DB_CS = DB_CT + 4;   // tile edges and LDS row strides in samples (odd dword counts)
+// Tile shape: 256 x 16 luma samples (128 x 8 chroma): a tile row is one 256-byte span, i.e. ONE coalesced dword-per-lane access of a wave;
+// 64 x 64 tiles (64-byte row pieces displaced by 4 bytes: two half-used cache lines per row and wave-instruction quarter) ran at 49.5 ms per
+// 2048 4K stills, slower than the two byte-access passes they replaced (27.4 ms).
+constexpr int DB_TW = 256, DB_TH = 16, DB_LS = DB_TW + 4, DB_CTW = DB_TW / 2, DB_CTH = DB_TH / 2, DB_CS = DB_CTW + 4;   // LDS row strides: odd dword counts
 
 template <typename Pix>
 struct DeblockLds {
-  alignas(16) Pix y[DB_TILE * DB_LS];
-  alignas(16) Pix c[2][DB_CT * DB_CS];
+  alignas(16) Pix y[DB_TH * DB_LS];
+  alignas(16) Pix c[2][DB_CTH * DB_CS];
 };
 
 template <typename Pix> struct Px4;
@@ -152,16 +155,17 @@ __device__ __forceinline__ EdgeMeta deblock_edge_meta(const FilterArgs& A, const
 {
   EdgeMeta M;
   M.valid = 0;
-  // items 0..127: luma (edge e = item & 7 of the tile, segment s = item >> 3 along it); 128..159: chroma (e = item & 3, s = (item >> 2) & 7,
-  // both planes by the same lane: they share every decision input)
+  // items 0..127: the tile's luma segments (128 of them in either direction); 128..159: the chroma segments (32; both planes by the same lane:
+  // they share every decision input).  Consecutive lanes take consecutive positions along a sample row (x): conflict-free LDS rows.
   M.luma = item < 128;
-  M.e = M.luma ? item & 7 : item & 3; M.sg = M.luma ? item >> 3 : (item >> 2) & 7;
+  const int it = M.luma ? item : item - 128;
+  const int tw = M.luma ? DB_TW : DB_CTW, th = M.luma ? DB_TH : DB_CTH;
+  if (DIR == 0) { M.e = it % (tw / 8); M.sg = it / (tw / 8); }      // vertical edges: tw / 8 edges x th / 4 segments
+  else { M.sg = it % (tw / 4); M.e = it / (tw / 4); }                // horizontal edges: th / 8 edges x tw / 4 segments
   M.qp_p = M.qp_q = M.no_p = M.no_q = M.beta_off2 = M.tc_off2 = M.cb_off = M.cr_off = 0;
   if (!M.luma && (item >= 160 || P.chroma_format_idc != 1)) return M;
   // position in the component's plane: `across` runs across the edge (the edge lies at it), `along` along it
-  const int t_across = DIR == 0 ? tx : ty, t_along = DIR == 0 ? ty : tx;
-  const int csz = M.luma ? DB_TILE : DB_CT;
-  const int across = csz * t_across + 8 * M.e, along = csz * t_along - 4 + 4 * M.sg;
+  const int across = (DIR == 0 ? tw * tx : th * ty) + 8 * M.e, along = (DIR == 0 ? th * ty : tw * tx) - 4 + 4 * M.sg;
   const int x = DIR == 0 ? across : along, y = DIR == 0 ? along : across;       // component samples
   const int lx = M.luma ? x : 2 * x, ly = M.luma ? y : 2 * y;                     // luma samples
   if (across == 0 || along < 0 || lx >= P.width || ly >= P.height) return M;
@@ -206,27 +210,26 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A, int tiles_x)
   __shared__ DeblockLds<Pix> L;
   const PicParams& P = A.pics[blockIdx.y];
   const int tx = (int)blockIdx.x % tiles_x, ty = (int)blockIdx.x / tiles_x;
-  if (64 * tx - 4 >= P.width + 4 || 64 * ty - 4 >= P.height + 4) return;     // (a smaller picture of a mixed batch)
+  if (DB_TW * tx - 8 >= P.width || DB_TH * ty - 8 >= P.height) return;     // (a smaller picture of a mixed batch; the chroma tile starts 8 luma samples early)
   typedef typename Px4<Pix>::type V4;
   const int tid = (int)threadIdx.x;
   const EdgeMeta mv = deblock_edge_meta<0>(A, P, tx, ty, tid), mh = deblock_edge_meta<1>(A, P, tx, ty, tid);   // in flight beside the tile loads
-  // ---- load: groups of 4 samples (plane widths are multiples of 8 luma / 4 chroma samples: a group never straddles the plane's edge)
-  {
-    const Pix* rec = (const Pix*)(A.arena + P.off_rec[0]);
-    const int stride = (int)(P.rec_stride[0] / sizeof(Pix));
-    const int x0 = 64 * tx - 4, y0 = 64 * ty - 4;
-    for (int u = tid; u < DB_TILE * (DB_TILE / 4); u += 256) {
-      const int r = u >> 4, g = u & 15, x = x0 + 4 * g, y = y0 + r;
-      if (x >= 0 && x < P.width && y >= 0 && y < P.height) *(V4*)&L.y[r * DB_LS + 4 * g] = *(const V4*)&rec[(size_t)y * stride + x];
-    }
-    if (P.chroma_format_idc == 1) {
-      const int cx0 = 32 * tx - 4, cy0 = 32 * ty - 4;
-      for (int u = tid; u < 2 * DB_CT * (DB_CT / 4); u += 256) {
-        const int c = u >> 8, r = (u >> 3) & 31, g = u & 7, x = cx0 + 4 * g, y = cy0 + r;
-        const Pix* rc = (const Pix*)(A.arena + P.off_rec[1 + c]);
-        const int cs = (int)(P.rec_stride[1 + c] / sizeof(Pix));
-        if (x >= 0 && x < P.cwidth && y >= 0 && y < P.cheight) *(V4*)&L.c[c][r * DB_CS + 4 * g] = *(const V4*)&rc[(size_t)y * cs + x];
-      }
+  const bool chroma = P.chroma_format_idc == 1;
+  // groups of 4 samples (plane widths are multiples of 8 luma / 4 chroma samples: a group never straddles the plane's edge); one luma tile row
+  // = 64 groups = one access of a wave
+  const int x0 = DB_TW * tx - 4, y0 = DB_TH * ty - 4, cx0 = DB_CTW * tx - 4, cy0 = DB_CTH * ty - 4;
+  const int ystride = (int)(P.rec_stride[0] / sizeof(Pix));
+  Pix* const rec_y = (Pix*)(A.arena + P.off_rec[0]);
+  for (int u = tid; u < DB_TH * (DB_TW / 4); u += 256) {
+    const int r = u / (DB_TW / 4), g = u % (DB_TW / 4), x = x0 + 4 * g, y = y0 + r;
+    if (x >= 0 && x < P.width && y >= 0 && y < P.height) *(V4*)&L.y[r * DB_LS + 4 * g] = *(const V4*)&rec_y[(size_t)y * ystride + x];
+  }
+  if (chroma) {
+    for (int u = tid; u < 2 * DB_CTH * (DB_CTW / 4); u += 256) {
+      const int c = u / (DB_CTH * (DB_CTW / 4)), v = u % (DB_CTH * (DB_CTW / 4)), r = v / (DB_CTW / 4), g = v % (DB_CTW / 4), x = cx0 + 4 * g, y = cy0 + r;
+      const Pix* rc = (const Pix*)(A.arena + P.off_rec[1 + c]);
+      const int cs = (int)(P.rec_stride[1 + c] / sizeof(Pix));
+      if (x >= 0 && x < P.cwidth && y >= 0 && y < P.cheight) *(V4*)&L.c[c][r * DB_CS + 4 * g] = *(const V4*)&rc[(size_t)y * cs + x];
     }
   }
   __syncthreads();
@@ -234,23 +237,16 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A, int tiles_x)
   __syncthreads();
   deblock_tile_edge<Pix, 1>(P, L, mh);     // horizontal edges, on the vertically filtered samples
   __syncthreads();
-  // ---- store
-  {
-    Pix* rec = (Pix*)(A.arena + P.off_rec[0]);
-    const int stride = (int)(P.rec_stride[0] / sizeof(Pix));
-    const int x0 = 64 * tx - 4, y0 = 64 * ty - 4;
-    for (int u = tid; u < DB_TILE * (DB_TILE / 4); u += 256) {
-      const int r = u >> 4, g = u & 15, x = x0 + 4 * g, y = y0 + r;
-      if (x >= 0 && x < P.width && y >= 0 && y < P.height) *(V4*)&rec[(size_t)y * stride + x] = *(const V4*)&L.y[r * DB_LS + 4 * g];
-    }
-    if (P.chroma_format_idc == 1) {
-      const int cx0 = 32 * tx - 4, cy0 = 32 * ty - 4;
-      for (int u = tid; u < 2 * DB_CT * (DB_CT / 4); u += 256) {
-        const int c = u >> 8, r = (u >> 3) & 31, g = u & 7, x = cx0 + 4 * g, y = cy0 + r;
-        Pix* rc = (Pix*)(A.arena + P.off_rec[1 + c]);
-        const int cs = (int)(P.rec_stride[1 + c] / sizeof(Pix));
-        if (x >= 0 && x < P.cwidth && y >= 0 && y < P.cheight) *(V4*)&rc[(size_t)y * cs + x] = *(const V4*)&L.c[c][r * DB_CS + 4 * g];
-      }
+  for (int u = tid; u < DB_TH * (DB_TW / 4); u += 256) {
+    const int r = u / (DB_TW / 4), g = u % (DB_TW / 4), x = x0 + 4 * g, y = y0 + r;
+    if (x >= 0 && x < P.width && y >= 0 && y < P.height) *(V4*)&rec_y[(size_t)y * ystride + x] = *(const V4*)&L.y[r * DB_LS + 4 * g];
+  }
+  if (chroma) {
+    for (int u = tid; u < 2 * DB_CTH * (DB_CTW / 4); u += 256) {
+      const int c = u / (DB_CTH * (DB_CTW / 4)), v = u % (DB_CTH * (DB_CTW / 4)), r = v / (DB_CTW / 4), g = v % (DB_CTW / 4), x = cx0 + 4 * g, y = cy0 + r;
+      Pix* rc = (Pix*)(A.arena + P.off_rec[1 + c]);
+      const int cs = (int)(P.rec_stride[1 + c] / sizeof(Pix));
+      if (x >= 0 && x < P.cwidth && y >= 0 && y < P.cheight) *(V4*)&rc[(size_t)y * cs + x] = *(const V4*)&L.c[c][r * DB_CS + 4 * g];
     }
   }
 }
@@ -566,8 +562,8 @@ __global__ __launch_bounds__(256) void k_sao_rgb(FilterArgs A, const colordev::C
 
 void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s)
 {
-  // tiles [64 i - 4, 64 i + 60) over the luma plane; the chroma tiles [32 i - 4, 32 i + 28) may need one more column / row
-  const int tiles_x = (max_w + 8 + 63) / 64, tiles_y = (max_h + 8 + 63) / 64;
+  // tiles [T i - 4, T i + T - 4) over the luma plane; the chroma tiles (displaced by -4 CHROMA samples) may need one more column / row
+  const int tiles_x = (max_w + 8 + DB_TW - 1) / DB_TW, tiles_y = (max_h + 8 + DB_TH - 1) / DB_TH;
   if (wide) hipLaunchKernelGGL((k_deblock<uint16_t>), dim3(tiles_x * tiles_y, n_pics), dim3(256), 0, s, a, tiles_x);
   else hipLaunchKernelGGL((k_deblock<uint8_t>), dim3(tiles_x * tiles_y, n_pics), dim3(256), 0, s, a, tiles_x);
 }
