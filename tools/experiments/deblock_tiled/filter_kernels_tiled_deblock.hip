@@ -6,11 +6,9 @@
 // convert_libde265_image_to_heif_image (libheif/plugins/decoder_libde265.cc:97-171).
 //
 // MI355X mapping: both filters are embarrassingly parallel streaming passes (HBM-bound):
-//   deblock  one thread per 4-sample edge segment; vertical edges of the whole batch first, then
-//            horizontal edges (kernel boundary = the ordering the standard requires); consecutive
-//            lanes take consecutive segments of one sample row so each row access of a wave is one
-//            contiguous 256-512 B span; in place (segments never overlap: edges are 8 apart, at most
-//            3 samples are modified per side).  Algorithmic bytes: 3*s per luma pixel per pass.
+//   deblock  one pass: a 256x16 luma tile (+ both 128x8 chroma tiles) displaced by -4 samples is staged in LDS, its vertical edges are
+//            filtered there, then its horizontal ones, and the tile is stored back in place (see k_deblock).  Algorithmic bytes:
+//            3*s + 1/16 per luma pixel for both directions together.
 //   SAO      one thread per 4 output samples, reads the deblocked picture, writes the cropped output
 //            plane.  Algorithmic bytes: 1.5*s in + 1.5*s out per luma pixel.
 // grid.y = picture index of the batch, grid.z = colour component where applicable.
@@ -119,57 +117,136 @@ __device__ __forceinline__ void deblock_chroma(Pix* pix, int xs, int ys, int qp_
 
 }  // namespace
 
-// DIR 0: vertical edges (filtering across x), DIR 1: horizontal edges
-template <typename Pix, int DIR>
-__global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
+// ---- deblocking: ONE pass over the picture, tiles staged in LDS ------------------------------------------------------------------------
+// Vertical edges must be filtered before horizontal ones (8.7.2), which round 1 / 2 enforced with a kernel boundary: two passes, each
+// reading and writing the planes with byte accesses (23.6 % of the HBM peak by the algorithmic 3 s + 1/16 B per luma pixel).  The filter
+// touches at most 4 samples on either side of an edge and edges lie on the 8-sample grid, so a tile displaced by -4 samples in both
+// directions — [T i - 4, T i + T - 4) — holds every sample its own edges read or write: the workgroup loads the tile once (4 samples per
+// lane and access), filters its vertical edges in LDS, then its horizontal edges on the result, and stores the tile.  Tiles partition the
+// plane, no tile reads another tile's samples, so the pass is in place and needs no ordering between workgroups.  Chroma (4:2:0) rides
+// along: its tile is the half-size one of both chroma planes (displaced by -4 chroma samples), edges on the 8-sample chroma grid.  Algorithmic bytes: 3 s + 1/16 per
+// luma pixel for BOTH directions together (read once, written once).
+// Tile shape: 256 x 16 luma samples (128 x 8 chroma): a tile row is one 256-byte span, i.e. ONE coalesced dword-per-lane access of a wave;
+// 64 x 64 tiles (64-byte row pieces displaced by 4 bytes: two half-used cache lines per row and wave-instruction quarter) ran at 49.5 ms per
+// 2048 4K stills, slower than the two byte-access passes they replaced (27.4 ms).
+constexpr int DB_TW = 256, DB_TH = 16, DB_LS = DB_TW + 4, DB_CTW = DB_TW / 2, DB_CTH = DB_TH / 2, DB_CS = DB_CTW + 4;   // LDS row strides: odd dword counts
+
+template <typename Pix>
+struct DeblockLds {
+  alignas(16) Pix y[DB_TH * DB_LS];
+  alignas(16) Pix c[2][DB_CTH * DB_CS];
+};
+
+template <typename Pix> struct Px4;
+template <> struct Px4<uint8_t> { typedef uint32_t type; };
+template <> struct Px4<uint16_t> { typedef uint2 type; };
+
+// What filtering one edge segment (4 lines) needs besides the samples.  Gathered for BOTH directions before the tile's first barrier: the
+// look-ups are chains of dependent, L2-latency loads (unit index -> flags -> QP -> slice parameters), and fetched inside the phases they
+// left every workgroup waiting twice between barriers (first version of this kernel: 49.8 ms per 2048 4K stills against 27.4 ms for the two
+// passes of round 2; profiles/r03f_bench.json).
+struct EdgeMeta {
+  int valid;          // the segment lies on a filtered edge inside the picture
+  int luma, e, sg;
+  int qp_p, qp_q, no_p, no_q, beta_off2, tc_off2, cb_off, cr_off;
+};
+template <int DIR>
+__device__ __forceinline__ EdgeMeta deblock_edge_meta(const FilterArgs& A, const PicParams& P, int tx, int ty, int item)
 {
-  if (*A.status != 0) return;
-  const PicParams& P = A.pics[blockIdx.y];
-  const int uw = (P.width + 3) >> 2, uh = (P.height + 3) >> 2;
-  // work item: (edge index along the filtered direction on the 8-sample grid, unit index along the edge)
-  const int n_edges = DIR == 0 ? (P.width + 7) >> 3 : (P.height + 7) >> 3;
-  const int n_along = DIR == 0 ? uh : uw;
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= n_edges * n_along) return;
-  int e, a;
-  if (DIR == 0) { e = tid % n_edges; a = tid / n_edges; }  // consecutive lanes: consecutive x
-  else { a = tid % n_along; e = tid / n_along; }            // consecutive lanes: consecutive x as well
-  if (e == 0) return;
-  const int x = DIR == 0 ? e * 8 : a * 4, y = DIR == 0 ? a * 4 : e * 8;
-  if (x >= P.width || y >= P.height) return;
+  EdgeMeta M;
+  M.valid = 0;
+  // items 0..127: the tile's luma segments (128 of them in either direction); 128..159: the chroma segments (32; both planes by the same lane:
+  // they share every decision input).  Consecutive lanes take consecutive positions along a sample row (x): conflict-free LDS rows.
+  M.luma = item < 128;
+  const int it = M.luma ? item : item - 128;
+  const int tw = M.luma ? DB_TW : DB_CTW, th = M.luma ? DB_TH : DB_CTH;
+  if (DIR == 0) { M.e = it % (tw / 8); M.sg = it / (tw / 8); }      // vertical edges: tw / 8 edges x th / 4 segments
+  else { M.sg = it % (tw / 4); M.e = it / (tw / 4); }                // horizontal edges: th / 8 edges x tw / 4 segments
+  M.qp_p = M.qp_q = M.no_p = M.no_q = M.beta_off2 = M.tc_off2 = M.cb_off = M.cr_off = 0;
+  if (!M.luma && (item >= 160 || P.chroma_format_idc != 1)) return M;
+  // position in the component's plane: `across` runs across the edge (the edge lies at it), `along` along it
+  const int across = (DIR == 0 ? tw * tx : th * ty) + 8 * M.e, along = (DIR == 0 ? th * ty : tw * tx) - 4 + 4 * M.sg;
+  const int x = DIR == 0 ? across : along, y = DIR == 0 ? along : across;       // component samples
+  const int lx = M.luma ? x : 2 * x, ly = M.luma ? y : 2 * y;                     // luma samples
+  if (across == 0 || along < 0 || lx >= P.width || ly >= P.height) return M;
   const uint8_t* u_flags = A.arena + P.off_u_flags;
   const int8_t* u_qp = (const int8_t*)(A.arena + P.off_u_qp);
+  const CtbInfo* ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
   int ctb_q, ctb_p;
-  const size_t iq = unit_index(P, x >> 2, y >> 2, &ctb_q);
-  const uint8_t fq = u_flags[iq];
-  if (!(fq & (DIR == 0 ? UF_VEDGE : UF_HEDGE))) return;
-  const size_t ip = DIR == 0 ? unit_index(P, (x >> 2) - 1, y >> 2, &ctb_p) : unit_index(P, x >> 2, (y >> 2) - 1, &ctb_p);
-  const uint8_t fp = u_flags[ip];
-  const int qp_q = u_qp[iq], qp_p = u_qp[ip];
+  const size_t iq = unit_index(P, lx >> 2, ly >> 2, &ctb_q);
+  const size_t ip = DIR == 0 ? unit_index(P, (lx >> 2) - 1, ly >> 2, &ctb_p) : unit_index(P, lx >> 2, (ly >> 2) - 1, &ctb_p);
+  const uint8_t fq = u_flags[iq], fp = u_flags[ip];       // (independent loads, issued together)
+  const int qq = u_qp[iq], qp = u_qp[ip];
+  const SliceParams sl = ((const SliceParams*)(A.arena + P.off_slices))[ctb_info[ctb_q].slice_idx];
+  if (!(fq & (DIR == 0 ? UF_VEDGE : UF_HEDGE))) return M;
   // 8.7.2.5.7: samples of cu_transquant_bypass units, and of PCM units when pcm_loop_filter_disabled_flag = 1, are left unchanged
   const int keep = UF_BYPASS | (P.pcm_loop_filter_disabled ? UF_PCM : 0);
-  const int no_q = (fq & keep) != 0, no_p = (fp & keep) != 0;
-  const CtbInfo* ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
-  const SliceParams sl = ((const SliceParams*)(A.arena + P.off_slices))[ctb_info[ctb_q].slice_idx];
-  {
-    Pix* rec = (Pix*)(A.arena + P.off_rec[0]);
-    const int stride = P.rec_stride[0] / sizeof(Pix);
-    Pix* pix = rec + (size_t)y * stride + x;
-    if (DIR == 0) deblock_luma<Pix>(pix, 1, stride, qp_p, qp_q, sl.beta_offset_div2, sl.tc_offset_div2, P.bit_depth_luma, no_p, no_q);
-    else deblock_luma<Pix>(pix, stride, 1, qp_p, qp_q, sl.beta_offset_div2, sl.tc_offset_div2, P.bit_depth_luma, no_p, no_q);
+  M.valid = 1; M.qp_q = qq; M.qp_p = qp; M.no_q = (fq & keep) != 0; M.no_p = (fp & keep) != 0;
+  M.beta_off2 = sl.beta_offset_div2; M.tc_off2 = sl.tc_offset_div2; M.cb_off = sl.pps_cb_qp_offset; M.cr_off = sl.pps_cr_qp_offset;
+  return M;
+}
+template <typename Pix, int DIR>
+__device__ __forceinline__ void deblock_tile_edge(const PicParams& P, DeblockLds<Pix>& L, const EdgeMeta& M)
+{
+  if (!M.valid) return;
+  const int l_across = 4 + 8 * M.e, l_along = 4 * M.sg;     // inside the tile (the tile starts 4 samples before the first edge)
+  if (M.luma) {
+    Pix* pix = L.y + (DIR == 0 ? l_along * DB_LS + l_across : l_across * DB_LS + l_along);
+    deblock_luma<Pix>(pix, DIR == 0 ? 1 : DB_LS, DIR == 0 ? DB_LS : 1, M.qp_p, M.qp_q, M.beta_off2, M.tc_off2, P.bit_depth_luma, M.no_p, M.no_q);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      Pix* pix = L.c[c] + (DIR == 0 ? l_along * DB_CS + l_across : l_across * DB_CS + l_along);
+      deblock_chroma<Pix>(pix, DIR == 0 ? 1 : DB_CS, DIR == 0 ? DB_CS : 1, M.qp_p, M.qp_q, c == 0 ? M.cb_off : M.cr_off, M.tc_off2, P.bit_depth_chroma, M.no_p,
+                          M.no_q);
+    }
   }
-  if (P.chroma_format_idc == 1) {
-    // chroma edges on the 8x8 chroma grid; one 4-sample chroma segment spans 8 luma samples along the edge
-    const int on_grid = DIR == 0 ? ((x & 15) == 0 && (y & 7) == 0) : ((y & 15) == 0 && (x & 7) == 0);
-    if (on_grid) {
-      for (int c = 1; c < 3; c++) {
-        Pix* rec = (Pix*)(A.arena + P.off_rec[c]);
-        const int stride = P.rec_stride[c] / sizeof(Pix);
-        Pix* pix = rec + (size_t)(y >> 1) * stride + (x >> 1);
-        const int off = c == 1 ? sl.pps_cb_qp_offset : sl.pps_cr_qp_offset;
-        if (DIR == 0) deblock_chroma<Pix>(pix, 1, stride, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q);
-        else deblock_chroma<Pix>(pix, stride, 1, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q);
-      }
+}
+
+template <typename Pix>
+__global__ __launch_bounds__(256) void k_deblock(FilterArgs A, int tiles_x)
+{
+  if (*A.status != 0) return;
+  __shared__ DeblockLds<Pix> L;
+  const PicParams& P = A.pics[blockIdx.y];
+  const int tx = (int)blockIdx.x % tiles_x, ty = (int)blockIdx.x / tiles_x;
+  if (DB_TW * tx - 8 >= P.width || DB_TH * ty - 8 >= P.height) return;     // (a smaller picture of a mixed batch; the chroma tile starts 8 luma samples early)
+  typedef typename Px4<Pix>::type V4;
+  const int tid = (int)threadIdx.x;
+  const EdgeMeta mv = deblock_edge_meta<0>(A, P, tx, ty, tid), mh = deblock_edge_meta<1>(A, P, tx, ty, tid);   // in flight beside the tile loads
+  const bool chroma = P.chroma_format_idc == 1;
+  // groups of 4 samples (plane widths are multiples of 8 luma / 4 chroma samples: a group never straddles the plane's edge); one luma tile row
+  // = 64 groups = one access of a wave
+  const int x0 = DB_TW * tx - 4, y0 = DB_TH * ty - 4, cx0 = DB_CTW * tx - 4, cy0 = DB_CTH * ty - 4;
+  const int ystride = (int)(P.rec_stride[0] / sizeof(Pix));
+  Pix* const rec_y = (Pix*)(A.arena + P.off_rec[0]);
+  for (int u = tid; u < DB_TH * (DB_TW / 4); u += 256) {
+    const int r = u / (DB_TW / 4), g = u % (DB_TW / 4), x = x0 + 4 * g, y = y0 + r;
+    if (x >= 0 && x < P.width && y >= 0 && y < P.height) *(V4*)&L.y[r * DB_LS + 4 * g] = *(const V4*)&rec_y[(size_t)y * ystride + x];
+  }
+  if (chroma) {
+    for (int u = tid; u < 2 * DB_CTH * (DB_CTW / 4); u += 256) {
+      const int c = u / (DB_CTH * (DB_CTW / 4)), v = u % (DB_CTH * (DB_CTW / 4)), r = v / (DB_CTW / 4), g = v % (DB_CTW / 4), x = cx0 + 4 * g, y = cy0 + r;
+      const Pix* rc = (const Pix*)(A.arena + P.off_rec[1 + c]);
+      const int cs = (int)(P.rec_stride[1 + c] / sizeof(Pix));
+      if (x >= 0 && x < P.cwidth && y >= 0 && y < P.cheight) *(V4*)&L.c[c][r * DB_CS + 4 * g] = *(const V4*)&rc[(size_t)y * cs + x];
+    }
+  }
+  __syncthreads();
+  deblock_tile_edge<Pix, 0>(P, L, mv);     // vertical edges of the tile
+  __syncthreads();
+  deblock_tile_edge<Pix, 1>(P, L, mh);     // horizontal edges, on the vertically filtered samples
+  __syncthreads();
+  for (int u = tid; u < DB_TH * (DB_TW / 4); u += 256) {
+    const int r = u / (DB_TW / 4), g = u % (DB_TW / 4), x = x0 + 4 * g, y = y0 + r;
+    if (x >= 0 && x < P.width && y >= 0 && y < P.height) *(V4*)&rec_y[(size_t)y * ystride + x] = *(const V4*)&L.y[r * DB_LS + 4 * g];
+  }
+  if (chroma) {
+    for (int u = tid; u < 2 * DB_CTH * (DB_CTW / 4); u += 256) {
+      const int c = u / (DB_CTH * (DB_CTW / 4)), v = u % (DB_CTH * (DB_CTW / 4)), r = v / (DB_CTW / 4), g = v % (DB_CTW / 4), x = cx0 + 4 * g, y = cy0 + r;
+      Pix* rc = (Pix*)(A.arena + P.off_rec[1 + c]);
+      const int cs = (int)(P.rec_stride[1 + c] / sizeof(Pix));
+      if (x >= 0 && x < P.cwidth && y >= 0 && y < P.cheight) *(V4*)&rc[(size_t)y * cs + x] = *(const V4*)&L.c[c][r * DB_CS + 4 * g];
     }
   }
 }
@@ -485,15 +562,10 @@ __global__ __launch_bounds__(256) void k_sao_rgb(FilterArgs A, const colordev::C
 
 void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s)
 {
-  const int uw = (max_w + 3) / 4, uh = (max_h + 3) / 4;
-  const int work_v = ((max_w + 7) / 8) * uh, work_h = ((max_h + 7) / 8) * uw;
-  if (wide) {
-    hipLaunchKernelGGL((k_deblock<uint16_t, 0>), dim3((work_v + 255) / 256, n_pics), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((k_deblock<uint16_t, 1>), dim3((work_h + 255) / 256, n_pics), dim3(256), 0, s, a);
-  } else {
-    hipLaunchKernelGGL((k_deblock<uint8_t, 0>), dim3((work_v + 255) / 256, n_pics), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((k_deblock<uint8_t, 1>), dim3((work_h + 255) / 256, n_pics), dim3(256), 0, s, a);
-  }
+  // tiles [T i - 4, T i + T - 4) over the luma plane; the chroma tiles (displaced by -4 CHROMA samples) may need one more column / row
+  const int tiles_x = (max_w + 8 + DB_TW - 1) / DB_TW, tiles_y = (max_h + 8 + DB_TH - 1) / DB_TH;
+  if (wide) hipLaunchKernelGGL((k_deblock<uint16_t>), dim3(tiles_x * tiles_y, n_pics), dim3(256), 0, s, a, tiles_x);
+  else hipLaunchKernelGGL((k_deblock<uint8_t>), dim3(tiles_x * tiles_y, n_pics), dim3(256), 0, s, a, tiles_x);
 }
 
 // kernel variants: without the "samples stay as they are" paths (no lossless CUs / unfiltered PCM in the batch) and / or without the per-neighbour
