@@ -532,8 +532,95 @@ PC_DEV uint32_t decode_g1_run(PS& s, int base_lane, int n, int& g_io)
   g_io = (int)g;
   return gb;
 }
+
+// A unary context-coded prefix (last_sig_coeff_x / y_prefix): bins with context lane base + (i >> shift) while they are 1, at most `max`
+// of them; returns the number of 1s.  One statement per run (the wrapper code around a decode_bin() per bin was ~13 instructions a bin).
+PC_DEV int decode_unary_ctx_run(PS& s, VReg& grp, int base_lane, int shift_, int max_)
+{
+  const uint32_t mx = (uint32_t)__builtin_amdgcn_readfirstlane(max_);
+  if (mx == 0) return 0;
+  uint32_t i = 0;
+  const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane(base_lane), sh = (uint32_t)__builtin_amdgcn_readfirstlane(shift_);
+  for (;;) {
+    uint32_t flag, c, st, row, b;
+    uint64_t mask;
+    uint32_t vt, vl, vn;
+    uint32_t pos = pc_uni(s.pos);
+    const uint32_t flim = pc_uni(s.fast_limit);
+    asm volatile(
+      "s_mov_b32 %[flag], 0\n\t"
+      "s_nop 1\n"
+      "300:\n\t"
+      "s_lshr_b32 %[c], %[i], %[sh]\n\t"
+      "s_add_u32 %[c], %[base], %[c]\n\t"
+      "v_cmp_eq_u32_e64 %[mask], %[c], %[lane]\n\t"
+      "v_readlane_b32 %[st], %[grp], %[c]\n\t"
+      PC_ASM_HEAD_Q
+      "s_nop 1\n\t"
+      "v_readlane_b32 %[row], %[tl], %[st]\n\t"
+      "s_lshr_b32 %[b], %[st], 16\n\t"
+      "s_nop 0\n\t"
+      "v_bfe_u32 %[vl], %[row], %[vt], 8\n\t"
+      "v_mad_i32_i24 %[R], %[vl], %[m128], %[R]\n\t"
+      "v_cmp_lt_u32_e32 vcc, %[val], %[R]\n\t"
+      "s_cbranch_vccz 301f\n\t"
+      "v_pk_sub_u16 %[vn], %[st], 1 clamp\n\t"
+      "v_cmp_gt_u32_e32 vcc, 0x8000, %[R]\n\t"
+      "s_cbranch_vccnz 302f\n"
+      "304:\n\t"
+      "v_cndmask_b32_e64 %[grp], %[grp], %[vn], %[mask]\n\t"
+      "s_cmp_eq_u32 %[b], 0\n\t"
+      "s_cbranch_scc1 390f\n\t"                  // a 0 bin ends the prefix
+      "s_add_u32 %[i], %[i], 1\n\t"
+      "s_cmp_lt_u32 %[i], %[mx]\n\t"
+      "s_cbranch_scc1 300b\n\t"
+      "s_branch 390f\n"
+      "301:\n\t"
+      PC_ASM_LPS("s_xor_b32 %[b], %[b], 1\n\t")
+      "s_branch 303f\n"
+      "302:\n\t"
+      "v_lshlrev_b32 %[R], 1, %[R]\n\t"
+      "v_lshlrev_b32 %[val], 1, %[val]\n\t"
+      "v_add_u32 %[bits], 1, %[bits]\n"
+      "303:\n\t"
+      "v_cmp_lt_i32_e32 vcc, -1, %[bits]\n\t"
+      "s_cbranch_vccz 304b\n\t"
+      PC_ASM_REFILL("305f")
+      "s_branch 304b\n"
+      "305:\n\t"                                   // slow refill: finish this bin's bookkeeping, leave with flag = 1 (+ 2 when the prefix is complete)
+      "v_cndmask_b32_e64 %[grp], %[grp], %[vn], %[mask]\n\t"
+      "s_mov_b32 %[flag], 1\n\t"
+      "s_cmp_eq_u32 %[b], 0\n\t"
+      "s_cbranch_scc1 306f\n\t"
+      "s_add_u32 %[i], %[i], 1\n\t"
+      "s_cmp_lt_u32 %[i], %[mx]\n\t"
+      "s_cbranch_scc1 390f\n"
+      "306:\n\t"
+      "s_mov_b32 %[flag], 3\n"
+      "390:\n\t"
+      : [grp] "+v"(grp), [R] "+v"(s.range), [val] "+v"(s.value), [bits] "+v"(s.bits_needed), [pos] "+s"(pos), [i] "+s"(i),
+        [flag] "=&s"(flag), [c] "=&s"(c), [st] "=&s"(st), [row] "=&s"(row), [b] "=&s"(b), [mask] "=&s"(mask),
+        [vt] "=&v"(vt), [vl] "=&v"(vl), [vn] "=&v"(vn)
+      : [base] "s"(base), [sh] "s"(sh), [mx] "s"(mx), [tl] "v"(s.t_lps), [tn] "v"(s.t_next), [lane] "v"((uint32_t)threadIdx.x), [win] "v"(s.win), [flim] "s"(flim),
+        [m128] "s"(0xffffff80u)
+      : "vcc", "scc");
+    s.pos = pc_uni(pos);
+    i = pc_uni(i);
+    const uint32_t f = pc_uni(flag);
+    if (__builtin_expect(f == 0u, 1)) break;
+    refill_byte(s);
+    if (f & 2u) break;
+  }
+  return (int)i;
+}
 #else
 PC_DEV int decode_bin(PS& s, VReg& grp, int ctx_lane) { return decode_bin_cxx(s, grp, ctx_lane); }
+PC_DEV int decode_unary_ctx_run(PS& s, VReg& grp, int base_lane, int shift, int max)
+{
+  int i = 0;
+  while (i < max && decode_bin(s, grp, base_lane + (i >> shift))) i++;
+  return i;
+}
 PC_DEV uint32_t decode_g1_run(PS& s, int base_lane, int n, int& g)
 {
   uint32_t gb = 0;
@@ -716,9 +803,8 @@ PC_DEV int residual_coding(PS& s, int log2n, int c_idx, int pred_mode)
   if (c_idx == 0) { ctx_offset = 3 * (log2n - 2) + ((log2n - 1) >> 2); ctx_shift = (log2n + 1) >> 2; }
   else { ctx_offset = 15; ctx_shift = log2n - 2; }
   const int c_max = (log2n << 1) - 1;
-  int px = 0, py = 0;
-  while (px < c_max && decode_bin(s, s.ctxA, A_LAST_X + ctx_offset + (px >> ctx_shift))) px++;
-  while (py < c_max && decode_bin(s, s.ctxA, A_LAST_Y + ctx_offset + (py >> ctx_shift))) py++;
+  const int px = decode_unary_ctx_run(s, s.ctxA, A_LAST_X + ctx_offset, ctx_shift, c_max);
+  const int py = decode_unary_ctx_run(s, s.ctxA, A_LAST_Y + ctx_offset, ctx_shift, c_max);
   int last_x = px, last_y = py;
   if (px > 3) last_x = (1 << ((px >> 1) - 1)) * (2 + (px & 1)) + decode_bypass_bits(s, (px >> 1) - 1);
   if (py > 3) last_y = (1 << ((py >> 1) - 1)) * (2 + (py & 1)) + decode_bypass_bits(s, (py >> 1) - 1);
