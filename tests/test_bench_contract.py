@@ -1,0 +1,28 @@
+"""The bench line contract (one JSON object with the driver's fields plus `roofline` and `cpu_baseline`), checked on the line
+bench.py printed on the MI355X at the end of the round (committed under profiles/ as r<NN>_final_bench.json)."""
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_every_contract_field():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_bench.json")))
+    assert files, "no bench line committed under profiles/"
+    text = open(files[-1]).read().strip()
+    assert len(text.splitlines()) == 1, "bench.py prints ONE JSON line"
+    d = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["unit"] == "Mpixel/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "u8" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and (r["traffic"] is None or r["traffic"] > 0)
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    assert abs(d["value"] - d["config"]["stills_per_step_per_gpu"] * 3840 * 2160 * d["n_gpus"] / (d["ms_per_step"] * 1e3)) / d["value"] < 1e-3
+    # round 3: the run checks a result against the CPU oracle and reports the SURVEY 8(d) from-host form as a first-class key
+    assert d["verified"]["planes_match"] is True and d["verified"]["rgb_match"] is True
+    assert d["value_from_host_bytes"] > 0 and d["single_still"]["ms"] > 0

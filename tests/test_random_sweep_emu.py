@@ -13,4 +13,5 @@ import emu_random_sweep as sweep
 def test_random_tool_combination_matches_oracle(seed, monkeypatch):
     monkeypatch.setenv("HIPDEC_PARSE_POOL", str(seed & 1))   # (run_case sets it too; this restores the environment afterwards)
     s, verdict, detail = sweep.run_case((seed, seed & 1))
-    assert verdict in ("ok", "skip"), detail
+    # none of these 40 seeds draws a combination the generator refuses: a "skip" here would mean the generator regressed
+    assert verdict == "ok", (verdict, detail)
