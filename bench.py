@@ -52,7 +52,6 @@ def parse_args():
                     "default grid8k mode gives every rank its own photos: photo i -> GPU i mod N)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the T threads x heif_decode_image() measurement through the real libheif + plugin")
     ap.add_argument("--qp", type=int, default=27)
-    ap.add_argument("--pixel-groups", type=int, default=8, help="picture groups whose pixel-stage chains overlap (0 / 1: one chain per batch)")
     ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic contents cycled through the batch")
     ap.add_argument("--enc", action="append", default=[], help="override a synthetic-encoder parameter, e.g. --enc wpp=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -234,7 +233,6 @@ def main():
     lib = libheif_amd.load_library()
     check(lib.hipdec_init(local_rank))
     lib.hipdec_set_arena_cache_bytes.argtypes = [__import__("ctypes").c_size_t]
-    check(lib.hipdec_set_pixel_groups(a.pixel_groups))
 
     def sync():
         check(lib.hipdec_stream_synchronize(None))
@@ -308,22 +306,7 @@ def main():
         gd.wait()
     ms_per_step = elapsed / a.steps * 1e3
     value = total_px / (elapsed / a.steps) / 1e6
-    avg_us = None
-    pixel_overlapped_us = None
-    if not grid:
-        # The timed steps ran the pixel stages as overlapping picture groups (hipdec_set_pixel_groups, default 8): their kernels are not
-        # separable by events there (the whole pixel interval is reported under `residual`).  The per-kernel table comes from two more
-        # steps with ONE chain per batch, outside the timed region: same kernels, same batch, each with the chip to itself.
-        grouped = kernel_times(wl.batches, a.steps)
-        pixel_overlapped_us = grouped["residual"] + grouped["recon"] + grouped["deblock"] + grouped["sao"]
-        lib.hipdec_set_pixel_groups(1)
-        wl.timing_slots(2)
-        for _ in range(2):
-            step()
-        sync(); wl.status()
-        avg_us = kernel_times(wl.batches, 2)
-        avg_us["parse"] = grouped["parse"]          # the parse kernel of the TIMED steps (identical launch in both forms)
-        lib.hipdec_set_pixel_groups(a.pixel_groups)
+    avg_us = kernel_times(wl.batches, a.steps) if not grid else None
     # what the timed steps produced for still 0 (checked against the CPU oracle further down; outside every timed region)
     check_item = None
     if batch is not None and rank == 0 and not a.only_main and not a.no_cpu_baseline:
@@ -352,7 +335,6 @@ def main():
                                     (n_items, w, h, bit_depth, "RGB24" if out_chroma == 10 else "RRGGBB")),
                        "timed_region": "inputs resident in HBM: hipdec_batch_run_rgb (decode + colour stage) per step (from host bytes: see from_host_bytes)",
                        "batches_per_step": a.parts if not grid else 1,
-                       "pixel_groups": a.pixel_groups if not grid else None,
                        "stage_overlap": bool(a.parts > 1 and not grid),
                        "stills_per_step_per_gpu": n_items, "distinct_contents": len(distinct), "bitstream_bytes_per_px": round(beta, 4),
                        "substreams_per_still": batch.info(0)["num_substreams"] if batch is not None else 16,
@@ -379,9 +361,6 @@ def main():
                                    note="dominant kernel by device time; CABAC parsing is bound by instruction issue (one dependency chain per "
                                         "substream), not by HBM (DESIGN.md §4); streaming kernels: see `kernels`")
             out["kernels"] = kernels
-            out["kernels_note"] = ("device time per kernel from two extra steps with one kernel chain per batch (hipdec_set_pixel_groups(1)), parse from the timed steps; "
-                                   "in the timed steps the pixel stages of %d picture groups overlap on three streams and take %.0f us per step together "
-                                   "(serially: %.0f us)" % (a.pixel_groups, pixel_overlapped_us, sum(v for k, v in avg_us.items() if k in ("residual", "recon", "deblock", "sao", "colour"))))
             out["coded_samples_per_px"] = round(coded, 4)
             e2e = (beta + 3.0 * s + 3.0 * s_out) * px_rank    # drop-in end-to-end bytes: beta + 1.5 s + 1.5 s + 3 s_out
             out["end_to_end"] = {"alg_bytes_per_px": round(beta + 3.0 * s + 3.0 * s_out, 3), "achieved_gbs": round(e2e / (elapsed / a.steps) / 1e9, 2),

@@ -147,11 +147,6 @@ HIPDEC_API int hipdec_set_arena_cache_bytes(size_t bytes);
  * that alternates two batches (two arenas) then has batch k+1's CABAC parse, which is issue- and dependency-bound, running beside batch k's
  * pixel stages.  hipdec_batch_status() / free wait for the batch as before. */
 HIPDEC_API int hipdec_set_stage_overlap(int on);
-/* Large batches (>= 64 items) run their pixel stages as `groups` picture groups whose kernel chains (residual -> reconstruction ->
- * deblocking -> SAO) overlap on a few streams: the kernels load different pipes (vector ALUs / the scalar ALU / HBM).  Default 8
- * (HIPDEC_PIXEL_GROUPS); 0 or 1 = one chain for the whole batch, which is also the form in which hipdec_batch_slot_kernel_timing_us()
- * can separate the kernels (with groups the pixel stages are reported as one interval under `residual`). */
-HIPDEC_API int hipdec_set_pixel_groups(int groups);
 
 /* Number of large batches the host keeps in flight at a time on separate streams (default 1).  The CABAC work pool of a
  * batch needs all its waves resident, so concurrent batches share the device's wave slots. */

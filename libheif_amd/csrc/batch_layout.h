@@ -22,7 +22,6 @@ struct BatchLayout {
   uint32_t num_subs = 0, num_rows = 0, num_waves = 0;
   std::vector<ParseWave> parse_waves;   // plan -> fill
   std::vector<ReconWave> recon_waves;
-  std::vector<uint32_t> rwave_first;    // index of picture i's first reconstruction wave (n + 1 entries): picture groups take wave sub-ranges
   bool wide = false;  // samples wider than 8 bit -> uint16 planes
   int max_w = 0, max_h = 0, max_ow = 0, max_oh = 0, max_ctbs = 0;
 };

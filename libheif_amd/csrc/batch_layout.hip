@@ -109,9 +109,7 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
     const uint32_t target = 24576;   // ~8 waves per component of a 4K still at 1024 stills in flight (measured optimum 4-16)
     const char* force = getenv("HIPDEC_RECON_WAVES_PER_PICTURE");
     uint32_t row_base = 0;
-    b.rwave_first.assign((size_t)n + 1, 0);
     for (int i = 0; i < n; i++) {
-      b.rwave_first[(size_t)i] = (uint32_t)rwaves.size();
       const auto& p = b.pics[i];
       const uint32_t rows = (uint32_t)((p.sps.pic_height + (1 << p.sps.log2_ctb) - 1) >> p.sps.log2_ctb);
       const uint32_t row_len = (uint32_t)((p.sps.pic_width + (1 << p.sps.log2_ctb) - 1) >> p.sps.log2_ctb);
@@ -128,7 +126,6 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
     }
   }
   b.num_rwaves = (uint32_t)rwaves.size();
-  b.rwave_first[(size_t)n] = b.num_rwaves;
   b.off_rwaves = off; off = align_up(off + sizeof(ReconWave) * rwaves.size(), 256);
   b.params.assign(n, PicParams{});
   uint32_t row_base = 0;
@@ -184,7 +181,7 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
   b.queue_cap = 1; while (b.queue_cap < nsubs) b.queue_cap <<= 1;
   b.off_queue = off; off = align_up(off + sizeof(uint32_t) * b.queue_cap, 256);
   b.off_qctl = off; off += 256;
-  b.off_ticket = off; off += 256;  // [0] parse ticket, [1 + g] recon ticket of picture group g (decoder.hip: launch_all)
+  b.off_ticket = off; off += 256;  // [0] parse ticket, [1] recon ticket
   b.off_status = off; off += 256;
   b.ctrl_size = off - b.off_ctrl;
   b.off_ctx = off; off = align_up(off + (size_t)CTX_STORE * nsubs, 256);

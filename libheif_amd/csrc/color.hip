@@ -424,8 +424,6 @@ void color_capture_abort()
 // Ends capture mode WITHOUT launching: uploads the recorded parameter blocks (one per captured call, in call order) and hands back the
 // device array — for a kernel of another translation unit that consumes them (SAO with fused RGB emission, filter_kernels.hip).
 // *uniform_variant = the kernel variant all blocks share (sizeof(Pix) * 16 + LAYOUT), or -1 when they differ.
-size_t color_params_stride() { return sizeof(colordev::ColorParams); }
-
 int color_capture_take(ColorBatchState& st, hipStream_t s, const void** dev, int* uniform_variant, int* count)
 {
   t_capture = false;

@@ -44,7 +44,6 @@ struct hipdec_batch : BatchLayout {
   hipStream_t last_stream = nullptr;
   bool ran = false;
   bool retired = false;         // its arena went to another batch (hipdec_batch_create_recycling): only status / timing / free remain
-  hipEvent_t join[3] = {nullptr, nullptr, nullptr};   // the pixel-stage chains of a run rejoin the launch stream through these
   uint32_t wave_share = 1;      // the CABAC work pool of this batch takes 1 / wave_share of the wave budget (launch sets of the decoder path overlap in pairs)
   ColorBatchState color;        // parameter blocks of hipdec_batch_to_rgb_all
   // decoder path (plugin): the output planes of every item staged in pinned host memory by ONE set of asynchronous copies behind the
@@ -79,7 +78,6 @@ struct hipdec_batch : BatchLayout {
     color_batch_state_free(color);
     if (arena) arena_release(arena, arena_capacity);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
-    for (auto& e : join) if (e) (void)hipEventDestroy(e);
     if (uploaded) (void)hipEventDestroy(uploaded);
     if (done) (void)hipEventDestroy(done);
     status_slot_release(host_status);
@@ -136,7 +134,6 @@ int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* s
   b.ev.assign(kEv, nullptr);
   b.colour_timed.assign(1, 0);
   for (auto& e : b.ev) HIPDEC_CHECK_HIP(hipEventCreate(&e));
-  for (auto& e : b.join) HIPDEC_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   takeover.ok = true;
   return 0;
 }
@@ -151,11 +148,6 @@ hipStream_t follow_stream(hipdec_batch* b, void* stream)
   hipStream_t s = (hipStream_t)stream;
   if (s != b->last_stream && b->done_recorded) (void)hipStreamWaitEvent(s, b->done, 0);
   return s;
-}
-
-const void* color_params_at(const void* params_dev, int item)   // the per-picture parameter block of the fused SAO + RGB kernel
-{
-  return (const uint8_t*)params_dev + (size_t)item * color_params_stride();
 }
 
 int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nullptr)
@@ -212,65 +204,26 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
   if (int rc = step("parse")) return rc;
   if (split) HIPDEC_CHECK_HIP(hipStreamWaitEvent(ps, ev[1], 0));
   static const bool parse_only = getenv("HIPDEC_DEBUG_PARSE_ONLY") != nullptr;   // tuning knob: isolate the CABAC kernel
-  bool may_keep = false, restricted = false;
-  for (const PicParams& P : b.params) {
-    if (P.transquant_bypass_enabled || (P.pcm_enabled && P.pcm_loop_filter_disabled)) may_keep = true;
-    if (!P.sao_free_neighbours) restricted = true;
+  if (!parse_only) launch_residual(fa, n, b.max_ctbs, ps);
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[2], ps));
+  if (int rc = step("residual")) return rc;
+  if (!parse_only) launch_recon(ra, b.wide, ps);
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[3], ps));
+  if (int rc = step("recon")) return rc;
+  if (!parse_only) launch_deblock(fa, n, b.max_w, b.max_h, b.wide, ps);
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[4], ps));
+  if (int rc = step("deblock")) return rc;
+  if (!parse_only) {
+    bool may_keep = false, restricted = false;
+    for (const PicParams& P : b.params) {
+      if (P.transquant_bypass_enabled || (P.pcm_enabled && P.pcm_loop_filter_disabled)) may_keep = true;
+      if (!P.sao_free_neighbours) restricted = true;
+    }
+    if (fused_rgb_params) launch_sao_rgb(fa, fused_rgb_params, n, b.max_ow, b.max_oh, ps, may_keep, restricted);   // SAO + crop + RGB24 in one pass
+    else launch_sao(fa, n, b.max_ow, b.max_oh, b.wide, ps, may_keep, restricted);
   }
-  // The pixel stages of one picture only depend on that picture's parse, and they load different pipes: k_residual the vector ALUs,
-  // k_recon the CU-shared scalar ALU (a dependency wavefront), k_deblock / k_sao HBM.  Run for the whole batch one after the other,
-  // each has the chip to itself and leaves the other pipes idle; so large batches are cut into picture GROUPS whose chains
-  // (residual -> recon -> deblock -> SAO) go to a few pooled streams: group g + 1's transforms overlap group g's reconstruction
-  // wavefront and group g - 1's filters.  (hipdec_set_pixel_groups: 0 / 1 = one chain, the per-kernel timing form.)
-  const int groups_wanted = pixel_groups();
-  const int G = (parse_only || dbg || n < 64 || groups_wanted < 2) ? 1 : std::min(groups_wanted, std::min(n / 16, 32));
-  if (G <= 1) {
-    if (!parse_only) launch_residual(fa, n, b.max_ctbs, ps);
-    HIPDEC_CHECK_HIP(hipEventRecord(ev[2], ps));
-    if (int rc = step("residual")) return rc;
-    if (!parse_only) launch_recon(ra, b.wide, ps);
-    HIPDEC_CHECK_HIP(hipEventRecord(ev[3], ps));
-    if (int rc = step("recon")) return rc;
-    if (!parse_only) launch_deblock(fa, n, b.max_w, b.max_h, b.wide, ps);
-    HIPDEC_CHECK_HIP(hipEventRecord(ev[4], ps));
-    if (int rc = step("deblock")) return rc;
-    if (!parse_only) {
-      if (fused_rgb_params) launch_sao_rgb(fa, fused_rgb_params, n, b.max_ow, b.max_oh, ps, may_keep, restricted);   // SAO + crop + RGB24 in one pass
-      else launch_sao(fa, n, b.max_ow, b.max_oh, b.wide, ps, may_keep, restricted);
-    }
-    HIPDEC_CHECK_HIP(hipEventRecord(ev[5], ps));
-    if (int rc = step("sao")) return rc;
-  } else {
-    constexpr int kLanes = 3;                       // chains in flight
-    hipStream_t lane[kLanes];
-    hipEvent_t fork = ev[1];
-    HIPDEC_CHECK_HIP(hipEventRecord(ev[2], ps));    // (per-kernel times are not separable in this form: ev[2..4] mark the start of the pixel stages)
-    HIPDEC_CHECK_HIP(hipEventRecord(ev[3], ps));
-    HIPDEC_CHECK_HIP(hipEventRecord(ev[4], ps));
-    for (int l = 0; l < kLanes; l++) { lane[l] = stream_acquire(); HIPDEC_CHECK_HIP(hipStreamWaitEvent(lane[l], fork, 0)); }
-    for (int g = 0; g < G; g++) {
-      const int p0 = (int)((long long)n * g / G), p1 = (int)((long long)n * (g + 1) / G);
-      if (p1 <= p0) continue;
-      hipStream_t ls = lane[g % kLanes];
-      FilterArgs fg = fa;
-      fg.pics = fa.pics + p0;
-      ReconArgs rg = ra;
-      rg.waves = ra.waves + b.rwave_first[(size_t)p0];
-      rg.num_waves = b.rwave_first[(size_t)p1] - b.rwave_first[(size_t)p0];
-      rg.ticket = (uint32_t*)(b.arena + b.off_ticket) + 1 + g;
-      launch_residual(fg, p1 - p0, b.max_ctbs, ls);
-      launch_recon(rg, b.wide, ls);
-      launch_deblock(fg, p1 - p0, b.max_w, b.max_h, b.wide, ls);
-      if (fused_rgb_params) launch_sao_rgb(fg, color_params_at(fused_rgb_params, p0), p1 - p0, b.max_ow, b.max_oh, ls, may_keep, restricted);
-      else launch_sao(fg, p1 - p0, b.max_ow, b.max_oh, b.wide, ls, may_keep, restricted);
-    }
-    for (int l = 0; l < kLanes; l++) {   // join: the caller's stream continues behind every chain
-      HIPDEC_CHECK_HIP(hipEventRecord(b.join[l], lane[l]));
-      HIPDEC_CHECK_HIP(hipStreamWaitEvent(ps, b.join[l], 0));
-      stream_release(lane[l]);
-    }
-    HIPDEC_CHECK_HIP(hipEventRecord(ev[5], ps));
-  }
+  HIPDEC_CHECK_HIP(hipEventRecord(ev[5], ps));
+  if (int rc = step("sao")) return rc;
   HIPDEC_CHECK_HIP(hipGetLastError());
   HIPDEC_CHECK_HIP(hipMemcpyAsync(b.host_status, b.arena + b.off_status, sizeof(int32_t), hipMemcpyDeviceToHost, ps));
   b.last_stream = ps;     // the colour stage, packs and plane reads of this run follow its last kernel

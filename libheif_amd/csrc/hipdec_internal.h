@@ -28,7 +28,6 @@ class DeviceScope {
 hipStream_t default_stream();
 hipStream_t post_stream();      // everything behind the CABAC kernel when stage overlap is on (hipdec_set_stage_overlap)
 bool stage_overlap();
-int pixel_groups();             // picture groups the pixel stages of a large batch are cut into (hipdec_set_pixel_groups)
 int max_devices();              // size of the per-device stream table: device indices beyond it are refused
 hipStream_t upload_stream();    // H2D copies of large batches (overlaps the kernels of the batch before)
 uint32_t parse_wave_budget();   // CABAC pool waves one batch may launch (wave slots / concurrent batches)
@@ -62,7 +61,6 @@ void color_capture_abort();
 int color_capture_launch(ColorBatchState& st, hipStream_t s);
 int color_capture_take(ColorBatchState& st, hipStream_t s, const void** dev, int* uniform_variant, int* count);   // upload only
 int color_variant_rgb24_u8();
-size_t color_params_stride();   // bytes per picture in the parameter array color_capture_take() uploads
 void color_batch_state_free(ColorBatchState& st);
 
 // No C++ exception may cross the C ABI (the caller is libheif, or cgo / JNI / ctypes): every entry point that parses untrusted

@@ -18,7 +18,6 @@ static thread_local int t_device_override = -1;   // ... unless a DeviceScope is
 constexpr int kMaxDevices = 16;
 struct DeviceStreams { hipStream_t stream = nullptr, upload = nullptr, post = nullptr; };
 static std::atomic<int> g_stage_overlap{0};
-static std::atomic<int> g_pixel_groups{getenv("HIPDEC_PIXEL_GROUPS") ? atoi(getenv("HIPDEC_PIXEL_GROUPS")) : 8};
 static DeviceStreams g_streams[kMaxDevices];   // created on first use of a device, destroyed by hipdec_shutdown()
 static std::mutex g_streams_mu;
 static int g_cu_count = 256;                 // compute units of the selected device
@@ -87,7 +86,6 @@ hipStream_t default_stream() { return streams_of_active_device().stream; }
 hipStream_t upload_stream() { DeviceStreams& d = streams_of_active_device(); return d.upload ? d.upload : d.stream; }
 hipStream_t post_stream() { DeviceStreams& d = streams_of_active_device(); return d.post ? d.post : d.stream; }
 bool stage_overlap() { return g_stage_overlap.load(std::memory_order_relaxed) != 0; }
-int pixel_groups() { return g_pixel_groups.load(std::memory_order_relaxed); }
 
 // Waves of the CABAC work pool one batch may launch: the pool only works while ALL its waves are resident (8 per SIMD with
 // the kernel's register budget), so concurrent batches have to share the machine's wave slots.
@@ -339,13 +337,6 @@ int hipdec_set_arena_cache_bytes(size_t bytes)
   g_max_cached_bytes.store(bytes);
   g_max_pooled_arena.store(bytes > (size_t(1) << 30) ? bytes : (size_t(1) << 30));
   if (bytes == 0) { arena_pool_clear(); pinned_pool_clear(); }
-  return 0;
-}
-
-int hipdec_set_pixel_groups(int groups)
-{
-  if (groups < 0 || groups > 32) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "set_pixel_groups: 0..32");
-  g_pixel_groups.store(groups, std::memory_order_relaxed);
   return 0;
 }
 
