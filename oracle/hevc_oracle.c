@@ -86,7 +86,8 @@ const uint8_t hevc_cabac_init_I[CTX_COUNT] = {
   /* coeff_abs_level_greater1_flag */
   140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166,
   182, 140, 227, 122, 197,
-  /* coeff_abs_level_greater2_flag */ 138, 153, 136, 167, 152, 152};
+  /* coeff_abs_level_greater2_flag */ 138, 153, 136, 167, 152, 152,
+  /* cbf_cb, cbf_cr ctxInc 4 */ 154};
 
 static const int8_t intraPredAngle[35] = {0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13,
   -17, -21, -26, -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32};
@@ -629,8 +630,11 @@ static void parse_sps(Dec* d, const uint8_t* rbsp, size_t n)
     }
   }
   /* constraints */
-  if (s->chroma_format_idc != 0 && s->chroma_format_idc != 1)
-    fail(d, "unsupported: chroma_format_idc %d (only 4:0:0 and 4:2:0)", s->chroma_format_idc);
+  if (s->chroma_format_idc == 2 || s->chroma_format_idc > 3 || (s->chroma_format_idc == 3 && s->separate_colour_plane_flag))
+    fail(d, "unsupported: chroma_format_idc %d%s (4:0:0, 4:2:0 and 4:4:4 without separate colour planes)", s->chroma_format_idc,
+         s->separate_colour_plane_flag ? " with separate_colour_plane_flag" : "");
+  if (s->chroma_format_idc == 3 && s->scaling_list_enabled_flag)
+    fail(d, "unsupported: scaling lists with 4:4:4 (the 32x32 chroma matrices of the range extensions)");
   if (s->bit_depth_luma > 16 || s->bit_depth_chroma > 16) fail(d, "bit depth out of range");
   if (s->log2_ctb > 6 || s->log2_ctb < 4) fail(d, "CTB size out of range");
   if (s->log2_max_tb > 5 || s->log2_max_tb > s->log2_ctb) fail(d, "bad max TB size");
@@ -717,8 +721,8 @@ static void setup_picture(Dec* d)
 {
   const SPS* s = d->s; const PPS* p = d->p;
   d->W = s->pic_width; d->H = s->pic_height;
-  d->Wc = s->chroma_format_idc ? d->W / 2 : 0;
-  d->Hc = s->chroma_format_idc ? d->H / 2 : 0;
+  d->Wc = s->chroma_format_idc == 3 ? d->W : (s->chroma_format_idc ? d->W / 2 : 0);
+  d->Hc = s->chroma_format_idc == 3 ? d->H : (s->chroma_format_idc ? d->H / 2 : 0);
   for (int c = 0; c < 3; c++) {
     size_t n = c ? (size_t)d->Wc * d->Hc : (size_t)d->W * d->H;
     d->rec[c] = (uint16_t*)xcalloc(d, n, sizeof(uint16_t));
@@ -1040,7 +1044,7 @@ static void intra_predict_block(Dec* d, int x0c, int y0c, int log2n, int cIdx, i
   /* (x0c,y0c) in component samples */
   const SPS* s = d->s;
   int nTbS = 1 << log2n, n2 = 2 * nTbS;
-  int sub = cIdx ? 2 : 1; /* 4:2:0 */
+  int sub = (cIdx && s->chroma_format_idc != 3) ? 2 : 1; /* SubWidthC = SubHeightC: 2 for 4:2:0, 1 for 4:4:4 */
   int stride = cIdx ? d->Wc : d->W;
   uint16_t* rec = d->rec[cIdx];
   int bit_depth = cIdx ? s->bit_depth_chroma : s->bit_depth_luma;
@@ -1175,7 +1179,7 @@ static void residual_coding(Dec* d, int x0, int y0, int log2TrafoSize, int cIdx,
   }
   /* 7.4.9.11 scanIdx */
   int scanIdx = 0;
-  if (log2TrafoSize == 2 || (log2TrafoSize == 3 && cIdx == 0)) {
+  if (log2TrafoSize == 2 || (log2TrafoSize == 3 && (cIdx == 0 || d->s->chroma_format_idc == 3))) {
     if (predModeIntra >= 6 && predModeIntra <= 14) scanIdx = 2;
     else if (predModeIntra >= 22 && predModeIntra <= 30) scanIdx = 1;
   }
@@ -1366,7 +1370,7 @@ static void reconstruct_tb(Dec* d, int x0c, int y0c, int log2n, int cIdx, int mo
       int QpBdOffsetC = 6 * (s->bit_depth_chroma - 8);
       int off = cIdx == 1 ? p->pps_cb_qp_offset + d->sh->slice_cb_qp_offset : p->pps_cr_qp_offset + d->sh->slice_cr_qp_offset;
       int qPi = Clip3(-QpBdOffsetC, 57, d->cur_qp_y + off);
-      qP = hevc_chroma_qp_420(qPi) + QpBdOffsetC;
+      qP = (s->chroma_format_idc == 1 ? hevc_chroma_qp_420(qPi) : Min(qPi, 51)) + QpBdOffsetC;   /* 8.6.1: table 8-10 only for ChromaArrayType 1 */
     }
     const uint8_t* m = NULL;
     uint8_t mbuf[32 * 32];
@@ -1449,13 +1453,16 @@ static void transform_unit(Dec* d, CuCtx* cu, int x0, int y0, int xBase, int yBa
   const SPS* s = d->s; const PPS* p = d->p;
   int ChromaArrayType = s->chroma_format_idc;
   int cbfChroma = cbf_cb || cbf_cr; /* for log2TrafoSize == 2 these are the parent's flags */
-  int32_t cY[32 * 32], cCb[16 * 16], cCr[16 * 16];
+  int32_t cY[32 * 32], cCb[32 * 32], cCr[32 * 32];
   int tsY = 0, tsCb = 0, tsCr = 0;
   (void)trafoDepth;
   int lumaMode = d->m_ipm[(y0 >> 2) * d->mw + (x0 >> 2)];
   int chromaMode = cu->chroma_mode;
   int do_chroma = 0, xC0 = 0, yC0 = 0, log2C = 0;
-  if (ChromaArrayType) {
+  if (ChromaArrayType == 3) {   /* chroma blocks coincide with the luma blocks; the mode is the one of the block's partition */
+    do_chroma = 1; xC0 = x0; yC0 = y0; log2C = log2TrafoSize;
+    chromaMode = d->m_ipmc[(y0 >> 2) * d->mw + (x0 >> 2)];
+  } else if (ChromaArrayType) {
     if (log2TrafoSize > 2) { do_chroma = 1; xC0 = x0 / 2; yC0 = y0 / 2; log2C = log2TrafoSize - 1; }
     else if (blkIdx == 3) { do_chroma = 1; xC0 = xBase / 2; yC0 = yBase / 2; log2C = 2; }
   }
@@ -1510,9 +1517,10 @@ static void transform_tree(Dec* d, CuCtx* cu, int x0, int y0, int xBase, int yBa
   else
     split = (log2TrafoSize > s->log2_max_tb || (cu->IntraSplitFlag && trafoDepth == 0)) ? 1 : 0;
   int cbf_cb = 0, cbf_cr = 0;
-  if (log2TrafoSize > 2 && ChromaArrayType != 0) {
-    if (trafoDepth == 0 || parent_cbf_cb) cbf_cb = decode_decision(d, CTX_CBF_CHROMA + trafoDepth);
-    if (trafoDepth == 0 || parent_cbf_cr) cbf_cr = decode_decision(d, CTX_CBF_CHROMA + trafoDepth);
+  if ((log2TrafoSize > 2 && ChromaArrayType != 0) || ChromaArrayType == 3) {
+    int cc = trafoDepth == 4 ? CTX_CBF_CHROMA4 : CTX_CBF_CHROMA + trafoDepth;
+    if (trafoDepth == 0 || parent_cbf_cb) cbf_cb = decode_decision(d, cc);
+    if (trafoDepth == 0 || parent_cbf_cr) cbf_cr = decode_decision(d, cc);
   } else if (ChromaArrayType != 0 && trafoDepth > 0 && log2TrafoSize == 2) {
     cbf_cb = parent_cbf_cb; cbf_cr = parent_cbf_cr; /* 7.4.9.8 inference */
   }
@@ -1575,7 +1583,8 @@ static void coding_unit(Dec* d, int x0, int y0, int log2CbSize, int cqtDepth)
     cabac_finish_and_align(d);
     Cabac* c = &d->c;
     for (int cIdx = 0; cIdx < (s->chroma_format_idc ? 3 : 1); cIdx++) {
-      int n = cIdx ? nCbS / 2 : nCbS, xs = cIdx ? x0 / 2 : x0, ys = cIdx ? y0 / 2 : y0;
+      int csub = (cIdx && s->chroma_format_idc != 3) ? 2 : 1;
+      int n = nCbS / csub, xs = x0 / csub, ys = y0 / csub;
       int depth = cIdx ? s->pcm_bit_depth_chroma : s->pcm_bit_depth_luma;
       int bd = cIdx ? s->bit_depth_chroma : s->bit_depth_luma;
       int stride = cIdx ? d->Wc : d->W;
@@ -1650,16 +1659,26 @@ static void coding_unit(Dec* d, int x0, int y0, int log2CbSize, int cqtDepth)
      nothing that reads the bitstream out of order, because the flags were all read beforehand. */
   int chroma_mode = 1;
   if (s->chroma_format_idc) {
-    int icpm;
-    if (!decode_decision(d, CTX_INTRA_CHROMA)) icpm = 4;
-    else icpm = decode_bypass_bits(d, 2);
-    int lm = d->m_ipm[(y0 >> 2) * d->mw + (x0 >> 2)];
+    /* 7.3.8.5: one intra_chroma_pred_mode per coding unit, or one per partition when ChromaArrayType is 3 and the CU is split NxN */
     static const uint8_t tab[4] = {0, 26, 10, 1};
-    if (icpm == 4) chroma_mode = lm;
-    else chroma_mode = (tab[icpm] == lm) ? 34 : tab[icpm];
+    int nc = (s->chroma_format_idc == 3 && PartMode == 1) ? 2 : 1;
+    int cpb = nc == 2 ? nCbS / 2 : nCbS;
+    for (int j = 0; j < nc; j++)
+      for (int i = 0; i < nc; i++) {
+        int icpm;
+        if (!decode_decision(d, CTX_INTRA_CHROMA)) icpm = 4;
+        else icpm = decode_bypass_bits(d, 2);
+        int xP = x0 + i * cpb, yP = y0 + j * cpb;
+        int lm = d->m_ipm[(yP >> 2) * d->mw + (xP >> 2)];
+        int m = icpm == 4 ? lm : ((tab[icpm] == lm) ? 34 : tab[icpm]);
+        if (i == 0 && j == 0) chroma_mode = m;
+        for (int jj = 0; jj < (cpb >> 2); jj++) for (int ii = 0; ii < (cpb >> 2); ii++)
+          d->m_ipmc[((yP >> 2) + jj) * d->mw + (xP >> 2) + ii] = (uint8_t)m;
+      }
+  } else {
+    for (int j = 0; j < nu; j++) for (int i = 0; i < nu; i++) d->m_ipmc[(u0y + j) * d->mw + u0x + i] = 1;
   }
   cu.chroma_mode = chroma_mode;
-  for (int j = 0; j < nu; j++) for (int i = 0; i < nu; i++) d->m_ipmc[(u0y + j) * d->mw + u0x + i] = (uint8_t)chroma_mode;
 
   cu.IntraSplitFlag = PartMode == 1;
   cu.MaxTrafoDepth = s->max_transform_hierarchy_depth_intra + cu.IntraSplitFlag;
@@ -2046,7 +2065,7 @@ static void deblock_chroma_edge(Dec* d, uint16_t* pix, int xstep, int ystep, int
 {
   int bitDepth = d->s->bit_depth_chroma;
   int qPi = ((QpQ + QpP + 1) >> 1) + cQpPicOffset;
-  int QpC = hevc_chroma_qp_420(qPi);
+  int QpC = d->s->chroma_format_idc == 1 ? hevc_chroma_qp_420(qPi) : Min(qPi, 51);   /* 8.7.2.5.5 */
   int Q = Clip3(0, 53, QpC + 2 * (2 - 1) + (sh->slice_tc_offset_div2 << 1));
   int tC = tcTable[Q] * (1 << (bitDepth - 8));
   int maxv = (1 << bitDepth) - 1;
@@ -2084,6 +2103,13 @@ static void deblock_picture(Dec* d)
         int noP = unit_no_filter(d, idxP), noQ = unit_no_filter(d, idx);
         if (dir == 0) deblock_luma_edge(d, d->rec[0] + y * d->W + x, 1, d->W, QpP, QpQ, sh, noP, noQ);
         else deblock_luma_edge(d, d->rec[0] + y * d->W + x, d->W, 1, QpP, QpQ, sh, noP, noQ);
+        if (s->chroma_format_idc == 3) {
+          /* 8.7.2: with ChromaArrayType 3 the chroma planes have the luma planes' edges (the 8-sample grid in chroma samples IS the luma
+             grid), filtered with the chroma filter */
+          for (int c = 1; c < 3; c++)
+            deblock_chroma_edge(d, d->rec[c] + y * d->Wc + x, dir == 0 ? 1 : d->Wc, dir == 0 ? d->Wc : 1, QpP, QpQ,
+                                c == 1 ? p->pps_cb_qp_offset : p->pps_cr_qp_offset, sh, noP, noQ);
+        }
         if (s->chroma_format_idc == 1) {
           /* chroma edges lie on the 8x8 chroma sample grid; a 4-row chroma segment corresponds to
              8 luma rows and takes its bS from the first 4-luma-row segment (8.7.2.5.?) */
@@ -2111,7 +2137,7 @@ static void sao_picture(Dec* d, uint16_t* const src[3], uint16_t* dst[3])
   const SPS* s = d->s; const PPS* p = d->p;
   int lm = s->log2_min_tb;
   for (int cIdx = 0; cIdx < (s->chroma_format_idc ? 3 : 1); cIdx++) {
-    int W = cIdx ? d->Wc : d->W, H = cIdx ? d->Hc : d->H, sub = cIdx ? 2 : 1;
+    int W = cIdx ? d->Wc : d->W, H = cIdx ? d->Hc : d->H, sub = (cIdx && s->chroma_format_idc != 3) ? 2 : 1;
     int bitDepth = cIdx ? s->bit_depth_chroma : s->bit_depth_luma;
     int maxv = (1 << bitDepth) - 1;
     int ctbSize = (1 << s->log2_ctb) / sub;
@@ -2245,11 +2271,11 @@ int hevc_oracle_decode(const uint8_t* data, size_t size, int keep_taps, hevc_ora
   int y0 = shh * s->conf_win_top, y1 = d->H - shh * s->conf_win_bottom;
   if (x1 <= x0 || y1 <= y0) fail(d, "empty conformance window");
   out->width = x1 - x0; out->height = y1 - y0;
-  out->cwidth = s->chroma_format_idc ? out->width / 2 : 0;
-  out->cheight = s->chroma_format_idc ? out->height / 2 : 0;
+  out->cwidth = s->chroma_format_idc ? out->width / sw : 0;
+  out->cheight = s->chroma_format_idc ? out->height / shh : 0;
   for (int c = 0; c < nc; c++) {
     int w = c ? out->cwidth : out->width, h = c ? out->cheight : out->height;
-    int xs = c ? x0 / 2 : x0, ys = c ? y0 / 2 : y0, st = c ? d->Wc : d->W;
+    int xs = c ? x0 / sw : x0, ys = c ? y0 / shh : y0, st = c ? d->Wc : d->W;
     out->plane[c] = (uint16_t*)xcalloc(d, (size_t)w * h, sizeof(uint16_t));
     for (int y = 0; y < h; y++) memcpy(out->plane[c] + (size_t)y * w, fin[c] + (size_t)(ys + y) * st + xs, sizeof(uint16_t) * w);
   }

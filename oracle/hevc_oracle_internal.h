@@ -50,7 +50,8 @@ enum {
   CTX_SIG_COEFF = 62,        /* 42 */
   CTX_GREATER1 = 104,        /* 24 */
   CTX_GREATER2 = 128,        /* 6 */
-  CTX_COUNT = 134
+  CTX_CBF_CHROMA4 = 134,     /* cbf_cb / cbf_cr at trafoDepth 4: reachable only with ChromaArrayType 3 (Table 9-4 of the 2nd edition on) */
+  CTX_COUNT = 135
 };
 extern const uint8_t hevc_cabac_init_I[CTX_COUNT];
 

@@ -312,7 +312,7 @@ static void emit_residual(Enc* e, const int32_t* lev, int log2TrafoSize, int cId
   if (p->transform_skip_enabled_flag && !d->cu_transquant_bypass_flag && log2TrafoSize <= 2)
     EV_D(CTX_TRANSFORM_SKIP + (cIdx ? 1 : 0), transform_skip);
   int scanIdx = 0;
-  if (log2TrafoSize == 2 || (log2TrafoSize == 3 && cIdx == 0)) {
+  if (log2TrafoSize == 2 || (log2TrafoSize == 3 && (cIdx == 0 || d->s->chroma_format_idc == 3))) {
     if (predModeIntra >= 6 && predModeIntra <= 14) scanIdx = 2;
     else if (predModeIntra >= 22 && predModeIntra <= 30) scanIdx = 1;
   }
@@ -471,7 +471,8 @@ static int analyse_tb(Enc* e, int x0c, int y0c, int log2n, int cIdx, int mode, i
   else {
     int QpBdOffsetC = 6 * (s->bit_depth_chroma - 8);
     int off = cIdx == 1 ? p->pps_cb_qp_offset + d->sh->slice_cb_qp_offset : p->pps_cr_qp_offset + d->sh->slice_cr_qp_offset;
-    qP = hevc_chroma_qp_420(Clip3(-QpBdOffsetC, 57, d->cur_qp_y + off)) + QpBdOffsetC;
+    int qPi = Clip3(-QpBdOffsetC, 57, d->cur_qp_y + off);
+    qP = (s->chroma_format_idc == 1 ? hevc_chroma_qp_420(qPi) : Min(qPi, 51)) + QpBdOffsetC;
   }
   forward_quant(e, lev, res, n, qP, bit_depth, cIdx == 0 && n == 4, ts, d->cu_transquant_bypass_flag);
   if (e->prm.zero_residual_pct && rnd_pct(e, e->prm.zero_residual_pct)) memset(lev, 0, sizeof(int32_t) * n * n);
@@ -479,7 +480,7 @@ static int analyse_tb(Enc* e, int x0c, int y0c, int log2n, int cIdx, int mode, i
   for (int i = 0; i < n * n; i++) if (lev[i]) { cbf = 1; break; }
   if (cbf && p->sign_data_hiding_enabled_flag && !d->cu_transquant_bypass_flag) {
     int scanIdx = 0;
-    if (log2n == 2 || (log2n == 3 && cIdx == 0)) {
+    if (log2n == 2 || (log2n == 3 && (cIdx == 0 || s->chroma_format_idc == 3))) {
       if (mode >= 6 && mode <= 14) scanIdx = 2; else if (mode >= 22 && mode <= 30) scanIdx = 1;
     }
     sdh_fix(lev, log2n, scanIdx);
@@ -532,6 +533,42 @@ static ChromaCbf enc_transform_tree(Enc* e, CuCtx* cu, int x0, int y0, int xBase
   int32_t levCb[16 * 16], levCr[16 * 16];
   int tsCb = 0, tsCr = 0;
   int chroma_here_early = 0;
+  if (ChromaArrayType == 3) {
+    /* 4:4:4: every node carries its chroma cbfs and every leaf its own chroma blocks, the size of the luma block */
+    int cc = trafoDepth == 4 ? CTX_CBF_CHROMA4 : CTX_CBF_CHROMA + trafoDepth;
+    my_cb = ev_add(e, EV_DECISION, cc, 0, 0, trafoDepth == 0 ? -1 : slot_cb);
+    my_cr = ev_add(e, EV_DECISION, cc, 0, 0, trafoDepth == 0 ? -1 : slot_cr);
+    if (split) {
+      int x1 = x0 + (1 << (log2TrafoSize - 1)), y1 = y0 + (1 << (log2TrafoSize - 1));
+      for (int k = 0; k < 4; k++) {
+        ChromaCbf c = enc_transform_tree(e, cu, (k & 1) ? x1 : x0, (k & 2) ? y1 : y0, x0, y0, log2TrafoSize - 1, trafoDepth + 1, k,
+                                         my_cb, my_cr, 0, 0);
+        out.cbf_cb |= c.cbf_cb; out.cbf_cr |= c.cbf_cr;
+      }
+      e->ev[my_cb].val = out.cbf_cb; e->ev[my_cr].val = out.cbf_cr;
+      return out;
+    }
+    int32_t* lev = (int32_t*)malloc(sizeof(int32_t) * 3 * 32 * 32);
+    int32_t *lY = lev, *lCb = lev + 1024, *lCr = lev + 2048;
+    int tsY = 0;
+    int mode = d->m_ipm[(y0 >> 2) * d->mw + (x0 >> 2)], cmode = d->m_ipmc[(y0 >> 2) * d->mw + (x0 >> 2)];
+    int pending = d->p->cu_qp_delta_enabled_flag && !d->IsCuQpDeltaCoded;
+    int saved_delta = d->CuQpDeltaVal, saved_qp = d->cur_qp_y;
+    if (pending) { d->CuQpDeltaVal = e->qg_delta; set_qp_y(d); }
+    int cbfY = analyse_tb(e, x0, y0, log2TrafoSize, 0, mode, lY, &tsY);
+    out.cbf_cb = analyse_tb(e, x0, y0, log2TrafoSize, 1, cmode, lCb, &tsCb);
+    out.cbf_cr = analyse_tb(e, x0, y0, log2TrafoSize, 2, cmode, lCr, &tsCr);
+    e->ev[my_cb].val = out.cbf_cb; e->ev[my_cr].val = out.cbf_cr;
+    if (pending) { d->CuQpDeltaVal = saved_delta; d->cur_qp_y = saved_qp; }
+    EV_D(CTX_CBF_LUMA + (trafoDepth == 0 ? 1 : 0), cbfY);
+    if (cbfY || out.cbf_cb || out.cbf_cr) enc_cu_qp_delta(e);
+    if (cbfY) emit_residual(e, lY, log2TrafoSize, 0, mode, tsY);
+    if (out.cbf_cb) emit_residual(e, lCb, log2TrafoSize, 1, cmode, tsCb);
+    if (out.cbf_cr) emit_residual(e, lCr, log2TrafoSize, 2, cmode, tsCr);
+    mark_tu(d, cu, x0, y0, log2TrafoSize, cbfY, out.cbf_cb, out.cbf_cr);
+    free(lev);
+    return out;
+  }
   if (log2TrafoSize > 2 && ChromaArrayType != 0) {
     my_cb = ev_add(e, EV_DECISION, CTX_CBF_CHROMA + trafoDepth, 0, 0, trafoDepth == 0 ? -1 : slot_cb);
     my_cr = ev_add(e, EV_DECISION, CTX_CBF_CHROMA + trafoDepth, 0, 0, trafoDepth == 0 ? -1 : slot_cr);
@@ -675,7 +712,8 @@ static void enc_coding_unit(Enc* e, int x0, int y0, int log2CbSize, int cqtDepth
   if (pcm_flag) {
     size_t start = e->pcm_bits;
     for (int cIdx = 0; cIdx < (s->chroma_format_idc ? 3 : 1); cIdx++) {
-      int n = cIdx ? nCbS / 2 : nCbS, xs = cIdx ? x0 / 2 : x0, ys = cIdx ? y0 / 2 : y0;
+      int csub = (cIdx && s->chroma_format_idc != 3) ? 2 : 1;
+      int n = nCbS / csub, xs = x0 / csub, ys = y0 / csub;
       int depth = cIdx ? s->pcm_bit_depth_chroma : s->pcm_bit_depth_luma;
       int bd = cIdx ? s->bit_depth_chroma : s->bit_depth_luma;
       int stride = cIdx ? d->Wc : d->W;
@@ -749,16 +787,26 @@ static void enc_coding_unit(Enc* e, int x0, int y0, int log2CbSize, int cqtDepth
     }
   (void)modes;
   int chroma_mode = 1;
+  for (int j = 0; j < nu; j++) for (int i = 0; i < nu; i++) d->m_ipmc[(u0y + j) * d->mw + u0x + i] = 1;
   if (s->chroma_format_idc) {
-    int icpm = e->prm.stress ? (int)(rnd(e) % 5) : (rnd_pct(e, 70) ? 4 : (int)(rnd(e) % 4));
-    if (icpm == 4) EV_D(CTX_INTRA_CHROMA, 0);
-    else { EV_D(CTX_INTRA_CHROMA, 1); EV_BB(icpm, 2); }
-    int lm = d->m_ipm[(y0 >> 2) * d->mw + (x0 >> 2)];
-    static const uint8_t tab[4] = {0, 26, 10, 1};
-    if (icpm == 4) chroma_mode = lm; else chroma_mode = (tab[icpm] == lm) ? 34 : tab[icpm];
+    /* one intra_chroma_pred_mode per CU, or one per partition for an NxN CU of a 4:4:4 picture (7.3.8.5) */
+    int ncp = (s->chroma_format_idc == 3 && PartMode == 1) ? 2 : 1;
+    int cpb = ncp == 2 ? nCbS / 2 : nCbS;
+    for (int j = 0; j < ncp; j++)
+      for (int i = 0; i < ncp; i++) {
+        int icpm = e->prm.stress ? (int)(rnd(e) % 5) : (rnd_pct(e, 70) ? 4 : (int)(rnd(e) % 4));
+        if (icpm == 4) EV_D(CTX_INTRA_CHROMA, 0);
+        else { EV_D(CTX_INTRA_CHROMA, 1); EV_BB(icpm, 2); }
+        int xP = x0 + i * cpb, yP = y0 + j * cpb;
+        int lm = d->m_ipm[(yP >> 2) * d->mw + (xP >> 2)];
+        static const uint8_t tab[4] = {0, 26, 10, 1};
+        int m = icpm == 4 ? lm : ((tab[icpm] == lm) ? 34 : tab[icpm]);
+        if (i == 0 && j == 0) chroma_mode = m;
+        for (int jj = 0; jj < (cpb >> 2); jj++) for (int ii = 0; ii < (cpb >> 2); ii++)
+          d->m_ipmc[((yP >> 2) + jj) * d->mw + (xP >> 2) + ii] = (uint8_t)m;
+      }
   }
   cu.chroma_mode = chroma_mode;
-  for (int j = 0; j < nu; j++) for (int i = 0; i < nu; i++) d->m_ipmc[(u0y + j) * d->mw + u0x + i] = (uint8_t)chroma_mode;
   cu.IntraSplitFlag = PartMode == 1;
   cu.MaxTrafoDepth = s->max_transform_hierarchy_depth_intra + cu.IntraSplitFlag;
   enc_transform_tree(e, &cu, x0, y0, x0, y0, log2CbSize, 0, 0, -1, -1, 0, 0);
@@ -896,7 +944,7 @@ static void put_nal(Bytes* out, int nal_type, const uint8_t* rbsp, size_t n)
 
 static void write_ptl(BW* w, int bit_depth, int chroma)
 {
-  int idc = chroma == 0 ? 4 : bit_depth > 8 ? 2 : 1;
+  int idc = (chroma == 0 || chroma == 3) ? 4 : bit_depth > 8 ? 2 : 1;   /* 4:0:0 and 4:4:4 are format-range-extension profiles */
   bw_u(w, 0, 2); bw_u(w, 0, 1); bw_u(w, idc, 5);
   for (int i = 0; i < 32; i++) bw_put(w, i == idc || (idc == 1 && i == 2));
   bw_u(w, 1, 1); bw_u(w, 0, 1); bw_u(w, 0, 1); bw_u(w, 1, 1);
@@ -942,6 +990,8 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
   s->max_transform_hierarchy_depth_inter = 1;
   s->max_transform_hierarchy_depth_intra = prm->max_transform_hierarchy_depth_intra;
   s->scaling_list_enabled_flag = prm->scaling_list ? 1 : 0;
+  if (prm->scaling_list && prm->chroma_format_idc == 3) fail(d, "scaling lists with 4:4:4 are not supported");
+  if (prm->chroma_format_idc == 2 || prm->chroma_format_idc > 3) fail(d, "chroma_format_idc must be 0, 1 or 3");
   scaling_list_default(&s->sl); scaling_list_default(&p->sl);
   s->amp_enabled_flag = 0; s->sao_enabled_flag = prm->sao;
   s->pcm_enabled_flag = prm->pcm_pct > 0;
@@ -996,6 +1046,7 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
   bw_u(&w, 0, 4); bw_u(&w, 0, 3); bw_u(&w, 1, 1);
   write_ptl(&w, prm->bit_depth, prm->chroma_format_idc);
   bw_ue(&w, 0); bw_ue(&w, s->chroma_format_idc);
+  if (s->chroma_format_idc == 3) bw_u(&w, 0, 1);   /* separate_colour_plane_flag */
   bw_ue(&w, s->pic_width); bw_ue(&w, s->pic_height);
   int cw = s->conf_win_right || s->conf_win_bottom;
   bw_u(&w, cw, 1);
@@ -1060,7 +1111,8 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
   setup_picture(d);
   for (int c = 0; c < (s->chroma_format_idc ? 3 : 1); c++) {
     int W = c ? d->Wc : d->W, H = c ? d->Hc : d->H;
-    int sw = c ? (prm->width + 1) / 2 : prm->width, sh_ = c ? (prm->height + 1) / 2 : prm->height;
+    int csub = (c && s->chroma_format_idc != 3) ? 2 : 1;
+    int sw = (prm->width + csub - 1) / csub, sh_ = (prm->height + csub - 1) / csub;
     src[c] = (uint16_t*)xcalloc(d, (size_t)W * H, sizeof(uint16_t));
     for (int y = 0; y < H; y++)
       for (int x = 0; x < W; x++) src[c][y * W + x] = planes[c][(size_t)Min(y, sh_ - 1) * sw + Min(x, sw - 1)];
