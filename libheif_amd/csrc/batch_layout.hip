@@ -121,7 +121,8 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
       uint32_t lag = 2;
       if (w < rows) { lag = row_len / (w + 1); if (lag < 2) lag = 2; }
       for (uint32_t j = 0; j < w; j++)
-        for (uint32_t c = 0; c < 2; c++) rwaves.push_back(ReconWave{(uint32_t)i, c, j, w, row_base, lag, 0, 0});   // 0 = luma, 1 = Cb + Cr in one wave
+        for (uint32_t c = 0; c < (p.sps.chroma_format_idc == 3 ? 3u : 2u); c++)   // 0 = luma, 1 = Cb + Cr in one wave (4:2:0); 4:4:4: one wave per plane
+          rwaves.push_back(ReconWave{(uint32_t)i, c, j, w, row_base, lag, 0, 0});
       row_base += rows;
     }
   }
@@ -135,7 +136,8 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
     PicParams& P = b.params[i];
     P.width = S.pic_width; P.height = S.pic_height;
     P.chroma_format_idc = S.chroma_format_idc;
-    P.cwidth = S.chroma_format_idc ? S.pic_width / 2 : 0; P.cheight = S.chroma_format_idc ? S.pic_height / 2 : 0;
+    const int csh = S.chroma_format_idc == 3 ? 0 : 1;   // log2 SubWidthC = log2 SubHeightC
+    P.cwidth = S.chroma_format_idc ? S.pic_width >> csh : 0; P.cheight = S.chroma_format_idc ? S.pic_height >> csh : 0;
     P.out_width = pp.info.width; P.out_height = pp.info.height; P.out_cwidth = pp.info.chroma_width; P.out_cheight = pp.info.chroma_height;
     const int subc = S.chroma_format_idc == 1 ? 2 : 1;
     P.crop_x = subc * S.conf_left; P.crop_y = subc * S.conf_top;
@@ -208,11 +210,12 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
     P.off_u_ipmc = off; off = align_up(off + nunits, 256);
     P.off_u_qp = off; off = align_up(off + nunits, 256);
     P.off_coeff[0] = off; off = align_up(off + nctb * ctb2 * 2, 256);
-    P.off_coeff[1] = off; off = align_up(off + nctb * ctb2 / 2, 256);
-    P.off_coeff[2] = off; off = align_up(off + nctb * ctb2 / 2, 256);
+    const int csh = P.chroma_format_idc == 3 ? 0 : 1;
+    P.off_coeff[1] = off; off = align_up(off + ((nctb * ctb2 * 2) >> (2 * csh)), 256);
+    P.off_coeff[2] = off; off = align_up(off + ((nctb * ctb2 * 2) >> (2 * csh)), 256);
     const int ctb = 1 << P.log2_ctb;
     for (int c = 0; c < 3; c++) {
-      const size_t w = c ? (size_t)P.ctb_w * ctb / 2 : (size_t)P.ctb_w * ctb, h = c ? (size_t)P.ctb_h * ctb / 2 : (size_t)P.ctb_h * ctb;
+      const size_t w = c ? ((size_t)P.ctb_w * ctb) >> csh : (size_t)P.ctb_w * ctb, h = c ? ((size_t)P.ctb_h * ctb) >> csh : (size_t)P.ctb_h * ctb;
       P.rec_stride[c] = (uint32_t)align_up(w * es, 64);
       P.off_rec[c] = off; off = align_up(off + (size_t)P.rec_stride[c] * (h + 1), 256);
       P.off_line[c] = off; off = align_up(off + (size_t)P.rec_stride[c] * (size_t)P.ctb_h + 256, 256);

@@ -424,14 +424,16 @@ int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void* out_dev, s
     if (b->wide) return set_error(HIPDEC_ERR_UNSUPPORTED, "to_rgb: 8-bit interleaved output from >8-bit planes needs hipdec_color_to_sdr first");
     // planner rule: integer op only for full range and a matrix it accepts
     const int m = I.matrix_coeffs == 2 ? 6 : I.matrix_coeffs;
-    if (I.full_range_flag && m != 0 && m != 8)
+    if (P.chroma_format_idc == 1 && I.full_range_flag && m != 0 && m != 8)
       return hipdec_color_420_to_rgb24(y, P.out_stride[0], cb, P.out_stride[1], cr, P.out_stride[2], P.out_width, P.out_height, &nclx, out_dev,
                                        out_stride, out_chroma == 11, s);
-    return hipdec_color_ycbcr_to_rgb24_float(y, P.out_stride[0], cb, P.out_stride[1], cr, P.out_stride[2], P.out_width, P.out_height, 1, &nclx,
-                                             out_dev, out_stride, out_chroma == 11, s);
+    // 4:4:4 planes take Op_YCbCr_to_RGB<uint8_t> + Op_RGB_to_RGB24_32 whatever the range (the only chain the planner has for them)
+    return hipdec_color_ycbcr_to_rgb24_float(y, P.out_stride[0], cb, P.out_stride[1], cr, P.out_stride[2], P.out_width, P.out_height,
+                                             P.chroma_format_idc, &nclx, out_dev, out_stride, out_chroma == 11, s);
   }
   if (out_chroma == 12 || out_chroma == 14) {
     if (!b->wide) return set_error(HIPDEC_ERR_UNSUPPORTED, "to_rgb: RRGGBB output needs >8-bit planes");
+    if (P.chroma_format_idc != 1) return set_error(HIPDEC_ERR_UNSUPPORTED, "to_rgb: RRGGBB output is implemented for 4:2:0 planes (Op_YCbCr420_to_RRGGBBaa)");
     return hipdec_color_420_to_rrggbb(y, P.out_stride[0], cb, P.out_stride[1], cr, P.out_stride[2], P.out_width, P.out_height, I.bit_depth_luma,
                                       &nclx, out_dev, out_stride, out_chroma == 14, s);
   }
@@ -1421,6 +1423,7 @@ int hipdec_grid_create(hipdec_grid** out, int rows, int cols, int out_width, int
           return set_error(HIPDEC_ERR_BITSTREAM, "grid_create: tiles differ in size, bit depth or chroma format");
     if (out_width > cols * g->tile_w || out_height > rows * g->tile_h)
       return set_error(HIPDEC_ERR_BITSTREAM, "grid_create: the output size exceeds the tiled area");
+    if (g->info.chroma_format_idc == 3) return set_error(HIPDEC_ERR_UNSUPPORTED, "grid_create: the device canvas takes 4:2:0 and 4:0:0 tiles (decode 4:4:4 tiles one by one)");
     if (g->info.chroma_format_idc && ((g->tile_w | g->tile_h) & 1)) return set_error(HIPDEC_ERR_UNSUPPORTED, "grid_create: 4:2:0 tiles with odd dimensions");
     {
       DeviceScope scope(g->root);

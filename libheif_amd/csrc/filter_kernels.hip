@@ -101,10 +101,11 @@ __device__ __forceinline__ void deblock_luma(Pix* pix, int xs, int ys, int qp_p,
 
 template <typename Pix>
 __device__ __forceinline__ void deblock_chroma(Pix* pix, int xs, int ys, int qp_p, int qp_q, int c_qp_pic_offset, int tc_off2, int bit_depth,
-                                               int no_p, int no_q)
+                                               int no_p, int no_q, bool c444 = false)
 {
   const int qpi = ((qp_q + qp_p + 1) >> 1) + c_qp_pic_offset;
-  const int qpc = qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : c_chroma_qp_f[qpi - 30]);
+  // 8.7.2.5.5: QpC "as specified in table 8-10" for ChromaArrayType 1, Min(qPi, 51) otherwise
+  const int qpc = c444 ? (qpi < 51 ? qpi : 51) : (qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : c_chroma_qp_f[qpi - 30]));
   const int tc = c_tc[clip3(0, 53, qpc + 2 + (tc_off2 << 1))] * (1 << (bit_depth - 8));
   const int maxv = (1 << bit_depth) - 1;
 #pragma unroll
@@ -158,6 +159,17 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
     if (DIR == 0) deblock_luma<Pix>(pix, 1, stride, qp_p, qp_q, sl.beta_offset_div2, sl.tc_offset_div2, P.bit_depth_luma, no_p, no_q);
     else deblock_luma<Pix>(pix, stride, 1, qp_p, qp_q, sl.beta_offset_div2, sl.tc_offset_div2, P.bit_depth_luma, no_p, no_q);
   }
+  if (P.chroma_format_idc == 3) {
+    // 4:4:4: the chroma planes have the luma planes' edges (the 8-sample chroma grid IS the luma grid) and take the chroma filter
+    for (int c = 1; c < 3; c++) {
+      Pix* rec = (Pix*)(A.arena + P.off_rec[c]);
+      const int stride = P.rec_stride[c] / sizeof(Pix);
+      Pix* pix = rec + (size_t)y * stride + x;
+      const int off = c == 1 ? sl.pps_cb_qp_offset : sl.pps_cr_qp_offset;
+      if (DIR == 0) deblock_chroma<Pix>(pix, 1, stride, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q, true);
+      else deblock_chroma<Pix>(pix, stride, 1, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q, true);
+    }
+  }
   if (P.chroma_format_idc == 1) {
     // chroma edges on the 8x8 chroma grid; one 4-sample chroma segment spans 8 luma samples along the edge
     const int on_grid = DIR == 0 ? ((x & 15) == 0 && (y & 7) == 0) : ((y & 15) == 0 && (x & 7) == 0);
@@ -208,7 +220,7 @@ template <typename Pix>
 __device__ __forceinline__ SaoComp<Pix> sao_comp(const FilterArgs& A, const PicParams& P, int c, bool may_keep, bool restricted)
 {
   SaoComp<Pix> S;
-  S.P = &P; S.c = c; S.sub = c ? 2 : 1;
+  S.P = &P; S.c = c; S.sub = (c && P.chroma_format_idc != 3) ? 2 : 1;
   S.ow = c ? P.out_cwidth : P.out_width; S.oh = c ? P.out_cheight : P.out_height;
   S.W = c ? P.cwidth : P.width; S.H = c ? P.cheight : P.height;
   S.bit_depth = c ? P.bit_depth_chroma : P.bit_depth_luma; S.maxv = (1 << S.bit_depth) - 1;
@@ -218,7 +230,7 @@ __device__ __forceinline__ SaoComp<Pix> sao_comp(const FilterArgs& A, const PicP
   S.sao = (const SaoParams*)(A.arena + P.off_sao);
   S.ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
   S.slices = (const SliceParams*)(A.arena + P.off_slices);
-  S.lctb = P.log2_ctb - (c ? 1 : 0);   // log2 CTB size in component samples
+  S.lctb = P.log2_ctb - (S.sub == 2 ? 1 : 0);   // log2 CTB size in component samples
   S.crop_xc = P.crop_x / S.sub; S.crop_yc = P.crop_y / S.sub; S.ctb_w = P.ctb_w;
   // may_keep: compile-time false in the kernel variant for batches without lossless CUs / unfiltered PCM (the common case): the per-sample
   // unit look-ups and the paths behind them leave the kernel, which is larger than the instruction cache

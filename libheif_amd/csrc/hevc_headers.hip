@@ -320,7 +320,9 @@ void parse_sps(NalReader& r, Sps& s)
       if (any) unsupported("range-extension coding tools");
     }
   }
-  if (s.chroma_format_idc != 0 && s.chroma_format_idc != 1) unsupported("chroma_format_idc " + std::to_string(s.chroma_format_idc));
+  if (s.chroma_format_idc == 2) unsupported("chroma_format_idc 2 (4:2:2)");
+  if (s.chroma_format_idc == 3 && s.separate_colour_plane) unsupported("4:4:4 with separate colour planes");
+  if (s.chroma_format_idc == 3 && s.scaling_list_enabled) unsupported("scaling lists with 4:4:4 (32x32 chroma matrices)");
   if (s.bit_depth_luma > 12 || s.bit_depth_chroma > 12) unsupported("bit depth above 12");
   // 7.4.3.2.1: 3 <= MinCbLog2SizeY <= CtbLog2SizeY, CtbLog2SizeY in 4..6; 2 <= MinTbLog2SizeY < MinCbLog2SizeY;
   // MinTbLog2SizeY <= MaxTbLog2SizeY <= Min(CtbLog2SizeY, 5); max_transform_hierarchy_depth_* <= CtbLog2SizeY - MinTbLog2SizeY
@@ -724,8 +726,8 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
     if (x1 <= x0 || y1 <= y0) bad("empty conformance window");
     I.width = x1 - x0; I.height = y1 - y0;
     I.chroma_format_idc = S.chroma_format_idc;
-    I.chroma_width = S.chroma_format_idc ? I.width / 2 : 0;
-    I.chroma_height = S.chroma_format_idc ? I.height / 2 : 0;
+    I.chroma_width = S.chroma_format_idc ? I.width / sub_w : 0;
+    I.chroma_height = S.chroma_format_idc ? I.height / sub_h : 0;
     I.bit_depth_luma = S.bit_depth_luma; I.bit_depth_chroma = S.bit_depth_chroma;
     I.colour_primaries = S.colour_primaries; I.transfer_characteristics = S.transfer_characteristics;
     I.matrix_coeffs = S.matrix_coeffs; I.full_range_flag = S.full_range;

@@ -809,7 +809,7 @@ PC_DEV int residual_coding(PS& s, int log2n, int c_idx, int pred_mode)
   if (px > 3) last_x = (1 << ((px >> 1) - 1)) * (2 + (px & 1)) + decode_bypass_bits(s, (px >> 1) - 1);
   if (py > 3) last_y = (1 << ((py >> 1) - 1)) * (2 + (py & 1)) + decode_bypass_bits(s, (py >> 1) - 1);
   int scan_idx = 0;
-  if (log2n == 2 || (log2n == 3 && c_idx == 0)) {
+  if (log2n == 2 || (log2n == 3 && (c_idx == 0 || s.chroma_format_idc == 3))) {   // 7.4.9.11: 8x8 chroma blocks too with ChromaArrayType 3
     if (pred_mode >= 6 && pred_mode <= 14) scan_idx = 2;
     else if (pred_mode >= 22 && pred_mode <= 30) scan_idx = 1;
   }
@@ -1022,7 +1022,8 @@ PC_DEV void pcm_coding_unit(PS& s, int zb, int log2cb, int16_t* coef_y, int16_t*
   uint32_t acc = 0;
   int nacc = 0;
   for (int c = 0; c < (s.chroma_format_idc ? 3 : 1); c++) {
-    const int lg = c ? log2cb - 1 : log2cb, n2 = 1 << (2 * lg);
+    const int c444 = s.chroma_format_idc == 3;
+    const int lg = (c && !c444) ? log2cb - 1 : log2cb, n2 = 1 << (2 * lg);
     const int depth = (int)((s.pcm >> (c ? 16 : 8)) & 255u), shift = (c ? s.bit_depth_chroma : s.bit_depth_luma) - depth;
     for (int i = 0; i < n2; i++) {
       while (nacc < depth) { acc = (acc << 8) | read_byte(s); nacc += 8; }
@@ -1030,7 +1031,7 @@ PC_DEV void pcm_coding_unit(PS& s, int zb, int log2cb, int16_t* coef_y, int16_t*
       nacc -= depth;
       PC_VEC_BEGIN if (lane == 0) s.L->coef[i] = (int16_t)(v << shift); PC_VEC_END
     }
-    flush_coef(s, c == 0 ? coef_y + zb * 16 : (c == 1 ? coef_cb : coef_cr) + zb * 4, n2);
+    flush_coef(s, c == 0 ? coef_y + zb * 16 : (c == 1 ? coef_cb : coef_cr) + zb * (c444 ? 16 : 4), n2);
   }
   s.range = pc_vec(510u << 7); s.bits_needed = pc_vec((uint32_t)-8);
   {
@@ -1098,15 +1099,20 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
     }
     map_fill(s.m_ipm, zb + k * pu_units, pu_units, (uint32_t)mode);
   }
+  // intra_chroma_pred_mode: one per coding unit, or one per partition of an NxN coding unit when ChromaArrayType is 3 (7.3.8.5)
+  const int c444 = s.chroma_format_idc == 3;
   int chroma_mode = 1;
   if (s.chroma_format_idc) {
-    int icpm = 4;
-    if (decode_bin(s, s.ctxA, A_INTRA_CHROMA)) icpm = decode_bypass_bits(s, 2);
-    const int lm = (int)(map_get(s.m_ipm, zb) & 63u);
-    if (icpm == 4) chroma_mode = lm;
-    else { const int m = icpm == 0 ? 0 : icpm == 1 ? 26 : icpm == 2 ? 10 : 1; chroma_mode = (m == lm) ? 34 : m; }
-  }
-  map_fill(s.m_ipmc, zb, n_units, (uint32_t)chroma_mode);
+    const int n_cp = (c444 && part_nxn) ? 4 : 1, cp_units = n_units / n_cp;
+    for (int k = 0; k < n_cp; k++) {
+      int icpm = 4;
+      if (decode_bin(s, s.ctxA, A_INTRA_CHROMA)) icpm = decode_bypass_bits(s, 2);
+      const int lm = (int)(map_get(s.m_ipm, zb + k * cp_units) & 63u);
+      if (icpm == 4) chroma_mode = lm;
+      else { const int m = icpm == 0 ? 0 : icpm == 1 ? 26 : icpm == 2 ? 10 : 1; chroma_mode = (m == lm) ? 34 : m; }
+      map_fill(s.m_ipmc, zb + k * cp_units, cp_units, (uint32_t)chroma_mode);
+    }
+  } else map_fill(s.m_ipmc, zb, n_units, 1u);
 
   // ---- transform tree ----
   const int max_trafo_depth = s.max_th_depth_intra + part_nxn;
@@ -1123,10 +1129,11 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
       else split = (t > s.log2_max_tb || (part_nxn && depth == 0)) ? 1 : 0;
       if (s.chroma_format_idc) {
         const uint32_t bit = 1u << depth, pbit = depth ? (1u << (depth - 1)) : 0;
-        if (t > 2) {
+        if (t > 2 || c444) {
           int cb = 0, cr = 0;
-          if (depth == 0 || (cbf_cb_bits & pbit)) cb = decode_bin(s, s.ctxA, A_CBF_CHROMA + depth);
-          if (depth == 0 || (cbf_cr_bits & pbit)) cr = decode_bin(s, s.ctxA, A_CBF_CHROMA + depth);
+          const int cc = depth == 4 ? A_CBF_CHROMA4 : A_CBF_CHROMA + depth;   // depth 4 only occurs with ChromaArrayType 3
+          if (depth == 0 || (cbf_cb_bits & pbit)) cb = decode_bin(s, s.ctxA, cc);
+          if (depth == 0 || (cbf_cr_bits & pbit)) cr = decode_bin(s, s.ctxA, cc);
           cbf_cb_bits = (cbf_cb_bits & ~bit) | (cb ? bit : 0);
           cbf_cr_bits = (cbf_cr_bits & ~bit) | (cr ? bit : 0);
         } else {  // 4x4 luma: inherits the parent's flags (7.4.9.8)
@@ -1146,7 +1153,8 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
     if ((cbf_luma | cbf_cb | cbf_cr) && (s.tools & TOOL_CUQPD) && !s.is_cu_qp_delta_coded) parse_cu_qp_delta(s);
     const int luma_mode = (int)(map_get(s.m_ipm, zu) & 63u);
     int do_chroma = 0, zc = zu, tc = t - 1;
-    if (s.chroma_format_idc) {
+    if (c444) { do_chroma = 1; tc = t; chroma_mode = (int)map_get(s.m_ipmc, zu); }   // chroma blocks coincide with the luma blocks
+    else if (s.chroma_format_idc) {
       if (t > 2) do_chroma = 1;
       else if ((q & 3) == 3) { do_chroma = 1; zc = zb + (q & ~3); tc = 2; }
     }
@@ -1157,7 +1165,7 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
       const int coded = c == 0 ? cbf_luma : (do_chroma && (c == 1 ? cbf_cb : cbf_cr));
       if (!coded) continue;
       const int lg = c == 0 ? t : tc;
-      int16_t* dst = c == 0 ? coef_y + zu * 16 : (c == 1 ? coef_cb : coef_cr) + zc * 4;
+      int16_t* dst = c == 0 ? coef_y + zu * 16 : (c == 1 ? coef_cb : coef_cr) + zc * (c444 ? 16 : 4);
       ts_bits |= (uint32_t)residual_coding(s, lg, c, c == 0 ? luma_mode : chroma_mode) << c;
       flush_coef(s, dst, 1 << (2 * lg));
     }
@@ -1538,8 +1546,9 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
     if (!(s.tools & TOOL_CUQPD)) { s.is_cu_qp_delta_coded = 0; s.cu_qp_delta_val = 0; s.qpy_pred = s.last_qp_y; }
 
     int16_t* coef_y = (int16_t*)(arena + uload64(&P->off_coeff[0])) + (size_t)ctb_rs * ctb_size * ctb_size;
-    int16_t* coef_cb = (int16_t*)(arena + uload64(&P->off_coeff[1])) + (size_t)ctb_rs * (ctb_size * ctb_size / 4);
-    int16_t* coef_cr = (int16_t*)(arena + uload64(&P->off_coeff[2])) + (size_t)ctb_rs * (ctb_size * ctb_size / 4);
+    const int cc_shift = s.chroma_format_idc == 3 ? 0 : 2;   // chroma samples per CTB = luma samples >> cc_shift
+    int16_t* coef_cb = (int16_t*)(arena + uload64(&P->off_coeff[1])) + (size_t)ctb_rs * ((ctb_size * ctb_size) >> cc_shift);
+    int16_t* coef_cr = (int16_t*)(arena + uload64(&P->off_coeff[2])) + (size_t)ctb_rs * ((ctb_size * ctb_size) >> cc_shift);
 
     // coding quadtree, stackless over the z-ordered min-CB index
     const int n_mincb = 1 << n_mincb_log2;

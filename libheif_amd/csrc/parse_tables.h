@@ -16,6 +16,7 @@ enum : int {
   A_SAO_MERGE = 0, A_SAO_TYPE = 1, A_SPLIT_CU = 2 /*3*/, A_CU_TQ_BYPASS = 5, A_PART_MODE = 6, A_PREV_INTRA_LUMA = 7,
   A_INTRA_CHROMA = 8, A_SPLIT_TRANSFORM = 9 /*3*/, A_CBF_LUMA = 12 /*2*/, A_CBF_CHROMA = 14 /*4*/, A_CU_QP_DELTA = 18 /*2*/,
   A_TRANSFORM_SKIP = 20 /*2*/, A_LAST_X = 22 /*18*/, A_LAST_Y = 40 /*18*/, A_CODED_SUB_BLOCK = 58 /*4*/,
+  A_CBF_CHROMA4 = 62 /* cbf_cb / cbf_cr at trafoDepth 4 (ChromaArrayType 3 only; initValue 154 like the padding lanes) */,
   // group B: sig_coeff_flag 0..43 (42 used by version 1), greater2 44..49
   B_SIG_COEFF = 0, B_GREATER2 = 44,
   // group C: greater1 0..23

@@ -113,8 +113,9 @@ struct Ctx {
   int ctbc, lg_ctbc;  // CTB size in component samples (and its log2)
   int ush;            // component samples -> 4x4-luma units: >> ush (2 for luma, 1 for 4:2:0 chroma)
   int bit_depth, maxv;
-  int luma;           // c_idx == 0
-  int strong;         // sps strong_intra_smoothing_enabled_flag
+  int luma;           // c_idx == 0: DC / horizontal / vertical boundary filters (8.4.4.2.6) apply
+  int smooth;         // reference-sample filtering (8.4.4.2.3) applies: c_idx == 0 or ChromaArrayType == 3
+  int strong;         // sps strong_intra_smoothing_enabled_flag (c_idx == 0 only)
 };
 
 // One transform block: prediction (+ residual) into the LDS tile.
@@ -209,8 +210,8 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
   }
   // accessors in scan order: left column p[-1][k-1] = ref[2n - k], top row p[k-1][-1] = ref[2n + k]
   const uint16_t* ref = ref0;
-  // ---- 8.4.4.2.3 smoothing of the reference samples (luma only in 4:2:0) ----
-  if (C.luma && mode != 1 && n != 4) {
+  // ---- 8.4.4.2.3 smoothing of the reference samples (luma; chroma too with ChromaArrayType 3) ----
+  if (C.smooth && mode != 1 && n != 4) {
     int d1 = mode - 26, d2 = mode - 10;
     d1 = d1 < 0 ? -d1 : d1; d2 = d2 < 0 ? -d2 : d2;
     const int min_dist = d1 < d2 ? d1 : d2;
@@ -455,17 +456,20 @@ __device__ __forceinline__ void reconstruct_chroma_pair(ReconLds<Pix>& L, const 
 
 }  // namespace
 
-// The CTB rows of one wave.  DUAL = false: the luma plane, 64 lanes per block.  DUAL = true: Cb (lanes 0..31) and Cr (lanes
-// 32..63) side by side — h / l below are a lane's half and its index inside the half, LW the lanes one component has.
+// The CTB rows of one wave.  DUAL = false: ONE plane at luma resolution, 64 lanes per block — the luma plane (plane 0) or, for a 4:4:4
+// picture, the Cb / Cr plane (plane 1 / 2: same geometry as luma, the chroma modes / flags / bit depth, no boundary filters).
+// DUAL = true: the 4:2:0 Cb (lanes 0..31) and Cr (lanes 32..63) side by side — h / l below are a lane's half and its index inside
+// the half, LW the lanes one component has.
 template <typename Pix, bool DUAL>
-__device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& wd, ReconLds<Pix>& L, int lane)
+__device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& wd, ReconLds<Pix>& L, int lane, int plane)
 {
   constexpr int ES = (int)sizeof(Pix);
   constexpr int LW = DUAL ? 32 : 64;
   constexpr int PPW = 4 / ES;            // pixels per 32-bit word
   const int h = DUAL ? lane >> 5 : 0, l = DUAL ? lane & 31 : lane;
-  const int comp = DUAL ? 1 + h : 0;     // colour component this lane works on
-  const int c_idx = DUAL ? 1 : 0;        // progress words / wave table: 0 = luma, 1 = the chroma pair
+  const int comp = DUAL ? 1 + h : plane; // colour component this lane works on
+  const int c_idx = DUAL ? 1 : plane;    // progress words / wave table: 0 = luma, 1 = the chroma pair (4:4:4: 1 = Cb, 2 = Cr)
+  const bool chroma = DUAL || plane != 0;
   const PicParams& P = A.pics[wd.pic];
   const int sub = DUAL ? 2 : 1;
   const int ctb = 1 << P.log2_ctb, ctbc = ctb / sub;
@@ -477,17 +481,18 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
   uint32_t* line = (uint32_t*)(A.arena + P.off_line[comp]);
   const uint32_t line_words = P.rec_stride[c_idx] / 4;
   const int16_t* coeff = (const int16_t*)(A.arena + P.off_coeff[comp]);
-  const size_t off_mode = DUAL ? P.off_u_ipmc : P.off_u_ipm, off_size = P.off_u_size, off_flags = P.off_u_flags;
+  const size_t off_mode = chroma ? P.off_u_ipmc : P.off_u_ipm, off_size = P.off_u_size, off_flags = P.off_u_flags;
+  const uint32_t mode_mask = chroma ? 255u : 63u;   // u_ipm carries the chroma transform-skip flags in bits 6 and 7
   int err = 0;
   uint32_t my_row = 0;
   Ctx C;
   C.lane = lane; C.ctbc = ctbc; C.lg_ctbc = P.log2_ctb - (DUAL ? 1 : 0); C.ush = DUAL ? 1 : 2;
-  C.bit_depth = DUAL ? P.bit_depth_chroma : P.bit_depth_luma; C.maxv = (1 << C.bit_depth) - 1;
-  C.luma = !DUAL; C.strong = P.strong_intra_smoothing;
+  C.bit_depth = chroma ? P.bit_depth_chroma : P.bit_depth_luma; C.maxv = (1 << C.bit_depth) - 1;
+  C.luma = !chroma; C.smooth = !DUAL; C.strong = !chroma && P.strong_intra_smoothing;
   const int Wc = DUAL ? P.cwidth : P.width, Hc = DUAL ? P.cheight : P.height;   // component plane size in samples
   const int pic_w = P.width, pic_h = P.height, ctb_w = P.ctb_w, ctb_h = P.ctb_h, log2_ctb = P.log2_ctb;
   const int side = 1 << (log2_ctb - 2);                                         // 4x4-luma units per CTB side
-  const int cbf_bit = DUAL ? (h ? UF_CBF_CR : UF_CBF_CB) : UF_CBF_LUMA;
+  const int cbf_bit = DUAL ? (h ? UF_CBF_CR : UF_CBF_CB) : (plane == 0 ? UF_CBF_LUMA : (plane == 1 ? UF_CBF_CB : UF_CBF_CR));
   // this lane's slices of the shared LDS arrays
   Pix* tile = L.tile + (DUAL ? h << (2 * C.lg_ctbc) : 0);
   Pix* left = L.left + (DUAL ? h * 32 : 0);
@@ -535,7 +540,7 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
         const uint32_t ux = compact1by1((uint32_t)i), uy = compact1by1((uint32_t)i >> 1);   // i is a multiple of 4: units i..i+3 are a 2x2 quad
 #pragma nounroll
         for (int k = 0; k < 4; k++)
-          L.m_unit[i + k] = ((sz >> (8 * k)) & 255u) | (((fl >> (8 * k)) & 255u) << 8) | (((md >> (8 * k)) & (DUAL ? 255u : 63u)) << 16) |
+          L.m_unit[i + k] = ((sz >> (8 * k)) & 255u) | (((fl >> (8 * k)) & 255u) << 8) | (((md >> (8 * k)) & mode_mask) << 16) |
                             ((ux + (k & 1)) << 24) | ((uy + (k >> 1)) << 28);
       }
       // availability rows: the borders come from the neighbouring CTBs (slice / tile / picture limits are in ci.avail,
@@ -613,8 +618,9 @@ __device__ __forceinline__ void recon_wave(const ReconArgs& A)
   if (ticket >= A.num_waves) return;
   if (__hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // failed parse: maps are garbage
   const ReconWave wd = A.waves[ticket];
-  if (wd.comp == 0) recon_rows<Pix, false>(A, wd, L, lane);
-  else if (A.pics[wd.pic].chroma_format_idc) recon_rows<Pix, true>(A, wd, L, lane);   // comp 1 = Cb and Cr together
+  const int cfi = A.pics[wd.pic].chroma_format_idc;
+  if (wd.comp == 0 || cfi == 3) { if (wd.comp == 0 || cfi) recon_rows<Pix, false>(A, wd, L, lane, (int)wd.comp); }   // luma; 4:4:4: one wave per plane
+  else if (cfi) recon_rows<Pix, true>(A, wd, L, lane, 1);                            // 4:2:0: comp 1 = Cb and Cr together
 }
 
 // 8-bit pictures: 7 waves per SIMD (<= 72 VGPRs; 6 KB of LDS per wave allows 26 per CU).  The 16-bit variant is limited by

@@ -31,6 +31,11 @@ __device__ __forceinline__ int chroma_qp_table(int qpi)   // table 8-10 for Chro
                           (6ull << 32) | (6ull << 36) | (7ull << 40) | (7ull << 44) | (8ull << 48) | (8ull << 52);
   return 29 + (int)((kT >> ((qpi - 30) * 4)) & 15u);
 }
+__device__ __forceinline__ int chroma_qp(int qpi, bool c444)   // 8.6.1: QpC from qPi; ChromaArrayType 3 (c444): Min(qPi, 51)
+{
+  if (c444) return qpi < 51 ? qpi : 51;
+  return qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : chroma_qp_table(qpi));
+}
 // Scaling (8.6.3, flat m = 16) in 32 bits: level * 16 * levelScale < 2^27, and with q = qP / 6, b = bdShift
 //   ((p << q) + (1 << (b - 1))) >> b  ==  q < b ? (p + (1 << (b - q - 1))) >> (b - q) : p << (q - b)      (q - b <= 3)
 // `rs` / `ls` are the right / left shift of the block (one of them is 0), `rnd` = rs ? 1 << (rs - 1) : 0.
@@ -63,8 +68,8 @@ struct ResLds {
   alignas(4) int16_t tmp[4][32 * (32 + RPAD)];   // per wave: first-stage output tmp[y][j]
   uint8_t m_size[256], m_flags[256], m_ipm[256];
   int8_t m_qp[256];
-  uint16_t list[448];    // blocks larger than 4x4: z | component << 8 (z = the unit that carries the TU's flags)
-  uint16_t list4[448];   // 4x4 blocks, four of them per wave pass
+  uint16_t list[256];    // blocks larger than 4x4: z | component << 8 (z = the unit that carries the TU's flags); at most 64 per component
+  uint16_t list4[768];   // 4x4 blocks, four of them per wave pass (4:2:0: at most 256 luma + 2 x 64 chroma; 4:4:4: 3 x 256)
   uint32_t count, count4;
 };
 
@@ -187,7 +192,7 @@ __device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, in
 // Four independent 4x4 blocks per wave pass: lane = 16 g + 4 y + x works on sample (y, x) of block g.  entry = z | c << 8.
 // (8.6.2 - 8.6.4 as in residual_block; both 1-D stages are two v_dot2 per output, no nonzero-extent bookkeeping)
 __device__ __forceinline__ void residual_quad(ResLds& L, int bd_luma, int bd_chroma, int cb_qp_offset, int cr_qp_offset, const uint8_t* sl_tab, int wave, int lane, int entry, bool valid,
-                                              int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr)
+                                              int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr, bool c444)
 {
   const int g = lane >> 4, l = lane & 15;
   const int z = entry & 255, c = (entry >> 8) & 3;
@@ -198,11 +203,11 @@ __device__ __forceinline__ void residual_quad(ResLds& L, int bd_luma, int bd_chr
   if (c == 0) {
     coef = coef_y + z * 16; bit_depth = bd_luma; qp = qp_y + 6 * (bd_luma - 8); ts = (fl & UF_TS_LUMA) != 0;
   } else {
-    const int zc = t > 2 ? z : (z & ~3);
+    const int zc = (t > 2 || c444) ? z : (z & ~3);
     const int off_c = 6 * (bd_chroma - 8);
     const int qpi = clip3(-off_c, 57, qp_y + (c == 1 ? cb_qp_offset : cr_qp_offset));
-    const int qpc = qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : chroma_qp_table(qpi));
-    coef = (c == 1 ? coef_cb : coef_cr) + zc * 4; bit_depth = bd_chroma; qp = qpc + off_c; ts = (ipm & (c == 1 ? 64 : 128)) != 0;
+    const int qpc = chroma_qp(qpi, c444);
+    coef = (c == 1 ? coef_cb : coef_cr) + zc * (c444 ? 16 : 4); bit_depth = bd_chroma; qp = qpc + off_c; ts = (ipm & (c == 1 ? 64 : 128)) != 0;
   }
   const bool act = valid && !bypass;      // cu_transquant_bypass: the coefficient levels are the residual
   const int q6 = (qp * 43) >> 8;          // qp / 6 for 0 <= qp < 128
@@ -279,6 +284,7 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
   }
   const uint8_t* sl_tab = P.scaling_lists ? A.arena + P.off_scaling : nullptr;   // ScalingFactor tables of the picture
   const bool use_sl = sl_tab != nullptr;
+  const bool c444 = P.chroma_format_idc == 3;   // chroma blocks have the luma blocks' size and position
   if (tid == 0) { L.count = 0; L.count4 = 0; }
   if (tid < units) {
     L.m_size[tid] = A.arena[P.off_u_size + base + tid];
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
         if (P.chroma_format_idc)
           for (int c = 1; c < 3; c++)
             if (fl & (c == 1 ? UF_CBF_CB : UF_CBF_CR)) {
-              if (t <= 3) L.list4[atomicAdd(&L.count4, 1u)] = (uint16_t)(z | (c << 8));
+              if (t <= (c444 ? 2 : 3)) L.list4[atomicAdd(&L.count4, 1u)] = (uint16_t)(z | (c << 8));
               else L.list[atomicAdd(&L.count, 1u)] = (uint16_t)(z | (c << 8));
             }
       }
@@ -315,14 +321,15 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
   const CtbInfo ci = ((const CtbInfo*)(A.arena + P.off_ctb_info))[ctb_rs];
   const SliceParams sl = ((const SliceParams*)(A.arena + P.off_slices))[ci.slice_idx];
   int16_t* coef_y = (int16_t*)(A.arena + P.off_coeff[0]) + (size_t)ctb_rs * ctb * ctb;
-  int16_t* coef_c[2] = {(int16_t*)(A.arena + P.off_coeff[1]) + (size_t)ctb_rs * (ctb * ctb / 4),
-                        (int16_t*)(A.arena + P.off_coeff[2]) + (size_t)ctb_rs * (ctb * ctb / 4)};
+  const int cc_shift = c444 ? 0 : 2;
+  int16_t* coef_c[2] = {(int16_t*)(A.arena + P.off_coeff[1]) + (size_t)ctb_rs * ((ctb * ctb) >> cc_shift),
+                        (int16_t*)(A.arena + P.off_coeff[2]) + (size_t)ctb_rs * ((ctb * ctb) >> cc_shift)};
   const int bd_luma = P.bit_depth_luma, bd_chroma = P.bit_depth_chroma, cb_off = sl.cb_qp_offset, cr_off = sl.cr_qp_offset;
   // 4x4 blocks, four per wave pass
   for (int q = wave; q * 4 < count4; q += 4) {
     const int idx = q * 4 + (lane >> 4);
     const bool valid = idx < count4;
-    residual_quad(L, bd_luma, bd_chroma, cb_off, cr_off, sl_tab, wave, lane, valid ? (int)L.list4[idx] : 0, valid, coef_y, coef_c[0], coef_c[1]);
+    residual_quad(L, bd_luma, bd_chroma, cb_off, cr_off, sl_tab, wave, lane, valid ? (int)L.list4[idx] : 0, valid, coef_y, coef_c[0], coef_c[1], c444);
   }
   // larger blocks, one per wave pass
   for (int e = wave; e < count; e += 4) {
@@ -336,10 +343,12 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
     else {
       const int off_c = 6 * (bd_chroma - 8);
       const int qpi = clip3(-off_c, 57, qp_y + (c == 1 ? cb_off : cr_off));
-      const int qpc = qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : chroma_qp_table(qpi));
-      if (use_sl) residual_block<true>(L, wave, lane, coef_c[c - 1] + z * 4, t - 1, bd_chroma, qpc + off_c, 0, (ipm & (c == 1 ? 64 : 128)) != 0, 0,
-                                       sl_tab + c * 336 + (t - 1 == 3 ? 16 : 80));
-      else residual_block<false>(L, wave, lane, coef_c[c - 1] + z * 4, t - 1, bd_chroma, qpc + off_c, 0, (ipm & (c == 1 ? 64 : 128)) != 0, 0, nullptr);
+      const int qpc = chroma_qp(qpi, c444);
+      const int tc = c444 ? t : t - 1;    // log2 size of the chroma block (scaling lists do not occur with 4:4:4: refused by the front end)
+      int16_t* cc = coef_c[c - 1] + z * (c444 ? 16 : 4);
+      if (use_sl) residual_block<true>(L, wave, lane, cc, tc, bd_chroma, qpc + off_c, 0, (ipm & (c == 1 ? 64 : 128)) != 0, 0,
+                                       sl_tab + c * 336 + (tc == 3 ? 16 : 80));
+      else residual_block<false>(L, wave, lane, cc, tc, bd_chroma, qpc + off_c, 0, (ipm & (c == 1 ? 64 : 128)) != 0, 0, nullptr);
     }
   }
 }

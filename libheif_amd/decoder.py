@@ -152,7 +152,8 @@ class Batch:
         """deblocked (pre-SAO) picture at coded size — debug tap"""
         d = self.info(i)
         dt = np.uint16 if d["bit_depth_luma"] > 8 else np.uint8
-        w, h = (d["coded_width"], d["coded_height"]) if c == 0 else (d["coded_width"] // 2, d["coded_height"] // 2)
+        sub = 1 if (c == 0 or d["chroma_format_idc"] == 3) else 2
+        w, h = d["coded_width"] // sub, d["coded_height"] // sub
         a = np.empty((h, w), dt)
         check(self._lib.hipdec_batch_read_tap(self._h, i, 1, c, a.ctypes.data, w * a.itemsize))
         return a

@@ -134,16 +134,20 @@ int emu_coeffs(EmuBatch* b, int i, int32_t* y, int32_t* cb, int32_t* cr)
             for (int xx = 0; xx < n; xx++) y[(size_t)(cy * ctb + uy * 4 + yy) * P.width + cx * ctb + ux * 4 + xx] = src[yy * n + xx];
         }
         if (P.chroma_format_idc) {
+          const bool c444 = P.chroma_format_idc == 3;
+          const int csh = c444 ? 0 : 1;
           int do_c = 0, zc = z, tc = t - 1;
-          if (t > 2) do_c = 1; else if ((z & 3) == 3) { do_c = 1; zc = z & ~3; tc = 2; }
+          if (c444) { do_c = 1; tc = t; }
+          else if (t > 2) do_c = 1; else if ((z & 3) == 3) { do_c = 1; zc = z & ~3; tc = 2; }
           if (do_c) {
             const int cux = (int)pcore::compact1by1((uint32_t)zc), cuy = (int)pcore::compact1by1((uint32_t)zc >> 1);
             for (int c = 1; c < 3; c++) {
               if (!(fl & (c == 1 ? UF_CBF_CB : UF_CBF_CR))) continue;
-              const int16_t* src = (const int16_t*)(a + P.off_coeff[c]) + (size_t)ctb_rs * (ctb * ctb / 4) + zc * 4;
+              const int16_t* src = (const int16_t*)(a + P.off_coeff[c]) + (size_t)ctb_rs * ((ctb * ctb) >> (2 * csh)) + zc * (c444 ? 16 : 4);
               const int n = 1 << tc;
               for (int yy = 0; yy < n; yy++)
-                for (int xx = 0; xx < n; xx++) out[c][(size_t)(cy * ctb / 2 + cuy * 2 + yy) * P.cwidth + cx * ctb / 2 + cux * 2 + xx] = src[yy * n + xx];
+                for (int xx = 0; xx < n; xx++)
+                  out[c][(size_t)(((cy * ctb + cuy * 4) >> csh) + yy) * P.cwidth + ((cx * ctb + cux * 4) >> csh) + xx] = src[yy * n + xx];
             }
           }
         }
