@@ -62,14 +62,18 @@ __device__ __forceinline__ int level_scale(int r)         // levelScale[qP % 6] 
 // Transposed, j-contiguous operands so that both 1-D passes are chains of v_dot2_i32_i16 (two MACs per instruction,
 // one 32-bit LDS read per operand pair).  Rows are padded by 2 samples: consecutive lanes then hit distinct banks.
 constexpr int RPAD = 2;
+constexpr int LIST_N = 896;
 struct ResLds {
   alignas(4) int16_t et32[32 * 32], et16[16 * 16], et8[8 * 8], et4[4 * 4], est4[4 * 4];   // E^T[i][j] per size, DST last
   alignas(4) int16_t blk[4][32 * (32 + RPAD)];   // per wave: scaled levels, TRANSPOSED: blk[x][j] = d[j][x]
   alignas(4) int16_t tmp[4][32 * (32 + RPAD)];   // per wave: first-stage output tmp[y][j]
   uint8_t m_size[256], m_flags[256], m_ipm[256];
   int8_t m_qp[256];
-  uint16_t list[256];    // blocks larger than 4x4: z | component << 8 (z = the unit that carries the TU's flags); at most 64 per component
-  uint16_t list4[768];   // 4x4 blocks, four of them per wave pass (4:2:0: at most 256 luma + 2 x 64 chroma; 4:4:4: 3 x 256)
+  // block lists, entry = z | component << 8 (z = the unit that carries the TU's flags), in ONE array: blocks larger than 4x4 fill it from the
+  // front (list[e]), 4x4 blocks — four of them per wave pass — from the back (list4(i) = list[LIST_N - 1 - i]).  An 8x8 luma area brings at
+  // most 3 entries of the first kind or 12 of the second (4:4:4; 4:2:0: 1 + 0 or 4 + 2), so the two never meet: <= 768 entries in all.
+  // (LDS is sized to the byte for 7 workgroups per CU: 160 KB / 7 in 512 B granules)
+  uint16_t list[LIST_N];
   uint32_t count, count4;
 };
 
@@ -304,13 +308,13 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
       const int first = t >= 2 && t <= 5 && (z & ((1 << (2 * (t - 2))) - 1)) == 0;
       if (first && !(fl & UF_BYPASS)) {
         if (fl & UF_CBF_LUMA) {
-          if (t == 2) L.list4[atomicAdd(&L.count4, 1u)] = (uint16_t)z;
+          if (t == 2) L.list[LIST_N - 1 - atomicAdd(&L.count4, 1u)] = (uint16_t)z;
           else L.list[atomicAdd(&L.count, 1u)] = (uint16_t)z;
         }
         if (P.chroma_format_idc)
           for (int c = 1; c < 3; c++)
             if (fl & (c == 1 ? UF_CBF_CB : UF_CBF_CR)) {
-              if (t <= (c444 ? 2 : 3)) L.list4[atomicAdd(&L.count4, 1u)] = (uint16_t)(z | (c << 8));
+              if (t <= (c444 ? 2 : 3)) L.list[LIST_N - 1 - atomicAdd(&L.count4, 1u)] = (uint16_t)(z | (c << 8));
               else L.list[atomicAdd(&L.count, 1u)] = (uint16_t)(z | (c << 8));
             }
       }
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
   for (int q = wave; q * 4 < count4; q += 4) {
     const int idx = q * 4 + (lane >> 4);
     const bool valid = idx < count4;
-    residual_quad(L, bd_luma, bd_chroma, cb_off, cr_off, sl_tab, wave, lane, valid ? (int)L.list4[idx] : 0, valid, coef_y, coef_c[0], coef_c[1], c444);
+    residual_quad(L, bd_luma, bd_chroma, cb_off, cr_off, sl_tab, wave, lane, valid ? (int)L.list[LIST_N - 1 - idx] : 0, valid, coef_y, coef_c[0], coef_c[1], c444);
   }
   // larger blocks, one per wave pass
   for (int e = wave; e < count; e += 4) {
