@@ -302,6 +302,7 @@ struct Dec {
 
   /* picture buffers (coded size) */
   int W, H, Wc, Hc;
+  int subw, subh;   /* SubWidthC, SubHeightC (6.2): 2,2 for 4:2:0; 2,1 for 4:2:2; 1,1 for 4:4:4 (and, unused, 4:0:0) */
   uint16_t* rec[3];
   int32_t* coeff[3];
   int have_picture;
@@ -630,9 +631,8 @@ static void parse_sps(Dec* d, const uint8_t* rbsp, size_t n)
     }
   }
   /* constraints */
-  if (s->chroma_format_idc == 2 || s->chroma_format_idc > 3 || (s->chroma_format_idc == 3 && s->separate_colour_plane_flag))
-    fail(d, "unsupported: chroma_format_idc %d%s (4:0:0, 4:2:0 and 4:4:4 without separate colour planes)", s->chroma_format_idc,
-         s->separate_colour_plane_flag ? " with separate_colour_plane_flag" : "");
+  if (s->chroma_format_idc > 3 || (s->chroma_format_idc == 3 && s->separate_colour_plane_flag))
+    fail(d, "unsupported: chroma_format_idc %d%s", s->chroma_format_idc, s->separate_colour_plane_flag ? " with separate_colour_plane_flag" : "");
   if (s->chroma_format_idc == 3 && s->scaling_list_enabled_flag)
     fail(d, "unsupported: scaling lists with 4:4:4 (the 32x32 chroma matrices of the range extensions)");
   if (s->bit_depth_luma > 16 || s->bit_depth_chroma > 16) fail(d, "bit depth out of range");
@@ -721,8 +721,10 @@ static void setup_picture(Dec* d)
 {
   const SPS* s = d->s; const PPS* p = d->p;
   d->W = s->pic_width; d->H = s->pic_height;
-  d->Wc = s->chroma_format_idc == 3 ? d->W : (s->chroma_format_idc ? d->W / 2 : 0);
-  d->Hc = s->chroma_format_idc == 3 ? d->H : (s->chroma_format_idc ? d->H / 2 : 0);
+  d->subw = (s->chroma_format_idc == 1 || s->chroma_format_idc == 2) ? 2 : 1;
+  d->subh = s->chroma_format_idc == 1 ? 2 : 1;
+  d->Wc = s->chroma_format_idc ? d->W / d->subw : 0;
+  d->Hc = s->chroma_format_idc ? d->H / d->subh : 0;
   for (int c = 0; c < 3; c++) {
     size_t n = c ? (size_t)d->Wc * d->Hc : (size_t)d->W * d->H;
     d->rec[c] = (uint16_t*)xcalloc(d, n, sizeof(uint16_t));
@@ -1044,25 +1046,25 @@ static void intra_predict_block(Dec* d, int x0c, int y0c, int log2n, int cIdx, i
   /* (x0c,y0c) in component samples */
   const SPS* s = d->s;
   int nTbS = 1 << log2n, n2 = 2 * nTbS;
-  int sub = (cIdx && s->chroma_format_idc != 3) ? 2 : 1; /* SubWidthC = SubHeightC: 2 for 4:2:0, 1 for 4:4:4 */
+  int subw = cIdx ? d->subw : 1, subh = cIdx ? d->subh : 1;
   int stride = cIdx ? d->Wc : d->W;
   uint16_t* rec = d->rec[cIdx];
   int bit_depth = cIdx ? s->bit_depth_chroma : s->bit_depth_luma;
-  int xTbY = x0c * sub, yTbY = y0c * sub;
+  int xTbY = x0c * subw, yTbY = y0c * subh;
   uint16_t L[65], T[65];
   uint8_t aL[65], aT[65]; /* availability; index 0 = corner */
   int any = 0;
   for (int i = 0; i <= n2; i++) {
     /* left column: p[-1][i-1] */
     int xN = x0c - 1, yN = y0c + i - 1;
-    int av = available_z(d, xTbY, yTbY, xN * sub, yN * sub);
+    int av = available_z(d, xTbY, yTbY, xN * subw, yN * subh);
     if (av && d->p->constrained_intra_pred_flag) av = 1; /* every CU is intra in this oracle */
     aL[i] = (uint8_t)av;
     if (av) { L[i] = rec[yN * stride + xN]; any = 1; }
     /* top row: p[i-1][-1] */
     xN = x0c + i - 1; yN = y0c - 1;
     if (i == 0) { aT[0] = aL[0]; T[0] = L[0]; continue; }
-    av = available_z(d, xTbY, yTbY, xN * sub, yN * sub);
+    av = available_z(d, xTbY, yTbY, xN * subw, yN * subh);
     aT[i] = (uint8_t)av;
     if (av) { T[i] = rec[yN * stride + xN]; any = 1; }
   }
@@ -1447,14 +1449,72 @@ static void mark_tu(Dec* d, const CuCtx* cu, int x0, int y0, int log2TrafoSize, 
     }
 }
 
+/* 7.3.8.14 cu_qp_delta_abs / cu_qp_delta_sign_flag, once per quantisation group, in the first transform unit with a coded block */
+static void parse_cu_qp_delta_if_needed(Dec* d, int coded)
+{
+  const SPS* s = d->s; const PPS* p = d->p;
+  if (!coded) return;
+  if (p->cu_qp_delta_enabled_flag && !d->IsCuQpDeltaCoded) {
+    /* cu_qp_delta_abs 9.3.3.10: prefix TU cMax 5 (ctx 0, then ctx 1), suffix EG0 */
+    int v = 0;
+    if (decode_decision(d, CTX_CU_QP_DELTA + 0)) {
+      v = 1;
+      while (v < 5 && decode_decision(d, CTX_CU_QP_DELTA + 1)) v++;
+      if (v == 5) {
+        int k = 0;
+        while (decode_bypass(d)) { v += 1 << k; k++; if (k > 16) fail(d, "cu_qp_delta_abs too large"); }
+        while (k--) v += decode_bypass(d) << k;
+      }
+    }
+    int sign = 0;
+    if (v) sign = decode_bypass(d);
+    d->IsCuQpDeltaCoded = 1;
+    d->CuQpDeltaVal = v * (1 - 2 * sign);
+    int QpBdOffsetY = 6 * (s->bit_depth_luma - 8);
+    if (d->CuQpDeltaVal < -(26 + QpBdOffsetY / 2) || d->CuQpDeltaVal > 25 + QpBdOffsetY / 2)
+      fail(d, "CuQpDeltaVal out of range");
+    set_qp_y(d);
+  }
+}
+
+
+/* 7.3.8.10 for ChromaArrayType 2: the chroma of a transform unit is a block half as wide and as tall as the luma block, coded as TWO square
+   blocks one above the other (tIdx 0, 1), each with its own coded-block flag (cbf_cb / cbf_cr: bit tIdx) and transform_skip_flag.
+   Order: luma, Cb 0, Cb 1, Cr 0, Cr 1; reconstruction in the same order (block 1 predicts from block 0). */
+static void transform_unit_422(Dec* d, CuCtx* cu, int x0, int y0, int xBase, int yBase, int log2TrafoSize, int blkIdx, int cbf_luma,
+                               int cbf_cb, int cbf_cr)
+{
+  int32_t cY[32 * 32];
+  int32_t cC[4][16 * 16];   /* Cb 0, Cb 1, Cr 0, Cr 1 */
+  int tsY = 0, tsC[4] = {0, 0, 0, 0};
+  int lumaMode = d->m_ipm[(y0 >> 2) * d->mw + (x0 >> 2)];
+  int chromaMode = cu->chroma_mode;
+  int do_chroma = 0, xC0 = 0, yC0 = 0, log2C = 2;
+  if (log2TrafoSize > 2) { do_chroma = 1; xC0 = x0 / 2; yC0 = y0; log2C = log2TrafoSize - 1; }
+  else if (blkIdx == 3) { do_chroma = 1; xC0 = xBase / 2; yC0 = yBase; log2C = 2; }
+  parse_cu_qp_delta_if_needed(d, cbf_luma || cbf_cb || cbf_cr);
+  if (cbf_luma) residual_coding(d, x0, y0, log2TrafoSize, 0, lumaMode, cY, &tsY);
+  if (do_chroma)
+    for (int c = 0; c < 2; c++)
+      for (int t = 0; t < 2; t++)
+        if (((c ? cbf_cr : cbf_cb) >> t) & 1) residual_coding(d, xC0, yC0 + (t << log2C), log2C, 1 + c, chromaMode, cC[2 * c + t], &tsC[2 * c + t]);
+  reconstruct_tb(d, x0, y0, log2TrafoSize, 0, lumaMode, cbf_luma, cY, tsY);
+  if (do_chroma)
+    for (int c = 0; c < 2; c++)
+      for (int t = 0; t < 2; t++)
+        reconstruct_tb(d, xC0, yC0 + (t << log2C), log2C, 1 + c, chromaMode, ((c ? cbf_cr : cbf_cb) >> t) & 1, cC[2 * c + t], tsC[2 * c + t]);
+  mark_tu(d, cu, x0, y0, log2TrafoSize, cbf_luma, do_chroma ? cbf_cb : 0, do_chroma ? cbf_cr : 0);
+}
+
 static void transform_unit(Dec* d, CuCtx* cu, int x0, int y0, int xBase, int yBase, int log2TrafoSize,
                            int trafoDepth, int blkIdx, int cbf_luma, int cbf_cb, int cbf_cr)
 {
-  const SPS* s = d->s; const PPS* p = d->p;
+  const SPS* s = d->s;
   int ChromaArrayType = s->chroma_format_idc;
-  int cbfChroma = cbf_cb || cbf_cr; /* for log2TrafoSize == 2 these are the parent's flags */
+  int cbfChroma = cbf_cb || cbf_cr; /* for log2TrafoSize == 2 these are the parent's flags; 4:2:2: bit 0 upper block, bit 1 lower block */
   int32_t cY[32 * 32], cCb[32 * 32], cCr[32 * 32];
   int tsY = 0, tsCb = 0, tsCr = 0;
+  if (ChromaArrayType == 2) { transform_unit_422(d, cu, x0, y0, xBase, yBase, log2TrafoSize, blkIdx, cbf_luma, cbf_cb, cbf_cr); return; }
   (void)trafoDepth;
   int lumaMode = d->m_ipm[(y0 >> 2) * d->mw + (x0 >> 2)];
   int chromaMode = cu->chroma_mode;
@@ -1467,29 +1527,7 @@ static void transform_unit(Dec* d, CuCtx* cu, int x0, int y0, int xBase, int yBa
     else if (blkIdx == 3) { do_chroma = 1; xC0 = xBase / 2; yC0 = yBase / 2; log2C = 2; }
   }
   /* 7.3.8.10: cbfChroma uses the parent's chroma cbf for 4x4 luma blocks regardless of blkIdx */
-  if (cbf_luma || cbfChroma) {
-    if (p->cu_qp_delta_enabled_flag && !d->IsCuQpDeltaCoded) {
-      /* cu_qp_delta_abs 9.3.3.10: prefix TU cMax 5 (ctx 0, then ctx 1), suffix EG0 */
-      int v = 0;
-      if (decode_decision(d, CTX_CU_QP_DELTA + 0)) {
-        v = 1;
-        while (v < 5 && decode_decision(d, CTX_CU_QP_DELTA + 1)) v++;
-        if (v == 5) {
-          int k = 0;
-          while (decode_bypass(d)) { v += 1 << k; k++; if (k > 16) fail(d, "cu_qp_delta_abs too large"); }
-          while (k--) v += decode_bypass(d) << k;
-        }
-      }
-      int sign = 0;
-      if (v) sign = decode_bypass(d);
-      d->IsCuQpDeltaCoded = 1;
-      d->CuQpDeltaVal = v * (1 - 2 * sign);
-      int QpBdOffsetY = 6 * (s->bit_depth_luma - 8);
-      if (d->CuQpDeltaVal < -(26 + QpBdOffsetY / 2) || d->CuQpDeltaVal > 25 + QpBdOffsetY / 2)
-        fail(d, "CuQpDeltaVal out of range");
-      set_qp_y(d);
-    }
-  }
+  parse_cu_qp_delta_if_needed(d, cbf_luma || cbfChroma);
   /* parse residuals (all parsing of the TU precedes its reconstruction; the order of
      reconstruction between colour components is irrelevant in v1) */
   if (cbf_luma) residual_coding(d, x0, y0, log2TrafoSize, 0, lumaMode, cY, &tsY);
@@ -1519,8 +1557,11 @@ static void transform_tree(Dec* d, CuCtx* cu, int x0, int y0, int xBase, int yBa
   int cbf_cb = 0, cbf_cr = 0;
   if ((log2TrafoSize > 2 && ChromaArrayType != 0) || ChromaArrayType == 3) {
     int cc = trafoDepth == 4 ? CTX_CBF_CHROMA4 : CTX_CBF_CHROMA + trafoDepth;
-    if (trafoDepth == 0 || parent_cbf_cb) cbf_cb = decode_decision(d, cc);
-    if (trafoDepth == 0 || parent_cbf_cr) cbf_cr = decode_decision(d, cc);
+    /* ChromaArrayType 2: a second flag for the lower chroma block where the chroma is coded (a leaf, or the 8x8 node above four 4x4 leaves);
+       the parent's flag that gates the parsing is the one at (xBase, yBase): its first */
+    int two = ChromaArrayType == 2 && (!split || log2TrafoSize == 3);
+    if (trafoDepth == 0 || (parent_cbf_cb & 1)) { cbf_cb = decode_decision(d, cc); if (two) cbf_cb |= decode_decision(d, cc) << 1; }
+    if (trafoDepth == 0 || (parent_cbf_cr & 1)) { cbf_cr = decode_decision(d, cc); if (two) cbf_cr |= decode_decision(d, cc) << 1; }
   } else if (ChromaArrayType != 0 && trafoDepth > 0 && log2TrafoSize == 2) {
     cbf_cb = parent_cbf_cb; cbf_cr = parent_cbf_cr; /* 7.4.9.8 inference */
   }
@@ -1583,12 +1624,12 @@ static void coding_unit(Dec* d, int x0, int y0, int log2CbSize, int cqtDepth)
     cabac_finish_and_align(d);
     Cabac* c = &d->c;
     for (int cIdx = 0; cIdx < (s->chroma_format_idc ? 3 : 1); cIdx++) {
-      int csub = (cIdx && s->chroma_format_idc != 3) ? 2 : 1;
-      int n = nCbS / csub, xs = x0 / csub, ys = y0 / csub;
+      int csw = cIdx ? d->subw : 1, csh = cIdx ? d->subh : 1;
+      int n = nCbS / csw, nh = nCbS / csh, xs = x0 / csw, ys = y0 / csh;
       int depth = cIdx ? s->pcm_bit_depth_chroma : s->pcm_bit_depth_luma;
       int bd = cIdx ? s->bit_depth_chroma : s->bit_depth_luma;
       int stride = cIdx ? d->Wc : d->W;
-      for (int y = 0; y < n; y++)
+      for (int y = 0; y < nh; y++)
         for (int x = 0; x < n; x++) {
           unsigned v = 0;
           for (int b = 0; b < depth; b++) {
@@ -1671,6 +1712,11 @@ static void coding_unit(Dec* d, int x0, int y0, int log2CbSize, int cqtDepth)
         int xP = x0 + i * cpb, yP = y0 + j * cpb;
         int lm = d->m_ipm[(yP >> 2) * d->mw + (xP >> 2)];
         int m = icpm == 4 ? lm : ((tab[icpm] == lm) ? 34 : tab[icpm]);
+        if (s->chroma_format_idc == 2) {   /* 8.4.3: the 4:2:2 sampling grid is not square, Table 8-3 maps the direction */
+          static const uint8_t map422[35] = {0, 1, 2, 2, 2, 2, 3, 5, 7, 8, 10, 11, 13, 15, 16, 18, 19, 20, 21, 22, 23, 23, 24, 24, 25, 25, 26, 27, 27,
+                                             28, 28, 29, 29, 30, 31};
+          m = map422[m];
+        }
         if (i == 0 && j == 0) chroma_mode = m;
         for (int jj = 0; jj < (cpb >> 2); jj++) for (int ii = 0; ii < (cpb >> 2); ii++)
           d->m_ipmc[((yP >> 2) + jj) * d->mw + (xP >> 2) + ii] = (uint8_t)m;
@@ -2060,8 +2106,15 @@ static void deblock_luma_edge(Dec* d, uint16_t* pix, int xstep, int ystep, int Q
 #undef QQ
 }
 
+static void deblock_chroma_edge_n(Dec* d, uint16_t* pix, int xstep, int ystep, int QpP, int QpQ,
+                                  int cQpPicOffset, const SliceHdr* sh, int noP, int noQ, int nlines);
 static void deblock_chroma_edge(Dec* d, uint16_t* pix, int xstep, int ystep, int QpP, int QpQ,
                                 int cQpPicOffset, const SliceHdr* sh, int noP, int noQ)
+{
+  deblock_chroma_edge_n(d, pix, xstep, ystep, QpP, QpQ, cQpPicOffset, sh, noP, noQ, 4);
+}
+static void deblock_chroma_edge_n(Dec* d, uint16_t* pix, int xstep, int ystep, int QpP, int QpQ,
+                                  int cQpPicOffset, const SliceHdr* sh, int noP, int noQ, int nlines)
 {
   int bitDepth = d->s->bit_depth_chroma;
   int qPi = ((QpQ + QpP + 1) >> 1) + cQpPicOffset;
@@ -2069,7 +2122,7 @@ static void deblock_chroma_edge(Dec* d, uint16_t* pix, int xstep, int ystep, int
   int Q = Clip3(0, 53, QpC + 2 * (2 - 1) + (sh->slice_tc_offset_div2 << 1));
   int tC = tcTable[Q] * (1 << (bitDepth - 8));
   int maxv = (1 << bitDepth) - 1;
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < nlines; k++) {
     uint16_t* l = pix + k * ystep;
     int p0 = l[-xstep], p1 = l[-2 * xstep], q0 = l[0], q1 = l[xstep];
     int delta = Clip3(-tC, tC, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
@@ -2110,6 +2163,14 @@ static void deblock_picture(Dec* d)
             deblock_chroma_edge(d, d->rec[c] + y * d->Wc + x, dir == 0 ? 1 : d->Wc, dir == 0 ? d->Wc : 1, QpP, QpQ,
                                 c == 1 ? p->pps_cb_qp_offset : p->pps_cr_qp_offset, sh, noP, noQ);
         }
+        if (s->chroma_format_idc == 2) {
+          /* 4:2:2: the 8x8 chroma sample grid is 16 luma samples wide and 8 tall.  A vertical edge segment of 4 luma rows is 4 chroma rows; a
+             horizontal one of 4 luma columns is 2 chroma columns */
+          if (dir == 0 ? (x & 15) == 0 : 1)
+            for (int c = 1; c < 3; c++)
+              deblock_chroma_edge_n(d, d->rec[c] + y * d->Wc + x / 2, dir == 0 ? 1 : d->Wc, dir == 0 ? d->Wc : 1, QpP, QpQ,
+                                    c == 1 ? p->pps_cb_qp_offset : p->pps_cr_qp_offset, sh, noP, noQ, dir == 0 ? 4 : 2);
+        }
         if (s->chroma_format_idc == 1) {
           /* chroma edges lie on the 8x8 chroma sample grid; a 4-row chroma segment corresponds to
              8 luma rows and takes its bS from the first 4-luma-row segment (8.7.2.5.?) */
@@ -2137,10 +2198,10 @@ static void sao_picture(Dec* d, uint16_t* const src[3], uint16_t* dst[3])
   const SPS* s = d->s; const PPS* p = d->p;
   int lm = s->log2_min_tb;
   for (int cIdx = 0; cIdx < (s->chroma_format_idc ? 3 : 1); cIdx++) {
-    int W = cIdx ? d->Wc : d->W, H = cIdx ? d->Hc : d->H, sub = (cIdx && s->chroma_format_idc != 3) ? 2 : 1;
+    int W = cIdx ? d->Wc : d->W, H = cIdx ? d->Hc : d->H, sub = cIdx ? d->subw : 1, subv = cIdx ? d->subh : 1;
     int bitDepth = cIdx ? s->bit_depth_chroma : s->bit_depth_luma;
     int maxv = (1 << bitDepth) - 1;
-    int ctbSize = (1 << s->log2_ctb) / sub;
+    int ctbSize = (1 << s->log2_ctb) / sub, ctbSizeV = (1 << s->log2_ctb) / subv;
     memcpy(dst[cIdx], src[cIdx], sizeof(uint16_t) * W * H);
     for (int ry = 0; ry < d->ctbH; ry++)
       for (int rx = 0; rx < d->ctbW; rx++) {
@@ -2150,9 +2211,9 @@ static void sao_picture(Dec* d, uint16_t* const src[3], uint16_t* dst[3])
         const int16_t* off = &d->sao_off[(ctb * 3 + cIdx) * 4];
         int bc = d->sao_bc[ctb * 3 + cIdx];
         const SliceHdr* shC = &d->slices[d->ctb_slice_idx[ctb]];
-        for (int y = ry * ctbSize; y < Min((ry + 1) * ctbSize, H); y++)
+        for (int y = ry * ctbSizeV; y < Min((ry + 1) * ctbSizeV, H); y++)
           for (int x = rx * ctbSize; x < Min((rx + 1) * ctbSize, W); x++) {
-            int uidx = ((y * sub) >> 2) * d->mw + ((x * sub) >> 2);
+            int uidx = ((y * subv) >> 2) * d->mw + ((x * sub) >> 2);
             if (unit_no_filter(d, uidx)) continue;
             int v = src[cIdx][y * W + x];
             if (type == 1) {
@@ -2166,11 +2227,11 @@ static void sao_picture(Dec* d, uint16_t* const src[3], uint16_t* dst[3])
               for (int k = 0; k < 2; k++) {
                 int xs = x + hPos[bc][k], ys = y + vPos[bc][k];
                 if (xs < 0 || ys < 0 || xs >= W || ys >= H) { skip = 1; break; }
-                int ctbN = ((ys * sub) >> s->log2_ctb) * d->ctbW + ((xs * sub) >> s->log2_ctb);
+                int ctbN = ((ys * subv) >> s->log2_ctb) * d->ctbW + ((xs * sub) >> s->log2_ctb);
                 if (ctbN != ctb) {
                   if (d->ctb_slice_addr[ctbN] != d->ctb_slice_addr[ctb]) {
-                    int zN = d->MinTbAddrZs[((ys * sub) >> lm) * d->minTbW + ((xs * sub) >> lm)];
-                    int zC = d->MinTbAddrZs[((y * sub) >> lm) * d->minTbW + ((x * sub) >> lm)];
+                    int zN = d->MinTbAddrZs[((ys * subv) >> lm) * d->minTbW + ((xs * sub) >> lm)];
+                    int zC = d->MinTbAddrZs[((y * subv) >> lm) * d->minTbW + ((x * sub) >> lm)];
                     const SliceHdr* shN = &d->slices[d->ctb_slice_idx[ctbN]];
                     if (zN < zC && !shC->slice_loop_filter_across_slices_enabled_flag) { skip = 1; break; }
                     if (zC < zN && !shN->slice_loop_filter_across_slices_enabled_flag) { skip = 1; break; }
@@ -2266,7 +2327,7 @@ int hevc_oracle_decode(const uint8_t* data, size_t size, int keep_taps, hevc_ora
   for (int c = 0; c < nc; c++) fin[c] = (uint16_t*)xcalloc(d, c ? (size_t)d->Wc * d->Hc : (size_t)d->W * d->H, sizeof(uint16_t));
   sao_picture(d, d->rec, fin);
   /* conformance window crop (7.4.3.2.1; hevc_boxes.cc:688-716) */
-  int sw = s->chroma_format_idc == 1 ? 2 : 1, shh = s->chroma_format_idc == 1 ? 2 : 1;
+  int sw = s->chroma_format_idc ? d->subw : 1, shh = s->chroma_format_idc ? d->subh : 1;
   int x0 = sw * s->conf_win_left, x1 = d->W - sw * s->conf_win_right;
   int y0 = shh * s->conf_win_top, y1 = d->H - shh * s->conf_win_bottom;
   if (x1 <= x0 || y1 <= y0) fail(d, "empty conformance window");

@@ -533,6 +533,73 @@ static ChromaCbf enc_transform_tree(Enc* e, CuCtx* cu, int x0, int y0, int xBase
   int32_t levCb[16 * 16], levCr[16 * 16];
   int tsCb = 0, tsCr = 0;
   int chroma_here_early = 0;
+  if (ChromaArrayType == 2) {
+    /* 4:2:2: the chroma of a transform unit is two square blocks one above the other (k = 2 c + t: Cb 0, Cb 1, Cr 0, Cr 1), each with its own
+       coded-block flag where the chroma is coded: at a leaf, or at the 8x8 node above four 4x4 luma leaves */
+    int two = !split || log2TrafoSize == 3;
+    int sl[4] = {-1, -1, -1, -1};
+    if (log2TrafoSize > 2)
+      for (int c = 0; c < 2; c++)
+        for (int t = 0; t < (two ? 2 : 1); t++)
+          sl[2 * c + t] = ev_add(e, EV_DECISION, CTX_CBF_CHROMA + trafoDepth, 0, 0, trafoDepth == 0 ? -1 : (c ? slot_cr : slot_cb));
+    int x1 = x0 + (1 << (log2TrafoSize - 1)), y1 = y0 + (1 << (log2TrafoSize - 1));
+    if (split && log2TrafoSize > 3) {
+      for (int k = 0; k < 4; k++) {
+        ChromaCbf c = enc_transform_tree(e, cu, (k & 1) ? x1 : x0, (k & 2) ? y1 : y0, x0, y0, log2TrafoSize - 1, trafoDepth + 1, k, sl[0], sl[2], 0, 0);
+        out.cbf_cb |= c.cbf_cb; out.cbf_cr |= c.cbf_cr;
+      }
+      e->ev[sl[0]].val = out.cbf_cb; e->ev[sl[2]].val = out.cbf_cr;
+      return out;
+    }
+    /* chroma blocks of this node: 4x4 pairs under an 8x8 split node, else blocks of half the luma size */
+    int log2C = split ? 2 : log2TrafoSize - 1, nC = 1 << log2C;
+    int32_t (*lv)[16 * 16] = (int32_t (*)[16 * 16])malloc(sizeof(int32_t) * 4 * 16 * 16);
+    int32_t* lY = (int32_t*)malloc(sizeof(int32_t) * 32 * 32);
+    int ts4[4] = {0, 0, 0, 0}, cbf4[4] = {0, 0, 0, 0};
+    int pending = d->p->cu_qp_delta_enabled_flag && !d->IsCuQpDeltaCoded;
+    int saved_delta = d->CuQpDeltaVal, saved_qp = d->cur_qp_y;
+    if (split) {   /* log2TrafoSize == 3: chroma first (its flags are coded here), then the four luma leaves; child 3 carries the chroma residuals */
+      if (pending) { d->CuQpDeltaVal = e->qg_delta; set_qp_y(d); }
+      for (int k = 0; k < 4; k++) cbf4[k] = analyse_tb(e, x0 / 2, y0 + (k & 1) * nC, log2C, 1 + (k >> 1), cu->chroma_mode, lv[k], &ts4[k]);
+      if (pending) { d->CuQpDeltaVal = saved_delta; d->cur_qp_y = saved_qp; }
+      for (int k = 0; k < 4; k++) e->ev[sl[k]].val = cbf4[k];
+      int anyC = cbf4[0] | cbf4[1] | cbf4[2] | cbf4[3];
+      for (int k = 0; k < 4; k++) {
+        int xx = (k & 1) ? x1 : x0, yy = (k & 2) ? y1 : y0, tsY;
+        int mode = d->m_ipm[(yy >> 2) * d->mw + (xx >> 2)];
+        int pend = d->p->cu_qp_delta_enabled_flag && !d->IsCuQpDeltaCoded;
+        int sv_delta = d->CuQpDeltaVal, sv_qp = d->cur_qp_y;
+        if (pend) { d->CuQpDeltaVal = e->qg_delta; set_qp_y(d); }
+        int cbfY = analyse_tb(e, xx, yy, 2, 0, mode, lY, &tsY);
+        if (pend) { d->CuQpDeltaVal = sv_delta; d->cur_qp_y = sv_qp; }
+        EV_D(CTX_CBF_LUMA + 0, cbfY);
+        if (cbfY || anyC) enc_cu_qp_delta(e);
+        if (cbfY) emit_residual(e, lY, 2, 0, mode, tsY);
+        if (k == 3)
+          for (int q = 0; q < 4; q++) if (cbf4[q]) emit_residual(e, lv[q], 2, 1 + (q >> 1), cu->chroma_mode, ts4[q]);
+        mark_tu(d, cu, xx, yy, 2, cbfY, k == 3 ? (cbf4[0] | cbf4[1]) : 0, k == 3 ? (cbf4[2] | cbf4[3]) : 0);
+      }
+      out.cbf_cb = cbf4[0] | cbf4[1]; out.cbf_cr = cbf4[2] | cbf4[3];
+      free(lv); free(lY);
+      return out;
+    }
+    /* leaf with log2TrafoSize >= 3 */
+    int tsY = 0;
+    int mode = d->m_ipm[(y0 >> 2) * d->mw + (x0 >> 2)];
+    if (pending) { d->CuQpDeltaVal = e->qg_delta; set_qp_y(d); }
+    int cbfY = analyse_tb(e, x0, y0, log2TrafoSize, 0, mode, lY, &tsY);
+    for (int k = 0; k < 4; k++) cbf4[k] = analyse_tb(e, x0 / 2, y0 + (k & 1) * nC, log2C, 1 + (k >> 1), cu->chroma_mode, lv[k], &ts4[k]);
+    if (pending) { d->CuQpDeltaVal = saved_delta; d->cur_qp_y = saved_qp; }
+    for (int k = 0; k < 4; k++) e->ev[sl[k]].val = cbf4[k];
+    EV_D(CTX_CBF_LUMA + (trafoDepth == 0 ? 1 : 0), cbfY);
+    if (cbfY || cbf4[0] || cbf4[1] || cbf4[2] || cbf4[3]) enc_cu_qp_delta(e);
+    if (cbfY) emit_residual(e, lY, log2TrafoSize, 0, mode, tsY);
+    for (int q = 0; q < 4; q++) if (cbf4[q]) emit_residual(e, lv[q], log2C, 1 + (q >> 1), cu->chroma_mode, ts4[q]);
+    mark_tu(d, cu, x0, y0, log2TrafoSize, cbfY, cbf4[0] | cbf4[1], cbf4[2] | cbf4[3]);
+    out.cbf_cb = cbf4[0] | cbf4[1]; out.cbf_cr = cbf4[2] | cbf4[3];
+    free(lv); free(lY);
+    return out;
+  }
   if (ChromaArrayType == 3) {
     /* 4:4:4: every node carries its chroma cbfs and every leaf its own chroma blocks, the size of the luma block */
     int cc = trafoDepth == 4 ? CTX_CBF_CHROMA4 : CTX_CBF_CHROMA + trafoDepth;
@@ -712,12 +779,12 @@ static void enc_coding_unit(Enc* e, int x0, int y0, int log2CbSize, int cqtDepth
   if (pcm_flag) {
     size_t start = e->pcm_bits;
     for (int cIdx = 0; cIdx < (s->chroma_format_idc ? 3 : 1); cIdx++) {
-      int csub = (cIdx && s->chroma_format_idc != 3) ? 2 : 1;
-      int n = nCbS / csub, xs = x0 / csub, ys = y0 / csub;
+      int csw = cIdx ? d->subw : 1, csh = cIdx ? d->subh : 1;
+      int n = nCbS / csw, nh = nCbS / csh, xs = x0 / csw, ys = y0 / csh;
       int depth = cIdx ? s->pcm_bit_depth_chroma : s->pcm_bit_depth_luma;
       int bd = cIdx ? s->bit_depth_chroma : s->bit_depth_luma;
       int stride = cIdx ? d->Wc : d->W;
-      for (int y = 0; y < n; y++)
+      for (int y = 0; y < nh; y++)
         for (int x = 0; x < n; x++) {
           unsigned v = e->src[cIdx][(ys + y) * stride + xs + x] >> (bd - depth);
           d->rec[cIdx][(ys + y) * stride + xs + x] = (uint16_t)(v << (bd - depth));
@@ -801,6 +868,11 @@ static void enc_coding_unit(Enc* e, int x0, int y0, int log2CbSize, int cqtDepth
         int lm = d->m_ipm[(yP >> 2) * d->mw + (xP >> 2)];
         static const uint8_t tab[4] = {0, 26, 10, 1};
         int m = icpm == 4 ? lm : ((tab[icpm] == lm) ? 34 : tab[icpm]);
+        if (s->chroma_format_idc == 2) {   /* Table 8-3 */
+          static const uint8_t map422[35] = {0, 1, 2, 2, 2, 2, 3, 5, 7, 8, 10, 11, 13, 15, 16, 18, 19, 20, 21, 22, 23, 23, 24, 24, 25, 25, 26, 27, 27,
+                                             28, 28, 29, 29, 30, 31};
+          m = map422[m];
+        }
         if (i == 0 && j == 0) chroma_mode = m;
         for (int jj = 0; jj < (cpb >> 2); jj++) for (int ii = 0; ii < (cpb >> 2); ii++)
           d->m_ipmc[((yP >> 2) + jj) * d->mw + (xP >> 2) + ii] = (uint8_t)m;
@@ -944,7 +1016,7 @@ static void put_nal(Bytes* out, int nal_type, const uint8_t* rbsp, size_t n)
 
 static void write_ptl(BW* w, int bit_depth, int chroma)
 {
-  int idc = (chroma == 0 || chroma == 3) ? 4 : bit_depth > 8 ? 2 : 1;   /* 4:0:0 and 4:4:4 are format-range-extension profiles */
+  int idc = chroma != 1 ? 4 : bit_depth > 8 ? 2 : 1;   /* 4:0:0, 4:2:2 and 4:4:4 are format-range-extension profiles */
   bw_u(w, 0, 2); bw_u(w, 0, 1); bw_u(w, idc, 5);
   for (int i = 0; i < 32; i++) bw_put(w, i == idc || (idc == 1 && i == 2));
   bw_u(w, 1, 1); bw_u(w, 0, 1); bw_u(w, 0, 1); bw_u(w, 1, 1);
@@ -979,10 +1051,10 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
   s->chroma_format_idc = prm->chroma_format_idc;
   s->pic_width = (prm->width + minCb - 1) / minCb * minCb;
   s->pic_height = (prm->height + minCb - 1) / minCb * minCb;
-  int subc = prm->chroma_format_idc == 1 ? 2 : 1;
-  if ((s->pic_width - prm->width) % subc || (s->pic_height - prm->height) % subc) fail(d, "odd picture size needs 4:0:0");
-  s->conf_win_right = (s->pic_width - prm->width) / subc;
-  s->conf_win_bottom = (s->pic_height - prm->height) / subc;
+  int subcw = (prm->chroma_format_idc == 1 || prm->chroma_format_idc == 2) ? 2 : 1, subch = prm->chroma_format_idc == 1 ? 2 : 1;
+  if ((s->pic_width - prm->width) % subcw || (s->pic_height - prm->height) % subch) fail(d, "odd picture size needs 4:0:0 or 4:4:4");
+  s->conf_win_right = (s->pic_width - prm->width) / subcw;
+  s->conf_win_bottom = (s->pic_height - prm->height) / subch;
   s->bit_depth_luma = s->bit_depth_chroma = prm->bit_depth;
   s->log2_max_poc_lsb = 8;
   s->log2_min_cb = prm->log2_min_cb; s->log2_ctb = prm->log2_ctb;
@@ -991,7 +1063,7 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
   s->max_transform_hierarchy_depth_intra = prm->max_transform_hierarchy_depth_intra;
   s->scaling_list_enabled_flag = prm->scaling_list ? 1 : 0;
   if (prm->scaling_list && prm->chroma_format_idc == 3) fail(d, "scaling lists with 4:4:4 are not supported");
-  if (prm->chroma_format_idc == 2 || prm->chroma_format_idc > 3) fail(d, "chroma_format_idc must be 0, 1 or 3");
+  if (prm->chroma_format_idc < 0 || prm->chroma_format_idc > 3) fail(d, "chroma_format_idc must be 0 .. 3");
   scaling_list_default(&s->sl); scaling_list_default(&p->sl);
   s->amp_enabled_flag = 0; s->sao_enabled_flag = prm->sao;
   s->pcm_enabled_flag = prm->pcm_pct > 0;
@@ -1111,8 +1183,8 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
   setup_picture(d);
   for (int c = 0; c < (s->chroma_format_idc ? 3 : 1); c++) {
     int W = c ? d->Wc : d->W, H = c ? d->Hc : d->H;
-    int csub = (c && s->chroma_format_idc != 3) ? 2 : 1;
-    int sw = (prm->width + csub - 1) / csub, sh_ = (prm->height + csub - 1) / csub;
+    int csw = c ? d->subw : 1, csh = c ? d->subh : 1;
+    int sw = (prm->width + csw - 1) / csw, sh_ = (prm->height + csh - 1) / csh;
     src[c] = (uint16_t*)xcalloc(d, (size_t)W * H, sizeof(uint16_t));
     for (int y = 0; y < H; y++)
       for (int x = 0; x < W; x++) src[c][y * W + x] = planes[c][(size_t)Min(y, sh_ - 1) * sw + Min(x, sw - 1)];

@@ -9,7 +9,7 @@ extern "C" {
 typedef struct hevc_testenc_params {
   int width, height;            /* display size; coded size is rounded up to the min CB size      */
   int bit_depth;                /* 8..12 (luma == chroma)                                          */
-  int chroma_format_idc;        /* 0, 1 or 3 (4:0:0, 4:2:0, 4:4:4)                                 */
+  int chroma_format_idc;        /* 0 .. 3 (4:0:0, 4:2:0, 4:2:2, 4:4:4)                             */
   int log2_ctb, log2_min_cb, log2_min_tb, log2_max_tb;
   int max_transform_hierarchy_depth_intra;
   int qp;

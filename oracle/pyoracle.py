@@ -244,7 +244,8 @@ def synth_image(width, height, bit_depth=8, chroma_format_idc=1, seed=1):
 
     planes = [plane(width, height, 1.0)]
     if chroma_format_idc:
-        cw, ch = (width, height) if chroma_format_idc == 3 else ((width + 1) // 2, (height + 1) // 2)
+        cw = width if chroma_format_idc == 3 else (width + 1) // 2
+        ch = (height + 1) // 2 if chroma_format_idc == 1 else height
         planes += [plane(cw, ch, 0.5), plane(cw, ch, 0.5)]
     return planes
 
@@ -256,7 +257,11 @@ def encode(planes, **kw):
     h, w = planes[0].shape
     prm.setdefault("width", w)
     prm.setdefault("height", h)
-    prm["chroma_format_idc"] = (3 if planes[1].shape == planes[0].shape and h > 1 else 1) if len(planes) == 3 else 0
+    if len(planes) == 3:   # the chroma format follows from the plane shapes (a one-row picture is 4:2:0 unless the widths say otherwise)
+        ch, cw = planes[1].shape
+        prm["chroma_format_idc"] = 3 if (cw == w and w > 1) else (2 if (ch == h and h > 1) else 1)
+    else:
+        prm["chroma_format_idc"] = 0
     st = _EncParams()
     for k, v in prm.items():
         setattr(st, k, int(v))
