@@ -136,11 +136,10 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
     PicParams& P = b.params[i];
     P.width = S.pic_width; P.height = S.pic_height;
     P.chroma_format_idc = S.chroma_format_idc;
-    const int csh = S.chroma_format_idc == 3 ? 0 : 1;   // log2 SubWidthC = log2 SubHeightC
-    P.cwidth = S.chroma_format_idc ? S.pic_width >> csh : 0; P.cheight = S.chroma_format_idc ? S.pic_height >> csh : 0;
+    const int csw = (S.chroma_format_idc == 1 || S.chroma_format_idc == 2) ? 1 : 0, csh = S.chroma_format_idc == 1 ? 1 : 0;   // log2 SubWidthC, log2 SubHeightC (6.2)
+    P.cwidth = S.chroma_format_idc ? S.pic_width >> csw : 0; P.cheight = S.chroma_format_idc ? S.pic_height >> csh : 0;
     P.out_width = pp.info.width; P.out_height = pp.info.height; P.out_cwidth = pp.info.chroma_width; P.out_cheight = pp.info.chroma_height;
-    const int subc = S.chroma_format_idc == 1 ? 2 : 1;
-    P.crop_x = subc * S.conf_left; P.crop_y = subc * S.conf_top;
+    P.crop_x = S.conf_left << csw; P.crop_y = S.conf_top << csh;
     P.bit_depth_luma = S.bit_depth_luma; P.bit_depth_chroma = S.bit_depth_chroma;
     P.log2_ctb = S.log2_ctb; P.log2_min_cb = S.log2_min_cb; P.log2_min_tb = S.log2_min_tb; P.log2_max_tb = S.log2_max_tb;
     P.max_th_depth_intra = S.max_th_depth_intra;
@@ -210,12 +209,12 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
     P.off_u_ipmc = off; off = align_up(off + nunits, 256);
     P.off_u_qp = off; off = align_up(off + nunits, 256);
     P.off_coeff[0] = off; off = align_up(off + nctb * ctb2 * 2, 256);
-    const int csh = P.chroma_format_idc == 3 ? 0 : 1;
-    P.off_coeff[1] = off; off = align_up(off + ((nctb * ctb2 * 2) >> (2 * csh)), 256);
-    P.off_coeff[2] = off; off = align_up(off + ((nctb * ctb2 * 2) >> (2 * csh)), 256);
+    const int csw = P.chroma_format_idc == 3 ? 0 : 1, csh = (P.chroma_format_idc == 3 || P.chroma_format_idc == 2) ? 0 : 1;   // log2 chroma subsampling (4:0:0: sized like 4:2:0, never touched)
+    P.off_coeff[1] = off; off = align_up(off + ((nctb * ctb2 * 2) >> (csw + csh)), 256);
+    P.off_coeff[2] = off; off = align_up(off + ((nctb * ctb2 * 2) >> (csw + csh)), 256);
     const int ctb = 1 << P.log2_ctb;
     for (int c = 0; c < 3; c++) {
-      const size_t w = c ? ((size_t)P.ctb_w * ctb) >> csh : (size_t)P.ctb_w * ctb, h = c ? ((size_t)P.ctb_h * ctb) >> csh : (size_t)P.ctb_h * ctb;
+      const size_t w = c ? ((size_t)P.ctb_w * ctb) >> csw : (size_t)P.ctb_w * ctb, h = c ? ((size_t)P.ctb_h * ctb) >> csh : (size_t)P.ctb_h * ctb;
       P.rec_stride[c] = (uint32_t)align_up(w * es, 64);
       P.off_rec[c] = off; off = align_up(off + (size_t)P.rec_stride[c] * (h + 1), 256);
       P.off_line[c] = off; off = align_up(off + (size_t)P.rec_stride[c] * (size_t)P.ctb_h + 256, 256);

@@ -1423,7 +1423,7 @@ int hipdec_grid_create(hipdec_grid** out, int rows, int cols, int out_width, int
           return set_error(HIPDEC_ERR_BITSTREAM, "grid_create: tiles differ in size, bit depth or chroma format");
     if (out_width > cols * g->tile_w || out_height > rows * g->tile_h)
       return set_error(HIPDEC_ERR_BITSTREAM, "grid_create: the output size exceeds the tiled area");
-    if (g->info.chroma_format_idc == 3) return set_error(HIPDEC_ERR_UNSUPPORTED, "grid_create: the device canvas takes 4:2:0 and 4:0:0 tiles (decode 4:4:4 tiles one by one)");
+    if (g->info.chroma_format_idc >= 2) return set_error(HIPDEC_ERR_UNSUPPORTED, "grid_create: the device canvas takes 4:2:0 and 4:0:0 tiles (decode 4:2:2 / 4:4:4 tiles one by one)");
     if (g->info.chroma_format_idc && ((g->tile_w | g->tile_h) & 1)) return set_error(HIPDEC_ERR_UNSUPPORTED, "grid_create: 4:2:0 tiles with odd dimensions");
     {
       DeviceScope scope(g->root);

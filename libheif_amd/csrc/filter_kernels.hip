@@ -101,7 +101,7 @@ __device__ __forceinline__ void deblock_luma(Pix* pix, int xs, int ys, int qp_p,
 
 template <typename Pix>
 __device__ __forceinline__ void deblock_chroma(Pix* pix, int xs, int ys, int qp_p, int qp_q, int c_qp_pic_offset, int tc_off2, int bit_depth,
-                                               int no_p, int no_q, bool c444 = false)
+                                               int no_p, int no_q, bool c444 = false, int nlines = 4)
 {
   const int qpi = ((qp_q + qp_p + 1) >> 1) + c_qp_pic_offset;
   // 8.7.2.5.5: QpC "as specified in table 8-10" for ChromaArrayType 1, Min(qPi, 51) otherwise
@@ -110,6 +110,7 @@ __device__ __forceinline__ void deblock_chroma(Pix* pix, int xs, int ys, int qp_
   const int maxv = (1 << bit_depth) - 1;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
+    if (k >= nlines) break;
     Pix* l = pix + k * ys;
     const int p0 = l[-xs], p1 = l[-2 * xs], q0 = l[0], q1 = l[xs];
     const int delta = clip3(-tc, tc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
@@ -170,6 +171,20 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
       else deblock_chroma<Pix>(pix, stride, 1, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q, true);
     }
   }
+  if (P.chroma_format_idc == 2) {
+    // 4:2:2: the 8x8 chroma grid is 16 luma samples wide and 8 tall; the 4 luma rows of a vertical edge segment are 4 chroma rows, the 4 luma columns
+    // of a horizontal one 2 chroma columns.  QpC = Min(qPi, 51) like 4:4:4
+    if (DIR == 1 || (x & 15) == 0) {
+      for (int c = 1; c < 3; c++) {
+        Pix* rec = (Pix*)(A.arena + P.off_rec[c]);
+        const int stride = P.rec_stride[c] / sizeof(Pix);
+        Pix* pix = rec + (size_t)y * stride + (x >> 1);
+        const int off = c == 1 ? sl.pps_cb_qp_offset : sl.pps_cr_qp_offset;
+        if (DIR == 0) deblock_chroma<Pix>(pix, 1, stride, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q, true, 4);
+        else deblock_chroma<Pix>(pix, stride, 1, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q, true, 2);
+      }
+    }
+  }
   if (P.chroma_format_idc == 1) {
     // chroma edges on the 8x8 chroma grid; one 4-sample chroma segment spans 8 luma samples along the edge
     const int on_grid = DIR == 0 ? ((x & 15) == 0 && (y & 7) == 0) : ((y & 15) == 0 && (x & 7) == 0);
@@ -207,7 +222,7 @@ constexpr int SAO_TW = 128, SAO_TH = 32, SAO_RPT = SAO_TH / 8;   // rows per thr
 template <typename Pix>
 struct SaoComp {
   const PicParams* P;
-  int c, sub, ow, oh, W, H, bit_depth, maxv, rs_bytes, os, lctb, crop_xc, crop_yc, ctb_w;
+  int c, sub, suby, ow, oh, W, H, bit_depth, maxv, rs_bytes, os, lctb, lctby, crop_xc, crop_yc, ctb_w;   // sub / lctb: horizontal, suby / lctby: vertical
   const uint8_t* rec;
   Pix* out;
   const uint8_t* u_flags;
@@ -220,7 +235,7 @@ template <typename Pix>
 __device__ __forceinline__ SaoComp<Pix> sao_comp(const FilterArgs& A, const PicParams& P, int c, bool may_keep, bool restricted)
 {
   SaoComp<Pix> S;
-  S.P = &P; S.c = c; S.sub = (c && P.chroma_format_idc != 3) ? 2 : 1;
+  S.P = &P; S.c = c; S.sub = (c && P.chroma_format_idc != 3) ? 2 : 1; S.suby = (c && P.chroma_format_idc == 1) ? 2 : 1;
   S.ow = c ? P.out_cwidth : P.out_width; S.oh = c ? P.out_cheight : P.out_height;
   S.W = c ? P.cwidth : P.width; S.H = c ? P.cheight : P.height;
   S.bit_depth = c ? P.bit_depth_chroma : P.bit_depth_luma; S.maxv = (1 << S.bit_depth) - 1;
@@ -230,8 +245,8 @@ __device__ __forceinline__ SaoComp<Pix> sao_comp(const FilterArgs& A, const PicP
   S.sao = (const SaoParams*)(A.arena + P.off_sao);
   S.ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
   S.slices = (const SliceParams*)(A.arena + P.off_slices);
-  S.lctb = P.log2_ctb - (S.sub == 2 ? 1 : 0);   // log2 CTB size in component samples
-  S.crop_xc = P.crop_x / S.sub; S.crop_yc = P.crop_y / S.sub; S.ctb_w = P.ctb_w;
+  S.lctb = P.log2_ctb - (S.sub == 2 ? 1 : 0); S.lctby = P.log2_ctb - (S.suby == 2 ? 1 : 0);   // log2 CTB width / height in component samples
+  S.crop_xc = P.crop_x / S.sub; S.crop_yc = P.crop_y / S.suby; S.ctb_w = P.ctb_w;
   // may_keep: compile-time false in the kernel variant for batches without lossless CUs / unfiltered PCM (the common case): the per-sample
   // unit look-ups and the paths behind them leave the kernel, which is larger than the instruction cache
   S.check_bypass = may_keep && (P.transquant_bypass_enabled != 0 || (P.pcm_enabled && P.pcm_loop_filter_disabled));
@@ -247,7 +262,7 @@ __device__ __forceinline__ void sao_params_at(const SaoComp<Pix>& S, int ox, int
 {
   int y = oy + S.crop_yc, x = ox + S.crop_xc;
   y = y < S.H ? y : S.H - 1; x = x < S.W ? x : S.W - 1;
-  const uint32_t* src = (const uint32_t*)&S.sao[(size_t)((y >> S.lctb) * S.ctb_w + (x >> S.lctb)) * 3 + S.c];
+  const uint32_t* src = (const uint32_t*)&S.sao[(size_t)((y >> S.lctby) * S.ctb_w + (x >> S.lctb)) * 3 + S.c];
   spw[0] = src[0]; spw[1] = src[1]; spw[2] = src[2];
 }
 // stages source rows ys0-1 .. ys0+TH, bytes [ab, ...) of each row, into tile[TH + 2][ROW_WORDS]; returns ab.  All threads of the workgroup
@@ -275,19 +290,19 @@ __device__ __forceinline__ int sao_quad(const SaoComp<Pix>& S, const uint32_t* t
 {
   constexpr int ES = (int)sizeof(Pix);
   if (oy >= S.oh || ox0 >= S.ow) return 0;
-  const int W = S.W, H = S.H, lctb = S.lctb, ctb_w = S.ctb_w, bit_depth = S.bit_depth, maxv = S.maxv, sub = S.sub, c = S.c;
+  const int W = S.W, H = S.H, lctb = S.lctb, lctby = S.lctby, ctb_w = S.ctb_w, bit_depth = S.bit_depth, maxv = S.maxv, sub = S.sub, suby = S.suby, c = S.c;
   const int y = oy + S.crop_yc;
   const int npx = S.ow - ox0 < 4 ? S.ow - ox0 : 4;
   const int xf = ox0 + S.crop_xc, xl = xf + npx - 1;
-  const int ctb_first = (y >> lctb) * ctb_w + (xf >> lctb);
+  const int ctb_first = (y >> lctby) * ctb_w + (xf >> lctb);
   const bool one_ctb = (xf >> lctb) == (xl >> lctb);
   const SaoRegs sp_first = sao_unpack(spw[0], spw[1], spw[2]);
 #define SAO_AT(row, x) (((const Pix*)((const uint8_t*)(tile + (row) * ROW_WORDS) + ((x) * ES - ab)))[0])
   // fast paths: the 4 samples share one CTB (one parameter set) and no per-sample lossless check is needed
-  const int cmask = (1 << lctb) - 1;
+  const int cmask = (1 << lctb) - 1, cmasky = (1 << lctby) - 1;
   // edge offsets without per-neighbour checks: no neighbour leaves the CTB - or nothing restricts neighbours in other
   // CTBs (one slice or filtering across slices / tiles allowed, no lossless CUs) - and none leaves the picture
-  const bool interior = (S.free_nb ? (xf > 0 && y > 0) : ((xf & cmask) > 0 && (xl & cmask) < cmask && (y & cmask) > 0 && (y & cmask) < cmask)) &&
+  const bool interior = (S.free_nb ? (xf > 0 && y > 0) : ((xf & cmask) > 0 && (xl & cmask) < cmask && (y & cmasky) > 0 && (y & cmasky) < cmasky)) &&
                         xl + 1 < W && y + 1 < H;
   bool done = false;
   if (one_ctb && !S.check_bypass && npx == 4) {
@@ -325,14 +340,14 @@ __device__ __forceinline__ int sao_quad(const SaoComp<Pix>& S, const uint32_t* t
     if (i >= npx) { res[i] = 0; continue; }
     const int x = xf + i;
     int v = SAO_AT(lr, x);
-    const int ctb = one_ctb ? ctb_first : (y >> lctb) * ctb_w + (x >> lctb);
+    const int ctb = one_ctb ? ctb_first : (y >> lctby) * ctb_w + (x >> lctb);
     SaoRegs sp = sp_first;
     if (!one_ctb) { const uint32_t* q = (const uint32_t*)&S.sao[(size_t)ctb * 3 + c]; sp = sao_unpack(q[0], q[1], q[2]); }
     if (sp.type) {
       int ctb_dummy;
       bool keep = false;   // 8.7.3: samples of cu_transquant_bypass units, and of PCM units with pcm_loop_filter_disabled_flag, stay as they are
       if (S.check_bypass) {
-        const uint8_t fl = S.u_flags[unit_index(*S.P, (x * sub) >> 2, (y * sub) >> 2, &ctb_dummy)];
+        const uint8_t fl = S.u_flags[unit_index(*S.P, (x * sub) >> 2, (y * suby) >> 2, &ctb_dummy)];
         keep = (fl & (UF_BYPASS | (S.P->pcm_loop_filter_disabled ? UF_PCM : 0))) != 0;
       }
       if (!keep) {
@@ -347,7 +362,7 @@ __device__ __forceinline__ int sao_quad(const SaoComp<Pix>& S, const uint32_t* t
             const int dx = k ? -hx : hx, dy = k ? -hy : hy;
             const int xs = x + dx, ys = y + dy;
             if (xs < 0 || ys < 0 || xs >= W || ys >= H) { skip = 1; break; }
-            const int ctb_n = (ys >> lctb) * ctb_w + (xs >> lctb);
+            const int ctb_n = (ys >> lctby) * ctb_w + (xs >> lctb);
             if (ctb_n != ctb) {
               const CtbInfo cn = S.ctb_info[ctb_n], cc = S.ctb_info[ctb];
               if (cn.slice_idx != cc.slice_idx) {

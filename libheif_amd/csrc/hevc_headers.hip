@@ -320,7 +320,6 @@ void parse_sps(NalReader& r, Sps& s)
       if (any) unsupported("range-extension coding tools");
     }
   }
-  if (s.chroma_format_idc == 2) unsupported("chroma_format_idc 2 (4:2:2)");
   if (s.chroma_format_idc == 3 && s.separate_colour_plane) unsupported("4:4:4 with separate colour planes");
   if (s.chroma_format_idc == 3 && s.scaling_list_enabled) unsupported("scaling lists with 4:4:4 (32x32 chroma matrices)");
   if (s.bit_depth_luma > 12 || s.bit_depth_chroma > 12) unsupported("bit depth above 12");
@@ -720,7 +719,7 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
     }
 
     hipdec_image_info& I = out.info;
-    int sub_w = S.chroma_format_idc == 1 ? 2 : 1, sub_h = S.chroma_format_idc == 1 ? 2 : 1;
+    int sub_w = (S.chroma_format_idc == 1 || S.chroma_format_idc == 2) ? 2 : 1, sub_h = S.chroma_format_idc == 1 ? 2 : 1;   // SubWidthC, SubHeightC
     int x0 = sub_w * S.conf_left, x1 = S.pic_width - sub_w * S.conf_right;
     int y0 = sub_h * S.conf_top, y1 = S.pic_height - sub_h * S.conf_bottom;
     if (x1 <= x0 || y1 <= y0) bad("empty conformance window");

@@ -1021,9 +1021,12 @@ PC_DEV void pcm_coding_unit(PS& s, int zb, int log2cb, int16_t* coef_y, int16_t*
   const int n_units = 1 << (2 * (log2cb - 2));
   uint32_t acc = 0;
   int nacc = 0;
-  for (int c = 0; c < (s.chroma_format_idc ? 3 : 1); c++) {
-    const int c444 = s.chroma_format_idc == 3;
-    const int lg = (c && !c444) ? log2cb - 1 : log2cb, n2 = 1 << (2 * lg);
+  // chroma: one block of half the CU size (4:2:0), of CU size (4:4:4), or - 4:2:2: half as wide, as tall - two square blocks one above the other,
+  // which in raster order are simply the first and the second half of the samples
+  const int cfi = s.chroma_format_idc;
+  for (int k = 0; k < (cfi ? (cfi == 2 ? 5 : 3) : 1); k++) {
+    const int c = cfi == 2 ? (k + 1) >> 1 : k, t = cfi == 2 ? ((k + 1) & 1) : 0;   // 4:2:2: k = 0 luma, 1 / 2 Cb upper / lower, 3 / 4 Cr
+    const int lg = (c && cfi != 3) ? log2cb - 1 : log2cb, n2 = 1 << (2 * lg);
     const int depth = (int)((s.pcm >> (c ? 16 : 8)) & 255u), shift = (c ? s.bit_depth_chroma : s.bit_depth_luma) - depth;
     for (int i = 0; i < n2; i++) {
       while (nacc < depth) { acc = (acc << 8) | read_byte(s); nacc += 8; }
@@ -1031,7 +1034,7 @@ PC_DEV void pcm_coding_unit(PS& s, int zb, int log2cb, int16_t* coef_y, int16_t*
       nacc -= depth;
       PC_VEC_BEGIN if (lane == 0) s.L->coef[i] = (int16_t)(v << shift); PC_VEC_END
     }
-    flush_coef(s, c == 0 ? coef_y + zb * 16 : (c == 1 ? coef_cb : coef_cr) + zb * (c444 ? 16 : 4), n2);
+    flush_coef(s, c == 0 ? coef_y + zb * 16 : (c == 1 ? coef_cb : coef_cr) + zb * (cfi == 3 ? 16 : (cfi == 2 ? 8 : 4)) + t * n2, n2);
   }
   s.range = pc_vec(510u << 7); s.bits_needed = pc_vec((uint32_t)-8);
   {
@@ -1110,13 +1113,15 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
       const int lm = (int)(map_get(s.m_ipm, zb + k * cp_units) & 63u);
       if (icpm == 4) chroma_mode = lm;
       else { const int m = icpm == 0 ? 0 : icpm == 1 ? 26 : icpm == 2 ? 10 : 1; chroma_mode = (m == lm) ? 34 : m; }
+      if (s.chroma_format_idc == 2) chroma_mode = (int)c_map422[chroma_mode];   // 8.4.3, Table 8-3: the 4:2:2 sampling grid is not square
       map_fill(s.m_ipmc, zb + k * cp_units, cp_units, (uint32_t)chroma_mode);
     }
   } else map_fill(s.m_ipmc, zb, n_units, 1u);
 
   // ---- transform tree ----
   const int max_trafo_depth = s.max_th_depth_intra + part_nxn;
-  uint32_t cbf_cb_bits = 0, cbf_cr_bits = 0;  // bit d = cbf at trafoDepth d along the current path
+  uint32_t cbf_cb_bits = 0, cbf_cr_bits = 0;  // bit d = cbf at trafoDepth d along the current path; 4:2:2: bit 8 + d = the flag of the lower chroma block
+  const int c422 = s.chroma_format_idc == 2;
   int q = 0;
   while (q < n_units && !s.err) {
     int t;  // log2 size of the node that starts at q
@@ -1132,13 +1137,16 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
         if (t > 2 || c444) {
           int cb = 0, cr = 0;
           const int cc = depth == 4 ? A_CBF_CHROMA4 : A_CBF_CHROMA + depth;   // depth 4 only occurs with ChromaArrayType 3
-          if (depth == 0 || (cbf_cb_bits & pbit)) cb = decode_bin(s, s.ctxA, cc);
-          if (depth == 0 || (cbf_cr_bits & pbit)) cr = decode_bin(s, s.ctxA, cc);
-          cbf_cb_bits = (cbf_cb_bits & ~bit) | (cb ? bit : 0);
-          cbf_cr_bits = (cbf_cr_bits & ~bit) | (cr ? bit : 0);
+          // ChromaArrayType 2: a second flag, for the lower chroma block, where the chroma is coded (a leaf, or the 8x8 node above four 4x4 leaves)
+          const int two = c422 && (!split || t == 3);
+          int cb2 = 0, cr2 = 0;
+          if (depth == 0 || (cbf_cb_bits & pbit)) { cb = decode_bin(s, s.ctxA, cc); if (two) cb2 = decode_bin(s, s.ctxA, cc); }
+          if (depth == 0 || (cbf_cr_bits & pbit)) { cr = decode_bin(s, s.ctxA, cc); if (two) cr2 = decode_bin(s, s.ctxA, cc); }
+          cbf_cb_bits = (cbf_cb_bits & ~(bit * 0x101u)) | (cb ? bit : 0) | (cb2 ? bit << 8 : 0);
+          cbf_cr_bits = (cbf_cr_bits & ~(bit * 0x101u)) | (cr ? bit : 0) | (cr2 ? bit << 8 : 0);
         } else {  // 4x4 luma: inherits the parent's flags (7.4.9.8)
-          cbf_cb_bits = (cbf_cb_bits & ~bit) | ((cbf_cb_bits & pbit) ? bit : 0);
-          cbf_cr_bits = (cbf_cr_bits & ~bit) | ((cbf_cr_bits & pbit) ? bit : 0);
+          cbf_cb_bits = (cbf_cb_bits & ~(bit * 0x101u)) | ((cbf_cb_bits & (pbit * 0x101u)) << 1);
+          cbf_cr_bits = (cbf_cr_bits & ~(bit * 0x101u)) | ((cbf_cr_bits & (pbit * 0x101u)) << 1);
         }
       }
       if (!split) break;
@@ -1150,7 +1158,8 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
     const int tu_units = 1 << (2 * (t - 2));
     const int cbf_luma = decode_bin(s, s.ctxA, A_CBF_LUMA + (depth == 0 ? 1 : 0));
     const int cbf_cb = (int)((cbf_cb_bits >> depth) & 1u), cbf_cr = (int)((cbf_cr_bits >> depth) & 1u);
-    if ((cbf_luma | cbf_cb | cbf_cr) && (s.tools & TOOL_CUQPD) && !s.is_cu_qp_delta_coded) parse_cu_qp_delta(s);
+    const int cbf_cb2 = (int)((cbf_cb_bits >> (8 + depth)) & 1u), cbf_cr2 = (int)((cbf_cr_bits >> (8 + depth)) & 1u);   // 4:2:2 only
+    if ((cbf_luma | cbf_cb | cbf_cr | cbf_cb2 | cbf_cr2) && (s.tools & TOOL_CUQPD) && !s.is_cu_qp_delta_coded) parse_cu_qp_delta(s);
     const int luma_mode = (int)(map_get(s.m_ipm, zu) & 63u);
     int do_chroma = 0, zc = zu, tc = t - 1;
     if (c444) { do_chroma = 1; tc = t; chroma_mode = (int)map_get(s.m_ipmc, zu); }   // chroma blocks coincide with the luma blocks
@@ -1158,15 +1167,19 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
       if (t > 2) do_chroma = 1;
       else if ((q & 3) == 3) { do_chroma = 1; zc = zb + (q & ~3); tc = 2; }
     }
-    // one residual_coding instance for the three components (keeps the hot code small)
+    // one residual_coding instance for all blocks of the unit (keeps the hot code small): luma, Cb, Cr - 4:2:2: luma, Cb upper, Cb lower, Cr upper,
+    // Cr lower (k = 3 / 4 are the lower blocks of Cb / Cr; their coefficients follow the upper block's)
     uint32_t ts_bits = 0;
+    const uint32_t coded_bits = (uint32_t)cbf_luma | (do_chroma ? (uint32_t)(cbf_cb << 1) | (uint32_t)(cbf_cr << 2) | (uint32_t)(cbf_cb2 << 3) | (uint32_t)(cbf_cr2 << 4) : 0u);
+    const int c_mult = c444 ? 16 : (c422 ? 8 : 4);    // chroma samples per 4x4 luma unit
 #pragma clang loop unroll(disable)
-    for (int c = 0; c < 3; c++) {
-      const int coded = c == 0 ? cbf_luma : (do_chroma && (c == 1 ? cbf_cb : cbf_cr));
-      if (!coded) continue;
+    for (int k0 = 0; k0 < (c422 ? 5 : 3); k0++) {
+      const int k = c422 ? (k0 == 0 ? 0 : (k0 == 1 ? 1 : (k0 == 2 ? 3 : (k0 == 3 ? 2 : 4)))) : k0;   // coding order: both Cb blocks before the Cr blocks
+      if (!((coded_bits >> k) & 1u)) continue;
+      const int c = k == 0 ? 0 : 1 + ((k - 1) & 1), low = k >= 3;
       const int lg = c == 0 ? t : tc;
-      int16_t* dst = c == 0 ? coef_y + zu * 16 : (c == 1 ? coef_cb : coef_cr) + zc * (c444 ? 16 : 4);
-      ts_bits |= (uint32_t)residual_coding(s, lg, c, c == 0 ? luma_mode : chroma_mode) << c;
+      int16_t* dst = c == 0 ? coef_y + zu * 16 : (c == 1 ? coef_cb : coef_cr) + zc * c_mult + (low << (2 * lg));
+      ts_bits |= (uint32_t)residual_coding(s, lg, c, c == 0 ? luma_mode : chroma_mode) << k;
       flush_coef(s, dst, 1 << (2 * lg));
     }
     const int ts_y = (int)(ts_bits & 1u), ts_cb = (int)((ts_bits >> 1) & 1u), ts_cr = (int)((ts_bits >> 2) & 1u);
@@ -1175,6 +1188,15 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
                  (uint32_t)((cbf_luma ? UF_CBF_LUMA : 0) | ((do_chroma && cbf_cb) ? UF_CBF_CB : 0) | ((do_chroma && cbf_cr) ? UF_CBF_CR : 0) |
                             (s.cu_tq_bypass ? UF_BYPASS : 0) | (ts_y ? UF_TS_LUMA : 0)),
                  (uint32_t)(luma_mode | (ts_cb ? 64 : 0) | (ts_cr ? 128 : 0)), (uint32_t)((log2cb << 4) | t));
+    if (c422 && do_chroma) {
+      // 4:2:2: the flags of the LOWER chroma blocks live in the unit next to the one that carries the upper blocks' (index ^ 1: the 2nd unit of a
+      // block of 8x8 and up, the 3rd of a quad of 4x4 luma blocks): its cbf_cb / cbf_cr bits and the transform-skip bits of its mode byte
+      const int z2 = zu ^ 1;
+      const uint32_t f2 = (map_get(s.m_flags, z2) & ~(uint32_t)(UF_CBF_CB | UF_CBF_CR)) | (cbf_cb2 ? UF_CBF_CB : 0u) | (cbf_cr2 ? UF_CBF_CR : 0u);
+      const uint32_t m2 = (map_get(s.m_ipm, z2) & 63u) | (((ts_bits >> 3) & 1u) ? 64u : 0u) | (((ts_bits >> 4) & 1u) ? 128u : 0u);
+      map_fill(s.m_flags, z2, 1, f2);
+      map_fill(s.m_ipm, z2, 1, m2);
+    }
     q += tu_units;
   }
   set_qp_y(s);
@@ -1546,7 +1568,7 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
     if (!(s.tools & TOOL_CUQPD)) { s.is_cu_qp_delta_coded = 0; s.cu_qp_delta_val = 0; s.qpy_pred = s.last_qp_y; }
 
     int16_t* coef_y = (int16_t*)(arena + uload64(&P->off_coeff[0])) + (size_t)ctb_rs * ctb_size * ctb_size;
-    const int cc_shift = s.chroma_format_idc == 3 ? 0 : 2;   // chroma samples per CTB = luma samples >> cc_shift
+    const int cc_shift = s.chroma_format_idc == 3 ? 0 : (s.chroma_format_idc == 2 ? 1 : 2);   // chroma samples per CTB = luma samples >> cc_shift
     int16_t* coef_cb = (int16_t*)(arena + uload64(&P->off_coeff[1])) + (size_t)ctb_rs * ((ctb_size * ctb_size) >> cc_shift);
     int16_t* coef_cr = (int16_t*)(arena + uload64(&P->off_coeff[2])) + (size_t)ctb_rs * ((ctb_size * ctb_size) >> cc_shift);
 

@@ -36,6 +36,9 @@ PC_CONST uint8_t c_init[3][64] = {
    154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
    154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154}};
 
+// Table 8-3: the intra prediction direction of a 4:2:2 chroma block from the mode the 4:2:0 / 4:4:4 derivation yields (8.4.3)
+PC_CONST uint8_t c_map422[35] = {0, 1, 2, 2, 2, 2, 3, 5, 7, 8, 10, 11, 13, 15, 16, 18, 19, 20, 21, 22, 23, 23, 24, 24, 25, 25, 26, 27, 27, 28, 28, 29, 29, 30, 31};
+
 // lane p: rangeTabLps[p][0..3] packed little-endian (table 9-46)
 PC_CONST uint8_t c_range_lps[64 * 4] = {
   128,176,208,240, 128,167,197,227, 128,158,187,216, 123,150,178,205, 116,142,169,195, 111,135,160,185,

@@ -60,7 +60,7 @@ template <typename Pix>
 struct ReconLds {
   Pix tile[64 * 64];        // the CTB of this wave's component
   uint32_t top_raw[72];     // words of the line buffer covering x_ctb - 1 .. x_ctb + 2 * ctb - 1 (+ one pad word in front)
-  Pix left[64];
+  Pix left[128];            // right column of the previous CTB (the chroma pair: Cb at [0, 64), Cr at [64, 128))
   uint16_t refbuf0[134], refbuf1[134];   // reference samples in scan order, one pad element in front (an unused weight-0 tap may read index -1)
   // availability of the neighbourhood in 4x4-luma units, one row of bits per unit row: row uy + 1, bit ux + 1 for the
   // units ux, uy in [-1, 2 * units_per_side): row 0 / bit 0 are the borders owned by the neighbouring CTBs, rows and bits
@@ -112,6 +112,8 @@ struct Ctx {
   int lane;
   int ctbc, lg_ctbc;  // CTB size in component samples (and its log2)
   int ush;            // component samples -> 4x4-luma units: >> ush (2 for luma, 1 for 4:2:0 chroma)
+  int ushy;           // the chroma pair: rows -> 4x4-luma units (1 for 4:2:0, 2 for 4:2:2 whose chroma is not subsampled vertically); columns: >> 1
+  int lg_ctbh;        // the chroma pair: log2 of the CTB height in chroma rows (the tiles are 1 << lg_ctbc wide and 1 << lg_ctbh tall)
   int bit_depth, maxv;
   int luma;           // c_idx == 0: DC / horizontal / vertical boundary filters (8.4.4.2.6) apply
   int smooth;         // reference-sample filtering (8.4.4.2.3) applies: c_idx == 0 or ChromaArrayType == 3
@@ -314,7 +316,7 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
 // Cb and Cr blocks of one position TOGETHER: lanes 0..31 work on Cb, lanes 32..63 on Cr.  Geometry, availability, substitution
 // pattern and prediction mode are the same for both (4:2:0 chroma has neither reference smoothing nor boundary filters), only
 // the samples, the residuals and the coded-block flags differ — so one instruction stream reconstructs both blocks.
-//   LDS: the Cr tile sits behind the Cb tile (ctbc x ctbc each), left borders at left[0..31] / left[32..63], reference lines
+//   LDS: the Cr tile sits behind the Cb tile (each 1 << lg_ctbc wide, 1 << lg_ctbh tall), left borders at left[0..63] / left[64..127], reference lines
 //   at refbuf0[1 + 67 h ...];  `top`, `cbf` and `res` are this lane's half's.
 template <typename Pix>
 __device__ __forceinline__ void reconstruct_chroma_pair(ReconLds<Pix>& L, const Ctx& C, const Pix* top, int xb, int yb, int log2n, int mode, int cbf,
@@ -323,9 +325,10 @@ __device__ __forceinline__ void reconstruct_chroma_pair(ReconLds<Pix>& L, const 
   const int lane = C.lane, l = lane & 31, h = lane >> 5;
   const int n = 1 << log2n, n2 = 2 * n, N = 4 * n + 1, nn = n * n;
   const int lg_ctbc = C.lg_ctbc, maxv = C.maxv;
-  Pix* tile = L.tile + (h << (2 * lg_ctbc));
-  const Pix* left = L.left + h * 32;
+  Pix* tile = L.tile + (h << (lg_ctbc + C.lg_ctbh));
+  const Pix* left = L.left + h * 64;
   uint16_t* ref0 = L.refbuf0 + 1 + h * 67;
+  const int ushy = C.ushy;
   const int iters = nn > 32 ? nn >> 5 : 1;   // 32 samples per pass and half: 1 / 2 / 8 passes for 4x4 / 8x8 / 16x16
 
   int rp0 = 0, rp1 = 0, rp2 = 0, rp3 = 0;
@@ -348,7 +351,7 @@ __device__ __forceinline__ void reconstruct_chroma_pair(ReconLds<Pix>& L, const 
     const int px = is_left ? -1 : e - n2 - 1, py = is_left ? n2 - 1 - e : -1;
     const int X = xb + px, Y = yb + py;
     int a = 0;
-    if (e < N) a = (int)((L.avrow[(Y >> 1) + 1] >> ((X >> 1) + 1)) & 1u);
+    if (e < N) a = (int)((L.avrow[(Y >> ushy) + 1] >> ((X >> 1) + 1)) & 1u);
     if (a) {
       const Pix* src = Y < 0 ? &top[X + 1] : (X < 0 ? &left[Y] : &tile[(Y << lg_ctbc) + X]);
       ref0[e] = (uint16_t)*src;
@@ -360,7 +363,7 @@ __device__ __forceinline__ void reconstruct_chroma_pair(ReconLds<Pix>& L, const 
   const int has_x = n >= 8;
   if (has_x) {
     const int X = xb + n2 - 1, Y = yb - 1;
-    ax = (int)((L.avrow[(Y >> 1) + 1] >> ((X >> 1) + 1)) & 1u);
+    ax = (int)((L.avrow[(Y >> ushy) + 1] >> ((X >> 1) + 1)) & 1u);
     if (ax && l == 0) ref0[N - 1] = (uint16_t)(Y < 0 ? top[X + 1] : tile[(Y << lg_ctbc) + X]);
   }
   lds_sync();
@@ -448,8 +451,8 @@ __device__ __forceinline__ void reconstruct_chroma_pair(ReconLds<Pix>& L, const 
 #undef RT
 #undef NEXT_RES
   {
-    const int k = n >> 1;    // units per side
-    if (lane < k) L.avrow[(yb >> 1) + 1 + lane] |= ((1ull << k) - 1ull) << ((xb >> 1) + 1);
+    const int k = n >> 1, rows = n >> ushy;    // units per row of the block, unit rows (4:2:2: a 4x4 block is two units wide and one tall)
+    if (lane < rows) L.avrow[(yb >> ushy) + 1 + lane] |= ((1ull << k) - 1ull) << ((xb >> 1) + 1);
   }
   lds_sync();
 }
@@ -471,8 +474,9 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
   const int c_idx = DUAL ? 1 : plane;    // progress words / wave table: 0 = luma, 1 = the chroma pair (4:4:4: 1 = Cb, 2 = Cr)
   const bool chroma = DUAL || plane != 0;
   const PicParams& P = A.pics[wd.pic];
-  const int sub = DUAL ? 2 : 1;
-  const int ctb = 1 << P.log2_ctb, ctbc = ctb / sub;
+  const int sub = DUAL ? 2 : 1;                                   // horizontal subsampling of this wave's plane(s)
+  const int suby = (DUAL && P.chroma_format_idc != 2) ? 2 : 1;    // vertical: the 4:2:2 pair has the luma rows
+  const int ctb = 1 << P.log2_ctb, ctbc = ctb / sub, ctbch = ctb / suby;   // CTB width / height in component samples
   const int units = 1 << P.units_per_ctb_log2;
   const CtbInfo* ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
   Pix* rec = (Pix*)(A.arena + P.off_rec[comp]);
@@ -487,6 +491,7 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
   uint32_t my_row = 0;
   Ctx C;
   C.lane = lane; C.ctbc = ctbc; C.lg_ctbc = P.log2_ctb - (DUAL ? 1 : 0); C.ush = DUAL ? 1 : 2;
+  C.ushy = suby == 2 ? 1 : 2; C.lg_ctbh = P.log2_ctb - (suby == 2 ? 1 : 0);
   C.bit_depth = chroma ? P.bit_depth_chroma : P.bit_depth_luma; C.maxv = (1 << C.bit_depth) - 1;
   C.luma = !chroma; C.smooth = !DUAL; C.strong = !chroma && P.strong_intra_smoothing;
   const int Wc = DUAL ? P.cwidth : P.width, Hc = DUAL ? P.cheight : P.height;   // component plane size in samples
@@ -494,8 +499,8 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
   const int side = 1 << (log2_ctb - 2);                                         // 4x4-luma units per CTB side
   const int cbf_bit = DUAL ? (h ? UF_CBF_CR : UF_CBF_CB) : (plane == 0 ? UF_CBF_LUMA : (plane == 1 ? UF_CBF_CB : UF_CBF_CR));
   // this lane's slices of the shared LDS arrays
-  Pix* tile = L.tile + (DUAL ? h << (2 * C.lg_ctbc) : 0);
-  Pix* left = L.left + (DUAL ? h * 32 : 0);
+  Pix* tile = L.tile + (DUAL ? h << (C.lg_ctbc + C.lg_ctbh) : 0);
+  Pix* left = L.left + (DUAL ? h * 64 : 0);
   uint32_t* top_raw = L.top_raw + (DUAL ? h * 36 : 0);
   const int lg_wpr = C.lg_ctbc - (ES == 1 ? 2 : 1);      // log2 of the words per tile row
   const int wpr = 1 << lg_wpr;
@@ -546,7 +551,7 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
       // availability rows: the borders come from the neighbouring CTBs (slice / tile / picture limits are in ci.avail,
       // units right of or below the picture never become available), the CTB's own units are set block by block
       if (lane < 33) {
-        const int usz = 4 / sub;                                        // component samples per unit
+        const int usz = 4 / sub, uszy = 4 / suby;                       // component samples per unit, horizontally / vertically
         uint64_t row = 0;
         if (lane == 0) {
           int nu = (Wc - xc0 + usz - 1) / usz;                          // units up to the right picture edge
@@ -555,14 +560,14 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
           if (ci.avail & AV_UPLEFT) row |= 1ull;
           if (ci.avail & AV_UP) row |= ((1ull << n_up) - 1ull) << 1;
           if ((ci.avail & AV_UPRIGHT) && nu > side) row |= ((1ull << (nu - side)) - 1ull) << (side + 1);
-        } else if (lane <= side && (ci.avail & AV_LEFT) && y_ctb / sub + (lane - 1) * usz < Hc) row = 1ull;
+        } else if (lane <= side && (ci.avail & AV_LEFT) && y_ctb / suby + (lane - 1) * uszy < Hc) row = 1ull;
         L.avrow[lane] = row;
       }
     }
     lds_sync();
 
     // ---- the blocks of the CTB in z-scan order ----
-    const int16_t* res_base = coeff + (size_t)ctb_rs * (ctb * ctb / (sub * sub));
+    const int16_t* res_base = coeff + (size_t)ctb_rs * (ctb * ctb / (sub * suby));
     int z = 0;
     while (z < units) {
       const uint32_t w = L.m_unit[z];
@@ -576,7 +581,14 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
         // the 4x4 chroma blocks of four 4x4 luma TUs hang off the 4th unit (their flags are there); they sit at the quad's origin
         const int quad = tb == 2;
         const int zc = quad ? (z & ~3) : z, cux = quad ? (ux & ~1) : ux, cuy = quad ? (uy & ~1) : uy;
-        reconstruct_chroma_pair<Pix>(L, C, top, cux * 2, cuy * 2, quad ? 2 : tb - 1, mode, fl & (cbf_bit | UF_PCM), res_base + zc * 4);
+        const int lgc = quad ? 2 : tb - 1;
+        if (suby == 2) reconstruct_chroma_pair<Pix>(L, C, top, cux * 2, cuy * 2, lgc, mode, fl & (cbf_bit | UF_PCM), res_base + zc * 4);
+        else {
+          // 4:2:2: two blocks one above the other, the upper one first (the lower one predicts from it); the lower one's flags sit in unit z ^ 1
+          const int fl2 = (int)((L.m_unit[z ^ 1] >> 8) & 255u);
+          reconstruct_chroma_pair<Pix>(L, C, top, cux * 2, cuy * 4, lgc, mode, fl & (cbf_bit | UF_PCM), res_base + zc * 8);
+          reconstruct_chroma_pair<Pix>(L, C, top, cux * 2, cuy * 4 + (1 << lgc), lgc, mode, fl2 & (cbf_bit | UF_PCM), res_base + zc * 8 + (1 << (2 * lgc)));
+        }
       }
       z += 1 << (2 * (tb - 2));
     }
@@ -585,19 +597,19 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
     // ---- write the CTB out (planes are allocated CTB-aligned, so no edge guards), hand its bottom row to the
     //      row below and keep its right column as the next CTB's left border ----
     {
-      const int yc0 = y_ctb / sub;
+      const int yc0 = y_ctb / suby;
       // LW lanes cover LW / wpr whole tile rows per pass (wpr <= 32 is a power of two): the plane offset advances by a
       // wave-uniform step, no per-pass multiplies or divisions
       const int y0 = l >> lg_wpr, xw = l & (wpr - 1);
       uint32_t off = (uint32_t)(yc0 + y0) * stride + (uint32_t)(xc0 + xw * PPW);
       const uint32_t step = ((uint32_t)LW >> lg_wpr) * stride;
-      for (int i = l; i < wpr * ctbc; i += LW, off += step)
+      for (int i = l; i < wpr * ctbch; i += LW, off += step)
         *(uint32_t*)&rec[off] = *(const uint32_t*)&tile[i * PPW];     // tile rows are wpr words: word i of the tile
       uint32_t* dst = line + (size_t)cy * line_words + (size_t)xc0 * ES / 4;
       for (int i = l; i < wpr; i += LW)
-        __hip_atomic_store(dst + i, *(const uint32_t*)&tile[(ctbc - 1) * ctbc + i * PPW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + i, *(const uint32_t*)&tile[(ctbch - 1) * ctbc + i * PPW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       lds_sync();
-      for (int i = l; i < ctbc; i += LW) left[i] = tile[i * ctbc + ctbc - 1];
+      for (int i = l; i < ctbch; i += LW) left[i] = tile[i * ctbc + ctbc - 1];
     }
     lds_sync();
     drain_stores();   // the line-buffer stores have left this wave

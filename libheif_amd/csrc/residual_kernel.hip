@@ -31,9 +31,9 @@ __device__ __forceinline__ int chroma_qp_table(int qpi)   // table 8-10 for Chro
                           (6ull << 32) | (6ull << 36) | (7ull << 40) | (7ull << 44) | (8ull << 48) | (8ull << 52);
   return 29 + (int)((kT >> ((qpi - 30) * 4)) & 15u);
 }
-__device__ __forceinline__ int chroma_qp(int qpi, bool c444)   // 8.6.1: QpC from qPi; ChromaArrayType 3 (c444): Min(qPi, 51)
+__device__ __forceinline__ int chroma_qp(int qpi, bool not420)   // 8.6.1: QpC from qPi: table 8-10 for ChromaArrayType 1, Min(qPi, 51) otherwise
 {
-  if (c444) return qpi < 51 ? qpi : 51;
+  if (not420) return qpi < 51 ? qpi : 51;
   return qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : chroma_qp_table(qpi));
 }
 // Scaling (8.6.3, flat m = 16) in 32 bits: level * 16 * levelScale < 2^27, and with q = qP / 6, b = bdShift
@@ -196,11 +196,12 @@ __device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, in
 // Four independent 4x4 blocks per wave pass: lane = 16 g + 4 y + x works on sample (y, x) of block g.  entry = z | c << 8.
 // (8.6.2 - 8.6.4 as in residual_block; both 1-D stages are two v_dot2 per output, no nonzero-extent bookkeeping)
 __device__ __forceinline__ void residual_quad(ResLds& L, int bd_luma, int bd_chroma, int cb_qp_offset, int cr_qp_offset, const uint8_t* sl_tab, int wave, int lane, int entry, bool valid,
-                                              int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr, bool c444)
+                                              int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr, int cfi)
 {
+  const bool c444 = cfi == 3, c422 = cfi == 2;
   const int g = lane >> 4, l = lane & 15;
-  const int z = entry & 255, c = (entry >> 8) & 3;
-  const int t = L.m_size[z] & 15, fl = L.m_flags[z], ipm = L.m_ipm[z], qp_y = L.m_qp[z];
+  const int z = entry & 255, c = (entry >> 8) & 3, low = (entry >> 10) & 1;   // low: the lower chroma block of a 4:2:2 unit (its flags sit in unit z ^ 1)
+  const int t = L.m_size[z] & 15, fl = L.m_flags[z], ipm = L.m_ipm[low ? (z ^ 1) : z], qp_y = L.m_qp[z];
   const bool bypass = (fl & UF_BYPASS) != 0;
   int16_t* coef;
   int bit_depth, qp, ts;
@@ -210,8 +211,8 @@ __device__ __forceinline__ void residual_quad(ResLds& L, int bd_luma, int bd_chr
     const int zc = (t > 2 || c444) ? z : (z & ~3);
     const int off_c = 6 * (bd_chroma - 8);
     const int qpi = clip3(-off_c, 57, qp_y + (c == 1 ? cb_qp_offset : cr_qp_offset));
-    const int qpc = chroma_qp(qpi, c444);
-    coef = (c == 1 ? coef_cb : coef_cr) + zc * (c444 ? 16 : 4); bit_depth = bd_chroma; qp = qpc + off_c; ts = (ipm & (c == 1 ? 64 : 128)) != 0;
+    const int qpc = chroma_qp(qpi, cfi != 1);
+    coef = (c == 1 ? coef_cb : coef_cr) + zc * (c444 ? 16 : (c422 ? 8 : 4)) + low * 16; bit_depth = bd_chroma; qp = qpc + off_c; ts = (ipm & (c == 1 ? 64 : 128)) != 0;
   }
   const bool act = valid && !bypass;      // cu_transquant_bypass: the coefficient levels are the residual
   const int q6 = (qp * 43) >> 8;          // qp / 6 for 0 <= qp < 128
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
   const uint8_t* sl_tab = P.scaling_lists ? A.arena + P.off_scaling : nullptr;   // ScalingFactor tables of the picture
   const bool use_sl = sl_tab != nullptr;
   const bool c444 = P.chroma_format_idc == 3;   // chroma blocks have the luma blocks' size and position
+  const bool c422 = P.chroma_format_idc == 2;   // two chroma blocks of half the luma block's size, one above the other
   if (tid == 0) { L.count = 0; L.count4 = 0; }
   if (tid < units) {
     L.m_size[tid] = A.arena[P.off_u_size + base + tid];
@@ -311,12 +313,16 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
           if (t == 2) L.list[LIST_N - 1 - atomicAdd(&L.count4, 1u)] = (uint16_t)z;
           else L.list[atomicAdd(&L.count, 1u)] = (uint16_t)z;
         }
-        if (P.chroma_format_idc)
+        // chroma blocks hang off the unit that carries their flags: a block's first unit, or the 4th unit of a quad of 4x4 luma blocks.  4:2:2 has
+        // two chroma blocks per unit; the lower one's flags sit in unit z ^ 1 (so in a 4:2:2 quad only the 4th unit's flags are block flags)
+        if (P.chroma_format_idc && !(c422 && t == 2 && (z & 3) != 3))
           for (int c = 1; c < 3; c++)
-            if (fl & (c == 1 ? UF_CBF_CB : UF_CBF_CR)) {
-              if (t <= (c444 ? 2 : 3)) L.list[LIST_N - 1 - atomicAdd(&L.count4, 1u)] = (uint16_t)(z | (c << 8));
-              else L.list[atomicAdd(&L.count, 1u)] = (uint16_t)(z | (c << 8));
-            }
+            for (int low = 0; low < (c422 ? 2 : 1); low++)
+              if ((low ? L.m_flags[z ^ 1] : fl) & (c == 1 ? UF_CBF_CB : UF_CBF_CR)) {
+                const uint16_t entry = (uint16_t)(z | (c << 8) | (low << 10));
+                if (t <= (c444 ? 2 : 3)) L.list[LIST_N - 1 - atomicAdd(&L.count4, 1u)] = entry;
+                else L.list[atomicAdd(&L.count, 1u)] = entry;
+              }
       }
     }
   }
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
   const CtbInfo ci = ((const CtbInfo*)(A.arena + P.off_ctb_info))[ctb_rs];
   const SliceParams sl = ((const SliceParams*)(A.arena + P.off_slices))[ci.slice_idx];
   int16_t* coef_y = (int16_t*)(A.arena + P.off_coeff[0]) + (size_t)ctb_rs * ctb * ctb;
-  const int cc_shift = c444 ? 0 : 2;
+  const int cc_shift = c444 ? 0 : (c422 ? 1 : 2);
   int16_t* coef_c[2] = {(int16_t*)(A.arena + P.off_coeff[1]) + (size_t)ctb_rs * ((ctb * ctb) >> cc_shift),
                         (int16_t*)(A.arena + P.off_coeff[2]) + (size_t)ctb_rs * ((ctb * ctb) >> cc_shift)};
   const int bd_luma = P.bit_depth_luma, bd_chroma = P.bit_depth_chroma, cb_off = sl.cb_qp_offset, cr_off = sl.cr_qp_offset;
@@ -333,12 +339,12 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
   for (int q = wave; q * 4 < count4; q += 4) {
     const int idx = q * 4 + (lane >> 4);
     const bool valid = idx < count4;
-    residual_quad(L, bd_luma, bd_chroma, cb_off, cr_off, sl_tab, wave, lane, valid ? (int)L.list[LIST_N - 1 - idx] : 0, valid, coef_y, coef_c[0], coef_c[1], c444);
+    residual_quad(L, bd_luma, bd_chroma, cb_off, cr_off, sl_tab, wave, lane, valid ? (int)L.list[LIST_N - 1 - idx] : 0, valid, coef_y, coef_c[0], coef_c[1], P.chroma_format_idc);
   }
   // larger blocks, one per wave pass
   for (int e = wave; e < count; e += 4) {
-    const int z = L.list[e] & 255, c = L.list[e] >> 8;
-    const int t = L.m_size[z] & 15, fl = L.m_flags[z], ipm = L.m_ipm[z], qp_y = L.m_qp[z];
+    const int z = L.list[e] & 255, c = (L.list[e] >> 8) & 3, low = L.list[e] >> 10;
+    const int t = L.m_size[z] & 15, fl = L.m_flags[z], ipm = L.m_ipm[low ? (z ^ 1) : z], qp_y = L.m_qp[z];
     if (c == 0) {
       if (use_sl) residual_block<true>(L, wave, lane, coef_y + z * 16, t, bd_luma, qp_y + 6 * (bd_luma - 8), 0, (fl & UF_TS_LUMA) != 0, 0,
                                        sl_tab + (t == 5 ? 1008 : (t == 3 ? 16 : 80)));
@@ -347,9 +353,9 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
     else {
       const int off_c = 6 * (bd_chroma - 8);
       const int qpi = clip3(-off_c, 57, qp_y + (c == 1 ? cb_off : cr_off));
-      const int qpc = chroma_qp(qpi, c444);
+      const int qpc = chroma_qp(qpi, P.chroma_format_idc != 1);
       const int tc = c444 ? t : t - 1;    // log2 size of the chroma block (scaling lists do not occur with 4:4:4: refused by the front end)
-      int16_t* cc = coef_c[c - 1] + z * (c444 ? 16 : 4);
+      int16_t* cc = coef_c[c - 1] + z * (c444 ? 16 : (c422 ? 8 : 4)) + (low << (2 * tc));
       if (use_sl) residual_block<true>(L, wave, lane, cc, tc, bd_chroma, qpc + off_c, 0, (ipm & (c == 1 ? 64 : 128)) != 0, 0,
                                        sl_tab + c * 336 + (tc == 3 ? 16 : 80));
       else residual_block<false>(L, wave, lane, cc, tc, bd_chroma, qpc + off_c, 0, (ipm & (c == 1 ? 64 : 128)) != 0, 0, nullptr);

@@ -152,8 +152,9 @@ class Batch:
         """deblocked (pre-SAO) picture at coded size — debug tap"""
         d = self.info(i)
         dt = np.uint16 if d["bit_depth_luma"] > 8 else np.uint8
-        sub = 1 if (c == 0 or d["chroma_format_idc"] == 3) else 2
-        w, h = d["coded_width"] // sub, d["coded_height"] // sub
+        cf = d["chroma_format_idc"]
+        subw, subh = (1, 1) if c == 0 else ((1 if cf == 3 else 2), (2 if cf == 1 else 1))
+        w, h = d["coded_width"] // subw, d["coded_height"] // subh
         a = np.empty((h, w), dt)
         check(self._lib.hipdec_batch_read_tap(self._h, i, 1, c, a.ctypes.data, w * a.itemsize))
         return a

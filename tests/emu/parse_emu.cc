@@ -134,21 +134,27 @@ int emu_coeffs(EmuBatch* b, int i, int32_t* y, int32_t* cb, int32_t* cr)
             for (int xx = 0; xx < n; xx++) y[(size_t)(cy * ctb + uy * 4 + yy) * P.width + cx * ctb + ux * 4 + xx] = src[yy * n + xx];
         }
         if (P.chroma_format_idc) {
-          const bool c444 = P.chroma_format_idc == 3;
-          const int csh = c444 ? 0 : 1;
+          // chroma blocks of the unit: 4:4:4 one of the luma block's size; 4:2:0 one of half the size (the 4x4 luma quads: one 4x4 block hanging off
+          // the 4th unit); 4:2:2 like 4:2:0 but TWO blocks one above the other, the lower one's flags in unit (z ^ 1)
+          const int cfi = P.chroma_format_idc;
+          const bool c444 = cfi == 3;
+          const int csw = c444 ? 0 : 1, csh = cfi == 1 ? 1 : 0;
           int do_c = 0, zc = z, tc = t - 1;
           if (c444) { do_c = 1; tc = t; }
           else if (t > 2) do_c = 1; else if ((z & 3) == 3) { do_c = 1; zc = z & ~3; tc = 2; }
           if (do_c) {
             const int cux = (int)pcore::compact1by1((uint32_t)zc), cuy = (int)pcore::compact1by1((uint32_t)zc >> 1);
-            for (int c = 1; c < 3; c++) {
-              if (!(fl & (c == 1 ? UF_CBF_CB : UF_CBF_CR))) continue;
-              const int16_t* src = (const int16_t*)(a + P.off_coeff[c]) + (size_t)ctb_rs * ((ctb * ctb) >> (2 * csh)) + zc * (c444 ? 16 : 4);
-              const int n = 1 << tc;
-              for (int yy = 0; yy < n; yy++)
-                for (int xx = 0; xx < n; xx++)
-                  out[c][(size_t)(((cy * ctb + cuy * 4) >> csh) + yy) * P.cwidth + ((cx * ctb + cux * 4) >> csh) + xx] = src[yy * n + xx];
-            }
+            const int mult = c444 ? 16 : (cfi == 2 ? 8 : 4);
+            const int n = 1 << tc;
+            for (int c = 1; c < 3; c++)
+              for (int low = 0; low < (cfi == 2 ? 2 : 1); low++) {
+                const int f = low ? a[P.off_u_flags + base + (z ^ 1)] : fl;
+                if (!(f & (c == 1 ? UF_CBF_CB : UF_CBF_CR))) continue;
+                const int16_t* src = (const int16_t*)(a + P.off_coeff[c]) + (size_t)ctb_rs * ((ctb * ctb) >> (csw + csh)) + zc * mult + low * n * n;
+                for (int yy = 0; yy < n; yy++)
+                  for (int xx = 0; xx < n; xx++)
+                    out[c][(size_t)(((cy * ctb + cuy * 4) >> csh) + low * n + yy) * P.cwidth + ((cx * ctb + cux * 4) >> csw) + xx] = src[yy * n + xx];
+              }
           }
         }
         z += 1 << (2 * (t - 2));

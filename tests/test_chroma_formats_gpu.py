@@ -1,0 +1,148 @@
+"""GPU parity for 4:2:2 and 4:4:4 (chroma_format_idc 2 / 3) stills through the C ABI and through an unmodified libheif: bit-exact planes
+against the CPU oracle over the coding-tool matrix, batches mixing chroma formats, the per-unit maps (4:4:4: one intra_chroma_pred_mode per
+NxN partition; 4:2:2: Table 8-3 modes), the colour stage on the decoded planes, full-HD stills, and heif_decode_image() handing out
+heif_chroma_422 / heif_chroma_444 planes.  See tests/test_chroma_formats_emu.py for what differs from 4:2:0 in the syntax and the decoding process."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+import heic_util as hu
+import libheif_host as lh
+from test_chroma_formats_emu import CONFIGS, CONFIGS_422, FORMATS
+
+pytestmark = pytest.mark.gpu
+needs_ref = pytest.mark.skipif(not lh.available(), reason="oracle/_ref/libheif.so not built")
+
+
+def _decode_gpu(stream):
+    from libheif_amd.decoder import HipDecoder
+    d = HipDecoder()
+    d.push_data(stream)
+    img = d.decode_next_image()
+    assert d.decode_next_image() is None
+    d.free()
+    return img
+
+
+def _ids(v):
+    return ("4%d%d" % ((2, 2) if v == 2 else (4, 4))) if isinstance(v, int) else (",".join("%s=%s" % kv for kv in v.items()) or "default")
+
+
+@pytest.mark.parametrize("cf,cfg", [(cf, c) for cf in (2, 3) for c in (CONFIGS if cf == 3 else CONFIGS_422)], ids=_ids)
+@pytest.mark.parametrize("size", [(200, 136), (74, 41)])
+def test_decode_matches_oracle(cf, cfg, size):
+    bd = cfg.get("bit_depth", 8)
+    stream = orc.encode(orc.synth_image(size[0], size[1], bd, cf, seed=3 + size[0]), **cfg)
+    ref = orc.decode(stream)
+    img = _decode_gpu(stream)
+    assert img.info["chroma_format_idc"] == cf
+    assert (img.info["width"], img.info["height"]) == (ref["width"], ref["height"])
+    assert (img.info["chroma_width"], img.info["chroma_height"]) == (ref["width"] if cf == 3 else ref["width"] // 2, ref["height"])
+    assert img.nclx == ref["nclx"]
+    assert len(img.planes) == 3
+    for c in range(3):
+        np.testing.assert_array_equal(img.planes[c], ref["planes"][c], err_msg="component %d" % c)
+
+
+def test_batch_mixing_chroma_formats_matches_oracle():
+    """4:4:4, 4:2:2, 4:2:0 and 4:0:0 pictures in ONE batch (one set of launches): three, two or one reconstruction wave chains per row chain"""
+    from libheif_amd.decoder import Batch
+    streams = []
+    for i, (w, h, cf) in enumerate([(128, 64, 3), (64, 128, 1), (200, 136, 2), (72, 40, 0), (136, 72, 1), (75, 41, 3), (264, 200, 3), (264, 200, 1), (70, 41, 2), (264, 200, 2)]):
+        streams.append(orc.encode(orc.synth_image(w, h, 8, cf, seed=40 + i), qp=24 + 2 * i, stress=i & 1, tile_cols=1 + (i % 2), wpp=(i >> 1) & 1))
+    b = Batch(streams)
+    b.run(); b.status()
+    for i, s in enumerate(streams):
+        ref = orc.decode(s)
+        got = b.planes(i)
+        assert len(got) == len(ref["planes"])
+        for c in range(len(got)):
+            np.testing.assert_array_equal(got[c], ref["planes"][c], err_msg="item %d component %d" % (i, c))
+
+
+@FORMATS
+def test_intermediate_maps_and_taps_match_oracle(cf):
+    from libheif_amd.decoder import Batch
+    stream = orc.encode(orc.synth_image(200, 136, 8, cf, seed=11), stress=1, transform_skip=1, lossless_pct=10)
+    ref = orc.decode(stream, taps=True)
+    b = Batch([stream])
+    b.run(); b.status()
+    m = b.maps(0)
+    np.testing.assert_array_equal(m["log2_cb"], ref["map_log2_cb"])
+    np.testing.assert_array_equal(m["log2_tb"], ref["map_log2_tb"])
+    np.testing.assert_array_equal(m["intra_luma"], ref["map_intra_luma"])
+    np.testing.assert_array_equal(m["intra_chroma"], ref["map_intra_chroma"])     # 4:4:4: per partition for NxN coding units; 4:2:2: after Table 8-3
+    np.testing.assert_array_equal(m["qp_y"], ref["map_qp_y"])
+    fmask = 0x79 if cf == 2 else 0x7f    # 4:2:2: a unit's cbf_cb / cbf_cr bits are those of ONE of its two chroma blocks (the other's sit in unit z ^ 1)
+    np.testing.assert_array_equal(m["flags"] & fmask, ref["map_flags"] & fmask)
+    for c in range(3):
+        np.testing.assert_array_equal(b.tap(0, c), ref["post_deblock"][c])
+
+
+@FORMATS
+@pytest.mark.parametrize("vui", [(1, 13, 6, 1), (1, 13, 1, 0), None], ids=["bt601-full", "bt709-limited", "unspecified"])
+def test_planes_to_rgb24_match_the_oracle_chain(vui, cf):
+    """Op_YCbCr_to_RGB<uint8_t> + Op_RGB_to_RGB24_32 — the chain libheif's planner has for 4:2:2 / 4:4:4 planes — on the decoded planes in HBM"""
+    from libheif_amd.decoder import Batch
+    kw = dict(vui_primaries=vui[0], vui_transfer=vui[1], vui_matrix=vui[2], vui_full_range=vui[3]) if vui else {}
+    stream = orc.encode(orc.synth_image(200, 136, 8, cf, seed=21), **kw)
+    ref = orc.decode(stream)
+    b = Batch([stream]); b.run(); b.status()
+    rgb = b.to_rgb(0, 10)
+    y, cb, cr = ref["planes"]
+    r, g, bb = orc.color_ycbcr_to_rgb_planar(y, cb, cr, 8, cf, ref["nclx"])
+    np.testing.assert_array_equal(rgb, orc.color_rgb_planar_to_interleaved8(r, g, bb).reshape(136, -1))
+
+
+@FORMATS
+def test_main10_to_rrggbb_is_refused_loudly(cf):
+    from libheif_amd.decoder import Batch
+    from libheif_amd._capi import HipDecError
+    stream = orc.encode(orc.synth_image(72, 40, 10, cf, seed=2), bit_depth=10)
+    b = Batch([stream]); b.run(); b.status()
+    with pytest.raises(HipDecError) as e:
+        b.to_rgb(0, 12)
+    assert "4:2:0" in str(e.value)
+    for c, p in enumerate(b.planes(0)):           # the planes themselves are there
+        np.testing.assert_array_equal(p, orc.decode(stream)["planes"][c])
+
+
+@pytest.mark.parametrize("cf,bd", [(3, 8), (2, 10)], ids=["444-8bit", "422-10bit"])
+def test_full_hd_still_matches_oracle(cf, bd):
+    """(4:2:2 10-bit is what cameras that write HEIF with more than 4:2:0 produce)"""
+    stream = orc.encode(orc.synth_image(1920, 1080, bd, cf, seed=77), qp=30, bit_depth=bd)
+    ref = orc.decode(stream)
+    img = _decode_gpu(stream)
+    for c in range(3):
+        np.testing.assert_array_equal(img.planes[c], ref["planes"][c], err_msg="component %d" % c)
+
+
+SRGB_VUI = dict(vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1)
+
+
+@needs_ref
+@FORMATS
+@pytest.mark.parametrize("bd", [8, 10])
+def test_heif_decode_image_hands_out_the_planes(bd, cf):
+    """an unmodified libheif + the plugin: a 4:2:2 / 4:4:4 HEIC item arrives as heif_chroma_422 / heif_chroma_444 planes, bit-exact"""
+    lh.load_hip_plugin()
+    w, h = 264, 200
+    s = orc.encode(orc.synth_image(w, h, bd, cf, seed=9), bit_depth=bd, stress=1, **SRGB_VUI)
+    ref = orc.decode(s)
+    out = lh.decode(hu.build_heic([(s, w, h)], bit_depth=bd, chroma_format_idc=cf), lh.COLORSPACE_YCBCR, cf)
+    assert out["bit_depth"] == bd and len(out["planes"]) == 3
+    for c in range(3):
+        np.testing.assert_array_equal(out["planes"][c], ref["planes"][c], err_msg="component %d" % c)
+
+
+@needs_ref
+@FORMATS
+def test_heif_decode_image_to_rgb_matches_reference_colour_ops_on_oracle_planes(cf):
+    import ref_harness as rh
+    lh.load_hip_plugin()
+    w, h = 200, 136
+    s = orc.encode(orc.synth_image(w, h, 8, cf, seed=5), **SRGB_VUI)
+    ref = orc.decode(s)
+    out = lh.decode(hu.build_heic([(s, w, h)], chroma_format_idc=cf), lh.COLORSPACE_RGB, lh.CHROMA_RGB)
+    exp = rh.convert(ref["planes"], 8, cf, ref["nclx"], rh.CS_RGB, rh.CH_RGB)[0]
+    np.testing.assert_array_equal(out["rgb"], exp[:, :w * 3])

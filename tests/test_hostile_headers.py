@@ -157,7 +157,6 @@ HOSTILE = {
     "chroma qp offset 13": sps() + pps(cb_off=13) + idr(),
     "init_qp out of range": sps() + pps(init_qp_m26=80) + idr(),
     "chroma_format_idc 7": sps(chroma_format_idc=7) + pps() + idr(),
-    "chroma_format_idc 2 (4:2:2 is not handled)": sps(chroma_format_idc=2) + pps() + idr(),
     "65 short-term RPS": sps(num_st_rps=65) + pps() + idr(),
     "sps id 16": sps(sps_id=16) + pps() + idr(),
 }

@@ -48,10 +48,15 @@ def random_case(rng):
         w, h = w - rng.choice([0, 1, 3]), h - rng.choice([0, 1, 5])     # odd sizes (the generator only takes them for 4:0:0)
     elif h & 1:
         h += 1
-    # 4:4:4 for a quarter of the colour cases, drawn from a generator of its own so that the other dimensions of a seed stay what they were
-    if cf == 1 and random.Random(rng.random()).random() < 0.25:
-        cf = 3
-        cfg["scaling_list"] = 0          # (32x32 chroma matrices: refused by the front end)
+    # 4:4:4 for a quarter and 4:2:2 for a fifth of the colour cases, drawn from a generator of its own so that the other dimensions of a seed stay
+    # what they were
+    if cf == 1:
+        r = random.Random(rng.random()).random()
+        if r < 0.25:
+            cf = 3
+            cfg["scaling_list"] = 0          # (32x32 chroma matrices: refused by the front end)
+        elif r < 0.45:
+            cf = 2
     return w, h, cf, cfg
 
 
