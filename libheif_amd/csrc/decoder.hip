@@ -170,6 +170,8 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
   // the row above (measured: parse 698 -> 591 ms against "run until blocked")
   pa.yield_ctbs = getenv("HIPDEC_POOL_YIELD") ? (uint32_t)atoi(getenv("HIPDEC_POOL_YIELD")) : 1;
   pa.wake_hyst = getenv("HIPDEC_POOL_HYST") ? (uint32_t)atoi(getenv("HIPDEC_POOL_HYST")) : 0u;
+  pa.general_chroma = 0;
+  for (const PicParams& P : b.params) if (P.chroma_format_idc >= 2) pa.general_chroma = 1;
   pa.pool = b.pool; pa.queue_cap = b.queue_cap; pa.num_subs = b.num_subs;
   pa.waitneed = (uint32_t*)(b.arena + b.off_waitneed); pa.resume_k = (uint32_t*)(b.arena + b.off_resume_k);
   pa.queue = (uint32_t*)(b.arena + b.off_queue); pa.qctl = (uint32_t*)(b.arena + b.off_qctl); pa.saved = (uint32_t*)(b.arena + b.off_saved);

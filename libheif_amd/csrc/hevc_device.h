@@ -163,6 +163,7 @@ struct ParseArgs {
   uint32_t* saved;       // per substream: SAVE_DWORDS of suspended state
   uint32_t yield_ctbs;   // test knob (0 = off): a row yields after this many CTBs per activation
   uint32_t wake_hyst;    // a parked row is woken when its predecessor is this many CTBs beyond the minimum distance
+  uint32_t general_chroma;   // 1: the batch holds a 4:2:2 or 4:4:4 picture (the parser build with the ChromaArrayType 2 / 3 paths is launched)
 };
 
 }  // namespace hipdec

@@ -101,6 +101,10 @@ PC_DEV uint32_t pc_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }     
 
 #include "parse_tables.h"
 
+#ifndef HIPDEC_PARSE_CHROMA_GENERAL
+#define HIPDEC_PARSE_CHROMA_GENERAL 1   // 0: a build for 4:0:0 / 4:2:0 pictures only (see pc_is444)
+#endif
+
 namespace hipdec {
 namespace pcore {
 
@@ -157,6 +161,10 @@ PC_DEV uint32_t compact1by1(uint32_t v)
 }
 
 // ---- lane-indexed byte maps ---------------------------------------------------------------------
+// ChromaArrayType 3 / 2.  The throughput kernels of parse_kernel.hip are compiled with HIPDEC_PARSE_CHROMA_GENERAL = 0: the 4:4:4 / 4:2:2 block loops
+// cost the scalar-bound 4:2:0 parser 1.5 % (measured), so batches that hold such pictures run the general build (parse_kernel_general.hip) instead
+PC_DEV bool pc_is444(const PS& s) { return HIPDEC_PARSE_CHROMA_GENERAL && s.chroma_format_idc == 3; }
+PC_DEV bool pc_is422(const PS& s) { return HIPDEC_PARSE_CHROMA_GENERAL && s.chroma_format_idc == 2; }
 PC_DEV uint32_t map_get(const VReg& m, int z) { return (pc_rdlane(m, z >> 2) >> ((z & 3) * 8)) & 255u; }
 // fills units [zb, zb + n) with byte b; n is 1 or a multiple of 4 with zb aligned to it
 PC_DEV void map_fill(VReg& m, int zb, int n, uint32_t b)
@@ -809,7 +817,7 @@ PC_DEV int residual_coding(PS& s, int log2n, int c_idx, int pred_mode)
   if (px > 3) last_x = (1 << ((px >> 1) - 1)) * (2 + (px & 1)) + decode_bypass_bits(s, (px >> 1) - 1);
   if (py > 3) last_y = (1 << ((py >> 1) - 1)) * (2 + (py & 1)) + decode_bypass_bits(s, (py >> 1) - 1);
   int scan_idx = 0;
-  if (log2n == 2 || (log2n == 3 && (c_idx == 0 || s.chroma_format_idc == 3))) {   // 7.4.9.11: 8x8 chroma blocks too with ChromaArrayType 3
+  if (log2n == 2 || (log2n == 3 && (c_idx == 0 || pc_is444(s)))) {   // 7.4.9.11: 8x8 chroma blocks too with ChromaArrayType 3
     if (pred_mode >= 6 && pred_mode <= 14) scan_idx = 2;
     else if (pred_mode >= 22 && pred_mode <= 30) scan_idx = 1;
   }
@@ -1023,7 +1031,7 @@ PC_DEV void pcm_coding_unit(PS& s, int zb, int log2cb, int16_t* coef_y, int16_t*
   int nacc = 0;
   // chroma: one block of half the CU size (4:2:0), of CU size (4:4:4), or - 4:2:2: half as wide, as tall - two square blocks one above the other,
   // which in raster order are simply the first and the second half of the samples
-  const int cfi = s.chroma_format_idc;
+  const int cfi = pc_is444(s) ? 3 : (pc_is422(s) ? 2 : (s.chroma_format_idc ? 1 : 0));
   for (int k = 0; k < (cfi ? (cfi == 2 ? 5 : 3) : 1); k++) {
     const int c = cfi == 2 ? (k + 1) >> 1 : k, t = cfi == 2 ? ((k + 1) & 1) : 0;   // 4:2:2: k = 0 luma, 1 / 2 Cb upper / lower, 3 / 4 Cr
     const int lg = (c && cfi != 3) ? log2cb - 1 : log2cb, n2 = 1 << (2 * lg);
@@ -1103,7 +1111,7 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
     map_fill(s.m_ipm, zb + k * pu_units, pu_units, (uint32_t)mode);
   }
   // intra_chroma_pred_mode: one per coding unit, or one per partition of an NxN coding unit when ChromaArrayType is 3 (7.3.8.5)
-  const int c444 = s.chroma_format_idc == 3;
+  const int c444 = pc_is444(s);
   int chroma_mode = 1;
   if (s.chroma_format_idc) {
     const int n_cp = (c444 && part_nxn) ? 4 : 1, cp_units = n_units / n_cp;
@@ -1113,7 +1121,7 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
       const int lm = (int)(map_get(s.m_ipm, zb + k * cp_units) & 63u);
       if (icpm == 4) chroma_mode = lm;
       else { const int m = icpm == 0 ? 0 : icpm == 1 ? 26 : icpm == 2 ? 10 : 1; chroma_mode = (m == lm) ? 34 : m; }
-      if (s.chroma_format_idc == 2) chroma_mode = (int)c_map422[chroma_mode];   // 8.4.3, Table 8-3: the 4:2:2 sampling grid is not square
+      if (pc_is422(s)) chroma_mode = (int)c_map422[chroma_mode];   // 8.4.3, Table 8-3: the 4:2:2 sampling grid is not square
       map_fill(s.m_ipmc, zb + k * cp_units, cp_units, (uint32_t)chroma_mode);
     }
   } else map_fill(s.m_ipmc, zb, n_units, 1u);
@@ -1121,7 +1129,7 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
   // ---- transform tree ----
   const int max_trafo_depth = s.max_th_depth_intra + part_nxn;
   uint32_t cbf_cb_bits = 0, cbf_cr_bits = 0;  // bit d = cbf at trafoDepth d along the current path; 4:2:2: bit 8 + d = the flag of the lower chroma block
-  const int c422 = s.chroma_format_idc == 2;
+  const int c422 = pc_is422(s);
   int q = 0;
   while (q < n_units && !s.err) {
     int t;  // log2 size of the node that starts at q
@@ -1462,6 +1470,7 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
   s.log2_min_tb = (int32_t)uload32(&P->log2_min_tb); s.log2_max_tb = (int32_t)uload32(&P->log2_max_tb);
   s.max_th_depth_intra = (int32_t)uload32(&P->max_th_depth_intra);
   s.chroma_format_idc = (int32_t)uload32(&P->chroma_format_idc);
+  if (!HIPDEC_PARSE_CHROMA_GENERAL && s.chroma_format_idc >= 2) s.err = DEV_ERR_SYNTAX;   // (the host launches the general build for such batches)
   s.bit_depth_luma = (int32_t)uload32(&P->bit_depth_luma); s.bit_depth_chroma = (int32_t)uload32(&P->bit_depth_chroma);
   s.log2_min_cu_qp_delta_size = (int32_t)uload32(&P->log2_min_cu_qp_delta_size);
   const int ctb_w = (int32_t)uload32(&P->ctb_w);
@@ -1568,7 +1577,7 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
     if (!(s.tools & TOOL_CUQPD)) { s.is_cu_qp_delta_coded = 0; s.cu_qp_delta_val = 0; s.qpy_pred = s.last_qp_y; }
 
     int16_t* coef_y = (int16_t*)(arena + uload64(&P->off_coeff[0])) + (size_t)ctb_rs * ctb_size * ctb_size;
-    const int cc_shift = s.chroma_format_idc == 3 ? 0 : (s.chroma_format_idc == 2 ? 1 : 2);   // chroma samples per CTB = luma samples >> cc_shift
+    const int cc_shift = pc_is444(s) ? 0 : (pc_is422(s) ? 1 : 2);   // chroma samples per CTB = luma samples >> cc_shift
     int16_t* coef_cb = (int16_t*)(arena + uload64(&P->off_coeff[1])) + (size_t)ctb_rs * ((ctb_size * ctb_size) >> cc_shift);
     int16_t* coef_cr = (int16_t*)(arena + uload64(&P->off_coeff[2])) + (size_t)ctb_rs * ((ctb_size * ctb_size) >> cc_shift);
 

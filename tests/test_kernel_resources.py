@@ -64,7 +64,9 @@ def test_occupancy_budgets():
                                                                       # (120 B before pcm_sample and the dependent-slice-segment state hand-over, 148 B with them, 164 B with the
                                                                       #  operand registers of the hand-scheduled CABAC statements of round 3)
     parse7 = _find(ks, "k_parse_occ7")[0]
-    assert parse7["vgpr"] <= 72 and parse7["scratch"] <= 152          # (a sweep variant, not a default: 124 B in round 3, 144 B with the 4:2:2 / 4:4:4 block loops)
+    assert parse7["vgpr"] <= 72 and parse7["scratch"] <= 136
+    gen8 = _find(ks, "k_parse_gen_occ8")[0]                               # the build with the 4:2:2 / 4:4:4 paths (batches that hold such pictures)
+    assert gen8["vgpr"] <= 64 and gen8["scratch"] <= 184
     recon8 = _find(ks, "k_recon8")[0]
     assert recon8["vgpr"] <= 72 and recon8["scratch"] <= 128 and recon8["lds"] <= 6400   # 7 waves / SIMD, 26 one-wave groups per CU
     residual = _find(ks, "k_residual")[0]
