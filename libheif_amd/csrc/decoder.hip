@@ -206,7 +206,7 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
   if (int rc = step("parse")) return rc;
   if (split) HIPDEC_CHECK_HIP(hipStreamWaitEvent(ps, ev[1], 0));
   static const bool parse_only = getenv("HIPDEC_DEBUG_PARSE_ONLY") != nullptr;   // tuning knob: isolate the CABAC kernel
-  if (!parse_only) launch_residual(fa, n, b.max_ctbs, ps);
+  if (!parse_only) launch_residual(fa, n, b.max_ctbs, pa.general_chroma != 0, ps);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[2], ps));
   if (int rc = step("residual")) return rc;
   if (!parse_only) launch_recon(ra, b.wide, ps);

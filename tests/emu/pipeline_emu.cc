@@ -23,7 +23,9 @@ int emu_run_pipeline_rgb(EmuBatch* b, int stages, uint8_t* rgb)
   ReconArgs ra{(const PicParams*)(a + L.off_pics), (const ReconWave*)(a + L.off_rwaves), L.num_rwaves, a,
                (uint32_t*)(a + L.off_row_progress), (uint32_t*)(a + L.off_ticket) + 1, (int32_t*)(a + L.off_status)};
   FilterArgs fa{(const PicParams*)(a + L.off_pics), a, (const int32_t*)(a + L.off_status)};
-  if (stages & 1) launch_residual(fa, n, L.max_ctbs, nullptr);
+  bool general = false;
+  for (const PicParams& P : L.params) if (P.chroma_format_idc >= 2) general = true;
+  if (stages & 1) launch_residual(fa, n, L.max_ctbs, general, nullptr);
   if (stages & 2) launch_recon(ra, L.wide, nullptr);
   if (stages & 4) launch_deblock(fa, n, L.max_w, L.max_h, L.wide, nullptr);
   bool may_keep = false, restricted = false;   // as decoder.hip:launch_all picks the kernel variant
