@@ -71,6 +71,9 @@ WORKLOADS = {
     "still1080": (1920, 1080, 1024, 8, dict(wpp=1), 10),
     "main10_4k": (3840, 2160, 256, 10, dict(wpp=1, vui_matrix=9, vui_primaries=9, vui_transfer=16), 14),
     "grid8k": (1024, 1024, 48, 8, dict(wpp=1, vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1), 10),
+    # 4:4:4 to RGB24 through Op_YCbCr_to_RGB + Op_RGB_to_RGB24_32 (no fused form); 4:2:2 Main10 (what cameras write) as planes: output chroma None
+    "still1080_444": (1920, 1080, 512, 8, dict(wpp=1, chroma_format_idc=3), 10),
+    "still1080_422_10": (1920, 1080, 512, 10, dict(wpp=1, chroma_format_idc=2), None),
 }
 
 
@@ -114,13 +117,17 @@ class Workload:
         self.batches = []
         for st in self.part_streams:
             b = Batch(st)                       # host header parsing + upload: outside the resident form's timed region
-            b.alloc_rgb(self.out_chroma)
+            if self.out_chroma is not None:
+                b.alloc_rgb(self.out_chroma)
             self.batches.append(b)
         return self.batches
 
     def step_resident(self):
         for b in self.batches:
-            b.run_rgb()        # decode + colour stage (fused into the SAO store path for 8-bit 4:2:0 -> RGB24)
+            if self.out_chroma is None:
+                b.run()        # planes only
+            else:
+                b.run_rgb()    # decode + colour stage (fused into the SAO store path for 8-bit 4:2:0 -> RGB24)
 
     def status(self):
         for b in self.batches:
@@ -148,13 +155,14 @@ def kernel_times(batches, steps):
     return {k: v / steps for k, v in acc.items()}
 
 
-def coded_fraction(batch):
-    """coded samples per luma pixel (luma + 2 x quarter-size chroma) from the device unit maps of item 0"""
+def coded_fraction(batch, chroma_weight=0.25):
+    """coded samples per luma pixel (luma + 2 x chroma at chroma_weight samples per luma pixel: 0.25 / 0.5 / 1 for 4:2:0 / 4:2:2 / 4:4:4) from the
+    device unit maps of item 0 (4:2:2: a unit's flags describe the upper one of its two chroma blocks)"""
     m = batch.maps(0)["flags"]
-    return float((m & 1).mean() + 0.25 * ((m >> 1) & 1).mean() + 0.25 * ((m >> 2) & 1).mean())
+    return float((m & 1).mean() + chroma_weight * ((m >> 1) & 1).mean() + chroma_weight * ((m >> 2) & 1).mean())
 
 
-def alg_bytes(beta, coded, s, s_out):
+def alg_bytes(beta, coded, s, s_out, spp=1.5):
     """algorithmic bytes per luma pixel: s = bytes per sample, s_out = bytes per output sample
          parse     beta (bitstream) in + 5/16 B unit maps + 2 B per coded sample (coefficient levels) out
          residual  2 B per coded sample in + 2 B out (in place)
@@ -162,8 +170,9 @@ def alg_bytes(beta, coded, s, s_out):
          deblock   3 s + 1/16 (bS / QP metadata), both edge directions together          (§8d "deblock")
          sao       1.5 s in + 1.5 s out                                                   (§8d "SAO")
          colour    1.5 s in + 3 s_out out                                                 (§8d "fused colour stage")"""
-    return dict(parse=beta + 5 / 16 + 2 * coded, residual=4 * coded, recon=1.5 * s + 2 * coded, deblock=3 * s + 1 / 16,
-                sao=3 * s, colour=1.5 * s + 3 * s_out)
+    # spp = samples per luma pixel over the three planes: 1.5 (4:2:0; the figures above), 2 (4:2:2), 3 (4:4:4)
+    return dict(parse=beta + 5 / 16 + 2 * coded, residual=4 * coded, recon=spp * s + 2 * coded, deblock=2 * spp * s + 1 / 16,
+                sao=2 * spp * s, colour=spp * s + 3 * s_out)
 
 
 def kernel_table(avg_us, alg, px):
@@ -210,6 +219,9 @@ def main():
             "s4_main10_4k": ("main10_4k", [(3840, 2160, 3 + i, 10, dict(WORKLOADS["main10_4k"][4], qp=a.qp)) for i in range(64)], 768),
             "s5_1080p": ("still1080", [(1920, 1080, 1000 + i, 8, dict(wpp=1, qp=a.qp)) for i in range(256)], 2048),
             "s3_grid8k": ("grid8k", [(1024, 1024, 2 + t, 8, dict(WORKLOADS["grid8k"][4], qp=a.qp)) for t in range(48)], 48),
+            # beyond SURVEY 8(d): the chroma formats added in round 3
+            "s6_444_1080p": ("still1080_444", [(1920, 1080, 2000 + i, 8, dict(WORKLOADS["still1080_444"][4], qp=a.qp)) for i in range(32)], 512),
+            "s7_422_main10_1080p": ("still1080_422_10", [(1920, 1080, 3000 + i, 10, dict(WORKLOADS["still1080_422_10"][4], qp=a.qp)) for i in range(32)], 512),
             # tiles-within-tiles expose more CABAC substreams per grid tile (WPP rows inside PPS tiles): 16 -> 32 -> 64
             "s3t_grid8k_pps_tiles_2x2": ("grid8k", [(1024, 1024, 2 + t, 8, dict(WORKLOADS["grid8k"][4], qp=a.qp, tile_cols=2, tile_rows=2)) for t in range(48)], 48),
             "s3t_grid8k_pps_tiles_4x4": ("grid8k", [(1024, 1024, 2 + t, 8, dict(WORKLOADS["grid8k"][4], qp=a.qp, tile_cols=4, tile_rows=4)) for t in range(48)], 48),
@@ -478,11 +490,17 @@ def main():
             eavg = kernel_times(e.batches, 2)
             es, eso = (2 if ebd > 8 else 1), (2 if eout in (12, 14) else 1)
             ebeta = e.bs_bytes / e.px
-            extras[key] = {"workload": "%d x %dx%d %d-bit stills (%d distinct), QP %d, fused YCbCr->%s" %
-                                       (n, ew, eh, ebd, len(st), sp[0][4].get("qp", a.qp), "RGB24" if eout == 10 else "RRGGBB"),
+            ecf = sp[0][4].get("chroma_format_idc", 1)
+            espp, ecw = {1: (1.5, 0.25), 2: (2.0, 0.5), 3: (3.0, 1.0)}[ecf]
+            ekt = kernel_table(eavg, alg_bytes(ebeta, coded_fraction(eb, ecw), es, eso, espp), e.px)
+            if eout is None:
+                ekt.pop("colour", None)
+            extras[key] = {"workload": "%d x %dx%d %d-bit %s stills (%d distinct), QP %d, %s" %
+                                       (n, ew, eh, ebd, {1: "4:2:0", 2: "4:2:2", 3: "4:4:4"}[ecf], len(st), sp[0][4].get("qp", a.qp),
+                                        "planes only" if eout is None else ("YCbCr->" + ("RGB24" if eout == 10 else "RRGGBB") + (" fused into SAO" if ecf == 1 else ""))),
                            "value": round(e.px / (el / 2) / 1e6, 2), "unit": "Mpixel/s", "ms_per_step": round(el / 2 * 1e3, 3),
                            "bitstream_bytes_per_px": round(ebeta, 4),
-                           "kernels": kernel_table(eavg, alg_bytes(ebeta, coded_fraction(eb), es, eso), e.px)}
+                           "kernels": ekt}
             e.free()
         out["extra_workloads"] = extras
 

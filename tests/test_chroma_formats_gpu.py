@@ -94,6 +94,26 @@ def test_planes_to_rgb24_match_the_oracle_chain(vui, cf):
     np.testing.assert_array_equal(rgb, orc.color_rgb_planar_to_interleaved8(r, g, bb).reshape(136, -1))
 
 
+@pytest.mark.parametrize("cfs", [(3, 3, 3), (2, 2, 2), (1, 3, 2, 1)], ids=["444", "422", "mixed"])
+def test_run_rgb_on_batches_with_other_chroma_formats(cfs):
+    """hipdec_batch_run_rgb: such batches take the unfused path (decode, then ONE batched colour launch); every item's RGB equals the per-item
+    colour stage, which the test above pins to the oracle chain"""
+    from libheif_amd.decoder import Batch
+    vui = dict(vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1)
+    streams = [orc.encode(orc.synth_image(200 + 64 * k, 136, 8, cf, seed=60 + k), **vui) for k, cf in enumerate(cfs)]
+    f = Batch(streams); f.alloc_rgb(10); f.run_rgb(); f.status()
+    f.run_rgb(); f.status()
+    assert f.kernel_timing_us()["colour"] > 0.0                 # not the fused SAO + RGB kernel
+    for i, st in enumerate(streams):
+        one = Batch([st]); one.run(); one.status()
+        np.testing.assert_array_equal(f.rgb(i), one.to_rgb(0, 10))
+        ref = orc.decode(st)
+        for c in range(3):
+            np.testing.assert_array_equal(f.planes(i)[c], ref["planes"][c])
+        one.free()
+    f.free()
+
+
 @FORMATS
 def test_main10_to_rrggbb_is_refused_loudly(cf):
     from libheif_amd.decoder import Batch

@@ -33,7 +33,8 @@ def make_stream(w, h, seed=1, bit_depth=8, **cfg):
         with open(path, "rb") as f:
             return f.read()
     from oracle import pyoracle as orc
-    planes = orc.synth_image(w, h, bit_depth, 1, seed=seed)
+    cfg = dict(cfg)
+    planes = orc.synth_image(w, h, bit_depth, cfg.pop("chroma_format_idc", 1), seed=seed)    # (the encoder takes the chroma format from the plane shapes)
     data = orc.encode(planes, bit_depth=bit_depth, **cfg)
     tmp = path + ".%d.tmp" % os.getpid()
     with open(tmp, "wb") as f:
