@@ -175,10 +175,12 @@ def alg_bytes(beta, coded, s, s_out, spp=1.5):
                 sao=2 * spp * s, colour=spp * s + 3 * s_out)
 
 
-def kernel_table(avg_us, alg, px):
+def kernel_table(avg_us, alg, px, colour_stage=True):
     out = {}
     keys = list(KERNEL_KEYS)
-    if avg_us["colour"] == 0.0 and avg_us["sao"] > 0.0:
+    if not colour_stage:
+        keys = [k for k in keys if k != "colour"]          # planes only: no colour stage ran, the SAO kernel is the plain one
+    elif avg_us["colour"] == 0.0 and avg_us["sao"] > 0.0:
         # the colour stage ran inside the SAO kernel (k_sao_rgb): one pass reads the deblocked picture (1.5 s) and writes the planes (1.5 s) and
         # the interleaved RGB (3 s_out); the separate colour pass's re-read of the planes is gone
         keys = [k for k in keys if k not in ("sao", "colour")] + ["sao_rgb"]
@@ -492,9 +494,7 @@ def main():
             ebeta = e.bs_bytes / e.px
             ecf = sp[0][4].get("chroma_format_idc", 1)
             espp, ecw = {1: (1.5, 0.25), 2: (2.0, 0.5), 3: (3.0, 1.0)}[ecf]
-            ekt = kernel_table(eavg, alg_bytes(ebeta, coded_fraction(eb, ecw), es, eso, espp), e.px)
-            if eout is None:
-                ekt.pop("colour", None)
+            ekt = kernel_table(eavg, alg_bytes(ebeta, coded_fraction(eb, ecw), es, eso, espp), e.px, colour_stage=eout is not None)
             extras[key] = {"workload": "%d x %dx%d %d-bit %s stills (%d distinct), QP %d, %s" %
                                        (n, ew, eh, ebd, {1: "4:2:0", 2: "4:2:2", 3: "4:4:4"}[ecf], len(st), sp[0][4].get("qp", a.qp),
                                         "planes only" if eout is None else ("YCbCr->" + ("RGB24" if eout == 10 else "RRGGBB") + (" fused into SAO" if ecf == 1 else ""))),
