@@ -387,7 +387,14 @@ void parse_pps(NalReader& r, Pps& p)
   if (r.u(1)) {
     bool range_ext = r.u(1);
     r.skip(7);
-    if (range_ext) unsupported("PPS range extension");
+    if (range_ext) {
+      // 7.3.2.3.2 pps_range_extension(): accepted when it switches nothing on (encoders of the format-range-extension profiles write it for
+      // 4:2:2 / 4:4:4 streams); every tool it can enable is outside this decoder
+      if (p.transform_skip && r.ue_max(3, "log2_max_transform_skip_block_size_minus2") != 0) unsupported("transform skip blocks larger than 4x4");
+      if (r.u(1)) unsupported("cross-component prediction");
+      if (r.u(1)) unsupported("chroma QP offset lists");
+      if (r.ue_max(6, "log2_sao_offset_scale_luma") != 0 || r.ue_max(6, "log2_sao_offset_scale_chroma") != 0) unsupported("SAO offset scaling");
+    }
   }
   p.valid = true;
 }

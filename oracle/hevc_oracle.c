@@ -708,7 +708,12 @@ static void parse_pps(Dec* d, const uint8_t* rbsp, size_t n)
   if (br_u(&b, 1)) { /* pps_extension_present_flag */
     int range_ext = br_u(&b, 1);
     br_u(&b, 7);
-    if (range_ext) fail(d, "unsupported: PPS range extension");
+    if (range_ext) {   /* 7.3.2.3.2: accepted when it enables nothing */
+      if (p->transform_skip_enabled_flag && br_ue(&b) != 0) fail(d, "unsupported: transform skip blocks larger than 4x4");
+      if (br_u(&b, 1)) fail(d, "unsupported: cross-component prediction");
+      if (br_u(&b, 1)) fail(d, "unsupported: chroma QP offset lists");
+      if (br_ue(&b) != 0 || br_ue(&b) != 0) fail(d, "unsupported: SAO offset scaling");
+    }
   }
   p->valid = 1;
   d->pps[id] = *p;

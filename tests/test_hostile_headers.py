@@ -91,7 +91,12 @@ def pps(**o):
         for v in tiles.get("row_h_m1", []): b.ue(v)
         b.u(1, 1)
     b.u(1, 1)                       # loop filter across slices
-    b.u(1, 0).u(1, 0).u(1, 0).ue(0).u(1, 0).u(1, 0)
+    b.u(1, 0).u(1, 0).u(1, 0).ue(0).u(1, 0)
+    rext = g("range_ext", None)     # pps_range_extension(): (cross_component_prediction, chroma_qp_offset_list_enabled, log2_sao_offset_scale_luma, _chroma)
+    b.u(1, 1 if rext else 0)
+    if rext:
+        b.u(1, 1).u(7, 0)
+        b.u(1, rext[0]).u(1, rext[1]).ue(rext[2]).ue(rext[3])
     return nal(34, b.rbsp())
 
 
@@ -158,6 +163,9 @@ HOSTILE = {
     "init_qp out of range": sps() + pps(init_qp_m26=80) + idr(),
     "chroma_format_idc 7": sps(chroma_format_idc=7) + pps() + idr(),
     "65 short-term RPS": sps(num_st_rps=65) + pps() + idr(),
+    "cross-component prediction": sps() + pps(range_ext=(1, 0, 0, 0)) + idr(),
+    "chroma qp offset lists": sps() + pps(range_ext=(0, 1, 0, 0)) + idr(),
+    "sao offset scale": sps() + pps(range_ext=(0, 0, 0, 2)) + idr(),
     "sps id 16": sps(sps_id=16) + pps() + idr(),
 }
 
@@ -167,6 +175,18 @@ def test_hostile_headers_are_rejected_cleanly(name):
     rc, msg = probe(HOSTILE[name])
     assert rc < 0 and msg, (name, rc, msg)
     assert rc in (-3, -4, -5), (name, rc, msg)      # bitstream / unsupported / limit: never a crash, never "memory"
+
+
+def test_pps_range_extension_that_enables_nothing_is_accepted():
+    rc, msg = probe(sps() + pps(range_ext=(0, 0, 0, 0)) + idr())
+    assert rc == 0, msg
+    from oracle import pyoracle as orc
+    with pytest.raises(orc.OracleError) as e:                       # the oracle parses it the same way (then runs out of slice data)
+        orc.decode(sps() + pps(range_ext=(0, 0, 0, 0)) + idr())
+    assert "unsupported" not in str(e.value)
+    with pytest.raises(orc.OracleError) as e:
+        orc.decode(sps() + pps(range_ext=(1, 0, 0, 0)) + idr())
+    assert "cross-component" in str(e.value)
 
 
 def test_size_limit_is_applied_before_any_table_is_sized():

@@ -25,6 +25,16 @@ rng=random.Random(int(sys.argv[1]))
 n=int(sys.argv[2])
 cfgs=[dict(scaling_list=2, stress=1), dict(scaling_list=3), dict(), dict(stress=1, num_slices=2), dict(log2_ctb=4,log2_min_cb=3,log2_max_tb=4,stress=1), dict(bit_depth=10), dict(wpp=0, transform_skip=1, lossless_pct=10), dict(pcm_pct=30, stress=1), dict(pcm_pct=25, pcm_loop_filter_disabled=1, bit_depth=10), dict(dependent_segments=3, wpp=0, stress=1), dict(dependent_segments=2, num_slices=2, wpp=1)]
 base=[orc.encode(orc.synth_image(136,72,c.get('bit_depth',8),1,seed=3+i),**c) for i,c in enumerate(cfgs)]
+# 4:2:2 and 4:4:4 (HIPDEC_FUZZ_CHROMA=2 / 3 / "all"): the same tool mixes minus what the format does not take
+cf_env=os.environ.get('HIPDEC_FUZZ_CHROMA','')
+if cf_env:
+    fmts=[2,3] if cf_env=='all' else [int(cf_env)]
+    base=[] if cf_env!='all' else base
+    for cf in fmts:
+        for i,c in enumerate(cfgs):
+            c=dict(c)
+            if cf==3: c.pop('scaling_list',None)
+            base.append(orc.encode(orc.synth_image(136,72,c.get('bit_depth',8),cf,seed=3+i),**c))
 print('clean:', [run(s) for s in base]); sys.stdout.flush()
 res={}
 for it in range(n):
