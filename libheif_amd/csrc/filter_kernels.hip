@@ -47,56 +47,112 @@ __device__ __forceinline__ size_t unit_index(const PicParams& P, int ux, int uy,
   return ((size_t)c << P.units_per_ctb_log2) + interleave4((uint32_t)(ux & mask), (uint32_t)(uy & mask));
 }
 
-// luma edge segment of 4 lines; pix -> q0 of line 0; xs = step across the edge, ys = step along it
-template <typename Pix>
-__device__ __forceinline__ void deblock_luma(Pix* pix, int xs, int ys, int qp_p, int qp_q, int beta_off2, int tc_off2, int bit_depth, int no_p,
-                                             int no_q)
+// The 8 x 4 window of a luma edge segment (4 lines along the edge, 4 samples on either side) in registers, moved with whole-dword accesses:
+// a vertical edge's lines are picture rows (8 contiguous samples each: x is a multiple of 8, so the window starts dword-aligned), a horizontal
+// edge's lines are columns (every picture row of the window is 4 contiguous samples).  Windows of different segments never overlap (edges are
+// 8 apart), so writing a whole window back - unchanged samples included - races with nobody.  (Byte accesses made this kernel issue 32 loads and
+// up to 24 stores per segment.)   p[k][i] / q[k][i]: line k, distance i from the edge
+template <typename Pix, int DIR>
+struct EdgeWindow {
+  static constexpr int ES = (int)sizeof(Pix), NW = ES == 1 ? 8 : 16;
+  uint32_t w[NW];   // packed as loaded: the samples are extracted line by line, so the live set stays small (8 waves per SIMD)
+  __device__ __forceinline__ void load(const Pix* pix, int stride)
+  {
+    if (DIR == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t* src = (const uint32_t*)(pix + (size_t)k * stride - 4);
+#pragma unroll
+        for (int i = 0; i < 2 * ES; i++) w[2 * ES * k + i] = src[i];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; r++) {           // picture rows y - 4 .. y + 3
+        const uint32_t* src = (const uint32_t*)(pix + (ptrdiff_t)(r - 4) * stride);
+#pragma unroll
+        for (int i = 0; i < ES; i++) w[ES * r + i] = src[i];
+      }
+    }
+  }
+  __device__ __forceinline__ void store(Pix* pix, int stride) const
+  {
+    if (DIR == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t* dst = (uint32_t*)(pix + (size_t)k * stride - 4);
+#pragma unroll
+        for (int i = 0; i < 2 * ES; i++) dst[i] = w[2 * ES * k + i];
+      }
+    } else {
+#pragma unroll
+      for (int r = 1; r < 7; r++) {           // rows p2 .. q2: the outermost rows (p3, q3) are never modified
+        uint32_t* dst = (uint32_t*)(pix + (ptrdiff_t)(r - 4) * stride);
+#pragma unroll
+        for (int i = 0; i < ES; i++) dst[i] = w[ES * r + i];
+      }
+    }
+  }
+  // sample of line k at position j across the edge: j = 0 .. 3 are p3 .. p0, j = 4 .. 7 are q0 .. q3
+  static __device__ __forceinline__ int word(int k, int j) { return DIR == 0 ? (ES == 1 ? 2 * k + (j >> 2) : 4 * k + (j >> 1)) : (ES == 1 ? j : 2 * j + (k >> 1)); }
+  static __device__ __forceinline__ int shift(int k, int j) { return DIR == 0 ? (ES == 1 ? 8 * (j & 3) : 16 * (j & 1)) : (ES == 1 ? 8 * k : 16 * (k & 1)); }
+  __device__ __forceinline__ int get(int k, int j) const { return (int)((w[word(k, j)] >> shift(k, j)) & (ES == 1 ? 255u : 0xffffu)); }
+  __device__ __forceinline__ void set(int k, int j, int v)
+  {
+    const uint32_t m = (ES == 1 ? 255u : 0xffffu) << shift(k, j);
+    w[word(k, j)] = (w[word(k, j)] & ~m) | ((uint32_t)v << shift(k, j));
+  }
+};
+
+// luma edge segment of 4 lines (8.7.2.5.3 decisions, 8.7.2.5.7 filters); pix -> q0 of line 0.  DIR 0: vertical edge (lines are rows), 1: horizontal
+template <typename Pix, int DIR>
+__device__ __forceinline__ void deblock_luma(Pix* pix, int stride, int qp_p, int qp_q, int beta_off2, int tc_off2, int bit_depth, int no_p, int no_q)
 {
   const int qpl = (qp_q + qp_p + 1) >> 1;
   const int beta = c_beta[clip3(0, 51, qpl + (beta_off2 << 1))] * (1 << (bit_depth - 8));
   const int tc = c_tc[clip3(0, 53, qpl + 2 + (tc_off2 << 1))] * (1 << (bit_depth - 8));
-  int p[4][4], q[4][4];  // [line][i]
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-#pragma unroll
-    for (int i = 0; i < 4; i++) { p[k][i] = pix[-(i + 1) * xs + k * ys]; q[k][i] = pix[i * xs + k * ys]; }
-  const int dp0 = iabs(p[0][2] - 2 * p[0][1] + p[0][0]), dp3 = iabs(p[3][2] - 2 * p[3][1] + p[3][0]);
-  const int dq0 = iabs(q[0][2] - 2 * q[0][1] + q[0][0]), dq3 = iabs(q[3][2] - 2 * q[3][1] + q[3][0]);
+  EdgeWindow<Pix, DIR> W;
+  W.load(pix, stride);
+#define WP(k, i) W.get(k, 3 - (i))
+#define WQ(k, i) W.get(k, 4 + (i))
+  const int dp0 = iabs(WP(0, 2) - 2 * WP(0, 1) + WP(0, 0)), dp3 = iabs(WP(3, 2) - 2 * WP(3, 1) + WP(3, 0));
+  const int dq0 = iabs(WQ(0, 2) - 2 * WQ(0, 1) + WQ(0, 0)), dq3 = iabs(WQ(3, 2) - 2 * WQ(3, 1) + WQ(3, 0));
   const int dpq0 = dp0 + dq0, dpq3 = dp3 + dq3, dp = dp0 + dp3, dq = dq0 + dq3;
   if (dpq0 + dpq3 >= beta) return;
-  const int s0 = (2 * dpq0 < (beta >> 2)) && (iabs(p[0][3] - p[0][0]) + iabs(q[0][0] - q[0][3]) < (beta >> 3)) &&
-                 (iabs(p[0][0] - q[0][0]) < ((5 * tc + 1) >> 1));
-  const int s3 = (2 * dpq3 < (beta >> 2)) && (iabs(p[3][3] - p[3][0]) + iabs(q[3][0] - q[3][3]) < (beta >> 3)) &&
-                 (iabs(p[3][0] - q[3][0]) < ((5 * tc + 1) >> 1));
+  const int s0 = (2 * dpq0 < (beta >> 2)) && (iabs(WP(0, 3) - WP(0, 0)) + iabs(WQ(0, 0) - WQ(0, 3)) < (beta >> 3)) &&
+                 (iabs(WP(0, 0) - WQ(0, 0)) < ((5 * tc + 1) >> 1));
+  const int s3 = (2 * dpq3 < (beta >> 2)) && (iabs(WP(3, 3) - WP(3, 0)) + iabs(WQ(3, 0) - WQ(3, 3)) < (beta >> 3)) &&
+                 (iabs(WP(3, 0) - WQ(3, 0)) < ((5 * tc + 1) >> 1));
   const int strong = s0 && s3;
   const int dep = dp < ((beta + (beta >> 1)) >> 3), deq = dq < ((beta + (beta >> 1)) >> 3);
   const int maxv = (1 << bit_depth) - 1;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int p0 = p[k][0], p1 = p[k][1], p2 = p[k][2], p3 = p[k][3], q0 = q[k][0], q1 = q[k][1], q2 = q[k][2], q3 = q[k][3];
-    Pix* l = pix + k * ys;
+    const int p0 = WP(k, 0), p1 = WP(k, 1), p2 = WP(k, 2), p3 = WP(k, 3), q0 = WQ(k, 0), q1 = WQ(k, 1), q2 = WQ(k, 2), q3 = WQ(k, 3);
     if (strong) {
       if (!no_p) {
-        l[-1 * xs] = (Pix)clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
-        l[-2 * xs] = (Pix)clip3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2);
-        l[-3 * xs] = (Pix)clip3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+        W.set(k, 3, clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3));
+        W.set(k, 2, clip3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2));
+        W.set(k, 1, clip3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3));
       }
       if (!no_q) {
-        l[0] = (Pix)clip3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
-        l[xs] = (Pix)clip3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2);
-        l[2 * xs] = (Pix)clip3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3);
+        W.set(k, 4, clip3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3));
+        W.set(k, 5, clip3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2));
+        W.set(k, 6, clip3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3));
       }
     } else {
       int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
       if (iabs(delta) < tc * 10) {
         delta = clip3(-tc, tc, delta);
-        if (!no_p) l[-xs] = (Pix)clip3(0, maxv, p0 + delta);
-        if (!no_q) l[0] = (Pix)clip3(0, maxv, q0 - delta);
-        if (dep && !no_p) l[-2 * xs] = (Pix)clip3(0, maxv, p1 + clip3(-(tc >> 1), tc >> 1, (((p2 + p0 + 1) >> 1) - p1 + delta) >> 1));
-        if (deq && !no_q) l[xs] = (Pix)clip3(0, maxv, q1 + clip3(-(tc >> 1), tc >> 1, (((q2 + q0 + 1) >> 1) - q1 - delta) >> 1));
+        if (!no_p) W.set(k, 3, clip3(0, maxv, p0 + delta));
+        if (!no_q) W.set(k, 4, clip3(0, maxv, q0 - delta));
+        if (dep && !no_p) W.set(k, 2, clip3(0, maxv, p1 + clip3(-(tc >> 1), tc >> 1, (((p2 + p0 + 1) >> 1) - p1 + delta) >> 1)));
+        if (deq && !no_q) W.set(k, 5, clip3(0, maxv, q1 + clip3(-(tc >> 1), tc >> 1, (((q2 + q0 + 1) >> 1) - q1 - delta) >> 1)));
       }
     }
   }
+#undef WP
+#undef WQ
+  W.store(pix, stride);
 }
 
 template <typename Pix>
@@ -157,8 +213,7 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
     Pix* rec = (Pix*)(A.arena + P.off_rec[0]);
     const int stride = P.rec_stride[0] / sizeof(Pix);
     Pix* pix = rec + (size_t)y * stride + x;
-    if (DIR == 0) deblock_luma<Pix>(pix, 1, stride, qp_p, qp_q, sl.beta_offset_div2, sl.tc_offset_div2, P.bit_depth_luma, no_p, no_q);
-    else deblock_luma<Pix>(pix, stride, 1, qp_p, qp_q, sl.beta_offset_div2, sl.tc_offset_div2, P.bit_depth_luma, no_p, no_q);
+    deblock_luma<Pix, DIR>(pix, stride, qp_p, qp_q, sl.beta_offset_div2, sl.tc_offset_div2, P.bit_depth_luma, no_p, no_q);
   }
   if (P.chroma_format_idc == 3) {
     // 4:4:4: the chroma planes have the luma planes' edges (the 8-sample chroma grid IS the luma grid) and take the chroma filter
