@@ -261,6 +261,11 @@ HIPDEC_API int hipdec_color_420_to_rrggbb(const void* y, size_t ys, const void* 
                                           int little_endian, void* stream);
 /* Op_YCbCr420_bilinear_to_YCbCr444<Pixel> (chroma_sampling.cc:501-724), one chroma plane;
  * (w, h) = luma size; reproduces the reference's border indexing. */
+/* Op_YCbCr_to_RGB<uint16_t> (libheif/color-conversion/yuv2rgb.cc:92-292) + Op_RGB_HDR_to_RRGGBBaa_BE (rgb2rgb.cc:470-560) [+ the endianness swap]:
+ * > 8-bit planes of any chroma format (1 / 2 / 3) to interleaved RRGGBB at the input bit depth, one pass */
+HIPDEC_API int hipdec_color_ycbcr_to_rrggbb_float(const void* y, size_t ys, const void* cb, size_t cbs, const void* cr, size_t crs,
+                                                  int w, int h, int bpp, int chroma, const hipdec_nclx* nclx, void* out,
+                                                  size_t out_stride, int little_endian, void* stream);
 HIPDEC_API int hipdec_color_bilinear_420_to_444(const void* in, size_t is, int w, int h, int bpp, void* out, size_t os,
                                                 void* stream);
 /* Op_YCbCr422_bilinear_to_YCbCr444<Pixel> (chroma_sampling.cc:732-954), one chroma plane of ((w + 1) / 2) x h samples -> w x h. */
@@ -286,7 +291,9 @@ typedef enum hipdec_color_op {   /* the reference operations a plan is made of *
   HIPDEC_OP_YCBCR_TO_RGB = 5,           /* Op_YCbCr_to_RGB<Pixel>            yuv2rgb.cc:92-292 */
   HIPDEC_OP_RGB_TO_RGB24_32 = 6,        /* Op_RGB_to_RGB24_32                rgb2rgb.cc:72-150 (fused into the op before it) */
   HIPDEC_OP_420_TO_RRGGBB = 7,          /* Op_YCbCr420_to_RRGGBBaa           yuv2rgb.cc:622-734 */
-  HIPDEC_OP_BILINEAR_422_TO_444 = 8     /* Op_YCbCr422_bilinear_to_YCbCr444  chroma_sampling.cc:732-954 */
+  HIPDEC_OP_BILINEAR_422_TO_444 = 8,    /* Op_YCbCr422_bilinear_to_YCbCr444  chroma_sampling.cc:732-954 */
+  HIPDEC_OP_RGB_HDR_TO_RRGGBB_BE = 9,   /* Op_RGB_HDR_to_RRGGBBaa_BE         rgb2rgb.cc (fused into the op before it) */
+  HIPDEC_OP_SWAP_ENDIANNESS = 10        /* Op_RRGGBBaa_swap_endianness       rgb2rgb.cc:647-764 (fused likewise) */
 } hipdec_color_op;
 
 typedef struct hipdec_color_image {

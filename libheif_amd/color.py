@@ -31,6 +31,9 @@ def _planning_matrix(nclx):
     return (6 if m == 2 else m), int(nclx[3])
 
 
+_BILINEAR = {CHROMA_420: "Op_YCbCr420_bilinear_to_YCbCr444", CHROMA_422: "Op_YCbCr422_bilinear_to_YCbCr444"}
+
+
 def plan(bpp, chroma, nclx, target_chroma, upsampling=UPSAMPLING_BILINEAR, only_preferred=False):
     """Names of the reference ops the planner would chain (cost 11 each -> fewest steps wins)."""
     matrix, full = _planning_matrix(nclx)
@@ -43,14 +46,18 @@ def plan(bpp, chroma, nclx, target_chroma, upsampling=UPSAMPLING_BILINEAR, only_
         if chroma == CHROMA_420 and nn_allowed and full and matrix not in (0, 8):
             return ["Op_YCbCr420_to_RGB24" if target_chroma == CHROMA_RGB else "Op_YCbCr420_to_RGB32"]
         if chroma != CHROMA_444 and not nn_allowed:
-            return ["Op_YCbCr420_bilinear_to_YCbCr444", "Op_YCbCr_to_RGB<u8>", "Op_RGB_to_RGB24_32"]
+            return [_BILINEAR[chroma], "Op_YCbCr_to_RGB<u8>", "Op_RGB_to_RGB24_32"]
         return ["Op_YCbCr_to_RGB<u8>", "Op_RGB_to_RGB24_32"]
     if target_chroma in (CHROMA_RRGGBB_BE, CHROMA_RRGGBB_LE):
         if bpp <= 8:
             raise HipDecError(-4, "8-bit to RRGGBB needs Op_to_hdr_planes, outside the hot path")
         if chroma == CHROMA_420 and nn_allowed and matrix not in (0, 8):
             return ["Op_YCbCr420_to_RRGGBBaa"]
-        raise HipDecError(-4, "this RRGGBB chain is outside the hot path")
+        # everything else: the generic float op on the 16-bit planes, the interleave, the swap for little endian (checked against the compiled
+        # reference pipeline for 4:2:0 / 4:2:2 / 4:4:4 in tests/test_color_emu.py)
+        chain = [_BILINEAR[chroma]] if (chroma != CHROMA_444 and not nn_allowed) else []
+        chain += ["Op_YCbCr_to_RGB<u16>", "Op_RGB_HDR_to_RRGGBBaa_BE"]
+        return chain + (["Op_RRGGBBaa_swap_endianness"] if target_chroma == CHROMA_RRGGBB_LE else [])
     if target_chroma == CHROMA_444:
         if chroma == CHROMA_420 and upsampling == UPSAMPLING_BILINEAR:
             return ["Op_YCbCr420_bilinear_to_YCbCr444"]
@@ -94,11 +101,12 @@ def convert_colorspace(planes, bpp, chroma, nclx, target_chroma, upsampling=UPSA
         ys, cs = w, dp.cshape[1]
         steps = steps[1:]
     cur_chroma = chroma
-    if steps and steps[0] == "Op_YCbCr420_bilinear_to_YCbCr444":
+    if steps and steps[0] in _BILINEAR.values():
         new = []
+        up = lib.hipdec_color_bilinear_420_to_444 if steps[0] == _BILINEAR[CHROMA_420] else lib.hipdec_color_bilinear_422_to_444
         for buf in (cbb, crb):
             o = DeviceBuffer(w * h * es)
-            check(lib.hipdec_color_bilinear_420_to_444(buf.ptr, cs, w, h, bpp, o.ptr, w * es, None))
+            check(up(buf.ptr, cs, w, h, bpp, o.ptr, w * es, None))
             new.append(o)
         cbb, crb = new
         keep.append(new)
@@ -125,6 +133,11 @@ def convert_colorspace(planes, bpp, chroma, nclx, target_chroma, upsampling=UPSA
         out = DeviceBuffer(w * h * 6)
         check(lib.hipdec_color_420_to_rrggbb(yb.ptr, ys, cbb.ptr, cs, crb.ptr, cs, w, h, bpp, C.byref(ns), out.ptr, w * 6,
                                              int(target_chroma == CHROMA_RRGGBB_LE), None))
+    elif name == "Op_YCbCr_to_RGB<u16>":
+        bppx = 6
+        out = DeviceBuffer(w * h * 6)
+        check(lib.hipdec_color_ycbcr_to_rrggbb_float(yb.ptr, ys, cbb.ptr, cs, crb.ptr, cs, w, h, bpp, cur_chroma, C.byref(ns), out.ptr, w * 6,
+                                                     int(target_chroma == CHROMA_RRGGBB_LE), None))
     else:
         raise HipDecError(-4, "unplanned op " + name)
     check(lib.hipdec_stream_synchronize(None))

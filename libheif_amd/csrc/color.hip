@@ -596,6 +596,24 @@ int hipdec_color_420_to_rrggbb(const void* y, size_t ys, const void* cb, size_t 
   return little_endian ? launch_rgb<uint16_t, LO_RRGGBB_LE>(p, s) : launch_rgb<uint16_t, LO_RRGGBB_BE>(p, s);
 }
 
+/* Op_YCbCr_to_RGB<uint16_t> (yuv2rgb.cc:92-292, nearest-neighbour chroma for 4:2:0 / 4:2:2 inputs) + Op_RGB_HDR_to_RRGGBBaa_BE (rgb2rgb.cc)
+ * [+ Op_RRGGBBaa_swap_endianness for little endian] as ONE pass: what the reference's planner chains for > 8-bit planes of any chroma format that
+ * the 4:2:0-only op above does not take (4:2:2, 4:4:4, matrix_coefficients 0 / 8); the components keep the input bit depth */
+int hipdec_color_ycbcr_to_rrggbb_float(const void* y, size_t ys, const void* cb, size_t cbs, const void* cr, size_t crs, int w, int h,
+                                       int bpp, int chroma, const hipdec_nclx* nclx, void* out, size_t out_stride, int little_endian, void* stream)
+{
+  if (int rc = ensure_init()) return rc;
+  if (bpp <= 8 || bpp > 14) return set_error(HIPDEC_ERR_UNSUPPORTED, "ycbcr_to_rrggbb: bits per pixel %d outside 9..14", bpp);
+  if (nclx && nclx->has_nclx && (nclx->matrix_coefficients == 11 || nclx->matrix_coefficients == 14))
+    return set_error(HIPDEC_ERR_UNSUPPORTED, "ycbcr_to_rrggbb: matrix_coefficients %d unsupported (as in the reference)", nclx->matrix_coefficients);
+  ColorParams p;
+  if (int rc = fill_common(p, y, ys, cb, cbs, cr, crs, w, h, bpp, chroma, nclx)) return rc;
+  if (!out) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "ycbcr_to_rrggbb: out is NULL");
+  p.arith = generic_arith(nclx); p.o0 = (uint8_t*)out; p.os = out_stride;
+  hipStream_t s = stream ? (hipStream_t)stream : default_stream();
+  return little_endian ? launch_rgb<uint16_t, LO_RRGGBB_LE>(p, s) : launch_rgb<uint16_t, LO_RRGGBB_BE>(p, s);
+}
+
 int hipdec_color_bilinear_420_to_444(const void* in, size_t is, int w, int h, int bpp, void* out, size_t os, void* stream)
 {
   if (int rc = ensure_init()) return rc;

@@ -435,7 +435,10 @@ int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void* out_dev, s
   }
   if (out_chroma == 12 || out_chroma == 14) {
     if (!b->wide) return set_error(HIPDEC_ERR_UNSUPPORTED, "to_rgb: RRGGBB output needs >8-bit planes");
-    if (P.chroma_format_idc != 1) return set_error(HIPDEC_ERR_UNSUPPORTED, "to_rgb: RRGGBB output is implemented for 4:2:0 planes (Op_YCbCr420_to_RRGGBBaa)");
+    const int m = I.matrix_coeffs == 2 ? 6 : I.matrix_coeffs;
+    if (P.chroma_format_idc != 1 || m == 0 || m == 8)     // planner rule: the 4:2:0 op does not take these; Op_YCbCr_to_RGB<uint16_t> + the interleave does
+      return hipdec_color_ycbcr_to_rrggbb_float(y, P.out_stride[0], cb, P.out_stride[1], cr, P.out_stride[2], P.out_width, P.out_height, I.bit_depth_luma,
+                                                P.chroma_format_idc, &nclx, out_dev, out_stride, out_chroma == 14, s);
     return hipdec_color_420_to_rrggbb(y, P.out_stride[0], cb, P.out_stride[1], cr, P.out_stride[2], P.out_width, P.out_height, I.bit_depth_luma,
                                       &nclx, out_dev, out_stride, out_chroma == 14, s);
   }
@@ -1127,7 +1130,12 @@ int hipdec_color_plan(int bit_depth, int chroma, int has_alpha, const hipdec_ncl
     if (has_alpha) return set_error(HIPDEC_ERR_UNSUPPORTED, "color_plan: RRGGBB from an image with alpha is left to the stock ops");
     if (bit_depth <= 8) return set_error(HIPDEC_ERR_UNSUPPORTED, "color_plan: 8-bit to RRGGBB needs Op_to_hdr_planes, outside the hot path");
     if (chroma == 1 && nn_allowed && matrix != 0 && matrix != 8) { push(HIPDEC_OP_420_TO_RRGGBB); return 0; }
-    return set_error(HIPDEC_ERR_UNSUPPORTED, "color_plan: this RRGGBB chain is outside the hot path");
+    // every other state: the generic float op on the 16-bit planes (after the preferred upsampling when nearest neighbour is ruled out), then the
+    // interleave, then the swap for little endian
+    if (chroma != 3 && !nn_allowed) push(chroma == 1 ? HIPDEC_OP_BILINEAR_420_TO_444 : HIPDEC_OP_BILINEAR_422_TO_444);
+    push(HIPDEC_OP_YCBCR_TO_RGB); push(HIPDEC_OP_RGB_HDR_TO_RRGGBB_BE);
+    if (out_chroma == 14) push(HIPDEC_OP_SWAP_ENDIANNESS);
+    return 0;
   }
   return set_error(HIPDEC_ERR_UNSUPPORTED, "color_plan: output chroma %d is outside the HEIC hot path", out_chroma);
 }
@@ -1222,7 +1230,9 @@ int hipdec_color_convert(const hipdec_color_image* in, const hipdec_nclx* nclx, 
       case HIPDEC_OP_420_TO_RGB32:
         rc = hipdec_color_420_to_rgba_alpha(dp[0], ds[0], dp[1], ds[1], dp[2], ds[2], w, h, nclx, dp[3], ds[3], 1, 1, dout, dout_stride, (void*)s); break;
       case HIPDEC_OP_YCBCR_TO_RGB:   // a10 + a11 as one pass
-        if (out_chroma == 11) rc = hipdec_color_420_to_rgba_alpha(dp[0], ds[0], dp[1], ds[1], dp[2], ds[2], w, h, nclx, dp[3], ds[3], 0, chroma, dout, dout_stride, (void*)s);
+        if (out_chroma == 12 || out_chroma == 14)
+          rc = hipdec_color_ycbcr_to_rrggbb_float(dp[0], ds[0], dp[1], ds[1], dp[2], ds[2], w, h, bits, chroma, nclx, dout, dout_stride, out_chroma == 14, (void*)s);
+        else if (out_chroma == 11) rc = hipdec_color_420_to_rgba_alpha(dp[0], ds[0], dp[1], ds[1], dp[2], ds[2], w, h, nclx, dp[3], ds[3], 0, chroma, dout, dout_stride, (void*)s);
         else rc = hipdec_color_ycbcr_to_rgb24_float(dp[0], ds[0], dp[1], ds[1], dp[2], ds[2], w, h, chroma, nclx, dout, dout_stride, 0, (void*)s);
         break;
       case HIPDEC_OP_420_TO_RRGGBB:

@@ -115,16 +115,37 @@ def test_run_rgb_on_batches_with_other_chroma_formats(cfs):
 
 
 @FORMATS
-def test_main10_to_rrggbb_is_refused_loudly(cf):
+@pytest.mark.parametrize("out_chroma", [14, 12], ids=["RRGGBB_LE", "RRGGBB_BE"])
+def test_main10_planes_to_rrggbb_match_the_oracle_chain(cf, out_chroma):
+    """Op_YCbCr_to_RGB<uint16_t> + Op_RGB_HDR_to_RRGGBBaa_BE [+ swap] on the decoded 10-bit planes in HBM (tests/test_color_emu.py pins the chain
+    to the compiled reference pipeline)"""
     from libheif_amd.decoder import Batch
-    from libheif_amd._capi import HipDecError
-    stream = orc.encode(orc.synth_image(72, 40, 10, cf, seed=2), bit_depth=10)
+    stream = orc.encode(orc.synth_image(200, 136, 10, cf, seed=2), bit_depth=10, vui_primaries=9, vui_transfer=16, vui_matrix=9, vui_full_range=0)
+    ref = orc.decode(stream)
     b = Batch([stream]); b.run(); b.status()
-    with pytest.raises(HipDecError) as e:
-        b.to_rgb(0, 12)
-    assert "4:2:0" in str(e.value)
-    for c, p in enumerate(b.planes(0)):           # the planes themselves are there
-        np.testing.assert_array_equal(p, orc.decode(stream)["planes"][c])
+    got = b.to_rgb(0, out_chroma)
+    r, g, bb = orc.color_ycbcr_to_rgb_planar(*ref["planes"], 10, cf, ref["nclx"])
+    inter = np.stack([r, g, bb], axis=-1).astype(np.uint16)
+    np.testing.assert_array_equal(got, (inter if out_chroma == 14 else inter.byteswap()).reshape(136, -1).view(np.uint8))
+    b.free()
+
+
+@FORMATS
+def test_color_boundary_takes_the_decoded_device_planes(cf):
+    """hipdec_color_convert (the colour boundary libheif's HIP op forwards to) on device planes of the new formats: Main10 -> RGB24 goes through
+    Op_to_sdr_planes first, then the generic op; equals the same chain on the oracle's planes through the Python mirror"""
+    import ctypes as C
+    import libheif_amd
+    from libheif_amd import color
+    from libheif_amd._capi import DeviceBuffer, check, Nclx
+    nclx = (9, 16, 9, 0)
+    stream = orc.encode(orc.synth_image(200, 136, 10, cf, seed=4), bit_depth=10, vui_primaries=9, vui_transfer=16, vui_matrix=9, vui_full_range=0)
+    ref = orc.decode(stream)
+    for out_chroma, bpp in ((10, 3), (14, 6)):
+        want = color.convert_colorspace(ref["planes"], 10, cf, nclx, out_chroma)
+        got = color.convert_colorspace(_decode_gpu(stream).planes, 10, cf, nclx, out_chroma)
+        np.testing.assert_array_equal(got, want)
+        assert got.shape == (136, 200 * bpp)
 
 
 @pytest.mark.parametrize("cf,bd", [(3, 8), (2, 10)], ids=["444-8bit", "422-10bit"])

@@ -22,7 +22,8 @@ import heic_util as hu
 import libheif_host as lh
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-OPS = {1: "to_sdr", 2: "bilinear", 3: "420_to_rgb24", 4: "420_to_rgb32", 5: "ycbcr_to_rgb", 6: "rgb_to_rgb24_32", 7: "420_to_rrggbb", 8: "bilinear_422"}
+OPS = {1: "to_sdr", 2: "bilinear", 3: "420_to_rgb24", 4: "420_to_rgb32", 5: "ycbcr_to_rgb", 6: "rgb_to_rgb24_32", 7: "420_to_rrggbb", 8: "bilinear_422",
+       9: "rgb_hdr_to_rrggbb_be", 10: "swap_endianness"}
 
 
 def _plan(bpp, chroma, has_alpha, nclx, out_chroma, ups, only):
@@ -40,22 +41,24 @@ def test_c_planner_matches_the_python_mirror_and_the_reference_rules():
     from libheif_amd import color
     names = {"Op_to_sdr_planes": "to_sdr", "Op_YCbCr420_bilinear_to_YCbCr444": "bilinear", "Op_YCbCr420_to_RGB24": "420_to_rgb24",
              "Op_YCbCr420_to_RGB32": "420_to_rgb32", "Op_YCbCr_to_RGB<u8>": "ycbcr_to_rgb", "Op_RGB_to_RGB24_32": "rgb_to_rgb24_32",
-             "Op_YCbCr420_to_RRGGBBaa": "420_to_rrggbb"}
+             "Op_YCbCr420_to_RRGGBBaa": "420_to_rrggbb", "Op_YCbCr422_bilinear_to_YCbCr444": "bilinear_422", "Op_YCbCr_to_RGB<u16>": "ycbcr_to_rgb",
+             "Op_RGB_HDR_to_RRGGBBaa_BE": "rgb_hdr_to_rrggbb_be", "Op_RRGGBBaa_swap_endianness": "swap_endianness"}
     n = 0
-    for bpp in (8, 10, 12):
+    for chroma in (1, 2, 3):
+      for bpp in (8, 10, 12):
         for nclx in (None, (1, 13, 6, 1), (1, 13, 6, 0), (9, 16, 9, 0), (9, 16, 9, 1), (1, 1, 1, 0), (2, 2, 2, 1), (1, 13, 0, 1), (1, 13, 8, 1), (1, 13, 11, 1)):
             for out in (10, 11, 12, 14):
                 for ups, only in ((1, False), (2, False), (2, True), (1, True)):
                     try:
-                        want = [names[x] for x in color.plan(bpp, 1, nclx, out, ups, only)]
+                        want = [names[x] for x in color.plan(bpp, chroma, nclx, out, ups, only)]
                     except libheif_amd.HipDecError:
                         want = None
-                    rc, got = _plan(bpp, 1, False, nclx, out, ups, only)
-                    assert (rc == 0) == (want is not None), (bpp, nclx, out, ups, only, rc, want)
+                    rc, got = _plan(bpp, chroma, False, nclx, out, ups, only)
+                    assert (rc == 0) == (want is not None), (chroma, bpp, nclx, out, ups, only, rc, want)
                     if want is not None:
-                        assert got == want, (bpp, nclx, out, ups, only)
+                        assert got == want, (chroma, bpp, nclx, out, ups, only)
                         n += 1
-    assert n > 100
+    assert n > 400
     assert _plan(8, 1, True, (1, 13, 6, 1), 11, 1, False) == (0, ["420_to_rgb32"])       # alpha plane travels with the integer op
     assert _plan(8, 1, True, (1, 13, 6, 0), 11, 1, False) == (0, ["ycbcr_to_rgb", "rgb_to_rgb24_32"])
     assert _plan(8, 1, True, (1, 13, 6, 1), 10, 1, False)[0] != 0                          # dropping alpha: stock ops

@@ -22,6 +22,8 @@ def _lib():
     L.hipdec_color_420_to_rgb24.argtypes = [vp, sz, vp, sz, vp, sz, ci, ci, np_, vp, sz, ci, vp]
     L.hipdec_color_ycbcr_to_rgb24_float.argtypes = [vp, sz, vp, sz, vp, sz, ci, ci, ci, np_, vp, sz, ci, vp]
     L.hipdec_color_420_to_rrggbb.argtypes = [vp, sz, vp, sz, vp, sz, ci, ci, ci, np_, vp, sz, ci, vp]
+    L.hipdec_color_ycbcr_to_rrggbb_float.argtypes = [vp, sz, vp, sz, vp, sz, ci, ci, ci, ci, np_, vp, sz, ci, vp]
+    L.hipdec_color_bilinear_422_to_444.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
     L.hipdec_color_bilinear_420_to_444.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
     L.hipdec_color_to_sdr.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
     L.emu_color_last_error.restype = C.c_char_p
@@ -144,3 +146,49 @@ def test_emulated_to_hdr_swap_and_pq(w, h):
         _ok(L, L.hipdec_color_pq_to_linear(src.ctypes.data, src.strides[0], w, h, 3, bits, be, out.ctypes.data, out.strides[0], None))
         np.testing.assert_allclose(out, _pq_reference(code, bits), rtol=1e-6, atol=1e-9)
         assert out[0, 0] == 0.0 and abs(out[0, 1] - 1.0) < 1e-6
+
+
+# ---- > 8-bit planes of any chroma format -> RRGGBB: Op_YCbCr_to_RGB<uint16_t> + Op_RGB_HDR_to_RRGGBBaa_BE [+ swap], one pass ------------------
+def _planes_cf(rng, w, h, bpp, chroma):
+    cw = w if chroma == 3 else (w + 1) // 2
+    ch = (h + 1) // 2 if chroma == 1 else h
+    return [np.ascontiguousarray(rng.integers(0, 1 << bpp, s).astype(np.uint16)) for s in ((h, w), (ch, cw), (ch, cw))]
+
+
+@pytest.mark.parametrize("chroma", [1, 2, 3])
+@pytest.mark.parametrize("nclx", [(9, 16, 9, 0), (1, 13, 6, 1), (1, 13, 0, 1), (1, 13, 8, 1), None], ids=["bt2020-limited", "bt601-full", "gbr", "ycgco", "none"])
+@pytest.mark.parametrize("bpp,le", [(10, True), (12, False)])
+def test_emulated_generic_rrggbb_equals_the_compiled_reference_pipeline(chroma, nclx, bpp, le):
+    """the host-compiled kernel against libheif's own convert_colorspace() (oracle/_ref) on the same planes: this pins the planner rule too
+    (which ops the reference chains for these states, default options) — and the colour oracle's restatement"""
+    import ref_harness as rh
+    if not rh.available():
+        pytest.skip("oracle/_ref not built")
+    L = _lib()
+    w, h = 70, 38
+    y, cb, cr = _planes_cf(np.random.default_rng(bpp + chroma), w, h, bpp, chroma)
+    out = np.zeros((h, w * 6), np.uint8)
+    ns = Nclx(1, *nclx) if nclx else Nclx(0, 2, 2, 2, 1)
+    _ok(L, L.hipdec_color_ycbcr_to_rrggbb_float(*_args([y, cb, cr]), w, h, bpp, chroma, C.byref(ns), out.ctypes.data, out.strides[0], int(le), None))
+    ref = rh.convert([y, cb, cr], bpp, chroma, nclx, rh.CS_RGB, rh.CH_RRGGBB_LE if le else rh.CH_RRGGBB_BE)[0]
+    np.testing.assert_array_equal(out, ref[:, :w * 6])
+    r, g, b = orc.color_ycbcr_to_rgb_planar(y, cb, cr, bpp, chroma, nclx)
+    inter = np.stack([r, g, b], axis=-1).astype(np.uint16)
+    np.testing.assert_array_equal(out, (inter if le else inter.byteswap()).reshape(h, -1).view(np.uint8))
+
+
+def test_emulated_422_bilinear_then_generic_rrggbb_equals_the_reference_with_only_preferred_upsampling():
+    """only_use_preferred_chroma_algorithm with bilinear: the reference upsamples the 16-bit chroma planes first (Op_YCbCr422_bilinear_to_YCbCr444)"""
+    import ref_harness as rh
+    if not rh.available():
+        pytest.skip("oracle/_ref not built")
+    L = _lib()
+    w, h, bpp, nclx = 70, 38, 10, (9, 16, 9, 0)
+    y, cb, cr = _planes_cf(np.random.default_rng(5), w, h, bpp, 2)
+    up = [np.zeros((h, w), np.uint16), np.zeros((h, w), np.uint16)]
+    for src, dst in zip((cb, cr), up):
+        _ok(L, L.hipdec_color_bilinear_422_to_444(src.ctypes.data, src.strides[0], w, h, bpp, dst.ctypes.data, dst.strides[0], None))
+    out = np.zeros((h, w * 6), np.uint8)
+    _ok(L, L.hipdec_color_ycbcr_to_rrggbb_float(*_args([y, up[0], up[1]]), w, h, bpp, 3, C.byref(Nclx(1, *nclx)), out.ctypes.data, out.strides[0], 1, None))
+    ref = rh.convert([y, cb, cr], bpp, 2, nclx, rh.CS_RGB, rh.CH_RRGGBB_LE, upsampling=rh.UPS_BILINEAR, only_preferred=True)[0]
+    np.testing.assert_array_equal(out, ref[:, :w * 6])
