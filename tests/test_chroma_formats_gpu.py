@@ -141,11 +141,20 @@ def test_color_boundary_takes_the_decoded_device_planes(cf):
     nclx = (9, 16, 9, 0)
     stream = orc.encode(orc.synth_image(200, 136, 10, cf, seed=4), bit_depth=10, vui_primaries=9, vui_transfer=16, vui_matrix=9, vui_full_range=0)
     ref = orc.decode(stream)
-    for out_chroma, bpp in ((10, 3), (14, 6)):
-        want = color.convert_colorspace(ref["planes"], 10, cf, nclx, out_chroma)
-        got = color.convert_colorspace(_decode_gpu(stream).planes, 10, cf, nclx, out_chroma)
+    class Img(C.Structure):
+        _fields_ = [("width", C.c_int), ("height", C.c_int), ("chroma", C.c_int), ("bit_depth", C.c_int), ("plane", C.c_void_p * 4), ("stride", C.c_size_t * 4),
+                    ("on_device", C.c_int)]
+    lib = libheif_amd.load_library()
+    lib.hipdec_color_convert.argtypes = [C.POINTER(Img), C.POINTER(Nclx), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int]
+    planes = [np.ascontiguousarray(p) for p in _decode_gpu(stream).planes]
+    for c in range(3):
+        np.testing.assert_array_equal(planes[c], ref["planes"][c])
+    for out_chroma, bpp in ((10, 3), (14, 6), (12, 6)):
+        want = color.convert_colorspace(ref["planes"], 10, cf, nclx, out_chroma)          # the Python mirror: op by op
+        img = Img(200, 136, cf, 10, (C.c_void_p * 4)(*[p.ctypes.data for p in planes], None), (C.c_size_t * 4)(*[p.strides[0] for p in planes], 0), 0)
+        got = np.zeros((136, 200 * bpp), np.uint8)
+        check(lib.hipdec_color_convert(C.byref(img), C.byref(Nclx(1, *nclx)), out_chroma, 2, 0, got.ctypes.data, got.strides[0], 0))   # the C boundary: plan + chain
         np.testing.assert_array_equal(got, want)
-        assert got.shape == (136, 200 * bpp)
 
 
 @pytest.mark.parametrize("cf,bd", [(3, 8), (2, 10)], ids=["444-8bit", "422-10bit"])
