@@ -80,7 +80,8 @@ struct PicParams {
   uint64_t off_ctb_info;          // CtbInfo[ctbs] (raster)
   uint64_t off_slices;            // SliceParams[nslices]
   uint64_t off_sao;               // SaoParams[ctbs*3]
-  uint64_t off_scaling;           // uint8[2048] ScalingFactor m[y][x], intra matrices: component c at c * 336 (4x4, 8x8 at +16, 16x16 at +80), luma 32x32 at 1008
+  uint64_t off_scaling;           // uint8[2048] ScalingFactor m[y][x], intra matrices: component c at c * 336 (4x4, 8x8 at +16, 16x16 at +80), luma 32x32 at 1008;
+                                  // 4:4:4 pictures: uint8[4096], the 32x32 matrices of Cb / Cr at 2048 / 3072
   uint64_t off_handoff;           // uint32[ctbs * HANDOFF_DWORDS]
   uint64_t off_u_size, off_u_flags, off_u_ipm, off_u_ipmc, off_u_qp;  // uint8[ctbs*units_per_ctb]
   uint64_t off_coeff[3];          // int16

@@ -190,9 +190,9 @@ void parse_scaling_list_data(NalReader& r, ScalingLists& sl)
 }
 
 // 8.6.4.2 / 7.4.5: the factors m[y][x] a block of the given size and (intra) component uses
-void build_scaling_tables(const ScalingLists& sl, std::vector<uint8_t>& out)
+void build_scaling_tables(const ScalingLists& sl, bool chroma444, std::vector<uint8_t>& out)
 {
-  out.assign(2048, 16);
+  out.assign(chroma444 ? 4096 : 2048, 16);
   for (int c = 0; c < 3; c++) {
     uint8_t* t = out.data() + c * 336;
     memcpy(t, sl.l4[c], 16);
@@ -205,6 +205,13 @@ void build_scaling_tables(const ScalingLists& sl, std::vector<uint8_t>& out)
   for (int y = 0; y < 32; y++)
     for (int x = 0; x < 32; x++) t32[y * 32 + x] = sl.l32[0][(y >> 2) * 8 + (x >> 2)];
   t32[0] = sl.dc32[0];
+  if (chroma444)   // 7.4.5: the 32x32 chroma matrices of a 4:4:4 picture are the component's 16x16 lists upsampled by 4, with the 16x16 DC
+    for (int c = 1; c < 3; c++) {
+      uint8_t* t = out.data() + 2048 + (c - 1) * 1024;
+      for (int y = 0; y < 32; y++)
+        for (int x = 0; x < 32; x++) t[y * 32 + x] = sl.l16[c][(y >> 2) * 8 + (x >> 2)];
+      t[0] = sl.dc16[c];
+    }
 }
 
 int parse_short_term_rps(NalReader& r, int idx, int num_sets, const std::vector<int>& num_delta_pocs)
@@ -321,7 +328,6 @@ void parse_sps(NalReader& r, Sps& s)
     }
   }
   if (s.chroma_format_idc == 3 && s.separate_colour_plane) unsupported("4:4:4 with separate colour planes");
-  if (s.chroma_format_idc == 3 && s.scaling_list_enabled) unsupported("scaling lists with 4:4:4 (32x32 chroma matrices)");
   if (s.bit_depth_luma > 12 || s.bit_depth_chroma > 12) unsupported("bit depth above 12");
   // 7.4.3.2.1: 3 <= MinCbLog2SizeY <= CtbLog2SizeY, CtbLog2SizeY in 4..6; 2 <= MinTbLog2SizeY < MinCbLog2SizeY;
   // MinTbLog2SizeY <= MaxTbLog2SizeY <= Min(CtbLog2SizeY, 5); max_transform_hierarchy_depth_* <= CtbLog2SizeY - MinTbLog2SizeY
@@ -605,7 +611,7 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
     out.subs.clear();
     out.slice_params.clear();
     out.scaling_tables.clear();
-    if (S.scaling_list_enabled) build_scaling_tables(P.scaling_list_data_present ? P.sl : S.sl, out.scaling_tables);
+    if (S.scaling_list_enabled) build_scaling_tables(P.scaling_list_data_present ? P.sl : S.sl, S.chroma_format_idc == 3, out.scaling_tables);
     std::vector<int> slice_head(out.slices.size(), 0);   // index of the (independent) slice segment that starts the slice a segment belongs to:
                                                          // what the kernels compare to tell slices apart (CtbInfo::slice_idx)
     for (size_t si = 0; si < out.slices.size(); si++) {

@@ -357,10 +357,10 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
       const int off_c = 6 * (bd_chroma - 8);
       const int qpi = clip3(-off_c, 57, qp_y + (c == 1 ? cb_off : cr_off));
       const int qpc = chroma_qp(qpi, cfi_p != 1);
-      const int tc = c444 ? t : t - 1;    // log2 size of the chroma block (scaling lists do not occur with 4:4:4: refused by the front end)
+      const int tc = c444 ? t : t - 1;    // log2 size of the chroma block
       int16_t* cc = coef_c[c - 1] + z * (c444 ? 16 : (c422 ? 8 : 4)) + (low << (2 * tc));
       if (use_sl) residual_block<true>(L, wave, lane, cc, tc, bd_chroma, qpc + off_c, 0, (ipm & (c == 1 ? 64 : 128)) != 0, 0,
-                                       sl_tab + c * 336 + (tc == 3 ? 16 : 80));
+                                       tc == 5 ? sl_tab + 2048 + (c - 1) * 1024 : sl_tab + c * 336 + (tc == 3 ? 16 : 80));   // 32x32 chroma: 4:4:4 only
       else residual_block<false>(L, wave, lane, cc, tc, bd_chroma, qpc + off_c, 0, (ipm & (c == 1 ? 64 : 128)) != 0, 0, nullptr);
     }
   }

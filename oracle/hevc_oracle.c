@@ -633,8 +633,6 @@ static void parse_sps(Dec* d, const uint8_t* rbsp, size_t n)
   /* constraints */
   if (s->chroma_format_idc > 3 || (s->chroma_format_idc == 3 && s->separate_colour_plane_flag))
     fail(d, "unsupported: chroma_format_idc %d%s", s->chroma_format_idc, s->separate_colour_plane_flag ? " with separate_colour_plane_flag" : "");
-  if (s->chroma_format_idc == 3 && s->scaling_list_enabled_flag)
-    fail(d, "unsupported: scaling lists with 4:4:4 (the 32x32 chroma matrices of the range extensions)");
   if (s->bit_depth_luma > 16 || s->bit_depth_chroma > 16) fail(d, "bit depth out of range");
   if (s->log2_ctb > 6 || s->log2_ctb < 4) fail(d, "CTB size out of range");
   if (s->log2_max_tb > 5 || s->log2_max_tb > s->log2_ctb) fail(d, "bad max TB size");
@@ -1390,7 +1388,9 @@ static void reconstruct_tb(Dec* d, int x0c, int y0c, int log2n, int cIdx, int mo
           if (n == 4) v = sl->ScalingFactor4[matrixId][y * 4 + x];
           else if (n == 8) v = sl->ScalingFactor8[matrixId][y * 8 + x];
           else if (n == 16) v = (x == 0 && y == 0) ? sl->dc16[matrixId] : sl->ScalingFactor16[matrixId][(y >> 1) * 8 + (x >> 1)];
-          else v = (x == 0 && y == 0) ? sl->dc32[matrixId] : sl->ScalingFactor32[matrixId][(y >> 2) * 8 + (x >> 2)];
+          else if (cIdx == 0) v = (x == 0 && y == 0) ? sl->dc32[matrixId] : sl->ScalingFactor32[matrixId][(y >> 2) * 8 + (x >> 2)];
+          /* 7.4.5: with ChromaArrayType 3 the 32x32 chroma matrices are the 16x16 lists of the component, upsampled by 4, with the 16x16 DC */
+          else v = (x == 0 && y == 0) ? sl->dc16[matrixId] : sl->ScalingFactor16[matrixId][(y >> 2) * 8 + (x >> 2)];
           mbuf[y * n + x] = (uint8_t)v;
         }
       m = mbuf;

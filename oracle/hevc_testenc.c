@@ -1062,7 +1062,6 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
   s->max_transform_hierarchy_depth_inter = 1;
   s->max_transform_hierarchy_depth_intra = prm->max_transform_hierarchy_depth_intra;
   s->scaling_list_enabled_flag = prm->scaling_list ? 1 : 0;
-  if (prm->scaling_list && prm->chroma_format_idc == 3) fail(d, "scaling lists with 4:4:4 are not supported");
   if (prm->chroma_format_idc < 0 || prm->chroma_format_idc > 3) fail(d, "chroma_format_idc must be 0 .. 3");
   scaling_list_default(&s->sl); scaling_list_default(&p->sl);
   s->amp_enabled_flag = 0; s->sao_enabled_flag = prm->sao;

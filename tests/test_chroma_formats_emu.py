@@ -56,8 +56,6 @@ def test_front_end_accepts_422_and_444():
     rc, info, msg = probe(orc.encode(orc.synth_image(70, 41, 8, 2, seed=2)))       # cropped: conformance window in chroma units, x only
     assert rc == 0, msg
     assert (info.chroma_format_idc, info.width, info.height, info.chroma_width, info.chroma_height) == (2, 70, 41, 35, 41)
-    with pytest.raises(orc.OracleError):
-        orc.encode(orc.synth_image(64, 64, 8, 3, seed=2), scaling_list=1)     # 32x32 chroma matrices: out of scope, refused on both sides
 
 
 CONFIGS = [
@@ -80,11 +78,15 @@ CONFIGS = [
 ]
 
 
-CONFIGS_422 = [c for c in CONFIGS if c.get("max_transform_hierarchy_depth_intra") != 4] + [
-    dict(scaling_list=1, stress=1),                                         # default lists: 4x4 .. 16x16 chroma matrices
+SCALING = [
+    dict(scaling_list=1, stress=1),                                         # default lists (4:4:4: 32x32 chroma matrices = the 16x16 lists upsampled)
     dict(scaling_list=3, bit_depth=10, transform_skip=1),                   # lists in the PPS
+    dict(scaling_list=2, qp=38),                                            # lists in the SPS, large blocks
+]
+CONFIGS_422 = [c for c in CONFIGS if c.get("max_transform_hierarchy_depth_intra") != 4] + SCALING + [
     dict(log2_ctb=6, log2_min_cb=3, log2_min_tb=2, log2_max_tb=5, max_transform_hierarchy_depth_intra=3, stress=1),
 ]
+CONFIGS = CONFIGS + SCALING
 
 
 def _configs(cf):
@@ -132,7 +134,7 @@ def test_emulated_pipeline_random_tool_mixes(cf):
                    wpp=rng.choice([0, 1]), num_slices=rng.choice([1, 1, 2, 4]), transform_skip=rng.choice([0, 1]),
                    strong_intra_smoothing=rng.choice([0, 1]), sao=rng.choice([0, 1]), lossless_pct=rng.choice([0, 0, 15]), pcm_pct=rng.choice([0, 0, 20]),
                    max_transform_hierarchy_depth_intra=rng.choice([0, 1, 2, 3]), cb_qp_offset=rng.choice([0, -7, 9]), cr_qp_offset=rng.choice([0, 5, -10]),
-                   tile_cols=rng.choice([1, 1, 2]), dependent_segments=rng.choice([0, 0, 2]), scaling_list=rng.choice([0, 0, 2]) if cf == 2 else 0)
+                   tile_cols=rng.choice([1, 1, 2]), dependent_segments=rng.choice([0, 0, 2]), scaling_list=rng.choice([0, 0, 2]))
         cfg["log2_max_tb"] = rng.choice([t for t in (3, 4, 5) if t <= lc])
         cfg["log2_min_tb"] = rng.choice([t for t in (2, 3) if t < cfg["log2_min_cb"] and t <= cfg["log2_max_tb"]])
         cfg["max_transform_hierarchy_depth_intra"] = min(cfg["max_transform_hierarchy_depth_intra"], lc - cfg["log2_min_tb"])

@@ -33,7 +33,6 @@ if cf_env:
     for cf in fmts:
         for i,c in enumerate(cfgs):
             c=dict(c)
-            if cf==3: c.pop('scaling_list',None)
             base.append(orc.encode(orc.synth_image(136,72,c.get('bit_depth',8),cf,seed=3+i),**c))
 print('clean:', [run(s) for s in base]); sys.stdout.flush()
 res={}

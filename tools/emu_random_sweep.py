@@ -54,7 +54,6 @@ def random_case(rng):
         r = random.Random(rng.random()).random()
         if r < 0.25:
             cf = 3
-            cfg["scaling_list"] = 0          # (32x32 chroma matrices: refused by the front end)
         elif r < 0.45:
             cf = 2
     return w, h, cf, cfg
