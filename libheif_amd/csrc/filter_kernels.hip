@@ -175,6 +175,46 @@ __device__ __forceinline__ void deblock_chroma(Pix* pix, int xs, int ys, int qp_
   }
 }
 
+// The same for a chroma edge segment of 4 lines: the 4 x 4 window (p1 p0 | q0 q1) moved with whole-dword accesses, p0 / q0 replaced in the packed
+// words.  A vertical edge's window rows start 2 samples left of a multiple of 8: 2-byte aligned for 8-bit samples (the hardware takes unaligned dwords)
+typedef uint32_t u32_a2 __attribute__((aligned(2)));
+template <typename Pix, int DIR>
+__device__ __forceinline__ void deblock_chroma4(Pix* pix, int stride, int qp_p, int qp_q, int c_qp_pic_offset, int tc_off2, int bit_depth, int no_p, int no_q,
+                                                bool not420)
+{
+  constexpr int ES = (int)sizeof(Pix);
+  const int qpi = ((qp_q + qp_p + 1) >> 1) + c_qp_pic_offset;
+  const int qpc = not420 ? (qpi < 51 ? qpi : 51) : (qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : c_chroma_qp_f[qpi - 30]));   // 8.7.2.5.5
+  const int tc = c_tc[clip3(0, 53, qpc + 2 + (tc_off2 << 1))] * (1 << (bit_depth - 8));
+  const int maxv = (1 << bit_depth) - 1;
+  uint32_t w[4 * ES];
+  // word / shift of sample j (0 .. 3 = p1 p0 q0 q1) of line k
+  auto word = [](int k, int j) { return DIR == 0 ? (ES == 1 ? k : 2 * k + (j >> 1)) : (ES == 1 ? j : 2 * j + (k >> 1)); };
+  auto shift = [](int k, int j) { return DIR == 0 ? (ES == 1 ? 8 * j : 16 * (j & 1)) : (ES == 1 ? 8 * k : 16 * (k & 1)); };
+#pragma unroll
+  for (int r = 0; r < 4; r++) {     // DIR 0: line r (a picture row); DIR 1: picture row y - 2 + r
+    const u32_a2* src = (const u32_a2*)(DIR == 0 ? pix + (size_t)r * stride - 2 : pix + (ptrdiff_t)(r - 2) * stride);
+#pragma unroll
+    for (int i = 0; i < ES; i++) w[ES * r + i] = src[i];
+  }
+  const uint32_t smask = ES == 1 ? 255u : 0xffffu;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int p1 = (int)((w[word(k, 0)] >> shift(k, 0)) & smask), p0 = (int)((w[word(k, 1)] >> shift(k, 1)) & smask);
+    const int q0 = (int)((w[word(k, 2)] >> shift(k, 2)) & smask), q1 = (int)((w[word(k, 3)] >> shift(k, 3)) & smask);
+    const int delta = clip3(-tc, tc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
+    if (!no_p) w[word(k, 1)] = (w[word(k, 1)] & ~(smask << shift(k, 1))) | ((uint32_t)clip3(0, maxv, p0 + delta) << shift(k, 1));
+    if (!no_q) w[word(k, 2)] = (w[word(k, 2)] & ~(smask << shift(k, 2))) | ((uint32_t)clip3(0, maxv, q0 - delta) << shift(k, 2));
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    if (DIR == 1 && (r == 0 || r == 3)) continue;     // rows p1 / q1 are never modified
+    u32_a2* dst = (u32_a2*)(DIR == 0 ? pix + (size_t)r * stride - 2 : pix + (ptrdiff_t)(r - 2) * stride);
+#pragma unroll
+    for (int i = 0; i < ES; i++) dst[i] = w[ES * r + i];
+  }
+}
+
 }  // namespace
 
 // DIR 0: vertical edges (filtering across x), DIR 1: horizontal edges
@@ -222,8 +262,7 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
       const int stride = P.rec_stride[c] / sizeof(Pix);
       Pix* pix = rec + (size_t)y * stride + x;
       const int off = c == 1 ? sl.pps_cb_qp_offset : sl.pps_cr_qp_offset;
-      if (DIR == 0) deblock_chroma<Pix>(pix, 1, stride, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q, true);
-      else deblock_chroma<Pix>(pix, stride, 1, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q, true);
+      deblock_chroma4<Pix, DIR>(pix, stride, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q, true);
     }
   }
   if (P.chroma_format_idc == 2) {
@@ -235,7 +274,7 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
         const int stride = P.rec_stride[c] / sizeof(Pix);
         Pix* pix = rec + (size_t)y * stride + (x >> 1);
         const int off = c == 1 ? sl.pps_cb_qp_offset : sl.pps_cr_qp_offset;
-        if (DIR == 0) deblock_chroma<Pix>(pix, 1, stride, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q, true, 4);
+        if (DIR == 0) deblock_chroma4<Pix, 0>(pix, stride, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q, true);
         else deblock_chroma<Pix>(pix, stride, 1, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q, true, 2);
       }
     }
@@ -249,8 +288,7 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
         const int stride = P.rec_stride[c] / sizeof(Pix);
         Pix* pix = rec + (size_t)(y >> 1) * stride + (x >> 1);
         const int off = c == 1 ? sl.pps_cb_qp_offset : sl.pps_cr_qp_offset;
-        if (DIR == 0) deblock_chroma<Pix>(pix, 1, stride, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q);
-        else deblock_chroma<Pix>(pix, stride, 1, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q);
+        deblock_chroma4<Pix, DIR>(pix, stride, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q, false);
       }
     }
   }
