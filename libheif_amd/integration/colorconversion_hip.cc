@@ -97,7 +97,7 @@ Op_YCbCr_to_RGB_hip::state_after_conversion(const ColorState& input_state,
   }
 
   if (input_state.colorspace != heif_colorspace_YCbCr ||
-      input_state.chroma != heif_chroma_420) {
+      (input_state.chroma != heif_chroma_420 && input_state.chroma != heif_chroma_422 && input_state.chroma != heif_chroma_444)) {
     return {};
   }
 
@@ -114,7 +114,8 @@ Op_YCbCr_to_RGB_hip::state_after_conversion(const ColorState& input_state,
   auto offer = [&](heif_chroma chroma, bool alpha, int bpp) {
     int ops[8], n = 0;
     // the planner of libheifhip.so decides whether this conversion is one it restates (same decision table the stock ops encode)
-    if (api.plan(input_state.bits_per_pixel, 1, input_state.has_alpha ? 1 : 0, &nclx, (int) chroma, upsampling, only_preferred, ops, &n) != 0) {
+    if (api.plan(input_state.bits_per_pixel, (int) input_state.chroma /* heif_chroma_420 / 422 / 444 = 1 / 2 / 3 */, input_state.has_alpha ? 1 : 0, &nclx,
+                 (int) chroma, upsampling, only_preferred, ops, &n) != 0) {
       return;
     }
     // 8-bit targets from >8-bit input run through Op_to_sdr_planes in the stock pipeline; that is an option of the caller
@@ -177,7 +178,7 @@ Op_YCbCr_to_RGB_hip::convert_colorspace(const std::shared_ptr<const HeifPixelIma
   hipdec_color_image img{};
   img.width = (int) width;
   img.height = (int) height;
-  img.chroma = 1;
+  img.chroma = (int) input->get_chroma_format();   // heif_chroma_420 / 422 / 444 = 1 / 2 / 3
   img.bit_depth = bpp;
   img.plane[0] = input->get_channel_memory(heif_channel_Y, &img.stride[0]);
   img.plane[1] = input->get_channel_memory(heif_channel_Cb, &img.stride[1]);

@@ -108,6 +108,14 @@ def test_heif_decode_image_to_rgb_runs_the_hip_colour_op_bit_exact(tmp_path):
     s10 = orc.encode(orc.synth_image(264, 200, 10, 1, seed=24), bit_depth=10, vui_matrix=9, vui_primaries=9, vui_transfer=16)
     add("main10_rrggbb_le", hu.build_heic([(s10, 264, 200)], bit_depth=10), lh.CHROMA_RRGGBB_LE)
     add("main10_rrggbb_be", hu.build_heic([(s10, 264, 200)], bit_depth=10), lh.CHROMA_RRGGBB_BE)
+    # the chroma formats of round 3: 4:4:4 8-bit and the camera format 4:2:2 10-bit, to 8-bit RGB (Op_to_sdr first for the latter) and to RRGGBB
+    s444 = orc.encode(orc.synth_image(264, 200, 8, 3, seed=27), **SRGB)
+    add("444_rgb", hu.build_heic([(s444, 264, 200)], chroma_format_idc=3), lh.CHROMA_RGB)
+    s422 = orc.encode(orc.synth_image(264, 200, 10, 2, seed=28), bit_depth=10, vui_matrix=9, vui_primaries=9, vui_transfer=16)
+    add("422_main10_rgb", hu.build_heic([(s422, 264, 200)], bit_depth=10, chroma_format_idc=2), lh.CHROMA_RGB)
+    add("422_main10_rrggbb_le", hu.build_heic([(s422, 264, 200)], bit_depth=10, chroma_format_idc=2), lh.CHROMA_RRGGBB_LE)
+    s444_10 = orc.encode(orc.synth_image(200, 136, 10, 3, seed=29), bit_depth=10, vui_matrix=9, vui_primaries=9, vui_transfer=16)
+    add("444_main10_rrggbb_be", hu.build_heic([(s444_10, 200, 136)], bit_depth=10, chroma_format_idc=3), lh.CHROMA_RRGGBB_BE)
     tiles = [(orc.encode(orc.synth_image(128, 128, 8, 1, seed=30 + i), **SRGB), 128, 128) for i in range(6)]
     add("grid_rgb", hu.build_heic(tiles, grid=(2, 3, 380, 250)), lh.CHROMA_RGB, threads=6)  # canvas assembled by libheif: upload path
     master = orc.encode(orc.synth_image(200, 136, 8, 1, seed=25), **SRGB)
@@ -122,7 +130,7 @@ def test_heif_decode_image_to_rgb_runs_the_hip_colour_op_bit_exact(tmp_path):
         conv, resident, launches = [int(v) for v in hipc[n + ".stats"]]
         assert tuple(int(v) for v in stock[n + ".stats"]) == (0, 0, 0), n                   # the stock build never reaches the boundary
         assert conv == 1 and launches >= 1, (n, conv, resident, launches)
-        if n not in ("grid_rgb",):
+        if n not in ("grid_rgb", "422_main10_rgb"):     # (8-bit RGB from Main10: the stock Op_to_sdr_planes runs first, on the host — its output is uploaded)
             assert resident >= 3, (n, resident)                                              # the decoder's own device planes were used
     # the alpha really is the auxiliary image's plane
     a_ref = orc.decode(alpha)["planes"][0]
