@@ -261,6 +261,12 @@ HIPDEC_API int hipdec_color_420_to_rrggbb(const void* y, size_t ys, const void* 
                                           int little_endian, void* stream);
 /* Op_YCbCr420_bilinear_to_YCbCr444<Pixel> (chroma_sampling.cc:501-724), one chroma plane;
  * (w, h) = luma size; reproduces the reference's border indexing. */
+/* > 8-bit planes (chroma 1 / 2 / 3) to 8-bit interleaved RGB(A) in one pass.  sdr_first = 1: Op_to_sdr_planes (hdr_sdr.cc:146-244) on the planes, then
+ * Op_YCbCr420_to_RGB24 / _RGB32 (4:2:0 only); sdr_first = 0: Op_YCbCr_to_RGB<uint16_t>, Op_to_sdr_planes on R, G, B, Op_RGB_to_RGB24_32.  Which of
+ * the two the reference's planner builds for a state: hipdec_color_plan. */
+HIPDEC_API int hipdec_color_hdr_to_rgb24(const void* y, size_t ys, const void* cb, size_t cbs, const void* cr, size_t crs, int w, int h,
+                                         int bpp, int chroma, const hipdec_nclx* nclx, void* out, size_t out_stride, int with_alpha,
+                                         int sdr_first, void* stream);
 /* Op_YCbCr_to_RGB<uint16_t> (libheif/color-conversion/yuv2rgb.cc:92-292) + Op_RGB_HDR_to_RRGGBBaa_BE (rgb2rgb.cc:470-560) [+ the endianness swap]:
  * > 8-bit planes of any chroma format (1 / 2 / 3) to interleaved RRGGBB at the input bit depth, one pass */
 HIPDEC_API int hipdec_color_ycbcr_to_rrggbb_float(const void* y, size_t ys, const void* cb, size_t cbs, const void* cr, size_t crs,

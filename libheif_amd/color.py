@@ -22,6 +22,14 @@ def _nclx_struct(nclx):
     return Nclx(1, int(nclx[0]), int(nclx[1]), int(nclx[2]), int(nclx[3]))
 
 
+def replaced_nclx(nclx):
+    """nclx_profile::replace_undefined_values_with_sRGB_defaults (libheif/nclx.cc:360-373) on (primaries, transfer, matrix, full_range)"""
+    if nclx is None:
+        return (1, 13, 6, 1)
+    p, t, m, f = nclx
+    return (1 if p == 2 else p, 13 if t == 2 else t, 6 if m == 2 else m, f)
+
+
 def _planning_matrix(nclx):
     """nclx_profile::replace_undefined_values_with_sRGB_defaults (libheif/nclx.cc:360-373) — only the
     *planner* sees these; the ops read the image's own profile."""
@@ -42,7 +50,13 @@ def plan(bpp, chroma, nclx, target_chroma, upsampling=UPSAMPLING_BILINEAR, only_
     nn_allowed = not (only_preferred and upsampling != UPSAMPLING_NEAREST)
     if target_chroma in (CHROMA_RGB, CHROMA_RGBA):
         if bpp > 8:
-            return ["Op_to_sdr_planes"] + plan(8, chroma, nclx, target_chroma, upsampling, only_preferred)
+            # the reference's search ends on one of two chains (tests/test_color_emu.py checks every state against the compiled pipeline):
+            # Op_to_sdr_planes first when the 8-bit chain behind it is the 4:2:0 integer op or when the preferred upsampling runs anyway,
+            # otherwise the generic op at the input depth and Op_to_sdr_planes on R, G, B
+            int_op = chroma == CHROMA_420 and nn_allowed and full and matrix not in (0, 8)
+            if int_op or (chroma != CHROMA_444 and not nn_allowed):
+                return ["Op_to_sdr_planes"] + plan(8, chroma, nclx, target_chroma, upsampling, only_preferred)
+            return ["Op_YCbCr_to_RGB<u16>", "Op_to_sdr_planes", "Op_RGB_to_RGB24_32"]
         if chroma == CHROMA_420 and nn_allowed and full and matrix not in (0, 8):
             return ["Op_YCbCr420_to_RGB24" if target_chroma == CHROMA_RGB else "Op_YCbCr420_to_RGB32"]
         if chroma != CHROMA_444 and not nn_allowed:
@@ -118,6 +132,10 @@ def convert_colorspace(planes, bpp, chroma, nclx, target_chroma, upsampling=UPSA
             dt = np.uint16 if bpp > 8 else np.uint8
             return [yb.to_numpy((h, w), dt), cbb.to_numpy((h, w), dt), crb.to_numpy((h, w), dt)]
     name = steps[0]
+    if len(keep) > 1:
+        # an op that is not the first of its chain reads the profile the pipeline attached to the intermediate image: the ColorState's, with
+        # unspecified values replaced by the sRGB defaults (colorconversion.cc:475, nclx.cc:360-373)
+        ns = _nclx_struct(replaced_nclx(nclx))
     if name in ("Op_YCbCr420_to_RGB24", "Op_YCbCr420_to_RGB32"):
         alpha = name.endswith("32")
         bppx = 4 if alpha else 3
@@ -133,6 +151,11 @@ def convert_colorspace(planes, bpp, chroma, nclx, target_chroma, upsampling=UPSA
         out = DeviceBuffer(w * h * 6)
         check(lib.hipdec_color_420_to_rrggbb(yb.ptr, ys, cbb.ptr, cs, crb.ptr, cs, w, h, bpp, C.byref(ns), out.ptr, w * 6,
                                              int(target_chroma == CHROMA_RRGGBB_LE), None))
+    elif name == "Op_YCbCr_to_RGB<u16>" and len(steps) > 1 and steps[1] == "Op_to_sdr_planes":
+        alpha = target_chroma == CHROMA_RGBA
+        bppx = 4 if alpha else 3
+        out = DeviceBuffer(w * h * bppx)
+        check(lib.hipdec_color_hdr_to_rgb24(yb.ptr, ys, cbb.ptr, cs, crb.ptr, cs, w, h, bpp, cur_chroma, C.byref(ns), out.ptr, w * bppx, int(alpha), 0, None))
     elif name == "Op_YCbCr_to_RGB<u16>":
         bppx = 6
         out = DeviceBuffer(w * h * 6)

@@ -63,7 +63,12 @@ __device__ __forceinline__ void rgb_block(const ColorParams& p)
     }
     int R[4], G[4], B[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) convert_px(p, Y[i], CB[i], CR[i], R[i], G[i], B[i]);
+    for (int i = 0; i < 4; i++) {
+      if (sizeof(Pix) == 2 && (LAYOUT == LO_RGB24 || LAYOUT == LO_RGBA32)) {   // > 8-bit planes to 8-bit interleaved output: Op_to_sdr_planes on either side
+        convert_px(p, Y[i] >> p.in_shift, CB[i] >> p.in_shift, CR[i] >> p.in_shift, R[i], G[i], B[i]);
+        R[i] >>= p.out_shift; G[i] >>= p.out_shift; B[i] >>= p.out_shift;
+      } else convert_px(p, Y[i], CB[i], CR[i], R[i], G[i], B[i]);
+    }
 
     if (LAYOUT == LO_PLANAR) {
       Pix* r = (Pix*)(p.o0 + (size_t)yy * p.os) + x0;
@@ -405,7 +410,8 @@ void launch_rgb_batch(const ColorParams* dev, int n, int max_w, int max_h, hipSt
 // variant = sizeof(Pix) * 16 + LAYOUT, as recorded by launch_rgb
 #define HIPDEC_RGB_VARIANTS(X)                                                                                     \
   X(16 + LO_PLANAR, uint8_t, LO_PLANAR) X(32 + LO_PLANAR, uint16_t, LO_PLANAR) X(16 + LO_RGB24, uint8_t, LO_RGB24) \
-  X(16 + LO_RGBA32, uint8_t, LO_RGBA32) X(32 + LO_RRGGBB_BE, uint16_t, LO_RRGGBB_BE) X(32 + LO_RRGGBB_LE, uint16_t, LO_RRGGBB_LE)
+  X(16 + LO_RGBA32, uint8_t, LO_RGBA32) X(32 + LO_RRGGBB_BE, uint16_t, LO_RRGGBB_BE) X(32 + LO_RRGGBB_LE, uint16_t, LO_RRGGBB_LE)                     \
+  X(32 + LO_RGB24, uint16_t, LO_RGB24) X(32 + LO_RGBA32, uint16_t, LO_RGBA32)
 
 namespace hipdec {
 
@@ -594,6 +600,35 @@ int hipdec_color_420_to_rrggbb(const void* y, size_t ys, const void* cb, size_t 
   p.arith = AR_FLOAT; p.o0 = (uint8_t*)out; p.os = out_stride;
   hipStream_t s = stream ? (hipStream_t)stream : default_stream();
   return little_endian ? launch_rgb<uint16_t, LO_RRGGBB_LE>(p, s) : launch_rgb<uint16_t, LO_RRGGBB_BE>(p, s);
+}
+
+/* > 8-bit planes to 8-bit interleaved RGB(A), one pass, as the two chains the reference's planner builds for it (which one: hipdec_color_plan):
+ *   sdr_first = 1: Op_to_sdr_planes on Y, Cb, Cr, then Op_YCbCr420_to_RGB24 / _RGB32 (4:2:0, full range, a matrix the integer op takes)
+ *   sdr_first = 0: Op_YCbCr_to_RGB<uint16_t> at the input depth, Op_to_sdr_planes on R, G, B, Op_RGB_to_RGB24_32 (everything else) */
+int hipdec_color_hdr_to_rgb24(const void* y, size_t ys, const void* cb, size_t cbs, const void* cr, size_t crs, int w, int h, int bpp, int chroma,
+                              const hipdec_nclx* nclx, void* out, size_t out_stride, int with_alpha, int sdr_first, void* stream)
+{
+  if (int rc = ensure_init()) return rc;
+  if (bpp <= 8 || bpp > 14) return set_error(HIPDEC_ERR_UNSUPPORTED, "hdr_to_rgb24: bits per pixel %d outside 9..14", bpp);
+  if (nclx && nclx->has_nclx && (nclx->matrix_coefficients == 11 || nclx->matrix_coefficients == 14))
+    return set_error(HIPDEC_ERR_UNSUPPORTED, "hdr_to_rgb24: matrix_coefficients %d unsupported (as in the reference)", nclx->matrix_coefficients);
+  ColorParams p;
+  if (sdr_first) {
+    if (chroma != 1) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "hdr_to_rgb24: the sdr-first chain is the 4:2:0 integer op's");
+    if (nclx && nclx->has_nclx) {   // Op_YCbCr420_to_RGB24::state_after_conversion (yuv2rgb.cc:298-341)
+      const int m = nclx->matrix_coefficients;
+      if (m == 0 || m == 8 || !nclx->full_range_flag) return set_error(HIPDEC_ERR_UNSUPPORTED, "hdr_to_rgb24: the integer op does not take this colour profile");
+    }
+    if (int rc = fill_common(p, y, ys, cb, cbs, cr, crs, w, h, 8, 1, nclx)) return rc;
+    p.arith = AR_INT88; p.in_shift = bpp - 8;
+  } else {
+    if (int rc = fill_common(p, y, ys, cb, cbs, cr, crs, w, h, bpp, chroma, nclx)) return rc;
+    p.arith = generic_arith(nclx); p.out_shift = bpp - 8;
+  }
+  if (!out) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "hdr_to_rgb24: out is NULL");
+  p.o0 = (uint8_t*)out; p.os = out_stride;
+  hipStream_t s = stream ? (hipStream_t)stream : default_stream();
+  return with_alpha ? launch_rgb<uint16_t, LO_RGBA32>(p, s) : launch_rgb<uint16_t, LO_RGB24>(p, s);
 }
 
 /* Op_YCbCr_to_RGB<uint16_t> (yuv2rgb.cc:92-292, nearest-neighbour chroma for 4:2:0 / 4:2:2 inputs) + Op_RGB_HDR_to_RRGGBBaa_BE (rgb2rgb.cc)

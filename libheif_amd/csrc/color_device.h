@@ -23,6 +23,8 @@ struct ColorParams {
   int i_r_cr, i_g_cb, i_g_cr, i_b_cb;
   float f_r_cr, f_g_cb, f_g_cr, f_b_cb;
   int full_range;
+  int in_shift;    // > 8-bit planes through an 8-bit chain: Op_to_sdr_planes (v >> (bits - 8), hdr_sdr.cc:193) applied to Y, Cb, Cr as they are loaded
+  int out_shift;   // > 8-bit planes to 8-bit interleaved RGB: Op_to_sdr_planes applied to R, G, B after the conversion at the input depth
 };
 
 __device__ __forceinline__ int clip_i(int x, int maxi) { return x < 0 ? 0 : (x > maxi ? maxi : x); }

@@ -422,8 +422,14 @@ int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void* out_dev, s
     hipdec_batch* b; hipStream_t s;
     ~MarkDone() { b->mark_done(s ? s : default_stream()); }
   } mark{b, (hipStream_t)s};
+  if ((out_chroma == 10 || out_chroma == 11) && b->wide) {
+    // > 8-bit planes to 8-bit RGB(A): one of the two chains of the planner (nearest-neighbour upsampling is this entry point's), fused into one pass
+    const int m = I.matrix_coeffs == 2 ? 6 : I.matrix_coeffs;
+    const int sdr_first = P.chroma_format_idc == 1 && I.full_range_flag && m != 0 && m != 8;
+    return hipdec_color_hdr_to_rgb24(y, P.out_stride[0], cb, P.out_stride[1], cr, P.out_stride[2], P.out_width, P.out_height, I.bit_depth_luma,
+                                     P.chroma_format_idc, &nclx, out_dev, out_stride, out_chroma == 11, sdr_first, s);
+  }
   if (out_chroma == 10 || out_chroma == 11) {
-    if (b->wide) return set_error(HIPDEC_ERR_UNSUPPORTED, "to_rgb: 8-bit interleaved output from >8-bit planes needs hipdec_color_to_sdr first");
     // planner rule: integer op only for full range and a matrix it accepts
     const int m = I.matrix_coeffs == 2 ? 6 : I.matrix_coeffs;
     if (P.chroma_format_idc == 1 && I.full_range_flag && m != 0 && m != 8)
@@ -1118,7 +1124,15 @@ int hipdec_color_plan(int bit_depth, int chroma, int has_alpha, const hipdec_ncl
   auto push = [&](int op) { ops[(*n_ops)++] = op; };
   if (out_chroma == 10 || out_chroma == 11) {          // interleaved RGB / RGBA, 8 bit
     if (out_chroma == 10 && has_alpha) return set_error(HIPDEC_ERR_UNSUPPORTED, "color_plan: dropping an alpha plane is left to the stock ops");
-    if (bit_depth > 8) { push(HIPDEC_OP_TO_SDR); bit_depth = 8; }
+    if (bit_depth > 8) {
+      // > 8-bit planes to 8-bit interleaved RGB: the search of the reference ends on one of two chains (checked state by state against the compiled
+      // pipeline, tests/test_color_emu.py): Op_to_sdr_planes FIRST when the 8-bit chain behind it is shorter (the 4:2:0 integer op) or when the
+      // preferred upsampling has to run anyway; otherwise the generic op at the input depth, THEN Op_to_sdr_planes on R, G, B
+      if (has_alpha) return set_error(HIPDEC_ERR_UNSUPPORTED, "color_plan: > 8-bit planes with alpha to 8-bit RGB are left to the stock ops");
+      const bool int_op = chroma == 1 && nn_allowed && full && matrix != 0 && matrix != 8;
+      if (!int_op && !(chroma != 3 && !nn_allowed)) { push(HIPDEC_OP_YCBCR_TO_RGB); push(HIPDEC_OP_TO_SDR); push(HIPDEC_OP_RGB_TO_RGB24_32); return 0; }
+      push(HIPDEC_OP_TO_SDR); bit_depth = 8;
+    }
     if (chroma == 1 && nn_allowed && full && matrix != 0 && matrix != 8) { push(out_chroma == 10 ? HIPDEC_OP_420_TO_RGB24 : HIPDEC_OP_420_TO_RGB32); return 0; }
     if (chroma != 3 && !nn_allowed) {
       push(chroma == 1 ? HIPDEC_OP_BILINEAR_420_TO_444 : HIPDEC_OP_BILINEAR_422_TO_444);
@@ -1223,6 +1237,17 @@ int hipdec_color_convert(const hipdec_color_image* in, const hipdec_nclx* nclx, 
       if (int rc = scratch(dout_stride * h, &dout)) return rc;
     }
     if (k >= n_ops) return set_error(HIPDEC_ERR_UNSUPPORTED, "color_convert: empty chain");
+    // The pipeline attaches the ColorState's profile - unspecified values replaced with the sRGB defaults - to every intermediate image
+    // (colorconversion.cc:475, nclx.cc:360-373): an op that is not the first of its chain reads THAT profile, not the input image's.  It matters
+    // for images without (or with unspecified) matrix_coefficients: computed BT.601 coefficients instead of the rounded default constants
+    hipdec_nclx later{1, 1, 13, 6, 1};
+    if (nclx && nclx->has_nclx) {
+      later = *nclx;
+      if (later.colour_primaries == 2) later.colour_primaries = 1;
+      if (later.transfer_characteristics == 2) later.transfer_characteristics = 13;
+      if (later.matrix_coefficients == 2) later.matrix_coefficients = 6;
+    }
+    if (k > 0) nclx = &later;
     int rc = 0;
     switch (ops[k]) {
       case HIPDEC_OP_420_TO_RGB24:
@@ -1230,7 +1255,9 @@ int hipdec_color_convert(const hipdec_color_image* in, const hipdec_nclx* nclx, 
       case HIPDEC_OP_420_TO_RGB32:
         rc = hipdec_color_420_to_rgba_alpha(dp[0], ds[0], dp[1], ds[1], dp[2], ds[2], w, h, nclx, dp[3], ds[3], 1, 1, dout, dout_stride, (void*)s); break;
       case HIPDEC_OP_YCBCR_TO_RGB:   // a10 + a11 as one pass
-        if (out_chroma == 12 || out_chroma == 14)
+        if (k + 1 < n_ops && ops[k + 1] == HIPDEC_OP_TO_SDR)     // > 8-bit planes to 8-bit RGB(A): generic op at the input depth, to_sdr on R, G, B, interleave
+          rc = hipdec_color_hdr_to_rgb24(dp[0], ds[0], dp[1], ds[1], dp[2], ds[2], w, h, bits, chroma, nclx, dout, dout_stride, out_chroma == 11, 0, (void*)s);
+        else if (out_chroma == 12 || out_chroma == 14)
           rc = hipdec_color_ycbcr_to_rrggbb_float(dp[0], ds[0], dp[1], ds[1], dp[2], ds[2], w, h, bits, chroma, nclx, dout, dout_stride, out_chroma == 14, (void*)s);
         else if (out_chroma == 11) rc = hipdec_color_420_to_rgba_alpha(dp[0], ds[0], dp[1], ds[1], dp[2], ds[2], w, h, nclx, dp[3], ds[3], 0, chroma, dout, dout_stride, (void*)s);
         else rc = hipdec_color_ycbcr_to_rgb24_float(dp[0], ds[0], dp[1], ds[1], dp[2], ds[2], w, h, chroma, nclx, dout, dout_stride, 0, (void*)s);

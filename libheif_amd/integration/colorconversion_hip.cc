@@ -118,9 +118,10 @@ Op_YCbCr_to_RGB_hip::state_after_conversion(const ColorState& input_state,
                  (int) chroma, upsampling, only_preferred, ops, &n) != 0) {
       return;
     }
-    // 8-bit targets from >8-bit input run through Op_to_sdr_planes in the stock pipeline; that is an option of the caller
-    // (convert_hdr_to_8bit), so the op only offers depth-preserving conversions
-    if ((input_state.bits_per_pixel > 8) != (bpp > 8)) {
+    // (an 8-bit target from > 8-bit planes - the caller's convert_hdr_to_8bit - is offered as well: the planner restates which of the stock
+    //  chains the search ends on for the state, Op_to_sdr_planes before or behind the conversion, so the result is the stock pipeline's.  If the
+    //  op only took 8-bit planes, the search would put Op_to_sdr_planes in front of it in every state - and change the pixels in most)
+    if (bpp > 8 && input_state.bits_per_pixel <= 8) {
       return;
     }
     ColorState output_state;
@@ -140,6 +141,8 @@ Op_YCbCr_to_RGB_hip::state_after_conversion(const ColorState& input_state,
   else if (!input_state.has_alpha) {
     offer(heif_chroma_interleaved_RRGGBB_LE, false, input_state.bits_per_pixel);
     offer(heif_chroma_interleaved_RRGGBB_BE, false, input_state.bits_per_pixel);
+    offer(heif_chroma_interleaved_RGB, false, 8);
+    offer(heif_chroma_interleaved_RGBA, true, 8);
   }
 
   return states;

@@ -130,6 +130,26 @@ def test_main10_planes_to_rrggbb_match_the_oracle_chain(cf, out_chroma):
     b.free()
 
 
+@pytest.mark.parametrize("cf", [1, 2, 3], ids=["420", "422", "444"])
+@pytest.mark.parametrize("full", [0, 1], ids=["limited", "full"])
+def test_main10_planes_to_rgb24_follow_the_reference_chain(cf, full):
+    """> 8-bit planes to 8-bit RGB, one fused pass: Op_to_sdr_planes + the integer op for full-range 4:2:0, the generic op at 10 bits with
+    Op_to_sdr_planes behind it for everything else (tests/test_color_emu.py pins the rule to the compiled reference pipeline)"""
+    from libheif_amd.decoder import Batch
+    stream = orc.encode(orc.synth_image(200, 136, 10, cf, seed=6), bit_depth=10, vui_primaries=9, vui_transfer=16, vui_matrix=9, vui_full_range=full)
+    ref = orc.decode(stream)
+    b = Batch([stream]); b.run(); b.status()
+    got = b.to_rgb(0, 10)
+    y, cb, cr = ref["planes"]
+    if cf == 1 and full:
+        exp = orc.color_420_to_rgb24(*[(p >> 2).astype(np.uint8) for p in (y, cb, cr)], ref["nclx"]).reshape(136, -1)
+    else:
+        r, g, bb = orc.color_ycbcr_to_rgb_planar(y, cb, cr, 10, cf, ref["nclx"])
+        exp = np.stack([r >> 2, g >> 2, bb >> 2], axis=-1).astype(np.uint8).reshape(136, -1)
+    np.testing.assert_array_equal(got, exp)
+    b.free()
+
+
 @FORMATS
 def test_color_boundary_takes_the_decoded_device_planes(cf):
     """hipdec_color_convert (the colour boundary libheif's HIP op forwards to) on device planes of the new formats: Main10 -> RGB24 goes through

@@ -24,6 +24,7 @@ def _lib():
     L.hipdec_color_420_to_rrggbb.argtypes = [vp, sz, vp, sz, vp, sz, ci, ci, ci, np_, vp, sz, ci, vp]
     L.hipdec_color_ycbcr_to_rrggbb_float.argtypes = [vp, sz, vp, sz, vp, sz, ci, ci, ci, ci, np_, vp, sz, ci, vp]
     L.hipdec_color_bilinear_422_to_444.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
+    L.hipdec_color_hdr_to_rgb24.argtypes = [vp, sz, vp, sz, vp, sz, ci, ci, ci, ci, np_, vp, sz, ci, ci, vp]
     L.hipdec_color_bilinear_420_to_444.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
     L.hipdec_color_to_sdr.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
     L.emu_color_last_error.restype = C.c_char_p
@@ -192,3 +193,74 @@ def test_emulated_422_bilinear_then_generic_rrggbb_equals_the_reference_with_onl
     _ok(L, L.hipdec_color_ycbcr_to_rrggbb_float(*_args([y, up[0], up[1]]), w, h, bpp, 3, C.byref(Nclx(1, *nclx)), out.ctypes.data, out.strides[0], 1, None))
     ref = rh.convert([y, cb, cr], bpp, 2, nclx, rh.CS_RGB, rh.CH_RRGGBB_LE, upsampling=rh.UPS_BILINEAR, only_preferred=True)[0]
     np.testing.assert_array_equal(out, ref[:, :w * 6])
+
+
+# ---- > 8-bit planes -> 8-bit interleaved RGB: which chain the reference's search ends on, and the fused kernels that run it --------------------
+def _run_plan_emu(L, planes, bpp, chroma, nclx, steps, w, h):
+    """the plan of libheif_amd/color.py:plan executed with the host-compiled kernels (what hipdec_color_convert does on the device)"""
+    ns = Nclx(1, *nclx) if nclx else Nclx(0, 2, 2, 2, 1)
+    from libheif_amd import color
+    y, cb, cr = planes
+    steps = list(steps)
+    first = steps[0]
+    if steps[0] == "Op_to_sdr_planes":
+        if steps[1:] in (["Op_YCbCr420_to_RGB24"],):                      # fused: to_sdr + the integer op
+            out = np.zeros((h, w * 3), np.uint8)
+            _ok(L, L.hipdec_color_hdr_to_rgb24(*_args([y, cb, cr]), w, h, bpp, chroma, C.byref(ns), out.ctypes.data, out.strides[0], 0, 1, None))
+            return out
+        sdr = []
+        for p in (y, cb, cr):
+            o = np.zeros(p.shape, np.uint8)
+            _ok(L, L.hipdec_color_to_sdr(p.ctypes.data, p.strides[0], p.shape[1], p.shape[0], bpp, o.ctypes.data, o.strides[0], None))
+            sdr.append(o)
+        y, cb, cr = sdr
+        bpp = 8
+        steps = steps[1:]
+    if steps[0].endswith("bilinear_to_YCbCr444"):
+        up = L.hipdec_color_bilinear_420_to_444 if "420" in steps[0] else L.hipdec_color_bilinear_422_to_444
+        new = []
+        for p in (cb, cr):
+            o = np.zeros((h, w), p.dtype)
+            _ok(L, up(p.ctypes.data, p.strides[0], w, h, bpp, o.ctypes.data, o.strides[0], None))
+            new.append(o)
+        cb, cr = new
+        chroma = 3
+        steps = steps[1:]
+    out = np.zeros((h, w * 3), np.uint8)
+    if steps[0] is not first:      # not the chain's first op: the pipeline attached the replaced profile to the intermediate image
+        ns = Nclx(1, *color.replaced_nclx(nclx))
+    if steps[0] == "Op_YCbCr420_to_RGB24":
+        _ok(L, L.hipdec_color_420_to_rgb24(*_args([y, cb, cr]), w, h, C.byref(ns), out.ctypes.data, out.strides[0], 0, None))
+    elif steps[0] == "Op_YCbCr_to_RGB<u8>":
+        _ok(L, L.hipdec_color_ycbcr_to_rgb24_float(*_args([y, cb, cr]), w, h, chroma, C.byref(ns), out.ctypes.data, out.strides[0], 0, None))
+    elif steps[:2] == ["Op_YCbCr_to_RGB<u16>", "Op_to_sdr_planes"]:
+        _ok(L, L.hipdec_color_hdr_to_rgb24(*_args([y, cb, cr]), w, h, bpp, chroma, C.byref(ns), out.ctypes.data, out.strides[0], 0, 0, None))
+    else:
+        raise AssertionError(steps)
+    return out
+
+
+@pytest.mark.parametrize("chroma", [1, 2, 3])
+@pytest.mark.parametrize("bpp", [10, 12])
+def test_emulated_hdr_to_rgb24_follows_the_reference_pipeline_in_every_state(chroma, bpp):
+    """> 8-bit planes -> RGB24 over colour profiles x upsampling options: the chain the Python mirror plans (the C planner is checked against the
+    mirror in tests/test_color_boundary.py), run with the host-compiled kernels, equals libheif's own convert_colorspace() bit for bit.
+    (Round 2's rule - Op_to_sdr_planes always first - was only right for full-range 4:2:0.)"""
+    import ref_harness as rh
+    from libheif_amd import color
+    if not rh.available():
+        pytest.skip("oracle/_ref not built")
+    L = _lib()
+    w, h = 70, 38
+    planes = _planes_cf(np.random.default_rng(bpp * 7 + chroma), w, h, bpp, chroma)
+    n = 0
+    for nclx in ((9, 16, 9, 0), (9, 16, 9, 1), (1, 13, 6, 1), (1, 13, 1, 0), (1, 13, 0, 1), (1, 13, 12, 0), None):
+        for ups, only in ((rh.UPS_BILINEAR, False), (rh.UPS_NN, False), (rh.UPS_BILINEAR, True), (rh.UPS_NN, True)):
+            try:
+                ref = rh.convert(planes, bpp, chroma, nclx, rh.CS_RGB, rh.CH_RGB, upsampling=ups, only_preferred=only)[0][:, :w * 3]
+            except RuntimeError:
+                continue          # a state the reference itself has no pipeline for
+            steps = color.plan(bpp, chroma, nclx, 10, ups, only)
+            np.testing.assert_array_equal(_run_plan_emu(L, planes, bpp, chroma, nclx, steps, w, h), ref, err_msg=str((nclx, ups, only, steps)))
+            n += 1
+    assert n >= 24
