@@ -15,7 +15,6 @@
 //            plane.  Algorithmic bytes: 1.5*s in + 1.5*s out per luma pixel.
 // grid.y = picture index of the batch, grid.z = colour component where applicable.
 #include <hip/hip_runtime.h>
-#include <cstdlib>
 #include "hevc_device.h"
 #include "kernels.h"
 #include "color_device.h"
@@ -604,84 +603,6 @@ __global__ __launch_bounds__(256) void k_sao_rgb(FilterArgs A, const colordev::C
   }
 }
 
-// The same kernel with its row loops ROLLED (k_sao_rgb above instantiates the per-quad SAO code six times - four luma rows, two chroma components -
-// and is larger than the instruction cache): one instance for luma, one for chroma, the filtered luma goes through LDS instead of registers, the
-// SAO parameters of a row are fetched inside its iteration.  Same arithmetic, same stores.
-template <bool MAY_KEEP, bool RESTRICTED>
-__global__ __launch_bounds__(256) void k_sao_rgb_rolled(FilterArgs A, const colordev::ColorParams* __restrict__ cps)
-{
-  typedef uint8_t Pix;
-  constexpr int ROW_WORDS = ((SAO_TW + 2) + 3) / 4 + 2;
-  constexpr int CROW_WORDS = ((SAO_CW + 2) + 3) / 4 + 2;
-  __shared__ uint32_t tile[(SAO_TH + 2) * ROW_WORDS];
-  __shared__ uint32_t luma_s[SAO_TH][SAO_TW / 4];
-  __shared__ uint8_t chroma_s[2][SAO_CH][SAO_CW];
-  if (*A.status != 0) return;
-  const PicParams& P = A.pics[blockIdx.y];
-  const SaoComp<Pix> SY = sao_comp<Pix>(A, P, 0, MAY_KEEP, RESTRICTED);
-  const int tiles_x = (SY.ow + SAO_TW - 1) / SAO_TW, tiles_y = (SY.oh + SAO_TH - 1) / SAO_TH;
-  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
-  const int ox_t = ((int)blockIdx.x % tiles_x) * SAO_TW, oy_t = ((int)blockIdx.x / tiles_x) * SAO_TH;
-  const int tid = threadIdx.x;
-  const int tx = (tid & 31) * 4, ty = tid >> 5;
-  // ---- luma
-  {
-    const int ab = sao_stage<Pix, SAO_TH, ROW_WORDS, 256>(SY, tile, ox_t, oy_t, tid);
-    __syncthreads();
-#pragma nounroll
-    for (int rr = 0; rr < SAO_RPT; rr++) {
-      const int ly = ty + rr * 8, oy = oy_t + ly, ox0 = ox_t + tx;
-      uint32_t spw[3];
-      sao_params_at(SY, ox0, oy, spw);
-      Pix res[4];
-      const int npx = sao_quad<Pix, ROW_WORDS>(SY, tile, ab, ox0, oy, ly + 1, spw, res);
-      if (npx) sao_store(SY, ox0, oy, npx, res);
-      luma_s[ly][tx >> 2] = npx ? ((uint32_t)res[0] | ((uint32_t)(npx > 1 ? res[1] : 0) << 8) | ((uint32_t)(npx > 2 ? res[2] : 0) << 16) | ((uint32_t)(npx > 3 ? res[3] : 0) << 24)) : 0u;
-    }
-  }
-  // ---- Cb, Cr: 64 x 16 samples each, one row of 4 samples per thread
-  const int ctx = (tid & 15) * 4, cty = tid >> 4;
-#pragma nounroll
-  for (int c = 1; c < 3; c++) {
-    const SaoComp<Pix> SC = sao_comp<Pix>(A, P, c, MAY_KEEP, RESTRICTED);
-    uint32_t spw[3];
-    sao_params_at(SC, ox_t / 2 + ctx, oy_t / 2 + cty, spw);
-    __syncthreads();                       // the previous component's reads of `tile` are done
-    const int ab = sao_stage<Pix, SAO_CH, CROW_WORDS, 256>(SC, tile, ox_t / 2, oy_t / 2, tid);
-    __syncthreads();
-    Pix res[4];
-    const int ox0 = ox_t / 2 + ctx, oy = oy_t / 2 + cty;
-    const int npx = sao_quad<Pix, CROW_WORDS>(SC, tile, ab, ox0, oy, cty + 1, spw, res);
-    if (npx) sao_store(SC, ox0, oy, npx, res);
-    *(uint32_t*)&chroma_s[c - 1][cty][ctx] = npx ? ((uint32_t)res[0] | ((uint32_t)(npx > 1 ? res[1] : 0) << 8) | ((uint32_t)(npx > 2 ? res[2] : 0) << 16) | ((uint32_t)(npx > 3 ? res[3] : 0) << 24)) : 0u;
-  }
-  __syncthreads();
-  // ---- RGB24 of this thread's luma samples (nearest-neighbour chroma: x / 2, y / 2)
-  const colordev::ColorParams cp = cps[blockIdx.y];
-#pragma nounroll
-  for (int rr = 0; rr < SAO_RPT; rr++) {
-    const int ly = ty + rr * 8, oy = oy_t + ly, ox0 = ox_t + tx;
-    if (oy >= SY.oh || ox0 >= SY.ow) continue;
-    const int npx = SY.ow - ox0 < 4 ? SY.ow - ox0 : 4;
-    const uint32_t yw = luma_s[ly][tx >> 2];
-    const uint32_t cbw = *(const uint16_t*)&chroma_s[0][ly >> 1][tx >> 1], crw = *(const uint16_t*)&chroma_s[1][ly >> 1][tx >> 1];
-    int R[4], G[4], B[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-      colordev::convert_px(cp, (int)((yw >> (8 * i)) & 255u), (int)((cbw >> (8 * (i >> 1))) & 255u), (int)((crw >> (8 * (i >> 1))) & 255u), R[i], G[i], B[i]);
-    uint8_t* o = cp.o0 + (size_t)oy * cp.os + (size_t)ox0 * 3;
-    if (npx == 4 && ((cp.os | (uintptr_t)cp.o0) & 3) == 0) {
-      colordev::U3 v;
-      v.a = R[0] | (G[0] << 8) | (B[0] << 16) | ((uint32_t)R[1] << 24);
-      v.b = G[1] | (B[1] << 8) | (R[2] << 16) | ((uint32_t)G[2] << 24);
-      v.c = B[2] | (R[3] << 8) | (G[3] << 16) | ((uint32_t)B[3] << 24);
-      *(colordev::U3*)o = v;
-    } else {
-      for (int i = 0; i < npx; i++) { o[3 * i] = (uint8_t)R[i]; o[3 * i + 1] = (uint8_t)G[i]; o[3 * i + 2] = (uint8_t)B[i]; }
-    }
-  }
-}
-
 void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s)
 {
   const int uw = (max_w + 3) / 4, uh = (max_h + 3) / 4;
@@ -708,12 +629,9 @@ void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool 
 void launch_sao_rgb(const FilterArgs& a, const void* color_params_dev, int n_pics, int max_out_w, int max_out_h, hipStream_t s, bool may_keep, bool restricted)
 {
   const int tiles = ((max_out_w + SAO_TW - 1) / SAO_TW) * ((max_out_h + SAO_TH - 1) / SAO_TH);
-  static const bool unrolled = getenv("HIPDEC_SAO_RGB_UNROLLED") != nullptr;   // A / B knob: the round-2 form with every row loop unrolled
 #define L_RGB(K, R) hipLaunchKernelGGL((k_sao_rgb<K, R>), dim3(tiles, n_pics), dim3(256), 0, s, a, (const colordev::ColorParams*)color_params_dev)
-#define L_RGB_ROLLED(K, R) hipLaunchKernelGGL((k_sao_rgb_rolled<K, R>), dim3(tiles, n_pics), dim3(256), 0, s, a, (const colordev::ColorParams*)color_params_dev)
-  if (unrolled) HIPDEC_SAO_DISPATCH(L_RGB); else HIPDEC_SAO_DISPATCH(L_RGB_ROLLED);
+  HIPDEC_SAO_DISPATCH(L_RGB);
 #undef L_RGB
-#undef L_RGB_ROLLED
 }
 
 void launch_sao(const FilterArgs& a, int n_pics, int max_out_w, int max_out_h, bool wide, hipStream_t s, bool may_keep, bool restricted)
