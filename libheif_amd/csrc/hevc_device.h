@@ -16,7 +16,12 @@
 //   coeff       int16 TransCoeffLevel, TU-contiguous: a luma TU whose first unit has z-index u owns
 //               [ctb*ctbSize^2 + u*16, +n*n) in raster order inside the TU; chroma likewise at
 //               [ctb*ctbSize^2/4 + u*4, +n*n/4).  A PCM coding unit is stored as one block of CU size per component whose
-//               "levels" are its samples (pcm_sample << (BitDepth - PcmBitDepth)); its coded-block flags stay 0
+//               "levels" are its samples (pcm_sample << (BitDepth - PcmBitDepth)); its coded-block flags stay 0.
+//               Other chroma formats: the chroma offsets scale with the samples per luma unit — 4:2:2 at [ctb*ctbSize^2/2 + u*8, ...), its TWO
+//               square blocks one after the other (upper, lower); 4:4:4 at [ctb*ctbSize^2 + u*16, +n*n) like luma.
+//   4:2:2 flags the LOWER chroma block of a unit has its own cbf_cb / cbf_cr / transform_skip flags: they sit in the map entries of unit u ^ 1
+//               (u_flags bits 1-2, u_ipm bits 6-7 of the block's second unit, or of the third unit of a quad of 4x4 luma blocks — bits those
+//               entries do not use otherwise; only a block's first unit / a quad's fourth unit is ever read for block flags)
 //   rec planes  reconstructed samples (coded size, stride padded to 64 B), deblocked in place
 //   out planes  SAO output cropped to the conformance window (what the plugin hands to libheif)
 #pragma once
