@@ -1391,6 +1391,7 @@ int hipdec_image_transform(const hipdec_color_image* in, int op, const int* args
 // The Python path (libheif_amd/grid.py: one process per GPU, torch.distributed gather) stays as the multi-process test driver.
 struct hipdec_grid {
   int rows = 0, cols = 0, out_w = 0, out_h = 0, tile_w = 0, tile_h = 0, bits = 8;
+  int csw = 2, csh = 2;   // chroma subsampling of the tiles
   std::vector<int> devices;                       // one entry per shard; entries may repeat (several shards on one device)
   std::vector<std::unique_ptr<hipdec_batch>> shard;
   std::vector<std::vector<int>> shard_tiles;      // tile indices of shard s, in batch order
@@ -1462,12 +1463,13 @@ int hipdec_grid_create(hipdec_grid** out, int rows, int cols, int out_width, int
           return set_error(HIPDEC_ERR_BITSTREAM, "grid_create: tiles differ in size, bit depth or chroma format");
     if (out_width > cols * g->tile_w || out_height > rows * g->tile_h)
       return set_error(HIPDEC_ERR_BITSTREAM, "grid_create: the output size exceeds the tiled area");
-    if (g->info.chroma_format_idc >= 2) return set_error(HIPDEC_ERR_UNSUPPORTED, "grid_create: the device canvas takes 4:2:0 and 4:0:0 tiles (decode 4:2:2 / 4:4:4 tiles one by one)");
-    if (g->info.chroma_format_idc && ((g->tile_w | g->tile_h) & 1)) return set_error(HIPDEC_ERR_UNSUPPORTED, "grid_create: 4:2:0 tiles with odd dimensions");
+    g->csw = (g->info.chroma_format_idc == 1 || g->info.chroma_format_idc == 2) ? 2 : 1;   // SubWidthC / SubHeightC of the tiles (and of the canvas)
+    g->csh = g->info.chroma_format_idc == 1 ? 2 : 1;
+    if (g->info.chroma_format_idc && ((g->tile_w % g->csw) || (g->tile_h % g->csh))) return set_error(HIPDEC_ERR_UNSUPPORTED, "grid_create: subsampled tiles with odd dimensions");
     {
       DeviceScope scope(g->root);
       const size_t es = g->bits > 8 ? 2 : 1;
-      const size_t cw = g->info.chroma_format_idc ? (size_t)(out_width + 1) / 2 : 0, ch = g->info.chroma_format_idc ? (size_t)(out_height + 1) / 2 : 0;
+      const size_t cw = g->info.chroma_format_idc ? (size_t)(out_width + g->csw - 1) / g->csw : 0, ch = g->info.chroma_format_idc ? (size_t)(out_height + g->csh - 1) / g->csh : 0;
       size_t o = 0;
       g->stride[0] = ((size_t)out_width * es + 255) & ~(size_t)255; g->off[0] = o; o += g->stride[0] * (size_t)out_height;
       g->stride[1] = g->stride[2] = (cw * es + 255) & ~(size_t)255;
@@ -1486,7 +1488,7 @@ int hipdec_grid_info(const hipdec_grid* g, hipdec_image_info* info, int* n_shard
   if (!g || !info) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_info: bad arguments");
   *info = g->info;
   info->width = g->out_w; info->height = g->out_h;
-  info->chroma_width = g->info.chroma_format_idc ? (g->out_w + 1) / 2 : 0; info->chroma_height = g->info.chroma_format_idc ? (g->out_h + 1) / 2 : 0;
+  info->chroma_width = g->info.chroma_format_idc ? (g->out_w + g->csw - 1) / g->csw : 0; info->chroma_height = g->info.chroma_format_idc ? (g->out_h + g->csh - 1) / g->csh : 0;
   info->coded_width = g->cols * g->tile_w; info->coded_height = g->rows * g->tile_h;
   size_t bytes = 0; int subs = 0;
   for (const auto& b : g->shard) for (const auto& p : b->pics) { bytes += p.info.bitstream_bytes; subs += p.info.num_substreams; }
@@ -1513,8 +1515,9 @@ int hipdec_grid_decode(hipdec_grid* g)
         if (w <= 0 || h <= 0) continue;
         const PicParams& P = b->params[i];
         for (int c = 0; c < ncomp; c++) {
-          const size_t pw = c ? (size_t)(w + 1) / 2 : (size_t)w, ph = c ? (size_t)(h + 1) / 2 : (size_t)h;
-          const size_t px = c ? (size_t)x0 / 2 : (size_t)x0, py = c ? (size_t)y0 / 2 : (size_t)y0;
+          const size_t sw = c ? (size_t)g->csw : 1, sh = c ? (size_t)g->csh : 1;
+          const size_t pw = ((size_t)w + sw - 1) / sw, ph = ((size_t)h + sh - 1) / sh;
+          const size_t px = (size_t)x0 / sw, py = (size_t)y0 / sh;
           HIPDEC_CHECK_HIP(hipMemcpy2DAsync(g->canvas + g->off[c] + py * g->stride[c] + px * es, g->stride[c], b->arena + P.off_out[c], P.out_stride[c],
                                             pw * es, ph, hipMemcpyDefault, g->stream[s]));   // (kind from the pointers: the canvas may sit on another device)
         }
@@ -1559,7 +1562,8 @@ int hipdec_grid_read_plane(hipdec_grid* g, int c, void* dst_host, size_t dst_str
   if (int rc = hipdec_grid_wait(g)) return rc;
   DeviceScope scope(g->root);
   const size_t es = g->bits > 8 ? 2 : 1;
-  const size_t w = c ? (size_t)(g->out_w + 1) / 2 : (size_t)g->out_w, h = c ? (size_t)(g->out_h + 1) / 2 : (size_t)g->out_h;
+  const size_t sw = c ? (size_t)g->csw : 1, sh = c ? (size_t)g->csh : 1;
+  const size_t w = ((size_t)g->out_w + sw - 1) / sw, h = ((size_t)g->out_h + sh - 1) / sh;
   HIPDEC_CHECK_HIP(hipMemcpy2D(dst_host, dst_stride, g->canvas + g->off[c], g->stride[c], w * es, h, hipMemcpyDeviceToHost));
   return 0;
 }
@@ -1571,7 +1575,7 @@ int hipdec_grid_to_rgb(hipdec_grid* g, int out_chroma, int upsampling, int only_
   if (int rc = hipdec_grid_wait(g)) return rc;
   DeviceScope scope(g->root);
   hipdec_color_image img{};
-  img.width = g->out_w; img.height = g->out_h; img.chroma = 1; img.bit_depth = g->bits; img.on_device = 1;
+  img.width = g->out_w; img.height = g->out_h; img.chroma = g->info.chroma_format_idc; img.bit_depth = g->bits; img.on_device = 1;
   for (int c = 0; c < 3; c++) { img.plane[c] = g->canvas + g->off[c]; img.stride[c] = g->stride[c]; }
   hipdec_nclx nclx{1, g->info.colour_primaries, g->info.transfer_characteristics, g->info.matrix_coeffs, g->info.full_range_flag};
   return hipdec_color_convert(&img, &nclx, out_chroma, upsampling, only_preferred, out, out_stride, out_on_device);

@@ -16,9 +16,11 @@ tile into the canvas with HeifPixelImage::copy_image_to (image/pixelimage.cc:111
 
 There is no all-reduce anywhere; single stills do not shard (they run as replicas).
 """
+import ctypes as C
+
 import numpy as np
 
-from ._capi import check, load_library
+from ._capi import check, load_library, ImageInfo
 
 
 class GridLayout:
@@ -200,6 +202,7 @@ class GridDecoderC:
         lib.hipdec_grid_read_plane.argtypes = [vp, ci, vp, sz]
         lib.hipdec_grid_to_rgb.argtypes = [vp, ci, ci, ci, vp, sz, ci]
         lib.hipdec_grid_canvas_plane.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(sz), C.POINTER(ci)]
+        lib.hipdec_grid_info.argtypes = [vp, C.POINTER(ImageInfo), C.POINTER(ci)]
         n = layout.n_tiles
         self._keep = [bytes(tile_streams[t]) for t in range(n)]
         arr = (C.c_char_p * n)(*self._keep)
@@ -221,8 +224,10 @@ class GridDecoderC:
         L = self.layout
         dt = np.uint16 if L.bit_depth > 8 else np.uint8
         out = []
-        for c in range(3):
-            w, h = (L.out_w, L.out_h) if c == 0 else ((L.out_w + 1) // 2, (L.out_h + 1) // 2)
+        info = ImageInfo()
+        check(self.lib.hipdec_grid_info(self._h, C.byref(info), None))
+        for c in range(3 if info.chroma_format_idc else 1):
+            w, h = (L.out_w, L.out_h) if c == 0 else (info.chroma_width, info.chroma_height)     # (4:2:2 / 4:4:4 tiles: the canvas keeps their subsampling)
             a = np.empty((h, w), dt)
             check(self.lib.hipdec_grid_read_plane(self._h, c, a.ctypes.data, w * a.itemsize))
             out.append(a)

@@ -216,3 +216,35 @@ def test_heif_decode_image_to_rgb_matches_reference_colour_ops_on_oracle_planes(
     out = lh.decode(hu.build_heic([(s, w, h)], chroma_format_idc=cf), lh.COLORSPACE_RGB, lh.CHROMA_RGB)
     exp = rh.convert(ref["planes"], 8, cf, ref["nclx"], rh.CS_RGB, rh.CH_RGB)[0]
     np.testing.assert_array_equal(out["rgb"], exp[:, :w * 3])
+
+
+@FORMATS
+@pytest.mark.parametrize("bd", [8, 10])
+def test_device_grid_canvas_takes_tiles_of_the_format(cf, bd):
+    """hipdec_grid_*: 2 x 3 tiles of the format decoded as one set of launches and pasted into a canvas with the tiles' subsampling (clipped to the
+    output size), then the colour stage over the whole canvas — against the oracle's tiles pasted the same way"""
+    from libheif_amd.grid import GridDecoderC, GridLayout
+    from libheif_amd import color
+    rows, cols, tw, th = 2, 3, 128, 64
+    ow, oh = cols * tw - 6, rows * th - 10
+    nclx = (9, 16, 9, 0) if bd > 8 else (1, 13, 6, 1)
+    vui = dict(vui_primaries=nclx[0], vui_transfer=nclx[1], vui_matrix=nclx[2], vui_full_range=nclx[3])
+    streams = {t: orc.encode(orc.synth_image(tw, th, bd, cf, seed=50 + t), bit_depth=bd, wpp=t % 2, **vui) for t in range(rows * cols)}
+    g = GridDecoderC(streams, GridLayout(rows, cols, tw, th, ow, oh, bit_depth=bd), [0])
+    g.decode(); g.wait()
+    sw = 1 if cf == 3 else 2
+    canvas = [np.zeros((rows * th, cols * tw), np.uint16), np.zeros((rows * th, cols * tw // sw), np.uint16), np.zeros((rows * th, cols * tw // sw), np.uint16)]
+    for t, s in streams.items():
+        ref = orc.decode(s)
+        r, c = divmod(t, cols)
+        canvas[0][r * th:(r + 1) * th, c * tw:(c + 1) * tw] = ref["planes"][0]
+        for k in (1, 2):
+            canvas[k][r * th:(r + 1) * th, c * tw // sw:(c + 1) * tw // sw] = ref["planes"][k]
+    got = g.planes()
+    want = [canvas[0][:oh, :ow], canvas[1][:oh, :(ow + sw - 1) // sw], canvas[2][:oh, :(ow + sw - 1) // sw]]
+    for k in range(3):
+        np.testing.assert_array_equal(got[k], want[k], err_msg="plane %d" % k)
+    out_chroma = 10 if bd == 8 else 14
+    rgb = g.to_rgb(out_chroma)
+    np.testing.assert_array_equal(rgb, color.convert_colorspace(want, bd, cf, nclx, out_chroma, upsampling=1))
+    g.free()
