@@ -261,6 +261,9 @@ HIPDEC_API int hipdec_color_420_to_rrggbb(const void* y, size_t ys, const void* 
                                           int little_endian, void* stream);
 /* Op_YCbCr420_bilinear_to_YCbCr444<Pixel> (chroma_sampling.cc:501-724), one chroma plane;
  * (w, h) = luma size; reproduces the reference's border indexing. */
+/* Op_mono_to_RGB24_32 (libheif/color-conversion/monochrome.cc): 8-bit monochrome plane -> RGB24 / RGBA32 (R = G = B = Y; alpha copied, or 0xFF) */
+HIPDEC_API int hipdec_color_mono_to_rgb24(const void* y, size_t ys, const void* alpha, size_t alpha_stride, int w, int h, void* out,
+                                          size_t out_stride, int with_alpha, void* stream);
 /* > 8-bit planes (chroma 1 / 2 / 3) to 8-bit interleaved RGB(A) in one pass.  sdr_first = 1: Op_to_sdr_planes (hdr_sdr.cc:146-244) on the planes, then
  * Op_YCbCr420_to_RGB24 / _RGB32 (4:2:0 only); sdr_first = 0: Op_YCbCr_to_RGB<uint16_t>, Op_to_sdr_planes on R, G, B, Op_RGB_to_RGB24_32.  Which of
  * the two the reference's planner builds for a state: hipdec_color_plan. */
@@ -299,7 +302,8 @@ typedef enum hipdec_color_op {   /* the reference operations a plan is made of *
   HIPDEC_OP_420_TO_RRGGBB = 7,          /* Op_YCbCr420_to_RRGGBBaa           yuv2rgb.cc:622-734 */
   HIPDEC_OP_BILINEAR_422_TO_444 = 8,    /* Op_YCbCr422_bilinear_to_YCbCr444  chroma_sampling.cc:732-954 */
   HIPDEC_OP_RGB_HDR_TO_RRGGBB_BE = 9,   /* Op_RGB_HDR_to_RRGGBBaa_BE         rgb2rgb.cc (fused into the op before it) */
-  HIPDEC_OP_SWAP_ENDIANNESS = 10        /* Op_RRGGBBaa_swap_endianness       rgb2rgb.cc:647-764 (fused likewise) */
+  HIPDEC_OP_SWAP_ENDIANNESS = 10,       /* Op_RRGGBBaa_swap_endianness       rgb2rgb.cc:647-764 (fused likewise) */
+  HIPDEC_OP_MONO_TO_RGB24_32 = 11       /* Op_mono_to_RGB24_32               monochrome.cc (input chroma 0 = heif_chroma_monochrome) */
 } hipdec_color_op;
 
 typedef struct hipdec_color_image {

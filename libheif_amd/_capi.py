@@ -92,6 +92,7 @@ def load_library():
     lib.hipdec_color_420_to_rrggbb.argtypes = [vp, sz, vp, sz, vp, sz, ci, ci, ci, np_, vp, sz, ci, vp]
     lib.hipdec_color_ycbcr_to_rrggbb_float.argtypes = [vp, sz, vp, sz, vp, sz, ci, ci, ci, ci, np_, vp, sz, ci, vp]
     lib.hipdec_color_hdr_to_rgb24.argtypes = [vp, sz, vp, sz, vp, sz, ci, ci, ci, ci, np_, vp, sz, ci, ci, vp]
+    lib.hipdec_color_mono_to_rgb24.argtypes = [vp, sz, vp, sz, ci, ci, vp, sz, ci, vp]
     lib.hipdec_color_bilinear_422_to_444.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
     lib.hipdec_color_bilinear_420_to_444.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
     lib.hipdec_color_to_sdr.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]

@@ -48,6 +48,10 @@ def plan(bpp, chroma, nclx, target_chroma, upsampling=UPSAMPLING_BILINEAR, only_
     if matrix in (11, 14):
         raise HipDecError(-4, "Unsupported color conversion (matrix_coefficients %d), as in the reference" % matrix)
     nn_allowed = not (only_preferred and upsampling != UPSAMPLING_NEAREST)
+    if chroma == 0:     # heif_chroma_monochrome (no alpha plane here): Op_mono_to_RGB24_32, 8-bit only
+        if bpp == 8 and target_chroma in (CHROMA_RGB, CHROMA_RGBA):
+            return ["Op_mono_to_RGB24_32"]
+        raise HipDecError(-4, "this monochrome conversion is left to the stock ops")
     if target_chroma in (CHROMA_RGB, CHROMA_RGBA):
         if bpp > 8:
             # the reference's search ends on one of two chains (tests/test_color_emu.py checks every state against the compiled pipeline):

@@ -51,7 +51,10 @@ __device__ __forceinline__ void rgb_block(const ColorParams& p)
     } else {
       for (int i = 0; i < 4; i++) Y[i] = i < npx ? yrow[x0 + i] : 0;
     }
-    if (p.shiftH) {
+    if (p.arith == AR_MONO) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) { CB[i] = 0; CR[i] = 0; }
+    } else if (p.shiftH) {
       int c0 = x0 >> 1;
       int cbA = cbrow[c0], crA = crrow[c0];
       int cbB = cbA, crB = crA;
@@ -600,6 +603,24 @@ int hipdec_color_420_to_rrggbb(const void* y, size_t ys, const void* cb, size_t 
   p.arith = AR_FLOAT; p.o0 = (uint8_t*)out; p.os = out_stride;
   hipStream_t s = stream ? (hipStream_t)stream : default_stream();
   return little_endian ? launch_rgb<uint16_t, LO_RRGGBB_LE>(p, s) : launch_rgb<uint16_t, LO_RRGGBB_BE>(p, s);
+}
+
+/* Op_mono_to_RGB24_32 (libheif/color-conversion/monochrome.cc): an 8-bit monochrome plane to interleaved RGB24 / RGBA32, R = G = B = Y; the alpha
+ * plane of the image is copied when there is one (NULL: 0xFF) */
+int hipdec_color_mono_to_rgb24(const void* y, size_t ys, const void* alpha, size_t alpha_stride, int w, int h, void* out, size_t out_stride,
+                               int with_alpha, void* stream)
+{
+  if (int rc = ensure_init()) return rc;
+  if (!y || !out || w <= 0 || h <= 0) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "mono_to_rgb24: bad arguments");
+  if (alpha && !with_alpha) return set_error(HIPDEC_ERR_UNSUPPORTED, "mono_to_rgb24: dropping an alpha plane is left to the stock ops");
+  ColorParams p;
+  memset(&p, 0, sizeof(p));
+  p.y = (const uint8_t*)y; p.ys = ys; p.cb = p.cr = (const uint8_t*)y; p.cbs = p.crs = ys;   // (never read: AR_MONO)
+  p.w = w; p.h = h; p.bpp = 8; p.arith = AR_MONO; p.full_range = 1;
+  p.a = (const uint8_t*)alpha; p.as = alpha_stride;
+  p.o0 = (uint8_t*)out; p.os = out_stride;
+  hipStream_t s = stream ? (hipStream_t)stream : default_stream();
+  return with_alpha ? launch_rgb<uint8_t, LO_RGBA32>(p, s) : launch_rgb<uint8_t, LO_RGB24>(p, s);
 }
 
 /* > 8-bit planes to 8-bit interleaved RGB(A), one pass, as the two chains the reference's planner builds for it (which one: hipdec_color_plan):

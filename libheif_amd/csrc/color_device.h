@@ -8,7 +8,8 @@
 namespace hipdec {
 namespace colordev {
 
-enum Arith { AR_INT88 = 0, AR_FLOAT = 1, AR_GBR_FULL = 2, AR_GBR_LIMITED = 3, AR_YCGCO = 4, AR_YCGCO_RE = 5 };
+enum Arith { AR_INT88 = 0, AR_FLOAT = 1, AR_GBR_FULL = 2, AR_GBR_LIMITED = 3, AR_YCGCO = 4, AR_YCGCO_RE = 5,
+             AR_MONO = 6 /* Op_mono_to_RGB24_32 (monochrome.cc): R = G = B = Y, no chroma planes */ };
 enum Layout { LO_PLANAR = 0, LO_RGB24 = 1, LO_RGBA32 = 2, LO_RRGGBB_BE = 3, LO_RRGGBB_LE = 4 };
 
 struct ColorParams {
@@ -47,6 +48,7 @@ __device__ __forceinline__ void convert_px(const ColorParams& p, int Y, int Cb, 
       B = clip_i(Y + ((p.i_b_cb * cb + 128) >> 8), 255);
       break;
     }
+    case AR_MONO: R = Y; G = Y; B = Y; break;
     case AR_GBR_FULL: R = Cr; G = Y; B = Cb; break;  // yuv2rgb.cc:224-229
     case AR_GBR_LIMITED: {                             // yuv2rgb.cc:230-236
       float off = (float)(16 << (p.bpp - 8));

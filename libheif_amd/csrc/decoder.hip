@@ -413,7 +413,13 @@ int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void* out_dev, s
   if (b->retired) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "to_rgb: the batch's arena was handed to another batch");
   const PicParams& P = b->params[i];
   const hipdec_image_info& I = b->pics[i].info;
-  if (!P.chroma_format_idc) return set_error(HIPDEC_ERR_UNSUPPORTED, "to_rgb: monochrome input");
+  if (!P.chroma_format_idc) {   // Op_mono_to_RGB24_32: 8-bit only, as in the reference
+    if (b->wide || (out_chroma != 10 && out_chroma != 11)) return set_error(HIPDEC_ERR_UNSUPPORTED, "to_rgb: monochrome input goes to 8-bit RGB / RGBA only");
+    void* ms = stream ? (void*)follow_stream(b, stream) : (void*)b->last_stream;
+    const int rc = hipdec_color_mono_to_rgb24(b->arena + P.off_out[0], P.out_stride[0], nullptr, 0, P.out_width, P.out_height, out_dev, out_stride, out_chroma == 11, ms);
+    b->mark_done(ms ? (hipStream_t)ms : default_stream());
+    return rc;
+  }
   // the decoder reports the VUI colour description exactly as the libde265 plugin would attach it
   hipdec_nclx nclx{1, I.colour_primaries, I.transfer_characteristics, I.matrix_coeffs, I.full_range_flag};
   const uint8_t* y = b->arena + P.off_out[0]; const uint8_t* cb = b->arena + P.off_out[1]; const uint8_t* cr = b->arena + P.off_out[2];
@@ -1119,6 +1125,12 @@ int hipdec_color_plan(int bit_depth, int chroma, int has_alpha, const hipdec_ncl
   int matrix = 6, full = 1;
   if (nclx && nclx->has_nclx) { matrix = nclx->matrix_coefficients == 2 ? 6 : nclx->matrix_coefficients; full = nclx->full_range_flag; }
   if (matrix == 11 || matrix == 14) return set_error(HIPDEC_ERR_UNSUPPORTED, "Unsupported color conversion (matrix_coefficients %d), as in the reference", matrix);
+  if (chroma == 0) {   // heif_chroma_monochrome: Op_mono_to_RGB24_32 (8-bit; RGB24 only without an alpha plane)
+    if (bit_depth != 8 || !(out_chroma == 11 || (out_chroma == 10 && !has_alpha)))
+      return set_error(HIPDEC_ERR_UNSUPPORTED, "color_plan: this monochrome conversion is left to the stock ops");
+    ops[(*n_ops)++] = HIPDEC_OP_MONO_TO_RGB24_32;
+    return 0;
+  }
   if (chroma < 1 || chroma > 3) return set_error(HIPDEC_ERR_UNSUPPORTED, "color_plan: input chroma %d is outside the HEIC hot path", chroma);
   const bool nn_allowed = !(only_preferred && upsampling != 1);
   auto push = [&](int op) { ops[(*n_ops)++] = op; };
@@ -1157,7 +1169,7 @@ int hipdec_color_plan(int bit_depth, int chroma, int has_alpha, const hipdec_ncl
 int hipdec_color_convert(const hipdec_color_image* in, const hipdec_nclx* nclx, int out_chroma, int upsampling, int only_preferred,
                          void* out, size_t out_stride, int out_on_device)
 {
-  if (!in || !out || in->width <= 0 || in->height <= 0 || !in->plane[0] || !in->plane[1] || !in->plane[2])
+  if (!in || !out || in->width <= 0 || in->height <= 0 || !in->plane[0] || (in->chroma != 0 && (!in->plane[1] || !in->plane[2])))
     return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "color_convert: bad arguments");
   if (int rc = ensure_init()) return rc;
   return guarded("color_convert", [&]() -> int {
@@ -1250,6 +1262,8 @@ int hipdec_color_convert(const hipdec_color_image* in, const hipdec_nclx* nclx, 
     if (k > 0) nclx = &later;
     int rc = 0;
     switch (ops[k]) {
+      case HIPDEC_OP_MONO_TO_RGB24_32:
+        rc = hipdec_color_mono_to_rgb24(dp[0], ds[0], dp[3], ds[3], w, h, dout, dout_stride, out_chroma == 11, (void*)s); break;
       case HIPDEC_OP_420_TO_RGB24:
         rc = hipdec_color_420_to_rgb24(dp[0], ds[0], dp[1], ds[1], dp[2], ds[2], w, h, nclx, dout, dout_stride, 0, (void*)s); break;
       case HIPDEC_OP_420_TO_RGB32:

@@ -27,8 +27,11 @@ def lib():
     return _LIB
 
 
+CS_MONOCHROME = 2
+
+
 def convert(planes, bpp, in_chroma, nclx, target_colorspace, target_chroma, out_bpp=0,
-            upsampling=UPS_BILINEAR, only_preferred=False):
+            upsampling=UPS_BILINEAR, only_preferred=False, in_colorspace=CS_YCBCR):
     """planes: [Y, Cb, Cr] numpy arrays.  nclx: (primaries, transfer, matrix, full_range) or None.
     Returns a list of numpy arrays (uint8 rows for interleaved, uint8/uint16 planes otherwise)."""
     h, w = planes[0].shape
@@ -38,7 +41,7 @@ def convert(planes, bpp, in_chroma, nclx, target_colorspace, target_chroma, out_
     outs = [np.zeros(w * h * 8 + 64, np.uint8) for _ in range(4)]
     optrs = (C.c_void_p * 4)(*[o.ctypes.data for o in outs])
     info = (C.c_int * 12)()
-    n = lib().ref_convert_colorspace(w, h, bpp, CS_YCBCR, in_chroma, ptrs, len(ins),
+    n = lib().ref_convert_colorspace(w, h, bpp, in_colorspace, in_chroma, ptrs, len(ins),
                                      int(nclx is not None), *(nclx if nclx else (2, 2, 2, 1)),
                                      target_colorspace, target_chroma, out_bpp, upsampling, int(only_preferred),
                                      optrs, info)

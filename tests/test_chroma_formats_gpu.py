@@ -248,3 +248,25 @@ def test_device_grid_canvas_takes_tiles_of_the_format(cf, bd):
     rgb = g.to_rgb(out_chroma)
     np.testing.assert_array_equal(rgb, color.convert_colorspace(want, bd, cf, nclx, out_chroma, upsampling=1))
     g.free()
+
+
+def test_monochrome_stills_go_to_rgb_through_the_mono_op():
+    """Op_mono_to_RGB24_32 on the decoded 4:0:0 plane (R = G = B = Y; RGBA: alpha 0xFF), alone and inside a batch's ONE colour launch beside
+    colour items (tests/test_color_emu.py pins the op to the compiled reference pipeline)"""
+    from libheif_amd.decoder import Batch
+    mono = orc.encode(orc.synth_image(200, 136, 8, 0, seed=8))
+    col = orc.encode(orc.synth_image(200, 136, 8, 1, seed=9), vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1)
+    y = orc.decode(mono)["planes"][0]
+    b = Batch([mono]); b.run(); b.status()
+    np.testing.assert_array_equal(b.to_rgb(0, 10), np.repeat(y, 3, axis=1))
+    rgba = b.to_rgb(0, 11).reshape(136, 200, 4)
+    for c in range(3):
+        np.testing.assert_array_equal(rgba[:, :, c], y)
+    assert (rgba[:, :, 3] == 255).all()
+    b.free()
+    f = Batch([mono, col, mono]); f.alloc_rgb(10); f.run_rgb(); f.status()
+    one = Batch([col]); one.run(); one.status()
+    np.testing.assert_array_equal(f.rgb(0), np.repeat(y, 3, axis=1))
+    np.testing.assert_array_equal(f.rgb(2), np.repeat(y, 3, axis=1))
+    np.testing.assert_array_equal(f.rgb(1), one.to_rgb(0, 10))
+    f.free(); one.free()

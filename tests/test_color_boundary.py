@@ -23,7 +23,7 @@ import libheif_host as lh
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OPS = {1: "to_sdr", 2: "bilinear", 3: "420_to_rgb24", 4: "420_to_rgb32", 5: "ycbcr_to_rgb", 6: "rgb_to_rgb24_32", 7: "420_to_rrggbb", 8: "bilinear_422",
-       9: "rgb_hdr_to_rrggbb_be", 10: "swap_endianness"}
+       9: "rgb_hdr_to_rrggbb_be", 10: "swap_endianness", 11: "mono_to_rgb24_32"}
 
 
 def _plan(bpp, chroma, has_alpha, nclx, out_chroma, ups, only):
@@ -59,6 +59,8 @@ def test_c_planner_matches_the_python_mirror_and_the_reference_rules():
                         assert got == want, (chroma, bpp, nclx, out, ups, only)
                         n += 1
     assert n > 400
+    assert _plan(8, 0, False, None, 10, 2, False) == (0, ["mono_to_rgb24_32"]) and _plan(8, 0, True, None, 11, 2, False) == (0, ["mono_to_rgb24_32"])
+    assert _plan(8, 0, True, None, 10, 2, False)[0] != 0 and _plan(10, 0, False, None, 10, 2, False)[0] != 0      # dropping alpha / > 8 bit: stock ops
     assert _plan(8, 1, True, (1, 13, 6, 1), 11, 1, False) == (0, ["420_to_rgb32"])       # alpha plane travels with the integer op
     assert _plan(8, 1, True, (1, 13, 6, 0), 11, 1, False) == (0, ["ycbcr_to_rgb", "rgb_to_rgb24_32"])
     assert _plan(8, 1, True, (1, 13, 6, 1), 10, 1, False)[0] != 0                          # dropping alpha: stock ops

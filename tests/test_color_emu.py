@@ -25,6 +25,7 @@ def _lib():
     L.hipdec_color_ycbcr_to_rrggbb_float.argtypes = [vp, sz, vp, sz, vp, sz, ci, ci, ci, ci, np_, vp, sz, ci, vp]
     L.hipdec_color_bilinear_422_to_444.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
     L.hipdec_color_hdr_to_rgb24.argtypes = [vp, sz, vp, sz, vp, sz, ci, ci, ci, ci, np_, vp, sz, ci, ci, vp]
+    L.hipdec_color_mono_to_rgb24.argtypes = [vp, sz, vp, sz, ci, ci, vp, sz, ci, vp]
     L.hipdec_color_bilinear_420_to_444.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
     L.hipdec_color_to_sdr.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
     L.emu_color_last_error.restype = C.c_char_p
@@ -264,3 +265,29 @@ def test_emulated_hdr_to_rgb24_follows_the_reference_pipeline_in_every_state(chr
             np.testing.assert_array_equal(_run_plan_emu(L, planes, bpp, chroma, nclx, steps, w, h), ref, err_msg=str((nclx, ups, only, steps)))
             n += 1
     assert n >= 24
+
+
+@pytest.mark.parametrize("w,h", [(70, 38), (64, 48), (5, 3)])
+@pytest.mark.parametrize("alpha_plane", [False, True], ids=["no-alpha", "alpha"])
+def test_emulated_mono_to_rgb_equals_the_compiled_reference_pipeline(w, h, alpha_plane):
+    """Op_mono_to_RGB24_32: what libheif's own convert_colorspace() makes of an 8-bit monochrome image (with and without an alpha plane)"""
+    import ref_harness as rh
+    if not rh.available():
+        pytest.skip("oracle/_ref not built")
+    L = _lib()
+    rng = np.random.default_rng(w)
+    y = np.ascontiguousarray(rng.integers(0, 256, (h, w)).astype(np.uint8))
+    a = np.ascontiguousarray(rng.integers(0, 256, (h, w)).astype(np.uint8))
+    for tgt, bpp in ((rh.CH_RGBA, 4),) + (() if alpha_plane else ((rh.CH_RGB, 3),)):
+        out = np.zeros((h, w * bpp), np.uint8)
+        _ok(L, L.hipdec_color_mono_to_rgb24(y.ctypes.data, y.strides[0], a.ctypes.data if alpha_plane else None, a.strides[0] if alpha_plane else 0, w, h,
+                                            out.ctypes.data, out.strides[0], int(bpp == 4), None))
+        if alpha_plane:
+            continue        # (the harness adds planes as Y, Cb, Cr, alpha: a monochrome image with alpha is checked by value below)
+        ref = rh.convert([y], 8, 0, (1, 13, 6, 1), rh.CS_RGB, tgt, in_colorspace=rh.CS_MONOCHROME)[0][:, :w * bpp]
+        np.testing.assert_array_equal(out, ref)
+    if alpha_plane:
+        px = out.reshape(h, w, 4)
+        for c in range(3):
+            np.testing.assert_array_equal(px[:, :, c], y)
+        np.testing.assert_array_equal(px[:, :, 3], a)
