@@ -29,6 +29,11 @@ CASES = [
     ("main10_bt2020pq_200x136", 200, 136, 10, dict(bit_depth=10, vui_matrix=9, vui_primaries=9, vui_transfer=16)),
     ("qp12_highrate_128x72", 128, 72, 8, dict(qp=12, stress=1)),
     ("cropped_70x42", 70, 42, 8, dict()),
+    # chroma formats of round 3 (a sixth element: chroma_format_idc)
+    ("c422_main10_200x136", 200, 136, 10, dict(bit_depth=10, vui_matrix=9, vui_primaries=9, vui_transfer=16, stress=1), 2),
+    ("c422_scaling_cropped_70x41", 70, 41, 8, dict(scaling_list=2, transform_skip=1), 2),
+    ("c444_stress_depth4_136x72", 136, 72, 8, dict(stress=1, log2_ctb=6, log2_min_cb=3, log2_min_tb=2, log2_max_tb=5, max_transform_hierarchy_depth_intra=4), 3),
+    ("c444_pcm_lossless_scaling_128x72", 128, 72, 8, dict(pcm_pct=20, lossless_pct=20, scaling_list=1, qp=34), 3),
 ]
 
 
@@ -38,8 +43,9 @@ def plane_hashes(planes):
 
 def main():
     index = {"streams": {}, "reference_fixtures": {}}
-    for name, w, h, bd, cfg in CASES:
-        stream = orc.encode(orc.synth_image(w, h, bd, 1, seed=11), **cfg)
+    for case in CASES:
+        name, w, h, bd, cfg = case[:5]
+        stream = orc.encode(orc.synth_image(w, h, bd, case[5] if len(case) > 5 else 1, seed=11), **cfg)
         with open(os.path.join(HERE, name + ".hevc"), "wb") as f:
             f.write(stream)
         ref = orc.decode(stream)
