@@ -55,6 +55,8 @@ def sps(**o):
     b.u(4, 0).u(3, 0).u(1, 1)
     b.u(2, 0).u(1, 0).u(5, 3).u(32, 1 << 28).u(48, 0).u(8, 90)     # profile_tier_level, no sub-layers
     b.ue(g("sps_id", 0)).ue(g("chroma_format_idc", 1))
+    if g("chroma_format_idc", 1) == 3:
+        b.u(1, g("separate_colour_plane", 0))
     b.ue(g("width", 64)).ue(g("height", 64))
     conf = g("conf", None)
     b.u(1, 1 if conf else 0)
@@ -163,6 +165,9 @@ HOSTILE = {
     "init_qp out of range": sps() + pps(init_qp_m26=80) + idr(),
     "chroma_format_idc 7": sps(chroma_format_idc=7) + pps() + idr(),
     "65 short-term RPS": sps(num_st_rps=65) + pps() + idr(),
+    "4:4:4 with separate colour planes": sps(chroma_format_idc=3, separate_colour_plane=1) + pps() + idr(),
+    "4:2:2 conformance window eats the picture (x in chroma units)": sps(chroma_format_idc=2, conf=(16, 16, 0, 0)) + pps() + idr(),
+    "4:2:2 conformance window eats the picture (y in luma rows)": sps(chroma_format_idc=2, conf=(0, 0, 32, 32)) + pps() + idr(),
     "cross-component prediction": sps() + pps(range_ext=(1, 0, 0, 0)) + idr(),
     "chroma qp offset lists": sps() + pps(range_ext=(0, 1, 0, 0)) + idr(),
     "sao offset scale": sps() + pps(range_ext=(0, 0, 0, 2)) + idr(),
@@ -175,6 +180,13 @@ def test_hostile_headers_are_rejected_cleanly(name):
     rc, msg = probe(HOSTILE[name])
     assert rc < 0 and msg, (name, rc, msg)
     assert rc in (-3, -4, -5), (name, rc, msg)      # bitstream / unsupported / limit: never a crash, never "memory"
+
+
+def test_other_chroma_formats_pass_the_front_end_with_their_own_window_units():
+    # (left, right, top, bottom) in chroma units: x doubles for 4:2:2, y never does; the last window leaves one luma row
+    for cfi, conf in ((2, (1, 2, 3, 4)), (3, (1, 2, 3, 4)), (2, (0, 0, 31, 32))):
+        rc, msg = probe(sps(chroma_format_idc=cfi, conf=conf) + pps() + idr())
+        assert rc == 0, (cfi, conf, msg)
 
 
 def test_pps_range_extension_that_enables_nothing_is_accepted():
