@@ -14,9 +14,8 @@
 
 namespace hipdec {
 
-// The kernel body, stamped out at several register budgets: more resident waves per SIMD hide more of the WPP
-// dependency stalls and scalar-pipe latency, fewer registers mean spills in the cold paths.  HIPDEC_PARSE_OCCUPANCY
-// picks one at run time (tuning knob; default = the measured best on MI355X).
+// The kernel body at three register budgets: all registers (latency mode: a lone still), 8 waves per SIMD (throughput mode: the measured
+// best on MI355X, profiles/r03_occupancy_sweep.txt) and 6 (80 VGPRs, less scratch: HIPDEC_PARSE_OCCUPANCY=6 selects it for measurements).
 #define HIPDEC_PARSE_BODY                                                                                   \
     __shared__ pcore::Lds lds;                                                                            \
     const int lane = (int)threadIdx.x;                                                                    \
@@ -29,10 +28,7 @@ namespace hipdec {
     pcore::parse_wave(A, wave_idx, &lds);                                                                 \
 
 __global__ __launch_bounds__(64) void k_parse(ParseArgs A) { HIPDEC_PARSE_BODY }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_parse_occ4(ParseArgs A) { HIPDEC_PARSE_BODY }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_parse_occ5(ParseArgs A) { HIPDEC_PARSE_BODY }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_parse_occ6(ParseArgs A) { HIPDEC_PARSE_BODY }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_parse_occ7(ParseArgs A) { HIPDEC_PARSE_BODY }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_parse_occ8(ParseArgs A) { HIPDEC_PARSE_BODY }
 
 void launch_parse(const ParseArgs& a, hipStream_t s)
@@ -47,10 +43,7 @@ void launch_parse(const ParseArgs& a, hipStream_t s)
   const int occ = forced >= 0 ? forced : (a.pool ? 8 : (a.num_waves >= 2048 ? 8 : 0));
   if (a.general_chroma) { launch_parse_general(a, occ != 0, s); return; }
   if (occ == 8) hipLaunchKernelGGL(k_parse_occ8, dim3(a.num_waves), dim3(64), 0, s, a);
-  else if (occ == 7) hipLaunchKernelGGL(k_parse_occ7, dim3(a.num_waves), dim3(64), 0, s, a);
   else if (occ == 6) hipLaunchKernelGGL(k_parse_occ6, dim3(a.num_waves), dim3(64), 0, s, a);
-  else if (occ == 5) hipLaunchKernelGGL(k_parse_occ5, dim3(a.num_waves), dim3(64), 0, s, a);
-  else if (occ == 4) hipLaunchKernelGGL(k_parse_occ4, dim3(a.num_waves), dim3(64), 0, s, a);
   else hipLaunchKernelGGL(k_parse, dim3(a.num_waves), dim3(64), 0, s, a);
 }
 

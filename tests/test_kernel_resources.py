@@ -63,8 +63,8 @@ def test_occupancy_budgets():
                                                                       # per-picture bases around the inlined row parser) sit in per-CTB / per-row code
                                                                       # (120 B before pcm_sample and the dependent-slice-segment state hand-over, 148 B with them, 164 B with the
                                                                       #  operand registers of the hand-scheduled CABAC statements of round 3)
-    parse7 = _find(ks, "k_parse_occ7")[0]
-    assert parse7["vgpr"] <= 72 and parse7["scratch"] <= 136
+    parse6 = _find(ks, "k_parse_occ6")[0]
+    assert parse6["vgpr"] <= 80 and parse6["scratch"] <= 128
     gen8 = _find(ks, "k_parse_gen_occ8")[0]                               # the build with the 4:2:2 / 4:4:4 paths (batches that hold such pictures)
     assert gen8["vgpr"] <= 64 and gen8["scratch"] <= 184
     recon8 = _find(ks, "k_recon8")[0]
