@@ -137,9 +137,11 @@ HIPDEC_API void hipdec_forget_resident_planes(void);
 /* device-resident hand-over for callers that keep the colour stage on the GPU */
 HIPDEC_API int hipdec_decoder_device_plane(hipdec_decoder* dec, int c, const void** dptr, size_t* stride);
 
-/* Device arenas and pinned staging buffers of retired batches are parked for reuse up to this many bytes (default 96 GiB of the
- * MI355X's 288 GB, single arenas up to 64 GiB: hipFree() synchronises the device, and the decoder path builds one batch per launch
- * set of concurrently decoding instances).  A host that wants the memory back lowers it; 0 empties the cache. */
+/* Device arenas and pinned staging buffers of retired batches are parked for reuse up to this many bytes (default: a third of the
+ * device's memory, single arenas up to two ninths of it - 96 / 64 GiB on an MI355X; pinned host buffers: an eighth of the host's RAM, at
+ * most 24 GiB; HIPDEC_ARENA_CACHE_GIB overrides the device figure at hipdec_init): hipFree() synchronises the device, and the decoder
+ * path builds one batch per launch set of concurrently decoding instances.  A host that wants the memory back lowers it; 0 empties the
+ * cache. */
 HIPDEC_API int hipdec_set_arena_cache_bytes(size_t bytes);
 
 /* Two-stage pipeline across batches (default off): hipdec_batch_run() keeps the CABAC kernel on the caller's stream and queues residual /
@@ -233,6 +235,35 @@ HIPDEC_API int hipdec_grid_read_plane(hipdec_grid* g, int c, void* dst_host, siz
 /* the planner + fused colour stage over the canvas (hipdec_color_convert); out on the host, or on devices[0] */
 HIPDEC_API int hipdec_grid_to_rgb(hipdec_grid* g, int out_chroma, int upsampling, int only_preferred, void* out, size_t out_stride,
                                   int out_on_device);
+
+/* shards on the root device / shards that write the canvas through enabled peer access (xGMI) / shards whose copies the runtime stages
+ * (hipDeviceCanAccessPeer said no, or hipDeviceEnablePeerAccess failed) */
+HIPDEC_API int hipdec_grid_transport(const hipdec_grid* g, int* local_shards, int* peer_shards, int* staged_shards);
+
+/* ---- grid images, SPMD form: one process per GPU, tiles gathered with RCCL over xGMI ----------------------------
+ * The same partition as hipdec_grid_* (tile t -> rank t mod nranks; libheif/image-items/grid.cc:405-453, :482-577) for hosts that run one
+ * process per GPU: every rank decodes its tiles on its own device, one grouped ncclSend / ncclRecv gather brings the packed tiles
+ * (Y | Cb | Cr, 1.5 B/px for 8-bit 4:2:0) to rank 0, which pastes them (HeifPixelImage::copy_image_to, image/pixelimage.cc:1115-1172) and runs
+ * the colour conversion once over the canvas.  create / decode are COLLECTIVE: every rank of the communicator calls them, with the same grid
+ * geometry.  `comm` is an ncclComm_t (the host's own, or one from hipdec_rccl_comm_create); librccl is loaded at run time - without it these
+ * entry points return HIPDEC_ERR_UNSUPPORTED. */
+#define HIPDEC_RCCL_UNIQUE_ID_BYTES 128
+HIPDEC_API int hipdec_rccl_available(void);
+HIPDEC_API int hipdec_rccl_unique_id(void* id_out /* HIPDEC_RCCL_UNIQUE_ID_BYTES, rank 0; the host sends it to the other ranks */);
+HIPDEC_API int hipdec_rccl_comm_create(void** comm_out, int nranks, int rank, const void* unique_id);   /* ncclCommInitRank on the hipdec_init device */
+HIPDEC_API void hipdec_rccl_comm_destroy(void* comm);
+typedef struct hipdec_grid_rccl hipdec_grid_rccl;
+/* tile_data[t] / tile_sizes[t]: needed for the tiles this rank owns (t mod nranks == rank); other entries may be NULL / 0 */
+HIPDEC_API int hipdec_grid_create_rccl(hipdec_grid_rccl** out, void* comm, int rank, int nranks, int rows, int cols, int out_width, int out_height,
+                                       const void* const* tile_data, const size_t* tile_sizes, uint64_t max_image_size_pixels);
+HIPDEC_API void hipdec_grid_rccl_free(hipdec_grid_rccl* g);
+HIPDEC_API int hipdec_grid_rccl_decode(hipdec_grid_rccl* g);   /* asynchronous: decode + gather + paste queued on the rank's stream */
+HIPDEC_API int hipdec_grid_rccl_wait(hipdec_grid_rccl* g);     /* this rank's work; device-side errors of its shard */
+/* rank 0 only (it owns the canvas): */
+HIPDEC_API int hipdec_grid_rccl_canvas_plane(hipdec_grid_rccl* g, int c, const void** dptr, size_t* stride);
+HIPDEC_API int hipdec_grid_rccl_read_plane(hipdec_grid_rccl* g, int c, void* dst_host, size_t dst_stride);
+HIPDEC_API int hipdec_grid_rccl_to_rgb(hipdec_grid_rccl* g, int out_chroma, int upsampling, int only_preferred, void* out, size_t out_stride,
+                                       int out_on_device);
 
 /* ---- colour stage ---------------------------------------------------------------------------- */
 typedef struct hipdec_nclx {

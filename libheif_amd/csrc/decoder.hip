@@ -48,8 +48,10 @@ struct hipdec_batch : BatchLayout {
   ColorBatchState color;        // parameter blocks of hipdec_batch_to_rgb_all
   // decoder path (plugin): the output planes of every item staged in pinned host memory by ONE set of asynchronous copies behind the
   // kernels, so that N decoder instances sharing the batch do not queue N x 3 pageable device-to-host copies (stage_planes_to_host)
-  struct HostItem { void* p = nullptr; size_t capacity = 0; size_t off[3] = {0, 0, 0}; };
+  struct HostItem { void* p = nullptr; size_t off[3] = {0, 0, 0}; };   // p points into host_slab
   std::vector<HostItem> host_items;
+  void* host_slab = nullptr;    // ONE pinned buffer per launch set, items sub-allocated at 256-B alignment (a buffer per item
+  size_t host_slab_capacity = 0; //  rounded every thumbnail up to a 16 MiB class)
   // Waits for everything enqueued for THIS batch — not for the stream, which may already carry the next batch.
   hipError_t wait() const
   {
@@ -74,7 +76,7 @@ struct hipdec_batch : BatchLayout {
     DeviceScope scope(device);
     if (arena || staging) (void)wait();   // nothing of this batch may still be running when the arena is recycled
     release_staging();
-    for (auto& h : host_items) pinned_release(h.p, h.capacity);
+    pinned_release(host_slab, host_slab_capacity);
     color_batch_state_free(color);
     if (arena) arena_release(arena, arena_capacity);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -149,6 +151,10 @@ hipStream_t follow_stream(hipdec_batch* b, void* stream)
   if (s != b->last_stream && b->done_recorded) (void)hipStreamWaitEvent(s, b->done, 0);
   return s;
 }
+
+}  // namespace
+namespace hipdec { hipStream_t batch_follow_stream(hipdec_batch* b, hipStream_t s) { return follow_stream(b, (void*)s); } }
+namespace {
 
 int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nullptr)
 {
@@ -252,18 +258,34 @@ int stage_planes_to_host(hipdec_batch& b, hipStream_t s)
   static const bool off = getenv("HIPDEC_NO_HOST_STAGING") != nullptr;
   if (off) return 0;
   const size_t es = b.wide ? 2 : 1;
-  b.host_items.assign(b.params.size(), hipdec_batch::HostItem{});
+  std::vector<hipdec_batch::HostItem> items(b.params.size());
+  std::vector<size_t> base(b.params.size(), 0);
+  size_t slab = 0;
   for (size_t i = 0; i < b.params.size(); i++) {
     const PicParams& P = b.params[i];
-    hipdec_batch::HostItem& h = b.host_items[i];
     size_t total = 0;
     for (int c = 0; c < (P.chroma_format_idc ? 3 : 1); c++) {
-      h.off[c] = total;
+      items[i].off[c] = total;
       total += (size_t)(c ? P.out_cwidth : P.out_width) * es * (size_t)(c ? P.out_cheight : P.out_height);
       total = (total + 255) & ~size_t(255);
     }
-    if (!total) continue;
-    HIPDEC_CHECK_HIP(pinned_acquire(&h.p, total, &h.capacity));
+    base[i] = slab;
+    slab += total;
+  }
+  if (!slab) return 0;
+  if (b.host_slab && b.host_slab_capacity < slab) { pinned_release(b.host_slab, b.host_slab_capacity); b.host_slab = nullptr; b.host_slab_capacity = 0; }
+  if (!b.host_slab && pinned_acquire(&b.host_slab, slab, &b.host_slab_capacity) != hipSuccess) {
+    // no pinned memory even after the pool was emptied (pinned_acquire retries once): the instances read their planes straight from the
+    // device instead (hipdec_batch_read_plane's unstaged path) - slower, but not an error
+    (void)hipGetLastError();
+    b.host_slab = nullptr; b.host_slab_capacity = 0;
+    b.host_items.clear();
+    return 0;
+  }
+  for (size_t i = 0; i < b.params.size(); i++) {
+    const PicParams& P = b.params[i];
+    hipdec_batch::HostItem& h = items[i];
+    h.p = (uint8_t*)b.host_slab + base[i];
     for (int c = 0; c < (P.chroma_format_idc ? 3 : 1); c++) {
       const size_t w = (size_t)(c ? P.out_cwidth : P.out_width) * es, hh = (size_t)(c ? P.out_cheight : P.out_height);
       if (!w || !hh) continue;
@@ -271,6 +293,7 @@ int stage_planes_to_host(hipdec_batch& b, hipStream_t s)
       else HIPDEC_CHECK_HIP(hipMemcpy2DAsync((uint8_t*)h.p + h.off[c], w, b.arena + P.off_out[c], P.out_stride[c], w, hh, hipMemcpyDeviceToHost, s));
     }
   }
+  b.host_items.swap(items);
   b.mark_done(s);
   return 0;
 }
@@ -660,7 +683,8 @@ struct Coalescer {
   Clock::time_point last_arrival{}, last_overlap{};
   long window_us = -1, quiet_us = 300;
   long busy_requests = 16;               // a leader keeps gathering while max_sets launch sets with more requests than this are running ...
-  long hold_us = 1000000;                // ... for at most this long (HIPDEC_COALESCE_BUSY / HIPDEC_COALESCE_HOLD_US)
+  long hold_us = 300000;                 // ... for at most this long (HIPDEC_COALESCE_BUSY / HIPDEC_COALESCE_HOLD_US; 1 s in round 3: a lone still that
+                                         // arrived behind a holding leader waited that long)
   int max_sets = 3;                      // launch sets in flight before a leader holds (HIPDEC_COALESCE_SETS): they overlap, each with a third of the pool
                                          // waves (measured, direct C ABI, 256 / 1024 threads: 3.8 / 7.4 Gpixel/s with 2, 4.2 / 7.9 with 3, 3.5 / 7.7 with 4)
   long max_set = 256;                    // requests per launch set at most (HIPDEC_COALESCE_MAX_SET): keeps the sets' arenas and staging buffers in a
@@ -709,7 +733,7 @@ void run_single(DecodeRequest& r, hipStream_t s)
   d->item = 0;
 }
 
-void run_group(std::vector<DecodeRequest*>& group, hipStream_t s)
+void run_group(std::vector<DecodeRequest*>& group, hipStream_t s, uint32_t wave_share)
 {
   if (group.size() == 1) { run_single(*group[0], s); return; }
   std::vector<const void*> ptrs;
@@ -722,7 +746,7 @@ void run_group(std::vector<DecodeRequest*>& group, hipStream_t s)
   const auto t1 = Clock::now();
   auto t2 = t1, t3 = t1;
   if (!rc) {
-    b->wave_share = (uint32_t)g_co.max_sets;
+    b->wave_share = wave_share;   // the launch sets in flight when this one started share the CABAC pool's wave slots (a lone burst gets them all)
     rc = hipdec_batch_run(b, (void*)s);
     t2 = Clock::now();
     if (!rc) rc = stage_planes_to_host(*b, follow_stream(b, (void*)s));
@@ -747,11 +771,11 @@ void run_group(std::vector<DecodeRequest*>& group, hipStream_t s)
   // a bad item, or a mix the batch layout refuses (8-bit with 10-bit items): halve the group until the culprit is alone,
   // so that it alone gets the error and the others still share launch sets
   std::vector<DecodeRequest*> lo(group.begin(), group.begin() + (long)(group.size() / 2)), hi(group.begin() + (long)(group.size() / 2), group.end());
-  run_group(lo, s);
-  run_group(hi, s);
+  run_group(lo, s, wave_share);
+  run_group(hi, s, wave_share);
 }
 
-void run_requests(std::vector<DecodeRequest*>& take)
+void run_requests(std::vector<DecodeRequest*>& take, uint32_t wave_share)
 {
   hipStream_t s = stream_acquire();   // own stream per launch set: batches of different leaders overlap on the GPU
   std::vector<bool> used(take.size(), false);
@@ -760,7 +784,7 @@ void run_requests(std::vector<DecodeRequest*>& take)
     std::vector<DecodeRequest*> group;   // security limits are per instance: only equal limits share a batch
     for (size_t j = i; j < take.size(); j++)
       if (!used[j] && take[j]->d->max_pixels == take[i]->d->max_pixels) { used[j] = true; group.push_back(take[j]); }
-    run_group(group, s);
+    run_group(group, s, wave_share);
   }
   stream_release(s);
 }
@@ -901,11 +925,13 @@ static int decoder_decode_impl(hipdec_decoder* d, hipdec_image_info* info)
         for (auto* r : take) { r->taken = true; uncount(r->d); }
         g_co.in_flight += (int)take.size();
         g_co.sets_in_flight++;
+        // a set that starts alone takes the whole pool; one that starts beside k others takes 1 / (k + 1), at least 1 / max_sets
+        const uint32_t wave_share = (uint32_t)std::min(std::max(g_co.sets_in_flight, 1), g_co.max_sets);
         counted_in_flight = true;
         g_co.collecting = false;
         g_co.cv.notify_all();
         lk.unlock();
-        run_requests(take);
+        run_requests(take, wave_share);
         lk.lock();
       } catch (...) {
         // (bad_alloc in the group vectors / batch construction): no follower may be left waiting on a request this leader took, and the
@@ -1411,6 +1437,8 @@ struct hipdec_grid {
   std::vector<std::vector<int>> shard_tiles;      // tile indices of shard s, in batch order
   std::vector<hipStream_t> stream;                // one per shard, on its device
   std::vector<hipEvent_t> pasted;                 // per shard: its tiles are in the canvas
+  std::vector<int> transport;                     // per shard: 0 = on the root device, 1 = peer access to the root enabled (direct xGMI writes), 2 = no peer
+                                                  // access (the runtime stages the copy)
   int root = 0;                                   // device of the canvas
   uint8_t* canvas = nullptr;
   size_t canvas_capacity = 0;
@@ -1451,13 +1479,18 @@ int hipdec_grid_create(hipdec_grid** out, int rows, int cols, int out_width, int
         return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_create: device %d is not usable (%d devices visible, at most %d supported)", d, visible, max_devices());
     const int G = (int)g->devices.size();
     g->rows = rows; g->cols = cols; g->out_w = out_width; g->out_h = out_height; g->root = g->devices[0];
-    g->shard.resize((size_t)G); g->shard_tiles.resize((size_t)G); g->stream.assign((size_t)G, nullptr); g->pasted.assign((size_t)G, nullptr);
+    g->shard.resize((size_t)G); g->shard_tiles.resize((size_t)G); g->stream.assign((size_t)G, nullptr); g->pasted.assign((size_t)G, nullptr); g->transport.assign((size_t)G, 0);
     for (int t = 0; t < n_tiles; t++) g->shard_tiles[(size_t)(t % G)].push_back(t);
     for (int s = 0; s < G; s++) {
       DeviceScope scope(g->devices[s]);
       if (g->devices[s] != g->root) {   // direct peer copies into the canvas where the topology allows them
         int can = 0;
-        if (hipDeviceCanAccessPeer(&can, g->devices[s], g->root) == hipSuccess && can) { (void)hipDeviceEnablePeerAccess(g->root, 0); (void)hipGetLastError(); }
+        g->transport[(size_t)s] = 2;
+        if (hipDeviceCanAccessPeer(&can, g->devices[s], g->root) == hipSuccess && can) {
+          const hipError_t pe = hipDeviceEnablePeerAccess(g->root, 0);
+          if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) g->transport[(size_t)s] = 1;
+          (void)hipGetLastError();
+        }
       }
       std::vector<const void*> ptrs;
       std::vector<size_t> sizes;
@@ -1508,6 +1541,17 @@ int hipdec_grid_info(const hipdec_grid* g, hipdec_image_info* info, int* n_shard
   for (const auto& b : g->shard) for (const auto& p : b->pics) { bytes += p.info.bitstream_bytes; subs += p.info.num_substreams; }
   info->bitstream_bytes = bytes; info->num_substreams = subs;
   if (n_shards) *n_shards = (int)g->shard.size();
+  return 0;
+}
+
+int hipdec_grid_transport(const hipdec_grid* g, int* local_shards, int* peer_shards, int* staged_shards)
+{
+  if (!g) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_transport: NULL grid");
+  int n[3] = {0, 0, 0};
+  for (int t : g->transport) n[t < 0 || t > 2 ? 2 : t]++;
+  if (local_shards) *local_shards = n[0];
+  if (peer_shards) *peer_shards = n[1];
+  if (staged_shards) *staged_shards = n[2];
   return 0;
 }
 

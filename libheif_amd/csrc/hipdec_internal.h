@@ -48,6 +48,12 @@ void status_slot_release(int32_t* p);
 hipStream_t stream_acquire();
 void stream_release(hipStream_t s);
 
+// the stream follow-up work of a batch goes on (made to wait for the batch's last recorded work when that ran elsewhere: decoder.hip follow_stream)
+}  // namespace hipdec
+struct hipdec_batch;
+namespace hipdec {
+hipStream_t batch_follow_stream(hipdec_batch* b, hipStream_t s);
+
 // Colour stage of a whole batch as ONE launch (color.hip): between begin and launch this thread's hipdec_color_* calls record
 // their parameter blocks instead of launching; the blocks live in a device array owned by the batch.
 struct ColorBatchState {

@@ -3,6 +3,8 @@
 // compute entry point fails with HIPDEC_ERR_DEVICE.
 #include "hipdec_internal.h"
 #include <atomic>
+#include <algorithm>
+#include <unistd.h>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -109,23 +111,26 @@ ArenaPool g_pool;
 // double-buffered "parse + upload batch k+1 while batch k decodes" pipeline.
 // (round 3: sized for the 288 GB of an MI355X.  The decoder path builds a batch per launch set — hundreds of stills, several GiB —
 //  and with the round-2 defaults (8 GiB parked, arenas above 1 GiB never) every set paid a hipMalloc and a device-synchronising hipFree.)
-std::atomic<size_t> g_max_cached_bytes{size_t(96) << 30};   // keep at most 96 GiB parked
-std::atomic<size_t> g_max_pooled_arena{size_t(64) << 30};   // bigger arenas are not cached
+// (round 4, ADVICE: the caps are derived from the device at hipdec_init — a third / two ninths of its memory, i.e. 96 / 64 GiB on the 288 GB of
+//  an MI355X and proportionally less on a smaller or shared device; hipdec_set_arena_cache_bytes() or HIPDEC_ARENA_CACHE_GIB override them.)
+std::atomic<size_t> g_max_cached_bytes{size_t(8) << 30};    // keep at most this much parked
+std::atomic<size_t> g_max_pooled_arena{size_t(4) << 30};    // bigger arenas are not cached
 
 struct PinnedPool {
   std::mutex mu;
   std::vector<std::pair<size_t, void*>> free_list;
   size_t cached_bytes = 0;
 };
-constexpr size_t kMaxPinnedCached = size_t(24) << 30;   // pinned buffers parked for reuse (upload staging, per-item plane staging of the decoder path)
-PinnedPool g_pinned;
+std::atomic<size_t> g_max_pinned_cached{size_t(2) << 30};   // pinned buffers parked for reuse (upload staging, plane staging of the decoder path): an eighth
+PinnedPool g_pinned;                                         // of the host's RAM, at most 24 GiB (set at hipdec_init)
 }  // namespace
 
 // Pinned host staging buffers for the upload region of large batches (so that the H2D copy is asynchronous and runs at PCIe
 // speed); recycled, because hipHostMalloc of a GiB costs more than the copy it feeds.
 hipError_t pinned_acquire(void** out, size_t bytes, size_t* capacity)
 {
-  const size_t kClass = size_t(16) << 20;
+  // size classes: 256 KiB steps up to 4 MiB, 1 MiB steps up to 64 MiB, 16 MiB steps above (a launch set of thumbnails must not pin 16 MiB each)
+  const size_t kClass = bytes <= (size_t(4) << 20) ? (size_t(256) << 10) : (bytes <= (size_t(64) << 20) ? (size_t(1) << 20) : (size_t(16) << 20));
   bytes = (bytes + kClass - 1) / kClass * kClass;
   {
     std::lock_guard<std::mutex> lock(g_pinned.mu);
@@ -143,7 +148,13 @@ hipError_t pinned_acquire(void** out, size_t bytes, size_t* capacity)
     }
   }
   *capacity = bytes;
-  return hipHostMalloc(out, bytes, hipHostMallocDefault);
+  hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {   // out of pinnable memory: hand the parked buffers back and retry once (as arena_acquire does)
+    (void)hipGetLastError();
+    pinned_pool_clear();
+    e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+  }
+  return e;
 }
 
 void pinned_release(void* p, size_t capacity)
@@ -151,7 +162,7 @@ void pinned_release(void* p, size_t capacity)
   if (!p) return;
   {
     std::lock_guard<std::mutex> lock(g_pinned.mu);
-    if (g_pinned.cached_bytes + capacity <= kMaxPinnedCached && g_pinned.free_list.size() < 8192) {
+    if (g_pinned.cached_bytes + capacity <= g_max_pinned_cached.load() && g_pinned.free_list.size() < 1024) {
       g_pinned.free_list.emplace_back(capacity, p); g_pinned.cached_bytes += capacity; return;
     }
   }
@@ -301,6 +312,16 @@ int hipdec_init(int device_index)
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) g_cu_count = cus;
+    // cache caps from the device and the host
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) {
+      size_t cached = total_b / 3, single = total_b / 9 * 2;
+      if (const char* q = getenv("HIPDEC_ARENA_CACHE_GIB")) { cached = (size_t)std::max(0L, atol(q)) << 30; single = cached; }
+      g_max_cached_bytes.store(cached);
+      g_max_pooled_arena.store(std::max(single, size_t(1) << 30));
+    }
+    const long pages = sysconf(_SC_PHYS_PAGES), page = sysconf(_SC_PAGESIZE);
+    if (pages > 0 && page > 0) g_max_pinned_cached.store(std::min((size_t)pages * (size_t)page / 8, size_t(24) << 30));
   }
   g_device = dev;
   g_initialised = true;

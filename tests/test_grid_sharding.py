@@ -165,3 +165,50 @@ def test_grid_c_api_main10_and_errors():
         GridDecoderC({0: a, 1: b}, GridLayout(1, 2, 64, 64, 128, 64))
     with pytest.raises(HipDecError):           # a device that does not exist
         GridDecoderC({0: a, 1: a}, GridLayout(1, 2, 64, 64, 128, 64), [0, 99])
+
+
+# ---- the SPMD product path: hipdec_grid_*_rccl (one process per GPU, RCCL gather inside libheifhip.so) --------------------------------
+def test_grid_rccl_entry_points_without_gpu_fail_loudly():
+    import ctypes as C
+    import libheif_amd
+    lib = libheif_amd.load_library()
+    if lib.hipdec_device_count() > 0:
+        pytest.skip("a GPU is present")
+    assert lib.hipdec_rccl_available() in (0, 1)
+    h = C.c_void_p()
+    lib.hipdec_rccl_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]
+    buf = C.create_string_buffer(128)
+    assert lib.hipdec_rccl_comm_create(C.byref(h), 1, 0, buf) != 0 and not h.value            # no device (or no RCCL): an error, never a fake communicator
+    assert lib.hipdec_rccl_comm_create(C.byref(h), 2, 2, buf) == -1                              # rank out of range
+    lib.hipdec_grid_create_rccl.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
+    assert lib.hipdec_grid_create_rccl(C.byref(h), None, 0, 1, 1, 2, 128, 64, None, None, 0) == -1   # NULL communicator / tiles
+    lib.hipdec_grid_rccl_decode.argtypes = [C.c_void_p]
+    assert lib.hipdec_grid_rccl_decode(None) == -1
+
+
+@pytest.mark.gpu
+def test_grid_rccl_world1_matches_oracle_and_the_one_process_form():
+    """the GPU box has one GPU (RCCL refuses two ranks on one device), so this runs the whole SPMD path - communicator from
+    hipdec_rccl_comm_create, the geometry all-reduce, decode, paste, colour stage - at world size 1; the N-rank sends / receives first run in
+    `bench.py --gpus N` (grid_sharded.rccl), which compares their canvas with this same one-GPU result"""
+    import libheif_amd
+    from libheif_amd.grid import GridDecoderC, GridDecoderRccl, GridLayout, RcclComm
+    if not libheif_amd.load_library().hipdec_rccl_available():
+        pytest.skip("librccl is not loadable here")
+    vui = dict(vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1)
+    L = GridLayout(2, 3, 128, 128, 380, 250)
+    streams = {t: orc.encode(orc.synth_image(128, 128, 8, 1, seed=90 + t), wpp=t % 2, **vui) for t in range(6)}
+    comm = RcclComm(0, 1)
+    g = GridDecoderRccl(streams, L, comm)
+    g.decode(); g.wait()
+    got = g.planes()
+    exp = _expected_canvas(L, streams)
+    for c in range(3):
+        np.testing.assert_array_equal(got[c], exp[c], err_msg="canvas component %d" % c)
+    rgb = g.to_rgb(10)
+    ref = GridDecoderC(streams, L, [0])
+    ref.decode(); ref.wait()
+    np.testing.assert_array_equal(rgb, ref.to_rgb(10))
+    g.decode(); g.wait()      # again over the same buffers
+    np.testing.assert_array_equal(g.planes()[0], exp[0])
+    g.free(); ref.free(); comm.free()
