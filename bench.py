@@ -4,24 +4,29 @@
 One "step" = one pass of the whole hot path over one batch of synthetic coded stills: CABAC parse -> dequantisation /
 inverse transforms -> intra reconstruction -> deblock -> SAO + crop -> fused YCbCr->RGB, all through the C ABI
 (include/heif_hipdec.h).  N=1 workload = BASELINE config 1 (3840x2160 4:2:0 8-bit stills, fused YCbCr->RGB24), `--batch`
-independent stills per step (throughput form).  Two timed regions are reported:
+independent stills per step (throughput form).  Two timed regions are measured, W warm-up + K timed steps each:
 
-  value / ms_per_step   inputs resident in HBM when the timed region starts (the bench contract): hipdec_batch_run +
-                        hipdec_batch_to_rgb_all per step;
-  from_host_bytes       SURVEY.md §8(d)'s definition, "from compressed bytes in host memory to planes + RGB complete in HBM":
-                        every step also pays hipdec_batch_create (host header parsing on worker threads, pinned staging, the
-                        H2D upload), double-buffered against the previous step's kernels.
+  value / ms_per_step   SURVEY.md 8(d)'s definition, "from compressed bytes in host memory to planes + RGB complete in HBM" (round 4: the
+                        headline, as the round-3 review asked): every step pays hipdec_batch_create_recycling (host header parsing on
+                        worker threads, pinned staging, the H2D upload) + decode + colour stage, double-buffered against the previous
+                        step's kernels;
+  value_resident        inputs resident in HBM when the timed region starts: hipdec_batch_run_rgb per step (the per-kernel HIP-event
+                        times and the roofline come from this region; with --only-main it is the only one and `value` reports it).
 
-Beside them: per-kernel device times (HIP events on the launch stream) with §8(d)'s algorithmic bytes, the single-still
-latency form, the other synthetic inputs of §8(d) (S2 at QP 17, S3 grid, S4 Main10, S5 1080p) as `extra_workloads`, and the
-CPU oracle on the host cores.  With --gpus N (torch.distributed.run, one rank per GPU) every rank decodes its own batch
-(weak scaling, no data-path collective: independent stills exchange nothing).  `--workload grid8k` measures grid photos:
-every rank decodes its own stream of 8K grid photos (photo i -> GPU i mod N: throughput scales with independent photos);
-`--workload grid8k --grid-single` is the single-photo latency form (rank 0 shards the 48 tiles t mod N over the N devices with
-hipdec_grid_*, strided peer-copy paste into the canvas on device 0: expected flat).
+Beside them: per-kernel device times (HIP events on the launch stream) with 8(d)'s algorithmic bytes, the issue roofline of the
+instruction-bound kernels, the batch-size curve (64 .. 2048 stills per batch), BASELINE.json's configs as written (`baseline_configs`:
+one 4K still; the 8K grid; Main10 4K with the PQ -> linear-RGB stage inside the timed region; 1024 x 1080p), further synthetic inputs
+(`extra_workloads`), the drop-in form through the real libheif, and the CPU oracle on the host cores.
 
-After the timed regions the run CHECKS a result: the planes and the RGB24 of still 0 are read back and compared with the CPU oracle's
-decode of the same stream (the cpu_baseline leg decodes it anyway); a mismatch fails the run.
+With --gpus N (torch.distributed.run, one rank per GPU) every rank decodes its own batches (weak scaling, no data-path collective:
+independent stills exchange nothing), and the line carries `grid_sharded`: ONE 8K grid photo (BASELINE config 3) with its 48 tiles
+sharded t mod N over the N GPUs, once through hipdec_grid_* (rank 0 drives all devices, strided peer-copy paste) and once through
+hipdec_grid_*_rccl (every rank decodes its tiles, grouped ncclSend / ncclRecv gather inside libheifhip.so), both checked against the
+one-GPU canvas, with the strong-scaling efficiency stated.  `--workload grid8k` makes that single photo the main measurement (strong
+scaling, as in rounds 1 - 2); `--workload grid8k_multi` gives every rank its own photos (weak).
+
+After the timed regions the run CHECKS results: planes and RGB24 of 32 stills spread over the batch are read back and compared with the
+CPU oracle's decode of their streams (the cpu_baseline leg decodes them anyway); a mismatch fails the run.
 
 Prints ONE JSON line (rank 0).
 """
@@ -46,16 +51,17 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="still4k", choices=["still4k", "still1080", "main10_4k", "grid8k"])
+    ap.add_argument("--workload", default="still4k", choices=["still4k", "still1080", "main10_4k", "grid8k", "grid8k_multi"])
     ap.add_argument("--batch", type=int, default=0, help="independent stills per rank and step (0 = workload default)")
-    ap.add_argument("--grid-single", action="store_true", help="grid8k: ONE photo, its 48 tiles sharded t mod N over the N devices by rank 0 (latency form; the "
-                    "default grid8k mode gives every rank its own photos: photo i -> GPU i mod N)")
+    ap.add_argument("--grid-single", action="store_true", help="(kept for old command lines: `--workload grid8k` IS the single-photo form again)")
+    ap.add_argument("--no-grid-sharded", action="store_true", help="skip the grid_sharded section (one 8K grid photo over the N GPUs: peer copies and RCCL)")
+    ap.add_argument("--verify-stills", type=int, default=32, help="stills of the batch checked against the CPU oracle after the timed regions")
     ap.add_argument("--no-dropin", action="store_true", help="skip the T threads x heif_decode_image() measurement through the real libheif + plugin")
     ap.add_argument("--qp", type=int, default=27)
     ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic contents cycled through the batch")
     ap.add_argument("--enc", action="append", default=[], help="override a synthetic-encoder parameter, e.g. --enc wpp=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads (S2 @ QP 17, S3, S4, S5) and the from-host form")
+    ap.add_argument("--no-extras", action="store_true", help="skip the batch curve, BASELINE's other configs and the extra workloads")
     ap.add_argument("--only-main", action="store_true", help="main resident measurement only (profiling runs)")
     ap.add_argument("--parts", type=int, default=1, help="batches a step is split into; with 2, batch k+1's CABAC parse is queued beside batch k's "
                     "pixel stages on a second stream (hipdec_set_stage_overlap).  Measured SLOWER (12.1 against 13.7 Gpixel/s): the CABAC work pool "
@@ -65,12 +71,14 @@ def parse_args():
     return ap.parse_args()
 
 
+GRID_VUI = dict(wpp=1, vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1)
 WORKLOADS = {
     # name: (width, height, default batch, bit depth, encoder config, output heif_chroma)
     "still4k": (3840, 2160, 2048, 8, dict(wpp=1), 10),
     "still1080": (1920, 1080, 1024, 8, dict(wpp=1), 10),
     "main10_4k": (3840, 2160, 256, 10, dict(wpp=1, vui_matrix=9, vui_primaries=9, vui_transfer=16), 14),
-    "grid8k": (1024, 1024, 48, 8, dict(wpp=1, vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1), 10),
+    "grid8k": (1024, 1024, 48, 8, GRID_VUI, 10),
+    "grid8k_multi": (1024, 1024, 48, 8, GRID_VUI, 10),
     # 4:4:4 to RGB24 through Op_YCbCr_to_RGB + Op_RGB_to_RGB24_32 (no fused form); 4:2:2 Main10 (what cameras write) as planes: output chroma None
     "still1080_444": (1920, 1080, 512, 8, dict(wpp=1, chroma_format_idc=3), 10),
     "still1080_422_10": (1920, 1080, 512, 10, dict(wpp=1, chroma_format_idc=2), None),
@@ -163,13 +171,13 @@ def coded_fraction(batch, chroma_weight=0.25):
 
 
 def alg_bytes(beta, coded, s, s_out, spp=1.5):
-    """algorithmic bytes per luma pixel (SURVEY.md §8d; DESIGN.md §4): s = bytes per sample, s_out = bytes per output sample
+    """algorithmic bytes per luma pixel (SURVEY.md 8d; DESIGN.md section 4): s = bytes per sample, s_out = bytes per output sample
          parse     beta (bitstream) in + 5/16 B unit maps + 2 B per coded sample (coefficient levels) out
          residual  2 B per coded sample in + 2 B out (in place)
-         recon     1.5 s written + 2 B per coded sample read                              (§8d "recon")
-         deblock   3 s + 1/16 (bS / QP metadata), both edge directions together          (§8d "deblock")
-         sao       1.5 s in + 1.5 s out                                                   (§8d "SAO")
-         colour    1.5 s in + 3 s_out out                                                 (§8d "fused colour stage")"""
+         recon     1.5 s written + 2 B per coded sample read                              (8d "recon")
+         deblock   3 s + 1/16 (bS / QP metadata), both edge directions together          (8d "deblock")
+         sao       1.5 s in + 1.5 s out                                                   (8d "SAO")
+         colour    1.5 s in + 3 s_out out                                                 (8d "fused colour stage")"""
     # spp = samples per luma pixel over the three planes: 1.5 (4:2:0; the figures above), 2 (4:2:2), 3 (4:4:4)
     return dict(parse=beta + 5 / 16 + 2 * coded, residual=4 * coded, recon=spp * s + 2 * coded, deblock=2 * spp * s + 1 / 16,
                 sao=2 * spp * s, colour=spp * s + 3 * s_out)
@@ -193,6 +201,27 @@ def kernel_table(avg_us, alg, px, colour_stage=True):
     return out
 
 
+def issue_roofline(kernels, px, cu_count, clock_ghz):
+    """The CABAC parser and the intra reconstruction are bound by instruction issue, not by HBM: their yardstick is the
+    CU-shared scalar pipe, one SALU instruction per cycle and CU.  Instructions per luma pixel come from the committed PMC passes
+    (profiles/pmc_issue.json: SQ_INSTS_SALU / _VALU / _BRANCH per kernel, tools/prof_parse_pmc.sh); they are a property of the code and the
+    content, not of the batch size, so the file's figures are applied to this run's pixels and kernel times."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_issue.json")))
+    except Exception:
+        return None
+    peak = cu_count * clock_ghz            # G scalar instructions / s
+    out = {"peak_ginst_s": round(peak, 1), "peak_is": "%d CUs x %.2f GHz x 1 SALU instruction per cycle and CU" % (cu_count, clock_ghz),
+           "source": rec.get("source"), "kernels": {}}
+    for key, name in (("parse", "k_parse"), ("recon", "k_recon")):
+        if key in kernels and name in rec.get("insts_per_px", {}) and kernels[key]["avg_us"] > 0:
+            ipp = rec["insts_per_px"][name]
+            ach = ipp["salu"] * px / (kernels[key]["avg_us"] * 1e-6) / 1e9
+            out["kernels"][key] = {"kernel": kernels[key]["kernel"], "salu_per_px": ipp["salu"], "valu_per_px": ipp["valu"], "branch_per_px": ipp.get("branch"),
+                                   "achieved_ginst_s": round(ach, 1), "frac_of_scalar_issue_peak": round(ach / peak, 4)}
+    return out
+
+
 def main():
     a = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -204,8 +233,10 @@ def main():
     for kv in a.enc:
         k, v = kv.split("=")
         enc_cfg[k] = int(v)
-    grid = a.workload == "grid8k"
+    grid = a.workload in ("grid8k", "grid8k_multi")
+    grid_single = a.workload == "grid8k"
     extras_on = not (a.no_extras or a.only_main) and world == 1 and not grid
+    sharded_on = not (a.no_grid_sharded or a.only_main or grid)
     if grid:
         specs = [(w, h, 2 + t, 8, enc_cfg) for t in range(48)]
         nb = 48
@@ -214,21 +245,26 @@ def main():
         nd = max(1, min(a.distinct, nb))
         specs = [(w, h, 1 + i, bit_depth, enc_cfg) for i in range(nd)]      # S2 / S4 / S5: seeds 1..nd (every rank cycles the same set,
     distinct = gen_streams(specs, rank, world)                                 # starting at its own offset)
+    grid_specs = {}
+    if sharded_on or extras_on:
+        grid_specs["wpp"] = [(1024, 1024, 2 + t, 8, dict(GRID_VUI, qp=a.qp)) for t in range(48)]
+        grid_specs["pps_tiles_4x4"] = [(1024, 1024, 2 + t, 8, dict(GRID_VUI, qp=a.qp, tile_cols=4, tile_rows=4)) for t in range(48)]
     extra_specs = {}
     if extras_on:
+        grid_specs["pps_tiles_2x2"] = [(1024, 1024, 2 + t, 8, dict(GRID_VUI, qp=a.qp, tile_cols=2, tile_rows=2)) for t in range(48)]
         extra_specs = {
             "s2_4k_qp17": ("still4k", [(3840, 2160, 1 + i, 8, dict(wpp=1, qp=17)) for i in range(64)], 1024),
-            "s4_main10_4k": ("main10_4k", [(3840, 2160, 3 + i, 10, dict(WORKLOADS["main10_4k"][4], qp=a.qp)) for i in range(64)], 768),
-            "s5_1080p": ("still1080", [(1920, 1080, 1000 + i, 8, dict(wpp=1, qp=a.qp)) for i in range(256)], 2048),
-            "s3_grid8k": ("grid8k", [(1024, 1024, 2 + t, 8, dict(WORKLOADS["grid8k"][4], qp=a.qp)) for t in range(48)], 48),
+            # BASELINE config 5 as written: 1024 x 1080p stills (256 distinct contents)
+            "c5_1080p_1024": ("still1080", [(1920, 1080, 1000 + i, 8, dict(wpp=1, qp=a.qp)) for i in range(256)], 1024),
+            "s5_1080p_2048": ("still1080", [(1920, 1080, 1000 + i, 8, dict(wpp=1, qp=a.qp)) for i in range(256)], 2048),
+            # BASELINE config 4 as written: Main10 4K, YCbCr -> RRGGBB and the PQ -> linear-RGB stage (hipdec_color_pq_to_linear) inside the timed region
+            "c4_main10_4k_pq_linear": ("main10_4k", [(3840, 2160, 3 + i, 10, dict(WORKLOADS["main10_4k"][4], qp=a.qp)) for i in range(64)], 512),
             # beyond SURVEY 8(d): the chroma formats added in round 3
             "s6_444_1080p": ("still1080_444", [(1920, 1080, 2000 + i, 8, dict(WORKLOADS["still1080_444"][4], qp=a.qp)) for i in range(32)], 512),
             "s7_422_main10_1080p": ("still1080_422_10", [(1920, 1080, 3000 + i, 10, dict(WORKLOADS["still1080_422_10"][4], qp=a.qp)) for i in range(32)], 512),
-            # tiles-within-tiles expose more CABAC substreams per grid tile (WPP rows inside PPS tiles): 16 -> 32 -> 64
-            "s3t_grid8k_pps_tiles_2x2": ("grid8k", [(1024, 1024, 2 + t, 8, dict(WORKLOADS["grid8k"][4], qp=a.qp, tile_cols=2, tile_rows=2)) for t in range(48)], 48),
-            "s3t_grid8k_pps_tiles_4x4": ("grid8k", [(1024, 1024, 2 + t, 8, dict(WORKLOADS["grid8k"][4], qp=a.qp, tile_cols=4, tile_rows=4)) for t in range(48)], 48),
         }
         extra_streams = {k: gen_streams(v[1]) for k, v in extra_specs.items()}
+    grid_streams = {k: gen_streams(v, rank, world) for k, v in grid_specs.items()}
 
     dist = None
     import torch
@@ -240,13 +276,18 @@ def main():
         raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
     torch.cuda.set_device(local_rank)
 
+    import ctypes as C
+    import numpy as np
     import libheif_amd
     from libheif_amd.decoder import Batch, HipDecoder
-    from libheif_amd._capi import check
+    from libheif_amd._capi import check, DeviceBuffer
+    from libheif_amd.grid import GridDecoderC, GridDecoderRccl, GridLayout, RcclComm
 
     lib = libheif_amd.load_library()
     check(lib.hipdec_init(local_rank))
-    lib.hipdec_set_arena_cache_bytes.argtypes = [__import__("ctypes").c_size_t]
+    props = torch.cuda.get_device_properties(local_rank)
+    cu_count = int(props.multi_processor_count)
+    clock_ghz = float(getattr(props, "clock_rate", 2400000)) / 1e6
 
     def sync():
         check(lib.hipdec_stream_synchronize(None))
@@ -275,22 +316,47 @@ def main():
             elapsed = float(tt.item())
         return elapsed
 
+    def grid_run(streams48, devices, steps=2, warmup=1, want_hash=False):
+        """one 8K grid photo through hipdec_grid_* on `devices` (this process drives them all): ms per photo, transport, canvas hash"""
+        g = GridDecoderC({t: streams48[t] for t in range(48)}, GridLayout(6, 8, 1024, 1024, 8192, 6144), devices)
+        rgb = torch.empty((6144, 8192 * 3), dtype=torch.uint8, device="cuda:%d" % devices[0])
+
+        def st():
+            g.decode(); g.to_rgb(10, out_dev=(rgb.data_ptr(), rgb.stride(0)))
+        for _ in range(warmup):
+            st()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st()
+        sync()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        n = [C.c_int(), C.c_int(), C.c_int()]
+        lib.hipdec_grid_transport.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 3
+        check(lib.hipdec_grid_transport(g._h, C.byref(n[0]), C.byref(n[1]), C.byref(n[2])))
+        hsh = None
+        if want_hash:
+            import hashlib
+            hsh = hashlib.sha1(rgb.cpu().numpy().tobytes()).hexdigest()
+        g.free()
+        return ms, {"shards_on_root_device": n[0].value, "peer_access_shards": n[1].value, "runtime_staged_shards": n[2].value}, hsh
+
     # ------------------------------------------------------------------------------------------------------------------
-    # main measurement: inputs resident in HBM
+    # main measurement, resident form: inputs in HBM when the timed region starts
     # ------------------------------------------------------------------------------------------------------------------
     gd = None
+    wl = None
+    rotated = distinct
     if grid:
-        # the product path: hipdec_grid_* in C++ (include/heif_hipdec.h).  Default: every rank decodes its own photos on its own GPU
-        # (photo i -> GPU i mod N; independent photos are what scales: DESIGN.md section 5).  --grid-single: ONE photo, rank 0 shards its
-        # 48 tiles t mod N over devices 0..N-1, every decoded tile is pasted into the canvas on device 0 by a strided peer copy
-        # (xGMI), the colour stage runs over the canvas; the other ranks only take part in the barriers.
-        from libheif_amd.grid import GridDecoderC, GridLayout
+        # the product path: hipdec_grid_* in C++ (include/heif_hipdec.h).  grid8k: ONE photo, rank 0 shards its 48 tiles t mod N over devices
+        # 0..N-1, every decoded tile is pasted into the canvas on device 0 by a strided peer copy (xGMI), the colour stage runs over the
+        # canvas; the other ranks only take part in the barriers (strong scaling).  grid8k_multi: every rank decodes its own photos on its
+        # own GPU (photo i -> GPU i mod N; weak scaling).
         layout = GridLayout(6, 8, w, h, 8 * w, 6 * h)
-        single = a.grid_single
         n_items, px_rank, bs_bytes = 48, w * h * 48, sum(len(x) for x in distinct)
-        total_px = w * h * 48 * (1 if single else world)
+        total_px = w * h * 48 * (1 if grid_single else world)
         batch = None
-        if single:
+        if grid_single:
             if rank == 0:
                 gd = GridDecoderC({t: distinct[t] for t in range(48)}, layout, list(range(world)))
                 rgb_out = torch.empty((6 * h, 8 * w * 3), dtype=torch.uint8, device="cuda:0")
@@ -305,7 +371,8 @@ def main():
     else:
         off = (rank * len(distinct)) // max(1, world)
         lib.hipdec_set_stage_overlap(1 if a.parts > 1 else 0)
-        wl = Workload(lib, a.workload, distinct[off:] + distinct[:off], nb, out_chroma, w, h, bit_depth, a.parts)
+        rotated = distinct[off:] + distinct[:off]
+        wl = Workload(lib, a.workload, rotated, nb, out_chroma, w, h, bit_depth, a.parts)
         wl.make_resident()
         batch = wl.batch
         n_items, px_rank, bs_bytes = wl.n, wl.px, wl.bs_bytes
@@ -318,18 +385,23 @@ def main():
         wl.status()            # device-side decode errors are loud
     elif gd is not None:
         gd.wait()
-    ms_per_step = elapsed / a.steps * 1e3
-    value = total_px / (elapsed / a.steps) / 1e6
+    ms_resident = elapsed / a.steps * 1e3
+    value_resident = total_px / (elapsed / a.steps) / 1e6
     avg_us = kernel_times(wl.batches, a.steps) if not grid else None
-    # what the timed steps produced for still 0 (checked against the CPU oracle further down; outside every timed region)
-    check_item = None
-    if batch is not None and rank == 0 and not a.only_main and not a.no_cpu_baseline:
+
+    # what the timed steps produced for stills spread over the batch (checked against the CPU oracle further down; outside every timed region)
+    check_items = {}
+    verify_on = batch is not None and rank == 0 and not a.only_main and not a.no_cpu_baseline and a.parts == 1 and world == 1
+    if verify_on:
         import hashlib
-        import numpy as np
-        got_planes = batch.planes(0)
-        got_rgb = batch.rgb(0)
-        check_item = {"planes": [hashlib.sha1(np.ascontiguousarray(p, dtype=np.uint16).tobytes()).hexdigest() for p in got_planes],
-                      "rgb": hashlib.sha1(np.ascontiguousarray(got_rgb).tobytes()).hexdigest()}
+        nv = max(1, min(a.verify_stills, n_items))
+        picks = sorted(set(min(n_items - 1, k * (n_items // nv) + k) for k in range(nv)))
+        for i in picks:
+            got_planes = batch.planes(i)
+            got_rgb = batch.rgb(i)
+            check_items[i] = {"content": i % len(rotated),
+                              "planes": [hashlib.sha1(np.ascontiguousarray(p, dtype=np.uint16).tobytes()).hexdigest() for p in got_planes],
+                              "rgb": hashlib.sha1(np.ascontiguousarray(got_rgb).tobytes()).hexdigest()}
 
     out = None
     if rank == 0:
@@ -338,21 +410,24 @@ def main():
         beta = bs_bytes / px_rank
         out = {
             "metric": "Mpixels/s HEIC 4:2:0 8-bit decode" if bit_depth == 8 else "Mpixels/s HEIC 4:2:0 %d-bit decode" % bit_depth,
-            "value": round(value, 2), "unit": "Mpixel/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "strong" if (grid and a.grid_single) else "weak", "vs_baseline": None,
+            "value": round(value_resident, 2), "unit": "Mpixel/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_resident, 3),
+            "higher_is_better": True, "scaling": "strong" if grid_single and grid else "weak", "vs_baseline": None,
             "dtype": "u8" if bit_depth == 8 else "u16",
             "data": "synthetic (seeded noise+gradient stills coded by the test-only HEVC intra encoder, QP %d, %d distinct contents)" % (a.qp, len(distinct)),
             "config": {"workload": (("one 8192x6144 grid photo = 48 tiles of 1024x1024, tiles t mod N over N GPUs in one process (hipdec_grid_*), peer-copy paste + RGB24 on GPU 0"
-                                     if a.grid_single else "one 8192x6144 grid photo (48 tiles of 1024x1024) per GPU and step through hipdec_grid_* + RGB24; photo i -> GPU i mod N") if grid else
+                                     if grid_single else "one 8192x6144 grid photo (48 tiles of 1024x1024) per GPU and step through hipdec_grid_* + RGB24; photo i -> GPU i mod N") if grid else
                                     "%d x %dx%d HEIC 4:2:0 %d-bit stills per GPU and step, WPP, CTB 64, fused YCbCr->%s" %
                                     (n_items, w, h, bit_depth, "RGB24" if out_chroma == 10 else "RRGGBB")),
-                       "timed_region": "inputs resident in HBM: hipdec_batch_run_rgb (decode + colour stage) per step (from host bytes: see from_host_bytes)",
+                       "timed_region": "inputs resident in HBM: hipdec_batch_run_rgb (decode + colour stage) per step",
                        "batches_per_step": a.parts if not grid else 1,
                        "stage_overlap": bool(a.parts > 1 and not grid),
                        "stills_per_step_per_gpu": n_items, "distinct_contents": len(distinct), "bitstream_bytes_per_px": round(beta, 4),
                        "substreams_per_still": batch.info(0)["num_substreams"] if batch is not None else 16,
-                       "parallelism": (("tiles sharded over %d GPUs, one process" % world) if a.grid_single else "independent photos, replicas x%d" % world) if grid else "replicas x%d" % world},
+                       "parallelism": (("tiles sharded over %d GPUs, one process" % world) if grid_single else "independent photos, replicas x%d" % world) if grid else "replicas x%d" % world},
+            "value_resident": round(value_resident, 2),
+            "resident": {"value": round(value_resident, 2), "unit": "Mpixel/s", "ms_per_step": round(ms_resident, 3),
+                         "timed_region": "inputs resident in HBM when the timed region starts: hipdec_batch_run_rgb per step"},
         }
         if avg_us is not None:
             coded = coded_fraction(batch)
@@ -372,16 +447,21 @@ def main():
                 pass
             out["roofline"] = dict(bound="hbm", kernel=KERNEL_NAMES[dom], achieved=kernels[dom]["achieved_gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
                                    frac=kernels[dom]["frac"], traffic=traffic, traffic_source=traffic_source,
-                                   note="dominant kernel by device time; CABAC parsing is bound by instruction issue (one dependency chain per "
-                                        "substream), not by HBM (DESIGN.md §4); streaming kernels: see `kernels`")
+                                   note="dominant kernel by device time, priced in algorithmic HBM bytes as the contract asks; CABAC parsing is bound by "
+                                        "instruction issue (one dependency chain per substream), not by HBM: its real yardstick is `issue_roofline` "
+                                        "(DESIGN.md section 4); streaming kernels: see `kernels`")
             out["kernels"] = kernels
+            ir = issue_roofline(kernels, px_rank, cu_count, clock_ghz)
+            if ir:
+                out["issue_roofline"] = ir
             out["coded_samples_per_px"] = round(coded, 4)
-            e2e = (beta + 3.0 * s + 3.0 * s_out) * px_rank    # drop-in end-to-end bytes (SURVEY §8d): beta + 1.5 s + 1.5 s + 3 s_out
+            e2e = (beta + 3.0 * s + 3.0 * s_out) * px_rank    # drop-in end-to-end bytes (SURVEY 8d): beta + 1.5 s + 1.5 s + 3 s_out
             out["end_to_end"] = {"alg_bytes_per_px": round(beta + 3.0 * s + 3.0 * s_out, 3), "achieved_gbs": round(e2e / (elapsed / a.steps) / 1e9, 2),
                                  "frac_of_hbm_peak": round(e2e / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS, 5)}
 
     # ------------------------------------------------------------------------------------------------------------------
-    # the same workload from compressed bytes in host memory: batch_create inside the step, double-buffered
+    # the same workload from compressed bytes in host memory: batch_create inside the step, double-buffered.
+    # This region is the headline `value` (round 4).
     # ------------------------------------------------------------------------------------------------------------------
     if not grid and not a.only_main:
         # one chain of batches per part: batch k+1 of a chain takes over batch k's arena and RGB buffers
@@ -419,20 +499,42 @@ def main():
             ch["prev"].free()
             ch["next"].free()
         if rank == 0:
-            out["value_from_host_bytes"] = round(total_px / (el_h / a.steps) / 1e6, 2)   # SURVEY 8(d)'s wall-clock definition, as a first-class key
+            v_h = total_px / (el_h / a.steps) / 1e6
+            out["value"] = round(v_h, 2)                    # SURVEY 8(d)'s wall-clock definition is the headline
+            out["ms_per_step"] = round(el_h / a.steps * 1e3, 3)
+            out["value_from_host_bytes"] = round(v_h, 2)    # (round-3 key, kept)
+            out["config"]["timed_region"] = ("compressed bytes in host memory -> planes + RGB complete in HBM (SURVEY 8d): hipdec_batch_create_recycling "
+                                             "(header parsing, pinned staging, asynchronous H2D upload into the predecessor's arena) + run + colour per step; "
+                                             "the host work of batch k+1 overlaps the kernels of batch k.  `value_resident`: inputs already in HBM")
             out["from_host_bytes"] = {
-                "value": round(total_px / (el_h / a.steps) / 1e6, 2), "unit": "Mpixel/s", "ms_per_step": round(el_h / a.steps * 1e3, 3),
+                "value": round(v_h, 2), "unit": "Mpixel/s", "ms_per_step": round(el_h / a.steps * 1e3, 3),
                 "host_ms_per_batch_create": round(state["host_s"] / max(1, state["creates"]) * 1e3, 2), "batches_per_step": len(wl.part_streams),
-                "h2d_bytes_per_step": wl.bs_bytes,
-                "timed_region": "compressed bytes in host memory -> planes + RGB complete in HBM: hipdec_batch_create_recycling (header parsing, "
-                                "pinned staging, asynchronous H2D upload into the predecessor's arena) + run + colour per step; the host work of "
-                                "batch k+1 overlaps the kernels of batch k, its upload follows them"}
+                "h2d_bytes_per_step": wl.bs_bytes}
         del chains
 
     # ------------------------------------------------------------------------------------------------------------------
-    # single-still latency form, plugin life cycle
+    # batch-size curve: stills per batch -> throughput, resident form (the parser's t(N) = a + b / N)
     # ------------------------------------------------------------------------------------------------------------------
-    if rank == 0 and not a.only_main:
+    if extras_on and rank == 0 and a.workload == "still4k":
+        curve = []
+        for n in (64, 128, 256, 512, 1024):
+            if n >= nb:
+                continue
+            e = Workload(lib, a.workload, rotated, n, out_chroma, w, h, bit_depth, 1)
+            e.make_resident()
+            e.timing_slots(2)
+            el = timed(e.step_resident, 2, 1, before_timed=lambda: (e.status(), e.timing_slots(2)))
+            e.status()
+            t = kernel_times(e.batches, 2)
+            curve.append({"stills": n, "value_resident": round(e.px / (el / 2) / 1e6, 1), "ms_per_step": round(el / 2 * 1e3, 2), "parse_ms": round(t["parse"] / 1e3, 2)})
+            e.free()
+        curve.append({"stills": nb, "value_resident": round(value_resident, 1), "ms_per_step": round(ms_resident, 2), "parse_ms": round(avg_us["parse"] / 1e3, 2)})
+        out["batch_curve"] = curve
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # single-still latency form (BASELINE config 2 as written), plugin life cycle
+    # ------------------------------------------------------------------------------------------------------------------
+    if rank == 0 and not a.only_main and not grid:
         lib.hipdec_set_stage_overlap(0)
         first = distinct[0]
         single = Batch([first])
@@ -454,40 +556,45 @@ def main():
             dec = HipDecoder(); dec.push_data(first); dec.decode_next_image(); dec.free()
         plugin_ms = (time.perf_counter() - tp) / 3 * 1e3
         single.free()
-        iw, ih = (w, h)
-        out["single_still"] = {"ms": round(single_ms, 3), "mpixel_s": round(iw * ih / single_ms / 1e3, 2),
+        out["single_still"] = {"ms": round(single_ms, 3), "mpixel_s": round(w * h / single_ms / 1e3, 2),
                                "kernel_us": {k: round(v, 1) for k, v in single_t.items()},
                                "plugin_lifecycle_host_to_host_ms": round(plugin_ms, 3)}
 
     # ------------------------------------------------------------------------------------------------------------------
-    # the other synthetic inputs of SURVEY §8(d), resident form, 1 warm-up + 2 timed steps each
+    # the other synthetic inputs of SURVEY 8(d) / BASELINE's configs as written, resident form, 1 warm-up + 2 timed steps each
     # ------------------------------------------------------------------------------------------------------------------
     if extras_on and rank == 0:
         lib.hipdec_set_stage_overlap(1 if a.parts > 1 else 0)
         extras = {}
+        for key in ("wpp", "pps_tiles_2x2", "pps_tiles_4x4"):
+            ms, _, _ = grid_run(grid_streams[key], [0])
+            nsub = {"wpp": 16, "pps_tiles_2x2": 32, "pps_tiles_4x4": 64}[key]
+            px = 1024 * 1024 * 48
+            extras["s3_grid8k_" + key] = {"workload": "one 8192x6144 grid photo = 48 tiles of 1024x1024 (%d substreams per tile, %d in all), hipdec_grid_* + RGB24 on one GPU" % (nsub, 48 * nsub),
+                                          "value": round(px / ms / 1e3, 2), "unit": "Mpixel/s", "ms_per_step": round(ms, 3),
+                                          "bitstream_bytes_per_px": round(sum(len(x) for x in grid_streams[key]) / px, 4)}
+        lib.hipdec_color_pq_to_linear.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         for key, (wname, sp, n) in extra_specs.items():
             ew, eh, _, ebd, _, eout = WORKLOADS[wname]
             st = extra_streams[key]
-            if wname == "grid8k":
-                from libheif_amd.grid import GridDecoderC, GridLayout
-                g = GridDecoderC({t: st[t] for t in range(48)}, GridLayout(6, 8, ew, eh, 8 * ew, 6 * eh), [0])
-                grgb = torch.empty((6 * eh, 8 * ew * 3), dtype=torch.uint8, device="cuda")
-
-                def estep():
-                    g.decode(); g.to_rgb(10, out_dev=(grgb.data_ptr(), grgb.stride(0)))
-                el = timed(estep, 2, 1)
-                px = ew * eh * 48
-                nsub = 16 * (4 if "2x2" in key else (16 if "4x4" in key else 1)) // (1 if "pps" not in key else (2 if "2x2" in key else 4))
-                extras[key] = {"workload": "one 8192x6144 grid photo = 48 tiles of 1024x1024 (%d substreams per tile, %d in all), hipdec_grid_* + RGB24 on one GPU" % (nsub, 48 * nsub),
-                               "value": round(px / (el / 2) / 1e6, 2), "unit": "Mpixel/s", "ms_per_step": round(el / 2 * 1e3, 3),
-                               "bitstream_bytes_per_px": round(sum(len(x) for x in st) / px, 4)}
-                g.free()
-                continue
             e = Workload(lib, wname, st, n, eout, ew, eh, ebd, a.parts)
             e.make_resident()
             eb = e.batch
+            step_fn = e.step_resident
+            pq = "pq_linear" in key
+            lin = None
+            if pq:
+                # config 4: PQ code values of the RRGGBB rows -> linear light, float32 R, G, B per pixel (12 B/px written), one launch per still on the
+                # library's stream right behind the batch's colour stage
+                lin = [DeviceBuffer(ew * eh * 12) for _ in range(n)]
+                rgb_bufs = [buf.ptr for buf, _, _ in eb._rgb]
+
+                def step_fn(e=e, lin=lin, rgb_bufs=rgb_bufs, ew=ew, eh=eh, ebd=ebd):
+                    e.step_resident()
+                    for i in range(len(lin)):
+                        check(lib.hipdec_color_pq_to_linear(rgb_bufs[i], ew * 6, ew, eh, 3, ebd, 0, lin[i].ptr, ew * 12, None))
             e.timing_slots(2)
-            el = timed(e.step_resident, 2, 1, before_timed=lambda: (e.status(), e.timing_slots(2)))
+            el = timed(step_fn, 2, 1, before_timed=lambda: (e.status(), e.timing_slots(2)))
             e.status()
             eavg = kernel_times(e.batches, 2)
             es, eso = (2 if ebd > 8 else 1), (2 if eout in (12, 14) else 1)
@@ -497,12 +604,104 @@ def main():
             ekt = kernel_table(eavg, alg_bytes(ebeta, coded_fraction(eb, ecw), es, eso, espp), e.px, colour_stage=eout is not None)
             extras[key] = {"workload": "%d x %dx%d %d-bit %s stills (%d distinct), QP %d, %s" %
                                        (n, ew, eh, ebd, {1: "4:2:0", 2: "4:2:2", 3: "4:4:4"}[ecf], len(st), sp[0][4].get("qp", a.qp),
-                                        "planes only" if eout is None else ("YCbCr->" + ("RGB24" if eout == 10 else "RRGGBB") + (" fused into SAO" if ecf == 1 else ""))),
+                                        "planes only" if eout is None else ("YCbCr->" + ("RGB24" if eout == 10 else "RRGGBB") + (" fused into SAO" if ecf == 1 and eout == 10 else "") +
+                                                                            (" + PQ->linear float32 RGB (hipdec_color_pq_to_linear) in the timed region" if pq else ""))),
                            "value": round(e.px / (el / 2) / 1e6, 2), "unit": "Mpixel/s", "ms_per_step": round(el / 2 * 1e3, 3),
                            "bitstream_bytes_per_px": round(ebeta, 4),
                            "kernels": ekt}
+            if pq:
+                extras[key]["pq_stage_ms_per_step"] = round(el / 2 * 1e3 - eavg["decode_total"] / 1e3 - eavg["colour"] / 1e3, 3)
+                lin = None
             e.free()
         out["extra_workloads"] = extras
+        # BASELINE.json's configs as written (config 1 is the CPU plumbing case)
+        ss = out.get("single_still", {})
+        out["baseline_configs"] = {
+            "config2_single_4k_still_fused_rgb": {"ms": ss.get("ms"), "mpixel_s": ss.get("mpixel_s")},
+            "config3_8k_grid_48_tiles_one_gpu": {"ms": extras["s3_grid8k_wpp"]["ms_per_step"], "mpixel_s": extras["s3_grid8k_wpp"]["value"],
+                                                 "sharded_over_n_gpus": "see grid_sharded"},
+            "config4_main10_4k_pq_to_linear_rgb": {"stills": 512, "mpixel_s": extras["c4_main10_4k_pq_linear"]["value"], "ms_per_step": extras["c4_main10_4k_pq_linear"]["ms_per_step"]},
+            "config5_1024_x_1080p": {"mpixel_s": extras["c5_1080p_1024"]["value"], "ms_per_step": extras["c5_1080p_1024"]["ms_per_step"]},
+        }
+
+    # ------------------------------------------------------------------------------------------------------------------
+    # grid_sharded: ONE 8K grid photo (BASELINE config 3) over the N GPUs of the job: peer copies (one process) and RCCL (SPMD)
+    # ------------------------------------------------------------------------------------------------------------------
+    if sharded_on:
+        res = {}
+
+        def section():
+            photos = {}
+            for key in ("wpp", "pps_tiles_4x4"):
+                st = grid_streams[key]
+                ph = {}
+                ref_hash = None
+                if rank == 0:
+                    one_ms, _, ref_hash = grid_run(st, [0], want_hash=True)
+                    ph["one_gpu_ms"] = round(one_ms, 3)
+                    ph["one_gpu_mpixel_s"] = round(8192 * 6144 / one_ms / 1e3, 1)
+                    if world > 1:
+                        pm, transport, ph_hash = grid_run(st, list(range(world)), want_hash=True)
+                        ph["peer_copy"] = {"ms": round(pm, 3), "mpixel_s": round(8192 * 6144 / pm / 1e3, 1), "transport": transport, "canvas_matches_one_gpu": ph_hash == ref_hash,
+                                           "strong_scaling_efficiency": round(one_ms / (world * pm), 4)}
+                barrier()
+                # SPMD: every rank decodes its tiles, grouped ncclSend / ncclRecv to rank 0 inside libheifhip.so
+                if lib.hipdec_rccl_available():
+                    def exchange(raw):
+                        t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+                        dist.broadcast(t, 0)
+                        return bytes(t.cpu().numpy().tobytes())
+                    comm = RcclComm(rank, world, exchange if world > 1 else None)
+                    g = GridDecoderRccl({t: st[t] for t in range(48)}, GridLayout(6, 8, 1024, 1024, 8192, 6144), comm)
+                    rgb = torch.empty((6144, 8192 * 3), dtype=torch.uint8, device="cuda") if rank == 0 else None
+
+                    def rstep():
+                        g.decode()
+                        if rank == 0:
+                            g.to_rgb(10, out_dev=(rgb.data_ptr(), rgb.stride(0)))
+                        else:
+                            g.wait()
+                    el = timed(rstep, 2, 1)
+                    if rank == 0:
+                        import hashlib
+                        rm = el / 2 * 1e3
+                        ph["rccl"] = {"ms": round(rm, 3), "mpixel_s": round(8192 * 6144 / rm / 1e3, 1), "ranks": world,
+                                      "canvas_matches_one_gpu": hashlib.sha1(rgb.cpu().numpy().tobytes()).hexdigest() == ref_hash,
+                                      "strong_scaling_efficiency": round(ph["one_gpu_ms"] / (world * rm), 4)}
+                    g.free(); comm.free()
+                elif rank == 0:
+                    ph["rccl"] = {"error": "librccl not loadable"}
+                photos[key] = ph
+            res["photos"] = photos
+
+        import threading
+
+        def guarded_section():
+            try:
+                torch.cuda.set_device(local_rank)
+                section()
+            except BaseException as e:      # reported in the line, never fatal for the main measurement
+                res["error"] = repr(e)[:400]
+        th = threading.Thread(target=guarded_section, daemon=True)
+        t_sec = time.perf_counter()
+        th.start()
+        th.join(timeout=420.0)
+        hung = th.is_alive()
+        if rank == 0:
+            gs = {"photo": "8192x6144 = 48 tiles of 1024x1024 (BASELINE config 3), tile t -> GPU t mod N, canvas + RGB24 on GPU 0; `wpp`: 16 CABAC substreams per tile, "
+                           "`pps_tiles_4x4`: 64 (SURVEY 8e: one photo scales with the substreams inside a tile, not with GPUs)",
+                  "n_gpus": world, "seconds": round(time.perf_counter() - t_sec, 1)}
+            gs.update(res.get("photos", {}))
+            if "error" in res:
+                gs["error"] = res["error"]
+            if hung:
+                gs["error"] = "section did not finish within 420 s (abandoned; the main measurement above is unaffected)"
+            out["grid_sharded"] = gs
+        if hung or (world > 1 and "error" in res):
+            # a rank that failed or hangs inside a collective cannot be waited for: the line goes out with what was measured
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            os._exit(0)
 
     # ------------------------------------------------------------------------------------------------------------------
     # the drop-in form: T application threads x heif_decode_image() on distinct 4K HEIC files through the UNMODIFIED reference libheif
@@ -515,16 +714,19 @@ def main():
         except Exception as e:   # the reference build is test infrastructure: its absence must not fail the bench
             out["dropin_through_libheif"] = {"error": repr(e)[:300]}
 
-    if rank == 0 and not a.no_cpu_baseline and not a.only_main and world == 1:
-        out["cpu_baseline"] = cpu_baseline(distinct[0], w * h, a.cpu_seconds, a.cpu_procs, bit_depth)
-        ref = out["cpu_baseline"].pop("_hashes")
-        if check_item is not None:
-            ok = check_item["planes"] == ref["planes"] and check_item["rgb"] == ref["rgb"]
-            out["verified"] = {"still": 0, "against": "CPU oracle decode + the reference's colour op of the same stream (sha1 of Y, Cb, Cr and of the RGB rows)",
-                               "planes_match": check_item["planes"] == ref["planes"], "rgb_match": check_item["rgb"] == ref["rgb"]}
-            if not ok:
+    if rank == 0 and not a.no_cpu_baseline and not a.only_main and world == 1 and not grid:
+        contents = sorted(set(v["content"] for v in check_items.values())) or [0]
+        out["cpu_baseline"] = cpu_baseline([rotated[c] for c in contents], w * h, a.cpu_seconds, a.cpu_procs, bit_depth)
+        ref = dict(zip(contents, out["cpu_baseline"].pop("_hashes")))
+        if check_items:
+            bad = [i for i, v in check_items.items() if ref.get(v["content"]) is None or v["planes"] != ref[v["content"]]["planes"] or v["rgb"] != ref[v["content"]]["rgb"]]
+            bad_planes = [i for i in bad if ref.get(check_items[i]["content"]) is None or check_items[i]["planes"] != ref[check_items[i]["content"]]["planes"]]
+            out["verified"] = {"stills": sorted(check_items), "count": len(check_items), "of": n_items,
+                               "against": "CPU oracle decode + the reference's colour op of each still's stream (sha1 of Y, Cb, Cr and of the RGB rows)",
+                               "planes_match": not bad_planes, "rgb_match": not bad, "mismatching_stills": bad}
+            if bad:
                 print(json.dumps(out), flush=True)
-                raise SystemExit("bench.py: the decoded still 0 differs from the CPU oracle: %r vs %r" % (check_item, ref))
+                raise SystemExit("bench.py: decoded stills %r differ from the CPU oracle" % bad)
     barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -561,20 +763,23 @@ def _cpu_worker(arg):
     return n, time.perf_counter() - t0, hashes
 
 
-def cpu_baseline(stream, px, budget_s, procs, bit_depth=8):
-    """The CPU oracle (a scalar, spec-literal port: libde265 itself is not available here) on this host: `procs`
-    independent processes, each decoding the same still of the bench workload (+ the reference's integer
-    4:2:0->RGB24 op) for a bounded time; throughput = all decodes / the slowest process' time."""
+def cpu_baseline(streams, px, budget_s, procs, bit_depth=8):
+    """The CPU oracle (a scalar, spec-literal port: libde265 itself is not available here) on this host: one job per still of `streams`
+    (distinct stills of the bench workload: the same decodes give the hashes the GPU results are checked against), at least `procs` jobs
+    on `procs` processes, each decoding its still (+ the reference's 4:2:0->RGB ops) for a bounded time; throughput = all decodes / wall."""
     import multiprocessing as mp
     procs = procs or min(32, os.cpu_count() or 1)
+    n_jobs = max(procs, len(streams))
     per_proc_s = max(1.0, budget_s / 2)      # ~2 x budget_s core-seconds per process pair keeps the run short
+    jobs = [(streams[i % len(streams)], per_proc_s, 6, bit_depth, i < len(streams)) for i in range(n_jobs)]
+    t0 = time.perf_counter()
     with mp.get_context("fork").Pool(procs) as pool:
-        res = pool.map(_cpu_worker, [(stream, per_proc_s, 6, bit_depth, i == 0) for i in range(procs)])
+        res = pool.map(_cpu_worker, jobs, chunksize=1)
+    wall = time.perf_counter() - t0
     n = sum(r[0] for r in res)
-    dt = max(r[1] for r in res)
-    return {"_hashes": res[0][2], "value": round(px * n / dt / 1e6, 2), "unit": "Mpixel/s", "cores": procs, "kind": "port",
-            "sample": "%d processes x ~%d decode(s) of one still of the bench workload (CPU oracle decode + the reference's "
-                      "4:2:0->RGB ops), %.1f s wall, %.0f core-seconds" % (procs, n // procs, dt, sum(r[1] for r in res))}
+    return {"_hashes": [res[i][2] for i in range(len(streams))], "value": round(px * n / wall / 1e6, 2), "unit": "Mpixel/s", "cores": procs, "kind": "port",
+            "sample": "%d processes, %d jobs x ~%d decode(s) of %d distinct stills of the bench workload (CPU oracle decode + the reference's "
+                      "4:2:0->RGB ops), %.1f s wall, %.0f core-seconds" % (procs, n_jobs, max(1, n // n_jobs), len(streams), wall, sum(r[1] for r in res))}
 
 
 if __name__ == "__main__":

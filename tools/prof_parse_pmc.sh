@@ -24,3 +24,32 @@ for k in agg:
 PY
   i=$((i+1))
 done
+# instructions per luma pixel of the issue-bound kernels -> gpurun_out/pmc_issue.json (copy to profiles/pmc_issue.json: bench.py's issue_roofline reads it)
+python - "$tag" "$@" <<'PY'
+import csv, collections, glob, json, os, subprocess, sys
+root = os.environ["GRAFT_REPO_ROOT"]; tag = sys.argv[1]
+f = glob.glob(os.path.join(root, "gpurun_out", "pmc_%s_1" % tag, "**", "*counter_collection.csv"), recursive=True)
+if f:
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(f[0])):
+        agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]] += float(r["Counter_Value"])
+    try:
+        bench = json.load(open(os.path.join(root, "gpurun_out", "pmc_%s_1" % tag, "bench.json")))
+        n = bench["config"]["stills_per_step_per_gpu"]
+    except Exception:
+        n = 512
+    px = n * 3840 * 2160
+    out = {}
+    for short in ("k_parse", "k_recon", "k_residual"):
+        tot = collections.defaultdict(float)
+        for k, v in agg.items():
+            if short in k:
+                for c, x in v.items(): tot[c] += x
+        if tot: out[short] = {"salu": round(tot["SQ_INSTS_SALU"] / px, 3), "valu": round(tot["SQ_INSTS_VALU"] / px, 3), "branch": round(tot["SQ_INSTS_BRANCH"] / px, 3)}
+    try: commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception: commit = os.environ.get("HIPDEC_COMMIT", "?")
+    doc = {"source": "rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_BRANCH ... (tools/prof_parse_pmc.sh, own pass, kernel trace only) over `bench.py --only-main --steps 1 --warmup 0 " + " ".join(sys.argv[2:]) + "` on MI355X",
+           "commit": commit, "stills_per_step": n, "insts_per_px": out}
+    json.dump(doc, open(os.path.join(root, "gpurun_out", "pmc_issue.json"), "w"), indent=1)
+    print(json.dumps(out))
+PY
