@@ -92,3 +92,16 @@ int ref_convert_colorspace(int w, int h, int bpp, int in_colorspace, int in_chro
 }
 
 }  // extern "C"
+
+// decoding options for the pin harness (tests/test_reference_decoder_pin.py), filled in against the REAL header layout: a named decoder
+// (plugin_registry.cc:264-288), no geometric transformations, and the decoded planes handed through untouched (output nclx = the image's own:
+// with the default options libheif converts limited-range YCbCr to its sRGB default, context.cc:1515-1567).  Caller frees with heif_decoding_options_free.
+extern "C" heif_decoding_options* refh_decoding_options(const char* decoder_id)
+{
+  heif_decoding_options* o = heif_decoding_options_alloc();
+  if (!o) return nullptr;
+  o->decoder_id = decoder_id;              // the caller keeps the string alive
+  o->ignore_transformations = 1;
+  o->output_image_nclx_profile_passthrough = 1;
+  return o;
+}
