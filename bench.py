@@ -222,8 +222,26 @@ def issue_roofline(kernels, px, cu_count, clock_ghz):
     return out
 
 
+_REAL_STDOUT = None
+
+
+def emit(line):
+    """the ONE JSON line, on the process' real stdout (everything else - RCCL's version banner comes through C stdio - went to stderr)"""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)      # C stdio buffers drain into the redirected descriptor, not behind the JSON line
+    except Exception:
+        pass
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (line + "\n").encode())
+
+
 def main():
+    global _REAL_STDOUT
     a = parse_args()
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)                           # from here on descriptor 1 is stderr
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -700,7 +718,7 @@ def main():
         if hung or (world > 1 and "error" in res):
             # a rank that failed or hangs inside a collective cannot be waited for: the line goes out with what was measured
             if rank == 0:
-                print(json.dumps(out), flush=True)
+                emit(json.dumps(out))
             os._exit(0)
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -725,11 +743,11 @@ def main():
                                "against": "CPU oracle decode + the reference's colour op of each still's stream (sha1 of Y, Cb, Cr and of the RGB rows)",
                                "planes_match": not bad_planes, "rgb_match": not bad, "mismatching_stills": bad}
             if bad:
-                print(json.dumps(out), flush=True)
+                emit(json.dumps(out))
                 raise SystemExit("bench.py: decoded stills %r differ from the CPU oracle" % bad)
     barrier()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 

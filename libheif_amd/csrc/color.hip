@@ -292,6 +292,52 @@ __global__ __launch_bounds__(256) void k_pq_to_linear(const uint8_t* in, size_t 
   ((float*)((uint8_t*)out + (size_t)y * os))[x] = (float)pow(num / den, 1.0 / m1);
 }
 
+// The same for code values of at most 12 bits through a table: the EOTF is a function of the code value alone, so every workgroup evaluates it
+// once per code (fp64, exactly the expression above: the entries ARE the per-sample results) into LDS - 4 KB for 10 bit, 16 KB for 12 - and the
+// samples become one LDS read each.  A workgroup covers 16 rows x 1024 samples (64 per thread, 8-byte loads / 16-byte stores), so the table costs
+// 4 (16) evaluations per thread against 64 samples.  HBM-bound: 2 B in + 4 B out per sample.  (round 4: the per-sample fp64 pow pair ran at
+// 0.5 TB/s on BASELINE config 4.)
+__global__ __launch_bounds__(256) void k_pq_to_linear_lut(const uint8_t* in, size_t is, int n_per_row, int h, int bits, int big_endian, float* out, size_t os)
+{
+  __shared__ float lut[4096];
+  const int n_codes = 1 << bits;
+  const double m1 = 2610.0 / 16384.0, m2 = 2523.0 / 4096.0 * 128.0, c1 = 3424.0 / 4096.0, c2 = 2413.0 / 4096.0 * 32.0, c3 = 2392.0 / 4096.0 * 32.0;
+  for (int v = threadIdx.x; v < n_codes; v += 256) {
+    const double e = (double)v / (double)((1u << bits) - 1u);
+    const double p = pow(e, 1.0 / m2);
+    const double num = fmax(p - c1, 0.0), den = c2 - c3 * p;
+    lut[v] = (float)pow(num / den, 1.0 / m1);
+  }
+  __syncthreads();
+  const int x0 = blockIdx.x * 1024 + (int)threadIdx.x * 4;
+  const int y0 = blockIdx.y * 16;
+  const uint32_t mask = (uint32_t)n_codes - 1u;
+  for (int r = 0; r < 16; r++) {
+    const int y = y0 + r;
+    if (y >= h || x0 >= n_per_row) break;
+    const uint16_t* src = (const uint16_t*)(in + (size_t)y * is) + x0;
+    float* dst = (float*)((uint8_t*)out + (size_t)y * os) + x0;
+    uint32_t v[4];
+    const bool full = x0 + 4 <= n_per_row && (((uintptr_t)src & 7u) == 0) && (((uintptr_t)dst & 15u) == 0);
+    if (full) { const uint2 w = *(const uint2*)src; v[0] = w.x & 0xffffu; v[1] = w.x >> 16; v[2] = w.y & 0xffffu; v[3] = w.y >> 16; }
+    else for (int k = 0; k < 4; k++) v[k] = x0 + k < n_per_row ? src[k] : 0u;
+    float f[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t c = v[k];
+      if (big_endian) c = ((c & 255u) << 8) | (c >> 8);
+      if (c <= mask) f[k] = lut[c];
+      else {   // a code above 2^bits - 1 (not produced by the colour stage): the formula itself, as k_pq_to_linear
+        const double e = (double)c / (double)((1u << bits) - 1u);
+        const double p = pow(e, 1.0 / m2);
+        f[k] = (float)pow(fmax(p - c1, 0.0) / (c2 - c3 * p), 1.0 / m1);
+      }
+    }
+    if (full) *(float4*)dst = make_float4(f[0], f[1], f[2], f[3]);
+    else for (int k = 0; k < 4; k++) if (x0 + k < n_per_row) dst[k] = f[k];
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------
 
 // libheif/nclx.cc:45-72
@@ -735,8 +781,12 @@ int hipdec_color_pq_to_linear(const void* in, size_t is, int w, int h, int compo
     return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "pq_to_linear: bad arguments");
   hipStream_t s = stream ? (hipStream_t)stream : default_stream();
   const int n = w * components;
-  dim3 block(64, 4), grid((n + 63) / 64, (h + 3) / 4);
-  hipLaunchKernelGGL(k_pq_to_linear, grid, block, 0, s, (const uint8_t*)in, is, n, h, bits, big_endian, (float*)out, os);
+  if (bits <= 12) {
+    hipLaunchKernelGGL(k_pq_to_linear_lut, dim3((n + 1023) / 1024, (h + 15) / 16), dim3(256), 0, s, (const uint8_t*)in, is, n, h, bits, big_endian, (float*)out, os);
+  } else {
+    dim3 block(64, 4), grid((n + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(k_pq_to_linear, grid, block, 0, s, (const uint8_t*)in, is, n, h, bits, big_endian, (float*)out, os);
+  }
   HIPDEC_CHECK_HIP(hipGetLastError());
   return 0;
 }

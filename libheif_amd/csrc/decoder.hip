@@ -48,10 +48,11 @@ struct hipdec_batch : BatchLayout {
   ColorBatchState color;        // parameter blocks of hipdec_batch_to_rgb_all
   // decoder path (plugin): the output planes of every item staged in pinned host memory by ONE set of asynchronous copies behind the
   // kernels, so that N decoder instances sharing the batch do not queue N x 3 pageable device-to-host copies (stage_planes_to_host)
-  struct HostItem { void* p = nullptr; size_t off[3] = {0, 0, 0}; };   // p points into host_slab
+  struct HostItem { void* p = nullptr; size_t off[3] = {0, 0, 0}; };   // p points into one of host_chunks
   std::vector<HostItem> host_items;
-  void* host_slab = nullptr;    // ONE pinned buffer per launch set, items sub-allocated at 256-B alignment (a buffer per item
-  size_t host_slab_capacity = 0; //  rounded every thumbnail up to a 16 MiB class)
+  // pinned chunks of ONE size (64 MiB; a larger item gets a chunk of its own), items sub-allocated at 256-B alignment: a launch set of 256
+  // thumbnails pins one chunk instead of 256 x 16 MiB, and sets of any size recycle the same chunks from the pool
+  std::vector<std::pair<void*, size_t>> host_chunks;
   // Waits for everything enqueued for THIS batch — not for the stream, which may already carry the next batch.
   hipError_t wait() const
   {
@@ -76,7 +77,7 @@ struct hipdec_batch : BatchLayout {
     DeviceScope scope(device);
     if (arena || staging) (void)wait();   // nothing of this batch may still be running when the arena is recycled
     release_staging();
-    pinned_release(host_slab, host_slab_capacity);
+    for (auto& c : host_chunks) pinned_release(c.first, c.second);
     color_batch_state_free(color);
     if (arena) arena_release(arena, arena_capacity);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -258,9 +259,10 @@ int stage_planes_to_host(hipdec_batch& b, hipStream_t s)
   static const bool off = getenv("HIPDEC_NO_HOST_STAGING") != nullptr;
   if (off) return 0;
   const size_t es = b.wide ? 2 : 1;
+  constexpr size_t kChunk = size_t(64) << 20;
   std::vector<hipdec_batch::HostItem> items(b.params.size());
-  std::vector<size_t> base(b.params.size(), 0);
-  size_t slab = 0;
+  std::vector<size_t> need;                       // bytes used of chunk k
+  std::vector<std::pair<int, size_t>> place(b.params.size(), {-1, 0});   // item -> (chunk, offset)
   for (size_t i = 0; i < b.params.size(); i++) {
     const PicParams& P = b.params[i];
     size_t total = 0;
@@ -269,23 +271,34 @@ int stage_planes_to_host(hipdec_batch& b, hipStream_t s)
       total += (size_t)(c ? P.out_cwidth : P.out_width) * es * (size_t)(c ? P.out_cheight : P.out_height);
       total = (total + 255) & ~size_t(255);
     }
-    base[i] = slab;
-    slab += total;
+    if (!total) continue;
+    if (need.empty() || need.back() + total > std::max(kChunk, need.back() ? kChunk : total)) need.push_back(0);
+    place[i] = {(int)need.size() - 1, need.back()};
+    need.back() += total;
   }
-  if (!slab) return 0;
-  if (b.host_slab && b.host_slab_capacity < slab) { pinned_release(b.host_slab, b.host_slab_capacity); b.host_slab = nullptr; b.host_slab_capacity = 0; }
-  if (!b.host_slab && pinned_acquire(&b.host_slab, slab, &b.host_slab_capacity) != hipSuccess) {
+  if (need.empty()) return 0;
+  // chunks this batch already holds are reused (a second run over the same arena); missing ones come from the pool
+  bool ok = true;
+  for (size_t k = 0; k < need.size() && ok; k++) {
+    const size_t want = std::max(kChunk, need[k]);
+    if (k < b.host_chunks.size() && b.host_chunks[k].second >= want) continue;
+    if (k < b.host_chunks.size()) { pinned_release(b.host_chunks[k].first, b.host_chunks[k].second); b.host_chunks[k] = {nullptr, 0}; }
+    else b.host_chunks.emplace_back(nullptr, 0);
+    if (pinned_acquire(&b.host_chunks[k].first, want, &b.host_chunks[k].second) != hipSuccess) { (void)hipGetLastError(); b.host_chunks[k] = {nullptr, 0}; ok = false; }
+  }
+  if (!ok) {
     // no pinned memory even after the pool was emptied (pinned_acquire retries once): the instances read their planes straight from the
     // device instead (hipdec_batch_read_plane's unstaged path) - slower, but not an error
-    (void)hipGetLastError();
-    b.host_slab = nullptr; b.host_slab_capacity = 0;
+    for (auto& c : b.host_chunks) pinned_release(c.first, c.second);
+    b.host_chunks.clear();
     b.host_items.clear();
     return 0;
   }
   for (size_t i = 0; i < b.params.size(); i++) {
+    if (place[i].first < 0) continue;
     const PicParams& P = b.params[i];
     hipdec_batch::HostItem& h = items[i];
-    h.p = (uint8_t*)b.host_slab + base[i];
+    h.p = (uint8_t*)b.host_chunks[(size_t)place[i].first].first + place[i].second;
     for (int c = 0; c < (P.chroma_format_idc ? 3 : 1); c++) {
       const size_t w = (size_t)(c ? P.out_cwidth : P.out_width) * es, hh = (size_t)(c ? P.out_cheight : P.out_height);
       if (!w || !hh) continue;
@@ -925,8 +938,10 @@ static int decoder_decode_impl(hipdec_decoder* d, hipdec_image_info* info)
         for (auto* r : take) { r->taken = true; uncount(r->d); }
         g_co.in_flight += (int)take.size();
         g_co.sets_in_flight++;
-        // a set that starts alone takes the whole pool; one that starts beside k others takes 1 / (k + 1), at least 1 / max_sets
-        const uint32_t wave_share = (uint32_t)std::min(std::max(g_co.sets_in_flight, 1), g_co.max_sets);
+        // a lone burst (nothing else in flight, no other instance waiting to decode) takes the whole CABAC pool; while other
+        // sets run or are about to, every set takes 1 / max_sets - a set that grabbed everything beside later ones oversubscribes the wave
+        // slots (measured: 2 x 4096 waves lose 20 % against 2 x 3584)
+        const uint32_t wave_share = (g_co.sets_in_flight == 1 && g_co.armed == 0 && g_co.pending.empty()) ? 1u : (uint32_t)g_co.max_sets;
         counted_in_flight = true;
         g_co.collecting = false;
         g_co.cv.notify_all();

@@ -87,7 +87,49 @@ const uint8_t hevc_cabac_init_I[CTX_COUNT] = {
   140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166,
   182, 140, 227, 122, 197,
   /* coeff_abs_level_greater2_flag */ 138, 153, 136, 167, 152, 152,
-  /* cbf_cb, cbf_cr ctxInc 4 */ 154};
+  /* cbf_cb, cbf_cr ctxInc 4 */ 154,
+  /* (contexts of P slices: unused in I slices) */ 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154};
+
+/* initValue for initType 1 and 2 (P and B slices; a P slice takes initType 2 when cabac_init_flag is set, else 1), Tables 9-5 .. 9-37 */
+const uint8_t hevc_cabac_init_P[2][CTX_COUNT] = {
+ {/* sao_merge */ 153, /* sao_type_idx */ 185, /* split_cu_flag */ 107, 139, 126, /* cu_transquant_bypass_flag */ 154,
+  /* part_mode bin 0 */ 154, /* prev_intra_luma_pred_flag */ 154, /* intra_chroma_pred_mode */ 152,
+  /* split_transform_flag */ 124, 138, 94, /* cbf_luma */ 153, 111, /* cbf_cb, cbf_cr */ 149, 107, 167, 154,
+  /* cu_qp_delta_abs */ 154, 154, /* transform_skip_flag */ 139, 139,
+  /* last_sig_coeff_x_prefix */ 125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94, 108, 123, 108,
+  /* last_sig_coeff_y_prefix */ 125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94, 108, 123, 108,
+  /* coded_sub_block_flag */ 121, 140, 61, 154,
+  /* sig_coeff_flag */
+  155, 154, 139, 153, 139, 123, 123, 63, 153, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136,
+  153, 154, 166, 183, 140, 136, 153, 154, 170, 153, 123, 123, 107, 121, 107, 121, 167, 151, 183,
+  140, 151, 183, 140,
+  /* coeff_abs_level_greater1_flag */
+  154, 196, 196, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 137, 169, 194, 166,
+  167, 154, 167, 137, 182,
+  /* coeff_abs_level_greater2_flag */ 107, 167, 91, 122, 107, 167,
+  /* cbf_cb, cbf_cr ctxInc 4 */ 154,
+  /* cu_skip_flag */ 197, 185, 201, /* pred_mode_flag */ 149, /* part_mode bins 1, 2 (min CB), 2 (AMP) */ 139, 154, 154,
+  /* merge_flag */ 110, /* merge_idx */ 122, /* ref_idx */ 153, 153, /* abs_mvd_greater0_flag */ 140, /* abs_mvd_greater1_flag */ 198,
+  /* mvp_flag */ 168, /* rqt_root_cbf */ 79},
+ {/* sao_merge */ 153, /* sao_type_idx */ 160, /* split_cu_flag */ 107, 139, 126, /* cu_transquant_bypass_flag */ 154,
+  /* part_mode bin 0 */ 154, /* prev_intra_luma_pred_flag */ 183, /* intra_chroma_pred_mode */ 152,
+  /* split_transform_flag */ 224, 167, 122, /* cbf_luma */ 153, 111, /* cbf_cb, cbf_cr */ 149, 92, 167, 154,
+  /* cu_qp_delta_abs */ 154, 154, /* transform_skip_flag */ 139, 139,
+  /* last_sig_coeff_x_prefix */ 125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79, 108, 123, 93,
+  /* last_sig_coeff_y_prefix */ 125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79, 108, 123, 93,
+  /* coded_sub_block_flag */ 121, 140, 61, 154,
+  /* sig_coeff_flag */
+  170, 154, 139, 153, 139, 123, 123, 63, 124, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136,
+  153, 154, 166, 183, 140, 136, 153, 154, 170, 153, 138, 138, 122, 121, 122, 121, 167, 151, 183,
+  140, 151, 183, 140,
+  /* coeff_abs_level_greater1_flag */
+  154, 196, 167, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 122, 169, 208, 166,
+  167, 154, 152, 167, 182,
+  /* coeff_abs_level_greater2_flag */ 107, 167, 91, 107, 107, 167,
+  /* cbf_cb, cbf_cr ctxInc 4 */ 154,
+  /* cu_skip_flag */ 197, 185, 201, /* pred_mode_flag */ 134, /* part_mode bins 1, 2 (min CB), 2 (AMP) */ 139, 154, 154,
+  /* merge_flag */ 154, /* merge_idx */ 137, /* ref_idx */ 153, 153, /* abs_mvd_greater0_flag */ 169, /* abs_mvd_greater1_flag */ 198,
+  /* mvp_flag */ 168, /* rqt_root_cbf */ 79}};
 
 static const int8_t intraPredAngle[35] = {0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13,
   -17, -21, -26, -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32};
@@ -238,6 +280,7 @@ typedef struct {
   int num_short_term_ref_pic_sets;
   int NumDeltaPocs[65], NumNegativePics[65], NumPositivePics[65];
   int DeltaPocS0[65][17], DeltaPocS1[65][17];
+  uint8_t UsedS0[65][17], UsedS1[65][17];   /* used_by_curr_pic_s0 / s1_flag */
   int long_term_ref_pics_present_flag, num_long_term_ref_pics_sps;
   int sps_temporal_mvp_enabled_flag, strong_intra_smoothing_enabled_flag;
   int colour_primaries, transfer_characteristics, matrix_coeffs, video_full_range_flag;
@@ -262,6 +305,7 @@ typedef struct {
   int pps_scaling_list_data_present_flag;
   ScalingList sl;
   int lists_modification_present_flag, log2_parallel_merge_level;
+  int num_ref_idx_l0_default_active, weighted_pred_flag;
   int slice_segment_header_extension_present_flag;
 } PPS;
 
@@ -275,6 +319,10 @@ typedef struct {
   uint32_t* entry_point_offset; /* in NAL bytes (emulation prevention bytes counted) */
   int SliceAddrRs;
   int SliceQpY;
+  /* P slices */
+  int num_ref_idx_l0_active, max_num_merge_cand, cabac_init_flag;
+  int8_t ref_list0[16];   /* RefPicList0: indices into Dec::dpb */
+  int32_t ref_poc0[16];
 } SliceHdr;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -291,6 +339,9 @@ typedef struct {
 /* ------------------------------------------------------------------------------------------ */
 /* decoder state                                                                              */
 /* ------------------------------------------------------------------------------------------ */
+#define MAX_DPB 17
+typedef struct { uint16_t* plane[3]; int poc; int valid; } RefPic;   /* a decoded picture (after deblocking and SAO, coded size) */
+
 struct Dec {
   jmp_buf jb;
   char err[256];
@@ -340,6 +391,16 @@ struct Dec {
 
   uint64_t n_bins_ctx, n_bins_bypass;
   int n_substreams;
+
+  /* ---- inter prediction (hevc_oracle_inter.c): decoded picture buffer, picture order count, the picture's motion field ---- */
+  RefPic dpb[MAX_DPB]; int n_dpb;
+  int first_picture;             /* no picture decoded yet in this sequence */
+  int poc, prev_tid0_lsb, prev_tid0_msb;
+  int st_curr_before[16], st_curr_after[16], n_st_curr_before, n_st_curr_after;   /* RefPicSetStCurrBefore / After as dpb indices */
+  uint8_t* m_pred;               /* per 4x4 unit: 0 MODE_INTRA, 1 MODE_INTER, 2 MODE_SKIP; NULL in a single intra picture */
+  int16_t* mf_mv; int8_t* mf_ref; int32_t* mf_poc;   /* mvL0, refIdxL0 and the POC of that reference picture, per 4x4 unit */
+  int cu_pred_inter;             /* CuPredMode of the coding unit being decoded != MODE_INTRA */
+  int seq_mode;                  /* hevc_oracle_seq: several pictures, P slices allowed */
 };
 
 static void fail(Dec* d, const char* fmt, ...)
@@ -501,35 +562,35 @@ static void parse_st_rps(Dec* d, BR* b, SPS* s, int idx, int num_sets)
       use_delta[j] = 1;
       if (!used[j]) use_delta[j] = br_u(b, 1);
     }
-    int i = 0;
+    int i = 0;   /* 7.4.8 (7-61), (7-62): the used_by_curr_pic flag of an entry is the one parsed for the entry it derives from */
     for (int j = s->NumPositivePics[RefRpsIdx] - 1; j >= 0; j--) {
       int dPoc = s->DeltaPocS1[RefRpsIdx][j] + deltaRps;
-      if (dPoc < 0 && use_delta[s->NumNegativePics[RefRpsIdx] + j]) s->DeltaPocS0[idx][i++] = dPoc;
+      if (dPoc < 0 && use_delta[s->NumNegativePics[RefRpsIdx] + j]) { s->UsedS0[idx][i] = (uint8_t)used[s->NumNegativePics[RefRpsIdx] + j]; s->DeltaPocS0[idx][i++] = dPoc; }
     }
-    if (deltaRps < 0 && use_delta[s->NumDeltaPocs[RefRpsIdx]]) s->DeltaPocS0[idx][i++] = deltaRps;
+    if (deltaRps < 0 && use_delta[s->NumDeltaPocs[RefRpsIdx]]) { s->UsedS0[idx][i] = (uint8_t)used[s->NumDeltaPocs[RefRpsIdx]]; s->DeltaPocS0[idx][i++] = deltaRps; }
     for (int j = 0; j < s->NumNegativePics[RefRpsIdx]; j++) {
       int dPoc = s->DeltaPocS0[RefRpsIdx][j] + deltaRps;
-      if (dPoc < 0 && use_delta[j]) s->DeltaPocS0[idx][i++] = dPoc;
+      if (dPoc < 0 && use_delta[j]) { s->UsedS0[idx][i] = (uint8_t)used[j]; s->DeltaPocS0[idx][i++] = dPoc; }
     }
     s->NumNegativePics[idx] = i;
     i = 0;
     for (int j = s->NumNegativePics[RefRpsIdx] - 1; j >= 0; j--) {
       int dPoc = s->DeltaPocS0[RefRpsIdx][j] + deltaRps;
-      if (dPoc > 0 && use_delta[j]) s->DeltaPocS1[idx][i++] = dPoc;
+      if (dPoc > 0 && use_delta[j]) { s->UsedS1[idx][i] = (uint8_t)used[j]; s->DeltaPocS1[idx][i++] = dPoc; }
     }
-    if (deltaRps > 0 && use_delta[s->NumDeltaPocs[RefRpsIdx]]) s->DeltaPocS1[idx][i++] = deltaRps;
+    if (deltaRps > 0 && use_delta[s->NumDeltaPocs[RefRpsIdx]]) { s->UsedS1[idx][i] = (uint8_t)used[s->NumDeltaPocs[RefRpsIdx]]; s->DeltaPocS1[idx][i++] = deltaRps; }
     for (int j = 0; j < s->NumPositivePics[RefRpsIdx]; j++) {
       int dPoc = s->DeltaPocS1[RefRpsIdx][j] + deltaRps;
-      if (dPoc > 0 && use_delta[s->NumNegativePics[RefRpsIdx] + j]) s->DeltaPocS1[idx][i++] = dPoc;
+      if (dPoc > 0 && use_delta[s->NumNegativePics[RefRpsIdx] + j]) { s->UsedS1[idx][i] = (uint8_t)used[s->NumNegativePics[RefRpsIdx] + j]; s->DeltaPocS1[idx][i++] = dPoc; }
     }
     s->NumPositivePics[idx] = i;
   } else {
     int nn = (int)br_ue(b), np = (int)br_ue(b);
     if (nn > 16 || np > 16) fail(d, "too many pictures in RPS");
     int poc = 0;
-    for (int i = 0; i < nn; i++) { poc -= (int)br_ue(b) + 1; br_u(b, 1); s->DeltaPocS0[idx][i] = poc; }
+    for (int i = 0; i < nn; i++) { poc -= (int)br_ue(b) + 1; s->UsedS0[idx][i] = (uint8_t)br_u(b, 1); s->DeltaPocS0[idx][i] = poc; }
     poc = 0;
-    for (int i = 0; i < np; i++) { poc += (int)br_ue(b) + 1; br_u(b, 1); s->DeltaPocS1[idx][i] = poc; }
+    for (int i = 0; i < np; i++) { poc += (int)br_ue(b) + 1; s->UsedS1[idx][i] = (uint8_t)br_u(b, 1); s->DeltaPocS1[idx][i] = poc; }
     s->NumNegativePics[idx] = nn; s->NumPositivePics[idx] = np;
   }
   s->NumDeltaPocs[idx] = s->NumNegativePics[idx] + s->NumPositivePics[idx];
@@ -661,7 +722,8 @@ static void parse_pps(Dec* d, const uint8_t* rbsp, size_t n)
   p->num_extra_slice_header_bits = br_u(&b, 3);
   p->sign_data_hiding_enabled_flag = br_u(&b, 1);
   p->cabac_init_present_flag = br_u(&b, 1);
-  br_ue(&b); br_ue(&b);
+  p->num_ref_idx_l0_default_active = (int)br_ue(&b) + 1; br_ue(&b);
+  if (p->num_ref_idx_l0_default_active > 15) fail(d, "num_ref_idx_l0_default_active_minus1 out of range");
   p->init_qp_minus26 = br_se(&b);
   p->constrained_intra_pred_flag = br_u(&b, 1);
   p->transform_skip_enabled_flag = br_u(&b, 1);
@@ -670,7 +732,7 @@ static void parse_pps(Dec* d, const uint8_t* rbsp, size_t n)
   p->pps_cb_qp_offset = br_se(&b);
   p->pps_cr_qp_offset = br_se(&b);
   p->pps_slice_chroma_qp_offsets_present_flag = br_u(&b, 1);
-  br_u(&b, 1); br_u(&b, 1); /* weighted_pred_flag, weighted_bipred_flag */
+  p->weighted_pred_flag = br_u(&b, 1); br_u(&b, 1); /* weighted_pred_flag, weighted_bipred_flag */
   p->transquant_bypass_enabled_flag = br_u(&b, 1);
   p->tiles_enabled_flag = br_u(&b, 1);
   p->entropy_coding_sync_enabled_flag = br_u(&b, 1);
@@ -739,6 +801,11 @@ static void setup_picture(Dec* d)
   d->m_ipm = (uint8_t*)xcalloc(d, mn, 1); d->m_ipmc = (uint8_t*)xcalloc(d, mn, 1);
   d->m_flags = (uint8_t*)xcalloc(d, mn, 1); d->m_ctdepth = (uint8_t*)xcalloc(d, mn, 1);
   d->m_qp = (int8_t*)xcalloc(d, mn, 1); d->m_decoded = (uint8_t*)xcalloc(d, mn, 1);
+  if (d->seq_mode) {
+    d->m_pred = (uint8_t*)xcalloc(d, mn, 1); d->mf_mv = (int16_t*)xcalloc(d, mn * 2, sizeof(int16_t));
+    d->mf_ref = (int8_t*)xcalloc(d, mn, 1); d->mf_poc = (int32_t*)xcalloc(d, mn, sizeof(int32_t));
+    memset(d->mf_ref, -1, mn);
+  }
   d->ctbW = s->PicWidthInCtbsY; d->ctbH = s->PicHeightInCtbsY; d->nCtb = d->ctbW * d->ctbH;
   d->CtbAddrRsToTs = (int*)xcalloc(d, d->nCtb, sizeof(int));
   d->CtbAddrTsToRs = (int*)xcalloc(d, d->nCtb, sizeof(int));
@@ -825,8 +892,10 @@ static int available_z(Dec* d, int xCurr, int yCurr, int xNbY, int yNbY)
 static void cabac_init_contexts(Dec* d)
 {
   int qp = Clip3(0, 51, d->sh->SliceQpY);
+  /* 9.3.2.2: initType 0 for I slices; P slices: cabac_init_flag ? 2 : 1 */
+  const uint8_t* tab = d->sh->slice_type == 2 ? hevc_cabac_init_I : hevc_cabac_init_P[d->sh->cabac_init_flag ? 1 : 0];
   for (int i = 0; i < MAXCTX; i++) {
-    int initValue = hevc_cabac_init_I[i];
+    int initValue = tab[i];
     int slopeIdx = initValue >> 4, offsetIdx = initValue & 15;
     int m = slopeIdx * 5 - 45, n = (offsetIdx << 3) - 16;
     int preCtxState = Clip3(1, 126, ((m * qp) >> 4) + n);
@@ -1360,7 +1429,7 @@ static void reconstruct_tb(Dec* d, int x0c, int y0c, int log2n, int cIdx, int mo
   int stride = cIdx ? d->Wc : d->W;
   uint16_t* rec = d->rec[cIdx];
   int bit_depth = cIdx ? s->bit_depth_chroma : s->bit_depth_luma;
-  intra_predict_block(d, x0c, y0c, log2n, cIdx, mode);
+  if (!d->cu_pred_inter) intra_predict_block(d, x0c, y0c, log2n, cIdx, mode);   /* inter: the prediction samples are in rec already */
   if (!cbf) return;
   if (d->keep_taps)
     for (int y = 0; y < n; y++)
@@ -1381,7 +1450,7 @@ static void reconstruct_tb(Dec* d, int x0c, int y0c, int log2n, int cIdx, int mo
     uint8_t mbuf[32 * 32];
     if (s->scaling_list_enabled_flag && !(transform_skip && n > 4)) {
       const ScalingList* sl = p->pps_scaling_list_data_present_flag ? &p->sl : &s->sl;
-      int matrixId = cIdx; /* intra */
+      int matrixId = cIdx + (d->cu_pred_inter ? 3 : 0); /* Table 7-4: intra 0..2, inter 3..5 */
       for (int y = 0; y < n; y++)
         for (int x = 0; x < n; x++) {
           int v;
@@ -1395,7 +1464,7 @@ static void reconstruct_tb(Dec* d, int x0c, int y0c, int log2n, int cIdx, int mo
         }
       m = mbuf;
     }
-    int trType = (cIdx == 0 && n == 4) ? 1 : 0;
+    int trType = (cIdx == 0 && n == 4 && !d->cu_pred_inter) ? 1 : 0;   /* DST-VII for intra 4x4 luma only (8.6.4.2) */
     hevc_scale_and_transform(res, coeffs, n, qP, bit_depth, m, transform_skip, trType);
   }
   int maxv = (1 << bit_depth) - 1;
@@ -1413,6 +1482,7 @@ typedef struct {
   int xCb, yCb, log2CbSize;
   int IntraSplitFlag, MaxTrafoDepth;
   int chroma_mode;
+  int inter, PartMode;     /* CuPredMode != MODE_INTRA; its partitioning (interSplitFlag, 7.4.9.8) */
 } CuCtx;
 
 static void mark_tu(Dec* d, const CuCtx* cu, int x0, int y0, int log2TrafoSize, int cbfL, int cbfCb, int cbfCr)
@@ -1554,11 +1624,13 @@ static void transform_tree(Dec* d, CuCtx* cu, int x0, int y0, int xBase, int yBa
   const SPS* s = d->s;
   int ChromaArrayType = s->chroma_format_idc;
   int split;
+  /* 7.4.9.8: interSplitFlag - an inter coding unit that is partitioned and may not split its transform tree by syntax splits it once anyway */
+  int interSplit = cu->inter && s->max_transform_hierarchy_depth_inter == 0 && cu->PartMode != PART_2Nx2N && trafoDepth == 0;
   if (log2TrafoSize <= s->log2_max_tb && log2TrafoSize > s->log2_min_tb && trafoDepth < cu->MaxTrafoDepth &&
       !(cu->IntraSplitFlag && trafoDepth == 0))
     split = decode_decision(d, CTX_SPLIT_TRANSFORM + 5 - log2TrafoSize);
   else
-    split = (log2TrafoSize > s->log2_max_tb || (cu->IntraSplitFlag && trafoDepth == 0)) ? 1 : 0;
+    split = (log2TrafoSize > s->log2_max_tb || (cu->IntraSplitFlag && trafoDepth == 0) || interSplit) ? 1 : 0;
   int cbf_cb = 0, cbf_cr = 0;
   if ((log2TrafoSize > 2 && ChromaArrayType != 0) || ChromaArrayType == 3) {
     int cc = trafoDepth == 4 ? CTX_CBF_CHROMA4 : CTX_CBF_CHROMA + trafoDepth;
@@ -1577,10 +1649,64 @@ static void transform_tree(Dec* d, CuCtx* cu, int x0, int y0, int xBase, int yBa
     transform_tree(d, cu, x0, y1, x0, y0, log2TrafoSize - 1, trafoDepth + 1, 2, cbf_cb, cbf_cr);
     transform_tree(d, cu, x1, y1, x0, y0, log2TrafoSize - 1, trafoDepth + 1, 3, cbf_cb, cbf_cr);
   } else {
-    /* CuPredMode == MODE_INTRA: cbf_luma is always present */
-    int cbf_luma = decode_decision(d, CTX_CBF_LUMA + (trafoDepth == 0 ? 1 : 0));
+    /* cbf_luma is present for intra coding units, below the root, or when a chroma block is coded; else inferred 1 (7.3.8.8) */
+    int cbf_luma = 1;
+    if (!cu->inter || trafoDepth != 0 || cbf_cb || cbf_cr) cbf_luma = decode_decision(d, CTX_CBF_LUMA + (trafoDepth == 0 ? 1 : 0));
     transform_unit(d, cu, x0, y0, xBase, yBase, log2TrafoSize, trafoDepth, blkIdx, cbf_luma, cbf_cb, cbf_cr);
   }
+}
+
+#include "hevc_oracle_inter.c"
+
+static void transform_tree(Dec* d, CuCtx* cu, int x0, int y0, int xBase, int yBase, int log2TrafoSize,
+                           int trafoDepth, int blkIdx, int parent_cbf_cb, int parent_cbf_cr);
+
+/* 7.3.8.5 for CuPredMode MODE_INTER / MODE_SKIP: part_mode, the prediction units, rqt_root_cbf, the transform tree */
+static void inter_coding_unit(Dec* d, CuCtx* cu, int x0, int y0, int log2CbSize, int cqtDepth, int cu_skip)
+{
+  const SPS* s = d->s;
+  int nCbS = 1 << log2CbSize;
+  int u0x = x0 >> 2, u0y = y0 >> 2, nu = nCbS >> 2;
+  d->cu_pred_inter = 1;
+  set_qp_y(d);
+  for (int j = 0; j < nu; j++)
+    for (int i = 0; i < nu; i++) {
+      int idx = (u0y + j) * d->mw + u0x + i;
+      d->m_log2_cb[idx] = (uint8_t)log2CbSize;
+      d->m_ctdepth[idx] = (uint8_t)cqtDepth;
+      d->m_flags[idx] = (uint8_t)(d->cu_transquant_bypass_flag ? 0x08 : 0);
+      d->m_decoded[idx] = 1;
+      d->m_ipm[idx] = 1; d->m_ipmc[idx] = 1;     /* a neighbour that is not intra coded counts as INTRA_DC (8.4.2) */
+      d->m_pred[idx] = (uint8_t)(cu_skip ? 2 : 1);
+    }
+  int PartMode = PART_2Nx2N;
+  if (!cu_skip) {
+    PartMode = parse_part_mode_inter(d, log2CbSize);
+    if (PartMode == PART_NxN && log2CbSize == 3) fail(d, "inter NxN partition of an 8x8 coding unit");
+  }
+  PbGeom g;
+  int nParts = part_geometry(PartMode, x0, y0, nCbS, 0, &g), merge0 = 0;
+  for (int k = 0; k < nParts; k++) {
+    part_geometry(PartMode, x0, y0, nCbS, k, &g);
+    int mf = prediction_unit(d, &g, PartMode, cu_skip);
+    if (k == 0) merge0 = mf;
+  }
+  int rqt_root_cbf = 0;
+  if (!cu_skip) {
+    rqt_root_cbf = 1;
+    if (!(PartMode == PART_2Nx2N && merge0)) rqt_root_cbf = decode_decision(d, CTX_RQT_ROOT_CBF);
+  }
+  cu->inter = 1; cu->PartMode = PartMode; cu->chroma_mode = 1;
+  if (rqt_root_cbf) {
+    cu->IntraSplitFlag = 0;
+    cu->MaxTrafoDepth = s->max_transform_hierarchy_depth_inter;
+    transform_tree(d, cu, x0, y0, x0, y0, log2CbSize, 0, 0, 0, 0);
+  } else mark_cu_no_residual(d, cu, x0, y0, log2CbSize);
+  mark_pu_edges(d, x0, y0, nCbS, PartMode);
+  set_qp_y(d);
+  for (int j = 0; j < nu; j++) for (int i = 0; i < nu; i++) d->m_qp[(u0y + j) * d->mw + u0x + i] = (int8_t)d->cur_qp_y;
+  d->last_qp_y = d->cur_qp_y;
+  d->cu_pred_inter = 0;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1591,6 +1717,7 @@ static int cand_mode(Dec* d, int xPb, int yPb, int xN, int yN, int isB)
   if (!available_z(d, xPb, yPb, xN, yN)) return 1;
   int idx = (yN >> 2) * d->mw + (xN >> 2);
   if (d->m_flags[idx] & 0x10) return 1; /* pcm_flag */
+  if (d->m_pred && d->m_pred[idx]) return 1; /* CuPredMode != MODE_INTRA */
   if (isB && yN < ((yPb >> d->s->log2_ctb) << d->s->log2_ctb)) return 1;
   return d->m_ipm[idx];
 }
@@ -1602,7 +1729,17 @@ static void coding_unit(Dec* d, int x0, int y0, int log2CbSize, int cqtDepth)
   CuCtx cu; memset(&cu, 0, sizeof(cu));
   cu.xCb = x0; cu.yCb = y0; cu.log2CbSize = log2CbSize;
   d->cu_transquant_bypass_flag = 0;
+  d->cu_pred_inter = 0;
   if (p->transquant_bypass_enabled_flag) d->cu_transquant_bypass_flag = decode_decision(d, CTX_CU_TQ_BYPASS);
+  if (d->sh->slice_type != 2) {   /* 7.3.8.5 in a P slice: cu_skip_flag, pred_mode_flag */
+    int ctxInc = 0;   /* 9.3.4.2.2: the left / above neighbours' cu_skip_flag */
+    if (available_z(d, x0, y0, x0 - 1, y0) && d->m_pred[(y0 >> 2) * d->mw + ((x0 - 1) >> 2)] == 2) ctxInc++;
+    if (available_z(d, x0, y0, x0, y0 - 1) && d->m_pred[((y0 - 1) >> 2) * d->mw + (x0 >> 2)] == 2) ctxInc++;
+    int cu_skip = decode_decision(d, CTX_SKIP_FLAG + ctxInc);
+    int inter = 1;
+    if (!cu_skip) inter = decode_decision(d, CTX_PRED_MODE) ? 0 : 1;   /* pred_mode_flag 1 = MODE_INTRA */
+    if (inter) { inter_coding_unit(d, &cu, x0, y0, log2CbSize, cqtDepth, cu_skip); return; }
+  }
   int PartMode = 0; /* 0 = 2Nx2N, 1 = NxN */
   if (log2CbSize == s->log2_min_cb) PartMode = decode_decision(d, CTX_PART_MODE) ? 0 : 1;
   if (PartMode == 1 && log2CbSize == 3 && s->log2_min_tb > 2) fail(d, "NxN partition with 8x8 CU needs 4x4 transforms");
@@ -1622,6 +1759,7 @@ static void coding_unit(Dec* d, int x0, int y0, int log2CbSize, int cqtDepth)
       d->m_flags[idx] = (uint8_t)((d->cu_transquant_bypass_flag ? 0x08 : 0) | (pcm_flag ? 0x10 : 0));
       d->m_decoded[idx] = 1;
       d->m_ipm[idx] = 1;
+      if (d->m_pred) { d->m_pred[idx] = 0; d->mf_ref[idx] = -1; d->mf_poc[idx] = 0; d->mf_mv[2 * idx] = d->mf_mv[2 * idx + 1] = 0; }
     }
 
   if (pcm_flag) {
@@ -1850,7 +1988,7 @@ static void decode_slice(Dec* d, int nal_type, const uint8_t* nal, size_t nal_le
   if (!d->sps[p->sps_id].valid) fail(d, "PPS refers to a missing SPS");
   const SPS* s = &d->sps[p->sps_id];
   if (hdr.first_slice_segment_in_pic_flag) {
-    if (d->have_picture) fail(d, "more than one picture in the item (only still pictures are supported)");
+    if (d->have_picture) fail(d, "more than one picture in one access unit");
     d->s = s; d->p = p;
     setup_picture(d);
   } else {
@@ -1874,31 +2012,64 @@ static void decode_slice(Dec* d, int nal_type, const uint8_t* nal, size_t nal_le
   } else {
     for (int i = 0; i < p->num_extra_slice_header_bits; i++) br_u(&b, 1);
     hdr.slice_type = (int)br_ue(&b);
-    if (hdr.slice_type != 2) fail(d, "unsupported: slice_type %d (only intra slices)", hdr.slice_type);
+    if (hdr.slice_type > 2) fail(d, "slice_type out of range");
+    if (hdr.slice_type == 0) fail(d, "unsupported: B slices");
+    if (hdr.slice_type == 1 && !d->seq_mode) fail(d, "unsupported: slice_type %d (a single picture must be intra coded)", hdr.slice_type);
     if (p->output_flag_present_flag) br_u(&b, 1);
     if (s->separate_colour_plane_flag) br_u(&b, 2);
+    int poc_lsb = 0, slice_temporal_mvp = 0;
+    StRps rps; memset(&rps, 0, sizeof(rps));
     if (nal_type != 19 && nal_type != 20) {
-      br_u(&b, s->log2_max_poc_lsb);
+      poc_lsb = (int)br_u(&b, s->log2_max_poc_lsb);
       int st_sps_flag = br_u(&b, 1);
+      int ridx = 0;
+      SPS scratch = *s; /* the slice-level RPS is parsed as entry num_short_term_ref_pic_sets of a copy */
       if (!st_sps_flag) {
-        SPS scratch = *s; /* the slice-level RPS is parsed only to skip it */
-        parse_st_rps(d, &b, &scratch, s->num_short_term_ref_pic_sets, s->num_short_term_ref_pic_sets);
-      } else if (s->num_short_term_ref_pic_sets > 1) br_u(&b, ceil_log2(s->num_short_term_ref_pic_sets));
+        ridx = s->num_short_term_ref_pic_sets;
+        parse_st_rps(d, &b, &scratch, ridx, s->num_short_term_ref_pic_sets);
+      } else {
+        if (s->num_short_term_ref_pic_sets == 0) fail(d, "short_term_ref_pic_set_sps_flag without an RPS in the SPS");
+        if (s->num_short_term_ref_pic_sets > 1) ridx = (int)br_u(&b, ceil_log2(s->num_short_term_ref_pic_sets));
+        if (ridx >= s->num_short_term_ref_pic_sets) fail(d, "short_term_ref_pic_set_idx out of range");
+      }
+      rps.num_neg = scratch.NumNegativePics[ridx]; rps.num_pos = scratch.NumPositivePics[ridx];
+      for (int i = 0; i < rps.num_neg; i++) { rps.delta_s0[i] = scratch.DeltaPocS0[ridx][i]; rps.used_s0[i] = scratch.UsedS0[ridx][i]; }
+      for (int i = 0; i < rps.num_pos; i++) { rps.delta_s1[i] = scratch.DeltaPocS1[ridx][i]; rps.used_s1[i] = scratch.UsedS1[ridx][i]; }
       if (s->long_term_ref_pics_present_flag) {
         int num_lt_sps = 0;
         if (s->num_long_term_ref_pics_sps > 0) num_lt_sps = (int)br_ue(&b);
         int num_lt_pics = (int)br_ue(&b);
+        if (d->seq_mode && num_lt_sps + num_lt_pics > 0) fail(d, "unsupported: long-term reference pictures");
         for (int i = 0; i < num_lt_sps + num_lt_pics; i++) {
           if (i < num_lt_sps) { if (s->num_long_term_ref_pics_sps > 1) br_u(&b, ceil_log2(s->num_long_term_ref_pics_sps)); }
           else { br_u(&b, s->log2_max_poc_lsb); br_u(&b, 1); }
           if (br_u(&b, 1)) br_ue(&b);
         }
       }
-      if (s->sps_temporal_mvp_enabled_flag) br_u(&b, 1);
+      if (s->sps_temporal_mvp_enabled_flag) slice_temporal_mvp = br_u(&b, 1);
     }
+    if (hdr.first_slice_segment_in_pic_flag && d->seq_mode) inter_begin_picture(d, nal_type, poc_lsb, &rps);
     if (s->sao_enabled_flag) {
       hdr.slice_sao_luma_flag = br_u(&b, 1);
       if (s->chroma_format_idc) hdr.slice_sao_chroma_flag = br_u(&b, 1);
+    }
+    if (hdr.slice_type == 1) {   /* 7.3.6.1, P slice */
+      if (s->chroma_format_idc > 1) fail(d, "unsupported: P slices of a 4:2:2 / 4:4:4 picture");
+      if (p->constrained_intra_pred_flag) fail(d, "unsupported: constrained_intra_pred_flag with P slices");
+      if (p->weighted_pred_flag) fail(d, "unsupported: weighted prediction");
+      if (slice_temporal_mvp) fail(d, "unsupported: temporal motion vector prediction");
+      hdr.num_ref_idx_l0_active = p->num_ref_idx_l0_default_active;
+      if (br_u(&b, 1)) hdr.num_ref_idx_l0_active = (int)br_ue(&b) + 1;   /* num_ref_idx_active_override_flag */
+      if (hdr.num_ref_idx_l0_active > 15) fail(d, "num_ref_idx_l0_active_minus1 out of range");
+      int total = d->n_st_curr_before + d->n_st_curr_after, entries[16], modified = 0;
+      if (p->lists_modification_present_flag && total > 1) {
+        modified = br_u(&b, 1);   /* ref_pic_list_modification_flag_l0 */
+        if (modified) for (int i = 0; i < hdr.num_ref_idx_l0_active; i++) entries[i] = (int)br_u(&b, ceil_log2(total));
+      }
+      if (p->cabac_init_present_flag) hdr.cabac_init_flag = br_u(&b, 1);
+      hdr.max_num_merge_cand = 5 - (int)br_ue(&b);
+      if (hdr.max_num_merge_cand < 1 || hdr.max_num_merge_cand > 5) fail(d, "five_minus_max_num_merge_cand out of range");
+      build_ref_list0(d, &hdr, modified ? entries : NULL);
     }
     hdr.slice_qp_delta = br_se(&b);
     if (p->pps_slice_chroma_qp_offsets_present_flag) { hdr.slice_cb_qp_offset = br_se(&b); hdr.slice_cr_qp_offset = br_se(&b); }
@@ -2048,14 +2219,14 @@ static void decode_slice(Dec* d, int nal_type, const uint8_t* nal, size_t nal_le
 /* 8.7.2 deblocking filter                                                                    */
 /* ------------------------------------------------------------------------------------------ */
 static void deblock_luma_edge(Dec* d, uint16_t* pix, int xstep, int ystep, int QpP, int QpQ,
-                              const SliceHdr* sh, int noP, int noQ)
+                              const SliceHdr* sh, int noP, int noQ, int bS)
 {
   /* pix points at q0 of line 0; p_i = pix[-(i+1)*xstep], q_i = pix[i*xstep]; lines advance by ystep */
   int bitDepth = d->s->bit_depth_luma;
   int qPL = (QpQ + QpP + 1) >> 1;
   int Q = Clip3(0, 51, qPL + (sh->slice_beta_offset_div2 << 1));
   int beta = betaTable[Q] * (1 << (bitDepth - 8));
-  Q = Clip3(0, 53, qPL + 2 * (2 - 1) + (sh->slice_tc_offset_div2 << 1));
+  Q = Clip3(0, 53, qPL + 2 * (bS - 1) + (sh->slice_tc_offset_div2 << 1));
   int tC = tcTable[Q] * (1 << (bitDepth - 8));
 #define P(i, k) ((int)pix[-((i) + 1) * xstep + (k) * ystep])
 #define QQ(i, k) ((int)pix[(i) * xstep + (k) * ystep])
@@ -2159,8 +2330,11 @@ static void deblock_picture(Dec* d)
         int ctb = (y >> s->log2_ctb) * d->ctbW + (x >> s->log2_ctb);
         const SliceHdr* sh = &d->slices[d->ctb_slice_idx[ctb]];
         int noP = unit_no_filter(d, idxP), noQ = unit_no_filter(d, idx);
-        if (dir == 0) deblock_luma_edge(d, d->rec[0] + y * d->W + x, 1, d->W, QpP, QpQ, sh, noP, noQ);
-        else deblock_luma_edge(d, d->rec[0] + y * d->W + x, d->W, 1, QpP, QpQ, sh, noP, noQ);
+        int bS = edge_bs(d, idxP, idx, x, y, dir);   /* 8.7.2.4: 2 where a side is intra coded (every edge of an intra picture) */
+        if (!bS) continue;
+        if (dir == 0) deblock_luma_edge(d, d->rec[0] + y * d->W + x, 1, d->W, QpP, QpQ, sh, noP, noQ, bS);
+        else deblock_luma_edge(d, d->rec[0] + y * d->W + x, d->W, 1, QpP, QpQ, sh, noP, noQ, bS);
+        if (bS != 2) continue;                        /* chroma edges are filtered where bS is 2 only (8.7.2.5.? edge filtering process) */
         if (s->chroma_format_idc == 3) {
           /* 8.7.2: with ChromaArrayType 3 the chroma planes have the luma planes' edges (the 8-sample grid in chroma samples IS the luma
              grid), filtered with the chroma filter */
@@ -2266,32 +2440,37 @@ static uint16_t* dup_plane(Dec* d, const uint16_t* src, size_t n)
   return r;
 }
 
-static void free_dec(Dec* d)
+/* everything that belongs to ONE picture (a sequence decoder keeps the parameter sets, the DPB and the POC state) */
+static void release_picture(Dec* d)
 {
-  for (int c = 0; c < 3; c++) { free(d->rec[c]); free(d->coeff[c]); }
+  for (int c = 0; c < 3; c++) { free(d->rec[c]); free(d->coeff[c]); d->rec[c] = NULL; d->coeff[c] = NULL; }
   free(d->m_log2_tb); free(d->m_log2_cb); free(d->m_ipm); free(d->m_ipmc); free(d->m_flags);
   free(d->m_ctdepth); free(d->m_qp); free(d->m_decoded);
+  d->m_log2_tb = d->m_log2_cb = d->m_ipm = d->m_ipmc = d->m_flags = d->m_ctdepth = d->m_decoded = NULL; d->m_qp = NULL;
+  free(d->m_pred); free(d->mf_mv); free(d->mf_ref); free(d->mf_poc);
+  d->m_pred = NULL; d->mf_mv = NULL; d->mf_ref = NULL; d->mf_poc = NULL;
   free(d->CtbAddrRsToTs); free(d->CtbAddrTsToRs); free(d->TileId); free(d->colBd); free(d->rowBd);
   free(d->MinTbAddrZs); free(d->ctb_slice_addr); free(d->ctb_slice_idx);
+  d->CtbAddrRsToTs = d->CtbAddrTsToRs = d->TileId = d->colBd = d->rowBd = d->MinTbAddrZs = d->ctb_slice_addr = d->ctb_slice_idx = NULL;
   for (int i = 0; i < d->nslices; i++) free(d->slices[i].entry_point_offset);
-  free(d->slices); free(d->sao_type); free(d->sao_bc); free(d->sao_off);
+  free(d->slices); d->slices = NULL; d->nslices = d->capslices = 0; d->sh = NULL;
+  free(d->sao_type); free(d->sao_bc); free(d->sao_off);
+  d->sao_type = d->sao_bc = NULL; d->sao_off = NULL;
+  d->have_picture = 0; d->ctx_ds_valid = 0;
+  d->n_bins_ctx = d->n_bins_bypass = 0; d->n_substreams = 0;
+}
+
+static void free_dec(Dec* d)
+{
+  release_picture(d);
+  for (int i = 0; i < MAX_DPB; i++) dpb_free_entry(&d->dpb[i]);
   free(d);
 }
 
-int hevc_oracle_decode(const uint8_t* data, size_t size, int keep_taps, hevc_oracle_picture* out,
-                       char* errbuf, size_t errbuf_len)
+/* one access unit in libheif's plugin framing -> *out; in sequence mode the decoded picture also enters the DPB.  Errors longjmp to d->jb. */
+static void decode_access_unit(Dec* d, const uint8_t* data, size_t size, int keep_taps, hevc_oracle_picture* out)
 {
-  Dec* d = (Dec*)calloc(1, sizeof(Dec));
-  if (!d) return -1;
-  memset(out, 0, sizeof(*out));
-  init_scans(); init_dct();
   d->keep_taps = keep_taps;
-  if (setjmp(d->jb)) {
-    if (errbuf && errbuf_len) snprintf(errbuf, errbuf_len, "%s", d->err);
-    hevc_oracle_free_picture(out);
-    free_dec(d);
-    return -2;
-  }
   /* NAL framing: [u32 BE length][NAL] ... (decoder_libde265.cc:322-368) */
   size_t ptr = 0;
   while (ptr < size) {
@@ -2312,7 +2491,7 @@ int hevc_oracle_decode(const uint8_t* data, size_t size, int keep_taps, hevc_ora
       if (nal_type > 9 && nal_type < 16) continue; /* reserved */
       decode_slice(d, nal_type, nal, nal_size);
     }
-    /* VPS (32), AUD, SEI, EOS ...: nothing to do for an intra still */
+    /* VPS (32), AUD, SEI, EOS ...: nothing to do */
   }
   if (!d->have_picture) fail(d, "no picture in the data");
   for (int i = 0; i < d->nCtb; i++) if (d->ctb_slice_addr[i] < 0) fail(d, "picture is incomplete (CTB %d missing)", i);
@@ -2325,6 +2504,7 @@ int hevc_oracle_decode(const uint8_t* data, size_t size, int keep_taps, hevc_ora
   out->colour_primaries = s->colour_primaries; out->transfer_characteristics = s->transfer_characteristics;
   out->matrix_coeffs = s->matrix_coeffs; out->full_range_flag = s->video_full_range_flag;
   out->n_bins_ctx = d->n_bins_ctx; out->n_bins_bypass = d->n_bins_bypass; out->n_substreams = d->n_substreams;
+  out->poc = d->poc;
   if (keep_taps) for (int c = 0; c < nc; c++) out->pre_deblock[c] = dup_plane(d, d->rec[c], c ? (size_t)d->Wc * d->Hc : (size_t)d->W * d->H);
   deblock_picture(d);
   if (keep_taps) for (int c = 0; c < nc; c++) out->post_deblock[c] = dup_plane(d, d->rec[c], c ? (size_t)d->Wc * d->Hc : (size_t)d->W * d->H);
@@ -2345,6 +2525,14 @@ int hevc_oracle_decode(const uint8_t* data, size_t size, int keep_taps, hevc_ora
     out->plane[c] = (uint16_t*)xcalloc(d, (size_t)w * h, sizeof(uint16_t));
     for (int y = 0; y < h; y++) memcpy(out->plane[c] + (size_t)y * w, fin[c] + (size_t)(ys + y) * st + xs, sizeof(uint16_t) * w);
   }
+  if (d->seq_mode) {   /* C.5.2.3: the current picture enters the DPB (every picture of these sequences is a reference picture) */
+    int slot = -1;
+    for (int i = 0; i < MAX_DPB; i++) if (!d->dpb[i].valid) { slot = i; break; }
+    if (slot < 0) fail(d, "decoded picture buffer is full");
+    if (slot >= d->n_dpb) d->n_dpb = slot + 1;
+    for (int c = 0; c < nc; c++) d->dpb[slot].plane[c] = dup_plane(d, fin[c], c ? (size_t)d->Wc * d->Hc : (size_t)d->W * d->H);
+    d->dpb[slot].poc = d->poc; d->dpb[slot].valid = 1;
+  }
   if (keep_taps) {
     for (int c = 0; c < nc; c++) { out->final_coded[c] = fin[c]; fin[c] = NULL; out->coeff[c] = d->coeff[c]; d->coeff[c] = NULL; }
     out->map_stride = d->mw; out->map_height = d->mh;
@@ -2358,10 +2546,67 @@ int hevc_oracle_decode(const uint8_t* data, size_t size, int keep_taps, hevc_ora
     out->sao_type = d->sao_type; d->sao_type = NULL;
     out->sao_band_or_class = d->sao_bc; d->sao_bc = NULL;
     out->sao_offset = d->sao_off; d->sao_off = NULL;
+    out->map_pred = d->m_pred; d->m_pred = NULL;
+    out->mf_mv = d->mf_mv; d->mf_mv = NULL;
+    out->mf_ref = d->mf_ref; d->mf_ref = NULL;
   }
   for (int c = 0; c < 3; c++) free(fin[c]);
+}
+
+int hevc_oracle_decode(const uint8_t* data, size_t size, int keep_taps, hevc_oracle_picture* out,
+                       char* errbuf, size_t errbuf_len)
+{
+  Dec* d = (Dec*)calloc(1, sizeof(Dec));
+  if (!d) return -1;
+  memset(out, 0, sizeof(*out));
+  init_scans(); init_dct();
+  d->first_picture = 1;
+  if (setjmp(d->jb)) {
+    if (errbuf && errbuf_len) snprintf(errbuf, errbuf_len, "%s", d->err);
+    hevc_oracle_free_picture(out);
+    free_dec(d);
+    return -2;
+  }
+  decode_access_unit(d, data, size, keep_taps, out);
   free_dec(d);
   return 0;
+}
+
+/* ---- a sequence of pictures (the samples libheif pushes for a track): parameter sets, POC state and the DPB persist ------------------ */
+struct hevc_oracle_seq { Dec* d; };
+
+hevc_oracle_seq* hevc_oracle_seq_new(void)
+{
+  hevc_oracle_seq* q = (hevc_oracle_seq*)calloc(1, sizeof(*q));
+  if (!q) return NULL;
+  q->d = (Dec*)calloc(1, sizeof(Dec));
+  if (!q->d) { free(q); return NULL; }
+  init_scans(); init_dct();
+  q->d->seq_mode = 1; q->d->first_picture = 1;
+  return q;
+}
+
+int hevc_oracle_seq_decode(hevc_oracle_seq* q, const uint8_t* data, size_t size, int keep_taps, hevc_oracle_picture* out,
+                           char* errbuf, size_t errbuf_len)
+{
+  Dec* d = q->d;
+  memset(out, 0, sizeof(*out));
+  if (setjmp(d->jb)) {
+    if (errbuf && errbuf_len) snprintf(errbuf, errbuf_len, "%s", d->err);
+    hevc_oracle_free_picture(out);
+    release_picture(d);
+    return -2;
+  }
+  decode_access_unit(d, data, size, keep_taps, out);
+  release_picture(d);
+  return 0;
+}
+
+void hevc_oracle_seq_free(hevc_oracle_seq* q)
+{
+  if (!q) return;
+  free_dec(q->d);
+  free(q);
 }
 
 void hevc_oracle_free_picture(hevc_oracle_picture* pic)
@@ -2372,5 +2617,6 @@ void hevc_oracle_free_picture(hevc_oracle_picture* pic)
   }
   free(pic->map_log2_tb); free(pic->map_log2_cb); free(pic->map_intra_luma); free(pic->map_intra_chroma);
   free(pic->map_qp_y); free(pic->map_flags); free(pic->sao_type); free(pic->sao_band_or_class); free(pic->sao_offset);
+  free(pic->map_pred); free(pic->mf_mv); free(pic->mf_ref);
   memset(pic, 0, sizeof(*pic));
 }

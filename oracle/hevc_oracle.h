@@ -59,6 +59,11 @@ typedef struct hevc_oracle_picture {
   /* statistics */
   uint64_t n_bins_ctx, n_bins_bypass; /* CABAC bins decoded                                */
   int      n_substreams;
+  /* ---- sequences (hevc_oracle_seq_*): picture order count and, with keep_taps, the motion field per 4x4 unit ---- */
+  int      poc;
+  uint8_t* map_pred;                 /* 0 MODE_INTRA, 1 MODE_INTER, 2 MODE_SKIP (NULL for hevc_oracle_decode)      */
+  int16_t* mf_mv;                    /* [unit*2] mvL0 in quarter luma samples                                         */
+  int8_t*  mf_ref;                   /* refIdxL0, -1 for intra units                                                  */
 } hevc_oracle_picture;
 
 /* Decode one intra picture.  `data` is libheif's plugin framing: a concatenation of
@@ -70,6 +75,15 @@ int hevc_oracle_decode(const uint8_t* data, size_t size, int keep_taps,
                        hevc_oracle_picture* out, char* errbuf, size_t errbuf_len);
 
 void hevc_oracle_free_picture(hevc_oracle_picture* pic);
+
+/* A sequence of pictures: one access unit per call, in decoding order, the way libheif pushes the samples of a track
+ * (libheif/sequences/track_visual.cc:200-280); parameter sets, the POC state and the decoded picture buffer persist between calls.
+ * P slices are decoded (scope: oracle/hevc_oracle_inter.c); every picture is output at once (decoding order). */
+typedef struct hevc_oracle_seq hevc_oracle_seq;
+hevc_oracle_seq* hevc_oracle_seq_new(void);
+int hevc_oracle_seq_decode(hevc_oracle_seq* q, const uint8_t* data, size_t size, int keep_taps, hevc_oracle_picture* out,
+                           char* errbuf, size_t errbuf_len);
+void hevc_oracle_seq_free(hevc_oracle_seq* q);
 
 #ifdef __cplusplus
 }

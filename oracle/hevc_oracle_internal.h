@@ -51,9 +51,22 @@ enum {
   CTX_GREATER1 = 104,        /* 24 */
   CTX_GREATER2 = 128,        /* 6 */
   CTX_CBF_CHROMA4 = 134,     /* cbf_cb / cbf_cr at trafoDepth 4: reachable only with ChromaArrayType 3 (Table 9-4 of the 2nd edition on) */
-  CTX_COUNT = 135
+  /* P slices (hevc_oracle_inter.c) */
+  CTX_SKIP_FLAG = 135,       /* 3 */
+  CTX_PRED_MODE = 138,
+  CTX_PART_MODE_INTER = 139, /* 3: part_mode bin 1, bin 2 at the minimum CB size, bin 2 with AMP (bin 0 is CTX_PART_MODE) */
+  CTX_MERGE_FLAG = 142,
+  CTX_MERGE_IDX = 143,
+  CTX_REF_IDX = 144,         /* 2 */
+  CTX_MVD_GT0 = 146,
+  CTX_MVD_GT1 = 147,
+  CTX_MVP_FLAG = 148,
+  CTX_RQT_ROOT_CBF = 149,
+  CTX_COUNT = 150
 };
 extern const uint8_t hevc_cabac_init_I[CTX_COUNT];
+extern const uint8_t hevc_cabac_init_P[2][CTX_COUNT];   /* initType 1 and 2 (P slice: cabac_init_flag ? 2 : 1) */
+enum { PART_2Nx2N = 0, PART_2NxN, PART_Nx2N, PART_NxN, PART_2NxnU, PART_2NxnD, PART_nLx2N, PART_nRx2N };   /* Table 7-10 */
 
 #ifdef __cplusplus
 }
