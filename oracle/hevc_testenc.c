@@ -88,7 +88,7 @@ static void bw_free(BW* w) { free(w->p); memset(w, 0, sizeof(*w)); }
 /* ------------------------------------------------------------------------------------------ */
 /* events + CABAC encoder (9.3.4.x encoding process)                                          */
 /* ------------------------------------------------------------------------------------------ */
-enum { EV_DECISION, EV_BYPASS, EV_BYPASS_BITS, EV_TERMINATE, EV_PCM };
+enum { EV_DECISION, EV_BYPASS, EV_BYPASS_BITS, EV_TERMINATE, EV_PCM, EV_NONE /* withdrawn */ };
 typedef struct { uint8_t kind; int16_t ctx; int32_t val; int32_t n; int32_t cond; } Event;
 
 typedef struct {
@@ -160,6 +160,9 @@ typedef struct {
   CabacEnc ce;
   uint8_t ctx[MAXCTX], ctx_wpp[MAXCTX];
   int qg_delta;           /* chosen delta for the current quantisation group */
+  int cu_any_cbf;         /* a transform block of the current coding unit has coefficients */
+  uint16_t* src_alloc[3];
+  int frame_idx;
 } Enc;
 
 static uint32_t rnd(Enc* e)
@@ -186,6 +189,7 @@ static void flush_events(Enc* e)
     Event* v = &e->ev[i];
     if (v->cond >= 0 && e->ev[v->cond].val == 0) continue; /* parent cbf is 0: flag not coded */
     switch (v->kind) {
+      case EV_NONE: break;
       case EV_DECISION: ce_decision(&e->ce, &e->ctx[v->ctx], v->val); break;
       case EV_BYPASS: ce_bypass(&e->ce, v->val); break;
       case EV_BYPASS_BITS: for (int k = v->n - 1; k >= 0; k--) ce_bypass(&e->ce, (v->val >> k) & 1); break;
@@ -459,7 +463,7 @@ static int analyse_tb(Enc* e, int x0c, int y0c, int log2n, int cIdx, int mode, i
   int n = 1 << log2n;
   int stride = cIdx ? d->Wc : d->W;
   int bit_depth = cIdx ? s->bit_depth_chroma : s->bit_depth_luma;
-  intra_predict_block(d, x0c, y0c, log2n, cIdx, mode);
+  if (!d->cu_pred_inter) intra_predict_block(d, x0c, y0c, log2n, cIdx, mode);   /* inter: rec holds the motion-compensated prediction */
   int32_t res[32 * 32];
   for (int y = 0; y < n; y++)
     for (int x = 0; x < n; x++)
@@ -474,7 +478,7 @@ static int analyse_tb(Enc* e, int x0c, int y0c, int log2n, int cIdx, int mode, i
     int qPi = Clip3(-QpBdOffsetC, 57, d->cur_qp_y + off);
     qP = (s->chroma_format_idc == 1 ? hevc_chroma_qp_420(qPi) : Min(qPi, 51)) + QpBdOffsetC;
   }
-  forward_quant(e, lev, res, n, qP, bit_depth, cIdx == 0 && n == 4, ts, d->cu_transquant_bypass_flag);
+  forward_quant(e, lev, res, n, qP, bit_depth, cIdx == 0 && n == 4 && !d->cu_pred_inter, ts, d->cu_transquant_bypass_flag);
   if (e->prm.zero_residual_pct && rnd_pct(e, e->prm.zero_residual_pct)) memset(lev, 0, sizeof(int32_t) * n * n);
   int cbf = 0;
   for (int i = 0; i < n * n; i++) if (lev[i]) { cbf = 1; break; }
@@ -486,6 +490,7 @@ static int analyse_tb(Enc* e, int x0c, int y0c, int log2n, int cIdx, int mode, i
     sdh_fix(lev, log2n, scanIdx);
   }
   *ts_out = ts;
+  if (cbf) e->cu_any_cbf = 1;
   reconstruct_tb(d, x0c, y0c, log2n, cIdx, mode, cbf, lev, ts);
   return cbf;
 }
@@ -527,7 +532,10 @@ static ChromaCbf enc_transform_tree(Enc* e, CuCtx* cu, int x0, int y0, int xBase
   if (can_signal) {
     split = e->prm.stress ? rnd_pct(e, 50) : (block_variance(e, x0, y0, 1 << log2TrafoSize) > 200 && rnd_pct(e, 60));
     EV_D(CTX_SPLIT_TRANSFORM + 5 - log2TrafoSize, split);
-  } else split = (log2TrafoSize > s->log2_max_tb || (cu->IntraSplitFlag && trafoDepth == 0)) ? 1 : 0;
+  } else {
+    int interSplit = cu->inter && s->max_transform_hierarchy_depth_inter == 0 && cu->PartMode != PART_2Nx2N && trafoDepth == 0;
+    split = (log2TrafoSize > s->log2_max_tb || (cu->IntraSplitFlag && trafoDepth == 0) || interSplit) ? 1 : 0;
+  }
 
   int my_cb = -1, my_cr = -1; /* event slots of this node's chroma cbfs */
   int32_t levCb[16 * 16], levCr[16 * 16];
@@ -709,7 +717,9 @@ static ChromaCbf enc_transform_tree(Enc* e, CuCtx* cu, int x0, int y0, int xBase
     e->ev[my_cb].val = out.cbf_cb; e->ev[my_cr].val = out.cbf_cr;
   }
   if (pending) { d->CuQpDeltaVal = saved_delta; d->cur_qp_y = saved_qp; }
-  EV_D(CTX_CBF_LUMA + (trafoDepth == 0 ? 1 : 0), cbfY);
+  /* 7.3.8.8: an inter coding unit's root leaf without chroma coefficients does not code cbf_luma (inferred 1; the caller turns a unit
+     whose blocks all came out empty into rqt_root_cbf 0 / a skipped unit) */
+  if (!cu->inter || trafoDepth != 0 || out.cbf_cb || out.cbf_cr) EV_D(CTX_CBF_LUMA + (trafoDepth == 0 ? 1 : 0), cbfY);
   if (cbfY || out.cbf_cb || out.cbf_cr) enc_cu_qp_delta(e);
   if (cbfY) emit_residual(e, levY, log2TrafoSize, 0, mode, tsY);
   if (out.cbf_cb) emit_residual(e, levCb, log2TrafoSize - 1, 1, cu->chroma_mode, tsCb);
@@ -742,6 +752,8 @@ static int pick_luma_mode(Enc* e, int xPb, int yPb, int nPb)
   return best;
 }
 
+#include "hevc_testenc_inter.c"
+
 static void enc_coding_unit(Enc* e, int x0, int y0, int log2CbSize, int cqtDepth)
 {
   Dec* d = e->d; const SPS* s = d->s; const PPS* p = d->p;
@@ -752,6 +764,17 @@ static void enc_coding_unit(Enc* e, int x0, int y0, int log2CbSize, int cqtDepth
   if (p->transquant_bypass_enabled_flag) {
     d->cu_transquant_bypass_flag = rnd_pct(e, e->prm.lossless_pct);
     EV_D(CTX_CU_TQ_BYPASS, d->cu_transquant_bypass_flag);
+  }
+  d->cu_pred_inter = 0;
+  if (d->sh->slice_type != 2) {   /* P slice: cu_skip_flag, pred_mode_flag (7.3.8.5) */
+    int ctxInc = 0;
+    if (available_z(d, x0, y0, x0 - 1, y0) && d->m_pred[(y0 >> 2) * d->mw + ((x0 - 1) >> 2)] == 2) ctxInc++;
+    if (available_z(d, x0, y0, x0, y0 - 1) && d->m_pred[((y0 - 1) >> 2) * d->mw + (x0 >> 2)] == 2) ctxInc++;
+    unsigned r = rnd(e) % 100;
+    int cu_skip = (int)r < e->prm.inter_skip_pct, intra = !cu_skip && (int)r < e->prm.inter_skip_pct + e->prm.inter_intra_pct;
+    int ev_skip = EV_D(CTX_SKIP_FLAG + ctxInc, cu_skip), ev_pred = -1;
+    if (!cu_skip) ev_pred = EV_D(CTX_PRED_MODE, intra);
+    if (!intra) { enc_inter_coding_unit(e, &cu, x0, y0, log2CbSize, cqtDepth, cu_skip, ev_skip, ev_pred); return; }
   }
   int PartMode = 0;
   if (log2CbSize == s->log2_min_cb) {
@@ -775,6 +798,7 @@ static void enc_coding_unit(Enc* e, int x0, int y0, int log2CbSize, int cqtDepth
       d->m_flags[idx] = (uint8_t)((d->cu_transquant_bypass_flag ? 0x08 : 0) | (pcm_flag ? 0x10 : 0));
       d->m_decoded[idx] = 1;
       d->m_ipm[idx] = 1;
+      if (d->m_pred) { d->m_pred[idx] = 0; d->mf_ref[idx] = -1; d->mf_poc[idx] = 0; d->mf_mv[2 * idx] = d->mf_mv[2 * idx + 1] = 0; }
     }
   if (pcm_flag) {
     size_t start = e->pcm_bits;
@@ -1025,26 +1049,12 @@ static void write_ptl(BW* w, int bit_depth, int chroma)
   bw_u(w, 186, 8);
 }
 
-int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const planes[3], uint8_t** out, size_t* out_size,
-                        char* errbuf, size_t errbuf_len)
+/* parameter sets (filled as decoder structs, then written as VPS / SPS / PPS NAL units into `stream`) */
+static void enc_parameter_sets(Enc* e, Bytes* pstream)
 {
-  init_scans(); init_dct();
-  Enc E; memset(&E, 0, sizeof(E));
-  Enc* e = &E;
-  e->prm = *prm;
-  e->rng = 0x9E3779B97F4A7C15ULL ^ ((uint64_t)prm->seed * 0x100000001B3ULL);
-  Dec* d = (Dec*)calloc(1, sizeof(Dec));
-  e->d = d;
-  d->keep_taps = 0;
-  Bytes stream = {0, 0, 0};
-  uint16_t* src[3] = {0, 0, 0};
-  if (setjmp(d->jb)) {
-    if (errbuf && errbuf_len) snprintf(errbuf, errbuf_len, "testenc: %s", d->err);
-    for (int c = 0; c < 3; c++) free(src[c]);
-    free(stream.p); free(e->ev); free(e->pcm_blob); bw_free(&e->ce.bw);
-    free_dec(d);
-    return -1;
-  }
+  Dec* d = e->d;
+  const hevc_testenc_params* prm = &e->prm;
+#define stream (*pstream)
   /* ---- parameter sets (filled as decoder structs, then written) ---- */
   SPS* s = &d->sps[0]; PPS* p = &d->pps[0];
   int minCb = 1 << prm->log2_min_cb;
@@ -1059,12 +1069,12 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
   s->log2_max_poc_lsb = 8;
   s->log2_min_cb = prm->log2_min_cb; s->log2_ctb = prm->log2_ctb;
   s->log2_min_tb = prm->log2_min_tb; s->log2_max_tb = prm->log2_max_tb;
-  s->max_transform_hierarchy_depth_inter = 1;
+  s->max_transform_hierarchy_depth_inter = prm->max_transform_hierarchy_depth_inter;
   s->max_transform_hierarchy_depth_intra = prm->max_transform_hierarchy_depth_intra;
   s->scaling_list_enabled_flag = prm->scaling_list ? 1 : 0;
   if (prm->chroma_format_idc < 0 || prm->chroma_format_idc > 3) fail(d, "chroma_format_idc must be 0 .. 3");
   scaling_list_default(&s->sl); scaling_list_default(&p->sl);
-  s->amp_enabled_flag = 0; s->sao_enabled_flag = prm->sao;
+  s->amp_enabled_flag = prm->amp ? 1 : 0; s->sao_enabled_flag = prm->sao;
   s->pcm_enabled_flag = prm->pcm_pct > 0;
   if (s->pcm_enabled_flag) {
     s->pcm_bit_depth_luma = prm->bit_depth - 1; s->pcm_bit_depth_chroma = prm->bit_depth;
@@ -1100,7 +1110,10 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
   p->deblocking_filter_override_enabled_flag = 0;
   p->pps_deblocking_filter_disabled_flag = prm->deblock_disable;
   p->pps_beta_offset_div2 = prm->beta_offset_div2; p->pps_tc_offset_div2 = prm->tc_offset_div2;
-  p->log2_parallel_merge_level = 2;
+  p->log2_parallel_merge_level = prm->parallel_merge_level >= 2 ? Min(prm->parallel_merge_level, s->log2_ctb) : 2;
+  p->num_ref_idx_l0_default_active = 1;
+  p->cabac_init_present_flag = prm->cabac_init_present ? 1 : 0;
+  p->lists_modification_present_flag = prm->lists_modification ? 1 : 0;
   p->valid = 1;
   d->s = s; d->p = p;
 
@@ -1133,7 +1146,7 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
     bw_u(&w, prm->scaling_list == 2, 1);
     if (prm->scaling_list == 2) write_scaling_list_data(d, &w, &s->sl, (unsigned)prm->seed + 17u);
   }
-  bw_u(&w, 0, 1); bw_u(&w, s->sao_enabled_flag, 1); bw_u(&w, s->pcm_enabled_flag, 1);
+  bw_u(&w, s->amp_enabled_flag, 1); bw_u(&w, s->sao_enabled_flag, 1); bw_u(&w, s->pcm_enabled_flag, 1);
   if (s->pcm_enabled_flag) {
     bw_u(&w, s->pcm_bit_depth_luma - 1, 4); bw_u(&w, s->pcm_bit_depth_chroma - 1, 4);
     bw_ue(&w, s->log2_min_pcm_cb - 3); bw_ue(&w, s->log2_max_pcm_cb - s->log2_min_pcm_cb);
@@ -1156,7 +1169,7 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
   /* PPS 7.3.2.3 */
   p->dependent_slice_segments_enabled_flag = prm->dependent_segments > 1;
   bw_ue(&w, 0); bw_ue(&w, 0); bw_u(&w, p->dependent_slice_segments_enabled_flag, 1); bw_u(&w, 0, 1); bw_u(&w, 0, 3);
-  bw_u(&w, p->sign_data_hiding_enabled_flag, 1); bw_u(&w, 0, 1); bw_ue(&w, 0); bw_ue(&w, 0);
+  bw_u(&w, p->sign_data_hiding_enabled_flag, 1); bw_u(&w, p->cabac_init_present_flag, 1); bw_ue(&w, 0); bw_ue(&w, 0);
   bw_se(&w, p->init_qp_minus26); bw_u(&w, 0, 1); bw_u(&w, p->transform_skip_enabled_flag, 1);
   bw_u(&w, p->cu_qp_delta_enabled_flag, 1);
   if (p->cu_qp_delta_enabled_flag) bw_ue(&w, p->diff_cu_qp_delta_depth);
@@ -1173,13 +1186,33 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
   p->pps_scaling_list_data_present_flag = prm->scaling_list == 3;
   bw_u(&w, p->pps_scaling_list_data_present_flag, 1);
   if (p->pps_scaling_list_data_present_flag) write_scaling_list_data(d, &w, &p->sl, (unsigned)prm->seed + 29u);
-  bw_u(&w, 0, 1); bw_ue(&w, 0); bw_u(&w, 0, 1); bw_u(&w, 0, 1);
+  bw_u(&w, p->lists_modification_present_flag, 1); bw_ue(&w, p->log2_parallel_merge_level - 2); bw_u(&w, 0, 1); bw_u(&w, 0, 1);
   bw_trailing(&w);
   put_nal(&stream, 34, w.p, w.nbits >> 3);
   bw_free(&w);
+#undef stream
+}
 
-  /* ---- picture ---- */
+/* one picture: frame 0 an IDR intra picture, the following ones P pictures (TRAIL_R) referencing the previous pictures */
+static void enc_picture(Enc* e, const uint16_t* const planes[3], int frame_idx, Bytes* pstream)
+{
+  Dec* d = e->d;
+  const hevc_testenc_params* prm = &e->prm;
+  const SPS* s = d->s; const PPS* p = d->p;
+  uint16_t** src = e->src_alloc;
+  BW w; memset(&w, 0, sizeof(w));
+#define stream (*pstream)
+  const int is_p = frame_idx > 0;
+  const int nal_type = is_p ? 1 : 19;
+  e->frame_idx = frame_idx;
   setup_picture(d);
+  StRps rps; memset(&rps, 0, sizeof(rps));
+  if (is_p) {   /* the RPS in the slice header: the previous pictures, the farthest of three or more kept but not used by this picture */
+    int nrefs = Min(frame_idx, Max(1, prm->inter_num_refs));
+    rps.num_neg = nrefs;
+    for (int i = 0; i < nrefs; i++) { rps.delta_s0[i] = -(i + 1); rps.used_s0[i] = !(nrefs >= 3 && i == nrefs - 1); }
+  }
+  if (d->seq_mode) inter_begin_picture(d, nal_type, frame_idx & 255, &rps);
   for (int c = 0; c < (s->chroma_format_idc ? 3 : 1); c++) {
     int W = c ? d->Wc : d->W, H = c ? d->Hc : d->H;
     int csw = c ? d->subw : 1, csh = c ? d->subh : 1;
@@ -1235,13 +1268,20 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
   }
   int CtbSizeY = 1 << s->log2_ctb;
   SliceHdr cur_hdr; memset(&cur_hdr, 0, sizeof(cur_hdr));
+  int list_mod = 0, list_entries[16];
   for (int si = 0; si < nsl; si++) {
     const int is_dep = seg_dependent ? seg_dependent[si] : 0;
     SliceHdr hdr; memset(&hdr, 0, sizeof(hdr));
     if (is_dep) goto segment_data;   /* a dependent slice segment continues the slice: its header fields are those of cur_hdr */
     hdr.first_slice_segment_in_pic_flag = si == 0;
     hdr.slice_segment_address = d->CtbAddrTsToRs[slice_start[si]];
-    hdr.slice_type = 2;
+    hdr.slice_type = is_p ? 1 : 2;
+    if (is_p) {
+      int total = d->n_st_curr_before;
+      hdr.num_ref_idx_l0_active = (si & 1) ? Min(15, total + 1) : total;   /* one more than there are pictures: the list wraps around (8.3.4) */
+      hdr.max_num_merge_cand = prm->max_merge_cand >= 1 && prm->max_merge_cand <= 5 ? prm->max_merge_cand : 5;
+      hdr.cabac_init_flag = p->cabac_init_present_flag ? (int)((si + frame_idx) & 1) : 0;
+    }
     hdr.slice_sao_luma_flag = s->sao_enabled_flag; hdr.slice_sao_chroma_flag = s->sao_enabled_flag && s->chroma_format_idc;
     hdr.slice_qp_delta = prm->qp - 26 + (si % 3) - (si ? 1 : 0) * 0;
     if (26 + hdr.slice_qp_delta < 1) hdr.slice_qp_delta = -25;
@@ -1255,6 +1295,12 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
     hdr.SliceAddrRs = hdr.slice_segment_address;
     hdr.SliceQpY = 26 + p->init_qp_minus26 + hdr.slice_qp_delta;
     if (d->nslices == d->capslices) { d->capslices = d->capslices ? d->capslices * 2 : 8; d->slices = (SliceHdr*)realloc(d->slices, sizeof(SliceHdr) * d->capslices); }
+    if (is_p) {
+      int total = d->n_st_curr_before;
+      list_mod = p->lists_modification_present_flag && total > 1 && ((si + frame_idx) % 3 != 0);
+      for (int i = 0; i < hdr.num_ref_idx_l0_active; i++) list_entries[i] = (int)(rnd(e) % (unsigned)total);
+      build_ref_list0(d, &hdr, list_mod ? list_entries : NULL);
+    }
     d->slices[d->nslices] = hdr; d->sh = &d->slices[d->nslices]; d->sh_idx = d->nslices; d->nslices++;
     cur_hdr = hdr;
   segment_data:
@@ -1336,15 +1382,30 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
     /* slice segment header 7.3.6.1 */
     memset(&w, 0, sizeof(w));
     bw_u(&w, hdr.first_slice_segment_in_pic_flag, 1);
-    bw_u(&w, 0, 1); /* no_output_of_prior_pics_flag (IDR) */
+    if (!is_p) bw_u(&w, 0, 1); /* no_output_of_prior_pics_flag (IRAP only) */
     bw_ue(&w, 0);
     if (!hdr.first_slice_segment_in_pic_flag) {
       if (p->dependent_slice_segments_enabled_flag) bw_u(&w, is_dep, 1);
       bw_u(&w, hdr.slice_segment_address, ceil_log2(d->nCtb));
     }
     if (!is_dep) {
-      bw_ue(&w, 2);
+      bw_ue(&w, hdr.slice_type);
+      if (is_p) {   /* 7.3.6.1: POC lsb, the picture's RPS coded in the slice header (idx == num_short_term_ref_pic_sets == 0: no inter-RPS flag) */
+        bw_u(&w, frame_idx & 255, s->log2_max_poc_lsb);
+        bw_u(&w, 0, 1);                                   /* short_term_ref_pic_set_sps_flag */
+        bw_ue(&w, rps.num_neg); bw_ue(&w, 0);
+        for (int i = 0; i < rps.num_neg; i++) { bw_ue(&w, 0); bw_u(&w, rps.used_s0[i], 1); }   /* delta_poc_s0_minus1 0: consecutive pictures */
+      }
       if (s->sao_enabled_flag) { bw_u(&w, hdr.slice_sao_luma_flag, 1); if (s->chroma_format_idc) bw_u(&w, hdr.slice_sao_chroma_flag, 1); }
+      if (is_p) {
+        bw_u(&w, 1, 1); bw_ue(&w, hdr.num_ref_idx_l0_active - 1);                               /* num_ref_idx_active_override_flag */
+        if (p->lists_modification_present_flag && d->n_st_curr_before > 1) {
+          bw_u(&w, list_mod, 1);
+          if (list_mod) for (int i = 0; i < hdr.num_ref_idx_l0_active; i++) bw_u(&w, list_entries[i], ceil_log2(d->n_st_curr_before));
+        }
+        if (p->cabac_init_present_flag) bw_u(&w, hdr.cabac_init_flag, 1);
+        bw_ue(&w, 5 - hdr.max_num_merge_cand);
+      }
       bw_se(&w, hdr.slice_qp_delta);
       if (lf_present) bw_u(&w, hdr.slice_loop_filter_across_slices_enabled_flag, 1);
     }
@@ -1360,7 +1421,7 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
     }
     bw_trailing(&w); /* byte_alignment(): same bit pattern */
     Bytes nal = {0, 0, 0};
-    uint8_t nh[2] = {(uint8_t)(19 << 1), 1};
+    uint8_t nh[2] = {(uint8_t)(nal_type << 1), 1};
     by_push(&nal, nh, 2);
     escape_into(&nal, w.p, w.nbits >> 3);
     by_push(&nal, esc.p, esc.n);
@@ -1370,11 +1431,69 @@ int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const pl
     bw_free(&w); free(nal.p); free(esc.p); free(esz); free(subs.p); free(sizes);
   }
   free(slice_start); free(seg_dependent);
-  for (int c = 0; c < 3; c++) free(src[c]);
+  for (int c = 0; c < 3; c++) { free(src[c]); src[c] = NULL; e->src[c] = NULL; }
+  if (d->seq_mode) {   /* the decoded picture (deblocked, SAO applied) becomes a reference picture, as in the decoder */
+    int nc = s->chroma_format_idc ? 3 : 1;
+    deblock_picture(d);
+    uint16_t* fin[3] = {0, 0, 0};
+    for (int c = 0; c < nc; c++) fin[c] = (uint16_t*)xcalloc(d, c ? (size_t)d->Wc * d->Hc : (size_t)d->W * d->H, sizeof(uint16_t));
+    sao_picture(d, d->rec, fin);
+    int slot = -1;
+    for (int i = 0; i < MAX_DPB; i++) if (!d->dpb[i].valid) { slot = i; break; }
+    if (slot < 0) fail(d, "decoded picture buffer is full");
+    if (slot >= d->n_dpb) d->n_dpb = slot + 1;
+    for (int c = 0; c < nc; c++) d->dpb[slot].plane[c] = fin[c];
+    d->dpb[slot].poc = d->poc; d->dpb[slot].valid = 1;
+  }
+  release_picture(d);
+#undef stream
+}
+
+static int enc_run(const hevc_testenc_params* prm, int n_frames, const uint16_t* const* planes, uint8_t** out, size_t* out_sizes,
+                   char* errbuf, size_t errbuf_len, int seq_mode)
+{
+  init_scans(); init_dct();
+  Enc E; memset(&E, 0, sizeof(E));
+  Enc* e = &E;
+  e->prm = *prm;
+  e->rng = 0x9E3779B97F4A7C15ULL ^ ((uint64_t)prm->seed * 0x100000001B3ULL);
+  Dec* d = (Dec*)calloc(1, sizeof(Dec));
+  e->d = d;
+  d->keep_taps = 0;
+  d->seq_mode = seq_mode; d->first_picture = 1;
+  Bytes stream = {0, 0, 0};
+  for (int f = 0; f < n_frames; f++) { out[f] = NULL; out_sizes[f] = 0; }
+  if (setjmp(d->jb)) {
+    if (errbuf && errbuf_len) snprintf(errbuf, errbuf_len, "testenc: %s", d->err);
+    for (int c = 0; c < 3; c++) free(e->src_alloc[c]);
+    free(stream.p); free(e->ev); free(e->pcm_blob); bw_free(&e->ce.bw);
+    for (int f = 0; f < n_frames; f++) { free(out[f]); out[f] = NULL; }
+    free_dec(d);
+    return -1;
+  }
+  if (seq_mode && (prm->chroma_format_idc > 1 || prm->scaling_list)) fail(d, "sequences with P pictures: 4:0:0 / 4:2:0 without scaling lists only");
+  enc_parameter_sets(e, &stream);
+  for (int f = 0; f < n_frames; f++) {
+    enc_picture(e, planes + 3 * f, f, &stream);
+    out[f] = stream.p; out_sizes[f] = stream.n;
+    stream.p = NULL; stream.n = stream.cap = 0;
+  }
   free(e->ev); free(e->pcm_blob);
   free_dec(d);
-  *out = stream.p; *out_size = stream.n;
   return 0;
+}
+
+int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const planes[3], uint8_t** out, size_t* out_size,
+                        char* errbuf, size_t errbuf_len)
+{
+  return enc_run(prm, 1, planes, out, out_size, errbuf, errbuf_len, 0);
+}
+
+int hevc_testenc_encode_seq(const hevc_testenc_params* prm, int n_frames, const uint16_t* const* planes, uint8_t** out, size_t* out_sizes,
+                            char* errbuf, size_t errbuf_len)
+{
+  if (n_frames < 1) return -1;
+  return enc_run(prm, n_frames, planes, out, out_sizes, errbuf, errbuf_len, 1);
 }
 
 void hevc_testenc_free(uint8_t* p) { free(p); }

@@ -1,4 +1,4 @@
-/* hevc_testenc.h — test-only HEVC intra stream generator (see hevc_testenc.c). */
+/* hevc_testenc.h — test-only HEVC stream generator: intra pictures, and sequences with P pictures (see hevc_testenc.c). */
 #ifndef HEVC_TESTENC_H
 #define HEVC_TESTENC_H
 #include <stddef.h>
@@ -26,6 +26,15 @@ typedef struct hevc_testenc_params {
   int stress;                   /* 1: random splits / modes (syntax coverage); 0: SAD-driven       */
   int zero_residual_pct;        /* % of transform blocks forced to cbf = 0                         */
   int dependent_segments;       /* > 1: every slice is split into that many slice segments, all but its first dependent */
+  /* ---- sequences (hevc_testenc_encode_seq): frame 0 is an IDR intra picture, the others are P pictures (TRAIL_R) ---- */
+  int inter_num_refs;           /* reference pictures a P picture may use (the previous ones; 0 = 1)                      */
+  int inter_skip_pct, inter_intra_pct, inter_merge_pct;   /* % of coding units skipped / intra coded, % of prediction units merged */
+  int amp;                      /* asymmetric motion partitions                                                            */
+  int max_merge_cand;           /* MaxNumMergeCand 1..5 (0 = 5)                                                            */
+  int parallel_merge_level;     /* Log2ParMrgLevel 2..log2_ctb (0 = 2)                                                     */
+  int max_transform_hierarchy_depth_inter;
+  int cabac_init_present, lists_modification;
+  int global_mv_x, global_mv_y; /* motion (quarter luma samples) most vectors are drawn around                             */
 } hevc_testenc_params;
 
 /* planes: tightly packed uint16 samples at display size (chroma (w+1)/2 x (h+1)/2).
@@ -33,6 +42,10 @@ typedef struct hevc_testenc_params {
  * hevc_testenc_free(). */
 int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const planes[3], uint8_t** out,
                         size_t* out_size, char* errbuf, size_t errbuf_len);
+/* n_frames pictures at display size: planes[3 * f + c].  out[f] / out_sizes[f]: one malloc'd access unit per picture in plugin framing
+ * (the first one carries VPS, SPS, PPS), what libheif pushes sample by sample for a track (libheif/sequences/track_visual.cc:200-280). */
+int hevc_testenc_encode_seq(const hevc_testenc_params* prm, int n_frames, const uint16_t* const* planes, uint8_t** out,
+                            size_t* out_sizes, char* errbuf, size_t errbuf_len);
 void hevc_testenc_free(uint8_t* p);
 #ifdef __cplusplus
 }

@@ -39,6 +39,7 @@ class _Pic(C.Structure):
         ("sao_type", C.POINTER(C.c_uint8)), ("sao_band_or_class", C.POINTER(C.c_uint8)),
         ("sao_offset", C.POINTER(C.c_int16)),
         ("n_bins_ctx", C.c_uint64), ("n_bins_bypass", C.c_uint64), ("n_substreams", C.c_int),
+        ("poc", C.c_int), ("map_pred", C.POINTER(C.c_uint8)), ("mf_mv", C.POINTER(C.c_int16)), ("mf_ref", C.POINTER(C.c_int8)),
     ]
 
 
@@ -71,6 +72,50 @@ def decode(stream: bytes, taps: bool = False) -> dict:
     rc = L.hevc_oracle_decode(stream, len(stream), 1 if taps else 0, C.byref(pic), err, 512)
     if rc != 0:
         raise OracleError(err.value.decode("latin1"))
+    return _picture_dict(L, pic, taps)
+
+
+class SeqDecoder:
+    """hevc_oracle_seq_*: one access unit per decode() call in decoding order (the samples of a track); P slices are decoded, parameter
+    sets and the decoded picture buffer persist between calls."""
+
+    def __init__(self):
+        L = lib()
+        L.hevc_oracle_seq_new.restype = C.c_void_p
+        L.hevc_oracle_seq_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(_Pic), C.c_char_p, C.c_size_t]
+        L.hevc_oracle_seq_free.argtypes = [C.c_void_p]
+        self._L = L
+        self._h = C.c_void_p(L.hevc_oracle_seq_new())
+
+    def decode(self, stream: bytes, taps: bool = False) -> dict:
+        pic = _Pic()
+        err = C.create_string_buffer(512)
+        rc = self._L.hevc_oracle_seq_decode(self._h, stream, len(stream), 1 if taps else 0, C.byref(pic), err, 512)
+        if rc != 0:
+            raise OracleError(err.value.decode("latin1"))
+        return _picture_dict(self._L, pic, taps)
+
+    def close(self):
+        if self._h:
+            self._L.hevc_oracle_seq_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def decode_sequence(streams, taps=False):
+    q = SeqDecoder()
+    try:
+        return [q.decode(s, taps) for s in streams]
+    finally:
+        q.close()
+
+
+def _picture_dict(L, pic, taps):
     try:
         nc = 3 if pic.chroma_format_idc else 1
         out = {
@@ -79,6 +124,7 @@ def decode(stream: bytes, taps: bool = False) -> dict:
             "nclx": (pic.colour_primaries, pic.transfer_characteristics, pic.matrix_coeffs, pic.full_range_flag),
             "coded_size": (pic.coded_width, pic.coded_height),
             "n_bins_ctx": pic.n_bins_ctx, "n_bins_bypass": pic.n_bins_bypass, "n_substreams": pic.n_substreams,
+            "poc": pic.poc,
             "planes": [],
         }
         for c in range(nc):
@@ -101,6 +147,10 @@ def decode(stream: bytes, taps: bool = False) -> dict:
             out["sao_type"] = _arr(pic.sao_type, (nctb, 3), np.uint8)
             out["sao_band_or_class"] = _arr(pic.sao_band_or_class, (nctb, 3), np.uint8)
             out["sao_offset"] = _arr(pic.sao_offset, (nctb, 3, 4), np.int16)
+            if pic.map_pred:
+                out["map_pred"] = _arr(pic.map_pred, (mh, ms), np.uint8)
+                out["mf_mv"] = _arr(pic.mf_mv, (mh, ms, 2), np.int16)
+                out["mf_ref"] = _arr(pic.mf_ref, (mh, ms), np.int8)
         return out
     finally:
         L.hevc_oracle_free_picture(C.byref(pic))
@@ -203,7 +253,10 @@ class _EncParams(C.Structure):
         "diff_cu_qp_delta_depth", "transform_skip", "lossless_pct", "pcm_pct", "pcm_loop_filter_disabled",
         "strong_intra_smoothing", "scaling_list", "cb_qp_offset", "cr_qp_offset", "loop_filter_across_tiles",
         "loop_filter_across_slices", "vui_primaries", "vui_transfer", "vui_matrix", "vui_full_range")] + \
-        [("seed", C.c_uint32), ("stress", C.c_int), ("zero_residual_pct", C.c_int), ("dependent_segments", C.c_int)]
+        [("seed", C.c_uint32), ("stress", C.c_int), ("zero_residual_pct", C.c_int), ("dependent_segments", C.c_int)] + \
+        [(n, C.c_int) for n in (
+            "inter_num_refs", "inter_skip_pct", "inter_intra_pct", "inter_merge_pct", "amp", "max_merge_cand", "parallel_merge_level",
+            "max_transform_hierarchy_depth_inter", "cabac_init_present", "lists_modification", "global_mv_x", "global_mv_y")]
 
 
 ENC_DEFAULTS = dict(bit_depth=8, chroma_format_idc=1, log2_ctb=6, log2_min_cb=3, log2_min_tb=2, log2_max_tb=5,
@@ -212,7 +265,9 @@ ENC_DEFAULTS = dict(bit_depth=8, chroma_format_idc=1, log2_ctb=6, log2_min_cb=3,
                     diff_cu_qp_delta_depth=1, transform_skip=0, lossless_pct=0, pcm_pct=0, pcm_loop_filter_disabled=0,
                     strong_intra_smoothing=1, scaling_list=0, cb_qp_offset=0, cr_qp_offset=0, loop_filter_across_tiles=1,
                     loop_filter_across_slices=1, vui_primaries=1, vui_transfer=13, vui_matrix=-1, vui_full_range=0,
-                    seed=1, stress=0, zero_residual_pct=0, dependent_segments=0)
+                    seed=1, stress=0, zero_residual_pct=0, dependent_segments=0,
+                    inter_num_refs=1, inter_skip_pct=20, inter_intra_pct=10, inter_merge_pct=40, amp=0, max_merge_cand=5, parallel_merge_level=2,
+                    max_transform_hierarchy_depth_inter=1, cabac_init_present=0, lists_modification=0, global_mv_x=0, global_mv_y=0)
 
 
 def synth_image(width, height, bit_depth=8, chroma_format_idc=1, seed=1):
@@ -281,3 +336,41 @@ def encode(planes, **kw):
     L.hevc_testenc_free.argtypes = [C.POINTER(C.c_uint8)]
     L.hevc_testenc_free(out)
     return data
+
+
+def encode_sequence(frames, **kw):
+    """frames: list of plane lists ([Y] or [Y, Cb, Cr] at display size, all of one shape).  Frame 0 becomes an IDR intra picture, the
+    others P pictures.  Returns one plugin-framed access unit per frame (the first carries the parameter sets)."""
+    prm = dict(ENC_DEFAULTS)
+    prm.update(kw)
+    h, w = frames[0][0].shape
+    prm.setdefault("width", w)
+    prm.setdefault("height", h)
+    prm["chroma_format_idc"] = 1 if len(frames[0]) == 3 else 0
+    st = _EncParams()
+    for k, v in prm.items():
+        setattr(st, k, int(v))
+    L = lib()
+    n = len(frames)
+    keep = []
+    ptrs = (C.POINTER(C.c_uint16) * (3 * n))()
+    for f, planes in enumerate(frames):
+        ps = [np.ascontiguousarray(p, dtype=np.uint16) for p in planes]
+        while len(ps) < 3:
+            ps.append(ps[0])
+        keep.append(ps)
+        for c in range(3):
+            ptrs[3 * f + c] = ps[c].ctypes.data_as(C.POINTER(C.c_uint16))
+    outs = (C.POINTER(C.c_uint8) * n)()
+    sizes = (C.c_size_t * n)()
+    err = C.create_string_buffer(512)
+    L.hevc_testenc_encode_seq.restype = C.c_int
+    rc = L.hevc_testenc_encode_seq(C.byref(st), n, ptrs, outs, sizes, err, 512)
+    if rc != 0:
+        raise OracleError(err.value.decode("latin1"))
+    L.hevc_testenc_free.argtypes = [C.POINTER(C.c_uint8)]
+    res = []
+    for f in range(n):
+        res.append(bytes(np.ctypeslib.as_array(outs[f], shape=(sizes[f],))))
+        L.hevc_testenc_free(outs[f])
+    return res

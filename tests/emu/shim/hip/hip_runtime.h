@@ -29,6 +29,8 @@ struct dim3 {
 struct uint2 { unsigned x, y; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
 struct uint4 { unsigned x, y, z, w; };
+struct float4 { float x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 typedef void* hipStream_t;
 // the few runtime calls the host side of color.hip makes (parameter-block upload of the batched colour launch)
 typedef int hipError_t;
