@@ -31,16 +31,17 @@ template <class F> void for_each_item(int n, size_t total_bytes, F&& fn)
 }  // namespace
 
 int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels,
-                 std::vector<uint8_t>& host, std::string& err_out)
+                 std::vector<uint8_t>& host, std::string& err_out, const SeqContext* const* seqs)
 {
-  int rc = layout_batch_plan(b, n, data, sizes, max_pixels, err_out);
+  int rc = layout_batch_plan(b, n, data, sizes, max_pixels, err_out, seqs);
   if (rc != HIPDEC_OK) return rc;
   host.assign(b.upload_size, 0);
   layout_batch_fill(b, data, sizes, host.data());
   return HIPDEC_OK;
 }
 
-int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels, std::string& err_out)
+int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels, std::string& err_out,
+                      const SeqContext* const* seqs)
 {
   b.pics.resize(n);
   {
@@ -48,7 +49,7 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
     for (int i = 0; i < n; i++) total += sizes[i];
     std::vector<int> rcs((size_t)n, HIPDEC_OK);
     std::vector<std::string> errs((size_t)n);
-    for_each_item(n, total, [&](int i) { rcs[i] = parse_picture((const uint8_t*)data[i], sizes[i], max_pixels, b.pics[i], errs[i]); });
+    for_each_item(n, total, [&](int i) { rcs[i] = parse_picture((const uint8_t*)data[i], sizes[i], max_pixels, b.pics[i], errs[i], seqs ? seqs[i] : nullptr); });
     for (int i = 0; i < n; i++)
       if (rcs[i] != HIPDEC_OK) { err_out = "item " + std::to_string(i) + ": " + errs[i]; return rcs[i]; }
   }
@@ -167,6 +168,11 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
     P.scaling_lists = pp.scaling_tables.empty() ? 0 : 1;
     P.off_scaling = off;
     if (P.scaling_lists) off = align_up(off + pp.scaling_tables.size(), 256);
+    // P pictures: the reference picture table (absolute device pointers into earlier batches' arenas)
+    P.is_inter = pp.is_inter ? 1 : 0; P.poc = pp.poc; P.num_refs = (uint32_t)pp.refs.size();
+    P.amp_enabled = S.amp ? 1 : 0; P.max_th_depth_inter = (uint8_t)S.max_th_depth_inter; P.log2_par_mrg_level = (uint8_t)Pp.log2_par_mrg_level;
+    P.off_reftab = off;
+    if (P.is_inter) { off = align_up(off + 16 * sizeof(RefFrame), 256); b.any_inter = true; }
     P.off_bitstream = off; P.bitstream_size = sizes[i]; off = align_up(off + sizes[i] + 512, 256);
     b.max_w = std::max(b.max_w, P.width); b.max_h = std::max(b.max_h, P.height);
     b.max_ctbs = std::max(b.max_ctbs, P.ctb_w * P.ctb_h);
@@ -208,6 +214,11 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
     P.off_u_ipm = off; off = align_up(off + nunits, 256);
     P.off_u_ipmc = off; off = align_up(off + nunits, 256);
     P.off_u_qp = off; off = align_up(off + nunits, 256);
+    P.off_msyn = P.off_mf = off;
+    if (P.is_inter) {
+      P.off_msyn = off; off = align_up(off + nunits * sizeof(MotionSyntax), 256);
+      P.off_mf = off; off = align_up(off + nunits * sizeof(MotionUnit), 256);
+    }
     P.off_coeff[0] = off; off = align_up(off + nctb * ctb2 * 2, 256);
     const int csw = P.chroma_format_idc == 3 ? 0 : 1, csh = (P.chroma_format_idc == 3 || P.chroma_format_idc == 2) ? 0 : 1;   // log2 chroma subsampling (4:0:0: sized like 4:2:0, never touched)
     P.off_coeff[1] = off; off = align_up(off + ((nctb * ctb2 * 2) >> (csw + csh)), 256);
@@ -267,7 +278,16 @@ void layout_batch_fill(BatchLayout& b, const void* const* data, const size_t* si
     put(P.off_ctb_ts_to_rs, pp.ts_to_rs.data(), pp.ts_to_rs.size() * sizeof(uint16_t), P.off_ctb_info);
     put(P.off_ctb_info, pp.ctb_info.data(), pp.ctb_info.size() * sizeof(CtbInfo), P.off_slices);
     put(P.off_slices, pp.slice_params.data(), pp.slice_params.size() * sizeof(SliceParams), P.off_scaling);
-    if (P.scaling_lists) put(P.off_scaling, pp.scaling_tables.data(), pp.scaling_tables.size(), P.off_bitstream);
+    if (P.scaling_lists) put(P.off_scaling, pp.scaling_tables.data(), pp.scaling_tables.size(), P.is_inter ? P.off_reftab : P.off_bitstream);
+    if (P.is_inter) {
+      RefFrame tab[16];
+      memset(tab, 0, sizeof(tab));
+      for (size_t k = 0; k < pp.refs.size() && k < 16; k++) {
+        for (int c = 0; c < 3; c++) { tab[k].plane[c] = pp.refs[k].plane[c]; tab[k].stride[c] = pp.refs[k].stride[c]; }
+        tab[k].poc = pp.refs[k].poc;
+      }
+      put(P.off_reftab, tab, sizeof(tab), P.off_bitstream);
+    }
     put(P.off_bitstream, data[i], sizes[i], end);
   });
   b.parse_waves.clear(); b.parse_waves.shrink_to_fit();

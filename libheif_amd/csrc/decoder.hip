@@ -179,6 +179,8 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
   pa.wake_hyst = getenv("HIPDEC_POOL_HYST") ? (uint32_t)atoi(getenv("HIPDEC_POOL_HYST")) : 0u;
   pa.general_chroma = 0;
   for (const PicParams& P : b.params) if (P.chroma_format_idc >= 2) pa.general_chroma = 1;
+  pa.inter = b.any_inter ? 1 : 0;
+  if (pa.inter && pa.general_chroma) return set_error(HIPDEC_ERR_UNSUPPORTED, "a batch that mixes P pictures with 4:2:2 / 4:4:4 pictures");
   pa.pool = b.pool; pa.queue_cap = b.queue_cap; pa.num_subs = b.num_subs;
   pa.waitneed = (uint32_t*)(b.arena + b.off_waitneed); pa.resume_k = (uint32_t*)(b.arena + b.off_resume_k);
   pa.queue = (uint32_t*)(b.arena + b.off_queue); pa.qctl = (uint32_t*)(b.arena + b.off_qctl); pa.saved = (uint32_t*)(b.arena + b.off_saved);
@@ -216,6 +218,15 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
   if (!parse_only) launch_residual(fa, n, b.max_ctbs, pa.general_chroma != 0, ps);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[2], ps));
   if (int rc = step("residual")) return rc;
+  if (!parse_only && b.any_inter) {
+    // P pictures: motion vectors (merge / AMVP candidates: a 2-CTB wavefront over CTB rows), then the motion-compensated prediction of every
+    // inter coded sample into the reconstruction planes; k_recon adds the residuals and predicts the intra blocks around them
+    MotionArgs ma{(const PicParams*)(b.arena + b.off_pics), (const RowDesc*)(b.arena + b.off_rows), b.num_rows, b.arena,
+                  (uint32_t*)(b.arena + b.off_row_progress), (uint32_t*)(b.arena + b.off_ticket) + 2, (int32_t*)(b.arena + b.off_status)};
+    launch_motion(ma, ps);
+    launch_mc(fa, n, b.max_w, b.max_h, b.wide, ps);
+    if (int rc = step("motion + mc")) return rc;
+  }
   if (!parse_only) launch_recon(ra, b.wide, ps);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[3], ps));
   if (int rc = step("recon")) return rc;

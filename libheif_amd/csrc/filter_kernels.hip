@@ -105,11 +105,11 @@ struct EdgeWindow {
 
 // luma edge segment of 4 lines (8.7.2.5.3 decisions, 8.7.2.5.7 filters); pix -> q0 of line 0.  DIR 0: vertical edge (lines are rows), 1: horizontal
 template <typename Pix, int DIR>
-__device__ __forceinline__ void deblock_luma(Pix* pix, int stride, int qp_p, int qp_q, int beta_off2, int tc_off2, int bit_depth, int no_p, int no_q)
+__device__ __forceinline__ void deblock_luma(Pix* pix, int stride, int qp_p, int qp_q, int beta_off2, int tc_off2, int bit_depth, int no_p, int no_q, int bs = 2)
 {
   const int qpl = (qp_q + qp_p + 1) >> 1;
   const int beta = c_beta[clip3(0, 51, qpl + (beta_off2 << 1))] * (1 << (bit_depth - 8));
-  const int tc = c_tc[clip3(0, 53, qpl + 2 + (tc_off2 << 1))] * (1 << (bit_depth - 8));
+  const int tc = c_tc[clip3(0, 53, qpl + 2 * (bs - 1) + (tc_off2 << 1))] * (1 << (bit_depth - 8));   // 8.7.2.5.3: bS 2 where a side is intra coded
   EdgeWindow<Pix, DIR> W;
   W.load(pix, stride);
 #define WP(k, i) W.get(k, 3 - (i))
@@ -249,12 +249,28 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
   const int no_q = (fq & keep) != 0, no_p = (fp & keep) != 0;
   const CtbInfo* ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
   const SliceParams sl = ((const SliceParams*)(A.arena + P.off_slices))[ctb_info[ctb_q].slice_idx];
+  int bs = 2;   // every edge of an intra picture
+  if (P.is_inter) {
+    // 8.7.2.4 in a P picture: 2 where a side is intra coded; else 1 at a transform block edge next to a block with luma coefficients, or where
+    // the two sides predict from different pictures / with vectors a sample or more apart; else no filtering.  (Transform blocks are aligned to
+    // their size, so the edge is a transform block edge iff the Q block starts there; prediction block edges were flagged by the parser.)
+    const MotionUnit* mf = (const MotionUnit*)(A.arena + P.off_mf);
+    const MotionUnit mq = mf[iq], mp = mf[ip];
+    if (mq.ref_idx >= 0 && mp.ref_idx >= 0) {
+      const int tbq = 1 << (A.arena[P.off_u_size + iq] & 15);
+      const bool tu_edge = ((DIR == 0 ? x : y) & (tbq - 1)) == 0;
+      if (tu_edge && ((fq | fp) & UF_CBF_LUMA)) bs = 1;
+      else if (mq.ref_slot != mp.ref_slot || iabs(mq.mv[0] - mp.mv[0]) >= 4 || iabs(mq.mv[1] - mp.mv[1]) >= 4) bs = 1;
+      else return;
+    }
+  }
   {
     Pix* rec = (Pix*)(A.arena + P.off_rec[0]);
     const int stride = P.rec_stride[0] / sizeof(Pix);
     Pix* pix = rec + (size_t)y * stride + x;
-    deblock_luma<Pix, DIR>(pix, stride, qp_p, qp_q, sl.beta_offset_div2, sl.tc_offset_div2, P.bit_depth_luma, no_p, no_q);
+    deblock_luma<Pix, DIR>(pix, stride, qp_p, qp_q, sl.beta_offset_div2, sl.tc_offset_div2, P.bit_depth_luma, no_p, no_q, bs);
   }
+  if (bs != 2) return;   // chroma edges are filtered where bS is 2 only (8.7.2.5)
   if (P.chroma_format_idc == 3) {
     // 4:4:4: the chroma planes have the luma planes' edges (the 8-sample chroma grid IS the luma grid) and take the chroma filter
     for (int c = 1; c < 3; c++) {

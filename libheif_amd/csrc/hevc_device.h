@@ -51,7 +51,42 @@ struct SliceParams {
   uint8_t sao_luma, sao_chroma;
   uint8_t lf_across_slices;                  // slice_loop_filter_across_slices_enabled_flag
   uint16_t slice_addr_rs;
+  // ---- P slices (sequence tracks); all 0 for an intra slice
+  uint8_t is_p;                              // slice_type == P
+  uint8_t num_ref_idx;                       // num_ref_idx_l0_active_minus1 + 1
+  uint8_t max_merge_cand;                    // MaxNumMergeCand
+  uint8_t init_type;                         // 9.3.2.2 initType: 0 (I), 1 or 2 (P: cabac_init_flag ? 2 : 1)
+  uint8_t ref_slot[16];                      // RefPicList0[i] as an index into the picture's RefFrame table (PicParams::off_reftab)
+  uint32_t pad_;
 };
+static_assert(sizeof(SliceParams) == 40, "SliceParams layout");
+
+// a reference picture of a P picture: absolute device pointers (the planes live in an EARLIER batch's arena: decoded, deblocked, SAO applied,
+// coded size), strides in bytes
+struct RefFrame {
+  uint64_t plane[3];
+  uint32_t stride[3];
+  int32_t poc;
+};
+static_assert(sizeof(RefFrame) == 40, "RefFrame layout");
+
+// motion of one 4x4 luma unit (the motion field k_motion writes; P slices: list 0 only)
+struct MotionUnit {
+  int16_t mv[2];       // quarter luma samples
+  int8_t ref_idx;      // refIdxL0, -1: the unit is intra coded
+  int8_t ref_slot;     // its picture as an index into the RefFrame table: equal slots <=> the same reference picture (8.7.2.4)
+  uint8_t pred;        // 0 MODE_INTRA, 1 MODE_INTER, 2 MODE_SKIP
+  uint8_t pad;
+};
+static_assert(sizeof(MotionUnit) == 8, "MotionUnit layout");
+
+// u_ipmc of a P picture: bits 0..5 IntraPredModeC (1 for units that are not intra coded), bit 6 the unit is inter coded, bit 7 it is skipped
+enum : uint8_t { UM_INTER = 64, UM_SKIP = 128 };
+
+// motion syntax of one prediction unit (the parser writes it at the unit index of the PU's top-left 4x4 unit; k_motion turns it into the motion
+// field): w0 = bit 0 merge_flag, bits 1..3 merge_idx, bits 4..7 ref_idx_l0, bit 8 mvp_l0_flag, bits 9..11 PartMode, bits 12..13 partIdx,
+// bit 15 valid; w1 = mvd_x (int16) | mvd_y (int16) << 16
+struct MotionSyntax { uint32_t w0, w1; };
 
 struct SaoParams {   // per CTB and colour component
   uint8_t type;      // 0 off, 1 band, 2 edge
@@ -97,6 +132,15 @@ struct PicParams {
   uint32_t out_stride[3];         // bytes
   uint32_t first_row;             // index of this picture's first CTB row in the batch row table
   uint32_t num_slices;
+  // ---- P pictures (0 / unused for an intra picture)
+  uint8_t is_inter;               // the picture has P slices: motion syntax / motion field are allocated, k_motion and k_mc run
+  uint8_t amp_enabled, max_th_depth_inter, log2_par_mrg_level;
+  int32_t poc;                    // PicOrderCntVal
+  uint32_t num_refs;              // entries of the RefFrame table
+  uint32_t pad_inter;
+  uint64_t off_reftab;            // RefFrame[16]
+  uint64_t off_msyn;              // MotionSyntax[ctbs * units_per_ctb]
+  uint64_t off_mf;                // MotionUnit[ctbs * units_per_ctb]
 };
 
 struct CtbInfo {
@@ -170,6 +214,7 @@ struct ParseArgs {
   uint32_t yield_ctbs;   // test knob (0 = off): a row yields after this many CTBs per activation
   uint32_t wake_hyst;    // a parked row is woken when its predecessor is this many CTBs beyond the minimum distance
   uint32_t general_chroma;   // 1: the batch holds a 4:2:2 or 4:4:4 picture (the parser build with the ChromaArrayType 2 / 3 paths is launched)
+  uint32_t inter;            // 1: the batch holds a P picture (the parser build with the inter syntax is launched)
 };
 
 }  // namespace hipdec

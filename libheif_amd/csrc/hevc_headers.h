@@ -18,6 +18,24 @@ struct ScalingLists {
 };
 void scaling_lists_default(ScalingLists& sl);   // Table 7-5 (flat 16) and Table 7-6
 
+// one short_term_ref_pic_set() (7.3.7, 7.4.8): DeltaPocS0 / S1 with their used_by_curr_pic flags
+struct StRps {
+  int num_neg = 0, num_pos = 0;
+  int delta_s0[16] = {0}, delta_s1[16] = {0};
+  bool used_s0[16] = {false}, used_s1[16] = {false};
+};
+
+// A decoded picture a later P picture may reference: device pointers of its planes (coded size, deblocked, SAO applied), strides in bytes
+struct RefPicture { int poc = 0; uint64_t plane[3] = {0, 0, 0}; uint32_t stride[3] = {0, 0, 0}; };
+
+// What a decoder instance keeps between the samples of a sequence track (libheif/sequences/track_visual.cc:200-280 pushes them one by one):
+// the picture order count state (8.3.1) and the decoded picture buffer.  nullptr where a single still is decoded: P slices are refused then.
+struct SeqContext {
+  bool first_picture = true;
+  int prev_tid0_lsb = 0, prev_tid0_msb = 0;
+  std::vector<RefPicture> dpb;
+};
+
 struct Sps {
   bool valid = false;
   int chroma_format_idc = 1, pic_width = 0, pic_height = 0;
@@ -30,7 +48,7 @@ struct Sps {
   bool pcm_loop_filter_disabled = false;
   bool long_term_ref_pics_present = false, temporal_mvp = false, separate_colour_plane = false;
   int num_short_term_ref_pic_sets = 0, num_long_term_ref_pics_sps = 0;
-  std::vector<int> rps_num_delta_pocs;  // NumDeltaPocs per short-term RPS (needed to skip slice-level RPS)
+  std::vector<StRps> st_rps;            // the short-term reference picture sets of the SPS
   int colour_primaries = 2, transfer_characteristics = 2, matrix_coeffs = 2, full_range = 0;
   ScalingLists sl{};   // valid when scaling_list_enabled (explicit lists or the defaults)
 };
@@ -46,6 +64,8 @@ struct Pps {
   bool slice_header_extension_present = false;
   int num_extra_slice_header_bits = 0, init_qp = 26, diff_cu_qp_delta_depth = 0;
   int cb_qp_offset = 0, cr_qp_offset = 0, beta_offset_div2 = 0, tc_offset_div2 = 0;
+  int num_ref_idx_l0_default = 1, log2_par_mrg_level = 2;
+  bool weighted_pred = false, lists_modification_present = false;
   int tile_cols = 1, tile_rows = 1;
   std::vector<int> col_width, row_height;  // explicit sizes when !uniform_spacing
   ScalingLists sl{};   // valid when scaling_list_data_present
@@ -58,6 +78,7 @@ struct ParsedSlice {
   size_t data_offset = 0;  // offset in the pushed blob of the first slice_segment_data byte
   size_t nal_end = 0;      // offset one past the slice NAL
   std::vector<uint32_t> entry_point_offsets;  // bytes, escaped domain
+  int ref_poc[16] = {0};   // P slice: PicOrderCntVal of RefPicList0[i] (sp.ref_slot is filled once the picture's reference table is known)
 };
 
 struct ParsedPicture {
@@ -73,9 +94,19 @@ struct ParsedPicture {
   // ScalingFactor m[y][x] of the intra matrices, expanded (8.6.4.2 / 7.4.5): per component c the 4x4 (16 B), 8x8 (64 B) and
   // 16x16 (256 B) factors at c * 336, then the luma 32x32 factors (1024 B) at 1008; empty when scaling lists are off
   std::vector<uint8_t> scaling_tables;
+  // ---- sequences: picture order count, the pictures its reference picture set keeps (8.3.2), the ones its P slices predict from
+  int poc = 0, poc_lsb = 0, nal_type = 0;
+  bool is_inter = false;                // some slice is a P slice
+  bool is_idr = false;
+  std::vector<int> keep_pocs;           // every picture of the RPS (the DPB drops the others once this picture is decoded)
+  std::vector<RefPicture> refs;         // the reference table of the picture (slots of SliceParams::ref_slot), at most 16
 };
 
 // Parses one coded picture from libheif's plugin framing.  Returns a hipdec_status.
-int parse_picture(const uint8_t* blob, size_t size, uint64_t max_image_size_pixels, ParsedPicture& out, std::string& err);
+// `seq`: the sequence state of the decoder instance the item belongs to (read for the POC and the reference pictures; the caller commits
+// the new POC state / DPB after a successful decode with seq_commit), or nullptr (a still: a P slice is HIPDEC_ERR_UNSUPPORTED).
+int parse_picture(const uint8_t* blob, size_t size, uint64_t max_image_size_pixels, ParsedPicture& out, std::string& err, const SeqContext* seq = nullptr);
+// after the picture was decoded: POC state, the DPB pruned to the picture's RPS; the caller appends the decoded picture itself
+void seq_commit(SeqContext& seq, const ParsedPicture& pic, int nal_type_hint_unused = 0);
 
 }  // namespace hipdec

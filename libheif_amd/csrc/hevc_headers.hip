@@ -214,28 +214,43 @@ void build_scaling_tables(const ScalingLists& sl, bool chroma444, std::vector<ui
     }
 }
 
-int parse_short_term_rps(NalReader& r, int idx, int num_sets, const std::vector<int>& num_delta_pocs)
+// short_term_ref_pic_set(idx) (7.3.7) with the derivation of 7.4.8 (7-61), (7-62) for inter-predicted sets.  `sets`: the sets parsed so far
+// (the SPS's; a slice header parses set num_sets from them)
+StRps parse_short_term_rps(NalReader& r, int idx, int num_sets, const std::vector<StRps>& sets)
 {
-  bool inter = idx != 0 ? r.u(1) : false;
+  StRps out;
+  const bool inter = idx != 0 ? r.u(1) : false;
   if (inter) {
-    int delta_idx_minus1 = idx == num_sets ? r.ue_max(63, "delta_idx_minus1") : 0;
-    int ref = idx - (delta_idx_minus1 + 1);
-    if (ref < 0 || ref >= (int)num_delta_pocs.size()) bad("short-term RPS refers to a missing set");
-    r.u(1); r.ue();
-    int n = 0;
-    for (int j = 0; j <= num_delta_pocs[ref]; j++) {
-      bool used = r.u(1), use_delta = true;
-      if (!used) use_delta = r.u(1);
-      if (used || use_delta) n++;
-    }
-    // NumDeltaPocs of an inter-predicted set is at most the count of kept entries; the exact value
-    // only matters for further inter RPS prediction from this set, where an upper bound would
-    // desynchronise the parse — so reject streams that chain inter RPS prediction.
-    return -n - 1;
+    const int delta_idx_minus1 = idx == num_sets ? r.ue_max(63, "delta_idx_minus1") : 0;
+    const int ref_idx = idx - (delta_idx_minus1 + 1);
+    if (ref_idx < 0 || ref_idx >= (int)sets.size()) bad("short-term RPS refers to a missing set");
+    const StRps& ref = sets[(size_t)ref_idx];
+    const int sign = r.u(1);
+    const int delta_rps = (1 - 2 * sign) * (r.ue_max(32767, "abs_delta_rps_minus1") + 1);
+    const int n_ref = ref.num_neg + ref.num_pos;
+    bool used[33], use_delta[33];
+    for (int j = 0; j <= n_ref; j++) { used[j] = r.u(1); use_delta[j] = true; if (!used[j]) use_delta[j] = r.u(1); }
+    int i = 0;
+    auto push0 = [&](int d, bool u) { if (i >= 16) bad("short-term RPS holds more than 16 pictures"); out.delta_s0[i] = d; out.used_s0[i] = u; i++; };
+    for (int j = ref.num_pos - 1; j >= 0; j--) { const int d = ref.delta_s1[j] + delta_rps; if (d < 0 && use_delta[ref.num_neg + j]) push0(d, used[ref.num_neg + j]); }
+    if (delta_rps < 0 && use_delta[n_ref]) push0(delta_rps, used[n_ref]);
+    for (int j = 0; j < ref.num_neg; j++) { const int d = ref.delta_s0[j] + delta_rps; if (d < 0 && use_delta[j]) push0(d, used[j]); }
+    out.num_neg = i;
+    i = 0;
+    auto push1 = [&](int d, bool u) { if (i >= 16) bad("short-term RPS holds more than 16 pictures"); out.delta_s1[i] = d; out.used_s1[i] = u; i++; };
+    for (int j = ref.num_neg - 1; j >= 0; j--) { const int d = ref.delta_s0[j] + delta_rps; if (d > 0 && use_delta[j]) push1(d, used[j]); }
+    if (delta_rps > 0 && use_delta[n_ref]) push1(delta_rps, used[n_ref]);
+    for (int j = 0; j < ref.num_pos; j++) { const int d = ref.delta_s1[j] + delta_rps; if (d > 0 && use_delta[ref.num_neg + j]) push1(d, used[ref.num_neg + j]); }
+    out.num_pos = i;
+  } else {
+    out.num_neg = r.ue_max(16, "num_negative_pics"); out.num_pos = r.ue_max(16, "num_positive_pics");
+    int poc = 0;
+    for (int i = 0; i < out.num_neg; i++) { poc -= r.ue_max(32767, "delta_poc_s0_minus1") + 1; out.delta_s0[i] = poc; out.used_s0[i] = r.u(1); }
+    poc = 0;
+    for (int i = 0; i < out.num_pos; i++) { poc += r.ue_max(32767, "delta_poc_s1_minus1") + 1; out.delta_s1[i] = poc; out.used_s1[i] = r.u(1); }
   }
-  int nn = r.ue_max(16, "num_negative_pics"), np = r.ue_max(16, "num_positive_pics");
-  for (int i = 0; i < nn + np; i++) { r.ue(); r.u(1); }
-  return nn + np;
+  if (out.num_neg + out.num_pos > 16) bad("short-term RPS holds more than 16 pictures");
+  return out;
 }
 
 void parse_sps(NalReader& r, Sps& s)
@@ -284,16 +299,8 @@ void parse_sps(NalReader& r, Sps& s)
     s.pcm_loop_filter_disabled = r.u(1) != 0;
   }
   s.num_short_term_ref_pic_sets = r.ue_max(64, "num_short_term_ref_pic_sets");
-  s.rps_num_delta_pocs.clear();
-  for (int i = 0; i < s.num_short_term_ref_pic_sets; i++) {
-    int n = parse_short_term_rps(r, i, s.num_short_term_ref_pic_sets, s.rps_num_delta_pocs);
-    if (n < 0) {
-      // inter-predicted set: its exact NumDeltaPocs needs the full derivation of 7.4.8; an intra-only
-      // still never uses it unless a later set predicts from it
-      n = -n - 1;
-    }
-    s.rps_num_delta_pocs.push_back(n);
-  }
+  s.st_rps.clear();
+  for (int i = 0; i < s.num_short_term_ref_pic_sets; i++) s.st_rps.push_back(parse_short_term_rps(r, i, s.num_short_term_ref_pic_sets, s.st_rps));
   s.long_term_ref_pics_present = r.u(1);
   if (s.long_term_ref_pics_present) {
     s.num_long_term_ref_pics_sps = r.ue_max(32, "num_long_term_ref_pics_sps");
@@ -355,7 +362,7 @@ void parse_pps(NalReader& r, Pps& p)
   p.num_extra_slice_header_bits = r.u(3);
   p.sign_data_hiding = r.u(1);
   p.cabac_init_present = r.u(1);
-  r.ue_max(14, "num_ref_idx_l0_default_active_minus1"); r.ue_max(14, "num_ref_idx_l1_default_active_minus1");
+  p.num_ref_idx_l0_default = r.ue_max(14, "num_ref_idx_l0_default_active_minus1") + 1; r.ue_max(14, "num_ref_idx_l1_default_active_minus1");
   p.init_qp = 26 + r.se_range(-(26 + 6 * 8), 25, "init_qp_minus26");
   p.constrained_intra_pred = r.u(1);
   p.transform_skip = r.u(1);
@@ -364,7 +371,7 @@ void parse_pps(NalReader& r, Pps& p)
   p.cb_qp_offset = r.se_range(-12, 12, "pps_cb_qp_offset");
   p.cr_qp_offset = r.se_range(-12, 12, "pps_cr_qp_offset");
   p.slice_chroma_qp_offsets_present = r.u(1);
-  r.skip(2);
+  p.weighted_pred = r.u(1); r.skip(1);   // weighted_pred_flag, weighted_bipred_flag
   p.transquant_bypass = r.u(1);
   p.tiles = r.u(1);
   p.wpp = r.u(1);
@@ -387,8 +394,8 @@ void parse_pps(NalReader& r, Pps& p)
   }
   p.scaling_list_data_present = r.u(1);
   if (p.scaling_list_data_present) { scaling_lists_default(p.sl); parse_scaling_list_data(r, p.sl); }
-  r.skip(1);
-  r.ue();
+  p.lists_modification_present = r.u(1);
+  p.log2_par_mrg_level = r.ue_max(4, "log2_parallel_merge_level_minus2") + 2;
   p.slice_header_extension_present = r.u(1);
   if (r.u(1)) {
     bool range_ext = r.u(1);
@@ -462,7 +469,7 @@ void scaling_lists_default(ScalingLists& sl)
   }
 }
 
-int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedPicture& out, std::string& err)
+int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedPicture& out, std::string& err, const SeqContext* seq)
 {
   try {
     Sps sps_tab[16];
@@ -472,6 +479,9 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
     int ctb_w = 0, ctb_h = 0, n_ctb = 0;
     std::vector<int> ctb_slice;       // slice index per CTB (raster), -1 = not covered
     std::vector<int> ctb_slice_addr;  // SliceAddrRs per CTB
+    StRps pic_rps;                     // the RPS of the picture (every slice segment header repeats it)
+    int pic_poc_lsb = 0, pic_nal_type = 0;
+    out.is_inter = false; out.refs.clear(); out.keep_pocs.clear();
     size_t ptr = 0;
     while (ptr < size) {
       if (size - ptr < 4) { err = "truncated NAL length field"; return HIPDEC_ERR_END_OF_DATA; }
@@ -538,27 +548,98 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
           sl.dependent = true;
         } else {
         r.skip(P.num_extra_slice_header_bits);
-        unsigned slice_type = r.ue();
-        if (slice_type != 2) unsupported("non-intra slice (slice_type " + std::to_string(slice_type) + ")");
+        const unsigned slice_type = r.ue_max(2, "slice_type");
+        if (slice_type == 0) unsupported("B slices");
+        if (slice_type == 1 && !seq) unsupported("non-intra slice (slice_type 1) outside a sequence");
         if (P.output_flag_present) r.skip(1);
         if (S.separate_colour_plane) r.skip(2);
-        if (type != 19 && type != 20) {
-          r.skip(S.log2_max_poc_lsb);
-          bool st_sps = r.u(1);
-          if (!st_sps) parse_short_term_rps(r, S.num_short_term_ref_pic_sets, S.num_short_term_ref_pic_sets, S.rps_num_delta_pocs);
-          else if (S.num_short_term_ref_pic_sets > 1) r.skip(ceil_log2(S.num_short_term_ref_pic_sets));
+        int poc_lsb = 0;
+        bool slice_tmvp = false;
+        StRps rps;
+        const bool idr = type == 19 || type == 20;
+        if (!idr) {
+          poc_lsb = (int)r.u(S.log2_max_poc_lsb);
+          const bool st_sps = r.u(1);
+          if (!st_sps) rps = parse_short_term_rps(r, S.num_short_term_ref_pic_sets, S.num_short_term_ref_pic_sets, S.st_rps);
+          else {
+            if (S.num_short_term_ref_pic_sets == 0) bad("short_term_ref_pic_set_sps_flag without a set in the SPS");
+            const int idx = S.num_short_term_ref_pic_sets > 1 ? (int)r.u(ceil_log2(S.num_short_term_ref_pic_sets)) : 0;
+            if (idx >= S.num_short_term_ref_pic_sets) bad("short_term_ref_pic_set_idx out of range");
+            rps = S.st_rps[(size_t)idx];
+          }
           if (S.long_term_ref_pics_present) {
             int lt_sps = S.num_long_term_ref_pics_sps > 0 ? r.ue_max(32, "num_long_term_sps") : 0;
             int lt_pics = r.ue_max(32, "num_long_term_pics");
+            if (seq && lt_sps + lt_pics > 0) unsupported("long-term reference pictures");
             for (int i = 0; i < lt_sps + lt_pics; i++) {
               if (i < lt_sps) { if (S.num_long_term_ref_pics_sps > 1) r.skip(ceil_log2(S.num_long_term_ref_pics_sps)); }
               else { r.skip(S.log2_max_poc_lsb); r.skip(1); }
               if (r.u(1)) r.ue();
             }
           }
-          if (S.temporal_mvp) r.skip(1);
+          if (S.temporal_mvp) slice_tmvp = r.u(1);
+        }
+        if (first) {   // 8.3.1 picture order count, 8.3.2: the pictures the RPS names (sequence mode)
+          out.is_idr = idr;
+          out.poc = 0;
+          out.keep_pocs.clear();
+          if (seq) {
+            const bool irap = type >= 16 && type <= 23;
+            if (idr || (irap && seq->first_picture)) out.poc = idr ? 0 : poc_lsb;
+            else {
+              const int max_lsb = 1 << S.log2_max_poc_lsb;
+              int msb = seq->prev_tid0_msb;
+              if (poc_lsb < seq->prev_tid0_lsb && seq->prev_tid0_lsb - poc_lsb >= max_lsb / 2) msb += max_lsb;
+              else if (poc_lsb > seq->prev_tid0_lsb && poc_lsb - seq->prev_tid0_lsb > max_lsb / 2) msb -= max_lsb;
+              out.poc = msb + poc_lsb;
+            }
+            pic_poc_lsb = poc_lsb; pic_nal_type = type;
+            if (!idr) {
+              for (int i = 0; i < rps.num_neg; i++) out.keep_pocs.push_back(out.poc + rps.delta_s0[i]);
+              for (int i = 0; i < rps.num_pos; i++) out.keep_pocs.push_back(out.poc + rps.delta_s1[i]);
+            }
+          }
+          pic_rps = rps;
         }
         if (S.sao) { sl.sp.sao_luma = r.u(1); if (S.chroma_format_idc) sl.sp.sao_chroma = r.u(1); }
+        if (slice_type == 1) {   // 7.3.6.1, P slice
+          if (S.chroma_format_idc > 1) unsupported("P slices of a 4:2:2 / 4:4:4 picture");
+          if (S.scaling_list_enabled) unsupported("P slices with scaling lists");
+          if (P.constrained_intra_pred) unsupported("constrained_intra_pred_flag with P slices");
+          if (P.weighted_pred) unsupported("weighted prediction");
+          if (slice_tmvp) unsupported("temporal motion vector prediction");
+          int num_ref = P.num_ref_idx_l0_default;
+          if (r.u(1)) num_ref = r.ue_max(14, "num_ref_idx_l0_active_minus1") + 1;   // num_ref_idx_active_override_flag
+          // RefPicSetStCurrBefore / After of the PICTURE's RPS (8.3.2), then RefPicListTemp0 (8.3.4)
+          std::vector<int> cur;
+          for (int i = 0; i < pic_rps.num_neg; i++) if (pic_rps.used_s0[i]) cur.push_back(out.poc + pic_rps.delta_s0[i]);
+          for (int i = 0; i < pic_rps.num_pos; i++) if (pic_rps.used_s1[i]) cur.push_back(out.poc + pic_rps.delta_s1[i]);
+          const int total = (int)cur.size();
+          if (total == 0) bad("P slice without a reference picture");
+          for (int poc : cur) {
+            bool have = false;
+            for (const RefPicture& rp : seq->dpb) if (rp.poc == poc) have = true;
+            if (!have) bad("reference picture with POC " + std::to_string(poc) + " is missing");
+          }
+          int entries[16];
+          bool modified = false;
+          if (P.lists_modification_present && total > 1) {
+            modified = r.u(1);
+            if (modified) for (int i = 0; i < num_ref; i++) { entries[i] = (int)r.u(ceil_log2(total)); }
+          }
+          const int want = num_ref > total ? num_ref : total;
+          for (int i = 0; i < num_ref; i++) {
+            const int e = modified ? entries[i] : i;
+            if (e < 0 || e >= want) bad("list_entry_l0 out of range");
+            sl.ref_poc[i] = cur[(size_t)(e % total)];
+          }
+          bool cabac_init_flag = false;
+          if (P.cabac_init_present) cabac_init_flag = r.u(1);
+          const int max_merge = 5 - r.ue_max(4, "five_minus_max_num_merge_cand");
+          sl.sp.is_p = 1; sl.sp.num_ref_idx = (uint8_t)num_ref; sl.sp.max_merge_cand = (uint8_t)max_merge;
+          sl.sp.init_type = cabac_init_flag ? 2 : 1;
+          out.is_inter = true;
+        }
         int slice_qp_delta = r.se_range(-128, 128, "slice_qp_delta");
         int s_cb = 0, s_cr = 0;
         if (P.slice_chroma_qp_offsets_present) { s_cb = r.se_range(-12, 12, "slice_cb_qp_offset"); s_cr = r.se_range(-12, 12, "slice_cr_qp_offset"); }
@@ -604,6 +685,23 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
       // VPS / AUD / SEI / EOS: nothing to do for an intra still
     }
     if (!have_picture) { err = "no coded picture in the pushed data"; return HIPDEC_ERR_NO_IMAGE; }
+    out.poc_lsb = pic_poc_lsb; out.nal_type = pic_nal_type;
+    if (out.is_inter) {   // the picture's reference table: every picture some P slice lists, once; SliceParams::ref_slot indexes it
+      for (ParsedSlice& sl : out.slices) {
+        if (!sl.sp.is_p) continue;
+        for (int i = 0; i < sl.sp.num_ref_idx; i++) {
+          int slot = -1;
+          for (size_t k = 0; k < out.refs.size(); k++) if (out.refs[k].poc == sl.ref_poc[i]) slot = (int)k;
+          if (slot < 0) {
+            for (const RefPicture& rp : seq->dpb) if (rp.poc == sl.ref_poc[i]) { out.refs.push_back(rp); slot = (int)out.refs.size() - 1; break; }
+          }
+          if (slot < 0 || slot > 15) bad("reference picture table overflow");
+          sl.sp.ref_slot[i] = (uint8_t)slot;
+        }
+      }
+      // a dependent slice segment carries its slice's fields: refresh the copies made before the slots were known
+      for (size_t si = 1; si < out.slices.size(); si++) if (out.slices[si].dependent) { const uint16_t a = out.slices[si].sp.slice_addr_rs; out.slices[si].sp = out.slices[si - 1].sp; out.slices[si].sp.slice_addr_rs = a; }
+    }
 
     const Sps& S = out.sps; const Pps& P = out.pps;
     // ---- substreams: one CABAC engine start each (slice segment / tile / WPP row) ----
@@ -757,6 +855,23 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
     err = std::string("bitstream header parsing failed: ") + e.what();
     return HIPDEC_ERR_BITSTREAM;
   }
+}
+
+// The picture was decoded: its POC becomes prevTid0Pic's where 8.3.1 says so, and the DPB drops every picture its reference picture set does
+// not name (8.3.2; an IDR picture names none).  The caller appends the decoded picture itself.
+void seq_commit(SeqContext& seq, const ParsedPicture& pic, int)
+{
+  const bool irap = pic.nal_type >= 16 && pic.nal_type <= 23;
+  if (pic.is_idr || (irap && seq.first_picture)) { seq.prev_tid0_lsb = pic.is_idr ? 0 : pic.poc_lsb; seq.prev_tid0_msb = 0; }
+  else if (irap || (pic.nal_type <= 9 && (pic.nal_type & 1))) { seq.prev_tid0_lsb = pic.poc_lsb; seq.prev_tid0_msb = pic.poc - pic.poc_lsb; }
+  seq.first_picture = false;
+  std::vector<RefPicture> kept;
+  for (const RefPicture& rp : seq.dpb) {
+    bool keep = false;
+    for (int poc : pic.keep_pocs) if (poc == rp.poc) keep = true;
+    if (keep) kept.push_back(rp);
+  }
+  seq.dpb.swap(kept);
 }
 
 }  // namespace hipdec

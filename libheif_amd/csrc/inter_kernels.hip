@@ -1,0 +1,408 @@
+// inter_kernels.hip — P pictures of sequence tracks: motion vector derivation and motion-compensated prediction.
+//
+// Stands in for libde265's inter decoding behind de265_decode() for the samples libheif pushes one by one for a track
+// (libheif/sequences/track_visual.cc:200-280; libheif/plugins/decoder_libde265.cc:360, :417-419).  ITU-T H.265 6.4.2 (prediction block
+// availability), 8.5.3.2.2 - 8.5.3.2.5 (merge mode: spatial and zero candidates), 8.5.3.2.6 - 8.5.3.2.8 (motion vector prediction: spatial
+// candidates with scaling), 8.5.3.3.3 (fractional sample interpolation), 8.5.3.3.4.2 (default weighted prediction, list 0 only).
+// Scope as the host front end enforces it: P slices, short-term reference pictures, no temporal candidates, 4:0:0 / 4:2:0.
+//
+// MI355X mapping
+//   * the entropy decoder (parse_core.h, HIPDEC_PARSE_INTER build) only PARSES prediction units into MotionSyntax records: HEVC keeps parsing free
+//     of the neighbours' motion.  k_motion turns them into the picture's motion field in decoding order.  A candidate list reads the left,
+//     above, above-left and above-RIGHT neighbours, so the parallelism is the 2-CTB-lag wavefront over CTB rows - one wave per CTB row, rows
+//     handed out by ticket so that a row's predecessor is resident or finished, progress published per CTB (release) and awaited (acquire).
+//     Inside a CTB the derivation is a serial chain over prediction units (lane 0); the 64 lanes write each unit's motion to its 4x4 units.
+//     The CTB being derived lives in LDS (2 KB); finished CTBs are read from the motion field in HBM (8 B per unit, 0.5 B per pixel).
+//   * k_mc is embarrassingly parallel once the motion field exists: one thread per sample of each plane, taps gathered from the reference
+//     picture (coordinates clamped to the picture: the padding of 8.5.3.3.3.1), separable 8-tap (luma) / 4-tap (chroma) filters with the
+//     intermediate precision of the specification, written to the reconstruction plane where k_recon adds the residual.  HBM-bound in
+//     principle (1.5 s in + 1.5 s out per pixel with cache-resident taps); sequences are not the benchmarked path.
+#include <hip/hip_runtime.h>
+#include "hevc_device.h"
+#include "kernels.h"
+
+namespace hipdec {
+
+namespace {
+
+__device__ __forceinline__ uint32_t mk_compact(uint32_t v)
+{
+  v &= 0x55555555u; v = (v | (v >> 1)) & 0x33333333u; v = (v | (v >> 2)) & 0x0f0f0f0fu; v = (v | (v >> 4)) & 0x00ff00ffu;
+  return v;
+}
+__device__ __forceinline__ uint32_t mk_interleave(uint32_t x, uint32_t y)   // z-index of unit (x, y), x, y < 16
+{
+  x = (x | (x << 2)) & 0x33; x = (x | (x << 1)) & 0x55;
+  y = (y | (y << 2)) & 0x33; y = (y | (y << 1)) & 0x55;
+  return x | (y << 1);
+}
+__device__ __forceinline__ int mk_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int mk_abs(int v) { return v < 0 ? -v : v; }
+
+__device__ __forceinline__ void mk_lds_sync()
+{
+#ifndef HIPDEC_HOST_EMU
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+  __builtin_amdgcn_wave_barrier();
+}
+
+struct Mv { int x, y, ref_idx; };   // P slices: predFlagL0 = 1 for every block that is not intra coded
+
+// everything the derivation of one CTB needs (lane 0 only)
+struct MotionCtx {
+  const PicParams* P;
+  const RefFrame* reftab;
+  const SliceParams* slice;
+  const MotionUnit* field;      // the picture's motion field in HBM
+  const MotionUnit* cur;        // the current CTB's units (LDS)
+  int cx, cy, avail;            // CTB position, AV_* bits
+  int log2_ctb, units_log2, lmt, ctb_w, width, height;
+  int poc, par_mrg;
+};
+
+// the motion of the 4x4 unit that covers luma sample (x, y); the caller has checked availability
+__device__ __forceinline__ MotionUnit unit_at(const MotionCtx& C, int x, int y)
+{
+  const int ncx = x >> C.log2_ctb, ncy = y >> C.log2_ctb;
+  const uint32_t z = mk_interleave((uint32_t)((x >> 2) & ((1 << (C.log2_ctb - 2)) - 1)), (uint32_t)((y >> 2) & ((1 << (C.log2_ctb - 2)) - 1)));
+  if (ncx == C.cx && ncy == C.cy) return C.cur[z];
+  return C.field[((size_t)(ncy * C.ctb_w + ncx) << C.units_log2) + z];
+}
+
+// 6.4.1 z-scan order availability of (xN, yN) seen from (xC, yC) of the current CTB: inside the picture, decoded earlier, same slice, same tile
+__device__ __forceinline__ int avail_z(const MotionCtx& C, int xC, int yC, int xN, int yN)
+{
+  if (xN < 0 || yN < 0 || xN >= C.width || yN >= C.height) return 0;
+  const int dx = (xN >> C.log2_ctb) - C.cx, dy = (yN >> C.log2_ctb) - C.cy;
+  if (dx == 0 && dy == 0) {   // same CTB: order of the minimum transform blocks in z-scan
+    const int m = (1 << (C.log2_ctb - C.lmt)) - 1;
+    const uint32_t zn = mk_interleave((uint32_t)((xN >> C.lmt) & m), (uint32_t)((yN >> C.lmt) & m));
+    const uint32_t zc = mk_interleave((uint32_t)((xC >> C.lmt) & m), (uint32_t)((yC >> C.lmt) & m));
+    return zn <= zc;
+  }
+  if (dx == -1 && dy == 0) return (C.avail & AV_LEFT) != 0;
+  if (dx == 0 && dy == -1) return (C.avail & AV_UP) != 0;
+  if (dx == 1 && dy == -1) return (C.avail & AV_UPRIGHT) != 0;
+  if (dx == -1 && dy == -1) return (C.avail & AV_UPLEFT) != 0;
+  return 0;   // to the right of / below the current CTB: decoded later
+}
+
+struct PbGeom { int xCb, yCb, nCbS, xPb, yPb, nPbW, nPbH, partIdx; };
+
+// 6.4.2 prediction block availability; *out = the neighbour's motion when it is available (and not intra coded)
+__device__ __forceinline__ int pb_available(const MotionCtx& C, const PbGeom& g, int xN, int yN, MotionUnit* out)
+{
+  const int same_cb = g.xCb <= xN && g.yCb <= yN && g.xCb + g.nCbS > xN && g.yCb + g.nCbS > yN;
+  int av;
+  if (!same_cb) av = avail_z(C, g.xPb, g.yPb, xN, yN);
+  else if ((g.nPbW << 1) == g.nCbS && (g.nPbH << 1) == g.nCbS && g.partIdx == 1 && g.yCb + g.nPbH <= yN && g.xCb + g.nPbW > xN) av = 0;
+  else av = 1;
+  if (!av) return 0;
+  const MotionUnit m = unit_at(C, xN, yN);
+  if (m.ref_idx < 0) return 0;   // MODE_INTRA
+  *out = m;
+  return 1;
+}
+
+__device__ __forceinline__ int same_motion(const MotionUnit& a, const MotionUnit& b) { return a.mv[0] == b.mv[0] && a.mv[1] == b.mv[1] && a.ref_idx == b.ref_idx; }
+
+// 8.5.3.2.2 - 8.5.3.2.5: merge candidate merge_idx (spatial candidates A1, B1, B0, A0, B2, then zero candidates)
+__device__ __forceinline__ Mv derive_merge(const MotionCtx& C, PbGeom g, int part_mode, int merge_idx)
+{
+  const int pl = C.par_mrg;
+  if (pl > 2 && g.nCbS == 8) { g.xPb = g.xCb; g.yPb = g.yCb; g.nPbW = g.nPbH = g.nCbS; g.partIdx = 0; part_mode = 0; }   // singleMCLFlag
+  const int xPb = g.xPb, yPb = g.yPb, nPbW = g.nPbW, nPbH = g.nPbH;
+  const int max_cand = C.slice->max_merge_cand;
+#define MK_SAME_MER(xn, yn) ((xPb >> pl) == ((xn) >> pl) && (yPb >> pl) == ((yn) >> pl))
+  MotionUnit cand[5];
+  int n = 0;
+  MotionUnit A1{}, B1{}, B0{}, A0{}, B2{};
+  // availableN: 6.4.2 minus the merge-estimation-region / second-partition exclusions; flagN: after pruning.  Comparisons read availableN of the other
+  // candidate, not its flag; only B2's "all four present" rule counts flags (8.5.3.2.3)
+  int avA1 = pb_available(C, g, xPb - 1, yPb + nPbH - 1, &A1);
+  if (MK_SAME_MER(xPb - 1, yPb + nPbH - 1) || (g.partIdx == 1 && (part_mode == 2 || part_mode == 6 || part_mode == 7))) avA1 = 0;   // Nx2N, nLx2N, nRx2N
+  const int fA1 = avA1;
+  if (fA1) cand[n++] = A1;
+  int avB1 = pb_available(C, g, xPb + nPbW - 1, yPb - 1, &B1);
+  if (MK_SAME_MER(xPb + nPbW - 1, yPb - 1) || (g.partIdx == 1 && (part_mode == 1 || part_mode == 4 || part_mode == 5))) avB1 = 0;   // 2NxN, 2NxnU, 2NxnD
+  const int fB1 = avB1 && !(avA1 && same_motion(A1, B1));
+  if (fB1) cand[n++] = B1;
+  int avB0 = pb_available(C, g, xPb + nPbW, yPb - 1, &B0);
+  if (MK_SAME_MER(xPb + nPbW, yPb - 1)) avB0 = 0;
+  const int fB0 = avB0 && !(avB1 && same_motion(B1, B0));
+  if (fB0) cand[n++] = B0;
+  int avA0 = pb_available(C, g, xPb - 1, yPb + nPbH, &A0);
+  if (MK_SAME_MER(xPb - 1, yPb + nPbH)) avA0 = 0;
+  const int fA0 = avA0 && !(avA1 && same_motion(A1, A0));
+  if (fA0) cand[n++] = A0;
+  int avB2 = pb_available(C, g, xPb - 1, yPb - 1, &B2);
+  if (MK_SAME_MER(xPb - 1, yPb - 1)) avB2 = 0;
+  const int fB2 = avB2 && !(avA1 && same_motion(A1, B2)) && !(avB1 && same_motion(B1, B2)) && fA0 + fA1 + fB0 + fB1 != 4;
+  if (fB2 && n < 5) cand[n++] = B2;
+#undef MK_SAME_MER
+  if (n > max_cand) n = max_cand;
+  Mv out;
+  if (merge_idx < n) { out.x = cand[merge_idx].mv[0]; out.y = cand[merge_idx].mv[1]; out.ref_idx = cand[merge_idx].ref_idx; }
+  else {   // zero candidates: refIdxL0 = zeroIdx while it is below the number of reference indices, then 0
+    const int zero_idx = merge_idx - n;
+    out.x = 0; out.y = 0; out.ref_idx = zero_idx < (int)C.slice->num_ref_idx ? zero_idx : 0;
+  }
+  return out;
+}
+
+__device__ __forceinline__ void scale_mv(int* mv, int td, int tb)
+{
+  td = mk_clip3(-128, 127, td); tb = mk_clip3(-128, 127, tb);
+  const int tx = (16384 + (mk_abs(td) >> 1)) / td;
+  const int dsf = mk_clip3(-4096, 4095, (tb * tx + 32) >> 6);
+  for (int k = 0; k < 2; k++) {
+    const int v = dsf * mv[k];
+    mv[k] = mk_clip3(-32768, 32767, (v < 0 ? -1 : 1) * ((mk_abs(v) + 127) >> 8));
+  }
+}
+
+// 8.5.3.2.6 - 8.5.3.2.8: motion vector predictor mvp_flag for reference index ref_idx
+__device__ __forceinline__ void derive_mvp(const MotionCtx& C, const PbGeom& g, int ref_idx, int mvp_flag, int* mvp)
+{
+  const int xPb = g.xPb, yPb = g.yPb, nPbW = g.nPbW, nPbH = g.nPbH;
+  const int cur_poc = C.poc, tgt_poc = C.reftab[C.slice->ref_slot[ref_idx]].poc;
+  const int xA[2] = {xPb - 1, xPb - 1}, yA[2] = {yPb + nPbH, yPb + nPbH - 1};
+  MotionUnit mA[2] = {};
+  int avA[2];
+  for (int k = 0; k < 2; k++) avA[k] = pb_available(C, g, xA[k], yA[k], &mA[k]);
+  const int is_scaled = avA[0] || avA[1];
+  int flagA = 0, mvA[2] = {0, 0};
+  for (int k = 0; k < 2 && !flagA; k++)
+    if (avA[k] && C.reftab[mA[k].ref_slot].poc == tgt_poc) { flagA = 1; mvA[0] = mA[k].mv[0]; mvA[1] = mA[k].mv[1]; }
+  for (int k = 0; k < 2 && !flagA; k++)
+    if (avA[k]) {
+      const int nb_poc = C.reftab[mA[k].ref_slot].poc;
+      flagA = 1; mvA[0] = mA[k].mv[0]; mvA[1] = mA[k].mv[1];
+      if (nb_poc != tgt_poc) scale_mv(mvA, cur_poc - nb_poc, cur_poc - tgt_poc);
+    }
+  const int xB[3] = {xPb + nPbW, xPb + nPbW - 1, xPb - 1}, yB[3] = {yPb - 1, yPb - 1, yPb - 1};
+  MotionUnit mB[3] = {};
+  int avB[3];
+  for (int k = 0; k < 3; k++) avB[k] = pb_available(C, g, xB[k], yB[k], &mB[k]);
+  int flagB = 0, mvB[2] = {0, 0};
+  for (int k = 0; k < 3 && !flagB; k++)
+    if (avB[k] && C.reftab[mB[k].ref_slot].poc == tgt_poc) { flagB = 1; mvB[0] = mB[k].mv[0]; mvB[1] = mB[k].mv[1]; }
+  if (!is_scaled && flagB) { flagA = 1; mvA[0] = mvB[0]; mvA[1] = mvB[1]; }
+  if (!is_scaled) {
+    flagB = 0;
+    for (int k = 0; k < 3 && !flagB; k++)
+      if (avB[k]) {
+        const int nb_poc = C.reftab[mB[k].ref_slot].poc;
+        flagB = 1; mvB[0] = mB[k].mv[0]; mvB[1] = mB[k].mv[1];
+        if (nb_poc != tgt_poc) scale_mv(mvB, cur_poc - nb_poc, cur_poc - tgt_poc);
+      }
+  }
+  int list[2][2] = {{0, 0}, {0, 0}}, n = 0;
+  if (flagA) { list[n][0] = mvA[0]; list[n][1] = mvA[1]; n++; }
+  if (flagB && !(flagA && mvA[0] == mvB[0] && mvA[1] == mvB[1]) && n < 2) { list[n][0] = mvB[0]; list[n][1] = mvB[1]; n++; }
+  mvp[0] = list[mvp_flag][0]; mvp[1] = list[mvp_flag][1];   // (entries the candidates did not fill are the zero vectors of 8.5.3.2.6)
+}
+
+struct MotionLds {
+  MotionUnit cur[256];   // the CTB being derived, z-order
+  MotionUnit pu;         // the motion of the prediction unit lane 0 just derived (broadcast to the lanes that fill its units)
+  int pu_geom[4];        // its rectangle in units relative to the CTB: x, y, w, h
+};
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void k_motion(MotionArgs A)
+{
+  __shared__ MotionLds L;
+  const int lane = (int)threadIdx.x;
+  uint32_t t = 0;
+  if (lane == 0) t = atomicAdd(A.ticket, 1u);
+  const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+  if (ticket >= A.num_rows) return;
+  if (__hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // failed parse: the maps are garbage
+  const RowDesc rd = A.rows[ticket];
+  const PicParams& P = A.pics[rd.pic];
+  if (!P.is_inter) return;
+  const int cy = (int)rd.row, ctb_w = P.ctb_w, log2_ctb = P.log2_ctb, units_log2 = P.units_per_ctb_log2, units = 1 << units_log2;
+  uint32_t* my_progress = A.row_progress + (size_t)(P.first_row + rd.row) * 3 + 2;   // slot 2 of the row: the reconstruction waves of a 4:2:0 picture use 0 and 1
+  const uint32_t* up_progress = my_progress - 3;
+  MotionUnit* field = (MotionUnit*)(A.arena + P.off_mf);
+  const MotionSyntax* msyn_base = (const MotionSyntax*)(A.arena + P.off_msyn);
+  const uint8_t* u_size = A.arena + P.off_u_size;
+  const uint8_t* u_ipmc = A.arena + P.off_u_ipmc;
+  const CtbInfo* ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
+  const SliceParams* slices = (const SliceParams*)(A.arena + P.off_slices);
+  int err = 0;
+  for (int cx = 0; cx < ctb_w && !err; cx++) {
+    if (cy > 0) {   // the row above: its CTB above-right is done (or the row is)
+      uint32_t need = (uint32_t)(cx + 2);
+      if (need > (uint32_t)ctb_w) need = (uint32_t)ctb_w;
+      uint32_t spins = 0;
+      while (__hip_atomic_load(up_progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > (1u << 22) || __hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { err = DEV_ERR_TIMEOUT; break; }
+      }
+      if (err) break;
+    }
+    const int ctb_rs = cy * ctb_w + cx;
+    const size_t base = (size_t)ctb_rs << units_log2;
+    const CtbInfo ci = ctb_info[ctb_rs];
+    MotionCtx C;
+    C.P = &P; C.reftab = (const RefFrame*)(A.arena + P.off_reftab); C.slice = slices + ci.slice_idx; C.field = field; C.cur = L.cur;
+    C.cx = cx; C.cy = cy; C.avail = ci.avail; C.log2_ctb = log2_ctb; C.units_log2 = units_log2; C.lmt = P.log2_min_tb; C.ctb_w = ctb_w;
+    C.width = P.width; C.height = P.height; C.poc = P.poc; C.par_mrg = P.log2_par_mrg_level;
+    const int x_ctb = cx << log2_ctb, y_ctb = cy << log2_ctb;
+    for (int i = lane; i < units; i += 64) { MotionUnit z{}; z.ref_idx = -1; z.ref_slot = -1; L.cur[i] = z; }
+    mk_lds_sync();
+    int z = 0;
+    while (z < units && !err) {
+      const int ux = (int)mk_compact((uint32_t)z), uy = (int)mk_compact((uint32_t)z >> 1);
+      if (x_ctb + ux * 4 >= P.width || y_ctb + uy * 4 >= P.height) { z++; continue; }
+      const int log2cb = u_size[base + z] >> 4;
+      if (log2cb < 3 || log2cb > log2_ctb) { err = DEV_ERR_SYNTAX; break; }
+      const int n_units = 1 << (2 * (log2cb - 2));
+      const uint32_t pm = u_ipmc[base + z];
+      if (pm & UM_INTER) {
+        const int nCbS = 1 << log2cb, xCb = x_ctb + ux * 4, yCb = y_ctb + uy * 4;
+        const MotionSyntax s0 = msyn_base[base + z];
+        const int part_mode = (int)((s0.w0 >> 9) & 7u);
+        const int q = nCbS >> 2, hf = nCbS >> 1;
+        int n_parts = 1, px[4] = {0, 0, 0, 0}, py[4] = {0, 0, 0, 0}, pw[4] = {nCbS, nCbS, nCbS, nCbS}, ph[4] = {nCbS, nCbS, nCbS, nCbS};
+        switch (part_mode) {   // Table 7-10
+          case 1: n_parts = 2; ph[0] = ph[1] = hf; py[1] = hf; break;
+          case 2: n_parts = 2; pw[0] = pw[1] = hf; px[1] = hf; break;
+          case 3: n_parts = 4; for (int k = 0; k < 4; k++) { pw[k] = ph[k] = hf; px[k] = (k & 1) * hf; py[k] = (k >> 1) * hf; } break;
+          case 4: n_parts = 2; ph[0] = q; ph[1] = nCbS - q; py[1] = q; break;
+          case 5: n_parts = 2; ph[0] = nCbS - q; ph[1] = q; py[1] = nCbS - q; break;
+          case 6: n_parts = 2; pw[0] = q; pw[1] = nCbS - q; px[1] = q; break;
+          case 7: n_parts = 2; pw[0] = nCbS - q; pw[1] = q; px[1] = nCbS - q; break;
+          default: break;
+        }
+        for (int k = 0; k < n_parts && !err; k++) {
+          if (lane == 0) {
+            PbGeom g{xCb, yCb, nCbS, xCb + px[k], yCb + py[k], pw[k], ph[k], k};
+            const uint32_t zk = mk_interleave((uint32_t)(ux + (px[k] >> 2)), (uint32_t)(uy + (py[k] >> 2)));
+            const MotionSyntax sy = msyn_base[base + zk];
+            Mv m{0, 0, 0};
+            int bad = !(sy.w0 & 0x8000u) || (int)((sy.w0 >> 12) & 3u) != k;
+            if (!bad) {
+              if (sy.w0 & 1u) m = derive_merge(C, g, part_mode, (int)((sy.w0 >> 1) & 7u));
+              else {
+                const int ref_idx = (int)((sy.w0 >> 4) & 15u);
+                if (ref_idx >= (int)C.slice->num_ref_idx) bad = 1;
+                else {
+                  int mvp[2];
+                  derive_mvp(C, g, ref_idx, (int)((sy.w0 >> 8) & 1u), mvp);
+                  const int mvd_x = (int16_t)(sy.w1 & 0xffffu), mvd_y = (int16_t)(sy.w1 >> 16);
+                  const int ux_ = (mvp[0] + mvd_x + 65536) & 65535, uy_ = (mvp[1] + mvd_y + 65536) & 65535;   // 8.5.3.2.1: wrapped into 16 bits
+                  m.x = ux_ >= 32768 ? ux_ - 65536 : ux_; m.y = uy_ >= 32768 ? uy_ - 65536 : uy_; m.ref_idx = ref_idx;
+                }
+              }
+              if (!bad && (m.ref_idx < 0 || m.ref_idx >= (int)C.slice->num_ref_idx)) bad = 1;
+            }
+            MotionUnit o{};
+            o.mv[0] = (int16_t)m.x; o.mv[1] = (int16_t)m.y; o.ref_idx = (int8_t)(bad ? -2 : m.ref_idx);
+            o.ref_slot = (int8_t)(bad ? 0 : C.slice->ref_slot[m.ref_idx]); o.pred = (uint8_t)((pm & UM_SKIP) ? 2 : 1);
+            L.pu = o;
+            L.pu_geom[0] = ux + (px[k] >> 2); L.pu_geom[1] = uy + (py[k] >> 2); L.pu_geom[2] = pw[k] >> 2; L.pu_geom[3] = ph[k] >> 2;
+          }
+          mk_lds_sync();
+          const MotionUnit o = L.pu;
+          if (o.ref_idx == -2) { err = DEV_ERR_SYNTAX; break; }
+          const int gx = L.pu_geom[0], gy = L.pu_geom[1], gw = L.pu_geom[2], gh = L.pu_geom[3];
+          for (int i = lane; i < gw * gh; i += 64) L.cur[mk_interleave((uint32_t)(gx + i % gw), (uint32_t)(gy + i / gw))] = o;
+          mk_lds_sync();
+        }
+      }
+      z += n_units;
+    }
+    if (err) break;
+    // the CTB's units leave LDS (coalesced 8-byte stores), then the row's progress is published
+    for (int i = lane; i < units; i += 64) field[base + i] = L.cur[i];
+    mk_lds_sync();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_store(my_progress, (uint32_t)(cx + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (err && lane == 0) atomicCAS((int*)A.status, 0, err | (int)(0x50000000u) | (int)(ticket << 8));
+}
+
+// ---- 8.5.3.3: motion-compensated prediction of every sample that belongs to an inter coded unit -------------------------------------------
+namespace {
+__device__ __forceinline__ int luma_tap(int frac, int i)
+{
+  // fL[frac][i] (Table 8-11), rows 1..3; row 0 is the integer position
+  constexpr int8_t t[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}};
+  return t[frac][i];
+}
+__device__ __forceinline__ int chroma_tap(int frac, int i)
+{
+  constexpr int8_t t[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4}, {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
+  return t[frac][i];
+}
+}  // namespace
+
+template <typename Pix>
+__global__ __launch_bounds__(256) void k_mc(FilterArgs A, int n_planes_per_pic)
+{
+  const int pic = (int)blockIdx.z / 3, plane = (int)blockIdx.z % 3;
+  (void)n_planes_per_pic;
+  if (__hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+  const PicParams& P = A.pics[pic];
+  if (!P.is_inter || (plane && !P.chroma_format_idc)) return;
+  const int W = plane ? P.cwidth : P.width, H = plane ? P.cheight : P.height;
+  const int x = (int)(blockIdx.x * 16 + (threadIdx.x & 15)), y = (int)(blockIdx.y * 16 + (threadIdx.x >> 4));
+  if (x >= W || y >= H) return;
+  const int sub = plane ? 1 : 0;                       // log2 subsampling (4:2:0 only)
+  const int xl = x << sub, yl = y << sub;              // the luma sample that decides which prediction unit the sample belongs to
+  const int log2_ctb = P.log2_ctb;
+  const int cx = xl >> log2_ctb, cy = yl >> log2_ctb, m = (1 << (log2_ctb - 2)) - 1;
+  const uint32_t z = mk_interleave((uint32_t)((xl >> 2) & m), (uint32_t)((yl >> 2) & m));
+  const MotionUnit mu = ((const MotionUnit*)(A.arena + P.off_mf))[((size_t)(cy * P.ctb_w + cx) << P.units_per_ctb_log2) + z];
+  if (mu.ref_idx < 0) return;                          // intra coded: k_recon predicts it
+  const RefFrame rf = ((const RefFrame*)(A.arena + P.off_reftab))[mu.ref_slot];
+  const Pix* ref = (const Pix*)(uintptr_t)rf.plane[plane];
+  const size_t rstride = rf.stride[plane] / sizeof(Pix);
+  const int bit_depth = plane ? P.bit_depth_chroma : P.bit_depth_luma;
+  const int shift1 = bit_depth - 8 < 4 ? bit_depth - 8 : 4, shift3 = 14 - bit_depth > 2 ? 14 - bit_depth : 2;
+  const int fbits = plane ? 3 : 2, taps = plane ? 4 : 8, before = plane ? 1 : 3;
+  const int mvx = mu.mv[0], mvy = mu.mv[1];
+  const int xf = mvx & ((1 << fbits) - 1), yf = mvy & ((1 << fbits) - 1);
+  const int xi = x + (mvx >> fbits), yi = y + (mvy >> fbits);
+#define MK_REF(xx, yy) ((int)ref[(size_t)mk_clip3(0, H - 1, (yy)) * rstride + (size_t)mk_clip3(0, W - 1, (xx))])
+#define MK_TAP(f, i) (plane ? chroma_tap((f), (i)) : luma_tap((f), (i)))
+  int v;
+  if (!xf && !yf) v = MK_REF(xi, yi) << shift3;
+  else if (!yf) { int a = 0; for (int i = 0; i < taps; i++) a += MK_TAP(xf, i) * MK_REF(xi + i - before, yi); v = a >> shift1; }
+  else if (!xf) { int a = 0; for (int i = 0; i < taps; i++) a += MK_TAP(yf, i) * MK_REF(xi, yi + i - before); v = a >> shift1; }
+  else {
+    int a = 0;
+    for (int j = 0; j < taps; j++) {
+      int t = 0;
+      for (int i = 0; i < taps; i++) t += MK_TAP(xf, i) * MK_REF(xi + i - before, yi + j - before);
+      a += MK_TAP(yf, j) * (t >> shift1);
+    }
+    v = a >> 6;
+  }
+#undef MK_REF
+#undef MK_TAP
+  const int wshift = 14 - bit_depth, woff = 1 << (wshift - 1), maxv = (1 << bit_depth) - 1;   // 8.5.3.3.4.2, predFlagL0 only (bit depth <= 12)
+  Pix* rec = (Pix*)(A.arena + P.off_rec[plane]);
+  rec[(size_t)y * (P.rec_stride[plane ? 1 : 0] / sizeof(Pix)) + x] = (Pix)mk_clip3(0, maxv, (v + woff) >> wshift);
+}
+
+void launch_motion(const MotionArgs& a, hipStream_t s)
+{
+  if (!a.num_rows) return;
+  hipLaunchKernelGGL(k_motion, dim3(a.num_rows), dim3(64), 0, s, a);
+}
+
+void launch_mc(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s)
+{
+  if (n_pics <= 0) return;
+  const dim3 grid((unsigned)((max_w + 15) / 16), (unsigned)((max_h + 15) / 16), (unsigned)(n_pics * 3));
+  if (wide) hipLaunchKernelGGL(k_mc<uint16_t>, grid, dim3(256), 0, s, a, 3);
+  else hipLaunchKernelGGL(k_mc<uint8_t>, grid, dim3(256), 0, s, a, 3);
+}
+
+}  // namespace hipdec

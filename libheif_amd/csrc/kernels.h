@@ -22,7 +22,21 @@ struct FilterArgs {
   const int32_t* status;   // batch status word: a failed parse leaves garbage maps, later stages skip the batch
 };
 
+// k_motion (inter_kernels.hip): one wave per CTB row of the batch (rows of intra pictures return at once)
+struct MotionArgs {
+  const PicParams* pics;
+  const RowDesc* rows;
+  uint32_t num_rows;
+  uint8_t* arena;
+  uint32_t* row_progress;  // per (batch row, slot): slot 2 is the motion wavefront's
+  uint32_t* ticket;
+  int32_t* status;
+};
+
 void launch_parse(const ParseArgs& a, hipStream_t s);
+void launch_parse_inter(const ParseArgs& a, hipStream_t s);   // parse_kernel_inter.hip: batches with P pictures (sequence tracks)
+void launch_motion(const MotionArgs& a, hipStream_t s);       // P pictures: MotionSyntax -> motion field (merge / AMVP derivation)
+void launch_mc(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s);   // motion-compensated prediction into the rec planes
 void launch_parse_general(const ParseArgs& a, bool throughput, hipStream_t s);   // parse_kernel_general.hip: batches with 4:2:2 / 4:4:4 pictures
 void launch_residual(const FilterArgs& a, int n_pics, int max_ctbs, bool general_chroma /* the batch holds 4:2:2 / 4:4:4 pictures */, hipStream_t s);
 void launch_recon(const ReconArgs& a, bool wide, hipStream_t s);

@@ -104,6 +104,9 @@ PC_DEV uint32_t pc_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }     
 #ifndef HIPDEC_PARSE_CHROMA_GENERAL
 #define HIPDEC_PARSE_CHROMA_GENERAL 1   // 0: a build for 4:0:0 / 4:2:0 pictures only (see pc_is444)
 #endif
+#ifndef HIPDEC_PARSE_INTER
+#define HIPDEC_PARSE_INTER 0            // 1: the build that also parses P slices (sequence tracks; parse_kernel_inter.hip, the CPU emulation)
+#endif
 
 namespace hipdec {
 namespace pcore {
@@ -145,6 +148,12 @@ struct PS {
   int32_t is_cu_qp_delta_coded, cu_qp_delta_val, qpy_pred, last_qp_y, cur_qp_y;
   int32_t cu_tq_bypass;
   Lds* L;
+#if HIPDEC_PARSE_INTER
+  // ---- P slices: slice_type P, num_ref_idx_l0_active, MaxNumMergeCand, initType; amp_enabled_flag, max_transform_hierarchy_depth_inter;
+  //      the motion syntax records of the CTB being parsed (one per prediction unit, at the unit index of its first 4x4 unit)
+  int32_t is_p, num_ref_idx, max_merge_cand, init_type, amp, max_th_depth_inter;
+  MotionSyntax* msyn;
+#endif
 };
 enum : uint32_t { TOOL_SDH = 1, TOOL_TS = 2, TOOL_CUQPD = 4, TOOL_TQBYPASS = 8 };
 
@@ -705,7 +714,11 @@ PC_DEV void init_contexts(PS& s)
   const int qp = s.slice_qp_y < 0 ? 0 : (s.slice_qp_y > 51 ? 51 : s.slice_qp_y);
   PC_VEC_BEGIN
     for (int g = 0; g < 3; g++) {
+#if HIPDEC_PARSE_INTER
+      const int init = s.init_type ? c_init_p[s.init_type - 1][g][lane] : c_init[g][lane];
+#else
       const int init = c_init[g][lane];
+#endif
       const int m = (init >> 4) * 5 - 45, n = ((init & 15) << 3) - 16;
       int pre = ((m * qp) >> 4) + n;
       pre = pre < 1 ? 1 : (pre > 126 ? 126 : pre);
@@ -1055,6 +1068,197 @@ PC_DEV void pcm_coding_unit(PS& s, int zb, int log2cb, int16_t* coef_y, int16_t*
   s.last_qp_y = s.cur_qp_y;
 }
 
+#if HIPDEC_PARSE_INTER
+// ---- P slices: 7.3.8.5 (cu_skip_flag, pred_mode_flag, inter part_mode), 7.3.8.6 prediction_unit, 7.3.8.9 mvd_coding, rqt_root_cbf ---------------
+// The parser only PARSES: what a prediction unit codes (merge_flag / merge_idx, or ref_idx / mvd / mvp flag) goes to its MotionSyntax record;
+// the candidate lists need the neighbours' final motion, i.e. the 2-CTB wavefront of k_motion (inter_kernels.hip), not the entropy decoder's order.
+enum : int { PM_2Nx2N = 0, PM_2NxN, PM_Nx2N, PM_NxN, PM_2NxnU, PM_2NxnD, PM_nLx2N, PM_nRx2N };   // Table 7-10
+
+PC_DEV int decode_egk(PS& s, int k)   // k-th order Exp-Golomb, bypass bins (9.3.3.5)
+{
+  int v = 0;
+  while (decode_bypass(s)) { v += 1 << k; k++; if (k > 20) { s.err = DEV_ERR_SYNTAX; return 0; } }
+  if (k) v += decode_bypass_bits(s, k);
+  return v;
+}
+
+PC_DEV int parse_part_mode_inter(PS& s, int log2cb)
+{
+  if (decode_bin(s, s.ctxA, A_PART_MODE)) return PM_2Nx2N;
+  if (log2cb == s.log2_min_cb) {
+    if (decode_bin(s, s.ctxC, C_PART_MODE_INTER + 0)) return PM_2NxN;
+    if (log2cb == 3) return PM_Nx2N;
+    return decode_bin(s, s.ctxC, C_PART_MODE_INTER + 1) ? PM_Nx2N : PM_NxN;
+  }
+  if (!s.amp) return decode_bin(s, s.ctxC, C_PART_MODE_INTER + 0) ? PM_2NxN : PM_Nx2N;
+  if (decode_bin(s, s.ctxC, C_PART_MODE_INTER + 0)) {
+    if (decode_bin(s, s.ctxC, C_PART_MODE_INTER + 2)) return PM_2NxN;
+    return decode_bypass(s) ? PM_2NxnD : PM_2NxnU;
+  }
+  if (decode_bin(s, s.ctxC, C_PART_MODE_INTER + 2)) return PM_Nx2N;
+  return decode_bypass(s) ? PM_nRx2N : PM_nLx2N;
+}
+
+// one prediction unit: its syntax into the record at unit index z (CTB-local z-order); returns merge_flag
+PC_DEV int prediction_unit(PS& s, int z, int part_mode, int part_idx, int cu_skip)
+{
+  int merge_flag = 1, merge_idx = 0, ref_idx = 0, mvp_flag = 0, mvd_x = 0, mvd_y = 0;
+  if (!cu_skip) merge_flag = decode_bin(s, s.ctxC, C_MERGE_FLAG);
+  if (merge_flag) {
+    if (s.max_merge_cand > 1 && decode_bin(s, s.ctxC, C_MERGE_IDX)) {
+      merge_idx = 1;
+      while (merge_idx < s.max_merge_cand - 1 && decode_bypass(s)) merge_idx++;
+    }
+  } else {
+    const int cmax = s.num_ref_idx - 1;
+    while (ref_idx < cmax) {
+      const int b = ref_idx < 2 ? decode_bin(s, s.ctxC, C_REF_IDX + ref_idx) : decode_bypass(s);
+      if (!b) break;
+      ref_idx++;
+    }
+    const int gx = decode_bin(s, s.ctxC, C_MVD_GT0), gy = decode_bin(s, s.ctxC, C_MVD_GT0);
+    int g1x = 0, g1y = 0;
+    if (gx) g1x = decode_bin(s, s.ctxC, C_MVD_GT1);
+    if (gy) g1y = decode_bin(s, s.ctxC, C_MVD_GT1);
+    if (gx) { int a = 1; if (g1x) a = decode_egk(s, 1) + 2; if (a > 32768) s.err = DEV_ERR_SYNTAX; mvd_x = decode_bypass(s) ? -a : a; }
+    if (gy) { int a = 1; if (g1y) a = decode_egk(s, 1) + 2; if (a > 32768) s.err = DEV_ERR_SYNTAX; mvd_y = decode_bypass(s) ? -a : a; }
+    mvp_flag = decode_bin(s, s.ctxC, C_MVP_FLAG);
+  }
+  const uint32_t w0 = (uint32_t)merge_flag | ((uint32_t)merge_idx << 1) | ((uint32_t)ref_idx << 4) | ((uint32_t)mvp_flag << 8) | ((uint32_t)part_mode << 9) |
+                      ((uint32_t)part_idx << 12) | 0x8000u;
+  const uint32_t w1 = ((uint32_t)mvd_x & 0xffffu) | ((uint32_t)mvd_y << 16);
+  MotionSyntax* dst = s.msyn + z;
+  PC_VEC_BEGIN if (lane == 0) { dst->w0 = w0; dst->w1 = w1; } PC_VEC_END
+  return merge_flag;
+}
+
+// a coding unit of a P slice that is not intra coded (cu_skip_flag = 1, or pred_mode_flag = 0)
+PC_DEV void inter_coding_unit(PS& s, int zb, int log2cb, int cu_skip, int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr)
+{
+  const int ux0 = (int)compact1by1((uint32_t)zb), uy0 = (int)compact1by1((uint32_t)zb >> 1);
+  const int n_units = 1 << (2 * (log2cb - 2)), nw = 1 << (log2cb - 2);   // units in the CU, units per CU side
+  set_qp_y(s);
+  const uint32_t bypass = s.cu_tq_bypass ? UF_BYPASS : 0u;
+  map_fill(s.m_size, zb, n_units, (uint32_t)(log2cb << 4));
+  map_fill(s.m_flags, zb, n_units, bypass);
+  map_fill(s.m_ipm, zb, n_units, 1u);                                     // a neighbour that is not intra coded counts as INTRA_DC (8.4.2)
+  map_fill(s.m_ipmc, zb, n_units, 1u | UM_INTER | (cu_skip ? UM_SKIP : 0u));
+  int part_mode = PM_2Nx2N;
+  if (!cu_skip) {
+    part_mode = parse_part_mode_inter(s, log2cb);
+    if (part_mode == PM_NxN && log2cb == 3) { s.err = DEV_ERR_SYNTAX; part_mode = PM_2Nx2N; }
+  }
+  // partitions (Table 7-10): offsets in 4x4 units; AMP quarters are whole units because AMP needs a coding block of 16 and up
+  const int q = nw >> 2, hf = nw >> 1;
+  int n_parts = 1, px[4] = {0, 0, 0, 0}, py[4] = {0, 0, 0, 0};
+  int vx = -1, hy = -1;   // prediction block edges inside the unit (deblocking edges, 8.7.2.3), in units from the CU origin
+  switch (part_mode) {
+    case PM_2NxN: n_parts = 2; py[1] = hf; hy = hf; break;
+    case PM_Nx2N: n_parts = 2; px[1] = hf; vx = hf; break;
+    case PM_NxN: n_parts = 4; px[1] = hf; py[2] = hf; px[3] = hf; py[3] = hf; vx = hy = hf; break;
+    case PM_2NxnU: n_parts = 2; py[1] = q; hy = q; break;
+    case PM_2NxnD: n_parts = 2; py[1] = nw - q; hy = nw - q; break;
+    case PM_nLx2N: n_parts = 2; px[1] = q; vx = q; break;
+    case PM_nRx2N: n_parts = 2; px[1] = nw - q; vx = nw - q; break;
+    default: break;
+  }
+  int merge0 = 0;
+  for (int k = 0; k < n_parts && !s.err; k++) {
+    const int z = (int)interleave4((uint32_t)(ux0 + px[k]), (uint32_t)(uy0 + py[k]));
+    const int mf = prediction_unit(s, z, part_mode, k, cu_skip);
+    if (k == 0) merge0 = mf;
+  }
+  int rqt_root_cbf = 0;
+  if (!cu_skip) {
+    rqt_root_cbf = 1;
+    if (!(part_mode == PM_2Nx2N && merge0)) rqt_root_cbf = decode_bin(s, s.ctxC, C_RQT_ROOT_CBF);
+  }
+  if (!rqt_root_cbf) {
+    // no transform tree: for the maps the unit is covered by transform blocks of min(CB size, 32) without coefficients whose only deblocking
+    // edges are the coding unit's own left / top edge (fill_tu_maps over the whole unit marks exactly those)
+    fill_tu_maps(s, zb, n_units, bypass, 1u, (uint32_t)((log2cb << 4) | (log2cb > 5 ? 5 : log2cb)));
+  } else {
+    // ---- transform tree of an inter coding unit (7.3.8.8): no IntraSplitFlag, interSplitFlag (7.4.9.8), cbf_luma inferred 1 at a root leaf
+    //      without chroma coefficients; chroma 4:2:0 / 4:0:0 only (the host refuses P slices of other formats)
+    const int max_trafo_depth = s.max_th_depth_inter;
+    const int inter_split = s.max_th_depth_inter == 0 && part_mode != PM_2Nx2N;
+    uint32_t cbf_cb_bits = 0, cbf_cr_bits = 0;
+    int qn = 0;
+    while (qn < n_units && !s.err) {
+      int t;
+      if (qn == 0) t = log2cb; else { t = 2 + ((pc_ffs((uint32_t)qn) - 1) >> 1); if (t > log2cb) t = log2cb; }
+      for (;;) {
+        const int depth = log2cb - t;
+        int split;
+        if (t <= s.log2_max_tb && t > s.log2_min_tb && depth < max_trafo_depth) split = decode_bin(s, s.ctxA, A_SPLIT_TRANSFORM + 5 - t);
+        else split = (t > s.log2_max_tb || (inter_split && depth == 0)) ? 1 : 0;
+        if (s.chroma_format_idc) {
+          const uint32_t bit = 1u << depth, pbit = depth ? (1u << (depth - 1)) : 0;
+          if (t > 2) {
+            int cb = 0, cr = 0;
+            if (depth == 0 || (cbf_cb_bits & pbit)) cb = decode_bin(s, s.ctxA, A_CBF_CHROMA + depth);
+            if (depth == 0 || (cbf_cr_bits & pbit)) cr = decode_bin(s, s.ctxA, A_CBF_CHROMA + depth);
+            cbf_cb_bits = (cbf_cb_bits & ~bit) | (cb ? bit : 0);
+            cbf_cr_bits = (cbf_cr_bits & ~bit) | (cr ? bit : 0);
+          } else {
+            cbf_cb_bits = (cbf_cb_bits & ~bit) | ((cbf_cb_bits & pbit) << 1);
+            cbf_cr_bits = (cbf_cr_bits & ~bit) | ((cbf_cr_bits & pbit) << 1);
+          }
+        }
+        if (!split) break;
+        t--;
+      }
+      const int depth = log2cb - t;
+      const int zu = zb + qn;
+      const int tu_units = 1 << (2 * (t - 2));
+      const int cbf_cb = (int)((cbf_cb_bits >> depth) & 1u), cbf_cr = (int)((cbf_cr_bits >> depth) & 1u);
+      int cbf_luma = 1;
+      if (depth != 0 || cbf_cb || cbf_cr) cbf_luma = decode_bin(s, s.ctxA, A_CBF_LUMA + (depth == 0 ? 1 : 0));
+      if ((cbf_luma | cbf_cb | cbf_cr) && (s.tools & TOOL_CUQPD) && !s.is_cu_qp_delta_coded) parse_cu_qp_delta(s);
+      int do_chroma = 0, zc = zu, tc = t - 1;
+      if (s.chroma_format_idc) {
+        if (t > 2) do_chroma = 1;
+        else if ((qn & 3) == 3) { do_chroma = 1; zc = zb + (qn & ~3); tc = 2; }
+      }
+      uint32_t ts_bits = 0;
+      const uint32_t coded_bits = (uint32_t)cbf_luma | (do_chroma ? (uint32_t)(cbf_cb << 1) | (uint32_t)(cbf_cr << 2) : 0u);
+#pragma clang loop unroll(disable)
+      for (int k = 0; k < 3; k++) {
+        if (!((coded_bits >> k) & 1u)) continue;
+        const int lg = k == 0 ? t : tc;
+        int16_t* dst = k == 0 ? coef_y + zu * 16 : (k == 1 ? coef_cb : coef_cr) + zc * 4;
+        ts_bits |= (uint32_t)residual_coding(s, lg, k, 1 /* not intra: the up-right diagonal scan */) << k;
+        flush_coef(s, dst, 1 << (2 * lg));
+      }
+      fill_tu_maps(s, zu, tu_units,
+                   (uint32_t)((cbf_luma ? UF_CBF_LUMA : 0) | ((do_chroma && cbf_cb) ? UF_CBF_CB : 0) | ((do_chroma && cbf_cr) ? UF_CBF_CR : 0) | bypass |
+                              ((ts_bits & 1u) ? UF_TS_LUMA : 0)),
+                   (uint32_t)(1u | ((ts_bits & 2u) ? 64u : 0u) | ((ts_bits & 4u) ? 128u : 0u)), (uint32_t)((log2cb << 4) | t));
+      qn += tu_units;
+    }
+  }
+  // prediction block edges inside the coding unit (only those on the 8x8 luma grid get filtered; the deblocking kernel checks that)
+  if (s.deblock && (vx >= 0 || hy >= 0)) {
+    PC_VEC_BEGIN
+      uint32_t add = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t z = (uint32_t)lane * 4u + (uint32_t)k;
+        const int ux = (int)compact1by1(z) - ux0, uy = (int)compact1by1(z >> 1) - uy0;
+        if ((uint32_t)ux < (uint32_t)nw && (uint32_t)uy < (uint32_t)nw) {
+          if (ux == vx) add |= (uint32_t)UF_VEDGE << (8 * k);
+          if (uy == hy) add |= (uint32_t)UF_HEDGE << (8 * k);
+        }
+      }
+      PC_L(s.m_flags) |= add;
+    PC_VEC_END
+  }
+  set_qp_y(s);
+  map_fill(s.m_qp, zb, n_units, (uint32_t)(uint8_t)(int8_t)s.cur_qp_y);
+  s.last_qp_y = s.cur_qp_y;
+}
+#endif   // HIPDEC_PARSE_INTER
+
 // ---- 7.3.8.5 coding_unit + 7.3.8.8 transform_tree, stackless over the z-ordered unit index -------
 PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/, int log2cb, int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr)
 {
@@ -1062,6 +1266,19 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
   const int n_units = 1 << (2 * (log2cb - 2));
   s.cu_tq_bypass = 0;
   if (s.tools & TOOL_TQBYPASS) s.cu_tq_bypass = decode_bin(s, s.ctxA, A_CU_TQ_BYPASS);
+#if HIPDEC_PARSE_INTER
+  if (s.is_p) {   // cu_skip_flag (context: the left / above neighbours' flags, 9.3.4.2.2), pred_mode_flag
+    int inc = 0;
+    if (ux0 > 0) inc += (int)(map_get(s.m_ipmc, (int)interleave4((uint32_t)ux0 - 1, (uint32_t)uy0)) >> 7);
+    else if (s.ctb_avail & AV_LEFT) inc += (int)((pc_rdlane(s.p_left, uy0) >> 23) & 1u);
+    if (uy0 > 0) inc += (int)(map_get(s.m_ipmc, (int)interleave4((uint32_t)ux0, (uint32_t)uy0 - 1)) >> 7);
+    else if (s.ctb_avail & AV_UP) inc += (int)((pc_rdlane(s.up, 13) >> ux0) & 1u);
+    const int cu_skip = decode_bin(s, s.ctxC, C_SKIP_FLAG + inc);
+    int inter = 1;
+    if (!cu_skip) inter = decode_bin(s, s.ctxC, C_PRED_MODE) ? 0 : 1;
+    if (inter) { inter_coding_unit(s, zb, log2cb, cu_skip, coef_y, coef_cb, coef_cr); return; }
+  }
+#endif
   int part_nxn = 0;
   if (log2cb == s.log2_min_cb) part_nxn = decode_bin(s, s.ctxA, A_PART_MODE) ? 0 : 1;
   if (part_nxn && log2cb == 3 && s.log2_min_tb > 2) { s.err = DEV_ERR_SYNTAX; part_nxn = 0; }
@@ -1493,6 +1710,15 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
     s.deblock = ((w2 >> 16) & 255u) ? 0 : 1;
     s.sao_luma = (int)((w2 >> 24) & 255u);
     s.sao_chroma = (int)(w3 & 255u);
+#if HIPDEC_PARSE_INTER
+    const uint32_t w4 = uload32(&sl->is_p);                // is_p, num_ref_idx, max_merge_cand, init_type
+    s.is_p = (int)(w4 & 255u); s.num_ref_idx = (int)((w4 >> 8) & 255u); s.max_merge_cand = (int)((w4 >> 16) & 255u); s.init_type = (int)(w4 >> 24);
+    const uint32_t w5 = uload32(&P->is_inter);             // is_inter, amp_enabled, max_th_depth_inter, log2_par_mrg_level
+    s.amp = (int)((w5 >> 8) & 255u); s.max_th_depth_inter = (int)((w5 >> 16) & 255u);
+    s.msyn = nullptr;
+#else
+    if (uload32(&sl->is_p) & 255u) s.err = DEV_ERR_SYNTAX;   // (the host launches the inter build for batches with P slices)
+#endif
   }
   s.is_cu_qp_delta_coded = 0; s.cu_qp_delta_val = 0; s.qpy_pred = s.slice_qp_y; s.last_qp_y = s.slice_qp_y; s.cur_qp_y = s.slice_qp_y;
   s.cu_tq_bypass = 0;
@@ -1565,7 +1791,7 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
     if (s.ctb_avail & AV_UP) {
       const uint32_t* src = (const uint32_t*)(arena + uload64(&P->off_handoff)) + (size_t)(ctb_rs - ctb_w) * HANDOFF_DWORDS;   // HANDOFF_DWORDS per CTB (raster)
       PC_VEC_BEGIN
-        PC_L(s.up) = lane < 13 ? pc_load_wt(src + lane) : 0u;
+        PC_L(s.up) = lane < (HIPDEC_PARSE_INTER ? 14 : 13) ? pc_load_wt(src + lane) : 0u;
       PC_VEC_END
     }
     // ---- coding_tree_unit ----
@@ -1581,6 +1807,9 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
     int16_t* coef_cb = (int16_t*)(arena + uload64(&P->off_coeff[1])) + (size_t)ctb_rs * ((ctb_size * ctb_size) >> cc_shift);
     int16_t* coef_cr = (int16_t*)(arena + uload64(&P->off_coeff[2])) + (size_t)ctb_rs * ((ctb_size * ctb_size) >> cc_shift);
 
+#if HIPDEC_PARSE_INTER
+    s.msyn = (MotionSyntax*)(arena + uload64(&P->off_msyn)) + ((size_t)ctb_rs << units_log2);
+#endif
     // coding quadtree, stackless over the z-ordered min-CB index
     const int n_mincb = 1 << n_mincb_log2;
     const int mincb_units_log2 = 2 * (s.log2_min_cb - 2);
@@ -1650,7 +1879,12 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
         PC_VEC_BEGIN
           const uint32_t z = interleave4((uint32_t)uw - 1u, (uint32_t)lane & 15u);
           const uint32_t sz = (PC_GATHER(s.m_size, z >> 2) >> ((z & 3u) * 8u)) & 255u, im = (PC_GATHER(s.m_ipm, z >> 2) >> ((z & 3u) * 8u)) & 255u;
+#if HIPDEC_PARSE_INTER
+          const uint32_t ic = (PC_GATHER(s.m_ipmc, z >> 2) >> ((z & 3u) * 8u)) & 255u;   // bit 7: the unit is skipped (cu_skip_flag's context)
+          PC_L(col) = (lane < uw) ? (sz | (im << 8) | (ic << 16)) : 0u;
+#else
           PC_L(col) = (lane < uw) ? (sz | (im << 8)) : 0u;
+#endif
         PC_VEC_END
         PC_VEC_BEGIN PC_L(s.p_left) = PC_L(col); PC_VEC_END
       }
@@ -1663,9 +1897,16 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
           for (int b = 0; b < 4 && 4 * j + b < uw; b++) w |= map_get(s.m_size, (int)interleave4((uint32_t)(4 * j + b), (uint32_t)uw - 1)) << (8 * b);
           pc_wrlane(rec, 9 + j, w);
         }
+#if HIPDEC_PARSE_INTER
+        {   // lane 13: cu_skip_flag of the bottom unit row, one bit per unit column
+          uint32_t sk = 0;
+          for (int j = 0; j < uw; j++) sk |= (map_get(s.m_ipmc, (int)interleave4((uint32_t)j, (uint32_t)uw - 1)) >> 7) << j;
+          pc_wrlane(rec, 13, sk);
+        }
+#endif
         uint32_t* dst = (uint32_t*)(arena + uload64(&P->off_handoff)) + (size_t)ctb_rs * HANDOFF_DWORDS;
         PC_VEC_BEGIN
-          if (lane < 13) pc_store_wt(dst + lane, PC_L(rec));
+          if (lane < (HIPDEC_PARSE_INTER ? 14 : 13)) pc_store_wt(dst + lane, PC_L(rec));
         PC_VEC_END
       }
       if (has_dependent == 2 && k + 1 == num_ctbs) save_row_state(s, nullptr, saved, num_ctbs);   // (the registers already hold this CTB as "the previous one")

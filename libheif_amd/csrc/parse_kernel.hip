@@ -41,6 +41,7 @@ void launch_parse(const ParseArgs& a, hipStream_t s)
   // (pool mode: 8 waves per SIMD since the scalar / vector rebalancing of round 2 — 895 against 907 ms per 2048 4K stills with 7; before it the
   //  scalar pipe was saturated and the eighth wave bought nothing)
   const int occ = forced >= 0 ? forced : (a.pool ? 8 : (a.num_waves >= 2048 ? 8 : 0));
+  if (a.inter) { launch_parse_inter(a, s); return; }
   if (a.general_chroma) { launch_parse_general(a, occ != 0, s); return; }
   if (occ == 8) hipLaunchKernelGGL(k_parse_occ8, dim3(a.num_waves), dim3(64), 0, s, a);
   else if (occ == 6) hipLaunchKernelGGL(k_parse_occ6, dim3(a.num_waves), dim3(64), 0, s, a);

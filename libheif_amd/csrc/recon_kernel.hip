@@ -120,6 +120,27 @@ struct Ctx {
   int strong;         // sps strong_intra_smoothing_enabled_flag (c_idx == 0 only)
 };
 
+// A transform block of a coding unit that is NOT intra coded (P pictures): the prediction samples are in the reconstruction plane already
+// (k_mc, inter_kernels.hip); the block enters the LDS tile with its residual added, so that intra blocks next to it predict from it and the
+// CTB leaves LDS as a whole.  LW lanes (64, or 32 per half of the chroma pair) cover the block; `pred` points at the block in the plane.
+template <typename Pix>
+__device__ __forceinline__ void reconstruct_inter_block(ReconLds<Pix>& L, const Ctx& C, Pix* tile, const Pix* pred, uint32_t pstride, int xb, int yb, int log2n, int cbf,
+                                                        const int16_t* res, int l, int LW, int ushx, int ushy)
+{
+  const int n = 1 << log2n, nn = n * n, lg_ctbc = C.lg_ctbc, maxv = C.maxv;
+  for (int idx = l; idx < nn; idx += LW) {
+    const int x = idx & (n - 1), y = idx >> log2n;
+    int v = (int)pred[(size_t)y * pstride + x];
+    if (cbf) v = clip3(0, maxv, v + (int)res[idx]);
+    tile[((yb + y) << lg_ctbc) + xb + x] = (Pix)v;
+  }
+  {
+    const int kx = n >> ushx, rows = n >> ushy;    // units per row of the block (>= 1), unit rows
+    if (C.lane < (rows > 0 ? rows : 1)) L.avrow[(yb >> ushy) + 1 + C.lane] |= ((1ull << (kx > 0 ? kx : 1)) - 1ull) << ((xb >> ushx) + 1);
+  }
+  lds_sync();
+}
+
 // One transform block: prediction (+ residual) into the LDS tile.
 //   (xb, yb): block origin inside the CTB in component samples; log2n: block size
 template <typename Pix>
@@ -486,7 +507,8 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
   const uint32_t line_words = P.rec_stride[c_idx] / 4;
   const int16_t* coeff = (const int16_t*)(A.arena + P.off_coeff[comp]);
   const size_t off_mode = chroma ? P.off_u_ipmc : P.off_u_ipm, off_size = P.off_u_size, off_flags = P.off_u_flags;
-  const uint32_t mode_mask = chroma ? 255u : 63u;   // u_ipm carries the chroma transform-skip flags in bits 6 and 7
+  const bool is_inter = P.is_inter != 0;
+  const uint32_t mode_mask = is_inter ? 127u : (chroma ? 255u : 63u);   // u_ipm carries the chroma transform-skip flags in bits 6 and 7; P pictures: bit 6 = inter
   int err = 0;
   uint32_t my_row = 0;
   Ctx C;
@@ -541,7 +563,11 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
       for (int i = lane * 4; i < units; i += 256) {
         const uint32_t sz = *(const uint32_t*)(A.arena + off_size + base + i);
         const uint32_t fl = *(const uint32_t*)(A.arena + off_flags + base + i);
-        const uint32_t md = *(const uint32_t*)(A.arena + off_mode + base + i);
+        uint32_t md = *(const uint32_t*)(A.arena + off_mode + base + i);
+        if (is_inter) {   // P picture: bit 6 of a unit's mode byte = the unit is not intra coded (u_ipmc carries it; the luma wave reads u_ipm)
+          const uint32_t pc = *(const uint32_t*)(A.arena + P.off_u_ipmc + base + i);
+          md = (md & 0x3f3f3f3fu) | (pc & 0x40404040u);
+        }
         const uint32_t ux = compact1by1((uint32_t)i), uy = compact1by1((uint32_t)i >> 1);   // i is a multiple of 4: units i..i+3 are a 2x2 quad
 #pragma nounroll
         for (int k = 0; k < 4; k++)
@@ -575,7 +601,18 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
       if (x_ctb + ux * 4 >= pic_w || y_ctb + uy * 4 >= pic_h) { z++; continue; }
       const int tb = (int)(w & 15u), fl = (int)((w >> 8) & 255u), mode = (int)((w >> 16) & 255u);
       if (tb < 2 || tb > 5) { err = DEV_ERR_SYNTAX; break; }
-      if (!DUAL) {
+      if (mode & 64) {   // a unit of an inter coded CU: prediction from the plane + residual
+        if (!DUAL) {
+          const Pix* pred = rec + (size_t)(y_ctb + uy * 4) * stride + (size_t)(x_ctb + ux * 4);
+          reconstruct_inter_block<Pix>(L, C, tile, pred, stride, ux * 4, uy * 4, tb, fl & cbf_bit, res_base + z * 16, lane, 64, 2, 2);
+        } else if (tb > 2 || (z & 3) == 3) {
+          const int quad = tb == 2;
+          const int zc = quad ? (z & ~3) : z, cux = quad ? (ux & ~1) : ux, cuy = quad ? (uy & ~1) : uy;
+          const int lgc = quad ? 2 : tb - 1;
+          const Pix* pred = rec + (size_t)(y_ctb / 2 + cuy * 2) * stride + (size_t)(xc0 + cux * 2);
+          reconstruct_inter_block<Pix>(L, C, tile, pred, stride, cux * 2, cuy * 2, lgc, fl & cbf_bit, res_base + zc * 4, l, 32, 1, 1);
+        }
+      } else if (!DUAL) {
         reconstruct_block<Pix>(L, C, top, ux * 4, uy * 4, tb, mode, fl & (cbf_bit | UF_PCM), res_base + z * 16);
       } else if (tb > 2 || (z & 3) == 3) {
         // the 4x4 chroma blocks of four 4x4 luma TUs hang off the 4th unit (their flags are there); they sit at the quad's origin

@@ -231,7 +231,8 @@ __device__ __forceinline__ void residual_quad(ResLds& L, int bd_luma, int bd_chr
   blk[x * 4 + y] = (int16_t)d;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  const uint32_t* e = (const uint32_t*)((c == 0 ? L.est4 : L.et4) + y * 4);   // E^T row of this lane's output index (luma 4x4: DST)
+  const bool use_dst = c == 0 && !((entry >> 11) & 1);   // DST-VII for the 4x4 luma blocks of intra coded units only
+  const uint32_t* e = (const uint32_t*)((use_dst ? L.est4 : L.et4) + y * 4);   // E^T row of this lane's output index
   {
     // first stage, lane (i = y, x): tmp[i][x] = clip16((sum_j E[j][i] d[j][x] + 64) >> 7)
     const uint32_t* v = (const uint32_t*)(blk + x * 4);
@@ -243,7 +244,7 @@ __device__ __forceinline__ void residual_quad(ResLds& L, int bd_luma, int bd_chr
   int r;
   {
     // second stage, lane (y, i = x): res[y][i] = (sum_j E[j][i] tmp[y][j] + rnd) >> bdShift
-    const uint32_t* ei = (const uint32_t*)((c == 0 ? L.est4 : L.et4) + x * 4);
+    const uint32_t* ei = (const uint32_t*)((use_dst ? L.est4 : L.et4) + x * 4);
     const uint32_t* v = (const uint32_t*)(tmp + y * 4);
     const int sum = dot2(ei[1], v[1], dot2(ei[0], v[0], 0));
     r = (sum + (1 << (bd_shift2 - 1))) >> bd_shift2;
@@ -313,7 +314,8 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
       const int first = t >= 2 && t <= 5 && (z & ((1 << (2 * (t - 2))) - 1)) == 0;
       if (first && !(fl & UF_BYPASS)) {
         if (fl & UF_CBF_LUMA) {
-          if (t == 2) L.list[LIST_N - 1 - atomicAdd(&L.count4, 1u)] = (uint16_t)z;
+          // (P pictures: bit 11 = the block belongs to an inter coded unit: its 4x4 luma transform is the DCT, not the DST of intra blocks, 8.6.4.2)
+          if (t == 2) L.list[LIST_N - 1 - atomicAdd(&L.count4, 1u)] = (uint16_t)(z | ((P.is_inter && (A.arena[P.off_u_ipmc + base + z] & UM_INTER)) ? 0x800 : 0));
           else L.list[atomicAdd(&L.count, 1u)] = (uint16_t)z;
         }
         // chroma blocks hang off the unit that carries their flags: a block's first unit, or the 4th unit of a quad of 4x4 luma blocks.  4:2:2 has

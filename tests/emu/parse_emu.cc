@@ -37,6 +37,35 @@ EmuBatch* emu_create(int n, const uint8_t* const* data, const size_t* sizes, cha
 
 void emu_free(EmuBatch* b) { delete b; }
 
+// ---- sequences: one access unit per emu_seq_create_picture(); emu_seq_commit() after the pipeline ran (pipeline_emu.cc) -----------------------
+EmuSeq* emu_seq_new() { return new EmuSeq(); }
+void emu_seq_free(EmuSeq* q)
+{
+  if (!q) return;
+  for (EmuBatch* b : q->alive) delete b;
+  for (auto* f : q->full_frames) delete f;
+  delete q;
+}
+EmuBatch* emu_seq_create_picture(EmuSeq* q, const uint8_t* data, size_t size, char* errbuf, size_t errlen)
+{
+  EmuBatch* b = new EmuBatch();
+  std::vector<uint8_t> host;
+  std::string err;
+  const void* ptrs[1] = {data};
+  const size_t sizes[1] = {size};
+  const SeqContext* seqs[1] = {&q->ctx};
+  int rc = layout_batch(b->L, 1, ptrs, sizes, 0, host, err, seqs);
+  if (rc != 0) {
+    snprintf(errbuf, errlen, "%d: %s", rc, err.c_str());
+    delete b;
+    return nullptr;
+  }
+  b->arena.assign(b->L.arena_size + 1024, 0);
+  memcpy(b->arena.data(), host.data(), host.size());
+  q->alive.push_back(b);
+  return b;
+}
+
 // runs every substream in index order (a WPP predecessor always has a smaller index); returns the device status word
 int emu_run_parse(EmuBatch* b)
 {
@@ -52,6 +81,7 @@ int emu_run_parse(EmuBatch* b)
   A.pool = b->L.pool; A.queue_cap = b->L.queue_cap; A.num_subs = b->L.num_subs;
   A.waitneed = (uint32_t*)(a + b->L.off_waitneed); A.resume_k = (uint32_t*)(a + b->L.off_resume_k);
   A.queue = (uint32_t*)(a + b->L.off_queue); A.qctl = (uint32_t*)(a + b->L.off_qctl); A.saved = (uint32_t*)(a + b->L.off_saved);
+  A.inter = b->L.any_inter ? 1 : 0;
   pcore::Lds lds;
   memset(&lds, 0, sizeof(lds));
   if (A.pool) {

@@ -26,6 +26,12 @@ int emu_run_pipeline_rgb(EmuBatch* b, int stages, uint8_t* rgb)
   bool general = false;
   for (const PicParams& P : L.params) if (P.chroma_format_idc >= 2) general = true;
   if (stages & 1) launch_residual(fa, n, L.max_ctbs, general, nullptr);
+  if ((stages & 2) && L.any_inter) {   // P pictures: motion field, motion-compensated prediction (as decoder.hip:launch_all)
+    MotionArgs ma{(const PicParams*)(a + L.off_pics), (const RowDesc*)(a + L.off_rows), L.num_rows, a, (uint32_t*)(a + L.off_row_progress),
+                  (uint32_t*)(a + L.off_ticket) + 2, (int32_t*)(a + L.off_status)};
+    launch_motion(ma, nullptr);
+    launch_mc(fa, n, L.max_w, L.max_h, L.wide, nullptr);
+  }
   if (stages & 2) launch_recon(ra, L.wide, nullptr);
   if (stages & 4) launch_deblock(fa, n, L.max_w, L.max_h, L.wide, nullptr);
   bool may_keep = false, restricted = false;   // as decoder.hip:launch_all picks the kernel variant
@@ -60,6 +66,66 @@ int emu_run_pipeline_rgb(EmuBatch* b, int stages, uint8_t* rgb)
   }
   b->status = *(int32_t*)(a + L.off_status);
   return b->status;
+}
+
+// The picture of batch `b` (one item) was decoded: it enters the sequence's DPB as a reference picture - its output planes when they ARE the
+// coded picture, else an uncropped copy made by running the SAO kernel once more without the conformance window (what the product's decoder
+// does lazily, decoder.hip) - and the DPB drops what the picture's RPS no longer names.
+int emu_seq_commit(EmuSeq* q, EmuBatch* b)
+{
+  const BatchLayout& L = b->L;
+  const PicParams& P = L.params[0];
+  const ParsedPicture& pp = L.pics[0];
+  uint8_t* a = b->arena.data();
+  RefPicture rp;
+  rp.poc = pp.poc;
+  const bool cropped = P.out_width != P.width || P.out_height != P.height || P.crop_x || P.crop_y;
+  if (!cropped) {
+    for (int c = 0; c < 3; c++) { rp.plane[c] = (uint64_t)(uintptr_t)(a + P.off_out[c]); rp.stride[c] = P.out_stride[c]; }
+  } else {
+    const size_t es = L.wide ? 2 : 1;
+    auto* buf = new std::vector<uint8_t>();
+    size_t off[3], total = 0;
+    uint32_t stride[3];
+    for (int c = 0; c < 3; c++) {
+      const size_t w = c ? P.cwidth : P.width, h = c ? P.cheight : P.height;
+      stride[c] = (uint32_t)(((w ? w : 1) * es + 63) / 64 * 64);
+      off[c] = total; total += (size_t)stride[c] * (h ? h : 1) + 256;
+    }
+    buf->assign(total, 0);
+    q->full_frames.push_back(buf);
+    std::vector<PicParams> tmp(1, P);
+    PicParams& F = tmp[0];
+    F.crop_x = F.crop_y = 0; F.out_width = P.width; F.out_height = P.height; F.out_cwidth = P.cwidth; F.out_cheight = P.cheight;
+    for (int c = 0; c < 3; c++) { F.off_out[c] = (uint64_t)(uintptr_t)(buf->data() + off[c]) - (uint64_t)(uintptr_t)a; F.out_stride[c] = stride[c]; }
+    FilterArgs fa{tmp.data(), a, (const int32_t*)(a + L.off_status)};
+    bool may_keep = P.transquant_bypass_enabled || (P.pcm_enabled && P.pcm_loop_filter_disabled), restricted = !P.sao_free_neighbours;
+    launch_sao(fa, 1, P.width, P.height, L.wide, nullptr, may_keep, restricted);
+    for (int c = 0; c < 3; c++) { rp.plane[c] = (uint64_t)(uintptr_t)(buf->data() + off[c]); rp.stride[c] = stride[c]; }
+  }
+  seq_commit(q->ctx, pp);
+  q->ctx.dpb.push_back(rp);
+  return 0;
+}
+
+// motion field of item i after the pipeline (k_motion): per 4x4 unit in RASTER order mv x, mv y (int16), ref_idx (int8), pred (uint8)
+int emu_motion(EmuBatch* b, int i, int16_t* mv, int8_t* ref_idx, uint8_t* pred)
+{
+  const PicParams& P = b->L.params[i];
+  if (!P.is_inter) return -1;
+  const uint8_t* a = b->arena.data();
+  const MotionUnit* mf = (const MotionUnit*)(a + P.off_mf);
+  const int uw = (P.width + 3) >> 2, uh = (P.height + 3) >> 2, side = 1 << (P.log2_ctb - 2);
+  for (int uy = 0; uy < uh; uy++)
+    for (int ux = 0; ux < uw; ux++) {
+      const int cx = ux / side, cy = uy / side, lx = ux % side, ly = uy % side;
+      uint32_t z = 0;
+      for (int k = 0; k < 4; k++) z |= (((uint32_t)lx >> k) & 1u) << (2 * k) | (((uint32_t)ly >> k) & 1u) << (2 * k + 1);
+      const MotionUnit m = mf[((size_t)(cy * P.ctb_w + cx) << P.units_per_ctb_log2) + z];
+      const size_t o = (size_t)uy * uw + ux;
+      mv[2 * o] = m.mv[0]; mv[2 * o + 1] = m.mv[1]; ref_idx[o] = m.ref_idx; pred[o] = m.pred;
+    }
+  return 0;
 }
 
 // output plane c of item i (cropped size, as hipdec_batch_read_plane); dst rows are tightly packed

@@ -1,0 +1,116 @@
+"""P pictures through the DEVICE code on the CPU (tests/emu: parse_core.h with the inter syntax, residual / k_motion / k_mc / reconstruction /
+deblocking / SAO kernels compiled for the host) against the oracle, picture by picture: motion field, output planes.  SURVEY.md 8 f3."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from test_parse_emu import emu
+from test_inter_oracle import make_frames, CONFIGS
+
+
+def _lib():
+    L = emu()
+    L.emu_seq_new.restype = C.c_void_p
+    L.emu_seq_free.argtypes = [C.c_void_p]
+    L.emu_seq_create_picture.restype = C.c_void_p
+    L.emu_seq_create_picture.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.emu_seq_commit.argtypes = [C.c_void_p, C.c_void_p]
+    L.emu_run_parse.argtypes = [C.c_void_p]
+    L.emu_run_pipeline.argtypes = [C.c_void_p, C.c_int]
+    L.emu_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.emu_out_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.emu_motion.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.emu_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    return L
+
+
+def parameter_sets(au):
+    """the VPS / SPS / PPS NAL units of an access unit in plugin framing: what the decoder instance keeps in front of later samples
+    (libheif/codecs/decoder.cc:422: only a chunk's first sample carries them)"""
+    out, p = b"", 0
+    while p + 4 <= len(au):
+        n = int.from_bytes(au[p:p + 4], "big")
+        if 32 <= ((au[p + 4] >> 1) & 63) <= 34:
+            out += au[p:p + 4 + n]
+        p += 4 + n
+    return out
+
+
+def decode_sequence_emu(aus, want_motion=False):
+    L = _lib()
+    ps = parameter_sets(aus[0])
+    aus = [aus[0]] + [ps + a for a in aus[1:]]
+    q = C.c_void_p(L.emu_seq_new())
+    out = []
+    try:
+        for au in aus:
+            err = C.create_string_buffer(512)
+            b = L.emu_seq_create_picture(q, au, len(au), err, 512)
+            assert b, err.value.decode()
+            b = C.c_void_p(b)
+            assert L.emu_run_parse(b) == 0, "parse status"
+            assert L.emu_run_pipeline(b, 15) == 0, "pipeline status"
+            sz = (C.c_int * 5)()
+            L.emu_out_size(b, 0, sz)
+            w, h, cw, ch, es = list(sz)
+            dt = np.uint16 if es == 2 else np.uint8
+            planes = []
+            for c in range(3 if cw else 1):
+                a = np.zeros((h, w) if c == 0 else (ch, cw), dt)
+                L.emu_plane(b, 0, c, a.ctypes.data)
+                planes.append(a)
+            pic = {"planes": planes}
+            if want_motion:
+                info = (C.c_int * 7)()
+                L.emu_info(b, 0, info)           # coded size: the motion field covers the coded picture
+                uw, uh = (info[0] + 3) // 4, (info[1] + 3) // 4
+                mv, ref, pred = np.zeros((uh, uw, 2), np.int16), np.zeros((uh, uw), np.int8), np.zeros((uh, uw), np.uint8)
+                if L.emu_motion(b, 0, mv.ctypes.data, ref.ctypes.data, pred.ctypes.data) == 0:
+                    pic.update(mf_mv=mv, mf_ref=ref, map_pred=pred)
+            out.append(pic)
+            assert L.emu_seq_commit(q, b) == 0
+    finally:
+        L.emu_seq_free(q)
+    return out
+
+
+def check_sequence(aus, name=""):
+    ref = orc.decode_sequence(aus, taps=True)
+    got = decode_sequence_emu(aus, want_motion=True)
+    for i, (r, g) in enumerate(zip(ref, got)):
+        if "map_pred" in g:      # a P picture: the motion field first (where the units are inter coded)
+            uh, uw = g["map_pred"].shape
+            rp = r["map_pred"][:uh, :uw]
+            np.testing.assert_array_equal(g["map_pred"], rp, err_msg="%s picture %d: prediction modes" % (name, i))
+            inter = rp > 0
+            np.testing.assert_array_equal(g["mf_ref"][inter], r["mf_ref"][:uh, :uw][inter], err_msg="%s picture %d: reference indices" % (name, i))
+            np.testing.assert_array_equal(g["mf_mv"][inter], r["mf_mv"][:uh, :uw][inter], err_msg="%s picture %d: motion vectors" % (name, i))
+        for c in range(len(r["planes"])):
+            np.testing.assert_array_equal(g["planes"][c], r["planes"][c], err_msg="%s picture %d plane %d" % (name, i, c))
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_emulated_device_pipeline_decodes_p_pictures(name):
+    frames = make_frames(136, 104, 4)
+    aus = orc.encode_sequence(frames, qp=26, global_mv_x=-8, global_mv_y=-4, inter_skip_pct=20, seed=21, **CONFIGS[name])
+    check_sequence(aus, name)
+
+
+@pytest.mark.parametrize("kw", [dict(bit_depth=10, amp=1, inter_num_refs=2), dict(lossless_pct=30, amp=1, transform_skip=1, log2_ctb=5),
+                                dict(pcm_pct=10, inter_intra_pct=40, cu_qp_delta=1, diff_cu_qp_delta_depth=2, deblock_disable=0, tc_offset_div2=2, beta_offset_div2=-2),
+                                dict(deblock_disable=1, sao=0, inter_merge_pct=90), dict(dependent_segments=3, num_slices=2, inter_num_refs=3, wpp=0)],
+                         ids=["main10", "lossless_tskip", "pcm_qpdelta_offsets", "no_filters", "dependent_segments"])
+def test_emulated_device_pipeline_tool_mix(kw):
+    bd = kw.get("bit_depth", 8)
+    frames = make_frames(120, 88, 3, bd)
+    aus = orc.encode_sequence(frames, qp=24, global_mv_x=6, global_mv_y=-10, seed=5, **kw)
+    check_sequence(aus, str(kw))
+
+
+def test_emulated_monochrome_and_cropped_sequence():
+    frames = make_frames(70, 42, 3, 8, mono=True)
+    check_sequence(orc.encode_sequence(frames, qp=22, inter_num_refs=2), "mono")
+    frames = make_frames(70, 42, 4)        # coded 72 x 48: the reference pictures need the rows below the conformance window
+    check_sequence(orc.encode_sequence(frames, qp=22, global_mv_x=3, global_mv_y=17, inter_num_refs=2, amp=1), "cropped")
