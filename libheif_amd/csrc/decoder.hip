@@ -93,11 +93,12 @@ namespace {
 // batches), staging and the upload.  Large upload regions go through pinned staging and ONE asynchronous copy on the
 // library's upload stream, so that hipdec_batch_create() of batch k+1 overlaps the kernels of batch k; small ones (a still, the
 // tiles of a grid photo) are copied synchronously from pageable memory, which is quicker than pinning.
-int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels, hipdec_batch* recycle = nullptr)
+int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels, hipdec_batch* recycle = nullptr,
+                const SeqContext* const* seqs = nullptr)
 {
   std::string err;
   b.device = active_device();
-  int rc = layout_batch_plan(b, n, data, sizes, max_pixels, err);
+  int rc = layout_batch_plan(b, n, data, sizes, max_pixels, err, seqs);
   if (rc != HIPDEC_OK) return set_error(rc, "%s", err.c_str());
   HIPDEC_CHECK_HIP(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
   b.host_status = status_slot_acquire();
@@ -227,7 +228,7 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
     launch_mc(fa, n, b.max_w, b.max_h, b.wide, ps);
     if (int rc = step("motion + mc")) return rc;
   }
-  if (!parse_only) launch_recon(ra, b.wide, ps);
+  if (!parse_only) launch_recon(ra, b.wide, ps, b.any_inter);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[3], ps));
   if (int rc = step("recon")) return rc;
   if (!parse_only) launch_deblock(fa, n, b.max_w, b.max_h, b.wide, ps);
@@ -684,6 +685,17 @@ struct hipdec_decoder {
   int item = 0;                          // this instance's picture inside `batch`
   bool decoded = false;
   bool counted = false;                  // included in Coalescer::armed
+  // ---- sequence tracks: a push after a decode continues a sequence; the pictures decoded so far that later P pictures may
+  //      reference stay alive here (their batches' arenas, or an uncropped copy when the conformance window cuts samples off), and the POC
+  //      state / reference picture list of 8.3.1 / 8.3.2 lives in `seq`
+  struct DpbHold { int poc = 0; std::shared_ptr<hipdec_batch> keep; void* full = nullptr; size_t full_capacity = 0; int device = 0; };
+  bool seq_active = false;
+  SeqContext seq;
+  std::vector<DpbHold> dpb;
+  ~hipdec_decoder()
+  {
+    for (auto& h : dpb) if (h.full) { DeviceScope scope(h.device); arena_release(h.full, h.full_capacity); }
+  }
 };
 
 namespace {
@@ -732,6 +744,78 @@ long coalesce_window_us()
   return g_co.window_us;
 }
 
+// hipdec_batch_create with the sequence contexts of the decoder instances (P pictures name their reference pictures through them)
+int create_batch_seq(hipdec_batch** out, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels, const SeqContext* const* seqs)
+{
+  *out = nullptr;
+  if (int rc = ensure_init()) return rc;
+  return guarded("batch_create", [&]() -> int {
+    std::unique_ptr<hipdec_batch> b(new hipdec_batch());
+    if (int rc = build_batch(*b, n, data, sizes, max_pixels, nullptr, seqs)) return rc;
+    *out = b.release();
+    return 0;
+  });
+}
+
+// The picture the instance decoded last becomes a reference picture of the sequence (called when the next sample is pushed): POC state and DPB
+// follow 8.3.1 / 8.3.2 (seq_commit), its planes are the batch's output planes when they ARE the coded picture - else one more SAO pass
+// without the conformance window writes an uncropped copy (references are addressed in coded coordinates, the rows a window cuts off included).
+int commit_reference(hipdec_decoder* d)
+{
+  hipdec_batch* b = d->batch.get();
+  if (!b || d->item < 0 || d->item >= (int)b->pics.size()) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "sequence: no decoded picture to keep");
+  DeviceScope scope(b->device);
+  const ParsedPicture& pp = b->pics[(size_t)d->item];
+  const PicParams& P = b->params[(size_t)d->item];
+  seq_commit(d->seq, pp);
+  // drop what the RPS no longer names
+  for (size_t i = 0; i < d->dpb.size();) {
+    bool keep = false;
+    for (const RefPicture& rp : d->seq.dpb) if (rp.poc == d->dpb[i].poc) keep = true;
+    if (keep) { i++; continue; }
+    if (d->dpb[i].full) arena_release(d->dpb[i].full, d->dpb[i].full_capacity);
+    d->dpb.erase(d->dpb.begin() + (long)i);
+  }
+  hipdec_decoder::DpbHold h;
+  h.poc = pp.poc; h.keep = d->batch; h.device = b->device;
+  RefPicture rp;
+  rp.poc = pp.poc;
+  const bool cropped = P.out_width != P.width || P.out_height != P.height || P.crop_x || P.crop_y;
+  if (!cropped) {
+    for (int c = 0; c < 3; c++) { rp.plane[c] = (uint64_t)(uintptr_t)(b->arena + P.off_out[c]); rp.stride[c] = P.out_stride[c]; }
+  } else {
+    const size_t es = b->wide ? 2 : 1;
+    size_t off[3], total = 256;   // [0, 256): the PicParams copy the SAO launch reads
+    uint32_t stride[3];
+    for (int c = 0; c < 3; c++) {
+      const size_t w = c ? (size_t)P.cwidth : (size_t)P.width, hh = c ? (size_t)P.cheight : (size_t)P.height;
+      stride[c] = (uint32_t)(((w ? w : 1) * es + 63) / 64 * 64);
+      off[c] = total; total += (size_t)stride[c] * (hh ? hh : 1) + 256;
+    }
+    static_assert(sizeof(PicParams) <= 512, "PicParams copy");
+    total += 512;
+    HIPDEC_CHECK_HIP(arena_acquire(&h.full, total, &h.full_capacity));
+    uint8_t* base = (uint8_t*)h.full + 512;
+    PicParams F = P;
+    F.crop_x = F.crop_y = 0; F.out_width = P.width; F.out_height = P.height; F.out_cwidth = P.cwidth; F.out_cheight = P.cheight;
+    for (int c = 0; c < 3; c++) { F.off_out[c] = (uint64_t)(uintptr_t)(base + off[c]) - (uint64_t)(uintptr_t)b->arena; F.out_stride[c] = stride[c]; }   // (offsets are added to the arena base)
+    hipStream_t s = default_stream();
+    hipError_t e = hipMemcpyAsync(h.full, &F, sizeof(F), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+      FilterArgs fa{(const PicParams*)h.full, b->arena, (const int32_t*)(b->arena + b->off_status)};
+      const bool may_keep = P.transquant_bypass_enabled || (P.pcm_enabled && P.pcm_loop_filter_disabled), restricted = !P.sao_free_neighbours;
+      launch_sao(fa, 1, P.width, P.height, b->wide, s, may_keep, restricted);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    if (e != hipSuccess) { arena_release(h.full, h.full_capacity); return set_error(HIPDEC_ERR_DEVICE, "sequence: reference picture copy: %s", hipGetErrorString(e)); }
+    for (int c = 0; c < 3; c++) { rp.plane[c] = (uint64_t)(uintptr_t)(base + off[c]); rp.stride[c] = stride[c]; }
+  }
+  d->seq.dpb.push_back(rp);
+  d->dpb.push_back(std::move(h));
+  return 0;
+}
+
 // one decoder in a batch of its own: the reference behaviour, and the fallback that gives every request its own
 // error when a shared batch could not be built or failed on the device
 void run_single(DecodeRequest& r, hipStream_t s)
@@ -740,7 +824,8 @@ void run_single(DecodeRequest& r, hipStream_t s)
   const void* ptrs[1] = {d->data.data()};
   const size_t sizes[1] = {d->data.size()};
   hipdec_batch* b = nullptr;
-  r.rc = hipdec_batch_create(&b, 1, ptrs, sizes, d->max_pixels);
+  const SeqContext* seqs[1] = {d->seq_active ? &d->seq : nullptr};
+  r.rc = create_batch_seq(&b, 1, ptrs, sizes, d->max_pixels, seqs);
   if (!r.rc) {
     r.rc = hipdec_batch_run(b, (void*)s);
     if (!r.rc) r.rc = stage_planes_to_host(*b, follow_stream(b, (void*)s));
@@ -762,11 +847,12 @@ void run_group(std::vector<DecodeRequest*>& group, hipStream_t s, uint32_t wave_
   if (group.size() == 1) { run_single(*group[0], s); return; }
   std::vector<const void*> ptrs;
   std::vector<size_t> sizes;
-  for (auto* r : group) { ptrs.push_back(r->d->data.data()); sizes.push_back(r->d->data.size()); }
+  std::vector<const SeqContext*> seqs;
+  for (auto* r : group) { ptrs.push_back(r->d->data.data()); sizes.push_back(r->d->data.size()); seqs.push_back(r->d->seq_active ? &r->d->seq : nullptr); }
   hipdec_batch* b = nullptr;
   static const bool trace = getenv("HIPDEC_COALESCE_TRACE") != nullptr;   // dev knob: where a launch set's wall time goes
   const auto t0 = Clock::now();
-  int rc = hipdec_batch_create(&b, (int)group.size(), ptrs.data(), sizes.data(), group[0]->d->max_pixels);
+  int rc = create_batch_seq(&b, (int)group.size(), ptrs.data(), sizes.data(), group[0]->d->max_pixels, seqs.data());
   const auto t1 = Clock::now();
   auto t2 = t1, t3 = t1;
   if (!rc) {
@@ -867,7 +953,10 @@ int hipdec_decoder_push_data(hipdec_decoder* d, const void* data, size_t size)
     if (d->decoded) {
       // The next sample of an image sequence (libheif/sequences/track_visual.cc:200-280 pushes one sample, polls for its frame, pushes
       // the next; only a chunk's first sample carries the parameter sets, codecs/decoder.cc:422): the instance is armed again with the
-      // parameter sets it has seen in front of the new sample.  Intra pictures only — a P / B slice is refused loudly by the header parser.
+      // parameter sets it has seen in front of the new sample.  P pictures predict from the pictures the instance keeps (commit_reference); B slices, temporal
+      // motion vector prediction, weighted prediction and long-term reference pictures are refused loudly by the header parser.
+      if (int rc = commit_reference(d)) return rc;   // the picture decoded last may be referenced by the samples that follow
+      d->seq_active = true;
       d->decoded = false;
       d->batch.reset();
       d->data = d->param_sets;

@@ -484,7 +484,7 @@ __device__ __forceinline__ void reconstruct_chroma_pair(ReconLds<Pix>& L, const 
 // picture, the Cb / Cr plane (plane 1 / 2: same geometry as luma, the chroma modes / flags / bit depth, no boundary filters).
 // DUAL = true: the 4:2:0 Cb (lanes 0..31) and Cr (lanes 32..63) side by side — h / l below are a lane's half and its index inside
 // the half, LW the lanes one component has.
-template <typename Pix, bool DUAL>
+template <typename Pix, bool DUAL, bool INTER>
 __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& wd, ReconLds<Pix>& L, int lane, int plane)
 {
   constexpr int ES = (int)sizeof(Pix);
@@ -507,7 +507,7 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
   const uint32_t line_words = P.rec_stride[c_idx] / 4;
   const int16_t* coeff = (const int16_t*)(A.arena + P.off_coeff[comp]);
   const size_t off_mode = chroma ? P.off_u_ipmc : P.off_u_ipm, off_size = P.off_u_size, off_flags = P.off_u_flags;
-  const bool is_inter = P.is_inter != 0;
+  const bool is_inter = INTER && P.is_inter != 0;   // (INTER = false: the build for batches without P pictures, the benchmarked path)
   const uint32_t mode_mask = is_inter ? 127u : (chroma ? 255u : 63u);   // u_ipm carries the chroma transform-skip flags in bits 6 and 7; P pictures: bit 6 = inter
   int err = 0;
   uint32_t my_row = 0;
@@ -601,7 +601,7 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
       if (x_ctb + ux * 4 >= pic_w || y_ctb + uy * 4 >= pic_h) { z++; continue; }
       const int tb = (int)(w & 15u), fl = (int)((w >> 8) & 255u), mode = (int)((w >> 16) & 255u);
       if (tb < 2 || tb > 5) { err = DEV_ERR_SYNTAX; break; }
-      if (mode & 64) {   // a unit of an inter coded CU: prediction from the plane + residual
+      if (INTER && (mode & 64)) {   // a unit of an inter coded CU: prediction from the plane + residual
         if (!DUAL) {
           const Pix* pred = rec + (size_t)(y_ctb + uy * 4) * stride + (size_t)(x_ctb + ux * 4);
           reconstruct_inter_block<Pix>(L, C, tile, pred, stride, ux * 4, uy * 4, tb, fl & cbf_bit, res_base + z * 16, lane, 64, 2, 2);
@@ -656,7 +656,7 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
   if (err && lane == 0) atomicCAS((int*)A.status, 0, err | (int)(0x40000000u) | (int)(my_row << 8));
 }
 
-template <typename Pix>
+template <typename Pix, bool INTER>
 __device__ __forceinline__ void recon_wave(const ReconArgs& A)
 {
   __shared__ ReconLds<Pix> L;
@@ -668,19 +668,25 @@ __device__ __forceinline__ void recon_wave(const ReconArgs& A)
   if (__hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // failed parse: maps are garbage
   const ReconWave wd = A.waves[ticket];
   const int cfi = A.pics[wd.pic].chroma_format_idc;
-  if (wd.comp == 0 || cfi == 3) { if (wd.comp == 0 || cfi) recon_rows<Pix, false>(A, wd, L, lane, (int)wd.comp); }   // luma; 4:4:4: one wave per plane
-  else if (cfi) recon_rows<Pix, true>(A, wd, L, lane, 1);                            // 4:2:0: comp 1 = Cb and Cr together
+  if (wd.comp == 0 || cfi == 3) { if (wd.comp == 0 || cfi) recon_rows<Pix, false, INTER>(A, wd, L, lane, (int)wd.comp); }   // luma; 4:4:4: one wave per plane
+  else if (cfi) recon_rows<Pix, true, INTER>(A, wd, L, lane, 1);                            // 4:2:0: comp 1 = Cb and Cr together
 }
 
 // 8-bit pictures: 7 waves per SIMD (<= 72 VGPRs; 6 KB of LDS per wave allows 26 per CU).  The 16-bit variant is limited by
 // its 10 KB of LDS per wave either way.
-__global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8(ReconArgs A) { recon_wave<uint8_t>(A); }
-__global__ __launch_bounds__(64) void k_recon16(ReconArgs A) { recon_wave<uint16_t>(A); }
+__global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8(ReconArgs A) { recon_wave<uint8_t, false>(A); }
+__global__ __launch_bounds__(64) void k_recon16(ReconArgs A) { recon_wave<uint16_t, false>(A); }
+// batches with P pictures (sequence tracks): inter coded blocks take their prediction from the plane (k_mc) instead of the intra predictor
+__global__ __launch_bounds__(64) void k_recon8_inter(ReconArgs A) { recon_wave<uint8_t, true>(A); }
+__global__ __launch_bounds__(64) void k_recon16_inter(ReconArgs A) { recon_wave<uint16_t, true>(A); }
 
-void launch_recon(const ReconArgs& a, bool wide, hipStream_t s)
+void launch_recon(const ReconArgs& a, bool wide, hipStream_t s, bool inter)
 {
   if (!a.num_waves) return;
-  if (wide) hipLaunchKernelGGL(k_recon16, dim3(a.num_waves), dim3(64), 0, s, a);
+  if (inter) {
+    if (wide) hipLaunchKernelGGL(k_recon16_inter, dim3(a.num_waves), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(k_recon8_inter, dim3(a.num_waves), dim3(64), 0, s, a);
+  } else if (wide) hipLaunchKernelGGL(k_recon16, dim3(a.num_waves), dim3(64), 0, s, a);
   else hipLaunchKernelGGL(k_recon8, dim3(a.num_waves), dim3(64), 0, s, a);
 }
 

@@ -32,7 +32,7 @@ int emu_run_pipeline_rgb(EmuBatch* b, int stages, uint8_t* rgb)
     launch_motion(ma, nullptr);
     launch_mc(fa, n, L.max_w, L.max_h, L.wide, nullptr);
   }
-  if (stages & 2) launch_recon(ra, L.wide, nullptr);
+  if (stages & 2) launch_recon(ra, L.wide, nullptr, L.any_inter);
   if (stages & 4) launch_deblock(fa, n, L.max_w, L.max_h, L.wide, nullptr);
   bool may_keep = false, restricted = false;   // as decoder.hip:launch_all picks the kernel variant
   for (const PicParams& P : L.params) {

@@ -1,7 +1,7 @@
-"""Intra-only image sequences through the decoder boundary (the part that needs no inter prediction): libheif pushes one
-sample per push_data2 with a user_data, polls decode_next_image2 for its frame, pushes the next (sequences/track_visual.cc:200-280,
-codecs/decoder.cc:355-563); only a chunk's first sample carries the parameter sets.  Checked at the C decoder object and at the plugin's own
-function table (the slots libheif calls), every frame against the oracle."""
+"""Image sequences through the decoder boundary: libheif pushes one sample per push_data2 with a user_data, polls
+decode_next_image2 for its frame, pushes the next (sequences/track_visual.cc:200-280, codecs/decoder.cc:355-563); only a chunk's first sample
+carries the parameter sets.  Intra-only tracks and tracks with P pictures (IPPP: skip / merge / AMVP, several reference pictures, AMP), checked
+at the C decoder object and at the plugin's own function table (the slots libheif calls), every frame against the oracle."""
 import ctypes as C
 import os
 import sys
@@ -93,6 +93,8 @@ def test_plugin_function_table_round_trips_user_data_per_sample():
     e = plug.new_decoder2(C.byref(dec), C.cast(C.byref(opts), vp))
     assert e.code == 0, e.message
     samples, refs = _samples(3)
+    p_aus, p_refs = _p_sequence(4, inter_num_refs=2, amp=1)      # then a track with P pictures through the same decoder instance
+    samples, refs = samples + p_aus, refs + p_refs
     try:
         for k, (s, ref) in enumerate(zip(samples, refs)):
             e = plug.push_data2(dec, s, len(s), 1000 + k)
@@ -112,8 +114,61 @@ def test_plugin_function_table_round_trips_user_data_per_sample():
         plug.free_decoder(dec)
 
 
-def test_inter_slices_are_refused_loudly():
-    """a P slice header (slice_type 1) in place of the I slice: UNSUPPORTED, not a mis-decode"""
+def _p_sequence(n, w=200, h=136, bit_depth=8, **cfg):
+    from test_inter_oracle import make_frames
+    frames = make_frames(w, h, n, bit_depth)
+    aus = orc.encode_sequence(frames, bit_depth=bit_depth, qp=cfg.pop("qp", 26), global_mv_x=-8, global_mv_y=-4, **cfg)
+    return aus, orc.decode_sequence(aus)
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(amp=1, inter_num_refs=3, max_merge_cand=3, parallel_merge_level=4, log2_ctb=4, log2_max_tb=4),
+                                 dict(stress=1, amp=1, inter_num_refs=2, lists_modification=1, cabac_init_present=1, num_slices=2, wpp=0),
+                                 dict(bit_depth=10, tile_cols=2, tile_rows=2, inter_num_refs=2), dict(w=70, h=42, amp=1, inter_num_refs=2, global_mv_y=17)],
+                         ids=["default", "amp_multiref_mer", "stress_slices_listmod", "main10_tiles", "cropped"])
+def test_p_pictures_decode_bit_exact_through_the_decoder_object(cfg):
+    """IPPP tracks: every sample pushed on its own (the first with the parameter sets), one frame per decode, planes == oracle"""
+    from libheif_amd.decoder import HipDecoder
+    cfg = dict(cfg)
+    aus, refs = _p_sequence(5, w=cfg.pop("w", 200), h=cfg.pop("h", 136), bit_depth=cfg.pop("bit_depth", 8), **cfg)
+    d = HipDecoder()
+    for k, (au, ref) in enumerate(zip(aus, refs)):
+        d.push_data(au)
+        img = d.decode_next_image()
+        assert img is not None and d.decode_next_image() is None
+        for c in range(3):
+            np.testing.assert_array_equal(img.planes[c], ref["planes"][c], err_msg="picture %d plane %d" % (k, c))
+    d.free()
+
+
+def test_two_tracks_decode_side_by_side():
+    """two decoder instances with their own reference pictures, samples interleaved (libheif decodes tracks independently)"""
+    from libheif_amd.decoder import HipDecoder
+    a_aus, a_refs = _p_sequence(4, seed=3)
+    b_aus, b_refs = _p_sequence(4, w=136, h=104, seed=9, inter_num_refs=2)
+    da, db = HipDecoder(), HipDecoder()
+    for k in range(4):
+        for d, aus, refs in ((da, a_aus, a_refs), (db, b_aus, b_refs)):
+            d.push_data(aus[k])
+            img = d.decode_next_image()
+            for c in range(3):
+                np.testing.assert_array_equal(img.planes[c], refs[k]["planes"][c])
+    da.free(); db.free()
+
+
+def test_p_picture_without_its_reference_is_an_error_not_a_misdecode():
+    from libheif_amd.decoder import HipDecoder
+    from libheif_amd import HipDecError
+    aus, _ = _p_sequence(3)
+    d = HipDecoder()
+    d.push_data(aus[0]); d.decode_next_image()
+    d.push_data(aus[2])                       # its RPS names POC 1, which was never pushed
+    with pytest.raises(HipDecError):
+        d.decode_next_image()
+    d.free()
+
+
+def test_inter_slices_outside_a_sequence_are_refused_loudly():
+    """a P slice header (slice_type 1) in place of the I slice of a still: UNSUPPORTED, not a mis-decode"""
     from libheif_amd.decoder import HipDecoder
     from libheif_amd import HipDecError
     s = orc.encode(orc.synth_image(64, 64, 8, 1, seed=3), wpp=0)
