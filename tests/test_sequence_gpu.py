@@ -117,7 +117,8 @@ def test_plugin_function_table_round_trips_user_data_per_sample():
 def _p_sequence(n, w=200, h=136, bit_depth=8, **cfg):
     from test_inter_oracle import make_frames
     frames = make_frames(w, h, n, bit_depth)
-    aus = orc.encode_sequence(frames, bit_depth=bit_depth, qp=cfg.pop("qp", 26), global_mv_x=-8, global_mv_y=-4, **cfg)
+    cfg = dict(cfg)
+    aus = orc.encode_sequence(frames, bit_depth=bit_depth, qp=cfg.pop("qp", 26), global_mv_x=cfg.pop("global_mv_x", -8), global_mv_y=cfg.pop("global_mv_y", -4), **cfg)
     return aus, orc.decode_sequence(aus)
 
 
