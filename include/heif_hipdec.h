@@ -232,6 +232,10 @@ HIPDEC_API int hipdec_grid_decode(hipdec_grid* g);                  /* asynchron
 HIPDEC_API int hipdec_grid_wait(hipdec_grid* g);                    /* waits for all shards; device-side errors */
 HIPDEC_API int hipdec_grid_canvas_plane(hipdec_grid* g, int c, const void** dptr, size_t* stride, int* device);
 HIPDEC_API int hipdec_grid_read_plane(hipdec_grid* g, int c, void* dst_host, size_t dst_stride);
+/* hipdec_grid_read_plane, and the host copy is remembered as device-resident (the canvas stays alive behind it until the entry is used):
+ * what the ImageItem_Grid fast path of libheif_amd/integration/image_ops_hip.cc fills the composed HeifPixelImage with, so that the colour
+ * conversion that follows (hipdec_color_convert) reads the canvas on the device */
+HIPDEC_API int hipdec_grid_read_plane_tracked(hipdec_grid* g, int c, void* dst_host, size_t dst_stride);
 /* the planner + fused colour stage over the canvas (hipdec_color_convert); out on the host, or on devices[0] */
 HIPDEC_API int hipdec_grid_to_rgb(hipdec_grid* g, int out_chroma, int upsampling, int only_preferred, void* out, size_t out_stride,
                                   int out_on_device);
@@ -374,6 +378,8 @@ HIPDEC_API int hipdec_plane_mirror(const void* in, size_t in_stride, int w, int 
 HIPDEC_API int hipdec_plane_crop(const void* in, size_t in_stride, int w, int h, int bytes_per_sample, int left, int top, int out_w, int out_h, void* out,
                                  size_t out_stride, void* stream);
 
+/* counters since load: images through hipdec_image_transform, grid canvases handed out by hipdec_grid_read_plane_tracked */
+HIPDEC_API void hipdec_image_ops_stats(uint64_t* transforms, uint64_t* grid_canvases);
 /* counters since load: conversions through hipdec_color_convert, input planes found device-resident, colour kernels launched */
 HIPDEC_API void hipdec_color_boundary_stats(uint64_t* conversions, uint64_t* resident_planes, uint64_t* kernel_launches);
 

@@ -1135,8 +1135,12 @@ struct ResidentPlane {
   size_t host_stride = 0;
   int w = 0, h = 0, bits = 0;
   uint64_t sample = 0;             // hash of EVERY byte of the host copy at hand-over time (plane_hash)
-  std::shared_ptr<hipdec_batch> batch;
+  std::shared_ptr<hipdec_batch> batch;   // a decoder's output plane: (batch, item, comp) ...
   int item = 0, comp = 0;
+  std::shared_ptr<void> buffer;           // ... or a plane of a device buffer this entry keeps alive (transform result, grid canvas)
+  const uint8_t* dev = nullptr;
+  size_t dev_stride = 0;
+  int device = 0;
   uint64_t tick = 0;
 };
 std::mutex g_res_mu;
@@ -1144,7 +1148,7 @@ std::mutex g_res_mu;
 //  run after the HIP runtime and this library's pools are gone; hipdec_shutdown() / the plugin's deinit empty it in good time)
 std::vector<ResidentPlane>& g_resident = *new std::vector<ResidentPlane>();
 uint64_t g_res_tick = 0;
-std::atomic<uint64_t> g_cb_conversions{0}, g_cb_resident{0}, g_cb_launches{0};
+std::atomic<uint64_t> g_cb_conversions{0}, g_cb_resident{0}, g_cb_launches{0}, g_xf_transforms{0}, g_grid_canvases{0};
 
 // Content identity of a host plane: EVERY byte of every row (64-bit lanes, four independent multiply-rotate chains, ~10 GB/s on one
 // host core).  libheif edits decoded planes in place between the plugin's hand-over and the colour conversion (mirror_inplace,
@@ -1181,6 +1185,8 @@ uint64_t plane_hash(const uint8_t* p, size_t stride, int w_bytes, int h)
 std::atomic<bool> g_track_planes{getenv("HIPDEC_TRACK_PLANES") ? atoi(getenv("HIPDEC_TRACK_PLANES")) != 0 : false};
 constexpr size_t kMaxResident = 6;
 
+void resident_insert(struct ResidentPlane&& r);
+
 void resident_note(hipdec_decoder* d, int c, const void* host, size_t stride)
 {
   if (!g_track_planes.load(std::memory_order_relaxed)) return;
@@ -1191,21 +1197,39 @@ void resident_note(hipdec_decoder* d, int c, const void* host, size_t stride)
   r.bits = c ? P.bit_depth_chroma : P.bit_depth_luma;
   r.sample = plane_hash((const uint8_t*)host, stride, r.w * (d->batch->wide ? 2 : 1), r.h);
   r.batch = d->batch; r.item = d->item; r.comp = c;
+  resident_insert(std::move(r));
+}
+
+void resident_insert(ResidentPlane&& r)
+{
   std::shared_ptr<hipdec_batch> evicted;   // dies outside the lock
+  std::shared_ptr<void> evicted_buffer;
   std::lock_guard<std::mutex> lock(g_res_mu);
   r.tick = ++g_res_tick;
-  for (auto& e : g_resident) if (e.host == host) { evicted = std::move(e.batch); e = r; return; }
+  for (auto& e : g_resident) if (e.host == r.host) { evicted = std::move(e.batch); evicted_buffer = std::move(e.buffer); e = std::move(r); return; }
   if (g_resident.size() >= kMaxResident) {
     size_t old = 0;
     for (size_t i = 1; i < g_resident.size(); i++) if (g_resident[i].tick < g_resident[old].tick) old = i;
-    evicted = std::move(g_resident[old].batch);
-    g_resident[old] = r;
-  } else g_resident.push_back(r);
+    evicted = std::move(g_resident[old].batch); evicted_buffer = std::move(g_resident[old].buffer);
+    g_resident[old] = std::move(r);
+  } else g_resident.push_back(std::move(r));
+}
+
+// a host plane that was just filled from a plane of `buffer` (w x h samples of `bits`, on the current device): a transform's result or the grid canvas
+void resident_note_buffer(const void* host, size_t stride, int w, int h, int bits, const uint8_t* dev, size_t dev_stride, std::shared_ptr<void> buffer)
+{
+  if (!g_track_planes.load(std::memory_order_relaxed)) return;
+  ResidentPlane r;
+  r.host = host; r.host_stride = stride; r.w = w; r.h = h; r.bits = bits;
+  r.sample = plane_hash((const uint8_t*)host, stride, w * (bits > 8 ? 2 : 1), h);
+  r.buffer = std::move(buffer); r.dev = dev; r.dev_stride = dev_stride;
+  (void)hipGetDevice(&r.device);
+  resident_insert(std::move(r));
 }
 
 // device copy of a host plane handed over by a decoder of this library, if the host plane still holds exactly those bytes; the entry
 // is consumed either way
-bool resident_find(const void* host, size_t stride, int w, int h, int bits, const uint8_t** dev, size_t* dev_stride, std::shared_ptr<hipdec_batch>& keep)
+bool resident_find(const void* host, size_t stride, int w, int h, int bits, const uint8_t** dev, size_t* dev_stride, std::shared_ptr<void>& keep)
 {
   g_track_planes.store(true, std::memory_order_relaxed);
   ResidentPlane r;
@@ -1216,8 +1240,16 @@ bool resident_find(const void* host, size_t stride, int w, int h, int bits, cons
       if (g_resident[i].host == host) { r = std::move(g_resident[i]); g_resident.erase(g_resident.begin() + (long)i); hit = true; break; }
     if (!hit) return false;
   }
-  if (r.host_stride != stride || r.w != w || r.h != h || r.bits != bits || r.batch->retired || !r.batch->arena) return false;
+  if (r.host_stride != stride || r.w != w || r.h != h || r.bits != bits) return false;
+  if (r.batch && (r.batch->retired || !r.batch->arena)) return false;
   if (plane_hash((const uint8_t*)host, stride, w * (bits > 8 ? 2 : 1), h) != r.sample) return false;
+  if (!r.batch) {
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != r.device) return false;
+    *dev = r.dev; *dev_stride = r.dev_stride; keep = r.buffer;
+    return true;
+  }
   const PicParams& P = r.batch->params[r.item];
   *dev = r.batch->arena + P.off_out[r.comp];
   *dev_stride = P.out_stride[r.comp];
@@ -1334,7 +1366,7 @@ int hipdec_color_convert(const hipdec_color_image* in, const hipdec_nclx* nclx, 
     // ---- the input planes on the device: the decoder's own copy when the host planes are still the ones it handed over
     const uint8_t* dp[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t ds[4] = {0, 0, 0, 0};
-    std::shared_ptr<hipdec_batch> keep[4];
+    std::shared_ptr<void> keep[4];
     for (int c = 0; c < 4; c++) {
       if (!in->plane[c]) continue;
       const int pw = (c == 0 || c == 3) ? w : cw, ph = (c == 0 || c == 3) ? h : ch;
@@ -1484,7 +1516,9 @@ int hipdec_image_transform(const hipdec_color_image* in, int op, const int* args
       rel.bufs.emplace_back(d, cap); *p = (uint8_t*)d;
       return 0;
     };
-    std::shared_ptr<hipdec_batch> keep[4];
+    std::shared_ptr<void> keep[4];
+    struct Result { int c, w, h; const uint8_t* dev; size_t dev_stride; std::shared_ptr<void> owner; };
+    std::vector<Result> results;
     for (int c = 0; c < 4; c++) {
       if (!in->plane[c]) continue;
       if ((c == 1 || c == 2) && !has_chroma) continue;
@@ -1513,7 +1547,16 @@ int hipdec_image_transform(const hipdec_color_image* in, int op, const int* args
       size_t dout_stride = out->stride[c];
       if (!out->on_device) {
         dout_stride = ((size_t)pow_ * es + 255) & ~(size_t)255;
-        if (int rc = scratch(dout_stride * poh, &dout)) return rc;
+        if (g_track_planes.load(std::memory_order_relaxed)) {
+          // the result stays on the device behind its host copy: the next transform or the colour conversion of this image reads it there
+          void* d = nullptr; size_t cap = 0;
+          HIPDEC_CHECK_HIP(arena_acquire(&d, dout_stride * poh ? dout_stride * poh : 256, &cap));
+          int dev_index = 0;
+          (void)hipGetDevice(&dev_index);
+          std::shared_ptr<void> owner(d, [cap, dev_index](void* q) { DeviceScope scope(dev_index); arena_release(q, cap); });
+          dout = (uint8_t*)d;
+          results.push_back(Result{c, pow_, poh, dout, dout_stride, std::move(owner)});
+        } else if (int rc = scratch(dout_stride * poh, &dout)) return rc;
       }
       int rc;
       if (op == HIPDEC_XF_ROTATE_CCW) rc = hipdec_plane_rotate_ccw(dp, ds, pw, ph, (int)es, args[0], dout, dout_stride, (void*)s);
@@ -1523,7 +1566,9 @@ int hipdec_image_transform(const hipdec_color_image* in, int op, const int* args
       if (!out->on_device) HIPDEC_CHECK_HIP(hipMemcpy2DAsync((void*)out->plane[c], out->stride[c], dout, dout_stride, (size_t)pow_ * es, poh, hipMemcpyDeviceToHost, s));
     }
     HIPDEC_CHECK_HIP(hipStreamSynchronize(s));
+    for (auto& r : results) resident_note_buffer(out->plane[r.c], out->stride[r.c], r.w, r.h, in->bit_depth, r.dev, r.dev_stride, std::move(r.owner));
     out->width = ow; out->height = oh; out->chroma = in->chroma; out->bit_depth = in->bit_depth;
+    g_xf_transforms++;
     return 0;
   });
 }
@@ -1568,8 +1613,9 @@ struct hipdec_grid {
       if (pasted[s]) (void)hipEventDestroy(pasted[s]);
       shard[s].reset();
     }
-    if (canvas) { DeviceScope scope(root); arena_release(canvas, canvas_capacity); }
+    canvas_owner.reset();   // (a host plane still registered as resident keeps the buffer until its entry is consumed)
   }
+  std::shared_ptr<void> canvas_owner;             // the canvas buffer; shared with the resident-plane registry (hipdec_grid_read_plane_tracked)
 };
 
 extern "C" {
@@ -1637,6 +1683,11 @@ int hipdec_grid_create(hipdec_grid** out, int rows, int cols, int out_width, int
       g->stride[1] = g->stride[2] = (cw * es + 255) & ~(size_t)255;
       g->off[1] = o; o += g->stride[1] * ch; g->off[2] = o; o += g->stride[2] * ch;
       HIPDEC_CHECK_HIP(arena_acquire((void**)&g->canvas, o ? o : 256, &g->canvas_capacity));
+      {
+        const size_t cap = g->canvas_capacity;
+        const int root = g->root;
+        g->canvas_owner = std::shared_ptr<void>(g->canvas, [cap, root](void* q) { DeviceScope scope(root); arena_release(q, cap); });
+      }
     }
     *out = g.release();
     return 0;
@@ -1739,6 +1790,26 @@ int hipdec_grid_read_plane(hipdec_grid* g, int c, void* dst_host, size_t dst_str
   const size_t w = ((size_t)g->out_w + sw - 1) / sw, h = ((size_t)g->out_h + sh - 1) / sh;
   HIPDEC_CHECK_HIP(hipMemcpy2D(dst_host, dst_stride, g->canvas + g->off[c], g->stride[c], w * es, h, hipMemcpyDeviceToHost));
   return 0;
+}
+
+// hipdec_grid_read_plane + the host plane registered as device-resident (the canvas stays alive behind it): the colour conversion of the
+// composed image then reads the canvas where it is instead of uploading it again
+int hipdec_grid_read_plane_tracked(hipdec_grid* g, int c, void* dst_host, size_t dst_stride)
+{
+  if (int rc = hipdec_grid_read_plane(g, c, dst_host, dst_stride)) return rc;
+  return guarded("grid_read_plane", [&]() -> int {
+    DeviceScope scope(g->root);
+    const int sw = c ? g->csw : 1, sh = c ? g->csh : 1;
+    resident_note_buffer(dst_host, dst_stride, (g->out_w + sw - 1) / sw, (g->out_h + sh - 1) / sh, g->bits, g->canvas + g->off[c], g->stride[c], g->canvas_owner);
+    if (c == 0) g_grid_canvases++;
+    return 0;
+  });
+}
+
+void hipdec_image_ops_stats(uint64_t* transforms, uint64_t* grid_canvases)
+{
+  if (transforms) *transforms = g_xf_transforms.load();
+  if (grid_canvases) *grid_canvases = g_grid_canvases.load();
 }
 
 int hipdec_grid_to_rgb(hipdec_grid* g, int out_chroma, int upsampling, int only_preferred, void* out, size_t out_stride, int out_on_device)

@@ -92,10 +92,36 @@ void announce_color_backend()
     hipdec_set_plane_tracking(1);   // this libheif converts on the GPU: keep decoded planes findable on the device (costs a hash pass per plane)
   }
 }
+// The same for the image-level hooks of that libheif (libheif_amd/integration/image_ops_hip.cc): 'irot' / 'imir' / 'clap' through
+// hipdec_image_transform, 'grid' items through hipdec_grid_*.  The table's layout is restated there.
+struct ImageOpsBackend {
+  int version;
+  int (*image_transform)(const hipdec_color_image*, int, const int*, hipdec_color_image*);
+  int (*grid_create)(hipdec_grid**, int, int, int, int, const void* const*, const size_t*, const int*, int, uint64_t);
+  void (*grid_free)(hipdec_grid*);
+  int (*grid_info)(const hipdec_grid*, hipdec_image_info*, int*);
+  int (*grid_decode)(hipdec_grid*);
+  int (*grid_wait)(hipdec_grid*);
+  int (*grid_read_plane_tracked)(hipdec_grid*, int, void*, size_t);
+  const char* (*last_error)(void);
+  const char* decoder_id;
+};
+const char kPluginId[] = "hipdec";
+void announce_image_ops_backend()
+{
+  using reg_fn = void (*)(const ImageOpsBackend*, int);
+  if (auto reg = (reg_fn)dlsym(RTLD_DEFAULT, "heif_image_ops_register_hip_backend")) {
+    static const ImageOpsBackend table = {1, hipdec_image_transform, hipdec_grid_create, hipdec_grid_free, hipdec_grid_info, hipdec_grid_decode,
+                                          hipdec_grid_wait, hipdec_grid_read_plane_tracked, hipdec_last_error, kPluginId};
+    reg(&table, hipdec_device_count() > 0 ? 1 : 0);
+    hipdec_set_plane_tracking(1);
+  }
+}
 void init_plugin()
 {
   std::call_once(g_api_once, resolve_api);
   announce_color_backend();
+  announce_image_ops_backend();
 }
 void deinit_plugin() { hipdec_forget_resident_planes(); }   // heif_deinit(): nothing of ours may outlive the host's use of the library
 int does_support_format(int format) { return format == HP_COMPRESSION_HEVC ? 200 /* above libde265's 100 */ : 0; }
@@ -221,7 +247,7 @@ const hp_decoder_plugin g_plugin = {
     push_data,
     decode_image,
     set_strict_decoding,
-    "hipdec",
+    kPluginId,
     decode_next_image,
     (1u << 24) | (22u << 16),  // LIBHEIF_MAKE_VERSION(1,22,0): first release with plugin API 6
     does_support_format2,

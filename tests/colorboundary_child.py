@@ -16,16 +16,27 @@ def main():
     hip = libheif_amd.load_library()
     hip.hipdec_color_boundary_stats.restype = None
     hip.hipdec_color_boundary_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
+    hip.hipdec_image_ops_stats.restype = None
+    hip.hipdec_image_ops_stats.argtypes = [C.POINTER(C.c_uint64)] * 2
     out = {}
     for j in jobs:
         data = open(j["heic"], "rb").read()
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         hip.hipdec_color_boundary_stats(C.byref(a), C.byref(b), C.byref(c))
         before = (a.value, b.value, c.value)
+        t, g = C.c_uint64(), C.c_uint64()
+        hip.hipdec_image_ops_stats(C.byref(t), C.byref(g))
+        ops_before = (t.value, g.value)
         res = lh.decode(data, j["colorspace"], j["chroma"], max_threads=j.get("threads"))
         hip.hipdec_color_boundary_stats(C.byref(a), C.byref(b), C.byref(c))
-        out[j["name"] + ".rgb"] = res["rgb"]
+        hip.hipdec_image_ops_stats(C.byref(t), C.byref(g))
+        if "rgb" in res:
+            out[j["name"] + ".rgb"] = res["rgb"]
+        else:
+            for k, p in enumerate(res["planes"]):
+                out[j["name"] + ".plane%d" % k] = p
         out[j["name"] + ".stats"] = np.array([a.value - before[0], b.value - before[1], c.value - before[2]], np.int64)
+        out[j["name"] + ".ops"] = np.array([t.value - ops_before[0], g.value - ops_before[1]], np.int64)   # transforms, grid canvases
     np.savez(sys.argv[2], **out)
 
 

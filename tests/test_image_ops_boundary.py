@@ -1,0 +1,123 @@
+"""The image-level hooks of the integration patch (libheif_amd/integration/image_ops_hip.cc) through the REAL libheif: the patched build
+(oracle/_ref/libheif_hipcolor.so: image_item.cc and grid.cc with the try-the-backend-first hooks) against the stock build, both with
+libheifhip.so as the HEVC decoder plugin, on the same files.
+
+  * 'irot' / 'imir' / 'clap' (ImageItem::decode_image, libheif/image-items/image_item.cc:958-1004): the patched build runs them through
+    hipdec_image_transform — counted — and the pixels heif_decode_image() returns are the stock build's, as planes and as RGB (where the
+    colour conversion behind the transformation finds the transformed planes on the device);
+  * 'grid' items (ImageItem_Grid::decode_full_grid_image, grid.cc:250-468): the patched build hands every tile stream to hipdec_grid_* in one
+    call — one canvas counted, no per-tile paste — and returns the stock build's image; grids outside the fast path (a tile with a
+    transformation of its own, odd geometry of the transformations) fall back to the stock code inside the same library."""
+import json
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from oracle import pyoracle as orc
+import heic_util as hu
+import libheif_host as lh
+
+SRGB = dict(vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1)
+
+
+def _run_child(libname, jobs, tmp_path):
+    jf, of = str(tmp_path / ("jobs_%s.json" % libname)), str(tmp_path / ("out_%s.npz" % libname))
+    json.dump(jobs, open(jf, "w"))
+    env = dict(os.environ, HIPDEC_TEST_LIBHEIF=libname, PYTHONPATH=os.pathsep.join([os.path.join(HERE, ".."), HERE]))
+    subprocess.run([sys.executable, os.path.join(HERE, "colorboundary_child.py"), jf, of], check=True, env=env, timeout=600)
+    return np.load(of)
+
+
+def test_the_patch_applies_to_the_reference_and_the_patched_build_exports_the_hooks():
+    if not os.path.isdir("/root/reference/libheif"):
+        pytest.skip("reference sources not present (GPU box)")
+    import ctypes
+    sys.path.insert(0, os.path.join(HERE, "..", "libheif_amd", "integration"))
+    import apply_patch
+    for which, rel in (("colorconversion", "color-conversion/colorconversion.cc"), ("image_item", "image-items/image_item.cc"),
+                       ("grid", "image-items/grid.cc")):
+        text = open(os.path.join("/root/reference/libheif", rel)).read()
+        for old, _ in apply_patch.EDITS[which]:
+            assert text.count(old) == 1, (which, old)
+    if lh.available("libheif_hipcolor.so"):
+        L = ctypes.CDLL(os.path.join(HERE, "..", "oracle", "_ref", "libheif_hipcolor.so"))
+        assert L.heif_image_ops_register_hip_backend and L.heif_color_conversion_register_hip_backend
+
+
+def _cases(tmp_path):
+    cases, expect = [], {}
+
+    def add(name, heic, chroma=lh.CHROMA_UNDEFINED, transforms=0, grids=0, threads=None):
+        path = str(tmp_path / (name + ".heic"))
+        open(path, "wb").write(heic)
+        cs = lh.COLORSPACE_UNDEFINED if chroma == lh.CHROMA_UNDEFINED else lh.COLORSPACE_RGB
+        cases.append(dict(name=name, heic=path, colorspace=cs, chroma=chroma, threads=threads))
+        expect[name] = (transforms, grids)
+
+    def still(w, h, seed, bit_depth=8, chroma=1, **kw):
+        return orc.encode(orc.synth_image(w, h, bit_depth, chroma, seed=seed), bit_depth=bit_depth, **kw)
+
+    s = still(200, 136, 41, **SRGB)
+    for k, xf in enumerate([[("irot", 1)], [("irot", 2)], [("irot", 3)], [("imir", 0)], [("imir", 1)], [("clap", (180, 120, 10, 8))]]):
+        add("xf%d_planes" % k, hu.build_heic([(s, 200, 136)], transforms=xf), transforms=1)
+        add("xf%d_rgb" % k, hu.build_heic([(s, 200, 136)], transforms=xf), lh.CHROMA_RGB, transforms=1)
+    # a chain: every step on the device, each reading the previous step's result where it already is
+    add("chain_rgb", hu.build_heic([(s, 200, 136)], transforms=[("clap", (160, 100, 20, 16)), ("irot", 1), ("imir", 1)]), lh.CHROMA_RGB, transforms=3)
+    s10 = still(264, 200, 42, bit_depth=10, vui_matrix=9, vui_primaries=9, vui_transfer=16)
+    add("main10_rot_planes", hu.build_heic([(s10, 264, 200)], bit_depth=10, transforms=[("irot", 3)]), transforms=1)
+    add("main10_rot_rrggbb", hu.build_heic([(s10, 264, 200)], bit_depth=10, transforms=[("irot", 3)]), lh.CHROMA_RRGGBB_LE, transforms=1)
+    s444 = still(200, 136, 43, chroma=3, **SRGB)
+    add("444_odd_crop_rgb", hu.build_heic([(s444, 200, 136)], chroma_format_idc=3, transforms=[("clap", (151, 99, 7, 5))]), lh.CHROMA_RGB, transforms=1)
+    mono = still(200, 136, 44, chroma=0)
+    add("mono_mirror_planes", hu.build_heic([(mono, 200, 136, 0)], chroma_format_idc=0, transforms=[("imir", 1)]), transforms=1)
+    # geometry the reference converts to 4:4:4 first: declined by the backend, the stock member function runs inside the patched build
+    add("odd_crop_rgb", hu.build_heic([(s, 200, 136)], transforms=[("clap", (151, 99, 7, 5))]), lh.CHROMA_RGB, transforms=0)
+
+    tiles = [(still(128, 128, 50 + i, **SRGB), 128, 128) for i in range(6)]
+    add("grid_planes", hu.build_heic(tiles, grid=(2, 3, 380, 250)), grids=1, threads=6)
+    add("grid_rgb", hu.build_heic(tiles, grid=(2, 3, 380, 250)), lh.CHROMA_RGB, grids=1, threads=6)
+    add("grid_rgb_single_thread", hu.build_heic(tiles, grid=(2, 3, 384, 256)), lh.CHROMA_RGB, grids=1, threads=0)
+    add("grid_rot_rgb", hu.build_heic(tiles, grid=(2, 3, 380, 250), transforms=[("irot", 1)]), lh.CHROMA_RGB, transforms=1, grids=1)
+    # (an odd size of a 4:2:0 image only comes out of a grid or a 'clap': the composed image is the device's, its rotation the stock code's)
+    add("grid_odd_rot_planes", hu.build_heic(tiles, grid=(2, 3, 379, 249), transforms=[("irot", 1)]), transforms=0, grids=1)
+    t10 = [(still(128, 64, 60 + i, bit_depth=10, vui_matrix=9, vui_primaries=9, vui_transfer=16), 128, 64) for i in range(4)]
+    add("grid_main10_rrggbb", hu.build_heic(t10, grid=(2, 2, 250, 120), bit_depth=10), lh.CHROMA_RRGGBB_BE, grids=1)
+    tm = [(still(64, 64, 70 + i, chroma=0), 64, 64, 0) for i in range(4)]
+    add("grid_mono_planes", hu.build_heic(tm, grid=(2, 2, 120, 128), chroma_format_idc=0), grids=1)
+
+    return cases, expect
+
+
+@pytest.mark.skipif(not lh.available(), reason="oracle/_ref/libheif.so not built")
+def test_the_test_files_are_what_the_reference_reads_them_as(tmp_path):
+    """(CPU) every synthetic file of the GPU test opens in the stock libheif with the transformed / composed size"""
+    cases, _ = _cases(tmp_path)
+    sizes = {c["name"]: lh.primary_size(open(c["heic"], "rb").read()) for c in cases}
+    assert sizes["xf0_planes"] == (136, 200) and sizes["xf5_rgb"] == (180, 120) and sizes["chain_rgb"] == (100, 160)
+    assert sizes["grid_odd_rot_planes"] == (249, 379) and sizes["grid_rot_rgb"] == (250, 380) and sizes["grid_mono_planes"] == (120, 128)
+    assert len(cases) == 25
+
+
+@pytest.mark.gpu
+def test_transformations_and_grids_run_on_the_device_inside_libheif_and_match_the_stock_build(tmp_path):
+    if not (lh.available("libheif.so") and lh.available("libheif_hipcolor.so")):
+        pytest.fail("oracle/_ref libraries missing on the GPU box")
+    cases, expect = _cases(tmp_path)
+    stock = _run_child("libheif.so", cases, tmp_path)
+    hipc = _run_child("libheif_hipcolor.so", cases, tmp_path)
+    for c in cases:
+        n = c["name"]
+        keys = sorted(k for k in stock.files if k.startswith(n + ".") and not k.endswith((".stats", ".ops")))
+        assert keys, n
+        for k in keys:
+            np.testing.assert_array_equal(hipc[k], stock[k], err_msg=k)
+        assert tuple(int(v) for v in stock[n + ".ops"]) == (0, 0), n          # the stock build has no hooks
+        assert tuple(int(v) for v in hipc[n + ".ops"]) == expect[n], (n, hipc[n + ".ops"], expect[n])
+        if c["chroma"] != lh.CHROMA_UNDEFINED and (expect[n][0] or expect[n][1]):
+            conv, resident, launches = [int(v) for v in hipc[n + ".stats"]]
+            # the colour conversion behind a device-side transformation / grid reads that result on the device: nothing is uploaded again
+            assert conv == 1 and resident >= 3, (n, conv, resident, launches)
