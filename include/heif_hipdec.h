@@ -154,6 +154,11 @@ HIPDEC_API int hipdec_set_stage_overlap(int on);
  * batch needs all its waves resident, so concurrent batches share the device's wave slots. */
 HIPDEC_API int hipdec_set_concurrent_batches(int n);
 
+/* Wave slots per SIMD (0 .. 4, default 0) the CABAC work pools leave free.  The pool's waves are resident for a whole launch set, so a host
+ * that runs image-level kernels beside decoding - libheif with the colour / transformation hooks: the plugin sets 1 when it announces them -
+ * keeps room for those, at 2 - 3 % of the parse rate; HIPDEC_RESERVED_WAVE_SLOTS overrides. */
+HIPDEC_API int hipdec_set_reserved_wave_slots(int per_simd);
+
 /* ---- batch decode (grid tiles / throughput mode) ------------------------------------------- */
 typedef struct hipdec_batch hipdec_batch;
 /* Parses n independent items (same framing as push_data; host worker threads for large batches) and uploads them; all

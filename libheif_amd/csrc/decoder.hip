@@ -719,8 +719,10 @@ struct Coalescer {
   Clock::time_point last_arrival{}, last_overlap{};
   long window_us = -1, quiet_us = 300;
   long busy_requests = 16;               // a leader keeps gathering while max_sets launch sets with more requests than this are running ...
-  long hold_us = 300000;                 // ... for at most this long (HIPDEC_COALESCE_BUSY / HIPDEC_COALESCE_HOLD_US; 1 s in round 3: a lone still that
-                                         // arrived behind a holding leader waited that long)
+  long hold_us = 1000000;                // ... for at most this long (HIPDEC_COALESCE_BUSY / HIPDEC_COALESCE_HOLD_US).  The hold only happens while max_sets big
+                                         // sets occupy the GPU, i.e. when a new set could not start earlier anyway; 300 ms (tried in round 4 for ADVICE round 3's
+                                         // "a lone still behind a holding leader waits that long") launches small extra sets instead and costs throughput:
+                                         // 2.56 / 4.68 against 2.88 / 5.66 Gpixel/s through libheif with 256 / 1024 threads (profiles/r04_dropin_throughput.txt)
   int max_sets = 3;                      // launch sets in flight before a leader holds (HIPDEC_COALESCE_SETS): they overlap, each with a third of the pool
                                          // waves (measured, direct C ABI, 256 / 1024 threads: 3.8 / 7.4 Gpixel/s with 2, 4.2 / 7.9 with 3, 3.5 / 7.7 with 4)
   long max_set = 256;                    // requests per launch set at most (HIPDEC_COALESCE_MAX_SET): keeps the sets' arenas and staging buffers in a
@@ -1187,6 +1189,49 @@ constexpr size_t kMaxResident = 6;
 
 void resident_insert(struct ResidentPlane&& r);
 
+// Device rows -> a host buffer the caller owns (libheif's image planes: pageable memory).  A direct hipMemcpy2DAsync to pageable memory is
+// staged by the runtime behind a process-wide lock at a few GB/s - with hundreds of application threads converting at once that was the whole
+// drop-in RGB throughput (0.4 Gpixel/s at 1024 threads) - so the copy goes to pinned staging at link speed and the calling thread moves the rows
+// itself (the threads do that in parallel).  Synchronises the stream.
+// ... and it waits for its stream with a blocking event instead of hipStreamSynchronize's spin: the kernels of an image-level call queue up
+// behind the resident CABAC pools of the decoder's launch sets (hundreds of ms under load), and a thousand application threads spinning
+// through that starve the threads that feed the decoder (measured through libheif, 1024 threads x 4K stills to RGB: 0.36 Gpixel/s with
+// launch sets of 10 stills).  (Admitting only a few callers at a time was tried and is worse - 0.17: each of them still waits for a
+// pool to drain, so the waits have to overlap.)
+hipError_t wait_stream_blocking(hipStream_t s)
+{
+  struct Ev { hipEvent_t e = nullptr; int device = -1; ~Ev() { if (e) (void)hipEventDestroy(e); } };
+  static thread_local Ev ev;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (ev.e && ev.device != dev) { (void)hipEventDestroy(ev.e); ev.e = nullptr; }
+  if (!ev.e) {
+    if (hipEventCreateWithFlags(&ev.e, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev.e = nullptr; return hipStreamSynchronize(s); }
+    ev.device = dev;
+  }
+  hipError_t e = hipEventRecord(ev.e, s);
+  return e == hipSuccess ? hipEventSynchronize(ev.e) : e;
+}
+
+int copy_rows_to_host(void* dst, size_t dst_stride, const void* dsrc, size_t src_stride, size_t row_bytes, int rows, hipStream_t s)
+{
+  void* pin = nullptr; size_t cap = 0;
+  const size_t bytes = row_bytes * (size_t)rows;
+  if (bytes >= (64u << 10) && pinned_acquire(&pin, bytes, &cap) == hipSuccess) {
+    hipError_t e = hipMemcpy2DAsync(pin, row_bytes, dsrc, src_stride, row_bytes, (size_t)rows, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = wait_stream_blocking(s);
+    if (e != hipSuccess) { pinned_release(pin, cap); return set_error(HIPDEC_ERR_DEVICE, "copy to host: %s", hipGetErrorString(e)); }
+    if (dst_stride == row_bytes) memcpy(dst, pin, bytes);
+    else for (int y = 0; y < rows; y++) memcpy((uint8_t*)dst + (size_t)y * dst_stride, (const uint8_t*)pin + (size_t)y * row_bytes, row_bytes);
+    pinned_release(pin, cap);
+    return 0;
+  }
+  (void)hipGetLastError();
+  HIPDEC_CHECK_HIP(hipMemcpy2DAsync(dst, dst_stride, dsrc, src_stride, row_bytes, (size_t)rows, hipMemcpyDeviceToHost, s));
+  HIPDEC_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 void resident_note(hipdec_decoder* d, int c, const void* host, size_t stride)
 {
   if (!g_track_planes.load(std::memory_order_relaxed)) return;
@@ -1455,8 +1500,8 @@ int hipdec_color_convert(const hipdec_color_image* in, const hipdec_nclx* nclx, 
     }
     if (rc) return rc;
     g_cb_launches++;
-    if (!out_on_device) HIPDEC_CHECK_HIP(hipMemcpy2DAsync(out, out_stride, dout, dout_stride, (size_t)w * out_bpp, h, hipMemcpyDeviceToHost, s));
-    HIPDEC_CHECK_HIP(hipStreamSynchronize(s));
+    if (!out_on_device) { if (int rc2 = copy_rows_to_host(out, out_stride, dout, dout_stride, (size_t)w * out_bpp, h, s)) return rc2; }
+    else HIPDEC_CHECK_HIP(hipStreamSynchronize(s));
     g_cb_conversions++;
     return 0;
   });
@@ -1563,7 +1608,7 @@ int hipdec_image_transform(const hipdec_color_image* in, int op, const int* args
       else if (op == HIPDEC_XF_MIRROR) rc = hipdec_plane_mirror(dp, ds, pw, ph, (int)es, args[0], dout, dout_stride, (void*)s);
       else rc = hipdec_plane_crop(dp, ds, pw, ph, (int)es, pl, pt, pow_, poh, dout, dout_stride, (void*)s);
       if (rc) return rc;
-      if (!out->on_device) HIPDEC_CHECK_HIP(hipMemcpy2DAsync((void*)out->plane[c], out->stride[c], dout, dout_stride, (size_t)pow_ * es, poh, hipMemcpyDeviceToHost, s));
+      if (!out->on_device) { if (int rc2 = copy_rows_to_host((void*)out->plane[c], out->stride[c], dout, dout_stride, (size_t)pow_ * es, poh, s)) return rc2; }
     }
     HIPDEC_CHECK_HIP(hipStreamSynchronize(s));
     for (auto& r : results) resident_note_buffer(out->plane[r.c], out->stride[r.c], r.w, r.h, in->bit_depth, r.dev, r.dev_stride, std::move(r.owner));
@@ -1788,8 +1833,7 @@ int hipdec_grid_read_plane(hipdec_grid* g, int c, void* dst_host, size_t dst_str
   const size_t es = g->bits > 8 ? 2 : 1;
   const size_t sw = c ? (size_t)g->csw : 1, sh = c ? (size_t)g->csh : 1;
   const size_t w = ((size_t)g->out_w + sw - 1) / sw, h = ((size_t)g->out_h + sh - 1) / sh;
-  HIPDEC_CHECK_HIP(hipMemcpy2D(dst_host, dst_stride, g->canvas + g->off[c], g->stride[c], w * es, h, hipMemcpyDeviceToHost));
-  return 0;
+  return copy_rows_to_host(dst_host, dst_stride, g->canvas + g->off[c], g->stride[c], w * es, (int)h, default_stream());
 }
 
 // hipdec_grid_read_plane + the host plane registered as device-resident (the canvas stays alive behind it): the colour conversion of the

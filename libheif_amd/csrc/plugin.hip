@@ -90,6 +90,7 @@ void announce_color_backend()
   if (auto reg = (reg_fn)dlsym(RTLD_DEFAULT, "heif_color_conversion_register_hip_backend")) {
     reg(hipdec_color_plan, hipdec_color_convert, hipdec_last_error, hipdec_device_count() > 0 ? 1 : 0);
     hipdec_set_plane_tracking(1);   // this libheif converts on the GPU: keep decoded planes findable on the device (costs a hash pass per plane)
+    hipdec_set_reserved_wave_slots(1);   // ... and keep a wave slot per SIMD for those kernels beside the resident CABAC pools
   }
 }
 // The same for the image-level hooks of that libheif (libheif_amd/integration/image_ops_hip.cc): 'irot' / 'imir' / 'clap' through
@@ -115,6 +116,7 @@ void announce_image_ops_backend()
                                           hipdec_grid_wait, hipdec_grid_read_plane_tracked, hipdec_last_error, kPluginId};
     reg(&table, hipdec_device_count() > 0 ? 1 : 0);
     hipdec_set_plane_tracking(1);
+    hipdec_set_reserved_wave_slots(1);
   }
 }
 void init_plugin()

@@ -24,6 +24,8 @@ static DeviceStreams g_streams[kMaxDevices];   // created on first use of a devi
 static std::mutex g_streams_mu;
 static int g_cu_count = 256;                 // compute units of the selected device
 static std::atomic<int> g_concurrent{1};      // batches the host keeps in flight at a time (hipdec_set_concurrent_batches)
+static std::atomic<int> g_reserved_slots{getenv("HIPDEC_RESERVED_WAVE_SLOTS") ? atoi(getenv("HIPDEC_RESERVED_WAVE_SLOTS")) : 0};   // wave slots per SIMD the
+                                              // CABAC pools leave free (hipdec_set_reserved_wave_slots)
 
 int set_error(int code, const char* fmt, ...)
 {
@@ -94,7 +96,12 @@ bool stage_overlap() { return g_stage_overlap.load(std::memory_order_relaxed) !=
 uint32_t parse_wave_budget()
 {
   const int c = g_concurrent.load(std::memory_order_relaxed);
-  const uint32_t slots = (uint32_t)g_cu_count * 4u * 8u;   // k_parse_occ8: 64 VGPRs, 8 waves per SIMD
+  // k_parse_occ8: 64 VGPRs, 8 waves per SIMD.  A host that runs image-level kernels (colour conversion, transformations) beside decoding keeps
+  // one of them free: the pool's waves are resident for the whole launch set, and a small kernel queued behind a full chip waits for the
+  // set to end (measured, tools/concurrency_probe.py: one 4K colour conversion 354 ms beside an 8-per-SIMD pool, 2 ms beside a 7-per-SIMD one)
+  int reserved = g_reserved_slots.load(std::memory_order_relaxed);
+  reserved = reserved < 0 ? 0 : (reserved > 4 ? 4 : reserved);
+  const uint32_t slots = (uint32_t)g_cu_count * 4u * (uint32_t)(8 - reserved);
   return slots / (uint32_t)(c < 1 ? 1 : c);
 }
 
@@ -371,6 +378,13 @@ int hipdec_set_concurrent_batches(int n)
 {
   if (n < 1 || n > 64) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "set_concurrent_batches: n must be in [1, 64]");
   g_concurrent.store(n, std::memory_order_relaxed);
+  return 0;
+}
+
+int hipdec_set_reserved_wave_slots(int per_simd)
+{
+  if (per_simd < 0 || per_simd > 4) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "set_reserved_wave_slots: 0 .. 4 wave slots per SIMD");
+  if (!getenv("HIPDEC_RESERVED_WAVE_SLOTS")) g_reserved_slots.store(per_simd, std::memory_order_relaxed);
   return 0;
 }
 

@@ -15,6 +15,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <future>
 #include <mutex>
 #include <vector>
 
@@ -280,16 +281,11 @@ std::shared_ptr<HeifPixelImage> decode_grid(const ImageItem_Grid& grid_item, con
     return nullptr;   // the stock loop turns this into heif_error_Canceled
   }
 
-  // --- tile 0 through the ordinary path: the composed image takes its format and every piece of metadata from that image
-  //     (decode_and_paste_tile_image, grid.cc:531-556: create_clone_image_at_new_size + copy_metadata_from)
+  // --- tile 0 through the ordinary path, concurrently with the grid decode below: the composed image takes its format and every piece
+  //     of metadata from that image (decode_and_paste_tile_image, grid.cc:531-556: create_clone_image_at_new_size + copy_metadata_from)
 
-  auto first = tiles[0]->decode_image(options, false, 0, 0, processed_ids);
-  if (!first || !*first) return nullptr;
-  const std::shared_ptr<HeifPixelImage>& tile_img = *first;
-  hipdec_color_image fmt;
-  if (!describe(*tile_img, &fmt) || tile_img->get_width() != tile_w || tile_img->get_height() != tile_h) {
-    return nullptr;
-  }
+  auto first_future = std::async(std::launch::async, [&]() { return tiles[0]->decode_image(options, false, 0, 0, processed_ids); });
+  struct Join { std::future<Result<std::shared_ptr<HeifPixelImage>>>& f; ~Join() { if (f.valid()) f.wait(); } } join_first{first_future};
 
   // --- all tiles on the GPUs of this node, pasted into one canvas on the device
 
@@ -307,13 +303,25 @@ std::shared_ptr<HeifPixelImage> decode_grid(const ImageItem_Grid& grid_item, con
 
   hipdec_image_info info{};
   int shards = 0;
-  if (api.grid_info(g, &info, &shards) != 0 || info.coded_width != (int) (tile_w * grid.get_columns()) ||
+  if (api.grid_info(g, &info, &shards) != 0 || api.grid_decode(g) != 0) {
+    return nullptr;
+  }
+
+  auto first = first_future.get();
+  if (!first || !*first) return nullptr;
+  const std::shared_ptr<HeifPixelImage>& tile_img = *first;
+  hipdec_color_image fmt;
+  if (!describe(*tile_img, &fmt) || tile_img->get_width() != tile_w || tile_img->get_height() != tile_h) {
+    return nullptr;
+  }
+
+  if (info.coded_width != (int) (tile_w * grid.get_columns()) ||
       info.coded_height != (int) (tile_h * grid.get_rows()) || info.chroma_format_idc != fmt.chroma || info.bit_depth_luma != fmt.bit_depth ||
       (fmt.chroma && info.bit_depth_chroma != fmt.bit_depth)) {
     return nullptr;   // tiles that differ from their 'ispe' / from tile 0: the stock loop reports it
   }
 
-  if (api.grid_decode(g) != 0 || api.grid_wait(g) != 0) {
+  if (api.grid_wait(g) != 0) {
     return nullptr;
   }
 

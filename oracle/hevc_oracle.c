@@ -88,9 +88,9 @@ const uint8_t hevc_cabac_init_I[CTX_COUNT] = {
   182, 140, 227, 122, 197,
   /* coeff_abs_level_greater2_flag */ 138, 153, 136, 167, 152, 152,
   /* cbf_cb, cbf_cr ctxInc 4 */ 154,
-  /* (contexts of P slices: unused in I slices) */ 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154};
+  /* (contexts of P / B slices: unused in I slices) */ 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154};
 
-/* initValue for initType 1 and 2 (P and B slices; a P slice takes initType 2 when cabac_init_flag is set, else 1), Tables 9-5 .. 9-37 */
+/* initValue for initType 1 and 2 (P and B slices: a P slice takes initType 1, a B slice 2; cabac_init_flag swaps them), Tables 9-5 .. 9-37 */
 const uint8_t hevc_cabac_init_P[2][CTX_COUNT] = {
  {/* sao_merge */ 153, /* sao_type_idx */ 185, /* split_cu_flag */ 107, 139, 126, /* cu_transquant_bypass_flag */ 154,
   /* part_mode bin 0 */ 154, /* prev_intra_luma_pred_flag */ 154, /* intra_chroma_pred_mode */ 152,
@@ -110,7 +110,7 @@ const uint8_t hevc_cabac_init_P[2][CTX_COUNT] = {
   /* cbf_cb, cbf_cr ctxInc 4 */ 154,
   /* cu_skip_flag */ 197, 185, 201, /* pred_mode_flag */ 149, /* part_mode bins 1, 2 (min CB), 2 (AMP) */ 139, 154, 154,
   /* merge_flag */ 110, /* merge_idx */ 122, /* ref_idx */ 153, 153, /* abs_mvd_greater0_flag */ 140, /* abs_mvd_greater1_flag */ 198,
-  /* mvp_flag */ 168, /* rqt_root_cbf */ 79},
+  /* mvp_flag */ 168, /* rqt_root_cbf */ 79, /* inter_pred_idc */ 95, 79, 63, 31, 31},
  {/* sao_merge */ 153, /* sao_type_idx */ 160, /* split_cu_flag */ 107, 139, 126, /* cu_transquant_bypass_flag */ 154,
   /* part_mode bin 0 */ 154, /* prev_intra_luma_pred_flag */ 183, /* intra_chroma_pred_mode */ 152,
   /* split_transform_flag */ 224, 167, 122, /* cbf_luma */ 153, 111, /* cbf_cb, cbf_cr */ 149, 92, 167, 154,
@@ -129,7 +129,7 @@ const uint8_t hevc_cabac_init_P[2][CTX_COUNT] = {
   /* cbf_cb, cbf_cr ctxInc 4 */ 154,
   /* cu_skip_flag */ 197, 185, 201, /* pred_mode_flag */ 134, /* part_mode bins 1, 2 (min CB), 2 (AMP) */ 139, 154, 154,
   /* merge_flag */ 154, /* merge_idx */ 137, /* ref_idx */ 153, 153, /* abs_mvd_greater0_flag */ 169, /* abs_mvd_greater1_flag */ 198,
-  /* mvp_flag */ 168, /* rqt_root_cbf */ 79}};
+  /* mvp_flag */ 168, /* rqt_root_cbf */ 79, /* inter_pred_idc */ 95, 79, 63, 31, 31}};
 
 static const int8_t intraPredAngle[35] = {0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13,
   -17, -21, -26, -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32};
@@ -305,7 +305,7 @@ typedef struct {
   int pps_scaling_list_data_present_flag;
   ScalingList sl;
   int lists_modification_present_flag, log2_parallel_merge_level;
-  int num_ref_idx_l0_default_active, weighted_pred_flag;
+  int num_ref_idx_l0_default_active, num_ref_idx_l1_default_active, weighted_pred_flag, weighted_bipred_flag;
   int slice_segment_header_extension_present_flag;
 } PPS;
 
@@ -319,10 +319,14 @@ typedef struct {
   uint32_t* entry_point_offset; /* in NAL bytes (emulation prevention bytes counted) */
   int SliceAddrRs;
   int SliceQpY;
-  /* P slices */
-  int num_ref_idx_l0_active, max_num_merge_cand, cabac_init_flag;
-  int8_t ref_list0[16];   /* RefPicList0: indices into Dec::dpb */
-  int32_t ref_poc0[16];
+  /* P / B slices */
+  int num_ref_idx_l0_active, num_ref_idx_l1_active, max_num_merge_cand, cabac_init_flag;
+  int mvd_l1_zero_flag, slice_temporal_mvp, collocated_from_l0, collocated_ref_idx;
+  int8_t ref_list[2][16];   /* RefPicList0 / 1: indices into Dec::dpb */
+  int32_t ref_poc[2][16];
+  /* pred_weight_table (7.3.6.3): weighted = the explicit process applies to this slice */
+  int weighted, luma_log2_wd, chroma_log2_wd;
+  int16_t wp_weight[2][16][3], wp_offset[2][16][3];   /* [list][refIdx][cIdx]; offsets before the bit-depth scaling */
 } SliceHdr;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -340,7 +344,10 @@ typedef struct {
 /* decoder state                                                                              */
 /* ------------------------------------------------------------------------------------------ */
 #define MAX_DPB 17
-typedef struct { uint16_t* plane[3]; int poc; int valid; } RefPic;   /* a decoded picture (after deblocking and SAO, coded size) */
+typedef struct {   /* a decoded picture (after deblocking and SAO, coded size) and the motion it was predicted with (for TMVP) */
+  uint16_t* plane[3]; int poc; int valid;
+  uint8_t* m_pred; int16_t* mf_mv; int8_t* mf_ref; int32_t* mf_poc;
+} RefPic;
 
 struct Dec {
   jmp_buf jb;
@@ -398,7 +405,8 @@ struct Dec {
   int poc, prev_tid0_lsb, prev_tid0_msb;
   int st_curr_before[16], st_curr_after[16], n_st_curr_before, n_st_curr_after;   /* RefPicSetStCurrBefore / After as dpb indices */
   uint8_t* m_pred;               /* per 4x4 unit: 0 MODE_INTRA, 1 MODE_INTER, 2 MODE_SKIP; NULL in a single intra picture */
-  int16_t* mf_mv; int8_t* mf_ref; int32_t* mf_poc;   /* mvL0, refIdxL0 and the POC of that reference picture, per 4x4 unit */
+  int16_t* mf_mv; int8_t* mf_ref; int32_t* mf_poc;   /* per 4x4 unit: mvL0, mvL1 (4 values), refIdxL0 / L1 (-1: list not used) and the POCs of
+                                                        those reference pictures */
   int cu_pred_inter;             /* CuPredMode of the coding unit being decoded != MODE_INTRA */
   int seq_mode;                  /* hevc_oracle_seq: several pictures, P slices allowed */
 };
@@ -722,8 +730,9 @@ static void parse_pps(Dec* d, const uint8_t* rbsp, size_t n)
   p->num_extra_slice_header_bits = br_u(&b, 3);
   p->sign_data_hiding_enabled_flag = br_u(&b, 1);
   p->cabac_init_present_flag = br_u(&b, 1);
-  p->num_ref_idx_l0_default_active = (int)br_ue(&b) + 1; br_ue(&b);
-  if (p->num_ref_idx_l0_default_active > 15) fail(d, "num_ref_idx_l0_default_active_minus1 out of range");
+  p->num_ref_idx_l0_default_active = (int)br_ue(&b) + 1;
+  p->num_ref_idx_l1_default_active = (int)br_ue(&b) + 1;
+  if (p->num_ref_idx_l0_default_active > 15 || p->num_ref_idx_l1_default_active > 15) fail(d, "num_ref_idx_lX_default_active_minus1 out of range");
   p->init_qp_minus26 = br_se(&b);
   p->constrained_intra_pred_flag = br_u(&b, 1);
   p->transform_skip_enabled_flag = br_u(&b, 1);
@@ -732,7 +741,7 @@ static void parse_pps(Dec* d, const uint8_t* rbsp, size_t n)
   p->pps_cb_qp_offset = br_se(&b);
   p->pps_cr_qp_offset = br_se(&b);
   p->pps_slice_chroma_qp_offsets_present_flag = br_u(&b, 1);
-  p->weighted_pred_flag = br_u(&b, 1); br_u(&b, 1); /* weighted_pred_flag, weighted_bipred_flag */
+  p->weighted_pred_flag = br_u(&b, 1); p->weighted_bipred_flag = br_u(&b, 1);
   p->transquant_bypass_enabled_flag = br_u(&b, 1);
   p->tiles_enabled_flag = br_u(&b, 1);
   p->entropy_coding_sync_enabled_flag = br_u(&b, 1);
@@ -802,9 +811,9 @@ static void setup_picture(Dec* d)
   d->m_flags = (uint8_t*)xcalloc(d, mn, 1); d->m_ctdepth = (uint8_t*)xcalloc(d, mn, 1);
   d->m_qp = (int8_t*)xcalloc(d, mn, 1); d->m_decoded = (uint8_t*)xcalloc(d, mn, 1);
   if (d->seq_mode) {
-    d->m_pred = (uint8_t*)xcalloc(d, mn, 1); d->mf_mv = (int16_t*)xcalloc(d, mn * 2, sizeof(int16_t));
-    d->mf_ref = (int8_t*)xcalloc(d, mn, 1); d->mf_poc = (int32_t*)xcalloc(d, mn, sizeof(int32_t));
-    memset(d->mf_ref, -1, mn);
+    d->m_pred = (uint8_t*)xcalloc(d, mn, 1); d->mf_mv = (int16_t*)xcalloc(d, mn * 4, sizeof(int16_t));
+    d->mf_ref = (int8_t*)xcalloc(d, mn * 2, 1); d->mf_poc = (int32_t*)xcalloc(d, mn * 2, sizeof(int32_t));
+    memset(d->mf_ref, -1, mn * 2);
   }
   d->ctbW = s->PicWidthInCtbsY; d->ctbH = s->PicHeightInCtbsY; d->nCtb = d->ctbW * d->ctbH;
   d->CtbAddrRsToTs = (int*)xcalloc(d, d->nCtb, sizeof(int));
@@ -893,7 +902,9 @@ static void cabac_init_contexts(Dec* d)
 {
   int qp = Clip3(0, 51, d->sh->SliceQpY);
   /* 9.3.2.2: initType 0 for I slices; P slices: cabac_init_flag ? 2 : 1 */
-  const uint8_t* tab = d->sh->slice_type == 2 ? hevc_cabac_init_I : hevc_cabac_init_P[d->sh->cabac_init_flag ? 1 : 0];
+  /* 9.3.2.2: initType 0 for I, 1 for P and 2 for B slices; cabac_init_flag swaps the latter two */
+  const uint8_t* tab = d->sh->slice_type == 2 ? hevc_cabac_init_I
+                     : hevc_cabac_init_P[(d->sh->slice_type == 1) == (d->sh->cabac_init_flag != 0) ? 1 : 0];
   for (int i = 0; i < MAXCTX; i++) {
     int initValue = tab[i];
     int slopeIdx = initValue >> 4, offsetIdx = initValue & 15;
@@ -1688,7 +1699,7 @@ static void inter_coding_unit(Dec* d, CuCtx* cu, int x0, int y0, int log2CbSize,
   int nParts = part_geometry(PartMode, x0, y0, nCbS, 0, &g), merge0 = 0;
   for (int k = 0; k < nParts; k++) {
     part_geometry(PartMode, x0, y0, nCbS, k, &g);
-    int mf = prediction_unit(d, &g, PartMode, cu_skip);
+    int mf = prediction_unit(d, &g, PartMode, cu_skip, cqtDepth);
     if (k == 0) merge0 = mf;
   }
   int rqt_root_cbf = 0;
@@ -1759,7 +1770,7 @@ static void coding_unit(Dec* d, int x0, int y0, int log2CbSize, int cqtDepth)
       d->m_flags[idx] = (uint8_t)((d->cu_transquant_bypass_flag ? 0x08 : 0) | (pcm_flag ? 0x10 : 0));
       d->m_decoded[idx] = 1;
       d->m_ipm[idx] = 1;
-      if (d->m_pred) { d->m_pred[idx] = 0; d->mf_ref[idx] = -1; d->mf_poc[idx] = 0; d->mf_mv[2 * idx] = d->mf_mv[2 * idx + 1] = 0; }
+      if (d->m_pred) { d->m_pred[idx] = 0; d->mf_ref[2 * idx] = d->mf_ref[2 * idx + 1] = -1; d->mf_poc[2 * idx] = d->mf_poc[2 * idx + 1] = 0; memset(d->mf_mv + 4 * idx, 0, 4 * sizeof(int16_t)); }
     }
 
   if (pcm_flag) {
@@ -2013,8 +2024,7 @@ static void decode_slice(Dec* d, int nal_type, const uint8_t* nal, size_t nal_le
     for (int i = 0; i < p->num_extra_slice_header_bits; i++) br_u(&b, 1);
     hdr.slice_type = (int)br_ue(&b);
     if (hdr.slice_type > 2) fail(d, "slice_type out of range");
-    if (hdr.slice_type == 0) fail(d, "unsupported: B slices");
-    if (hdr.slice_type == 1 && !d->seq_mode) fail(d, "unsupported: slice_type %d (a single picture must be intra coded)", hdr.slice_type);
+    if (hdr.slice_type != 2 && !d->seq_mode) fail(d, "unsupported: slice_type %d (a single picture must be intra coded)", hdr.slice_type);
     if (p->output_flag_present_flag) br_u(&b, 1);
     if (s->separate_colour_plane_flag) br_u(&b, 2);
     int poc_lsb = 0, slice_temporal_mvp = 0;
@@ -2053,23 +2063,70 @@ static void decode_slice(Dec* d, int nal_type, const uint8_t* nal, size_t nal_le
       hdr.slice_sao_luma_flag = br_u(&b, 1);
       if (s->chroma_format_idc) hdr.slice_sao_chroma_flag = br_u(&b, 1);
     }
-    if (hdr.slice_type == 1) {   /* 7.3.6.1, P slice */
-      if (s->chroma_format_idc > 1) fail(d, "unsupported: P slices of a 4:2:2 / 4:4:4 picture");
-      if (p->constrained_intra_pred_flag) fail(d, "unsupported: constrained_intra_pred_flag with P slices");
-      if (p->weighted_pred_flag) fail(d, "unsupported: weighted prediction");
-      if (slice_temporal_mvp) fail(d, "unsupported: temporal motion vector prediction");
+    if (hdr.slice_type != 2) {   /* 7.3.6.1, P / B slice */
+      const int is_b = hdr.slice_type == 0;
+      if (s->chroma_format_idc > 1) fail(d, "unsupported: P / B slices of a 4:2:2 / 4:4:4 picture");
+      if (p->constrained_intra_pred_flag) fail(d, "unsupported: constrained_intra_pred_flag with P / B slices");
+      hdr.slice_temporal_mvp = slice_temporal_mvp;
       hdr.num_ref_idx_l0_active = p->num_ref_idx_l0_default_active;
-      if (br_u(&b, 1)) hdr.num_ref_idx_l0_active = (int)br_ue(&b) + 1;   /* num_ref_idx_active_override_flag */
-      if (hdr.num_ref_idx_l0_active > 15) fail(d, "num_ref_idx_l0_active_minus1 out of range");
-      int total = d->n_st_curr_before + d->n_st_curr_after, entries[16], modified = 0;
-      if (p->lists_modification_present_flag && total > 1) {
-        modified = br_u(&b, 1);   /* ref_pic_list_modification_flag_l0 */
-        if (modified) for (int i = 0; i < hdr.num_ref_idx_l0_active; i++) entries[i] = (int)br_u(&b, ceil_log2(total));
+      hdr.num_ref_idx_l1_active = is_b ? p->num_ref_idx_l1_default_active : 0;
+      if (br_u(&b, 1)) {   /* num_ref_idx_active_override_flag */
+        hdr.num_ref_idx_l0_active = (int)br_ue(&b) + 1;
+        if (is_b) hdr.num_ref_idx_l1_active = (int)br_ue(&b) + 1;
       }
+      if (hdr.num_ref_idx_l0_active > 15 || hdr.num_ref_idx_l1_active > 15) fail(d, "num_ref_idx_lX_active_minus1 out of range");
+      int total = d->n_st_curr_before + d->n_st_curr_after, entries[2][16], modified[2] = {0, 0};
+      if (p->lists_modification_present_flag && total > 1)
+        for (int X = 0; X < (is_b ? 2 : 1); X++) {
+          modified[X] = br_u(&b, 1);   /* ref_pic_list_modification_flag_lX */
+          if (modified[X]) for (int i = 0; i < (X ? hdr.num_ref_idx_l1_active : hdr.num_ref_idx_l0_active); i++) entries[X][i] = (int)br_u(&b, ceil_log2(total));
+        }
+      if (is_b) hdr.mvd_l1_zero_flag = br_u(&b, 1);
       if (p->cabac_init_present_flag) hdr.cabac_init_flag = br_u(&b, 1);
+      hdr.collocated_from_l0 = 1; hdr.collocated_ref_idx = 0;
+      if (slice_temporal_mvp) {
+        if (is_b) hdr.collocated_from_l0 = br_u(&b, 1);
+        if ((hdr.collocated_from_l0 && hdr.num_ref_idx_l0_active > 1) || (!hdr.collocated_from_l0 && hdr.num_ref_idx_l1_active > 1))
+          hdr.collocated_ref_idx = (int)br_ue(&b);
+        if (hdr.collocated_ref_idx >= (hdr.collocated_from_l0 ? hdr.num_ref_idx_l0_active : hdr.num_ref_idx_l1_active)) fail(d, "collocated_ref_idx out of range");
+      }
+      build_ref_list(d, &hdr, 0, modified[0] ? entries[0] : NULL);
+      if (is_b) build_ref_list(d, &hdr, 1, modified[1] ? entries[1] : NULL);
+      hdr.weighted = is_b ? p->weighted_bipred_flag : p->weighted_pred_flag;
+      if (hdr.weighted) {   /* 7.3.6.3 pred_weight_table */
+        int nc = s->chroma_format_idc ? 3 : 1;
+        hdr.luma_log2_wd = (int)br_ue(&b);
+        if (hdr.luma_log2_wd > 7) fail(d, "luma_log2_weight_denom out of range");
+        hdr.chroma_log2_wd = hdr.luma_log2_wd;
+        if (nc == 3) { hdr.chroma_log2_wd += br_se(&b); if (hdr.chroma_log2_wd < 0 || hdr.chroma_log2_wd > 7) fail(d, "delta_chroma_log2_weight_denom out of range"); }
+        for (int X = 0; X < (is_b ? 2 : 1); X++) {
+          int n = X ? hdr.num_ref_idx_l1_active : hdr.num_ref_idx_l0_active;
+          uint8_t lf[16], cf[16];
+          memset(cf, 0, sizeof(cf));
+          /* (the flags are present for every entry: a reference picture of these single-layer streams never has the current picture's POC) */
+          for (int i = 0; i < n; i++) lf[i] = (uint8_t)br_u(&b, 1);
+          if (nc == 3) for (int i = 0; i < n; i++) cf[i] = (uint8_t)br_u(&b, 1);
+          for (int i = 0; i < n; i++) {
+            hdr.wp_weight[X][i][0] = (int16_t)(1 << hdr.luma_log2_wd); hdr.wp_offset[X][i][0] = 0;
+            hdr.wp_weight[X][i][1] = hdr.wp_weight[X][i][2] = (int16_t)(1 << hdr.chroma_log2_wd); hdr.wp_offset[X][i][1] = hdr.wp_offset[X][i][2] = 0;
+            if (lf[i]) {
+              int dw = br_se(&b), o = br_se(&b);
+              if (dw < -128 || dw > 127 || o < -128 || o > 127) fail(d, "luma weight / offset out of range");
+              hdr.wp_weight[X][i][0] = (int16_t)((1 << hdr.luma_log2_wd) + dw); hdr.wp_offset[X][i][0] = (int16_t)o;
+            }
+            if (cf[i])
+              for (int j = 1; j < 3; j++) {
+                int dw = br_se(&b), dof = br_se(&b);
+                if (dw < -128 || dw > 127 || dof < -512 || dof > 511) fail(d, "chroma weight / offset out of range");
+                int wgt = (1 << hdr.chroma_log2_wd) + dw;
+                hdr.wp_weight[X][i][j] = (int16_t)wgt;
+                hdr.wp_offset[X][i][j] = (int16_t)Clip3(-128, 127, (128 + dof - ((128 * wgt) >> hdr.chroma_log2_wd)));
+              }
+          }
+        }
+      }
       hdr.max_num_merge_cand = 5 - (int)br_ue(&b);
       if (hdr.max_num_merge_cand < 1 || hdr.max_num_merge_cand > 5) fail(d, "five_minus_max_num_merge_cand out of range");
-      build_ref_list0(d, &hdr, modified ? entries : NULL);
     }
     hdr.slice_qp_delta = br_se(&b);
     if (p->pps_slice_chroma_qp_offsets_present_flag) { hdr.slice_cb_qp_offset = br_se(&b); hdr.slice_cr_qp_offset = br_se(&b); }
@@ -2532,6 +2589,7 @@ static void decode_access_unit(Dec* d, const uint8_t* data, size_t size, int kee
     if (slot >= d->n_dpb) d->n_dpb = slot + 1;
     for (int c = 0; c < nc; c++) d->dpb[slot].plane[c] = dup_plane(d, fin[c], c ? (size_t)d->Wc * d->Hc : (size_t)d->W * d->H);
     d->dpb[slot].poc = d->poc; d->dpb[slot].valid = 1;
+    dpb_store_motion(d, &d->dpb[slot]);
   }
   if (keep_taps) {
     for (int c = 0; c < nc; c++) { out->final_coded[c] = fin[c]; fin[c] = NULL; out->coeff[c] = d->coeff[c]; d->coeff[c] = NULL; }

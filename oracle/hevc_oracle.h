@@ -62,8 +62,8 @@ typedef struct hevc_oracle_picture {
   /* ---- sequences (hevc_oracle_seq_*): picture order count and, with keep_taps, the motion field per 4x4 unit ---- */
   int      poc;
   uint8_t* map_pred;                 /* 0 MODE_INTRA, 1 MODE_INTER, 2 MODE_SKIP (NULL for hevc_oracle_decode)      */
-  int16_t* mf_mv;                    /* [unit*2] mvL0 in quarter luma samples                                         */
-  int8_t*  mf_ref;                   /* refIdxL0, -1 for intra units                                                  */
+  int16_t* mf_mv;                    /* [unit][list 0 / 1][x, y] motion vectors in quarter luma samples (0 where unused)  */
+  int8_t*  mf_ref;                   /* [unit][list 0 / 1] reference indices, -1 where the list is not used / intra units */
 } hevc_oracle_picture;
 
 /* Decode one intra picture.  `data` is libheif's plugin framing: a concatenation of

@@ -1,16 +1,18 @@
 /*
  * hevc_oracle_inter.c — CPU ORACLE, inter prediction part (test infrastructure, NOT product code; #included by hevc_oracle.c).
  *
- * Spec-literal restatement of what a P slice adds to the intra decoding process (ITU-T H.265): picture order count and reference
+ * Spec-literal restatement of what P and B slices add to the intra decoding process (ITU-T H.265): picture order count and reference
  * picture set (8.3.1, 8.3.2), reference picture list construction (8.3.4), prediction block availability (6.4.2), merge mode
- * (8.5.3.2.2 - 8.5.3.2.5, spatial and zero candidates), motion vector prediction (8.5.3.2.6 - 8.5.3.2.8, spatial candidates with
- * scaling), fractional sample interpolation (8.5.3.3.3) and the default weighted sample prediction (8.5.3.3.4.2).  It stands in for
- * libde265's handling of the samples libheif's sequence tracks push through the same plugin (libheif/sequences/track_visual.cc:200-280,
- * libheif/plugins/decoder_libde265.cc:360, :417-419).
+ * (8.5.3.2.2 - 8.5.3.2.5: spatial, temporal, combined bi-predictive and zero candidates), motion vector prediction (8.5.3.2.6 - 8.5.3.2.9:
+ * spatial candidates with scaling, the collocated candidate), fractional sample interpolation (8.5.3.3.3), default and explicit
+ * weighted sample prediction (8.5.3.3.4.2, 8.5.3.3.4.3).  It stands in for libde265's handling of the samples libheif's sequence
+ * tracks push through the same plugin (libheif/sequences/track_visual.cc:200-280, libheif/plugins/decoder_libde265.cc:360, :417-419) -
+ * the streams libheif's own x265 plugin writes for its "lowdelay" (P pictures: TMVP, weighted prediction, several reference
+ * pictures) and "unrestricted" (B pictures) GOP structures (libheif/plugins/encoder_x265.cc:875-888).
  *
- * Scope (what the HIP path implements too): P slices, uni-prediction from list 0 with any number of short-term reference pictures,
- * all partition modes incl. AMP, skip / merge / AMVP, parallel merge level, 4:0:0 and 4:2:0, 8 - 12 bit.  Refused loudly: B slices,
- * temporal motion vector prediction, weighted prediction, long-term reference pictures, constrained intra prediction in P slices.
+ * Scope (what the HIP path implements too): P and B slices, any number of short-term reference pictures, all partition modes incl.
+ * AMP, skip / merge / AMVP, parallel merge level, TMVP, explicit weighted prediction, 4:0:0 and 4:2:0, 8 - 12 bit.  Refused loudly:
+ * long-term reference pictures, constrained intra prediction in P / B slices, 4:2:2 / 4:4:4 inter pictures.
  * PARITY: unpinned - no fixture of the reference holds inter-coded pictures; the generator's lossless round trips pin the syntax.
  */
 
@@ -30,7 +32,19 @@ static int dpb_find(Dec* d, int poc)
 static void dpb_free_entry(RefPic* r)
 {
   for (int c = 0; c < 3; c++) { free(r->plane[c]); r->plane[c] = NULL; }
+  free(r->m_pred); free(r->mf_mv); free(r->mf_ref); free(r->mf_poc);
+  r->m_pred = NULL; r->mf_mv = NULL; r->mf_ref = NULL; r->mf_poc = NULL;
   r->valid = 0;
+}
+
+/* the motion field of the picture that has just been decoded stays with it in the DPB: the collocated picture of later slices (8.5.3.2.8) */
+static void dpb_store_motion(Dec* d, RefPic* r)
+{
+  size_t mn = (size_t)d->mw * d->mh;
+  r->m_pred = (uint8_t*)xcalloc(d, mn, 1); r->mf_mv = (int16_t*)xcalloc(d, mn * 4, sizeof(int16_t));
+  r->mf_ref = (int8_t*)xcalloc(d, mn * 2, 1); r->mf_poc = (int32_t*)xcalloc(d, mn * 2, sizeof(int32_t));
+  memcpy(r->m_pred, d->m_pred, mn); memcpy(r->mf_mv, d->mf_mv, mn * 4 * sizeof(int16_t));
+  memcpy(r->mf_ref, d->mf_ref, mn * 2); memcpy(r->mf_poc, d->mf_poc, mn * 2 * sizeof(int32_t));
 }
 
 /* at the first slice segment of a picture: POC of the picture, then the RPS decides which pictures stay and which one(s) list 0 holds */
@@ -67,21 +81,25 @@ static void inter_begin_picture(Dec* d, int nal_type, int poc_lsb, const StRps* 
   for (int i = 0; i < d->n_dpb; i++) if (d->dpb[i].valid && !keep[i]) dpb_free_entry(&d->dpb[i]);
 }
 
-/* 8.3.4 (P slices): RefPicListTemp0 = StCurrBefore, StCurrAfter (no long-term pictures here), repeated; optional list_entry_l0 */
-static void build_ref_list0(Dec* d, SliceHdr* h, const int* list_entry /* NULL: no modification */)
+/* 8.3.4: RefPicListTemp0 = StCurrBefore, StCurrAfter; RefPicListTemp1 = StCurrAfter, StCurrBefore (no long-term pictures here), repeated up
+   to the list size; optional list_entry_lX */
+static void build_ref_list(Dec* d, SliceHdr* h, int X, const int* list_entry /* NULL: no modification */)
 {
   int total = d->n_st_curr_before + d->n_st_curr_after;
-  if (total == 0) fail(d, "P slice without a reference picture");
-  int temp[32], n = 0, want = Max(h->num_ref_idx_l0_active, total);
+  if (total == 0) fail(d, "P / B slice without a reference picture");
+  int active = X ? h->num_ref_idx_l1_active : h->num_ref_idx_l0_active;
+  int temp[32], n = 0, want = Max(active, total);
+  const int* first = X ? d->st_curr_after : d->st_curr_before; int n_first = X ? d->n_st_curr_after : d->n_st_curr_before;
+  const int* second = X ? d->st_curr_before : d->st_curr_after; int n_second = X ? d->n_st_curr_before : d->n_st_curr_after;
   while (n < want) {
-    for (int i = 0; i < d->n_st_curr_before && n < want; i++) temp[n++] = d->st_curr_before[i];
-    for (int i = 0; i < d->n_st_curr_after && n < want; i++) temp[n++] = d->st_curr_after[i];
+    for (int i = 0; i < n_first && n < want; i++) temp[n++] = first[i];
+    for (int i = 0; i < n_second && n < want; i++) temp[n++] = second[i];
   }
-  for (int i = 0; i < h->num_ref_idx_l0_active; i++) {
+  for (int i = 0; i < active; i++) {
     int e = list_entry ? list_entry[i] : i;
-    if (e < 0 || e >= want) fail(d, "list_entry_l0 out of range");
-    h->ref_list0[i] = (int8_t)temp[e];
-    h->ref_poc0[i] = d->dpb[temp[e]].poc;
+    if (e < 0 || e >= want) fail(d, "list_entry_l%d out of range", X);
+    h->ref_list[X][i] = (int8_t)temp[e];
+    h->ref_poc[X][i] = d->dpb[temp[e]].poc;
   }
 }
 
@@ -99,27 +117,95 @@ static int pb_available(Dec* d, const PbGeom* g, int xN, int yN)
   return av;
 }
 
-typedef struct { int mv[2]; int ref_idx; } Motion;   /* P slices: predFlagL0 is 1 for every inter block */
+typedef struct { int mv[2][2]; int ref_idx[2]; int pred_flag[2]; } Motion;   /* [list][component]; ref_idx -1 when the list is not used */
 
 static Motion motion_at(Dec* d, int x, int y)
 {
   int idx = (y >> 2) * d->mw + (x >> 2);
-  Motion m = {{d->mf_mv[2 * idx], d->mf_mv[2 * idx + 1]}, d->mf_ref[idx]};
+  Motion m;
+  for (int X = 0; X < 2; X++) {
+    m.mv[X][0] = d->mf_mv[4 * idx + 2 * X]; m.mv[X][1] = d->mf_mv[4 * idx + 2 * X + 1];
+    m.ref_idx[X] = d->mf_ref[2 * idx + X]; m.pred_flag[X] = m.ref_idx[X] >= 0;
+  }
   return m;
 }
-static int same_motion(const Motion* a, const Motion* b) { return a->mv[0] == b->mv[0] && a->mv[1] == b->mv[1] && a->ref_idx == b->ref_idx; }
+static int same_motion(const Motion* a, const Motion* b)
+{
+  for (int X = 0; X < 2; X++) {
+    if (a->pred_flag[X] != b->pred_flag[X]) return 0;
+    if (a->pred_flag[X] && (a->mv[X][0] != b->mv[X][0] || a->mv[X][1] != b->mv[X][1] || a->ref_idx[X] != b->ref_idx[X])) return 0;
+  }
+  return 1;
+}
+static Motion motion_none(void) { Motion m; memset(&m, 0, sizeof(m)); m.ref_idx[0] = m.ref_idx[1] = -1; return m; }
 
-/* ---- 8.5.3.2.2 - 8.5.3.2.5 merge mode (spatial candidates, then zero candidates; no temporal candidate: TMVP is refused) ---------- */
+static void scale_mv(int* mv, int td, int tb)
+{
+  td = Clip3(-128, 127, td); tb = Clip3(-128, 127, tb);
+  int tx = (16384 + (Abs(td) >> 1)) / td;
+  int dsf = Clip3(-4096, 4095, (tb * tx + 32) >> 6);
+  for (int k = 0; k < 2; k++) {
+    int v = dsf * mv[k];
+    mv[k] = Clip3(-32768, 32767, (v < 0 ? -1 : 1) * ((Abs(v) + 127) >> 8));
+  }
+}
+
+/* ---- 8.5.3.2.8 temporal luma motion vector prediction, 8.5.3.2.9 collocated motion vectors ------------------------------------------ */
+/* the motion the collocated picture stored for the unit covering (x, y) & ~15: the "compressed" motion field of 16x16 granularity */
+static int collocated_mv(Dec* d, const RefPic* col, int xCol, int yCol, int refIdxLX, int X, int* mvLXCol)
+{
+  const SliceHdr* h = d->sh;
+  int idx = (((yCol >> 4) << 4) >> 2) * d->mw + (((xCol >> 4) << 4) >> 2);
+  if (!col->m_pred || col->m_pred[idx] == 0) return 0;                       /* colPb is intra coded */
+  int f0 = col->mf_ref[2 * idx] >= 0, f1 = col->mf_ref[2 * idx + 1] >= 0, L;
+  if (!f0) L = 1;
+  else if (!f1) L = 0;
+  else {
+    /* both lists used: NoBackwardPredFlag (no reference picture of the current slice follows the current picture) takes the list the
+       prediction is derived for, otherwise the list collocated_from_l0_flag names */
+    int no_backward = 1;
+    for (int Y = 0; Y < 2; Y++) {
+      int n = Y ? h->num_ref_idx_l1_active : h->num_ref_idx_l0_active;
+      if (Y == 1 && h->slice_type != 0) n = 0;
+      for (int i = 0; i < n; i++) if (h->ref_poc[Y][i] > d->poc) no_backward = 0;
+    }
+    L = no_backward ? X : h->collocated_from_l0;
+  }
+  int mv[2] = {col->mf_mv[4 * idx + 2 * L], col->mf_mv[4 * idx + 2 * L + 1]};
+  int colPocDiff = col->poc - col->mf_poc[2 * idx + L];
+  int currPocDiff = d->poc - h->ref_poc[X][refIdxLX];
+  /* (all reference pictures are short-term ones here: the long-term mismatch rule never fires) */
+  if (colPocDiff != currPocDiff) {
+    if (colPocDiff == 0) return 0;   /* cannot happen in a conforming stream (a picture never references itself) */
+    scale_mv(mv, colPocDiff, currPocDiff);
+  }
+  mvLXCol[0] = mv[0]; mvLXCol[1] = mv[1];
+  return 1;
+}
+
+static int temporal_mv(Dec* d, int xPb, int yPb, int nPbW, int nPbH, int refIdxLX, int X, int* mvLXCol)
+{
+  const SliceHdr* h = d->sh; const SPS* s = d->s;
+  if (!h->slice_temporal_mvp) return 0;
+  const RefPic* col = &d->dpb[h->ref_list[(h->slice_type == 0 && !h->collocated_from_l0) ? 1 : 0][h->collocated_ref_idx]];
+  int xBr = xPb + nPbW, yBr = yPb + nPbH;
+  if ((yPb >> s->log2_ctb) == (yBr >> s->log2_ctb) && yBr < s->pic_height && xBr < s->pic_width &&
+      collocated_mv(d, col, xBr, yBr, refIdxLX, X, mvLXCol)) return 1;
+  return collocated_mv(d, col, xPb + (nPbW >> 1), yPb + (nPbH >> 1), refIdxLX, X, mvLXCol);
+}
+
+/* ---- 8.5.3.2.2 - 8.5.3.2.5 merge mode: spatial candidates, the temporal candidate, combined bi-predictive candidates (B), zero candidates */
 static Motion derive_merge(Dec* d, const PbGeom* g0, int PartMode, int merge_idx)
 {
-  const PPS* p = d->p;
+  const PPS* p = d->p; const SliceHdr* h = d->sh;
   PbGeom g = *g0;
+  const int nOrigPbW = g0->nPbW, nOrigPbH = g0->nPbH;
   int plevel = p->log2_parallel_merge_level;
   if (plevel > 2 && g.nCbS == 8) { g.xPb = g.xCb; g.yPb = g.yCb; g.nPbW = g.nPbH = g.nCbS; g.partIdx = 0; PartMode = PART_2Nx2N; }   /* singleMCLFlag */
   int xPb = g.xPb, yPb = g.yPb, nPbW = g.nPbW, nPbH = g.nPbH;
 #define SAME_MER(xn, yn) ((xPb >> plevel) == ((xn) >> plevel) && (yPb >> plevel) == ((yn) >> plevel))
-  Motion cand[6]; int n = 0;
-  Motion A1 = {{0, 0}, 0}, B1 = A1, B0 = A1, A0 = A1, B2 = A1;
+  Motion cand[8]; int n = 0;
+  Motion A1 = motion_none(), B1 = A1, B0 = A1, A0 = A1, B2 = A1;
   /* availableN: 6.4.2 availability minus the merge-estimation-region / second-partition exclusions; availableFlagN: after the pruning against the
      neighbours compared with.  The comparisons read availableN of the other candidate, NOT its flag (B0 is compared with a B1 that was itself
      pruned against A1); only the "all four present" rule of B2 counts flags */
@@ -154,83 +240,112 @@ static Motion derive_merge(Dec* d, const PbGeom* g0, int PartMode, int merge_idx
   int fB2 = avB2 && !(avA1 && same_motion(&A1, &B2)) && !(avB1 && same_motion(&B1, &B2)) && fA0 + fA1 + fB0 + fB1 != 4;
   if (fB2) cand[n++] = B2;
 #undef SAME_MER
-  if (n > d->sh->max_num_merge_cand) n = d->sh->max_num_merge_cand;   /* (slice-level MaxNumMergeCand caps the list: 8.5.3.2.2 step 8 onward fills, never trims
-                                                                          spatial candidates below five - the cap only matters when merge_idx addresses them) */
-  /* 8.5.3.2.5 zero candidates: refIdxL0 = zeroIdx while below the number of reference pictures, then 0 */
+  /* the temporal candidate: refIdxLXCol = 0 in each list the slice has (8.5.3.2.2 steps 3 - 5) */
+  if (h->slice_temporal_mvp) {
+    Motion c = motion_none();
+    for (int X = 0; X < (h->slice_type == 0 ? 2 : 1); X++)
+      if (temporal_mv(d, xPb, yPb, nPbW, nPbH, 0, X, c.mv[X])) { c.pred_flag[X] = 1; c.ref_idx[X] = 0; }
+    if (c.pred_flag[0] || c.pred_flag[1]) cand[n++] = c;
+  }
+  const int MaxNumMergeCand = h->max_num_merge_cand;
+  if (n > MaxNumMergeCand) n = MaxNumMergeCand;   /* (merge_idx < MaxNumMergeCand: entries beyond it are never addressed, and the steps below only
+                                                      run while the list is shorter) */
+  /* 8.5.3.2.4 combined bi-predictive candidates (B slices) */
+  if (h->slice_type == 0 && n > 1 && n < MaxNumMergeCand) {
+    static const uint8_t l0Cand[12] = {0, 1, 0, 2, 1, 2, 0, 3, 1, 3, 2, 3}, l1Cand[12] = {1, 0, 2, 0, 2, 1, 3, 0, 3, 1, 3, 2};
+    const int numOrig = n;
+    for (int combIdx = 0; combIdx < numOrig * (numOrig - 1) && n < MaxNumMergeCand; combIdx++) {
+      const Motion* a = &cand[l0Cand[combIdx]]; const Motion* b = &cand[l1Cand[combIdx]];
+      if (a->pred_flag[0] && b->pred_flag[1] &&
+          (h->ref_poc[0][a->ref_idx[0]] != h->ref_poc[1][b->ref_idx[1]] || a->mv[0][0] != b->mv[1][0] || a->mv[0][1] != b->mv[1][1])) {
+        Motion c = motion_none();
+        c.pred_flag[0] = c.pred_flag[1] = 1;
+        c.ref_idx[0] = a->ref_idx[0]; c.mv[0][0] = a->mv[0][0]; c.mv[0][1] = a->mv[0][1];
+        c.ref_idx[1] = b->ref_idx[1]; c.mv[1][0] = b->mv[1][0]; c.mv[1][1] = b->mv[1][1];
+        cand[n++] = c;
+      }
+    }
+  }
+  /* 8.5.3.2.5 zero candidates: the reference index counts up while below the number of reference pictures (B: of the shorter list), then 0 */
+  int numRefIdx = h->slice_type == 0 ? Min(h->num_ref_idx_l0_active, h->num_ref_idx_l1_active) : h->num_ref_idx_l0_active;
   int zeroIdx = 0;
-  while (n < d->sh->max_num_merge_cand) {
-    Motion z = {{0, 0}, zeroIdx < d->sh->num_ref_idx_l0_active ? zeroIdx : 0};
+  while (n < MaxNumMergeCand) {
+    Motion z = motion_none();
+    int r = zeroIdx < numRefIdx ? zeroIdx : 0;
+    z.pred_flag[0] = 1; z.ref_idx[0] = r;
+    if (h->slice_type == 0) { z.pred_flag[1] = 1; z.ref_idx[1] = r; }
     cand[n++] = z; zeroIdx++;
   }
   if (merge_idx >= n) fail(d, "merge_idx out of range");
-  return cand[merge_idx];
+  Motion m = cand[merge_idx];
+  if (m.pred_flag[0] && m.pred_flag[1] && nOrigPbW + nOrigPbH == 12) { m.pred_flag[1] = 0; m.ref_idx[1] = -1; m.mv[1][0] = m.mv[1][1] = 0; }   /* 8x4 / 4x8: uni-prediction */
+  return m;
 }
 
-/* ---- 8.5.3.2.6 - 8.5.3.2.8 luma motion vector prediction (spatial candidates, no temporal one) ----------------------------------- */
-static void scale_mv(int* mv, int td, int tb)
+/* ---- 8.5.3.2.6 - 8.5.3.2.7 luma motion vector prediction for list X: spatial candidates (the neighbour's own list X first, then its other
+        list; unscaled when it points at the target picture, scaled otherwise), then the temporal candidate ------------------------------- */
+static int nb_mv_same_poc(Dec* d, int x, int y, int X, int tgtPoc, int* mv)
 {
-  td = Clip3(-128, 127, td); tb = Clip3(-128, 127, tb);
-  int tx = (16384 + (Abs(td) >> 1)) / td;
-  int dsf = Clip3(-4096, 4095, (tb * tx + 32) >> 6);
+  int idx = (y >> 2) * d->mw + (x >> 2);
   for (int k = 0; k < 2; k++) {
-    int v = dsf * mv[k];
-    mv[k] = Clip3(-32768, 32767, (v < 0 ? -1 : 1) * ((Abs(v) + 127) >> 8));
+    int L = k ? 1 - X : X;
+    if (d->mf_ref[2 * idx + L] >= 0 && d->mf_poc[2 * idx + L] == tgtPoc) { mv[0] = d->mf_mv[4 * idx + 2 * L]; mv[1] = d->mf_mv[4 * idx + 2 * L + 1]; return 1; }
   }
+  return 0;
+}
+static int nb_mv_scaled(Dec* d, int x, int y, int X, int tgtPoc, int* mv)
+{
+  int idx = (y >> 2) * d->mw + (x >> 2);
+  for (int k = 0; k < 2; k++) {
+    int L = k ? 1 - X : X;
+    if (d->mf_ref[2 * idx + L] >= 0) {
+      mv[0] = d->mf_mv[4 * idx + 2 * L]; mv[1] = d->mf_mv[4 * idx + 2 * L + 1];
+      int nbPoc = d->mf_poc[2 * idx + L];
+      if (nbPoc != tgtPoc) scale_mv(mv, d->poc - nbPoc, d->poc - tgtPoc);
+      return 1;
+    }
+  }
+  return 0;
 }
 
-static void derive_mvp(Dec* d, const PbGeom* g, int refIdx, int mvp_flag, int* mvp)
+static void derive_mvp(Dec* d, const PbGeom* g, int X, int refIdx, int mvp_flag, int* mvp)
 {
   int xPb = g->xPb, yPb = g->yPb, nPbW = g->nPbW, nPbH = g->nPbH;
-  int curPoc = d->poc, tgtPoc = d->sh->ref_poc0[refIdx];
+  int tgtPoc = d->sh->ref_poc[X][refIdx];
   int xA[2] = {xPb - 1, xPb - 1}, yA[2] = {yPb + nPbH, yPb + nPbH - 1};
   int avA[2];
   for (int k = 0; k < 2; k++) avA[k] = pb_available(d, g, xA[k], yA[k]);
   int isScaled = avA[0] || avA[1];
   int flagA = 0, mvA[2] = {0, 0};
-  for (int k = 0; k < 2 && !flagA; k++)
-    if (avA[k]) {
-      Motion m = motion_at(d, xA[k], yA[k]);
-      if (d->mf_poc[(yA[k] >> 2) * d->mw + (xA[k] >> 2)] == tgtPoc) { flagA = 1; mvA[0] = m.mv[0]; mvA[1] = m.mv[1]; }
-    }
-  for (int k = 0; k < 2 && !flagA; k++)
-    if (avA[k]) {
-      Motion m = motion_at(d, xA[k], yA[k]);
-      int nbPoc = d->mf_poc[(yA[k] >> 2) * d->mw + (xA[k] >> 2)];
-      flagA = 1; mvA[0] = m.mv[0]; mvA[1] = m.mv[1];
-      if (nbPoc != tgtPoc) scale_mv(mvA, curPoc - nbPoc, curPoc - tgtPoc);
-    }
+  for (int k = 0; k < 2 && !flagA; k++) if (avA[k]) flagA = nb_mv_same_poc(d, xA[k], yA[k], X, tgtPoc, mvA);
+  for (int k = 0; k < 2 && !flagA; k++) if (avA[k]) flagA = nb_mv_scaled(d, xA[k], yA[k], X, tgtPoc, mvA);
   int xB[3] = {xPb + nPbW, xPb + nPbW - 1, xPb - 1}, yB[3] = {yPb - 1, yPb - 1, yPb - 1};
   int avB[3];
   for (int k = 0; k < 3; k++) avB[k] = pb_available(d, g, xB[k], yB[k]);
   int flagB = 0, mvB[2] = {0, 0};
-  for (int k = 0; k < 3 && !flagB; k++)
-    if (avB[k] && d->mf_poc[(yB[k] >> 2) * d->mw + (xB[k] >> 2)] == tgtPoc) {
-      Motion m = motion_at(d, xB[k], yB[k]);
-      flagB = 1; mvB[0] = m.mv[0]; mvB[1] = m.mv[1];
-    }
+  for (int k = 0; k < 3 && !flagB; k++) if (avB[k]) flagB = nb_mv_same_poc(d, xB[k], yB[k], X, tgtPoc, mvB);
   if (!isScaled && flagB) { flagA = 1; mvA[0] = mvB[0]; mvA[1] = mvB[1]; }
   if (!isScaled) {
     flagB = 0;
-    for (int k = 0; k < 3 && !flagB; k++)
-      if (avB[k]) {
-        Motion m = motion_at(d, xB[k], yB[k]);
-        int nbPoc = d->mf_poc[(yB[k] >> 2) * d->mw + (xB[k] >> 2)];
-        flagB = 1; mvB[0] = m.mv[0]; mvB[1] = m.mv[1];
-        if (nbPoc != tgtPoc) scale_mv(mvB, curPoc - nbPoc, curPoc - tgtPoc);
-      }
+    for (int k = 0; k < 3 && !flagB; k++) if (avB[k]) flagB = nb_mv_scaled(d, xB[k], yB[k], X, tgtPoc, mvB);
   }
   int list[3][2], n = 0;
   if (flagA) { list[n][0] = mvA[0]; list[n][1] = mvA[1]; n++; }
   if (flagB && !(flagA && mvA[0] == mvB[0] && mvA[1] == mvB[1])) { list[n][0] = mvB[0]; list[n][1] = mvB[1]; n++; }
+  if (n < 2) {   /* the temporal candidate is only derived when the spatial ones left a place (8.5.3.2.6 step 2) */
+    int mvCol[2];
+    if (temporal_mv(d, xPb, yPb, nPbW, nPbH, refIdx, X, mvCol)) { list[n][0] = mvCol[0]; list[n][1] = mvCol[1]; n++; }
+  }
   while (n < 2) { list[n][0] = 0; list[n][1] = 0; n++; }
   mvp[0] = list[mvp_flag][0]; mvp[1] = list[mvp_flag][1];
 }
 
-/* ---- 8.5.3.3 decoding process for inter sample prediction (uni-prediction from list 0, default weights) --------------------------- */
+/* ---- 8.5.3.3 decoding process for inter sample prediction: 14-bit prediction sample arrays per list (8.5.3.3.3), then the default
+        (8.5.3.3.4.2) or explicit (8.5.3.3.4.3) weighted sample prediction ------------------------------------------------------------------ */
 static const int8_t fL[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}};
 static const int8_t fC[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4}, {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
 
-static void mc_block(Dec* d, const RefPic* ref, int cIdx, int xP, int yP, int w, int h, int mvx, int mvy)
+static void mc_block(Dec* d, const RefPic* ref, int cIdx, int xP, int yP, int w, int h, int mvx, int mvy, int16_t* out /* w x h */)
 {
   /* (xP, yP), w, h in samples of component cIdx; mv in quarter luma samples = eighth chroma samples for 4:2:0 */
   const SPS* s = d->s;
@@ -241,9 +356,6 @@ static void mc_block(Dec* d, const RefPic* ref, int cIdx, int xP, int yP, int w,
   int xFrac = mvx & ((1 << fbits) - 1), yFrac = mvy & ((1 << fbits) - 1);
   int xInt0 = xP + (mvx >> fbits), yInt0 = yP + (mvy >> fbits);
   const uint16_t* rp = ref->plane[cIdx];
-  uint16_t* dst = d->rec[cIdx];
-  int maxv = (1 << bitDepth) - 1;
-  int wshift = 14 - bitDepth, woff = wshift > 0 ? 1 << (wshift - 1) : 0;
 #define REF(x, y) ((int)rp[(size_t)Clip3(0, H - 1, (y)) * W + Clip3(0, W - 1, (x))])
 #define COEF_H(i) (cIdx ? fC[xFrac][i] : fL[xFrac][i])
 #define COEF_V(i) (cIdx ? fC[yFrac][i] : fL[yFrac][i])
@@ -262,20 +374,60 @@ static void mc_block(Dec* d, const RefPic* ref, int cIdx, int xP, int yP, int w,
         }
         v = a >> shift2;
       }
-      dst[(size_t)(yP + y) * W + xP + x] = (uint16_t)Clip3(0, maxv, (v + woff) >> wshift);   /* 8.5.3.3.4.2, predFlagL0 only */
+      out[y * w + x] = (int16_t)v;
     }
 #undef REF
 #undef COEF_H
 #undef COEF_V
 }
 
+static void predict_component(Dec* d, int cIdx, int xP, int yP, int w, int h, const Motion* m)
+{
+  const SPS* s = d->s; const SliceHdr* sh = d->sh;
+  int W = cIdx ? d->Wc : d->W;
+  int bitDepth = cIdx ? s->bit_depth_chroma : s->bit_depth_luma, maxv = (1 << bitDepth) - 1;
+  int16_t* pred[2] = {NULL, NULL};
+  for (int X = 0; X < 2; X++)
+    if (m->pred_flag[X]) {
+      pred[X] = (int16_t*)xcalloc(d, (size_t)w * h, sizeof(int16_t));
+      mc_block(d, &d->dpb[sh->ref_list[X][m->ref_idx[X]]], cIdx, xP, yP, w, h, m->mv[X][0], m->mv[X][1], pred[X]);
+    }
+  uint16_t* dst = d->rec[cIdx];
+  int shift1 = 14 - bitDepth;
+  if (!sh->weighted) {   /* 8.5.3.3.4.2 */
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) {
+        int v;
+        if (pred[0] && pred[1]) v = (pred[0][y * w + x] + pred[1][y * w + x] + (1 << shift1)) >> (shift1 + 1);
+        else { const int16_t* q = pred[0] ? pred[0] : pred[1]; v = (q[y * w + x] + (shift1 > 0 ? 1 << (shift1 - 1) : 0)) >> shift1; }
+        dst[(size_t)(yP + y) * W + xP + x] = (uint16_t)Clip3(0, maxv, v);
+      }
+  } else {               /* 8.5.3.3.4.3 */
+    int log2WD = (cIdx ? sh->chroma_log2_wd : sh->luma_log2_wd) + shift1;
+    int wgt[2] = {0, 0}, off[2] = {0, 0};
+    for (int X = 0; X < 2; X++)
+      if (m->pred_flag[X]) { wgt[X] = sh->wp_weight[X][m->ref_idx[X]][cIdx]; off[X] = sh->wp_offset[X][m->ref_idx[X]][cIdx] << (bitDepth - 8); }
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) {
+        int v;
+        if (pred[0] && pred[1]) v = (pred[0][y * w + x] * wgt[0] + pred[1][y * w + x] * wgt[1] + ((off[0] + off[1] + 1) << log2WD)) >> (log2WD + 1);
+        else {
+          int X = pred[0] ? 0 : 1;
+          int q = pred[X][y * w + x];
+          v = log2WD >= 1 ? ((q * wgt[X] + (1 << (log2WD - 1))) >> log2WD) + off[X] : q * wgt[X] + off[X];
+        }
+        dst[(size_t)(yP + y) * W + xP + x] = (uint16_t)Clip3(0, maxv, v);
+      }
+  }
+  free(pred[0]); free(pred[1]);
+}
+
 static void predict_pu(Dec* d, int xPb, int yPb, int nPbW, int nPbH, const Motion* m)
 {
-  const RefPic* ref = &d->dpb[d->sh->ref_list0[m->ref_idx]];
-  mc_block(d, ref, 0, xPb, yPb, nPbW, nPbH, m->mv[0], m->mv[1]);
+  predict_component(d, 0, xPb, yPb, nPbW, nPbH, m);
   if (d->s->chroma_format_idc == 1) {
-    mc_block(d, ref, 1, xPb / 2, yPb / 2, nPbW / 2, nPbH / 2, m->mv[0], m->mv[1]);
-    mc_block(d, ref, 2, xPb / 2, yPb / 2, nPbW / 2, nPbH / 2, m->mv[0], m->mv[1]);
+    predict_component(d, 1, xPb / 2, yPb / 2, nPbW / 2, nPbH / 2, m);
+    predict_component(d, 2, xPb / 2, yPb / 2, nPbW / 2, nPbH / 2, m);
   }
 }
 
@@ -284,9 +436,12 @@ static void store_motion(Dec* d, int xPb, int yPb, int nPbW, int nPbH, const Mot
   for (int y = yPb >> 2; y < (yPb + nPbH) >> 2; y++)
     for (int x = xPb >> 2; x < (xPb + nPbW) >> 2; x++) {
       int idx = y * d->mw + x;
-      d->mf_mv[2 * idx] = (int16_t)m->mv[0]; d->mf_mv[2 * idx + 1] = (int16_t)m->mv[1];
-      d->mf_ref[idx] = (int8_t)m->ref_idx;
-      d->mf_poc[idx] = d->sh->ref_poc0[m->ref_idx];
+      for (int X = 0; X < 2; X++) {
+        int used = m->pred_flag[X];
+        d->mf_mv[4 * idx + 2 * X] = (int16_t)(used ? m->mv[X][0] : 0); d->mf_mv[4 * idx + 2 * X + 1] = (int16_t)(used ? m->mv[X][1] : 0);
+        d->mf_ref[2 * idx + X] = (int8_t)(used ? m->ref_idx[X] : -1);
+        d->mf_poc[2 * idx + X] = used ? d->sh->ref_poc[X][m->ref_idx[X]] : 0;
+      }
     }
 }
 
@@ -318,11 +473,11 @@ static void parse_mvd(Dec* d, int* mvd)
 }
 
 /* returns merge_flag */
-static int prediction_unit(Dec* d, const PbGeom* g, int PartMode, int cu_skip)
+static int prediction_unit(Dec* d, const PbGeom* g, int PartMode, int cu_skip, int ctDepth)
 {
   const SliceHdr* h = d->sh;
   int merge_flag = 1, merge_idx = 0;
-  Motion m;
+  Motion m = motion_none();
   if (!cu_skip) merge_flag = decode_decision(d, CTX_MERGE_FLAG);
   if (merge_flag) {
     if (h->max_num_merge_cand > 1) {   /* TR, cMax = MaxNumMergeCand - 1: first bin context coded, the others bypass */
@@ -330,24 +485,40 @@ static int prediction_unit(Dec* d, const PbGeom* g, int PartMode, int cu_skip)
     }
     m = derive_merge(d, g, PartMode, merge_idx);
   } else {
-    int ref_idx = 0;
-    if (h->num_ref_idx_l0_active > 1) {   /* TR, cMax = num_ref_idx_l0_active_minus1: bins 0 and 1 context coded, the rest bypass */
-      int cmax = h->num_ref_idx_l0_active - 1;
-      while (ref_idx < cmax) {
-        int b = ref_idx < 2 ? decode_decision(d, CTX_REF_IDX + ref_idx) : decode_bypass(d);
-        if (!b) break;
-        ref_idx++;
+    /* inter_pred_idc (9.3.3.8 / Table 9-41): PRED_L0 0, PRED_L1 1, PRED_BI 2; blocks of 8x4 / 4x8 cannot be bi-predicted */
+    int idc = 0;
+    if (h->slice_type == 0) {
+      if (g->nPbW + g->nPbH != 12 && decode_decision(d, CTX_INTER_PRED_IDC + ctDepth)) idc = 2;
+      else idc = decode_decision(d, CTX_INTER_PRED_IDC + 4);
+    }
+    int mvd[2][2] = {{0, 0}, {0, 0}}, ref_idx[2] = {-1, -1}, mvp_flag[2] = {0, 0};
+    for (int X = 0; X < 2; X++) {
+      if (!(idc == 2 || idc == X)) continue;
+      int active = X ? h->num_ref_idx_l1_active : h->num_ref_idx_l0_active;
+      ref_idx[X] = 0;
+      if (active > 1) {   /* TR, cMax = num_ref_idx_lX_active_minus1: bins 0 and 1 context coded, the rest bypass */
+        int cmax = active - 1, r = 0;
+        while (r < cmax) {
+          int b = r < 2 ? decode_decision(d, CTX_REF_IDX + r) : decode_bypass(d);
+          if (!b) break;
+          r++;
+        }
+        ref_idx[X] = r;
+      }
+      if (X == 1 && h->mvd_l1_zero_flag && idc == 2) { mvd[1][0] = mvd[1][1] = 0; }
+      else parse_mvd(d, mvd[X]);
+      mvp_flag[X] = decode_decision(d, CTX_MVP_FLAG);
+    }
+    for (int X = 0; X < 2; X++) {
+      if (ref_idx[X] < 0) continue;
+      int mvp[2];
+      derive_mvp(d, g, X, ref_idx[X], mvp_flag[X], mvp);
+      m.pred_flag[X] = 1; m.ref_idx[X] = ref_idx[X];
+      for (int k = 0; k < 2; k++) {   /* 8.5.3.2.1: uLX = (mvpLX + mvdLX + 2^16) % 2^16, wrapped into 16 bits */
+        int u = (mvp[k] + mvd[X][k] + 65536) & 65535;
+        m.mv[X][k] = u >= 32768 ? u - 65536 : u;
       }
     }
-    int mvd[2], mvp[2];
-    parse_mvd(d, mvd);
-    int mvp_flag = decode_decision(d, CTX_MVP_FLAG);
-    derive_mvp(d, g, ref_idx, mvp_flag, mvp);
-    for (int k = 0; k < 2; k++) {   /* 8.5.3.2.1: uLX = (mvpLX + mvdLX + 2^16) % 2^16, wrapped into 16 bits */
-      int u = (mvp[k] + mvd[k] + 65536) & 65535;
-      m.mv[k] = u >= 32768 ? u - 65536 : u;
-    }
-    m.ref_idx = ref_idx;
   }
   store_motion(d, g->xPb, g->yPb, g->nPbW, g->nPbH, &m);
   predict_pu(d, g->xPb, g->yPb, g->nPbW, g->nPbH, &m);
@@ -424,6 +595,7 @@ static void mark_cu_no_residual(Dec* d, CuCtx* cu, int x0, int y0, int log2CbSiz
 }
 
 /* 8.7.2.4 boundary filtering strength of the edge between units idxP and idxQ (luma sample position (x, y) of q0; dir 0: vertical edge) */
+static int mv_far(const int16_t* a, const int16_t* b) { return Abs(a[0] - b[0]) >= 4 || Abs(a[1] - b[1]) >= 4; }
 static int edge_bs(Dec* d, int idxP, int idxQ, int x, int y, int dir)
 {
   if (!d->m_pred) return 2;                                     /* intra picture */
@@ -431,7 +603,22 @@ static int edge_bs(Dec* d, int idxP, int idxQ, int x, int y, int dir)
   int tbq = 1 << d->m_log2_tb[idxQ];
   int tu_edge = dir == 0 ? (x & (tbq - 1)) == 0 : (y & (tbq - 1)) == 0;      /* transform blocks are aligned to their size */
   if (tu_edge && ((d->m_flags[idxP] | d->m_flags[idxQ]) & 1)) return 1;     /* a block with non-zero luma coefficient levels */
-  if (d->mf_poc[idxP] != d->mf_poc[idxQ]) return 1;                          /* different reference PICTURES (not indices) */
-  if (Abs(d->mf_mv[2 * idxP] - d->mf_mv[2 * idxQ]) >= 4 || Abs(d->mf_mv[2 * idxP + 1] - d->mf_mv[2 * idxQ + 1]) >= 4) return 1;
-  return 0;
+  /* different reference PICTURES (not indices, not lists) or a different number of motion vectors */
+  const int8_t* rP = d->mf_ref + 2 * idxP; const int8_t* rQ = d->mf_ref + 2 * idxQ;
+  const int32_t* pP = d->mf_poc + 2 * idxP; const int32_t* pQ = d->mf_poc + 2 * idxQ;
+  const int16_t* vP = d->mf_mv + 4 * idxP; const int16_t* vQ = d->mf_mv + 4 * idxQ;
+  int nP = (rP[0] >= 0) + (rP[1] >= 0), nQ = (rQ[0] >= 0) + (rQ[1] >= 0);
+  if (nP != nQ) return 1;
+  if (nP == 1) {
+    int LP = rP[0] >= 0 ? 0 : 1, LQ = rQ[0] >= 0 ? 0 : 1;
+    if (pP[LP] != pQ[LQ]) return 1;
+    return mv_far(vP + 2 * LP, vQ + 2 * LQ);
+  }
+  if (!((pP[0] == pQ[0] && pP[1] == pQ[1]) || (pP[0] == pQ[1] && pP[1] == pQ[0]))) return 1;
+  if (pP[0] != pP[1]) {   /* two different reference pictures: compare the vectors that point at the same one */
+    if (pP[0] == pQ[0]) return mv_far(vP, vQ) || mv_far(vP + 2, vQ + 2);
+    return mv_far(vP, vQ + 2) || mv_far(vP + 2, vQ);
+  }
+  /* both vectors of both blocks point at the same picture: either pairing may match */
+  return (mv_far(vP, vQ) || mv_far(vP + 2, vQ + 2)) && (mv_far(vP, vQ + 2) || mv_far(vP + 2, vQ));
 }

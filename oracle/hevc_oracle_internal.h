@@ -62,7 +62,8 @@ enum {
   CTX_MVD_GT1 = 147,
   CTX_MVP_FLAG = 148,
   CTX_RQT_ROOT_CBF = 149,
-  CTX_COUNT = 150
+  CTX_INTER_PRED_IDC = 150,  /* 5: bin 0 by CtDepth 0..3, bin 1 (B slices) */
+  CTX_COUNT = 155
 };
 extern const uint8_t hevc_cabac_init_I[CTX_COUNT];
 extern const uint8_t hevc_cabac_init_P[2][CTX_COUNT];   /* initType 1 and 2 (P slice: cabac_init_flag ? 2 : 1) */

@@ -165,6 +165,13 @@ typedef struct {
   int frame_idx;
 } Enc;
 
+/* one picture of a sequence in coding order: its type and its reference picture set (POCs, closest first) */
+typedef struct {
+  int poc, slice_type /* 2 I, 1 P, 0 B */, nal_type;
+  int n_neg, n_pos, neg_poc[16], pos_poc[16];
+  uint8_t neg_used[16], pos_used[16];
+} PicPlan;
+
 static uint32_t rnd(Enc* e)
 {
   e->rng = e->rng * 6364136223846793005ULL + 1442695040888963407ULL;
@@ -798,7 +805,7 @@ static void enc_coding_unit(Enc* e, int x0, int y0, int log2CbSize, int cqtDepth
       d->m_flags[idx] = (uint8_t)((d->cu_transquant_bypass_flag ? 0x08 : 0) | (pcm_flag ? 0x10 : 0));
       d->m_decoded[idx] = 1;
       d->m_ipm[idx] = 1;
-      if (d->m_pred) { d->m_pred[idx] = 0; d->mf_ref[idx] = -1; d->mf_poc[idx] = 0; d->mf_mv[2 * idx] = d->mf_mv[2 * idx + 1] = 0; }
+      if (d->m_pred) { d->m_pred[idx] = 0; d->mf_ref[2 * idx] = d->mf_ref[2 * idx + 1] = -1; d->mf_poc[2 * idx] = d->mf_poc[2 * idx + 1] = 0; memset(d->mf_mv + 4 * idx, 0, 4 * sizeof(int16_t)); }
     }
   if (pcm_flag) {
     size_t start = e->pcm_bits;
@@ -1111,7 +1118,8 @@ static void enc_parameter_sets(Enc* e, Bytes* pstream)
   p->pps_deblocking_filter_disabled_flag = prm->deblock_disable;
   p->pps_beta_offset_div2 = prm->beta_offset_div2; p->pps_tc_offset_div2 = prm->tc_offset_div2;
   p->log2_parallel_merge_level = prm->parallel_merge_level >= 2 ? Min(prm->parallel_merge_level, s->log2_ctb) : 2;
-  p->num_ref_idx_l0_default_active = 1;
+  p->num_ref_idx_l0_default_active = 1; p->num_ref_idx_l1_default_active = 1;
+  p->weighted_pred_flag = p->weighted_bipred_flag = d->seq_mode && prm->weighted_pred ? 1 : 0;
   p->cabac_init_present_flag = prm->cabac_init_present ? 1 : 0;
   p->lists_modification_present_flag = prm->lists_modification ? 1 : 0;
   p->valid = 1;
@@ -1121,7 +1129,9 @@ static void enc_parameter_sets(Enc* e, Bytes* pstream)
   /* VPS 7.3.2.1 */
   bw_u(&w, 0, 4); bw_u(&w, 3, 2); bw_u(&w, 0, 6); bw_u(&w, 0, 3); bw_u(&w, 1, 1); bw_u(&w, 0xffff, 16);
   write_ptl(&w, prm->bit_depth, prm->chroma_format_idc);
-  bw_u(&w, 1, 1); bw_ue(&w, 0); bw_ue(&w, 0); bw_ue(&w, 0);
+  /* vps_max_dec_pic_buffering_minus1, vps_max_num_reorder_pics (B pictures are coded after the anchor that follows them), vps_max_latency_increase_plus1 */
+  const int dpb_minus1 = d->seq_mode ? Min(15, Max(1, prm->inter_num_refs) + (prm->b_frames > 0 ? 2 : 0)) : 0, reorder = d->seq_mode && prm->b_frames > 0 ? 1 : 0;
+  bw_u(&w, 1, 1); bw_ue(&w, dpb_minus1); bw_ue(&w, reorder); bw_ue(&w, 0);
   bw_u(&w, 0, 6); bw_ue(&w, 0); bw_u(&w, 0, 1); bw_u(&w, 0, 1);
   bw_trailing(&w);
   put_nal(&stream, 32, w.p, w.nbits >> 3);
@@ -1137,7 +1147,7 @@ static void enc_parameter_sets(Enc* e, Bytes* pstream)
   if (cw) { bw_ue(&w, 0); bw_ue(&w, s->conf_win_right); bw_ue(&w, 0); bw_ue(&w, s->conf_win_bottom); }
   bw_ue(&w, s->bit_depth_luma - 8); bw_ue(&w, s->bit_depth_chroma - 8);
   bw_ue(&w, s->log2_max_poc_lsb - 4);
-  bw_u(&w, 1, 1); bw_ue(&w, 0); bw_ue(&w, 0); bw_ue(&w, 0);
+  bw_u(&w, 1, 1); bw_ue(&w, dpb_minus1); bw_ue(&w, reorder); bw_ue(&w, 0);
   bw_ue(&w, s->log2_min_cb - 3); bw_ue(&w, s->log2_ctb - s->log2_min_cb);
   bw_ue(&w, s->log2_min_tb - 2); bw_ue(&w, s->log2_max_tb - s->log2_min_tb);
   bw_ue(&w, s->max_transform_hierarchy_depth_inter); bw_ue(&w, s->max_transform_hierarchy_depth_intra);
@@ -1152,7 +1162,8 @@ static void enc_parameter_sets(Enc* e, Bytes* pstream)
     bw_ue(&w, s->log2_min_pcm_cb - 3); bw_ue(&w, s->log2_max_pcm_cb - s->log2_min_pcm_cb);
     bw_u(&w, s->pcm_loop_filter_disabled_flag, 1);
   }
-  bw_ue(&w, 0); bw_u(&w, 0, 1); bw_u(&w, 0, 1); bw_u(&w, s->strong_intra_smoothing_enabled_flag, 1);
+  s->sps_temporal_mvp_enabled_flag = d->seq_mode && prm->temporal_mvp ? 1 : 0;
+  bw_ue(&w, 0); bw_u(&w, 0, 1); bw_u(&w, s->sps_temporal_mvp_enabled_flag, 1); bw_u(&w, s->strong_intra_smoothing_enabled_flag, 1);
   if (prm->vui_matrix >= 0) {
     s->colour_primaries = prm->vui_primaries; s->transfer_characteristics = prm->vui_transfer;
     s->matrix_coeffs = prm->vui_matrix; s->video_full_range_flag = prm->vui_full_range;
@@ -1174,7 +1185,7 @@ static void enc_parameter_sets(Enc* e, Bytes* pstream)
   bw_u(&w, p->cu_qp_delta_enabled_flag, 1);
   if (p->cu_qp_delta_enabled_flag) bw_ue(&w, p->diff_cu_qp_delta_depth);
   bw_se(&w, p->pps_cb_qp_offset); bw_se(&w, p->pps_cr_qp_offset); bw_u(&w, 0, 1);
-  bw_u(&w, 0, 1); bw_u(&w, 0, 1);
+  bw_u(&w, p->weighted_pred_flag, 1); bw_u(&w, p->weighted_bipred_flag, 1);
   bw_u(&w, p->transquant_bypass_enabled_flag, 1); bw_u(&w, p->tiles_enabled_flag, 1); bw_u(&w, p->entropy_coding_sync_enabled_flag, 1);
   if (p->tiles_enabled_flag) {
     bw_ue(&w, p->num_tile_columns - 1); bw_ue(&w, p->num_tile_rows - 1); bw_u(&w, 1, 1);
@@ -1193,8 +1204,8 @@ static void enc_parameter_sets(Enc* e, Bytes* pstream)
 #undef stream
 }
 
-/* one picture: frame 0 an IDR intra picture, the following ones P pictures (TRAIL_R) referencing the previous pictures */
-static void enc_picture(Enc* e, const uint16_t* const planes[3], int frame_idx, Bytes* pstream)
+/* one picture of the coding-order plan (enc_run): an IDR intra picture, a P or a B picture */
+static void enc_picture(Enc* e, const uint16_t* const planes[3], const PicPlan* plan, Bytes* pstream)
 {
   Dec* d = e->d;
   const hevc_testenc_params* prm = &e->prm;
@@ -1202,16 +1213,16 @@ static void enc_picture(Enc* e, const uint16_t* const planes[3], int frame_idx, 
   uint16_t** src = e->src_alloc;
   BW w; memset(&w, 0, sizeof(w));
 #define stream (*pstream)
-  const int is_p = frame_idx > 0;
-  const int nal_type = is_p ? 1 : 19;
+  const int frame_idx = plan->poc;
+  const int is_p = plan->slice_type != 2;      /* a P or B picture */
+  const int is_b = plan->slice_type == 0;
+  const int nal_type = plan->nal_type;
   e->frame_idx = frame_idx;
   setup_picture(d);
   StRps rps; memset(&rps, 0, sizeof(rps));
-  if (is_p) {   /* the RPS in the slice header: the previous pictures, the farthest of three or more kept but not used by this picture */
-    int nrefs = Min(frame_idx, Max(1, prm->inter_num_refs));
-    rps.num_neg = nrefs;
-    for (int i = 0; i < nrefs; i++) { rps.delta_s0[i] = -(i + 1); rps.used_s0[i] = !(nrefs >= 3 && i == nrefs - 1); }
-  }
+  rps.num_neg = plan->n_neg; rps.num_pos = plan->n_pos;
+  for (int i = 0; i < plan->n_neg; i++) { rps.delta_s0[i] = plan->neg_poc[i] - plan->poc; rps.used_s0[i] = plan->neg_used[i]; }
+  for (int i = 0; i < plan->n_pos; i++) { rps.delta_s1[i] = plan->pos_poc[i] - plan->poc; rps.used_s1[i] = plan->pos_used[i]; }
   if (d->seq_mode) inter_begin_picture(d, nal_type, frame_idx & 255, &rps);
   for (int c = 0; c < (s->chroma_format_idc ? 3 : 1); c++) {
     int W = c ? d->Wc : d->W, H = c ? d->Hc : d->H;
@@ -1268,19 +1279,25 @@ static void enc_picture(Enc* e, const uint16_t* const planes[3], int frame_idx, 
   }
   int CtbSizeY = 1 << s->log2_ctb;
   SliceHdr cur_hdr; memset(&cur_hdr, 0, sizeof(cur_hdr));
-  int list_mod = 0, list_entries[16];
+  int list_mod[2] = {0, 0}, list_entries[2][16];
+  uint8_t wp_lf[2][16], wp_cf[2][16]; int wp_dw[2][16][3], wp_do[2][16][3];   /* pred_weight_table as coded (flags, deltas) */
+  memset(wp_lf, 0, sizeof(wp_lf)); memset(wp_cf, 0, sizeof(wp_cf)); memset(wp_dw, 0, sizeof(wp_dw)); memset(wp_do, 0, sizeof(wp_do));
   for (int si = 0; si < nsl; si++) {
     const int is_dep = seg_dependent ? seg_dependent[si] : 0;
     SliceHdr hdr; memset(&hdr, 0, sizeof(hdr));
     if (is_dep) goto segment_data;   /* a dependent slice segment continues the slice: its header fields are those of cur_hdr */
     hdr.first_slice_segment_in_pic_flag = si == 0;
     hdr.slice_segment_address = d->CtbAddrTsToRs[slice_start[si]];
-    hdr.slice_type = is_p ? 1 : 2;
+    hdr.slice_type = plan->slice_type;
     if (is_p) {
-      int total = d->n_st_curr_before;
+      int total = d->n_st_curr_before + d->n_st_curr_after;
       hdr.num_ref_idx_l0_active = (si & 1) ? Min(15, total + 1) : total;   /* one more than there are pictures: the list wraps around (8.3.4) */
+      if (is_b) hdr.num_ref_idx_l1_active = (si & 1) ? total : Min(15, total + 1);
       hdr.max_num_merge_cand = prm->max_merge_cand >= 1 && prm->max_merge_cand <= 5 ? prm->max_merge_cand : 5;
       hdr.cabac_init_flag = p->cabac_init_present_flag ? (int)((si + frame_idx) & 1) : 0;
+      hdr.slice_temporal_mvp = s->sps_temporal_mvp_enabled_flag;
+      hdr.mvd_l1_zero_flag = is_b && prm->mvd_l1_zero ? (int)((si + frame_idx) & 1) ^ 1 : 0;
+      hdr.collocated_from_l0 = 1;
     }
     hdr.slice_sao_luma_flag = s->sao_enabled_flag; hdr.slice_sao_chroma_flag = s->sao_enabled_flag && s->chroma_format_idc;
     hdr.slice_qp_delta = prm->qp - 26 + (si % 3) - (si ? 1 : 0) * 0;
@@ -1296,10 +1313,41 @@ static void enc_picture(Enc* e, const uint16_t* const planes[3], int frame_idx, 
     hdr.SliceQpY = 26 + p->init_qp_minus26 + hdr.slice_qp_delta;
     if (d->nslices == d->capslices) { d->capslices = d->capslices ? d->capslices * 2 : 8; d->slices = (SliceHdr*)realloc(d->slices, sizeof(SliceHdr) * d->capslices); }
     if (is_p) {
-      int total = d->n_st_curr_before;
-      list_mod = p->lists_modification_present_flag && total > 1 && ((si + frame_idx) % 3 != 0);
-      for (int i = 0; i < hdr.num_ref_idx_l0_active; i++) list_entries[i] = (int)(rnd(e) % (unsigned)total);
-      build_ref_list0(d, &hdr, list_mod ? list_entries : NULL);
+      int total = d->n_st_curr_before + d->n_st_curr_after;
+      for (int X = 0; X < (is_b ? 2 : 1); X++) {
+        list_mod[X] = p->lists_modification_present_flag && total > 1 && ((si + frame_idx + X) % 3 != 0);
+        for (int i = 0; i < (X ? hdr.num_ref_idx_l1_active : hdr.num_ref_idx_l0_active); i++) list_entries[X][i] = (int)(rnd(e) % (unsigned)total);
+        build_ref_list(d, &hdr, X, list_mod[X] ? list_entries[X] : NULL);
+      }
+      if (hdr.slice_temporal_mvp) {   /* the collocated picture: any entry of either list */
+        if (is_b) hdr.collocated_from_l0 = (int)(rnd(e) & 1);
+        int n = hdr.collocated_from_l0 ? hdr.num_ref_idx_l0_active : hdr.num_ref_idx_l1_active;
+        hdr.collocated_ref_idx = (int)(rnd(e) % (unsigned)n);
+      }
+      hdr.weighted = is_b ? p->weighted_bipred_flag : p->weighted_pred_flag;
+      if (hdr.weighted) {   /* a random pred_weight_table; entries without a flag keep the default weight */
+        int nc = s->chroma_format_idc ? 3 : 1;
+        hdr.luma_log2_wd = (int)(rnd(e) % 8); hdr.chroma_log2_wd = nc == 3 ? (int)(rnd(e) % 8) : hdr.luma_log2_wd;
+        for (int X = 0; X < (is_b ? 2 : 1); X++)
+          for (int i = 0; i < (X ? hdr.num_ref_idx_l1_active : hdr.num_ref_idx_l0_active); i++) {
+            wp_lf[X][i] = (uint8_t)rnd_pct(e, 60); wp_cf[X][i] = (uint8_t)(nc == 3 && rnd_pct(e, 60));
+            hdr.wp_weight[X][i][0] = (int16_t)(1 << hdr.luma_log2_wd); hdr.wp_offset[X][i][0] = 0;
+            hdr.wp_weight[X][i][1] = hdr.wp_weight[X][i][2] = (int16_t)(1 << hdr.chroma_log2_wd); hdr.wp_offset[X][i][1] = hdr.wp_offset[X][i][2] = 0;
+            if (wp_lf[X][i]) {
+              wp_dw[X][i][0] = (int)(rnd(e) % 17) - 8; wp_do[X][i][0] = (int)(rnd(e) % 41) - 20;
+              if (rnd_pct(e, 10)) { wp_dw[X][i][0] = rnd_pct(e, 50) ? -128 : 127; wp_do[X][i][0] = rnd_pct(e, 50) ? -128 : 127; }   /* range ends */
+              hdr.wp_weight[X][i][0] = (int16_t)((1 << hdr.luma_log2_wd) + wp_dw[X][i][0]); hdr.wp_offset[X][i][0] = (int16_t)wp_do[X][i][0];
+            }
+            if (wp_cf[X][i])
+              for (int j = 1; j < 3; j++) {
+                wp_dw[X][i][j] = (int)(rnd(e) % 17) - 8; wp_do[X][i][j] = (int)(rnd(e) % 81) - 40;
+                if (rnd_pct(e, 10)) { wp_dw[X][i][j] = rnd_pct(e, 50) ? -128 : 127; wp_do[X][i][j] = rnd_pct(e, 50) ? -512 : 511; }
+                int wgt = (1 << hdr.chroma_log2_wd) + wp_dw[X][i][j];
+                hdr.wp_weight[X][i][j] = (int16_t)wgt;
+                hdr.wp_offset[X][i][j] = (int16_t)Clip3(-128, 127, (128 + wp_do[X][i][j] - ((128 * wgt) >> hdr.chroma_log2_wd)));
+              }
+          }
+      }
     }
     d->slices[d->nslices] = hdr; d->sh = &d->slices[d->nslices]; d->sh_idx = d->nslices; d->nslices++;
     cur_hdr = hdr;
@@ -1382,7 +1430,7 @@ static void enc_picture(Enc* e, const uint16_t* const planes[3], int frame_idx, 
     /* slice segment header 7.3.6.1 */
     memset(&w, 0, sizeof(w));
     bw_u(&w, hdr.first_slice_segment_in_pic_flag, 1);
-    if (!is_p) bw_u(&w, 0, 1); /* no_output_of_prior_pics_flag (IRAP only) */
+    if (nal_type >= 16 && nal_type <= 23) bw_u(&w, 0, 1); /* no_output_of_prior_pics_flag (IRAP only) */
     bw_ue(&w, 0);
     if (!hdr.first_slice_segment_in_pic_flag) {
       if (p->dependent_slice_segments_enabled_flag) bw_u(&w, is_dep, 1);
@@ -1390,20 +1438,44 @@ static void enc_picture(Enc* e, const uint16_t* const planes[3], int frame_idx, 
     }
     if (!is_dep) {
       bw_ue(&w, hdr.slice_type);
-      if (is_p) {   /* 7.3.6.1: POC lsb, the picture's RPS coded in the slice header (idx == num_short_term_ref_pic_sets == 0: no inter-RPS flag) */
+      if (nal_type != 19 && nal_type != 20) {   /* 7.3.6.1: POC lsb, the picture's RPS coded in the slice header (idx == num_short_term_ref_pic_sets == 0: no inter-RPS flag) */
         bw_u(&w, frame_idx & 255, s->log2_max_poc_lsb);
         bw_u(&w, 0, 1);                                   /* short_term_ref_pic_set_sps_flag */
-        bw_ue(&w, rps.num_neg); bw_ue(&w, 0);
-        for (int i = 0; i < rps.num_neg; i++) { bw_ue(&w, 0); bw_u(&w, rps.used_s0[i], 1); }   /* delta_poc_s0_minus1 0: consecutive pictures */
+        bw_ue(&w, rps.num_neg); bw_ue(&w, rps.num_pos);
+        for (int i = 0, prev = 0; i < rps.num_neg; i++) { bw_ue(&w, prev - rps.delta_s0[i] - 1); bw_u(&w, rps.used_s0[i], 1); prev = rps.delta_s0[i]; }
+        for (int i = 0, prev = 0; i < rps.num_pos; i++) { bw_ue(&w, rps.delta_s1[i] - prev - 1); bw_u(&w, rps.used_s1[i], 1); prev = rps.delta_s1[i]; }
+        if (s->sps_temporal_mvp_enabled_flag) bw_u(&w, hdr.slice_temporal_mvp, 1);
       }
       if (s->sao_enabled_flag) { bw_u(&w, hdr.slice_sao_luma_flag, 1); if (s->chroma_format_idc) bw_u(&w, hdr.slice_sao_chroma_flag, 1); }
       if (is_p) {
         bw_u(&w, 1, 1); bw_ue(&w, hdr.num_ref_idx_l0_active - 1);                               /* num_ref_idx_active_override_flag */
-        if (p->lists_modification_present_flag && d->n_st_curr_before > 1) {
-          bw_u(&w, list_mod, 1);
-          if (list_mod) for (int i = 0; i < hdr.num_ref_idx_l0_active; i++) bw_u(&w, list_entries[i], ceil_log2(d->n_st_curr_before));
-        }
+        if (is_b) bw_ue(&w, hdr.num_ref_idx_l1_active - 1);
+        int total = d->n_st_curr_before + d->n_st_curr_after;
+        if (p->lists_modification_present_flag && total > 1)
+          for (int X = 0; X < (is_b ? 2 : 1); X++) {
+            bw_u(&w, list_mod[X], 1);
+            if (list_mod[X]) for (int i = 0; i < (X ? hdr.num_ref_idx_l1_active : hdr.num_ref_idx_l0_active); i++) bw_u(&w, list_entries[X][i], ceil_log2(total));
+          }
+        if (is_b) bw_u(&w, hdr.mvd_l1_zero_flag, 1);
         if (p->cabac_init_present_flag) bw_u(&w, hdr.cabac_init_flag, 1);
+        if (hdr.slice_temporal_mvp) {
+          if (is_b) bw_u(&w, hdr.collocated_from_l0, 1);
+          if ((hdr.collocated_from_l0 && hdr.num_ref_idx_l0_active > 1) || (!hdr.collocated_from_l0 && hdr.num_ref_idx_l1_active > 1)) bw_ue(&w, hdr.collocated_ref_idx);
+        }
+        if (hdr.weighted) {   /* 7.3.6.3 */
+          int nc = s->chroma_format_idc ? 3 : 1;
+          bw_ue(&w, hdr.luma_log2_wd);
+          if (nc == 3) bw_se(&w, hdr.chroma_log2_wd - hdr.luma_log2_wd);
+          for (int X = 0; X < (is_b ? 2 : 1); X++) {
+            int n = X ? hdr.num_ref_idx_l1_active : hdr.num_ref_idx_l0_active;
+            for (int i = 0; i < n; i++) bw_u(&w, wp_lf[X][i], 1);
+            if (nc == 3) for (int i = 0; i < n; i++) bw_u(&w, wp_cf[X][i], 1);
+            for (int i = 0; i < n; i++) {
+              if (wp_lf[X][i]) { bw_se(&w, wp_dw[X][i][0]); bw_se(&w, wp_do[X][i][0]); }
+              if (wp_cf[X][i]) for (int j = 1; j < 3; j++) { bw_se(&w, wp_dw[X][i][j]); bw_se(&w, wp_do[X][i][j]); }
+            }
+          }
+        }
         bw_ue(&w, 5 - hdr.max_num_merge_cand);
       }
       bw_se(&w, hdr.slice_qp_delta);
@@ -1444,6 +1516,7 @@ static void enc_picture(Enc* e, const uint16_t* const planes[3], int frame_idx, 
     if (slot >= d->n_dpb) d->n_dpb = slot + 1;
     for (int c = 0; c < nc; c++) d->dpb[slot].plane[c] = fin[c];
     d->dpb[slot].poc = d->poc; d->dpb[slot].valid = 1;
+    dpb_store_motion(d, &d->dpb[slot]);
   }
   release_picture(d);
 #undef stream
@@ -1473,11 +1546,62 @@ static int enc_run(const hevc_testenc_params* prm, int n_frames, const uint16_t*
   }
   if (seq_mode && (prm->chroma_format_idc > 1 || prm->scaling_list)) fail(d, "sequences with P pictures: 4:0:0 / 4:2:0 without scaling lists only");
   enc_parameter_sets(e, &stream);
-  for (int f = 0; f < n_frames; f++) {
-    enc_picture(e, planes + 3 * f, f, &stream);
-    out[f] = stream.p; out_sizes[f] = stream.n;
+  /* ---- coding order: frame 0 an IDR picture; with b_frames = b every (b + 1)-th picture is a P picture (an "anchor") and the b pictures
+     before it are B pictures coded after it; the pictures behind the last anchor are P pictures.  A picture's own references: the anchors
+     before it (inter_num_refs of them; the farthest of three or more is kept in the RPS but not used), for a B picture also the anchor
+     after it and, with b_ref, the B picture before it.  Its RPS additionally keeps every decoded picture a later picture still needs. */
+  PicPlan* plan = (PicPlan*)xcalloc(d, (size_t)n_frames, sizeof(PicPlan));
+  {
+    const int b = seq_mode ? Max(0, prm->b_frames) : 0, step = b + 1;
+    int n = 0;
+    plan[n].poc = 0; plan[n].slice_type = 2; plan[n].nal_type = 19; n++;
+    for (int a = step; a - step < n_frames - 1; a += step) {
+      if (a < n_frames) {
+        plan[n].poc = a; plan[n].slice_type = 1; plan[n].nal_type = 1; n++;
+        for (int q = a - b; q < a; q++) { plan[n].poc = q; plan[n].slice_type = 0; plan[n].nal_type = prm->b_ref ? 1 : 0; n++; }
+      } else
+        for (int q = a - b; q < n_frames; q++) { plan[n].poc = q; plan[n].slice_type = 1; plan[n].nal_type = 1; n++; }
+    }
+    if (n != n_frames) fail(d, "testenc: picture plan");
+    const int nrefs = Max(1, prm->inter_num_refs);
+    for (int k = 1; k < n_frames; k++) {   /* own references */
+      PicPlan* P = &plan[k];
+      int prev_anchors[16], npa = 0;
+      for (int j = k - 1; j >= 0 && npa < 16; j--) if (plan[j].slice_type != 0 && plan[j].poc < P->poc) prev_anchors[npa++] = plan[j].poc;
+      /* (coding order of anchors is POC order, so prev_anchors is sorted closest first) */
+      if (P->slice_type == 0) {
+        if (prm->b_ref && k > 0 && plan[k - 1].slice_type == 0 && plan[k - 1].poc == P->poc - 1) { P->neg_poc[P->n_neg] = P->poc - 1; P->neg_used[P->n_neg++] = 1; }
+        for (int j = k - 1; j >= 0; j--) if (plan[j].slice_type != 0 && plan[j].poc > P->poc) { P->pos_poc[0] = plan[j].poc; P->pos_used[0] = 1; P->n_pos = 1; break; }
+      }
+      int take = Min(npa, nrefs);
+      for (int i = 0; i < take; i++) { P->neg_poc[P->n_neg] = prev_anchors[i]; P->neg_used[P->n_neg++] = !(take >= 3 && i == take - 1); }
+    }
+    for (int k = 1; k < n_frames; k++) {   /* keep what later pictures need */
+      PicPlan* P = &plan[k];
+      for (int j = k + 1; j < n_frames; j++)
+        for (int t = 0; t < plan[j].n_neg + plan[j].n_pos; t++) {
+          int poc = t < plan[j].n_neg ? plan[j].neg_poc[t] : plan[j].pos_poc[t - plan[j].n_neg];
+          int decoded = 0, have = 0;
+          for (int q = 0; q < k; q++) if (plan[q].poc == poc) decoded = 1;
+          for (int q = 0; q < P->n_neg; q++) if (P->neg_poc[q] == poc) have = 1;
+          for (int q = 0; q < P->n_pos; q++) if (P->pos_poc[q] == poc) have = 1;
+          if (!decoded || have || poc == P->poc) continue;
+          if (poc < P->poc) { if (P->n_neg < 16) { P->neg_poc[P->n_neg] = poc; P->neg_used[P->n_neg++] = 0; } }
+          else if (P->n_pos < 16) { P->pos_poc[P->n_pos] = poc; P->pos_used[P->n_pos++] = 0; }
+        }
+      /* S0 by decreasing, S1 by increasing POC (7.4.8) */
+      for (int i = 0; i < P->n_neg; i++) for (int j = i + 1; j < P->n_neg; j++) if (P->neg_poc[j] > P->neg_poc[i]) {
+        int t = P->neg_poc[i]; P->neg_poc[i] = P->neg_poc[j]; P->neg_poc[j] = t; uint8_t u = P->neg_used[i]; P->neg_used[i] = P->neg_used[j]; P->neg_used[j] = u; }
+      for (int i = 0; i < P->n_pos; i++) for (int j = i + 1; j < P->n_pos; j++) if (P->pos_poc[j] < P->pos_poc[i]) {
+        int t = P->pos_poc[i]; P->pos_poc[i] = P->pos_poc[j]; P->pos_poc[j] = t; uint8_t u = P->pos_used[i]; P->pos_used[i] = P->pos_used[j]; P->pos_used[j] = u; }
+    }
+  }
+  for (int k = 0; k < n_frames; k++) {
+    enc_picture(e, planes + 3 * plan[k].poc, &plan[k], &stream);
+    out[k] = stream.p; out_sizes[k] = stream.n;
     stream.p = NULL; stream.n = stream.cap = 0;
   }
+  free(plan);
   free(e->ev); free(e->pcm_blob);
   free_dec(d);
   return 0;

@@ -35,6 +35,13 @@ typedef struct hevc_testenc_params {
   int max_transform_hierarchy_depth_inter;
   int cabac_init_present, lists_modification;
   int global_mv_x, global_mv_y; /* motion (quarter luma samples) most vectors are drawn around                             */
+  /* ---- B pictures, TMVP, weighted prediction ---- */
+  int b_frames;                 /* B pictures between two anchor (I / P) pictures: coded after the later anchor, POC order != coding order */
+  int b_ref;                    /* 1: B pictures are reference pictures too (TRAIL_R; a B picture also predicts from the one before it)    */
+  int inter_bi_pct;             /* % of the non-merged prediction units of a B picture that are bi-predicted (the rest: list 0 or list 1)   */
+  int temporal_mvp;             /* sps_temporal_mvp_enabled_flag, slice_temporal_mvp_enabled_flag in every P / B picture                  */
+  int weighted_pred;            /* weighted_pred_flag / weighted_bipred_flag with a random pred_weight_table per slice                     */
+  int mvd_l1_zero;              /* mvd_l1_zero_flag in B slices                                                                            */
 } hevc_testenc_params;
 
 /* planes: tightly packed uint16 samples at display size (chroma (w+1)/2 x (h+1)/2).
@@ -42,8 +49,9 @@ typedef struct hevc_testenc_params {
  * hevc_testenc_free(). */
 int hevc_testenc_encode(const hevc_testenc_params* prm, const uint16_t* const planes[3], uint8_t** out,
                         size_t* out_size, char* errbuf, size_t errbuf_len);
-/* n_frames pictures at display size: planes[3 * f + c].  out[f] / out_sizes[f]: one malloc'd access unit per picture in plugin framing
- * (the first one carries VPS, SPS, PPS), what libheif pushes sample by sample for a track (libheif/sequences/track_visual.cc:200-280). */
+/* n_frames pictures at display size: planes[3 * f + c], f = output (POC) order.  out[k] / out_sizes[k]: one malloc'd access unit per picture
+ * in plugin framing, k = DECODING order (equal to f without B pictures; the first one carries VPS, SPS, PPS), what libheif pushes sample by
+ * sample for a track (libheif/sequences/track_visual.cc:200-280). */
 int hevc_testenc_encode_seq(const hevc_testenc_params* prm, int n_frames, const uint16_t* const* planes, uint8_t** out,
                             size_t* out_sizes, char* errbuf, size_t errbuf_len);
 void hevc_testenc_free(uint8_t* p);

@@ -81,7 +81,7 @@ static void enc_inter_coding_unit(Enc* e, CuCtx* cu, int x0, int y0, int log2CbS
   for (int k = 0; k < nParts; k++) {
     part_geometry(PartMode, x0, y0, nCbS, k, &g);
     int merge = cu_skip || rnd_pct(e, prm->inter_merge_pct);
-    Motion m;
+    Motion m = motion_none();
     if (!cu_skip) EV_D(CTX_MERGE_FLAG, merge);
     if (k == 0) merge0 = merge;
     if (merge) {
@@ -95,29 +95,45 @@ static void enc_inter_coding_unit(Enc* e, CuCtx* cu, int x0, int y0, int log2CbS
       if (k == 0) n_merge_idx0 = e->nev - ev_merge_idx0;
       m = derive_merge(d, &g, PartMode, merge_idx);
     } else {
-      int ref_idx = nref > 1 ? (int)(rnd(e) % (unsigned)nref) : 0;
-      if (nref > 1) {
-        int cmax = nref - 1;
-        for (int i = 0; i < cmax; i++) {
-          int b = ref_idx > i;
-          if (i < 2) EV_D(CTX_REF_IDX + i, b); else EV_B(b);
-          if (!b) break;
-        }
+      /* inter_pred_idc of a B slice: PRED_L0 0, PRED_L1 1, PRED_BI 2 (not for 8x4 / 4x8 blocks) */
+      int idc = 0;
+      if (d->sh->slice_type == 0) {
+        int can_bi = g.nPbW + g.nPbH != 12;
+        idc = can_bi && rnd_pct(e, prm->inter_bi_pct) ? 2 : (int)(rnd(e) & 1);
+        if (can_bi) EV_D(CTX_INTER_PRED_IDC + cqtDepth, idc == 2);
+        if (idc != 2) EV_D(CTX_INTER_PRED_IDC + 4, idc);
       }
-      int mvp_flag = (int)(rnd(e) & 1), mvp[2];
-      derive_mvp(d, &g, ref_idx, mvp_flag, mvp);
-      int mv[2];
-      unsigned r = rnd(e) % 100;
-      if (r < 30) { mv[0] = mvp[0]; mv[1] = mvp[1]; }                                          /* mvd 0 */
-      else if (r < 85) { mv[0] = prm->global_mv_x + (int)(rnd(e) % 9) - 4; mv[1] = prm->global_mv_y + (int)(rnd(e) % 9) - 4; }
-      else if (r < 97) { mv[0] = (int)(rnd(e) % 257) - 128; mv[1] = (int)(rnd(e) % 257) - 128; }
-      else { mv[0] = (int)(rnd(e) % (unsigned)(8 * d->W + 1)) - 4 * d->W; mv[1] = (int)(rnd(e) % (unsigned)(8 * d->H + 1)) - 4 * d->H; }   /* far outside: padding */
-      int mvd[2];
-      for (int c = 0; c < 2; c++) { mv[c] = Clip3(-32768, 32767, mv[c]); mvd[c] = Clip3(-32768, 32767, mv[c] - mvp[c]); }
-      enc_mvd(e, mvd);
-      EV_D(CTX_MVP_FLAG, mvp_flag);
-      for (int c = 0; c < 2; c++) { int u = (mvp[c] + mvd[c] + 65536) & 65535; m.mv[c] = u >= 32768 ? u - 65536 : u; }
-      m.ref_idx = ref_idx;
+      for (int X = 0; X < 2; X++) {
+        if (!(idc == 2 || idc == X)) continue;
+        int nrefX = X ? d->sh->num_ref_idx_l1_active : nref;
+        int ref_idx = nrefX > 1 ? (int)(rnd(e) % (unsigned)nrefX) : 0;
+        if (nrefX > 1) {
+          int cmax = nrefX - 1;
+          for (int i = 0; i < cmax; i++) {
+            int b = ref_idx > i;
+            if (i < 2) EV_D(CTX_REF_IDX + i, b); else EV_B(b);
+            if (!b) break;
+          }
+        }
+        int mvp_flag = (int)(rnd(e) & 1), mvp[2];
+        derive_mvp(d, &g, X, ref_idx, mvp_flag, mvp);
+        int mv[2];
+        unsigned r = rnd(e) % 100;
+        if (r < 30) { mv[0] = mvp[0]; mv[1] = mvp[1]; }                                          /* mvd 0 */
+        else if (r < 85) {   /* around the global motion: towards a picture after this one the scene moves the other way */
+          int sgn = d->sh->ref_poc[X][ref_idx] > d->poc ? -1 : 1;
+          mv[0] = sgn * prm->global_mv_x + (int)(rnd(e) % 9) - 4; mv[1] = sgn * prm->global_mv_y + (int)(rnd(e) % 9) - 4;
+        }
+        else if (r < 97) { mv[0] = (int)(rnd(e) % 257) - 128; mv[1] = (int)(rnd(e) % 257) - 128; }
+        else { mv[0] = (int)(rnd(e) % (unsigned)(8 * d->W + 1)) - 4 * d->W; mv[1] = (int)(rnd(e) % (unsigned)(8 * d->H + 1)) - 4 * d->H; }   /* far outside: padding */
+        int mvd[2];
+        for (int c = 0; c < 2; c++) { mv[c] = Clip3(-32768, 32767, mv[c]); mvd[c] = Clip3(-32768, 32767, mv[c] - mvp[c]); }
+        if (X == 1 && idc == 2 && d->sh->mvd_l1_zero_flag) mvd[0] = mvd[1] = 0;                   /* MvdL1 is inferred: not coded */
+        else enc_mvd(e, mvd);
+        EV_D(CTX_MVP_FLAG, mvp_flag);
+        for (int c = 0; c < 2; c++) { int u = (mvp[c] + mvd[c] + 65536) & 65535; m.mv[X][c] = u >= 32768 ? u - 65536 : u; }
+        m.ref_idx[X] = ref_idx; m.pred_flag[X] = 1;
+      }
     }
     store_motion(d, g.xPb, g.yPb, g.nPbW, g.nPbH, &m);
     predict_pu(d, g.xPb, g.yPb, g.nPbW, g.nPbH, &m);

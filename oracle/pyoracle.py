@@ -149,8 +149,8 @@ def _picture_dict(L, pic, taps):
             out["sao_offset"] = _arr(pic.sao_offset, (nctb, 3, 4), np.int16)
             if pic.map_pred:
                 out["map_pred"] = _arr(pic.map_pred, (mh, ms), np.uint8)
-                out["mf_mv"] = _arr(pic.mf_mv, (mh, ms, 2), np.int16)
-                out["mf_ref"] = _arr(pic.mf_ref, (mh, ms), np.int8)
+                out["mf_mv"] = _arr(pic.mf_mv, (mh, ms, 2, 2), np.int16)    # [row, column, list, component]
+                out["mf_ref"] = _arr(pic.mf_ref, (mh, ms, 2), np.int8)
         return out
     finally:
         L.hevc_oracle_free_picture(C.byref(pic))
@@ -256,7 +256,8 @@ class _EncParams(C.Structure):
         [("seed", C.c_uint32), ("stress", C.c_int), ("zero_residual_pct", C.c_int), ("dependent_segments", C.c_int)] + \
         [(n, C.c_int) for n in (
             "inter_num_refs", "inter_skip_pct", "inter_intra_pct", "inter_merge_pct", "amp", "max_merge_cand", "parallel_merge_level",
-            "max_transform_hierarchy_depth_inter", "cabac_init_present", "lists_modification", "global_mv_x", "global_mv_y")]
+            "max_transform_hierarchy_depth_inter", "cabac_init_present", "lists_modification", "global_mv_x", "global_mv_y",
+            "b_frames", "b_ref", "inter_bi_pct", "temporal_mvp", "weighted_pred", "mvd_l1_zero")]
 
 
 ENC_DEFAULTS = dict(bit_depth=8, chroma_format_idc=1, log2_ctb=6, log2_min_cb=3, log2_min_tb=2, log2_max_tb=5,
@@ -267,7 +268,8 @@ ENC_DEFAULTS = dict(bit_depth=8, chroma_format_idc=1, log2_ctb=6, log2_min_cb=3,
                     loop_filter_across_slices=1, vui_primaries=1, vui_transfer=13, vui_matrix=-1, vui_full_range=0,
                     seed=1, stress=0, zero_residual_pct=0, dependent_segments=0,
                     inter_num_refs=1, inter_skip_pct=20, inter_intra_pct=10, inter_merge_pct=40, amp=0, max_merge_cand=5, parallel_merge_level=2,
-                    max_transform_hierarchy_depth_inter=1, cabac_init_present=0, lists_modification=0, global_mv_x=0, global_mv_y=0)
+                    max_transform_hierarchy_depth_inter=1, cabac_init_present=0, lists_modification=0, global_mv_x=0, global_mv_y=0,
+                    b_frames=0, b_ref=0, inter_bi_pct=50, temporal_mvp=0, weighted_pred=0, mvd_l1_zero=0)
 
 
 def synth_image(width, height, bit_depth=8, chroma_format_idc=1, seed=1):

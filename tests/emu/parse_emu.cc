@@ -37,6 +37,13 @@ EmuBatch* emu_create(int n, const uint8_t* const* data, const size_t* sizes, cha
 
 void emu_free(EmuBatch* b) { delete b; }
 
+// initValue of the device's context tables (parse_tables.h): table 0 = slice_type I, 1 / 2 = initType 1 / 2 of P slices; group 0..2 (A, B, C), lane 0..63
+int emu_ctx_init_value(int table, int group, int lane)
+{
+  if (table < 0 || table > 2 || group < 0 || group > 2 || lane < 0 || lane > 63) return -1;
+  return table == 0 ? pcore::c_init[group][lane] : pcore::c_init_p[table - 1][group][lane];
+}
+
 // ---- sequences: one access unit per emu_seq_create_picture(); emu_seq_commit() after the pipeline ran (pipeline_emu.cc) -----------------------
 EmuSeq* emu_seq_new() { return new EmuSeq(); }
 void emu_seq_free(EmuSeq* q)

@@ -85,8 +85,8 @@ def check_sequence(aus, name=""):
             rp = r["map_pred"][:uh, :uw]
             np.testing.assert_array_equal(g["map_pred"], rp, err_msg="%s picture %d: prediction modes" % (name, i))
             inter = rp > 0
-            np.testing.assert_array_equal(g["mf_ref"][inter], r["mf_ref"][:uh, :uw][inter], err_msg="%s picture %d: reference indices" % (name, i))
-            np.testing.assert_array_equal(g["mf_mv"][inter], r["mf_mv"][:uh, :uw][inter], err_msg="%s picture %d: motion vectors" % (name, i))
+            np.testing.assert_array_equal(g["mf_ref"][inter], r["mf_ref"][:uh, :uw, 0][inter], err_msg="%s picture %d: reference indices" % (name, i))
+            np.testing.assert_array_equal(g["mf_mv"][inter], r["mf_mv"][:uh, :uw, 0][inter], err_msg="%s picture %d: motion vectors" % (name, i))
         for c in range(len(r["planes"])):
             np.testing.assert_array_equal(g["planes"][c], r["planes"][c], err_msg="%s picture %d plane %d" % (name, i, c))
 

@@ -229,3 +229,38 @@ def test_missing_dependent_segment_is_a_device_error():
     except AssertionError:
         return          # refused by the host front end: also fine
     assert status != 0
+
+
+def test_context_init_tables_of_the_device_parser_equal_the_oracles():
+    """The initValue tables (9.3.2.2, tables 9-5 .. 9-37) are typed in twice, once per side - the oracle's flat table per initType
+    (oracle/hevc_oracle.c) and the device's per-group / per-lane layout (csrc/parse_tables.h).  Same numbers, context by context, for
+    slice_type I and both P initTypes; the padding lanes hold 154."""
+    L = emu()
+    L.emu_ctx_init_value.argtypes = [C.c_int] * 3
+    O = orc.lib()
+    n_ctx = 150
+    tab_i = list((C.c_uint8 * n_ctx).in_dll(O, "hevc_cabac_init_I"))
+    tab_p = list((C.c_uint8 * (2 * n_ctx)).in_dll(O, "hevc_cabac_init_P"))
+    oracle = [tab_i, tab_p[:n_ctx], tab_p[n_ctx:]]
+    # (group, first lane, count, first oracle context): the enums of parse_tables.h against those of hevc_oracle_internal.h
+    layout = [(0, 0, 62, 0),        # sao_merge .. coded_sub_block_flag: same order on both sides
+              (0, 62, 1, 134),      # cbf_cb / cbf_cr at trafoDepth 4
+              (1, 0, 42, 62),       # sig_coeff_flag
+              (1, 44, 6, 128),      # coeff_abs_level_greater2
+              (2, 0, 24, 104),      # coeff_abs_level_greater1
+              (2, 24, 15, 135)]     # cu_skip_flag .. rqt_root_cbf (P slices)
+    covered = set()
+    for table in range(3):
+        used = {g: set() for g in range(3)}
+        for g, lane0, count, ctx0 in layout:
+            for k in range(count):
+                if table == 0 and ctx0 >= 135:
+                    continue    # the I table of the device carries no inter contexts
+                assert L.emu_ctx_init_value(table, g, lane0 + k) == oracle[table][ctx0 + k], (table, g, lane0 + k, ctx0 + k)
+                used[g].add(lane0 + k)
+                covered.add(ctx0 + k)
+        for g in range(3):
+            for lane in range(64):
+                if lane not in used[g] and not (g == 1 and lane in (42, 43)):
+                    assert L.emu_ctx_init_value(table, g, lane) == 154, (table, g, lane)
+    assert covered == set(range(n_ctx))

@@ -1,0 +1,83 @@
+"""Memory-safety fuzz of the P-picture device code on the CPU (MODE=inter bash tools/emu_asan_fuzz.sh <seed> <count>): short IPP
+sequences from the test generator, the P pictures randomly corrupted (slice header, motion syntax, residuals), decoded by the
+ASAN-instrumented host build of the kernels with the decoder's DPB logic around them (tests/emu: emu_seq_*).  Every picture must end in a
+host rejection or a device status word, never in an out-of-bounds access; a picture that failed is not committed as a reference."""
+import sys, ctypes as C, random, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+from oracle import pyoracle as orc
+from test_inter_oracle import make_frames
+L = C.CDLL(os.path.join(ROOT, 'build/asan/libparse_emu_asan.so'))
+L.emu_seq_new.restype = C.c_void_p
+L.emu_seq_free.argtypes = [C.c_void_p]
+L.emu_seq_create_picture.restype = C.c_void_p
+L.emu_seq_create_picture.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+L.emu_seq_commit.argtypes = [C.c_void_p, C.c_void_p]
+L.emu_run_parse.argtypes = [C.c_void_p]
+L.emu_run_pipeline.argtypes = [C.c_void_p, C.c_int]
+L.emu_free.argtypes = [C.c_void_p]
+
+
+def parameter_sets(au):
+    out, p = b"", 0
+    while p + 4 <= len(au):
+        n = int.from_bytes(au[p:p + 4], "big")
+        if 32 <= ((au[p + 4] >> 1) & 63) <= 34:
+            out += au[p:p + 4 + n]
+        p += 4 + n
+    return out
+
+
+def run(aus):
+    ps = parameter_sets(aus[0])
+    q = C.c_void_p(L.emu_seq_new())
+    res = []
+    try:
+        for i, au in enumerate(aus):
+            data = au if i == 0 else ps + au
+            err = C.create_string_buffer(512)
+            b = L.emu_seq_create_picture(q, data, len(data), err, 512)
+            if not b:
+                res.append('rejected')
+                continue
+            b = C.c_void_p(b)
+            st = L.emu_run_parse(b)
+            if st == 0:
+                st = L.emu_run_pipeline(b, 15)
+            if st == 0:
+                L.emu_seq_commit(q, b)     # (the sequence keeps the batch: its planes are reference pictures)
+                res.append('ok')
+            else:
+                res.append('status')      # (the sequence object owns every batch it created; a failed picture is simply not committed)
+    finally:
+        L.emu_seq_free(q)
+    return ','.join(res)
+
+
+rng = random.Random(int(sys.argv[1]))
+n = int(sys.argv[2])
+cfgs = [dict(), dict(amp=1, inter_num_refs=2), dict(inter_num_refs=3, lists_modification=1, max_merge_cand=3), dict(wpp=0, tile_cols=2, tile_rows=2),
+        dict(num_slices=3, parallel_merge_level=4), dict(bit_depth=10, amp=1), dict(lossless_pct=20, transform_skip=1, log2_ctb=5),
+        dict(pcm_pct=10, inter_intra_pct=40, cu_qp_delta=1), dict(dependent_segments=3, num_slices=2, wpp=0)]
+base = []
+for i, c in enumerate(cfgs):
+    frames = make_frames(104, 72, 3, c.get('bit_depth', 8))
+    base.append(orc.encode_sequence(frames, qp=26, global_mv_x=-6, global_mv_y=4, seed=11 + i, **c))
+print('clean:', [run(a) for a in base]); sys.stdout.flush()
+res = {}
+for it in range(n):
+    aus = [bytes(a) for a in rng.choice(base)]
+    victim = rng.randrange(1, len(aus))
+    s = bytearray(aus[victim])
+    for _ in range(rng.choice([1, 1, 2, 4, 16])):
+        # the first bytes are the slice header (reference picture set, list sizes, merge candidates): hit them more often
+        p = rng.randrange(4, min(len(s), 24)) if rng.random() < 0.35 else rng.randrange(len(s))
+        mode = rng.randrange(3)
+        if mode == 0: s[p] ^= 1 << rng.randrange(8)
+        elif mode == 1: s[p] = rng.randrange(256)
+        else: s[p] = 0xff
+    aus[victim] = bytes(s)
+    r = run(aus)
+    res[r] = res.get(r, 0) + 1
+print(res)
