@@ -103,6 +103,14 @@ HIPDEC_API int hipdec_decoder_push_data(hipdec_decoder* dec, const void* data, s
  * host, runs the HIP decode pipeline and leaves the planes in HBM.  Returns HIPDEC_ERR_NO_IMAGE
  * when no picture was pushed (libheif sees "no image yet"). */
 HIPDEC_API int hipdec_decoder_decode(hipdec_decoder* dec, hipdec_image_info* info);
+/* The same with OUTPUT ORDER (de265_get_next_picture behind decoder_libde265.cc:402-419): decodes the pushed sample if one is pending, then
+ * releases the next picture in output (POC) order when the bumping process of C.5.2.2 allows it - more pictures of the coded video sequence
+ * are waiting than sps_max_num_reorder_pics, a new coded video sequence has started, or `flush` (the host's flush_data: end of the data).
+ * *have = 0: no picture yet (libheif pushes the next sample).  Afterwards hipdec_decoder_read_plane* / _device_plane serve the released
+ * picture.  Streams without B pictures come out in coding order, one picture per sample.  user_data: what hipdec_decoder_set_user_data
+ * attached to the sample the picture was decoded from (push_data2's user_data, decoder_libde265.cc:360). */
+HIPDEC_API void hipdec_decoder_set_user_data(hipdec_decoder* dec, uintptr_t user_data);
+HIPDEC_API int hipdec_decoder_next_picture(hipdec_decoder* dec, int flush, hipdec_image_info* info, int* have, uintptr_t* user_data);
 /* Concurrent hipdec_decoder_decode() calls (libheif decodes the tiles of a 'grid' item on worker threads,
  * libheif/image-items/grid.cc:405-453, one decoder instance per tile) are coalesced into shared launch sets; a
  * serial host never waits.  HIPDEC_COALESCE_WINDOW_US (default 2000, 0 = off) bounds the gathering time.

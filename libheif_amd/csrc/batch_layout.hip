@@ -171,6 +171,8 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
     // P pictures: the reference picture table (absolute device pointers into earlier batches' arenas)
     P.is_inter = pp.is_inter ? 1 : 0; P.poc = pp.poc; P.num_refs = (uint32_t)pp.refs.size();
     P.amp_enabled = S.amp ? 1 : 0; P.max_th_depth_inter = (uint8_t)S.max_th_depth_inter; P.log2_par_mrg_level = (uint8_t)Pp.log2_par_mrg_level;
+    P.off_wp = off;
+    if (P.is_inter && !pp.weight_tables.empty()) off = align_up(off + pp.weight_tables.size() * sizeof(WeightTable), 256);
     P.off_reftab = off;
     if (P.is_inter) { off = align_up(off + 16 * sizeof(RefFrame), 256); b.any_inter = true; }
     P.off_bitstream = off; P.bitstream_size = sizes[i]; off = align_up(off + sizes[i] + 512, 256);
@@ -278,13 +280,14 @@ void layout_batch_fill(BatchLayout& b, const void* const* data, const size_t* si
     put(P.off_ctb_ts_to_rs, pp.ts_to_rs.data(), pp.ts_to_rs.size() * sizeof(uint16_t), P.off_ctb_info);
     put(P.off_ctb_info, pp.ctb_info.data(), pp.ctb_info.size() * sizeof(CtbInfo), P.off_slices);
     put(P.off_slices, pp.slice_params.data(), pp.slice_params.size() * sizeof(SliceParams), P.off_scaling);
-    if (P.scaling_lists) put(P.off_scaling, pp.scaling_tables.data(), pp.scaling_tables.size(), P.is_inter ? P.off_reftab : P.off_bitstream);
+    if (P.scaling_lists) put(P.off_scaling, pp.scaling_tables.data(), pp.scaling_tables.size(), P.is_inter ? P.off_wp : P.off_bitstream);
     if (P.is_inter) {
+      if (!pp.weight_tables.empty()) put(P.off_wp, pp.weight_tables.data(), pp.weight_tables.size() * sizeof(WeightTable), P.off_reftab);
       RefFrame tab[16];
       memset(tab, 0, sizeof(tab));
       for (size_t k = 0; k < pp.refs.size() && k < 16; k++) {
         for (int c = 0; c < 3; c++) { tab[k].plane[c] = pp.refs[k].plane[c]; tab[k].stride[c] = pp.refs[k].stride[c]; }
-        tab[k].poc = pp.refs[k].poc;
+        tab[k].poc = pp.refs[k].poc; tab[k].mf = pp.refs[k].mf;
       }
       put(P.off_reftab, tab, sizeof(tab), P.off_bitstream);
     }

@@ -692,6 +692,16 @@ struct hipdec_decoder {
   bool seq_active = false;
   SeqContext seq;
   std::vector<DpbHold> dpb;
+  // ---- output order (C.5.2.2 "bumping"): with B pictures the coding order is not the output order.  Decoded pictures wait here until more
+  //      than sps_max_num_reorder_pics of their coded video sequence are waiting (or the host flushes); hipdec_decoder_next_picture hands them
+  //      out by increasing POC.  `out` is the picture the plane readers currently serve (empty: the picture decoded last, the still-image use)
+  struct Output { std::shared_ptr<hipdec_batch> batch; int item = 0; int poc = 0; uint64_t cvs = 0; uintptr_t user_data = 0; };
+  std::vector<Output> waiting;
+  Output out;
+  uint64_t cvs = 0;                      // coded video sequence counter (a new one starts at every IDR / first IRAP)
+  uintptr_t pending_user_data = 0;       // of the sample pushed last (decoder_libde265.cc:360, :417-419)
+  hipdec_batch* plane_batch() const { return out.batch ? out.batch.get() : batch.get(); }
+  int plane_item() const { return out.batch ? out.item : item; }
   ~hipdec_decoder()
   {
     for (auto& h : dpb) if (h.full) { DeviceScope scope(h.device); arena_release(h.full, h.full_capacity); }
@@ -813,6 +823,7 @@ int commit_reference(hipdec_decoder* d)
     if (e != hipSuccess) { arena_release(h.full, h.full_capacity); return set_error(HIPDEC_ERR_DEVICE, "sequence: reference picture copy: %s", hipGetErrorString(e)); }
     for (int c = 0; c < 3; c++) { rp.plane[c] = (uint64_t)(uintptr_t)(base + off[c]); rp.stride[c] = stride[c]; }
   }
+  rp.mf = P.is_inter ? (uint64_t)(uintptr_t)(b->arena + P.off_mf) : 0;   // the collocated picture of later temporal candidates (the batch stays alive with it)
   d->seq.dpb.push_back(rp);
   d->dpb.push_back(std::move(h));
   return 0;
@@ -1100,24 +1111,62 @@ void hipdec_decoder_coalesce_stats(uint64_t* requests, uint64_t* launch_sets, ui
 
 int hipdec_decoder_read_plane(hipdec_decoder* d, int c, void* dst, size_t dst_stride)
 {
-  if (!d || !d->decoded) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: nothing decoded");
-  hipdec_batch* b = d->batch.get();
-  if (b && c >= 0 && c <= 2 && dst && d->item < (int)b->host_items.size() && b->host_items[(size_t)d->item].p) {   // staged by the launch set
-    const PicParams& P = b->params[(size_t)d->item];
+  if (!d || (!d->decoded && !d->out.batch)) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: nothing decoded");
+  hipdec_batch* b = d->plane_batch();
+  const int item = d->plane_item();
+  if (b && c >= 0 && c <= 2 && dst && item < (int)b->host_items.size() && b->host_items[(size_t)item].p) {   // staged by the launch set
+    const PicParams& P = b->params[(size_t)item];
     if (c > 0 && !P.chroma_format_idc) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: monochrome image has no chroma planes");
     const size_t w = (size_t)(c ? P.out_cwidth : P.out_width) * (b->wide ? 2 : 1), h = (size_t)(c ? P.out_cheight : P.out_height);
-    const uint8_t* src = (const uint8_t*)b->host_items[(size_t)d->item].p + b->host_items[(size_t)d->item].off[c];
+    const uint8_t* src = (const uint8_t*)b->host_items[(size_t)item].p + b->host_items[(size_t)item].off[c];
     if (dst_stride == w) memcpy(dst, src, w * h);
     else for (size_t y = 0; y < h; y++) memcpy((uint8_t*)dst + y * dst_stride, src + y * w, w);
     return 0;
   }
-  return hipdec_batch_read_plane(b, d->item, c, dst, dst_stride);
+  return hipdec_batch_read_plane(b, item, c, dst, dst_stride);
 }
 
 int hipdec_decoder_device_plane(hipdec_decoder* d, int c, const void** dptr, size_t* stride)
 {
-  if (!d || !d->decoded) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "device_plane: nothing decoded");
-  return hipdec_batch_device_plane(d->batch.get(), d->item, c, dptr, stride);
+  if (!d || (!d->decoded && !d->out.batch)) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "device_plane: nothing decoded");
+  return hipdec_batch_device_plane(d->plane_batch(), d->plane_item(), c, dptr, stride);
+}
+
+void hipdec_decoder_set_user_data(hipdec_decoder* d, uintptr_t user_data) { if (d) d->pending_user_data = user_data; }
+
+// decode_next_image2 with output order (heif_plugin.h:164; decoder_libde265.cc:386-457 around de265_get_next_picture): decodes the pushed sample
+// if one is pending, then hands out the next picture in OUTPUT order if the bumping process releases one.
+int hipdec_decoder_next_picture(hipdec_decoder* d, int flush, hipdec_image_info* info, int* have, uintptr_t* user_data)
+{
+  if (!d || !have) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "next_picture: bad arguments");
+  *have = 0;
+  return guarded("next_picture", [&]() -> int {
+    if (!d->decoded && !d->data.empty()) {
+      hipdec_image_info ii;
+      if (int rc = decoder_decode_impl(d, &ii)) return rc;
+      const ParsedPicture& pp = d->batch->pics[(size_t)d->item];
+      if (pp.is_idr || !d->seq_active) d->cvs++;   // POCs start over: everything still waiting precedes this picture in output order
+      hipdec_decoder::Output o;
+      o.batch = d->batch; o.item = d->item; o.poc = pp.poc; o.cvs = d->cvs; o.user_data = d->pending_user_data;
+      d->waiting.push_back(std::move(o));
+    }
+    if (d->waiting.empty()) return 0;
+    size_t first = 0, in_cvs = 0;
+    for (size_t i = 0; i < d->waiting.size(); i++) {
+      const auto& a = d->waiting[i]; const auto& f = d->waiting[first];
+      if (a.cvs < f.cvs || (a.cvs == f.cvs && a.poc < f.poc)) first = i;
+      if (a.cvs == d->cvs) in_cvs++;
+    }
+    const auto& f = d->waiting[first];
+    const ParsedPicture& fp = f.batch->pics[(size_t)f.item];
+    if (!(flush || f.cvs < d->cvs || (int)in_cvs > fp.max_num_reorder)) return 0;   // C.5.2.2: nothing is released yet
+    d->out = d->waiting[first];
+    d->waiting.erase(d->waiting.begin() + (long)first);
+    if (info) { if (int rc = hipdec_batch_info(d->out.batch.get(), d->out.item, info)) return rc; }
+    if (user_data) *user_data = d->out.user_data;
+    *have = 1;
+    return 0;
+  });
 }
 
 }  // extern "C"
@@ -1235,13 +1284,15 @@ int copy_rows_to_host(void* dst, size_t dst_stride, const void* dsrc, size_t src
 void resident_note(hipdec_decoder* d, int c, const void* host, size_t stride)
 {
   if (!g_track_planes.load(std::memory_order_relaxed)) return;
-  const PicParams& P = d->batch->params[d->item];
+  hipdec_batch* pb = d->plane_batch();
+  const int pitem = d->plane_item();
+  const PicParams& P = pb->params[pitem];
   ResidentPlane r;
   r.host = host; r.host_stride = stride;
   r.w = c ? P.out_cwidth : P.out_width; r.h = c ? P.out_cheight : P.out_height;
   r.bits = c ? P.bit_depth_chroma : P.bit_depth_luma;
-  r.sample = plane_hash((const uint8_t*)host, stride, r.w * (d->batch->wide ? 2 : 1), r.h);
-  r.batch = d->batch; r.item = d->item; r.comp = c;
+  r.sample = plane_hash((const uint8_t*)host, stride, r.w * (pb->wide ? 2 : 1), r.h);
+  r.batch = d->out.batch ? d->out.batch : d->batch; r.item = pitem; r.comp = c;
   resident_insert(std::move(r));
 }
 

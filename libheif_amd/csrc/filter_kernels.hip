@@ -218,6 +218,28 @@ __device__ __forceinline__ void deblock_chroma4(Pix* pix, int stride, int qp_p, 
 }  // namespace
 
 // DIR 0: vertical edges (filtering across x), DIR 1: horizontal edges
+// 8.7.2.4, the motion part: the two blocks use different reference PICTURES (RefFrame slots: not indices, not lists) or a different number of
+// motion vectors, or vectors that point at the same picture differ by a luma sample or more
+__device__ __forceinline__ bool mv_far(const int16_t* a, const int16_t* b) { return iabs(a[0] - b[0]) >= 4 || iabs(a[1] - b[1]) >= 4; }
+__device__ __forceinline__ bool motion_differs(const MotionUnit& p, const MotionUnit& q)
+{
+  const int np = (p.ref_idx[0] >= 0) + (p.ref_idx[1] >= 0), nq = (q.ref_idx[0] >= 0) + (q.ref_idx[1] >= 0);
+  if (np != nq) return true;
+  const int sp0 = p.slot_pred[0] & 63, sp1 = p.slot_pred[1] & 63, sq0 = q.slot_pred[0] & 63, sq1 = q.slot_pred[1] & 63;
+  if (np == 1) {
+    const int lp = p.ref_idx[0] >= 0 ? 0 : 1, lq = q.ref_idx[0] >= 0 ? 0 : 1;
+    if ((lp ? sp1 : sp0) != (lq ? sq1 : sq0)) return true;
+    return mv_far(p.mv[lp], q.mv[lq]);
+  }
+  if (!((sp0 == sq0 && sp1 == sq1) || (sp0 == sq1 && sp1 == sq0))) return true;
+  if (sp0 != sp1) {   // two different reference pictures: compare the vectors that point at the same one
+    if (sp0 == sq0) return mv_far(p.mv[0], q.mv[0]) || mv_far(p.mv[1], q.mv[1]);
+    return mv_far(p.mv[0], q.mv[1]) || mv_far(p.mv[1], q.mv[0]);
+  }
+  // both vectors of both blocks point at the same picture: either pairing may match
+  return (mv_far(p.mv[0], q.mv[0]) || mv_far(p.mv[1], q.mv[1])) && (mv_far(p.mv[0], q.mv[1]) || mv_far(p.mv[1], q.mv[0]));
+}
+
 template <typename Pix, int DIR>
 __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
 {
@@ -256,11 +278,12 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
     // their size, so the edge is a transform block edge iff the Q block starts there; prediction block edges were flagged by the parser.)
     const MotionUnit* mf = (const MotionUnit*)(A.arena + P.off_mf);
     const MotionUnit mq = mf[iq], mp = mf[ip];
-    if (mq.ref_idx >= 0 && mp.ref_idx >= 0) {
+    const bool inter_q = mq.ref_idx[0] >= 0 || mq.ref_idx[1] >= 0, inter_p = mp.ref_idx[0] >= 0 || mp.ref_idx[1] >= 0;
+    if (inter_q && inter_p) {
       const int tbq = 1 << (A.arena[P.off_u_size + iq] & 15);
       const bool tu_edge = ((DIR == 0 ? x : y) & (tbq - 1)) == 0;
       if (tu_edge && ((fq | fp) & UF_CBF_LUMA)) bs = 1;
-      else if (mq.ref_slot != mp.ref_slot || iabs(mq.mv[0] - mp.mv[0]) >= 4 || iabs(mq.mv[1] - mp.mv[1]) >= 4) bs = 1;
+      else if (motion_differs(mp, mq)) bs = 1;
       else return;
     }
   }

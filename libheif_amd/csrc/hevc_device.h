@@ -51,42 +51,59 @@ struct SliceParams {
   uint8_t sao_luma, sao_chroma;
   uint8_t lf_across_slices;                  // slice_loop_filter_across_slices_enabled_flag
   uint16_t slice_addr_rs;
-  // ---- P slices (sequence tracks); all 0 for an intra slice
-  uint8_t is_p;                              // slice_type == P
+  // ---- P / B slices (sequence tracks); all 0 for an intra slice
+  uint8_t is_p;                              // slice_type != I (a P or a B slice)
   uint8_t num_ref_idx;                       // num_ref_idx_l0_active_minus1 + 1
   uint8_t max_merge_cand;                    // MaxNumMergeCand
-  uint8_t init_type;                         // 9.3.2.2 initType: 0 (I), 1 or 2 (P: cabac_init_flag ? 2 : 1)
+  uint8_t init_type;                         // 9.3.2.2 initType: 0 (I), 1 (P) or 2 (B); cabac_init_flag swaps the latter two
   uint8_t ref_slot[16];                      // RefPicList0[i] as an index into the picture's RefFrame table (PicParams::off_reftab)
-  uint32_t pad_;
+  uint8_t is_b;                              // slice_type == B
+  uint8_t num_ref_idx_l1;                    // num_ref_idx_l1_active_minus1 + 1 (0 in a P slice)
+  uint8_t mvd_l1_zero;                       // mvd_l1_zero_flag
+  uint8_t tmvp;                              // slice_temporal_mvp_enabled_flag
+  uint8_t col_slot;                          // the collocated picture (collocated_from_l0_flag / collocated_ref_idx) as a RefFrame slot
+  uint8_t col_from_l0;                       // collocated_from_l0_flag (8.5.3.2.9: which list of a bi-predicted collocated block counts)
+  uint8_t no_backward;                       // NoBackwardPredFlag: no reference picture of the slice follows the current picture in output order
+  uint8_t weighted;                          // explicit weighted prediction (weighted_pred_flag / weighted_bipred_flag): the table below applies
+  uint8_t luma_log2_wd, chroma_log2_wd;      // luma_log2_weight_denom, ChromaLog2WeightDenom
+  uint16_t wp_index;                         // the slice's WeightTable in PicParams::off_wp
+  uint8_t ref_slot_l1[16];                   // RefPicList1[i]
 };
-static_assert(sizeof(SliceParams) == 40, "SliceParams layout");
+static_assert(sizeof(SliceParams) == 64, "SliceParams layout");
 
-// a reference picture of a P picture: absolute device pointers (the planes live in an EARLIER batch's arena: decoded, deblocked, SAO applied,
-// coded size), strides in bytes
+// pred_weight_table of one slice (7.3.6.3) as the weighted sample prediction uses it (8.5.3.3.4.3): [list][refIdx][cIdx]
+struct WeightTable { int16_t w[2][16][3]; int16_t o[2][16][3]; };   // o: before the << (BitDepth - 8)
+static_assert(sizeof(WeightTable) == 384, "WeightTable layout");
+
+// a reference picture of a P / B picture: absolute device pointers (the planes live in an EARLIER batch's arena: decoded, deblocked, SAO applied,
+// coded size), strides in bytes; mf: that picture's motion field (MotionUnit per 4x4 unit, CTB-major z-order like the current picture's; 0 if it
+// was an intra picture), read by the temporal candidates
 struct RefFrame {
   uint64_t plane[3];
   uint32_t stride[3];
   int32_t poc;
+  uint64_t mf;
 };
-static_assert(sizeof(RefFrame) == 40, "RefFrame layout");
+static_assert(sizeof(RefFrame) == 48, "RefFrame layout");
 
-// motion of one 4x4 luma unit (the motion field k_motion writes; P slices: list 0 only)
+// motion of one 4x4 luma unit (the motion field k_motion writes)
 struct MotionUnit {
-  int16_t mv[2];       // quarter luma samples
-  int8_t ref_idx;      // refIdxL0, -1: the unit is intra coded
-  int8_t ref_slot;     // its picture as an index into the RefFrame table: equal slots <=> the same reference picture (8.7.2.4)
-  uint8_t pred;        // 0 MODE_INTRA, 1 MODE_INTER, 2 MODE_SKIP
-  uint8_t pad;
+  int16_t mv[2][2];      // [list][x, y], quarter luma samples
+  int16_t poc_delta[2];  // PicOrderCnt(this picture) - PicOrderCnt(the list's reference picture): all the temporal candidates of LATER pictures need
+  int8_t ref_idx[2];     // refIdxL0 / L1, -1: the list is not used (both -1: the unit is intra coded)
+  uint8_t slot_pred[2];  // bits 0..5: the list's reference picture as a RefFrame slot (equal slots <=> the same picture, 8.7.2.4);
+                         // [0] bits 6..7: 0 MODE_INTRA, 1 MODE_INTER, 2 MODE_SKIP
 };
-static_assert(sizeof(MotionUnit) == 8, "MotionUnit layout");
+static_assert(sizeof(MotionUnit) == 16, "MotionUnit layout");
 
 // u_ipmc of a P picture: bits 0..5 IntraPredModeC (1 for units that are not intra coded), bit 6 the unit is inter coded, bit 7 it is skipped
 enum : uint8_t { UM_INTER = 64, UM_SKIP = 128 };
 
 // motion syntax of one prediction unit (the parser writes it at the unit index of the PU's top-left 4x4 unit; k_motion turns it into the motion
 // field): w0 = bit 0 merge_flag, bits 1..3 merge_idx, bits 4..7 ref_idx_l0, bit 8 mvp_l0_flag, bits 9..11 PartMode, bits 12..13 partIdx,
-// bit 15 valid; w1 = mvd_x (int16) | mvd_y (int16) << 16
-struct MotionSyntax { uint32_t w0, w1; };
+// bit 15 valid, bits 16..17 inter_pred_idc (0 PRED_L0, 1 PRED_L1, 2 PRED_BI), bits 18..21 ref_idx_l1, bit 22 mvp_l1_flag, bits 24..26 the
+// coding quadtree depth (unused by k_motion); mvd[X] = mvd_x (int16) | mvd_y (int16) << 16
+struct MotionSyntax { uint32_t w0, mvd[2], pad; };
 
 struct SaoParams {   // per CTB and colour component
   uint8_t type;      // 0 off, 1 band, 2 edge
@@ -138,6 +155,7 @@ struct PicParams {
   int32_t poc;                    // PicOrderCntVal
   uint32_t num_refs;              // entries of the RefFrame table
   uint32_t pad_inter;
+  uint64_t off_wp;                // WeightTable per slice with explicit weights (SliceParams::wp_index)
   uint64_t off_reftab;            // RefFrame[16]
   uint64_t off_msyn;              // MotionSyntax[ctbs * units_per_ctb]
   uint64_t off_mf;                // MotionUnit[ctbs * units_per_ctb]

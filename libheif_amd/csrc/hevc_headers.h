@@ -26,7 +26,8 @@ struct StRps {
 };
 
 // A decoded picture a later P picture may reference: device pointers of its planes (coded size, deblocked, SAO applied), strides in bytes
-struct RefPicture { int poc = 0; uint64_t plane[3] = {0, 0, 0}; uint32_t stride[3] = {0, 0, 0}; };
+// mf: its motion field on the device (0: an intra picture) - the collocated picture of temporal candidates (8.5.3.2.8)
+struct RefPicture { int poc = 0; uint64_t plane[3] = {0, 0, 0}; uint32_t stride[3] = {0, 0, 0}; uint64_t mf = 0; };
 
 // What a decoder instance keeps between the samples of a sequence track (libheif/sequences/track_visual.cc:200-280 pushes them one by one):
 // the picture order count state (8.3.1) and the decoded picture buffer.  nullptr where a single still is decoded: P slices are refused then.
@@ -47,6 +48,7 @@ struct Sps {
   int pcm_bit_depth_luma = 8, pcm_bit_depth_chroma = 8, log2_min_pcm_cb = 3, log2_max_pcm_cb = 3;   // valid when pcm
   bool pcm_loop_filter_disabled = false;
   bool long_term_ref_pics_present = false, temporal_mvp = false, separate_colour_plane = false;
+  int max_num_reorder = 0, max_dec_pic_buffering = 1;   // of the highest sub-layer (output order: C.5.2.2)
   int num_short_term_ref_pic_sets = 0, num_long_term_ref_pics_sps = 0;
   std::vector<StRps> st_rps;            // the short-term reference picture sets of the SPS
   int colour_primaries = 2, transfer_characteristics = 2, matrix_coeffs = 2, full_range = 0;
@@ -64,8 +66,8 @@ struct Pps {
   bool slice_header_extension_present = false;
   int num_extra_slice_header_bits = 0, init_qp = 26, diff_cu_qp_delta_depth = 0;
   int cb_qp_offset = 0, cr_qp_offset = 0, beta_offset_div2 = 0, tc_offset_div2 = 0;
-  int num_ref_idx_l0_default = 1, log2_par_mrg_level = 2;
-  bool weighted_pred = false, lists_modification_present = false;
+  int num_ref_idx_l0_default = 1, num_ref_idx_l1_default = 1, log2_par_mrg_level = 2;
+  bool weighted_pred = false, weighted_bipred = false, lists_modification_present = false;
   int tile_cols = 1, tile_rows = 1;
   std::vector<int> col_width, row_height;  // explicit sizes when !uniform_spacing
   ScalingLists sl{};   // valid when scaling_list_data_present
@@ -78,7 +80,10 @@ struct ParsedSlice {
   size_t data_offset = 0;  // offset in the pushed blob of the first slice_segment_data byte
   size_t nal_end = 0;      // offset one past the slice NAL
   std::vector<uint32_t> entry_point_offsets;  // bytes, escaped domain
-  int ref_poc[16] = {0};   // P slice: PicOrderCntVal of RefPicList0[i] (sp.ref_slot is filled once the picture's reference table is known)
+  int ref_poc[2][16] = {{0}, {0}};   // P / B slice: PicOrderCntVal of RefPicListX[i] (sp.ref_slot / ref_slot_l1 are filled once the picture's reference table is known)
+  int col_poc = 0;                   // the collocated picture (slice_temporal_mvp_enabled_flag)
+  bool has_weights = false;
+  WeightTable weights{};             // valid when has_weights (sp.weighted)
 };
 
 struct ParsedPicture {
@@ -100,6 +105,8 @@ struct ParsedPicture {
   bool is_idr = false;
   std::vector<int> keep_pocs;           // every picture of the RPS (the DPB drops the others once this picture is decoded)
   std::vector<RefPicture> refs;         // the reference table of the picture (slots of SliceParams::ref_slot), at most 16
+  std::vector<WeightTable> weight_tables;   // of the slices with explicit weights (SliceParams::wp_index)
+  int max_num_reorder = 0, max_dec_pic_buffering = 1;   // sps_max_num_reorder_pics / sps_max_dec_pic_buffering_minus1 + 1 of the highest sub-layer
 };
 
 // Parses one coded picture from libheif's plugin framing.  Returns a hipdec_status.

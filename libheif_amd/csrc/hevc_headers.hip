@@ -273,7 +273,11 @@ void parse_sps(NalReader& r, Sps& s)
   s.bit_depth_chroma = r.ue_max(8, "bit_depth_chroma_minus8") + 8;
   s.log2_max_poc_lsb = r.ue_max(12, "log2_max_pic_order_cnt_lsb_minus4") + 4;
   bool sub_layer_ordering = r.u(1);
-  for (int i = sub_layer_ordering ? 0 : max_sub_layers_minus1; i <= max_sub_layers_minus1; i++) { r.ue(); r.ue(); r.ue(); }
+  for (int i = sub_layer_ordering ? 0 : max_sub_layers_minus1; i <= max_sub_layers_minus1; i++) {
+    s.max_dec_pic_buffering = r.ue_max(15, "sps_max_dec_pic_buffering_minus1") + 1;
+    s.max_num_reorder = r.ue_max(15, "sps_max_num_reorder_pics");
+    r.ue();   // sps_max_latency_increase_plus1
+  }
   s.log2_min_cb = r.ue_max(3, "log2_min_luma_coding_block_size_minus3") + 3;
   s.log2_ctb = s.log2_min_cb + r.ue_max(3, "log2_diff_max_min_luma_coding_block_size");
   s.log2_min_tb = r.ue_max(3, "log2_min_luma_transform_block_size_minus2") + 2;
@@ -362,7 +366,8 @@ void parse_pps(NalReader& r, Pps& p)
   p.num_extra_slice_header_bits = r.u(3);
   p.sign_data_hiding = r.u(1);
   p.cabac_init_present = r.u(1);
-  p.num_ref_idx_l0_default = r.ue_max(14, "num_ref_idx_l0_default_active_minus1") + 1; r.ue_max(14, "num_ref_idx_l1_default_active_minus1");
+  p.num_ref_idx_l0_default = r.ue_max(14, "num_ref_idx_l0_default_active_minus1") + 1;
+  p.num_ref_idx_l1_default = r.ue_max(14, "num_ref_idx_l1_default_active_minus1") + 1;
   p.init_qp = 26 + r.se_range(-(26 + 6 * 8), 25, "init_qp_minus26");
   p.constrained_intra_pred = r.u(1);
   p.transform_skip = r.u(1);
@@ -371,7 +376,7 @@ void parse_pps(NalReader& r, Pps& p)
   p.cb_qp_offset = r.se_range(-12, 12, "pps_cb_qp_offset");
   p.cr_qp_offset = r.se_range(-12, 12, "pps_cr_qp_offset");
   p.slice_chroma_qp_offsets_present = r.u(1);
-  p.weighted_pred = r.u(1); r.skip(1);   // weighted_pred_flag, weighted_bipred_flag
+  p.weighted_pred = r.u(1); p.weighted_bipred = r.u(1);
   p.transquant_bypass = r.u(1);
   p.tiles = r.u(1);
   p.wpp = r.u(1);
@@ -549,8 +554,7 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
         } else {
         r.skip(P.num_extra_slice_header_bits);
         const unsigned slice_type = r.ue_max(2, "slice_type");
-        if (slice_type == 0) unsupported("B slices");
-        if (slice_type == 1 && !seq) unsupported("non-intra slice (slice_type 1) outside a sequence");
+        if (slice_type != 2 && !seq) unsupported("non-intra slice (slice_type " + std::to_string(slice_type) + ") outside a sequence");
         if (P.output_flag_present) r.skip(1);
         if (S.separate_colour_plane) r.skip(2);
         int poc_lsb = 0;
@@ -602,42 +606,100 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
           pic_rps = rps;
         }
         if (S.sao) { sl.sp.sao_luma = r.u(1); if (S.chroma_format_idc) sl.sp.sao_chroma = r.u(1); }
-        if (slice_type == 1) {   // 7.3.6.1, P slice
-          if (S.chroma_format_idc > 1) unsupported("P slices of a 4:2:2 / 4:4:4 picture");
-          if (S.scaling_list_enabled) unsupported("P slices with scaling lists");
-          if (P.constrained_intra_pred) unsupported("constrained_intra_pred_flag with P slices");
-          if (P.weighted_pred) unsupported("weighted prediction");
-          if (slice_tmvp) unsupported("temporal motion vector prediction");
-          int num_ref = P.num_ref_idx_l0_default;
-          if (r.u(1)) num_ref = r.ue_max(14, "num_ref_idx_l0_active_minus1") + 1;   // num_ref_idx_active_override_flag
-          // RefPicSetStCurrBefore / After of the PICTURE's RPS (8.3.2), then RefPicListTemp0 (8.3.4)
-          std::vector<int> cur;
-          for (int i = 0; i < pic_rps.num_neg; i++) if (pic_rps.used_s0[i]) cur.push_back(out.poc + pic_rps.delta_s0[i]);
-          for (int i = 0; i < pic_rps.num_pos; i++) if (pic_rps.used_s1[i]) cur.push_back(out.poc + pic_rps.delta_s1[i]);
-          const int total = (int)cur.size();
-          if (total == 0) bad("P slice without a reference picture");
-          for (int poc : cur) {
+        if (slice_type != 2) {   // 7.3.6.1, P / B slice
+          const bool is_b = slice_type == 0;
+          if (S.chroma_format_idc > 1) unsupported("P / B slices of a 4:2:2 / 4:4:4 picture");
+          if (S.scaling_list_enabled) unsupported("P / B slices with scaling lists");
+          if (P.constrained_intra_pred) unsupported("constrained_intra_pred_flag with P / B slices");
+          int num_ref[2] = {P.num_ref_idx_l0_default, is_b ? P.num_ref_idx_l1_default : 0};
+          if (r.u(1)) {   // num_ref_idx_active_override_flag
+            num_ref[0] = r.ue_max(14, "num_ref_idx_l0_active_minus1") + 1;
+            if (is_b) num_ref[1] = r.ue_max(14, "num_ref_idx_l1_active_minus1") + 1;
+          }
+          // RefPicSetStCurrBefore / After of the PICTURE's RPS (8.3.2); RefPicListTemp0 = Before, After; RefPicListTemp1 = After, Before (8.3.4)
+          std::vector<int> before, after;
+          for (int i = 0; i < pic_rps.num_neg; i++) if (pic_rps.used_s0[i]) before.push_back(out.poc + pic_rps.delta_s0[i]);
+          for (int i = 0; i < pic_rps.num_pos; i++) if (pic_rps.used_s1[i]) after.push_back(out.poc + pic_rps.delta_s1[i]);
+          const int total = (int)(before.size() + after.size());
+          if (total == 0) bad("P / B slice without a reference picture");
+          for (int k = 0; k < total; k++) {
+            const int poc = k < (int)before.size() ? before[(size_t)k] : after[(size_t)k - before.size()];
             bool have = false;
             for (const RefPicture& rp : seq->dpb) if (rp.poc == poc) have = true;
             if (!have) bad("reference picture with POC " + std::to_string(poc) + " is missing");
           }
-          int entries[16];
-          bool modified = false;
-          if (P.lists_modification_present && total > 1) {
-            modified = r.u(1);
-            if (modified) for (int i = 0; i < num_ref; i++) { entries[i] = (int)r.u(ceil_log2(total)); }
+          int entries[2][16];
+          bool modified[2] = {false, false};
+          if (P.lists_modification_present && total > 1)
+            for (int X = 0; X < (is_b ? 2 : 1); X++) {
+              modified[X] = r.u(1);
+              if (modified[X]) for (int i = 0; i < num_ref[X]; i++) entries[X][i] = (int)r.u(ceil_log2(total));
+            }
+          for (int X = 0; X < (is_b ? 2 : 1); X++) {
+            std::vector<int> temp;
+            const std::vector<int>& first = X ? after : before;
+            const std::vector<int>& second = X ? before : after;
+            temp.insert(temp.end(), first.begin(), first.end());
+            temp.insert(temp.end(), second.begin(), second.end());
+            const int want = num_ref[X] > total ? num_ref[X] : total;
+            for (int i = 0; i < num_ref[X]; i++) {
+              const int e = modified[X] ? entries[X][i] : i;
+              if (e < 0 || e >= want) bad("list_entry_lX out of range");
+              sl.ref_poc[X][i] = temp[(size_t)(e % total)];
+            }
           }
-          const int want = num_ref > total ? num_ref : total;
-          for (int i = 0; i < num_ref; i++) {
-            const int e = modified ? entries[i] : i;
-            if (e < 0 || e >= want) bad("list_entry_l0 out of range");
-            sl.ref_poc[i] = cur[(size_t)(e % total)];
-          }
+          if (is_b) sl.sp.mvd_l1_zero = r.u(1);
           bool cabac_init_flag = false;
           if (P.cabac_init_present) cabac_init_flag = r.u(1);
+          bool col_from_l0 = true;
+          int col_ref_idx = 0;
+          if (slice_tmvp) {
+            if (is_b) col_from_l0 = r.u(1);
+            if ((col_from_l0 && num_ref[0] > 1) || (!col_from_l0 && num_ref[1] > 1)) col_ref_idx = r.ue_max(15, "collocated_ref_idx");
+            if (col_ref_idx >= num_ref[col_from_l0 ? 0 : 1]) bad("collocated_ref_idx out of range");
+            sl.col_poc = sl.ref_poc[col_from_l0 ? 0 : 1][col_ref_idx];
+          }
+          if (is_b ? P.weighted_bipred : P.weighted_pred) {   // 7.3.6.3 pred_weight_table
+            const int nc = S.chroma_format_idc ? 3 : 1;
+            WeightTable& wt = sl.weights;
+            sl.has_weights = true;
+            const int luma_denom = r.ue_max(7, "luma_log2_weight_denom");
+            int chroma_denom = luma_denom;
+            if (nc == 3) { chroma_denom += r.se_range(-7, 7, "delta_chroma_log2_weight_denom"); if (chroma_denom < 0 || chroma_denom > 7) bad("ChromaLog2WeightDenom out of range"); }
+            sl.sp.luma_log2_wd = (uint8_t)luma_denom; sl.sp.chroma_log2_wd = (uint8_t)chroma_denom;
+            for (int X = 0; X < (is_b ? 2 : 1); X++) {
+              bool lf[16], cf[16];
+              for (int i = 0; i < 16; i++) lf[i] = cf[i] = false;
+              // (the flags are present for every entry: a reference picture of these single-layer streams never has the current picture's POC)
+              for (int i = 0; i < num_ref[X]; i++) lf[i] = r.u(1);
+              if (nc == 3) for (int i = 0; i < num_ref[X]; i++) cf[i] = r.u(1);
+              for (int i = 0; i < num_ref[X]; i++) {
+                wt.w[X][i][0] = (int16_t)(1 << luma_denom); wt.o[X][i][0] = 0;
+                wt.w[X][i][1] = wt.w[X][i][2] = (int16_t)(1 << chroma_denom); wt.o[X][i][1] = wt.o[X][i][2] = 0;
+                if (lf[i]) {
+                  wt.w[X][i][0] = (int16_t)((1 << luma_denom) + r.se_range(-128, 127, "delta_luma_weight"));
+                  wt.o[X][i][0] = (int16_t)r.se_range(-128, 127, "luma_offset");
+                }
+                if (cf[i])
+                  for (int j = 1; j < 3; j++) {
+                    const int wgt = (1 << chroma_denom) + r.se_range(-128, 127, "delta_chroma_weight");
+                    const int dof = r.se_range(-512, 511, "delta_chroma_offset");
+                    int o = 128 + dof - ((128 * wgt) >> chroma_denom);
+                    o = o < -128 ? -128 : (o > 127 ? 127 : o);
+                    wt.w[X][i][j] = (int16_t)wgt; wt.o[X][i][j] = (int16_t)o;
+                  }
+              }
+            }
+          }
           const int max_merge = 5 - r.ue_max(4, "five_minus_max_num_merge_cand");
-          sl.sp.is_p = 1; sl.sp.num_ref_idx = (uint8_t)num_ref; sl.sp.max_merge_cand = (uint8_t)max_merge;
-          sl.sp.init_type = cabac_init_flag ? 2 : 1;
+          sl.sp.is_p = 1; sl.sp.is_b = is_b ? 1 : 0;
+          sl.sp.num_ref_idx = (uint8_t)num_ref[0]; sl.sp.num_ref_idx_l1 = (uint8_t)num_ref[1]; sl.sp.max_merge_cand = (uint8_t)max_merge;
+          sl.sp.init_type = (uint8_t)((is_b != cabac_init_flag) ? 2 : 1);   // 9.3.2.2: P -> 1, B -> 2, swapped by cabac_init_flag
+          sl.sp.tmvp = slice_tmvp ? 1 : 0; sl.sp.col_from_l0 = col_from_l0 ? 1 : 0;
+          sl.sp.weighted = sl.has_weights ? 1 : 0;
+          bool no_backward = true;
+          for (int X = 0; X < 2; X++) for (int i = 0; i < num_ref[X]; i++) if (sl.ref_poc[X][i] > out.poc) no_backward = false;
+          sl.sp.no_backward = no_backward ? 1 : 0;
           out.is_inter = true;
         }
         int slice_qp_delta = r.se_range(-128, 128, "slice_qp_delta");
@@ -686,18 +748,28 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
     }
     if (!have_picture) { err = "no coded picture in the pushed data"; return HIPDEC_ERR_NO_IMAGE; }
     out.poc_lsb = pic_poc_lsb; out.nal_type = pic_nal_type;
-    if (out.is_inter) {   // the picture's reference table: every picture some P slice lists, once; SliceParams::ref_slot indexes it
+    out.max_num_reorder = out.sps.max_num_reorder; out.max_dec_pic_buffering = out.sps.max_dec_pic_buffering;
+    out.weight_tables.clear();
+    if (out.is_inter) {   // the picture's reference table: every picture some P / B slice lists, once; SliceParams::ref_slot(_l1) index it
+      auto slot_of = [&](int poc) -> int {
+        for (size_t k = 0; k < out.refs.size(); k++) if (out.refs[k].poc == poc) return (int)k;
+        for (const RefPicture& rp : seq->dpb) if (rp.poc == poc) { out.refs.push_back(rp); return (int)out.refs.size() - 1; }
+        return -1;
+      };
       for (ParsedSlice& sl : out.slices) {
-        if (!sl.sp.is_p) continue;
-        for (int i = 0; i < sl.sp.num_ref_idx; i++) {
-          int slot = -1;
-          for (size_t k = 0; k < out.refs.size(); k++) if (out.refs[k].poc == sl.ref_poc[i]) slot = (int)k;
-          if (slot < 0) {
-            for (const RefPicture& rp : seq->dpb) if (rp.poc == sl.ref_poc[i]) { out.refs.push_back(rp); slot = (int)out.refs.size() - 1; break; }
+        if (!sl.sp.is_p || sl.dependent) continue;
+        for (int X = 0; X < 2; X++)
+          for (int i = 0; i < (X ? sl.sp.num_ref_idx_l1 : sl.sp.num_ref_idx); i++) {
+            const int slot = slot_of(sl.ref_poc[X][i]);
+            if (slot < 0 || slot > 15) bad("reference picture table overflow");
+            (X ? sl.sp.ref_slot_l1 : sl.sp.ref_slot)[i] = (uint8_t)slot;
           }
+        if (sl.sp.tmvp) {
+          const int slot = slot_of(sl.col_poc);
           if (slot < 0 || slot > 15) bad("reference picture table overflow");
-          sl.sp.ref_slot[i] = (uint8_t)slot;
+          sl.sp.col_slot = (uint8_t)slot;
         }
+        if (sl.has_weights) { sl.sp.wp_index = (uint16_t)out.weight_tables.size(); out.weight_tables.push_back(sl.weights); }
       }
       // a dependent slice segment carries its slice's fields: refresh the copies made before the slots were known
       for (size_t si = 1; si < out.slices.size(); si++) if (out.slices[si].dependent) { const uint16_t a = out.slices[si].sp.slice_addr_rs; out.slices[si].sp = out.slices[si - 1].sp; out.slices[si].sp.slice_addr_rs = a; }

@@ -1,10 +1,11 @@
-// inter_kernels.hip — P pictures of sequence tracks: motion vector derivation and motion-compensated prediction.
+// inter_kernels.hip — P and B pictures of sequence tracks: motion vector derivation and motion-compensated prediction.
 //
 // Stands in for libde265's inter decoding behind de265_decode() for the samples libheif pushes one by one for a track
 // (libheif/sequences/track_visual.cc:200-280; libheif/plugins/decoder_libde265.cc:360, :417-419).  ITU-T H.265 6.4.2 (prediction block
-// availability), 8.5.3.2.2 - 8.5.3.2.5 (merge mode: spatial and zero candidates), 8.5.3.2.6 - 8.5.3.2.8 (motion vector prediction: spatial
-// candidates with scaling), 8.5.3.3.3 (fractional sample interpolation), 8.5.3.3.4.2 (default weighted prediction, list 0 only).
-// Scope as the host front end enforces it: P slices, short-term reference pictures, no temporal candidates, 4:0:0 / 4:2:0.
+// availability), 8.5.3.2.2 - 8.5.3.2.5 (merge mode: spatial, temporal, combined bi-predictive and zero candidates), 8.5.3.2.6 - 8.5.3.2.9 (motion
+// vector prediction: spatial candidates with scaling, the collocated candidate), 8.5.3.3.3 (fractional sample interpolation), 8.5.3.3.4.2 /
+// 8.5.3.3.4.3 (default and explicit weighted sample prediction, one or two lists).
+// Scope as the host front end enforces it: P and B slices, short-term reference pictures, 4:0:0 / 4:2:0.
 //
 // MI355X mapping
 //   * the entropy decoder (parse_core.h, HIPDEC_PARSE_INTER build) only PARSES prediction units into MotionSyntax records: HEVC keeps parsing free
@@ -47,7 +48,7 @@ __device__ __forceinline__ void mk_lds_sync()
   __builtin_amdgcn_wave_barrier();
 }
 
-struct Mv { int x, y, ref_idx; };   // P slices: predFlagL0 = 1 for every block that is not intra coded
+struct Mo { int mv[2][2]; int ref_idx[2]; };   // [list][x, y]; ref_idx < 0: the list is not used
 
 // everything the derivation of one CTB needs (lane 0 only)
 struct MotionCtx {
@@ -56,18 +57,28 @@ struct MotionCtx {
   const SliceParams* slice;
   const MotionUnit* field;      // the picture's motion field in HBM
   const MotionUnit* cur;        // the current CTB's units (LDS)
+  const MotionUnit* col;        // the collocated picture's motion field (nullptr: no temporal candidates / an intra picture)
   int cx, cy, avail;            // CTB position, AV_* bits
   int log2_ctb, units_log2, lmt, ctb_w, width, height;
   int poc, par_mrg;
 };
 
+__device__ __forceinline__ int slot_of(const MotionCtx& C, int X, int ref_idx) { return X ? C.slice->ref_slot_l1[ref_idx] : C.slice->ref_slot[ref_idx]; }
+__device__ __forceinline__ int num_ref_of(const MotionCtx& C, int X) { return X ? C.slice->num_ref_idx_l1 : C.slice->num_ref_idx; }
+
+__device__ __forceinline__ size_t unit_index(const MotionCtx& C, int x, int y)
+{
+  const uint32_t z = mk_interleave((uint32_t)((x >> 2) & ((1 << (C.log2_ctb - 2)) - 1)), (uint32_t)((y >> 2) & ((1 << (C.log2_ctb - 2)) - 1)));
+  return ((size_t)((y >> C.log2_ctb) * C.ctb_w + (x >> C.log2_ctb)) << C.units_log2) + z;
+}
+
 // the motion of the 4x4 unit that covers luma sample (x, y); the caller has checked availability
 __device__ __forceinline__ MotionUnit unit_at(const MotionCtx& C, int x, int y)
 {
   const int ncx = x >> C.log2_ctb, ncy = y >> C.log2_ctb;
-  const uint32_t z = mk_interleave((uint32_t)((x >> 2) & ((1 << (C.log2_ctb - 2)) - 1)), (uint32_t)((y >> 2) & ((1 << (C.log2_ctb - 2)) - 1)));
-  if (ncx == C.cx && ncy == C.cy) return C.cur[z];
-  return C.field[((size_t)(ncy * C.ctb_w + ncx) << C.units_log2) + z];
+  if (ncx == C.cx && ncy == C.cy)
+    return C.cur[mk_interleave((uint32_t)((x >> 2) & ((1 << (C.log2_ctb - 2)) - 1)), (uint32_t)((y >> 2) & ((1 << (C.log2_ctb - 2)) - 1)))];
+  return C.field[unit_index(C, x, y)];
 }
 
 // 6.4.1 z-scan order availability of (xN, yN) seen from (xC, yC) of the current CTB: inside the picture, decoded earlier, same slice, same tile
@@ -100,55 +111,22 @@ __device__ __forceinline__ int pb_available(const MotionCtx& C, const PbGeom& g,
   else av = 1;
   if (!av) return 0;
   const MotionUnit m = unit_at(C, xN, yN);
-  if (m.ref_idx < 0) return 0;   // MODE_INTRA
+  if (m.ref_idx[0] < 0 && m.ref_idx[1] < 0) return 0;   // MODE_INTRA
   *out = m;
   return 1;
 }
 
-__device__ __forceinline__ int same_motion(const MotionUnit& a, const MotionUnit& b) { return a.mv[0] == b.mv[0] && a.mv[1] == b.mv[1] && a.ref_idx == b.ref_idx; }
-
-// 8.5.3.2.2 - 8.5.3.2.5: merge candidate merge_idx (spatial candidates A1, B1, B0, A0, B2, then zero candidates)
-__device__ __forceinline__ Mv derive_merge(const MotionCtx& C, PbGeom g, int part_mode, int merge_idx)
+// (the fields of a list that is not used are stored as 0 / -1, so whole-record comparison is the comparison of 8.5.3.2.3)
+__device__ __forceinline__ int same_motion(const MotionUnit& a, const MotionUnit& b)
 {
-  const int pl = C.par_mrg;
-  if (pl > 2 && g.nCbS == 8) { g.xPb = g.xCb; g.yPb = g.yCb; g.nPbW = g.nPbH = g.nCbS; g.partIdx = 0; part_mode = 0; }   // singleMCLFlag
-  const int xPb = g.xPb, yPb = g.yPb, nPbW = g.nPbW, nPbH = g.nPbH;
-  const int max_cand = C.slice->max_merge_cand;
-#define MK_SAME_MER(xn, yn) ((xPb >> pl) == ((xn) >> pl) && (yPb >> pl) == ((yn) >> pl))
-  MotionUnit cand[5];
-  int n = 0;
-  MotionUnit A1{}, B1{}, B0{}, A0{}, B2{};
-  // availableN: 6.4.2 minus the merge-estimation-region / second-partition exclusions; flagN: after pruning.  Comparisons read availableN of the other
-  // candidate, not its flag; only B2's "all four present" rule counts flags (8.5.3.2.3)
-  int avA1 = pb_available(C, g, xPb - 1, yPb + nPbH - 1, &A1);
-  if (MK_SAME_MER(xPb - 1, yPb + nPbH - 1) || (g.partIdx == 1 && (part_mode == 2 || part_mode == 6 || part_mode == 7))) avA1 = 0;   // Nx2N, nLx2N, nRx2N
-  const int fA1 = avA1;
-  if (fA1) cand[n++] = A1;
-  int avB1 = pb_available(C, g, xPb + nPbW - 1, yPb - 1, &B1);
-  if (MK_SAME_MER(xPb + nPbW - 1, yPb - 1) || (g.partIdx == 1 && (part_mode == 1 || part_mode == 4 || part_mode == 5))) avB1 = 0;   // 2NxN, 2NxnU, 2NxnD
-  const int fB1 = avB1 && !(avA1 && same_motion(A1, B1));
-  if (fB1) cand[n++] = B1;
-  int avB0 = pb_available(C, g, xPb + nPbW, yPb - 1, &B0);
-  if (MK_SAME_MER(xPb + nPbW, yPb - 1)) avB0 = 0;
-  const int fB0 = avB0 && !(avB1 && same_motion(B1, B0));
-  if (fB0) cand[n++] = B0;
-  int avA0 = pb_available(C, g, xPb - 1, yPb + nPbH, &A0);
-  if (MK_SAME_MER(xPb - 1, yPb + nPbH)) avA0 = 0;
-  const int fA0 = avA0 && !(avA1 && same_motion(A1, A0));
-  if (fA0) cand[n++] = A0;
-  int avB2 = pb_available(C, g, xPb - 1, yPb - 1, &B2);
-  if (MK_SAME_MER(xPb - 1, yPb - 1)) avB2 = 0;
-  const int fB2 = avB2 && !(avA1 && same_motion(A1, B2)) && !(avB1 && same_motion(B1, B2)) && fA0 + fA1 + fB0 + fB1 != 4;
-  if (fB2 && n < 5) cand[n++] = B2;
-#undef MK_SAME_MER
-  if (n > max_cand) n = max_cand;
-  Mv out;
-  if (merge_idx < n) { out.x = cand[merge_idx].mv[0]; out.y = cand[merge_idx].mv[1]; out.ref_idx = cand[merge_idx].ref_idx; }
-  else {   // zero candidates: refIdxL0 = zeroIdx while it is below the number of reference indices, then 0
-    const int zero_idx = merge_idx - n;
-    out.x = 0; out.y = 0; out.ref_idx = zero_idx < (int)C.slice->num_ref_idx ? zero_idx : 0;
-  }
-  return out;
+  return a.mv[0][0] == b.mv[0][0] && a.mv[0][1] == b.mv[0][1] && a.mv[1][0] == b.mv[1][0] && a.mv[1][1] == b.mv[1][1] &&
+         a.ref_idx[0] == b.ref_idx[0] && a.ref_idx[1] == b.ref_idx[1];
+}
+__device__ __forceinline__ Mo to_mo(const MotionUnit& u)
+{
+  Mo m;
+  for (int X = 0; X < 2; X++) { m.mv[X][0] = u.mv[X][0]; m.mv[X][1] = u.mv[X][1]; m.ref_idx[X] = u.ref_idx[X]; }
+  return m;
 }
 
 __device__ __forceinline__ void scale_mv(int* mv, int td, int tb)
@@ -162,45 +140,161 @@ __device__ __forceinline__ void scale_mv(int* mv, int td, int tb)
   }
 }
 
-// 8.5.3.2.6 - 8.5.3.2.8: motion vector predictor mvp_flag for reference index ref_idx
-__device__ __forceinline__ void derive_mvp(const MotionCtx& C, const PbGeom& g, int ref_idx, int mvp_flag, int* mvp)
+// 8.5.3.2.9: the motion vector the collocated picture stored for the 16x16 block that covers (x, y), scaled to the distance of the target picture
+__device__ __forceinline__ int collocated_mv(const MotionCtx& C, int x, int y, int ref_idx, int X, int* mv_out)
+{
+  const MotionUnit cu = C.col[unit_index(C, (x >> 4) << 4, (y >> 4) << 4)];
+  const int f0 = cu.ref_idx[0] >= 0, f1 = cu.ref_idx[1] >= 0;
+  if (!f0 && !f1) return 0;   // intra coded
+  int L;
+  if (!f0) L = 1;
+  else if (!f1) L = 0;
+  else L = C.slice->no_backward ? X : C.slice->col_from_l0;
+  int mv[2] = {cu.mv[L][0], cu.mv[L][1]};
+  const int col_diff = cu.poc_delta[L], cur_diff = C.poc - C.reftab[slot_of(C, X, ref_idx)].poc;
+  if (col_diff != cur_diff) {
+    if (col_diff == 0) return 0;
+    scale_mv(mv, col_diff, cur_diff);
+  }
+  mv_out[0] = mv[0]; mv_out[1] = mv[1];
+  return 1;
+}
+
+// 8.5.3.2.8: the bottom-right candidate (inside the CTB row and the picture), then the centre
+__device__ __forceinline__ int temporal_mv(const MotionCtx& C, int xPb, int yPb, int nPbW, int nPbH, int ref_idx, int X, int* mv_out)
+{
+  if (!C.col) return 0;
+  const int xBr = xPb + nPbW, yBr = yPb + nPbH;
+  if ((yPb >> C.log2_ctb) == (yBr >> C.log2_ctb) && yBr < C.height && xBr < C.width && collocated_mv(C, xBr, yBr, ref_idx, X, mv_out)) return 1;
+  return collocated_mv(C, xPb + (nPbW >> 1), yPb + (nPbH >> 1), ref_idx, X, mv_out);
+}
+
+// 8.5.3.2.2 - 8.5.3.2.5: merge candidate merge_idx (spatial candidates A1, B1, B0, A0, B2, the temporal candidate, combined bi-predictive candidates
+// of a B slice, zero candidates)
+__device__ __forceinline__ Mo derive_merge(const MotionCtx& C, PbGeom g, int part_mode, int merge_idx)
+{
+  const int pl = C.par_mrg;
+  const int orig_w = g.nPbW, orig_h = g.nPbH;
+  if (pl > 2 && g.nCbS == 8) { g.xPb = g.xCb; g.yPb = g.yCb; g.nPbW = g.nPbH = g.nCbS; g.partIdx = 0; part_mode = 0; }   // singleMCLFlag
+  const int xPb = g.xPb, yPb = g.yPb, nPbW = g.nPbW, nPbH = g.nPbH;
+  const int max_cand = C.slice->max_merge_cand, is_b = C.slice->is_b;
+#define MK_SAME_MER(xn, yn) ((xPb >> pl) == ((xn) >> pl) && (yPb >> pl) == ((yn) >> pl))
+  Mo cand[6];
+  int n = 0;
+  MotionUnit A1{}, B1{}, B0{}, A0{}, B2{};
+  // availableN: 6.4.2 minus the merge-estimation-region / second-partition exclusions; flagN: after pruning.  Comparisons read availableN of the other
+  // candidate, not its flag; only B2's "all four present" rule counts flags (8.5.3.2.3)
+  int avA1 = pb_available(C, g, xPb - 1, yPb + nPbH - 1, &A1);
+  if (MK_SAME_MER(xPb - 1, yPb + nPbH - 1) || (g.partIdx == 1 && (part_mode == 2 || part_mode == 6 || part_mode == 7))) avA1 = 0;   // Nx2N, nLx2N, nRx2N
+  const int fA1 = avA1;
+  if (fA1) cand[n++] = to_mo(A1);
+  int avB1 = pb_available(C, g, xPb + nPbW - 1, yPb - 1, &B1);
+  if (MK_SAME_MER(xPb + nPbW - 1, yPb - 1) || (g.partIdx == 1 && (part_mode == 1 || part_mode == 4 || part_mode == 5))) avB1 = 0;   // 2NxN, 2NxnU, 2NxnD
+  const int fB1 = avB1 && !(avA1 && same_motion(A1, B1));
+  if (fB1) cand[n++] = to_mo(B1);
+  int avB0 = pb_available(C, g, xPb + nPbW, yPb - 1, &B0);
+  if (MK_SAME_MER(xPb + nPbW, yPb - 1)) avB0 = 0;
+  const int fB0 = avB0 && !(avB1 && same_motion(B1, B0));
+  if (fB0) cand[n++] = to_mo(B0);
+  int avA0 = pb_available(C, g, xPb - 1, yPb + nPbH, &A0);
+  if (MK_SAME_MER(xPb - 1, yPb + nPbH)) avA0 = 0;
+  const int fA0 = avA0 && !(avA1 && same_motion(A1, A0));
+  if (fA0) cand[n++] = to_mo(A0);
+  int avB2 = pb_available(C, g, xPb - 1, yPb - 1, &B2);
+  if (MK_SAME_MER(xPb - 1, yPb - 1)) avB2 = 0;
+  const int fB2 = avB2 && !(avA1 && same_motion(A1, B2)) && !(avB1 && same_motion(B1, B2)) && fA0 + fA1 + fB0 + fB1 != 4;
+  if (fB2) cand[n++] = to_mo(B2);
+#undef MK_SAME_MER
+  if (C.slice->tmvp && n <= merge_idx) {   // the temporal candidate: reference index 0 in each list of the slice (only needed when merge_idx reaches it)
+    Mo c;
+    for (int X = 0; X < 2; X++) { c.mv[X][0] = c.mv[X][1] = 0; c.ref_idx[X] = -1; }
+    for (int X = 0; X < (is_b ? 2 : 1); X++) if (temporal_mv(C, xPb, yPb, nPbW, nPbH, 0, X, c.mv[X])) c.ref_idx[X] = 0;
+    if (c.ref_idx[0] >= 0 || c.ref_idx[1] >= 0) cand[n++] = c;
+  }
+  if (n > max_cand) n = max_cand;
+  if (is_b && n > 1 && n < max_cand && n <= merge_idx) {   // 8.5.3.2.4 combined bi-predictive candidates
+    const int num_orig = n;
+    for (int comb = 0; comb < num_orig * (num_orig - 1) && n < max_cand; comb++) {
+      // l0CandIdx / l1CandIdx of Table 8-7: (0,1) (1,0) (0,2) (2,0) (1,2) (2,1) (0,3) (3,0) (1,3) (3,1) (2,3) (3,2)
+      const int l0 = (int)((0x323130212010ull >> (4 * comb)) & 3u), l1 = (int)((0x231303120201ull >> (4 * comb)) & 3u);   // one nibble per combIdx
+      const Mo& a = cand[l0]; const Mo& b = cand[l1];
+      if (a.ref_idx[0] >= 0 && b.ref_idx[1] >= 0 &&
+          (slot_of(C, 0, a.ref_idx[0]) != slot_of(C, 1, b.ref_idx[1]) || a.mv[0][0] != b.mv[1][0] || a.mv[0][1] != b.mv[1][1])) {
+        Mo c;
+        c.ref_idx[0] = a.ref_idx[0]; c.mv[0][0] = a.mv[0][0]; c.mv[0][1] = a.mv[0][1];
+        c.ref_idx[1] = b.ref_idx[1]; c.mv[1][0] = b.mv[1][0]; c.mv[1][1] = b.mv[1][1];
+        cand[n++] = c;
+      }
+    }
+  }
+  Mo out;
+  if (merge_idx < n) out = cand[merge_idx];
+  else {   // zero candidates: the reference index counts up while below the number of reference pictures (B: of the shorter list), then 0
+    const int zero_idx = merge_idx - n;
+    const int num_ref = is_b ? (C.slice->num_ref_idx < C.slice->num_ref_idx_l1 ? C.slice->num_ref_idx : C.slice->num_ref_idx_l1) : C.slice->num_ref_idx;
+    const int r = zero_idx < num_ref ? zero_idx : 0;
+    for (int X = 0; X < 2; X++) { out.mv[X][0] = out.mv[X][1] = 0; out.ref_idx[X] = -1; }
+    out.ref_idx[0] = r;
+    if (is_b) out.ref_idx[1] = r;
+  }
+  if (out.ref_idx[0] >= 0 && out.ref_idx[1] >= 0 && orig_w + orig_h == 12) { out.ref_idx[1] = -1; out.mv[1][0] = out.mv[1][1] = 0; }   // 8x4 / 4x8: uni-prediction
+  return out;
+}
+
+// the motion vector of neighbour m that points at the target picture (its own list X first, then the other list); 8.5.3.2.7
+__device__ __forceinline__ int nb_same_pic(const MotionCtx& C, const MotionUnit& m, int X, int tgt_slot, int* mv)
+{
+  for (int k = 0; k < 2; k++) {
+    const int L = k ? 1 - X : X;
+    if (m.ref_idx[L] >= 0 && (int)(m.slot_pred[L] & 63u) == tgt_slot) { mv[0] = m.mv[L][0]; mv[1] = m.mv[L][1]; return 1; }
+  }
+  return 0;
+}
+__device__ __forceinline__ int nb_scaled(const MotionCtx& C, const MotionUnit& m, int X, int tgt_slot, int* mv)
+{
+  for (int k = 0; k < 2; k++) {
+    const int L = k ? 1 - X : X;
+    if (m.ref_idx[L] >= 0) {
+      mv[0] = m.mv[L][0]; mv[1] = m.mv[L][1];
+      const int nb_slot = (int)(m.slot_pred[L] & 63u);
+      if (nb_slot != tgt_slot) scale_mv(mv, C.poc - C.reftab[nb_slot].poc, C.poc - C.reftab[tgt_slot].poc);
+      return 1;
+    }
+  }
+  return 0;
+}
+
+// 8.5.3.2.6 - 8.5.3.2.8: motion vector predictor mvp_flag of list X for reference index ref_idx
+__device__ __forceinline__ void derive_mvp(const MotionCtx& C, const PbGeom& g, int X, int ref_idx, int mvp_flag, int* mvp)
 {
   const int xPb = g.xPb, yPb = g.yPb, nPbW = g.nPbW, nPbH = g.nPbH;
-  const int cur_poc = C.poc, tgt_poc = C.reftab[C.slice->ref_slot[ref_idx]].poc;
+  const int tgt_slot = slot_of(C, X, ref_idx);
   const int xA[2] = {xPb - 1, xPb - 1}, yA[2] = {yPb + nPbH, yPb + nPbH - 1};
   MotionUnit mA[2] = {};
   int avA[2];
   for (int k = 0; k < 2; k++) avA[k] = pb_available(C, g, xA[k], yA[k], &mA[k]);
   const int is_scaled = avA[0] || avA[1];
   int flagA = 0, mvA[2] = {0, 0};
-  for (int k = 0; k < 2 && !flagA; k++)
-    if (avA[k] && C.reftab[mA[k].ref_slot].poc == tgt_poc) { flagA = 1; mvA[0] = mA[k].mv[0]; mvA[1] = mA[k].mv[1]; }
-  for (int k = 0; k < 2 && !flagA; k++)
-    if (avA[k]) {
-      const int nb_poc = C.reftab[mA[k].ref_slot].poc;
-      flagA = 1; mvA[0] = mA[k].mv[0]; mvA[1] = mA[k].mv[1];
-      if (nb_poc != tgt_poc) scale_mv(mvA, cur_poc - nb_poc, cur_poc - tgt_poc);
-    }
+  for (int k = 0; k < 2 && !flagA; k++) if (avA[k]) flagA = nb_same_pic(C, mA[k], X, tgt_slot, mvA);
+  for (int k = 0; k < 2 && !flagA; k++) if (avA[k]) flagA = nb_scaled(C, mA[k], X, tgt_slot, mvA);
   const int xB[3] = {xPb + nPbW, xPb + nPbW - 1, xPb - 1}, yB[3] = {yPb - 1, yPb - 1, yPb - 1};
   MotionUnit mB[3] = {};
   int avB[3];
   for (int k = 0; k < 3; k++) avB[k] = pb_available(C, g, xB[k], yB[k], &mB[k]);
   int flagB = 0, mvB[2] = {0, 0};
-  for (int k = 0; k < 3 && !flagB; k++)
-    if (avB[k] && C.reftab[mB[k].ref_slot].poc == tgt_poc) { flagB = 1; mvB[0] = mB[k].mv[0]; mvB[1] = mB[k].mv[1]; }
+  for (int k = 0; k < 3 && !flagB; k++) if (avB[k]) flagB = nb_same_pic(C, mB[k], X, tgt_slot, mvB);
   if (!is_scaled && flagB) { flagA = 1; mvA[0] = mvB[0]; mvA[1] = mvB[1]; }
   if (!is_scaled) {
     flagB = 0;
-    for (int k = 0; k < 3 && !flagB; k++)
-      if (avB[k]) {
-        const int nb_poc = C.reftab[mB[k].ref_slot].poc;
-        flagB = 1; mvB[0] = mB[k].mv[0]; mvB[1] = mB[k].mv[1];
-        if (nb_poc != tgt_poc) scale_mv(mvB, cur_poc - nb_poc, cur_poc - tgt_poc);
-      }
+    for (int k = 0; k < 3 && !flagB; k++) if (avB[k]) flagB = nb_scaled(C, mB[k], X, tgt_slot, mvB);
   }
   int list[2][2] = {{0, 0}, {0, 0}}, n = 0;
   if (flagA) { list[n][0] = mvA[0]; list[n][1] = mvA[1]; n++; }
   if (flagB && !(flagA && mvA[0] == mvB[0] && mvA[1] == mvB[1]) && n < 2) { list[n][0] = mvB[0]; list[n][1] = mvB[1]; n++; }
+  if (n < 2 && C.slice->tmvp) {   // the temporal candidate only when the spatial ones left a place
+    int mvc[2];
+    if (temporal_mv(C, xPb, yPb, nPbW, nPbH, ref_idx, X, mvc)) { list[n][0] = mvc[0]; list[n][1] = mvc[1]; n++; }
+  }
   mvp[0] = list[mvp_flag][0]; mvp[1] = list[mvp_flag][1];   // (entries the candidates did not fill are the zero vectors of 8.5.3.2.6)
 }
 
@@ -208,6 +302,7 @@ struct MotionLds {
   MotionUnit cur[256];   // the CTB being derived, z-order
   MotionUnit pu;         // the motion of the prediction unit lane 0 just derived (broadcast to the lanes that fill its units)
   int pu_geom[4];        // its rectangle in units relative to the CTB: x, y, w, h
+  int pu_bad;
 };
 
 }  // namespace
@@ -250,10 +345,11 @@ __global__ __launch_bounds__(64) void k_motion(MotionArgs A)
     const CtbInfo ci = ctb_info[ctb_rs];
     MotionCtx C;
     C.P = &P; C.reftab = (const RefFrame*)(A.arena + P.off_reftab); C.slice = slices + ci.slice_idx; C.field = field; C.cur = L.cur;
+    C.col = C.slice->tmvp ? (const MotionUnit*)(uintptr_t)C.reftab[C.slice->col_slot].mf : nullptr;
     C.cx = cx; C.cy = cy; C.avail = ci.avail; C.log2_ctb = log2_ctb; C.units_log2 = units_log2; C.lmt = P.log2_min_tb; C.ctb_w = ctb_w;
     C.width = P.width; C.height = P.height; C.poc = P.poc; C.par_mrg = P.log2_par_mrg_level;
     const int x_ctb = cx << log2_ctb, y_ctb = cy << log2_ctb;
-    for (int i = lane; i < units; i += 64) { MotionUnit z{}; z.ref_idx = -1; z.ref_slot = -1; L.cur[i] = z; }
+    for (int i = lane; i < units; i += 64) { MotionUnit z{}; z.ref_idx[0] = z.ref_idx[1] = -1; L.cur[i] = z; }
     mk_lds_sync();
     int z = 0;
     while (z < units && !err) {
@@ -284,32 +380,48 @@ __global__ __launch_bounds__(64) void k_motion(MotionArgs A)
             PbGeom g{xCb, yCb, nCbS, xCb + px[k], yCb + py[k], pw[k], ph[k], k};
             const uint32_t zk = mk_interleave((uint32_t)(ux + (px[k] >> 2)), (uint32_t)(uy + (py[k] >> 2)));
             const MotionSyntax sy = msyn_base[base + zk];
-            Mv m{0, 0, 0};
+            Mo m;
+            for (int X = 0; X < 2; X++) { m.mv[X][0] = m.mv[X][1] = 0; m.ref_idx[X] = -1; }
             int bad = !(sy.w0 & 0x8000u) || (int)((sy.w0 >> 12) & 3u) != k;
             if (!bad) {
               if (sy.w0 & 1u) m = derive_merge(C, g, part_mode, (int)((sy.w0 >> 1) & 7u));
               else {
-                const int ref_idx = (int)((sy.w0 >> 4) & 15u);
-                if (ref_idx >= (int)C.slice->num_ref_idx) bad = 1;
-                else {
+                const int idc = C.slice->is_b ? (int)((sy.w0 >> 16) & 3u) : 0;
+                if (idc > 2 || (idc == 2 && pw[k] + ph[k] == 12)) bad = 1;
+                for (int X = 0; X < 2 && !bad; X++) {
+                  if (!(idc == 2 || idc == X)) continue;
+                  const int ref_idx = X ? (int)((sy.w0 >> 18) & 15u) : (int)((sy.w0 >> 4) & 15u);
+                  if (ref_idx >= num_ref_of(C, X)) { bad = 1; break; }
                   int mvp[2];
-                  derive_mvp(C, g, ref_idx, (int)((sy.w0 >> 8) & 1u), mvp);
-                  const int mvd_x = (int16_t)(sy.w1 & 0xffffu), mvd_y = (int16_t)(sy.w1 >> 16);
+                  derive_mvp(C, g, X, ref_idx, X ? (int)((sy.w0 >> 22) & 1u) : (int)((sy.w0 >> 8) & 1u), mvp);
+                  const int mvd_x = (int16_t)(sy.mvd[X] & 0xffffu), mvd_y = (int16_t)(sy.mvd[X] >> 16);
                   const int ux_ = (mvp[0] + mvd_x + 65536) & 65535, uy_ = (mvp[1] + mvd_y + 65536) & 65535;   // 8.5.3.2.1: wrapped into 16 bits
-                  m.x = ux_ >= 32768 ? ux_ - 65536 : ux_; m.y = uy_ >= 32768 ? uy_ - 65536 : uy_; m.ref_idx = ref_idx;
+                  m.mv[X][0] = ux_ >= 32768 ? ux_ - 65536 : ux_; m.mv[X][1] = uy_ >= 32768 ? uy_ - 65536 : uy_; m.ref_idx[X] = ref_idx;
                 }
               }
-              if (!bad && (m.ref_idx < 0 || m.ref_idx >= (int)C.slice->num_ref_idx)) bad = 1;
+              if (!bad) {
+                if (m.ref_idx[0] < 0 && m.ref_idx[1] < 0) bad = 1;
+                for (int X = 0; X < 2; X++) if (m.ref_idx[X] >= num_ref_of(C, X)) bad = 1;
+              }
             }
             MotionUnit o{};
-            o.mv[0] = (int16_t)m.x; o.mv[1] = (int16_t)m.y; o.ref_idx = (int8_t)(bad ? -2 : m.ref_idx);
-            o.ref_slot = (int8_t)(bad ? 0 : C.slice->ref_slot[m.ref_idx]); o.pred = (uint8_t)((pm & UM_SKIP) ? 2 : 1);
+            o.ref_idx[0] = o.ref_idx[1] = -1;
+            if (!bad)
+              for (int X = 0; X < 2; X++)
+                if (m.ref_idx[X] >= 0) {
+                  const int slot = slot_of(C, X, m.ref_idx[X]);
+                  o.mv[X][0] = (int16_t)m.mv[X][0]; o.mv[X][1] = (int16_t)m.mv[X][1]; o.ref_idx[X] = (int8_t)m.ref_idx[X];
+                  o.poc_delta[X] = (int16_t)mk_clip3(-32768, 32767, C.poc - C.reftab[slot].poc);
+                  o.slot_pred[X] = (uint8_t)slot;
+                }
+            o.slot_pred[0] = (uint8_t)(o.slot_pred[0] | (((pm & UM_SKIP) ? 2u : 1u) << 6));
             L.pu = o;
+            L.pu_bad = bad;
             L.pu_geom[0] = ux + (px[k] >> 2); L.pu_geom[1] = uy + (py[k] >> 2); L.pu_geom[2] = pw[k] >> 2; L.pu_geom[3] = ph[k] >> 2;
           }
           mk_lds_sync();
           const MotionUnit o = L.pu;
-          if (o.ref_idx == -2) { err = DEV_ERR_SYNTAX; break; }
+          if (L.pu_bad) { err = DEV_ERR_SYNTAX; break; }
           const int gx = L.pu_geom[0], gy = L.pu_geom[1], gw = L.pu_geom[2], gh = L.pu_geom[3];
           for (int i = lane; i < gw * gh; i += 64) L.cur[mk_interleave((uint32_t)(gx + i % gw), (uint32_t)(gy + i / gw))] = o;
           mk_lds_sync();
@@ -318,7 +430,7 @@ __global__ __launch_bounds__(64) void k_motion(MotionArgs A)
       z += n_units;
     }
     if (err) break;
-    // the CTB's units leave LDS (coalesced 8-byte stores), then the row's progress is published
+    // the CTB's units leave LDS (coalesced 16-byte stores), then the row's progress is published
     for (int i = lane; i < units; i += 64) field[base + i] = L.cur[i];
     mk_lds_sync();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -342,31 +454,12 @@ __device__ __forceinline__ int chroma_tap(int frac, int i)
 }
 }  // namespace
 
+// the 14-bit prediction sample of list X at (x, y) of the plane (8.5.3.3.3): integer copy, one separable pass, or both
 template <typename Pix>
-__global__ __launch_bounds__(256) void k_mc(FilterArgs A, int n_planes_per_pic)
+__device__ __forceinline__ int mc_sample(const Pix* ref, size_t rstride, int W, int H, int plane, int bit_depth, int x, int y, int mvx, int mvy)
 {
-  const int pic = (int)blockIdx.z / 3, plane = (int)blockIdx.z % 3;
-  (void)n_planes_per_pic;
-  if (__hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
-  const PicParams& P = A.pics[pic];
-  if (!P.is_inter || (plane && !P.chroma_format_idc)) return;
-  const int W = plane ? P.cwidth : P.width, H = plane ? P.cheight : P.height;
-  const int x = (int)(blockIdx.x * 16 + (threadIdx.x & 15)), y = (int)(blockIdx.y * 16 + (threadIdx.x >> 4));
-  if (x >= W || y >= H) return;
-  const int sub = plane ? 1 : 0;                       // log2 subsampling (4:2:0 only)
-  const int xl = x << sub, yl = y << sub;              // the luma sample that decides which prediction unit the sample belongs to
-  const int log2_ctb = P.log2_ctb;
-  const int cx = xl >> log2_ctb, cy = yl >> log2_ctb, m = (1 << (log2_ctb - 2)) - 1;
-  const uint32_t z = mk_interleave((uint32_t)((xl >> 2) & m), (uint32_t)((yl >> 2) & m));
-  const MotionUnit mu = ((const MotionUnit*)(A.arena + P.off_mf))[((size_t)(cy * P.ctb_w + cx) << P.units_per_ctb_log2) + z];
-  if (mu.ref_idx < 0) return;                          // intra coded: k_recon predicts it
-  const RefFrame rf = ((const RefFrame*)(A.arena + P.off_reftab))[mu.ref_slot];
-  const Pix* ref = (const Pix*)(uintptr_t)rf.plane[plane];
-  const size_t rstride = rf.stride[plane] / sizeof(Pix);
-  const int bit_depth = plane ? P.bit_depth_chroma : P.bit_depth_luma;
   const int shift1 = bit_depth - 8 < 4 ? bit_depth - 8 : 4, shift3 = 14 - bit_depth > 2 ? 14 - bit_depth : 2;
   const int fbits = plane ? 3 : 2, taps = plane ? 4 : 8, before = plane ? 1 : 3;
-  const int mvx = mu.mv[0], mvy = mu.mv[1];
   const int xf = mvx & ((1 << fbits) - 1), yf = mvy & ((1 << fbits) - 1);
   const int xi = x + (mvx >> fbits), yi = y + (mvy >> fbits);
 #define MK_REF(xx, yy) ((int)ref[(size_t)mk_clip3(0, H - 1, (yy)) * rstride + (size_t)mk_clip3(0, W - 1, (xx))])
@@ -386,9 +479,55 @@ __global__ __launch_bounds__(256) void k_mc(FilterArgs A, int n_planes_per_pic)
   }
 #undef MK_REF
 #undef MK_TAP
-  const int wshift = 14 - bit_depth, woff = 1 << (wshift - 1), maxv = (1 << bit_depth) - 1;   // 8.5.3.3.4.2, predFlagL0 only (bit depth <= 12)
+  return v;
+}
+
+template <typename Pix>
+__global__ __launch_bounds__(256) void k_mc(FilterArgs A, int n_planes_per_pic)
+{
+  const int pic = (int)blockIdx.z / 3, plane = (int)blockIdx.z % 3;
+  (void)n_planes_per_pic;
+  if (__hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+  const PicParams& P = A.pics[pic];
+  if (!P.is_inter || (plane && !P.chroma_format_idc)) return;
+  const int W = plane ? P.cwidth : P.width, H = plane ? P.cheight : P.height;
+  const int x = (int)(blockIdx.x * 16 + (threadIdx.x & 15)), y = (int)(blockIdx.y * 16 + (threadIdx.x >> 4));
+  if (x >= W || y >= H) return;
+  const int sub = plane ? 1 : 0;                       // log2 subsampling (4:2:0 only)
+  const int xl = x << sub, yl = y << sub;              // the luma sample that decides which prediction unit the sample belongs to
+  const int log2_ctb = P.log2_ctb;
+  const int cx = xl >> log2_ctb, cy = yl >> log2_ctb, m = (1 << (log2_ctb - 2)) - 1;
+  const uint32_t z = mk_interleave((uint32_t)((xl >> 2) & m), (uint32_t)((yl >> 2) & m));
+  const MotionUnit mu = ((const MotionUnit*)(A.arena + P.off_mf))[((size_t)(cy * P.ctb_w + cx) << P.units_per_ctb_log2) + z];
+  if (mu.ref_idx[0] < 0 && mu.ref_idx[1] < 0) return;   // intra coded: k_recon predicts it
+  const RefFrame* reftab = (const RefFrame*)(A.arena + P.off_reftab);
+  const int bit_depth = plane ? P.bit_depth_chroma : P.bit_depth_luma;
+  int pred[2] = {0, 0};
+  for (int X = 0; X < 2; X++) {
+    if (mu.ref_idx[X] < 0) continue;
+    const RefFrame rf = reftab[mu.slot_pred[X] & 63u];
+    pred[X] = mc_sample<Pix>((const Pix*)(uintptr_t)rf.plane[plane], rf.stride[plane] / sizeof(Pix), W, H, plane, bit_depth, x, y, mu.mv[X][0], mu.mv[X][1]);
+  }
+  const int bi = mu.ref_idx[0] >= 0 && mu.ref_idx[1] >= 0, one = mu.ref_idx[0] >= 0 ? 0 : 1;
+  const int shift1 = 14 - bit_depth, maxv = (1 << bit_depth) - 1;   // (bit depth <= 12)
+  const SliceParams& sl = ((const SliceParams*)(A.arena + P.off_slices))[((const CtbInfo*)(A.arena + P.off_ctb_info))[cy * P.ctb_w + cx].slice_idx];
+  int v;
+  if (!sl.weighted) {   // 8.5.3.3.4.2
+    v = bi ? (pred[0] + pred[1] + (1 << shift1)) >> (shift1 + 1) : (pred[one] + (1 << (shift1 - 1))) >> shift1;
+  } else {              // 8.5.3.3.4.3
+    const WeightTable& wt = ((const WeightTable*)(A.arena + P.off_wp))[sl.wp_index];
+    const int log2wd = (plane ? sl.chroma_log2_wd : sl.luma_log2_wd) + shift1;
+    if (bi) {
+      const int w0 = wt.w[0][mu.ref_idx[0]][plane], w1 = wt.w[1][mu.ref_idx[1]][plane];
+      const int o0 = wt.o[0][mu.ref_idx[0]][plane] << (bit_depth - 8), o1 = wt.o[1][mu.ref_idx[1]][plane] << (bit_depth - 8);
+      v = (pred[0] * w0 + pred[1] * w1 + ((o0 + o1 + 1) << log2wd)) >> (log2wd + 1);
+    } else {
+      const int w = wt.w[one][mu.ref_idx[one]][plane], o = wt.o[one][mu.ref_idx[one]][plane] << (bit_depth - 8);
+      v = ((pred[one] * w + (1 << (log2wd - 1))) >> log2wd) + o;   // (log2WD >= 2: shift1 >= 2)
+    }
+  }
   Pix* rec = (Pix*)(A.arena + P.off_rec[plane]);
-  rec[(size_t)y * (P.rec_stride[plane ? 1 : 0] / sizeof(Pix)) + x] = (Pix)mk_clip3(0, maxv, (v + woff) >> wshift);
+  rec[(size_t)y * (P.rec_stride[plane ? 1 : 0] / sizeof(Pix)) + x] = (Pix)mk_clip3(0, maxv, v);
 }
 
 void launch_motion(const MotionArgs& a, hipStream_t s)

@@ -152,6 +152,7 @@ struct PS {
   // ---- P slices: slice_type P, num_ref_idx_l0_active, MaxNumMergeCand, initType; amp_enabled_flag, max_transform_hierarchy_depth_inter;
   //      the motion syntax records of the CTB being parsed (one per prediction unit, at the unit index of its first 4x4 unit)
   int32_t is_p, num_ref_idx, max_merge_cand, init_type, amp, max_th_depth_inter;
+  int32_t is_b, num_ref_idx_l1, mvd_l1_zero;   // B slices: slice_type B, num_ref_idx_l1_active, mvd_l1_zero_flag
   MotionSyntax* msyn;
 #endif
 };
@@ -772,10 +773,37 @@ PC_DEV int parse_part_mode_inter(PS& s, int log2cb)
   return decode_bypass(s) ? PM_nRx2N : PM_nLx2N;
 }
 
-// one prediction unit: its syntax into the record at unit index z (CTB-local z-order); returns merge_flag
-PC_DEV int prediction_unit(PS& s, int z, int part_mode, int part_idx, int cu_skip)
+// mvd_coding (7.3.8.9): mvd_x | mvd_y << 16 as int16 halves
+PC_DEV uint32_t parse_mvd(PS& s)
 {
-  int merge_flag = 1, merge_idx = 0, ref_idx = 0, mvp_flag = 0, mvd_x = 0, mvd_y = 0;
+  int mvd_x = 0, mvd_y = 0;
+  const int gx = decode_bin(s, s.ctxC, C_MVD_GT0), gy = decode_bin(s, s.ctxC, C_MVD_GT0);
+  int g1x = 0, g1y = 0;
+  if (gx) g1x = decode_bin(s, s.ctxC, C_MVD_GT1);
+  if (gy) g1y = decode_bin(s, s.ctxC, C_MVD_GT1);
+  if (gx) { int a = 1; if (g1x) a = decode_egk(s, 1) + 2; if (a > 32768) s.err = DEV_ERR_SYNTAX; mvd_x = decode_bypass(s) ? -a : a; }
+  if (gy) { int a = 1; if (g1y) a = decode_egk(s, 1) + 2; if (a > 32768) s.err = DEV_ERR_SYNTAX; mvd_y = decode_bypass(s) ? -a : a; }
+  return ((uint32_t)mvd_x & 0xffffu) | ((uint32_t)mvd_y << 16);
+}
+
+PC_DEV int parse_ref_idx(PS& s, int num_ref)   // TR, cMax = num_ref_idx_lX_active_minus1: bins 0 and 1 context coded, the rest bypass
+{
+  int ref_idx = 0;
+  const int cmax = num_ref - 1;
+  while (ref_idx < cmax) {
+    const int b = ref_idx < 2 ? decode_bin(s, s.ctxC, C_REF_IDX + ref_idx) : decode_bypass(s);
+    if (!b) break;
+    ref_idx++;
+  }
+  return ref_idx;
+}
+
+// one prediction unit: its syntax into the record at unit index z (CTB-local z-order); returns merge_flag.  ct_depth: the coding quadtree depth
+// of the unit (context of inter_pred_idc); small: an 8x4 / 4x8 block (no bi-prediction: inter_pred_idc has one bin)
+PC_DEV int prediction_unit(PS& s, int z, int part_mode, int part_idx, int cu_skip, int ct_depth, int small)
+{
+  int merge_flag = 1, merge_idx = 0, idc = 0, ref_idx[2] = {0, 0}, mvp_flag[2] = {0, 0};
+  uint32_t mvd[2] = {0, 0};
   if (!cu_skip) merge_flag = decode_bin(s, s.ctxC, C_MERGE_FLAG);
   if (merge_flag) {
     if (s.max_merge_cand > 1 && decode_bin(s, s.ctxC, C_MERGE_IDX)) {
@@ -783,25 +811,26 @@ PC_DEV int prediction_unit(PS& s, int z, int part_mode, int part_idx, int cu_ski
       while (merge_idx < s.max_merge_cand - 1 && decode_bypass(s)) merge_idx++;
     }
   } else {
-    const int cmax = s.num_ref_idx - 1;
-    while (ref_idx < cmax) {
-      const int b = ref_idx < 2 ? decode_bin(s, s.ctxC, C_REF_IDX + ref_idx) : decode_bypass(s);
-      if (!b) break;
-      ref_idx++;
+    if (s.is_b) {   // inter_pred_idc (9.3.3.8): PRED_L0 0, PRED_L1 1, PRED_BI 2
+      if (!small && decode_bin(s, s.ctxC, C_INTER_PRED_IDC + ct_depth)) idc = 2;
+      else idc = decode_bin(s, s.ctxC, C_INTER_PRED_IDC + 4);
     }
-    const int gx = decode_bin(s, s.ctxC, C_MVD_GT0), gy = decode_bin(s, s.ctxC, C_MVD_GT0);
-    int g1x = 0, g1y = 0;
-    if (gx) g1x = decode_bin(s, s.ctxC, C_MVD_GT1);
-    if (gy) g1y = decode_bin(s, s.ctxC, C_MVD_GT1);
-    if (gx) { int a = 1; if (g1x) a = decode_egk(s, 1) + 2; if (a > 32768) s.err = DEV_ERR_SYNTAX; mvd_x = decode_bypass(s) ? -a : a; }
-    if (gy) { int a = 1; if (g1y) a = decode_egk(s, 1) + 2; if (a > 32768) s.err = DEV_ERR_SYNTAX; mvd_y = decode_bypass(s) ? -a : a; }
-    mvp_flag = decode_bin(s, s.ctxC, C_MVP_FLAG);
+    if (idc != 1) {
+      ref_idx[0] = parse_ref_idx(s, s.num_ref_idx);
+      mvd[0] = parse_mvd(s);
+      mvp_flag[0] = decode_bin(s, s.ctxC, C_MVP_FLAG);
+    }
+    if (idc != 0) {
+      ref_idx[1] = parse_ref_idx(s, s.num_ref_idx_l1);
+      if (!(s.mvd_l1_zero && idc == 2)) mvd[1] = parse_mvd(s);
+      mvp_flag[1] = decode_bin(s, s.ctxC, C_MVP_FLAG);
+    }
   }
-  const uint32_t w0 = (uint32_t)merge_flag | ((uint32_t)merge_idx << 1) | ((uint32_t)ref_idx << 4) | ((uint32_t)mvp_flag << 8) | ((uint32_t)part_mode << 9) |
-                      ((uint32_t)part_idx << 12) | 0x8000u;
-  const uint32_t w1 = ((uint32_t)mvd_x & 0xffffu) | ((uint32_t)mvd_y << 16);
+  const uint32_t w0 = (uint32_t)merge_flag | ((uint32_t)merge_idx << 1) | ((uint32_t)ref_idx[0] << 4) | ((uint32_t)mvp_flag[0] << 8) | ((uint32_t)part_mode << 9) |
+                      ((uint32_t)part_idx << 12) | 0x8000u | ((uint32_t)idc << 16) | ((uint32_t)ref_idx[1] << 18) | ((uint32_t)mvp_flag[1] << 22);
   MotionSyntax* dst = s.msyn + z;
-  PC_VEC_BEGIN if (lane == 0) { dst->w0 = w0; dst->w1 = w1; } PC_VEC_END
+  const uint32_t m0 = mvd[0], m1 = mvd[1];
+  PC_VEC_BEGIN if (lane == 0) { dst->w0 = w0; dst->mvd[0] = m0; dst->mvd[1] = m1; } PC_VEC_END
   return merge_flag;
 }
 
@@ -838,7 +867,7 @@ PC_DEV void inter_coding_unit(PS& s, int zb, int log2cb, int cu_skip, int16_t* c
   int merge0 = 0;
   for (int k = 0; k < n_parts && !s.err; k++) {
     const int z = (int)interleave4((uint32_t)(ux0 + px[k]), (uint32_t)(uy0 + py[k]));
-    const int mf = prediction_unit(s, z, part_mode, k, cu_skip);
+    const int mf = prediction_unit(s, z, part_mode, k, cu_skip, s.log2_ctb - log2cb, log2cb == 3 && part_mode != PM_2Nx2N);
     if (k == 0) merge0 = mf;
   }
   int rqt_root_cbf = 0;
@@ -1386,6 +1415,8 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
 #if HIPDEC_PARSE_INTER
     const uint32_t w4 = uload32(&sl->is_p);                // is_p, num_ref_idx, max_merge_cand, init_type
     s.is_p = (int)(w4 & 255u); s.num_ref_idx = (int)((w4 >> 8) & 255u); s.max_merge_cand = (int)((w4 >> 16) & 255u); s.init_type = (int)(w4 >> 24);
+    const uint32_t w6 = uload32(&sl->is_b);                // is_b, num_ref_idx_l1, mvd_l1_zero, tmvp
+    s.is_b = (int)(w6 & 255u); s.num_ref_idx_l1 = (int)((w6 >> 8) & 255u); s.mvd_l1_zero = (int)((w6 >> 16) & 255u);
     const uint32_t w5 = uload32(&P->is_inter);             // is_inter, amp_enabled, max_th_depth_inter, log2_par_mrg_level
     s.amp = (int)((w5 >> 8) & 255u); s.max_th_depth_inter = (int)((w5 >> 16) & 255u);
     s.msyn = nullptr;

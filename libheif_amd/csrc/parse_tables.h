@@ -22,7 +22,8 @@ enum : int {
   // group C: greater1 0..23, then the contexts P slices add (parse_core.h with HIPDEC_PARSE_INTER)
   C_GREATER1 = 0,
   C_SKIP_FLAG = 24 /*3*/, C_PRED_MODE = 27, C_PART_MODE_INTER = 28 /*3: part_mode bin 1, bin 2 at the minimum CB size, bin 2 with AMP*/, C_MERGE_FLAG = 31,
-  C_MERGE_IDX = 32, C_REF_IDX = 33 /*2*/, C_MVD_GT0 = 35, C_MVD_GT1 = 36, C_MVP_FLAG = 37, C_RQT_ROOT_CBF = 38
+  C_MERGE_IDX = 32, C_REF_IDX = 33 /*2*/, C_MVD_GT0 = 35, C_MVD_GT1 = 36, C_MVP_FLAG = 37, C_RQT_ROOT_CBF = 38,
+  C_INTER_PRED_IDC = 39 /*5: bin 0 by coding quadtree depth 0..3, bin 1*/
 };
 
 // initValue for slice_type I (9.3.2.2, tables 9-5 .. 9-37), laid out per group / lane
@@ -48,8 +49,8 @@ PC_CONST uint8_t c_init_p[2][3][64] = {
    136, 153, 154, 170, 153, 123, 123, 107, 121, 107, 121, 167, 151, 183, 140, 151, 183, 140, 140, 140,
    107, 167, 91, 122, 107, 167, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154},
   {154, 196, 196, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 137, 169, 194, 166, 167, 154, 167, 137, 182,
-   197, 185, 201, 149, 139, 154, 154, 110, 122, 153, 153, 140, 198, 168, 79, 154,
-   154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154}},
+   197, 185, 201, 149, 139, 154, 154, 110, 122, 153, 153, 140, 198, 168, 79, 95,
+   79, 63, 31, 31, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154}},
  {{153, 160, 107, 139, 126, 154, 154, 183, 152, 224, 167, 122, 153, 111, 149, 92, 167, 154, 154, 154, 139, 139,
    125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79, 108, 123, 93,
    125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79, 108, 123, 93,
@@ -58,8 +59,8 @@ PC_CONST uint8_t c_init_p[2][3][64] = {
    136, 153, 154, 170, 153, 138, 138, 122, 121, 122, 121, 167, 151, 183, 140, 151, 183, 140, 140, 140,
    107, 167, 91, 107, 107, 167, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154},
   {154, 196, 167, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 122, 169, 208, 166, 167, 154, 152, 167, 182,
-   197, 185, 201, 134, 139, 154, 154, 154, 137, 153, 153, 169, 198, 168, 79, 154,
-   154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154}}};
+   197, 185, 201, 134, 139, 154, 154, 154, 137, 153, 153, 169, 198, 168, 79, 95,
+   79, 63, 31, 31, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154}}};
 
 // Table 8-3: the intra prediction direction of a 4:2:2 chroma block from the mode the 4:2:0 / 4:4:4 derivation yields (8.4.3)
 PC_CONST uint8_t c_map422[35] = {0, 1, 2, 2, 2, 2, 3, 5, 7, 8, 10, 11, 13, 15, 16, 18, 19, 20, 21, 22, 23, 23, 24, 24, 25, 25, 26, 27, 27, 28, 28, 29, 29, 30, 31};

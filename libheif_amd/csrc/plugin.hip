@@ -61,7 +61,7 @@ struct PluginDecoder {
   hipdec_decoder* dec = nullptr;
   int strict = 0;
   const void* limits = nullptr;
-  uintptr_t user_data = 0;    // of the push that completed the pending picture
+  bool flushed = false;       // flush_data was called: the pictures still waiting for output come out (C.5.2.2)
   std::string error_message;  // keeps messages alive beyond the call (decoder_libde265.cc:150-156)
 };
 
@@ -166,12 +166,13 @@ void set_strict_decoding(void* p, int flag)
 hp_error push_data2(void* p, const void* data, size_t size, uintptr_t user_data)
 {
   PluginDecoder* d = (PluginDecoder*)p;
-  d->user_data = user_data;   // handed back with the picture this data decodes to (decoder_libde265.cc:360, :417-419)
+  d->flushed = false;
   int rc = hipdec_decoder_push_data(d->dec, data, size);
+  if (!rc) hipdec_decoder_set_user_data(d->dec, user_data);   // handed back with the picture this data decodes to (decoder_libde265.cc:360, :417-419)
   return rc ? make_error(d, rc) : kOk;
 }
 hp_error push_data(void* p, const void* data, size_t size) { return push_data2(p, data, size, 0); }
-hp_error flush_data(void*) { return kOk; }
+hp_error flush_data(void* p) { if (p) ((PluginDecoder*)p)->flushed = true; return kOk; }
 
 hp_error decode_next_image2(void* p, hp_image** out_img, uintptr_t* out_user_data, const void* limits)
 {
@@ -180,9 +181,12 @@ hp_error decode_next_image2(void* p, hp_image** out_img, uintptr_t* out_user_dat
   if (out_user_data) *out_user_data = 0;
   if (!g_api.ok) return hp_error{HP_ERR_DECODER_PLUGIN, HP_SUB_UNSPECIFIED, kNoHost};
   hipdec_image_info info;
-  int rc = hipdec_decoder_decode(d->dec, &info);
+  int have = 0;
+  uintptr_t picture_user_data = 0;
+  int rc = hipdec_decoder_next_picture(d->dec, d->flushed ? 1 : 0, &info, &have, &picture_user_data);
   if (rc == HIPDEC_ERR_NO_IMAGE) return kOk;  // "nothing (more) to deliver": *out_img stays NULL
   if (rc) return make_error(d, rc);
+  if (!have) return kOk;                      // decoded, but an earlier picture in output order is still to come (B pictures): push the next sample
   const bool mono = info.chroma_format_idc == 0;
   hp_image* img = nullptr;
   hp_error err = g_api.image_create(info.width, info.height, mono ? HP_COLORSPACE_MONOCHROME : HP_COLORSPACE_YCBCR, info.chroma_format_idc, &img);
@@ -228,7 +232,7 @@ hp_error decode_next_image2(void* p, hp_image** out_img, uintptr_t* out_user_dat
     g_api.image_set_nclx(img, nclx);
     g_api.nclx_free(nclx);
   }
-  if (out_user_data) *out_user_data = d->user_data;
+  if (out_user_data) *out_user_data = picture_user_data;
   *out_img = img;
   return kOk;
 }

@@ -97,6 +97,31 @@ class HipDecoder:
             planes.append(a)
         return DecodedImage(d, planes)
 
+    def _read_planes(self, info):
+        d = _info_dict(info)
+        dt = np.uint16 if d["bit_depth_luma"] > 8 else np.uint8
+        planes = []
+        for c in range(3 if d["chroma_format_idc"] else 1):
+            w, h = (d["width"], d["height"]) if c == 0 else (d["chroma_width"], d["chroma_height"])
+            a = np.empty((h, w), dt)
+            check(self._lib.hipdec_decoder_read_plane(self._h, c, a.ctypes.data, w * a.itemsize))
+            planes.append(a)
+        return DecodedImage(d, planes)
+
+    def next_picture(self, flush=False, user_data=None):
+        """decode_next_image2 with output order (hipdec_decoder_next_picture): decodes the pushed sample if one is pending and returns
+        (DecodedImage, user_data) of the next picture in OUTPUT order, or None while the bumping process holds it back (B pictures)."""
+        if user_data is not None:
+            self._lib.hipdec_decoder_set_user_data.argtypes = [C.c_void_p, C.c_size_t]
+            self._lib.hipdec_decoder_set_user_data.restype = None
+            self._lib.hipdec_decoder_set_user_data(self._h, int(user_data))
+        self._lib.hipdec_decoder_next_picture.argtypes = [C.c_void_p, C.c_int, C.POINTER(ImageInfo), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+        info, have, ud = ImageInfo(), C.c_int(0), C.c_size_t(0)
+        check(self._lib.hipdec_decoder_next_picture(self._h, 1 if flush else 0, C.byref(info), C.byref(have), C.byref(ud)))
+        if not have.value:
+            return None
+        return self._read_planes(info), ud.value
+
     def free(self):
         if self._h:
             self._lib.hipdec_decoder_free(self._h)

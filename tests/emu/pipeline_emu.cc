@@ -103,12 +103,14 @@ int emu_seq_commit(EmuSeq* q, EmuBatch* b)
     launch_sao(fa, 1, P.width, P.height, L.wide, nullptr, may_keep, restricted);
     for (int c = 0; c < 3; c++) { rp.plane[c] = (uint64_t)(uintptr_t)(buf->data() + off[c]); rp.stride[c] = stride[c]; }
   }
+  rp.mf = P.is_inter ? (uint64_t)(uintptr_t)(a + P.off_mf) : 0;   // the picture's motion field stays with it: the collocated picture of temporal candidates
   seq_commit(q->ctx, pp);
   q->ctx.dpb.push_back(rp);
   return 0;
 }
 
-// motion field of item i after the pipeline (k_motion): per 4x4 unit in RASTER order mv x, mv y (int16), ref_idx (int8), pred (uint8)
+// motion field of item i after the pipeline (k_motion): per 4x4 unit in RASTER order [list][x, y] motion vectors (int16), [list] ref_idx (int8),
+// pred (uint8) - the layout of the oracle's taps
 int emu_motion(EmuBatch* b, int i, int16_t* mv, int8_t* ref_idx, uint8_t* pred)
 {
   const PicParams& P = b->L.params[i];
@@ -123,7 +125,8 @@ int emu_motion(EmuBatch* b, int i, int16_t* mv, int8_t* ref_idx, uint8_t* pred)
       for (int k = 0; k < 4; k++) z |= (((uint32_t)lx >> k) & 1u) << (2 * k) | (((uint32_t)ly >> k) & 1u) << (2 * k + 1);
       const MotionUnit m = mf[((size_t)(cy * P.ctb_w + cx) << P.units_per_ctb_log2) + z];
       const size_t o = (size_t)uy * uw + ux;
-      mv[2 * o] = m.mv[0]; mv[2 * o + 1] = m.mv[1]; ref_idx[o] = m.ref_idx; pred[o] = m.pred;
+      for (int X = 0; X < 2; X++) { mv[4 * o + 2 * X] = m.mv[X][0]; mv[4 * o + 2 * X + 1] = m.mv[X][1]; ref_idx[2 * o + X] = m.ref_idx[X]; }
+      pred[o] = (uint8_t)(m.slot_pred[0] >> 6);
     }
   return 0;
 }

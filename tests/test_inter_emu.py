@@ -66,7 +66,7 @@ def decode_sequence_emu(aus, want_motion=False):
                 info = (C.c_int * 7)()
                 L.emu_info(b, 0, info)           # coded size: the motion field covers the coded picture
                 uw, uh = (info[0] + 3) // 4, (info[1] + 3) // 4
-                mv, ref, pred = np.zeros((uh, uw, 2), np.int16), np.zeros((uh, uw), np.int8), np.zeros((uh, uw), np.uint8)
+                mv, ref, pred = np.zeros((uh, uw, 2, 2), np.int16), np.zeros((uh, uw, 2), np.int8), np.zeros((uh, uw), np.uint8)
                 if L.emu_motion(b, 0, mv.ctypes.data, ref.ctypes.data, pred.ctypes.data) == 0:
                     pic.update(mf_mv=mv, mf_ref=ref, map_pred=pred)
             out.append(pic)
@@ -85,8 +85,8 @@ def check_sequence(aus, name=""):
             rp = r["map_pred"][:uh, :uw]
             np.testing.assert_array_equal(g["map_pred"], rp, err_msg="%s picture %d: prediction modes" % (name, i))
             inter = rp > 0
-            np.testing.assert_array_equal(g["mf_ref"][inter], r["mf_ref"][:uh, :uw, 0][inter], err_msg="%s picture %d: reference indices" % (name, i))
-            np.testing.assert_array_equal(g["mf_mv"][inter], r["mf_mv"][:uh, :uw, 0][inter], err_msg="%s picture %d: motion vectors" % (name, i))
+            np.testing.assert_array_equal(g["mf_ref"][inter], r["mf_ref"][:uh, :uw][inter], err_msg="%s picture %d: reference indices" % (name, i))
+            np.testing.assert_array_equal(g["mf_mv"][inter], r["mf_mv"][:uh, :uw][inter], err_msg="%s picture %d: motion vectors" % (name, i))
         for c in range(len(r["planes"])):
             np.testing.assert_array_equal(g["planes"][c], r["planes"][c], err_msg="%s picture %d plane %d" % (name, i, c))
 
@@ -114,3 +114,34 @@ def test_emulated_monochrome_and_cropped_sequence():
     check_sequence(orc.encode_sequence(frames, qp=22, inter_num_refs=2), "mono")
     frames = make_frames(70, 42, 4)        # coded 72 x 48: the reference pictures need the rows below the conformance window
     check_sequence(orc.encode_sequence(frames, qp=22, global_mv_x=3, global_mv_y=17, inter_num_refs=2, amp=1), "cropped")
+
+
+from test_inter_oracle import B_CONFIGS
+
+
+@pytest.mark.parametrize("name", sorted(B_CONFIGS))
+def test_emulated_device_pipeline_decodes_b_tmvp_weighted(name):
+    """B pictures (two lists, bi-prediction, combined merge candidates, coding order != POC order), temporal candidates from the collocated
+    picture's motion field, explicit weighted prediction: motion field and samples of every picture against the oracle, in coding order"""
+    frames = make_frames(136, 104, 7)
+    aus = orc.encode_sequence(frames, qp=26, global_mv_x=-8, global_mv_y=-4, inter_skip_pct=20, seed=21, **B_CONFIGS[name])
+    check_sequence(aus, name)
+
+
+@pytest.mark.parametrize("kw", [dict(b_frames=2, b_ref=1, temporal_mvp=1, weighted_pred=1, bit_depth=10, amp=1, inter_num_refs=2),
+                                dict(b_frames=1, temporal_mvp=1, lossless_pct=30, transform_skip=1, log2_ctb=5, mvd_l1_zero=1),
+                                dict(b_frames=3, b_ref=1, temporal_mvp=1, weighted_pred=1, dependent_segments=3, num_slices=2, inter_num_refs=3, wpp=0, max_merge_cand=2),
+                                dict(b_frames=2, temporal_mvp=1, deblock_disable=0, sao=1, inter_merge_pct=90, inter_bi_pct=90, cu_qp_delta=1)],
+                         ids=["main10", "lossless_tskip", "dependent_segments", "merge_heavy"])
+def test_emulated_b_tool_mix(kw):
+    bd = kw.get("bit_depth", 8)
+    frames = make_frames(120, 88, 6, bd)
+    aus = orc.encode_sequence(frames, qp=24, global_mv_x=6, global_mv_y=-10, seed=5, **kw)
+    check_sequence(aus, str(kw))
+
+
+def test_emulated_b_monochrome_and_cropped():
+    frames = make_frames(70, 42, 5, 8, mono=True)
+    check_sequence(orc.encode_sequence(frames, qp=22, inter_num_refs=2, b_frames=1, temporal_mvp=1, weighted_pred=1), "mono")
+    frames = make_frames(70, 42, 6)        # coded 72 x 48: references and collocated motion cover the rows below the conformance window
+    check_sequence(orc.encode_sequence(frames, qp=22, global_mv_x=3, global_mv_y=17, inter_num_refs=2, amp=1, b_frames=2, b_ref=1, temporal_mvp=1), "cropped")

@@ -238,7 +238,7 @@ def test_context_init_tables_of_the_device_parser_equal_the_oracles():
     L = emu()
     L.emu_ctx_init_value.argtypes = [C.c_int] * 3
     O = orc.lib()
-    n_ctx = 150
+    n_ctx = 155
     tab_i = list((C.c_uint8 * n_ctx).in_dll(O, "hevc_cabac_init_I"))
     tab_p = list((C.c_uint8 * (2 * n_ctx)).in_dll(O, "hevc_cabac_init_P"))
     oracle = [tab_i, tab_p[:n_ctx], tab_p[n_ctx:]]
@@ -248,7 +248,7 @@ def test_context_init_tables_of_the_device_parser_equal_the_oracles():
               (1, 0, 42, 62),       # sig_coeff_flag
               (1, 44, 6, 128),      # coeff_abs_level_greater2
               (2, 0, 24, 104),      # coeff_abs_level_greater1
-              (2, 24, 15, 135)]     # cu_skip_flag .. rqt_root_cbf (P slices)
+              (2, 24, 20, 135)]     # cu_skip_flag .. rqt_root_cbf, inter_pred_idc (P / B slices)
     covered = set()
     for table in range(3):
         used = {g: set() for g in range(3)}

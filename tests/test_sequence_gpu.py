@@ -113,6 +113,40 @@ def test_plugin_function_table_round_trips_user_data_per_sample():
     finally:
         plug.free_decoder(dec)
 
+    # a track with B pictures: samples in coding order; decode_next_image2 returns Ok + NULL while the next picture in output order is still to
+    # come (libheif then pushes the next sample, track_visual.cc:200-260), flush_data releases what is left; user_data travels with the picture
+    dec = vp()
+    assert plug.new_decoder2(C.byref(dec), C.cast(C.byref(opts), vp)).code == 0
+    b_aus, b_refs = _p_sequence(7, b_frames=2, b_ref=1, temporal_mvp=1, weighted_pred=1, inter_num_refs=2)
+    by_poc = {r["poc"]: r for r in b_refs}
+    coding_pocs = [r["poc"] for r in b_refs]
+    outputs = []
+
+    def poll():
+        while True:
+            img, ud = vp(), C.c_size_t(0)
+            e = plug.decode_next_image2(dec, C.byref(img), C.byref(ud), None)
+            assert e.code == 0, e.message
+            if not img.value:
+                return
+            outputs.append(([lh._plane(L, img, ch) for ch in (lh.CHANNEL_Y, lh.CHANNEL_CB, lh.CHANNEL_CR)], ud.value))
+            L.heif_image_release(img)
+
+    try:
+        for k, s in enumerate(b_aus):
+            assert plug.push_data2(dec, s, len(s), 7000 + k).code == 0
+            poll()
+        assert len(outputs) < len(b_aus)                      # the last anchor's B pictures were still waiting
+        assert plug.flush_data(dec).code == 0
+        poll()
+        assert len(outputs) == len(b_aus)
+        for poc, (planes, ud) in enumerate(outputs):
+            assert ud == 7000 + coding_pocs.index(poc)
+            for c in range(3):
+                np.testing.assert_array_equal(planes[c], by_poc[poc]["planes"][c], err_msg="B track POC %d plane %d" % (poc, c))
+    finally:
+        plug.free_decoder(dec)
+
 
 def _p_sequence(n, w=200, h=136, bit_depth=8, **cfg):
     from test_inter_oracle import make_frames
@@ -190,4 +224,59 @@ def test_inter_slices_outside_a_sequence_are_refused_loudly():
     with pytest.raises(HipDecError) as e:
         d.decode_next_image()
     assert e.value.code == -4
+    d.free()
+
+
+# ---- B pictures, temporal motion vector prediction, weighted prediction: what libheif's x265 plugin writes for its "lowdelay" and "unrestricted" GOP
+#      structures (libheif/plugins/encoder_x265.cc:875-888) ------------------------------------------------------------------------------------------
+B_CASES = {
+    "lowdelay_tmvp_weighted": dict(temporal_mvp=1, weighted_pred=1, inter_num_refs=3),
+    "b1": dict(b_frames=1, temporal_mvp=1),
+    "b2_ref_multiref_weighted": dict(b_frames=2, b_ref=1, inter_num_refs=2, temporal_mvp=1, weighted_pred=1, mvd_l1_zero=1, amp=1),
+    "b3_slices_listmod": dict(b_frames=3, temporal_mvp=1, num_slices=2, lists_modification=1, cabac_init_present=1, max_merge_cand=4, wpp=0),
+    "b_main10_tiles": dict(b_frames=2, b_ref=1, temporal_mvp=1, bit_depth=10, tile_cols=2, tile_rows=2, inter_num_refs=2),
+    "b_cropped": dict(b_frames=1, temporal_mvp=1, weighted_pred=1, w=70, h=42, global_mv_y=17, inter_num_refs=2),
+}
+
+
+@pytest.mark.parametrize("name", sorted(B_CASES))
+def test_b_tmvp_weighted_sequences_decode_bit_exact_in_output_order(name):
+    """samples pushed in CODING order (as the track stores them); the pictures come out in OUTPUT order (bumping, C.5.2.2), each with the user_data of
+    its own sample, each bit-exact against the oracle's picture of that POC"""
+    from libheif_amd.decoder import HipDecoder
+    cfg = dict(B_CASES[name])
+    n = 8
+    aus, refs = _p_sequence(n, w=cfg.pop("w", 200), h=cfg.pop("h", 136), bit_depth=cfg.pop("bit_depth", 8), **cfg)
+    by_poc = {r["poc"]: r for r in refs}
+    coding_pocs = [r["poc"] for r in refs]
+    d = HipDecoder()
+    got = []
+    for k, au in enumerate(aus):
+        d.push_data(au)
+        r = d.next_picture(user_data=500 + k)
+        while r is not None:
+            got.append(r)
+            r = d.next_picture()
+    r = d.next_picture(flush=True)
+    while r is not None:
+        got.append(r)
+        r = d.next_picture(flush=True)
+    assert len(got) == n
+    for out_idx, (img, ud) in enumerate(got):
+        assert ud == 500 + coding_pocs.index(out_idx), (out_idx, ud)          # output order == POC order; user_data of the sample that coded it
+        for c in range(3):
+            np.testing.assert_array_equal(img.planes[c], by_poc[out_idx]["planes"][c], err_msg="%s POC %d plane %d" % (name, out_idx, c))
+    d.free()
+
+
+def test_b_sequence_in_coding_order_through_the_legacy_call():
+    """hipdec_decoder_decode keeps delivering the picture of the sample just pushed (coding order): the planes are those of that POC"""
+    from libheif_amd.decoder import HipDecoder
+    aus, refs = _p_sequence(6, b_frames=2, temporal_mvp=1, b_ref=1)
+    d = HipDecoder()
+    for au, ref in zip(aus, refs):
+        d.push_data(au)
+        img = d.decode_next_image()
+        for c in range(3):
+            np.testing.assert_array_equal(img.planes[c], ref["planes"][c], err_msg="POC %d" % ref["poc"])
     d.free()
