@@ -15,6 +15,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <unordered_map>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -1193,11 +1194,12 @@ struct ResidentPlane {
   size_t dev_stride = 0;
   int device = 0;
   uint64_t tick = 0;
+  std::chrono::steady_clock::time_point born{};
 };
 std::mutex g_res_mu;
 // (heap-allocated and never destroyed: its entries own batches, and destroying those from a static destructor at process exit would
 //  run after the HIP runtime and this library's pools are gone; hipdec_shutdown() / the plugin's deinit empty it in good time)
-std::vector<ResidentPlane>& g_resident = *new std::vector<ResidentPlane>();
+std::unordered_map<const void*, ResidentPlane>& g_resident = *new std::unordered_map<const void*, ResidentPlane>();   // by host plane address
 uint64_t g_res_tick = 0;
 std::atomic<uint64_t> g_cb_conversions{0}, g_cb_resident{0}, g_cb_launches{0}, g_xf_transforms{0}, g_grid_canvases{0};
 
@@ -1231,10 +1233,14 @@ uint64_t plane_hash(const uint8_t* p, size_t stride, int w_bytes, int h)
 }
 
 // Tracking costs a pass over every decoded plane, so it only runs once a colour conversion has actually arrived at this library (the
-// stock libheif never calls hipdec_color_convert: no hashing there); an entry serves ONE conversion and is dropped, which also bounds
-// what the registry pins: at most kMaxResident (6) planes' batches, normally those of the image being converted.
+// stock libheif never calls hipdec_color_convert: no hashing there); an entry serves ONE conversion and is dropped.  What the registry
+// pins is bounded in TIME: libheif converts a decoded image within milliseconds of receiving its planes (same thread, same call), so an entry
+// older than kResidentTtlMs (3 s) is stale - the host kept the planes without converting them - and goes at the next insert.  (Rounds 2 - 3 bounded it
+// to 6 entries: with hundreds of application threads between read_plane and conversion the entries evicted each other and every conversion
+// uploaded its planes again from pageable memory - 0.4 - 1.0 Gpixel/s of RGB through libheif where the planes alone ran at 3.)
 std::atomic<bool> g_track_planes{getenv("HIPDEC_TRACK_PLANES") ? atoi(getenv("HIPDEC_TRACK_PLANES")) != 0 : false};
-constexpr size_t kMaxResident = 6;
+const long kResidentTtlMs = getenv("HIPDEC_RESIDENT_TTL_MS") ? atol(getenv("HIPDEC_RESIDENT_TTL_MS")) : 3000;
+constexpr size_t kMaxResident = 16384;
 
 void resident_insert(struct ResidentPlane&& r);
 
@@ -1262,17 +1268,35 @@ hipError_t wait_stream_blocking(hipStream_t s)
   return e == hipSuccess ? hipEventSynchronize(ev.e) : e;
 }
 
+// HIPDEC_IMAGE_OPS_TIMING=1: where the host time of hipdec_color_convert goes, summed over all calls and printed at exit (development aid)
+struct OpsTiming {
+  std::atomic<uint64_t> calls{0}, find_us{0}, gpu_us{0}, copy_us{0}, hits{0}, misses{0};
+  bool on = getenv("HIPDEC_IMAGE_OPS_TIMING") != nullptr;
+  ~OpsTiming()
+  {
+    if (on && calls.load())
+      fprintf(stderr, "[hipdec] color_convert: %llu calls; per call: locate planes %.2f ms (resident %llu, uploaded %llu), device work until synced %.2f ms, rows to the caller %.2f ms\n",
+              (unsigned long long)calls.load(), find_us.load() / 1e3 / calls.load(), (unsigned long long)hits.load(), (unsigned long long)misses.load(),
+              gpu_us.load() / 1e3 / calls.load(), copy_us.load() / 1e3 / calls.load());
+  }
+} g_ops_timing;
+inline uint64_t us_since(Clock::time_point t0) { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - t0).count(); }
+
 int copy_rows_to_host(void* dst, size_t dst_stride, const void* dsrc, size_t src_stride, size_t row_bytes, int rows, hipStream_t s)
 {
   void* pin = nullptr; size_t cap = 0;
   const size_t bytes = row_bytes * (size_t)rows;
   if (bytes >= (64u << 10) && pinned_acquire(&pin, bytes, &cap) == hipSuccess) {
     hipError_t e = hipMemcpy2DAsync(pin, row_bytes, dsrc, src_stride, row_bytes, (size_t)rows, hipMemcpyDeviceToHost, s);
+    const auto t_wait = Clock::now();
     if (e == hipSuccess) e = wait_stream_blocking(s);
+    if (g_ops_timing.on) g_ops_timing.gpu_us += us_since(t_wait);
     if (e != hipSuccess) { pinned_release(pin, cap); return set_error(HIPDEC_ERR_DEVICE, "copy to host: %s", hipGetErrorString(e)); }
+    const auto t_copy = Clock::now();
     if (dst_stride == row_bytes) memcpy(dst, pin, bytes);
     else for (int y = 0; y < rows; y++) memcpy((uint8_t*)dst + (size_t)y * dst_stride, (const uint8_t*)pin + (size_t)y * row_bytes, row_bytes);
     pinned_release(pin, cap);
+    if (g_ops_timing.on) g_ops_timing.copy_us += us_since(t_copy);
     return 0;
   }
   (void)hipGetLastError();
@@ -1298,17 +1322,19 @@ void resident_note(hipdec_decoder* d, int c, const void* host, size_t stride)
 
 void resident_insert(ResidentPlane&& r)
 {
-  std::shared_ptr<hipdec_batch> evicted;   // dies outside the lock
-  std::shared_ptr<void> evicted_buffer;
+  std::vector<ResidentPlane> dropped;   // what they keep alive dies outside the lock
   std::lock_guard<std::mutex> lock(g_res_mu);
   r.tick = ++g_res_tick;
-  for (auto& e : g_resident) if (e.host == r.host) { evicted = std::move(e.batch); evicted_buffer = std::move(e.buffer); e = std::move(r); return; }
-  if (g_resident.size() >= kMaxResident) {
-    size_t old = 0;
-    for (size_t i = 1; i < g_resident.size(); i++) if (g_resident[i].tick < g_resident[old].tick) old = i;
-    evicted = std::move(g_resident[old].batch); evicted_buffer = std::move(g_resident[old].buffer);
-    g_resident[old] = std::move(r);
-  } else g_resident.push_back(std::move(r));
+  r.born = Clock::now();
+  auto it = g_resident.find(r.host);
+  if (it != g_resident.end()) { dropped.push_back(std::move(it->second)); it->second = std::move(r); return; }
+  if ((g_res_tick & 63u) == 0 || g_resident.size() >= kMaxResident) {   // every so often: entries nobody came for
+    const auto limit = r.born - std::chrono::milliseconds(g_resident.size() >= kMaxResident ? 0 : kResidentTtlMs);
+    for (auto e = g_resident.begin(); e != g_resident.end();)
+      if (e->second.born <= limit) { dropped.push_back(std::move(e->second)); e = g_resident.erase(e); } else ++e;
+  }
+  const void* key = r.host;
+  g_resident.emplace(key, std::move(r));
 }
 
 // a host plane that was just filled from a plane of `buffer` (w x h samples of `bits`, on the current device): a transform's result or the grid canvas
@@ -1331,10 +1357,10 @@ bool resident_find(const void* host, size_t stride, int w, int h, int bits, cons
   ResidentPlane r;
   {
     std::lock_guard<std::mutex> lock(g_res_mu);
-    bool hit = false;
-    for (size_t i = 0; i < g_resident.size(); i++)
-      if (g_resident[i].host == host) { r = std::move(g_resident[i]); g_resident.erase(g_resident.begin() + (long)i); hit = true; break; }
-    if (!hit) return false;
+    auto it = g_resident.find(host);
+    if (it == g_resident.end()) return false;
+    r = std::move(it->second);
+    g_resident.erase(it);
   }
   if (r.host_stride != stride || r.w != w || r.h != h || r.bits != bits) return false;
   if (r.batch && (r.batch->retired || !r.batch->arena)) return false;
@@ -1361,7 +1387,7 @@ void hipdec_set_plane_tracking(int on) { g_track_planes.store(on != 0, std::memo
 
 void hipdec_forget_resident_planes(void)
 {
-  std::vector<ResidentPlane> drop;
+  std::unordered_map<const void*, ResidentPlane> drop;
   {
     std::lock_guard<std::mutex> lock(g_res_mu);
     drop.swap(g_resident);
@@ -1450,7 +1476,7 @@ int hipdec_color_convert(const hipdec_color_image* in, const hipdec_nclx* nclx, 
     int bits = in->bit_depth;
     size_t es = bits > 8 ? 2 : 1;
     const size_t out_bpp = out_chroma == 10 ? 3 : (out_chroma == 11 ? 4 : 6);
-    hipStream_t s = stream_acquire();
+    hipStream_t s = stream_acquire_priority();
     struct Release { hipStream_t s; std::vector<std::pair<void*, size_t>> bufs;
                      ~Release() { (void)hipStreamSynchronize(s); for (auto& b : bufs) arena_release(b.first, b.second); stream_release(s); } } rel{s, {}};
     auto scratch = [&](size_t bytes, uint8_t** p) -> int {
@@ -1463,17 +1489,21 @@ int hipdec_color_convert(const hipdec_color_image* in, const hipdec_nclx* nclx, 
     const uint8_t* dp[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t ds[4] = {0, 0, 0, 0};
     std::shared_ptr<void> keep[4];
+    const auto t_find = Clock::now();
+    if (g_ops_timing.on) g_ops_timing.calls++;
     for (int c = 0; c < 4; c++) {
       if (!in->plane[c]) continue;
       const int pw = (c == 0 || c == 3) ? w : cw, ph = (c == 0 || c == 3) ? h : ch;
       if (in->on_device) { dp[c] = (const uint8_t*)in->plane[c]; ds[c] = in->stride[c]; continue; }
-      if (resident_find(in->plane[c], in->stride[c], pw, ph, bits, &dp[c], &ds[c], keep[c])) { g_cb_resident++; continue; }
+      if (resident_find(in->plane[c], in->stride[c], pw, ph, bits, &dp[c], &ds[c], keep[c])) { g_cb_resident++; if (g_ops_timing.on) g_ops_timing.hits++; continue; }
+      if (g_ops_timing.on) g_ops_timing.misses++;
       uint8_t* d = nullptr;
       const size_t st = ((size_t)pw * es + 255) & ~(size_t)255;
       if (int rc = scratch(st * ph, &d)) return rc;
       HIPDEC_CHECK_HIP(hipMemcpy2DAsync(d, st, in->plane[c], in->stride[c], (size_t)pw * es, ph, hipMemcpyHostToDevice, s));
       dp[c] = d; ds[c] = st;
     }
+    if (g_ops_timing.on) g_ops_timing.find_us += us_since(t_find);
     // ---- the chain
     int chroma = in->chroma, k = 0;
     if (k < n_ops && ops[k] == HIPDEC_OP_TO_SDR) {                     // a14 on every plane
@@ -1603,7 +1633,7 @@ int hipdec_image_transform(const hipdec_color_image* in, int op, const int* args
     if (needs_444) return set_error(HIPDEC_ERR_UNSUPPORTED, "image_transform: odd size / offset of a subsampled image (the reference converts to 4:4:4 first or treats the half-covered chroma edge itself): host path");
     const size_t es = in->bit_depth > 8 ? 2 : 1;
     const int sx = (chroma == 1 || chroma == 2) ? 2 : 1, sy = chroma == 1 ? 2 : 1;
-    hipStream_t s = stream_acquire();
+    hipStream_t s = stream_acquire_priority();
     struct Release { hipStream_t s; std::vector<std::pair<void*, size_t>> bufs;
                      ~Release() { (void)hipStreamSynchronize(s); for (auto& b : bufs) arena_release(b.first, b.second); stream_release(s); } } rel{s, {}};
     auto scratch = [&](size_t bytes, uint8_t** p) -> int {

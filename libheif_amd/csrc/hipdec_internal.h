@@ -46,6 +46,7 @@ void status_slot_release(int32_t* p);
 // A small pool of HIP streams: concurrent plugin decoder instances (libheif decodes grid tiles on several threads,
 // libheif/image-items/grid.cc:436) each run on their own stream so that their kernels overlap on the GPU.
 hipStream_t stream_acquire();
+hipStream_t stream_acquire_priority();   // for image-level calls beside the decoder's launch sets (released with stream_release)
 void stream_release(hipStream_t s);
 
 // the stream follow-up work of a batch goes on (made to wait for the batch's last recorded work when that ran elsewhere: decoder.hip follow_stream)

@@ -282,9 +282,45 @@ hipStream_t stream_acquire()
   return s;
 }
 
+// Streams of the image-level calls (colour conversion, transformations): created with the device's highest priority.  HIP multiplexes its
+// streams onto a few hardware queues, in order within a queue: a conversion on an ordinary stream shares a queue with some launch set's CABAC
+// kernel and waits for it to end (measured through libheif, 256 threads: 218 ms per conversion); priority streams live on queues of their own,
+// and the command processor serves them first.
+namespace {
+std::vector<std::pair<hipStream_t, int>> g_free_prio_streams;
+std::vector<hipStream_t> g_all_prio_streams;
+}  // namespace
+
+hipStream_t stream_acquire_priority()
+{
+  const int dev = active_device();
+  {
+    std::lock_guard<std::mutex> lock(g_stream_mu);
+    for (size_t i = g_free_prio_streams.size(); i-- > 0;)
+      if (g_free_prio_streams[i].second == dev) { hipStream_t s = g_free_prio_streams[i].first; g_free_prio_streams.erase(g_free_prio_streams.begin() + (long)i); return s; }
+  }
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) != hipSuccess) { (void)hipGetLastError(); return stream_acquire(); }
+  std::lock_guard<std::mutex> lock(g_stream_mu);
+  g_all_prio_streams.push_back(s);
+  return s;
+}
+
 void stream_release(hipStream_t s)
 {
   if (!s) return;
+  {
+    std::lock_guard<std::mutex> lock(g_stream_mu);
+    for (hipStream_t p : g_all_prio_streams)
+      if (p == s) {
+        if (g_free_prio_streams.size() < 256) { g_free_prio_streams.emplace_back(s, active_device()); return; }
+        g_all_prio_streams.erase(std::find(g_all_prio_streams.begin(), g_all_prio_streams.end(), s));
+        (void)hipStreamDestroy(s);
+        return;
+      }
+  }
   for (const auto& d : g_streams) if (s == d.stream || s == d.upload || s == d.post) return;
   std::lock_guard<std::mutex> lock(g_stream_mu);
   if (g_free_streams.size() < 64) g_free_streams.emplace_back(s, active_device()); else (void)hipStreamDestroy(s);
@@ -347,6 +383,8 @@ void hipdec_shutdown(void)
     std::lock_guard<std::mutex> lock(g_stream_mu);
     for (auto& st : g_free_streams) (void)hipStreamDestroy(st.first);
     g_free_streams.clear();
+    for (auto& st : g_free_prio_streams) (void)hipStreamDestroy(st.first);
+    g_free_prio_streams.clear(); g_all_prio_streams.clear();
   }
   {
     std::lock_guard<std::mutex> lock(g_streams_mu);
