@@ -27,7 +27,12 @@ struct StRps {
 
 // A decoded picture a later P picture may reference: device pointers of its planes (coded size, deblocked, SAO applied), strides in bytes
 // mf: its motion field on the device (0: an intra picture) - the collocated picture of temporal candidates (8.5.3.2.8)
-struct RefPicture { int poc = 0; uint64_t plane[3] = {0, 0, 0}; uint32_t stride[3] = {0, 0, 0}; uint64_t mf = 0; };
+// width .. log2_ctb: the format it was decoded in - a picture only predicts from pictures of its own format (a parameter set change without an IDR
+// picture in between is refused: the kernels address references with the current picture's geometry)
+struct RefPicture {
+  int poc = 0; uint64_t plane[3] = {0, 0, 0}; uint32_t stride[3] = {0, 0, 0}; uint64_t mf = 0;
+  int width = 0, height = 0, chroma_format_idc = 0, bit_depth_luma = 0, bit_depth_chroma = 0, log2_ctb = 0;
+};
 
 // What a decoder instance keeps between the samples of a sequence track (libheif/sequences/track_visual.cc:200-280 pushes them one by one):
 // the picture order count state (8.3.1) and the decoded picture buffer.  nullptr where a single still is decoded: P slices are refused then.

@@ -753,7 +753,14 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
     if (out.is_inter) {   // the picture's reference table: every picture some P / B slice lists, once; SliceParams::ref_slot(_l1) index it
       auto slot_of = [&](int poc) -> int {
         for (size_t k = 0; k < out.refs.size(); k++) if (out.refs[k].poc == poc) return (int)k;
-        for (const RefPicture& rp : seq->dpb) if (rp.poc == poc) { out.refs.push_back(rp); return (int)out.refs.size() - 1; }
+        for (const RefPicture& rp : seq->dpb)
+          if (rp.poc == poc) {
+            if (rp.width != out.sps.pic_width || rp.height != out.sps.pic_height || rp.chroma_format_idc != out.sps.chroma_format_idc ||
+                rp.bit_depth_luma != out.sps.bit_depth_luma || rp.bit_depth_chroma != out.sps.bit_depth_chroma || rp.log2_ctb != out.sps.log2_ctb)
+              bad("reference picture with POC " + std::to_string(poc) + " was decoded in another format (parameter sets changed without an IDR picture)");
+            out.refs.push_back(rp);
+            return (int)out.refs.size() - 1;
+          }
         return -1;
       };
       for (ParsedSlice& sl : out.slices) {

@@ -79,6 +79,8 @@ int emu_seq_commit(EmuSeq* q, EmuBatch* b)
   uint8_t* a = b->arena.data();
   RefPicture rp;
   rp.poc = pp.poc;
+  rp.width = P.width; rp.height = P.height; rp.chroma_format_idc = P.chroma_format_idc; rp.bit_depth_luma = P.bit_depth_luma; rp.bit_depth_chroma = P.bit_depth_chroma;
+  rp.log2_ctb = P.log2_ctb;
   const bool cropped = P.out_width != P.width || P.out_height != P.height || P.crop_x || P.crop_y;
   if (!cropped) {
     for (int c = 0; c < 3; c++) { rp.plane[c] = (uint64_t)(uintptr_t)(a + P.off_out[c]); rp.stride[c] = P.out_stride[c]; }

@@ -26,3 +26,15 @@ def test_committed_bench_line_has_every_contract_field():
     # round 3: the run checks a result against the CPU oracle and reports the SURVEY 8(d) from-host form as a first-class key
     assert d["verified"]["planes_match"] is True and d["verified"]["rgb_match"] is True
     assert d["value_from_host_bytes"] > 0 and d["single_still"]["ms"] > 0
+    if os.path.basename(files[-1]) >= "r04":
+        # round 4: `value` is the from-host-bytes number of SURVEY 8(d) (the resident form beside it), >= 32 stills spread over the batch are verified,
+        # the scalar-issue roofline of the CABAC kernel stands beside the HBM one, BASELINE's other configurations and the batch curve are in the line
+        assert d["value_resident"] >= d["value"] > 0 and abs(d["value"] - d["value_from_host_bytes"]) / d["value"] < 1e-6
+        assert d["verified"]["count"] >= 32 and len(set(d["verified"]["stills"])) == d["verified"]["count"] and d["verified"]["mismatching_stills"] == []
+        assert max(d["verified"]["stills"]) - min(d["verified"]["stills"]) > d["verified"]["of"] // 2
+        assert 0 < d["issue_roofline"]["kernels"]["parse"]["frac_of_scalar_issue_peak"] <= 1.0
+        assert [p["stills"] for p in d["batch_curve"]] == sorted(p["stills"] for p in d["batch_curve"]) and len(d["batch_curve"]) >= 5
+        for k in ("config2_single_4k_still_fused_rgb", "config3_8k_grid_48_tiles_one_gpu", "config4_main10_4k_pq_to_linear_rgb", "config5_1024_x_1080p"):
+            assert d["baseline_configs"][k]["mpixel_s"] > 0, k
+        g = d["grid_sharded"]
+        assert g["wpp"]["one_gpu_ms"] > 0 and g["wpp"]["rccl"]["canvas_matches_one_gpu"] is True and g["wpp"]["rccl"]["ranks"] == d["n_gpus"]

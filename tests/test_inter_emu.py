@@ -145,3 +145,21 @@ def test_emulated_b_monochrome_and_cropped():
     check_sequence(orc.encode_sequence(frames, qp=22, inter_num_refs=2, b_frames=1, temporal_mvp=1, weighted_pred=1), "mono")
     frames = make_frames(70, 42, 6)        # coded 72 x 48: references and collocated motion cover the rows below the conformance window
     check_sequence(orc.encode_sequence(frames, qp=22, global_mv_x=3, global_mv_y=17, inter_num_refs=2, amp=1, b_frames=2, b_ref=1, temporal_mvp=1), "cropped")
+
+
+def test_reference_of_another_format_is_refused_by_the_host():
+    """parameter sets that change without an IDR picture: a P picture whose reference was decoded at another size must not reach the kernels (they address
+    references with the current picture's geometry)"""
+    L = _lib()
+    a = orc.encode_sequence(make_frames(136, 104, 2), qp=26)
+    b = orc.encode_sequence(make_frames(72, 56, 2), qp=26)
+    q = C.c_void_p(L.emu_seq_new())
+    try:
+        err = C.create_string_buffer(512)
+        pic = C.c_void_p(L.emu_seq_create_picture(q, a[0], len(a[0]), err, 512))
+        assert pic and L.emu_run_parse(pic) == 0 and L.emu_run_pipeline(pic, 15) == 0 and L.emu_seq_commit(q, pic) == 0
+        au = parameter_sets(b[0]) + b[1]                      # the other stream's parameter sets in front of its P picture: POC 1 references POC 0
+        assert not L.emu_seq_create_picture(q, au, len(au), err, 512)
+        assert b"another format" in err.value
+    finally:
+        L.emu_seq_free(q)

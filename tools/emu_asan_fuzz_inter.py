@@ -59,10 +59,12 @@ rng = random.Random(int(sys.argv[1]))
 n = int(sys.argv[2])
 cfgs = [dict(), dict(amp=1, inter_num_refs=2), dict(inter_num_refs=3, lists_modification=1, max_merge_cand=3), dict(wpp=0, tile_cols=2, tile_rows=2),
         dict(num_slices=3, parallel_merge_level=4), dict(bit_depth=10, amp=1), dict(lossless_pct=20, transform_skip=1, log2_ctb=5),
-        dict(pcm_pct=10, inter_intra_pct=40, cu_qp_delta=1), dict(dependent_segments=3, num_slices=2, wpp=0)]
+        dict(pcm_pct=10, inter_intra_pct=40, cu_qp_delta=1), dict(dependent_segments=3, num_slices=2, wpp=0),
+        dict(b_frames=1, temporal_mvp=1), dict(b_frames=2, b_ref=1, temporal_mvp=1, weighted_pred=1, inter_num_refs=2, mvd_l1_zero=1),
+        dict(temporal_mvp=1, weighted_pred=1, inter_num_refs=3), dict(b_frames=1, weighted_pred=1, lists_modification=1, num_slices=2, amp=1)]
 base = []
 for i, c in enumerate(cfgs):
-    frames = make_frames(104, 72, 3, c.get('bit_depth', 8))
+    frames = make_frames(104, 72, 4 if c.get('b_frames') else 3, c.get('bit_depth', 8))
     base.append(orc.encode_sequence(frames, qp=26, global_mv_x=-6, global_mv_y=4, seed=11 + i, **c))
 print('clean:', [run(a) for a in base]); sys.stdout.flush()
 res = {}
