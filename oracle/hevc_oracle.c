@@ -408,7 +408,7 @@ struct Dec {
   int16_t* mf_mv; int8_t* mf_ref; int32_t* mf_poc;   /* per 4x4 unit: mvL0, mvL1 (4 values), refIdxL0 / L1 (-1: list not used) and the POCs of
                                                         those reference pictures */
   int cu_pred_inter;             /* CuPredMode of the coding unit being decoded != MODE_INTRA */
-  int seq_mode;                  /* hevc_oracle_seq: several pictures, P slices allowed */
+  int seq_mode;                  /* hevc_oracle_seq: several pictures, P / B slices allowed */
 };
 
 static void fail(Dec* d, const char* fmt, ...)
@@ -901,7 +901,6 @@ static int available_z(Dec* d, int xCurr, int yCurr, int xNbY, int yNbY)
 static void cabac_init_contexts(Dec* d)
 {
   int qp = Clip3(0, 51, d->sh->SliceQpY);
-  /* 9.3.2.2: initType 0 for I slices; P slices: cabac_init_flag ? 2 : 1 */
   /* 9.3.2.2: initType 0 for I, 1 for P and 2 for B slices; cabac_init_flag swaps the latter two */
   const uint8_t* tab = d->sh->slice_type == 2 ? hevc_cabac_init_I
                      : hevc_cabac_init_P[(d->sh->slice_type == 1) == (d->sh->cabac_init_flag != 0) ? 1 : 0];
@@ -1742,7 +1741,7 @@ static void coding_unit(Dec* d, int x0, int y0, int log2CbSize, int cqtDepth)
   d->cu_transquant_bypass_flag = 0;
   d->cu_pred_inter = 0;
   if (p->transquant_bypass_enabled_flag) d->cu_transquant_bypass_flag = decode_decision(d, CTX_CU_TQ_BYPASS);
-  if (d->sh->slice_type != 2) {   /* 7.3.8.5 in a P slice: cu_skip_flag, pred_mode_flag */
+  if (d->sh->slice_type != 2) {   /* 7.3.8.5 in a P / B slice: cu_skip_flag, pred_mode_flag */
     int ctxInc = 0;   /* 9.3.4.2.2: the left / above neighbours' cu_skip_flag */
     if (available_z(d, x0, y0, x0 - 1, y0) && d->m_pred[(y0 >> 2) * d->mw + ((x0 - 1) >> 2)] == 2) ctxInc++;
     if (available_z(d, x0, y0, x0, y0 - 1) && d->m_pred[((y0 - 1) >> 2) * d->mw + (x0 >> 2)] == 2) ctxInc++;

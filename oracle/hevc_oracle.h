@@ -78,7 +78,7 @@ void hevc_oracle_free_picture(hevc_oracle_picture* pic);
 
 /* A sequence of pictures: one access unit per call, in decoding order, the way libheif pushes the samples of a track
  * (libheif/sequences/track_visual.cc:200-280); parameter sets, the POC state and the decoded picture buffer persist between calls.
- * P slices are decoded (scope: oracle/hevc_oracle_inter.c); every picture is output at once (decoding order). */
+ * P and B slices are decoded (scope: oracle/hevc_oracle_inter.c); every picture is returned at once, i.e. in DECODING order, with its POC. */
 typedef struct hevc_oracle_seq hevc_oracle_seq;
 hevc_oracle_seq* hevc_oracle_seq_new(void);
 int hevc_oracle_seq_decode(hevc_oracle_seq* q, const uint8_t* data, size_t size, int keep_taps, hevc_oracle_picture* out,

@@ -773,7 +773,7 @@ static void enc_coding_unit(Enc* e, int x0, int y0, int log2CbSize, int cqtDepth
     EV_D(CTX_CU_TQ_BYPASS, d->cu_transquant_bypass_flag);
   }
   d->cu_pred_inter = 0;
-  if (d->sh->slice_type != 2) {   /* P slice: cu_skip_flag, pred_mode_flag (7.3.8.5) */
+  if (d->sh->slice_type != 2) {   /* P / B slice: cu_skip_flag, pred_mode_flag (7.3.8.5) */
     int ctxInc = 0;
     if (available_z(d, x0, y0, x0 - 1, y0) && d->m_pred[(y0 >> 2) * d->mw + ((x0 - 1) >> 2)] == 2) ctxInc++;
     if (available_z(d, x0, y0, x0, y0 - 1) && d->m_pred[((y0 - 1) >> 2) * d->mw + (x0 >> 2)] == 2) ctxInc++;
@@ -1544,7 +1544,7 @@ static int enc_run(const hevc_testenc_params* prm, int n_frames, const uint16_t*
     free_dec(d);
     return -1;
   }
-  if (seq_mode && (prm->chroma_format_idc > 1 || prm->scaling_list)) fail(d, "sequences with P pictures: 4:0:0 / 4:2:0 without scaling lists only");
+  if (seq_mode && (prm->chroma_format_idc > 1 || prm->scaling_list)) fail(d, "sequences with P / B pictures: 4:0:0 / 4:2:0 without scaling lists only");
   enc_parameter_sets(e, &stream);
   /* ---- coding order: frame 0 an IDR picture; with b_frames = b every (b + 1)-th picture is a P picture (an "anchor") and the b pictures
      before it are B pictures coded after it; the pictures behind the last anchor are P pictures.  A picture's own references: the anchors

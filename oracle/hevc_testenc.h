@@ -1,4 +1,4 @@
-/* hevc_testenc.h — test-only HEVC stream generator: intra pictures, and sequences with P pictures (see hevc_testenc.c). */
+/* hevc_testenc.h — test-only HEVC stream generator: intra pictures, and sequences with P and B pictures (see hevc_testenc.c). */
 #ifndef HEVC_TESTENC_H
 #define HEVC_TESTENC_H
 #include <stddef.h>
@@ -26,8 +26,8 @@ typedef struct hevc_testenc_params {
   int stress;                   /* 1: random splits / modes (syntax coverage); 0: SAD-driven       */
   int zero_residual_pct;        /* % of transform blocks forced to cbf = 0                         */
   int dependent_segments;       /* > 1: every slice is split into that many slice segments, all but its first dependent */
-  /* ---- sequences (hevc_testenc_encode_seq): frame 0 is an IDR intra picture, the others are P pictures (TRAIL_R) ---- */
-  int inter_num_refs;           /* reference pictures a P picture may use (the previous ones; 0 = 1)                      */
+  /* ---- sequences (hevc_testenc_encode_seq): frame 0 is an IDR intra picture, the others are P pictures (TRAIL_R) - or, with b_frames, B pictures between P anchors ---- */
+  int inter_num_refs;           /* reference pictures a picture may use before it (the previous anchors; 0 = 1)           */
   int inter_skip_pct, inter_intra_pct, inter_merge_pct;   /* % of coding units skipped / intra coded, % of prediction units merged */
   int amp;                      /* asymmetric motion partitions                                                            */
   int max_merge_cand;           /* MaxNumMergeCand 1..5 (0 = 5)                                                            */

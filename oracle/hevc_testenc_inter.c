@@ -1,7 +1,7 @@
 /*
- * hevc_testenc_inter.c — TEST-ONLY stream generator, P pictures (#included by hevc_testenc.c; see there).
+ * hevc_testenc_inter.c — TEST-ONLY stream generator, P and B pictures (#included by hevc_testenc.c; see there).
  *
- * Emits the syntax a P slice adds (7.3.8.5 cu_skip_flag / pred_mode_flag / inter part_mode, 7.3.8.6 prediction_unit, 7.3.8.9 mvd_coding,
+ * Emits the syntax a P / B slice adds (7.3.8.5 cu_skip_flag / pred_mode_flag / inter part_mode, 7.3.8.6 prediction_unit incl. inter_pred_idc and list 1, 7.3.8.9 mvd_coding,
  * rqt_root_cbf) with pseudo-random decisions, while driving the oracle's own state machine (hevc_oracle_inter.c: candidate derivation,
  * interpolation, motion field) so that the residual it codes is the difference to exactly the prediction a decoder will form.
  * The syntax side is independent of the oracle's parser; lossless (cu_transquant_bypass) sequences make decoded == source a hard check.
@@ -46,7 +46,7 @@ static void enc_part_mode_inter(Enc* e, int log2CbSize, int PartMode)
   if (!symmetric) EV_B(PartMode == PART_2NxnD || PartMode == PART_nRx2N);
 }
 
-/* a coding unit of a P slice that is not intra coded; ev_skip / ev_pred: the events of its cu_skip_flag / pred_mode_flag */
+/* a coding unit of a P / B slice that is not intra coded; ev_skip / ev_pred: the events of its cu_skip_flag / pred_mode_flag */
 static void enc_inter_coding_unit(Enc* e, CuCtx* cu, int x0, int y0, int log2CbSize, int cqtDepth, int cu_skip, int ev_skip, int ev_pred)
 {
   Dec* d = e->d; const SPS* s = d->s;
