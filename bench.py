@@ -211,8 +211,8 @@ def issue_roofline(kernels, px, cu_count, clock_ghz):
     except Exception:
         return None
     peak = cu_count * clock_ghz            # G scalar instructions / s
-    out = {"peak_ginst_s": round(peak, 1), "peak_is": "%d CUs x %.2f GHz x 1 SALU instruction per cycle and CU; the vector pipes have the same ceiling for "
-                                                   "wave64 instructions (4 SIMDs per CU, one VALU instruction per 4 cycles each)" % (cu_count, clock_ghz),
+    out = {"peak_ginst_s": round(peak, 1), "peak_is": "%d CUs x %.2f GHz x 1 SALU instruction per cycle and CU; the vector pipes take twice that in wave64 "
+                                                   "instructions (4 SIMD-32 units per CU, 2 cycles per wave64 VALU instruction)" % (cu_count, clock_ghz),
            "source": rec.get("source"), "commit": rec.get("commit"), "kernels": {}}
     for key, name in (("parse", "k_parse"), ("recon", "k_recon")):
         if key in kernels and name in rec.get("insts_per_px", {}) and kernels[key]["avg_us"] > 0:
@@ -220,7 +220,7 @@ def issue_roofline(kernels, px, cu_count, clock_ghz):
             ach = ipp["salu"] * px / (kernels[key]["avg_us"] * 1e-6) / 1e9
             out["kernels"][key] = {"kernel": kernels[key]["kernel"], "salu_per_px": ipp["salu"], "valu_per_px": ipp["valu"], "branch_per_px": ipp.get("branch"),
                                    "achieved_ginst_s": round(ach, 1), "frac_of_scalar_issue_peak": round(ach / peak, 4),
-                                   "frac_of_vector_issue_peak": round(ach / peak * ipp["valu"] / ipp["salu"], 4)}
+                                   "frac_of_vector_issue_peak": round(ach / peak * ipp["valu"] / ipp["salu"] / 2.0, 4)}
     return out
 
 

@@ -13,7 +13,8 @@
 //     above, above-left and above-RIGHT neighbours, so the parallelism is the 2-CTB-lag wavefront over CTB rows - one wave per CTB row, rows
 //     handed out by ticket so that a row's predecessor is resident or finished, progress published per CTB (release) and awaited (acquire).
 //     Inside a CTB the derivation is a serial chain over prediction units (lane 0); the 64 lanes write each unit's motion to its 4x4 units.
-//     The CTB being derived lives in LDS (2 KB); finished CTBs are read from the motion field in HBM (8 B per unit, 0.5 B per pixel).
+//     Everything the chain reads is staged in LDS by all lanes first (14 KB): the CTB being derived and the one to its left, the bottom unit rows of
+//     the three CTBs above, the CTB's syntax records and unit maps; only the collocated picture's units (temporal candidates) come from HBM.
 //   * k_mc is embarrassingly parallel once the motion field exists: one thread per sample of each plane, taps gathered from the reference
 //     picture (coordinates clamped to the picture: the padding of 8.5.3.3.3.1), separable 8-tap (luma) / 4-tap (chroma) filters with the
 //     intermediate precision of the specification, written to the reconstruction plane where k_recon adds the residual.  HBM-bound in
@@ -48,7 +49,43 @@ __device__ __forceinline__ void mk_lds_sync()
   __builtin_amdgcn_wave_barrier();
 }
 
-struct Mo { int mv[2][2]; int ref_idx[2]; };   // [list][x, y]; ref_idx < 0: the list is not used
+// Motion of a prediction block while it is being derived.  Plain scalars and select-based accessors on purpose: the derivation runs on ONE lane, and
+// any array indexed with a run-time value (candidate lists, [list] members) is placed in scratch memory by the compiler - a global-memory round trip
+// per access for a lone lane (the first version spent 11.5 ms on a 720p picture that way).  This version uses no scratch.
+struct Mo { int x0, y0, x1, y1, r0, r1; };   // list 0 / list 1 vector (quarter samples) and reference index (< 0: the list is not used)
+__device__ __forceinline__ Mo mo_none() { return Mo{0, 0, 0, 0, -1, -1}; }
+__device__ __forceinline__ int mo_ref(const Mo& m, int L) { return L ? m.r1 : m.r0; }
+__device__ __forceinline__ void mo_set(Mo& m, int L, int x, int y, int r) { if (L) { m.x1 = x; m.y1 = y; m.r1 = r; } else { m.x0 = x; m.y0 = y; m.r0 = r; } }
+__device__ __forceinline__ Mo mo_pick(int i, const Mo& a, const Mo& b, const Mo& c, const Mo& d, const Mo& e, const Mo& f)
+{
+  Mo r = a;
+  if (i == 1) r = b;
+  if (i == 2) r = c;
+  if (i == 3) r = d;
+  if (i == 4) r = e;
+  if (i == 5) r = f;
+  return r;
+}
+// the i-th candidate that is present, in list order (the lists are never stored: a run-time index into one would put it in scratch)
+__device__ __forceinline__ Mo nth_present(int i, int f0, const Mo& m0, int f1, const Mo& m1, int f2, const Mo& m2, int f3, const Mo& m3, int f4, const Mo& m4,
+                                          int f5, const Mo& m5)
+{
+  Mo r = mo_none();
+  int c = 0;
+  if (f0) { if (c == i) r = m0; c++; }
+  if (f1) { if (c == i) r = m1; c++; }
+  if (f2) { if (c == i) r = m2; c++; }
+  if (f3) { if (c == i) r = m3; c++; }
+  if (f4) { if (c == i) r = m4; c++; }
+  if (f5) { if (c == i) r = m5; c++; }
+  return r;
+}
+// [list] members of a stored unit without run-time indexing
+__device__ __forceinline__ int unit_ref(const MotionUnit& u, int L) { return L ? u.ref_idx[1] : u.ref_idx[0]; }
+__device__ __forceinline__ int unit_slot(const MotionUnit& u, int L) { return (int)((L ? u.slot_pred[1] : u.slot_pred[0]) & 63u); }
+__device__ __forceinline__ int unit_mvx(const MotionUnit& u, int L) { return L ? u.mv[1][0] : u.mv[0][0]; }
+__device__ __forceinline__ int unit_mvy(const MotionUnit& u, int L) { return L ? u.mv[1][1] : u.mv[0][1]; }
+__device__ __forceinline__ int unit_poc_delta(const MotionUnit& u, int L) { return L ? u.poc_delta[1] : u.poc_delta[0]; }
 
 // everything the derivation of one CTB needs (lane 0 only)
 struct MotionCtx {
@@ -57,6 +94,8 @@ struct MotionCtx {
   const SliceParams* slice;
   const MotionUnit* field;      // the picture's motion field in HBM
   const MotionUnit* cur;        // the current CTB's units (LDS)
+  const MotionUnit* left;       // the CTB to the left, as it was derived a moment ago (LDS)
+  const MotionUnit* up;         // bottom unit rows of the CTBs above-left, above and above-right (LDS): [3][units per CTB side]
   const MotionUnit* col;        // the collocated picture's motion field (nullptr: no temporal candidates / an intra picture)
   int cx, cy, avail;            // CTB position, AV_* bits
   int log2_ctb, units_log2, lmt, ctb_w, width, height;
@@ -72,12 +111,16 @@ __device__ __forceinline__ size_t unit_index(const MotionCtx& C, int x, int y)
   return ((size_t)((y >> C.log2_ctb) * C.ctb_w + (x >> C.log2_ctb)) << C.units_log2) + z;
 }
 
-// the motion of the 4x4 unit that covers luma sample (x, y); the caller has checked availability
+// the motion of the 4x4 unit that covers luma sample (x, y); the caller has checked availability.  Every spatial neighbour a candidate list can
+// name lies in the current CTB, in the CTB to the left, or in the bottom unit row of the three CTBs above: all of them are in LDS
 __device__ __forceinline__ MotionUnit unit_at(const MotionCtx& C, int x, int y)
 {
-  const int ncx = x >> C.log2_ctb, ncy = y >> C.log2_ctb;
-  if (ncx == C.cx && ncy == C.cy)
-    return C.cur[mk_interleave((uint32_t)((x >> 2) & ((1 << (C.log2_ctb - 2)) - 1)), (uint32_t)((y >> 2) & ((1 << (C.log2_ctb - 2)) - 1)))];
+  const int ncx = x >> C.log2_ctb, ncy = y >> C.log2_ctb, side = 1 << (C.log2_ctb - 2);
+  const uint32_t ux = (uint32_t)((x >> 2) & (side - 1)), uy = (uint32_t)((y >> 2) & (side - 1));
+  if (ncy == C.cy) {
+    if (ncx == C.cx) return C.cur[mk_interleave(ux, uy)];
+    if (ncx == C.cx - 1) return C.left[mk_interleave(ux, uy)];
+  } else if (ncy == C.cy - 1 && (int)uy == side - 1 && ncx >= C.cx - 1 && ncx <= C.cx + 1) return C.up[(ncx - C.cx + 1) * side + (int)ux];
   return C.field[unit_index(C, x, y)];
 }
 
@@ -122,26 +165,20 @@ __device__ __forceinline__ int same_motion(const MotionUnit& a, const MotionUnit
   return a.mv[0][0] == b.mv[0][0] && a.mv[0][1] == b.mv[0][1] && a.mv[1][0] == b.mv[1][0] && a.mv[1][1] == b.mv[1][1] &&
          a.ref_idx[0] == b.ref_idx[0] && a.ref_idx[1] == b.ref_idx[1];
 }
-__device__ __forceinline__ Mo to_mo(const MotionUnit& u)
-{
-  Mo m;
-  for (int X = 0; X < 2; X++) { m.mv[X][0] = u.mv[X][0]; m.mv[X][1] = u.mv[X][1]; m.ref_idx[X] = u.ref_idx[X]; }
-  return m;
-}
+__device__ __forceinline__ Mo to_mo(const MotionUnit& u) { return Mo{u.mv[0][0], u.mv[0][1], u.mv[1][0], u.mv[1][1], u.ref_idx[0], u.ref_idx[1]}; }
 
-__device__ __forceinline__ void scale_mv(int* mv, int td, int tb)
+__device__ __forceinline__ void scale_mv(int& mvx, int& mvy, int td, int tb)
 {
   td = mk_clip3(-128, 127, td); tb = mk_clip3(-128, 127, tb);
   const int tx = (16384 + (mk_abs(td) >> 1)) / td;
   const int dsf = mk_clip3(-4096, 4095, (tb * tx + 32) >> 6);
-  for (int k = 0; k < 2; k++) {
-    const int v = dsf * mv[k];
-    mv[k] = mk_clip3(-32768, 32767, (v < 0 ? -1 : 1) * ((mk_abs(v) + 127) >> 8));
-  }
+  const int vx = dsf * mvx, vy = dsf * mvy;
+  mvx = mk_clip3(-32768, 32767, (vx < 0 ? -1 : 1) * ((mk_abs(vx) + 127) >> 8));
+  mvy = mk_clip3(-32768, 32767, (vy < 0 ? -1 : 1) * ((mk_abs(vy) + 127) >> 8));
 }
 
 // 8.5.3.2.9: the motion vector the collocated picture stored for the 16x16 block that covers (x, y), scaled to the distance of the target picture
-__device__ __forceinline__ int collocated_mv(const MotionCtx& C, int x, int y, int ref_idx, int X, int* mv_out)
+__device__ __forceinline__ int collocated_mv(const MotionCtx& C, int x, int y, int ref_idx, int X, int& mvx, int& mvy)
 {
   const MotionUnit cu = C.col[unit_index(C, (x >> 4) << 4, (y >> 4) << 4)];
   const int f0 = cu.ref_idx[0] >= 0, f1 = cu.ref_idx[1] >= 0;
@@ -150,23 +187,23 @@ __device__ __forceinline__ int collocated_mv(const MotionCtx& C, int x, int y, i
   if (!f0) L = 1;
   else if (!f1) L = 0;
   else L = C.slice->no_backward ? X : C.slice->col_from_l0;
-  int mv[2] = {cu.mv[L][0], cu.mv[L][1]};
-  const int col_diff = cu.poc_delta[L], cur_diff = C.poc - C.reftab[slot_of(C, X, ref_idx)].poc;
+  int vx = unit_mvx(cu, L), vy = unit_mvy(cu, L);
+  const int col_diff = unit_poc_delta(cu, L), cur_diff = C.poc - C.reftab[slot_of(C, X, ref_idx)].poc;
   if (col_diff != cur_diff) {
     if (col_diff == 0) return 0;
-    scale_mv(mv, col_diff, cur_diff);
+    scale_mv(vx, vy, col_diff, cur_diff);
   }
-  mv_out[0] = mv[0]; mv_out[1] = mv[1];
+  mvx = vx; mvy = vy;
   return 1;
 }
 
 // 8.5.3.2.8: the bottom-right candidate (inside the CTB row and the picture), then the centre
-__device__ __forceinline__ int temporal_mv(const MotionCtx& C, int xPb, int yPb, int nPbW, int nPbH, int ref_idx, int X, int* mv_out)
+__device__ __forceinline__ int temporal_mv(const MotionCtx& C, int xPb, int yPb, int nPbW, int nPbH, int ref_idx, int X, int& mvx, int& mvy)
 {
   if (!C.col) return 0;
   const int xBr = xPb + nPbW, yBr = yPb + nPbH;
-  if ((yPb >> C.log2_ctb) == (yBr >> C.log2_ctb) && yBr < C.height && xBr < C.width && collocated_mv(C, xBr, yBr, ref_idx, X, mv_out)) return 1;
-  return collocated_mv(C, xPb + (nPbW >> 1), yPb + (nPbH >> 1), ref_idx, X, mv_out);
+  if ((yPb >> C.log2_ctb) == (yBr >> C.log2_ctb) && yBr < C.height && xBr < C.width && collocated_mv(C, xBr, yBr, ref_idx, X, mvx, mvy)) return 1;
+  return collocated_mv(C, xPb + (nPbW >> 1), yPb + (nPbH >> 1), ref_idx, X, mvx, mvy);
 }
 
 // 8.5.3.2.2 - 8.5.3.2.5: merge candidate merge_idx (spatial candidates A1, B1, B0, A0, B2, the temporal candidate, combined bi-predictive candidates
@@ -179,129 +216,129 @@ __device__ __forceinline__ Mo derive_merge(const MotionCtx& C, PbGeom g, int par
   const int xPb = g.xPb, yPb = g.yPb, nPbW = g.nPbW, nPbH = g.nPbH;
   const int max_cand = C.slice->max_merge_cand, is_b = C.slice->is_b;
 #define MK_SAME_MER(xn, yn) ((xPb >> pl) == ((xn) >> pl) && (yPb >> pl) == ((yn) >> pl))
-  Mo cand[6];
-  int n = 0;
   MotionUnit A1{}, B1{}, B0{}, A0{}, B2{};
   // availableN: 6.4.2 minus the merge-estimation-region / second-partition exclusions; flagN: after pruning.  Comparisons read availableN of the other
   // candidate, not its flag; only B2's "all four present" rule counts flags (8.5.3.2.3)
   int avA1 = pb_available(C, g, xPb - 1, yPb + nPbH - 1, &A1);
   if (MK_SAME_MER(xPb - 1, yPb + nPbH - 1) || (g.partIdx == 1 && (part_mode == 2 || part_mode == 6 || part_mode == 7))) avA1 = 0;   // Nx2N, nLx2N, nRx2N
   const int fA1 = avA1;
-  if (fA1) cand[n++] = to_mo(A1);
   int avB1 = pb_available(C, g, xPb + nPbW - 1, yPb - 1, &B1);
   if (MK_SAME_MER(xPb + nPbW - 1, yPb - 1) || (g.partIdx == 1 && (part_mode == 1 || part_mode == 4 || part_mode == 5))) avB1 = 0;   // 2NxN, 2NxnU, 2NxnD
   const int fB1 = avB1 && !(avA1 && same_motion(A1, B1));
-  if (fB1) cand[n++] = to_mo(B1);
   int avB0 = pb_available(C, g, xPb + nPbW, yPb - 1, &B0);
   if (MK_SAME_MER(xPb + nPbW, yPb - 1)) avB0 = 0;
   const int fB0 = avB0 && !(avB1 && same_motion(B1, B0));
-  if (fB0) cand[n++] = to_mo(B0);
   int avA0 = pb_available(C, g, xPb - 1, yPb + nPbH, &A0);
   if (MK_SAME_MER(xPb - 1, yPb + nPbH)) avA0 = 0;
   const int fA0 = avA0 && !(avA1 && same_motion(A1, A0));
-  if (fA0) cand[n++] = to_mo(A0);
   int avB2 = pb_available(C, g, xPb - 1, yPb - 1, &B2);
   if (MK_SAME_MER(xPb - 1, yPb - 1)) avB2 = 0;
   const int fB2 = avB2 && !(avA1 && same_motion(A1, B2)) && !(avB1 && same_motion(B1, B2)) && fA0 + fA1 + fB0 + fB1 != 4;
-  if (fB2) cand[n++] = to_mo(B2);
 #undef MK_SAME_MER
+  const Mo mA1 = to_mo(A1), mB1 = to_mo(B1), mB0 = to_mo(B0), mA0 = to_mo(A0), mB2 = to_mo(B2);
+  int n = fA1 + fB1 + fB0 + fA0 + fB2;
+  Mo mCol = mo_none();
+  int fCol = 0;
   if (C.slice->tmvp && n <= merge_idx) {   // the temporal candidate: reference index 0 in each list of the slice (only needed when merge_idx reaches it)
-    Mo c;
-    for (int X = 0; X < 2; X++) { c.mv[X][0] = c.mv[X][1] = 0; c.ref_idx[X] = -1; }
-    for (int X = 0; X < (is_b ? 2 : 1); X++) if (temporal_mv(C, xPb, yPb, nPbW, nPbH, 0, X, c.mv[X])) c.ref_idx[X] = 0;
-    if (c.ref_idx[0] >= 0 || c.ref_idx[1] >= 0) cand[n++] = c;
+    int vx = 0, vy = 0;
+    if (temporal_mv(C, xPb, yPb, nPbW, nPbH, 0, 0, vx, vy)) mo_set(mCol, 0, vx, vy, 0);
+    if (is_b && temporal_mv(C, xPb, yPb, nPbW, nPbH, 0, 1, vx, vy)) mo_set(mCol, 1, vx, vy, 0);
+    fCol = mCol.r0 >= 0 || mCol.r1 >= 0;
+    n += fCol;
   }
   if (n > max_cand) n = max_cand;
-  if (is_b && n > 1 && n < max_cand && n <= merge_idx) {   // 8.5.3.2.4 combined bi-predictive candidates
-    const int num_orig = n;
-    for (int comb = 0; comb < num_orig * (num_orig - 1) && n < max_cand; comb++) {
-      // l0CandIdx / l1CandIdx of Table 8-7: (0,1) (1,0) (0,2) (2,0) (1,2) (2,1) (0,3) (3,0) (1,3) (3,1) (2,3) (3,2)
-      const int l0 = (int)((0x323130212010ull >> (4 * comb)) & 3u), l1 = (int)((0x231303120201ull >> (4 * comb)) & 3u);   // one nibble per combIdx
-      const Mo& a = cand[l0]; const Mo& b = cand[l1];
-      if (a.ref_idx[0] >= 0 && b.ref_idx[1] >= 0 &&
-          (slot_of(C, 0, a.ref_idx[0]) != slot_of(C, 1, b.ref_idx[1]) || a.mv[0][0] != b.mv[1][0] || a.mv[0][1] != b.mv[1][1])) {
-        Mo c;
-        c.ref_idx[0] = a.ref_idx[0]; c.mv[0][0] = a.mv[0][0]; c.mv[0][1] = a.mv[0][1];
-        c.ref_idx[1] = b.ref_idx[1]; c.mv[1][0] = b.mv[1][0]; c.mv[1][1] = b.mv[1][1];
-        cand[n++] = c;
+#define MK_ORIG(i) nth_present((i), fA1, mA1, fB1, mB1, fB0, mB0, fA0, mA0, fB2, mB2, fCol, mCol)
+  Mo out = mo_none();
+  if (merge_idx < n) out = MK_ORIG(merge_idx);
+  else {
+    int found = 0;
+    if (is_b && n > 1 && n < max_cand) {   // 8.5.3.2.4 combined bi-predictive candidates: walked in list order until merge_idx is reached
+      const int num_orig = n;
+      for (int comb = 0; comb < num_orig * (num_orig - 1) && n < max_cand && !found; comb++) {
+        // l0CandIdx / l1CandIdx of Table 8-7: (0,1) (1,0) (0,2) (2,0) (1,2) (2,1) (0,3) (3,0) (1,3) (3,1) (2,3) (3,2), one nibble per combIdx
+        const int l0 = (int)((0x323130212010ull >> (4 * comb)) & 3u), l1 = (int)((0x231303120201ull >> (4 * comb)) & 3u);
+        const Mo a = MK_ORIG(l0), b = MK_ORIG(l1);
+        if (a.r0 >= 0 && b.r1 >= 0 && (slot_of(C, 0, a.r0) != slot_of(C, 1, b.r1) || a.x0 != b.x1 || a.y0 != b.y1)) {
+          if (n == merge_idx) { out = Mo{a.x0, a.y0, b.x1, b.y1, a.r0, b.r1}; found = 1; }
+          n++;
+        }
       }
     }
+    if (!found) {   // zero candidates: the reference index counts up while below the number of reference pictures (B: of the shorter list), then 0
+      const int zero_idx = merge_idx - n;
+      const int num_ref = is_b ? (C.slice->num_ref_idx < C.slice->num_ref_idx_l1 ? C.slice->num_ref_idx : C.slice->num_ref_idx_l1) : C.slice->num_ref_idx;
+      const int r = zero_idx < num_ref ? zero_idx : 0;
+      out = Mo{0, 0, 0, 0, r, is_b ? r : -1};
+    }
   }
-  Mo out;
-  if (merge_idx < n) out = cand[merge_idx];
-  else {   // zero candidates: the reference index counts up while below the number of reference pictures (B: of the shorter list), then 0
-    const int zero_idx = merge_idx - n;
-    const int num_ref = is_b ? (C.slice->num_ref_idx < C.slice->num_ref_idx_l1 ? C.slice->num_ref_idx : C.slice->num_ref_idx_l1) : C.slice->num_ref_idx;
-    const int r = zero_idx < num_ref ? zero_idx : 0;
-    for (int X = 0; X < 2; X++) { out.mv[X][0] = out.mv[X][1] = 0; out.ref_idx[X] = -1; }
-    out.ref_idx[0] = r;
-    if (is_b) out.ref_idx[1] = r;
-  }
-  if (out.ref_idx[0] >= 0 && out.ref_idx[1] >= 0 && orig_w + orig_h == 12) { out.ref_idx[1] = -1; out.mv[1][0] = out.mv[1][1] = 0; }   // 8x4 / 4x8: uni-prediction
+#undef MK_ORIG
+  if (out.r0 >= 0 && out.r1 >= 0 && orig_w + orig_h == 12) { out.r1 = -1; out.x1 = out.y1 = 0; }   // 8x4 / 4x8: uni-prediction
   return out;
 }
 
 // the motion vector of neighbour m that points at the target picture (its own list X first, then the other list); 8.5.3.2.7
-__device__ __forceinline__ int nb_same_pic(const MotionCtx& C, const MotionUnit& m, int X, int tgt_slot, int* mv)
+__device__ __forceinline__ int nb_same_pic(const MotionUnit& m, int X, int tgt_slot, int& mvx, int& mvy)
 {
-  for (int k = 0; k < 2; k++) {
-    const int L = k ? 1 - X : X;
-    if (m.ref_idx[L] >= 0 && (int)(m.slot_pred[L] & 63u) == tgt_slot) { mv[0] = m.mv[L][0]; mv[1] = m.mv[L][1]; return 1; }
-  }
+  if (unit_ref(m, X) >= 0 && unit_slot(m, X) == tgt_slot) { mvx = unit_mvx(m, X); mvy = unit_mvy(m, X); return 1; }
+  if (unit_ref(m, 1 - X) >= 0 && unit_slot(m, 1 - X) == tgt_slot) { mvx = unit_mvx(m, 1 - X); mvy = unit_mvy(m, 1 - X); return 1; }
   return 0;
 }
-__device__ __forceinline__ int nb_scaled(const MotionCtx& C, const MotionUnit& m, int X, int tgt_slot, int* mv)
+__device__ __forceinline__ int nb_scaled(const MotionCtx& C, const MotionUnit& m, int X, int tgt_slot, int& mvx, int& mvy)
 {
-  for (int k = 0; k < 2; k++) {
-    const int L = k ? 1 - X : X;
-    if (m.ref_idx[L] >= 0) {
-      mv[0] = m.mv[L][0]; mv[1] = m.mv[L][1];
-      const int nb_slot = (int)(m.slot_pred[L] & 63u);
-      if (nb_slot != tgt_slot) scale_mv(mv, C.poc - C.reftab[nb_slot].poc, C.poc - C.reftab[tgt_slot].poc);
-      return 1;
-    }
-  }
-  return 0;
+  int L = -1;
+  if (unit_ref(m, X) >= 0) L = X;
+  else if (unit_ref(m, 1 - X) >= 0) L = 1 - X;
+  if (L < 0) return 0;
+  mvx = unit_mvx(m, L); mvy = unit_mvy(m, L);
+  const int nb_slot = unit_slot(m, L);
+  if (nb_slot != tgt_slot) scale_mv(mvx, mvy, C.poc - C.reftab[nb_slot].poc, C.poc - C.reftab[tgt_slot].poc);
+  return 1;
 }
 
 // 8.5.3.2.6 - 8.5.3.2.8: motion vector predictor mvp_flag of list X for reference index ref_idx
-__device__ __forceinline__ void derive_mvp(const MotionCtx& C, const PbGeom& g, int X, int ref_idx, int mvp_flag, int* mvp)
+__device__ __forceinline__ void derive_mvp(const MotionCtx& C, const PbGeom& g, int X, int ref_idx, int mvp_flag, int& out_x, int& out_y)
 {
   const int xPb = g.xPb, yPb = g.yPb, nPbW = g.nPbW, nPbH = g.nPbH;
   const int tgt_slot = slot_of(C, X, ref_idx);
-  const int xA[2] = {xPb - 1, xPb - 1}, yA[2] = {yPb + nPbH, yPb + nPbH - 1};
-  MotionUnit mA[2] = {};
-  int avA[2];
-  for (int k = 0; k < 2; k++) avA[k] = pb_available(C, g, xA[k], yA[k], &mA[k]);
-  const int is_scaled = avA[0] || avA[1];
-  int flagA = 0, mvA[2] = {0, 0};
-  for (int k = 0; k < 2 && !flagA; k++) if (avA[k]) flagA = nb_same_pic(C, mA[k], X, tgt_slot, mvA);
-  for (int k = 0; k < 2 && !flagA; k++) if (avA[k]) flagA = nb_scaled(C, mA[k], X, tgt_slot, mvA);
-  const int xB[3] = {xPb + nPbW, xPb + nPbW - 1, xPb - 1}, yB[3] = {yPb - 1, yPb - 1, yPb - 1};
-  MotionUnit mB[3] = {};
-  int avB[3];
-  for (int k = 0; k < 3; k++) avB[k] = pb_available(C, g, xB[k], yB[k], &mB[k]);
-  int flagB = 0, mvB[2] = {0, 0};
-  for (int k = 0; k < 3 && !flagB; k++) if (avB[k]) flagB = nb_same_pic(C, mB[k], X, tgt_slot, mvB);
-  if (!is_scaled && flagB) { flagA = 1; mvA[0] = mvB[0]; mvA[1] = mvB[1]; }
+  MotionUnit a0{}, a1{};
+  const int av_a0 = pb_available(C, g, xPb - 1, yPb + nPbH, &a0), av_a1 = pb_available(C, g, xPb - 1, yPb + nPbH - 1, &a1);
+  const int is_scaled = av_a0 || av_a1;
+  int flagA = 0, ax = 0, ay = 0;
+  if (av_a0) flagA = nb_same_pic(a0, X, tgt_slot, ax, ay);
+  if (!flagA && av_a1) flagA = nb_same_pic(a1, X, tgt_slot, ax, ay);
+  if (!flagA && av_a0) flagA = nb_scaled(C, a0, X, tgt_slot, ax, ay);
+  if (!flagA && av_a1) flagA = nb_scaled(C, a1, X, tgt_slot, ax, ay);
+  MotionUnit b0{}, b1{}, b2{};
+  const int av_b0 = pb_available(C, g, xPb + nPbW, yPb - 1, &b0), av_b1 = pb_available(C, g, xPb + nPbW - 1, yPb - 1, &b1), av_b2 = pb_available(C, g, xPb - 1, yPb - 1, &b2);
+  int flagB = 0, bx = 0, by = 0;
+  if (av_b0) flagB = nb_same_pic(b0, X, tgt_slot, bx, by);
+  if (!flagB && av_b1) flagB = nb_same_pic(b1, X, tgt_slot, bx, by);
+  if (!flagB && av_b2) flagB = nb_same_pic(b2, X, tgt_slot, bx, by);
+  if (!is_scaled && flagB) { flagA = 1; ax = bx; ay = by; }
   if (!is_scaled) {
     flagB = 0;
-    for (int k = 0; k < 3 && !flagB; k++) if (avB[k]) flagB = nb_scaled(C, mB[k], X, tgt_slot, mvB);
+    if (av_b0) flagB = nb_scaled(C, b0, X, tgt_slot, bx, by);
+    if (!flagB && av_b1) flagB = nb_scaled(C, b1, X, tgt_slot, bx, by);
+    if (!flagB && av_b2) flagB = nb_scaled(C, b2, X, tgt_slot, bx, by);
   }
-  int list[2][2] = {{0, 0}, {0, 0}}, n = 0;
-  if (flagA) { list[n][0] = mvA[0]; list[n][1] = mvA[1]; n++; }
-  if (flagB && !(flagA && mvA[0] == mvB[0] && mvA[1] == mvB[1]) && n < 2) { list[n][0] = mvB[0]; list[n][1] = mvB[1]; n++; }
-  if (n < 2 && C.slice->tmvp) {   // the temporal candidate only when the spatial ones left a place
-    int mvc[2];
-    if (temporal_mv(C, xPb, yPb, nPbW, nPbH, ref_idx, X, mvc)) { list[n][0] = mvc[0]; list[n][1] = mvc[1]; n++; }
+  // the list: A, B unless it repeats A, the temporal candidate only when the spatial ones left a place, zero vectors behind
+  int l0x = 0, l0y = 0, l1x = 0, l1y = 0, n = 0;
+  if (flagA) { l0x = ax; l0y = ay; n = 1; }
+  if (flagB && !(flagA && ax == bx && ay == by)) { if (n == 0) { l0x = bx; l0y = by; } else { l1x = bx; l1y = by; } n++; }
+  if (n < 2 && C.slice->tmvp) {
+    int cx = 0, cy = 0;
+    if (temporal_mv(C, xPb, yPb, nPbW, nPbH, ref_idx, X, cx, cy)) { if (n == 0) { l0x = cx; l0y = cy; } else { l1x = cx; l1y = cy; } n++; }
   }
-  mvp[0] = list[mvp_flag][0]; mvp[1] = list[mvp_flag][1];   // (entries the candidates did not fill are the zero vectors of 8.5.3.2.6)
+  out_x = mvp_flag ? l1x : l0x; out_y = mvp_flag ? l1y : l0y;
 }
 
 struct MotionLds {
-  MotionUnit cur[256];   // the CTB being derived, z-order
-  MotionUnit pu;         // the motion of the prediction unit lane 0 just derived (broadcast to the lanes that fill its units)
-  int pu_geom[4];        // its rectangle in units relative to the CTB: x, y, w, h
+  MotionUnit cur[2][256];  // the CTB being derived and the one before it (its left neighbour), z-order; they alternate
+  MotionUnit up[3 * 16];   // bottom unit rows of the CTBs above-left, above, above-right
+  MotionSyntax msyn[256];  // what the parser read for the CTB's prediction units
+  uint8_t usize[256], uipmc[256];   // the CTB's coding block sizes / prediction modes (unit maps)
+  MotionUnit pu;           // the motion of the prediction unit lane 0 just derived (broadcast to the lanes that fill its units)
+  int pu_geom[4];          // its rectangle in units relative to the CTB: x, y, w, h
   int pu_bad;
 };
 
@@ -343,87 +380,116 @@ __global__ __launch_bounds__(64) void k_motion(MotionArgs A)
     const int ctb_rs = cy * ctb_w + cx;
     const size_t base = (size_t)ctb_rs << units_log2;
     const CtbInfo ci = ctb_info[ctb_rs];
+    MotionUnit* const cur = L.cur[cx & 1];
     MotionCtx C;
-    C.P = &P; C.reftab = (const RefFrame*)(A.arena + P.off_reftab); C.slice = slices + ci.slice_idx; C.field = field; C.cur = L.cur;
+    C.P = &P; C.reftab = (const RefFrame*)(A.arena + P.off_reftab); C.slice = slices + ci.slice_idx; C.field = field; C.cur = cur;
+    C.left = L.cur[(cx & 1) ^ 1]; C.up = L.up;
     C.col = C.slice->tmvp ? (const MotionUnit*)(uintptr_t)C.reftab[C.slice->col_slot].mf : nullptr;
     C.cx = cx; C.cy = cy; C.avail = ci.avail; C.log2_ctb = log2_ctb; C.units_log2 = units_log2; C.lmt = P.log2_min_tb; C.ctb_w = ctb_w;
     C.width = P.width; C.height = P.height; C.poc = P.poc; C.par_mrg = P.log2_par_mrg_level;
     const int x_ctb = cx << log2_ctb, y_ctb = cy << log2_ctb;
-    for (int i = lane; i < units; i += 64) { MotionUnit z{}; z.ref_idx[0] = z.ref_idx[1] = -1; L.cur[i] = z; }
+    // what the serial derivation reads goes to LDS first, with all lanes: the CTB's syntax records and unit maps, and the bottom unit rows of the
+    // CTBs above (a lone lane chasing them through HBM one by one was 12 ms of a 720p picture's 60)
+    const int side = 1 << (log2_ctb - 2);
+    for (int i = lane; i < units; i += 64) { MotionUnit z{}; z.ref_idx[0] = z.ref_idx[1] = -1; cur[i] = z; L.msyn[i] = msyn_base[base + i]; }
+    for (int i = lane; i < units / 4; i += 64) {
+      ((uint32_t*)L.usize)[i] = ((const uint32_t*)(u_size + base))[i];
+      ((uint32_t*)L.uipmc)[i] = ((const uint32_t*)(u_ipmc + base))[i];
+    }
+    if (cy > 0)
+      for (int i = lane; i < 3 * side; i += 64) {
+        const int ncx = cx - 1 + i / side;
+        if (ncx >= 0 && ncx < ctb_w) L.up[i] = field[((size_t)((cy - 1) * ctb_w + ncx) << units_log2) + mk_interleave((uint32_t)(i % side), (uint32_t)(side - 1))];
+      }
     mk_lds_sync();
     int z = 0;
     while (z < units && !err) {
       const int ux = (int)mk_compact((uint32_t)z), uy = (int)mk_compact((uint32_t)z >> 1);
       if (x_ctb + ux * 4 >= P.width || y_ctb + uy * 4 >= P.height) { z++; continue; }
-      const int log2cb = u_size[base + z] >> 4;
+      const int log2cb = L.usize[z] >> 4;
       if (log2cb < 3 || log2cb > log2_ctb) { err = DEV_ERR_SYNTAX; break; }
       const int n_units = 1 << (2 * (log2cb - 2));
-      const uint32_t pm = u_ipmc[base + z];
+      const uint32_t pm = L.uipmc[z];
       if (pm & UM_INTER) {
         const int nCbS = 1 << log2cb, xCb = x_ctb + ux * 4, yCb = y_ctb + uy * 4;
-        const MotionSyntax s0 = msyn_base[base + z];
+        const MotionSyntax s0 = L.msyn[z];
         const int part_mode = (int)((s0.w0 >> 9) & 7u);
         const int q = nCbS >> 2, hf = nCbS >> 1;
-        int n_parts = 1, px[4] = {0, 0, 0, 0}, py[4] = {0, 0, 0, 0}, pw[4] = {nCbS, nCbS, nCbS, nCbS}, ph[4] = {nCbS, nCbS, nCbS, nCbS};
-        switch (part_mode) {   // Table 7-10
-          case 1: n_parts = 2; ph[0] = ph[1] = hf; py[1] = hf; break;
-          case 2: n_parts = 2; pw[0] = pw[1] = hf; px[1] = hf; break;
-          case 3: n_parts = 4; for (int k = 0; k < 4; k++) { pw[k] = ph[k] = hf; px[k] = (k & 1) * hf; py[k] = (k >> 1) * hf; } break;
-          case 4: n_parts = 2; ph[0] = q; ph[1] = nCbS - q; py[1] = q; break;
-          case 5: n_parts = 2; ph[0] = nCbS - q; ph[1] = q; py[1] = nCbS - q; break;
-          case 6: n_parts = 2; pw[0] = q; pw[1] = nCbS - q; px[1] = q; break;
-          case 7: n_parts = 2; pw[0] = nCbS - q; pw[1] = q; px[1] = nCbS - q; break;
-          default: break;
-        }
+        const int n_parts = part_mode == 0 ? 1 : (part_mode == 3 ? 4 : 2);
         for (int k = 0; k < n_parts && !err; k++) {
+          // the partition's rectangle inside the coding block (Table 7-10)
+          int rx = 0, ry = 0, rw = nCbS, rh = nCbS;
+          switch (part_mode) {
+            case 1: rh = hf; ry = k * hf; break;
+            case 2: rw = hf; rx = k * hf; break;
+            case 3: rw = rh = hf; rx = (k & 1) * hf; ry = (k >> 1) * hf; break;
+            case 4: rh = k ? nCbS - q : q; ry = k ? q : 0; break;
+            case 5: rh = k ? q : nCbS - q; ry = k ? nCbS - q : 0; break;
+            case 6: rw = k ? nCbS - q : q; rx = k ? q : 0; break;
+            case 7: rw = k ? q : nCbS - q; rx = k ? nCbS - q : 0; break;
+            default: break;
+          }
           if (lane == 0) {
-            PbGeom g{xCb, yCb, nCbS, xCb + px[k], yCb + py[k], pw[k], ph[k], k};
-            const uint32_t zk = mk_interleave((uint32_t)(ux + (px[k] >> 2)), (uint32_t)(uy + (py[k] >> 2)));
-            const MotionSyntax sy = msyn_base[base + zk];
-            Mo m;
-            for (int X = 0; X < 2; X++) { m.mv[X][0] = m.mv[X][1] = 0; m.ref_idx[X] = -1; }
+            PbGeom g{xCb, yCb, nCbS, xCb + rx, yCb + ry, rw, rh, k};
+            const uint32_t zk = mk_interleave((uint32_t)(ux + (rx >> 2)), (uint32_t)(uy + (ry >> 2)));
+            const MotionSyntax sy = L.msyn[zk];
+            Mo m = mo_none();
             int bad = !(sy.w0 & 0x8000u) || (int)((sy.w0 >> 12) & 3u) != k;
             if (!bad) {
               if (sy.w0 & 1u) m = derive_merge(C, g, part_mode, (int)((sy.w0 >> 1) & 7u));
               else {
                 const int idc = C.slice->is_b ? (int)((sy.w0 >> 16) & 3u) : 0;
-                if (idc > 2 || (idc == 2 && pw[k] + ph[k] == 12)) bad = 1;
-                for (int X = 0; X < 2 && !bad; X++) {
-                  if (!(idc == 2 || idc == X)) continue;
-                  const int ref_idx = X ? (int)((sy.w0 >> 18) & 15u) : (int)((sy.w0 >> 4) & 15u);
-                  if (ref_idx >= num_ref_of(C, X)) { bad = 1; break; }
-                  int mvp[2];
-                  derive_mvp(C, g, X, ref_idx, X ? (int)((sy.w0 >> 22) & 1u) : (int)((sy.w0 >> 8) & 1u), mvp);
-                  const int mvd_x = (int16_t)(sy.mvd[X] & 0xffffu), mvd_y = (int16_t)(sy.mvd[X] >> 16);
-                  const int ux_ = (mvp[0] + mvd_x + 65536) & 65535, uy_ = (mvp[1] + mvd_y + 65536) & 65535;   // 8.5.3.2.1: wrapped into 16 bits
-                  m.mv[X][0] = ux_ >= 32768 ? ux_ - 65536 : ux_; m.mv[X][1] = uy_ >= 32768 ? uy_ - 65536 : uy_; m.ref_idx[X] = ref_idx;
+                if (idc > 2 || (idc == 2 && rw + rh == 12)) bad = 1;
+                if (!bad && idc != 1) {   // list 0
+                  const int ref_idx = (int)((sy.w0 >> 4) & 15u);
+                  if (ref_idx >= num_ref_of(C, 0)) bad = 1;
+                  else {
+                    int px_ = 0, py_ = 0;
+                    derive_mvp(C, g, 0, ref_idx, (int)((sy.w0 >> 8) & 1u), px_, py_);
+                    const int ux_ = (px_ + (int16_t)(sy.mvd[0] & 0xffffu) + 65536) & 65535, uy_ = (py_ + (int16_t)(sy.mvd[0] >> 16) + 65536) & 65535;   // 8.5.3.2.1: wrapped into 16 bits
+                    mo_set(m, 0, ux_ >= 32768 ? ux_ - 65536 : ux_, uy_ >= 32768 ? uy_ - 65536 : uy_, ref_idx);
+                  }
+                }
+                if (!bad && idc != 0) {   // list 1
+                  const int ref_idx = (int)((sy.w0 >> 18) & 15u);
+                  if (ref_idx >= num_ref_of(C, 1)) bad = 1;
+                  else {
+                    int px_ = 0, py_ = 0;
+                    derive_mvp(C, g, 1, ref_idx, (int)((sy.w0 >> 22) & 1u), px_, py_);
+                    const int ux_ = (px_ + (int16_t)(sy.mvd[1] & 0xffffu) + 65536) & 65535, uy_ = (py_ + (int16_t)(sy.mvd[1] >> 16) + 65536) & 65535;
+                    mo_set(m, 1, ux_ >= 32768 ? ux_ - 65536 : ux_, uy_ >= 32768 ? uy_ - 65536 : uy_, ref_idx);
+                  }
                 }
               }
               if (!bad) {
-                if (m.ref_idx[0] < 0 && m.ref_idx[1] < 0) bad = 1;
-                for (int X = 0; X < 2; X++) if (m.ref_idx[X] >= num_ref_of(C, X)) bad = 1;
+                if (m.r0 < 0 && m.r1 < 0) bad = 1;
+                if (m.r0 >= num_ref_of(C, 0) || m.r1 >= num_ref_of(C, 1)) bad = 1;
               }
             }
             MotionUnit o{};
             o.ref_idx[0] = o.ref_idx[1] = -1;
-            if (!bad)
-              for (int X = 0; X < 2; X++)
-                if (m.ref_idx[X] >= 0) {
-                  const int slot = slot_of(C, X, m.ref_idx[X]);
-                  o.mv[X][0] = (int16_t)m.mv[X][0]; o.mv[X][1] = (int16_t)m.mv[X][1]; o.ref_idx[X] = (int8_t)m.ref_idx[X];
-                  o.poc_delta[X] = (int16_t)mk_clip3(-32768, 32767, C.poc - C.reftab[slot].poc);
-                  o.slot_pred[X] = (uint8_t)slot;
-                }
+            if (!bad) {
+              if (m.r0 >= 0) {
+                const int slot = slot_of(C, 0, m.r0);
+                o.mv[0][0] = (int16_t)m.x0; o.mv[0][1] = (int16_t)m.y0; o.ref_idx[0] = (int8_t)m.r0;
+                o.poc_delta[0] = (int16_t)mk_clip3(-32768, 32767, C.poc - C.reftab[slot].poc); o.slot_pred[0] = (uint8_t)slot;
+              }
+              if (m.r1 >= 0) {
+                const int slot = slot_of(C, 1, m.r1);
+                o.mv[1][0] = (int16_t)m.x1; o.mv[1][1] = (int16_t)m.y1; o.ref_idx[1] = (int8_t)m.r1;
+                o.poc_delta[1] = (int16_t)mk_clip3(-32768, 32767, C.poc - C.reftab[slot].poc); o.slot_pred[1] = (uint8_t)slot;
+              }
+            }
             o.slot_pred[0] = (uint8_t)(o.slot_pred[0] | (((pm & UM_SKIP) ? 2u : 1u) << 6));
             L.pu = o;
             L.pu_bad = bad;
-            L.pu_geom[0] = ux + (px[k] >> 2); L.pu_geom[1] = uy + (py[k] >> 2); L.pu_geom[2] = pw[k] >> 2; L.pu_geom[3] = ph[k] >> 2;
+            L.pu_geom[0] = ux + (rx >> 2); L.pu_geom[1] = uy + (ry >> 2); L.pu_geom[2] = rw >> 2; L.pu_geom[3] = rh >> 2;
           }
           mk_lds_sync();
           const MotionUnit o = L.pu;
           if (L.pu_bad) { err = DEV_ERR_SYNTAX; break; }
           const int gx = L.pu_geom[0], gy = L.pu_geom[1], gw = L.pu_geom[2], gh = L.pu_geom[3];
-          for (int i = lane; i < gw * gh; i += 64) L.cur[mk_interleave((uint32_t)(gx + i % gw), (uint32_t)(gy + i / gw))] = o;
+          for (int i = lane; i < gw * gh; i += 64) cur[mk_interleave((uint32_t)(gx + i % gw), (uint32_t)(gy + i / gw))] = o;
           mk_lds_sync();
         }
       }
@@ -431,7 +497,7 @@ __global__ __launch_bounds__(64) void k_motion(MotionArgs A)
     }
     if (err) break;
     // the CTB's units leave LDS (coalesced 16-byte stores), then the row's progress is published
-    for (int i = lane; i < units; i += 64) field[base + i] = L.cur[i];
+    for (int i = lane; i < units; i += 64) field[base + i] = cur[i];
     mk_lds_sync();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane == 0) __hip_atomic_store(my_progress, (uint32_t)(cx + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
