@@ -280,3 +280,29 @@ def test_b_sequence_in_coding_order_through_the_legacy_call():
         for c in range(3):
             np.testing.assert_array_equal(img.planes[c], ref["planes"][c], err_msg="POC %d" % ref["poc"])
     d.free()
+
+
+def test_two_coded_video_sequences_back_to_back_come_out_in_order():
+    """an IDR picture in the middle of a track starts a new coded video sequence: POCs start over, and everything of the first sequence that is still
+    waiting for output precedes it (C.5.2.2); no flush in between"""
+    from libheif_amd.decoder import HipDecoder
+    a_aus, a_refs = _p_sequence(6, b_frames=2, temporal_mvp=1, seed=3)
+    b_aus, b_refs = _p_sequence(5, b_frames=1, b_ref=0, temporal_mvp=1, weighted_pred=1, seed=8)
+    expect = [r for _, r in sorted((r["poc"], r) for r in a_refs)] + [r for _, r in sorted((r["poc"], r) for r in b_refs)]
+    d = HipDecoder()
+    got = []
+    for au in a_aus + b_aus:          # (the second sequence's first sample carries its own parameter sets and an IDR picture)
+        d.push_data(au)
+        r = d.next_picture()
+        while r is not None:
+            got.append(r[0])
+            r = d.next_picture()
+    r = d.next_picture(flush=True)
+    while r is not None:
+        got.append(r[0])
+        r = d.next_picture(flush=True)
+    assert len(got) == len(expect)
+    for k, (img, ref) in enumerate(zip(got, expect)):
+        for c in range(3):
+            np.testing.assert_array_equal(img.planes[c], ref["planes"][c], err_msg="output %d (POC %d) plane %d" % (k, ref["poc"], c))
+    d.free()
