@@ -250,6 +250,18 @@ PC_DEV uint32_t read_byte(PS& s)
   }
   return b;
 }
+// the same byte as a wave-uniform VECTOR value: the arithmetic decoder adds it to its (vector-resident) window, so position masking, shift and
+// extraction issue on the SIMD instead of the CU-shared scalar pipe (5 of the 8 scalar instructions of a byte read)
+PC_DEV UReg read_byte_v(PS& s)
+{
+  if (__builtin_expect(s.pos < s.fast_limit, 1)) {
+    const uint32_t p = s.pos++;
+    const uint32_t dw = pc_rdlane(s.win, (int)(p >> 2));     // (v_readlane takes the lane from bits 5:0 of the select)
+    const UReg sh = (pc_vec(p) & 3u) << 3;
+    return ((UReg)dw >> sh) & 255u;
+  }
+  return pc_vec(read_byte(s));
+}
 PC_DEV void cabac_start(PS& s, uint32_t start, uint32_t end)
 {
   s.pos = start; s.end = end; s.zeros = 0; s.win_base = 0xfffff000u; s.fast_limit = 0;
@@ -268,7 +280,7 @@ PC_DEV void cabac_start(PS& s, uint32_t start, uint32_t end)
 //                  bits 13:8 / 29:24 carry the 8x8 diagonal scan and its inverse (lane = scan position / raster index)
 // Both pipes matter: the scalar ALU is shared by the CU's four SIMDs, so the decoder's arithmetic runs on the VALU (UReg) and only lane
 // selects, the bin value and the syntax control flow are scalar (profiles/r02g_pmc_parse_b512.txt).
-PC_DEV void refill_byte(PS& s) { s.value += read_byte(s) << s.bits_needed; s.bits_needed -= 8u; }
+PC_DEV void refill_byte(PS& s) { s.value += read_byte_v(s) << s.bits_needed; s.bits_needed -= 8u; }
 
 PC_DEV int decode_bin_cxx(PS& s, VReg& grp, int ctx_lane)
 {
@@ -335,7 +347,7 @@ PC_DEV int decode_bypass(PS& s)
 {
   s.value <<= 1;
   s.bits_needed += 1u;
-  if (pc_any((int32_t)s.bits_needed >= 0)) { s.bits_needed = pc_vec((uint32_t)-8); s.value += read_byte(s); }
+  if (pc_any((int32_t)s.bits_needed >= 0)) { s.bits_needed = pc_vec((uint32_t)-8); s.value += read_byte_v(s); }
   if (pc_any(s.value >= s.range)) { s.value -= s.range; return 1; }
   return 0;
 }
@@ -477,6 +489,46 @@ PC_DEV int decode_remaining(PS& s, int rice)
   if (prefix <= 3) return (prefix << rice) + decode_bypass_bits(s, rice);
   return (((1 << (prefix - 3)) + 3 - 1) << rice) + decode_bypass_bits(s, prefix - 3 + rice);
 }
+// coeff_abs_level_remaining (9.3.3.11: unary prefix, then rice / escape suffix - all bypass bins) in ONE step when the whole code is at most 8 bins
+// long and the window needs no special handling: the next 8 bypass bins are the quotient of the window extended by the next byte (looked at,
+// not consumed) by the range - sequential bypass decoding is long division, so the first L bins of that quotient are the L bins sequential
+// decoding would produce -; prefix length, code length L and value come from the quotient's bits, and exactly L bins are committed (window,
+// position) with the quotient already known.  Everything is vector arithmetic on wave-uniform values: the bin-by-bin form cost ~25 scalar
+// instructions per coefficient.  Longer codes and windows with emulation-prevention candidates take decode_remaining().
+PC_DEV UReg decode_remaining_v(PS& s, UReg rice)
+{
+  if (__builtin_expect(s.pos < s.fast_limit, 1)) {
+    const uint32_t p = s.pos;
+    const uint32_t dw = pc_rdlane(s.win, (int)(p >> 2));
+    const UReg byte = ((UReg)dw >> ((pc_vec(p) & 3u) << 3)) & 255u;
+    const UReg bn = s.bits_needed;                                  // -8 .. -1
+    const UReg v8 = (s.value << 8) + (byte << (bn + 8u));           // what 8 steps of 9.3.4.3.4 would have shifted in (the refill always happens within 8)
+    const UReg scaled = s.range;
+    UReg q = (UReg)((float)v8 * pc_rcp((float)scaled));             // v8 < 2^24, scaled < 2^16: exact in fp32 up to an error of one, repaired below
+    UReg r = v8 - pc_mul24(q, scaled);
+    if (pc_any((int32_t)r < 0)) q -= 1u;
+    else if (pc_any(r >= scaled)) q += 1u;
+    if (__builtin_expect(!pc_any(q > 255u), 1)) {
+      const UReg inv = (~q) & 255u;
+      const UReg prefix = (UReg)pc_clz(inv | 1u) - 24u + ((inv == 0u) ? 1u : 0u);   // leading ones of the 8 bins; 8 if all are ones
+      const UReg suffix_len = prefix <= 3u ? rice : prefix - 3u + rice;
+      const UReg len = prefix + 1u + suffix_len;
+      if (__builtin_expect(pc_any(len <= 8u), 1)) {
+        const UReg suffix = (q >> (8u - len)) & ((1u << suffix_len) - 1u);
+        const UReg val = (prefix <= 3u ? (prefix << rice) : ((((1u << (prefix - 3u)) + 2u) << rice))) + suffix;
+        // commit len bins: the window after len shifts (with the byte if the shifts reached it) minus the bins' multiples of the range
+        const UReg bn2 = bn + len;
+        const bool took = pc_any((int32_t)bn2 >= 0);
+        UReg vl = s.value << len;
+        if (took) { vl += byte << bn2; s.pos = p + 1u; }
+        s.value = vl - pc_mul24(q >> (8u - len), scaled);
+        s.bits_needed = took ? bn2 - 8u : bn2;
+        return val;
+      }
+    }
+  }
+  return pc_vec((uint32_t)decode_remaining(s, (int)pc_uni(rice)));
+}
 // scan of sub-blocks: lg = log2 of the sub-block grid width (0..3)
 PC_DEV void scan_sb(PS& s, int lg, int scan_idx, int i, int& xs, int& ys)
 {
@@ -608,18 +660,18 @@ PC_DEV int residual_coding(PS& s, int log2n, int c_idx, int pred_mode)
     const uint32_t sign_bits = (uint32_t)decode_bypass_bits(s, n_signs);
     // coeff_abs_level_remaining for the positions whose base level hit its cap (9.3.3.11 order: descending k)
     const uint32_t need_rem = (g1_coded & g1 & ~(first_g1_bit & ~g2)) | (sig & ~g1_coded);
-    VReg vrem;
-    PC_VEC_BEGIN PC_L(vrem) = 0u; PC_VEC_END
+    VReg vrem, vbase;   // vbase: baseLevel of scan position k (1 + greater1 + greater2) on lane k, computed once for the sub-block
+    PC_VEC_BEGIN PC_L(vrem) = 0u; PC_L(vbase) = 1u + ((g1 >> (lane & 15)) & 1u) + ((g2 >> (lane & 15)) & 1u); PC_VEC_END
     {
       uint32_t rem = need_rem;
-      int rice = 0;
+      UReg rice = pc_vec(0u);   // cRiceParam and the level arithmetic stay on the vector side
       while (rem) {
         const int k = 31 - pc_clz(rem);
         rem &= ~(1u << k);
-        const int r = decode_remaining(s, rice);
-        const int abs_level = 1 + (int)((g1 >> k) & 1u) + (int)((g2 >> k) & 1u) + r;
-        if (abs_level > 3 * (1 << rice)) rice = rice < 4 ? rice + 1 : 4;
-        pc_wrlane(vrem, k, (uint32_t)r);
+        const UReg r = decode_remaining_v(s, rice);
+        const UReg abs_level = (UReg)pc_rdlane(vbase, k) + r;
+        rice = (abs_level > (3u << rice) && rice < 4u) ? rice + 1u : rice;
+        pc_wrlane_v(vrem, k, r);
       }
     }
     // levels, signs (incl. the hidden one) and positions of the 16 scan positions in parallel, one lane each
