@@ -372,6 +372,10 @@ PC_DEV uint32_t decode_bypass_multi(PS& s, int n)
 }
 PC_DEV int decode_bypass_bits(PS& s, int n)   // n <= 32, MSB first
 {
+  if (n <= 8) {   // the common case (rice suffixes, most sign groups, last-position suffixes): one division, or one bin
+    if (n >= 2) return (int)decode_bypass_multi(s, n);
+    return n ? decode_bypass(s) : 0;
+  }
   uint32_t v = 0;
   while (n > 0) {
     const int c = n > 8 ? 8 : n;
