@@ -529,6 +529,38 @@ PC_DEV UReg decode_remaining_v(PS& s, UReg rice)
         s.bits_needed = took ? bn2 - 8u : bn2;
         return val;
       }
+      // codes of 9 .. 16 bins (escape codes of large levels: the first coefficients of a busy sub-block, before cRiceParam has grown): the next 8
+      // bins are a second division of the first one's remainder extended by the byte after (both bytes only looked at)
+      if (__builtin_expect(s.pos + 1u < s.fast_limit, 1)) {
+        const uint32_t dw2 = pc_rdlane(s.win, (int)((p + 1u) >> 2));   // (the window register holds 256 bytes: p + 1 < fast_limit stays inside it)
+        const UReg byte2 = ((UReg)dw2 >> ((pc_vec(p + 1u) & 3u) << 3)) & 255u;
+        const UReg r8 = v8 - pc_mul24(q, scaled);                      // remainder after the first 8 bins (bits_needed is back at bn)
+        const UReg v16 = (r8 << 8) + (byte2 << (bn + 8u));
+        UReg q2 = (UReg)((float)v16 * pc_rcp((float)scaled));
+        UReg r2 = v16 - pc_mul24(q2, scaled);
+        if (pc_any((int32_t)r2 < 0)) q2 -= 1u;
+        else if (pc_any(r2 >= scaled)) q2 += 1u;
+        if (__builtin_expect(!pc_any(q2 > 255u), 1)) {
+          const UReg bins = (q << 8) | q2;                              // 16 bins, first bin in bit 15
+          const UReg inv16 = (~bins) & 0xffffu;
+          const UReg prefix16 = (UReg)pc_clz(inv16 | 1u) - 16u + ((inv16 == 0u) ? 1u : 0u);
+          const UReg suffix_len16 = prefix16 <= 3u ? rice : prefix16 - 3u + rice;
+          const UReg len16 = prefix16 + 1u + suffix_len16;
+          if (__builtin_expect(pc_any(len16 <= 16u), 1)) {
+            const UReg suffix = (bins >> (16u - len16)) & ((1u << suffix_len16) - 1u);
+            const UReg val = (prefix16 <= 3u ? (prefix16 << rice) : ((((1u << (prefix16 - 3u)) + 2u) << rice))) + suffix;
+            const UReg m = len16 - 8u;                                  // bins taken from the second group (1 .. 8)
+            const UReg bn3 = bn + m;
+            const bool took2 = pc_any((int32_t)bn3 >= 0);
+            UReg vl = r8 << m;
+            if (took2) vl += byte2 << bn3;
+            s.pos = p + (took2 ? 2u : 1u);
+            s.value = vl - pc_mul24(q2 >> (8u - m), scaled);
+            s.bits_needed = took2 ? bn3 - 8u : bn3;
+            return val;
+          }
+        }
+      }
     }
   }
   return pc_vec((uint32_t)decode_remaining(s, (int)pc_uni(rice)));
