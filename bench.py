@@ -63,6 +63,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch curve, BASELINE's other configs and the extra workloads")
     ap.add_argument("--only-main", action="store_true", help="main resident measurement only (profiling runs)")
+    ap.add_argument("--only-sequences", action="store_true", help="the sequence_tracks section only (development)")
     ap.add_argument("--parts", type=int, default=1, help="batches a step is split into; with 2, batch k+1's CABAC parse is queued beside batch k's "
                     "pixel stages on a second stream (hipdec_set_stage_overlap).  Measured SLOWER (12.1 against 13.7 Gpixel/s): the CABAC work pool "
                     "holds every wave slot of the chip, the other kernels only start when it exits, and smaller batches parse less efficiently")
@@ -224,6 +225,54 @@ def issue_roofline(kernels, px, cu_count, clock_ghz):
     return out
 
 
+def sequence_tracks(n_frames=13, tracks=16, w=1280, h=720):
+    """sequence tracks through the decoder object the way libheif drives it (one sample per push_data2, pictures polled in output order,
+    flush at the end): frames per second of ONE track - every picture is one CABAC critical path, the instance holds one sample at a time - and of
+    `tracks` tracks decoded side by side by as many threads (their decodes coalesce into shared launch sets).  The first pass of each kind checks
+    every picture against the CPU oracle."""
+    import threading
+    import numpy as np
+    from oracle import pyoracle as orc
+    from libheif_amd.decoder import HipDecoder
+    f0 = orc.synth_image(w, h, 8, 1, seed=77)
+    frames = [[np.roll(np.roll(p, k // (1 if i == 0 else 2), 0), 2 * k // (1 if i == 0 else 2), 1) for i, p in enumerate(f0)] for k in range(n_frames)]
+    kinds = {"lowdelay_ippp_2refs_tmvp_weighted": dict(inter_num_refs=2, temporal_mvp=1, weighted_pred=1),
+             "unrestricted_ibbp_tmvp": dict(b_frames=2, inter_num_refs=2, temporal_mvp=1)}
+    res = {"pictures_per_track": n_frames, "size": "%dx%d" % (w, h), "tracks_side_by_side": tracks}
+    for name, kw in kinds.items():
+        aus = orc.encode_sequence(frames, qp=27, global_mv_x=-8, global_mv_y=-4, inter_skip_pct=30, **kw)
+        ref = {r["poc"]: r for r in orc.decode_sequence(aus)}
+
+        def play(check):
+            d = HipDecoder()
+            got = 0
+            try:
+                for au in aus + [None]:
+                    if au is not None:
+                        d.push_data(au)
+                    r = d.next_picture(flush=au is None)
+                    while r is not None:
+                        if check and not all((r[0].planes[c] == ref[got]["planes"][c]).all() for c in range(3)):
+                            raise RuntimeError("sequence %s: picture with POC %d differs from the oracle" % (name, got))
+                        got += 1
+                        r = d.next_picture(flush=au is None)
+            finally:
+                d.free()
+            if got != len(aus):
+                raise RuntimeError("sequence %s: %d of %d pictures came out" % (name, got, len(aus)))
+
+        play(True)
+        t0 = time.perf_counter(); play(False); one = time.perf_counter() - t0
+        th = [threading.Thread(target=play, args=(False,)) for _ in range(tracks)]
+        t0 = time.perf_counter()
+        for t in th: t.start()
+        for t in th: t.join()
+        many = time.perf_counter() - t0
+        res[name] = {"one_track_fps": round(n_frames / one, 1), "ms_per_picture": round(one / n_frames * 1e3, 1), "all_tracks_fps": round(tracks * n_frames / many, 1),
+                     "kbytes_per_picture": round(sum(len(a) for a in aus) / len(aus) / 1e3, 1), "verified_against_oracle": True}
+    return res
+
+
 _REAL_STDOUT = None
 
 
@@ -248,6 +297,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
+    if a.only_sequences:
+        import libheif_amd
+        libheif_amd.load_library()
+        emit(json.dumps({"sequence_tracks": sequence_tracks()}))
+        return
     w, h, def_batch, bit_depth, enc_cfg, out_chroma = WORKLOADS[a.workload]
     enc_cfg = dict(enc_cfg, qp=a.qp)
     for kv in a.enc:
@@ -634,6 +688,10 @@ def main():
                 lin = None
             e.free()
         out["extra_workloads"] = extras
+        try:
+            out["sequence_tracks"] = sequence_tracks()
+        except Exception as ex:   # noqa: a failure here is reported, it does not take the line down
+            out["sequence_tracks"] = {"error": str(ex)[:300]}
         # BASELINE.json's configs as written (config 1 is the CPU plumbing case)
         ss = out.get("single_still", {})
         out["baseline_configs"] = {

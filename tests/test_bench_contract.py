@@ -38,3 +38,8 @@ def test_committed_bench_line_has_every_contract_field():
             assert d["baseline_configs"][k]["mpixel_s"] > 0, k
         g = d["grid_sharded"]
         assert g["wpp"]["one_gpu_ms"] > 0 and g["wpp"]["rccl"]["canvas_matches_one_gpu"] is True and g["wpp"]["rccl"]["ranks"] == d["n_gpus"]
+        if "sequence_tracks" in d:     # SURVEY 8 f3 measured: P and B tracks through the decoder object, checked against the oracle inside the run
+            st = d["sequence_tracks"]
+            assert "error" not in st, st
+            for k in ("lowdelay_ippp_2refs_tmvp_weighted", "unrestricted_ibbp_tmvp"):
+                assert st[k]["one_track_fps"] > 0 and st[k]["all_tracks_fps"] > st[k]["one_track_fps"] and st[k]["verified_against_oracle"] is True
