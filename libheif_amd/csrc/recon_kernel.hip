@@ -27,6 +27,7 @@
 //     stores (only the next kernel reads them).
 //   * HBM traffic per luma pixel: 1.5*s written + <= 3 B residual and 0.3 B unit maps read.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "hevc_device.h"
 #include "kernels.h"
 
@@ -56,19 +57,21 @@ __device__ __forceinline__ int inv_angle_magnitude(int k)   // k = 1..8 -> round
   return (int)(((k <= 4 ? kLo : kHi) >> (((k - 1) & 3) * 16)) & 0xffffu);
 }
 
-template <typename Pix>
+// Unit: the type of a unit-map entry.  uint32_t: the full word below; uint16_t: the compact form of the 8-bit intra kernel (the unit's position
+// comes from a lane-held table instead), which brings the wave's LDS to 5824 B: 28 waves per CU instead of 25.
+template <typename Pix, typename Unit = uint32_t>
 struct ReconLds {
   Pix tile[64 * 64];        // the CTB of this wave's component
   uint32_t top_raw[72];     // words of the line buffer covering x_ctb - 1 .. x_ctb + 2 * ctb - 1 (+ one pad word in front)
   Pix left[128];            // right column of the previous CTB (the chroma pair: Cb at [0, 64), Cr at [64, 128))
-  uint16_t refbuf0[134], refbuf1[134];   // reference samples in scan order, one pad element in front (an unused weight-0 tap may read index -1)
+  uint16_t refbuf0[134];    // reference samples in scan order, one pad element in front (an unused weight-0 tap may read index -1); filtered in place (8.4.4.2.3)
   // availability of the neighbourhood in 4x4-luma units, one row of bits per unit row: row uy + 1, bit ux + 1 for the
   // units ux, uy in [-1, 2 * units_per_side): row 0 / bit 0 are the borders owned by the neighbouring CTBs, rows and bits
   // past the CTB stay 0 (not decoded yet), a unit of the CTB is set when its block has been reconstructed
   uint64_t avrow[33];
   // per 4x4-luma unit (z order): log2 TU size | log2 CB size << 4 | UF_* flags << 8 | intra mode of this component << 16 |
-  // unit x << 24 | unit y << 28
-  uint32_t m_unit[256];
+  // unit x << 24 | unit y << 28;   compact form: (log2 TU size - 2) | (UF_* flags & 31) << 2 | mode << 7 | invalid size << 15
+  Unit m_unit[256];
 };
 
 __device__ __forceinline__ uint32_t compact1by1(uint32_t v)
@@ -98,6 +101,15 @@ __device__ __forceinline__ void lds_sync()
 #endif
   __builtin_amdgcn_wave_barrier();
 }
+// the value lane `src` (wave-uniform) holds
+__device__ __forceinline__ uint32_t wave_read_lane(uint32_t v, int src)
+{
+#ifndef HIPDEC_HOST_EMU
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, src);
+#else
+  return (uint32_t)__shfl((int)v, src);
+#endif
+}
 // all of this wave's global stores have left it (the CPU-test build of tests/emu orders them with a fence instead)
 __device__ __forceinline__ void drain_stores()
 {
@@ -123,8 +135,8 @@ struct Ctx {
 // A transform block of a coding unit that is NOT intra coded (P pictures): the prediction samples are in the reconstruction plane already
 // (k_mc, inter_kernels.hip); the block enters the LDS tile with its residual added, so that intra blocks next to it predict from it and the
 // CTB leaves LDS as a whole.  LW lanes (64, or 32 per half of the chroma pair) cover the block; `pred` points at the block in the plane.
-template <typename Pix>
-__device__ __forceinline__ void reconstruct_inter_block(ReconLds<Pix>& L, const Ctx& C, Pix* tile, const Pix* pred, uint32_t pstride, int xb, int yb, int log2n, int cbf,
+template <typename Pix, typename LdsT>
+__device__ __forceinline__ void reconstruct_inter_block(LdsT& L, const Ctx& C, Pix* tile, const Pix* pred, uint32_t pstride, int xb, int yb, int log2n, int cbf,
                                                         const int16_t* res, int l, int LW, int ushx, int ushy)
 {
   const int n = 1 << log2n, nn = n * n, lg_ctbc = C.lg_ctbc, maxv = C.maxv;
@@ -143,15 +155,17 @@ __device__ __forceinline__ void reconstruct_inter_block(ReconLds<Pix>& L, const 
 
 // One transform block: prediction (+ residual) into the LDS tile.
 //   (xb, yb): block origin inside the CTB in component samples; log2n: block size
-template <typename Pix>
-__device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C, const Pix* top, int xb, int yb, int log2n, int mode, int cbf, const int16_t* res)
+//   LOG2N: the block size as a compile-time constant (the size-specialised build: pass counts, the extra sample, the smoothing threshold and the
+//   residual rotation fold away - a block costs about a third fewer scalar instructions), 0 = taken from `log2n_rt`
+template <typename Pix, int LOG2N, typename LdsT>
+__device__ __forceinline__ void reconstruct_block(LdsT& L, const Ctx& C, const Pix* top, int xb, int yb, int log2n_rt, int mode, int cbf, const int16_t* res)
 {
   const int lane = C.lane;
+  const int log2n = LOG2N ? LOG2N : log2n_rt;
   const int n = 1 << log2n, n2 = 2 * n, N = 4 * n + 1, nn = n * n;
   const int lg_ctbc = C.lg_ctbc, maxv = C.maxv;
   Pix* tile = L.tile;
   uint16_t* ref0 = L.refbuf0 + 1;
-  uint16_t* ref1 = L.refbuf1 + 1;
 
   // the block's residual is requested from HBM first, so that its latency hides behind the prediction
   // (lane l owns samples l, l + 64, ...; the first 4 cover blocks up to 16x16, a 32x32 block reads the rest late)
@@ -247,18 +261,31 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
         a1 = a1 < 0 ? -a1 : a1; a2 = a2 < 0 ? -a2 : a2;
         strong = a1 < (1 << (C.bit_depth - 5)) && a2 < (1 << (C.bit_depth - 5));
       }
-      for (int e = lane; e < N; e += 64) {
-        int v;
-        if (e == 0 || e == N - 1) v = ref[e];
-        else if (strong) {
-          if (e == n2) v = ref[n2];
-          else if (e < n2) { const int y = 63 - e; v = ((63 - y) * ref[n2] + (y + 1) * ref[0] + 32) >> 6; }
-          else { const int x = e - n2 - 1; v = ((63 - x) * ref[n2] + (x + 1) * ref[N - 1] + 32) >> 6; }
-        } else v = (ref[e - 1] + 2 * ref[e] + ref[e + 1] + 2) >> 2;
-        ref1[e] = (uint16_t)v;
+      // in place: every lane filters its (at most three) samples into registers, then all write back
+      int fv[3] = {0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int e = lane + 64 * j;
+        if (64 * j >= N) continue;      // wave-uniform
+        if (e < N) {
+          int v;
+          if (e == 0 || e == N - 1) v = ref0[e];
+          else if (strong) {
+            if (e == n2) v = ref0[n2];
+            else if (e < n2) { const int y = 63 - e; v = ((63 - y) * ref0[n2] + (y + 1) * ref0[0] + 32) >> 6; }
+            else { const int x = e - n2 - 1; v = ((63 - x) * ref0[n2] + (x + 1) * ref0[N - 1] + 32) >> 6; }
+          } else v = (ref0[e - 1] + 2 * ref0[e] + ref0[e + 1] + 2) >> 2;
+          fv[j] = v;
+        }
       }
       lds_sync();
-      ref = ref1;
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int e = lane + 64 * j;
+        if (64 * j >= N) continue;
+        if (e < N) ref0[e] = (uint16_t)fv[j];
+      }
+      lds_sync();
     }
   }
 #define RL(k) ((int)ref[n2 - (k)])
@@ -339,11 +366,12 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
 // the samples, the residuals and the coded-block flags differ — so one instruction stream reconstructs both blocks.
 //   LDS: the Cr tile sits behind the Cb tile (each 1 << lg_ctbc wide, 1 << lg_ctbh tall), left borders at left[0..63] / left[64..127], reference lines
 //   at refbuf0[1 + 67 h ...];  `top`, `cbf` and `res` are this lane's half's.
-template <typename Pix>
-__device__ __forceinline__ void reconstruct_chroma_pair(ReconLds<Pix>& L, const Ctx& C, const Pix* top, int xb, int yb, int log2n, int mode, int cbf,
+template <typename Pix, int LOG2N, typename LdsT>
+__device__ __forceinline__ void reconstruct_chroma_pair(LdsT& L, const Ctx& C, const Pix* top, int xb, int yb, int log2n_rt, int mode, int cbf,
                                                         const int16_t* res)
 {
   const int lane = C.lane, l = lane & 31, h = lane >> 5;
+  const int log2n = LOG2N ? LOG2N : log2n_rt;
   const int n = 1 << log2n, n2 = 2 * n, N = 4 * n + 1, nn = n * n;
   const int lg_ctbc = C.lg_ctbc, maxv = C.maxv;
   Pix* tile = L.tile + (h << (lg_ctbc + C.lg_ctbh));
@@ -484,9 +512,11 @@ __device__ __forceinline__ void reconstruct_chroma_pair(ReconLds<Pix>& L, const 
 // picture, the Cb / Cr plane (plane 1 / 2: same geometry as luma, the chroma modes / flags / bit depth, no boundary filters).
 // DUAL = true: the 4:2:0 Cb (lanes 0..31) and Cr (lanes 32..63) side by side — h / l below are a lane's half and its index inside
 // the half, LW the lanes one component has.
-template <typename Pix, bool DUAL, bool INTER>
-__device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& wd, ReconLds<Pix>& L, int lane, int plane)
+// SPEC: intra blocks go through the size-specialised copies of the block functions (4:2:2 chroma pairs keep the run-time size).
+template <typename Pix, bool DUAL, bool INTER, bool SPEC, typename Unit>
+__device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& wd, ReconLds<Pix, Unit>& L, int lane, int plane)
 {
+  constexpr bool COMPACT = sizeof(Unit) == 2;
   constexpr int ES = (int)sizeof(Pix);
   constexpr int LW = DUAL ? 32 : 64;
   constexpr int PPW = 4 / ES;            // pixels per 32-bit word
@@ -526,6 +556,7 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
   uint32_t* top_raw = L.top_raw + (DUAL ? h * 36 : 0);
   const int lg_wpr = C.lg_ctbc - (ES == 1 ? 2 : 1);      // log2 of the words per tile row
   const int wpr = 1 << lg_wpr;
+  const uint32_t vpos = compact1by1((uint32_t)lane) | (compact1by1((uint32_t)lane >> 1) << 3);   // unit lane of a quadrant: x | y << 3 (compact unit words)
 
   for (int cy = (int)wd.first_row; cy < ctb_h && !err; cy += (int)wd.stride) {
   my_row = wd.base_row + (uint32_t)cy;     // batch row index
@@ -570,9 +601,14 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
         }
         const uint32_t ux = compact1by1((uint32_t)i), uy = compact1by1((uint32_t)i >> 1);   // i is a multiple of 4: units i..i+3 are a 2x2 quad
 #pragma nounroll
-        for (int k = 0; k < 4; k++)
-          L.m_unit[i + k] = ((sz >> (8 * k)) & 255u) | (((fl >> (8 * k)) & 255u) << 8) | (((md >> (8 * k)) & mode_mask) << 16) |
-                            ((ux + (k & 1)) << 24) | ((uy + (k >> 1)) << 28);
+        for (int k = 0; k < 4; k++) {
+          if (COMPACT) {
+            const uint32_t tbk = (sz >> (8 * k)) & 15u;
+            L.m_unit[i + k] = (Unit)(((tbk - 2u) & 3u) | (((fl >> (8 * k)) & 31u) << 2) | (((md >> (8 * k)) & mode_mask & 127u) << 7) | ((tbk - 2u) > 3u ? 0x8000u : 0u));
+          } else
+            L.m_unit[i + k] = (Unit)(((sz >> (8 * k)) & 255u) | (((fl >> (8 * k)) & 255u) << 8) | (((md >> (8 * k)) & mode_mask) << 16) |
+                                     ((ux + (k & 1)) << 24) | ((uy + (k >> 1)) << 28));
+        }
       }
       // availability rows: the borders come from the neighbouring CTBs (slice / tile / picture limits are in ci.avail,
       // units right of or below the picture never become available), the CTB's own units are set block by block
@@ -597,10 +633,20 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
     int z = 0;
     while (z < units) {
       const uint32_t w = L.m_unit[z];
-      const int ux = (int)((w >> 24) & 15u), uy = (int)(w >> 28);
+      int ux, uy, tb, fl, mode;
+      if (COMPACT) {
+        // the position of unit z inside its 8x8-unit quadrant comes from lane z & 63's entry of the lane-held table, the quadrant from z's top bits
+        const uint32_t pos = wave_read_lane(vpos, z & 63);
+        ux = (int)((pos & 7u) | ((uint32_t)(z >> 3) & 8u)); uy = (int)((pos >> 3) | ((uint32_t)(z >> 4) & 8u));
+      } else { ux = (int)((w >> 24) & 15u); uy = (int)(w >> 28); }
       if (x_ctb + ux * 4 >= pic_w || y_ctb + uy * 4 >= pic_h) { z++; continue; }
-      const int tb = (int)(w & 15u), fl = (int)((w >> 8) & 255u), mode = (int)((w >> 16) & 255u);
-      if (tb < 2 || tb > 5) { err = DEV_ERR_SYNTAX; break; }
+      if (COMPACT) {
+        tb = (int)(w & 3u) + 2; fl = (int)((w >> 2) & 31u); mode = (int)((w >> 7) & 127u);
+        if (w & 0x8000u) { err = DEV_ERR_SYNTAX; break; }
+      } else {
+        tb = (int)(w & 15u); fl = (int)((w >> 8) & 255u); mode = (int)((w >> 16) & 255u);
+        if (tb < 2 || tb > 5) { err = DEV_ERR_SYNTAX; break; }
+      }
       if (INTER && (mode & 64)) {   // a unit of an inter coded CU: prediction from the plane + residual
         if (!DUAL) {
           const Pix* pred = rec + (size_t)(y_ctb + uy * 4) * stride + (size_t)(x_ctb + ux * 4);
@@ -613,18 +659,38 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
           reconstruct_inter_block<Pix>(L, C, tile, pred, stride, cux * 2, cuy * 2, lgc, fl & cbf_bit, res_base + zc * 4, l, 32, 1, 1);
         }
       } else if (!DUAL) {
-        reconstruct_block<Pix>(L, C, top, ux * 4, uy * 4, tb, mode, fl & (cbf_bit | UF_PCM), res_base + z * 16);
+        const int cf = fl & (cbf_bit | UF_PCM);
+        const int16_t* res = res_base + z * 16;
+        if (SPEC) {
+          switch (tb) {
+            case 2: reconstruct_block<Pix, 2>(L, C, top, ux * 4, uy * 4, 2, mode, cf, res); break;
+            case 3: reconstruct_block<Pix, 3>(L, C, top, ux * 4, uy * 4, 3, mode, cf, res); break;
+            case 4: reconstruct_block<Pix, 4>(L, C, top, ux * 4, uy * 4, 4, mode, cf, res); break;
+            default: reconstruct_block<Pix, 5>(L, C, top, ux * 4, uy * 4, 5, mode, cf, res); break;
+          }
+        } else reconstruct_block<Pix, 0>(L, C, top, ux * 4, uy * 4, tb, mode, cf, res);
       } else if (tb > 2 || (z & 3) == 3) {
         // the 4x4 chroma blocks of four 4x4 luma TUs hang off the 4th unit (their flags are there); they sit at the quad's origin
         const int quad = tb == 2;
         const int zc = quad ? (z & ~3) : z, cux = quad ? (ux & ~1) : ux, cuy = quad ? (uy & ~1) : uy;
         const int lgc = quad ? 2 : tb - 1;
-        if (suby == 2) reconstruct_chroma_pair<Pix>(L, C, top, cux * 2, cuy * 2, lgc, mode, fl & (cbf_bit | UF_PCM), res_base + zc * 4);
-        else {
+        if (suby == 2) {
+          const int cf = fl & (cbf_bit | UF_PCM);
+          const int16_t* res = res_base + zc * 4;
+          if (SPEC) {
+            switch (lgc) {
+              case 2: reconstruct_chroma_pair<Pix, 2>(L, C, top, cux * 2, cuy * 2, 2, mode, cf, res); break;
+              case 3: reconstruct_chroma_pair<Pix, 3>(L, C, top, cux * 2, cuy * 2, 3, mode, cf, res); break;
+              default: reconstruct_chroma_pair<Pix, 4>(L, C, top, cux * 2, cuy * 2, 4, mode, cf, res); break;
+            }
+          } else reconstruct_chroma_pair<Pix, 0>(L, C, top, cux * 2, cuy * 2, lgc, mode, cf, res);
+        } else {
           // 4:2:2: two blocks one above the other, the upper one first (the lower one predicts from it); the lower one's flags sit in unit z ^ 1
-          const int fl2 = (int)((L.m_unit[z ^ 1] >> 8) & 255u);
-          reconstruct_chroma_pair<Pix>(L, C, top, cux * 2, cuy * 4, lgc, mode, fl & (cbf_bit | UF_PCM), res_base + zc * 8);
-          reconstruct_chroma_pair<Pix>(L, C, top, cux * 2, cuy * 4 + (1 << lgc), lgc, mode, fl2 & (cbf_bit | UF_PCM), res_base + zc * 8 + (1 << (2 * lgc)));
+          const int fl2 = COMPACT ? (int)(((uint32_t)L.m_unit[z ^ 1] >> 2) & 31u) : (int)(((uint32_t)L.m_unit[z ^ 1] >> 8) & 255u);
+#pragma nounroll
+          for (int lower = 0; lower < 2; lower++)
+            reconstruct_chroma_pair<Pix, 0>(L, C, top, cux * 2, cuy * 4 + (lower << lgc), lgc, mode, (lower ? fl2 : fl) & (cbf_bit | UF_PCM),
+                                            res_base + zc * 8 + (lower << (2 * lgc)));
         }
       }
       z += 1 << (2 * (tb - 2));
@@ -656,10 +722,10 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
   if (err && lane == 0) atomicCAS((int*)A.status, 0, err | (int)(0x40000000u) | (int)(my_row << 8));
 }
 
-template <typename Pix, bool INTER>
+template <typename Pix, bool INTER, bool SPEC, typename Unit>
 __device__ __forceinline__ void recon_wave(const ReconArgs& A)
 {
-  __shared__ ReconLds<Pix> L;
+  __shared__ ReconLds<Pix, Unit> L;
   const int lane = threadIdx.x;
   uint32_t t = 0;
   if (lane == 0) t = atomicAdd(A.ticket, 1u);
@@ -668,25 +734,33 @@ __device__ __forceinline__ void recon_wave(const ReconArgs& A)
   if (__hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // failed parse: maps are garbage
   const ReconWave wd = A.waves[ticket];
   const int cfi = A.pics[wd.pic].chroma_format_idc;
-  if (wd.comp == 0 || cfi == 3) { if (wd.comp == 0 || cfi) recon_rows<Pix, false, INTER>(A, wd, L, lane, (int)wd.comp); }   // luma; 4:4:4: one wave per plane
-  else if (cfi) recon_rows<Pix, true, INTER>(A, wd, L, lane, 1);                            // 4:2:0: comp 1 = Cb and Cr together
+  if (wd.comp == 0 || cfi == 3) { if (wd.comp == 0 || cfi) recon_rows<Pix, false, INTER, SPEC, Unit>(A, wd, L, lane, (int)wd.comp); }   // luma; 4:4:4: one wave per plane
+  else if (cfi) recon_rows<Pix, true, INTER, SPEC, Unit>(A, wd, L, lane, 1);                            // 4:2:0: comp 1 = Cb and Cr together
 }
 
-// 8-bit pictures: 7 waves per SIMD (<= 72 VGPRs; 6 KB of LDS per wave allows 26 per CU).  The 16-bit variant is limited by
-// its 10 KB of LDS per wave either way.
-__global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8(ReconArgs A) { recon_wave<uint8_t, false>(A); }
-__global__ __launch_bounds__(64) void k_recon16(ReconArgs A) { recon_wave<uint16_t, false>(A); }
+// 8-bit pictures: 7 waves per SIMD (<= 72 VGPRs).  Variants of the 8-bit intra kernel (HIPDEC_RECON_VARIANT, development: bit 0 = run-time block
+// sizes instead of the size-specialised copies, bit 1 = full unit words: 6336 B of LDS per wave = 25 waves per CU instead of 28).  The 16-bit
+// variant is limited by its 10 KB of LDS per wave either way.
+__global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8(ReconArgs A) { recon_wave<uint8_t, false, true, uint16_t>(A); }
+__global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8_v1(ReconArgs A) { recon_wave<uint8_t, false, false, uint16_t>(A); }
+__global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8_v2(ReconArgs A) { recon_wave<uint8_t, false, true, uint32_t>(A); }
+__global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8_v3(ReconArgs A) { recon_wave<uint8_t, false, false, uint32_t>(A); }
+__global__ __launch_bounds__(64) void k_recon16(ReconArgs A) { recon_wave<uint16_t, false, false, uint32_t>(A); }
 // batches with P pictures (sequence tracks): inter coded blocks take their prediction from the plane (k_mc) instead of the intra predictor
-__global__ __launch_bounds__(64) void k_recon8_inter(ReconArgs A) { recon_wave<uint8_t, true>(A); }
-__global__ __launch_bounds__(64) void k_recon16_inter(ReconArgs A) { recon_wave<uint16_t, true>(A); }
+__global__ __launch_bounds__(64) void k_recon8_inter(ReconArgs A) { recon_wave<uint8_t, true, false, uint32_t>(A); }
+__global__ __launch_bounds__(64) void k_recon16_inter(ReconArgs A) { recon_wave<uint16_t, true, false, uint32_t>(A); }
 
 void launch_recon(const ReconArgs& a, bool wide, hipStream_t s, bool inter)
 {
   if (!a.num_waves) return;
+  static const int variant = [] { const char* e = getenv("HIPDEC_RECON_VARIANT"); return e ? atoi(e) & 3 : 0; }();
   if (inter) {
     if (wide) hipLaunchKernelGGL(k_recon16_inter, dim3(a.num_waves), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(k_recon8_inter, dim3(a.num_waves), dim3(64), 0, s, a);
   } else if (wide) hipLaunchKernelGGL(k_recon16, dim3(a.num_waves), dim3(64), 0, s, a);
+  else if (variant == 1) hipLaunchKernelGGL(k_recon8_v1, dim3(a.num_waves), dim3(64), 0, s, a);
+  else if (variant == 2) hipLaunchKernelGGL(k_recon8_v2, dim3(a.num_waves), dim3(64), 0, s, a);
+  else if (variant == 3) hipLaunchKernelGGL(k_recon8_v3, dim3(a.num_waves), dim3(64), 0, s, a);
   else hipLaunchKernelGGL(k_recon8, dim3(a.num_waves), dim3(64), 0, s, a);
 }
 

@@ -52,7 +52,7 @@ def count(ln):
     for k in range(ln, max(ln - 6, 0), -1):
         if k in dyn:
             c = dyn[k]
-            return c / 64.0 if k in invec and "PC_VEC_BEGIN" not in text[k] else c
+            return c / 64.0 if k in invec else c   # the emulated-lane loop runs its header 65x and its body 64x per wave step
     return 0
 # enclosing function of every line (heuristic) and the number of inlined copies of each function: every copy
 # contributes at least one instruction to each executed statement, so the smallest static count of a function's
@@ -82,6 +82,9 @@ for (key, cls), cc in static_cls.items():
         srows.append((cc / k * count(ln), ln, cc / k, count(ln)))
 srows.sort(reverse=True)
 if os.environ.get("SALU"):
+    sbyf = collections.Counter()
+    for d, ln, c, k in srows: sbyf[func_at.get(ln, "?")] += d
+    print("-- SALU by function:", {f: round(d / (px or 1), 2) for f, d in sbyf.most_common(12)})
     print("-- top SALU lines")
     for d, ln, c, k in srows[:int(os.environ.get("TOPN", "45"))]: print("%5.2f/px line %4d static %5.1f x %9.0f  %s" % (d / (px or 1), ln, c, k, text[ln].strip()[:100]))
 rows.sort(reverse=True)
