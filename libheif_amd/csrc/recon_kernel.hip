@@ -42,24 +42,43 @@ namespace hipdec {
 
 namespace {
 
-// intraPredAngle / invAngle (8.4.4.2.6, tables 8-4 and 8-5) are functions of the distance k of the mode from the pure
-// horizontal (10) or vertical (26) direction; they are kept as packed immediates (a __constant__ array indexed by the mode
-// costs a global load and a vmcnt(0) wait - which also waits for the residual prefetch - in every angular block)
-__device__ __forceinline__ int angle_magnitude(int k)   // k = 0..8 -> 0, 2, 5, 9, 13, 17, 21, 26, 32
+// intraPredAngle / invAngle (8.4.4.2.6, tables 8-4 and 8-5) are functions of the distance k of the mode from the pure horizontal (10) or vertical (26)
+// direction.  The mode of a block is wave-uniform (a scalar register), so a table indexed by it is ONE scalar load from the constant cache whose
+// latency hides behind the reference-sample gather (the same table indexed per lane would be a vector load and a vmcnt(0) wait - which also waits
+// for the residual prefetch - in every angular block).  Entry: intraPredAngle in the low byte (signed), invAngle in the high half (signed; 0 where
+// the angle is not negative); it replaces ~ 17 scalar instructions of mode arithmetic per angular block.
+struct AngleTable {
+  int32_t v[64];
+  constexpr AngleTable() : v{}
+  {
+    constexpr int mag[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};
+    constexpr int inv[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};
+    for (int mode = 2; mode <= 34; mode++) {
+      const bool vertical = mode >= 18;
+      const int dm = mode - (vertical ? 26 : 10), k = dm < 0 ? -dm : dm;
+      const int angle = ((dm < 0) == vertical) ? -mag[k] : mag[k];
+      const int inv_angle = angle < 0 ? -inv[k] : 0;
+      v[mode] = (int32_t)(((uint32_t)angle & 255u) | ((uint32_t)inv_angle << 16));
+    }
+  }
+};
+__constant__ AngleTable k_angles;
+// 8.4.4.2.3: the reference samples of a block are filtered when minDistVerHor = Min(|mode - 26|, |mode - 10|) exceeds intraHorVerDistThres[nTbS] (7 / 1 / 0
+// for 8 / 16 / 32; planar counts with its mode number 0, DC never, 4x4 never): one bit per mode (bits 35..63 as the formula gives for them)
+constexpr uint64_t smooth_mode_mask(int n)
 {
-  constexpr uint64_t kMag = 0ull | (2ull << 7) | (5ull << 14) | (9ull << 21) | (13ull << 28) | (17ull << 35) | (21ull << 42) | (26ull << 49) | (32ull << 56);
-  return (int)((kMag >> (k * 7)) & 127u);
-}
-__device__ __forceinline__ int inv_angle_magnitude(int k)   // k = 1..8 -> round(8192 / angle): 4096, 1638, 910, 630, 482, 390, 315, 256
-{
-  constexpr uint64_t kLo = 4096ull | (1638ull << 16) | (910ull << 32) | (630ull << 48);
-  constexpr uint64_t kHi = 482ull | (390ull << 16) | (315ull << 32) | (256ull << 48);
-  return (int)(((k <= 4 ? kLo : kHi) >> (((k - 1) & 3) * 16)) & 0xffffu);
+  uint64_t m = 0;
+  for (int mode = 0; mode < 64; mode++) {
+    if (mode == 1 || n == 4) continue;
+    int d1 = mode - 26, d2 = mode - 10;
+    d1 = d1 < 0 ? -d1 : d1; d2 = d2 < 0 ? -d2 : d2;
+    const int thres = n == 8 ? 7 : (n == 16 ? 1 : 0);
+    if ((d1 < d2 ? d1 : d2) > thres) m |= 1ull << mode;
+  }
+  return m;
 }
 
-// Unit: the type of a unit-map entry.  uint32_t: the full word below; uint16_t: the compact form of the 8-bit intra kernel (the unit's position
-// comes from a lane-held table instead), which brings the wave's LDS to 5824 B: 28 waves per CU instead of 25.
-template <typename Pix, typename Unit = uint32_t>
+template <typename Pix>
 struct ReconLds {
   Pix tile[64 * 64];        // the CTB of this wave's component
   uint32_t top_raw[72];     // words of the line buffer covering x_ctb - 1 .. x_ctb + 2 * ctb - 1 (+ one pad word in front)
@@ -69,10 +88,12 @@ struct ReconLds {
   // units ux, uy in [-1, 2 * units_per_side): row 0 / bit 0 are the borders owned by the neighbouring CTBs, rows and bits
   // past the CTB stay 0 (not decoded yet), a unit of the CTB is set when its block has been reconstructed
   uint64_t avrow[33];
-  // per 4x4-luma unit (z order): log2 TU size | log2 CB size << 4 | UF_* flags << 8 | intra mode of this component << 16 |
-  // unit x << 24 | unit y << 28;   compact form: (log2 TU size - 2) | (UF_* flags & 31) << 2 | mode << 7 | invalid size << 15
-  Unit m_unit[256];
+  // per 4x4-luma unit (z order): log2 TU size | UM_OUTSIDE / UM_INVALID | UF_* flags << 8 | intra mode of this component << 16 |
+  // unit x << 24 | unit y << 28
+  uint32_t m_unit[256];
 };
+
+constexpr uint32_t UM_OUTSIDE = 16u, UM_INVALID = 32u;   // unit-word bits 4 / 5 (ReconLds::m_unit): the unit lies outside the picture / carries an impossible transform size
 
 __device__ __forceinline__ uint32_t compact1by1(uint32_t v)
 {
@@ -101,14 +122,10 @@ __device__ __forceinline__ void lds_sync()
 #endif
   __builtin_amdgcn_wave_barrier();
 }
-// the value lane `src` (wave-uniform) holds
-__device__ __forceinline__ uint32_t wave_read_lane(uint32_t v, int src)
+// bits into a word of the availability map: a DS atomic without return value (a plain |= is a read, a wait and a write)
+__device__ __forceinline__ void lds_or(uint64_t* p, uint64_t bits)
 {
-#ifndef HIPDEC_HOST_EMU
-  return (uint32_t)__builtin_amdgcn_readlane((int)v, src);
-#else
-  return (uint32_t)__shfl((int)v, src);
-#endif
+  __hip_atomic_fetch_or(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // all of this wave's global stores have left it (the CPU-test build of tests/emu orders them with a fence instead)
 __device__ __forceinline__ void drain_stores()
@@ -148,7 +165,7 @@ __device__ __forceinline__ void reconstruct_inter_block(LdsT& L, const Ctx& C, P
   }
   {
     const int kx = n >> ushx, rows = n >> ushy;    // units per row of the block (>= 1), unit rows
-    if (C.lane < (rows > 0 ? rows : 1)) L.avrow[(yb >> ushy) + 1 + C.lane] |= ((1ull << (kx > 0 ? kx : 1)) - 1ull) << ((xb >> ushx) + 1);
+    if (C.lane < (rows > 0 ? rows : 1)) lds_or(&L.avrow[(yb >> ushy) + 1 + C.lane], ((1ull << (kx > 0 ? kx : 1)) - 1ull) << ((xb >> ushx) + 1));
   }
   lds_sync();
 }
@@ -248,12 +265,10 @@ __device__ __forceinline__ void reconstruct_block(LdsT& L, const Ctx& C, const P
   // accessors in scan order: left column p[-1][k-1] = ref[2n - k], top row p[k-1][-1] = ref[2n + k]
   const uint16_t* ref = ref0;
   // ---- 8.4.4.2.3 smoothing of the reference samples (luma; chroma too with ChromaArrayType 3) ----
-  if (C.smooth && mode != 1 && n != 4) {
-    int d1 = mode - 26, d2 = mode - 10;
-    d1 = d1 < 0 ? -d1 : d1; d2 = d2 < 0 ? -d2 : d2;
-    const int min_dist = d1 < d2 ? d1 : d2;
-    const int thres = n == 8 ? 7 : (n == 16 ? 1 : 0);
-    if (min_dist > thres) {
+  if (C.smooth && n != 4) {
+    constexpr uint64_t k8 = smooth_mode_mask(8), k16 = smooth_mode_mask(16), k32 = smooth_mode_mask(32);
+    const uint64_t filtered_modes = n == 8 ? k8 : (n == 16 ? k16 : k32);
+    if ((filtered_modes >> (mode & 63)) & 1ull) {
       int strong = 0;
       if (C.strong && n == 32) {
         const int c0 = ref[n2], tl = ref[0], tm = ref[n], rt = ref[N - 1], rm = ref[n2 + n];  // corner, p[-1][63], p[-1][31], p[63][-1], p[31][-1]
@@ -328,10 +343,9 @@ __device__ __forceinline__ void reconstruct_block(LdsT& L, const Ctx& C, const P
     // main(k) = ref[2n + s k], side(k) = ref[2n - s k]  (s = +1 vertical, -1 horizontal)
     const int vertical = mode >= 18;
     const int s = vertical ? 1 : -1;
-    const int dm = mode - (vertical ? 26 : 10), k_dir = dm < 0 ? -dm : dm;                       // distance from the pure direction
-    const int angle = ((dm < 0) == vertical) ? -angle_magnitude(k_dir) : angle_magnitude(k_dir);   // modes 11..25 point up-left
-    const int inv_angle = angle < 0 ? -inv_angle_magnitude(k_dir) : 0;
-    const int pure = edge && (mode == 26 || mode == 10);     // pure vertical / horizontal with boundary smoothing
+    const int32_t ae = k_angles.v[mode & 63];                // modes 11..25 point up-left: negative angle, taps projected with invAngle
+    const int angle = (int)(int8_t)(ae & 255), inv_angle = ae >> 16;
+    const int pure = edge && angle == 0;                     // pure vertical / horizontal (modes 26 / 10) with boundary smoothing
     for (int it = 0; it < iters; it++) {
       const int idx = lane + 64 * it, x = idx & (n - 1), y = idx >> log2n;
       if (idx < nn) {
@@ -356,7 +370,7 @@ __device__ __forceinline__ void reconstruct_block(LdsT& L, const Ctx& C, const P
   // ---- the block's units are decoded now ----
   {
     const int k = n >> C.ush;    // units per side (>= 1)
-    if (lane < k) L.avrow[(yb >> C.ush) + 1 + lane] |= ((1ull << k) - 1ull) << ((xb >> C.ush) + 1);
+    if (lane < k) lds_or(&L.avrow[(yb >> C.ush) + 1 + lane], ((1ull << k) - 1ull) << ((xb >> C.ush) + 1));
   }
   lds_sync();
 }
@@ -477,9 +491,8 @@ __device__ __forceinline__ void reconstruct_chroma_pair(LdsT& L, const Ctx& C, c
   } else {
     const int vertical = mode >= 18;
     const int s = vertical ? 1 : -1;
-    const int dm = mode - (vertical ? 26 : 10), k_dir = dm < 0 ? -dm : dm;
-    const int angle = ((dm < 0) == vertical) ? -angle_magnitude(k_dir) : angle_magnitude(k_dir);
-    const int inv_angle = angle < 0 ? -inv_angle_magnitude(k_dir) : 0;
+    const int32_t ae = k_angles.v[mode & 63];
+    const int angle = (int)(int8_t)(ae & 255), inv_angle = ae >> 16;
     for (int it = 0; it < iters; it++) {
       const int idx = l + 32 * it, x = idx & (n - 1), y = idx >> log2n;
       if (idx < nn) {
@@ -501,7 +514,7 @@ __device__ __forceinline__ void reconstruct_chroma_pair(LdsT& L, const Ctx& C, c
 #undef NEXT_RES
   {
     const int k = n >> 1, rows = n >> ushy;    // units per row of the block, unit rows (4:2:2: a 4x4 block is two units wide and one tall)
-    if (lane < rows) L.avrow[(yb >> ushy) + 1 + lane] |= ((1ull << k) - 1ull) << ((xb >> 1) + 1);
+    if (lane < rows) lds_or(&L.avrow[(yb >> ushy) + 1 + lane], ((1ull << k) - 1ull) << ((xb >> 1) + 1));
   }
   lds_sync();
 }
@@ -513,10 +526,9 @@ __device__ __forceinline__ void reconstruct_chroma_pair(LdsT& L, const Ctx& C, c
 // DUAL = true: the 4:2:0 Cb (lanes 0..31) and Cr (lanes 32..63) side by side — h / l below are a lane's half and its index inside
 // the half, LW the lanes one component has.
 // SPEC: intra blocks go through the size-specialised copies of the block functions (4:2:2 chroma pairs keep the run-time size).
-template <typename Pix, bool DUAL, bool INTER, bool SPEC, typename Unit>
-__device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& wd, ReconLds<Pix, Unit>& L, int lane, int plane)
+template <typename Pix, bool DUAL, bool INTER, bool SPEC>
+__device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& wd, ReconLds<Pix>& L, int lane, int plane)
 {
-  constexpr bool COMPACT = sizeof(Unit) == 2;
   constexpr int ES = (int)sizeof(Pix);
   constexpr int LW = DUAL ? 32 : 64;
   constexpr int PPW = 4 / ES;            // pixels per 32-bit word
@@ -556,7 +568,6 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
   uint32_t* top_raw = L.top_raw + (DUAL ? h * 36 : 0);
   const int lg_wpr = C.lg_ctbc - (ES == 1 ? 2 : 1);      // log2 of the words per tile row
   const int wpr = 1 << lg_wpr;
-  const uint32_t vpos = compact1by1((uint32_t)lane) | (compact1by1((uint32_t)lane >> 1) << 3);   // unit lane of a quadrant: x | y << 3 (compact unit words)
 
   for (int cy = (int)wd.first_row; cy < ctb_h && !err; cy += (int)wd.stride) {
   my_row = wd.base_row + (uint32_t)cy;     // batch row index
@@ -602,12 +613,10 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
         const uint32_t ux = compact1by1((uint32_t)i), uy = compact1by1((uint32_t)i >> 1);   // i is a multiple of 4: units i..i+3 are a 2x2 quad
 #pragma nounroll
         for (int k = 0; k < 4; k++) {
-          if (COMPACT) {
-            const uint32_t tbk = (sz >> (8 * k)) & 15u;
-            L.m_unit[i + k] = (Unit)(((tbk - 2u) & 3u) | (((fl >> (8 * k)) & 31u) << 2) | (((md >> (8 * k)) & mode_mask & 127u) << 7) | ((tbk - 2u) > 3u ? 0x8000u : 0u));
-          } else
-            L.m_unit[i + k] = (Unit)(((sz >> (8 * k)) & 255u) | (((fl >> (8 * k)) & 255u) << 8) | (((md >> (8 * k)) & mode_mask) << 16) |
-                                     ((ux + (k & 1)) << 24) | ((uy + (k >> 1)) << 28));
+          // units right of / below the picture are skipped, a transform size outside 4..32 is a broken map: both are decided here by the lanes
+          const uint32_t tbk = (sz >> (8 * k)) & 15u, uxk = ux + (k & 1), uyk = uy + (k >> 1);
+          const uint32_t special = (x_ctb + (int)uxk * 4 >= pic_w || y_ctb + (int)uyk * 4 >= pic_h) ? UM_OUTSIDE : ((tbk - 2u) > 3u ? UM_INVALID : 0u);
+          L.m_unit[i + k] = tbk | special | (((fl >> (8 * k)) & 255u) << 8) | (((md >> (8 * k)) & mode_mask) << 16) | (uxk << 24) | (uyk << 28);
         }
       }
       // availability rows: the borders come from the neighbouring CTBs (slice / tile / picture limits are in ci.avail,
@@ -633,20 +642,14 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
     int z = 0;
     while (z < units) {
       const uint32_t w = L.m_unit[z];
-      int ux, uy, tb, fl, mode;
-      if (COMPACT) {
-        // the position of unit z inside its 8x8-unit quadrant comes from lane z & 63's entry of the lane-held table, the quadrant from z's top bits
-        const uint32_t pos = wave_read_lane(vpos, z & 63);
-        ux = (int)((pos & 7u) | ((uint32_t)(z >> 3) & 8u)); uy = (int)((pos >> 3) | ((uint32_t)(z >> 4) & 8u));
-      } else { ux = (int)((w >> 24) & 15u); uy = (int)(w >> 28); }
-      if (x_ctb + ux * 4 >= pic_w || y_ctb + uy * 4 >= pic_h) { z++; continue; }
-      if (COMPACT) {
-        tb = (int)(w & 3u) + 2; fl = (int)((w >> 2) & 31u); mode = (int)((w >> 7) & 127u);
-        if (w & 0x8000u) { err = DEV_ERR_SYNTAX; break; }
-      } else {
-        tb = (int)(w & 15u); fl = (int)((w >> 8) & 255u); mode = (int)((w >> 16) & 255u);
-        if (tb < 2 || tb > 5) { err = DEV_ERR_SYNTAX; break; }
+      if (w & (UM_OUTSIDE | UM_INVALID)) {
+        if (w & UM_OUTSIDE) { z++; continue; }
+        err = DEV_ERR_SYNTAX; break;
       }
+      const int ux = (int)((w >> 24) & 15u), uy = (int)(w >> 28);
+      const int tb = (int)(w & 15u), fl = (int)((w >> 8) & 255u), mode = (int)((w >> 16) & 255u);
+      // the chroma pair: the 4x4 chroma blocks of four 4x4 luma TUs hang off the quad's 4th unit (their flags are there) - straight to it
+      if (DUAL && tb == 2 && (z & 3) != 3) { z |= 3; continue; }
       if (INTER && (mode & 64)) {   // a unit of an inter coded CU: prediction from the plane + residual
         if (!DUAL) {
           const Pix* pred = rec + (size_t)(y_ctb + uy * 4) * stride + (size_t)(x_ctb + ux * 4);
@@ -686,7 +689,7 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
           } else reconstruct_chroma_pair<Pix, 0>(L, C, top, cux * 2, cuy * 2, lgc, mode, cf, res);
         } else {
           // 4:2:2: two blocks one above the other, the upper one first (the lower one predicts from it); the lower one's flags sit in unit z ^ 1
-          const int fl2 = COMPACT ? (int)(((uint32_t)L.m_unit[z ^ 1] >> 2) & 31u) : (int)(((uint32_t)L.m_unit[z ^ 1] >> 8) & 255u);
+          const int fl2 = (int)((L.m_unit[z ^ 1] >> 8) & 255u);
 #pragma nounroll
           for (int lower = 0; lower < 2; lower++)
             reconstruct_chroma_pair<Pix, 0>(L, C, top, cux * 2, cuy * 4 + (lower << lgc), lgc, mode, (lower ? fl2 : fl) & (cbf_bit | UF_PCM),
@@ -722,10 +725,10 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
   if (err && lane == 0) atomicCAS((int*)A.status, 0, err | (int)(0x40000000u) | (int)(my_row << 8));
 }
 
-template <typename Pix, bool INTER, bool SPEC, typename Unit>
+template <typename Pix, bool INTER, bool SPEC>
 __device__ __forceinline__ void recon_wave(const ReconArgs& A)
 {
-  __shared__ ReconLds<Pix, Unit> L;
+  __shared__ ReconLds<Pix> L;
   const int lane = threadIdx.x;
   uint32_t t = 0;
   if (lane == 0) t = atomicAdd(A.ticket, 1u);
@@ -734,21 +737,24 @@ __device__ __forceinline__ void recon_wave(const ReconArgs& A)
   if (__hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // failed parse: maps are garbage
   const ReconWave wd = A.waves[ticket];
   const int cfi = A.pics[wd.pic].chroma_format_idc;
-  if (wd.comp == 0 || cfi == 3) { if (wd.comp == 0 || cfi) recon_rows<Pix, false, INTER, SPEC, Unit>(A, wd, L, lane, (int)wd.comp); }   // luma; 4:4:4: one wave per plane
-  else if (cfi) recon_rows<Pix, true, INTER, SPEC, Unit>(A, wd, L, lane, 1);                            // 4:2:0: comp 1 = Cb and Cr together
+  if (wd.comp == 0 || cfi == 3) { if (wd.comp == 0 || cfi) recon_rows<Pix, false, INTER, SPEC>(A, wd, L, lane, (int)wd.comp); }   // luma; 4:4:4: one wave per plane
+  else if (cfi) recon_rows<Pix, true, INTER, SPEC>(A, wd, L, lane, 1);                            // 4:2:0: comp 1 = Cb and Cr together
 }
 
-// 8-bit pictures: 7 waves per SIMD (<= 72 VGPRs).  Variants of the 8-bit intra kernel (HIPDEC_RECON_VARIANT, development: bit 0 = run-time block
-// sizes instead of the size-specialised copies, bit 1 = full unit words: 6336 B of LDS per wave = 25 waves per CU instead of 28).  The 16-bit
-// variant is limited by its 10 KB of LDS per wave either way.
-__global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8(ReconArgs A) { recon_wave<uint8_t, false, true, uint16_t>(A); }
-__global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8_v1(ReconArgs A) { recon_wave<uint8_t, false, false, uint16_t>(A); }
-__global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8_v2(ReconArgs A) { recon_wave<uint8_t, false, true, uint32_t>(A); }
-__global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8_v3(ReconArgs A) { recon_wave<uint8_t, false, false, uint32_t>(A); }
-__global__ __launch_bounds__(64) void k_recon16(ReconArgs A) { recon_wave<uint16_t, false, false, uint32_t>(A); }
+// 8-bit pictures: 7 waves per SIMD by registers (<= 72 VGPRs), 26 by LDS (6072 B per wave, handed out in 512 B granules).  Measured on 1024 4K stills
+// (profiles/r04_recon_variants.txt): size-specialised block functions 78.0 -> 73.6 ms; a compact unit map that allowed 28 waves per CU bought nothing
+// (74.3 ms) - the kernel is bound by instruction issue, not by latency hiding.  HIPDEC_RECON_VARIANT=1 launches the run-time-size build (development).
+// The 16-bit variant is limited by its 10 KB of LDS per wave either way.
+__global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8(ReconArgs A) { recon_wave<uint8_t, false, true>(A); }
+__global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8_generic(ReconArgs A) { recon_wave<uint8_t, false, false>(A); }
+#ifndef HIPDEC_HOST_EMU
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_recon8_occ6(ReconArgs A) { recon_wave<uint8_t, false, true>(A); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_recon8_occ5(ReconArgs A) { recon_wave<uint8_t, false, true>(A); }
+#endif
+__global__ __launch_bounds__(64) void k_recon16(ReconArgs A) { recon_wave<uint16_t, false, false>(A); }
 // batches with P pictures (sequence tracks): inter coded blocks take their prediction from the plane (k_mc) instead of the intra predictor
-__global__ __launch_bounds__(64) void k_recon8_inter(ReconArgs A) { recon_wave<uint8_t, true, false, uint32_t>(A); }
-__global__ __launch_bounds__(64) void k_recon16_inter(ReconArgs A) { recon_wave<uint16_t, true, false, uint32_t>(A); }
+__global__ __launch_bounds__(64) void k_recon8_inter(ReconArgs A) { recon_wave<uint8_t, true, false>(A); }
+__global__ __launch_bounds__(64) void k_recon16_inter(ReconArgs A) { recon_wave<uint16_t, true, false>(A); }
 
 void launch_recon(const ReconArgs& a, bool wide, hipStream_t s, bool inter)
 {
@@ -758,9 +764,11 @@ void launch_recon(const ReconArgs& a, bool wide, hipStream_t s, bool inter)
     if (wide) hipLaunchKernelGGL(k_recon16_inter, dim3(a.num_waves), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(k_recon8_inter, dim3(a.num_waves), dim3(64), 0, s, a);
   } else if (wide) hipLaunchKernelGGL(k_recon16, dim3(a.num_waves), dim3(64), 0, s, a);
-  else if (variant == 1) hipLaunchKernelGGL(k_recon8_v1, dim3(a.num_waves), dim3(64), 0, s, a);
-  else if (variant == 2) hipLaunchKernelGGL(k_recon8_v2, dim3(a.num_waves), dim3(64), 0, s, a);
-  else if (variant == 3) hipLaunchKernelGGL(k_recon8_v3, dim3(a.num_waves), dim3(64), 0, s, a);
+  else if (variant == 1) hipLaunchKernelGGL(k_recon8_generic, dim3(a.num_waves), dim3(64), 0, s, a);
+#ifndef HIPDEC_HOST_EMU
+  else if (variant == 2) hipLaunchKernelGGL(k_recon8_occ6, dim3(a.num_waves), dim3(64), 0, s, a);
+  else if (variant == 3) hipLaunchKernelGGL(k_recon8_occ5, dim3(a.num_waves), dim3(64), 0, s, a);
+#endif
   else hipLaunchKernelGGL(k_recon8, dim3(a.num_waves), dim3(64), 0, s, a);
 }
 

@@ -210,6 +210,7 @@ void launch(dim3 grid, dim3 block, F&& fn)
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_ACQUIRE)
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
+#define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), __ATOMIC_ACQ_REL)
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define __builtin_amdgcn_s_sleep(n) do { hipemu::yield_lane(); sched_yield(); } while (0)
 #define __builtin_amdgcn_wave_barrier() ((void)hipemu::wave_converge(false, 0))
