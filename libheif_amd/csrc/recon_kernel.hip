@@ -27,7 +27,6 @@
 //     stores (only the next kernel reads them).
 //   * HBM traffic per luma pixel: 1.5*s written + <= 3 B residual and 0.3 B unit maps read.
 #include <hip/hip_runtime.h>
-#include <cstdlib>
 #include "hevc_device.h"
 #include "kernels.h"
 
@@ -152,8 +151,8 @@ struct Ctx {
 // A transform block of a coding unit that is NOT intra coded (P pictures): the prediction samples are in the reconstruction plane already
 // (k_mc, inter_kernels.hip); the block enters the LDS tile with its residual added, so that intra blocks next to it predict from it and the
 // CTB leaves LDS as a whole.  LW lanes (64, or 32 per half of the chroma pair) cover the block; `pred` points at the block in the plane.
-template <typename Pix, typename LdsT>
-__device__ __forceinline__ void reconstruct_inter_block(LdsT& L, const Ctx& C, Pix* tile, const Pix* pred, uint32_t pstride, int xb, int yb, int log2n, int cbf,
+template <typename Pix>
+__device__ __forceinline__ void reconstruct_inter_block(ReconLds<Pix>& L, const Ctx& C, Pix* tile, const Pix* pred, uint32_t pstride, int xb, int yb, int log2n, int cbf,
                                                         const int16_t* res, int l, int LW, int ushx, int ushy)
 {
   const int n = 1 << log2n, nn = n * n, lg_ctbc = C.lg_ctbc, maxv = C.maxv;
@@ -172,13 +171,10 @@ __device__ __forceinline__ void reconstruct_inter_block(LdsT& L, const Ctx& C, P
 
 // One transform block: prediction (+ residual) into the LDS tile.
 //   (xb, yb): block origin inside the CTB in component samples; log2n: block size
-//   LOG2N: the block size as a compile-time constant (the size-specialised build: pass counts, the extra sample, the smoothing threshold and the
-//   residual rotation fold away - a block costs about a third fewer scalar instructions), 0 = taken from `log2n_rt`
-template <typename Pix, int LOG2N, typename LdsT>
-__device__ __forceinline__ void reconstruct_block(LdsT& L, const Ctx& C, const Pix* top, int xb, int yb, int log2n_rt, int mode, int cbf, const int16_t* res)
+template <typename Pix>
+__device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C, const Pix* top, int xb, int yb, int log2n, int mode, int cbf, const int16_t* res)
 {
   const int lane = C.lane;
-  const int log2n = LOG2N ? LOG2N : log2n_rt;
   const int n = 1 << log2n, n2 = 2 * n, N = 4 * n + 1, nn = n * n;
   const int lg_ctbc = C.lg_ctbc, maxv = C.maxv;
   Pix* tile = L.tile;
@@ -380,12 +376,11 @@ __device__ __forceinline__ void reconstruct_block(LdsT& L, const Ctx& C, const P
 // the samples, the residuals and the coded-block flags differ — so one instruction stream reconstructs both blocks.
 //   LDS: the Cr tile sits behind the Cb tile (each 1 << lg_ctbc wide, 1 << lg_ctbh tall), left borders at left[0..63] / left[64..127], reference lines
 //   at refbuf0[1 + 67 h ...];  `top`, `cbf` and `res` are this lane's half's.
-template <typename Pix, int LOG2N, typename LdsT>
-__device__ __forceinline__ void reconstruct_chroma_pair(LdsT& L, const Ctx& C, const Pix* top, int xb, int yb, int log2n_rt, int mode, int cbf,
+template <typename Pix>
+__device__ __forceinline__ void reconstruct_chroma_pair(ReconLds<Pix>& L, const Ctx& C, const Pix* top, int xb, int yb, int log2n, int mode, int cbf,
                                                         const int16_t* res)
 {
   const int lane = C.lane, l = lane & 31, h = lane >> 5;
-  const int log2n = LOG2N ? LOG2N : log2n_rt;
   const int n = 1 << log2n, n2 = 2 * n, N = 4 * n + 1, nn = n * n;
   const int lg_ctbc = C.lg_ctbc, maxv = C.maxv;
   Pix* tile = L.tile + (h << (lg_ctbc + C.lg_ctbh));
@@ -525,8 +520,7 @@ __device__ __forceinline__ void reconstruct_chroma_pair(LdsT& L, const Ctx& C, c
 // picture, the Cb / Cr plane (plane 1 / 2: same geometry as luma, the chroma modes / flags / bit depth, no boundary filters).
 // DUAL = true: the 4:2:0 Cb (lanes 0..31) and Cr (lanes 32..63) side by side — h / l below are a lane's half and its index inside
 // the half, LW the lanes one component has.
-// SPEC: intra blocks go through the size-specialised copies of the block functions (4:2:2 chroma pairs keep the run-time size).
-template <typename Pix, bool DUAL, bool INTER, bool SPEC>
+template <typename Pix, bool DUAL, bool INTER>
 __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& wd, ReconLds<Pix>& L, int lane, int plane)
 {
   constexpr int ES = (int)sizeof(Pix);
@@ -662,38 +656,20 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
           reconstruct_inter_block<Pix>(L, C, tile, pred, stride, cux * 2, cuy * 2, lgc, fl & cbf_bit, res_base + zc * 4, l, 32, 1, 1);
         }
       } else if (!DUAL) {
-        const int cf = fl & (cbf_bit | UF_PCM);
-        const int16_t* res = res_base + z * 16;
-        if (SPEC) {
-          switch (tb) {
-            case 2: reconstruct_block<Pix, 2>(L, C, top, ux * 4, uy * 4, 2, mode, cf, res); break;
-            case 3: reconstruct_block<Pix, 3>(L, C, top, ux * 4, uy * 4, 3, mode, cf, res); break;
-            case 4: reconstruct_block<Pix, 4>(L, C, top, ux * 4, uy * 4, 4, mode, cf, res); break;
-            default: reconstruct_block<Pix, 5>(L, C, top, ux * 4, uy * 4, 5, mode, cf, res); break;
-          }
-        } else reconstruct_block<Pix, 0>(L, C, top, ux * 4, uy * 4, tb, mode, cf, res);
+        reconstruct_block<Pix>(L, C, top, ux * 4, uy * 4, tb, mode, fl & (cbf_bit | UF_PCM), res_base + z * 16);
       } else if (tb > 2 || (z & 3) == 3) {
         // the 4x4 chroma blocks of four 4x4 luma TUs hang off the 4th unit (their flags are there); they sit at the quad's origin
         const int quad = tb == 2;
         const int zc = quad ? (z & ~3) : z, cux = quad ? (ux & ~1) : ux, cuy = quad ? (uy & ~1) : uy;
         const int lgc = quad ? 2 : tb - 1;
-        if (suby == 2) {
-          const int cf = fl & (cbf_bit | UF_PCM);
-          const int16_t* res = res_base + zc * 4;
-          if (SPEC) {
-            switch (lgc) {
-              case 2: reconstruct_chroma_pair<Pix, 2>(L, C, top, cux * 2, cuy * 2, 2, mode, cf, res); break;
-              case 3: reconstruct_chroma_pair<Pix, 3>(L, C, top, cux * 2, cuy * 2, 3, mode, cf, res); break;
-              default: reconstruct_chroma_pair<Pix, 4>(L, C, top, cux * 2, cuy * 2, 4, mode, cf, res); break;
-            }
-          } else reconstruct_chroma_pair<Pix, 0>(L, C, top, cux * 2, cuy * 2, lgc, mode, cf, res);
-        } else {
+        if (suby == 2) reconstruct_chroma_pair<Pix>(L, C, top, cux * 2, cuy * 2, lgc, mode, fl & (cbf_bit | UF_PCM), res_base + zc * 4);
+        else {
           // 4:2:2: two blocks one above the other, the upper one first (the lower one predicts from it); the lower one's flags sit in unit z ^ 1
           const int fl2 = (int)((L.m_unit[z ^ 1] >> 8) & 255u);
 #pragma nounroll
           for (int lower = 0; lower < 2; lower++)
-            reconstruct_chroma_pair<Pix, 0>(L, C, top, cux * 2, cuy * 4 + (lower << lgc), lgc, mode, (lower ? fl2 : fl) & (cbf_bit | UF_PCM),
-                                            res_base + zc * 8 + (lower << (2 * lgc)));
+            reconstruct_chroma_pair<Pix>(L, C, top, cux * 2, cuy * 4 + (lower << lgc), lgc, mode, (lower ? fl2 : fl) & (cbf_bit | UF_PCM),
+                                         res_base + zc * 8 + (lower << (2 * lgc)));
         }
       }
       z += 1 << (2 * (tb - 2));
@@ -725,7 +701,7 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
   if (err && lane == 0) atomicCAS((int*)A.status, 0, err | (int)(0x40000000u) | (int)(my_row << 8));
 }
 
-template <typename Pix, bool INTER, bool SPEC>
+template <typename Pix, bool INTER>
 __device__ __forceinline__ void recon_wave(const ReconArgs& A)
 {
   __shared__ ReconLds<Pix> L;
@@ -737,38 +713,29 @@ __device__ __forceinline__ void recon_wave(const ReconArgs& A)
   if (__hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // failed parse: maps are garbage
   const ReconWave wd = A.waves[ticket];
   const int cfi = A.pics[wd.pic].chroma_format_idc;
-  if (wd.comp == 0 || cfi == 3) { if (wd.comp == 0 || cfi) recon_rows<Pix, false, INTER, SPEC>(A, wd, L, lane, (int)wd.comp); }   // luma; 4:4:4: one wave per plane
-  else if (cfi) recon_rows<Pix, true, INTER, SPEC>(A, wd, L, lane, 1);                            // 4:2:0: comp 1 = Cb and Cr together
+  if (wd.comp == 0 || cfi == 3) { if (wd.comp == 0 || cfi) recon_rows<Pix, false, INTER>(A, wd, L, lane, (int)wd.comp); }   // luma; 4:4:4: one wave per plane
+  else if (cfi) recon_rows<Pix, true, INTER>(A, wd, L, lane, 1);                            // 4:2:0: comp 1 = Cb and Cr together
 }
 
-// 8-bit pictures: 7 waves per SIMD by registers (<= 72 VGPRs), 26 by LDS (6072 B per wave, handed out in 512 B granules).  Measured on 1024 4K stills
-// (profiles/r04_recon_variants.txt): size-specialised block functions 78.0 -> 73.6 ms; a compact unit map that allowed 28 waves per CU bought nothing
-// (74.3 ms) - the kernel is bound by instruction issue, not by latency hiding.  HIPDEC_RECON_VARIANT=1 launches the run-time-size build (development).
-// The 16-bit variant is limited by its 10 KB of LDS per wave either way.
-__global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8(ReconArgs A) { recon_wave<uint8_t, false, true>(A); }
-__global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8_generic(ReconArgs A) { recon_wave<uint8_t, false, false>(A); }
-#ifndef HIPDEC_HOST_EMU
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_recon8_occ6(ReconArgs A) { recon_wave<uint8_t, false, true>(A); }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_recon8_occ5(ReconArgs A) { recon_wave<uint8_t, false, true>(A); }
-#endif
-__global__ __launch_bounds__(64) void k_recon16(ReconArgs A) { recon_wave<uint16_t, false, false>(A); }
+// 8-bit pictures: 7 waves per SIMD by registers (<= 72 VGPRs), 26 per CU by LDS (6072 B per wave, handed out in 512 B granules).  What was measured
+// on the way here (1024 4K stills, profiles/r04_recon_variants.txt): the kernel is bound by instruction issue, not by latency hiding - a compact unit
+// map that allowed 28 waves per CU bought nothing, 6 / 5 waves per SIMD with fewer spills cost 1 % / 10 %; fewer scalar instructions per block did
+// pay (78.0 -> 72.8 ms: mode tables, DS atomics on the availability map, units classified at staging, the chroma pair skipping to a quad's 4th
+// unit); size-specialised copies of the block functions gained 5 % before those changes and nothing after them (74.8 ms; twice the code), so the
+// block functions keep their run-time sizes.  The 16-bit variant is limited by its 10 KB of LDS per wave either way.
+__global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8(ReconArgs A) { recon_wave<uint8_t, false>(A); }
+__global__ __launch_bounds__(64) void k_recon16(ReconArgs A) { recon_wave<uint16_t, false>(A); }
 // batches with P pictures (sequence tracks): inter coded blocks take their prediction from the plane (k_mc) instead of the intra predictor
-__global__ __launch_bounds__(64) void k_recon8_inter(ReconArgs A) { recon_wave<uint8_t, true, false>(A); }
-__global__ __launch_bounds__(64) void k_recon16_inter(ReconArgs A) { recon_wave<uint16_t, true, false>(A); }
+__global__ __launch_bounds__(64) void k_recon8_inter(ReconArgs A) { recon_wave<uint8_t, true>(A); }
+__global__ __launch_bounds__(64) void k_recon16_inter(ReconArgs A) { recon_wave<uint16_t, true>(A); }
 
 void launch_recon(const ReconArgs& a, bool wide, hipStream_t s, bool inter)
 {
   if (!a.num_waves) return;
-  static const int variant = [] { const char* e = getenv("HIPDEC_RECON_VARIANT"); return e ? atoi(e) & 3 : 0; }();
   if (inter) {
     if (wide) hipLaunchKernelGGL(k_recon16_inter, dim3(a.num_waves), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(k_recon8_inter, dim3(a.num_waves), dim3(64), 0, s, a);
   } else if (wide) hipLaunchKernelGGL(k_recon16, dim3(a.num_waves), dim3(64), 0, s, a);
-  else if (variant == 1) hipLaunchKernelGGL(k_recon8_generic, dim3(a.num_waves), dim3(64), 0, s, a);
-#ifndef HIPDEC_HOST_EMU
-  else if (variant == 2) hipLaunchKernelGGL(k_recon8_occ6, dim3(a.num_waves), dim3(64), 0, s, a);
-  else if (variant == 3) hipLaunchKernelGGL(k_recon8_occ5, dim3(a.num_waves), dim3(64), 0, s, a);
-#endif
   else hipLaunchKernelGGL(k_recon8, dim3(a.num_waves), dim3(64), 0, s, a);
 }
 

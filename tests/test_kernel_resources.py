@@ -67,8 +67,10 @@ def test_occupancy_budgets():
     assert parse6["vgpr"] <= 80 and parse6["scratch"] <= 128
     gen8 = _find(ks, "k_parse_gen_occ8")[0]                               # the build with the 4:2:2 / 4:4:4 paths (batches that hold such pictures)
     assert gen8["vgpr"] <= 64 and gen8["scratch"] <= 184
-    recon8 = _find(ks, "k_recon8")[0]
-    assert recon8["vgpr"] <= 72 and recon8["scratch"] <= 128 and recon8["lds"] <= 6400   # 7 waves / SIMD, 26 one-wave groups per CU
+    recon8 = _find(ks, "8k_recon8E")[0]
+    # 7 waves / SIMD by registers, 26 one-wave groups per CU by LDS (512 B granules); the spills sit in the per-wave / per-CTB code around the block
+    # loop (scalar registers parked in VGPR lanes, 172 B of scratch), not in the block functions
+    assert recon8["vgpr"] <= 72 and recon8["scratch"] <= 176 and recon8["lds"] <= 6144
     residual = _find(ks, "k_residual")[0]
     assert residual["lds"] <= 23040 and residual["vgpr"] <= 64          # 7 workgroups of 4 waves per CU: LDS is handed out in 512 B granules, 7 x 23040 <= 160 KB
                                                                           # (measured: 23240 B -> 6 workgroups per CU, k_residual 84 -> 91.5 ms at 2048 4K stills)
