@@ -2064,7 +2064,6 @@ static void decode_slice(Dec* d, int nal_type, const uint8_t* nal, size_t nal_le
     }
     if (hdr.slice_type != 2) {   /* 7.3.6.1, P / B slice */
       const int is_b = hdr.slice_type == 0;
-      if (s->chroma_format_idc > 1) fail(d, "unsupported: P / B slices of a 4:2:2 / 4:4:4 picture");
       if (p->constrained_intra_pred_flag) fail(d, "unsupported: constrained_intra_pred_flag with P / B slices");
       hdr.slice_temporal_mvp = slice_temporal_mvp;
       hdr.num_ref_idx_l0_active = p->num_ref_idx_l0_default_active;

@@ -347,7 +347,7 @@ static const int8_t fC[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2
 
 static void mc_block(Dec* d, const RefPic* ref, int cIdx, int xP, int yP, int w, int h, int mvx, int mvy, int16_t* out /* w x h */)
 {
-  /* (xP, yP), w, h in samples of component cIdx; mv in quarter luma samples = eighth chroma samples for 4:2:0 */
+  /* (xP, yP), w, h in samples of component cIdx; luma: mv in quarter samples; chroma: in eighth samples (the caller applies 8.5.3.2.10) */
   const SPS* s = d->s;
   int W = cIdx ? d->Wc : d->W, H = cIdx ? d->Hc : d->H;
   int bitDepth = cIdx ? s->bit_depth_chroma : s->bit_depth_luma;
@@ -390,7 +390,11 @@ static void predict_component(Dec* d, int cIdx, int xP, int yP, int w, int h, co
   for (int X = 0; X < 2; X++)
     if (m->pred_flag[X]) {
       pred[X] = (int16_t*)xcalloc(d, (size_t)w * h, sizeof(int16_t));
-      mc_block(d, &d->dpb[sh->ref_list[X][m->ref_idx[X]]], cIdx, xP, yP, w, h, m->mv[X][0], m->mv[X][1], pred[X]);
+      /* 8.5.3.2.10: mvCLX = mvLX * 2 / SubWidthC (SubHeightC), in units of 1/8 chroma sample: the luma vector itself where the chroma plane is
+         subsampled in that direction, twice it where it is not (4:2:2 vertically, 4:4:4 both ways: only the even eighths occur then) */
+      int mvx = m->mv[X][0], mvy = m->mv[X][1];
+      if (cIdx) { if (s->chroma_format_idc == 3) mvx *= 2; if (s->chroma_format_idc != 1) mvy *= 2; }
+      mc_block(d, &d->dpb[sh->ref_list[X][m->ref_idx[X]]], cIdx, xP, yP, w, h, mvx, mvy, pred[X]);
     }
   uint16_t* dst = d->rec[cIdx];
   int shift1 = 14 - bitDepth;
@@ -425,9 +429,10 @@ static void predict_component(Dec* d, int cIdx, int xP, int yP, int w, int h, co
 static void predict_pu(Dec* d, int xPb, int yPb, int nPbW, int nPbH, const Motion* m)
 {
   predict_component(d, 0, xPb, yPb, nPbW, nPbH, m);
-  if (d->s->chroma_format_idc == 1) {
-    predict_component(d, 1, xPb / 2, yPb / 2, nPbW / 2, nPbH / 2, m);
-    predict_component(d, 2, xPb / 2, yPb / 2, nPbW / 2, nPbH / 2, m);
+  if (d->s->chroma_format_idc) {
+    const int sw = d->s->chroma_format_idc == 3 ? 1 : 2, shh = d->s->chroma_format_idc == 1 ? 2 : 1;   /* SubWidthC, SubHeightC */
+    predict_component(d, 1, xPb / sw, yPb / shh, nPbW / sw, nPbH / shh, m);
+    predict_component(d, 2, xPb / sw, yPb / shh, nPbW / sw, nPbH / shh, m);
   }
 }
 

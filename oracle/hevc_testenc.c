@@ -606,7 +606,8 @@ static ChromaCbf enc_transform_tree(Enc* e, CuCtx* cu, int x0, int y0, int xBase
     for (int k = 0; k < 4; k++) cbf4[k] = analyse_tb(e, x0 / 2, y0 + (k & 1) * nC, log2C, 1 + (k >> 1), cu->chroma_mode, lv[k], &ts4[k]);
     if (pending) { d->CuQpDeltaVal = saved_delta; d->cur_qp_y = saved_qp; }
     for (int k = 0; k < 4; k++) e->ev[sl[k]].val = cbf4[k];
-    EV_D(CTX_CBF_LUMA + (trafoDepth == 0 ? 1 : 0), cbfY);
+    /* 7.3.8.8: an inter coding unit's root leaf without chroma coefficients - all four flags of 4:2:2 - does not code cbf_luma (inferred 1) */
+    if (!cu->inter || trafoDepth != 0 || cbf4[0] || cbf4[1] || cbf4[2] || cbf4[3]) EV_D(CTX_CBF_LUMA + (trafoDepth == 0 ? 1 : 0), cbfY);
     if (cbfY || cbf4[0] || cbf4[1] || cbf4[2] || cbf4[3]) enc_cu_qp_delta(e);
     if (cbfY) emit_residual(e, lY, log2TrafoSize, 0, mode, tsY);
     for (int q = 0; q < 4; q++) if (cbf4[q]) emit_residual(e, lv[q], log2C, 1 + (q >> 1), cu->chroma_mode, ts4[q]);
@@ -642,7 +643,7 @@ static ChromaCbf enc_transform_tree(Enc* e, CuCtx* cu, int x0, int y0, int xBase
     out.cbf_cr = analyse_tb(e, x0, y0, log2TrafoSize, 2, cmode, lCr, &tsCr);
     e->ev[my_cb].val = out.cbf_cb; e->ev[my_cr].val = out.cbf_cr;
     if (pending) { d->CuQpDeltaVal = saved_delta; d->cur_qp_y = saved_qp; }
-    EV_D(CTX_CBF_LUMA + (trafoDepth == 0 ? 1 : 0), cbfY);
+    if (!cu->inter || trafoDepth != 0 || out.cbf_cb || out.cbf_cr) EV_D(CTX_CBF_LUMA + (trafoDepth == 0 ? 1 : 0), cbfY);   /* (7.3.8.8, as below) */
     if (cbfY || out.cbf_cb || out.cbf_cr) enc_cu_qp_delta(e);
     if (cbfY) emit_residual(e, lY, log2TrafoSize, 0, mode, tsY);
     if (out.cbf_cb) emit_residual(e, lCb, log2TrafoSize, 1, cmode, tsCb);
@@ -1544,7 +1545,7 @@ static int enc_run(const hevc_testenc_params* prm, int n_frames, const uint16_t*
     free_dec(d);
     return -1;
   }
-  if (seq_mode && (prm->chroma_format_idc > 1 || prm->scaling_list)) fail(d, "sequences with P / B pictures: 4:0:0 / 4:2:0 without scaling lists only");
+  if (seq_mode && prm->scaling_list) fail(d, "sequences with P / B pictures: without scaling lists only");
   enc_parameter_sets(e, &stream);
   /* ---- coding order: frame 0 an IDR picture; with b_frames = b every (b + 1)-th picture is a P picture (an "anchor") and the b pictures
      before it are B pictures coded after it; the pictures behind the last anchor are P pictures.  A picture's own references: the anchors

@@ -348,7 +348,11 @@ def encode_sequence(frames, **kw):
     h, w = frames[0][0].shape
     prm.setdefault("width", w)
     prm.setdefault("height", h)
-    prm["chroma_format_idc"] = 1 if len(frames[0]) == 3 else 0
+    if len(frames[0]) == 3:   # the chroma format follows from the plane shapes, as in encode()
+        ch, cw = frames[0][1].shape
+        prm["chroma_format_idc"] = 3 if (cw == w and w > 1) else (2 if (ch == h and h > 1) else 1)
+    else:
+        prm["chroma_format_idc"] = 0
     st = _EncParams()
     for k, v in prm.items():
         setattr(st, k, int(v))

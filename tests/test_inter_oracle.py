@@ -11,11 +11,17 @@ from oracle import pyoracle as orc
 
 
 def shifted(planes, dx, dy):
-    return [np.roll(np.roll(p, dy // (1 if i == 0 else 2), 0), dx // (1 if i == 0 else 2), 1) for i, p in enumerate(planes)]
+    h, w = planes[0].shape
+    out = []
+    for i, p in enumerate(planes):
+        sx = 1 if (i == 0 or p.shape[1] == w) else 2      # SubWidthC / SubHeightC of the plane
+        sy = 1 if (i == 0 or p.shape[0] == h) else 2
+        out.append(np.roll(np.roll(p, dy // sy, 0), dx // sx, 1))
+    return out
 
 
-def make_frames(w, h, n, bit_depth=8, mono=False, seed=5):
-    f0 = orc.synth_image(w, h, bit_depth, 0 if mono else 1, seed=seed)
+def make_frames(w, h, n, bit_depth=8, mono=False, seed=5, chroma_format_idc=1):
+    f0 = orc.synth_image(w, h, bit_depth, 0 if mono else chroma_format_idc, seed=seed)
     return [shifted(f0, 2 * k, k) for k in range(n)]
 
 
@@ -107,6 +113,45 @@ def test_lossless_b_tmvp_weighted_round_trip_exactly(name):
         bi = [int(((p["mf_ref"][..., 0] >= 0) & (p["mf_ref"][..., 1] >= 0)).sum()) for p in pics]
         l1_only = [int(((p["mf_ref"][..., 0] < 0) & (p["mf_ref"][..., 1] >= 0)).sum()) for p in pics]
         assert max(bi) > 50 and max(l1_only) > 10, (bi, l1_only)          # bi-predicted and list-1-only blocks both occur
+
+
+CHROMA_FORMAT_CONFIGS = {
+    "p_default": dict(),
+    "p_amp_multiref_tmvp": dict(amp=1, inter_num_refs=2, temporal_mvp=1, log2_ctb=4, log2_max_tb=4),
+    "b_weighted": dict(b_frames=2, b_ref=1, weighted_pred=1, inter_num_refs=2, inter_bi_pct=70),
+    "b_everything": dict(b_frames=2, temporal_mvp=1, weighted_pred=1, mvd_l1_zero=1, amp=1, inter_num_refs=2, b_ref=1, lists_modification=1,
+                         num_slices=2, max_merge_cand=4, tile_cols=2, wpp=1),
+    "min_cb16_depth2": dict(log2_min_cb=4, log2_ctb=5, max_transform_hierarchy_depth_inter=2, inter_merge_pct=20),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CHROMA_FORMAT_CONFIGS))
+@pytest.mark.parametrize("cfi,bit_depth", [(3, 8), (2, 8), (3, 10), (2, 12)])
+def test_lossless_round_trip_in_422_and_444(cfi, bit_depth, name):
+    """P / B pictures of 4:2:2 and 4:4:4 sequences: the chroma motion vectors of 8.5.3.2.10 (mvLX * 2 / SubWidthC, / SubHeightC: twice the luma
+    vector where the chroma plane is not subsampled), chroma prediction blocks of nPbW / SubWidthC x nPbH / SubHeightC, the chroma transform trees
+    of those formats inside inter coded units - lossless, so every decoded sample equals the source"""
+    frames = make_frames(104, 72, 5, bit_depth, chroma_format_idc=cfi)
+    assert frames[0][1].shape == (72 if cfi != 1 else 36, 104 if cfi == 3 else 52)
+    aus = orc.encode_sequence(frames, bit_depth=bit_depth, qp=30, global_mv_x=-6, global_mv_y=-3, inter_skip_pct=0, lossless_pct=100, seed=13, **CHROMA_FORMAT_CONFIGS[name])
+    pics = orc.decode_sequence(aus, taps=True)
+    assert sorted(p["poc"] for p in pics) == list(range(5))
+    for p in pics:
+        assert p["chroma_format_idc"] == cfi
+        for c in range(3):
+            np.testing.assert_array_equal(p["planes"][c], frames[p["poc"]][c], err_msg="%s %d: POC %d component %d" % (name, cfi, p["poc"], c))
+    assert all((p["map_pred"] == 1).mean() > 0.4 for p in pics if p["poc"] > 0)
+
+
+@pytest.mark.parametrize("cfi", [2, 3])
+def test_lossy_422_444_sequences_do_not_drift(cfi):
+    frames = make_frames(136, 104, 6, chroma_format_idc=cfi)
+    kw = dict(b_frames=1, temporal_mvp=1, inter_num_refs=2, amp=1, sao=1)
+    for p in orc.decode_sequence(orc.encode_sequence(frames, qp=4, global_mv_x=-8, global_mv_y=-4, inter_skip_pct=0, **kw)):
+        for c in range(3):
+            assert float(np.mean((p["planes"][c].astype(np.float64) - frames[p["poc"]][c]) ** 2)) < 5.0, (cfi, p["poc"], c)   # (4:2:0 with these parameters: up to 3.3 - quantisation noise of the random QP deltas, not drift)
+    pics = orc.decode_sequence(orc.encode_sequence(frames, qp=26, global_mv_x=-8, global_mv_y=-4, inter_skip_pct=25, **kw), taps=True)
+    assert any((p["map_pred"] == 2).any() for p in pics)
 
 
 def test_lossy_b_sequence_no_drift_and_skips():
