@@ -969,8 +969,9 @@ int hipdec_decoder_push_data(hipdec_decoder* d, const void* data, size_t size)
     if (d->decoded) {
       // The next sample of an image sequence (libheif/sequences/track_visual.cc:200-280 pushes one sample, polls for its frame, pushes
       // the next; only a chunk's first sample carries the parameter sets, codecs/decoder.cc:422): the instance is armed again with the
-      // parameter sets it has seen in front of the new sample.  P pictures predict from the pictures the instance keeps (commit_reference); B slices, temporal
-      // motion vector prediction, weighted prediction and long-term reference pictures are refused loudly by the header parser.
+      // parameter sets it has seen in front of the new sample.  P and B pictures predict from the pictures the instance keeps (commit_reference: planes and
+      // motion fields); what the device path does not decode - long-term reference pictures, P / B slices of 4:2:2 / 4:4:4 pictures or with scaling
+      // lists / constrained_intra_pred_flag - is refused loudly by the header parser.
       if (int rc = commit_reference(d)) return rc;   // the picture decoded last may be referenced by the samples that follow
       d->seq_active = true;
       d->decoded = false;
