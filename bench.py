@@ -204,7 +204,8 @@ def kernel_table(avg_us, alg, px, colour_stage=True):
 
 def issue_roofline(kernels, px, cu_count, clock_ghz):
     """The CABAC parser and the intra reconstruction are bound by instruction issue, not by HBM: their yardstick is the
-    CU-shared scalar pipe, one SALU instruction per cycle and CU.  Instructions per luma pixel come from the committed PMC passes
+    CU-shared scalar pipe, one SALU instruction per cycle and CU (the other kernels are listed with the same arithmetic: none of them is near
+    the HBM roofline because all of them sit at 40 - 60 % of one of the issue peaks).  Instructions per luma pixel come from the committed PMC passes
     (profiles/pmc_issue.json: SQ_INSTS_SALU / _VALU / _BRANCH per kernel, tools/prof_parse_pmc.sh); they are a property of the code and the
     content, not of the batch size, so the file's figures are applied to this run's pixels and kernel times."""
     try:
@@ -215,8 +216,8 @@ def issue_roofline(kernels, px, cu_count, clock_ghz):
     out = {"peak_ginst_s": round(peak, 1), "peak_is": "%d CUs x %.2f GHz x 1 SALU instruction per cycle and CU; the vector pipes take twice that in wave64 "
                                                    "instructions (4 SIMD-32 units per CU, 2 cycles per wave64 VALU instruction)" % (cu_count, clock_ghz),
            "source": rec.get("source"), "commit": rec.get("commit"), "kernels": {}}
-    for key, name in (("parse", "k_parse"), ("recon", "k_recon")):
-        if key in kernels and name in rec.get("insts_per_px", {}) and kernels[key]["avg_us"] > 0:
+    for key, name in (("parse", "k_parse"), ("recon", "k_recon"), ("residual", "k_residual"), ("deblock", "k_deblock"), ("sao_rgb", "k_sao"), ("sao", "k_sao")):
+        if key in kernels and key not in out["kernels"] and name in rec.get("insts_per_px", {}) and kernels[key]["avg_us"] > 0:
             ipp = rec["insts_per_px"][name]
             ach = ipp["salu"] * px / (kernels[key]["avg_us"] * 1e-6) / 1e9
             out["kernels"][key] = {"kernel": kernels[key]["kernel"], "salu_per_px": ipp["salu"], "valu_per_px": ipp["valu"], "branch_per_px": ipp.get("branch"),

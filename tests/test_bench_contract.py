@@ -43,3 +43,21 @@ def test_committed_bench_line_has_every_contract_field():
             assert "error" not in st, st
             for k in ("lowdelay_ippp_2refs_tmvp_weighted", "unrestricted_ibbp_tmvp"):
                 assert st[k]["one_track_fps"] > 0 and st[k]["all_tracks_fps"] > st[k]["one_track_fps"] and st[k]["verified_against_oracle"] is True
+
+
+def test_issue_roofline_covers_every_kernel_of_the_pmc_record():
+    """bench.py's issue_roofline applies profiles/pmc_issue.json (instructions per luma pixel, one PMC pass) to the run's kernel times: every kernel
+    the record holds gets its share of the scalar / vector issue peaks, and none may exceed a peak"""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_issue.json")))
+    assert {"k_parse", "k_recon", "k_residual", "k_sao", "k_deblock"} <= set(rec["insts_per_px"])
+    kern = {"parse": {"kernel": "k_parse", "avg_us": 738604.4}, "recon": {"kernel": "k_recon", "avg_us": 128503.6}, "residual": {"kernel": "k_residual", "avg_us": 83848.1},
+            "deblock": {"kernel": "k_deblock", "avg_us": 21106.3}, "sao_rgb": {"kernel": "k_sao", "avg_us": 53736.4}}
+    r = bench.issue_roofline(kern, 2048 * 3840 * 2160, 256, 2.4)
+    assert set(r["kernels"]) == set(kern)
+    for k, v in r["kernels"].items():
+        assert 0 < v["frac_of_scalar_issue_peak"] < 1 and 0 < v["frac_of_vector_issue_peak"] < 1, (k, v)
+    assert r["kernels"]["parse"]["frac_of_scalar_issue_peak"] > r["kernels"]["recon"]["frac_of_scalar_issue_peak"] > r["kernels"]["deblock"]["frac_of_scalar_issue_peak"]

@@ -19,7 +19,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(float))
 for r in csv.DictReader(open("$f")):
     agg[r["Kernel_Name"].split("(")[0][:36]][r["Counter_Name"]]+=float(r["Counter_Value"])
 for k in agg:
-    if "parse" in k or "recon" in k or "residual" in k:
+    if any(x in k for x in ("parse", "recon", "residual", "k_sao", "k_deblock")):
         print(k, " ".join("%s=%.5g"%(c,v) for c,v in sorted(agg[k].items())))
 PY
   i=$((i+1))
@@ -40,7 +40,7 @@ if f:
         n = 512
     px = n * 3840 * 2160
     out = {}
-    for short in ("k_parse", "k_recon", "k_residual"):
+    for short in ("k_parse", "k_recon", "k_residual", "k_sao", "k_deblock"):
         tot = collections.defaultdict(float)
         for k, v in agg.items():
             if short in k:
