@@ -30,7 +30,8 @@ class Nclx(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "libheifhip.so")
+    # HIPDEC_LIBRARY: development override (tools/ab_bench.sh measures another branch's build beside this one); the product loads the in-tree library
+    return os.environ.get("HIPDEC_LIBRARY") or os.path.join(_HERE, "libheifhip.so")
 
 
 def _share_torch_hip_runtime():
