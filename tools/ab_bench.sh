@@ -1,6 +1,7 @@
 #!/bin/bash
 # inside gpurun: the main workload's kernel times with the in-tree library and with another branch's build (tools/ab_build.sh), then - with
-# TESTS=1 - the GPU tier under that build.  usage: bash tools/ab_bench.sh [branch] [bench args]   (default branch: candidates)
+# TESTS=1 - the GPU tier under that build; SINGLE=1 adds one 4K still, FROM_HOST=1 the from-host-bytes `value`.
+# usage: [TESTS=1] [SINGLE=1] [FROM_HOST=1] bash tools/ab_bench.sh [branch] [bench args]   (default branch: candidates)
 br=${1:-candidates}; shift || true
 alt=build/ab/$br/libheif_amd/libheifhip.so
 mkdir -p gpurun_out
@@ -15,6 +16,14 @@ try:
 except Exception as e: print("$which: no line", e)
 PY
 done
+if [ -n "$SINGLE" ]; then   # one 4K still (BASELINE config 2): the latency-bound form
+  for which in tree $br; do
+    lib=""; [ $which = tree ] || lib=$PWD/$alt
+    HIPDEC_LIBRARY=$lib timeout 120 python bench.py --batch 1 --only-main --steps 3 > gpurun_out/ab_single_$which.json 2> gpurun_out/ab_single_$which.err
+    python -c "
+import json; d=json.load(open('gpurun_out/ab_single_$which.json')); print('%-12s' % '$which', 'one still', d['ms_per_step'], 'ms', {k: v['avg_us'] for k, v in d['kernels'].items()})"
+  done
+fi
 if [ -n "$FROM_HOST" ]; then   # `value` (from host bytes) needs the default line's first section: both libraries, without the extras
   for which in tree $br; do
     lib=""; [ $which = tree ] || lib=$PWD/$alt
