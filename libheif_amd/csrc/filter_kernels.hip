@@ -347,8 +347,22 @@ __device__ __forceinline__ SaoRegs sao_unpack(uint32_t w0, uint32_t w1, uint32_t
   return r;
 }
 __device__ __forceinline__ int sao_off(const SaoRegs& sp, int i) { return i == 0 ? sp.o0 : (i == 1 ? sp.o1 : (i == 2 ? sp.o2 : sp.o3)); }
+// offset j (0 .. 3) out of four offsets packed as signed bytes: one v_bfe_i32
+__device__ __forceinline__ int sao_packed_offset(uint32_t packed, int j) { return (int)(int8_t)(packed >> ((j & 3) * 8)); }
 
 constexpr int SAO_TW = 128, SAO_TH = 32, SAO_RPT = SAO_TH / 8;   // rows per thread
+
+// Workgroup barrier for data that travels through LDS only.  __syncthreads() also drains the wave's GLOBAL memory counter (s_waitcnt vmcnt(0)): in
+// the SAO kernels that made every phase wait for the plane stores of the phase before it (nothing in these kernels reads global memory another
+// thread of the launch has written; a value loaded for the tile is waited for where it is stored to LDS, by the compiler).
+__device__ __forceinline__ void lds_barrier()
+{
+#ifndef HIPDEC_HOST_EMU
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+  __syncthreads();
+#endif
+}
 
 // What one component of one picture needs for SAO, gathered once per workgroup (wave-uniform)
 template <typename Pix>
@@ -439,28 +453,35 @@ __device__ __forceinline__ int sao_quad(const SaoComp<Pix>& S, const uint32_t* t
   bool done = false;
   if (one_ctb && !S.check_bypass && npx == 4) {
     const SaoRegs sp = sp_first;
+    // The two filtering paths below are pure lane arithmetic: signs through clamps, the offset of a band / an edge category through a bit-field
+    // extract out of the four offsets packed into one word - compare-and-select chains here compile to exec-mask bookkeeping on the scalar pipe,
+    // which is what this kernel is short of (1.1 scalar instructions per pixel, 56 % of the issue peak: profiles/pmc_issue.json).  SaoOffsetVal
+    // fits a byte for every bit depth this path takes (|offset| <= 31 << (bitDepth - 10) = 124 at 12 bits).
+    const uint32_t packed = ((uint32_t)sp.o0 & 255u) | (((uint32_t)sp.o1 & 255u) << 8) | (((uint32_t)sp.o2 & 255u) << 16) | (((uint32_t)sp.o3 & 255u) << 24);
     if (sp.type == 0) {
 #pragma unroll
       for (int i = 0; i < 4; i++) res[i] = SAO_AT(lr, xf + i);
       done = true;
-    } else if (sp.type == 1) {
+    } else if (sp.type == 1 && bit_depth <= 12) {
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        int v = SAO_AT(lr, xf + i);
-        const int k = ((v >> (bit_depth - 5)) - sp.cls) & 31;
-        const int off = k < 4 ? sao_off(sp, k) : 0;
+        const int v = SAO_AT(lr, xf + i);
+        const int k = ((v >> (bit_depth - 5)) - sp.cls) & 31;                  // band position relative to sao_band_position: the first four carry offsets
+        int off = sao_packed_offset(packed, k & 3);
+        off = k < 4 ? off : 0;
         res[i] = (Pix)clip3(0, maxv, v + off);
       }
       done = true;
-    } else if (interior) {
+    } else if (sp.type == 2 && interior && bit_depth <= 12) {
       const int cls = sp.cls;
       const int hx = cls == 1 ? 0 : (cls == 3 ? 1 : -1), hy = cls == 0 ? 0 : -1;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int x = xf + i;
         const int v = SAO_AT(lr, x), a = SAO_AT(lr + hy, x + hx), b = SAO_AT(lr - hy, x - hx);
-        const int e = ((v > a) - (v < a)) + ((v > b) - (v < b));     // -2 .. 2 ; edgeIdx = 2 + e remapped {0,1,2,3,4} -> {1,2,0,3,4}
-        const int off = e == -2 ? sp.o0 : (e == -1 ? sp.o1 : (e == 1 ? sp.o2 : (e == 2 ? sp.o3 : 0)));
+        const int t = 2 + clip3(-1, 1, v - a) + clip3(-1, 1, v - b);          // Sign(v - a) + Sign(v - b) + 2: 0 .. 4; edgeIdx = {1, 2, 0, 3, 4}[t] (8.7.3.2)
+        int off = sao_packed_offset(packed, t - ((t + 1) >> 2));               // t = 0, 1 -> offsets 0, 1; t = 3, 4 -> offsets 2, 3
+        off = t == 2 ? 0 : off;
         res[i] = (Pix)clip3(0, maxv, v + off);
       }
       done = true;
@@ -551,7 +572,7 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
 #pragma unroll
   for (int rr = 0; rr < SAO_RPT; rr++) sao_params_at(S, ox_t + tx, oy_t + ty + rr * 8, spw[rr]);
   const int ab = sao_stage<Pix, SAO_TH, ROW_WORDS, 256>(S, tile, ox_t, oy_t, tid);
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int rr = 0; rr < SAO_RPT; rr++) {
     const int oy = oy_t + ty + rr * 8, ox0 = ox_t + tx;
@@ -573,7 +594,7 @@ __global__ __launch_bounds__(256) void k_sao_rgb(FilterArgs A, const colordev::C
   constexpr int ROW_WORDS = ((SAO_TW + 2) + 3) / 4 + 2;
   constexpr int CROW_WORDS = ((SAO_CW + 2) + 3) / 4 + 2;
   __shared__ uint32_t tile[(SAO_TH + 2) * ROW_WORDS];
-  __shared__ uint8_t chroma_s[2][SAO_CH][SAO_CW];
+  __shared__ __attribute__((aligned(4))) uint8_t chroma_s[2][SAO_CH][SAO_CW];   // (read back two samples at a time)
   if (*A.status != 0) return;
   const PicParams& P = A.pics[blockIdx.y];
   const SaoComp<Pix> SY = sao_comp<Pix>(A, P, 0, MAY_KEEP, RESTRICTED);
@@ -590,7 +611,7 @@ __global__ __launch_bounds__(256) void k_sao_rgb(FilterArgs A, const colordev::C
 #pragma unroll
     for (int rr = 0; rr < SAO_RPT; rr++) sao_params_at(SY, ox_t + tx, oy_t + ty + rr * 8, spw[rr]);
     const int ab = sao_stage<Pix, SAO_TH, ROW_WORDS, 256>(SY, tile, ox_t, oy_t, tid);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int rr = 0; rr < SAO_RPT; rr++) {
       const int oy = oy_t + ty + rr * 8, ox0 = ox_t + tx;
@@ -605,9 +626,9 @@ __global__ __launch_bounds__(256) void k_sao_rgb(FilterArgs A, const colordev::C
     const SaoComp<Pix> SC = sao_comp<Pix>(A, P, c, MAY_KEEP, RESTRICTED);
     uint32_t spw[3];
     sao_params_at(SC, ox_t / 2 + ctx, oy_t / 2 + cty, spw);
-    __syncthreads();                       // the previous component's reads of `tile` are done
+    lds_barrier();                       // the previous component's reads of `tile` are done
     const int ab = sao_stage<Pix, SAO_CH, CROW_WORDS, 256>(SC, tile, ox_t / 2, oy_t / 2, tid);
-    __syncthreads();
+    lds_barrier();
     Pix res[4];
     const int ox0 = ox_t / 2 + ctx, oy = oy_t / 2 + cty;
     const int npx = sao_quad<Pix, CROW_WORDS>(SC, tile, ab, ox0, oy, cty + 1, spw, res);
@@ -615,19 +636,29 @@ __global__ __launch_bounds__(256) void k_sao_rgb(FilterArgs A, const colordev::C
 #pragma unroll
     for (int i = 0; i < 4; i++) chroma_s[c - 1][cty][ctx + i] = i < npx ? res[i] : (Pix)0;
   }
-  __syncthreads();
+  lds_barrier();
   // ---- RGB24 of this thread's luma samples (nearest-neighbour chroma: x / 2, y / 2)
   const colordev::ColorParams cp = cps[blockIdx.y];
+  const bool int88 = cp.arith == colordev::AR_INT88;   // Op_YCbCr420_to_RGB24's integer arithmetic (the common case): decided once, not per sample
 #pragma unroll
   for (int rr = 0; rr < SAO_RPT; rr++) {
     const int npx = ynpx[rr];
     if (!npx) continue;
     const int ly = ty + rr * 8, oy = oy_t + ly, ox0 = ox_t + tx;
     int R[4], G[4], B[4];
+    // the two chroma samples under this thread's four luma samples (nearest neighbour: x / 2; tx is a multiple of 4): one 16-bit LDS read each
+    const uint32_t cb2 = *(const uint16_t*)&chroma_s[0][ly >> 1][tx >> 1], cr2 = *(const uint16_t*)&chroma_s[1][ly >> 1][tx >> 1];
+    if (int88) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int cb = chroma_s[0][ly >> 1][(tx + i) >> 1], cr = chroma_s[1][ly >> 1][(tx + i) >> 1];
-      colordev::convert_px(cp, yres[rr][i], cb, cr, R[i], G[i], B[i]);
+      for (int i = 0; i < 4; i++) {
+        const int cb = (int)((cb2 >> ((i >> 1) * 8)) & 255u) - 128, cr = (int)((cr2 >> ((i >> 1) * 8)) & 255u) - 128, Y = yres[rr][i];   // yuv2rgb.cc:377-421
+        R[i] = colordev::clip_i(Y + ((cp.i_r_cr * cr + 128) >> 8), 255);
+        G[i] = colordev::clip_i(Y + ((cp.i_g_cb * cb + cp.i_g_cr * cr + 128) >> 8), 255);
+        B[i] = colordev::clip_i(Y + ((cp.i_b_cb * cb + 128) >> 8), 255);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) colordev::convert_px(cp, yres[rr][i], (int)((cb2 >> ((i >> 1) * 8)) & 255u), (int)((cr2 >> ((i >> 1) * 8)) & 255u), R[i], G[i], B[i]);
     }
     uint8_t* o = cp.o0 + (size_t)oy * cp.os + (size_t)ox0 * 3;
     if (npx == 4 && ((cp.os | (uintptr_t)cp.o0) & 3) == 0) {

@@ -246,4 +246,5 @@ static inline int __mul24(int a, int b) { return a * b; }
 static inline unsigned __umul24(unsigned a, unsigned b) { return a * b; }
 static inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }

@@ -72,7 +72,7 @@ def test_occupancy_budgets():
     # loop (scalar registers parked in VGPR lanes, 172 B of scratch), not in the block functions
     assert recon8["vgpr"] <= 72 and recon8["scratch"] <= 176 and recon8["lds"] <= 6144
     residual = _find(ks, "k_residual")[0]
-    assert residual["lds"] <= 23040 and residual["vgpr"] <= 64          # 7 workgroups of 4 waves per CU: LDS is handed out in 512 B granules, 7 x 23040 <= 160 KB
+    assert residual["lds"] <= 23040 and residual["vgpr"] <= 72          # 7 workgroups of 4 waves per CU: LDS is handed out in 512 B granules, 7 x 23040 <= 160 KB
                                                                           # (measured: 23240 B -> 6 workgroups per CU, k_residual 84 -> 91.5 ms at 2048 4K stills)
     assert _find(ks, "k_parse")[0]["scratch"] == 0      # (the unconstrained variant lone stills run)
     for k in _find(ks, "k_sao"):
