@@ -110,6 +110,12 @@ HIPDEC_API int hipdec_decoder_decode(hipdec_decoder* dec, hipdec_image_info* inf
  * picture.  Streams without B pictures come out in coding order, one picture per sample.  user_data: what hipdec_decoder_set_user_data
  * attached to the sample the picture was decoded from (push_data2's user_data, decoder_libde265.cc:360). */
 HIPDEC_API void hipdec_decoder_set_user_data(hipdec_decoder* dec, uintptr_t user_data);
+/* Look-ahead of sequence tracks: behind a decoder's first picture, hipdec_decoder_next_picture() decodes the pushed samples once `samples` of them
+ * wait (or the host flushed): ONE launch set parses all of them (CABAC parsing needs nothing of a neighbour picture), the pixel stages follow picture
+ * by picture in decoding order.  Until then it reports *have = 0 and libheif pushes the next sample (sequences/track_visual.cc:200-260).
+ * 0 / 1: every sample is decoded at the poll behind its push.  Default 8 (environment: HIPDEC_SEQ_LOOKAHEAD); at most 64.  Stills are not affected:
+ * the first picture of a decoder is always decoded at once. */
+HIPDEC_API void hipdec_set_sequence_lookahead(int samples);
 HIPDEC_API int hipdec_decoder_next_picture(hipdec_decoder* dec, int flush, hipdec_image_info* info, int* have, uintptr_t* user_data);
 /* Concurrent hipdec_decoder_decode() calls (libheif decodes the tiles of a 'grid' item on worker threads,
  * libheif/image-items/grid.cc:405-453, one decoder instance per tile) are coalesced into shared launch sets; a
@@ -395,6 +401,11 @@ HIPDEC_API int hipdec_plane_crop(const void* in, size_t in_stride, int w, int h,
 HIPDEC_API void hipdec_image_ops_stats(uint64_t* transforms, uint64_t* grid_canvases);
 /* counters since load: conversions through hipdec_color_convert, input planes found device-resident, colour kernels launched */
 HIPDEC_API void hipdec_color_boundary_stats(uint64_t* conversions, uint64_t* resident_planes, uint64_t* kernel_launches);
+/* What the registry of handed-over planes holds right now: entries, and the device bytes they pin (every entry keeps its launch set's arena, a
+ * transform result or a grid canvas alive; holders are counted once).  Bounded by age (HIPDEC_RESIDENT_TTL_MS, 3 s), by count, and by pinned bytes:
+ * an eighth of the device's memory unless HIPDEC_RESIDENT_MAX_BYTES says otherwise (0: nothing is registered).  A device allocation that fails
+ * empties the registry before its last retry. */
+HIPDEC_API void hipdec_resident_plane_stats(uint64_t* entries, uint64_t* pinned_bytes);
 
 /* Op_to_hdr_planes (hdr_sdr.cc:25-109): 8-bit plane -> uint16 plane of out_bits (9..16): (v << (out_bits - 8)) | (v >> (16 - out_bits)). */
 HIPDEC_API int hipdec_color_to_hdr(const void* in, size_t is, int w, int h, int out_bits, void* out, size_t os, void* stream);

@@ -30,8 +30,18 @@ class Nclx(C.Structure):
 
 
 def library_path():
-    # HIPDEC_LIBRARY: development override (tools/ab_bench.sh measures another branch's build beside this one); the product loads the in-tree library
-    return os.environ.get("HIPDEC_LIBRARY") or os.path.join(_HERE, "libheifhip.so")
+    """The in-tree library.  Development only: with HIPDEC_DEV_AB=1 (set by tools/ab_*.sh, never by the product) HIPDEC_LIBRARY names another
+    build to measure beside this one; without that flag the variable is ignored with a warning - the native decoder takes untrusted input, and
+    no environment may silently swap it.  bench.py records the resolved path in its JSON line."""
+    override = os.environ.get("HIPDEC_LIBRARY")
+    if override:
+        if os.environ.get("HIPDEC_DEV_AB") == "1":
+            import sys
+            print("[libheif_amd] development override: loading %s" % override, file=sys.stderr)
+            return override
+        import warnings
+        warnings.warn("HIPDEC_LIBRARY is set but HIPDEC_DEV_AB=1 is not: ignored, loading the in-tree libheifhip.so")
+    return os.path.join(_HERE, "libheifhip.so")
 
 
 def _share_torch_hip_runtime():

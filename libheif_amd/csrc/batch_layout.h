@@ -25,6 +25,31 @@ struct BatchLayout {
   bool wide = false;  // samples wider than 8 bit -> uint16 planes
   bool any_inter = false;   // the batch holds a P picture: the parser build with the inter syntax, k_motion and k_mc run
   int max_w = 0, max_h = 0, max_ow = 0, max_oh = 0, max_ctbs = 0;
+  // ---- chains (sequence tracks with look-ahead): the items are consecutive samples of ONE track in decoding order.  The CABAC parser
+  //      and the residual kernel run over all of them at once (parsing needs nothing of another picture: the parser emits MotionSyntax records,
+  //      k_motion derives the vectors); motion derivation, prediction, reconstruction and the in-loop filters are launched picture by picture in
+  //      decoding order, so an item's reference pictures - earlier items of the same batch among them - are complete when it starts
+  bool chain = false;
+  struct ChainItem {
+    uint32_t first_rwave = 0, num_rwaves = 0;   // the picture's reconstruction wavefronts in the ReconWave table
+    size_t off_full_pic = 0;                    // != 0: a PicParams copy without the conformance window in the upload region; one more SAO pass with it
+                                                // writes the whole coded picture (reference pictures are addressed in coded coordinates)
+    size_t off_full[3] = {0, 0, 0};
+    uint32_t full_stride[3] = {0, 0, 0};
+  };
+  std::vector<ChainItem> chain_items;
+  // Steps: maximal runs of consecutive items without a dependency INSIDE the run, launched together.  Pixel steps break where an item predicts from
+  // an earlier item of the run (an intra-only track is one step: a plain batch; the non-reference B pictures between two anchors share one);
+  // motion steps break only where an item's COLLOCATED picture (temporal candidates, 8.5.3.2.8) is in the run - merge / AMVP derivation reads
+  // nothing else of another picture - and run on a stream of their own beside the pixel steps of earlier pictures.
+  struct ChainStep { int first = 0, count = 0; uint32_t first_rwave = 0, num_rwaves = 0, first_row = 0, num_rows = 0; int max_w = 0, max_h = 0, max_ow = 0, max_oh = 0; bool any_inter = false; };
+  std::vector<ChainStep> pixel_steps, motion_steps;
+  std::vector<int> motion_step_of;   // item -> index into motion_steps
+  std::vector<int> src_index;   // item -> index into the caller's data[] / sizes[] (RASL pictures that 8.3.3 drops are no items); empty: identity
+  SeqContext seq_after;         // the track's sequence state behind the last item; pictures of this batch carry RefPicture::batch_item until chain_resolve()
+  // ticket words of the per-step launches (dwords from off_ticket): [chain_ticket(k)] reconstruction of pixel step k, [+ 1] motion of motion step k
+  static uint32_t chain_ticket(int k) { return 64u + 2u * (uint32_t)k; }
+  int src(int i) const { return src_index.empty() ? i : src_index[(size_t)i]; }
 };
 
 // Parses n items (host worker threads for large batches) and lays the arena out ([upload region][control words][device-only
@@ -32,9 +57,18 @@ struct BatchLayout {
 // seqs: per item the sequence context of its decoder instance (reference pictures, POC state), or nullptr / an array of nullptrs for stills
 int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size_t* sizes, uint64_t max_image_size_pixels,
                       std::string& err, const SeqContext* const* seqs = nullptr);
+// The same for a chain: n consecutive samples of one track whose sequence state is `seq` (parsed one after the other, each committed to a working
+// copy before the next is parsed).  Samples 8.3.3 drops are left out (b.src_index maps items to inputs).  b.pics may end up EMPTY (all dropped).
+int layout_batch_plan_chain(BatchLayout& b, int n, const void* const* data, const size_t* sizes, uint64_t max_image_size_pixels,
+                            std::string& err, const SeqContext& seq);
 // Writes the upload region (b.upload_size bytes: descriptors, tables, the bitstreams as pushed) into `dst`, e.g. a pinned
 // staging buffer.  The wave tables built by the plan are released afterwards.
-void layout_batch_fill(BatchLayout& b, const void* const* data, const size_t* sizes, uint8_t* dst);
+// arena_base: the device address the arena will live at - needed by chains only (reference pictures inside the batch are addressed absolutely)
+void layout_batch_fill(BatchLayout& b, const void* const* data, const size_t* sizes, uint8_t* dst, uint64_t arena_base = 0);
+// reference picture of item j of a chain as later pictures (of this batch or of later ones) address it
+RefPicture chain_ref_picture(const BatchLayout& b, int j, uint64_t arena_base);
+// b.seq_after with the batch's own pictures addressed absolutely; `own` receives the POCs of those entries (their memory is this batch's arena)
+void chain_resolve(BatchLayout& b, uint64_t arena_base, std::vector<int>& own);
 // plan + fill into a vector (CPU-test emulation, small batches)
 int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* sizes, uint64_t max_image_size_pixels,
                  std::vector<uint8_t>& host_image, std::string& err, const SeqContext* const* seqs = nullptr);

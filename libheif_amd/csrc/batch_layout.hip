@@ -40,6 +40,10 @@ int layout_batch(BatchLayout& b, int n, const void* const* data, const size_t* s
   return HIPDEC_OK;
 }
 
+namespace {
+int layout_core(BatchLayout& b, const size_t* sizes, std::string& err_out);
+}
+
 int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels, std::string& err_out,
                       const SeqContext* const* seqs)
 {
@@ -50,9 +54,70 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
     std::vector<int> rcs((size_t)n, HIPDEC_OK);
     std::vector<std::string> errs((size_t)n);
     for_each_item(n, total, [&](int i) { rcs[i] = parse_picture((const uint8_t*)data[i], sizes[i], max_pixels, b.pics[i], errs[i], seqs ? seqs[i] : nullptr); });
-    for (int i = 0; i < n; i++)
+    for (int i = 0; i < n; i++) {
       if (rcs[i] != HIPDEC_OK) { err_out = "item " + std::to_string(i) + ": " + errs[i]; return rcs[i]; }
+      if (b.pics[i].skipped) { err_out = "item " + std::to_string(i) + ": a RASL picture whose CRA picture started the sequence is not decoded (8.3.3)"; return HIPDEC_ERR_NO_IMAGE; }
+    }
   }
+  return layout_core(b, sizes, err_out);
+}
+
+RefPicture chain_ref_picture(const BatchLayout& b, int j, uint64_t arena_base)
+{
+  const PicParams& P = b.params[(size_t)j];
+  const BatchLayout::ChainItem& ci = b.chain_items[(size_t)j];
+  RefPicture rp;
+  rp.poc = b.pics[(size_t)j].poc;
+  rp.width = P.width; rp.height = P.height; rp.chroma_format_idc = P.chroma_format_idc; rp.bit_depth_luma = P.bit_depth_luma; rp.bit_depth_chroma = P.bit_depth_chroma;
+  rp.log2_ctb = P.log2_ctb;
+  for (int c = 0; c < 3; c++) {
+    rp.plane[c] = arena_base + (ci.off_full_pic ? (uint64_t)ci.off_full[c] : (uint64_t)P.off_out[c]);
+    rp.stride[c] = ci.off_full_pic ? ci.full_stride[c] : P.out_stride[c];
+  }
+  rp.mf = P.is_inter ? arena_base + (uint64_t)P.off_mf : 0;
+  return rp;
+}
+
+void chain_resolve(BatchLayout& b, uint64_t arena_base, std::vector<int>& own)
+{
+  own.clear();
+  for (RefPicture& rp : b.seq_after.dpb)
+    if (rp.batch_item >= 0) { rp = chain_ref_picture(b, rp.batch_item, arena_base); own.push_back(rp.poc); }
+}
+
+int layout_batch_plan_chain(BatchLayout& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels, std::string& err_out,
+                            const SeqContext& seq)
+{
+  b.chain = true;
+  b.pics.clear(); b.src_index.clear();
+  SeqContext work = seq;
+  for (int i = 0; i < n; i++) {
+    ParsedPicture pp;
+    std::string err;
+    const int rc = parse_picture((const uint8_t*)data[i], sizes[i], max_pixels, pp, err, &work);
+    if (rc != HIPDEC_OK) { err_out = "sample " + std::to_string(i) + " of the chain: " + err; return rc; }
+    if (pp.skipped) continue;
+    // the picture becomes a reference picture of the samples behind it (8.3.2 keeps / drops through their RPS): addressed as "item j of this batch"
+    seq_commit(work, pp);
+    RefPicture rp;
+    rp.poc = pp.poc; rp.batch_item = (int)b.pics.size();
+    rp.width = pp.sps.pic_width; rp.height = pp.sps.pic_height; rp.chroma_format_idc = pp.sps.chroma_format_idc;
+    rp.bit_depth_luma = pp.sps.bit_depth_luma; rp.bit_depth_chroma = pp.sps.bit_depth_chroma; rp.log2_ctb = pp.sps.log2_ctb;
+    work.dpb.push_back(rp);
+    b.pics.push_back(std::move(pp));
+    b.src_index.push_back(i);
+  }
+  b.seq_after = work;
+  if (b.pics.empty()) return HIPDEC_OK;
+  std::vector<size_t> item_sizes;
+  for (int j : b.src_index) item_sizes.push_back(sizes[j]);
+  return layout_core(b, item_sizes.data(), err_out);
+}
+
+namespace {
+int layout_core(BatchLayout& b, const size_t* sizes, std::string& err_out)
+{
+  const int n = (int)b.pics.size();
   b.wide = b.pics[0].info.bit_depth_luma > 8 || b.pics[0].info.bit_depth_chroma > 8;
   for (int i = 0; i < n; i++) {
     const bool w = b.pics[i].info.bit_depth_luma > 8 || b.pics[i].info.bit_depth_chroma > 8;
@@ -106,6 +171,7 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
   // finishes row r continues with row r + W), so that in large batches the resident waves are mostly busy ones.
   std::vector<ReconWave>& rwaves = b.recon_waves;
   rwaves.clear();
+  if (b.chain) b.chain_items.assign((size_t)n, BatchLayout::ChainItem{});
   {
     const uint32_t target = 24576;   // ~8 waves per component of a 4K still at 1024 stills in flight (measured optimum 4-16)
     const char* force = getenv("HIPDEC_RECON_WAVES_PER_PICTURE");
@@ -121,9 +187,11 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
       if (w > rows) w = rows;
       uint32_t lag = 2;
       if (w < rows) { lag = row_len / (w + 1); if (lag < 2) lag = 2; }
+      if (b.chain) b.chain_items[(size_t)i].first_rwave = (uint32_t)rwaves.size();
       for (uint32_t j = 0; j < w; j++)
         for (uint32_t c = 0; c < (p.sps.chroma_format_idc == 3 ? 3u : 2u); c++)   // 0 = luma, 1 = Cb + Cr in one wave (4:2:0); 4:4:4: one wave per plane
           rwaves.push_back(ReconWave{(uint32_t)i, c, j, w, row_base, lag, 0, 0});
+      if (b.chain) b.chain_items[(size_t)i].num_rwaves = (uint32_t)rwaves.size() - b.chain_items[(size_t)i].first_rwave;
       row_base += rows;
     }
   }
@@ -180,6 +248,11 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
     b.max_ctbs = std::max(b.max_ctbs, P.ctb_w * P.ctb_h);
     b.max_ow = std::max(b.max_ow, P.out_width); b.max_oh = std::max(b.max_oh, P.out_height);
   }
+  if (b.chain)
+    for (int i = 0; i < n; i++) {
+      const PicParams& P = b.params[i];
+      if (P.out_width != P.width || P.out_height != P.height || P.crop_x || P.crop_y) { b.chain_items[(size_t)i].off_full_pic = off; off = align_up(off + sizeof(PicParams), 256); }
+    }
   b.upload_size = off;
   // control words (zeroed before every run)
   b.off_ctrl = off;
@@ -190,7 +263,8 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
   b.queue_cap = 1; while (b.queue_cap < nsubs) b.queue_cap <<= 1;
   b.off_queue = off; off = align_up(off + sizeof(uint32_t) * b.queue_cap, 256);
   b.off_qctl = off; off += 256;
-  b.off_ticket = off; off += 256;  // [0] parse ticket, [1] recon ticket
+  b.off_ticket = off; off += 256;  // [0] parse ticket, [1] recon ticket, [2] motion ticket
+  if (b.chain) off = align_up(off + 8 * (size_t)n, 256);   // + per item: recon and motion tickets of the per-picture launches (BatchLayout::chain_ticket)
   b.off_status = off; off += 256;
   b.ctrl_size = off - b.off_ctrl;
   b.off_ctx = off; off = align_up(off + (size_t)CTX_STORE * nsubs, 256);
@@ -235,12 +309,52 @@ int layout_batch_plan(BatchLayout& b, int n, const void* const* data, const size
       P.out_stride[c] = (uint32_t)align_up(std::max<size_t>(ow, 1) * es, 64);
       P.off_out[c] = off; off = align_up(off + (size_t)P.out_stride[c] * std::max<size_t>(oh, 1), 256);
     }
+    if (b.chain && b.chain_items[(size_t)i].off_full_pic) {   // the whole coded picture behind the filters, for the pictures that predict from it
+      BatchLayout::ChainItem& ci = b.chain_items[(size_t)i];
+      for (int c = 0; c < 3; c++) {
+        const size_t w = c ? (size_t)P.cwidth : (size_t)P.width, h = c ? (size_t)P.cheight : (size_t)P.height;
+        ci.full_stride[c] = (uint32_t)align_up(std::max<size_t>(w, 1) * es, 64);
+        ci.off_full[c] = off; off = align_up(off + (size_t)ci.full_stride[c] * std::max<size_t>(h, 1) + 256, 256);
+      }
+    }
   }
   b.arena_size = off;
+  if (b.chain) {
+    // steps (batch_layout.h): where does an item depend on an earlier item of the run that is being gathered?
+    b.pixel_steps.clear(); b.motion_steps.clear(); b.motion_step_of.assign((size_t)n, 0);
+    auto close = [&](std::vector<BatchLayout::ChainStep>& steps, int first, int end) {
+      BatchLayout::ChainStep st;
+      st.first = first; st.count = end - first;
+      st.first_rwave = b.chain_items[(size_t)first].first_rwave;
+      st.first_row = b.params[(size_t)first].first_row;
+      for (int i = first; i < end; i++) {
+        const PicParams& P = b.params[(size_t)i];
+        st.num_rwaves += b.chain_items[(size_t)i].num_rwaves; st.num_rows += (uint32_t)P.ctb_h;
+        st.max_w = std::max(st.max_w, (int)P.width); st.max_h = std::max(st.max_h, (int)P.height);
+        st.max_ow = std::max(st.max_ow, (int)P.out_width); st.max_oh = std::max(st.max_oh, (int)P.out_height);
+        st.any_inter = st.any_inter || P.is_inter;
+      }
+      steps.push_back(st);
+    };
+    int px_first = 0, mo_first = 0;
+    for (int i = 0; i < n; i++) {
+      const ParsedPicture& pp = b.pics[(size_t)i];
+      bool px_dep = false, mo_dep = false;
+      for (const RefPicture& rp : pp.refs) if (rp.batch_item >= px_first) px_dep = true;
+      for (const ParsedSlice& sl : pp.slices)
+        if (sl.sp.is_p && sl.sp.tmvp && sl.sp.col_slot < pp.refs.size() && pp.refs[sl.sp.col_slot].batch_item >= mo_first) mo_dep = true;
+      if (px_dep) { close(b.pixel_steps, px_first, i); px_first = i; }
+      if (mo_dep) { close(b.motion_steps, mo_first, i); mo_first = i; }
+      b.motion_step_of[(size_t)i] = (int)b.motion_steps.size();
+    }
+    close(b.pixel_steps, px_first, n);
+    close(b.motion_steps, mo_first, n);
+  }
   return HIPDEC_OK;
 }
+}  // namespace
 
-void layout_batch_fill(BatchLayout& b, const void* const* data, const size_t* sizes, uint8_t* host)
+void layout_batch_fill(BatchLayout& b, const void* const* data, const size_t* sizes, uint8_t* host, uint64_t arena_base)
 {
   const int n = (int)b.pics.size();
   // alignment gaps of the descriptor area are zeroed; the gap behind every bitstream (the parser's window loads run up to 512 B
@@ -268,11 +382,22 @@ void layout_batch_fill(BatchLayout& b, const void* const* data, const size_t* si
     for (int y = 0; y < P.ctb_h; y++) { rows[r].pic = (uint32_t)i; rows[r].row = (uint32_t)y; r++; }
   }
   size_t total = 0;
-  for (int i = 0; i < n; i++) total += sizes[i];
+  for (int i = 0; i < n; i++) total += sizes[b.src(i)];
+  const size_t items_end = b.chain ? [&]() { for (const auto& ci : b.chain_items) if (ci.off_full_pic) return ci.off_full_pic; return b.upload_size; }() : b.upload_size;
+  if (b.chain)
+    for (int i = 0; i < n; i++) {
+      const BatchLayout::ChainItem& ci = b.chain_items[(size_t)i];
+      if (!ci.off_full_pic) continue;
+      PicParams F = b.params[i];
+      F.crop_x = F.crop_y = 0; F.out_width = F.width; F.out_height = F.height; F.out_cwidth = F.cwidth; F.out_cheight = F.cheight;
+      for (int c = 0; c < 3; c++) { F.off_out[c] = ci.off_full[c]; F.out_stride[c] = ci.full_stride[c]; }
+      memset(host + ci.off_full_pic, 0, align_up(sizeof(PicParams), 256));
+      memcpy(host + ci.off_full_pic, &F, sizeof(F));
+    }
   for_each_item(n, total, [&](int i) {
     const ParsedPicture& pp = b.pics[i];
     const PicParams& P = b.params[i];
-    const size_t end = i + 1 < n ? (size_t)b.params[i + 1].off_ctb_ts_to_rs : b.upload_size;   // this item's slice of the upload region
+    const size_t end = i + 1 < n ? (size_t)b.params[i + 1].off_ctb_ts_to_rs : items_end;   // this item's slice of the upload region
     auto put = [&](size_t off, const void* src, size_t bytes, size_t next) {
       memcpy(host + off, src, bytes);
       memset(host + off + bytes, 0, next - off - bytes);
@@ -286,12 +411,13 @@ void layout_batch_fill(BatchLayout& b, const void* const* data, const size_t* si
       RefFrame tab[16];
       memset(tab, 0, sizeof(tab));
       for (size_t k = 0; k < pp.refs.size() && k < 16; k++) {
-        for (int c = 0; c < 3; c++) { tab[k].plane[c] = pp.refs[k].plane[c]; tab[k].stride[c] = pp.refs[k].stride[c]; }
-        tab[k].poc = pp.refs[k].poc; tab[k].mf = pp.refs[k].mf;
+        const RefPicture rp = pp.refs[k].batch_item >= 0 ? chain_ref_picture(b, pp.refs[k].batch_item, arena_base) : pp.refs[k];
+        for (int c = 0; c < 3; c++) { tab[k].plane[c] = rp.plane[c]; tab[k].stride[c] = rp.stride[c]; }
+        tab[k].poc = rp.poc; tab[k].mf = rp.mf;
       }
       put(P.off_reftab, tab, sizeof(tab), P.off_bitstream);
     }
-    put(P.off_bitstream, data[i], sizes[i], end);
+    put(P.off_bitstream, data[b.src(i)], sizes[b.src(i)], end);
   });
   b.parse_waves.clear(); b.parse_waves.shrink_to_fit();
   b.recon_waves.clear(); b.recon_waves.shrink_to_fit();

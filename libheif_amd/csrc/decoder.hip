@@ -15,6 +15,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <unordered_map>
 #include <cstdlib>
 #include <cstring>
@@ -40,6 +41,7 @@ struct hipdec_batch : BatchLayout {
   int32_t* host_status = nullptr;  // pinned: the device status word of the last run, copied behind its kernels (the arena may already
                                    // belong to the next batch when hipdec_batch_status() looks)
   std::vector<hipEvent_t> ev;   // kEv events per timing slot; run k records into slot k % slots
+  std::vector<hipEvent_t> chain_events;   // chain batches: one per motion step (the motion stream's progress, awaited by the pixel steps)
   std::vector<uint8_t> colour_timed;   // per slot: the colour stage of that run was recorded
   uint64_t runs = 0;
   hipStream_t last_stream = nullptr;
@@ -82,6 +84,7 @@ struct hipdec_batch : BatchLayout {
     color_batch_state_free(color);
     if (arena) arena_release(arena, arena_capacity);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : chain_events) if (e) (void)hipEventDestroy(e);
     if (uploaded) (void)hipEventDestroy(uploaded);
     if (done) (void)hipEventDestroy(done);
     status_slot_release(host_status);
@@ -94,13 +97,16 @@ namespace {
 // batches), staging and the upload.  Large upload regions go through pinned staging and ONE asynchronous copy on the
 // library's upload stream, so that hipdec_batch_create() of batch k+1 overlaps the kernels of batch k; small ones (a still, the
 // tiles of a grid photo) are copied synchronously from pageable memory, which is quicker than pinning.
+// chain_seq: the n items are consecutive samples of ONE sequence track whose state is *chain_seq (BatchLayout::chain): the batch may come out EMPTY
+// (every sample was a RASL picture 8.3.3 drops) - then nothing is allocated
 int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels, hipdec_batch* recycle = nullptr,
-                const SeqContext* const* seqs = nullptr)
+                const SeqContext* const* seqs = nullptr, const SeqContext* chain_seq = nullptr)
 {
   std::string err;
   b.device = active_device();
-  int rc = layout_batch_plan(b, n, data, sizes, max_pixels, err, seqs);
+  int rc = chain_seq ? layout_batch_plan_chain(b, n, data, sizes, max_pixels, err, *chain_seq) : layout_batch_plan(b, n, data, sizes, max_pixels, err, seqs);
   if (rc != HIPDEC_OK) return set_error(rc, "%s", err.c_str());
+  if (b.pics.empty()) return 0;
   HIPDEC_CHECK_HIP(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
   b.host_status = status_slot_acquire();
   if (!b.host_status) return set_error(HIPDEC_ERR_MEMORY, "batch_create: more than 4096 live batches (no pinned status slot left)");
@@ -122,8 +128,8 @@ int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* s
   static const bool sync_upload = getenv("HIPDEC_SYNC_UPLOAD") != nullptr;   // profiling knob: one stream, no cross-stream event waits
   if (b.upload_size > (size_t(4) << 20) && !sync_upload) {
     HIPDEC_CHECK_HIP(pinned_acquire(&b.staging, b.upload_size, &b.staging_capacity));
-    layout_batch_fill(b, data, sizes, (uint8_t*)b.staging);
-    if (!b.arena) HIPDEC_CHECK_HIP(arena_acquire((void**)&b.arena, b.arena_size, &b.arena_capacity));
+    if (!b.arena) HIPDEC_CHECK_HIP(arena_acquire((void**)&b.arena, b.arena_size, &b.arena_capacity));   // (first: a chain's reference tables hold addresses inside it)
+    layout_batch_fill(b, data, sizes, (uint8_t*)b.staging, (uint64_t)(uintptr_t)b.arena);
     HIPDEC_CHECK_HIP(hipEventCreateWithFlags(&b.uploaded, hipEventDisableTiming));
     hipStream_t us = upload_stream();
     if (after) HIPDEC_CHECK_HIP(hipStreamWaitEvent(us, after, 0));
@@ -131,8 +137,8 @@ int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* s
     HIPDEC_CHECK_HIP(hipEventRecord(b.uploaded, us));
   } else {
     std::vector<uint8_t> host(b.upload_size);
-    layout_batch_fill(b, data, sizes, host.data());
     if (!b.arena) HIPDEC_CHECK_HIP(arena_acquire((void**)&b.arena, b.arena_size, &b.arena_capacity));
+    layout_batch_fill(b, data, sizes, host.data(), (uint64_t)(uintptr_t)b.arena);
     if (after) HIPDEC_CHECK_HIP(hipEventSynchronize(after));
     HIPDEC_CHECK_HIP(hipMemcpy(b.arena, host.data(), b.upload_size, hipMemcpyHostToDevice));
   }
@@ -220,6 +226,45 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
   if (!parse_only) launch_residual(fa, n, b.max_ctbs, pa.general_chroma != 0, ps);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[2], ps));
   if (int rc = step("residual")) return rc;
+  if (!parse_only && b.chain) {
+    // A chain (consecutive samples of one track, parsed and inverse-transformed together above).  Motion derivation needs the parser's output and
+    // the collocated picture's motion field only, so the motion steps run on a stream of their own behind the parser, beside the pixel steps of
+    // earlier pictures; a pixel step (prediction, reconstruction, filters of pictures that do not predict from each other) waits for the motion
+    // fields of its pictures, and stream order makes every reference picture - earlier items of this batch among them - complete.
+    hipStream_t ms = nullptr;
+    if (b.any_inter && b.motion_steps.size() > 1) {
+      ms = stream_acquire();
+      while (b.chain_events.size() < b.motion_steps.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { stream_release(ms); return set_error(HIPDEC_ERR_DEVICE, "chain: no event"); }
+        b.chain_events.push_back(e);
+      }
+      HIPDEC_CHECK_HIP(hipStreamWaitEvent(ms, ev[1], 0));
+      for (size_t k = 0; k < b.motion_steps.size(); k++) {
+        launch_chain_motion(b, b.arena, (int)k, ms);
+        HIPDEC_CHECK_HIP(hipEventRecord(b.chain_events[k], ms));
+      }
+      stream_release(ms);   // (everything it carries is ordered into `ps` through the events below)
+    }
+    int motion_done = 0;
+    for (size_t k = 0; k < b.pixel_steps.size(); k++) {
+      const BatchLayout::ChainStep& st = b.pixel_steps[k];
+      const int need = b.motion_step_of[(size_t)(st.first + st.count - 1)] + 1;
+      if (ms) { if (st.any_inter) HIPDEC_CHECK_HIP(hipStreamWaitEvent(ps, b.chain_events[(size_t)need - 1], 0)); }
+      else for (; motion_done < need; motion_done++) launch_chain_motion(b, b.arena, motion_done, ps);
+      launch_chain_pixels(b, b.arena, (int)k, ps);
+    }
+    if (ms) HIPDEC_CHECK_HIP(hipStreamWaitEvent(ps, b.chain_events[b.motion_steps.size() - 1], 0));   // nothing of this batch outlives its `done` event
+    HIPDEC_CHECK_HIP(hipEventRecord(ev[3], ps));
+    HIPDEC_CHECK_HIP(hipEventRecord(ev[4], ps));
+    HIPDEC_CHECK_HIP(hipEventRecord(ev[5], ps));
+    if (int rc = step("chain pixel stages")) return rc;
+    HIPDEC_CHECK_HIP(hipGetLastError());
+    HIPDEC_CHECK_HIP(hipMemcpyAsync(b.host_status, b.arena + b.off_status, sizeof(int32_t), hipMemcpyDeviceToHost, ps));
+    b.last_stream = ps;
+    b.mark_done(ps);
+    return 0;
+  }
   if (!parse_only && b.any_inter) {
     // P pictures: motion vectors (merge / AMVP candidates: a 2-CTB wavefront over CTB rows), then the motion-compensated prediction of every
     // inter coded sample into the reconstruction planes; k_recon adds the residuals and predicts the intra blocks around them
@@ -696,11 +741,22 @@ struct hipdec_decoder {
   // ---- output order (C.5.2.2 "bumping"): with B pictures the coding order is not the output order.  Decoded pictures wait here until more
   //      than sps_max_num_reorder_pics of their coded video sequence are waiting (or the host flushes); hipdec_decoder_next_picture hands them
   //      out by increasing POC.  `out` is the picture the plane readers currently serve (empty: the picture decoded last, the still-image use)
-  struct Output { std::shared_ptr<hipdec_batch> batch; int item = 0; int poc = 0; uint64_t cvs = 0; uintptr_t user_data = 0; };
+  struct Output { std::shared_ptr<hipdec_batch> batch; int item = 0; int poc = 0; uint64_t cvs = 0; uintptr_t user_data = 0; bool pic_output = true; };
   std::vector<Output> waiting;
   Output out;
   uint64_t cvs = 0;                      // coded video sequence counter (a new one starts at every IDR / first IRAP)
   uintptr_t pending_user_data = 0;       // of the sample pushed last (decoder_libde265.cc:360, :417-419)
+  // ---- look-ahead: the samples behind the first picture wait here (one access unit each, the parameter sets known at its push in front) until
+  //      HIPDEC_SEQ_LOOKAHEAD of them are there or the host flushes; they are then decoded as ONE chain (batch_layout.h): one CABAC launch over all of
+  //      them - parsing needs nothing of another picture - and the pixel stages picture by picture.  libheif's track loop pushes the next sample
+  //      whenever decode_next_image2 returns no image (sequences/track_visual.cc:200-260), so holding samples back costs it nothing.
+  struct Sample { std::vector<uint8_t> blob; uintptr_t user_data = 0; bool has_vcl = false; };
+  std::deque<Sample> queue;
+  bool first_has_vcl = false, first_closed = false;   // the access unit in `data` (the first picture): holds a slice / is complete (a later access unit was pushed)
+  size_t last_push_first = 0;            // queue index of the first sample the last push touched (set_user_data names them)
+  bool last_push_touched_first = false;
+  uintptr_t first_user_data = 0;
+  bool last_open = false;                // the newest queued sample may still be continued by the next push
   hipdec_batch* plane_batch() const { return out.batch ? out.batch.get() : batch.get(); }
   int plane_item() const { return out.batch ? out.item : item; }
   ~hipdec_decoder()
@@ -966,35 +1022,108 @@ int hipdec_decoder_push_data(hipdec_decoder* d, const void* data, size_t size)
     ptr += n;
   }
   return guarded("push_data", [&]() -> int {
-    if (d->decoded) {
-      // The next sample of an image sequence (libheif/sequences/track_visual.cc:200-280 pushes one sample, polls for its frame, pushes
-      // the next; only a chunk's first sample carries the parameter sets, codecs/decoder.cc:422): the instance is armed again with the
-      // parameter sets it has seen in front of the new sample.  P and B pictures predict from the pictures the instance keeps (commit_reference: planes and
-      // motion fields); what the device path does not decode - long-term reference pictures, P / B slices of 4:2:2 / 4:4:4 pictures or with scaling
-      // lists / constrained_intra_pred_flag - is refused loudly by the header parser.
-      if (int rc = commit_reference(d)) return rc;   // the picture decoded last may be referenced by the samples that follow
+    // Access units (7.4.2.4.4): a coded slice segment with first_slice_segment_in_pic_flag, or a parameter set / AUD / prefix SEI behind the last
+    // slice of a picture, starts the next one.  The first access unit is the still-image case (everything pushed before the decode, as
+    // decoder_libde265.cc:322-368 takes it); every later one is a sample of a sequence track (libheif/sequences/track_visual.cc:200-280 pushes them
+    // one by one; only a chunk's first sample carries the parameter sets, codecs/decoder.cc:422) and waits in the look-ahead queue.
+    if (d->decoded && !d->seq_active) {
+      // the first picture was decoded and more data arrives: the instance becomes a sequence decoder; that picture may be referenced by the samples that follow
+      if (int rc = commit_reference(d)) return rc;
       d->seq_active = true;
-      d->decoded = false;
-      d->batch.reset();
-      d->data = d->param_sets;
-      std::lock_guard<std::mutex> lock(g_co.mu);
-      if (!d->counted) { d->counted = true; g_co.armed++; }
+      d->first_closed = true;
     }
-    d->data.insert(d->data.end(), p, p + size);
+    d->last_push_first = d->queue.size();
+    d->last_push_touched_first = false;
+    bool open = !d->queue.empty() && d->last_open;   // the newest sample may be continued by this push (a picture pushed in pieces)
+    if (open) d->last_push_first = d->queue.size() - 1;
+    for (size_t q = 0; q < size;) {
+      const uint32_t n = ((uint32_t)p[q] << 24) | ((uint32_t)p[q + 1] << 16) | ((uint32_t)p[q + 2] << 8) | p[q + 3];
+      const uint8_t* nal = p + q + 4;
+      const size_t whole = 4 + (size_t)n;
+      q += whole;
+      if (n < 2) continue;
+      const int t = (nal[0] >> 1) & 63;
+      const bool vcl = t < 32;
+      const bool starts = vcl ? (n >= 3 && (nal[2] & 0x80)) : ((t >= 32 && t <= 35) || t == 39 || (t >= 41 && t <= 44) || (t >= 48 && t <= 55));
+      if (t >= 32 && t <= 34) {   // VPS / SPS / PPS: remembered for the samples that follow (a repeated one moves to the end: the newest wins when parsed)
+        std::vector<uint8_t>& ps = d->param_sets;
+        for (size_t a = 0; a + 4 <= ps.size();) {
+          const size_t len = 4 + (((size_t)ps[a] << 24) | ((size_t)ps[a + 1] << 16) | ((size_t)ps[a + 2] << 8) | ps[a + 3]);
+          if (len == whole && !memcmp(ps.data() + a, nal - 4, whole)) { ps.erase(ps.begin() + (long)a, ps.begin() + (long)(a + len)); break; }
+          a += len;
+        }
+        ps.insert(ps.end(), nal - 4, nal + n);
+      }
+      const bool in_first = !d->first_closed;
+      if (in_first) {
+        if (starts && d->first_has_vcl) d->first_closed = true;   // the still's access unit is complete: what follows are samples of a sequence
+        else {
+          d->data.insert(d->data.end(), nal - 4, nal + n);
+          if (vcl) d->first_has_vcl = true;
+          d->last_push_touched_first = true;
+          continue;
+        }
+      }
+      if (!open || (starts && d->queue.back().has_vcl)) {
+        d->queue.emplace_back();
+        d->queue.back().user_data = d->pending_user_data;
+        open = true;
+        // a parameter set that opens the sample is already in param_sets (appended above): the blob starts with all of them either way
+        d->queue.back().blob = d->param_sets;
+        if (t >= 32 && t <= 34) continue;
+      } else if (t >= 32 && t <= 34) {   // a parameter set inside an open sample: in front of its slices, like the others
+        d->queue.back().blob.insert(d->queue.back().blob.end(), nal - 4, nal + n);
+        continue;
+      }
+      d->queue.back().blob.insert(d->queue.back().blob.end(), nal - 4, nal + n);
+      if (vcl) d->queue.back().has_vcl = true;
+    }
+    d->last_open = open;
     return 0;
   });
 }
 
 static int decoder_decode_impl(hipdec_decoder* d, hipdec_image_info* info);
+static int decode_chain(hipdec_decoder* d, size_t n, std::vector<hipdec_decoder::Output>* outputs);
+static std::atomic<long> g_seq_lookahead{-1};
+static long seq_lookahead()
+{
+  long k = g_seq_lookahead.load(std::memory_order_relaxed);
+  if (k < 0) {
+    const char* e = std::getenv("HIPDEC_SEQ_LOOKAHEAD");
+    k = e ? std::atol(e) : 8;
+    k = k < 0 ? 0 : (k > 64 ? 64 : k);
+    g_seq_lookahead.store(k, std::memory_order_relaxed);
+  }
+  return k;
+}
+void hipdec_set_sequence_lookahead(int samples) { g_seq_lookahead.store(samples < 0 ? 0 : (samples > 64 ? 64 : samples), std::memory_order_relaxed); }
+// decode_next_image in DECODING order (the still-image call, and sequence hosts that want every sample's picture at once): the first picture, or the
+// oldest queued sample on its own (a chain of one); the plane readers then serve that picture.  Output order: hipdec_decoder_next_picture.
 int hipdec_decoder_decode(hipdec_decoder* d, hipdec_image_info* info)
 {
-  return guarded("decode", [&]() -> int { return decoder_decode_impl(d, info); });
+  return guarded("decode", [&]() -> int {
+    if (!d) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "decode: NULL decoder");
+    if (!d->decoded) return decoder_decode_impl(d, info);
+    for (;;) {
+      while (!d->queue.empty() && !d->queue.front().has_vcl && d->queue.size() > 1) d->queue.pop_front();   // (parameter sets / SEI only: nothing to decode)
+      if (d->queue.empty() || !d->queue.front().has_vcl) return set_error(HIPDEC_ERR_NO_IMAGE, "no further image");
+      if (!d->seq_active) { if (int rc = commit_reference(d)) return rc; d->seq_active = true; }
+      std::vector<hipdec_decoder::Output> outs;
+      if (int rc = decode_chain(d, 1, &outs)) return rc;
+      if (outs.empty()) continue;   // the sample was a RASL picture 8.3.3 drops: the next one
+      d->out = hipdec_decoder::Output{};
+      d->batch = outs[0].batch; d->item = outs[0].item;
+      if (info) *info = d->batch->pics[(size_t)d->item].info;
+      return 0;
+    }
+  });
 }
 static int decoder_decode_impl(hipdec_decoder* d, hipdec_image_info* info)
 {
   if (!d) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "decode: NULL decoder");
   if (d->decoded) return set_error(HIPDEC_ERR_NO_IMAGE, "no further image");
-  if (d->data.empty()) return set_error(HIPDEC_ERR_NO_IMAGE, "no data was pushed");
+  if (d->data.empty() || !d->first_has_vcl) return set_error(HIPDEC_ERR_NO_IMAGE, "no data was pushed");
   DecodeRequest req;
   req.d = d;
   const long window = coalesce_window_us();
@@ -1089,18 +1218,7 @@ static int decoder_decode_impl(hipdec_decoder* d, hipdec_image_info* info)
   }
   if (req.rc) return set_error(req.rc, "%s", req.err.c_str());
   d->decoded = true;
-  {   // keep the parameter sets for a following sample (nal_unit_type 32 VPS, 33 SPS, 34 PPS; later ones replace earlier ones when parsed)
-    d->param_sets.clear();
-    const uint8_t* p = d->data.data();
-    const size_t size = d->data.size();
-    for (size_t ptr = 0; ptr + 4 <= size;) {
-      const uint32_t n = ((uint32_t)p[ptr] << 24) | ((uint32_t)p[ptr + 1] << 16) | ((uint32_t)p[ptr + 2] << 8) | p[ptr + 3];
-      if (n > size - ptr - 4) break;
-      if (n >= 2) { const int t = (p[ptr + 4] >> 1) & 63; if (t >= 32 && t <= 34) d->param_sets.insert(d->param_sets.end(), p + ptr, p + ptr + 4 + n); }
-      ptr += 4 + (size_t)n;
-    }
-    d->data.clear(); d->data.shrink_to_fit();
-  }
+  d->data.clear(); d->data.shrink_to_fit();
   if (info) *info = d->batch->pics[d->item].info;
   return 0;
 }
@@ -1136,36 +1254,127 @@ int hipdec_decoder_device_plane(hipdec_decoder* d, int c, const void** dptr, siz
   return hipdec_batch_device_plane(d->plane_batch(), d->plane_item(), c, dptr, stride);
 }
 
-void hipdec_decoder_set_user_data(hipdec_decoder* d, uintptr_t user_data) { if (d) d->pending_user_data = user_data; }
+void hipdec_decoder_set_user_data(hipdec_decoder* d, uintptr_t user_data)
+{
+  if (!d) return;
+  d->pending_user_data = user_data;   // of the sample(s) the last push brought (push_data2's argument)
+  if (d->last_push_touched_first) d->first_user_data = user_data;
+  for (size_t i = d->last_push_first; i < d->queue.size(); i++) d->queue[i].user_data = user_data;
+}
 
-// decode_next_image2 with output order (heif_plugin.h:164; decoder_libde265.cc:386-457 around de265_get_next_picture): decodes the pushed sample
-// if one is pending, then hands out the next picture in OUTPUT order if the bumping process releases one.
+// The queued samples [0, n) as ONE chain (batch_layout.h): parsed against the track's sequence state one after the other on the host, one CABAC
+// launch and one residual launch over all of them, the pixel stages picture by picture.  Afterwards the state sits behind the last of them, the
+// DPB holds name this batch for its pictures, and `outputs` lists the decoded pictures in decoding order.
+static int decode_chain(hipdec_decoder* d, size_t n, std::vector<hipdec_decoder::Output>* outputs)
+{
+  if (n > d->queue.size()) n = d->queue.size();
+  if (!n) return 0;
+  std::vector<const void*> ptrs;
+  std::vector<size_t> sizes;
+  for (size_t i = 0; i < n; i++) { ptrs.push_back(d->queue[i].blob.data()); sizes.push_back(d->queue[i].blob.size()); }
+  if (int rc = ensure_init()) return rc;
+  std::shared_ptr<hipdec_batch> sp(new hipdec_batch());
+  hipdec_batch& b = *sp;
+  // (a chain that fails - a sample the front end refuses, a corrupt one - is dropped as a whole: the host gets the error once, not at every poll)
+  auto drop = [&]() { d->queue.erase(d->queue.begin(), d->queue.begin() + (long)n); if (d->queue.empty()) d->last_open = false; d->last_push_first = d->last_push_first > n ? d->last_push_first - n : 0; };
+  if (int rc = build_batch(b, (int)n, ptrs.data(), sizes.data(), d->max_pixels, nullptr, nullptr, &d->seq)) { drop(); return rc; }
+  {
+    std::lock_guard<std::mutex> lock(g_co.mu);
+    g_co.n_requests += n;
+    g_co.n_launch_sets++;
+  }
+  if (!b.pics.empty()) {
+    hipStream_t s = stream_acquire();
+    int rc = hipdec_batch_run(&b, (void*)s);
+    if (!rc) rc = stage_planes_to_host(b, follow_stream(&b, (void*)s));
+    if (!rc) rc = hipdec_batch_status(&b);   // synchronises
+    else (void)hipStreamSynchronize(s);
+    b.last_stream = nullptr;
+    stream_release(s);
+    if (rc) { drop(); return rc; }
+  }
+  // the sequence state moves behind the chain; its pictures' memory is this batch's arena
+  std::vector<int> own;
+  if (!b.pics.empty()) chain_resolve(b, (uint64_t)(uintptr_t)b.arena, own);
+  std::vector<hipdec_decoder::DpbHold> holds;
+  for (const RefPicture& rp : b.seq_after.dpb) {
+    if (std::find(own.begin(), own.end(), rp.poc) != own.end()) {
+      hipdec_decoder::DpbHold h; h.poc = rp.poc; h.keep = sp; h.device = b.device;
+      holds.push_back(std::move(h));
+      continue;
+    }
+    for (auto& h : d->dpb) if (h.poc == rp.poc && (h.keep || h.full)) { holds.push_back(std::move(h)); h = hipdec_decoder::DpbHold{}; break; }
+  }
+  for (auto& h : d->dpb) if (h.full) { DeviceScope scope(h.device); arena_release(h.full, h.full_capacity); }
+  d->dpb.swap(holds);
+  d->seq = b.seq_after;
+  for (size_t i = 0; i < b.pics.size(); i++) {
+    const ParsedPicture& pp = b.pics[i];
+    if (pp.is_idr) d->cvs++;   // POCs start over: everything still waiting precedes this picture in output order
+    if (!outputs) continue;
+    hipdec_decoder::Output o;
+    o.batch = sp; o.item = (int)i; o.poc = pp.poc; o.cvs = d->cvs; o.user_data = d->queue[(size_t)b.src((int)i)].user_data; o.pic_output = pp.pic_output;
+    outputs->push_back(std::move(o));
+  }
+  drop();
+  return 0;
+}
+
+// decode_next_image2 with output order (heif_plugin.h:164; decoder_libde265.cc:386-457 around de265_get_next_picture): decodes what is pending - the
+// first picture at once, later samples once HIPDEC_SEQ_LOOKAHEAD of them wait or the host flushed - then hands out the next picture in OUTPUT order
+// if the bumping process (C.5.2.2) releases one.  *have = 0: push the next sample.
 int hipdec_decoder_next_picture(hipdec_decoder* d, int flush, hipdec_image_info* info, int* have, uintptr_t* user_data)
 {
   if (!d || !have) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "next_picture: bad arguments");
   *have = 0;
   return guarded("next_picture", [&]() -> int {
-    if (!d->decoded && !d->data.empty()) {
+    if (!d->decoded && !d->data.empty() && d->first_has_vcl) {
       hipdec_image_info ii;
       if (int rc = decoder_decode_impl(d, &ii)) return rc;
       const ParsedPicture& pp = d->batch->pics[(size_t)d->item];
-      if (pp.is_idr || !d->seq_active) d->cvs++;   // POCs start over: everything still waiting precedes this picture in output order
+      d->cvs++;
       hipdec_decoder::Output o;
-      o.batch = d->batch; o.item = d->item; o.poc = pp.poc; o.cvs = d->cvs; o.user_data = d->pending_user_data;
-      d->waiting.push_back(std::move(o));
+      o.batch = d->batch; o.item = d->item; o.poc = pp.poc; o.cvs = d->cvs; o.user_data = d->first_user_data; o.pic_output = pp.pic_output;
+      if (o.pic_output) d->waiting.push_back(std::move(o));
     }
-    if (d->waiting.empty()) return 0;
-    size_t first = 0, in_cvs = 0;
-    for (size_t i = 0; i < d->waiting.size(); i++) {
-      const auto& a = d->waiting[i]; const auto& f = d->waiting[first];
-      if (a.cvs < f.cvs || (a.cvs == f.cvs && a.poc < f.poc)) first = i;
-      if (a.cvs == d->cvs) in_cvs++;
+    auto release = [&](bool force) -> bool {   // the bumping process: the waiting picture that is first in output order, if it may go
+      if (d->waiting.empty()) return false;
+      size_t first = 0, in_cvs = 0;
+      for (size_t i = 0; i < d->waiting.size(); i++) {
+        const auto& a = d->waiting[i]; const auto& f = d->waiting[first];
+        if (a.cvs < f.cvs || (a.cvs == f.cvs && a.poc < f.poc)) first = i;
+        if (a.cvs == d->cvs) in_cvs++;
+      }
+      const auto& f = d->waiting[first];
+      const ParsedPicture& fp = f.batch->pics[(size_t)f.item];
+      // DPB fullness (C.5.2.2): pictures waiting for output plus the reference pictures that are not among them
+      size_t fullness = in_cvs;
+      for (const RefPicture& rp : d->seq.dpb) {
+        bool waits = false;
+        for (const auto& w : d->waiting) if (w.cvs == d->cvs && w.poc == rp.poc) waits = true;
+        if (!waits) fullness++;
+      }
+      if (!(force || f.cvs < d->cvs || (int)in_cvs > fp.max_num_reorder || (int)fullness > fp.max_dec_pic_buffering)) return false;
+      d->out = d->waiting[first];
+      d->waiting.erase(d->waiting.begin() + (long)first);
+      return true;
+    };
+    // pictures already decoded go out first; only when none may go are the queued samples decoded - the whole look-ahead window as one chain
+    bool got = release(false);
+    while (!got) {
+      while (!d->queue.empty() && !d->queue.front().has_vcl && (d->queue.size() > 1 || flush)) d->queue.pop_front();
+      size_t ready = 0;
+      for (const auto& sm : d->queue) if (sm.has_vcl) ready++;
+      const size_t k = (size_t)std::max(1L, seq_lookahead());
+      if (!d->decoded || !ready || !(flush || ready >= k)) break;
+      if (!d->seq_active) { if (int rc = commit_reference(d)) return rc; d->seq_active = true; }
+      std::vector<hipdec_decoder::Output> outs;
+      if (int rc = decode_chain(d, std::min(d->queue.size(), k), &outs)) return rc;
+      for (auto& o : outs) if (o.pic_output) d->waiting.push_back(std::move(o));
+      got = release(false);
     }
-    const auto& f = d->waiting[first];
-    const ParsedPicture& fp = f.batch->pics[(size_t)f.item];
-    if (!(flush || f.cvs < d->cvs || (int)in_cvs > fp.max_num_reorder)) return 0;   // C.5.2.2: nothing is released yet
-    d->out = d->waiting[first];
-    d->waiting.erase(d->waiting.begin() + (long)first);
+    if (!got && flush && d->queue.empty()) got = release(true);
+    if (!got) return 0;
     if (info) { if (int rc = hipdec_batch_info(d->out.batch.get(), d->out.item, info)) return rc; }
     if (user_data) *user_data = d->out.user_data;
     *have = 1;
@@ -1246,6 +1455,9 @@ const long kResidentTtlMs = getenv("HIPDEC_RESIDENT_TTL_MS") ? atol(getenv("HIPD
 constexpr size_t kMaxResident = 16384;
 
 void resident_insert(struct ResidentPlane&& r);
+}  // namespace
+extern "C" void hipdec_forget_resident_planes(void);
+namespace {
 
 // Device rows -> a host buffer the caller owns (libheif's image planes: pageable memory).  A direct hipMemcpy2DAsync to pageable memory is
 // staged by the runtime behind a process-wide lock at a few GB/s - with hundreds of application threads converting at once that was the whole
@@ -1323,21 +1535,77 @@ void resident_note(hipdec_decoder* d, int c, const void* host, size_t stride)
   resident_insert(std::move(r));
 }
 
+// What an entry pins in HBM: a decoder's plane keeps the whole arena of its launch set alive, a buffer entry its transform result / grid canvas.
+// Entries of one holder are counted once (the three planes of an image; up to 256 images of one launch set).
+const void* resident_holder(const ResidentPlane& r) { return r.batch ? (const void*)r.batch.get() : (const void*)r.buffer.get(); }
+size_t resident_holder_bytes(const ResidentPlane& r)
+{
+  if (r.batch) return r.batch->arena_capacity;
+  return (size_t)r.dev_stride * (size_t)(r.h > 0 ? r.h : 1) * 2;   // (a canvas / transform result: its planes, roughly)
+}
+std::unordered_map<const void*, std::pair<int, size_t>>& g_res_holders = *new std::unordered_map<const void*, std::pair<int, size_t>>();
+size_t g_res_bytes = 0;
+uint64_t g_res_ops = 0;
+// the registry is bounded by what it PINS, not only by age - a host on the patched libheif that never converts colour never consumes
+// entries.  Default: an eighth of the device's memory (HIPDEC_RESIDENT_MAX_BYTES overrides; 0 = no tracking at all).
+size_t resident_byte_cap()
+{
+  static const size_t cap = [] {
+    if (const char* e = getenv("HIPDEC_RESIDENT_MAX_BYTES")) return (size_t)strtoull(e, nullptr, 10);
+    size_t free_b = 0, total = 0;
+    if (hipMemGetInfo(&free_b, &total) != hipSuccess) { (void)hipGetLastError(); total = size_t(64) << 30; }
+    return total / 8;
+  }();
+  return cap;
+}
+void resident_account(const ResidentPlane& r, int sign)   // g_res_mu held
+{
+  const void* h = resident_holder(r);
+  if (!h) return;
+  if (sign > 0) {
+    auto& e = g_res_holders[h];
+    if (e.first++ == 0) { e.second = resident_holder_bytes(r); g_res_bytes += e.second; }
+  } else {
+    auto it = g_res_holders.find(h);
+    if (it != g_res_holders.end() && --it->second.first <= 0) { g_res_bytes -= std::min(g_res_bytes, it->second.second); g_res_holders.erase(it); }
+  }
+}
+// g_res_mu held: entries older than the time to live, and - while the registry pins more than its byte cap or holds too many entries - the oldest ones
+void resident_sweep(std::vector<ResidentPlane>& dropped, bool all_expired_only)
+{
+  const auto now = Clock::now();
+  const auto limit = now - std::chrono::milliseconds(kResidentTtlMs);
+  for (auto e = g_resident.begin(); e != g_resident.end();)
+    if (e->second.born <= limit) { resident_account(e->second, -1); dropped.push_back(std::move(e->second)); e = g_resident.erase(e); } else ++e;
+  if (all_expired_only) return;
+  const size_t cap = resident_byte_cap();
+  if (g_res_bytes <= cap && g_resident.size() < kMaxResident) return;
+  std::vector<std::pair<uint64_t, const void*>> by_age;
+  for (auto& e : g_resident) by_age.emplace_back(e.second.tick, e.first);
+  std::sort(by_age.begin(), by_age.end());
+  for (size_t i = 0; i < by_age.size() && (g_res_bytes > cap / 2 || g_resident.size() >= kMaxResident / 2); i++) {   // (down to half: not again at the next insert)
+    auto it = g_resident.find(by_age[i].second);
+    resident_account(it->second, -1);
+    dropped.push_back(std::move(it->second));
+    g_resident.erase(it);
+  }
+}
+
 void resident_insert(ResidentPlane&& r)
 {
+  if (resident_byte_cap() == 0) return;
+  static const bool hooked = [] { set_memory_pressure_handler(hipdec_forget_resident_planes); return true; }();   // a failing device allocation empties the registry
+  (void)hooked;
   std::vector<ResidentPlane> dropped;   // what they keep alive dies outside the lock
   std::lock_guard<std::mutex> lock(g_res_mu);
   r.tick = ++g_res_tick;
   r.born = Clock::now();
   auto it = g_resident.find(r.host);
-  if (it != g_resident.end()) { dropped.push_back(std::move(it->second)); it->second = std::move(r); return; }
-  if ((g_res_tick & 63u) == 0 || g_resident.size() >= kMaxResident) {   // every so often: entries nobody came for
-    const auto limit = r.born - std::chrono::milliseconds(g_resident.size() >= kMaxResident ? 0 : kResidentTtlMs);
-    for (auto e = g_resident.begin(); e != g_resident.end();)
-      if (e->second.born <= limit) { dropped.push_back(std::move(e->second)); e = g_resident.erase(e); } else ++e;
-  }
+  if (it != g_resident.end()) { resident_account(it->second, -1); dropped.push_back(std::move(it->second)); g_resident.erase(it); }
+  resident_account(r, +1);
   const void* key = r.host;
   g_resident.emplace(key, std::move(r));
+  if ((++g_res_ops & 15u) == 0 || g_res_bytes > resident_byte_cap() || g_resident.size() >= kMaxResident) resident_sweep(dropped, false);
 }
 
 // a host plane that was just filled from a plane of `buffer` (w x h samples of `bits`, on the current device): a transform's result or the grid canvas
@@ -1359,11 +1627,15 @@ bool resident_find(const void* host, size_t stride, int w, int h, int bits, cons
   g_track_planes.store(true, std::memory_order_relaxed);
   ResidentPlane r;
   {
-    std::lock_guard<std::mutex> lock(g_res_mu);
+    std::vector<ResidentPlane> dropped;
+    std::unique_lock<std::mutex> lock(g_res_mu);
+    if ((++g_res_ops & 15u) == 0) resident_sweep(dropped, true);   // (expired entries go from here too: a host that only converts still ages the registry)
     auto it = g_resident.find(host);
-    if (it == g_resident.end()) return false;
-    r = std::move(it->second);
-    g_resident.erase(it);
+    const bool found = it != g_resident.end();
+    if (found) { resident_account(it->second, -1); r = std::move(it->second); g_resident.erase(it); }
+    lock.unlock();
+    dropped.clear();
+    if (!found) return false;
   }
   if (r.host_stride != stride || r.w != w || r.h != h || r.bits != bits) return false;
   if (r.batch && (r.batch->retired || !r.batch->arena)) return false;
@@ -1394,8 +1666,17 @@ void hipdec_forget_resident_planes(void)
   {
     std::lock_guard<std::mutex> lock(g_res_mu);
     drop.swap(g_resident);
+    g_res_holders.clear();
+    g_res_bytes = 0;
   }
 }   // the batches die here, outside the lock
+
+void hipdec_resident_plane_stats(uint64_t* entries, uint64_t* pinned_bytes)
+{
+  std::lock_guard<std::mutex> lock(g_res_mu);
+  if (entries) *entries = g_resident.size();
+  if (pinned_bytes) *pinned_bytes = g_res_bytes;
+}
 
 int hipdec_decoder_read_plane_tracked(hipdec_decoder* d, int c, void* dst, size_t dst_stride)
 {

@@ -29,15 +29,20 @@ struct StRps {
 // mf: its motion field on the device (0: an intra picture) - the collocated picture of temporal candidates (8.5.3.2.8)
 // width .. log2_ctb: the format it was decoded in - a picture only predicts from pictures of its own format (a parameter set change without an IDR
 // picture in between is refused: the kernels address references with the current picture's geometry)
+// batch_item >= 0: a picture of the SAME launch set (an earlier sample of the chain the batch decodes, batch_layout.h): its planes are addressed once
+// the arena is known (layout_batch_fill), and it is complete when the later picture's pixel stages start because those are launched picture by picture
 struct RefPicture {
   int poc = 0; uint64_t plane[3] = {0, 0, 0}; uint32_t stride[3] = {0, 0, 0}; uint64_t mf = 0;
   int width = 0, height = 0, chroma_format_idc = 0, bit_depth_luma = 0, bit_depth_chroma = 0, log2_ctb = 0;
+  int batch_item = -1;
+  bool long_term = false;   // marked "used for long-term reference" (8.3.2): referenced by its POC LSBs / full POC, never scaled (8.5.3.2.7)
 };
 
 // What a decoder instance keeps between the samples of a sequence track (libheif/sequences/track_visual.cc:200-280 pushes them one by one):
 // the picture order count state (8.3.1) and the decoded picture buffer.  nullptr where a single still is decoded: P slices are refused then.
 struct SeqContext {
   bool first_picture = true;
+  bool no_rasl_output = false;   // the IRAP picture decoded last had NoRaslOutputFlag = 1 (first picture, IDR, BLA): its RASL pictures are dropped (8.3.3)
   int prev_tid0_lsb = 0, prev_tid0_msb = 0;
   std::vector<RefPicture> dpb;
 };
@@ -105,7 +110,9 @@ struct ParsedPicture {
   // 16x16 (256 B) factors at c * 336, then the luma 32x32 factors (1024 B) at 1008; empty when scaling lists are off
   std::vector<uint8_t> scaling_tables;
   // ---- sequences: picture order count, the pictures its reference picture set keeps (8.3.2), the ones its P slices predict from
-  int poc = 0, poc_lsb = 0, nal_type = 0;
+  int poc = 0, poc_lsb = 0, nal_type = 0, temporal_id = 0;
+  bool pic_output = true;               // pic_output_flag (7.4.7.1); RASL pictures of a NoRaslOutputFlag IRAP are not output either (and not decoded: `skipped`)
+  bool skipped = false;                 // a RASL picture associated with a CRA that started the sequence: its references are unavailable, 8.3.3 drops it
   bool is_inter = false;                // some slice is a P slice
   bool is_idr = false;
   std::vector<int> keep_pocs;           // every picture of the RPS (the DPB drops the others once this picture is decoded)

@@ -485,8 +485,9 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
     std::vector<int> ctb_slice;       // slice index per CTB (raster), -1 = not covered
     std::vector<int> ctb_slice_addr;  // SliceAddrRs per CTB
     StRps pic_rps;                     // the RPS of the picture (every slice segment header repeats it)
-    int pic_poc_lsb = 0, pic_nal_type = 0;
+    int pic_poc_lsb = 0, pic_nal_type = 0, pic_tid = 0;
     out.is_inter = false; out.refs.clear(); out.keep_pocs.clear();
+    out.pic_output = true; out.skipped = false;
     size_t ptr = 0;
     while (ptr < size) {
       if (size - ptr < 4) { err = "truncated NAL length field"; return HIPDEC_ERR_END_OF_DATA; }
@@ -555,7 +556,7 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
         r.skip(P.num_extra_slice_header_bits);
         const unsigned slice_type = r.ue_max(2, "slice_type");
         if (slice_type != 2 && !seq) unsupported("non-intra slice (slice_type " + std::to_string(slice_type) + ") outside a sequence");
-        if (P.output_flag_present) r.skip(1);
+        const bool pic_output_flag = P.output_flag_present ? r.u(1) : true;
         if (S.separate_colour_plane) r.skip(2);
         int poc_lsb = 0;
         bool slice_tmvp = false;
@@ -585,10 +586,15 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
         }
         if (first) {   // 8.3.1 picture order count, 8.3.2: the pictures the RPS names (sequence mode)
           out.is_idr = idr;
-          out.poc = 0;
+          out.poc = idr ? 0 : poc_lsb;   // (a first IRAP picture: PicOrderCntMsb = 0, 8.3.1; what a still / the first sample of a track is committed with)
           out.keep_pocs.clear();
+          pic_poc_lsb = poc_lsb; pic_nal_type = type; pic_tid = (nal[1] & 7) - 1;
+          out.pic_output = pic_output_flag;
           if (seq) {
             const bool irap = type >= 16 && type <= 23;
+            // 8.3.3: the RASL pictures of an IRAP picture with NoRaslOutputFlag = 1 (a CRA that starts the sequence, a BLA) reference pictures that
+            // precede it in decoding order and are not there: they are neither decoded nor output
+            if ((type == 8 || type == 9) && seq->no_rasl_output) { out.skipped = true; out.pic_output = false; out.nal_type = type; return HIPDEC_OK; }
             if (idr || (irap && seq->first_picture)) out.poc = idr ? 0 : poc_lsb;
             else {
               const int max_lsb = 1 << S.log2_max_poc_lsb;
@@ -597,7 +603,6 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
               else if (poc_lsb > seq->prev_tid0_lsb && poc_lsb - seq->prev_tid0_lsb > max_lsb / 2) msb -= max_lsb;
               out.poc = msb + poc_lsb;
             }
-            pic_poc_lsb = poc_lsb; pic_nal_type = type;
             if (!idr) {
               for (int i = 0; i < rps.num_neg; i++) out.keep_pocs.push_back(out.poc + rps.delta_s0[i]);
               for (int i = 0; i < rps.num_pos; i++) out.keep_pocs.push_back(out.poc + rps.delta_s1[i]);
@@ -747,7 +752,7 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
       // VPS / AUD / SEI / EOS: nothing to do for an intra still
     }
     if (!have_picture) { err = "no coded picture in the pushed data"; return HIPDEC_ERR_NO_IMAGE; }
-    out.poc_lsb = pic_poc_lsb; out.nal_type = pic_nal_type;
+    out.poc_lsb = pic_poc_lsb; out.nal_type = pic_nal_type; out.temporal_id = pic_tid < 0 ? 0 : pic_tid;
     out.max_num_reorder = out.sps.max_num_reorder; out.max_dec_pic_buffering = out.sps.max_dec_pic_buffering;
     out.weight_tables.clear();
     if (out.is_inter) {   // the picture's reference table: every picture some P / B slice lists, once; SliceParams::ref_slot(_l1) index it
@@ -941,8 +946,11 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
 void seq_commit(SeqContext& seq, const ParsedPicture& pic, int)
 {
   const bool irap = pic.nal_type >= 16 && pic.nal_type <= 23;
+  // NoRaslOutputFlag (8.1.3): IDR and BLA pictures, and a CRA picture that is the first of the sequence
+  if (irap) seq.no_rasl_output = pic.is_idr || pic.nal_type <= 18 || seq.first_picture;
+  // prevTidOPic (8.3.1): the previous picture with TemporalId = 0 that is not a RASL, RADL or sub-layer non-reference picture
   if (pic.is_idr || (irap && seq.first_picture)) { seq.prev_tid0_lsb = pic.is_idr ? 0 : pic.poc_lsb; seq.prev_tid0_msb = 0; }
-  else if (irap || (pic.nal_type <= 9 && (pic.nal_type & 1))) { seq.prev_tid0_lsb = pic.poc_lsb; seq.prev_tid0_msb = pic.poc - pic.poc_lsb; }
+  else if (pic.temporal_id == 0 && (irap || (pic.nal_type <= 5 && (pic.nal_type & 1)))) { seq.prev_tid0_lsb = pic.poc_lsb; seq.prev_tid0_msb = pic.poc - pic.poc_lsb; }
   seq.first_picture = false;
   std::vector<RefPicture> kept;
   for (const RefPicture& rp : seq.dpb) {

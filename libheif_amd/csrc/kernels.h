@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "hevc_device.h"
+#include "batch_layout.h"
 
 namespace hipdec {
 
@@ -46,5 +47,45 @@ void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool 
 void launch_sao(const FilterArgs& a, int n_pics, int max_out_w, int max_out_h, bool wide, hipStream_t s, bool may_keep = true, bool restricted = true);
 // SAO + crop with the RGB24 emission fused into the store path (8-bit 4:2:0 only); color_params_dev: one colordev::ColorParams per picture
 void launch_sao_rgb(const FilterArgs& a, const void* color_params_dev, int n_pics, int max_out_w, int max_out_h, hipStream_t s, bool may_keep = true, bool restricted = true);
+
+// Chain batches (BatchLayout::chain; used by decoder.hip:launch_all and by the CPU-test emulation).  The motion fields of motion step k: k_motion over
+// the CTB rows of the step's pictures (rows of intra pictures return at once).  Needs the parser's output and the motion fields of earlier steps only.
+inline void launch_chain_motion(const BatchLayout& L, uint8_t* arena, int k, hipStream_t s)
+{
+  const BatchLayout::ChainStep& st = L.motion_steps[(size_t)k];
+  if (!st.any_inter) return;
+  MotionArgs ma{(const PicParams*)(arena + L.off_pics), (const RowDesc*)(arena + L.off_rows) + st.first_row, st.num_rows, arena,
+                (uint32_t*)(arena + L.off_row_progress), (uint32_t*)(arena + L.off_ticket) + BatchLayout::chain_ticket(k) + 1, (int32_t*)(arena + L.off_status)};
+  launch_motion(ma, s);
+}
+// The pixel stages of pixel step k: motion-compensated prediction, reconstruction, deblocking, SAO of the step's pictures together - and for a
+// picture with a conformance window one more SAO pass that writes the whole coded picture for the pictures that predict from it.  Stream order
+// makes every earlier step complete; the motion fields of the step's pictures must be (the caller orders launch_chain_motion before it).
+inline void launch_chain_pixels(const BatchLayout& L, uint8_t* arena, int k, hipStream_t s)
+{
+  const BatchLayout::ChainStep& st = L.pixel_steps[(size_t)k];
+  const PicParams* pics = (const PicParams*)(arena + L.off_pics);
+  int32_t* status = (int32_t*)(arena + L.off_status);
+  FilterArgs fa{pics + st.first, arena, status};
+  if (st.any_inter) launch_mc(fa, st.count, st.max_w, st.max_h, L.wide, s);
+  ReconArgs ra{pics, (const ReconWave*)(arena + L.off_rwaves) + st.first_rwave, st.num_rwaves, arena, (uint32_t*)(arena + L.off_row_progress),
+               (uint32_t*)(arena + L.off_ticket) + BatchLayout::chain_ticket(k), status};
+  launch_recon(ra, L.wide, s, L.any_inter);
+  launch_deblock(fa, st.count, st.max_w, st.max_h, L.wide, s);
+  bool may_keep = false, restricted = false;
+  for (int i = st.first; i < st.first + st.count; i++) {
+    const PicParams& P = L.params[(size_t)i];
+    if (P.transquant_bypass_enabled || (P.pcm_enabled && P.pcm_loop_filter_disabled)) may_keep = true;
+    if (!P.sao_free_neighbours) restricted = true;
+  }
+  launch_sao(fa, st.count, st.max_ow, st.max_oh, L.wide, s, may_keep, restricted);
+  for (int i = st.first; i < st.first + st.count; i++) {
+    const BatchLayout::ChainItem& ci = L.chain_items[(size_t)i];
+    if (!ci.off_full_pic) continue;
+    const PicParams& P = L.params[(size_t)i];
+    FilterArgs full{(const PicParams*)(arena + ci.off_full_pic), arena, status};
+    launch_sao(full, 1, P.width, P.height, L.wide, s, may_keep, restricted);
+  }
+}
 
 }  // namespace hipdec

@@ -216,6 +216,9 @@ void pinned_pool_clear()
   g_pinned.cached_bytes = 0;
 }
 
+static std::atomic<void (*)()> g_memory_pressure{nullptr};
+void set_memory_pressure_handler(void (*fn)()) { g_memory_pressure.store(fn); }
+
 hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity)
 {
   // round small arenas up so that items of similar size share a class
@@ -245,6 +248,10 @@ hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity)
   if (e != hipSuccess) {   // out of memory: drop the cache and retry once
     arena_pool_clear();
     e = hipMalloc(out, cap);
+  }
+  if (e != hipSuccess) {   // still none: whatever only a cache keeps alive goes too (the resident-plane registry of decoder.hip pins whole batch arenas)
+    (void)hipGetLastError();
+    if (auto cb = g_memory_pressure.load()) { cb(); arena_pool_clear(); e = hipMalloc(out, cap); }
   }
   *capacity = cap;
   return e;

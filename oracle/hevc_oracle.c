@@ -2057,7 +2057,7 @@ static void decode_slice(Dec* d, int nal_type, const uint8_t* nal, size_t nal_le
       }
       if (s->sps_temporal_mvp_enabled_flag) slice_temporal_mvp = br_u(&b, 1);
     }
-    if (hdr.first_slice_segment_in_pic_flag && d->seq_mode) inter_begin_picture(d, nal_type, poc_lsb, &rps);
+    if (hdr.first_slice_segment_in_pic_flag && d->seq_mode) inter_begin_picture(d, nal_type, (nal[1] & 7) - 1, poc_lsb, &rps);
     if (s->sao_enabled_flag) {
       hdr.slice_sao_luma_flag = br_u(&b, 1);
       if (s->chroma_format_idc) hdr.slice_sao_chroma_flag = br_u(&b, 1);

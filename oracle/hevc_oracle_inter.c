@@ -48,7 +48,7 @@ static void dpb_store_motion(Dec* d, RefPic* r)
 }
 
 /* at the first slice segment of a picture: POC of the picture, then the RPS decides which pictures stay and which one(s) list 0 holds */
-static void inter_begin_picture(Dec* d, int nal_type, int poc_lsb, const StRps* rps)
+static void inter_begin_picture(Dec* d, int nal_type, int temporal_id, int poc_lsb, const StRps* rps)
 {
   const SPS* s = d->s;
   int irap = nal_type >= 16 && nal_type <= 23, idr = nal_type == 19 || nal_type == 20;
@@ -59,8 +59,8 @@ static void inter_begin_picture(Dec* d, int nal_type, int poc_lsb, const StRps* 
     else if (poc_lsb > d->prev_tid0_lsb && poc_lsb - d->prev_tid0_lsb > MaxLsb / 2) msb = d->prev_tid0_msb - MaxLsb;
     else msb = d->prev_tid0_msb;
     d->poc = msb + poc_lsb;
-    /* prevTid0Pic: TemporalId 0 and not RASL / RADL / a sub-layer non-reference picture (here: every odd nal_unit_type below 16, and IRAPs) */
-    if (irap || (nal_type <= 9 && (nal_type & 1))) { d->prev_tid0_lsb = poc_lsb; d->prev_tid0_msb = msb; }
+    /* prevTid0Pic (8.3.1): TemporalId 0 and not a RASL / RADL / sub-layer non-reference picture: TRAIL_R 1, TSA_R 3, STSA_R 5 and the IRAPs */
+    if (temporal_id == 0 && (irap || (nal_type <= 5 && (nal_type & 1)))) { d->prev_tid0_lsb = poc_lsb; d->prev_tid0_msb = msb; }
   }
   d->first_picture = 0;
   /* 8.3.2: pictures that are in no subset of the RPS are no longer "used for reference" (IDR: none is) */

@@ -1224,7 +1224,7 @@ static void enc_picture(Enc* e, const uint16_t* const planes[3], const PicPlan* 
   rps.num_neg = plan->n_neg; rps.num_pos = plan->n_pos;
   for (int i = 0; i < plan->n_neg; i++) { rps.delta_s0[i] = plan->neg_poc[i] - plan->poc; rps.used_s0[i] = plan->neg_used[i]; }
   for (int i = 0; i < plan->n_pos; i++) { rps.delta_s1[i] = plan->pos_poc[i] - plan->poc; rps.used_s1[i] = plan->pos_used[i]; }
-  if (d->seq_mode) inter_begin_picture(d, nal_type, frame_idx & 255, &rps);
+  if (d->seq_mode) inter_begin_picture(d, nal_type, 0, frame_idx & 255, &rps);
   for (int c = 0; c < (s->chroma_format_idc ? 3 : 1); c++) {
     int W = c ? d->Wc : d->W, H = c ? d->Hc : d->H;
     int csw = c ? d->subw : 1, csh = c ? d->subh : 1;

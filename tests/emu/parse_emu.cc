@@ -73,6 +73,36 @@ EmuBatch* emu_seq_create_picture(EmuSeq* q, const uint8_t* data, size_t size, ch
   return b;
 }
 
+// A chain: n consecutive samples of the track parsed against the sequence state (each committed to a working copy before the next), ONE batch whose
+// reference tables address the earlier pictures of the same arena (batch_layout.h: layout_batch_plan_chain, as the product's decoder with look-ahead)
+EmuBatch* emu_seq_create_chain(EmuSeq* q, int n, const uint8_t* const* data, const size_t* sizes, char* errbuf, size_t errlen)
+{
+  EmuBatch* b = new EmuBatch();
+  std::string err;
+  int rc = layout_batch_plan_chain(b->L, n, (const void* const*)data, sizes, 0, err, q->ctx);
+  if (rc != 0) {
+    snprintf(errbuf, errlen, "%d: %s", rc, err.c_str());
+    delete b;
+    return nullptr;
+  }
+  if (!b->L.pics.empty()) {
+    b->arena.assign(b->L.arena_size + 1024, 0);
+    layout_batch_fill(b->L, (const void* const*)data, sizes, b->arena.data(), (uint64_t)(uintptr_t)b->arena.data());
+  }
+  q->alive.push_back(b);
+  return b;
+}
+int emu_num_items(EmuBatch* b) { return (int)b->L.pics.size(); }
+int emu_item_source(EmuBatch* b, int i) { return b->L.src(i); }
+// the chain was decoded: the track's sequence state moves behind its last picture (its pictures addressed absolutely from here on)
+int emu_seq_commit_chain(EmuSeq* q, EmuBatch* b)
+{
+  std::vector<int> own;
+  chain_resolve(b->L, (uint64_t)(uintptr_t)b->arena.data(), own);
+  q->ctx = b->L.seq_after;
+  return 0;
+}
+
 // runs every substream in index order (a WPP predecessor always has a smaller index); returns the device status word
 int emu_run_parse(EmuBatch* b)
 {

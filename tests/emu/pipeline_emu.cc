@@ -68,6 +68,39 @@ int emu_run_pipeline_rgb(EmuBatch* b, int stages, uint8_t* rgb)
   return b->status;
 }
 
+// a chain batch (emu_seq_create_chain) behind emu_run_parse(): the residual kernel over every picture, then the pixel stages picture by picture in
+// decoding order - the launch sequence of decoder.hip:launch_all for BatchLayout::chain
+int emu_run_pipeline_chain(EmuBatch* b)
+{
+  uint8_t* a = b->arena.data();
+  const BatchLayout& L = b->L;
+  const int n = (int)L.params.size();
+  if (!L.chain) return -1;
+  if (!n) return 0;
+  FilterArgs fa{(const PicParams*)(a + L.off_pics), a, (const int32_t*)(a + L.off_status)};
+  bool general = false;
+  for (const PicParams& P : L.params) if (P.chroma_format_idc >= 2) general = true;
+  launch_residual(fa, n, L.max_ctbs, general, nullptr);
+  // (the product runs the motion steps on a stream of their own; here: every motion step a pixel step needs, then the pixel step)
+  int motion_done = 0;
+  for (int k = 0; k < (int)L.pixel_steps.size(); k++) {
+    const BatchLayout::ChainStep& st = L.pixel_steps[(size_t)k];
+    const int need = L.motion_step_of[(size_t)(st.first + st.count - 1)] + 1;
+    for (; motion_done < need; motion_done++) launch_chain_motion(L, a, motion_done, nullptr);
+    launch_chain_pixels(L, a, k, nullptr);
+  }
+  b->status = *(int32_t*)(a + L.off_status);
+  return b->status;
+}
+
+// step structure of a chain batch: number of pixel steps / motion steps (batch_layout.h)
+int emu_chain_steps(EmuBatch* b, int* pixel_steps, int* motion_steps)
+{
+  if (!b->L.chain) return -1;
+  *pixel_steps = (int)b->L.pixel_steps.size(); *motion_steps = (int)b->L.motion_steps.size();
+  return 0;
+}
+
 // The picture of batch `b` (one item) was decoded: it enters the sequence's DPB as a reference picture - its output planes when they ARE the
 // coded picture, else an uncropped copy made by running the SAO kernel once more without the conformance window (what the product's decoder
 // does lazily, decoder.hip) - and the DPB drops what the picture's RPS no longer names.

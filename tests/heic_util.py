@@ -383,3 +383,56 @@ def build_tili(tiles, rows, cols, tile_w, tile_h, out_w, out_h, bit_depth=8, chr
 
     off = len(ftyp) + len(make_meta(0)) + 8
     return ftyp + make_meta(off) + _box("mdat", item_data)
+
+
+def build_sequence(samples, width, height, bit_depth=8, chroma_format_idc=1, timescale=30, composition_offsets=None, chunk_size=0):
+    """An image-sequence file the REAL libheif opens as a visual track (ISO/IEC 14496-12 movie structure, brand 'msf1'; boxes as
+    libheif/sequences/seq_boxes.cc parses them, requirements of Track::load, sequences/track.cc:208-460): ftyp + moov(mvhd, trak(tkhd, mdia(mdhd, hdlr
+    'pict', minf(vmhd, dinf, stbl(stsd(hvc1 + hvcC), stts, [ctts], stsc, stsz, stco))))) + mdat.
+    samples: access units in DECODING order, plugin framing; the parameter sets of the first one go into the sample entry's hvcC (libheif pushes them
+    with a chunk's first sample, codecs/decoder.cc:422) and every sample is stored with its slice NAL units only.
+    composition_offsets: per sample (B tracks: decoding order != output order) -> a version-0 'ctts'; libheif pushes samples in file order and
+    takes the output order from the decoder.  chunk_size: samples per chunk (0: one chunk)."""
+    n = len(samples)
+    nals0 = split_nals(samples[0])
+    payloads = [_payload(split_nals(s)) for s in samples]
+    hvcc = _hvcc(nals0, chroma_format_idc, bit_depth)
+    entry = (b"\0" * 6 + struct.pack(">H", 1) + struct.pack(">HH", 0, 0) + b"\0" * 12 + struct.pack(">HH", width, height) +
+             struct.pack(">II", 0x00480000, 0x00480000) + struct.pack(">I", 0) + struct.pack(">H", 1) + b"\0" * 32 + struct.pack(">Hh", 24, -1))
+    stsd = _fullbox("stsd", 0, 0, struct.pack(">I", 1) + _box("hvc1", entry + hvcc))
+    stts = _fullbox("stts", 0, 0, struct.pack(">I", 1) + struct.pack(">II", n, 1))
+    ctts = b""
+    if composition_offsets is not None:
+        ctts = _fullbox("ctts", 0, 0, struct.pack(">I", n) + b"".join(struct.pack(">II", 1, int(o)) for o in composition_offsets))
+    per = chunk_size if chunk_size and chunk_size > 0 else n
+    chunks = [list(range(a, min(a + per, n))) for a in range(0, n, per)]
+    stsc_entries = []
+    for ci, ch in enumerate(chunks):
+        if not stsc_entries or stsc_entries[-1][1] != len(ch):
+            stsc_entries.append((ci + 1, len(ch), 1))
+    stsc = _fullbox("stsc", 0, 0, struct.pack(">I", len(stsc_entries)) + b"".join(struct.pack(">III", *e) for e in stsc_entries))
+    stsz = _fullbox("stsz", 0, 0, struct.pack(">II", 0, n) + b"".join(struct.pack(">I", len(p)) for p in payloads))
+    matrix = struct.pack(">9I", 0x10000, 0, 0, 0, 0x10000, 0, 0, 0, 0x40000000)
+    mvhd = _fullbox("mvhd", 0, 0, struct.pack(">IIII", 0, 0, timescale, n) + struct.pack(">IH", 0x10000, 0x100) + b"\0" * 10 + matrix + b"\0" * 24 + struct.pack(">I", 2))
+    tkhd = _fullbox("tkhd", 0, 3, struct.pack(">IIII", 0, 0, 1, 0) + struct.pack(">I", n) + b"\0" * 8 + struct.pack(">HHHH", 0, 0, 0, 0) + matrix +
+                    struct.pack(">II", width << 16, height << 16))
+    mdhd = _fullbox("mdhd", 0, 0, struct.pack(">IIII", 0, 0, timescale, n) + struct.pack(">HH", 0x55C4, 0))
+    hdlr = _fullbox("hdlr", 0, 0, struct.pack(">I4s", 0, b"pict") + b"\0" * 12 + b"\0")
+    vmhd = _fullbox("vmhd", 0, 1, b"\0" * 8)
+    dinf = _box("dinf", _fullbox("dref", 0, 0, struct.pack(">I", 1) + _fullbox("url ", 0, 1, b"")))
+    ftyp = _box("ftyp", b"msf1" + struct.pack(">I", 0) + b"msf1heic")
+
+    def make_moov(offsets):
+        stco = _fullbox("stco", 0, 0, struct.pack(">I", len(offsets)) + b"".join(struct.pack(">I", o) for o in offsets))
+        stbl = _box("stbl", stsd + stts + ctts + stsc + stsz + stco)
+        minf = _box("minf", vmhd + dinf + stbl)
+        mdia = _box("mdia", mdhd + hdlr + minf)
+        return _box("moov", mvhd + _box("trak", tkhd + mdia))
+
+    moov_len = len(make_moov([0] * len(chunks)))
+    pos = len(ftyp) + moov_len + 8
+    offsets = []
+    for ch in chunks:
+        offsets.append(pos)
+        pos += sum(len(payloads[i]) for i in ch)
+    return ftyp + make_moov(offsets) + _box("mdat", b"".join(payloads))

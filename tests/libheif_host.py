@@ -158,3 +158,49 @@ def decode(data, colorspace=COLORSPACE_UNDEFINED, chroma=CHROMA_UNDEFINED, max_t
             L.heif_image_release(img)
         L.heif_image_handle_release(h)
         L.heif_context_free(ctx)
+
+
+ERROR_END_OF_SEQUENCE = 13
+
+
+def decode_track(data, colorspace=COLORSPACE_UNDEFINED, chroma=CHROMA_UNDEFINED, track_id=0, max_images=None):
+    """heif_track_decode_next_image() (api/libheif/heif_sequences.h:218) on the first visual track until End_of_sequence: what an application does
+    with an image-sequence file.  libheif's Track_Visual::decode_next_image_sample (sequences/track_visual.cc:175-330) drives the decoder plugin:
+    push_data2 per sample with the sample index as user_data, decode_next_image2 polls, flush_data at the end.  Returns the images in the
+    order libheif delivers them: [{'planes': [Y, Cb, Cr]} | {'rgb': rows}]."""
+    L = lib()
+    vp = C.c_void_p
+    L.heif_context_get_track.restype = vp
+    L.heif_context_get_track.argtypes = [vp, C.c_uint32]
+    L.heif_track_release.argtypes = [vp]
+    L.heif_track_decode_next_image.restype = HeifError
+    L.heif_track_decode_next_image.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int, vp]
+    L.heif_context_has_sequence.argtypes = [vp]
+    ctx = L.heif_context_alloc()
+    out = []
+    track = None
+    try:
+        check(L.heif_context_read_from_memory_without_copy(ctx, data, len(data), None))
+        assert L.heif_context_has_sequence(ctx)
+        track = vp(L.heif_context_get_track(ctx, track_id))
+        assert track
+        while max_images is None or len(out) < max_images:
+            img = vp()
+            e = L.heif_track_decode_next_image(track, C.byref(img), colorspace, chroma, None)
+            if e.code == ERROR_END_OF_SEQUENCE:
+                break
+            check(e)
+            try:
+                if chroma in (CHROMA_RGB, CHROMA_RGBA):
+                    out.append({"rgb": _plane(L, img, CHANNEL_INTERLEAVED, 1, 3 if chroma == CHROMA_RGB else 4)})
+                else:
+                    bpp = L.heif_image_get_bits_per_pixel_range(img, CHANNEL_Y)
+                    bs = 2 if bpp > 8 else 1
+                    out.append({"planes": [p for p in (_plane(L, img, c, bs) for c in (CHANNEL_Y, CHANNEL_CB, CHANNEL_CR)) if p is not None], "bit_depth": bpp})
+            finally:
+                L.heif_image_release(img)
+        return out
+    finally:
+        if track:
+            L.heif_track_release(track)
+        L.heif_context_free(ctx)

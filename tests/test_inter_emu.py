@@ -23,6 +23,12 @@ def _lib():
     L.emu_out_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     L.emu_motion.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.emu_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.emu_seq_create_chain.restype = C.c_void_p
+    L.emu_seq_create_chain.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+    L.emu_seq_commit_chain.argtypes = [C.c_void_p, C.c_void_p]
+    L.emu_run_pipeline_chain.argtypes = [C.c_void_p]
+    L.emu_num_items.argtypes = [C.c_void_p]
+    L.emu_item_source.argtypes = [C.c_void_p, C.c_int]
     return L
 
 
@@ -38,47 +44,74 @@ def parameter_sets(au):
     return out
 
 
-def decode_sequence_emu(aus, want_motion=False):
+def _read_picture(L, b, i, want_motion):
+    sz = (C.c_int * 5)()
+    L.emu_out_size(b, i, sz)
+    w, h, cw, ch, es = list(sz)
+    dt = np.uint16 if es == 2 else np.uint8
+    planes = []
+    for c in range(3 if cw else 1):
+        a = np.zeros((h, w) if c == 0 else (ch, cw), dt)
+        L.emu_plane(b, i, c, a.ctypes.data)
+        planes.append(a)
+    pic = {"planes": planes}
+    if want_motion:
+        info = (C.c_int * 7)()
+        L.emu_info(b, i, info)           # coded size: the motion field covers the coded picture
+        uw, uh = (info[0] + 3) // 4, (info[1] + 3) // 4
+        mv, ref, pred = np.zeros((uh, uw, 2, 2), np.int16), np.zeros((uh, uw, 2), np.int8), np.zeros((uh, uw), np.uint8)
+        if L.emu_motion(b, i, mv.ctypes.data, ref.ctypes.data, pred.ctypes.data) == 0:
+            pic.update(mf_mv=mv, mf_ref=ref, map_pred=pred)
+    return pic
+
+
+def decode_sequence_emu(aus, want_motion=False, chain=0):
+    """chain = 0: one launch set per sample (the instance's state committed after every picture); chain = K: the first sample alone, then K samples
+    per launch set the way the decoder's look-ahead runs them (parse + residual over all K, the pixel stages picture by picture)"""
     L = _lib()
     ps = parameter_sets(aus[0])
     aus = [aus[0]] + [ps + a for a in aus[1:]]
     q = C.c_void_p(L.emu_seq_new())
     out = []
     try:
-        for au in aus:
+        k = 0
+        while k < len(aus):
             err = C.create_string_buffer(512)
+            if chain and k > 0:
+                group = aus[k:k + chain]
+                ptrs = (C.c_char_p * len(group))(*group)
+                sizes = (C.c_size_t * len(group))(*[len(a) for a in group])
+                b = L.emu_seq_create_chain(q, len(group), ptrs, sizes, err, 512)
+                assert b, err.value.decode()
+                b = C.c_void_p(b)
+                n = L.emu_num_items(b)
+                if n:
+                    assert L.emu_run_parse(b) == 0, "parse status"
+                    assert L.emu_run_pipeline_chain(b) == 0, "pipeline status"
+                assert [L.emu_item_source(b, i) for i in range(n)] == list(range(len(group)))      # (no RASL picture is dropped in these streams)
+                for i in range(n):
+                    out.append(_read_picture(L, b, i, want_motion))
+                assert L.emu_seq_commit_chain(q, b) == 0
+                k += len(group)
+                continue
+            au = aus[k]
             b = L.emu_seq_create_picture(q, au, len(au), err, 512)
             assert b, err.value.decode()
             b = C.c_void_p(b)
             assert L.emu_run_parse(b) == 0, "parse status"
             assert L.emu_run_pipeline(b, 15) == 0, "pipeline status"
-            sz = (C.c_int * 5)()
-            L.emu_out_size(b, 0, sz)
-            w, h, cw, ch, es = list(sz)
-            dt = np.uint16 if es == 2 else np.uint8
-            planes = []
-            for c in range(3 if cw else 1):
-                a = np.zeros((h, w) if c == 0 else (ch, cw), dt)
-                L.emu_plane(b, 0, c, a.ctypes.data)
-                planes.append(a)
-            pic = {"planes": planes}
-            if want_motion:
-                info = (C.c_int * 7)()
-                L.emu_info(b, 0, info)           # coded size: the motion field covers the coded picture
-                uw, uh = (info[0] + 3) // 4, (info[1] + 3) // 4
-                mv, ref, pred = np.zeros((uh, uw, 2, 2), np.int16), np.zeros((uh, uw, 2), np.int8), np.zeros((uh, uw), np.uint8)
-                if L.emu_motion(b, 0, mv.ctypes.data, ref.ctypes.data, pred.ctypes.data) == 0:
-                    pic.update(mf_mv=mv, mf_ref=ref, map_pred=pred)
-            out.append(pic)
+            out.append(_read_picture(L, b, 0, want_motion))
             assert L.emu_seq_commit(q, b) == 0
+            k += 1
     finally:
         L.emu_seq_free(q)
     return out
 
 
-def check_sequence(aus, name=""):
+def check_sequence(aus, name="", chain=0):
     ref = orc.decode_sequence(aus, taps=True)
-    got = decode_sequence_emu(aus, want_motion=True)
+    got = decode_sequence_emu(aus, want_motion=True, chain=chain)
+    assert len(got) == len(ref)
     for i, (r, g) in enumerate(zip(ref, got)):
         if "map_pred" in g:      # a P picture: the motion field first (where the units are inter coded)
             uh, uw = g["map_pred"].shape
@@ -163,3 +196,83 @@ def test_reference_of_another_format_is_refused_by_the_host():
         assert b"another format" in err.value
     finally:
         L.emu_seq_free(q)
+
+
+# ---- chains: the decoder's look-ahead (HIPDEC_SEQ_LOOKAHEAD) parses K samples of a track in ONE launch set; references inside the set ----------
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+@pytest.mark.parametrize("chain", [2, 8])
+def test_emulated_chain_p_pictures(name, chain):
+    frames = make_frames(136, 104, 6)
+    aus = orc.encode_sequence(frames, qp=26, global_mv_x=-8, global_mv_y=-4, inter_skip_pct=20, seed=21, **CONFIGS[name])
+    check_sequence(aus, name, chain=chain)
+
+
+@pytest.mark.parametrize("name", sorted(B_CONFIGS))
+@pytest.mark.parametrize("chain", [3, 16])
+def test_emulated_chain_b_tmvp_weighted(name, chain):
+    """coding order != output order inside a chain; the collocated picture and both lists' references are earlier items of the same launch set"""
+    frames = make_frames(136, 104, 8)
+    aus = orc.encode_sequence(frames, qp=26, global_mv_x=-8, global_mv_y=-4, inter_skip_pct=20, seed=21, **B_CONFIGS[name])
+    check_sequence(aus, name, chain=chain)
+
+
+def test_emulated_chain_main10_mono_cropped_and_idr_inside():
+    frames = make_frames(120, 88, 6, 10)
+    check_sequence(orc.encode_sequence(frames, qp=24, global_mv_x=6, global_mv_y=-10, seed=5, bit_depth=10, amp=1, inter_num_refs=2, b_frames=2, b_ref=1,
+                                       temporal_mvp=1, weighted_pred=1), "main10", chain=4)
+    frames = make_frames(70, 42, 5, 8, mono=True)
+    check_sequence(orc.encode_sequence(frames, qp=22, inter_num_refs=2, b_frames=1, temporal_mvp=1, weighted_pred=1), "mono", chain=3)
+    frames = make_frames(70, 42, 7)        # coded 72 x 48: the in-batch references are the uncropped copies of the second SAO pass
+    check_sequence(orc.encode_sequence(frames, qp=22, global_mv_x=3, global_mv_y=17, inter_num_refs=2, amp=1, b_frames=2, b_ref=1, temporal_mvp=1), "cropped", chain=4)
+    # two coded video sequences back to back: the IDR picture of the second one sits inside a chain
+    a = orc.encode_sequence(make_frames(136, 104, 4), qp=26, inter_num_refs=2)
+    b = orc.encode_sequence(make_frames(136, 104, 4, seed=9), qp=26, inter_num_refs=2)
+    both = a + [parameter_sets(b[0]) + x if i else x for i, x in enumerate(b)]
+    ref = orc.decode_sequence(a) + orc.decode_sequence(b)
+    got = decode_sequence_emu(both, chain=5)
+    assert len(got) == len(ref)
+    for i, (r, g) in enumerate(zip(ref, got)):
+        for c in range(3):
+            np.testing.assert_array_equal(g["planes"][c], r["planes"][c], err_msg="two sequences: picture %d plane %d" % (i, c))
+
+
+def test_chain_steps_follow_the_dependencies():
+    """pixel steps break where a picture predicts from an earlier picture of the run, motion steps only where the COLLOCATED picture is in the run:
+    an intra-only chain is one step (a plain batch), IPPP without temporal candidates is one motion step, non-reference B pictures share a step"""
+    L = _lib()
+    L.emu_chain_steps.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+
+    def steps(aus, first_alone=True):
+        ps = parameter_sets(aus[0])
+        q = C.c_void_p(L.emu_seq_new())
+        try:
+            err = C.create_string_buffer(512)
+            b = C.c_void_p(L.emu_seq_create_picture(q, aus[0], len(aus[0]), err, 512))
+            assert L.emu_run_parse(b) == 0 and L.emu_run_pipeline(b, 15) == 0 and L.emu_seq_commit(q, b) == 0
+            group = [ps + a for a in aus[1:]]
+            ptrs = (C.c_char_p * len(group))(*group)
+            sizes = (C.c_size_t * len(group))(*[len(a) for a in group])
+            b = L.emu_seq_create_chain(q, len(group), ptrs, sizes, err, 512)
+            assert b, err.value.decode()
+            px, mo = C.c_int(), C.c_int()
+            assert L.emu_chain_steps(C.c_void_p(b), C.byref(px), C.byref(mo)) == 0
+            return px.value, mo.value
+        finally:
+            L.emu_seq_free(q)
+
+    frames = make_frames(72, 56, 7)
+    intra = [orc.encode(f, qp=30) for f in frames]
+    assert steps([intra[0]] + [b"".join(x for x in _split(a) if (x[4] >> 1) & 63 < 32) for a in intra[1:]]) == (1, 1)
+    assert steps(orc.encode_sequence(frames, qp=30, temporal_mvp=0)) == (6, 1)          # every P picture predicts from the one before; no collocated picture
+    assert steps(orc.encode_sequence(frames, qp=30, temporal_mvp=1)) == (6, 6)
+    px, mo = steps(orc.encode_sequence(frames, qp=30, b_frames=2, b_ref=0, temporal_mvp=0))
+    assert px < 6 and mo == 1                                                          # the two B pictures between anchors predict from the anchors only
+
+
+def _split(stream):
+    out, p = [], 0
+    while p + 4 <= len(stream):
+        n = int.from_bytes(stream[p:p + 4], "big")
+        out.append(stream[p:p + 4 + n])
+        p += 4 + n
+    return out

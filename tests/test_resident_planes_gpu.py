@@ -117,3 +117,36 @@ def test_entries_serve_one_conversion_and_tracking_can_be_switched_off():
     assert _resident(lib) == b1
     lib.hipdec_decoder_free(dec)
     lib.hipdec_forget_resident_planes()
+
+
+def test_registry_is_bounded_by_the_device_bytes_it_pins():
+    """a host that never converts colour never consumes entries; every entry keeps a whole launch-set arena alive.  With a byte cap
+    (HIPDEC_RESIDENT_MAX_BYTES; default an eighth of the device) the registry drops its oldest entries instead of pinning HBM without bound."""
+    import os, subprocess, sys
+    code = r"""
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import test_resident_planes_gpu as t
+from oracle import pyoracle as orc
+lib = t._lib()
+lib.hipdec_resident_plane_stats.restype = None
+lib.hipdec_resident_plane_stats.argtypes = [C.POINTER(C.c_uint64)] * 2
+lib.hipdec_set_plane_tracking(1)
+s = orc.encode(orc.synth_image(256, 192, 8, 1, seed=2))
+keep, peak = [], 0
+for i in range(40):
+    h, planes = t._decode_tracked(lib, s)       # never converted: nothing consumes the entries
+    keep.append(planes)
+    lib.hipdec_decoder_free(h)
+    n, b = C.c_uint64(), C.c_uint64()
+    lib.hipdec_resident_plane_stats(C.byref(n), C.byref(b))
+    peak = max(peak, b.value)
+print("PEAK", peak, n.value)
+""" % (os.path.dirname(os.path.abspath(__file__)), os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    cap = 24 << 20                                  # six 4 MiB arenas
+    env = dict(os.environ, HIPDEC_RESIDENT_MAX_BYTES=str(cap), HIPDEC_RESIDENT_TTL_MS="600000")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    peak, entries = [int(x) for x in out.stdout.split("PEAK")[1].split()]
+    assert 0 < peak <= cap + (8 << 20), (peak, cap)   # (one arena above the cap at most, before the sweep behind the insert)
+    assert entries < 40 * 3

@@ -16,6 +16,22 @@ import libheif_host as lh
 pytestmark = pytest.mark.gpu
 
 
+def _set_lookahead(k):
+    """samples the decoder gathers behind a track's first picture before it decodes them as ONE launch set (hipdec_set_sequence_lookahead)"""
+    import libheif_amd
+    lib = libheif_amd.load_library()
+    lib.hipdec_set_sequence_lookahead.argtypes = [C.c_int]
+    lib.hipdec_set_sequence_lookahead.restype = None
+    lib.hipdec_set_sequence_lookahead(k)
+
+
+@pytest.fixture(params=[8, 0, 3], ids=["lookahead8", "lookahead0", "lookahead3"])
+def lookahead(request):
+    _set_lookahead(request.param)
+    yield request.param
+    _set_lookahead(8)
+
+
 def _nals(stream):
     out, p = [], 0
     while p < len(stream):
@@ -61,7 +77,7 @@ class HeifError(C.Structure):
 
 
 @pytest.mark.skipif(not lh.available(), reason="oracle/_ref/libheif.so not built")
-def test_plugin_function_table_round_trips_user_data_per_sample():
+def test_plugin_function_table_round_trips_user_data_per_sample(lookahead):
     """the slots of heif_decoder_plugin as libheif calls them for a track: new_decoder2, then per sample push_data2(user_data) and
     decode_next_image2(&user_data) (api/libheif/heif_plugin.h:85-169)"""
     import libheif_amd
@@ -95,21 +111,32 @@ def test_plugin_function_table_round_trips_user_data_per_sample():
     samples, refs = _samples(3)
     p_aus, p_refs = _p_sequence(4, inter_num_refs=2, amp=1)      # then a track with P pictures through the same decoder instance
     samples, refs = samples + p_aus, refs + p_refs
-    try:
-        for k, (s, ref) in enumerate(zip(samples, refs)):
-            e = plug.push_data2(dec, s, len(s), 1000 + k)
-            assert e.code == 0, e.message
+    got = []
+
+    def poll_all():
+        while True:
             img, ud = vp(), C.c_size_t(12345)
             e = plug.decode_next_image2(dec, C.byref(img), C.byref(ud), None)
             assert e.code == 0, e.message
-            assert img.value and ud.value == 1000 + k
-            for c, ch in enumerate((lh.CHANNEL_Y, lh.CHANNEL_CB, lh.CHANNEL_CR)):
-                np.testing.assert_array_equal(lh._plane(L, img, ch), ref["planes"][c])
+            if not img.value:                  # Ok with *out == NULL (decoder.cc:538-552): libheif pushes the next sample (track_visual.cc:200-260)
+                return
+            got.append(([lh._plane(L, img, ch) for ch in (lh.CHANNEL_Y, lh.CHANNEL_CB, lh.CHANNEL_CR)], ud.value))
             L.heif_image_release(img)
-            img2, ud2 = vp(), C.c_size_t(0)
-            e = plug.decode_next_image2(dec, C.byref(img2), C.byref(ud2), None)   # nothing behind it: Ok with *out == NULL (decoder.cc:538-552)
-            assert e.code == 0 and not img2.value
+
+    try:
+        for k, s in enumerate(samples):
+            e = plug.push_data2(dec, s, len(s), 1000 + k)
+            assert e.code == 0, e.message
+            poll_all()
+            if k == 0 or lookahead <= 1:
+                assert len(got) == k + 1       # the first picture of a decoder never waits; without look-ahead none does (no B pictures here)
         assert plug.flush_data(dec).code == 0
+        poll_all()
+        assert len(got) == len(samples)
+        for k, ((planes, ud), ref) in enumerate(zip(got, refs)):
+            assert ud == 1000 + k              # coding order == output order in these tracks; every picture carries its own sample's user_data
+            for c in range(3):
+                np.testing.assert_array_equal(planes[c], ref["planes"][c], err_msg="sample %d plane %d" % (k, c))
     finally:
         plug.free_decoder(dec)
 
@@ -136,7 +163,7 @@ def test_plugin_function_table_round_trips_user_data_per_sample():
         for k, s in enumerate(b_aus):
             assert plug.push_data2(dec, s, len(s), 7000 + k).code == 0
             poll()
-        assert len(outputs) < len(b_aus)                      # the last anchor's B pictures were still waiting
+        assert len(outputs) < len(b_aus)                      # the last anchor's B pictures (and the samples the look-ahead holds) were still waiting
         assert plug.flush_data(dec).code == 0
         poll()
         assert len(outputs) == len(b_aus)
@@ -240,7 +267,7 @@ B_CASES = {
 
 
 @pytest.mark.parametrize("name", sorted(B_CASES))
-def test_b_tmvp_weighted_sequences_decode_bit_exact_in_output_order(name):
+def test_b_tmvp_weighted_sequences_decode_bit_exact_in_output_order(name, lookahead):
     """samples pushed in CODING order (as the track stores them); the pictures come out in OUTPUT order (bumping, C.5.2.2), each with the user_data of
     its own sample, each bit-exact against the oracle's picture of that POC"""
     from libheif_amd.decoder import HipDecoder
@@ -282,7 +309,7 @@ def test_b_sequence_in_coding_order_through_the_legacy_call():
     d.free()
 
 
-def test_two_coded_video_sequences_back_to_back_come_out_in_order():
+def test_two_coded_video_sequences_back_to_back_come_out_in_order(lookahead):
     """an IDR picture in the middle of a track starts a new coded video sequence: POCs start over, and everything of the first sequence that is still
     waiting for output precedes it (C.5.2.2); no flush in between"""
     from libheif_amd.decoder import HipDecoder
@@ -306,3 +333,93 @@ def test_two_coded_video_sequences_back_to_back_come_out_in_order():
         for c in range(3):
             np.testing.assert_array_equal(img.planes[c], ref["planes"][c], err_msg="output %d (POC %d) plane %d" % (k, ref["poc"], c))
     d.free()
+
+
+def test_whole_track_pushed_at_once_is_split_into_access_units(lookahead):
+    """libde265 takes any number of pictures per push (decoder_libde265.cc:322-368 only frames NAL units): a host that pushes a whole track in one
+    call gets every picture, in output order; the first access unit is the still-image case, the rest goes through the look-ahead in chains"""
+    from libheif_amd.decoder import HipDecoder
+    aus, refs = _p_sequence(11, b_frames=2, b_ref=1, temporal_mvp=1, inter_num_refs=2)
+    expect = [r for _, r in sorted((r["poc"], r) for r in refs)]
+    d = HipDecoder()
+    d.push_data(b"".join(aus))
+    got = []
+    r = d.next_picture(flush=True)
+    while r is not None:
+        got.append(r[0])
+        r = d.next_picture(flush=True)
+    assert len(got) == len(expect)
+    for k, (img, ref) in enumerate(zip(got, expect)):
+        for c in range(3):
+            np.testing.assert_array_equal(img.planes[c], ref["planes"][c], err_msg="output %d plane %d" % (k, c))
+    d.free()
+
+
+def test_a_picture_pushed_in_pieces_is_one_sample():
+    """heif_plugin.h:113-115: push_data may be called several times for one picture - parameter sets, then the slice segments one by one"""
+    from libheif_amd.decoder import HipDecoder
+    aus, refs = _p_sequence(3, num_slices=3, wpp=0)
+    d = HipDecoder()
+    for au, ref in zip(aus, refs):
+        for x in _nals(au):
+            d.push_data(x)
+        img = d.decode_next_image()
+        assert img is not None and d.decode_next_image() is None
+        for c in range(3):
+            np.testing.assert_array_equal(img.planes[c], ref["planes"][c])
+    d.free()
+
+
+# ---- f3 through the REAL libheif: an image-sequence file (moov / trak), heif_track_decode_next_image() until End_of_sequence -----------------------
+# libheif's default decoding options convert every decoded image to the sRGB nclx (context.cc:1533-1558), so the tracks signal exactly that profile in
+# the VUI: the plugin's planes then pass through untouched (as tests/test_plugin_dropin.py does for stills)
+SRGB_VUI = dict(vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1)
+TRACKS = {
+    "ippp": dict(inter_num_refs=2, amp=1),
+    "ibbp_tmvp_weighted": dict(b_frames=2, b_ref=1, temporal_mvp=1, weighted_pred=1, inter_num_refs=2),
+    "ibp_main10": dict(b_frames=1, temporal_mvp=1, bit_depth=10),
+    "intra_only": None,
+}
+
+
+@pytest.mark.skipif(not lh.available(), reason="oracle/_ref/libheif.so not built")
+@pytest.mark.parametrize("name", sorted(TRACKS))
+def test_sequence_track_through_libheif(name, lookahead):
+    """libheif/sequences/track_visual.cc:175-330 (Track_Visual::decode_next_image_sample) drives the plugin: one push_data2 per sample, polls of
+    decode_next_image2 in between, flush_data behind the last sample.  Every image of the track, in the order libheif delivers them (= output
+    order), equals the oracle's picture of that POC; with the look-ahead the plugin answers 'no image yet' until its window is full."""
+    from heic_util import build_sequence
+    lh.load_hip_plugin()
+    n = 13
+    if TRACKS[name] is None:
+        aus, refs = _samples(6, **SRGB_VUI)
+        expect = refs
+        bd = 8
+    else:
+        cfg = dict(TRACKS[name], **SRGB_VUI)
+        bd = cfg.pop("bit_depth", 8)
+        aus, refs = _p_sequence(n, bit_depth=bd, **cfg)
+        expect = [r for _, r in sorted((r["poc"], r) for r in refs)]
+    data = build_sequence(aus, 200, 136, bit_depth=bd)
+    got = lh.decode_track(data)
+    assert len(got) == len(expect)
+    for k, (g, r) in enumerate(zip(got, expect)):
+        assert g["bit_depth"] == bd
+        for c in range(3):
+            np.testing.assert_array_equal(g["planes"][c], r["planes"][c], err_msg="%s: image %d plane %d" % (name, k, c))
+
+
+@pytest.mark.skipif(not lh.available(), reason="oracle/_ref/libheif.so not built")
+def test_sequence_track_to_rgb_through_libheif():
+    """the same call with interleaved RGB requested: libheif's colour conversion runs behind every frame; expectation = the compiled reference
+    colour op (ref_harness) on the oracle's planes"""
+    import ref_harness as rh
+    from heic_util import build_sequence
+    lh.load_hip_plugin()
+    aus, refs = _p_sequence(6, b_frames=1, temporal_mvp=1, **SRGB_VUI)
+    expect = [r for _, r in sorted((r["poc"], r) for r in refs)]
+    got = lh.decode_track(build_sequence(aus, 200, 136), lh.COLORSPACE_RGB, lh.CHROMA_RGB)
+    assert len(got) == len(expect)
+    for k, (g, r) in enumerate(zip(got, expect)):
+        exp = rh.convert(r["planes"], 8, rh.CH_420, r["nclx"], rh.CS_RGB, rh.CH_RGB)[0]
+        np.testing.assert_array_equal(g["rgb"], exp[:, :200 * 3], err_msg="image %d" % k)

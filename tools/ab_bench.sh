@@ -5,6 +5,7 @@
 br=${1:-candidates}; shift || true
 alt=build/ab/$br/libheif_amd/libheifhip.so
 mkdir -p gpurun_out
+export HIPDEC_DEV_AB=1   # libheif_amd/_capi.py honours HIPDEC_LIBRARY only with this
 [ -f $alt ] || { echo "no $alt: run tools/ab_build.sh $br first"; exit 1; }
 for which in tree $br; do
   lib=""; [ $which = tree ] || lib=$PWD/$alt

@@ -3,6 +3,7 @@
 # times, one 4K still, optionally `value` from host bytes and the GPU tier under the last build named.
 # usage: [TESTS=1] [FROM_HOST=1] [STEPS=4] bash tools/ab_multi.sh <branch> [<branch> ...]
 mkdir -p gpurun_out
+export HIPDEC_DEV_AB=1   # libheif_amd/_capi.py honours HIPDEC_LIBRARY only with this
 libs="tree $*"; last=""
 show() { python - "$1" "$2" <<'PY'
 import json, sys
