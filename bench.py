@@ -212,9 +212,17 @@ def issue_roofline(kernels, px, cu_count, clock_ghz):
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_issue.json")))
     except Exception:
         return None
+    # the clock the chip actually sustains under these kernels (MI355X guide, DVFS: effective clock = GRBM_GUI_ACTIVE / kernel wall time), recorded by
+    # the PMC pass when it collected that counter; else the nominal maximum, which UNDERSTATES the fractions (the guide reports 1.9 - 2.3 GHz under load)
+    eff = rec.get("effective_clock_ghz") or {}
+    nominal = clock_ghz
+    if eff.get("k_parse"):
+        clock_ghz = float(eff["k_parse"])
     peak = cu_count * clock_ghz            # G scalar instructions / s
     out = {"peak_ginst_s": round(peak, 1), "peak_is": "%d CUs x %.2f GHz x 1 SALU instruction per cycle and CU; the vector pipes take twice that in wave64 "
                                                    "instructions (4 SIMD-32 units per CU, 2 cycles per wave64 VALU instruction)" % (cu_count, clock_ghz),
+           "clock_ghz": round(clock_ghz, 3), "clock_source": ("GRBM_GUI_ACTIVE / kernel time of k_parse in the PMC pass (profiles/pmc_issue.json)" if eff.get("k_parse")
+                                                               else "nominal maximum clock %.2f GHz: the effective clock under load is lower, so the fractions are lower bounds" % nominal),
            "source": rec.get("source"), "commit": rec.get("commit"), "kernels": {}}
     for key, name in (("parse", "k_parse"), ("recon", "k_recon"), ("residual", "k_residual"), ("deblock", "k_deblock"), ("sao_rgb", "k_sao"), ("sao", "k_sao")):
         if key in kernels and key not in out["kernels"] and name in rec.get("insts_per_px", {}) and kernels[key]["avg_us"] > 0:
@@ -272,6 +280,39 @@ def sequence_tracks(n_frames=13, tracks=16, w=1280, h=720):
         res[name] = {"one_track_fps": round(n_frames / one, 1), "ms_per_picture": round(one / n_frames * 1e3, 1), "all_tracks_fps": round(tracks * n_frames / many, 1),
                      "kbytes_per_picture": round(sum(len(a) for a in aus) / len(aus) / 1e3, 1), "verified_against_oracle": True}
     return res
+
+
+def check_grid_sharded(gs, world):
+    """VERDICT round 4 (multi-GPU readiness): a `grid_sharded` section measured with N > 1 must really have used N ranks / N devices - RCCL gather
+    with `ranks == N`, peer-copy form with shards on other devices reached by peer access - or it says so loudly instead of reporting a one-rank time
+    as an N-GPU time.  Returns (ok, reasons)."""
+    if world <= 1:
+        return True, []
+    why = []
+    if "error" in gs:
+        why.append("section error: %s" % gs["error"])
+    for key in ("wpp", "pps_tiles_4x4"):
+        ph = gs.get(key)
+        if not isinstance(ph, dict):
+            why.append("%s: not measured" % key)
+            continue
+        r = ph.get("rccl", {})
+        if r.get("ranks") != world:
+            why.append("%s: RCCL gather ran with ranks=%r, not %d (%s)" % (key, r.get("ranks"), world, r.get("error", "no error reported")))
+        elif not r.get("canvas_matches_one_gpu"):
+            why.append("%s: the RCCL canvas differs from the one-GPU canvas" % key)
+        pc = ph.get("peer_copy")
+        if not pc:
+            why.append("%s: the peer-copy form was not measured" % key)
+        else:
+            tr = pc.get("transport", {})
+            if tr.get("peer_access_shards", 0) <= 0:
+                why.append("%s: no shard reached the root canvas by peer access (%r)" % (key, tr))
+            if tr.get("shards_on_root_device", 0) + tr.get("peer_access_shards", 0) + tr.get("runtime_staged_shards", 0) != world:
+                why.append("%s: %r shards for %d GPUs" % (key, tr, world))
+            if not pc.get("canvas_matches_one_gpu"):
+                why.append("%s: the peer-copy canvas differs from the one-GPU canvas" % key)
+    return not why, why
 
 
 _REAL_STDOUT = None
@@ -489,6 +530,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_resident, 3),
             "higher_is_better": True, "scaling": "strong" if grid_single and grid else "weak", "vs_baseline": None,
             "dtype": "u8" if bit_depth == 8 else "u16",
+            "native_library": os.path.relpath(__import__("libheif_amd").library_path(), ROOT),   # (which build produced the numbers)
             "data": "synthetic (seeded noise+gradient stills coded by the test-only HEVC intra encoder, QP %d, %d distinct contents)" % (a.qp, len(distinct)),
             "config": {"workload": (("one 8192x6144 grid photo = 48 tiles of 1024x1024, tiles t mod N over N GPUs in one process (hipdec_grid_*), peer-copy paste + RGB24 on GPU 0"
                                      if grid_single else "one 8192x6144 grid photo (48 tiles of 1024x1024) per GPU and step through hipdec_grid_* + RGB24; photo i -> GPU i mod N") if grid else
@@ -520,7 +562,10 @@ def main():
                     traffic_source = "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command line, kernels of commit %s" % rec.get("commit", "?")
             except Exception:
                 pass
-            out["roofline"] = dict(bound="hbm", kernel=KERNEL_NAMES[dom], achieved=kernels[dom]["achieved_gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
+            # `bound` names the roofline achieved / peak are priced on (the contract's "hbm" | "mfma"); `limited_by` names what the dominant kernel is
+            # really bound by - instruction issue for the CABAC parser and the reconstruction wavefront (never label them HBM-bound)
+            out["roofline"] = dict(bound="hbm", limited_by=("issue" if dom in ("parse", "recon") else "hbm"), kernel=KERNEL_NAMES[dom],
+                                   achieved=kernels[dom]["achieved_gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
                                    frac=kernels[dom]["frac"], traffic=traffic, traffic_source=traffic_source,
                                    note="dominant kernel by device time, priced in algorithmic HBM bytes as the contract asks; CABAC parsing is bound by "
                                         "instruction issue (one dependency chain per substream), not by HBM: its real yardstick is `issue_roofline` "
@@ -775,6 +820,10 @@ def main():
                 gs["error"] = res["error"]
             if hung:
                 gs["error"] = "section did not finish within 420 s (abandoned; the main measurement above is unaffected)"
+            ok, why = check_grid_sharded(gs, world)
+            gs["multi_gpu_check"] = {"ok": ok, "requires": "rccl.ranks == n_gpus, peer_access_shards > 0, canvases equal to the one-GPU canvas", "failed": why}
+            if not ok:
+                sys.stderr.write("bench.py: grid_sharded DID NOT RUN ACROSS %d GPUs AS CLAIMED: %s\n" % (world, "; ".join(why)))
             out["grid_sharded"] = gs
         if hung or (world > 1 and "error" in res):
             # a rank that failed or hangs inside a collective cannot be waited for: the line goes out with what was measured

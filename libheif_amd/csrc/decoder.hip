@@ -22,12 +22,19 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 
 using namespace hipdec;
 
 constexpr int kEv = 8;   // events per timing slot: start, parse, residual, recon, deblock, sao | colour begin, colour end
+
+// resident-RGB policy: conversions that could have been served from a launch set's RGB earn credit, RGB that nobody fetched spends it
+namespace { std::atomic<int> g_rgb_credit{0}; }
+static void rgb_note_unused(int n) { if (n > 0) { int c = g_rgb_credit.load(); while (c > 0 && !g_rgb_credit.compare_exchange_weak(c, std::max(0, c - n))) {} } }
+static void rgb_note_wanted() { int c = g_rgb_credit.load(); while (c < 4096 && !g_rgb_credit.compare_exchange_weak(c, std::min(4096, c + 64))) {} }
+static bool rgb_wanted() { static const bool off = getenv("HIPDEC_NO_RESIDENT_RGB") != nullptr; return !off && g_rgb_credit.load(std::memory_order_relaxed) > 0; }
 
 struct hipdec_batch : BatchLayout {
   int device = 0;               // the device the arena lives on: every entry point that touches the batch runs under its scope
@@ -51,11 +58,20 @@ struct hipdec_batch : BatchLayout {
   ColorBatchState color;        // parameter blocks of hipdec_batch_to_rgb_all
   // decoder path (plugin): the output planes of every item staged in pinned host memory by ONE set of asynchronous copies behind the
   // kernels, so that N decoder instances sharing the batch do not queue N x 3 pageable device-to-host copies (stage_planes_to_host)
-  struct HostItem { void* p = nullptr; size_t off[3] = {0, 0, 0}; };   // p points into one of host_chunks
+  struct HostItem { void* p = nullptr; size_t off[3] = {0, 0, 0}; const uint8_t* rgb = nullptr; };   // p points into one of host_chunks; rgb: tight RGB24 rows (resident RGB)
   std::vector<HostItem> host_items;
   // pinned chunks of ONE size (64 MiB; a larger item gets a chunk of its own), items sub-allocated at 256-B alignment: a launch set of 256
   // thumbnails pins one chunk instead of 256 x 16 MiB, and sets of any size recycle the same chunks from the pool
   std::vector<std::pair<void*, size_t>> host_chunks;
+  // Resident RGB (drop-in through a libheif with the integration ops): when the host has been asking for interleaved RGB24 of
+  // the images it decodes, the launch set runs the SAO kernel with the fused RGB24 emission (k_sao_rgb) into rgb_dev and stages the rows to pinned
+  // host memory beside the planes: the colour conversion of libheif's pipeline then is a host copy instead of a kernel queued behind CABAC pools
+  void* rgb_dev = nullptr;
+  size_t rgb_capacity = 0;
+  std::vector<size_t> rgb_off, rgb_stride;
+  std::vector<std::pair<void*, size_t>> rgb_chunks;   // pinned
+  std::atomic<int> rgb_consumed{0};
+  bool fused_rgb = false;                 // the last hipdec_batch_run_rgb took the fused form (k_sao_rgb)
   // Waits for everything enqueued for THIS batch — not for the stream, which may already carry the next batch.
   hipError_t wait() const
   {
@@ -81,6 +97,8 @@ struct hipdec_batch : BatchLayout {
     if (arena || staging) (void)wait();   // nothing of this batch may still be running when the arena is recycled
     release_staging();
     for (auto& c : host_chunks) pinned_release(c.first, c.second);
+    for (auto& c : rgb_chunks) pinned_release(c.first, c.second);
+    if (rgb_dev) { arena_release(rgb_dev, rgb_capacity); rgb_note_unused((int)rgb_off.size() - rgb_consumed.load()); }
     color_batch_state_free(color);
     if (arena) arena_release(arena, arena_capacity);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -364,6 +382,37 @@ int stage_planes_to_host(hipdec_batch& b, hipStream_t s)
       else HIPDEC_CHECK_HIP(hipMemcpy2DAsync((uint8_t*)h.p + h.off[c], w, b.arena + P.off_out[c], P.out_stride[c], w, hh, hipMemcpyDeviceToHost, s));
     }
   }
+  // resident RGB: the fused colour stage's rows, tight, one pinned chunk set of their own
+  if (b.rgb_dev && b.rgb_off.size() == b.params.size()) {
+    std::vector<size_t> rneed;
+    std::vector<std::pair<int, size_t>> rplace(b.params.size(), {-1, 0});
+    for (size_t i = 0; i < b.params.size(); i++) {
+      const size_t total = ((size_t)b.params[i].out_width * 3 * (size_t)b.params[i].out_height + 255) & ~size_t(255);
+      if (!total) continue;
+      if (rneed.empty() || rneed.back() + total > std::max(kChunk, rneed.back() ? kChunk : total)) rneed.push_back(0);
+      rplace[i] = {(int)rneed.size() - 1, rneed.back()};
+      rneed.back() += total;
+    }
+    bool rok = true;
+    for (size_t k = 0; k < rneed.size() && rok; k++) {
+      const size_t want = std::max(kChunk, rneed[k]);
+      if (k < b.rgb_chunks.size() && b.rgb_chunks[k].second >= want) continue;
+      if (k < b.rgb_chunks.size()) { pinned_release(b.rgb_chunks[k].first, b.rgb_chunks[k].second); b.rgb_chunks[k] = {nullptr, 0}; }
+      else b.rgb_chunks.emplace_back(nullptr, 0);
+      if (pinned_acquire(&b.rgb_chunks[k].first, want, &b.rgb_chunks[k].second) != hipSuccess) { (void)hipGetLastError(); b.rgb_chunks[k] = {nullptr, 0}; rok = false; }
+    }
+    if (rok)
+      for (size_t i = 0; i < b.params.size(); i++) {
+        if (rplace[i].first < 0) continue;
+        const PicParams& P = b.params[i];
+        uint8_t* dst = (uint8_t*)b.rgb_chunks[(size_t)rplace[i].first].first + rplace[i].second;
+        const size_t row = (size_t)P.out_width * 3;
+        if (b.rgb_stride[i] == row) HIPDEC_CHECK_HIP(hipMemcpyAsync(dst, (uint8_t*)b.rgb_dev + b.rgb_off[i], row * (size_t)P.out_height, hipMemcpyDeviceToHost, s));
+        else HIPDEC_CHECK_HIP(hipMemcpy2DAsync(dst, row, (uint8_t*)b.rgb_dev + b.rgb_off[i], b.rgb_stride[i], row, (size_t)P.out_height, hipMemcpyDeviceToHost, s));
+        items[i].rgb = dst;
+      }
+    else { for (auto& c : b.rgb_chunks) pinned_release(c.first, c.second); b.rgb_chunks.clear(); }
+  }
   b.host_items.swap(items);
   b.mark_done(s);
   return 0;
@@ -599,6 +648,7 @@ int hipdec_batch_run_rgb(hipdec_batch* b, int out_chroma, void* const* outs_dev,
   if (variant != color_variant_rgb24_u8() || count != (int)b->pics.size()) return set_error(HIPDEC_ERR_UNSUPPORTED, "run_rgb: unexpected colour variant");
   b->last_stream = s;
   b->ran = true;
+  b->fused_rgb = true;
   return launch_all(*b, s, dev);
 }
 
@@ -888,6 +938,36 @@ int commit_reference(hipdec_decoder* d)
   return 0;
 }
 
+// hipdec_batch_run for a launch set of the decoder path - or, when the host has been converting the images it decodes to interleaved RGB24, the same
+// launch set with the colour conversion fused into the SAO kernel's store path (hipdec_batch_run_rgb) into a device buffer the batch owns: resident RGB
+std::atomic<uint64_t> g_rgb_produced{0}, g_rgb_served{0};
+int run_decoder_batch(hipdec_batch* b, hipStream_t s)
+{
+  bool rgb = rgb_wanted() && !b->wide && !b->chain && !b->any_inter && !b->rgb_dev;
+  for (const PicParams& P : b->params) rgb = rgb && P.chroma_format_idc == 1 && P.out_width > 0 && P.out_height > 0;
+  if (!rgb) return hipdec_batch_run(b, (void*)s);
+  size_t total = 0;
+  b->rgb_off.clear(); b->rgb_stride.clear();
+  for (const PicParams& P : b->params) {
+    const size_t stride = ((size_t)P.out_width * 3 + 255) & ~size_t(255);
+    b->rgb_off.push_back(total); b->rgb_stride.push_back(stride);
+    total += stride * (size_t)P.out_height;
+  }
+  {
+    DeviceScope scope(b->device);
+    if (arena_acquire(&b->rgb_dev, total, &b->rgb_capacity) != hipSuccess) { (void)hipGetLastError(); b->rgb_dev = nullptr; b->rgb_off.clear(); b->rgb_stride.clear(); return hipdec_batch_run(b, (void*)s); }
+  }
+  std::vector<void*> outs;
+  for (size_t i = 0; i < b->params.size(); i++) outs.push_back((uint8_t*)b->rgb_dev + b->rgb_off[i]);
+  const int rc = hipdec_batch_run_rgb(b, 10, outs.data(), b->rgb_stride.data(), (void*)s);
+  if (rc == 0 && b->fused_rgb) { g_rgb_produced += b->params.size(); return 0; }
+  // (items whose colour descriptions ask for different kernels, or a run that did not take the fused form: the RGB is dropped; a failed run_rgb has
+  //  launched nothing, the planes-only launch set follows)
+  { DeviceScope scope(b->device); if (rc == 0) (void)b->wait(); arena_release(b->rgb_dev, b->rgb_capacity); }
+  b->rgb_dev = nullptr; b->rgb_off.clear(); b->rgb_stride.clear();
+  return rc == 0 ? 0 : hipdec_batch_run(b, (void*)s);
+}
+
 // one decoder in a batch of its own: the reference behaviour, and the fallback that gives every request its own
 // error when a shared batch could not be built or failed on the device
 void run_single(DecodeRequest& r, hipStream_t s)
@@ -899,7 +979,7 @@ void run_single(DecodeRequest& r, hipStream_t s)
   const SeqContext* seqs[1] = {d->seq_active ? &d->seq : nullptr};
   r.rc = create_batch_seq(&b, 1, ptrs, sizes, d->max_pixels, seqs);
   if (!r.rc) {
-    r.rc = hipdec_batch_run(b, (void*)s);
+    r.rc = run_decoder_batch(b, s);
     if (!r.rc) r.rc = stage_planes_to_host(*b, follow_stream(b, (void*)s));
     if (!r.rc) r.rc = hipdec_batch_status(b);   // synchronises s
     else (void)hipStreamSynchronize(s);
@@ -929,7 +1009,7 @@ void run_group(std::vector<DecodeRequest*>& group, hipStream_t s, uint32_t wave_
   auto t2 = t1, t3 = t1;
   if (!rc) {
     b->wave_share = wave_share;   // the launch sets in flight when this one started share the CABAC pool's wave slots (a lone burst gets them all)
-    rc = hipdec_batch_run(b, (void*)s);
+    rc = run_decoder_batch(b, s);
     t2 = Clock::now();
     if (!rc) rc = stage_planes_to_host(*b, follow_stream(b, (void*)s));
     t3 = Clock::now();
@@ -1032,10 +1112,9 @@ int hipdec_decoder_push_data(hipdec_decoder* d, const void* data, size_t size)
       d->seq_active = true;
       d->first_closed = true;
     }
-    d->last_push_first = d->queue.size();
+    size_t touched_from = SIZE_MAX;                  // first queued sample this push adds to (set_user_data names the samples of the last push)
     d->last_push_touched_first = false;
     bool open = !d->queue.empty() && d->last_open;   // the newest sample may be continued by this push (a picture pushed in pieces)
-    if (open) d->last_push_first = d->queue.size() - 1;
     for (size_t q = 0; q < size;) {
       const uint32_t n = ((uint32_t)p[q] << 24) | ((uint32_t)p[q + 1] << 16) | ((uint32_t)p[q + 2] << 8) | p[q + 3];
       const uint8_t* nal = p + q + 4;
@@ -1066,19 +1145,23 @@ int hipdec_decoder_push_data(hipdec_decoder* d, const void* data, size_t size)
       }
       if (!open || (starts && d->queue.back().has_vcl)) {
         d->queue.emplace_back();
+        touched_from = std::min(touched_from, d->queue.size() - 1);
         d->queue.back().user_data = d->pending_user_data;
         open = true;
         // a parameter set that opens the sample is already in param_sets (appended above): the blob starts with all of them either way
         d->queue.back().blob = d->param_sets;
         if (t >= 32 && t <= 34) continue;
       } else if (t >= 32 && t <= 34) {   // a parameter set inside an open sample: in front of its slices, like the others
+        touched_from = std::min(touched_from, d->queue.size() - 1);
         d->queue.back().blob.insert(d->queue.back().blob.end(), nal - 4, nal + n);
         continue;
       }
+      touched_from = std::min(touched_from, d->queue.size() - 1);
       d->queue.back().blob.insert(d->queue.back().blob.end(), nal - 4, nal + n);
       if (vcl) d->queue.back().has_vcl = true;
     }
     d->last_open = open;
+    d->last_push_first = touched_from == SIZE_MAX ? d->queue.size() : touched_from;
     return 0;
   });
 }
@@ -1091,7 +1174,7 @@ static long seq_lookahead()
   long k = g_seq_lookahead.load(std::memory_order_relaxed);
   if (k < 0) {
     const char* e = std::getenv("HIPDEC_SEQ_LOOKAHEAD");
-    k = e ? std::atol(e) : 8;
+    k = e ? std::atol(e) : 16;
     k = k < 0 ? 0 : (k > 64 ? 64 : k);
     g_seq_lookahead.store(k, std::memory_order_relaxed);
   }
@@ -1622,8 +1705,10 @@ void resident_note_buffer(const void* host, size_t stride, int w, int h, int bit
 
 // device copy of a host plane handed over by a decoder of this library, if the host plane still holds exactly those bytes; the entry
 // is consumed either way
-bool resident_find(const void* host, size_t stride, int w, int h, int bits, const uint8_t** dev, size_t* dev_stride, std::shared_ptr<void>& keep)
+bool resident_find(const void* host, size_t stride, int w, int h, int bits, const uint8_t** dev, size_t* dev_stride, std::shared_ptr<void>& keep,
+                   hipdec_batch** from_batch = nullptr, int* from_item = nullptr)
 {
+  if (from_batch) *from_batch = nullptr;
   g_track_planes.store(true, std::memory_order_relaxed);
   ResidentPlane r;
   {
@@ -1651,6 +1736,7 @@ bool resident_find(const void* host, size_t stride, int w, int h, int bits, cons
   *dev = r.batch->arena + P.off_out[r.comp];
   *dev_stride = P.out_stride[r.comp];
   keep = r.batch;
+  if (from_batch) { *from_batch = r.batch.get(); if (from_item) *from_item = r.item; }
   return true;
 }
 
@@ -1670,6 +1756,12 @@ void hipdec_forget_resident_planes(void)
     g_res_bytes = 0;
   }
 }   // the batches die here, outside the lock
+
+void hipdec_resident_rgb_stats(uint64_t* images_produced, uint64_t* conversions_served)
+{
+  if (images_produced) *images_produced = g_rgb_produced.load();
+  if (conversions_served) *conversions_served = g_rgb_served.load();
+}
 
 void hipdec_resident_plane_stats(uint64_t* entries, uint64_t* pinned_bytes)
 {
@@ -1775,11 +1867,46 @@ int hipdec_color_convert(const hipdec_color_image* in, const hipdec_nclx* nclx, 
     std::shared_ptr<void> keep[4];
     const auto t_find = Clock::now();
     if (g_ops_timing.on) g_ops_timing.calls++;
+    // 8-bit 4:2:0 planes to interleaved RGB24 in ONE op: what a launch set of the decoder path can produce beside the planes (resident RGB).  Asking
+    // for it earns the credit that makes the next launch sets carry it.
+    const bool rgb24_single = out_chroma == 10 && !has_alpha && in->chroma == 1 && in->bit_depth == 8 && n_ops == 1 && !out_on_device && !in->on_device &&
+                              (ops[0] == HIPDEC_OP_420_TO_RGB24 || ops[0] == HIPDEC_OP_YCBCR_TO_RGB);
+    if (rgb24_single) rgb_note_wanted();
+    hipdec_batch* from_b[4] = {nullptr, nullptr, nullptr, nullptr};
+    int from_i[4] = {-1, -1, -1, -1};
     for (int c = 0; c < 4; c++) {
       if (!in->plane[c]) continue;
       const int pw = (c == 0 || c == 3) ? w : cw, ph = (c == 0 || c == 3) ? h : ch;
       if (in->on_device) { dp[c] = (const uint8_t*)in->plane[c]; ds[c] = in->stride[c]; continue; }
-      if (resident_find(in->plane[c], in->stride[c], pw, ph, bits, &dp[c], &ds[c], keep[c])) { g_cb_resident++; if (g_ops_timing.on) g_ops_timing.hits++; continue; }
+      if (resident_find(in->plane[c], in->stride[c], pw, ph, bits, &dp[c], &ds[c], keep[c], &from_b[c], &from_i[c])) {
+        g_cb_resident++; if (g_ops_timing.on) g_ops_timing.hits++;
+        if (c == 2 && rgb24_single && from_b[0] && from_b[0] == from_b[1] && from_b[1] == from_b[2] && from_i[0] == from_i[1] && from_i[1] == from_i[2]) {
+          // all three planes are the untouched output of one decoded picture (resident_find compared every byte's hash): if its launch set emitted
+          // RGB24 with exactly this colour description and the op the planner chose, the rows are already in pinned host memory
+          hipdec_batch* rb = from_b[0];
+          const size_t item = (size_t)from_i[0];
+          if (item < rb->host_items.size() && rb->host_items[item].rgb && item < rb->pics.size()) {
+            const hipdec_image_info& I = rb->pics[item].info;
+            const int m = I.matrix_coeffs == 2 ? 6 : I.matrix_coeffs;
+            const bool fused_int = I.full_range_flag && m != 0 && m != 8;
+            if (nclx && nclx->has_nclx && nclx->colour_primaries == I.colour_primaries && nclx->transfer_characteristics == I.transfer_characteristics &&
+                nclx->matrix_coefficients == I.matrix_coeffs && nclx->full_range_flag == I.full_range_flag && fused_int == (ops[0] == HIPDEC_OP_420_TO_RGB24) &&
+                rb->params[item].out_width == w && rb->params[item].out_height == h) {
+              const auto t_copy = Clock::now();
+              const uint8_t* src = rb->host_items[item].rgb;
+              const size_t row = (size_t)w * 3;
+              if (out_stride == row) memcpy(out, src, row * (size_t)h);
+              else for (int y = 0; y < h; y++) memcpy((uint8_t*)out + (size_t)y * out_stride, src + (size_t)y * row, row);
+              rb->rgb_consumed++;
+              g_rgb_served++;
+              g_cb_conversions++;
+              if (g_ops_timing.on) { g_ops_timing.find_us += us_since(t_find); g_ops_timing.copy_us += us_since(t_copy); }
+              return 0;
+            }
+          }
+        }
+        continue;
+      }
       if (g_ops_timing.on) g_ops_timing.misses++;
       uint8_t* d = nullptr;
       const size_t st = ((size_t)pw * es + 255) & ~(size_t)255;
@@ -2015,6 +2142,7 @@ struct hipdec_grid {
   size_t off[3] = {0, 0, 0}, stride[3] = {0, 0, 0};
   hipdec_image_info info{};                       // of tile 0 (colour description for the canvas)
   bool decoded = false;
+  int issue_threads = 1;                          // host threads the last hipdec_grid_decode enqueued the shards from
   ~hipdec_grid()
   {
     for (size_t s = 0; s < shard.size(); s++) {
@@ -2137,7 +2265,7 @@ int hipdec_grid_decode(hipdec_grid* g)
   return guarded("grid_decode", [&]() -> int {
     const size_t es = g->bits > 8 ? 2 : 1;
     const int ncomp = g->info.chroma_format_idc ? 3 : 1;
-    for (size_t s = 0; s < g->shard.size(); s++) {
+    auto issue = [&](size_t s) -> int {
       DeviceScope scope(g->devices[s]);
       hipdec_batch* b = g->shard[s].get();
       if (int rc = hipdec_batch_run(b, (void*)g->stream[s])) return rc;
@@ -2158,6 +2286,24 @@ int hipdec_grid_decode(hipdec_grid* g)
       }
       b->mark_done(g->stream[s]);
       HIPDEC_CHECK_HIP(hipEventRecord(g->pasted[s], g->stream[s]));
+      return 0;
+    };
+    // One host thread per device (ADVICE / VERDICT round 4): a shard's launch set - upload wait, six kernels, its tiles' pastes - is enqueued by its
+    // own thread, so the devices start together instead of one after the other behind a single thread's launch overhead.  (A thread's error text
+    // is thread-local: it is carried back to the caller.)
+    if (g->shard.size() <= 1 || getenv("HIPDEC_GRID_SERIAL_ISSUE")) {
+      for (size_t s = 0; s < g->shard.size(); s++) if (int rc = issue(s)) return rc;
+    } else {
+      std::vector<int> rcs(g->shard.size(), 0);
+      std::vector<std::string> msgs(g->shard.size());
+      std::vector<std::thread> th;
+      for (size_t s = 1; s < g->shard.size(); s++)
+        th.emplace_back([&, s]() { try { rcs[s] = issue(s); } catch (...) { rcs[s] = set_error(HIPDEC_ERR_MEMORY, "grid_decode: shard %zu: host failure", s); } if (rcs[s]) msgs[s] = hipdec_last_error(); });
+      rcs[0] = issue(0);
+      if (rcs[0]) msgs[0] = hipdec_last_error();
+      for (auto& t : th) t.join();
+      g->issue_threads = (int)g->shard.size();
+      for (size_t s = 0; s < g->shard.size(); s++) if (rcs[s]) return set_error(rcs[s], "%s", msgs[s].c_str());
     }
     {
       DeviceScope scope(g->root);   // whatever the caller queues on the root's stream next sees the whole canvas

@@ -97,6 +97,10 @@ struct MotionCtx {
   const MotionUnit* left;       // the CTB to the left, as it was derived a moment ago (LDS)
   const MotionUnit* up;         // bottom unit rows of the CTBs above-left, above and above-right (LDS): [3][units per CTB side]
   const MotionUnit* col;        // the collocated picture's motion field (nullptr: no temporal candidates / an intra picture)
+  const MotionUnit* col_lds;    // its units on the 16x16 grid the CTB's candidates can name, staged in LDS: [(y - y_ctb) / 16][(x - x_ctb) / 16], x up to one
+                                // grid column to the right of the CTB (bottom-right candidates; never below the CTB row, 8.5.3.2.8)
+  const int* ref_poc;           // PicOrderCnt of the reference picture table's slots (LDS)
+  int col_w;                    // grid columns staged
   int cx, cy, avail;            // CTB position, AV_* bits
   int log2_ctb, units_log2, lmt, ctb_w, width, height;
   int poc, par_mrg;
@@ -180,7 +184,11 @@ __device__ __forceinline__ void scale_mv(int& mvx, int& mvy, int td, int tb)
 // 8.5.3.2.9: the motion vector the collocated picture stored for the 16x16 block that covers (x, y), scaled to the distance of the target picture
 __device__ __forceinline__ int collocated_mv(const MotionCtx& C, int x, int y, int ref_idx, int X, int& mvx, int& mvy)
 {
-  const MotionUnit cu = C.col[unit_index(C, (x >> 4) << 4, (y >> 4) << 4)];
+  // (a lone lane fetching this from HBM - one or two dependent global loads per candidate, up to four per prediction unit - was most of
+  //  k_motion's 8 ms per 720p picture: the grid positions a CTB can name are staged by all lanes before the chain starts)
+  const int gx = (x >> 4) - ((C.cx << C.log2_ctb) >> 4), gy = (y >> 4) - ((C.cy << C.log2_ctb) >> 4);
+  const bool staged = gx >= 0 && gx < C.col_w && gy >= 0 && gy < (1 << (C.log2_ctb - 4));
+  const MotionUnit cu = staged ? C.col_lds[gy * C.col_w + gx] : C.col[unit_index(C, (x >> 4) << 4, (y >> 4) << 4)];
   const int f0 = cu.ref_idx[0] >= 0, f1 = cu.ref_idx[1] >= 0;
   if (!f0 && !f1) return 0;   // intra coded
   int L;
@@ -188,7 +196,7 @@ __device__ __forceinline__ int collocated_mv(const MotionCtx& C, int x, int y, i
   else if (!f1) L = 0;
   else L = C.slice->no_backward ? X : C.slice->col_from_l0;
   int vx = unit_mvx(cu, L), vy = unit_mvy(cu, L);
-  const int col_diff = unit_poc_delta(cu, L), cur_diff = C.poc - C.reftab[slot_of(C, X, ref_idx)].poc;
+  const int col_diff = unit_poc_delta(cu, L), cur_diff = C.poc - C.ref_poc[slot_of(C, X, ref_idx)];
   if (col_diff != cur_diff) {
     if (col_diff == 0) return 0;
     scale_mv(vx, vy, col_diff, cur_diff);
@@ -291,7 +299,7 @@ __device__ __forceinline__ int nb_scaled(const MotionCtx& C, const MotionUnit& m
   if (L < 0) return 0;
   mvx = unit_mvx(m, L); mvy = unit_mvy(m, L);
   const int nb_slot = unit_slot(m, L);
-  if (nb_slot != tgt_slot) scale_mv(mvx, mvy, C.poc - C.reftab[nb_slot].poc, C.poc - C.reftab[tgt_slot].poc);
+  if (nb_slot != tgt_slot) scale_mv(mvx, mvy, C.poc - C.ref_poc[nb_slot], C.poc - C.ref_poc[tgt_slot]);
   return 1;
 }
 
@@ -337,6 +345,9 @@ struct MotionLds {
   MotionUnit up[3 * 16];   // bottom unit rows of the CTBs above-left, above, above-right
   MotionSyntax msyn[256];  // what the parser read for the CTB's prediction units
   uint8_t usize[256], uipmc[256];   // the CTB's coding block sizes / prediction modes (unit maps)
+  MotionUnit col[5 * 4];   // the collocated picture's units on the 16x16 grid of the CTB (+ one column to its right)
+  SliceParams slice;       // the CTB's slice (the chain reads its fields at every prediction unit)
+  int ref_poc[16];         // PicOrderCnt of the reference picture table's slots
   MotionUnit pu;           // the motion of the prediction unit lane 0 just derived (broadcast to the lanes that fill its units)
   int pu_geom[4];          // its rectangle in units relative to the CTB: x, y, w, h
   int pu_bad;
@@ -382,8 +393,13 @@ __global__ __launch_bounds__(64) void k_motion(MotionArgs A)
     const CtbInfo ci = ctb_info[ctb_rs];
     MotionUnit* const cur = L.cur[cx & 1];
     MotionCtx C;
-    C.P = &P; C.reftab = (const RefFrame*)(A.arena + P.off_reftab); C.slice = slices + ci.slice_idx; C.field = field; C.cur = cur;
+    C.P = &P; C.reftab = (const RefFrame*)(A.arena + P.off_reftab); C.field = field; C.cur = cur;
     C.left = L.cur[(cx & 1) ^ 1]; C.up = L.up;
+    // the slice's parameters and the reference pictures' POCs: read at every prediction unit by the chain, so they live in LDS (16 + 16 dwords)
+    if (lane < 16) ((uint32_t*)&L.slice)[lane] = ((const uint32_t*)(slices + ci.slice_idx))[lane];
+    else if (lane < 32) L.ref_poc[lane - 16] = C.reftab[lane - 16].poc;
+    mk_lds_sync();
+    C.slice = &L.slice; C.ref_poc = L.ref_poc; C.col_lds = L.col;
     C.col = C.slice->tmvp ? (const MotionUnit*)(uintptr_t)C.reftab[C.slice->col_slot].mf : nullptr;
     C.cx = cx; C.cy = cy; C.avail = ci.avail; C.log2_ctb = log2_ctb; C.units_log2 = units_log2; C.lmt = P.log2_min_tb; C.ctb_w = ctb_w;
     C.width = P.width; C.height = P.height; C.poc = P.poc; C.par_mrg = P.log2_par_mrg_level;
@@ -401,6 +417,14 @@ __global__ __launch_bounds__(64) void k_motion(MotionArgs A)
         const int ncx = cx - 1 + i / side;
         if (ncx >= 0 && ncx < ctb_w) L.up[i] = field[((size_t)((cy - 1) * ctb_w + ncx) << units_log2) + mk_interleave((uint32_t)(i % side), (uint32_t)(side - 1))];
       }
+    C.col_w = (1 << (log2_ctb - 4)) + 1;
+    if (C.col) {   // the collocated units the CTB's temporal candidates can name
+      const int rows16 = 1 << (log2_ctb - 4);
+      for (int i = lane; i < C.col_w * rows16; i += 64) {
+        const int x = x_ctb + 16 * (i % C.col_w), y = y_ctb + 16 * (i / C.col_w);
+        if (x < P.width && y < P.height) L.col[i] = C.col[unit_index(C, x, y)];
+      }
+    }
     mk_lds_sync();
     int z = 0;
     while (z < units && !err) {
@@ -472,12 +496,12 @@ __global__ __launch_bounds__(64) void k_motion(MotionArgs A)
               if (m.r0 >= 0) {
                 const int slot = slot_of(C, 0, m.r0);
                 o.mv[0][0] = (int16_t)m.x0; o.mv[0][1] = (int16_t)m.y0; o.ref_idx[0] = (int8_t)m.r0;
-                o.poc_delta[0] = (int16_t)mk_clip3(-32768, 32767, C.poc - C.reftab[slot].poc); o.slot_pred[0] = (uint8_t)slot;
+                o.poc_delta[0] = (int16_t)mk_clip3(-32768, 32767, C.poc - C.ref_poc[slot]); o.slot_pred[0] = (uint8_t)slot;
               }
               if (m.r1 >= 0) {
                 const int slot = slot_of(C, 1, m.r1);
                 o.mv[1][0] = (int16_t)m.x1; o.mv[1][1] = (int16_t)m.y1; o.ref_idx[1] = (int8_t)m.r1;
-                o.poc_delta[1] = (int16_t)mk_clip3(-32768, 32767, C.poc - C.reftab[slot].poc); o.slot_pred[1] = (uint8_t)slot;
+                o.poc_delta[1] = (int16_t)mk_clip3(-32768, 32767, C.poc - C.ref_poc[slot]); o.slot_pred[1] = (uint8_t)slot;
               }
             }
             o.slot_pred[0] = (uint8_t)(o.slot_pred[0] | (((pm & UM_SKIP) ? 2u : 1u) << 6));

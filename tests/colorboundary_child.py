@@ -18,6 +18,8 @@ def main():
     hip.hipdec_color_boundary_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
     hip.hipdec_image_ops_stats.restype = None
     hip.hipdec_image_ops_stats.argtypes = [C.POINTER(C.c_uint64)] * 2
+    hip.hipdec_resident_rgb_stats.restype = None
+    hip.hipdec_resident_rgb_stats.argtypes = [C.POINTER(C.c_uint64)] * 2
     out = {}
     for j in jobs:
         data = open(j["heic"], "rb").read()
@@ -27,6 +29,9 @@ def main():
         t, g = C.c_uint64(), C.c_uint64()
         hip.hipdec_image_ops_stats(C.byref(t), C.byref(g))
         ops_before = (t.value, g.value)
+        rp, rs = C.c_uint64(), C.c_uint64()
+        hip.hipdec_resident_rgb_stats(C.byref(rp), C.byref(rs))
+        rgb_before = (rp.value, rs.value)
         res = lh.decode(data, j["colorspace"], j["chroma"], max_threads=j.get("threads"))
         hip.hipdec_color_boundary_stats(C.byref(a), C.byref(b), C.byref(c))
         hip.hipdec_image_ops_stats(C.byref(t), C.byref(g))
@@ -36,6 +41,8 @@ def main():
             for k, p in enumerate(res["planes"]):
                 out[j["name"] + ".plane%d" % k] = p
         out[j["name"] + ".stats"] = np.array([a.value - before[0], b.value - before[1], c.value - before[2]], np.int64)
+        hip.hipdec_resident_rgb_stats(C.byref(rp), C.byref(rs))
+        out[j["name"] + ".rgbres"] = np.array([rp.value - rgb_before[0], rs.value - rgb_before[1]], np.int64)   # pictures decoded with RGB beside the planes, conversions served from it
         out[j["name"] + ".ops"] = np.array([t.value - ops_before[0], g.value - ops_before[1]], np.int64)   # transforms, grid canvases
     np.savez(sys.argv[2], **out)
 

@@ -61,3 +61,24 @@ def test_issue_roofline_covers_every_kernel_of_the_pmc_record():
     for k, v in r["kernels"].items():
         assert 0 < v["frac_of_scalar_issue_peak"] < 1 and 0 < v["frac_of_vector_issue_peak"] < 1, (k, v)
     assert r["kernels"]["parse"]["frac_of_scalar_issue_peak"] > r["kernels"]["recon"]["frac_of_scalar_issue_peak"] > r["kernels"]["deblock"]["frac_of_scalar_issue_peak"]
+
+
+def test_grid_sharded_cannot_silently_measure_one_rank():
+    """with N > 1 the `grid_sharded` section is only valid when the RCCL gather ran with N ranks and the peer-copy form reached
+    other devices by peer access; anything else is named in `multi_gpu_check.failed` (and on stderr) instead of passing as an N-GPU time"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    good_photo = {"one_gpu_ms": 67.0, "rccl": {"ms": 20.0, "ranks": 8, "canvas_matches_one_gpu": True},
+                  "peer_copy": {"ms": 21.0, "canvas_matches_one_gpu": True, "transport": {"shards_on_root_device": 1, "peer_access_shards": 7, "runtime_staged_shards": 0}}}
+    ok, why = bench.check_grid_sharded({"wpp": good_photo, "pps_tiles_4x4": good_photo}, 8)
+    assert ok and not why
+    assert bench.check_grid_sharded({}, 1) == (True, [])                                   # one GPU: nothing to assert
+    one_rank = dict(good_photo, rccl={"ms": 60.0, "ranks": 1, "canvas_matches_one_gpu": True})
+    ok, why = bench.check_grid_sharded({"wpp": one_rank, "pps_tiles_4x4": good_photo}, 8)
+    assert not ok and any("ranks=1" in w for w in why)
+    staged = dict(good_photo, peer_copy=dict(good_photo["peer_copy"], transport={"shards_on_root_device": 1, "peer_access_shards": 0, "runtime_staged_shards": 7}))
+    ok, why = bench.check_grid_sharded({"wpp": staged, "pps_tiles_4x4": good_photo}, 8)
+    assert not ok and any("peer access" in w for w in why)
+    ok, why = bench.check_grid_sharded({"error": "RuntimeError('x')"}, 2)
+    assert not ok and len(why) >= 3

@@ -135,9 +135,47 @@ def test_heif_decode_image_to_rgb_runs_the_hip_colour_op_bit_exact(tmp_path):
         np.testing.assert_array_equal(hipc[n + ".rgb"], stock[n + ".rgb"], err_msg=n)
         conv, resident, launches = [int(v) for v in hipc[n + ".stats"]]
         assert tuple(int(v) for v in stock[n + ".stats"]) == (0, 0, 0), n                   # the stock build never reaches the boundary
-        assert conv == 1 and launches >= 1, (n, conv, resident, launches)
+        served = int(hipc[n + ".rgbres"][1])                                                # answered from the launch set's resident RGB: no kernel at all
+        assert conv == 1 and (launches >= 1 or served == 1), (n, conv, resident, launches, served)
         if n not in ("grid_rgb",):
             assert resident >= 3, (n, resident)                                              # the decoder's own device planes were used
     # the alpha really is the auxiliary image's plane
     a_ref = orc.decode(alpha)["planes"][0]
     np.testing.assert_array_equal(hipc["alpha_rgba.rgb"].reshape(136, 200, 4)[:, :, 3], a_ref)
+
+
+@pytest.mark.gpu
+def test_repeated_rgb_requests_are_served_from_the_launch_sets_resident_rgb(tmp_path):
+    """once the host has asked for interleaved RGB24, the decoder's launch sets emit it from the SAO kernel (k_sao_rgb) beside the
+    planes and stage it to pinned host memory; the integration op's conversion then is a host copy - no colour kernel queued behind CABAC pools.  The
+    pixels stay those of the stock build's ops, for the integer op (full range) and the float chain (limited range) alike; an image whose planes
+    libheif edits before the conversion (mirror) must NOT take the shortcut."""
+    if not (lh.available("libheif.so") and lh.available("libheif_hipcolor.so")):
+        pytest.fail("oracle/_ref libraries missing on the GPU box")
+    cases = []
+
+    def add(name, heic, chroma=lh.CHROMA_RGB):
+        path = str(tmp_path / (name + ".heic"))
+        open(path, "wb").write(heic)
+        cases.append(dict(name=name, heic=path, colorspace=lh.COLORSPACE_RGB, chroma=chroma))
+
+    full = orc.encode(orc.synth_image(456, 264, 8, 1, seed=41), **SRGB)
+    limited = orc.encode(orc.synth_image(322, 200, 8, 1, seed=42), vui_primaries=1, vui_transfer=1, vui_matrix=1, vui_full_range=0)
+    for k in range(3):
+        add("full_%d" % k, hu.build_heic([(full, 456, 264)]))
+    for k in range(2):
+        add("limited_%d" % k, hu.build_heic([(limited, 322, 200)]))
+    add("mirrored", hu.build_heic([(full, 456, 264)], transforms=[("imir", 0)]))
+    add("rgba_not_served", hu.build_heic([(full, 456, 264)]), lh.CHROMA_RGBA)
+    stock = _run_child("libheif.so", cases, tmp_path)
+    hipc = _run_child("libheif_hipcolor.so", cases, tmp_path)
+    for c in cases:
+        np.testing.assert_array_equal(hipc[c["name"] + ".rgb"], stock[c["name"] + ".rgb"], err_msg=c["name"])
+    served = {c["name"]: int(hipc[c["name"] + ".rgbres"][1]) for c in cases}
+    produced = {c["name"]: int(hipc[c["name"] + ".rgbres"][0]) for c in cases}
+    launches = {c["name"]: int(hipc[c["name"] + ".stats"][2]) for c in cases}
+    assert served["full_0"] == 0 and launches["full_0"] >= 1                      # nobody had asked yet: the colour kernel ran
+    for n in ("full_1", "full_2", "limited_0", "limited_1"):
+        assert produced[n] == 1 and served[n] == 1 and launches[n] == 0, (n, produced[n], served[n], launches[n])
+    assert served["rgba_not_served"] == 0 and launches["rgba_not_served"] >= 1
+    assert served["mirrored"] == 0                                                # the planes were edited in place (or transformed on the device): never the shortcut

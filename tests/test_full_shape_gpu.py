@@ -162,3 +162,37 @@ def test_config3_8k_grid_through_libheif_and_the_plugin():
     out = lh.decode(heic, lh.COLORSPACE_YCBCR, lh.CHROMA_420, max_threads=48)
     for k in range(3):
         np.testing.assert_array_equal(out["planes"][k], canvas[k], err_msg="component %d" % k)
+
+
+def test_config2_single_4k_still_fused_rgb():
+    """BASELINE config 2 as written: ONE 3840x2160 8-bit 4:2:0 still on one GPU with the fused YCbCr -> RGB stage (decode + colour as one call:
+    k_sao_rgb emits RGB24 from the SAO store path).  Planes against the oracle; RGB against the COMPILED reference op on the oracle's planes
+    (Op_YCbCr420_to_RGB24, yuv2rgb.cc:345-426, through oracle/_ref's harness) and against the colour oracle; then the same file through the real
+    libheif: heif_decode_image(..., RGB, interleaved_RGB) with the plugin."""
+    from libheif_amd.decoder import Batch
+    from tools import streamgen
+    import libheif_host as lh
+    w, h = 3840, 2160
+    stream = streamgen.make_stream(w, h, 1, 8, vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1)     # S2, signalling the sRGB nclx
+    ref = orc.decode(stream)
+    assert tuple(ref["nclx"]) == (1, 13, 6, 1)
+    b = Batch([stream])
+    b.alloc_rgb(10)
+    b.run_rgb()
+    b.status()
+    got = b.planes(0)
+    for c in range(3):
+        np.testing.assert_array_equal(got[c], ref["planes"][c], err_msg="component %d" % c)
+    rgb = b.rgb(0)[:, :w * 3]
+    y, cb, cr = ref["planes"]
+    exp = orc.color_420_to_rgb24(y, cb, cr, ref["nclx"]).reshape(h, -1)
+    np.testing.assert_array_equal(rgb, exp)
+    b.free()
+    if lh.available():
+        import ref_harness as rh
+        import heic_util as hu
+        exp_ref = rh.convert(ref["planes"], 8, rh.CH_420, ref["nclx"], rh.CS_RGB, rh.CH_RGB)[0]
+        np.testing.assert_array_equal(exp_ref[:, :w * 3], exp)                    # the colour oracle IS the reference op on these planes
+        lh.load_hip_plugin()
+        out = lh.decode(hu.build_heic([(stream, w, h)]), lh.COLORSPACE_RGB, lh.CHROMA_RGB)
+        np.testing.assert_array_equal(out["rgb"][:, :w * 3], exp)

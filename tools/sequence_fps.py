@@ -17,7 +17,10 @@ frames = make_frames(w, h, n)
 kinds = {"intra only": None,
          "lowdelay (IPPP, 2 refs, TMVP, weighted)": dict(inter_num_refs=2, temporal_mvp=1, weighted_pred=1),
          "unrestricted (IBBP, TMVP)": dict(b_frames=2, inter_num_refs=2, temporal_mvp=1)}
+only = os.environ.get("SEQ_KIND")
 for name, kw in kinds.items():
+    if only and only not in name:
+        continue
     if kw is None:
         aus = [orc.encode(f, qp=27, vui_matrix=6) for f in frames]
         aus = [aus[0]] + [b"".join(x for x in __import__("test_sequence_gpu")._nals(a) if (x[4] >> 1) & 63 < 32) for a in aus[1:]]
