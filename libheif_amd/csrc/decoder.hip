@@ -1869,8 +1869,10 @@ int hipdec_color_convert(const hipdec_color_image* in, const hipdec_nclx* nclx, 
     if (g_ops_timing.on) g_ops_timing.calls++;
     // 8-bit 4:2:0 planes to interleaved RGB24 in ONE op: what a launch set of the decoder path can produce beside the planes (resident RGB).  Asking
     // for it earns the credit that makes the next launch sets carry it.
-    const bool rgb24_single = out_chroma == 10 && !has_alpha && in->chroma == 1 && in->bit_depth == 8 && n_ops == 1 && !out_on_device && !in->on_device &&
-                              (ops[0] == HIPDEC_OP_420_TO_RGB24 || ops[0] == HIPDEC_OP_YCBCR_TO_RGB);
+    // (the planner lists Op_YCbCr_to_RGB + Op_RGB_to_RGB24_32 as two ops; they run as one pass here and in the fused kernel)
+    const bool rgb24_single = out_chroma == 10 && !has_alpha && in->chroma == 1 && in->bit_depth == 8 && !out_on_device && !in->on_device &&
+                              ((n_ops == 1 && ops[0] == HIPDEC_OP_420_TO_RGB24) ||
+                               (n_ops == 2 && ops[0] == HIPDEC_OP_YCBCR_TO_RGB && ops[1] == HIPDEC_OP_RGB_TO_RGB24_32));
     if (rgb24_single) rgb_note_wanted();
     hipdec_batch* from_b[4] = {nullptr, nullptr, nullptr, nullptr};
     int from_i[4] = {-1, -1, -1, -1};

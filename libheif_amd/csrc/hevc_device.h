@@ -154,7 +154,8 @@ struct PicParams {
   uint8_t amp_enabled, max_th_depth_inter, log2_par_mrg_level;
   int32_t poc;                    // PicOrderCntVal
   uint32_t num_refs;              // entries of the RefFrame table
-  uint32_t pad_inter;
+  uint8_t constrained_intra_pred; // constrained_intra_pred_flag in a picture with P / B slices: samples of units that are not intra coded are "not available" for intra prediction (8.4.4.2.2)
+  uint8_t pad_inter[3];
   uint64_t off_wp;                // WeightTable per slice with explicit weights (SliceParams::wp_index)
   uint64_t off_reftab;            // RefFrame[16]
   uint64_t off_msyn;              // MotionSyntax[ctbs * units_per_ctb]

@@ -190,21 +190,29 @@ void parse_scaling_list_data(NalReader& r, ScalingLists& sl)
 }
 
 // 8.6.4.2 / 7.4.5: the factors m[y][x] a block of the given size and (intra) component uses
-void build_scaling_tables(const ScalingLists& sl, bool chroma444, std::vector<uint8_t>& out)
+// inter: a second block of the same layout behind the first with the matrices of inter coded units (matrixId 3 .. 5, Table 7-4; P / B pictures are
+// 4:0:0 / 4:2:0 here, so the block is 2048 bytes)
+void build_scaling_tables(const ScalingLists& sl, bool chroma444, std::vector<uint8_t>& out, bool inter = false)
 {
-  out.assign(chroma444 ? 4096 : 2048, 16);
-  for (int c = 0; c < 3; c++) {
-    uint8_t* t = out.data() + c * 336;
-    memcpy(t, sl.l4[c], 16);
-    memcpy(t + 16, sl.l8[c], 64);
-    for (int y = 0; y < 16; y++)
-      for (int x = 0; x < 16; x++) t[80 + y * 16 + x] = sl.l16[c][(y >> 1) * 8 + (x >> 1)];
-    t[80] = sl.dc16[c];
+  const size_t block = chroma444 ? 4096 : 2048;
+  out.assign(block * (inter ? 2 : 1), 16);
+  for (int pass = 0; pass < (inter ? 2 : 1); pass++)
+    for (int c = 0; c < 3; c++) {
+      const int m = c + 3 * pass;
+      uint8_t* t = out.data() + block * (size_t)pass + c * 336;
+      memcpy(t, sl.l4[m], 16);
+      memcpy(t + 16, sl.l8[m], 64);
+      for (int y = 0; y < 16; y++)
+        for (int x = 0; x < 16; x++) t[80 + y * 16 + x] = sl.l16[m][(y >> 1) * 8 + (x >> 1)];
+      t[80] = sl.dc16[m];
+    }
+  for (int pass = 0; pass < (inter ? 2 : 1); pass++) {
+    uint8_t* t32 = out.data() + block * (size_t)pass + 1008;
+    for (int y = 0; y < 32; y++)
+      for (int x = 0; x < 32; x++) t32[y * 32 + x] = sl.l32[3 * pass][(y >> 2) * 8 + (x >> 2)];
+    t32[0] = sl.dc32[3 * pass];
   }
   uint8_t* t32 = out.data() + 1008;
-  for (int y = 0; y < 32; y++)
-    for (int x = 0; x < 32; x++) t32[y * 32 + x] = sl.l32[0][(y >> 2) * 8 + (x >> 2)];
-  t32[0] = sl.dc32[0];
   if (chroma444)   // 7.4.5: the 32x32 chroma matrices of a 4:4:4 picture are the component's 16x16 lists upsampled by 4, with the 16x16 DC
     for (int c = 1; c < 3; c++) {
       uint8_t* t = out.data() + 2048 + (c - 1) * 1024;
@@ -614,8 +622,6 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
         if (slice_type != 2) {   // 7.3.6.1, P / B slice
           const bool is_b = slice_type == 0;
           if (S.chroma_format_idc > 1) unsupported("P / B slices of a 4:2:2 / 4:4:4 picture");
-          if (S.scaling_list_enabled) unsupported("P / B slices with scaling lists");
-          if (P.constrained_intra_pred) unsupported("constrained_intra_pred_flag with P / B slices");
           int num_ref[2] = {P.num_ref_idx_l0_default, is_b ? P.num_ref_idx_l1_default : 0};
           if (r.u(1)) {   // num_ref_idx_active_override_flag
             num_ref[0] = r.ue_max(14, "num_ref_idx_l0_active_minus1") + 1;
@@ -793,7 +799,7 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
     out.subs.clear();
     out.slice_params.clear();
     out.scaling_tables.clear();
-    if (S.scaling_list_enabled) build_scaling_tables(P.scaling_list_data_present ? P.sl : S.sl, S.chroma_format_idc == 3, out.scaling_tables);
+    if (S.scaling_list_enabled) build_scaling_tables(P.scaling_list_data_present ? P.sl : S.sl, S.chroma_format_idc == 3, out.scaling_tables, out.is_inter);
     std::vector<int> slice_head(out.slices.size(), 0);   // index of the (independent) slice segment that starts the slice a segment belongs to:
                                                          // what the kernels compare to tell slices apart (CtbInfo::slice_idx)
     for (size_t si = 0; si < out.slices.size(); si++) {

@@ -146,6 +146,7 @@ struct Ctx {
   int luma;           // c_idx == 0: DC / horizontal / vertical boundary filters (8.4.4.2.6) apply
   int smooth;         // reference-sample filtering (8.4.4.2.3) applies: c_idx == 0 or ChromaArrayType == 3
   int strong;         // sps strong_intra_smoothing_enabled_flag (c_idx == 0 only)
+  int cip;            // constrained_intra_pred_flag of a picture with P / B slices: inter coded units never become "available" for intra prediction
 };
 
 // A transform block of a coding unit that is NOT intra coded (P pictures): the prediction samples are in the reconstruction plane already
@@ -162,7 +163,7 @@ __device__ __forceinline__ void reconstruct_inter_block(ReconLds<Pix>& L, const 
     if (cbf) v = clip3(0, maxv, v + (int)res[idx]);
     tile[((yb + y) << lg_ctbc) + xb + x] = (Pix)v;
   }
-  {
+  if (!C.cip) {   // (constrained_intra_pred_flag: the samples stay "not available for intra prediction", 8.4.4.2.2)
     const int kx = n >> ushx, rows = n >> ushy;    // units per row of the block (>= 1), unit rows
     if (C.lane < (rows > 0 ? rows : 1)) lds_or(&L.avrow[(yb >> ushy) + 1 + C.lane], ((1ull << (kx > 0 ? kx : 1)) - 1ull) << ((xb >> ushx) + 1));
   }
@@ -552,6 +553,7 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
   C.ushy = suby == 2 ? 1 : 2; C.lg_ctbh = P.log2_ctb - (suby == 2 ? 1 : 0);
   C.bit_depth = chroma ? P.bit_depth_chroma : P.bit_depth_luma; C.maxv = (1 << C.bit_depth) - 1;
   C.luma = !chroma; C.smooth = !DUAL; C.strong = !chroma && P.strong_intra_smoothing;
+  C.cip = (INTER && P.is_inter && P.constrained_intra_pred) ? 1 : 0;
   const int Wc = DUAL ? P.cwidth : P.width, Hc = DUAL ? P.cheight : P.height;   // component plane size in samples
   const int pic_w = P.width, pic_h = P.height, ctb_w = P.ctb_w, ctb_h = P.ctb_h, log2_ctb = P.log2_ctb;
   const int side = 1 << (log2_ctb - 2);                                         // 4x4-luma units per CTB side
@@ -615,6 +617,23 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
       }
       // availability rows: the borders come from the neighbouring CTBs (slice / tile / picture limits are in ci.avail,
       // units right of or below the picture never become available), the CTB's own units are set block by block
+      // constrained_intra_pred_flag (P / B pictures): units of the neighbouring CTBs that are not intra coded stay unavailable too.  Lane j looks at
+      // the unit above the CTB at column j - 1 (above-left, above, above-right) and, lanes 1 .. side, at the unit left of unit row lane - 1
+      uint64_t up_inter = 0;
+      bool left_inter = false;
+      if (INTER && C.cip) {
+        const uint8_t* pc = A.arena + P.off_u_ipmc;
+        auto unit_is_inter = [&](int gx, int gy) -> bool {   // (gx, gy): 4x4-luma unit in the picture
+          if (gx < 0 || gy < 0 || gx * 4 >= pic_w || gy * 4 >= pic_h) return false;
+          const int cxx = gx >> (log2_ctb - 2), cyy = gy >> (log2_ctb - 2);
+          uint32_t x = (uint32_t)(gx & (side - 1)), y = (uint32_t)(gy & (side - 1));
+          x = (x | (x << 2)) & 0x33u; x = (x | (x << 1)) & 0x55u; y = (y | (y << 2)) & 0x33u; y = (y | (y << 1)) & 0x55u;
+          return (pc[((size_t)(cyy * ctb_w + cxx) << (2 * (log2_ctb - 2))) + (x | (y << 1))] & UM_INTER) != 0;
+        };
+        const bool up = lane <= 2 * side && unit_is_inter((x_ctb >> 2) - 1 + lane, (y_ctb >> 2) - 1);
+        up_inter = __ballot(up);
+        left_inter = lane >= 1 && lane <= side && unit_is_inter((x_ctb >> 2) - 1, (y_ctb >> 2) + lane - 1);
+      }
       if (lane < 33) {
         const int usz = 4 / sub, uszy = 4 / suby;                       // component samples per unit, horizontally / vertically
         uint64_t row = 0;
@@ -625,7 +644,8 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
           if (ci.avail & AV_UPLEFT) row |= 1ull;
           if (ci.avail & AV_UP) row |= ((1ull << n_up) - 1ull) << 1;
           if ((ci.avail & AV_UPRIGHT) && nu > side) row |= ((1ull << (nu - side)) - 1ull) << (side + 1);
-        } else if (lane <= side && (ci.avail & AV_LEFT) && y_ctb / suby + (lane - 1) * uszy < Hc) row = 1ull;
+          row &= ~up_inter;
+        } else if (lane <= side && (ci.avail & AV_LEFT) && y_ctb / suby + (lane - 1) * uszy < Hc && !left_inter) row = 1ull;
         L.avrow[lane] = row;
       }
     }

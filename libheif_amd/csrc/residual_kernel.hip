@@ -240,7 +240,7 @@ __device__ __forceinline__ void residual_quad(ResLds& L, int bd_luma, int bd_chr
   const int bd_shift = bit_depth - 3;     // bitDepth + log2(4) - 5
   const int bd_shift2 = 20 - bit_depth;
   const bool use_sl = sl_tab != nullptr;
-  const int mfac = use_sl ? (int)sl_tab[c * 336 + l] : 16;    // 4x4 ScalingFactor of this lane's coefficient (8.6.4.2)
+  const int mfac = use_sl ? (int)sl_tab[c * 336 + l + (((entry >> 11) & 1) << 11)] : 16;    // 4x4 ScalingFactor of this lane's coefficient (8.6.4.2); inter coded units: the second block of tables
   const int f = mfac * level_scale(qp - 6 * q6);
   const int sh_r = q6 < bd_shift ? bd_shift - q6 : 0, sh_l = q6 < bd_shift ? 0 : q6 - bd_shift, rnd = sh_r ? 1 << (sh_r - 1) : 0;
   const int lev = act ? first_lev : 0;
@@ -343,10 +343,12 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
       const int t = L.m_size[z] & 15, fl = L.m_flags[z];
       const int first = t >= 2 && t <= 5 && (z & ((1 << (2 * (t - 2))) - 1)) == 0;
       if (first && !(fl & UF_BYPASS)) {
+        const int inter_bit = (P.is_inter && (A.arena[P.off_u_ipmc + base + z] & UM_INTER)) ? 0x800 : 0;
         if (fl & UF_CBF_LUMA) {
           // (P pictures: bit 11 = the block belongs to an inter coded unit: its 4x4 luma transform is the DCT, not the DST of intra blocks, 8.6.4.2)
-          if (t == 2) L.list[LIST_N - 1 - atomicAdd(&L.count4, 1u)] = (uint16_t)(z | ((P.is_inter && (A.arena[P.off_u_ipmc + base + z] & UM_INTER)) ? 0x800 : 0));
-          else L.list[atomicAdd(&L.count, 1u)] = (uint16_t)z;
+          // (with scaling lists the bit also selects the matrices of inter coded units for every block size and component, Table 7-4)
+          if (t == 2) L.list[LIST_N - 1 - atomicAdd(&L.count4, 1u)] = (uint16_t)(z | inter_bit);
+          else L.list[atomicAdd(&L.count, 1u)] = (uint16_t)(z | inter_bit);
         }
         // chroma blocks hang off the unit that carries their flags: a block's first unit, or the 4th unit of a quad of 4x4 luma blocks.  4:2:2 has
         // two chroma blocks per unit; the lower one's flags sit in unit z ^ 1 (so in a 4:2:2 quad only the 4th unit's flags are block flags)
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
           for (int c = 1; c < 3; c++)
             for (int low = 0; low < (c422 ? 2 : 1); low++)
               if ((low ? L.m_flags[z ^ 1] : fl) & (c == 1 ? UF_CBF_CB : UF_CBF_CR)) {
-                const uint16_t entry = (uint16_t)(z | (c << 8) | (low << 10));
+                const uint16_t entry = (uint16_t)(z | (c << 8) | (low << 10) | inter_bit);
                 if (t <= (c444 ? 2 : 3)) L.list[LIST_N - 1 - atomicAdd(&L.count4, 1u)] = entry;
                 else L.list[atomicAdd(&L.count, 1u)] = entry;
               }
@@ -389,8 +391,9 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
     }
   }
   // larger blocks, one per wave pass; the first levels of the NEXT block are requested before the current one is worked on
-  auto block_of = [&](int e, int& c, int& t, int& tc, int& fl, int& ipm, int& qp_y) -> int16_t* {   // list entry -> component, sizes, flags, levels
-    const int z = L.list[e] & 255, low = c422 ? L.list[e] >> 10 : 0;
+  auto block_of = [&](int e, int& c, int& t, int& tc, int& fl, int& ipm, int& qp_y, int& sl_off) -> int16_t* {   // list entry -> component, sizes, flags, levels
+    const int z = L.list[e] & 255, low = c422 ? (L.list[e] >> 10) & 1 : 0;
+    sl_off = ((L.list[e] >> 11) & 1) << 11;   // scaling lists: the tables of inter coded units follow the intra ones (P / B pictures: 2048-byte blocks)
     c = (L.list[e] >> 8) & 3;
     t = L.m_size[z] & 15; fl = L.m_flags[z]; ipm = L.m_ipm[low ? (z ^ 1) : z]; qp_y = L.m_qp[z];
     tc = c == 0 ? t : (c444 ? t : t - 1);    // log2 size of the block
@@ -399,18 +402,18 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
   auto first_levels = [&](const int16_t* cc, int tc) -> uint2 {
     return lane * 4 < (1 << (2 * tc)) ? *(const uint2*)&cc[lane * 4] : make_uint2(0, 0);
   };
-  int c = 0, t = 0, tc = 0, fl = 0, ipm = 0, qp_y = 0;
+  int c = 0, t = 0, tc = 0, fl = 0, ipm = 0, qp_y = 0, sl_off = 0;
   int16_t* cc = nullptr;
   uint2 ahead = make_uint2(0, 0);
-  if (wave < count) { cc = block_of(wave, c, t, tc, fl, ipm, qp_y); ahead = first_levels(cc, tc); }
+  if (wave < count) { cc = block_of(wave, c, t, tc, fl, ipm, qp_y, sl_off); ahead = first_levels(cc, tc); }
   for (int e = wave; e < count; e += 4) {
     const uint2 first_raw = ahead;
     int16_t* const cur = cc;
-    const int cur_c = c, cur_t = t, cur_tc = tc, cur_fl = fl, cur_ipm = ipm, cur_qp = qp_y;
-    if (e + 4 < count) { cc = block_of(e + 4, c, t, tc, fl, ipm, qp_y); ahead = first_levels(cc, tc); }
+    const int cur_c = c, cur_t = t, cur_tc = tc, cur_fl = fl, cur_ipm = ipm, cur_qp = qp_y, cur_sl = sl_off;
+    if (e + 4 < count) { cc = block_of(e + 4, c, t, tc, fl, ipm, qp_y, sl_off); ahead = first_levels(cc, tc); }
     if (cur_c == 0) {
       if (use_sl) residual_block<true>(L, wave, lane, cur, cur_t, bd_luma, cur_qp + 6 * (bd_luma - 8), 0, (cur_fl & UF_TS_LUMA) != 0, 0,
-                                       sl_tab + (cur_t == 5 ? 1008 : (cur_t == 3 ? 16 : 80)), first_raw);
+                                       sl_tab + cur_sl + (cur_t == 5 ? 1008 : (cur_t == 3 ? 16 : 80)), first_raw);
       else residual_block<false>(L, wave, lane, cur, cur_t, bd_luma, cur_qp + 6 * (bd_luma - 8), 0, (cur_fl & UF_TS_LUMA) != 0, 0, nullptr, first_raw);
     }
     else {
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
       const int qpi = clip3(-off_c, 57, cur_qp + (cur_c == 1 ? cb_off : cr_off));
       const int qpc = chroma_qp(qpi, cfi_p != 1);
       if (use_sl) residual_block<true>(L, wave, lane, cur, cur_tc, bd_chroma, qpc + off_c, 0, (cur_ipm & (cur_c == 1 ? 64 : 128)) != 0, 0,
-                                       cur_tc == 5 ? sl_tab + 2048 + (cur_c - 1) * 1024 : sl_tab + cur_c * 336 + (cur_tc == 3 ? 16 : 80), first_raw);   // 32x32 chroma: 4:4:4 only
+                                       cur_tc == 5 ? sl_tab + 2048 + (cur_c - 1) * 1024 : sl_tab + cur_sl + cur_c * 336 + (cur_tc == 3 ? 16 : 80), first_raw);   // 32x32 chroma: 4:4:4 only
       else residual_block<false>(L, wave, lane, cur, cur_tc, bd_chroma, qpc + off_c, 0, (cur_ipm & (cur_c == 1 ? 64 : 128)) != 0, 0, nullptr, first_raw);
     }
   }

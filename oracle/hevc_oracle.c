@@ -1140,13 +1140,15 @@ static void intra_predict_block(Dec* d, int x0c, int y0c, int log2n, int cIdx, i
     /* left column: p[-1][i-1] */
     int xN = x0c - 1, yN = y0c + i - 1;
     int av = available_z(d, xTbY, yTbY, xN * subw, yN * subh);
-    if (av && d->p->constrained_intra_pred_flag) av = 1; /* every CU is intra in this oracle */
+    /* 8.4.4.2.2: with constrained_intra_pred_flag a sample of a unit that is not intra coded is marked "not available for intra prediction" */
+    if (av && d->p->constrained_intra_pred_flag && d->m_pred && d->m_pred[((yN * subh) >> 2) * d->mw + ((xN * subw) >> 2)] != 0) av = 0;
     aL[i] = (uint8_t)av;
     if (av) { L[i] = rec[yN * stride + xN]; any = 1; }
     /* top row: p[i-1][-1] */
     xN = x0c + i - 1; yN = y0c - 1;
     if (i == 0) { aT[0] = aL[0]; T[0] = L[0]; continue; }
     av = available_z(d, xTbY, yTbY, xN * subw, yN * subh);
+    if (av && d->p->constrained_intra_pred_flag && d->m_pred && d->m_pred[((yN * subh) >> 2) * d->mw + ((xN * subw) >> 2)] != 0) av = 0;
     aT[i] = (uint8_t)av;
     if (av) { T[i] = rec[yN * stride + xN]; any = 1; }
   }
@@ -2064,7 +2066,6 @@ static void decode_slice(Dec* d, int nal_type, const uint8_t* nal, size_t nal_le
     }
     if (hdr.slice_type != 2) {   /* 7.3.6.1, P / B slice */
       const int is_b = hdr.slice_type == 0;
-      if (p->constrained_intra_pred_flag) fail(d, "unsupported: constrained_intra_pred_flag with P / B slices");
       hdr.slice_temporal_mvp = slice_temporal_mvp;
       hdr.num_ref_idx_l0_active = p->num_ref_idx_l0_default_active;
       hdr.num_ref_idx_l1_active = is_b ? p->num_ref_idx_l1_default_active : 0;

@@ -1101,6 +1101,7 @@ static void enc_parameter_sets(Enc* e, Bytes* pstream)
   p->sps_id = 0;
   p->sign_data_hiding_enabled_flag = prm->sign_data_hiding;
   p->init_qp_minus26 = 0;
+  p->constrained_intra_pred_flag = prm->constrained_intra_pred ? 1 : 0;
   p->transform_skip_enabled_flag = prm->transform_skip;
   p->cu_qp_delta_enabled_flag = prm->cu_qp_delta;
   p->diff_cu_qp_delta_depth = prm->cu_qp_delta ? Min(prm->diff_cu_qp_delta_depth, s->log2_ctb - s->log2_min_cb) : 0;
@@ -1182,7 +1183,7 @@ static void enc_parameter_sets(Enc* e, Bytes* pstream)
   p->dependent_slice_segments_enabled_flag = prm->dependent_segments > 1;
   bw_ue(&w, 0); bw_ue(&w, 0); bw_u(&w, p->dependent_slice_segments_enabled_flag, 1); bw_u(&w, 0, 1); bw_u(&w, 0, 3);
   bw_u(&w, p->sign_data_hiding_enabled_flag, 1); bw_u(&w, p->cabac_init_present_flag, 1); bw_ue(&w, 0); bw_ue(&w, 0);
-  bw_se(&w, p->init_qp_minus26); bw_u(&w, 0, 1); bw_u(&w, p->transform_skip_enabled_flag, 1);
+  bw_se(&w, p->init_qp_minus26); bw_u(&w, p->constrained_intra_pred_flag, 1); bw_u(&w, p->transform_skip_enabled_flag, 1);
   bw_u(&w, p->cu_qp_delta_enabled_flag, 1);
   if (p->cu_qp_delta_enabled_flag) bw_ue(&w, p->diff_cu_qp_delta_depth);
   bw_se(&w, p->pps_cb_qp_offset); bw_se(&w, p->pps_cr_qp_offset); bw_u(&w, 0, 1);
@@ -1545,7 +1546,6 @@ static int enc_run(const hevc_testenc_params* prm, int n_frames, const uint16_t*
     free_dec(d);
     return -1;
   }
-  if (seq_mode && prm->scaling_list) fail(d, "sequences with P / B pictures: without scaling lists only");
   enc_parameter_sets(e, &stream);
   /* ---- coding order: frame 0 an IDR picture; with b_frames = b every (b + 1)-th picture is a P picture (an "anchor") and the b pictures
      before it are B pictures coded after it; the pictures behind the last anchor are P pictures.  A picture's own references: the anchors

@@ -42,6 +42,7 @@ typedef struct hevc_testenc_params {
   int temporal_mvp;             /* sps_temporal_mvp_enabled_flag, slice_temporal_mvp_enabled_flag in every P / B picture                  */
   int weighted_pred;            /* weighted_pred_flag / weighted_bipred_flag with a random pred_weight_table per slice                     */
   int mvd_l1_zero;              /* mvd_l1_zero_flag in B slices                                                                            */
+  int constrained_intra_pred;   /* constrained_intra_pred_flag: intra blocks of P / B pictures predict from intra coded neighbours only    */
 } hevc_testenc_params;
 
 /* planes: tightly packed uint16 samples at display size (chroma (w+1)/2 x (h+1)/2).

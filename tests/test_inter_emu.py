@@ -276,3 +276,27 @@ def _split(stream):
         out.append(stream[p:p + 4 + n])
         p += 4 + n
     return out
+
+
+@pytest.mark.parametrize("sl", [1, 2, 3], ids=["default_lists", "sps_lists", "pps_lists"])
+def test_emulated_p_b_pictures_with_scaling_lists(sl):
+    """scaling_list_enabled_flag in P / B pictures (missing 4): blocks of inter coded units dequantise with the matrices of
+    matrixId 3 .. 5 (Table 7-4; the 32x32 inter luma matrix), intra units of the same picture with 0 .. 2 - default lists (Table 7-6 differs
+    between the two), lists coded in the SPS, lists coded in the PPS"""
+    frames = make_frames(136, 104, 5)
+    aus = orc.encode_sequence(frames, qp=24, global_mv_x=-8, global_mv_y=-4, scaling_list=sl, b_frames=1, temporal_mvp=1, inter_intra_pct=30, seed=3 + sl)
+    check_sequence(aus, "scaling_list=%d" % sl)
+    check_sequence(aus, "scaling_list=%d, chain" % sl, chain=4)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(b_frames=2, b_ref=1, temporal_mvp=1, log2_ctb=4, log2_max_tb=4), dict(log2_ctb=5, amp=1, inter_num_refs=2, num_slices=2, wpp=0),
+                                dict(tile_cols=2, tile_rows=2, log2_ctb=4, log2_max_tb=4)], ids=["ctb64", "b_ctb16", "slices_ctb32", "tiles_ctb16"])
+def test_emulated_constrained_intra_pred_in_p_b_pictures(kw):
+    """constrained_intra_pred_flag with P / B slices (missing 4): samples of units that are not intra coded are "not available for
+    intra prediction" (8.4.4.2.2) - inside the CTB (inter units never enter the availability map) and across CTB borders (the neighbouring CTBs'
+    units are looked up in the prediction-mode map); small CTBs put most neighbours in another CTB"""
+    aus = orc.encode_sequence(make_frames(136, 104, 5), qp=24, global_mv_x=-8, global_mv_y=-4, constrained_intra_pred=1, inter_intra_pct=45, inter_skip_pct=10, **kw)
+    check_sequence(aus, "constrained_intra_pred %r" % kw)
+    check_sequence(aus, "constrained_intra_pred, chain", chain=4)
+    # the flag matters in these streams: the same pictures coded without it give another bitstream (another prediction for the intra blocks)
+    assert aus != orc.encode_sequence(make_frames(136, 104, 5), qp=24, global_mv_x=-8, global_mv_y=-4, constrained_intra_pred=0, inter_intra_pct=45, inter_skip_pct=10, **kw)

@@ -194,3 +194,16 @@ def test_missing_reference_picture_is_an_error():
     with pytest.raises(orc.OracleError):
         q.decode(aus[2])                                        # its RPS names POC 1, which was never decoded
     q.close()
+
+
+@pytest.mark.parametrize("cip", [0, 1])
+def test_lossless_round_trip_with_constrained_intra_pred(cip):
+    """oracle + generator agree on constrained_intra_pred_flag in P / B pictures: lossless coded pictures come back exactly (the intra blocks
+    predict from intra coded neighbours only on both sides), and the flag changes the bitstream"""
+    frames = make_frames(136, 104, 4)
+    aus = orc.encode_sequence(frames, qp=30, global_mv_x=-8, global_mv_y=-4, lossless_pct=100, inter_skip_pct=0, inter_intra_pct=40, constrained_intra_pred=cip, b_frames=1, temporal_mvp=1)
+    pics = sorted(orc.decode_sequence(aus, taps=True), key=lambda p: p["poc"])
+    for i, p in enumerate(pics):
+        for c in range(3):
+            np.testing.assert_array_equal(p["planes"][c], frames[i][c], err_msg="picture %d component %d" % (i, c))
+    assert all(0.1 < (p["map_pred"] == 0).mean() < 0.9 for p in pics[1:])      # intra and inter units side by side

@@ -263,6 +263,9 @@ B_CASES = {
     "b3_slices_listmod": dict(b_frames=3, temporal_mvp=1, num_slices=2, lists_modification=1, cabac_init_present=1, max_merge_cand=4, wpp=0),
     "b_main10_tiles": dict(b_frames=2, b_ref=1, temporal_mvp=1, bit_depth=10, tile_cols=2, tile_rows=2, inter_num_refs=2),
     "b_cropped": dict(b_frames=1, temporal_mvp=1, weighted_pred=1, w=70, h=42, global_mv_y=17, inter_num_refs=2),
+    "b_scaling_lists_sps": dict(b_frames=1, temporal_mvp=1, scaling_list=2, inter_intra_pct=30),      # inter matrices (matrixId 3 .. 5) beside the intra ones
+    "p_scaling_lists_default": dict(scaling_list=1, inter_num_refs=2, inter_intra_pct=30),
+    "b_constrained_intra_pred": dict(b_frames=1, temporal_mvp=1, constrained_intra_pred=1, inter_intra_pct=45, log2_ctb=4, log2_max_tb=4),
 }
 
 
