@@ -238,6 +238,8 @@ int layout_core(BatchLayout& b, const size_t* sizes, std::string& err_out)
     if (P.scaling_lists) off = align_up(off + pp.scaling_tables.size(), 256);
     // P pictures: the reference picture table (absolute device pointers into earlier batches' arenas)
     P.is_inter = pp.is_inter ? 1 : 0; P.poc = pp.poc; P.num_refs = (uint32_t)pp.refs.size();
+    P.lt_mask = 0;
+    for (size_t k = 0; k < pp.refs.size() && k < 16; k++) if (pp.refs[k].long_term) P.lt_mask = (uint16_t)(P.lt_mask | (1u << k));
     P.constrained_intra_pred = (pp.is_inter && Pp.constrained_intra_pred) ? 1 : 0;   // (an intra picture: every unit is intra coded, the flag changes nothing)
     P.amp_enabled = S.amp ? 1 : 0; P.max_th_depth_inter = (uint8_t)S.max_th_depth_inter; P.log2_par_mrg_level = (uint8_t)Pp.log2_par_mrg_level;
     P.off_wp = off;

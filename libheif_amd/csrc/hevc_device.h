@@ -92,6 +92,7 @@ struct MotionUnit {
   int16_t poc_delta[2];  // PicOrderCnt(this picture) - PicOrderCnt(the list's reference picture): all the temporal candidates of LATER pictures need
   int8_t ref_idx[2];     // refIdxL0 / L1, -1: the list is not used (both -1: the unit is intra coded)
   uint8_t slot_pred[2];  // bits 0..5: the list's reference picture as a RefFrame slot (equal slots <=> the same picture, 8.7.2.4);
+                         // [1] bits 6 / 7: the reference picture of list 0 / 1 was a LONG-TERM one when this picture was decoded (LongTermRefPic of 8.5.3.2.9);
                          // [0] bits 6..7: 0 MODE_INTRA, 1 MODE_INTER, 2 MODE_SKIP
 };
 static_assert(sizeof(MotionUnit) == 16, "MotionUnit layout");
@@ -155,7 +156,8 @@ struct PicParams {
   int32_t poc;                    // PicOrderCntVal
   uint32_t num_refs;              // entries of the RefFrame table
   uint8_t constrained_intra_pred; // constrained_intra_pred_flag in a picture with P / B slices: samples of units that are not intra coded are "not available" for intra prediction (8.4.4.2.2)
-  uint8_t pad_inter[3];
+  uint8_t pad_inter;
+  uint16_t lt_mask;               // bit k: slot k of the RefFrame table is a long-term reference picture (8.5.3.2.7 / 8.5.3.2.9: never scaled, only paired with long-term ones)
   uint64_t off_wp;                // WeightTable per slice with explicit weights (SliceParams::wp_index)
   uint64_t off_reftab;            // RefFrame[16]
   uint64_t off_msyn;              // MotionSyntax[ctbs * units_per_ctb]

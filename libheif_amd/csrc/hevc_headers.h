@@ -23,6 +23,10 @@ struct StRps {
   int num_neg = 0, num_pos = 0;
   int delta_s0[16] = {0}, delta_s1[16] = {0};
   bool used_s0[16] = {false}, used_s1[16] = {false};
+  // the long-term part of a slice header's reference picture set (7.3.6.1): PocLsbLt, UsedByCurrPicLt, delta_poc_msb_present_flag, DeltaPocMsbCycleLt (7-52)
+  int num_lt = 0;
+  int lt_poc_lsb[33] = {0}, lt_msb_cycle[33] = {0};
+  bool lt_used[33] = {false}, lt_msb_present[33] = {false};
 };
 
 // A decoded picture a later P picture may reference: device pointers of its planes (coded size, deblocked, SAO applied), strides in bytes
@@ -60,6 +64,8 @@ struct Sps {
   bool long_term_ref_pics_present = false, temporal_mvp = false, separate_colour_plane = false;
   int max_num_reorder = 0, max_dec_pic_buffering = 1;   // of the highest sub-layer (output order: C.5.2.2)
   int num_short_term_ref_pic_sets = 0, num_long_term_ref_pics_sps = 0;
+  int lt_poc_lsb_sps[32] = {0};          // lt_ref_pic_poc_lsb_sps / used_by_curr_pic_lt_sps_flag: long-term candidates slice headers name by index
+  bool lt_used_sps[32] = {false};
   std::vector<StRps> st_rps;            // the short-term reference picture sets of the SPS
   int colour_primaries = 2, transfer_characteristics = 2, matrix_coeffs = 2, full_range = 0;
   ScalingLists sl{};   // valid when scaling_list_enabled (explicit lists or the defaults)
@@ -90,6 +96,7 @@ struct ParsedSlice {
   size_t data_offset = 0;  // offset in the pushed blob of the first slice_segment_data byte
   size_t nal_end = 0;      // offset one past the slice NAL
   std::vector<uint32_t> entry_point_offsets;  // bytes, escaped domain
+  bool ref_lt[2][16] = {{false}, {false}};   // ... it is a long-term reference picture
   int ref_poc[2][16] = {{0}, {0}};   // P / B slice: PicOrderCntVal of RefPicListX[i] (sp.ref_slot / ref_slot_l1 are filled once the picture's reference table is known)
   int col_poc = 0;                   // the collocated picture (slice_temporal_mvp_enabled_flag)
   bool has_weights = false;
@@ -116,6 +123,7 @@ struct ParsedPicture {
   bool is_inter = false;                // some slice is a P slice
   bool is_idr = false;
   std::vector<int> keep_pocs;           // every picture of the RPS (the DPB drops the others once this picture is decoded)
+  std::vector<int> lt_pocs;             // the pictures of RefPicSetLtCurr / LtFoll: marked "used for long-term reference" from this picture on (8.3.2)
   std::vector<RefPicture> refs;         // the reference table of the picture (slots of SliceParams::ref_slot), at most 16
   std::vector<WeightTable> weight_tables;   // of the slices with explicit weights (SliceParams::wp_index)
   int max_num_reorder = 0, max_dec_pic_buffering = 1;   // sps_max_num_reorder_pics / sps_max_dec_pic_buffering_minus1 + 1 of the highest sub-layer

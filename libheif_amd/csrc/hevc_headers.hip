@@ -316,7 +316,7 @@ void parse_sps(NalReader& r, Sps& s)
   s.long_term_ref_pics_present = r.u(1);
   if (s.long_term_ref_pics_present) {
     s.num_long_term_ref_pics_sps = r.ue_max(32, "num_long_term_ref_pics_sps");
-    for (int i = 0; i < s.num_long_term_ref_pics_sps; i++) { r.skip(s.log2_max_poc_lsb); r.skip(1); }
+    for (int i = 0; i < s.num_long_term_ref_pics_sps; i++) { s.lt_poc_lsb_sps[i] = (int)r.u(s.log2_max_poc_lsb); s.lt_used_sps[i] = r.u(1); }
   }
   s.temporal_mvp = r.u(1);
   s.strong_intra_smoothing = r.u(1);
@@ -493,6 +493,7 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
     std::vector<int> ctb_slice;       // slice index per CTB (raster), -1 = not covered
     std::vector<int> ctb_slice_addr;  // SliceAddrRs per CTB
     StRps pic_rps;                     // the RPS of the picture (every slice segment header repeats it)
+    std::vector<int> pic_lt_curr;      // RefPicSetLtCurr as POCs
     int pic_poc_lsb = 0, pic_nal_type = 0, pic_tid = 0;
     out.is_inter = false; out.refs.clear(); out.keep_pocs.clear();
     out.pic_output = true; out.skipped = false;
@@ -580,14 +581,20 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
             if (idx >= S.num_short_term_ref_pic_sets) bad("short_term_ref_pic_set_idx out of range");
             rps = S.st_rps[(size_t)idx];
           }
-          if (S.long_term_ref_pics_present) {
-            int lt_sps = S.num_long_term_ref_pics_sps > 0 ? r.ue_max(32, "num_long_term_sps") : 0;
-            int lt_pics = r.ue_max(32, "num_long_term_pics");
-            if (seq && lt_sps + lt_pics > 0) unsupported("long-term reference pictures");
-            for (int i = 0; i < lt_sps + lt_pics; i++) {
-              if (i < lt_sps) { if (S.num_long_term_ref_pics_sps > 1) r.skip(ceil_log2(S.num_long_term_ref_pics_sps)); }
-              else { r.skip(S.log2_max_poc_lsb); r.skip(1); }
-              if (r.u(1)) r.ue();
+          if (S.long_term_ref_pics_present) {   // 7.3.6.1 / 7.4.7.1: the long-term pictures of the RPS
+            const int lt_sps = S.num_long_term_ref_pics_sps > 0 ? r.ue_max((uint32_t)S.num_long_term_ref_pics_sps, "num_long_term_sps") : 0;
+            const int lt_pics = r.ue_max(32, "num_long_term_pics");
+            if (lt_sps + lt_pics > 32) bad("more than 32 long-term reference pictures");
+            rps.num_lt = lt_sps + lt_pics;
+            for (int i = 0; i < rps.num_lt; i++) {
+              if (i < lt_sps) {
+                const int idx = S.num_long_term_ref_pics_sps > 1 ? (int)r.u(ceil_log2(S.num_long_term_ref_pics_sps)) : 0;
+                if (idx >= S.num_long_term_ref_pics_sps) bad("lt_idx_sps out of range");
+                rps.lt_poc_lsb[i] = S.lt_poc_lsb_sps[idx]; rps.lt_used[i] = S.lt_used_sps[idx];
+              } else { rps.lt_poc_lsb[i] = (int)r.u(S.log2_max_poc_lsb); rps.lt_used[i] = r.u(1); }
+              rps.lt_msb_present[i] = r.u(1);
+              const int cycle = rps.lt_msb_present[i] ? r.ue_max(1 << 20, "delta_poc_msb_cycle_lt") : 0;
+              rps.lt_msb_cycle[i] = (i == 0 || i == lt_sps) ? cycle : cycle + rps.lt_msb_cycle[i - 1];
             }
           }
           if (S.temporal_mvp) slice_tmvp = r.u(1);
@@ -611,7 +618,24 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
               else if (poc_lsb > seq->prev_tid0_lsb && poc_lsb - seq->prev_tid0_lsb > max_lsb / 2) msb -= max_lsb;
               out.poc = msb + poc_lsb;
             }
+            out.lt_pocs.clear();
             if (!idr) {
+              // 8.3.2: the long-term subsets first - a candidate is ANY reference picture of the DPB, named by its POC LSBs or (delta_poc_msb_present_flag) its
+              // whole POC -, then the short-term ones among the pictures that are not long-term reference pictures
+              const int max_lsb = 1 << S.log2_max_poc_lsb;
+              pic_lt_curr.clear();
+              for (int i = 0; i < rps.num_lt; i++) {
+                int poc_lt = rps.lt_poc_lsb[i];
+                if (rps.lt_msb_present[i]) poc_lt += out.poc - rps.lt_msb_cycle[i] * max_lsb - (out.poc & (max_lsb - 1));
+                const RefPicture* found = nullptr;
+                for (const RefPicture& rp : seq->dpb)
+                  if (!found && (rps.lt_msb_present[i] ? rp.poc == poc_lt : (rp.poc & (max_lsb - 1)) == poc_lt)) found = &rp;
+                if (found) { out.keep_pocs.push_back(found->poc); out.lt_pocs.push_back(found->poc); }
+                if (rps.lt_used[i]) {
+                  if (!found) bad("long-term reference picture with POC (LSBs) " + std::to_string(poc_lt) + " is missing");
+                  pic_lt_curr.push_back(found->poc);
+                }
+              }
               for (int i = 0; i < rps.num_neg; i++) out.keep_pocs.push_back(out.poc + rps.delta_s0[i]);
               for (int i = 0; i < rps.num_pos; i++) out.keep_pocs.push_back(out.poc + rps.delta_s1[i]);
             }
@@ -627,16 +651,23 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
             num_ref[0] = r.ue_max(14, "num_ref_idx_l0_active_minus1") + 1;
             if (is_b) num_ref[1] = r.ue_max(14, "num_ref_idx_l1_active_minus1") + 1;
           }
-          // RefPicSetStCurrBefore / After of the PICTURE's RPS (8.3.2); RefPicListTemp0 = Before, After; RefPicListTemp1 = After, Before (8.3.4)
+          // RefPicSetStCurrBefore / After / LtCurr of the PICTURE's RPS (8.3.2); RefPicListTemp0 = Before, After, Lt; RefPicListTemp1 = After, Before, Lt (8.3.4)
+          auto is_lt = [&](int poc) {   // marked long-term before this picture, or by this picture's RPS
+            for (int q : out.lt_pocs) if (q == poc) return true;
+            for (const RefPicture& rp : seq->dpb) if (rp.poc == poc) return rp.long_term;
+            return false;
+          };
           std::vector<int> before, after;
           for (int i = 0; i < pic_rps.num_neg; i++) if (pic_rps.used_s0[i]) before.push_back(out.poc + pic_rps.delta_s0[i]);
           for (int i = 0; i < pic_rps.num_pos; i++) if (pic_rps.used_s1[i]) after.push_back(out.poc + pic_rps.delta_s1[i]);
-          const int total = (int)(before.size() + after.size());
+          const int n_st = (int)(before.size() + after.size());
+          const int total = n_st + (int)pic_lt_curr.size();   // NumPicTotalCurr
           if (total == 0) bad("P / B slice without a reference picture");
-          for (int k = 0; k < total; k++) {
+          for (int k = 0; k < n_st; k++) {
             const int poc = k < (int)before.size() ? before[(size_t)k] : after[(size_t)k - before.size()];
             bool have = false;
             for (const RefPicture& rp : seq->dpb) if (rp.poc == poc) have = true;
+            if (have && is_lt(poc)) have = false;   // (a short-term entry never names a long-term reference picture)
             if (!have) bad("reference picture with POC " + std::to_string(poc) + " is missing");
           }
           int entries[2][16];
@@ -652,11 +683,13 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
             const std::vector<int>& second = X ? before : after;
             temp.insert(temp.end(), first.begin(), first.end());
             temp.insert(temp.end(), second.begin(), second.end());
+            temp.insert(temp.end(), pic_lt_curr.begin(), pic_lt_curr.end());
             const int want = num_ref[X] > total ? num_ref[X] : total;
             for (int i = 0; i < num_ref[X]; i++) {
               const int e = modified[X] ? entries[X][i] : i;
               if (e < 0 || e >= want) bad("list_entry_lX out of range");
               sl.ref_poc[X][i] = temp[(size_t)(e % total)];
+              sl.ref_lt[X][i] = (e % total) >= n_st;
             }
           }
           if (is_b) sl.sp.mvd_l1_zero = r.u(1);
@@ -770,6 +803,7 @@ int parse_picture(const uint8_t* blob, size_t size, uint64_t max_pixels, ParsedP
                 rp.bit_depth_luma != out.sps.bit_depth_luma || rp.bit_depth_chroma != out.sps.bit_depth_chroma || rp.log2_ctb != out.sps.log2_ctb)
               bad("reference picture with POC " + std::to_string(poc) + " was decoded in another format (parameter sets changed without an IDR picture)");
             out.refs.push_back(rp);
+            for (int q : out.lt_pocs) if (q == poc) out.refs.back().long_term = true;
             return (int)out.refs.size() - 1;
           }
         return -1;
@@ -958,6 +992,7 @@ void seq_commit(SeqContext& seq, const ParsedPicture& pic, int)
   if (pic.is_idr || (irap && seq.first_picture)) { seq.prev_tid0_lsb = pic.is_idr ? 0 : pic.poc_lsb; seq.prev_tid0_msb = 0; }
   else if (pic.temporal_id == 0 && (irap || (pic.nal_type <= 5 && (pic.nal_type & 1)))) { seq.prev_tid0_lsb = pic.poc_lsb; seq.prev_tid0_msb = pic.poc - pic.poc_lsb; }
   seq.first_picture = false;
+  for (RefPicture& rp : seq.dpb) for (int poc : pic.lt_pocs) if (poc == rp.poc) rp.long_term = true;   // 8.3.2: RefPicSetLtCurr / LtFoll
   std::vector<RefPicture> kept;
   for (const RefPicture& rp : seq.dpb) {
     bool keep = false;

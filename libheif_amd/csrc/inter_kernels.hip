@@ -5,7 +5,7 @@
 // availability), 8.5.3.2.2 - 8.5.3.2.5 (merge mode: spatial, temporal, combined bi-predictive and zero candidates), 8.5.3.2.6 - 8.5.3.2.9 (motion
 // vector prediction: spatial candidates with scaling, the collocated candidate), 8.5.3.3.3 (fractional sample interpolation), 8.5.3.3.4.2 /
 // 8.5.3.3.4.3 (default and explicit weighted sample prediction, one or two lists).
-// Scope as the host front end enforces it: P and B slices, short-term reference pictures, 4:0:0 / 4:2:0.
+// Scope as the host front end enforces it: P and B slices, short-term and long-term reference pictures, 4:0:0 / 4:2:0.
 //
 // MI355X mapping
 //   * the entropy decoder (parse_core.h, HIPDEC_PARSE_INTER build) only PARSES prediction units into MotionSyntax records: HEVC keeps parsing free
@@ -101,6 +101,7 @@ struct MotionCtx {
                                 // grid column to the right of the CTB (bottom-right candidates; never below the CTB row, 8.5.3.2.8)
   const int* ref_poc;           // PicOrderCnt of the reference picture table's slots (LDS)
   int col_w;                    // grid columns staged
+  int lt_mask;                  // PicParams::lt_mask: the reference picture table's long-term slots
   int cx, cy, avail;            // CTB position, AV_* bits
   int log2_ctb, units_log2, lmt, ctb_w, width, height;
   int poc, par_mrg;
@@ -196,8 +197,13 @@ __device__ __forceinline__ int collocated_mv(const MotionCtx& C, int x, int y, i
   else if (!f1) L = 0;
   else L = C.slice->no_backward ? X : C.slice->col_from_l0;
   int vx = unit_mvx(cu, L), vy = unit_mvy(cu, L);
-  const int col_diff = unit_poc_delta(cu, L), cur_diff = C.poc - C.ref_poc[slot_of(C, X, ref_idx)];
-  if (col_diff != cur_diff) {
+  const int tgt_slot = slot_of(C, X, ref_idx);
+  const int col_diff = unit_poc_delta(cu, L), cur_diff = C.poc - C.ref_poc[tgt_slot];
+  // LongTermRefPic(current) != LongTermRefPic(collocated block, as marked when ITS picture was decoded): no candidate; a long-term target takes the
+  // collocated vector as it is
+  const int col_lt = (cu.slot_pred[1] >> (6 + L)) & 1, cur_lt = (C.lt_mask >> tgt_slot) & 1;
+  if (col_lt != cur_lt) return 0;
+  if (!cur_lt && col_diff != cur_diff) {
     if (col_diff == 0) return 0;
     scale_mv(vx, vy, col_diff, cur_diff);
   }
@@ -293,13 +299,16 @@ __device__ __forceinline__ int nb_same_pic(const MotionUnit& m, int X, int tgt_s
 }
 __device__ __forceinline__ int nb_scaled(const MotionCtx& C, const MotionUnit& m, int X, int tgt_slot, int& mvx, int& mvy)
 {
+  // 8.5.3.2.7 (7): the neighbour's vector of list X, else of the other list, counts when its reference picture and the target are both long-term
+  // or both short-term pictures; it is scaled only between short-term pictures
+  const int tgt_lt = (C.lt_mask >> tgt_slot) & 1;
   int L = -1;
-  if (unit_ref(m, X) >= 0) L = X;
-  else if (unit_ref(m, 1 - X) >= 0) L = 1 - X;
+  if (unit_ref(m, X) >= 0 && ((C.lt_mask >> unit_slot(m, X)) & 1) == tgt_lt) L = X;
+  else if (unit_ref(m, 1 - X) >= 0 && ((C.lt_mask >> unit_slot(m, 1 - X)) & 1) == tgt_lt) L = 1 - X;
   if (L < 0) return 0;
   mvx = unit_mvx(m, L); mvy = unit_mvy(m, L);
   const int nb_slot = unit_slot(m, L);
-  if (nb_slot != tgt_slot) scale_mv(mvx, mvy, C.poc - C.ref_poc[nb_slot], C.poc - C.ref_poc[tgt_slot]);
+  if (!tgt_lt && nb_slot != tgt_slot) scale_mv(mvx, mvy, C.poc - C.ref_poc[nb_slot], C.poc - C.ref_poc[tgt_slot]);
   return 1;
 }
 
@@ -402,7 +411,7 @@ __global__ __launch_bounds__(64) void k_motion(MotionArgs A)
     C.slice = &L.slice; C.ref_poc = L.ref_poc; C.col_lds = L.col;
     C.col = C.slice->tmvp ? (const MotionUnit*)(uintptr_t)C.reftab[C.slice->col_slot].mf : nullptr;
     C.cx = cx; C.cy = cy; C.avail = ci.avail; C.log2_ctb = log2_ctb; C.units_log2 = units_log2; C.lmt = P.log2_min_tb; C.ctb_w = ctb_w;
-    C.width = P.width; C.height = P.height; C.poc = P.poc; C.par_mrg = P.log2_par_mrg_level;
+    C.width = P.width; C.height = P.height; C.poc = P.poc; C.par_mrg = P.log2_par_mrg_level; C.lt_mask = P.lt_mask;
     const int x_ctb = cx << log2_ctb, y_ctb = cy << log2_ctb;
     // what the serial derivation reads goes to LDS first, with all lanes: the CTB's syntax records and unit maps, and the bottom unit rows of the
     // CTBs above (a lone lane chasing them through HBM one by one was 12 ms of a 720p picture's 60)
@@ -503,6 +512,9 @@ __global__ __launch_bounds__(64) void k_motion(MotionArgs A)
                 o.mv[1][0] = (int16_t)m.x1; o.mv[1][1] = (int16_t)m.y1; o.ref_idx[1] = (int8_t)m.r1;
                 o.poc_delta[1] = (int16_t)mk_clip3(-32768, 32767, C.poc - C.ref_poc[slot]); o.slot_pred[1] = (uint8_t)slot;
               }
+              // what later pictures' temporal candidates ask about this unit: were its reference pictures long-term ones NOW
+              if (m.r0 >= 0) o.slot_pred[1] = (uint8_t)(o.slot_pred[1] | (((C.lt_mask >> (o.slot_pred[0] & 63)) & 1) << 6));
+              if (m.r1 >= 0) o.slot_pred[1] = (uint8_t)(o.slot_pred[1] | (((C.lt_mask >> (o.slot_pred[1] & 63)) & 1) << 7));
             }
             o.slot_pred[0] = (uint8_t)(o.slot_pred[0] | (((pm & UM_SKIP) ? 2u : 1u) << 6));
             L.pu = o;

@@ -282,6 +282,7 @@ typedef struct {
   int DeltaPocS0[65][17], DeltaPocS1[65][17];
   uint8_t UsedS0[65][17], UsedS1[65][17];   /* used_by_curr_pic_s0 / s1_flag */
   int long_term_ref_pics_present_flag, num_long_term_ref_pics_sps;
+  int lt_ref_pic_poc_lsb_sps[32]; uint8_t used_by_curr_pic_lt_sps_flag[32];
   int sps_temporal_mvp_enabled_flag, strong_intra_smoothing_enabled_flag;
   int colour_primaries, transfer_characteristics, matrix_coeffs, video_full_range_flag;
   /* derived */
@@ -324,6 +325,7 @@ typedef struct {
   int mvd_l1_zero_flag, slice_temporal_mvp, collocated_from_l0, collocated_ref_idx;
   int8_t ref_list[2][16];   /* RefPicList0 / 1: indices into Dec::dpb */
   int32_t ref_poc[2][16];
+  uint8_t ref_is_lt[2][16]; /* the entry is a long-term reference picture */
   /* pred_weight_table (7.3.6.3): weighted = the explicit process applies to this slice */
   int weighted, luma_log2_wd, chroma_log2_wd;
   int16_t wp_weight[2][16][3], wp_offset[2][16][3];   /* [list][refIdx][cIdx]; offsets before the bit-depth scaling */
@@ -346,7 +348,9 @@ typedef struct {
 #define MAX_DPB 17
 typedef struct {   /* a decoded picture (after deblocking and SAO, coded size) and the motion it was predicted with (for TMVP) */
   uint16_t* plane[3]; int poc; int valid;
+  int is_lt;                     /* marked "used for long-term reference" (8.3.2) */
   uint8_t* m_pred; int16_t* mf_mv; int8_t* mf_ref; int32_t* mf_poc;
+  uint8_t* mf_lt;                /* per unit and list: the reference picture was a long-term one when this picture was decoded (8.5.3.2.9 LongTermRefPic) */
 } RefPic;
 
 struct Dec {
@@ -404,6 +408,8 @@ struct Dec {
   int first_picture;             /* no picture decoded yet in this sequence */
   int poc, prev_tid0_lsb, prev_tid0_msb;
   int st_curr_before[16], st_curr_after[16], n_st_curr_before, n_st_curr_after;   /* RefPicSetStCurrBefore / After as dpb indices */
+  int lt_curr[16], n_lt_curr;    /* RefPicSetLtCurr as dpb indices */
+  uint8_t* mf_lt;                /* per 4x4 unit and list: the unit's reference picture is a long-term one */
   uint8_t* m_pred;               /* per 4x4 unit: 0 MODE_INTRA, 1 MODE_INTER, 2 MODE_SKIP; NULL in a single intra picture */
   int16_t* mf_mv; int8_t* mf_ref; int32_t* mf_poc;   /* per 4x4 unit: mvL0, mvL1 (4 values), refIdxL0 / L1 (-1: list not used) and the POCs of
                                                         those reference pictures */
@@ -659,7 +665,8 @@ static void parse_sps(Dec* d, const uint8_t* rbsp, size_t n)
   s->long_term_ref_pics_present_flag = br_u(&b, 1);
   if (s->long_term_ref_pics_present_flag) {
     s->num_long_term_ref_pics_sps = (int)br_ue(&b);
-    for (int i = 0; i < s->num_long_term_ref_pics_sps; i++) { br_u(&b, s->log2_max_poc_lsb); br_u(&b, 1); }
+    if (s->num_long_term_ref_pics_sps > 32) fail(d, "num_long_term_ref_pics_sps out of range");
+    for (int i = 0; i < s->num_long_term_ref_pics_sps; i++) { s->lt_ref_pic_poc_lsb_sps[i] = (int)br_u(&b, s->log2_max_poc_lsb); s->used_by_curr_pic_lt_sps_flag[i] = (uint8_t)br_u(&b, 1); }
   }
   s->sps_temporal_mvp_enabled_flag = br_u(&b, 1);
   s->strong_intra_smoothing_enabled_flag = br_u(&b, 1);
@@ -813,6 +820,7 @@ static void setup_picture(Dec* d)
   if (d->seq_mode) {
     d->m_pred = (uint8_t*)xcalloc(d, mn, 1); d->mf_mv = (int16_t*)xcalloc(d, mn * 4, sizeof(int16_t));
     d->mf_ref = (int8_t*)xcalloc(d, mn * 2, 1); d->mf_poc = (int32_t*)xcalloc(d, mn * 2, sizeof(int32_t));
+    d->mf_lt = (uint8_t*)xcalloc(d, mn * 2, 1);
     memset(d->mf_ref, -1, mn * 2);
   }
   d->ctbW = s->PicWidthInCtbsY; d->ctbH = s->PicHeightInCtbsY; d->nCtb = d->ctbW * d->ctbH;
@@ -2046,15 +2054,21 @@ static void decode_slice(Dec* d, int nal_type, const uint8_t* nal, size_t nal_le
       rps.num_neg = scratch.NumNegativePics[ridx]; rps.num_pos = scratch.NumPositivePics[ridx];
       for (int i = 0; i < rps.num_neg; i++) { rps.delta_s0[i] = scratch.DeltaPocS0[ridx][i]; rps.used_s0[i] = scratch.UsedS0[ridx][i]; }
       for (int i = 0; i < rps.num_pos; i++) { rps.delta_s1[i] = scratch.DeltaPocS1[ridx][i]; rps.used_s1[i] = scratch.UsedS1[ridx][i]; }
-      if (s->long_term_ref_pics_present_flag) {
+      if (s->long_term_ref_pics_present_flag) {   /* 7.3.6.1 / 7.4.7.1: PocLsbLt, UsedByCurrPicLt, DeltaPocMsbCycleLt (7-52) */
         int num_lt_sps = 0;
         if (s->num_long_term_ref_pics_sps > 0) num_lt_sps = (int)br_ue(&b);
         int num_lt_pics = (int)br_ue(&b);
-        if (d->seq_mode && num_lt_sps + num_lt_pics > 0) fail(d, "unsupported: long-term reference pictures");
-        for (int i = 0; i < num_lt_sps + num_lt_pics; i++) {
-          if (i < num_lt_sps) { if (s->num_long_term_ref_pics_sps > 1) br_u(&b, ceil_log2(s->num_long_term_ref_pics_sps)); }
-          else { br_u(&b, s->log2_max_poc_lsb); br_u(&b, 1); }
-          if (br_u(&b, 1)) br_ue(&b);
+        if (num_lt_sps > s->num_long_term_ref_pics_sps || num_lt_sps + num_lt_pics > 32) fail(d, "num_long_term_sps / num_long_term_pics out of range");
+        rps.num_lt = num_lt_sps + num_lt_pics;
+        for (int i = 0; i < rps.num_lt; i++) {
+          if (i < num_lt_sps) {
+            int lt_idx = s->num_long_term_ref_pics_sps > 1 ? (int)br_u(&b, ceil_log2(s->num_long_term_ref_pics_sps)) : 0;
+            if (lt_idx >= s->num_long_term_ref_pics_sps) fail(d, "lt_idx_sps out of range");
+            rps.lt_poc_lsb[i] = s->lt_ref_pic_poc_lsb_sps[lt_idx]; rps.lt_used[i] = s->used_by_curr_pic_lt_sps_flag[lt_idx];
+          } else { rps.lt_poc_lsb[i] = (int)br_u(&b, s->log2_max_poc_lsb); rps.lt_used[i] = (uint8_t)br_u(&b, 1); }
+          rps.lt_msb_present[i] = (uint8_t)br_u(&b, 1);
+          int cycle = rps.lt_msb_present[i] ? (int)br_ue(&b) : 0;
+          rps.lt_msb_cycle[i] = (i == 0 || i == num_lt_sps) ? cycle : cycle + rps.lt_msb_cycle[i - 1];
         }
       }
       if (s->sps_temporal_mvp_enabled_flag) slice_temporal_mvp = br_u(&b, 1);
@@ -2074,7 +2088,7 @@ static void decode_slice(Dec* d, int nal_type, const uint8_t* nal, size_t nal_le
         if (is_b) hdr.num_ref_idx_l1_active = (int)br_ue(&b) + 1;
       }
       if (hdr.num_ref_idx_l0_active > 15 || hdr.num_ref_idx_l1_active > 15) fail(d, "num_ref_idx_lX_active_minus1 out of range");
-      int total = d->n_st_curr_before + d->n_st_curr_after, entries[2][16], modified[2] = {0, 0};
+      int total = d->n_st_curr_before + d->n_st_curr_after + d->n_lt_curr, entries[2][16], modified[2] = {0, 0};
       if (p->lists_modification_present_flag && total > 1)
         for (int X = 0; X < (is_b ? 2 : 1); X++) {
           modified[X] = br_u(&b, 1);   /* ref_pic_list_modification_flag_lX */
@@ -2503,8 +2517,8 @@ static void release_picture(Dec* d)
   free(d->m_log2_tb); free(d->m_log2_cb); free(d->m_ipm); free(d->m_ipmc); free(d->m_flags);
   free(d->m_ctdepth); free(d->m_qp); free(d->m_decoded);
   d->m_log2_tb = d->m_log2_cb = d->m_ipm = d->m_ipmc = d->m_flags = d->m_ctdepth = d->m_decoded = NULL; d->m_qp = NULL;
-  free(d->m_pred); free(d->mf_mv); free(d->mf_ref); free(d->mf_poc);
-  d->m_pred = NULL; d->mf_mv = NULL; d->mf_ref = NULL; d->mf_poc = NULL;
+  free(d->m_pred); free(d->mf_mv); free(d->mf_ref); free(d->mf_poc); free(d->mf_lt);
+  d->m_pred = NULL; d->mf_mv = NULL; d->mf_ref = NULL; d->mf_poc = NULL; d->mf_lt = NULL;
   free(d->CtbAddrRsToTs); free(d->CtbAddrTsToRs); free(d->TileId); free(d->colBd); free(d->rowBd);
   free(d->MinTbAddrZs); free(d->ctb_slice_addr); free(d->ctb_slice_idx);
   d->CtbAddrRsToTs = d->CtbAddrTsToRs = d->TileId = d->colBd = d->rowBd = d->MinTbAddrZs = d->ctb_slice_addr = d->ctb_slice_idx = NULL;
@@ -2587,7 +2601,7 @@ static void decode_access_unit(Dec* d, const uint8_t* data, size_t size, int kee
     if (slot < 0) fail(d, "decoded picture buffer is full");
     if (slot >= d->n_dpb) d->n_dpb = slot + 1;
     for (int c = 0; c < nc; c++) d->dpb[slot].plane[c] = dup_plane(d, fin[c], c ? (size_t)d->Wc * d->Hc : (size_t)d->W * d->H);
-    d->dpb[slot].poc = d->poc; d->dpb[slot].valid = 1;
+    d->dpb[slot].poc = d->poc; d->dpb[slot].valid = 1; d->dpb[slot].is_lt = 0;
     dpb_store_motion(d, &d->dpb[slot]);
   }
   if (keep_taps) {

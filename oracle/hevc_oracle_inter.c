@@ -10,9 +10,9 @@
  * the streams libheif's own x265 plugin writes for its "lowdelay" (P pictures: TMVP, weighted prediction, several reference
  * pictures) and "unrestricted" (B pictures) GOP structures (libheif/plugins/encoder_x265.cc:875-888).
  *
- * Scope (what the HIP path implements too): P and B slices, any number of short-term reference pictures, all partition modes incl.
- * AMP, skip / merge / AMVP, parallel merge level, TMVP, explicit weighted prediction, 4:0:0 and 4:2:0, 8 - 12 bit.  Refused loudly:
- * long-term reference pictures, constrained intra prediction in P / B slices, 4:2:2 / 4:4:4 inter pictures.
+ * Scope: P and B slices, short-term and long-term reference pictures (8.3.2; the motion vector rules of 8.5.3.2.7 / 8.5.3.2.9 for them), all
+ * partition modes incl. AMP, skip / merge / AMVP, parallel merge level, TMVP, explicit weighted prediction, scaling lists and constrained
+ * intra prediction in P / B pictures, 8 - 12 bit; 4:0:0 and 4:2:0 on the HIP path (this oracle also decodes 4:2:2 / 4:4:4 inter pictures).
  * PARITY: unpinned - no fixture of the reference holds inter-coded pictures; the generator's lossless round trips pin the syntax.
  */
 
@@ -21,6 +21,10 @@ typedef struct {
   int num_neg, num_pos;
   int delta_s0[17], delta_s1[17];
   uint8_t used_s0[17], used_s1[17];
+  /* long-term part of the slice header (7.3.6.1): PocLsbLt, UsedByCurrPicLt, delta_poc_msb_present_flag, DeltaPocMsbCycleLt (7-52: accumulated) */
+  int num_lt;
+  int lt_poc_lsb[33], lt_msb_cycle[33];
+  uint8_t lt_used[33], lt_msb_present[33];
 } StRps;
 
 static int dpb_find(Dec* d, int poc)
@@ -32,9 +36,9 @@ static int dpb_find(Dec* d, int poc)
 static void dpb_free_entry(RefPic* r)
 {
   for (int c = 0; c < 3; c++) { free(r->plane[c]); r->plane[c] = NULL; }
-  free(r->m_pred); free(r->mf_mv); free(r->mf_ref); free(r->mf_poc);
-  r->m_pred = NULL; r->mf_mv = NULL; r->mf_ref = NULL; r->mf_poc = NULL;
-  r->valid = 0;
+  free(r->m_pred); free(r->mf_mv); free(r->mf_ref); free(r->mf_poc); free(r->mf_lt);
+  r->m_pred = NULL; r->mf_mv = NULL; r->mf_ref = NULL; r->mf_poc = NULL; r->mf_lt = NULL;
+  r->valid = 0; r->is_lt = 0;
 }
 
 /* the motion field of the picture that has just been decoded stays with it in the DPB: the collocated picture of later slices (8.5.3.2.8) */
@@ -45,6 +49,7 @@ static void dpb_store_motion(Dec* d, RefPic* r)
   r->mf_ref = (int8_t*)xcalloc(d, mn * 2, 1); r->mf_poc = (int32_t*)xcalloc(d, mn * 2, sizeof(int32_t));
   memcpy(r->m_pred, d->m_pred, mn); memcpy(r->mf_mv, d->mf_mv, mn * 4 * sizeof(int16_t));
   memcpy(r->mf_ref, d->mf_ref, mn * 2); memcpy(r->mf_poc, d->mf_poc, mn * 2 * sizeof(int32_t));
+  r->mf_lt = (uint8_t*)xcalloc(d, mn * 2, 1); memcpy(r->mf_lt, d->mf_lt, mn * 2);
 }
 
 /* at the first slice segment of a picture: POC of the picture, then the RPS decides which pictures stay and which one(s) list 0 holds */
@@ -63,17 +68,30 @@ static void inter_begin_picture(Dec* d, int nal_type, int temporal_id, int poc_l
     if (temporal_id == 0 && (irap || (nal_type <= 5 && (nal_type & 1)))) { d->prev_tid0_lsb = poc_lsb; d->prev_tid0_msb = msb; }
   }
   d->first_picture = 0;
-  /* 8.3.2: pictures that are in no subset of the RPS are no longer "used for reference" (IDR: none is) */
-  d->n_st_curr_before = d->n_st_curr_after = 0;
+  /* 8.3.2: first the long-term subsets - a candidate is ANY reference picture of the DPB, named by its POC LSBs or, with
+     delta_poc_msb_present_flag, by its whole POC; everything in RefPicSetLtCurr / LtFoll is marked "used for long-term reference" -, then the
+     short-term subsets among the pictures that are still short-term reference pictures; pictures in no subset are no longer reference pictures */
+  d->n_st_curr_before = d->n_st_curr_after = d->n_lt_curr = 0;
   uint8_t keep[MAX_DPB]; memset(keep, 0, sizeof(keep));
   if (!idr) {
+    int MaxLsb = 1 << s->log2_max_poc_lsb;
+    for (int i = 0; i < rps->num_lt; i++) {
+      int pocLt = rps->lt_poc_lsb[i], k = -1;
+      if (rps->lt_msb_present[i]) pocLt += d->poc - rps->lt_msb_cycle[i] * MaxLsb - (d->poc & (MaxLsb - 1));
+      for (int j = 0; j < d->n_dpb && k < 0; j++)
+        if (d->dpb[j].valid && (rps->lt_msb_present[i] ? d->dpb[j].poc == pocLt : (d->dpb[j].poc & (MaxLsb - 1)) == pocLt)) k = j;
+      if (k >= 0) { keep[k] = 1; d->dpb[k].is_lt = 1; }
+      if (rps->lt_used[i]) { if (k < 0) fail(d, "long-term reference picture with POC (LSBs) %d is missing", pocLt); if (d->n_lt_curr < 16) d->lt_curr[d->n_lt_curr++] = k; }
+    }
     for (int i = 0; i < rps->num_neg; i++) {
       int k = dpb_find(d, d->poc + rps->delta_s0[i]);
+      if (k >= 0 && d->dpb[k].is_lt) k = -1;
       if (k >= 0) keep[k] = 1;
       if (rps->used_s0[i]) { if (k < 0) fail(d, "reference picture with POC %d is missing", d->poc + rps->delta_s0[i]); d->st_curr_before[d->n_st_curr_before++] = k; }
     }
     for (int i = 0; i < rps->num_pos; i++) {
       int k = dpb_find(d, d->poc + rps->delta_s1[i]);
+      if (k >= 0 && d->dpb[k].is_lt) k = -1;
       if (k >= 0) keep[k] = 1;
       if (rps->used_s1[i]) { if (k < 0) fail(d, "reference picture with POC %d is missing", d->poc + rps->delta_s1[i]); d->st_curr_after[d->n_st_curr_after++] = k; }
     }
@@ -81,11 +99,11 @@ static void inter_begin_picture(Dec* d, int nal_type, int temporal_id, int poc_l
   for (int i = 0; i < d->n_dpb; i++) if (d->dpb[i].valid && !keep[i]) dpb_free_entry(&d->dpb[i]);
 }
 
-/* 8.3.4: RefPicListTemp0 = StCurrBefore, StCurrAfter; RefPicListTemp1 = StCurrAfter, StCurrBefore (no long-term pictures here), repeated up
-   to the list size; optional list_entry_lX */
+/* 8.3.4: RefPicListTemp0 = StCurrBefore, StCurrAfter, LtCurr; RefPicListTemp1 = StCurrAfter, StCurrBefore, LtCurr, repeated up to the list
+   size; optional list_entry_lX */
 static void build_ref_list(Dec* d, SliceHdr* h, int X, const int* list_entry /* NULL: no modification */)
 {
-  int total = d->n_st_curr_before + d->n_st_curr_after;
+  int total = d->n_st_curr_before + d->n_st_curr_after + d->n_lt_curr;   /* NumPicTotalCurr */
   if (total == 0) fail(d, "P / B slice without a reference picture");
   int active = X ? h->num_ref_idx_l1_active : h->num_ref_idx_l0_active;
   int temp[32], n = 0, want = Max(active, total);
@@ -94,12 +112,14 @@ static void build_ref_list(Dec* d, SliceHdr* h, int X, const int* list_entry /* 
   while (n < want) {
     for (int i = 0; i < n_first && n < want; i++) temp[n++] = first[i];
     for (int i = 0; i < n_second && n < want; i++) temp[n++] = second[i];
+    for (int i = 0; i < d->n_lt_curr && n < want; i++) temp[n++] = d->lt_curr[i];
   }
   for (int i = 0; i < active; i++) {
     int e = list_entry ? list_entry[i] : i;
     if (e < 0 || e >= want) fail(d, "list_entry_l%d out of range", X);
     h->ref_list[X][i] = (int8_t)temp[e];
     h->ref_poc[X][i] = d->dpb[temp[e]].poc;
+    h->ref_is_lt[X][i] = (uint8_t)d->dpb[temp[e]].is_lt;
   }
 }
 
@@ -174,8 +194,11 @@ static int collocated_mv(Dec* d, const RefPic* col, int xCol, int yCol, int refI
   int mv[2] = {col->mf_mv[4 * idx + 2 * L], col->mf_mv[4 * idx + 2 * L + 1]};
   int colPocDiff = col->poc - col->mf_poc[2 * idx + L];
   int currPocDiff = d->poc - h->ref_poc[X][refIdxLX];
-  /* (all reference pictures are short-term ones here: the long-term mismatch rule never fires) */
-  if (colPocDiff != currPocDiff) {
+  /* LongTermRefPic(currPic, currPb, refIdxLX, LX) != LongTermRefPic(ColPic, colPb, refIdxCol, listCol): no candidate; a long-term target takes the
+     collocated vector as it is (the flag of the collocated block is the marking its reference had when ColPic was decoded) */
+  int colLt = col->mf_lt ? col->mf_lt[2 * idx + L] : 0, curLt = h->ref_is_lt[X][refIdxLX];
+  if (colLt != curLt) return 0;
+  if (!curLt && colPocDiff != currPocDiff) {
     if (colPocDiff == 0) return 0;   /* cannot happen in a conforming stream (a picture never references itself) */
     scale_mv(mv, colPocDiff, currPocDiff);
   }
@@ -293,15 +316,17 @@ static int nb_mv_same_poc(Dec* d, int x, int y, int X, int tgtPoc, int* mv)
   }
   return 0;
 }
-static int nb_mv_scaled(Dec* d, int x, int y, int X, int tgtPoc, int* mv)
+static int nb_mv_scaled(Dec* d, int x, int y, int X, int tgtPoc, int tgtLt, int* mv)
 {
   int idx = (y >> 2) * d->mw + (x >> 2);
   for (int k = 0; k < 2; k++) {
     int L = k ? 1 - X : X;
-    if (d->mf_ref[2 * idx + L] >= 0) {
+    /* 8.5.3.2.7 (7): the neighbour's vector counts when its reference picture and the target are both long-term or both short-term pictures;
+       it is scaled only between short-term pictures */
+    if (d->mf_ref[2 * idx + L] >= 0 && d->mf_lt[2 * idx + L] == tgtLt) {
       mv[0] = d->mf_mv[4 * idx + 2 * L]; mv[1] = d->mf_mv[4 * idx + 2 * L + 1];
       int nbPoc = d->mf_poc[2 * idx + L];
-      if (nbPoc != tgtPoc) scale_mv(mv, d->poc - nbPoc, d->poc - tgtPoc);
+      if (!tgtLt && nbPoc != tgtPoc) scale_mv(mv, d->poc - nbPoc, d->poc - tgtPoc);
       return 1;
     }
   }
@@ -311,14 +336,14 @@ static int nb_mv_scaled(Dec* d, int x, int y, int X, int tgtPoc, int* mv)
 static void derive_mvp(Dec* d, const PbGeom* g, int X, int refIdx, int mvp_flag, int* mvp)
 {
   int xPb = g->xPb, yPb = g->yPb, nPbW = g->nPbW, nPbH = g->nPbH;
-  int tgtPoc = d->sh->ref_poc[X][refIdx];
+  int tgtPoc = d->sh->ref_poc[X][refIdx], tgtLt = d->sh->ref_is_lt[X][refIdx];
   int xA[2] = {xPb - 1, xPb - 1}, yA[2] = {yPb + nPbH, yPb + nPbH - 1};
   int avA[2];
   for (int k = 0; k < 2; k++) avA[k] = pb_available(d, g, xA[k], yA[k]);
   int isScaled = avA[0] || avA[1];
   int flagA = 0, mvA[2] = {0, 0};
   for (int k = 0; k < 2 && !flagA; k++) if (avA[k]) flagA = nb_mv_same_poc(d, xA[k], yA[k], X, tgtPoc, mvA);
-  for (int k = 0; k < 2 && !flagA; k++) if (avA[k]) flagA = nb_mv_scaled(d, xA[k], yA[k], X, tgtPoc, mvA);
+  for (int k = 0; k < 2 && !flagA; k++) if (avA[k]) flagA = nb_mv_scaled(d, xA[k], yA[k], X, tgtPoc, tgtLt, mvA);
   int xB[3] = {xPb + nPbW, xPb + nPbW - 1, xPb - 1}, yB[3] = {yPb - 1, yPb - 1, yPb - 1};
   int avB[3];
   for (int k = 0; k < 3; k++) avB[k] = pb_available(d, g, xB[k], yB[k]);
@@ -327,7 +352,7 @@ static void derive_mvp(Dec* d, const PbGeom* g, int X, int refIdx, int mvp_flag,
   if (!isScaled && flagB) { flagA = 1; mvA[0] = mvB[0]; mvA[1] = mvB[1]; }
   if (!isScaled) {
     flagB = 0;
-    for (int k = 0; k < 3 && !flagB; k++) if (avB[k]) flagB = nb_mv_scaled(d, xB[k], yB[k], X, tgtPoc, mvB);
+    for (int k = 0; k < 3 && !flagB; k++) if (avB[k]) flagB = nb_mv_scaled(d, xB[k], yB[k], X, tgtPoc, tgtLt, mvB);
   }
   int list[3][2], n = 0;
   if (flagA) { list[n][0] = mvA[0]; list[n][1] = mvA[1]; n++; }
@@ -446,6 +471,7 @@ static void store_motion(Dec* d, int xPb, int yPb, int nPbW, int nPbH, const Mot
         d->mf_mv[4 * idx + 2 * X] = (int16_t)(used ? m->mv[X][0] : 0); d->mf_mv[4 * idx + 2 * X + 1] = (int16_t)(used ? m->mv[X][1] : 0);
         d->mf_ref[2 * idx + X] = (int8_t)(used ? m->ref_idx[X] : -1);
         d->mf_poc[2 * idx + X] = used ? d->sh->ref_poc[X][m->ref_idx[X]] : 0;
+        d->mf_lt[2 * idx + X] = (uint8_t)(used ? d->sh->ref_is_lt[X][m->ref_idx[X]] : 0);
       }
     }
 }

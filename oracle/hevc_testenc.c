@@ -170,6 +170,7 @@ typedef struct {
   int poc, slice_type /* 2 I, 1 P, 0 B */, nal_type;
   int n_neg, n_pos, neg_poc[16], pos_poc[16];
   uint8_t neg_used[16], pos_used[16];
+  int n_lt, lt_poc[4];                      /* long-term reference pictures (hevc_testenc_params::long_term_ref): always used by the picture */
 } PicPlan;
 
 static uint32_t rnd(Enc* e)
@@ -1165,7 +1166,18 @@ static void enc_parameter_sets(Enc* e, Bytes* pstream)
     bw_u(&w, s->pcm_loop_filter_disabled_flag, 1);
   }
   s->sps_temporal_mvp_enabled_flag = d->seq_mode && prm->temporal_mvp ? 1 : 0;
-  bw_ue(&w, 0); bw_u(&w, 0, 1); bw_u(&w, s->sps_temporal_mvp_enabled_flag, 1); bw_u(&w, s->strong_intra_smoothing_enabled_flag, 1);
+  bw_ue(&w, 0);                                   /* num_short_term_ref_pic_sets */
+  s->long_term_ref_pics_present_flag = d->seq_mode && prm->long_term_ref ? 1 : 0;
+  s->num_long_term_ref_pics_sps = prm->long_term_ref == 3 ? 2 : 0;   /* two candidates in the SPS: LSBs 5 (never used) and 0 (the IDR picture) */
+  bw_u(&w, s->long_term_ref_pics_present_flag, 1);
+  if (s->long_term_ref_pics_present_flag) {
+    bw_ue(&w, s->num_long_term_ref_pics_sps);
+    for (int i = 0; i < s->num_long_term_ref_pics_sps; i++) {
+      s->lt_ref_pic_poc_lsb_sps[i] = i == 0 ? 5 : 0; s->used_by_curr_pic_lt_sps_flag[i] = 1;
+      bw_u(&w, s->lt_ref_pic_poc_lsb_sps[i], s->log2_max_poc_lsb); bw_u(&w, 1, 1);
+    }
+  }
+  bw_u(&w, s->sps_temporal_mvp_enabled_flag, 1); bw_u(&w, s->strong_intra_smoothing_enabled_flag, 1);
   if (prm->vui_matrix >= 0) {
     s->colour_primaries = prm->vui_primaries; s->transfer_characteristics = prm->vui_transfer;
     s->matrix_coeffs = prm->vui_matrix; s->video_full_range_flag = prm->vui_full_range;
@@ -1225,6 +1237,14 @@ static void enc_picture(Enc* e, const uint16_t* const planes[3], const PicPlan* 
   rps.num_neg = plan->n_neg; rps.num_pos = plan->n_pos;
   for (int i = 0; i < plan->n_neg; i++) { rps.delta_s0[i] = plan->neg_poc[i] - plan->poc; rps.used_s0[i] = plan->neg_used[i]; }
   for (int i = 0; i < plan->n_pos; i++) { rps.delta_s1[i] = plan->pos_poc[i] - plan->poc; rps.used_s1[i] = plan->pos_used[i]; }
+  rps.num_lt = plan->n_lt;
+  for (int i = 0; i < plan->n_lt; i++) {
+    const int MaxLsb = 1 << s->log2_max_poc_lsb;
+    rps.lt_poc_lsb[i] = plan->lt_poc[i] & (MaxLsb - 1); rps.lt_used[i] = 1;
+    rps.lt_msb_present[i] = prm->long_term_ref == 2;
+    /* pocLt = PocLsbLt + PicOrderCntVal - DeltaPocMsbCycleLt * MaxLsb - (PicOrderCntVal & (MaxLsb - 1))  (8.3.2) */
+    rps.lt_msb_cycle[i] = ((frame_idx - (frame_idx & (MaxLsb - 1))) - (plan->lt_poc[i] - rps.lt_poc_lsb[i])) / MaxLsb;
+  }
   if (d->seq_mode) inter_begin_picture(d, nal_type, 0, frame_idx & 255, &rps);
   for (int c = 0; c < (s->chroma_format_idc ? 3 : 1); c++) {
     int W = c ? d->Wc : d->W, H = c ? d->Hc : d->H;
@@ -1292,7 +1312,7 @@ static void enc_picture(Enc* e, const uint16_t* const planes[3], const PicPlan* 
     hdr.slice_segment_address = d->CtbAddrTsToRs[slice_start[si]];
     hdr.slice_type = plan->slice_type;
     if (is_p) {
-      int total = d->n_st_curr_before + d->n_st_curr_after;
+      int total = d->n_st_curr_before + d->n_st_curr_after + d->n_lt_curr;
       hdr.num_ref_idx_l0_active = (si & 1) ? Min(15, total + 1) : total;   /* one more than there are pictures: the list wraps around (8.3.4) */
       if (is_b) hdr.num_ref_idx_l1_active = (si & 1) ? total : Min(15, total + 1);
       hdr.max_num_merge_cand = prm->max_merge_cand >= 1 && prm->max_merge_cand <= 5 ? prm->max_merge_cand : 5;
@@ -1315,7 +1335,7 @@ static void enc_picture(Enc* e, const uint16_t* const planes[3], const PicPlan* 
     hdr.SliceQpY = 26 + p->init_qp_minus26 + hdr.slice_qp_delta;
     if (d->nslices == d->capslices) { d->capslices = d->capslices ? d->capslices * 2 : 8; d->slices = (SliceHdr*)realloc(d->slices, sizeof(SliceHdr) * d->capslices); }
     if (is_p) {
-      int total = d->n_st_curr_before + d->n_st_curr_after;
+      int total = d->n_st_curr_before + d->n_st_curr_after + d->n_lt_curr;
       for (int X = 0; X < (is_b ? 2 : 1); X++) {
         list_mod[X] = p->lists_modification_present_flag && total > 1 && ((si + frame_idx + X) % 3 != 0);
         for (int i = 0; i < (X ? hdr.num_ref_idx_l1_active : hdr.num_ref_idx_l0_active); i++) list_entries[X][i] = (int)(rnd(e) % (unsigned)total);
@@ -1446,13 +1466,25 @@ static void enc_picture(Enc* e, const uint16_t* const planes[3], const PicPlan* 
         bw_ue(&w, rps.num_neg); bw_ue(&w, rps.num_pos);
         for (int i = 0, prev = 0; i < rps.num_neg; i++) { bw_ue(&w, prev - rps.delta_s0[i] - 1); bw_u(&w, rps.used_s0[i], 1); prev = rps.delta_s0[i]; }
         for (int i = 0, prev = 0; i < rps.num_pos; i++) { bw_ue(&w, rps.delta_s1[i] - prev - 1); bw_u(&w, rps.used_s1[i], 1); prev = rps.delta_s1[i]; }
+        if (s->long_term_ref_pics_present_flag) {   /* 7.3.6.1: the long-term pictures of the RPS */
+          const int from_sps = s->num_long_term_ref_pics_sps > 0 ? rps.num_lt : 0;   /* mode 3: every entry names a candidate of the SPS */
+          if (s->num_long_term_ref_pics_sps > 0) bw_ue(&w, from_sps);
+          bw_ue(&w, rps.num_lt - from_sps);
+          for (int i = 0, prev_cycle = 0; i < rps.num_lt; i++) {
+            if (i < from_sps) { if (s->num_long_term_ref_pics_sps > 1) bw_u(&w, 1, ceil_log2(s->num_long_term_ref_pics_sps)); }   /* candidate 1: LSBs 0 */
+            else { bw_u(&w, rps.lt_poc_lsb[i], s->log2_max_poc_lsb); bw_u(&w, rps.lt_used[i], 1); }
+            bw_u(&w, rps.lt_msb_present[i], 1);
+            if (rps.lt_msb_present[i]) bw_ue(&w, rps.lt_msb_cycle[i] - ((i == 0 || i == from_sps) ? 0 : prev_cycle));
+            prev_cycle = rps.lt_msb_cycle[i];
+          }
+        }
         if (s->sps_temporal_mvp_enabled_flag) bw_u(&w, hdr.slice_temporal_mvp, 1);
       }
       if (s->sao_enabled_flag) { bw_u(&w, hdr.slice_sao_luma_flag, 1); if (s->chroma_format_idc) bw_u(&w, hdr.slice_sao_chroma_flag, 1); }
       if (is_p) {
         bw_u(&w, 1, 1); bw_ue(&w, hdr.num_ref_idx_l0_active - 1);                               /* num_ref_idx_active_override_flag */
         if (is_b) bw_ue(&w, hdr.num_ref_idx_l1_active - 1);
-        int total = d->n_st_curr_before + d->n_st_curr_after;
+        int total = d->n_st_curr_before + d->n_st_curr_after + d->n_lt_curr;
         if (p->lists_modification_present_flag && total > 1)
           for (int X = 0; X < (is_b ? 2 : 1); X++) {
             bw_u(&w, list_mod[X], 1);
@@ -1576,6 +1608,12 @@ static int enc_run(const hevc_testenc_params* prm, int n_frames, const uint16_t*
       }
       int take = Min(npa, nrefs);
       for (int i = 0; i < take; i++) { P->neg_poc[P->n_neg] = prev_anchors[i]; P->neg_used[P->n_neg++] = !(take >= 3 && i == take - 1); }
+      if (prm->long_term_ref) {   /* the IDR picture (POC 0): a long-term reference picture of every later picture, never a short-term one */
+        int m = 0;
+        for (int i = 0; i < P->n_neg; i++) if (P->neg_poc[i] != 0) { P->neg_poc[m] = P->neg_poc[i]; P->neg_used[m++] = P->neg_used[i]; }
+        P->n_neg = m;
+        P->lt_poc[0] = 0; P->n_lt = 1;
+      }
     }
     for (int k = 1; k < n_frames; k++) {   /* keep what later pictures need */
       PicPlan* P = &plan[k];
@@ -1586,7 +1624,7 @@ static int enc_run(const hevc_testenc_params* prm, int n_frames, const uint16_t*
           for (int q = 0; q < k; q++) if (plan[q].poc == poc) decoded = 1;
           for (int q = 0; q < P->n_neg; q++) if (P->neg_poc[q] == poc) have = 1;
           for (int q = 0; q < P->n_pos; q++) if (P->pos_poc[q] == poc) have = 1;
-          if (!decoded || have || poc == P->poc) continue;
+          if (!decoded || have || poc == P->poc || (prm->long_term_ref && poc == 0)) continue;
           if (poc < P->poc) { if (P->n_neg < 16) { P->neg_poc[P->n_neg] = poc; P->neg_used[P->n_neg++] = 0; } }
           else if (P->n_pos < 16) { P->pos_poc[P->n_pos] = poc; P->pos_used[P->n_pos++] = 0; }
         }

@@ -43,6 +43,8 @@ typedef struct hevc_testenc_params {
   int weighted_pred;            /* weighted_pred_flag / weighted_bipred_flag with a random pred_weight_table per slice                     */
   int mvd_l1_zero;              /* mvd_l1_zero_flag in B slices                                                                            */
   int constrained_intra_pred;   /* constrained_intra_pred_flag: intra blocks of P / B pictures predict from intra coded neighbours only    */
+  int long_term_ref;            /* > 0: the IDR picture stays in the DPB as a LONG-TERM reference picture of every later picture (behind the short-term
+                                   ones in both lists): 1 coded in the slice header by its POC LSBs, 2 with delta_poc_msb_present_flag, 3 as a candidate of the SPS */
 } hevc_testenc_params;
 
 /* planes: tightly packed uint16 samples at display size (chroma (w+1)/2 x (h+1)/2).

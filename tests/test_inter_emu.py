@@ -300,3 +300,18 @@ def test_emulated_constrained_intra_pred_in_p_b_pictures(kw):
     check_sequence(aus, "constrained_intra_pred, chain", chain=4)
     # the flag matters in these streams: the same pictures coded without it give another bitstream (another prediction for the intra blocks)
     assert aus != orc.encode_sequence(make_frames(136, 104, 5), qp=24, global_mv_x=-8, global_mv_y=-4, constrained_intra_pred=0, inter_intra_pct=45, inter_skip_pct=10, **kw)
+
+
+@pytest.mark.parametrize("lt", [1, 2, 3], ids=["slice_lsb", "slice_msb_present", "sps_candidate"])
+@pytest.mark.parametrize("kw", [dict(), dict(b_frames=2, b_ref=1, temporal_mvp=1, inter_num_refs=2),
+                                dict(temporal_mvp=1, inter_num_refs=3, lists_modification=1, weighted_pred=1, amp=1)], ids=["p", "b_tmvp", "p_multiref_listmod_weighted"])
+def test_emulated_long_term_reference_pictures(lt, kw):
+    """Long-term reference pictures (missing 4): the IDR picture stays in the DPB as a long-term reference of every later picture, named
+    in the slice header by its POC LSBs, by LSBs + delta_poc_msb_cycle_lt, or through a candidate of the SPS (7.3.6.1, 8.3.2); it sits behind the
+    short-term pictures in both lists (8.3.4); a motion vector is only predicted between two long-term or two short-term references and never
+    scaled towards a long-term one (8.5.3.2.7), the collocated candidate compares the marking its block's reference had when ITS picture was decoded
+    (8.5.3.2.9: two bits per unit of the stored motion field)"""
+    frames = make_frames(136, 104, 7)
+    aus = orc.encode_sequence(frames, qp=26, global_mv_x=-8, global_mv_y=-4, long_term_ref=lt, **kw)
+    check_sequence(aus, "long_term_ref=%d %r" % (lt, kw))
+    check_sequence(aus, "long_term_ref=%d %r, chain" % (lt, kw), chain=4)

@@ -207,3 +207,16 @@ def test_lossless_round_trip_with_constrained_intra_pred(cip):
         for c in range(3):
             np.testing.assert_array_equal(p["planes"][c], frames[i][c], err_msg="picture %d component %d" % (i, c))
     assert all(0.1 < (p["map_pred"] == 0).mean() < 0.9 for p in pics[1:])      # intra and inter units side by side
+
+
+@pytest.mark.parametrize("lt", [1, 2, 3])
+def test_lossless_round_trip_with_a_long_term_reference_picture(lt):
+    """oracle + generator agree on the long-term syntax (slice header by LSBs / with the MSB cycle / SPS candidate), the RPS derivation and the lists"""
+    frames = make_frames(136, 104, 7)
+    for kw in (dict(), dict(b_frames=2, b_ref=1, temporal_mvp=1, inter_num_refs=2), dict(temporal_mvp=1, inter_num_refs=3, lists_modification=1, weighted_pred=1)):
+        aus = orc.encode_sequence(frames, qp=30, global_mv_x=-8, global_mv_y=-4, lossless_pct=100, inter_skip_pct=0, long_term_ref=lt, **kw)
+        pics = sorted(orc.decode_sequence(aus), key=lambda p: p["poc"])
+        for i, p in enumerate(pics):
+            for c in range(3):
+                np.testing.assert_array_equal(p["planes"][c], frames[i][c], err_msg="%r picture %d component %d" % (kw, i, c))
+        assert aus != orc.encode_sequence(frames, qp=30, global_mv_x=-8, global_mv_y=-4, lossless_pct=100, inter_skip_pct=0, long_term_ref=0, **kw)

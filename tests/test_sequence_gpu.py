@@ -266,6 +266,8 @@ B_CASES = {
     "b_scaling_lists_sps": dict(b_frames=1, temporal_mvp=1, scaling_list=2, inter_intra_pct=30),      # inter matrices (matrixId 3 .. 5) beside the intra ones
     "p_scaling_lists_default": dict(scaling_list=1, inter_num_refs=2, inter_intra_pct=30),
     "b_constrained_intra_pred": dict(b_frames=1, temporal_mvp=1, constrained_intra_pred=1, inter_intra_pct=45, log2_ctb=4, log2_max_tb=4),
+    "b_long_term_ref": dict(b_frames=2, b_ref=1, temporal_mvp=1, inter_num_refs=2, long_term_ref=1),
+    "p_long_term_ref_sps_listmod": dict(temporal_mvp=1, inter_num_refs=3, lists_modification=1, weighted_pred=1, long_term_ref=3),
 }
 
 
