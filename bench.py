@@ -234,7 +234,7 @@ def issue_roofline(kernels, px, cu_count, clock_ghz):
     return out
 
 
-def sequence_tracks(n_frames=13, tracks=16, w=1280, h=720):
+def sequence_tracks(n_frames=33, tracks=16, w=1280, h=720):
     """sequence tracks through the decoder object the way libheif drives it (one sample per push_data2, pictures polled in output order,
     flush at the end): frames per second of ONE track - every picture is one CABAC critical path, the instance holds one sample at a time - and of
     `tracks` tracks decoded side by side by as many threads (their decodes coalesce into shared launch sets).  The first pass of each kind checks
@@ -247,7 +247,14 @@ def sequence_tracks(n_frames=13, tracks=16, w=1280, h=720):
     frames = [[np.roll(np.roll(p, k // (1 if i == 0 else 2), 0), 2 * k // (1 if i == 0 else 2), 1) for i, p in enumerate(f0)] for k in range(n_frames)]
     kinds = {"lowdelay_ippp_2refs_tmvp_weighted": dict(inter_num_refs=2, temporal_mvp=1, weighted_pred=1),
              "unrestricted_ibbp_tmvp": dict(b_frames=2, inter_num_refs=2, temporal_mvp=1)}
-    res = {"pictures_per_track": n_frames, "size": "%dx%d" % (w, h), "tracks_side_by_side": tracks}
+    import libheif_amd
+    lib = libheif_amd.load_library()
+    lib.hipdec_set_sequence_lookahead.argtypes = [__import__("ctypes").c_int]
+    lib.hipdec_set_sequence_lookahead.restype = None
+    default_lookahead = int(os.environ.get("HIPDEC_SEQ_LOOKAHEAD", "16"))
+    res = {"pictures_per_track": n_frames, "size": "%dx%d" % (w, h), "tracks_side_by_side": tracks, "lookahead_samples": default_lookahead,
+           "lookahead": "behind a track's first picture the decoder gathers this many samples (libheif pushes the next one whenever decode_next_image2 returns no image) "
+                        "and decodes them as ONE launch set: one CABAC launch over all of them, pixel stages picture by picture (hipdec_set_sequence_lookahead)"}
     for name, kw in kinds.items():
         aus = orc.encode_sequence(frames, qp=27, global_mv_x=-8, global_mv_y=-4, inter_skip_pct=30, **kw)
         ref = {r["poc"]: r for r in orc.decode_sequence(aus)}
@@ -279,6 +286,9 @@ def sequence_tracks(n_frames=13, tracks=16, w=1280, h=720):
         many = time.perf_counter() - t0
         res[name] = {"one_track_fps": round(n_frames / one, 1), "ms_per_picture": round(one / n_frames * 1e3, 1), "all_tracks_fps": round(tracks * n_frames / many, 1),
                      "kbytes_per_picture": round(sum(len(a) for a in aus) / len(aus) / 1e3, 1), "verified_against_oracle": True}
+        lib.hipdec_set_sequence_lookahead(0)          # round 4's behaviour beside it: every sample decoded at the poll behind its push
+        t0 = time.perf_counter(); play(False); res[name]["one_track_fps_without_lookahead"] = round(n_frames / (time.perf_counter() - t0), 1)
+        lib.hipdec_set_sequence_lookahead(default_lookahead)
     return res
 
 

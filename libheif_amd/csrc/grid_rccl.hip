@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <vector>
 
 using namespace hipdec;
@@ -72,6 +73,15 @@ int need_rccl()
   return 0;
 }
 
+// ncclGroupStart / ncclGroupEnd as a scope: an error return between them still closes the group, so that the peers - which are inside the same
+// collective - are not left waiting for this rank's half of it
+struct RcclGroup {
+  bool open = false;
+  ncclResult_t start() { const ncclResult_t r = rccl().GroupStart(); open = r == ncclSuccess; return r; }
+  ncclResult_t end() { open = false; return rccl().GroupEnd(); }
+  ~RcclGroup() { if (open) (void)rccl().GroupEnd(); }
+};
+
 #define HIPDEC_CHECK_NCCL(expr)                                                                                 \
   do {                                                                                                          \
     ncclResult_t _r = (expr);                                                                                   \
@@ -97,6 +107,8 @@ struct hipdec_grid_rccl {
   size_t off[3] = {0, 0, 0}, stride[3] = {0, 0, 0};
   hipdec_image_info info{};                  // of this rank's first tile (rank 0: tile 0, the canvas' colour description)
   bool decoded = false;
+  bool status_known = false; int status_rc = 0; std::string status_msg;   // wait()'s result for the last decode (the exchange runs once per decode)
+  int queue_rc = 0;                          // this rank could not queue its shard's decode (its tiles are undefined): reported to every rank by wait()
   ~hipdec_grid_rccl()
   {
     DeviceScope scope(device);
@@ -193,10 +205,13 @@ int hipdec_grid_create_rccl(hipdec_grid_rccl** out, void* comm, int rank, int nr
       for (int k = 0; k < 5; k++) { h[k] = g->mine.empty() ? INT64_MIN : geo[k]; h[6 + k] = g->mine.empty() ? INT64_MAX : geo[k]; }
       h[5] = local_rc ? 1 : 0; h[11] = 0;
       HIPDEC_CHECK_HIP(hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, g->stream));
-      HIPDEC_CHECK_NCCL(rccl().GroupStart());
-      HIPDEC_CHECK_NCCL(rccl().AllReduce(d, d, 6, ncclInt64, ncclMax, g->comm, g->stream));
-      HIPDEC_CHECK_NCCL(rccl().AllReduce(d + 6, d + 6, 6, ncclInt64, ncclMin, g->comm, g->stream));
-      HIPDEC_CHECK_NCCL(rccl().GroupEnd());
+      {
+        RcclGroup grp;
+        HIPDEC_CHECK_NCCL(grp.start());
+        HIPDEC_CHECK_NCCL(rccl().AllReduce(d, d, 6, ncclInt64, ncclMax, g->comm, g->stream));
+        HIPDEC_CHECK_NCCL(rccl().AllReduce(d + 6, d + 6, 6, ncclInt64, ncclMin, g->comm, g->stream));
+        HIPDEC_CHECK_NCCL(grp.end());
+      }
       HIPDEC_CHECK_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, g->stream));
       HIPDEC_CHECK_HIP(hipStreamSynchronize(g->stream));
       if (local_rc) return local_rc;
@@ -267,7 +282,8 @@ int hipdec_grid_rccl_decode(hipdec_grid_rccl* g)
     }
     const int n_tiles = g->rows * g->cols;
     if (g->nranks > 1) {
-      HIPDEC_CHECK_NCCL(rccl().GroupStart());
+      RcclGroup grp;
+      HIPDEC_CHECK_NCCL(grp.start());
       if (g->rank != 0) {
         if (!g->mine.empty()) HIPDEC_CHECK_NCCL(rccl().Send(g->send, g->tile_bytes * g->mine.size(), ncclUint8, 0, g->comm, g->stream));
       } else {
@@ -276,8 +292,9 @@ int hipdec_grid_rccl_decode(hipdec_grid_rccl* g)
           HIPDEC_CHECK_NCCL(rccl().Recv(g->recv + g->recv_off[(size_t)p], n_p * g->tile_bytes, ncclUint8, p, g->comm, g->stream));
         }
       }
-      HIPDEC_CHECK_NCCL(rccl().GroupEnd());
+      HIPDEC_CHECK_NCCL(grp.end());
     }
+    g->queue_rc = rc; g->status_known = false;
     if (rc) return rc;
     if (g->rank == 0) {
       if (g->batch) (void)batch_follow_stream(g->batch, g->stream);   // (with stage overlap the pixel stages ran on the post stream)
@@ -311,8 +328,28 @@ int hipdec_grid_rccl_wait(hipdec_grid_rccl* g)
   if (!g || !g->decoded) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_rccl_wait: nothing was decoded");
   DeviceScope scope(g->device);
   HIPDEC_CHECK_HIP(hipStreamSynchronize(g->stream));
-  if (g->batch) if (int rc = hipdec_batch_status(g->batch)) return rc;   // device-side decode errors of this rank's shard
-  return 0;
+  if (g->status_known) return g->status_rc ? set_error(g->status_rc, "%s", g->status_msg.c_str()) : 0;   // (rank 0 waits again inside to_rgb / read_plane)
+  auto done = [&](int rc, const std::string& msg) { g->status_known = true; g->status_rc = rc; g->status_msg = msg; return rc ? set_error(rc, "%s", msg.c_str()) : 0; };
+  int local = g->queue_rc;
+  if (!local && g->batch) local = hipdec_batch_status(g->batch);   // device-side decode errors of this rank's shard
+  const std::string local_msg = local ? hipdec_last_error() : "";
+  // Every rank learns whether EVERY shard decoded (one 8-byte all-reduce): rank 0 has pasted whatever the peers sent, and must not hand out a canvas
+  // with the undefined tiles of a rank whose shard failed.  All ranks call wait(), so the collective is matched.
+  if (g->nranks > 1) {
+    int64_t* d = nullptr;
+    size_t cap = 0;
+    HIPDEC_CHECK_HIP(arena_acquire((void**)&d, 256, &cap));
+    struct Rel { void* p; size_t c; ~Rel() { arena_release(p, c); } } rel{d, cap};
+    int64_t h = local ? 1 + g->rank : 0;
+    HIPDEC_CHECK_HIP(hipMemcpyAsync(d, &h, sizeof(h), hipMemcpyHostToDevice, g->stream));
+    HIPDEC_CHECK_NCCL(rccl().AllReduce(d, d, 1, ncclInt64, ncclMax, g->comm, g->stream));
+    HIPDEC_CHECK_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, g->stream));
+    HIPDEC_CHECK_HIP(hipStreamSynchronize(g->stream));
+    if (local) return done(local, local_msg);
+    if (h) return done(HIPDEC_ERR_BITSTREAM, "grid_rccl_wait: the shard of rank " + std::to_string((int)h - 1) + " failed to decode: the canvas is incomplete");
+    return done(0, "");
+  }
+  return done(local, local_msg);
 }
 
 int hipdec_grid_rccl_canvas_plane(hipdec_grid_rccl* g, int c, const void** dptr, size_t* stride)

@@ -34,7 +34,7 @@ f = {k: round(2.0 * v, 4) for k, v in f_raw.items()}
 import subprocess
 try: commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
 except Exception: commit = os.environ.get("HIPDEC_COMMIT", "?")
-doc = {"commit": commit, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof_hbm_traffic.sh) over `bench.py --only-main --steps 1 --warmup 0 " + " ".join(sys.argv[1:]) + "` on MI355X; counter unit KiB; FETCH_SIZE DOUBLED (calibrated: profiles/r05_fetch_calibration.txt), WRITE_SIZE as reported (d here (the guide's x2 applies to 16-B-per-lane streaming reads)",
+doc = {"commit": commit, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/prof_hbm_traffic.sh) over `bench.py --only-main --steps 1 --warmup 0 " + " ".join(sys.argv[1:]) + "` on MI355X; counter unit KiB; FETCH_SIZE DOUBLED (calibrated: profiles/r05_fetch_calibration.txt), WRITE_SIZE as reported",
        "workload": "still4k", "qp": 27, "stills_per_step": bench["config"]["stills_per_step_per_gpu"],
        "fetch_bytes_per_px": f, "fetch_size_counter_bytes_per_px": f_raw, "write_bytes_per_px": w, "bytes_per_px": {k: round(f[k] + w[k], 4) for k in f}}
 json.dump(doc, open(os.path.join(root, "gpurun_out", "pmc_traffic.json"), "w"), indent=1)
