@@ -773,8 +773,6 @@ int hipdec_probe(const void* data, size_t size, uint64_t max_image_size_pixels, 
 // A host that decodes serially never waits: the window only opens when other instances exist that have not decoded
 // yet, or when overlapping requests were seen a moment ago.
 struct hipdec_decoder {
-  std::vector<uint8_t> data;
-  std::vector<uint8_t> param_sets;       // VPS / SPS / PPS NAL units of the picture decoded last (framed): samples of an image sequence carry them once
   int strict = 0;
   uint64_t max_pixels = 0;
   std::shared_ptr<hipdec_batch> batch;   // shared with the other instances decoded in the same launch
@@ -795,18 +793,11 @@ struct hipdec_decoder {
   std::vector<Output> waiting;
   Output out;
   uint64_t cvs = 0;                      // coded video sequence counter (a new one starts at every IDR / first IRAP)
-  uintptr_t pending_user_data = 0;       // of the sample pushed last (decoder_libde265.cc:360, :417-419)
   // ---- look-ahead: the samples behind the first picture wait here (one access unit each, the parameter sets known at its push in front) until
   //      HIPDEC_SEQ_LOOKAHEAD of them are there or the host flushes; they are then decoded as ONE chain (batch_layout.h): one CABAC launch over all of
   //      them - parsing needs nothing of another picture - and the pixel stages picture by picture.  libheif's track loop pushes the next sample
   //      whenever decode_next_image2 returns no image (sequences/track_visual.cc:200-260), so holding samples back costs it nothing.
-  struct Sample { std::vector<uint8_t> blob; uintptr_t user_data = 0; bool has_vcl = false; };
-  std::deque<Sample> queue;
-  bool first_has_vcl = false, first_closed = false;   // the access unit in `data` (the first picture): holds a slice / is complete (a later access unit was pushed)
-  size_t last_push_first = 0;            // queue index of the first sample the last push touched (set_user_data names them)
-  bool last_push_touched_first = false;
-  uintptr_t first_user_data = 0;
-  bool last_open = false;                // the newest queued sample may still be continued by the next push
+  SampleQueue sq;                        // (hevc_headers.h: pure host logic, tested and fuzzed on the CPU)
   hipdec_batch* plane_batch() const { return out.batch ? out.batch.get() : batch.get(); }
   int plane_item() const { return out.batch ? out.item : item; }
   ~hipdec_decoder()
@@ -973,8 +964,8 @@ int run_decoder_batch(hipdec_batch* b, hipStream_t s)
 void run_single(DecodeRequest& r, hipStream_t s)
 {
   hipdec_decoder* d = r.d;
-  const void* ptrs[1] = {d->data.data()};
-  const size_t sizes[1] = {d->data.size()};
+  const void* ptrs[1] = {d->sq.first.data()};
+  const size_t sizes[1] = {d->sq.first.size()};
   hipdec_batch* b = nullptr;
   const SeqContext* seqs[1] = {d->seq_active ? &d->seq : nullptr};
   r.rc = create_batch_seq(&b, 1, ptrs, sizes, d->max_pixels, seqs);
@@ -1000,7 +991,7 @@ void run_group(std::vector<DecodeRequest*>& group, hipStream_t s, uint32_t wave_
   std::vector<const void*> ptrs;
   std::vector<size_t> sizes;
   std::vector<const SeqContext*> seqs;
-  for (auto* r : group) { ptrs.push_back(r->d->data.data()); sizes.push_back(r->d->data.size()); seqs.push_back(r->d->seq_active ? &r->d->seq : nullptr); }
+  for (auto* r : group) { ptrs.push_back(r->d->sq.first.data()); sizes.push_back(r->d->sq.first.size()); seqs.push_back(r->d->seq_active ? &r->d->seq : nullptr); }
   hipdec_batch* b = nullptr;
   static const bool trace = getenv("HIPDEC_COALESCE_TRACE") != nullptr;   // dev knob: where a launch set's wall time goes
   const auto t0 = Clock::now();
@@ -1110,58 +1101,9 @@ int hipdec_decoder_push_data(hipdec_decoder* d, const void* data, size_t size)
       // the first picture was decoded and more data arrives: the instance becomes a sequence decoder; that picture may be referenced by the samples that follow
       if (int rc = commit_reference(d)) return rc;
       d->seq_active = true;
-      d->first_closed = true;
+      d->sq.first_closed = true;
     }
-    size_t touched_from = SIZE_MAX;                  // first queued sample this push adds to (set_user_data names the samples of the last push)
-    d->last_push_touched_first = false;
-    bool open = !d->queue.empty() && d->last_open;   // the newest sample may be continued by this push (a picture pushed in pieces)
-    for (size_t q = 0; q < size;) {
-      const uint32_t n = ((uint32_t)p[q] << 24) | ((uint32_t)p[q + 1] << 16) | ((uint32_t)p[q + 2] << 8) | p[q + 3];
-      const uint8_t* nal = p + q + 4;
-      const size_t whole = 4 + (size_t)n;
-      q += whole;
-      if (n < 2) continue;
-      const int t = (nal[0] >> 1) & 63;
-      const bool vcl = t < 32;
-      const bool starts = vcl ? (n >= 3 && (nal[2] & 0x80)) : ((t >= 32 && t <= 35) || t == 39 || (t >= 41 && t <= 44) || (t >= 48 && t <= 55));
-      if (t >= 32 && t <= 34) {   // VPS / SPS / PPS: remembered for the samples that follow (a repeated one moves to the end: the newest wins when parsed)
-        std::vector<uint8_t>& ps = d->param_sets;
-        for (size_t a = 0; a + 4 <= ps.size();) {
-          const size_t len = 4 + (((size_t)ps[a] << 24) | ((size_t)ps[a + 1] << 16) | ((size_t)ps[a + 2] << 8) | ps[a + 3]);
-          if (len == whole && !memcmp(ps.data() + a, nal - 4, whole)) { ps.erase(ps.begin() + (long)a, ps.begin() + (long)(a + len)); break; }
-          a += len;
-        }
-        ps.insert(ps.end(), nal - 4, nal + n);
-      }
-      const bool in_first = !d->first_closed;
-      if (in_first) {
-        if (starts && d->first_has_vcl) d->first_closed = true;   // the still's access unit is complete: what follows are samples of a sequence
-        else {
-          d->data.insert(d->data.end(), nal - 4, nal + n);
-          if (vcl) d->first_has_vcl = true;
-          d->last_push_touched_first = true;
-          continue;
-        }
-      }
-      if (!open || (starts && d->queue.back().has_vcl)) {
-        d->queue.emplace_back();
-        touched_from = std::min(touched_from, d->queue.size() - 1);
-        d->queue.back().user_data = d->pending_user_data;
-        open = true;
-        // a parameter set that opens the sample is already in param_sets (appended above): the blob starts with all of them either way
-        d->queue.back().blob = d->param_sets;
-        if (t >= 32 && t <= 34) continue;
-      } else if (t >= 32 && t <= 34) {   // a parameter set inside an open sample: in front of its slices, like the others
-        touched_from = std::min(touched_from, d->queue.size() - 1);
-        d->queue.back().blob.insert(d->queue.back().blob.end(), nal - 4, nal + n);
-        continue;
-      }
-      touched_from = std::min(touched_from, d->queue.size() - 1);
-      d->queue.back().blob.insert(d->queue.back().blob.end(), nal - 4, nal + n);
-      if (vcl) d->queue.back().has_vcl = true;
-    }
-    d->last_open = open;
-    d->last_push_first = touched_from == SIZE_MAX ? d->queue.size() : touched_from;
+    d->sq.push(p, size);
     return 0;
   });
 }
@@ -1189,8 +1131,8 @@ int hipdec_decoder_decode(hipdec_decoder* d, hipdec_image_info* info)
     if (!d) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "decode: NULL decoder");
     if (!d->decoded) return decoder_decode_impl(d, info);
     for (;;) {
-      while (!d->queue.empty() && !d->queue.front().has_vcl && d->queue.size() > 1) d->queue.pop_front();   // (parameter sets / SEI only: nothing to decode)
-      if (d->queue.empty() || !d->queue.front().has_vcl) return set_error(HIPDEC_ERR_NO_IMAGE, "no further image");
+      while (!d->sq.queue.empty() && !d->sq.queue.front().has_vcl && d->sq.queue.size() > 1) d->sq.queue.pop_front();   // (parameter sets / SEI only: nothing to decode)
+      if (d->sq.queue.empty() || !d->sq.queue.front().has_vcl) return set_error(HIPDEC_ERR_NO_IMAGE, "no further image");
       if (!d->seq_active) { if (int rc = commit_reference(d)) return rc; d->seq_active = true; }
       std::vector<hipdec_decoder::Output> outs;
       if (int rc = decode_chain(d, 1, &outs)) return rc;
@@ -1206,7 +1148,7 @@ static int decoder_decode_impl(hipdec_decoder* d, hipdec_image_info* info)
 {
   if (!d) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "decode: NULL decoder");
   if (d->decoded) return set_error(HIPDEC_ERR_NO_IMAGE, "no further image");
-  if (d->data.empty() || !d->first_has_vcl) return set_error(HIPDEC_ERR_NO_IMAGE, "no data was pushed");
+  if (d->sq.first.empty() || !d->sq.first_has_vcl) return set_error(HIPDEC_ERR_NO_IMAGE, "no data was pushed");
   DecodeRequest req;
   req.d = d;
   const long window = coalesce_window_us();
@@ -1301,7 +1243,7 @@ static int decoder_decode_impl(hipdec_decoder* d, hipdec_image_info* info)
   }
   if (req.rc) return set_error(req.rc, "%s", req.err.c_str());
   d->decoded = true;
-  d->data.clear(); d->data.shrink_to_fit();
+  d->sq.first.clear(); d->sq.first.shrink_to_fit();
   if (info) *info = d->batch->pics[d->item].info;
   return 0;
 }
@@ -1340,9 +1282,7 @@ int hipdec_decoder_device_plane(hipdec_decoder* d, int c, const void** dptr, siz
 void hipdec_decoder_set_user_data(hipdec_decoder* d, uintptr_t user_data)
 {
   if (!d) return;
-  d->pending_user_data = user_data;   // of the sample(s) the last push brought (push_data2's argument)
-  if (d->last_push_touched_first) d->first_user_data = user_data;
-  for (size_t i = d->last_push_first; i < d->queue.size(); i++) d->queue[i].user_data = user_data;
+  d->sq.set_user_data(user_data);   // of the sample(s) the last push brought (push_data2's argument)
 }
 
 // The queued samples [0, n) as ONE chain (batch_layout.h): parsed against the track's sequence state one after the other on the host, one CABAC
@@ -1350,16 +1290,16 @@ void hipdec_decoder_set_user_data(hipdec_decoder* d, uintptr_t user_data)
 // DPB holds name this batch for its pictures, and `outputs` lists the decoded pictures in decoding order.
 static int decode_chain(hipdec_decoder* d, size_t n, std::vector<hipdec_decoder::Output>* outputs)
 {
-  if (n > d->queue.size()) n = d->queue.size();
+  if (n > d->sq.queue.size()) n = d->sq.queue.size();
   if (!n) return 0;
   std::vector<const void*> ptrs;
   std::vector<size_t> sizes;
-  for (size_t i = 0; i < n; i++) { ptrs.push_back(d->queue[i].blob.data()); sizes.push_back(d->queue[i].blob.size()); }
+  for (size_t i = 0; i < n; i++) { ptrs.push_back(d->sq.queue[i].blob.data()); sizes.push_back(d->sq.queue[i].blob.size()); }
   if (int rc = ensure_init()) return rc;
   std::shared_ptr<hipdec_batch> sp(new hipdec_batch());
   hipdec_batch& b = *sp;
   // (a chain that fails - a sample the front end refuses, a corrupt one - is dropped as a whole: the host gets the error once, not at every poll)
-  auto drop = [&]() { d->queue.erase(d->queue.begin(), d->queue.begin() + (long)n); if (d->queue.empty()) d->last_open = false; d->last_push_first = d->last_push_first > n ? d->last_push_first - n : 0; };
+  auto drop = [&]() { d->sq.drop_front(n); };
   if (int rc = build_batch(b, (int)n, ptrs.data(), sizes.data(), d->max_pixels, nullptr, nullptr, &d->seq)) { drop(); return rc; }
   {
     std::lock_guard<std::mutex> lock(g_co.mu);
@@ -1396,7 +1336,7 @@ static int decode_chain(hipdec_decoder* d, size_t n, std::vector<hipdec_decoder:
     if (pp.is_idr) d->cvs++;   // POCs start over: everything still waiting precedes this picture in output order
     if (!outputs) continue;
     hipdec_decoder::Output o;
-    o.batch = sp; o.item = (int)i; o.poc = pp.poc; o.cvs = d->cvs; o.user_data = d->queue[(size_t)b.src((int)i)].user_data; o.pic_output = pp.pic_output;
+    o.batch = sp; o.item = (int)i; o.poc = pp.poc; o.cvs = d->cvs; o.user_data = d->sq.queue[(size_t)b.src((int)i)].user_data; o.pic_output = pp.pic_output;
     outputs->push_back(std::move(o));
   }
   drop();
@@ -1411,13 +1351,13 @@ int hipdec_decoder_next_picture(hipdec_decoder* d, int flush, hipdec_image_info*
   if (!d || !have) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "next_picture: bad arguments");
   *have = 0;
   return guarded("next_picture", [&]() -> int {
-    if (!d->decoded && !d->data.empty() && d->first_has_vcl) {
+    if (!d->decoded && !d->sq.first.empty() && d->sq.first_has_vcl) {
       hipdec_image_info ii;
       if (int rc = decoder_decode_impl(d, &ii)) return rc;
       const ParsedPicture& pp = d->batch->pics[(size_t)d->item];
       d->cvs++;
       hipdec_decoder::Output o;
-      o.batch = d->batch; o.item = d->item; o.poc = pp.poc; o.cvs = d->cvs; o.user_data = d->first_user_data; o.pic_output = pp.pic_output;
+      o.batch = d->batch; o.item = d->item; o.poc = pp.poc; o.cvs = d->cvs; o.user_data = d->sq.first_user_data; o.pic_output = pp.pic_output;
       if (o.pic_output) d->waiting.push_back(std::move(o));
     }
     auto release = [&](bool force) -> bool {   // the bumping process: the waiting picture that is first in output order, if it may go
@@ -1445,18 +1385,18 @@ int hipdec_decoder_next_picture(hipdec_decoder* d, int flush, hipdec_image_info*
     // pictures already decoded go out first; only when none may go are the queued samples decoded - the whole look-ahead window as one chain
     bool got = release(false);
     while (!got) {
-      while (!d->queue.empty() && !d->queue.front().has_vcl && (d->queue.size() > 1 || flush)) d->queue.pop_front();
+      while (!d->sq.queue.empty() && !d->sq.queue.front().has_vcl && (d->sq.queue.size() > 1 || flush)) d->sq.queue.pop_front();
       size_t ready = 0;
-      for (const auto& sm : d->queue) if (sm.has_vcl) ready++;
+      for (const auto& sm : d->sq.queue) if (sm.has_vcl) ready++;
       const size_t k = (size_t)std::max(1L, seq_lookahead());
       if (!d->decoded || !ready || !(flush || ready >= k)) break;
       if (!d->seq_active) { if (int rc = commit_reference(d)) return rc; d->seq_active = true; }
       std::vector<hipdec_decoder::Output> outs;
-      if (int rc = decode_chain(d, std::min(d->queue.size(), k), &outs)) return rc;
+      if (int rc = decode_chain(d, std::min(d->sq.queue.size(), k), &outs)) return rc;
       for (auto& o : outs) if (o.pic_output) d->waiting.push_back(std::move(o));
       got = release(false);
     }
-    if (!got && flush && d->queue.empty()) got = release(true);
+    if (!got && flush && d->sq.queue.empty()) got = release(true);
     if (!got) return 0;
     if (info) { if (int rc = hipdec_batch_info(d->out.batch.get(), d->out.item, info)) return rc; }
     if (user_data) *user_data = d->out.user_data;

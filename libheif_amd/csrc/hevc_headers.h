@@ -3,6 +3,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <deque>
 #include <string>
 #include <vector>
 #include "heif_hipdec.h"
@@ -127,6 +128,27 @@ struct ParsedPicture {
   std::vector<RefPicture> refs;         // the reference table of the picture (slots of SliceParams::ref_slot), at most 16
   std::vector<WeightTable> weight_tables;   // of the slices with explicit weights (SliceParams::wp_index)
   int max_num_reorder = 0, max_dec_pic_buffering = 1;   // sps_max_num_reorder_pics / sps_max_dec_pic_buffering_minus1 + 1 of the highest sub-layer
+};
+
+// What a decoder instance has been pushed and has not decoded yet, split into access units (7.4.2.4.4: a coded slice segment with
+// first_slice_segment_in_pic_flag, or a parameter set / AUD / prefix SEI behind the last slice of a picture, starts the next one).  The first
+// access unit is the still-image case (everything pushed before the decode, as decoder_libde265.cc:322-368 takes it); every later one is a
+// sample of a sequence track (libheif/sequences/track_visual.cc:200-280 pushes them one by one; only a chunk's first sample carries the parameter
+// sets, codecs/decoder.cc:422) and waits in `queue` with the parameter sets known at its push in front.  Pure host logic over untrusted bytes:
+// the framing ([u32 BE length][NAL]...) has been validated by the caller; exercised on the CPU by tests/test_frontend_cpu.py and the header fuzzer.
+struct SampleQueue {
+  struct Sample { std::vector<uint8_t> blob; uintptr_t user_data = 0; bool has_vcl = false; };
+  std::vector<uint8_t> first;            // the first access unit, as pushed
+  bool first_has_vcl = false, first_closed = false;   // it holds a slice / is complete (a later access unit was pushed, or it was decoded)
+  std::vector<uint8_t> param_sets;       // VPS / SPS / PPS seen so far (framed; a repeated one moves to the end: the newest wins when parsed)
+  std::deque<Sample> queue;
+  uintptr_t pending_user_data = 0, first_user_data = 0;   // push_data2's user_data: of the sample(s) the last push brought (decoder_libde265.cc:360, :417-419)
+  size_t last_push_first = 0;            // queue index of the first sample the last push added to
+  bool last_push_touched_first = false;
+  bool last_open = false;                // the newest queued sample may still be continued by the next push (a picture pushed in pieces)
+  void push(const uint8_t* p, size_t size);
+  void set_user_data(uintptr_t user_data);
+  void drop_front(size_t n);             // the n oldest samples were decoded (or refused)
 };
 
 // Parses one coded picture from libheif's plugin framing.  Returns a hipdec_status.

@@ -1002,4 +1002,70 @@ void seq_commit(SeqContext& seq, const ParsedPicture& pic, int)
   seq.dpb.swap(kept);
 }
 
+void SampleQueue::push(const uint8_t* p, size_t size)
+{
+  size_t touched_from = SIZE_MAX;
+  last_push_touched_first = false;
+  bool open = !queue.empty() && last_open;
+  for (size_t q = 0; q + 4 <= size;) {
+    const uint32_t n = ((uint32_t)p[q] << 24) | ((uint32_t)p[q + 1] << 16) | ((uint32_t)p[q + 2] << 8) | p[q + 3];
+    if ((size_t)n > size - q - 4) break;   // (the caller validated the framing; never read past the push)
+    const uint8_t* nal = p + q + 4;
+    const size_t whole = 4 + (size_t)n;
+    q += whole;
+    if (n < 2) continue;
+    const int t = (nal[0] >> 1) & 63;
+    const bool vcl = t < 32;
+    const bool starts = vcl ? (n >= 3 && (nal[2] & 0x80)) : ((t >= 32 && t <= 35) || t == 39 || (t >= 41 && t <= 44) || (t >= 48 && t <= 55));
+    if (t >= 32 && t <= 34) {   // VPS / SPS / PPS: remembered for the samples that follow
+      std::vector<uint8_t>& ps = param_sets;
+      for (size_t a = 0; a + 4 <= ps.size();) {
+        const size_t len = 4 + (((size_t)ps[a] << 24) | ((size_t)ps[a + 1] << 16) | ((size_t)ps[a + 2] << 8) | ps[a + 3]);
+        if (len > ps.size() - a) break;
+        if (len == whole && !memcmp(ps.data() + a, nal - 4, whole)) { ps.erase(ps.begin() + (long)a, ps.begin() + (long)(a + len)); break; }
+        a += len;
+      }
+      ps.insert(ps.end(), nal - 4, nal + n);
+    }
+    if (!first_closed) {
+      if (starts && first_has_vcl) first_closed = true;   // the still's access unit is complete: what follows are samples of a sequence
+      else {
+        first.insert(first.end(), nal - 4, nal + n);
+        if (vcl) first_has_vcl = true;
+        last_push_touched_first = true;
+        continue;
+      }
+    }
+    if (!open || (starts && queue.back().has_vcl)) {
+      queue.emplace_back();
+      touched_from = std::min(touched_from, queue.size() - 1);
+      queue.back().user_data = pending_user_data;
+      open = true;
+      // a parameter set that opens the sample is already in param_sets (appended above): the blob starts with all of them either way
+      queue.back().blob = param_sets;
+      if (t >= 32 && t <= 34) continue;
+    }
+    touched_from = std::min(touched_from, queue.size() - 1);
+    queue.back().blob.insert(queue.back().blob.end(), nal - 4, nal + n);   // (a parameter set inside an open sample stays in front of its slices like the others)
+    if (vcl) queue.back().has_vcl = true;
+  }
+  last_open = open;
+  last_push_first = touched_from == SIZE_MAX ? queue.size() : touched_from;
+}
+
+void SampleQueue::set_user_data(uintptr_t user_data)
+{
+  pending_user_data = user_data;
+  if (last_push_touched_first) first_user_data = user_data;
+  for (size_t i = last_push_first; i < queue.size(); i++) queue[i].user_data = user_data;
+}
+
+void SampleQueue::drop_front(size_t n)
+{
+  if (n > queue.size()) n = queue.size();
+  queue.erase(queue.begin(), queue.begin() + (long)n);
+  if (queue.empty()) last_open = false;
+  last_push_first = last_push_first > n ? last_push_first - n : 0;
+}
+
 }  // namespace hipdec

@@ -103,6 +103,39 @@ int emu_seq_commit_chain(EmuSeq* q, EmuBatch* b)
   return 0;
 }
 
+// ---- the decoder's sample queue (hevc_headers.h: SampleQueue) on its own: access-unit splitting of pushed data, user_data attribution ----------
+void* emu_sq_new() { return new SampleQueue(); }
+void emu_sq_free(void* q) { delete (SampleQueue*)q; }
+// push as hipdec_decoder_push_data does (framing validated first: -2 = End_of_data as the C ABI reports it); with_user_data: push_data2's argument follows
+int emu_sq_push(void* q, const uint8_t* p, size_t size, int with_user_data, uint64_t user_data)
+{
+  for (size_t ptr = 0; ptr < size;) {
+    if (size - ptr < 4) return -2;
+    const uint32_t n = ((uint32_t)p[ptr] << 24) | ((uint32_t)p[ptr + 1] << 16) | ((uint32_t)p[ptr + 2] << 8) | p[ptr + 3];
+    ptr += 4;
+    if (n > size - ptr) return -2;
+    ptr += n;
+  }
+  ((SampleQueue*)q)->push(p, size);
+  if (with_user_data) ((SampleQueue*)q)->set_user_data((uintptr_t)user_data);
+  return 0;
+}
+void emu_sq_close_first(void* q) { ((SampleQueue*)q)->first_closed = true; }   // the first picture was decoded
+void emu_sq_drop(void* q, size_t n) { ((SampleQueue*)q)->drop_front(n); }
+int emu_sq_count(void* q) { return (int)((SampleQueue*)q)->queue.size(); }
+// i = -1: the first access unit, i = -2: the parameter sets, else queued sample i.  Returns its size (copied up to cap)
+size_t emu_sq_get(void* q, int i, uint8_t* dst, size_t cap, uint64_t* user_data, int* has_vcl)
+{
+  SampleQueue* s = (SampleQueue*)q;
+  const std::vector<uint8_t>* v = nullptr;
+  if (i == -1) { v = &s->first; if (user_data) *user_data = s->first_user_data; if (has_vcl) *has_vcl = s->first_has_vcl; }
+  else if (i == -2) v = &s->param_sets;
+  else if (i >= 0 && i < (int)s->queue.size()) { v = &s->queue[(size_t)i].blob; if (user_data) *user_data = s->queue[(size_t)i].user_data; if (has_vcl) *has_vcl = s->queue[(size_t)i].has_vcl; }
+  if (!v) return 0;
+  if (dst && cap) memcpy(dst, v->data(), v->size() < cap ? v->size() : cap);
+  return v->size();
+}
+
 // runs every substream in index order (a WPP predecessor always has a smaller index); returns the device status word
 int emu_run_parse(EmuBatch* b)
 {

@@ -17,6 +17,11 @@ L.emu_seq_commit.argtypes = [C.c_void_p, C.c_void_p]
 L.emu_run_parse.argtypes = [C.c_void_p]
 L.emu_run_pipeline.argtypes = [C.c_void_p, C.c_int]
 L.emu_free.argtypes = [C.c_void_p]
+L.emu_seq_create_chain.restype = C.c_void_p
+L.emu_seq_create_chain.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+L.emu_seq_commit_chain.argtypes = [C.c_void_p, C.c_void_p]
+L.emu_run_pipeline_chain.argtypes = [C.c_void_p]
+L.emu_num_items.argtypes = [C.c_void_p]
 
 
 def parameter_sets(au):
@@ -29,11 +34,35 @@ def parameter_sets(au):
     return out
 
 
-def run(aus):
+def run(aus, chain=False):
     ps = parameter_sets(aus[0])
     q = C.c_void_p(L.emu_seq_new())
     res = []
     try:
+        if chain:   # the look-ahead's form (round 5): the first picture alone, everything behind it as ONE chain batch (references inside the batch)
+            err = C.create_string_buffer(512)
+            b = L.emu_seq_create_picture(q, aus[0], len(aus[0]), err, 512)
+            if not b:
+                return 'rejected'
+            b = C.c_void_p(b)
+            if L.emu_run_parse(b) or L.emu_run_pipeline(b, 15):
+                return 'status'
+            L.emu_seq_commit(q, b)
+            group = [ps + a for a in aus[1:]]
+            ptrs = (C.c_char_p * len(group))(*group)
+            sizes = (C.c_size_t * len(group))(*[len(a) for a in group])
+            b = L.emu_seq_create_chain(q, len(group), ptrs, sizes, err, 512)
+            if not b:
+                return 'ok,chain rejected'
+            b = C.c_void_p(b)
+            st = 0
+            if L.emu_num_items(b):
+                st = L.emu_run_parse(b)
+                if st == 0:
+                    st = L.emu_run_pipeline_chain(b)
+            if st == 0:
+                L.emu_seq_commit_chain(q, b)
+            return 'ok,chain ' + ('ok' if st == 0 else 'status')
         for i, au in enumerate(aus):
             data = au if i == 0 else ps + au
             err = C.create_string_buffer(512)
@@ -61,12 +90,16 @@ cfgs = [dict(), dict(amp=1, inter_num_refs=2), dict(inter_num_refs=3, lists_modi
         dict(num_slices=3, parallel_merge_level=4), dict(bit_depth=10, amp=1), dict(lossless_pct=20, transform_skip=1, log2_ctb=5),
         dict(pcm_pct=10, inter_intra_pct=40, cu_qp_delta=1), dict(dependent_segments=3, num_slices=2, wpp=0),
         dict(b_frames=1, temporal_mvp=1), dict(b_frames=2, b_ref=1, temporal_mvp=1, weighted_pred=1, inter_num_refs=2, mvd_l1_zero=1),
-        dict(temporal_mvp=1, weighted_pred=1, inter_num_refs=3), dict(b_frames=1, weighted_pred=1, lists_modification=1, num_slices=2, amp=1)]
+        dict(temporal_mvp=1, weighted_pred=1, inter_num_refs=3), dict(b_frames=1, weighted_pred=1, lists_modification=1, num_slices=2, amp=1),
+        # round 5: long-term reference pictures (three syntax forms), constrained intra prediction, scaling lists in P / B pictures
+        dict(long_term_ref=1, inter_num_refs=2, temporal_mvp=1), dict(long_term_ref=2, b_frames=1, temporal_mvp=1), dict(long_term_ref=3, lists_modification=1, inter_num_refs=3),
+        dict(constrained_intra_pred=1, inter_intra_pct=45, log2_ctb=4, log2_max_tb=4), dict(scaling_list=2, inter_intra_pct=30, b_frames=1), dict(scaling_list=3, temporal_mvp=1)]
 base = []
 for i, c in enumerate(cfgs):
     frames = make_frames(104, 72, 4 if c.get('b_frames') else 3, c.get('bit_depth', 8))
     base.append(orc.encode_sequence(frames, qp=26, global_mv_x=-6, global_mv_y=4, seed=11 + i, **c))
 print('clean:', [run(a) for a in base]); sys.stdout.flush()
+print('clean (chains):', [run(a, True) for a in base]); sys.stdout.flush()
 res = {}
 for it in range(n):
     aus = [bytes(a) for a in rng.choice(base)]
@@ -80,6 +113,6 @@ for it in range(n):
         elif mode == 1: s[p] = rng.randrange(256)
         else: s[p] = 0xff
     aus[victim] = bytes(s)
-    r = run(aus)
+    r = run(aus, chain=(it % 3 == 2))       # every third case through the chain form
     res[r] = res.get(r, 0) + 1
 print(res)
