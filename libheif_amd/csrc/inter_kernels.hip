@@ -232,27 +232,46 @@ __device__ __forceinline__ Mo derive_merge(const MotionCtx& C, PbGeom g, int par
 #define MK_SAME_MER(xn, yn) ((xPb >> pl) == ((xn) >> pl) && (yPb >> pl) == ((yn) >> pl))
   MotionUnit A1{}, B1{}, B0{}, A0{}, B2{};
   // availableN: 6.4.2 minus the merge-estimation-region / second-partition exclusions; flagN: after pruning.  Comparisons read availableN of the other
-  // candidate, not its flag; only B2's "all four present" rule counts flags (8.5.3.2.3)
-  int avA1 = pb_available(C, g, xPb - 1, yPb + nPbH - 1, &A1);
-  if (MK_SAME_MER(xPb - 1, yPb + nPbH - 1) || (g.partIdx == 1 && (part_mode == 2 || part_mode == 6 || part_mode == 7))) avA1 = 0;   // Nx2N, nLx2N, nRx2N
-  const int fA1 = avA1;
-  int avB1 = pb_available(C, g, xPb + nPbW - 1, yPb - 1, &B1);
-  if (MK_SAME_MER(xPb + nPbW - 1, yPb - 1) || (g.partIdx == 1 && (part_mode == 1 || part_mode == 4 || part_mode == 5))) avB1 = 0;   // 2NxN, 2NxnU, 2NxnD
-  const int fB1 = avB1 && !(avA1 && same_motion(A1, B1));
-  int avB0 = pb_available(C, g, xPb + nPbW, yPb - 1, &B0);
-  if (MK_SAME_MER(xPb + nPbW, yPb - 1)) avB0 = 0;
-  const int fB0 = avB0 && !(avB1 && same_motion(B1, B0));
-  int avA0 = pb_available(C, g, xPb - 1, yPb + nPbH, &A0);
-  if (MK_SAME_MER(xPb - 1, yPb + nPbH)) avA0 = 0;
-  const int fA0 = avA0 && !(avA1 && same_motion(A1, A0));
-  int avB2 = pb_available(C, g, xPb - 1, yPb - 1, &B2);
-  if (MK_SAME_MER(xPb - 1, yPb - 1)) avB2 = 0;
-  const int fB2 = avB2 && !(avA1 && same_motion(A1, B2)) && !(avB1 && same_motion(B1, B2)) && fA0 + fA1 + fB0 + fB1 != 4;
+  // candidate, not its flag; only B2's "all four present" rule counts flags (8.5.3.2.3).
+  // The list is only needed up to merge_idx, and a candidate's flag depends on EARLIER candidates only: the walk stops at the merge_idx-th
+  // present one (round 5: every prediction unit evaluated all five neighbours - availability, an LDS read and the pruning compares each - on
+  // the one lane that derives, whatever merge_idx was; small indices are the common case)
+  Mo out = mo_none();
+  bool found = false;
+  int avA1 = 0, avB1 = 0, avB0 = 0, avA0 = 0, avB2 = 0, fA1 = 0, fB1 = 0, fB0 = 0, fA0 = 0, fB2 = 0, n = 0, fCol = 0;
+  Mo mA1 = mo_none(), mB1 = mo_none(), mB0 = mo_none(), mA0 = mo_none(), mB2 = mo_none(), mCol = mo_none();
+  do {
+    avA1 = pb_available(C, g, xPb - 1, yPb + nPbH - 1, &A1);
+    if (MK_SAME_MER(xPb - 1, yPb + nPbH - 1) || (g.partIdx == 1 && (part_mode == 2 || part_mode == 6 || part_mode == 7))) avA1 = 0;   // Nx2N, nLx2N, nRx2N
+    fA1 = avA1; mA1 = to_mo(A1);
+    if (fA1 && n == merge_idx) { out = mA1; found = true; break; }
+    n += fA1;
+    avB1 = pb_available(C, g, xPb + nPbW - 1, yPb - 1, &B1);
+    if (MK_SAME_MER(xPb + nPbW - 1, yPb - 1) || (g.partIdx == 1 && (part_mode == 1 || part_mode == 4 || part_mode == 5))) avB1 = 0;   // 2NxN, 2NxnU, 2NxnD
+    fB1 = avB1 && !(avA1 && same_motion(A1, B1)); mB1 = to_mo(B1);
+    if (fB1 && n == merge_idx) { out = mB1; found = true; break; }
+    n += fB1;
+    avB0 = pb_available(C, g, xPb + nPbW, yPb - 1, &B0);
+    if (MK_SAME_MER(xPb + nPbW, yPb - 1)) avB0 = 0;
+    fB0 = avB0 && !(avB1 && same_motion(B1, B0)); mB0 = to_mo(B0);
+    if (fB0 && n == merge_idx) { out = mB0; found = true; break; }
+    n += fB0;
+    avA0 = pb_available(C, g, xPb - 1, yPb + nPbH, &A0);
+    if (MK_SAME_MER(xPb - 1, yPb + nPbH)) avA0 = 0;
+    fA0 = avA0 && !(avA1 && same_motion(A1, A0)); mA0 = to_mo(A0);
+    if (fA0 && n == merge_idx) { out = mA0; found = true; break; }
+    n += fA0;
+    avB2 = pb_available(C, g, xPb - 1, yPb - 1, &B2);
+    if (MK_SAME_MER(xPb - 1, yPb - 1)) avB2 = 0;
+    fB2 = avB2 && !(avA1 && same_motion(A1, B2)) && !(avB1 && same_motion(B1, B2)) && fA0 + fA1 + fB0 + fB1 != 4; mB2 = to_mo(B2);
+    if (fB2 && n == merge_idx) { out = mB2; found = true; break; }
+    n += fB2;
+  } while (0);
 #undef MK_SAME_MER
-  const Mo mA1 = to_mo(A1), mB1 = to_mo(B1), mB0 = to_mo(B0), mA0 = to_mo(A0), mB2 = to_mo(B2);
-  int n = fA1 + fB1 + fB0 + fA0 + fB2;
-  Mo mCol = mo_none();
-  int fCol = 0;
+  if (found) {
+    if (out.r0 >= 0 && out.r1 >= 0 && orig_w + orig_h == 12) { out.r1 = -1; out.x1 = out.y1 = 0; }   // 8x4 / 4x8: uni-prediction
+    return out;
+  }
   if (C.slice->tmvp && n <= merge_idx) {   // the temporal candidate: reference index 0 in each list of the slice (only needed when merge_idx reaches it)
     int vx = 0, vy = 0;
     if (temporal_mv(C, xPb, yPb, nPbW, nPbH, 0, 0, vx, vy)) mo_set(mCol, 0, vx, vy, 0);
@@ -262,23 +281,22 @@ __device__ __forceinline__ Mo derive_merge(const MotionCtx& C, PbGeom g, int par
   }
   if (n > max_cand) n = max_cand;
 #define MK_ORIG(i) nth_present((i), fA1, mA1, fB1, mB1, fB0, mB0, fA0, mA0, fB2, mB2, fCol, mCol)
-  Mo out = mo_none();
   if (merge_idx < n) out = MK_ORIG(merge_idx);
   else {
-    int found = 0;
+    int found_comb = 0;
     if (is_b && n > 1 && n < max_cand) {   // 8.5.3.2.4 combined bi-predictive candidates: walked in list order until merge_idx is reached
       const int num_orig = n;
-      for (int comb = 0; comb < num_orig * (num_orig - 1) && n < max_cand && !found; comb++) {
+      for (int comb = 0; comb < num_orig * (num_orig - 1) && n < max_cand && !found_comb; comb++) {
         // l0CandIdx / l1CandIdx of Table 8-7: (0,1) (1,0) (0,2) (2,0) (1,2) (2,1) (0,3) (3,0) (1,3) (3,1) (2,3) (3,2), one nibble per combIdx
         const int l0 = (int)((0x323130212010ull >> (4 * comb)) & 3u), l1 = (int)((0x231303120201ull >> (4 * comb)) & 3u);
         const Mo a = MK_ORIG(l0), b = MK_ORIG(l1);
         if (a.r0 >= 0 && b.r1 >= 0 && (slot_of(C, 0, a.r0) != slot_of(C, 1, b.r1) || a.x0 != b.x1 || a.y0 != b.y1)) {
-          if (n == merge_idx) { out = Mo{a.x0, a.y0, b.x1, b.y1, a.r0, b.r1}; found = 1; }
+          if (n == merge_idx) { out = Mo{a.x0, a.y0, b.x1, b.y1, a.r0, b.r1}; found_comb = 1; }
           n++;
         }
       }
     }
-    if (!found) {   // zero candidates: the reference index counts up while below the number of reference pictures (B: of the shorter list), then 0
+    if (!found_comb) {   // zero candidates: the reference index counts up while below the number of reference pictures (B: of the shorter list), then 0
       const int zero_idx = merge_idx - n;
       const int num_ref = is_b ? (C.slice->num_ref_idx < C.slice->num_ref_idx_l1 ? C.slice->num_ref_idx : C.slice->num_ref_idx_l1) : C.slice->num_ref_idx;
       const int r = zero_idx < num_ref ? zero_idx : 0;
@@ -325,6 +343,7 @@ __device__ __forceinline__ void derive_mvp(const MotionCtx& C, const PbGeom& g, 
   if (!flagA && av_a1) flagA = nb_same_pic(a1, X, tgt_slot, ax, ay);
   if (!flagA && av_a0) flagA = nb_scaled(C, a0, X, tgt_slot, ax, ay);
   if (!flagA && av_a1) flagA = nb_scaled(C, a1, X, tgt_slot, ax, ay);
+  if (flagA && !mvp_flag) { out_x = ax; out_y = ay; return; }   // mvpListLX[0] is the A candidate whenever there is one: B and the temporal candidate are not needed
   MotionUnit b0{}, b1{}, b2{};
   const int av_b0 = pb_available(C, g, xPb + nPbW, yPb - 1, &b0), av_b1 = pb_available(C, g, xPb + nPbW - 1, yPb - 1, &b1), av_b2 = pb_available(C, g, xPb - 1, yPb - 1, &b2);
   int flagB = 0, bx = 0, by = 0;

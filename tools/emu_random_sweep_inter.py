@@ -52,6 +52,10 @@ def random_case(rng):
     cfg["weighted_pred"] = rng.choice([0, 0, 1])
     cfg["mvd_l1_zero"] = rng.choice([0, 1])
     cfg["global_mv_x"], cfg["global_mv_y"] = rng.choice([0, -8, 6, 21]), rng.choice([0, -4, 10, -17])
+    # round 5: long-term reference pictures (three syntax forms), constrained intra prediction, scaling lists in P / B pictures
+    cfg["long_term_ref"] = rng.choice([0, 0, 1, 2, 3])
+    cfg["constrained_intra_pred"] = rng.choice([0, 0, 1])
+    cfg["scaling_list"] = rng.choice([0, 0, 0, 1, 2, 3])
     w, h = rng.choice([16, 40, 64, 72, 136, 200]), rng.choice([16, 24, 42, 64, 72, 104])
     mono = rng.random() < 0.15
     if not mono and (h & 1):
@@ -73,7 +77,7 @@ def run_case(args):
     except orc.OracleError as ex:
         return (k, "generator: " + str(ex)[:80], None)
     try:
-        T.check_sequence(aus, "case %d" % k)
+        T.check_sequence(aus, "case %d" % k, chain=rng.choice([0, 0, 2, 5, 16]))      # per picture, or the decoder's look-ahead chains
     except Exception as ex:   # noqa
         return (k, "MISMATCH " + str(ex)[:300], (w, h, mono, n, cfg))
     return (k, "ok", None)
