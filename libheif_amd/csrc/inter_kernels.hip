@@ -41,6 +41,15 @@ __device__ __forceinline__ uint32_t mk_interleave(uint32_t x, uint32_t y)   // z
 __device__ __forceinline__ int mk_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int mk_abs(int v) { return v < 0 ? -v : v; }
 
+// all of this wave's global stores have left it (the CPU-test build orders them with a fence instead)
+__device__ __forceinline__ void mk_drain_stores()
+{
+#ifndef HIPDEC_HOST_EMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+}
 __device__ __forceinline__ void mk_lds_sync()
 {
 #ifndef HIPDEC_HOST_EMU
@@ -122,11 +131,16 @@ __device__ __forceinline__ MotionUnit unit_at(const MotionCtx& C, int x, int y)
 {
   const int ncx = x >> C.log2_ctb, ncy = y >> C.log2_ctb, side = 1 << (C.log2_ctb - 2);
   const uint32_t ux = (uint32_t)((x >> 2) & (side - 1)), uy = (uint32_t)((y >> 2) & (side - 1));
+  // Every source below is LDS, and it has to stay that way: a fall-back to the field in HBM here (it was never taken: the three regions cover every
+  // neighbour a candidate list can name) made the compiler merge the LDS and the global pointer into a GENERIC one - every neighbour read, field
+  // by field, became a FLAT load with global-memory latency on the one lane that derives (64 of them per unit walk: 12 000 cycles per prediction unit)
   if (ncy == C.cy) {
     if (ncx == C.cx) return C.cur[mk_interleave(ux, uy)];
     if (ncx == C.cx - 1) return C.left[mk_interleave(ux, uy)];
   } else if (ncy == C.cy - 1 && (int)uy == side - 1 && ncx >= C.cx - 1 && ncx <= C.cx + 1) return C.up[(ncx - C.cx + 1) * side + (int)ux];
-  return C.field[unit_index(C, x, y)];
+  MotionUnit none{};   // (not reachable for an available neighbour: reads as an intra coded unit)
+  none.ref_idx[0] = none.ref_idx[1] = -1;
+  return none;
 }
 
 // 6.4.1 z-scan order availability of (xN, yN) seen from (xC, yC) of the current CTB: inside the picture, decoded earlier, same slice, same tile
@@ -188,8 +202,8 @@ __device__ __forceinline__ int collocated_mv(const MotionCtx& C, int x, int y, i
   // (a lone lane fetching this from HBM - one or two dependent global loads per candidate, up to four per prediction unit - was most of
   //  k_motion's 8 ms per 720p picture: the grid positions a CTB can name are staged by all lanes before the chain starts)
   const int gx = (x >> 4) - ((C.cx << C.log2_ctb) >> 4), gy = (y >> 4) - ((C.cy << C.log2_ctb) >> 4);
-  const bool staged = gx >= 0 && gx < C.col_w && gy >= 0 && gy < (1 << (C.log2_ctb - 4));
-  const MotionUnit cu = staged ? C.col_lds[gy * C.col_w + gx] : C.col[unit_index(C, (x >> 4) << 4, (y >> 4) << 4)];
+  if (gx < 0 || gx >= C.col_w || gy < 0 || gy >= (1 << (C.log2_ctb - 4))) return 0;   // (not reachable: the staged grid covers every position 8.5.3.2.8 can name)
+  const MotionUnit cu = C.col_lds[gy * C.col_w + gx];   // LDS only: mixing in a global fall-back turns the read into FLAT loads (see unit_at)
   const int f0 = cu.ref_idx[0] >= 0, f1 = cu.ref_idx[1] >= 0;
   if (!f0 && !f1) return 0;   // intra coded
   int L;
@@ -410,8 +424,10 @@ __global__ __launch_bounds__(64) void k_motion(MotionArgs A)
       uint32_t need = (uint32_t)(cx + 2);
       if (need > (uint32_t)ctb_w) need = (uint32_t)ctb_w;
       uint32_t spins = 0;
-      while (__hip_atomic_load(up_progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
-        __builtin_amdgcn_s_sleep(32);
+      // (relaxed poll + write-through data, the reconstruction kernel's protocol: an ACQUIRE here and a RELEASE fence per CTB on the producer side cost an
+      //  L2 invalidate / write-back per CTB - on a chip with one L2 per XCD that was most of this kernel's 7.7 ms per 720p picture, not the derivation)
+      while (__hip_atomic_load(up_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(8);
         if (++spins > (1u << 22) || __hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { err = DEV_ERR_TIMEOUT; break; }
       }
       if (err) break;
@@ -443,7 +459,11 @@ __global__ __launch_bounds__(64) void k_motion(MotionArgs A)
     if (cy > 0)
       for (int i = lane; i < 3 * side; i += 64) {
         const int ncx = cx - 1 + i / side;
-        if (ncx >= 0 && ncx < ctb_w) L.up[i] = field[((size_t)((cy - 1) * ctb_w + ncx) << units_log2) + mk_interleave((uint32_t)(i % side), (uint32_t)(side - 1))];
+        if (ncx >= 0 && ncx < ctb_w) {   // written by another wave of this launch: read with sc1 loads (four dwords per unit)
+          const uint32_t* src = (const uint32_t*)&field[((size_t)((cy - 1) * ctb_w + ncx) << units_log2) + mk_interleave((uint32_t)(i % side), (uint32_t)(side - 1))];
+          uint32_t* dst = (uint32_t*)&L.up[i];
+          for (int k = 0; k < 4; k++) dst[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     C.col_w = (1 << (log2_ctb - 4)) + 1;
     if (C.col) {   // the collocated units the CTB's temporal candidates can name
@@ -551,11 +571,16 @@ __global__ __launch_bounds__(64) void k_motion(MotionArgs A)
       z += n_units;
     }
     if (err) break;
-    // the CTB's units leave LDS (coalesced 16-byte stores), then the row's progress is published
+    // the CTB's units leave LDS (coalesced 16-byte stores; later KERNELS read them), the bottom unit row - what the row below reads while this
+    // launch runs - additionally as write-through dword stores; the stores are drained and ONE relaxed progress store announces them (no fence)
     for (int i = lane; i < units; i += 64) field[base + i] = cur[i];
+    for (int i = lane; i < 4 * side; i += 64) {
+      const uint32_t zi = mk_interleave((uint32_t)(i >> 2), (uint32_t)(side - 1));
+      __hip_atomic_store((uint32_t*)&field[base + zi] + (i & 3), ((const uint32_t*)&cur[zi])[i & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     mk_lds_sync();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if (lane == 0) __hip_atomic_store(my_progress, (uint32_t)(cx + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    mk_drain_stores();
+    if (lane == 0) __hip_atomic_store(my_progress, (uint32_t)(cx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (err && lane == 0) atomicCAS((int*)A.status, 0, err | (int)(0x50000000u) | (int)(ticket << 8));
 }
