@@ -38,15 +38,15 @@ __device__ __forceinline__ void rgb_block(const ColorParams& p)
   for (int dy = 0; dy < 2; dy++) {
     const int yy = y0 + dy;
     if (yy >= p.h) break;
-    const Pix* yrow = (const Pix*)(p.y + (size_t)yy * p.ys);
-    const Pix* cbrow = (const Pix*)(p.cb + (size_t)(yy >> p.shiftV) * p.cbs);
-    const Pix* crrow = (const Pix*)(p.cr + (size_t)(yy >> p.shiftV) * p.crs);
+    HIPDEC_GLOBAL const Pix* yrow = (HIPDEC_GLOBAL const Pix*)((HIPDEC_GLOBAL const uint8_t*)p.y + (size_t)yy * p.ys);   // (address space 1: see color_device.h)
+    HIPDEC_GLOBAL const Pix* cbrow = (HIPDEC_GLOBAL const Pix*)((HIPDEC_GLOBAL const uint8_t*)p.cb + (size_t)(yy >> p.shiftV) * p.cbs);
+    HIPDEC_GLOBAL const Pix* crrow = (HIPDEC_GLOBAL const Pix*)((HIPDEC_GLOBAL const uint8_t*)p.cr + (size_t)(yy >> p.shiftV) * p.crs);
     int Y[4], CB[4], CR[4];
     if (npx == 4 && sizeof(Pix) == 1 && (((uintptr_t)(yrow + x0)) & 3) == 0) {
-      uint32_t v = *(const uint32_t*)(yrow + x0);
+      uint32_t v = *(HIPDEC_GLOBAL const uint32_t*)(yrow + x0);
       Y[0] = v & 255; Y[1] = (v >> 8) & 255; Y[2] = (v >> 16) & 255; Y[3] = v >> 24;
     } else if (npx == 4 && sizeof(Pix) == 2 && (((uintptr_t)(yrow + x0)) & 7) == 0) {
-      uint2 v = *(const uint2*)(yrow + x0);
+      uint2 v = *(HIPDEC_GLOBAL const uint2*)(yrow + x0);
       Y[0] = v.x & 0xffff; Y[1] = v.x >> 16; Y[2] = v.y & 0xffff; Y[3] = v.y >> 16;
     } else {
       for (int i = 0; i < 4; i++) Y[i] = i < npx ? yrow[x0 + i] : 0;
@@ -74,38 +74,38 @@ __device__ __forceinline__ void rgb_block(const ColorParams& p)
     }
 
     if (LAYOUT == LO_PLANAR) {
-      Pix* r = (Pix*)(p.o0 + (size_t)yy * p.os) + x0;
-      Pix* g = (Pix*)(p.o1 + (size_t)yy * p.os) + x0;
-      Pix* b = (Pix*)(p.o2 + (size_t)yy * p.os) + x0;
+      HIPDEC_GLOBAL Pix* r = (HIPDEC_GLOBAL Pix*)((HIPDEC_GLOBAL uint8_t*)p.o0 + (size_t)yy * p.os) + x0;
+      HIPDEC_GLOBAL Pix* g = (HIPDEC_GLOBAL Pix*)((HIPDEC_GLOBAL uint8_t*)p.o1 + (size_t)yy * p.os) + x0;
+      HIPDEC_GLOBAL Pix* b = (HIPDEC_GLOBAL Pix*)((HIPDEC_GLOBAL uint8_t*)p.o2 + (size_t)yy * p.os) + x0;
       if (npx == 4 && sizeof(Pix) == 1 && ((p.os | (uintptr_t)p.o0 | (uintptr_t)p.o1 | (uintptr_t)p.o2) & 3) == 0) {
-        *(uint32_t*)r = R[0] | (R[1] << 8) | (R[2] << 16) | ((uint32_t)R[3] << 24);
-        *(uint32_t*)g = G[0] | (G[1] << 8) | (G[2] << 16) | ((uint32_t)G[3] << 24);
-        *(uint32_t*)b = B[0] | (B[1] << 8) | (B[2] << 16) | ((uint32_t)B[3] << 24);
+        *(HIPDEC_GLOBAL uint32_t*)r = R[0] | (R[1] << 8) | (R[2] << 16) | ((uint32_t)R[3] << 24);
+        *(HIPDEC_GLOBAL uint32_t*)g = G[0] | (G[1] << 8) | (G[2] << 16) | ((uint32_t)G[3] << 24);
+        *(HIPDEC_GLOBAL uint32_t*)b = B[0] | (B[1] << 8) | (B[2] << 16) | ((uint32_t)B[3] << 24);
       } else if (npx == 4 && sizeof(Pix) == 2 && ((p.os | (uintptr_t)p.o0 | (uintptr_t)p.o1 | (uintptr_t)p.o2) & 7) == 0) {
-        *(uint2*)r = make_uint2(R[0] | (R[1] << 16), R[2] | (R[3] << 16));
-        *(uint2*)g = make_uint2(G[0] | (G[1] << 16), G[2] | (G[3] << 16));
-        *(uint2*)b = make_uint2(B[0] | (B[1] << 16), B[2] | (B[3] << 16));
+        *(HIPDEC_GLOBAL uint2*)r = make_uint2(R[0] | (R[1] << 16), R[2] | (R[3] << 16));
+        *(HIPDEC_GLOBAL uint2*)g = make_uint2(G[0] | (G[1] << 16), G[2] | (G[3] << 16));
+        *(HIPDEC_GLOBAL uint2*)b = make_uint2(B[0] | (B[1] << 16), B[2] | (B[3] << 16));
       } else {
         for (int i = 0; i < npx; i++) { r[i] = (Pix)R[i]; g[i] = (Pix)G[i]; b[i] = (Pix)B[i]; }
       }
     } else if (LAYOUT == LO_RGB24) {
-      uint8_t* o = p.o0 + (size_t)yy * p.os + (size_t)x0 * 3;
+      HIPDEC_GLOBAL uint8_t* o = (HIPDEC_GLOBAL uint8_t*)p.o0 + (size_t)yy * p.os + (size_t)x0 * 3;
       if (npx == 4 && ((p.os | (uintptr_t)p.o0) & 3) == 0) {
         U3 v;
         v.a = R[0] | (G[0] << 8) | (B[0] << 16) | ((uint32_t)R[1] << 24);
         v.b = G[1] | (B[1] << 8) | (R[2] << 16) | ((uint32_t)G[2] << 24);
         v.c = B[2] | (R[3] << 8) | (G[3] << 16) | ((uint32_t)B[3] << 24);
-        *(U3*)o = v;
+        *(HIPDEC_GLOBAL U3*)o = v;
       } else {
         for (int i = 0; i < npx; i++) { o[3 * i] = (uint8_t)R[i]; o[3 * i + 1] = (uint8_t)G[i]; o[3 * i + 2] = (uint8_t)B[i]; }
       }
     } else if (LAYOUT == LO_RGBA32) {
-      uint8_t* o = p.o0 + (size_t)yy * p.os + (size_t)x0 * 4;
+      HIPDEC_GLOBAL uint8_t* o = (HIPDEC_GLOBAL uint8_t*)p.o0 + (size_t)yy * p.os + (size_t)x0 * 4;
       uint32_t A[4] = {255u, 255u, 255u, 255u};
       if (p.a) {
-        const uint8_t* arow = p.a + (size_t)yy * p.as + x0;
+        HIPDEC_GLOBAL const uint8_t* arow = (HIPDEC_GLOBAL const uint8_t*)p.a + (size_t)yy * p.as + x0;
         if (npx == 4 && (((uintptr_t)arow) & 3) == 0) {
-          const uint32_t v = *(const uint32_t*)arow;
+          const uint32_t v = *(HIPDEC_GLOBAL const uint32_t*)arow;
           A[0] = v & 255u; A[1] = (v >> 8) & 255u; A[2] = (v >> 16) & 255u; A[3] = v >> 24;
         } else {
           for (int i = 0; i < npx; i++) A[i] = arow[i];
@@ -117,12 +117,12 @@ __device__ __forceinline__ void rgb_block(const ColorParams& p)
         v.y = R[1] | (G[1] << 8) | (B[1] << 16) | (A[1] << 24);
         v.z = R[2] | (G[2] << 8) | (B[2] << 16) | (A[2] << 24);
         v.w = R[3] | (G[3] << 8) | (B[3] << 16) | (A[3] << 24);
-        *(uint4*)o = v;
+        *(HIPDEC_GLOBAL uint4*)o = v;
       } else {
         for (int i = 0; i < npx; i++) { o[4 * i] = (uint8_t)R[i]; o[4 * i + 1] = (uint8_t)G[i]; o[4 * i + 2] = (uint8_t)B[i]; o[4 * i + 3] = (uint8_t)A[i]; }
       }
     } else {  // RRGGBB BE / LE, yuv2rgb.cc:717-723
-      uint8_t* o = p.o0 + (size_t)yy * p.os + (size_t)x0 * 6;
+      HIPDEC_GLOBAL uint8_t* o = (HIPDEC_GLOBAL uint8_t*)p.o0 + (size_t)yy * p.os + (size_t)x0 * 6;
       const bool le = LAYOUT == LO_RRGGBB_LE;
       uint16_t s[12];
 #pragma unroll
@@ -135,7 +135,7 @@ __device__ __forceinline__ void rgb_block(const ColorParams& p)
         U3 v0, v1;
         v0.a = s[0] | ((uint32_t)s[1] << 16); v0.b = s[2] | ((uint32_t)s[3] << 16); v0.c = s[4] | ((uint32_t)s[5] << 16);
         v1.a = s[6] | ((uint32_t)s[7] << 16); v1.b = s[8] | ((uint32_t)s[9] << 16); v1.c = s[10] | ((uint32_t)s[11] << 16);
-        ((U3*)o)[0] = v0; ((U3*)o)[1] = v1;
+        ((HIPDEC_GLOBAL U3*)o)[0] = v0; ((HIPDEC_GLOBAL U3*)o)[1] = v1;
       } else {
         for (int i = 0; i < npx * 3; i++) { o[2 * i] = (uint8_t)(s[i] & 255); o[2 * i + 1] = (uint8_t)(s[i] >> 8); }
       }

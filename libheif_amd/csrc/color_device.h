@@ -28,6 +28,16 @@ struct ColorParams {
   int out_shift;   // > 8-bit planes to 8-bit interleaved RGB: Op_to_sdr_planes applied to R, G, B after the conversion at the input depth
 };
 
+// A pointer that came out of a parameter block in MEMORY (or out of an integer) is a generic pointer to the compiler: every access through it is a FLAT
+// instruction (aperture check per access; it counts in vmcnt AND lgkmcnt, so a wait for LDS also waits for the plane traffic).  These buffers are device
+// global memory by contract; only an access through a pointer TYPED as address space 1 makes the compiler believe it (a cast there and back is folded
+// away, assumptions are not used): HIPDEC_GLOBAL at the access sites.  Round 5: the batched colour kernels had 40 - 46 FLAT instructions each, k_sao_rgb 12, k_mc 14.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIPDEC_HOST_EMU)
+#define HIPDEC_GLOBAL __attribute__((address_space(1)))
+#else
+#define HIPDEC_GLOBAL
+#endif
+
 __device__ __forceinline__ int clip_i(int x, int maxi) { return x < 0 ? 0 : (x > maxi ? maxi : x); }
 // libheif/common_utils.h:108-114 clip_f_u16: (int32)(fx + 0.5f), then clamp
 __device__ __forceinline__ int clip_f(float fx, int maxi)

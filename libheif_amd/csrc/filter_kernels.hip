@@ -660,13 +660,15 @@ __global__ __launch_bounds__(256) void k_sao_rgb(FilterArgs A, const colordev::C
 #pragma unroll
       for (int i = 0; i < 4; i++) colordev::convert_px(cp, yres[rr][i], (int)((cb2 >> ((i >> 1) * 8)) & 255u), (int)((cr2 >> ((i >> 1) * 8)) & 255u), R[i], G[i], B[i]);
     }
-    uint8_t* o = cp.o0 + (size_t)oy * cp.os + (size_t)ox0 * 3;
+    // (typed as global memory: through the generic pointer of the parameter block these were FLAT stores, which count in lgkmcnt - every LDS wait of the
+    //  next phase waited for the RGB stores of this one)
+    HIPDEC_GLOBAL uint8_t* o = (HIPDEC_GLOBAL uint8_t*)cp.o0 + (size_t)oy * cp.os + (size_t)ox0 * 3;
     if (npx == 4 && ((cp.os | (uintptr_t)cp.o0) & 3) == 0) {
       colordev::U3 v;
       v.a = R[0] | (G[0] << 8) | (B[0] << 16) | ((uint32_t)R[1] << 24);
       v.b = G[1] | (B[1] << 8) | (R[2] << 16) | ((uint32_t)G[2] << 24);
       v.c = B[2] | (R[3] << 8) | (G[3] << 16) | ((uint32_t)B[3] << 24);
-      *(colordev::U3*)o = v;
+      *(HIPDEC_GLOBAL colordev::U3*)o = v;
     } else {
       for (int i = 0; i < npx; i++) { o[3 * i] = (uint8_t)R[i]; o[3 * i + 1] = (uint8_t)G[i]; o[3 * i + 2] = (uint8_t)B[i]; }
     }

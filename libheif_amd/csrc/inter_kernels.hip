@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include "hevc_device.h"
 #include "kernels.h"
+#include "color_device.h"
 
 namespace hipdec {
 
@@ -105,7 +106,7 @@ struct MotionCtx {
   const MotionUnit* cur;        // the current CTB's units (LDS)
   const MotionUnit* left;       // the CTB to the left, as it was derived a moment ago (LDS)
   const MotionUnit* up;         // bottom unit rows of the CTBs above-left, above and above-right (LDS): [3][units per CTB side]
-  const MotionUnit* col;        // the collocated picture's motion field (nullptr: no temporal candidates / an intra picture)
+  HIPDEC_GLOBAL const MotionUnit* col;   // the collocated picture's motion field in HBM (nullptr: no temporal candidates / an intra picture)
   const MotionUnit* col_lds;    // its units on the 16x16 grid the CTB's candidates can name, staged in LDS: [(y - y_ctb) / 16][(x - x_ctb) / 16], x up to one
                                 // grid column to the right of the CTB (bottom-right candidates; never below the CTB row, 8.5.3.2.8)
   const int* ref_poc;           // PicOrderCnt of the reference picture table's slots (LDS)
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(64) void k_motion(MotionArgs A)
     else if (lane < 32) L.ref_poc[lane - 16] = C.reftab[lane - 16].poc;
     mk_lds_sync();
     C.slice = &L.slice; C.ref_poc = L.ref_poc; C.col_lds = L.col;
-    C.col = C.slice->tmvp ? (const MotionUnit*)(uintptr_t)C.reftab[C.slice->col_slot].mf : nullptr;
+    C.col = C.slice->tmvp ? (HIPDEC_GLOBAL const MotionUnit*)(uintptr_t)C.reftab[C.slice->col_slot].mf : nullptr;
     C.cx = cx; C.cy = cy; C.avail = ci.avail; C.log2_ctb = log2_ctb; C.units_log2 = units_log2; C.lmt = P.log2_min_tb; C.ctb_w = ctb_w;
     C.width = P.width; C.height = P.height; C.poc = P.poc; C.par_mrg = P.log2_par_mrg_level; C.lt_mask = P.lt_mask;
     const int x_ctb = cx << log2_ctb, y_ctb = cy << log2_ctb;
@@ -602,7 +603,7 @@ __device__ __forceinline__ int chroma_tap(int frac, int i)
 
 // the 14-bit prediction sample of list X at (x, y) of the plane (8.5.3.3.3): integer copy, one separable pass, or both
 template <typename Pix>
-__device__ __forceinline__ int mc_sample(const Pix* ref, size_t rstride, int W, int H, int plane, int bit_depth, int x, int y, int mvx, int mvy)
+__device__ __forceinline__ int mc_sample(HIPDEC_GLOBAL const Pix* ref, size_t rstride, int W, int H, int plane, int bit_depth, int x, int y, int mvx, int mvy)
 {
   const int shift1 = bit_depth - 8 < 4 ? bit_depth - 8 : 4, shift3 = 14 - bit_depth > 2 ? 14 - bit_depth : 2;
   const int fbits = plane ? 3 : 2, taps = plane ? 4 : 8, before = plane ? 1 : 3;
@@ -652,7 +653,8 @@ __global__ __launch_bounds__(256) void k_mc(FilterArgs A, int n_planes_per_pic)
   for (int X = 0; X < 2; X++) {
     if (mu.ref_idx[X] < 0) continue;
     const RefFrame rf = reftab[mu.slot_pred[X] & 63u];
-    pred[X] = mc_sample<Pix>((const Pix*)(uintptr_t)rf.plane[plane], rf.stride[plane] / sizeof(Pix), W, H, plane, bit_depth, x, y, mu.mv[X][0], mu.mv[X][1]);
+    pred[X] = mc_sample<Pix>((HIPDEC_GLOBAL const Pix*)(uintptr_t)rf.plane[plane],   // (an integer turned pointer is generic - FLAT loads - unless typed as global memory)
+                             rf.stride[plane] / sizeof(Pix), W, H, plane, bit_depth, x, y, mu.mv[X][0], mu.mv[X][1]);
   }
   const int bi = mu.ref_idx[0] >= 0 && mu.ref_idx[1] >= 0, one = mu.ref_idx[0] >= 0 ? 0 : 1;
   const int shift1 = 14 - bit_depth, maxv = (1 << bit_depth) - 1;   // (bit depth <= 12)
