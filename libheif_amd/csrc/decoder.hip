@@ -893,7 +893,10 @@ int commit_reference(hipdec_decoder* d)
   rp.width = P.width; rp.height = P.height; rp.chroma_format_idc = P.chroma_format_idc; rp.bit_depth_luma = P.bit_depth_luma; rp.bit_depth_chroma = P.bit_depth_chroma;
   rp.log2_ctb = P.log2_ctb;
   const bool cropped = P.out_width != P.width || P.out_height != P.height || P.crop_x || P.crop_y;
-  if (!cropped) {
+  // A first picture that was decoded in a SHARED launch set (the coalescer put up to 256 instances' pictures into one arena) gets a copy of its own as
+  // well: holding the shared arena for as long as the track references the picture would pin every other instance's memory with it
+  const bool shared_set = b->pics.size() > 1;
+  if (!cropped && !shared_set) {
     for (int c = 0; c < 3; c++) { rp.plane[c] = (uint64_t)(uintptr_t)(b->arena + P.off_out[c]); rp.stride[c] = P.out_stride[c]; }
   } else {
     const size_t es = b->wide ? 2 : 1;
@@ -922,6 +925,7 @@ int commit_reference(hipdec_decoder* d)
     }
     if (e != hipSuccess) { arena_release(h.full, h.full_capacity); return set_error(HIPDEC_ERR_DEVICE, "sequence: reference picture copy: %s", hipGetErrorString(e)); }
     for (int c = 0; c < 3; c++) { rp.plane[c] = (uint64_t)(uintptr_t)(base + off[c]); rp.stride[c] = stride[c]; }
+    if (!P.is_inter) h.keep.reset();   // the copy is all later pictures need of an intra picture (an inter picture's motion field lives in the arena)
   }
   rp.mf = P.is_inter ? (uint64_t)(uintptr_t)(b->arena + P.off_mf) : 0;   // the collocated picture of later temporal candidates (the batch stays alive with it)
   d->seq.dpb.push_back(rp);

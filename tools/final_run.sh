@@ -2,7 +2,8 @@
 # round-end GPU run: the whole GPU test tier, the default bench line, a rocprofv3 kernel-stats pass over the main workload, the parser's PMC
 # passes and the HBM traffic passes -> gpurun_out/final_* (copied to profiles/r<NN>z_* by hand)
 mkdir -p gpurun_out
-timeout ${FINAL_TESTS_LIMIT:-300} python -m pytest tests -m gpu -q > gpurun_out/final_tests.log 2>&1
+python -c "import torch" 2>/dev/null   # (a cold import takes minutes on a fresh box: not inside the tier's time limit)
+timeout ${FINAL_TESTS_LIMIT:-500} python -m pytest tests -m gpu -q --timeout 400 > gpurun_out/final_tests.log 2>&1
 echo "tests rc=$?"; tail -3 gpurun_out/final_tests.log
 timeout ${FINAL_BENCH_LIMIT:-600} python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
 echo "bench rc=$?"; tail -c 300 gpurun_out/final_bench.err; head -c 300 gpurun_out/final_bench.json; echo
