@@ -237,7 +237,7 @@ def issue_roofline(kernels, px, cu_count, clock_ghz):
 def sequence_tracks(n_frames=33, tracks=16, w=1280, h=720):
     """sequence tracks through the decoder object the way libheif drives it (one sample per push_data2, pictures polled in output order,
     flush at the end): frames per second of ONE track - every picture is one CABAC critical path, the instance holds one sample at a time - and of
-    `tracks` tracks decoded side by side by as many threads (their decodes coalesce into shared launch sets).  The first pass of each kind checks
+    `tracks` tracks decoded side by side by as many threads (their first pictures and their look-ahead chains coalesce into shared launch sets).  The first pass of each kind checks
     every picture against the CPU oracle."""
     import threading
     import numpy as np
@@ -279,12 +279,17 @@ def sequence_tracks(n_frames=33, tracks=16, w=1280, h=720):
 
         play(True)
         t0 = time.perf_counter(); play(False); one = time.perf_counter() - t0
+        from libheif_amd.decoder import chain_stats
+        before = chain_stats()
         th = [threading.Thread(target=play, args=(False,)) for _ in range(tracks)]
         t0 = time.perf_counter()
         for t in th: t.start()
         for t in th: t.join()
         many = time.perf_counter() - t0
+        after = chain_stats()
         res[name] = {"one_track_fps": round(n_frames / one, 1), "ms_per_picture": round(one / n_frames * 1e3, 1), "all_tracks_fps": round(tracks * n_frames / many, 1),
+                     # side by side: the chains of tracks that ask together run as one launch set (hipdec_decoder_chain_stats)
+                     "all_tracks_chains": after[0] - before[0], "all_tracks_launch_sets": after[1] - before[1],
                      "kbytes_per_picture": round(sum(len(a) for a in aus) / len(aus) / 1e3, 1), "verified_against_oracle": True}
         lib.hipdec_set_sequence_lookahead(0)          # round 4's behaviour beside it: every sample decoded at the poll behind its push
         t0 = time.perf_counter(); play(False); res[name]["one_track_fps_without_lookahead"] = round(n_frames / (time.perf_counter() - t0), 1)

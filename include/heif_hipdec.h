@@ -122,6 +122,12 @@ HIPDEC_API int hipdec_decoder_next_picture(hipdec_decoder* dec, int flush, hipde
  * serial host never waits.  HIPDEC_COALESCE_WINDOW_US (default 2000, 0 = off) bounds the gathering time.
  * Counters since load: decode requests, launch sets issued, requests that shared a launch set with others. */
 HIPDEC_API void hipdec_decoder_coalesce_stats(uint64_t* requests, uint64_t* launch_sets, uint64_t* shared_requests);
+/* The same for sequence tracks decoded side by side (one decoder instance and one host thread per track, as libheif's Track_Visual objects,
+ * libheif/sequences/track_visual.cc:200-280, are): the look-ahead chains (hipdec_set_sequence_lookahead) of instances that ask within
+ * HIPDEC_CHAIN_WINDOW_US (default 20000; 0 = every chain on its own) of each other run as ONE launch set - step k of the set holds the k-th
+ * dependency step of every track.  A leader only waits for instances that took part in a chain during the last second; a lone track never waits.
+ * Counters since load: chains asked for, launch sets issued for them, launch sets that held more than one track's chain. */
+HIPDEC_API void hipdec_decoder_chain_stats(uint64_t* chains, uint64_t* launch_sets, uint64_t* shared_launch_sets);
 
 /* Host-only header probe: parses the parameter sets and slice segment headers of one pushed item
  * and fills `info` without touching the GPU (what libheif's own SPS pre-check does in

@@ -78,39 +78,97 @@ RefPicture chain_ref_picture(const BatchLayout& b, int j, uint64_t arena_base)
   return rp;
 }
 
-void chain_resolve(BatchLayout& b, uint64_t arena_base, std::vector<int>& own)
+void chain_resolve(BatchLayout& b, uint64_t arena_base, std::vector<int>& own, int track)
 {
   own.clear();
-  for (RefPicture& rp : b.seq_after.dpb)
+  for (RefPicture& rp : b.tracks[(size_t)track].seq_after.dpb)
     if (rp.batch_item >= 0) { rp = chain_ref_picture(b, rp.batch_item, arena_base); own.push_back(rp.poc); }
 }
 
 int layout_batch_plan_chain(BatchLayout& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels, std::string& err_out,
                             const SeqContext& seq)
 {
+  const int first = 0;
+  const SeqContext* seqs[1] = {&seq};
+  return layout_batch_plan_chains(b, 1, &first, &n, data, sizes, max_pixels, err_out, seqs);
+}
+
+int layout_batch_plan_chains(BatchLayout& b, int n_tracks, const int* first, const int* count, const void* const* data, const size_t* sizes,
+                             uint64_t max_pixels, std::string& err_out, const SeqContext* const* seqs, int* bad_track)
+{
   b.chain = true;
-  b.pics.clear(); b.src_index.clear();
-  SeqContext work = seq;
-  for (int i = 0; i < n; i++) {
-    ParsedPicture pp;
-    std::string err;
-    const int rc = parse_picture((const uint8_t*)data[i], sizes[i], max_pixels, pp, err, &work);
-    if (rc != HIPDEC_OK) { err_out = "sample " + std::to_string(i) + " of the chain: " + err; return rc; }
-    if (pp.skipped) continue;
-    // the picture becomes a reference picture of the samples behind it (8.3.2 keeps / drops through their RPS): addressed as "item j of this batch"
-    seq_commit(work, pp);
-    RefPicture rp;
-    rp.poc = pp.poc; rp.batch_item = (int)b.pics.size();
-    rp.width = pp.sps.pic_width; rp.height = pp.sps.pic_height; rp.chroma_format_idc = pp.sps.chroma_format_idc;
-    rp.bit_depth_luma = pp.sps.bit_depth_luma; rp.bit_depth_chroma = pp.sps.bit_depth_chroma; rp.log2_ctb = pp.sps.log2_ctb;
-    work.dpb.push_back(rp);
-    b.pics.push_back(std::move(pp));
-    b.src_index.push_back(i);
-  }
-  b.seq_after = work;
-  if (b.pics.empty()) return HIPDEC_OK;
+  b.pics.clear(); b.src_index.clear(); b.pixel_step_of.clear(); b.motion_step_of.clear();
+  b.tracks.assign((size_t)n_tracks, BatchLayout::ChainTrack{});
+  if (bad_track) *bad_track = -1;
+  // every track on its own first: its samples one after the other against a working copy of its sequence state (a decoded sample becomes a
+  // reference picture of the samples behind it, 8.3.2 keeps / drops it through their RPS: addressed as "picture j of this track's chain"), and
+  // the track's steps (batch_layout.h)
+  struct Planned { ParsedPicture pp; int sample = 0, px = 0, mo = 0; };
+  std::vector<std::vector<Planned>> planned((size_t)n_tracks);
+  std::vector<int> rcs((size_t)n_tracks, HIPDEC_OK);
+  std::vector<std::string> errs((size_t)n_tracks);
+  size_t total = 0;
+  for (int t = 0; t < n_tracks; t++) for (int i = 0; i < count[t]; i++) total += sizes[first[t] + i];
+  for_each_item(n_tracks, n_tracks >= 4 ? std::max(total, size_t(8) << 20) : 0, [&](int t) {
+    SeqContext work = *seqs[t];
+    std::vector<Planned>& mine = planned[(size_t)t];
+    int px_first = 0, mo_first = 0, px = 0, mo = 0;
+    for (int i = 0; i < count[t]; i++) {
+      Planned pl;
+      std::string err;
+      const int rc = parse_picture((const uint8_t*)data[first[t] + i], sizes[first[t] + i], max_pixels, pl.pp, err, &work);
+      if (rc != HIPDEC_OK) { rcs[(size_t)t] = rc; errs[(size_t)t] = "sample " + std::to_string(i) + " of the chain: " + err; return; }
+      if (pl.pp.skipped) continue;
+      const int j = (int)mine.size();
+      bool px_dep = false, mo_dep = false;
+      for (const RefPicture& rp : pl.pp.refs) if (rp.batch_item >= px_first) px_dep = true;
+      for (const ParsedSlice& sl : pl.pp.slices)
+        if (sl.sp.is_p && sl.sp.tmvp && sl.sp.col_slot < pl.pp.refs.size() && pl.pp.refs[sl.sp.col_slot].batch_item >= mo_first) mo_dep = true;
+      if (px_dep) { px++; px_first = j; }
+      if (mo_dep) { mo++; mo_first = j; }
+      pl.sample = i; pl.px = px; pl.mo = mo;
+      seq_commit(work, pl.pp);
+      RefPicture rp;
+      rp.poc = pl.pp.poc; rp.batch_item = j;
+      rp.width = pl.pp.sps.pic_width; rp.height = pl.pp.sps.pic_height; rp.chroma_format_idc = pl.pp.sps.chroma_format_idc;
+      rp.bit_depth_luma = pl.pp.sps.bit_depth_luma; rp.bit_depth_chroma = pl.pp.sps.bit_depth_chroma; rp.log2_ctb = pl.pp.sps.log2_ctb;
+      work.dpb.push_back(rp);
+      mine.push_back(std::move(pl));
+    }
+    b.tracks[(size_t)t].seq_after = std::move(work);
+  });
+  for (int t = 0; t < n_tracks; t++)
+    if (rcs[(size_t)t] != HIPDEC_OK) {
+      err_out = n_tracks > 1 ? "track " + std::to_string(t) + " of the launch set, " + errs[(size_t)t] : errs[(size_t)t];
+      if (bad_track) *bad_track = t;
+      return rcs[(size_t)t];
+    }
+  // the batch's items: by (pixel step, track, decoding order); "picture j of the track's chain" becomes "item g of the batch"
+  int steps = 0;
+  for (const auto& mine : planned) if (!mine.empty()) steps = std::max(steps, mine.back().px + 1);
+  std::vector<std::vector<int>> item_of((size_t)n_tracks);
+  for (int t = 0; t < n_tracks; t++) item_of[(size_t)t].assign(planned[(size_t)t].size(), -1);
+  std::vector<size_t> cursor((size_t)n_tracks, 0);
   std::vector<size_t> item_sizes;
-  for (int j : b.src_index) item_sizes.push_back(sizes[j]);
+  for (int k = 0; k < steps; k++)
+    for (int t = 0; t < n_tracks; t++) {
+      std::vector<Planned>& mine = planned[(size_t)t];
+      for (size_t& j = cursor[(size_t)t]; j < mine.size() && mine[j].px == k; j++) {
+        const int g = (int)b.pics.size();
+        item_of[(size_t)t][j] = g;
+        b.tracks[(size_t)t].items.push_back(g); b.tracks[(size_t)t].samples.push_back(mine[j].sample);
+        b.src_index.push_back(first[t] + mine[j].sample);
+        b.pixel_step_of.push_back(k); b.motion_step_of.push_back(mine[j].mo);
+        item_sizes.push_back(sizes[first[t] + mine[j].sample]);
+        b.pics.push_back(std::move(mine[j].pp));
+      }
+    }
+  for (int t = 0; t < n_tracks; t++) {
+    for (int g : b.tracks[(size_t)t].items)
+      for (RefPicture& rp : b.pics[(size_t)g].refs) if (rp.batch_item >= 0) rp.batch_item = item_of[(size_t)t][(size_t)rp.batch_item];
+    for (RefPicture& rp : b.tracks[(size_t)t].seq_after.dpb) if (rp.batch_item >= 0) rp.batch_item = item_of[(size_t)t][(size_t)rp.batch_item];
+  }
+  if (b.pics.empty()) return HIPDEC_OK;
   return layout_core(b, item_sizes.data(), err_out);
 }
 
@@ -323,35 +381,26 @@ int layout_core(BatchLayout& b, const size_t* sizes, std::string& err_out)
   }
   b.arena_size = off;
   if (b.chain) {
-    // steps (batch_layout.h): where does an item depend on an earlier item of the run that is being gathered?
-    b.pixel_steps.clear(); b.motion_steps.clear(); b.motion_step_of.assign((size_t)n, 0);
-    auto close = [&](std::vector<BatchLayout::ChainStep>& steps, int first, int end) {
-      BatchLayout::ChainStep st;
-      st.first = first; st.count = end - first;
-      st.first_rwave = b.chain_items[(size_t)first].first_rwave;
-      st.first_row = b.params[(size_t)first].first_row;
-      for (int i = first; i < end; i++) {
-        const PicParams& P = b.params[(size_t)i];
-        st.num_rwaves += b.chain_items[(size_t)i].num_rwaves; st.num_rows += (uint32_t)P.ctb_h;
-        st.max_w = std::max(st.max_w, (int)P.width); st.max_h = std::max(st.max_h, (int)P.height);
-        st.max_ow = std::max(st.max_ow, (int)P.out_width); st.max_oh = std::max(st.max_oh, (int)P.out_height);
-        st.any_inter = st.any_inter || P.is_inter;
-      }
-      steps.push_back(st);
+    // steps (batch_layout.h): the plan numbered them per item; a pixel step is a range of items, a motion step a range of the RowDesc table
+    int n_px = 0, n_mo = 0;
+    for (int i = 0; i < n; i++) { n_px = std::max(n_px, b.pixel_step_of[(size_t)i] + 1); n_mo = std::max(n_mo, b.motion_step_of[(size_t)i] + 1); }
+    b.pixel_steps.assign((size_t)n_px, BatchLayout::ChainStep{}); b.motion_steps.assign((size_t)n_mo, BatchLayout::ChainStep{});
+    auto add = [&](BatchLayout::ChainStep& st, int i) {
+      const PicParams& P = b.params[(size_t)i];
+      st.count++; st.num_rwaves += b.chain_items[(size_t)i].num_rwaves; st.num_rows += (uint32_t)P.ctb_h;
+      st.max_w = std::max(st.max_w, (int)P.width); st.max_h = std::max(st.max_h, (int)P.height);
+      st.max_ow = std::max(st.max_ow, (int)P.out_width); st.max_oh = std::max(st.max_oh, (int)P.out_height);
+      st.any_inter = st.any_inter || P.is_inter;
     };
-    int px_first = 0, mo_first = 0;
     for (int i = 0; i < n; i++) {
-      const ParsedPicture& pp = b.pics[(size_t)i];
-      bool px_dep = false, mo_dep = false;
-      for (const RefPicture& rp : pp.refs) if (rp.batch_item >= px_first) px_dep = true;
-      for (const ParsedSlice& sl : pp.slices)
-        if (sl.sp.is_p && sl.sp.tmvp && sl.sp.col_slot < pp.refs.size() && pp.refs[sl.sp.col_slot].batch_item >= mo_first) mo_dep = true;
-      if (px_dep) { close(b.pixel_steps, px_first, i); px_first = i; }
-      if (mo_dep) { close(b.motion_steps, mo_first, i); mo_first = i; }
-      b.motion_step_of[(size_t)i] = (int)b.motion_steps.size();
+      BatchLayout::ChainStep& px = b.pixel_steps[(size_t)b.pixel_step_of[(size_t)i]];
+      if (!px.count) { px.first = i; px.first_rwave = b.chain_items[(size_t)i].first_rwave; }
+      add(px, i);
+      px.motion_need = std::max(px.motion_need, b.motion_step_of[(size_t)i] + 1);
+      add(b.motion_steps[(size_t)b.motion_step_of[(size_t)i]], i);
     }
-    close(b.pixel_steps, px_first, n);
-    close(b.motion_steps, mo_first, n);
+    uint32_t row = 0;
+    for (auto& mo : b.motion_steps) { mo.first_row = row; row += mo.num_rows; }
   }
   return HIPDEC_OK;
 }
@@ -382,8 +431,13 @@ void layout_batch_fill(BatchLayout& b, const void* const* data, const size_t* si
     for (size_t k = 0; k < pp.subs.size(); k++)
       if (subs[sub_base + k].dep_sub >= 0) subs[subs[sub_base + k].dep_sub].dependent = (int32_t)(sub_base + k);
     sub_base += (uint32_t)pp.subs.size();
-    for (int y = 0; y < P.ctb_h; y++) { rows[r].pic = (uint32_t)i; rows[r].row = (uint32_t)y; r++; }
+    if (!b.chain) for (int y = 0; y < P.ctb_h; y++) { rows[r].pic = (uint32_t)i; rows[r].row = (uint32_t)y; r++; }
   }
+  if (b.chain)   // by (motion step, item): k_motion takes a step's rows as one range (a picture's rows ascending: row r waits for row r - 1)
+    for (int m = 0; m < (int)b.motion_steps.size(); m++)
+      for (int i = 0; i < n; i++)
+        if (b.motion_step_of[(size_t)i] == m)
+          for (int y = 0; y < b.params[(size_t)i].ctb_h; y++) { rows[r].pic = (uint32_t)i; rows[r].row = (uint32_t)y; r++; }
   size_t total = 0;
   for (int i = 0; i < n; i++) total += sizes[b.src(i)];
   const size_t items_end = b.chain ? [&]() { for (const auto& ci : b.chain_items) if (ci.off_full_pic) return ci.off_full_pic; return b.upload_size; }() : b.upload_size;

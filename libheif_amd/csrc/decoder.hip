@@ -115,14 +115,16 @@ namespace {
 // batches), staging and the upload.  Large upload regions go through pinned staging and ONE asynchronous copy on the
 // library's upload stream, so that hipdec_batch_create() of batch k+1 overlaps the kernels of batch k; small ones (a still, the
 // tiles of a grid photo) are copied synchronously from pageable memory, which is quicker than pinning.
-// chain_seq: the n items are consecutive samples of ONE sequence track whose state is *chain_seq (BatchLayout::chain): the batch may come out EMPTY
-// (every sample was a RASL picture 8.3.3 drops) - then nothing is allocated
+// chains: the n items are consecutive samples of sequence tracks (BatchLayout::chain; items [first[t], first[t] + count[t]) belong to track t whose
+// state is *seqs[t]): the batch may come out EMPTY (every sample was a RASL picture 8.3.3 drops) - then nothing is allocated
+struct ChainPlan { int n_tracks; const int* first; const int* count; const SeqContext* const* seqs; int* bad_track; };
 int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels, hipdec_batch* recycle = nullptr,
-                const SeqContext* const* seqs = nullptr, const SeqContext* chain_seq = nullptr)
+                const SeqContext* const* seqs = nullptr, const ChainPlan* chains = nullptr)
 {
   std::string err;
   b.device = active_device();
-  int rc = chain_seq ? layout_batch_plan_chain(b, n, data, sizes, max_pixels, err, *chain_seq) : layout_batch_plan(b, n, data, sizes, max_pixels, err, seqs);
+  int rc = chains ? layout_batch_plan_chains(b, chains->n_tracks, chains->first, chains->count, data, sizes, max_pixels, err, chains->seqs, chains->bad_track)
+                  : layout_batch_plan(b, n, data, sizes, max_pixels, err, seqs);
   if (rc != HIPDEC_OK) return set_error(rc, "%s", err.c_str());
   if (b.pics.empty()) return 0;
   HIPDEC_CHECK_HIP(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
@@ -267,7 +269,7 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
     int motion_done = 0;
     for (size_t k = 0; k < b.pixel_steps.size(); k++) {
       const BatchLayout::ChainStep& st = b.pixel_steps[k];
-      const int need = b.motion_step_of[(size_t)(st.first + st.count - 1)] + 1;
+      const int need = st.motion_need;
       if (ms) { if (st.any_inter) HIPDEC_CHECK_HIP(hipStreamWaitEvent(ps, b.chain_events[(size_t)need - 1], 0)); }
       else for (; motion_done < need; motion_done++) launch_chain_motion(b, b.arena, motion_done, ps);
       launch_chain_pixels(b, b.arena, (int)k, ps);
@@ -798,6 +800,8 @@ struct hipdec_decoder {
   //      them - parsing needs nothing of another picture - and the pixel stages picture by picture.  libheif's track loop pushes the next sample
   //      whenever decode_next_image2 returns no image (sequences/track_visual.cc:200-260), so holding samples back costs it nothing.
   SampleQueue sq;                        // (hevc_headers.h: pure host logic, tested and fuzzed on the CPU)
+  std::chrono::steady_clock::time_point chain_active{};   // when the instance last asked for / got a chain (ChainCoalescer: whom a leader waits for)
+  bool chain_in_flight = false;                           // its chain is inside a running launch set
   hipdec_batch* plane_batch() const { return out.batch ? out.batch.get() : batch.get(); }
   int plane_item() const { return out.batch ? out.item : item; }
   ~hipdec_decoder()
@@ -1053,6 +1057,16 @@ void uncount(hipdec_decoder* d)   // g_co.mu held
 
 }  // namespace
 
+namespace { void chain_member_add(hipdec_decoder* d); void chain_member_remove(hipdec_decoder* d); void g_chains_notify(); }
+// the first picture was decoded and more data arrives: the instance becomes a sequence decoder; that picture may be referenced by the samples that follow
+static int seq_activate(hipdec_decoder* d)
+{
+  if (int rc = commit_reference(d)) return rc;
+  d->seq_active = true;
+  chain_member_add(d);
+  return 0;
+}
+
 int hipdec_decoder_new(hipdec_decoder** out, int strict_decoding, uint64_t max_image_size_pixels)
 {
   if (!out) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "decoder_new: out is NULL");
@@ -1077,6 +1091,10 @@ void hipdec_decoder_free(hipdec_decoder* d)
     std::lock_guard<std::mutex> lock(g_co.mu);
     uncount(d);
     g_co.cv.notify_all();   // a leader may be waiting for this instance to join
+  }
+  if (d->seq_active) {
+    chain_member_remove(d);
+    g_chains_notify();      // (the same for the leader of a chain launch set)
   }
   delete d;
 }
@@ -1103,8 +1121,7 @@ int hipdec_decoder_push_data(hipdec_decoder* d, const void* data, size_t size)
     // one by one; only a chunk's first sample carries the parameter sets, codecs/decoder.cc:422) and waits in the look-ahead queue.
     if (d->decoded && !d->seq_active) {
       // the first picture was decoded and more data arrives: the instance becomes a sequence decoder; that picture may be referenced by the samples that follow
-      if (int rc = commit_reference(d)) return rc;
-      d->seq_active = true;
+      if (int rc = seq_activate(d)) return rc;
       d->sq.first_closed = true;
     }
     d->sq.push(p, size);
@@ -1137,7 +1154,7 @@ int hipdec_decoder_decode(hipdec_decoder* d, hipdec_image_info* info)
     for (;;) {
       while (!d->sq.queue.empty() && !d->sq.queue.front().has_vcl && d->sq.queue.size() > 1) d->sq.queue.pop_front();   // (parameter sets / SEI only: nothing to decode)
       if (d->sq.queue.empty() || !d->sq.queue.front().has_vcl) return set_error(HIPDEC_ERR_NO_IMAGE, "no further image");
-      if (!d->seq_active) { if (int rc = commit_reference(d)) return rc; d->seq_active = true; }
+      if (!d->seq_active) { if (int rc = seq_activate(d)) return rc; }
       std::vector<hipdec_decoder::Output> outs;
       if (int rc = decode_chain(d, 1, &outs)) return rc;
       if (outs.empty()) continue;   // the sample was a RASL picture 8.3.3 drops: the next one
@@ -1289,42 +1306,232 @@ void hipdec_decoder_set_user_data(hipdec_decoder* d, uintptr_t user_data)
   d->sq.set_user_data(user_data);   // of the sample(s) the last push brought (push_data2's argument)
 }
 
-// The queued samples [0, n) as ONE chain (batch_layout.h): parsed against the track's sequence state one after the other on the host, one CABAC
-// launch and one residual launch over all of them, the pixel stages picture by picture.  Afterwards the state sits behind the last of them, the
-// DPB holds name this batch for its pictures, and `outputs` lists the decoded pictures in decoding order.
+// ---- chains ------------------------------------------------------------------------------------------------------------------------------
+// The queued samples [0, n) of a track as ONE chain (batch_layout.h): parsed against the track's sequence state one after the other on the host, one
+// CABAC launch and one residual launch over all of them, the pixel stages step by step.  Tracks that are decoded side by side (one decoder
+// instance and one host thread each, as libheif's Track_Visual objects are) ask within a few milliseconds of each other - they were served by the
+// same launch set a moment ago - so, like the still-image requests above, their chains are gathered by the first one that asks and run as ONE
+// launch set: step k holds the k-th step of every track, and the small wavefront kernels (k_motion: one wave per CTB row) of 16 tracks become
+// one launch of 16 x as many waves instead of 16 launches that mostly run one after the other (profiles/r05_sequence_fps.txt).
+namespace {
+
+struct ChainRequest {
+  hipdec_decoder* d = nullptr;
+  size_t n = 0;
+  int device = 0;
+  int rc = 0;
+  std::string err;
+  bool taken = false, done = false;
+  std::shared_ptr<hipdec_batch> batch;   // the launch set that decoded the samples ...
+  int track = 0;                         // ... and which of its tracks they are
+};
+
+struct ChainCoalescer {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<ChainRequest*> pending;
+  bool collecting = false;
+  std::vector<hipdec_decoder*> members;   // live sequence decoders
+  int in_flight = 0;                      // chains inside running launch sets
+  Clock::time_point last_overlap{};       // when a request last arrived while another one was waiting or running: the host decodes tracks side by side
+  long window_us = -1;                    // how long a leader waits for tracks that were active a moment ago and are idle now (HIPDEC_CHAIN_WINDOW_US; 0: every
+                                          // chain on its own); for tracks whose chain is inside a running launch set it waits up to flight_us: a track that fell
+                                          // out of step would otherwise run beside the others' set for good (a chain alone takes as long as 16 together)
+  long flight_us = 250000;
+  long max_pictures = 1024;               // samples per launch set at most (HIPDEC_CHAIN_MAX_PICTURES): bounds the arena (~7 MB per 720p picture)
+  uint64_t n_sets = 0, n_shared_sets = 0, n_chains = 0;
+} g_chains;
+
+long chain_window_us()
+{
+  if (g_chains.window_us < 0) {
+    const char* e = std::getenv("HIPDEC_CHAIN_WINDOW_US");
+    g_chains.window_us = e ? std::max(0L, std::atol(e)) : 20000;
+    if (const char* q = std::getenv("HIPDEC_CHAIN_FLIGHT_US")) g_chains.flight_us = std::max(0L, std::atol(q));
+    if (const char* q = std::getenv("HIPDEC_CHAIN_MAX_PICTURES")) g_chains.max_pictures = std::max(1L, std::atol(q));
+  }
+  return g_chains.window_us;
+}
+
+// one launch set for the chains of `group` (all on one device, with one security limit); false: it could not be built or failed on the device
+bool run_chain_set(std::vector<ChainRequest*>& group)
+{
+  std::vector<const void*> ptrs;
+  std::vector<size_t> sizes;
+  std::vector<int> first, count;
+  std::vector<const SeqContext*> seqs;
+  for (ChainRequest* r : group) {
+    first.push_back((int)ptrs.size()); count.push_back((int)r->n); seqs.push_back(&r->d->seq);
+    for (size_t i = 0; i < r->n; i++) { ptrs.push_back(r->d->sq.queue[i].blob.data()); sizes.push_back(r->d->sq.queue[i].blob.size()); }
+  }
+  DeviceScope scope(group[0]->device);
+  std::shared_ptr<hipdec_batch> sp(new hipdec_batch());
+  hipdec_batch& b = *sp;
+  int bad = -1;
+  const ChainPlan plan{(int)group.size(), first.data(), count.data(), seqs.data(), &bad};
+  static const bool trace = getenv("HIPDEC_CHAIN_TRACE") != nullptr;   // dev knob: where a chain launch set's wall time goes
+  const auto t0 = Clock::now();
+  int rc = build_batch(b, (int)ptrs.size(), ptrs.data(), sizes.data(), group[0]->d->max_pixels, nullptr, nullptr, &plan);
+  const auto t1 = Clock::now();
+  auto t2 = t1;
+  if (!rc && !b.pics.empty()) {
+    hipStream_t s = stream_acquire();
+    rc = hipdec_batch_run(&b, (void*)s);
+    if (!rc) rc = stage_planes_to_host(b, follow_stream(&b, (void*)s));
+    t2 = Clock::now();
+    if (!rc) rc = hipdec_batch_status(&b);   // synchronises
+    else (void)hipStreamSynchronize(s);
+    b.last_stream = nullptr;
+    stream_release(s);
+  }
+  if (trace) {
+    auto ms = [](Clock::time_point a, Clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+    fprintf(stderr, "[hipdec] chain set: %zu tracks, %zu pictures, %zu pixel / %zu motion steps: build %.1f ms, enqueue %.1f ms, wait %.1f ms, rc %d\n", group.size(),
+            b.pics.size(), b.pixel_steps.size(), b.motion_steps.size(), ms(t0, t1), ms(t1, t2), ms(t2, Clock::now()), rc);
+  }
+  if (rc) {
+    if (group.size() > 1) return false;   // every track on its own then: the one with the bad sample alone gets the error
+    group[0]->rc = rc; group[0]->err = hipdec_last_error();
+    return true;
+  }
+  for (size_t t = 0; t < group.size(); t++) { group[t]->rc = 0; group[t]->batch = sp; group[t]->track = (int)t; }
+  return true;
+}
+
+void run_chain_requests(std::vector<ChainRequest*>& take)
+{
+  std::vector<bool> used(take.size(), false);
+  for (size_t i = 0; i < take.size(); i++) {
+    if (used[i]) continue;
+    std::vector<ChainRequest*> group;   // security limits are per instance, arenas per device: only equal ones share a launch set
+    for (size_t j = i; j < take.size(); j++)
+      if (!used[j] && take[j]->d->max_pixels == take[i]->d->max_pixels && take[j]->device == take[i]->device) { used[j] = true; group.push_back(take[j]); }
+    bool ok = false;
+    try { ok = run_chain_set(group); } catch (...) { ok = false; }
+    if (!ok)
+      for (ChainRequest* r : group) {
+        std::vector<ChainRequest*> one{r};
+        try { (void)run_chain_set(one); } catch (const std::exception& e) { r->rc = HIPDEC_ERR_MEMORY; r->err = std::string("decode: ") + e.what(); }
+      }
+    std::lock_guard<std::mutex> lock(g_chains.mu);
+    g_chains.n_sets += ok ? 1 : group.size();
+    if (ok && group.size() > 1) g_chains.n_shared_sets++;
+  }
+}
+
+void chain_member_add(hipdec_decoder* d)
+{
+  std::lock_guard<std::mutex> lock(g_chains.mu);
+  if (std::find(g_chains.members.begin(), g_chains.members.end(), d) == g_chains.members.end()) g_chains.members.push_back(d);
+  d->chain_active = Clock::now();
+}
+void chain_member_remove(hipdec_decoder* d)
+{
+  std::lock_guard<std::mutex> lock(g_chains.mu);
+  g_chains.members.erase(std::remove(g_chains.members.begin(), g_chains.members.end(), d), g_chains.members.end());
+}
+void g_chains_notify() { g_chains.cv.notify_all(); }
+
+}  // namespace
+
+extern "C" void hipdec_decoder_chain_stats(uint64_t* chains, uint64_t* launch_sets, uint64_t* shared_launch_sets)
+{
+  std::lock_guard<std::mutex> lock(g_chains.mu);
+  if (chains) *chains = g_chains.n_chains;
+  if (launch_sets) *launch_sets = g_chains.n_sets;
+  if (shared_launch_sets) *shared_launch_sets = g_chains.n_shared_sets;
+}
+
+// Afterwards the track's state sits behind the last of the samples, the DPB holds name the launch set for its pictures, and `outputs` lists the
+// decoded pictures in decoding order.
 static int decode_chain(hipdec_decoder* d, size_t n, std::vector<hipdec_decoder::Output>* outputs)
 {
   if (n > d->sq.queue.size()) n = d->sq.queue.size();
   if (!n) return 0;
-  std::vector<const void*> ptrs;
-  std::vector<size_t> sizes;
-  for (size_t i = 0; i < n; i++) { ptrs.push_back(d->sq.queue[i].blob.data()); sizes.push_back(d->sq.queue[i].blob.size()); }
   if (int rc = ensure_init()) return rc;
-  std::shared_ptr<hipdec_batch> sp(new hipdec_batch());
-  hipdec_batch& b = *sp;
+  ChainRequest req;
+  req.d = d; req.n = n; req.device = active_device();
+  const long window = chain_window_us();
+  {
+    std::unique_lock<std::mutex> lk(g_chains.mu);
+    g_chains.n_chains++;
+    d->chain_active = Clock::now();
+    if (!g_chains.pending.empty() || g_chains.in_flight > 0) g_chains.last_overlap = d->chain_active;
+    g_chains.pending.push_back(&req);
+    g_chains.cv.notify_all();
+    while (!req.done) {
+      if (req.taken || g_chains.collecting) { g_chains.cv.wait(lk); continue; }
+      // leader: wait for the tracks that were served a moment ago (they are reading their pictures out and pushing the next samples), then run
+      // everything that asked as one launch set.  A host that decodes its tracks one after the other (requests never overlap) never waits.
+      g_chains.collecting = true;
+      std::vector<ChainRequest*> take;
+      try {
+        const auto t0 = Clock::now();
+        const bool side_by_side = window > 0 && g_chains.last_overlap.time_since_epoch().count() != 0 && t0 - g_chains.last_overlap < std::chrono::seconds(1);
+        const auto idle_deadline = t0 + std::chrono::microseconds(window), flight_deadline = t0 + std::chrono::microseconds(std::max(window, g_chains.flight_us));
+        while (side_by_side) {
+          const auto t = Clock::now();
+          bool idle_joiners = false, flying_joiners = false;
+          for (hipdec_decoder* m : g_chains.members) {
+            if (t - m->chain_active > std::chrono::seconds(1)) continue;
+            bool asked = false;
+            for (ChainRequest* r : g_chains.pending) if (r->d == m) asked = true;
+            if (asked) continue;
+            if (m->chain_in_flight) flying_joiners = true; else idle_joiners = true;
+          }
+          const bool wait_idle = idle_joiners && t < idle_deadline, wait_flying = flying_joiners && t < flight_deadline;
+          if (!wait_idle && !wait_flying) break;
+          g_chains.cv.wait_until(lk, wait_flying ? flight_deadline : idle_deadline);
+        }
+        long pictures = 0;
+        take.push_back(&req); pictures += (long)req.n;
+        for (ChainRequest* r : g_chains.pending)
+          if (r != &req && pictures + (long)r->n <= g_chains.max_pictures) { take.push_back(r); pictures += (long)r->n; }
+        g_chains.pending.erase(std::remove_if(g_chains.pending.begin(), g_chains.pending.end(),
+                                              [&](ChainRequest* r) { return std::find(take.begin(), take.end(), r) != take.end(); }),
+                               g_chains.pending.end());
+        for (ChainRequest* r : take) { r->taken = true; r->d->chain_in_flight = true; }
+        g_chains.in_flight += (int)take.size();
+        g_chains.collecting = false;
+        g_chains.cv.notify_all();
+        lk.unlock();
+        run_chain_requests(take);
+        lk.lock();
+      } catch (...) {
+        if (!lk.owns_lock()) lk.lock();
+        g_chains.collecting = false;
+        g_chains.pending.erase(std::remove(g_chains.pending.begin(), g_chains.pending.end(), &req), g_chains.pending.end());
+        for (ChainRequest* r : take)
+          if (!r->done) {
+            if (!r->rc && !r->batch) { r->rc = HIPDEC_ERR_MEMORY; r->err = "decode: out of memory while building a shared launch set"; }
+            if (r->taken) { r->d->chain_in_flight = false; g_chains.in_flight--; }
+            r->done = true;
+          }
+        g_chains.cv.notify_all();
+        throw;
+      }
+      const auto now = Clock::now();
+      g_chains.in_flight -= (int)take.size();
+      for (ChainRequest* r : take) { r->done = true; r->d->chain_in_flight = false; r->d->chain_active = now; }
+      g_chains.cv.notify_all();
+    }
+  }
   // (a chain that fails - a sample the front end refuses, a corrupt one - is dropped as a whole: the host gets the error once, not at every poll)
   auto drop = [&]() { d->sq.drop_front(n); };
-  if (int rc = build_batch(b, (int)n, ptrs.data(), sizes.data(), d->max_pixels, nullptr, nullptr, &d->seq)) { drop(); return rc; }
   {
     std::lock_guard<std::mutex> lock(g_co.mu);
     g_co.n_requests += n;
     g_co.n_launch_sets++;
   }
-  if (!b.pics.empty()) {
-    hipStream_t s = stream_acquire();
-    int rc = hipdec_batch_run(&b, (void*)s);
-    if (!rc) rc = stage_planes_to_host(b, follow_stream(&b, (void*)s));
-    if (!rc) rc = hipdec_batch_status(&b);   // synchronises
-    else (void)hipStreamSynchronize(s);
-    b.last_stream = nullptr;
-    stream_release(s);
-    if (rc) { drop(); return rc; }
-  }
-  // the sequence state moves behind the chain; its pictures' memory is this batch's arena
+  if (req.rc) { drop(); return set_error(req.rc, "%s", req.err.c_str()); }
+  std::shared_ptr<hipdec_batch> sp = req.batch;
+  hipdec_batch& b = *sp;
+  BatchLayout::ChainTrack& tr = b.tracks[(size_t)req.track];
+  // the sequence state moves behind the chain; its pictures' memory is the launch set's arena
   std::vector<int> own;
-  if (!b.pics.empty()) chain_resolve(b, (uint64_t)(uintptr_t)b.arena, own);
+  if (!tr.items.empty()) chain_resolve(b, (uint64_t)(uintptr_t)b.arena, own, req.track);
   std::vector<hipdec_decoder::DpbHold> holds;
-  for (const RefPicture& rp : b.seq_after.dpb) {
+  for (const RefPicture& rp : tr.seq_after.dpb) {
     if (std::find(own.begin(), own.end(), rp.poc) != own.end()) {
       hipdec_decoder::DpbHold h; h.poc = rp.poc; h.keep = sp; h.device = b.device;
       holds.push_back(std::move(h));
@@ -1334,13 +1541,14 @@ static int decode_chain(hipdec_decoder* d, size_t n, std::vector<hipdec_decoder:
   }
   for (auto& h : d->dpb) if (h.full) { DeviceScope scope(h.device); arena_release(h.full, h.full_capacity); }
   d->dpb.swap(holds);
-  d->seq = b.seq_after;
-  for (size_t i = 0; i < b.pics.size(); i++) {
-    const ParsedPicture& pp = b.pics[i];
+  d->seq = tr.seq_after;
+  for (size_t k = 0; k < tr.items.size(); k++) {
+    const int i = tr.items[k];
+    const ParsedPicture& pp = b.pics[(size_t)i];
     if (pp.is_idr) d->cvs++;   // POCs start over: everything still waiting precedes this picture in output order
     if (!outputs) continue;
     hipdec_decoder::Output o;
-    o.batch = sp; o.item = (int)i; o.poc = pp.poc; o.cvs = d->cvs; o.user_data = d->sq.queue[(size_t)b.src((int)i)].user_data; o.pic_output = pp.pic_output;
+    o.batch = sp; o.item = i; o.poc = pp.poc; o.cvs = d->cvs; o.user_data = d->sq.queue[(size_t)tr.samples[k]].user_data; o.pic_output = pp.pic_output;
     outputs->push_back(std::move(o));
   }
   drop();
@@ -1394,7 +1602,7 @@ int hipdec_decoder_next_picture(hipdec_decoder* d, int flush, hipdec_image_info*
       for (const auto& sm : d->sq.queue) if (sm.has_vcl) ready++;
       const size_t k = (size_t)std::max(1L, seq_lookahead());
       if (!d->decoded || !ready || !(flush || ready >= k)) break;
-      if (!d->seq_active) { if (int rc = commit_reference(d)) return rc; d->seq_active = true; }
+      if (!d->seq_active) { if (int rc = seq_activate(d)) return rc; }
       std::vector<hipdec_decoder::Output> outs;
       if (int rc = decode_chain(d, std::min(d->sq.queue.size(), k), &outs)) return rc;
       for (auto& o : outs) if (o.pic_output) d->waiting.push_back(std::move(o));

@@ -23,6 +23,8 @@ def _bind(lib):
     lib.hipdec_decoder_read_plane.argtypes = [vp, ci, vp, sz]
     lib.hipdec_decoder_coalesce_stats.restype = None
     lib.hipdec_decoder_coalesce_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
+    lib.hipdec_decoder_chain_stats.restype = None
+    lib.hipdec_decoder_chain_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
     lib.hipdec_batch_create.argtypes = [C.POINTER(vp), ci, C.POINTER(C.c_char_p), C.POINTER(sz), C.c_uint64]
     lib.hipdec_batch_create_recycling.argtypes = [C.POINTER(vp), ci, C.POINTER(C.c_char_p), C.POINTER(sz), C.c_uint64, vp]
     lib.hipdec_batch_free.argtypes = [vp]
@@ -58,6 +60,14 @@ def coalesce_stats():
     lib = _bind(load_library())
     a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
     lib.hipdec_decoder_coalesce_stats(C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def chain_stats():
+    """(look-ahead chains of sequence tracks, launch sets issued for them, launch sets that held several tracks' chains) since the library was loaded"""
+    lib = _bind(load_library())
+    a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    lib.hipdec_decoder_chain_stats(C.byref(a), C.byref(b), C.byref(c))
     return a.value, b.value, c.value
 
 

@@ -4,6 +4,7 @@
 // parameters, substream termination) against the oracle without a GPU.  NOT part of the product:
 // never linked into libheifhip.so, never used by libheif_amd/.
 #define HIPDEC_HOST_EMU 1
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -92,6 +93,45 @@ EmuBatch* emu_seq_create_chain(EmuSeq* q, int n, const uint8_t* const* data, con
   q->alive.push_back(b);
   return b;
 }
+// Several tracks' chains in ONE batch (layout_batch_plan_chains, as the product's chain coalescer builds it): track t = samples [first[t], first[t] +
+// count[t]) of data[] with sequence state qs[t].  The batch belongs to the CALLER (emu_free after every sequence that references it was freed).
+EmuBatch* emu_seq_create_chains(EmuSeq* const* qs, int n_tracks, const int* first, const int* count, const uint8_t* const* data, const size_t* sizes,
+                                char* errbuf, size_t errlen)
+{
+  EmuBatch* b = new EmuBatch();
+  std::string err;
+  std::vector<const SeqContext*> seqs;
+  int total = 0;
+  for (int t = 0; t < n_tracks; t++) { seqs.push_back(&qs[t]->ctx); total = std::max(total, first[t] + count[t]); }
+  int bad = -1;
+  int rc = layout_batch_plan_chains(b->L, n_tracks, first, count, (const void* const*)data, sizes, 0, err, seqs.data(), &bad);
+  if (rc != 0) {
+    snprintf(errbuf, errlen, "%d (track %d): %s", rc, bad, err.c_str());
+    delete b;
+    return nullptr;
+  }
+  if (!b->L.pics.empty()) {
+    b->arena.assign(b->L.arena_size + 1024, 0);
+    layout_batch_fill(b->L, (const void* const*)data, sizes, b->arena.data(), (uint64_t)(uintptr_t)b->arena.data());
+  }
+  return b;
+}
+// items of track t in decoding order (and which of the track's samples each one is); returns their number
+int emu_track_items(EmuBatch* b, int t, int* items, int* samples, int cap)
+{
+  const BatchLayout::ChainTrack& tr = b->L.tracks[(size_t)t];
+  for (size_t k = 0; k < tr.items.size() && (int)k < cap; k++) { items[k] = tr.items[k]; samples[k] = tr.samples[k]; }
+  return (int)tr.items.size();
+}
+int emu_seq_commit_chains(EmuSeq* const* qs, int n_tracks, EmuBatch* b)
+{
+  for (int t = 0; t < n_tracks; t++) {
+    std::vector<int> own;
+    chain_resolve(b->L, (uint64_t)(uintptr_t)b->arena.data(), own, t);
+    qs[t]->ctx = b->L.tracks[(size_t)t].seq_after;
+  }
+  return 0;
+}
 int emu_num_items(EmuBatch* b) { return (int)b->L.pics.size(); }
 int emu_item_source(EmuBatch* b, int i) { return b->L.src(i); }
 // the chain was decoded: the track's sequence state moves behind its last picture (its pictures addressed absolutely from here on)
@@ -99,7 +139,7 @@ int emu_seq_commit_chain(EmuSeq* q, EmuBatch* b)
 {
   std::vector<int> own;
   chain_resolve(b->L, (uint64_t)(uintptr_t)b->arena.data(), own);
-  q->ctx = b->L.seq_after;
+  q->ctx = b->L.tracks[0].seq_after;
   return 0;
 }
 

@@ -85,7 +85,7 @@ int emu_run_pipeline_chain(EmuBatch* b)
   int motion_done = 0;
   for (int k = 0; k < (int)L.pixel_steps.size(); k++) {
     const BatchLayout::ChainStep& st = L.pixel_steps[(size_t)k];
-    const int need = L.motion_step_of[(size_t)(st.first + st.count - 1)] + 1;
+    const int need = st.motion_need;
     for (; motion_done < need; motion_done++) launch_chain_motion(L, a, motion_done, nullptr);
     launch_chain_pixels(L, a, k, nullptr);
   }

@@ -315,3 +315,111 @@ def test_emulated_long_term_reference_pictures(lt, kw):
     aus = orc.encode_sequence(frames, qp=26, global_mv_x=-8, global_mv_y=-4, long_term_ref=lt, **kw)
     check_sequence(aus, "long_term_ref=%d %r" % (lt, kw))
     check_sequence(aus, "long_term_ref=%d %r, chain" % (lt, kw), chain=4)
+
+
+# ---- several tracks' chains in ONE launch set (batch_layout.h: layout_batch_plan_chains; the product's chain coalescer in decoder.hip) ---------------
+def decode_tracks_emu(tracks, chains):
+    """tracks: access-unit lists; chains[t]: samples of track t per shared launch set.  Every track's first sample is decoded alone, then round after
+    round the next chains[t] samples of every track that still has some go into ONE batch: items ordered by (pixel step, track), the RowDesc table
+    by (motion step, item); step k of the batch = step k of every track."""
+    L = _lib()
+    L.emu_seq_create_chains.restype = C.c_void_p
+    L.emu_seq_create_chains.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t),
+                                        C.c_char_p, C.c_size_t]
+    L.emu_seq_commit_chains.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
+    L.emu_track_items.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    L.emu_chain_steps.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.emu_free.argtypes = [C.c_void_p]
+    T = len(tracks)
+    tracks = [[aus[0]] + [parameter_sets(aus[0]) + a for a in aus[1:]] for aus in tracks]
+    qs = [C.c_void_p(L.emu_seq_new()) for _ in range(T)]
+    out = [[] for _ in range(T)]
+    shared, step_counts = [], []
+    try:
+        err = C.create_string_buffer(512)
+        for t in range(T):
+            au = tracks[t][0]
+            b = L.emu_seq_create_picture(qs[t], au, len(au), err, 512)
+            assert b, err.value.decode()
+            b = C.c_void_p(b)
+            assert L.emu_run_parse(b) == 0 and L.emu_run_pipeline(b, 15) == 0
+            out[t].append(_read_picture(L, b, 0, True))
+            assert L.emu_seq_commit(qs[t], b) == 0
+        pos = [1] * T
+        while any(pos[t] < len(tracks[t]) for t in range(T)):
+            live = [t for t in range(T) if pos[t] < len(tracks[t])]
+            data, first, count = [], [], []
+            for t in live:
+                group = tracks[t][pos[t]:pos[t] + chains[t]]
+                first.append(len(data)); count.append(len(group)); data += group
+            n = len(live)
+            qarr = (C.c_void_p * n)(*[qs[t] for t in live])
+            b = L.emu_seq_create_chains(qarr, n, (C.c_int * n)(*first), (C.c_int * n)(*count), (C.c_char_p * len(data))(*data),
+                                        (C.c_size_t * len(data))(*[len(a) for a in data]), err, 512)
+            assert b, err.value.decode()
+            b = C.c_void_p(b)
+            shared.append(b)
+            assert L.emu_num_items(b) == len(data)
+            assert L.emu_run_parse(b) == 0, "parse status"
+            assert L.emu_run_pipeline_chain(b) == 0, "pipeline status"
+            px, mo = C.c_int(), C.c_int()
+            L.emu_chain_steps(b, C.byref(px), C.byref(mo))
+            step_counts.append((px.value, mo.value))
+            for k, t in enumerate(live):
+                items, samples = (C.c_int * 64)(), (C.c_int * 64)()
+                m = L.emu_track_items(b, k, items, samples, 64)
+                assert m == count[k] and list(samples[:m]) == list(range(m))
+                for i in items[:m]:
+                    out[t].append(_read_picture(L, b, i, True))
+                pos[t] += count[k]
+            assert L.emu_seq_commit_chains(qarr, n, b) == 0
+    finally:
+        for q in qs:
+            L.emu_seq_free(q)
+        for b in shared:
+            L.emu_free(b)
+    return out, step_counts
+
+
+def _check_tracks(tracks, chains, names):
+    got, step_counts = decode_tracks_emu(tracks, chains)
+    for t, aus in enumerate(tracks):
+        ref = orc.decode_sequence(aus, taps=True)
+        assert len(got[t]) == len(ref)
+        for i, (r, g) in enumerate(zip(ref, got[t])):
+            if "map_pred" in g:
+                uh, uw = g["map_pred"].shape
+                inter = r["map_pred"][:uh, :uw] > 0
+                np.testing.assert_array_equal(g["mf_mv"][inter], r["mf_mv"][:uh, :uw][inter], err_msg="%s picture %d: motion vectors" % (names[t], i))
+            for c in range(len(r["planes"])):
+                np.testing.assert_array_equal(g["planes"][c], r["planes"][c], err_msg="%s picture %d plane %d" % (names[t], i, c))
+    return step_counts
+
+
+def test_emulated_chains_of_several_tracks_share_one_launch_set():
+    """four tracks with different structures, picture sizes and chain lengths side by side: low-delay P with two references and temporal candidates,
+    B pictures with a reference B, an intra-only track, weighted P with CTB 32 - every picture of every track equals the oracle's"""
+    specs = [("ippp_tmvp", (136, 104), 7, dict(inter_num_refs=2, temporal_mvp=1), 3),
+             ("ibbp", (72, 56), 8, dict(b_frames=2, b_ref=1, temporal_mvp=1, inter_num_refs=2), 4),
+             ("weighted_ctb32", (104, 72), 6, dict(weighted_pred=1, log2_ctb=5, amp=1), 2),
+             ("ippp_no_tmvp", (136, 104), 5, dict(temporal_mvp=0), 6)]
+    tracks, chains, names = [], [], []
+    for k, (name, (w, h), n, kw, chain) in enumerate(specs):
+        frames = make_frames(w, h, n)
+        tracks.append(orc.encode_sequence(frames, qp=27, global_mv_x=-8, global_mv_y=4, inter_skip_pct=20, seed=40 + k, **kw))
+        chains.append(chain); names.append(name)
+    intra = [orc.encode(f, qp=30) for f in make_frames(72, 56, 4)]
+    tracks.append([intra[0]] + [b"".join(x for x in _split(a) if (x[4] >> 1) & 63 < 32) for a in intra[1:]])
+    chains.append(3); names.append("intra_only")
+    step_counts = _check_tracks(tracks, chains, names)
+    # the batch has as many steps as its deepest track: the B track's first four samples (P B B P: the second anchor predicts from the first) need more
+    # than one pixel step, the three P samples of the first track three
+    assert step_counts[0][0] >= 3 and step_counts[0][1] >= 2
+
+
+def test_emulated_chains_of_equal_tracks_keep_the_step_count_of_one():
+    """8 copies of one IPPP track in one launch set have the steps of one track: step k holds the k-th picture of all of them"""
+    frames = make_frames(72, 56, 6)
+    aus = orc.encode_sequence(frames, qp=30, temporal_mvp=1, inter_num_refs=2, seed=3)
+    step_counts = _check_tracks([aus] * 8, [5] * 8, ["copy%d" % i for i in range(8)])
+    assert step_counts == _check_tracks([aus], [5], ["alone"]) and step_counts[0][0] == 5

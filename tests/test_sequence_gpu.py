@@ -301,6 +301,106 @@ def test_b_tmvp_weighted_sequences_decode_bit_exact_in_output_order(name, lookah
     d.free()
 
 
+def _play_track(aus, refs, look_for_error=False):
+    """a track the way libheif drives it: push a sample, take every picture that is ready; flush at the end.  Returns [(planes, user_data)] in output order"""
+    from libheif_amd.decoder import HipDecoder
+    d = HipDecoder()
+    got = []
+    try:
+        for k, au in enumerate(aus):
+            d.push_data(au)
+            r = d.next_picture(user_data=900 + k)
+            while r is not None:
+                got.append(r)
+                r = d.next_picture()
+        r = d.next_picture(flush=True)
+        while r is not None:
+            got.append(r)
+            r = d.next_picture(flush=True)
+    finally:
+        d.free()
+    return got
+
+
+def test_tracks_side_by_side_share_launch_sets(lookahead):
+    """six tracks with different GOP structures, picture sizes and lengths, one host thread and one decoder instance each (as libheif's Track_Visual
+    objects): the look-ahead chains of tracks that ask together run as ONE launch set (decoder.hip: ChainCoalescer; step k = step k of every track) and
+    every picture of every track still equals the oracle's, in output order, with its own sample's user_data"""
+    import threading
+    from libheif_amd.decoder import chain_stats
+    specs = [dict(n=9, temporal_mvp=1, weighted_pred=1, inter_num_refs=3),
+             dict(n=12, b_frames=2, b_ref=1, inter_num_refs=2, temporal_mvp=1),
+             dict(n=7, w=136, h=104, b_frames=1, temporal_mvp=1, long_term_ref=1),
+             dict(n=10, w=70, h=42, amp=1, inter_num_refs=2, global_mv_y=17),
+             dict(n=9, scaling_list=2, b_frames=1, temporal_mvp=1, inter_intra_pct=30),
+             dict(n=11, temporal_mvp=0, log2_ctb=5)]
+    tracks = []
+    for k, cfg in enumerate(specs):
+        cfg = dict(cfg)
+        n = cfg.pop("n")
+        tracks.append(_p_sequence(n, w=cfg.pop("w", 200), h=cfg.pop("h", 136), seed=60 + k, **cfg))
+    before = chain_stats()
+    results, errors = [None] * len(tracks), []
+
+    def run(t):
+        try:
+            results[t] = _play_track(*tracks[t])
+        except Exception as e:      # noqa: BLE001 - reported below with the track's number
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(len(tracks))]
+    for th in threads: th.start()
+    for th in threads: th.join()
+    assert not errors, errors
+    for t, (aus, refs) in enumerate(tracks):
+        by_poc = {r["poc"]: r for r in refs}
+        coding = [r["poc"] for r in refs]
+        assert len(results[t]) == len(aus)
+        for out_idx, (img, ud) in enumerate(results[t]):
+            assert ud == 900 + coding.index(out_idx), (t, out_idx, ud)
+            for c in range(3):
+                np.testing.assert_array_equal(img.planes[c], by_poc[out_idx]["planes"][c], err_msg="track %d POC %d plane %d" % (t, out_idx, c))
+    after = chain_stats()
+    if lookahead:
+        assert after[0] > before[0]
+        assert after[2] > before[2], "no launch set held more than one track's chain: %r -> %r" % (before, after)
+
+
+def test_a_corrupt_track_beside_good_ones_fails_alone():
+    """one track's sample is damaged (its slice data cut short): the shared launch set is given up, every track runs on its own, the damaged one reports
+    the error and the others decode bit-exact"""
+    import threading
+    from libheif_amd import HipDecError
+    good = [_p_sequence(6, seed=70 + k, temporal_mvp=1, inter_num_refs=2) for k in range(3)]
+    bad_aus, _ = _p_sequence(6, seed=75)
+    bad_aus = list(bad_aus)
+    nals = _nals(bad_aus[3])
+    last = nals[-1]
+    cut = 4 + (len(last) - 4) // 2
+    bad_aus[3] = b"".join(nals[:-1]) + (cut - 4).to_bytes(4, "big") + last[4:cut]      # a slice NAL whose data ends early: the device parser runs out of bitstream
+    outcomes = {}
+
+    def run(name, aus, refs):
+        try:
+            outcomes[name] = _play_track(aus, refs)
+        except HipDecError as e:
+            outcomes[name] = e
+
+    threads = [threading.Thread(target=run, args=("good%d" % k, g[0], g[1])) for k, g in enumerate(good)]
+    threads.append(threading.Thread(target=run, args=("bad", bad_aus, None)))
+    for th in threads: th.start()
+    for th in threads: th.join()
+    assert isinstance(outcomes["bad"], HipDecError), outcomes["bad"]
+    for k, (aus, refs) in enumerate(good):
+        got = outcomes["good%d" % k]
+        assert not isinstance(got, Exception), got
+        by_poc = {r["poc"]: r for r in refs}
+        assert len(got) == len(aus)
+        for out_idx, (img, _) in enumerate(got):
+            for c in range(3):
+                np.testing.assert_array_equal(img.planes[c], by_poc[out_idx]["planes"][c], err_msg="track %d POC %d plane %d" % (k, out_idx, c))
+
+
 def test_b_sequence_in_coding_order_through_the_legacy_call():
     """hipdec_decoder_decode keeps delivering the picture of the sample just pushed (coding order): the planes are those of that POC"""
     from libheif_amd.decoder import HipDecoder

@@ -49,11 +49,14 @@ for name, kw in kinds.items():
 
     play(True)                                   # warm-up + correctness against the oracle
     t0 = time.perf_counter(); play(False); one = time.perf_counter() - t0
+    from libheif_amd.decoder import chain_stats
+    before = chain_stats()
     th = [threading.Thread(target=play, args=(False,)) for _ in range(tracks)]
     t0 = time.perf_counter()
     for t in th: t.start()
     for t in th: t.join()
     many = time.perf_counter() - t0
+    after = chain_stats()
     bytes_per_frame = sum(len(a) for a in aus) / len(aus)
-    print("%-42s %d x %dx%d pictures (%.0f KB per picture): 1 track %.1f fps (%.1f ms per picture); %d tracks side by side %.1f fps in total" %
-          (name, n, w, h, bytes_per_frame / 1e3, n / one, one / n * 1e3, tracks, tracks * n / many), flush=True)
+    print("%-42s %d x %dx%d pictures (%.0f KB per picture): 1 track %.1f fps (%.1f ms per picture); %d tracks side by side %.1f fps in total (%d chains in %d launch sets)" %
+          (name, n, w, h, bytes_per_frame / 1e3, n / one, one / n * 1e3, tracks, tracks * n / many, after[0] - before[0], after[1] - before[1]), flush=True)
