@@ -471,6 +471,7 @@ void layout_batch_fill(BatchLayout& b, const void* const* data, const size_t* si
         const RefPicture rp = pp.refs[k].batch_item >= 0 ? chain_ref_picture(b, pp.refs[k].batch_item, arena_base) : pp.refs[k];
         for (int c = 0; c < 3; c++) { tab[k].plane[c] = rp.plane[c]; tab[k].stride[c] = rp.stride[c]; }
         tab[k].poc = rp.poc; tab[k].mf = rp.mf;
+        if (pp.refs[k].batch_item >= 0) tab[k].progress_row = b.params[(size_t)pp.refs[k].batch_item].first_row + 1;
       }
       put(P.off_reftab, tab, sizeof(tab), P.off_bitstream);
     }

@@ -251,6 +251,36 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
     // the collocated picture's motion field only, so the motion steps run on a stream of their own behind the parser, beside the pixel steps of
     // earlier pictures; a pixel step (prediction, reconstruction, filters of pictures that do not predict from each other) waits for the motion
     // fields of its pictures, and stream order makes every reference picture - earlier items of this batch among them - complete.
+    static const bool motion_by_steps = getenv("HIPDEC_CHAIN_MOTION_STEPS") != nullptr;   // A/B knob: one k_motion launch per motion step (the form before the
+                                                                                          // kernel waited for its collocated picture's rows itself)
+    if (b.any_inter && !motion_by_steps) {
+      // the motion fields of ALL pictures with one launch on a stream of its own (kernels.h: launch_chain_motion_all), the pixel steps behind it
+      hipStream_t ms = stream_acquire();
+      if (b.chain_events.empty()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { stream_release(ms); return set_error(HIPDEC_ERR_DEVICE, "chain: no event"); }
+        b.chain_events.push_back(e);
+      }
+      HIPDEC_CHECK_HIP(hipStreamWaitEvent(ms, ev[1], 0));
+      launch_chain_motion_all(b, b.arena, ms);
+      HIPDEC_CHECK_HIP(hipEventRecord(b.chain_events[0], ms));
+      stream_release(ms);
+      bool waited = false;
+      for (size_t k = 0; k < b.pixel_steps.size(); k++) {
+        if (b.pixel_steps[k].any_inter && !waited) { HIPDEC_CHECK_HIP(hipStreamWaitEvent(ps, b.chain_events[0], 0)); waited = true; }
+        launch_chain_pixels(b, b.arena, (int)k, ps);
+      }
+      if (!waited) HIPDEC_CHECK_HIP(hipStreamWaitEvent(ps, b.chain_events[0], 0));   // nothing of this batch outlives its `done` event
+      HIPDEC_CHECK_HIP(hipEventRecord(ev[3], ps));
+      HIPDEC_CHECK_HIP(hipEventRecord(ev[4], ps));
+      HIPDEC_CHECK_HIP(hipEventRecord(ev[5], ps));
+      if (int rc = step("chain pixel stages")) return rc;
+      HIPDEC_CHECK_HIP(hipGetLastError());
+      HIPDEC_CHECK_HIP(hipMemcpyAsync(b.host_status, b.arena + b.off_status, sizeof(int32_t), hipMemcpyDeviceToHost, ps));
+      b.last_stream = ps;
+      b.mark_done(ps);
+      return 0;
+    }
     hipStream_t ms = nullptr;
     if (b.any_inter && b.motion_steps.size() > 1) {
       ms = stream_acquire();

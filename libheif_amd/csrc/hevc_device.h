@@ -83,8 +83,11 @@ struct RefFrame {
   uint32_t stride[3];
   int32_t poc;
   uint64_t mf;
+  uint32_t progress_row;   // != 0: the picture is an earlier item of the SAME launch set (a chain, batch_layout.h) and its motion field is derived by the same
+                           // k_motion launch: 1 + its first row in the row-progress table (slot 2 of a row counts the CTBs whose motion is complete)
+  uint32_t reserved;
 };
-static_assert(sizeof(RefFrame) == 48, "RefFrame layout");
+static_assert(sizeof(RefFrame) == 56, "RefFrame layout");
 
 // motion of one 4x4 luma unit (the motion field k_motion writes)
 struct MotionUnit {

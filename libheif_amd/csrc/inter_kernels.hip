@@ -468,10 +468,29 @@ __global__ __launch_bounds__(64) void k_motion(MotionArgs A)
       }
     C.col_w = (1 << (log2_ctb - 4)) + 1;
     if (C.col) {   // the collocated units the CTB's temporal candidates can name
+      // The collocated picture may be an earlier picture of the same chain whose motion this very launch derives (its rows hold earlier tickets): the
+      // candidates of this CTB name units of its CTB (cx, cy) and of the grid column right of it - never below the CTB row, 8.5.3.2.8 - so its row
+      // cy must be past CTB cx + 1.  Pictures of a chain thus follow each other at a 2-CTB distance instead of one launch per picture.
+      const uint32_t col_row = C.reftab[C.slice->col_slot].progress_row;
+      if (col_row) {
+        const uint32_t* col_progress = A.row_progress + (size_t)(col_row - 1 + (uint32_t)cy) * 3 + 2;
+        uint32_t need = (uint32_t)(cx + 2);
+        if (need > (uint32_t)ctb_w) need = (uint32_t)ctb_w;
+        uint32_t spins = 0;
+        while (__hip_atomic_load(col_progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1u << 22) || __hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { err = DEV_ERR_TIMEOUT; break; }
+        }
+        if (err) break;
+      }
       const int rows16 = 1 << (log2_ctb - 4);
       for (int i = lane; i < C.col_w * rows16; i += 64) {
         const int x = x_ctb + 16 * (i % C.col_w), y = y_ctb + 16 * (i / C.col_w);
-        if (x < P.width && y < P.height) L.col[i] = C.col[unit_index(C, x, y)];
+        if (x < P.width && y < P.height) {   // (possibly written by another wave of this launch: write-through data, sc1 loads - four dwords per unit)
+          HIPDEC_GLOBAL const uint32_t* src = (HIPDEC_GLOBAL const uint32_t*)&C.col[unit_index(C, x, y)];
+          uint32_t* dst = (uint32_t*)&L.col[i];
+          for (int k = 0; k < 4; k++) dst[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
     mk_lds_sync();
@@ -577,6 +596,11 @@ __global__ __launch_bounds__(64) void k_motion(MotionArgs A)
     for (int i = lane; i < units; i += 64) field[base + i] = cur[i];
     for (int i = lane; i < 4 * side; i += 64) {
       const uint32_t zi = mk_interleave((uint32_t)(i >> 2), (uint32_t)(side - 1));
+      __hip_atomic_store((uint32_t*)&field[base + zi] + (i & 3), ((const uint32_t*)&cur[zi])[i & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ... and the units on the 16x16 grid: what the temporal candidates of a LATER picture of the chain read while this launch runs
+    for (int i = lane; i < units / 4; i += 64) {
+      const uint32_t zi = (uint32_t)(i >> 2) << 4;
       __hip_atomic_store((uint32_t*)&field[base + zi] + (i & 3), ((const uint32_t*)&cur[zi])[i & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     mk_lds_sync();

@@ -58,6 +58,16 @@ inline void launch_chain_motion(const BatchLayout& L, uint8_t* arena, int k, hip
                 (uint32_t*)(arena + L.off_row_progress), (uint32_t*)(arena + L.off_ticket) + BatchLayout::chain_ticket(k) + 1, (int32_t*)(arena + L.off_status)};
   launch_motion(ma, s);
 }
+// All motion steps as ONE launch: the RowDesc table is ordered by (motion step, item, row) and k_motion hands rows out by ticket, so a picture's
+// collocated picture - an item of an earlier motion step - holds earlier tickets; the kernel waits for that picture's row progress CTB by CTB
+// (RefFrame::progress_row), and the pictures of a chain follow each other at a 2-CTB distance instead of one launch per step.
+inline void launch_chain_motion_all(const BatchLayout& L, uint8_t* arena, hipStream_t s)
+{
+  if (!L.any_inter) return;
+  MotionArgs ma{(const PicParams*)(arena + L.off_pics), (const RowDesc*)(arena + L.off_rows), L.num_rows, arena,
+                (uint32_t*)(arena + L.off_row_progress), (uint32_t*)(arena + L.off_ticket) + BatchLayout::chain_ticket(0) + 1, (int32_t*)(arena + L.off_status)};
+  launch_motion(ma, s);
+}
 // The pixel stages of pixel step k: motion-compensated prediction, reconstruction, deblocking, SAO of the step's pictures together - and for a
 // picture with a conformance window one more SAO pass that writes the whole coded picture for the pictures that predict from it.  Stream order
 // makes every earlier step complete; the motion fields of the step's pictures must be (the caller orders launch_chain_motion before it).

@@ -1,6 +1,7 @@
 // pipeline_emu.cc — CPU-TEST-ONLY: runs the kernels AFTER the parser (residual, reconstruction, deblocking, SAO; the very
 // sources of libheif_amd/csrc/*.hip, compiled for the host against tests/emu/shim/hip/hip_runtime.h) on a batch that
 // emu_run_parse() has parsed, with the same argument blocks as decoder.hip:launch_all.  NOT part of the product.
+#include <cstdlib>
 #include <cstring>
 #include "emu_batch.h"
 #include "kernels.h"
@@ -81,13 +82,19 @@ int emu_run_pipeline_chain(EmuBatch* b)
   bool general = false;
   for (const PicParams& P : L.params) if (P.chroma_format_idc >= 2) general = true;
   launch_residual(fa, n, L.max_ctbs, general, nullptr);
-  // (the product runs the motion steps on a stream of their own; here: every motion step a pixel step needs, then the pixel step)
-  int motion_done = 0;
-  for (int k = 0; k < (int)L.pixel_steps.size(); k++) {
-    const BatchLayout::ChainStep& st = L.pixel_steps[(size_t)k];
-    const int need = st.motion_need;
-    for (; motion_done < need; motion_done++) launch_chain_motion(L, a, motion_done, nullptr);
-    launch_chain_pixels(L, a, k, nullptr);
+  if (!getenv("HIPDEC_CHAIN_MOTION_STEPS")) {
+    // as the product: the motion fields of all pictures with ONE launch (rows by ticket in (motion step, item) order), then the pixel steps
+    launch_chain_motion_all(L, a, nullptr);
+    for (int k = 0; k < (int)L.pixel_steps.size(); k++) launch_chain_pixels(L, a, k, nullptr);
+  } else {
+    // (the A/B form: every motion step a pixel step needs, then the pixel step)
+    int motion_done = 0;
+    for (int k = 0; k < (int)L.pixel_steps.size(); k++) {
+      const BatchLayout::ChainStep& st = L.pixel_steps[(size_t)k];
+      const int need = st.motion_need;
+      for (; motion_done < need; motion_done++) launch_chain_motion(L, a, motion_done, nullptr);
+      launch_chain_pixels(L, a, k, nullptr);
+    }
   }
   b->status = *(int32_t*)(a + L.off_status);
   return b->status;
