@@ -234,7 +234,7 @@ def issue_roofline(kernels, px, cu_count, clock_ghz):
     return out
 
 
-def sequence_tracks(n_frames=33, tracks=16, w=1280, h=720):
+def sequence_tracks(n_frames=65, tracks=16, w=1280, h=720):
     """sequence tracks through the decoder object the way libheif drives it (one sample per push_data2, pictures polled in output order,
     flush at the end): frames per second of ONE track - every picture is one CABAC critical path, the instance holds one sample at a time - and of
     `tracks` tracks decoded side by side by as many threads (their first pictures and their look-ahead chains coalesce into shared launch sets).  The first pass of each kind checks
@@ -251,7 +251,7 @@ def sequence_tracks(n_frames=33, tracks=16, w=1280, h=720):
     lib = libheif_amd.load_library()
     lib.hipdec_set_sequence_lookahead.argtypes = [__import__("ctypes").c_int]
     lib.hipdec_set_sequence_lookahead.restype = None
-    default_lookahead = int(os.environ.get("HIPDEC_SEQ_LOOKAHEAD", "16"))
+    default_lookahead = int(os.environ.get("HIPDEC_SEQ_LOOKAHEAD", "32"))
     res = {"pictures_per_track": n_frames, "size": "%dx%d" % (w, h), "tracks_side_by_side": tracks, "lookahead_samples": default_lookahead,
            "lookahead": "behind a track's first picture the decoder gathers this many samples (libheif pushes the next one whenever decode_next_image2 returns no image) "
                         "and decodes them as ONE launch set: one CABAC launch over all of them, pixel stages picture by picture (hipdec_set_sequence_lookahead)"}

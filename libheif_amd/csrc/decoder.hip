@@ -1167,7 +1167,7 @@ static long seq_lookahead()
   long k = g_seq_lookahead.load(std::memory_order_relaxed);
   if (k < 0) {
     const char* e = std::getenv("HIPDEC_SEQ_LOOKAHEAD");
-    k = e ? std::atol(e) : 16;
+    k = e ? std::atol(e) : 32;
     k = k < 0 ? 0 : (k > 64 ? 64 : k);
     g_seq_lookahead.store(k, std::memory_order_relaxed);
   }

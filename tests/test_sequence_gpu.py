@@ -25,11 +25,11 @@ def _set_lookahead(k):
     lib.hipdec_set_sequence_lookahead(k)
 
 
-@pytest.fixture(params=[16, 0, 3], ids=["lookahead16", "lookahead0", "lookahead3"])
+@pytest.fixture(params=[32, 0, 3], ids=["lookahead32", "lookahead0", "lookahead3"])
 def lookahead(request):
     _set_lookahead(request.param)
     yield request.param
-    _set_lookahead(16)
+    _set_lookahead(32)
 
 
 def _nals(stream):

@@ -24,6 +24,11 @@ L.emu_run_pipeline_chain.argtypes = [C.c_void_p]
 L.emu_num_items.argtypes = [C.c_void_p]
 
 
+L.emu_seq_create_chains.restype = C.c_void_p
+L.emu_seq_create_chains.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+L.emu_seq_commit_chains.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
+
+
 def parameter_sets(au):
     out, p = b"", 0
     while p + 4 <= len(au):
@@ -84,6 +89,46 @@ def run(aus, chain=False):
     return ','.join(res)
 
 
+def run_tracks(tracks):
+    """the chain coalescer's form: every track's first picture alone, then the rest of ALL tracks as one batch (layout_batch_plan_chains)"""
+    qs = [C.c_void_p(L.emu_seq_new()) for _ in tracks]
+    shared = None
+    try:
+        err = C.create_string_buffer(512)
+        data, first, count = [], [], []
+        for q, aus in zip(qs, tracks):
+            b = L.emu_seq_create_picture(q, aus[0], len(aus[0]), err, 512)
+            if not b:
+                return 'tracks: first rejected'
+            b = C.c_void_p(b)
+            if L.emu_run_parse(b) or L.emu_run_pipeline(b, 15):
+                return 'tracks: first status'
+            L.emu_seq_commit(q, b)
+            ps = parameter_sets(aus[0])
+            group = [ps + a for a in aus[1:]]
+            first.append(len(data)); count.append(len(group)); data += group
+        n = len(tracks)
+        qarr = (C.c_void_p * n)(*qs)
+        b = L.emu_seq_create_chains(qarr, n, (C.c_int * n)(*first), (C.c_int * n)(*count), (C.c_char_p * len(data))(*data),
+                                    (C.c_size_t * len(data))(*[len(a) for a in data]), err, 512)
+        if not b:
+            return 'tracks: rejected'
+        shared = C.c_void_p(b)
+        st = 0
+        if L.emu_num_items(shared):
+            st = L.emu_run_parse(shared)
+            if st == 0:
+                st = L.emu_run_pipeline_chain(shared)
+        if st == 0:
+            L.emu_seq_commit_chains(qarr, n, shared)
+        return 'tracks: ' + ('ok' if st == 0 else 'status')
+    finally:
+        for q in qs:
+            L.emu_seq_free(q)
+        if shared:
+            L.emu_free(shared)
+
+
 rng = random.Random(int(sys.argv[1]))
 n = int(sys.argv[2])
 cfgs = [dict(), dict(amp=1, inter_num_refs=2), dict(inter_num_refs=3, lists_modification=1, max_merge_cand=3), dict(wpp=0, tile_cols=2, tile_rows=2),
@@ -102,7 +147,8 @@ print('clean:', [run(a) for a in base]); sys.stdout.flush()
 print('clean (chains):', [run(a, True) for a in base]); sys.stdout.flush()
 res = {}
 for it in range(n):
-    aus = [bytes(a) for a in rng.choice(base)]
+    src = rng.choice(base)
+    aus = [bytes(a) for a in src]
     victim = rng.randrange(1, len(aus))
     s = bytearray(aus[victim])
     for _ in range(rng.choice([1, 1, 2, 4, 16])):
@@ -113,6 +159,10 @@ for it in range(n):
         elif mode == 1: s[p] = rng.randrange(256)
         else: s[p] = 0xff
     aus[victim] = bytes(s)
-    r = run(aus, chain=(it % 3 == 2))       # every third case through the chain form
+    if it % 3 == 1:                         # every third case beside two clean tracks of the same bit depth in ONE batch
+        same = [b for i, b in enumerate(base) if (cfgs[i].get('bit_depth', 8) > 8) == (cfgs[[id(x) for x in base].index(id(src))].get('bit_depth', 8) > 8)]
+        r = run_tracks([rng.choice(same), aus, rng.choice(same)])
+    else:
+        r = run(aus, chain=(it % 3 == 2))   # every third case through the chain form
     res[r] = res.get(r, 0) + 1
 print(res)

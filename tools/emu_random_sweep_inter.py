@@ -2,7 +2,7 @@
 (IPPP, B pictures between anchors, B pictures as references), numbers of reference pictures, TMVP, explicit weights, list modification, AMP,
 merge-candidate limits, parallel merge levels, slices / tiles / WPP / dependent segments, lossless / PCM / transform-skip units, bit depths,
 monochrome; the motion field (both lists) and every plane of every picture compared bit by bit.
-usage: python tools/emu_random_sweep_inter.py <seed> <count> [procs]"""
+usage: python tools/emu_random_sweep_inter.py <seed> <count> [procs] [tracks]     ("tracks": several random tracks side by side, their chains in one batch)"""
 import os
 import random
 import sys
@@ -83,9 +83,39 @@ def run_case(args):
     return (k, "ok", None)
 
 
+def run_tracks_case(args):
+    """several random tracks (one bit-depth class: 8-bit and deeper tracks never share a launch set) decoded side by side: their chains in ONE batch
+    per round (layout_batch_plan_chains), random chain lengths per track"""
+    seed, k = args
+    rng = random.Random(seed * 100019 + k)
+    from oracle import pyoracle as orc
+    from test_inter_oracle import make_frames
+    import test_inter_emu as T
+    depth = rng.choice([8, 8, 10])
+    tracks, chains, names, cfgs = [], [], [], []
+    for t in range(rng.choice([2, 3, 4, 6])):
+        w, h, mono, n, cfg = random_case(rng)
+        cfg["bit_depth"] = depth
+        try:
+            frames = make_frames(w, h, n, depth, mono, seed=seed + 31 * k + t)
+            tracks.append(orc.encode_sequence(frames, seed=seed * 7 + 13 * k + t, **cfg))
+        except orc.OracleError:
+            continue
+        chains.append(rng.choice([1, 2, 3, 5, 16])); names.append("case %d track %d" % (k, t)); cfgs.append((w, h, mono, n, cfg))
+    if len(tracks) < 2:
+        return (k, "generator: fewer than two tracks", None)
+    try:
+        T._check_tracks(tracks, chains, names)
+    except Exception as ex:   # noqa
+        return (k, "MISMATCH " + str(ex)[:300], (chains, cfgs))
+    return (k, "ok", None)
+
+
 if __name__ == "__main__":
     seed, count = int(sys.argv[1]), int(sys.argv[2])
     procs = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+    if len(sys.argv) > 4 and sys.argv[4] == "tracks":
+        run_case = run_tracks_case      # noqa: F811 - the multi-track form of the sweep
     import multiprocessing as mp
     from test_parse_emu import emu
     emu()   # build once before the workers start
