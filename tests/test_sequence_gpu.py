@@ -340,30 +340,33 @@ def test_tracks_side_by_side_share_launch_sets(lookahead):
         n = cfg.pop("n")
         tracks.append(_p_sequence(n, w=cfg.pop("w", 200), h=cfg.pop("h", 136), seed=60 + k, **cfg))
     before = chain_stats()
-    results, errors = [None] * len(tracks), []
+    for attempt in range(3):      # (whether two threads' chains meet is a matter of timing: the pictures are checked every time, the sharing once)
+        results, errors = [None] * len(tracks), []
 
-    def run(t):
-        try:
-            results[t] = _play_track(*tracks[t])
-        except Exception as e:      # noqa: BLE001 - reported below with the track's number
-            errors.append((t, repr(e)))
+        def run(t):
+            try:
+                results[t] = _play_track(*tracks[t])
+            except Exception as e:      # noqa: BLE001 - reported below with the track's number
+                errors.append((t, repr(e)))
 
-    threads = [threading.Thread(target=run, args=(t,)) for t in range(len(tracks))]
-    for th in threads: th.start()
-    for th in threads: th.join()
-    assert not errors, errors
-    for t, (aus, refs) in enumerate(tracks):
-        by_poc = {r["poc"]: r for r in refs}
-        coding = [r["poc"] for r in refs]
-        assert len(results[t]) == len(aus)
-        for out_idx, (img, ud) in enumerate(results[t]):
-            assert ud == 900 + coding.index(out_idx), (t, out_idx, ud)
-            for c in range(3):
-                np.testing.assert_array_equal(img.planes[c], by_poc[out_idx]["planes"][c], err_msg="track %d POC %d plane %d" % (t, out_idx, c))
-    after = chain_stats()
-    if lookahead:
+        threads = [threading.Thread(target=run, args=(t,)) for t in range(len(tracks))]
+        for th in threads: th.start()
+        for th in threads: th.join()
+        assert not errors, errors
+        for t, (aus, refs) in enumerate(tracks):
+            by_poc = {r["poc"]: r for r in refs}
+            coding = [r["poc"] for r in refs]
+            assert len(results[t]) == len(aus)
+            for out_idx, (img, ud) in enumerate(results[t]):
+                assert ud == 900 + coding.index(out_idx), (t, out_idx, ud)
+                for c in range(3):
+                    np.testing.assert_array_equal(img.planes[c], by_poc[out_idx]["planes"][c], err_msg="track %d POC %d plane %d" % (t, out_idx, c))
+        after = chain_stats()
         assert after[0] > before[0]
-        assert after[2] > before[2], "no launch set held more than one track's chain: %r -> %r" % (before, after)
+        if not lookahead or after[2] > before[2]:
+            break
+    else:
+        raise AssertionError("no launch set held more than one track's chain in three runs: %r -> %r" % (before, after))
 
 
 def test_a_corrupt_track_beside_good_ones_fails_alone():
