@@ -254,7 +254,8 @@ def sequence_tracks(n_frames=65, tracks=16, w=1280, h=720):
     default_lookahead = int(os.environ.get("HIPDEC_SEQ_LOOKAHEAD", "32"))
     res = {"pictures_per_track": n_frames, "size": "%dx%d" % (w, h), "tracks_side_by_side": tracks, "lookahead_samples": default_lookahead,
            "lookahead": "behind a track's first picture the decoder gathers this many samples (libheif pushes the next one whenever decode_next_image2 returns no image) "
-                        "and decodes them as ONE launch set: one CABAC launch over all of them, pixel stages picture by picture (hipdec_set_sequence_lookahead)"}
+                        "and decodes them as ONE launch set: one CABAC launch and one motion-derivation launch over all of them, pixel stages in dependency steps "
+                        "(hipdec_set_sequence_lookahead); the chains of tracks decoded side by side that ask together share a launch set (hipdec_decoder_chain_stats)"}
     for name, kw in kinds.items():
         aus = orc.encode_sequence(frames, qp=27, global_mv_x=-8, global_mv_y=-4, inter_skip_pct=30, **kw)
         ref = {r["poc"]: r for r in orc.decode_sequence(aus)}
