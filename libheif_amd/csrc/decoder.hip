@@ -321,7 +321,8 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
     MotionArgs ma{(const PicParams*)(b.arena + b.off_pics), (const RowDesc*)(b.arena + b.off_rows), b.num_rows, b.arena,
                   (uint32_t*)(b.arena + b.off_row_progress), (uint32_t*)(b.arena + b.off_ticket) + 2, (int32_t*)(b.arena + b.off_status)};
     launch_motion(ma, ps);
-    launch_mc(fa, n, b.max_w, b.max_h, b.wide, ps);
+    launch_mc(fa, n, b.max_w, b.max_h, b.wide, ps, inter_residual_in_mc());
+    ra.inter_from_plane = inter_residual_in_mc() ? 1u : 0u;
     if (int rc = step("motion + mc")) return rc;
   }
   if (!parse_only) launch_recon(ra, b.wide, ps, b.any_inter);

@@ -653,11 +653,12 @@ __device__ __forceinline__ int mc_sample(HIPDEC_GLOBAL const Pix* ref, size_t rs
   return v;
 }
 
+// add_residual: the sample leaves with its residual added (8.6.7 for the units of inter coded CUs) - then the reconstruction wavefront, a serial walk over
+// the blocks of a CTB, has nothing left to do for them (ReconArgs::inter_from_plane)
 template <typename Pix>
-__global__ __launch_bounds__(256) void k_mc(FilterArgs A, int n_planes_per_pic)
+__global__ __launch_bounds__(256) void k_mc(FilterArgs A, int add_residual)
 {
   const int pic = (int)blockIdx.z / 3, plane = (int)blockIdx.z % 3;
-  (void)n_planes_per_pic;
   if (__hip_atomic_load(A.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   const PicParams& P = A.pics[pic];
   if (!P.is_inter || (plane && !P.chroma_format_idc)) return;
@@ -698,8 +699,38 @@ __global__ __launch_bounds__(256) void k_mc(FilterArgs A, int n_planes_per_pic)
       v = ((pred[one] * w + (1 << (log2wd - 1))) >> log2wd) + o;   // (log2WD >= 2: shift1 >= 2)
     }
   }
+  v = mk_clip3(0, maxv, v);
+  if (add_residual) {
+    // the transform block that covers the sample: its size sits in the low nibble of the unit's size byte, its flags and its residual at its first unit
+    // (z order; the residual arrays hold a CTB's blocks one behind the other, each block in raster order: residual_kernel.hip).  4:2:0 chroma: a block of
+    // half the luma size - the 4x4 block of four 4x4 luma blocks hangs off the quad's 4th unit and sits at the quad's origin
+    const size_t ctb_rs = (size_t)(cy * P.ctb_w + cx), base = ctb_rs << P.units_per_ctb_log2;
+    const uint8_t* u_size = A.arena + P.off_u_size + base;
+    const uint8_t* u_flags = A.arena + P.off_u_flags + base;
+    const int tb = u_size[z] & 15;
+    if (tb >= 2 && tb <= 5) {   // (anything else is a broken map: k_recon reports it)
+      const uint32_t ux = (uint32_t)((xl >> 2) & m), uy = (uint32_t)((yl >> 2) & m), tmask = ~(uint32_t)((1 << (tb - 2)) - 1);
+      const uint32_t z0 = mk_interleave(ux & tmask, uy & tmask);
+      const int ctb2 = 1 << (2 * log2_ctb);
+      int res = 0;
+      if (!plane) {
+        if (u_flags[z0] & UF_CBF_LUMA) res = ((const int16_t*)(A.arena + P.off_coeff[0]))[ctb_rs * (size_t)ctb2 + z0 * 16u + (uint32_t)(((y & ((1 << tb) - 1)) << tb) + (x & ((1 << tb) - 1)))];
+      } else {
+        const int16_t* coeff = (const int16_t*)(A.arena + P.off_coeff[plane]) + ctb_rs * (size_t)(ctb2 >> 2);
+        const int bit = plane == 1 ? UF_CBF_CB : UF_CBF_CR;
+        if (tb > 2) {
+          const int lgc = tb - 1;
+          if (u_flags[z0] & bit) res = coeff[z0 * 4u + (uint32_t)(((y & ((1 << lgc) - 1)) << lgc) + (x & ((1 << lgc) - 1)))];
+        } else {
+          const uint32_t zc = z & ~3u;
+          if (u_flags[zc | 3u] & bit) res = coeff[zc * 4u + (uint32_t)(((y & 3) << 2) + (x & 3))];
+        }
+      }
+      v = mk_clip3(0, maxv, v + res);
+    }
+  }
   Pix* rec = (Pix*)(A.arena + P.off_rec[plane]);
-  rec[(size_t)y * (P.rec_stride[plane ? 1 : 0] / sizeof(Pix)) + x] = (Pix)mk_clip3(0, maxv, v);
+  rec[(size_t)y * (P.rec_stride[plane ? 1 : 0] / sizeof(Pix)) + x] = (Pix)v;
 }
 
 void launch_motion(const MotionArgs& a, hipStream_t s)
@@ -708,12 +739,12 @@ void launch_motion(const MotionArgs& a, hipStream_t s)
   hipLaunchKernelGGL(k_motion, dim3(a.num_rows), dim3(64), 0, s, a);
 }
 
-void launch_mc(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s)
+void launch_mc(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s, bool add_residual)
 {
   if (n_pics <= 0) return;
   const dim3 grid((unsigned)((max_w + 15) / 16), (unsigned)((max_h + 15) / 16), (unsigned)(n_pics * 3));
-  if (wide) hipLaunchKernelGGL(k_mc<uint16_t>, grid, dim3(256), 0, s, a, 3);
-  else hipLaunchKernelGGL(k_mc<uint8_t>, grid, dim3(256), 0, s, a, 3);
+  if (wide) hipLaunchKernelGGL(k_mc<uint16_t>, grid, dim3(256), 0, s, a, add_residual ? 1 : 0);
+  else hipLaunchKernelGGL(k_mc<uint8_t>, grid, dim3(256), 0, s, a, add_residual ? 1 : 0);
 }
 
 }  // namespace hipdec

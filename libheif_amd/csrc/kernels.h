@@ -1,5 +1,6 @@
 // kernels.h — kernel argument blocks and the host-side launchers each kernel translation unit exports.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include "hevc_device.h"
 #include "batch_layout.h"
@@ -15,6 +16,8 @@ struct ReconArgs {
   uint32_t* row_progress;  // per (batch row, component): CTBs completed
   uint32_t* ticket;
   int32_t* status;
+  uint32_t inter_from_plane = 0;   // P / B pictures: k_mc has added the residuals of the inter coded units to its prediction (launch_mc(..., add_residual)): the rec
+                                   // plane holds them complete, a CTB's tile is loaded whole and the wavefront only reconstructs the intra blocks
 };
 
 struct FilterArgs {
@@ -37,7 +40,12 @@ struct MotionArgs {
 void launch_parse(const ParseArgs& a, hipStream_t s);
 void launch_parse_inter(const ParseArgs& a, hipStream_t s);   // parse_kernel_inter.hip: batches with P pictures (sequence tracks)
 void launch_motion(const MotionArgs& a, hipStream_t s);       // P pictures: MotionSyntax -> motion field (merge / AMVP derivation)
-void launch_mc(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s);   // motion-compensated prediction into the rec planes
+// motion-compensated prediction into the rec planes; add_residual: plus the residual of every inter coded sample (then k_recon runs with inter_from_plane)
+void launch_mc(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s, bool add_residual = false);
+// Where do the residuals of inter coded units get added?  In k_mc (fully parallel over the picture), so that the reconstruction wavefront - a serial walk over a
+// CTB's blocks, 2 CTBs behind the row above - only deals with the intra blocks of a P / B picture.  HIPDEC_INTER_RECON_PER_BLOCK=1: the form before (k_recon
+// copies every inter block out of the plane and adds its residual), kept for A/B measurements.
+inline bool inter_residual_in_mc() { static const bool per_block = getenv("HIPDEC_INTER_RECON_PER_BLOCK") != nullptr; return !per_block; }
 void launch_parse_general(const ParseArgs& a, bool throughput, hipStream_t s);   // parse_kernel_general.hip: batches with 4:2:2 / 4:4:4 pictures
 void launch_residual(const FilterArgs& a, int n_pics, int max_ctbs, bool general_chroma /* the batch holds 4:2:2 / 4:4:4 pictures */, hipStream_t s);
 void launch_recon(const ReconArgs& a, bool wide, hipStream_t s, bool inter = false /* the batch holds P pictures */);
@@ -77,9 +85,9 @@ inline void launch_chain_pixels(const BatchLayout& L, uint8_t* arena, int k, hip
   const PicParams* pics = (const PicParams*)(arena + L.off_pics);
   int32_t* status = (int32_t*)(arena + L.off_status);
   FilterArgs fa{pics + st.first, arena, status};
-  if (st.any_inter) launch_mc(fa, st.count, st.max_w, st.max_h, L.wide, s);
+  if (st.any_inter) launch_mc(fa, st.count, st.max_w, st.max_h, L.wide, s, inter_residual_in_mc());
   ReconArgs ra{pics, (const ReconWave*)(arena + L.off_rwaves) + st.first_rwave, st.num_rwaves, arena, (uint32_t*)(arena + L.off_row_progress),
-               (uint32_t*)(arena + L.off_ticket) + BatchLayout::chain_ticket(k), status};
+               (uint32_t*)(arena + L.off_ticket) + BatchLayout::chain_ticket(k), status, inter_residual_in_mc() ? 1u : 0u};
   launch_recon(ra, L.wide, s, L.any_inter);
   launch_deblock(fa, st.count, st.max_w, st.max_h, L.wide, s);
   bool may_keep = false, restricted = false;

@@ -152,6 +152,19 @@ struct Ctx {
 // A transform block of a coding unit that is NOT intra coded (P pictures): the prediction samples are in the reconstruction plane already
 // (k_mc, inter_kernels.hip); the block enters the LDS tile with its residual added, so that intra blocks next to it predict from it and the
 // CTB leaves LDS as a whole.  LW lanes (64, or 32 per half of the chroma pair) cover the block; `pred` points at the block in the plane.
+// the units of an inter coded block become available to the intra blocks behind them (not with constrained_intra_pred_flag: their samples stay "not
+// available for intra prediction", 8.4.4.2.2)
+template <typename Pix>
+__device__ __forceinline__ void mark_inter_available(ReconLds<Pix>& L, const Ctx& C, int xb, int yb, int log2n, int ushx, int ushy)
+{
+  if (!C.cip) {
+    const int n = 1 << log2n;
+    const int kx = n >> ushx, rows = n >> ushy;    // units per row of the block (>= 1), unit rows
+    if (C.lane < (rows > 0 ? rows : 1)) lds_or(&L.avrow[(yb >> ushy) + 1 + C.lane], ((1ull << (kx > 0 ? kx : 1)) - 1ull) << ((xb >> ushx) + 1));
+  }
+  lds_sync();
+}
+
 template <typename Pix>
 __device__ __forceinline__ void reconstruct_inter_block(ReconLds<Pix>& L, const Ctx& C, Pix* tile, const Pix* pred, uint32_t pstride, int xb, int yb, int log2n, int cbf,
                                                         const int16_t* res, int l, int LW, int ushx, int ushy)
@@ -163,11 +176,7 @@ __device__ __forceinline__ void reconstruct_inter_block(ReconLds<Pix>& L, const 
     if (cbf) v = clip3(0, maxv, v + (int)res[idx]);
     tile[((yb + y) << lg_ctbc) + xb + x] = (Pix)v;
   }
-  if (!C.cip) {   // (constrained_intra_pred_flag: the samples stay "not available for intra prediction", 8.4.4.2.2)
-    const int kx = n >> ushx, rows = n >> ushy;    // units per row of the block (>= 1), unit rows
-    if (C.lane < (rows > 0 ? rows : 1)) lds_or(&L.avrow[(yb >> ushy) + 1 + C.lane], ((1ull << (kx > 0 ? kx : 1)) - 1ull) << ((xb >> ushx) + 1));
-  }
-  lds_sync();
+  mark_inter_available<Pix>(L, C, xb, yb, log2n, ushx, ushy);
 }
 
 // One transform block: prediction (+ residual) into the LDS tile.
@@ -554,6 +563,7 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
   C.bit_depth = chroma ? P.bit_depth_chroma : P.bit_depth_luma; C.maxv = (1 << C.bit_depth) - 1;
   C.luma = !chroma; C.smooth = !DUAL; C.strong = !chroma && P.strong_intra_smoothing;
   C.cip = (INTER && P.is_inter && P.constrained_intra_pred) ? 1 : 0;
+  const bool from_plane = INTER && is_inter && A.inter_from_plane != 0;
   const int Wc = DUAL ? P.cwidth : P.width, Hc = DUAL ? P.cheight : P.height;   // component plane size in samples
   const int pic_w = P.width, pic_h = P.height, ctb_w = P.ctb_w, ctb_h = P.ctb_h, log2_ctb = P.log2_ctb;
   const int side = 1 << (log2_ctb - 2);                                         // 4x4-luma units per CTB side
@@ -598,6 +608,7 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
     // ---- stage the CTB's maps, one packed word per unit ----
     {
       const size_t base = (size_t)ctb_rs * units;
+      int inter_units = 0;
       for (int i = lane * 4; i < units; i += 256) {
         const uint32_t sz = *(const uint32_t*)(A.arena + off_size + base + i);
         const uint32_t fl = *(const uint32_t*)(A.arena + off_flags + base + i);
@@ -605,6 +616,7 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
         if (is_inter) {   // P picture: bit 6 of a unit's mode byte = the unit is not intra coded (u_ipmc carries it; the luma wave reads u_ipm)
           const uint32_t pc = *(const uint32_t*)(A.arena + P.off_u_ipmc + base + i);
           md = (md & 0x3f3f3f3fu) | (pc & 0x40404040u);
+          inter_units |= (int)(pc & 0x40404040u);
         }
         const uint32_t ux = compact1by1((uint32_t)i), uy = compact1by1((uint32_t)i >> 1);   // i is a multiple of 4: units i..i+3 are a 2x2 quad
 #pragma nounroll
@@ -648,6 +660,15 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
         } else if (lane <= side && (ci.avail & AV_LEFT) && y_ctb / suby + (lane - 1) * uszy < Hc && !left_inter) row = 1ull;
         L.avrow[lane] = row;
       }
+      // inter_from_plane: k_mc left the inter coded units complete in the plane (prediction + residual) - the tile starts as a copy of the CTB (the
+      // positions of the intra blocks hold whatever was there: they are written before anything reads them) and the walk below only marks those units
+      if (INTER && from_plane && __ballot(inter_units != 0) != 0) {
+        const int yc0 = y_ctb / suby;
+        const int y0 = l >> lg_wpr, xw = l & (wpr - 1);
+        uint32_t off = (uint32_t)(yc0 + y0) * stride + (uint32_t)(xc0 + xw * PPW);
+        const uint32_t step = ((uint32_t)LW >> lg_wpr) * stride;
+        for (int i = l; i < wpr * ctbch; i += LW, off += step) *(uint32_t*)&tile[i * PPW] = *(const uint32_t*)&rec[off];
+      }
     }
     lds_sync();
 
@@ -664,7 +685,13 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
       const int tb = (int)(w & 15u), fl = (int)((w >> 8) & 255u), mode = (int)((w >> 16) & 255u);
       // the chroma pair: the 4x4 chroma blocks of four 4x4 luma TUs hang off the quad's 4th unit (their flags are there) - straight to it
       if (DUAL && tb == 2 && (z & 3) != 3) { z |= 3; continue; }
-      if (INTER && (mode & 64)) {   // a unit of an inter coded CU: prediction from the plane + residual
+      if (INTER && (mode & 64) && from_plane) {   // a unit of an inter coded CU, complete in the plane and in the tile already
+        if (!DUAL) mark_inter_available<Pix>(L, C, ux * 4, uy * 4, tb, 2, 2);
+        else if (tb > 2 || (z & 3) == 3) {
+          const int quad = tb == 2;
+          mark_inter_available<Pix>(L, C, (quad ? (ux & ~1) : ux) * 2, (quad ? (uy & ~1) : uy) * 2, quad ? 2 : tb - 1, 1, 1);
+        }
+      } else if (INTER && (mode & 64)) {   // the same with the residual added here: prediction from the plane + residual
         if (!DUAL) {
           const Pix* pred = rec + (size_t)(y_ctb + uy * 4) * stride + (size_t)(x_ctb + ux * 4);
           reconstruct_inter_block<Pix>(L, C, tile, pred, stride, ux * 4, uy * 4, tb, fl & cbf_bit, res_base + z * 16, lane, 64, 2, 2);

@@ -31,7 +31,8 @@ int emu_run_pipeline_rgb(EmuBatch* b, int stages, uint8_t* rgb)
     MotionArgs ma{(const PicParams*)(a + L.off_pics), (const RowDesc*)(a + L.off_rows), L.num_rows, a, (uint32_t*)(a + L.off_row_progress),
                   (uint32_t*)(a + L.off_ticket) + 2, (int32_t*)(a + L.off_status)};
     launch_motion(ma, nullptr);
-    launch_mc(fa, n, L.max_w, L.max_h, L.wide, nullptr);
+    launch_mc(fa, n, L.max_w, L.max_h, L.wide, nullptr, inter_residual_in_mc());
+    ra.inter_from_plane = inter_residual_in_mc() ? 1u : 0u;
   }
   if (stages & 2) launch_recon(ra, L.wide, nullptr, L.any_inter);
   if (stages & 4) launch_deblock(fa, n, L.max_w, L.max_h, L.wide, nullptr);
