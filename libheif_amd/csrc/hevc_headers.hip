@@ -212,7 +212,6 @@ void build_scaling_tables(const ScalingLists& sl, bool chroma444, std::vector<ui
       for (int x = 0; x < 32; x++) t32[y * 32 + x] = sl.l32[3 * pass][(y >> 2) * 8 + (x >> 2)];
     t32[0] = sl.dc32[3 * pass];
   }
-  uint8_t* t32 = out.data() + 1008;
   if (chroma444)   // 7.4.5: the 32x32 chroma matrices of a 4:4:4 picture are the component's 16x16 lists upsampled by 4, with the 16x16 DC
     for (int c = 1; c < 3; c++) {
       uint8_t* t = out.data() + 2048 + (c - 1) * 1024;

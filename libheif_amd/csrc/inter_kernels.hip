@@ -64,18 +64,7 @@ __device__ __forceinline__ void mk_lds_sync()
 // per access for a lone lane (the first version spent 11.5 ms on a 720p picture that way).  This version uses no scratch.
 struct Mo { int x0, y0, x1, y1, r0, r1; };   // list 0 / list 1 vector (quarter samples) and reference index (< 0: the list is not used)
 __device__ __forceinline__ Mo mo_none() { return Mo{0, 0, 0, 0, -1, -1}; }
-__device__ __forceinline__ int mo_ref(const Mo& m, int L) { return L ? m.r1 : m.r0; }
 __device__ __forceinline__ void mo_set(Mo& m, int L, int x, int y, int r) { if (L) { m.x1 = x; m.y1 = y; m.r1 = r; } else { m.x0 = x; m.y0 = y; m.r0 = r; } }
-__device__ __forceinline__ Mo mo_pick(int i, const Mo& a, const Mo& b, const Mo& c, const Mo& d, const Mo& e, const Mo& f)
-{
-  Mo r = a;
-  if (i == 1) r = b;
-  if (i == 2) r = c;
-  if (i == 3) r = d;
-  if (i == 4) r = e;
-  if (i == 5) r = f;
-  return r;
-}
 // the i-th candidate that is present, in list order (the lists are never stored: a run-time index into one would put it in scratch)
 __device__ __forceinline__ Mo nth_present(int i, int f0, const Mo& m0, int f1, const Mo& m1, int f2, const Mo& m2, int f3, const Mo& m3, int f4, const Mo& m4,
                                           int f5, const Mo& m5)
