@@ -163,11 +163,12 @@ def decode(data, colorspace=COLORSPACE_UNDEFINED, chroma=CHROMA_UNDEFINED, max_t
 ERROR_END_OF_SEQUENCE = 13
 
 
-def decode_track(data, colorspace=COLORSPACE_UNDEFINED, chroma=CHROMA_UNDEFINED, track_id=0, max_images=None):
+def decode_track(data, colorspace=COLORSPACE_UNDEFINED, chroma=CHROMA_UNDEFINED, track_id=0, max_images=None, options=None):
     """heif_track_decode_next_image() (api/libheif/heif_sequences.h:218) on the first visual track until End_of_sequence: what an application does
     with an image-sequence file.  libheif's Track_Visual::decode_next_image_sample (sequences/track_visual.cc:175-330) drives the decoder plugin:
     push_data2 per sample with the sample index as user_data, decode_next_image2 polls, flush_data at the end.  Returns the images in the
-    order libheif delivers them: [{'planes': [Y, Cb, Cr]} | {'rgb': rows}]."""
+    order libheif delivers them: [{'planes': [Y, Cb, Cr]} | {'rgb': rows}].  options: a heif_decoding_options* (e.g. with decoder_id pinned,
+    codecs/decoder.cc:327-340), or None for libheif's defaults."""
     L = lib()
     vp = C.c_void_p
     L.heif_context_get_track.restype = vp
@@ -186,7 +187,7 @@ def decode_track(data, colorspace=COLORSPACE_UNDEFINED, chroma=CHROMA_UNDEFINED,
         assert track
         while max_images is None or len(out) < max_images:
             img = vp()
-            e = L.heif_track_decode_next_image(track, C.byref(img), colorspace, chroma, None)
+            e = L.heif_track_decode_next_image(track, C.byref(img), colorspace, chroma, options)
             if e.code == ERROR_END_OF_SEQUENCE:
                 break
             check(e)

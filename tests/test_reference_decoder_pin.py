@@ -106,6 +106,55 @@ def _check(decoder_id, table, name):
     assert got == g["planes_sha256"][:len(got)], "%s decodes %s/%s differently from the golden planes" % (decoder_id, table, name)
 
 
+# ---- sequence tracks (inter prediction): tests/golden/seq_*.hevcs as image-sequence files through heif_track_decode_next_image() ------------------------
+SEQ_INDEX = json.load(open(os.path.join(GOLD, "golden_sequences.json")))
+
+
+def _check_sequence(decoder_id, name):
+    """the committed track wrapped as an ISO/IEC 14496-12 image sequence (tests/heic_util.py:build_sequence), decoded by libheif's Track_Visual
+    (sequences/track_visual.cc:175-330) with the decoder pinned by id: every image, in the order libheif delivers them (= output order), has the
+    golden hashes of the picture with that PicOrderCnt"""
+    import test_golden_sequences as gs
+    aus, g = gs.load(name)
+    data = heic_util.build_sequence(aus, g["width"], g["height"], bit_depth=g["bit_depth"], chroma_format_idc=g["chroma_format_idc"])
+    H = ref_harness.lib()
+    H.refh_decoding_options.restype = C.c_void_p
+    H.refh_decoding_options.argtypes = [C.c_char_p]
+    keep = C.c_char_p(decoder_id.encode())
+    opts = C.c_void_p(H.refh_decoding_options(keep))
+    try:
+        got = host.decode_track(data, options=opts)
+    finally:
+        host.lib().heif_decoding_options_free(opts)
+    assert len(got) == g["samples"], "%s: %d of %d images came out of the track" % (name, len(got), g["samples"])
+    for poc, img in enumerate(got):
+        assert img["bit_depth"] == g["bit_depth"]
+        gs.check_picture("%s through %s" % (name, decoder_id), g, poc, img["planes"])
+
+
+def test_harness_selftest_decodes_golden_sequences_through_a_second_decoder():
+    """the oracle behind the plugin ABI again (NOT a pin): image-sequence file -> Track_Visual -> the decoder selected by id -> output order -> hashes;
+    proves the sequence harness below before an independent decoder shows up"""
+    sd = os.path.join(REF, "plugins_selftest")
+    if not glob.glob(os.path.join(sd, "*.so")):
+        pytest.skip("self-test plugin not built")
+    _load_plugins([sd])
+    assert "oraclepin" in [i for i, _ in _hevc_decoder_ids()]
+    for name in sorted(SEQ_INDEX):
+        _check_sequence("oraclepin", name)
+
+
+def test_independent_hevc_decoder_reproduces_golden_sequences():
+    """THE pin for inter prediction (8.5.3: merge / AMVP / temporal candidates / weighted prediction, long-term references, ...): no stream of the
+    reference's own fixtures holds a P or B picture, so these generated tracks are what an independent decoder is asked about"""
+    dec = _independent_decoder()
+    if dec is None:
+        pytest.skip("HEVC inter-prediction parity UNPINNED: no independent HEVC decoder plugin is loadable by the reference libheif (see "
+                    "test_independent_hevc_decoder_reproduces_golden)")
+    for name in sorted(SEQ_INDEX):
+        _check_sequence(dec[0], name)
+
+
 def test_harness_selftest_activates_on_a_second_decoder():
     """the oracle behind the plugin ABI: found among the HEVC decoders, selected by id, every golden stream compared — so the harness below is
     known to work before a real independent decoder ever shows up (this is NOT a pin)"""
