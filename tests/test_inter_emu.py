@@ -423,3 +423,21 @@ def test_emulated_chains_of_equal_tracks_keep_the_step_count_of_one():
     aus = orc.encode_sequence(frames, qp=30, temporal_mvp=1, inter_num_refs=2, seed=3)
     step_counts = _check_tracks([aus] * 8, [5] * 8, ["copy%d" % i for i in range(8)])
     assert step_counts == _check_tracks([aus], [5], ["alone"]) and step_counts[0][0] == 5
+
+
+def test_emulated_chains_of_tracks_with_a_cropped_a_monochrome_and_a_restarting_track():
+    """one launch set with: a cropped track (its in-batch references are the uncropped copies of the second SAO pass, whose slots move with the item
+    order), a monochrome track (no chroma waves in the shared ReconWave table), and a track whose second coded video sequence starts INSIDE the chain
+    (an IDR picture in the middle: PicOrderCnt starts over, the pictures before it stop being references)"""
+    cropped = orc.encode_sequence(make_frames(70, 42, 7), qp=22, global_mv_x=3, global_mv_y=17, inter_num_refs=2, amp=1, b_frames=2, b_ref=1, temporal_mvp=1, seed=4)
+    mono = orc.encode_sequence(make_frames(72, 56, 6, 8, mono=True), qp=24, inter_num_refs=2, temporal_mvp=1, weighted_pred=1, seed=5)
+    a = orc.encode_sequence(make_frames(136, 104, 4), qp=26, inter_num_refs=2, temporal_mvp=1)
+    b = orc.encode_sequence(make_frames(136, 104, 4, seed=9), qp=26, inter_num_refs=2, temporal_mvp=1)
+    both = a + [parameter_sets(b[0]) + x if i else x for i, x in enumerate(b)]
+    got, _ = decode_tracks_emu([cropped, mono, both], [4, 5, 7])
+    for t, (name, refs) in enumerate((("cropped", orc.decode_sequence(cropped)), ("mono", orc.decode_sequence(mono)),
+                                      ("two sequences", orc.decode_sequence(a) + orc.decode_sequence(b)))):
+        assert len(got[t]) == len(refs)
+        for i, (r, g) in enumerate(zip(refs, got[t])):
+            for c in range(len(r["planes"])):
+                np.testing.assert_array_equal(g["planes"][c], r["planes"][c], err_msg="%s: picture %d plane %d" % (name, i, c))
