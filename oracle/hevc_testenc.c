@@ -1596,11 +1596,24 @@ static int enc_run(const hevc_testenc_params* prm, int n_frames, const uint16_t*
         for (int q = a - b; q < n_frames; q++) { plan[n].poc = q; plan[n].slice_type = 1; plan[n].nal_type = 1; n++; }
     }
     if (n != n_frames) fail(d, "testenc: picture plan");
+    int cra_poc = -1;
+    if (seq_mode && prm->open_gop > 0) {
+      if (!b || prm->long_term_ref) fail(d, "testenc: open_gop needs b_frames and no long_term_ref");
+      cra_poc = step * prm->open_gop;
+      if (cra_poc >= n_frames) fail(d, "testenc: open_gop names an anchor behind the last picture");
+      for (int k = 1; k < n_frames; k++) {
+        if (plan[k].poc == cra_poc) { plan[k].slice_type = 2; plan[k].nal_type = 21; }                                   /* CRA_NUT */
+        else if (plan[k].slice_type == 0 && plan[k].poc > cra_poc - step && plan[k].poc < cra_poc) plan[k].nal_type = prm->b_ref ? 9 : 8;   /* RASL_R / RASL_N */
+      }
+    }
     const int nrefs = Max(1, prm->inter_num_refs);
     for (int k = 1; k < n_frames; k++) {   /* own references */
       PicPlan* P = &plan[k];
       int prev_anchors[16], npa = 0;
-      for (int j = k - 1; j >= 0 && npa < 16; j--) if (plan[j].slice_type != 0 && plan[j].poc < P->poc) prev_anchors[npa++] = plan[j].poc;
+      if (P->slice_type == 2) continue;   /* (the CRA picture of open_gop: intra; what its RASL pictures need is kept by the loop below) */
+      for (int j = k - 1; j >= 0 && npa < 16; j--)
+        if (plan[j].slice_type != 0 && plan[j].poc < P->poc && !(cra_poc >= 0 && P->poc > cra_poc && plan[j].poc < cra_poc))
+          prev_anchors[npa++] = plan[j].poc;
       /* (coding order of anchors is POC order, so prev_anchors is sorted closest first) */
       if (P->slice_type == 0) {
         if (prm->b_ref && k > 0 && plan[k - 1].slice_type == 0 && plan[k - 1].poc == P->poc - 1) { P->neg_poc[P->n_neg] = P->poc - 1; P->neg_used[P->n_neg++] = 1; }

@@ -45,6 +45,10 @@ typedef struct hevc_testenc_params {
   int constrained_intra_pred;   /* constrained_intra_pred_flag: intra blocks of P / B pictures predict from intra coded neighbours only    */
   int long_term_ref;            /* > 0: the IDR picture stays in the DPB as a LONG-TERM reference picture of every later picture (behind the short-term
                                    ones in both lists): 1 coded in the slice header by its POC LSBs, 2 with delta_poc_msb_present_flag, 3 as a candidate of the SPS */
+  int open_gop;                 /* n > 0 (needs b_frames): the n-th anchor behind the IDR picture is an intra CRA picture (NAL type 21) and the B pictures coded
+                                   after it that precede it in output order are its RASL pictures (RASL_R 9 with b_ref, else RASL_N 8: they predict from the anchor
+                                   BEFORE the CRA picture); pictures behind the CRA picture in output order reference nothing in front of it.  A decoder that starts
+                                   at the CRA picture drops the RASL pictures (8.3.3) and decodes everything else identically */
 } hevc_testenc_params;
 
 /* planes: tightly packed uint16 samples at display size (chroma (w+1)/2 x (h+1)/2).

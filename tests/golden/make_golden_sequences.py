@@ -34,6 +34,8 @@ CASES = [
     ("b_constrained_intra_pred", 136, 104, 7, dict(b_frames=1, temporal_mvp=1, constrained_intra_pred=1, inter_intra_pct=45, log2_ctb=4, log2_max_tb=4)),
     ("b_scaling_lists_sps", 136, 104, 7, dict(b_frames=1, temporal_mvp=1, scaling_list=2, inter_intra_pct=30)),
     ("p_lossless_tskip_ctb32", 104, 72, 6, dict(lossless_pct=30, amp=1, transform_skip=1, log2_ctb=5)),
+    # open GOP: IDR P B B CRA RASL RASL P B B - from the IDR picture on, the CRA picture and its RASL pictures are ordinary pictures
+    ("ibbp_open_gop_cra_rasl", 136, 104, 10, dict(b_frames=2, b_ref=1, temporal_mvp=1, inter_num_refs=2, open_gop=2)),
 ]
 
 

@@ -441,3 +441,64 @@ def test_emulated_chains_of_tracks_with_a_cropped_a_monochrome_and_a_restarting_
         for i, (r, g) in enumerate(zip(refs, got[t])):
             for c in range(len(r["planes"])):
                 np.testing.assert_array_equal(g["planes"][c], r["planes"][c], err_msg="%s: picture %d plane %d" % (name, i, c))
+
+
+# ---- open GOP: a CRA picture with RASL pictures (oracle/hevc_testenc.h: open_gop) ---------------------------------------------------------------------
+def _open_gop_track():
+    frames = make_frames(136, 104, 10)
+    return orc.encode_sequence(frames, qp=27, b_frames=2, b_ref=1, temporal_mvp=1, inter_num_refs=2, open_gop=2, seed=3)
+
+
+def _slice_types(au):
+    return [(x[4] >> 1) & 63 for x in _split(au) if (x[4] >> 1) & 63 < 32]
+
+
+@pytest.mark.parametrize("chain", [0, 16])
+def test_emulated_open_gop_track_from_its_idr_picture(chain):
+    """IDR P B B CRA RASL RASL P B B: decoded from the start, the CRA picture is an ordinary intra picture with a reference picture set and its RASL
+    pictures are ordinary B pictures (NoRaslOutputFlag = 0): every picture equals the oracle's"""
+    aus = _open_gop_track()
+    assert [t for a in aus for t in _slice_types(a)] == [19, 1, 1, 1, 21, 9, 9, 1, 1, 1]
+    check_sequence(aus, "open gop", chain=chain)
+
+
+def test_emulated_track_that_starts_at_a_cra_picture_drops_its_rasl_pictures():
+    """the same track entered at the CRA picture (a seek; libheif pushes from a sync sample): NoRaslOutputFlag = 1, the two RASL pictures reference a
+    picture that was never decoded and are dropped (8.3.3) - they are no items of the chain -, everything else decodes exactly as in the full track:
+    the CRA picture's PicOrderCnt comes from its LSBs alone, the pictures behind it find their references by PicOrderCnt"""
+    L = _lib()
+    aus = _open_gop_track()
+    full = {p["poc"]: p for p in orc.decode_sequence(aus)}
+    ps = parameter_sets(aus[0])
+    entered = [ps + a for a in aus[4:]]          # CRA, RASL, RASL, P, B, B
+    q = C.c_void_p(L.emu_seq_new())
+    try:
+        err = C.create_string_buffer(512)
+        b = L.emu_seq_create_picture(q, entered[0], len(entered[0]), err, 512)
+        assert b, err.value.decode()
+        b = C.c_void_p(b)
+        assert L.emu_run_parse(b) == 0 and L.emu_run_pipeline(b, 15) == 0
+        cra = _read_picture(L, b, 0, False)
+        assert L.emu_seq_commit(q, b) == 0
+        for c in range(3):
+            np.testing.assert_array_equal(cra["planes"][c], full[6]["planes"][c], err_msg="the CRA picture, plane %d" % c)
+        # a RASL picture on its own is refused with "no image" (the decoder object then moves on to the next sample) ...
+        lone = L.emu_seq_create_picture(q, entered[1], len(entered[1]), err, 512)
+        assert not lone and b"RASL" in err.value, err.value
+        # ... and inside a chain it simply is no item
+        group = entered[1:]
+        ptrs = (C.c_char_p * len(group))(*group)
+        sizes = (C.c_size_t * len(group))(*[len(a) for a in group])
+        b = L.emu_seq_create_chain(q, len(group), ptrs, sizes, err, 512)
+        assert b, err.value.decode()
+        b = C.c_void_p(b)
+        n = L.emu_num_items(b)
+        assert [L.emu_item_source(b, i) for i in range(n)] == [2, 3, 4]
+        assert L.emu_run_parse(b) == 0 and L.emu_run_pipeline_chain(b) == 0
+        for i, poc in enumerate([9, 7, 8]):
+            pic = _read_picture(L, b, i, False)
+            for c in range(3):
+                np.testing.assert_array_equal(pic["planes"][c], full[poc]["planes"][c], err_msg="PicOrderCnt %d plane %d" % (poc, c))
+        assert L.emu_seq_commit_chain(q, b) == 0
+    finally:
+        L.emu_seq_free(q)
