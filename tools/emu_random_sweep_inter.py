@@ -61,6 +61,11 @@ def random_case(rng):
     if not mono and (h & 1):
         h += 1
     n = rng.choice([3, 4, 6, 8])
+    # an open GOP (a CRA picture with RASL pictures in the middle of the track) where the structure allows one
+    if cfg["b_frames"] and not cfg["long_term_ref"] and rng.random() < 0.4:
+        k = rng.choice([1, 2])
+        if (cfg["b_frames"] + 1) * k < n:
+            cfg["open_gop"] = k
     return w, h, mono, n, cfg
 
 
