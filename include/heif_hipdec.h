@@ -430,6 +430,10 @@ HIPDEC_API int hipdec_color_swap_endianness(const void* in, size_t is, int w, in
  * no transfer-function maths): BASELINE config 4's "PQ -> linear" stage; evaluated in fp64, tolerance against the published formula 1e-6 relative. */
 HIPDEC_API int hipdec_color_pq_to_linear(const void* in, size_t is, int w, int h, int components, int bits, int big_endian, void* out, size_t os,
                                          void* stream);
+/* The same for hybrid log-gamma code values (ARIB STD-B67 / BT.2100 HLG, transfer_characteristics 18): the inverse OETF per component, scene linear
+ * light normalised to 1.0 (the display's OOTF is not applied).  Not in the reference either ("a real PQ / HLG EOTF stage"). */
+HIPDEC_API int hipdec_color_hlg_to_linear(const void* in, size_t is, int w, int h, int components, int bits, int big_endian, void* out, size_t os,
+                                          void* stream);
 /* nclx.cc:143-173 get_YCbCr_to_RGB_coefficients: {r_cr, g_cb, g_cr, b_cb} */
 HIPDEC_API void hipdec_color_coefficients(const hipdec_nclx* nclx, float out[4]);
 

@@ -338,6 +338,54 @@ __global__ __launch_bounds__(256) void k_pq_to_linear_lut(const uint8_t* in, siz
   }
 }
 
+// Hybrid log-gamma (ARIB STD-B67 / Rec. ITU-R BT.2100 table 5, the inverse OETF): E = E'^2 / 3 for E' <= 1/2, (exp((E' - c) / a) + b) / 12 above, with
+// a = 0.17883277, b = 1 - 4a, c = 1/2 - a ln(4a); per component, scene linear light normalised to 1.0, float32.  (The display's OOTF - a gain over the
+// scene luminance with the system gamma of the viewing environment - is the renderer's business and mixes the components; it is not applied.)  Like
+// the PQ stage it is NOT in the reference (libheif has no transfer-function maths) and it is the PQ kernels' structure with another curve.
+__device__ __forceinline__ double hlg_inverse_oetf(double e)
+{
+  const double a = 0.17883277, b = 1.0 - 4.0 * a, c = 0.5 - a * log(4.0 * a);
+  return e <= 0.5 ? e * e / 3.0 : (exp((e - c) / a) + b) / 12.0;
+}
+__global__ __launch_bounds__(256) void k_hlg_to_linear(const uint8_t* in, size_t is, int n_per_row, int h, int bits, int big_endian, float* out, size_t os)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= n_per_row || y >= h) return;
+  uint32_t v = ((const uint16_t*)(in + (size_t)y * is))[x];
+  if (big_endian) v = ((v & 255u) << 8) | (v >> 8);
+  ((float*)((uint8_t*)out + (size_t)y * os))[x] = (float)hlg_inverse_oetf((double)v / (double)((1u << bits) - 1u));
+}
+__global__ __launch_bounds__(256) void k_hlg_to_linear_lut(const uint8_t* in, size_t is, int n_per_row, int h, int bits, int big_endian, float* out, size_t os)
+{
+  __shared__ float lut[4096];
+  const int n_codes = 1 << bits;
+  for (int v = threadIdx.x; v < n_codes; v += 256) lut[v] = (float)hlg_inverse_oetf((double)v / (double)((1u << bits) - 1u));
+  __syncthreads();
+  const int x0 = blockIdx.x * 1024 + (int)threadIdx.x * 4;
+  const int y0 = blockIdx.y * 16;
+  const uint32_t mask = (uint32_t)n_codes - 1u;
+  for (int r = 0; r < 16; r++) {
+    const int y = y0 + r;
+    if (y >= h || x0 >= n_per_row) break;
+    const uint16_t* src = (const uint16_t*)(in + (size_t)y * is) + x0;
+    float* dst = (float*)((uint8_t*)out + (size_t)y * os) + x0;
+    uint32_t v[4];
+    const bool full = x0 + 4 <= n_per_row && (((uintptr_t)src & 7u) == 0) && (((uintptr_t)dst & 15u) == 0);
+    if (full) { const uint2 w = *(const uint2*)src; v[0] = w.x & 0xffffu; v[1] = w.x >> 16; v[2] = w.y & 0xffffu; v[3] = w.y >> 16; }
+    else for (int k = 0; k < 4; k++) v[k] = x0 + k < n_per_row ? src[k] : 0u;
+    float f[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint32_t c = v[k];
+      if (big_endian) c = ((c & 255u) << 8) | (c >> 8);
+      f[k] = c <= mask ? lut[c] : (float)hlg_inverse_oetf((double)c / (double)((1u << bits) - 1u));   // (a code above 2^bits - 1: the formula itself)
+    }
+    if (full) *(float4*)dst = make_float4(f[0], f[1], f[2], f[3]);
+    else for (int k = 0; k < 4; k++) if (x0 + k < n_per_row) dst[k] = f[k];
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------
 
 // libheif/nclx.cc:45-72
@@ -786,6 +834,23 @@ int hipdec_color_pq_to_linear(const void* in, size_t is, int w, int h, int compo
   } else {
     dim3 block(64, 4), grid((n + 63) / 64, (h + 3) / 4);
     hipLaunchKernelGGL(k_pq_to_linear, grid, block, 0, s, (const uint8_t*)in, is, n, h, bits, big_endian, (float*)out, os);
+  }
+  HIPDEC_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int hipdec_color_hlg_to_linear(const void* in, size_t is, int w, int h, int components, int bits, int big_endian, void* out, size_t os, void* stream)
+{
+  if (int rc = ensure_init()) return rc;
+  if (!in || !out || w <= 0 || h <= 0 || components < 1 || components > 4 || bits < 8 || bits > 16)
+    return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "hlg_to_linear: bad arguments");
+  hipStream_t s = stream ? (hipStream_t)stream : default_stream();
+  const int n = w * components;
+  if (bits <= 12) {
+    hipLaunchKernelGGL(k_hlg_to_linear_lut, dim3((n + 1023) / 1024, (h + 15) / 16), dim3(256), 0, s, (const uint8_t*)in, is, n, h, bits, big_endian, (float*)out, os);
+  } else {
+    dim3 block(64, 4), grid((n + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(k_hlg_to_linear, grid, block, 0, s, (const uint8_t*)in, is, n, h, bits, big_endian, (float*)out, os);
   }
   HIPDEC_CHECK_HIP(hipGetLastError());
   return 0;

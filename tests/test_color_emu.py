@@ -116,11 +116,20 @@ def _pq_reference(code, bits):
     return (np.maximum(p - c1, 0) / (c2 - c3 * p)) ** (1 / m1)
 
 
+def _hlg_reference(code, bits):
+    """ARIB STD-B67 / BT.2100 HLG inverse OETF in fp64 (scene linear light, 1.0 = nominal peak)"""
+    e = code.astype(np.float64) / ((1 << bits) - 1)
+    a = 0.17883277
+    b, c = 1 - 4 * a, 0.5 - a * np.log(4 * a)
+    return np.where(e <= 0.5, e * e / 3.0, (np.exp((e - c) / a) + b) / 12.0)
+
+
 def _bind_f4(L):
     vp, sz, ci = C.c_void_p, C.c_size_t, C.c_int
     L.hipdec_color_to_hdr.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
     L.hipdec_color_swap_endianness.argtypes = [vp, sz, ci, ci, ci, vp, sz, vp]
     L.hipdec_color_pq_to_linear.argtypes = [vp, sz, ci, ci, ci, ci, ci, vp, sz, vp]
+    L.hipdec_color_hlg_to_linear.argtypes = [vp, sz, ci, ci, ci, ci, ci, vp, sz, vp]
     return L
 
 
@@ -148,6 +157,14 @@ def test_emulated_to_hdr_swap_and_pq(w, h):
         _ok(L, L.hipdec_color_pq_to_linear(src.ctypes.data, src.strides[0], w, h, 3, bits, be, out.ctypes.data, out.strides[0], None))
         np.testing.assert_allclose(out, _pq_reference(code, bits), rtol=1e-6, atol=1e-9)
         assert out[0, 0] == 0.0 and abs(out[0, 1] - 1.0) < 1e-6
+    for bits, be in ((10, 0), (12, 1), (16, 0)):      # hybrid log-gamma: both branches of the curve, the table form (<= 12 bit) and the per-sample form
+        code = np.ascontiguousarray(rng.integers(0, 1 << bits, (h, w * 3)).astype(np.uint16))
+        code[0, :3] = (0, (1 << bits) - 1, ((1 << bits) - 1) // 2)
+        src = code.byteswap() if be else code
+        out = np.zeros((h, w * 3), np.float32)
+        _ok(L, L.hipdec_color_hlg_to_linear(src.ctypes.data, src.strides[0], w, h, 3, bits, be, out.ctypes.data, out.strides[0], None))
+        np.testing.assert_allclose(out, _hlg_reference(code, bits), rtol=1e-6, atol=1e-9)
+        assert out[0, 0] == 0.0 and abs(out[0, 1] - 1.0) < 1e-6 and abs(out[0, 2] - 1.0 / 12.0) < 2e-3
 
 
 # ---- > 8-bit planes of any chroma format -> RRGGBB: Op_YCbCr_to_RGB<uint16_t> + Op_RGB_HDR_to_RRGGBBaa_BE [+ swap], one pass ------------------

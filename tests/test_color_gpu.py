@@ -156,6 +156,27 @@ def test_f4_to_hdr_matches_the_compiled_reference_and_swap_pq():
     np.testing.assert_allclose(dst.to_numpy((h, w * 3), np.float32), _pq_reference(code, 10), rtol=1e-6, atol=1e-9)
 
 
+def test_f4_hlg_inverse_oetf_matches_the_published_formula():
+    """hybrid log-gamma code values -> scene linear light (ARIB STD-B67 / BT.2100; SURVEY 8 f4 asks for a PQ / HLG stage, the reference has neither):
+    the table form (10 / 12 bit) and the per-sample form (16 bit) against the formula in fp64, 1e-6 relative"""
+    import ctypes as C
+    import libheif_amd
+    from libheif_amd._capi import DeviceBuffer, check
+    from test_color_emu import _hlg_reference
+    lib = libheif_amd.load_library()
+    vp, sz, ci = C.c_void_p, C.c_size_t, C.c_int
+    lib.hipdec_color_hlg_to_linear.argtypes = [vp, sz, ci, ci, ci, ci, ci, vp, sz, vp]
+    rng = np.random.default_rng(8)
+    w, h = 322, 70
+    for bits in (10, 12, 16):
+        code = np.ascontiguousarray(rng.integers(0, 1 << bits, (h, w * 3)).astype(np.uint16))
+        code[0, :3] = (0, (1 << bits) - 1, ((1 << bits) - 1) // 2)
+        src = DeviceBuffer.from_numpy(code); dst = DeviceBuffer(code.size * 4)
+        check(lib.hipdec_color_hlg_to_linear(src.ptr, w * 6, w, h, 3, bits, 0, dst.ptr, w * 12, None))
+        check(lib.hipdec_stream_synchronize(None))
+        np.testing.assert_allclose(dst.to_numpy((h, w * 3), np.float32), _hlg_reference(code, bits), rtol=1e-6, atol=1e-9)
+
+
 @pytest.mark.parametrize("w,h", [(64, 48), (65, 49), (34, 13), (2, 3), (1, 2), (1281, 33)])
 @pytest.mark.parametrize("bpp", [8, 10])
 def test_f4_bilinear_422_to_444(w, h, bpp):
