@@ -12,7 +12,19 @@
 // librccl is loaded at run time (dlopen), so the plugin has no link-time dependency on it: a host without RCCL gets
 // HIPDEC_ERR_UNSUPPORTED from these entry points and everything else works.
 #include "hipdec_internal.h"
+// Build time needs RCCL's TYPES only (the functions come from dlopen): taken from its header where the toolchain has one, otherwise the handful this
+// file uses is declared here with the values of the NCCL 2.x / RCCL ABI (opaque communicator, 128-byte unique id, enum codes).
+#if defined(__has_include) && __has_include(<rccl/rccl.h>) && !defined(HIPDEC_NO_RCCL_HEADER)
 #include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
+}
+#endif
 #include <dlfcn.h>
 #include <cstring>
 #include <cstdlib>
