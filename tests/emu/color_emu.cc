@@ -6,6 +6,10 @@
 #include <string>
 #include "hipdec_internal.h"
 
+#ifdef HIPEMU_WHOLE_LIBRARY   // libheifhip_emu.so: runtime.hip itself is compiled in
+extern "C" const char* hipdec_last_error(void);
+extern "C" const char* emu_color_last_error() { return hipdec_last_error(); }
+#else
 namespace hipdec {
 
 static thread_local std::string t_err;
@@ -28,3 +32,4 @@ void arena_release(void* p, size_t) { (void)hipFree(p); }
 }  // namespace hipdec
 
 extern "C" const char* emu_color_last_error() { return hipdec::t_err.c_str(); }
+#endif

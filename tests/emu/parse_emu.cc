@@ -176,6 +176,35 @@ size_t emu_sq_get(void* q, int i, uint8_t* dst, size_t cap, uint64_t* user_data,
   return v->size();
 }
 
+}  // extern "C"
+
+// The product's CABAC launchers (parse_kernel*.hip hold gfx950 assembly) for the host build of the WHOLE library (libheifhip_emu.so: decoder.hip,
+// runtime.hip, ... compiled against the shim): the lane-emulated parser over the arguments decoder.hip:launch_all prepared, scheduled as emu_run_parse
+// below does it.  One build of parse_core.h serves intra, inter and 4:2:2 / 4:4:4 batches here.
+typedef void* hipStream_t;   // (as tests/emu/shim/hip/hip_runtime.h has it; this unit does not include the SIMT shim)
+namespace hipdec {
+void launch_parse(const ParseArgs& args, hipStream_t)
+{
+  ParseArgs A = args;
+  if (!A.num_waves) return;
+  pcore::Lds lds;
+  memset(&lds, 0, sizeof(lds));
+  if (A.pool) {
+    A.num_waves = 1;
+    pcore::parse_wave(A, 0, &lds);
+    return;
+  }
+  std::vector<ParseWave> one(A.num_subs);
+  for (uint32_t s = 0; s < A.num_subs; s++) one[s] = ParseWave{s, 1, s + 1, 2};
+  A.waves = one.data();
+  for (uint32_t s = 0; s < A.num_subs; s++) pcore::parse_wave(A, s, &lds);
+}
+void launch_parse_inter(const ParseArgs& a, hipStream_t s) { launch_parse(a, s); }
+void launch_parse_general(const ParseArgs& a, bool, hipStream_t s) { launch_parse(a, s); }
+}  // namespace hipdec
+
+extern "C" {
+
 // runs every substream in index order (a WPP predecessor always has a smaller index); returns the device status word
 int emu_run_parse(EmuBatch* b)
 {

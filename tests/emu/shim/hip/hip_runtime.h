@@ -32,15 +32,58 @@ struct uint4 { unsigned x, y, z, w; };
 struct float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 typedef void* hipStream_t;
-// the few runtime calls the host side of color.hip makes (parameter-block upload of the batched colour launch)
+typedef void* hipEvent_t;
+// The runtime API the HOST side of the library uses (runtime.hip, decoder.hip, color.hip, ...), so that the product's own orchestration - launch
+// sets, chains, the coalescers, pools - runs on the CPU as well (tests/emu/libheifhip_emu.so).  Everything is SYNCHRONOUS: a kernel has finished when
+// its launch returns, so copies are memcpy, streams and events are tokens, synchronisation is a no-op; "device memory" is host memory.  That keeps
+// every ordering the product asks for (it only ever waits for work it enqueued earlier) and hides none of its logic.  HIPEMU_DEVICES: emulated GPUs.
 typedef int hipError_t;
-enum { hipSuccess = 0 };
-enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorPeerAccessAlreadyEnabled = 704 };
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+enum { hipStreamDefault = 0, hipStreamNonBlocking = 1 };
+enum { hipEventDefault = 0, hipEventBlockingSync = 1, hipEventDisableTiming = 2 };
+enum { hipHostMallocDefault = 0 };
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+namespace hipemu {
+inline thread_local int current_device = 0;
+inline int device_count() { const char* e = getenv("HIPEMU_DEVICES"); const int n = e ? atoi(e) : 1; return n < 1 ? 1 : n; }
+}
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 1; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy2D(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind)
+{
+  for (size_t y = 0; y < h; y++) memcpy((char*)d + y * dp, (const char*)s + y * sp, w);
+  return hipSuccess;
+}
+static inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind k, hipStream_t) { return hipMemcpy2D(d, dp, s, sp, w, h, k); }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) { *free_b = size_t(48) << 30; *total_b = size_t(64) << 30; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = hipemu::device_count(); return hipSuccess; }
+static inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= hipemu::device_count()) return hipErrorInvalidValue; hipemu::current_device = d; return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = hipemu::current_device; return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = -1; return hipSuccess; }
+static inline hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return hipSuccess; }
+static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = malloc(8); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { return hipStreamCreate(s); }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = malloc(8); return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.001f; return hipSuccess; }
 using std::min;
 using std::max;
 
