@@ -14,10 +14,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
+def build_emu(target=None):
+    """make -C tests/emu [target] under a file lock: pytest-xdist workers (and tests/test_product_on_emulator.py) ask for it at the same time"""
+    import fcntl
+    with open(os.path.join(HERE, "emu", ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "emu")] + ([target] if target else []))
+
+
 def emu():
     global _LIB
     if _LIB is None:
-        subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "emu")])
+        build_emu()
         L = C.CDLL(os.path.join(HERE, "emu", "libparse_emu.so"))
         L.emu_create.restype = C.c_void_p
         L.emu_create.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]

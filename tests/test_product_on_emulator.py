@@ -23,7 +23,8 @@ MODULES = ["test_sequence_gpu.py", "test_golden_sequences.py", "test_plugin_drop
 
 
 def _build():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "emu"), "libheifhip_emu.so"])
+    from test_parse_emu import build_emu
+    build_emu("libheifhip_emu.so")
     assert os.path.exists(EMU_LIB)
 
 

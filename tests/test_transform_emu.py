@@ -15,7 +15,8 @@ _LIB = None
 def emu():
     global _LIB
     if _LIB is None:
-        subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "emu")])
+        from test_parse_emu import build_emu
+        build_emu()
         L = C.CDLL(os.path.join(HERE, "emu", "libparse_emu.so"))
         L.hipdec_plane_rotate_ccw.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         L.hipdec_plane_mirror.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
