@@ -404,6 +404,29 @@ def test_a_corrupt_track_beside_good_ones_fails_alone():
                 np.testing.assert_array_equal(img.planes[c], by_poc[out_idx]["planes"][c], err_msg="track %d POC %d plane %d" % (k, out_idx, c))
 
 
+def test_track_entered_at_a_cra_picture_drops_its_rasl_pictures(lookahead):
+    """IDR P B B CRA RASL RASL P B B, decoded from the CRA picture on (a seek to a sync sample): the CRA picture's PicOrderCnt comes from its LSBs
+    alone, its two RASL pictures predict from a picture that was never decoded and are dropped (8.3.3) - no picture, no error -, everything else equals
+    the full track's pictures, in output order with the user_data of its own sample"""
+    from test_inter_oracle import make_frames
+    from test_inter_emu import parameter_sets
+    frames = make_frames(136, 104, 10)
+    aus = orc.encode_sequence(frames, qp=27, b_frames=2, b_ref=1, temporal_mvp=1, inter_num_refs=2, open_gop=2, seed=3)
+    full = {p["poc"]: p for p in orc.decode_sequence(aus)}
+    entered = [parameter_sets(aus[0]) + aus[4]] + list(aus[5:])      # CRA, RASL, RASL, P (POC 9), B (7), B (8)
+    got = _play_track(entered, None)
+    assert [ud for _, ud in got] == [900, 904, 905, 903], [ud for _, ud in got]
+    for (img, _), poc in zip(got, [6, 7, 8, 9]):
+        for c in range(3):
+            np.testing.assert_array_equal(img.planes[c], full[poc]["planes"][c], err_msg="PicOrderCnt %d plane %d" % (poc, c))
+    # and the whole track from its IDR picture: the CRA picture and its RASL pictures are ordinary pictures there
+    got = _play_track(aus, None)
+    assert len(got) == 10
+    for out_idx, (img, _) in enumerate(got):
+        for c in range(3):
+            np.testing.assert_array_equal(img.planes[c], full[out_idx]["planes"][c], err_msg="from the IDR picture: PicOrderCnt %d plane %d" % (out_idx, c))
+
+
 def test_b_sequence_in_coding_order_through_the_legacy_call():
     """hipdec_decoder_decode keeps delivering the picture of the sample just pushed (coding order): the planes are those of that POC"""
     from libheif_amd.decoder import HipDecoder
