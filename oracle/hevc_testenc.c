@@ -1193,7 +1193,8 @@ static void enc_parameter_sets(Enc* e, Bytes* pstream)
   bw_free(&w);
   /* PPS 7.3.2.3 */
   p->dependent_slice_segments_enabled_flag = prm->dependent_segments > 1;
-  bw_ue(&w, 0); bw_ue(&w, 0); bw_u(&w, p->dependent_slice_segments_enabled_flag, 1); bw_u(&w, 0, 1); bw_u(&w, 0, 3);
+  p->output_flag_present_flag = d->seq_mode && prm->hidden_poc > 0;
+  bw_ue(&w, 0); bw_ue(&w, 0); bw_u(&w, p->dependent_slice_segments_enabled_flag, 1); bw_u(&w, p->output_flag_present_flag, 1); bw_u(&w, 0, 3);
   bw_u(&w, p->sign_data_hiding_enabled_flag, 1); bw_u(&w, p->cabac_init_present_flag, 1); bw_ue(&w, 0); bw_ue(&w, 0);
   bw_se(&w, p->init_qp_minus26); bw_u(&w, p->constrained_intra_pred_flag, 1); bw_u(&w, p->transform_skip_enabled_flag, 1);
   bw_u(&w, p->cu_qp_delta_enabled_flag, 1);
@@ -1460,6 +1461,7 @@ static void enc_picture(Enc* e, const uint16_t* const planes[3], const PicPlan* 
     }
     if (!is_dep) {
       bw_ue(&w, hdr.slice_type);
+      if (p->output_flag_present_flag) bw_u(&w, frame_idx != prm->hidden_poc, 1);   /* pic_output_flag */
       if (nal_type != 19 && nal_type != 20) {   /* 7.3.6.1: POC lsb, the picture's RPS coded in the slice header (idx == num_short_term_ref_pic_sets == 0: no inter-RPS flag) */
         bw_u(&w, frame_idx & 255, s->log2_max_poc_lsb);
         bw_u(&w, 0, 1);                                   /* short_term_ref_pic_set_sps_flag */

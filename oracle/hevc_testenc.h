@@ -49,6 +49,8 @@ typedef struct hevc_testenc_params {
                                    after it that precede it in output order are its RASL pictures (RASL_R 9 with b_ref, else RASL_N 8: they predict from the anchor
                                    BEFORE the CRA picture); pictures behind the CRA picture in output order reference nothing in front of it.  A decoder that starts
                                    at the CRA picture drops the RASL pictures (8.3.3) and decodes everything else identically */
+  int hidden_poc;               /* > 0: output_flag_present_flag = 1 and the picture with this PicOrderCnt carries pic_output_flag = 0: it is decoded and may be
+                                   referenced but never output (C.5.2.2); every other picture carries pic_output_flag = 1 */
 } hevc_testenc_params;
 
 /* planes: tightly packed uint16 samples at display size (chroma (w+1)/2 x (h+1)/2).

@@ -257,7 +257,7 @@ class _EncParams(C.Structure):
         [(n, C.c_int) for n in (
             "inter_num_refs", "inter_skip_pct", "inter_intra_pct", "inter_merge_pct", "amp", "max_merge_cand", "parallel_merge_level",
             "max_transform_hierarchy_depth_inter", "cabac_init_present", "lists_modification", "global_mv_x", "global_mv_y",
-            "b_frames", "b_ref", "inter_bi_pct", "temporal_mvp", "weighted_pred", "mvd_l1_zero", "constrained_intra_pred", "long_term_ref", "open_gop")]
+            "b_frames", "b_ref", "inter_bi_pct", "temporal_mvp", "weighted_pred", "mvd_l1_zero", "constrained_intra_pred", "long_term_ref", "open_gop", "hidden_poc")]
 
 
 ENC_DEFAULTS = dict(bit_depth=8, chroma_format_idc=1, log2_ctb=6, log2_min_cb=3, log2_min_tb=2, log2_max_tb=5,
@@ -269,7 +269,7 @@ ENC_DEFAULTS = dict(bit_depth=8, chroma_format_idc=1, log2_ctb=6, log2_min_cb=3,
                     seed=1, stress=0, zero_residual_pct=0, dependent_segments=0,
                     inter_num_refs=1, inter_skip_pct=20, inter_intra_pct=10, inter_merge_pct=40, amp=0, max_merge_cand=5, parallel_merge_level=2,
                     max_transform_hierarchy_depth_inter=1, cabac_init_present=0, lists_modification=0, global_mv_x=0, global_mv_y=0,
-                    b_frames=0, b_ref=0, inter_bi_pct=50, temporal_mvp=0, weighted_pred=0, mvd_l1_zero=0, constrained_intra_pred=0, long_term_ref=0, open_gop=0)
+                    b_frames=0, b_ref=0, inter_bi_pct=50, temporal_mvp=0, weighted_pred=0, mvd_l1_zero=0, constrained_intra_pred=0, long_term_ref=0, open_gop=0, hidden_poc=0)
 
 
 def synth_image(width, height, bit_depth=8, chroma_format_idc=1, seed=1):

@@ -427,6 +427,21 @@ def test_track_entered_at_a_cra_picture_drops_its_rasl_pictures(lookahead):
             np.testing.assert_array_equal(img.planes[c], full[out_idx]["planes"][c], err_msg="from the IDR picture: PicOrderCnt %d plane %d" % (out_idx, c))
 
 
+@pytest.mark.parametrize("hidden", [3, 2], ids=["an_anchor", "a_reference_b"])
+def test_picture_with_pic_output_flag_0_is_decoded_but_never_output(hidden, lookahead):
+    """output_flag_present_flag = 1 and one picture with pic_output_flag = 0 (7.4.7.1): it is a reference picture of its neighbours like any other, the
+    bumping process never hands it out (C.5.2.2) - the track delivers one picture less, the others unchanged and in output order"""
+    aus, refs = _p_sequence(8, b_frames=2, b_ref=1, temporal_mvp=1, inter_num_refs=2, hidden_poc=hidden, seed=5)
+    by_poc = {r["poc"]: r for r in refs}
+    coding = [r["poc"] for r in refs]
+    got = _play_track(aus, refs)
+    shown = [p for p in range(8) if p != hidden]
+    assert [ud for _, ud in got] == [900 + coding.index(p) for p in shown]
+    for (img, _), poc in zip(got, shown):
+        for c in range(3):
+            np.testing.assert_array_equal(img.planes[c], by_poc[poc]["planes"][c], err_msg="PicOrderCnt %d plane %d" % (poc, c))
+
+
 def test_b_sequence_in_coding_order_through_the_legacy_call():
     """hipdec_decoder_decode keeps delivering the picture of the sample just pushed (coding order): the planes are those of that POC"""
     from libheif_amd.decoder import HipDecoder
