@@ -84,6 +84,24 @@ for devices in (None, [0, 1, 2, 3], [3, 1], [0, 1, 2, 3, 0, 1]):
     assert (g.planes()[0] == canvas[0][:250, :380]).all()
     g.free()
     out.append([a.value, b.value, c.value])
+# a damaged tile that lives on another device than the root's: the decode reports the device error (no hang, no half-written success), and the next
+# photo decodes on all four devices again
+from libheif_amd import HipDecError
+from libheif_amd.grid import GridDecoderC, GridLayout
+streams = [orc.encode(orc.synth_image(128, 128, 8, 1, seed=70 + t)) for t in range(6)]
+bad = bytearray(streams[2])
+for k in range(200, 260):
+    bad[k] ^= 0x55
+try:
+    g = GridDecoderC({t: (bytes(bad) if t == 2 else s) for t, s in enumerate(streams)}, GridLayout(2, 3, 128, 128, 380, 250), None)
+    g.decode(); g.wait()
+    raise SystemExit("the damaged tile decoded without an error")
+except HipDecError as e:
+    assert "device decode error" in str(e) or "bitstream" in str(e).lower(), str(e)
+g = GridDecoderC({t: s for t, s in enumerate(streams)}, GridLayout(2, 3, 128, 128, 380, 250), None)
+g.decode(); g.wait()
+assert (g.planes()[0][:128, 256:380] == orc.decode(streams[2])["planes"][0][:, :124]).all()
+g.free()
 print("TRANSPORT " + json.dumps(out))
 """
 
