@@ -121,3 +121,28 @@ def test_grid_shards_over_four_emulated_devices():
     # [local, peer, staged] shards: with all four devices (or the explicit list) one shard is the root's own, three reach the canvas by peer access
     assert transport[0] == [1, 3, 0] and transport[1] == [1, 3, 0], transport
     assert transport[2][0] + transport[2][1] + transport[2][2] == 2 and transport[3][0] + transport[3][1] + transport[3][2] == 6, transport
+
+
+def test_grid_rccl_path_with_three_ranks_over_a_toy_transport(tmp_path):
+    """hipdec_grid_*_rccl, the one-process-per-GPU form, with THREE ranks: three processes, each with the emulated library on its own emulated
+    device, and tests/emu/libfake_rccl.so (files in a directory) where librccl would be.  Every rank decodes its tiles t mod 3, the grouped send / receive
+    gathers the packed tiles on rank 0, which pastes and converts; a damaged tile on rank 1 makes EVERY rank's wait fail; the communicator survives.  The
+    RCCL transport itself is not exercised (world size 1 on the GPU box, N ranks first in `bench.py --gpus N`)."""
+    from test_parse_emu import build_emu
+    _build()
+    build_emu("libfake_rccl.so")
+    env = dict(os.environ, HIPDEC_LIBRARY=EMU_LIB, HIPDEC_DEV_AB="1", HIPEMU_DEVICES="3", HIPDEC_RCCL_LIBRARY=os.path.join(HERE, "emu", "libfake_rccl.so"),
+               TMPDIR=str(tmp_path), PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    idfile = str(tmp_path / "unique_id")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "emu", "rccl_rank.py"), str(r), "3", idfile], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(3)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=900)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("a rank hangs (a collective nobody answers?)")
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("RANK %d OK" % r) in o, "rank %d:\n%s" % (r, o[-3000:])
