@@ -43,7 +43,7 @@ for rnd in range(rounds):
         jobs = []
         for _ in range(rng.choice([1, 2, 4])):
             s, ref = pool[rng.randrange(len(pool))]
-            bad = rng.random() < 0.12
+            bad = rng.random() < float(os.environ.get("STRESS_DAMAGED", "0.12"))
             if bad:
                 b = bytearray(s)
                 for _ in range(rng.choice([1, 4, 16])):

@@ -70,7 +70,7 @@ for rnd in range(rounds):
     jobs = []
     for t in range(n_threads):
         aus, by_poc, coding = pool[rng.randrange(len(pool))]
-        bad = rng.random() < 0.15
+        bad = rng.random() < float(os.environ.get("STRESS_DAMAGED", "0.15"))
         pauses = [rng.choice([0, 0, 0, 0.001, 0.01, 0.05]) for _ in aus]
         jobs.append((damaged(aus) if bad else aus, by_poc, coding, bad, pauses, []))
     threads = [threading.Thread(target=play, args=(j[0], j[4], j[5])) for j in jobs]
