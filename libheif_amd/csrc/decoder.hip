@@ -877,15 +877,19 @@ struct Coalescer {
 
 long coalesce_window_us()
 {
-  if (g_co.window_us < 0) {
+  // the knobs are read ONCE, by whichever thread asks first (a function-local static: initialised under the language's own lock - application threads
+  // reach this concurrently, and an unguarded "if (window_us < 0)" was a data race ThreadSanitizer pointed at on the host build of the library)
+  static const bool once = [] {
     const char* e = std::getenv("HIPDEC_COALESCE_WINDOW_US");   // 0 disables coalescing
-    g_co.window_us = e ? std::max(0L, std::atol(e)) : 2000;
     if (const char* q = std::getenv("HIPDEC_COALESCE_QUIET_US")) g_co.quiet_us = std::max(1L, std::atol(q));
     if (const char* q = std::getenv("HIPDEC_COALESCE_BUSY")) g_co.busy_requests = std::max(0L, std::atol(q));
     if (const char* q = std::getenv("HIPDEC_COALESCE_HOLD_US")) g_co.hold_us = std::max(0L, std::atol(q));
     if (const char* q = std::getenv("HIPDEC_COALESCE_SETS")) g_co.max_sets = (int)std::max(1L, std::atol(q));
     if (const char* q = std::getenv("HIPDEC_COALESCE_MAX_SET")) g_co.max_set = std::max(1L, std::atol(q));
-  }
+    g_co.window_us = e ? std::max(0L, std::atol(e)) : 2000;
+    return true;
+  }();
+  (void)once;
   return g_co.window_us;
 }
 
@@ -1375,12 +1379,14 @@ struct ChainCoalescer {
 
 long chain_window_us()
 {
-  if (g_chains.window_us < 0) {
+  static const bool once = [] {      // (read once, thread-safely: see coalesce_window_us)
     const char* e = std::getenv("HIPDEC_CHAIN_WINDOW_US");
-    g_chains.window_us = e ? std::max(0L, std::atol(e)) : 20000;
     if (const char* q = std::getenv("HIPDEC_CHAIN_FLIGHT_US")) g_chains.flight_us = std::max(0L, std::atol(q));
     if (const char* q = std::getenv("HIPDEC_CHAIN_MAX_PICTURES")) g_chains.max_pictures = std::max(1L, std::atol(q));
-  }
+    g_chains.window_us = e ? std::max(0L, std::atol(e)) : 20000;
+    return true;
+  }();
+  (void)once;
   return g_chains.window_us;
 }
 
