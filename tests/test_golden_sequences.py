@@ -75,3 +75,23 @@ def test_hip_decoder_reproduces_golden_sequence(name):
     for out_idx, (img, user_data) in enumerate(got):
         assert user_data == 900 + g["coding_order_pocs"].index(out_idx), (name, out_idx, user_data)
         check_picture(name, g, out_idx, img.planes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(INDEX))
+def test_hip_plugin_reproduces_golden_sequence_through_libheif(name):
+    """the track as an image-sequence file (ISO/IEC 14496-12 movie boxes, tests/heic_util.py:build_sequence) through the REAL libheif: Track_Visual pushes
+    the samples into the plugin and polls it (sequences/track_visual.cc:175-330); every image heif_track_decode_next_image() delivers, in output order,
+    has the golden hashes"""
+    import heic_util
+    import libheif_host as lh
+    if not lh.available():
+        pytest.skip("oracle/_ref/libheif.so not built")
+    lh.load_hip_plugin()
+    aus, g = load(name)
+    data = heic_util.build_sequence(aus, g["width"], g["height"], bit_depth=g["bit_depth"], chroma_format_idc=g["chroma_format_idc"])
+    got = lh.decode_track(data)
+    assert len(got) == g["samples"]
+    for poc, img in enumerate(got):
+        assert img["bit_depth"] == g["bit_depth"]
+        check_picture(name + " through libheif", g, poc, img["planes"])
