@@ -8,7 +8,7 @@ sets, a corrupt track beside good ones, concurrent decoder instances) and the ca
 
 Only what depends on timing or on the hardware stays GPU-only: kernel performance, memory ordering between wavefronts (the emulator runs a launch to
 completion before the next one starts), and the tests that need torch's CUDA runtime.  `bash tools/gpu_tier_on_emulator.sh` runs the WHOLE GPU tier this
-way (466 of 468 tests in ~2 minutes on 8 cores); this module runs the host-orchestration subset inside the CPU tier."""
+way (478 of 480 tests in ~2 minutes on 8 cores); this module runs the host-orchestration subset inside the CPU tier."""
 import os
 import subprocess
 import sys
