@@ -13,6 +13,9 @@ class HipDecError(RuntimeError):
         self.code = code
         self.message = message
 
+    def __reduce__(self):   # (picklable: worker processes of the sweep tools hand exceptions back to their parent)
+        return (HipDecError, (self.code, self.message))
+
 
 class ImageInfo(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("chroma_format_idc", C.c_int),

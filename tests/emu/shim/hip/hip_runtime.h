@@ -228,6 +228,7 @@ void launch(dim3 grid, dim3 block, F&& fn)
     munmap(stacks, kStack * (size_t)n);
   };
   const int nt = (int)std::min<size_t>(total, (size_t)std::max(1, pool_threads()));
+  if (nt <= 1) { worker(); return; }   // (HIPEMU_THREADS=1: the groups run on the launching thread - what the ThreadSanitizer host wants, tools/emu_tsan_host.sh)
   std::vector<std::thread> th;
   for (int i = 0; i < nt; i++) th.emplace_back(worker);
   for (auto& t : th) t.join();
