@@ -32,8 +32,11 @@ static release_fn image_release, handle_release; static dim_fn handle_w, handle_
 
 struct file { uint8_t* data; size_t size; };
 static struct file* files; static int n_files; static int n_threads; static int want_rgb;
-static volatile int stop_flag; static pthread_barrier_t start_barrier;
-struct worker { pthread_t th; int k; volatile long decodes; volatile double px; int failed; };
+static int stop_flag; static pthread_barrier_t start_barrier;
+struct worker { pthread_t th; int k; long decodes; double px; int failed; };   /* decodes / px: the owner adds, main reads (relaxed atomics) */
+static long ld_long(const long* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+static double ld_double(const double* p) { uint64_t u = __atomic_load_n((const uint64_t*)p, __ATOMIC_RELAXED); double d; memcpy(&d, &u, 8); return d; }
+static void add_double(double* p, double v) { double d = ld_double(p) + v; uint64_t u; memcpy(&u, &d, 8); __atomic_store_n((uint64_t*)p, u, __ATOMIC_RELAXED); }
 
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
@@ -44,7 +47,7 @@ typedef int (*dnew_fn)(void**, int, uint64_t); typedef void (*dfree_fn)(void*); 
 typedef int (*ddec_fn)(void*, void*); typedef int (*dread_fn)(void*, int, void*, size_t);
 static dnew_fn d_new; static dfree_fn d_free; static dpush_fn d_push; static ddec_fn d_decode; static dread_fn d_read;
 static int direct_mode;
-static int decode_direct(const struct file* f, volatile double* px, uint8_t* buf)
+static int decode_direct(const struct file* f, double* px, uint8_t* buf)
 {
   void* d = NULL;
   int info[32];
@@ -56,14 +59,14 @@ static int decode_direct(const struct file* f, volatile double* px, uint8_t* buf
     rc = d_read(d, 0, buf, (size_t)w);
     if (!rc) rc = d_read(d, 1, buf + (size_t)w * h, (size_t)w / 2);
     if (!rc) rc = d_read(d, 2, buf + (size_t)w * h * 5 / 4, (size_t)w / 2);
-    *px += (double)w * h;
+    add_double(px, (double)w * h);
   }
   d_free(d);
   return rc;
 }
 
 static uint64_t decode_us_total, decode_calls_total;   /* time inside heif_decode_image, all threads */
-static int decode_one(const struct file* f, volatile double* px)
+static int decode_one(const struct file* f, double* px)
 {
   void* ctx = ctx_alloc();
   struct heif_error e = read_mem(ctx, f->data, f->size, NULL);
@@ -73,7 +76,7 @@ static int decode_one(const struct file* f, volatile double* px)
   if (!e.code) e = decode(h, &img, want_rgb ? 1 /* heif_colorspace_RGB */ : 0 /* YCbCr */, want_rgb ? 10 /* interleaved RGB */ : 1 /* 4:2:0 */, NULL);
   __atomic_fetch_add(&decode_us_total, (uint64_t)((now() - t0) * 1e6), __ATOMIC_RELAXED);
   __atomic_fetch_add(&decode_calls_total, 1, __ATOMIC_RELAXED);
-  if (!e.code) *px += (double)handle_w(h) * handle_h(h);
+  if (!e.code) add_double(px, (double)handle_w(h) * handle_h(h));
   else fprintf(stderr, "decode failed: %d.%d %s\n", e.code, e.subcode, e.message ? e.message : "");
   if (img) image_release(img);
   if (h) handle_release(h);
@@ -87,9 +90,9 @@ static void* run(void* arg)
   uint8_t* buf = direct_mode ? (uint8_t*)malloc((size_t)3840 * 2160 * 2) : NULL;
   if (buf) memset(buf, 1, (size_t)3840 * 2160 * 2);
   pthread_barrier_wait(&start_barrier);
-  for (int i = w->k; !stop_flag; i += n_threads) {
+  for (int i = w->k; !__atomic_load_n(&stop_flag, __ATOMIC_RELAXED); i += n_threads) {
     if (direct_mode ? decode_direct(&files[i % n_files], &w->px, buf) : decode_one(&files[i % n_files], &w->px)) { w->failed = 1; break; }
-    w->decodes++;
+    __atomic_store_n(&w->decodes, w->decodes + 1, __ATOMIC_RELAXED);
   }
   free(buf);
   return NULL;
@@ -143,16 +146,16 @@ int main(int argc, char** argv)
   const double warm = getenv("DROPIN_WARMUP_S") ? atof(getenv("DROPIN_WARMUP_S")) : 3.0;
   usleep((useconds_t)(warm * 1e6));
   long n0 = 0; double p0 = 0;
-  for (int k = 0; k < n_threads; k++) { n0 += ws[k].decodes; p0 += ws[k].px; }
+  for (int k = 0; k < n_threads; k++) { n0 += ld_long(&ws[k].decodes); p0 += ld_double(&ws[k].px); }
   if (stats) stats(&r0, &s0, &x0);
   const double t0 = now();
   usleep((useconds_t)(seconds * 1e6));
   long n = 0; double px = 0; int failed = 0;
-  for (int k = 0; k < n_threads; k++) { n += ws[k].decodes; px += ws[k].px; }
+  for (int k = 0; k < n_threads; k++) { n += ld_long(&ws[k].decodes); px += ld_double(&ws[k].px); }
   const double dt = now() - t0;
   if (stats) stats(&r1, &s1, &x1);
   n -= n0; px -= p0;
-  stop_flag = 1;
+  __atomic_store_n(&stop_flag, 1, __ATOMIC_RELAXED);
   for (int k = 0; k < n_threads; k++) { pthread_join(ws[k].th, NULL); failed |= ws[k].failed; }
   if (decode_calls_total) fprintf(stderr, "[dropin_host] %d threads: heif_decode_image took %.1f ms on average over %llu calls\n", n_threads,
                                   decode_us_total / 1e3 / decode_calls_total, (unsigned long long)decode_calls_total);

@@ -10,16 +10,8 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SAN=${SAN:-thread}
 B=${TSAN_HOST_BUILD:-$ROOT/build/$SAN-host}
 mkdir -p $B
-C=$ROOT/libheif_amd/csrc; E=$ROOT/tests/emu
-FLAGS="-std=c++17 -fPIC -Wno-unknown-pragmas -fno-strict-aliasing -w -DHIPDEC_HOST_EMU=1 -DHIPDEC_PARSE_INTER=1 -DHIPDEC_NO_RCCL_HEADER -DHIPEMU_WHOLE_LIBRARY -I$E/shim -I$E -I$ROOT/include -I$C"
-pids=()
-for f in $E/parse_emu.cc $E/pipeline_emu.cc $E/color_emu.cc $C/residual_kernel.hip $C/recon_kernel.hip $C/filter_kernels.hip $C/color.hip $C/transform.hip $C/inter_kernels.hip; do
-  g++ -O2 -g $FLAGS -c -x c++ $f -o $B/$(basename $f).o & pids+=($!)
-done
-for f in $C/hevc_headers.hip $C/batch_layout.hip $C/decoder.hip $C/runtime.hip $C/plugin.hip $C/grid_rccl.hip $E/tsan_host.cc; do
-  g++ -O1 -g -fsanitize=$SAN -fno-omit-frame-pointer $FLAGS -c -x c++ $f -o $B/$(basename $f).o & pids+=($!)
-done
-for p in "${pids[@]}"; do wait $p; done
-g++ -fsanitize=$SAN -o $B/tsan_host $B/*.o -lpthread -ldl
+. $ROOT/tools/emu_tsan_objects.sh
+g++ -O1 -g -fsanitize=$SAN -fno-omit-frame-pointer $FLAGS -c $E/tsan_host.cc -o $B/tsan_host.o
+g++ -fsanitize=$SAN -o $B/tsan_host $B/tsan_host.o $B/obj/*.o -lpthread -ldl
 cd $ROOT
 HIPEMU_THREADS=1 TSAN_OPTIONS="halt_on_error=0 second_deadlock_stack=1 history_size=4" $B/tsan_host $ROOT/tests/golden "${@}"
