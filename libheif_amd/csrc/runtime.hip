@@ -14,15 +14,15 @@ namespace hipdec {
 
 static thread_local std::string t_last_error = "";
 static std::mutex g_init_mutex;
-static bool g_initialised = false;
-static int g_device = 0;                      // the device hipdec_init() selected: what every entry point uses ...
+static std::atomic<bool> g_initialised{false};   // read without the mutex by every entry point (ensure_init): release-stored once everything below is set up
+static std::atomic<int> g_device{0};          // the device hipdec_init() selected: what every entry point uses ...
 static thread_local int t_device_override = -1;   // ... unless a DeviceScope is active on this thread (multi-device grid decode)
 constexpr int kMaxDevices = 16;
 struct DeviceStreams { hipStream_t stream = nullptr, upload = nullptr, post = nullptr; };
 static std::atomic<int> g_stage_overlap{0};
 static DeviceStreams g_streams[kMaxDevices];   // created on first use of a device, destroyed by hipdec_shutdown()
 static std::mutex g_streams_mu;
-static int g_cu_count = 256;                 // compute units of the selected device
+static std::atomic<int> g_cu_count{256};      // compute units of the selected device
 static std::atomic<int> g_concurrent{1};      // batches the host keeps in flight at a time (hipdec_set_concurrent_batches)
 static std::atomic<int> g_reserved_slots{getenv("HIPDEC_RESERVED_WAVE_SLOTS") ? atoi(getenv("HIPDEC_RESERVED_WAVE_SLOTS")) : 0};   // wave slots per SIMD the
                                               // CABAC pools leave free (hipdec_set_reserved_wave_slots)
@@ -38,11 +38,11 @@ int set_error(int code, const char* fmt, ...)
   return code;
 }
 
-int active_device() { return t_device_override >= 0 ? t_device_override : g_device; }
+int active_device() { return t_device_override >= 0 ? t_device_override : g_device.load(std::memory_order_relaxed); }
 
 int ensure_init()
 {
-  if (g_initialised) {
+  if (g_initialised.load(std::memory_order_acquire)) {
     // every host thread needs the device selected once; hipSetDevice is cheap
     const int dev = active_device();
     hipError_t e = hipSetDevice(dev);
@@ -101,7 +101,7 @@ uint32_t parse_wave_budget()
   // set to end (measured, tools/concurrency_probe.py: one 4K colour conversion 354 ms beside an 8-per-SIMD pool, 2 ms beside a 7-per-SIMD one)
   int reserved = g_reserved_slots.load(std::memory_order_relaxed);
   reserved = reserved < 0 ? 0 : (reserved > 4 ? 4 : reserved);
-  const uint32_t slots = (uint32_t)g_cu_count * 4u * (uint32_t)(8 - reserved);
+  const uint32_t slots = (uint32_t)g_cu_count.load(std::memory_order_relaxed) * 4u * (uint32_t)(8 - reserved);
   return slots / (uint32_t)(c < 1 ? 1 : c);
 }
 
@@ -350,7 +350,7 @@ extern "C" {
 int hipdec_init(int device_index)
 {
   std::lock_guard<std::mutex> lock(g_init_mutex);
-  if (g_initialised && (device_index < 0 || device_index == g_device)) return 0;
+  if (g_initialised.load(std::memory_order_relaxed) && (device_index < 0 || device_index == g_device.load(std::memory_order_relaxed))) return 0;
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0)
@@ -373,16 +373,19 @@ int hipdec_init(int device_index)
     const long pages = sysconf(_SC_PHYS_PAGES), page = sysconf(_SC_PAGESIZE);
     if (pages > 0 && page > 0) g_max_pinned_cached.store(std::min((size_t)pages * (size_t)page / 8, size_t(24) << 30));
   }
-  g_device = dev;
-  g_initialised = true;
-  if (!default_stream()) { g_initialised = false; return set_error(HIPDEC_ERR_DEVICE, "could not create a HIP stream on device %d", dev); }
+  const int prev_dev = g_device.load(std::memory_order_relaxed);
+  g_device.store(dev, std::memory_order_relaxed);   // (default_stream() is the stream of the active device)
+  if (!default_stream()) { g_device.store(prev_dev, std::memory_order_relaxed); return set_error(HIPDEC_ERR_DEVICE, "could not create a HIP stream on device %d", dev); }
+  // published LAST: a thread that finds the flag set in ensure_init() skips this mutex (a plain bool read there was a data race ThreadSanitizer
+  // reported when application threads made the library's first calls concurrently - and the flag used to be set before the stream existed)
+  g_initialised.store(true, std::memory_order_release);
   return 0;
 }
 
 void hipdec_shutdown(void)
 {
   std::lock_guard<std::mutex> lock(g_init_mutex);
-  if (!g_initialised) return;
+  if (!g_initialised.load(std::memory_order_relaxed)) return;
   hipdec_forget_resident_planes();
   arena_pool_clear();
   pinned_pool_clear();
@@ -402,7 +405,7 @@ void hipdec_shutdown(void)
       d = DeviceStreams{};
     }
   }
-  g_initialised = false;
+  g_initialised.store(false, std::memory_order_release);
 }
 
 int hipdec_set_arena_cache_bytes(size_t bytes)

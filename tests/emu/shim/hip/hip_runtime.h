@@ -87,6 +87,11 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) 
 using std::min;
 using std::max;
 
+#if defined(__SANITIZE_THREAD__)
+#define HIPEMU_NOSAN __attribute__((no_sanitize_thread))
+#else
+#define HIPEMU_NOSAN
+#endif
 namespace hipemu {
 
 constexpr size_t kStack = 256 << 10;
@@ -128,10 +133,10 @@ struct Group {
 
 inline thread_local Group* g = nullptr;
 
-inline void yield_lane() { Group* G = g; swapcontext(&G->lanes[G->cur].ctx, &G->sched); }
+HIPEMU_NOSAN inline void yield_lane() { Group* G = g; swapcontext(&G->lanes[G->cur].ctx, &G->sched); }
 
 // returns the result slot of the convergence point the calling lane took part in
-inline int wave_converge(bool pred, uint32_t val)
+HIPEMU_NOSAN inline int wave_converge(bool pred, uint32_t val)
 {
   Group* G = g;
   const int t = G->cur, w = t >> 6, l = t & 63;
@@ -146,7 +151,7 @@ inline int wave_converge(bool pred, uint32_t val)
   return (int)(my & 1);
 }
 
-inline void group_converge()
+HIPEMU_NOSAN inline void group_converge()
 {
   Group* G = g;
   Coll& C = G->bar;
@@ -156,7 +161,7 @@ inline void group_converge()
   else while (C.gen == my) yield_lane();
 }
 
-inline void lane_entry()
+HIPEMU_NOSAN inline void lane_entry()
 {
   Group* G = g;
   (*G->body)();
@@ -172,7 +177,7 @@ inline void lane_entry()
   swapcontext(&L.ctx, &G->sched);
 }
 
-inline void run_group(Group& G)
+HIPEMU_NOSAN inline void run_group(Group& G)
 {
   const int n = (int)(G.bdim.x * G.bdim.y * G.bdim.z);
   g = &G;
@@ -206,13 +211,13 @@ inline int pool_threads()
 }
 
 template <typename F>
-void launch(dim3 grid, dim3 block, F&& fn)
+HIPEMU_NOSAN void launch(dim3 grid, dim3 block, F&& fn)
 {
   const std::function<void()> body = fn;
   const size_t total = (size_t)grid.x * grid.y * grid.z;
   const int n = (int)(block.x * block.y * block.z);
   std::atomic<size_t> next{0};
-  auto worker = [&]() {
+  auto worker = [&]() HIPEMU_NOSAN {
     Group G;
     G.gdim = grid; G.bdim = block; G.body = &body;
     G.lanes.resize((size_t)n);
@@ -237,8 +242,15 @@ void launch(dim3 grid, dim3 block, F&& fn)
 }  // namespace hipemu
 
 // ---- language surface used by libheif_amd/csrc/*.hip -----------------------------------------------------------------
+#if defined(__SANITIZE_THREAD__)
+// ThreadSanitizer builds (tools/emu_tsan_objects.sh, ALL=1): device code runs on ucontext lanes the sanitizer cannot follow - kernels and device
+// functions stay uninstrumented, the host functions of the same translation unit (launchers, planner, capture state) are watched
+#define __global__ __attribute__((no_sanitize_thread))
+#define __device__ __attribute__((no_sanitize_thread))
+#else
 #define __global__
 #define __device__
+#endif
 #define __host__
 #define __forceinline__ inline
 #define __constant__ static const
@@ -249,7 +261,7 @@ void launch(dim3 grid, dim3 block, F&& fn)
 #define blockDim (hipemu::g->bdim)
 #define gridDim (hipemu::g->gdim)
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-  do { (void)(stream); hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); }); } while (0)
+  do { (void)(stream); hipemu::launch((grid), (block), [&]() HIPEMU_NOSAN { kernel(__VA_ARGS__); }); } while (0)
 
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_ACQUIRE)
@@ -264,22 +276,22 @@ template <typename T> static inline T atomicAdd(T* p, T v) { return __atomic_fet
 static inline int atomicCAS(int* p, int cmp, int v) { __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE); return cmp; }
 static inline unsigned atomicCAS(unsigned* p, unsigned cmp, unsigned v) { __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE); return cmp; }
 
-static inline uint64_t __ballot(int pred)
+HIPEMU_NOSAN static inline uint64_t __ballot(int pred)
 {
   const int s = hipemu::wave_converge(pred != 0, 0);
   return hipemu::g->waves[hipemu::g->cur >> 6].ballot_res[s];
 }
-static inline int __shfl_xor(int v, int mask)
+HIPEMU_NOSAN static inline int __shfl_xor(int v, int mask)
 {
   const int s = hipemu::wave_converge(false, (uint32_t)v);
   return (int)hipemu::g->waves[hipemu::g->cur >> 6].val_res[s][((hipemu::g->cur & 63) ^ mask) & 63];
 }
-static inline int __shfl(int v, int src)
+HIPEMU_NOSAN static inline int __shfl(int v, int src)
 {
   const int s = hipemu::wave_converge(false, (uint32_t)v);
   return (int)hipemu::g->waves[hipemu::g->cur >> 6].val_res[s][src & 63];
 }
-static inline int hipemu_readfirstlane(int v)
+HIPEMU_NOSAN static inline int hipemu_readfirstlane(int v)
 {
   const int s = hipemu::wave_converge(false, (uint32_t)v);
   const hipemu::Coll& C = hipemu::g->waves[hipemu::g->cur >> 6];

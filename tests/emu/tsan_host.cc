@@ -8,7 +8,9 @@
 // stills through hipdec_decoder_decode (the still-image coalescer; every other one with tracked planes + hipdec_color_convert, the resident registry),
 // tracks sample by sample through hipdec_decoder_next_picture (look-ahead chains, the chain coalescer), a share of the inputs damaged - and every
 // picture of every undamaged input must come out with the hashes of the serial pass.  ThreadSanitizer watches the host code while that happens.
-// usage: tsan_host <tests/golden> [threads] [rounds] [seed] [damaged_percent]
+// usage: tsan_host <tests/golden> [threads] [rounds] [seed] [damaged_percent] [cold]
+//   cold = 1: the application threads come FIRST - nothing of the library has run, so its lazy initialisation (device, pools, knobs read on first use)
+//   happens under concurrency - and the serial pass they are compared with runs afterwards
 #include "heif_hipdec.h"
 #include <dirent.h>
 #include <array>
@@ -197,7 +199,8 @@ int main(int argc, char** argv)
   const int threads = argc > 2 ? atoi(argv[2]) : 8, rounds = argc > 3 ? atoi(argv[3]) : 6;
   const unsigned seed = argc > 4 ? (unsigned)atoi(argv[4]) : 1u;
   const int damaged_pct = argc > 5 ? atoi(argv[5]) : 15;
-  if (hipdec_init(0)) { fprintf(stderr, "hipdec_init: %s\n", hipdec_last_error()); return 2; }
+  const bool cold = argc > 6 && atoi(argv[6]) != 0;
+  if (!cold && hipdec_init(0)) { fprintf(stderr, "hipdec_init: %s\n", hipdec_last_error()); return 2; }
 
   std::vector<Input> inputs;
   if (DIR* dp = opendir(dir.c_str())) {
@@ -238,22 +241,28 @@ int main(int argc, char** argv)
     }
   }
 
+  auto serial_pass = [&]() -> bool {
   // ---- the serial pass: what every concurrent decode must reproduce (the Python tiers hold these pictures to the oracle) ----
   hipdec_set_sequence_lookahead(32);
   size_t n_pics = 0;
   for (Input& in : inputs) {
     const int rc = play(in, in.samples, false, in.expected);
-    if (rc) { fprintf(stderr, "serial pass: %s: %d %s\n", in.name.c_str(), rc, hipdec_last_error()); return 1; }
+    if (rc) { fprintf(stderr, "serial pass: %s: %d %s\n", in.name.c_str(), rc, hipdec_last_error()); return false; }
     if (!in.track && !in.grid_rows) {   // the tracked form adds the RGB hash
       std::vector<PicHash> t;
-      if (play(in, in.samples, true, t) || t.size() != 1 || t[0][0] != in.expected[0][0]) { fprintf(stderr, "serial pass (tracked): %s\n", in.name.c_str()); return 1; }
+      if (play(in, in.samples, true, t) || t.size() != 1 || t[0][0] != in.expected[0][0]) { fprintf(stderr, "serial pass (tracked): %s\n", in.name.c_str()); return false; }
       in.expected = t;
     }
     n_pics += in.expected.size();
   }
   printf("serial pass: %zu inputs (%zu pictures)\n", inputs.size(), n_pics);
 
+    return true;
+  };
+  if (!cold && !serial_pass()) return 1;
   std::atomic<long> ok{0}, failed{0}, damaged_runs{0}, damaged_errors{0};
+  struct Deferred { size_t input; bool tracked; int rc; std::vector<PicHash> got; };
+  std::vector<std::vector<Deferred>> deferred((size_t)threads);   // cold mode: compared once the serial pass has run
   Barrier bar;
   bar.n = threads;
   const int lookaheads[5] = {32, 0, 3, 8, 1};
@@ -281,6 +290,7 @@ int main(int argc, char** argv)
           }
           const bool tracked = !in.track && (rng() & 1);
           const int rc = play(in, in.samples, tracked, got);
+          if (cold) { deferred[(size_t)t].push_back(Deferred{pick, tracked, rc, got}); continue; }
           bool good = rc == 0 && got.size() == in.expected.size();
           for (size_t i = 0; good && i < got.size(); i++)
             for (int c = 0; c < 4; c++)
@@ -291,6 +301,19 @@ int main(int argc, char** argv)
       }
     });
   for (auto& x : th) x.join();
+  if (cold) {
+    if (!serial_pass()) return 1;
+    for (auto& v : deferred)
+      for (const Deferred& d : v) {
+        const Input& in = inputs[d.input];
+        bool good = d.rc == 0 && d.got.size() == in.expected.size();
+        for (size_t i = 0; good && i < d.got.size(); i++)
+          for (int c = 0; c < 4; c++)
+            if (c < 3 || in.track || (d.tracked && !in.grid_rows)) good = good && d.got[i][(size_t)c] == in.expected[i][(size_t)c];
+        if (good) ok++;
+        else { failed++; fprintf(stderr, "MISMATCH %s (cold): rc %d, %zu of %zu pictures\n", in.name.c_str(), d.rc, d.got.size(), in.expected.size()); }
+      }
+  }
   uint64_t rq = 0, ls = 0, sh = 0, ch = 0, cls = 0, csh = 0;
   hipdec_decoder_coalesce_stats(&rq, &ls, &sh);
   hipdec_decoder_chain_stats(&ch, &cls, &csh);

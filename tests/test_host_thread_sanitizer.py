@@ -2,7 +2,8 @@
 chains, DPB holds, the resident-plane registry), runtime.hip (pools), hevc_headers.hip, batch_layout.hip, plugin.hip and grid_rccl.hip with
 -fsanitize=thread, links them with the kernels under the SIMT emulator and with tests/emu/tsan_host.cc - application threads that decode the golden
 stills, golden tracks and two grid photos (four emulated devices, one issue thread per device) side by side through the C ABI, some inputs damaged - and
-every picture must equal the serial pass while the sanitizer reports nothing.  (What it found when it was first run is in profiles/r05_emulation_sweeps.txt:
+every picture must equal the serial pass while the sanitizer reports nothing.  The threads come first (cold mode): the library's lazy initialisation
+happens under concurrency, which is where both findings were - the coalescers' knobs and the init flag of runtime.hip.  (What it found when it was first run is in profiles/r05_emulation_sweeps.txt:
 the unguarded first-use read of the coalescers' environment knobs.)"""
 import os
 import subprocess
@@ -30,8 +31,8 @@ def build_dir(tmp_path_factory):
 
 
 def test_application_threads_on_the_whole_library_under_thread_sanitizer(build_dir):
-    env = dict(os.environ, HIPEMU_DEVICES="4", TSAN_HOST_BUILD=build_dir)
-    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "emu_tsan_host.sh"), "6", "3", "1", "15"], capture_output=True, text=True, timeout=900, env=env)
+    env = dict(os.environ, HIPEMU_DEVICES="4", TSAN_HOST_BUILD=build_dir, ALL="1")   # ALL=1: the host functions beside the kernels are watched too
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "emu_tsan_host.sh"), "8", "3", "1", "15", "1"], capture_output=True, text=True, timeout=900, env=env)
     out = r.stdout + r.stderr
     assert "WARNING: ThreadSanitizer" not in out, out[-6000:]
     assert r.returncode == 0, out[-3000:]
@@ -53,7 +54,7 @@ def test_the_plugin_inside_the_real_libheif_under_thread_sanitizer(build_dir, rg
     lib = os.path.join(ROOT, "oracle", "_ref", "libheif_hipcolor.so" if rgb else "libheif.so")
     if not os.path.exists(lib):
         pytest.skip("oracle/_ref is not built")
-    env = dict(os.environ, TSAN_HOST_BUILD=build_dir, RGB=str(rgb), DROPIN_WARMUP_S="1")
+    env = dict(os.environ, TSAN_HOST_BUILD=build_dir, RGB=str(rgb), DROPIN_WARMUP_S="1", ALL="1")
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "emu_tsan_libheif.sh"), "6", "4"], capture_output=True, text=True, timeout=900, env=env)
     out = r.stdout + r.stderr
     ours = _reports_about_the_plugin(out)

@@ -8,9 +8,9 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 B=${TSAN_HOST_BUILD:-$ROOT/build/thread-host}
-mkdir -p $B/files
 SAN=thread
 . $ROOT/tools/emu_tsan_objects.sh
+mkdir -p $B/files
 g++ -shared -fsanitize=thread -o $B/libheifhip_emu_tsan.so $B/obj/*.o -lpthread -ldl
 gcc -O1 -g -fsanitize=thread -pthread $ROOT/tools/dropin_host.c $E/tsan_clockwait.c -ldl -o $B/dropin_host_tsan
 cd $ROOT
