@@ -76,6 +76,7 @@ struct Input {
   bool track = false;
   std::vector<Bytes> samples;        // a still: one element; a track: its access units in decoding order
   std::vector<PicHash> expected;     // pictures in output order (serial pass)
+  std::vector<size_t> batch_of;      // a batch: the stills (indices into the input list) hipdec_batch_* decodes in one launch set
   int grid_rows = 0, grid_cols = 0, tile_w = 0, tile_h = 0;   // a grid photo: samples[0] is the tile every cell shows (hipdec_grid_*: shards on every emulated device)
 };
 
@@ -101,6 +102,15 @@ int hash_planes(hipdec_decoder* d, const hipdec_image_info& I, bool tracked, Pic
     hipdec_color_image img{};
     img.width = I.width; img.height = I.height; img.chroma = 1; img.bit_depth = 8;
     for (int c = 0; c < 3; c++) { img.plane[c] = plane[c].data(); img.stride[c] = stride[c]; }
+    Bytes mirrored[3];
+    if (!(I.width & 1) && !(I.height & 1)) {   // ... with an 'imir' in between, as the patched libheif applies it (resident planes feed the transform, its result the conversion)
+      hipdec_color_image outi{};
+      for (int c = 0; c < 3; c++) { mirrored[c].assign(plane[c].size(), 0); outi.plane[c] = mirrored[c].data(); outi.stride[c] = stride[c]; }
+      const int args[1] = {1};
+      const int rc = hipdec_image_transform(&img, HIPDEC_XF_MIRROR, args, &outi);
+      if (rc == 0) { for (int c = 0; c < 3; c++) img.plane[c] = mirrored[c].data(); }
+      else if (rc != HIPDEC_ERR_UNSUPPORTED) return rc;
+    }
     hipdec_nclx nclx{1, I.colour_primaries, I.transfer_characteristics, I.matrix_coeffs, I.full_range_flag};
     const size_t os = ((size_t)I.width * 3 + 15) & ~size_t(15);
     Bytes rgb(os * (size_t)I.height, 0);
@@ -122,6 +132,30 @@ int play(const Input& in, const std::vector<Bytes>& samples, bool tracked, std::
   int rc = hipdec_decoder_new(&d, 0, 0);
   if (rc) return rc;
   hipdec_image_info I{};
+  if (!in.batch_of.empty()) {   // the throughput interface: one launch set for n stills, planes read back item by item
+    hipdec_decoder_free(d);
+    std::vector<const void*> ptrs;
+    std::vector<size_t> sizes;
+    for (const Bytes& b : samples) { ptrs.push_back(b.data()); sizes.push_back(b.size()); }
+    hipdec_batch* b = nullptr;
+    rc = hipdec_batch_create(&b, (int)ptrs.size(), ptrs.data(), sizes.data(), 0);
+    if (rc) return rc;
+    rc = hipdec_batch_run(b, nullptr);
+    if (!rc) rc = hipdec_batch_status(b);
+    for (int i = 0; i < (int)ptrs.size() && !rc; i++) {
+      rc = hipdec_batch_info(b, i, &I);
+      PicHash h{0, 0, 0, 0};
+      for (int c = 0; c < 3 && !rc; c++) {
+        const int w = c ? I.chroma_width : I.width, hh = c ? I.chroma_height : I.height;
+        Bytes plane((size_t)w * (size_t)hh, 0);
+        rc = hipdec_batch_read_plane(b, i, c, plane.data(), (size_t)w);
+        h[(size_t)c] = fnv(plane.data(), plane.size());
+      }
+      if (!rc) got.push_back(h);
+    }
+    hipdec_batch_free(b);
+    return rc;
+  }
   if (in.grid_rows) {
     hipdec_decoder_free(d);
     const int n = in.grid_rows * in.grid_cols;
@@ -242,13 +276,31 @@ int main(int argc, char** argv)
   }
 
   auto serial_pass = [&]() -> bool {
+  {   // three batches of 8-bit 4:2:0 stills for the hipdec_batch_* interface
+    std::vector<size_t> pool;
+    for (size_t i = 0; i < inputs.size(); i++) {
+      hipdec_image_info P{};
+      if (!inputs[i].track && !inputs[i].grid_rows && !hipdec_probe(inputs[i].samples[0].data(), inputs[i].samples[0].size(), 0, &P) && P.chroma_format_idc == 1 && P.bit_depth_luma == 8)
+        pool.push_back(i);
+    }
+    for (int k = 0; k < 3 && pool.size() >= 3; k++) {
+      Input bin;
+      bin.name = "batch " + std::to_string(k);
+      for (size_t j = 0; j < 3 + (size_t)k && j < pool.size(); j++) {
+        const size_t i = pool[((size_t)k * 5 + j * 3) % pool.size()];
+        bin.batch_of.push_back(i);
+        bin.samples.push_back(inputs[i].samples[0]);
+      }
+      inputs.push_back(std::move(bin));
+    }
+  }
   // ---- the serial pass: what every concurrent decode must reproduce (the Python tiers hold these pictures to the oracle) ----
   hipdec_set_sequence_lookahead(32);
   size_t n_pics = 0;
   for (Input& in : inputs) {
     const int rc = play(in, in.samples, false, in.expected);
     if (rc) { fprintf(stderr, "serial pass: %s: %d %s\n", in.name.c_str(), rc, hipdec_last_error()); return false; }
-    if (!in.track && !in.grid_rows) {   // the tracked form adds the RGB hash
+    if (!in.track && !in.grid_rows && in.batch_of.empty()) {   // the tracked form adds the RGB hash
       std::vector<PicHash> t;
       if (play(in, in.samples, true, t) || t.size() != 1 || t[0][0] != in.expected[0][0]) { fprintf(stderr, "serial pass (tracked): %s\n", in.name.c_str()); return false; }
       in.expected = t;
@@ -278,6 +330,17 @@ int main(int argc, char** argv)
           size_t pick = rng() % inputs.size();
           if (r % 2 == 0) for (int tries = 0; tries < 64 && inputs[pick].track != (r % 4 == 0); tries++) pick = rng() % inputs.size();
           const Input& in = inputs[pick];
+          if (rng() % 8 == 0) {   // an instance that is created, fed and given up without a decode (a leader may be waiting for it to join)
+            hipdec_decoder* a = nullptr;
+            if (!hipdec_decoder_new(&a, 0, 0)) { if (in.batch_of.empty()) (void)hipdec_decoder_push_data(a, in.samples[0].data(), in.samples[0].size()); hipdec_decoder_free(a); }
+          }
+          if (t == 1 && rng() % 3 == 0) {   // a host that wants memory back while the others decode: the registry and the pools are emptied under their feet
+            hipdec_forget_resident_planes();
+            (void)hipdec_set_arena_cache_bytes(0);
+            (void)hipdec_set_arena_cache_bytes(size_t(8) << 30);
+            uint64_t a0 = 0, a1 = 0, a2 = 0;
+            hipdec_decoder_coalesce_stats(&a0, &a1, &a2); hipdec_decoder_chain_stats(&a0, &a1, &a2);
+          }
           const bool damage = (int)(rng() % 100) < damaged_pct;
           std::vector<PicHash> got;
           if (damage) {
@@ -294,7 +357,7 @@ int main(int argc, char** argv)
           bool good = rc == 0 && got.size() == in.expected.size();
           for (size_t i = 0; good && i < got.size(); i++)
             for (int c = 0; c < 4; c++)
-              if (c < 3 || in.track || (tracked && !in.grid_rows)) good = good && got[i][(size_t)c] == in.expected[i][(size_t)c];
+              if (c < 3 || in.track || (tracked && !in.grid_rows && in.batch_of.empty())) good = good && got[i][(size_t)c] == in.expected[i][(size_t)c];
           if (good) ok++;
           else { failed++; fprintf(stderr, "MISMATCH %s (round %d, thread %d): rc %d %s, %zu of %zu pictures\n", in.name.c_str(), r, t, rc, rc ? hipdec_last_error() : "", got.size(), in.expected.size()); }
         }
@@ -309,7 +372,7 @@ int main(int argc, char** argv)
         bool good = d.rc == 0 && d.got.size() == in.expected.size();
         for (size_t i = 0; good && i < d.got.size(); i++)
           for (int c = 0; c < 4; c++)
-            if (c < 3 || in.track || (d.tracked && !in.grid_rows)) good = good && d.got[i][(size_t)c] == in.expected[i][(size_t)c];
+            if (c < 3 || in.track || (d.tracked && !in.grid_rows && in.batch_of.empty())) good = good && d.got[i][(size_t)c] == in.expected[i][(size_t)c];
         if (good) ok++;
         else { failed++; fprintf(stderr, "MISMATCH %s (cold): rc %d, %zu of %zu pictures\n", in.name.c_str(), d.rc, d.got.size(), in.expected.size()); }
       }
