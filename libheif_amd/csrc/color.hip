@@ -614,7 +614,7 @@ using namespace hipdec;
 
 extern "C" {
 
-void hipdec_color_coefficients(const hipdec_nclx* nclx, float out[4]) { coefficients(nclx, out); }
+void hipdec_color_coefficients(const hipdec_nclx* nclx, float out[4]) { if (out) coefficients(nclx, out); }   // (nclx NULL: the reference's defaults)
 
 int hipdec_color_420_to_rgb24(const void* y, size_t ys, const void* cb, size_t cbs, const void* cr, size_t crs, int w, int h,
                               const hipdec_nclx* nclx, void* out, size_t out_stride, int with_alpha, void* stream)

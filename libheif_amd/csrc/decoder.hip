@@ -455,6 +455,8 @@ int copy_plane_d2h(const hipdec_batch& b, size_t off, uint32_t stride, int w, in
 {
   const size_t es = b.wide ? 2 : 1;
   if (w <= 0 || h <= 0) return 0;
+  // (a stride below the row length would put the last row past the end of a buffer of h * stride bytes)
+  if (dst_stride < (size_t)w * es) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: dst_stride %zu is smaller than a row of %zu bytes", dst_stride, (size_t)w * es);
   HIPDEC_CHECK_HIP(hipMemcpy2D(dst, dst_stride, b.arena + off, stride, (size_t)w * es, (size_t)h, hipMemcpyDeviceToHost));
   return 0;
 }
@@ -589,6 +591,11 @@ int hipdec_batch_to_rgb(hipdec_batch* b, int i, int out_chroma, void* out_dev, s
   if (b->retired) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "to_rgb: the batch's arena was handed to another batch");
   const PicParams& P = b->params[i];
   const hipdec_image_info& I = b->pics[i].info;
+  {
+    const size_t bpp = out_chroma == 10 ? 3 : (out_chroma == 11 ? 4 : (out_chroma == 12 || out_chroma == 14 ? 6 : 0));
+    if (bpp && out_stride < (size_t)P.out_width * bpp)
+      return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "to_rgb: out_stride %zu is smaller than a row of %zu bytes", out_stride, (size_t)P.out_width * bpp);
+  }
   if (!P.chroma_format_idc) {   // Op_mono_to_RGB24_32: 8-bit only, as in the reference
     if (b->wide || (out_chroma != 10 && out_chroma != 11)) return set_error(HIPDEC_ERR_UNSUPPORTED, "to_rgb: monochrome input goes to 8-bit RGB / RGBA only");
     void* ms = stream ? (void*)follow_stream(b, stream) : (void*)b->last_stream;
@@ -1322,6 +1329,7 @@ int hipdec_decoder_read_plane(hipdec_decoder* d, int c, void* dst, size_t dst_st
     if (c > 0 && !P.chroma_format_idc) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: monochrome image has no chroma planes");
     const size_t w = (size_t)(c ? P.out_cwidth : P.out_width) * (b->wide ? 2 : 1), h = (size_t)(c ? P.out_cheight : P.out_height);
     const uint8_t* src = (const uint8_t*)b->host_items[(size_t)item].p + b->host_items[(size_t)item].off[c];
+    if (dst_stride < w) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "read_plane: dst_stride %zu is smaller than a row of %zu bytes", dst_stride, w);
     if (dst_stride == w) memcpy(dst, src, w * h);
     else for (size_t y = 0; y < h; y++) memcpy((uint8_t*)dst + y * dst_stride, src + y * w, w);
     return 0;
@@ -2041,6 +2049,11 @@ int hipdec_color_convert(const hipdec_color_image* in, const hipdec_nclx* nclx, 
     int bits = in->bit_depth;
     size_t es = bits > 8 ? 2 : 1;
     const size_t out_bpp = out_chroma == 10 ? 3 : (out_chroma == 11 ? 4 : 6);
+    if ((out_chroma == 10 || out_chroma == 11 || out_chroma == 12 || out_chroma == 14) && out_stride < (size_t)w * out_bpp)
+      return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "color_convert: out_stride %zu is smaller than a row of %zu bytes", out_stride, (size_t)w * out_bpp);
+    for (int c = 0; c < 4; c++)
+      if (in->plane[c] && in->stride[c] < (size_t)((c == 0 || c == 3) ? w : cw) * es)
+        return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "color_convert: stride %zu of plane %d is smaller than its rows", in->stride[c], c);
     hipStream_t s = stream_acquire_priority();
     struct Release { hipStream_t s; std::vector<std::pair<void*, size_t>> bufs;
                      ~Release() { (void)hipStreamSynchronize(s); for (auto& b : bufs) arena_release(b.first, b.second); stream_release(s); } } rel{s, {}};
@@ -2535,6 +2548,7 @@ int hipdec_grid_read_plane(hipdec_grid* g, int c, void* dst_host, size_t dst_str
   const size_t es = g->bits > 8 ? 2 : 1;
   const size_t sw = c ? (size_t)g->csw : 1, sh = c ? (size_t)g->csh : 1;
   const size_t w = ((size_t)g->out_w + sw - 1) / sw, h = ((size_t)g->out_h + sh - 1) / sh;
+  if (dst_stride < w * es) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_read_plane: dst_stride %zu is smaller than a row of %zu bytes", dst_stride, w * es);
   return copy_rows_to_host(dst_host, dst_stride, g->canvas + g->off[c], g->stride[c], w * es, (int)h, default_stream());
 }
 
