@@ -195,12 +195,25 @@ HIPEMU_NOSAN inline void run_group(Group& G)
     L.ctx.uc_stack.ss_sp = L.stack; L.ctx.uc_stack.ss_size = kStack; L.ctx.uc_link = &G.sched;
     makecontext(&L.ctx, (void (*)())lane_entry, 0);
   }
-  while (G.alive > 0)
-    for (int i = 0; i < n; i++) {
+  // HIPEMU_LANE_ORDER: 0 = lanes are resumed in index order (default), 1 = in reverse order, 2 = in a pseudo-random order that changes with every pass.
+  // Between two convergence points the hardware promises no order among the lanes of a group (and none a compiler has to respect even inside a wave
+  // without a fence): a kernel whose result depends on the order - a missing barrier between an LDS write and another lane's read - decodes
+  // differently under 1 or 2 (tools/emu_random_sweep*.py under HIPEMU_LANE_ORDER).
+  static const int lane_order = getenv("HIPEMU_LANE_ORDER") ? atoi(getenv("HIPEMU_LANE_ORDER")) : 0;
+  uint32_t lcg = 12345u + G.bid.x * 2654435761u + G.bid.y * 40503u;
+  while (G.alive > 0) {
+    lcg = lcg * 1664525u + 1013904223u;
+    const int start = lane_order == 2 ? (int)((lcg >> 8) % (uint32_t)n) : 0, stride = lane_order == 2 && n > 2 ? ((int)((lcg >> 20) % (uint32_t)(n - 1)) | 1) : 1;
+    // (a stride coprime to n visits every lane; fall back to 1 when it is not)
+    int st = stride;
+    if (lane_order == 2) { int a = n, b = st; while (b) { const int t = a % b; a = b; b = t; } if (a != 1) st = 1; }
+    for (int k = 0; k < n; k++) {
+      const int i = lane_order == 1 ? n - 1 - k : (lane_order == 2 ? (int)(((long)start + (long)k * st) % n) : k);
       if (G.lanes[i].done) continue;
       G.cur = i;
       swapcontext(&G.sched, &G.lanes[i].ctx);
     }
+  }
   g = nullptr;
 }
 
