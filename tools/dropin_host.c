@@ -26,9 +26,12 @@ typedef struct heif_error (*primary_fn)(void*, void**);
 typedef struct heif_error (*decode_fn)(void*, void**, int, int, const void*);
 typedef void (*release_fn)(void*);
 typedef int (*dim_fn)(void*);
+typedef void* (*get_track_fn)(void*, uint32_t);
+typedef struct heif_error (*track_next_fn)(void*, void**, int, int, const void*);
 
 static ctx_alloc_fn ctx_alloc; static ctx_free_fn ctx_free; static read_mem_fn read_mem; static primary_fn primary; static decode_fn decode;
 static release_fn image_release, handle_release; static dim_fn handle_w, handle_h;
+static get_track_fn get_track; static track_next_fn track_next; static release_fn track_release; static dim_fn has_sequence, image_w, image_h;   /* image sequences (moov / trak) */
 
 struct file { uint8_t* data; size_t size; };
 static struct file* files; static int n_files; static int n_threads; static int want_rgb;
@@ -71,6 +74,25 @@ static int decode_one(const struct file* f, double* px)
   void* ctx = ctx_alloc();
   struct heif_error e = read_mem(ctx, f->data, f->size, NULL);
   void* h = NULL; void* img = NULL;
+  if (!e.code && has_sequence && has_sequence(ctx)) {
+    /* an image-sequence file: every picture of its first visual track, the way an application plays it (libheif's Track_Visual pushes the samples into
+     * the plugin and polls it, sequences/track_visual.cc:175-330) */
+    void* track = get_track(ctx, 0);
+    int n = 0;
+    while (track) {
+      void* im = NULL;
+      e = track_next(track, &im, 99 /* heif_colorspace_undefined */, 99 /* heif_chroma_undefined */, NULL);
+      if (e.code) { if (e.code == 13 /* heif_error_End_of_sequence */) e.code = 0; break; }
+      n++;
+      add_double(px, image_w && image_h ? (double)image_w(im) * image_h(im) : 1.0);
+      image_release(im);
+    }
+    if (track) track_release(track);
+    if (!track || (!e.code && n == 0)) { fprintf(stderr, "sequence file: no picture came out\n"); e.code = 1; }
+    else if (e.code) fprintf(stderr, "track decode failed: %d.%d %s\n", e.code, e.subcode, e.message ? e.message : "");
+    ctx_free(ctx);
+    return e.code;
+  }
   if (!e.code) e = primary(ctx, &h);
   const double t0 = now();
   if (!e.code) e = decode(h, &img, want_rgb ? 1 /* heif_colorspace_RGB */ : 0 /* YCbCr */, want_rgb ? 10 /* interleaved RGB */ : 1 /* 4:2:0 */, NULL);
@@ -109,6 +131,10 @@ int main(int argc, char** argv)
   decode = (decode_fn)dlsym(L, "heif_decode_image"); image_release = (release_fn)dlsym(L, "heif_image_release");
   handle_release = (release_fn)dlsym(L, "heif_image_handle_release");
   handle_w = (dim_fn)dlsym(L, "heif_image_handle_get_width"); handle_h = (dim_fn)dlsym(L, "heif_image_handle_get_height");
+  get_track = (get_track_fn)dlsym(L, "heif_context_get_track"); track_next = (track_next_fn)dlsym(L, "heif_track_decode_next_image");
+  track_release = (release_fn)dlsym(L, "heif_track_release"); has_sequence = (dim_fn)dlsym(L, "heif_context_has_sequence");
+  image_w = (dim_fn)dlsym(L, "heif_image_get_primary_width"); image_h = (dim_fn)dlsym(L, "heif_image_get_primary_height");
+  if (!get_track || !track_next || !track_release) has_sequence = NULL;   /* a libheif without sequence support */
   const void* info = NULL;
   struct heif_error e = load_plugin(argv[2], &info);
   if (e.code) { fprintf(stderr, "heif_load_plugin: %s\n", e.message); return 1; }

@@ -4,7 +4,9 @@
 # sanitizer: T application threads x heif_decode_image() on small HEIC files (golden stills, one of them as a 2 x 3 grid item) - the plugin's function
 # table, plane hand-over into heif_image, both coalescers' still path; with RGB=1 through the patched libheif (the integration colour op -> hipdec_color_convert,
 # resident planes / RGB, the grid hook).  libheif itself is not instrumented: only reports that name the plugin's sources count.
-# usage: [RGB=0|1] bash tools/emu_tsan_libheif.sh [threads] [seconds]
+# The golden tracks go along as image-sequence files (moov / trak): heif_track_decode_next_image() plays them - Track_Visual pushes the samples into the plugin,
+# look-ahead chains, the chain coalescer (TRACKS=0 leaves them out).
+# usage: [RGB=0|1] [TRACKS=0] bash tools/emu_tsan_libheif.sh [threads] [seconds]
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 B=${TSAN_HOST_BUILD:-$ROOT/build/thread-host}
@@ -32,6 +34,18 @@ for f in sorted(glob.glob("tests/golden/*.hevc")):
     n += 1
     if name.startswith("default_"):
         open(os.path.join(out, "%02d_grid_2x3.heic" % n), "wb").write(heic_util.build_heic([(s, w, h, cf)] * 6, grid=(2, 3, 3 * w - 8, 2 * h - 4), bit_depth=bd, chroma_format_idc=cf))
+        n += 1
+if os.environ.get("TRACKS", "1") != "0":   # image-sequence files out of the golden tracks: heif_track_decode_next_image() on every picture
+    import json
+    idx = json.load(open("tests/golden/golden_sequences.json"))
+    for name in sorted(idx):
+        g = idx[name]
+        blob = open("tests/golden/seq_%s.hevcs" % name, "rb").read()
+        aus, p = [], 0
+        while p < len(blob):
+            k = int.from_bytes(blob[p:p + 4], "big"); aus.append(blob[p + 4:p + 4 + k]); p += 4 + k
+        open(os.path.join(out, "%02d_seq_%s.heic" % (n, name)), "wb").write(
+            heic_util.build_sequence(aus, g["width"], g["height"], bit_depth=g["bit_depth"], chroma_format_idc=g["chroma_format_idc"]))
         n += 1
 print("%d HEIC files" % n)
 PY
