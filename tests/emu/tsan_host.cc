@@ -385,5 +385,20 @@ int main(int argc, char** argv)
   printf("still requests %llu in %llu launch sets (%llu shared one); chains %llu in %llu launch sets (%llu shared by several tracks)\n", (unsigned long long)rq,
          (unsigned long long)ls, (unsigned long long)sh, (unsigned long long)ch, (unsigned long long)cls, (unsigned long long)csh);
   hipdec_shutdown();
+  {   // the library comes up again by itself after a shutdown (streams, pools, registry were given back): one input of every kind once more
+    long again = 0;
+    for (const Input& in : inputs) {
+      if (again >= 4 && !in.grid_rows && in.batch_of.empty()) continue;
+      std::vector<PicHash> got;
+      const int rc = play(in, in.samples, false, got);
+      bool good = rc == 0 && got.size() == in.expected.size();
+      for (size_t i = 0; good && i < got.size(); i++)
+        for (int c = 0; c < 3; c++) good = good && got[i][(size_t)c] == in.expected[i][(size_t)c];
+      if (!good) { failed++; fprintf(stderr, "MISMATCH %s after shutdown + re-initialisation: rc %d %s\n", in.name.c_str(), rc, rc ? hipdec_last_error() : ""); }
+      again++;
+    }
+    printf("after hipdec_shutdown(): %ld inputs decoded again by a library that re-initialised itself\n", again);
+    hipdec_shutdown();
+  }
   return failed.load() ? 1 : 0;
 }
