@@ -139,7 +139,9 @@ HIPDEC_API const void* hipdec_get_decoder_plugin(void);
 
 /* plane hand-over (decoder_libde265.cc:97-171): copies plane c (0 = Y, 1 = Cb, 2 = Cr) into a host
  * buffer with the caller's stride; samples are uint8 for bit depth 8, little-endian uint16
- * above. */
+ * above.  A stride below the row length is refused (HIPDEC_ERR_INVALID_ARGUMENT: the last row would end past a buffer of
+ * height x stride bytes); the same holds for every call that writes rows into a caller's buffer (hipdec_batch_read_plane,
+ * hipdec_grid_read_plane, hipdec_batch_to_rgb, hipdec_color_convert, hipdec_grid_to_rgb). */
 HIPDEC_API int hipdec_decoder_read_plane(hipdec_decoder* dec, int c, void* dst_host, size_t dst_stride);
 /* the same, and remembers (host pointer -> device copy) so that hipdec_color_convert() on those very host planes skips the upload:
  * what the libheif plugin uses */
