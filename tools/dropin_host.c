@@ -35,7 +35,7 @@ static get_track_fn get_track; static track_next_fn track_next; static release_f
 
 struct file { uint8_t* data; size_t size; };
 static struct file* files; static int n_files; static int n_threads; static int want_rgb;
-static int stop_flag; static pthread_barrier_t start_barrier;
+static int stop_flag; static int tolerate; static long tolerated; static pthread_barrier_t start_barrier;
 struct worker { pthread_t th; int k; long decodes; double px; int failed; };   /* decodes / px: the owner adds, main reads (relaxed atomics) */
 static long ld_long(const long* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 static double ld_double(const double* p) { uint64_t u = __atomic_load_n((const uint64_t*)p, __ATOMIC_RELAXED); double d; memcpy(&d, &u, 8); return d; }
@@ -99,7 +99,7 @@ static int decode_one(const struct file* f, double* px)
   __atomic_fetch_add(&decode_us_total, (uint64_t)((now() - t0) * 1e6), __ATOMIC_RELAXED);
   __atomic_fetch_add(&decode_calls_total, 1, __ATOMIC_RELAXED);
   if (!e.code) add_double(px, (double)handle_w(h) * handle_h(h));
-  else fprintf(stderr, "decode failed: %d.%d %s\n", e.code, e.subcode, e.message ? e.message : "");
+  else if (!tolerate) fprintf(stderr, "decode failed: %d.%d %s\n", e.code, e.subcode, e.message ? e.message : "");
   if (img) image_release(img);
   if (h) handle_release(h);
   ctx_free(ctx);
@@ -113,7 +113,10 @@ static void* run(void* arg)
   if (buf) memset(buf, 1, (size_t)3840 * 2160 * 2);
   pthread_barrier_wait(&start_barrier);
   for (int i = w->k; !__atomic_load_n(&stop_flag, __ATOMIC_RELAXED); i += n_threads) {
-    if (direct_mode ? decode_direct(&files[i % n_files], &w->px, buf) : decode_one(&files[i % n_files], &w->px)) { w->failed = 1; break; }
+    if (direct_mode ? decode_direct(&files[i % n_files], &w->px, buf) : decode_one(&files[i % n_files], &w->px)) {
+      if (tolerate) { __atomic_fetch_add(&tolerated, 1, __ATOMIC_RELAXED); continue; }   /* DROPIN_TOLERATE=1: damaged files are part of the mix */
+      w->failed = 1; break;
+    }
     __atomic_store_n(&w->decodes, w->decodes + 1, __ATOMIC_RELAXED);
   }
   free(buf);
@@ -155,9 +158,10 @@ int main(int argc, char** argv)
     if (fread(files[i].data, 1, files[i].size, f) != files[i].size) return 1;
     fclose(f);
   }
+  tolerate = getenv("DROPIN_TOLERATE") && atoi(getenv("DROPIN_TOLERATE"));
   double px0 = 0;   /* warm-up: HIP runtime, code objects, arena pool */
   if (direct_mode) { uint8_t* b0 = (uint8_t*)malloc((size_t)3840 * 2160 * 2); if (decode_direct(&files[0], &px0, b0)) return 1; free(b0); }
-  else if (decode_one(&files[0], &px0)) return 1;
+  else if (decode_one(&files[0], &px0) && !tolerate) return 1;
   void* hip = dlopen(argv[2], RTLD_NOW | RTLD_NOLOAD);
   void (*stats)(uint64_t*, uint64_t*, uint64_t*) = hip ? (void (*)(uint64_t*, uint64_t*, uint64_t*))dlsym(hip, "hipdec_decoder_coalesce_stats") : NULL;
   uint64_t r0 = 0, s0 = 0, x0 = 0, r1 = 0, s1 = 0, x1 = 0;
@@ -185,6 +189,7 @@ int main(int argc, char** argv)
   for (int k = 0; k < n_threads; k++) { pthread_join(ws[k].th, NULL); failed |= ws[k].failed; }
   if (decode_calls_total) fprintf(stderr, "[dropin_host] %d threads: heif_decode_image took %.1f ms on average over %llu calls\n", n_threads,
                                   decode_us_total / 1e3 / decode_calls_total, (unsigned long long)decode_calls_total);
+  if (tolerate) fprintf(stderr, "[dropin_host] %ld decodes reported an error and were tolerated\n", tolerated);
   printf("%ld %.3f %.1f %llu %llu %d\n", n, dt, px / dt / 1e6, (unsigned long long)(r1 - r0), (unsigned long long)(s1 - s0), failed);
   return failed;
 }

@@ -10,11 +10,12 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 B=${TSAN_HOST_BUILD:-$ROOT/build/thread-host}
-SAN=thread
+SAN=${SAN:-thread}
+[ "$SAN" = "thread" ] || B=$ROOT/build/$SAN-host
 . $ROOT/tools/emu_tsan_objects.sh
 mkdir -p $B/files
-g++ -shared -fsanitize=thread -o $B/libheifhip_emu_tsan.so $B/obj/*.o -lpthread -ldl
-gcc -O1 -g -fsanitize=thread -pthread $ROOT/tools/dropin_host.c $E/tsan_clockwait.c -ldl -o $B/dropin_host_tsan
+g++ -shared -fsanitize=$SAN -o $B/libheifhip_emu_tsan.so $B/obj/*.o -lpthread -ldl
+gcc -O1 -g -fsanitize=$SAN -pthread $ROOT/tools/dropin_host.c $E/tsan_clockwait.c -ldl -lstdc++ -o $B/dropin_host_tsan   # (libstdc++ at start-up: AddressSanitizer resolves __cxa_throw when it initialises)
 cd $ROOT
 python - "$B/files" <<'PY'
 import glob, os, sys
@@ -49,7 +50,9 @@ if os.environ.get("TRACKS", "1") != "0":   # image-sequence files out of the gol
         n += 1
 print("%d HEIC files" % n)
 PY
+# FILES=<directory>: decode those files instead (e.g. the reference's fuzzing corpus with DROPIN_TOLERATE=1 and SAN=address)
+[ -n "$FILES" ] && { rm -f $B/files/*; cp $FILES/* $B/files/; }
 LIBHEIF=$ROOT/oracle/_ref/libheif.so
 [ "${RGB:-0}" = "1" ] && LIBHEIF=$ROOT/oracle/_ref/libheif_hipcolor.so
 HIPEMU_THREADS=1 HIPEMU_DEVICES=${HIPEMU_DEVICES:-2} TSAN_OPTIONS="halt_on_error=0 history_size=4" \
-  $B/dropin_host_tsan $LIBHEIF $B/libheifhip_emu_tsan.so ${1:-8} ${2:-10} ${RGB:-0} $B/files/*.heic
+  $B/dropin_host_tsan $LIBHEIF $B/libheifhip_emu_tsan.so ${1:-8} ${2:-10} ${RGB:-0} $B/files/*
