@@ -63,3 +63,15 @@ def test_the_plugin_inside_the_real_libheif_under_thread_sanitizer(build_dir, rg
     assert last, out[-3000:]
     decodes, _, _, requests, launch_sets, failed = last[-1].split()
     assert int(failed) == 0 and int(decodes) > 0 and int(requests) > 0, out[-3000:]
+
+
+def test_random_walks_over_the_decoder_abi(build_dir):
+    """tests/emu/api_fuzz.cc: legal calls in any order - poll before push, push after a flush, samples of other streams and random bytes between good ones,
+    decode() between polls, plane reads at any time, instances dropped half way - from three threads; the library answers every one (a picture or an error
+    code), does not crash, does not hang, and the sanitizer stays silent.  (The AddressSanitizer / LeakSanitizer campaigns of the same program:
+    profiles/r05_emulation_sweeps.txt.)"""
+    env = dict(os.environ, TSAN_HOST_BUILD=build_dir, SAN="thread", ALL="1", FUZZ_TIMEOUT="600")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "emu_api_fuzz.sh"), "7", "24", "50", "3"], capture_output=True, text=True, timeout=900, env=env)
+    out = r.stdout + r.stderr
+    assert "WARNING: ThreadSanitizer" not in out, out[-6000:]
+    assert r.returncode == 0 and "no crash" in out, out[-3000:]
