@@ -7,7 +7,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SAN=${SAN:-address}
 ALL=${ALL:-1}
-B=${TSAN_HOST_BUILD:-$ROOT/build/$SAN-host}
+B=${TSAN_HOST_BUILD:-${TMPDIR:-/tmp}/hipdec_sanitizer_builds/$SAN-host}   # (outside the tree: ~100 MB of objects per sanitizer must not travel with the repository)
 mkdir -p $B
 . $ROOT/tools/emu_tsan_objects.sh
 g++ -O1 -g -fsanitize=$SAN -fno-omit-frame-pointer $FLAGS -c $E/api_fuzz.cc -o $B/api_fuzz.o

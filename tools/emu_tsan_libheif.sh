@@ -9,9 +9,9 @@
 # usage: [RGB=0|1] [TRACKS=0] bash tools/emu_tsan_libheif.sh [threads] [seconds]
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-B=${TSAN_HOST_BUILD:-$ROOT/build/thread-host}
+B=${TSAN_HOST_BUILD:-${TMPDIR:-/tmp}/hipdec_sanitizer_builds/thread-host}
 SAN=${SAN:-thread}
-[ "$SAN" = "thread" ] || B=$ROOT/build/$SAN-host
+[ "$SAN" = "thread" ] || B=${TSAN_HOST_BUILD:-${TMPDIR:-/tmp}/hipdec_sanitizer_builds/$SAN-host}
 . $ROOT/tools/emu_tsan_objects.sh
 mkdir -p $B/files
 g++ -shared -fsanitize=$SAN -o $B/libheifhip_emu_tsan.so $B/obj/*.o -lpthread -ldl
