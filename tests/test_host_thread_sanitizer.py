@@ -41,8 +41,9 @@ def test_application_threads_on_the_whole_library_under_thread_sanitizer(build_d
 
 
 def _reports_about_the_plugin(out):
-    """ThreadSanitizer report blocks that name the product's sources (libheif itself is not instrumented: what it does between its own threads - the
-    stock grid loop pastes tiles into a canvas another thread allocated - shows up as reports without a frame of ours, and is not ours to judge)"""
+    """ThreadSanitizer report blocks that name the product's sources.  (The one report stock libheif earns by itself: its grid loop checks `inout_image`
+    without the mutex before pasting a tile - image-items/grid.cc:534-560 - so a paste is not ordered behind the other thread's canvas allocation; no frame
+    of the plugin is in it.)"""
     blocks = [b for b in out.split("==================") if "WARNING: ThreadSanitizer" in b]
     return [b for b in blocks if "libheif_amd/csrc" in b or "tests/emu" in b]
 

@@ -159,8 +159,10 @@ int main(int argc, char** argv)
     fclose(f);
   }
   tolerate = getenv("DROPIN_TOLERATE") && atoi(getenv("DROPIN_TOLERATE"));
-  double px0 = 0;   /* warm-up: HIP runtime, code objects, arena pool */
-  if (direct_mode) { uint8_t* b0 = (uint8_t*)malloc((size_t)3840 * 2160 * 2); if (decode_direct(&files[0], &px0, b0)) return 1; free(b0); }
+  double px0 = 0;   /* warm-up: HIP runtime, code objects, arena pool (DROPIN_COLD=1: none - the threads make the library's first calls, side by side) */
+  const int cold = getenv("DROPIN_COLD") && atoi(getenv("DROPIN_COLD"));
+  if (cold) { }
+  else if (direct_mode) { uint8_t* b0 = (uint8_t*)malloc((size_t)3840 * 2160 * 2); if (decode_direct(&files[0], &px0, b0)) return 1; free(b0); }
   else if (decode_one(&files[0], &px0) && !tolerate) return 1;
   void* hip = dlopen(argv[2], RTLD_NOW | RTLD_NOLOAD);
   void (*stats)(uint64_t*, uint64_t*, uint64_t*) = hip ? (void (*)(uint64_t*, uint64_t*, uint64_t*))dlsym(hip, "hipdec_decoder_coalesce_stats") : NULL;
