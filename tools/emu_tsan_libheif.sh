@@ -54,5 +54,8 @@ PY
 [ -n "$FILES" ] && { rm -f $B/files/*; cp $FILES/* $B/files/; }
 LIBHEIF=$ROOT/oracle/_ref/libheif.so
 [ "${RGB:-0}" = "1" ] && LIBHEIF=$ROOT/oracle/_ref/libheif_hipcolor.so
+# LIBHEIF_OVERRIDE: another build of libheif, e.g. one compiled with the sanitizer as well (make -f oracle/Makefile.ref OUT=<dir outside the tree> CXXFLAGS="... -fsanitize=thread"
+# <dir>/libheif_hipcolor.so): then the integration sources (libheif_amd/integration/*.cc, compiled INTO libheif) and libheif's own threads are watched too
+[ -n "$LIBHEIF_OVERRIDE" ] && LIBHEIF=$LIBHEIF_OVERRIDE
 HIPEMU_THREADS=1 HIPEMU_DEVICES=${HIPEMU_DEVICES:-2} TSAN_OPTIONS="halt_on_error=0 history_size=4" \
   $B/dropin_host_tsan $LIBHEIF $B/libheifhip_emu_tsan.so ${1:-8} ${2:-10} ${RGB:-0} $B/files/*
