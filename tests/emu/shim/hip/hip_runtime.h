@@ -50,9 +50,12 @@ inline int device_count() { const char* e = getenv("HIPEMU_DEVICES"); const int 
 }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+// HIPEMU_POISON=<byte>: device and pinned allocations come back filled with that byte instead of whatever malloc hands out (mostly fresh zero pages):
+// device memory is NOT zeroed by hipMalloc, so a kernel or a read-back that leans on zeros shows up as a mismatch against the oracle
+namespace hipemu { inline int poison_byte() { static const int v = getenv("HIPEMU_POISON") ? (int)strtol(getenv("HIPEMU_POISON"), nullptr, 0) & 255 : -1; return v; } }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); if (*p && hipemu::poison_byte() >= 0) memset(*p, hipemu::poison_byte(), n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
-static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); if (*p && hipemu::poison_byte() >= 0) memset(*p, hipemu::poison_byte(), n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
