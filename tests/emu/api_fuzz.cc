@@ -208,6 +208,7 @@ int main(int argc, char** argv)
     closedir(dp);
   }
   if (g_sources.empty()) { fprintf(stderr, "no inputs under %s\n", dir.c_str()); return 2; }
+  if (getenv("API_FUZZ_NO_CACHE")) (void)hipdec_set_arena_cache_bytes(0);   // every launch set allocates and frees: with HIPEMU_FAIL_ALLOC the failures land everywhere
   std::vector<std::thread> th;
   std::atomic<int> next{0};
   for (int t = 0; t < threads; t++)

@@ -53,9 +53,12 @@ static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 // HIPEMU_POISON=<byte>: device and pinned allocations come back filled with that byte instead of whatever malloc hands out (mostly fresh zero pages):
 // device memory is NOT zeroed by hipMalloc, so a kernel or a read-back that leans on zeros shows up as a mismatch against the oracle
 namespace hipemu { inline int poison_byte() { static const int v = getenv("HIPEMU_POISON") ? (int)strtol(getenv("HIPEMU_POISON"), nullptr, 0) & 255 : -1; return v; } }
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); if (*p && hipemu::poison_byte() >= 0) memset(*p, hipemu::poison_byte(), n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+// HIPEMU_FAIL_ALLOC=<n>: every n-th device / pinned allocation of the process fails with hipErrorOutOfMemory - the error paths behind arena_acquire / pinned_acquire
+// (memory-pressure hook, fall-backs, clean-up of half-built launch sets) under the sanitizers (tools/emu_api_fuzz.sh)
+namespace hipemu { inline bool fail_this_alloc() { static const long n = getenv("HIPEMU_FAIL_ALLOC") ? atol(getenv("HIPEMU_FAIL_ALLOC")) : 0; static std::atomic<long> k{0}; return n > 0 && (k.fetch_add(1) + 1) % n == 0; } }
+static inline hipError_t hipMalloc(void** p, size_t n) { if (hipemu::fail_this_alloc()) { *p = nullptr; return hipErrorOutOfMemory; } *p = malloc(n ? n : 1); if (*p && hipemu::poison_byte() >= 0) memset(*p, hipemu::poison_byte(), n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
-static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); if (*p && hipemu::poison_byte() >= 0) memset(*p, hipemu::poison_byte(), n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { if (hipemu::fail_this_alloc()) { *p = nullptr; return hipErrorOutOfMemory; } *p = malloc(n ? n : 1); if (*p && hipemu::poison_byte() >= 0) memset(*p, hipemu::poison_byte(), n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
