@@ -52,7 +52,8 @@ typedef enum hipdec_status {
 
 /* ---- library ---------------------------------------------------------------------------------- */
 HIPDEC_API int hipdec_init(int device_index);          /* idempotent; selects the device            */
-HIPDEC_API void hipdec_shutdown(void);
+HIPDEC_API void hipdec_shutdown(void);                  /* gives pools, streams and the resident-plane registry back; call it when no other thread is inside the
+                                                          * library and no object of it is alive - a later call re-initialises the library by itself */
 HIPDEC_API const char* hipdec_last_error(void);        /* thread-local, never NULL                  */
 HIPDEC_API const char* hipdec_version(void);
 HIPDEC_API int hipdec_device_count(void);
