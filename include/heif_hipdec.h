@@ -291,7 +291,8 @@ HIPDEC_API int hipdec_grid_create_rccl(hipdec_grid_rccl** out, void* comm, int r
 HIPDEC_API void hipdec_grid_rccl_free(hipdec_grid_rccl* g);
 HIPDEC_API int hipdec_grid_rccl_decode(hipdec_grid_rccl* g);   /* asynchronous: decode + gather + paste queued on the rank's stream */
 HIPDEC_API int hipdec_grid_rccl_wait(hipdec_grid_rccl* g);     /* this rank's work, then ONE 8-byte all-reduce per decode: every rank - rank 0 with the canvas first of all -
-                                                                  * learns whether every shard decoded.  EVERY rank must call it (or to_rgb / read_plane, which do) after each decode */
+                                                                  * learns whether every shard decoded.  EVERY rank must call it (or to_rgb / read_plane, which do) after each decode -
+                                                                  * ALSO a rank whose decode() returned an error (its peers are inside the all-reduce); it then returns that error */
 /* rank 0 only (it owns the canvas): */
 HIPDEC_API int hipdec_grid_rccl_canvas_plane(hipdec_grid_rccl* g, int c, const void** dptr, size_t* stride);
 HIPDEC_API int hipdec_grid_rccl_read_plane(hipdec_grid_rccl* g, int c, void* dst_host, size_t dst_stride);

@@ -82,7 +82,12 @@ void chain_resolve(BatchLayout& b, uint64_t arena_base, std::vector<int>& own, i
 {
   own.clear();
   for (RefPicture& rp : b.tracks[(size_t)track].seq_after.dpb)
-    if (rp.batch_item >= 0) { rp = chain_ref_picture(b, rp.batch_item, arena_base); own.push_back(rp.poc); }
+    if (rp.batch_item >= 0) {
+      const bool lt = rp.long_term;   // (marked on the working copy when a later picture of the chain made it a long-term reference: keep it)
+      rp = chain_ref_picture(b, rp.batch_item, arena_base);
+      rp.long_term = lt;
+      own.push_back(rp.poc);
+    }
 }
 
 int layout_batch_plan_chain(BatchLayout& b, int n, const void* const* data, const size_t* sizes, uint64_t max_pixels, std::string& err_out,

@@ -1002,9 +1002,10 @@ int run_decoder_batch(hipdec_batch* b, hipStream_t s)
   for (size_t i = 0; i < b->params.size(); i++) outs.push_back((uint8_t*)b->rgb_dev + b->rgb_off[i]);
   const int rc = hipdec_batch_run_rgb(b, 10, outs.data(), b->rgb_stride.data(), (void*)s);
   if (rc == 0 && b->fused_rgb) { g_rgb_produced += b->params.size(); return 0; }
-  // (items whose colour descriptions ask for different kernels, or a run that did not take the fused form: the RGB is dropped; a failed run_rgb has
-  //  launched nothing, the planes-only launch set follows)
-  { DeviceScope scope(b->device); if (rc == 0) (void)b->wait(); arena_release(b->rgb_dev, b->rgb_capacity); }
+  // (items whose colour descriptions ask for different kernels, or a run that did not take the fused form: the RGB is dropped and the planes-only
+  //  launch set follows.  A failed run_rgb may have queued kernels that write into rgb_dev - the unfused form converts item by item behind a
+  //  complete decode -, so the stream is drained on EVERY path before the buffer goes back to the pool)
+  { DeviceScope scope(b->device); if (rc == 0) (void)b->wait(); else (void)hipStreamSynchronize(s); arena_release(b->rgb_dev, b->rgb_capacity); }
   b->rgb_dev = nullptr; b->rgb_off.clear(); b->rgb_stride.clear();
   return rc == 0 ? 0 : hipdec_batch_run(b, (void*)s);
 }
@@ -1365,6 +1366,7 @@ struct ChainRequest {
   int rc = 0;
   std::string err;
   bool taken = false, done = false;
+  bool oom = false;                      // rc is a failed device allocation: the same samples may fit as a shorter chain
   std::shared_ptr<hipdec_batch> batch;   // the launch set that decoded the samples ...
   int track = 0;                         // ... and which of its tracks they are
 };
@@ -1415,6 +1417,7 @@ bool run_chain_set(std::vector<ChainRequest*>& group)
   int bad = -1;
   const ChainPlan plan{(int)group.size(), first.data(), count.data(), seqs.data(), &bad};
   static const bool trace = getenv("HIPDEC_CHAIN_TRACE") != nullptr;   // dev knob: where a chain launch set's wall time goes
+  (void)arena_oom_take();
   const auto t0 = Clock::now();
   int rc = build_batch(b, (int)ptrs.size(), ptrs.data(), sizes.data(), group[0]->d->max_pixels, nullptr, nullptr, &plan);
   const auto t1 = Clock::now();
@@ -1435,8 +1438,9 @@ bool run_chain_set(std::vector<ChainRequest*>& group)
             b.pics.size(), b.pixel_steps.size(), b.motion_steps.size(), ms(t0, t1), ms(t1, t2), ms(t2, Clock::now()), rc);
   }
   if (rc) {
+    const bool oom = arena_oom_take() || rc == HIPDEC_ERR_MEMORY;
     if (group.size() > 1) return false;   // every track on its own then: the one with the bad sample alone gets the error
-    group[0]->rc = rc; group[0]->err = hipdec_last_error();
+    group[0]->rc = rc; group[0]->err = hipdec_last_error(); group[0]->oom = oom;
     return true;
   }
   for (size_t t = 0; t < group.size(); t++) { group[t]->rc = 0; group[t]->batch = sp; group[t]->track = (int)t; }
@@ -1456,7 +1460,7 @@ void run_chain_requests(std::vector<ChainRequest*>& take)
     if (!ok)
       for (ChainRequest* r : group) {
         std::vector<ChainRequest*> one{r};
-        try { (void)run_chain_set(one); } catch (const std::exception& e) { r->rc = HIPDEC_ERR_MEMORY; r->err = std::string("decode: ") + e.what(); }
+        try { (void)run_chain_set(one); } catch (const std::exception& e) { r->rc = HIPDEC_ERR_MEMORY; r->err = std::string("decode: ") + e.what(); r->oom = true; }
       }
     std::lock_guard<std::mutex> lock(g_chains.mu);
     g_chains.n_sets += ok ? 1 : group.size();
@@ -1489,10 +1493,32 @@ extern "C" void hipdec_decoder_chain_stats(uint64_t* chains, uint64_t* launch_se
 
 // Afterwards the track's state sits behind the last of the samples, the DPB holds name the launch set for its pictures, and `outputs` lists the
 // decoded pictures in decoding order.
+static int decode_chain_once(hipdec_decoder* d, size_t n, std::vector<hipdec_decoder::Output>* outputs, bool* retry_shorter);
+// The chain is bounded in BYTES as well as in pictures: a launch set holds every picture of the chain with its coefficients, unit
+// maps, motion field and an uncropped copy - about 10 bytes per luma pixel -, so 32 pictures of an 8K track are > 10 GB.  n is cut to what a quarter
+// of the free device memory holds (at least one picture), and a chain whose arena still cannot be allocated is retried at half the length down to
+// one picture instead of dropping its samples: a large track decodes as it did in the one-sample-per-poll form, only slower.
 static int decode_chain(hipdec_decoder* d, size_t n, std::vector<hipdec_decoder::Output>* outputs)
 {
   if (n > d->sq.queue.size()) n = d->sq.queue.size();
   if (!n) return 0;
+  if (n > 1 && d->batch && !d->batch->pics.empty()) {
+    const hipdec_image_info& ii = d->batch->pics[(size_t)d->item < d->batch->pics.size() ? (size_t)d->item : 0].info;
+    const double per_picture = 10.0 * (double)ii.width * (double)ii.height + double(1 << 20);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = size_t(8) << 30; }
+    const size_t fit = (size_t)std::max(1.0, (double)free_b / 4.0 / per_picture);
+    if (n > fit) n = fit;
+  }
+  for (;;) {
+    bool retry = false;
+    const int rc = decode_chain_once(d, n, outputs, &retry);
+    if (!retry) return rc;
+    n = (n + 1) / 2;
+  }
+}
+static int decode_chain_once(hipdec_decoder* d, size_t n, std::vector<hipdec_decoder::Output>* outputs, bool* retry_shorter)
+{
   if (int rc = ensure_init()) return rc;
   ChainRequest req;
   req.d = d; req.n = n; req.device = active_device();
@@ -1568,6 +1594,7 @@ static int decode_chain(hipdec_decoder* d, size_t n, std::vector<hipdec_decoder:
     g_co.n_requests += n;
     g_co.n_launch_sets++;
   }
+  if (req.rc && req.oom && n > 1) { *retry_shorter = true; return req.rc; }   // out of device memory: the samples stay queued, the caller halves the chain
   if (req.rc) { drop(); return set_error(req.rc, "%s", req.err.c_str()); }
   std::shared_ptr<hipdec_batch> sp = req.batch;
   hipdec_batch& b = *sp;
@@ -1649,7 +1676,11 @@ int hipdec_decoder_next_picture(hipdec_decoder* d, int flush, hipdec_image_info*
       if (!d->decoded || !ready || !(flush || ready >= k)) break;
       if (!d->seq_active) { if (int rc = seq_activate(d)) return rc; }
       std::vector<hipdec_decoder::Output> outs;
-      if (int rc = decode_chain(d, std::min(d->sq.queue.size(), k), &outs)) return rc;
+      // only the leading run of samples that hold a coded picture: a sample of parameter sets / AUD / SEI only (say, pushed behind the last picture
+      // before a flush) has no picture to parse and would fail the whole chain; it is skipped at the front of the next round
+      size_t lead = 0;
+      while (lead < d->sq.queue.size() && lead < k && d->sq.queue[lead].has_vcl) lead++;
+      if (int rc = decode_chain(d, lead, &outs)) return rc;
       for (auto& o : outs) if (o.pic_output) d->waiting.push_back(std::move(o));
       got = release(false);
     }

@@ -119,7 +119,10 @@ struct hipdec_grid_rccl {
   size_t off[3] = {0, 0, 0}, stride[3] = {0, 0, 0};
   hipdec_image_info info{};                  // of this rank's first tile (rank 0: tile 0, the canvas' colour description)
   bool decoded = false;
+  bool attempted = false;                    // a decode posted this rank's part of the exchange (whatever its own result): wait() must join the status all-reduce
+  int64_t* status_dev = nullptr; size_t status_capacity = 0;   // the 8 bytes of wait()'s all-reduce, held for the object's life: no allocation can fail there
   bool status_known = false; int status_rc = 0; std::string status_msg;   // wait()'s result for the last decode (the exchange runs once per decode)
+  std::string queue_msg;
   int queue_rc = 0;                          // this rank could not queue its shard's decode (its tiles are undefined): reported to every rank by wait()
   ~hipdec_grid_rccl()
   {
@@ -129,6 +132,7 @@ struct hipdec_grid_rccl {
     if (send) arena_release(send, send_capacity);
     if (recv) arena_release(recv, recv_capacity);
     if (canvas) arena_release(canvas, canvas_capacity);
+    if (status_dev) arena_release(status_dev, status_capacity);
   }
 };
 
@@ -255,6 +259,7 @@ int hipdec_grid_create_rccl(hipdec_grid_rccl** out, void* comm, int rank, int nr
       g->off[1] = c; c += g->stride[1] * ch; g->off[2] = c; c += g->stride[2] * ch;
       HIPDEC_CHECK_HIP(arena_acquire((void**)&g->canvas, c ? c : 256, &g->canvas_capacity));
     }
+    if (nranks > 1) HIPDEC_CHECK_HIP(arena_acquire((void**)&g->status_dev, 256, &g->status_capacity));
     *out = g.release();
     return 0;
   });
@@ -306,59 +311,66 @@ int hipdec_grid_rccl_decode(hipdec_grid_rccl* g)
       }
       HIPDEC_CHECK_NCCL(grp.end());
     }
-    g->queue_rc = rc; g->status_known = false;
-    if (rc) return rc;
-    if (g->rank == 0) {
+    // from here on this rank has posted its part of the exchange: whatever happens next, wait() joins the status all-reduce (a rank that returned
+    // early used to skip it and leave its peers inside the collective - ADVICE round 5); a failure of the paste below is this rank's status too
+    g->attempted = true; g->decoded = false; g->status_known = false;
+    if (!rc && g->rank == 0) {
       if (g->batch) (void)batch_follow_stream(g->batch, g->stream);   // (with stage overlap the pixel stages ran on the post stream)
-      for (int i = 0; i < (int)g->mine.size(); i++) {   // own tiles: straight from the batch's output planes
+      for (int i = 0; i < (int)g->mine.size() && !rc; i++) {   // own tiles: straight from the batch's output planes
         const uint8_t* src[3] = {nullptr, nullptr, nullptr};
         size_t ss[3] = {0, 0, 0};
-        for (int c = 0; c < (g->chroma ? 3 : 1); c++) {
+        for (int c = 0; c < (g->chroma ? 3 : 1) && !rc; c++) {
           const void* p = nullptr;
-          if (int r2 = hipdec_batch_device_plane(g->batch, i, c, &p, &ss[c])) return r2;
+          rc = hipdec_batch_device_plane(g->batch, i, c, &p, &ss[c]);
           src[c] = (const uint8_t*)p;
         }
-        if (int r2 = paste_tile(g, g->mine[(size_t)i], src, ss)) return r2;
+        if (!rc) rc = paste_tile(g, g->mine[(size_t)i], src, ss);
       }
-      for (int p = 1; p < g->nranks && p < n_tiles; p++) {
+      for (int p = 1; p < g->nranks && p < n_tiles && !rc; p++) {
         int slot = 0;
-        for (int t = p; t < n_tiles; t += g->nranks, slot++) {
+        for (int t = p; t < n_tiles && !rc; t += g->nranks, slot++) {
           const uint8_t* base = g->recv + g->recv_off[(size_t)p] + (size_t)slot * g->tile_bytes;
           const uint8_t* src[3] = {base, base + ysz, base + ysz + csz};
           const size_t ss[3] = {(size_t)g->tile_w * es, cw * es, cw * es};
-          if (int r2 = paste_tile(g, t, src, ss)) return r2;
+          rc = paste_tile(g, t, src, ss);
         }
       }
     }
-    g->decoded = true;
-    return 0;
+    g->queue_rc = rc;
+    g->queue_msg = rc ? hipdec_last_error() : "";
+    g->decoded = rc == 0;
+    return rc;
   });
 }
 
+// Every rank that called decode() calls wait() - also a rank whose decode() FAILED (its peers are inside the status all-reduce and would wait for it
+// for ever): the Python host does that in a finally block, a C host must do the same.
 int hipdec_grid_rccl_wait(hipdec_grid_rccl* g)
 {
-  if (!g || !g->decoded) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_rccl_wait: nothing was decoded");
+  if (!g || !g->attempted) return set_error(HIPDEC_ERR_INVALID_ARGUMENT, "grid_rccl_wait: nothing was decoded");
   DeviceScope scope(g->device);
-  HIPDEC_CHECK_HIP(hipStreamSynchronize(g->stream));
-  if (g->status_known) return g->status_rc ? set_error(g->status_rc, "%s", g->status_msg.c_str()) : 0;   // (rank 0 waits again inside to_rgb / read_plane)
+  if (g->status_known) {   // (rank 0 waits again inside to_rgb / read_plane)
+    if (hipStreamSynchronize(g->stream) != hipSuccess) return set_error(HIPDEC_ERR_DEVICE, "grid_rccl_wait: the stream failed");
+    return g->status_rc ? set_error(g->status_rc, "%s", g->status_msg.c_str()) : 0;
+  }
   auto done = [&](int rc, const std::string& msg) { g->status_known = true; g->status_rc = rc; g->status_msg = msg; return rc ? set_error(rc, "%s", msg.c_str()) : 0; };
   int local = g->queue_rc;
-  if (!local && g->batch) local = hipdec_batch_status(g->batch);   // device-side decode errors of this rank's shard
-  const std::string local_msg = local ? hipdec_last_error() : "";
+  std::string local_msg = g->queue_msg;
+  // local HIP failures are FOLDED into the reduced value instead of returning in front of the collective
+  if (hipStreamSynchronize(g->stream) != hipSuccess && !local) { local = HIPDEC_ERR_DEVICE; local_msg = "grid_rccl_wait: the stream failed"; }
+  if (!local && g->batch) { local = hipdec_batch_status(g->batch); if (local) local_msg = hipdec_last_error(); }   // device-side decode errors of this rank's shard
   // Every rank learns whether EVERY shard decoded (one 8-byte all-reduce): rank 0 has pasted whatever the peers sent, and must not hand out a canvas
   // with the undefined tiles of a rank whose shard failed.  All ranks call wait(), so the collective is matched.
   if (g->nranks > 1) {
-    int64_t* d = nullptr;
-    size_t cap = 0;
-    HIPDEC_CHECK_HIP(arena_acquire((void**)&d, 256, &cap));
-    struct Rel { void* p; size_t c; ~Rel() { arena_release(p, c); } } rel{d, cap};
     int64_t h = local ? 1 + g->rank : 0;
-    HIPDEC_CHECK_HIP(hipMemcpyAsync(d, &h, sizeof(h), hipMemcpyHostToDevice, g->stream));
-    HIPDEC_CHECK_NCCL(rccl().AllReduce(d, d, 1, ncclInt64, ncclMax, g->comm, g->stream));
-    HIPDEC_CHECK_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, g->stream));
-    HIPDEC_CHECK_HIP(hipStreamSynchronize(g->stream));
+    bool hip_ok = hipMemcpyAsync(g->status_dev, &h, sizeof(h), hipMemcpyHostToDevice, g->stream) == hipSuccess;
+    const bool nccl_ok = rccl().AllReduce(g->status_dev, g->status_dev, 1, ncclInt64, ncclMax, g->comm, g->stream) == ncclSuccess;
+    int64_t r = 0;
+    hip_ok = hip_ok && hipMemcpyAsync(&r, g->status_dev, sizeof(r), hipMemcpyDeviceToHost, g->stream) == hipSuccess;
+    hip_ok = hipStreamSynchronize(g->stream) == hipSuccess && hip_ok;
     if (local) return done(local, local_msg);
-    if (h) return done(HIPDEC_ERR_BITSTREAM, "grid_rccl_wait: the shard of rank " + std::to_string((int)h - 1) + " failed to decode: the canvas is incomplete");
+    if (!nccl_ok || !hip_ok) return done(HIPDEC_ERR_DEVICE, "grid_rccl_wait: the status exchange failed");
+    if (r) return done(HIPDEC_ERR_BITSTREAM, "grid_rccl_wait: the shard of rank " + std::to_string((int)r - 1) + " failed to decode: the canvas is incomplete");
     return done(0, "");
   }
   return done(local, local_msg);

@@ -37,6 +37,7 @@ uint32_t parse_wave_budget();   // CABAC pool waves one batch may launch (wave s
 hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity);
 void arena_release(void* p, size_t capacity);
 void arena_pool_clear();
+bool arena_oom_take();   // did an arena_acquire of this thread fail since the last call?  (clears the mark: a chain that ran out of device memory is retried shorter)
 void set_memory_pressure_handler(void (*fn)());   // called when a device allocation fails even with the arena pool empty, before the last retry
 hipError_t pinned_acquire(void** out, size_t bytes, size_t* capacity);   // pinned host staging for large uploads, recycled
 void pinned_release(void* p, size_t capacity);

@@ -38,6 +38,7 @@ struct MotionArgs {
 };
 
 void launch_parse(const ParseArgs& a, hipStream_t s);
+void launch_parse_throughput(const ParseArgs& a, hipStream_t s);   // parse_kernel_tp.hip: k_parse_occ8, LDS-resident contexts (4:0:0 / 4:2:0 intra batches)
 void launch_parse_inter(const ParseArgs& a, hipStream_t s);   // parse_kernel_inter.hip: batches with P pictures (sequence tracks)
 void launch_motion(const MotionArgs& a, hipStream_t s);       // P pictures: MotionSyntax -> motion field (merge / AMVP derivation)
 // motion-compensated prediction into the rec planes; add_residual: plus the residual of every inter coded sample (then k_recon runs with inter_from_plane)

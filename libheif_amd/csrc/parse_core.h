@@ -104,6 +104,9 @@ PC_DEV uint32_t pc_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }     
 #ifndef HIPDEC_PARSE_CHROMA_GENERAL
 #define HIPDEC_PARSE_CHROMA_GENERAL 1   // 0: a build for 4:0:0 / 4:2:0 pictures only (see pc_is444)
 #endif
+#ifndef HIPDEC_PARSE_LDS_CTX
+#define HIPDEC_PARSE_LDS_CTX 0          // 1: context variables and the rangeTabLps / transIdxLps tables live in LDS (the throughput kernel, see "LDS-resident contexts" below)
+#endif
 #ifndef HIPDEC_PARSE_INTER
 #define HIPDEC_PARSE_INTER 0            // 1: the build that also parses P slices (sequence tracks; parse_kernel_inter.hip, the CPU emulation)
 #endif
@@ -114,7 +117,26 @@ namespace pcore {
 struct Lds {
   alignas(16) int16_t coef[32 * 32];  // coefficient block being parsed (zero outside the parse of a block)
   alignas(16) uint32_t park[SAVE_DWORDS];   // staging image of a parked row's record (save_row_state / load_row_state)
+#if HIPDEC_PARSE_LDS_CTX
+  // LDS-resident contexts (round 6).  Measured on MI355X (profiles/r06_issue_model_*.txt): a VALU instruction that touches the scalar register
+  // file - an SGPR operand, VCC, v_readlane / v_writelane, every v_cmp and v_cndmask - issues at HALF the rate of one that only reads and writes
+  // VGPRs / inline constants (0.9 against 1.76 instructions per cycle and CU at 8 waves per SIMD), and k_parse sat at exactly that 0.9.  The
+  // register-file form of a context-coded bin is 9 such instructions (two v_readlane, the write-back mask + select, operands that came out of a
+  // v_readlane ...).  Here the context variable and its rangeTabLps row come from LDS with wave-uniform addresses (a broadcast read, the third
+  // issue pipe of the CU, idle in this kernel), everything between them is pure-VGPR arithmetic on wave-uniform values, and only the two decisions
+  // (MPS / LPS, renormalise or not) cross to the scalar side.
+  alignas(16) uint32_t ctx[3 * 64];   // context variables, groups A | B | C: (p' << 2) | valMps << 16 with p' = 62 - pStateIdx (the low half is the byte offset of its row in tlps)
+  uint32_t tlps[64];                  // entry p': rangeTabLps[62 - p'][0..3], one byte per qRangeIdx
+  uint32_t tnext[64];                 // entry p': the variable after an LPS - (p'_next << 2), bit 16 set where the LPS flips valMps (pStateIdx 0)
+  uint32_t vctx[16];                  // sig_coeff_flag run: byte address (inside this struct) of the context variable of each scan position
+#endif
 };
+#if HIPDEC_PARSE_LDS_CTX
+struct CtxGroup { int base; };         // a context group is an index range of Lds::ctx
+typedef CtxGroup CtxRef;
+#else
+typedef VReg& CtxRef;                  // ... or a 64-lane register
+#endif
 
 // everything here is wave-uniform unless it is a VReg
 struct PS {
@@ -127,8 +149,13 @@ struct PS {
   int32_t err;
   const uint8_t* bs;
   // ---- lane-indexed register files
+#if HIPDEC_PARSE_LDS_CTX
+  static constexpr CtxGroup ctxA{0}, ctxB{64}, ctxC{128};
+  VReg t_next;                                  // (only the scan tables in bits 13:8 / 29:24)
+#else
   VReg ctxA, ctxB, ctxC;
   VReg t_lps, t_next;
+#endif
   VReg win, win_next;
   VReg m_size, m_flags, m_ipm, m_ipmc, m_qp;  // 4 units per lane, z-scan order
   VReg p_left;                                  // left neighbour CTB: lane y = size byte | intra mode byte << 8 of its rightmost unit in unit row y
@@ -282,6 +309,39 @@ PC_DEV void cabac_start(PS& s, uint32_t start, uint32_t end)
 // selects, the bin value and the syntax control flow are scalar (profiles/r02g_pmc_parse_b512.txt).
 PC_DEV void refill_byte(PS& s) { s.value += read_byte_v(s) << s.bits_needed; s.bits_needed -= 8u; }
 
+#if HIPDEC_PARSE_LDS_CTX
+// the C++ form over the LDS-resident contexts (host emulation of this build, -DHIPDEC_PARSE_CXX_BINS on the device): same arithmetic as below with
+// the variable's low half scaled by four
+PC_DEV int decode_bin_cxx(PS& s, CtxRef grp, int ctx_lane)
+{
+  uint32_t* const cv = &s.L->ctx[grp.base + ctx_lane];
+  const uint32_t st = pc_uni(*cv);
+  const uint32_t row = pc_uni(s.L->tlps[(st & 0xfcu) >> 2]);
+  const UReg lps = (row >> ((s.range >> 10) & 24u)) & 255u;
+  UReg range = s.range - (lps << 7);
+  uint32_t nst;
+  int bin;
+  UReg nb;
+  if (__builtin_expect(pc_any(s.value < range), 1)) {
+    bin = (int)(st >> 16);
+    nst = st - (((st & 0xfcu) != 0u) ? 4u : 0u);
+    nb = 1u - (range >> 15);
+    range <<= nb;
+  } else {
+    bin = (int)((st >> 16) ^ 1u);
+    nb = (UReg)pc_clz(lps) - 23u;
+    s.value -= range;
+    range = lps << (nb + 7u);
+    nst = pc_uni(s.L->tnext[(st & 0xfcu) >> 2]) ^ (st & 0x10000u);
+  }
+  PC_VEC_BEGIN if (lane == 0) *cv = nst; PC_VEC_END
+  s.range = range;
+  s.value <<= nb;
+  s.bits_needed += nb;
+  if (__builtin_expect(pc_any((int32_t)s.bits_needed >= 0), 0)) refill_byte(s);
+  return bin;
+}
+#else
 PC_DEV int decode_bin_cxx(PS& s, VReg& grp, int ctx_lane)
 {
   const uint32_t st = pc_rdlane(grp, ctx_lane);
@@ -312,13 +372,18 @@ PC_DEV int decode_bin_cxx(PS& s, VReg& grp, int ctx_lane)
   if (__builtin_expect(pc_any((int32_t)s.bits_needed >= 0), 0)) refill_byte(s);
   return bin;
 }
+#endif
 
 #if !defined(HIPDEC_HOST_EMU) && !defined(HIPDEC_PARSE_CXX_BINS)
 #define PC_ASM_BINS 1
-#include "parse_bins_gfx950.h"
+#if HIPDEC_PARSE_LDS_CTX
+#include "parse_bins_lds_gfx950.h"
 #else
-PC_DEV int decode_bin(PS& s, VReg& grp, int ctx_lane) { return decode_bin_cxx(s, grp, ctx_lane); }
-PC_DEV int decode_unary_ctx_run(PS& s, VReg& grp, int base_lane, int shift, int max)
+#include "parse_bins_gfx950.h"
+#endif
+#else
+PC_DEV int decode_bin(PS& s, CtxRef grp, int ctx_lane) { return decode_bin_cxx(s, grp, ctx_lane); }
+PC_DEV int decode_unary_ctx_run(PS& s, CtxRef grp, int base_lane, int shift, int max)
 {
   int i = 0;
   while (i < max && decode_bin(s, grp, base_lane + (i >> shift))) i++;
@@ -414,18 +479,30 @@ PC_DEV void init_contexts(PS& s)
       pre = pre < 1 ? 1 : (pre > 126 ? 126 : pre);
       const int mps = pre <= 63 ? 0 : 1;
       const int p_state = mps ? pre - 64 : 63 - pre;
+#if HIPDEC_PARSE_LDS_CTX
+      s.L->ctx[g * 64 + lane] = (uint32_t)(((62 - p_state) << 2) | (mps << 16));
+#else
       const uint32_t v = (uint32_t)((62 - p_state) | (mps << 16));   // p' | valMps << 16
       if (g == 0) PC_L(s.ctxA) = v; else if (g == 1) PC_L(s.ctxB) = v; else PC_L(s.ctxC) = v;
+#endif
     }
   PC_VEC_END
+  PC_LDS_SYNC();
 }
 PC_DEV void load_tables(PS& s)
 {
   PC_VEC_BEGIN
     const int ps = lane < 63 ? 62 - lane : 63;   // lane p' serves pStateIdx 62 - p' (lane 63: the terminate state's row, never addressed)
-    PC_L(s.t_lps) = (uint32_t)c_range_lps[ps * 4] | ((uint32_t)c_range_lps[ps * 4 + 1] << 8) | ((uint32_t)c_range_lps[ps * 4 + 2] << 16) |
-                    ((uint32_t)c_range_lps[ps * 4 + 3] << 24);
+    const uint32_t lps_row = (uint32_t)c_range_lps[ps * 4] | ((uint32_t)c_range_lps[ps * 4 + 1] << 8) | ((uint32_t)c_range_lps[ps * 4 + 2] << 16) |
+                             ((uint32_t)c_range_lps[ps * 4 + 3] << 24);
+#if HIPDEC_PARSE_LDS_CTX
+    s.L->tlps[lane] = lps_row;
+    s.L->tnext[lane] = (lane < 63 ? (uint32_t)(62 - c_next_lps[ps]) << 2 : 0u) | (lane == 62 ? 0x10000u : 0u);
+    PC_L(s.t_next) = (uint32_t)c_diag8[lane] << 8;
+#else
+    PC_L(s.t_lps) = lps_row;
     PC_L(s.t_next) = (lane < 63 ? (uint32_t)(62 - c_next_lps[ps]) : 0u) | (lane == 62 ? 0x10000u : 0u) | ((uint32_t)c_diag8[lane] << 8);
+#endif
   PC_VEC_END
   {   // inverse of the 8x8 diagonal scan, scattered with one masked move per position (once per substream)
     VReg inv;
@@ -650,6 +727,9 @@ PC_DEV int residual_coding(PS& s, int log2n, int c_idx, int pred_mode)
         else if (dc_sb && r == 0) c = c_idx ? 27u : 0u;
         else c = (uint32_t)sig_off + ((pat >> (r * 2)) & 3u);
         PC_L(vctx) = c;
+#if HIPDEC_PARSE_LDS_CTX
+        if (lane < 16) s.L->vctx[lane] = (uint32_t)__builtin_offsetof(Lds, ctx) + 4u * (uint32_t)(PS::ctxB.base + B_SIG_COEFF) + 4u * c;
+#endif
       PC_VEC_END
     }
     uint32_t sig = 0;  // bit k = sig_coeff_flag at scan position k
@@ -1390,16 +1470,30 @@ PC_DEV uint32_t ctx_unpack(uint32_t b) { return (b & 63u) | ((b >> 6) << 16); }
 PC_DEV void stage_contexts(PS& s)   // -> bytes 0 .. 191 of the LDS image
 {
   uint8_t* pb = (uint8_t*)s.L->park;
+#if HIPDEC_PARSE_LDS_CTX
+  PC_LDS_SYNC();
+  PC_VEC_BEGIN
+    for (int g = 0; g < 3; g++) { const uint32_t w = s.L->ctx[g * 64 + lane]; pb[g * 64 + lane] = (uint8_t)(((w >> 2) & 63u) | ((w >> 16) << 6)); }
+  PC_VEC_END
+#else
   PC_VEC_BEGIN
     pb[lane] = (uint8_t)ctx_pack(PC_L(s.ctxA)); pb[64 + lane] = (uint8_t)ctx_pack(PC_L(s.ctxB)); pb[128 + lane] = (uint8_t)ctx_pack(PC_L(s.ctxC));
   PC_VEC_END
+#endif
 }
 PC_DEV void unstage_contexts(PS& s)
 {
   const uint8_t* pb = (const uint8_t*)s.L->park;
+#if HIPDEC_PARSE_LDS_CTX
+  PC_VEC_BEGIN
+    for (int g = 0; g < 3; g++) { const uint32_t b = pb[g * 64 + lane]; s.L->ctx[g * 64 + lane] = ((b & 63u) << 2) | ((b >> 6) << 16); }
+  PC_VEC_END
+  PC_LDS_SYNC();
+#else
   PC_VEC_BEGIN
     PC_L(s.ctxA) = ctx_unpack(pb[lane]); PC_L(s.ctxB) = ctx_unpack(pb[64 + lane]); PC_L(s.ctxC) = ctx_unpack(pb[128 + lane]);
   PC_VEC_END
+#endif
 }
 PC_DEV void park_flush(PS& s, uint32_t* dst, int dwords)   // LDS image -> HBM, write-through; the caller drains
 {
@@ -1528,7 +1622,13 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
   PC_VEC_BEGIN
     PC_L(s.m_size) = 0; PC_L(s.m_flags) = 0; PC_L(s.m_ipm) = 0; PC_L(s.m_ipmc) = 0; PC_L(s.m_qp) = 0;
     PC_L(s.p_left) = 0; PC_L(s.up) = 0; PC_L(s.sao) = 0; PC_L(s.sao_left) = 0;
-    PC_L(s.ctxA) = 0; PC_L(s.ctxB) = 0; PC_L(s.ctxC) = 0; PC_L(s.win) = 0; PC_L(s.win_next) = 0;
+#if HIPDEC_PARSE_LDS_CTX
+    for (int g = 0; g < 3; g++) s.L->ctx[g * 64 + lane] = 0;
+    if (lane < 16) s.L->vctx[lane] = (uint32_t)__builtin_offsetof(Lds, ctx);
+#else
+    PC_L(s.ctxA) = 0; PC_L(s.ctxB) = 0; PC_L(s.ctxC) = 0;
+#endif
+    PC_L(s.win) = 0; PC_L(s.win_next) = 0;
   PC_VEC_END
   uint32_t k0 = 0;
   uint32_t* saved = A.saved + (size_t)sub_idx * SAVE_DWORDS;

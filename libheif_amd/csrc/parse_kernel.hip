@@ -29,7 +29,9 @@ namespace hipdec {
 
 __global__ __launch_bounds__(64) void k_parse(ParseArgs A) { HIPDEC_PARSE_BODY }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_parse_occ6(ParseArgs A) { HIPDEC_PARSE_BODY }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_parse_occ8(ParseArgs A) { HIPDEC_PARSE_BODY }
+// (the register-file build at 8 waves per SIMD: round 5's throughput kernel, kept for A/B measurements - HIPDEC_PARSE_CTX=rf; the throughput kernel
+//  k_parse_occ8 is parse_kernel_tp.hip's, with LDS-resident contexts)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_parse_occ8_rf(ParseArgs A) { HIPDEC_PARSE_BODY }
 
 void launch_parse(const ParseArgs& a, hipStream_t s)
 {
@@ -43,7 +45,9 @@ void launch_parse(const ParseArgs& a, hipStream_t s)
   const int occ = forced >= 0 ? forced : (a.pool ? 8 : (a.num_waves >= 2048 ? 8 : 0));
   if (a.inter) { launch_parse_inter(a, s); return; }
   if (a.general_chroma) { launch_parse_general(a, occ != 0, s); return; }
-  if (occ == 8) hipLaunchKernelGGL(k_parse_occ8, dim3(a.num_waves), dim3(64), 0, s, a);
+  static const bool rf = getenv("HIPDEC_PARSE_CTX") && getenv("HIPDEC_PARSE_CTX")[0] == 'r';
+  if (occ == 8 && !rf) launch_parse_throughput(a, s);
+  else if (occ == 8) hipLaunchKernelGGL(k_parse_occ8_rf, dim3(a.num_waves), dim3(64), 0, s, a);
   else if (occ == 6) hipLaunchKernelGGL(k_parse_occ6, dim3(a.num_waves), dim3(64), 0, s, a);
   else hipLaunchKernelGGL(k_parse, dim3(a.num_waves), dim3(64), 0, s, a);
 }

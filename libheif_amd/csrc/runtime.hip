@@ -217,6 +217,8 @@ void pinned_pool_clear()
 }
 
 static std::atomic<void (*)()> g_memory_pressure{nullptr};
+static thread_local bool t_arena_oom = false;   // the calling thread's last arena_acquire failed for want of device memory
+bool arena_oom_take() { const bool v = t_arena_oom; t_arena_oom = false; return v; }
 void set_memory_pressure_handler(void (*fn)()) { g_memory_pressure.store(fn); }
 
 hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity)
@@ -254,6 +256,7 @@ hipError_t arena_acquire(void** out, size_t bytes, size_t* capacity)
     if (auto cb = g_memory_pressure.load()) { cb(); arena_pool_clear(); e = hipMalloc(out, cap); }
   }
   *capacity = cap;
+  if (e != hipSuccess) t_arena_oom = true;
   return e;
 }
 

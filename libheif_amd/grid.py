@@ -327,7 +327,129 @@ class GridDecoderRccl:
                                           arr, sizes, int(max_image_size_pixels)))
 
     def decode(self):
-        check(self.lib.hipdec_grid_rccl_decode(self._h))
+        rc = self.lib.hipdec_grid_rccl_decode(self._h)
+        if rc != 0:
+            # a rank whose shard could not be queued still joins the status exchange of wait() - its peers are inside that all-reduce;
+            # wait() then returns this rank's own error again
+            self.lib.hipdec_grid_rccl_wait(self._h)
+        check(rc)
+
+    def wait(self):
+        check(self.lib.hipdec_grid_wait(self._h))
+
+    def planes(self):
+        L = self.layout
+        dt = np.uint16 if L.bit_depth > 8 else np.uint8
+        out = []
+        info = ImageInfo()
+        check(self.lib.hipdec_grid_info(self._h, C.byref(info), None))
+        for c in range(3 if info.chroma_format_idc else 1):
+            w, h = (L.out_w, L.out_h) if c == 0 else (info.chroma_width, info.chroma_height)     # (4:2:2 / 4:4:4 tiles: the canvas keeps their subsampling)
+            a = np.empty((h, w), dt)
+            check(self.lib.hipdec_grid_read_plane(self._h, c, a.ctypes.data, w * a.itemsize))
+            out.append(a)
+        return out
+
+    def to_rgb(self, out_chroma=10, upsampling=1, only_preferred=False, out_dev=None):
+        """host array (h, w * bytes per pixel) — or, with out_dev = (device pointer, stride), converts into that device buffer"""
+        L = self.layout
+        bpp = {10: 3, 11: 4, 12: 6, 14: 6}[out_chroma]
+        if out_dev is not None:
+            check(self.lib.hipdec_grid_to_rgb(self._h, out_chroma, upsampling, int(only_preferred), out_dev[0], out_dev[1], 1))
+            return None
+        a = np.empty((L.out_h, L.out_w * bpp), np.uint8)
+        check(self.lib.hipdec_grid_to_rgb(self._h, out_chroma, upsampling, int(only_preferred), a.ctypes.data, L.out_w * bpp, 0))
+        return a
+
+    def free(self):
+        if self._h:
+            self.lib.hipdec_grid_free(self._h)
+            self._h = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _torch_rccl_path():
+    """PyTorch-ROCm wheels bundle their own librccl next to their HIP runtime; when it is there the product's dlopen() takes that copy
+    (one RCCL per process), otherwise the system's librccl.so.1"""
+    import importlib.util
+    import os
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for loc in (spec.submodule_search_locations if spec and spec.submodule_search_locations else []):
+        p = os.path.join(loc, "lib", "librccl.so")
+        if os.path.exists(p):
+            return p
+    return None
+
+
+class RcclComm:
+    """An RCCL communicator made by the library itself (hipdec_rccl_comm_create = ncclCommInitRank on the hipdec_init device).  `exchange_id`
+    carries rank 0's 128-byte unique id to the other ranks: a callable bytes -> bytes (e.g. a torch.distributed broadcast); world 1 needs none."""
+
+    def __init__(self, rank=0, world=1, exchange_id=None):
+        import os
+        p = _torch_rccl_path()
+        if p and "HIPDEC_RCCL_LIBRARY" not in os.environ:
+            os.environ["HIPDEC_RCCL_LIBRARY"] = p
+        self.lib = lib = load_library()
+        lib.hipdec_rccl_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]
+        lib.hipdec_rccl_comm_destroy.argtypes = [C.c_void_p]
+        lib.hipdec_rccl_unique_id.argtypes = [C.c_void_p]
+        self.rank, self.world = int(rank), int(world)
+        buf = C.create_string_buffer(128)
+        if self.rank == 0:
+            check(lib.hipdec_rccl_unique_id(buf))
+        raw = bytes(buf.raw)
+        if self.world > 1:
+            if exchange_id is None:
+                raise ValueError("RcclComm: world > 1 needs exchange_id to distribute rank 0's unique id")
+            raw = exchange_id(raw)
+        self._h = C.c_void_p()
+        check(lib.hipdec_rccl_comm_create(C.byref(self._h), self.world, self.rank, C.c_char_p(raw)))
+
+    def free(self):
+        if self._h:
+            self.lib.hipdec_rccl_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class GridDecoderRccl:
+    """The SPMD product path: hipdec_grid_create_rccl / _decode / _to_rgb (include/heif_hipdec.h) - one process per GPU, this rank's tiles decoded on its
+    device, the packed tiles gathered to rank 0 by one grouped ncclSend / ncclRecv inside libheifhip.so, pasted and colour-converted there."""
+
+    def __init__(self, tile_streams, layout, comm, max_image_size_pixels=0):
+        self.layout, self.comm = layout, comm
+        self.lib = lib = load_library()
+        vp, sz, ci = C.c_void_p, C.c_size_t, C.c_int
+        lib.hipdec_grid_create_rccl.argtypes = [C.POINTER(vp), vp, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_char_p), C.POINTER(sz), C.c_uint64]
+        lib.hipdec_grid_rccl_free.argtypes = [vp]
+        lib.hipdec_grid_rccl_decode.argtypes = [vp]
+        lib.hipdec_grid_rccl_wait.argtypes = [vp]
+        lib.hipdec_grid_rccl_read_plane.argtypes = [vp, ci, vp, sz]
+        lib.hipdec_grid_rccl_to_rgb.argtypes = [vp, ci, ci, ci, vp, sz, ci]
+        n = layout.n_tiles
+        mine = set(shard(n, comm.rank, comm.world))
+        self._keep = [bytes(tile_streams[t]) if t in mine else None for t in range(n)]
+        arr = (C.c_char_p * n)(*self._keep)
+        sizes = (sz * n)(*[len(s) if s is not None else 0 for s in self._keep])
+        self._h = vp()
+        check(lib.hipdec_grid_create_rccl(C.byref(self._h), comm._h, comm.rank, comm.world, layout.rows, layout.cols, layout.out_w, layout.out_h,
+                                          arr, sizes, int(max_image_size_pixels)))
+
+    def decode(self):
+        rc = self.lib.hipdec_grid_rccl_decode(self._h)
+        if rc != 0:
+            # a rank whose shard could not be queued still joins the status exchange of wait(): its peers are inside that all-reduce
+            msg = self.lib.hipdec_last_error()
+            self.lib.hipdec_grid_rccl_wait(self._h)
+            raise RuntimeError("hipdec_grid_rccl_decode failed (%d): %s" % (rc, msg.decode() if isinstance(msg, bytes) else msg))
 
     def wait(self):
         check(self.lib.hipdec_grid_rccl_wait(self._h))

@@ -24,6 +24,12 @@ for l in lines[start:]:
         static[cur] += 1
         op = l.split()[0]
         cls = "B" if op.startswith(("s_cbranch", "s_branch")) else ("N" if op.startswith(("s_nop", "s_waitcnt")) else ("S" if op.startswith("s_") else ("V" if op.startswith("v_") else "M")))
+        # round 6 (profiles/r06_issue_model_*.txt): a VALU instruction that reads or writes the scalar register file (SGPR operand, VCC, v_readlane,
+        # v_cmp, v_cndmask ...) issues at half the rate of one that only touches VGPRs / inline constants: class "Vs" against "Vp"
+        if cls == "V":
+            args = l.split(";")[0].split(None, 1)[1] if len(l.split(";")[0].split(None, 1)) > 1 else ""
+            sg = bool(re.search(r"(?<![a-z0-9_])(s\d+|s\[\d+:\d+\]|vcc|vcc_lo|vcc_hi|exec|m0|scc)(?![a-z0-9_])", args)) or op.startswith(("v_cmp", "v_readlane", "v_readfirstlane", "v_writelane"))
+            static_cls[(cur, "Vs" if sg else "Vp")] += 1
         static_cls[(cur, cls)] += 1
 st_line = collections.Counter()
 unattributed = 0
@@ -74,13 +80,25 @@ for ln, c in st_line.items():
     d = c / k * count(ln); tot += d; rows.append((d, ln, c / k, count(ln)))
     for (key, cls), cc in static_cls.items():
         if key[1] == ln and key[0].endswith(srcname): cls_tot[cls] += cc / k * count(ln)
-print("by class (S salu, V valu, B branch, N nop/waitcnt, M memory/lds):", {k: round(v / (px or 1), 2) for k, v in cls_tot.items()})
+print("by class (S salu, V valu = Vs scalar-file-touching + Vp pure, B branch, N nop/waitcnt, M memory/lds):", {k: round(v / (px or 1), 2) for k, v in cls_tot.items()})
 srows = []
 for (key, cls), cc in static_cls.items():
     if cls == "S" and key[0].endswith(srcname) and key[1]:
         ln = key[1]; k = max(1, copies.get(func_at.get(ln, "?"), 1))
         srows.append((cc / k * count(ln), ln, cc / k, count(ln)))
 srows.sort(reverse=True)
+if os.environ.get("VS"):
+    vrows = []
+    for (key, cls), cc in static_cls.items():
+        if cls == "Vs" and key[0].endswith(srcname) and key[1]:
+            ln = key[1]; k = max(1, copies.get(func_at.get(ln, "?"), 1))
+            vrows.append((cc / k * count(ln), ln, cc / k, count(ln)))
+    vrows.sort(reverse=True)
+    vbyf = collections.Counter()
+    for d, ln, c, k in vrows: vbyf[func_at.get(ln, "?")] += d
+    print("-- scalar-file-touching VALU by function:", {f: round(d / (px or 1), 2) for f, d in vbyf.most_common(14)})
+    print("-- top scalar-file-touching VALU lines")
+    for d, ln, c, k in vrows[:int(os.environ.get("TOPN", "45"))]: print("%5.2f/px line %4d static %5.1f x %9.0f  %s" % (d / (px or 1), ln, c, k, text[ln].strip()[:100]))
 if os.environ.get("SALU"):
     sbyf = collections.Counter()
     for d, ln, c, k in srows: sbyf[func_at.get(ln, "?")] += d
