@@ -46,7 +46,13 @@
   "v_add_u32 %[bits], -8, %[bits]\n\t"
 // the part of a bin every statement shares: state in %[vst] (being loaded) -> range update, MPS / LPS decision.  Falls through on an MPS
 // with %[vn] = the variable after the MPS and VCC = "renormalise"; LPS_LABEL is taken for an LPS.
+#ifdef HIPDEC_EXP_BIN_LATENCY   // measurement build: ~64 cycles of pure latency per bin (is the pool latency- or issue-bound?)
+#define PC_LDS_EXP "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\t"
+#else
+#define PC_LDS_EXP
+#endif
 #define PC_LDS_CORE(LPS_LABEL)                                                                                                     \
+  PC_LDS_EXP                                                                                                                        \
   "v_and_b32 %[vr], 0xfc, %[vst]\n\t"                                                                                               \
   "ds_read_b32 %[vrow], %[vr] offset:%c[tlps]\n\t"                                                                                  \
   "v_lshrrev_b32 %[vb], 16, %[vst]\n\t"                                                                                             \

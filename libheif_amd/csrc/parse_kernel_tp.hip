@@ -11,7 +11,10 @@
 
 namespace hipdec {
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_parse_occ8(ParseArgs A)
+#ifndef HIPDEC_TP_OCC
+#define HIPDEC_TP_OCC 8   // (measurement builds: tools/ab_variant.sh tp7 -DHIPDEC_TP_OCC=7 with HIPDEC_POOL_WAVES=7168)
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HIPDEC_TP_OCC, HIPDEC_TP_OCC))) void k_parse_occ8(ParseArgs A)
 {
   __shared__ pcore::Lds lds;
   const int lane = (int)threadIdx.x;

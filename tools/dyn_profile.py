@@ -30,6 +30,9 @@ for l in lines[start:]:
             args = l.split(";")[0].split(None, 1)[1] if len(l.split(";")[0].split(None, 1)) > 1 else ""
             sg = bool(re.search(r"(?<![a-z0-9_])(s\d+|s\[\d+:\d+\]|vcc|vcc_lo|vcc_hi|exec|m0|scc)(?![a-z0-9_])", args)) or op.startswith(("v_cmp", "v_readlane", "v_readfirstlane", "v_writelane"))
             static_cls[(cur, "Vs" if sg else "Vp")] += 1
+            # SGPR spills live in VGPR lanes: a reload is v_readlane sN, vK, <constant lane>, a spill v_writelane vK, sN, <constant lane>
+            if re.match(r"v_readlane_b32\s+s\d+,\s*v\d+,\s*\d+\s*$", l.split(";")[0].strip()): static_cls[(cur, "spill_reload")] += 1
+            if re.match(r"v_writelane_b32\s+v\d+,\s*s\d+,\s*\d+\s*$", l.split(";")[0].strip()): static_cls[(cur, "spill_store")] += 1
         static_cls[(cur, cls)] += 1
 st_line = collections.Counter()
 unattributed = 0
@@ -87,6 +90,16 @@ for (key, cls), cc in static_cls.items():
         ln = key[1]; k = max(1, copies.get(func_at.get(ln, "?"), 1))
         srows.append((cc / k * count(ln), ln, cc / k, count(ln)))
 srows.sort(reverse=True)
+if os.environ.get("SPILL"):
+    for what in ("spill_reload", "spill_store"):
+        vrows = []
+        for (key, cls), cc in static_cls.items():
+            if cls == what and key[0].endswith(srcname) and key[1]:
+                ln = key[1]; k = max(1, copies.get(func_at.get(ln, "?"), 1))
+                vrows.append((cc / k * count(ln), ln, cc / k, count(ln)))
+        vrows.sort(reverse=True)
+        print("-- %s: %.2f per pixel; top lines" % (what, sum(r[0] for r in vrows) / (px or 1)))
+        for d, ln, c, k in vrows[:int(os.environ.get("TOPN", "45"))]: print("%5.2f/px line %4d static %5.1f x %9.0f  %s" % (d / (px or 1), ln, c, k, text[ln].strip()[:100]))
 if os.environ.get("VS"):
     vrows = []
     for (key, cls), cc in static_cls.items():

@@ -3,7 +3,8 @@
 # Stages: every stage of tools/gpu_stage.sh (tests bench benchmain single pmc traffic prof), plus
 #   ubench_issue          tools/ubench/issue_model.hip (prebuilt: build/ubench/issue_model) -> gpurun_out/<tag>_issue_model.txt
 #   att_try               does `rocprofv3 --att` work on this box at all?  (the trace-decoder library is not in the image)
-#   ab:<name>[,<name>..]  main workload under build/ab/<name>/libheif_amd/libheifhip.so variants (tools/ab_variants.sh), tree first
+#   ab:<name>[@ENV=V..][,<name>..]  main workload under build/ab/<name>/libheif_amd/libheifhip.so variants (tools/ab_variant.sh), tree first;
+#                         "tree@ENV=V" runs the tree's library with that environment
 #   absingle:<names>      one 4K still under the same variants
 #   abtests:<name>        the GPU tier under that variant
 #   wait                  tools/prof_wait_breakdown.sh
@@ -17,9 +18,11 @@ for what in "$@"; do
     att_try) ( cd /tmp && export TMPDIR=/tmp
                timeout 120 rocprofv3 --att --att-target-cu 1 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_att -- $GRAFT_REPO_ROOT/build/ubench/issue_model 200 12 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_att.log 2>&1
                echo "att rc=$?"; tail -15 $GRAFT_REPO_ROOT/gpurun_out/${tag}_att.log; find $GRAFT_REPO_ROOT/gpurun_out/${tag}_att -type f | head -20; find / \( -name "*trace-decoder*" -o -name "*trace_decoder*.so*" \) 2>/dev/null | head ) ;;
-    ab:*) for name in tree $(echo ${what#ab:} | tr ',' ' '); do
+    ab:*) for spec in tree $(echo ${what#ab:} | tr ',' ' '); do     # <name>[@ENV=VALUE[@ENV=VALUE..]]: environment of that variant's run
+            name=${spec%%@*}; envs=$(echo "${spec#$name}" | tr '@' ' ')
             lib=""; [ $name = tree ] || lib=$PWD/build/ab/$name/libheif_amd/libheifhip.so
-            HIPDEC_LIBRARY=$lib timeout 240 python bench.py --only-main --steps ${AB_STEPS:-3} --warmup 1 ${AB_ARGS} > gpurun_out/${tag}_ab_$name.json 2> gpurun_out/${tag}_ab_$name.err
+            name=$(echo $spec | tr '@=' '__')
+            env $envs HIPDEC_LIBRARY=$lib timeout 240 python bench.py --only-main --steps ${AB_STEPS:-3} --warmup 1 ${AB_ARGS} > gpurun_out/${tag}_ab_$name.json 2> gpurun_out/${tag}_ab_$name.err
             python - <<PY
 import json
 try:
