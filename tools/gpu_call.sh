@@ -38,6 +38,17 @@ import json; d=json.load(open('gpurun_out/${tag}_absingle_$name.json')); print('
           done ;;
     abtests:*) name=${what#abtests:}
             HIPDEC_LIBRARY=$PWD/build/ab/$name/libheif_amd/libheifhip.so timeout ${TESTS_LIMIT:-420} python -m pytest tests -m gpu -q -x > gpurun_out/${tag}_abtests_$name.log 2>&1; echo "tests under $name rc=$?"; tail -3 gpurun_out/${tag}_abtests_$name.log ;;
+    overlap) # pixel stages of batch k beside the CABAC parse of batch k+1, FULL-size batches, pool of 8 / 7 / 6 / 5 waves per SIMD
+          for spec in "1:1536:8192" "1:3072:8192" "2:3072:8192" "2:3072:7168" "2:3072:6144" "2:3072:5120"; do
+            parts=${spec%%:*}; rest=${spec#*:}; n=${rest%%:*}; pw=${rest#*:}
+            HIPDEC_POOL_WAVES=$pw timeout 400 python bench.py --only-main --steps 3 --warmup 1 --parts $parts --batch $n > gpurun_out/${tag}_overlap_${parts}_${n}_${pw}.json 2> gpurun_out/${tag}_overlap_${parts}_${n}_${pw}.err
+            python - <<PY
+import json
+try:
+    d = json.load(open("gpurun_out/${tag}_overlap_${parts}_${n}_${pw}.json")); print("parts $parts  stills $n  pool waves $pw :", d["value"], "Mpx/s", d["ms_per_step"], "ms/step", {k: round(v["avg_us"]) for k, v in d["kernels"].items()})
+except Exception as e: print("$spec: no line", e)
+PY
+          done ;;
     wait) bash tools/prof_wait_breakdown.sh $tag --batch 512 2>&1 | tail -40 ;;
     *) bash tools/gpu_stage.sh $tag $what ;;
   esac
