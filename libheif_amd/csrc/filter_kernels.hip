@@ -104,14 +104,13 @@ struct EdgeWindow {
 };
 
 // luma edge segment of 4 lines (8.7.2.5.3 decisions, 8.7.2.5.7 filters); pix -> q0 of line 0.  DIR 0: vertical edge (lines are rows), 1: horizontal
+// (W: the segment's window, loaded by the caller together with everything else the segment reads - see k_deblock)
 template <typename Pix, int DIR>
-__device__ __forceinline__ void deblock_luma(Pix* pix, int stride, int qp_p, int qp_q, int beta_off2, int tc_off2, int bit_depth, int no_p, int no_q, int bs = 2)
+__device__ __forceinline__ void deblock_luma(EdgeWindow<Pix, DIR>& W, Pix* pix, int stride, int qp_p, int qp_q, int beta_off2, int tc_off2, int bit_depth, int no_p, int no_q, int bs = 2)
 {
   const int qpl = (qp_q + qp_p + 1) >> 1;
   const int beta = c_beta[clip3(0, 51, qpl + (beta_off2 << 1))] * (1 << (bit_depth - 8));
   const int tc = c_tc[clip3(0, 53, qpl + 2 * (bs - 1) + (tc_off2 << 1))] * (1 << (bit_depth - 8));   // 8.7.2.5.3: bS 2 where a side is intra coded
-  EdgeWindow<Pix, DIR> W;
-  W.load(pix, stride);
 #define WP(k, i) W.get(k, 3 - (i))
 #define WQ(k, i) W.get(k, 4 + (i))
   const int dp0 = iabs(WP(0, 2) - 2 * WP(0, 1) + WP(0, 0)), dp3 = iabs(WP(3, 2) - 2 * WP(3, 1) + WP(3, 0));
@@ -179,7 +178,21 @@ __device__ __forceinline__ void deblock_chroma(Pix* pix, int xs, int ys, int qp_
 // words.  A vertical edge's window rows start 2 samples left of a multiple of 8: 2-byte aligned for 8-bit samples (the hardware takes unaligned dwords)
 typedef uint32_t u32_a2 __attribute__((aligned(2)));
 template <typename Pix, int DIR>
-__device__ __forceinline__ void deblock_chroma4(Pix* pix, int stride, int qp_p, int qp_q, int c_qp_pic_offset, int tc_off2, int bit_depth, int no_p, int no_q,
+struct ChromaWindow {
+  static constexpr int ES = (int)sizeof(Pix);
+  uint32_t w[4 * ES];
+  __device__ __forceinline__ void load(const Pix* pix, int stride)
+  {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {     // DIR 0: line r (a picture row); DIR 1: picture row y - 2 + r
+      const u32_a2* src = (const u32_a2*)(DIR == 0 ? pix + (size_t)r * stride - 2 : pix + (ptrdiff_t)(r - 2) * stride);
+#pragma unroll
+      for (int i = 0; i < ES; i++) w[ES * r + i] = src[i];
+    }
+  }
+};
+template <typename Pix, int DIR>
+__device__ __forceinline__ void deblock_chroma4(ChromaWindow<Pix, DIR>& CW, Pix* pix, int stride, int qp_p, int qp_q, int c_qp_pic_offset, int tc_off2, int bit_depth, int no_p, int no_q,
                                                 bool not420)
 {
   constexpr int ES = (int)sizeof(Pix);
@@ -187,16 +200,10 @@ __device__ __forceinline__ void deblock_chroma4(Pix* pix, int stride, int qp_p, 
   const int qpc = not420 ? (qpi < 51 ? qpi : 51) : (qpi < 30 ? qpi : (qpi >= 44 ? qpi - 6 : c_chroma_qp_f[qpi - 30]));   // 8.7.2.5.5
   const int tc = c_tc[clip3(0, 53, qpc + 2 + (tc_off2 << 1))] * (1 << (bit_depth - 8));
   const int maxv = (1 << bit_depth) - 1;
-  uint32_t w[4 * ES];
+  uint32_t* w = CW.w;
   // word / shift of sample j (0 .. 3 = p1 p0 q0 q1) of line k
   auto word = [](int k, int j) { return DIR == 0 ? (ES == 1 ? k : 2 * k + (j >> 1)) : (ES == 1 ? j : 2 * j + (k >> 1)); };
   auto shift = [](int k, int j) { return DIR == 0 ? (ES == 1 ? 8 * j : 16 * (j & 1)) : (ES == 1 ? 8 * k : 16 * (k & 1)); };
-#pragma unroll
-  for (int r = 0; r < 4; r++) {     // DIR 0: line r (a picture row); DIR 1: picture row y - 2 + r
-    const u32_a2* src = (const u32_a2*)(DIR == 0 ? pix + (size_t)r * stride - 2 : pix + (ptrdiff_t)(r - 2) * stride);
-#pragma unroll
-    for (int i = 0; i < ES; i++) w[ES * r + i] = src[i];
-  }
   const uint32_t smask = ES == 1 ? 255u : 0xffffu;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -213,6 +220,13 @@ __device__ __forceinline__ void deblock_chroma4(Pix* pix, int stride, int qp_p, 
 #pragma unroll
     for (int i = 0; i < ES; i++) dst[i] = w[ES * r + i];
   }
+}
+template <typename Pix, int DIR>
+__device__ __forceinline__ void deblock_chroma4(Pix* pix, int stride, int qp_p, int qp_q, int c_qp_pic_offset, int tc_off2, int bit_depth, int no_p, int no_q, bool not420)
+{
+  ChromaWindow<Pix, DIR> CW;
+  CW.load(pix, stride);
+  deblock_chroma4<Pix, DIR>(CW, pix, stride, qp_p, qp_q, c_qp_pic_offset, tc_off2, bit_depth, no_p, no_q, not420);
 }
 
 }  // namespace
@@ -260,17 +274,51 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
   const uint8_t* u_flags = A.arena + P.off_u_flags;
   const int8_t* u_qp = (const int8_t*)(A.arena + P.off_u_qp);
   int ctb_q, ctb_p;
+  // Everything a segment reads is requested BEFORE the first decision (round 6: the kernel kept 0.12 memory instructions in flight per wave - flags, then
+  // the neighbour's flags and QPs, then the slice parameters, then the samples, each behind the answer to the one before: four memory round trips per
+  // segment; now one, with the slice parameters of slice 0 - the only slice of most pictures - requested speculatively beside the CTB's slice index).
+  // Segments without an edge flag have read a window for nothing: the kernel is far from the HBM roof, it was waiting.
   const size_t iq = unit_index(P, x >> 2, y >> 2, &ctb_q);
-  const uint8_t fq = u_flags[iq];
-  if (!(fq & (DIR == 0 ? UF_VEDGE : UF_HEDGE))) return;
   const size_t ip = DIR == 0 ? unit_index(P, (x >> 2) - 1, y >> 2, &ctb_p) : unit_index(P, x >> 2, (y >> 2) - 1, &ctb_p);
-  const uint8_t fp = u_flags[ip];
+  const CtbInfo* ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
+  const SliceParams* slices = (const SliceParams*)(A.arena + P.off_slices);
+  const uint8_t fq = u_flags[iq], fp = u_flags[ip];
   const int qp_q = u_qp[iq], qp_p = u_qp[ip];
+  const uint32_t slice_idx = ctb_info[ctb_q].slice_idx;
+  int s_beta = slices[0].beta_offset_div2, s_tc = slices[0].tc_offset_div2, s_cb = slices[0].pps_cb_qp_offset, s_cr = slices[0].pps_cr_qp_offset;
+  Pix* const rec_y = (Pix*)(A.arena + P.off_rec[0]);
+  const int stride_y = P.rec_stride[0] / sizeof(Pix);
+  Pix* const pix_y = rec_y + (size_t)y * stride_y + x;
+  EdgeWindow<Pix, DIR> W;
+  W.load(pix_y, stride_y);
+  // 4:2:0 chroma edges on the 8x8 chroma grid; one 4-sample chroma segment spans 8 luma samples along the edge
+  const bool c420_grid = P.chroma_format_idc == 1 && (DIR == 0 ? ((x & 15) == 0 && (y & 7) == 0) : ((y & 15) == 0 && (x & 7) == 0));
+  const int stride_c = P.rec_stride[1] / sizeof(Pix);
+  Pix* const pix_cb = (Pix*)(A.arena + P.off_rec[1]) + (size_t)(y >> 1) * stride_c + (x >> 1);
+  Pix* const pix_cr = (Pix*)(A.arena + P.off_rec[2]) + (size_t)(y >> 1) * stride_c + (x >> 1);
+  ChromaWindow<Pix, DIR> WB, WR;
+  if (c420_grid) { WB.load(pix_cb, stride_c); WR.load(pix_cr, stride_c); }
+  else {
+#pragma unroll
+    for (int i = 0; i < 4 * (int)sizeof(Pix); i++) { WB.w[i] = 0; WR.w[i] = 0; }
+  }
+#ifndef HIPDEC_HOST_EMU
+  // (the loads above stay above the branches below: a value pinned here cannot be sunk into the block that uses it)
+#pragma unroll
+  for (int i = 0; i < EdgeWindow<Pix, DIR>::NW; i++) asm volatile("" : "+v"(W.w[i]));
+#pragma unroll
+  for (int i = 0; i < 4 * (int)sizeof(Pix); i++) asm volatile("" : "+v"(WB.w[i]), "+v"(WR.w[i]));
+  asm volatile("" : "+v"(s_beta), "+v"(s_tc), "+v"(s_cb), "+v"(s_cr));
+#endif
+  if (!(fq & (DIR == 0 ? UF_VEDGE : UF_HEDGE))) return;
   // 8.7.2.5.7: samples of cu_transquant_bypass units, and of PCM units when pcm_loop_filter_disabled_flag = 1, are left unchanged
   const int keep = UF_BYPASS | (P.pcm_loop_filter_disabled ? UF_PCM : 0);
   const int no_q = (fq & keep) != 0, no_p = (fp & keep) != 0;
-  const CtbInfo* ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
-  const SliceParams sl = ((const SliceParams*)(A.arena + P.off_slices))[ctb_info[ctb_q].slice_idx];
+  if (slice_idx != 0) {
+    s_beta = slices[slice_idx].beta_offset_div2; s_tc = slices[slice_idx].tc_offset_div2;
+    s_cb = slices[slice_idx].pps_cb_qp_offset; s_cr = slices[slice_idx].pps_cr_qp_offset;
+  }
+  struct { int beta_offset_div2, tc_offset_div2, pps_cb_qp_offset, pps_cr_qp_offset; } sl = {s_beta, s_tc, s_cb, s_cr};
   int bs = 2;   // every edge of an intra picture
   if (P.is_inter) {
     // 8.7.2.4 in a P picture: 2 where a side is intra coded; else 1 at a transform block edge next to a block with luma coefficients, or where
@@ -287,12 +335,7 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
       else return;
     }
   }
-  {
-    Pix* rec = (Pix*)(A.arena + P.off_rec[0]);
-    const int stride = P.rec_stride[0] / sizeof(Pix);
-    Pix* pix = rec + (size_t)y * stride + x;
-    deblock_luma<Pix, DIR>(pix, stride, qp_p, qp_q, sl.beta_offset_div2, sl.tc_offset_div2, P.bit_depth_luma, no_p, no_q, bs);
-  }
+  deblock_luma<Pix, DIR>(W, pix_y, stride_y, qp_p, qp_q, sl.beta_offset_div2, sl.tc_offset_div2, P.bit_depth_luma, no_p, no_q, bs);
   if (bs != 2) return;   // chroma edges are filtered where bS is 2 only (8.7.2.5)
   if (P.chroma_format_idc == 3) {
     // 4:4:4: the chroma planes have the luma planes' edges (the 8-sample chroma grid IS the luma grid) and take the chroma filter
@@ -318,18 +361,9 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
       }
     }
   }
-  if (P.chroma_format_idc == 1) {
-    // chroma edges on the 8x8 chroma grid; one 4-sample chroma segment spans 8 luma samples along the edge
-    const int on_grid = DIR == 0 ? ((x & 15) == 0 && (y & 7) == 0) : ((y & 15) == 0 && (x & 7) == 0);
-    if (on_grid) {
-      for (int c = 1; c < 3; c++) {
-        Pix* rec = (Pix*)(A.arena + P.off_rec[c]);
-        const int stride = P.rec_stride[c] / sizeof(Pix);
-        Pix* pix = rec + (size_t)(y >> 1) * stride + (x >> 1);
-        const int off = c == 1 ? sl.pps_cb_qp_offset : sl.pps_cr_qp_offset;
-        deblock_chroma4<Pix, DIR>(pix, stride, qp_p, qp_q, off, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q, false);
-      }
-    }
+  if (c420_grid) {
+    deblock_chroma4<Pix, DIR>(WB, pix_cb, stride_c, qp_p, qp_q, sl.pps_cb_qp_offset, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q, false);
+    deblock_chroma4<Pix, DIR>(WR, pix_cr, stride_c, qp_p, qp_q, sl.pps_cr_qp_offset, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q, false);
   }
 }
 
@@ -428,6 +462,33 @@ __device__ __forceinline__ int sao_stage(const SaoComp<Pix>& S, uint32_t* tile, 
     tile[i] = v;
   }
   return ab;
+}
+// The same in two halves, so that a kernel can request SEVERAL tiles (luma, Cb, Cr) before it waits for any of them: sao_stage_load issues the loads into
+// registers (NL = words per thread), sao_stage_store puts them into LDS.  One memory round trip for all three components instead of one per component
+// (round 6: k_sao_rgb kept 0.06 memory instructions in flight per wave, profiles/r05_wait_breakdown_b512.txt).
+template <typename Pix, int TH, int ROW_WORDS, int NT, int NL>
+__device__ __forceinline__ int sao_stage_load(const SaoComp<Pix>& S, int ox_t, int oy_t, int tid, uint32_t v[NL])
+{
+  constexpr int ES = (int)sizeof(Pix);
+  static_assert(NL * NT >= (TH + 2) * ROW_WORDS, "words per thread");
+  const int xs0 = ox_t + S.crop_xc, ys0 = oy_t + S.crop_yc;
+  int ab = (xs0 - 1) * ES;
+  ab = ab < 0 ? 0 : (ab & ~3);
+#pragma unroll
+  for (int k = 0; k < NL; k++) {
+    const int i = tid + k * NT;
+    const int r = i / ROW_WORDS, wi = i - r * ROW_WORDS;
+    const int ys = ys0 - 1 + r, bo = ab + wi * 4;
+    v[k] = 0;
+    if (i < (TH + 2) * ROW_WORDS && ys >= 0 && ys < S.H && bo < S.rs_bytes) v[k] = *(const uint32_t*)(S.rec + (size_t)ys * S.rs_bytes + bo);
+  }
+  return ab;
+}
+template <int TH, int ROW_WORDS, int NT, int NL>
+__device__ __forceinline__ void sao_stage_store(uint32_t* tile, int tid, const uint32_t v[NL])
+{
+#pragma unroll
+  for (int k = 0; k < NL; k++) { const int i = tid + k * NT; if (i < (TH + 2) * ROW_WORDS) tile[i] = v[k]; }
 }
 // SAO of the (up to) 4 output samples (ox0 .. ox0+3, oy) out of the staged tile (tile row `lr` holds source row oy + crop); returns the
 // number of valid samples (0: outside the output)
@@ -587,13 +648,19 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
 // plugin ABI hands those to libheif — and emits the tile's interleaved RGB24 from registers + LDS.  Against k_sao + k_ycbcr_to_rgb_batch
 // this saves the colour pass's 1.5 B/px re-read of the planes and one launch.  Same arithmetic: colordev::convert_px.
 constexpr int SAO_CW = SAO_TW / 2, SAO_CH = SAO_TH / 2;
+#ifndef HIPDEC_HOST_EMU
+#define SAO_RGB_OCCUPANCY __attribute__((amdgpu_waves_per_eu(7, 8)))   // <= 72 VGPRs: 7 waves per SIMD as before the tiles were requested together
+#else
+#define SAO_RGB_OCCUPANCY
+#endif
 template <bool MAY_KEEP, bool RESTRICTED>
-__global__ __launch_bounds__(256) void k_sao_rgb(FilterArgs A, const colordev::ColorParams* __restrict__ cps)
+__global__ __launch_bounds__(256) SAO_RGB_OCCUPANCY void k_sao_rgb(FilterArgs A, const colordev::ColorParams* __restrict__ cps)
 {
   typedef uint8_t Pix;
   constexpr int ROW_WORDS = ((SAO_TW + 2) + 3) / 4 + 2;
   constexpr int CROW_WORDS = ((SAO_CW + 2) + 3) / 4 + 2;
   __shared__ uint32_t tile[(SAO_TH + 2) * ROW_WORDS];
+  __shared__ uint32_t tile_c[2][(SAO_CH + 2) * CROW_WORDS];
   __shared__ __attribute__((aligned(4))) uint8_t chroma_s[2][SAO_CH][SAO_CW];   // (read back two samples at a time)
   if (*A.status != 0) return;
   const PicParams& P = A.pics[blockIdx.y];
@@ -603,35 +670,39 @@ __global__ __launch_bounds__(256) void k_sao_rgb(FilterArgs A, const colordev::C
   const int ox_t = ((int)blockIdx.x % tiles_x) * SAO_TW, oy_t = ((int)blockIdx.x / tiles_x) * SAO_TH;
   const int tid = threadIdx.x;
   const int tx = (tid & 31) * 4, ty = tid >> 5;
+  const int ctx = (tid & 15) * 4, cty = tid >> 4;
+  const SaoComp<Pix> SB = sao_comp<Pix>(A, P, 1, MAY_KEEP, RESTRICTED), SR = sao_comp<Pix>(A, P, 2, MAY_KEEP, RESTRICTED);
+  // ---- everything the tile needs from global memory is requested first: the SAO parameters of the thread's rows and the three source tiles
+  constexpr int NL_Y = ((SAO_TH + 2) * ROW_WORDS + 255) / 256, NL_C = ((SAO_CH + 2) * CROW_WORDS + 255) / 256;
+  uint32_t spw[SAO_RPT][3], spw_b[3], spw_r[3];
+#pragma unroll
+  for (int rr = 0; rr < SAO_RPT; rr++) sao_params_at(SY, ox_t + tx, oy_t + ty + rr * 8, spw[rr]);
+  sao_params_at(SB, ox_t / 2 + ctx, oy_t / 2 + cty, spw_b);
+  sao_params_at(SR, ox_t / 2 + ctx, oy_t / 2 + cty, spw_r);
+  uint32_t vy[NL_Y], vb[NL_C], vr[NL_C];
+  const int ab = sao_stage_load<Pix, SAO_TH, ROW_WORDS, 256, NL_Y>(SY, ox_t, oy_t, tid, vy);
+  const int ab_b = sao_stage_load<Pix, SAO_CH, CROW_WORDS, 256, NL_C>(SB, ox_t / 2, oy_t / 2, tid, vb);
+  const int ab_r = sao_stage_load<Pix, SAO_CH, CROW_WORDS, 256, NL_C>(SR, ox_t / 2, oy_t / 2, tid, vr);
+  sao_stage_store<SAO_TH, ROW_WORDS, 256, NL_Y>(tile, tid, vy);
+  sao_stage_store<SAO_CH, CROW_WORDS, 256, NL_C>(tile_c[0], tid, vb);
+  sao_stage_store<SAO_CH, CROW_WORDS, 256, NL_C>(tile_c[1], tid, vr);
+  lds_barrier();
   // ---- luma
   Pix yres[SAO_RPT][4];
   int ynpx[SAO_RPT];
-  {
-    uint32_t spw[SAO_RPT][3];
 #pragma unroll
-    for (int rr = 0; rr < SAO_RPT; rr++) sao_params_at(SY, ox_t + tx, oy_t + ty + rr * 8, spw[rr]);
-    const int ab = sao_stage<Pix, SAO_TH, ROW_WORDS, 256>(SY, tile, ox_t, oy_t, tid);
-    lds_barrier();
-#pragma unroll
-    for (int rr = 0; rr < SAO_RPT; rr++) {
-      const int oy = oy_t + ty + rr * 8, ox0 = ox_t + tx;
-      ynpx[rr] = sao_quad<Pix, ROW_WORDS>(SY, tile, ab, ox0, oy, ty + rr * 8 + 1, spw[rr], yres[rr]);
-      if (ynpx[rr]) sao_store(SY, ox0, oy, ynpx[rr], yres[rr]);
-    }
+  for (int rr = 0; rr < SAO_RPT; rr++) {
+    const int oy = oy_t + ty + rr * 8, ox0 = ox_t + tx;
+    ynpx[rr] = sao_quad<Pix, ROW_WORDS>(SY, tile, ab, ox0, oy, ty + rr * 8 + 1, spw[rr], yres[rr]);
+    if (ynpx[rr]) sao_store(SY, ox0, oy, ynpx[rr], yres[rr]);
   }
   // ---- Cb, Cr: 64 x 16 samples each, one row of 4 samples per thread
-  const int ctx = (tid & 15) * 4, cty = tid >> 4;
 #pragma unroll
   for (int c = 1; c < 3; c++) {
-    const SaoComp<Pix> SC = sao_comp<Pix>(A, P, c, MAY_KEEP, RESTRICTED);
-    uint32_t spw[3];
-    sao_params_at(SC, ox_t / 2 + ctx, oy_t / 2 + cty, spw);
-    lds_barrier();                       // the previous component's reads of `tile` are done
-    const int ab = sao_stage<Pix, SAO_CH, CROW_WORDS, 256>(SC, tile, ox_t / 2, oy_t / 2, tid);
-    lds_barrier();
+    const SaoComp<Pix>& SC = c == 1 ? SB : SR;
     Pix res[4];
     const int ox0 = ox_t / 2 + ctx, oy = oy_t / 2 + cty;
-    const int npx = sao_quad<Pix, CROW_WORDS>(SC, tile, ab, ox0, oy, cty + 1, spw, res);
+    const int npx = sao_quad<Pix, CROW_WORDS>(SC, tile_c[c - 1], c == 1 ? ab_b : ab_r, ox0, oy, cty + 1, c == 1 ? spw_b : spw_r, res);
     if (npx) sao_store(SC, ox0, oy, npx, res);
 #pragma unroll
     for (int i = 0; i < 4; i++) chroma_s[c - 1][cty][ctx + i] = i < npx ? res[i] : (Pix)0;

@@ -66,6 +66,7 @@ enum Mode : int {
   M_DSW_SAME,           // 32 x ds_write_b32, all lanes one address
   M_DSW_LANE0,          // 32 x ds_write_b32, lane 0 in range, the others out of range (dropped)
   M_DSR_CHAIN,          // 16 x (ds_read_b32 same address -> wait -> v_and) dependent chain
+  M_SNOP15,             // 32 x s_nop 15
   M_COUNT
 };
 static const char* kNames[M_COUNT] = {
@@ -81,12 +82,12 @@ static const char* kNames[M_COUNT] = {
   "v_pk_sub_u16 v, s, 1 clamp", "mix (v_add v,v,s ; s_add)", "mix (v_add inline ; s_cbranch not taken)", "mix (s_add ; s_cbranch not taken)",
   "mix (V S B)", "v_writelane_b32 v, s, const",
   "LDS-context MPS bin (per bin)", "ds_read_b32 one address x32, one wait", "ds_write_b32 one address x32", "ds_write_b32 lane 0 only (others out of range)",
-  "ds_read_b32 -> wait -> v_and chain (per pair)",
+  "ds_read_b32 -> wait -> v_and chain (per pair)", "s_nop 15",
 };
 static const int kUnits[M_COUNT] = {32, 32, 32, 32, 32, 32, 16, 16, 16, 16, 16, 16, 8, 96, 96, 32, 32, 32, 8, 32,
-                                    32, 32, 32, 32, 32, 96, 80, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 30, 32, 8, 32, 32, 32, 16};         // reported units per body
+                                    32, 32, 32, 32, 32, 96, 80, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 30, 32, 8, 32, 32, 32, 16, 32};         // reported units per body
 static const int kInstrs[M_COUNT] = {32, 32, 32, 32, 32, 32, 32, 48, 16, 32, 32, 32, 8 * 17, 96, 96, 32, 32, 64, 16, 32,
-                                     32, 32, 32, 32, 32, 96, 80, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 30, 32, 8 * 22, 33, 33, 33, 48};  // instructions per body
+                                     32, 32, 32, 32, 32, 96, 80, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 30, 32, 8 * 22, 33, 33, 33, 48, 32};  // instructions per body
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_issue(int iters, uint64_t* out, uint32_t* sink)
@@ -257,6 +258,8 @@ __global__ __launch_bounds__(256) void k_issue(int iters, uint64_t* out, uint32_
     } else if constexpr (MODE == M_DSW_LANE0) {
       uint32_t a = (threadIdx.x & 63) ? 0xfffffff0u : lbase; asm volatile("" : "+v"(a));
       asm volatile(REP32("ds_write_b32 %0, %1\n\t") "s_waitcnt lgkmcnt(0)\n\t" :: "v"(a), "v"(v1) : "memory");
+    } else if constexpr (MODE == M_SNOP15) {
+      asm volatile(REP32("s_nop 15\n\t"));
     } else if constexpr (MODE == M_DSR_CHAIN) {
       uint32_t a = lbase; asm volatile("" : "+v"(a));
       asm volatile(REP16("ds_read_b32 %0, %0\n\ts_waitcnt lgkmcnt(0)\n\tv_and_b32 %0, 0xfc, %0\n\t") : "+v"(a) :: "memory");
