@@ -328,7 +328,7 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
   if (!parse_only) launch_recon(ra, b.wide, ps, b.any_inter);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[3], ps));
   if (int rc = step("recon")) return rc;
-  if (!parse_only) launch_deblock(fa, n, b.max_w, b.max_h, b.wide, ps);
+  if (!parse_only) launch_deblock(fa, n, b.max_w, b.max_h, b.wide, ps, !b.any_inter && !pa.general_chroma);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[4], ps));
   if (int rc = step("deblock")) return rc;
   if (!parse_only) {

@@ -15,6 +15,7 @@
 //            plane.  Algorithmic bytes: 1.5*s in + 1.5*s out per luma pixel.
 // grid.y = picture index of the batch, grid.z = colour component where applicable.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "hevc_device.h"
 #include "kernels.h"
 #include "color_device.h"
@@ -105,8 +106,9 @@ struct EdgeWindow {
 
 // luma edge segment of 4 lines (8.7.2.5.3 decisions, 8.7.2.5.7 filters); pix -> q0 of line 0.  DIR 0: vertical edge (lines are rows), 1: horizontal
 // (W: the segment's window, loaded by the caller together with everything else the segment reads - see k_deblock)
+// deblock_luma_regs filters the window in registers and says whether anything may have changed; deblock_luma stores it as well
 template <typename Pix, int DIR>
-__device__ __forceinline__ void deblock_luma(EdgeWindow<Pix, DIR>& W, Pix* pix, int stride, int qp_p, int qp_q, int beta_off2, int tc_off2, int bit_depth, int no_p, int no_q, int bs = 2)
+__device__ __forceinline__ bool deblock_luma_regs(EdgeWindow<Pix, DIR>& W, int qp_p, int qp_q, int beta_off2, int tc_off2, int bit_depth, int no_p, int no_q, int bs = 2)
 {
   const int qpl = (qp_q + qp_p + 1) >> 1;
   const int beta = c_beta[clip3(0, 51, qpl + (beta_off2 << 1))] * (1 << (bit_depth - 8));
@@ -116,7 +118,7 @@ __device__ __forceinline__ void deblock_luma(EdgeWindow<Pix, DIR>& W, Pix* pix, 
   const int dp0 = iabs(WP(0, 2) - 2 * WP(0, 1) + WP(0, 0)), dp3 = iabs(WP(3, 2) - 2 * WP(3, 1) + WP(3, 0));
   const int dq0 = iabs(WQ(0, 2) - 2 * WQ(0, 1) + WQ(0, 0)), dq3 = iabs(WQ(3, 2) - 2 * WQ(3, 1) + WQ(3, 0));
   const int dpq0 = dp0 + dq0, dpq3 = dp3 + dq3, dp = dp0 + dp3, dq = dq0 + dq3;
-  if (dpq0 + dpq3 >= beta) return;
+  if (dpq0 + dpq3 >= beta) return false;
   const int s0 = (2 * dpq0 < (beta >> 2)) && (iabs(WP(0, 3) - WP(0, 0)) + iabs(WQ(0, 0) - WQ(0, 3)) < (beta >> 3)) &&
                  (iabs(WP(0, 0) - WQ(0, 0)) < ((5 * tc + 1) >> 1));
   const int s3 = (2 * dpq3 < (beta >> 2)) && (iabs(WP(3, 3) - WP(3, 0)) + iabs(WQ(3, 0) - WQ(3, 3)) < (beta >> 3)) &&
@@ -151,7 +153,12 @@ __device__ __forceinline__ void deblock_luma(EdgeWindow<Pix, DIR>& W, Pix* pix, 
   }
 #undef WP
 #undef WQ
-  W.store(pix, stride);
+  return true;
+}
+template <typename Pix, int DIR>
+__device__ __forceinline__ void deblock_luma(EdgeWindow<Pix, DIR>& W, Pix* pix, int stride, int qp_p, int qp_q, int beta_off2, int tc_off2, int bit_depth, int no_p, int no_q, int bs = 2)
+{
+  if (deblock_luma_regs<Pix, DIR>(W, qp_p, qp_q, beta_off2, tc_off2, bit_depth, no_p, no_q, bs)) W.store(pix, stride);
 }
 
 template <typename Pix>
@@ -192,8 +199,7 @@ struct ChromaWindow {
   }
 };
 template <typename Pix, int DIR>
-__device__ __forceinline__ void deblock_chroma4(ChromaWindow<Pix, DIR>& CW, Pix* pix, int stride, int qp_p, int qp_q, int c_qp_pic_offset, int tc_off2, int bit_depth, int no_p, int no_q,
-                                                bool not420)
+__device__ __forceinline__ void deblock_chroma4_regs(ChromaWindow<Pix, DIR>& CW, int qp_p, int qp_q, int c_qp_pic_offset, int tc_off2, int bit_depth, int no_p, int no_q, bool not420)
 {
   constexpr int ES = (int)sizeof(Pix);
   const int qpi = ((qp_q + qp_p + 1) >> 1) + c_qp_pic_offset;
@@ -213,6 +219,14 @@ __device__ __forceinline__ void deblock_chroma4(ChromaWindow<Pix, DIR>& CW, Pix*
     if (!no_p) w[word(k, 1)] = (w[word(k, 1)] & ~(smask << shift(k, 1))) | ((uint32_t)clip3(0, maxv, p0 + delta) << shift(k, 1));
     if (!no_q) w[word(k, 2)] = (w[word(k, 2)] & ~(smask << shift(k, 2))) | ((uint32_t)clip3(0, maxv, q0 - delta) << shift(k, 2));
   }
+}
+template <typename Pix, int DIR>
+__device__ __forceinline__ void deblock_chroma4(ChromaWindow<Pix, DIR>& CW, Pix* pix, int stride, int qp_p, int qp_q, int c_qp_pic_offset, int tc_off2, int bit_depth, int no_p, int no_q,
+                                                bool not420)
+{
+  constexpr int ES = (int)sizeof(Pix);
+  deblock_chroma4_regs<Pix, DIR>(CW, qp_p, qp_q, c_qp_pic_offset, tc_off2, bit_depth, no_p, no_q, not420);
+  const uint32_t* w = CW.w;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     if (DIR == 1 && (r == 0 || r == 3)) continue;     // rows p1 / q1 are never modified
@@ -365,6 +379,174 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
     deblock_chroma4<Pix, DIR>(WB, pix_cb, stride_c, qp_p, qp_q, sl.pps_cb_qp_offset, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q, false);
     deblock_chroma4<Pix, DIR>(WR, pix_cr, stride_c, qp_p, qp_q, sl.pps_cr_qp_offset, sl.tc_offset_div2, P.bit_depth_chroma, no_p, no_q, false);
   }
+}
+
+
+// ---- both edge directions in ONE pass (intra pictures, 4:0:0 / 4:2:0) -----------------------------------------------------------------------
+// The window of a vertical edge segment is [x - 4, x + 4) x 4 rows, that of a horizontal one 4 columns x [y - 4, y + 4), edges sit on the 8-sample
+// grid: the 8 x 8 blocks centred on the grid's crossings - [8j - 4, 8j + 4) x [8k - 4, 8k + 4) - tile the plane, and each holds exactly the two segments
+// of vertical edge 8j that cross it and the two segments of horizontal edge 8k, whose windows lie inside it.  The horizontal edges must see the
+// vertically filtered samples (8.7.2: all vertical edges of the picture first) - of THIS block only, since no other vertical edge touches its
+// columns.  So one thread takes one block: 8 rows x 8 samples into registers, the vertical edge's two segments, then the horizontal edge's two on
+// the result, one store.  Every sample is read once and written once: 3 s B per luma pixel instead of the 6 s of the two-pass form (k_deblock<0>,
+// k_deblock<1>, which stay for P / B pictures - their boundary strength needs the motion field - and for 4:2:2 / 4:4:4 chroma grids).
+// CH = 0: the luma plane.  CH = 1: the Cb and Cr planes of a 4:2:0 picture (one thread filters the block of both; chroma edges lie on the 8-sample
+// CHROMA grid = 16 luma samples, a 4-sample chroma segment takes the flags and QPs of the luma segment at its first row / column, as k_deblock does).
+template <typename Pix, int CH>
+__global__ __launch_bounds__(256) void k_deblock_fused(FilterArgs A)
+{
+  constexpr int ES = (int)sizeof(Pix), RW = 2 * ES;    // dwords per 8-sample row of the block
+  if (*A.status != 0) return;
+  const PicParams& P = A.pics[blockIdx.y];
+  if (CH && P.chroma_format_idc != 1) return;
+  const int Wc = CH ? P.cwidth : P.width, Hc = CH ? P.cheight : P.height;
+  const int nbx = (Wc >> 3) + 1, nby = (Hc >> 3) + 1;                 // grid crossings 0, 8, ... <= W (the first / last blocks are half outside)
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= nbx * nby) return;
+  const int j = tid % nbx, k = tid / nbx;                            // consecutive lanes: consecutive x
+  const int xc = j * 8, yc = k * 8;
+  // what exists of the block: left / right half (columns), upper / lower half (rows)
+  const bool hl = xc > 0, hr = xc < Wc, vu = yc > 0, vd = yc < Hc;
+  // the luma units (4x4) the four segments take their flags and QPs from: Q and P unit of V segment 0 / 1 (upper / lower rows) and H segment 0 / 1
+  // (left / right columns).  Luma: the 2 x 2 units around the crossing.  Chroma: the luma segment at the chroma segment's first row / column.
+  const int cx = CH ? xc >> 1 : xc >> 2, cy = CH ? yc >> 1 : yc >> 2;   // unit right of / below the crossing
+  const int d = CH ? 2 : 1;                                           // a chroma half block is two units
+  const int vq_y[2] = {cy - d, cy}, hq_x[2] = {cx - d, cx};
+  const uint8_t* u_flags = A.arena + P.off_u_flags;
+  const int8_t* u_qp = (const int8_t*)(A.arena + P.off_u_qp);
+  const CtbInfo* ctb_info = (const CtbInfo*)(A.arena + P.off_ctb_info);
+  const SliceParams* slices = (const SliceParams*)(A.arena + P.off_slices);
+  uint8_t fq[4] = {0, 0, 0, 0}, fp[4] = {0, 0, 0, 0};
+  int qq[4] = {0, 0, 0, 0}, qp[4] = {0, 0, 0, 0};
+  uint32_t sidx[4] = {0, 0, 0, 0};
+  const bool seg_on[4] = {hl && hr && vu, hl && hr && vd, vu && vd && hl, vu && vd && hr};   // V0, V1, H0, H1 exist (an edge needs both of its sides)
+#pragma unroll
+  for (int sgm = 0; sgm < 4; sgm++) {
+    if (!seg_on[sgm]) continue;
+    const int qx = sgm < 2 ? cx : hq_x[sgm - 2], qy = sgm < 2 ? vq_y[sgm] : cy;
+    const int px = sgm < 2 ? cx - 1 : qx, py = sgm < 2 ? qy : cy - 1;
+    int ctb_q, ctb_p;
+    const size_t iq = unit_index(P, qx, qy, &ctb_q), ip = unit_index(P, px, py, &ctb_p);
+    fq[sgm] = u_flags[iq]; fp[sgm] = u_flags[ip]; qq[sgm] = u_qp[iq]; qp[sgm] = u_qp[ip];
+    sidx[sgm] = ctb_info[ctb_q].slice_idx;
+  }
+  // the slice parameters of slice 0 (most pictures have one slice) travel with the first round of loads; other slices are read when they turn up
+  const int s0_beta = slices[0].beta_offset_div2, s0_tc = slices[0].tc_offset_div2, s0_cb = slices[0].pps_cb_qp_offset, s0_cr = slices[0].pps_cr_qp_offset;
+  // ---- the block(s): row r = picture row yc - 4 + r, dwords [0, ES) the left half, [ES, 2 ES) the right half
+  constexpr int NP = CH ? 2 : 1;
+  uint32_t w[NP][8][RW];
+  Pix* base[NP];
+  int stride;
+  {
+    stride = (int)(P.rec_stride[CH ? 1 : 0] / sizeof(Pix));
+#pragma unroll
+    for (int pl = 0; pl < NP; pl++) {
+      base[pl] = (Pix*)(A.arena + P.off_rec[CH ? 1 + pl : 0]) + (ptrdiff_t)(yc - 4) * stride + (xc - 4);
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const bool row_on = r < 4 ? vu : vd;
+        const uint32_t* src = (const uint32_t*)(base[pl] + (ptrdiff_t)r * stride);
+#pragma unroll
+        for (int i = 0; i < RW; i++) {
+          w[pl][r][i] = 0;
+          if (row_on && (i < ES ? hl : hr)) w[pl][r][i] = src[i];
+        }
+      }
+    }
+  }
+  const int keep = UF_BYPASS | (P.pcm_loop_filter_disabled ? UF_PCM : 0);   // 8.7.2.5.7: such units stay as they are
+  const int bd = CH ? P.bit_depth_chroma : P.bit_depth_luma;
+  bool dirty = false;
+  // ---- vertical edge xc: segments of rows 0..3 and 4..7
+#pragma unroll
+  for (int sgm = 0; sgm < 2; sgm++) {
+    if (!seg_on[sgm] || !(fq[sgm] & UF_VEDGE)) continue;
+    int beta = s0_beta, tc = s0_tc, ocb = s0_cb, ocr = s0_cr;
+    if (sidx[sgm] != 0) { const SliceParams& sl = slices[sidx[sgm]]; beta = sl.beta_offset_div2; tc = sl.tc_offset_div2; ocb = sl.pps_cb_qp_offset; ocr = sl.pps_cr_qp_offset; }
+    const int no_q = (fq[sgm] & keep) != 0, no_p = (fp[sgm] & keep) != 0;
+    if (!CH) {
+      EdgeWindow<Pix, 0> W;
+#pragma unroll
+      for (int l = 0; l < 4; l++)
+#pragma unroll
+        for (int i = 0; i < RW; i++) W.w[RW * l + i] = w[0][4 * sgm + l][i];
+      if (deblock_luma_regs<Pix, 0>(W, qp[sgm], qq[sgm], beta, tc, bd, no_p, no_q)) {
+        dirty = true;
+#pragma unroll
+        for (int l = 0; l < 4; l++)
+#pragma unroll
+          for (int i = 0; i < RW; i++) w[0][4 * sgm + l][i] = W.w[RW * l + i];
+      }
+    } else {
+      // the chroma window of a vertical edge: samples xc - 2 .. xc + 1 of 4 rows = the upper half word of the left dword(s) and the lower of the right
+#pragma unroll
+      for (int pl = 0; pl < 2; pl++) {
+        ChromaWindow<Pix, 0> CW;
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+          if (ES == 1) CW.w[l] = (w[pl][4 * sgm + l][0] >> 16) | (w[pl][4 * sgm + l][1] << 16);
+          else { CW.w[2 * l] = w[pl][4 * sgm + l][1]; CW.w[2 * l + 1] = w[pl][4 * sgm + l][2]; }
+        }
+        deblock_chroma4_regs<Pix, 0>(CW, qp[sgm], qq[sgm], pl ? ocr : ocb, tc, bd, no_p, no_q, false);
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+          if (ES == 1) {
+            w[pl][4 * sgm + l][0] = (w[pl][4 * sgm + l][0] & 0xffffu) | (CW.w[l] << 16);
+            w[pl][4 * sgm + l][1] = (w[pl][4 * sgm + l][1] & 0xffff0000u) | (CW.w[l] >> 16);
+          } else { w[pl][4 * sgm + l][1] = CW.w[2 * l]; w[pl][4 * sgm + l][2] = CW.w[2 * l + 1]; }
+        }
+      }
+      dirty = true;
+    }
+  }
+  // ---- horizontal edge yc: segments of columns 0..3 and 4..7, on the vertically filtered block
+#pragma unroll
+  for (int sgm = 0; sgm < 2; sgm++) {
+    if (!seg_on[2 + sgm] || !(fq[2 + sgm] & UF_HEDGE)) continue;
+    int beta = s0_beta, tc = s0_tc, ocb = s0_cb, ocr = s0_cr;
+    if (sidx[2 + sgm] != 0) { const SliceParams& sl = slices[sidx[2 + sgm]]; beta = sl.beta_offset_div2; tc = sl.tc_offset_div2; ocb = sl.pps_cb_qp_offset; ocr = sl.pps_cr_qp_offset; }
+    const int no_q = (fq[2 + sgm] & keep) != 0, no_p = (fp[2 + sgm] & keep) != 0;
+    if (!CH) {
+      EdgeWindow<Pix, 1> W;
+#pragma unroll
+      for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int i = 0; i < ES; i++) W.w[ES * r + i] = w[0][r][ES * sgm + i];
+      if (deblock_luma_regs<Pix, 1>(W, qp[2 + sgm], qq[2 + sgm], beta, tc, bd, no_p, no_q)) {
+        dirty = true;
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+          for (int i = 0; i < ES; i++) w[0][r][ES * sgm + i] = W.w[ES * r + i];
+      }
+    } else {
+#pragma unroll
+      for (int pl = 0; pl < 2; pl++) {
+        ChromaWindow<Pix, 1> CW;   // picture rows yc - 2 .. yc + 1 = block rows 2 .. 5, the segment's 4 columns
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int i = 0; i < ES; i++) CW.w[ES * r + i] = w[pl][2 + r][ES * sgm + i];
+        deblock_chroma4_regs<Pix, 1>(CW, qp[2 + sgm], qq[2 + sgm], pl ? ocr : ocb, tc, bd, no_p, no_q, false);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+          for (int i = 0; i < ES; i++) w[pl][2 + r][ES * sgm + i] = CW.w[ES * r + i];
+      }
+      dirty = true;
+    }
+  }
+  if (!dirty) return;
+  // ---- store (rows / halves that exist; the outermost luma rows and columns of a block are never modified but travel with their dword)
+#pragma unroll
+  for (int pl = 0; pl < NP; pl++)
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const bool row_on = r < 4 ? vu : vd;
+      uint32_t* dst = (uint32_t*)(base[pl] + (ptrdiff_t)r * stride);
+#pragma unroll
+      for (int i = 0; i < RW; i++) if (row_on && (i < ES ? hl : hr)) dst[i] = w[pl][r][i];
+    }
 }
 
 // SAO + conformance crop.  One 256-thread workgroup per 128x16 tile of OUTPUT samples of one component (blockIdx.z) of one
@@ -746,8 +928,21 @@ __global__ __launch_bounds__(256) SAO_RGB_OCCUPANCY void k_sao_rgb(FilterArgs A,
   }
 }
 
-void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s)
+void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s, bool one_pass)
 {
+  static const bool two_pass_forced = getenv("HIPDEC_DEBLOCK_TWO_PASS") != nullptr;   // A/B knob
+  if (one_pass && !two_pass_forced) {
+    // intra pictures with 4:0:0 / 4:2:0 sampling only: both edge directions in one pass over each plane (k_deblock_fused)
+    const int blocks_y = ((max_w >> 3) + 1) * ((max_h >> 3) + 1), blocks_c = ((max_w >> 4) + 1) * ((max_h >> 4) + 1);
+    if (wide) {
+      hipLaunchKernelGGL((k_deblock_fused<uint16_t, 0>), dim3((blocks_y + 255) / 256, n_pics), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_deblock_fused<uint16_t, 1>), dim3((blocks_c + 255) / 256, n_pics), dim3(256), 0, s, a);
+    } else {
+      hipLaunchKernelGGL((k_deblock_fused<uint8_t, 0>), dim3((blocks_y + 255) / 256, n_pics), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_deblock_fused<uint8_t, 1>), dim3((blocks_c + 255) / 256, n_pics), dim3(256), 0, s, a);
+    }
+    return;
+  }
   const int uw = (max_w + 3) / 4, uh = (max_h + 3) / 4;
   const int work_v = ((max_w + 7) / 8) * uh, work_h = ((max_h + 7) / 8) * uw;
   if (wide) {

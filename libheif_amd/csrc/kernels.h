@@ -50,7 +50,8 @@ inline bool inter_residual_in_mc() { static const bool per_block = getenv("HIPDE
 void launch_parse_general(const ParseArgs& a, bool throughput, hipStream_t s);   // parse_kernel_general.hip: batches with 4:2:2 / 4:4:4 pictures
 void launch_residual(const FilterArgs& a, int n_pics, int max_ctbs, bool general_chroma /* the batch holds 4:2:2 / 4:4:4 pictures */, hipStream_t s);
 void launch_recon(const ReconArgs& a, bool wide, hipStream_t s, bool inter = false /* the batch holds P pictures */);
-void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s);
+// one_pass: the batch holds intra pictures with 4:0:0 / 4:2:0 sampling only - both edge directions in one pass (k_deblock_fused)
+void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s, bool one_pass = false);
 // may_keep = false: no picture of the batch has lossless CUs or unfiltered PCM units (8.7.3 "samples stay as they are"): the kernel variant without those paths
 // restricted = false: every picture has PicParams::sao_free_neighbours (no slice / tile boundary restricts the edge-offset neighbours)
 void launch_sao(const FilterArgs& a, int n_pics, int max_out_w, int max_out_h, bool wide, hipStream_t s, bool may_keep = true, bool restricted = true);

@@ -35,7 +35,7 @@ int emu_run_pipeline_rgb(EmuBatch* b, int stages, uint8_t* rgb)
     ra.inter_from_plane = inter_residual_in_mc() ? 1u : 0u;
   }
   if (stages & 2) launch_recon(ra, L.wide, nullptr, L.any_inter);
-  if (stages & 4) launch_deblock(fa, n, L.max_w, L.max_h, L.wide, nullptr);
+  if (stages & 4) launch_deblock(fa, n, L.max_w, L.max_h, L.wide, nullptr, !L.any_inter && !general);   // (as decoder.hip:launch_all)
   bool may_keep = false, restricted = false;   // as decoder.hip:launch_all picks the kernel variant
   for (const PicParams& P : L.params) {
     if (P.transquant_bypass_enabled || (P.pcm_enabled && P.pcm_loop_filter_disabled)) may_keep = true;
