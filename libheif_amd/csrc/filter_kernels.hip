@@ -434,6 +434,8 @@ __global__ __launch_bounds__(256) void k_deblock_fused(FilterArgs A)
   const int s0_beta = slices[0].beta_offset_div2, s0_tc = slices[0].tc_offset_div2, s0_cb = slices[0].pps_cb_qp_offset, s0_cr = slices[0].pps_cr_qp_offset;
   // ---- the block(s): row r = picture row yc - 4 + r, dwords [0, ES) the left half, [ES, 2 ES) the right half
   constexpr int NP = CH ? 2 : 1;
+  struct __attribute__((packed, aligned(4))) RowT { uint32_t d[RW]; };   // a block row: 8 samples at a 4-sample-aligned address
+  const bool interior = hl && hr && vu && vd;
   uint32_t w[NP][8][RW];
   Pix* base[NP];
   int stride;
@@ -442,14 +444,23 @@ __global__ __launch_bounds__(256) void k_deblock_fused(FilterArgs A)
 #pragma unroll
     for (int pl = 0; pl < NP; pl++) {
       base[pl] = (Pix*)(A.arena + P.off_rec[CH ? 1 + pl : 0]) + (ptrdiff_t)(yc - 4) * stride + (xc - 4);
+      if (interior) {   // all of the block exists (everywhere but at the picture's borders): whole rows, no per-dword predicates
 #pragma unroll
-      for (int r = 0; r < 8; r++) {
-        const bool row_on = r < 4 ? vu : vd;
-        const uint32_t* src = (const uint32_t*)(base[pl] + (ptrdiff_t)r * stride);
+        for (int r = 0; r < 8; r++) {
+          const RowT row = *(const RowT*)(base[pl] + (ptrdiff_t)r * stride);
 #pragma unroll
-        for (int i = 0; i < RW; i++) {
-          w[pl][r][i] = 0;
-          if (row_on && (i < ES ? hl : hr)) w[pl][r][i] = src[i];
+          for (int i = 0; i < RW; i++) w[pl][r][i] = row.d[i];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          const bool row_on = r < 4 ? vu : vd;
+          const uint32_t* src = (const uint32_t*)(base[pl] + (ptrdiff_t)r * stride);
+#pragma unroll
+          for (int i = 0; i < RW; i++) {
+            w[pl][r][i] = 0;
+            if (row_on && (i < ES ? hl : hr)) w[pl][r][i] = src[i];
+          }
         }
       }
     }
@@ -539,14 +550,25 @@ __global__ __launch_bounds__(256) void k_deblock_fused(FilterArgs A)
   if (!dirty) return;
   // ---- store (rows / halves that exist; the outermost luma rows and columns of a block are never modified but travel with their dword)
 #pragma unroll
-  for (int pl = 0; pl < NP; pl++)
+  for (int pl = 0; pl < NP; pl++) {
+    if (interior) {
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-      const bool row_on = r < 4 ? vu : vd;
-      uint32_t* dst = (uint32_t*)(base[pl] + (ptrdiff_t)r * stride);
+      for (int r = 0; r < 8; r++) {
+        RowT row;
 #pragma unroll
-      for (int i = 0; i < RW; i++) if (row_on && (i < ES ? hl : hr)) dst[i] = w[pl][r][i];
+        for (int i = 0; i < RW; i++) row.d[i] = w[pl][r][i];
+        *(RowT*)(base[pl] + (ptrdiff_t)r * stride) = row;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const bool row_on = r < 4 ? vu : vd;
+        uint32_t* dst = (uint32_t*)(base[pl] + (ptrdiff_t)r * stride);
+#pragma unroll
+        for (int i = 0; i < RW; i++) if (row_on && (i < ES ? hl : hr)) dst[i] = w[pl][r][i];
+      }
     }
+  }
 }
 
 // SAO + conformance crop.  One 256-thread workgroup per 128x16 tile of OUTPUT samples of one component (blockIdx.z) of one
