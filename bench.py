@@ -854,7 +854,15 @@ def main():
     if rank == 0 and not a.only_main and not a.no_dropin and not a.no_extras and world == 1 and not grid and a.workload == "still4k":
         try:
             from tools import dropin_throughput
-            out["dropin_through_libheif"] = dropin_throughput.measure((256, 1024), n_files=64, seconds=4.0, qp=a.qp)
+            # the thread counts the reference itself runs at (4 decoding threads per context, libheif/context.h:72; tests/test-race.go: 100) beside the
+            # counts the coalescer needs for throughput; per call: mean and p95 wall time of heif_decode_image()
+            d = dropin_throughput.measure((1, 8, 32, 64, 256, 1024), n_files=64, seconds=3.0, qp=a.qp)
+            try:   # ... and to interleaved RGB24 through the patched libheif (HIP colour op, libheif_amd/integration) where oracle/_ref holds one
+                if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libheif_hipcolor.so")):
+                    d["rgb24_through_patched_libheif"] = dropin_throughput.measure((64, 256), n_files=64, seconds=3.0, qp=a.qp, rgb=True, libheif="libheif_hipcolor.so")["runs"]
+            except Exception as e:
+                d["rgb24_through_patched_libheif"] = {"error": repr(e)[:300]}
+            out["dropin_through_libheif"] = d
         except Exception as e:   # the reference build is test infrastructure: its absence must not fail the bench
             out["dropin_through_libheif"] = {"error": repr(e)[:300]}
 

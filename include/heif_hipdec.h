@@ -154,6 +154,10 @@ HIPDEC_API int hipdec_decoder_read_plane_tracked(hipdec_decoder* dec, int c, voi
  * An entry serves one conversion.  The plugin switches tracking on when the hosting libheif registers the HIP colour op
  * (INTEGRATION.md §4); the first hipdec_color_convert() call switches it on as well. */
 HIPDEC_API void hipdec_set_plane_tracking(int on);
+/* on = 2: for a host that ANNOUNCES every in-place edit of a handed-over plane with hipdec_forget_plane() before the colour conversion (the patched
+ * libheif of libheif_amd/integration: image_item.cc:958-1004 mirror_inplace is its only one, and only as the fall-back of the device transform).  The
+ * identity check then reads every 16th row instead of every byte (round 5: 38 ms of hashing per heif_decode_image() call under 256 threads). */
+HIPDEC_API void hipdec_forget_plane(const void* host_plane);
 /* drops every remembered (host pointer -> device copy) pair and with them the decode arenas they keep alive; hipdec_shutdown() and the
  * plugin's deinit_plugin() call it */
 HIPDEC_API void hipdec_forget_resident_planes(void);

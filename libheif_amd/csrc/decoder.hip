@@ -1709,7 +1709,8 @@ struct ResidentPlane {
   const void* host = nullptr;      // where hipdec_decoder_read_plane_tracked() copied the plane
   size_t host_stride = 0;
   int w = 0, h = 0, bits = 0;
-  uint64_t sample = 0;             // hash of EVERY byte of the host copy at hand-over time (plane_hash)
+  uint64_t sample = 0;             // hash of the host copy at hand-over time: EVERY byte (plane_hash), or - mode 2 - every 16th row
+  int mode = 1;                    // the tracking mode the hash was taken in
   std::shared_ptr<hipdec_batch> batch;   // a decoder's output plane: (batch, item, comp) ...
   int item = 0, comp = 0;
   std::shared_ptr<void> buffer;           // ... or a plane of a device buffer this entry keeps alive (transform result, grid canvas)
@@ -1755,13 +1756,25 @@ uint64_t plane_hash(const uint8_t* p, size_t stride, int w_bytes, int h)
   return x;
 }
 
+// The identity of tracking mode 2 (the host announces in-place edits through hipdec_forget_plane - the patched libheif of libheif_amd/integration
+// does, its only in-place edit between hand-over and conversion being the mirror fall-back): the first and the last row and every 16th one.  Round 5
+// measured the full hash at 38 ms per heif_decode_image() call under 256 threads (it reads 12 MB per 4K image twice, hand-over and conversion).
+uint64_t plane_hash_mode(const uint8_t* p, size_t stride, int w_bytes, int h, int mode)
+{
+  if (mode != 2 || h <= 32) return plane_hash(p, stride, w_bytes, h);
+  uint64_t x = plane_hash(p, stride * 16, w_bytes, (h + 15) / 16);
+  return x ^ (plane_hash(p + (size_t)(h - 1) * stride, stride, w_bytes, 1) * 0x9E3779B185EBCA87ull);
+}
+
 // Tracking costs a pass over every decoded plane, so it only runs once a colour conversion has actually arrived at this library (the
 // stock libheif never calls hipdec_color_convert: no hashing there); an entry serves ONE conversion and is dropped.  What the registry
 // pins is bounded in TIME: libheif converts a decoded image within milliseconds of receiving its planes (same thread, same call), so an entry
 // older than kResidentTtlMs (3 s) is stale - the host kept the planes without converting them - and goes at the next insert.  (Rounds 2 - 3 bounded it
 // to 6 entries: with hundreds of application threads between read_plane and conversion the entries evicted each other and every conversion
 // uploaded its planes again from pageable memory - 0.4 - 1.0 Gpixel/s of RGB through libheif where the planes alone ran at 3.)
-std::atomic<bool> g_track_planes{getenv("HIPDEC_TRACK_PLANES") ? atoi(getenv("HIPDEC_TRACK_PLANES")) != 0 : false};
+// 0 off; 1 on, identity = a hash over every byte; 2 on for a host that ANNOUNCES its in-place edits (hipdec_forget_plane): identity = a hash over
+// every 16th row - the safety net behind the announcements, not the identity itself
+std::atomic<int> g_track_planes{getenv("HIPDEC_TRACK_PLANES") ? atoi(getenv("HIPDEC_TRACK_PLANES")) : 0};
 const long kResidentTtlMs = getenv("HIPDEC_RESIDENT_TTL_MS") ? atol(getenv("HIPDEC_RESIDENT_TTL_MS")) : 3000;
 constexpr size_t kMaxResident = 16384;
 
@@ -1841,7 +1854,8 @@ void resident_note(hipdec_decoder* d, int c, const void* host, size_t stride)
   r.host = host; r.host_stride = stride;
   r.w = c ? P.out_cwidth : P.out_width; r.h = c ? P.out_cheight : P.out_height;
   r.bits = c ? P.bit_depth_chroma : P.bit_depth_luma;
-  r.sample = plane_hash((const uint8_t*)host, stride, r.w * (pb->wide ? 2 : 1), r.h);
+  r.mode = g_track_planes.load(std::memory_order_relaxed);
+  r.sample = plane_hash_mode((const uint8_t*)host, stride, r.w * (pb->wide ? 2 : 1), r.h, r.mode);
   r.batch = d->out.batch ? d->out.batch : d->batch; r.item = pitem; r.comp = c;
   resident_insert(std::move(r));
 }
@@ -1925,7 +1939,8 @@ void resident_note_buffer(const void* host, size_t stride, int w, int h, int bit
   if (!g_track_planes.load(std::memory_order_relaxed)) return;
   ResidentPlane r;
   r.host = host; r.host_stride = stride; r.w = w; r.h = h; r.bits = bits;
-  r.sample = plane_hash((const uint8_t*)host, stride, w * (bits > 8 ? 2 : 1), h);
+  r.mode = g_track_planes.load(std::memory_order_relaxed);
+  r.sample = plane_hash_mode((const uint8_t*)host, stride, w * (bits > 8 ? 2 : 1), h, r.mode);
   r.buffer = std::move(buffer); r.dev = dev; r.dev_stride = dev_stride;
   (void)hipGetDevice(&r.device);
   resident_insert(std::move(r));
@@ -1937,7 +1952,7 @@ bool resident_find(const void* host, size_t stride, int w, int h, int bits, cons
                    hipdec_batch** from_batch = nullptr, int* from_item = nullptr)
 {
   if (from_batch) *from_batch = nullptr;
-  g_track_planes.store(true, std::memory_order_relaxed);
+  if (!g_track_planes.load(std::memory_order_relaxed)) g_track_planes.store(1, std::memory_order_relaxed);
   ResidentPlane r;
   {
     std::vector<ResidentPlane> dropped;
@@ -1952,7 +1967,7 @@ bool resident_find(const void* host, size_t stride, int w, int h, int bits, cons
   }
   if (r.host_stride != stride || r.w != w || r.h != h || r.bits != bits) return false;
   if (r.batch && (r.batch->retired || !r.batch->arena)) return false;
-  if (plane_hash((const uint8_t*)host, stride, w * (bits > 8 ? 2 : 1), h) != r.sample) return false;
+  if (plane_hash_mode((const uint8_t*)host, stride, w * (bits > 8 ? 2 : 1), h, r.mode) != r.sample) return false;
   if (!r.batch) {
     int cur = 0;
     (void)hipGetDevice(&cur);
@@ -1972,7 +1987,19 @@ bool resident_find(const void* host, size_t stride, int w, int h, int bits, cons
 
 extern "C" {
 
-void hipdec_set_plane_tracking(int on) { g_track_planes.store(on != 0, std::memory_order_relaxed); }
+void hipdec_set_plane_tracking(int on) { g_track_planes.store(on < 0 ? 0 : (on > 2 ? 2 : on), std::memory_order_relaxed); }
+
+// the host is about to edit (or has freed) the plane at `host_plane`: its device copy must not serve a later conversion
+void hipdec_forget_plane(const void* host_plane)
+{
+  ResidentPlane r;   // (dies outside the lock: an entry may own a batch)
+  std::lock_guard<std::mutex> lock(g_res_mu);
+  auto it = g_resident.find(host_plane);
+  if (it == g_resident.end()) return;
+  resident_account(it->second, -1);
+  r = std::move(it->second);
+  g_resident.erase(it);
+}
 
 void hipdec_forget_resident_planes(void)
 {

@@ -106,16 +106,23 @@ struct ImageOpsBackend {
   int (*grid_read_plane_tracked)(hipdec_grid*, int, void*, size_t);
   const char* (*last_error)(void);
   const char* decoder_id;
+  void (*forget_plane)(const void*);   // version 2: the host announces an in-place edit of a plane the decoder handed over
 };
 const char kPluginId[] = "hipdec";
 void announce_image_ops_backend()
 {
   using reg_fn = void (*)(const ImageOpsBackend*, int);
   if (auto reg = (reg_fn)dlsym(RTLD_DEFAULT, "heif_image_ops_register_hip_backend")) {
-    static const ImageOpsBackend table = {1, hipdec_image_transform, hipdec_grid_create, hipdec_grid_free, hipdec_grid_info, hipdec_grid_decode,
-                                          hipdec_grid_wait, hipdec_grid_read_plane_tracked, hipdec_last_error, kPluginId};
-    reg(&table, hipdec_device_count() > 0 ? 1 : 0);
-    hipdec_set_plane_tracking(1);
+    // a host whose hooks announce their in-place edits (heif_image_ops_hip_capabilities() bit 0) gets table version 2 and the cheap plane identity
+    using cap_fn = int (*)(void);
+    const auto caps = (cap_fn)dlsym(RTLD_DEFAULT, "heif_image_ops_hip_capabilities");
+    const bool announces = caps && (caps() & 1) && !getenv("HIPDEC_PLANE_IDENTITY_FULL");   // (A/B knob: the full hash although the host announces)
+    static const ImageOpsBackend table1 = {1, hipdec_image_transform, hipdec_grid_create, hipdec_grid_free, hipdec_grid_info, hipdec_grid_decode,
+                                           hipdec_grid_wait, hipdec_grid_read_plane_tracked, hipdec_last_error, kPluginId, nullptr};
+    static const ImageOpsBackend table2 = {2, hipdec_image_transform, hipdec_grid_create, hipdec_grid_free, hipdec_grid_info, hipdec_grid_decode,
+                                           hipdec_grid_wait, hipdec_grid_read_plane_tracked, hipdec_last_error, kPluginId, hipdec_forget_plane};
+    reg(announces ? &table2 : &table1, hipdec_device_count() > 0 ? 1 : 0);
+    hipdec_set_plane_tracking(announces ? 2 : 1);
     hipdec_set_reserved_wave_slots(1);
   }
 }

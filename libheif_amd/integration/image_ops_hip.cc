@@ -42,7 +42,7 @@ enum { XF_ROTATE_CCW = 0, XF_MIRROR = 1, XF_CROP = 2 };
 extern "C" {
 // the table libheifhip.so fills in (csrc/plugin.hip: announce_image_ops_backend)
 struct heif_hip_image_ops_backend {
-  int version;   // 1
+  int version;   // 1, or 2: forget_plane follows decoder_id
   int (*image_transform)(const void* in, int op, const int* args, void* out);
   int (*grid_create)(void** out, int rows, int cols, int out_width, int out_height, const void* const* tile_data, const size_t* tile_sizes,
                      const int* devices, int n_devices, uint64_t max_image_size_pixels);
@@ -53,6 +53,7 @@ struct heif_hip_image_ops_backend {
   int (*grid_read_plane_tracked)(void* g, int c, void* dst_host, size_t dst_stride);
   const char* (*last_error)(void);
   const char* decoder_id;   // id_name of the decoder plugin these entry points belong to
+  void (*forget_plane)(const void* host_plane);   // version 2: "this plane is about to be edited in place" (the device copy must not serve the conversion)
 };
 }
 
@@ -164,9 +165,17 @@ extern "C" __attribute__((visibility("default")))
 void heif_image_ops_register_hip_backend(const heif_hip_image_ops_backend* api, int usable)
 {
   std::lock_guard<std::mutex> lock(g_backend_mutex);
-  g_backend = api && api->version == 1 ? *api : heif_hip_image_ops_backend{};
-  g_backend_usable = api && api->version == 1 && usable;
+  g_backend = heif_hip_image_ops_backend{};
+  if (api && api->version == 2) g_backend = *api;
+  else if (api && api->version == 1) { memcpy(&g_backend, api, offsetof(heif_hip_image_ops_backend, forget_plane)); g_backend.forget_plane = nullptr; }
+  g_backend_usable = api && (api->version == 1 || api->version == 2) && usable;
 }
+
+// What these hooks promise the backend.  Bit 0: every in-place edit of a decoded image between the plugin's hand-over and the colour conversion is
+// announced through forget_plane() first (the mirror fall-back below is the only one: rotation and cropping make new images, image_item.cc:958-1004),
+// so the backend may identify a handed-over plane cheaply instead of hashing every byte of it.
+extern "C" __attribute__((visibility("default")))
+int heif_image_ops_hip_capabilities(void) { return 1; }
 
 
 namespace hip_image_ops {
@@ -193,6 +202,15 @@ Result<std::shared_ptr<HeifPixelImage>> mirror(const std::shared_ptr<HeifPixelIm
     const int args[1] = {(int) direction};
     if (auto out = transformed(*img, XF_MIRROR, args, img->get_width(), img->get_height(), limits)) {
       return out;
+    }
+  }
+  // the stock code mirrors IN PLACE (same plane pointers, new content): the backend's device copies of these planes are stale from here on
+  {
+    heif_hip_image_ops_backend api;
+    if (backend(&api) && api.forget_plane) {
+      for (heif_channel ch : {heif_channel_Y, heif_channel_Cb, heif_channel_Cr, heif_channel_Alpha, heif_channel_R, heif_channel_G, heif_channel_B, heif_channel_interleaved}) {
+        if (img->has_channel(ch)) { size_t stride = 0; api.forget_plane(img->get_channel_memory(ch, &stride)); }
+      }
     }
   }
   return img->mirror_inplace(direction, limits);

@@ -5,7 +5,7 @@
  *
  *   gcc -O2 -pthread tools/dropin_host.c -ldl -o build/dropin_host
  *   build/dropin_host <libheif.so> <libheifhip.so> <threads> <seconds> <rgb 0|1> file0.heic file1.heic ...
- * prints: decodes seconds mpixel_s requests launch_sets
+ * prints: decodes seconds mpixel_s requests launch_sets failed mean_ms p95_ms   (the last two: wall time of a heif_decode_image() call inside the measured window)
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -69,6 +69,9 @@ static int decode_direct(const struct file* f, double* px, uint8_t* buf)
 }
 
 static uint64_t decode_us_total, decode_calls_total;   /* time inside heif_decode_image, all threads */
+#define LAT_CAP (1 << 20)
+static uint32_t* lat_us; static uint32_t lat_n; static int lat_on;   /* per-call latencies of the measured window (relaxed atomics) */
+static int cmp_u32(const void* a, const void* b) { const uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b; return x < y ? -1 : x > y; }
 static int decode_one(const struct file* f, double* px)
 {
   void* ctx = ctx_alloc();
@@ -96,8 +99,13 @@ static int decode_one(const struct file* f, double* px)
   if (!e.code) e = primary(ctx, &h);
   const double t0 = now();
   if (!e.code) e = decode(h, &img, want_rgb ? 1 /* heif_colorspace_RGB */ : 0 /* YCbCr */, want_rgb ? 10 /* interleaved RGB */ : 1 /* 4:2:0 */, NULL);
-  __atomic_fetch_add(&decode_us_total, (uint64_t)((now() - t0) * 1e6), __ATOMIC_RELAXED);
+  const uint64_t us = (uint64_t)((now() - t0) * 1e6);
+  __atomic_fetch_add(&decode_us_total, us, __ATOMIC_RELAXED);
   __atomic_fetch_add(&decode_calls_total, 1, __ATOMIC_RELAXED);
+  if (__atomic_load_n(&lat_on, __ATOMIC_RELAXED) && lat_us) {
+    const uint32_t k = __atomic_fetch_add(&lat_n, 1, __ATOMIC_RELAXED);
+    if (k < LAT_CAP) lat_us[k] = (uint32_t)us;
+  }
   if (!e.code) add_double(px, (double)handle_w(h) * handle_h(h));
   else if (!tolerate) fprintf(stderr, "decode failed: %d.%d %s\n", e.code, e.subcode, e.message ? e.message : "");
   if (img) image_release(img);
@@ -180,8 +188,11 @@ int main(int argc, char** argv)
   long n0 = 0; double p0 = 0;
   for (int k = 0; k < n_threads; k++) { n0 += ld_long(&ws[k].decodes); p0 += ld_double(&ws[k].px); }
   if (stats) stats(&r0, &s0, &x0);
+  lat_us = (uint32_t*)malloc(sizeof(uint32_t) * LAT_CAP);
+  __atomic_store_n(&lat_on, 1, __ATOMIC_RELAXED);
   const double t0 = now();
   usleep((useconds_t)(seconds * 1e6));
+  __atomic_store_n(&lat_on, 0, __ATOMIC_RELAXED);
   long n = 0; double px = 0; int failed = 0;
   for (int k = 0; k < n_threads; k++) { n += ld_long(&ws[k].decodes); px += ld_double(&ws[k].px); }
   const double dt = now() - t0;
@@ -192,6 +203,17 @@ int main(int argc, char** argv)
   if (decode_calls_total) fprintf(stderr, "[dropin_host] %d threads: heif_decode_image took %.1f ms on average over %llu calls\n", n_threads,
                                   decode_us_total / 1e3 / decode_calls_total, (unsigned long long)decode_calls_total);
   if (tolerate) fprintf(stderr, "[dropin_host] %ld decodes reported an error and were tolerated\n", tolerated);
-  printf("%ld %.3f %.1f %llu %llu %d\n", n, dt, px / dt / 1e6, (unsigned long long)(r1 - r0), (unsigned long long)(s1 - s0), failed);
+  double mean_ms = 0, p95_ms = 0;
+  {
+    uint32_t m = __atomic_load_n(&lat_n, __ATOMIC_RELAXED);
+    if (m > LAT_CAP) m = LAT_CAP;
+    if (m && lat_us) {
+      qsort(lat_us, m, sizeof(uint32_t), cmp_u32);
+      double sum = 0;
+      for (uint32_t i = 0; i < m; i++) sum += lat_us[i];
+      mean_ms = sum / m / 1e3; p95_ms = lat_us[(uint32_t)((m - 1) * 0.95)] / 1e3;
+    }
+  }
+  printf("%ld %.3f %.1f %llu %llu %d %.2f %.2f\n", n, dt, px / dt / 1e6, (unsigned long long)(r1 - r0), (unsigned long long)(s1 - s0), failed, mean_ms, p95_ms);
   return failed;
 }

@@ -50,9 +50,9 @@ def measure(threads_list=(64, 256), n_files=64, seconds=6.0, w=3840, h=2160, qp=
         if r.returncode != 0:
             results.append({"threads": T, "error": (r.stderr or r.stdout)[-400:]})
             continue
-        n, dt, mpx, req, sets, failed = r.stdout.split()[-6:]
+        n, dt, mpx, req, sets, failed, mean_ms, p95_ms = r.stdout.split()[-8:]
         rec = {"threads": T, "decodes": int(n), "seconds": float(dt), "mpixel_s": float(mpx), "decoder_requests": int(req), "launch_sets": int(sets),
-               "stills_per_launch_set": round(int(req) / max(1, int(sets)), 1)}
+               "stills_per_launch_set": round(int(req) / max(1, int(sets)), 1), "call_ms_mean": float(mean_ms), "call_ms_p95": float(p95_ms)}
         results.append(rec)
         if not quiet:
             print(json.dumps(rec), flush=True)

@@ -49,6 +49,8 @@ try:
 except Exception as e: print("$spec: no line", e)
 PY
           done ;;
+    dropin) python tools/dropin_throughput.py --threads ${DROPIN_THREADS:-1,8,32,64,256} --seconds 3 > gpurun_out/${tag}_dropin_planes.txt 2> gpurun_out/${tag}_dropin_planes.err; tail -8 gpurun_out/${tag}_dropin_planes.txt
+            python tools/dropin_throughput.py --threads ${DROPIN_RGB_THREADS:-64,256} --seconds 3 --rgb --libheif libheif_hipcolor.so > gpurun_out/${tag}_dropin_rgb.txt 2> gpurun_out/${tag}_dropin_rgb.err; tail -4 gpurun_out/${tag}_dropin_rgb.txt; grep -h "on average" gpurun_out/${tag}_dropin_*.err | tail -8 ;;
     wait) bash tools/prof_wait_breakdown.sh $tag --batch 512 2>&1 | tail -40 ;;
     *) bash tools/gpu_stage.sh $tag $what ;;
   esac
