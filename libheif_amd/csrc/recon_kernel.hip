@@ -584,6 +584,25 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
     const CtbInfo ci = ctb_info[ctb_rs];
     const int x_ctb = cx << log2_ctb, y_ctb = cy << log2_ctb;   // luma origin of the CTB
     const int xc0 = x_ctb / sub;  // component x of the CTB
+    // ---- a CTB of a P / B picture without a single intra coded unit (the common one): k_mc has left it complete in the plane, nothing is predicted here,
+    //      nothing above it is read - its bottom row goes to the line buffer, its right column becomes the next CTB's left border, done.  (Round 5 walked
+    //      its 256 units marking each available: 25 us per CTB, and the pixel step of a 720p picture is a 42-CTB wavefront of those.)
+    if (INTER && from_plane && x_ctb + ctb <= pic_w && y_ctb + ctb <= pic_h) {
+      const size_t mbase = (size_t)ctb_rs * units;
+      bool all_inter = true;
+      for (int i = lane * 4; i < units; i += 256) all_inter = all_inter && (*(const uint32_t*)(A.arena + P.off_u_ipmc + mbase + i) & 0x40404040u) == 0x40404040u;
+      if (__ballot(!all_inter) == 0) {
+        const int yc0 = y_ctb / suby;
+        uint32_t* dst = line + (size_t)cy * line_words + (size_t)xc0 * ES / 4;
+        const Pix* bottom = rec + (size_t)(yc0 + ctbch - 1) * stride + xc0;
+        for (int i = l; i < wpr; i += LW) __hip_atomic_store(dst + i, *(const uint32_t*)&bottom[i * PPW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = l; i < ctbch; i += LW) left[i] = rec[(size_t)(yc0 + i) * stride + xc0 + ctbc - 1];
+        lds_sync();
+        drain_stores();
+        if (lane == 0) __hip_atomic_store(my_progress, (uint32_t)(cx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+      }
+    }
     // ---- wait for the row above: above-right CTB done (or the row end) ----
     const Pix* top = (const Pix*)(top_raw + 1);
     if (cy > 0) {
