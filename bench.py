@@ -202,35 +202,42 @@ def kernel_table(avg_us, alg, px, colour_stage=True):
     return out
 
 
+# What one gfx950 CU issues per cycle, measured at 8 waves per SIMD (tools/ubench/issue_model.hip, profiles/r06_issue_model_*.txt): the CU-shared scalar
+# pipe 0.92 SALU instructions; the four SIMDs together 1.76 wave64 VALU instructions that touch only VGPRs / inline constants, but 0.90 of those that
+# read or write the scalar register file (an SGPR operand, VCC, v_readlane / v_writelane, every v_cmp and v_cndmask).
+ISSUE_PEAK_SALU, ISSUE_PEAK_VALU_PURE, ISSUE_PEAK_VALU_SFILE = 0.92, 1.76, 0.90
+
+
 def issue_roofline(kernels, px, cu_count, clock_ghz):
-    """The CABAC parser and the intra reconstruction are bound by instruction issue, not by HBM: their yardstick is the
-    CU-shared scalar pipe, one SALU instruction per cycle and CU (the other kernels are listed with the same arithmetic: none of them is near
-    the HBM roofline because all of them sit at 40 - 60 % of one of the issue peaks).  Instructions per luma pixel come from the committed PMC passes
-    (profiles/pmc_issue.json: SQ_INSTS_SALU / _VALU / _BRANCH per kernel, tools/prof_parse_pmc.sh); they are a property of the code and the
-    content, not of the batch size, so the file's figures are applied to this run's pixels and kernel times."""
+    """The CABAC parser and the intra reconstruction are bound by instruction issue and per-wave latency, not by HBM.  Their
+    yardsticks are the CU's issue rates as MEASURED in round 6 (constants above): the scalar pipe, and the vector pipes - whose rate depends on whether
+    an instruction touches the scalar register file, which the PMC counters do not split, so the vector fraction is a RANGE: [all instructions pure,
+    all instructions scalar-file].  (Rounds 2 - 5 priced the vector pipes at 2 per cycle and CU and read k_parse as scalar-bound at 45 % vector
+    utilisation; measured, its 24 VALU per pixel ran at 0.906 per cycle and CU - the scalar-file rate.)  Instructions per luma pixel come from the
+    committed PMC passes (profiles/pmc_issue.json, tools/prof_parse_pmc.sh); they are a property of the code and the content, not of the batch size."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_issue.json")))
     except Exception:
         return None
-    # the clock the chip actually sustains under these kernels (MI355X guide, DVFS: effective clock = GRBM_GUI_ACTIVE / kernel wall time), recorded by
-    # the PMC pass when it collected that counter; else the nominal maximum, which UNDERSTATES the fractions (the guide reports 1.9 - 2.3 GHz under load)
     eff = rec.get("effective_clock_ghz") or {}
     nominal = clock_ghz
     if eff.get("k_parse"):
         clock_ghz = float(eff["k_parse"])
-    peak = cu_count * clock_ghz            # G scalar instructions / s
-    out = {"peak_ginst_s": round(peak, 1), "peak_is": "%d CUs x %.2f GHz x 1 SALU instruction per cycle and CU; the vector pipes take twice that in wave64 "
-                                                   "instructions (4 SIMD-32 units per CU, 2 cycles per wave64 VALU instruction)" % (cu_count, clock_ghz),
-           "clock_ghz": round(clock_ghz, 3), "clock_source": ("GRBM_GUI_ACTIVE / kernel time of k_parse in the PMC pass (profiles/pmc_issue.json)" if eff.get("k_parse")
-                                                               else "nominal maximum clock %.2f GHz: the effective clock under load is lower, so the fractions are lower bounds" % nominal),
+    cyc = cu_count * clock_ghz            # G CU-cycles / s
+    out = {"peaks_per_cycle_and_cu": {"salu": ISSUE_PEAK_SALU, "valu_vgpr_only": ISSUE_PEAK_VALU_PURE, "valu_touching_scalar_file": ISSUE_PEAK_VALU_SFILE},
+           "peaks_source": "tools/ubench/issue_model.hip at 8 waves per SIMD on this chip (profiles/r06_issue_model_a.txt, _b.txt)",
+           "peak_ginst_s": round(cyc * ISSUE_PEAK_SALU, 1), "clock_ghz": round(clock_ghz, 3),
+           "clock_source": ("GRBM_GUI_ACTIVE / kernel time of k_parse in the PMC pass (profiles/pmc_issue.json)" if eff.get("k_parse")
+                            else "nominal maximum clock %.2f GHz: the effective clock under load is lower, so the fractions are lower bounds" % nominal),
            "source": rec.get("source"), "commit": rec.get("commit"), "kernels": {}}
     for key, name in (("parse", "k_parse"), ("recon", "k_recon"), ("residual", "k_residual"), ("deblock", "k_deblock"), ("sao_rgb", "k_sao"), ("sao", "k_sao")):
         if key in kernels and key not in out["kernels"] and name in rec.get("insts_per_px", {}) and kernels[key]["avg_us"] > 0:
             ipp = rec["insts_per_px"][name]
-            ach = ipp["salu"] * px / (kernels[key]["avg_us"] * 1e-6) / 1e9
+            per_s = px / (kernels[key]["avg_us"] * 1e-6) / 1e9      # G pixels / s
+            salu, valu = ipp["salu"] * per_s, ipp["valu"] * per_s
             out["kernels"][key] = {"kernel": kernels[key]["kernel"], "salu_per_px": ipp["salu"], "valu_per_px": ipp["valu"], "branch_per_px": ipp.get("branch"),
-                                   "achieved_ginst_s": round(ach, 1), "frac_of_scalar_issue_peak": round(ach / peak, 4),
-                                   "frac_of_vector_issue_peak": round(ach / peak * ipp["valu"] / ipp["salu"] / 2.0, 4)}
+                                   "lds_per_px": ipp.get("lds"), "achieved_ginst_s": round(salu, 1), "frac_of_scalar_issue_peak": round(salu / (cyc * ISSUE_PEAK_SALU), 4),
+                                   "frac_of_vector_issue_peak_range": [round(valu / (cyc * ISSUE_PEAK_VALU_PURE), 4), round(valu / (cyc * ISSUE_PEAK_VALU_SFILE), 4)]}
     return out
 
 

@@ -852,8 +852,8 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
 // plugin ABI hands those to libheif — and emits the tile's interleaved RGB24 from registers + LDS.  Against k_sao + k_ycbcr_to_rgb_batch
 // this saves the colour pass's 1.5 B/px re-read of the planes and one launch.  Same arithmetic: colordev::convert_px.
 constexpr int SAO_CW = SAO_TW / 2, SAO_CH = SAO_TH / 2;
-#ifndef HIPDEC_HOST_EMU
-#define SAO_RGB_OCCUPANCY __attribute__((amdgpu_waves_per_eu(7, 8)))   // <= 72 VGPRs: 7 waves per SIMD as before the tiles were requested together
+#if !defined(HIPDEC_HOST_EMU) && defined(HIPDEC_SAO_RGB_OCC7)
+#define SAO_RGB_OCCUPANCY __attribute__((amdgpu_waves_per_eu(7, 8)))   // <= 72 VGPRs (measurement build: costs 12 - 40 B of scratch per lane)
 #else
 #define SAO_RGB_OCCUPANCY
 #endif

@@ -59,7 +59,8 @@ def test_issue_roofline_covers_every_kernel_of_the_pmc_record():
     r = bench.issue_roofline(kern, 2048 * 3840 * 2160, 256, 2.4)
     assert set(r["kernels"]) == set(kern)
     for k, v in r["kernels"].items():
-        assert 0 < v["frac_of_scalar_issue_peak"] < 1 and 0 < v["frac_of_vector_issue_peak"] < 1, (k, v)
+        lo, hi = v["frac_of_vector_issue_peak_range"]   # [every VALU instruction VGPR-only, every one touching the scalar register file] (round 6: measured peaks)
+        assert 0 < v["frac_of_scalar_issue_peak"] < 1 and 0 < lo < hi and lo < 1, (k, v)
     assert r["kernels"]["parse"]["frac_of_scalar_issue_peak"] > r["kernels"]["recon"]["frac_of_scalar_issue_peak"] > r["kernels"]["deblock"]["frac_of_scalar_issue_peak"]
 
 

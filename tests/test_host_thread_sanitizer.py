@@ -62,7 +62,7 @@ def test_the_plugin_inside_the_real_libheif_under_thread_sanitizer(build_dir, rg
     assert not ours, ours[0][-6000:]
     last = [l for l in r.stdout.strip().splitlines() if l and l[0].isdigit()]
     assert last, out[-3000:]
-    decodes, _, _, requests, launch_sets, failed = last[-1].split()
+    decodes, _, _, requests, launch_sets, failed = last[-1].split()[:6]   # (+ mean / p95 ms per call since round 6)
     assert int(failed) == 0 and int(decodes) > 0 and int(requests) > 0, out[-3000:]
 
 
