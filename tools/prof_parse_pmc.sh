@@ -47,7 +47,7 @@ if f:
         for k, v in agg.items():
             if short in k:
                 for c, x in v.items(): tot[c] += x
-        if tot: out[short] = {"salu": round(tot["SQ_INSTS_SALU"] / px, 3), "valu": round(tot["SQ_INSTS_VALU"] / px, 3), "branch": round(tot["SQ_INSTS_BRANCH"] / px, 3)}
+        if tot: out[short] = {"salu": round(tot["SQ_INSTS_SALU"] / px, 3), "valu": round(tot["SQ_INSTS_VALU"] / px, 3), "branch": round(tot["SQ_INSTS_BRANCH"] / px, 3), "lds": round(tot["SQ_INSTS_LDS"] / px, 3)}
     try: commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
     except Exception: commit = os.environ.get("HIPDEC_COMMIT", "?")
     # effective clock (MI355X guide, DVFS): GRBM_GUI_ACTIVE of a dispatch / its duration, from the pass that collected it beside the kernel trace
