@@ -6,13 +6,21 @@
 //
 // MI355X mapping: residuals do not depend on prediction, so they are taken off the intra-prediction
 // dependency chain entirely: this kernel runs over ALL transform blocks of the batch in parallel (one
-// 256-thread workgroup per CTB, its four waves take the CTB's coded blocks round-robin) and overwrites each
-// TU-contiguous int16 coefficient block with its int16 residual block; the reconstruction wavefront
-// (recon_kernel.hip) then only adds.  Per block the wave stages the dequantised coefficients in LDS and runs
-// the two 1-D passes as n MACs per output sample against the LDS-resident 32-point matrix, skipping the
-// all-zero high-frequency rows / columns that dominate real content.  Integer butterflies, no MFMA: the
-// largest block is 32x32x32 int16 MACs with 16-bit clipping between the passes (not a dense contraction
-// worth matrix cores).  Traffic: reads and writes 2 B per coded sample (<= 3 B per luma pixel each way).
+// 256-thread workgroup per CTB) and overwrites each TU-contiguous int16 coefficient block with its int16
+// residual block; the reconstruction wavefront (recon_kernel.hip) then only adds.
+//
+// Round 6 form.  The CTB's coded blocks are sorted by size into LDS lists and a wave pass takes 64 / n blocks of
+// size n x n at once (16 4x4, 8 8x8 or 4 16x16 blocks), ONE THREAD PER ROW / COLUMN: a thread loads its row of
+// levels with one or two 16-byte loads (the lanes of a block cover its n * n * 2 contiguous bytes), scales it,
+// hands it through LDS to the thread that owns the column, which runs the column's 1-D inverse transform as
+// an even-odd butterfly in registers (constants are instruction operands: no transform matrix in LDS, no table
+// prologue), hands the clipped intermediate back through LDS by rows and runs the row transform the same way.
+// Per 16x16 block that is ~120 wave instructions (0.47 per sample) where the wave-per-block form of rounds
+// 1 - 5 (n MACs per output sample as v_dot2 chains over LDS operands: two LDS reads per MAC pair, 16 of 64
+// lanes busy in the second pass of an 8x8 block, ~100 instructions of bookkeeping per block) spent 360 (1.4)
+// and 3.2 per sample of an 8x8 block.  32x32 blocks (rare, and 32 + 32 live values per thread would cost the
+// common sizes their occupancy) keep the wave-per-block form below.  Integer butterflies, no MFMA: 16-bit
+// clipping sits between the two passes.  Traffic: reads and writes 2 B per coded sample.
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include "hevc_device.h"
@@ -21,13 +29,7 @@
 namespace hipdec {
 namespace {
 
-// the 33 magnitudes of the 32-point DCT matrix (8.6.4.2: M32[j][i] = +-c[(2 i + 1) j mod 128 folded]) and the 4x4 DST-VII matrix (row-major),
-// behind one another: the table fill of the kernel's prologue reads entry (is DST ? 33 + i : k) with ONE unconditional load per pass, so
-// that the passes' loads are all in flight together (a load in each arm of a branch is waited for where the arms meet)
-__constant__ int8_t r_tab[33 + 16] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64, 61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0,
-                                      29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29};
-// small per-block lookups as packed immediates: a __constant__ array indexed at run time is a global load plus a wait
-// in front of every block
+// small per-block lookups as packed immediates: a __constant__ array indexed at run time is a global load plus a wait in front of every block
 __device__ __forceinline__ int chroma_qp_table(int qpi)   // table 8-10 for ChromaArrayType 1, qPi in [30, 43]
 {
   constexpr uint64_t kT = 0ull | (1ull << 4) | (2ull << 8) | (3ull << 12) | (4ull << 16) | (4ull << 20) | (5ull << 24) | (5ull << 28) |
@@ -44,14 +46,14 @@ __device__ __forceinline__ int chroma_qp(int qpi, bool not420)   // 8.6.1: QpC f
 // `rs` / `ls` are the right / left shift of the block (one of them is 0), `rnd` = rs ? 1 << (rs - 1) : 0.
 __device__ __forceinline__ int scale_level(int level, int f, int rs, int ls, int rnd)
 {
-  const int v = ((level * f + rnd) >> rs) << ls;
+  const int v = ((__mul24(level, f) + rnd) >> rs) << ls;   // |level| < 2^15, f <= 16 * 72
   return v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
 }
 // ... with a scaling list: f = m[x][y] * levelScale <= 255 * 72, level * f < 2^30; the left-shift case (q - b <= 3) is clamped
 // first so that it cannot wrap before the 16-bit clip
 __device__ __forceinline__ int scale_level_sl(int level, int f, int rs, int ls, int rnd)
 {
-  int v = (level * f + rnd) >> rs;
+  int v = (__mul24(level, f) + rnd) >> rs;   // f <= 255 * 72 < 2^15: the product is below 2^30
   v = v < -(1 << 27) ? -(1 << 27) : (v > (1 << 27) ? (1 << 27) : v);
   v <<= ls;
   return v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
@@ -62,23 +64,30 @@ __device__ __forceinline__ int level_scale(int r)         // levelScale[qP % 6] 
   return (int)((kS >> (r * 8)) & 255u);
 }
 
-// Transposed, j-contiguous operands so that both 1-D passes are chains of v_dot2_i32_i16 (two MACs per instruction,
-// one 32-bit LDS read per operand pair).  Rows are padded by 2 samples: consecutive lanes then hit distinct banks.
+// ---- LDS of one workgroup (one CTB) ------------------------------------------------------------------------------------------------------
+// 32x32 blocks (wave-per-block form): transposed, j-contiguous operands so that both 1-D passes are chains of v_dot2_i32_i16 (two MACs per
+// instruction, one 32-bit LDS read per operand pair).  Rows are padded by 2 samples: consecutive lanes then hit distinct banks.
 constexpr int RPAD = 2;
-constexpr int LIST_N = 896;
+// 4x4 / 8x8 / 16x16 blocks (thread-per-row form): a wave's 64 / n blocks of one pass, rows of n int16, the blocks BS bytes apart so that
+// the column accesses of a pass (lane = block * n + column reads / writes ONE int16 of row j, the same j in every lane) fall into distinct
+// banks: a block's n lanes cover n * 2 contiguous bytes = n / 2 banks, and 64 / n blocks at a bank distance of n / 2 fill the 32 banks once
+//   n = 16: BS = 512 + 32 (8 banks per block, 4 blocks), n = 8: 128 + 16 (4 banks, 8 blocks), n = 4: 32 + 8 (2 banks at multiples of 10: all 16 distinct)
+constexpr int kSmallBufBytes = 4 * (512 + 32);
 struct ResLds {
-  alignas(4) int16_t et32[32 * 32], et16[16 * 16], et8[8 * 8], et4[4 * 4], est4[4 * 4];   // E^T[i][j] per size, DST last (filled as ONE array of 1376 entries)
-  alignas(4) int16_t blk[4][32 * (32 + RPAD)];   // per wave: scaled levels, TRANSPOSED: blk[x][j] = d[j][x]
-  alignas(4) int16_t tmp[4][32 * (32 + RPAD)];   // per wave: first-stage output tmp[y][j]
+  union {
+    struct { alignas(4) int16_t et32[32 * 32];            // E^T[i][j] of the 32-point matrix (filled only by a CTB that has a 32x32 block)
+             alignas(4) int16_t blk[4][32 * (32 + RPAD)];   // per wave: scaled levels, TRANSPOSED: blk[x][j] = d[j][x]
+             alignas(4) int16_t tmp[4][32 * (32 + RPAD)];   // per wave: first-stage output tmp[y][j]
+    } big;
+    struct { alignas(16) uint8_t buf[4][kSmallBufBytes]; } small;   // per wave
+  } u;
   uint8_t m_size[256], m_flags[256], m_ipm[256];
   int8_t m_qp[256];
-  // block lists, entry = z | component << 8 (z = the unit that carries the TU's flags), in ONE array: blocks larger than 4x4 fill it from the
-  // front (list[e]), 4x4 blocks — four of them per wave pass — from the back (list4(i) = list[LIST_N - 1 - i]).  An 8x8 luma area brings at
-  // most 3 entries of the first kind or 12 of the second (4:4:4; 4:2:0: 1 + 0 or 4 + 2), so the two never meet: <= 768 entries in all.
-  // (LDS is sized to the byte for 7 workgroups per CU: 160 KB / 7 in 512 B granules)
-  uint16_t list[LIST_N];
-  uint32_t count, count4;
-  uint32_t colmask[4];   // per wave: columns of the current block that hold a nonzero level (DS atomic OR of the lanes' bits; zero between blocks)
+  // block lists by size, entry = z | component << 8 | lower 4:2:2 block << 10 | inter coded unit << 11 (z = the unit that carries the TU's flags).
+  // Capacities: a 64x64 CTB in 4:4:4 (three components of 256 / 64 / 16 / 4 blocks); 4:2:2 stays below them
+  uint16_t l4[768], l8[192], l16[48], l32[12];
+  uint32_t count[4];     // entries in l4, l8, l16, l32
+  uint32_t colmask[4];   // 32x32 form, per wave: columns of the current block that hold a nonzero level (DS atomic OR of the lanes' bits; zero between blocks)
 };
 
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -123,9 +132,9 @@ __device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, in
 {
   if (bypass) return;  // cu_transquant_bypass: the coefficient levels are the residual (8.6.2)
   const int n = 1 << log2n, nn = n * n, rs = n + RPAD;
-  int16_t* blk = L.blk[wave];
-  int16_t* tmp = L.tmp[wave];
-  const int16_t* et = dst ? L.est4 : (log2n == 2 ? L.et4 : (log2n == 3 ? L.et8 : (log2n == 4 ? L.et16 : L.et32)));
+  int16_t* blk = L.u.big.blk[wave];
+  int16_t* tmp = L.u.big.tmp[wave];
+  const int16_t* et = L.u.big.et32;   // (this form only serves 32x32 blocks since round 6: E_32 itself)
   // ---- scaling (8.6.3, flat m = 16) + nonzero extent ----
   const int bd_shift = bit_depth + log2n - 5;
   const int q6 = qp / 6, ls6 = level_scale(qp - 6 * q6), f = 16 * ls6;
@@ -203,79 +212,207 @@ __device__ __forceinline__ void residual_block(ResLds& L, int wave, int lane, in
   lds_sync();
 }
 
-// Four independent 4x4 blocks per wave pass: lane = 16 g + 4 y + x works on sample (y, x) of block g.  entry = z | c << 8.
-// (8.6.2 - 8.6.4 as in residual_block; both 1-D stages are two v_dot2 per output, no nonzero-extent bookkeeping)
-// the levels of the 4x4 block `entry` names (z | component << 8 | lower 4:2:2 block << 10)
-__device__ __forceinline__ int16_t* quad_levels(const ResLds& L, int entry, int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr, int cfi)
+// ---- thread-per-row form (4x4, 8x8, 16x16) -------------------------------------------------------------------------------------------------
+// 8.6.4.2: the n-point matrix is E_n[j][i] = M32[j * 32 / n][i], M32[j][i] = +-c[(2 i + 1) j mod 128, folded into 0 .. 32], c = the 33 magnitudes kMag
+constexpr int kMag[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64, 61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0};
+constexpr int m32(int j, int i)
 {
-  const bool c444 = cfi == 3, c422 = cfi == 2;
-  const int z = entry & 255, c = (entry >> 8) & 3, low = c422 ? (entry >> 10) & 1 : 0;
-  if (c == 0) return coef_y + z * 16;
-  const int t = L.m_size[z] & 15;
-  const int zc = (t > 2 || c444) ? z : (z & ~3);
-  return (c == 1 ? coef_cb : coef_cr) + zc * (c444 ? 16 : (c422 ? 8 : 4)) + low * 16;
+  int k = ((2 * i + 1) * j) & 127;
+  if (k > 64) k = 128 - k;
+  return k <= 32 ? kMag[k] : -kMag[64 - k];
 }
-// first_lev: this lane's level, loaded by the caller one pass ahead (0 for an invalid / bypass block: such a block is not written either)
-__device__ __forceinline__ void residual_quad(ResLds& L, int bd_luma, int bd_chroma, int cb_qp_offset, int cr_qp_offset, const uint8_t* sl_tab, int wave, int lane, int entry, bool valid,
-                                              int16_t* coef_y, int16_t* coef_cb, int16_t* coef_cr, int cfi, int first_lev)
+#ifdef HIPDEC_HOST_EMU
+#define RES_UNROLL
+#else
+#define RES_UNROLL _Pragma("unroll")
+#endif
+// y[i] = sum_j E_N[j][i] x[j] as the even-odd butterfly: E_N[j][N - 1 - i] = (-1)^j E_N[j][i], and the even rows of E_N are E_(N/2), so
+//   y[k] = even[k] + odd[k], y[N - 1 - k] = even[k] - odd[k]   with even = the N/2-point transform of x[0], x[2], ... and odd[k] = sum over odd j.
+// All sums are exact 32-bit integers (|x| < 2^15, sum of |E| over a column < 2^12): the same numbers as the n-MACs-per-sample form.
+// x[j] = in[j * S]; every index is a compile-time constant after unrolling, so in / y live in registers; MACs are v_mad_i32_i24.
+template <int N, int S>
+struct Idct {
+  static __device__ __forceinline__ void run(const int* in, int* y)
+  {
+    int ev[N / 2];
+    Idct<N / 2, 2 * S>::run(in, ev);
+    RES_UNROLL
+    for (int k = 0; k < N / 2; k++) {
+      int od = 0;
+      RES_UNROLL
+      for (int j = 1; j < N; j += 2) od += __mul24(m32(j * (32 / N), k), in[j * S]);
+      y[k] = ev[k] + od;
+      y[N - 1 - k] = ev[k] - od;
+    }
+  }
+};
+template <int S>
+struct Idct<2, S> {
+  static __device__ __forceinline__ void run(const int* in, int* y) { const int a = in[0] * 64, b = in[S] * 64; y[0] = a + b; y[1] = a - b; }
+};
+// 4x4 DST-VII of intra luma blocks (8.6.4.2, equation 8-xxx: transMatrix rows {29 55 74 84} {74 74 0 -74} {84 -29 -74 55} {55 -84 74 -29})
+__device__ __forceinline__ void idst4(const int* x, int* y)
 {
-  const bool c444 = cfi == 3, c422 = cfi == 2;
-  const int g = lane >> 4, l = lane & 15;
-  const int z = entry & 255, c = (entry >> 8) & 3, low = c422 ? (entry >> 10) & 1 : 0;   // low: the lower chroma block of a 4:2:2 unit (its flags sit in unit z ^ 1)
+  y[0] = __mul24(29, x[0]) + __mul24(74, x[1]) + __mul24(84, x[2]) + __mul24(55, x[3]);
+  y[1] = __mul24(55, x[0]) + __mul24(74, x[1]) - __mul24(29, x[2]) - __mul24(84, x[3]);
+  y[2] = __mul24(74, x[0]) - __mul24(74, x[2]) + __mul24(74, x[3]);
+  y[3] = __mul24(84, x[0]) - __mul24(74, x[1]) + __mul24(55, x[2]) - __mul24(29, x[3]);
+}
+
+// what the kernel knows about its CTB / picture
+struct ResCtx {
+  int16_t *coef_y, *coef_cb, *coef_cr;
+  const uint8_t* sl_tab;
+  int cfi, bd_luma, bd_chroma, cb_off, cr_off;
+};
+// a list entry -> the block's levels and everything its scaling needs (per lane: the lanes of a pass work on different blocks)
+struct BlkMeta {
+  int16_t* p;          // the block's n * n levels (TU-contiguous, raster)
+  const uint8_t* m;    // its ScalingFactor table (scaling lists only)
+  int ls6, sh_r, sh_l, rnd, bd2, ts, dst;
+};
+template <bool GEN>
+__device__ __forceinline__ BlkMeta block_meta(const ResLds& L, const ResCtx& cx, int entry, int log2n)
+{
+  const bool c444 = GEN && cx.cfi == 3, c422 = GEN && cx.cfi == 2;
+  const int z = entry & 255, c = (entry >> 8) & 3, low = c422 ? (entry >> 10) & 1 : 0, inter = (entry >> 11) & 1;
   const int t = L.m_size[z] & 15, fl = L.m_flags[z], ipm = L.m_ipm[low ? (z ^ 1) : z], qp_y = L.m_qp[z];
-  const bool bypass = (fl & UF_BYPASS) != 0;
-  int16_t* coef;
-  int bit_depth, qp, ts;
+  BlkMeta b;
+  int bit_depth, qp;
   if (c == 0) {
-    coef = coef_y + z * 16; bit_depth = bd_luma; qp = qp_y + 6 * (bd_luma - 8); ts = (fl & UF_TS_LUMA) != 0;
+    b.p = cx.coef_y + z * 16; bit_depth = cx.bd_luma; qp = qp_y + 6 * (cx.bd_luma - 8); b.ts = (fl & UF_TS_LUMA) != 0;
+    b.dst = log2n == 2 && !inter;   // DST-VII for the 4x4 luma blocks of intra coded units only
   } else {
+    // the chroma blocks of four 4x4 luma blocks hang off the quad's first unit; 4:2:2: the lower block follows the upper one
     const int zc = (t > 2 || c444) ? z : (z & ~3);
-    const int off_c = 6 * (bd_chroma - 8);
-    const int qpi = clip3(-off_c, 57, qp_y + (c == 1 ? cb_qp_offset : cr_qp_offset));
-    const int qpc = chroma_qp(qpi, cfi != 1);
-    coef = (c == 1 ? coef_cb : coef_cr) + zc * (c444 ? 16 : (c422 ? 8 : 4)) + low * 16; bit_depth = bd_chroma; qp = qpc + off_c; ts = (ipm & (c == 1 ? 64 : 128)) != 0;
+    const int off_c = 6 * (cx.bd_chroma - 8);
+    const int qpi = clip3(-off_c, 57, qp_y + (c == 1 ? cx.cb_off : cx.cr_off));
+    b.p = (c == 1 ? cx.coef_cb : cx.coef_cr) + zc * (c444 ? 16 : (c422 ? 8 : 4)) + (low << (2 * log2n));
+    bit_depth = cx.bd_chroma; qp = chroma_qp(qpi, GEN && cx.cfi != 1) + off_c; b.ts = (ipm & (c == 1 ? 64 : 128)) != 0;
+    b.dst = 0;
   }
-  const bool act = valid && !bypass;      // cu_transquant_bypass: the coefficient levels are the residual
-  const int q6 = (qp * 43) >> 8;          // qp / 6 for 0 <= qp < 128
-  const int bd_shift = bit_depth - 3;     // bitDepth + log2(4) - 5
-  const int bd_shift2 = 20 - bit_depth;
-  const bool use_sl = sl_tab != nullptr;
-  const int mfac = use_sl ? (int)sl_tab[c * 336 + l + (((entry >> 11) & 1) << 11)] : 16;    // 4x4 ScalingFactor of this lane's coefficient (8.6.4.2); inter coded units: the second block of tables
-  const int f = mfac * level_scale(qp - 6 * q6);
-  const int sh_r = q6 < bd_shift ? bd_shift - q6 : 0, sh_l = q6 < bd_shift ? 0 : q6 - bd_shift, rnd = sh_r ? 1 << (sh_r - 1) : 0;
-  const int lev = act ? first_lev : 0;
-  const int d = use_sl ? scale_level_sl(lev, f, sh_r, sh_l, rnd) : scale_level(lev, f, sh_r, sh_l, rnd);
-  int16_t* blk = L.blk[wave] + g * 16;    // blk[x][j] = d[j][x]
-  int16_t* tmp = L.tmp[wave] + g * 16;    // tmp[i][x]
-  const int y = l >> 2, x = l & 3;
-  blk[x * 4 + y] = (int16_t)d;
-  lds_sync();
-  const bool use_dst = c == 0 && !((entry >> 11) & 1);   // DST-VII for the 4x4 luma blocks of intra coded units only
-  const uint32_t* e = (const uint32_t*)((use_dst ? L.est4 : L.et4) + y * 4);   // E^T row of this lane's output index
-  {
-    // first stage, lane (i = y, x): tmp[i][x] = clip16((sum_j E[j][i] d[j][x] + 64) >> 7)
-    const uint32_t* v = (const uint32_t*)(blk + x * 4);
-    const int sum = dot2(e[1], v[1], dot2(e[0], v[0], 0));
-    tmp[y * 4 + x] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
+  const int q6 = (qp * 43) >> 8;           // qp / 6 for 0 <= qp < 128
+  const int bd_shift = bit_depth + log2n - 5;
+  b.ls6 = level_scale(qp - 6 * q6);
+  b.sh_r = q6 < bd_shift ? bd_shift - q6 : 0; b.sh_l = q6 < bd_shift ? 0 : q6 - bd_shift; b.rnd = b.sh_r ? 1 << (b.sh_r - 1) : 0;
+  if (!cx.sl_tab) b.ls6 = (16 * b.ls6) << b.sh_l;   // flat lists: the whole factor (m = 16, levelScale, the left shift; q - b <= 3: < 2^14)
+  b.bd2 = 20 - bit_depth;
+  // ScalingFactor tables (hevc_device.h, PicParams::off_scaling): component c at c * 336 (4x4, 8x8 at + 16, 16x16 at + 80), inter coded units 2048 bytes on
+  b.m = cx.sl_tab ? cx.sl_tab + (inter << 11) + c * 336 + (log2n == 2 ? 0 : (log2n == 3 ? 16 : 80)) : nullptr;
+  return b;
+}
+template <int N> struct RowRaw { uint32_t w[N / 2]; };     // a row of N int16
+template <int N>
+__device__ __forceinline__ RowRaw<N> row_load(const int16_t* p)
+{
+  RowRaw<N> r;
+  if constexpr (N == 4) { const uint2 v = *(const uint2*)p; r.w[0] = v.x; r.w[1] = v.y; }
+  else {
+    RES_UNROLL
+    for (int q = 0; q < N / 8; q++) { const uint4 v = ((const uint4*)p)[q]; r.w[4 * q] = v.x; r.w[4 * q + 1] = v.y; r.w[4 * q + 2] = v.z; r.w[4 * q + 3] = v.w; }
   }
-  lds_sync();
-  int r;
-  {
-    // second stage, lane (y, i = x): res[y][i] = (sum_j E[j][i] tmp[y][j] + rnd) >> bdShift
-    const uint32_t* ei = (const uint32_t*)((use_dst ? L.est4 : L.et4) + x * 4);
-    const uint32_t* v = (const uint32_t*)(tmp + y * 4);
-    const int sum = dot2(ei[1], v[1], dot2(ei[0], v[0], 0));
-    r = (sum + (1 << (bd_shift2 - 1))) >> bd_shift2;
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void row_store(int16_t* p, const RowRaw<N>& r)
+{
+  if constexpr (N == 4) *(uint2*)p = make_uint2(r.w[0], r.w[1]);
+  else {
+    RES_UNROLL
+    for (int q = 0; q < N / 8; q++) { uint4 v; v.x = r.w[4 * q]; v.y = r.w[4 * q + 1]; v.z = r.w[4 * q + 2]; v.w = r.w[4 * q + 3]; ((uint4*)p)[q] = v; }
   }
-  if (ts) r = (d * 128 + (1 << (bd_shift2 - 1))) >> bd_shift2;   // 8.6.4.2 with transform_skip_flag: r = d << 7
-  if (act) coef[l] = (int16_t)r;
-  lds_sync();
+}
+template <int N> __device__ __forceinline__ int row_get(const RowRaw<N>& r, int k) { return (int)(int16_t)(r.w[k >> 1] >> ((k & 1) * 16)); }
+__device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+
+// All blocks of one size (N = 1 << LG) of the CTB: pass q takes the blocks q * BPP .. of `list`, lane = block * N + row; a wave takes the passes
+// first, first + 4, ...  The NEXT pass's rows are requested before the current pass is worked on.
+template <int LG, bool SL, bool GEN>
+__device__ __forceinline__ void residual_class(ResLds& L, const ResCtx& cx, int wave, int lane, int first, int count, const uint16_t* list)
+{
+  constexpr int N = 1 << LG, BPP = 64 >> LG;
+  constexpr int BS = LG == 4 ? 512 + 32 : (LG == 3 ? 128 + 16 : 32 + 8);
+  static_assert(BPP * BS <= kSmallBufBytes, "a pass fits the wave's buffer");
+  const int g = lane >> LG, r = lane & (N - 1);
+  uint8_t* const blk = L.u.small.buf[wave] + g * BS;           // this lane's block
+  int16_t* const my_row = (int16_t*)(blk + r * (2 * N));
+  int16_t* const my_col = (int16_t*)blk + r;                   // element j of the column: my_col[j * N]
+  const int passes = (count + BPP - 1) / BPP;
+  bool valid = false;
+  BlkMeta bm{};
+  bm.bd2 = 12;                                                  // (lanes without a block compute on zeros with legal shift counts)
+  RowRaw<N> raw{};
+  RowRaw<N / 2> mrow{};                                        // the row's ScalingFactors (N bytes; scaling lists only)
+  auto fetch = [&](int q, BlkMeta& b, RowRaw<N>& rw, decltype(mrow)& mr) -> bool {
+    const int idx = q * BPP + g;
+    const bool ok = idx < count;
+    rw = RowRaw<N>{};
+    if (ok) {
+      b = block_meta<GEN>(L, cx, (int)list[idx], LG);
+      rw = row_load<N>(b.p + r * N);
+      if (SL) {
+        if constexpr (N == 4) mr.w[0] = *(const uint32_t*)(b.m + r * 4);
+        else if constexpr (N == 8) { const uint2 v = *(const uint2*)(b.m + r * 8); mr.w[0] = v.x; mr.w[1] = v.y; }
+        else { const uint4 v = *(const uint4*)(b.m + r * 16); mr.w[0] = v.x; mr.w[1] = v.y; mr.w[2] = v.z; mr.w[3] = v.w; }
+      }
+    }
+    return ok;
+  };
+  if (first < passes) valid = fetch(first, bm, raw, mrow);
+  for (int q = first; q < passes; q += 4) {
+    const bool cur_valid = valid;
+    const BlkMeta b = bm;
+    const RowRaw<N> cur = raw;
+    const auto cur_m = mrow;
+    if (q + 4 < passes) valid = fetch(q + 4, bm, raw, mrow);
+    // ---- scaling (8.6.3) of this lane's row, into LDS by rows ----
+    int d[N];
+    RES_UNROLL
+    for (int k = 0; k < N; k++) {
+      const int lev = row_get<N>(cur, k);      // (a lane without a block holds zeros)
+      // flat lists: one of the two shifts is 0, and a left shift of the product is a left shift of the factor: (level * (f << ls) + rnd) >> rs
+      d[k] = SL ? scale_level_sl(lev, (int)((cur_m.w[k >> 2] >> ((k & 3) * 8)) & 255u) * b.ls6, b.sh_r, b.sh_l, b.rnd)
+                : clip3(-32768, 32767, (__mul24(lev, b.ls6) + b.rnd) >> b.sh_r);
+    }
+    {
+      RowRaw<N> pk;
+      RES_UNROLL
+      for (int k = 0; k < N / 2; k++) pk.w[k] = pack16(d[2 * k], d[2 * k + 1]);
+      row_store<N>(my_row, pk);
+    }
+    lds_sync();
+    // ---- first stage (columns): tmp[i][x] = clip16((sum_j E[j][i] d[j][x] + 64) >> 7), this lane owns column x = r ----
+    int x[N], y[N];
+    RES_UNROLL
+    for (int j = 0; j < N; j++) x[j] = my_col[j * N];
+    if (N == 4 && b.dst) idst4(x, y); else Idct<N, 1>::run(x, y);
+    RES_UNROLL
+    for (int i = 0; i < N; i++) my_col[i * N] = (int16_t)clip3(-32768, 32767, (y[i] + 64) >> 7);    // (the column is this lane's own: read above, written here)
+    lds_sync();
+    // ---- second stage (rows): res[y][i] = (sum_j E[j][i] tmp[y][j] + rnd) >> bdShift, this lane owns row y = r ----
+    {
+      const RowRaw<N> t = row_load<N>(my_row);
+      RES_UNROLL
+      for (int j = 0; j < N; j++) x[j] = row_get<N>(t, j);
+    }
+    if (N == 4 && b.dst) idst4(x, y); else Idct<N, 1>::run(x, y);
+    const int rnd2 = 1 << (b.bd2 - 1);
+    RowRaw<N> out;
+    RES_UNROLL
+    for (int k = 0; k < N / 2; k++) {
+      int r0 = (y[2 * k] + rnd2) >> b.bd2, r1 = (y[2 * k + 1] + rnd2) >> b.bd2;
+      if (N == 4 && b.ts) { r0 = (d[2 * k] * 128 + rnd2) >> b.bd2; r1 = (d[2 * k + 1] * 128 + rnd2) >> b.bd2; }   // 8.6.4.2 with transform_skip_flag: r = d << 7
+      out.w[k] = pack16(r0, r1);
+    }
+    if (cur_valid) row_store<N>(b.p + r * N, out);
+    lds_sync();      // the next pass's rows overwrite the buffer
+  }
 }
 
 }  // namespace
 
 // blockIdx.x = CTB (raster) of picture blockIdx.y.  GEN = false: a build for batches of 4:0:0 / 4:2:0 pictures only (the 4:2:2 / 4:4:4 block
-// addressing costs the common batch 3 % of this kernel: 84 -> 87 ms per 2048 4K stills)
+// addressing costs the common batch a few per cent of this kernel)
 template <bool GEN>
 __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
 {
@@ -290,139 +427,95 @@ __global__ __launch_bounds__(256) void k_residual(FilterArgs A)
   const int units = 1 << P.units_per_ctb_log2;
   const int ctb = 1 << P.log2_ctb;
   const size_t base = (size_t)ctb_rs * units;
-  // Everything the prologue reads from global memory is requested FIRST and used afterwards - the CTB's unit maps (four bytes per thread) and the
-  // table entries below (one byte each, six per thread): as a loop of load - wait - store the table alone was six memory latencies in a row at the
-  // start of every workgroup (one workgroup per CTB, ~18 blocks per wave: the prologue is a visible part of its life).
-  uint8_t u_size = 0, u_flags = 0, u_ipm = 0, u_qp = 0;
+  // Everything the prologue reads from global memory is requested FIRST and used afterwards: the CTB's unit maps (four bytes per thread, five in
+  // P / B pictures), its slice's chroma QP offsets
+  uint8_t u_size = 0, u_flags = 0, u_ipm = 0, u_qp = 0, u_ipmc = 0;
   if (tid < units) {
     u_size = A.arena[P.off_u_size + base + tid]; u_flags = A.arena[P.off_u_flags + base + tid];
     u_ipm = A.arena[P.off_u_ipm + base + tid]; u_qp = A.arena[P.off_u_qp + base + tid];
+    if (P.is_inter) u_ipmc = A.arena[P.off_u_ipmc + base + tid];
   }
-  // E^T[i][j] for every transform size (8.6.4.2): E_n[j][i] = M32[j * 32/n][i], the 32-point matrix from its 33 magnitudes
-  constexpr int kTabEntries = 1024 + 256 + 64 + 16 + 16, kTabPasses = (kTabEntries + 255) / 256;
-  int tab_v[kTabPasses], tab_neg[kTabPasses];
-#pragma unroll
-  for (int it = 0; it < kTabPasses; it++) {
-    const int idx = tid + 256 * it;
-    const int lg = idx < 1024 ? 5 : (idx < 1280 ? 4 : (idx < 1344 ? 3 : 2));
-    const int off = idx - (idx < 1024 ? 0 : (idx < 1280 ? 1024 : (idx < 1344 ? 1280 : (idx < 1360 ? 1344 : 1360))));
-    const int nsz = 1 << lg, i = off >> lg, j = off & (nsz - 1);
-    const int mm = j * (32 >> lg);          // row of the 32-point matrix
-    int k = ((2 * i + 1) * mm) & 127;
-    if (k > 64) k = 128 - k;
-    const bool dst = idx >= 1360;           // est4[off]: r_dst[(off & 3) * 4 + (off >> 2)]
-    const int e = dst ? 33 + ((off & 3) * 4 + ((off >> 2) & 3)) : (k <= 32 ? k : 64 - k);
-    tab_neg[it] = !dst && k > 32;
-    tab_v[it] = r_tab[e];                   // (idx past the tables: some valid entry, not stored)
-  }
-#pragma unroll
-  for (int it = 0; it < kTabPasses; it++) tab_v[it] = tab_neg[it] ? -tab_v[it] : tab_v[it];
-  static_assert(offsetof(ResLds, et32) == 0 && offsetof(ResLds, et16) == 2 * 1024 && offsetof(ResLds, et8) == 2 * 1280 && offsetof(ResLds, et4) == 2 * 1344 &&
-                offsetof(ResLds, est4) == 2 * 1360, "the transform tables are filled as one array");
-  int16_t* const tab = reinterpret_cast<int16_t*>(&L);
-#pragma unroll
-  for (int it = 0; it < kTabPasses; it++) {
-    const int idx = tid + 256 * it;
-    if (idx < kTabEntries) tab[idx] = (int16_t)tab_v[it];
-  }
-  const uint8_t* sl_tab = P.scaling_lists ? A.arena + P.off_scaling : nullptr;   // ScalingFactor tables of the picture
-  const bool use_sl = sl_tab != nullptr;
+  const CtbInfo ci = ((const CtbInfo*)(A.arena + P.off_ctb_info))[ctb_rs];
   const bool c444 = cfi_p == 3;   // chroma blocks have the luma blocks' size and position
   const bool c422 = cfi_p == 2;   // two chroma blocks of half the luma block's size, one above the other
-  if (tid == 0) { L.count = 0; L.count4 = 0; }
-  if (tid < 4) L.colmask[tid] = 0;
+  if (tid < 4) { L.count[tid] = 0; L.colmask[tid] = 0; }
   if (tid < units) { L.m_size[tid] = u_size; L.m_flags[tid] = u_flags; L.m_ipm[tid] = u_ipm; L.m_qp[tid] = (int8_t)u_qp; }
   __syncthreads();
-  // ---- lists of coded blocks, one entry per block and component: z | c << 8 with z the unit that carries the flags (a TU's
+  // ---- lists of coded blocks by size, one entry per block and component: z | c << 8 with z the unit that carries the flags (a TU's
   //      first unit; for the chroma blocks of four 4x4 luma TUs the 4th unit, where the parser leaves their flags) ----
+  auto push = [&](int log2n, uint16_t entry) {
+    if (log2n == 2) L.l4[atomicAdd(&L.count[0], 1u)] = entry;
+    else if (log2n == 3) L.l8[atomicAdd(&L.count[1], 1u)] = entry;
+    else if (log2n == 4) L.l16[atomicAdd(&L.count[2], 1u)] = entry;
+    else L.l32[atomicAdd(&L.count[3], 1u)] = entry;
+  };
   if (tid < units) {
     const int z = tid;
     const int ux = (int)compact1by1((uint32_t)z), uy = (int)compact1by1((uint32_t)z >> 1);
     const int x_ctb = (ctb_rs % P.ctb_w) << P.log2_ctb, y_ctb = (ctb_rs / P.ctb_w) << P.log2_ctb;
     if (x_ctb + ux * 4 < P.width && y_ctb + uy * 4 < P.height) {
-      const int t = L.m_size[z] & 15, fl = L.m_flags[z];
+      const int t = u_size & 15, fl = u_flags;
       const int first = t >= 2 && t <= 5 && (z & ((1 << (2 * (t - 2))) - 1)) == 0;
       if (first && !(fl & UF_BYPASS)) {
-        const int inter_bit = (P.is_inter && (A.arena[P.off_u_ipmc + base + z] & UM_INTER)) ? 0x800 : 0;
-        if (fl & UF_CBF_LUMA) {
-          // (P pictures: bit 11 = the block belongs to an inter coded unit: its 4x4 luma transform is the DCT, not the DST of intra blocks, 8.6.4.2)
-          // (with scaling lists the bit also selects the matrices of inter coded units for every block size and component, Table 7-4)
-          if (t == 2) L.list[LIST_N - 1 - atomicAdd(&L.count4, 1u)] = (uint16_t)(z | inter_bit);
-          else L.list[atomicAdd(&L.count, 1u)] = (uint16_t)(z | inter_bit);
-        }
+        // (P pictures: bit 11 = the block belongs to an inter coded unit: its 4x4 luma transform is the DCT, not the DST of intra blocks, 8.6.4.2;
+        //  with scaling lists the bit also selects the matrices of inter coded units for every block size and component, Table 7-4)
+        const int inter_bit = (P.is_inter && (u_ipmc & UM_INTER)) ? 0x800 : 0;
+        if (fl & UF_CBF_LUMA) push(t, (uint16_t)(z | inter_bit));
         // chroma blocks hang off the unit that carries their flags: a block's first unit, or the 4th unit of a quad of 4x4 luma blocks.  4:2:2 has
         // two chroma blocks per unit; the lower one's flags sit in unit z ^ 1 (so in a 4:2:2 quad only the 4th unit's flags are block flags)
         if (cfi_p && !(c422 && t == 2 && (z & 3) != 3))
           for (int c = 1; c < 3; c++)
             for (int low = 0; low < (c422 ? 2 : 1); low++)
-              if ((low ? L.m_flags[z ^ 1] : fl) & (c == 1 ? UF_CBF_CB : UF_CBF_CR)) {
-                const uint16_t entry = (uint16_t)(z | (c << 8) | (low << 10) | inter_bit);
-                if (t <= (c444 ? 2 : 3)) L.list[LIST_N - 1 - atomicAdd(&L.count4, 1u)] = entry;
-                else L.list[atomicAdd(&L.count, 1u)] = entry;
-              }
+              if ((low ? L.m_flags[z ^ 1] : fl) & (c == 1 ? UF_CBF_CB : UF_CBF_CR))
+                push(c444 ? t : (t > 3 ? t - 1 : 2), (uint16_t)(z | (c << 8) | (low << 10) | inter_bit));
       }
     }
   }
   __syncthreads();
-  const int count = (int)L.count, count4 = (int)L.count4;
-  const CtbInfo ci = ((const CtbInfo*)(A.arena + P.off_ctb_info))[ctb_rs];
+  const int n4 = (int)L.count[0], n8 = (int)L.count[1], n16 = (int)L.count[2], n32 = (int)L.count[3];
   const SliceParams sl = ((const SliceParams*)(A.arena + P.off_slices))[ci.slice_idx];
-  int16_t* coef_y = (int16_t*)(A.arena + P.off_coeff[0]) + (size_t)ctb_rs * ctb * ctb;
   const int cc_shift = c444 ? 0 : (c422 ? 1 : 2);
+  ResCtx cx;
+  cx.coef_y = (int16_t*)(A.arena + P.off_coeff[0]) + (size_t)ctb_rs * ctb * ctb;
   // (two named pointers, selected by comparison: an array indexed by the component goes through memory and comes back as a generic pointer -
   //  FLAT loads and stores, which also count in lgkmcnt, so that every LDS wait waited for the global traffic too)
-  int16_t* const coef_cb = (int16_t*)(A.arena + P.off_coeff[1]) + (size_t)ctb_rs * ((ctb * ctb) >> cc_shift);
-  int16_t* const coef_cr = (int16_t*)(A.arena + P.off_coeff[2]) + (size_t)ctb_rs * ((ctb * ctb) >> cc_shift);
-  const int bd_luma = P.bit_depth_luma, bd_chroma = P.bit_depth_chroma, cb_off = sl.cb_qp_offset, cr_off = sl.cr_qp_offset;
-  // 4x4 blocks, four per wave pass
-  {
-    auto quad_entry = [&](int q, bool& valid) -> int { const int idx = q * 4 + (lane >> 4); valid = idx < (int)count4; return valid ? (int)L.list[LIST_N - 1 - idx] : 0; };
-    bool valid = false, valid_next = false;
-    int entry = 0, ahead = 0;
-    if (wave * 4 < (int)count4) { entry = quad_entry(wave, valid); if (valid) ahead = quad_levels(L, entry, coef_y, coef_cb, coef_cr, cfi_p)[lane & 15]; }
-    for (int q = wave; q * 4 < (int)count4; q += 4) {
-      const int lev = ahead, cur = entry;
-      const bool cur_valid = valid;
-      if ((q + 4) * 4 < (int)count4) {   // the next pass's levels are requested before this pass is worked on
-        entry = quad_entry(q + 4, valid_next); valid = valid_next; ahead = 0;
-        if (valid) ahead = quad_levels(L, entry, coef_y, coef_cb, coef_cr, cfi_p)[lane & 15];
-      }
-      residual_quad(L, bd_luma, bd_chroma, cb_off, cr_off, sl_tab, wave, lane, cur, cur_valid, coef_y, coef_cb, coef_cr, cfi_p, lev);
-    }
+  cx.coef_cb = (int16_t*)(A.arena + P.off_coeff[1]) + (size_t)ctb_rs * ((ctb * ctb) >> cc_shift);
+  cx.coef_cr = (int16_t*)(A.arena + P.off_coeff[2]) + (size_t)ctb_rs * ((ctb * ctb) >> cc_shift);
+  cx.sl_tab = P.scaling_lists ? A.arena + P.off_scaling : nullptr;   // ScalingFactor tables of the picture
+  cx.cfi = cfi_p; cx.bd_luma = P.bit_depth_luma; cx.bd_chroma = P.bit_depth_chroma; cx.cb_off = sl.cb_qp_offset; cx.cr_off = sl.cr_qp_offset;
+  const bool use_sl = cx.sl_tab != nullptr;
+  // the passes of the three sizes behind one another, dealt to the four waves round-robin (largest blocks first)
+  const int p16 = (n16 + 3) >> 2, p8 = (n8 + 7) >> 3;
+  const int f16 = wave, f8 = (wave - p16) & 3, f4 = (wave - p16 - p8) & 3;
+  if (use_sl) {
+    residual_class<4, true, GEN>(L, cx, wave, lane, f16, n16, L.l16);
+    residual_class<3, true, GEN>(L, cx, wave, lane, f8, n8, L.l8);
+    residual_class<2, true, GEN>(L, cx, wave, lane, f4, n4, L.l4);
+  } else {
+    residual_class<4, false, GEN>(L, cx, wave, lane, f16, n16, L.l16);
+    residual_class<3, false, GEN>(L, cx, wave, lane, f8, n8, L.l8);
+    residual_class<2, false, GEN>(L, cx, wave, lane, f4, n4, L.l4);
   }
-  // larger blocks, one per wave pass; the first levels of the NEXT block are requested before the current one is worked on
-  auto block_of = [&](int e, int& c, int& t, int& tc, int& fl, int& ipm, int& qp_y, int& sl_off) -> int16_t* {   // list entry -> component, sizes, flags, levels
-    const int z = L.list[e] & 255, low = c422 ? (L.list[e] >> 10) & 1 : 0;
-    sl_off = ((L.list[e] >> 11) & 1) << 11;   // scaling lists: the tables of inter coded units follow the intra ones (P / B pictures: 2048-byte blocks)
-    c = (L.list[e] >> 8) & 3;
-    t = L.m_size[z] & 15; fl = L.m_flags[z]; ipm = L.m_ipm[low ? (z ^ 1) : z]; qp_y = L.m_qp[z];
-    tc = c == 0 ? t : (c444 ? t : t - 1);    // log2 size of the block
-    return c == 0 ? coef_y + z * 16 : (c == 1 ? coef_cb : coef_cr) + z * (c444 ? 16 : (c422 ? 8 : 4)) + (low << (2 * tc));
-  };
-  auto first_levels = [&](const int16_t* cc, int tc) -> uint2 {
-    return lane * 4 < (1 << (2 * tc)) ? *(const uint2*)&cc[lane * 4] : make_uint2(0, 0);
-  };
-  int c = 0, t = 0, tc = 0, fl = 0, ipm = 0, qp_y = 0, sl_off = 0;
-  int16_t* cc = nullptr;
-  uint2 ahead = make_uint2(0, 0);
-  if (wave < count) { cc = block_of(wave, c, t, tc, fl, ipm, qp_y, sl_off); ahead = first_levels(cc, tc); }
-  for (int e = wave; e < count; e += 4) {
-    const uint2 first_raw = ahead;
-    int16_t* const cur = cc;
-    const int cur_c = c, cur_t = t, cur_tc = tc, cur_fl = fl, cur_ipm = ipm, cur_qp = qp_y, cur_sl = sl_off;
-    if (e + 4 < count) { cc = block_of(e + 4, c, t, tc, fl, ipm, qp_y, sl_off); ahead = first_levels(cc, tc); }
-    if (cur_c == 0) {
-      if (use_sl) residual_block<true>(L, wave, lane, cur, cur_t, bd_luma, cur_qp + 6 * (bd_luma - 8), 0, (cur_fl & UF_TS_LUMA) != 0, 0,
-                                       sl_tab + cur_sl + (cur_t == 5 ? 1008 : (cur_t == 3 ? 16 : 80)), first_raw);
-      else residual_block<false>(L, wave, lane, cur, cur_t, bd_luma, cur_qp + 6 * (bd_luma - 8), 0, (cur_fl & UF_TS_LUMA) != 0, 0, nullptr, first_raw);
-    }
-    else {
-      const int off_c = 6 * (bd_chroma - 8);
-      const int qpi = clip3(-off_c, 57, cur_qp + (cur_c == 1 ? cb_off : cr_off));
+  if (n32 == 0) return;
+  // ---- 32x32 blocks, one per wave pass (wave-per-block form); the buffers above are dead behind the barrier ----
+  __syncthreads();
+  for (int idx = tid; idx < 1024; idx += 256) { const int i = idx >> 5, j = idx & 31; L.u.big.et32[idx] = (int16_t)m32(j, i); }   // E^T[i][j]
+  __syncthreads();
+  for (int e = wave; e < n32; e += 4) {
+    const int entry = L.l32[e];
+    const int z = entry & 255, c = (entry >> 8) & 3, sl_off = ((entry >> 11) & 1) << 11;
+    const int fl = L.m_flags[z], ipm = L.m_ipm[z], qp_y = L.m_qp[z];
+    int16_t* const cc = c == 0 ? cx.coef_y + z * 16 : (c == 1 ? cx.coef_cb : cx.coef_cr) + z * 16;   // (a 32x32 chroma block: 4:4:4 only)
+    const uint2 first_raw = *(const uint2*)&cc[lane * 4];
+    if (c == 0) {
+      if (use_sl) residual_block<true>(L, wave, lane, cc, 5, cx.bd_luma, qp_y + 6 * (cx.bd_luma - 8), 0, (fl & UF_TS_LUMA) != 0, 0, cx.sl_tab + sl_off + 1008, first_raw);
+      else residual_block<false>(L, wave, lane, cc, 5, cx.bd_luma, qp_y + 6 * (cx.bd_luma - 8), 0, (fl & UF_TS_LUMA) != 0, 0, nullptr, first_raw);
+    } else {
+      const int off_c = 6 * (cx.bd_chroma - 8);
+      const int qpi = clip3(-off_c, 57, qp_y + (c == 1 ? cx.cb_off : cx.cr_off));
       const int qpc = chroma_qp(qpi, cfi_p != 1);
-      if (use_sl) residual_block<true>(L, wave, lane, cur, cur_tc, bd_chroma, qpc + off_c, 0, (cur_ipm & (cur_c == 1 ? 64 : 128)) != 0, 0,
-                                       cur_tc == 5 ? sl_tab + 2048 + (cur_c - 1) * 1024 : sl_tab + cur_sl + cur_c * 336 + (cur_tc == 3 ? 16 : 80), first_raw);   // 32x32 chroma: 4:4:4 only
-      else residual_block<false>(L, wave, lane, cur, cur_tc, bd_chroma, qpc + off_c, 0, (cur_ipm & (cur_c == 1 ? 64 : 128)) != 0, 0, nullptr, first_raw);
+      if (use_sl) residual_block<true>(L, wave, lane, cc, 5, cx.bd_chroma, qpc + off_c, 0, (ipm & (c == 1 ? 64 : 128)) != 0, 0, cx.sl_tab + 2048 + (c - 1) * 1024, first_raw);
+      else residual_block<false>(L, wave, lane, cc, 5, cx.bd_chroma, qpc + off_c, 0, (ipm & (c == 1 ? 64 : 128)) != 0, 0, nullptr, first_raw);
     }
   }
 }
