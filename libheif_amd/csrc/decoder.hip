@@ -42,6 +42,8 @@ struct hipdec_batch : BatchLayout {
   size_t arena_capacity = 0;
   void* staging = nullptr;      // pinned upload staging (large batches), returned to its pool once the upload has completed
   size_t staging_capacity = 0;
+  void* upload_dev = nullptr;   // a batch that takes over a busy arena: its upload region lands here first (beside the predecessor's kernels), build_batch
+  size_t upload_dev_capacity = 0;
   hipEvent_t uploaded = nullptr;   // recorded on the upload stream behind the H2D copy; launch streams wait on it
   hipEvent_t done = nullptr;       // recorded behind the last piece of work enqueued for this batch (decode, colour stage, packs)
   bool done_recorded = false;
@@ -90,6 +92,7 @@ struct hipdec_batch : BatchLayout {
     if (uploaded) (void)hipEventSynchronize(uploaded);
     pinned_release(staging, staging_capacity);
     staging = nullptr;
+    if (upload_dev) { arena_release(upload_dev, upload_dev_capacity); upload_dev = nullptr; }
   }
   ~hipdec_batch()
   {
@@ -152,8 +155,19 @@ int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* s
     layout_batch_fill(b, data, sizes, (uint8_t*)b.staging, (uint64_t)(uintptr_t)b.arena);
     HIPDEC_CHECK_HIP(hipEventCreateWithFlags(&b.uploaded, hipEventDisableTiming));
     hipStream_t us = upload_stream();
-    if (after) HIPDEC_CHECK_HIP(hipStreamWaitEvent(us, after, 0));
-    HIPDEC_CHECK_HIP(hipMemcpyAsync(b.arena, b.staging, b.upload_size, hipMemcpyHostToDevice, us));
+    // An arena taken over from a batch whose kernels are still running cannot receive the upload yet: the bytes cross PCIe NOW into a bounce
+    // buffer in HBM (beside those kernels) and move into the arena with a device copy once the predecessor has finished - 2 GB per 2048 4K
+    // stills are ~ 40 ms of link time against ~ 1 ms of HBM copy between two batches.  No memory for the bounce buffer: the upload waits.
+    static const bool no_bounce = getenv("HIPDEC_NO_UPLOAD_BOUNCE") != nullptr;   // A/B knob
+    if (after && !no_bounce && arena_acquire(&b.upload_dev, b.upload_size, &b.upload_dev_capacity) != hipSuccess) { b.upload_dev = nullptr; (void)hipGetLastError(); }
+    if (after && b.upload_dev) {
+      HIPDEC_CHECK_HIP(hipMemcpyAsync(b.upload_dev, b.staging, b.upload_size, hipMemcpyHostToDevice, us));
+      HIPDEC_CHECK_HIP(hipStreamWaitEvent(us, after, 0));
+      HIPDEC_CHECK_HIP(hipMemcpyAsync(b.arena, b.upload_dev, b.upload_size, hipMemcpyDeviceToDevice, us));
+    } else {
+      if (after) HIPDEC_CHECK_HIP(hipStreamWaitEvent(us, after, 0));
+      HIPDEC_CHECK_HIP(hipMemcpyAsync(b.arena, b.staging, b.upload_size, hipMemcpyHostToDevice, us));
+    }
     HIPDEC_CHECK_HIP(hipEventRecord(b.uploaded, us));
   } else {
     std::vector<uint8_t> host(b.upload_size);
