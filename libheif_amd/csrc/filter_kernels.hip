@@ -817,6 +817,17 @@ __device__ __forceinline__ void sao_store(const SaoComp<Pix>& S, int ox0, int oy
   }
 }
 
+// Tile of a workgroup, XCD-aware.  Workgroups go to the chip's 8 XCDs (each with an L2 of its own) round-robin by their linear id, and a tile's rows
+// start one sample left of a 128-byte line and end one sample into the next: with tile = blockIdx.x the two neighbours of every tile ran on other
+// XCDs and each of them fetched those two lines from HBM again (measured: 5.2 B/px fetched for 1.5 B/px of planes, profiles/pmc_traffic.json round 5:
+// three lines per luma row and two per chroma row instead of one).  Here every XCD takes a contiguous band of the picture's tiles, so that
+// horizontal neighbours run on the same XCD at about the same time and share the lines in its L2.  gridDim.x is a multiple of 8.
+__device__ __forceinline__ int sao_tile_of_block(int n_tiles)
+{
+  const int bid = (int)blockIdx.x, chunk = (n_tiles + 7) >> 3;
+  const int t = (bid & 7) * chunk + (bid >> 3);
+  return ((bid >> 3) < chunk && t < n_tiles) ? t : -1;
+}
 template <typename Pix, bool MAY_KEEP, bool RESTRICTED>
 __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
 {
@@ -829,8 +840,9 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
   if (c > 0 && !P.chroma_format_idc) return;
   const SaoComp<Pix> S = sao_comp<Pix>(A, P, c, MAY_KEEP, RESTRICTED);
   const int tiles_x = (S.ow + SAO_TW - 1) / SAO_TW, tiles_y = (S.oh + SAO_TH - 1) / SAO_TH;
-  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
-  const int ox_t = ((int)blockIdx.x % tiles_x) * SAO_TW, oy_t = ((int)blockIdx.x / tiles_x) * SAO_TH;
+  const int tile_idx = sao_tile_of_block(tiles_x * tiles_y);
+  if (tile_idx < 0) return;
+  const int ox_t = (tile_idx % tiles_x) * SAO_TW, oy_t = (tile_idx / tiles_x) * SAO_TH;
   const int tid = threadIdx.x;
   const int tx = (tid & 31) * 4, ty = tid >> 5;
   uint32_t spw[SAO_RPT][3];   // SaoParams as three dwords per row (statically indexed: stays in registers)
@@ -870,17 +882,23 @@ __global__ __launch_bounds__(256) SAO_RGB_OCCUPANCY void k_sao_rgb(FilterArgs A,
   const PicParams& P = A.pics[blockIdx.y];
   const SaoComp<Pix> SY = sao_comp<Pix>(A, P, 0, MAY_KEEP, RESTRICTED);
   const int tiles_x = (SY.ow + SAO_TW - 1) / SAO_TW, tiles_y = (SY.oh + SAO_TH - 1) / SAO_TH;
-  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
-  const int ox_t = ((int)blockIdx.x % tiles_x) * SAO_TW, oy_t = ((int)blockIdx.x / tiles_x) * SAO_TH;
+  const int tile_idx = sao_tile_of_block(tiles_x * tiles_y);
+  if (tile_idx < 0) return;
+  const int ox_t = (tile_idx % tiles_x) * SAO_TW, oy_t = (tile_idx / tiles_x) * SAO_TH;
   const int tid = threadIdx.x;
-  const int tx = (tid & 31) * 4, ty = tid >> 5;
-  const int ctx = (tid & 15) * 4, cty = tid >> 4;
+  // A wave stays inside ONE CTB column (64 luma samples wide, CTB 64 and an aligned crop: the benchmarked streams): its lanes then share the CTB's SAO
+  // parameters, so that of the three paths of sao_quad (off / band / edge) a wave runs the one its CTB takes - with 128 samples per wave row every wave
+  // straddled two CTBs and ran whatever both of them needed.  Wave w: luma columns (w & 1) * 64 .., rows (w >> 1) * 16 + lane / 16 + 4 rr; chroma alike.
+  const int wv = tid >> 6, ln = tid & 63;
+  const int tx = (wv & 1) * 64 + (ln & 15) * 4, ty = (wv >> 1) * 16 + (ln >> 4);
+  const int ctx = (wv & 1) * 32 + (ln & 7) * 4, cty = (wv >> 1) * 8 + (ln >> 3);
+  constexpr int RSTEP = 4;   // rows between a thread's luma quads
   const SaoComp<Pix> SB = sao_comp<Pix>(A, P, 1, MAY_KEEP, RESTRICTED), SR = sao_comp<Pix>(A, P, 2, MAY_KEEP, RESTRICTED);
   // ---- everything the tile needs from global memory is requested first: the SAO parameters of the thread's rows and the three source tiles
   constexpr int NL_Y = ((SAO_TH + 2) * ROW_WORDS + 255) / 256, NL_C = ((SAO_CH + 2) * CROW_WORDS + 255) / 256;
   uint32_t spw[SAO_RPT][3], spw_b[3], spw_r[3];
 #pragma unroll
-  for (int rr = 0; rr < SAO_RPT; rr++) sao_params_at(SY, ox_t + tx, oy_t + ty + rr * 8, spw[rr]);
+  for (int rr = 0; rr < SAO_RPT; rr++) sao_params_at(SY, ox_t + tx, oy_t + ty + rr * RSTEP, spw[rr]);
   sao_params_at(SB, ox_t / 2 + ctx, oy_t / 2 + cty, spw_b);
   sao_params_at(SR, ox_t / 2 + ctx, oy_t / 2 + cty, spw_r);
   uint32_t vy[NL_Y], vb[NL_C], vr[NL_C];
@@ -896,8 +914,8 @@ __global__ __launch_bounds__(256) SAO_RGB_OCCUPANCY void k_sao_rgb(FilterArgs A,
   int ynpx[SAO_RPT];
 #pragma unroll
   for (int rr = 0; rr < SAO_RPT; rr++) {
-    const int oy = oy_t + ty + rr * 8, ox0 = ox_t + tx;
-    ynpx[rr] = sao_quad<Pix, ROW_WORDS>(SY, tile, ab, ox0, oy, ty + rr * 8 + 1, spw[rr], yres[rr]);
+    const int oy = oy_t + ty + rr * RSTEP, ox0 = ox_t + tx;
+    ynpx[rr] = sao_quad<Pix, ROW_WORDS>(SY, tile, ab, ox0, oy, ty + rr * RSTEP + 1, spw[rr], yres[rr]);
     if (ynpx[rr]) sao_store(SY, ox0, oy, ynpx[rr], yres[rr]);
   }
   // ---- Cb, Cr: 64 x 16 samples each, one row of 4 samples per thread
@@ -919,7 +937,7 @@ __global__ __launch_bounds__(256) SAO_RGB_OCCUPANCY void k_sao_rgb(FilterArgs A,
   for (int rr = 0; rr < SAO_RPT; rr++) {
     const int npx = ynpx[rr];
     if (!npx) continue;
-    const int ly = ty + rr * 8, oy = oy_t + ly, ox0 = ox_t + tx;
+    const int ly = ty + rr * RSTEP, oy = oy_t + ly, ox0 = ox_t + tx;
     int R[4], G[4], B[4];
     // the two chroma samples under this thread's four luma samples (nearest neighbour: x / 2; tx is a multiple of 4): one 16-bit LDS read each
     const uint32_t cb2 = *(const uint16_t*)&chroma_s[0][ly >> 1][tx >> 1], cr2 = *(const uint16_t*)&chroma_s[1][ly >> 1][tx >> 1];
@@ -988,7 +1006,7 @@ void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool 
 
 void launch_sao_rgb(const FilterArgs& a, const void* color_params_dev, int n_pics, int max_out_w, int max_out_h, hipStream_t s, bool may_keep, bool restricted)
 {
-  const int tiles = ((max_out_w + SAO_TW - 1) / SAO_TW) * ((max_out_h + SAO_TH - 1) / SAO_TH);
+  const int tiles = (((max_out_w + SAO_TW - 1) / SAO_TW) * ((max_out_h + SAO_TH - 1) / SAO_TH) + 7) & ~7;   // (sao_tile_of_block)
 #define L_RGB(K, R) hipLaunchKernelGGL((k_sao_rgb<K, R>), dim3(tiles, n_pics), dim3(256), 0, s, a, (const colordev::ColorParams*)color_params_dev)
   HIPDEC_SAO_DISPATCH(L_RGB);
 #undef L_RGB
@@ -996,7 +1014,7 @@ void launch_sao_rgb(const FilterArgs& a, const void* color_params_dev, int n_pic
 
 void launch_sao(const FilterArgs& a, int n_pics, int max_out_w, int max_out_h, bool wide, hipStream_t s, bool may_keep, bool restricted)
 {
-  const int tiles = ((max_out_w + SAO_TW - 1) / SAO_TW) * ((max_out_h + SAO_TH - 1) / SAO_TH);
+  const int tiles = (((max_out_w + SAO_TW - 1) / SAO_TW) * ((max_out_h + SAO_TH - 1) / SAO_TH) + 7) & ~7;   // (sao_tile_of_block)
 #define L_16(K, R) hipLaunchKernelGGL((k_sao<uint16_t, K, R>), dim3(tiles, n_pics, 3), dim3(256), 0, s, a)
 #define L_8(K, R) hipLaunchKernelGGL((k_sao<uint8_t, K, R>), dim3(tiles, n_pics, 3), dim3(256), 0, s, a)
   if (wide) HIPDEC_SAO_DISPATCH(L_16); else HIPDEC_SAO_DISPATCH(L_8);

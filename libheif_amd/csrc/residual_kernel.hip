@@ -226,37 +226,50 @@ constexpr int m32(int j, int i)
 #else
 #define RES_UNROLL _Pragma("unroll")
 #endif
-// y[i] = sum_j E_N[j][i] x[j] as the even-odd butterfly: E_N[j][N - 1 - i] = (-1)^j E_N[j][i], and the even rows of E_N are E_(N/2), so
+// y[i] = rnd + sum_j E_N[j][i] x[j] as the even-odd butterfly: E_N[j][N - 1 - i] = (-1)^j E_N[j][i], and the even rows of E_N are E_(N/2), so
 //   y[k] = even[k] + odd[k], y[N - 1 - k] = even[k] - odd[k]   with even = the N/2-point transform of x[0], x[2], ... and odd[k] = sum over odd j.
 // All sums are exact 32-bit integers (|x| < 2^15, sum of |E| over a column < 2^12): the same numbers as the n-MACs-per-sample form.
-// x[j] = in[j * S]; every index is a compile-time constant after unrolling, so in / y live in registers; MACs are v_mad_i32_i24.
-template <int N, int S>
+// The inputs arrive PACKED in pairs that one v_dot2_i32_i16 consumes (two MACs per instruction against a constant pair), in the order the recursion
+// wants them - "butterfly order": the even-index inputs first (in the butterfly order of the half-size transform), then the odd ones as
+// (x1, x3), (x5, x7), ...  For N = 16: (x0, x8) (x4, x12) (x2, x6) (x10, x14) (x1, x3) (x5, x7) (x9, x11) (x13, x15).  The transposes through LDS
+// deliver that order for free: the writer of element j puts it at position bfly_pos(j) of its row.  16 points: 44 dot2 + 30 additions.
+constexpr uint32_t pk16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+__device__ __forceinline__ int bfly_pos(int j, int n)      // position of input j in the butterfly order of an n-point transform
+{
+  int base = 0;
+  for (; n > 2; n >>= 1) {
+    if (j & 1) return base + (n >> 1) + (j >> 1);
+    j >>= 1;
+  }
+  return base + j;
+}
+template <int N>
 struct Idct {
-  static __device__ __forceinline__ void run(const int* in, int* y)
+  static __device__ __forceinline__ void run(const uint32_t* p, int rnd, int* y)
   {
     int ev[N / 2];
-    Idct<N / 2, 2 * S>::run(in, ev);
+    Idct<N / 2>::run(p, rnd, ev);
     RES_UNROLL
     for (int k = 0; k < N / 2; k++) {
       int od = 0;
       RES_UNROLL
-      for (int j = 1; j < N; j += 2) od += __mul24(m32(j * (32 / N), k), in[j * S]);
+      for (int m = 0; m < N / 4; m++) od = dot2(p[N / 4 + m], pk16(m32((4 * m + 1) * (32 / N), k), m32((4 * m + 3) * (32 / N), k)), od);
       y[k] = ev[k] + od;
       y[N - 1 - k] = ev[k] - od;
     }
   }
 };
-template <int S>
-struct Idct<2, S> {
-  static __device__ __forceinline__ void run(const int* in, int* y) { const int a = in[0] * 64, b = in[S] * 64; y[0] = a + b; y[1] = a - b; }
+template <>
+struct Idct<2> {
+  static __device__ __forceinline__ void run(const uint32_t* p, int rnd, int* y) { y[0] = dot2(p[0], pk16(64, 64), rnd); y[1] = dot2(p[0], pk16(64, -64), rnd); }
 };
-// 4x4 DST-VII of intra luma blocks (8.6.4.2, equation 8-xxx: transMatrix rows {29 55 74 84} {74 74 0 -74} {84 -29 -74 55} {55 -84 74 -29})
-__device__ __forceinline__ void idst4(const int* x, int* y)
+// 4x4 DST-VII of intra luma blocks (8.6.4.2: transMatrix rows {29 55 74 84} {74 74 0 -74} {84 -29 -74 55} {55 -84 74 -29}); p = (x0, x2) (x1, x3)
+__device__ __forceinline__ void idst4(const uint32_t* p, int rnd, int* y)
 {
-  y[0] = __mul24(29, x[0]) + __mul24(74, x[1]) + __mul24(84, x[2]) + __mul24(55, x[3]);
-  y[1] = __mul24(55, x[0]) + __mul24(74, x[1]) - __mul24(29, x[2]) - __mul24(84, x[3]);
-  y[2] = __mul24(74, x[0]) - __mul24(74, x[2]) + __mul24(74, x[3]);
-  y[3] = __mul24(84, x[0]) - __mul24(74, x[1]) + __mul24(55, x[2]) - __mul24(29, x[3]);
+  y[0] = dot2(p[1], pk16(74, 55), dot2(p[0], pk16(29, 84), rnd));
+  y[1] = dot2(p[1], pk16(74, -84), dot2(p[0], pk16(55, -29), rnd));
+  y[2] = dot2(p[1], pk16(0, 74), dot2(p[0], pk16(74, -74), rnd));
+  y[3] = dot2(p[1], pk16(-74, -29), dot2(p[0], pk16(84, 55), rnd));
 }
 
 // what the kernel knows about its CTB / picture
@@ -335,8 +348,8 @@ __device__ __forceinline__ void residual_class(ResLds& L, const ResCtx& cx, int 
   static_assert(BPP * BS <= kSmallBufBytes, "a pass fits the wave's buffer");
   const int g = lane >> LG, r = lane & (N - 1);
   uint8_t* const blk = L.u.small.buf[wave] + g * BS;           // this lane's block
-  int16_t* const my_row = (int16_t*)(blk + r * (2 * N));
-  int16_t* const my_col = (int16_t*)blk + r;                   // element j of the column: my_col[j * N]
+  int16_t* const my_row = (int16_t*)(blk + r * (2 * N));      // row r of the block's N x N int16
+  int16_t* const my_pos = (int16_t*)blk + bfly_pos(r, N);      // this lane's slot in row j: my_pos[j * N]
   const int passes = (count + BPP - 1) / BPP;
   bool valid = false;
   BlkMeta bm{};
@@ -365,7 +378,7 @@ __device__ __forceinline__ void residual_class(ResLds& L, const ResCtx& cx, int 
     const RowRaw<N> cur = raw;
     const auto cur_m = mrow;
     if (q + 4 < passes) valid = fetch(q + 4, bm, raw, mrow);
-    // ---- scaling (8.6.3) of this lane's row, into LDS by rows ----
+    // ---- scaling (8.6.3) of this lane's row d[r][.]; element k goes to the thread of column k: row k of the buffer, slot bfly_pos(r) ----
     int d[N];
     RES_UNROLL
     for (int k = 0; k < N; k++) {
@@ -373,34 +386,31 @@ __device__ __forceinline__ void residual_class(ResLds& L, const ResCtx& cx, int 
       // flat lists: one of the two shifts is 0, and a left shift of the product is a left shift of the factor: (level * (f << ls) + rnd) >> rs
       d[k] = SL ? scale_level_sl(lev, (int)((cur_m.w[k >> 2] >> ((k & 3) * 8)) & 255u) * b.ls6, b.sh_r, b.sh_l, b.rnd)
                 : clip3(-32768, 32767, (__mul24(lev, b.ls6) + b.rnd) >> b.sh_r);
-    }
-    {
-      RowRaw<N> pk;
-      RES_UNROLL
-      for (int k = 0; k < N / 2; k++) pk.w[k] = pack16(d[2 * k], d[2 * k + 1]);
-      row_store<N>(my_row, pk);
+      my_pos[k * N] = (int16_t)d[k];
     }
     lds_sync();
-    // ---- first stage (columns): tmp[i][x] = clip16((sum_j E[j][i] d[j][x] + 64) >> 7), this lane owns column x = r ----
-    int x[N], y[N];
-    RES_UNROLL
-    for (int j = 0; j < N; j++) x[j] = my_col[j * N];
-    if (N == 4 && b.dst) idst4(x, y); else Idct<N, 1>::run(x, y);
-    RES_UNROLL
-    for (int i = 0; i < N; i++) my_col[i * N] = (int16_t)clip3(-32768, 32767, (y[i] + 64) >> 7);    // (the column is this lane's own: read above, written here)
-    lds_sync();
-    // ---- second stage (rows): res[y][i] = (sum_j E[j][i] tmp[y][j] + rnd) >> bdShift, this lane owns row y = r ----
+    // ---- first stage (columns): tmp[i][x] = clip16((sum_j E[j][i] d[j][x] + 64) >> 7), this lane owns column x = r: row r of the buffer holds
+    //      d[.][r] in butterfly order.  Its outputs go to the threads of the rows: row i of the buffer, slot bfly_pos(r).  (Reads of a wave complete before
+    //      its writes: the buffer is reused in place.)
+    int y[N];
     {
       const RowRaw<N> t = row_load<N>(my_row);
-      RES_UNROLL
-      for (int j = 0; j < N; j++) x[j] = row_get<N>(t, j);
+      if (N == 4 && b.dst) idst4(t.w, 64, y); else Idct<N>::run(t.w, 64, y);
     }
-    if (N == 4 && b.dst) idst4(x, y); else Idct<N, 1>::run(x, y);
+    lds_sync();
+    RES_UNROLL
+    for (int i = 0; i < N; i++) my_pos[i * N] = (int16_t)clip3(-32768, 32767, y[i] >> 7);
+    lds_sync();
+    // ---- second stage (rows): res[y][i] = (sum_j E[j][i] tmp[y][j] + rnd) >> bdShift, this lane owns row y = r ----
     const int rnd2 = 1 << (b.bd2 - 1);
+    {
+      const RowRaw<N> t = row_load<N>(my_row);
+      if (N == 4 && b.dst) idst4(t.w, rnd2, y); else Idct<N>::run(t.w, rnd2, y);
+    }
     RowRaw<N> out;
     RES_UNROLL
     for (int k = 0; k < N / 2; k++) {
-      int r0 = (y[2 * k] + rnd2) >> b.bd2, r1 = (y[2 * k + 1] + rnd2) >> b.bd2;
+      int r0 = y[2 * k] >> b.bd2, r1 = y[2 * k + 1] >> b.bd2;
       if (N == 4 && b.ts) { r0 = (d[2 * k] * 128 + rnd2) >> b.bd2; r1 = (d[2 * k + 1] * 128 + rnd2) >> b.bd2; }   // 8.6.4.2 with transform_skip_flag: r = d << 7
       out.w[k] = pack16(r0, r1);
     }
