@@ -11,6 +11,7 @@
 #include "hevc_headers.h"
 #include "kernels.h"
 #include "batch_layout.h"
+#include "color_device.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -351,7 +352,9 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
       if (P.transquant_bypass_enabled || (P.pcm_enabled && P.pcm_loop_filter_disabled)) may_keep = true;
       if (!P.sao_free_neighbours) restricted = true;
     }
-    if (fused_rgb_params) launch_sao_rgb(fa, fused_rgb_params, n, b.max_ow, b.max_oh, ps, may_keep, restricted);   // SAO + crop + RGB24 in one pass
+    if (fused_rgb_params)   // SAO + crop + RGB24 in one pass
+      launch_sao_rgb(fa, fused_rgb_params, n, b.max_ow, b.max_oh, ps, may_keep, restricted, b.params.data(),
+                     b.color.host.size() == (size_t)n * sizeof(colordev::ColorParams) ? b.color.host.data() : nullptr);
     else launch_sao(fa, n, b.max_ow, b.max_oh, b.wide, ps, may_keep, restricted);
   }
   HIPDEC_CHECK_HIP(hipEventRecord(ev[5], ps));

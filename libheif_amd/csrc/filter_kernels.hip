@@ -864,13 +864,16 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
 // plugin ABI hands those to libheif — and emits the tile's interleaved RGB24 from registers + LDS.  Against k_sao + k_ycbcr_to_rgb_batch
 // this saves the colour pass's 1.5 B/px re-read of the planes and one launch.  Same arithmetic: colordev::convert_px.
 constexpr int SAO_CW = SAO_TW / 2, SAO_CH = SAO_TH / 2;
+constexpr int SAO_TPW = 4;   // tiles per workgroup of k_sao_rgb / k_sao_rgb_lean
 #if !defined(HIPDEC_HOST_EMU) && defined(HIPDEC_SAO_RGB_OCC7)
 #define SAO_RGB_OCCUPANCY __attribute__((amdgpu_waves_per_eu(7, 8)))   // <= 72 VGPRs (measurement build: costs 12 - 40 B of scratch per lane)
 #else
 #define SAO_RGB_OCCUPANCY
 #endif
+__host__ __device__ inline bool sao_rgb_pic_is_lean(const PicParams& P, const colordev::ColorParams& cp);   // (below, with k_sao_rgb_lean)
+// skip_lean: the launch is paired with k_sao_rgb_lean, which takes the pictures that qualify for it
 template <bool MAY_KEEP, bool RESTRICTED>
-__global__ __launch_bounds__(256) SAO_RGB_OCCUPANCY void k_sao_rgb(FilterArgs A, const colordev::ColorParams* __restrict__ cps)
+__global__ __launch_bounds__(256) SAO_RGB_OCCUPANCY void k_sao_rgb(FilterArgs A, const colordev::ColorParams* __restrict__ cps, int skip_lean)
 {
   typedef uint8_t Pix;
   constexpr int ROW_WORDS = ((SAO_TW + 2) + 3) / 4 + 2;
@@ -880,12 +883,15 @@ __global__ __launch_bounds__(256) SAO_RGB_OCCUPANCY void k_sao_rgb(FilterArgs A,
   __shared__ __attribute__((aligned(4))) uint8_t chroma_s[2][SAO_CH][SAO_CW];   // (read back two samples at a time)
   if (*A.status != 0) return;
   const PicParams& P = A.pics[blockIdx.y];
+  if (skip_lean && sao_rgb_pic_is_lean(P, cps[blockIdx.y])) return;
   const SaoComp<Pix> SY = sao_comp<Pix>(A, P, 0, MAY_KEEP, RESTRICTED);
   const int tiles_x = (SY.ow + SAO_TW - 1) / SAO_TW, tiles_y = (SY.oh + SAO_TH - 1) / SAO_TH;
-  const int tile_idx = sao_tile_of_block(tiles_x * tiles_y);
-  if (tile_idx < 0) return;
-  const int ox_t = (tile_idx % tiles_x) * SAO_TW, oy_t = (tile_idx / tiles_x) * SAO_TH;
+  const int n_tiles = tiles_x * tiles_y;
+  const int group = sao_tile_of_block((n_tiles + SAO_TPW - 1) / SAO_TPW);   // SAO_TPW consecutive tiles per workgroup (a quarter of the workgroups to dispatch)
+  if (group < 0) return;
   const int tid = threadIdx.x;
+  for (int tile_idx = group * SAO_TPW; tile_idx < (group + 1) * SAO_TPW && tile_idx < n_tiles; tile_idx++) {
+  const int ox_t = (tile_idx % tiles_x) * SAO_TW, oy_t = (tile_idx / tiles_x) * SAO_TH;
   // A wave stays inside ONE CTB column (64 luma samples wide, CTB 64 and an aligned crop: the benchmarked streams): its lanes then share the CTB's SAO
   // parameters, so that of the three paths of sao_quad (off / band / edge) a wave runs the one its CTB takes - with 128 samples per wave row every wave
   // straddled two CTBs and ran whatever both of them needed.  Wave w: luma columns (w & 1) * 64 .., rows (w >> 1) * 16 + lane / 16 + 4 rr; chroma alike.
@@ -966,6 +972,274 @@ __global__ __launch_bounds__(256) SAO_RGB_OCCUPANCY void k_sao_rgb(FilterArgs A,
       for (int i = 0; i < npx; i++) { o[3 * i] = (uint8_t)R[i]; o[3 * i + 1] = (uint8_t)G[i]; o[3 * i + 2] = (uint8_t)B[i]; }
     }
   }
+  lds_barrier();   // the next tile overwrites the staged tiles
+  }
+}
+
+// ---- the lean form of k_sao_rgb --------------------------------------------------------------------------------------------------------------------
+// k_sao_rgb spends 1.7 vector wave-instructions per pixel (109 lane operations: byte-wise LDS reads with run-time neighbour offsets, compare /
+// select chains, per-sample colour arithmetic) and is bound by vector issue at 43 ms per 2048 4K stills (30 % of the HBM roofline; its fetched bytes
+// are at the algorithmic figure since the XCD-aware tile order).  Tiles in the INTERIOR of a plain 8-bit 4:2:0 picture (the tile inside the output
+// and one sample away from the picture's borders, no lossless / unfiltered PCM units, neighbours free, integer RGB24 arithmetic, aligned crop) take this
+// kernel instead: four samples per operation.
+//   * a quad is ONE LDS dword; its two edge neighbours are dword reads at byte addresses (gfx950 reads LDS dwords at any alignment,
+//     tools/ubench/lds_unaligned.hip) - 3 reads instead of 12;
+//   * the four bytes are split into two registers of 2 x 16 bits (samples 0, 2 / samples 1, 3: v_perm_b32) and everything runs on v_pk_*_i16: the
+//     two signs are clamps of differences, edgeIdx - or the band index - of the four samples becomes the SELECTOR of one v_perm_b32 that looks the four
+//     offsets up in an 8-byte table built once per thread from the CTB's parameters (edge: o0 o1 0 o2 o3, band: o0 o1 o2 o3 0), and the offsets are added
+//     and clipped as pairs;
+//   * the chroma threads leave the three colour terms of their samples ((i_r_cr (Cr - 128) + 128) >> 8 ...: yuv2rgb.cc:377-421, 32-bit arithmetic as
+//     there) in LDS as 16-bit pairs, so that R, G, B of a luma quad are three packed additions with clamps per register, and three v_perm_b32
+//     interleave them into the 12 bytes of RGB24.
+// About 30 lane operations per pixel.  Everything else of the tile - staging, the planes it writes, the arithmetic results - is k_sao_rgb's; tiles that do
+// not qualify are left to it (launch_sao_rgb runs both; each returns at once from the other's tiles).
+namespace swar {
+#ifndef HIPDEC_HOST_EMU
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+#define HIPDEC_SWAR_PK(NAME, INSN)                                                                                                              \
+  __device__ __forceinline__ uint32_t NAME(uint32_t a, uint32_t b) { uint32_t r; asm(INSN " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }  \
+  __device__ __forceinline__ uint32_t NAME##_c(uint32_t a, uint32_t b) { uint32_t r; asm(INSN " %0, %1, %2" : "=v"(r) : "v"(a), "s"(b)); return r; }   // b: a wave-uniform constant pair
+HIPDEC_SWAR_PK(pk_add, "v_pk_add_i16") HIPDEC_SWAR_PK(pk_sub, "v_pk_sub_i16") HIPDEC_SWAR_PK(pk_max, "v_pk_max_i16") HIPDEC_SWAR_PK(pk_min, "v_pk_min_i16")
+#undef HIPDEC_SWAR_PK
+struct __attribute__((packed)) U1 { uint32_t v; };
+__device__ __forceinline__ uint32_t lds32u(const uint8_t* p) { return ((const U1*)p)->v; }   // any alignment: one ds_read_b32
+#else   // CPU-test build: the same operations spelled out
+inline uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)   // v_perm_b32: byte i of the result = byte sel[i] of {hi, lo}; 8 .. 11: the sign of byte 1 / 3 / 5 / 7; 12: 0; >= 13: 0xff
+{
+  const uint64_t in = ((uint64_t)hi << 32) | lo;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; i++) {
+    const uint32_t k = (sel >> (8 * i)) & 255u;
+    uint32_t b;
+    if (k < 8) b = (uint32_t)(in >> (8 * k)) & 255u;
+    else if (k < 12) b = ((in >> (16 * (k - 8) + 15)) & 1u) ? 255u : 0u;
+    else b = k == 12 ? 0u : 255u;
+    r |= b << (8 * i);
+  }
+  return r;
+}
+#define HIPDEC_SWAR_PK(NAME, EXPR)                                                                              \
+  inline uint32_t NAME(uint32_t a, uint32_t b)                                                                  \
+  {                                                                                                             \
+    uint32_t r = 0;                                                                                             \
+    for (int h = 0; h < 2; h++) { const int x = (int16_t)(a >> (16 * h)), y = (int16_t)(b >> (16 * h)); r |= ((uint32_t)(EXPR) & 0xffffu) << (16 * h); }  \
+    return r;                                                                                                   \
+  }                                                                                                             \
+  inline uint32_t NAME##_c(uint32_t a, uint32_t b) { return NAME(a, b); }
+HIPDEC_SWAR_PK(pk_add, x + y) HIPDEC_SWAR_PK(pk_sub, x - y) HIPDEC_SWAR_PK(pk_max, x > y ? x : y) HIPDEC_SWAR_PK(pk_min, x < y ? x : y)
+#undef HIPDEC_SWAR_PK
+inline uint32_t lds32u(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+#endif
+constexpr uint32_t kEven = 0x0c020c00u, kOdd = 0x0c030c01u;   // bytes 0, 2 / 1, 3 of a dword as two zero-extended 16-bit values
+constexpr uint32_t kSextOdd = 0x09030801u;                   // bytes 1, 3 as two SIGN-extended 16-bit values
+}  // namespace swar
+
+// does picture P (with colour stage cp) take the lean kernel?  The same answer on the host (launch_sao_rgb) and in both kernels.
+__host__ __device__ inline bool sao_rgb_pic_is_lean(const PicParams& P, const colordev::ColorParams& cp)
+{
+  return P.chroma_format_idc == 1 && P.bit_depth_luma == 8 && P.bit_depth_chroma == 8 &&
+         P.transquant_bypass_enabled == 0 && !(P.pcm_enabled && P.pcm_loop_filter_disabled) && P.sao_free_neighbours != 0 &&
+         (cp.arith == colordev::AR_INT88 || cp.arith == colordev::AR_FLOAT) && cp.bpp == 8 && ((cp.os | (uintptr_t)cp.o0) & 3) == 0 &&
+         (P.crop_x & 7) == 0 && (P.crop_y & 31) == 0 && P.log2_ctb >= 5 &&                  // quads are LDS dwords, a tile's 32 rows share one CTB row
+         (P.out_width & 7) == 0 && (P.out_height & 1) == 0 && (P.width & 7) == 0 && (P.height & 1) == 0;   // a quad is inside the output or outside it, luma and chroma
+}
+// a CTB's SAO parameters as the lean kernel wants them
+struct SaoLeanTab { uint32_t lo, hi, cls2; int type, cls, a_off; };
+__device__ __forceinline__ SaoLeanTab sao_lean_tab(const uint32_t w[3], int rowb)
+{
+  SaoLeanTab t;
+  t.type = (int)(w[0] & 255u);
+  const int cls = (int)((w[0] >> 8) & 255u);
+  t.cls = cls;
+  // the low bytes of the four offsets (SaoOffsetVal fits a signed byte at 8 bits): o0 = w0 >> 16, o1 = w1 & 0xffff, o2 = w1 >> 16, o3 = w2 & 0xffff
+  const uint32_t p3 = swar::perm(w[1], w[0], 0x0c060402u);            // o0 o1 o2 -
+  const uint32_t p4 = swar::perm(w[2], p3, 0x04020100u);              // o0 o1 o2 o3
+  const bool edge = t.type == 2, band = t.type == 1;
+  t.lo = edge ? swar::perm(0u, p4, 0x020c0100u) : (band ? p4 : 0u);   // edge: edgeIdx' 0 1 2 3 4 -> o0 o1 0 o2 o3 (8.7.3.2); band: k 0 .. 3 -> o0 .. o3, 4 -> 0
+  t.hi = edge ? (p4 >> 24) : 0u;
+  t.cls2 = (uint32_t)cls * 0x00010001u;                               // band: sao_band_position for both halves
+  const int hx = cls == 1 ? 0 : (cls == 3 ? 1 : -1), hy = cls == 0 ? 0 : -1;   // edge: the first neighbour (the second one is its mirror image)
+  t.a_off = hy * rowb + hx;
+  return t;
+}
+// SAO of the four samples at byte `base` of the staged tile `tb`: returns them as four bytes and as 16-bit pairs (samples 0, 2 / 1, 3).
+// keep: bytes 0xff where an edge-offset sample stays as it is because a neighbour lies outside the picture (8.7.3: picture-border samples; 0 inside)
+__device__ __forceinline__ uint32_t sao_quad_lean(const uint8_t* tb, int base, const SaoLeanTab& t, uint32_t keep, uint32_t& rlo, uint32_t& rhi)
+{
+  using namespace swar;
+  const uint32_t v = lds32u(tb + base);
+  const uint32_t vlo = perm(0u, v, kEven), vhi = perm(0u, v, kOdd);
+  uint32_t sel = 0;
+  if (t.type == 2) {
+    const uint32_t a = lds32u(tb + base + t.a_off), b = lds32u(tb + base - t.a_off);
+    const uint32_t alo = perm(0u, a, kEven), ahi = perm(0u, a, kOdd), blo = perm(0u, b, kEven), bhi = perm(0u, b, kOdd);
+    // Sign(v - a) + Sign(v - b) + 2 per sample: 0 .. 4
+    const uint32_t slo = pk_add(pk_min_c(pk_max_c(pk_sub(vlo, alo), 0xffffffffu), 0x00010001u), pk_min_c(pk_max_c(pk_sub(vlo, blo), 0xffffffffu), 0x00010001u));
+    const uint32_t shi = pk_add(pk_min_c(pk_max_c(pk_sub(vhi, ahi), 0xffffffffu), 0x00010001u), pk_min_c(pk_max_c(pk_sub(vhi, bhi), 0xffffffffu), 0x00010001u));
+    sel = pk_add_c(slo, 0x00020002u) | (pk_add_c(shi, 0x00020002u) << 8);
+    sel = (sel & ~keep) | (0x02020202u & keep);        // edgeIdx' 2: offset 0
+  } else if (t.type == 1) {
+    // band position relative to sao_band_position, bands 4 .. 31 share the table's zero
+    const uint32_t klo = pk_min_c(pk_sub((vlo >> 3) & 0x001f001fu, t.cls2) & 0x001f001fu, 0x00040004u);
+    const uint32_t khi = pk_min_c(pk_sub((vhi >> 3) & 0x001f001fu, t.cls2) & 0x001f001fu, 0x00040004u);
+    sel = klo | (khi << 8);
+  }
+  const uint32_t off4 = perm(t.hi, t.lo, sel);            // the four offsets, signed bytes
+  const uint32_t off4s = off4 << 8;
+  const uint32_t olo = perm(off4s, off4s, kSextOdd), ohi = perm(off4, off4, kSextOdd);
+  rlo = pk_min_c(pk_max_c(pk_add(vlo, olo), 0u), 0x00ff00ffu);
+  rhi = pk_min_c(pk_max_c(pk_add(vhi, ohi), 0u), 0x00ff00ffu);
+  return rlo | (rhi << 8);
+}
+// the keep mask of a quad whose first sample is (x0, y) in a component plane of W x H samples (tiles at the picture's border only)
+__device__ __forceinline__ uint32_t sao_lean_keep(const SaoLeanTab& t, int x0, int y, int W, int H)
+{
+  const bool hx = t.cls != 1, hy = t.cls != 0;         // the class looks left / right, up / down
+  uint32_t keep = 0;
+  if (hx && x0 == 0) keep |= 0x000000ffu;
+  if (hx && x0 + 4 == W) keep |= 0xff000000u;
+  if (hy && (y == 0 || y == H - 1)) keep = 0xffffffffu;
+  return keep;
+}
+
+__global__ __launch_bounds__(256) void k_sao_rgb_lean(FilterArgs A, const colordev::ColorParams* __restrict__ cps)
+{
+  typedef uint8_t Pix;
+  constexpr int ROW_WORDS = ((SAO_TW + 2) + 3) / 4 + 2, ROWB = ROW_WORDS * 4;
+  constexpr int CROW_WORDS = ((SAO_CW + 2) + 3) / 4 + 2, CROWB = CROW_WORDS * 4;
+  // (one word in front of each staged tile: at the picture's left / upper border a neighbour read reaches one byte in front of it - the sample is masked)
+  __shared__ uint32_t tile_buf[1 + (SAO_TH + 2) * ROW_WORDS];
+  __shared__ uint32_t tile_c_buf[2][1 + (SAO_CH + 2) * CROW_WORDS];
+  // the colour terms of the tile's chroma positions: integer arithmetic R, G, B as 16-bit values; float arithmetic f_r_cr cr, f_g_cb cb, f_g_cr cr, f_b_cb cb
+  __shared__ union { int16_t i[3][SAO_CH][SAO_CW]; float4 f[SAO_CH][SAO_CW]; } term;
+  uint32_t* const tile = tile_buf + 1;
+  if (*A.status != 0) return;
+  const PicParams& P = A.pics[blockIdx.y];
+  const colordev::ColorParams cp = cps[blockIdx.y];
+  if (!sao_rgb_pic_is_lean(P, cp)) return;
+  const int tiles_x = (P.out_width + SAO_TW - 1) / SAO_TW, tiles_y = (P.out_height + SAO_TH - 1) / SAO_TH, n_tiles = tiles_x * tiles_y;
+  const int group = sao_tile_of_block((n_tiles + SAO_TPW - 1) / SAO_TPW);
+  if (group < 0) return;
+  const SaoComp<Pix> SY = sao_comp<Pix>(A, P, 0, false, false), SB = sao_comp<Pix>(A, P, 1, false, false), SR = sao_comp<Pix>(A, P, 2, false, false);
+  const int tid = threadIdx.x;
+  // thread -> samples as in k_sao_rgb: a wave stays inside one CTB column
+  const int wv = tid >> 6, ln = tid & 63;
+  const int tx = (wv & 1) * 64 + (ln & 15) * 4, ty = (wv >> 1) * 16 + (ln >> 4);
+  const int ctx = (wv & 1) * 32 + (ln & 7) * 4, cty = (wv >> 1) * 8 + (ln >> 3);
+  constexpr int RSTEP = 4;
+  const bool int88 = cp.arith == colordev::AR_INT88;
+  const int first = group * SAO_TPW, last = (group + 1) * SAO_TPW < n_tiles ? (group + 1) * SAO_TPW : n_tiles;
+  // what a tile needs from global memory - the SAO parameters of the thread's CTBs and its words of the three source tiles - is requested one tile AHEAD:
+  // while a tile is worked on, the next one's loads are in flight (with 5 workgroups per CU and a load - barrier - arithmetic - barrier sequence per
+  // tile the kernel waited for memory most of the time)
+  constexpr int NL_Y = ((SAO_TH + 2) * ROW_WORDS + 255) / 256, NL_C = ((SAO_CH + 2) * CROW_WORDS + 255) / 256;
+  uint32_t vy[NL_Y], vb[NL_C], vr[NL_C], spw_y[3], spw_b[3], spw_r[3];
+  auto request = [&](int t) {
+    const int ox = (t % tiles_x) * SAO_TW, oy = (t / tiles_x) * SAO_TH;
+    sao_params_at(SY, ox + tx, oy + ty, spw_y);
+    sao_params_at(SB, ox / 2 + ctx, oy / 2 + cty, spw_b);
+    sao_params_at(SR, ox / 2 + ctx, oy / 2 + cty, spw_r);
+    (void)sao_stage_load<Pix, SAO_TH, ROW_WORDS, 256, NL_Y>(SY, ox, oy, tid, vy);
+    (void)sao_stage_load<Pix, SAO_CH, CROW_WORDS, 256, NL_C>(SB, ox / 2, oy / 2, tid, vb);
+    (void)sao_stage_load<Pix, SAO_CH, CROW_WORDS, 256, NL_C>(SR, ox / 2, oy / 2, tid, vr);
+  };
+  request(first);
+  for (int tile_idx = first; tile_idx < last; tile_idx++) {
+    const int ox_t = (tile_idx % tiles_x) * SAO_TW, oy_t = (tile_idx / tiles_x) * SAO_TH;
+    const int xs0 = ox_t + SY.crop_xc, ys0 = oy_t + SY.crop_yc, cxs0 = xs0 >> 1, cys0 = ys0 >> 1;
+    sao_stage_store<SAO_TH, ROW_WORDS, 256, NL_Y>(tile, tid, vy);
+    sao_stage_store<SAO_CH, CROW_WORDS, 256, NL_C>(tile_c_buf[0] + 1, tid, vb);
+    sao_stage_store<SAO_CH, CROW_WORDS, 256, NL_C>(tile_c_buf[1] + 1, tid, vr);
+    const SaoLeanTab ty_tab = sao_lean_tab(spw_y, ROWB), tb_tab = sao_lean_tab(spw_b, CROWB), tr_tab = sao_lean_tab(spw_r, CROWB);
+    lds_barrier();
+    if (tile_idx + 1 < last) request(tile_idx + 1);
+    // the staged rows start at byte ab of the plane's rows (4 bytes left of the tile's first sample; 0 at the picture's left border), one row above the tile
+    const int xoff = xs0 - (xs0 > 0 ? xs0 - 4 : 0), cxoff = cxs0 - (cxs0 > 0 ? cxs0 - 4 : 0);
+    // a tile at a border of the picture or of the output: quads outside the output are not stored, edge-offset samples at the picture's border are kept
+    const bool border = xs0 == 0 || xs0 + SAO_TW >= SY.W || ys0 == 0 || ys0 + SAO_TH >= SY.H || ox_t + SAO_TW > SY.ow || oy_t + SAO_TH > SY.oh;
+    // ---- luma: four quads, rows ty + 4 rr
+    uint32_t ylo[SAO_RPT], yhi[SAO_RPT];
+    const bool col_ok = !border || ox_t + tx + 4 <= SY.ow;
+#pragma unroll
+    for (int rr = 0; rr < SAO_RPT; rr++) {
+      const int ly = ty + rr * RSTEP;
+      const uint32_t keep = border ? sao_lean_keep(ty_tab, xs0 + tx, ys0 + ly, SY.W, SY.H) : 0u;
+      const uint32_t r4 = sao_quad_lean((const uint8_t*)tile, (ly + 1) * ROWB + tx + xoff, ty_tab, keep, ylo[rr], yhi[rr]);
+      if (col_ok && (!border || oy_t + ly < SY.oh)) *(uint32_t*)(SY.out + (size_t)(oy_t + ly) * SY.os + ox_t + tx) = r4;
+    }
+    // ---- Cb, Cr: one quad each, and the colour terms of its four positions
+    uint32_t c4[2];
+    const bool c_ok = !border || (ox_t / 2 + ctx + 4 <= SB.ow && oy_t / 2 + cty < SB.oh);
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const SaoComp<Pix>& SC = c == 0 ? SB : SR;
+      const SaoLeanTab& tab = c == 0 ? tb_tab : tr_tab;
+      const uint32_t keep = border ? sao_lean_keep(tab, cxs0 + ctx, cys0 + cty, SC.W, SC.H) : 0u;
+      uint32_t lo, hi;
+      c4[c] = sao_quad_lean((const uint8_t*)(tile_c_buf[c] + 1), (cty + 1) * CROWB + ctx + cxoff, tab, keep, lo, hi);
+      if (c_ok) *(uint32_t*)(SC.out + (size_t)(oy_t / 2 + cty) * SC.os + ox_t / 2 + ctx) = c4[c];
+    }
+    if (int88) {
+      int tr[4], tg[4], tb[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {   // yuv2rgb.cc:377-421
+        const int cb = (int)((c4[0] >> (8 * k)) & 255u) - 128, cr = (int)((c4[1] >> (8 * k)) & 255u) - 128;
+        tr[k] = (cp.i_r_cr * cr + 128) >> 8;
+        tg[k] = (cp.i_g_cb * cb + cp.i_g_cr * cr + 128) >> 8;
+        tb[k] = (cp.i_b_cb * cb + 128) >> 8;
+      }
+      *(uint2*)&term.i[0][cty][ctx] = make_uint2(((uint32_t)tr[0] & 0xffffu) | ((uint32_t)tr[1] << 16), ((uint32_t)tr[2] & 0xffffu) | ((uint32_t)tr[3] << 16));
+      *(uint2*)&term.i[1][cty][ctx] = make_uint2(((uint32_t)tg[0] & 0xffffu) | ((uint32_t)tg[1] << 16), ((uint32_t)tg[2] & 0xffffu) | ((uint32_t)tg[3] << 16));
+      *(uint2*)&term.i[2][cty][ctx] = make_uint2(((uint32_t)tb[0] & 0xffffu) | ((uint32_t)tb[1] << 16), ((uint32_t)tb[2] & 0xffffu) | ((uint32_t)tb[3] << 16));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {   // yuv2rgb.cc:267-282, the products of colordev::convert_px's float arm (8 bits: halfRange 128)
+        float cb = (float)((int)((c4[0] >> (8 * k)) & 255u) - 128), cr = (float)((int)((c4[1] >> (8 * k)) & 255u) - 128);
+        if (!cp.full_range) { cb = cb * 1.1429f; cr = cr * 1.1429f; }
+        term.f[cty][ctx + k] = make_float4(cp.f_r_cr * cr, cp.f_g_cb * cb, cp.f_g_cr * cr, cp.f_b_cb * cb);
+      }
+    }
+    lds_barrier();
+    // ---- RGB24 of the luma quads (nearest-neighbour chroma: samples 0, 1 take the terms of chroma position tx / 2, samples 2, 3 those of the next one)
+#pragma unroll
+    for (int rr = 0; rr < SAO_RPT; rr++) {
+      using namespace swar;
+      const int ly = ty + rr * RSTEP;
+      colordev::U3 v;
+      if (int88) {
+        // exactly the pairing of the 16-bit halves: (Y0, Y2) and (Y1, Y3) both add the pair (term(c0), term(c1))
+        const uint32_t t_r = *(const uint32_t*)&term.i[0][ly >> 1][tx >> 1], t_g = *(const uint32_t*)&term.i[1][ly >> 1][tx >> 1], t_b = *(const uint32_t*)&term.i[2][ly >> 1][tx >> 1];
+        const uint32_t r_lo = pk_min_c(pk_max_c(pk_add(ylo[rr], t_r), 0u), 0x00ff00ffu), r_hi = pk_min_c(pk_max_c(pk_add(yhi[rr], t_r), 0u), 0x00ff00ffu);
+        const uint32_t g_lo = pk_min_c(pk_max_c(pk_add(ylo[rr], t_g), 0u), 0x00ff00ffu), g_hi = pk_min_c(pk_max_c(pk_add(yhi[rr], t_g), 0u), 0x00ff00ffu);
+        const uint32_t b_lo = pk_min_c(pk_max_c(pk_add(ylo[rr], t_b), 0u), 0x00ff00ffu), b_hi = pk_min_c(pk_max_c(pk_add(yhi[rr], t_b), 0u), 0x00ff00ffu);
+        const uint32_t rg_lo = r_lo | (g_lo << 8);   // R0 G0 R2 G2
+        const uint32_t br_x = b_lo | (r_hi << 8);    // B0 R1 B2 R3
+        const uint32_t gb_hi = g_hi | (b_hi << 8);   // G1 B1 G3 B3
+        v.a = perm(br_x, rg_lo, 0x05040100u);        // R0 G0 B0 R1
+        v.b = perm(gb_hi, rg_lo, 0x03020504u);       // G1 B1 R2 G2
+        v.c = perm(gb_hi, br_x, 0x07060302u);        // B2 R3 G3 B3
+      } else {
+        const float4 t0 = term.f[ly >> 1][tx >> 1], t1 = term.f[ly >> 1][(tx >> 1) + 1];
+        int R[4], G[4], B[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int Y = (int)(((i & 1) ? yhi[rr] : ylo[rr]) >> ((i >> 1) * 16)) & 255;
+          const float4 t = (i >> 1) ? t1 : t0;
+          float yv = (float)Y;
+          if (!cp.full_range) yv = (yv - 16.0f) * 1.1689f;
+          R[i] = colordev::clip_f(yv + t.x, 255);
+          G[i] = colordev::clip_f(yv + t.y + t.z, 255);
+          B[i] = colordev::clip_f(yv + t.w, 255);
+        }
+        v.a = R[0] | (G[0] << 8) | (B[0] << 16) | ((uint32_t)R[1] << 24);
+        v.b = G[1] | (B[1] << 8) | (R[2] << 16) | ((uint32_t)G[2] << 24);
+        v.c = B[2] | (R[3] << 8) | (G[3] << 16) | ((uint32_t)B[3] << 24);
+      }
+      if (col_ok && (!border || oy_t + ly < SY.oh))
+        *(HIPDEC_GLOBAL colordev::U3*)((HIPDEC_GLOBAL uint8_t*)cp.o0 + (size_t)(oy_t + ly) * cp.os + (size_t)(ox_t + tx) * 3) = v;
+    }
+    lds_barrier();   // the next tile overwrites the staged tiles and the terms
+  }
 }
 
 void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool wide, hipStream_t s, bool one_pass)
@@ -1004,11 +1278,25 @@ void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool 
     else { LAUNCH(false, false); }                           \
   } while (0)
 
-void launch_sao_rgb(const FilterArgs& a, const void* color_params_dev, int n_pics, int max_out_w, int max_out_h, hipStream_t s, bool may_keep, bool restricted)
+void launch_sao_rgb(const FilterArgs& a, const void* color_params_dev, int n_pics, int max_out_w, int max_out_h, hipStream_t s, bool may_keep, bool restricted,
+                    const PicParams* host_pics, const void* host_color_params)
 {
-  const int tiles = (((max_out_w + SAO_TW - 1) / SAO_TW) * ((max_out_h + SAO_TH - 1) / SAO_TH) + 7) & ~7;   // (sao_tile_of_block)
-#define L_RGB(K, R) hipLaunchKernelGGL((k_sao_rgb<K, R>), dim3(tiles, n_pics), dim3(256), 0, s, a, (const colordev::ColorParams*)color_params_dev)
-  HIPDEC_SAO_DISPATCH(L_RGB);
+  const int n_tiles = ((max_out_w + SAO_TW - 1) / SAO_TW) * ((max_out_h + SAO_TH - 1) / SAO_TH);
+  const int tiles = ((n_tiles + SAO_TPW - 1) / SAO_TPW + 7) & ~7;   // workgroups: SAO_TPW tiles each, a multiple of 8 (sao_tile_of_block)
+  // the lean kernel takes plain 8-bit 4:2:0 pictures (sao_rgb_pic_is_lean), the general one the rest; each returns at once from the other's pictures, and a
+  // kernel without a picture is not launched when the host copies of the parameter blocks say so
+  static const bool no_lean = getenv("HIPDEC_SAO_NO_LEAN") != nullptr;   // A/B knob
+  const int skip_lean = no_lean ? 0 : 1;
+  bool any_lean = skip_lean != 0, any_general = true;
+  if (skip_lean && host_pics && host_color_params) {
+    any_lean = any_general = false;
+    for (int i = 0; i < n_pics; i++) {
+      if (sao_rgb_pic_is_lean(host_pics[i], ((const colordev::ColorParams*)host_color_params)[i])) any_lean = true; else any_general = true;
+    }
+  }
+  if (any_lean) hipLaunchKernelGGL(k_sao_rgb_lean, dim3(tiles, n_pics), dim3(256), 0, s, a, (const colordev::ColorParams*)color_params_dev);
+#define L_RGB(K, R) hipLaunchKernelGGL((k_sao_rgb<K, R>), dim3(tiles, n_pics), dim3(256), 0, s, a, (const colordev::ColorParams*)color_params_dev, skip_lean)
+  if (any_general) HIPDEC_SAO_DISPATCH(L_RGB);
 #undef L_RGB
 }
 

@@ -56,7 +56,9 @@ void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool 
 // restricted = false: every picture has PicParams::sao_free_neighbours (no slice / tile boundary restricts the edge-offset neighbours)
 void launch_sao(const FilterArgs& a, int n_pics, int max_out_w, int max_out_h, bool wide, hipStream_t s, bool may_keep = true, bool restricted = true);
 // SAO + crop with the RGB24 emission fused into the store path (8-bit 4:2:0 only); color_params_dev: one colordev::ColorParams per picture
-void launch_sao_rgb(const FilterArgs& a, const void* color_params_dev, int n_pics, int max_out_w, int max_out_h, hipStream_t s, bool may_keep = true, bool restricted = true);
+// host_pics / host_color_params: the host's copies of the n_pics parameter blocks (may be null): which of the two kernels the batch needs
+void launch_sao_rgb(const FilterArgs& a, const void* color_params_dev, int n_pics, int max_out_w, int max_out_h, hipStream_t s, bool may_keep = true, bool restricted = true,
+                    const PicParams* host_pics = nullptr, const void* host_color_params = nullptr);
 
 // Chain batches (BatchLayout::chain; used by decoder.hip:launch_all and by the CPU-test emulation).  The motion fields of motion step k: k_motion over
 // the CTB rows of the step's pictures (rows of intra pictures return at once).  Needs the parser's output and the motion fields of earlier steps only.

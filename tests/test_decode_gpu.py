@@ -429,3 +429,23 @@ def test_run_rgb_fused_sao_colour_equals_the_two_step_path(cfg):
         t = f.kernel_timing_us()
         assert (t["colour"] == 0.0) == (bd == 8)               # fused: no separate colour kernel was timed
         a.free(); f.free()
+
+
+@pytest.mark.parametrize("size", [(128, 32), (136, 66), (264, 98), (392, 130), (256, 64), (520, 34)], ids=lambda s: "%dx%d" % s)
+@pytest.mark.parametrize("cfg", [dict(vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1, stress=1), dict(stress=1, qp=34), dict(vui_matrix=1, vui_full_range=0, qp=20)],
+                         ids=["int88", "float_default", "float_bt709"])
+def test_run_rgb_lean_kernel_at_picture_and_output_borders(size, cfg):
+    """k_sao_rgb_lean (filter_kernels.hip): pictures whose tiles are ALL border tiles in one way or another - one tile column (the picture's left and
+    right border in the same tile), widths that are multiples of 8 but not of the 128-sample tile (quads outside the output), heights that end inside a
+    tile, edge offsets against the picture's four borders - planes against the oracle, RGB against the two-step path (k_sao + the batched colour kernel)"""
+    from libheif_amd.decoder import Batch
+    w, h = size
+    streams = [orc.encode(orc.synth_image(w, h, 8, 1, seed=300 + k), **cfg) for k in range(2)]
+    a = Batch(streams); a.alloc_rgb(10); a.run(); a.to_rgb_all(); a.status()
+    f = Batch(streams); f.alloc_rgb(10); f.run_rgb(); f.status()
+    for i in range(len(streams)):
+        ref = orc.decode(streams[i])
+        for c in range(3):
+            np.testing.assert_array_equal(f.planes(i)[c], ref["planes"][c], err_msg="item %d component %d" % (i, c))
+        np.testing.assert_array_equal(f.rgb(i), a.rgb(i), err_msg="item %d" % i)
+    a.free(); f.free()
