@@ -864,7 +864,10 @@ __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
 // plugin ABI hands those to libheif — and emits the tile's interleaved RGB24 from registers + LDS.  Against k_sao + k_ycbcr_to_rgb_batch
 // this saves the colour pass's 1.5 B/px re-read of the planes and one launch.  Same arithmetic: colordev::convert_px.
 constexpr int SAO_CW = SAO_TW / 2, SAO_CH = SAO_TH / 2;
-constexpr int SAO_TPW = 4;   // tiles per workgroup of k_sao_rgb / k_sao_rgb_lean
+#ifndef HIPDEC_SAO_TPW
+#define HIPDEC_SAO_TPW 4
+#endif
+constexpr int SAO_TPW = HIPDEC_SAO_TPW;   // tiles per workgroup of k_sao_rgb / k_sao_rgb_lean (measurement builds: -DHIPDEC_SAO_TPW=8)
 #if !defined(HIPDEC_HOST_EMU) && defined(HIPDEC_SAO_RGB_OCC7)
 #define SAO_RGB_OCCUPANCY __attribute__((amdgpu_waves_per_eu(7, 8)))   // <= 72 VGPRs (measurement build: costs 12 - 40 B of scratch per lane)
 #else
@@ -1117,9 +1120,14 @@ __global__ __launch_bounds__(256) void k_sao_rgb_lean(FilterArgs A, const colord
   const PicParams& P = A.pics[blockIdx.y];
   const colordev::ColorParams cp = cps[blockIdx.y];
   if (!sao_rgb_pic_is_lean(P, cp)) return;
-  const int tiles_x = (P.out_width + SAO_TW - 1) / SAO_TW, tiles_y = (P.out_height + SAO_TH - 1) / SAO_TH, n_tiles = tiles_x * tiles_y;
-  const int group = sao_tile_of_block((n_tiles + SAO_TPW - 1) / SAO_TPW);
+  // A workgroup takes SAO_TPW tiles one BELOW the other (group g: tile column g % tiles_x, tile rows SAO_TPW (g / tiles_x) ..): its horizontal
+  // neighbours - the groups g - 1 and g + 1, on the same XCD (sao_tile_of_block) and started with it - walk down beside it, so that the lines the
+  // tiles share at their left and right ends are fetched by both at about the same time and once from HBM.  (Four tiles side by side, one after
+  // the other: 3.2 B/px fetched instead of 1.55 - a tile's end lines had left the L2 when its neighbour came to them.)
+  const int tiles_x = (P.out_width + SAO_TW - 1) / SAO_TW, tiles_y = (P.out_height + SAO_TH - 1) / SAO_TH;
+  const int group = sao_tile_of_block(tiles_x * ((tiles_y + SAO_TPW - 1) / SAO_TPW));
   if (group < 0) return;
+  const int tile_col = group % tiles_x, row0 = (group / tiles_x) * SAO_TPW;
   const SaoComp<Pix> SY = sao_comp<Pix>(A, P, 0, false, false), SB = sao_comp<Pix>(A, P, 1, false, false), SR = sao_comp<Pix>(A, P, 2, false, false);
   const int tid = threadIdx.x;
   // thread -> samples as in k_sao_rgb: a wave stays inside one CTB column
@@ -1128,14 +1136,14 @@ __global__ __launch_bounds__(256) void k_sao_rgb_lean(FilterArgs A, const colord
   const int ctx = (wv & 1) * 32 + (ln & 7) * 4, cty = (wv >> 1) * 8 + (ln >> 3);
   constexpr int RSTEP = 4;
   const bool int88 = cp.arith == colordev::AR_INT88;
-  const int first = group * SAO_TPW, last = (group + 1) * SAO_TPW < n_tiles ? (group + 1) * SAO_TPW : n_tiles;
+  const int first = row0, last = row0 + SAO_TPW < tiles_y ? row0 + SAO_TPW : tiles_y;   // tile rows
   // what a tile needs from global memory - the SAO parameters of the thread's CTBs and its words of the three source tiles - is requested one tile AHEAD:
   // while a tile is worked on, the next one's loads are in flight (with 5 workgroups per CU and a load - barrier - arithmetic - barrier sequence per
   // tile the kernel waited for memory most of the time)
   constexpr int NL_Y = ((SAO_TH + 2) * ROW_WORDS + 255) / 256, NL_C = ((SAO_CH + 2) * CROW_WORDS + 255) / 256;
   uint32_t vy[NL_Y], vb[NL_C], vr[NL_C], spw_y[3], spw_b[3], spw_r[3];
   auto request = [&](int t) {
-    const int ox = (t % tiles_x) * SAO_TW, oy = (t / tiles_x) * SAO_TH;
+    const int ox = tile_col * SAO_TW, oy = t * SAO_TH;
     sao_params_at(SY, ox + tx, oy + ty, spw_y);
     sao_params_at(SB, ox / 2 + ctx, oy / 2 + cty, spw_b);
     sao_params_at(SR, ox / 2 + ctx, oy / 2 + cty, spw_r);
@@ -1145,7 +1153,7 @@ __global__ __launch_bounds__(256) void k_sao_rgb_lean(FilterArgs A, const colord
   };
   request(first);
   for (int tile_idx = first; tile_idx < last; tile_idx++) {
-    const int ox_t = (tile_idx % tiles_x) * SAO_TW, oy_t = (tile_idx / tiles_x) * SAO_TH;
+    const int ox_t = tile_col * SAO_TW, oy_t = tile_idx * SAO_TH;
     const int xs0 = ox_t + SY.crop_xc, ys0 = oy_t + SY.crop_yc, cxs0 = xs0 >> 1, cys0 = ys0 >> 1;
     sao_stage_store<SAO_TH, ROW_WORDS, 256, NL_Y>(tile, tid, vy);
     sao_stage_store<SAO_CH, CROW_WORDS, 256, NL_C>(tile_c_buf[0] + 1, tid, vb);
@@ -1281,8 +1289,9 @@ void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool 
 void launch_sao_rgb(const FilterArgs& a, const void* color_params_dev, int n_pics, int max_out_w, int max_out_h, hipStream_t s, bool may_keep, bool restricted,
                     const PicParams* host_pics, const void* host_color_params)
 {
-  const int n_tiles = ((max_out_w + SAO_TW - 1) / SAO_TW) * ((max_out_h + SAO_TH - 1) / SAO_TH);
-  const int tiles = ((n_tiles + SAO_TPW - 1) / SAO_TPW + 7) & ~7;   // workgroups: SAO_TPW tiles each, a multiple of 8 (sao_tile_of_block)
+  const int tiles_x = (max_out_w + SAO_TW - 1) / SAO_TW, tiles_y = (max_out_h + SAO_TH - 1) / SAO_TH;
+  const int tiles = ((tiles_x * tiles_y + SAO_TPW - 1) / SAO_TPW + 7) & ~7;          // workgroups: SAO_TPW tiles each, a multiple of 8 (sao_tile_of_block)
+  const int tiles_lean = (tiles_x * ((tiles_y + SAO_TPW - 1) / SAO_TPW) + 7) & ~7;   // the lean kernel's groups are columns of SAO_TPW tiles
   // the lean kernel takes plain 8-bit 4:2:0 pictures (sao_rgb_pic_is_lean), the general one the rest; each returns at once from the other's pictures, and a
   // kernel without a picture is not launched when the host copies of the parameter blocks say so
   static const bool no_lean = getenv("HIPDEC_SAO_NO_LEAN") != nullptr;   // A/B knob
@@ -1294,7 +1303,7 @@ void launch_sao_rgb(const FilterArgs& a, const void* color_params_dev, int n_pic
       if (sao_rgb_pic_is_lean(host_pics[i], ((const colordev::ColorParams*)host_color_params)[i])) any_lean = true; else any_general = true;
     }
   }
-  if (any_lean) hipLaunchKernelGGL(k_sao_rgb_lean, dim3(tiles, n_pics), dim3(256), 0, s, a, (const colordev::ColorParams*)color_params_dev);
+  if (any_lean) hipLaunchKernelGGL(k_sao_rgb_lean, dim3(tiles_lean, n_pics), dim3(256), 0, s, a, (const colordev::ColorParams*)color_params_dev);
 #define L_RGB(K, R) hipLaunchKernelGGL((k_sao_rgb<K, R>), dim3(tiles, n_pics), dim3(256), 0, s, a, (const colordev::ColorParams*)color_params_dev, skip_lean)
   if (any_general) HIPDEC_SAO_DISPATCH(L_RGB);
 #undef L_RGB
