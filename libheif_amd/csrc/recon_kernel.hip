@@ -381,6 +381,93 @@ __device__ __forceinline__ void reconstruct_block(ReconLds<Pix>& L, const Ctx& C
   lds_sync();
 }
 
+// The same for 4x4 and 8x8 blocks (LG = 2, 3: three quarters of a picture's block calls at the benchmark's QP), REGISTER-RESIDENT: the 4n + 1 <= 33
+// reference samples stay one per lane - gathered, substituted ([8.4.4.2.2]: the nearest available sample below in scan order) and smoothed with
+// wave shuffles - and the prediction reads them with ds_bpermute instead of through a reference line in LDS: no line to write, no passes over 64 j + lane,
+// no LDS round trips between the stages (the general form's four wave-level LDS fences per block were most of a small block's latency, its run-time
+// sizes a third of its instructions).  Every sample of the block is one lane (16 or 64 of them).  Same arithmetic as reconstruct_block.
+template <typename Pix, int LG>
+__device__ __forceinline__ void reconstruct_block_reg(ReconLds<Pix>& L, const Ctx& C, const Pix* top, int xb, int yb, int mode, int cbf, const int16_t* res)
+{
+  constexpr int n = 1 << LG, n2 = 2 * n, N = 4 * n + 1, nn = n * n;
+  static_assert(N <= 64 && nn <= 64, "one lane per reference sample and per block sample");
+  const int lane = C.lane, lg_ctbc = C.lg_ctbc, maxv = C.maxv;
+  Pix* tile = L.tile;
+  int rp0 = 0;
+  if (cbf && lane < nn) rp0 = res[lane];   // requested first: its latency hides behind the prediction
+  // ---- reference samples, scan order e = lane: left column bottom-up (e < 2n), corner (e = 2n), top row left to right ----
+  const int e = lane;
+  const int is_left = e < n2;
+  const int X = xb + (is_left ? -1 : e - n2 - 1), Y = yb + (is_left ? n2 - 1 - e : -1);
+  int a = 0;
+  if (e < N) a = (int)((L.avrow[(Y >> C.ush) + 1] >> ((X >> C.ush) + 1)) & 1u);
+  int r = 0;
+  if (a) r = (int)(Y < 0 ? top[X + 1] : (X < 0 ? L.left[Y] : tile[(Y << lg_ctbc) + X]));
+  const uint64_t m = __ballot(a);
+  if (m != (1ull << N) - 1ull) {   // (wave-uniform) substitution
+    if (m == 0) r = 1 << (C.bit_depth - 1);
+    else {
+      const int first = __ffsll((long long)m) - 1;
+      const uint64_t below = m & ((1ull << lane) - 1ull);   // available samples below this lane's
+      const int src = a ? lane : (below ? 63 - __clzll((long long)below) : first);
+      r = __shfl(r, src);
+    }
+  }
+  // ---- 8.4.4.2.3 smoothing (8x8; 4x4 blocks are never filtered): [1 2 1] on everything but the two ends ----
+  if (LG == 3 && C.smooth) {
+    constexpr uint64_t k8 = smooth_mode_mask(8);
+    if ((k8 >> (mode & 63)) & 1ull) {
+      const int lo = __shfl(r, lane - 1), hi = __shfl(r, lane + 1);
+      const int f = (lo + 2 * r + hi + 2) >> 2;
+      r = (e == 0 || e >= N - 1) ? r : f;
+    }
+  }
+  // ref[k] for a lane-varying k: __shfl(r, k); left column p[-1][k-1] = ref[2n - k], top row p[k-1][-1] = ref[2n + k]
+  const int idx = lane & (nn - 1), x = idx & (n - 1), y = idx >> LG;   // (lanes >= nn compute on a copy of a block sample and store nothing)
+  const int edge = C.luma;   // DC / horizontal / vertical boundary smoothing (n < 32)
+  int v;
+  if (mode == 0) {
+    const int tr = __shfl(r, n2 + n + 1), bl = __shfl(r, n2 - n - 1), rl = __shfl(r, n2 - (y + 1)), rt = __shfl(r, n2 + (x + 1));
+    v = (mul24(n - 1 - x, rl) + mul24(x + 1, tr) + mul24(n - 1 - y, rt) + mul24(y + 1, bl) + n) >> (LG + 1);
+  } else if (mode == 1) {
+    // sum of p[-1][0 .. n-1] and p[0 .. n-1][-1]: the lanes e in [n, 2n) and (2n, 3n]
+    int part = ((e >= n && e < n2) || (e > n2 && e <= n2 + n)) ? r : 0;
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    const int dc_val = (part + n) >> (LG + 1);
+    const int rl = __shfl(r, n2 - (y + 1)), rt = __shfl(r, n2 + (x + 1));
+    v = dc_val;
+    if (edge) {
+      if (x == 0 && y == 0) v = (rl + 2 * dc_val + rt + 2) >> 2;
+      else if (y == 0) v = (rt + 3 * dc_val + 2) >> 2;
+      else if (x == 0) v = (rl + 3 * dc_val + 2) >> 2;
+    }
+  } else {
+    const int vertical = mode >= 18;
+    const int s = vertical ? 1 : -1;
+    const int32_t ae = k_angles.v[mode & 63];
+    const int angle = (int)(int8_t)(ae & 255), inv_angle = ae >> 16;
+    const int a_ = vertical ? x : y, b_ = vertical ? y : x;   // along / across the main arm
+    const int t = mul24(b_ + 1, angle), i_idx = t >> 5, i_fact = t & 31;
+    const int k0 = a_ + i_idx + 1, k1 = k0 + 1;
+    const int p0 = -((mul24(k0, inv_angle) + 128) >> 8), p1 = -((mul24(k1, inv_angle) + 128) >> 8);
+    const int r0 = __shfl(r, n2 + mul24(s, k0 >= 0 ? k0 : p0));
+    const int r1 = __shfl(r, n2 + mul24(s, k1 >= 0 ? k1 : p1));
+    v = (mul24(32 - i_fact, r0) + mul24(i_fact, r1) + 16) >> 5;
+    if (edge && angle == 0) {   // pure vertical / horizontal (modes 26 / 10) with boundary smoothing (wave-uniform)
+      const int c0 = __shfl(r, n2), m1 = __shfl(r, n2 + s), o1 = __shfl(r, n2 - mul24(s, b_ + 1));
+      if (a_ == 0) v = clip3(0, maxv, m1 + ((o1 - c0) >> 1));
+    }
+  }
+  if (cbf) v = (cbf & UF_PCM) ? rp0 : clip3(0, maxv, v + rp0);   // a PCM unit's "residual" is the sample itself
+  if (lane < nn) tile[((yb + y) << lg_ctbc) + xb + x] = (Pix)v;
+  // ---- the block's units are decoded now ----
+  {
+    const int k = n >> C.ush;    // units per side (>= 1)
+    if (lane < k) lds_or(&L.avrow[(yb >> C.ush) + 1 + lane], ((1ull << k) - 1ull) << ((xb >> C.ush) + 1));
+  }
+  lds_sync();
+}
+
 // Cb and Cr blocks of one position TOGETHER: lanes 0..31 work on Cb, lanes 32..63 on Cr.  Geometry, availability, substitution
 // pattern and prediction mode are the same for both (4:2:0 chroma has neither reference smoothing nor boundary filters), only
 // the samples, the residuals and the coded-block flags differ — so one instruction stream reconstructs both blocks.
@@ -520,6 +607,66 @@ __device__ __forceinline__ void reconstruct_chroma_pair(ReconLds<Pix>& L, const 
   {
     const int k = n >> 1, rows = n >> ushy;    // units per row of the block, unit rows (4:2:2: a 4x4 block is two units wide and one tall)
     if (lane < rows) lds_or(&L.avrow[(yb >> ushy) + 1 + lane], ((1ull << k) - 1ull) << ((xb >> 1) + 1));
+  }
+  lds_sync();
+}
+
+// The 4x4 blocks of the chroma pair register-resident (reconstruct_block_reg's scheme in each half of the wave: 17 reference samples and 16 block
+// samples per half; 4:2:0 / 4:2:2 chroma has neither reference smoothing nor boundary filters)
+template <typename Pix>
+__device__ __forceinline__ void reconstruct_chroma_pair_reg4(ReconLds<Pix>& L, const Ctx& C, const Pix* top, int xb, int yb, int mode, int cbf, const int16_t* res)
+{
+  constexpr int LG = 2, n = 4, n2 = 8, N = 17, nn = 16;
+  const int lane = C.lane, l = lane & 31, hb = lane & 32;   // hb: the first lane of this lane's half
+  const int lg_ctbc = C.lg_ctbc, maxv = C.maxv, ushy = C.ushy;
+  Pix* tile = L.tile + ((lane >> 5) << (lg_ctbc + C.lg_ctbh));
+  const Pix* left = L.left + (lane >> 5) * 64;
+  int rp0 = 0;
+  if (cbf && l < nn) rp0 = res[l];
+  const int e = l;
+  const int is_left = e < n2;
+  const int X = xb + (is_left ? -1 : e - n2 - 1), Y = yb + (is_left ? n2 - 1 - e : -1);
+  int a = 0;
+  if (e < N) a = (int)((L.avrow[(Y >> ushy) + 1] >> ((X >> 1) + 1)) & 1u);
+  int r = 0;
+  if (a) r = (int)(Y < 0 ? top[X + 1] : (X < 0 ? left[Y] : tile[(Y << lg_ctbc) + X]));
+  const uint32_t m = (uint32_t)__ballot(a);   // availability is the same in both halves: the Cb lanes' bits
+  if (m != (1u << N) - 1u) {
+    if (m == 0) r = 1 << (C.bit_depth - 1);
+    else {
+      const int first = __ffsll((long long)m) - 1;
+      const uint32_t below = m & ((1u << l) - 1u);
+      const int src = a ? l : (below ? 63 - __clzll((long long)below) : first);
+      r = __shfl(r, hb + src);
+    }
+  }
+  const int idx = l & (nn - 1), x = idx & (n - 1), y = idx >> LG;
+  int v;
+  if (mode == 0) {
+    const int tr = __shfl(r, hb + n2 + n + 1), bl = __shfl(r, hb + n2 - n - 1), rl = __shfl(r, hb + n2 - (y + 1)), rt = __shfl(r, hb + n2 + (x + 1));
+    v = (mul24(n - 1 - x, rl) + mul24(x + 1, tr) + mul24(n - 1 - y, rt) + mul24(y + 1, bl) + n) >> (LG + 1);
+  } else if (mode == 1) {
+    int part = ((e >= n && e < n2) || (e > n2 && e <= n2 + n)) ? r : 0;
+    for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o);      // every lane of a half ends up with its half's sum
+    v = (part + n) >> (LG + 1);
+  } else {
+    const int vertical = mode >= 18;
+    const int s = vertical ? 1 : -1;
+    const int32_t ae = k_angles.v[mode & 63];
+    const int angle = (int)(int8_t)(ae & 255), inv_angle = ae >> 16;
+    const int a_ = vertical ? x : y, b_ = vertical ? y : x;
+    const int t = mul24(b_ + 1, angle), i_idx = t >> 5, i_fact = t & 31;
+    const int k0 = a_ + i_idx + 1, k1 = k0 + 1;
+    const int p0 = -((mul24(k0, inv_angle) + 128) >> 8), p1 = -((mul24(k1, inv_angle) + 128) >> 8);
+    const int r0 = __shfl(r, hb + n2 + mul24(s, k0 >= 0 ? k0 : p0));
+    const int r1 = __shfl(r, hb + n2 + mul24(s, k1 >= 0 ? k1 : p1));
+    v = (mul24(32 - i_fact, r0) + mul24(i_fact, r1) + 16) >> 5;
+  }
+  if (cbf) v = (cbf & UF_PCM) ? rp0 : clip3(0, maxv, v + rp0);   // a PCM unit's "residual" is the sample itself
+  if (l < nn) tile[((yb + y) << lg_ctbc) + xb + x] = (Pix)v;
+  {
+    const int k = n >> 1, rows = n >> ushy;    // units per row of the block, unit rows (4:2:2: a 4x4 block is two units wide and one tall)
+    if (lane < (rows > 0 ? rows : 1)) lds_or(&L.avrow[(yb >> ushy) + 1 + lane], ((1ull << k) - 1ull) << ((xb >> 1) + 1));
   }
   lds_sync();
 }
@@ -722,13 +869,16 @@ __device__ __forceinline__ void recon_rows(const ReconArgs& A, const ReconWave& 
           reconstruct_inter_block<Pix>(L, C, tile, pred, stride, cux * 2, cuy * 2, lgc, fl & cbf_bit, res_base + zc * 4, l, 32, 1, 1);
         }
       } else if (!DUAL) {
-        reconstruct_block<Pix>(L, C, top, ux * 4, uy * 4, tb, mode, fl & (cbf_bit | UF_PCM), res_base + z * 16);
+        if (tb == 2) reconstruct_block_reg<Pix, 2>(L, C, top, ux * 4, uy * 4, mode, fl & (cbf_bit | UF_PCM), res_base + z * 16);
+        else if (tb == 3) reconstruct_block_reg<Pix, 3>(L, C, top, ux * 4, uy * 4, mode, fl & (cbf_bit | UF_PCM), res_base + z * 16);
+        else reconstruct_block<Pix>(L, C, top, ux * 4, uy * 4, tb, mode, fl & (cbf_bit | UF_PCM), res_base + z * 16);
       } else if (tb > 2 || (z & 3) == 3) {
         // the 4x4 chroma blocks of four 4x4 luma TUs hang off the 4th unit (their flags are there); they sit at the quad's origin
         const int quad = tb == 2;
         const int zc = quad ? (z & ~3) : z, cux = quad ? (ux & ~1) : ux, cuy = quad ? (uy & ~1) : uy;
         const int lgc = quad ? 2 : tb - 1;
-        if (suby == 2) reconstruct_chroma_pair<Pix>(L, C, top, cux * 2, cuy * 2, lgc, mode, fl & (cbf_bit | UF_PCM), res_base + zc * 4);
+        if (suby == 2 && lgc == 2) reconstruct_chroma_pair_reg4<Pix>(L, C, top, cux * 2, cuy * 2, mode, fl & (cbf_bit | UF_PCM), res_base + zc * 4);
+        else if (suby == 2) reconstruct_chroma_pair<Pix>(L, C, top, cux * 2, cuy * 2, lgc, mode, fl & (cbf_bit | UF_PCM), res_base + zc * 4);
         else {
           // 4:2:2: two blocks one above the other, the upper one first (the lower one predicts from it); the lower one's flags sit in unit z ^ 1
           const int fl2 = (int)((L.m_unit[z ^ 1] >> 8) & 255u);

@@ -69,8 +69,8 @@ def test_occupancy_budgets():
     assert gen8["vgpr"] <= 64 and gen8["scratch"] <= 192
     recon8 = _find(ks, "8k_recon8E")[0]
     # 7 waves / SIMD by registers, 26 one-wave groups per CU by LDS (512 B granules); the spills sit in the per-wave / per-CTB code around the block
-    # loop (scalar registers parked in VGPR lanes, 172 B of scratch), not in the block functions
-    assert recon8["vgpr"] <= 72 and recon8["scratch"] <= 176 and recon8["lds"] <= 6144
+    # loop (scalar registers parked in VGPR lanes, 172 B of scratch; 244 B with the register-resident small-block forms of round 6), not in the block functions
+    assert recon8["vgpr"] <= 72 and recon8["scratch"] <= 280 and recon8["lds"] <= 6144
     residual = _find(ks, "k_residual")[0]
     assert residual["lds"] <= 23040 and residual["vgpr"] <= 72          # 7 workgroups of 4 waves per CU: LDS is handed out in 512 B granules, 7 x 23040 <= 160 KB;
                                                                           # 7 waves per SIMD by registers (round 6: the thread-per-row form with v_dot2 butterflies, 70 VGPRs)
