@@ -140,6 +140,9 @@ typedef VReg& CtxRef;                  // ... or a 64-lane register
 
 // everything here is wave-uniform unless it is a VReg
 struct PS {
+#ifdef HIPDEC_PARSE_CYCLES   // measurement build (tools/ab_variant.sh cyc -DHIPDEC_PARSE_CYCLES): where does a row's time go?  printed per row
+  unsigned long long c_resid = 0, c_flush = 0, c_wait = 0, c_cu = 0, c_pub = 0; uint32_t n_resid = 0;
+#endif
   // ---- arithmetic decoder: range / value / bits_needed are wave-uniform values kept in VECTOR registers (UReg), so the
   //      decoder's arithmetic issues on the SIMD's VALU while the CU-shared scalar pipe keeps the syntax control flow
   UReg range, value, bits_needed;
@@ -1281,8 +1284,17 @@ PC_DEV void coding_unit(PS& s, int zb /*unit z-index of the CU inside the CTB*/,
       const int c = k == 0 ? 0 : 1 + ((k - 1) & 1), low = k >= 3;
       const int lg = c == 0 ? t : tc;
       int16_t* dst = c == 0 ? coef_y + zu * 16 : (c == 1 ? coef_cb : coef_cr) + zc * c_mult + (low << (2 * lg));
+#ifdef HIPDEC_PARSE_CYCLES
+      const unsigned long long pc_t0 = __builtin_readcyclecounter();
+#endif
       ts_bits |= (uint32_t)residual_coding(s, lg, c, c == 0 ? luma_mode : chroma_mode) << k;
+#ifdef HIPDEC_PARSE_CYCLES
+      const unsigned long long pc_t1 = __builtin_readcyclecounter();
+#endif
       flush_coef(s, dst, 1 << (2 * lg));
+#ifdef HIPDEC_PARSE_CYCLES
+      { const unsigned long long pc_t2 = __builtin_readcyclecounter(); s.c_resid += pc_t1 - pc_t0; s.c_flush += pc_t2 - pc_t1; s.n_resid++; }
+#endif
     }
     const int ts_y = (int)(ts_bits & 1u), ts_cb = (int)((ts_bits >> 1) & 1u), ts_cr = (int)((ts_bits >> 2) & 1u);
     // TU-level map fill: size, cbf, transform-skip, deblocking edges (8.7.2.2 / 8.7.2.3)
@@ -1561,6 +1573,9 @@ enum : int { PARSE_DONE = 0, PARSE_SUSPENDED = -1 };   // > 0: device error code
 PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_dep, uint32_t start_lag, Lds* lds)
 {
   PS s;
+#ifdef HIPDEC_PARSE_CYCLES
+  const unsigned long long pc_row0 = __builtin_readcyclecounter();
+#endif
   const Substream* subp = A.subs + sub_idx;
   const uint32_t sub_pic = uload32(&subp->pic), byte_start = uload32(&subp->byte_start), byte_end = uload32(&subp->byte_end);
   const uint32_t first_ctb_ts = uload32(&subp->first_ctb_ts), num_ctbs = uload32(&subp->num_ctbs), slice_idx = uload32(&subp->slice_idx);
@@ -1664,7 +1679,13 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
       uint32_t need = k == 0 ? start_lag : k + 1;
       if (need > dep_len || wpp_sync == 2) need = dep_len;   // (a dependent slice segment continues the END of its predecessor: all of it)
       if (!pool) {
+#ifdef HIPDEC_PARSE_CYCLES
+        const unsigned long long pc_w0 = __builtin_readcyclecounter();
+#endif
         const int e = pc_wait_progress(A.progress + dep_sub, need, A.status);
+#ifdef HIPDEC_PARSE_CYCLES
+        s.c_wait += __builtin_readcyclecounter() - pc_w0;
+#endif
         if (e) { s.err = e; break; }
       } else if (pc_load_wt_uni(A.progress + dep_sub) < need) {
         // suspend: save the row's state, record what it waits for (with two CTBs of hysteresis), re-check
@@ -1739,7 +1760,13 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
         lg--;
       }
       if (!(s.tools & TOOL_CUQPD)) s.qpy_pred = s.last_qp_y;
+#ifdef HIPDEC_PARSE_CYCLES
+      const unsigned long long pc_c0 = __builtin_readcyclecounter();
+#endif
       coding_unit(s, zb, lg, coef_y, coef_cb, coef_cr);
+#ifdef HIPDEC_PARSE_CYCLES
+      s.c_cu += __builtin_readcyclecounter() - pc_c0;
+#endif
       p += 1 << (2 * (lg - s.log2_min_cb));
     }
 
@@ -1820,6 +1847,11 @@ PC_DEV int parse_substream(const ParseArgs& A, uint32_t sub_idx, int same_wave_d
       if (has_dependent) { pc_atomic_exch(A.progress + sub_idx, k + 1); pool_wake_dependent(A, dependent, k + 1); }
     }
   }
+#if defined(HIPDEC_PARSE_CYCLES) && !defined(HIPDEC_HOST_EMU)
+  if (threadIdx.x == 0 && sub_pic == 0)
+    printf("cyc sub %u ctbs %u total %llu wait %llu cu %llu resid %llu flush %llu nresid %u\n", sub_idx, num_ctbs, __builtin_readcyclecounter() - pc_row0, s.c_wait, s.c_cu, s.c_resid,
+           s.c_flush, s.n_resid);
+#endif
   if (s.err) pc_report(A.status, s.err | (int32_t)(sub_idx << 8));
   return s.err;
 }
