@@ -253,6 +253,21 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
   HIPDEC_CHECK_HIP(hipMemsetAsync(b.arena + b.off_ctrl, 0, b.ctrl_size, s));
   HIPDEC_CHECK_HIP(hipEventRecord(ev[0], s));
   if (int rc = step("memset")) return rc;
+#ifdef HIPDEC_POOL_TRACE   // measurement build: per pool wave {start, end of its last row, last look at the queue, time waiting for work, rows run, time in rows}
+  {                        // in 100 MHz ticks; the previous run's table is appended to $HIPDEC_POOL_TRACE (binary, 32 x uint64 per wave - [8 + k]: time waiting for work in the k-th 42 ms of its life -, 8192 waves per run)
+    static unsigned long long* trace = nullptr;
+    const size_t bytes = 8192 * 32 * sizeof(unsigned long long);
+    if (!trace) { HIPDEC_CHECK_HIP(hipMalloc((void**)&trace, bytes)); HIPDEC_CHECK_HIP(hipMemset(trace, 0, bytes)); }
+    else if (const char* path = getenv("HIPDEC_POOL_TRACE")) {
+      HIPDEC_CHECK_HIP(hipDeviceSynchronize());
+      std::vector<unsigned long long> h(8192 * 32);
+      HIPDEC_CHECK_HIP(hipMemcpy(h.data(), trace, bytes, hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(path, "ab")) { fwrite(h.data(), 1, bytes, f); fclose(f); }
+      HIPDEC_CHECK_HIP(hipMemset(trace, 0, bytes));
+    }
+    pa.trace = trace;
+  }
+#endif
   launch_parse(pa, s);
   HIPDEC_CHECK_HIP(hipEventRecord(ev[1], s));
   if (int rc = step("parse")) return rc;

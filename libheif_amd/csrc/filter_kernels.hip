@@ -382,6 +382,18 @@ __global__ __launch_bounds__(256) void k_deblock(FilterArgs A)
 }
 
 
+// Tile of a workgroup, XCD-aware.  Workgroups go to the chip's 8 XCDs (each with an L2 of its own) round-robin by their linear id, and a tile's rows
+// start one sample left of a 128-byte line and end one sample into the next: with tile = blockIdx.x the two neighbours of every tile ran on other
+// XCDs and each of them fetched those two lines from HBM again (measured: 5.2 B/px fetched for 1.5 B/px of planes, profiles/pmc_traffic.json round 5:
+// three lines per luma row and two per chroma row instead of one).  Here every XCD takes a contiguous band of the picture's tiles, so that
+// horizontal neighbours run on the same XCD at about the same time and share the lines in its L2.  gridDim.x is a multiple of 8.
+__device__ __forceinline__ int sao_tile_of_block(int n_tiles)
+{
+  const int bid = (int)blockIdx.x, chunk = (n_tiles + 7) >> 3;
+  const int t = (bid & 7) * chunk + (bid >> 3);
+  return ((bid >> 3) < chunk && t < n_tiles) ? t : -1;
+}
+
 // ---- both edge directions in ONE pass (intra pictures, 4:0:0 / 4:2:0) -----------------------------------------------------------------------
 // The window of a vertical edge segment is [x - 4, x + 4) x 4 rows, that of a horizontal one 4 columns x [y - 4, y + 4), edges sit on the 8-sample
 // grid: the 8 x 8 blocks centred on the grid's crossings - [8j - 4, 8j + 4) x [8k - 4, 8k + 4) - tile the plane, and each holds exactly the two segments
@@ -401,7 +413,25 @@ __global__ __launch_bounds__(256) void k_deblock_fused(FilterArgs A)
   if (CH && P.chroma_format_idc != 1) return;
   const int Wc = CH ? P.cwidth : P.width, Hc = CH ? P.cheight : P.height;
   const int nbx = (Wc >> 3) + 1, nby = (Hc >> 3) + 1;                 // grid crossings 0, 8, ... <= W (the first / last blocks are half outside)
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  // XCD-aware, like the SAO tiles: an XCD takes RUNS of consecutive workgroups (256 consecutive blocks each, about half a block row of a 4K picture), so
+  // that the unit-map lines of a CTB - read again by each of the 8 block rows that cross it - and the plane lines two neighbouring workgroups share are
+  // fetched into few L2s instead of all eight (with workgroup = blockIdx.x: 2.58 B/px fetched for 1.5 B/px of planes + 0.2 of maps)
+#ifndef HIPDEC_DBK_XCD_RUN
+#define HIPDEC_DBK_XCD_RUN 2   // N > 0: every XCD takes runs of N consecutive workgroups out of each group of 8 N; measurement builds: 0 = one contiguous band of the
+                               // picture per XCD (fewest bytes, 3.13 B/px, but +0.5 ms: eight distant regions of HBM at a time), -1 = workgroup = blockIdx.x
+#endif
+  const int n_wg = (nbx * nby + 255) >> 8;
+  int wg;
+  if (HIPDEC_DBK_XCD_RUN == 0) wg = sao_tile_of_block(n_wg);
+  else if (HIPDEC_DBK_XCD_RUN < 0) wg = (int)blockIdx.x < n_wg ? (int)blockIdx.x : -1;
+  else {
+    constexpr int R = HIPDEC_DBK_XCD_RUN > 0 ? HIPDEC_DBK_XCD_RUN : 1;
+    const int bid = (int)blockIdx.x, g = bid / (8 * R), o = bid % (8 * R);
+    wg = g * 8 * R + (o & 7) * R + (o >> 3);
+    if (wg >= n_wg) wg = -1;
+  }
+  if (wg < 0) return;
+  const int tid = wg * 256 + (int)threadIdx.x;
   if (tid >= nbx * nby) return;
   const int j = tid % nbx, k = tid / nbx;                            // consecutive lanes: consecutive x
   const int xc = j * 8, yc = k * 8;
@@ -817,17 +847,6 @@ __device__ __forceinline__ void sao_store(const SaoComp<Pix>& S, int ox0, int oy
   }
 }
 
-// Tile of a workgroup, XCD-aware.  Workgroups go to the chip's 8 XCDs (each with an L2 of its own) round-robin by their linear id, and a tile's rows
-// start one sample left of a 128-byte line and end one sample into the next: with tile = blockIdx.x the two neighbours of every tile ran on other
-// XCDs and each of them fetched those two lines from HBM again (measured: 5.2 B/px fetched for 1.5 B/px of planes, profiles/pmc_traffic.json round 5:
-// three lines per luma row and two per chroma row instead of one).  Here every XCD takes a contiguous band of the picture's tiles, so that
-// horizontal neighbours run on the same XCD at about the same time and share the lines in its L2.  gridDim.x is a multiple of 8.
-__device__ __forceinline__ int sao_tile_of_block(int n_tiles)
-{
-  const int bid = (int)blockIdx.x, chunk = (n_tiles + 7) >> 3;
-  const int t = (bid & 7) * chunk + (bid >> 3);
-  return ((bid >> 3) < chunk && t < n_tiles) ? t : -1;
-}
 template <typename Pix, bool MAY_KEEP, bool RESTRICTED>
 __global__ __launch_bounds__(256) void k_sao(FilterArgs A)
 {
@@ -1254,14 +1273,15 @@ void launch_deblock(const FilterArgs& a, int n_pics, int max_w, int max_h, bool 
 {
   static const bool two_pass_forced = getenv("HIPDEC_DEBLOCK_TWO_PASS") != nullptr;   // A/B knob
   if (one_pass && !two_pass_forced) {
-    // intra pictures with 4:0:0 / 4:2:0 sampling only: both edge directions in one pass over each plane (k_deblock_fused)
+    // intra pictures with 4:0:0 / 4:2:0 sampling only: both edge directions in one pass over each plane (k_deblock_fused); workgroups: a multiple of 8
+    // (sao_tile_of_block)
     const int blocks_y = ((max_w >> 3) + 1) * ((max_h >> 3) + 1), blocks_c = ((max_w >> 4) + 1) * ((max_h >> 4) + 1);
     if (wide) {
-      hipLaunchKernelGGL((k_deblock_fused<uint16_t, 0>), dim3((blocks_y + 255) / 256, n_pics), dim3(256), 0, s, a);
-      hipLaunchKernelGGL((k_deblock_fused<uint16_t, 1>), dim3((blocks_c + 255) / 256, n_pics), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_deblock_fused<uint16_t, 0>), dim3(((blocks_y + 255) / 256 + 63) & ~63, n_pics), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_deblock_fused<uint16_t, 1>), dim3(((blocks_c + 255) / 256 + 63) & ~63, n_pics), dim3(256), 0, s, a);
     } else {
-      hipLaunchKernelGGL((k_deblock_fused<uint8_t, 0>), dim3((blocks_y + 255) / 256, n_pics), dim3(256), 0, s, a);
-      hipLaunchKernelGGL((k_deblock_fused<uint8_t, 1>), dim3((blocks_c + 255) / 256, n_pics), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_deblock_fused<uint8_t, 0>), dim3(((blocks_y + 255) / 256 + 63) & ~63, n_pics), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_deblock_fused<uint8_t, 1>), dim3(((blocks_c + 255) / 256 + 63) & ~63, n_pics), dim3(256), 0, s, a);
     }
     return;
   }

@@ -239,6 +239,9 @@ struct ParseArgs {
   uint32_t wake_hyst;    // a parked row is woken when its predecessor is this many CTBs beyond the minimum distance
   uint32_t general_chroma;   // 1: the batch holds a 4:2:2 or 4:4:4 picture (the parser build with the ChromaArrayType 2 / 3 paths is launched)
   uint32_t inter;            // 1: the batch holds a P picture (the parser build with the inter syntax is launched)
+#ifdef HIPDEC_POOL_TRACE     // measurement build (tools/ab_variant.sh trace -DHIPDEC_POOL_TRACE): 8 x uint64 per pool wave, see parse_wave
+  unsigned long long* trace;
+#endif
 };
 
 }  // namespace hipdec

@@ -1882,10 +1882,24 @@ PC_DEV void parse_wave(const ParseArgs& A, uint32_t wave_idx, Lds* lds)
       }
     }
   }
+#if defined(HIPDEC_POOL_TRACE) && !defined(HIPDEC_HOST_EMU)
+  unsigned long long tr_start = 0, tr_last = 0, tr_idle = 0, tr_tasks = 0, tr_busy = 0, tr_now0 = wall_clock64();
+#endif
   for (;;) {
     uint32_t* slot = A.queue;
+#if defined(HIPDEC_POOL_TRACE) && !defined(HIPDEC_HOST_EMU)
+    tr_now0 = wall_clock64();
+#endif
     if (!pool) { if (sub >= end) return; }
     else {
+#if defined(HIPDEC_POOL_TRACE) && !defined(HIPDEC_HOST_EMU)
+      const unsigned long long tr_now = wall_clock64();   // 100 MHz
+      if (tr_tasks == 0 && tr_idle == 0) tr_start = tr_now;
+      if (threadIdx.x == 0 && A.trace) {   // (kept current: the wave returns from several places)
+        unsigned long long* tr = A.trace + (size_t)wave_idx * 32;
+        tr[0] = tr_start; tr[1] = tr_last; tr[2] = tr_now; tr[3] = tr_idle; tr[4] = tr_tasks; tr[5] = tr_busy;
+      }
+#endif
       if (pc_load_wt_uni(A.qctl + 2) >= A.num_subs) return;                      // every row finished
       if (pc_load_wt_uni((const uint32_t*)A.status) != 0) return;               // a row failed: stop the batch
       const uint32_t h = pc_atomic_add(A.qctl + 0, 1u);
@@ -1909,7 +1923,19 @@ PC_DEV void parse_wave(const ParseArgs& A, uint32_t wave_idx, Lds* lds)
       PC_VEC_BEGIN if (lane == 0) pc_store_wt(slot, 0u); PC_VEC_END
       sub = v - 1u;
     }
+#if defined(HIPDEC_POOL_TRACE) && !defined(HIPDEC_HOST_EMU)
+    const unsigned long long tr_t0 = wall_clock64();
+    if (pool) {
+      tr_idle += tr_t0 - tr_now0;
+      if (tr_start == 0) tr_start = tr_now0;
+      const unsigned long long bk = (tr_t0 - tr_start) >> 22;   // waiting for work, by 42 ms bucket of the wave's life (booked where the wait ended)
+      if (threadIdx.x == 0 && A.trace && bk < 24) A.trace[(size_t)wave_idx * 32 + 8 + bk] += tr_t0 - tr_now0;
+    }
+#endif
     const int r = parse_substream(A, sub, !pool && stride == 1, lag, lds);
+#if defined(HIPDEC_POOL_TRACE) && !defined(HIPDEC_HOST_EMU)
+    tr_last = wall_clock64(); tr_busy += tr_last - tr_t0; tr_tasks++;
+#endif
     if (!pool) { if (r) return; sub += stride; }
     else if (r == PARSE_DONE) pc_atomic_add(A.qctl + 2, 1u);
     else if (r > 0) return;
