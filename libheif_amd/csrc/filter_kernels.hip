@@ -31,6 +31,55 @@ __constant__ uint8_t c_tc[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
                                  5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
 __constant__ uint8_t c_chroma_qp_f[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37};
 
+// ---- two 16-bit values per operation (v_pk_*_i16, v_perm_b32): the lean SAO + RGB kernel and the 8-bit luma deblocking filter ----
+namespace swar {
+#ifndef HIPDEC_HOST_EMU
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+#define HIPDEC_SWAR_PK(NAME, INSN)                                                                                                              \
+  __device__ __forceinline__ uint32_t NAME(uint32_t a, uint32_t b) { uint32_t r; asm(INSN " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }  \
+  __device__ __forceinline__ uint32_t NAME##_c(uint32_t a, uint32_t b) { uint32_t r; asm(INSN " %0, %1, %2" : "=v"(r) : "v"(a), "s"(b)); return r; }   // b: a wave-uniform constant pair
+HIPDEC_SWAR_PK(pk_add, "v_pk_add_i16") HIPDEC_SWAR_PK(pk_sub, "v_pk_sub_i16") HIPDEC_SWAR_PK(pk_max, "v_pk_max_i16") HIPDEC_SWAR_PK(pk_min, "v_pk_min_i16")
+#undef HIPDEC_SWAR_PK
+// shifts of both halves by the (wave-uniform) amounts in the halves of n, e.g. 0x00030003
+__device__ __forceinline__ uint32_t pk_shl_c(uint32_t a, uint32_t n) { uint32_t r; asm("v_pk_lshlrev_b16 %0, %2, %1" : "=v"(r) : "v"(a), "s"(n)); return r; }
+__device__ __forceinline__ uint32_t pk_ashr_c(uint32_t a, uint32_t n) { uint32_t r; asm("v_pk_ashrrev_i16 %0, %2, %1" : "=v"(r) : "v"(a), "s"(n)); return r; }
+struct __attribute__((packed)) U1 { uint32_t v; };
+__device__ __forceinline__ uint32_t lds32u(const uint8_t* p) { return ((const U1*)p)->v; }   // any alignment: one ds_read_b32
+#else   // CPU-test build: the same operations spelled out
+inline uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)   // v_perm_b32: byte i of the result = byte sel[i] of {hi, lo}; 8 .. 11: the sign of byte 1 / 3 / 5 / 7; 12: 0; >= 13: 0xff
+{
+  const uint64_t in = ((uint64_t)hi << 32) | lo;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; i++) {
+    const uint32_t k = (sel >> (8 * i)) & 255u;
+    uint32_t b;
+    if (k < 8) b = (uint32_t)(in >> (8 * k)) & 255u;
+    else if (k < 12) b = ((in >> (16 * (k - 8) + 15)) & 1u) ? 255u : 0u;
+    else b = k == 12 ? 0u : 255u;
+    r |= b << (8 * i);
+  }
+  return r;
+}
+#define HIPDEC_SWAR_PK(NAME, EXPR)                                                                              \
+  inline uint32_t NAME(uint32_t a, uint32_t b)                                                                  \
+  {                                                                                                             \
+    uint32_t r = 0;                                                                                             \
+    for (int h = 0; h < 2; h++) { const int x = (int16_t)(a >> (16 * h)), y = (int16_t)(b >> (16 * h)); r |= ((uint32_t)(EXPR) & 0xffffu) << (16 * h); }  \
+    return r;                                                                                                   \
+  }                                                                                                             \
+  inline uint32_t NAME##_c(uint32_t a, uint32_t b) { return NAME(a, b); }
+HIPDEC_SWAR_PK(pk_add, x + y) HIPDEC_SWAR_PK(pk_sub, x - y) HIPDEC_SWAR_PK(pk_max, x > y ? x : y) HIPDEC_SWAR_PK(pk_min, x < y ? x : y)
+HIPDEC_SWAR_PK(pk_shl_c, x << (y & 15)) HIPDEC_SWAR_PK(pk_ashr_c, x >> (y & 15))
+#undef HIPDEC_SWAR_PK
+inline uint32_t lds32u(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+#endif
+constexpr uint32_t kEven = 0x0c020c00u, kOdd = 0x0c030c01u;   // bytes 0, 2 / 1, 3 of a dword as two zero-extended 16-bit values
+constexpr uint32_t kSextOdd = 0x09030801u;                   // bytes 1, 3 as two SIGN-extended 16-bit values
+__device__ __forceinline__ uint32_t pk_neg(uint32_t a) { return pk_sub(0u, a); }
+__device__ __forceinline__ uint32_t pk_sel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }   // v_bfi_b32
+__device__ __forceinline__ uint32_t pk_clip255(uint32_t a) { return pk_min_c(pk_max_c(a, 0u), 0x00ff00ffu); }
+}  // namespace swar
+
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ uint32_t interleave4(uint32_t x, uint32_t y)
@@ -159,6 +208,120 @@ template <typename Pix, int DIR>
 __device__ __forceinline__ void deblock_luma(EdgeWindow<Pix, DIR>& W, Pix* pix, int stride, int qp_p, int qp_q, int beta_off2, int tc_off2, int bit_depth, int no_p, int no_q, int bs = 2)
 {
   if (deblock_luma_regs<Pix, DIR>(W, qp_p, qp_q, beta_off2, tc_off2, bit_depth, no_p, no_q, bs)) W.store(pix, stride);
+}
+
+// The same segment for 8-bit luma with both sides filtered (no PCM / bypass side), TWO LINES PER OPERATION: the block of k_deblock_fused is eight rows of
+// two dwords; the samples at distance i from the edge of the line pairs (0, 1) and (2, 3) are gathered into the halves of one register each with one
+// v_perm_b32, decisions (lines 0 and 3: the low half of the first pair, the high half of the second) and both filters run on v_pk_*_i16 - every
+// intermediate of 8.7.2.5.7 fits 16 bits (9 |q0 - p0| + 3 |q1 - p1| + 8 <= 3068) -, the per-line condition |delta| < 10 tc is a mask (sign of a
+// difference, v_bfi_b32), and the results go back into the rows with v_perm_b32.  About half the vector instructions of the scalar form above.
+// w: the block, row r = picture row yc - 4 + r, dword 0 / 1 = columns xc - 4 .. xc - 1 / xc .. xc + 3.  DIR 0: the vertical edge's rows 4 sgm .. 4 sgm + 3;
+// DIR 1: the horizontal edge's columns 4 sgm .. 4 sgm + 3 (dword sgm of every row).
+template <int DIR>
+__device__ __forceinline__ bool deblock_luma_pk8(uint32_t (&w)[8][2], int sgm, int qp_p, int qp_q, int beta_off2, int tc_off2)
+{
+  using namespace swar;
+  const int qpl = (qp_q + qp_p + 1) >> 1;
+  const int beta = c_beta[clip3(0, 51, qpl + (beta_off2 << 1))];
+  const int tc = c_tc[clip3(0, 53, qpl + 2 + (tc_off2 << 1))];   // bS 2 (intra pictures)
+  uint32_t P[4][2], Q[4][2];   // [distance from the edge][line pair]: line 2 pr in the low half, line 2 pr + 1 in the high half
+#pragma unroll
+  for (int pr = 0; pr < 2; pr++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (DIR == 0) {
+        const int r = 4 * sgm + 2 * pr;
+        P[i][pr] = perm(w[r + 1][0], w[r][0], 0x0c000c00u | (uint32_t)(3 - i) | ((uint32_t)(7 - i) << 16));
+        Q[i][pr] = perm(w[r + 1][1], w[r][1], 0x0c000c00u | (uint32_t)i | ((uint32_t)(4 + i) << 16));
+      } else {
+        const uint32_t sel = 0x0c000c00u | (uint32_t)(2 * pr) | ((uint32_t)(2 * pr + 1) << 16);
+        P[i][pr] = perm(0u, w[3 - i][sgm], sel);
+        Q[i][pr] = perm(0u, w[4 + i][sgm], sel);
+      }
+    }
+  constexpr uint32_t K1 = 0x00010001u, K2 = 0x00020002u, K3 = 0x00030003u, K4 = 0x00040004u, K8 = 0x00080008u, K15 = 0x000f000fu;
+  uint32_t dP[2], dQ[2];
+#pragma unroll
+  for (int pr = 0; pr < 2; pr++) {
+    const uint32_t a = pk_sub(pk_add(P[2][pr], P[0][pr]), pk_shl_c(P[1][pr], K1)), b = pk_sub(pk_add(Q[2][pr], Q[0][pr]), pk_shl_c(Q[1][pr], K1));
+    dP[pr] = pk_max(a, pk_neg(a)); dQ[pr] = pk_max(b, pk_neg(b));
+  }
+  const int dp0 = (int)(dP[0] & 0xffffu), dp3 = (int)(dP[1] >> 16), dq0 = (int)(dQ[0] & 0xffffu), dq3 = (int)(dQ[1] >> 16);
+  const int dpq0 = dp0 + dq0, dpq3 = dp3 + dq3, dp = dp0 + dp3, dq = dq0 + dq3;
+  if (dpq0 + dpq3 >= beta) return false;
+  const int p00 = (int)(P[0][0] & 0xffffu), p30 = (int)(P[3][0] & 0xffffu), q00 = (int)(Q[0][0] & 0xffffu), q30 = (int)(Q[3][0] & 0xffffu);   // line 0
+  const int p03 = (int)(P[0][1] >> 16), p33 = (int)(P[3][1] >> 16), q03 = (int)(Q[0][1] >> 16), q33 = (int)(Q[3][1] >> 16);                   // line 3
+  const int s0 = (2 * dpq0 < (beta >> 2)) && (iabs(p30 - p00) + iabs(q00 - q30) < (beta >> 3)) && (iabs(p00 - q00) < ((5 * tc + 1) >> 1));
+  const int s3 = (2 * dpq3 < (beta >> 2)) && (iabs(p33 - p03) + iabs(q03 - q33) < (beta >> 3)) && (iabs(p03 - q03) < ((5 * tc + 1) >> 1));
+  const int dep = dp < ((beta + (beta >> 1)) >> 3), deq = dq < ((beta + (beta >> 1)) >> 3);
+  if (s0 && s3) {
+    const uint32_t T2 = (uint32_t)(2 * tc) * 0x00010001u;
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) {
+      const uint32_t p0 = P[0][pr], p1 = P[1][pr], p2 = P[2][pr], p3 = P[3][pr], q0 = Q[0][pr], q1 = Q[1][pr], q2 = Q[2][pr], q3 = Q[3][pr];
+      const uint32_t s = pk_add(p0, q0), t = pk_add(p1, s), u = pk_add(q1, s);
+      const uint32_t np0 = pk_ashr_c(pk_add_c(pk_add(pk_add(p2, q1), pk_shl_c(t, K1)), K4), K3);                    // (p2 + 2 p1 + 2 p0 + 2 q0 + q1 + 4) >> 3
+      const uint32_t np1 = pk_ashr_c(pk_add_c(pk_add(p2, t), K2), K2);                                              // (p2 + p1 + p0 + q0 + 2) >> 2
+      const uint32_t np2 = pk_ashr_c(pk_add_c(pk_add(pk_add(pk_shl_c(pk_add(p3, p2), K1), p2), t), K4), K3);        // (2 p3 + 3 p2 + p1 + p0 + q0 + 4) >> 3
+      const uint32_t nq0 = pk_ashr_c(pk_add_c(pk_add(pk_add(p1, q2), pk_shl_c(u, K1)), K4), K3);                    // (p1 + 2 p0 + 2 q0 + 2 q1 + q2 + 4) >> 3
+      const uint32_t nq1 = pk_ashr_c(pk_add_c(pk_add(q2, u), K2), K2);                                              // (p0 + q0 + q1 + q2 + 2) >> 2
+      const uint32_t nq2 = pk_ashr_c(pk_add_c(pk_add(pk_add(pk_shl_c(pk_add(q3, q2), K1), q2), u), K4), K3);        // (p0 + q0 + q1 + 3 q2 + 2 q3 + 4) >> 3
+      P[0][pr] = pk_min(pk_max(np0, pk_sub(p0, T2)), pk_add(p0, T2));
+      P[1][pr] = pk_min(pk_max(np1, pk_sub(p1, T2)), pk_add(p1, T2));
+      P[2][pr] = pk_min(pk_max(np2, pk_sub(p2, T2)), pk_add(p2, T2));
+      Q[0][pr] = pk_min(pk_max(nq0, pk_sub(q0, T2)), pk_add(q0, T2));
+      Q[1][pr] = pk_min(pk_max(nq1, pk_sub(q1, T2)), pk_add(q1, T2));
+      Q[2][pr] = pk_min(pk_max(nq2, pk_sub(q2, T2)), pk_add(q2, T2));
+    }
+  } else {
+    const uint32_t TC = (uint32_t)tc * 0x00010001u, TC10 = (uint32_t)(10 * tc) * 0x00010001u, TCH = (uint32_t)(tc >> 1) * 0x00010001u;
+    const uint32_t nTC = pk_neg(TC), nTCH = pk_neg(TCH);
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) {
+      const uint32_t p0 = P[0][pr], p1 = P[1][pr], p2 = P[2][pr], q0 = Q[0][pr], q1 = Q[1][pr], q2 = Q[2][pr];
+      const uint32_t d0 = pk_sub(q0, p0), d1 = pk_sub(q1, p1);
+      const uint32_t delta = pk_ashr_c(pk_add_c(pk_sub(pk_add(pk_shl_c(d0, K3), d0), pk_add(pk_shl_c(d1, K1), d1)), K8), K4);   // (9 (q0 - p0) - 3 (q1 - p1) + 8) >> 4
+      const uint32_t m = pk_ashr_c(pk_sub(pk_max(delta, pk_neg(delta)), TC10), K15);                                            // 0xffff where |delta| < 10 tc
+      const uint32_t dc = pk_min(pk_max(delta, nTC), TC);
+      P[0][pr] = pk_sel(m, pk_clip255(pk_add(p0, dc)), p0);
+      Q[0][pr] = pk_sel(m, pk_clip255(pk_sub(q0, dc)), q0);
+      if (dep) {
+        const uint32_t x = pk_ashr_c(pk_add(pk_sub(pk_ashr_c(pk_add_c(pk_add(p2, p0), K1), K1), p1), dc), K1);                  // (((p2 + p0 + 1) >> 1) - p1 + delta) >> 1
+        P[1][pr] = pk_sel(m, pk_clip255(pk_add(p1, pk_min(pk_max(x, nTCH), TCH))), p1);
+      }
+      if (deq) {
+        const uint32_t y = pk_ashr_c(pk_sub(pk_sub(pk_ashr_c(pk_add_c(pk_add(q2, q0), K1), K1), q1), dc), K1);                  // (((q2 + q0 + 1) >> 1) - q1 - delta) >> 1
+        Q[1][pr] = pk_sel(m, pk_clip255(pk_add(q1, pk_min(pk_max(y, nTCH), TCH))), q1);
+      }
+    }
+  }
+  // back into the rows (p3 / q3 never change)
+#pragma unroll
+  for (int pr = 0; pr < 2; pr++) {
+    if (DIR == 0) {
+      const int r = 4 * sgm + 2 * pr;
+      {   // line 2 pr: the low halves
+        const uint32_t xp = perm(P[1][pr], P[2][pr], 0x0c04000cu), yp = perm(P[0][pr], xp, 0x0402010cu);
+        w[r][0] = (w[r][0] & 0x000000ffu) | yp;
+        const uint32_t xq = perm(Q[1][pr], Q[0][pr], 0x0c0c0400u), yq = perm(Q[2][pr], xq, 0x0c040100u);
+        w[r][1] = (w[r][1] & 0xff000000u) | yq;
+      }
+      {   // line 2 pr + 1: the high halves
+        const uint32_t xp = perm(P[1][pr], P[2][pr], 0x0c06020cu), yp = perm(P[0][pr], xp, 0x0602010cu);
+        w[r + 1][0] = (w[r + 1][0] & 0x000000ffu) | yp;
+        const uint32_t xq = perm(Q[1][pr], Q[0][pr], 0x0c0c0602u), yq = perm(Q[2][pr], xq, 0x0c060100u);
+        w[r + 1][1] = (w[r + 1][1] & 0xff000000u) | yq;
+      }
+    }
+  }
+  if (DIR == 1) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      w[3 - i][sgm] = perm(P[i][1], P[i][0], 0x06040200u);
+      w[4 + i][sgm] = perm(Q[i][1], Q[i][0], 0x06040200u);
+    }
+  }
+  return true;
 }
 
 template <typename Pix>
@@ -505,6 +668,12 @@ __global__ __launch_bounds__(256) void k_deblock_fused(FilterArgs A)
     int beta = s0_beta, tc = s0_tc, ocb = s0_cb, ocr = s0_cr;
     if (sidx[sgm] != 0) { const SliceParams& sl = slices[sidx[sgm]]; beta = sl.beta_offset_div2; tc = sl.tc_offset_div2; ocb = sl.pps_cb_qp_offset; ocr = sl.pps_cr_qp_offset; }
     const int no_q = (fq[sgm] & keep) != 0, no_p = (fp[sgm] & keep) != 0;
+    if constexpr (!CH && ES == 1) {
+      if (!(no_p | no_q)) {   // (almost always: no PCM / bypass unit on either side) two lines per operation
+        if (deblock_luma_pk8<0>(w[0], sgm, qp[sgm], qq[sgm], beta, tc)) dirty = true;
+        continue;
+      }
+    }
     if (!CH) {
       EdgeWindow<Pix, 0> W;
 #pragma unroll
@@ -547,6 +716,12 @@ __global__ __launch_bounds__(256) void k_deblock_fused(FilterArgs A)
     int beta = s0_beta, tc = s0_tc, ocb = s0_cb, ocr = s0_cr;
     if (sidx[2 + sgm] != 0) { const SliceParams& sl = slices[sidx[2 + sgm]]; beta = sl.beta_offset_div2; tc = sl.tc_offset_div2; ocb = sl.pps_cb_qp_offset; ocr = sl.pps_cr_qp_offset; }
     const int no_q = (fq[2 + sgm] & keep) != 0, no_p = (fp[2 + sgm] & keep) != 0;
+    if constexpr (!CH && ES == 1) {
+      if (!(no_p | no_q)) {
+        if (deblock_luma_pk8<1>(w[0], sgm, qp[2 + sgm], qq[2 + sgm], beta, tc)) dirty = true;
+        continue;
+      }
+    }
     if (!CH) {
       EdgeWindow<Pix, 1> W;
 #pragma unroll
@@ -1015,46 +1190,6 @@ __global__ __launch_bounds__(256) SAO_RGB_OCCUPANCY void k_sao_rgb(FilterArgs A,
 //     interleave them into the 12 bytes of RGB24.
 // About 30 lane operations per pixel.  Everything else of the tile - staging, the planes it writes, the arithmetic results - is k_sao_rgb's; tiles that do
 // not qualify are left to it (launch_sao_rgb runs both; each returns at once from the other's tiles).
-namespace swar {
-#ifndef HIPDEC_HOST_EMU
-__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-#define HIPDEC_SWAR_PK(NAME, INSN)                                                                                                              \
-  __device__ __forceinline__ uint32_t NAME(uint32_t a, uint32_t b) { uint32_t r; asm(INSN " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }  \
-  __device__ __forceinline__ uint32_t NAME##_c(uint32_t a, uint32_t b) { uint32_t r; asm(INSN " %0, %1, %2" : "=v"(r) : "v"(a), "s"(b)); return r; }   // b: a wave-uniform constant pair
-HIPDEC_SWAR_PK(pk_add, "v_pk_add_i16") HIPDEC_SWAR_PK(pk_sub, "v_pk_sub_i16") HIPDEC_SWAR_PK(pk_max, "v_pk_max_i16") HIPDEC_SWAR_PK(pk_min, "v_pk_min_i16")
-#undef HIPDEC_SWAR_PK
-struct __attribute__((packed)) U1 { uint32_t v; };
-__device__ __forceinline__ uint32_t lds32u(const uint8_t* p) { return ((const U1*)p)->v; }   // any alignment: one ds_read_b32
-#else   // CPU-test build: the same operations spelled out
-inline uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)   // v_perm_b32: byte i of the result = byte sel[i] of {hi, lo}; 8 .. 11: the sign of byte 1 / 3 / 5 / 7; 12: 0; >= 13: 0xff
-{
-  const uint64_t in = ((uint64_t)hi << 32) | lo;
-  uint32_t r = 0;
-  for (int i = 0; i < 4; i++) {
-    const uint32_t k = (sel >> (8 * i)) & 255u;
-    uint32_t b;
-    if (k < 8) b = (uint32_t)(in >> (8 * k)) & 255u;
-    else if (k < 12) b = ((in >> (16 * (k - 8) + 15)) & 1u) ? 255u : 0u;
-    else b = k == 12 ? 0u : 255u;
-    r |= b << (8 * i);
-  }
-  return r;
-}
-#define HIPDEC_SWAR_PK(NAME, EXPR)                                                                              \
-  inline uint32_t NAME(uint32_t a, uint32_t b)                                                                  \
-  {                                                                                                             \
-    uint32_t r = 0;                                                                                             \
-    for (int h = 0; h < 2; h++) { const int x = (int16_t)(a >> (16 * h)), y = (int16_t)(b >> (16 * h)); r |= ((uint32_t)(EXPR) & 0xffffu) << (16 * h); }  \
-    return r;                                                                                                   \
-  }                                                                                                             \
-  inline uint32_t NAME##_c(uint32_t a, uint32_t b) { return NAME(a, b); }
-HIPDEC_SWAR_PK(pk_add, x + y) HIPDEC_SWAR_PK(pk_sub, x - y) HIPDEC_SWAR_PK(pk_max, x > y ? x : y) HIPDEC_SWAR_PK(pk_min, x < y ? x : y)
-#undef HIPDEC_SWAR_PK
-inline uint32_t lds32u(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
-#endif
-constexpr uint32_t kEven = 0x0c020c00u, kOdd = 0x0c030c01u;   // bytes 0, 2 / 1, 3 of a dword as two zero-extended 16-bit values
-constexpr uint32_t kSextOdd = 0x09030801u;                   // bytes 1, 3 as two SIGN-extended 16-bit values
-}  // namespace swar
 
 // does picture P (with colour stage cp) take the lean kernel?  The same answer on the host (launch_sao_rgb) and in both kernels.
 __host__ __device__ inline bool sao_rgb_pic_is_lean(const PicParams& P, const colordev::ColorParams& cp)

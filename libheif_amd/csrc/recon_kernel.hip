@@ -34,7 +34,10 @@ namespace hipdec {
 
 // 7 waves per SIMD (<= 72 VGPRs): the reconstruction wavefront hides its LDS / HBM latencies with resident waves
 #ifndef HIPDEC_HOST_EMU
-#define RECON_OCCUPANCY __attribute__((amdgpu_waves_per_eu(7, 8)))
+#ifndef HIPDEC_RECON_OCC
+#define HIPDEC_RECON_OCC 7   // (measurement builds: tools/ab_variant.sh rocc6 -DHIPDEC_RECON_OCC=6 ...)
+#endif
+#define RECON_OCCUPANCY __attribute__((amdgpu_waves_per_eu(HIPDEC_RECON_OCC, 8)))
 #else
 #define RECON_OCCUPANCY
 #endif
