@@ -404,6 +404,9 @@ def main():
         }
         extra_streams = {k: gen_streams(v[1]) for k, v in extra_specs.items()}
     grid_streams = {k: gen_streams(v, rank, world) for k, v in grid_specs.items()}
+    # BASELINE config 5 as written at N > 1: 1024 x 1080p stills interleaved over the GPUs (still i -> GPU i mod N; at N = 1 it is extra_workloads.c5_1080p_1024)
+    c5_on = (world > 1 or os.environ.get("HIPDEC_BENCH_C5")) and not (a.no_extras or a.only_main or grid) and a.workload == "still4k"   # (env: exercise the section on one GPU)
+    c5_streams = gen_streams([(1920, 1080, 1000 + i, 8, dict(wpp=1, qp=a.qp)) for i in range(256)], rank, world) if c5_on else None
 
     dist = None
     import torch
@@ -528,6 +531,32 @@ def main():
     value_resident = total_px / (elapsed / a.steps) / 1e6
     avg_us = kernel_times(wl.batches, a.steps) if not grid else None
 
+    # config 5 over the job's GPUs: every rank decodes ITS stills (i mod N == rank) of the 1024 as one batch, no data-path collective; barrier + max over
+    # ranks as the main measurement.  Total work is fixed: the line says "strong".  (A rank that cannot build its batch takes the others out of the
+    # section before any of them enters a barrier.)
+    c5_line = None
+    if c5_on:
+        c5w, c5_err = None, ""
+        try:
+            mine = [c5_streams[i % 256] for i in range(1024) if i % world == rank]
+            c5w = Workload(lib, "still1080", mine, len(mine), 10, 1920, 1080, 8, 1)
+            c5w.make_resident()
+        except Exception as ex:   # noqa
+            c5w, c5_err = None, str(ex)[:200]
+        flag = torch.tensor([1 if c5w is not None else 0], dtype=torch.int32, device="cuda")
+        if dist is not None:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            el5 = timed(c5w.step_resident, 2, 1)
+            c5w.status()
+            c5_line = {"workload": "1024 x 1920x1080 HEIC 4:2:0 8-bit stills, still i -> GPU i mod %d (%d per GPU), fused YCbCr->RGB24, inputs resident" % (world, len(mine)),
+                       "value": round(1024 * 1920 * 1080 / (el5 / 2) / 1e6, 2), "unit": "Mpixel/s", "ms_per_step": round(el5 / 2 * 1e3, 3), "n_gpus": world,
+                       "scaling": "strong", "one_gpu": "extra_workloads.c5_1080p_1024 of the N = 1 line"}
+        else:
+            c5_line = {"error": "a rank could not build its batch: " + (c5_err or "another rank")}
+        if c5w is not None:
+            c5w.free()
+
     # what the timed steps produced for stills spread over the batch (checked against the CPU oracle further down; outside every timed region)
     check_items = {}
     verify_on = batch is not None and rank == 0 and not a.only_main and not a.no_cpu_baseline and a.parts == 1 and world == 1
@@ -569,6 +598,8 @@ def main():
             "resident": {"value": round(value_resident, 2), "unit": "Mpixel/s", "ms_per_step": round(ms_resident, 3),
                          "timed_region": "inputs resident in HBM when the timed region starts: hipdec_batch_run_rgb per step"},
         }
+        if c5_line is not None:
+            out["config5_interleaved"] = c5_line
         if avg_us is not None:
             coded = coded_fraction(batch)
             alg = alg_bytes(beta, coded, s, s_out)
