@@ -943,7 +943,13 @@ __device__ __forceinline__ void recon_wave(const ReconArgs& A)
 // unit); size-specialised copies of the block functions gained 5 % before those changes and nothing after them (74.8 ms; twice the code), so the
 // block functions keep their run-time sizes.  The 16-bit variant is limited by its 10 KB of LDS per wave either way.
 __global__ __launch_bounds__(64) RECON_OCCUPANCY void k_recon8(ReconArgs A) { recon_wave<uint8_t, false>(A); }
+// (16-bit samples: 10.3 KB of LDS per wave allow 15 waves per CU; at 128 VGPRs - 4 waves per SIMD - the kernel runs 512 Main10 4K stills in 47.3 ms, unconstrained
+//  (132 VGPRs, 3 waves) in 50.0, at 5 waves per SIMD (spills) in 49.9: GPU call 64)
+#ifndef HIPDEC_HOST_EMU
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_recon16(ReconArgs A) { recon_wave<uint16_t, false>(A); }
+#else
 __global__ __launch_bounds__(64) void k_recon16(ReconArgs A) { recon_wave<uint16_t, false>(A); }
+#endif
 // batches with P pictures (sequence tracks): inter coded blocks take their prediction from the plane (k_mc) instead of the intra predictor
 __global__ __launch_bounds__(64) void k_recon8_inter(ReconArgs A) { recon_wave<uint8_t, true>(A); }
 __global__ __launch_bounds__(64) void k_recon16_inter(ReconArgs A) { recon_wave<uint16_t, true>(A); }
