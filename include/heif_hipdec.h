@@ -117,6 +117,15 @@ HIPDEC_API void hipdec_decoder_set_user_data(hipdec_decoder* dec, uintptr_t user
  * 0 / 1: every sample is decoded at the poll behind its push.  Default 32 (environment: HIPDEC_SEQ_LOOKAHEAD; measured on 720p IPPP tracks: 19 fps without, 138 with 16, 205 with 32 samples); at most 64.  Stills are not affected:
  * the first picture of a decoder is always decoded at once. */
 HIPDEC_API void hipdec_set_sequence_lookahead(int samples);
+/* Pipelined chains: with `chains` > 1 a look-ahead chain is only ENQUEUED when its window is full, and its pictures are held back until `chains` of
+ * them are in flight (or the host flushes) - libheif keeps pushing samples while no picture comes out (sequences/track_visual.cc:200-260), so the next
+ * window fills while the chain runs and its CABAC launch (one WPP critical path, whatever the number of pictures) runs beside the pixel steps of the
+ * chains in front of it.  The first picture of a chain in flight that goes out is preceded by the look at that chain's status; a chain that fails on
+ * the device is undone together with the chains built on it and decoded again the plain way, so the sample that is to blame gets the error.
+ * 1: every chain is waited for where it is launched.  Environment: HIPDEC_SEQ_PIPELINE; at most 8. */
+HIPDEC_API void hipdec_set_sequence_pipeline(int chains);
+/* statistics: chains that were left in flight when they were enqueued, and how often a failed one was undone */
+HIPDEC_API void hipdec_decoder_pipeline_stats(uint64_t* chains_left_in_flight, uint64_t* rollbacks);
 HIPDEC_API int hipdec_decoder_next_picture(hipdec_decoder* dec, int flush, hipdec_image_info* info, int* have, uintptr_t* user_data);
 /* Concurrent hipdec_decoder_decode() calls (libheif decodes the tiles of a 'grid' item on worker threads,
  * libheif/image-items/grid.cc:405-453, one decoder instance per tile) are coalesced into shared launch sets; a

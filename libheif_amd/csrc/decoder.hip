@@ -75,6 +75,18 @@ struct hipdec_batch : BatchLayout {
   std::vector<std::pair<void*, size_t>> rgb_chunks;   // pinned
   std::atomic<int> rgb_consumed{0};
   bool fused_rgb = false;                 // the last hipdec_batch_run_rgb took the fused form (k_sao_rgb)
+  // Pipelined chains (decoder_chains.inc): a chain launch set that is enqueued while earlier chains of the same tracks are still running.  Its CABAC
+  // and residual launches need nothing of them and start at once; its motion derivation waits for their motion fields, its pixel steps for their
+  // pictures.  The set keeps its streams until somebody has looked at its status (a stream handed back early would carry the NEXT set's CABAC
+  // launch behind this set's pixel steps), and that look happens once, by whichever decoder instance needs a picture of the set first.
+  std::vector<std::shared_ptr<hipdec_batch>> after;
+  bool hold_streams = false;
+  std::vector<hipStream_t> held_streams;
+  bool motion_recorded = false;           // chain_events[0] stands behind the motion fields of ALL pictures
+  std::mutex fin_mu;
+  bool finished = false;
+  int fin_rc = 0;
+  std::string fin_err;
   // Waits for everything enqueued for THIS batch — not for the stream, which may already carry the next batch.
   hipError_t wait() const
   {
@@ -100,6 +112,7 @@ struct hipdec_batch : BatchLayout {
     DeviceScope scope(device);
     if (arena || staging) (void)wait();   // nothing of this batch may still be running when the arena is recycled
     release_staging();
+    for (hipStream_t hs : held_streams) stream_release(hs);
     for (auto& c : host_chunks) pinned_release(c.first, c.second);
     for (auto& c : rgb_chunks) pinned_release(c.first, c.second);
     if (rgb_dev) { arena_release(rgb_dev, rgb_capacity); rgb_note_unused((int)rgb_off.size() - rgb_consumed.load()); }
@@ -292,9 +305,16 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
         b.chain_events.push_back(e);
       }
       HIPDEC_CHECK_HIP(hipStreamWaitEvent(ms, ev[1], 0));
+      for (const auto& pred : b.after) {   // collocated pictures of chains still in flight: their motion fields
+        if (pred->motion_recorded) HIPDEC_CHECK_HIP(hipStreamWaitEvent(ms, pred->chain_events[0], 0));
+        else if (pred->done_recorded) HIPDEC_CHECK_HIP(hipStreamWaitEvent(ms, pred->done, 0));
+      }
       launch_chain_motion_all(b, b.arena, ms);
       HIPDEC_CHECK_HIP(hipEventRecord(b.chain_events[0], ms));
-      stream_release(ms);
+      b.motion_recorded = true;
+      if (b.hold_streams) b.held_streams.push_back(ms); else stream_release(ms);
+      for (const auto& pred : b.after)     // reference pictures of chains still in flight
+        if (pred->done_recorded) HIPDEC_CHECK_HIP(hipStreamWaitEvent(ps, pred->done, 0));
       bool waited = false;
       for (size_t k = 0; k < b.pixel_steps.size(); k++) {
         if (b.pixel_steps[k].any_inter && !waited) { HIPDEC_CHECK_HIP(hipStreamWaitEvent(ps, b.chain_events[0], 0)); waited = true; }
@@ -311,6 +331,8 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
       b.mark_done(ps);
       return 0;
     }
+    for (const auto& pred : b.after)       // (the forms below keep the simple order: everything of this chain's later stages behind the chains in flight)
+      if (pred->done_recorded) HIPDEC_CHECK_HIP(hipStreamWaitEvent(ps, pred->done, 0));
     hipStream_t ms = nullptr;
     if (b.any_inter && b.motion_steps.size() > 1) {
       ms = stream_acquire();
@@ -320,6 +342,7 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
         b.chain_events.push_back(e);
       }
       HIPDEC_CHECK_HIP(hipStreamWaitEvent(ms, ev[1], 0));
+      for (const auto& pred : b.after) if (pred->done_recorded) HIPDEC_CHECK_HIP(hipStreamWaitEvent(ms, pred->done, 0));
       for (size_t k = 0; k < b.motion_steps.size(); k++) {
         launch_chain_motion(b, b.arena, (int)k, ms);
         HIPDEC_CHECK_HIP(hipEventRecord(b.chain_events[k], ms));

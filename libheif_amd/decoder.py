@@ -71,6 +71,24 @@ def chain_stats():
     return a.value, b.value, c.value
 
 
+def set_sequence_pipeline(chains):
+    """look-ahead chains of one track in flight at a time (hipdec_set_sequence_pipeline; 1: every chain is waited for where it is launched)"""
+    lib = load_library()
+    lib.hipdec_set_sequence_pipeline.argtypes = [C.c_int]
+    lib.hipdec_set_sequence_pipeline.restype = None
+    lib.hipdec_set_sequence_pipeline(int(chains))
+
+
+def pipeline_stats():
+    """(chains that were left in flight when they were enqueued, roll-backs of failed ones) since the library was loaded"""
+    lib = load_library()
+    lib.hipdec_decoder_pipeline_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.hipdec_decoder_pipeline_stats.restype = None
+    a, b = C.c_uint64(), C.c_uint64()
+    lib.hipdec_decoder_pipeline_stats(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
 class DecodedImage:
     def __init__(self, info, planes):
         self.info = info

@@ -47,16 +47,24 @@ for name, kw in kinds.items():
         d.free()
         assert got == len(aus)
 
-    play(True)                                   # warm-up + correctness against the oracle
-    t0 = time.perf_counter(); play(False); one = time.perf_counter() - t0
-    from libheif_amd.decoder import chain_stats
-    before = chain_stats()
-    th = [threading.Thread(target=play, args=(False,)) for _ in range(tracks)]
-    t0 = time.perf_counter()
-    for t in th: t.start()
-    for t in th: t.join()
-    many = time.perf_counter() - t0
-    after = chain_stats()
-    bytes_per_frame = sum(len(a) for a in aus) / len(aus)
-    print("%-42s %d x %dx%d pictures (%.0f KB per picture): 1 track %.1f fps (%.1f ms per picture); %d tracks side by side %.1f fps in total (%d chains in %d launch sets)" %
-          (name, n, w, h, bytes_per_frame / 1e3, n / one, one / n * 1e3, tracks, tracks * n / many, after[0] - before[0], after[1] - before[1]), flush=True)
+    # SEQ_SWEEP="pipeline:lookahead,..." (hipdec_set_sequence_pipeline / _lookahead between the runs); default: what the environment says
+    from libheif_amd.decoder import chain_stats, set_sequence_pipeline
+    import test_sequence_gpu as _ts
+    sweep = [tuple(int(x) for x in c.split(":")) for c in os.environ.get("SEQ_SWEEP", "").split(",") if c] or [None]
+    for combo in sweep:
+        tag = ""
+        if combo:
+            set_sequence_pipeline(combo[0]); _ts._set_lookahead(combo[1])
+            tag = "pipeline %d look-ahead %2d: " % combo
+        play(True)                                   # warm-up + correctness against the oracle
+        t0 = time.perf_counter(); play(False); one = time.perf_counter() - t0
+        before = chain_stats()
+        th = [threading.Thread(target=play, args=(False,)) for _ in range(tracks)]
+        t0 = time.perf_counter()
+        for t in th: t.start()
+        for t in th: t.join()
+        many = time.perf_counter() - t0
+        after = chain_stats()
+        bytes_per_frame = sum(len(a) for a in aus) / len(aus)
+        print("%s%-42s %d x %dx%d pictures (%.0f KB per picture): 1 track %.1f fps (%.1f ms per picture); %d tracks side by side %.1f fps in total (%d chains in %d launch sets)" %
+              (tag, name, n, w, h, bytes_per_frame / 1e3, n / one, one / n * 1e3, tracks, tracks * n / many, after[0] - before[0], after[1] - before[1]), flush=True)
