@@ -163,7 +163,9 @@ int build_batch(hipdec_batch& b, int n, const void* const* data, const size_t* s
     ~TakeoverGuard() { if (!ok && after) (void)hipEventSynchronize(after); }
   } takeover{after, false};
   static const bool sync_upload = getenv("HIPDEC_SYNC_UPLOAD") != nullptr;   // profiling knob: one stream, no cross-stream event waits
-  if (b.upload_size > (size_t(4) << 20) && !sync_upload) {
+  // (a chain that is enqueued beside chains in flight never takes the synchronous copy: hipMemcpy from pageable memory waits for the device - measured,
+  //  80 ms per chain of 16 720p pictures, i.e. for everything in flight)
+  if ((b.upload_size > (size_t(4) << 20) || b.hold_streams) && !sync_upload) {
     HIPDEC_CHECK_HIP(pinned_acquire(&b.staging, b.upload_size, &b.staging_capacity));
     if (!b.arena) HIPDEC_CHECK_HIP(arena_acquire((void**)&b.arena, b.arena_size, &b.arena_capacity));   // (first: a chain's reference tables hold addresses inside it)
     layout_batch_fill(b, data, sizes, (uint8_t*)b.staging, (uint64_t)(uintptr_t)b.arena);
@@ -326,7 +328,9 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
       HIPDEC_CHECK_HIP(hipEventRecord(ev[5], ps));
       if (int rc = step("chain pixel stages")) return rc;
       HIPDEC_CHECK_HIP(hipGetLastError());
-      HIPDEC_CHECK_HIP(hipMemcpyAsync(b.host_status, b.arena + b.off_status, sizeof(int32_t), hipMemcpyDeviceToHost, ps));
+      // (a set left in flight queues NO copy behind its kernels: a DMA copy that waits for the pixel steps holds its copy engine's queue, and the upload
+      //  of the next set - whose CABAC launch is to run beside those pixel steps - sits behind it; batch_finish copies once the kernels are done)
+      if (!b.hold_streams) HIPDEC_CHECK_HIP(hipMemcpyAsync(b.host_status, b.arena + b.off_status, sizeof(int32_t), hipMemcpyDeviceToHost, ps));
       b.last_stream = ps;
       b.mark_done(ps);
       return 0;
@@ -363,7 +367,7 @@ int launch_all(hipdec_batch& b, hipStream_t s, const void* fused_rgb_params = nu
     HIPDEC_CHECK_HIP(hipEventRecord(ev[5], ps));
     if (int rc = step("chain pixel stages")) return rc;
     HIPDEC_CHECK_HIP(hipGetLastError());
-    HIPDEC_CHECK_HIP(hipMemcpyAsync(b.host_status, b.arena + b.off_status, sizeof(int32_t), hipMemcpyDeviceToHost, ps));
+    if (!b.hold_streams) HIPDEC_CHECK_HIP(hipMemcpyAsync(b.host_status, b.arena + b.off_status, sizeof(int32_t), hipMemcpyDeviceToHost, ps));
     b.last_stream = ps;
     b.mark_done(ps);
     return 0;
