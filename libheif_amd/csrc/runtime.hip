@@ -279,6 +279,13 @@ std::mutex g_stream_mu;
 std::vector<std::pair<hipStream_t, int>> g_free_streams;   // (stream, device)
 }  // namespace
 
+// HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), in order within a queue.  Pipelined look-ahead chains
+// (decoder_chains.inc) keep three launch sets of two streams each in flight, and a CABAC launch that shares a hardware queue with the pixel steps of
+// the set in front of it waits for them instead of running beside them (measured on MI355X, one 720p IPPP track, pipeline 3: 370 fps with 4
+// queues, 559 fps with 16; round 5 saw the same for tracks side by side: profiles/r05_sequence_fps.txt, call 12).  The runtime reads the variable
+// when it initialises - at the process's first HIP call, after this library was loaded -, so it is set here unless the host has chosen a value.
+__attribute__((constructor)) static void hipdec_more_hardware_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 hipStream_t stream_acquire()
 {
   const int dev = active_device();
