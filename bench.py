@@ -241,7 +241,7 @@ def issue_roofline(kernels, px, cu_count, clock_ghz):
     return out
 
 
-def sequence_tracks(n_frames=65, tracks=16, w=1280, h=720):
+def sequence_tracks(n_frames=257, tracks=16, w=1280, h=720):
     """sequence tracks through the decoder object the way libheif drives it (one sample per push_data2, pictures polled in output order,
     flush at the end): frames per second of ONE track - every picture is one CABAC critical path, the instance holds one sample at a time - and of
     `tracks` tracks decoded side by side by as many threads (their first pictures and their look-ahead chains coalesce into shared launch sets).  The first pass of each kind checks
@@ -259,7 +259,12 @@ def sequence_tracks(n_frames=65, tracks=16, w=1280, h=720):
     lib.hipdec_set_sequence_lookahead.argtypes = [__import__("ctypes").c_int]
     lib.hipdec_set_sequence_lookahead.restype = None
     default_lookahead = int(os.environ.get("HIPDEC_SEQ_LOOKAHEAD", "32"))
-    res = {"pictures_per_track": n_frames, "size": "%dx%d" % (w, h), "tracks_side_by_side": tracks, "lookahead_samples": default_lookahead,
+    default_pipeline = int(os.environ.get("HIPDEC_SEQ_PIPELINE", "3"))
+    from libheif_amd.decoder import set_sequence_pipeline
+    res = {"pictures_per_track": n_frames, "size": "%dx%d" % (w, h), "tracks_side_by_side": tracks, "lookahead_samples": default_lookahead, "chains_in_flight": default_pipeline,
+           "pipeline": "a chain is enqueued when its look-ahead window is full and its pictures are held back until this many chains are in flight (or the host flushes): "
+                       "the CABAC launch of a chain runs beside the pixel steps of the chains in front of it (hipdec_set_sequence_pipeline); *_one_chain_at_a_time = the same "
+                       "tracks with every chain waited for where it is launched (rounds 5 / 6 until this change)",
            "lookahead": "behind a track's first picture the decoder gathers this many samples (libheif pushes the next one whenever decode_next_image2 returns no image) "
                         "and decodes them as ONE launch set: one CABAC launch and one motion-derivation launch over all of them, pixel stages in dependency steps "
                         "(hipdec_set_sequence_lookahead); the chains of tracks decoded side by side that ask together share a launch set (hipdec_decoder_chain_stats)"}
@@ -267,11 +272,11 @@ def sequence_tracks(n_frames=65, tracks=16, w=1280, h=720):
         aus = orc.encode_sequence(frames, qp=27, global_mv_x=-8, global_mv_y=-4, inter_skip_pct=30, **kw)
         ref = {r["poc"]: r for r in orc.decode_sequence(aus)}
 
-        def play(check):
+        def play(check, first=None):
             d = HipDecoder()
             got = 0
             try:
-                for au in aus + [None]:
+                for au in (aus if first is None else aus[:first]) + [None]:
                     if au is not None:
                         d.push_data(au)
                     r = d.next_picture(flush=au is None)
@@ -282,7 +287,7 @@ def sequence_tracks(n_frames=65, tracks=16, w=1280, h=720):
                         r = d.next_picture(flush=au is None)
             finally:
                 d.free()
-            if got != len(aus):
+            if got != (len(aus) if first is None else first):
                 raise RuntimeError("sequence %s: %d of %d pictures came out" % (name, got, len(aus)))
 
         play(True)
@@ -299,8 +304,17 @@ def sequence_tracks(n_frames=65, tracks=16, w=1280, h=720):
                      # side by side: the chains of tracks that ask together run as one launch set (hipdec_decoder_chain_stats)
                      "all_tracks_chains": after[0] - before[0], "all_tracks_launch_sets": after[1] - before[1],
                      "kbytes_per_picture": round(sum(len(a) for a in aus) / len(aus) / 1e3, 1), "verified_against_oracle": True}
-        lib.hipdec_set_sequence_lookahead(0)          # round 4's behaviour beside it: every sample decoded at the poll behind its push
-        t0 = time.perf_counter(); play(False); res[name]["one_track_fps_without_lookahead"] = round(n_frames / (time.perf_counter() - t0), 1)
+        set_sequence_pipeline(1)                      # every chain waited for where it is launched
+        t0 = time.perf_counter(); play(False); res[name]["one_track_fps_one_chain_at_a_time"] = round(n_frames / (time.perf_counter() - t0), 1)
+        th = [threading.Thread(target=play, args=(False,)) for _ in range(tracks)]
+        t0 = time.perf_counter()
+        for t in th: t.start()
+        for t in th: t.join()
+        res[name]["all_tracks_fps_one_chain_at_a_time"] = round(tracks * n_frames / (time.perf_counter() - t0), 1)
+        set_sequence_pipeline(default_pipeline)
+        lib.hipdec_set_sequence_lookahead(0)          # round 4's behaviour beside it: every sample decoded at the poll behind its push (the P / B pictures in front of the
+        k = 33 if n_frames > 33 else n_frames          # first IRAP of the track's first chunk: one CABAC critical path each)
+        t0 = time.perf_counter(); play(False, k); res[name]["one_track_fps_without_lookahead"] = round(k / (time.perf_counter() - t0), 1)
         lib.hipdec_set_sequence_lookahead(default_lookahead)
     return res
 

@@ -22,7 +22,7 @@ def pipeline3():
     from libheif_amd.decoder import set_sequence_pipeline
     set_sequence_pipeline(3)
     yield 3
-    set_sequence_pipeline(1)
+    set_sequence_pipeline(3)      # (the library's default)
     _set_lookahead(32)
 
 
@@ -151,8 +151,8 @@ def test_a_corrupt_sample_in_a_chain_in_flight_fails_its_own_track_only(where, d
         assert pipeline_stats()[1] > before[1]      # the failed chain was undone
 
 
-def test_plain_form_is_untouched_by_default():
-    """D = 1 (the default): nothing is left in flight"""
+def test_plain_form_leaves_nothing_in_flight():
+    """D = 1: every chain is waited for where it is launched (the form of rounds 5 / 6; a host that wants the least delay)"""
     from libheif_amd.decoder import pipeline_stats, set_sequence_pipeline
     set_sequence_pipeline(1)
     aus, refs = _p_sequence(9, seed=33, temporal_mvp=1)
@@ -162,6 +162,7 @@ def test_plain_form_is_untouched_by_default():
         _check(_play_track(aus, refs), aus, refs)
     finally:
         _set_lookahead(32)
+        set_sequence_pipeline(3)
     assert pipeline_stats() == before
 
 
