@@ -36,6 +36,11 @@ import os
 import sys
 import time
 
+# HIP reads this when the runtime initialises - at the process's first HIP call, which in this script is torch's, before libheifhip.so (whose load-time
+# hook sets the same default for C hosts) is loaded: the chains of sequence tracks keep several launch sets in flight on streams of their own, and HIP's
+# default of 4 hardware queues serialises streams that share one (libheif_amd/csrc/runtime.hip, profiles/r06_sequence_pipeline.txt)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -6,4 +6,10 @@ is a thin ctypes host layer over that C ABI whose classes mirror the reference's
 (new_decoder / push_data / decode_next_image) so that the parity tests read like the reference's
 own.  There is no CPU fallback: importing works anywhere, computing needs the .so and a GPU.
 """
+import os as _os
+
+# (HIP reads this when its runtime initialises, i.e. at the process's first HIP call - which may be torch's, before libheifhip.so and its load-time hook
+#  are there: see libheif_amd/csrc/runtime.hip)
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 from ._capi import HipDecError, load_library, library_path  # noqa: F401
