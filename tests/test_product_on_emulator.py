@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 EMU_LIB = os.path.join(HERE, "emu", "libheifhip_emu.so")
 # the GPU-tier modules that are about host logic (small pictures: seconds under the emulator)
-MODULES = ["test_sequence_gpu.py", "test_golden_sequences.py", "test_plugin_dropin.py", "test_resident_planes_gpu.py", "test_color_boundary.py",
+MODULES = ["test_sequence_gpu.py", "test_sequence_pipeline_gpu.py", "test_golden_sequences.py", "test_plugin_dropin.py", "test_resident_planes_gpu.py", "test_color_boundary.py",
            "test_image_ops_boundary.py", "test_tili_gpu.py"]
 
 
