@@ -321,6 +321,14 @@ def sequence_tracks(n_frames=257, tracks=16, w=1280, h=720):
         k = 33 if n_frames > 33 else n_frames          # first IRAP of the track's first chunk: one CABAC critical path each)
         t0 = time.perf_counter(); play(False, k); res[name]["one_track_fps_without_lookahead"] = round(k / (time.perf_counter() - t0), 1)
         lib.hipdec_set_sequence_lookahead(default_lookahead)
+    # the same kind of track through the REAL libheif (heif_track_decode_next_image: Track_Visual pushes the samples into the plugin and polls it), C threads
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools")) if os.path.join(ROOT, "tools") not in sys.path else None
+        import sequence_through_libheif as stl
+        r = stl.measure(frames=n_frames, threads_list=(1, tracks), seconds=3.0, pipelines=(default_pipeline,), w=w, h=h)
+        res["through_libheif"] = {"workload": r["workload"], "runs": r["runs"]}
+    except Exception as ex:   # noqa: BLE001 - reported, does not take the section down
+        res["through_libheif"] = {"error": str(ex)[:300]}
     return res
 
 
