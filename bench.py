@@ -274,7 +274,10 @@ def sequence_tracks(n_frames=257, tracks=16, w=1280, h=720):
                         "and decodes them as ONE launch set: one CABAC launch and one motion-derivation launch over all of them, pixel stages in dependency steps "
                         "(hipdec_set_sequence_lookahead); the chains of tracks decoded side by side that ask together share a launch set (hipdec_decoder_chain_stats)"}
     for name, kw in kinds.items():
-        aus = orc.encode_sequence(frames, qp=27, global_mv_x=-8, global_mv_y=-4, inter_skip_pct=30, **kw)
+        # (the VUI names libheif's default nclx, as the stills' streams do: a track without one makes libheif convert every picture on the CPU, context.cc:1533-1543)
+        aus = orc.encode_sequence(frames, qp=27, global_mv_x=-8, global_mv_y=-4, inter_skip_pct=30, vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1, **kw)
+        if name.startswith("lowdelay"):
+            aus_for_libheif = aus
         ref = {r["poc"]: r for r in orc.decode_sequence(aus)}
 
         def play(check, first=None):
@@ -325,7 +328,7 @@ def sequence_tracks(n_frames=257, tracks=16, w=1280, h=720):
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools")) if os.path.join(ROOT, "tools") not in sys.path else None
         import sequence_through_libheif as stl
-        r = stl.measure(frames=n_frames, threads_list=(1, tracks), seconds=3.0, pipelines=(default_pipeline,), w=w, h=h)
+        r = stl.measure(frames=n_frames, threads_list=(1, tracks), seconds=3.0, pipelines=(default_pipeline,), w=w, h=h, aus=aus_for_libheif)
         res["through_libheif"] = {"workload": r["workload"], "runs": r["runs"]}
     except Exception as ex:   # noqa: BLE001 - reported, does not take the section down
         res["through_libheif"] = {"error": str(ex)[:300]}

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def measure(frames=257, threads_list=(1, 16), seconds=5.0, pipelines=(3, 1), w=1280, h=720, verbose=False):
+def measure(frames=257, threads_list=(1, 16), seconds=5.0, pipelines=(3, 1), w=1280, h=720, verbose=False, aus=None):
     from oracle import pyoracle as orc
     from test_inter_oracle import make_frames
     import heic_util as hu
@@ -21,8 +21,10 @@ def measure(frames=257, threads_list=(1, 16), seconds=5.0, pipelines=(3, 1), w=1
     if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
         os.makedirs(os.path.dirname(exe), exist_ok=True)
         subprocess.check_call(["gcc", "-O2", "-pthread", src, "-ldl", "-o", exe])
-    aus = orc.encode_sequence(make_frames(w, h, frames), qp=27, global_mv_x=-8, global_mv_y=-4, inter_skip_pct=30, inter_num_refs=2, temporal_mvp=1, weighted_pred=1,
-                              vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1)   # (libheif's defaults: no colour conversion behind the decoder - context.cc:1533-1543)
+    if aus is None:
+        aus = orc.encode_sequence(make_frames(w, h, frames), qp=27, global_mv_x=-8, global_mv_y=-4, inter_skip_pct=30, inter_num_refs=2, temporal_mvp=1, weighted_pred=1,
+                                  vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1)   # (libheif's defaults: no colour conversion behind the decoder - context.cc:1533-1543)
+    frames = len(aus)
     tmp = tempfile.mkdtemp(prefix="hipdec_seq_")
     pth = os.path.join(tmp, "track.heic")
     with open(pth, "wb") as f:
