@@ -278,7 +278,9 @@ def sequence_tracks(n_frames=257, tracks=16, w=1280, h=720):
         aus = orc.encode_sequence(frames, qp=27, global_mv_x=-8, global_mv_y=-4, inter_skip_pct=30, vui_primaries=1, vui_transfer=13, vui_matrix=6, vui_full_range=1, **kw)
         if name.startswith("lowdelay"):
             aus_for_libheif = aus
-        ref = {r["poc"]: r for r in orc.decode_sequence(aus)}
+        # (the oracle decodes the first 97 pictures - the track's first picture and three chains, references across chain boundaries included -: its 257
+        #  pictures would cost as much CPU time again as the encoder above; whole tracks against the oracle are the GPU tier's business)
+        ref = {r["poc"]: r for r in orc.decode_sequence(aus[:97])}
 
         def play(check, first=None):
             d = HipDecoder()
@@ -289,7 +291,7 @@ def sequence_tracks(n_frames=257, tracks=16, w=1280, h=720):
                         d.push_data(au)
                     r = d.next_picture(flush=au is None)
                     while r is not None:
-                        if check and not all((r[0].planes[c] == ref[got]["planes"][c]).all() for c in range(3)):
+                        if check and got in ref and not all((r[0].planes[c] == ref[got]["planes"][c]).all() for c in range(3)):
                             raise RuntimeError("sequence %s: picture with POC %d differs from the oracle" % (name, got))
                         got += 1
                         r = d.next_picture(flush=au is None)
@@ -311,7 +313,7 @@ def sequence_tracks(n_frames=257, tracks=16, w=1280, h=720):
         res[name] = {"one_track_fps": round(n_frames / one, 1), "ms_per_picture": round(one / n_frames * 1e3, 1), "all_tracks_fps": round(tracks * n_frames / many, 1),
                      # side by side: the chains of tracks that ask together run as one launch set (hipdec_decoder_chain_stats)
                      "all_tracks_chains": after[0] - before[0], "all_tracks_launch_sets": after[1] - before[1],
-                     "kbytes_per_picture": round(sum(len(a) for a in aus) / len(aus) / 1e3, 1), "verified_against_oracle": True}
+                     "kbytes_per_picture": round(sum(len(a) for a in aus) / len(aus) / 1e3, 1), "verified_against_oracle": True, "verified_pictures": len(ref)}
         set_sequence_pipeline(1)                      # every chain waited for where it is launched
         t0 = time.perf_counter(); play(False); res[name]["one_track_fps_one_chain_at_a_time"] = round(n_frames / (time.perf_counter() - t0), 1)
         th = [threading.Thread(target=play, args=(False,)) for _ in range(tracks)]
