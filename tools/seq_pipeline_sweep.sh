@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU call: fps sweeps of pipelined chains under different numbers of HIP hardware queues.  usage: bash tools/r06_pipeline_call2.sh <tag> [frames]
+# GPU call: fps sweeps of pipelined chains under different numbers of HIP hardware queues.  usage (inside gpurun): [QUEUES="4 16"] [SWEEP=1:32,3:32] bash tools/seq_pipeline_sweep.sh <tag> [frames]   (SWEEP = chains in flight : look-ahead)
 tag=$1; n=${2:-161}
 mkdir -p gpurun_out
 python -c "import torch" 2>/dev/null
